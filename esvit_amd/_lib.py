@@ -1,0 +1,100 @@
+"""ctypes binding of libesvit_hip.so (include/esvit_hip.h).
+
+The product path has no fallback: if the shared library is missing or a symbol fails to
+resolve, importing this module raises.  Build it with ``python -m esvit_amd.build``.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libesvit_hip.so")
+
+F32, BF16 = 0, 1
+EPI_NONE, EPI_GELU, EPI_GELU_BWD = 0, 1, 2
+
+vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [
+        ("A", vp), ("B", vp), ("C", vp),
+        ("M", i32), ("N", i32), ("K", i32),
+        ("lda", i64), ("ldb", i64), ("ldc", i64),
+        ("a_kstrided", i32), ("b_kstrided", i32),
+        ("batch", i32),
+        ("strideA", i64), ("strideB", i64), ("strideC", i64),
+        ("bias", vp), ("residual", vp), ("ldr", i64),
+        ("rowmap", vp), ("rowmap_period", i32), ("rowmap_tokens", i32),
+        ("rowscale", vp), ("rows_per_sample", i32),
+        ("aux", vp), ("ldaux", i64),
+        ("epilogue", i32), ("out_f32", i32), ("splitk", i32),
+        ("partial", vp), ("accumulate", i32), ("alpha", f32),
+    ]
+
+
+# name -> (restype, argtypes); every symbol declared in include/esvit_hip.h
+SIGNATURES = {
+    "esvit_version": (C.c_int, []),
+    "esvit_last_error": (C.c_char_p, []),
+    "esvit_relative_position_index": (C.c_int, [C.c_int, vp]),
+    "esvit_window_maps": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
+    "esvit_shift_mask": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
+    "esvit_gemm": (C.c_int, [C.c_int, C.POINTER(GemmDesc), vp]),
+    "esvit_layernorm_fwd": (C.c_int, [C.c_int, vp, vp, vp, f32, i64, C.c_int, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp]),
+    "esvit_layernorm_bwd_blocks": (C.c_int, [i64, C.c_int]),
+    "esvit_layernorm_bwd": (C.c_int, [C.c_int, vp, vp, vp, vp, vp, vp, i64, C.c_int, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp]),
+    "esvit_gather_cast": (C.c_int, [C.c_int, vp, vp, i64, C.c_int, vp, C.c_int, C.c_int, vp, C.c_int, vp]),
+    "esvit_cast_f32_to": (C.c_int, [C.c_int, vp, vp, i64, vp]),
+    "esvit_cast_to_f32": (C.c_int, [C.c_int, vp, vp, i64, vp]),
+    "esvit_transpose_cast": (C.c_int, [C.c_int, vp, vp, C.c_int, C.c_int, vp]),
+    "esvit_colsum_blocks": (C.c_int, [i64]),
+    "esvit_colsum": (C.c_int, [C.c_int, vp, i64, C.c_int, i64, vp, vp, C.c_int, vp]),
+    "esvit_patch_im2col": (C.c_int, [C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    "esvit_merge_ln_fwd": (C.c_int, [C.c_int, vp, vp, vp, f32, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]),
+    "esvit_merge_ln_bwd": (C.c_int, [C.c_int, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp]),
+    "esvit_token_mean_fwd": (C.c_int, [C.c_int, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp]),
+    "esvit_token_mean_bwd": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp]),
+    "esvit_attn_frag_elems": (C.c_int, [C.c_int]),
+    "esvit_relpos_bias_fwd": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, vp]),
+    "esvit_dense_to_frag": (C.c_int, [vp, C.c_int, C.c_int, vp, vp]),
+    "esvit_window_attn_fwd": (C.c_int, [C.c_int, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, f32, vp, vp, vp]),
+    "esvit_window_attn_bwd_parts": (C.c_int, [C.c_int, C.c_int]),
+    "esvit_window_attn_bwd": (C.c_int, [C.c_int, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, f32, vp, vp, vp]),
+    "esvit_relpos_bias_bwd": (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, vp, vp]),
+    "esvit_l2norm_fwd": (C.c_int, [C.c_int, vp, i64, C.c_int, vp, vp, vp]),
+    "esvit_l2norm_bwd": (C.c_int, [C.c_int, vp, vp, vp, i64, C.c_int, vp, vp]),
+    "esvit_weightnorm_fwd": (C.c_int, [C.c_int, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp]),
+    "esvit_weightnorm_bwd": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, vp, vp, vp]),
+    "esvit_teacher_row_stats": (C.c_int, [C.c_int, vp, vp, f32, i64, C.c_int, vp, vp, vp]),
+    "esvit_row_argmax": (C.c_int, [vp, i64, C.c_int, C.c_int, vp, vp]),
+    "esvit_dino_ce_fwd_bwd": (C.c_int, [C.c_int, vp, vp, vp, vp, vp, vp, vp, f32, f32, i64, C.c_int, vp, vp, vp]),
+    "esvit_sum_f32": (C.c_int, [vp, i64, vp, vp]),
+    "esvit_scale_inplace": (C.c_int, [C.c_int, vp, i64, vp, vp]),
+    "esvit_center_ema": (C.c_int, [vp, vp, f32, f32, C.c_int, vp]),
+    "esvit_update_chunk_elems": (C.c_int, []),
+    "esvit_grad_sqnorm": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, vp]),
+    "esvit_fused_clip_adamw_ema": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, f32, f32, f32, f32, f32, f32, f32, vp]),
+    "esvit_debug_set_tr_read": (None, [C.c_int]),
+    "esvit_debug_set_attn_tr_read": (None, [C.c_int]),
+}
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "esvit_amd: %s not found -- build it with `python -m esvit_amd.build` "
+            "(there is no fallback path)" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = _load()
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError("%s failed (%d): %s" % (what, rc, lib.esvit_last_error().decode()))

@@ -1,0 +1,164 @@
+// esvit_amd device/host common helpers (gfx950 / CDNA4 only).
+//
+// Everything in csrc/ is written for one target: MI355X (gfx950), wave64,
+// MFMA 16x16x32 bf16 / 16x16x4 f32, 160 KiB LDS per CU.  No portability layer.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#define ESVIT_F32 0
+#define ESVIT_BF16 1
+
+#define ESVIT_OK 0
+#define ESVIT_ERR_ARG (-1)
+#define ESVIT_ERR_HIP (-2)
+#define ESVIT_ERR_UNSUPPORTED (-3)
+
+typedef __bf16 bf16;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// ---------------------------------------------------------------------------
+// error plumbing (host)
+// ---------------------------------------------------------------------------
+void esvit_set_error(const char* fmt, ...);
+
+#define ESVIT_CHECK_ARG(cond, ...)                         \
+    do {                                                   \
+        if (!(cond)) {                                     \
+            esvit_set_error(__VA_ARGS__);                  \
+            return ESVIT_ERR_ARG;                          \
+        }                                                  \
+    } while (0)
+
+#define ESVIT_CHECK_LAUNCH(name)                                                        \
+    do {                                                                                \
+        hipError_t e__ = hipGetLastError();                                             \
+        if (e__ != hipSuccess) {                                                        \
+            esvit_set_error("%s: launch failed: %s", name, hipGetErrorString(e__));     \
+            return ESVIT_ERR_HIP;                                                       \
+        }                                                                               \
+    } while (0)
+
+// ---------------------------------------------------------------------------
+// element access helpers: activations are stored either as f32 or bf16
+// ---------------------------------------------------------------------------
+template <typename T>
+struct ElemTraits;
+template <>
+struct ElemTraits<float> {
+    static constexpr int VEC = 4;  // elements per 16-byte vector
+    static constexpr int DT = ESVIT_F32;
+};
+template <>
+struct ElemTraits<bf16> {
+    static constexpr int VEC = 8;
+    static constexpr int DT = ESVIT_BF16;
+};
+
+__device__ __forceinline__ float to_f32(float v) { return v; }
+__device__ __forceinline__ float to_f32(bf16 v) { return (float)v; }
+template <typename T>
+__device__ __forceinline__ T from_f32(float v);
+template <>
+__device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <>
+__device__ __forceinline__ bf16 from_f32<bf16>(float v) { return (bf16)v; }
+
+// 16-byte vector of T with float views of each lane
+template <typename T>
+struct Vec16;
+template <>
+struct Vec16<float> {
+    f32x4 v;
+    static constexpr int N = 4;
+    __device__ __forceinline__ float get(int i) const { return v[i]; }
+    __device__ __forceinline__ void set(int i, float x) { v[i] = x; }
+};
+template <>
+struct Vec16<bf16> {
+    bf16x8 v;
+    static constexpr int N = 8;
+    __device__ __forceinline__ float get(int i) const { return (float)v[i]; }
+    __device__ __forceinline__ void set(int i, float x) { v[i] = (bf16)x; }
+};
+
+template <typename T>
+__device__ __forceinline__ Vec16<T> ld16(const T* p) {
+    Vec16<T> r;
+    r.v = *reinterpret_cast<const decltype(r.v)*>(p);
+    return r;
+}
+template <typename T>
+__device__ __forceinline__ void st16(T* p, const Vec16<T>& r) {
+    *reinterpret_cast<decltype(r.v)*>(p) = r.v;
+}
+template <typename T>
+__device__ __forceinline__ Vec16<T> zero16() {
+    Vec16<T> r;
+#pragma unroll
+    for (int i = 0; i < Vec16<T>::N; ++i) r.set(i, 0.f);
+    return r;
+}
+
+// ---------------------------------------------------------------------------
+// wave / block reductions (wave = 64 lanes)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+// reduce over a power-of-two lane group of width G (G <= 64)
+template <int G>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// block-wide sum for blockDim.x == NT (multiple of 64); scratch >= NT/64 floats
+template <int NT>
+__device__ __forceinline__ float block_sum(float v, float* scratch) {
+    v = wave_sum(v);
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    __syncthreads();
+    if (l == 0) scratch[w] = v;
+    __syncthreads();
+    float r = 0.f;
+#pragma unroll
+    for (int i = 0; i < NT / 64; ++i) r += scratch[i];
+    return r;
+}
+template <int NT>
+__device__ __forceinline__ float block_max(float v, float* scratch) {
+    v = wave_max(v);
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    __syncthreads();
+    if (l == 0) scratch[w] = v;
+    __syncthreads();
+    float r = scratch[0];
+#pragma unroll
+    for (int i = 1; i < NT / 64; ++i) r = fmaxf(r, scratch[i]);
+    return r;
+}
+
+// exact-erf GELU (reference: nn.GELU default) and its derivative
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad_f(float x) {
+    const float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752f));
+    const float pdf = 0.39894228040143268f * __expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
+
+static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }

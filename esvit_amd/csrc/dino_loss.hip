@@ -1,0 +1,192 @@
+// Fused DINOLoss / DDINOLoss kernels (main_esvit.py:603-770).
+//
+// The reference materialises softmax(teacher), log_softmax(student) and the gathered teacher
+// rows for each of its 18 (teacher view, student crop) pairs.  Here every student logit row is
+// visited by ONE workgroup that (pass 1) computes its log-sum-exp and (pass 2) streams the row
+// again together with the <= 2 teacher rows it is scored against, producing the row's loss and
+// its complete gradient in one go:
+//     loss_r = w_r * sum_terms ( lse(z) - sum_k p_term[k] z[k] ),          z = s / tau_s
+//     ds[k]  = w_r / tau_s * ( n_terms * softmax(z)[k] - sum_terms p_term[k] )
+// Teacher probabilities are rebuilt on the fly from per-row (max, lse) statistics, so the
+// sharpened/centred teacher distribution is never written to memory.  HBM-bound: algorithmic
+// bytes = read s twice (second pass from L2), read the matched teacher rows, write ds.
+#include "common.h"
+#include "../../include/esvit_hip.h"
+
+namespace {
+
+constexpr int NT = 256;
+
+// online (max, sum exp) accumulation
+struct MS {
+    float m, s;
+};
+__device__ __forceinline__ void ms_add(MS& a, float v) {
+    if (v > a.m) {
+        a.s = a.s * __expf(a.m - v) + 1.f;
+        a.m = v;
+    } else {
+        a.s += __expf(v - a.m);
+    }
+}
+__device__ __forceinline__ MS ms_merge(MS a, MS b) {
+    const float m = fmaxf(a.m, b.m);
+    MS r;
+    r.m = m;
+    r.s = a.s * __expf(a.m - m) + b.s * __expf(b.m - m);
+    return r;
+}
+__device__ __forceinline__ MS block_ms(MS a, float* sm /* >= 2*NT/64 floats */) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        MS b;
+        b.m = __shfl_xor(a.m, o, 64);
+        b.s = __shfl_xor(a.s, o, 64);
+        a = ms_merge(a, b);
+    }
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    __syncthreads();
+    if (l == 0) {
+        sm[2 * w] = a.m;
+        sm[2 * w + 1] = a.s;
+    }
+    __syncthreads();
+    MS r{sm[0], sm[1]};
+#pragma unroll
+    for (int i = 1; i < NT / 64; ++i) r = ms_merge(r, MS{sm[2 * i], sm[2 * i + 1]});
+    return r;
+}
+
+// row stats of (t - c) * inv_temp
+template <typename T>
+__global__ __launch_bounds__(NT) void teacher_stats_kernel(const T* __restrict__ t, const float* __restrict__ center,
+                                                           float inv_temp, int K, float* __restrict__ row_max,
+                                                           float* __restrict__ row_lse) {
+    __shared__ float sm[2 * NT / 64];
+    constexpr int V = Vec16<T>::N;
+    const long r = blockIdx.x;
+    const T* row = t + r * K;
+    MS a{-3.0e38f, 0.f};
+    for (int k = threadIdx.x * V; k < K; k += NT * V) {
+        const Vec16<T> x = ld16<T>(row + k);
+        float vals[V];
+        float mx = -3.0e38f;
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            vals[e] = (x.get(e) - center[k + e]) * inv_temp;
+            mx = fmaxf(mx, vals[e]);
+        }
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < V; ++e) s += __expf(vals[e] - mx);
+        a = ms_merge(a, MS{mx, s});
+    }
+    a = block_ms(a, sm);
+    if (threadIdx.x == 0) {
+        row_max[r] = a.m;
+        row_lse[r] = __logf(a.s);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(NT) void dino_ce_kernel(const T* __restrict__ s, const T* __restrict__ t,
+                                                     const float* __restrict__ center, const float* __restrict__ t_row_max,
+                                                     const float* __restrict__ t_row_lse, const int* __restrict__ tmatch,
+                                                     const float* __restrict__ row_w, float inv_st, float inv_tt, int K,
+                                                     float* __restrict__ row_loss, T* __restrict__ ds) {
+    __shared__ float sm[2 * NT / 64];
+    __shared__ float sm2[NT / 64];
+    constexpr int V = Vec16<T>::N;
+    const long r = blockIdx.x;
+    const T* srow = s + r * K;
+    T* drow = ds + r * K;
+    const int t0 = tmatch[2 * r], t1 = tmatch[2 * r + 1];
+    const float w = row_w[r];
+    const int nterms = (t0 >= 0) + (t1 >= 0);
+
+    // pass 1: log-sum-exp of z = s * inv_st
+    MS a{-3.0e38f, 0.f};
+    for (int k = threadIdx.x * V; k < K; k += NT * V) {
+        const Vec16<T> x = ld16<T>(srow + k);
+        float mx = -3.0e38f;
+#pragma unroll
+        for (int e = 0; e < V; ++e) mx = fmaxf(mx, x.get(e) * inv_st);
+        float sum = 0.f;
+#pragma unroll
+        for (int e = 0; e < V; ++e) sum += __expf(x.get(e) * inv_st - mx);
+        a = ms_merge(a, MS{mx, sum});
+    }
+    a = block_ms(a, sm);
+    const float lse = a.m + __logf(a.s);
+
+    // pass 2: gradient + sum_k p_t[k] z[k]
+    const T* trow0 = t + (long)(t0 >= 0 ? t0 : 0) * K;
+    const T* trow1 = t + (long)(t1 >= 0 ? t1 : 0) * K;
+    const float off0 = t0 >= 0 ? t_row_max[t0] + t_row_lse[t0] : 0.f;
+    const float off1 = t1 >= 0 ? t_row_max[t1] + t_row_lse[t1] : 0.f;
+    const float gscale = w * inv_st;
+    float dot = 0.f;
+    for (int k = threadIdx.x * V; k < K; k += NT * V) {
+        const Vec16<T> x = ld16<T>(srow + k);
+        Vec16<T> y0 = zero16<T>(), y1 = zero16<T>();
+        if (t0 >= 0) y0 = ld16<T>(trow0 + k);
+        if (t1 >= 0) y1 = ld16<T>(trow1 + k);
+        Vec16<T> o;
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            const float z = x.get(e) * inv_st;
+            const float ps = __expf(z - lse);
+            const float ck = center[k + e];
+            float pt = 0.f;
+            if (t0 >= 0) pt += __expf((y0.get(e) - ck) * inv_tt - off0);
+            if (t1 >= 0) pt += __expf((y1.get(e) - ck) * inv_tt - off1);
+            dot += pt * z;
+            o.set(e, gscale * (nterms * ps - pt));
+        }
+        st16<T>(drow + k, o);
+    }
+    dot = block_sum<NT>(dot, sm2);
+    if (threadIdx.x == 0) row_loss[r] = w * (nterms * lse - dot);
+}
+
+}  // namespace
+
+#define STREAM(s_) hipStream_t stream = reinterpret_cast<hipStream_t>(s_)
+
+extern "C" int esvit_teacher_row_stats(int dtype, const void* t, const float* center, float inv_temp, int64_t R, int K,
+                                       float* row_max, float* row_lse, esvit_stream_t s_) {
+    STREAM(s_);
+    ESVIT_CHECK_ARG(t && center && row_max && row_lse && R > 0 && K > 0 && K % 8 == 0, "esvit_teacher_row_stats: bad args (K=%d)", K);
+    if (dtype == ESVIT_BF16)
+        hipLaunchKernelGGL(teacher_stats_kernel<bf16>, dim3((unsigned)R), dim3(NT), 0, stream, (const bf16*)t, center, inv_temp, K,
+                           row_max, row_lse);
+    else if (dtype == ESVIT_F32)
+        hipLaunchKernelGGL(teacher_stats_kernel<float>, dim3((unsigned)R), dim3(NT), 0, stream, (const float*)t, center, inv_temp, K,
+                           row_max, row_lse);
+    else {
+        esvit_set_error("esvit_teacher_row_stats: bad dtype");
+        return ESVIT_ERR_ARG;
+    }
+    ESVIT_CHECK_LAUNCH("teacher_row_stats");
+    return ESVIT_OK;
+}
+
+extern "C" int esvit_dino_ce_fwd_bwd(int dtype, const void* s, const void* t, const float* center, const float* t_row_max,
+                                     const float* t_row_lse, const int32_t* tmatch, const float* row_w, float inv_student_temp,
+                                     float inv_teacher_temp, int64_t Rs, int K, float* row_loss, void* ds, esvit_stream_t s_) {
+    STREAM(s_);
+    ESVIT_CHECK_ARG(s && t && center && t_row_max && t_row_lse && tmatch && row_w && row_loss && ds && Rs > 0 && K > 0 && K % 8 == 0,
+                    "esvit_dino_ce_fwd_bwd: bad args (K=%d)", K);
+    if (dtype == ESVIT_BF16)
+        hipLaunchKernelGGL(dino_ce_kernel<bf16>, dim3((unsigned)Rs), dim3(NT), 0, stream, (const bf16*)s, (const bf16*)t, center,
+                           t_row_max, t_row_lse, tmatch, row_w, inv_student_temp, inv_teacher_temp, K, row_loss, (bf16*)ds);
+    else if (dtype == ESVIT_F32)
+        hipLaunchKernelGGL(dino_ce_kernel<float>, dim3((unsigned)Rs), dim3(NT), 0, stream, (const float*)s, (const float*)t, center,
+                           t_row_max, t_row_lse, tmatch, row_w, inv_student_temp, inv_teacher_temp, K, row_loss, (float*)ds);
+    else {
+        esvit_set_error("esvit_dino_ce_fwd_bwd: bad dtype");
+        return ESVIT_ERR_ARG;
+    }
+    ESVIT_CHECK_LAUNCH("dino_ce_fwd_bwd");
+    return ESVIT_OK;
+}

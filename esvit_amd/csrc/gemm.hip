@@ -1,0 +1,326 @@
+// MFMA GEMM family for the EsViT hot path (gfx950).
+//
+//   C[M,N] = alpha * op(A)[M,K] * op(B)[K,N]  (+ fused epilogue)
+//
+// One kernel template covers the three shapes autograd needs:
+//   forward  Y  = X  W^T   : A k-contiguous (M x K),  B k-contiguous (N x K)
+//   dgrad    dX = dY W     : A k-contiguous,          B k-strided    (K x N)   [or cached W^T]
+//   wgrad    dW = dY^T X   : A k-strided (K x M),     B k-strided    (K x N), split-K over rows
+//
+// Tiling: 256 threads = 4 waves (2 x 2), block tile BM x BN x 32, wave tile (BM/2) x (BN/2)
+// built from 16x16 MFMA fragments (v_mfma_f32_16x16x32_bf16, or 8 x v_mfma_f32_16x16x4_f32 for
+// the exact-fp32 parity mode).  Operands are register-staged global -> LDS (double-buffered,
+// one barrier per k-tile).  K-contiguous tiles are read as one ds_read_b128 per fragment;
+// K-strided tiles are stored as they lie in HBM and read with the gfx950 transpose read
+// (ds_read_b64_tr_b16), so no operand is ever transposed through HBM.
+//
+// The lane->k assignment inside a fragment is "lane group g holds k = 8g..8g+7" for both A and
+// B; a dot product is invariant to a permutation applied to both operands, so the fp32 path
+// simply feeds element j of that 8-vector to the j-th 16x16x4 MFMA.
+//
+// Epilogue (all optional, fused on the fp32 accumulators): bias, GELU (+ pre-activation side
+// output), GELU', per-sample DropPath scale, window->token row scatter (window_reverse + roll +
+// crop of swin_transformer.py:315-325), residual add, bf16/fp32 store, split-K partial store.
+#include "common.h"
+#include "mfma.h"
+#include "../../include/esvit_hip.h"
+
+namespace {
+
+constexpr int BK = 32;
+constexpr int NTHREADS = 256;
+
+// One operand tile: ROWS (BM or BN) x BK, in LDS either as [ROWS][BK+pad] (k contiguous) or as
+// [BK][ROWS+pad] (k strided, i.e. exactly the HBM orientation).
+template <typename T, bool KS, int ROWS, bool USE_TR>
+struct Tile {
+    static constexpr int VEC = ElemTraits<T>::VEC;
+    static constexpr int LD = KS ? (ROWS + VEC) : (BK + VEC);
+    static constexpr int ELEMS = KS ? (BK * LD) : (ROWS * LD);
+    static constexpr int NVEC = ROWS * BK / VEC;
+    static constexpr int VPT = (NVEC + NTHREADS - 1) / NTHREADS;
+
+    Vec16<T> regs[VPT];
+
+    // global -> registers.  base: operand pointer; ld: leading dim (elements); row0: first tile
+    // row along the non-K dim; k0: first k; nrows/K: extents for zero-fill guards.
+    __device__ __forceinline__ void load(const T* __restrict__ base, long ld, int row0, int k0, int nrows, int K) {
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) {
+            const int v = threadIdx.x + i * NTHREADS;
+            bool ok = v < NVEC;
+            long off = 0;
+            if (KS) {
+                const int kr = v / (ROWS / VEC), rv = v % (ROWS / VEC);
+                ok = ok && (k0 + kr < K) && (row0 + rv * VEC < nrows);
+                off = (long)(k0 + kr) * ld + row0 + rv * VEC;
+            } else {
+                const int r = v / (BK / VEC), kv = v % (BK / VEC);
+                ok = ok && (row0 + r < nrows) && (k0 + kv * VEC < K);
+                off = (long)(row0 + r) * ld + k0 + kv * VEC;
+            }
+            regs[i] = ok ? ld16<T>(base + off) : zero16<T>();
+        }
+    }
+    // registers -> LDS
+    __device__ __forceinline__ void store(T* lds) const {
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) {
+            const int v = threadIdx.x + i * NTHREADS;
+            if (v < NVEC) {
+                int off;
+                if (KS) {
+                    const int kr = v / (ROWS / VEC), rv = v % (ROWS / VEC);
+                    off = kr * LD + rv * VEC;
+                } else {
+                    const int r = v / (BK / VEC), kv = v % (BK / VEC);
+                    off = r * LD + kv * VEC;
+                }
+                st16<T>(lds + off, regs[i]);
+            }
+        }
+    }
+    // LDS -> MFMA fragment for the 16 tile rows starting at r0: lane (c = l&15, g = l>>4) gets
+    // element (row r0+c, k = 8g+j), j = 0..7.
+    __device__ __forceinline__ static Frag<T> frag(const T* lds, int r0, int c, int g) {
+        if constexpr (KS) return frag_ks<T, USE_TR>(lds, LD, r0, 0, c, g);
+        else return frag_kc<T>(lds, LD, r0, 0, c, g);
+    }
+};
+
+template <typename T, bool AKS, bool BKS, int BM, int BN, bool USE_TR>
+__global__ __launch_bounds__(NTHREADS) void gemm_kernel(const esvit_gemm_desc p) {
+    using TA = Tile<T, AKS, BM, USE_TR>;
+    using TB = Tile<T, BKS, BN, USE_TR>;
+    constexpr int WTM = BM / 2, WTN = BN / 2;  // wave tile
+    constexpr int FM = WTM / 16, FN = WTN / 16;
+
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    T* smem = reinterpret_cast<T*>(smem_raw);
+    T* sA = smem;                   // 2 buffers
+    T* sB = smem + 2 * TA::ELEMS;   // 2 buffers
+
+    const int M = p.M, N = p.N, K = p.K;
+    const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+    // XCD-aware tile order: block b runs on XCD b%8; give every XCD a contiguous range of
+    // tile ids so the tiles that share an A panel hit the same L2 (bijective remap).
+    const int ntiles = tiles_m * tiles_n;
+    int pid = blockIdx.x;
+    {
+        const int q = ntiles / 8, r = ntiles % 8;
+        const int xcd = pid % 8, idx = pid / 8;
+        pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tm = pid / tiles_n, tn = pid % tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int z = blockIdx.y;
+
+    const T* A = reinterpret_cast<const T*>(p.A);
+    const T* B = reinterpret_cast<const T*>(p.B);
+    int kbeg = 0, kend = K;
+    if (p.splitk > 1) {
+        const int nkt = (K + BK - 1) / BK;
+        const int per = (nkt + p.splitk - 1) / p.splitk;
+        kbeg = z * per * BK;
+        kend = min(K, (z + 1) * per * BK);
+    } else {
+        A += (long)z * p.strideA;
+        B += (long)z * p.strideB;
+    }
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 15, g = lane >> 4;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    f32x4 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    TA ta;
+    TB tb;
+    const int nk = (kend > kbeg) ? (kend - kbeg + BK - 1) / BK : 0;
+    if (nk > 0) {
+        ta.load(A, p.lda, m0, kbeg, M, kend);
+        tb.load(B, p.ldb, n0, kbeg, N, kend);
+        ta.store(sA);
+        tb.store(sB);
+    }
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) {
+            ta.load(A, p.lda, m0, kbeg + (kt + 1) * BK, M, kend);
+            tb.load(B, p.ldb, n0, kbeg + (kt + 1) * BK, N, kend);
+        }
+        const T* a_lds = sA + cur * TA::ELEMS;
+        const T* b_lds = sB + cur * TB::ELEMS;
+        Frag<T> af[FM], bfr[FN];
+#pragma unroll
+        for (int i = 0; i < FM; ++i) af[i] = TA::frag(a_lds, wm * WTM + i * 16, c, g);
+#pragma unroll
+        for (int j = 0; j < FN; ++j) bfr[j] = TB::frag(b_lds, wn * WTN + j * 16, c, g);
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j) mma(af[i], bfr[j], acc[i][j]);
+        if (kt + 1 < nk) {
+            ta.store(sA + (cur ^ 1) * TA::ELEMS);
+            tb.store(sB + (cur ^ 1) * TB::ELEMS);
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue ----
+    const float alpha = p.alpha;
+    if (p.splitk > 1) {
+        float* part = p.partial + (long)z * M * N;
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + wm * WTM + i * 16 + 4 * g + r;
+                if (m >= M) continue;
+#pragma unroll
+                for (int j = 0; j < FN; ++j) {
+                    const int n = n0 + wn * WTN + j * 16 + c;
+                    if (n < N) part[(long)m * N + n] = acc[i][j][r] * alpha;
+                }
+            }
+        return;
+    }
+    char* Cb = reinterpret_cast<char*>(p.C);
+    const long c_batch = (long)z * p.strideC;
+    const T* aux_in = reinterpret_cast<const T*>(p.aux);
+    T* aux_out = reinterpret_cast<T*>(p.aux);
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = m0 + wm * WTM + i * 16 + 4 * g + r;
+            if (m >= M) continue;
+            long drow = m;
+            if (p.rowmap) {
+                const int t = p.rowmap[m % p.rowmap_period];
+                if (t < 0) continue;
+                drow = (long)(m / p.rowmap_period) * p.rowmap_tokens + t;
+            }
+            const float rs = p.rowscale ? p.rowscale[drow / p.rows_per_sample] : 1.f;
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                const int n = n0 + wn * WTN + j * 16 + c;
+                if (n >= N) continue;
+                float v = acc[i][j][r] * alpha;
+                if (p.bias) v += p.bias[n];
+                if (p.epilogue == ESVIT_EPI_GELU) {
+                    if (aux_out) aux_out[(long)m * p.ldaux + n] = from_f32<T>(v);
+                    v = gelu_f(v);
+                } else if (p.epilogue == ESVIT_EPI_GELU_BWD) {
+                    v *= gelu_grad_f(to_f32(aux_in[(long)m * p.ldaux + n]));
+                }
+                v *= rs;
+                if (p.residual) v += p.residual[drow * p.ldr + n];
+                const long o = c_batch + drow * p.ldc + n;
+                if (p.out_f32) reinterpret_cast<float*>(Cb)[o] = v;
+                else reinterpret_cast<T*>(Cb)[o] = from_f32<T>(v);
+            }
+        }
+}
+
+// sum split-K partials: out[i] (+)= sum_z part[z*n + i]
+__global__ void splitk_reduce_kernel(const float* __restrict__ part, int splits, long n, float* __restrict__ out,
+                                     int accumulate) {
+    const long i4 = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i4 >= n) return;
+    if (i4 + 4 <= n) {
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        for (int z = 0; z < splits; ++z) s += *reinterpret_cast<const f32x4*>(part + (long)z * n + i4);
+        if (accumulate) s += *reinterpret_cast<const f32x4*>(out + i4);
+        *reinterpret_cast<f32x4*>(out + i4) = s;
+    } else {
+        for (long i = i4; i < n; ++i) {
+            float s = 0.f;
+            for (int z = 0; z < splits; ++z) s += part[(long)z * n + i];
+            out[i] = accumulate ? out[i] + s : s;
+        }
+    }
+}
+
+template <typename T, bool AKS, bool BKS, int BM, int BN, bool USE_TR>
+int launch_gemm(const esvit_gemm_desc& d, hipStream_t stream) {
+    using TA = Tile<T, AKS, BM, USE_TR>;
+    using TB = Tile<T, BKS, BN, USE_TR>;
+    const size_t lds = 2 * (size_t)(TA::ELEMS + TB::ELEMS) * sizeof(T);
+    auto kern = gemm_kernel<T, AKS, BKS, BM, BN, USE_TR>;
+    static bool attr_done = false;  // one-time raise of the dynamic LDS cap (per instantiation)
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds);
+        attr_done = true;
+    }
+    const int tiles = ceil_div(d.M, BM) * ceil_div(d.N, BN);
+    dim3 grid(tiles, d.splitk > 1 ? d.splitk : d.batch);
+    hipLaunchKernelGGL(kern, grid, dim3(NTHREADS), lds, stream, d);
+    ESVIT_CHECK_LAUNCH("esvit_gemm");
+    if (d.splitk > 1) {
+        const long n = (long)d.M * d.N;
+        const int blocks = ceil_div(ceil_div(n, 4), 256);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, d.partial, d.splitk, n,
+                           reinterpret_cast<float*>(d.C), d.accumulate);
+        ESVIT_CHECK_LAUNCH("esvit_gemm(splitk_reduce)");
+    }
+    return ESVIT_OK;
+}
+
+template <typename T, bool AKS, bool BKS, bool USE_TR>
+int dispatch_tile(const esvit_gemm_desc& d, hipStream_t stream) {
+    // backbone widths are multiples of 96 (96*2^s, x3, x4); head widths are powers of two.
+    const bool n96 = (d.N % 96 == 0) && (d.N % 128 != 0);
+    if (n96) return launch_gemm<T, AKS, BKS, 128, 96, USE_TR>(d, stream);
+    if (d.N <= 64) return launch_gemm<T, AKS, BKS, 128, 64, USE_TR>(d, stream);
+    return launch_gemm<T, AKS, BKS, 128, 128, USE_TR>(d, stream);
+}
+
+template <typename T, bool USE_TR>
+int dispatch_layout(const esvit_gemm_desc& d, hipStream_t stream) {
+    if (!d.a_kstrided && !d.b_kstrided) return dispatch_tile<T, false, false, USE_TR>(d, stream);
+    if (!d.a_kstrided && d.b_kstrided) return dispatch_tile<T, false, true, USE_TR>(d, stream);
+    if (d.a_kstrided && d.b_kstrided) return dispatch_tile<T, true, true, USE_TR>(d, stream);
+    esvit_set_error("esvit_gemm: layout a_kstrided=1,b_kstrided=0 is not used on the path");
+    return ESVIT_ERR_UNSUPPORTED;
+}
+
+}  // namespace
+
+static int g_use_tr = 1;
+extern "C" void esvit_debug_set_tr_read(int on) { g_use_tr = on; }
+
+extern "C" int esvit_gemm(int dtype, const esvit_gemm_desc* dp, esvit_stream_t stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    ESVIT_CHECK_ARG(dp != nullptr, "esvit_gemm: null descriptor");
+    esvit_gemm_desc d = *dp;
+    ESVIT_CHECK_ARG(d.A && d.B && d.C, "esvit_gemm: null operand");
+    ESVIT_CHECK_ARG(d.M > 0 && d.N > 0 && d.K > 0, "esvit_gemm: bad shape M=%d N=%d K=%d", d.M, d.N, d.K);
+    const int vec = dtype == ESVIT_BF16 ? 8 : 4;
+    ESVIT_CHECK_ARG(dtype == ESVIT_BF16 || dtype == ESVIT_F32, "esvit_gemm: bad dtype %d", dtype);
+    ESVIT_CHECK_ARG(d.lda % vec == 0 && d.ldb % vec == 0, "esvit_gemm: lda/ldb must be multiples of %d", vec);
+    if (!d.a_kstrided) ESVIT_CHECK_ARG(d.K % vec == 0, "esvit_gemm: K=%d must be a multiple of %d", d.K, vec);
+    if (d.a_kstrided) ESVIT_CHECK_ARG(d.M % vec == 0, "esvit_gemm: M=%d must be a multiple of %d (k-strided A)", d.M, vec);
+    if (d.b_kstrided) ESVIT_CHECK_ARG(d.N % vec == 0, "esvit_gemm: N=%d must be a multiple of %d (k-strided B)", d.N, vec);
+    ESVIT_CHECK_ARG(((uintptr_t)d.A % 16 == 0) && ((uintptr_t)d.B % 16 == 0), "esvit_gemm: operands must be 16-byte aligned");
+    if (d.batch < 1) d.batch = 1;
+    if (d.splitk > 1) {
+        ESVIT_CHECK_ARG(d.batch == 1 && d.out_f32 && d.partial, "esvit_gemm: split-K needs batch=1, fp32 out and a workspace");
+        ESVIT_CHECK_ARG(!d.bias && !d.residual && !d.rowmap && d.epilogue == 0, "esvit_gemm: split-K has no fused epilogue");
+    } else {
+        d.splitk = 1;
+    }
+    if (d.rowmap) ESVIT_CHECK_ARG(d.rowmap_period > 0 && d.rowmap_tokens > 0, "esvit_gemm: bad rowmap geometry");
+    if (d.rowscale) ESVIT_CHECK_ARG(d.rows_per_sample > 0, "esvit_gemm: rowscale needs rows_per_sample");
+    if (d.epilogue == ESVIT_EPI_GELU_BWD) ESVIT_CHECK_ARG(d.aux != nullptr, "esvit_gemm: GELU' needs aux");
+    if (dtype == ESVIT_BF16) {
+        return g_use_tr ? dispatch_layout<bf16, true>(d, stream) : dispatch_layout<bf16, false>(d, stream);
+    }
+    return dispatch_layout<float, false>(d, stream);
+}

@@ -1,0 +1,506 @@
+"""Tensor-level wrappers over the C-ABI of libesvit_hip.so.
+
+Each function takes/returns torch CUDA tensors, allocates outputs with torch (the library never
+allocates) and enqueues on torch's current stream.  There is no CPU or eager fallback: a
+non-CUDA tensor is an error.  Shapes and semantics are documented in include/esvit_hip.h.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import BF16, EPI_GELU, EPI_GELU_BWD, EPI_NONE, F32, GemmDesc, check, lib
+
+_ACT_DTYPE = torch.bfloat16
+
+
+def set_act_dtype(dt):
+    """Storage type of activations: torch.bfloat16 (benchmark mode) or torch.float32 (exact-parity mode)."""
+    global _ACT_DTYPE
+    assert dt in (torch.bfloat16, torch.float32)
+    _ACT_DTYPE = dt
+
+
+def act_dtype():
+    return _ACT_DTYPE
+
+
+def _code(dt):
+    if dt == torch.bfloat16:
+        return BF16
+    if dt == torch.float32:
+        return F32
+    raise TypeError("unsupported activation dtype %s" % dt)
+
+
+def _p(t):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("esvit_amd.ops: tensor is not on the GPU (no CPU fallback exists)")
+    return C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _f32c(t):
+    assert t.dtype == torch.float32 and t.is_contiguous(), (t.dtype, t.is_contiguous())
+    return t
+
+
+def _actc(t):
+    assert t.dtype in (torch.float32, torch.bfloat16) and t.is_contiguous()
+    return t
+
+
+# ------------------------------------------------------------------------------------------------
+# shared scratch (split-K partials, column-sum partials, LN partials); stream-ordered reuse
+# ------------------------------------------------------------------------------------------------
+_WS = {}
+
+
+def workspace(nfloats, device, slot=0):
+    key = (device, slot)
+    buf = _WS.get(key)
+    if buf is None or buf.numel() < nfloats:
+        buf = torch.empty(max(int(nfloats), 1 << 20), dtype=torch.float32, device=device)
+        _WS[key] = buf
+    return buf
+
+
+# ------------------------------------------------------------------------------------------------
+# host-side integer index maps
+# ------------------------------------------------------------------------------------------------
+def relative_position_index(ws):
+    out = np.empty((ws * ws, ws * ws), dtype=np.int64)
+    check(lib.esvit_relative_position_index(ws, out.ctypes.data_as(C.c_void_p)), "relative_position_index")
+    return out
+
+
+def window_maps(H, W, ws, shift):
+    Hp, Wp = -(-H // ws) * ws, -(-W // ws) * ws
+    win2tok = np.empty((Hp // ws) * (Wp // ws) * ws * ws, dtype=np.int32)
+    tok2win = np.empty(H * W, dtype=np.int32)
+    check(lib.esvit_window_maps(H, W, ws, shift, win2tok.ctypes.data_as(C.c_void_p), tok2win.ctypes.data_as(C.c_void_p)),
+          "window_maps")
+    return win2tok, tok2win
+
+
+def shift_mask(H, W, ws, shift):
+    Hp, Wp = -(-H // ws) * ws, -(-W // ws) * ws
+    nW, N = (Hp // ws) * (Wp // ws), ws * ws
+    mask = np.empty((nW, N, N), dtype=np.float32)
+    n = C.c_int(0)
+    check(lib.esvit_shift_mask(H, W, ws, shift, mask.ctypes.data_as(C.c_void_p), C.byref(n)), "shift_mask")
+    assert n.value == nW
+    return mask
+
+
+# ------------------------------------------------------------------------------------------------
+# GEMM family
+# ------------------------------------------------------------------------------------------------
+def _gemm(dt, **kw):
+    d = GemmDesc()
+    for k in ("A", "B", "C", "bias", "residual", "rowmap", "rowscale", "aux", "partial"):
+        setattr(d, k, _p(kw.get(k)))
+    for k in ("M", "N", "K", "lda", "ldb", "ldc", "a_kstrided", "b_kstrided", "strideA", "strideB", "strideC", "ldr",
+              "rowmap_period", "rowmap_tokens", "rows_per_sample", "ldaux", "epilogue", "out_f32", "splitk", "accumulate"):
+        setattr(d, k, int(kw.get(k, 0)))
+    d.batch = int(kw.get("batch", 1))
+    d.alpha = float(kw.get("alpha", 1.0))
+    check(lib.esvit_gemm(_code(dt), C.byref(d), _stream()), "esvit_gemm")
+
+
+def linear_fwd(x, w, bias=None, *, gelu=False, want_preact=False, residual=None, rowmap=None, rowmap_tokens=0,
+               out_rows=None, rowscale=None, rows_per_sample=0, out_f32=False):
+    """y = x @ w^T (+bias) with the fused epilogue of the GEMM kernel.
+
+    x [M, K] act; w [N, K] act (cached cast of the fp32 parameter); bias fp32 [N].
+    rowmap (int32 [period]) scatters window rows to token rows (out_rows rows, tokens per image =
+    rowmap_tokens); residual fp32 [out_rows, N] is added at the destination row."""
+    x, w = _actc(x), _actc(w)
+    M, K = x.shape
+    N = w.shape[0]
+    assert w.shape[1] == K and x.dtype == w.dtype
+    rows = M if out_rows is None else out_rows
+    y = torch.empty((rows, N), dtype=torch.float32 if out_f32 else x.dtype, device=x.device)
+    pre = torch.empty((M, N), dtype=x.dtype, device=x.device) if (gelu and want_preact) else None
+    _gemm(x.dtype, A=x, B=w, C=y, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, bias=bias, residual=residual, ldr=N,
+          rowmap=rowmap, rowmap_period=0 if rowmap is None else rowmap.numel(), rowmap_tokens=rowmap_tokens,
+          rowscale=rowscale, rows_per_sample=rows_per_sample, aux=pre, ldaux=N,
+          epilogue=EPI_GELU if gelu else EPI_NONE, out_f32=out_f32)
+    return (y, pre) if gelu and want_preact else y
+
+
+def linear_dgrad(dy, w, *, gelu_preact=None, out_f32=False):
+    """dx = dy @ w  (w [Nout, Kin] act, read k-strided); optional fused GELU': dx *= gelu'(preact)."""
+    dy, w = _actc(dy), _actc(w)
+    M, Nout = dy.shape
+    Kin = w.shape[1]
+    assert w.shape[0] == Nout and dy.dtype == w.dtype
+    dx = torch.empty((M, Kin), dtype=torch.float32 if out_f32 else dy.dtype, device=dy.device)
+    _gemm(dy.dtype, A=dy, B=w, C=dx, M=M, N=Kin, K=Nout, lda=Nout, ldb=Kin, ldc=Kin, b_kstrided=1, aux=gelu_preact,
+          ldaux=Kin, epilogue=EPI_GELU_BWD if gelu_preact is not None else EPI_NONE, out_f32=out_f32)
+    return dx
+
+
+def _pick_splitk(rows, tiles):
+    # aim for ~1024 workgroups (4 per CU), at least 256 reduction rows per split
+    want = max(1, 1024 // max(tiles, 1))
+    return int(max(1, min(want, rows // 256 if rows >= 512 else 1, 256)))
+
+
+def linear_wgrad(dy, x, *, out=None, accumulate=False):
+    """dw[Nout, Kin] = dy^T @ x (fp32), both operands read k-strided, split-K over the rows."""
+    dy, x = _actc(dy), _actc(x)
+    rows, Nout = dy.shape
+    Kin = x.shape[1]
+    assert x.shape[0] == rows and dy.dtype == x.dtype
+    if out is None:
+        out = torch.empty((Nout, Kin), dtype=torch.float32, device=dy.device)
+        accumulate = False
+    bn = 96 if (Kin % 96 == 0 and Kin % 128 != 0) else (64 if Kin <= 64 else 128)
+    tiles = (-(-Nout // 128)) * (-(-Kin // bn))
+    splitk = _pick_splitk(rows, tiles)
+    if splitk > 1:
+        part = workspace(splitk * Nout * Kin, dy.device)
+        _gemm(dy.dtype, A=dy, B=x, C=out, M=Nout, N=Kin, K=rows, lda=Nout, ldb=Kin, ldc=Kin, a_kstrided=1, b_kstrided=1,
+              out_f32=1, splitk=splitk, partial=part, accumulate=int(accumulate))
+    else:
+        assert not accumulate
+        _gemm(dy.dtype, A=dy, B=x, C=out, M=Nout, N=Kin, K=rows, lda=Nout, ldb=Kin, ldc=Kin, a_kstrided=1, b_kstrided=1,
+              out_f32=1)
+    return out
+
+
+def batched_nt(a, b, out_ld):
+    """out[p] = a[p] @ b[p]^T in fp32: a [P, M, K], b [P, N, K] fp32 -> out [P, M, out_ld] (cols >= N undefined)."""
+    a, b = _f32c(a), _f32c(b)
+    P, M, K = a.shape
+    N = b.shape[1]
+    out = torch.empty((P, M, out_ld), dtype=torch.float32, device=a.device)
+    _gemm(torch.float32, A=a, B=b, C=out, M=M, N=N, K=K, lda=K, ldb=K, ldc=out_ld, batch=P, strideA=M * K, strideB=N * K,
+          strideC=M * out_ld, out_f32=1)
+    return out
+
+
+def colsum(x, *, out=None, accumulate=False):
+    x = _actc(x)
+    rows, N = x.shape
+    if out is None:
+        out = torch.empty((N,), dtype=torch.float32, device=x.device)
+        accumulate = False
+    ws = workspace(lib.esvit_colsum_blocks(rows) * N, x.device, slot=1)
+    check(lib.esvit_colsum(_code(x.dtype), _p(x), rows, N, N, _p(out), _p(ws), int(accumulate), _stream()), "colsum")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# normalisation
+# ------------------------------------------------------------------------------------------------
+def layernorm_fwd(x, gamma, beta, eps, *, rowmap=None, period_out=0, out_rows=None, want_f32=False, dtype=None):
+    """x fp32 [nB, T, C] or [rows, C] -> (y act, y_f32 or None, mean, rstd).  With rowmap (int32 [T], token ->
+    window slot) y has out_rows rows, zero at the pad slots."""
+    x = _f32c(x)
+    Cc = x.shape[-1]
+    rows = x.numel() // Cc
+    dt = dtype or _ACT_DTYPE
+    tokens = 0
+    if rowmap is not None:
+        tokens = rowmap.numel()
+        y = torch.zeros((out_rows, Cc), dtype=dt, device=x.device)
+    else:
+        y = torch.empty((rows, Cc), dtype=dt, device=x.device)
+    yf = torch.empty((rows, Cc), dtype=torch.float32, device=x.device) if want_f32 else None
+    mean = torch.empty((rows,), dtype=torch.float32, device=x.device)
+    rstd = torch.empty_like(mean)
+    check(lib.esvit_layernorm_fwd(_code(dt), _p(x), _p(gamma), _p(beta), eps, rows, Cc, _p(y), _p(yf), _p(mean), _p(rstd),
+                                  _p(rowmap), tokens, period_out, _stream()), "layernorm_fwd")
+    return y, yf, mean, rstd
+
+
+def layernorm_bwd(dy, x, mean, rstd, gamma, *, g_in=None, rowmap=None, period_in=0):
+    """-> (dx fp32 like x, dgamma, dbeta).  dy act, read through rowmap (token -> window slot) if given."""
+    x, dy = _f32c(x), _actc(dy)
+    Cc = x.shape[-1]
+    rows = x.numel() // Cc
+    dx = torch.empty_like(x)
+    dgamma = torch.empty((Cc,), dtype=torch.float32, device=x.device)
+    dbeta = torch.empty_like(dgamma)
+    ws = workspace(lib.esvit_layernorm_bwd_blocks(rows, Cc) * 2 * Cc, x.device, slot=1)
+    check(lib.esvit_layernorm_bwd(_code(dy.dtype), _p(dy), _p(x), _p(mean), _p(rstd), _p(gamma), _p(g_in), rows, Cc, _p(dx),
+                                  _p(dgamma), _p(dbeta), _p(ws), _p(rowmap), 0 if rowmap is None else rowmap.numel(),
+                                  period_in, _stream()), "layernorm_bwd")
+    return dx, dgamma, dbeta
+
+
+def merge_ln_fwd(x, gamma, beta, eps, H, W, dtype=None):
+    """x fp32 [nB, H*W, C] -> (y act [nB*H/2*W/2, 4C], mean, rstd)."""
+    x = _f32c(x)
+    nB, L, Cc = x.shape
+    assert L == H * W
+    rows = nB * (H // 2) * (W // 2)
+    dt = dtype or _ACT_DTYPE
+    y = torch.empty((rows, 4 * Cc), dtype=dt, device=x.device)
+    mean = torch.empty((rows,), dtype=torch.float32, device=x.device)
+    rstd = torch.empty_like(mean)
+    check(lib.esvit_merge_ln_fwd(_code(dt), _p(x), _p(gamma), _p(beta), eps, nB, H, W, Cc, _p(y), _p(mean), _p(rstd), _stream()),
+          "merge_ln_fwd")
+    return y, mean, rstd
+
+
+def merge_ln_bwd(dy, x, mean, rstd, gamma, H, W):
+    x, dy = _f32c(x), _actc(dy)
+    nB, L, Cc = x.shape
+    dx = torch.empty_like(x)
+    dgamma = torch.empty((4 * Cc,), dtype=torch.float32, device=x.device)
+    dbeta = torch.empty_like(dgamma)
+    rows = nB * (H // 2) * (W // 2)
+    ws = workspace(lib.esvit_layernorm_bwd_blocks(rows, 4 * Cc) * 8 * Cc, x.device, slot=1)
+    check(lib.esvit_merge_ln_bwd(_code(dy.dtype), _p(dy), _p(x), _p(mean), _p(rstd), _p(gamma), nB, H, W, Cc, _p(dx), _p(dgamma),
+                                 _p(dbeta), _p(ws), _stream()), "merge_ln_bwd")
+    return dx, dgamma, dbeta
+
+
+# ------------------------------------------------------------------------------------------------
+# data movement
+# ------------------------------------------------------------------------------------------------
+def gather_cast(src, rows, *, rowmap=None, tokens=0, rowscale=None, rows_per_sample=0, dtype=None):
+    """dst[r] = cast(scale * src[map(r)]); src fp32 [*, C] -> dst act [rows, C]."""
+    src = _f32c(src)
+    Cc = src.shape[-1]
+    dt = dtype or _ACT_DTYPE
+    dst = torch.empty((rows, Cc), dtype=dt, device=src.device)
+    check(lib.esvit_gather_cast(_code(dt), _p(src), _p(dst), rows, Cc, _p(rowmap), 0 if rowmap is None else rowmap.numel(),
+                                tokens, _p(rowscale), rows_per_sample, _stream()), "gather_cast")
+    return dst
+
+
+def cast_to_act(x, dtype=None):
+    x = _f32c(x)
+    dt = dtype or _ACT_DTYPE
+    out = torch.empty(x.shape, dtype=dt, device=x.device)
+    check(lib.esvit_cast_f32_to(_code(dt), _p(x), _p(out), x.numel(), _stream()), "cast_f32_to")
+    return out
+
+
+def cast_to_f32(x):
+    x = _actc(x)
+    out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    check(lib.esvit_cast_to_f32(_code(x.dtype), _p(x), _p(out), x.numel(), _stream()), "cast_to_f32")
+    return out
+
+
+def transpose_cast(w, dtype=None):
+    w = _f32c(w)
+    R, Cc = w.shape
+    dt = dtype or _ACT_DTYPE
+    out = torch.empty((Cc, R), dtype=dt, device=w.device)
+    check(lib.esvit_transpose_cast(_code(dt), _p(w), _p(out), R, Cc, _stream()), "transpose_cast")
+    return out
+
+
+def patch_im2col(img, P, Kpad, dtype=None):
+    img = _f32c(img)
+    nB, ch, S, S2 = img.shape
+    assert ch == 3 and S == S2
+    dt = dtype or _ACT_DTYPE
+    G = S // P
+    cols = torch.empty((nB * G * G, Kpad), dtype=dt, device=img.device)
+    check(lib.esvit_patch_im2col(_code(dt), _p(img), _p(cols), nB, S, P, Kpad, _stream()), "patch_im2col")
+    return cols
+
+
+def token_mean_fwd(x, dtype=None):
+    """x fp32 [nB, T, C] -> (mean fp32 [nB, C], mean act [nB, C])."""
+    x = _f32c(x)
+    nB, T, Cc = x.shape
+    dt = dtype or _ACT_DTYPE
+    out = torch.empty((nB, Cc), dtype=torch.float32, device=x.device)
+    out_act = torch.empty((nB, Cc), dtype=dt, device=x.device)
+    check(lib.esvit_token_mean_fwd(_code(dt), _p(x), nB, T, Cc, _p(out), _p(out_act), _stream()), "token_mean_fwd")
+    return out, out_act
+
+
+def token_mean_bwd(g_mean, g_tok, T):
+    g_mean = _f32c(g_mean)
+    nB, Cc = g_mean.shape
+    dx = torch.empty((nB, T, Cc), dtype=torch.float32, device=g_mean.device)
+    check(lib.esvit_token_mean_bwd(_p(g_mean), _p(g_tok), nB, T, Cc, _p(dx), _stream()), "token_mean_bwd")
+    return dx
+
+
+# ------------------------------------------------------------------------------------------------
+# window attention
+# ------------------------------------------------------------------------------------------------
+def attn_frag_elems(N):
+    n = lib.esvit_attn_frag_elems(N)
+    if n < 0:
+        raise RuntimeError("window size with %d tokens is not supported by the HIP attention kernel yet" % N)
+    return n
+
+
+def relpos_bias_fwd(table, index, N):
+    table = _f32c(table)
+    nH = table.shape[1]
+    out = torch.empty((nH, attn_frag_elems(N)), dtype=torch.float32, device=table.device)
+    check(lib.esvit_relpos_bias_fwd(_p(table), _p(index), N, nH, _p(out), _stream()), "relpos_bias_fwd")
+    return out
+
+
+def dense_to_frag(dense):
+    dense = _f32c(dense)
+    n, N, _ = dense.shape
+    out = torch.empty((n, attn_frag_elems(N)), dtype=torch.float32, device=dense.device)
+    check(lib.esvit_dense_to_frag(_p(dense), n, N, _p(out), _stream()), "dense_to_frag")
+    return out
+
+
+def window_attn_fwd(qkv, bias_frag, mask_frag, nW, N, nH, scale, want_attn=False):
+    qkv = _actc(qkv)
+    rows, C3 = qkv.shape
+    Cc = C3 // 3
+    Bw = rows // N
+    out = torch.empty((rows, Cc), dtype=qkv.dtype, device=qkv.device)
+    attn = torch.empty((Bw, nH, N, N), dtype=torch.float32, device=qkv.device) if want_attn else None
+    check(lib.esvit_window_attn_fwd(_code(qkv.dtype), _p(qkv), _p(bias_frag), _p(mask_frag), nW, Bw, N, nH, Cc // nH, scale,
+                                    _p(out), _p(attn), _stream()), "window_attn_fwd")
+    return (out, attn) if want_attn else out
+
+
+def window_attn_bwd(qkv, dout, bias_frag, mask_frag, nW, N, nH, scale):
+    """-> (dqkv act, dbias_ws fp32 [parts, nH, frag])."""
+    qkv, dout = _actc(qkv), _actc(dout)
+    rows, C3 = qkv.shape
+    Cc = C3 // 3
+    Bw = rows // N
+    dqkv = torch.empty_like(qkv)
+    parts = lib.esvit_window_attn_bwd_parts(Bw, nH)
+    ws = torch.empty((parts, nH, attn_frag_elems(N)), dtype=torch.float32, device=qkv.device)
+    check(lib.esvit_window_attn_bwd(_code(qkv.dtype), _p(qkv), _p(dout), _p(bias_frag), _p(mask_frag), nW, Bw, N, nH, Cc // nH,
+                                    scale, _p(dqkv), _p(ws), _stream()), "window_attn_bwd")
+    return dqkv, ws
+
+
+def relpos_bias_bwd(dbias_ws, index, N, table_rows):
+    parts, nH, _ = dbias_ws.shape
+    dtable = torch.empty((table_rows, nH), dtype=torch.float32, device=dbias_ws.device)
+    check(lib.esvit_relpos_bias_bwd(_p(dbias_ws), parts, _p(index), N, nH, table_rows, _p(dtable), _stream()), "relpos_bias_bwd")
+    return dtable
+
+
+# ------------------------------------------------------------------------------------------------
+# DINOHead pieces
+# ------------------------------------------------------------------------------------------------
+def l2norm_fwd(x):
+    x = _actc(x)
+    R, D = x.shape
+    z = torch.empty_like(x)
+    inv = torch.empty((R,), dtype=torch.float32, device=x.device)
+    check(lib.esvit_l2norm_fwd(_code(x.dtype), _p(x), R, D, _p(z), _p(inv), _stream()), "l2norm_fwd")
+    return z, inv
+
+
+def l2norm_bwd(dz, z, inv):
+    dz, z = _actc(dz), _actc(z)
+    R, D = z.shape
+    dx = torch.empty_like(z)
+    check(lib.esvit_l2norm_bwd(_code(z.dtype), _p(dz), _p(z), _p(inv), R, D, _p(dx), _stream()), "l2norm_bwd")
+    return dx
+
+
+def weightnorm_fwd(v, g, dtype=None):
+    """v fp32 [K, D], g fp32 [K, 1] -> (w act [K, D], inv_norm fp32 [K])."""
+    v, g = _f32c(v), _f32c(g)
+    K, D = v.shape
+    dt = dtype or _ACT_DTYPE
+    w = torch.empty((K, D), dtype=dt, device=v.device)
+    inv = torch.empty((K,), dtype=torch.float32, device=v.device)
+    check(lib.esvit_weightnorm_fwd(_code(dt), _p(v), _p(g), K, D, _p(w), None, _p(inv), _stream()), "weightnorm_fwd")
+    return w, inv
+
+
+def weightnorm_bwd(dw, v, g, inv, need_dg):
+    dw, v, g = _f32c(dw), _f32c(v), _f32c(g)
+    K, D = v.shape
+    dv = torch.empty_like(v)
+    dg = torch.empty((K, 1), dtype=torch.float32, device=v.device) if need_dg else None
+    check(lib.esvit_weightnorm_bwd(_p(dw), _p(v), _p(g), _p(inv), K, D, _p(dv), _p(dg), _stream()), "weightnorm_bwd")
+    return dv, dg
+
+
+# ------------------------------------------------------------------------------------------------
+# loss
+# ------------------------------------------------------------------------------------------------
+def teacher_row_stats(t, center, inv_temp):
+    t = _actc(t)
+    R, K = t.shape
+    mx = torch.empty((R,), dtype=torch.float32, device=t.device)
+    lse = torch.empty_like(mx)
+    check(lib.esvit_teacher_row_stats(_code(t.dtype), _p(t), _p(center), inv_temp, R, K, _p(mx), _p(lse), _stream()),
+          "teacher_row_stats")
+    return mx, lse
+
+
+def row_argmax(sim, Tt):
+    sim = _f32c(sim)
+    ld = sim.shape[-1]
+    rows = sim.numel() // ld
+    idx = torch.empty((rows,), dtype=torch.int32, device=sim.device)
+    check(lib.esvit_row_argmax(_p(sim), rows, Tt, ld, _p(idx), _stream()), "row_argmax")
+    return idx
+
+
+def dino_ce(s, t, center, t_max, t_lse, tmatch, row_w, inv_student_temp, inv_teacher_temp):
+    """-> (row_loss fp32 [Rs], ds act [Rs, K])."""
+    s, t = _actc(s), _actc(t)
+    Rs, K = s.shape
+    assert t.shape[1] == K and s.dtype == t.dtype and tmatch.dtype == torch.int32
+    row_loss = torch.empty((Rs,), dtype=torch.float32, device=s.device)
+    ds = torch.empty_like(s)
+    check(lib.esvit_dino_ce_fwd_bwd(_code(s.dtype), _p(s), _p(t), _p(center), _p(t_max), _p(t_lse), _p(tmatch), _p(row_w),
+                                    inv_student_temp, inv_teacher_temp, Rs, K, _p(row_loss), _p(ds), _stream()), "dino_ce_fwd_bwd")
+    return row_loss, ds
+
+
+def sum_f32(x):
+    x = _f32c(x)
+    out = torch.empty((), dtype=torch.float32, device=x.device)
+    check(lib.esvit_sum_f32(_p(x), x.numel(), _p(out), _stream()), "sum_f32")
+    return out
+
+
+def scale_inplace(x, scale):
+    x = _actc(x)
+    check(lib.esvit_scale_inplace(_code(x.dtype), _p(x), x.numel(), _p(_f32c(scale)), _stream()), "scale_inplace")
+    return x
+
+
+def center_ema(center, colsum_, momentum, denom):
+    check(lib.esvit_center_ema(_p(_f32c(center)), _p(_f32c(colsum_)), momentum, float(denom), center.numel(), _stream()),
+          "center_ema")
+    return center
+
+
+# ------------------------------------------------------------------------------------------------
+# fused update
+# ------------------------------------------------------------------------------------------------
+def update_chunk_elems():
+    return lib.esvit_update_chunk_elems()
+
+
+def grad_sqnorm(tensors, ntensors, chunks, nchunks, sqnorms):
+    check(lib.esvit_grad_sqnorm(_p(tensors), ntensors, _p(chunks), nchunks, _p(sqnorms), _stream()), "grad_sqnorm")
+
+
+def fused_clip_adamw_ema(tensors, ntensors, chunks, nchunks, sqnorms, clip, lr, wd, beta1, beta2, eps, ema_m):
+    check(lib.esvit_fused_clip_adamw_ema(_p(tensors), ntensors, _p(chunks), nchunks, _p(sqnorms), clip, lr, wd, beta1, beta2, eps,
+                                         ema_m, _stream()), "fused_clip_adamw_ema")
+
+
+def debug_set_tr_read(on):
+    lib.esvit_debug_set_tr_read(int(on))
+    lib.esvit_debug_set_attn_tr_read(int(on))

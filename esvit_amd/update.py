@@ -1,0 +1,170 @@
+"""Fused student update + teacher EMA (reference: utils.py:106-123, torch.optim.AdamW as driven by
+main_esvit.py:506-510/574, EMA loop main_esvit.py:587-590) -- two multi-tensor HIP launches, no
+host synchronisation.
+
+``FusedClipAdamWEMA`` keeps the optimizer state in the same layout as ``torch.optim.AdamW``
+(``state_dict()`` / ``load_state_dict()`` produce / accept the reference checkpoint's
+``optimizer`` entry: per-parameter ``step``, ``exp_avg``, ``exp_avg_sq``; two param groups from
+``get_params_groups``), so checkpoints stay interchangeable with the unmodified caller.
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import ops
+
+TFIELDS = 10
+
+
+def get_params_groups(model):
+    """utils.py:672-683: biases and 1-D parameters are not regularised; frozen parameters are skipped."""
+    regularized, not_regularized = [], []
+    for name, param in model.named_parameters():
+        if not param.requires_grad:
+            continue
+        if name.endswith(".bias") or len(param.shape) == 1:
+            not_regularized.append(param)
+        else:
+            regularized.append(param)
+    return [{"params": regularized}, {"params": not_regularized, "weight_decay": 0.0}]
+
+
+def cosine_scheduler(base_value, final_value, epochs, niter_per_ep, warmup_epochs=0, start_warmup_value=0):
+    """utils.py:161-173."""
+    warmup_iters = warmup_epochs * niter_per_ep
+    warm = np.linspace(start_warmup_value, base_value, warmup_iters) if warmup_epochs > 0 else np.array([])
+    n = epochs * niter_per_ep - warmup_iters
+    it = np.arange(n)
+    sched = final_value + 0.5 * (base_value - final_value) * (1 + np.cos(np.pi * it / n))
+    sched = np.concatenate((warm, sched))
+    assert len(sched) == epochs * niter_per_ep
+    return sched
+
+
+class FusedClipAdamWEMA:
+    """clip -> AdamW -> EMA for (student, teacher) in one pass.
+
+    student / teacher: modules with positionally matching ``.parameters()`` (main_esvit.py:589).
+    Only parameters with ``requires_grad`` are optimised; *every* parameter is EMA-ed, exactly as the
+    reference loop does.
+    """
+
+    def __init__(self, student, teacher, betas=(0.9, 0.999), eps=1e-8):
+        self.betas, self.eps = betas, eps
+        self.params = list(student.parameters())
+        self.names = [n for n, _ in student.named_parameters()]
+        self.teacher_params = list(teacher.parameters()) if teacher is not None else [None] * len(self.params)
+        assert len(self.teacher_params) == len(self.params)
+        groups = get_params_groups(student)
+        self.param_groups = [dict(params=groups[0]["params"], lr=0.0, weight_decay=0.0, betas=betas, eps=eps),
+                             dict(params=groups[1]["params"], lr=0.0, weight_decay=0.0, betas=betas, eps=eps)]
+        gid = {}
+        for gi, g in enumerate(groups):
+            for p in g["params"]:
+                gid[id(p)] = gi
+        self.group_of = [gid.get(id(p), 1) for p in self.params]
+        self.trainable = [p.requires_grad for p in self.params]
+        dev = self.params[0].device
+        self.device = dev
+        self.exp_avg = [torch.zeros_like(p) if t else None for p, t in zip(self.params, self.trainable)]
+        self.exp_avg_sq = [torch.zeros_like(p) if t else None for p, t in zip(self.params, self.trainable)]
+        self.steps = [0] * len(self.params)
+        chunk = ops.update_chunk_elems()
+        chunks = []
+        for ti, p in enumerate(self.params):
+            for ci in range(-(-p.numel() // chunk)):
+                chunks.append((ti, ci))
+        self.nchunks = len(chunks)
+        self.chunks = torch.tensor(chunks, dtype=torch.int32).to(dev)
+        self.sqnorms = torch.zeros(len(self.params), dtype=torch.float32, device=dev)
+        # ring of pinned staging tables: a buffer is rewritten only after the async H2D copy that read it completed
+        self._ring = [torch.zeros((len(self.params), TFIELDS), dtype=torch.int64).pin_memory() for _ in range(4)]
+        self._ring_ev = [None] * len(self._ring)
+        self._ring_pos = 0
+        self._table_dev = torch.zeros((len(self.params), TFIELDS), dtype=torch.int64, device=dev)
+
+    @staticmethod
+    def _bits(x):
+        return int(np.float32(x).view(np.uint32))
+
+    def step(self, lr, weight_decay, ema_momentum, clip_grad=3.0, skip_last_layer=False):
+        """One update.  lr / weight_decay / ema_momentum are the per-iteration schedule values
+        (main_esvit.py:506-510, 588); skip_last_layer mirrors cancel_gradients_last_layer (utils.py:118-123)."""
+        b1, b2 = self.betas
+        slot = self._ring_pos
+        self._ring_pos = (slot + 1) % len(self._ring)
+        if self._ring_ev[slot] is not None:
+            self._ring_ev[slot].synchronize()
+        tab = self._ring[slot]
+        for i, p in enumerate(self.params):
+            g = p.grad
+            has = self.trainable[i] and g is not None and not (skip_last_layer and "last_layer" in self.names[i])
+            if has:
+                assert g.is_contiguous() and g.dtype == torch.float32
+                self.steps[i] += 1
+                t = self.steps[i]
+                bc = self._bits(1.0 - b1 ** t) | (self._bits(1.0 - b2 ** t) << 32)
+                if bc >= 1 << 63:
+                    bc -= 1 << 64
+            tp = self.teacher_params[i]
+            row = tab[i]
+            row[0] = p.data_ptr()
+            row[1] = g.data_ptr() if has else 0
+            row[2] = self.exp_avg[i].data_ptr() if self.trainable[i] else 0
+            row[3] = self.exp_avg_sq[i].data_ptr() if self.trainable[i] else 0
+            row[4] = tp.data_ptr() if tp is not None else 0
+            row[5] = p.numel()
+            row[6] = self.group_of[i]
+            row[7] = 1 if has else 0
+            row[8] = bc if has else 0
+        self._table_dev.copy_(tab, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._ring_ev[slot] = ev
+        n = len(self.params)
+        ops.grad_sqnorm(self._table_dev, n, self.chunks, self.nchunks, self.sqnorms)
+        ops.fused_clip_adamw_ema(self._table_dev, n, self.chunks, self.nchunks, self.sqnorms, float(clip_grad or 0.0), float(lr),
+                                 float(weight_decay), b1, b2, self.eps, float(ema_momentum))
+        for g in self.param_groups:
+            g["lr"] = float(lr)
+        self.param_groups[0]["weight_decay"] = float(weight_decay)
+
+    def zero_grad(self, set_to_none=True):
+        for p in self.params:
+            if set_to_none:
+                p.grad = None
+            elif p.grad is not None:
+                p.grad.zero_()
+
+    # ---- torch.optim.AdamW-compatible checkpoint layout -----------------------------------------
+    def _ordered(self):
+        order = []
+        for g in self.param_groups:
+            order.extend(g["params"])
+        pos = {id(p): i for i, p in enumerate(self.params)}
+        return [pos[id(p)] for p in order]
+
+    def state_dict(self):
+        order = self._ordered()
+        state = {}
+        for k, i in enumerate(order):
+            if self.steps[i] > 0:
+                state[k] = {"step": torch.tensor(float(self.steps[i])), "exp_avg": self.exp_avg[i], "exp_avg_sq": self.exp_avg_sq[i]}
+        groups, k = [], 0
+        for g in self.param_groups:
+            n = len(g["params"])
+            groups.append({"lr": g["lr"], "betas": self.betas, "eps": self.eps, "weight_decay": g["weight_decay"],
+                           "amsgrad": False, "params": list(range(k, k + n))})
+            k += n
+        return {"state": state, "param_groups": groups}
+
+    def load_state_dict(self, sd):
+        order = self._ordered()
+        for k, st in sd["state"].items():
+            i = order[int(k)]
+            self.steps[i] = int(float(st["step"]))
+            self.exp_avg[i].copy_(st["exp_avg"])
+            self.exp_avg_sq[i].copy_(st["exp_avg_sq"])
+        for g, sg in zip(self.param_groups, sd["param_groups"]):
+            g["lr"], g["weight_decay"] = sg["lr"], sg["weight_decay"]

@@ -1,0 +1,235 @@
+/* libesvit_hip.so -- C ABI of the MI355X-native EsViT pre-training hot path.
+ *
+ * Every entry point replaces a stretch of the reference's PyTorch code (cited per
+ * function as reference file:line, paths relative to microsoft/esvit).  Conventions
+ * (SURVEY.md 8b):
+ *   - all buffers are caller-allocated DEVICE memory passed as raw pointers; the
+ *     library never allocates, frees or retains device memory;
+ *   - all work is enqueued on the caller's hipStream_t; no internal synchronisation;
+ *   - return 0 on success, negative on failure (ESVIT_ERR_*); the message is
+ *     available through esvit_last_error(); no C++ exception crosses the ABI;
+ *   - `dtype` selects the storage type of *activations* (ESVIT_F32 / ESVIT_BF16);
+ *     parameters, the residual stream, statistics and gradients of parameters are
+ *     always fp32.
+ */
+#ifndef ESVIT_HIP_H
+#define ESVIT_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ESVIT_F32 0
+#define ESVIT_BF16 1
+
+#define ESVIT_OK 0
+#define ESVIT_ERR_ARG (-1)
+#define ESVIT_ERR_HIP (-2)
+#define ESVIT_ERR_UNSUPPORTED (-3)
+
+typedef void* esvit_stream_t; /* hipStream_t */
+
+/* ---- library ---------------------------------------------------------- */
+int esvit_version(void);
+const char* esvit_last_error(void);
+
+/* ---- host-side integer index maps (bit-exact vs reference) -------------
+ * swin_transformer.py:100-110 (relative_position_index), :40-69 + :286-325
+ * (pad -> roll -> window_partition and its inverse), :249-272 (shift mask).  */
+/* out[N*N], N = ws*ws */
+int esvit_relative_position_index(int ws, int64_t* out);
+/* win2tok[nW*N]: source token (i*W+j) for every window slot, -1 for zero-pad slots.
+ * tok2win[H*W]: window slot of every real token.  Either pointer may be NULL. */
+int esvit_window_maps(int H, int W, int ws, int shift, int32_t* win2tok, int32_t* tok2win);
+/* mask[nW*N*N] in {0,-100}; returns nW through *n_windows */
+int esvit_shift_mask(int H, int W, int ws, int shift, float* mask, int* n_windows);
+
+/* ---- MFMA GEMM family -------------------------------------------------- */
+#define ESVIT_EPI_NONE 0
+#define ESVIT_EPI_GELU 1     /* out = gelu(acc+bias); aux (if set) receives acc+bias */
+#define ESVIT_EPI_GELU_BWD 2 /* out = acc * gelu'(aux) */
+
+typedef struct {
+    const void* A;
+    const void* B;
+    void* C;
+    int32_t M, N, K;
+    int64_t lda, ldb, ldc;
+    int32_t a_kstrided; /* 0: A is M x K row-major (K contiguous); 1: A is K x M row-major */
+    int32_t b_kstrided; /* 0: B is N x K row-major (K contiguous); 1: B is K x N row-major */
+    int32_t batch;      /* >=1; strides in elements */
+    int64_t strideA, strideB, strideC;
+    const float* bias;     /* [N] or NULL */
+    const float* residual; /* fp32, indexed [dst_row*ldr + n] or NULL */
+    int64_t ldr;
+    const int32_t* rowmap; /* NULL or [rowmap_period]: dst_row = (m/period)*rowmap_tokens + rowmap[m%period]; <0 => row dropped */
+    int32_t rowmap_period, rowmap_tokens;
+    const float* rowscale; /* NULL or per-sample scale, index dst_row / rows_per_sample */
+    int32_t rows_per_sample;
+    void* aux; /* activation dtype, ld = ldaux */
+    int64_t ldaux;
+    int32_t epilogue; /* ESVIT_EPI_* */
+    int32_t out_f32;  /* 1: C is fp32, 0: C has the activation dtype */
+    int32_t splitk;   /* >1: partial sums in `partial` then reduced into C (fp32, out_f32 must be 1) */
+    float* partial;   /* workspace >= splitk*M*N floats */
+    int32_t accumulate; /* split-K reduce: C += sum (1) or C = sum (0) */
+    float alpha;
+} esvit_gemm_desc;
+
+/* C = alpha * op(A) op(B) (+ epilogue).  Replaces every nn.Linear / conv-as-GEMM on the
+ * path: swin_transformer.py:31-37,127,150,418,531; vision_transformer.py:414-418;
+ * and their autograd backward (dgrad: b_kstrided or cached W^T; wgrad: a_kstrided && b_kstrided). */
+int esvit_gemm(int dtype, const esvit_gemm_desc* d, esvit_stream_t stream);
+
+/* ---- normalisation ----------------------------------------------------- */
+/* LayerNorm forward over rows of C channels (swin_transformer.py:283,331,417,546,687;
+ * eps 1e-6 at :963).  x: fp32 [rows, C] (or gathered, see gather).  y has `dtype`.
+ * rowmap (optional): y row = (r/tokens)*period_out + rowmap[r%tokens] (token -> window slot);
+ * the caller pre-zeroes y so pad slots stay 0 (swin_transformer.py:286-290).
+ * y_f32 (optional) receives an fp32 copy at the un-mapped row. */
+int esvit_layernorm_fwd(int dtype, const float* x, const float* gamma, const float* beta, float eps,
+                        int64_t rows, int C, void* y, float* y_f32, float* mean, float* rstd,
+                        const int32_t* rowmap, int tokens, int period_out, esvit_stream_t stream);
+/* LayerNorm backward.  dy (dtype) is read at the mapped row when rowmap is given.
+ * dx = g_in (optional fp32 residual gradient) + LN'(dy).  dgamma/dbeta partials are
+ * written to ws ([nblk,2,C] floats, nblk returned via esvit_layernorm_bwd_blocks) and
+ * reduced into dgamma/dbeta (fp32, overwritten). */
+int esvit_layernorm_bwd_blocks(int64_t rows, int C);
+int esvit_layernorm_bwd(int dtype, const void* dy, const float* x, const float* mean, const float* rstd,
+                        const float* gamma, const float* g_in, int64_t rows, int C, float* dx,
+                        float* dgamma, float* dbeta, float* ws, const int32_t* rowmap, int tokens,
+                        int period_in, esvit_stream_t stream);
+
+/* ---- element-wise / data-movement helpers ------------------------------ */
+/* dst[r,:] = cast(scale[r/rows_per_sample] * src[map(r),:]); src fp32 [*, C]; dst dtype [rows, C].
+ * rowmap (optional, [period]): src row = (r/period)*tokens + rowmap[r%period]; <0 => zeros.
+ * Used for dY staging of the windowed proj backward (swin_transformer.py:315-330 reversed). */
+int esvit_gather_cast(int dtype, const float* src, void* dst, int64_t rows, int C, const int32_t* rowmap,
+                      int period, int tokens, const float* rowscale, int rows_per_sample,
+                      esvit_stream_t stream);
+/* plain casts between fp32 and activation dtype (weight caches) */
+int esvit_cast_f32_to(int dtype, const float* src, void* dst, int64_t n, esvit_stream_t stream);
+int esvit_cast_to_f32(int dtype, const void* src, float* dst, int64_t n, esvit_stream_t stream);
+/* dst[C,R] = cast(src[R,C])^T -- cached W^T for the dgrad GEMMs */
+int esvit_transpose_cast(int dtype, const float* src, void* dst, int R, int C, esvit_stream_t stream);
+/* out[n] (+)= sum_r x[r,n]  (bias gradients).  ws >= esvit_colsum_blocks(rows)*N floats */
+int esvit_colsum_blocks(int64_t rows);
+int esvit_colsum(int dtype, const void* x, int64_t rows, int N, int64_t ld, float* out, float* ws,
+                 int accumulate, esvit_stream_t stream);
+
+/* PatchEmbed im2col for the 4x4/4 conv (swin_transformer.py:531,544): img fp32 NCHW [nB,3,S,S]
+ * -> cols dtype [nB*(S/P)^2, Kpad], column order (c, ph, pw), zero padded to Kpad. */
+int esvit_patch_im2col(int dtype, const float* img, void* cols, int nB, int S, int P, int Kpad,
+                       esvit_stream_t stream);
+/* PatchMerging gather + LayerNorm(4C) (swin_transformer.py:410-417): x fp32 [nB,H,W,C] ->
+ * y dtype [nB*(H/2)*(W/2), 4C]; channel blocks [x(2i,2j), x(2i+1,2j), x(2i,2j+1), x(2i+1,2j+1)]. */
+int esvit_merge_ln_fwd(int dtype, const float* x, const float* gamma, const float* beta, float eps,
+                       int nB, int H, int W, int C, void* y, float* mean, float* rstd,
+                       esvit_stream_t stream);
+/* backward of the above: dy dtype [nB*(H/2)*(W/2), 4C] -> dx fp32 [nB,H,W,C] (overwritten) */
+int esvit_merge_ln_bwd(int dtype, const void* dy, const float* x, const float* mean, const float* rstd,
+                       const float* gamma, int nB, int H, int W, int C, float* dx, float* dgamma,
+                       float* dbeta, float* ws, esvit_stream_t stream);
+/* token mean (swin_transformer.py:688-689): x fp32 [nB,T,C] -> out fp32 [nB,C] (+ act copy) */
+int esvit_token_mean_fwd(int dtype, const float* x, int nB, int T, int C, float* out, void* out_act,
+                         esvit_stream_t stream);
+/* dx[b,t,:] = g_tok[b,t,:] (optional) + g_mean[b,:]/T */
+int esvit_token_mean_bwd(const float* g_mean, const float* g_tok, int nB, int T, int C, float* dx,
+                         esvit_stream_t stream);
+
+/* ---- window attention (swin_transformer.py:126-152) ---------------------
+ * "frag layout" of an NP x NP matrix X[q][key] (NP = 64 for 7x7 windows): the order in which the
+ * MFMA accumulators of the transposed score tile hold it,
+ *   X_frag[((ki*4 + qj)*64 + lane)*4 + r] = X[q = 16*qj + c][key = 16*ki + 4*g + r], lane = 16*g + c.
+ * esvit_attn_frag_elems(N) = floats per matrix in that layout (4096), -1 if N is unsupported. */
+int esvit_attn_frag_elems(int N);
+/* dense relative-position bias in frag layout (swin_transformer.py:133-135): table fp32
+ * [(2ws-1)^2, nH], index int64 [N*N] -> bias_frag fp32 [nH, frag]; key columns >= N get -1e30. */
+int esvit_relpos_bias_fwd(const float* table, const int64_t* index, int N, int nH, float* bias_frag,
+                          esvit_stream_t stream);
+/* dense fp32 [n_mats, N, N] -> frag layout [n_mats, frag] (zero padded); used once per geometry
+ * for the shift mask of swin_transformer.py:249-272. */
+int esvit_dense_to_frag(const float* dense, int n_mats, int N, float* frag, esvit_stream_t stream);
+/* qkv dtype [Bw*N, 3C] (row = window slot; columns [3][nH][hd]) -> out dtype [Bw*N, C].
+ * mask_frag fp32 [nW, frag] or NULL (window w uses mask w % nW); scale = hd^-0.5 applied to q
+ * before the product (swin_transformer.py:130).  N = ws*ws = 49, hd = 32.
+ * attn_out (optional, fp32 [Bw,nH,N,N]) receives the softmax (swin_transformer.py:146,152). */
+int esvit_window_attn_fwd(int dtype, const void* qkv, const float* bias_frag, const float* mask_frag,
+                          int nW, int Bw, int N, int nH, int hd, float scale, void* out,
+                          float* attn_out, esvit_stream_t stream);
+/* dout dtype [Bw*N, C] -> dqkv dtype [Bw*N, 3C]; dbias_ws fp32 [parts, nH, frag] receives
+ * per-wave partial bias gradients, parts = esvit_window_attn_bwd_parts(Bw, nH). */
+int esvit_window_attn_bwd_parts(int Bw, int nH);
+int esvit_window_attn_bwd(int dtype, const void* qkv, const void* dout, const float* bias_frag,
+                          const float* mask_frag, int nW, int Bw, int N, int nH, int hd, float scale,
+                          void* dqkv, float* dbias_ws, esvit_stream_t stream);
+/* dtable fp32 [table_rows, nH] (overwritten) = scatter-add over index of sum_parts dbias_ws */
+int esvit_relpos_bias_bwd(const float* dbias_ws, int parts, const int64_t* index, int N, int nH,
+                          int table_rows, float* dtable, esvit_stream_t stream);
+
+/* ---- DINOHead pieces (vision_transformer.py:414-418) -------------------- */
+/* z = x / max(||x||_2, 1e-12) row-wise; x dtype [R, D]; z dtype; inv_norm fp32 [R] */
+int esvit_l2norm_fwd(int dtype, const void* x, int64_t R, int D, void* z, float* inv_norm,
+                     esvit_stream_t stream);
+/* dx = (dz - (dz.z) z) * inv_norm */
+int esvit_l2norm_bwd(int dtype, const void* dz, const void* z, const float* inv_norm, int64_t R, int D,
+                     void* dx, esvit_stream_t stream);
+/* legacy weight_norm(dim=0): w[k,:] = g[k] * v[k,:]/||v[k,:]||; v fp32 [K,D]; g fp32 [K];
+ * w, wT in dtype ([K,D] and [D,K], either may be NULL); inv_norm fp32 [K] */
+int esvit_weightnorm_fwd(int dtype, const float* v, const float* g, int K, int D, void* w, void* wT,
+                         float* inv_norm, esvit_stream_t stream);
+/* dv = g*inv*(dw - (dw.vhat) vhat); dg = dw.vhat (dg may be NULL) */
+int esvit_weightnorm_bwd(const float* dw, const float* v, const float* g, const float* inv_norm, int K,
+                         int D, float* dv, float* dg, esvit_stream_t stream);
+
+/* ---- DINOLoss / DDINOLoss (main_esvit.py:603-770) ----------------------- */
+/* per-row stats of the sharpened, centred teacher logits (main_esvit.py:629,694,697):
+ * for row r: mx[r] = max_k (t[r,k]-c[k])/temp ; lse[r] = log sum exp(.. - mx) */
+int esvit_teacher_row_stats(int dtype, const void* t, const float* center, float inv_temp, int64_t R,
+                            int K, float* row_max, float* row_lse, esvit_stream_t stream);
+/* region matching (main_esvit.py:735-736): sim fp32 [P, Ts, ldsim] -> idx int32 [P*Ts] =
+ * argmax over first Tt columns (first index on ties) */
+int esvit_row_argmax(const float* sim, int64_t rows, int Tt, int ld, int32_t* idx, esvit_stream_t stream);
+/* fused student log-softmax CE + gradient (main_esvit.py:706-746).
+ * s dtype [Rs, K] student logits (un-tempered); for student row r the teacher rows it is
+ * scored against are tmatch[r*2+0], tmatch[r*2+1] (row index into t, -1 = unused term).
+ * row_w[r] = weight of each term of that row (0.5/(n_terms*B) or 0.5/(n_terms*B*Ts), 1/.. for DINOLoss).
+ * Outputs: row_loss fp32 [Rs] (sum over the row's terms, already weighted), ds dtype [Rs, K]
+ * = d loss / d s (includes 1/student_temp). */
+int esvit_dino_ce_fwd_bwd(int dtype, const void* s, const void* t, const float* center,
+                          const float* t_row_max, const float* t_row_lse, const int32_t* tmatch,
+                          const float* row_w, float inv_student_temp, float inv_teacher_temp,
+                          int64_t Rs, int K, float* row_loss, void* ds, esvit_stream_t stream);
+/* deterministic sum of row_loss -> loss[0] */
+int esvit_sum_f32(const float* x, int64_t n, float* out, esvit_stream_t stream);
+/* ds *= scale[0] (scale on device: grad_output of the scalar loss) */
+int esvit_scale_inplace(int dtype, void* x, int64_t n, const float* scale, esvit_stream_t stream);
+/* center EMA (main_esvit.py:651-660, 752-770): c = c*m + (1-m) * colsum / denom */
+int esvit_center_ema(float* center, const float* colsum, float momentum, float denom, int K,
+                     esvit_stream_t stream);
+
+/* ---- fused update: per-parameter clip + AdamW + teacher EMA -------------
+ * utils.py:106-115 (clip), torch.optim.AdamW as driven by main_esvit.py:506-510,574,
+ * EMA main_esvit.py:587-590.  Tensor table (device, int64[ntensors*10]):
+ *   [p, g, exp_avg, exp_avg_sq, teacher_p (0 = none), numel, group (0: weight decay, 1: none),
+ *    flags (bit0: has gradient; otherwise only the EMA is applied),
+ *    bits(1-beta1^t) | bits(1-beta2^t) << 32, reserved]
+ * chunk table (device, int32[nchunks*2]): [tensor_id, chunk_index], chunk =
+ * esvit_update_chunk_elems() elements.  sqnorms: fp32 scratch [ntensors]. */
+int esvit_update_chunk_elems(void);
+int esvit_grad_sqnorm(const int64_t* tensors, int ntensors, const int32_t* chunks, int nchunks,
+                      float* sqnorms, esvit_stream_t stream);
+int esvit_fused_clip_adamw_ema(const int64_t* tensors, int ntensors, const int32_t* chunks, int nchunks,
+                               const float* sqnorms, float clip, float lr, float wd, float beta1,
+                               float beta2, float eps, float ema_m, esvit_stream_t stream);
+
+/* ---- debug switches (tests only) ---------------------------------------- */
+void esvit_debug_set_tr_read(int on);      /* GEMM: ds_read_b64_tr_b16 vs scalar LDS gathers */
+void esvit_debug_set_attn_tr_read(int on); /* attention backward: same */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ESVIT_HIP_H */

@@ -1,0 +1,445 @@
+"""TEST INFRASTRUCTURE ONLY -- plain-PyTorch restatement of every op in esvit_amd/ops.py.
+
+Same function names and signatures as ``esvit_amd.ops`` so that (a) the ``-m gpu`` tests can
+compare each HIP kernel with an independent implementation on identical inputs, and (b) the
+CPU tests can monkeypatch ``esvit_amd.ops`` with this module to check the host-side composition
+(manual backward formulas, index maps, autograd plumbing) against the reference model without
+a GPU.  Nothing under esvit_amd/ imports this file; only tests/, bench.py's cpu_baseline leg and
+__graft_entry__.smoke() may.
+
+Everything is computed in fp32 (fp64 where cheap) from the *given* inputs; outputs are rounded
+to the activation dtype only at the points where the HIP kernels store activations.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+_ACT_DTYPE = torch.float32
+
+
+def set_act_dtype(dt):
+    global _ACT_DTYPE
+    _ACT_DTYPE = dt
+
+
+def act_dtype():
+    return _ACT_DTYPE
+
+
+# ---- host-side integer maps (independent restatement with torch ops, swin_transformer.py) ----
+def relative_position_index(ws):
+    # swin_transformer.py:100-109
+    co = torch.stack(torch.meshgrid(torch.arange(ws), torch.arange(ws), indexing="ij")).flatten(1)
+    rel = (co[:, :, None] - co[:, None, :]).permute(1, 2, 0).contiguous()
+    rel[:, :, 0] += ws - 1
+    rel[:, :, 1] += ws - 1
+    rel[:, :, 0] *= 2 * ws - 1
+    return rel.sum(-1).numpy().astype(np.int64)
+
+
+def _partition(x, ws):
+    # swin_transformer.py:49-51
+    B, H, W, C = x.shape
+    x = x.view(B, H // ws, ws, W // ws, ws, C)
+    return x.permute(0, 1, 3, 2, 4, 5).contiguous().view(-1, ws, ws, C)
+
+
+def window_maps(H, W, ws, shift):
+    # swin_transformer.py:286-309 applied to token ids
+    Hp, Wp = -(-H // ws) * ws, -(-W // ws) * ws
+    ids = torch.arange(H * W, dtype=torch.float32).view(1, H, W, 1) + 1.0  # 0 reserved for pad
+    ids = F.pad(ids, (0, 0, 0, Wp - W, 0, Hp - H))
+    if shift > 0:
+        ids = torch.roll(ids, shifts=(-shift, -shift), dims=(1, 2))
+    win = _partition(ids, ws).view(-1).to(torch.int64) - 1
+    win2tok = win.numpy().astype(np.int32)
+    tok2win = np.empty(H * W, dtype=np.int32)
+    slots = np.nonzero(win2tok >= 0)[0]
+    tok2win[win2tok[slots]] = slots.astype(np.int32)
+    return win2tok, tok2win
+
+
+def shift_mask(H, W, ws, shift):
+    # swin_transformer.py:249-272
+    Hp, Wp = -(-H // ws) * ws, -(-W // ws) * ws
+    img = torch.zeros((1, Hp, Wp, 1))
+    cnt = 0
+    for h in (slice(0, -ws), slice(-ws, -shift), slice(-shift, None)):
+        for w in (slice(0, -ws), slice(-ws, -shift), slice(-shift, None)):
+            img[:, h, w, :] = cnt
+            cnt += 1
+    mw = _partition(img, ws).view(-1, ws * ws)
+    m = mw.unsqueeze(1) - mw.unsqueeze(2)
+    m = m.masked_fill(m != 0, -100.0).masked_fill(m == 0, 0.0)
+    return m.numpy().astype(np.float32)
+
+
+# ---- helpers -----------------------------------------------------------------------------
+def _r(x, dt=None):
+    return x.to(dt or _ACT_DTYPE)
+
+
+def _gelu(x):
+    return 0.5 * x * (1.0 + torch.erf(x * 0.7071067811865476))
+
+
+def _gelu_grad(x):
+    return 0.5 * (1.0 + torch.erf(x * 0.7071067811865476)) + x * torch.exp(-0.5 * x * x) * 0.3989422804014327
+
+
+def workspace(n, device, slot=0):
+    return torch.empty(int(n), dtype=torch.float32, device=device)
+
+
+# ---- GEMM family -------------------------------------------------------------------------
+def linear_fwd(x, w, bias=None, *, gelu=False, want_preact=False, residual=None, rowmap=None, rowmap_tokens=0,
+               out_rows=None, rowscale=None, rows_per_sample=0, out_f32=False):
+    acc = x.float() @ w.float().t()
+    if bias is not None:
+        acc = acc + bias
+    pre = None
+    if gelu:
+        pre = _r(acc, x.dtype)
+        acc = _gelu(acc)
+    M = x.shape[0]
+    if rowmap is not None:
+        period = rowmap.numel()
+        m = torch.arange(M, device=x.device)
+        t = rowmap.long()[m % period]
+        keep = t >= 0
+        drow = (m // period) * rowmap_tokens + t
+        acc, drow = acc[keep], drow[keep]
+        rows = out_rows
+    else:
+        drow = torch.arange(M, device=x.device)
+        rows = M if out_rows is None else out_rows
+    if rowscale is not None:
+        acc = acc * rowscale[drow // rows_per_sample].unsqueeze(1)
+    if residual is not None:
+        acc = acc + residual[drow]
+    y = torch.zeros((rows, w.shape[0]), dtype=torch.float32, device=x.device)
+    if residual is not None and rowmap is not None:
+        y = y  # rows never written by the kernel are undefined; tests only compare written rows
+    y[drow] = acc
+    y = y if out_f32 else _r(y, x.dtype)
+    return (y, pre) if gelu and want_preact else y
+
+
+def linear_dgrad(dy, w, *, gelu_preact=None, out_f32=False):
+    dx = dy.float() @ w.float()
+    if gelu_preact is not None:
+        dx = dx * _gelu_grad(gelu_preact.float())
+    return dx if out_f32 else _r(dx, dy.dtype)
+
+
+def linear_wgrad(dy, x, *, out=None, accumulate=False):
+    dw = dy.float().t() @ x.float()
+    if out is not None:
+        if accumulate:
+            out += dw
+        else:
+            out.copy_(dw)
+        return out
+    return dw
+
+
+def batched_nt(a, b, out_ld):
+    P, M, K = a.shape
+    N = b.shape[1]
+    out = torch.zeros((P, M, out_ld), dtype=torch.float32, device=a.device)
+    out[:, :, :N] = torch.bmm(a, b.transpose(1, 2))
+    return out
+
+
+def colsum(x, *, out=None, accumulate=False):
+    s = x.float().sum(0)
+    if out is not None:
+        if accumulate:
+            out += s
+        else:
+            out.copy_(s)
+        return out
+    return s
+
+
+# ---- normalisation ---------------------------------------------------------------------------
+def layernorm_fwd(x, gamma, beta, eps, *, rowmap=None, period_out=0, out_rows=None, want_f32=False, dtype=None):
+    C = x.shape[-1]
+    x2 = x.reshape(-1, C).float()
+    mean = x2.mean(1)
+    var = ((x2 - mean[:, None]) ** 2).mean(1)
+    rstd = torch.rsqrt(var + eps)
+    y = (x2 - mean[:, None]) * rstd[:, None] * gamma + beta
+    dt = dtype or _ACT_DTYPE
+    if rowmap is not None:
+        T = rowmap.numel()
+        r = torch.arange(x2.shape[0], device=x.device)
+        ro = (r // T) * period_out + rowmap.long()[r % T]
+        out = torch.zeros((out_rows, C), dtype=dt, device=x.device)
+        out[ro] = _r(y, dt)
+    else:
+        out = _r(y, dt)
+    return out, (y if want_f32 else None), mean, rstd
+
+
+def layernorm_bwd(dy, x, mean, rstd, gamma, *, g_in=None, rowmap=None, period_in=0):
+    C = x.shape[-1]
+    x2 = x.reshape(-1, C).float()
+    if rowmap is not None:
+        T = rowmap.numel()
+        r = torch.arange(x2.shape[0], device=x.device)
+        ri = (r // T) * period_in + rowmap.long()[r % T]
+        d = dy.float()[ri]
+    else:
+        d = dy.float().reshape(-1, C)
+    xh = (x2 - mean[:, None]) * rstd[:, None]
+    gd = d * gamma
+    dx = (gd - gd.mean(1, keepdim=True) - xh * (gd * xh).mean(1, keepdim=True)) * rstd[:, None]
+    if g_in is not None:
+        dx = dx + g_in.reshape(-1, C)
+    return dx.reshape(x.shape), (d * xh).sum(0), d.sum(0)
+
+
+def _merge_gather(x, H, W):
+    nB, L, C = x.shape
+    xg = x.view(nB, H, W, C)
+    return torch.cat([xg[:, 0::2, 0::2], xg[:, 1::2, 0::2], xg[:, 0::2, 1::2], xg[:, 1::2, 1::2]], -1).reshape(-1, 4 * C)
+
+
+def merge_ln_fwd(x, gamma, beta, eps, H, W, dtype=None):
+    g = _merge_gather(x.float(), H, W)
+    y, _, mean, rstd = layernorm_fwd(g, gamma, beta, eps, dtype=dtype)
+    return y, mean, rstd
+
+
+def merge_ln_bwd(dy, x, mean, rstd, gamma, H, W):
+    nB, L, C = x.shape
+    g = _merge_gather(x.float(), H, W)
+    dg, dgamma, dbeta = layernorm_bwd(dy, g, mean, rstd, gamma)
+    dg = dg.view(nB, H // 2, W // 2, 4 * C)
+    dx = torch.zeros((nB, H, W, C), dtype=torch.float32, device=x.device)
+    dx[:, 0::2, 0::2] = dg[..., 0:C]
+    dx[:, 1::2, 0::2] = dg[..., C:2 * C]
+    dx[:, 0::2, 1::2] = dg[..., 2 * C:3 * C]
+    dx[:, 1::2, 1::2] = dg[..., 3 * C:]
+    return dx.view(nB, L, C), dgamma, dbeta
+
+
+# ---- data movement ---------------------------------------------------------------------------
+def gather_cast(src, rows, *, rowmap=None, tokens=0, rowscale=None, rows_per_sample=0, dtype=None):
+    C = src.shape[-1]
+    s2 = src.reshape(-1, C).float()
+    r = torch.arange(rows, device=src.device)
+    if rowmap is not None:
+        period = rowmap.numel()
+        t = rowmap.long()[r % period]
+        sr = (r // period) * tokens + t.clamp(min=0)
+        v = s2[sr]
+        if rowscale is not None:
+            v = v * rowscale[sr // rows_per_sample].unsqueeze(1)
+        v = v * (t >= 0).unsqueeze(1)
+    else:
+        v = s2[r]
+        if rowscale is not None:
+            v = v * rowscale[r // rows_per_sample].unsqueeze(1)
+    return _r(v, dtype)
+
+
+def cast_to_act(x, dtype=None):
+    return _r(x, dtype)
+
+
+def cast_to_f32(x):
+    return x.float()
+
+
+def transpose_cast(w, dtype=None):
+    return _r(w.t().contiguous(), dtype)
+
+
+def patch_im2col(img, P, Kpad, dtype=None):
+    nB, ch, S, _ = img.shape
+    G = S // P
+    cols = img.view(nB, ch, G, P, G, P).permute(0, 2, 4, 1, 3, 5).reshape(nB * G * G, ch * P * P)
+    out = torch.zeros((nB * G * G, Kpad), dtype=torch.float32, device=img.device)
+    out[:, :ch * P * P] = cols
+    return _r(out, dtype)
+
+
+def token_mean_fwd(x, dtype=None):
+    m = x.float().mean(1)
+    return m, _r(m, dtype)
+
+
+def token_mean_bwd(g_mean, g_tok, T):
+    dx = (g_mean / T).unsqueeze(1).expand(-1, T, -1).clone()
+    if g_tok is not None:
+        dx = dx + g_tok.view(dx.shape)
+    return dx
+
+
+# ---- window attention ------------------------------------------------------------------------
+NP_ = 64
+
+
+def attn_frag_elems(N):
+    if N > NP_:
+        raise RuntimeError("unsupported window")
+    return 4096
+
+
+def _frag_qk():
+    e = np.arange(4096)
+    r, lane, f = e & 3, (e >> 2) & 63, e >> 8
+    c, g = lane & 15, lane >> 4
+    q = 16 * (f & 3) + c
+    key = 16 * (f >> 2) + 4 * g + r
+    return q, key
+
+
+def _dense_from_frag(frag, N):
+    q, key = _frag_qk()
+    dense = torch.zeros(frag.shape[:-1] + (NP_, NP_), dtype=torch.float32, device=frag.device)
+    dense[..., torch.as_tensor(q), torch.as_tensor(key)] = frag
+    return dense[..., :N, :N]
+
+
+def _frag_from_dense(dense, pad_key_value=0.0):
+    N = dense.shape[-1]
+    full = torch.zeros(dense.shape[:-2] + (NP_, NP_), dtype=torch.float32, device=dense.device)
+    full[..., :, N:] = pad_key_value
+    full[..., :N, :N] = dense
+    q, key = _frag_qk()
+    return full[..., torch.as_tensor(q), torch.as_tensor(key)].contiguous()
+
+
+def relpos_bias_fwd(table, index, N):
+    nH = table.shape[1]
+    dense = table[index.view(-1)].view(N, N, nH).permute(2, 0, 1).contiguous()
+    return _frag_from_dense(dense, -1.0e30)
+
+
+def dense_to_frag(dense):
+    return _frag_from_dense(dense, 0.0)
+
+
+def _attn_core(qkv, bias_frag, mask_frag, nW, N, nH, scale):
+    rows, C3 = qkv.shape
+    C = C3 // 3
+    hd = C // nH
+    Bw = rows // N
+    dt = qkv.dtype
+    x = qkv.float().view(Bw, N, 3, nH, hd).permute(2, 0, 3, 1, 4)
+    q = _r(x[0] * scale, dt).float()  # kernel rounds scale*q to the activation dtype in LDS
+    k, v = x[1], x[2]
+    s = q @ k.transpose(-2, -1) + _dense_from_frag(bias_frag, N).unsqueeze(0)
+    if mask_frag is not None:
+        m = _dense_from_frag(mask_frag, N)  # [nW, N, N]
+        s = (s.view(Bw // nW, nW, nH, N, N) + m.view(1, nW, 1, N, N)).view(Bw, nH, N, N)
+    p = torch.softmax(s, -1)
+    return q, k, v, p
+
+
+def window_attn_fwd(qkv, bias_frag, mask_frag, nW, N, nH, scale, want_attn=False):
+    q, k, v, p = _attn_core(qkv, bias_frag, mask_frag, nW, N, nH, scale)
+    pr = _r(p, qkv.dtype).float()  # P is rounded to the activation dtype before P@V
+    o = (pr @ v).transpose(1, 2).reshape(qkv.shape[0], -1)
+    o = _r(o, qkv.dtype)
+    return (o, p) if want_attn else o
+
+
+def window_attn_bwd(qkv, dout, bias_frag, mask_frag, nW, N, nH, scale):
+    q, k, v, p = _attn_core(qkv, bias_frag, mask_frag, nW, N, nH, scale)
+    dt = qkv.dtype
+    Bw = qkv.shape[0] // N
+    hd = q.shape[-1]
+    do = dout.float().view(Bw, N, nH, hd).permute(0, 2, 1, 3)
+    pr = _r(p, dt).float()
+    dv = pr.transpose(-2, -1) @ do
+    dp = do @ v.transpose(-2, -1)
+    ds = p * (dp - (p * dp).sum(-1, keepdim=True))
+    dsr = _r(ds, dt).float()
+    dq = (dsr @ k) * scale
+    dk = dsr.transpose(-2, -1) @ q
+    dqkv = torch.stack([dq, dk, dv], 0).permute(1, 3, 0, 2, 4).reshape(qkv.shape)
+    dbias = ds.sum(0)  # [nH, N, N]
+    ws = _frag_from_dense(dbias, 0.0).unsqueeze(0)  # parts = 1
+    return _r(dqkv, dt), ws
+
+
+def relpos_bias_bwd(dbias_ws, index, N, table_rows):
+    nH = dbias_ws.shape[1]
+    dense = _dense_from_frag(dbias_ws.sum(0), N)  # [nH, N, N]
+    dtable = torch.zeros((table_rows, nH), dtype=torch.float32, device=dbias_ws.device)
+    dtable.index_add_(0, index.view(-1), dense.permute(1, 2, 0).reshape(N * N, nH))
+    return dtable
+
+
+# ---- DINOHead pieces ---------------------------------------------------------------------------
+def l2norm_fwd(x):
+    xf = x.float()
+    inv = 1.0 / xf.norm(dim=1).clamp_min(1e-12)
+    return _r(xf * inv[:, None], x.dtype), inv
+
+
+def l2norm_bwd(dz, z, inv):
+    g, zz = dz.float(), z.float()
+    return _r((g - zz * (g * zz).sum(1, keepdim=True)) * inv[:, None], z.dtype)
+
+
+def weightnorm_fwd(v, g, dtype=None):
+    inv = 1.0 / v.norm(dim=1)
+    return _r(v * (g.view(-1) * inv)[:, None], dtype), inv
+
+
+def weightnorm_bwd(dw, v, g, inv, need_dg):
+    vh = v * inv[:, None]
+    dot = (dw * vh).sum(1, keepdim=True)
+    dv = (dw - vh * dot) * (g.view(-1, 1) * inv[:, None])
+    return dv, (dot if need_dg else None)
+
+
+# ---- loss ----------------------------------------------------------------------------------------
+def teacher_row_stats(t, center, inv_temp):
+    z = (t.float() - center.view(1, -1)) * inv_temp
+    mx = z.max(1).values
+    return mx, torch.log(torch.exp(z - mx[:, None]).sum(1))
+
+
+def row_argmax(sim, Tt):
+    ld = sim.shape[-1]
+    return sim.reshape(-1, ld)[:, :Tt].argmax(1).to(torch.int32)
+
+
+def dino_ce(s, t, center, t_max, t_lse, tmatch, row_w, inv_student_temp, inv_teacher_temp):
+    z = s.float() * inv_student_temp
+    lse = torch.logsumexp(z, 1)
+    ps = torch.exp(z - lse[:, None])
+    tm = tmatch.view(-1, 2).long()
+    pt = torch.zeros_like(z)
+    nterms = (tm >= 0).sum(1).float()
+    for j in range(2):
+        idx = tm[:, j]
+        ok = idx >= 0
+        ii = idx.clamp(min=0)
+        pj = torch.exp((t.float()[ii] - center.view(1, -1)) * inv_teacher_temp - (t_max[ii] + t_lse[ii])[:, None])
+        pt = pt + pj * ok[:, None]
+    row_loss = row_w * (nterms * lse - (pt * z).sum(1))
+    ds = (row_w * inv_student_temp)[:, None] * (nterms[:, None] * ps - pt)
+    return row_loss, _r(ds, s.dtype)
+
+
+def sum_f32(x):
+    return x.sum()
+
+
+def scale_inplace(x, scale):
+    x.mul_(scale.to(x.dtype) if x.dtype == torch.float32 else scale)
+    return x
+
+
+def center_ema(center, colsum_, momentum, denom):
+    center.copy_(center * momentum + colsum_.view_as(center) / denom * (1 - momentum))
+    return center

@@ -1,0 +1,364 @@
+"""-m gpu: every HIP kernel behind the C-ABI vs the plain-PyTorch restatement (oracle/ops_ref.py)
+on identical seeded inputs.  fp32 mode must agree to fp32 round-off; bf16 mode to bf16 round-off
+(tolerances written per test)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+def _dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+def _tol(dt, f32=2e-5, bf=1.5e-2):
+    return f32 if dt == torch.float32 else bf
+
+
+def _close(name, got, ref, tol):
+    got, ref = got.float(), ref.float()
+    assert got.shape == ref.shape, (name, got.shape, ref.shape)
+    scale = ref.abs().max().item() + 1e-12
+    err = (got - ref).abs().max().item()
+    assert math.isfinite(err), "%s: non-finite output" % name
+    assert err <= tol * scale, "%s: max err %.3e vs scale %.3e (rel %.3e > tol %.1e)" % (name, err, scale, err / scale, tol)
+
+
+@pytest.fixture(scope="module")
+def mods(lib_built):
+    from esvit_amd import ops
+    from oracle import ops_ref
+    return ops, ops_ref
+
+
+def _rand(shape, dev, seed, dt=torch.float32, scale=1.0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(dev).to(dt)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("M,N,K", [(300, 96, 96), (257, 288, 96), (128, 384, 192), (1000, 256, 2048), (64, 64, 48), (520, 1024, 256)])
+def test_gemm_nt(mods, dt, M, N, K):
+    ops, ref = mods
+    dev = _dev()
+    x, w, b = _rand((M, K), dev, 1, dt), _rand((N, K), dev, 2, dt, 0.1), _rand((N,), dev, 3)
+    _close("nt", ops.linear_fwd(x, w, b), ref.linear_fwd(x, w, b), _tol(dt))
+    y, pre = ops.linear_fwd(x, w, b, gelu=True, want_preact=True)
+    yr, prer = ref.linear_fwd(x, w, b, gelu=True, want_preact=True)
+    _close("nt+gelu", y, yr, _tol(dt))
+    _close("nt preact", pre, prer, _tol(dt))
+    res = _rand((M, N), dev, 4)
+    _close("nt+res f32", ops.linear_fwd(x, w, b, residual=res, out_f32=True), ref.linear_fwd(x, w, b, residual=res, out_f32=True), _tol(dt, bf=5e-3))
+
+
+@pytest.mark.parametrize("tr", [1, 0])
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("M,N,K", [(300, 96, 384), (257, 192, 576), (1000, 2048, 256), (130, 768, 3072)])
+def test_gemm_dgrad(mods, dt, tr, M, N, K):
+    """dx[M,N] = dy[M,K] @ w[K,N] (B read k-strided; tr=1 uses ds_read_b64_tr_b16)."""
+    ops, ref = mods
+    dev = _dev()
+    ops.debug_set_tr_read(tr)
+    try:
+        dy, w = _rand((M, K), dev, 5, dt), _rand((K, N), dev, 6, dt, 0.1)
+        _close("dgrad", ops.linear_dgrad(dy, w), ref.linear_dgrad(dy, w), _tol(dt))
+        pre = _rand((M, N), dev, 7, dt)
+        _close("dgrad+gelu'", ops.linear_dgrad(dy, w, gelu_preact=pre), ref.linear_dgrad(dy, w, gelu_preact=pre), _tol(dt))
+    finally:
+        ops.debug_set_tr_read(1)
+
+
+@pytest.mark.parametrize("tr", [1, 0])
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("rows,Nout,Kin", [(392, 288, 96), (3136, 96, 384), (1000, 256, 2048), (98, 768, 768), (6272, 64, 48)])
+def test_gemm_wgrad(mods, dt, tr, rows, Nout, Kin):
+    ops, ref = mods
+    dev = _dev()
+    ops.debug_set_tr_read(tr)
+    try:
+        dy, x = _rand((rows, Nout), dev, 8, dt), _rand((rows, Kin), dev, 9, dt)
+        _close("wgrad", ops.linear_wgrad(dy, x), ref.linear_wgrad(dy, x), _tol(dt, f32=5e-5, bf=2e-3))
+        acc = _rand((Nout, Kin), dev, 10)
+        acc_ref = acc.clone()
+        _close("wgrad acc", ops.linear_wgrad(dy, x, out=acc, accumulate=True), ref.linear_wgrad(dy, x, out=acc_ref, accumulate=True),
+               _tol(dt, f32=5e-5, bf=2e-3))
+    finally:
+        ops.debug_set_tr_read(1)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_gemm_rowmap_scatter(mods, dt):
+    """window rows -> token rows with pad rows dropped, DropPath scale and residual (proj epilogue)."""
+    ops, ref = mods
+    dev = _dev()
+    H, ws, shift, C, nB = 6, 7, 3, 96, 3
+    win2tok, _ = ops.window_maps(H, H, ws, shift)
+    rm = torch.from_numpy(win2tok).to(dev)
+    M = nB * rm.numel()
+    x, w, b = _rand((M, C), dev, 11, dt), _rand((C, C), dev, 12, dt, 0.1), _rand((C,), dev, 13)
+    res = _rand((nB * H * H, C), dev, 14)
+    sc = torch.tensor([1.0, 0.0, 1.0 / 0.9], device=dev)
+    kw = dict(residual=res, rowmap=rm, rowmap_tokens=H * H, out_rows=nB * H * H, rowscale=sc, rows_per_sample=H * H, out_f32=True)
+    _close("scatter", ops.linear_fwd(x, w, b, **kw), ref.linear_fwd(x, w, b, **kw), _tol(dt, bf=5e-3))
+
+
+def test_batched_sim(mods):
+    ops, ref = mods
+    dev = _dev()
+    a, b = _rand((6, 170, 768), dev, 15), _rand((6, 49, 768), dev, 16)
+    got, want = ops.batched_nt(a, b, 64), ref.batched_nt(a, b, 64)
+    _close("sim", got[:, :, :49], want[:, :, :49], 2e-5)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("C", [96, 192, 384, 768, 1536])
+def test_layernorm(mods, dt, C):
+    ops, ref = mods
+    dev = _dev()
+    rows = 333
+    x = _rand((rows, C), dev, 20) * 2 + 0.5
+    g, b = _rand((C,), dev, 21) * 0.2 + 1, _rand((C,), dev, 22) * 0.1
+    y, yf, mean, rstd = ops.layernorm_fwd(x, g, b, 1e-6, want_f32=True, dtype=dt)
+    yr, yfr, meanr, rstdr = ref.layernorm_fwd(x, g, b, 1e-6, want_f32=True, dtype=dt)
+    _close("ln y", y, yr, _tol(dt, bf=8e-3))
+    _close("ln yf", yf, yfr, 2e-5)
+    _close("ln mean", mean, meanr, 2e-5)
+    _close("ln rstd", rstd, rstdr, 2e-5)
+    dy = _rand((rows, C), dev, 23, dt)
+    gin = _rand((rows, C), dev, 24)
+    dx, dg, db = ops.layernorm_bwd(dy, x, meanr, rstdr, g, g_in=gin)
+    dxr, dgr, dbr = ref.layernorm_bwd(dy, x, meanr, rstdr, g, g_in=gin)
+    _close("ln dx", dx, dxr, 5e-5)
+    _close("ln dgamma", dg, dgr, 5e-5)
+    _close("ln dbeta", db, dbr, 5e-5)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("H,shift", [(24, 3), (6, 3), (14, 0), (3, 0)])
+def test_layernorm_window_maps(mods, dt, H, shift):
+    ops, ref = mods
+    dev = _dev()
+    C, nB, ws = 96, 2, 7
+    win2tok, tok2win = ops.window_maps(H, H, ws, shift)
+    t2w = torch.from_numpy(tok2win).to(dev)
+    period = win2tok.size
+    x = _rand((nB, H * H, C), dev, 25)
+    g, b = _rand((C,), dev, 26) * 0.2 + 1, _rand((C,), dev, 27) * 0.1
+    kw = dict(rowmap=t2w, period_out=period, out_rows=nB * period, dtype=dt)
+    y, _, mean, rstd = ops.layernorm_fwd(x, g, b, 1e-6, **kw)
+    yr, _, meanr, rstdr = ref.layernorm_fwd(x, g, b, 1e-6, **kw)
+    _close("lnw y", y, yr, _tol(dt, bf=8e-3))
+    dy = _rand((nB * period, C), dev, 28, dt)
+    dx, dg, db = ops.layernorm_bwd(dy, x, meanr, rstdr, g, rowmap=t2w, period_in=period)
+    dxr, dgr, dbr = ref.layernorm_bwd(dy, x, meanr, rstdr, g, rowmap=t2w, period_in=period)
+    _close("lnw dx", dx, dxr, 5e-5)
+    _close("lnw dgamma", dg, dgr, 5e-5)
+    w2t = torch.from_numpy(win2tok).to(dev)
+    src = _rand((nB * H * H, C), dev, 29)
+    sc = torch.tensor([0.0, 1.25], device=dev)
+    kw = dict(rowmap=w2t, tokens=H * H, rowscale=sc, rows_per_sample=H * H, dtype=dt)
+    _close("gather_cast", ops.gather_cast(src, nB * period, **kw), ref.gather_cast(src, nB * period, **kw), _tol(dt, bf=8e-3))
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_merge_ln(mods, dt):
+    ops, ref = mods
+    dev = _dev()
+    nB, H, C = 3, 12, 96
+    x = _rand((nB, H * H, C), dev, 30)
+    g, b = _rand((4 * C,), dev, 31) * 0.2 + 1, _rand((4 * C,), dev, 32) * 0.1
+    y, mean, rstd = ops.merge_ln_fwd(x, g, b, 1e-6, H, H, dtype=dt)
+    yr, meanr, rstdr = ref.merge_ln_fwd(x, g, b, 1e-6, H, H, dtype=dt)
+    _close("merge y", y, yr, _tol(dt, bf=8e-3))
+    dy = _rand(tuple(yr.shape), dev, 33, dt)
+    dx, dg, db = ops.merge_ln_bwd(dy, x, meanr, rstdr, g, H, H)
+    dxr, dgr, dbr = ref.merge_ln_bwd(dy, x, meanr, rstdr, g, H, H)
+    _close("merge dx", dx, dxr, 5e-5)
+    _close("merge dgamma", dg, dgr, 5e-5)
+    _close("merge dbeta", db, dbr, 5e-5)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_small_ops(mods, dt):
+    ops, ref = mods
+    dev = _dev()
+    img = _rand((3, 3, 96, 96), dev, 40)
+    _close("im2col", ops.patch_im2col(img, 4, 64, dtype=dt), ref.patch_im2col(img, 4, 64, dtype=dt), _tol(dt, bf=8e-3))
+    x = _rand((5, 49, 768), dev, 41)
+    m, ma = ops.token_mean_fwd(x, dtype=dt)
+    mr, mar = ref.token_mean_fwd(x, dtype=dt)
+    _close("mean", m, mr, 2e-5)
+    _close("mean act", ma, mar, _tol(dt, bf=8e-3))
+    gm, gt = _rand((5, 768), dev, 42), _rand((5, 49, 768), dev, 43)
+    _close("mean bwd", ops.token_mean_bwd(gm, gt, 49), ref.token_mean_bwd(gm, gt, 49), 2e-5)
+    w = _rand((300, 520), dev, 44)
+    _close("cast", ops.cast_to_act(w, dtype=dt), ref.cast_to_act(w, dtype=dt), _tol(dt, bf=8e-3))
+    _close("transpose", ops.transpose_cast(w, dtype=dt), ref.transpose_cast(w, dtype=dt), _tol(dt, bf=8e-3))
+    xa = _rand((1300, 288), dev, 45, dt)
+    _close("colsum", ops.colsum(xa), ref.colsum(xa), 5e-5)
+    _close("cast_to_f32", ops.cast_to_f32(xa), ref.cast_to_f32(xa), 1e-7)
+    v = _rand((777,), dev, 46)
+    _close("sum", ops.sum_f32(v), ref.sum_f32(v), 1e-5)
+    xs, xs2 = xa.clone(), xa.clone()
+    sc = torch.tensor(0.37, device=dev)
+    _close("scale", ops.scale_inplace(xs, sc), ref.scale_inplace(xs2, sc), _tol(dt, bf=8e-3))
+    c1 = _rand((1, 4096), dev, 47)
+    c2 = c1.clone()
+    cs = _rand((4096,), dev, 48)
+    _close("center", ops.center_ema(c1, cs, 0.9, 13.0), ref.center_ema(c2, cs, 0.9, 13.0), 1e-6)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("nH,nW,shifted", [(3, 4, True), (6, 1, False), (12, 1, True), (24, 1, False)])
+def test_window_attention(mods, dt, nH, nW, shifted):
+    ops, ref = mods
+    dev = _dev()
+    ws, N, hd = 7, 49, 32
+    C = nH * hd
+    Bw = nW * 3
+    qkv = _rand((Bw * N, 3 * C), dev, 50, dt)
+    table = _rand((169, nH), dev, 51) * 0.5
+    index = torch.from_numpy(ops.relative_position_index(ws)).to(dev)
+    bias = ops.relpos_bias_fwd(table, index, N)
+    _close("bias frag", bias.clamp(min=-1e4), ref.relpos_bias_fwd(table, index, N).clamp(min=-1e4), 1e-6)
+    mask_frag = None
+    if shifted:
+        H = {4: 14, 1: 6}[nW]
+        mask = torch.from_numpy(ops.shift_mask(H, H, ws, 3)).to(dev)
+        assert mask.shape[0] == nW
+        mask_frag = ops.dense_to_frag(mask)
+        _close("mask frag", mask_frag, ref.dense_to_frag(mask), 1e-6)
+    scale = hd ** -0.5
+    o, attn = ops.window_attn_fwd(qkv, bias, mask_frag, nW, N, nH, scale, want_attn=True)
+    orf, attnr = ref.window_attn_fwd(qkv, bias, mask_frag, nW, N, nH, scale, want_attn=True)
+    _close("attn probs", attn, attnr, _tol(dt, f32=5e-5, bf=2e-2))
+    _close("attn out", o, orf, _tol(dt, f32=5e-5, bf=2e-2))
+    dout = _rand((Bw * N, C), dev, 52, dt)
+    for tr in (1, 0):
+        ops.debug_set_tr_read(tr)
+        dqkv, ws_ = ops.window_attn_bwd(qkv, dout, bias, mask_frag, nW, N, nH, scale)
+        ops.debug_set_tr_read(1)
+        dqkvr, wsr = ref.window_attn_bwd(qkv, dout, bias, mask_frag, nW, N, nH, scale)
+        for i, nm in enumerate("qkv"):
+            _close("attn d%s tr=%d" % (nm, tr), dqkv.view(-1, 3, C)[:, i], dqkvr.view(-1, 3, C)[:, i], _tol(dt, f32=1e-4, bf=3e-2))
+        dt_ = ops.relpos_bias_bwd(ws_, index, N, 169)
+        dtr = ref.relpos_bias_bwd(wsr, index, N, 169)
+        _close("attn dtable tr=%d" % tr, dt_, dtr, _tol(dt, f32=1e-4, bf=3e-2))
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_head_pieces(mods, dt):
+    ops, ref = mods
+    dev = _dev()
+    x = _rand((300, 256), dev, 60, dt)
+    z, inv = ops.l2norm_fwd(x)
+    zr, invr = ref.l2norm_fwd(x)
+    _close("l2 z", z, zr, _tol(dt, bf=8e-3))
+    _close("l2 inv", inv, invr, 2e-5)
+    dz = _rand((300, 256), dev, 61, dt)
+    _close("l2 bwd", ops.l2norm_bwd(dz, zr, invr), ref.l2norm_bwd(dz, zr, invr), _tol(dt, bf=1e-2))
+    v, g = _rand((4096, 256), dev, 62) * 0.02, torch.ones((4096, 1), device=dev) * 1.5
+    w, winv = ops.weightnorm_fwd(v, g, dtype=dt)
+    wr, winvr = ref.weightnorm_fwd(v, g, dtype=dt)
+    _close("wn w", w, wr, _tol(dt, bf=8e-3))
+    _close("wn inv", winv, winvr, 2e-5)
+    dw = _rand((4096, 256), dev, 63)
+    dv, dg = ops.weightnorm_bwd(dw, v, g, winvr, True)
+    dvr, dgr = ref.weightnorm_bwd(dw, v, g, winvr, True)
+    _close("wn dv", dv, dvr, 5e-5)
+    _close("wn dg", dg, dgr, 5e-5)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("K", [4096, 65536])
+def test_dino_loss_kernels(mods, dt, K):
+    ops, ref = mods
+    dev = _dev()
+    Rs, Rt = 37, 11
+    s, t = _rand((Rs, K), dev, 70, dt), _rand((Rt, K), dev, 71, dt)
+    center = _rand((1, K), dev, 72) * 0.3
+    mx, lse = ops.teacher_row_stats(t, center, 1 / 0.04)
+    mxr, lser = ref.teacher_row_stats(t, center, 1 / 0.04)
+    _close("t max", mx, mxr, 1e-5)
+    _close("t lse", lse, lser, 2e-4)
+    g = torch.Generator().manual_seed(73)
+    tm = torch.randint(-1, Rt, (Rs, 2), generator=g).to(torch.int32)
+    tm[0] = torch.tensor([-1, 3])
+    tm[1] = torch.tensor([2, -1])
+    tm = tm.to(dev)
+    w = (torch.rand(Rs, generator=g) * 0.1).to(dev)
+    rl, ds = ops.dino_ce(s, t, center, mxr, lser, tm, w, 10.0, 25.0)
+    rlr, dsr = ref.dino_ce(s, t, center, mxr, lser, tm, w, 10.0, 25.0)
+    _close("row loss", rl, rlr, 2e-5)
+    _close("ds", ds, dsr, _tol(dt, f32=2e-4, bf=1e-2))
+    sim = _rand((200, 64), dev, 74)
+    assert torch.equal(ops.row_argmax(sim, 49), ref.row_argmax(sim, 49))
+
+
+def test_index_maps_match_restatement(mods):
+    ops, ref = mods
+    for ws in (7, 14):
+        assert np.array_equal(ops.relative_position_index(ws), ref.relative_position_index(ws))
+        for H in (56, 28, 14, 7, 24, 12, 6, 3):
+            for shift in (0, ws // 2):
+                a, b = ops.window_maps(H, H, ws, shift), ref.window_maps(H, H, ws, shift)
+                assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), (ws, H, shift)
+            assert np.array_equal(ops.shift_mask(H, H, ws, ws // 2), ref.shift_mask(H, H, ws, ws // 2)), (ws, H)
+
+
+def test_fused_update_matches_torch(mods):
+    """clip (utils.py:106-115) + torch.optim.AdamW + EMA (main_esvit.py:587-590) for 3 steps."""
+    import copy
+    from esvit_amd.update import FusedClipAdamWEMA, get_params_groups
+    dev = _dev()
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(300, 77), torch.nn.LayerNorm(77), torch.nn.Linear(77, 5000)).to(dev)
+    net[2].last_layer = None
+    net[0].weight.requires_grad_(True)
+    frozen = torch.nn.Parameter(torch.ones(10, device=dev), requires_grad=False)
+    net.register_parameter("frozen", frozen)
+    s_ref, t_ref = copy.deepcopy(net), copy.deepcopy(net)
+    s_fus, t_fus = copy.deepcopy(net), copy.deepcopy(net)
+    for t in (t_ref, t_fus):
+        for p in t.parameters():
+            p.data.mul_(0.5)
+    opt_ref = torch.optim.AdamW(get_params_groups(s_ref))
+    opt_fus = FusedClipAdamWEMA(s_fus, t_fus)
+    for it in range(3):
+        lr, wd, m = 1e-3 * (it + 1), 0.04 + 0.01 * it, 0.99
+        grads = [torch.randn_like(p) * (10.0 if i == 0 else 0.01) for i, p in enumerate(s_ref.parameters())]
+        for (p1, p2, g) in zip(s_ref.parameters(), s_fus.parameters(), grads):
+            if p1.requires_grad:
+                p1.grad, p2.grad = g.clone(), g.clone()
+        # reference
+        for i, pg in enumerate(opt_ref.param_groups):
+            pg["lr"] = lr
+            if i == 0:
+                pg["weight_decay"] = wd
+        for p in s_ref.parameters():
+            if p.grad is not None:
+                n = p.grad.norm(2)
+                coef = 3.0 / (n + 1e-6)
+                if coef < 1:
+                    p.grad.mul_(coef)
+        opt_ref.step()
+        with torch.no_grad():
+            for q, k in zip(s_ref.parameters(), t_ref.parameters()):
+                k.mul_(m).add_((1 - m) * q.detach())
+        opt_fus.step(lr, wd, m, clip_grad=3.0)
+    for (a, b) in zip(s_ref.parameters(), s_fus.parameters()):
+        _close("student param", b, a, 2e-6)
+    for (a, b) in zip(t_ref.parameters(), t_fus.parameters()):
+        _close("teacher param", b, a, 2e-6)
+    sd_ref, sd_fus = opt_ref.state_dict(), opt_fus.state_dict()
+    assert [g["params"] for g in sd_ref["param_groups"]] == [g["params"] for g in sd_fus["param_groups"]]
+    for k in sd_ref["state"]:
+        _close("exp_avg", sd_fus["state"][k]["exp_avg"], sd_ref["state"][k]["exp_avg"], 2e-6)
+        _close("exp_avg_sq", sd_fus["state"][k]["exp_avg_sq"], sd_ref["state"][k]["exp_avg_sq"], 2e-6)
+        assert float(sd_fus["state"][k]["step"]) == float(sd_ref["state"][k]["step"])
