@@ -80,6 +80,17 @@ class FusedClipAdamWEMA:
         self.sqnorms = torch.zeros(len(self.params), dtype=torch.float32, device=dev)
         # ring of pinned staging tables: a buffer is rewritten only after the async H2D copy that read it completed
         self._ring = [torch.zeros((len(self.params), TFIELDS), dtype=torch.int64).pin_memory() for _ in range(4)]
+        self._ring_np = [t.numpy() for t in self._ring]
+        for tab in self._ring_np:  # static columns
+            for i, p in enumerate(self.params):
+                tp = self.teacher_params[i]
+                tab[i, 0] = p.data_ptr()
+                tab[i, 2] = self.exp_avg[i].data_ptr() if self.trainable[i] else 0
+                tab[i, 3] = self.exp_avg_sq[i].data_ptr() if self.trainable[i] else 0
+                tab[i, 4] = tp.data_ptr() if tp is not None else 0
+                tab[i, 5] = p.numel()
+                tab[i, 6] = self.group_of[i]
+        self._bc_cache = {}
         self._ring_ev = [None] * len(self._ring)
         self._ring_pos = 0
         self._table_dev = torch.zeros((len(self.params), TFIELDS), dtype=torch.int64, device=dev)
@@ -96,28 +107,26 @@ class FusedClipAdamWEMA:
         self._ring_pos = (slot + 1) % len(self._ring)
         if self._ring_ev[slot] is not None:
             self._ring_ev[slot].synchronize()
-        tab = self._ring[slot]
+        tab = self._ring_np[slot]
+        gptr, flags, bcs = [0] * len(self.params), [0] * len(self.params), [0] * len(self.params)
         for i, p in enumerate(self.params):
             g = p.grad
-            has = self.trainable[i] and g is not None and not (skip_last_layer and "last_layer" in self.names[i])
-            if has:
-                assert g.is_contiguous() and g.dtype == torch.float32
-                self.steps[i] += 1
-                t = self.steps[i]
+            if g is None or not self.trainable[i] or (skip_last_layer and "last_layer" in self.names[i]):
+                continue
+            assert g.is_contiguous() and g.dtype == torch.float32
+            self.steps[i] += 1
+            t = self.steps[i]
+            bc = self._bc_cache.get(t)
+            if bc is None:
                 bc = self._bits(1.0 - b1 ** t) | (self._bits(1.0 - b2 ** t) << 32)
                 if bc >= 1 << 63:
                     bc -= 1 << 64
-            tp = self.teacher_params[i]
-            row = tab[i]
-            row[0] = p.data_ptr()
-            row[1] = g.data_ptr() if has else 0
-            row[2] = self.exp_avg[i].data_ptr() if self.trainable[i] else 0
-            row[3] = self.exp_avg_sq[i].data_ptr() if self.trainable[i] else 0
-            row[4] = tp.data_ptr() if tp is not None else 0
-            row[5] = p.numel()
-            row[6] = self.group_of[i]
-            row[7] = 1 if has else 0
-            row[8] = bc if has else 0
+                if len(self._bc_cache) > 64:
+                    self._bc_cache.clear()
+                self._bc_cache[t] = bc
+            gptr[i], flags[i], bcs[i] = g.data_ptr(), 1, bc
+        tab[:, 1], tab[:, 7], tab[:, 8] = gptr, flags, bcs
+        tab = self._ring[slot]
         self._table_dev.copy_(tab, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
