@@ -170,9 +170,9 @@ def linear_wgrad(dy, x, *, out=None, accumulate=False):
         _gemm(dy.dtype, A=dy, B=x, C=out, M=Nout, N=Kin, K=rows, lda=Nout, ldb=Kin, ldc=Kin, a_kstrided=1, b_kstrided=1,
               out_f32=1, splitk=splitk, partial=part, accumulate=int(accumulate))
     else:
-        assert not accumulate
+        # accumulate through the residual input (each element is read and written by the same lane)
         _gemm(dy.dtype, A=dy, B=x, C=out, M=Nout, N=Kin, K=rows, lda=Nout, ldb=Kin, ldc=Kin, a_kstrided=1, b_kstrided=1,
-              out_f32=1)
+              out_f32=1, residual=out if accumulate else None, ldr=Kin)
     return out
 
 

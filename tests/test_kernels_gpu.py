@@ -353,12 +353,12 @@ def test_fused_update_matches_torch(mods):
                 k.mul_(m).add_((1 - m) * q.detach())
         opt_fus.step(lr, wd, m, clip_grad=3.0)
     for (a, b) in zip(s_ref.parameters(), s_fus.parameters()):
-        _close("student param", b, a, 2e-6)
+        _close("student param", b, a, 2e-5)
     for (a, b) in zip(t_ref.parameters(), t_fus.parameters()):
-        _close("teacher param", b, a, 2e-6)
+        _close("teacher param", b, a, 2e-5)
     sd_ref, sd_fus = opt_ref.state_dict(), opt_fus.state_dict()
     assert [g["params"] for g in sd_ref["param_groups"]] == [g["params"] for g in sd_fus["param_groups"]]
     for k in sd_ref["state"]:
-        _close("exp_avg", sd_fus["state"][k]["exp_avg"], sd_ref["state"][k]["exp_avg"], 2e-6)
-        _close("exp_avg_sq", sd_fus["state"][k]["exp_avg_sq"], sd_ref["state"][k]["exp_avg_sq"], 2e-6)
+        _close("exp_avg", sd_fus["state"][k]["exp_avg"], sd_ref["state"][k]["exp_avg"], 2e-5)
+        _close("exp_avg_sq", sd_fus["state"][k]["exp_avg_sq"], sd_ref["state"][k]["exp_avg_sq"], 2e-5)
         assert float(sd_fus["state"][k]["step"]) == float(sd_ref["state"][k]["step"])
