@@ -1,0 +1,137 @@
+"""Generate tests/golden/*.pt from the REFERENCE's own modules (run in the build container only):
+
+    python -m oracle.gen_golden
+
+Fixtures are small (fingerprints + a few full tensors); inputs and weights are regenerated in the
+tests from tests/golden_utils.py, so nothing large is committed."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import ref_loader as RL  # noqa: E402
+from tests import golden_utils as GU  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def gen_index_maps(ns):
+    swin = ns.models.swin_transformer
+    out = {}
+    for ws in (7, 14):
+        attn = swin.WindowAttention(32, (ws, ws), 1)
+        out["rpi_%d" % ws] = attn.relative_position_index.numpy().astype(np.int64)
+        for H in (56, 28, 14, 7, 24, 12, 6, 3):
+            for shift in (0, ws // 2):
+                blk = swin.SwinTransformerBlock(32, (1024, 1024), 1, window_size=ws, shift_size=shift)
+                blk.norm1 = torch.nn.Identity()
+                cap = {}
+
+                def hook(mod, args, cap=cap):
+                    cap["xw"], cap["mask"] = args[0].detach().clone(), (None if args[1] is None else args[1].detach().clone())
+
+                h = blk.attn.register_forward_pre_hook(hook)
+                x = torch.zeros(1, H * H, 32)
+                x[0, :, 0] = torch.arange(H * H, dtype=torch.float32) + 1.0
+                with torch.no_grad():
+                    blk(x)
+                h.remove()
+                ids = cap["xw"][..., 0].round().to(torch.int64).reshape(-1) - 1
+                out["win2tok_%d_%d_%d" % (ws, H, shift)] = ids.numpy().astype(np.int32)
+                if shift > 0:
+                    out["mask_%d_%d" % (ws, H)] = cap["mask"].numpy().astype(np.float32)
+    np.savez_compressed(os.path.join(OUT, "index_maps.npz"), **out)
+    print("index_maps.npz:", len(out), "arrays")
+
+
+def build_nano(ns, teacher=False):
+    cfg = RL.swin_config(embed_dim=GU.NANO["embed_dim"], depths=GU.NANO["depths"], heads=GU.NANO["heads"], window=GU.NANO["window"])
+    m = ns.models.build_model(cfg, is_teacher=teacher, use_dense_prediction=True)
+    hk = dict(hidden_dim=GU.NANO_HEAD["hidden_dim"], bottleneck_dim=GU.NANO_HEAD["bottleneck_dim"])
+    m.head = ns.DINOHead(m.num_features, GU.NANO_HEAD["out_dim"], norm_last_layer=True, **hk)
+    m.head_dense = ns.DINOHead(m.num_features, GU.NANO_HEAD["out_dim"], norm_last_layer=False, **hk)
+    return m
+
+
+def gen_nano(ns):
+    RL.ensure_single_process_group()
+    torch.manual_seed(0)
+    student, teacher = build_nano(ns), build_nano(ns, teacher=True)
+    GU.fill_state_dict(student.state_dict(), seed=0)
+    GU.fill_state_dict(teacher.state_dict(), seed=7)  # a different teacher so that the EMA is visible
+    student.head.last_layer.weight_g.data.fill_(1)    # norm_last_layer=True keeps g == 1 (vision_transformer.py:404)
+    for p in teacher.parameters():
+        p.requires_grad = False
+    B = 2
+    crops = GU.make_crops(B)
+    K = GU.NANO_HEAD["out_dim"]
+    g = {"keys": [(k, tuple(v.shape), str(v.dtype)) for k, v in student.state_dict().items()],
+         "param_names": [n for n, _ in student.named_parameters()],
+         "trainable": [n for n, p in student.named_parameters() if p.requires_grad]}
+
+    loss_fn = ns.DDINOLoss(K, 10, 0.04, 0.07, 5, 10)
+    loss_fn.center.copy_(0.01 * torch.randn(1, K, generator=torch.Generator().manual_seed(5)))
+    loss_fn.center_grid.copy_(0.01 * torch.randn(1, K, generator=torch.Generator().manual_seed(6)))
+    g["center0"], g["center_grid0"] = loss_fn.center.clone(), loss_fn.center_grid.clone()
+    epoch = 2
+    t_out = teacher(crops[:2])
+    s_out = student(crops)
+    g["s_cls"], g["s_reg"], g["s_fea"] = GU.probe(s_out[0]), GU.probe(s_out[1]), GU.probe(s_out[2])
+    g["t_cls"], g["t_reg"], g["t_fea"] = GU.probe(t_out[0]), GU.probe(t_out[1]), GU.probe(t_out[2])
+    g["s_cls_full"] = s_out[0].detach().clone()          # [20, K] fp32 = 320 KB
+    g["s_reg_rows"] = s_out[1][::17].detach().clone()    # 20 rows
+    g["npatch"] = (list(s_out[3]), list(t_out[3]))
+    loss = loss_fn(s_out, t_out, epoch, None)
+    g["ddino_loss"] = loss.item()
+    g["center1"], g["center_grid1"] = loss_fn.center.clone(), loss_fn.center_grid.clone()
+    student.zero_grad()
+    loss.backward()
+    g["grads"] = {n: GU.probe(p.grad) for n, p in student.named_parameters() if p.grad is not None}
+    g["grad_norms"] = {n: p.grad.norm().item() for n, p in student.named_parameters() if p.grad is not None}
+    g["no_grad"] = [n for n, p in student.named_parameters() if p.grad is None]
+    # second loss call with the updated centres (same activations)
+    with torch.no_grad():
+        g["ddino_loss_2"] = loss_fn([t.detach() if torch.is_tensor(t) else t for t in s_out], t_out, epoch, None).item()
+    # view-level DINOLoss on the cls logits of the two global crops only (config 1 shape)
+    vl = ns.DINOLoss(K, 2, 0.04, 0.07, 5, 10)
+    vl.center.copy_(g["center0"])
+    s2 = student.head(student.forward_features(torch.cat(crops[:2]))[0])
+    l2 = vl(s2, t_out[0], epoch, None)
+    g["dino_loss_2crops"] = l2.item()
+    g["dino_center1"] = vl.center.clone()
+    # one update step: clip 3.0 -> AdamW -> EMA (utils.py:106-115, main_esvit.py:574, 587-590)
+    opt = torch.optim.AdamW(ns.utils.get_params_groups(student))
+    lr, wd, m = 5e-4, 0.04, 0.996
+    for i, pg in enumerate(opt.param_groups):
+        pg["lr"] = lr
+        if i == 0:
+            pg["weight_decay"] = wd
+    g["clip_norms"] = ns.utils.clip_gradients(student, 3.0)
+    opt.step()
+    with torch.no_grad():
+        for pq, pk in zip(student.parameters(), teacher.parameters()):
+            pk.data.mul_(m).add_((1 - m) * pq.detach().data)
+    g["student_after"] = {n: GU.probe(p) for n, p in student.named_parameters()}
+    g["teacher_after"] = {n: GU.probe(p) for n, p in teacher.named_parameters()}
+    g["group_sizes"] = [len(pg["params"]) for pg in opt.param_groups]
+    # attention probabilities of the last block for one global crop (forward_selfattention, swin_transformer.py:766-787)
+    with torch.no_grad():
+        GU.fill_state_dict(student.state_dict(), seed=0)
+        student.head.last_layer.weight_g.data.fill_(1)
+        g["last_attn"] = GU.probe(student.forward_selfattention(crops[0]))
+    torch.save(g, os.path.join(OUT, "nano_step.pt"))
+    print("nano_step.pt: loss", g["ddino_loss"], g["ddino_loss_2"], g["dino_loss_2crops"], "no_grad", g["no_grad"])
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    ns = RL.load()
+    gen_index_maps(ns)
+    gen_nano(ns)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,46 @@
+"""Shared by oracle/gen_golden.py (which runs the reference) and the tests (which run the oracle and the HIP
+path): deterministic parameter fill and synthetic crops, so goldens need to store outputs only."""
+import zlib
+
+import torch
+
+NANO = dict(embed_dim=32, depths=(2, 2, 2, 2), heads=(1, 2, 4, 8), window=7, img=224)
+NANO_HEAD = dict(out_dim=4096, hidden_dim=256, bottleneck_dim=64)
+SWIN_T = dict(embed_dim=96, depths=(2, 2, 6, 2), heads=(3, 6, 12, 24), window=7, img=224)
+
+
+def fill_state_dict(sd, seed=0):
+    """In-place deterministic fill keyed by parameter name (independent of construction order / RNG stream)."""
+    for name, t in sd.items():
+        if not t.is_floating_point():
+            continue
+        g = torch.Generator().manual_seed((zlib.crc32(name.encode()) + seed) % (2 ** 31))
+        r = torch.randn(t.shape, generator=g)
+        if name.endswith("weight_g"):
+            v = 1.0 + 0.1 * r
+        elif "norm" in name and name.endswith("weight"):
+            v = 1.0 + 0.1 * r
+        elif name.endswith("bias"):
+            v = 0.02 * r
+        elif "relative_position_bias_table" in name:
+            v = 0.2 * r
+        else:
+            v = 0.05 * r
+        t.copy_(v.to(t.dtype))
+    return sd
+
+
+def make_crops(B, n_local=8, seed=1234, sizes=(224, 96)):
+    """torch.randn crops, list order [g, g, l x n_local]."""
+    g = torch.Generator().manual_seed(seed)
+    crops = [torch.randn(B, 3, sizes[0], sizes[0], generator=g) for _ in range(2)]
+    crops += [torch.randn(B, 3, sizes[1], sizes[1], generator=g) for _ in range(n_local)]
+    return crops
+
+
+def probe(t, n=16):
+    """small fingerprint of a tensor: (shape, sum, abs-sum, first n and strided n values)"""
+    f = t.detach().float().reshape(-1)
+    stride = max(1, f.numel() // n)
+    return dict(shape=tuple(t.shape), sum=f.double().sum().item(), asum=f.double().abs().sum().item(),
+                head=f[:n].clone(), strided=f[::stride][:n].clone())
