@@ -149,6 +149,32 @@ __global__ __launch_bounds__(NT) void dino_ce_kernel(const T* __restrict__ s, co
     if (threadIdx.x == 0) row_loss[r] = w * (nterms * lse - dot);
 }
 
+// region matching (main_esvit.py:735-738): argmax over the Tt teacher tokens of view iq + row assembly
+__global__ void region_match_kernel(const float* __restrict__ sim, int B, int S, int Tt, int ld, const int* __restrict__ crop_id,
+                                    const int* __restrict__ cm_row, int* __restrict__ tmatch) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)B * S * 2) return;
+    const int iq = (int)(i & 1);
+    const long bs = i >> 1;
+    const int s = (int)(bs % S);
+    const long b = bs / S;
+    int out = -1;
+    if (crop_id[s] != iq) {
+        const float* p = sim + bs * ld + iq * Tt;
+        float best = p[0];
+        int bj = 0;
+        for (int j = 1; j < Tt; ++j) {
+            const float v = p[j];
+            if (v > best) {
+                best = v;
+                bj = j;
+            }
+        }
+        out = iq * B * Tt + (int)b * Tt + bj;
+    }
+    tmatch[(long)cm_row[bs] * 2 + iq] = out;
+}
+
 }  // namespace
 
 #define STREAM(s_) hipStream_t stream = reinterpret_cast<hipStream_t>(s_)
@@ -188,5 +214,15 @@ extern "C" int esvit_dino_ce_fwd_bwd(int dtype, const void* s, const void* t, co
         return ESVIT_ERR_ARG;
     }
     ESVIT_CHECK_LAUNCH("dino_ce_fwd_bwd");
+    return ESVIT_OK;
+}
+
+extern "C" int esvit_region_match(const float* sim, int B, int S, int Tt, int ld, const int32_t* crop_id, const int32_t* cm_row,
+                                  int32_t* tmatch, esvit_stream_t s_) {
+    STREAM(s_);
+    ESVIT_CHECK_ARG(sim && crop_id && cm_row && tmatch && B > 0 && S > 0 && Tt > 0 && ld >= 2 * Tt, "esvit_region_match: bad args");
+    hipLaunchKernelGGL(region_match_kernel, dim3(ceil_div((long)B * S * 2, 128)), dim3(128), 0, stream, sim, B, S, Tt, ld, crop_id,
+                       cm_row, tmatch);
+    ESVIT_CHECK_LAUNCH("region_match");
     return ESVIT_OK;
 }

@@ -1,0 +1,46 @@
+"""DINOHead behind the reference constructor (vision_transformer.py:384-418): parameters are registered under
+the reference's names -- ``mlp.{0,2,4}.{weight,bias}`` and the legacy weight-norm pair
+``last_layer.weight_g`` [K,1] / ``last_layer.weight_v`` [K,256] -- and the forward is one fused autograd node."""
+import torch
+import torch.nn as nn
+
+from . import functional as Fn
+
+
+class _WeightNormLinear(nn.Module):
+    """parameter holder with the state_dict layout of ``nn.utils.weight_norm(nn.Linear(in, out, bias=False))``"""
+
+    def __init__(self, in_features, out_features):
+        super().__init__()
+        self.in_features, self.out_features = in_features, out_features
+        w = torch.empty(out_features, in_features)
+        nn.init.kaiming_uniform_(w, a=5 ** 0.5)  # nn.Linear default init, as in the reference before weight_norm
+        self.weight_g = nn.Parameter(w.norm(dim=1, keepdim=True))
+        self.weight_v = nn.Parameter(w)
+
+
+class DINOHead(nn.Module):
+    def __init__(self, in_dim, out_dim, use_bn=False, norm_last_layer=True, nlayers=3, hidden_dim=2048, bottleneck_dim=256):
+        super().__init__()
+        if use_bn:
+            raise NotImplementedError("use_bn_in_head is a 'next' row (SURVEY.md 8f-3)")
+        if max(nlayers, 1) != 3:
+            raise NotImplementedError("the fused head implements the reference default nlayers=3")
+        self.mlp = nn.Sequential(nn.Linear(in_dim, hidden_dim), nn.GELU(), nn.Linear(hidden_dim, hidden_dim), nn.GELU(),
+                                 nn.Linear(hidden_dim, bottleneck_dim))
+        for m in self.mlp:
+            if isinstance(m, nn.Linear):
+                nn.init.trunc_normal_(m.weight, std=.02, a=-2.0, b=2.0)
+                nn.init.constant_(m.bias, 0)
+        self.last_layer = _WeightNormLinear(bottleneck_dim, out_dim)
+        self.last_layer.weight_g.data.fill_(1)
+        if norm_last_layer:
+            self.last_layer.weight_g.requires_grad = False
+
+    def forward(self, x):
+        lead = x.shape[:-1]
+        x2 = x.reshape(-1, x.shape[-1])
+        prm = [self.mlp[0].weight, self.mlp[0].bias, self.mlp[2].weight, self.mlp[2].bias, self.mlp[4].weight, self.mlp[4].bias,
+               self.last_layer.weight_v, self.last_layer.weight_g]
+        y = Fn.dino_head(x2, prm)
+        return y.view(*lead, y.shape[-1])

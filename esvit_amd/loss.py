@@ -1,0 +1,189 @@
+"""DINOLoss / DDINOLoss behind the reference signatures (main_esvit.py:603-770).
+
+forward(student_output, teacher_output, epoch, targets_mixup) -> 0-d fp32 loss whose backward feeds the
+student logits; ``state_dict()`` = {center[, center_grid]} as in the reference.  The work is done by
+four fused HIP kernels (teacher row statistics, cosine-similarity GEMM + region matching, the student
+log-softmax-CE + gradient kernel, centre column sums + EMA); the teacher softmax, the 18 per-pair
+log-softmax tensors and the gathered teacher rows of the reference are never materialised.
+``targets_mixup`` is accepted and ignored by DDINOLoss exactly as in the reference; the DINOLoss mixup branch
+(main_esvit.py:639-641) is a 'next' row.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+from . import ops
+
+
+def _ops():
+    return ops
+
+
+class _LossFn(torch.autograd.Function):
+    """loss value with precomputed d loss / d logits (the CE kernel produces both in one pass)"""
+
+    @staticmethod
+    def forward(ctx, loss, unit_grad, *pairs):
+        n = len(pairs) // 2
+        ctx.unit_grad = unit_grad
+        ctx.save_for_backward(*pairs[n:])
+        return loss.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        grads = list(ctx.saved_tensors)
+        if not ctx.unit_grad:
+            g = g.contiguous().float()
+            grads = [_ops().scale_inplace(d, g) for d in grads]
+        return (None, None) + tuple(grads) + (None,) * len(grads)
+
+
+def _teacher_temp_schedule(warmup_teacher_temp, teacher_temp, warmup_teacher_temp_epochs, nepochs):
+    return np.concatenate((np.linspace(warmup_teacher_temp, teacher_temp, warmup_teacher_temp_epochs),
+                           np.ones(nepochs - warmup_teacher_temp_epochs) * teacher_temp))
+
+
+def _world():
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+class DINOLoss(nn.Module):
+    def __init__(self, out_dim, ncrops, warmup_teacher_temp, teacher_temp, warmup_teacher_temp_epochs, nepochs,
+                 student_temp=0.1, center_momentum=0.9):
+        super().__init__()
+        self.student_temp, self.center_momentum, self.ncrops = student_temp, center_momentum, ncrops
+        self.register_buffer("center", torch.zeros(1, out_dim))
+        self.teacher_temp_schedule = _teacher_temp_schedule(warmup_teacher_temp, teacher_temp, warmup_teacher_temp_epochs, nepochs)
+        self.assume_unit_grad = False  # set by the fused train step: loss.backward() with grad 1 needs no rescale pass
+        self._tables = {}
+
+    def _static(self, B, device):
+        key = (B, str(device))
+        t = self._tables.get(key)
+        if t is None:
+            n_terms = 2 * self.ncrops - 2
+            tm = np.full((self.ncrops * B, 2), -1, dtype=np.int32)
+            for v in range(self.ncrops):
+                for iq in range(2):
+                    if v != iq:
+                        tm[v * B:(v + 1) * B, iq] = iq * B + np.arange(B)
+            w = np.full((self.ncrops * B,), 1.0 / (n_terms * B), dtype=np.float32)
+            t = (torch.from_numpy(tm).to(device), torch.from_numpy(w).to(device))
+            self._tables[key] = t
+        return t
+
+    def forward(self, student_output, teacher_output, epoch, targets_mixup=None):
+        if targets_mixup:
+            raise NotImplementedError("DINOLoss mixup targets (main_esvit.py:639-641) are out of scope (SURVEY.md 8f-3)")
+        o = _ops()
+        s, t = student_output.contiguous(), teacher_output.detach().contiguous()
+        B = t.shape[0] // 2
+        inv_tt = 1.0 / float(self.teacher_temp_schedule[epoch])
+        tmatch, w = self._static(B, s.device)
+        mx, lse = o.teacher_row_stats(t, self.center, inv_tt)
+        row_loss, ds = o.dino_ce(s.detach(), t, self.center, mx, lse, tmatch, w, 1.0 / self.student_temp, inv_tt)
+        loss = o.sum_f32(row_loss)
+        self.update_center(t)
+        return _LossFn.apply(loss, self.assume_unit_grad, student_output, ds)
+
+    @torch.no_grad()
+    def update_center(self, teacher_output):
+        o = _ops()
+        cs = o.colsum(teacher_output)
+        if _world() > 1:
+            dist.all_reduce(cs)
+        o.center_ema(self.center, cs, self.center_momentum, teacher_output.shape[0] * _world())
+
+
+class DDINOLoss(nn.Module):
+    def __init__(self, out_dim, ncrops, warmup_teacher_temp, teacher_temp, warmup_teacher_temp_epochs, nepochs,
+                 student_temp=0.1, center_momentum=0.9):
+        super().__init__()
+        self.student_temp, self.center_momentum, self.ncrops = student_temp, center_momentum, ncrops
+        self.register_buffer("center", torch.zeros(1, out_dim))
+        self.register_buffer("center_grid", torch.zeros(1, out_dim))
+        self.teacher_temp_schedule = _teacher_temp_schedule(warmup_teacher_temp, teacher_temp, warmup_teacher_temp_epochs, nepochs)
+        self.assume_unit_grad = False
+        self._tables = {}
+
+    def _static(self, B, s_npatch, Tt, device):
+        """index tables that depend only on (B, crop layout): crop-major <-> image-major permutations, the cls
+        teacher rows, and the per-row loss weights 0.5/(n_terms*B) and 0.5/(n_terms*B*Ts) (Appendix A5)."""
+        key = (B, tuple(s_npatch), Tt, str(device))
+        t = self._tables.get(key)
+        if t is not None:
+            return t
+        nc = self.ncrops
+        n_terms = 2 * nc - 2
+        sizes = [s_npatch[0]] * 2 + [s_npatch[1]] * (nc - 2)  # main_esvit.py:710
+        S = int(sum(sizes))
+        soff = np.concatenate(([0], np.cumsum(sizes)))
+        crop_id = np.concatenate([np.full(sz, v, dtype=np.int32) for v, sz in enumerate(sizes)])
+        cm_row = np.empty((B, S), dtype=np.int32)
+        w_reg = np.empty((B * S,), dtype=np.float32)
+        for v, sz in enumerate(sizes):
+            rows = B * soff[v] + np.arange(B)[:, None] * sz + np.arange(sz)[None, :]   # [B, sz]
+            cm_row[:, soff[v]:soff[v + 1]] = rows
+            w_reg[rows.reshape(-1)] = 0.5 / (n_terms * B * sz)
+        t_perm = (np.arange(2)[None, :, None] * B * Tt + np.arange(B)[:, None, None] * Tt + np.arange(Tt)[None, None, :]).reshape(-1)
+        tm_cls = np.full((nc * B, 2), -1, dtype=np.int32)
+        for v in range(nc):
+            for iq in range(2):
+                if v != iq:
+                    tm_cls[v * B:(v + 1) * B, iq] = iq * B + np.arange(B)
+        w_cls = np.full((nc * B,), 0.5 / (n_terms * B), dtype=np.float32)
+        dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
+        t = dict(S=S, crop_id=dev(crop_id), cm_row=dev(cm_row.reshape(-1)), t_perm=dev(t_perm.astype(np.int32)), tm_cls=dev(tm_cls),
+                 w_cls=dev(w_cls), w_reg=dev(w_reg))
+        self._tables[key] = t
+        return t
+
+    def forward(self, student_output, teacher_output, epoch, targets_mixup=None):
+        o = _ops()
+        s_cls, s_reg, s_fea, s_np = student_output
+        t_cls, t_reg, t_fea, t_np = teacher_output
+        s_cls_c, s_reg_c = s_cls.contiguous(), s_reg.contiguous()
+        t_cls, t_reg = t_cls.detach().contiguous(), t_reg.detach().contiguous()
+        Tt = int(t_np[0])
+        B = t_reg.shape[0] // (2 * Tt)
+        tb = self._static(B, [int(n) for n in s_np], Tt, s_cls.device)
+        S = tb["S"]
+        inv_tt = 1.0 / float(self.teacher_temp_schedule[epoch])
+        inv_st = 1.0 / self.student_temp
+        # region matching on fp32 backbone features (main_esvit.py:735-736)
+        sf = o.gather_cast(s_fea.detach().float().contiguous(), B * S, rowmap=tb["cm_row"], tokens=1, dtype=torch.float32)
+        tf = o.gather_cast(t_fea.detach().float().contiguous(), B * 2 * Tt, rowmap=tb["t_perm"], tokens=1, dtype=torch.float32)
+        sfn, _ = o.l2norm_fwd(sf)
+        tfn, _ = o.l2norm_fwd(tf)
+        D = sfn.shape[1]
+        ld = -(-2 * Tt // 8) * 8
+        sim = o.batched_nt(sfn.view(B, S, D), tfn.view(B, 2 * Tt, D), ld)
+        tm_reg = torch.empty((B * S, 2), dtype=torch.int32, device=s_cls.device)
+        o.region_match(sim, Tt, tb["crop_id"], tb["cm_row"], tm_reg)
+        # teacher statistics, student CE + gradient
+        mx_c, lse_c = o.teacher_row_stats(t_cls, self.center, inv_tt)
+        mx_g, lse_g = o.teacher_row_stats(t_reg, self.center_grid, inv_tt)
+        n_cls = s_cls_c.shape[0]
+        row_loss = torch.empty((n_cls + s_reg_c.shape[0],), dtype=torch.float32, device=s_cls.device)
+        _, ds_cls = o.dino_ce(s_cls_c.detach(), t_cls, self.center, mx_c, lse_c, tb["tm_cls"], tb["w_cls"], inv_st, inv_tt,
+                              row_loss=row_loss[:n_cls])
+        _, ds_reg = o.dino_ce(s_reg_c.detach(), t_reg, self.center_grid, mx_g, lse_g, tm_reg, tb["w_reg"], inv_st, inv_tt,
+                              row_loss=row_loss[n_cls:])
+        loss = o.sum_f32(row_loss)
+        self.update_center(t_cls, t_reg)
+        return _LossFn.apply(loss, self.assume_unit_grad, s_cls, s_reg, ds_cls, ds_reg)
+
+    @torch.no_grad()
+    def update_center(self, teacher_output, teacher_grid_output):
+        """main_esvit.py:752-770; the two (1,K) partial sums travel in ONE all-reduce."""
+        o = _ops()
+        K = self.center.shape[1]
+        buf = torch.empty((2, K), dtype=torch.float32, device=self.center.device)
+        o.colsum(teacher_output, out=buf[0])
+        o.colsum(teacher_grid_output, out=buf[1])
+        w = _world()
+        if w > 1:
+            dist.all_reduce(buf)
+        o.center_ema(self.center, buf[0], self.center_momentum, teacher_output.shape[0] * w)
+        o.center_ema(self.center_grid, buf[1], self.center_momentum, teacher_grid_output.shape[0] * w)

@@ -1,0 +1,347 @@
+"""MI355X-native Swin backbone behind the reference's module interface (models/swin_transformer.py).
+
+The module tree only *holds parameters* -- names, shapes, dtypes, registration order and init are those of
+the reference (so state_dicts, ``.parameters()`` zips for the EMA, DDP and ``get_params_groups`` behave
+identically, SURVEY.md 5 "checkpoint / resume") -- while every forward runs the fused HIP pipeline in
+esvit_amd.functional: one autograd node per Swin block, window partition / roll / pad folded into kernel
+address maps, bf16 MFMA GEMMs with fused epilogues.
+"""
+import logging
+import os
+from functools import partial
+from math import sqrt
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import functional as Fn
+from .registry import register_model
+
+
+def _trunc_normal_(t, std=0.02):
+    return nn.init.trunc_normal_(t, mean=0.0, std=std, a=-2.0, b=2.0)
+
+
+def _pair(x):
+    return tuple(x) if isinstance(x, (tuple, list)) else (x, x)
+
+
+class DropPath(nn.Module):
+    """holder for the stochastic-depth rate; the per-sample factors are drawn in the block (vision_transformer.py:30-38)"""
+
+    def __init__(self, drop_prob=None):
+        super().__init__()
+        self.drop_prob = drop_prob
+
+    def factors(self, nB, device):
+        if not self.drop_prob or not self.training:
+            return None
+        keep = 1.0 - self.drop_prob
+        return (keep + torch.rand(nB, device=device)).floor_().div_(keep)
+
+
+class Mlp(nn.Module):
+    def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=nn.GELU, drop=0.):
+        super().__init__()
+        assert drop == 0., "dropout is 0 in every reference yaml"
+        self.fc1 = nn.Linear(in_features, hidden_features or in_features)
+        self.act = act_layer()
+        self.fc2 = nn.Linear(hidden_features or in_features, out_features or in_features)
+        self.drop = nn.Dropout(drop)
+
+
+class WindowAttention(nn.Module):
+    def __init__(self, dim, window_size, num_heads, qkv_bias=True, qk_scale=None, attn_drop=0., proj_drop=0.):
+        super().__init__()
+        assert qkv_bias and qk_scale is None and attn_drop == 0. and proj_drop == 0.
+        self.dim, self.window_size, self.num_heads = dim, window_size, num_heads
+        self.scale = (dim // num_heads) ** -0.5
+        ws = window_size[0]
+        self.relative_position_bias_table = nn.Parameter(torch.zeros((2 * ws - 1) * (2 * ws - 1), num_heads))
+        p = np.arange(ws * ws)
+        rel = (p[:, None] // ws - p[None, :] // ws + ws - 1) * (2 * ws - 1) + (p[:, None] % ws - p[None, :] % ws + ws - 1)
+        self.register_buffer("relative_position_index", torch.from_numpy(rel.astype(np.int64)))
+        self.qkv = nn.Linear(dim, dim * 3, bias=True)
+        self.attn_drop = nn.Dropout(attn_drop)
+        self.proj = nn.Linear(dim, dim)
+        self.proj_drop = nn.Dropout(proj_drop)
+        _trunc_normal_(self.relative_position_bias_table, std=.02)
+        self.softmax = nn.Softmax(dim=-1)
+
+
+class SwinTransformerBlock(nn.Module):
+    def __init__(self, dim, input_resolution, num_heads, window_size=7, shift_size=0, mlp_ratio=4., qkv_bias=True,
+                 qk_scale=None, drop=0., attn_drop=0., drop_path=0., act_layer=nn.GELU, norm_layer=nn.LayerNorm):
+        super().__init__()
+        self.dim, self.input_resolution, self.num_heads = dim, input_resolution, num_heads
+        self.window_size, self.shift_size, self.mlp_ratio = window_size, shift_size, mlp_ratio
+        if min(input_resolution) <= window_size:  # swin_transformer.py:206-209
+            self.shift_size = 0
+            self.window_size = min(input_resolution)
+        assert 0 <= self.shift_size < self.window_size
+        self.norm1 = norm_layer(dim)
+        self.attn = WindowAttention(dim, _pair(self.window_size), num_heads, qkv_bias, qk_scale, attn_drop, drop)
+        self.drop_path = DropPath(drop_path) if drop_path > 0. else nn.Identity()
+        self.norm2 = norm_layer(dim)
+        self.mlp = Mlp(dim, int(dim * mlp_ratio), act_layer=act_layer, drop=drop)
+        self.H, self.W = input_resolution
+
+    def _params(self):
+        a, m = self.attn, self.mlp
+        return [self.norm1.weight, self.norm1.bias, a.relative_position_bias_table, a.qkv.weight, a.qkv.bias, a.proj.weight,
+                a.proj.bias, self.norm2.weight, self.norm2.bias, m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias]
+
+    def forward(self, x, return_attention=False):
+        B, L, C = x.shape
+        H = W = int(sqrt(L))
+        geom = Fn.geometry(H, W, self.window_size, self.shift_size, x.device)
+        dp = None
+        if isinstance(self.drop_path, DropPath):
+            f1, f2 = self.drop_path.factors(B, x.device), self.drop_path.factors(B, x.device)
+            dp = None if f1 is None else (f1, f2)
+        attn = None
+        if return_attention:
+            attn = Fn.swin_block_attention(x, geom, self.num_heads, self.attn.relative_position_index, self._params())
+        y = Fn.swin_block(x, geom, self.num_heads, self.attn.relative_position_index, dp, self._params())
+        return y, attn
+
+
+class PatchMerging(nn.Module):
+    def __init__(self, input_resolution, dim, norm_layer=nn.LayerNorm):
+        super().__init__()
+        self.input_resolution, self.dim = input_resolution, dim
+        self.reduction = nn.Linear(4 * dim, 2 * dim, bias=False)
+        self.norm = norm_layer(4 * dim)
+
+    def forward(self, x):
+        B, L, C = x.shape
+        H = W = int(sqrt(L))
+        if H % 2 or W % 2:
+            raise NotImplementedError("odd feature maps are not reachable from 224/96 crops (swin_transformer.py:406-408)")
+        return Fn.PatchMergeFn.apply(x, H, W, self.norm.weight, self.norm.bias, self.reduction.weight)
+
+
+class BasicLayer(nn.Module):
+    def __init__(self, dim, input_resolution, depth, num_heads, window_size, mlp_ratio=4., qkv_bias=True, qk_scale=None,
+                 drop=0., attn_drop=0., drop_path=0., norm_layer=nn.LayerNorm, downsample=None):
+        super().__init__()
+        self.dim, self.input_resolution, self.depth = dim, input_resolution, depth
+        self.blocks = nn.ModuleList([
+            SwinTransformerBlock(dim, input_resolution, num_heads, window_size, 0 if i % 2 == 0 else window_size // 2, mlp_ratio,
+                                 qkv_bias, qk_scale, drop, attn_drop, drop_path[i] if isinstance(drop_path, list) else drop_path,
+                                 norm_layer=norm_layer) for i in range(depth)])
+        self.downsample = downsample(input_resolution, dim=dim, norm_layer=norm_layer) if downsample is not None else None
+
+    def forward(self, x):
+        for blk in self.blocks:
+            x, _ = blk(x)
+        return self.downsample(x) if self.downsample is not None else x
+
+    def forward_with_features(self, x):
+        fea = []
+        for blk in self.blocks:
+            x, _ = blk(x)
+            fea.append(x)
+        return (self.downsample(x) if self.downsample is not None else x), fea
+
+    def forward_with_attention(self, x):
+        attns = []
+        for blk in self.blocks:
+            x, a = blk(x, return_attention=True)
+            attns.append(a)
+        return (self.downsample(x) if self.downsample is not None else x), attns
+
+
+class PatchEmbed(nn.Module):
+    def __init__(self, img_size=224, patch_size=4, in_chans=3, embed_dim=96, norm_layer=None):
+        super().__init__()
+        img_size, patch_size = _pair(img_size), _pair(patch_size)
+        self.img_size, self.patch_size = img_size, patch_size
+        self.patches_resolution = [img_size[0] // patch_size[0], img_size[1] // patch_size[1]]
+        self.num_patches = self.patches_resolution[0] * self.patches_resolution[1]
+        self.in_chans, self.embed_dim = in_chans, embed_dim
+        self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=patch_size, stride=patch_size)
+        self.norm = norm_layer(embed_dim) if norm_layer is not None else None
+
+    def forward(self, x):
+        if self.norm is None:
+            raise NotImplementedError("PATCH_NORM False is not used by any reference yaml")
+        return Fn.PatchEmbedFn.apply(x, self.proj.weight, self.proj.bias, self.norm.weight, self.norm.bias, self.patch_size[0])
+
+
+class SwinTransformer(nn.Module):
+    """Same constructor, attributes and methods as the reference class (swin_transformer.py:576-943)."""
+
+    def __init__(self, img_size=224, patch_size=4, in_chans=3, num_classes=1000, embed_dim=96, depths=[2, 2, 6, 2],
+                 num_heads=[3, 6, 12, 24], window_size=7, mlp_ratio=4., qkv_bias=True, qk_scale=None, drop_rate=0.,
+                 attn_drop_rate=0., drop_path_rate=0.1, norm_layer=nn.LayerNorm, ape=False, patch_norm=True,
+                 use_dense_prediction=False, **kwargs):
+        super().__init__()
+        if ape:
+            raise NotImplementedError("USE_APE is False in every reference yaml")
+        self.num_classes, self.num_layers, self.embed_dim = num_classes, len(depths), embed_dim
+        self.ape, self.patch_norm, self.mlp_ratio = ape, patch_norm, mlp_ratio
+        self.num_features = int(embed_dim * 2 ** (self.num_layers - 1))
+        self.patch_embed = PatchEmbed(img_size, patch_size, in_chans, embed_dim, norm_layer if patch_norm else None)
+        self.patches_resolution = self.patch_embed.patches_resolution
+        self.pos_drop = nn.Dropout(p=drop_rate)
+        dpr = [x.item() for x in torch.linspace(0, drop_path_rate, sum(depths))]
+        self.layers = nn.ModuleList()
+        for i in range(self.num_layers):
+            self.layers.append(BasicLayer(
+                dim=int(embed_dim * 2 ** i),
+                input_resolution=(self.patches_resolution[0] // (2 ** i), self.patches_resolution[1] // (2 ** i)),
+                depth=depths[i], num_heads=num_heads[i], window_size=window_size, mlp_ratio=mlp_ratio, qkv_bias=qkv_bias,
+                qk_scale=qk_scale, drop=drop_rate, attn_drop=attn_drop_rate,
+                drop_path=dpr[sum(depths[:i]):sum(depths[:i + 1])], norm_layer=norm_layer,
+                downsample=PatchMerging if i < self.num_layers - 1 else None))
+        self.norm = norm_layer(self.num_features)
+        self.avgpool = nn.AdaptiveAvgPool1d(1)
+        self.head = nn.Linear(self.num_features, num_classes) if num_classes > 0 else nn.Identity()
+        self.use_dense_prediction = use_dense_prediction
+        if self.use_dense_prediction:
+            self.head_dense = None
+        self.apply(self._init_weights)
+
+    def _init_weights(self, m):
+        if isinstance(m, nn.Linear):
+            _trunc_normal_(m.weight, std=.02)
+            if m.bias is not None:
+                nn.init.constant_(m.bias, 0)
+        elif isinstance(m, nn.LayerNorm):
+            nn.init.constant_(m.bias, 0)
+            nn.init.constant_(m.weight, 1.0)
+
+    @torch.jit.ignore
+    def no_weight_decay(self):
+        return {'absolute_pos_embed'}
+
+    @torch.jit.ignore
+    def no_weight_decay_keywords(self):
+        return {'relative_position_bias_table'}
+
+    # ---- forward paths -----------------------------------------------------------------------
+    def _tokens(self, x):
+        return self.patch_embed(x)
+
+    def forward_feature_maps(self, x):
+        x = self._tokens(x)
+        for layer in self.layers:
+            x = layer(x)
+        x_grid = Fn.FinalNormFn.apply(x, self.norm.weight, self.norm.bias)
+        return Fn.TokenMeanFn.apply(x_grid), x_grid
+
+    def forward_features(self, x):
+        cls, region = self.forward_feature_maps(x)
+        return (cls, region) if self.use_dense_prediction else cls
+
+    def _apply_head(self, head, feats):
+        from ..head import DINOHead
+        if isinstance(head, (DINOHead, nn.Identity)):
+            return head(feats)
+        return head(feats)  # e.g. the default nn.Linear classifier: plain torch module supplied by the caller
+
+    def forward(self, x):
+        if not isinstance(x, list):
+            x = [x]
+        # group consecutive crops of equal resolution (swin_transformer.py:729-732)
+        bounds, start = [], 0
+        for i in range(1, len(x) + 1):
+            if i == len(x) or x[i].shape[-1] != x[start].shape[-1]:
+                bounds.append((start, i))
+                start = i
+        if self.use_dense_prediction:
+            cls_parts, fea_parts, npatch = [], [], []
+            for a, b in bounds:
+                cls, fea = self.forward_feature_maps(torch.cat(x[a:b]))
+                B, N, C = fea.shape
+                cls_parts.append(cls)
+                fea_parts.append(fea.reshape(B * N, C))
+                npatch.append(N)
+            output_cls = cls_parts[0] if len(cls_parts) == 1 else torch.cat(cls_parts)
+            output_fea = fea_parts[0] if len(fea_parts) == 1 else torch.cat(fea_parts)
+            return self._apply_head(self.head, output_cls), self._apply_head(self.head_dense, output_fea), output_fea, npatch
+        outs = [self.forward_features(torch.cat(x[a:b])) for a, b in bounds]
+        return self._apply_head(self.head, outs[0] if len(outs) == 1 else torch.cat(outs))
+
+    def forward_selfattention(self, x, n=1):
+        x = self._tokens(x)
+        if n == 1:
+            return self.forward_last_selfattention(x)
+        return self.forward_all_selfattention(x)
+
+    def forward_last_selfattention(self, x):
+        for i, layer in enumerate(self.layers):
+            if i < len(self.layers) - 1:
+                x = layer(x)
+            else:
+                x, attns = layer.forward_with_attention(x)
+                return attns[-1]
+
+    def forward_all_selfattention(self, x):
+        out = []
+        for layer in self.layers:
+            x, attns = layer.forward_with_attention(x)
+            out += attns
+        return out
+
+    def forward_return_n_last_blocks(self, x, n=1, return_patch_avgpool=False, depth=[]):
+        """mean-pooled tokens of the last n blocks, concatenated (swin_transformer.py:799-837)"""
+        start_idx = sum(depth) - n
+        acc = 0
+        for i, d in enumerate(depth):
+            if acc <= start_idx < acc + d:
+                start_stage, start_blk = i, start_idx - acc
+            acc += d
+        x = self._tokens(x)
+        output = []
+        for i, layer in enumerate(self.layers):
+            x, fea = layer.forward_with_features(x)
+            if i >= start_stage:
+                for x_ in fea[start_blk:]:
+                    if i == len(self.layers) - 1:
+                        x_ = Fn.FinalNormFn.apply(x_, self.norm.weight, self.norm.bias)
+                    output.append(Fn.TokenMeanFn.apply(x_))
+                start_blk = 0
+        return torch.cat(output, dim=-1)
+
+    def init_weights(self, pretrained='', pretrained_layers=[], verbose=True):
+        """load matching keys of a pretrained state_dict (swin_transformer.py:852-917; bias-table / APE resizing of
+        mismatched window sizes is out of scope: tables must match)."""
+        if os.path.isfile(pretrained):
+            sd = torch.load(pretrained, map_location='cpu')
+            own = self.state_dict()
+            sd = {k: v for k, v in sd.items() if k in own and v.shape == own[k].shape}
+            if verbose:
+                logging.info(f'=> loading {len(sd)} tensors from {pretrained}')
+            self.load_state_dict(sd, strict=False)
+
+    def freeze_pretrained_layers(self, frozen_layers=[]):
+        for name, module in self.named_modules():
+            if name.split('.')[0] in frozen_layers or '.'.join(name.split('.')[0:2]) in frozen_layers \
+                    or (len(frozen_layers) > 0 and frozen_layers[0] == '*'):
+                for p in module.parameters():
+                    p.requires_grad = False
+        for name, p in self.named_parameters():
+            if name.split('.')[0] in frozen_layers or (len(frozen_layers) > 0 and frozen_layers[0] == '*'):
+                p.requires_grad = False
+        return self
+
+
+@register_model
+def get_cls_model(config, is_teacher=False, use_dense_prediction=False, **kwargs):
+    """same config keys as the reference factory (swin_transformer.py:946-980)"""
+    spec = config.MODEL.SPEC
+    swin = SwinTransformer(
+        img_size=config.TRAIN.IMAGE_SIZE[0], in_chans=3, num_classes=config.MODEL.NUM_CLASSES, patch_size=spec['PATCH_SIZE'],
+        embed_dim=spec['DIM_EMBED'], depths=spec['DEPTHS'], num_heads=spec['NUM_HEADS'], window_size=spec['WINDOW_SIZE'],
+        mlp_ratio=spec['MLP_RATIO'], qkv_bias=spec['QKV_BIAS'], drop_rate=spec['DROP_RATE'],
+        attn_drop_rate=spec['ATTN_DROP_RATE'], drop_path_rate=0.0 if is_teacher else spec['DROP_PATH_RATE'],
+        norm_layer=partial(nn.LayerNorm, eps=1e-6), ape=spec['USE_APE'], patch_norm=spec['PATCH_NORM'],
+        use_dense_prediction=use_dense_prediction)
+    if config.MODEL.INIT_WEIGHTS:
+        swin.init_weights(config.MODEL.PRETRAINED, config.MODEL.PRETRAINED_LAYERS, config.VERBOSE)
+    if config.FINETUNE.FINETUNE:
+        swin.freeze_pretrained_layers(config.FINETUNE.FROZEN_LAYERS)
+    return swin

@@ -454,12 +454,22 @@ def row_argmax(sim, Tt):
     return idx
 
 
-def dino_ce(s, t, center, t_max, t_lse, tmatch, row_w, inv_student_temp, inv_teacher_temp):
+def region_match(sim, Tt, crop_id, cm_row, tmatch):
+    """sim fp32 [B, S, ld]; writes tmatch (int32 [rows, 2]) in place."""
+    sim = _f32c(sim)
+    B, S, ld = sim.shape
+    check(lib.esvit_region_match(_p(sim), B, S, Tt, ld, _p(crop_id), _p(cm_row), _p(tmatch), _stream()), "region_match")
+    return tmatch
+
+
+def dino_ce(s, t, center, t_max, t_lse, tmatch, row_w, inv_student_temp, inv_teacher_temp, row_loss=None):
     """-> (row_loss fp32 [Rs], ds act [Rs, K])."""
     s, t = _actc(s), _actc(t)
     Rs, K = s.shape
     assert t.shape[1] == K and s.dtype == t.dtype and tmatch.dtype == torch.int32
-    row_loss = torch.empty((Rs,), dtype=torch.float32, device=s.device)
+    if row_loss is None:
+        row_loss = torch.empty((Rs,), dtype=torch.float32, device=s.device)
+    assert row_loss.numel() == Rs and row_loss.is_contiguous()
     ds = torch.empty_like(s)
     check(lib.esvit_dino_ce_fwd_bwd(_code(s.dtype), _p(s), _p(t), _p(center), _p(t_max), _p(t_lse), _p(tmatch), _p(row_w),
                                     inv_student_temp, inv_teacher_temp, Rs, K, _p(row_loss), _p(ds), _stream()), "dino_ce_fwd_bwd")

@@ -1,0 +1,51 @@
+"""Activation-dtype caches of fp32 parameters (the GEMM kernels read weights in the activation dtype).
+
+A cached copy is refreshed when the parameter's autograd version changes (torch optimizers, load_state_dict)
+or when ``invalidate()`` is called (the fused HIP update writes parameters through raw pointers, which does
+not bump the version counter)."""
+import torch
+
+from . import ops
+
+_GEN = 0
+_CACHE = {}
+
+
+def invalidate():
+    global _GEN
+    _GEN += 1
+
+
+def _tag(p):
+    return (p._version, _GEN, p.data_ptr(), ops.act_dtype())
+
+
+def cached_cast(p, shape2d=None):
+    """fp32 parameter -> activation-dtype copy (optionally viewed as a 2-D matrix first)."""
+    key = (id(p), "cast")
+    tag = _tag(p)
+    ent = _CACHE.get(key)
+    if ent is not None and ent[0] == tag:
+        return ent[1]
+    src = p.detach()
+    if shape2d is not None:
+        src = src.reshape(shape2d)
+    w = ops.cast_to_act(src.contiguous())
+    _CACHE[key] = (tag, w)
+    return w
+
+
+def cached(p, name, fn):
+    """generic per-parameter cache for derived tensors (e.g. the weight-normed last layer)."""
+    key = (id(p), name)
+    tag = _tag(p)
+    ent = _CACHE.get(key)
+    if ent is not None and ent[0] == tag:
+        return ent[1]
+    val = fn()
+    _CACHE[key] = (tag, val)
+    return val
+
+
+def clear():
+    _CACHE.clear()

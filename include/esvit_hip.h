@@ -192,6 +192,13 @@ int esvit_teacher_row_stats(int dtype, const void* t, const float* center, float
 /* region matching (main_esvit.py:735-736): sim fp32 [P, Ts, ldsim] -> idx int32 [P*Ts] =
  * argmax over first Tt columns (first index on ties) */
 int esvit_row_argmax(const float* sim, int64_t rows, int Tt, int ld, int32_t* idx, esvit_stream_t stream);
+/* fused argmax + row assembly for the region loss: sim fp32 [B, S, ld] holds, for image b, the cosine
+ * similarities of its S student tokens (all crops, image-major) against the 2*Tt teacher tokens
+ * (view 0 then view 1).  For student position s of crop crop_id[s] and teacher view iq:
+ *   tmatch[cm_row[b*S+s]*2 + iq] = crop_id[s]==iq ? -1 : iq*B*Tt + b*Tt + argmax_j sim[b,s,iq*Tt+j]
+ * cm_row maps the image-major position to the student's crop-major logit row (main_esvit.py:710-715). */
+int esvit_region_match(const float* sim, int B, int S, int Tt, int ld, const int32_t* crop_id,
+                       const int32_t* cm_row, int32_t* tmatch, esvit_stream_t stream);
 /* fused student log-softmax CE + gradient (main_esvit.py:706-746).
  * s dtype [Rs, K] student logits (un-tempered); for student row r the teacher rows it is
  * scored against are tmatch[r*2+0], tmatch[r*2+1] (row index into t, -1 = unused term).

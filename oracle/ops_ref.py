@@ -413,7 +413,17 @@ def row_argmax(sim, Tt):
     return sim.reshape(-1, ld)[:, :Tt].argmax(1).to(torch.int32)
 
 
-def dino_ce(s, t, center, t_max, t_lse, tmatch, row_w, inv_student_temp, inv_teacher_temp):
+def region_match(sim, Tt, crop_id, cm_row, tmatch):
+    B, S, ld = sim.shape
+    for iq in range(2):
+        j = sim[:, :, iq * Tt:(iq + 1) * Tt].argmax(-1)                       # [B, S]
+        val = iq * B * Tt + torch.arange(B, device=sim.device)[:, None] * Tt + j
+        val = torch.where(crop_id.view(1, S) == iq, torch.full_like(val, -1), val)
+        tmatch[cm_row.long(), iq] = val.reshape(-1).to(torch.int32)
+    return tmatch
+
+
+def dino_ce(s, t, center, t_max, t_lse, tmatch, row_w, inv_student_temp, inv_teacher_temp, row_loss=None):
     z = s.float() * inv_student_temp
     lse = torch.logsumexp(z, 1)
     ps = torch.exp(z - lse[:, None])
@@ -426,7 +436,11 @@ def dino_ce(s, t, center, t_max, t_lse, tmatch, row_w, inv_student_temp, inv_tea
         ii = idx.clamp(min=0)
         pj = torch.exp((t.float()[ii] - center.view(1, -1)) * inv_teacher_temp - (t_max[ii] + t_lse[ii])[:, None])
         pt = pt + pj * ok[:, None]
-    row_loss = row_w * (nterms * lse - (pt * z).sum(1))
+    rl = row_w * (nterms * lse - (pt * z).sum(1))
+    if row_loss is not None:
+        row_loss.copy_(rl)
+    else:
+        row_loss = rl
     ds = (row_w * inv_student_temp)[:, None] * (nterms[:, None] * ps - pt)
     return row_loss, _r(ds, s.dtype)
 

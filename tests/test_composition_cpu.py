@@ -1,0 +1,120 @@
+"""CPU test of the HOST-SIDE composition (autograd glue, manual backward formulas, index-map plumbing, loss
+tables) of the product modules: esvit_amd.ops is monkeypatched with the plain-PyTorch op restatement
+(oracle/ops_ref.py) so the whole EsViT step can run without a GPU and be compared with the golden vectors
+generated from the reference.  The HIP kernels themselves are checked op-by-op in tests/test_kernels_gpu.py."""
+import os
+
+import pytest
+import torch
+
+from oracle import esvit_oracle as O
+from oracle import ops_ref
+from oracle import ref_loader as RL
+from tests import golden_utils as GU
+from tests.test_oracle_cpu import GOLD, probe_close
+
+
+@pytest.fixture()
+def cpu_ops(monkeypatch, lib_built):
+    import esvit_amd.functional as Fn
+    import esvit_amd.loss as L
+    import esvit_amd.params as P
+    for mod in (Fn, L, P):
+        monkeypatch.setattr(mod, "ops", ops_ref)
+    ops_ref.set_act_dtype(torch.float32)
+    P.clear()
+    Fn._GEOM.clear()
+    yield ops_ref
+    ops_ref.set_act_dtype(torch.float32)
+    P.clear()
+    Fn._GEOM.clear()
+
+
+def build_nano(teacher=False):
+    from esvit_amd import models
+    cfg = RL.swin_config(embed_dim=GU.NANO["embed_dim"], depths=GU.NANO["depths"], heads=GU.NANO["heads"], window=GU.NANO["window"])
+    m = models.build_model(cfg, is_teacher=teacher, use_dense_prediction=True)
+    hk = dict(hidden_dim=GU.NANO_HEAD["hidden_dim"], bottleneck_dim=GU.NANO_HEAD["bottleneck_dim"])
+    m.head = models.DINOHead(m.num_features, GU.NANO_HEAD["out_dim"], norm_last_layer=True, **hk)
+    m.head_dense = models.DINOHead(m.num_features, GU.NANO_HEAD["out_dim"], norm_last_layer=False, **hk)
+    return m
+
+
+def nano_pair():
+    student, teacher = build_nano(), build_nano(teacher=True)
+    GU.fill_state_dict(student.state_dict(), 0)
+    GU.fill_state_dict(teacher.state_dict(), 7)
+    student.head.last_layer.weight_g.data.fill_(1)
+    for p in teacher.parameters():
+        p.requires_grad = False
+    return student, teacher
+
+
+def run_nano_step(nano, student, teacher, loss_mod, crops, dev="cpu"):
+    K = GU.NANO_HEAD["out_dim"]
+    loss_fn = loss_mod.DDINOLoss(K, 10, 0.04, 0.07, 5, 10).to(dev)
+    loss_fn.center.copy_(nano["center0"])
+    loss_fn.center_grid.copy_(nano["center_grid0"])
+    t_out = teacher(crops[:2])
+    s_out = student(crops)
+    loss = loss_fn(s_out, t_out, 2, None)
+    loss.backward()
+    return s_out, t_out, loss, loss_fn
+
+
+def test_state_dict_layout_matches_golden():
+    nano = torch.load(os.path.join(GOLD, "nano_step.pt"), weights_only=False)
+    m = build_nano()
+    assert [(k, tuple(v.shape), str(v.dtype)) for k, v in m.state_dict().items()] == nano["keys"]
+    assert [n for n, _ in m.named_parameters()] == nano["param_names"]
+    assert [n for n, p in m.named_parameters() if p.requires_grad] == nano["trainable"]
+
+
+def test_composition_fp32_matches_reference_golden(cpu_ops):
+    import esvit_amd.loss as L
+    nano = torch.load(os.path.join(GOLD, "nano_step.pt"), weights_only=False)
+    student, teacher = nano_pair()
+    crops = GU.make_crops(2)
+    s_out, t_out, loss, loss_fn = run_nano_step(nano, student, teacher, L, crops)
+    for nm, t in (("s_cls", s_out[0]), ("s_reg", s_out[1]), ("s_fea", s_out[2]), ("t_cls", t_out[0]), ("t_reg", t_out[1]),
+                  ("t_fea", t_out[2])):
+        probe_close(nm, t, nano[nm])
+    assert (list(s_out[3]), list(t_out[3])) == nano["npatch"]
+    assert abs(loss.item() - nano["ddino_loss"]) < 2e-5
+    assert (loss_fn.center - nano["center1"]).abs().max().item() < 1e-6
+    assert (loss_fn.center_grid - nano["center_grid1"]).abs().max().item() < 1e-6
+    assert [n for n, p in student.named_parameters() if p.grad is None] == nano["no_grad"]
+    for n, p in student.named_parameters():
+        if p.grad is not None:
+            probe_close("grad " + n, p.grad, nano["grads"][n], rtol=1e-3)
+    # second call sees the updated centres
+    with torch.no_grad():
+        l2 = loss_fn([t.detach() if torch.is_tensor(t) else t for t in s_out], t_out, 2, None)
+    assert abs(l2.item() - nano["ddino_loss_2"]) < 2e-5
+    # view-level DINOLoss on the two global crops
+    vl = L.DINOLoss(GU.NANO_HEAD["out_dim"], 2, 0.04, 0.07, 5, 10)
+    vl.center.copy_(nano["center0"])
+    with torch.no_grad():
+        cls2 = student.head(student.forward_features(torch.cat(crops[:2]))[0])
+        lv = vl(cls2, t_out[0], 2, None)
+    assert abs(lv.item() - nano["dino_loss_2crops"]) < 2e-5
+    assert (vl.center - nano["dino_center1"]).abs().max().item() < 1e-6
+    with torch.no_grad():
+        probe_close("last_attn", student.forward_selfattention(crops[0]), nano["last_attn"])
+
+
+def test_composition_bf16_emulation_error_budget(cpu_ops):
+    """bf16 activation storage emulated on CPU: records how far bf16 rounding alone moves the loss/gradients, which
+    is the tolerance the -m gpu bf16 tests are allowed (the HIP kernels round at the same points)."""
+    import esvit_amd.loss as L
+    nano = torch.load(os.path.join(GOLD, "nano_step.pt"), weights_only=False)
+    ops_ref.set_act_dtype(torch.bfloat16)
+    student, teacher = nano_pair()
+    s_out, t_out, loss, _ = run_nano_step(nano, student, teacher, L, GU.make_crops(2))
+    assert abs(loss.item() - nano["ddino_loss"]) < 2e-2
+    worst = 0.0
+    for n, p in student.named_parameters():
+        if p.grad is not None:
+            ref = nano["grad_norms"][n]
+            worst = max(worst, abs(p.grad.norm().item() - ref) / (ref + 1e-12))
+    assert worst < 0.15, worst
