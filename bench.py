@@ -1,0 +1,180 @@
+#!/usr/bin/env python
+"""EsViT pre-training step benchmark (BASELINE.json metric: images/sec, Swin-T W=7, 2x224^2 + 8x96^2 crops, view+region
+loss, bf16, per-parameter clip + AdamW + teacher EMA, DP over RCCL when --gpus > 1).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0.  A "step" = teacher fwd (2 global crops) + student fwd (10 crops) + DDINOLoss + backward +
+gradient all-reduce (N>1) + fused clip/AdamW/EMA on a fixed synthetic batch resident in HBM.  `value` = images/s over all
+ranks.  `roofline` describes the dominant kernel family (the MFMA GEMM: 99% of the step's FLOPs) from HIP events recorded
+around every GEMM launch inside the timed region; `cpu_baseline` times the CPU oracle (a port of the reference's PyTorch
+path, oracle/esvit_oracle.py) on the host cores on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+GFLOP_PER_IMG = 154.5          # Swin-T W7 V+R, teacher fwd + student fwd + 2x student bwd + loss
+BF16_PEAK_TFLOPS = 2500.0      # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+OUT_DIM = 65536
+
+
+def build(dev, drop_path):
+    import esvit_amd
+    from esvit_amd import config as CFG
+    cfg = CFG.swin_config("swin_tiny_w7", DROP_PATH_RATE=drop_path)
+    student = esvit_amd.build_model(cfg, use_dense_prediction=True)
+    student.head = esvit_amd.DINOHead(student.num_features, OUT_DIM)
+    student.head_dense = esvit_amd.DINOHead(student.num_features, OUT_DIM)
+    teacher = esvit_amd.build_model(cfg, is_teacher=True, use_dense_prediction=True)
+    teacher.head = esvit_amd.DINOHead(teacher.num_features, OUT_DIM)
+    teacher.head_dense = esvit_amd.DINOHead(teacher.num_features, OUT_DIM)
+    student, teacher = student.to(dev), teacher.to(dev)
+    teacher.load_state_dict(student.state_dict())
+    for p in teacher.parameters():
+        p.requires_grad = False
+    loss = esvit_amd.DDINOLoss(OUT_DIM, 10, 0.04, 0.04, 0, 100).to(dev)
+    return student, teacher, loss
+
+
+def cpu_baseline(bs=2, steps=6):
+    """CPU oracle (port of the reference path) on the same workload shape at a bounded batch: fp32, all host cores."""
+    from oracle import esvit_oracle as O
+    from tests import golden_utils as GU
+    import esvit_amd
+    from esvit_amd import config as CFG
+    torch.manual_seed(0)
+    cfg = CFG.swin_config("swin_tiny_w7", DROP_PATH_RATE=0.0)
+    m = esvit_amd.build_model(cfg, use_dense_prediction=True)
+    m.head = esvit_amd.DINOHead(m.num_features, OUT_DIM)
+    m.head_dense = esvit_amd.DINOHead(m.num_features, OUT_DIM)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    names = [n for n, p in m.named_parameters() if p.requires_grad]
+    all_names = [n for n, _ in m.named_parameters()]
+    params = {n: sd[n] for n in all_names}
+    teacher = {n: sd[n].clone() for n in all_names}
+    reg = {n for n in names if not (n.endswith(".bias") or sd[n].ndim == 1)}
+    crops = GU.make_crops(bs)
+    c0, cg0 = torch.zeros(1, OUT_DIM), torch.zeros(1, OUT_DIM)
+    state = {}
+    times = []
+    for it in range(steps + 1):
+        t0 = time.perf_counter()
+        leaf = {n: params[n].detach().requires_grad_(True) for n in names}
+        full = dict(sd)
+        full.update(params)
+        full.update(leaf)
+        tfull = dict(sd)
+        tfull.update(teacher)
+        with torch.no_grad():
+            t_out = O.swin_multicrop(tfull, crops[:2], GU.SWIN_T)
+        s_out = O.swin_multicrop(full, crops, GU.SWIN_T)
+        loss, bc, bg = O.ddino_loss(s_out, t_out, c0, cg0, 0.04, 10)
+        loss.backward()
+        with torch.no_grad():
+            c0, cg0 = O.center_update(c0, bc, 2 * bs), O.center_update(cg0, bg, 98 * bs)
+            grads = {n: leaf[n].grad for n in names}
+            O.clip_adamw_ema(params, grads, state, teacher, reg, 5e-4, 0.04, 0.996, clip=3.0)
+        times.append(time.perf_counter() - t0)
+    times = sorted(times[1:])
+    med = times[len(times) // 2]
+    return {"value": bs / med, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "oracle/esvit_oracle.py fp32, Swin-T W7 2x224+8x96 V+R, bs=%d, median of %d steps (%.2f s/step)" % (bs, steps, med)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=64, help="images per GPU")
+    ap.add_argument("--drop-path", type=float, default=0.1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 or world > 1:
+        assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+
+    import esvit_amd
+    from esvit_amd import ops
+    from esvit_amd.engine import EsvitTrainer
+    from tests import golden_utils as GU
+    esvit_amd.set_precision("bf16")
+    torch.manual_seed(0)
+    student, teacher, loss_fn = build(dev, args.drop_path)
+    trainer = EsvitTrainer(student, teacher, loss_fn, clip_grad=3.0, freeze_last_layer=1)
+    B = args.batch
+    crops = [c.to(dev) for c in GU.make_crops(B, seed=1234 + rank)]
+    # constants from the first post-warm-up iteration of the reference schedules
+    lr, wd, mom, epoch = 5e-4 * B * world / 256.0, 0.04, 0.996, 1
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        trainer.step(crops, lr, wd, mom, epoch)
+    sync()
+    prof = None
+    if not args.no_roofline:
+        ops._EVENT_POOL.extend(torch.cuda.Event(enable_timing=True) for _ in range(2400 * args.steps))
+        prof = ops.GEMM_PROFILE = []
+    t0 = time.perf_counter()
+    loss = None
+    for _ in range(args.steps):
+        loss = trainer.step(crops, lr, wd, mom, epoch)
+    sync()
+    dt = time.perf_counter() - t0
+    ops.GEMM_PROFILE = None
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = t.item()
+    loss_v = loss.item()
+
+    if rank == 0:
+        ips = args.steps * B * world / dt
+        out = {"metric": "images/sec (global+local crops) Swin-T W=7 V+R", "value": ips, "unit": "images/s", "n_gpus": world,
+               "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+               "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+               "config": {"workload": "Swin-T W=7, 2x224^2+8x96^2 crops, DDINOLoss (view+region), out_dim 65536, per-param clip 3.0 + "
+                                      "AdamW + teacher EMA, drop_path %.2f" % args.drop_path,
+                          "global_batch": B * world, "per_gpu_batch": B, "parallelism": "dp%d" % world},
+               "final_loss": loss_v,
+               "step_mfma_frac": ips / world * GFLOP_PER_IMG / 1e3 / BF16_PEAK_TFLOPS}
+        if prof:
+            tot_fl = sum(f for f, _, _ in prof)
+            tot_ms = sum(a.elapsed_time(b) for _, a, b in prof)
+            ach = tot_fl / (tot_ms * 1e-3) / 1e12
+            out["roofline"] = {"bound": "mfma", "kernel": "gemm_kernel<bf16,...> (all fwd/dgrad/wgrad GEMM launches of the step)",
+                               "achieved": ach, "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / BF16_PEAK_TFLOPS,
+                               "traffic": None, "launches_per_step": len(prof) / args.steps,
+                               "flops_per_launch": tot_fl / len(prof), "avg_launch_us": tot_ms * 1e3 / len(prof),
+                               "gemm_ms_per_step": tot_ms / args.steps}
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,59 @@
+"""Minimal config object with the attribute surface the model factory reads (config/default.py keys
+MODEL.NAME / MODEL.SPEC.* / MODEL.NUM_CLASSES / MODEL.INIT_WEIGHTS / TRAIN.IMAGE_SIZE / FINETUNE.* / VERBOSE),
+buildable from a reference yaml (experiments/imagenet/swin/*.yaml) without yacs."""
+import yaml
+
+
+class CfgNode(dict):
+    """attribute access; missing keys raise AttributeError (so ``getattr(spec, 'X', default)`` works as with yacs)"""
+
+    def __getattr__(self, k):
+        try:
+            v = self[k]
+        except KeyError:
+            raise AttributeError(k)
+        return CfgNode(v) if isinstance(v, dict) and not isinstance(v, CfgNode) else v
+
+    def __setattr__(self, k, v):
+        self[k] = v
+
+
+_DEFAULTS = dict(
+    MODEL=dict(NAME="swin_transformer", NUM_CLASSES=0, INIT_WEIGHTS=False, PRETRAINED="", PRETRAINED_LAYERS=["*"], SPEC={}),
+    TRAIN=dict(IMAGE_SIZE=[224, 224]), FINETUNE=dict(FINETUNE=False, FROZEN_LAYERS=[]), VERBOSE=False)
+
+SWIN_SPECS = {
+    "swin_tiny_w7": dict(PATCH_SIZE=4, DIM_EMBED=96, DEPTHS=[2, 2, 6, 2], NUM_HEADS=[3, 6, 12, 24], WINDOW_SIZE=7, MLP_RATIO=4,
+                         QKV_BIAS=True, DROP_RATE=0, ATTN_DROP_RATE=0, DROP_PATH_RATE=0.1, USE_APE=False, PATCH_NORM=True),
+    "swin_small_w7": dict(PATCH_SIZE=4, DIM_EMBED=96, DEPTHS=[2, 2, 18, 2], NUM_HEADS=[3, 6, 12, 24], WINDOW_SIZE=7, MLP_RATIO=4,
+                          QKV_BIAS=True, DROP_RATE=0, ATTN_DROP_RATE=0, DROP_PATH_RATE=0.2, USE_APE=False, PATCH_NORM=True),
+    "swin_base_w7": dict(PATCH_SIZE=4, DIM_EMBED=128, DEPTHS=[2, 2, 18, 2], NUM_HEADS=[4, 8, 16, 32], WINDOW_SIZE=7, MLP_RATIO=4,
+                         QKV_BIAS=True, DROP_RATE=0, ATTN_DROP_RATE=0, DROP_PATH_RATE=0.2, USE_APE=False, PATCH_NORM=True),
+}
+
+
+def _merge(base, over):
+    out = dict(base)
+    for k, v in over.items():
+        out[k] = _merge(out[k], v) if isinstance(v, dict) and isinstance(out.get(k), dict) else v
+    return out
+
+
+def swin_config(name="swin_tiny_w7", **spec_overrides):
+    spec = dict(SWIN_SPECS[name])
+    spec.update(spec_overrides)
+    cfg = _merge(_DEFAULTS, dict(MODEL=dict(SPEC=spec)))
+    return CfgNode(cfg)
+
+
+def from_yaml(path, opts=None):
+    """read a reference experiment yaml (no BASE inheritance needed for swin yamls); opts = [KEY, VALUE, ...]"""
+    with open(path) as f:
+        cfg = _merge(_DEFAULTS, yaml.safe_load(f) or {})
+    for k, v in zip((opts or [])[0::2], (opts or [])[1::2]):
+        node = cfg
+        parts = k.split(".")
+        for p in parts[:-1]:
+            node = node.setdefault(p, {})
+        node[parts[-1]] = yaml.safe_load(v) if isinstance(v, str) else v
+    return CfgNode(cfg)

@@ -102,7 +102,27 @@ def shift_mask(H, W, ws, shift):
 # ------------------------------------------------------------------------------------------------
 # GEMM family
 # ------------------------------------------------------------------------------------------------
+# optional launch timing for bench.py's roofline leg: list of (flops, start_event, end_event) or None
+GEMM_PROFILE = None
+_EVENT_POOL = []
+
+
+def _event():
+    return _EVENT_POOL.pop() if _EVENT_POOL else torch.cuda.Event(enable_timing=True)
+
+
 def _gemm(dt, **kw):
+    if GEMM_PROFILE is not None:
+        e0, e1 = _event(), _event()
+        e0.record()
+        _gemm_launch(dt, **kw)
+        e1.record()
+        GEMM_PROFILE.append((2.0 * kw["M"] * kw["N"] * kw["K"] * kw.get("batch", 1), e0, e1))
+        return
+    _gemm_launch(dt, **kw)
+
+
+def _gemm_launch(dt, **kw):
     d = GemmDesc()
     for k in ("A", "B", "C", "bias", "residual", "rowmap", "rowscale", "aux", "partial"):
         setattr(d, k, _p(kw.get(k)))

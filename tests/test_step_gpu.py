@@ -1,0 +1,159 @@
+"""-m gpu: the whole EsViT step through the HIP path vs (a) the golden vectors generated from the reference
+(nano Swin, all 14 window geometries of 224/96 crops) and (b) the CPU oracle on real Swin-T widths."""
+import os
+
+import pytest
+import torch
+
+from oracle import esvit_oracle as O
+from tests import golden_utils as GU
+from tests.test_composition_cpu import build_nano, nano_pair, run_nano_step
+from tests.test_oracle_cpu import GOLD, probe_close
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def nano():
+    return torch.load(os.path.join(GOLD, "nano_step.pt"), weights_only=False)
+
+
+def _setup(prec):
+    import esvit_amd
+    assert torch.cuda.is_available()
+    esvit_amd.set_precision(prec)
+    return torch.device("cuda:0")
+
+
+def _to(crops, dev):
+    return [c.to(dev) for c in crops]
+
+
+def _teardown():
+    import esvit_amd
+    esvit_amd.set_precision("bf16")
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_nano_step_matches_reference_golden(nano, prec, lib_built):
+    import esvit_amd.loss as L
+    dev = _setup(prec)
+    try:
+        student, teacher = nano_pair()
+        student, teacher = student.to(dev), teacher.to(dev)
+        nano_dev = dict(nano)
+        nano_dev["center0"], nano_dev["center_grid0"] = nano["center0"].to(dev), nano["center_grid0"].to(dev)
+        crops = _to(GU.make_crops(2), dev)
+        s_out, t_out, loss, loss_fn = run_nano_step(nano_dev, student, teacher, L, crops, dev=dev)
+        fp = prec == "fp32"
+        rt = 3e-4 if fp else 3e-2
+        for nm, t in (("s_cls", s_out[0]), ("s_reg", s_out[1]), ("s_fea", s_out[2]), ("t_cls", t_out[0]), ("t_reg", t_out[1]),
+                      ("t_fea", t_out[2])):
+            probe_close(nm, t.float().cpu(), nano[nm], rtol=rt)
+        assert (list(s_out[3]), list(t_out[3])) == nano["npatch"]
+        # loss within 1e-3 of the reference (north_star); fp32 mode is far tighter
+        assert abs(loss.item() - nano["ddino_loss"]) < (1e-4 if fp else 1e-2), (loss.item(), nano["ddino_loss"])
+        tol_c = 1e-6 if fp else 2e-4
+        assert (loss_fn.center.cpu() - nano["center1"]).abs().max().item() < tol_c
+        assert (loss_fn.center_grid.cpu() - nano["center_grid1"]).abs().max().item() < tol_c
+        assert [n for n, p in student.named_parameters() if p.grad is None] == nano["no_grad"]
+        worst = 0.0
+        for n, p in student.named_parameters():
+            if p.grad is not None:
+                ref = nano["grad_norms"][n]
+                worst = max(worst, abs(p.grad.norm().item() - ref) / (ref + 1e-12))
+                if fp:
+                    probe_close("grad " + n, p.grad.cpu(), nano["grads"][n], rtol=2e-3)
+        assert worst < (2e-3 if fp else 0.15), worst
+        if fp:
+            with torch.no_grad():
+                probe_close("last_attn", student.forward_selfattention(crops[0]).cpu(), nano["last_attn"], rtol=3e-4)
+    finally:
+        _teardown()
+
+
+def test_nano_fused_update_matches_reference_golden(nano, lib_built):
+    """clip 3.0 -> AdamW -> EMA on the reference's own gradients (fp32 mode so that gradients agree to 1e-3)."""
+    import esvit_amd.loss as L
+    from esvit_amd.update import FusedClipAdamWEMA
+    dev = _setup("fp32")
+    try:
+        student, teacher = nano_pair()
+        student, teacher = student.to(dev), teacher.to(dev)
+        nano_dev = dict(nano)
+        nano_dev["center0"], nano_dev["center_grid0"] = nano["center0"].to(dev), nano["center_grid0"].to(dev)
+        run_nano_step(nano_dev, student, teacher, L, _to(GU.make_crops(2), dev), dev=dev)
+        upd = FusedClipAdamWEMA(student, teacher)
+        assert [len(g["params"]) for g in upd.param_groups] == nano["group_sizes"]
+        upd.step(5e-4, 0.04, 0.996, clip_grad=3.0)
+        torch.cuda.synchronize()
+        for n, p in student.named_parameters():
+            probe_close("student_after " + n, p.detach().cpu(), nano["student_after"][n], rtol=2e-4)
+        for n, p in teacher.named_parameters():
+            probe_close("teacher_after " + n, p.detach().cpu(), nano["teacher_after"][n], rtol=2e-4)
+    finally:
+        _teardown()
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_swin_tiny_step_matches_cpu_oracle(prec, lib_built):
+    """real Swin-T widths (96..768, heads 3..24), K = 8192, B = 2, 2x224 + 8x96 crops: loss, logits and gradient norms
+    against the CPU oracle with the same weights."""
+    import esvit_amd
+    from esvit_amd import config as CFG
+    dev = _setup(prec)
+    try:
+        torch.manual_seed(0)
+        K = 8192
+        cfg = CFG.swin_config("swin_tiny_w7", DROP_PATH_RATE=0.0)
+        student = esvit_amd.build_model(cfg, use_dense_prediction=True)
+        student.head = esvit_amd.DINOHead(student.num_features, K)
+        student.head_dense = esvit_amd.DINOHead(student.num_features, K, norm_last_layer=False)
+        teacher = esvit_amd.build_model(cfg, is_teacher=True, use_dense_prediction=True)
+        teacher.head = esvit_amd.DINOHead(teacher.num_features, K)
+        teacher.head_dense = esvit_amd.DINOHead(teacher.num_features, K)
+        GU.fill_state_dict(student.state_dict(), 3)
+        GU.fill_state_dict(teacher.state_dict(), 4)
+        student.head.last_layer.weight_g.data.fill_(1)
+        sd = {k: v.clone() for k, v in student.state_dict().items()}
+        tsd = {k: v.clone() for k, v in teacher.state_dict().items()}
+        crops = GU.make_crops(2, seed=99)
+        # oracle (CPU fp32)
+        names = [n for n, p in student.named_parameters() if p.requires_grad]
+        leaf = {n: sd[n].clone().requires_grad_(True) for n in names}
+        full = dict(sd)
+        full.update(leaf)
+        s_ref = O.swin_multicrop(full, crops, GU.SWIN_T)
+        with torch.no_grad():
+            t_ref = O.swin_multicrop(tsd, crops[:2], GU.SWIN_T)
+        temp = O.teacher_temp(0, 0.04, 0.04, 0, 1)
+        c0 = torch.zeros(1, K)
+        l_ref, _, _ = O.ddino_loss(s_ref, t_ref, c0, c0, temp, 10)
+        l_ref.backward()
+        # HIP path
+        student, teacher = student.to(dev), teacher.to(dev)
+        for p in teacher.parameters():
+            p.requires_grad = False
+        loss_fn = esvit_amd.DDINOLoss(K, 10, 0.04, 0.04, 0, 1).to(dev)
+        dcrops = _to(crops, dev)
+        t_out = teacher(dcrops[:2])
+        s_out = student(dcrops)
+        loss = loss_fn(s_out, t_out, 0, None)
+        loss.backward()
+        fp = prec == "fp32"
+
+        def rel(a, b):
+            return ((a.float().cpu() - b).abs().max() / (b.abs().max() + 1e-12)).item()
+
+        assert rel(s_out[2], s_ref[2]) < (1e-4 if fp else 5e-2), rel(s_out[2], s_ref[2])
+        assert rel(s_out[0], s_ref[0]) < (1e-4 if fp else 5e-2), rel(s_out[0], s_ref[0])
+        assert rel(s_out[1], s_ref[1]) < (1e-4 if fp else 5e-2), rel(s_out[1], s_ref[1])
+        assert abs(loss.item() - l_ref.item()) < (1e-4 if fp else 1e-2), (loss.item(), l_ref.item())
+        worst = 0.0
+        for n, p in student.named_parameters():
+            if p.requires_grad:
+                ref = leaf[n].grad.norm().item()
+                worst = max(worst, abs(p.grad.norm().item() - ref) / (ref + 1e-12))
+        assert worst < (5e-3 if fp else 0.2), worst
+    finally:
+        _teardown()
