@@ -53,7 +53,7 @@ def test_nano_step_matches_reference_golden(nano, prec, lib_built):
         assert (list(s_out[3]), list(t_out[3])) == nano["npatch"]
         # loss within 1e-3 of the reference (north_star); fp32 mode is far tighter
         assert abs(loss.item() - nano["ddino_loss"]) < (1e-4 if fp else 1e-2), (loss.item(), nano["ddino_loss"])
-        tol_c = 1e-6 if fp else 2e-4
+        tol_c = 1e-6 if fp else 1e-3
         assert (loss_fn.center.cpu() - nano["center1"]).abs().max().item() < tol_c
         assert (loss_fn.center_grid.cpu() - nano["center_grid1"]).abs().max().item() < tol_c
         assert [n for n, p in student.named_parameters() if p.grad is None] == nano["no_grad"]
