@@ -162,3 +162,6 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
 }
 
 static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
+
+// out[c] (+)= sum_b ws[b*ld + c], c < ncols  (elementwise.hip) -- second stage of every two-stage column reduction
+int esvit_partial_reduce(const float* ws, int nblk, int ncols, long ld, float* out, int accumulate, hipStream_t stream);

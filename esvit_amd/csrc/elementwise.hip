@@ -63,31 +63,62 @@ __global__ __launch_bounds__(256) void transpose_cast_kernel(const float* __rest
 }
 
 // ---- column sums (bias gradients, centre partials) ---------------------------------------------
-// grid (ceil(N/256), nblk): each thread owns one column and a strided row range; partials -> ws[blk][N]
-constexpr int COLSUM_ROWS_PER_BLOCK = 512;
+// stage 1: block = 32 column-vectors (8 columns each, one 16-byte load) x 8 row lanes over COLSUM_ROWS_PER_BLOCK rows
+constexpr int COLSUM_ROWS_PER_BLOCK = 256;
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, long rows, int N, long ld, float* __restrict__ ws) {
-    const int n = blockIdx.x * 256 + threadIdx.x;
-    if (n >= N) return;
+    constexpr int V = Vec16<T>::N;
+    __shared__ float sm[8][32 * V + 1];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int n0 = (blockIdx.x * 32 + tx) * V;
     const long r0 = (long)blockIdx.y * COLSUM_ROWS_PER_BLOCK;
     const long r1 = min(rows, r0 + COLSUM_ROWS_PER_BLOCK);
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    long r = r0;
-    for (; r + 4 <= r1; r += 4) {
-        s0 += to_f32(x[r * ld + n]);
-        s1 += to_f32(x[(r + 1) * ld + n]);
-        s2 += to_f32(x[(r + 2) * ld + n]);
-        s3 += to_f32(x[(r + 3) * ld + n]);
+    float acc[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) acc[e] = 0.f;
+    if (n0 < N) {
+        if (n0 + V <= N && (ld % V) == 0) {
+            for (long r = r0 + ty; r < r1; r += 8) {
+                const Vec16<T> v = ld16<T>(x + r * ld + n0);
+#pragma unroll
+                for (int e = 0; e < V; ++e) acc[e] += v.get(e);
+            }
+        } else {
+            for (long r = r0 + ty; r < r1; r += 8)
+                for (int e = 0; e < V && n0 + e < N; ++e) acc[e] += to_f32(x[r * ld + n0 + e]);
+        }
     }
-    for (; r < r1; ++r) s0 += to_f32(x[r * ld + n]);
-    ws[(long)blockIdx.y * N + n] = (s0 + s1) + (s2 + s3);
+#pragma unroll
+    for (int e = 0; e < V; ++e) sm[ty][tx * V + e] = acc[e];
+    __syncthreads();
+    for (int i = threadIdx.x; i < 32 * V; i += 256) {
+        const int n = blockIdx.x * 32 * V + i;
+        if (n < N) {
+            float s2 = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s2 += sm[k][i];
+            ws[(long)blockIdx.y * N + n] = s2;
+        }
+    }
 }
-__global__ void colsum_final_kernel(const float* __restrict__ ws, int nblk, int N, float* __restrict__ out, int accumulate) {
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= N) return;
+
+// stage 2 (shared): block = 32 columns x 8 row slices
+__global__ __launch_bounds__(256) void partial_reduce_kernel(const float* __restrict__ ws, int nblk, int ncols, long ld,
+                                                             float* __restrict__ out, int accumulate) {
+    __shared__ float sm[8][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + tx;
     float s = 0.f;
-    for (int b = 0; b < nblk; ++b) s += ws[(long)b * N + n];
-    out[n] = accumulate ? out[n] + s : s;
+    if (c < ncols)
+        for (int b = ty; b < nblk; b += 8) s += ws[(long)b * ld + c];
+    sm[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0 && c < ncols) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += sm[k][tx];
+        out[c] = accumulate ? out[c] + t : t;
+    }
 }
 
 // ---- PatchEmbed im2col -------------------------------------------------------------------------
@@ -253,23 +284,31 @@ extern "C" int esvit_transpose_cast(int dtype, const float* src, void* dst, int 
     return ESVIT_OK;
 }
 
+int esvit_partial_reduce(const float* ws, int nblk, int ncols, long ld, float* out, int accumulate, hipStream_t stream) {
+    hipLaunchKernelGGL(partial_reduce_kernel, dim3(ceil_div(ncols, 32)), dim3(256), 0, stream, ws, nblk, ncols, ld, out, accumulate);
+    ESVIT_CHECK_LAUNCH("partial_reduce");
+    return ESVIT_OK;
+}
+
 extern "C" int esvit_colsum_blocks(int64_t rows) { return ceil_div(rows, COLSUM_ROWS_PER_BLOCK); }
 
 extern "C" int esvit_colsum(int dtype, const void* x, int64_t rows, int N, int64_t ld, float* out, float* ws, int accumulate,
                             esvit_stream_t s_) {
     STREAM(s_);
     ESVIT_CHECK_ARG(x && out && ws && rows > 0 && N > 0 && ld >= N, "esvit_colsum: bad args");
+    ESVIT_CHECK_ARG(((uintptr_t)x % 16) == 0, "esvit_colsum: x must be 16-byte aligned");
     const int nblk = ceil_div(rows, COLSUM_ROWS_PER_BLOCK);
-    dim3 grid(ceil_div(N, 256), nblk);
-    if (dtype == ESVIT_BF16) hipLaunchKernelGGL(colsum_kernel<bf16>, grid, dim3(256), 0, stream, (const bf16*)x, (long)rows, N, (long)ld, ws);
-    else if (dtype == ESVIT_F32) hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, stream, (const float*)x, (long)rows, N, (long)ld, ws);
-    else {
+    if (dtype == ESVIT_BF16) {
+        dim3 grid(ceil_div(N, 32 * 8), nblk);
+        hipLaunchKernelGGL(colsum_kernel<bf16>, grid, dim3(256), 0, stream, (const bf16*)x, (long)rows, N, (long)ld, ws);
+    } else if (dtype == ESVIT_F32) {
+        dim3 grid(ceil_div(N, 32 * 4), nblk);
+        hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, stream, (const float*)x, (long)rows, N, (long)ld, ws);
+    } else {
         BAD_DTYPE("esvit_colsum");
     }
     ESVIT_CHECK_LAUNCH("colsum");
-    hipLaunchKernelGGL(colsum_final_kernel, dim3(ceil_div(N, 256)), dim3(256), 0, stream, ws, nblk, N, out, accumulate);
-    ESVIT_CHECK_LAUNCH("colsum(final)");
-    return ESVIT_OK;
+    return esvit_partial_reduce(ws, nblk, N, N, out, accumulate, stream);
 }
 
 extern "C" int esvit_patch_im2col(int dtype, const float* img, void* cols, int nB, int S, int P, int Kpad, esvit_stream_t s_) {

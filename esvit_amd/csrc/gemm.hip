@@ -173,77 +173,193 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const esvit_gemm_desc p)
     }
 
     // ---- epilogue ----
+    // Accumulator fragments hold a 4x1 column strip per lane (stride-16 columns), which would mean 2-byte
+    // scattered stores.  Each wave therefore stages 32 rows of its tile at a time through its own LDS region
+    // (the operand buffers are free by now) and re-reads them as row-contiguous groups of 8 columns, so every
+    // global access of the epilogue (bias, aux, residual, C) is a 16/32-byte vector.
+    constexpr int LDE = WTN + 4;             // floats per staged row
+    constexpr int CG = WTN / 8;              // 8-column groups per row
+    constexpr int ITEMS = 32 * CG / 64;      // groups per lane per pass
+    static_assert(FM % 2 == 0 && (32 * CG) % 64 == 0, "tile shape");
+    float* stage = reinterpret_cast<float*>(smem_raw) + wave * (32 * LDE);
     const float alpha = p.alpha;
-    if (p.splitk > 1) {
-        float* part = p.partial + (long)z * M * N;
+    const bool is_split = p.splitk > 1;
+    float* part = is_split ? p.partial + (long)z * M * N : nullptr;
+    char* Cb = reinterpret_cast<char*>(p.C);
+    const long c_batch = is_split ? 0 : (long)z * p.strideC;
+    T* auxp = reinterpret_cast<T*>(p.aux);
+    const bool c_vec = is_split ? (N % 4 == 0) : ((p.ldc % 8 == 0) && ((reinterpret_cast<uintptr_t>(p.C) & 15) == 0) &&
+                                                   ((c_batch % 8) == 0));
+    const bool aux_vec = auxp && (p.ldaux % 8 == 0) && ((reinterpret_cast<uintptr_t>(p.aux) & 15) == 0);
+    const bool res_vec = p.residual && (p.ldr % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.residual) & 15) == 0);
+    const bool bias_vec = p.bias && ((reinterpret_cast<uintptr_t>(p.bias) & 15) == 0);
 #pragma unroll
-        for (int i = 0; i < FM; ++i)
+    for (int ps = 0; ps < FM / 2; ++ps) {
+        __syncthreads();
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int m = m0 + wm * WTM + i * 16 + 4 * g + r;
-                if (m >= M) continue;
+        for (int il = 0; il < 2; ++il)
 #pragma unroll
-                for (int j = 0; j < FN; ++j) {
-                    const int n = n0 + wn * WTN + j * 16 + c;
-                    if (n < N) part[(long)m * N + n] = acc[i][j][r] * alpha;
+            for (int j = 0; j < FN; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) stage[(il * 16 + 4 * g + r) * LDE + j * 16 + c] = acc[2 * ps + il][j][r] * alpha;
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < ITEMS; ++t) {
+            const int id = lane + 64 * t;
+            const int row_l = id / CG, cg = id % CG;
+            const int m = m0 + wm * WTM + ps * 32 + row_l;
+            const int n = n0 + wn * WTN + cg * 8;
+            if (m >= M || n >= N) continue;
+            const int ne = min(8, N - n);
+            float v[8];
+            {
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(stage + row_l * LDE + cg * 8);
+                const f32x4 hi = *reinterpret_cast<const f32x4*>(stage + row_l * LDE + cg * 8 + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = lo[e];
+                    v[4 + e] = hi[e];
                 }
             }
-        return;
-    }
-    char* Cb = reinterpret_cast<char*>(p.C);
-    const long c_batch = (long)z * p.strideC;
-    const T* aux_in = reinterpret_cast<const T*>(p.aux);
-    T* aux_out = reinterpret_cast<T*>(p.aux);
-#pragma unroll
-    for (int i = 0; i < FM; ++i)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int m = m0 + wm * WTM + i * 16 + 4 * g + r;
-            if (m >= M) continue;
+            if (is_split) {
+                float* dst = part + (long)m * N + n;
+                if (ne == 8 && c_vec) {
+                    *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
+                    *reinterpret_cast<f32x4*>(dst + 4) = f32x4{v[4], v[5], v[6], v[7]};
+                } else {
+                    for (int e = 0; e < ne; ++e) dst[e] = v[e];
+                }
+                continue;
+            }
             long drow = m;
             if (p.rowmap) {
-                const int t = p.rowmap[m % p.rowmap_period];
-                if (t < 0) continue;
-                drow = (long)(m / p.rowmap_period) * p.rowmap_tokens + t;
+                const int tk = p.rowmap[m % p.rowmap_period];
+                if (tk < 0) continue;
+                drow = (long)(m / p.rowmap_period) * p.rowmap_tokens + tk;
             }
             const float rs = p.rowscale ? p.rowscale[drow / p.rows_per_sample] : 1.f;
+            if (p.bias) {
+                if (ne == 8 && bias_vec) {
+                    const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + n);
+                    const f32x4 b1 = *reinterpret_cast<const f32x4*>(p.bias + n + 4);
 #pragma unroll
-            for (int j = 0; j < FN; ++j) {
-                const int n = n0 + wn * WTN + j * 16 + c;
-                if (n >= N) continue;
-                float v = acc[i][j][r] * alpha;
-                if (p.bias) v += p.bias[n];
-                if (p.epilogue == ESVIT_EPI_GELU) {
-                    if (aux_out) aux_out[(long)m * p.ldaux + n] = from_f32<T>(v);
-                    v = gelu_f(v);
-                } else if (p.epilogue == ESVIT_EPI_GELU_BWD) {
-                    v *= gelu_grad_f(to_f32(aux_in[(long)m * p.ldaux + n]));
+                    for (int e = 0; e < 4; ++e) {
+                        v[e] += b0[e];
+                        v[4 + e] += b1[e];
+                    }
+                } else {
+                    for (int e = 0; e < ne; ++e) v[e] += p.bias[n + e];
                 }
-                v *= rs;
-                if (p.residual) v += p.residual[drow * p.ldr + n];
-                const long o = c_batch + drow * p.ldc + n;
-                if (p.out_f32) reinterpret_cast<float*>(Cb)[o] = v;
-                else reinterpret_cast<T*>(Cb)[o] = from_f32<T>(v);
+            }
+            if (p.epilogue == ESVIT_EPI_GELU) {
+                if (auxp) {
+                    T* ap = auxp + (long)m * p.ldaux + n;
+                    if (ne == 8 && aux_vec) {
+                        if constexpr (sizeof(T) == 2) {
+                            bf16x8 o;
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
+                            *reinterpret_cast<bf16x8*>(ap) = o;
+                        } else {
+                            *reinterpret_cast<f32x4*>(ap) = f32x4{v[0], v[1], v[2], v[3]};
+                            *reinterpret_cast<f32x4*>(ap + 4) = f32x4{v[4], v[5], v[6], v[7]};
+                        }
+                    } else {
+                        for (int e = 0; e < ne; ++e) ap[e] = from_f32<T>(v[e]);
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
+            } else if (p.epilogue == ESVIT_EPI_GELU_BWD) {
+                const T* ap = auxp + (long)m * p.ldaux + n;
+                float a[8];
+                if (ne == 8 && aux_vec) {
+                    if constexpr (sizeof(T) == 2) {
+                        const bf16x8 x = *reinterpret_cast<const bf16x8*>(ap);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) a[e] = (float)x[e];
+                    } else {
+                        const f32x4 x0 = *reinterpret_cast<const f32x4*>(ap), x1 = *reinterpret_cast<const f32x4*>(ap + 4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            a[e] = x0[e];
+                            a[4 + e] = x1[e];
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) a[e] = e < ne ? to_f32(ap[e]) : 0.f;
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] *= gelu_grad_f(a[e]);
+            }
+            if (p.rowscale) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] *= rs;
+            }
+            if (p.residual) {
+                const float* rp = p.residual + drow * p.ldr + n;
+                if (ne == 8 && res_vec) {
+                    const f32x4 r0 = *reinterpret_cast<const f32x4*>(rp), r1 = *reinterpret_cast<const f32x4*>(rp + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[e] += r0[e];
+                        v[4 + e] += r1[e];
+                    }
+                } else {
+                    for (int e = 0; e < ne; ++e) v[e] += rp[e];
+                }
+            }
+            const long o = c_batch + drow * p.ldc + n;
+            if (p.out_f32) {
+                float* cp = reinterpret_cast<float*>(Cb) + o;
+                if (ne == 8 && c_vec) {
+                    *reinterpret_cast<f32x4*>(cp) = f32x4{v[0], v[1], v[2], v[3]};
+                    *reinterpret_cast<f32x4*>(cp + 4) = f32x4{v[4], v[5], v[6], v[7]};
+                } else {
+                    for (int e = 0; e < ne; ++e) cp[e] = v[e];
+                }
+            } else {
+                T* cp = reinterpret_cast<T*>(Cb) + o;
+                if (ne == 8 && c_vec) {
+                    if constexpr (sizeof(T) == 2) {
+                        bf16x8 ov;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) ov[e] = (bf16)v[e];
+                        *reinterpret_cast<bf16x8*>(cp) = ov;
+                    } else {
+                        *reinterpret_cast<f32x4*>(cp) = f32x4{v[0], v[1], v[2], v[3]};
+                        *reinterpret_cast<f32x4*>(cp + 4) = f32x4{v[4], v[5], v[6], v[7]};
+                    }
+                } else {
+                    for (int e = 0; e < ne; ++e) cp[e] = from_f32<T>(v[e]);
+                }
             }
         }
+    }
 }
 
-// sum split-K partials: out[i] (+)= sum_z part[z*n + i]
-__global__ void splitk_reduce_kernel(const float* __restrict__ part, int splits, long n, float* __restrict__ out,
-                                     int accumulate) {
+// sum split-K partials: out[i] (+)= sum_z part[z*n + i]   (TO = float or the activation dtype)
+template <typename TO>
+__global__ void splitk_reduce_kernel(const float* __restrict__ part, int splits, long n, TO* __restrict__ out, int accumulate) {
     const long i4 = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (i4 >= n) return;
-    if (i4 + 4 <= n) {
-        f32x4 s = {0.f, 0.f, 0.f, 0.f};
-        for (int z = 0; z < splits; ++z) s += *reinterpret_cast<const f32x4*>(part + (long)z * n + i4);
-        if (accumulate) s += *reinterpret_cast<const f32x4*>(out + i4);
-        *reinterpret_cast<f32x4*>(out + i4) = s;
-    } else {
-        for (long i = i4; i < n; ++i) {
-            float s = 0.f;
-            for (int z = 0; z < splits; ++z) s += part[(long)z * n + i];
-            out[i] = accumulate ? out[i] + s : s;
+    const int cnt = (int)min(4L, n - i4);
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    if (cnt == 4) {
+        for (int z = 0; z < splits; ++z) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(part + (long)z * n + i4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s[e] += v[e];
         }
+    } else {
+        for (int z = 0; z < splits; ++z)
+            for (int e = 0; e < cnt; ++e) s[e] += part[(long)z * n + i4 + e];
+    }
+    for (int e = 0; e < cnt; ++e) {
+        float v = s[e];
+        if (accumulate) v += to_f32(out[i4 + e]);
+        out[i4 + e] = from_f32<TO>(v);
     }
 }
 
@@ -251,7 +367,9 @@ template <typename T, bool AKS, bool BKS, int BM, int BN, bool USE_TR>
 int launch_gemm(const esvit_gemm_desc& d, hipStream_t stream) {
     using TA = Tile<T, AKS, BM, USE_TR>;
     using TB = Tile<T, BKS, BN, USE_TR>;
-    const size_t lds = 2 * (size_t)(TA::ELEMS + TB::ELEMS) * sizeof(T);
+    size_t lds = 2 * (size_t)(TA::ELEMS + TB::ELEMS) * sizeof(T);
+    const size_t stage_bytes = 4 * 32 * (size_t)(BN / 2 + 4) * sizeof(float);
+    if (lds < stage_bytes) lds = stage_bytes;
     auto kern = gemm_kernel<T, AKS, BKS, BM, BN, USE_TR>;
     static bool attr_done = false;  // one-time raise of the dynamic LDS cap (per instantiation)
     if (!attr_done) {
@@ -266,8 +384,12 @@ int launch_gemm(const esvit_gemm_desc& d, hipStream_t stream) {
     if (d.splitk > 1) {
         const long n = (long)d.M * d.N;
         const int blocks = ceil_div(ceil_div(n, 4), 256);
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, d.partial, d.splitk, n,
-                           reinterpret_cast<float*>(d.C), d.accumulate);
+        if (d.out_f32)
+            hipLaunchKernelGGL(splitk_reduce_kernel<float>, dim3(blocks), dim3(256), 0, stream, d.partial, d.splitk, n,
+                               reinterpret_cast<float*>(d.C), d.accumulate);
+        else
+            hipLaunchKernelGGL(splitk_reduce_kernel<T>, dim3(blocks), dim3(256), 0, stream, d.partial, d.splitk, n,
+                               reinterpret_cast<T*>(d.C), d.accumulate);
         ESVIT_CHECK_LAUNCH("esvit_gemm(splitk_reduce)");
     }
     return ESVIT_OK;
@@ -311,7 +433,7 @@ extern "C" int esvit_gemm(int dtype, const esvit_gemm_desc* dp, esvit_stream_t s
     ESVIT_CHECK_ARG(((uintptr_t)d.A % 16 == 0) && ((uintptr_t)d.B % 16 == 0), "esvit_gemm: operands must be 16-byte aligned");
     if (d.batch < 1) d.batch = 1;
     if (d.splitk > 1) {
-        ESVIT_CHECK_ARG(d.batch == 1 && d.out_f32 && d.partial, "esvit_gemm: split-K needs batch=1, fp32 out and a workspace");
+        ESVIT_CHECK_ARG(d.batch == 1 && d.partial && d.ldc == d.N, "esvit_gemm: split-K needs batch=1, a workspace and a dense C");
         ESVIT_CHECK_ARG(!d.bias && !d.residual && !d.rowmap && d.epilogue == 0, "esvit_gemm: split-K has no fused epilogue");
     } else {
         d.splitk = 1;

@@ -184,17 +184,6 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(RowSrc src, const T*
     }
 }
 
-// out[0:C] = sum_blk ws[blk][0][:], out2[0:C] = sum_blk ws[blk][1][:]
-__global__ void ln_param_reduce_kernel(const float* __restrict__ ws, int nblk, int C, float* __restrict__ dgamma,
-                                       float* __restrict__ dbeta) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= 2 * C) return;
-    float s = 0.f;
-    for (int b = 0; b < nblk; ++b) s += ws[(long)b * 2 * C + i];
-    if (i < C) dgamma[i] = s;
-    else dbeta[i - C] = s;
-}
-
 struct LnCfg {
     int G, ITERS;
 };
@@ -276,10 +265,12 @@ int ln_bwd_launch(RowSrc src, const void* dy, const float* mean, const float* rs
                            rstd, gamma, g_in, rows, dx, ws, rowmap, tokens, period_in);
     });
     ESVIT_CHECK_LAUNCH("layernorm_bwd");
-    hipLaunchKernelGGL(ln_param_reduce_kernel, dim3(ceil_div(2 * src.C, 256)), dim3(256), 0, stream, ws, nblk, src.C,
-                       dgamma, dbeta);
-    ESVIT_CHECK_LAUNCH("layernorm_bwd(param reduce)");
-    return ESVIT_OK;
+    // ws rows are [dgamma(C) | dbeta(C)]; reduce both halves (dgamma and dbeta may be separate allocations)
+    const int C = src.C;
+    if (dbeta == dgamma + C) return esvit_partial_reduce(ws, nblk, 2 * C, 2L * C, dgamma, 0, stream);
+    int rc = esvit_partial_reduce(ws, nblk, C, 2L * C, dgamma, 0, stream);
+    if (rc != ESVIT_OK) return rc;
+    return esvit_partial_reduce(ws + C, nblk, C, 2L * C, dbeta, 0, stream);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -421,7 +421,7 @@ __global__ void dense_to_frag_kernel(const float* __restrict__ dense, int nM, in
     frag[i] = (q < N && key < N) ? dense[((long)w * N + q) * N + key] : 0.f;
 }
 
-// dtable[index[q,key]][h] += sum_parts ws[part][h][frag(q,key)]
+// dtable[index[q,key]][h] += total[h][frag(q,key)]   (total = partials already summed)
 __global__ void relpos_bias_bwd_kernel(const float* __restrict__ ws, int parts, const long* __restrict__ index, int N, int nH,
                                        float* __restrict__ dtable) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -478,7 +478,12 @@ extern "C" int esvit_relpos_bias_bwd(const float* dbias_ws, int parts, const int
         esvit_set_error("esvit_relpos_bias_bwd: memset failed: %s", hipGetErrorString(e));
         return ESVIT_ERR_HIP;
     }
-    hipLaunchKernelGGL(relpos_bias_bwd_kernel, dim3(ceil_div((long)nH * N * N, 256)), dim3(256), 0, stream, dbias_ws, parts,
+    // sum the per-wave partial slabs in place into slab 0 (out may alias row 0: each column is read then written by one thread)
+    if (parts > 1) {
+        int rc = esvit_partial_reduce(dbias_ws, parts, nH * FRAG_ELEMS, (long)nH * FRAG_ELEMS, const_cast<float*>(dbias_ws), 0, stream);
+        if (rc != ESVIT_OK) return rc;
+    }
+    hipLaunchKernelGGL(relpos_bias_bwd_kernel, dim3(ceil_div((long)nH * N * N, 256)), dim3(256), 0, stream, dbias_ws, 1,
                        (const long*)index, N, nH, dtable);
     ESVIT_CHECK_LAUNCH("relpos_bias_bwd");
     return ESVIT_OK;

@@ -162,6 +162,14 @@ def linear_dgrad(dy, w, *, gelu_preact=None, out_f32=False):
     Kin = w.shape[1]
     assert w.shape[0] == Nout and dy.dtype == w.dtype
     dx = torch.empty((M, Kin), dtype=torch.float32 if out_f32 else dy.dtype, device=dy.device)
+    tiles = (-(-M // 128)) * (-(-Kin // 128))
+    if gelu_preact is None and tiles < 192 and Nout >= 4096:
+        # few output tiles but a very long reduction (DINOHead last layer: K = out_dim): split-K to fill the chip
+        splitk = int(min(16, max(2, 512 // tiles)))
+        part = workspace(splitk * M * Kin, dy.device)
+        _gemm(dy.dtype, A=dy, B=w, C=dx, M=M, N=Kin, K=Nout, lda=Nout, ldb=Kin, ldc=Kin, b_kstrided=1, out_f32=out_f32,
+              splitk=splitk, partial=part)
+        return dx
     _gemm(dy.dtype, A=dy, B=w, C=dx, M=M, N=Kin, K=Nout, lda=Nout, ldb=Kin, ldc=Kin, b_kstrided=1, aux=gelu_preact,
           ldaux=Kin, epilogue=EPI_GELU_BWD if gelu_preact is not None else EPI_NONE, out_f32=out_f32)
     return dx
@@ -248,8 +256,8 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, *, g_in=None, rowmap=None, period_in
     Cc = x.shape[-1]
     rows = x.numel() // Cc
     dx = torch.empty_like(x)
-    dgamma = torch.empty((Cc,), dtype=torch.float32, device=x.device)
-    dbeta = torch.empty_like(dgamma)
+    gb = torch.empty((2, Cc), dtype=torch.float32, device=x.device)
+    dgamma, dbeta = gb[0], gb[1]
     ws = workspace(lib.esvit_layernorm_bwd_blocks(rows, Cc) * 2 * Cc, x.device, slot=1)
     check(lib.esvit_layernorm_bwd(_code(dy.dtype), _p(dy), _p(x), _p(mean), _p(rstd), _p(gamma), _p(g_in), rows, Cc, _p(dx),
                                   _p(dgamma), _p(dbeta), _p(ws), _p(rowmap), 0 if rowmap is None else rowmap.numel(),
@@ -276,8 +284,8 @@ def merge_ln_bwd(dy, x, mean, rstd, gamma, H, W):
     x, dy = _f32c(x), _actc(dy)
     nB, L, Cc = x.shape
     dx = torch.empty_like(x)
-    dgamma = torch.empty((4 * Cc,), dtype=torch.float32, device=x.device)
-    dbeta = torch.empty_like(dgamma)
+    gb = torch.empty((2, 4 * Cc), dtype=torch.float32, device=x.device)
+    dgamma, dbeta = gb[0], gb[1]
     rows = nB * (H // 2) * (W // 2)
     ws = workspace(lib.esvit_layernorm_bwd_blocks(rows, 4 * Cc) * 8 * Cc, x.device, slot=1)
     check(lib.esvit_merge_ln_bwd(_code(dy.dtype), _p(dy), _p(x), _p(mean), _p(rstd), _p(gamma), nB, H, W, Cc, _p(dx), _p(dgamma),
