@@ -100,6 +100,7 @@ def main():
     ap.add_argument("--drop-path", type=float, default=0.1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--gemm-table", default=None, help="write a per-shape GEMM time table to this file")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -161,8 +162,19 @@ def main():
                "final_loss": loss_v,
                "step_mfma_frac": ips / world * GFLOP_PER_IMG / 1e3 / BF16_PEAK_TFLOPS}
         if prof:
-            tot_fl = sum(f for f, _, _ in prof)
-            tot_ms = sum(a.elapsed_time(b) for _, a, b in prof)
+            tot_fl = sum(f for f, _, _, _ in prof)
+            tot_ms = sum(a.elapsed_time(b) for _, a, b, _ in prof)
+            if args.gemm_table:
+                agg = {}
+                for f, a, b, key in prof:
+                    e = agg.setdefault(key, [0, 0.0, 0.0])
+                    e[0] += 1
+                    e[1] += a.elapsed_time(b)
+                    e[2] += f
+                with open(args.gemm_table, "w") as fh:
+                    for key, (n, ms, fl) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+                        fh.write("M=%7d N=%6d K=%7d aks=%d bks=%d splitk=%3d calls/step %5.1f ms/step %7.3f TF %7.1f\n" % (
+                            key + (n / args.steps, ms / args.steps, fl / ms / 1e9)))
             ach = tot_fl / (tot_ms * 1e-3) / 1e12
             out["roofline"] = {"bound": "mfma", "kernel": "gemm_kernel<bf16,...> (all fwd/dgrad/wgrad GEMM launches of the step)",
                                "achieved": ach, "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / BF16_PEAK_TFLOPS,

@@ -117,7 +117,8 @@ def _gemm(dt, **kw):
         e0.record()
         _gemm_launch(dt, **kw)
         e1.record()
-        GEMM_PROFILE.append((2.0 * kw["M"] * kw["N"] * kw["K"] * kw.get("batch", 1), e0, e1))
+        GEMM_PROFILE.append((2.0 * kw["M"] * kw["N"] * kw["K"] * kw.get("batch", 1), e0, e1,
+                             (kw["M"], kw["N"], kw["K"], kw.get("a_kstrided", 0), kw.get("b_kstrided", 0), kw.get("splitk", 0))))
         return
     _gemm_launch(dt, **kw)
 
