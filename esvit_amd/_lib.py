@@ -77,20 +77,33 @@ SIGNATURES = {
     "esvit_fused_clip_adamw_ema": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, f32, f32, f32, f32, f32, f32, f32, vp]),
     "esvit_debug_set_tr_read": (None, [C.c_int]),
     "esvit_debug_set_attn_tr_read": (None, [C.c_int]),
+    "esvit_debug_set_gemm_dma": (None, [C.c_int]),
 }
 
 
-def _load():
-    if not os.path.exists(LIB_PATH):
-        raise ImportError(
-            "esvit_amd: %s not found -- build it with `python -m esvit_amd.build` "
-            "(there is no fallback path)" % LIB_PATH)
+def _open():
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
     return lib
+
+
+def _load():
+    """Load the library; if it is missing or older than this binding (a symbol of include/esvit_hip.h is absent),
+    (re)build it in-tree with hipcc once.  There is no non-HIP fallback: failure to build or load raises."""
+    try:
+        if os.path.exists(LIB_PATH):
+            return _open()
+    except (AttributeError, OSError):
+        pass
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_esvit_amd_build", os.path.join(_HERE, "build.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    mod.build(force=False, verbose=False)
+    return _open()
 
 
 lib = _load()

@@ -88,91 +88,16 @@ struct Tile {
     }
 };
 
-template <typename T, bool AKS, bool BKS, int BM, int BN, bool USE_TR>
-__global__ __launch_bounds__(NTHREADS) void gemm_kernel(const esvit_gemm_desc p) {
-    using TA = Tile<T, AKS, BM, USE_TR>;
-    using TB = Tile<T, BKS, BN, USE_TR>;
-    constexpr int WTM = BM / 2, WTN = BN / 2;  // wave tile
+// ---- epilogue (shared by both main-loop variants) ----
+template <typename T, int BM, int BN>
+__device__ __forceinline__ void gemm_epilogue(const esvit_gemm_desc& p, f32x4 (&acc)[BM / 32][BN / 32], char* smem_raw, int m0, int n0,
+                                              int z) {
+    constexpr int WTM = BM / 2, WTN = BN / 2;
     constexpr int FM = WTM / 16, FN = WTN / 16;
-
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    T* smem = reinterpret_cast<T*>(smem_raw);
-    T* sA = smem;                   // 2 buffers
-    T* sB = smem + 2 * TA::ELEMS;   // 2 buffers
-
-    const int M = p.M, N = p.N, K = p.K;
-    const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
-    // XCD-aware tile order: block b runs on XCD b%8; give every XCD a contiguous range of
-    // tile ids so the tiles that share an A panel hit the same L2 (bijective remap).
-    const int ntiles = tiles_m * tiles_n;
-    int pid = blockIdx.x;
-    {
-        const int q = ntiles / 8, r = ntiles % 8;
-        const int xcd = pid % 8, idx = pid / 8;
-        pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    const int tm = pid / tiles_n, tn = pid % tiles_n;
-    const int m0 = tm * BM, n0 = tn * BN;
-    const int z = blockIdx.y;
-
-    const T* A = reinterpret_cast<const T*>(p.A);
-    const T* B = reinterpret_cast<const T*>(p.B);
-    int kbeg = 0, kend = K;
-    if (p.splitk > 1) {
-        const int nkt = (K + BK - 1) / BK;
-        const int per = (nkt + p.splitk - 1) / p.splitk;
-        kbeg = z * per * BK;
-        kend = min(K, (z + 1) * per * BK);
-    } else {
-        A += (long)z * p.strideA;
-        B += (long)z * p.strideB;
-    }
-
+    const int M = p.M, N = p.N;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane & 15, g = lane >> 4;
     const int wm = wave >> 1, wn = wave & 1;
-
-    f32x4 acc[FM][FN];
-#pragma unroll
-    for (int i = 0; i < FM; ++i)
-#pragma unroll
-        for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    TA ta;
-    TB tb;
-    const int nk = (kend > kbeg) ? (kend - kbeg + BK - 1) / BK : 0;
-    if (nk > 0) {
-        ta.load(A, p.lda, m0, kbeg, M, kend);
-        tb.load(B, p.ldb, n0, kbeg, N, kend);
-        ta.store(sA);
-        tb.store(sB);
-    }
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) {
-            ta.load(A, p.lda, m0, kbeg + (kt + 1) * BK, M, kend);
-            tb.load(B, p.ldb, n0, kbeg + (kt + 1) * BK, N, kend);
-        }
-        const T* a_lds = sA + cur * TA::ELEMS;
-        const T* b_lds = sB + cur * TB::ELEMS;
-        Frag<T> af[FM], bfr[FN];
-#pragma unroll
-        for (int i = 0; i < FM; ++i) af[i] = TA::frag(a_lds, wm * WTM + i * 16, c, g);
-#pragma unroll
-        for (int j = 0; j < FN; ++j) bfr[j] = TB::frag(b_lds, wn * WTN + j * 16, c, g);
-#pragma unroll
-        for (int i = 0; i < FM; ++i)
-#pragma unroll
-            for (int j = 0; j < FN; ++j) mma(af[i], bfr[j], acc[i][j]);
-        if (kt + 1 < nk) {
-            ta.store(sA + (cur ^ 1) * TA::ELEMS);
-            tb.store(sB + (cur ^ 1) * TB::ELEMS);
-        }
-        __syncthreads();
-    }
-
-    // ---- epilogue ----
     // Accumulator fragments hold a 4x1 column strip per lane (stride-16 columns), which would mean 2-byte
     // scattered stores.  Each wave therefore stages 32 rows of its tile at a time through its own LDS region
     // (the operand buffers are free by now) and re-reads them as row-contiguous groups of 8 columns, so every
@@ -339,6 +264,259 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const esvit_gemm_desc p)
     }
 }
 
+template <typename T, bool AKS, bool BKS, int BM, int BN, bool USE_TR>
+__global__ __launch_bounds__(NTHREADS) void gemm_kernel(const esvit_gemm_desc p) {
+    using TA = Tile<T, AKS, BM, USE_TR>;
+    using TB = Tile<T, BKS, BN, USE_TR>;
+    constexpr int WTM = BM / 2, WTN = BN / 2;  // wave tile
+    constexpr int FM = WTM / 16, FN = WTN / 16;
+
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    T* smem = reinterpret_cast<T*>(smem_raw);
+    T* sA = smem;                   // 2 buffers
+    T* sB = smem + 2 * TA::ELEMS;   // 2 buffers
+
+    const int M = p.M, N = p.N, K = p.K;
+    const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+    // XCD-aware tile order: block b runs on XCD b%8; give every XCD a contiguous range of
+    // tile ids so the tiles that share an A panel hit the same L2 (bijective remap).
+    const int ntiles = tiles_m * tiles_n;
+    int pid = blockIdx.x;
+    {
+        const int q = ntiles / 8, r = ntiles % 8;
+        const int xcd = pid % 8, idx = pid / 8;
+        pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tm = pid / tiles_n, tn = pid % tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int z = blockIdx.y;
+
+    const T* A = reinterpret_cast<const T*>(p.A);
+    const T* B = reinterpret_cast<const T*>(p.B);
+    int kbeg = 0, kend = K;
+    if (p.splitk > 1) {
+        const int nkt = (K + BK - 1) / BK;
+        const int per = (nkt + p.splitk - 1) / p.splitk;
+        kbeg = z * per * BK;
+        kend = min(K, (z + 1) * per * BK);
+    } else {
+        A += (long)z * p.strideA;
+        B += (long)z * p.strideB;
+    }
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 15, g = lane >> 4;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    f32x4 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    TA ta;
+    TB tb;
+    const int nk = (kend > kbeg) ? (kend - kbeg + BK - 1) / BK : 0;
+    if (nk > 0) {
+        ta.load(A, p.lda, m0, kbeg, M, kend);
+        tb.load(B, p.ldb, n0, kbeg, N, kend);
+        ta.store(sA);
+        tb.store(sB);
+    }
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) {
+            ta.load(A, p.lda, m0, kbeg + (kt + 1) * BK, M, kend);
+            tb.load(B, p.ldb, n0, kbeg + (kt + 1) * BK, N, kend);
+        }
+        const T* a_lds = sA + cur * TA::ELEMS;
+        const T* b_lds = sB + cur * TB::ELEMS;
+        Frag<T> af[FM], bfr[FN];
+#pragma unroll
+        for (int i = 0; i < FM; ++i) af[i] = TA::frag(a_lds, wm * WTM + i * 16, c, g);
+#pragma unroll
+        for (int j = 0; j < FN; ++j) bfr[j] = TB::frag(b_lds, wn * WTN + j * 16, c, g);
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j) mma(af[i], bfr[j], acc[i][j]);
+        if (kt + 1 < nk) {
+            ta.store(sA + (cur ^ 1) * TA::ELEMS);
+            tb.store(sB + (cur ^ 1) * TB::ELEMS);
+        }
+        __syncthreads();
+    }
+
+    gemm_epilogue<T, BM, BN>(p, acc, smem_raw, m0, n0, z);
+}
+
+// =================================================================================================
+// bf16 fast path: operands travel HBM -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds), BK = 64.
+// No staging registers, no ds_write pass; the LDS image is lane-linear (1 KiB per wave instruction), so
+// bank conflicts are removed by an XOR swizzle applied to the per-lane SOURCE address and to the
+// fragment read address (guide rule 21).  k-contiguous tiles: [ROWS][64] with chunk ^= row & 7
+// (conflict-free ds_read_b128); k-strided tiles: [64][ROWS] with a per-k chunk XOR that spreads the
+// 8 k-rows touched by one ds_read_b64_tr_b16 over distinct banks.  Two LDS buffers; the barrier at the
+// end of a k-tile drains the DMA of the next one while this tile's 32 MFMAs per wave run.
+// =================================================================================================
+constexpr int BKD = 64;
+
+template <bool KS, int ROWS>
+struct DmaTile {
+    static constexpr int ELEMS = ROWS * BKD;
+    static constexpr int CHUNKS = ELEMS / 8;
+    static constexpr int INSTR_PER_WAVE = CHUNKS / 256;
+    static constexpr int CPR = KS ? ROWS / 8 : BKD / 8;  // 16-byte chunks per LDS row
+    static_assert(CHUNKS % 256 == 0, "tile must be a whole number of wave instructions");
+
+    __device__ __forceinline__ static int sw_ks(int k) {
+        if constexpr (ROWS == 128) return ((k & 3) << 1) | (((k >> 3) & 1) << 3);
+        else if constexpr (ROWS == 64) return (((k >> 1) & 1) << 1) | (((k >> 3) & 1) << 2);
+        else return ((k >> 3) & 1) << 1;
+    }
+
+    // base: operand pointer already advanced to the tile's first row (k-contiguous) / column (k-strided)
+    __device__ __forceinline__ static void issue(__amdgpu_buffer_rsrc_t rsrc, char* lds_tile, long ld, int rows_left, int k0, int K,
+                                                 int wave, int lane) {
+        typedef __attribute__((address_space(3))) void lds_void;
+#pragma unroll
+        for (int i = 0; i < INSTR_PER_WAVE; ++i) {
+            const int slot = wave * INSTR_PER_WAVE + i;
+            const int p = slot * 64 + lane;
+            long off;
+            bool ok;
+            if constexpr (KS) {
+                const int kr = p / CPR, cp = p % CPR;
+                const int col = (cp ^ sw_ks(kr)) * 8;
+                ok = (k0 + kr < K) && (col < rows_left);
+                off = (long)(k0 + kr) * ld + col;
+            } else {
+                const int r = p / CPR, cp = p % CPR;
+                const int k = k0 + ((cp ^ (r & 7)) * 8);
+                ok = (r < rows_left) && (k < K);
+                off = (long)r * ld + k;
+            }
+            const int voff = ok ? (int)(off * 2) : (int)0xfffffff8u;  // beyond num_records -> hardware returns 0
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void*)(lds_tile + slot * 1024), 16, voff, 0, 0, 0);
+        }
+    }
+
+    // fragment for the 16 tile rows at r0, k-step kk (32 deep)
+    __device__ __forceinline__ static Frag<bf16> frag(const bf16* lds, int r0, int kk, int c, int g) {
+        Frag<bf16> f;
+        if constexpr (!KS) {
+            const int row = r0 + c;
+            const int pos = row * CPR + ((kk * 4 + g) ^ (row & 7));
+            f.v = *reinterpret_cast<const bf16x8*>(lds + pos * 8);
+        } else {
+            typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+            const int k_lo = kk * 32 + 8 * g + (c >> 2);
+            const int chunk = (r0 >> 3) + ((c & 3) >> 1);
+            const bf16* p0 = lds + (k_lo * CPR + (chunk ^ sw_ks(k_lo))) * 8 + (c & 1) * 4;
+            const int k_hi = k_lo + 4;
+            const bf16* p1 = lds + (k_hi * CPR + (chunk ^ sw_ks(k_hi))) * 8 + (c & 1) * 4;
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p0));
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p1));
+            const s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            f.v = __builtin_bit_cast(bf16x8, both);
+        }
+        return f;
+    }
+};
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, long bytes_left) {
+    const long capped = bytes_left > 0xfffffff0L ? 0xfffffff0L : (bytes_left < 0 ? 0 : bytes_left);
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)capped, 0x00020000);
+}
+
+template <bool AKS, bool BKS, int BM, int BN>
+__global__ __launch_bounds__(NTHREADS) void gemm_dma_kernel(const esvit_gemm_desc p) {
+    using TA = DmaTile<AKS, BM>;
+    using TB = DmaTile<BKS, BN>;
+    constexpr int WTM = BM / 2, WTN = BN / 2;
+    constexpr int FM = WTM / 16, FN = WTN / 16;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    constexpr int A_BYTES = TA::ELEMS * 2, B_BYTES = TB::ELEMS * 2;
+    char* sA = smem_raw;                // 2 buffers
+    char* sB = smem_raw + 2 * A_BYTES;  // 2 buffers
+
+    const int M = p.M, N = p.N, K = p.K;
+    const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+    const int ntiles = tiles_m * tiles_n;
+    int pid = blockIdx.x;
+    {
+        const int q = ntiles / 8, r = ntiles % 8;
+        const int xcd = pid % 8, idx = pid / 8;
+        pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tm = pid / tiles_n, tn = pid % tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int z = blockIdx.y;
+    const bf16* A = reinterpret_cast<const bf16*>(p.A);
+    const bf16* B = reinterpret_cast<const bf16*>(p.B);
+    int kbeg = 0, kend = K;
+    if (p.splitk > 1) {
+        const int nkt = (K + BKD - 1) / BKD;
+        const int per = (nkt + p.splitk - 1) / p.splitk;
+        kbeg = z * per * BKD;
+        kend = min(K, (z + 1) * per * BKD);
+    } else {
+        A += (long)z * p.strideA;
+        B += (long)z * p.strideB;
+    }
+    // per-block descriptors: base at the tile's first row / column, so every byte offset fits 32 bits
+    const long a_rows_total = AKS ? (long)K : (long)M;  // rows of the stored matrix
+    const long b_rows_total = BKS ? (long)K : (long)N;
+    const bf16* a_base = AKS ? A + m0 : A + (long)m0 * p.lda;
+    const bf16* b_base = BKS ? B + n0 : B + (long)n0 * p.ldb;
+    const long a_left = ((AKS ? a_rows_total : a_rows_total - m0) * p.lda - (AKS ? m0 : 0)) * 2;
+    const long b_left = ((BKS ? b_rows_total : b_rows_total - n0) * p.ldb - (BKS ? n0 : 0)) * 2;
+    const __amdgpu_buffer_rsrc_t ra = make_rsrc(a_base, a_left);
+    const __amdgpu_buffer_rsrc_t rb = make_rsrc(b_base, b_left);
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c = lane & 15, g = lane >> 4;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    f32x4 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = (kend > kbeg) ? (kend - kbeg + BKD - 1) / BKD : 0;
+    if (nk > 0) {
+        TA::issue(ra, sA, p.lda, M - m0, kbeg, kend, wave, lane);
+        TB::issue(rb, sB, p.ldb, N - n0, kbeg, kend, wave, lane);
+    }
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) {
+            TA::issue(ra, sA + (cur ^ 1) * A_BYTES, p.lda, M - m0, kbeg + (kt + 1) * BKD, kend, wave, lane);
+            TB::issue(rb, sB + (cur ^ 1) * B_BYTES, p.ldb, N - n0, kbeg + (kt + 1) * BKD, kend, wave, lane);
+        }
+        const bf16* a_lds = reinterpret_cast<const bf16*>(sA + cur * A_BYTES);
+        const bf16* b_lds = reinterpret_cast<const bf16*>(sB + cur * B_BYTES);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            Frag<bf16> af[FM], bfr[FN];
+#pragma unroll
+            for (int i = 0; i < FM; ++i) af[i] = TA::frag(a_lds, wm * WTM + i * 16, kk, c, g);
+#pragma unroll
+            for (int j = 0; j < FN; ++j) bfr[j] = TB::frag(b_lds, wn * WTN + j * 16, kk, c, g);
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j) mma(af[i], bfr[j], acc[i][j]);
+        }
+        __syncthreads();
+    }
+    gemm_epilogue<bf16, BM, BN>(p, acc, smem_raw, m0, n0, z);
+}
+
 // sum split-K partials: out[i] (+)= sum_z part[z*n + i]   (TO = float or the activation dtype)
 template <typename TO>
 __global__ void splitk_reduce_kernel(const float* __restrict__ part, int splits, long n, TO* __restrict__ out, int accumulate) {
@@ -395,6 +573,43 @@ int launch_gemm(const esvit_gemm_desc& d, hipStream_t stream) {
     return ESVIT_OK;
 }
 
+template <bool AKS, bool BKS, int BM, int BN>
+int launch_gemm_dma(const esvit_gemm_desc& d, hipStream_t stream) {
+    using TA = DmaTile<AKS, BM>;
+    using TB = DmaTile<BKS, BN>;
+    size_t lds = 2 * (size_t)(TA::ELEMS + TB::ELEMS) * 2;
+    auto kern = gemm_dma_kernel<AKS, BKS, BM, BN>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    const int tiles = ceil_div(d.M, BM) * ceil_div(d.N, BN);
+    dim3 grid(tiles, d.splitk > 1 ? d.splitk : d.batch);
+    hipLaunchKernelGGL(kern, grid, dim3(NTHREADS), lds, stream, d);
+    ESVIT_CHECK_LAUNCH("esvit_gemm(dma)");
+    if (d.splitk > 1) {
+        const long n = (long)d.M * d.N;
+        const int blocks = ceil_div(ceil_div(n, 4), 256);
+        if (d.out_f32)
+            hipLaunchKernelGGL(splitk_reduce_kernel<float>, dim3(blocks), dim3(256), 0, stream, d.partial, d.splitk, n,
+                               reinterpret_cast<float*>(d.C), d.accumulate);
+        else
+            hipLaunchKernelGGL(splitk_reduce_kernel<bf16>, dim3(blocks), dim3(256), 0, stream, d.partial, d.splitk, n,
+                               reinterpret_cast<bf16*>(d.C), d.accumulate);
+        ESVIT_CHECK_LAUNCH("esvit_gemm(dma splitk_reduce)");
+    }
+    return ESVIT_OK;
+}
+
+template <bool AKS, bool BKS>
+int dispatch_tile_dma(const esvit_gemm_desc& d, hipStream_t stream) {
+    const bool n96 = (d.N % 96 == 0) && (d.N % 128 != 0);
+    if (n96) return launch_gemm_dma<AKS, BKS, 128, 96>(d, stream);
+    if (d.N <= 64) return launch_gemm_dma<AKS, BKS, 128, 64>(d, stream);
+    return launch_gemm_dma<AKS, BKS, 128, 128>(d, stream);
+}
+
 template <typename T, bool AKS, bool BKS, bool USE_TR>
 int dispatch_tile(const esvit_gemm_desc& d, hipStream_t stream) {
     // backbone widths are multiples of 96 (96*2^s, x3, x4); head widths are powers of two.
@@ -416,7 +631,9 @@ int dispatch_layout(const esvit_gemm_desc& d, hipStream_t stream) {
 }  // namespace
 
 static int g_use_tr = 1;
+static int g_use_dma = 1;
 extern "C" void esvit_debug_set_tr_read(int on) { g_use_tr = on; }
+extern "C" void esvit_debug_set_gemm_dma(int on) { g_use_dma = on; }
 
 extern "C" int esvit_gemm(int dtype, const esvit_gemm_desc* dp, esvit_stream_t stream_) {
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
@@ -442,6 +659,11 @@ extern "C" int esvit_gemm(int dtype, const esvit_gemm_desc* dp, esvit_stream_t s
     if (d.rowscale) ESVIT_CHECK_ARG(d.rows_per_sample > 0, "esvit_gemm: rowscale needs rows_per_sample");
     if (d.epilogue == ESVIT_EPI_GELU_BWD) ESVIT_CHECK_ARG(d.aux != nullptr, "esvit_gemm: GELU' needs aux");
     if (dtype == ESVIT_BF16) {
+        if (g_use_dma && g_use_tr) {
+            if (!d.a_kstrided && !d.b_kstrided) return dispatch_tile_dma<false, false>(d, stream);
+            if (!d.a_kstrided && d.b_kstrided) return dispatch_tile_dma<false, true>(d, stream);
+            if (d.a_kstrided && d.b_kstrided) return dispatch_tile_dma<true, true>(d, stream);
+        }
         return g_use_tr ? dispatch_layout<bf16, true>(d, stream) : dispatch_layout<bf16, false>(d, stream);
     }
     return dispatch_layout<float, false>(d, stream);

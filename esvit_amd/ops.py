@@ -543,3 +543,7 @@ def fused_clip_adamw_ema(tensors, ntensors, chunks, nchunks, sqnorms, clip, lr, 
 def debug_set_tr_read(on):
     lib.esvit_debug_set_tr_read(int(on))
     lib.esvit_debug_set_attn_tr_read(int(on))
+
+
+def debug_set_gemm_dma(on):
+    lib.esvit_debug_set_gemm_dma(int(on))

@@ -42,9 +42,19 @@ def _rand(shape, dev, seed, dt=torch.float32, scale=1.0):
     return (torch.randn(shape, generator=g) * scale).to(dev).to(dt)
 
 
+@pytest.fixture(params=[1, 0], ids=["dma", "regstage"])
+def gemm_path(request, mods):
+    """both GEMM main loops: LDS-DMA (buffer_load ... lds, BK=64) and register-staged (BK=32)"""
+    ops, _ = mods
+    ops.debug_set_gemm_dma(request.param)
+    yield request.param
+    ops.debug_set_gemm_dma(1)
+
+
 @pytest.mark.parametrize("dt", DTYPES)
-@pytest.mark.parametrize("M,N,K", [(300, 96, 96), (257, 288, 96), (128, 384, 192), (1000, 256, 2048), (64, 64, 48), (520, 1024, 256)])
-def test_gemm_nt(mods, dt, M, N, K):
+@pytest.mark.parametrize("M,N,K", [(300, 96, 96), (257, 288, 96), (128, 384, 192), (1000, 256, 2048), (64, 64, 48), (520, 1024, 256),
+                                   (777, 2048, 768), (130, 96, 384)])
+def test_gemm_nt(mods, gemm_path, dt, M, N, K):
     ops, ref = mods
     dev = _dev()
     x, w, b = _rand((M, K), dev, 1, dt), _rand((N, K), dev, 2, dt, 0.1), _rand((N,), dev, 3)
@@ -60,7 +70,7 @@ def test_gemm_nt(mods, dt, M, N, K):
 @pytest.mark.parametrize("tr", [1, 0])
 @pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("M,N,K", [(300, 96, 384), (257, 192, 576), (1000, 2048, 256), (130, 768, 3072)])
-def test_gemm_dgrad(mods, dt, tr, M, N, K):
+def test_gemm_dgrad(mods, gemm_path, dt, tr, M, N, K):
     """dx[M,N] = dy[M,K] @ w[K,N] (B read k-strided; tr=1 uses ds_read_b64_tr_b16)."""
     ops, ref = mods
     dev = _dev()
@@ -76,8 +86,9 @@ def test_gemm_dgrad(mods, dt, tr, M, N, K):
 
 @pytest.mark.parametrize("tr", [1, 0])
 @pytest.mark.parametrize("dt", DTYPES)
-@pytest.mark.parametrize("rows,Nout,Kin", [(392, 288, 96), (3136, 96, 384), (1000, 256, 2048), (98, 768, 768), (6272, 64, 48)])
-def test_gemm_wgrad(mods, dt, tr, rows, Nout, Kin):
+@pytest.mark.parametrize("rows,Nout,Kin", [(392, 288, 96), (3136, 96, 384), (1000, 256, 2048), (98, 768, 768), (6272, 64, 48),
+                                           (25088, 1152, 384), (12545 * 8, 192, 576)])
+def test_gemm_wgrad(mods, gemm_path, dt, tr, rows, Nout, Kin):
     ops, ref = mods
     dev = _dev()
     ops.debug_set_tr_read(tr)
@@ -93,7 +104,7 @@ def test_gemm_wgrad(mods, dt, tr, rows, Nout, Kin):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
-def test_gemm_rowmap_scatter(mods, dt):
+def test_gemm_rowmap_scatter(mods, gemm_path, dt):
     """window rows -> token rows with pad rows dropped, DropPath scale and residual (proj epilogue)."""
     ops, ref = mods
     dev = _dev()

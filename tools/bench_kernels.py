@@ -22,6 +22,8 @@ def timeit(fn, iters=20, warm=3):
 
 def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+    if len(sys.argv) > 2:
+        ops.debug_set_gemm_dma(int(sys.argv[2]))
     dt = torch.bfloat16
     res = []
     shapes = []
