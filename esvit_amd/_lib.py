@@ -29,6 +29,7 @@ class GemmDesc(C.Structure):
         ("aux", vp), ("ldaux", i64),
         ("epilogue", i32), ("out_f32", i32), ("splitk", i32),
         ("partial", vp), ("accumulate", i32), ("alpha", f32),
+        ("colsum", vp), ("colsum_partial", vp),
     ]
 
 

@@ -30,6 +30,33 @@ namespace {
 constexpr int BK = 32;
 constexpr int NTHREADS = 256;
 
+__device__ __forceinline__ Frag<bf16> ones_frag(bf16) {
+    Frag<bf16> f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f.v[j] = (bf16)1.0f;
+    return f;
+}
+__device__ __forceinline__ Frag<float> ones_frag(float) {
+    Frag<float> f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f.v[j] = 1.0f;
+    return f;
+}
+
+// row sums of op(A) (accumulated with an all-ones B fragment): lane c == 0 of each 16-lane group owns rows 4g+r
+template <int FM>
+__device__ __forceinline__ void store_colsum(const esvit_gemm_desc& p, const f32x4 (&accb)[FM], int m0, int wm_rows0, int z, int c, int g) {
+    if (c != 0) return;
+    float* dst = p.splitk > 1 ? p.colsum_partial + (long)z * p.M : p.colsum;
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = m0 + wm_rows0 + i * 16 + 4 * g + r;
+            if (m < p.M) dst[m] = accb[i][r] * p.alpha;
+        }
+}
+
 // One operand tile: ROWS (BM or BN) x BK, in LDS either as [ROWS][BK+pad] (k contiguous) or as
 // [BK][ROWS+pad] (k strided, i.e. exactly the HBM orientation).
 template <typename T, bool KS, int ROWS, bool USE_TR>
@@ -314,6 +341,12 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const esvit_gemm_desc p)
 #pragma unroll
         for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    const bool do_colsum = p.colsum && tn == 0 && wn == 0;
+    f32x4 accb[FM];
+#pragma unroll
+    for (int i = 0; i < FM; ++i) accb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const Frag<T> ones = ones_frag(T());
+
     TA ta;
     TB tb;
     const int nk = (kend > kbeg) ? (kend - kbeg + BK - 1) / BK : 0;
@@ -341,6 +374,10 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const esvit_gemm_desc p)
         for (int i = 0; i < FM; ++i)
 #pragma unroll
             for (int j = 0; j < FN; ++j) mma(af[i], bfr[j], acc[i][j]);
+        if (do_colsum) {
+#pragma unroll
+            for (int i = 0; i < FM; ++i) mma(af[i], ones, accb[i]);
+        }
         if (kt + 1 < nk) {
             ta.store(sA + (cur ^ 1) * TA::ELEMS);
             tb.store(sB + (cur ^ 1) * TB::ELEMS);
@@ -348,6 +385,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const esvit_gemm_desc p)
         __syncthreads();
     }
 
+    if (do_colsum) store_colsum<FM>(p, accb, m0, wm * WTM, z, c, g);
     gemm_epilogue<T, BM, BN>(p, acc, smem_raw, m0, n0, z);
 }
 
@@ -486,6 +524,12 @@ __global__ __launch_bounds__(NTHREADS) void gemm_dma_kernel(const esvit_gemm_des
 #pragma unroll
         for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    const bool do_colsum = p.colsum && tn == 0 && wn == 0;
+    f32x4 accb[FM];
+#pragma unroll
+    for (int i = 0; i < FM; ++i) accb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const Frag<bf16> ones = ones_frag(bf16());
+
     const int nk = (kend > kbeg) ? (kend - kbeg + BKD - 1) / BKD : 0;
     if (nk > 0) {
         TA::issue(ra, sA, p.lda, M - m0, kbeg, kend, wave, lane);
@@ -511,9 +555,14 @@ __global__ __launch_bounds__(NTHREADS) void gemm_dma_kernel(const esvit_gemm_des
             for (int i = 0; i < FM; ++i)
 #pragma unroll
                 for (int j = 0; j < FN; ++j) mma(af[i], bfr[j], acc[i][j]);
+            if (do_colsum) {
+#pragma unroll
+                for (int i = 0; i < FM; ++i) mma(af[i], ones, accb[i]);
+            }
         }
         __syncthreads();
     }
+    if (do_colsum) store_colsum<FM>(p, accb, m0, wm * WTM, z, c, g);
     gemm_epilogue<bf16, BM, BN>(p, acc, smem_raw, m0, n0, z);
 }
 
@@ -569,6 +618,7 @@ int launch_gemm(const esvit_gemm_desc& d, hipStream_t stream) {
             hipLaunchKernelGGL(splitk_reduce_kernel<T>, dim3(blocks), dim3(256), 0, stream, d.partial, d.splitk, n,
                                reinterpret_cast<T*>(d.C), d.accumulate);
         ESVIT_CHECK_LAUNCH("esvit_gemm(splitk_reduce)");
+        if (d.colsum) return esvit_partial_reduce(d.colsum_partial, d.splitk, d.M, d.M, d.colsum, 0, stream);
     }
     return ESVIT_OK;
 }
@@ -598,6 +648,7 @@ int launch_gemm_dma(const esvit_gemm_desc& d, hipStream_t stream) {
             hipLaunchKernelGGL(splitk_reduce_kernel<bf16>, dim3(blocks), dim3(256), 0, stream, d.partial, d.splitk, n,
                                reinterpret_cast<bf16*>(d.C), d.accumulate);
         ESVIT_CHECK_LAUNCH("esvit_gemm(dma splitk_reduce)");
+        if (d.colsum) return esvit_partial_reduce(d.colsum_partial, d.splitk, d.M, d.M, d.colsum, 0, stream);
     }
     return ESVIT_OK;
 }
@@ -658,8 +709,13 @@ extern "C" int esvit_gemm(int dtype, const esvit_gemm_desc* dp, esvit_stream_t s
     if (d.rowmap) ESVIT_CHECK_ARG(d.rowmap_period > 0 && d.rowmap_tokens > 0, "esvit_gemm: bad rowmap geometry");
     if (d.rowscale) ESVIT_CHECK_ARG(d.rows_per_sample > 0, "esvit_gemm: rowscale needs rows_per_sample");
     if (d.epilogue == ESVIT_EPI_GELU_BWD) ESVIT_CHECK_ARG(d.aux != nullptr, "esvit_gemm: GELU' needs aux");
+    if (d.colsum && d.splitk > 1) ESVIT_CHECK_ARG(d.colsum_partial != nullptr, "esvit_gemm: colsum with split-K needs colsum_partial");
+    if (d.colsum) ESVIT_CHECK_ARG(d.batch == 1, "esvit_gemm: colsum is not batched");
     if (dtype == ESVIT_BF16) {
-        if (g_use_dma && g_use_tr) {
+        // LDS-DMA main loop (BK = 64) for every reduction deep enough to pipeline; short-K forward/dgrad GEMMs
+        // (K = 96 / 128: two half-empty k-tiles, no overlap to win) stay on the register-staged BK = 32 loop
+        const bool deep = d.a_kstrided || d.K >= 192;
+        if (g_use_dma && g_use_tr && (deep || g_use_dma == 2)) {
             if (!d.a_kstrided && !d.b_kstrided) return dispatch_tile_dma<false, false>(d, stream);
             if (!d.a_kstrided && d.b_kstrided) return dispatch_tile_dma<false, true>(d, stream);
             if (d.a_kstrided && d.b_kstrided) return dispatch_tile_dma<true, true>(d, stream);

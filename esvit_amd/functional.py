@@ -121,22 +121,18 @@ class SwinBlockFn(torch.autograd.Function):
         gy = gy.contiguous().view(M, C)
         # ---- MLP branch ----
         dyb = o.gather_cast(gy, M, rowscale=dp2, rows_per_sample=L)
-        dW2 = o.linear_wgrad(dyb, a1g)
-        dbfc2 = o.colsum(dyb)
+        dW2, dbfc2 = o.linear_wgrad(dyb, a1g, want_bias=True)
         da1 = o.linear_dgrad(dyb, W2, gelu_preact=a1)
-        dW1 = o.linear_wgrad(da1, h)
-        dbfc1 = o.colsum(da1)
+        dW1, dbfc1 = o.linear_wgrad(da1, h, want_bias=True)
         dh = o.linear_dgrad(da1, W1)
         gx1, dg2, db2 = o.layernorm_bwd(dh, x1, mean2, rstd2, g2, g_in=gy)
         # ---- attention branch ----
         dyw = o.gather_cast(gx1, Mw, rowmap=geom.win2tok, tokens=L, rowscale=dp1, rows_per_sample=L)
-        dWproj = o.linear_wgrad(dyw, ao)
-        dbproj = o.colsum(dyw)
+        dWproj, dbproj = o.linear_wgrad(dyw, ao, want_bias=True)
         dao = o.linear_dgrad(dyw, Wproj)
         dqkv, dbias_ws = o.window_attn_bwd(qkv, dao, bias_frag, geom.mask_frag, geom.nW, geom.N, nH, scale)
         dtable = o.relpos_bias_bwd(dbias_ws, index, geom.N, table.shape[0])
-        dWqkv = o.linear_wgrad(dqkv, xw)
-        dbqkv = o.colsum(dqkv)
+        dWqkv, dbqkv = o.linear_wgrad(dqkv, xw, want_bias=True)
         dxw = o.linear_dgrad(dqkv, Wqkv)
         gx, dg1, db1 = o.layernorm_bwd(dxw, x.view(M, C), mean1, rstd1, g1, g_in=gx1, rowmap=geom.tok2win, period_in=geom.period)
         return (gx.view(nB, L, C), None, None, None, None, dg1, db1, dtable, dWqkv, dbqkv, dWproj, dbproj, dg2, db2, dW1, dbfc1,
@@ -191,8 +187,8 @@ class PatchEmbedFn(torch.autograd.Function):
         M, E = y.shape
         dy, dg, db = o.layernorm_bwd(gx.contiguous().view(M, E), y, mean, rstd, g)
         dyb = o.gather_cast(dy, M)
-        dW = o.linear_wgrad(dyb, cols).view(ctx.wshape)
-        dbp = o.colsum(dyb)
+        dW, dbp = o.linear_wgrad(dyb, cols, want_bias=True)
+        dW = dW.view(ctx.wshape)
         return None, dW, dbp, dg, db, None
 
 
@@ -304,14 +300,11 @@ class DinoHeadFn(torch.autograd.Function):
         dw = o.linear_wgrad(dlogits, z)
         dv, dg = o.weightnorm_bwd(dw, v, g, winv, ctx.need_dg)
         dh3 = o.l2norm_bwd(dz, z, inv)
-        dW3 = o.linear_wgrad(dh3, h2g)
-        db3 = o.colsum(dh3)
+        dW3, db3 = o.linear_wgrad(dh3, h2g, want_bias=True)
         dh2 = o.linear_dgrad(dh3, W3, gelu_preact=h2)
-        dW2 = o.linear_wgrad(dh2, h1g)
-        db2 = o.colsum(dh2)
+        dW2, db2 = o.linear_wgrad(dh2, h1g, want_bias=True)
         dh1 = o.linear_dgrad(dh2, W2, gelu_preact=h1)
-        dW1 = o.linear_wgrad(dh1, xa)
-        db1 = o.colsum(dh1)
+        dW1, db1 = o.linear_wgrad(dh1, xa, want_bias=True)
         dx = o.linear_dgrad(dh1, W1, out_f32=True)
         return dx, dW1, db1, dW2, db2, dW3, db3, dv, dg
 

@@ -125,7 +125,7 @@ def _gemm(dt, **kw):
 
 def _gemm_launch(dt, **kw):
     d = GemmDesc()
-    for k in ("A", "B", "C", "bias", "residual", "rowmap", "rowscale", "aux", "partial"):
+    for k in ("A", "B", "C", "bias", "residual", "rowmap", "rowscale", "aux", "partial", "colsum", "colsum_partial"):
         setattr(d, k, _p(kw.get(k)))
     for k in ("M", "N", "K", "lda", "ldb", "ldc", "a_kstrided", "b_kstrided", "strideA", "strideB", "strideC", "ldr",
               "rowmap_period", "rowmap_tokens", "rows_per_sample", "ldaux", "epilogue", "out_f32", "splitk", "accumulate"):
@@ -176,14 +176,18 @@ def linear_dgrad(dy, w, *, gelu_preact=None, out_f32=False):
     return dx
 
 
-def _pick_splitk(rows, tiles):
-    # aim for ~1024 workgroups (4 per CU), at least 256 reduction rows per split
-    want = max(1, 1024 // max(tiles, 1))
-    return int(max(1, min(want, rows // 256 if rows >= 512 else 1, 256)))
+def _pick_splitk(rows, Nout, Kin, tiles):
+    """split-K factor for wgrad: ~512 workgroups, >= 512 reduction rows per split, and partial slabs (written + re-read)
+    no larger than the operand traffic"""
+    want = -(-512 // max(tiles, 1))
+    by_rows = max(1, rows // 512)
+    by_bytes = max(1, (rows * (Nout + Kin) * 2) // (Nout * Kin * 8))
+    return int(max(1, min(want, by_rows, by_bytes, 512)))
 
 
-def linear_wgrad(dy, x, *, out=None, accumulate=False):
-    """dw[Nout, Kin] = dy^T @ x (fp32), both operands read k-strided, split-K over the rows."""
+def linear_wgrad(dy, x, *, out=None, accumulate=False, want_bias=False):
+    """dw[Nout, Kin] = dy^T @ x (fp32), both operands read k-strided, split-K over the rows.
+    want_bias: also return db[Nout] = column sums of dy, fused into the same kernel (all-ones MFMA fragment)."""
     dy, x = _actc(dy), _actc(x)
     rows, Nout = dy.shape
     Kin = x.shape[1]
@@ -191,18 +195,20 @@ def linear_wgrad(dy, x, *, out=None, accumulate=False):
     if out is None:
         out = torch.empty((Nout, Kin), dtype=torch.float32, device=dy.device)
         accumulate = False
+    db = torch.empty((Nout,), dtype=torch.float32, device=dy.device) if want_bias else None
     bn = 96 if (Kin % 96 == 0 and Kin % 128 != 0) else (64 if Kin <= 64 else 128)
     tiles = (-(-Nout // 128)) * (-(-Kin // bn))
-    splitk = _pick_splitk(rows, tiles)
+    splitk = _pick_splitk(rows, Nout, Kin, tiles)
     if splitk > 1:
-        part = workspace(splitk * Nout * Kin, dy.device)
+        part = workspace(splitk * Nout * (Kin + 1), dy.device)
+        cpart = part[splitk * Nout * Kin:] if want_bias else None
         _gemm(dy.dtype, A=dy, B=x, C=out, M=Nout, N=Kin, K=rows, lda=Nout, ldb=Kin, ldc=Kin, a_kstrided=1, b_kstrided=1,
-              out_f32=1, splitk=splitk, partial=part, accumulate=int(accumulate))
+              out_f32=1, splitk=splitk, partial=part, accumulate=int(accumulate), colsum=db, colsum_partial=cpart)
     else:
         # accumulate through the residual input (each element is read and written by the same lane)
         _gemm(dy.dtype, A=dy, B=x, C=out, M=Nout, N=Kin, K=rows, lda=Nout, ldb=Kin, ldc=Kin, a_kstrided=1, b_kstrided=1,
-              out_f32=1, residual=out if accumulate else None, ldr=Kin)
-    return out
+              out_f32=1, residual=out if accumulate else None, ldr=Kin, colsum=db)
+    return (out, db) if want_bias else out
 
 
 def batched_nt(a, b, out_ld):

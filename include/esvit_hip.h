@@ -76,6 +76,8 @@ typedef struct {
     float* partial;   /* workspace >= splitk*M*N floats */
     int32_t accumulate; /* split-K reduce: C += sum (1) or C = sum (0) */
     float alpha;
+    float* colsum;         /* optional, fp32 [M]: row sums of op(A) over K (= bias gradient when A = dY^T); fused via an all-ones B fragment */
+    float* colsum_partial; /* workspace >= splitk*M floats when splitk > 1 */
 } esvit_gemm_desc;
 
 /* C = alpha * op(A) op(B) (+ epilogue).  Replaces every nn.Linear / conv-as-GEMM on the

@@ -134,15 +134,15 @@ def linear_dgrad(dy, w, *, gelu_preact=None, out_f32=False):
     return dx if out_f32 else _r(dx, dy.dtype)
 
 
-def linear_wgrad(dy, x, *, out=None, accumulate=False):
+def linear_wgrad(dy, x, *, out=None, accumulate=False, want_bias=False):
     dw = dy.float().t() @ x.float()
     if out is not None:
         if accumulate:
             out += dw
         else:
             out.copy_(dw)
-        return out
-    return dw
+        dw = out
+    return (dw, dy.float().sum(0)) if want_bias else dw
 
 
 def batched_nt(a, b, out_ld):

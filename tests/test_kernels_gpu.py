@@ -46,7 +46,7 @@ def _rand(shape, dev, seed, dt=torch.float32, scale=1.0):
 def gemm_path(request, mods):
     """both GEMM main loops: LDS-DMA (buffer_load ... lds, BK=64) and register-staged (BK=32)"""
     ops, _ = mods
-    ops.debug_set_gemm_dma(request.param)
+    ops.debug_set_gemm_dma(2 if request.param else 0)
     yield request.param
     ops.debug_set_gemm_dma(1)
 
@@ -95,6 +95,10 @@ def test_gemm_wgrad(mods, gemm_path, dt, tr, rows, Nout, Kin):
     try:
         dy, x = _rand((rows, Nout), dev, 8, dt), _rand((rows, Kin), dev, 9, dt)
         _close("wgrad", ops.linear_wgrad(dy, x), ref.linear_wgrad(dy, x), _tol(dt, f32=5e-5, bf=2e-3))
+        dw, db = ops.linear_wgrad(dy, x, want_bias=True)
+        dwr, dbr = ref.linear_wgrad(dy, x, want_bias=True)
+        _close("wgrad(+bias) dw", dw, dwr, _tol(dt, f32=5e-5, bf=2e-3))
+        _close("wgrad(+bias) db", db, dbr, _tol(dt, f32=5e-5, bf=2e-3))
         acc = _rand((Nout, Kin), dev, 10)
         acc_ref = acc.clone()
         _close("wgrad acc", ops.linear_wgrad(dy, x, out=acc, accumulate=True), ref.linear_wgrad(dy, x, out=acc_ref, accumulate=True),
