@@ -79,6 +79,7 @@ SIGNATURES = {
     "esvit_debug_set_tr_read": (None, [C.c_int]),
     "esvit_debug_set_attn_tr_read": (None, [C.c_int]),
     "esvit_debug_set_gemm_dma": (None, [C.c_int]),
+    "esvit_debug_set_gemm_pipe": (None, [C.c_int]),
 }
 
 

@@ -153,10 +153,18 @@ __device__ __forceinline__ float block_max(float v, float* scratch) {
     return r;
 }
 
-// exact-erf GELU (reference: nn.GELU default) and its derivative
-__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+// erf to fp32 round-off without the branches of libm's erff: Abramowitz-Stegun 7.1.26, |error| <= 1.5e-7
+__device__ __forceinline__ float erf_fast(float x) {
+    const float ax = fabsf(x);
+    const float t = __frcp_rn(1.f + 0.3275911f * ax);
+    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    const float r = 1.f - poly * __expf(-ax * ax);
+    return copysignf(r, x);
+}
+// erf-GELU (reference: nn.GELU default, "none" approximation) and its derivative
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erf_fast(x * 0.70710678118654752f)); }
 __device__ __forceinline__ float gelu_grad_f(float x) {
-    const float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752f));
+    const float cdf = 0.5f * (1.f + erf_fast(x * 0.70710678118654752f));
     const float pdf = 0.39894228040143268f * __expf(-0.5f * x * x);
     return cdf + x * pdf;
 }

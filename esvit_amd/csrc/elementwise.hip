@@ -109,8 +109,19 @@ __global__ __launch_bounds__(256) void partial_reduce_kernel(const float* __rest
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + tx;
     float s = 0.f;
-    if (c < ncols)
-        for (int b = ty; b < nblk; b += 8) s += ws[(long)b * ld + c];
+    if (c < ncols) {
+        // 4 independent partial sums: the loads are latency-bound (tiny grid), keep several in flight
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int b = ty;
+        for (; b + 24 < nblk; b += 32) {
+            s0 += ws[(long)b * ld + c];
+            s1 += ws[(long)(b + 8) * ld + c];
+            s2 += ws[(long)(b + 16) * ld + c];
+            s3 += ws[(long)(b + 24) * ld + c];
+        }
+        for (; b < nblk; b += 8) s0 += ws[(long)b * ld + c];
+        s = (s0 + s1) + (s2 + s3);
+    }
     sm[ty][tx] = s;
     __syncthreads();
     if (ty == 0 && c < ncols) {

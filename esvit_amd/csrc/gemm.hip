@@ -398,9 +398,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const esvit_gemm_desc p)
 // 8 k-rows touched by one ds_read_b64_tr_b16 over distinct banks.  Two LDS buffers; the barrier at the
 // end of a k-tile drains the DMA of the next one while this tile's 32 MFMAs per wave run.
 // =================================================================================================
-constexpr int BKD = 64;
-
-template <bool KS, int ROWS>
+template <bool KS, int ROWS, int BKD>
 struct DmaTile {
     static constexpr int ELEMS = ROWS * BKD;
     static constexpr int CHUNKS = ELEMS / 8;
@@ -412,6 +410,10 @@ struct DmaTile {
         if constexpr (ROWS == 128) return ((k & 3) << 1) | (((k >> 3) & 1) << 3);
         else if constexpr (ROWS == 64) return (((k >> 1) & 1) << 1) | (((k >> 3) & 1) << 2);
         else return ((k >> 3) & 1) << 1;
+    }
+    __device__ __forceinline__ static int sw_kc(int r) {
+        if constexpr (BKD == 64) return r & 7;               // 128-byte rows: 8 chunks
+        else return (0x78 >> (2 * ((r >> 2) & 3))) & 3;      // 64-byte rows: 4 chunks, f(r>>2) = {0,2,3,1}
     }
 
     // base: operand pointer already advanced to the tile's first row (k-contiguous) / column (k-strided)
@@ -431,7 +433,7 @@ struct DmaTile {
                 off = (long)(k0 + kr) * ld + col;
             } else {
                 const int r = p / CPR, cp = p % CPR;
-                const int k = k0 + ((cp ^ (r & 7)) * 8);
+                const int k = k0 + ((cp ^ sw_kc(r)) * 8);
                 ok = (r < rows_left) && (k < K);
                 off = (long)r * ld + k;
             }
@@ -445,7 +447,7 @@ struct DmaTile {
         Frag<bf16> f;
         if constexpr (!KS) {
             const int row = r0 + c;
-            const int pos = row * CPR + ((kk * 4 + g) ^ (row & 7));
+            const int pos = row * CPR + ((kk * 4 + g) ^ sw_kc(row));
             f.v = *reinterpret_cast<const bf16x8*>(lds + pos * 8);
         } else {
             typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
@@ -468,16 +470,27 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, lo
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)capped, 0x00020000);
 }
 
-template <bool AKS, bool BKS, int BM, int BN>
+// counted wait: at most N of this wave's LDS-DMA loads still in flight (loads retire in order)
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    static_assert(N >= 0 && N < 64, "vmcnt immediate");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// NBUF-deep ring of LDS tiles: NBUF-1 tiles are requested ahead; per k-tile ONE counted wait (only for the tile
+// about to be consumed -- later tiles stay in flight across the barrier) and ONE barrier.
+template <bool AKS, bool BKS, int BM, int BN, int BKD, int NBUF>
 __global__ __launch_bounds__(NTHREADS) void gemm_dma_kernel(const esvit_gemm_desc p) {
-    using TA = DmaTile<AKS, BM>;
-    using TB = DmaTile<BKS, BN>;
+    using TA = DmaTile<AKS, BM, BKD>;
+    using TB = DmaTile<BKS, BN, BKD>;
     constexpr int WTM = BM / 2, WTN = BN / 2;
     constexpr int FM = WTM / 16, FN = WTN / 16;
+    constexpr int L = TA::INSTR_PER_WAVE + TB::INSTR_PER_WAVE;  // DMA instructions per wave per tile
+    static_assert(NBUF >= 2 && NBUF <= 4, "ring depth");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr int A_BYTES = TA::ELEMS * 2, B_BYTES = TB::ELEMS * 2;
-    char* sA = smem_raw;                // 2 buffers
-    char* sB = smem_raw + 2 * A_BYTES;  // 2 buffers
+    char* sA = smem_raw;                   // NBUF buffers
+    char* sB = smem_raw + NBUF * A_BYTES;  // NBUF buffers
 
     const int M = p.M, N = p.N, K = p.K;
     const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
@@ -531,21 +544,31 @@ __global__ __launch_bounds__(NTHREADS) void gemm_dma_kernel(const esvit_gemm_des
     const Frag<bf16> ones = ones_frag(bf16());
 
     const int nk = (kend > kbeg) ? (kend - kbeg + BKD - 1) / BKD : 0;
-    if (nk > 0) {
-        TA::issue(ra, sA, p.lda, M - m0, kbeg, kend, wave, lane);
-        TB::issue(rb, sB, p.ldb, N - n0, kbeg, kend, wave, lane);
-    }
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) {
-            TA::issue(ra, sA + (cur ^ 1) * A_BYTES, p.lda, M - m0, kbeg + (kt + 1) * BKD, kend, wave, lane);
-            TB::issue(rb, sB + (cur ^ 1) * B_BYTES, p.ldb, N - n0, kbeg + (kt + 1) * BKD, kend, wave, lane);
-        }
-        const bf16* a_lds = reinterpret_cast<const bf16*>(sA + cur * A_BYTES);
-        const bf16* b_lds = reinterpret_cast<const bf16*>(sB + cur * B_BYTES);
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
+    for (int t = 0; t < NBUF - 1; ++t) {
+        if (t < nk) {
+            TA::issue(ra, sA + t * A_BYTES, p.lda, M - m0, kbeg + t * BKD, kend, wave, lane);
+            TB::issue(rb, sB + t * B_BYTES, p.ldb, N - n0, kbeg + t * BKD, kend, wave, lane);
+        }
+    }
+    int buf = 0;  // ring slot of tile kt
+    for (int kt = 0; kt < nk; ++kt) {
+        const int ahead = min(nk - 1 - kt, NBUF - 2);  // tiles requested after kt that may stay in flight
+        if (NBUF >= 4 && ahead >= 2) wait_vmcnt<2 * L>();
+        else if (NBUF >= 3 && ahead >= 1) wait_vmcnt<L>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();  // tile kt landed for every wave; every wave is done with tile kt-1
+        asm volatile("" ::: "memory");
+        const int nt = kt + NBUF - 1;
+        if (nt < nk) {
+            const int nb = (buf == 0) ? NBUF - 1 : buf - 1;  // the slot tile kt-1 just vacated
+            TA::issue(ra, sA + nb * A_BYTES, p.lda, M - m0, kbeg + nt * BKD, kend, wave, lane);
+            TB::issue(rb, sB + nb * B_BYTES, p.ldb, N - n0, kbeg + nt * BKD, kend, wave, lane);
+        }
+        const bf16* a_lds = reinterpret_cast<const bf16*>(sA + buf * A_BYTES);
+        const bf16* b_lds = reinterpret_cast<const bf16*>(sB + buf * B_BYTES);
+#pragma unroll
+        for (int kk = 0; kk < BKD / 32; ++kk) {
             Frag<bf16> af[FM], bfr[FN];
 #pragma unroll
             for (int i = 0; i < FM; ++i) af[i] = TA::frag(a_lds, wm * WTM + i * 16, kk, c, g);
@@ -560,8 +583,9 @@ __global__ __launch_bounds__(NTHREADS) void gemm_dma_kernel(const esvit_gemm_des
                 for (int i = 0; i < FM; ++i) mma(af[i], ones, accb[i]);
             }
         }
-        __syncthreads();
+        buf = (buf + 1 == NBUF) ? 0 : buf + 1;
     }
+    __syncthreads();  // all waves finished reading the operand tiles before the epilogue reuses the LDS
     if (do_colsum) store_colsum<FM>(p, accb, m0, wm * WTM, z, c, g);
     gemm_epilogue<bf16, BM, BN>(p, acc, smem_raw, m0, n0, z);
 }
@@ -623,12 +647,14 @@ int launch_gemm(const esvit_gemm_desc& d, hipStream_t stream) {
     return ESVIT_OK;
 }
 
-template <bool AKS, bool BKS, int BM, int BN>
+template <bool AKS, bool BKS, int BM, int BN, int BKD, int NBUF>
 int launch_gemm_dma(const esvit_gemm_desc& d, hipStream_t stream) {
-    using TA = DmaTile<AKS, BM>;
-    using TB = DmaTile<BKS, BN>;
-    size_t lds = 2 * (size_t)(TA::ELEMS + TB::ELEMS) * 2;
-    auto kern = gemm_dma_kernel<AKS, BKS, BM, BN>;
+    using TA = DmaTile<AKS, BM, BKD>;
+    using TB = DmaTile<BKS, BN, BKD>;
+    size_t lds = (size_t)NBUF * (TA::ELEMS + TB::ELEMS) * 2;
+    const size_t stage_bytes = 4 * 32 * (size_t)(BN / 2 + 4) * sizeof(float);
+    if (lds < stage_bytes) lds = stage_bytes;
+    auto kern = gemm_dma_kernel<AKS, BKS, BM, BN, BKD, NBUF>;
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -653,12 +679,24 @@ int launch_gemm_dma(const esvit_gemm_desc& d, hipStream_t stream) {
     return ESVIT_OK;
 }
 
+// pipeline shape: 1 = BK 64, 2 buffers (drain every tile); 3 = BK 64, 3-deep ring; 4 = BK 32, 4-deep ring
+static int g_dma_pipe = 3;
+
 template <bool AKS, bool BKS>
 int dispatch_tile_dma(const esvit_gemm_desc& d, hipStream_t stream) {
     const bool n96 = (d.N % 96 == 0) && (d.N % 128 != 0);
-    if (n96) return launch_gemm_dma<AKS, BKS, 128, 96>(d, stream);
-    if (d.N <= 64) return launch_gemm_dma<AKS, BKS, 128, 64>(d, stream);
-    return launch_gemm_dma<AKS, BKS, 128, 128>(d, stream);
+    if (n96) {  // 96-wide tiles are only a whole number of DMA instructions at BK = 64
+        if (g_dma_pipe == 1) return launch_gemm_dma<AKS, BKS, 128, 96, 64, 2>(d, stream);
+        return launch_gemm_dma<AKS, BKS, 128, 96, 64, 3>(d, stream);
+    }
+    if (d.N <= 64) {
+        if (g_dma_pipe == 1) return launch_gemm_dma<AKS, BKS, 128, 64, 64, 2>(d, stream);
+        if (g_dma_pipe == 4) return launch_gemm_dma<AKS, BKS, 128, 64, 32, 4>(d, stream);
+        return launch_gemm_dma<AKS, BKS, 128, 64, 64, 3>(d, stream);
+    }
+    if (g_dma_pipe == 1) return launch_gemm_dma<AKS, BKS, 128, 128, 64, 2>(d, stream);
+    if (g_dma_pipe == 4) return launch_gemm_dma<AKS, BKS, 128, 128, 32, 4>(d, stream);
+    return launch_gemm_dma<AKS, BKS, 128, 128, 64, 3>(d, stream);
 }
 
 template <typename T, bool AKS, bool BKS, bool USE_TR>
@@ -685,6 +723,7 @@ static int g_use_tr = 1;
 static int g_use_dma = 1;
 extern "C" void esvit_debug_set_tr_read(int on) { g_use_tr = on; }
 extern "C" void esvit_debug_set_gemm_dma(int on) { g_use_dma = on; }
+extern "C" void esvit_debug_set_gemm_pipe(int mode) { g_dma_pipe = mode; }
 
 extern "C" int esvit_gemm(int dtype, const esvit_gemm_desc* dp, esvit_stream_t stream_) {
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);

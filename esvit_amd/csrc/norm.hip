@@ -224,7 +224,7 @@ inline int ln_bwd_nblk(long rows, int C) {
     if (!ln_cfg(C, &cfg)) return 0;
     const int rpb = LN_THREADS / cfg.G;
     long nb = (rows + rpb - 1) / rpb;
-    if (nb > 1024) nb = 1024;
+    if (nb > 512) nb = 512;
     if (nb < 1) nb = 1;
     return (int)nb;
 }

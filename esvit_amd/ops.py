@@ -553,3 +553,7 @@ def debug_set_tr_read(on):
 
 def debug_set_gemm_dma(on):
     lib.esvit_debug_set_gemm_dma(int(on))
+
+
+def debug_set_gemm_pipe(mode):
+    lib.esvit_debug_set_gemm_pipe(int(mode))

@@ -1,0 +1,75 @@
+"""world_size-2 gloo tests (CPU): the data-parallel pieces of the step -- bucketed, hook-driven gradient averaging
+(engine.GradBucketReducer) and the single fused all-reduce of the two loss centres (DDINOLoss.update_center) -- give
+the same result as one process seeing the whole batch."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _init(rank, world, port):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+
+def _reducer_worker(rank, world, port, out):
+    _init(rank, world, port)
+    from esvit_amd.engine import GradBucketReducer
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(40, 300), torch.nn.GELU(), torch.nn.Linear(300, 300), torch.nn.Linear(300, 7))
+    net[3].weight.requires_grad_(False)  # a frozen parameter must be skipped
+    red = GradBucketReducer(net, bucket_mb=0.2)  # 0.2 MiB buckets -> several buckets
+    assert red.enabled and len(red.buckets) >= 2
+    g = torch.Generator().manual_seed(100)
+    xs = torch.randn(world, 16, 40, generator=g)
+    for step in range(2):  # two steps: grads are re-pointed at bucket views, must keep working
+        net.zero_grad(set_to_none=True)
+        red.begin()
+        (net(xs[rank]) ** 2).mean().backward()
+        red.finish()
+    got = {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None}
+    # reference: average of the per-rank gradients computed without the reducer
+    ref = torch.nn.Sequential(torch.nn.Linear(40, 300), torch.nn.GELU(), torch.nn.Linear(300, 300), torch.nn.Linear(300, 7))
+    ref.load_state_dict(net.state_dict())
+    ref[3].weight.requires_grad_(False)
+    acc = None
+    for r in range(world):
+        ref.zero_grad(set_to_none=True)
+        (ref(xs[r]) ** 2).mean().backward()
+        gr = {n: p.grad.clone() for n, p in ref.named_parameters() if p.grad is not None}
+        acc = gr if acc is None else {n: acc[n] + gr[n] for n in gr}
+    ok = set(got) == set(acc) and all(torch.allclose(got[n], acc[n] / world, rtol=1e-5, atol=1e-7) for n in got)
+    out[rank] = bool(ok)
+    dist.destroy_process_group()
+
+
+def _center_worker(rank, world, port, out):
+    _init(rank, world, port)
+    import esvit_amd.loss as L
+    from oracle import ops_ref
+    L.ops = ops_ref  # CPU restatement of the kernels (test infrastructure); the collective logic under test is in loss.py
+    ops_ref.set_act_dtype(torch.float32)
+    K, B = 256, 3
+    g = torch.Generator().manual_seed(7)
+    t_cls, t_reg = torch.randn(world, 2 * B, K, generator=g), torch.randn(world, 2 * B * 49, K, generator=g)
+    loss = L.DDINOLoss(K, 10, 0.04, 0.04, 0, 1)
+    loss.update_center(t_cls[rank], t_reg[rank])
+    want_c = 0.1 * t_cls.reshape(-1, K).mean(0, keepdim=True)
+    want_g = 0.1 * t_reg.reshape(-1, K).mean(0, keepdim=True)
+    out[rank] = bool(torch.allclose(loss.center, want_c, atol=1e-6) and torch.allclose(loss.center_grid, want_g, atol=1e-6))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("worker,port", [(_reducer_worker, 29611), (_center_worker, 29612)])
+def test_world2_gloo(worker, port, lib_built):
+    world = 2
+    out = mp.Manager().dict()
+    mp.spawn(worker, args=(world, port, out), nprocs=world, join=True)
+    assert dict(out) == {0: True, 1: True}, dict(out)

@@ -42,13 +42,16 @@ def _rand(shape, dev, seed, dt=torch.float32, scale=1.0):
     return (torch.randn(shape, generator=g) * scale).to(dev).to(dt)
 
 
-@pytest.fixture(params=[1, 0], ids=["dma", "regstage"])
+@pytest.fixture(params=[3, 4, 1, 0], ids=["dma-ring3xBK64", "dma-ring4xBK32", "dma-2buf", "regstage"])
 def gemm_path(request, mods):
-    """both GEMM main loops: LDS-DMA (buffer_load ... lds, BK=64) and register-staged (BK=32)"""
+    """every GEMM main loop: LDS-DMA rings (buffer_load ... lds + counted vmcnt) and the register-staged BK=32 loop"""
     ops, _ = mods
     ops.debug_set_gemm_dma(2 if request.param else 0)
+    if request.param:
+        ops.debug_set_gemm_pipe(request.param)
     yield request.param
     ops.debug_set_gemm_dma(1)
+    ops.debug_set_gemm_pipe(3)
 
 
 @pytest.mark.parametrize("dt", DTYPES)

@@ -24,6 +24,9 @@ def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
     if len(sys.argv) > 2:
         ops.debug_set_gemm_dma(int(sys.argv[2]))
+    if len(sys.argv) > 3:
+        ops.debug_set_gemm_pipe(int(sys.argv[3]))
+    only_gemm = len(sys.argv) > 4
     dt = torch.bfloat16
     res = []
     shapes = []
@@ -47,6 +50,8 @@ def main():
                         torch_TF=fl / t_t / 1e12, fwd_GBs=byt / t_f / 1e9))
         print(json.dumps(res[-1]))
         del x, w, dy
+    if only_gemm:
+        return
     # attention
     for s, (C, nW, nH) in enumerate([(96, 64, 3), (192, 16, 6), (384, 4, 12), (768, 1, 24)]):
         Bw = 2 * B * nW
