@@ -679,24 +679,27 @@ int launch_gemm_dma(const esvit_gemm_desc& d, hipStream_t stream) {
     return ESVIT_OK;
 }
 
-// pipeline shape: 1 = BK 64, 2 buffers (drain every tile); 3 = BK 64, 3-deep ring; 4 = BK 32, 4-deep ring
-static int g_dma_pipe = 3;
+// pipeline shape (debug switch): 1 = BK64 x 2 buffers (default: 64 KiB -> 2 workgroups/CU); 2 = BK32 x 2 (32 KiB -> 4/CU);
+// 3 = BK64 x 3-deep ring; 4 = BK32 x 4-deep ring; 5 = BK32 x 3-deep ring (48 KiB -> 3/CU)
+static int g_dma_pipe = 1;
+
+template <bool AKS, bool BKS, int BM, int BN>
+int dispatch_pipe(const esvit_gemm_desc& d, hipStream_t stream) {
+    if constexpr (BN != 96) {  // 96-wide tiles are a whole number of DMA instructions only at BK = 64
+        if (g_dma_pipe == 2) return launch_gemm_dma<AKS, BKS, BM, BN, 32, 2>(d, stream);
+        if (g_dma_pipe == 4) return launch_gemm_dma<AKS, BKS, BM, BN, 32, 4>(d, stream);
+        if (g_dma_pipe == 5) return launch_gemm_dma<AKS, BKS, BM, BN, 32, 3>(d, stream);
+    }
+    if (g_dma_pipe >= 3) return launch_gemm_dma<AKS, BKS, BM, BN, 64, 3>(d, stream);
+    return launch_gemm_dma<AKS, BKS, BM, BN, 64, 2>(d, stream);
+}
 
 template <bool AKS, bool BKS>
 int dispatch_tile_dma(const esvit_gemm_desc& d, hipStream_t stream) {
     const bool n96 = (d.N % 96 == 0) && (d.N % 128 != 0);
-    if (n96) {  // 96-wide tiles are only a whole number of DMA instructions at BK = 64
-        if (g_dma_pipe == 1) return launch_gemm_dma<AKS, BKS, 128, 96, 64, 2>(d, stream);
-        return launch_gemm_dma<AKS, BKS, 128, 96, 64, 3>(d, stream);
-    }
-    if (d.N <= 64) {
-        if (g_dma_pipe == 1) return launch_gemm_dma<AKS, BKS, 128, 64, 64, 2>(d, stream);
-        if (g_dma_pipe == 4) return launch_gemm_dma<AKS, BKS, 128, 64, 32, 4>(d, stream);
-        return launch_gemm_dma<AKS, BKS, 128, 64, 64, 3>(d, stream);
-    }
-    if (g_dma_pipe == 1) return launch_gemm_dma<AKS, BKS, 128, 128, 64, 2>(d, stream);
-    if (g_dma_pipe == 4) return launch_gemm_dma<AKS, BKS, 128, 128, 32, 4>(d, stream);
-    return launch_gemm_dma<AKS, BKS, 128, 128, 64, 3>(d, stream);
+    if (n96) return dispatch_pipe<AKS, BKS, 128, 96>(d, stream);
+    if (d.N <= 64) return dispatch_pipe<AKS, BKS, 128, 64>(d, stream);
+    return dispatch_pipe<AKS, BKS, 128, 128>(d, stream);
 }
 
 template <typename T, bool AKS, bool BKS, bool USE_TR>

@@ -42,7 +42,7 @@ def _rand(shape, dev, seed, dt=torch.float32, scale=1.0):
     return (torch.randn(shape, generator=g) * scale).to(dev).to(dt)
 
 
-@pytest.fixture(params=[3, 4, 1, 0], ids=["dma-ring3xBK64", "dma-ring4xBK32", "dma-2buf", "regstage"])
+@pytest.fixture(params=[1, 2, 3, 4, 5, 0], ids=["dma-2xBK64", "dma-2xBK32", "dma-ring3xBK64", "dma-ring4xBK32", "dma-ring3xBK32", "regstage"])
 def gemm_path(request, mods):
     """every GEMM main loop: LDS-DMA rings (buffer_load ... lds + counted vmcnt) and the register-staged BK=32 loop"""
     ops, _ = mods
@@ -51,7 +51,7 @@ def gemm_path(request, mods):
         ops.debug_set_gemm_pipe(request.param)
     yield request.param
     ops.debug_set_gemm_dma(1)
-    ops.debug_set_gemm_pipe(3)
+    ops.debug_set_gemm_pipe(1)
 
 
 @pytest.mark.parametrize("dt", DTYPES)
