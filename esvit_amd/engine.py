@@ -4,6 +4,7 @@ exchange.  ``train_one_epoch`` has the reference's signature (main_esvit.py:499-
 185 x .item() clipping, AdamW, EMA loop) by backward + bucketed RCCL all-reduce + the fused update kernels.
 """
 import math
+import os
 import sys
 
 import torch
@@ -35,7 +36,9 @@ class GradBucketReducer:
         self.group = process_group
         self.world = _world()
         self.params = [p for p in module.parameters() if p.requires_grad]
-        self.enabled = self.world > 1
+        # ESVIT_FORCE_REDUCER=1 exercises the hook/bucket/all-reduce machinery on a single rank (used to validate the
+        # RCCL code path on a 1-GPU box)
+        self.enabled = self.world > 1 or (os.environ.get("ESVIT_FORCE_REDUCER") == "1" and dist.is_initialized())
         self.buckets, self.slot = [], {}
         if not self.enabled:
             return
@@ -59,7 +62,7 @@ class GradBucketReducer:
                 self.slot[id(p)] = (bi, off, p.numel())
                 off += p.numel()
             self.pending.append(len(plist))
-        self._avg = dist.ReduceOp.AVG if dist.get_backend(self.group) == "nccl" else dist.ReduceOp.SUM
+        self._inv_world = torch.full((), 1.0 / self.world, dtype=torch.float32, device=dev)
         for p in self.params:
             p.register_post_accumulate_grad_hook(self._hook)
         self._armed = False
@@ -84,7 +87,7 @@ class GradBucketReducer:
             self._launch(bi)
 
     def _launch(self, bi):
-        h = dist.all_reduce(self.flat[bi], op=self._avg, group=self.group, async_op=True)
+        h = dist.all_reduce(self.flat[bi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         self.handles.append((bi, h))
 
     def finish(self):
@@ -97,8 +100,12 @@ class GradBucketReducer:
                 self._launch(bi)
         for bi, h in self.handles:
             h.wait()
-            if self._avg == dist.ReduceOp.SUM:
-                self.flat[bi].div_(self.world)
+            if self.world > 1:
+                if self.flat[bi].is_cuda:
+                    from . import ops
+                    ops.scale_inplace(self.flat[bi], self._inv_world)  # SUM -> mean
+                else:
+                    self.flat[bi].mul_(self._inv_world)
         self.handles = []
 
 
