@@ -38,7 +38,7 @@ struct AttnCfg {
     static constexpr int VT_ELEMS = HD * LDP;
     static constexpr int R1 = (2 * QK_ELEMS > P_ELEMS) ? 2 * QK_ELEMS : P_ELEMS;  // Q,K overlaid by P
     static constexpr int FWD_PER_WAVE = R1 + VT_ELEMS;
-    static constexpr int BWD_PER_WAVE = 4 * QK_ELEMS + P_ELEMS;
+    static constexpr int BWD_PER_WAVE = 2 * QK_ELEMS + P_ELEMS;
 };
 
 template <typename T>
@@ -51,17 +51,28 @@ __device__ __forceinline__ void store_frag4(T* p, f32x4 v) {
     }
 }
 
-// stage one [N][HD] matrix of the (window, head) slice into a [NP][LDQ] LDS image (rows >= N zero)
+// stage one [N][HD] matrix of the (window, head) slice into a [NP][LDQ] LDS image (rows >= N zero).
+// Rows are window slots; slot t reads token row tok_base + w2t[t] of the token-ordered matrix `g`, or -- for a
+// zero-pad slot (w2t[t] < 0, swin_transformer.py:286-290) -- the constant `pad` (the qkv bias of this head: LN'd
+// zero rows give qkv = bias; nullptr = zeros).  Values are optionally scaled and re-rounded (q * head_dim^-0.5).
 template <typename T>
-__device__ __forceinline__ void stage_rows(const T* __restrict__ g, long row_stride, int N, bool active, float scale,
-                                           T* lds, int lane) {
+__device__ __forceinline__ void stage_rows(const T* __restrict__ g, long row_stride, const int* __restrict__ w2t, long tok_base,
+                                           int N, bool active, float scale, const float* __restrict__ pad, T* lds, int lane) {
     constexpr int VEC = AttnCfg<T>::VEC, LDQ = AttnCfg<T>::LDQ, VPR = HD / VEC;
 #pragma unroll
     for (int i = 0; i < NP * VPR / 64; ++i) {
         const int v = lane + 64 * i;
         const int t = v / VPR, dv = v % VPR;
         Vec16<T> x = zero16<T>();
-        if (active && t < N) x = ld16<T>(g + (long)t * row_stride + dv * VEC);
+        if (active && t < N) {
+            const int tok = w2t[t];
+            if (tok >= 0) {
+                x = ld16<T>(g + (tok_base + tok) * row_stride + dv * VEC);
+            } else if (pad) {
+#pragma unroll
+                for (int e = 0; e < Vec16<T>::N; ++e) x.set(e, pad[dv * VEC + e]);
+            }
+        }
         if (scale != 1.f) {
 #pragma unroll
             for (int e = 0; e < Vec16<T>::N; ++e) x.set(e, x.get(e) * scale);
@@ -128,8 +139,11 @@ __device__ __forceinline__ void store_pt(T* Ps, const f32x4 (&p)[4][4], int c, i
 }
 
 // -------------------------------------------------------------------------------------------------
+// Forward.  One wave per (window, head); qkv / out are TOKEN-ordered: pad -> roll -> window_partition and its
+// inverse (swin_transformer.py:286-325) are the slot->token map `win2tok`, applied on the fly.
 template <typename T>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv, const float* __restrict__ bias_frag,
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv, const float* __restrict__ qkv_bias,
+                                                       const int* __restrict__ win2tok, int L, const float* __restrict__ bias_frag,
                                                        const float* __restrict__ mask_frag, int nW, int Bw, int N, int nH,
                                                        float scale, T* __restrict__ out, float* __restrict__ attn_out) {
     using Cfg = AttnCfg<T>;
@@ -148,18 +162,29 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv
     const int bw = active ? (int)(unit / nH) : 0;
     const int h = active ? (int)(unit % nH) : 0;
     const int C = nH * HD;
-    const T* src = qkv + (long)bw * N * 3 * C + h * HD;
+    const int* w2t = win2tok + (long)(bw % nW) * N;
+    const long tok_base = (long)(bw / nW) * L;
+    const T* src = qkv + h * HD;
 
-    stage_rows<T>(src, 3L * C, N, active, scale, Qs, lane);
-    stage_rows<T>(src + C, 3L * C, N, active, 1.f, Ks, lane);
+    stage_rows<T>(src, 3L * C, w2t, tok_base, N, active, scale, qkv_bias + h * HD, Qs, lane);
+    stage_rows<T>(src + C, 3L * C, w2t, tok_base, N, active, 1.f, qkv_bias + C + h * HD, Ks, lane);
     {  // V transposed: Vt[d][key]
         constexpr int VPR = HD / VEC;
+        const float* padv = qkv_bias + 2 * C + h * HD;
 #pragma unroll
         for (int i = 0; i < NP * VPR / 64; ++i) {
             const int v = lane + 64 * i;
             const int t = v / VPR, dv = v % VPR;
             Vec16<T> x = zero16<T>();
-            if (active && t < N) x = ld16<T>(src + 2 * C + (long)t * 3 * C + dv * VEC);
+            if (active && t < N) {
+                const int tok = w2t[t];
+                if (tok >= 0) {
+                    x = ld16<T>(src + 2 * C + (tok_base + tok) * 3L * C + dv * VEC);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < Vec16<T>::N; ++e) x.set(e, padv[dv * VEC + e]);
+                }
+            }
 #pragma unroll
             for (int e = 0; e < Vec16<T>::N; ++e) Vt[(dv * VEC + e) * LDP + t] = from_f32<T>(x.get(e));
         }
@@ -205,80 +230,135 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv
         }
     }
     if (active) {
-        T* dst = out + (long)bw * N * C + h * HD;
+        T* dst = out + h * HD;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int q = 16 * i + 4 * g + r;
-                if (q < N) {
-                    dst[(long)q * C + c] = from_f32<T>(o[i][0][r]);
-                    dst[(long)q * C + 16 + c] = from_f32<T>(o[i][1][r]);
+                const int tok = q < N ? w2t[q] : -1;
+                if (tok >= 0) {
+                    T* rowp = dst + (tok_base + tok) * (long)C;
+                    rowp[c] = from_f32<T>(o[i][0][r]);
+                    rowp[16 + c] = from_f32<T>(o[i][1][r]);
                 }
             }
     }
 }
 
+// store a [slot][d] result tile (D layout: row = 16i+4g+r, cols c / 16+c) to the token-ordered matrix; rows of
+// zero-pad slots are summed into `pad` (they are gradients of the qkv bias)
+template <typename T>
+__device__ __forceinline__ void store_tok_rows(const f32x4 (&acc)[4][2], float mul, T* __restrict__ dst, long row_stride,
+                                               const int* __restrict__ w2t, long tok_base, int N, bool active, f32x2* pad, int c,
+                                               int g) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int t = 16 * i + 4 * g + r;
+            if (!active || t >= N) continue;
+            const int tok = w2t[t];
+            const float v0 = acc[i][0][r] * mul, v1 = acc[i][1][r] * mul;
+            if (tok >= 0) {
+                T* rowp = dst + (tok_base + tok) * row_stride;
+                rowp[c] = from_f32<T>(v0);
+                rowp[16 + c] = from_f32<T>(v1);
+            } else if (pad) {
+                (*pad)[0] += v0;
+                (*pad)[1] += v1;
+            }
+        }
+}
+
 // -------------------------------------------------------------------------------------------------
-// Backward.  Block = 2 waves; wave `wv` (global) owns head h = wv % nH and the windows
-// bw = wv / nH + k * parts, k = 0,1,...; its bias-gradient partial goes to dbias_ws[wv / nH][h].
+// Backward.  Block = 4 waves; wave `wv` (global) owns head h = wv % nH and the windows bw = wv / nH + k * parts.
+// LDS per wave: two [64][32] operand images (Q,K then V,dO then Q,K again) + the [64][64] P / dS image = 19 KiB,
+// so 8 waves fit a CU.  Partials written once per wave: bias gradient (frag layout) and the dK/dV sums of zero-pad
+// slots.
 template <typename T, bool USE_TR>
-__global__ __launch_bounds__(128) void attn_bwd_kernel(const T* __restrict__ qkv, const T* __restrict__ dout,
-                                                       const float* __restrict__ bias_frag,
-                                                       const float* __restrict__ mask_frag, int nW, int Bw, int N, int nH,
-                                                       float scale, int parts, T* __restrict__ dqkv,
-                                                       float* __restrict__ dbias_ws) {
+__global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const T* __restrict__ qkv, const float* __restrict__ qkv_bias,
+                                                          const int* __restrict__ win2tok, int L, const T* __restrict__ dout,
+                                                          const float* __restrict__ bias_frag, const float* __restrict__ mask_frag,
+                                                          int nW, int Bw, int N, int nH, float scale, int parts,
+                                                          T* __restrict__ dqkv, float* __restrict__ dbias_ws,
+                                                          float* __restrict__ dpad_ws) {
     using Cfg = AttnCfg<T>;
     constexpr int LDQ = Cfg::LDQ, LDP = Cfg::LDP;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane & 15, g = lane >> 4;
     T* base = reinterpret_cast<T*>(smem_raw) + wave * Cfg::BWD_PER_WAVE;
-    T* Qs = base;
-    T* Ks = base + Cfg::QK_ELEMS;
-    T* Vs = base + 2 * Cfg::QK_ELEMS;
-    T* Os = base + 3 * Cfg::QK_ELEMS;  // dO
-    T* Ps = base + 4 * Cfg::QK_ELEMS;  // P, then dS  ([q][key])
+    T* bufA = base;                      // scale*Q, then V, then scale*Q
+    T* bufB = base + Cfg::QK_ELEMS;      // K, then dO, then K
+    T* Ps = base + 2 * Cfg::QK_ELEMS;    // P, then dS  ([q][key])
 
-    const long wv = (long)blockIdx.x * 2 + wave;
+    const long wv = (long)blockIdx.x * 4 + wave;
     const bool wave_ok = wv < (long)parts * nH;
     const int h = (int)(wv % nH);
     const int part = (int)(wv / nH);
     const int C = nH * HD;
     const float* bias_f = bias_frag + (long)h * FRAG_ELEMS;
+    const T* src = qkv + h * HD;
+    T* dst = dqkv + h * HD;
 
     f32x4 db[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) db[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x2 padk = {0.f, 0.f}, padv = {0.f, 0.f};
 
     const int iters = (Bw + parts - 1) / parts;
     for (int it = 0; it < iters; ++it) {
         const int bw = part + it * parts;
         const bool active = wave_ok && bw < Bw;
         const int bwc = active ? bw : 0;
-        const T* src = qkv + (long)bwc * N * 3 * C + h * HD;
-        __syncthreads();  // previous iteration's LDS reads are complete
-        stage_rows<T>(src, 3L * C, N, active, scale, Qs, lane);
-        stage_rows<T>(src + C, 3L * C, N, active, 1.f, Ks, lane);
-        stage_rows<T>(src + 2 * C, 3L * C, N, active, 1.f, Vs, lane);
-        stage_rows<T>(dout + (long)bwc * N * C + h * HD, (long)C, N, active, 1.f, Os, lane);
-        __syncthreads();
-
-        f32x4 p[4][4];
+        const int* w2t = win2tok + (long)(bwc % nW) * N;
+        const long tok_base = (long)(bwc / nW) * L;
         const float* mask_f = mask_frag ? mask_frag + (long)(bwc % nW) * FRAG_ELEMS : nullptr;
-        scores_softmax<T>(Qs, Ks, bias_f, mask_f, lane, c, g, p);
-        store_pt<T>(Ps, p, c, g);
 
-        // dP^T = V dO^T  (same fragment positions as p)
+        // ---- phase 1: P = softmax(scale q k^T + bias + mask) ----
+        __syncthreads();  // previous iteration's reads of bufA/bufB/Ps are complete
+        stage_rows<T>(src, 3L * C, w2t, tok_base, N, active, scale, qkv_bias + h * HD, bufA, lane);
+        stage_rows<T>(src + C, 3L * C, w2t, tok_base, N, active, 1.f, qkv_bias + C + h * HD, bufB, lane);
+        __syncthreads();
+        f32x4 p[4][4];
+        scores_softmax<T>(bufA, bufB, bias_f, mask_f, lane, c, g, p);
+        store_pt<T>(Ps, p, c, g);
+        __syncthreads();  // score reads of bufA/bufB done; Ps visible
+
+        // ---- phase 2: dV = P^T dO;  dP^T = V dO^T;  dS = P o (dP - delta) ----
+        stage_rows<T>(src + 2 * C, 3L * C, w2t, tok_base, N, active, 1.f, qkv_bias + 2 * C + h * HD, bufA, lane);
+        stage_rows<T>(dout + h * HD, (long)C, w2t, tok_base, N, active, 1.f, nullptr, bufB, lane);
+        __syncthreads();
+        {
+            f32x4 acc[4][2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                acc[i][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+                acc[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const Frag<T> b0 = frag_ks<T, USE_TR>(bufB, LDQ, 0, 32 * ks, c, g);
+                const Frag<T> b1 = frag_ks<T, USE_TR>(bufB, LDQ, 16, 32 * ks, c, g);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const Frag<T> a = frag_ks<T, USE_TR>(Ps, LDP, 16 * i, 32 * ks, c, g);
+                    mma(a, b0, acc[i][0]);
+                    mma(a, b1, acc[i][1]);
+                }
+            }
+            store_tok_rows<T>(acc, 1.f, dst + 2 * C, 3L * C, w2t, tok_base, N, active, &padv, c, g);
+        }
         f32x4 dp[4][4];
         {
             Frag<T> vf[4], of[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                vf[i] = frag_kc<T>(Vs, LDQ, 16 * i, 0, c, g);
-                of[i] = frag_kc<T>(Os, LDQ, 16 * i, 0, c, g);
+                vf[i] = frag_kc<T>(bufA, LDQ, 16 * i, 0, c, g);
+                of[i] = frag_kc<T>(bufB, LDQ, 16 * i, 0, c, g);
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i)
@@ -288,7 +368,6 @@ __global__ __launch_bounds__(128) void attn_bwd_kernel(const T* __restrict__ qkv
                     mma(vf[i], of[j], dp[i][j]);
                 }
         }
-        // dS = P o (dP - delta_q)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             float d = 0.f;
@@ -304,47 +383,13 @@ __global__ __launch_bounds__(128) void attn_bwd_kernel(const T* __restrict__ qkv
                 if (active) db[i][j] += dp[i][j];
             }
         }
-        __syncthreads();  // Ps (= P) written by all lanes
+        __syncthreads();  // reads of Ps (= P), bufA (= V), bufB (= dO) are complete
 
-        // dV[key][d] = sum_q P[q][key] dO[q][d]: A = P^T via k-strided read of Ps, B = dO k-strided
-        T* dst = dqkv + (long)bwc * N * 3 * C + h * HD;
-        {
-            f32x4 acc[4][2];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                acc[i][0] = f32x4{0.f, 0.f, 0.f, 0.f};
-                acc[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-            }
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                const Frag<T> b0 = frag_ks<T, USE_TR>(Os, LDQ, 0, 32 * ks, c, g);
-                const Frag<T> b1 = frag_ks<T, USE_TR>(Os, LDQ, 16, 32 * ks, c, g);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const Frag<T> a = frag_ks<T, USE_TR>(Ps, LDP, 16 * i, 32 * ks, c, g);
-                    mma(a, b0, acc[i][0]);
-                    mma(a, b1, acc[i][1]);
-                }
-            }
-            if (active) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int key = 16 * i + 4 * g + r;
-                        if (key < N) {
-                            dst[(long)key * 3 * C + 2 * C + c] = from_f32<T>(acc[i][0][r]);
-                            dst[(long)key * 3 * C + 2 * C + 16 + c] = from_f32<T>(acc[i][1][r]);
-                        }
-                    }
-            }
-        }
-        __syncthreads();  // reads of P complete
-        store_pt<T>(Ps, dp, c, g);  // dS as [q][key]
+        // ---- phase 3: dQ = scale * dS K;  dK = dS^T (scale q) ----
+        store_pt<T>(Ps, dp, c, g);
+        stage_rows<T>(src, 3L * C, w2t, tok_base, N, active, scale, qkv_bias + h * HD, bufA, lane);
+        stage_rows<T>(src + C, 3L * C, w2t, tok_base, N, active, 1.f, qkv_bias + C + h * HD, bufB, lane);
         __syncthreads();
-
-        // dQ[q][d] = scale * sum_key dS[q][key] K[key][d]: A = dS k-contiguous, B = K k-strided
-        // dK[key][d] = sum_q dS[q][key] Qs[q][d] (Qs already holds scale*q): A = dS^T k-strided, B = Qs k-strided
         {
             f32x4 aq[4][2], ak[4][2];
 #pragma unroll
@@ -356,10 +401,10 @@ __global__ __launch_bounds__(128) void attn_bwd_kernel(const T* __restrict__ qkv
             }
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                const Frag<T> kb0 = frag_ks<T, USE_TR>(Ks, LDQ, 0, 32 * ks, c, g);
-                const Frag<T> kb1 = frag_ks<T, USE_TR>(Ks, LDQ, 16, 32 * ks, c, g);
-                const Frag<T> qb0 = frag_ks<T, USE_TR>(Qs, LDQ, 0, 32 * ks, c, g);
-                const Frag<T> qb1 = frag_ks<T, USE_TR>(Qs, LDQ, 16, 32 * ks, c, g);
+                const Frag<T> kb0 = frag_ks<T, USE_TR>(bufB, LDQ, 0, 32 * ks, c, g);
+                const Frag<T> kb1 = frag_ks<T, USE_TR>(bufB, LDQ, 16, 32 * ks, c, g);
+                const Frag<T> qb0 = frag_ks<T, USE_TR>(bufA, LDQ, 0, 32 * ks, c, g);
+                const Frag<T> qb1 = frag_ks<T, USE_TR>(bufA, LDQ, 16, 32 * ks, c, g);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const Frag<T> a = frag_kc<T>(Ps, LDP, 16 * i, 32 * ks, c, g);
@@ -370,28 +415,29 @@ __global__ __launch_bounds__(128) void attn_bwd_kernel(const T* __restrict__ qkv
                     mma(at, qb1, ak[i][1]);
                 }
             }
-            if (active) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int t = 16 * i + 4 * g + r;
-                        if (t < N) {
-                            dst[(long)t * 3 * C + c] = from_f32<T>(aq[i][0][r] * scale);
-                            dst[(long)t * 3 * C + 16 + c] = from_f32<T>(aq[i][1][r] * scale);
-                            dst[(long)t * 3 * C + C + c] = from_f32<T>(ak[i][0][r]);
-                            dst[(long)t * 3 * C + C + 16 + c] = from_f32<T>(ak[i][1][r]);
-                        }
-                    }
-            }
+            // dQ of a zero-pad slot is exactly 0 (its dO row is 0), so only dK needs the pad accumulator
+            store_tok_rows<T>(aq, scale, dst, 3L * C, w2t, tok_base, N, active, nullptr, c, g);
+            store_tok_rows<T>(ak, 1.f, dst + C, 3L * C, w2t, tok_base, N, active, &padk, c, g);
         }
     }
+    // column c (and 16+c) sums over this lane's rows -> reduce the 4 row groups g
+    padk[0] += __shfl_xor(padk[0], 16, 64); padk[0] += __shfl_xor(padk[0], 32, 64);
+    padk[1] += __shfl_xor(padk[1], 16, 64); padk[1] += __shfl_xor(padk[1], 32, 64);
+    padv[0] += __shfl_xor(padv[0], 16, 64); padv[0] += __shfl_xor(padv[0], 32, 64);
+    padv[1] += __shfl_xor(padv[1], 16, 64); padv[1] += __shfl_xor(padv[1], 32, 64);
     if (wave_ok) {
         float* ws = dbias_ws + ((long)part * nH + h) * FRAG_ELEMS;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(ws + ((i * 4 + j) * 64 + lane) * 4) = db[i][j];
+        if (g == 0) {
+            float* pw = dpad_ws + (long)part * 2 * C + h * HD;  // [k | v][nH][hd]
+            pw[c] = padk[0];
+            pw[16 + c] = padk[1];
+            pw[C + c] = padv[0];
+            pw[C + 16 + c] = padv[1];
+        }
     }
 }
 
@@ -492,29 +538,31 @@ extern "C" int esvit_relpos_bias_bwd(const float* dbias_ws, int parts, const int
 static int g_attn_use_tr = 1;
 extern "C" void esvit_debug_set_attn_tr_read(int on) { g_attn_use_tr = on; }
 
-extern "C" int esvit_window_attn_fwd(int dtype, const void* qkv, const float* bias_frag, const float* mask_frag, int nW, int Bw,
-                                     int N, int nH, int hd, float scale, void* out, float* attn_out, esvit_stream_t s_) {
+extern "C" int esvit_window_attn_fwd(int dtype, const void* qkv, const float* qkv_bias, const int32_t* win2tok, int L,
+                                     const float* bias_frag, const float* mask_frag, int nW, int nB, int N, int nH, int hd,
+                                     float scale, void* out, float* attn_out, esvit_stream_t s_) {
     STREAM(s_);
-    ESVIT_CHECK_ARG(qkv && bias_frag && out && Bw > 0 && nH > 0, "esvit_window_attn_fwd: bad args");
+    ESVIT_CHECK_ARG(qkv && qkv_bias && win2tok && bias_frag && out && nB > 0 && nW > 0 && nH > 0 && L > 0,
+                    "esvit_window_attn_fwd: bad args");
     ESVIT_CHECK_ARG(hd == HD, "esvit_window_attn_fwd: head_dim %d unsupported (32 only)", hd);
     if (N > NP) {
         esvit_set_error("esvit_window_attn_fwd: N=%d > %d (14x14 windows) not built yet", N, NP);
         return ESVIT_ERR_UNSUPPORTED;
     }
-    if (mask_frag) ESVIT_CHECK_ARG(nW > 0 && Bw % nW == 0, "esvit_window_attn_fwd: Bw must be a multiple of nW");
+    const int Bw = nB * nW;
     const int grid = ceil_div((long)Bw * nH, 4);
     if (dtype == ESVIT_BF16) {
         const size_t lds = 4 * (size_t)AttnCfg<bf16>::FWD_PER_WAVE * sizeof(bf16);
         auto kern = attn_fwd_kernel<bf16>;
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, (const bf16*)qkv, bias_frag, mask_frag, nW, Bw, N, nH, scale,
-                           (bf16*)out, attn_out);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, (const bf16*)qkv, qkv_bias, win2tok, L, bias_frag, mask_frag, nW,
+                           Bw, N, nH, scale, (bf16*)out, attn_out);
     } else if (dtype == ESVIT_F32) {
         const size_t lds = 4 * (size_t)AttnCfg<float>::FWD_PER_WAVE * sizeof(float);
         auto kern = attn_fwd_kernel<float>;
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, (const float*)qkv, bias_frag, mask_frag, nW, Bw, N, nH, scale,
-                           (float*)out, attn_out);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, (const float*)qkv, qkv_bias, win2tok, L, bias_frag, mask_frag, nW,
+                           Bw, N, nH, scale, (float*)out, attn_out);
     } else {
         esvit_set_error("esvit_window_attn_fwd: bad dtype");
         return ESVIT_ERR_ARG;
@@ -525,42 +573,37 @@ extern "C" int esvit_window_attn_fwd(int dtype, const void* qkv, const float* bi
 
 extern "C" int esvit_window_attn_bwd_parts(int Bw, int nH) { return bwd_parts(Bw, nH); }
 
-extern "C" int esvit_window_attn_bwd(int dtype, const void* qkv, const void* dout, const float* bias_frag, const float* mask_frag,
-                                     int nW, int Bw, int N, int nH, int hd, float scale, void* dqkv, float* dbias_ws,
-                                     esvit_stream_t s_) {
+extern "C" int esvit_window_attn_bwd(int dtype, const void* qkv, const float* qkv_bias, const int32_t* win2tok, int L,
+                                     const void* dout, const float* bias_frag, const float* mask_frag, int nW, int nB, int N, int nH,
+                                     int hd, float scale, void* dqkv, float* dbias_ws, float* dpad_ws, esvit_stream_t s_) {
     STREAM(s_);
-    ESVIT_CHECK_ARG(qkv && dout && bias_frag && dqkv && dbias_ws && Bw > 0 && nH > 0, "esvit_window_attn_bwd: bad args");
+    ESVIT_CHECK_ARG(qkv && qkv_bias && win2tok && dout && bias_frag && dqkv && dbias_ws && dpad_ws && nB > 0 && nW > 0 && nH > 0 && L > 0,
+                    "esvit_window_attn_bwd: bad args");
     ESVIT_CHECK_ARG(hd == HD, "esvit_window_attn_bwd: head_dim %d unsupported (32 only)", hd);
     if (N > NP) {
         esvit_set_error("esvit_window_attn_bwd: N=%d > %d (14x14 windows) not built yet", N, NP);
         return ESVIT_ERR_UNSUPPORTED;
     }
-    if (mask_frag) ESVIT_CHECK_ARG(nW > 0 && Bw % nW == 0, "esvit_window_attn_bwd: Bw must be a multiple of nW");
+    const int Bw = nB * nW;
     const int parts = bwd_parts(Bw, nH);
-    const int grid = ceil_div((long)parts * nH, 2);
+    const int grid = ceil_div((long)parts * nH, 4);
+#define LAUNCH_BWD(TT, TR)                                                                                                      \
+    {                                                                                                                           \
+        const size_t lds = 4 * (size_t)AttnCfg<TT>::BWD_PER_WAVE * sizeof(TT);                                                  \
+        auto kern = attn_bwd_kernel<TT, TR>;                                                                                    \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);   \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, (const TT*)qkv, qkv_bias, win2tok, L, (const TT*)dout,      \
+                           bias_frag, mask_frag, nW, Bw, N, nH, scale, parts, (TT*)dqkv, dbias_ws, dpad_ws);                    \
+    }
     if (dtype == ESVIT_BF16) {
-        const size_t lds = 2 * (size_t)AttnCfg<bf16>::BWD_PER_WAVE * sizeof(bf16);
-        if (g_attn_use_tr) {
-            auto kern = attn_bwd_kernel<bf16, true>;
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL(kern, dim3(grid), dim3(128), lds, stream, (const bf16*)qkv, (const bf16*)dout, bias_frag, mask_frag, nW,
-                               Bw, N, nH, scale, parts, (bf16*)dqkv, dbias_ws);
-        } else {
-            auto kern = attn_bwd_kernel<bf16, false>;
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL(kern, dim3(grid), dim3(128), lds, stream, (const bf16*)qkv, (const bf16*)dout, bias_frag, mask_frag, nW,
-                               Bw, N, nH, scale, parts, (bf16*)dqkv, dbias_ws);
-        }
+        if (g_attn_use_tr) LAUNCH_BWD(bf16, true) else LAUNCH_BWD(bf16, false)
     } else if (dtype == ESVIT_F32) {
-        const size_t lds = 2 * (size_t)AttnCfg<float>::BWD_PER_WAVE * sizeof(float);
-        auto kern = attn_bwd_kernel<float, false>;
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(128), lds, stream, (const float*)qkv, (const float*)dout, bias_frag, mask_frag, nW,
-                           Bw, N, nH, scale, parts, (float*)dqkv, dbias_ws);
+        LAUNCH_BWD(float, false)
     } else {
         esvit_set_error("esvit_window_attn_bwd: bad dtype");
         return ESVIT_ERR_ARG;
     }
+#undef LAUNCH_BWD
     ESVIT_CHECK_LAUNCH("window_attn_bwd");
     return ESVIT_OK;
 }

@@ -79,15 +79,15 @@ def _block_forward(x, geom, nH, index, dp, prm, wts, save):
     (Wqkv, Wproj, W1, W2) = wts
     nB, L, C = x.shape
     x2d = x.view(nB * L, C)
-    Mw = nB * geom.period
     scale = (C // nH) ** -0.5
     dp1, dp2 = (None, None) if dp is None else dp
-    xw, _, mean1, rstd1 = o.layernorm_fwd(x2d, g1, b1, LN_EPS, rowmap=geom.tok2win, period_out=geom.period, out_rows=Mw)
+    # everything stays in token order: the attention kernel applies pad/roll/partition through geom.win2tok and
+    # injects the qkv bias at zero-pad slots, so no GEMM ever runs on pad rows
+    xw, _, mean1, rstd1 = o.layernorm_fwd(x2d, g1, b1, LN_EPS)
     qkv = o.linear_fwd(xw, Wqkv, bqkv)
     bias_frag = o.relpos_bias_fwd(table, index, geom.N)
-    ao = o.window_attn_fwd(qkv, bias_frag, geom.mask_frag, geom.nW, geom.N, nH, scale)
-    x1 = o.linear_fwd(ao, Wproj, bproj, residual=x2d, rowmap=geom.win2tok, rowmap_tokens=L, out_rows=nB * L,
-                      rowscale=dp1, rows_per_sample=L, out_f32=True)
+    ao = o.window_attn_fwd(qkv, bqkv, geom.win2tok, L, bias_frag, geom.mask_frag, geom.nW, geom.N, nH, scale)
+    x1 = o.linear_fwd(ao, Wproj, bproj, residual=x2d, rowscale=dp1, rows_per_sample=L, out_f32=True)
     h, _, mean2, rstd2 = o.layernorm_fwd(x1, g2, b2, LN_EPS)
     if save:
         a1g, a1 = o.linear_fwd(h, W1, bfc1, gelu=True, want_preact=True)
@@ -105,17 +105,17 @@ class SwinBlockFn(torch.autograd.Function):
         x = x.contiguous()
         y, saved = _block_forward(x, geom, nH, index, dp, (g1, b1, table, bqkv, bproj, g2, b2, bfc1, bfc2), wts, True)
         ctx.geom, ctx.nH, ctx.dp = geom, nH, dp
-        ctx.save_for_backward(x, index, g1, table, g2, *wts, *saved)
+        ctx.save_for_backward(x, index, g1, table, g2, bqkv, *wts, *saved)
         return y
 
     @staticmethod
     def backward(ctx, gy):
         o = ops_module()
         geom, nH, dp = ctx.geom, ctx.nH, ctx.dp
-        (x, index, g1, table, g2, Wqkv, Wproj, W1, W2, mean1, rstd1, xw, qkv, bias_frag, ao, x1, mean2, rstd2, h, a1,
+        (x, index, g1, table, g2, bqkv, Wqkv, Wproj, W1, W2, mean1, rstd1, xw, qkv, bias_frag, ao, x1, mean2, rstd2, h, a1,
          a1g) = ctx.saved_tensors
         nB, L, C = x.shape
-        M, Mw = nB * L, nB * geom.period
+        M = nB * L
         scale = (C // nH) ** -0.5
         dp1, dp2 = (None, None) if dp is None else dp
         gy = gy.contiguous().view(M, C)
@@ -127,14 +127,16 @@ class SwinBlockFn(torch.autograd.Function):
         dh = o.linear_dgrad(da1, W1)
         gx1, dg2, db2 = o.layernorm_bwd(dh, x1, mean2, rstd2, g2, g_in=gy)
         # ---- attention branch ----
-        dyw = o.gather_cast(gx1, Mw, rowmap=geom.win2tok, tokens=L, rowscale=dp1, rows_per_sample=L)
+        dyw = o.gather_cast(gx1, M, rowscale=dp1, rows_per_sample=L)
         dWproj, dbproj = o.linear_wgrad(dyw, ao, want_bias=True)
         dao = o.linear_dgrad(dyw, Wproj)
-        dqkv, dbias_ws = o.window_attn_bwd(qkv, dao, bias_frag, geom.mask_frag, geom.nW, geom.N, nH, scale)
+        dqkv, dbias_ws, dpad_ws = o.window_attn_bwd(qkv, bqkv, geom.win2tok, L, dao, bias_frag, geom.mask_frag, geom.nW, geom.N,
+                                                    nH, scale)
         dtable = o.relpos_bias_bwd(dbias_ws, index, geom.N, table.shape[0])
         dWqkv, dbqkv = o.linear_wgrad(dqkv, xw, want_bias=True)
+        o.colsum(dpad_ws, out=dbqkv[C:], accumulate=True)  # k/v bias gradient from the zero-pad slots
         dxw = o.linear_dgrad(dqkv, Wqkv)
-        gx, dg1, db1 = o.layernorm_bwd(dxw, x.view(M, C), mean1, rstd1, g1, g_in=gx1, rowmap=geom.tok2win, period_in=geom.period)
+        gx, dg1, db1 = o.layernorm_bwd(dxw, x.view(M, C), mean1, rstd1, g1, g_in=gx1)
         return (gx.view(nB, L, C), None, None, None, None, dg1, db1, dtable, dWqkv, dbqkv, dWproj, dbproj, dg2, db2, dW1, dbfc1,
                 dW2, dbfc2)
 
@@ -155,10 +157,11 @@ def swin_block_attention(x, geom, nH, index, prm_list):
     g1, b1, table, Wqkv, bqkv, Wproj, bproj, g2, b2, W1, bfc1, W2, bfc2 = prm_list
     nB, L, C = x.shape
     x2d = x.contiguous().view(nB * L, C)
-    xw, _, _, _ = o.layernorm_fwd(x2d, g1, b1, LN_EPS, rowmap=geom.tok2win, period_out=geom.period, out_rows=nB * geom.period)
+    xw, _, _, _ = o.layernorm_fwd(x2d, g1, b1, LN_EPS)
     qkv = o.linear_fwd(xw, _weight(Wqkv), bqkv)
     bias_frag = o.relpos_bias_fwd(table, index, geom.N)
-    _, attn = o.window_attn_fwd(qkv, bias_frag, geom.mask_frag, geom.nW, geom.N, nH, (C // nH) ** -0.5, want_attn=True)
+    _, attn = o.window_attn_fwd(qkv, bqkv, geom.win2tok, L, bias_frag, geom.mask_frag, geom.nW, geom.N, nH, (C // nH) ** -0.5,
+                                want_attn=True)
     return attn
 
 

@@ -154,19 +154,25 @@ int esvit_relpos_bias_fwd(const float* table, const int64_t* index, int N, int n
 /* dense fp32 [n_mats, N, N] -> frag layout [n_mats, frag] (zero padded); used once per geometry
  * for the shift mask of swin_transformer.py:249-272. */
 int esvit_dense_to_frag(const float* dense, int n_mats, int N, float* frag, esvit_stream_t stream);
-/* qkv dtype [Bw*N, 3C] (row = window slot; columns [3][nH][hd]) -> out dtype [Bw*N, C].
- * mask_frag fp32 [nW, frag] or NULL (window w uses mask w % nW); scale = hd^-0.5 applied to q
- * before the product (swin_transformer.py:130).  N = ws*ws = 49, hd = 32.
- * attn_out (optional, fp32 [Bw,nH,N,N]) receives the softmax (swin_transformer.py:146,152). */
-int esvit_window_attn_fwd(int dtype, const void* qkv, const float* bias_frag, const float* mask_frag,
-                          int nW, int Bw, int N, int nH, int hd, float scale, void* out,
-                          float* attn_out, esvit_stream_t stream);
-/* dout dtype [Bw*N, C] -> dqkv dtype [Bw*N, 3C]; dbias_ws fp32 [parts, nH, frag] receives
- * per-wave partial bias gradients, parts = esvit_window_attn_bwd_parts(Bw, nH). */
+/* Token-ordered window attention.  qkv dtype [nB*L, 3C] (columns [3][nH][hd]) -> out dtype [nB*L, C].
+ * win2tok int32 [nW*N] (esvit_window_maps): window slot -> token of the image, -1 for a zero-pad slot; this map
+ * IS pad -> roll -> window_partition and its inverse (swin_transformer.py:286-325), applied on the fly.
+ * qkv_bias fp32 [3C]: the value of q,k,v at a zero-pad slot (LayerNorm output is zero-padded, so qkv = bias there;
+ * pad keys/values take part in every softmax exactly as in the reference, pad query rows are dropped).
+ * mask_frag fp32 [nW, frag] or NULL; scale = hd^-0.5 applied to q before the product (swin_transformer.py:130).
+ * N = ws*ws = 49, hd = 32.  attn_out (optional, fp32 [nB*nW,nH,N,N]) receives the softmax (swin_transformer.py:146,152). */
+int esvit_window_attn_fwd(int dtype, const void* qkv, const float* qkv_bias, const int32_t* win2tok, int L,
+                          const float* bias_frag, const float* mask_frag, int nW, int nB, int N, int nH, int hd,
+                          float scale, void* out, float* attn_out, esvit_stream_t stream);
+/* dout dtype [nB*L, C] -> dqkv dtype [nB*L, 3C] (every row written).  Per-wave partials, parts =
+ * esvit_window_attn_bwd_parts(nB*nW, nH): dbias_ws fp32 [parts, nH, frag] (relative-position-bias gradient) and
+ * dpad_ws fp32 [parts, 2C] = sums of the dK / dV rows of zero-pad slots, layout [k|v][nH][hd] -- they are
+ * gradients of qkv_bias[C:3C]. */
 int esvit_window_attn_bwd_parts(int Bw, int nH);
-int esvit_window_attn_bwd(int dtype, const void* qkv, const void* dout, const float* bias_frag,
-                          const float* mask_frag, int nW, int Bw, int N, int nH, int hd, float scale,
-                          void* dqkv, float* dbias_ws, esvit_stream_t stream);
+int esvit_window_attn_bwd(int dtype, const void* qkv, const float* qkv_bias, const int32_t* win2tok, int L,
+                          const void* dout, const float* bias_frag, const float* mask_frag, int nW, int nB, int N,
+                          int nH, int hd, float scale, void* dqkv, float* dbias_ws, float* dpad_ws,
+                          esvit_stream_t stream);
 /* dtable fp32 [table_rows, nH] (overwritten) = scatter-add over index of sum_parts dbias_ws */
 int esvit_relpos_bias_bwd(const float* dbias_ws, int parts, const int64_t* index, int N, int nH,
                           int table_rows, float* dtable, esvit_stream_t stream);

@@ -325,13 +325,24 @@ def dense_to_frag(dense):
     return _frag_from_dense(dense, 0.0)
 
 
-def _attn_core(qkv, bias_frag, mask_frag, nW, N, nH, scale):
-    rows, C3 = qkv.shape
+def _to_windows(x, fill, win2tok, L, nW, N):
+    """token-ordered [nB*L, D] -> window-ordered [nB*nW*N, D]; zero-pad slots take the row `fill` ([D])"""
+    nB = x.shape[0] // L
+    w2t = win2tok.long().view(1, nW * N)
+    idx = (torch.arange(nB, device=x.device).view(nB, 1) * L + w2t.clamp(min=0)).reshape(-1)
+    xw = x[idx].clone()
+    pad = (w2t < 0).expand(nB, -1).reshape(-1)
+    xw[pad] = fill.to(x.dtype)
+    return xw, pad
+
+
+def _attn_core(qkvw, bias_frag, mask_frag, nW, N, nH, scale):
+    rows, C3 = qkvw.shape
     C = C3 // 3
     hd = C // nH
     Bw = rows // N
-    dt = qkv.dtype
-    x = qkv.float().view(Bw, N, 3, nH, hd).permute(2, 0, 3, 1, 4)
+    dt = qkvw.dtype
+    x = qkvw.float().view(Bw, N, 3, nH, hd).permute(2, 0, 3, 1, 4)
     q = _r(x[0] * scale, dt).float()  # kernel rounds scale*q to the activation dtype in LDS
     k, v = x[1], x[2]
     s = q @ k.transpose(-2, -1) + _dense_from_frag(bias_frag, N).unsqueeze(0)
@@ -342,20 +353,29 @@ def _attn_core(qkv, bias_frag, mask_frag, nW, N, nH, scale):
     return q, k, v, p
 
 
-def window_attn_fwd(qkv, bias_frag, mask_frag, nW, N, nH, scale, want_attn=False):
-    q, k, v, p = _attn_core(qkv, bias_frag, mask_frag, nW, N, nH, scale)
+def window_attn_fwd(qkv, qkv_bias, win2tok, L, bias_frag, mask_frag, nW, N, nH, scale, want_attn=False):
+    C = qkv.shape[1] // 3
+    qkvw, pad = _to_windows(qkv, _r(qkv_bias, qkv.dtype), win2tok, L, nW, N)
+    q, k, v, p = _attn_core(qkvw, bias_frag, mask_frag, nW, N, nH, scale)
     pr = _r(p, qkv.dtype).float()  # P is rounded to the activation dtype before P@V
-    o = (pr @ v).transpose(1, 2).reshape(qkv.shape[0], -1)
-    o = _r(o, qkv.dtype)
-    return (o, p) if want_attn else o
+    ow = (pr @ v).transpose(1, 2).reshape(qkvw.shape[0], C)
+    nB = qkv.shape[0] // L
+    idx = (torch.arange(nB, device=qkv.device).view(nB, 1) * L + win2tok.long().view(1, -1).clamp(min=0)).reshape(-1)
+    out = torch.zeros((qkv.shape[0], C), dtype=torch.float32, device=qkv.device)
+    out[idx[~pad]] = ow[~pad]
+    out = _r(out, qkv.dtype)
+    return (out, p) if want_attn else out
 
 
-def window_attn_bwd(qkv, dout, bias_frag, mask_frag, nW, N, nH, scale):
-    q, k, v, p = _attn_core(qkv, bias_frag, mask_frag, nW, N, nH, scale)
+def window_attn_bwd(qkv, qkv_bias, win2tok, L, dout, bias_frag, mask_frag, nW, N, nH, scale):
+    C = qkv.shape[1] // 3
     dt = qkv.dtype
-    Bw = qkv.shape[0] // N
+    qkvw, pad = _to_windows(qkv, _r(qkv_bias, dt), win2tok, L, nW, N)
+    dow, _ = _to_windows(dout, torch.zeros(C, device=qkv.device), win2tok, L, nW, N)
+    q, k, v, p = _attn_core(qkvw, bias_frag, mask_frag, nW, N, nH, scale)
+    Bw = qkvw.shape[0] // N
     hd = q.shape[-1]
-    do = dout.float().view(Bw, N, nH, hd).permute(0, 2, 1, 3)
+    do = dow.float().view(Bw, N, nH, hd).permute(0, 2, 1, 3)
     pr = _r(p, dt).float()
     dv = pr.transpose(-2, -1) @ do
     dp = do @ v.transpose(-2, -1)
@@ -363,10 +383,15 @@ def window_attn_bwd(qkv, dout, bias_frag, mask_frag, nW, N, nH, scale):
     dsr = _r(ds, dt).float()
     dq = (dsr @ k) * scale
     dk = dsr.transpose(-2, -1) @ q
-    dqkv = torch.stack([dq, dk, dv], 0).permute(1, 3, 0, 2, 4).reshape(qkv.shape)
+    dqkvw = torch.stack([dq, dk, dv], 0).permute(1, 3, 0, 2, 4).reshape(qkvw.shape)  # [Bw*N, 3C] fp32
+    nB = qkv.shape[0] // L
+    idx = (torch.arange(nB, device=qkv.device).view(nB, 1) * L + win2tok.long().view(1, -1).clamp(min=0)).reshape(-1)
+    dqkv = torch.zeros(qkv.shape, dtype=torch.float32, device=qkv.device)
+    dqkv[idx[~pad]] = dqkvw[~pad]
+    dpad = dqkvw[pad][:, C:].sum(0, keepdim=True) if pad.any() else torch.zeros((1, 2 * C), device=qkv.device)
     dbias = ds.sum(0)  # [nH, N, N]
     ws = _frag_from_dense(dbias, 0.0).unsqueeze(0)  # parts = 1
-    return _r(dqkv, dt), ws
+    return _r(dqkv, dt), ws, dpad
 
 
 def relpos_bias_bwd(dbias_ws, index, N, table_rows):

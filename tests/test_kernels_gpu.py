@@ -233,41 +233,49 @@ def test_small_ops(mods, dt):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
-@pytest.mark.parametrize("nH,nW,shifted", [(3, 4, True), (6, 1, False), (12, 1, True), (24, 1, False)])
-def test_window_attention(mods, dt, nH, nW, shifted):
+@pytest.mark.parametrize("nH,H,shift", [(3, 14, 3), (3, 12, 3), (6, 12, 0), (12, 6, 3), (24, 3, 0), (6, 7, 0)])
+def test_window_attention(mods, dt, nH, H, shift):
+    """token-ordered attention over every padded / shifted geometry class of 224 and 96 crops (H = 12, 6, 3 need padding)"""
     ops, ref = mods
     dev = _dev()
     ws, N, hd = 7, 49, 32
     C = nH * hd
-    Bw = nW * 3
-    qkv = _rand((Bw * N, 3 * C), dev, 50, dt)
+    nB, L = 3, H * H
+    win2tok_np, _ = ops.window_maps(H, H, ws, shift)
+    w2t = torch.from_numpy(win2tok_np).to(dev)
+    nW = w2t.numel() // N
+    qkv = _rand((nB * L, 3 * C), dev, 50, dt)
+    qb = _rand((3 * C,), dev, 49) * 0.5
     table = _rand((169, nH), dev, 51) * 0.5
     index = torch.from_numpy(ops.relative_position_index(ws)).to(dev)
     bias = ops.relpos_bias_fwd(table, index, N)
     _close("bias frag", bias.clamp(min=-1e4), ref.relpos_bias_fwd(table, index, N).clamp(min=-1e4), 1e-6)
     mask_frag = None
-    if shifted:
-        H = {4: 14, 1: 6}[nW]
-        mask = torch.from_numpy(ops.shift_mask(H, H, ws, 3)).to(dev)
+    if shift:
+        mask = torch.from_numpy(ops.shift_mask(H, H, ws, shift)).to(dev)
         assert mask.shape[0] == nW
         mask_frag = ops.dense_to_frag(mask)
         _close("mask frag", mask_frag, ref.dense_to_frag(mask), 1e-6)
     scale = hd ** -0.5
-    o, attn = ops.window_attn_fwd(qkv, bias, mask_frag, nW, N, nH, scale, want_attn=True)
-    orf, attnr = ref.window_attn_fwd(qkv, bias, mask_frag, nW, N, nH, scale, want_attn=True)
+    o, attn = ops.window_attn_fwd(qkv, qb, w2t, L, bias, mask_frag, nW, N, nH, scale, want_attn=True)
+    orf, attnr = ref.window_attn_fwd(qkv, qb, w2t, L, bias, mask_frag, nW, N, nH, scale, want_attn=True)
     _close("attn probs", attn, attnr, _tol(dt, f32=5e-5, bf=2e-2))
     _close("attn out", o, orf, _tol(dt, f32=5e-5, bf=2e-2))
-    dout = _rand((Bw * N, C), dev, 52, dt)
+    dout = _rand((nB * L, C), dev, 52, dt)
     for tr in (1, 0):
         ops.debug_set_tr_read(tr)
-        dqkv, ws_ = ops.window_attn_bwd(qkv, dout, bias, mask_frag, nW, N, nH, scale)
+        dqkv, ws_, pad_ = ops.window_attn_bwd(qkv, qb, w2t, L, dout, bias, mask_frag, nW, N, nH, scale)
         ops.debug_set_tr_read(1)
-        dqkvr, wsr = ref.window_attn_bwd(qkv, dout, bias, mask_frag, nW, N, nH, scale)
+        dqkvr, wsr, padr = ref.window_attn_bwd(qkv, qb, w2t, L, dout, bias, mask_frag, nW, N, nH, scale)
         for i, nm in enumerate("qkv"):
             _close("attn d%s tr=%d" % (nm, tr), dqkv.view(-1, 3, C)[:, i], dqkvr.view(-1, 3, C)[:, i], _tol(dt, f32=1e-4, bf=3e-2))
         dt_ = ops.relpos_bias_bwd(ws_, index, N, 169)
         dtr = ref.relpos_bias_bwd(wsr, index, N, 169)
         _close("attn dtable tr=%d" % tr, dt_, dtr, _tol(dt, f32=1e-4, bf=3e-2))
+        if (win2tok_np < 0).any():
+            _close("attn dpad tr=%d" % tr, pad_.sum(0, keepdim=True), padr, _tol(dt, f32=1e-4, bf=3e-2))
+        else:
+            assert float(pad_.abs().max()) == 0.0
 
 
 @pytest.mark.parametrize("dt", DTYPES)
