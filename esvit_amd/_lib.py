@@ -78,6 +78,7 @@ SIGNATURES = {
     "esvit_fused_clip_adamw_ema": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, f32, f32, f32, f32, f32, f32, f32, vp]),
     "esvit_debug_set_tr_read": (None, [C.c_int]),
     "esvit_debug_set_attn_tr_read": (None, [C.c_int]),
+    "esvit_debug_set_attn_bwd_waves": (None, [C.c_int]),
     "esvit_debug_set_gemm_dma": (None, [C.c_int]),
     "esvit_debug_set_gemm_pipe": (None, [C.c_int]),
 }

@@ -276,8 +276,8 @@ __device__ __forceinline__ void store_tok_rows(const f32x4 (&acc)[4][2], float m
 // LDS per wave: two [64][32] operand images (Q,K then V,dO then Q,K again) + the [64][64] P / dS image = 19 KiB,
 // so 8 waves fit a CU.  Partials written once per wave: bias gradient (frag layout) and the dK/dV sums of zero-pad
 // slots.
-template <typename T, bool USE_TR>
-__global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const T* __restrict__ qkv, const float* __restrict__ qkv_bias,
+template <typename T, bool USE_TR, int MINW>
+__global__ __launch_bounds__(256, MINW) void attn_bwd_kernel(const T* __restrict__ qkv, const float* __restrict__ qkv_bias,
                                                           const int* __restrict__ win2tok, int L, const T* __restrict__ dout,
                                                           const float* __restrict__ bias_frag, const float* __restrict__ mask_frag,
                                                           int nW, int Bw, int N, int nH, float scale, int parts,
@@ -352,41 +352,38 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const T* __restrict__ 
             }
             store_tok_rows<T>(acc, 1.f, dst + 2 * C, 3L * C, w2t, tok_base, N, active, &padv, c, g);
         }
-        f32x4 dp[4][4];
+        __syncthreads();  // dV's reads of Ps (= P) are complete: its rows may now be overwritten with dS
+        // dP^T = V dO^T and dS = P o (dP - delta), one query tile (16 columns) at a time to keep only 16 dP
+        // registers live; dS goes straight into the [q][key] image
         {
-            Frag<T> vf[4], of[4];
+            Frag<T> vf[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                vf[i] = frag_kc<T>(bufA, LDQ, 16 * i, 0, c, g);
-                of[i] = frag_kc<T>(bufB, LDQ, 16 * i, 0, c, g);
-            }
+            for (int i = 0; i < 4; ++i) vf[i] = frag_kc<T>(bufA, LDQ, 16 * i, 0, c, g);
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < 4; ++j) {
+                const Frag<T> of = frag_kc<T>(bufB, LDQ, 16 * j, 0, c, g);
+                f32x4 dpj[4];
+                float d = 0.f;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    dp[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    mma(vf[i], of[j], dp[i][j]);
+                for (int i = 0; i < 4; ++i) {
+                    dpj[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    mma(vf[i], of, dpj[i]);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) d += p[i][j][r] * dpj[i][r];
                 }
-        }
+                d += __shfl_xor(d, 16, 64);
+                d += __shfl_xor(d, 32, 64);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float d = 0.f;
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) d += p[i][j][r] * dp[i][j][r];
-            d += __shfl_xor(d, 16, 64);
-            d += __shfl_xor(d, 32, 64);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                dp[i][j] = p[i][j] * (dp[i][j] - d);
-                if (active) db[i][j] += dp[i][j];
+                for (int i = 0; i < 4; ++i) {
+                    const f32x4 ds = p[i][j] * (dpj[i] - d);
+                    if (active) db[i][j] += ds;
+                    store_frag4<T>(Ps + (16 * j + c) * LDP + 16 * i + 4 * g, ds);
+                }
             }
         }
-        __syncthreads();  // reads of Ps (= P), bufA (= V), bufB (= dO) are complete
+        __syncthreads();  // dS image complete; reads of bufA (= V), bufB (= dO) are complete
 
         // ---- phase 3: dQ = scale * dS K;  dK = dS^T (scale q) ----
-        store_pt<T>(Ps, dp, c, g);
         stage_rows<T>(src, 3L * C, w2t, tok_base, N, active, scale, qkv_bias + h * HD, bufA, lane);
         stage_rows<T>(src + C, 3L * C, w2t, tok_base, N, active, 1.f, qkv_bias + C + h * HD, bufB, lane);
         __syncthreads();
@@ -536,7 +533,9 @@ extern "C" int esvit_relpos_bias_bwd(const float* dbias_ws, int parts, const int
 }
 
 static int g_attn_use_tr = 1;
+static int g_attn_minw = 2;  // waves per SIMD the backward kernel is compiled for (2: 256 registers + some scratch, 1: 512 registers)
 extern "C" void esvit_debug_set_attn_tr_read(int on) { g_attn_use_tr = on; }
+extern "C" void esvit_debug_set_attn_bwd_waves(int w) { g_attn_minw = w; }
 
 extern "C" int esvit_window_attn_fwd(int dtype, const void* qkv, const float* qkv_bias, const int32_t* win2tok, int L,
                                      const float* bias_frag, const float* mask_frag, int nW, int nB, int N, int nH, int hd,
@@ -590,7 +589,7 @@ extern "C" int esvit_window_attn_bwd(int dtype, const void* qkv, const float* qk
 #define LAUNCH_BWD(TT, TR)                                                                                                      \
     {                                                                                                                           \
         const size_t lds = 4 * (size_t)AttnCfg<TT>::BWD_PER_WAVE * sizeof(TT);                                                  \
-        auto kern = attn_bwd_kernel<TT, TR>;                                                                                    \
+        auto kern = g_attn_minw == 2 ? attn_bwd_kernel<TT, TR, 2> : attn_bwd_kernel<TT, TR, 1>;                                \
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);   \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, (const TT*)qkv, qkv_bias, win2tok, L, (const TT*)dout,      \
                            bias_frag, mask_frag, nW, Bw, N, nH, scale, parts, (TT*)dqkv, dbias_ws, dpad_ws);                    \

@@ -243,6 +243,7 @@ int esvit_fused_clip_adamw_ema(const int64_t* tensors, int ntensors, const int32
 /* ---- debug switches (tests only) ---------------------------------------- */
 void esvit_debug_set_tr_read(int on);      /* GEMM: ds_read_b64_tr_b16 vs scalar LDS gathers */
 void esvit_debug_set_attn_tr_read(int on); /* attention backward: same */
+void esvit_debug_set_attn_bwd_waves(int w); /* attention backward compiled for 2 (256 regs) or 1 (512 regs) waves per SIMD */
 void esvit_debug_set_gemm_dma(int on);     /* GEMM: LDS-DMA main loop (1: by shape, 2: always) vs register-staged main loop (0) */
 void esvit_debug_set_gemm_pipe(int mode);  /* LDS-DMA pipeline: 1 = BK64 x 2 buffers, 3 = BK64 x 3-deep ring, 4 = BK32 x 4-deep ring */
 

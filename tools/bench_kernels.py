@@ -35,6 +35,8 @@ def main():
         shapes += [("s%d qkv" % s, M, 3 * C, C), ("s%d proj" % s, M, C, C), ("s%d fc1" % s, M, 4 * C, C), ("s%d fc2" % s, M, C, 4 * C)]
     shapes += [("head fc1", 170 * B, 2048, 768), ("head fc2", 170 * B, 2048, 2048), ("head fc3", 170 * B, 256, 2048),
                ("head last", 170 * B, 65536, 256)]
+    if len(sys.argv) > 5:
+        shapes = []
     for name, M, N, K in shapes:
         x = torch.randn(M, K, device=dev).to(dt)
         w = (torch.randn(N, K, device=dev) * 0.05).to(dt)
@@ -50,21 +52,31 @@ def main():
                         torch_TF=fl / t_t / 1e12, fwd_GBs=byt / t_f / 1e9))
         print(json.dumps(res[-1]))
         del x, w, dy
-    if only_gemm:
+    if only_gemm and len(sys.argv) <= 5:
         return
-    # attention
-    for s, (C, nW, nH) in enumerate([(96, 64, 3), (192, 16, 6), (384, 4, 12), (768, 1, 24)]):
-        Bw = 2 * B * nW
-        qkv = torch.randn(Bw * 49, 3 * C, device=dev).to(dt)
-        table = torch.randn(169, nH, device=dev)
-        index = torch.from_numpy(ops.relative_position_index(7)).to(dev)
-        bias = ops.relpos_bias_fwd(table, index, 49)
-        dout = torch.randn(Bw * 49, C, device=dev).to(dt)
-        t_f = timeit(lambda: ops.window_attn_fwd(qkv, bias, None, 1, 49, nH, 32 ** -0.5))
-        t_b = timeit(lambda: ops.window_attn_bwd(qkv, dout, bias, None, 1, 49, nH, 32 ** -0.5))
-        byt_f = qkv.numel() * 2 + dout.numel() * 2
-        print(json.dumps(dict(name="attn s%d" % s, Bw=Bw, nH=nH, fwd_us=t_f * 1e6, bwd_us=t_b * 1e6, fwd_GBs=byt_f / t_f / 1e9,
-                              bwd_GBs=(2 * qkv.numel() * 2 + dout.numel() * 2) / t_b / 1e9)))
+    # attention (token-ordered; 224-crop geometries H = 56, 28, 14, 7 and the padded 96-crop ones H = 24, 12, 6, 3)
+    for s, (C, nH) in enumerate([(96, 3), (192, 6), (384, 12), (768, 24)]):
+        for H, nimg in ((56 >> s, 2 * B), (24 >> s, 8 * B)):
+            shift = 3 if H > 7 or (H == 6) else 0
+            w2t_np, _ = ops.window_maps(H, H, 7, shift)
+            w2t = torch.from_numpy(w2t_np).to(dev)
+            nW = w2t.numel() // 49
+            L = H * H
+            qkv = torch.randn(nimg * L, 3 * C, device=dev).to(dt)
+            qb = torch.zeros(3 * C, device=dev)
+            table = torch.randn(169, nH, device=dev)
+            index = torch.from_numpy(ops.relative_position_index(7)).to(dev)
+            bias = ops.relpos_bias_fwd(table, index, 49)
+            mask = ops.dense_to_frag(torch.from_numpy(ops.shift_mask(H, H, 7, shift)).to(dev)) if shift else None
+            dout = torch.randn(nimg * L, C, device=dev).to(dt)
+            t_f = timeit(lambda: ops.window_attn_fwd(qkv, qb, w2t, L, bias, mask, nW, 49, nH, 32 ** -0.5))
+            t_b = timeit(lambda: ops.window_attn_bwd(qkv, qb, w2t, L, dout, bias, mask, nW, 49, nH, 32 ** -0.5))
+            ops.lib.esvit_debug_set_attn_bwd_waves(1)
+            t_b1 = timeit(lambda: ops.window_attn_bwd(qkv, qb, w2t, L, dout, bias, mask, nW, 49, nH, 32 ** -0.5))
+            ops.lib.esvit_debug_set_attn_bwd_waves(2)
+            print(json.dumps(dict(name="attn s%d H%d" % (s, H), windows=nimg * nW, nH=nH, fwd_us=t_f * 1e6, bwd_us=t_b * 1e6, bwd_us_1wave=t_b1 * 1e6,
+                                  fwd_GBs=(qkv.numel() + dout.numel()) * 2 / t_f / 1e9,
+                                  bwd_GBs=(2 * qkv.numel() + dout.numel()) * 2 / t_b / 1e9)))
     # loss
     K = 65536
     s_ = torch.randn(170 * B, K, device=dev).to(dt)
