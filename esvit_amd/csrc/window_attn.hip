@@ -55,17 +55,19 @@ __device__ __forceinline__ void store_frag4(T* p, f32x4 v) {
 // Rows are window slots; slot t reads token row tok_base + w2t[t] of the token-ordered matrix `g`, or -- for a
 // zero-pad slot (w2t[t] < 0, swin_transformer.py:286-290) -- the constant `pad` (the qkv bias of this head: LN'd
 // zero rows give qkv = bias; nullptr = zeros).  Values are optionally scaled and re-rounded (q * head_dim^-0.5).
+// `mytok` holds the window's slot->token map in registers (lane l: slot l; -1 for pad slots, slots >= N and idle
+// waves), so the per-slot lookups are cross-lane reads (ds_bpermute) instead of dependent global loads.
 template <typename T>
-__device__ __forceinline__ void stage_rows(const T* __restrict__ g, long row_stride, const int* __restrict__ w2t, long tok_base,
-                                           int N, bool active, float scale, const float* __restrict__ pad, T* lds, int lane) {
+__device__ __forceinline__ void stage_rows(const T* __restrict__ g, long row_stride, int mytok, long tok_base, int N, bool active,
+                                           float scale, const float* __restrict__ pad, T* lds, int lane) {
     constexpr int VEC = AttnCfg<T>::VEC, LDQ = AttnCfg<T>::LDQ, VPR = HD / VEC;
 #pragma unroll
     for (int i = 0; i < NP * VPR / 64; ++i) {
         const int v = lane + 64 * i;
         const int t = v / VPR, dv = v % VPR;
+        const int tok = __shfl(mytok, t, 64);
         Vec16<T> x = zero16<T>();
         if (active && t < N) {
-            const int tok = w2t[t];
             if (tok >= 0) {
                 x = ld16<T>(g + (tok_base + tok) * row_stride + dv * VEC);
             } else if (pad) {
@@ -162,12 +164,12 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv
     const int bw = active ? (int)(unit / nH) : 0;
     const int h = active ? (int)(unit % nH) : 0;
     const int C = nH * HD;
-    const int* w2t = win2tok + (long)(bw % nW) * N;
+    const int mytok = (active && lane < N) ? win2tok[(long)(bw % nW) * N + lane] : -1;
     const long tok_base = (long)(bw / nW) * L;
     const T* src = qkv + h * HD;
 
-    stage_rows<T>(src, 3L * C, w2t, tok_base, N, active, scale, qkv_bias + h * HD, Qs, lane);
-    stage_rows<T>(src + C, 3L * C, w2t, tok_base, N, active, 1.f, qkv_bias + C + h * HD, Ks, lane);
+    stage_rows<T>(src, 3L * C, mytok, tok_base, N, active, scale, qkv_bias + h * HD, Qs, lane);
+    stage_rows<T>(src + C, 3L * C, mytok, tok_base, N, active, 1.f, qkv_bias + C + h * HD, Ks, lane);
     {  // V transposed: Vt[d][key]
         constexpr int VPR = HD / VEC;
         const float* padv = qkv_bias + 2 * C + h * HD;
@@ -175,9 +177,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv
         for (int i = 0; i < NP * VPR / 64; ++i) {
             const int v = lane + 64 * i;
             const int t = v / VPR, dv = v % VPR;
+            const int tok = __shfl(mytok, t, 64);
             Vec16<T> x = zero16<T>();
             if (active && t < N) {
-                const int tok = w2t[t];
                 if (tok >= 0) {
                     x = ld16<T>(src + 2 * C + (tok_base + tok) * 3L * C + dv * VEC);
                 } else {
@@ -236,7 +238,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int q = 16 * i + 4 * g + r;
-                const int tok = q < N ? w2t[q] : -1;
+                const int tok = __shfl(mytok, q, 64);  // -1 for q >= N
                 if (tok >= 0) {
                     T* rowp = dst + (tok_base + tok) * (long)C;
                     rowp[c] = from_f32<T>(o[i][0][r]);
@@ -250,15 +252,14 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv
 // zero-pad slots are summed into `pad` (they are gradients of the qkv bias)
 template <typename T>
 __device__ __forceinline__ void store_tok_rows(const f32x4 (&acc)[4][2], float mul, T* __restrict__ dst, long row_stride,
-                                               const int* __restrict__ w2t, long tok_base, int N, bool active, f32x2* pad, int c,
-                                               int g) {
+                                               int mytok, long tok_base, int N, bool active, f32x2* pad, int c, int g) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int t = 16 * i + 4 * g + r;
+            const int tok = __shfl(mytok, t, 64);
             if (!active || t >= N) continue;
-            const int tok = w2t[t];
             const float v0 = acc[i][0][r] * mul, v1 = acc[i][1][r] * mul;
             if (tok >= 0) {
                 T* rowp = dst + (tok_base + tok) * row_stride;
@@ -314,14 +315,14 @@ __global__ __launch_bounds__(256, MINW) void attn_bwd_kernel(const T* __restrict
         const int bw = part + it * parts;
         const bool active = wave_ok && bw < Bw;
         const int bwc = active ? bw : 0;
-        const int* w2t = win2tok + (long)(bwc % nW) * N;
+        const int mytok = (active && lane < N) ? win2tok[(long)(bwc % nW) * N + lane] : -1;
         const long tok_base = (long)(bwc / nW) * L;
         const float* mask_f = mask_frag ? mask_frag + (long)(bwc % nW) * FRAG_ELEMS : nullptr;
 
         // ---- phase 1: P = softmax(scale q k^T + bias + mask) ----
         __syncthreads();  // previous iteration's reads of bufA/bufB/Ps are complete
-        stage_rows<T>(src, 3L * C, w2t, tok_base, N, active, scale, qkv_bias + h * HD, bufA, lane);
-        stage_rows<T>(src + C, 3L * C, w2t, tok_base, N, active, 1.f, qkv_bias + C + h * HD, bufB, lane);
+        stage_rows<T>(src, 3L * C, mytok, tok_base, N, active, scale, qkv_bias + h * HD, bufA, lane);
+        stage_rows<T>(src + C, 3L * C, mytok, tok_base, N, active, 1.f, qkv_bias + C + h * HD, bufB, lane);
         __syncthreads();
         f32x4 p[4][4];
         scores_softmax<T>(bufA, bufB, bias_f, mask_f, lane, c, g, p);
@@ -329,8 +330,8 @@ __global__ __launch_bounds__(256, MINW) void attn_bwd_kernel(const T* __restrict
         __syncthreads();  // score reads of bufA/bufB done; Ps visible
 
         // ---- phase 2: dV = P^T dO;  dP^T = V dO^T;  dS = P o (dP - delta) ----
-        stage_rows<T>(src + 2 * C, 3L * C, w2t, tok_base, N, active, 1.f, qkv_bias + 2 * C + h * HD, bufA, lane);
-        stage_rows<T>(dout + h * HD, (long)C, w2t, tok_base, N, active, 1.f, nullptr, bufB, lane);
+        stage_rows<T>(src + 2 * C, 3L * C, mytok, tok_base, N, active, 1.f, qkv_bias + 2 * C + h * HD, bufA, lane);
+        stage_rows<T>(dout + h * HD, (long)C, mytok, tok_base, N, active, 1.f, nullptr, bufB, lane);
         __syncthreads();
         {
             f32x4 acc[4][2];
@@ -350,7 +351,7 @@ __global__ __launch_bounds__(256, MINW) void attn_bwd_kernel(const T* __restrict
                     mma(a, b1, acc[i][1]);
                 }
             }
-            store_tok_rows<T>(acc, 1.f, dst + 2 * C, 3L * C, w2t, tok_base, N, active, &padv, c, g);
+            store_tok_rows<T>(acc, 1.f, dst + 2 * C, 3L * C, mytok, tok_base, N, active, &padv, c, g);
         }
         __syncthreads();  // dV's reads of Ps (= P) are complete: its rows may now be overwritten with dS
         // dP^T = V dO^T and dS = P o (dP - delta), one query tile (16 columns) at a time to keep only 16 dP
@@ -384,8 +385,8 @@ __global__ __launch_bounds__(256, MINW) void attn_bwd_kernel(const T* __restrict
         __syncthreads();  // dS image complete; reads of bufA (= V), bufB (= dO) are complete
 
         // ---- phase 3: dQ = scale * dS K;  dK = dS^T (scale q) ----
-        stage_rows<T>(src, 3L * C, w2t, tok_base, N, active, scale, qkv_bias + h * HD, bufA, lane);
-        stage_rows<T>(src + C, 3L * C, w2t, tok_base, N, active, 1.f, qkv_bias + C + h * HD, bufB, lane);
+        stage_rows<T>(src, 3L * C, mytok, tok_base, N, active, scale, qkv_bias + h * HD, bufA, lane);
+        stage_rows<T>(src + C, 3L * C, mytok, tok_base, N, active, 1.f, qkv_bias + C + h * HD, bufB, lane);
         __syncthreads();
         {
             f32x4 aq[4][2], ak[4][2];
@@ -413,8 +414,8 @@ __global__ __launch_bounds__(256, MINW) void attn_bwd_kernel(const T* __restrict
                 }
             }
             // dQ of a zero-pad slot is exactly 0 (its dO row is 0), so only dK needs the pad accumulator
-            store_tok_rows<T>(aq, scale, dst, 3L * C, w2t, tok_base, N, active, nullptr, c, g);
-            store_tok_rows<T>(ak, 1.f, dst + C, 3L * C, w2t, tok_base, N, active, &padk, c, g);
+            store_tok_rows<T>(aq, scale, dst, 3L * C, mytok, tok_base, N, active, nullptr, c, g);
+            store_tok_rows<T>(ak, 1.f, dst + C, 3L * C, mytok, tok_base, N, active, &padk, c, g);
         }
     }
     // column c (and 16+c) sums over this lane's rows -> reduce the 4 row groups g
