@@ -40,6 +40,7 @@ SIGNATURES = {
     "esvit_relative_position_index": (C.c_int, [C.c_int, vp]),
     "esvit_window_maps": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
     "esvit_shift_mask": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
+    "esvit_shift_region_ids": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
     "esvit_gemm": (C.c_int, [C.c_int, C.POINTER(GemmDesc), vp]),
     "esvit_layernorm_fwd": (C.c_int, [C.c_int, vp, vp, vp, f32, i64, C.c_int, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp]),
     "esvit_layernorm_bwd_blocks": (C.c_int, [i64, C.c_int]),

@@ -59,6 +59,22 @@ extern "C" int esvit_window_maps(int H, int W, int ws, int shift, int32_t* win2t
 
 // swin_transformer.py:249-272: region ids on the padded grid in rolled coordinates via the three
 // python slices (0,-ws), (-ws,-shift), (-shift,None) applied in order (later slices overwrite).
+// region id (3*band(i)+band(j)) of every window slot; the shift mask is 0 where two slots of a window share an id
+extern "C" int esvit_shift_region_ids(int H, int W, int ws, int shift, int32_t* ids, int* n_windows) {
+    if (H <= 0 || W <= 0 || ws <= 0 || shift <= 0 || shift >= ws || !ids) {
+        esvit_set_error("esvit_shift_region_ids: bad geometry H=%d W=%d ws=%d shift=%d", H, W, ws, shift);
+        return ESVIT_ERR_ARG;
+    }
+    const int Hp = (H + ws - 1) / ws * ws, Wp = (W + ws - 1) / ws * ws;
+    const int nWw = Wp / ws, N = ws * ws;
+    auto band = [&](int t, int L) { return t < L - ws ? 0 : (t < L - shift ? 1 : 2); };
+    for (int i = 0; i < Hp; ++i)
+        for (int j = 0; j < Wp; ++j)
+            ids[((i / ws) * nWw + (j / ws)) * N + (i % ws) * ws + (j % ws)] = 3 * band(i, Hp) + band(j, Wp);
+    if (n_windows) *n_windows = (Hp / ws) * nWw;
+    return ESVIT_OK;
+}
+
 extern "C" int esvit_shift_mask(int H, int W, int ws, int shift, float* mask, int* n_windows) {
     if (H <= 0 || W <= 0 || ws <= 0 || shift <= 0 || shift >= ws || !mask) {
         esvit_set_error("esvit_shift_mask: bad geometry H=%d W=%d ws=%d shift=%d", H, W, ws, shift);

@@ -84,10 +84,12 @@ __device__ __forceinline__ void stage_rows(const T* __restrict__ g, long row_str
 }
 
 // scores + softmax, shared by fwd and bwd: returns P^T fragments p[ki][qj] (fp32)
+// Shift mask (swin_transformer.py:249-272): mask[q][key] = 0 if region(q) == region(key) else -100.  `myreg` holds the
+// window's per-slot region ids in registers (lane l: slot l), or -1 in every lane when the block is unshifted, so the
+// 49x49 mask is rebuilt from 20 cross-lane reads instead of a 16 KiB load per (window, head).
 template <typename T>
-__device__ __forceinline__ void scores_softmax(const T* Qs, const T* Ks, const float* __restrict__ bias_f,
-                                               const float* __restrict__ mask_f, int lane, int c, int g,
-                                               f32x4 (&p)[4][4]) {
+__device__ __forceinline__ void scores_softmax(const T* Qs, const T* Ks, const float* __restrict__ bias_f, int myreg,
+                                               bool masked, int lane, int c, int g, f32x4 (&p)[4][4]) {
     constexpr int LDQ = AttnCfg<T>::LDQ;
     Frag<T> kf[4], qf[4];
 #pragma unroll
@@ -95,15 +97,25 @@ __device__ __forceinline__ void scores_softmax(const T* Qs, const T* Ks, const f
         kf[i] = frag_kc<T>(Ks, LDQ, 16 * i, 0, c, g);
         qf[i] = frag_kc<T>(Qs, LDQ, 16 * i, 0, c, g);
     }
+    int rq[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) rq[j] = __shfl(myreg, 16 * j + c, 64);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int rk[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rk[r] = __shfl(myreg, 16 * i + 4 * g + r, 64);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             f32x4 b = *reinterpret_cast<const f32x4*>(bias_f + ((i * 4 + j) * 64 + lane) * 4);
-            if (mask_f) b += *reinterpret_cast<const f32x4*>(mask_f + ((i * 4 + j) * 64 + lane) * 4);
+            if (masked) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) b[r] += (rk[r] != rq[j]) ? -100.f : 0.f;
+            }
             p[i][j] = b;
             mma(kf[i], qf[j], p[i][j]);
         }
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         float m = -3.0e38f;
@@ -146,7 +158,7 @@ __device__ __forceinline__ void store_pt(T* Ps, const f32x4 (&p)[4][4], int c, i
 template <typename T>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv, const float* __restrict__ qkv_bias,
                                                        const int* __restrict__ win2tok, int L, const float* __restrict__ bias_frag,
-                                                       const float* __restrict__ mask_frag, int nW, int Bw, int N, int nH,
+                                                       const int* __restrict__ region_ids, int nW, int Bw, int N, int nH,
                                                        float scale, T* __restrict__ out, float* __restrict__ attn_out) {
     using Cfg = AttnCfg<T>;
     constexpr int LDQ = Cfg::LDQ, LDP = Cfg::LDP, VEC = Cfg::VEC;
@@ -195,8 +207,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv
 
     f32x4 p[4][4];
     const float* bias_f = bias_frag + (long)h * FRAG_ELEMS;
-    const float* mask_f = mask_frag ? mask_frag + (long)(bw % nW) * FRAG_ELEMS : nullptr;
-    scores_softmax<T>(Qs, Ks, bias_f, mask_f, lane, c, g, p);
+    const bool masked = region_ids != nullptr;
+    const int myreg = (masked && active && lane < N) ? region_ids[(long)(bw % nW) * N + lane] : -1;
+    scores_softmax<T>(Qs, Ks, bias_f, myreg, masked, lane, c, g, p);
 
     if (attn_out && active) {
 #pragma unroll
@@ -280,7 +293,7 @@ __device__ __forceinline__ void store_tok_rows(const f32x4 (&acc)[4][2], float m
 template <typename T, bool USE_TR, int MINW>
 __global__ __launch_bounds__(256, MINW) void attn_bwd_kernel(const T* __restrict__ qkv, const float* __restrict__ qkv_bias,
                                                           const int* __restrict__ win2tok, int L, const T* __restrict__ dout,
-                                                          const float* __restrict__ bias_frag, const float* __restrict__ mask_frag,
+                                                          const float* __restrict__ bias_frag, const int* __restrict__ region_ids,
                                                           int nW, int Bw, int N, int nH, float scale, int parts,
                                                           T* __restrict__ dqkv, float* __restrict__ dbias_ws,
                                                           float* __restrict__ dpad_ws) {
@@ -317,7 +330,8 @@ __global__ __launch_bounds__(256, MINW) void attn_bwd_kernel(const T* __restrict
         const int bwc = active ? bw : 0;
         const int mytok = (active && lane < N) ? win2tok[(long)(bwc % nW) * N + lane] : -1;
         const long tok_base = (long)(bwc / nW) * L;
-        const float* mask_f = mask_frag ? mask_frag + (long)(bwc % nW) * FRAG_ELEMS : nullptr;
+        const bool masked = region_ids != nullptr;
+        const int myreg = (masked && active && lane < N) ? region_ids[(long)(bwc % nW) * N + lane] : -1;
 
         // ---- phase 1: P = softmax(scale q k^T + bias + mask) ----
         __syncthreads();  // previous iteration's reads of bufA/bufB/Ps are complete
@@ -325,7 +339,7 @@ __global__ __launch_bounds__(256, MINW) void attn_bwd_kernel(const T* __restrict
         stage_rows<T>(src + C, 3L * C, mytok, tok_base, N, active, 1.f, qkv_bias + C + h * HD, bufB, lane);
         __syncthreads();
         f32x4 p[4][4];
-        scores_softmax<T>(bufA, bufB, bias_f, mask_f, lane, c, g, p);
+        scores_softmax<T>(bufA, bufB, bias_f, myreg, masked, lane, c, g, p);
         store_pt<T>(Ps, p, c, g);
         __syncthreads();  // score reads of bufA/bufB done; Ps visible
 
@@ -534,12 +548,12 @@ extern "C" int esvit_relpos_bias_bwd(const float* dbias_ws, int parts, const int
 }
 
 static int g_attn_use_tr = 1;
-static int g_attn_minw = 2;  // waves per SIMD the backward kernel is compiled for (2: 256 registers + some scratch, 1: 512 registers)
+static int g_attn_minw = 1;  // waves per SIMD the backward kernel is compiled for (2: 256 registers + some scratch, 1: 512 registers)
 extern "C" void esvit_debug_set_attn_tr_read(int on) { g_attn_use_tr = on; }
 extern "C" void esvit_debug_set_attn_bwd_waves(int w) { g_attn_minw = w; }
 
 extern "C" int esvit_window_attn_fwd(int dtype, const void* qkv, const float* qkv_bias, const int32_t* win2tok, int L,
-                                     const float* bias_frag, const float* mask_frag, int nW, int nB, int N, int nH, int hd,
+                                     const float* bias_frag, const int32_t* region_ids, int nW, int nB, int N, int nH, int hd,
                                      float scale, void* out, float* attn_out, esvit_stream_t s_) {
     STREAM(s_);
     ESVIT_CHECK_ARG(qkv && qkv_bias && win2tok && bias_frag && out && nB > 0 && nW > 0 && nH > 0 && L > 0,
@@ -555,13 +569,13 @@ extern "C" int esvit_window_attn_fwd(int dtype, const void* qkv, const float* qk
         const size_t lds = 4 * (size_t)AttnCfg<bf16>::FWD_PER_WAVE * sizeof(bf16);
         auto kern = attn_fwd_kernel<bf16>;
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, (const bf16*)qkv, qkv_bias, win2tok, L, bias_frag, mask_frag, nW,
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, (const bf16*)qkv, qkv_bias, win2tok, L, bias_frag, region_ids, nW,
                            Bw, N, nH, scale, (bf16*)out, attn_out);
     } else if (dtype == ESVIT_F32) {
         const size_t lds = 4 * (size_t)AttnCfg<float>::FWD_PER_WAVE * sizeof(float);
         auto kern = attn_fwd_kernel<float>;
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, (const float*)qkv, qkv_bias, win2tok, L, bias_frag, mask_frag, nW,
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, (const float*)qkv, qkv_bias, win2tok, L, bias_frag, region_ids, nW,
                            Bw, N, nH, scale, (float*)out, attn_out);
     } else {
         esvit_set_error("esvit_window_attn_fwd: bad dtype");
@@ -574,7 +588,7 @@ extern "C" int esvit_window_attn_fwd(int dtype, const void* qkv, const float* qk
 extern "C" int esvit_window_attn_bwd_parts(int Bw, int nH) { return bwd_parts(Bw, nH); }
 
 extern "C" int esvit_window_attn_bwd(int dtype, const void* qkv, const float* qkv_bias, const int32_t* win2tok, int L,
-                                     const void* dout, const float* bias_frag, const float* mask_frag, int nW, int nB, int N, int nH,
+                                     const void* dout, const float* bias_frag, const int32_t* region_ids, int nW, int nB, int N, int nH,
                                      int hd, float scale, void* dqkv, float* dbias_ws, float* dpad_ws, esvit_stream_t s_) {
     STREAM(s_);
     ESVIT_CHECK_ARG(qkv && qkv_bias && win2tok && dout && bias_frag && dqkv && dbias_ws && dpad_ws && nB > 0 && nW > 0 && nH > 0 && L > 0,
@@ -593,7 +607,7 @@ extern "C" int esvit_window_attn_bwd(int dtype, const void* qkv, const float* qk
         auto kern = g_attn_minw == 2 ? attn_bwd_kernel<TT, TR, 2> : attn_bwd_kernel<TT, TR, 1>;                                \
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);   \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, (const TT*)qkv, qkv_bias, win2tok, L, (const TT*)dout,      \
-                           bias_frag, mask_frag, nW, Bw, N, nH, scale, parts, (TT*)dqkv, dbias_ws, dpad_ws);                    \
+                           bias_frag, region_ids, nW, Bw, N, nH, scale, parts, (TT*)dqkv, dbias_ws, dpad_ws);                    \
     }
     if (dtype == ESVIT_BF16) {
         if (g_attn_use_tr) LAUNCH_BWD(bf16, true) else LAUNCH_BWD(bf16, false)

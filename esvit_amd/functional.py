@@ -44,10 +44,9 @@ class WindowGeometry:
         self.tokens = H * W
         self.win2tok = torch.from_numpy(win2tok).to(device)
         self.tok2win = torch.from_numpy(tok2win).to(device)
-        self.mask_frag = None
+        self.region_ids = None
         if shift > 0:
-            mask = torch.from_numpy(o.shift_mask(H, W, ws, shift)).to(device)
-            self.mask_frag = o.dense_to_frag(mask)
+            self.region_ids = torch.from_numpy(o.shift_region_ids(H, W, ws, shift)).to(device)
 
 
 def geometry(H, W, ws, shift, device):
@@ -86,7 +85,7 @@ def _block_forward(x, geom, nH, index, dp, prm, wts, save):
     xw, _, mean1, rstd1 = o.layernorm_fwd(x2d, g1, b1, LN_EPS)
     qkv = o.linear_fwd(xw, Wqkv, bqkv)
     bias_frag = o.relpos_bias_fwd(table, index, geom.N)
-    ao = o.window_attn_fwd(qkv, bqkv, geom.win2tok, L, bias_frag, geom.mask_frag, geom.nW, geom.N, nH, scale)
+    ao = o.window_attn_fwd(qkv, bqkv, geom.win2tok, L, bias_frag, geom.region_ids, geom.nW, geom.N, nH, scale)
     x1 = o.linear_fwd(ao, Wproj, bproj, residual=x2d, rowscale=dp1, rows_per_sample=L, out_f32=True)
     h, _, mean2, rstd2 = o.layernorm_fwd(x1, g2, b2, LN_EPS)
     if save:
@@ -130,7 +129,7 @@ class SwinBlockFn(torch.autograd.Function):
         dyw = o.gather_cast(gx1, M, rowscale=dp1, rows_per_sample=L)
         dWproj, dbproj = o.linear_wgrad(dyw, ao, want_bias=True)
         dao = o.linear_dgrad(dyw, Wproj)
-        dqkv, dbias_ws, dpad_ws = o.window_attn_bwd(qkv, bqkv, geom.win2tok, L, dao, bias_frag, geom.mask_frag, geom.nW, geom.N,
+        dqkv, dbias_ws, dpad_ws = o.window_attn_bwd(qkv, bqkv, geom.win2tok, L, dao, bias_frag, geom.region_ids, geom.nW, geom.N,
                                                     nH, scale)
         dtable = o.relpos_bias_bwd(dbias_ws, index, geom.N, table.shape[0])
         dWqkv, dbqkv = o.linear_wgrad(dqkv, xw, want_bias=True)
@@ -160,7 +159,7 @@ def swin_block_attention(x, geom, nH, index, prm_list):
     xw, _, _, _ = o.layernorm_fwd(x2d, g1, b1, LN_EPS)
     qkv = o.linear_fwd(xw, _weight(Wqkv), bqkv)
     bias_frag = o.relpos_bias_fwd(table, index, geom.N)
-    _, attn = o.window_attn_fwd(qkv, bqkv, geom.win2tok, L, bias_frag, geom.mask_frag, geom.nW, geom.N, nH, (C // nH) ** -0.5,
+    _, attn = o.window_attn_fwd(qkv, bqkv, geom.win2tok, L, bias_frag, geom.region_ids, geom.nW, geom.N, nH, (C // nH) ** -0.5,
                                 want_attn=True)
     return attn
 

@@ -99,6 +99,13 @@ def shift_mask(H, W, ws, shift):
     return mask
 
 
+def shift_region_ids(H, W, ws, shift):
+    Hp, Wp = -(-H // ws) * ws, -(-W // ws) * ws
+    ids = np.empty((Hp // ws) * (Wp // ws) * ws * ws, dtype=np.int32)
+    check(lib.esvit_shift_region_ids(H, W, ws, shift, ids.ctypes.data_as(C.c_void_p), None), "shift_region_ids")
+    return ids
+
+
 # ------------------------------------------------------------------------------------------------
 # GEMM family
 # ------------------------------------------------------------------------------------------------
@@ -394,7 +401,7 @@ def dense_to_frag(dense):
     return out
 
 
-def window_attn_fwd(qkv, qkv_bias, win2tok, L, bias_frag, mask_frag, nW, N, nH, scale, want_attn=False):
+def window_attn_fwd(qkv, qkv_bias, win2tok, L, bias_frag, region_ids, nW, N, nH, scale, want_attn=False):
     """token-ordered qkv [nB*L, 3C] -> out [nB*L, C]; win2tok int32 [nW*N] slot -> token (-1 = zero-pad slot)."""
     qkv = _actc(qkv)
     rows, C3 = qkv.shape
@@ -402,12 +409,12 @@ def window_attn_fwd(qkv, qkv_bias, win2tok, L, bias_frag, mask_frag, nW, N, nH, 
     nB = rows // L
     out = torch.empty((rows, Cc), dtype=qkv.dtype, device=qkv.device)
     attn = torch.empty((nB * nW, nH, N, N), dtype=torch.float32, device=qkv.device) if want_attn else None
-    check(lib.esvit_window_attn_fwd(_code(qkv.dtype), _p(qkv), _p(_f32c(qkv_bias)), _p(win2tok), L, _p(bias_frag), _p(mask_frag), nW, nB,
+    check(lib.esvit_window_attn_fwd(_code(qkv.dtype), _p(qkv), _p(_f32c(qkv_bias)), _p(win2tok), L, _p(bias_frag), _p(region_ids), nW, nB,
                                     N, nH, Cc // nH, scale, _p(out), _p(attn), _stream()), "window_attn_fwd")
     return (out, attn) if want_attn else out
 
 
-def window_attn_bwd(qkv, qkv_bias, win2tok, L, dout, bias_frag, mask_frag, nW, N, nH, scale):
+def window_attn_bwd(qkv, qkv_bias, win2tok, L, dout, bias_frag, region_ids, nW, N, nH, scale):
     """-> (dqkv act [nB*L, 3C], dbias_ws fp32 [parts, nH, frag], dpad_ws fp32 [parts, 2C])."""
     qkv, dout = _actc(qkv), _actc(dout)
     rows, C3 = qkv.shape
@@ -418,7 +425,7 @@ def window_attn_bwd(qkv, qkv_bias, win2tok, L, dout, bias_frag, mask_frag, nW, N
     ws = torch.empty((parts, nH, attn_frag_elems(N)), dtype=torch.float32, device=qkv.device)
     pad = torch.empty((parts, 2 * Cc), dtype=torch.float32, device=qkv.device)
     check(lib.esvit_window_attn_bwd(_code(qkv.dtype), _p(qkv), _p(_f32c(qkv_bias)), _p(win2tok), L, _p(dout), _p(bias_frag),
-                                    _p(mask_frag), nW, nB, N, nH, Cc // nH, scale, _p(dqkv), _p(ws), _p(pad), _stream()),
+                                    _p(region_ids), nW, nB, N, nH, Cc // nH, scale, _p(dqkv), _p(ws), _p(pad), _stream()),
           "window_attn_bwd")
     return dqkv, ws, pad
 

@@ -336,7 +336,19 @@ def _to_windows(x, fill, win2tok, L, nW, N):
     return xw, pad
 
 
-def _attn_core(qkvw, bias_frag, mask_frag, nW, N, nH, scale):
+def shift_region_ids(H, W, ws, shift):
+    """region labels per window slot, recovered from the reference-style mask construction (swin_transformer.py:249-267)"""
+    Hp, Wp = -(-H // ws) * ws, -(-W // ws) * ws
+    img = torch.zeros((1, Hp, Wp, 1))
+    cnt = 0
+    for h in (slice(0, -ws), slice(-ws, -shift), slice(-shift, None)):
+        for w in (slice(0, -ws), slice(-ws, -shift), slice(-shift, None)):
+            img[:, h, w, :] = cnt
+            cnt += 1
+    return _partition(img, ws).view(-1).numpy().astype(np.int32)
+
+
+def _attn_core(qkvw, bias_frag, region_ids, nW, N, nH, scale):
     rows, C3 = qkvw.shape
     C = C3 // 3
     hd = C // nH
@@ -346,17 +358,18 @@ def _attn_core(qkvw, bias_frag, mask_frag, nW, N, nH, scale):
     q = _r(x[0] * scale, dt).float()  # kernel rounds scale*q to the activation dtype in LDS
     k, v = x[1], x[2]
     s = q @ k.transpose(-2, -1) + _dense_from_frag(bias_frag, N).unsqueeze(0)
-    if mask_frag is not None:
-        m = _dense_from_frag(mask_frag, N)  # [nW, N, N]
+    if region_ids is not None:
+        ids = region_ids.view(nW, N)
+        m = torch.where(ids[:, :, None] == ids[:, None, :], 0.0, -100.0)  # [nW, N, N]
         s = (s.view(Bw // nW, nW, nH, N, N) + m.view(1, nW, 1, N, N)).view(Bw, nH, N, N)
     p = torch.softmax(s, -1)
     return q, k, v, p
 
 
-def window_attn_fwd(qkv, qkv_bias, win2tok, L, bias_frag, mask_frag, nW, N, nH, scale, want_attn=False):
+def window_attn_fwd(qkv, qkv_bias, win2tok, L, bias_frag, region_ids, nW, N, nH, scale, want_attn=False):
     C = qkv.shape[1] // 3
     qkvw, pad = _to_windows(qkv, _r(qkv_bias, qkv.dtype), win2tok, L, nW, N)
-    q, k, v, p = _attn_core(qkvw, bias_frag, mask_frag, nW, N, nH, scale)
+    q, k, v, p = _attn_core(qkvw, bias_frag, region_ids, nW, N, nH, scale)
     pr = _r(p, qkv.dtype).float()  # P is rounded to the activation dtype before P@V
     ow = (pr @ v).transpose(1, 2).reshape(qkvw.shape[0], C)
     nB = qkv.shape[0] // L
@@ -367,12 +380,12 @@ def window_attn_fwd(qkv, qkv_bias, win2tok, L, bias_frag, mask_frag, nW, N, nH, 
     return (out, p) if want_attn else out
 
 
-def window_attn_bwd(qkv, qkv_bias, win2tok, L, dout, bias_frag, mask_frag, nW, N, nH, scale):
+def window_attn_bwd(qkv, qkv_bias, win2tok, L, dout, bias_frag, region_ids, nW, N, nH, scale):
     C = qkv.shape[1] // 3
     dt = qkv.dtype
     qkvw, pad = _to_windows(qkv, _r(qkv_bias, dt), win2tok, L, nW, N)
     dow, _ = _to_windows(dout, torch.zeros(C, device=qkv.device), win2tok, L, nW, N)
-    q, k, v, p = _attn_core(qkvw, bias_frag, mask_frag, nW, N, nH, scale)
+    q, k, v, p = _attn_core(qkvw, bias_frag, region_ids, nW, N, nH, scale)
     Bw = qkvw.shape[0] // N
     hd = q.shape[-1]
     do = dow.float().view(Bw, N, nH, hd).permute(0, 2, 1, 3)

@@ -252,10 +252,12 @@ def test_window_attention(mods, dt, nH, H, shift):
     _close("bias frag", bias.clamp(min=-1e4), ref.relpos_bias_fwd(table, index, N).clamp(min=-1e4), 1e-6)
     mask_frag = None
     if shift:
-        mask = torch.from_numpy(ops.shift_mask(H, H, ws, shift)).to(dev)
-        assert mask.shape[0] == nW
-        mask_frag = ops.dense_to_frag(mask)
-        _close("mask frag", mask_frag, ref.dense_to_frag(mask), 1e-6)
+        ids_np = ops.shift_region_ids(H, H, ws, shift)
+        assert np.array_equal(ids_np, ref.shift_region_ids(H, H, ws, shift))
+        mask_frag = torch.from_numpy(ids_np).to(dev)  # the kernels rebuild the 0/-100 mask from the region labels
+        m_np = ops.shift_mask(H, H, ws, shift)
+        assert np.array_equal(np.where(ids_np.reshape(nW, N, 1) == ids_np.reshape(nW, 1, N), 0.0, -100.0).astype(np.float32), m_np)
+        _close("mask frag", ops.dense_to_frag(torch.from_numpy(m_np).to(dev)), ref.dense_to_frag(torch.from_numpy(m_np).to(dev)), 1e-6)
     scale = hd ** -0.5
     o, attn = ops.window_attn_fwd(qkv, qb, w2t, L, bias, mask_frag, nW, N, nH, scale, want_attn=True)
     orf, attnr = ref.window_attn_fwd(qkv, qb, w2t, L, bias, mask_frag, nW, N, nH, scale, want_attn=True)

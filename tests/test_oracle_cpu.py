@@ -62,6 +62,9 @@ def test_index_maps_library_bit_exact(maps, lib_built):
         assert np.array_equal(w2t[t2w], np.arange(H * H)), "tok2win is not the inverse"
         if s > 0:
             assert np.array_equal(ops.shift_mask(H, H, ws, s), maps["mask_%d_%d" % (ws, H)]), (ws, H)
+            ids = ops.shift_region_ids(H, H, ws, s).reshape(-1, ws * ws)
+            rebuilt = np.where(ids[:, :, None] == ids[:, None, :], 0.0, -100.0).astype(np.float32)
+            assert np.array_equal(rebuilt, maps["mask_%d_%d" % (ws, H)]), (ws, H)
 
 
 def _nano_sd(nano, seed):

@@ -67,7 +67,7 @@ def main():
             table = torch.randn(169, nH, device=dev)
             index = torch.from_numpy(ops.relative_position_index(7)).to(dev)
             bias = ops.relpos_bias_fwd(table, index, 49)
-            mask = ops.dense_to_frag(torch.from_numpy(ops.shift_mask(H, H, 7, shift)).to(dev)) if shift else None
+            mask = torch.from_numpy(ops.shift_region_ids(H, H, 7, shift)).to(dev) if shift else None
             dout = torch.randn(nimg * L, C, device=dev).to(dt)
             t_f = timeit(lambda: ops.window_attn_fwd(qkv, qb, w2t, L, bias, mask, nW, 49, nH, 32 ** -0.5))
             t_b = timeit(lambda: ops.window_attn_bwd(qkv, qb, w2t, L, dout, bias, mask, nW, 49, nH, 32 ** -0.5))
