@@ -401,7 +401,7 @@ def dense_to_frag(dense):
     return out
 
 
-def window_attn_fwd(qkv, qkv_bias, win2tok, L, bias_frag, region_ids, nW, N, nH, scale, want_attn=False):
+def window_attn_fwd(qkv, qkv_bias, win2tok, L, rel_table, ws, region_ids, nW, N, nH, scale, want_attn=False):
     """token-ordered qkv [nB*L, 3C] -> out [nB*L, C]; win2tok int32 [nW*N] slot -> token (-1 = zero-pad slot)."""
     qkv = _actc(qkv)
     rows, C3 = qkv.shape
@@ -409,12 +409,12 @@ def window_attn_fwd(qkv, qkv_bias, win2tok, L, bias_frag, region_ids, nW, N, nH,
     nB = rows // L
     out = torch.empty((rows, Cc), dtype=qkv.dtype, device=qkv.device)
     attn = torch.empty((nB * nW, nH, N, N), dtype=torch.float32, device=qkv.device) if want_attn else None
-    check(lib.esvit_window_attn_fwd(_code(qkv.dtype), _p(qkv), _p(_f32c(qkv_bias)), _p(win2tok), L, _p(bias_frag), _p(region_ids), nW, nB,
-                                    N, nH, Cc // nH, scale, _p(out), _p(attn), _stream()), "window_attn_fwd")
+    check(lib.esvit_window_attn_fwd(_code(qkv.dtype), _p(qkv), _p(_f32c(qkv_bias)), _p(win2tok), L, _p(_f32c(rel_table)), ws, _p(region_ids), nW,
+                                    nB, N, nH, Cc // nH, scale, _p(out), _p(attn), _stream()), "window_attn_fwd")
     return (out, attn) if want_attn else out
 
 
-def window_attn_bwd(qkv, qkv_bias, win2tok, L, dout, bias_frag, region_ids, nW, N, nH, scale):
+def window_attn_bwd(qkv, qkv_bias, win2tok, L, dout, rel_table, ws, region_ids, nW, N, nH, scale):
     """-> (dqkv act [nB*L, 3C], dbias_ws fp32 [parts, nH, frag], dpad_ws fp32 [parts, 2C])."""
     qkv, dout = _actc(qkv), _actc(dout)
     rows, C3 = qkv.shape
@@ -424,7 +424,7 @@ def window_attn_bwd(qkv, qkv_bias, win2tok, L, dout, bias_frag, region_ids, nW, 
     parts = lib.esvit_window_attn_bwd_parts(nB * nW, nH)
     ws = torch.empty((parts, nH, attn_frag_elems(N)), dtype=torch.float32, device=qkv.device)
     pad = torch.empty((parts, 2 * Cc), dtype=torch.float32, device=qkv.device)
-    check(lib.esvit_window_attn_bwd(_code(qkv.dtype), _p(qkv), _p(_f32c(qkv_bias)), _p(win2tok), L, _p(dout), _p(bias_frag),
+    check(lib.esvit_window_attn_bwd(_code(qkv.dtype), _p(qkv), _p(_f32c(qkv_bias)), _p(win2tok), L, _p(dout), _p(_f32c(rel_table)), ws,
                                     _p(region_ids), nW, nB, N, nH, Cc // nH, scale, _p(dqkv), _p(ws), _p(pad), _stream()),
           "window_attn_bwd")
     return dqkv, ws, pad

@@ -366,7 +366,8 @@ def _attn_core(qkvw, bias_frag, region_ids, nW, N, nH, scale):
     return q, k, v, p
 
 
-def window_attn_fwd(qkv, qkv_bias, win2tok, L, bias_frag, region_ids, nW, N, nH, scale, want_attn=False):
+def window_attn_fwd(qkv, qkv_bias, win2tok, L, rel_table, ws, region_ids, nW, N, nH, scale, want_attn=False):
+    bias_frag = relpos_bias_fwd(rel_table, torch.as_tensor(relative_position_index(ws), device=qkv.device), N)
     C = qkv.shape[1] // 3
     qkvw, pad = _to_windows(qkv, _r(qkv_bias, qkv.dtype), win2tok, L, nW, N)
     q, k, v, p = _attn_core(qkvw, bias_frag, region_ids, nW, N, nH, scale)
@@ -380,7 +381,8 @@ def window_attn_fwd(qkv, qkv_bias, win2tok, L, bias_frag, region_ids, nW, N, nH,
     return (out, p) if want_attn else out
 
 
-def window_attn_bwd(qkv, qkv_bias, win2tok, L, dout, bias_frag, region_ids, nW, N, nH, scale):
+def window_attn_bwd(qkv, qkv_bias, win2tok, L, dout, rel_table, ws, region_ids, nW, N, nH, scale):
+    bias_frag = relpos_bias_fwd(rel_table, torch.as_tensor(relative_position_index(ws), device=qkv.device), N)
     C = qkv.shape[1] // 3
     dt = qkv.dtype
     qkvw, pad = _to_windows(qkv, _r(qkv_bias, dt), win2tok, L, nW, N)

@@ -259,16 +259,16 @@ def test_window_attention(mods, dt, nH, H, shift):
         assert np.array_equal(np.where(ids_np.reshape(nW, N, 1) == ids_np.reshape(nW, 1, N), 0.0, -100.0).astype(np.float32), m_np)
         _close("mask frag", ops.dense_to_frag(torch.from_numpy(m_np).to(dev)), ref.dense_to_frag(torch.from_numpy(m_np).to(dev)), 1e-6)
     scale = hd ** -0.5
-    o, attn = ops.window_attn_fwd(qkv, qb, w2t, L, bias, mask_frag, nW, N, nH, scale, want_attn=True)
-    orf, attnr = ref.window_attn_fwd(qkv, qb, w2t, L, bias, mask_frag, nW, N, nH, scale, want_attn=True)
+    o, attn = ops.window_attn_fwd(qkv, qb, w2t, L, table, ws, mask_frag, nW, N, nH, scale, want_attn=True)
+    orf, attnr = ref.window_attn_fwd(qkv, qb, w2t, L, table, ws, mask_frag, nW, N, nH, scale, want_attn=True)
     _close("attn probs", attn, attnr, _tol(dt, f32=5e-5, bf=2e-2))
     _close("attn out", o, orf, _tol(dt, f32=5e-5, bf=2e-2))
     dout = _rand((nB * L, C), dev, 52, dt)
     for tr in (1, 0):
         ops.debug_set_tr_read(tr)
-        dqkv, ws_, pad_ = ops.window_attn_bwd(qkv, qb, w2t, L, dout, bias, mask_frag, nW, N, nH, scale)
+        dqkv, ws_, pad_ = ops.window_attn_bwd(qkv, qb, w2t, L, dout, table, ws, mask_frag, nW, N, nH, scale)
         ops.debug_set_tr_read(1)
-        dqkvr, wsr, padr = ref.window_attn_bwd(qkv, qb, w2t, L, dout, bias, mask_frag, nW, N, nH, scale)
+        dqkvr, wsr, padr = ref.window_attn_bwd(qkv, qb, w2t, L, dout, table, ws, mask_frag, nW, N, nH, scale)
         for i, nm in enumerate("qkv"):
             _close("attn d%s tr=%d" % (nm, tr), dqkv.view(-1, 3, C)[:, i], dqkvr.view(-1, 3, C)[:, i], _tol(dt, f32=1e-4, bf=3e-2))
         dt_ = ops.relpos_bias_bwd(ws_, index, N, 169)
