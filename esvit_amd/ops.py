@@ -422,12 +422,12 @@ def window_attn_bwd(qkv, qkv_bias, win2tok, L, dout, rel_table, ws, region_ids, 
     nB = rows // L
     dqkv = torch.empty_like(qkv)
     parts = lib.esvit_window_attn_bwd_parts(nB * nW, nH)
-    ws = torch.empty((parts, nH, attn_frag_elems(N)), dtype=torch.float32, device=qkv.device)
+    dbias_ws = torch.empty((parts, nH, attn_frag_elems(N)), dtype=torch.float32, device=qkv.device)
     pad = torch.empty((parts, 2 * Cc), dtype=torch.float32, device=qkv.device)
     check(lib.esvit_window_attn_bwd(_code(qkv.dtype), _p(qkv), _p(_f32c(qkv_bias)), _p(win2tok), L, _p(dout), _p(_f32c(rel_table)), ws,
-                                    _p(region_ids), nW, nB, N, nH, Cc // nH, scale, _p(dqkv), _p(ws), _p(pad), _stream()),
+                                    _p(region_ids), nW, nB, N, nH, Cc // nH, scale, _p(dqkv), _p(dbias_ws), _p(pad), _stream()),
           "window_attn_bwd")
-    return dqkv, ws, pad
+    return dqkv, dbias_ws, pad
 
 
 def relpos_bias_bwd(dbias_ws, index, N, table_rows):
