@@ -59,9 +59,11 @@ SIGNATURES = {
     "esvit_attn_frag_elems": (C.c_int, [C.c_int]),
     "esvit_relpos_bias_fwd": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, vp]),
     "esvit_dense_to_frag": (C.c_int, [vp, C.c_int, C.c_int, vp, vp]),
-    "esvit_window_attn_fwd": (C.c_int, [C.c_int, vp, vp, vp, C.c_int, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, f32, vp, vp, vp]),
-    "esvit_window_attn_bwd_parts": (C.c_int, [C.c_int, C.c_int]),
-    "esvit_window_attn_bwd": (C.c_int, [C.c_int, vp, vp, vp, C.c_int, vp, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, f32, vp, vp, vp, vp]),
+    "esvit_window_attn_lse_elems": (C.c_int, [C.c_int]),
+    "esvit_window_attn_fwd": (C.c_int, [C.c_int, vp, vp, vp, C.c_int, vp, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, f32, vp, vp, vp, vp]),
+    "esvit_window_attn_bwd_parts": (C.c_int, [C.c_int, C.c_int, C.c_int]),
+    "esvit_window_attn_bwd_pad_rows": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "esvit_window_attn_bwd": (C.c_int, [C.c_int, vp, vp, vp, C.c_int, vp, vp, vp, vp, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, f32, vp, vp, vp, vp]),
     "esvit_relpos_bias_bwd": (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, vp, vp]),
     "esvit_l2norm_fwd": (C.c_int, [C.c_int, vp, i64, C.c_int, vp, vp, vp]),
     "esvit_l2norm_bwd": (C.c_int, [C.c_int, vp, vp, vp, i64, C.c_int, vp, vp]),

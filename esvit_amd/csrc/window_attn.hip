@@ -118,9 +118,11 @@ __device__ __forceinline__ void load_rel_table(const float* __restrict__ table, 
 // Shift mask (swin_transformer.py:249-272): mask[q][key] = 0 if region(q) == region(key) else -100.  `myreg` holds the
 // window's per-slot region ids in registers (lane l: slot l), so the 49x49 mask is rebuilt from 20 cross-lane reads
 // instead of a 16 KiB load per (window, head).
+// bias_f (optional): the head's bias already in fragment order (one 16-byte load per tile, -1e30 in padded key columns);
+// measured faster than the LDS gather for 7x7 windows, so the host passes it whenever it has a workspace for it.
 template <typename T>
-__device__ __forceinline__ void scores_softmax(const T* Qs, const T* Ks, const float* tab_lds, const RelIdx& ri, int N, int myreg,
-                                               bool masked, int lane, int c, int g, f32x4 (&p)[4][4]) {
+__device__ __forceinline__ void scores_softmax(const T* Qs, const T* Ks, const float* __restrict__ bias_f, const float* tab_lds,
+                                               const RelIdx& ri, int N, int myreg, bool masked, int lane, int c, int g, f32x4 (&p)[4][4]) {
     constexpr int LDQ = AttnCfg<T>::LDQ;
     Frag<T> kf[4], qf[4];
 #pragma unroll
@@ -140,13 +142,20 @@ __device__ __forceinline__ void scores_softmax(const T* Qs, const T* Ks, const f
         for (int j = 0; j < 4; ++j) {
             const bool qok = 16 * j + c < N;
             f32x4 b;
+            if (bias_f) {
+                b = *reinterpret_cast<const f32x4*>(bias_f + ((i * 4 + j) * 64 + lane) * 4);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const bool kok = 16 * i + 4 * g + r < N;
-                float v = (qok && kok) ? tab_lds[ri.aq[j] - ri.ak[i][r]] : 0.f;
-                if (!kok) v = -1.0e30f;  // padded key columns never receive probability
-                if (masked && rk[r] != rq[j]) v += -100.f;
-                b[r] = v;
+                for (int r = 0; r < 4; ++r)
+                    if (masked && rk[r] != rq[j]) b[r] += -100.f;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const bool kok = 16 * i + 4 * g + r < N;
+                    float v = (qok && kok) ? tab_lds[ri.aq[j] - ri.ak[i][r]] : 0.f;
+                    if (!kok) v = -1.0e30f;  // padded key columns never receive probability
+                    if (masked && rk[r] != rq[j]) v += -100.f;
+                    b[r] = v;
+                }
             }
             p[i][j] = b;
             mma(kf[i], qf[j], p[i][j]);
@@ -194,8 +203,9 @@ __device__ __forceinline__ void store_pt(T* Ps, const f32x4 (&p)[4][4], int c, i
 template <typename T>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv, const float* __restrict__ qkv_bias,
                                                        const int* __restrict__ win2tok, int L, const float* __restrict__ rel_table,
-                                                       int rel_rows, int ws, const int* __restrict__ region_ids, int nW, int Bw, int N,
-                                                       int nH, float scale, T* __restrict__ out, float* __restrict__ attn_out) {
+                                                       int rel_rows, int ws, const float* __restrict__ bias_frag,
+                                                       const int* __restrict__ region_ids, int nW, int Bw, int N, int nH, float scale,
+                                                       T* __restrict__ out, float* __restrict__ attn_out) {
     using Cfg = AttnCfg<T>;
     constexpr int LDQ = Cfg::LDQ, LDP = Cfg::LDP, VEC = Cfg::VEC;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -220,14 +230,15 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv
     stage_rows<T>(src, 3L * C, mytok, tok_base, N, active, scale, qkv_bias + h * HD, Qs, lane);
     stage_rows<T>(src + C, 3L * C, mytok, tok_base, N, active, 1.f, qkv_bias + C + h * HD, Ks, lane);
     stage_rows<T>(src + 2 * C, 3L * C, mytok, tok_base, N, active, 1.f, qkv_bias + 2 * C + h * HD, Vs, lane);
-    load_rel_table(rel_table, rel_rows, nH, h, tab, lane);
+    if (!bias_frag) load_rel_table(rel_table, rel_rows, nH, h, tab, lane);
     const RelIdx ri = make_relidx(ws, c, g);
+    const float* bias_f = bias_frag ? bias_frag + (long)h * FRAG_ELEMS : nullptr;
     __syncthreads();
 
     f32x4 p[4][4];
     const bool masked = region_ids != nullptr;
     const int myreg = (masked && active && lane < N) ? region_ids[(long)(bw % nW) * N + lane] : -1;
-    scores_softmax<T>(Qs, Ks, tab, ri, N, myreg, masked, lane, c, g, p);
+    scores_softmax<T>(Qs, Ks, bias_f, tab, ri, N, myreg, masked, lane, c, g, p);
 
     if (attn_out && active) {
 #pragma unroll
@@ -312,8 +323,8 @@ template <typename T, bool USE_TR, int MINW>
 __global__ __launch_bounds__(256, MINW) void attn_bwd_kernel(const T* __restrict__ qkv, const float* __restrict__ qkv_bias,
                                                           const int* __restrict__ win2tok, int L, const T* __restrict__ dout,
                                                           const float* __restrict__ rel_table, int rel_rows, int ws,
-                                                          const int* __restrict__ region_ids, int nW, int Bw, int N, int nH, float scale,
-                                                          int parts,
+                                                          const float* __restrict__ bias_frag, const int* __restrict__ region_ids, int nW,
+                                                          int Bw, int N, int nH, float scale, int parts,
                                                           T* __restrict__ dqkv, float* __restrict__ dbias_ws,
                                                           float* __restrict__ dpad_ws) {
     using Cfg = AttnCfg<T>;
@@ -334,8 +345,9 @@ __global__ __launch_bounds__(256, MINW) void attn_bwd_kernel(const T* __restrict
     const int C = nH * HD;
     const T* src = qkv + h * HD;
     T* dst = dqkv + h * HD;
-    load_rel_table(rel_table, rel_rows, nH, h, tab, lane);  // visible after the first barrier of the window loop
+    if (!bias_frag) load_rel_table(rel_table, rel_rows, nH, h, tab, lane);  // visible after the first barrier of the window loop
     const RelIdx ri = make_relidx(ws, c, g);
+    const float* bias_f = bias_frag ? bias_frag + (long)h * FRAG_ELEMS : nullptr;
 
     f32x4 db[4][4];
 #pragma unroll
@@ -360,7 +372,7 @@ __global__ __launch_bounds__(256, MINW) void attn_bwd_kernel(const T* __restrict
         stage_rows<T>(src + C, 3L * C, mytok, tok_base, N, active, 1.f, qkv_bias + C + h * HD, bufB, lane);
         __syncthreads();
         f32x4 p[4][4];
-        scores_softmax<T>(bufA, bufB, tab, ri, N, myreg, masked, lane, c, g, p);
+        scores_softmax<T>(bufA, bufB, bias_f, tab, ri, N, myreg, masked, lane, c, g, p);
         store_pt<T>(Ps, p, c, g);
         __syncthreads();  // score reads of bufA/bufB done; Ps visible
 
@@ -489,6 +501,24 @@ __global__ void relpos_bias_fwd_kernel(const float* __restrict__ table, const lo
     bias_frag[i] = v;
 }
 
+// same, with the index computed in closed form (a(q) - a(key) + (ws-1) 2ws) instead of read from the index buffer
+__global__ void relpos_bias_frag_from_table_kernel(const float* __restrict__ table, int ws, int N, int nH, float* __restrict__ bias_frag) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nH * FRAG_ELEMS) return;
+    const int h = i / FRAG_ELEMS, e = i % FRAG_ELEMS;
+    const int r = e & 3, lane = (e >> 2) & 63, f = e >> 8;
+    const int c = lane & 15, g = lane >> 4;
+    const int q = 16 * (f & 3) + c, key = 16 * (f >> 2) + 4 * g + r;
+    float v = 0.f;
+    if (key >= N) v = -1.0e30f;
+    else if (q < N) {
+        const int w2 = 2 * ws - 1;
+        const int idx = (q / ws - key / ws + ws - 1) * w2 + (q % ws - key % ws + ws - 1);
+        v = table[(long)idx * nH + h];
+    }
+    bias_frag[i] = v;
+}
+
 // dense [nW][N][N] -> frag layout (padding 0)
 __global__ void dense_to_frag_kernel(const float* __restrict__ dense, int nM, int N, float* __restrict__ frag) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -527,7 +557,6 @@ inline int bwd_parts(int Bw, int nH) {
 
 #define STREAM(s_) hipStream_t stream = reinterpret_cast<hipStream_t>(s_)
 
-extern "C" int esvit_attn_frag_elems(int N) { return N <= NP ? FRAG_ELEMS : -1; }
 
 extern "C" int esvit_relpos_bias_fwd(const float* table, const int64_t* index, int N, int nH, float* bias_frag, esvit_stream_t s_) {
     STREAM(s_);
@@ -547,11 +576,16 @@ extern "C" int esvit_dense_to_frag(const float* dense, int n_mats, int N, float*
     return ESVIT_OK;
 }
 
+int esvit_big_relpos_bias_bwd(const float* dbias_ws, int parts, const int64_t* index, int N, int nH, int table_rows, float* dtable,
+                              hipStream_t stream);
+int esvit_big_npb();
+
 extern "C" int esvit_relpos_bias_bwd(const float* dbias_ws, int parts, const int64_t* index, int N, int nH, int table_rows,
                                      float* dtable, esvit_stream_t s_) {
     STREAM(s_);
-    ESVIT_CHECK_ARG(dbias_ws && index && dtable && parts > 0 && N > 0 && N <= NP && nH > 0 && table_rows > 0,
+    ESVIT_CHECK_ARG(dbias_ws && index && dtable && parts > 0 && N > 0 && N <= esvit_big_npb() && nH > 0 && table_rows > 0,
                     "esvit_relpos_bias_bwd: bad args");
+    if (N > NP) return esvit_big_relpos_bias_bwd(dbias_ws, parts, index, N, nH, table_rows, dtable, stream);
     hipError_t e = hipMemsetAsync(dtable, 0, (size_t)table_rows * nH * sizeof(float), stream);
     if (e != hipSuccess) {
         esvit_set_error("esvit_relpos_bias_bwd: memset failed: %s", hipGetErrorString(e));
@@ -573,17 +607,48 @@ static int g_attn_minw = 1;  // waves per SIMD the backward kernel is compiled f
 extern "C" void esvit_debug_set_attn_tr_read(int on) { g_attn_use_tr = on; }
 extern "C" void esvit_debug_set_attn_bwd_waves(int w) { g_attn_minw = w; }
 
+// 14x14-window kernels (window_attn_big.hip)
+int esvit_big_frag_elems();
+int esvit_big_npb();
+int esvit_big_parts(int Bw, int nH);
+int esvit_big_pad_rows(int Bw, int nH, int dtype);
+int esvit_big_attn_fwd(int dtype, const void* qkv, const float* qkv_bias, const int32_t* win2tok, int L, const float* rel_table, int ws,
+                       const int32_t* region_ids, int nW, int nB, int N, int nH, float scale, void* out, float* lse, float* attn_out,
+                       hipStream_t stream);
+int esvit_big_attn_bwd(int dtype, int use_tr, const void* qkv, const float* qkv_bias, const int32_t* win2tok, int L, const void* dout,
+                       const void* fout, const float* lse, const float* rel_table, int ws, const int32_t* region_ids, int nW, int nB, int N,
+                       int nH, float scale, void* dqkv, float* dbias_ws, float* dpad_ws, hipStream_t stream);
+int esvit_big_relpos_bias_bwd(const float* dbias_ws, int parts, const int64_t* index, int N, int nH, int table_rows, float* dtable,
+                              hipStream_t stream);
+
+extern "C" int esvit_attn_frag_elems(int N) { return N <= NP ? FRAG_ELEMS : (N <= esvit_big_npb() ? esvit_big_frag_elems() : -1); }
+extern "C" int esvit_window_attn_lse_elems(int N) { return N <= NP ? 0 : esvit_big_npb(); }
+extern "C" int esvit_window_attn_bwd_parts(int N, int Bw, int nH) { return N <= NP ? bwd_parts(Bw, nH) : esvit_big_parts(Bw, nH); }
+extern "C" int esvit_window_attn_bwd_pad_rows(int dtype, int N, int Bw, int nH) {
+    return N <= NP ? bwd_parts(Bw, nH) : esvit_big_pad_rows(Bw, nH, dtype);
+}
+
+static int fill_bias_frag(const float* rel_table, int ws, int N, int nH, float* bias_frag_ws, hipStream_t stream) {
+    // closed-form index (no index tensor needed): same values as relative_position_index
+    hipLaunchKernelGGL(relpos_bias_frag_from_table_kernel, dim3(ceil_div((long)nH * FRAG_ELEMS, 256)), dim3(256), 0, stream, rel_table, ws, N,
+                       nH, bias_frag_ws);
+    ESVIT_CHECK_LAUNCH("relpos_bias(frag)");
+    return ESVIT_OK;
+}
+
 extern "C" int esvit_window_attn_fwd(int dtype, const void* qkv, const float* qkv_bias, const int32_t* win2tok, int L,
-                                     const float* rel_table, int ws, const int32_t* region_ids, int nW, int nB, int N, int nH, int hd,
-                                     float scale, void* out, float* attn_out, esvit_stream_t s_) {
+                                     const float* rel_table, int ws, float* bias_frag_ws, const int32_t* region_ids, int nW, int nB, int N,
+                                     int nH, int hd, float scale, void* out, float* lse, float* attn_out, esvit_stream_t s_) {
     STREAM(s_);
     ESVIT_CHECK_ARG(qkv && qkv_bias && win2tok && rel_table && out && nB > 0 && nW > 0 && nH > 0 && L > 0 && ws > 0 && N == ws * ws,
                     "esvit_window_attn_fwd: bad args");
-    const int rel_rows = (2 * ws - 1) * (2 * ws - 1);
     ESVIT_CHECK_ARG(hd == HD, "esvit_window_attn_fwd: head_dim %d unsupported (32 only)", hd);
-    if (N > NP) {
-        esvit_set_error("esvit_window_attn_fwd: N=%d > %d (14x14 windows) not built yet", N, NP);
-        return ESVIT_ERR_UNSUPPORTED;
+    ESVIT_CHECK_ARG(dtype == ESVIT_BF16 || dtype == ESVIT_F32, "esvit_window_attn_fwd: bad dtype");
+    if (N > NP) return esvit_big_attn_fwd(dtype, qkv, qkv_bias, win2tok, L, rel_table, ws, region_ids, nW, nB, N, nH, scale, out, lse, attn_out, stream);
+    const int rel_rows = (2 * ws - 1) * (2 * ws - 1);
+    if (bias_frag_ws) {
+        int rc = fill_bias_frag(rel_table, ws, N, nH, bias_frag_ws, stream);
+        if (rc != ESVIT_OK) return rc;
     }
     const int Bw = nB * nW;
     const int grid = ceil_div((long)Bw * nH, 4);
@@ -592,35 +657,35 @@ extern "C" int esvit_window_attn_fwd(int dtype, const void* qkv, const float* qk
         auto kern = attn_fwd_kernel<bf16>;
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, (const bf16*)qkv, qkv_bias, win2tok, L, rel_table, rel_rows, ws,
-                           region_ids, nW, Bw, N, nH, scale, (bf16*)out, attn_out);
-    } else if (dtype == ESVIT_F32) {
+                           (const float*)bias_frag_ws, region_ids, nW, Bw, N, nH, scale, (bf16*)out, attn_out);
+    } else {
         const size_t lds = 4 * (size_t)AttnCfg<float>::FWD_PER_WAVE * sizeof(float);
         auto kern = attn_fwd_kernel<float>;
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, (const float*)qkv, qkv_bias, win2tok, L, rel_table, rel_rows, ws,
-                           region_ids, nW, Bw, N, nH, scale, (float*)out, attn_out);
-    } else {
-        esvit_set_error("esvit_window_attn_fwd: bad dtype");
-        return ESVIT_ERR_ARG;
+                           (const float*)bias_frag_ws, region_ids, nW, Bw, N, nH, scale, (float*)out, attn_out);
     }
     ESVIT_CHECK_LAUNCH("window_attn_fwd");
     return ESVIT_OK;
 }
 
-extern "C" int esvit_window_attn_bwd_parts(int Bw, int nH) { return bwd_parts(Bw, nH); }
-
-extern "C" int esvit_window_attn_bwd(int dtype, const void* qkv, const float* qkv_bias, const int32_t* win2tok, int L,
-                                     const void* dout, const float* rel_table, int ws, const int32_t* region_ids, int nW, int nB, int N,
-                                     int nH, int hd, float scale, void* dqkv, float* dbias_ws, float* dpad_ws, esvit_stream_t s_) {
+extern "C" int esvit_window_attn_bwd(int dtype, const void* qkv, const float* qkv_bias, const int32_t* win2tok, int L, const void* dout,
+                                     const void* fwd_out, const float* lse, const float* rel_table, int ws, float* bias_frag_ws,
+                                     const int32_t* region_ids, int nW, int nB, int N, int nH, int hd, float scale, void* dqkv,
+                                     float* dbias_ws, float* dpad_ws, esvit_stream_t s_) {
     STREAM(s_);
     ESVIT_CHECK_ARG(qkv && qkv_bias && win2tok && dout && rel_table && dqkv && dbias_ws && dpad_ws && nB > 0 && nW > 0 && nH > 0 && L > 0 &&
                         ws > 0 && N == ws * ws,
                     "esvit_window_attn_bwd: bad args");
-    const int rel_rows = (2 * ws - 1) * (2 * ws - 1);
     ESVIT_CHECK_ARG(hd == HD, "esvit_window_attn_bwd: head_dim %d unsupported (32 only)", hd);
-    if (N > NP) {
-        esvit_set_error("esvit_window_attn_bwd: N=%d > %d (14x14 windows) not built yet", N, NP);
-        return ESVIT_ERR_UNSUPPORTED;
+    ESVIT_CHECK_ARG(dtype == ESVIT_BF16 || dtype == ESVIT_F32, "esvit_window_attn_bwd: bad dtype");
+    if (N > NP)
+        return esvit_big_attn_bwd(dtype, g_attn_use_tr, qkv, qkv_bias, win2tok, L, dout, fwd_out, lse, rel_table, ws, region_ids, nW, nB, N, nH,
+                                  scale, dqkv, dbias_ws, dpad_ws, stream);
+    const int rel_rows = (2 * ws - 1) * (2 * ws - 1);
+    if (bias_frag_ws) {
+        int rc = fill_bias_frag(rel_table, ws, N, nH, bias_frag_ws, stream);
+        if (rc != ESVIT_OK) return rc;
     }
     const int Bw = nB * nW;
     const int parts = bwd_parts(Bw, nH);
@@ -631,15 +696,13 @@ extern "C" int esvit_window_attn_bwd(int dtype, const void* qkv, const float* qk
         auto kern = g_attn_minw == 2 ? attn_bwd_kernel<TT, TR, 2> : attn_bwd_kernel<TT, TR, 1>;                                \
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);   \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, (const TT*)qkv, qkv_bias, win2tok, L, (const TT*)dout,      \
-                           rel_table, rel_rows, ws, region_ids, nW, Bw, N, nH, scale, parts, (TT*)dqkv, dbias_ws, dpad_ws);      \
+                           rel_table, rel_rows, ws, (const float*)bias_frag_ws, region_ids, nW, Bw, N, nH, scale, parts,        \
+                           (TT*)dqkv, dbias_ws, dpad_ws);                                                                       \
     }
     if (dtype == ESVIT_BF16) {
         if (g_attn_use_tr) LAUNCH_BWD(bf16, true) else LAUNCH_BWD(bf16, false)
-    } else if (dtype == ESVIT_F32) {
-        LAUNCH_BWD(float, false)
     } else {
-        esvit_set_error("esvit_window_attn_bwd: bad dtype");
-        return ESVIT_ERR_ARG;
+        LAUNCH_BWD(float, false)
     }
 #undef LAUNCH_BWD
     ESVIT_CHECK_LAUNCH("window_attn_bwd");

@@ -1,0 +1,732 @@
+// Window attention for 14x14 windows (N = 196 tokens, head_dim 32): the W=14 configurations of the reference
+// (swin_*_patch4_window14_224.yaml).  Same mathematics and token-ordered I/O as window_attn.hip,
+// but a 196x196 score tile does not fit one wave's registers, so the work is blocked flash-style:
+//
+//   forward        one workgroup per (window, head): K, V staged once in LDS; every wave owns 32-query blocks, forms
+//                  S^T = K (scale Q)^T for its block (14 x 2 MFMA tiles), softmax in registers, writes P to LDS and
+//                  multiplies by V (transpose read).  The per-query log-sum-exp is saved for the backward.
+//   backward dQ    wave <-> fixed (head, query block), looping over windows so the relative-position-bias gradient of
+//                  its 32 x 196 strip accumulates in registers (no atomics); dP^T = V dO^T, dS, dQ = scale dS K.
+//   backward dK,dV one workgroup per (window, head): scale*Q and dO staged once; every wave owns 32-key blocks, rebuilds
+//                  P^T from the saved log-sum-exp, delta = rowsum(dO o O), dV = P^T dO, dK = dS^T (scale Q).
+//
+// Tokens are padded to 224 = 14 MFMA tiles (keys >= 196 get -1e30, never any probability).  Small per-window tables live
+// in LDS: slot->token map, a(t) = (t/ws)(2ws-1) + t%ws packed with the shift-mask region label, and the head's column
+// of the (2ws-1)^2-entry relative-position table (bias = table[a(q) - a(key) + (ws-1) 2ws]).
+#include "common.h"
+#include "mfma.h"
+#include "../../include/esvit_hip.h"
+
+namespace {
+
+constexpr int HD = 32;
+constexpr int NT = 14;         // 16-wide tiles per window side
+constexpr int NPB = NT * 16;   // 224 padded tokens
+constexpr int NQB = NPB / 32;  // 7 blocks of 32 queries / keys
+constexpr int TAB_FLOATS = 768;
+
+template <typename T>
+struct BigCfg {
+    static constexpr int VEC = ElemTraits<T>::VEC;
+    static constexpr int LDQ = HD + VEC;    // [*][LDQ] images with d contiguous
+    static constexpr int LDP = NPB + VEC;   // [32][LDP] P / dS image of one query block
+    static constexpr int WAVES = sizeof(T) == 2 ? 4 : 2;  // fp32 parity mode: half the waves, same LDS budget
+    static constexpr int FULL = NPB * LDQ;  // one [224][LDQ] image
+    static constexpr int BLK = 32 * LDQ;    // one [32][LDQ] image
+    static constexpr int PIMG = 32 * LDP;
+    static constexpr int TABLE_BYTES = TAB_FLOATS * 4 + 2 * NPB * 4 + 2 * NPB * 4;  // tab, tok, packed, lse, delta
+};
+
+struct BigTables {
+    float* tab;
+    int* tok;
+    int* pk;      // a(t) | region << 16
+    float* lse;
+    float* delta;
+};
+__device__ __forceinline__ BigTables carve_tables(char* p) {
+    BigTables t;
+    t.tab = reinterpret_cast<float*>(p);
+    t.tok = reinterpret_cast<int*>(p + TAB_FLOATS * 4);
+    t.pk = t.tok + NPB;
+    t.lse = reinterpret_cast<float*>(t.pk + NPB);
+    t.delta = t.lse + NPB;
+    return t;
+}
+
+// per-window tables (all threads of the block)
+__device__ __forceinline__ void load_window_tables(const BigTables& tb, const int* __restrict__ win2tok, const int* __restrict__ region_ids,
+                                                   int w, int N, int ws, bool active) {
+    const int w2 = 2 * ws - 1;
+    for (int t = threadIdx.x; t < NPB; t += blockDim.x) {
+        int tok = -1, pk = 0;
+        if (t < N) {
+            if (active) tok = win2tok[(long)w * N + t];
+            const int reg = region_ids ? region_ids[(long)w * N + t] : 0;
+            pk = ((t / ws) * w2 + t % ws) | (reg << 16);
+        }
+        tb.tok[t] = tok;
+        tb.pk[t] = pk;
+    }
+}
+__device__ __forceinline__ void load_table_column(const BigTables& tb, const float* __restrict__ table, int rows, int nH, int h) {
+    for (int t = threadIdx.x; t < rows; t += blockDim.x) tb.tab[t] = table[(long)t * nH + h];
+}
+
+// stage `nrows` window slots (first slot s0) of a token-ordered matrix into a [nrows][LDQ] image; `nthr` threads cooperate
+template <typename T>
+__device__ __forceinline__ void stage_slots(const T* __restrict__ g, long row_stride, const int* tok_lds, long tok_base, int s0, int nrows,
+                                            int N, float scale, const float* __restrict__ pad, T* lds, int tid, int nthr) {
+    constexpr int VEC = BigCfg<T>::VEC, LDQ = BigCfg<T>::LDQ, VPR = HD / VEC;
+    for (int v = tid; v < nrows * VPR; v += nthr) {
+        const int rl = v / VPR, dv = v % VPR;
+        const int t = s0 + rl;
+        Vec16<T> x = zero16<T>();
+        if (t < N) {
+            const int tok = tok_lds[t];
+            if (tok >= 0) {
+                x = ld16<T>(g + (tok_base + tok) * row_stride + dv * VEC);
+            } else if (pad) {
+#pragma unroll
+                for (int e = 0; e < Vec16<T>::N; ++e) x.set(e, pad[dv * VEC + e]);
+            }
+        }
+        if (scale != 1.f) {
+#pragma unroll
+            for (int e = 0; e < Vec16<T>::N; ++e) x.set(e, x.get(e) * scale);
+        }
+        st16<T>(lds + rl * LDQ + dv * VEC, x);
+    }
+}
+
+template <typename T>
+__device__ __forceinline__ void store_frag4(T* p, f32x4 v) {
+    if constexpr (sizeof(T) == 4) {
+        *reinterpret_cast<f32x4*>(p) = v;
+    } else {
+        bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+        *reinterpret_cast<bf16x4*>(p) = o;
+    }
+}
+
+// bias + mask value of the score element (query slot q, key slot k)
+__device__ __forceinline__ float score_bias(const BigTables& tb, int pq, int pkk, bool qok, bool kok, int off, bool masked) {
+    float v = (qok && kok) ? tb.tab[(pq & 0xffff) - (pkk & 0xffff) + off] : 0.f;
+    if (!kok) v = -1.0e30f;
+    if (masked && (pq >> 16) != (pkk >> 16)) v += -100.f;
+    return v;
+}
+
+// write a [32 rows][32 d] result (D layout acc[ti][jd]: row 16ti+4g+r, cols 16jd+c) to token rows; pad slots -> pad sums
+template <typename T>
+__device__ __forceinline__ void store_block_rows(const f32x4 (&acc)[2][2], float mul, T* __restrict__ dst, long row_stride,
+                                                 const int* tok_lds, long tok_base, int s0, int N, bool active, f32x2* pad, int c, int g) {
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int t = s0 + 16 * ti + 4 * g + r;
+            if (!active || t >= N) continue;
+            const int tok = tok_lds[t];
+            const float v0 = acc[ti][0][r] * mul, v1 = acc[ti][1][r] * mul;
+            if (tok >= 0) {
+                T* rowp = dst + (tok_base + tok) * row_stride;
+                rowp[c] = from_f32<T>(v0);
+                rowp[16 + c] = from_f32<T>(v1);
+            } else if (pad) {
+                (*pad)[0] += v0;
+                (*pad)[1] += v1;
+            }
+        }
+}
+
+// -------------------------------------------------------------------------------------------------------------
+// forward
+// -------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(BigCfg<T>::WAVES * 64) void attn_big_fwd_kernel(
+    const T* __restrict__ qkv, const float* __restrict__ qkv_bias, const int* __restrict__ win2tok, int L,
+    const float* __restrict__ rel_table, int rel_rows, int ws, const int* __restrict__ region_ids, int nW, int Bw, int N, int nH,
+    float scale, T* __restrict__ out, float* __restrict__ lse_out, float* __restrict__ attn_out) {
+    using Cfg = BigCfg<T>;
+    constexpr int LDQ = Cfg::LDQ, LDP = Cfg::LDP, WAVES = Cfg::WAVES;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const BigTables tb = carve_tables(smem_raw);
+    T* Ks = reinterpret_cast<T*>(smem_raw + Cfg::TABLE_BYTES);
+    T* Vs = Ks + Cfg::FULL;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 15, g = lane >> 4;
+    T* Qs = Vs + Cfg::FULL + wave * (Cfg::BLK + Cfg::PIMG);
+    T* Ps = Qs + Cfg::BLK;
+
+    const int unit = blockIdx.x;  // (bw, h)
+    const int bw = unit / nH, h = unit % nH;
+    const int C = nH * HD;
+    const long tok_base = (long)(bw / nW) * L;
+    const T* src = qkv + h * HD;
+    const bool masked = region_ids != nullptr;
+    const int off = (ws - 1) * 2 * ws;
+
+    load_window_tables(tb, win2tok, region_ids, bw % nW, N, ws, true);
+    load_table_column(tb, rel_table, rel_rows, nH, h);
+    __syncthreads();
+    stage_slots<T>(src + C, 3L * C, tb.tok, tok_base, 0, NPB, N, 1.f, qkv_bias + C + h * HD, Ks, threadIdx.x, WAVES * 64);
+    stage_slots<T>(src + 2 * C, 3L * C, tb.tok, tok_base, 0, NPB, N, 1.f, qkv_bias + 2 * C + h * HD, Vs, threadIdx.x, WAVES * 64);
+
+    for (int pass = 0; pass < (NQB + WAVES - 1) / WAVES; ++pass) {
+        const int qb = wave + pass * WAVES;
+        const bool valid = qb < NQB;
+        const int q0 = valid ? 32 * qb : 0;
+        __syncthreads();  // K, V staged (first pass) / previous pass finished with Qs, Ps
+        stage_slots<T>(src, 3L * C, tb.tok, tok_base, q0, 32, N, scale, qkv_bias + h * HD, Qs, lane, 64);
+        __syncthreads();
+
+        f32x4 p[NT][2];
+        {
+            Frag<T> qf[2];
+            qf[0] = frag_kc<T>(Qs, LDQ, 0, 0, c, g);
+            qf[1] = frag_kc<T>(Qs, LDQ, 16, 0, c, g);
+            const int pq0 = tb.pk[q0 + c], pq1 = tb.pk[q0 + 16 + c];
+            const bool qok0 = q0 + c < N, qok1 = q0 + 16 + c < N;
+#pragma unroll
+            for (int i = 0; i < NT; ++i) {
+                const Frag<T> kf = frag_kc<T>(Ks, LDQ, 16 * i, 0, c, g);
+                f32x4 b0, b1;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int k = 16 * i + 4 * g + r;
+                    const int pkk = tb.pk[k];
+                    b0[r] = score_bias(tb, pq0, pkk, qok0, k < N, off, masked);
+                    b1[r] = score_bias(tb, pq1, pkk, qok1, k < N, off, masked);
+                }
+                p[i][0] = b0;
+                p[i][1] = b1;
+                mma(kf, qf[0], p[i][0]);
+                mma(kf, qf[1], p[i][1]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            float m = -3.0e38f;
+#pragma unroll
+            for (int i = 0; i < NT; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) m = fmaxf(m, p[i][j][r]);
+            m = fmaxf(m, __shfl_xor(m, 16, 64));
+            m = fmaxf(m, __shfl_xor(m, 32, 64));
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < NT; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float e = __expf(p[i][j][r] - m);
+                    p[i][j][r] = e;
+                    s += e;
+                }
+            s += __shfl_xor(s, 16, 64);
+            s += __shfl_xor(s, 32, 64);
+            const float inv = 1.f / s;
+#pragma unroll
+            for (int i = 0; i < NT; ++i) p[i][j] *= inv;
+            const int q = q0 + 16 * j + c;
+            if (valid && g == 0 && lse_out) lse_out[(long)unit * NPB + q] = m + __logf(s);
+        }
+        if (attn_out && valid) {
+#pragma unroll
+            for (int i = 0; i < NT; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int q = q0 + 16 * j + c, key = 16 * i + 4 * g + r;
+                        if (q < N && key < N) attn_out[((long)unit * N + q) * N + key] = p[i][j][r];
+                    }
+        }
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) store_frag4<T>(Ps + (16 * j + c) * LDP + 16 * i + 4 * g, p[i][j]);
+        __syncthreads();
+
+        f32x4 o[2][2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            o[a][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+            o[a][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int ks = 0; ks < NPB / 32; ++ks) {
+            const Frag<T> v0 = frag_ks<T, true>(Vs, LDQ, 0, 32 * ks, c, g);
+            const Frag<T> v1 = frag_ks<T, true>(Vs, LDQ, 16, 32 * ks, c, g);
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                const Frag<T> pf = frag_kc<T>(Ps, LDP, 16 * a, 32 * ks, c, g);
+                mma(pf, v0, o[a][0]);
+                mma(pf, v1, o[a][1]);
+            }
+        }
+        store_block_rows<T>(o, 1.f, out + h * HD, (long)C, tb.tok, tok_base, q0, N, valid, nullptr, c, g);
+    }
+}
+
+// -------------------------------------------------------------------------------------------------------------
+// backward, part 1: dQ and the relative-position-bias gradient.  grid = parts * nH * GROUPS workgroups; wave `wave` of
+// group `grp` owns query block qb = grp * WAVES + wave for every window bw = part + k * parts.
+// -------------------------------------------------------------------------------------------------------------
+template <typename T, bool USE_TR>
+__global__ __launch_bounds__(BigCfg<T>::WAVES * 64) void attn_big_bwd_dq_kernel(
+    const T* __restrict__ qkv, const float* __restrict__ qkv_bias, const int* __restrict__ win2tok, int L, const T* __restrict__ dout,
+    const float* __restrict__ rel_table, int rel_rows, int ws, const int* __restrict__ region_ids, int nW, int Bw, int N, int nH,
+    float scale, int parts, T* __restrict__ dqkv, float* __restrict__ dbias_ws) {
+    using Cfg = BigCfg<T>;
+    constexpr int LDQ = Cfg::LDQ, LDP = Cfg::LDP, WAVES = Cfg::WAVES;
+    constexpr int GROUPS = (NQB + WAVES - 1) / WAVES;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const BigTables tb = carve_tables(smem_raw);
+    T* Ks = reinterpret_cast<T*>(smem_raw + Cfg::TABLE_BYTES);
+    T* Vs = Ks + Cfg::FULL;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 15, g = lane >> 4;
+    T* Qs = Vs + Cfg::FULL + wave * (2 * Cfg::BLK + Cfg::PIMG);
+    T* Os = Qs + Cfg::BLK;
+    T* Ss = Os + Cfg::BLK;  // dS image [32 q][LDP]
+
+    const int grp = blockIdx.x % GROUPS;
+    const int ph = blockIdx.x / GROUPS;  // (part, h)
+    const int h = ph % nH, part = ph / nH;
+    const int qb = grp * WAVES + wave;
+    const bool wave_ok = qb < NQB;
+    const int q0 = wave_ok ? 32 * qb : 0;
+    const int C = nH * HD;
+    const bool masked = region_ids != nullptr;
+    const int off = (ws - 1) * 2 * ws;
+    const T* src = qkv + h * HD;
+
+    f32x4 db[NT][2];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        db[i][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+        db[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    load_table_column(tb, rel_table, rel_rows, nH, h);
+
+    const int iters = (Bw + parts - 1) / parts;
+    for (int it = 0; it < iters; ++it) {
+        const int bw = part + it * parts;
+        const bool win_ok = bw < Bw;
+        const int bwc = win_ok ? bw : 0;
+        const bool active = win_ok && wave_ok;
+        const long tok_base = (long)(bwc / nW) * L;
+        __syncthreads();  // previous window's reads are complete
+        load_window_tables(tb, win2tok, region_ids, bwc % nW, N, ws, win_ok);
+        __syncthreads();
+        stage_slots<T>(src + C, 3L * C, tb.tok, tok_base, 0, NPB, N, 1.f, qkv_bias + C + h * HD, Ks, threadIdx.x, WAVES * 64);
+        stage_slots<T>(src + 2 * C, 3L * C, tb.tok, tok_base, 0, NPB, N, 1.f, qkv_bias + 2 * C + h * HD, Vs, threadIdx.x, WAVES * 64);
+        stage_slots<T>(src, 3L * C, tb.tok, tok_base, q0, 32, N, scale, qkv_bias + h * HD, Qs, lane, 64);
+        stage_slots<T>(dout + h * HD, (long)C, tb.tok, tok_base, q0, 32, N, 1.f, nullptr, Os, lane, 64);
+        __syncthreads();
+
+        // P^T strip (softmax over all keys: the wave holds every key of its 32 queries)
+        f32x4 p[NT][2];
+        {
+            Frag<T> qf[2];
+            qf[0] = frag_kc<T>(Qs, LDQ, 0, 0, c, g);
+            qf[1] = frag_kc<T>(Qs, LDQ, 16, 0, c, g);
+            const int pq0 = tb.pk[q0 + c], pq1 = tb.pk[q0 + 16 + c];
+            const bool qok0 = q0 + c < N, qok1 = q0 + 16 + c < N;
+#pragma unroll
+            for (int i = 0; i < NT; ++i) {
+                const Frag<T> kf = frag_kc<T>(Ks, LDQ, 16 * i, 0, c, g);
+                f32x4 b0, b1;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int k = 16 * i + 4 * g + r;
+                    const int pkk = tb.pk[k];
+                    b0[r] = score_bias(tb, pq0, pkk, qok0, k < N, off, masked);
+                    b1[r] = score_bias(tb, pq1, pkk, qok1, k < N, off, masked);
+                }
+                p[i][0] = b0;
+                p[i][1] = b1;
+                mma(kf, qf[0], p[i][0]);
+                mma(kf, qf[1], p[i][1]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            float m = -3.0e38f;
+#pragma unroll
+            for (int i = 0; i < NT; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) m = fmaxf(m, p[i][j][r]);
+            m = fmaxf(m, __shfl_xor(m, 16, 64));
+            m = fmaxf(m, __shfl_xor(m, 32, 64));
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < NT; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float e = __expf(p[i][j][r] - m);
+                    p[i][j][r] = e;
+                    s += e;
+                }
+            s += __shfl_xor(s, 16, 64);
+            s += __shfl_xor(s, 32, 64);
+            const float inv = 1.f / s;
+#pragma unroll
+            for (int i = 0; i < NT; ++i) p[i][j] *= inv;
+        }
+        // dP^T = V dO^T, dS = P o (dP - delta), one query tile at a time
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const Frag<T> of = frag_kc<T>(Os, LDQ, 16 * j, 0, c, g);
+            f32x4 dp[NT];
+            float d = 0.f;
+#pragma unroll
+            for (int i = 0; i < NT; ++i) {
+                const Frag<T> vf = frag_kc<T>(Vs, LDQ, 16 * i, 0, c, g);
+                dp[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+                mma(vf, of, dp[i]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) d += p[i][j][r] * dp[i][r];
+            }
+            d += __shfl_xor(d, 16, 64);
+            d += __shfl_xor(d, 32, 64);
+#pragma unroll
+            for (int i = 0; i < NT; ++i) {
+                const f32x4 ds = p[i][j] * (dp[i] - d);
+                if (active) db[i][j] += ds;
+                store_frag4<T>(Ss + (16 * j + c) * LDP + 16 * i + 4 * g, ds);
+            }
+        }
+        __syncthreads();
+        // dQ = scale * dS K
+        f32x4 aq[2][2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            aq[a][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+            aq[a][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int ks = 0; ks < NPB / 32; ++ks) {
+            const Frag<T> k0 = frag_ks<T, USE_TR>(Ks, LDQ, 0, 32 * ks, c, g);
+            const Frag<T> k1 = frag_ks<T, USE_TR>(Ks, LDQ, 16, 32 * ks, c, g);
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                const Frag<T> sf = frag_kc<T>(Ss, LDP, 16 * a, 32 * ks, c, g);
+                mma(sf, k0, aq[a][0]);
+                mma(sf, k1, aq[a][1]);
+            }
+        }
+        store_block_rows<T>(aq, scale, dqkv + h * HD, 3L * C, tb.tok, tok_base, q0, N, active, nullptr, c, g);
+    }
+    if (wave_ok) {
+        // frag layout of the NPB x NPB bias gradient: ((ki*NT + qj)*64 + lane)*4 + r, qj = 2*qb + j
+        float* wsp = dbias_ws + ((long)part * nH + h) * (NT * NT * 256);
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) *reinterpret_cast<f32x4*>(wsp + ((i * NT + 2 * qb + j) * 64 + lane) * 4) = db[i][j];
+    }
+}
+
+// -------------------------------------------------------------------------------------------------------------
+// backward, part 2: dK and dV.  One workgroup per (window, head); every wave owns 32-key blocks.
+// -------------------------------------------------------------------------------------------------------------
+template <typename T, bool USE_TR>
+__global__ __launch_bounds__(BigCfg<T>::WAVES * 64) void attn_big_bwd_dkv_kernel(
+    const T* __restrict__ qkv, const float* __restrict__ qkv_bias, const int* __restrict__ win2tok, int L, const T* __restrict__ dout,
+    const T* __restrict__ fout, const float* __restrict__ lse_in, const float* __restrict__ rel_table, int rel_rows, int ws,
+    const int* __restrict__ region_ids, int nW, int Bw, int N, int nH, float scale, T* __restrict__ dqkv, float* __restrict__ dpad_ws) {
+    using Cfg = BigCfg<T>;
+    constexpr int LDQ = Cfg::LDQ, WAVES = Cfg::WAVES;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const BigTables tb = carve_tables(smem_raw);
+    T* Qs = reinterpret_cast<T*>(smem_raw + Cfg::TABLE_BYTES);  // scale*Q, [224][LDQ]
+    T* Os = Qs + Cfg::FULL;                                      // dO,      [224][LDQ]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 15, g = lane >> 4;
+    T* Kb = Os + Cfg::FULL + wave * (2 * Cfg::BLK + Cfg::FULL);
+    T* Vb = Kb + Cfg::BLK;
+    T* Pq = Vb + Cfg::BLK;  // [224 q][LDQ]: P (then dS) of this key block, stored [q][key_local]
+
+    const int unit = blockIdx.x;
+    const int bw = unit / nH, h = unit % nH;
+    const int C = nH * HD;
+    const long tok_base = (long)(bw / nW) * L;
+    const T* src = qkv + h * HD;
+    const bool masked = region_ids != nullptr;
+    const int off = (ws - 1) * 2 * ws;
+
+    load_window_tables(tb, win2tok, region_ids, bw % nW, N, ws, true);
+    load_table_column(tb, rel_table, rel_rows, nH, h);
+    __syncthreads();
+    stage_slots<T>(src, 3L * C, tb.tok, tok_base, 0, NPB, N, scale, qkv_bias + h * HD, Qs, threadIdx.x, WAVES * 64);
+    stage_slots<T>(dout + h * HD, (long)C, tb.tok, tok_base, 0, NPB, N, 1.f, nullptr, Os, threadIdx.x, WAVES * 64);
+    // per-query statistics: saved log-sum-exp and delta = sum_d dO[q,d] * O[q,d]
+    for (int t = threadIdx.x; t < NPB; t += WAVES * 64) {
+        float l = 0.f, d = 0.f;
+        if (t < N) {
+            l = lse_in[(long)unit * NPB + t];
+            const int tok = tb.tok[t];
+            if (tok >= 0) {
+                const T* orow = fout + (tok_base + tok) * (long)C + h * HD;
+                const T* grow = dout + (tok_base + tok) * (long)C + h * HD;
+#pragma unroll
+                for (int e = 0; e < HD; ++e) d += to_f32(orow[e]) * to_f32(grow[e]);
+            }
+        }
+        tb.lse[t] = l;
+        tb.delta[t] = d;
+    }
+    f32x2 padk = {0.f, 0.f}, padv = {0.f, 0.f};
+
+    for (int pass = 0; pass < (NQB + WAVES - 1) / WAVES; ++pass) {
+        const int kb = wave + pass * WAVES;
+        const bool valid = kb < NQB;
+        const int k0 = valid ? 32 * kb : 0;
+        __syncthreads();
+        stage_slots<T>(src + C, 3L * C, tb.tok, tok_base, k0, 32, N, 1.f, qkv_bias + C + h * HD, Kb, lane, 64);
+        stage_slots<T>(src + 2 * C, 3L * C, tb.tok, tok_base, k0, 32, N, 1.f, qkv_bias + 2 * C + h * HD, Vb, lane, 64);
+        __syncthreads();
+
+        // P^T block: rows = this block's 32 keys (2 tiles), columns = all queries (14 tiles)
+        f32x4 p[2][NT];
+        {
+            Frag<T> kf[2];
+            kf[0] = frag_kc<T>(Kb, LDQ, 0, 0, c, g);
+            kf[1] = frag_kc<T>(Kb, LDQ, 16, 0, c, g);
+            int pkk[2][4];
+            bool kok[2][4];
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int k = k0 + 16 * a + 4 * g + r;
+                    pkk[a][r] = tb.pk[k];
+                    kok[a][r] = k < N;
+                }
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const Frag<T> qf = frag_kc<T>(Qs, LDQ, 16 * j, 0, c, g);
+                const int q = 16 * j + c;
+                const int pq = tb.pk[q];
+                const bool qok = q < N;
+                const float l = tb.lse[q];
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    f32x4 b;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) b[r] = score_bias(tb, pq, pkk[a][r], qok, kok[a][r], off, masked);
+                    mma(kf[a], qf, b);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) b[r] = qok ? __expf(b[r] - l) : 0.f;  // padded query columns carry no gradient
+                    p[a][j] = b;
+                    store_frag4<T>(Pq + (16 * j + c) * LDQ + 16 * a + 4 * g, b);
+                }
+            }
+        }
+        __syncthreads();
+        // dV[key][d] = sum_q P[q][key] dO[q][d]
+        {
+            f32x4 av[2][2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                av[a][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+                av[a][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int ks = 0; ks < NPB / 32; ++ks) {
+                const Frag<T> o0 = frag_ks<T, USE_TR>(Os, LDQ, 0, 32 * ks, c, g);
+                const Frag<T> o1 = frag_ks<T, USE_TR>(Os, LDQ, 16, 32 * ks, c, g);
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    const Frag<T> pf = frag_ks<T, USE_TR>(Pq, LDQ, 16 * a, 32 * ks, c, g);
+                    mma(pf, o0, av[a][0]);
+                    mma(pf, o1, av[a][1]);
+                }
+            }
+            store_block_rows<T>(av, 1.f, dqkv + 2 * C + h * HD, 3L * C, tb.tok, tok_base, k0, N, valid, &padv, c, g);
+        }
+        __syncthreads();  // reads of Pq (= P) complete
+        // dS^T = P^T o (dP^T - delta), dP^T[key][q] = sum_d V[key][d] dO[q][d]
+        {
+            Frag<T> vf[2];
+            vf[0] = frag_kc<T>(Vb, LDQ, 0, 0, c, g);
+            vf[1] = frag_kc<T>(Vb, LDQ, 16, 0, c, g);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const Frag<T> of = frag_kc<T>(Os, LDQ, 16 * j, 0, c, g);
+                const float dl = tb.delta[16 * j + c];
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    f32x4 dp = {0.f, 0.f, 0.f, 0.f};
+                    mma(vf[a], of, dp);
+                    const f32x4 ds = p[a][j] * (dp - dl);
+                    store_frag4<T>(Pq + (16 * j + c) * LDQ + 16 * a + 4 * g, ds);
+                }
+            }
+        }
+        __syncthreads();
+        // dK[key][d] = sum_q dS[q][key] (scale q)[q][d]
+        {
+            f32x4 ak[2][2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                ak[a][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+                ak[a][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int ks = 0; ks < NPB / 32; ++ks) {
+                const Frag<T> q0f = frag_ks<T, USE_TR>(Qs, LDQ, 0, 32 * ks, c, g);
+                const Frag<T> q1f = frag_ks<T, USE_TR>(Qs, LDQ, 16, 32 * ks, c, g);
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    const Frag<T> sf = frag_ks<T, USE_TR>(Pq, LDQ, 16 * a, 32 * ks, c, g);
+                    mma(sf, q0f, ak[a][0]);
+                    mma(sf, q1f, ak[a][1]);
+                }
+            }
+            store_block_rows<T>(ak, 1.f, dqkv + C + h * HD, 3L * C, tb.tok, tok_base, k0, N, valid, &padk, c, g);
+        }
+    }
+    padk[0] += __shfl_xor(padk[0], 16, 64); padk[0] += __shfl_xor(padk[0], 32, 64);
+    padk[1] += __shfl_xor(padk[1], 16, 64); padk[1] += __shfl_xor(padk[1], 32, 64);
+    padv[0] += __shfl_xor(padv[0], 16, 64); padv[0] += __shfl_xor(padv[0], 32, 64);
+    padv[1] += __shfl_xor(padv[1], 16, 64); padv[1] += __shfl_xor(padv[1], 32, 64);
+    if (g == 0) {  // one slab row per (unit, wave): [k | v][nH][hd]
+        float* pw = dpad_ws + ((long)unit * WAVES + wave) * 2 * C + h * HD;
+        pw[c] = padk[0];
+        pw[16 + c] = padk[1];
+        pw[C + c] = padv[0];
+        pw[C + 16 + c] = padv[1];
+    }
+}
+
+// dtable[index[q,key]][h] += total[h][frag(q,key)] for the 14-tile frag layout
+__global__ void relpos_bias_bwd_big_kernel(const float* __restrict__ ws, const long* __restrict__ index, int N, int nH,
+                                           float* __restrict__ dtable) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nH * N * N) return;
+    const int h = i / (N * N), qk = i % (N * N);
+    const int q = qk / N, key = qk % N;
+    const int f = (key >> 4) * NT + (q >> 4);
+    const int lane = ((key & 15) >> 2) * 16 + (q & 15), r = key & 3;
+    atomicAdd(dtable + index[qk] * nH + h, ws[(long)h * (NT * NT * 256) + (f * 64 + lane) * 4 + r]);
+}
+
+template <typename T>
+size_t fwd_lds() {
+    using Cfg = BigCfg<T>;
+    return Cfg::TABLE_BYTES + (size_t)(2 * Cfg::FULL + Cfg::WAVES * (Cfg::BLK + Cfg::PIMG)) * sizeof(T);
+}
+template <typename T>
+size_t dq_lds() {
+    using Cfg = BigCfg<T>;
+    return Cfg::TABLE_BYTES + (size_t)(2 * Cfg::FULL + Cfg::WAVES * (2 * Cfg::BLK + Cfg::PIMG)) * sizeof(T);
+}
+template <typename T>
+size_t dkv_lds() {
+    using Cfg = BigCfg<T>;
+    return Cfg::TABLE_BYTES + (size_t)(2 * Cfg::FULL + Cfg::WAVES * (2 * Cfg::BLK + Cfg::FULL)) * sizeof(T);
+}
+
+inline int big_parts(int Bw, int nH) {
+    int parts = (512 + nH - 1) / nH;  // ~2 workgroups per CU across heads and query-block groups
+    if (parts > Bw) parts = Bw;
+    return parts < 1 ? 1 : parts;
+}
+
+}  // namespace
+
+#define STREAM(s_) hipStream_t stream = reinterpret_cast<hipStream_t>(s_)
+
+int esvit_big_frag_elems() { return NT * NT * 256; }
+int esvit_big_npb() { return NPB; }
+int esvit_big_parts(int Bw, int nH) { return big_parts(Bw, nH); }
+int esvit_big_pad_rows(int Bw, int nH, int dtype) { return Bw * nH * (dtype == ESVIT_BF16 ? 4 : 2); }
+
+template <typename T>
+static int big_fwd_launch(const void* qkv, const float* qkv_bias, const int32_t* win2tok, int L, const float* rel_table, int rel_rows, int ws,
+                          const int32_t* region_ids, int nW, int Bw, int N, int nH, float scale, void* out, float* lse, float* attn_out,
+                          hipStream_t stream) {
+    auto kern = attn_big_fwd_kernel<T>;
+    const size_t lds = fwd_lds<T>();
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kern, dim3(Bw * nH), dim3(BigCfg<T>::WAVES * 64), lds, stream, (const T*)qkv, qkv_bias, win2tok, L, rel_table,
+                       rel_rows, ws, region_ids, nW, Bw, N, nH, scale, (T*)out, lse, attn_out);
+    ESVIT_CHECK_LAUNCH("window_attn_fwd(14x14)");
+    return ESVIT_OK;
+}
+
+int esvit_big_attn_fwd(int dtype, const void* qkv, const float* qkv_bias, const int32_t* win2tok, int L, const float* rel_table, int ws,
+                       const int32_t* region_ids, int nW, int nB, int N, int nH, float scale, void* out, float* lse, float* attn_out,
+                       hipStream_t stream) {
+    const int rel_rows = (2 * ws - 1) * (2 * ws - 1);
+    ESVIT_CHECK_ARG(rel_rows <= TAB_FLOATS && N <= NPB, "window_attn: window %d too large", ws);
+    const int Bw = nB * nW;
+    if (dtype == ESVIT_BF16)
+        return big_fwd_launch<bf16>(qkv, qkv_bias, win2tok, L, rel_table, rel_rows, ws, region_ids, nW, Bw, N, nH, scale, out, lse, attn_out, stream);
+    return big_fwd_launch<float>(qkv, qkv_bias, win2tok, L, rel_table, rel_rows, ws, region_ids, nW, Bw, N, nH, scale, out, lse, attn_out, stream);
+}
+
+template <typename T, bool TR>
+static int big_bwd_launch(const void* qkv, const float* qkv_bias, const int32_t* win2tok, int L, const void* dout, const void* fout,
+                          const float* lse, const float* rel_table, int rel_rows, int ws, const int32_t* region_ids, int nW, int Bw, int N,
+                          int nH, float scale, void* dqkv, float* dbias_ws, float* dpad_ws, hipStream_t stream) {
+    using Cfg = BigCfg<T>;
+    constexpr int GROUPS = (NQB + Cfg::WAVES - 1) / Cfg::WAVES;
+    const int parts = big_parts(Bw, nH);
+    {
+        auto kern = attn_big_bwd_dq_kernel<T, TR>;
+        const size_t lds = dq_lds<T>();
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kern, dim3(parts * nH * GROUPS), dim3(Cfg::WAVES * 64), lds, stream, (const T*)qkv, qkv_bias, win2tok, L,
+                           (const T*)dout, rel_table, rel_rows, ws, region_ids, nW, Bw, N, nH, scale, parts, (T*)dqkv, dbias_ws);
+        ESVIT_CHECK_LAUNCH("window_attn_bwd(14x14, dQ)");
+    }
+    {
+        auto kern = attn_big_bwd_dkv_kernel<T, TR>;
+        const size_t lds = dkv_lds<T>();
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kern, dim3(Bw * nH), dim3(Cfg::WAVES * 64), lds, stream, (const T*)qkv, qkv_bias, win2tok, L, (const T*)dout,
+                           (const T*)fout, lse, rel_table, rel_rows, ws, region_ids, nW, Bw, N, nH, scale, (T*)dqkv, dpad_ws);
+        ESVIT_CHECK_LAUNCH("window_attn_bwd(14x14, dK dV)");
+    }
+    return ESVIT_OK;
+}
+
+int esvit_big_attn_bwd(int dtype, int use_tr, const void* qkv, const float* qkv_bias, const int32_t* win2tok, int L, const void* dout,
+                       const void* fout, const float* lse, const float* rel_table, int ws, const int32_t* region_ids, int nW, int nB, int N,
+                       int nH, float scale, void* dqkv, float* dbias_ws, float* dpad_ws, hipStream_t stream) {
+    const int rel_rows = (2 * ws - 1) * (2 * ws - 1);
+    ESVIT_CHECK_ARG(rel_rows <= TAB_FLOATS && N <= NPB, "window_attn: window %d too large", ws);
+    ESVIT_CHECK_ARG(fout && lse, "esvit_window_attn_bwd: 14x14 windows need the forward output and log-sum-exp");
+    const int Bw = nB * nW;
+    if (dtype == ESVIT_BF16) {
+        if (use_tr)
+            return big_bwd_launch<bf16, true>(qkv, qkv_bias, win2tok, L, dout, fout, lse, rel_table, rel_rows, ws, region_ids, nW, Bw, N, nH,
+                                              scale, dqkv, dbias_ws, dpad_ws, stream);
+        return big_bwd_launch<bf16, false>(qkv, qkv_bias, win2tok, L, dout, fout, lse, rel_table, rel_rows, ws, region_ids, nW, Bw, N, nH,
+                                           scale, dqkv, dbias_ws, dpad_ws, stream);
+    }
+    return big_bwd_launch<float, false>(qkv, qkv_bias, win2tok, L, dout, fout, lse, rel_table, rel_rows, ws, region_ids, nW, Bw, N, nH, scale,
+                                        dqkv, dbias_ws, dpad_ws, stream);
+}
+
+int esvit_big_relpos_bias_bwd(const float* dbias_ws, int parts, const int64_t* index, int N, int nH, int table_rows, float* dtable,
+                              hipStream_t stream) {
+    const int FE = NT * NT * 256;
+    if (parts > 1) {
+        int rc = esvit_partial_reduce(dbias_ws, parts, nH * FE, (long)nH * FE, const_cast<float*>(dbias_ws), 0, stream);
+        if (rc != ESVIT_OK) return rc;
+    }
+    hipError_t e = hipMemsetAsync(dtable, 0, (size_t)table_rows * nH * sizeof(float), stream);
+    if (e != hipSuccess) {
+        esvit_set_error("esvit_relpos_bias_bwd: memset failed: %s", hipGetErrorString(e));
+        return ESVIT_ERR_HIP;
+    }
+    hipLaunchKernelGGL(relpos_bias_bwd_big_kernel, dim3(ceil_div((long)nH * N * N, 256)), dim3(256), 0, stream, dbias_ws, (const long*)index, N,
+                       nH, dtable);
+    ESVIT_CHECK_LAUNCH("relpos_bias_bwd(14x14)");
+    return ESVIT_OK;
+}

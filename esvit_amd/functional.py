@@ -84,7 +84,7 @@ def _block_forward(x, geom, nH, index, dp, prm, wts, save):
     # injects the qkv bias at zero-pad slots, so no GEMM ever runs on pad rows
     xw, _, mean1, rstd1 = o.layernorm_fwd(x2d, g1, b1, LN_EPS)
     qkv = o.linear_fwd(xw, Wqkv, bqkv)
-    ao = o.window_attn_fwd(qkv, bqkv, geom.win2tok, L, table, geom.ws, geom.region_ids, geom.nW, geom.N, nH, scale)
+    ao, lse = o.window_attn_fwd(qkv, bqkv, geom.win2tok, L, table, geom.ws, geom.region_ids, geom.nW, geom.N, nH, scale)
     x1 = o.linear_fwd(ao, Wproj, bproj, residual=x2d, rowscale=dp1, rows_per_sample=L, out_f32=True)
     h, _, mean2, rstd2 = o.layernorm_fwd(x1, g2, b2, LN_EPS)
     if save:
@@ -92,7 +92,7 @@ def _block_forward(x, geom, nH, index, dp, prm, wts, save):
     else:
         a1g, a1 = o.linear_fwd(h, W1, bfc1, gelu=True), None
     x2 = o.linear_fwd(a1g, W2, bfc2, residual=x1, rowscale=dp2, rows_per_sample=L, out_f32=True)
-    saved = (mean1, rstd1, xw, qkv, ao, x1, mean2, rstd2, h, a1, a1g) if save else None
+    saved = (mean1, rstd1, xw, qkv, ao, x1, mean2, rstd2, h, a1, a1g, lse) if save else None
     return x2.view(nB, L, C), saved
 
 
@@ -111,7 +111,7 @@ class SwinBlockFn(torch.autograd.Function):
         o = ops_module()
         geom, nH, dp = ctx.geom, ctx.nH, ctx.dp
         (x, index, g1, table, g2, bqkv, Wqkv, Wproj, W1, W2, mean1, rstd1, xw, qkv, ao, x1, mean2, rstd2, h, a1,
-         a1g) = ctx.saved_tensors
+         a1g, lse) = ctx.saved_tensors
         nB, L, C = x.shape
         M = nB * L
         scale = (C // nH) ** -0.5
@@ -128,8 +128,8 @@ class SwinBlockFn(torch.autograd.Function):
         dyw = o.gather_cast(gx1, M, rowscale=dp1, rows_per_sample=L)
         dWproj, dbproj = o.linear_wgrad(dyw, ao, want_bias=True)
         dao = o.linear_dgrad(dyw, Wproj)
-        dqkv, dbias_ws, dpad_ws = o.window_attn_bwd(qkv, bqkv, geom.win2tok, L, dao, table, geom.ws, geom.region_ids, geom.nW,
-                                                    geom.N, nH, scale)
+        dqkv, dbias_ws, dpad_ws = o.window_attn_bwd(qkv, bqkv, geom.win2tok, L, dao, ao, lse, table, geom.ws, geom.region_ids,
+                                                    geom.nW, geom.N, nH, scale)
         dtable = o.relpos_bias_bwd(dbias_ws, index, geom.N, table.shape[0])
         dWqkv, dbqkv = o.linear_wgrad(dqkv, xw, want_bias=True)
         o.colsum(dpad_ws, out=dbqkv[C:], accumulate=True)  # k/v bias gradient from the zero-pad slots
@@ -157,8 +157,8 @@ def swin_block_attention(x, geom, nH, index, prm_list):
     x2d = x.contiguous().view(nB * L, C)
     xw, _, _, _ = o.layernorm_fwd(x2d, g1, b1, LN_EPS)
     qkv = o.linear_fwd(xw, _weight(Wqkv), bqkv)
-    _, attn = o.window_attn_fwd(qkv, bqkv, geom.win2tok, L, table, geom.ws, geom.region_ids, geom.nW, geom.N, nH, (C // nH) ** -0.5,
-                                want_attn=True)
+    _, _, attn = o.window_attn_fwd(qkv, bqkv, geom.win2tok, L, table, geom.ws, geom.region_ids, geom.nW, geom.N, nH, (C // nH) ** -0.5,
+                                   want_attn=True)
     return attn
 
 

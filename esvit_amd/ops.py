@@ -402,31 +402,38 @@ def dense_to_frag(dense):
 
 
 def window_attn_fwd(qkv, qkv_bias, win2tok, L, rel_table, ws, region_ids, nW, N, nH, scale, want_attn=False):
-    """token-ordered qkv [nB*L, 3C] -> out [nB*L, C]; win2tok int32 [nW*N] slot -> token (-1 = zero-pad slot)."""
+    """token-ordered qkv [nB*L, 3C] -> (out [nB*L, C], lse or None[, attn]); win2tok int32 [nW*N] slot -> token (-1 = zero-pad slot).
+    lse (per-query log-sum-exp) is produced for 14x14 windows, whose blocked backward needs it."""
     qkv = _actc(qkv)
     rows, C3 = qkv.shape
     Cc = C3 // 3
     nB = rows // L
     out = torch.empty((rows, Cc), dtype=qkv.dtype, device=qkv.device)
     attn = torch.empty((nB * nW, nH, N, N), dtype=torch.float32, device=qkv.device) if want_attn else None
-    check(lib.esvit_window_attn_fwd(_code(qkv.dtype), _p(qkv), _p(_f32c(qkv_bias)), _p(win2tok), L, _p(_f32c(rel_table)), ws, _p(region_ids), nW,
-                                    nB, N, nH, Cc // nH, scale, _p(out), _p(attn), _stream()), "window_attn_fwd")
-    return (out, attn) if want_attn else out
+    nl = lib.esvit_window_attn_lse_elems(N)
+    lse = torch.empty((nB * nW * nH, nl), dtype=torch.float32, device=qkv.device) if nl else None
+    bias_ws = workspace(nH * attn_frag_elems(N), qkv.device, slot=2) if N <= 64 else None
+    check(lib.esvit_window_attn_fwd(_code(qkv.dtype), _p(qkv), _p(_f32c(qkv_bias)), _p(win2tok), L, _p(_f32c(rel_table)), ws, _p(bias_ws),
+                                    _p(region_ids), nW, nB, N, nH, Cc // nH, scale, _p(out), _p(lse), _p(attn), _stream()),
+          "window_attn_fwd")
+    return (out, lse, attn) if want_attn else (out, lse)
 
 
-def window_attn_bwd(qkv, qkv_bias, win2tok, L, dout, rel_table, ws, region_ids, nW, N, nH, scale):
-    """-> (dqkv act [nB*L, 3C], dbias_ws fp32 [parts, nH, frag], dpad_ws fp32 [parts, 2C])."""
+def window_attn_bwd(qkv, qkv_bias, win2tok, L, dout, fwd_out, lse, rel_table, ws, region_ids, nW, N, nH, scale):
+    """-> (dqkv act [nB*L, 3C], dbias_ws fp32 [parts, nH, frag], dpad_ws fp32 [rows, 2C])."""
     qkv, dout = _actc(qkv), _actc(dout)
     rows, C3 = qkv.shape
     Cc = C3 // 3
     nB = rows // L
+    code = _code(qkv.dtype)
     dqkv = torch.empty_like(qkv)
-    parts = lib.esvit_window_attn_bwd_parts(nB * nW, nH)
+    parts = lib.esvit_window_attn_bwd_parts(N, nB * nW, nH)
     dbias_ws = torch.empty((parts, nH, attn_frag_elems(N)), dtype=torch.float32, device=qkv.device)
-    pad = torch.empty((parts, 2 * Cc), dtype=torch.float32, device=qkv.device)
-    check(lib.esvit_window_attn_bwd(_code(qkv.dtype), _p(qkv), _p(_f32c(qkv_bias)), _p(win2tok), L, _p(dout), _p(_f32c(rel_table)), ws,
-                                    _p(region_ids), nW, nB, N, nH, Cc // nH, scale, _p(dqkv), _p(dbias_ws), _p(pad), _stream()),
-          "window_attn_bwd")
+    pad = torch.zeros((lib.esvit_window_attn_bwd_pad_rows(code, N, nB * nW, nH), 2 * Cc), dtype=torch.float32, device=qkv.device)
+    bias_ws = workspace(nH * attn_frag_elems(N), qkv.device, slot=2) if N <= 64 else None
+    check(lib.esvit_window_attn_bwd(code, _p(qkv), _p(_f32c(qkv_bias)), _p(win2tok), L, _p(dout), _p(fwd_out), _p(lse), _p(_f32c(rel_table)),
+                                    ws, _p(bias_ws), _p(region_ids), nW, nB, N, nH, Cc // nH, scale, _p(dqkv), _p(dbias_ws), _p(pad),
+                                    _stream()), "window_attn_bwd")
     return dqkv, dbias_ws, pad
 
 

@@ -162,23 +162,30 @@ int esvit_dense_to_frag(const float* dense, int n_mats, int N, float* frag, esvi
  * IS pad -> roll -> window_partition and its inverse (swin_transformer.py:286-325), applied on the fly.
  * qkv_bias fp32 [3C]: the value of q,k,v at a zero-pad slot (LayerNorm output is zero-padded, so qkv = bias there;
  * pad keys/values take part in every softmax exactly as in the reference, pad query rows are dropped).
- * rel_table fp32 [(2ws-1)^2, nH] is the relative_position_bias_table parameter itself: the kernels gather
- * table[index[q,key], h] (swin_transformer.py:133-136) from an LDS copy of the head's column, index computed in closed form.
- * region_ids int32 [nW*N] (esvit_shift_region_ids) for shifted blocks or NULL; scale = hd^-0.5 applied to q before
- * the product (swin_transformer.py:130).
- * N = ws*ws = 49, hd = 32.  attn_out (optional, fp32 [nB*nW,nH,N,N]) receives the softmax (swin_transformer.py:146,152). */
+ * rel_table fp32 [(2ws-1)^2, nH] is the relative_position_bias_table parameter itself (swin_transformer.py:133-136,
+ * index in closed form).  bias_frag_ws (7x7 windows, optional): fp32 scratch [nH, esvit_attn_frag_elems(N)] the
+ * library fills with the bias in fragment order (faster than gathering from the table inside the kernel); ignored for
+ * 14x14 windows.  region_ids int32 [nW*N] (esvit_shift_region_ids) for shifted blocks or NULL.
+ * scale = hd^-0.5 applied to q before the product (swin_transformer.py:130).  N = ws*ws in {49, 196}, hd = 32.
+ * lse fp32 [nB*nW*nH, esvit_window_attn_lse_elems(N)]: per-query log-sum-exp, written for 14x14 windows (the blocked
+ * backward needs it), unused (may be NULL) for 7x7.
+ * attn_out (optional, fp32 [nB*nW,nH,N,N]) receives the softmax (swin_transformer.py:146,152). */
+int esvit_window_attn_lse_elems(int N);
 int esvit_window_attn_fwd(int dtype, const void* qkv, const float* qkv_bias, const int32_t* win2tok, int L,
-                          const float* rel_table, int ws, const int32_t* region_ids, int nW, int nB, int N, int nH, int hd,
-                          float scale, void* out, float* attn_out, esvit_stream_t stream);
-/* dout dtype [nB*L, C] -> dqkv dtype [nB*L, 3C] (every row written).  Per-wave partials, parts =
- * esvit_window_attn_bwd_parts(nB*nW, nH): dbias_ws fp32 [parts, nH, frag] (relative-position-bias gradient) and
- * dpad_ws fp32 [parts, 2C] = sums of the dK / dV rows of zero-pad slots, layout [k|v][nH][hd] -- they are
- * gradients of qkv_bias[C:3C]. */
-int esvit_window_attn_bwd_parts(int Bw, int nH);
-int esvit_window_attn_bwd(int dtype, const void* qkv, const float* qkv_bias, const int32_t* win2tok, int L,
-                          const void* dout, const float* rel_table, int ws, const int32_t* region_ids, int nW, int nB,
-                          int N, int nH, int hd, float scale, void* dqkv, float* dbias_ws, float* dpad_ws,
+                          const float* rel_table, int ws, float* bias_frag_ws, const int32_t* region_ids, int nW, int nB,
+                          int N, int nH, int hd, float scale, void* out, float* lse, float* attn_out,
                           esvit_stream_t stream);
+/* dout dtype [nB*L, C] -> dqkv dtype [nB*L, 3C] (every row written).  fwd_out / lse: the forward's outputs (needed for
+ * 14x14 windows only).  Partials: dbias_ws fp32 [esvit_window_attn_bwd_parts(N, nB*nW, nH), nH, frag]
+ * (relative-position-bias gradient, reduced by esvit_relpos_bias_bwd) and dpad_ws fp32
+ * [esvit_window_attn_bwd_pad_rows(dtype, N, nB*nW, nH), 2C], ZERO-INITIALISED by the caller: sums of the dK / dV rows
+ * of zero-pad slots, layout [k|v][nH][hd] -- gradients of qkv_bias[C:3C] (column-sum them into the bias gradient). */
+int esvit_window_attn_bwd_parts(int N, int Bw, int nH);
+int esvit_window_attn_bwd_pad_rows(int dtype, int N, int Bw, int nH);
+int esvit_window_attn_bwd(int dtype, const void* qkv, const float* qkv_bias, const int32_t* win2tok, int L,
+                          const void* dout, const void* fwd_out, const float* lse, const float* rel_table, int ws,
+                          float* bias_frag_ws, const int32_t* region_ids, int nW, int nB, int N, int nH, int hd,
+                          float scale, void* dqkv, float* dbias_ws, float* dpad_ws, esvit_stream_t stream);
 /* dtable fp32 [table_rows, nH] (overwritten) = scatter-add over index of sum_parts dbias_ws */
 int esvit_relpos_bias_bwd(const float* dbias_ws, int parts, const int64_t* index, int N, int nH,
                           int table_rows, float* dtable, esvit_stream_t stream);

@@ -47,8 +47,9 @@ def gen_index_maps(ns):
     print("index_maps.npz:", len(out), "arrays")
 
 
-def build_nano(ns, teacher=False):
-    cfg = RL.swin_config(embed_dim=GU.NANO["embed_dim"], depths=GU.NANO["depths"], heads=GU.NANO["heads"], window=GU.NANO["window"])
+def build_nano(ns, teacher=False, window=None):
+    cfg = RL.swin_config(embed_dim=GU.NANO["embed_dim"], depths=GU.NANO["depths"], heads=GU.NANO["heads"],
+                         window=window or GU.NANO["window"])
     m = ns.models.build_model(cfg, is_teacher=teacher, use_dense_prediction=True)
     hk = dict(hidden_dim=GU.NANO_HEAD["hidden_dim"], bottleneck_dim=GU.NANO_HEAD["bottleneck_dim"])
     m.head = ns.DINOHead(m.num_features, GU.NANO_HEAD["out_dim"], norm_last_layer=True, **hk)
@@ -126,11 +127,40 @@ def gen_nano(ns):
     print("nano_step.pt: loss", g["ddino_loss"], g["ddino_loss_2"], g["dino_loss_2crops"], "no_grad", g["no_grad"])
 
 
+def gen_nano14(ns):
+    """W=14 variant (BASELINE.json configs 3/4 use 14x14 windows): 196-token windows, 27x27 bias tables, stage 3 falls back to
+    7x7.  One image, 2 global + 2 local crops, to keep the fixture and the CPU time small."""
+    RL.ensure_single_process_group()
+    student, teacher = build_nano(ns, window=14), build_nano(ns, teacher=True, window=14)
+    GU.fill_state_dict(student.state_dict(), seed=0)
+    GU.fill_state_dict(teacher.state_dict(), seed=7)
+    student.head.last_layer.weight_g.data.fill_(1)
+    for p in teacher.parameters():
+        p.requires_grad = False
+    crops = GU.make_crops(1, n_local=2)
+    K = GU.NANO_HEAD["out_dim"]
+    g = {"keys": [(k, tuple(v.shape), str(v.dtype)) for k, v in student.state_dict().items()]}
+    loss_fn = ns.DDINOLoss(K, 4, 0.04, 0.07, 5, 10)
+    t_out = teacher(crops[:2])
+    s_out = student(crops)
+    for nm, t in (("s_cls", s_out[0]), ("s_reg", s_out[1]), ("s_fea", s_out[2]), ("t_cls", t_out[0]), ("t_reg", t_out[1])):
+        g[nm] = GU.probe(t)
+    loss = loss_fn(s_out, t_out, 2, None)
+    g["ddino_loss"] = loss.item()
+    student.zero_grad()
+    loss.backward()
+    g["grad_norms"] = {n: p.grad.norm().item() for n, p in student.named_parameters() if p.grad is not None}
+    g["grads"] = {n: GU.probe(p.grad) for n, p in student.named_parameters() if p.grad is not None and ("attn" in n or "patch_embed" in n)}
+    torch.save(g, os.path.join(OUT, "nano14_step.pt"))
+    print("nano14_step.pt: loss", g["ddino_loss"])
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ns = RL.load()
     gen_index_maps(ns)
     gen_nano(ns)
+    gen_nano14(ns)
 
 
 if __name__ == "__main__":

@@ -281,37 +281,43 @@ def token_mean_bwd(g_mean, g_tok, T):
 
 
 # ---- window attention ------------------------------------------------------------------------
-NP_ = 64
+def _nt(N):
+    """MFMA tiles per window side: 4 (64 padded tokens) for 7x7 windows, 14 (224) for 14x14"""
+    if N <= 64:
+        return 4
+    if N <= 224:
+        return 14
+    raise RuntimeError("unsupported window")
 
 
 def attn_frag_elems(N):
-    if N > NP_:
-        raise RuntimeError("unsupported window")
-    return 4096
+    return _nt(N) ** 2 * 256
 
 
-def _frag_qk():
-    e = np.arange(4096)
+def _frag_qk(nt):
+    e = np.arange(nt * nt * 256)
     r, lane, f = e & 3, (e >> 2) & 63, e >> 8
     c, g = lane & 15, lane >> 4
-    q = 16 * (f & 3) + c
-    key = 16 * (f >> 2) + 4 * g + r
+    q = 16 * (f % nt) + c
+    key = 16 * (f // nt) + 4 * g + r
     return q, key
 
 
 def _dense_from_frag(frag, N):
-    q, key = _frag_qk()
-    dense = torch.zeros(frag.shape[:-1] + (NP_, NP_), dtype=torch.float32, device=frag.device)
+    nt = _nt(N)
+    q, key = _frag_qk(nt)
+    dense = torch.zeros(frag.shape[:-1] + (16 * nt, 16 * nt), dtype=torch.float32, device=frag.device)
     dense[..., torch.as_tensor(q), torch.as_tensor(key)] = frag
     return dense[..., :N, :N]
 
 
 def _frag_from_dense(dense, pad_key_value=0.0):
     N = dense.shape[-1]
-    full = torch.zeros(dense.shape[:-2] + (NP_, NP_), dtype=torch.float32, device=dense.device)
+    nt = _nt(N)
+    full = torch.zeros(dense.shape[:-2] + (16 * nt, 16 * nt), dtype=torch.float32, device=dense.device)
     full[..., :, N:] = pad_key_value
     full[..., :N, :N] = dense
-    q, key = _frag_qk()
+    q, key = _frag_qk(nt)
     return full[..., torch.as_tensor(q), torch.as_tensor(key)].contiguous()
 
 
@@ -378,10 +384,10 @@ def window_attn_fwd(qkv, qkv_bias, win2tok, L, rel_table, ws, region_ids, nW, N,
     out = torch.zeros((qkv.shape[0], C), dtype=torch.float32, device=qkv.device)
     out[idx[~pad]] = ow[~pad]
     out = _r(out, qkv.dtype)
-    return (out, p) if want_attn else out
+    return (out, None, p) if want_attn else (out, None)
 
 
-def window_attn_bwd(qkv, qkv_bias, win2tok, L, dout, rel_table, ws, region_ids, nW, N, nH, scale):
+def window_attn_bwd(qkv, qkv_bias, win2tok, L, dout, fwd_out, lse, rel_table, ws, region_ids, nW, N, nH, scale):
     bias_frag = relpos_bias_fwd(rel_table, torch.as_tensor(relative_position_index(ws), device=qkv.device), N)
     C = qkv.shape[1] // 3
     dt = qkv.dtype

@@ -30,9 +30,10 @@ def cpu_ops(monkeypatch, lib_built):
     Fn._GEOM.clear()
 
 
-def build_nano(teacher=False):
+def build_nano(teacher=False, window=None):
     from esvit_amd import models
-    cfg = RL.swin_config(embed_dim=GU.NANO["embed_dim"], depths=GU.NANO["depths"], heads=GU.NANO["heads"], window=GU.NANO["window"])
+    cfg = RL.swin_config(embed_dim=GU.NANO["embed_dim"], depths=GU.NANO["depths"], heads=GU.NANO["heads"],
+                         window=window or GU.NANO["window"])
     m = models.build_model(cfg, is_teacher=teacher, use_dense_prediction=True)
     hk = dict(hidden_dim=GU.NANO_HEAD["hidden_dim"], bottleneck_dim=GU.NANO_HEAD["bottleneck_dim"])
     m.head = models.DINOHead(m.num_features, GU.NANO_HEAD["out_dim"], norm_last_layer=True, **hk)
@@ -40,8 +41,8 @@ def build_nano(teacher=False):
     return m
 
 
-def nano_pair():
-    student, teacher = build_nano(), build_nano(teacher=True)
+def nano_pair(window=None):
+    student, teacher = build_nano(window=window), build_nano(teacher=True, window=window)
     GU.fill_state_dict(student.state_dict(), 0)
     GU.fill_state_dict(teacher.state_dict(), 7)
     student.head.last_layer.weight_g.data.fill_(1)
@@ -118,3 +119,36 @@ def test_composition_bf16_emulation_error_budget(cpu_ops):
             ref = nano["grad_norms"][n]
             worst = max(worst, abs(p.grad.norm().item() - ref) / (ref + 1e-12))
     assert worst < 0.15, worst
+
+
+def run_nano14_step(student, teacher, loss_mod, dev="cpu"):
+    crops = [c.to(dev) for c in GU.make_crops(1, n_local=2)]
+    loss_fn = loss_mod.DDINOLoss(GU.NANO_HEAD["out_dim"], 4, 0.04, 0.07, 5, 10).to(dev)
+    t_out = teacher(crops[:2])
+    s_out = student(crops)
+    loss = loss_fn(s_out, t_out, 2, None)
+    loss.backward()
+    return s_out, t_out, loss
+
+
+def check_nano14(g14, student, s_out, t_out, loss, rt, loss_tol, grad_tol, probes=True):
+    for nm, t in (("s_cls", s_out[0]), ("s_reg", s_out[1]), ("s_fea", s_out[2]), ("t_cls", t_out[0]), ("t_reg", t_out[1])):
+        probe_close(nm, t.float().cpu(), g14[nm], rtol=rt)
+    assert abs(loss.item() - g14["ddino_loss"]) < loss_tol, (loss.item(), g14["ddino_loss"])
+    worst = 0.0
+    for n, p in student.named_parameters():
+        if p.grad is not None:
+            ref = g14["grad_norms"][n]
+            worst = max(worst, abs(p.grad.norm().item() - ref) / (ref + 1e-12))
+            if probes and n in g14["grads"]:
+                probe_close("grad " + n, p.grad.cpu(), g14["grads"][n], rtol=2e-3)
+    assert worst < grad_tol, worst
+
+
+def test_composition_w14_matches_reference_golden(cpu_ops):
+    import esvit_amd.loss as L
+    g14 = torch.load(os.path.join(GOLD, "nano14_step.pt"), weights_only=False)
+    student, teacher = nano_pair(window=14)
+    assert [(k, tuple(v.shape), str(v.dtype)) for k, v in student.state_dict().items()] == g14["keys"]
+    s_out, t_out, loss = run_nano14_step(student, teacher, L)
+    check_nano14(g14, student, s_out, t_out, loss, rt=2e-4, loss_tol=2e-5, grad_tol=1e-3)

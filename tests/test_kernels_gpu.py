@@ -233,12 +233,13 @@ def test_small_ops(mods, dt):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
-@pytest.mark.parametrize("nH,H,shift", [(3, 14, 3), (3, 12, 3), (6, 12, 0), (12, 6, 3), (24, 3, 0), (6, 7, 0)])
-def test_window_attention(mods, dt, nH, H, shift):
-    """token-ordered attention over every padded / shifted geometry class of 224 and 96 crops (H = 12, 6, 3 need padding)"""
+@pytest.mark.parametrize("ws,nH,H,shift", [(7, 3, 14, 3), (7, 3, 12, 3), (7, 6, 12, 0), (7, 12, 6, 3), (7, 24, 3, 0), (7, 6, 7, 0),
+                                           (14, 3, 28, 7), (14, 3, 24, 7), (14, 6, 12, 7), (14, 4, 14, 0), (14, 2, 6, 0)])
+def test_window_attention(mods, dt, ws, nH, H, shift):
+    """token-ordered attention over every padded / shifted geometry class of 224 and 96 crops, 7x7 and 14x14 windows"""
     ops, ref = mods
     dev = _dev()
-    ws, N, hd = 7, 49, 32
+    N, hd = ws * ws, 32
     C = nH * hd
     nB, L = 3, H * H
     win2tok_np, _ = ops.window_maps(H, H, ws, shift)
@@ -246,10 +247,12 @@ def test_window_attention(mods, dt, nH, H, shift):
     nW = w2t.numel() // N
     qkv = _rand((nB * L, 3 * C), dev, 50, dt)
     qb = _rand((3 * C,), dev, 49) * 0.5
-    table = _rand((169, nH), dev, 51) * 0.5
+    trows = (2 * ws - 1) ** 2
+    table = _rand((trows, nH), dev, 51) * 0.5
     index = torch.from_numpy(ops.relative_position_index(ws)).to(dev)
-    bias = ops.relpos_bias_fwd(table, index, N)
-    _close("bias frag", bias.clamp(min=-1e4), ref.relpos_bias_fwd(table, index, N).clamp(min=-1e4), 1e-6)
+    if ws == 7:
+        bias = ops.relpos_bias_fwd(table, index, N)
+        _close("bias frag", bias.clamp(min=-1e4), ref.relpos_bias_fwd(table, index, N).clamp(min=-1e4), 1e-6)
     mask_frag = None
     if shift:
         ids_np = ops.shift_region_ids(H, H, ws, shift)
@@ -257,22 +260,23 @@ def test_window_attention(mods, dt, nH, H, shift):
         mask_frag = torch.from_numpy(ids_np).to(dev)  # the kernels rebuild the 0/-100 mask from the region labels
         m_np = ops.shift_mask(H, H, ws, shift)
         assert np.array_equal(np.where(ids_np.reshape(nW, N, 1) == ids_np.reshape(nW, 1, N), 0.0, -100.0).astype(np.float32), m_np)
-        _close("mask frag", ops.dense_to_frag(torch.from_numpy(m_np).to(dev)), ref.dense_to_frag(torch.from_numpy(m_np).to(dev)), 1e-6)
+        if ws == 7:
+            _close("mask frag", ops.dense_to_frag(torch.from_numpy(m_np).to(dev)), ref.dense_to_frag(torch.from_numpy(m_np).to(dev)), 1e-6)
     scale = hd ** -0.5
-    o, attn = ops.window_attn_fwd(qkv, qb, w2t, L, table, ws, mask_frag, nW, N, nH, scale, want_attn=True)
-    orf, attnr = ref.window_attn_fwd(qkv, qb, w2t, L, table, ws, mask_frag, nW, N, nH, scale, want_attn=True)
+    o, lse, attn = ops.window_attn_fwd(qkv, qb, w2t, L, table, ws, mask_frag, nW, N, nH, scale, want_attn=True)
+    orf, _, attnr = ref.window_attn_fwd(qkv, qb, w2t, L, table, ws, mask_frag, nW, N, nH, scale, want_attn=True)
     _close("attn probs", attn, attnr, _tol(dt, f32=5e-5, bf=2e-2))
     _close("attn out", o, orf, _tol(dt, f32=5e-5, bf=2e-2))
     dout = _rand((nB * L, C), dev, 52, dt)
     for tr in (1, 0):
         ops.debug_set_tr_read(tr)
-        dqkv, ws_, pad_ = ops.window_attn_bwd(qkv, qb, w2t, L, dout, table, ws, mask_frag, nW, N, nH, scale)
+        dqkv, ws_, pad_ = ops.window_attn_bwd(qkv, qb, w2t, L, dout, orf, lse, table, ws, mask_frag, nW, N, nH, scale)
         ops.debug_set_tr_read(1)
-        dqkvr, wsr, padr = ref.window_attn_bwd(qkv, qb, w2t, L, dout, table, ws, mask_frag, nW, N, nH, scale)
+        dqkvr, wsr, padr = ref.window_attn_bwd(qkv, qb, w2t, L, dout, orf, lse, table, ws, mask_frag, nW, N, nH, scale)
         for i, nm in enumerate("qkv"):
             _close("attn d%s tr=%d" % (nm, tr), dqkv.view(-1, 3, C)[:, i], dqkvr.view(-1, 3, C)[:, i], _tol(dt, f32=1e-4, bf=3e-2))
-        dt_ = ops.relpos_bias_bwd(ws_, index, N, 169)
-        dtr = ref.relpos_bias_bwd(wsr, index, N, 169)
+        dt_ = ops.relpos_bias_bwd(ws_, index, N, trows)
+        dtr = ref.relpos_bias_bwd(wsr, index, N, trows)
         _close("attn dtable tr=%d" % tr, dt_, dtr, _tol(dt, f32=1e-4, bf=3e-2))
         if (win2tok_np < 0).any():
             _close("attn dpad tr=%d" % tr, pad_.sum(0, keepdim=True), padr, _tol(dt, f32=1e-4, bf=3e-2))

@@ -72,8 +72,33 @@ def _nano_sd(nano, seed):
     GU.fill_state_dict(sd, seed)
     for k in sd:
         if k.endswith("relative_position_index"):
-            sd[k] = torch.as_tensor(O.rel_pos_index(7))
+            sd[k] = torch.as_tensor(O.rel_pos_index(int(round(sd[k].shape[0] ** 0.5))))
     return sd
+
+
+def test_oracle_w14_matches_reference_golden():
+    """14x14 windows (196 tokens, 27x27 bias table; stage 3 falls back to 7x7): BASELINE.json configs 3 and 4"""
+    g14 = torch.load(os.path.join(GOLD, "nano14_step.pt"), weights_only=False)
+    sd, tsd = _nano_sd(g14, 0), _nano_sd(g14, 7)
+    sd["head.last_layer.weight_g"].fill_(1)
+    names = [n for n in g14["grad_norms"]]
+    params = {n: sd[n].clone().requires_grad_(True) for n in names}
+    full = dict(sd)
+    full.update(params)
+    crops = GU.make_crops(1, n_local=2)
+    s_out = O.swin_multicrop(full, crops, GU.NANO14)
+    with torch.no_grad():
+        t_out = O.swin_multicrop(tsd, crops[:2], GU.NANO14)
+    for nm, t in (("s_cls", s_out[0]), ("s_reg", s_out[1]), ("s_fea", s_out[2]), ("t_cls", t_out[0]), ("t_reg", t_out[1])):
+        probe_close(nm, t, g14[nm])
+    K = GU.NANO_HEAD["out_dim"]
+    loss, _, _ = O.ddino_loss(s_out, t_out, torch.zeros(1, K), torch.zeros(1, K), O.teacher_temp(2, 0.04, 0.07, 5, 10), 4)
+    assert abs(loss.item() - g14["ddino_loss"]) < 1e-5
+    loss.backward()
+    for n, ref in g14["grad_norms"].items():
+        assert abs(params[n].grad.norm().item() - ref) <= 1e-3 * ref + 1e-9, n
+    for n, p in g14["grads"].items():
+        probe_close("grad " + n, params[n].grad, p, rtol=1e-3)
 
 
 def test_oracle_step_matches_reference_golden(nano):

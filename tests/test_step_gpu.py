@@ -7,7 +7,7 @@ import torch
 
 from oracle import esvit_oracle as O
 from tests import golden_utils as GU
-from tests.test_composition_cpu import build_nano, nano_pair, run_nano_step
+from tests.test_composition_cpu import build_nano, check_nano14, nano_pair, run_nano14_step, run_nano_step
 from tests.test_oracle_cpu import GOLD, probe_close
 
 pytestmark = pytest.mark.gpu
@@ -155,5 +155,22 @@ def test_swin_tiny_step_matches_cpu_oracle(prec, lib_built):
                 ref = leaf[n].grad.norm().item()
                 worst = max(worst, abs(p.grad.norm().item() - ref) / (ref + 1e-12))
         assert worst < (5e-3 if fp else 0.2), worst
+    finally:
+        _teardown()
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_nano_w14_step_matches_reference_golden(prec, lib_built):
+    """14x14 windows through the blocked attention kernels (window_attn_big.hip) vs the reference golden"""
+    import esvit_amd.loss as L
+    g14 = torch.load(os.path.join(GOLD, "nano14_step.pt"), weights_only=False)
+    dev = _setup(prec)
+    try:
+        student, teacher = nano_pair(window=14)
+        student, teacher = student.to(dev), teacher.to(dev)
+        s_out, t_out, loss = run_nano14_step(student, teacher, L, dev=dev)
+        fp = prec == "fp32"
+        check_nano14(g14, student, s_out, t_out, loss, rt=3e-4 if fp else 3e-2, loss_tol=1e-4 if fp else 1e-2,
+                     grad_tol=2e-3 if fp else 0.15, probes=fp)
     finally:
         _teardown()

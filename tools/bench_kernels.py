@@ -70,9 +70,9 @@ def main():
             mask = torch.from_numpy(ops.shift_region_ids(H, H, 7, shift)).to(dev) if shift else None
             dout = torch.randn(nimg * L, C, device=dev).to(dt)
             t_f = timeit(lambda: ops.window_attn_fwd(qkv, qb, w2t, L, table, 7, mask, nW, 49, nH, 32 ** -0.5))
-            t_b = timeit(lambda: ops.window_attn_bwd(qkv, qb, w2t, L, dout, table, 7, mask, nW, 49, nH, 32 ** -0.5))
+            t_b = timeit(lambda: ops.window_attn_bwd(qkv, qb, w2t, L, dout, None, None, table, 7, mask, nW, 49, nH, 32 ** -0.5))
             ops.lib.esvit_debug_set_attn_bwd_waves(1)
-            t_b1 = timeit(lambda: ops.window_attn_bwd(qkv, qb, w2t, L, dout, table, 7, mask, nW, 49, nH, 32 ** -0.5))
+            t_b1 = timeit(lambda: ops.window_attn_bwd(qkv, qb, w2t, L, dout, None, None, table, 7, mask, nW, 49, nH, 32 ** -0.5))
             ops.lib.esvit_debug_set_attn_bwd_waves(2)
             print(json.dumps(dict(name="attn s%d H%d" % (s, H), windows=nimg * nW, nH=nH, fwd_us=t_f * 1e6, bwd_us=t_b * 1e6, bwd_us_1wave=t_b1 * 1e6,
                                   fwd_GBs=(qkv.numel() + dout.numel()) * 2 / t_f / 1e9,
