@@ -91,16 +91,70 @@ def cpu_baseline(bs=2, steps=6):
             "sample": "oracle/esvit_oracle.py fp32, Swin-T W7 2x224+8x96 V+R, bs=%d, median of %d steps (%.2f s/step)" % (bs, steps, med)}
 
 
+def torch_eager_gpu_baseline(dev, bs, steps=5):
+    """The same CPU-oracle code (a port of the reference's PyTorch path) run on the GPU under torch.autocast(bf16): what
+    stock PyTorch-ROCm (hipBLASLt + eager aten kernels) delivers for this step on the same MI355X.  Informational only."""
+    from oracle import esvit_oracle as O
+    from tests import golden_utils as GU
+    import esvit_amd
+    from esvit_amd import config as CFG
+    torch.manual_seed(0)
+    cfg = CFG.swin_config("swin_tiny_w7", DROP_PATH_RATE=0.0)
+    m = esvit_amd.build_model(cfg, use_dense_prediction=True)
+    m.head = esvit_amd.DINOHead(m.num_features, OUT_DIM)
+    m.head_dense = esvit_amd.DINOHead(m.num_features, OUT_DIM)
+    sd = {k: v.clone().to(dev) for k, v in m.state_dict().items()}
+    names = [n for n, p in m.named_parameters() if p.requires_grad]
+    all_names = [n for n, _ in m.named_parameters()]
+    params = {n: sd[n] for n in all_names}
+    teacher = {n: sd[n].clone() for n in all_names}
+    reg = {n for n in names if not (n.endswith(".bias") or sd[n].ndim == 1)}
+    crops = [c.to(dev) for c in GU.make_crops(bs)]
+    c0, cg0 = torch.zeros(1, OUT_DIM, device=dev), torch.zeros(1, OUT_DIM, device=dev)
+    state = {}
+
+    def step():
+        nonlocal c0, cg0
+        leaf = {n: params[n].detach().requires_grad_(True) for n in names}
+        full = dict(sd)
+        full.update(params)
+        full.update(leaf)
+        tfull = dict(sd)
+        tfull.update(teacher)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            with torch.no_grad():
+                t_out = O.swin_multicrop(tfull, crops[:2], GU.SWIN_T)
+            s_out = O.swin_multicrop(full, crops, GU.SWIN_T)
+            loss, bc, bg = O.ddino_loss(s_out, t_out, c0, cg0, 0.04, 10)
+        loss.backward()
+        with torch.no_grad():
+            c0, cg0 = O.center_update(c0, bc.float(), 2 * bs), O.center_update(cg0, bg.float(), 98 * bs)
+            O.clip_adamw_ema(params, {n: leaf[n].grad for n in names}, state, teacher, reg, 5e-4, 0.04, 0.996, clip=3.0)
+
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    return {"value": bs / dt, "unit": "images/s", "batch": bs, "ms_per_step": dt * 1e3,
+            "what": "oracle/esvit_oracle.py (port of the reference path) on the same GPU, torch eager + autocast(bf16)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=64, help="images per GPU")
+    ap.add_argument("--batch", type=int, default=128, help="images per GPU (BASELINE.json configs 3/4: 1024 over 8 GPUs)")
     ap.add_argument("--drop-path", type=float, default=0.1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--gemm-table", default=None, help="write a per-shape GEMM time table to this file")
+    ap.add_argument("--torch-eager", type=int, default=0, metavar="BATCH",
+                    help="also time the reference-path port under torch eager + autocast(bf16) on this GPU at the given batch")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -183,6 +237,10 @@ def main():
                                "gemm_ms_per_step": tot_ms / args.steps}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
+        if args.torch_eager and world == 1:
+            del trainer, student, teacher, loss_fn, crops
+            torch.cuda.empty_cache()
+            out["torch_eager_gpu"] = torch_eager_gpu_baseline(dev, args.torch_eager)
         print(json.dumps(out))
     if dist.is_initialized():
         dist.destroy_process_group()

@@ -37,9 +37,8 @@ struct AttnCfg {
     static constexpr int P_ELEMS = NP * LDP;
     static constexpr int VT_ELEMS = HD * LDP;
     static constexpr int R1 = (2 * QK_ELEMS > P_ELEMS) ? 2 * QK_ELEMS : P_ELEMS;  // Q,K overlaid by P
-    static constexpr int TAB_ELEMS = 256 * 4 / (int)sizeof(T);                     // 256 floats: the head's bias-table column
-    static constexpr int FWD_PER_WAVE = R1 + QK_ELEMS + TAB_ELEMS;                 // + V as [key][d]
-    static constexpr int BWD_PER_WAVE = 2 * QK_ELEMS + P_ELEMS + TAB_ELEMS;
+    static constexpr int FWD_PER_WAVE = R1 + VT_ELEMS;
+    static constexpr int BWD_PER_WAVE = 2 * QK_ELEMS + P_ELEMS;
 };
 
 template <typename T>
@@ -85,44 +84,12 @@ __device__ __forceinline__ void stage_rows(const T* __restrict__ g, long row_str
 }
 
 // scores + softmax, shared by fwd and bwd: returns P^T fragments p[ki][qj] (fp32)
-// Relative-position bias (swin_transformer.py:133-136) is gathered from the head's (2ws-1)^2-entry table column held in
-// LDS: index[q][key] = a(q) - a(key) + (ws-1)*2ws with a(t) = (t/ws)*(2ws-1) + t%ws, so each element costs one
-// subtraction and one ds_read instead of a 16 KiB dense-bias load per (window, head).  RelIdx holds the per-lane
-// constants (they depend only on the lane and ws).
-struct RelIdx {
-    int aq[4];      // a(q) for q = 16j + c
-    int ak[4][4];   // a(key) - offset for key = 16i + 4g + r
-};
-__device__ __forceinline__ RelIdx make_relidx(int ws, int c, int g) {
-    RelIdx x;
-    const int w2 = 2 * ws - 1, off = (ws - 1) * 2 * ws;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int q = 16 * j + c;
-        x.aq[j] = (q / ws) * w2 + q % ws;
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int k = 16 * i + 4 * g + r;
-            x.ak[i][r] = (k / ws) * w2 + k % ws - off;
-        }
-    return x;
-}
-// copy the head's table column (stride nH in HBM) into the wave's LDS slice
-__device__ __forceinline__ void load_rel_table(const float* __restrict__ table, int rows, int nH, int h, float* tab_lds, int lane) {
-    for (int t = lane; t < rows; t += 64) tab_lds[t] = table[(long)t * nH + h];
-}
-
 // Shift mask (swin_transformer.py:249-272): mask[q][key] = 0 if region(q) == region(key) else -100.  `myreg` holds the
-// window's per-slot region ids in registers (lane l: slot l), so the 49x49 mask is rebuilt from 20 cross-lane reads
-// instead of a 16 KiB load per (window, head).
-// bias_f (optional): the head's bias already in fragment order (one 16-byte load per tile, -1e30 in padded key columns);
-// measured faster than the LDS gather for 7x7 windows, so the host passes it whenever it has a workspace for it.
+// window's per-slot region ids in registers (lane l: slot l), or -1 in every lane when the block is unshifted, so the
+// 49x49 mask is rebuilt from 20 cross-lane reads instead of a 16 KiB load per (window, head).
 template <typename T>
-__device__ __forceinline__ void scores_softmax(const T* Qs, const T* Ks, const float* __restrict__ bias_f, const float* tab_lds,
-                                               const RelIdx& ri, int N, int myreg, bool masked, int lane, int c, int g, f32x4 (&p)[4][4]) {
+__device__ __forceinline__ void scores_softmax(const T* Qs, const T* Ks, const float* __restrict__ bias_f, int myreg,
+                                               bool masked, int lane, int c, int g, f32x4 (&p)[4][4]) {
     constexpr int LDQ = AttnCfg<T>::LDQ;
     Frag<T> kf[4], qf[4];
 #pragma unroll
@@ -140,22 +107,10 @@ __device__ __forceinline__ void scores_softmax(const T* Qs, const T* Ks, const f
         for (int r = 0; r < 4; ++r) rk[r] = __shfl(myreg, 16 * i + 4 * g + r, 64);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const bool qok = 16 * j + c < N;
-            f32x4 b;
-            if (bias_f) {
-                b = *reinterpret_cast<const f32x4*>(bias_f + ((i * 4 + j) * 64 + lane) * 4);
+            f32x4 b = *reinterpret_cast<const f32x4*>(bias_f + ((i * 4 + j) * 64 + lane) * 4);
+            if (masked) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (masked && rk[r] != rq[j]) b[r] += -100.f;
-            } else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const bool kok = 16 * i + 4 * g + r < N;
-                    float v = (qok && kok) ? tab_lds[ri.aq[j] - ri.ak[i][r]] : 0.f;
-                    if (!kok) v = -1.0e30f;  // padded key columns never receive probability
-                    if (masked && rk[r] != rq[j]) v += -100.f;
-                    b[r] = v;
-                }
+                for (int r = 0; r < 4; ++r) b[r] += (rk[r] != rq[j]) ? -100.f : 0.f;
             }
             p[i][j] = b;
             mma(kf[i], qf[j], p[i][j]);
@@ -202,10 +157,9 @@ __device__ __forceinline__ void store_pt(T* Ps, const f32x4 (&p)[4][4], int c, i
 // inverse (swin_transformer.py:286-325) are the slot->token map `win2tok`, applied on the fly.
 template <typename T>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv, const float* __restrict__ qkv_bias,
-                                                       const int* __restrict__ win2tok, int L, const float* __restrict__ rel_table,
-                                                       int rel_rows, int ws, const float* __restrict__ bias_frag,
-                                                       const int* __restrict__ region_ids, int nW, int Bw, int N, int nH, float scale,
-                                                       T* __restrict__ out, float* __restrict__ attn_out) {
+                                                       const int* __restrict__ win2tok, int L, const float* __restrict__ bias_frag,
+                                                       const int* __restrict__ region_ids, int nW, int Bw, int N, int nH,
+                                                       float scale, T* __restrict__ out, float* __restrict__ attn_out) {
     using Cfg = AttnCfg<T>;
     constexpr int LDQ = Cfg::LDQ, LDP = Cfg::LDP, VEC = Cfg::VEC;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -215,8 +169,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv
     T* Qs = base;
     T* Ks = base + Cfg::QK_ELEMS;
     T* Ps = base;  // overlays Q,K once the scores are in registers
-    T* Vs = base + Cfg::R1;  // V as [key][d]; the PV product reads it with the transpose read
-    float* tab = reinterpret_cast<float*>(base + Cfg::R1 + Cfg::QK_ELEMS);
+    T* Vt = base + Cfg::R1;
 
     const long unit = (long)blockIdx.x * 4 + wave;
     const bool active = unit < (long)Bw * nH;
@@ -229,16 +182,34 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv
 
     stage_rows<T>(src, 3L * C, mytok, tok_base, N, active, scale, qkv_bias + h * HD, Qs, lane);
     stage_rows<T>(src + C, 3L * C, mytok, tok_base, N, active, 1.f, qkv_bias + C + h * HD, Ks, lane);
-    stage_rows<T>(src + 2 * C, 3L * C, mytok, tok_base, N, active, 1.f, qkv_bias + 2 * C + h * HD, Vs, lane);
-    if (!bias_frag) load_rel_table(rel_table, rel_rows, nH, h, tab, lane);
-    const RelIdx ri = make_relidx(ws, c, g);
-    const float* bias_f = bias_frag ? bias_frag + (long)h * FRAG_ELEMS : nullptr;
+    {  // V transposed: Vt[d][key]
+        constexpr int VPR = HD / VEC;
+        const float* padv = qkv_bias + 2 * C + h * HD;
+#pragma unroll
+        for (int i = 0; i < NP * VPR / 64; ++i) {
+            const int v = lane + 64 * i;
+            const int t = v / VPR, dv = v % VPR;
+            const int tok = __shfl(mytok, t, 64);
+            Vec16<T> x = zero16<T>();
+            if (active && t < N) {
+                if (tok >= 0) {
+                    x = ld16<T>(src + 2 * C + (tok_base + tok) * 3L * C + dv * VEC);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < Vec16<T>::N; ++e) x.set(e, padv[dv * VEC + e]);
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < Vec16<T>::N; ++e) Vt[(dv * VEC + e) * LDP + t] = from_f32<T>(x.get(e));
+        }
+    }
     __syncthreads();
 
     f32x4 p[4][4];
+    const float* bias_f = bias_frag + (long)h * FRAG_ELEMS;
     const bool masked = region_ids != nullptr;
     const int myreg = (masked && active && lane < N) ? region_ids[(long)(bw % nW) * N + lane] : -1;
-    scores_softmax<T>(Qs, Ks, bias_f, tab, ri, N, myreg, masked, lane, c, g, p);
+    scores_softmax<T>(Qs, Ks, bias_f, myreg, masked, lane, c, g, p);
 
     if (attn_out && active) {
 #pragma unroll
@@ -264,8 +235,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
         Frag<T> vf[2];
-        vf[0] = frag_ks<T, true>(Vs, LDQ, 0, 32 * ks, c, g);
-        vf[1] = frag_ks<T, true>(Vs, LDQ, 16, 32 * ks, c, g);
+        vf[0] = frag_kc<T>(Vt, LDP, 0, 32 * ks, c, g);
+        vf[1] = frag_kc<T>(Vt, LDP, 16, 32 * ks, c, g);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const Frag<T> pf = frag_kc<T>(Ps, LDP, 16 * i, 32 * ks, c, g);
@@ -322,9 +293,8 @@ __device__ __forceinline__ void store_tok_rows(const f32x4 (&acc)[4][2], float m
 template <typename T, bool USE_TR, int MINW>
 __global__ __launch_bounds__(256, MINW) void attn_bwd_kernel(const T* __restrict__ qkv, const float* __restrict__ qkv_bias,
                                                           const int* __restrict__ win2tok, int L, const T* __restrict__ dout,
-                                                          const float* __restrict__ rel_table, int rel_rows, int ws,
-                                                          const float* __restrict__ bias_frag, const int* __restrict__ region_ids, int nW,
-                                                          int Bw, int N, int nH, float scale, int parts,
+                                                          const float* __restrict__ bias_frag, const int* __restrict__ region_ids,
+                                                          int nW, int Bw, int N, int nH, float scale, int parts,
                                                           T* __restrict__ dqkv, float* __restrict__ dbias_ws,
                                                           float* __restrict__ dpad_ws) {
     using Cfg = AttnCfg<T>;
@@ -336,18 +306,15 @@ __global__ __launch_bounds__(256, MINW) void attn_bwd_kernel(const T* __restrict
     T* bufA = base;                      // scale*Q, then V, then scale*Q
     T* bufB = base + Cfg::QK_ELEMS;      // K, then dO, then K
     T* Ps = base + 2 * Cfg::QK_ELEMS;    // P, then dS  ([q][key])
-    float* tab = reinterpret_cast<float*>(base + 2 * Cfg::QK_ELEMS + Cfg::P_ELEMS);
 
     const long wv = (long)blockIdx.x * 4 + wave;
     const bool wave_ok = wv < (long)parts * nH;
     const int h = (int)(wv % nH);
     const int part = (int)(wv / nH);
     const int C = nH * HD;
+    const float* bias_f = bias_frag + (long)h * FRAG_ELEMS;
     const T* src = qkv + h * HD;
     T* dst = dqkv + h * HD;
-    if (!bias_frag) load_rel_table(rel_table, rel_rows, nH, h, tab, lane);  // visible after the first barrier of the window loop
-    const RelIdx ri = make_relidx(ws, c, g);
-    const float* bias_f = bias_frag ? bias_frag + (long)h * FRAG_ELEMS : nullptr;
 
     f32x4 db[4][4];
 #pragma unroll
@@ -372,7 +339,7 @@ __global__ __launch_bounds__(256, MINW) void attn_bwd_kernel(const T* __restrict
         stage_rows<T>(src + C, 3L * C, mytok, tok_base, N, active, 1.f, qkv_bias + C + h * HD, bufB, lane);
         __syncthreads();
         f32x4 p[4][4];
-        scores_softmax<T>(bufA, bufB, bias_f, tab, ri, N, myreg, masked, lane, c, g, p);
+        scores_softmax<T>(bufA, bufB, bias_f, myreg, masked, lane, c, g, p);
         store_pt<T>(Ps, p, c, g);
         __syncthreads();  // score reads of bufA/bufB done; Ps visible
 
@@ -645,8 +612,8 @@ extern "C" int esvit_window_attn_fwd(int dtype, const void* qkv, const float* qk
     ESVIT_CHECK_ARG(hd == HD, "esvit_window_attn_fwd: head_dim %d unsupported (32 only)", hd);
     ESVIT_CHECK_ARG(dtype == ESVIT_BF16 || dtype == ESVIT_F32, "esvit_window_attn_fwd: bad dtype");
     if (N > NP) return esvit_big_attn_fwd(dtype, qkv, qkv_bias, win2tok, L, rel_table, ws, region_ids, nW, nB, N, nH, scale, out, lse, attn_out, stream);
-    const int rel_rows = (2 * ws - 1) * (2 * ws - 1);
-    if (bias_frag_ws) {
+    ESVIT_CHECK_ARG(bias_frag_ws != nullptr, "esvit_window_attn_fwd: 7x7 windows need the bias_frag_ws scratch");
+    {
         int rc = fill_bias_frag(rel_table, ws, N, nH, bias_frag_ws, stream);
         if (rc != ESVIT_OK) return rc;
     }
@@ -656,13 +623,13 @@ extern "C" int esvit_window_attn_fwd(int dtype, const void* qkv, const float* qk
         const size_t lds = 4 * (size_t)AttnCfg<bf16>::FWD_PER_WAVE * sizeof(bf16);
         auto kern = attn_fwd_kernel<bf16>;
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, (const bf16*)qkv, qkv_bias, win2tok, L, rel_table, rel_rows, ws,
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, (const bf16*)qkv, qkv_bias, win2tok, L,
                            (const float*)bias_frag_ws, region_ids, nW, Bw, N, nH, scale, (bf16*)out, attn_out);
     } else {
         const size_t lds = 4 * (size_t)AttnCfg<float>::FWD_PER_WAVE * sizeof(float);
         auto kern = attn_fwd_kernel<float>;
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, (const float*)qkv, qkv_bias, win2tok, L, rel_table, rel_rows, ws,
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, (const float*)qkv, qkv_bias, win2tok, L,
                            (const float*)bias_frag_ws, region_ids, nW, Bw, N, nH, scale, (float*)out, attn_out);
     }
     ESVIT_CHECK_LAUNCH("window_attn_fwd");
@@ -682,8 +649,8 @@ extern "C" int esvit_window_attn_bwd(int dtype, const void* qkv, const float* qk
     if (N > NP)
         return esvit_big_attn_bwd(dtype, g_attn_use_tr, qkv, qkv_bias, win2tok, L, dout, fwd_out, lse, rel_table, ws, region_ids, nW, nB, N, nH,
                                   scale, dqkv, dbias_ws, dpad_ws, stream);
-    const int rel_rows = (2 * ws - 1) * (2 * ws - 1);
-    if (bias_frag_ws) {
+    ESVIT_CHECK_ARG(bias_frag_ws != nullptr, "esvit_window_attn_bwd: 7x7 windows need the bias_frag_ws scratch");
+    {
         int rc = fill_bias_frag(rel_table, ws, N, nH, bias_frag_ws, stream);
         if (rc != ESVIT_OK) return rc;
     }
@@ -696,7 +663,7 @@ extern "C" int esvit_window_attn_bwd(int dtype, const void* qkv, const float* qk
         auto kern = g_attn_minw == 2 ? attn_bwd_kernel<TT, TR, 2> : attn_bwd_kernel<TT, TR, 1>;                                \
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);   \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, (const TT*)qkv, qkv_bias, win2tok, L, (const TT*)dout,      \
-                           rel_table, rel_rows, ws, (const float*)bias_frag_ws, region_ids, nW, Bw, N, nH, scale, parts,        \
+                           (const float*)bias_frag_ws, region_ids, nW, Bw, N, nH, scale, parts,                                 \
                            (TT*)dqkv, dbias_ws, dpad_ws);                                                                       \
     }
     if (dtype == ESVIT_BF16) {
