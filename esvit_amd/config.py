@@ -25,6 +25,10 @@ _DEFAULTS = dict(
 SWIN_SPECS = {
     "swin_tiny_w7": dict(PATCH_SIZE=4, DIM_EMBED=96, DEPTHS=[2, 2, 6, 2], NUM_HEADS=[3, 6, 12, 24], WINDOW_SIZE=7, MLP_RATIO=4,
                          QKV_BIAS=True, DROP_RATE=0, ATTN_DROP_RATE=0, DROP_PATH_RATE=0.1, USE_APE=False, PATCH_NORM=True),
+    "swin_tiny_w14": dict(PATCH_SIZE=4, DIM_EMBED=96, DEPTHS=[2, 2, 6, 2], NUM_HEADS=[3, 6, 12, 24], WINDOW_SIZE=14, MLP_RATIO=4,
+                          QKV_BIAS=True, DROP_RATE=0, ATTN_DROP_RATE=0, DROP_PATH_RATE=0.1, USE_APE=False, PATCH_NORM=True),
+    "swin_base_w14": dict(PATCH_SIZE=4, DIM_EMBED=128, DEPTHS=[2, 2, 18, 2], NUM_HEADS=[4, 8, 16, 32], WINDOW_SIZE=14, MLP_RATIO=4,
+                          QKV_BIAS=True, DROP_RATE=0, ATTN_DROP_RATE=0, DROP_PATH_RATE=0.2, USE_APE=False, PATCH_NORM=True),
     "swin_small_w7": dict(PATCH_SIZE=4, DIM_EMBED=96, DEPTHS=[2, 2, 18, 2], NUM_HEADS=[3, 6, 12, 24], WINDOW_SIZE=7, MLP_RATIO=4,
                           QKV_BIAS=True, DROP_RATE=0, ATTN_DROP_RATE=0, DROP_PATH_RATE=0.2, USE_APE=False, PATCH_NORM=True),
     "swin_base_w7": dict(PATCH_SIZE=4, DIM_EMBED=128, DEPTHS=[2, 2, 18, 2], NUM_HEADS=[4, 8, 16, 32], WINDOW_SIZE=7, MLP_RATIO=4,
