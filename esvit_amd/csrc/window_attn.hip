@@ -51,6 +51,16 @@ __device__ __forceinline__ void store_frag4(T* p, f32x4 v) {
     }
 }
 
+template <typename T>
+__device__ __forceinline__ f32x4 load_frag4(const T* p) {
+    if constexpr (sizeof(T) == 4) {
+        return *reinterpret_cast<const f32x4*>(p);
+    } else {
+        const bf16x4 v = *reinterpret_cast<const bf16x4*>(p);
+        return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+    }
+}
+
 // stage one [N][HD] matrix of the (window, head) slice into a [NP][LDQ] LDS image (rows >= N zero).
 // Rows are window slots; slot t reads token row tok_base + w2t[t] of the token-ordered matrix `g`, or -- for a
 // zero-pad slot (w2t[t] < 0, swin_transformer.py:286-290) -- the constant `pad` (the qkv bias of this head: LN'd
@@ -338,9 +348,11 @@ __global__ __launch_bounds__(256, MINW) void attn_bwd_kernel(const T* __restrict
         stage_rows<T>(src, 3L * C, mytok, tok_base, N, active, scale, qkv_bias + h * HD, bufA, lane);
         stage_rows<T>(src + C, 3L * C, mytok, tok_base, N, active, 1.f, qkv_bias + C + h * HD, bufB, lane);
         __syncthreads();
-        f32x4 p[4][4];
-        scores_softmax<T>(bufA, bufB, bias_f, myreg, masked, lane, c, g, p);
-        store_pt<T>(Ps, p, c, g);
+        {
+            f32x4 p[4][4];  // dies here: the dS step re-reads P from its LDS image, which keeps the kernel at 2 waves/SIMD
+            scores_softmax<T>(bufA, bufB, bias_f, myreg, masked, lane, c, g, p);
+            store_pt<T>(Ps, p, c, g);
+        }
         __syncthreads();  // score reads of bufA/bufB done; Ps visible
 
         // ---- phase 2: dV = P^T dO;  dP^T = V dO^T;  dS = P o (dP - delta) ----
@@ -377,20 +389,21 @@ __global__ __launch_bounds__(256, MINW) void attn_bwd_kernel(const T* __restrict
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const Frag<T> of = frag_kc<T>(bufB, LDQ, 16 * j, 0, c, g);
-                f32x4 dpj[4];
+                f32x4 dpj[4], pj[4];
                 float d = 0.f;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     dpj[i] = f32x4{0.f, 0.f, 0.f, 0.f};
                     mma(vf[i], of, dpj[i]);
+                    pj[i] = load_frag4<T>(Ps + (16 * j + c) * LDP + 16 * i + 4 * g);  // this lane's own P elements
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) d += p[i][j][r] * dpj[i][r];
+                    for (int r = 0; r < 4; ++r) d += pj[i][r] * dpj[i][r];
                 }
                 d += __shfl_xor(d, 16, 64);
                 d += __shfl_xor(d, 32, 64);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const f32x4 ds = p[i][j] * (dpj[i] - d);
+                    const f32x4 ds = pj[i] * (dpj[i] - d);
                     if (active) db[i][j] += ds;
                     store_frag4<T>(Ps + (16 * j + c) * LDP + 16 * i + 4 * g, ds);
                 }
@@ -570,7 +583,7 @@ extern "C" int esvit_relpos_bias_bwd(const float* dbias_ws, int parts, const int
 }
 
 static int g_attn_use_tr = 1;
-static int g_attn_minw = 1;  // waves per SIMD the backward kernel is compiled for (2: 256 registers + some scratch, 1: 512 registers)
+static int g_attn_minw = 2;  // waves per SIMD the backward kernel is compiled for (2: 256 registers + some scratch, 1: 512 registers)
 extern "C" void esvit_debug_set_attn_tr_read(int on) { g_attn_use_tr = on; }
 extern "C" void esvit_debug_set_attn_bwd_waves(int w) { g_attn_minw = w; }
 

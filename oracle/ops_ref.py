@@ -400,7 +400,7 @@ def window_attn_bwd(qkv, qkv_bias, win2tok, L, dout, fwd_out, lse, rel_table, ws
     pr = _r(p, dt).float()
     dv = pr.transpose(-2, -1) @ do
     dp = do @ v.transpose(-2, -1)
-    ds = p * (dp - (p * dp).sum(-1, keepdim=True))
+    ds = pr * (dp - (pr * dp).sum(-1, keepdim=True))  # the kernel re-reads P from its (activation-dtype) LDS image
     dsr = _r(ds, dt).float()
     dq = (dsr @ k) * scale
     dk = dsr.transpose(-2, -1) @ q
