@@ -583,7 +583,7 @@ extern "C" int esvit_relpos_bias_bwd(const float* dbias_ws, int parts, const int
 }
 
 static int g_attn_use_tr = 1;
-static int g_attn_minw = 2;  // waves per SIMD the backward kernel is compiled for (2: 256 registers + some scratch, 1: 512 registers)
+static int g_attn_minw = 1;  // waves per SIMD the backward kernel is compiled for (2: 256 registers + some scratch, 1: 512 registers)
 extern "C" void esvit_debug_set_attn_tr_read(int on) { g_attn_use_tr = on; }
 extern "C" void esvit_debug_set_attn_bwd_waves(int w) { g_attn_minw = w; }
 
