@@ -26,7 +26,24 @@ sys.path.insert(0, ROOT)
 GFLOP_PER_IMG = 154.5          # Swin-T W7 V+R, teacher fwd + student fwd + 2x student bwd + loss
 GFLOP_PER_IMG_BY_ARCH = {"swin_tiny_w7": 154.5, "swin_tiny_w14": 197.0, "swin_base_w14": 628.5}
 BF16_PEAK_TFLOPS = 2500.0      # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E (MI355X_MICROARCH.md; ~6.3 TB/s is what a streaming kernel reaches)
 OUT_DIM = 65536
+PMC_TRAFFIC_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
+
+
+def pmc_gemm_traffic_per_launch(arch, batch, launches_per_step):
+    """HBM bytes per GEMM launch from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE in separate
+    runs of this same command, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950; produced by
+    tools/pmc_traffic.py).  None when no PMC run exists for this arch / batch."""
+    try:
+        with open(PMC_TRAFFIC_FILE) as fh:
+            runs = json.load(fh)["runs"]
+    except (OSError, ValueError, KeyError):
+        return None
+    for r in runs:
+        if r["arch"] == arch and r["batch"] == batch:
+            return r["gemm_bytes_per_step"] / launches_per_step
+    return None
 
 
 def build(dev, drop_path, arch="swin_tiny_w7"):
@@ -178,6 +195,9 @@ def main():
     from esvit_amd.engine import EsvitTrainer
     from tests import golden_utils as GU
     esvit_amd.set_precision("bf16")
+    for var, setter in (("ESVIT_GEMM_XCDMAP", "esvit_debug_set_gemm_xcdmap"), ("ESVIT_GEMM_PIPE", "esvit_debug_set_gemm_pipe")):
+        if os.environ.get(var):  # kernel A/B switches for profiling runs; defaults are the shipped configuration
+            getattr(ops.lib, setter)(int(os.environ[var]))
     torch.manual_seed(0)
     student, teacher, loss_fn = build(dev, args.drop_path, args.arch)
     trainer = EsvitTrainer(student, teacher, loss_fn, clip_grad=3.0, freeze_last_layer=1)
@@ -223,25 +243,33 @@ def main():
                "step_mfma_frac": (ips / world * GFLOP_PER_IMG_BY_ARCH[args.arch] / 1e3 / BF16_PEAK_TFLOPS
                                   if args.arch in GFLOP_PER_IMG_BY_ARCH else None)}
         if prof:
-            tot_fl = sum(f for f, _, _, _ in prof)
-            tot_ms = sum(a.elapsed_time(b) for _, a, b, _ in prof)
+            tot_fl = sum(r[0] for r in prof)
+            tot_by = sum(r[4] for r in prof)
+            tot_ms = sum(r[1].elapsed_time(r[2]) for r in prof)
             if args.gemm_table:
                 agg = {}
-                for f, a, b, key in prof:
-                    e = agg.setdefault(key, [0, 0.0, 0.0])
+                for f, a, b, key, by in prof:
+                    e = agg.setdefault(key, [0, 0.0, 0.0, 0.0])
                     e[0] += 1
                     e[1] += a.elapsed_time(b)
                     e[2] += f
+                    e[3] += by
                 with open(args.gemm_table, "w") as fh:
-                    for key, (n, ms, fl) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
-                        fh.write("M=%7d N=%6d K=%7d aks=%d bks=%d splitk=%3d calls/step %5.1f ms/step %7.3f TF %7.1f\n" % (
-                            key + (n / args.steps, ms / args.steps, fl / ms / 1e9)))
-            ach = tot_fl / (tot_ms * 1e-3) / 1e12
-            out["roofline"] = {"bound": "mfma", "kernel": "gemm_kernel<bf16,...> (all fwd/dgrad/wgrad GEMM launches of the step)",
-                               "achieved": ach, "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / BF16_PEAK_TFLOPS,
-                               "traffic": None, "launches_per_step": len(prof) / args.steps,
-                               "flops_per_launch": tot_fl / len(prof), "avg_launch_us": tot_ms * 1e3 / len(prof),
-                               "gemm_ms_per_step": tot_ms / args.steps}
+                    for key, (n, ms, fl, by) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+                        fh.write("M=%7d N=%6d K=%7d aks=%d bks=%d splitk=%3d calls/step %5.1f ms/step %7.3f TF %7.1f GB/s %6.0f MB/call %7.1f\n" % (
+                            key + (n / args.steps, ms / args.steps, fl / ms / 1e9, by / ms / 1e6, by / n / 1e6)))
+            # The GEMM family (all fwd / dgrad / wgrad launches of the step) is the dominant kernel.  Its arithmetic
+            # intensity on this workload is ~180 FLOP/B against a ridge of 2500 TFLOP/s / 8 TB/s = 312 FLOP/B, so
+            # HBM is the roof that binds; the MFMA figure is kept beside it.
+            gbs = tot_by / (tot_ms * 1e-3) / 1e9
+            ach_tf = tot_fl / (tot_ms * 1e-3) / 1e12
+            out["roofline"] = {"bound": "hbm", "kernel": "gemm_dma_kernel / gemm_kernel (all fwd/dgrad/wgrad GEMM launches of the step)",
+                               "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                               "traffic": pmc_gemm_traffic_per_launch(args.arch, B, len(prof) / args.steps),
+                               "launches_per_step": len(prof) / args.steps,
+                               "algorithmic_bytes_per_launch": tot_by / len(prof), "flops_per_launch": tot_fl / len(prof),
+                               "avg_launch_us": tot_ms * 1e3 / len(prof), "gemm_ms_per_step": tot_ms / args.steps,
+                               "flop_per_byte": tot_fl / tot_by, "mfma_tflops": ach_tf, "mfma_frac": ach_tf / BF16_PEAK_TFLOPS}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
         if args.torch_eager and world == 1:

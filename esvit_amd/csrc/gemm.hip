@@ -291,6 +291,29 @@ __device__ __forceinline__ void gemm_epilogue(const esvit_gemm_desc& p, f32x4 (&
     }
 }
 
+
+// XCD-aware work order over a 1-D grid of ntiles * nz blocks.  The dispatcher places block b on XCD b % 8; give
+// every XCD a contiguous range of the virtual ids v = z * ntiles + tile (bijective remap), so (a) the tiles of one
+// output row panel share an L2 and (b) all tiles of one split-K slice / batch item run on the same XCD at the same
+// time -- the slice of A and B they all read is then fetched from HBM once instead of once per XCD.
+__device__ __forceinline__ void xcd_tile_map(int ntiles, int& tile, int& z) {
+    if (gridDim.y > 1) {  // debug layout (esvit_debug_set_gemm_xcdmap(0)): remap the tiles only, z on grid.y
+        const int b = blockIdx.x;
+        const int q = ntiles / 8, r = ntiles % 8;
+        const int xcd = b % 8, idx = b / 8;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        z = blockIdx.y;
+        return;
+    }
+    const int total = gridDim.x;
+    const int b = blockIdx.x;
+    const int q = total / 8, r = total % 8;
+    const int xcd = b % 8, idx = b / 8;
+    const int v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    z = v / ntiles;
+    tile = v - z * ntiles;
+}
+
 template <typename T, bool AKS, bool BKS, int BM, int BN, bool USE_TR>
 __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const esvit_gemm_desc p) {
     using TA = Tile<T, AKS, BM, USE_TR>;
@@ -308,15 +331,10 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const esvit_gemm_desc p)
     // XCD-aware tile order: block b runs on XCD b%8; give every XCD a contiguous range of
     // tile ids so the tiles that share an A panel hit the same L2 (bijective remap).
     const int ntiles = tiles_m * tiles_n;
-    int pid = blockIdx.x;
-    {
-        const int q = ntiles / 8, r = ntiles % 8;
-        const int xcd = pid % 8, idx = pid / 8;
-        pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
+    int pid, z;
+    xcd_tile_map(ntiles, pid, z);
     const int tm = pid / tiles_n, tn = pid % tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
-    const int z = blockIdx.y;
 
     const T* A = reinterpret_cast<const T*>(p.A);
     const T* B = reinterpret_cast<const T*>(p.B);
@@ -495,15 +513,10 @@ __global__ __launch_bounds__(NTHREADS) void gemm_dma_kernel(const esvit_gemm_des
     const int M = p.M, N = p.N, K = p.K;
     const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
     const int ntiles = tiles_m * tiles_n;
-    int pid = blockIdx.x;
-    {
-        const int q = ntiles / 8, r = ntiles % 8;
-        const int xcd = pid % 8, idx = pid / 8;
-        pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
+    int pid, z;
+    xcd_tile_map(ntiles, pid, z);
     const int tm = pid / tiles_n, tn = pid % tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
-    const int z = blockIdx.y;
     const bf16* A = reinterpret_cast<const bf16*>(p.A);
     const bf16* B = reinterpret_cast<const bf16*>(p.B);
     int kbeg = 0, kend = K;
@@ -614,6 +627,8 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ part, int splits,
     }
 }
 
+static int g_xcd_map = 0;  // 0: tiles on grid.x (XCD-remapped), z on grid.y; 1: 1-D grid, XCD-contiguous over (z, tile) -- measured 8% slower on the wgrad family (profiles/r01_gemm_xcdmap_ab.txt)
+
 template <typename T, bool AKS, bool BKS, int BM, int BN, bool USE_TR>
 int launch_gemm(const esvit_gemm_desc& d, hipStream_t stream) {
     using TA = Tile<T, AKS, BM, USE_TR>;
@@ -629,7 +644,8 @@ int launch_gemm(const esvit_gemm_desc& d, hipStream_t stream) {
         attr_done = true;
     }
     const int tiles = ceil_div(d.M, BM) * ceil_div(d.N, BN);
-    dim3 grid(tiles, d.splitk > 1 ? d.splitk : d.batch);
+    const int nz = d.splitk > 1 ? d.splitk : d.batch;
+    dim3 grid = g_xcd_map ? dim3(tiles * nz) : dim3(tiles, nz);
     hipLaunchKernelGGL(kern, grid, dim3(NTHREADS), lds, stream, d);
     ESVIT_CHECK_LAUNCH("esvit_gemm");
     if (d.splitk > 1) {
@@ -661,7 +677,8 @@ int launch_gemm_dma(const esvit_gemm_desc& d, hipStream_t stream) {
         attr_done = true;
     }
     const int tiles = ceil_div(d.M, BM) * ceil_div(d.N, BN);
-    dim3 grid(tiles, d.splitk > 1 ? d.splitk : d.batch);
+    const int nz = d.splitk > 1 ? d.splitk : d.batch;
+    dim3 grid = g_xcd_map ? dim3(tiles * nz) : dim3(tiles, nz);
     hipLaunchKernelGGL(kern, grid, dim3(NTHREADS), lds, stream, d);
     ESVIT_CHECK_LAUNCH("esvit_gemm(dma)");
     if (d.splitk > 1) {
@@ -727,6 +744,7 @@ static int g_use_dma = 1;
 extern "C" void esvit_debug_set_tr_read(int on) { g_use_tr = on; }
 extern "C" void esvit_debug_set_gemm_dma(int on) { g_use_dma = on; }
 extern "C" void esvit_debug_set_gemm_pipe(int mode) { g_dma_pipe = mode; }
+extern "C" void esvit_debug_set_gemm_xcdmap(int mode) { g_xcd_map = mode; }
 
 extern "C" int esvit_gemm(int dtype, const esvit_gemm_desc* dp, esvit_stream_t stream_) {
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);

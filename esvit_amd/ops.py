@@ -125,9 +125,24 @@ def _gemm(dt, **kw):
         _gemm_launch(dt, **kw)
         e1.record()
         GEMM_PROFILE.append((2.0 * kw["M"] * kw["N"] * kw["K"] * kw.get("batch", 1), e0, e1,
-                             (kw["M"], kw["N"], kw["K"], kw.get("a_kstrided", 0), kw.get("b_kstrided", 0), kw.get("splitk", 0))))
+                             (kw["M"], kw["N"], kw["K"], kw.get("a_kstrided", 0), kw.get("b_kstrided", 0), kw.get("splitk", 0)),
+                             gemm_algorithmic_bytes(dt, kw)))
         return
     _gemm_launch(dt, **kw)
+
+
+def gemm_algorithmic_bytes(dt, kw):
+    """HBM bytes one esvit_gemm call has to move when every operand is read once and every output written once:
+    A + B + C (+ the GELU pre-activation / derivative side tensor, + the fp32 residual).  Split-K partials are NOT
+    algorithmic (they are this implementation's overhead and show up in the PMC traffic instead)."""
+    es = 2 if dt == torch.bfloat16 else 4
+    M, N, K, batch = kw["M"], kw["N"], kw["K"], kw.get("batch", 1)
+    b = batch * (M * K + N * K) * es + batch * M * N * (4 if kw.get("out_f32", 0) else es)
+    if kw.get("aux") is not None:
+        b += M * N * es
+    if kw.get("residual") is not None:
+        b += M * N * 4
+    return float(b)
 
 
 def _gemm_launch(dt, **kw):
