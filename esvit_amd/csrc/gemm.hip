@@ -30,6 +30,17 @@ namespace {
 constexpr int BK = 32;
 constexpr int NTHREADS = 256;
 
+// compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>) -- every index is a constant by
+// construction, so per-iteration register arrays never end up dynamically indexed (i.e. in scratch)
+template <typename F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
 __device__ __forceinline__ Frag<bf16> ones_frag(bf16) {
     Frag<bf16> f;
 #pragma unroll
@@ -116,7 +127,15 @@ struct Tile {
 };
 
 // ---- epilogue (shared by both main-loop variants) ----
-template <typename T, int BM, int BN>
+// SR: rows staged per pass.  The wave's staging region is private (callers barrier once before the epilogue when the
+// region aliases operand buffers), so passes need no workgroup barrier -- LDS instructions of one wave execute in
+// order.  LOCAL: tight LDS budget (persistent kernel) -> no row pad, XOR swizzle instead.
+//
+// Memory-op ordering matters more than anything else here: vmcnt retires in order, so a wave that waits for a load
+// issued AFTER its stores sits out the full store latency.  Every tensor the epilogue reads is therefore requested
+// ahead of the stores it would otherwise queue behind: bias and the row map once per tile, and the per-element
+// inputs of pass ps+1 (residual or GELU pre-activation, DropPath scale) before the stores of pass ps.
+template <typename T, int BM, int BN, int SR = 16, bool LOCAL = false>
 __device__ __forceinline__ void gemm_epilogue(const esvit_gemm_desc& p, f32x4 (&acc)[BM / 32][BN / 32], char* smem_raw, int m0, int n0,
                                               int z) {
     constexpr int WTM = BM / 2, WTN = BN / 2;
@@ -126,84 +145,137 @@ __device__ __forceinline__ void gemm_epilogue(const esvit_gemm_desc& p, f32x4 (&
     const int c = lane & 15, g = lane >> 4;
     const int wm = wave >> 1, wn = wave & 1;
     // Accumulator fragments hold a 4x1 column strip per lane (stride-16 columns), which would mean 2-byte
-    // scattered stores.  Each wave therefore stages 32 rows of its tile at a time through its own LDS region
-    // (the operand buffers are free by now) and re-reads them as row-contiguous groups of 8 columns, so every
-    // global access of the epilogue (bias, aux, residual, C) is a 16/32-byte vector.
-    constexpr int LDE = WTN + 4;             // floats per staged row
-    constexpr int CG = WTN / 8;              // 8-column groups per row
-    constexpr int ITEMS = 32 * CG / 64;      // groups per lane per pass
-    static_assert(FM % 2 == 0 && (32 * CG) % 64 == 0, "tile shape");
-    float* stage = reinterpret_cast<float*>(smem_raw) + wave * (32 * LDE);
+    // scattered stores.  Each wave therefore stages SR rows of its tile at a time through its own LDS region
+    // and re-reads them as row-contiguous groups of 8 columns, so every global access of the epilogue (bias,
+    // aux, residual, C) is a 16/32-byte vector.  Bank spread of the four lane groups (rows 4g+r): a 4-float
+    // row pad, or (64-wide wave tiles, no room for a pad) an XOR of the 16-column block with g.
+    constexpr bool SWZ = LOCAL && FN == 4;
+    constexpr int LDE = SWZ ? WTN : WTN + 4;    // floats per staged row
+    constexpr int CG = WTN / 8;                 // 8-column groups per row
+    constexpr int ITEMS = (SR * CG + 63) / 64;  // groups per lane per pass
+    constexpr int FPP = SR / 16;                // fragment rows per pass
+    constexpr int NP = FM / FPP;                // passes
+    constexpr bool CG_FIXED = (64 % CG) == 0;   // a lane keeps its column group across items -> bias loaded once
+    static_assert(FM % FPP == 0 && (SR == 16 || SR == 32), "tile shape");
+    float* stage = reinterpret_cast<float*>(smem_raw) + wave * (SR * LDE);
     const float alpha = p.alpha;
-    const bool is_split = p.splitk > 1;
-    float* part = is_split ? p.partial + (long)z * M * N : nullptr;
-    char* Cb = reinterpret_cast<char*>(p.C);
-    const long c_batch = is_split ? 0 : (long)z * p.strideC;
-    T* auxp = reinterpret_cast<T*>(p.aux);
-    const bool c_vec = is_split ? (N % 4 == 0) : ((p.ldc % 8 == 0) && ((reinterpret_cast<uintptr_t>(p.C) & 15) == 0) &&
-                                                   ((c_batch % 8) == 0));
-    const bool aux_vec = auxp && (p.ldaux % 8 == 0) && ((reinterpret_cast<uintptr_t>(p.aux) & 15) == 0);
-    const bool res_vec = p.residual && (p.ldr % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.residual) & 15) == 0);
-    const bool bias_vec = p.bias && ((reinterpret_cast<uintptr_t>(p.bias) & 15) == 0);
+
+    auto stage_pass = [&](int ps) {  // accumulator rows of pass ps -> this wave's private LDS region
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int ps = 0; ps < FM / 2; ++ps) {
-        __syncthreads();
-#pragma unroll
-        for (int il = 0; il < 2; ++il)
+        for (int il = 0; il < FPP; ++il)
 #pragma unroll
             for (int j = 0; j < FN; ++j)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) stage[(il * 16 + 4 * g + r) * LDE + j * 16 + c] = acc[2 * ps + il][j][r] * alpha;
-        __syncthreads();
+                for (int r = 0; r < 4; ++r)
+                    stage[(il * 16 + 4 * g + r) * LDE + ((j * 16 + c) ^ (SWZ ? (g << 4) : 0))] = acc[FPP * ps + il][j][r] * alpha;
+        __builtin_amdgcn_wave_barrier();
+    };
+    auto read_item = [&](int row_l, int cg, float (&v)[8]) {
+        const int scol = (cg * 8) ^ (SWZ ? (((row_l >> 2) & 3) << 4) : 0);
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(stage + row_l * LDE + scol);
+        const f32x4 hi = *reinterpret_cast<const f32x4*>(stage + row_l * LDE + scol + 4);
 #pragma unroll
-        for (int t = 0; t < ITEMS; ++t) {
-            const int id = lane + 64 * t;
-            const int row_l = id / CG, cg = id % CG;
-            const int m = m0 + wm * WTM + ps * 32 + row_l;
-            const int n = n0 + wn * WTN + cg * 8;
-            if (m >= M || n >= N) continue;
-            const int ne = min(8, N - n);
-            float v[8];
-            {
-                const f32x4 lo = *reinterpret_cast<const f32x4*>(stage + row_l * LDE + cg * 8);
-                const f32x4 hi = *reinterpret_cast<const f32x4*>(stage + row_l * LDE + cg * 8 + 4);
+        for (int e = 0; e < 4; ++e) {
+            v[e] = lo[e];
+            v[4 + e] = hi[e];
+        }
+    };
+    // item t of pass ps: 8 columns starting at n of row m (false: nothing to do)
+    auto item_geom = [&](int ps, int t, int& row_l, int& cg, int& m, int& n) -> bool {
+        const int id = lane + 64 * t;
+        row_l = id / CG;
+        cg = id % CG;
+        m = m0 + wm * WTM + ps * SR + row_l;
+        n = n0 + wn * WTN + cg * 8;
+        return ((SR * CG) % 64 == 0 || id < SR * CG) && m < M && n < N;
+    };
+
+    if (p.splitk > 1) {  // fp32 partial of this split-K slice: no inputs, no conversions
+        float* part = p.partial + (long)z * M * N;
+        const bool pvec = (N % 4) == 0;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    v[e] = lo[e];
-                    v[4 + e] = hi[e];
-                }
-            }
-            if (is_split) {
+        for (int ps = 0; ps < NP; ++ps) {
+            stage_pass(ps);
+#pragma unroll
+            for (int t = 0; t < ITEMS; ++t) {
+                int row_l, cg, m, n;
+                if (!item_geom(ps, t, row_l, cg, m, n)) continue;
+                float v[8];
+                read_item(row_l, cg, v);
+                const int ne = min(8, N - n);
                 float* dst = part + (long)m * N + n;
-                if (ne == 8 && c_vec) {
+                if (ne == 8 && pvec) {
                     *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
                     *reinterpret_cast<f32x4*>(dst + 4) = f32x4{v[4], v[5], v[6], v[7]};
                 } else {
                     for (int e = 0; e < ne; ++e) dst[e] = v[e];
                 }
-                continue;
             }
-            long drow = m;
-            if (p.rowmap) {
-                const int tk = p.rowmap[m % p.rowmap_period];
-                if (tk < 0) continue;
-                drow = (long)(m / p.rowmap_period) * p.rowmap_tokens + tk;
-            }
-            const float rs = p.rowscale ? p.rowscale[drow / p.rows_per_sample] : 1.f;
-            if (p.bias) {
-                if (ne == 8 && bias_vec) {
-                    const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + n);
-                    const f32x4 b1 = *reinterpret_cast<const f32x4*>(p.bias + n + 4);
+        }
+        return;
+    }
+
+    char* Cb = reinterpret_cast<char*>(p.C);
+    const long c_batch = (long)z * p.strideC;
+    T* auxp = reinterpret_cast<T*>(p.aux);
+    const bool c_vec = (p.ldc % 8 == 0) && ((reinterpret_cast<uintptr_t>(p.C) & 15) == 0) && ((c_batch % 8) == 0);
+    const bool aux_vec = auxp && (p.ldaux % 8 == 0) && ((reinterpret_cast<uintptr_t>(p.aux) & 15) == 0);
+    const bool res_vec = p.residual && (p.ldr % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.residual) & 15) == 0);
+    const bool bias_vec = p.bias && ((reinterpret_cast<uintptr_t>(p.bias) & 15) == 0);
+    const int mode = p.epilogue;
+
+    auto load_bias8 = [&](int n, float (&b)[8]) {
+        const int ne = min(8, N - n);
+        if (ne == 8 && bias_vec) {
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + n);
+            const f32x4 b1 = *reinterpret_cast<const f32x4*>(p.bias + n + 4);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        v[e] += b0[e];
-                        v[4 + e] += b1[e];
-                    }
-                } else {
-                    for (int e = 0; e < ne; ++e) v[e] += p.bias[n + e];
-                }
+            for (int e = 0; e < 4; ++e) {
+                b[e] = b0[e];
+                b[4 + e] = b1[e];
             }
-            if (p.epilogue == ESVIT_EPI_GELU) {
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) b[e] = e < ne ? p.bias[n + e] : 0.f;
+        }
+    };
+
+    // once per tile: bias of this lane's column group(s) -- item t of every pass covers the same 8 columns
+    constexpr int NBH = CG_FIXED ? 1 : ITEMS;
+    float bias_h[NBH][8];
+    static_for<NBH>([&](auto tc) {
+        constexpr int t = decltype(tc)::value;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bias_h[t][e] = 0.f;
+        const int n = n0 + wn * WTN + ((lane + 64 * t) % CG) * 8;
+        if (p.bias && n < N) load_bias8(n, bias_h[t]);
+    });
+
+    // general path (ragged edge tiles, row maps, unaligned operands, fp32 parity mode): inputs are read where they
+    // are used -- the lean epilogue below covers the tiles that matter for speed
+    auto dest_row = [&](int m, int tk) -> long { return p.rowmap ? (long)(m / p.rowmap_period) * p.rowmap_tokens + tk : (long)m; };
+    static_for<NP>([&](auto psc) {
+        constexpr int ps = decltype(psc)::value;
+        stage_pass(ps);
+        static_for<ITEMS>([&](auto tc) {
+            constexpr int t = decltype(tc)::value;
+            int row_l, cg, m, n;
+            if (!item_geom(ps, t, row_l, cg, m, n)) return;
+            int tk = 0;
+            if (p.rowmap) {
+                tk = p.rowmap[m % p.rowmap_period];
+                if (tk < 0) return;
+            }
+            const int ne = min(8, N - n);
+            const long drow = dest_row(m, tk);
+            float v[8];
+            read_item(row_l, cg, v);
+            if (p.bias) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += bias_h[CG_FIXED ? 0 : t][e];
+            }
+            if (mode == ESVIT_EPI_GELU) {
                 if (auxp) {
                     T* ap = auxp + (long)m * p.ldaux + n;
                     if (ne == 8 && aux_vec) {
@@ -222,7 +294,7 @@ __device__ __forceinline__ void gemm_epilogue(const esvit_gemm_desc& p, f32x4 (&
                 }
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
-            } else if (p.epilogue == ESVIT_EPI_GELU_BWD) {
+            } else if (mode == ESVIT_EPI_GELU_BWD) {
                 const T* ap = auxp + (long)m * p.ldaux + n;
                 float a[8];
                 if (ne == 8 && aux_vec) {
@@ -246,6 +318,7 @@ __device__ __forceinline__ void gemm_epilogue(const esvit_gemm_desc& p, f32x4 (&
                 for (int e = 0; e < 8; ++e) v[e] *= gelu_grad_f(a[e]);
             }
             if (p.rowscale) {
+                const float rs = p.rowscale[drow / p.rows_per_sample];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] *= rs;
             }
@@ -287,10 +360,194 @@ __device__ __forceinline__ void gemm_epilogue(const esvit_gemm_desc& p, f32x4 (&
                     for (int e = 0; e < ne; ++e) cp[e] = from_f32<T>(v[e]);
                 }
             }
-        }
-    }
+        });
+    });
 }
 
+// ---- lean epilogue for the common case ----
+// The GEMM kernels of this path are VALU-bound, not MFMA-bound (profiles/r01_gemm_sq_counters.txt: ~9 VALU
+// instructions per MFMA before this path existed, most of them epilogue address arithmetic, predicates and wait
+// states).  For a FULL interior tile with vector-aligned operands the epilogue below is straight-line code per kind:
+// lane offsets are computed once per tile, staging uses immediate LDS offsets, there are no per-element predicates,
+// and -- because there are no branches -- the compiler's own vmcnt bookkeeping is exact, so the per-element inputs
+// requested one pass ahead never wait for the stores issued after them.
+enum { EK_PLAIN = 0, EK_GELU = 1, EK_RES = 2, EK_GELU_BWD = 3 };
+
+template <int BM, int BN, bool SWZ, int KIND, bool OUTF32>
+__device__ __forceinline__ void epilogue_fast(const esvit_gemm_desc& p, f32x4 (&acc)[BM / 32][BN / 32], float* stage, int m0, int n0, int z) {
+    constexpr int WTM = BM / 2, WTN = BN / 2;
+    constexpr int FM = WTM / 16, FN = WTN / 16;
+    constexpr int SR = 16;
+    constexpr int LDE = SWZ ? WTN : WTN + 4;
+    constexpr int CG = WTN / 8;
+    constexpr int ITEMS = (SR * CG + 63) / 64;
+    constexpr int NP = FM;
+    constexpr bool RAGGED = (SR * CG) % 64 != 0;  // the last item of a pass covers only some lanes (96-wide tiles)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 15, g = lane >> 4;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int row_w = m0 + wm * WTM, col_w = n0 + wn * WTN;  // first row / column of the wave tile
+
+    // staging write bases (floats): row 4g, column block j (XOR-swizzled with g when there is no room for a row pad)
+    int wbase[FN];
+#pragma unroll
+    for (int j = 0; j < FN; ++j) wbase[j] = 4 * g * LDE + (SWZ ? ((j ^ g) & (FN - 1)) * 16 + c : j * 16 + c);
+
+    // per item t (fixed over passes): staged row / column group, read offset, destination offsets
+    int rd_off[ITEMS];
+    long c_off[ITEMS], x_off[ITEMS];  // element offsets into C and into aux / residual for pass 0
+    bool live[ITEMS];
+    float bias_h[ITEMS][8];
+    static_for<ITEMS>([&](auto tc) {
+        constexpr int t = decltype(tc)::value;
+        const int id = lane + 64 * t;
+        const int row_l = id / CG, cg = id % CG;
+        live[t] = !RAGGED || id < SR * CG;
+        rd_off[t] = row_l * LDE + ((cg * 8) ^ (SWZ ? (((row_l >> 2) & 3) << 4) : 0));
+        const long row = row_w + row_l;
+        const int n = col_w + cg * 8;
+        c_off[t] = (long)z * p.strideC + row * p.ldc + n;
+        x_off[t] = KIND == EK_RES ? row * p.ldr + n : row * p.ldaux + n;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bias_h[t][e] = 0.f;
+        if (p.bias && live[t]) {
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + n);
+            const f32x4 b1 = *reinterpret_cast<const f32x4*>(p.bias + n + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                bias_h[t][e] = b0[e];
+                bias_h[t][4 + e] = b1[e];
+            }
+        }
+    });
+    if (p.alpha != 1.f) {
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j) acc[i][j] *= p.alpha;
+    }
+    const long c_step = (long)SR * p.ldc;
+    const long x_step = (long)SR * (KIND == EK_RES ? p.ldr : p.ldaux);
+    bf16* auxp = reinterpret_cast<bf16*>(p.aux);
+
+    // inputs requested one pass ahead: residual (8 fp32) + DropPath scale, or the GELU pre-activation (8 bf16)
+    f32x4 in0[2][ITEMS], in1[2][ITEMS];
+    float rs[2][ITEMS];
+    auto load_in = [&](auto psc) {
+        constexpr int ps = decltype(psc)::value;
+        static_for<ITEMS>([&](auto tc) {
+            constexpr int t = decltype(tc)::value;
+            rs[ps & 1][t] = 1.f;
+            if (!live[t]) return;
+            if constexpr (KIND == EK_RES) {
+                const float* rp = p.residual + x_off[t] + ps * x_step;
+                in0[ps & 1][t] = *reinterpret_cast<const f32x4*>(rp);
+                in1[ps & 1][t] = *reinterpret_cast<const f32x4*>(rp + 4);
+                if (p.rowscale) rs[ps & 1][t] = p.rowscale[(row_w + ps * SR + (lane + 64 * t) / CG) / p.rows_per_sample];
+            } else if constexpr (KIND == EK_GELU_BWD) {
+                in0[ps & 1][t] = *reinterpret_cast<const f32x4*>(auxp + x_off[t] + ps * x_step);
+            }
+        });
+    };
+    if constexpr (KIND == EK_RES || KIND == EK_GELU_BWD) load_in(std::integral_constant<int, 0>{});
+
+    static_for<NP>([&](auto psc) {
+        constexpr int ps = decltype(psc)::value;
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) stage[wbase[j] + r * LDE] = acc[ps][j][r];
+        __builtin_amdgcn_wave_barrier();
+        if constexpr ((KIND == EK_RES || KIND == EK_GELU_BWD) && ps + 1 < NP) load_in(std::integral_constant<int, ps + 1>{});
+        static_for<ITEMS>([&](auto tc) {
+            constexpr int t = decltype(tc)::value;
+            if (!live[t]) return;
+            float v[8];
+            {
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(stage + rd_off[t]);
+                const f32x4 hi = *reinterpret_cast<const f32x4*>(stage + rd_off[t] + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = lo[e] + bias_h[t][e];
+                    v[4 + e] = hi[e] + bias_h[t][4 + e];
+                }
+            }
+            if constexpr (KIND == EK_GELU) {
+                if (auxp) {
+                    bf16x8 o;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
+                    *reinterpret_cast<bf16x8*>(auxp + x_off[t] + ps * x_step) = o;
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
+            } else if constexpr (KIND == EK_GELU_BWD) {
+                const bf16x8 x = __builtin_bit_cast(bf16x8, in0[ps & 1][t]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] *= gelu_grad_f((float)x[e]);
+            } else if constexpr (KIND == EK_RES) {
+                const float s = rs[ps & 1][t];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = v[e] * s + in0[ps & 1][t][e];
+                    v[4 + e] = v[4 + e] * s + in1[ps & 1][t][e];
+                }
+            }
+            if constexpr (OUTF32) {
+                float* cp = reinterpret_cast<float*>(p.C) + c_off[t] + ps * c_step;
+                *reinterpret_cast<f32x4*>(cp) = f32x4{v[0], v[1], v[2], v[3]};
+                *reinterpret_cast<f32x4*>(cp + 4) = f32x4{v[4], v[5], v[6], v[7]};
+            } else {
+                bf16x8 ov;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) ov[e] = (bf16)v[e];
+                *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(p.C) + c_off[t] + ps * c_step) = ov;
+            }
+        });
+    });
+}
+
+// bf16 kernels: pick the lean epilogue when the tile and the operands allow it, else the general one
+template <int BM, int BN, bool LOCAL>
+__device__ __forceinline__ void gemm_epilogue_bf16(const esvit_gemm_desc& p, f32x4 (&acc)[BM / 32][BN / 32], char* smem_raw, int m0, int n0,
+                                                   int z) {
+    constexpr int WTN = BN / 2, FN = WTN / 16;
+    constexpr bool SWZ = LOCAL && FN == 4;
+    constexpr int LDE = SWZ ? WTN : WTN + 4;
+    auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    bool fast = p.splitk <= 1 && !p.rowmap && m0 + BM <= p.M && n0 + BN <= p.N && (p.ldc % 8 == 0) && al16(p.C) &&
+                ((p.strideC * (long)z) % 8 == 0) && (!p.bias || al16(p.bias));
+    int kind = EK_PLAIN;
+    if (p.epilogue == ESVIT_EPI_GELU) {
+        kind = EK_GELU;
+        fast = fast && !p.residual && !p.rowscale && !p.out_f32 && (!p.aux || ((p.ldaux % 8 == 0) && al16(p.aux)));
+    } else if (p.epilogue == ESVIT_EPI_GELU_BWD) {
+        kind = EK_GELU_BWD;
+        fast = fast && !p.residual && !p.rowscale && (p.ldaux % 8 == 0) && al16(p.aux);
+    } else if (p.residual) {
+        kind = EK_RES;
+        fast = fast && (p.ldr % 4 == 0) && al16(p.residual);
+    } else {
+        fast = fast && !p.rowscale;
+    }
+    if (!fast) {
+        gemm_epilogue<bf16, BM, BN, 16, LOCAL>(p, acc, smem_raw, m0, n0, z);
+        return;
+    }
+    float* stage = reinterpret_cast<float*>(smem_raw) + (threadIdx.x >> 6) * (16 * LDE);
+    if (kind == EK_GELU) epilogue_fast<BM, BN, SWZ, EK_GELU, false>(p, acc, stage, m0, n0, z);
+    else if (kind == EK_GELU_BWD) {
+        if (p.out_f32) epilogue_fast<BM, BN, SWZ, EK_GELU_BWD, true>(p, acc, stage, m0, n0, z);
+        else epilogue_fast<BM, BN, SWZ, EK_GELU_BWD, false>(p, acc, stage, m0, n0, z);
+    } else if (kind == EK_RES) {
+        if (p.out_f32) epilogue_fast<BM, BN, SWZ, EK_RES, true>(p, acc, stage, m0, n0, z);
+        else epilogue_fast<BM, BN, SWZ, EK_RES, false>(p, acc, stage, m0, n0, z);
+    } else {
+        if (p.out_f32) epilogue_fast<BM, BN, SWZ, EK_PLAIN, true>(p, acc, stage, m0, n0, z);
+        else epilogue_fast<BM, BN, SWZ, EK_PLAIN, false>(p, acc, stage, m0, n0, z);
+    }
+}
 
 // XCD-aware work order over a 1-D grid of ntiles * nz blocks.  The dispatcher places block b on XCD b % 8; give
 // every XCD a contiguous range of the virtual ids v = z * ntiles + tile (bijective remap), so (a) the tiles of one
@@ -315,7 +572,7 @@ __device__ __forceinline__ void xcd_tile_map(int ntiles, int& tile, int& z) {
 }
 
 template <typename T, bool AKS, bool BKS, int BM, int BN, bool USE_TR>
-__global__ __launch_bounds__(NTHREADS) void gemm_kernel(const esvit_gemm_desc p) {
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const esvit_gemm_desc p) {
     using TA = Tile<T, AKS, BM, USE_TR>;
     using TB = Tile<T, BKS, BN, USE_TR>;
     constexpr int WTM = BM / 2, WTN = BN / 2;  // wave tile
@@ -404,7 +661,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const esvit_gemm_desc p)
     }
 
     if (do_colsum) store_colsum<FM>(p, accb, m0, wm * WTM, z, c, g);
-    gemm_epilogue<T, BM, BN>(p, acc, smem_raw, m0, n0, z);
+    if constexpr (sizeof(T) == 2) gemm_epilogue_bf16<BM, BN, false>(p, acc, smem_raw, m0, n0, z);
+    else gemm_epilogue<T, BM, BN>(p, acc, smem_raw, m0, n0, z);
 }
 
 // =================================================================================================
@@ -422,7 +680,7 @@ struct DmaTile {
     static constexpr int CHUNKS = ELEMS / 8;
     static constexpr int INSTR_PER_WAVE = CHUNKS / 256;
     static constexpr int CPR = KS ? ROWS / 8 : BKD / 8;  // 16-byte chunks per LDS row
-    static_assert(CHUNKS % 256 == 0, "tile must be a whole number of wave instructions");
+    static_assert(CHUNKS % 64 == 0, "tile must be a whole number of wave instructions");
 
     __device__ __forceinline__ static int sw_ks(int k) {
         if constexpr (ROWS == 128) return ((k & 3) << 1) | (((k >> 3) & 1) << 3);
@@ -434,30 +692,65 @@ struct DmaTile {
         else return (0x78 >> (2 * ((r >> 2) & 3))) & 3;      // 64-byte rows: 4 chunks, f(r>>2) = {0,2,3,1}
     }
 
-    // base: operand pointer already advanced to the tile's first row (k-contiguous) / column (k-strided)
+    // one DMA instruction: 64 lanes x 16 bytes -> LDS bytes [slot * 1024, slot * 1024 + 1024) of the tile
+    __device__ __forceinline__ static void issue_slot(__amdgpu_buffer_rsrc_t rsrc, char* lds_tile, long ld, int rows_left, int k0, int K,
+                                                      int slot, int lane) {
+        typedef __attribute__((address_space(3))) void lds_void;
+        const int p = slot * 64 + lane;
+        long off;
+        bool ok;
+        if constexpr (KS) {
+            const int kr = p / CPR, cp = p % CPR;
+            const int col = (cp ^ sw_ks(kr)) * 8;
+            ok = (k0 + kr < K) && (col < rows_left);
+            off = (long)(k0 + kr) * ld + col;
+        } else {
+            const int r = p / CPR, cp = p % CPR;
+            const int k = k0 + ((cp ^ sw_kc(r)) * 8);
+            ok = (r < rows_left) && (k < K);
+            off = (long)r * ld + k;
+        }
+        const int voff = ok ? (int)(off * 2) : (int)0xfffffff8u;  // beyond num_records -> hardware returns 0
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void*)(lds_tile + slot * 1024), 16, voff, 0, 0, 0);
+    }
+
+    // base: operand pointer already advanced to the tile's first row (k-contiguous) / column (k-strided).
+    // The tile's instructions are spread over the workgroup's 4 waves.
     __device__ __forceinline__ static void issue(__amdgpu_buffer_rsrc_t rsrc, char* lds_tile, long ld, int rows_left, int k0, int K,
                                                  int wave, int lane) {
-        typedef __attribute__((address_space(3))) void lds_void;
+        static_assert(CHUNKS % 256 == 0, "tile must be a whole number of instructions per wave");
 #pragma unroll
-        for (int i = 0; i < INSTR_PER_WAVE; ++i) {
-            const int slot = wave * INSTR_PER_WAVE + i;
-            const int p = slot * 64 + lane;
-            long off;
-            bool ok;
-            if constexpr (KS) {
-                const int kr = p / CPR, cp = p % CPR;
-                const int col = (cp ^ sw_ks(kr)) * 8;
-                ok = (k0 + kr < K) && (col < rows_left);
-                off = (long)(k0 + kr) * ld + col;
-            } else {
-                const int r = p / CPR, cp = p % CPR;
-                const int k = k0 + ((cp ^ sw_kc(r)) * 8);
-                ok = (r < rows_left) && (k < K);
-                off = (long)r * ld + k;
-            }
-            const int voff = ok ? (int)(off * 2) : (int)0xfffffff8u;  // beyond num_records -> hardware returns 0
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void*)(lds_tile + slot * 1024), 16, voff, 0, 0, 0);
+        for (int i = 0; i < INSTR_PER_WAVE; ++i) issue_slot(rsrc, lds_tile, ld, rows_left, k0, K, wave * INSTR_PER_WAVE + i, lane);
+    }
+
+    // the whole tile from ONE wave (producer wave of the warp-specialised kernel)
+    static constexpr int INSTR_PER_TILE = CHUNKS / 64;
+    // Fast path of issue_all for a FULL k-tile: the per-lane byte offsets of the tile's instructions relative to
+    // (tile base, k0 = 0) depend only on ld, so a producer computes them once (lane_offsets) and every k-tile is
+    // INSTR_PER_TILE bare DMA instructions with k0 folded into the scalar offset.  Rows past the end of a
+    // k-contiguous operand fall outside the descriptor's num_records (checked on the vector offset) and read as 0;
+    // a k-strided operand's partial row tile and any partial k-tile need per-lane predicates -> issue_all().
+    __device__ __forceinline__ static void lane_offsets(long ld, int lane, int (&voff)[INSTR_PER_TILE]) {
+#pragma unroll
+        for (int i = 0; i < INSTR_PER_TILE; ++i) {
+            const int p = i * 64 + lane;
+            const int r = p / CPR, cp = p % CPR;
+            const long off = KS ? (long)r * ld + (cp ^ sw_ks(r)) * 8 : (long)r * ld + (cp ^ sw_kc(r)) * 8;
+            voff[i] = (int)(off * 2);
         }
+    }
+    __device__ __forceinline__ static void issue_all_fast(__amdgpu_buffer_rsrc_t rsrc, char* lds_tile, long ld, int k0,
+                                                          const int (&voff)[INSTR_PER_TILE]) {
+        typedef __attribute__((address_space(3))) void lds_void;
+        const int soff = (int)(KS ? (long)k0 * ld * 2 : (long)k0 * 2);
+#pragma unroll
+        for (int i = 0; i < INSTR_PER_TILE; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void*)(lds_tile + i * 1024), 16, voff[i], soff, 0, 0);
+    }
+    __device__ __forceinline__ static void issue_all(__amdgpu_buffer_rsrc_t rsrc, char* lds_tile, long ld, int rows_left, int k0, int K,
+                                                     int lane) {
+#pragma unroll
+        for (int i = 0; i < INSTR_PER_TILE; ++i) issue_slot(rsrc, lds_tile, ld, rows_left, k0, K, i, lane);
     }
 
     // fragment for the 16 tile rows at r0, k-step kk (32 deep)
@@ -498,7 +791,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 // NBUF-deep ring of LDS tiles: NBUF-1 tiles are requested ahead; per k-tile ONE counted wait (only for the tile
 // about to be consumed -- later tiles stay in flight across the barrier) and ONE barrier.
 template <bool AKS, bool BKS, int BM, int BN, int BKD, int NBUF>
-__global__ __launch_bounds__(NTHREADS) void gemm_dma_kernel(const esvit_gemm_desc p) {
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_dma_kernel(const esvit_gemm_desc p) {
     using TA = DmaTile<AKS, BM, BKD>;
     using TB = DmaTile<BKS, BN, BKD>;
     constexpr int WTM = BM / 2, WTN = BN / 2;
@@ -600,7 +893,220 @@ __global__ __launch_bounds__(NTHREADS) void gemm_dma_kernel(const esvit_gemm_des
     }
     __syncthreads();  // all waves finished reading the operand tiles before the epilogue reuses the LDS
     if (do_colsum) store_colsum<FM>(p, accb, m0, wm * WTM, z, c, g);
-    gemm_epilogue<bf16, BM, BN>(p, acc, smem_raw, m0, n0, z);
+    gemm_epilogue_bf16<BM, BN, false>(p, acc, smem_raw, m0, n0, z);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Persistent, warp-specialised variant (the default bf16 main loop).
+//
+// Why: with one output tile per workgroup the DMA kernel above is latency bound on this path's short-K shapes
+// (K = 96..384 is 2..6 k-tiles): every k-tile waits a full memory round trip with one tile in flight, and the heavy
+// epilogue (GELU, side tensors, residual) runs with nothing in flight at all.  Here a workgroup is 6 waves:
+//   waves 0-3  consumers: MFMA main loop + fused epilogue, one output tile after another (persistent);
+//   wave  4    producer of the A tiles, wave 5 producer of the B tiles: nothing but LDS-DMA issue + counted waits.
+// The producers run NST-1 k-tiles ahead of the consumers ACROSS output tiles, so the next tile's operands stream in
+// while the consumers are still in the epilogue of the current one; a producer's vmcnt only ever counts its own DMA
+// loads, so the counted waits stay exact (the consumers' epilogue loads / stores live on other waves' counters).
+// One s_barrier per k-tile joins all 6 waves: "k-tile t has landed" and "k-tile t-1 has been consumed".
+// Two workgroups share a CU (2 x 80 KiB of LDS), so one's epilogue VALU work overlaps the other's MFMA work.
+constexpr int WS_THREADS = 384;
+
+// this workgroup's sequence of work items (output tile x split-K slice / batch item), XCD-aware: the dispatcher places
+// workgroup b on XCD b % 8; every XCD owns a contiguous range of item ids and its workgroups stride through it, so at
+// any time the tiles in flight on one XCD are neighbours (shared A row panels / B column panels hit the same L2).
+struct WorkIter {
+    int hi, stride, v;
+    __device__ __forceinline__ void init(int total) {
+        const int G = gridDim.x, b = blockIdx.x;
+        if (G >= 8) {
+            const int xcd = b & 7, j = b >> 3;
+            const int q = total / 8, r = total % 8;
+            const int lo = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+            hi = lo + (xcd < r ? q + 1 : q);
+            stride = G / 8 + ((xcd < (G & 7)) ? 1 : 0);
+            v = lo + j;
+        } else {
+            hi = total;
+            stride = G;
+            v = b;
+        }
+    }
+    __device__ __forceinline__ bool valid() const { return v < hi; }
+    __device__ __forceinline__ void next() { v += stride; }
+};
+
+struct WorkItem {
+    int m0, n0, z, kbeg, kend, nk;
+};
+
+template <int BM, int BN, int BKD>
+__device__ __forceinline__ WorkItem decode_item(const esvit_gemm_desc& p, int v, int ntiles, int tiles_n, int nz, int zmajor) {
+    WorkItem w;
+    int tile;
+    if (zmajor) {
+        w.z = v / ntiles;
+        tile = v - w.z * ntiles;
+    } else {
+        tile = v / nz;
+        w.z = v - tile * nz;
+    }
+    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+    w.m0 = tm * BM;
+    w.n0 = tn * BN;
+    w.kbeg = 0;
+    w.kend = p.K;
+    if (p.splitk > 1) {
+        const int nkt = (p.K + BKD - 1) / BKD;
+        const int per = (nkt + p.splitk - 1) / p.splitk;
+        w.kbeg = w.z * per * BKD;
+        w.kend = min(p.K, (w.z + 1) * per * BKD);
+    }
+    w.nk = w.kend > w.kbeg ? (w.kend - w.kbeg + BKD - 1) / BKD : 0;
+    return w;
+}
+
+// producer wave: streams the ROWS x BKD tiles of one operand (IS_A: rows = m, else rows = n) for every k-tile of every
+// work item of this workgroup into the ring, NST-1 ahead of the consumers.
+template <bool KS, int ROWS, int BM, int BN, int BKD, int NST, bool IS_A>
+__device__ __forceinline__ void ws_producer(const esvit_gemm_desc& p, char* ring, int ntiles, int tiles_n, int nz, int zmajor, int lane, int ablate) {
+    using TT = DmaTile<KS, ROWS, BKD>;
+    constexpr int TILE_BYTES = TT::ELEMS * 2;
+    constexpr int LP = TT::INSTR_PER_TILE;
+    static_assert((NST - 1) * LP < 64, "vmcnt is 6 bits");
+    const bf16* base0 = reinterpret_cast<const bf16*>(IS_A ? p.A : p.B);
+    const long ld = IS_A ? p.lda : p.ldb;
+    const int rows_total = IS_A ? p.M : p.N;
+    const long stride_z = IS_A ? p.strideA : p.strideB;
+
+    WorkIter it;
+    it.init(ntiles * nz);
+    WorkItem w{};
+    int kt = 0;          // next k-tile of the current item to request
+    bool have = false;   // w holds an item with k-tiles left
+    __amdgpu_buffer_rsrc_t rs = make_rsrc(base0, 0);
+    int rows_left = 0;
+    auto fetch_item = [&]() {
+        have = false;
+        while (it.valid()) {
+            w = decode_item<BM, BN, BKD>(p, it.v, ntiles, tiles_n, nz, zmajor);
+            it.next();
+            if (w.nk > 0) {
+                const int r0 = IS_A ? w.m0 : w.n0;
+                const bf16* mat = base0 + (p.splitk > 1 ? 0L : (long)w.z * stride_z);
+                const long rows_stored = KS ? (long)p.K : (long)rows_total;  // rows of the stored matrix
+                const bf16* tb = KS ? mat + r0 : mat + (long)r0 * ld;
+                const long left = ((KS ? rows_stored : rows_stored - r0) * ld - (KS ? r0 : 0)) * 2;
+                rs = make_rsrc(tb, left);
+                rows_left = rows_total - r0;
+                kt = 0;
+                have = true;
+                return;
+            }
+        }
+    };
+    int voff[TT::INSTR_PER_TILE];
+    TT::lane_offsets(ld, lane, voff);
+    int issued = 0, consumed = 0, slot = 0;
+    auto issue_next = [&]() {
+        if (!have) return;
+        const int k0 = w.kbeg + kt * BKD;
+        if (ablate & 2) {  // profiling ablation: no loads (the consumers multiply whatever the LDS holds)
+        } else if (k0 + BKD <= w.kend && (!KS || rows_left >= ROWS)) TT::issue_all_fast(rs, ring + slot * TILE_BYTES, ld, k0, voff);
+        else TT::issue_all(rs, ring + slot * TILE_BYTES, ld, rows_left, k0, w.kend, lane);
+        slot = (slot + 1 == NST) ? 0 : slot + 1;
+        ++issued;
+        if (++kt == w.nk) fetch_item();
+    };
+    fetch_item();
+#pragma unroll
+    for (int t = 0; t < NST - 1; ++t) issue_next();
+    while (consumed < issued) {
+        const int ahead = issued - consumed - 1;  // k-tiles requested after the one the consumers need next
+        if (NST >= 4 && ahead >= 2) wait_vmcnt<(NST >= 4 ? 2 : 0) * LP>();
+        else if (NST >= 3 && ahead >= 1) wait_vmcnt<(NST >= 3 ? 1 : 0) * LP>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();  // k-tile `consumed` is in LDS; the consumers are done with k-tile consumed-1
+        asm volatile("" ::: "memory");
+        issue_next();                  // refills the slot of k-tile consumed-1
+        ++consumed;
+    }
+}
+
+template <bool AKS, bool BKS, int BM, int BN, int BKD, int NST>
+__global__ __launch_bounds__(WS_THREADS, 3) void gemm_ws_kernel(const esvit_gemm_desc p, int zmajor, int ablate) {
+    using TA = DmaTile<AKS, BM, BKD>;
+    using TB = DmaTile<BKS, BN, BKD>;
+    constexpr int WTM = BM / 2, WTN = BN / 2;
+    constexpr int FM = WTM / 16, FN = WTN / 16;
+    static_assert(NST >= 2 && NST <= 4, "ring depth");
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    constexpr int A_BYTES = TA::ELEMS * 2, B_BYTES = TB::ELEMS * 2;
+    char* sA = smem_raw;                  // NST slots
+    char* sB = smem_raw + NST * A_BYTES;  // NST slots
+    char* sE = sB + NST * B_BYTES;        // epilogue staging, one private region per consumer wave
+
+    const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
+    const int ntiles = tiles_m * tiles_n;
+    const int nz = p.splitk > 1 ? p.splitk : p.batch;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+
+    if (wave == 4) {
+        ws_producer<AKS, BM, BM, BN, BKD, NST, true>(p, sA, ntiles, tiles_n, nz, zmajor, lane, ablate);
+        return;
+    }
+    if (wave == 5) {
+        ws_producer<BKS, BN, BM, BN, BKD, NST, false>(p, sB, ntiles, tiles_n, nz, zmajor, lane, ablate);
+        return;
+    }
+
+    const int c = lane & 15, g = lane >> 4;
+    const int wm = wave >> 1, wn = wave & 1;
+    const Frag<bf16> ones = ones_frag(bf16());
+    WorkIter it;
+    it.init(ntiles * nz);
+    int slot = 0;
+    for (; it.valid(); it.next()) {
+        const WorkItem w = decode_item<BM, BN, BKD>(p, it.v, ntiles, tiles_n, nz, zmajor);
+        f32x4 acc[FM][FN];
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const bool do_colsum = p.colsum && w.n0 == 0 && wn == 0;
+        f32x4 accb[FM];
+#pragma unroll
+        for (int i = 0; i < FM; ++i) accb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        for (int kt = 0; kt < w.nk; ++kt) {
+            __builtin_amdgcn_s_barrier();  // this k-tile has landed (the producers waited for it before arriving)
+            asm volatile("" ::: "memory");
+            const bf16* a_lds = reinterpret_cast<const bf16*>(sA + slot * A_BYTES);
+            const bf16* b_lds = reinterpret_cast<const bf16*>(sB + slot * B_BYTES);
+            if (!(ablate & 1)) {  // profiling ablation bit 0: no LDS reads / MFMAs
+#pragma unroll
+                for (int kk = 0; kk < BKD / 32; ++kk) {
+                    Frag<bf16> af[FM], bfr[FN];
+#pragma unroll
+                    for (int i = 0; i < FM; ++i) af[i] = TA::frag(a_lds, wm * WTM + i * 16, kk, c, g);
+#pragma unroll
+                    for (int j = 0; j < FN; ++j) bfr[j] = TB::frag(b_lds, wn * WTN + j * 16, kk, c, g);
+#pragma unroll
+                    for (int i = 0; i < FM; ++i)
+#pragma unroll
+                        for (int j = 0; j < FN; ++j) mma(af[i], bfr[j], acc[i][j]);
+                    if (do_colsum) {
+#pragma unroll
+                        for (int i = 0; i < FM; ++i) mma(af[i], ones, accb[i]);
+                    }
+                }
+            }
+            slot = (slot + 1 == NST) ? 0 : slot + 1;
+        }
+        if (ablate & 4) continue;  // profiling ablation bit 2: no epilogue
+        if (do_colsum) store_colsum<FM>(p, accb, w.m0, wm * WTM, w.z, c, g);
+        gemm_epilogue_bf16<BM, BN, true>(p, acc, sE, w.m0, w.n0, w.z);
+    }
 }
 
 // sum split-K partials: out[i] (+)= sum_z part[z*n + i]   (TO = float or the activation dtype)
@@ -696,6 +1202,54 @@ int launch_gemm_dma(const esvit_gemm_desc& d, hipStream_t stream) {
     return ESVIT_OK;
 }
 
+// work-item order of the persistent kernel: 0 = tile-major (all split-K slices of a tile adjacent), 1 = slice-major
+static int g_ws_zmajor = 0;
+static int g_ws_ablate = 0;  // profiling only: bit 0 no MFMA loop, bit 1 no DMA loads, bit 2 no epilogue (results are garbage)
+static int g_num_cus = 0;
+
+template <bool AKS, bool BKS, int BM, int BN, int BKD, int NST>
+int launch_gemm_ws(const esvit_gemm_desc& d, hipStream_t stream) {
+    using TA = DmaTile<AKS, BM, BKD>;
+    using TB = DmaTile<BKS, BN, BKD>;
+    constexpr int WTN = BN / 2;
+    constexpr int LDE = (WTN == 64) ? 64 : WTN + 4;
+    const size_t lds = (size_t)NST * (TA::ELEMS + TB::ELEMS) * 2 + 4 * 16 * (size_t)LDE * sizeof(float);
+    auto kern = gemm_ws_kernel<AKS, BKS, BM, BN, BKD, NST>;
+    static int wg_per_cu = 0;  // per instantiation
+    if (!wg_per_cu) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (!g_num_cus) {
+            int dev = 0;
+            hipDeviceProp_t prop;
+            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) g_num_cus = prop.multiProcessorCount;
+            if (g_num_cus <= 0) g_num_cus = 256;
+        }
+        int occ = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(kern), WS_THREADS, lds) != hipSuccess || occ < 1) occ = 1;
+        wg_per_cu = occ > 2 ? 2 : occ;
+    }
+    const int tiles = ceil_div(d.M, BM) * ceil_div(d.N, BN);
+    const int nz = d.splitk > 1 ? d.splitk : d.batch;
+    const long total = (long)tiles * nz;
+    const int grid = (int)(total < (long)wg_per_cu * g_num_cus ? total : (long)wg_per_cu * g_num_cus);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(WS_THREADS), lds, stream, d, g_ws_zmajor, g_ws_ablate);
+    ESVIT_CHECK_LAUNCH("esvit_gemm(ws)");
+    if (d.splitk > 1) {
+        const long n = (long)d.M * d.N;
+        const int blocks = ceil_div(ceil_div(n, 4), 256);
+        if (d.out_f32)
+            hipLaunchKernelGGL(splitk_reduce_kernel<float>, dim3(blocks), dim3(256), 0, stream, d.partial, d.splitk, n,
+                               reinterpret_cast<float*>(d.C), d.accumulate);
+        else
+            hipLaunchKernelGGL(splitk_reduce_kernel<bf16>, dim3(blocks), dim3(256), 0, stream, d.partial, d.splitk, n,
+                               reinterpret_cast<bf16*>(d.C), d.accumulate);
+        ESVIT_CHECK_LAUNCH("esvit_gemm(ws splitk_reduce)");
+        if (d.colsum) return esvit_partial_reduce(d.colsum_partial, d.splitk, d.M, d.M, d.colsum, 0, stream);
+    }
+    return ESVIT_OK;
+}
+
+
 // pipeline shape (debug switch): 1 = BK64 x 2 buffers (default: 64 KiB -> 2 workgroups/CU); 2 = BK32 x 2 (32 KiB -> 4/CU);
 // 3 = BK64 x 3-deep ring; 4 = BK32 x 4-deep ring; 5 = BK32 x 3-deep ring (48 KiB -> 3/CU)
 static int g_dma_pipe = 1;
@@ -707,6 +1261,8 @@ int dispatch_pipe(const esvit_gemm_desc& d, hipStream_t stream) {
         if (g_dma_pipe == 4) return launch_gemm_dma<AKS, BKS, BM, BN, 32, 4>(d, stream);
         if (g_dma_pipe == 5) return launch_gemm_dma<AKS, BKS, BM, BN, 32, 3>(d, stream);
     }
+    if (g_dma_pipe == 6) return launch_gemm_ws<AKS, BKS, BM, BN, 64, 2>(d, stream);
+    if (g_dma_pipe == 7) return launch_gemm_ws<AKS, BKS, BM, BN, 32, 4>(d, stream);
     if (g_dma_pipe >= 3) return launch_gemm_dma<AKS, BKS, BM, BN, 64, 3>(d, stream);
     return launch_gemm_dma<AKS, BKS, BM, BN, 64, 2>(d, stream);
 }
@@ -744,7 +1300,16 @@ static int g_use_dma = 1;
 extern "C" void esvit_debug_set_tr_read(int on) { g_use_tr = on; }
 extern "C" void esvit_debug_set_gemm_dma(int on) { g_use_dma = on; }
 extern "C" void esvit_debug_set_gemm_pipe(int mode) { g_dma_pipe = mode; }
-extern "C" void esvit_debug_set_gemm_xcdmap(int mode) { g_xcd_map = mode; }
+extern "C" void esvit_debug_set_gemm_xcdmap(int mode) { g_xcd_map = mode; g_ws_zmajor = mode; }
+extern "C" void esvit_debug_set_gemm_ws_ablate(int bits) { g_ws_ablate = bits; }
+// resident workgroups per CU of the persistent kernel's 128x128 tile (LDS-limited: 2 x 80 KiB), for tests / tuning
+extern "C" int esvit_debug_gemm_ws_occupancy(int lds_bytes) {
+    int occ = -1;
+    auto kern = gemm_ws_kernel<false, false, 128, 128, 64, 2>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(kern), WS_THREADS, (size_t)lds_bytes) != hipSuccess) return -1;
+    return occ;
+}
 
 extern "C" int esvit_gemm(int dtype, const esvit_gemm_desc* dp, esvit_stream_t stream_) {
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);

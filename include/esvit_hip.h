@@ -259,6 +259,8 @@ void esvit_debug_set_attn_tr_read(int on); /* attention backward: same */
 void esvit_debug_set_attn_bwd_waves(int w); /* attention backward compiled for 2 (256 regs) or 1 (512 regs) waves per SIMD */
 void esvit_debug_set_gemm_dma(int on);     /* GEMM: LDS-DMA main loop (1: by shape, 2: always) vs register-staged main loop (0) */
 void esvit_debug_set_gemm_xcdmap(int mode); /* 0 (default): tiles XCD-remapped, split/batch on grid.y; 1: split-K slices / batch items contiguous per XCD */
+void esvit_debug_set_gemm_ws_ablate(int bits); /* PROFILING ONLY (results become garbage): 1 no MFMA loop, 2 no DMA loads, 4 no epilogue */
+int esvit_debug_gemm_ws_occupancy(int lds_bytes); /* resident workgroups / CU of the persistent GEMM at this LDS size */
 void esvit_debug_set_gemm_pipe(int mode);  /* LDS-DMA pipeline: 1 = BK64 x 2 buffers, 3 = BK64 x 3-deep ring, 4 = BK32 x 4-deep ring */
 
 #ifdef __cplusplus

@@ -42,9 +42,10 @@ def _rand(shape, dev, seed, dt=torch.float32, scale=1.0):
     return (torch.randn(shape, generator=g) * scale).to(dev).to(dt)
 
 
-@pytest.fixture(params=[1, 2, 3, 4, 5, 0], ids=["dma-2xBK64", "dma-2xBK32", "dma-ring3xBK64", "dma-ring4xBK32", "dma-ring3xBK32", "regstage"])
+@pytest.fixture(params=[6, 7, 1, 2, 3, 4, 5, 0], ids=["ws-2xBK64", "ws-4xBK32", "dma-2xBK64", "dma-2xBK32", "dma-ring3xBK64", "dma-ring4xBK32", "dma-ring3xBK32", "regstage"])
 def gemm_path(request, mods):
-    """every GEMM main loop: LDS-DMA rings (buffer_load ... lds + counted vmcnt) and the register-staged BK=32 loop"""
+    """every GEMM main loop: the persistent warp-specialised kernel (producer waves + consumer waves), the
+    one-tile-per-workgroup LDS-DMA rings (buffer_load ... lds + counted vmcnt) and the register-staged BK=32 loop"""
     ops, _ = mods
     ops.debug_set_gemm_dma(2 if request.param else 0)
     if request.param:
@@ -56,7 +57,7 @@ def gemm_path(request, mods):
 
 @pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("M,N,K", [(300, 96, 96), (257, 288, 96), (128, 384, 192), (1000, 256, 2048), (64, 64, 48), (520, 1024, 256),
-                                   (777, 2048, 768), (130, 96, 384)])
+                                   (777, 2048, 768), (130, 96, 384), (33000, 384, 200)])
 def test_gemm_nt(mods, gemm_path, dt, M, N, K):
     ops, ref = mods
     dev = _dev()
@@ -72,7 +73,7 @@ def test_gemm_nt(mods, gemm_path, dt, M, N, K):
 
 @pytest.mark.parametrize("tr", [1, 0])
 @pytest.mark.parametrize("dt", DTYPES)
-@pytest.mark.parametrize("M,N,K", [(300, 96, 384), (257, 192, 576), (1000, 2048, 256), (130, 768, 3072)])
+@pytest.mark.parametrize("M,N,K", [(300, 96, 384), (257, 192, 576), (1000, 2048, 256), (130, 768, 3072), (40000, 192, 96)])
 def test_gemm_dgrad(mods, gemm_path, dt, tr, M, N, K):
     """dx[M,N] = dy[M,K] @ w[K,N] (B read k-strided; tr=1 uses ds_read_b64_tr_b16)."""
     ops, ref = mods
