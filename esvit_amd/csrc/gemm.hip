@@ -374,7 +374,8 @@ __device__ __forceinline__ void gemm_epilogue(const esvit_gemm_desc& p, f32x4 (&
 enum { EK_PLAIN = 0, EK_GELU = 1, EK_RES = 2, EK_GELU_BWD = 3 };
 
 template <int BM, int BN, bool SWZ, int KIND, bool OUTF32>
-__device__ __forceinline__ void epilogue_fast(const esvit_gemm_desc& p, f32x4 (&acc)[BM / 32][BN / 32], float* stage, int m0, int n0, int z) {
+__device__ __forceinline__ void epilogue_fast(const esvit_gemm_desc& p, f32x4 (&acc)[BM / 32][BN / 32], float* stage, int m0, int n0,
+                                              void* Cbase, long ldc, long c_first, const float* bias) {
     constexpr int WTM = BM / 2, WTN = BN / 2;
     constexpr int FM = WTM / 16, FN = WTN / 16;
     constexpr int SR = 16;
@@ -406,13 +407,13 @@ __device__ __forceinline__ void epilogue_fast(const esvit_gemm_desc& p, f32x4 (&
         rd_off[t] = row_l * LDE + ((cg * 8) ^ (SWZ ? (((row_l >> 2) & 3) << 4) : 0));
         const long row = row_w + row_l;
         const int n = col_w + cg * 8;
-        c_off[t] = (long)z * p.strideC + row * p.ldc + n;
+        c_off[t] = c_first + row * ldc + n;
         x_off[t] = KIND == EK_RES ? row * p.ldr + n : row * p.ldaux + n;
 #pragma unroll
         for (int e = 0; e < 8; ++e) bias_h[t][e] = 0.f;
-        if (p.bias && live[t]) {
-            const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + n);
-            const f32x4 b1 = *reinterpret_cast<const f32x4*>(p.bias + n + 4);
+        if (bias && live[t]) {
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(bias + n);
+            const f32x4 b1 = *reinterpret_cast<const f32x4*>(bias + n + 4);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 bias_h[t][e] = b0[e];
@@ -426,7 +427,7 @@ __device__ __forceinline__ void epilogue_fast(const esvit_gemm_desc& p, f32x4 (&
 #pragma unroll
             for (int j = 0; j < FN; ++j) acc[i][j] *= p.alpha;
     }
-    const long c_step = (long)SR * p.ldc;
+    const long c_step = (long)SR * ldc;
     const long x_step = (long)SR * (KIND == EK_RES ? p.ldr : p.ldaux);
     bf16* auxp = reinterpret_cast<bf16*>(p.aux);
 
@@ -495,14 +496,14 @@ __device__ __forceinline__ void epilogue_fast(const esvit_gemm_desc& p, f32x4 (&
                 }
             }
             if constexpr (OUTF32) {
-                float* cp = reinterpret_cast<float*>(p.C) + c_off[t] + ps * c_step;
+                float* cp = reinterpret_cast<float*>(Cbase) + c_off[t] + ps * c_step;
                 *reinterpret_cast<f32x4*>(cp) = f32x4{v[0], v[1], v[2], v[3]};
                 *reinterpret_cast<f32x4*>(cp + 4) = f32x4{v[4], v[5], v[6], v[7]};
             } else {
                 bf16x8 ov;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) ov[e] = (bf16)v[e];
-                *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(p.C) + c_off[t] + ps * c_step) = ov;
+                *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(Cbase) + c_off[t] + ps * c_step) = ov;
             }
         });
     });
@@ -516,6 +517,12 @@ __device__ __forceinline__ void gemm_epilogue_bf16(const esvit_gemm_desc& p, f32
     constexpr bool SWZ = LOCAL && FN == 4;
     constexpr int LDE = SWZ ? WTN : WTN + 4;
     auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    if (p.splitk > 1 && m0 + BM <= p.M && n0 + BN <= p.N && (p.N % 4 == 0) && al16(p.partial)) {
+        // split-K partial of a full tile: a plain fp32 store into this slice's [M, N] plane
+        float* stage = reinterpret_cast<float*>(smem_raw) + (threadIdx.x >> 6) * (16 * LDE);
+        epilogue_fast<BM, BN, SWZ, EK_PLAIN, true>(p, acc, stage, m0, n0, p.partial + (long)z * p.M * p.N, p.N, 0, nullptr);
+        return;
+    }
     bool fast = p.splitk <= 1 && !p.rowmap && m0 + BM <= p.M && n0 + BN <= p.N && (p.ldc % 8 == 0) && al16(p.C) &&
                 ((p.strideC * (long)z) % 8 == 0) && (!p.bias || al16(p.bias));
     int kind = EK_PLAIN;
@@ -536,16 +543,16 @@ __device__ __forceinline__ void gemm_epilogue_bf16(const esvit_gemm_desc& p, f32
         return;
     }
     float* stage = reinterpret_cast<float*>(smem_raw) + (threadIdx.x >> 6) * (16 * LDE);
-    if (kind == EK_GELU) epilogue_fast<BM, BN, SWZ, EK_GELU, false>(p, acc, stage, m0, n0, z);
+    if (kind == EK_GELU) epilogue_fast<BM, BN, SWZ, EK_GELU, false>(p, acc, stage, m0, n0, p.C, p.ldc, (long)z * p.strideC, p.bias);
     else if (kind == EK_GELU_BWD) {
-        if (p.out_f32) epilogue_fast<BM, BN, SWZ, EK_GELU_BWD, true>(p, acc, stage, m0, n0, z);
-        else epilogue_fast<BM, BN, SWZ, EK_GELU_BWD, false>(p, acc, stage, m0, n0, z);
+        if (p.out_f32) epilogue_fast<BM, BN, SWZ, EK_GELU_BWD, true>(p, acc, stage, m0, n0, p.C, p.ldc, (long)z * p.strideC, p.bias);
+        else epilogue_fast<BM, BN, SWZ, EK_GELU_BWD, false>(p, acc, stage, m0, n0, p.C, p.ldc, (long)z * p.strideC, p.bias);
     } else if (kind == EK_RES) {
-        if (p.out_f32) epilogue_fast<BM, BN, SWZ, EK_RES, true>(p, acc, stage, m0, n0, z);
-        else epilogue_fast<BM, BN, SWZ, EK_RES, false>(p, acc, stage, m0, n0, z);
+        if (p.out_f32) epilogue_fast<BM, BN, SWZ, EK_RES, true>(p, acc, stage, m0, n0, p.C, p.ldc, (long)z * p.strideC, p.bias);
+        else epilogue_fast<BM, BN, SWZ, EK_RES, false>(p, acc, stage, m0, n0, p.C, p.ldc, (long)z * p.strideC, p.bias);
     } else {
-        if (p.out_f32) epilogue_fast<BM, BN, SWZ, EK_PLAIN, true>(p, acc, stage, m0, n0, z);
-        else epilogue_fast<BM, BN, SWZ, EK_PLAIN, false>(p, acc, stage, m0, n0, z);
+        if (p.out_f32) epilogue_fast<BM, BN, SWZ, EK_PLAIN, true>(p, acc, stage, m0, n0, p.C, p.ldc, (long)z * p.strideC, p.bias);
+        else epilogue_fast<BM, BN, SWZ, EK_PLAIN, false>(p, acc, stage, m0, n0, p.C, p.ldc, (long)z * p.strideC, p.bias);
     }
 }
 
@@ -723,6 +730,27 @@ struct DmaTile {
         for (int i = 0; i < INSTR_PER_WAVE; ++i) issue_slot(rsrc, lds_tile, ld, rows_left, k0, K, wave * INSTR_PER_WAVE + i, lane);
     }
 
+    // Fast path of issue() for a FULL k-tile (see issue_all_fast below): per-lane offsets once per kernel, k0 in the
+    // scalar offset, no per-instruction address arithmetic or predicates.
+    __device__ __forceinline__ static void wave_offsets(long ld, int wave, int lane, int (&voff)[CHUNKS / 256]) {
+        static_for<CHUNKS / 256>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            const int p = (wave * INSTR_PER_WAVE + i) * 64 + lane;
+            const int r = p / CPR, cp = p % CPR;
+            const long off = KS ? (long)r * ld + (cp ^ sw_ks(r)) * 8 : (long)r * ld + (cp ^ sw_kc(r)) * 8;
+            voff[i] = (int)(off * 2);
+        });
+    }
+    __device__ __forceinline__ static void issue_fast(__amdgpu_buffer_rsrc_t rsrc, char* lds_tile, long ld, int k0, int wave,
+                                                      const int (&voff)[CHUNKS / 256]) {
+        typedef __attribute__((address_space(3))) void lds_void;
+        const int soff = (int)(KS ? (long)k0 * ld * 2 : (long)k0 * 2);
+        static_for<INSTR_PER_WAVE>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void*)(lds_tile + (wave * INSTR_PER_WAVE + i) * 1024), 16, voff[i], soff, 0, 0);
+        });
+    }
+
     // the whole tile from ONE wave (producer wave of the warp-specialised kernel)
     static constexpr int INSTR_PER_TILE = CHUNKS / 64;
     // Fast path of issue_all for a FULL k-tile: the per-lane byte offsets of the tile's instructions relative to
@@ -850,12 +878,22 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_dma_kernel(const esvit_gemm_
     const Frag<bf16> ones = ones_frag(bf16());
 
     const int nk = (kend > kbeg) ? (kend - kbeg + BKD - 1) / BKD : 0;
+    // full k-tiles of row-complete operand tiles take the bare-DMA path (offsets precomputed, k0 in the scalar offset)
+    int voffA[TA::INSTR_PER_WAVE], voffB[TB::INSTR_PER_WAVE];
+    TA::wave_offsets(p.lda, wave, lane, voffA);
+    TB::wave_offsets(p.ldb, wave, lane, voffB);
+    const bool rows_ok_a = !AKS || (M - m0 >= BM), rows_ok_b = !BKS || (N - n0 >= BN);
+    auto issue_tile = [&](int t, int slot) {
+        const int k0 = kbeg + t * BKD;
+        const bool fullk = k0 + BKD <= kend;
+        if (fullk && rows_ok_a) TA::issue_fast(ra, sA + slot * A_BYTES, p.lda, k0, wave, voffA);
+        else TA::issue(ra, sA + slot * A_BYTES, p.lda, M - m0, k0, kend, wave, lane);
+        if (fullk && rows_ok_b) TB::issue_fast(rb, sB + slot * B_BYTES, p.ldb, k0, wave, voffB);
+        else TB::issue(rb, sB + slot * B_BYTES, p.ldb, N - n0, k0, kend, wave, lane);
+    };
 #pragma unroll
     for (int t = 0; t < NBUF - 1; ++t) {
-        if (t < nk) {
-            TA::issue(ra, sA + t * A_BYTES, p.lda, M - m0, kbeg + t * BKD, kend, wave, lane);
-            TB::issue(rb, sB + t * B_BYTES, p.ldb, N - n0, kbeg + t * BKD, kend, wave, lane);
-        }
+        if (t < nk) issue_tile(t, t);
     }
     int buf = 0;  // ring slot of tile kt
     for (int kt = 0; kt < nk; ++kt) {
@@ -868,8 +906,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_dma_kernel(const esvit_gemm_
         const int nt = kt + NBUF - 1;
         if (nt < nk) {
             const int nb = (buf == 0) ? NBUF - 1 : buf - 1;  // the slot tile kt-1 just vacated
-            TA::issue(ra, sA + nb * A_BYTES, p.lda, M - m0, kbeg + nt * BKD, kend, wave, lane);
-            TB::issue(rb, sB + nb * B_BYTES, p.ldb, N - n0, kbeg + nt * BKD, kend, wave, lane);
+            issue_tile(nt, nb);
         }
         const bf16* a_lds = reinterpret_cast<const bf16*>(sA + buf * A_BYTES);
         const bf16* b_lds = reinterpret_cast<const bf16*>(sB + buf * B_BYTES);
