@@ -1374,10 +1374,11 @@ extern "C" int esvit_gemm(int dtype, const esvit_gemm_desc* dp, esvit_stream_t s
     if (d.colsum && d.splitk > 1) ESVIT_CHECK_ARG(d.colsum_partial != nullptr, "esvit_gemm: colsum with split-K needs colsum_partial");
     if (d.colsum) ESVIT_CHECK_ARG(d.batch == 1, "esvit_gemm: colsum is not batched");
     if (dtype == ESVIT_BF16) {
-        // LDS-DMA main loop (BK = 64) for every reduction deep enough to pipeline; short-K forward/dgrad GEMMs
-        // (K = 96 / 128: two half-empty k-tiles, no overlap to win) stay on the register-staged BK = 32 loop
+        // LDS-DMA main loop (BK = 64) for every bf16 GEMM; K = 96 runs two k-tiles with the second half zero-filled
+        // by the descriptor's range check, which costs MFMA issue slots these HBM-bound shapes do not miss
+        // (profiles/r01_gemm_k96_dma_vs_regstage.txt).  g_use_dma = 3 restores the old K >= 192 rule.
         const bool deep = d.a_kstrided || d.K >= 192;
-        if (g_use_dma && g_use_tr && (deep || g_use_dma == 2)) {
+        if (g_use_dma && g_use_tr && (deep || g_use_dma != 3)) {
             if (!d.a_kstrided && !d.b_kstrided) return dispatch_tile_dma<false, false>(d, stream);
             if (!d.a_kstrided && d.b_kstrided) return dispatch_tile_dma<false, true>(d, stream);
             if (d.a_kstrided && d.b_kstrided) return dispatch_tile_dma<true, true>(d, stream);

@@ -190,6 +190,22 @@ struct LnCfg {
 inline bool ln_cfg(int C, LnCfg* cfg) {
     if (C % 4 != 0 || C <= 0) return false;
     const int C4 = C / 4;
+    // Swin widths are 96 * 2^s (and 4x that in PatchMerging): C4 = 3 * 2^k.  A lane group of C4/3 lanes with three
+    // 16-byte vectors per lane keeps every lane busy (a power-of-two group would idle a quarter of them) and puts
+    // three loads per lane in flight -- these kernels are latency-bound, not bandwidth-bound, at one vector per lane.
+    if (C4 % 3 == 0) {
+        const int G = C4 / 3;
+        if (G == 8 || G == 16 || G == 32 || G == 64) {
+            cfg->G = G;
+            cfg->ITERS = 3;
+            return true;
+        }
+    }
+    if (C4 == 64) {  // bottleneck width 256
+        cfg->G = 16;
+        cfg->ITERS = 4;
+        return true;
+    }
     const int G = C4 <= 16 ? 16 : (C4 <= 32 ? 32 : 64);
     const int it = (C4 + G - 1) / G;
     const int allowed[] = {1, 2, 3, 4, 6, 8};
@@ -209,7 +225,11 @@ struct LnShape {
 };
 template <typename F>
 inline void ln_dispatch(const LnCfg& cfg, F&& f) {
-    if (cfg.G == 16) f(LnShape<16, 1>{});
+    if (cfg.G == 8) f(LnShape<8, 3>{});
+    else if (cfg.G == 16 && cfg.ITERS == 3) f(LnShape<16, 3>{});
+    else if (cfg.G == 16 && cfg.ITERS == 4) f(LnShape<16, 4>{});
+    else if (cfg.G == 16) f(LnShape<16, 1>{});
+    else if (cfg.G == 32 && cfg.ITERS == 3) f(LnShape<32, 3>{});
     else if (cfg.G == 32) f(LnShape<32, 1>{});
     else if (cfg.ITERS == 1) f(LnShape<64, 1>{});
     else if (cfg.ITERS == 2) f(LnShape<64, 2>{});
@@ -224,7 +244,7 @@ inline int ln_bwd_nblk(long rows, int C) {
     if (!ln_cfg(C, &cfg)) return 0;
     const int rpb = LN_THREADS / cfg.G;
     long nb = (rows + rpb - 1) / rpb;
-    if (nb > 512) nb = 512;
+    if (nb > 1024) nb = 1024;  // 8 resident 256-thread blocks per CU: one row per lane group in flight each
     if (nb < 1) nb = 1;
     return (int)nb;
 }
