@@ -2,20 +2,21 @@
 // driven by main_esvit.py:506-510,574) + teacher EMA (main_esvit.py:587-590) in two multi-tensor
 // launches with no host synchronisation (the reference does one .item() per tensor).
 //
-// Tensor table (device, int64[ntensors * 10]):
+// Tensor table (device, int64[ntensors * 12]):
 //   0 p  1 g  2 exp_avg  3 exp_avg_sq  4 teacher_p  5 numel  6 group (0: weight decay, 1: none)
 //   7 flags (bit0: has gradient this step)  8 bias corrections: bits(1-beta1^t) | bits(1-beta2^t) << 32
-//   9 reserved
+//   9 reserved  10 bf16 copy of p (0 = none)  11 bf16 copy of teacher_p (0 = none): the activation-dtype weights the
+//   next forward's GEMMs read, written here instead of by ~120 separate cast launches per step
 // Chunk table (device, int32[nchunks * 2]): [tensor id, chunk index]; a chunk is 4096 elements and
 // is processed by one 256-thread workgroup with float4 accesses.  HBM-bound: 9 floats of traffic
-// per parameter (read p,g,m,v,teacher; write p,m,v,teacher).
+// per parameter (read p,g,m,v,teacher; write p,m,v,teacher) + 1 for the two bf16 copies.
 #include "common.h"
 #include "../../include/esvit_hip.h"
 
 namespace {
 
 constexpr int CHUNK = 4096;
-constexpr int TFIELDS = 10;
+constexpr int TFIELDS = 12;
 
 __global__ __launch_bounds__(256) void grad_sqnorm_kernel(const long* __restrict__ tensors, const int* __restrict__ chunks,
                                                           float* __restrict__ sqnorms) {
@@ -60,6 +61,8 @@ __global__ __launch_bounds__(256) void clip_adamw_ema_kernel(const long* __restr
     float* m = reinterpret_cast<float*>(tt[2]);
     float* v = reinterpret_cast<float*>(tt[3]);
     float* tp = reinterpret_cast<float*>(tt[4]);
+    bf16* pb = reinterpret_cast<bf16*>(tt[10]);  // optional bf16 copies the next forward reads (student / teacher)
+    bf16* tb = reinterpret_cast<bf16*>(tt[11]);
     const long n = tt[5];
     const bool has_grad = tt[7] & 1;
     const float decay = (tt[6] == 0) ? 1.f - lr * wd : 1.f;
@@ -93,9 +96,12 @@ __global__ __launch_bounds__(256) void clip_adamw_ema_kernel(const long* __restr
                 *reinterpret_cast<f32x4*>(m + o) = mv;
                 *reinterpret_cast<f32x4*>(v + o) = vv;
             }
+            if (pb) *reinterpret_cast<bf16x4*>(pb + o) = bf16x4{(bf16)pv[0], (bf16)pv[1], (bf16)pv[2], (bf16)pv[3]};
             if (tp) {
                 const f32x4 tv = *reinterpret_cast<f32x4*>(tp + o);
-                *reinterpret_cast<f32x4*>(tp + o) = tv * ema_m + pv * (1.f - ema_m);
+                const f32x4 tn = tv * ema_m + pv * (1.f - ema_m);
+                *reinterpret_cast<f32x4*>(tp + o) = tn;
+                if (tb) *reinterpret_cast<bf16x4*>(tb + o) = bf16x4{(bf16)tn[0], (bf16)tn[1], (bf16)tn[2], (bf16)tn[3]};
             }
         } else {
             for (long j = o; j < n; ++j) {
@@ -107,7 +113,12 @@ __global__ __launch_bounds__(256) void clip_adamw_ema_kernel(const long* __restr
                     m[j] = me;
                     v[j] = ve;
                 }
-                if (tp) tp[j] = tp[j] * ema_m + pe * (1.f - ema_m);
+                if (pb) pb[j] = (bf16)pe;
+                if (tp) {
+                    const float tn = tp[j] * ema_m + pe * (1.f - ema_m);
+                    tp[j] = tn;
+                    if (tb) tb[j] = (bf16)tn;
+                }
             }
         }
     }

@@ -128,8 +128,7 @@ class EsvitTrainer:
         loss.backward()
         self.reducer.finish()
         self.updater.step(lr, wd, momentum, clip_grad=self.clip_grad, skip_last_layer=epoch < self.freeze_last_layer)
-        self.updater.zero_grad(set_to_none=True)
-        P.invalidate()
+        self.updater.zero_grad(set_to_none=True)  # (the updater invalidated / refreshed the cached weight casts itself)
         return loss.detach()
 
 

@@ -98,8 +98,10 @@ class SwinTransformerBlock(nn.Module):
         geom = Fn.geometry(H, W, self.window_size, self.shift_size, x.device)
         dp = None
         if isinstance(self.drop_path, DropPath):
-            f1, f2 = self.drop_path.factors(B, x.device), self.drop_path.factors(B, x.device)
-            dp = None if f1 is None else (f1, f2)
+            dp = self.__dict__.pop("_dp_pending", None)  # drawn for every block at once by SwinTransformer._tokens
+            if dp is None or dp[0].shape[0] != B:
+                f1, f2 = self.drop_path.factors(B, x.device), self.drop_path.factors(B, x.device)
+                dp = None if f1 is None else (f1, f2)
         attn = None
         if return_attention:
             attn = Fn.swin_block_attention(x, geom, self.num_heads, self.attn.relative_position_index, self._params())
@@ -223,7 +225,22 @@ class SwinTransformer(nn.Module):
 
     # ---- forward paths -----------------------------------------------------------------------
     def _tokens(self, x):
+        self._draw_drop_path(x.shape[0], x.device)
         return self.patch_embed(x)
+
+    def _draw_drop_path(self, nB, device):
+        """Stochastic-depth factors floor(keep + U[0,1)) / keep (vision_transformer.py:30-38) for BOTH residual branches
+        of EVERY block of this pass in four launches, instead of eight tiny launches per block."""
+        blocks = [b for layer in self.layers for b in layer.blocks if isinstance(b.drop_path, DropPath) and b.drop_path.drop_prob]
+        if not self.training or not blocks:
+            return
+        keep = getattr(self, "_dp_keep", None)
+        if keep is None or keep.device != device or keep.shape[0] != 2 * len(blocks):
+            keep = torch.tensor([1.0 - b.drop_path.drop_prob for b in blocks for _ in range(2)], device=device).unsqueeze(1)
+            self.__dict__["_dp_keep"] = keep
+        f = torch.rand(2 * len(blocks), nB, device=device).add_(keep).floor_().div_(keep)
+        for i, b in enumerate(blocks):
+            b.__dict__["_dp_pending"] = (f[2 * i], f[2 * i + 1])
 
     def forward_feature_maps(self, x):
         x = self._tokens(x)

@@ -47,5 +47,26 @@ def cached(p, name, fn):
     return val
 
 
+def cast_buffer_ptr(p, fresh):
+    """Device pointer of p's cached bf16 cast (0 if there is none, or the activation dtype is not bf16).  The fused
+    update writes the new values straight into that buffer; the caller passes the collected `fresh` list to
+    mark_fresh() after invalidate() so the entries are not recast."""
+    if ops.act_dtype() != torch.bfloat16:
+        return 0
+    key = (id(p), "cast")
+    ent = _CACHE.get(key)
+    if ent is None or ent[1].dtype != torch.bfloat16 or ent[1].numel() != p.numel() or ent[1].data_ptr() == p.data_ptr():
+        return 0
+    fresh.append((key, p))
+    return ent[1].data_ptr()
+
+
+def mark_fresh(fresh):
+    for key, p in fresh:
+        ent = _CACHE.get(key)
+        if ent is not None:
+            _CACHE[key] = (_tag(p), ent[1])
+
+
 def clear():
     _CACHE.clear()

@@ -13,8 +13,9 @@ import numpy as np
 import torch
 
 from . import ops
+from . import params as P
 
-TFIELDS = 10
+TFIELDS = 12
 
 
 def get_params_groups(model):
@@ -126,6 +127,14 @@ class FusedClipAdamWEMA:
                 self._bc_cache[t] = bc
             gptr[i], flags[i], bcs[i] = g.data_ptr(), 1, bc
         tab[:, 1], tab[:, 7], tab[:, 8] = gptr, flags, bcs
+        # activation-dtype copies the forward GEMMs read (esvit_amd.params): refreshed by the update kernel itself
+        fresh = []
+        sb, tb = [0] * len(self.params), [0] * len(self.params)
+        for i, p in enumerate(self.params):
+            sb[i] = P.cast_buffer_ptr(p, fresh)
+            tp = self.teacher_params[i]
+            tb[i] = P.cast_buffer_ptr(tp, fresh) if tp is not None else 0
+        tab[:, 10], tab[:, 11] = sb, tb
         tab = self._ring[slot]
         self._table_dev.copy_(tab, non_blocking=True)
         ev = torch.cuda.Event()
@@ -135,6 +144,8 @@ class FusedClipAdamWEMA:
         ops.grad_sqnorm(self._table_dev, n, self.chunks, self.nchunks, self.sqnorms)
         ops.fused_clip_adamw_ema(self._table_dev, n, self.chunks, self.nchunks, self.sqnorms, float(clip_grad or 0.0), float(lr),
                                  float(weight_decay), b1, b2, self.eps, float(ema_momentum))
+        P.invalidate()          # parameters changed behind autograd's back ...
+        P.mark_fresh(fresh)     # ... but these cached casts were rewritten by the kernel
         for g in self.param_groups:
             g["lr"] = float(lr)
         self.param_groups[0]["weight_decay"] = float(weight_decay)

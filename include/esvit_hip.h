@@ -240,10 +240,11 @@ int esvit_center_ema(float* center, const float* colsum, float momentum, float d
 
 /* ---- fused update: per-parameter clip + AdamW + teacher EMA -------------
  * utils.py:106-115 (clip), torch.optim.AdamW as driven by main_esvit.py:506-510,574,
- * EMA main_esvit.py:587-590.  Tensor table (device, int64[ntensors*10]):
+ * EMA main_esvit.py:587-590.  Tensor table (device, int64[ntensors*12]):
  *   [p, g, exp_avg, exp_avg_sq, teacher_p (0 = none), numel, group (0: weight decay, 1: none),
  *    flags (bit0: has gradient; otherwise only the EMA is applied),
- *    bits(1-beta1^t) | bits(1-beta2^t) << 32, reserved]
+ *    bits(1-beta1^t) | bits(1-beta2^t) << 32, reserved,
+ *    bf16 copy of p (0 = none), bf16 copy of teacher_p (0 = none)]   -- the copies are refreshed in the same pass
  * chunk table (device, int32[nchunks*2]): [tensor_id, chunk_index], chunk =
  * esvit_update_chunk_elems() elements.  sqnorms: fp32 scratch [ntensors]. */
 int esvit_update_chunk_elems(void);
