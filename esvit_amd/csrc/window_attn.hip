@@ -1008,6 +1008,354 @@ __global__ __launch_bounds__(WAVES * 64, 1) void attn_bwd2_kernel(const T* __res
     }
 }
 
+// -------------------------------------------------------------------------------------------------
+// Backward, third generation (the default): attn_bwd2_kernel with each (window, head) shared by a PAIR of waves (one
+// 128-thread workgroup).  The LDS images of a window-head (34.6 KiB in bf16) limit a CU to four of them, so one wave per
+// window-head means one wave per SIMD and nothing to hide LDS / MFMA / transcendental latency behind.  Splitting the
+// 64 query columns (and the 64 key rows of the dK / dV outputs) between two waves halves every wave's register
+// footprint (<= 256 VGPRs -> two waves per SIMD) and its dependent instruction chains, at the price of five
+// two-wave barriers per window.  Wave w owns query tiles {2w, 2w+1} for P, dS, dQ and the bias gradient, and key
+// tiles {2w, 2w+1} for dK and dV; everything else (prefetch, buffer loads / stores, pad-slot sums) is as in bwd2.
+template <typename T, bool USE_TR>
+__global__ __launch_bounds__(128, 2) void attn_bwd3_kernel(const T* __restrict__ qkv, const float* __restrict__ qkv_bias,
+                                                          const int* __restrict__ win2tok, int L, const T* __restrict__ dout,
+                                                          const float* __restrict__ bias_frag, const int* __restrict__ region_ids,
+                                                          int nW, int Bw, int N, int nH, float scale, int parts,
+                                                          T* __restrict__ dqkv, float* __restrict__ dbias_ws,
+                                                          float* __restrict__ dpad_ws) {
+    using Cfg = AttnCfg<T>;
+    constexpr int LDQ = Cfg::LDQ, LDP = Cfg::LDP, VEC = Cfg::VEC, ES = sizeof(T);
+    constexpr int VPR = HD / VEC;          // 16-byte vectors per [slot][HD] row
+    constexpr int NV = NP * VPR / 128;     // row vectors per thread per matrix (loads: 128 threads cover 64 slots)
+    constexpr int LSTEP = 128 / VPR;       // slot stride between a thread's load vectors
+    constexpr int NS = 32 * VPR / 64;      // row vectors per lane per 32-row output tile (stores)
+    constexpr int SSTEP = 64 / VPR;
+    constexpr int OOB = 0x7ffffff0;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int c = lane & 15, g = lane >> 4;
+    T* base = reinterpret_cast<T*>(smem_raw);
+    T* Qs = base;
+    T* Ks = base + Cfg::QK_ELEMS;
+    T* Vs = base + 2 * Cfg::QK_ELEMS;
+    T* Os = base + 3 * Cfg::QK_ELEMS;
+    T* Sg = base + 4 * Cfg::QK_ELEMS + w * (32 * LDQ);  // this wave's half of the output staging image
+    T* Ps = base + 5 * Cfg::QK_ELEMS;
+
+    const long unit = blockIdx.x;  // one (head, part) per workgroup
+    const bool unit_ok = unit < (long)parts * nH;
+    const int h = (int)(unit % nH);
+    const int part = (int)(unit / nH);
+    const int C = nH * HD;
+    const bool masked = region_ids != nullptr;
+    const int lrow0 = tid / VPR, dv = tid % VPR;         // load rows: lrow0 + LSTEP*i
+    const int srow0 = 32 * w + lane / VPR;                // store rows: srow0 + SSTEP*i  (dv is the same: 64 % VPR == 0)
+
+    f32x4 bias_r[4][2];
+    {
+        const float* bias_f = bias_frag + (long)h * FRAG_ELEMS;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int jl = 0; jl < 2; ++jl) bias_r[i][jl] = *reinterpret_cast<const f32x4*>(bias_f + ((i * 4 + 2 * w + jl) * 64 + lane) * 4);
+    }
+    Vec16<T> padq, padk_v, padv_v;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+        padq.set(e, qkv_bias[h * HD + dv * VEC + e]);
+        padq.set(e, padq.get(e) * scale);
+        padk_v.set(e, qkv_bias[C + h * HD + dv * VEC + e]);
+        padv_v.set(e, qkv_bias[2 * C + h * HD + dv * VEC + e]);
+    }
+    f32x4 db[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int jl = 0; jl < 2; ++jl) db[i][jl] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float padk[VEC], padv[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) padk[e] = padv[e] = 0.f;
+
+    const int iters = (Bw + parts - 1) / parts;
+    auto win_of = [&](int it, bool& act) -> int {
+        const int bw = part + it * parts;
+        act = unit_ok && it < iters && bw < Bw;
+        return act ? bw : 0;
+    };
+    auto load_map = [&](int it, int& tok, int& reg) {
+        bool act;
+        const int bw = win_of(it, act);
+        tok = (act && lane < N) ? win2tok[(long)(bw % nW) * N + lane] : -1;
+        reg = (masked && act && lane < N) ? region_ids[(long)(bw % nW) * N + lane] : -1;
+    };
+    struct Win {
+        u32x4 q[NV], k[NV], v[NV], o[NV];
+        int ltok[NV];  // token rows of the slots this thread loads
+        int mytok, myreg;
+        long tok_base;
+        bool active;
+    };
+    auto issue_rows = [&](int it, int mytok, int myreg, Win& x) {
+        const int bw = win_of(it, x.active);
+        x.mytok = mytok;
+        x.myreg = myreg;
+        x.tok_base = (long)(bw / nW) * L;
+        const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(qkv + x.tok_base * 3L * C), 0, (int)(L * 3L * C * ES), 0x00020000);
+        const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(dout + x.tok_base * (long)C), 0, (int)(L * (long)C * ES), 0x00020000);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int tok = __shfl(mytok, lrow0 + LSTEP * i, 64);
+            x.ltok[i] = tok;
+            const int vq = tok >= 0 ? tok * 3 * C * ES + dv * 16 : OOB;
+            const int vo = tok >= 0 ? tok * C * ES + dv * 16 : OOB;
+            x.q[i] = __builtin_amdgcn_raw_buffer_load_b128(rq, vq, h * HD * ES, 0);
+            x.k[i] = __builtin_amdgcn_raw_buffer_load_b128(rq, vq, (C + h * HD) * ES, 0);
+            x.v[i] = __builtin_amdgcn_raw_buffer_load_b128(rq, vq, (2 * C + h * HD) * ES, 0);
+            x.o[i] = __builtin_amdgcn_raw_buffer_load_b128(ro, vo, h * HD * ES, 0);
+        }
+    };
+
+    Win cur, nxt;
+    int tok1, reg1, tok2 = -1, reg2 = -1;
+    load_map(0, tok1, reg1);
+    issue_rows(0, tok1, reg1, cur);
+    load_map(1, tok1, reg1);
+
+    for (int it = 0; it < iters; ++it) {
+        __syncthreads();  // the other wave is done with the previous window's images
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int t = lrow0 + LSTEP * i;
+            const bool padslot = cur.active && t < N && cur.ltok[i] < 0;
+            Vec16<T> xq, xk, xv, xo;
+            xq.v = __builtin_bit_cast(decltype(xq.v), cur.q[i]);
+            xk.v = __builtin_bit_cast(decltype(xk.v), cur.k[i]);
+            xv.v = __builtin_bit_cast(decltype(xv.v), cur.v[i]);
+            xo.v = __builtin_bit_cast(decltype(xo.v), cur.o[i]);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) xq.set(e, xq.get(e) * scale);
+            if (padslot) {
+                xq = padq;
+                xk = padk_v;
+                xv = padv_v;
+            }
+            st16<T>(Qs + t * LDQ + dv * VEC, xq);
+            st16<T>(Ks + t * LDQ + dv * VEC, xk);
+            st16<T>(Vs + t * LDQ + dv * VEC, xv);
+            st16<T>(Os + t * LDQ + dv * VEC, xo);
+        }
+        const int mytok = cur.mytok, myreg = cur.myreg;
+        const bool active = cur.active;
+        const long tok_base = cur.tok_base;
+        int stok[NS];  // token rows of the slots this lane stores
+#pragma unroll
+        for (int i = 0; i < NS; ++i) stok[i] = __shfl(mytok, srow0 + SSTEP * i, 64);
+        __syncthreads();  // images complete
+        issue_rows(it + 1, tok1, reg1, nxt);
+        load_map(it + 2, tok2, reg2);
+
+        // ---- phase 1: this wave's two query tiles of P ----
+        {
+            f32x4 p[4][2];
+            Frag<T> kf[4], qf[2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) kf[i] = frag_kc<T>(Ks, LDQ, 16 * i, 0, c, g);
+#pragma unroll
+            for (int jl = 0; jl < 2; ++jl) qf[jl] = frag_kc<T>(Qs, LDQ, 16 * (2 * w + jl), 0, c, g);
+            int rq[2];
+#pragma unroll
+            for (int jl = 0; jl < 2; ++jl) rq[jl] = __shfl(myreg, 16 * (2 * w + jl) + c, 64);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                int rk[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) rk[r] = __shfl(myreg, 16 * i + 4 * g + r, 64);
+#pragma unroll
+                for (int jl = 0; jl < 2; ++jl) {
+                    f32x4 b = bias_r[i][jl];
+                    if (masked) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) b[r] += (rk[r] != rq[jl]) ? -100.f : 0.f;
+                    }
+                    p[i][jl] = b;
+                    mma(kf[i], qf[jl], p[i][jl]);
+                }
+            }
+#pragma unroll
+            for (int jl = 0; jl < 2; ++jl) {
+                float m = -3.0e38f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) m = fmaxf(m, p[i][jl][r]);
+                m = fmaxf(m, __shfl_xor(m, 16, 64));
+                m = fmaxf(m, __shfl_xor(m, 32, 64));
+                float s = 0.f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float e = __expf(p[i][jl][r] - m);
+                        p[i][jl][r] = e;
+                        s += e;
+                    }
+                s += __shfl_xor(s, 16, 64);
+                s += __shfl_xor(s, 32, 64);
+                const float inv = 1.f / s;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    p[i][jl] *= inv;
+                    store_frag4<T>(Ps + (16 * (2 * w + jl) + c) * LDP + 16 * i + 4 * g, p[i][jl]);
+                }
+            }
+        }
+        __syncthreads();  // P complete (both waves' query tiles)
+
+        // 32 result rows (slots 32w .. 32w+31) x HD: LDS transpose, 16-byte row stores, pad-slot rows into `padacc`
+        auto emit = [&](const f32x4 (&acc)[2][2], float mul, int col0, float* padacc) {
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int il = 0; il < 2; ++il)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    Sg[(16 * il + 4 * g + r) * LDQ + c] = from_f32<T>(acc[il][0][r] * mul);
+                    Sg[(16 * il + 4 * g + r) * LDQ + 16 + c] = from_f32<T>(acc[il][1][r] * mul);
+                }
+            __builtin_amdgcn_wave_barrier();
+            const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(dqkv + tok_base * 3L * C, 0, (int)(L * 3L * C * ES), 0x00020000);
+#pragma unroll
+            for (int i = 0; i < NS; ++i) {
+                const int tl = lane / VPR + SSTEP * i;  // row inside the wave's 32-row tile
+                const int t = 32 * w + tl;
+                const Vec16<T> x = ld16<T>(Sg + tl * LDQ + dv * VEC);
+                const int vo = (active && stok[i] >= 0) ? stok[i] * 3 * C * ES + dv * 16 : OOB;
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, x.v), rd, vo, (col0 + h * HD) * ES, 0);
+                if (padacc && active && t < N && stok[i] < 0) {
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) padacc[e] += x.get(e);
+                }
+            }
+        };
+
+        // ---- phase 2: dV rows of this wave's key tiles = P^T dO (all queries) ----
+        {
+            f32x4 acc[2][2];
+#pragma unroll
+            for (int il = 0; il < 2; ++il) {
+                acc[il][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+                acc[il][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const Frag<T> b0 = frag_ks<T, USE_TR>(Os, LDQ, 0, 32 * ks, c, g);
+                const Frag<T> b1 = frag_ks<T, USE_TR>(Os, LDQ, 16, 32 * ks, c, g);
+#pragma unroll
+                for (int il = 0; il < 2; ++il) {
+                    const Frag<T> a = frag_ks<T, USE_TR>(Ps, LDP, 16 * (2 * w + il), 32 * ks, c, g);
+                    mma(a, b0, acc[il][0]);
+                    mma(a, b1, acc[il][1]);
+                }
+            }
+            emit(acc, 1.f, 2 * C, padv);
+        }
+        __syncthreads();  // both waves have read P: its rows may now be overwritten with dS
+        // ---- dP^T = V dO^T and dS = P o (dP - delta) for this wave's query tiles ----
+        {
+            Frag<T> vf[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) vf[i] = frag_kc<T>(Vs, LDQ, 16 * i, 0, c, g);
+#pragma unroll
+            for (int jl = 0; jl < 2; ++jl) {
+                const int j = 2 * w + jl;
+                const Frag<T> of = frag_kc<T>(Os, LDQ, 16 * j, 0, c, g);
+                f32x4 dpj[4], pj[4];
+                float d = 0.f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    dpj[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    mma(vf[i], of, dpj[i]);
+                    pj[i] = load_frag4<T>(Ps + (16 * j + c) * LDP + 16 * i + 4 * g);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) d += pj[i][r] * dpj[i][r];
+                }
+                d += __shfl_xor(d, 16, 64);
+                d += __shfl_xor(d, 32, 64);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const f32x4 ds = pj[i] * (dpj[i] - d);
+                    if (active) db[i][jl] += ds;
+                    store_frag4<T>(Ps + (16 * j + c) * LDP + 16 * i + 4 * g, ds);
+                }
+            }
+        }
+        __syncthreads();  // dS complete
+
+        // ---- phase 3: dQ rows of this wave's query tiles = scale dS K;  dK rows of its key tiles = dS^T (scale q) ----
+        {
+            f32x4 aq[2][2], ak[2][2];
+#pragma unroll
+            for (int il = 0; il < 2; ++il) {
+                aq[il][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+                aq[il][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+                ak[il][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+                ak[il][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const Frag<T> kb0 = frag_ks<T, USE_TR>(Ks, LDQ, 0, 32 * ks, c, g);
+                const Frag<T> kb1 = frag_ks<T, USE_TR>(Ks, LDQ, 16, 32 * ks, c, g);
+                const Frag<T> qb0 = frag_ks<T, USE_TR>(Qs, LDQ, 0, 32 * ks, c, g);
+                const Frag<T> qb1 = frag_ks<T, USE_TR>(Qs, LDQ, 16, 32 * ks, c, g);
+#pragma unroll
+                for (int il = 0; il < 2; ++il) {
+                    const Frag<T> a = frag_kc<T>(Ps, LDP, 16 * (2 * w + il), 32 * ks, c, g);
+                    mma(a, kb0, aq[il][0]);
+                    mma(a, kb1, aq[il][1]);
+                    const Frag<T> at = frag_ks<T, USE_TR>(Ps, LDP, 16 * (2 * w + il), 32 * ks, c, g);
+                    mma(at, qb0, ak[il][0]);
+                    mma(at, qb1, ak[il][1]);
+                }
+            }
+            emit(aq, scale, 0, nullptr);
+            emit(ak, 1.f, C, padk);
+        }
+        cur = nxt;
+        tok1 = tok2;
+        reg1 = reg2;
+    }
+
+    if (unit_ok) {
+        float* ws = dbias_ws + ((long)part * nH + h) * FRAG_ELEMS;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int jl = 0; jl < 2; ++jl) *reinterpret_cast<f32x4*>(ws + ((i * 4 + 2 * w + jl) * 64 + lane) * 4) = db[i][jl];
+    }
+    // pad-row sums: reduce over the row bits inside the wave, then over the two waves through LDS
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+#pragma unroll
+        for (int o = VPR; o < 64; o <<= 1) {
+            padk[e] += __shfl_xor(padk[e], o, 64);
+            padv[e] += __shfl_xor(padv[e], o, 64);
+        }
+    }
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem_raw);  // [2 waves][k|v][HD]
+    if (lane < VPR) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            red[(w * 2 + 0) * HD + dv * VEC + e] = padk[e];
+            red[(w * 2 + 1) * HD + dv * VEC + e] = padv[e];
+        }
+    }
+    __syncthreads();
+    if (unit_ok && tid < 2 * HD) {
+        const int kv = tid / HD, d = tid % HD;
+        dpad_ws[(long)part * 2 * C + kv * C + h * HD + d] = red[(0 * 2 + kv) * HD + d] + red[(1 * 2 + kv) * HD + d];
+    }
+}
+
 // bias_frag[h][frag] from the (2ws-1)^2 x nH table (swin_transformer.py:133-135)
 __global__ void relpos_bias_fwd_kernel(const float* __restrict__ table, const long* __restrict__ index, int N, int nH,
                                        float* __restrict__ bias_frag) {
@@ -1068,12 +1416,12 @@ __global__ void relpos_bias_bwd_kernel(const float* __restrict__ ws, int parts, 
 }
 
 static int g_attn_fwd_impl = 2;  // 2: attn_fwd2_kernel (persistent waves, prefetch); 1: attn_fwd_kernel (one window per wave)
-static int g_attn_bwd_impl = 2;  // 2: attn_bwd2_kernel (prefetching, wave-local sync, vector stores); 1: attn_bwd_kernel
+static int g_attn_bwd_impl = 3;  // 3: attn_bwd3_kernel (bwd2 with a window-head shared by two waves); 2: attn_bwd2_kernel; 1: attn_bwd_kernel
 
 inline int bwd_parts(int Bw, int nH) {
     // enough waves to fill the chip: 256 CUs x the resident backward waves (one 4-wave workgroup per CU for the
     // second-generation kernel, two for the first), at most one window per wave
-    int parts = ((g_attn_bwd_impl == 2 ? 1024 : 2048) + nH - 1) / nH;
+    int parts = ((g_attn_bwd_impl == 2 ? 1024 : (g_attn_bwd_impl == 3 ? 1024 : 2048)) + nH - 1) / nH;  // v3: 4 two-wave workgroups per CU
     if (parts > Bw) parts = Bw;
     if (parts < 1) parts = 1;
     return parts;
@@ -1238,6 +1586,25 @@ extern "C" int esvit_window_attn_bwd(int dtype, const void* qkv, const float* qk
     }
     const int Bw = nB * nW;
     const int parts = bwd_parts(Bw, nH);
+    if (g_attn_bwd_impl == 3 && (long)L * 3 * nH * HD * 4 < 0x7fff0000L) {
+#define LAUNCH_BWD3(TT, TR)                                                                                                     \
+    {                                                                                                                           \
+        const size_t lds = (size_t)Bwd2Cfg<TT>::PER_WAVE * sizeof(TT);                                                          \
+        auto kern = attn_bwd3_kernel<TT, TR>;                                                                                   \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);   \
+        hipLaunchKernelGGL(kern, dim3(parts * nH), dim3(128), lds, stream, (const TT*)qkv, qkv_bias, win2tok, L,                \
+                           (const TT*)dout, (const float*)bias_frag_ws, region_ids, nW, Bw, N, nH, scale, parts, (TT*)dqkv,     \
+                           dbias_ws, dpad_ws);                                                                                  \
+    }
+        if (dtype == ESVIT_BF16) {
+            if (g_attn_use_tr) LAUNCH_BWD3(bf16, true) else LAUNCH_BWD3(bf16, false)
+        } else {
+            LAUNCH_BWD3(float, false)
+        }
+#undef LAUNCH_BWD3
+        ESVIT_CHECK_LAUNCH("window_attn_bwd(v3)");
+        return ESVIT_OK;
+    }
     if (g_attn_bwd_impl == 2 && (long)L * 3 * nH * HD * 4 < 0x7fff0000L) {
 #define LAUNCH_BWD2(TT, TR)                                                                                                     \
     {                                                                                                                           \
