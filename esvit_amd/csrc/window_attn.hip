@@ -653,6 +653,237 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const T* __restrict__
 }
 
 // -------------------------------------------------------------------------------------------------
+// Forward, third generation (the default): attn_fwd2_kernel with each (window, head) shared by a pair of waves (one
+// 128-thread workgroup): wave w owns query tiles {2w, 2w+1} -- their score columns, softmax, P rows and output rows.
+// Half the registers per wave (three or more waves per SIMD instead of two) and half the dependent chain per window;
+// three two-wave barriers per window.
+template <typename T, bool WANT_ATTN>
+__global__ __launch_bounds__(128, 3) void attn_fwd3_kernel(const T* __restrict__ qkv, const float* __restrict__ qkv_bias,
+                                                          const int* __restrict__ win2tok, int L, const float* __restrict__ bias_frag,
+                                                          const int* __restrict__ region_ids, int nW, int Bw, int N, int nH, float scale,
+                                                          int parts, T* __restrict__ out, float* __restrict__ attn_out) {
+    using Cfg = AttnCfg<T>;
+    constexpr int LDQ = Cfg::LDQ, LDP = Cfg::LDP, VEC = Cfg::VEC, ES = sizeof(T);
+    constexpr int VPR = HD / VEC, NV = NP * VPR / 128, LSTEP = 128 / VPR;
+    constexpr int NS = 32 * VPR / 64, SSTEP = 64 / VPR;
+    constexpr int OOB = 0x7ffffff0;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int c = lane & 15, g = lane >> 4;
+    T* base = reinterpret_cast<T*>(smem_raw);
+    T* Qs = base;
+    T* Ks = base + Cfg::QK_ELEMS;
+    T* Ps = base;  // overlays Q,K once both waves have their scores
+    T* Vt = base + Cfg::R1;
+
+    const long unit = blockIdx.x;
+    const bool unit_ok = unit < (long)parts * nH;
+    const int h = (int)(unit % nH);
+    const int part = (int)(unit / nH);
+    const int C = nH * HD;
+    const bool masked = region_ids != nullptr;
+    const int lrow0 = tid / VPR, dv = tid % VPR;
+    const int srow0 = 32 * w + lane / VPR;
+    const float* bias_f = bias_frag + (long)h * FRAG_ELEMS;
+
+    Vec16<T> padq, padk_v, padv_v;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+        padq.set(e, qkv_bias[h * HD + dv * VEC + e]);
+        padq.set(e, padq.get(e) * scale);
+        padk_v.set(e, qkv_bias[C + h * HD + dv * VEC + e]);
+        padv_v.set(e, qkv_bias[2 * C + h * HD + dv * VEC + e]);
+    }
+
+    const int iters = (Bw + parts - 1) / parts;
+    auto win_of = [&](int it, bool& act) -> int {
+        const int bw = part + it * parts;
+        act = unit_ok && it < iters && bw < Bw;
+        return act ? bw : 0;
+    };
+    auto load_map = [&](int it, int& tok, int& reg) {
+        bool act;
+        const int bw = win_of(it, act);
+        tok = (act && lane < N) ? win2tok[(long)(bw % nW) * N + lane] : -1;
+        reg = (masked && act && lane < N) ? region_ids[(long)(bw % nW) * N + lane] : -1;
+    };
+    struct Win {
+        u32x4_f q[NV], k[NV], v[NV];
+        int ltok[NV];
+        int mytok, myreg, bw;
+        long tok_base;
+        bool active;
+    };
+    auto issue_rows = [&](int it, int mytok, int myreg, Win& x) {
+        x.bw = win_of(it, x.active);
+        x.mytok = mytok;
+        x.myreg = myreg;
+        x.tok_base = (long)(x.bw / nW) * L;
+        const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(qkv + x.tok_base * 3L * C), 0, (int)(L * 3L * C * ES), 0x00020000);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int tok = __shfl(mytok, lrow0 + LSTEP * i, 64);
+            x.ltok[i] = tok;
+            const int vq = tok >= 0 ? tok * 3 * C * ES + dv * 16 : OOB;
+            x.q[i] = __builtin_amdgcn_raw_buffer_load_b128(rq, vq, h * HD * ES, 0);
+            x.k[i] = __builtin_amdgcn_raw_buffer_load_b128(rq, vq, (C + h * HD) * ES, 0);
+            x.v[i] = __builtin_amdgcn_raw_buffer_load_b128(rq, vq, (2 * C + h * HD) * ES, 0);
+        }
+    };
+
+    Win cur, nxt;
+    int tok1, reg1, tok2 = -1, reg2 = -1;
+    load_map(0, tok1, reg1);
+    issue_rows(0, tok1, reg1, cur);
+    load_map(1, tok1, reg1);
+
+    for (int it = 0; it < iters; ++it) {
+        __syncthreads();  // the other wave is done with the previous window's P / V images
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int t = lrow0 + LSTEP * i;
+            const bool padslot = cur.active && t < N && cur.ltok[i] < 0;
+            Vec16<T> xq, xk, xv;
+            xq.v = __builtin_bit_cast(decltype(xq.v), cur.q[i]);
+            xk.v = __builtin_bit_cast(decltype(xk.v), cur.k[i]);
+            xv.v = __builtin_bit_cast(decltype(xv.v), cur.v[i]);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) xq.set(e, xq.get(e) * scale);
+            if (padslot) {
+                xq = padq;
+                xk = padk_v;
+                xv = padv_v;
+            }
+            st16<T>(Qs + t * LDQ + dv * VEC, xq);
+            st16<T>(Ks + t * LDQ + dv * VEC, xk);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) Vt[(dv * VEC + e) * LDP + t] = from_f32<T>(xv.get(e));
+        }
+        const bool active = cur.active;
+        const int mytok = cur.mytok, myreg = cur.myreg;
+        const long tok_base = cur.tok_base;
+        const long unit_wh = (long)cur.bw * nH + h;
+        int stok[NS];
+#pragma unroll
+        for (int i = 0; i < NS; ++i) stok[i] = __shfl(mytok, srow0 + SSTEP * i, 64);
+        __syncthreads();  // images complete
+        issue_rows(it + 1, tok1, reg1, nxt);
+        load_map(it + 2, tok2, reg2);
+
+        f32x4 p[4][2];
+        {
+            Frag<T> kf[4], qf[2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) kf[i] = frag_kc<T>(Ks, LDQ, 16 * i, 0, c, g);
+#pragma unroll
+            for (int jl = 0; jl < 2; ++jl) qf[jl] = frag_kc<T>(Qs, LDQ, 16 * (2 * w + jl), 0, c, g);
+            int rq[2];
+#pragma unroll
+            for (int jl = 0; jl < 2; ++jl) rq[jl] = __shfl(myreg, 16 * (2 * w + jl) + c, 64);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                int rk[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) rk[r] = __shfl(myreg, 16 * i + 4 * g + r, 64);
+#pragma unroll
+                for (int jl = 0; jl < 2; ++jl) {
+                    f32x4 b = *reinterpret_cast<const f32x4*>(bias_f + ((i * 4 + 2 * w + jl) * 64 + lane) * 4);
+                    if (masked) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) b[r] += (rk[r] != rq[jl]) ? -100.f : 0.f;
+                    }
+                    p[i][jl] = b;
+                    mma(kf[i], qf[jl], p[i][jl]);
+                }
+            }
+#pragma unroll
+            for (int jl = 0; jl < 2; ++jl) {
+                float m = -3.0e38f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) m = fmaxf(m, p[i][jl][r]);
+                m = fmaxf(m, __shfl_xor(m, 16, 64));
+                m = fmaxf(m, __shfl_xor(m, 32, 64));
+                float sum = 0.f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float e = __expf(p[i][jl][r] - m);
+                        p[i][jl][r] = e;
+                        sum += e;
+                    }
+                sum += __shfl_xor(sum, 16, 64);
+                sum += __shfl_xor(sum, 32, 64);
+                const float inv = 1.f / sum;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) p[i][jl] *= inv;
+            }
+        }
+        if constexpr (WANT_ATTN) {
+            if (attn_out && active) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int jl = 0; jl < 2; ++jl)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int q = 16 * (2 * w + jl) + c, key = 16 * i + 4 * g + r;
+                            if (q < N && key < N) attn_out[((unit_wh * N) + q) * N + key] = p[i][jl][r];
+                        }
+            }
+        }
+        __syncthreads();  // both waves hold their scores: Q,K may be overlaid by P
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int jl = 0; jl < 2; ++jl) store_frag4<T>(Ps + (16 * (2 * w + jl) + c) * LDP + 16 * i + 4 * g, p[i][jl]);
+        __builtin_amdgcn_wave_barrier();  // P rows of this wave's queries are read back by this wave only
+
+        f32x4 o[2][2];
+#pragma unroll
+        for (int il = 0; il < 2; ++il) {
+            o[il][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+            o[il][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            Frag<T> vf[2];
+            vf[0] = frag_kc<T>(Vt, LDP, 0, 32 * ks, c, g);
+            vf[1] = frag_kc<T>(Vt, LDP, 16, 32 * ks, c, g);
+#pragma unroll
+            for (int il = 0; il < 2; ++il) {
+                const Frag<T> pf = frag_kc<T>(Ps, LDP, 16 * (2 * w + il), 32 * ks, c, g);
+                mma(pf, vf[0], o[il][0]);
+                mma(pf, vf[1], o[il][1]);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        T* Og = Ps + 32 * w * LDP;  // [32][LDQ] over this wave's own (now dead) P rows
+#pragma unroll
+        for (int il = 0; il < 2; ++il)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                Og[(16 * il + 4 * g + r) * LDQ + c] = from_f32<T>(o[il][0][r]);
+                Og[(16 * il + 4 * g + r) * LDQ + 16 + c] = from_f32<T>(o[il][1][r]);
+            }
+        __builtin_amdgcn_wave_barrier();
+        const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(out + tok_base * (long)C, 0, (int)(L * (long)C * ES), 0x00020000);
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            const int tl = lane / VPR + SSTEP * i;
+            const Vec16<T> x = ld16<T>(Og + tl * LDQ + dv * VEC);
+            const int vo = (active && stok[i] >= 0) ? stok[i] * C * ES + dv * 16 : OOB;
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_f, x.v), ro, vo, h * HD * ES, 0);
+        }
+        cur = nxt;
+        tok1 = tok2;
+        reg1 = reg2;
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
 // Backward, second generation (the default).  Same math and the same work split as attn_bwd_kernel (wave = one head x a
 // strided set of windows), rebuilt around what the profile showed the first one to be bound by -- exposed memory
 // latency, block barriers and 2-byte scattered stores, not MFMA:
@@ -1415,7 +1646,7 @@ __global__ void relpos_bias_bwd_kernel(const float* __restrict__ ws, int parts, 
     atomicAdd(dtable + index[qk] * nH + h, s);
 }
 
-static int g_attn_fwd_impl = 2;  // 2: attn_fwd2_kernel (persistent waves, prefetch); 1: attn_fwd_kernel (one window per wave)
+static int g_attn_fwd_impl = 3;  // 3: attn_fwd3_kernel (a window-head per wave pair); 2: attn_fwd2_kernel (persistent waves, prefetch); 1: attn_fwd_kernel
 static int g_attn_bwd_impl = 3;  // 3: attn_bwd3_kernel (bwd2 with a window-head shared by two waves); 2: attn_bwd2_kernel; 1: attn_bwd_kernel
 
 inline int bwd_parts(int Bw, int nH) {
@@ -1527,6 +1758,26 @@ extern "C" int esvit_window_attn_fwd(int dtype, const void* qkv, const float* qk
         if (rc != ESVIT_OK) return rc;
     }
     const int Bw = nB * nW;
+    if (g_attn_fwd_impl == 3 && (long)L * 3 * nH * HD * 4 < 0x7fff0000L) {
+        // persistent wave pairs: 256 CUs x 10 resident two-wave workgroups, one head each, at most one window per pair
+        int parts = (2560 + nH - 1) / nH;
+        if (parts > Bw) parts = Bw;
+        if (dtype == ESVIT_BF16) {
+            const size_t lds = (size_t)AttnCfg<bf16>::FWD_PER_WAVE * sizeof(bf16);
+            auto kern = attn_out ? attn_fwd3_kernel<bf16, true> : attn_fwd3_kernel<bf16, false>;
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(kern, dim3(parts * nH), dim3(128), lds, stream, (const bf16*)qkv, qkv_bias, win2tok, L,
+                               (const float*)bias_frag_ws, region_ids, nW, Bw, N, nH, scale, parts, (bf16*)out, attn_out);
+        } else {
+            const size_t lds = (size_t)AttnCfg<float>::FWD_PER_WAVE * sizeof(float);
+            auto kern = attn_out ? attn_fwd3_kernel<float, true> : attn_fwd3_kernel<float, false>;
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(kern, dim3(parts * nH), dim3(128), lds, stream, (const float*)qkv, qkv_bias, win2tok, L,
+                               (const float*)bias_frag_ws, region_ids, nW, Bw, N, nH, scale, parts, (float*)out, attn_out);
+        }
+        ESVIT_CHECK_LAUNCH("window_attn_fwd(v3)");
+        return ESVIT_OK;
+    }
     if (g_attn_fwd_impl == 2 && (long)L * 3 * nH * HD * 4 < 0x7fff0000L) {
         // persistent waves: 256 CUs x 8 resident waves, one head each, at most one window per wave
         int parts = (2048 + nH - 1) / nH;

@@ -259,7 +259,7 @@ void esvit_debug_set_tr_read(int on);      /* GEMM: ds_read_b64_tr_b16 vs scalar
 void esvit_debug_set_attn_tr_read(int on); /* attention backward: same */
 void esvit_debug_set_attn_bwd_waves(int w); /* attention backward compiled for 2 (256 regs) or 1 (512 regs) waves per SIMD */
 void esvit_debug_set_gemm_dma(int on);     /* GEMM: LDS-DMA main loop (1: by shape, 2: always) vs register-staged main loop (0) */
-void esvit_debug_set_attn_fwd_impl(int v);   /* 7x7 attention forward: 2 (default) persistent prefetching kernel, 1 one window per wave */
+void esvit_debug_set_attn_fwd_impl(int v);   /* 7x7 attention forward: 3 (default) two waves per (window, head), 2 persistent prefetching kernel, 1 one window per wave */
 void esvit_debug_set_attn_bwd_impl(int v);   /* 7x7 attention backward: 3 (default) two waves per (window, head), 2 prefetching one-wave kernel, 1 first generation */
 void esvit_debug_set_gemm_xcdmap(int mode); /* 0 (default): tiles XCD-remapped, split/batch on grid.y; 1: split-K slices / batch items contiguous per XCD */
 void esvit_debug_set_gemm_ws_ablate(int bits); /* PROFILING ONLY (results become garbage): 1 no MFMA loop, 2 no DMA loads, 4 no epilogue */
