@@ -1146,23 +1146,38 @@ __global__ __launch_bounds__(WS_THREADS, 3) void gemm_ws_kernel(const esvit_gemm
     }
 }
 
-// sum split-K partials: out[i] (+)= sum_z part[z*n + i]   (TO = float or the activation dtype)
+// sum split-K partials: out[i] (+)= sum_z part[z*n + i]   (TO = float or the activation dtype).
+// 256 threads = 64 element quads x 4 split slices (slice sl sums z = sl, sl+4, ...), four loads in flight per thread,
+// slices combined through LDS: the 512-way reductions of the 96x96 stage-0 weights were latency-bound at one load in
+// flight and 9 workgroups.
+constexpr int SKR_QUADS = 64, SKR_SLICES = 4;
 template <typename TO>
-__global__ void splitk_reduce_kernel(const float* __restrict__ part, int splits, long n, TO* __restrict__ out, int accumulate) {
-    const long i4 = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
-    if (i4 >= n) return;
-    const int cnt = (int)min(4L, n - i4);
-    float s[4] = {0.f, 0.f, 0.f, 0.f};
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, int splits, long n, TO* __restrict__ out,
+                                                            int accumulate) {
+    __shared__ f32x4 sm[SKR_SLICES][SKR_QUADS];
+    const int q = threadIdx.x & (SKR_QUADS - 1), sl = threadIdx.x / SKR_QUADS;
+    const long i4 = ((long)blockIdx.x * SKR_QUADS + q) * 4;
+    const int cnt = i4 < n ? (int)min(4L, n - i4) : 0;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
     if (cnt == 4) {
-        for (int z = 0; z < splits; ++z) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(part + (long)z * n + i4);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) s[e] += v[e];
+        const float* p = part + i4;
+        int z = sl;
+        for (; z + 3 * SKR_SLICES < splits; z += 4 * SKR_SLICES) {
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(p + (long)z * n);
+            const f32x4 v1 = *reinterpret_cast<const f32x4*>(p + (long)(z + SKR_SLICES) * n);
+            const f32x4 v2 = *reinterpret_cast<const f32x4*>(p + (long)(z + 2 * SKR_SLICES) * n);
+            const f32x4 v3 = *reinterpret_cast<const f32x4*>(p + (long)(z + 3 * SKR_SLICES) * n);
+            s += (v0 + v1) + (v2 + v3);
         }
-    } else {
-        for (int z = 0; z < splits; ++z)
+        for (; z < splits; z += SKR_SLICES) s += *reinterpret_cast<const f32x4*>(p + (long)z * n);
+    } else if (cnt > 0) {
+        for (int z = sl; z < splits; z += SKR_SLICES)
             for (int e = 0; e < cnt; ++e) s[e] += part[(long)z * n + i4 + e];
     }
+    sm[sl][q] = s;
+    __syncthreads();
+    if (sl != 0 || cnt == 0) return;
+    s = (sm[0][q] + sm[1][q]) + (sm[2][q] + sm[3][q]);
     for (int e = 0; e < cnt; ++e) {
         float v = s[e];
         if (accumulate) v += to_f32(out[i4 + e]);
@@ -1193,7 +1208,7 @@ int launch_gemm(const esvit_gemm_desc& d, hipStream_t stream) {
     ESVIT_CHECK_LAUNCH("esvit_gemm");
     if (d.splitk > 1) {
         const long n = (long)d.M * d.N;
-        const int blocks = ceil_div(ceil_div(n, 4), 256);
+        const int blocks = ceil_div(ceil_div(n, 4), SKR_QUADS);
         if (d.out_f32)
             hipLaunchKernelGGL(splitk_reduce_kernel<float>, dim3(blocks), dim3(256), 0, stream, d.partial, d.splitk, n,
                                reinterpret_cast<float*>(d.C), d.accumulate);
@@ -1226,7 +1241,7 @@ int launch_gemm_dma(const esvit_gemm_desc& d, hipStream_t stream) {
     ESVIT_CHECK_LAUNCH("esvit_gemm(dma)");
     if (d.splitk > 1) {
         const long n = (long)d.M * d.N;
-        const int blocks = ceil_div(ceil_div(n, 4), 256);
+        const int blocks = ceil_div(ceil_div(n, 4), SKR_QUADS);
         if (d.out_f32)
             hipLaunchKernelGGL(splitk_reduce_kernel<float>, dim3(blocks), dim3(256), 0, stream, d.partial, d.splitk, n,
                                reinterpret_cast<float*>(d.C), d.accumulate);
@@ -1273,7 +1288,7 @@ int launch_gemm_ws(const esvit_gemm_desc& d, hipStream_t stream) {
     ESVIT_CHECK_LAUNCH("esvit_gemm(ws)");
     if (d.splitk > 1) {
         const long n = (long)d.M * d.N;
-        const int blocks = ceil_div(ceil_div(n, 4), 256);
+        const int blocks = ceil_div(ceil_div(n, 4), SKR_QUADS);
         if (d.out_f32)
             hipLaunchKernelGGL(splitk_reduce_kernel<float>, dim3(blocks), dim3(256), 0, stream, d.partial, d.splitk, n,
                                reinterpret_cast<float*>(d.C), d.accumulate);

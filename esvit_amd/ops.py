@@ -199,9 +199,10 @@ def linear_dgrad(dy, w, *, gelu_preact=None, out_f32=False):
 
 
 def _pick_splitk(rows, Nout, Kin, tiles):
-    """split-K factor for wgrad: ~512 workgroups, >= 512 reduction rows per split, and partial slabs (written + re-read)
-    no larger than the operand traffic"""
-    want = -(-512 // max(tiles, 1))
+    """split-K factor for wgrad: as many workgroups as fit the chip AT ONCE (256 CUs x 2 resident 64-KiB workgroups) and
+    never one more -- every workgroup runs for the whole kernel, so a 513th doubles its duration --, >= 512 reduction
+    rows per split, and partial slabs (written + re-read) no larger than the operand traffic"""
+    want = max(1, 512 // max(tiles, 1))
     by_rows = max(1, rows // 512)
     by_bytes = max(1, (rows * (Nout + Kin) * 2) // (Nout * Kin * 8))
     return int(max(1, min(want, by_rows, by_bytes, 512)))
