@@ -1319,9 +1319,30 @@ int dispatch_pipe(const esvit_gemm_desc& d, hipStream_t stream) {
     return launch_gemm_dma<AKS, BKS, BM, BN, 64, 2>(d, stream);
 }
 
+static int g_tile_m64 = 0;  // 1: use 64-row tiles where 128-row tiles quantise badly over the resident workgroup slots (measured 3 % slower over the step at B = 128: the shorter tile costs more than the 0.58 assumed below -- kept as a switch)
+
+// Every workgroup of a GEMM launch runs about equally long, so the launch takes ceil(tiles / resident slots) rounds:
+// 588 tiles on 512 slots (stage-3 fc2 at B = 128) leave the chip 43 % idle.  Where the 128-row tiling would waste more
+// than a fifth of the last round, 64-row tiles (48 KiB of LDS -> 3 workgroups per CU) give twice as many, shorter,
+// tiles.  Forward / dgrad only: wgrad sizes its grid with split-K instead.
+inline bool prefer_m64(const esvit_gemm_desc& d, int bn) {
+    if (!g_tile_m64 || d.splitk > 1 || d.batch > 1 || d.a_kstrided) return false;
+    const long t128 = (long)ceil_div(d.M, 128) * ceil_div(d.N, bn);
+    const long t64 = (long)ceil_div(d.M, 64) * ceil_div(d.N, bn);
+    const double r128 = (double)((t128 + 511) / 512);          // rounds of full-size tiles
+    const double r64 = (double)((t64 + 767) / 768) * 0.58;     // a 64-row tile costs ~0.58 of a 128-row one
+    return t128 > 256 && r64 < 0.85 * r128;
+}
+
 template <bool AKS, bool BKS>
 int dispatch_tile_dma(const esvit_gemm_desc& d, hipStream_t stream) {
     const bool n96 = (d.N % 96 == 0) && (d.N % 128 != 0);
+    if constexpr (!AKS) {
+        if (g_dma_pipe == 1) {
+            if (n96 && prefer_m64(d, 96)) return launch_gemm_dma<AKS, BKS, 64, 96, 64, 2>(d, stream);
+            if (!n96 && d.N > 64 && prefer_m64(d, 128)) return launch_gemm_dma<AKS, BKS, 64, 128, 64, 2>(d, stream);
+        }
+    }
     if (n96) return dispatch_pipe<AKS, BKS, 128, 96>(d, stream);
     if (d.N <= 64) return dispatch_pipe<AKS, BKS, 128, 64>(d, stream);
     return dispatch_pipe<AKS, BKS, 128, 128>(d, stream);
@@ -1352,6 +1373,7 @@ static int g_use_dma = 1;
 extern "C" void esvit_debug_set_tr_read(int on) { g_use_tr = on; }
 extern "C" void esvit_debug_set_gemm_dma(int on) { g_use_dma = on; }
 extern "C" void esvit_debug_set_gemm_pipe(int mode) { g_dma_pipe = mode; }
+extern "C" void esvit_debug_set_gemm_m64(int on) { g_tile_m64 = on; }
 extern "C" void esvit_debug_set_gemm_xcdmap(int mode) { g_xcd_map = mode; g_ws_zmajor = mode; }
 extern "C" void esvit_debug_set_gemm_ws_ablate(int bits) { g_ws_ablate = bits; }
 // resident workgroups per CU of the persistent kernel's 128x128 tile (LDS-limited: 2 x 80 KiB), for tests / tuning

@@ -57,7 +57,7 @@ def gemm_path(request, mods):
 
 @pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("M,N,K", [(300, 96, 96), (257, 288, 96), (128, 384, 192), (1000, 256, 2048), (64, 64, 48), (520, 1024, 256),
-                                   (777, 2048, 768), (130, 96, 384), (33000, 384, 200)])
+                                   (777, 2048, 768), (130, 96, 384), (33000, 384, 200), (37000, 256, 128)])
 def test_gemm_nt(mods, gemm_path, dt, M, N, K):
     ops, ref = mods
     dev = _dev()
