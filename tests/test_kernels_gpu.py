@@ -71,6 +71,25 @@ def test_gemm_nt(mods, gemm_path, dt, M, N, K):
     _close("nt+res f32", ops.linear_fwd(x, w, b, residual=res, out_f32=True), ref.linear_fwd(x, w, b, residual=res, out_f32=True), _tol(dt, bf=5e-3))
 
 
+def test_gemm_m64_tiles(mods):
+    """the optional 64-row tiling (esvit_debug_set_gemm_m64) on shapes whose 128-row grid quantises badly"""
+    ops, ref = mods
+    dev = _dev()
+    dt = torch.bfloat16
+    ops.lib.esvit_debug_set_gemm_m64(1)
+    try:
+        for M, N, K in ((37000, 256, 128), (40000, 192, 96)):
+            x, w, b = _rand((M, K), dev, 1, dt), _rand((N, K), dev, 2, dt, 0.1), _rand((N,), dev, 3)
+            _close("m64 nt", ops.linear_fwd(x, w, b), ref.linear_fwd(x, w, b), _tol(dt))
+            res = _rand((M, N), dev, 4)
+            _close("m64 nt+res", ops.linear_fwd(x, w, b, residual=res, out_f32=True), ref.linear_fwd(x, w, b, residual=res, out_f32=True),
+                   _tol(dt, bf=5e-3))
+            dy, wd = _rand((M, K), dev, 5, dt), _rand((K, N), dev, 6, dt, 0.1)
+            _close("m64 dgrad", ops.linear_dgrad(dy, wd), ref.linear_dgrad(dy, wd), _tol(dt))
+    finally:
+        ops.lib.esvit_debug_set_gemm_m64(0)
+
+
 @pytest.mark.parametrize("tr", [1, 0])
 @pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("M,N,K", [(300, 96, 384), (257, 192, 576), (1000, 2048, 256), (130, 768, 3072), (40000, 192, 96)])
