@@ -61,7 +61,7 @@ def geometry(H, W, ws, shift, device):
 def _weight(p, shape2d=None):
     """activation-dtype copy of an fp32 parameter; frozen parameters (the EMA teacher) are recast on every
     use because in-place `.data` updates (main_esvit.py:590) are invisible to version counters."""
-    if p.requires_grad:
+    if p.requires_grad or P.is_managed(p):
         return P.cached_cast(p, shape2d)
     src = p.detach() if shape2d is None else p.detach().reshape(shape2d)
     return ops_module().cast_to_act(src.contiguous())

@@ -9,6 +9,18 @@ from . import ops
 
 _GEN = 0
 _CACHE = {}
+_MANAGED = set()   # ids of frozen parameters whose every update goes through the fused updater (the EMA teacher)
+
+
+def manage(p):
+    """Declare that `p` (requires_grad=False) is only ever written by the fused update kernel, which refreshes its
+    cached cast itself; without this, frozen parameters are recast on every use because in-place `.data` updates
+    (main_esvit.py:590) are invisible to version counters."""
+    _MANAGED.add(id(p))
+
+
+def is_managed(p):
+    return id(p) in _MANAGED
 
 
 def invalidate():

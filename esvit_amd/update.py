@@ -91,6 +91,9 @@ class FusedClipAdamWEMA:
                 tab[i, 4] = tp.data_ptr() if tp is not None else 0
                 tab[i, 5] = p.numel()
                 tab[i, 6] = self.group_of[i]
+        for tp in self.teacher_params:
+            if tp is not None and not tp.requires_grad:
+                P.manage(tp)  # the teacher is written by this updater only: its bf16 copies are refreshed in the same kernel
         self._bc_cache = {}
         self._ring_ev = [None] * len(self._ring)
         self._ring_pos = 0
