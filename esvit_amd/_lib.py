@@ -85,6 +85,7 @@ SIGNATURES = {
     "esvit_debug_set_gemm_dma": (None, [C.c_int]),
     "esvit_debug_set_gemm_pipe": (None, [C.c_int]),
     "esvit_debug_set_gemm_m64": (None, [C.c_int]),
+    "esvit_debug_set_gemm_m256": (None, [C.c_int]),
     "esvit_debug_set_attn_bwd_impl": (None, [C.c_int]),
     "esvit_debug_set_attn_fwd_impl": (None, [C.c_int]),
     "esvit_debug_gemm_ws_occupancy": (C.c_int, [C.c_int]),

@@ -819,7 +819,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 // NBUF-deep ring of LDS tiles: NBUF-1 tiles are requested ahead; per k-tile ONE counted wait (only for the tile
 // about to be consumed -- later tiles stay in flight across the barrier) and ONE barrier.
 template <bool AKS, bool BKS, int BM, int BN, int BKD, int NBUF>
-__global__ __launch_bounds__(NTHREADS, 2) void gemm_dma_kernel(const esvit_gemm_desc p) {
+__global__ __launch_bounds__(NTHREADS, (BM >= 256 ? 1 : 2)) void gemm_dma_kernel(const esvit_gemm_desc p) {
     using TA = DmaTile<AKS, BM, BKD>;
     using TB = DmaTile<BKS, BN, BKD>;
     constexpr int WTM = BM / 2, WTN = BN / 2;
@@ -921,15 +921,19 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_dma_kernel(const esvit_gemm_
             for (int i = 0; i < FM; ++i)
 #pragma unroll
                 for (int j = 0; j < FN; ++j) mma(af[i], bfr[j], acc[i][j]);
-            if (do_colsum) {
+            if constexpr (AKS) {  // the fused bias gradient exists for wgrad only: no branch in the fwd / dgrad loops
+                if (do_colsum) {
 #pragma unroll
-                for (int i = 0; i < FM; ++i) mma(af[i], ones, accb[i]);
+                    for (int i = 0; i < FM; ++i) mma(af[i], ones, accb[i]);
+                }
             }
         }
         buf = (buf + 1 == NBUF) ? 0 : buf + 1;
     }
     __syncthreads();  // all waves finished reading the operand tiles before the epilogue reuses the LDS
-    if (do_colsum) store_colsum<FM>(p, accb, m0, wm * WTM, z, c, g);
+    if constexpr (AKS) {
+        if (do_colsum) store_colsum<FM>(p, accb, m0, wm * WTM, z, c, g);
+    }
     gemm_epilogue_bf16<BM, BN, false>(p, acc, smem_raw, m0, n0, z);
 }
 
@@ -1334,10 +1338,18 @@ inline bool prefer_m64(const esvit_gemm_desc& d, int bn) {
     return t128 > 256 && r64 < 0.85 * r128;
 }
 
+static int g_tile_m256 = 0;  // 1: 256-row tiles (wave tile 128 x 64|48, BK = 32) for grids that still fill the chip twice over
+
+inline bool prefer_m256(const esvit_gemm_desc& d, int bn) {
+    if (!g_tile_m256 || d.splitk > 1 || d.batch > 1 || d.a_kstrided || d.K < 256) return false;
+    return (long)ceil_div(d.M, 256) * ceil_div(d.N, bn) >= 1024;
+}
+
 template <bool AKS, bool BKS>
 int dispatch_tile_dma(const esvit_gemm_desc& d, hipStream_t stream) {
     const bool n96 = (d.N % 96 == 0) && (d.N % 128 != 0);
     if constexpr (!AKS) {
+        if (g_dma_pipe == 1 && !n96 && d.N > 64 && prefer_m256(d, 128)) return launch_gemm_dma<AKS, BKS, 256, 128, 32, 2>(d, stream);
         if (g_dma_pipe == 1) {
             if (n96 && prefer_m64(d, 96)) return launch_gemm_dma<AKS, BKS, 64, 96, 64, 2>(d, stream);
             if (!n96 && d.N > 64 && prefer_m64(d, 128)) return launch_gemm_dma<AKS, BKS, 64, 128, 64, 2>(d, stream);
@@ -1374,6 +1386,7 @@ extern "C" void esvit_debug_set_tr_read(int on) { g_use_tr = on; }
 extern "C" void esvit_debug_set_gemm_dma(int on) { g_use_dma = on; }
 extern "C" void esvit_debug_set_gemm_pipe(int mode) { g_dma_pipe = mode; }
 extern "C" void esvit_debug_set_gemm_m64(int on) { g_tile_m64 = on; }
+extern "C" void esvit_debug_set_gemm_m256(int on) { g_tile_m256 = on; }
 extern "C" void esvit_debug_set_gemm_xcdmap(int mode) { g_xcd_map = mode; g_ws_zmajor = mode; }
 extern "C" void esvit_debug_set_gemm_ws_ablate(int bits) { g_ws_ablate = bits; }
 // resident workgroups per CU of the persistent kernel's 128x128 tile (LDS-limited: 2 x 80 KiB), for tests / tuning

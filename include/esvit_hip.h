@@ -264,6 +264,7 @@ void esvit_debug_set_attn_bwd_impl(int v);   /* 7x7 attention backward: 3 (defau
 void esvit_debug_set_gemm_xcdmap(int mode); /* 0 (default): tiles XCD-remapped, split/batch on grid.y; 1: split-K slices / batch items contiguous per XCD */
 void esvit_debug_set_gemm_ws_ablate(int bits); /* PROFILING ONLY (results become garbage): 1 no MFMA loop, 2 no DMA loads, 4 no epilogue */
 int esvit_debug_gemm_ws_occupancy(int lds_bytes); /* resident workgroups / CU of the persistent GEMM at this LDS size */
+void esvit_debug_set_gemm_m256(int on);   /* 1: 256 x 128 x BK32 tiles for large forward / dgrad grids (default 0) */
 void esvit_debug_set_gemm_m64(int on);    /* 1: 64-row tiles where 128-row tiles quantise badly over the resident workgroups (default 0: measured slower) */
 void esvit_debug_set_gemm_pipe(int mode);  /* LDS-DMA pipeline: 1 = BK64 x 2 buffers, 3 = BK64 x 3-deep ring, 4 = BK32 x 4-deep ring */
 

@@ -10,6 +10,8 @@ iters = int(sys.argv[6]) if len(sys.argv) > 6 else 20
 dev = torch.device("cuda:0")
 ops.lib.esvit_debug_set_gemm_pipe(pipe)
 ablate = int(os.environ.get("ABLATE", "0"))
+if os.environ.get("GEMM_M256"):
+    ops.lib.esvit_debug_set_gemm_m256(int(os.environ["GEMM_M256"]))
 if os.environ.get("GEMM_DMA"):
     ops.debug_set_gemm_dma(int(os.environ["GEMM_DMA"]))
 ops.lib.esvit_debug_set_gemm_ws_ablate(ablate)
