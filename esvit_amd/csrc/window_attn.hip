@@ -28,18 +28,21 @@ constexpr int HD = 32;  // head dim
 constexpr int NF = (NP / 16) * (NP / 16);
 constexpr int FRAG_ELEMS = NF * 256;  // floats per (head) or (window) frag-layout matrix
 
-template <typename T>
-struct AttnCfg {
+template <typename T, int HDIM>
+struct AttnCfgH {
     static constexpr int VEC = ElemTraits<T>::VEC;
-    static constexpr int LDQ = HD + VEC;  // [NP][LDQ] images of q, k, v, dO
-    static constexpr int LDP = NP + VEC;  // [NP][LDP] image of P / dS, [HD][LDP] image of V^T
+    static constexpr int LDQ = HDIM + VEC;  // [NP][LDQ] images of q, k, v, dO
+    static constexpr int LDP = NP + VEC;    // [NP][LDP] image of P / dS, [HDIM][LDP] image of V^T
     static constexpr int QK_ELEMS = NP * LDQ;
     static constexpr int P_ELEMS = NP * LDP;
-    static constexpr int VT_ELEMS = HD * LDP;
+    static constexpr int VT_ELEMS = HDIM * LDP;
     static constexpr int R1 = (2 * QK_ELEMS > P_ELEMS) ? 2 * QK_ELEMS : P_ELEMS;  // Q,K overlaid by P
     static constexpr int FWD_PER_WAVE = R1 + VT_ELEMS;
     static constexpr int BWD_PER_WAVE = 2 * QK_ELEMS + P_ELEMS;
+    static constexpr int BWD3_PER_PAIR = 5 * QK_ELEMS + P_ELEMS;  // Q, K, V, dO, out-staging, P/dS
 };
+template <typename T>
+using AttnCfg = AttnCfgH<T, HD>;  // head_dim 32 (Swin); the third-generation kernels also take 64 (CvT: dim / heads)
 
 template <typename T>
 __device__ __forceinline__ void store_frag4(T* p, f32x4 v) {
@@ -657,14 +660,15 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const T* __restrict__
 // 128-thread workgroup): wave w owns query tiles {2w, 2w+1} -- their score columns, softmax, P rows and output rows.
 // Half the registers per wave (three or more waves per SIMD instead of two) and half the dependent chain per window;
 // three two-wave barriers per window.
-template <typename T, bool WANT_ATTN>
-__global__ __launch_bounds__(128, 3) void attn_fwd3_kernel(const T* __restrict__ qkv, const float* __restrict__ qkv_bias,
+template <typename T, bool WANT_ATTN, int HDIM>
+__global__ __launch_bounds__(128, (HDIM == 32 ? 3 : 2)) void attn_fwd3_kernel(const T* __restrict__ qkv, const float* __restrict__ qkv_bias,
                                                           const int* __restrict__ win2tok, int L, const float* __restrict__ bias_frag,
                                                           const int* __restrict__ region_ids, int nW, int Bw, int N, int nH, float scale,
                                                           int parts, T* __restrict__ out, float* __restrict__ attn_out) {
-    using Cfg = AttnCfg<T>;
+    using Cfg = AttnCfgH<T, HDIM>;
+    constexpr int KS = HDIM / 32, DT = HDIM / 16;  // k-steps over the head dim, 16-wide output column tiles
     constexpr int LDQ = Cfg::LDQ, LDP = Cfg::LDP, VEC = Cfg::VEC, ES = sizeof(T);
-    constexpr int VPR = HD / VEC, NV = NP * VPR / 128, LSTEP = 128 / VPR;
+    constexpr int VPR = HDIM / VEC, NV = NP * VPR / 128, LSTEP = 128 / VPR;
     constexpr int NS = 32 * VPR / 64, SSTEP = 64 / VPR;
     constexpr int OOB = 0x7ffffff0;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -680,7 +684,7 @@ __global__ __launch_bounds__(128, 3) void attn_fwd3_kernel(const T* __restrict__
     const bool unit_ok = unit < (long)parts * nH;
     const int h = (int)(unit % nH);
     const int part = (int)(unit / nH);
-    const int C = nH * HD;
+    const int C = nH * HDIM;
     const bool masked = region_ids != nullptr;
     const int lrow0 = tid / VPR, dv = tid % VPR;
     const int srow0 = 32 * w + lane / VPR;
@@ -689,10 +693,10 @@ __global__ __launch_bounds__(128, 3) void attn_fwd3_kernel(const T* __restrict__
     Vec16<T> padq, padk_v, padv_v;
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
-        padq.set(e, qkv_bias[h * HD + dv * VEC + e]);
+        padq.set(e, qkv_bias[h * HDIM + dv * VEC + e]);
         padq.set(e, padq.get(e) * scale);
-        padk_v.set(e, qkv_bias[C + h * HD + dv * VEC + e]);
-        padv_v.set(e, qkv_bias[2 * C + h * HD + dv * VEC + e]);
+        padk_v.set(e, qkv_bias[C + h * HDIM + dv * VEC + e]);
+        padv_v.set(e, qkv_bias[2 * C + h * HDIM + dv * VEC + e]);
     }
 
     const int iters = (Bw + parts - 1) / parts;
@@ -725,9 +729,9 @@ __global__ __launch_bounds__(128, 3) void attn_fwd3_kernel(const T* __restrict__
             const int tok = __shfl(mytok, lrow0 + LSTEP * i, 64);
             x.ltok[i] = tok;
             const int vq = tok >= 0 ? tok * 3 * C * ES + dv * 16 : OOB;
-            x.q[i] = __builtin_amdgcn_raw_buffer_load_b128(rq, vq, h * HD * ES, 0);
-            x.k[i] = __builtin_amdgcn_raw_buffer_load_b128(rq, vq, (C + h * HD) * ES, 0);
-            x.v[i] = __builtin_amdgcn_raw_buffer_load_b128(rq, vq, (2 * C + h * HD) * ES, 0);
+            x.q[i] = __builtin_amdgcn_raw_buffer_load_b128(rq, vq, h * HDIM * ES, 0);
+            x.k[i] = __builtin_amdgcn_raw_buffer_load_b128(rq, vq, (C + h * HDIM) * ES, 0);
+            x.v[i] = __builtin_amdgcn_raw_buffer_load_b128(rq, vq, (2 * C + h * HDIM) * ES, 0);
         }
     };
 
@@ -772,11 +776,14 @@ __global__ __launch_bounds__(128, 3) void attn_fwd3_kernel(const T* __restrict__
 
         f32x4 p[4][2];
         {
-            Frag<T> kf[4], qf[2];
+            Frag<T> kf[4][KS], qf[2][KS];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) kf[i] = frag_kc<T>(Ks, LDQ, 16 * i, 0, c, g);
+            for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
-            for (int jl = 0; jl < 2; ++jl) qf[jl] = frag_kc<T>(Qs, LDQ, 16 * (2 * w + jl), 0, c, g);
+                for (int i = 0; i < 4; ++i) kf[i][ks] = frag_kc<T>(Ks, LDQ, 16 * i, 32 * ks, c, g);
+#pragma unroll
+                for (int jl = 0; jl < 2; ++jl) qf[jl][ks] = frag_kc<T>(Qs, LDQ, 16 * (2 * w + jl), 32 * ks, c, g);
+            }
             int rq[2];
 #pragma unroll
             for (int jl = 0; jl < 2; ++jl) rq[jl] = __shfl(myreg, 16 * (2 * w + jl) + c, 64);
@@ -793,7 +800,8 @@ __global__ __launch_bounds__(128, 3) void attn_fwd3_kernel(const T* __restrict__
                         for (int r = 0; r < 4; ++r) b[r] += (rk[r] != rq[jl]) ? -100.f : 0.f;
                     }
                     p[i][jl] = b;
-                    mma(kf[i], qf[jl], p[i][jl]);
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) mma(kf[i][ks], qf[jl][ks], p[i][jl]);
                 }
             }
 #pragma unroll
@@ -841,22 +849,21 @@ __global__ __launch_bounds__(128, 3) void attn_fwd3_kernel(const T* __restrict__
             for (int jl = 0; jl < 2; ++jl) store_frag4<T>(Ps + (16 * (2 * w + jl) + c) * LDP + 16 * i + 4 * g, p[i][jl]);
         __builtin_amdgcn_wave_barrier();  // P rows of this wave's queries are read back by this wave only
 
-        f32x4 o[2][2];
+        f32x4 o[2][DT];
 #pragma unroll
-        for (int il = 0; il < 2; ++il) {
-            o[il][0] = f32x4{0.f, 0.f, 0.f, 0.f};
-            o[il][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
+        for (int il = 0; il < 2; ++il)
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            Frag<T> vf[2];
-            vf[0] = frag_kc<T>(Vt, LDP, 0, 32 * ks, c, g);
-            vf[1] = frag_kc<T>(Vt, LDP, 16, 32 * ks, c, g);
+            for (int dt = 0; dt < DT; ++dt) o[il][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {  // 64 keys = two 32-deep steps
+            Frag<T> vf[DT];
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) vf[dt] = frag_kc<T>(Vt, LDP, 16 * dt, 32 * ks, c, g);
 #pragma unroll
             for (int il = 0; il < 2; ++il) {
                 const Frag<T> pf = frag_kc<T>(Ps, LDP, 16 * (2 * w + il), 32 * ks, c, g);
-                mma(pf, vf[0], o[il][0]);
-                mma(pf, vf[1], o[il][1]);
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) mma(pf, vf[dt], o[il][dt]);
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -864,10 +871,9 @@ __global__ __launch_bounds__(128, 3) void attn_fwd3_kernel(const T* __restrict__
 #pragma unroll
         for (int il = 0; il < 2; ++il)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                Og[(16 * il + 4 * g + r) * LDQ + c] = from_f32<T>(o[il][0][r]);
-                Og[(16 * il + 4 * g + r) * LDQ + 16 + c] = from_f32<T>(o[il][1][r]);
-            }
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) Og[(16 * il + 4 * g + r) * LDQ + 16 * dt + c] = from_f32<T>(o[il][dt][r]);
         __builtin_amdgcn_wave_barrier();
         const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(out + tok_base * (long)C, 0, (int)(L * (long)C * ES), 0x00020000);
 #pragma unroll
@@ -875,7 +881,7 @@ __global__ __launch_bounds__(128, 3) void attn_fwd3_kernel(const T* __restrict__
             const int tl = lane / VPR + SSTEP * i;
             const Vec16<T> x = ld16<T>(Og + tl * LDQ + dv * VEC);
             const int vo = (active && stok[i] >= 0) ? stok[i] * C * ES + dv * 16 : OOB;
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_f, x.v), ro, vo, h * HD * ES, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_f, x.v), ro, vo, h * HDIM * ES, 0);
         }
         cur = nxt;
         tok1 = tok2;
@@ -1247,16 +1253,17 @@ __global__ __launch_bounds__(WAVES * 64, 1) void attn_bwd2_kernel(const T* __res
 // footprint (<= 256 VGPRs -> two waves per SIMD) and its dependent instruction chains, at the price of five
 // two-wave barriers per window.  Wave w owns query tiles {2w, 2w+1} for P, dS, dQ and the bias gradient, and key
 // tiles {2w, 2w+1} for dK and dV; everything else (prefetch, buffer loads / stores, pad-slot sums) is as in bwd2.
-template <typename T, bool USE_TR>
-__global__ __launch_bounds__(128, 2) void attn_bwd3_kernel(const T* __restrict__ qkv, const float* __restrict__ qkv_bias,
+template <typename T, bool USE_TR, int HDIM>
+__global__ __launch_bounds__(128, (HDIM == 32 ? 2 : 1)) void attn_bwd3_kernel(const T* __restrict__ qkv, const float* __restrict__ qkv_bias,
                                                           const int* __restrict__ win2tok, int L, const T* __restrict__ dout,
                                                           const float* __restrict__ bias_frag, const int* __restrict__ region_ids,
                                                           int nW, int Bw, int N, int nH, float scale, int parts,
                                                           T* __restrict__ dqkv, float* __restrict__ dbias_ws,
                                                           float* __restrict__ dpad_ws) {
-    using Cfg = AttnCfg<T>;
+    using Cfg = AttnCfgH<T, HDIM>;
+    constexpr int KS = HDIM / 32, DT = HDIM / 16;  // k-steps over the head dim, 16-wide output column tiles
     constexpr int LDQ = Cfg::LDQ, LDP = Cfg::LDP, VEC = Cfg::VEC, ES = sizeof(T);
-    constexpr int VPR = HD / VEC;          // 16-byte vectors per [slot][HD] row
+    constexpr int VPR = HDIM / VEC;          // 16-byte vectors per [slot][HDIM] row
     constexpr int NV = NP * VPR / 128;     // row vectors per thread per matrix (loads: 128 threads cover 64 slots)
     constexpr int LSTEP = 128 / VPR;       // slot stride between a thread's load vectors
     constexpr int NS = 32 * VPR / 64;      // row vectors per lane per 32-row output tile (stores)
@@ -1277,7 +1284,7 @@ __global__ __launch_bounds__(128, 2) void attn_bwd3_kernel(const T* __restrict__
     const bool unit_ok = unit < (long)parts * nH;
     const int h = (int)(unit % nH);
     const int part = (int)(unit / nH);
-    const int C = nH * HD;
+    const int C = nH * HDIM;
     const bool masked = region_ids != nullptr;
     const int lrow0 = tid / VPR, dv = tid % VPR;         // load rows: lrow0 + LSTEP*i
     const int srow0 = 32 * w + lane / VPR;                // store rows: srow0 + SSTEP*i  (dv is the same: 64 % VPR == 0)
@@ -1293,10 +1300,10 @@ __global__ __launch_bounds__(128, 2) void attn_bwd3_kernel(const T* __restrict__
     Vec16<T> padq, padk_v, padv_v;
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
-        padq.set(e, qkv_bias[h * HD + dv * VEC + e]);
+        padq.set(e, qkv_bias[h * HDIM + dv * VEC + e]);
         padq.set(e, padq.get(e) * scale);
-        padk_v.set(e, qkv_bias[C + h * HD + dv * VEC + e]);
-        padv_v.set(e, qkv_bias[2 * C + h * HD + dv * VEC + e]);
+        padk_v.set(e, qkv_bias[C + h * HDIM + dv * VEC + e]);
+        padv_v.set(e, qkv_bias[2 * C + h * HDIM + dv * VEC + e]);
     }
     f32x4 db[4][2];
 #pragma unroll
@@ -1339,10 +1346,10 @@ __global__ __launch_bounds__(128, 2) void attn_bwd3_kernel(const T* __restrict__
             x.ltok[i] = tok;
             const int vq = tok >= 0 ? tok * 3 * C * ES + dv * 16 : OOB;
             const int vo = tok >= 0 ? tok * C * ES + dv * 16 : OOB;
-            x.q[i] = __builtin_amdgcn_raw_buffer_load_b128(rq, vq, h * HD * ES, 0);
-            x.k[i] = __builtin_amdgcn_raw_buffer_load_b128(rq, vq, (C + h * HD) * ES, 0);
-            x.v[i] = __builtin_amdgcn_raw_buffer_load_b128(rq, vq, (2 * C + h * HD) * ES, 0);
-            x.o[i] = __builtin_amdgcn_raw_buffer_load_b128(ro, vo, h * HD * ES, 0);
+            x.q[i] = __builtin_amdgcn_raw_buffer_load_b128(rq, vq, h * HDIM * ES, 0);
+            x.k[i] = __builtin_amdgcn_raw_buffer_load_b128(rq, vq, (C + h * HDIM) * ES, 0);
+            x.v[i] = __builtin_amdgcn_raw_buffer_load_b128(rq, vq, (2 * C + h * HDIM) * ES, 0);
+            x.o[i] = __builtin_amdgcn_raw_buffer_load_b128(ro, vo, h * HDIM * ES, 0);
         }
     };
 
@@ -1388,11 +1395,14 @@ __global__ __launch_bounds__(128, 2) void attn_bwd3_kernel(const T* __restrict__
         // ---- phase 1: this wave's two query tiles of P ----
         {
             f32x4 p[4][2];
-            Frag<T> kf[4], qf[2];
+            Frag<T> kf[4][KS], qf[2][KS];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) kf[i] = frag_kc<T>(Ks, LDQ, 16 * i, 0, c, g);
+            for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
-            for (int jl = 0; jl < 2; ++jl) qf[jl] = frag_kc<T>(Qs, LDQ, 16 * (2 * w + jl), 0, c, g);
+                for (int i = 0; i < 4; ++i) kf[i][ks] = frag_kc<T>(Ks, LDQ, 16 * i, 32 * ks, c, g);
+#pragma unroll
+                for (int jl = 0; jl < 2; ++jl) qf[jl][ks] = frag_kc<T>(Qs, LDQ, 16 * (2 * w + jl), 32 * ks, c, g);
+            }
             int rq[2];
 #pragma unroll
             for (int jl = 0; jl < 2; ++jl) rq[jl] = __shfl(myreg, 16 * (2 * w + jl) + c, 64);
@@ -1409,7 +1419,8 @@ __global__ __launch_bounds__(128, 2) void attn_bwd3_kernel(const T* __restrict__
                         for (int r = 0; r < 4; ++r) b[r] += (rk[r] != rq[jl]) ? -100.f : 0.f;
                     }
                     p[i][jl] = b;
-                    mma(kf[i], qf[jl], p[i][jl]);
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) mma(kf[i][ks], qf[jl][ks], p[i][jl]);
                 }
             }
 #pragma unroll
@@ -1442,16 +1453,15 @@ __global__ __launch_bounds__(128, 2) void attn_bwd3_kernel(const T* __restrict__
         }
         __syncthreads();  // P complete (both waves' query tiles)
 
-        // 32 result rows (slots 32w .. 32w+31) x HD: LDS transpose, 16-byte row stores, pad-slot rows into `padacc`
-        auto emit = [&](const f32x4 (&acc)[2][2], float mul, int col0, float* padacc) {
+        // 32 result rows (slots 32w .. 32w+31) x HDIM: LDS transpose, 16-byte row stores, pad-slot rows into `padacc`
+        auto emit = [&](const f32x4 (&acc)[2][DT], float mul, int col0, float* padacc) {
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int il = 0; il < 2; ++il)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    Sg[(16 * il + 4 * g + r) * LDQ + c] = from_f32<T>(acc[il][0][r] * mul);
-                    Sg[(16 * il + 4 * g + r) * LDQ + 16 + c] = from_f32<T>(acc[il][1][r] * mul);
-                }
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int dt = 0; dt < DT; ++dt) Sg[(16 * il + 4 * g + r) * LDQ + 16 * dt + c] = from_f32<T>(acc[il][dt][r] * mul);
             __builtin_amdgcn_wave_barrier();
             const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(dqkv + tok_base * 3L * C, 0, (int)(L * 3L * C * ES), 0x00020000);
 #pragma unroll
@@ -1460,7 +1470,7 @@ __global__ __launch_bounds__(128, 2) void attn_bwd3_kernel(const T* __restrict__
                 const int t = 32 * w + tl;
                 const Vec16<T> x = ld16<T>(Sg + tl * LDQ + dv * VEC);
                 const int vo = (active && stok[i] >= 0) ? stok[i] * 3 * C * ES + dv * 16 : OOB;
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, x.v), rd, vo, (col0 + h * HD) * ES, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, x.v), rd, vo, (col0 + h * HDIM) * ES, 0);
                 if (padacc && active && t < N && stok[i] < 0) {
 #pragma unroll
                     for (int e = 0; e < VEC; ++e) padacc[e] += x.get(e);
@@ -1470,21 +1480,21 @@ __global__ __launch_bounds__(128, 2) void attn_bwd3_kernel(const T* __restrict__
 
         // ---- phase 2: dV rows of this wave's key tiles = P^T dO (all queries) ----
         {
-            f32x4 acc[2][2];
+            f32x4 acc[2][DT];
 #pragma unroll
-            for (int il = 0; il < 2; ++il) {
-                acc[il][0] = f32x4{0.f, 0.f, 0.f, 0.f};
-                acc[il][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-            }
+            for (int il = 0; il < 2; ++il)
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                const Frag<T> b0 = frag_ks<T, USE_TR>(Os, LDQ, 0, 32 * ks, c, g);
-                const Frag<T> b1 = frag_ks<T, USE_TR>(Os, LDQ, 16, 32 * ks, c, g);
+                for (int dt = 0; dt < DT; ++dt) acc[il][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {  // reduction over the 64 queries
+                Frag<T> bo[DT];
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) bo[dt] = frag_ks<T, USE_TR>(Os, LDQ, 16 * dt, 32 * ks, c, g);
 #pragma unroll
                 for (int il = 0; il < 2; ++il) {
                     const Frag<T> a = frag_ks<T, USE_TR>(Ps, LDP, 16 * (2 * w + il), 32 * ks, c, g);
-                    mma(a, b0, acc[il][0]);
-                    mma(a, b1, acc[il][1]);
+#pragma unroll
+                    for (int dt = 0; dt < DT; ++dt) mma(a, bo[dt], acc[il][dt]);
                 }
             }
             emit(acc, 1.f, 2 * C, padv);
@@ -1492,19 +1502,24 @@ __global__ __launch_bounds__(128, 2) void attn_bwd3_kernel(const T* __restrict__
         __syncthreads();  // both waves have read P: its rows may now be overwritten with dS
         // ---- dP^T = V dO^T and dS = P o (dP - delta) for this wave's query tiles ----
         {
-            Frag<T> vf[4];
+            Frag<T> vf[4][KS];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) vf[i] = frag_kc<T>(Vs, LDQ, 16 * i, 0, c, g);
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) vf[i][ks] = frag_kc<T>(Vs, LDQ, 16 * i, 32 * ks, c, g);
 #pragma unroll
             for (int jl = 0; jl < 2; ++jl) {
                 const int j = 2 * w + jl;
-                const Frag<T> of = frag_kc<T>(Os, LDQ, 16 * j, 0, c, g);
+                Frag<T> of[KS];
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) of[ks] = frag_kc<T>(Os, LDQ, 16 * j, 32 * ks, c, g);
                 f32x4 dpj[4], pj[4];
                 float d = 0.f;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     dpj[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    mma(vf[i], of, dpj[i]);
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) mma(vf[i][ks], of[ks], dpj[i]);
                     pj[i] = load_frag4<T>(Ps + (16 * j + c) * LDP + 16 * i + 4 * g);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) d += pj[i][r] * dpj[i][r];
@@ -1523,28 +1538,31 @@ __global__ __launch_bounds__(128, 2) void attn_bwd3_kernel(const T* __restrict__
 
         // ---- phase 3: dQ rows of this wave's query tiles = scale dS K;  dK rows of its key tiles = dS^T (scale q) ----
         {
-            f32x4 aq[2][2], ak[2][2];
+            f32x4 aq[2][DT], ak[2][DT];
 #pragma unroll
-            for (int il = 0; il < 2; ++il) {
-                aq[il][0] = f32x4{0.f, 0.f, 0.f, 0.f};
-                aq[il][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-                ak[il][0] = f32x4{0.f, 0.f, 0.f, 0.f};
-                ak[il][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-            }
+            for (int il = 0; il < 2; ++il)
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                const Frag<T> kb0 = frag_ks<T, USE_TR>(Ks, LDQ, 0, 32 * ks, c, g);
-                const Frag<T> kb1 = frag_ks<T, USE_TR>(Ks, LDQ, 16, 32 * ks, c, g);
-                const Frag<T> qb0 = frag_ks<T, USE_TR>(Qs, LDQ, 0, 32 * ks, c, g);
-                const Frag<T> qb1 = frag_ks<T, USE_TR>(Qs, LDQ, 16, 32 * ks, c, g);
+                for (int dt = 0; dt < DT; ++dt) {
+                    aq[il][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    ak[il][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {  // reduction over the 64 keys (dQ) / the 64 queries (dK)
+                Frag<T> kb[DT], qb[DT];
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) {
+                    kb[dt] = frag_ks<T, USE_TR>(Ks, LDQ, 16 * dt, 32 * ks, c, g);
+                    qb[dt] = frag_ks<T, USE_TR>(Qs, LDQ, 16 * dt, 32 * ks, c, g);
+                }
 #pragma unroll
                 for (int il = 0; il < 2; ++il) {
                     const Frag<T> a = frag_kc<T>(Ps, LDP, 16 * (2 * w + il), 32 * ks, c, g);
-                    mma(a, kb0, aq[il][0]);
-                    mma(a, kb1, aq[il][1]);
                     const Frag<T> at = frag_ks<T, USE_TR>(Ps, LDP, 16 * (2 * w + il), 32 * ks, c, g);
-                    mma(at, qb0, ak[il][0]);
-                    mma(at, qb1, ak[il][1]);
+#pragma unroll
+                    for (int dt = 0; dt < DT; ++dt) {
+                        mma(a, kb[dt], aq[il][dt]);
+                        mma(at, qb[dt], ak[il][dt]);
+                    }
                 }
             }
             emit(aq, scale, 0, nullptr);
@@ -1572,18 +1590,18 @@ __global__ __launch_bounds__(128, 2) void attn_bwd3_kernel(const T* __restrict__
         }
     }
     __syncthreads();
-    float* red = reinterpret_cast<float*>(smem_raw);  // [2 waves][k|v][HD]
+    float* red = reinterpret_cast<float*>(smem_raw);  // [2 waves][k|v][HDIM]
     if (lane < VPR) {
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
-            red[(w * 2 + 0) * HD + dv * VEC + e] = padk[e];
-            red[(w * 2 + 1) * HD + dv * VEC + e] = padv[e];
+            red[(w * 2 + 0) * HDIM + dv * VEC + e] = padk[e];
+            red[(w * 2 + 1) * HDIM + dv * VEC + e] = padv[e];
         }
     }
     __syncthreads();
-    if (unit_ok && tid < 2 * HD) {
-        const int kv = tid / HD, d = tid % HD;
-        dpad_ws[(long)part * 2 * C + kv * C + h * HD + d] = red[(0 * 2 + kv) * HD + d] + red[(1 * 2 + kv) * HD + d];
+    if (unit_ok && tid < 2 * HDIM) {
+        const int kv = tid / HDIM, d = tid % HDIM;
+        dpad_ws[(long)part * 2 * C + kv * C + h * HDIM + d] = red[(0 * 2 + kv) * HDIM + d] + red[(1 * 2 + kv) * HDIM + d];
     }
 }
 
@@ -1749,7 +1767,7 @@ extern "C" int esvit_window_attn_fwd(int dtype, const void* qkv, const float* qk
     STREAM(s_);
     ESVIT_CHECK_ARG(qkv && qkv_bias && win2tok && rel_table && out && nB > 0 && nW > 0 && nH > 0 && L > 0 && ws > 0 && N == ws * ws,
                     "esvit_window_attn_fwd: bad args");
-    ESVIT_CHECK_ARG(hd == HD, "esvit_window_attn_fwd: head_dim %d unsupported (32 only)", hd);
+    ESVIT_CHECK_ARG(hd == HD || (hd == 64 && N <= NP), "esvit_window_attn_fwd: head_dim %d unsupported (32, or 64 with N <= 64)", hd);
     ESVIT_CHECK_ARG(dtype == ESVIT_BF16 || dtype == ESVIT_F32, "esvit_window_attn_fwd: bad dtype");
     if (N > NP) return esvit_big_attn_fwd(dtype, qkv, qkv_bias, win2tok, L, rel_table, ws, region_ids, nW, nB, N, nH, scale, out, lse, attn_out, stream);
     ESVIT_CHECK_ARG(bias_frag_ws != nullptr, "esvit_window_attn_fwd: 7x7 windows need the bias_frag_ws scratch");
@@ -1758,23 +1776,25 @@ extern "C" int esvit_window_attn_fwd(int dtype, const void* qkv, const float* qk
         if (rc != ESVIT_OK) return rc;
     }
     const int Bw = nB * nW;
-    if (g_attn_fwd_impl == 3 && (long)L * 3 * nH * HD * 4 < 0x7fff0000L) {
+    ESVIT_CHECK_ARG((long)L * 3 * nH * hd * 4 < 0x7fff0000L || hd == HD, "esvit_window_attn_fwd: image too large for head_dim 64");
+    if ((g_attn_fwd_impl == 3 || hd != HD) && (long)L * 3 * nH * hd * 4 < 0x7fff0000L) {
         // persistent wave pairs: 256 CUs x 10 resident two-wave workgroups, one head each, at most one window per pair
-        int parts = (2560 + nH - 1) / nH;
+        int parts = ((hd == HD ? 2560 : 1024) + nH - 1) / nH;
         if (parts > Bw) parts = Bw;
+#define LAUNCH_FWD3(TT, HH)                                                                                                     \
+    {                                                                                                                           \
+        const size_t lds = (size_t)AttnCfgH<TT, HH>::FWD_PER_WAVE * sizeof(TT);                                                 \
+        auto kern = attn_out ? attn_fwd3_kernel<TT, true, HH> : attn_fwd3_kernel<TT, false, HH>;                                \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);   \
+        hipLaunchKernelGGL(kern, dim3(parts * nH), dim3(128), lds, stream, (const TT*)qkv, qkv_bias, win2tok, L,                \
+                           (const float*)bias_frag_ws, region_ids, nW, Bw, N, nH, scale, parts, (TT*)out, attn_out);            \
+    }
         if (dtype == ESVIT_BF16) {
-            const size_t lds = (size_t)AttnCfg<bf16>::FWD_PER_WAVE * sizeof(bf16);
-            auto kern = attn_out ? attn_fwd3_kernel<bf16, true> : attn_fwd3_kernel<bf16, false>;
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL(kern, dim3(parts * nH), dim3(128), lds, stream, (const bf16*)qkv, qkv_bias, win2tok, L,
-                               (const float*)bias_frag_ws, region_ids, nW, Bw, N, nH, scale, parts, (bf16*)out, attn_out);
+            if (hd == HD) LAUNCH_FWD3(bf16, 32) else LAUNCH_FWD3(bf16, 64)
         } else {
-            const size_t lds = (size_t)AttnCfg<float>::FWD_PER_WAVE * sizeof(float);
-            auto kern = attn_out ? attn_fwd3_kernel<float, true> : attn_fwd3_kernel<float, false>;
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL(kern, dim3(parts * nH), dim3(128), lds, stream, (const float*)qkv, qkv_bias, win2tok, L,
-                               (const float*)bias_frag_ws, region_ids, nW, Bw, N, nH, scale, parts, (float*)out, attn_out);
+            if (hd == HD) LAUNCH_FWD3(float, 32) else LAUNCH_FWD3(float, 64)
         }
+#undef LAUNCH_FWD3
         ESVIT_CHECK_LAUNCH("window_attn_fwd(v3)");
         return ESVIT_OK;
     }
@@ -1825,7 +1845,7 @@ extern "C" int esvit_window_attn_bwd(int dtype, const void* qkv, const float* qk
     ESVIT_CHECK_ARG(qkv && qkv_bias && win2tok && dout && rel_table && dqkv && dbias_ws && dpad_ws && nB > 0 && nW > 0 && nH > 0 && L > 0 &&
                         ws > 0 && N == ws * ws,
                     "esvit_window_attn_bwd: bad args");
-    ESVIT_CHECK_ARG(hd == HD, "esvit_window_attn_bwd: head_dim %d unsupported (32 only)", hd);
+    ESVIT_CHECK_ARG(hd == HD || (hd == 64 && N <= NP), "esvit_window_attn_bwd: head_dim %d unsupported (32, or 64 with N <= 64)", hd);
     ESVIT_CHECK_ARG(dtype == ESVIT_BF16 || dtype == ESVIT_F32, "esvit_window_attn_bwd: bad dtype");
     if (N > NP)
         return esvit_big_attn_bwd(dtype, g_attn_use_tr, qkv, qkv_bias, win2tok, L, dout, fwd_out, lse, rel_table, ws, region_ids, nW, nB, N, nH,
@@ -1837,20 +1857,25 @@ extern "C" int esvit_window_attn_bwd(int dtype, const void* qkv, const float* qk
     }
     const int Bw = nB * nW;
     const int parts = bwd_parts(Bw, nH);
-    if (g_attn_bwd_impl == 3 && (long)L * 3 * nH * HD * 4 < 0x7fff0000L) {
-#define LAUNCH_BWD3(TT, TR)                                                                                                     \
+    ESVIT_CHECK_ARG((long)L * 3 * nH * hd * 4 < 0x7fff0000L || hd == HD, "esvit_window_attn_bwd: image too large for head_dim 64");
+    if ((g_attn_bwd_impl == 3 || hd != HD) && (long)L * 3 * nH * hd * 4 < 0x7fff0000L) {
+#define LAUNCH_BWD3(TT, TR, HH)                                                                                                     \
     {                                                                                                                           \
-        const size_t lds = (size_t)Bwd2Cfg<TT>::PER_WAVE * sizeof(TT);                                                          \
-        auto kern = attn_bwd3_kernel<TT, TR>;                                                                                   \
+        const size_t lds = (size_t)AttnCfgH<TT, HH>::BWD3_PER_PAIR * sizeof(TT);                                                 \
+        auto kern = attn_bwd3_kernel<TT, TR, HH>;                                                                                   \
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);   \
         hipLaunchKernelGGL(kern, dim3(parts * nH), dim3(128), lds, stream, (const TT*)qkv, qkv_bias, win2tok, L,                \
                            (const TT*)dout, (const float*)bias_frag_ws, region_ids, nW, Bw, N, nH, scale, parts, (TT*)dqkv,     \
                            dbias_ws, dpad_ws);                                                                                  \
     }
         if (dtype == ESVIT_BF16) {
-            if (g_attn_use_tr) LAUNCH_BWD3(bf16, true) else LAUNCH_BWD3(bf16, false)
+            if (hd == HD) {
+                if (g_attn_use_tr) LAUNCH_BWD3(bf16, true, 32) else LAUNCH_BWD3(bf16, false, 32)
+            } else {
+                LAUNCH_BWD3(bf16, true, 64)
+            }
         } else {
-            LAUNCH_BWD3(float, false)
+            if (hd == HD) LAUNCH_BWD3(float, false, 32) else LAUNCH_BWD3(float, false, 64)
         }
 #undef LAUNCH_BWD3
         ESVIT_CHECK_LAUNCH("window_attn_bwd(v3)");

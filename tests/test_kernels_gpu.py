@@ -253,13 +253,16 @@ def test_small_ops(mods, dt):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
-@pytest.mark.parametrize("ws,nH,H,shift", [(7, 3, 14, 3), (7, 3, 12, 3), (7, 6, 12, 0), (7, 12, 6, 3), (7, 24, 3, 0), (7, 6, 7, 0),
-                                           (14, 3, 28, 7), (14, 3, 24, 7), (14, 6, 12, 7), (14, 4, 14, 0), (14, 2, 6, 0)])
-def test_window_attention(mods, dt, ws, nH, H, shift):
+@pytest.mark.parametrize("ws,nH,H,shift,hd", [(7, 3, 14, 3, 32), (7, 3, 12, 3, 32), (7, 6, 12, 0, 32), (7, 12, 6, 3, 32), (7, 24, 3, 0, 32),
+                                              (7, 6, 7, 0, 32), (14, 3, 28, 7, 32), (14, 3, 24, 7, 32), (14, 6, 12, 7, 32), (14, 4, 14, 0, 32),
+                                              (14, 2, 6, 0, 32),
+                                              # head_dim 64 (CvT: dim / heads): 7x7 windows, and the 6x6 / 3x3 windows of 96^2 crops
+                                              (7, 1, 14, 0, 64), (7, 3, 12, 3, 64), (6, 6, 6, 0, 64), (3, 12, 3, 0, 64), (7, 3, 28, 0, 64)])
+def test_window_attention(mods, dt, ws, nH, H, shift, hd):
     """token-ordered attention over every padded / shifted geometry class of 224 and 96 crops, 7x7 and 14x14 windows"""
     ops, ref = mods
     dev = _dev()
-    N, hd = ws * ws, 32
+    N = ws * ws
     C = nH * hd
     nB, L = 3, H * H
     win2tok_np, _ = ops.window_maps(H, H, ws, shift)
@@ -270,7 +273,7 @@ def test_window_attention(mods, dt, ws, nH, H, shift):
     trows = (2 * ws - 1) ** 2
     table = _rand((trows, nH), dev, 51) * 0.5
     index = torch.from_numpy(ops.relative_position_index(ws)).to(dev)
-    if ws == 7:
+    if ws == 7 and hd == 32:
         bias = ops.relpos_bias_fwd(table, index, N)
         _close("bias frag", bias.clamp(min=-1e4), ref.relpos_bias_fwd(table, index, N).clamp(min=-1e4), 1e-6)
     mask_frag = None
