@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libesvit_hip.so")
 
 F32, BF16 = 0, 1
-EPI_NONE, EPI_GELU, EPI_GELU_BWD = 0, 1, 2
+EPI_NONE, EPI_GELU, EPI_GELU_BWD, EPI_QGELU, EPI_QGELU_BWD = 0, 1, 2, 3, 4
 
 vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
@@ -44,6 +44,15 @@ SIGNATURES = {
     "esvit_gemm": (C.c_int, [C.c_int, C.POINTER(GemmDesc), vp]),
     "esvit_layernorm_fwd": (C.c_int, [C.c_int, vp, vp, vp, f32, i64, C.c_int, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp]),
     "esvit_layernorm_bwd_blocks": (C.c_int, [i64, C.c_int]),
+    "esvit_conv_im2col": (C.c_int, [C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                    C.c_int, vp, vp]),
+    "esvit_conv_col2im": (C.c_int, [C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                    vp, vp]),
+    "esvit_dwconv3x3": (C.c_int, [C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
+    "esvit_col_reduce_blocks": (C.c_int, [i64]),
+    "esvit_dwconv3x3_wgrad": (C.c_int, [C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp]),
+    "esvit_col_sums2": (C.c_int, [C.c_int, vp, vp, i64, C.c_int, vp, vp, vp]),
+    "esvit_col_affine2": (C.c_int, [C.c_int, vp, vp, i64, C.c_int, vp, vp, vp, vp, vp]),
     "esvit_layernorm_bwd": (C.c_int, [C.c_int, vp, vp, vp, vp, vp, vp, i64, C.c_int, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp]),
     "esvit_gather_cast": (C.c_int, [C.c_int, vp, vp, i64, C.c_int, vp, C.c_int, C.c_int, vp, C.c_int, vp]),
     "esvit_cast_f32_to": (C.c_int, [C.c_int, vp, vp, i64, vp]),

@@ -169,6 +169,13 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
     return cdf + x * pdf;
 }
 
+// QuickGELU of the CvT feed-forward (cvt_v4_transformer.py:44-46) and its derivative
+__device__ __forceinline__ float qgelu_f(float x) { return x * __builtin_amdgcn_rcpf(1.f + __expf(-1.702f * x)); }
+__device__ __forceinline__ float qgelu_grad_f(float x) {
+    const float s = __builtin_amdgcn_rcpf(1.f + __expf(-1.702f * x));
+    return s * (1.f + 1.702f * x * (1.f - s));
+}
+
 static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
 
 // out[c] (+)= sum_b ws[b*ld + c], c < ncols  (elementwise.hip) -- second stage of every two-stage column reduction

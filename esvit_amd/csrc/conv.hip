@@ -1,0 +1,272 @@
+// Convolutional pieces of the CvT backbone (BASELINE config 5; cvt_v4_transformer.py): ConvEmbed as im2col + the MFMA
+// GEMM, the depthwise 3x3 convolution and the train-mode BatchNorm of the qkv projection.  Activations are token-major
+// NHWC ([nB, H, W, C] == [nB*H*W, C]) like everywhere else in this library, so the reference's NCHW <-> NHWC rearranges
+// around every LayerNorm (cvt_v4_transformer.py:55-58) never happen.  All kernels here are HBM-bound streaming kernels.
+//
+//   esvit_conv_im2col / esvit_conv_col2im   ConvEmbed.proj (cvt:363-368) forward gather and its adjoint
+//   esvit_dwconv3x3 / esvit_dwconv3x3_wgrad DepthWiseConv2d.dw (cvt:87-94), data gradient = same kernel with flipped taps
+//   esvit_col_sums2                         per-channel  sum(a), sum(a*b)  over rows: BatchNorm batch statistics (b = a) and
+//                                           the two reductions of its backward (a = dy, b = pre-norm activations)
+//   esvit_col_affine2                       y = a1[c]*x1 + a2[c]*x2 + a3[c]: BatchNorm apply and BatchNorm backward apply
+#include "common.h"
+#include "../../include/esvit_hip.h"
+
+namespace {
+
+template <typename T>
+__global__ void im2col_kernel(const void* __restrict__ src_, int nchw, int nB, int H, int W, int Cin, int k, int stride, int pad,
+                              int Ho, int Wo, int Kpad, T* __restrict__ cols) {
+    const long total = (long)nB * Ho * Wo * Kpad;
+    const int KK = k * k * Cin;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int j = (int)(i % Kpad);
+        const long r = i / Kpad;
+        float v = 0.f;
+        if (j < KK) {
+            const int c = j % Cin, kk = j / Cin;
+            const int ky = kk / k, kx = kk % k;
+            const int ox = (int)(r % Wo), oy = (int)((r / Wo) % Ho);
+            const long b = r / ((long)Wo * Ho);
+            const int iy = oy * stride - pad + ky, ix = ox * stride - pad + kx;
+            if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
+                if (nchw) v = reinterpret_cast<const float*>(src_)[((b * Cin + c) * H + iy) * W + ix];
+                else v = to_f32(reinterpret_cast<const T*>(src_)[((b * H + iy) * W + ix) * Cin + c]);
+            }
+        }
+        cols[i] = from_f32<T>(v);
+    }
+}
+
+// dsrc[b,iy,ix,c] = sum over the (ky,kx) taps whose output position exists
+template <typename T>
+__global__ void col2im_kernel(const T* __restrict__ dcols, int nB, int H, int W, int Cin, int k, int stride, int pad, int Ho, int Wo,
+                              int Kpad, float* __restrict__ dsrc) {
+    const long total = (long)nB * H * W * Cin;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % Cin);
+        const long p = i / Cin;
+        const int ix = (int)(p % W), iy = (int)((p / W) % H);
+        const long b = p / ((long)W * H);
+        float s = 0.f;
+        for (int ky = 0; ky < k; ++ky) {
+            const int ty = iy + pad - ky;
+            if (ty < 0 || ty % stride != 0) continue;
+            const int oy = ty / stride;
+            if (oy >= Ho) continue;
+            for (int kx = 0; kx < k; ++kx) {
+                const int tx = ix + pad - kx;
+                if (tx < 0 || tx % stride != 0) continue;
+                const int ox = tx / stride;
+                if (ox >= Wo) continue;
+                s += to_f32(dcols[((b * Ho + oy) * Wo + ox) * Kpad + (ky * k + kx) * Cin + c]);
+            }
+        }
+        dsrc[i] = s;
+    }
+}
+
+// one thread per (position, 4-channel group)
+template <typename T>
+__global__ void dwconv3x3_kernel(const T* __restrict__ x, const float* __restrict__ w, int flip, int nB, int H, int W, int C,
+                                 T* __restrict__ y) {
+    const int C4 = C / 4;
+    const long total = (long)nB * H * W * C4;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4) * 4;
+        const long p = i / C4;
+        const int ix = (int)(p % W), iy = (int)((p / W) % H);
+        const long b = p / ((long)W * H);
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int sy = iy + ky - 1;
+            if (sy < 0 || sy >= H) continue;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int sx = ix + kx - 1;
+                if (sx < 0 || sx >= W) continue;
+                const T* xp = x + ((b * H + sy) * W + sx) * C + c;
+                const int t = flip ? (2 - ky) * 3 + (2 - kx) : ky * 3 + kx;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[e] += to_f32(xp[e]) * w[(c + e) * 9 + t];
+            }
+        }
+        T* yp = y + p * C + c;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) yp[e] = from_f32<T>(acc[e]);
+    }
+}
+
+// ws[blk][c*9 + t] = sum over the block's positions of x(shifted by tap t) * dy
+template <typename T>
+__global__ __launch_bounds__(256) void dwconv3x3_wgrad_kernel(const T* __restrict__ x, const T* __restrict__ dy, int nB, int H, int W, int C,
+                                                              float* __restrict__ ws) {
+    const long P = (long)nB * H * W;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float acc[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) acc[t] = 0.f;
+        for (long p = blockIdx.x; p < P; p += gridDim.x) {
+            const int ix = (int)(p % W), iy = (int)((p / W) % H);
+            const long b = p / ((long)W * H);
+            const float g = to_f32(dy[p * C + c]);
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const int sy = iy + ky - 1;
+                if (sy < 0 || sy >= H) continue;
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int sx = ix + kx - 1;
+                    if (sx < 0 || sx >= W) continue;
+                    acc[ky * 3 + kx] += g * to_f32(x[((b * H + sy) * W + sx) * C + c]);
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 9; ++t) ws[((long)blockIdx.x * C + c) * 9 + t] = acc[t];
+    }
+}
+
+// ws[blk][0..C) = sum_r a[r][c],  ws[blk][C..2C) = sum_r a[r][c] * b[r][c]   (rows strided over the grid)
+template <typename T>
+__global__ __launch_bounds__(256) void col_sums2_kernel(const T* __restrict__ a, const T* __restrict__ b, long rows, int C,
+                                                        float* __restrict__ ws) {
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float s1 = 0.f, s2 = 0.f;
+        for (long r = blockIdx.x; r < rows; r += gridDim.x) {
+            const float av = to_f32(a[r * C + c]);
+            s1 += av;
+            s2 += av * to_f32(b[r * C + c]);
+        }
+        ws[(long)blockIdx.x * 2 * C + c] = s1;
+        ws[(long)blockIdx.x * 2 * C + C + c] = s2;
+    }
+}
+
+template <typename T>
+__global__ void col_affine2_kernel(const T* __restrict__ x1, const T* __restrict__ x2, long n, int C, const float* __restrict__ a1,
+                                   const float* __restrict__ a2, const float* __restrict__ a3, T* __restrict__ y) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        float v = a1[c] * to_f32(x1[i]) + a3[c];
+        if (x2) v += a2[c] * to_f32(x2[i]);
+        y[i] = from_f32<T>(v);
+    }
+}
+
+inline int grid_for(long n, int threads = 256, int cap = 8192) {
+    long g = (n + threads - 1) / threads;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+inline int reduce_blocks(long rows) {
+    long nb = rows;
+    if (nb > 512) nb = 512;
+    if (nb < 1) nb = 1;
+    return (int)nb;
+}
+
+}  // namespace
+
+#define STREAM(s_) hipStream_t stream = reinterpret_cast<hipStream_t>(s_)
+
+extern "C" int esvit_conv_im2col(int dtype, const void* src, int nchw, int nB, int H, int W, int Cin, int k, int stride, int pad, int Ho,
+                                 int Wo, int Kpad, void* cols, esvit_stream_t s_) {
+    STREAM(s_);
+    ESVIT_CHECK_ARG(src && cols && nB > 0 && H > 0 && W > 0 && Cin > 0 && k > 0 && stride > 0 && pad >= 0 && Kpad >= k * k * Cin,
+                    "esvit_conv_im2col: bad args");
+    ESVIT_CHECK_ARG(Ho == (H + 2 * pad - k) / stride + 1 && Wo == (W + 2 * pad - k) / stride + 1, "esvit_conv_im2col: bad output size");
+    ESVIT_CHECK_ARG(dtype == ESVIT_BF16 || dtype == ESVIT_F32, "esvit_conv_im2col: bad dtype");
+    const long total = (long)nB * Ho * Wo * Kpad;
+    if (dtype == ESVIT_BF16)
+        hipLaunchKernelGGL(im2col_kernel<bf16>, dim3(grid_for(total)), dim3(256), 0, stream, src, nchw, nB, H, W, Cin, k, stride, pad, Ho, Wo,
+                           Kpad, reinterpret_cast<bf16*>(cols));
+    else
+        hipLaunchKernelGGL(im2col_kernel<float>, dim3(grid_for(total)), dim3(256), 0, stream, src, nchw, nB, H, W, Cin, k, stride, pad, Ho, Wo,
+                           Kpad, reinterpret_cast<float*>(cols));
+    ESVIT_CHECK_LAUNCH("conv_im2col");
+    return ESVIT_OK;
+}
+
+extern "C" int esvit_conv_col2im(int dtype, const void* dcols, int nB, int H, int W, int Cin, int k, int stride, int pad, int Ho, int Wo,
+                                 int Kpad, float* dsrc, esvit_stream_t s_) {
+    STREAM(s_);
+    ESVIT_CHECK_ARG(dcols && dsrc && nB > 0 && H > 0 && W > 0 && Cin > 0 && k > 0 && stride > 0 && Kpad >= k * k * Cin,
+                    "esvit_conv_col2im: bad args");
+    ESVIT_CHECK_ARG(dtype == ESVIT_BF16 || dtype == ESVIT_F32, "esvit_conv_col2im: bad dtype");
+    const long total = (long)nB * H * W * Cin;
+    if (dtype == ESVIT_BF16)
+        hipLaunchKernelGGL(col2im_kernel<bf16>, dim3(grid_for(total)), dim3(256), 0, stream, reinterpret_cast<const bf16*>(dcols), nB, H, W,
+                           Cin, k, stride, pad, Ho, Wo, Kpad, dsrc);
+    else
+        hipLaunchKernelGGL(col2im_kernel<float>, dim3(grid_for(total)), dim3(256), 0, stream, reinterpret_cast<const float*>(dcols), nB, H, W,
+                           Cin, k, stride, pad, Ho, Wo, Kpad, dsrc);
+    ESVIT_CHECK_LAUNCH("conv_col2im");
+    return ESVIT_OK;
+}
+
+extern "C" int esvit_dwconv3x3(int dtype, const void* x, const float* w, int flip, int nB, int H, int W, int C, void* y, esvit_stream_t s_) {
+    STREAM(s_);
+    ESVIT_CHECK_ARG(x && w && y && nB > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "esvit_dwconv3x3: bad args (C=%d)", C);
+    ESVIT_CHECK_ARG(dtype == ESVIT_BF16 || dtype == ESVIT_F32, "esvit_dwconv3x3: bad dtype");
+    const long total = (long)nB * H * W * (C / 4);
+    if (dtype == ESVIT_BF16)
+        hipLaunchKernelGGL(dwconv3x3_kernel<bf16>, dim3(grid_for(total)), dim3(256), 0, stream, reinterpret_cast<const bf16*>(x), w, flip, nB,
+                           H, W, C, reinterpret_cast<bf16*>(y));
+    else
+        hipLaunchKernelGGL(dwconv3x3_kernel<float>, dim3(grid_for(total)), dim3(256), 0, stream, reinterpret_cast<const float*>(x), w, flip, nB,
+                           H, W, C, reinterpret_cast<float*>(y));
+    ESVIT_CHECK_LAUNCH("dwconv3x3");
+    return ESVIT_OK;
+}
+
+extern "C" int esvit_col_reduce_blocks(int64_t rows) { return reduce_blocks(rows); }
+
+extern "C" int esvit_dwconv3x3_wgrad(int dtype, const void* x, const void* dy, int nB, int H, int W, int C, float* dw, float* ws,
+                                     esvit_stream_t s_) {
+    STREAM(s_);
+    ESVIT_CHECK_ARG(x && dy && dw && ws && nB > 0 && H > 0 && W > 0 && C > 0, "esvit_dwconv3x3_wgrad: bad args");
+    ESVIT_CHECK_ARG(dtype == ESVIT_BF16 || dtype == ESVIT_F32, "esvit_dwconv3x3_wgrad: bad dtype");
+    const int nblk = reduce_blocks((long)nB * H * W);
+    if (dtype == ESVIT_BF16)
+        hipLaunchKernelGGL(dwconv3x3_wgrad_kernel<bf16>, dim3(nblk), dim3(256), 0, stream, reinterpret_cast<const bf16*>(x),
+                           reinterpret_cast<const bf16*>(dy), nB, H, W, C, ws);
+    else
+        hipLaunchKernelGGL(dwconv3x3_wgrad_kernel<float>, dim3(nblk), dim3(256), 0, stream, reinterpret_cast<const float*>(x),
+                           reinterpret_cast<const float*>(dy), nB, H, W, C, ws);
+    ESVIT_CHECK_LAUNCH("dwconv3x3_wgrad");
+    return esvit_partial_reduce(ws, nblk, 9 * C, 9L * C, dw, 0, stream);
+}
+
+extern "C" int esvit_col_sums2(int dtype, const void* a, const void* b, int64_t rows, int C, float* out, float* ws, esvit_stream_t s_) {
+    STREAM(s_);
+    ESVIT_CHECK_ARG(a && b && out && ws && rows > 0 && C > 0, "esvit_col_sums2: bad args");
+    ESVIT_CHECK_ARG(dtype == ESVIT_BF16 || dtype == ESVIT_F32, "esvit_col_sums2: bad dtype");
+    const int nblk = reduce_blocks(rows);
+    if (dtype == ESVIT_BF16)
+        hipLaunchKernelGGL(col_sums2_kernel<bf16>, dim3(nblk), dim3(256), 0, stream, reinterpret_cast<const bf16*>(a),
+                           reinterpret_cast<const bf16*>(b), (long)rows, C, ws);
+    else
+        hipLaunchKernelGGL(col_sums2_kernel<float>, dim3(nblk), dim3(256), 0, stream, reinterpret_cast<const float*>(a),
+                           reinterpret_cast<const float*>(b), (long)rows, C, ws);
+    ESVIT_CHECK_LAUNCH("col_sums2");
+    return esvit_partial_reduce(ws, nblk, 2 * C, 2L * C, out, 0, stream);
+}
+
+extern "C" int esvit_col_affine2(int dtype, const void* x1, const void* x2, int64_t rows, int C, const float* a1, const float* a2,
+                                 const float* a3, void* y, esvit_stream_t s_) {
+    STREAM(s_);
+    ESVIT_CHECK_ARG(x1 && a1 && a3 && y && rows > 0 && C > 0 && (!x2 || a2), "esvit_col_affine2: bad args");
+    ESVIT_CHECK_ARG(dtype == ESVIT_BF16 || dtype == ESVIT_F32, "esvit_col_affine2: bad dtype");
+    const long n = (long)rows * C;
+    if (dtype == ESVIT_BF16)
+        hipLaunchKernelGGL(col_affine2_kernel<bf16>, dim3(grid_for(n)), dim3(256), 0, stream, reinterpret_cast<const bf16*>(x1),
+                           reinterpret_cast<const bf16*>(x2), n, C, a1, a2, a3, reinterpret_cast<bf16*>(y));
+    else
+        hipLaunchKernelGGL(col_affine2_kernel<float>, dim3(grid_for(n)), dim3(256), 0, stream, reinterpret_cast<const float*>(x1),
+                           reinterpret_cast<const float*>(x2), n, C, a1, a2, a3, reinterpret_cast<float*>(y));
+    ESVIT_CHECK_LAUNCH("col_affine2");
+    return ESVIT_OK;
+}

@@ -275,7 +275,7 @@ __device__ __forceinline__ void gemm_epilogue(const esvit_gemm_desc& p, f32x4 (&
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] += bias_h[CG_FIXED ? 0 : t][e];
             }
-            if (mode == ESVIT_EPI_GELU) {
+            if (mode == ESVIT_EPI_GELU || mode == ESVIT_EPI_QGELU) {
                 if (auxp) {
                     T* ap = auxp + (long)m * p.ldaux + n;
                     if (ne == 8 && aux_vec) {
@@ -293,8 +293,8 @@ __device__ __forceinline__ void gemm_epilogue(const esvit_gemm_desc& p, f32x4 (&
                     }
                 }
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
-            } else if (mode == ESVIT_EPI_GELU_BWD) {
+                for (int e = 0; e < 8; ++e) v[e] = mode == ESVIT_EPI_GELU ? gelu_f(v[e]) : qgelu_f(v[e]);
+            } else if (mode == ESVIT_EPI_GELU_BWD || mode == ESVIT_EPI_QGELU_BWD) {
                 const T* ap = auxp + (long)m * p.ldaux + n;
                 float a[8];
                 if (ne == 8 && aux_vec) {
@@ -315,7 +315,7 @@ __device__ __forceinline__ void gemm_epilogue(const esvit_gemm_desc& p, f32x4 (&
                     for (int e = 0; e < 8; ++e) a[e] = e < ne ? to_f32(ap[e]) : 0.f;
                 }
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] *= gelu_grad_f(a[e]);
+                for (int e = 0; e < 8; ++e) v[e] *= mode == ESVIT_EPI_GELU_BWD ? gelu_grad_f(a[e]) : qgelu_grad_f(a[e]);
             }
             if (p.rowscale) {
                 const float rs = p.rowscale[drow / p.rows_per_sample];
@@ -427,6 +427,7 @@ __device__ __forceinline__ void epilogue_fast(const esvit_gemm_desc& p, f32x4 (&
 #pragma unroll
             for (int j = 0; j < FN; ++j) acc[i][j] *= p.alpha;
     }
+    const bool quick = p.epilogue == ESVIT_EPI_QGELU || p.epilogue == ESVIT_EPI_QGELU_BWD;  // QuickGELU instead of erf-GELU
     const long c_step = (long)SR * ldc;
     const long x_step = (long)SR * (KIND == EK_RES ? p.ldr : p.ldaux);
     bf16* auxp = reinterpret_cast<bf16*>(p.aux);
@@ -481,12 +482,22 @@ __device__ __forceinline__ void epilogue_fast(const esvit_gemm_desc& p, f32x4 (&
                     for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
                     *reinterpret_cast<bf16x8*>(auxp + x_off[t] + ps * x_step) = o;
                 }
+                if (quick) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
+                    for (int e = 0; e < 8; ++e) v[e] = qgelu_f(v[e]);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
+                }
             } else if constexpr (KIND == EK_GELU_BWD) {
                 const bf16x8 x = __builtin_bit_cast(bf16x8, in0[ps & 1][t]);
+                if (quick) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] *= gelu_grad_f((float)x[e]);
+                    for (int e = 0; e < 8; ++e) v[e] *= qgelu_grad_f((float)x[e]);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] *= gelu_grad_f((float)x[e]);
+                }
             } else if constexpr (KIND == EK_RES) {
                 const float s = rs[ps & 1][t];
 #pragma unroll
@@ -526,10 +537,10 @@ __device__ __forceinline__ void gemm_epilogue_bf16(const esvit_gemm_desc& p, f32
     bool fast = p.splitk <= 1 && !p.rowmap && m0 + BM <= p.M && n0 + BN <= p.N && (p.ldc % 8 == 0) && al16(p.C) &&
                 ((p.strideC * (long)z) % 8 == 0) && (!p.bias || al16(p.bias));
     int kind = EK_PLAIN;
-    if (p.epilogue == ESVIT_EPI_GELU) {
+    if (p.epilogue == ESVIT_EPI_GELU || p.epilogue == ESVIT_EPI_QGELU) {
         kind = EK_GELU;
         fast = fast && !p.residual && !p.rowscale && !p.out_f32 && (!p.aux || ((p.ldaux % 8 == 0) && al16(p.aux)));
-    } else if (p.epilogue == ESVIT_EPI_GELU_BWD) {
+    } else if (p.epilogue == ESVIT_EPI_GELU_BWD || p.epilogue == ESVIT_EPI_QGELU_BWD) {
         kind = EK_GELU_BWD;
         fast = fast && !p.residual && !p.rowscale && (p.ldaux % 8 == 0) && al16(p.aux);
     } else if (p.residual) {
@@ -1420,7 +1431,8 @@ extern "C" int esvit_gemm(int dtype, const esvit_gemm_desc* dp, esvit_stream_t s
     }
     if (d.rowmap) ESVIT_CHECK_ARG(d.rowmap_period > 0 && d.rowmap_tokens > 0, "esvit_gemm: bad rowmap geometry");
     if (d.rowscale) ESVIT_CHECK_ARG(d.rows_per_sample > 0, "esvit_gemm: rowscale needs rows_per_sample");
-    if (d.epilogue == ESVIT_EPI_GELU_BWD) ESVIT_CHECK_ARG(d.aux != nullptr, "esvit_gemm: GELU' needs aux");
+    if (d.epilogue == ESVIT_EPI_GELU_BWD || d.epilogue == ESVIT_EPI_QGELU_BWD) ESVIT_CHECK_ARG(d.aux != nullptr, "esvit_gemm: GELU' needs aux");
+    ESVIT_CHECK_ARG(d.epilogue >= 0 && d.epilogue <= ESVIT_EPI_QGELU_BWD, "esvit_gemm: bad epilogue %d", d.epilogue);
     if (d.colsum && d.splitk > 1) ESVIT_CHECK_ARG(d.colsum_partial != nullptr, "esvit_gemm: colsum with split-K needs colsum_partial");
     if (d.colsum) ESVIT_CHECK_ARG(d.batch == 1, "esvit_gemm: colsum is not batched");
     if (dtype == ESVIT_BF16) {

@@ -10,7 +10,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import BF16, EPI_GELU, EPI_GELU_BWD, EPI_NONE, F32, GemmDesc, check, lib
+from ._lib import BF16, EPI_GELU, EPI_GELU_BWD, EPI_NONE, EPI_QGELU, EPI_QGELU_BWD, F32, GemmDesc, check, lib
 
 _ACT_DTYPE = torch.bfloat16
 
@@ -158,8 +158,9 @@ def _gemm_launch(dt, **kw):
 
 
 def linear_fwd(x, w, bias=None, *, gelu=False, want_preact=False, residual=None, rowmap=None, rowmap_tokens=0,
-               out_rows=None, rowscale=None, rows_per_sample=0, out_f32=False):
-    """y = x @ w^T (+bias) with the fused epilogue of the GEMM kernel.
+               out_rows=None, rowscale=None, rows_per_sample=0, out_f32=False, quick=False):
+    """y = x @ w^T (+bias) with the fused epilogue of the GEMM kernel.  gelu: exact erf-GELU, or (quick=True) the
+    QuickGELU x*sigmoid(1.702x) of the CvT feed-forward.
 
     x [M, K] act; w [N, K] act (cached cast of the fp32 parameter); bias fp32 [N].
     rowmap (int32 [period]) scatters window rows to token rows (out_rows rows, tokens per image =
@@ -174,12 +175,12 @@ def linear_fwd(x, w, bias=None, *, gelu=False, want_preact=False, residual=None,
     _gemm(x.dtype, A=x, B=w, C=y, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, bias=bias, residual=residual, ldr=N,
           rowmap=rowmap, rowmap_period=0 if rowmap is None else rowmap.numel(), rowmap_tokens=rowmap_tokens,
           rowscale=rowscale, rows_per_sample=rows_per_sample, aux=pre, ldaux=N,
-          epilogue=EPI_GELU if gelu else EPI_NONE, out_f32=out_f32)
+          epilogue=(EPI_QGELU if quick else EPI_GELU) if gelu else EPI_NONE, out_f32=out_f32)
     return (y, pre) if gelu and want_preact else y
 
 
-def linear_dgrad(dy, w, *, gelu_preact=None, out_f32=False):
-    """dx = dy @ w  (w [Nout, Kin] act, read k-strided); optional fused GELU': dx *= gelu'(preact)."""
+def linear_dgrad(dy, w, *, gelu_preact=None, out_f32=False, quick=False):
+    """dx = dy @ w  (w [Nout, Kin] act, read k-strided); optional fused GELU': dx *= gelu'(preact) (quick: QuickGELU')."""
     dy, w = _actc(dy), _actc(w)
     M, Nout = dy.shape
     Kin = w.shape[1]
@@ -194,7 +195,7 @@ def linear_dgrad(dy, w, *, gelu_preact=None, out_f32=False):
               splitk=splitk, partial=part)
         return dx
     _gemm(dy.dtype, A=dy, B=w, C=dx, M=M, N=Kin, K=Nout, lda=Nout, ldb=Kin, ldc=Kin, b_kstrided=1, aux=gelu_preact,
-          ldaux=Kin, epilogue=EPI_GELU_BWD if gelu_preact is not None else EPI_NONE, out_f32=out_f32)
+          ldaux=Kin, epilogue=(EPI_QGELU_BWD if quick else EPI_GELU_BWD) if gelu_preact is not None else EPI_NONE, out_f32=out_f32)
     return dx
 
 
@@ -590,3 +591,75 @@ def debug_set_gemm_dma(on):
 
 def debug_set_gemm_pipe(mode):
     lib.esvit_debug_set_gemm_pipe(int(mode))
+
+
+# ------------------------------------------------------------------------------------------------
+# CvT backbone pieces (cvt_v4_transformer.py): ConvEmbed im2col, depthwise 3x3, BatchNorm reductions
+# ------------------------------------------------------------------------------------------------
+def conv_out_size(n, k, stride, pad):
+    return (n + 2 * pad - k) // stride + 1
+
+
+def conv_im2col(src, nchw, nB, H, W, Cin, k, stride, pad, dtype=None):
+    """-> cols [nB*Ho*Wo, Kpad] (Kpad = k*k*Cin rounded up to 8), column order (ky, kx, c).
+    src: fp32 NCHW images (nchw=True) or activation-dtype NHWC tokens [nB*H*W, Cin]."""
+    dt = dtype or (_ACT_DTYPE if nchw else src.dtype)
+    Ho, Wo = conv_out_size(H, k, stride, pad), conv_out_size(W, k, stride, pad)
+    Kpad = -(-(k * k * Cin) // 8) * 8
+    assert src.is_contiguous() and (src.dtype == torch.float32 if nchw else src.dtype == dt)
+    cols = torch.empty((nB * Ho * Wo, Kpad), dtype=dt, device=src.device)
+    check(lib.esvit_conv_im2col(_code(dt), _p(src), int(bool(nchw)), nB, H, W, Cin, k, stride, pad, Ho, Wo, Kpad, _p(cols), _stream()),
+          "conv_im2col")
+    return cols
+
+
+def conv_col2im(dcols, nB, H, W, Cin, k, stride, pad):
+    """adjoint of conv_im2col for NHWC sources: dcols act [nB*Ho*Wo, Kpad] -> dsrc fp32 [nB*H*W, Cin]."""
+    dcols = _actc(dcols)
+    Ho, Wo = conv_out_size(H, k, stride, pad), conv_out_size(W, k, stride, pad)
+    dsrc = torch.empty((nB * H * W, Cin), dtype=torch.float32, device=dcols.device)
+    check(lib.esvit_conv_col2im(_code(dcols.dtype), _p(dcols), nB, H, W, Cin, k, stride, pad, Ho, Wo, dcols.shape[1], _p(dsrc), _stream()),
+          "conv_col2im")
+    return dsrc
+
+
+def dwconv3x3(x, w, nB, H, W, flip=False):
+    """depthwise 3x3, stride 1, zero pad 1 on NHWC tokens x [nB*H*W, C] (act); w fp32 [C, 9]; flip: mirrored taps."""
+    x = _actc(x)
+    Cc = x.shape[1]
+    assert x.shape[0] == nB * H * W and w.numel() == 9 * Cc
+    y = torch.empty_like(x)
+    check(lib.esvit_dwconv3x3(_code(x.dtype), _p(x), _p(_f32c(w)), int(bool(flip)), nB, H, W, Cc, _p(y), _stream()), "dwconv3x3")
+    return y
+
+
+def dwconv3x3_wgrad(x, dy, nB, H, W):
+    """-> dw fp32 [C, 9]"""
+    x, dy = _actc(x), _actc(dy)
+    Cc = x.shape[1]
+    assert x.dtype == dy.dtype and x.shape == dy.shape
+    dw = torch.empty((Cc, 9), dtype=torch.float32, device=x.device)
+    ws = workspace(lib.esvit_col_reduce_blocks(nB * H * W) * 9 * Cc, x.device, slot=1)
+    check(lib.esvit_dwconv3x3_wgrad(_code(x.dtype), _p(x), _p(dy), nB, H, W, Cc, _p(dw), _p(ws), _stream()), "dwconv3x3_wgrad")
+    return dw
+
+
+def col_sums2(a, b):
+    """-> fp32 [2, C]: sum_r a[r, c]  and  sum_r a[r, c] * b[r, c]"""
+    a, b = _actc(a), _actc(b)
+    rows, Cc = a.shape
+    assert a.dtype == b.dtype and a.shape == b.shape
+    out = torch.empty((2, Cc), dtype=torch.float32, device=a.device)
+    ws = workspace(lib.esvit_col_reduce_blocks(rows) * 2 * Cc, a.device, slot=1)
+    check(lib.esvit_col_sums2(_code(a.dtype), _p(a), _p(b), rows, Cc, _p(out), _p(ws), _stream()), "col_sums2")
+    return out
+
+
+def col_affine2(x1, a1, a3, x2=None, a2=None):
+    """y = a1[c] * x1 + a2[c] * x2 + a3[c]  (act dtype in / out, fp32 per-channel coefficients)"""
+    x1 = _actc(x1)
+    rows, Cc = x1.shape
+    y = torch.empty_like(x1)
+    check(lib.esvit_col_affine2(_code(x1.dtype), _p(x1), _p(x2), rows, Cc, _p(_f32c(a1)), _p(a2), _p(_f32c(a3)), _p(y), _stream()),
+          "col_affine2")
+    return y

@@ -53,6 +53,8 @@ int esvit_shift_region_ids(int H, int W, int ws, int shift, int32_t* ids, int* n
 #define ESVIT_EPI_NONE 0
 #define ESVIT_EPI_GELU 1     /* out = gelu(acc+bias); aux (if set) receives acc+bias */
 #define ESVIT_EPI_GELU_BWD 2 /* out = acc * gelu'(aux) */
+#define ESVIT_EPI_QGELU 3     /* QuickGELU (cvt_v4_transformer.py:44-46): out = v*sigmoid(1.702 v), v = acc+bias; aux receives v */
+#define ESVIT_EPI_QGELU_BWD 4 /* out = acc * d/dv[v*sigmoid(1.702 v)] at v = aux */
 
 typedef struct {
     const void* A;
@@ -253,6 +255,31 @@ int esvit_grad_sqnorm(const int64_t* tensors, int ntensors, const int32_t* chunk
 int esvit_fused_clip_adamw_ema(const int64_t* tensors, int ntensors, const int32_t* chunks, int nchunks,
                                const float* sqnorms, float clip, float lr, float wd, float beta1,
                                float beta2, float eps, float ema_m, esvit_stream_t stream);
+
+/* ---- CvT backbone pieces (BASELINE config 5) ------------------------------
+ * Token-major NHWC activations.  cvt_v4_transformer.py:349-382 (ConvEmbed), :75-105 (DepthWiseConv2d = dw 3x3 +
+ * BatchNorm2d + 1x1), :44-46 (QuickGELU: see ESVIT_EPI_QGELU).
+ * esvit_conv_im2col: cols[(b,oy,ox)][(ky*k+kx)*Cin + c] = src(b, oy*stride-pad+ky, ox*stride-pad+kx, c), zero outside
+ *   the image and in the tail columns [k*k*Cin, Kpad); src = fp32 NCHW images (nchw=1) or activation-dtype NHWC tokens.
+ * esvit_conv_col2im: the adjoint, dsrc fp32 NHWC [nB,H,W,Cin].
+ * esvit_dwconv3x3: y[b,y,x,c] = sum_t w[c][t] x[b,y+ky-1,x+kx-1,c] (stride 1, zero pad 1); flip=1 applies the taps
+ *   mirrored (the data gradient).  esvit_dwconv3x3_wgrad: dw[c][t]; ws: fp32 [esvit_col_reduce_blocks(rows)*9*C].
+ * esvit_col_sums2: out[0..C) = sum_r a[r][c], out[C..2C) = sum_r a[r][c]*b[r][c]  (BatchNorm statistics: b = a;
+ *   BatchNorm backward: a = dy, b = pre-norm activations); ws: fp32 [esvit_col_reduce_blocks(rows)*2*C].
+ * esvit_col_affine2: y = a1[c]*x1 + a2[c]*x2 + a3[c]  (x2 may be null). */
+int esvit_conv_im2col(int dtype, const void* src, int nchw, int nB, int H, int W, int Cin, int k, int stride, int pad,
+                      int Ho, int Wo, int Kpad, void* cols, esvit_stream_t stream);
+int esvit_conv_col2im(int dtype, const void* dcols, int nB, int H, int W, int Cin, int k, int stride, int pad, int Ho,
+                      int Wo, int Kpad, float* dsrc, esvit_stream_t stream);
+int esvit_dwconv3x3(int dtype, const void* x, const float* w, int flip, int nB, int H, int W, int C, void* y,
+                    esvit_stream_t stream);
+int esvit_col_reduce_blocks(int64_t rows);
+int esvit_dwconv3x3_wgrad(int dtype, const void* x, const void* dy, int nB, int H, int W, int C, float* dw, float* ws,
+                          esvit_stream_t stream);
+int esvit_col_sums2(int dtype, const void* a, const void* b, int64_t rows, int C, float* out, float* ws,
+                    esvit_stream_t stream);
+int esvit_col_affine2(int dtype, const void* x1, const void* x2, int64_t rows, int C, const float* a1, const float* a2,
+                      const float* a3, void* y, esvit_stream_t stream);
 
 /* ---- debug switches (tests only) ---------------------------------------- */
 void esvit_debug_set_tr_read(int on);      /* GEMM: ds_read_b64_tr_b16 vs scalar LDS gathers */

@@ -89,20 +89,29 @@ def _gelu_grad(x):
     return 0.5 * (1.0 + torch.erf(x * 0.7071067811865476)) + x * torch.exp(-0.5 * x * x) * 0.3989422804014327
 
 
+def _qgelu(x):
+    return x * torch.sigmoid(1.702 * x)
+
+
+def _qgelu_grad(x):
+    s = torch.sigmoid(1.702 * x)
+    return s * (1.0 + 1.702 * x * (1.0 - s))
+
+
 def workspace(n, device, slot=0):
     return torch.empty(int(n), dtype=torch.float32, device=device)
 
 
 # ---- GEMM family -------------------------------------------------------------------------
 def linear_fwd(x, w, bias=None, *, gelu=False, want_preact=False, residual=None, rowmap=None, rowmap_tokens=0,
-               out_rows=None, rowscale=None, rows_per_sample=0, out_f32=False):
+               out_rows=None, rowscale=None, rows_per_sample=0, out_f32=False, quick=False):
     acc = x.float() @ w.float().t()
     if bias is not None:
         acc = acc + bias
     pre = None
     if gelu:
         pre = _r(acc, x.dtype)
-        acc = _gelu(acc)
+        acc = _qgelu(acc) if quick else _gelu(acc)
     M = x.shape[0]
     if rowmap is not None:
         period = rowmap.numel()
@@ -127,10 +136,10 @@ def linear_fwd(x, w, bias=None, *, gelu=False, want_preact=False, residual=None,
     return (y, pre) if gelu and want_preact else y
 
 
-def linear_dgrad(dy, w, *, gelu_preact=None, out_f32=False):
+def linear_dgrad(dy, w, *, gelu_preact=None, out_f32=False, quick=False):
     dx = dy.float() @ w.float()
     if gelu_preact is not None:
-        dx = dx * _gelu_grad(gelu_preact.float())
+        dx = dx * (_qgelu_grad(gelu_preact.float()) if quick else _gelu_grad(gelu_preact.float()))
     return dx if out_f32 else _r(dx, dy.dtype)
 
 
@@ -503,3 +512,60 @@ def scale_inplace(x, scale):
 def center_ema(center, colsum_, momentum, denom):
     center.copy_(center * momentum + colsum_.view_as(center) / denom * (1 - momentum))
     return center
+
+
+# ---- CvT backbone pieces ----------------------------------------------------------------------
+def conv_out_size(n, k, stride, pad):
+    return (n + 2 * pad - k) // stride + 1
+
+
+def conv_im2col(src, nchw, nB, H, W, Cin, k, stride, pad, dtype=None):
+    import torch.nn.functional as F
+    dt = dtype or (_ACT_DTYPE if nchw else src.dtype)
+    x = src.float() if nchw else src.float().view(nB, H, W, Cin).permute(0, 3, 1, 2)
+    Ho, Wo = conv_out_size(H, k, stride, pad), conv_out_size(W, k, stride, pad)
+    u = F.unfold(x, k, padding=pad, stride=stride)                      # [nB, Cin*k*k, Ho*Wo], channel-major (c, ky, kx)
+    u = u.view(nB, Cin, k * k, Ho * Wo).permute(0, 3, 2, 1).reshape(nB * Ho * Wo, k * k * Cin)  # -> (ky, kx, c)
+    Kpad = -(-(k * k * Cin) // 8) * 8
+    cols = torch.zeros((nB * Ho * Wo, Kpad), dtype=torch.float32, device=src.device)
+    cols[:, :k * k * Cin] = u
+    return _r(cols, dt)
+
+
+def conv_col2im(dcols, nB, H, W, Cin, k, stride, pad):
+    import torch.nn.functional as F
+    Ho, Wo = conv_out_size(H, k, stride, pad), conv_out_size(W, k, stride, pad)
+    u = dcols.float()[:, :k * k * Cin].view(nB, Ho * Wo, k * k, Cin).permute(0, 3, 2, 1).reshape(nB, Cin * k * k, Ho * Wo)
+    x = F.fold(u, (H, W), k, padding=pad, stride=stride)                # [nB, Cin, H, W]
+    return x.permute(0, 2, 3, 1).reshape(nB * H * W, Cin).contiguous()
+
+
+def dwconv3x3(x, w, nB, H, W, flip=False):
+    import torch.nn.functional as F
+    Cc = x.shape[1]
+    wk = w.float().view(Cc, 1, 3, 3)
+    if flip:
+        wk = wk.flip(2, 3)
+    y = F.conv2d(x.float().view(nB, H, W, Cc).permute(0, 3, 1, 2), wk, padding=1, groups=Cc)
+    return _r(y.permute(0, 2, 3, 1).reshape(nB * H * W, Cc), x.dtype)
+
+
+def dwconv3x3_wgrad(x, dy, nB, H, W):
+    import torch.nn.functional as F
+    Cc = x.shape[1]
+    xp = F.pad(x.float().view(nB, H, W, Cc), (0, 0, 1, 1, 1, 1))
+    g = dy.float().view(nB, H, W, Cc)
+    dw = torch.stack([(xp[:, ky:ky + H, kx:kx + W] * g).sum((0, 1, 2)) for ky in range(3) for kx in range(3)], 1)
+    return dw.contiguous()
+
+
+def col_sums2(a, b):
+    af = a.float()
+    return torch.stack([af.sum(0), (af * b.float()).sum(0)], 0)
+
+
+def col_affine2(x1, a1, a3, x2=None, a2=None):
+    y = x1.float() * a1 + a3
+    if x2 is not None:
+        y = y + x2.float() * a2
+    return _r(y, x1.dtype)

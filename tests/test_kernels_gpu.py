@@ -67,6 +67,10 @@ def test_gemm_nt(mods, gemm_path, dt, M, N, K):
     yr, prer = ref.linear_fwd(x, w, b, gelu=True, want_preact=True)
     _close("nt+gelu", y, yr, _tol(dt))
     _close("nt preact", pre, prer, _tol(dt))
+    y, pre = ops.linear_fwd(x, w, b, gelu=True, want_preact=True, quick=True)
+    yr, prer = ref.linear_fwd(x, w, b, gelu=True, want_preact=True, quick=True)
+    _close("nt+quickgelu", y, yr, _tol(dt))
+    _close("nt quick preact", pre, prer, _tol(dt))
     res = _rand((M, N), dev, 4)
     _close("nt+res f32", ops.linear_fwd(x, w, b, residual=res, out_f32=True), ref.linear_fwd(x, w, b, residual=res, out_f32=True), _tol(dt, bf=5e-3))
 
@@ -103,6 +107,8 @@ def test_gemm_dgrad(mods, gemm_path, dt, tr, M, N, K):
         _close("dgrad", ops.linear_dgrad(dy, w), ref.linear_dgrad(dy, w), _tol(dt))
         pre = _rand((M, N), dev, 7, dt)
         _close("dgrad+gelu'", ops.linear_dgrad(dy, w, gelu_preact=pre), ref.linear_dgrad(dy, w, gelu_preact=pre), _tol(dt))
+        _close("dgrad+quickgelu'", ops.linear_dgrad(dy, w, gelu_preact=pre, quick=True), ref.linear_dgrad(dy, w, gelu_preact=pre, quick=True),
+               _tol(dt))
     finally:
         ops.debug_set_tr_read(1)
 
@@ -305,6 +311,36 @@ def test_window_attention(mods, dt, ws, nH, H, shift, hd):
             _close("attn dpad tr=%d" % tr, pad_.sum(0, keepdim=True), padr, _tol(dt, f32=1e-4, bf=3e-2))
         else:
             assert float(pad_.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_cvt_conv_pieces(mods, dt):
+    """ConvEmbed im2col / col2im, depthwise 3x3 (+ flipped, + weight gradient), BatchNorm reductions and affine apply"""
+    ops, ref = mods
+    dev = _dev()
+    # stage-0 embed: 7x7 stride 4 pad 2 on NCHW images (K = 147 -> padded to 152)
+    img = _rand((3, 3, 40, 40), dev, 70)
+    _close("im2col nchw", ops.conv_im2col(img, True, 3, 40, 40, 3, 7, 4, 2, dtype=dt), ref.conv_im2col(img, True, 3, 40, 40, 3, 7, 4, 2, dtype=dt),
+           _tol(dt))
+    # later embeds: 3x3 stride 2 pad 1 on NHWC tokens, odd and even grids
+    for H, Cin in ((14, 64), (5, 24)):
+        tok = _rand((2 * H * H, Cin), dev, 71, dt)
+        _close("im2col nhwc", ops.conv_im2col(tok, False, 2, H, H, Cin, 3, 2, 1), ref.conv_im2col(tok, False, 2, H, H, Cin, 3, 2, 1), _tol(dt))
+        Ho = ops.conv_out_size(H, 3, 2, 1)
+        dcols = _rand((2 * Ho * Ho, -(-(9 * Cin) // 8) * 8), dev, 72, dt)
+        _close("col2im", ops.conv_col2im(dcols, 2, H, H, Cin, 3, 2, 1), ref.conv_col2im(dcols, 2, H, H, Cin, 3, 2, 1), _tol(dt, f32=1e-5, bf=1e-5))
+    for H, Cc in ((14, 64), (6, 192), (3, 32)):
+        x = _rand((2 * H * H, Cc), dev, 73, dt)
+        w = _rand((Cc, 9), dev, 74) * 0.3
+        _close("dwconv", ops.dwconv3x3(x, w, 2, H, H), ref.dwconv3x3(x, w, 2, H, H), _tol(dt, bf=2e-2))
+        _close("dwconv flip", ops.dwconv3x3(x, w, 2, H, H, flip=True), ref.dwconv3x3(x, w, 2, H, H, flip=True), _tol(dt, bf=2e-2))
+        dy = _rand((2 * H * H, Cc), dev, 75, dt)
+        _close("dwconv wgrad", ops.dwconv3x3_wgrad(x, dy, 2, H, H), ref.dwconv3x3_wgrad(x, dy, 2, H, H), _tol(dt, f32=1e-4, bf=1e-4))
+        _close("col sums (bn stats)", ops.col_sums2(x, x), ref.col_sums2(x, x), _tol(dt, f32=1e-4, bf=1e-4))
+        _close("col sums (bn bwd)", ops.col_sums2(dy, x), ref.col_sums2(dy, x), _tol(dt, f32=1e-4, bf=1e-4))
+        a1, a2, a3 = _rand((Cc,), dev, 76), _rand((Cc,), dev, 77), _rand((Cc,), dev, 78)
+        _close("affine", ops.col_affine2(x, a1, a3), ref.col_affine2(x, a1, a3), _tol(dt, bf=2e-2))
+        _close("affine2", ops.col_affine2(x, a1, a3, dy, a2), ref.col_affine2(x, a1, a3, dy, a2), _tol(dt, bf=2e-2))
 
 
 @pytest.mark.parametrize("dt", DTYPES)
