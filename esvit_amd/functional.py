@@ -10,6 +10,7 @@ Stages (reference lines):
   FinalNormFn      swin_transformer.py:687
   TokenMeanFn      swin_transformer.py:688-689
   DinoHeadFn       vision_transformer.py:414-418
+  ConvEmbedFn, CvtAttnFn, CvtFfnFn   cvt_v4_transformer.py:349-382, 108-220 (+75-105), 62-72  (BASELINE config 5)
 """
 import numpy as np
 import torch
@@ -226,10 +227,10 @@ class FinalNormFn(torch.autograd.Function):
     """x fp32 [nB, T, C] -> LayerNorm(x) fp32 (the region features the loss matches on stay fp32)."""
 
     @staticmethod
-    def forward(ctx, x, g, b):
+    def forward(ctx, x, g, b, eps=LN_EPS):
         o = ops_module()
         x = x.contiguous()
-        y, _, mean, rstd = o.layernorm_fwd(x.view(-1, x.shape[-1]), g, b, LN_EPS, dtype=torch.float32)
+        y, _, mean, rstd = o.layernorm_fwd(x.view(-1, x.shape[-1]), g, b, eps, dtype=torch.float32)
         ctx.save_for_backward(x, mean, rstd, g)
         return y.view(x.shape)
 
@@ -239,7 +240,7 @@ class FinalNormFn(torch.autograd.Function):
         x, mean, rstd, g = ctx.saved_tensors
         C = x.shape[-1]
         dx, dg, db = o.layernorm_bwd(gy.contiguous().view(-1, C), x.view(-1, C), mean, rstd, g)
-        return dx.view(x.shape), dg, db
+        return dx.view(x.shape), dg, db, None
 
 
 class TokenMeanFn(torch.autograd.Function):
@@ -313,3 +314,219 @@ def dino_head(x, prm):
     if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in prm)):
         return DinoHeadFn.apply(x, *prm)
     return _head_forward(x, prm, False)[0]
+
+
+# ------------------------------------------------------------------------------------------------
+# CvT (cvt_v4_transformer.py; BASELINE config 5).  Activations stay token-major NHWC, so the reference's
+# 'b c h w <-> b h w c' rearranges around every LayerNorm do not exist here.
+# ------------------------------------------------------------------------------------------------
+CVT_LN_EPS = 1e-5   # get_cls_model: norm_layer=partial(LayerNorm, eps=1e-5)  (cvt_v4_transformer.py:694)
+BN_EPS = 1e-5       # nn.BatchNorm2d defaults (cvt_v4_transformer.py:95)
+BN_MOMENTUM = 0.1
+
+
+def _conv_weight_matrix(Wp):
+    """conv weight [E, Cin, k, k] -> activation-dtype GEMM operand [E, Kpad], column order (ky, kx, c), zero tail"""
+    def make():
+        E, Cin, k, _ = Wp.shape
+        K = k * k * Cin
+        Kpad = -(-K // 8) * 8
+        m = torch.zeros((E, Kpad), dtype=torch.float32, device=Wp.device)
+        m[:, :K] = Wp.detach().permute(0, 2, 3, 1).reshape(E, K)
+        return ops_module().cast_to_act(m)
+    if Wp.requires_grad or P.is_managed(Wp):
+        return P.cached(Wp, "convk", make)
+    return make()
+
+
+def _pad_tokens(t, nB, H, W, Hp, Wp):
+    """[nB*H*W, C] -> [nB*Hp*Wp, C] with zero rows/cols appended bottom/right (F.pad of cvt_v4_transformer.py:173)"""
+    if Hp == H and Wp == W:
+        return t
+    C = t.shape[1]
+    out = torch.zeros((nB, Hp, Wp, C), dtype=t.dtype, device=t.device)
+    out[:, :H, :W] = t.view(nB, H, W, C)
+    return out.view(nB * Hp * Wp, C)
+
+
+def _crop_tokens(t, nB, H, W, Hp, Wp):
+    if Hp == H and Wp == W:
+        return t
+    C = t.shape[1]
+    return t.view(nB, Hp, Wp, C)[:, :H, :W].contiguous().view(nB * H * W, C)
+
+
+def _allreduce_stats(t, group):
+    """SyncBatchNorm: batch statistics are sums over every rank's positions (main_esvit.py:365-379 converts the BN layers)"""
+    import torch.distributed as dist
+    if group is not False and dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(t, group=group)
+        return dist.get_world_size(group)
+    return 1
+
+
+class ConvEmbedFn(torch.autograd.Function):
+    """ConvEmbed (cvt_v4_transformer.py:349-382): conv k x k / stride / pad as im2col + GEMM, then LayerNorm.
+    src: fp32 NCHW images (first stage) or fp32 tokens [nB, H*W, Cin]; returns fp32 tokens [nB, Ho*Wo, E]."""
+
+    @staticmethod
+    def forward(ctx, src, geo, Wp, bp, g, b):
+        o = ops_module()
+        nchw, nB, H, W, Cin, k, stride, pad = geo
+        src = src.contiguous()
+        if nchw:
+            cols = o.conv_im2col(src, True, nB, H, W, Cin, k, stride, pad)
+        else:
+            cols = o.conv_im2col(o.gather_cast(src.view(nB * H * W, Cin), nB * H * W), False, nB, H, W, Cin, k, stride, pad)
+        Wk = _conv_weight_matrix(Wp)
+        y = o.linear_fwd(cols, Wk, bp, out_f32=True)
+        t, _, mean, rstd = o.layernorm_fwd(y, g, b, CVT_LN_EPS, dtype=torch.float32)
+        ctx.geo = geo
+        ctx.wshape = tuple(Wp.shape)
+        ctx.save_for_backward(cols, Wk, y, mean, rstd, g)
+        Ho, Wo = o.conv_out_size(H, k, stride, pad), o.conv_out_size(W, k, stride, pad)
+        return t.view(nB, Ho * Wo, -1)
+
+    @staticmethod
+    def backward(ctx, gt):
+        o = ops_module()
+        cols, Wk, y, mean, rstd, g = ctx.saved_tensors
+        nchw, nB, H, W, Cin, k, stride, pad = ctx.geo
+        E = y.shape[1]
+        dy, dg, db = o.layernorm_bwd(gt.contiguous().view(-1, E), y, mean, rstd, g)
+        dyb = o.gather_cast(dy, dy.shape[0])
+        dWk, dbp = o.linear_wgrad(dyb, cols, want_bias=True)
+        K = k * k * Cin
+        dWp = dWk[:, :K].reshape(E, k, k, Cin).permute(0, 3, 1, 2).contiguous()
+        dsrc = None
+        if not nchw and ctx.needs_input_grad[0]:
+            dcols = o.linear_dgrad(dyb, Wk)
+            dsrc = o.conv_col2im(dcols, nB, H, W, Cin, k, stride, pad).view(nB, H * W, Cin)
+        return dsrc, None, dWp, dbp, dg, db
+
+
+class CvtAttnFn(torch.autograd.Function):
+    """x + DropPath(Attention(LayerNorm(x)))  (cvt_v4_transformer.py:331-336, 49-58, 108-220): LN -> zero-pad the grid to a
+    multiple of the window -> depthwise 3x3 -> BatchNorm (batch statistics, synchronised across ranks) -> 1x1 to q|k|v ->
+    windowed attention (w = min(window, H, W), scale = dim ** -0.5, no bias / mask in s1.yaml) -> crop -> 1x1 proj."""
+
+    @staticmethod
+    def forward(ctx, x, H, W, nH, window, dp, bn_state, g1, b1, dw_w, bn_g, bn_b, pw_Wp, pw_b, proj_Wp, proj_b):
+        o = ops_module()
+        nB, L, C = x.shape
+        x = x.contiguous()
+        x2d = x.view(nB * L, C)
+        w = min(window, H, W)
+        Hp, Wp = -(-H // w) * w, -(-W // w) * w
+        xn, _, mean1, rstd1 = o.layernorm_fwd(x2d, g1, b1, CVT_LN_EPS)
+        xp = _pad_tokens(xn, nB, H, W, Hp, Wp)
+        dw9 = dw_w.detach().reshape(C, 9).contiguous()
+        d = o.dwconv3x3(xp, dw9, nB, Hp, Wp)
+        # BatchNorm2d, training statistics over every position of the (padded) map on every rank
+        rows = nB * Hp * Wp
+        stats = torch.cat([o.col_sums2(d, d).view(-1), torch.tensor([float(rows)], device=x.device)])
+        _allreduce_stats(stats, bn_state.get("group"))
+        n = stats[-1]
+        bmean = stats[:C] / n
+        bvar = (stats[C:2 * C] / n - bmean * bmean).clamp_min_(0.0)
+        brstd = torch.rsqrt(bvar + BN_EPS)
+        a = bn_g.detach() * brstd
+        bnout = o.col_affine2(d, a.contiguous(), (bn_b.detach() - bmean * a).contiguous())
+        if bn_state.get("running_mean") is not None:  # buffers of the nn.BatchNorm2d holder (momentum 0.1, unbiased variance)
+            with torch.no_grad():
+                bn_state["running_mean"].mul_(1 - BN_MOMENTUM).add_(BN_MOMENTUM * bmean)
+                bn_state["running_var"].mul_(1 - BN_MOMENTUM).add_(BN_MOMENTUM * bvar * (n / (n - 1)))
+                bn_state["num_batches_tracked"].add_(1)
+        Wpw, Wproj = _weight(pw_Wp, (3 * C, C)), _weight(proj_Wp, (C, C))
+        qkv = o.linear_fwd(bnout, Wpw, pw_b)
+        geom = geometry(Hp, Wp, w, 0, x.device)
+        table = _zero_table(w, nH, x.device)
+        scale = float(C) ** -0.5
+        ao, lse = o.window_attn_fwd(qkv, pw_b, geom.win2tok, Hp * Wp, table, w, None, geom.nW, geom.N, nH, scale)
+        aoc = _crop_tokens(ao, nB, H, W, Hp, Wp)
+        x1 = o.linear_fwd(aoc, Wproj, proj_b, residual=x2d, rowscale=dp, rows_per_sample=L, out_f32=True)
+        ctx.meta = (H, W, Hp, Wp, w, nH, scale, dp, bn_state.get("group"))
+        ctx.save_for_backward(x, mean1, rstd1, g1, xp, dw9, d, bmean, brstd, n, bn_g, bnout, Wpw, pw_b, qkv, ao, aoc, Wproj)
+        return x1.view(nB, L, C)
+
+    @staticmethod
+    def backward(ctx, gy):
+        o = ops_module()
+        x, mean1, rstd1, g1, xp, dw9, d, bmean, brstd, n, bn_g, bnout, Wpw, pw_b, qkv, ao, aoc, Wproj = ctx.saved_tensors
+        H, W, Hp, Wp, w, nH, scale, dp, group = ctx.meta
+        nB, L, C = x.shape
+        M = nB * L
+        gy = gy.contiguous().view(M, C)
+        dyb = o.gather_cast(gy, M, rowscale=dp, rows_per_sample=L)
+        dWproj, dbproj = o.linear_wgrad(dyb, aoc, want_bias=True)
+        dao = _pad_tokens(o.linear_dgrad(dyb, Wproj), nB, H, W, Hp, Wp)
+        geom = geometry(Hp, Wp, w, 0, x.device)
+        table = _zero_table(w, nH, x.device)
+        dqkv, _, _ = o.window_attn_bwd(qkv, pw_b, geom.win2tok, Hp * Wp, dao, ao, None, table, w, None, geom.nW, geom.N, nH, scale)
+        dWpw, dbpw = o.linear_wgrad(dqkv, bnout, want_bias=True)
+        dbn = o.linear_dgrad(dqkv, Wpw)
+        # BatchNorm backward: d(d) = gamma rstd (dy - mean(dy) - xhat mean(dy xhat)), xhat = (d - mean) rstd
+        sums = o.col_sums2(dbn, d)
+        s_dy, s_dyd = sums[0].clone(), sums[1].clone()
+        s_dyx = brstd * (s_dyd - bmean * s_dy)          # sum(dy * xhat), local
+        dgam, dbet = s_dyx.clone(), s_dy.clone()
+        red = torch.cat([s_dy, s_dyx])
+        _allreduce_stats(red, group)
+        m1, m2 = red[:C] / n, red[C:] / n
+        gam = bn_g.detach()
+        A = gam * brstd
+        B = -gam * brstd * brstd * m2
+        Cc = -gam * brstd * m1 - B * bmean
+        dd = o.col_affine2(dbn, A.contiguous(), Cc.contiguous(), d, B.contiguous())
+        ddw = o.dwconv3x3_wgrad(xp, dd, nB, Hp, Wp).view(C, 1, 3, 3)
+        dxn = _crop_tokens(o.dwconv3x3(dd, dw9, nB, Hp, Wp, flip=True), nB, H, W, Hp, Wp)
+        gx, dg1, db1 = o.layernorm_bwd(dxn, x.view(M, C), mean1, rstd1, g1, g_in=gy)
+        return (gx.view(nB, L, C), None, None, None, None, None, None, dg1, db1, ddw, dgam, dbet, dWpw.view(3 * C, C, 1, 1), dbpw,
+                dWproj.view(C, C, 1, 1), dbproj)
+
+
+_ZTAB = {}
+
+
+def _zero_table(w, nH, device):
+    key = (w, nH, str(device))
+    t = _ZTAB.get(key)
+    if t is None:
+        t = torch.zeros(((2 * w - 1) ** 2, nH), dtype=torch.float32, device=device)
+        _ZTAB[key] = t
+    return t
+
+
+class CvtFfnFn(torch.autograd.Function):
+    """x + DropPath(FeedForward(LayerNorm(x)))  (cvt_v4_transformer.py:62-72): 1x1 conv -> QuickGELU -> 1x1 conv"""
+
+    @staticmethod
+    def forward(ctx, x, dp, g2, b2, W1p, bf1, W2p, bf2):
+        o = ops_module()
+        nB, L, C = x.shape
+        x = x.contiguous()
+        x2d = x.view(nB * L, C)
+        Hd = W1p.shape[0]
+        W1, W2 = _weight(W1p, (Hd, C)), _weight(W2p, (C, Hd))
+        h, _, mean, rstd = o.layernorm_fwd(x2d, g2, b2, CVT_LN_EPS)
+        a1g, a1 = o.linear_fwd(h, W1, bf1, gelu=True, want_preact=True, quick=True)
+        y = o.linear_fwd(a1g, W2, bf2, residual=x2d, rowscale=dp, rows_per_sample=L, out_f32=True)
+        ctx.dp = dp
+        ctx.save_for_backward(x, mean, rstd, g2, h, a1, a1g, W1, W2)
+        return y.view(nB, L, C)
+
+    @staticmethod
+    def backward(ctx, gy):
+        o = ops_module()
+        x, mean, rstd, g2, h, a1, a1g, W1, W2 = ctx.saved_tensors
+        nB, L, C = x.shape
+        M = nB * L
+        Hd = W1.shape[0]
+        gy = gy.contiguous().view(M, C)
+        dyb = o.gather_cast(gy, M, rowscale=ctx.dp, rows_per_sample=L)
+        dW2, dbf2 = o.linear_wgrad(dyb, a1g, want_bias=True)
+        da1 = o.linear_dgrad(dyb, W2, gelu_preact=a1, quick=True)
+        dW1, dbf1 = o.linear_wgrad(da1, h, want_bias=True)
+        dh = o.linear_dgrad(da1, W1)
+        gx, dg2, db2 = o.layernorm_bwd(dh, x.view(M, C), mean, rstd, g2, g_in=gy)
+        return gx.view(nB, L, C), None, dg2, db2, dW1.view(Hd, C, 1, 1), dbf1, dW2.view(C, Hd, 1, 1), dbf2

@@ -1,0 +1,218 @@
+"""CvT backbone (BASELINE config 5) behind the reference's interface: ``get_cls_model(config, is_teacher,
+use_dense_prediction)`` registered as ``cvt_v4_transformer`` (reference: models/cvt_v4_transformer.py:434-700).
+
+The module tree reproduces the reference's parameter / buffer names, shapes and order (``stage{i}.0.proj``,
+``stage{i}.1.layers.{j}.0.fn.qkv.{dw,bn,pw}``, ``...1.fn.net.{0,2}``, ``norm``, ``head``), so checkpoints are
+interchangeable; the modules are parameter holders only -- the computation runs through the HIP kernels
+(``esvit_amd.functional``: ConvEmbedFn, CvtAttnFn, CvtFfnFn) on token-major NHWC activations.
+
+Scope (what experiments/imagenet/cvt_v4/s1.yaml uses): no relative-position embedding, no shifted windows, no residual
+stem; ``REL_POS_EMBED`` / ``SHIFT`` / ``RES_STEM`` raise NotImplementedError.
+"""
+from functools import partial
+
+import torch
+import torch.nn as nn
+
+from .. import functional as Fn
+from .registry import register_model
+from .swin_transformer import DropPath
+
+
+def _trunc_normal_(t, std=0.02):
+    return nn.init.trunc_normal_(t, std=std, a=-2.0, b=2.0)
+
+
+class LayerNorm(nn.LayerNorm):
+    """parameter holder (cvt_v4_transformer.py:35-41)"""
+
+
+class QuickGELU(nn.Module):
+    """x * sigmoid(1.702 x) (cvt_v4_transformer.py:44-46); fused into the fc1 GEMM epilogue"""
+
+
+class DepthWiseConv2d(nn.Module):
+    """dw 3x3 -> BatchNorm2d -> 1x1 (cvt_v4_transformer.py:75-105): parameter holder"""
+
+    def __init__(self, dim_in, dim_out, kernel_size, padding, stride, bias=True):
+        super().__init__()
+        if kernel_size != 3 or padding != 1 or stride != 1:
+            raise NotImplementedError("depthwise qkv convolution: only 3x3 / pad 1 / stride 1 (s1.yaml)")
+        self.dw = nn.Conv2d(dim_in, dim_in, kernel_size=kernel_size, padding=padding, groups=dim_in, stride=stride, bias=False)
+        self.bn = nn.BatchNorm2d(dim_in)
+        self.pw = nn.Conv2d(dim_in, dim_out, kernel_size=1, bias=bias)
+
+
+class Attention(nn.Module):
+    def __init__(self, dim_in, dim_out, num_heads, qkv_bias, kernel_size, padding, window_size, shift_size, rel_pos_embed, **kwargs):
+        super().__init__()
+        if rel_pos_embed or shift_size:
+            raise NotImplementedError("CvT relative-position embedding / shifted windows are not on the s1.yaml path")
+        self.heads = num_heads
+        self.window_size = window_size
+        self.qkv = DepthWiseConv2d(dim_in, dim_out * 3, kernel_size, padding=padding, stride=1, bias=qkv_bias)
+        self.proj_out = nn.Conv2d(dim_out, dim_in, 1)
+
+
+class FeedForward(nn.Module):
+    def __init__(self, dim, act_layer, mult=4):
+        super().__init__()
+        self.net = nn.Sequential(nn.Conv2d(dim, int(dim * mult), 1), act_layer(), nn.Conv2d(int(dim * mult), dim, 1))
+
+
+class PreNorm(nn.Module):
+    def __init__(self, norm, dim, fn):
+        super().__init__()
+        self.norm = norm(dim)
+        self.fn = fn
+
+
+class Transformer(nn.Module):
+    def __init__(self, embed_dim=768, depth=12, num_heads=12, mlp_ratio=4., qkv_bias=False, drop_path_rate=None, act_layer=QuickGELU,
+                 norm_layer=nn.LayerNorm, kernel_qkv=3, padding_qkv=1, window_size=-1, shift=False, rel_pos_embed=False, **kwargs):
+        super().__init__()
+        if shift:
+            raise NotImplementedError("CvT shifted windows are not on the s1.yaml path")
+        self.layers = nn.ModuleList([])
+        for i in range(depth):
+            self.layers.append(nn.ModuleList([
+                PreNorm(norm_layer, embed_dim,
+                        Attention(dim_in=embed_dim, dim_out=embed_dim, num_heads=num_heads, qkv_bias=qkv_bias, kernel_size=kernel_qkv,
+                                  padding=padding_qkv, window_size=window_size, shift_size=0, rel_pos_embed=rel_pos_embed)),
+                PreNorm(norm_layer, embed_dim, FeedForward(embed_dim, act_layer, mlp_ratio)),
+                DropPath(drop_path_rate[i]) if isinstance(drop_path_rate, list) else nn.Identity()]))
+        self.window_size = window_size
+        self.shift = shift
+        self.sync_bn_group = None  # process group of the SyncBatchNorm statistics (None: default group; False: local statistics)
+
+    def forward_tokens(self, x, H, W):
+        """x fp32 [nB, H*W, C] (token-major)"""
+        nB = x.shape[0]
+        for attn, ff, drop_path in self.layers:
+            dp1 = dp2 = None
+            if isinstance(drop_path, DropPath):
+                dp1, dp2 = drop_path.factors(nB, x.device), drop_path.factors(nB, x.device)
+            a, bn = attn.fn, attn.fn.qkv.bn
+            bn_state = {"group": self.sync_bn_group}
+            if self.training and bn.track_running_stats:
+                bn_state.update(running_mean=bn.running_mean, running_var=bn.running_var, num_batches_tracked=bn.num_batches_tracked)
+            if not self.training:
+                raise NotImplementedError("CvT eval-mode BatchNorm (running statistics) is not built: the EsViT step keeps both networks "
+                                          "in train mode (main_esvit.py never calls .eval() on student or teacher)")
+            x = Fn.CvtAttnFn.apply(x, H, W, a.heads, a.window_size, dp1, bn_state, attn.norm.weight, attn.norm.bias, a.qkv.dw.weight,
+                                   bn.weight, bn.bias, a.qkv.pw.weight, a.qkv.pw.bias, a.proj_out.weight, a.proj_out.bias)
+            x = Fn.CvtFfnFn.apply(x, dp2, ff.norm.weight, ff.norm.bias, ff.fn.net[0].weight, ff.fn.net[0].bias, ff.fn.net[2].weight,
+                                  ff.fn.net[2].bias)
+        return x
+
+
+class ConvEmbed(nn.Module):
+    def __init__(self, patch_size=7, in_chans=3, embed_dim=64, stride=4, padding=2, norm_layer=None):
+        super().__init__()
+        self.patch_size, self.stride, self.padding, self.in_chans = patch_size, stride, padding, in_chans
+        self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=patch_size, stride=stride, padding=padding)
+        self.norm = norm_layer(embed_dim) if norm_layer else None
+        if self.norm is None:
+            raise NotImplementedError("ConvEmbed without a norm layer is not on the reference path")
+
+    def forward_tokens(self, src, nchw, nB, H, W):
+        geo = (nchw, nB, H, W, self.in_chans, self.patch_size, self.stride, self.padding)
+        t = Fn.ConvEmbedFn.apply(src, geo, self.proj.weight, self.proj.bias, self.norm.weight, self.norm.bias)
+        o = Fn.ops_module()
+        return t, o.conv_out_size(H, self.patch_size, self.stride, self.padding), o.conv_out_size(W, self.patch_size, self.stride, self.padding)
+
+
+class CvT(nn.Module):
+    def __init__(self, *, num_classes, act_layer=QuickGELU, norm_layer=nn.LayerNorm, init='trunc_norm', use_dense_prediction=False, spec=None):
+        super().__init__()
+        self.num_stages = spec['NUM_STAGES']
+        total_depth = sum(spec['DEPTH'])
+        dpr = [x.item() for x in torch.linspace(0, spec['DROP_PATH_RATE'], total_depth)]
+        if spec['REL_POS_EMBED'] or any(spec['SHIFT']) or spec.get('RES_STEM', False):
+            raise NotImplementedError("CvT REL_POS_EMBED / SHIFT / RES_STEM variants are not built (s1.yaml uses none of them)")
+        in_chans, depth_accum = 3, 0
+        for i in range(self.num_stages):
+            conv = ConvEmbed(patch_size=spec['PATCH_SIZE'][i], in_chans=in_chans, embed_dim=spec['DIM_EMBED'][i],
+                             stride=spec['PATCH_STRIDE'][i], padding=spec['PATCH_PADDING'][i], norm_layer=norm_layer)
+            tr = Transformer(embed_dim=spec['DIM_EMBED'][i], depth=spec['DEPTH'][i], num_heads=spec['NUM_HEADS'][i],
+                             mlp_ratio=spec['MLP_RATIO'][i], qkv_bias=spec['QKV_BIAS'][i],
+                             drop_path_rate=dpr[depth_accum: depth_accum + spec['DEPTH'][i]], act_layer=act_layer, norm_layer=norm_layer,
+                             kernel_qkv=spec['KERNEL_QKV'][i], padding_qkv=spec['PADDING_QKV'][i], window_size=spec['WINDOW_SIZE'][i],
+                             shift=spec['SHIFT'][i], rel_pos_embed=spec['REL_POS_EMBED'])
+            setattr(self, f'stage{i}', nn.Sequential(conv, tr))
+            in_chans = spec['DIM_EMBED'][i]
+            depth_accum += spec['DEPTH'][i]
+        self.norm = norm_layer(in_chans)
+        self.num_features = in_chans
+        self.head = nn.Linear(in_chans, num_classes) if num_classes > 0 else nn.Identity()
+        self.use_dense_prediction = use_dense_prediction
+        if self.use_dense_prediction:
+            self.head_dense = None
+        self.apply(self._init_weights_trunc_normal)
+
+    def _init_weights_trunc_normal(self, m):
+        if isinstance(m, (nn.Linear, nn.Conv2d)):
+            _trunc_normal_(m.weight, std=0.02)
+            if m.bias is not None:
+                nn.init.constant_(m.bias, 0)
+        elif isinstance(m, (nn.LayerNorm, nn.BatchNorm2d)):
+            nn.init.constant_(m.bias, 0)
+            nn.init.constant_(m.weight, 1.0)
+
+    def forward_feature_maps(self, x):
+        """images fp32 NCHW -> (cls [nB, C], region tokens [nB, H*W, C]) fp32  (cvt_v4_transformer.py:549-566)"""
+        nB, _, H, W = x.shape
+        src, nchw = x, True
+        for i in range(self.num_stages):
+            conv, tr = getattr(self, f'stage{i}')
+            t, H, W = conv.forward_tokens(src, nchw, nB, H, W)
+            src, nchw = tr.forward_tokens(t, H, W), False
+        x_region = Fn.FinalNormFn.apply(src, self.norm.weight, self.norm.bias, Fn.CVT_LN_EPS)
+        return Fn.TokenMeanFn.apply(x_region), x_region
+
+    def forward_features(self, x):
+        cls, region = self.forward_feature_maps(x)
+        return (cls, region) if self.use_dense_prediction else cls
+
+    def forward(self, x):
+        if not isinstance(x, list):
+            x = [x]
+        bounds, start = [], 0  # consecutive crops of equal resolution run as one batch (cvt_v4_transformer.py:625-628)
+        for i in range(1, len(x) + 1):
+            if i == len(x) or x[i].shape[-1] != x[start].shape[-1]:
+                bounds.append((start, i))
+                start = i
+        if self.use_dense_prediction:
+            cls_parts, fea_parts, npatch = [], [], []
+            for a, b in bounds:
+                cls, fea = self.forward_feature_maps(torch.cat(x[a:b]))
+                B, N, C = fea.shape
+                cls_parts.append(cls)
+                fea_parts.append(fea.reshape(B * N, C))
+                npatch.append(N)
+            output_cls = cls_parts[0] if len(cls_parts) == 1 else torch.cat(cls_parts)
+            output_fea = fea_parts[0] if len(fea_parts) == 1 else torch.cat(fea_parts)
+            return self.head(output_cls), self.head_dense(output_fea), output_fea, npatch
+        outs = [self.forward_features(torch.cat(x[a:b])) for a, b in bounds]
+        return self.head(outs[0] if len(outs) == 1 else torch.cat(outs))
+
+    def init_weights(self, pretrained='', pretrained_layers=[], verbose=True):
+        import os
+        if os.path.isfile(pretrained):
+            pretrained_dict = torch.load(pretrained, map_location='cpu')
+            model_dict = self.state_dict()
+            need = {k: v for k, v in pretrained_dict.items() if k in model_dict and (k.split('.')[0] in pretrained_layers or
+                                                                                       pretrained_layers[0] == '*')}
+            self.load_state_dict(need, strict=False)
+
+
+@register_model
+def get_cls_model(config, is_teacher=False, use_dense_prediction=False, **kwargs):
+    cvt_spec = config.MODEL.SPEC
+    if is_teacher:
+        cvt_spec['DROP_PATH_RATE'] = 0.0
+    cvt = CvT(num_classes=config.MODEL.NUM_CLASSES, act_layer=QuickGELU, norm_layer=partial(LayerNorm, eps=1e-5), init='trunc_norm',
+              use_dense_prediction=use_dense_prediction, spec=cvt_spec)
+    if config.MODEL.INIT_WEIGHTS:
+        cvt.init_weights(config.MODEL.PRETRAINED, config.MODEL.PRETRAINED_LAYERS, config.VERBOSE)
+    return cvt

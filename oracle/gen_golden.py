@@ -155,12 +155,65 @@ def gen_nano14(ns):
     print("nano14_step.pt: loss", g["ddino_loss"])
 
 
+def build_nano_cvt(ns, teacher=False):
+    cfg = RL.cvt_config(dims=GU.NANO_CVT["dims"], heads=GU.NANO_CVT["heads"], depths=GU.NANO_CVT["depths"])
+    m = ns.models.build_model(cfg, is_teacher=teacher, use_dense_prediction=True)
+    hk = dict(hidden_dim=GU.NANO_HEAD["hidden_dim"], bottleneck_dim=GU.NANO_HEAD["bottleneck_dim"])
+    fea = GU.NANO_CVT["dims"][-1]
+    m.head = ns.DINOHead(fea, GU.NANO_HEAD["out_dim"], norm_last_layer=True, **hk)
+    m.head_dense = ns.DINOHead(fea, GU.NANO_HEAD["out_dim"], norm_last_layer=False, **hk)
+    return m
+
+
+def gen_nano_cvt(ns):
+    """CvT (cvt_v4_transformer, BASELINE config 5) in miniature: ConvEmbed 7/4/2 + 3/2/1, depthwise-conv + BatchNorm qkv, windowed
+    attention at head_dim 64 with 7x7 / 6x6 / 3x3 windows and a padded 12 -> 14 grid, QuickGELU FFN; train-mode BatchNorm."""
+    RL.ensure_single_process_group()
+    student, teacher = build_nano_cvt(ns), build_nano_cvt(ns, teacher=True)
+    GU.fill_state_dict(student.state_dict(), seed=0)
+    GU.fill_state_dict(teacher.state_dict(), seed=7)
+    for m in (student, teacher):
+        for k, v in m.state_dict().items():
+            if k.endswith("running_var"):
+                v.abs_().add_(0.5)
+    student.head.last_layer.weight_g.data.fill_(1)
+    for p in teacher.parameters():
+        p.requires_grad = False
+    crops = GU.make_crops(2, n_local=3, sizes=GU.NANO_CVT["sizes"])
+    K = GU.NANO_HEAD["out_dim"]
+    g = {"keys": [(k, tuple(v.shape), str(v.dtype)) for k, v in student.state_dict().items()],
+         "param_names": [n for n, _ in student.named_parameters()]}
+    loss_fn = ns.DDINOLoss(K, 5, 0.04, 0.07, 5, 10)
+    t_out = teacher(crops[:2])
+    s_out = student(crops)
+    for nm, t in (("s_cls", s_out[0]), ("s_reg", s_out[1]), ("s_fea", s_out[2]), ("t_cls", t_out[0]), ("t_reg", t_out[1]), ("t_fea", t_out[2])):
+        g[nm] = GU.probe(t)
+    g["s_fea_full"] = s_out[2].detach().clone()
+    g["npatch"] = (list(s_out[3]), list(t_out[3]))
+    loss = loss_fn(s_out, t_out, 2, None)
+    g["ddino_loss"] = loss.item()
+    student.zero_grad()
+    loss.backward()
+    g["grads"] = {n: GU.probe(p.grad) for n, p in student.named_parameters() if p.grad is not None}
+    g["grad_norms"] = {n: p.grad.norm().item() for n, p in student.named_parameters() if p.grad is not None}
+    g["no_grad"] = [n for n, p in student.named_parameters() if p.grad is None]
+    g["bn_buffers"] = {k: v.detach().clone() for k, v in student.state_dict().items() if "running_" in k or "num_batches" in k}
+    torch.save(g, os.path.join(OUT, "nano_cvt_step.pt"))
+    print("nano_cvt_step.pt: loss", g["ddino_loss"], "npatch", g["npatch"], "params", len(g["param_names"]), "no_grad", g["no_grad"])
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ns = RL.load()
-    gen_index_maps(ns)
-    gen_nano(ns)
-    gen_nano14(ns)
+    only = sys.argv[1:]  # e.g. `python oracle/gen_golden.py cvt` regenerates one fixture
+    if not only or "maps" in only:
+        gen_index_maps(ns)
+    if not only or "nano" in only:
+        gen_nano(ns)
+    if not only or "nano14" in only:
+        gen_nano14(ns)
+    if not only or "cvt" in only:
+        gen_nano_cvt(ns)
 
 
 if __name__ == "__main__":

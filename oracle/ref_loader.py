@@ -118,3 +118,14 @@ def swin_config(embed_dim=96, depths=(2, 2, 6, 2), heads=(3, 6, 12, 24), window=
                                          MLP_RATIO=4, QKV_BIAS=True, DROP_RATE=0, ATTN_DROP_RATE=0, DROP_PATH_RATE=drop_path,
                                          USE_APE=False, PATCH_NORM=True)),
                     TRAIN=dict(IMAGE_SIZE=[img, img]), FINETUNE=dict(FINETUNE=False, FROZEN_LAYERS=[]), VERBOSE=False)
+
+
+def cvt_config(dims=(64, 192, 384, 768), heads=(1, 3, 6, 12), depths=(2, 2, 6, 2), drop_path=0.0, num_classes=0):
+    """experiments/imagenet/cvt_v4/s1.yaml with the stage lists cut to len(dims) (no relative-position embedding, no shift)."""
+    n = len(dims)
+    return AttrDict(MODEL=dict(NAME="cvt_v4_transformer", NUM_CLASSES=num_classes, INIT_WEIGHTS=False, PRETRAINED="", PRETRAINED_LAYERS=["*"],
+                               SPEC=dict(INIT="trunc_norm", NUM_STAGES=n, REL_POS_EMBED=False, SHIFT=[False] * n, DROP_PATH_RATE=drop_path,
+                                         PATCH_SIZE=[7] + [3] * (n - 1), PATCH_STRIDE=[4] + [2] * (n - 1), PATCH_PADDING=[2] + [1] * (n - 1),
+                                         WINDOW_SIZE=[7] * n, DIM_EMBED=list(dims), NUM_HEADS=list(heads), DEPTH=list(depths),
+                                         MLP_RATIO=[4.0] * n, QKV_BIAS=[True] * n, KERNEL_QKV=[3] * n, PADDING_QKV=[1] * n)),
+                    VERBOSE=False)

@@ -152,3 +152,69 @@ def test_composition_w14_matches_reference_golden(cpu_ops):
     assert [(k, tuple(v.shape), str(v.dtype)) for k, v in student.state_dict().items()] == g14["keys"]
     s_out, t_out, loss = run_nano14_step(student, teacher, L)
     check_nano14(g14, student, s_out, t_out, loss, rt=2e-4, loss_tol=2e-5, grad_tol=1e-3)
+
+
+# ---- CvT (BASELINE config 5) -------------------------------------------------------------------
+def build_nano_cvt(teacher=False):
+    from esvit_amd import models
+    cfg = RL.cvt_config(dims=GU.NANO_CVT["dims"], heads=GU.NANO_CVT["heads"], depths=GU.NANO_CVT["depths"])
+    m = models.build_model(cfg, is_teacher=teacher, use_dense_prediction=True)
+    hk = dict(hidden_dim=GU.NANO_HEAD["hidden_dim"], bottleneck_dim=GU.NANO_HEAD["bottleneck_dim"])
+    fea = GU.NANO_CVT["dims"][-1]
+    m.head = models.DINOHead(fea, GU.NANO_HEAD["out_dim"], norm_last_layer=True, **hk)
+    m.head_dense = models.DINOHead(fea, GU.NANO_HEAD["out_dim"], norm_last_layer=False, **hk)
+    return m
+
+
+def nano_cvt_pair(dev="cpu"):
+    student, teacher = build_nano_cvt(), build_nano_cvt(teacher=True)
+    GU.fill_state_dict(student.state_dict(), 0)
+    GU.fill_state_dict(teacher.state_dict(), 7)
+    for m in (student, teacher):
+        for k, v in m.state_dict().items():
+            if k.endswith("running_var"):
+                v.abs_().add_(0.5)
+    student.head.last_layer.weight_g.data.fill_(1)
+    for p in teacher.parameters():
+        p.requires_grad = False
+    return student.to(dev), teacher.to(dev)
+
+
+def run_nano_cvt_step(student, teacher, loss_mod, dev="cpu"):
+    crops = [c.to(dev) for c in GU.make_crops(2, n_local=3, sizes=GU.NANO_CVT["sizes"])]
+    loss_fn = loss_mod.DDINOLoss(GU.NANO_HEAD["out_dim"], 5, 0.04, 0.07, 5, 10).to(dev)
+    t_out = teacher(crops[:2])
+    s_out = student(crops)
+    loss = loss_fn(s_out, t_out, 2, None)
+    loss.backward()
+    return s_out, t_out, loss
+
+
+def check_nano_cvt(g, student, s_out, t_out, loss, rt, loss_tol, grad_tol, buf_tol):
+    assert list(s_out[3]) == g["npatch"][0] and list(t_out[3]) == g["npatch"][1]
+    for nm, t in (("s_cls", s_out[0]), ("s_reg", s_out[1]), ("s_fea", s_out[2]), ("t_cls", t_out[0]), ("t_reg", t_out[1]), ("t_fea", t_out[2])):
+        probe_close(nm, t.float().cpu(), g[nm], rtol=rt)
+    assert abs(loss.item() - g["ddino_loss"]) < loss_tol, (loss.item(), g["ddino_loss"])
+    got = {n: p.grad for n, p in student.named_parameters() if p.grad is not None}
+    assert sorted(got) == sorted(g["grad_norms"])
+    for n, ref in g["grad_norms"].items():
+        assert abs(got[n].norm().item() - ref) <= grad_tol * ref + 1e-9, (n, got[n].norm().item(), ref)
+    sd = student.state_dict()
+    for k, v in g["bn_buffers"].items():
+        assert torch.allclose(sd[k].float().cpu(), v.float(), rtol=buf_tol, atol=buf_tol), k
+
+
+def test_cvt_state_dict_layout_matches_golden():
+    g = torch.load(os.path.join(GOLD, "nano_cvt_step.pt"), weights_only=False)
+    student = build_nano_cvt()
+    assert [(k, tuple(v.shape), str(v.dtype)) for k, v in student.state_dict().items()] == g["keys"]
+    assert [n for n, _ in student.named_parameters()] == g["param_names"]
+
+
+def test_cvt_composition_matches_reference_golden(cpu_ops):
+    """the CvT module tree + autograd glue (ConvEmbedFn / CvtAttnFn / CvtFfnFn) on the torch restatement of every kernel"""
+    import esvit_amd.loss as L
+    g = torch.load(os.path.join(GOLD, "nano_cvt_step.pt"), weights_only=False)
+    student, teacher = nano_cvt_pair()
+    s_out, t_out, loss = run_nano_cvt_step(student, teacher, L)
+    check_nano_cvt(g, student, s_out, t_out, loss, rt=3e-4, loss_tol=2e-5, grad_tol=2e-3, buf_tol=1e-4)

@@ -101,6 +101,39 @@ def test_oracle_w14_matches_reference_golden():
         probe_close("grad " + n, params[n].grad, p, rtol=1e-3)
 
 
+def test_oracle_cvt_matches_reference_golden():
+    """CvT (cvt_v4_transformer, BASELINE config 5): conv embeds, depthwise-conv + train-mode BatchNorm qkv, head_dim-64 windows
+    (7x7, padded 12 -> 14, 6x6, 3x3), QuickGELU FFN -- outputs, loss and every gradient against the reference"""
+    g = torch.load(os.path.join(GOLD, "nano_cvt_step.pt"), weights_only=False)
+    shapes = {k: (shp, dt) for k, shp, dt in g["keys"]}
+
+    def make_sd(seed):
+        sd = {k: torch.zeros(shp, dtype=getattr(torch, dt.split(".")[1])) for k, (shp, dt) in shapes.items()}
+        GU.fill_state_dict(sd, seed)
+        return sd
+    sd, tsd = make_sd(0), make_sd(7)
+    sd["head.last_layer.weight_g"].fill_(1)
+    names = list(g["grad_norms"])
+    params = {n: sd[n].clone().requires_grad_(True) for n in names}
+    full = dict(sd)
+    full.update(params)
+    crops = GU.make_crops(2, n_local=3, sizes=GU.NANO_CVT["sizes"])
+    s_out = O.cvt_multicrop(full, crops, GU.NANO_CVT)
+    with torch.no_grad():
+        t_out = O.cvt_multicrop(tsd, crops[:2], GU.NANO_CVT)
+    assert list(s_out[3]) == g["npatch"][0] and list(t_out[3]) == g["npatch"][1]
+    for nm, t in (("s_cls", s_out[0]), ("s_reg", s_out[1]), ("s_fea", s_out[2]), ("t_cls", t_out[0]), ("t_reg", t_out[1]), ("t_fea", t_out[2])):
+        probe_close(nm, t, g[nm])
+    K = GU.NANO_HEAD["out_dim"]
+    loss, _, _ = O.ddino_loss(s_out, t_out, torch.zeros(1, K), torch.zeros(1, K), O.teacher_temp(2, 0.04, 0.07, 5, 10), 5)
+    assert abs(loss.item() - g["ddino_loss"]) < 1e-5
+    loss.backward()
+    for n, ref in g["grad_norms"].items():
+        assert abs(params[n].grad.norm().item() - ref) <= 2e-3 * ref + 1e-9, n
+    for n, p in g["grads"].items():
+        probe_close("grad " + n, params[n].grad, p, rtol=2e-3)
+
+
 def test_oracle_step_matches_reference_golden(nano):
     torch.manual_seed(0)
     K = GU.NANO_HEAD["out_dim"]

@@ -7,7 +7,8 @@ import torch
 
 from oracle import esvit_oracle as O
 from tests import golden_utils as GU
-from tests.test_composition_cpu import build_nano, check_nano14, nano_pair, run_nano14_step, run_nano_step
+from tests.test_composition_cpu import (build_nano, check_nano14, check_nano_cvt, nano_cvt_pair, nano_pair, run_nano14_step,
+                                        run_nano_cvt_step, run_nano_step)
 from tests.test_oracle_cpu import GOLD, probe_close
 
 pytestmark = pytest.mark.gpu
@@ -172,5 +173,28 @@ def test_nano_w14_step_matches_reference_golden(prec, lib_built):
         fp = prec == "fp32"
         check_nano14(g14, student, s_out, t_out, loss, rt=3e-4 if fp else 3e-2, loss_tol=1e-4 if fp else 1e-2,
                      grad_tol=2e-3 if fp else 0.15, probes=fp)
+    finally:
+        _teardown()
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_nano_cvt_step_matches_reference_golden(prec, lib_built):
+    """CvT (BASELINE config 5) through the HIP path: ConvEmbed im2col + GEMM, depthwise 3x3 + BatchNorm kernels, head_dim-64 window
+    attention (7x7, padded 12 -> 14, 6x6, 3x3), QuickGELU GEMM epilogues -- forward, loss, every gradient, BN running statistics"""
+    import esvit_amd.loss as L
+    g = torch.load(os.path.join(GOLD, "nano_cvt_step.pt"), weights_only=False)
+    dev = _setup(prec)
+    try:
+        student, teacher = nano_cvt_pair(dev)
+        s_out, t_out, loss = run_nano_cvt_step(student, teacher, L, dev=dev)
+        fp = prec == "fp32"
+        if fp:
+            check_nano_cvt(g, student, s_out, t_out, loss, rt=5e-4, loss_tol=1e-4, grad_tol=3e-3, buf_tol=1e-4)
+        else:
+            assert abs(loss.item() - g["ddino_loss"]) < 2e-2, (loss.item(), g["ddino_loss"])
+            got = {n: p.grad for n, p in student.named_parameters() if p.grad is not None}
+            assert sorted(got) == sorted(g["grad_norms"])
+            for n, ref in g["grad_norms"].items():
+                assert abs(got[n].norm().item() - ref) <= 0.2 * ref + 1e-6, (n, got[n].norm().item(), ref)
     finally:
         _teardown()
