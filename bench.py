@@ -24,7 +24,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 GFLOP_PER_IMG = 154.5          # Swin-T W7 V+R, teacher fwd + student fwd + 2x student bwd + loss
-GFLOP_PER_IMG_BY_ARCH = {"swin_tiny_w7": 154.5, "swin_tiny_w14": 197.0, "swin_base_w14": 628.5}
+GFLOP_PER_IMG_BY_ARCH = {"swin_tiny_w7": 154.5, "swin_tiny_w14": 197.0, "swin_base_w14": 628.5, "cvt_s1": 136.7}
 BF16_PEAK_TFLOPS = 2500.0      # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E (MI355X_MICROARCH.md; ~6.3 TB/s is what a streaming kernel reaches)
 OUT_DIM = 65536
@@ -49,7 +49,7 @@ def pmc_gemm_traffic_per_launch(arch, batch, launches_per_step):
 def build(dev, drop_path, arch="swin_tiny_w7"):
     import esvit_amd
     from esvit_amd import config as CFG
-    cfg = CFG.swin_config(arch, DROP_PATH_RATE=drop_path)
+    cfg = CFG.model_config(arch, DROP_PATH_RATE=drop_path)
     student = esvit_amd.build_model(cfg, use_dense_prediction=True)
     student.head = esvit_amd.DINOHead(student.num_features, OUT_DIM)
     student.head_dense = esvit_amd.DINOHead(student.num_features, OUT_DIM)
@@ -171,7 +171,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=128, help="images per GPU (BASELINE.json configs 3/4: 1024 over 8 GPUs)")
     ap.add_argument("--drop-path", type=float, default=0.1)
-    ap.add_argument("--arch", default="swin_tiny_w7", choices=["swin_tiny_w7", "swin_tiny_w14", "swin_base_w14", "swin_small_w7", "swin_base_w7"],
+    ap.add_argument("--arch", default="swin_tiny_w7", choices=["swin_tiny_w7", "swin_tiny_w14", "swin_base_w14", "swin_small_w7", "swin_base_w7", "cvt_s1"],
                     help="BASELINE.json's metric is quoted on swin_tiny_w7 (default); configs 3/4 are swin_tiny_w14 / swin_base_w14")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")

@@ -36,6 +36,15 @@ SWIN_SPECS = {
 }
 
 
+# experiments/imagenet/cvt_v4/s1.yaml (CvT-13: BASELINE config 5)
+CVT_SPECS = {
+    "cvt_s1": dict(INIT="trunc_norm", NUM_STAGES=4, REL_POS_EMBED=False, SHIFT=[False] * 4, DROP_PATH_RATE=0.1, PATCH_SIZE=[7, 3, 3, 3],
+                   PATCH_STRIDE=[4, 2, 2, 2], PATCH_PADDING=[2, 1, 1, 1], WINDOW_SIZE=[7, 7, 7, 7], DIM_EMBED=[64, 192, 384, 768],
+                   NUM_HEADS=[1, 3, 6, 12], DEPTH=[2, 2, 6, 2], MLP_RATIO=[4.0] * 4, QKV_BIAS=[True] * 4, KERNEL_QKV=[3] * 4,
+                   PADDING_QKV=[1] * 4),
+}
+
+
 def _merge(base, over):
     out = dict(base)
     for k, v in over.items():
@@ -48,6 +57,18 @@ def swin_config(name="swin_tiny_w7", **spec_overrides):
     spec.update(spec_overrides)
     cfg = _merge(_DEFAULTS, dict(MODEL=dict(SPEC=spec)))
     return CfgNode(cfg)
+
+
+def cvt_config(name="cvt_s1", **spec_overrides):
+    spec = dict(CVT_SPECS[name])
+    spec.update(spec_overrides)
+    cfg = _merge(_DEFAULTS, dict(MODEL=dict(NAME="cvt_v4_transformer", SPEC=spec)))
+    return CfgNode(cfg)
+
+
+def model_config(name, **spec_overrides):
+    """named architecture -> config (swin_* -> swin_transformer, cvt_* -> cvt_v4_transformer)"""
+    return cvt_config(name, **spec_overrides) if name in CVT_SPECS else swin_config(name, **spec_overrides)
 
 
 def from_yaml(path, opts=None):

@@ -67,7 +67,43 @@ def _center_worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("worker,port", [(_reducer_worker, 29611), (_center_worker, 29612)])
+def _syncbn_worker(rank, world, port, out):
+    """CvT attention block (depthwise conv + BatchNorm): batch statistics and the BatchNorm backward reductions all-reduced over the
+    ranks give, per rank, exactly the outputs / input gradients of one process that sees the whole batch (SyncBatchNorm semantics,
+    main_esvit.py:365-379), and the summed parameter gradients equal the single-process ones."""
+    _init(rank, world, port)
+    import esvit_amd.functional as Fn
+    import esvit_amd.params as P
+    from oracle import ops_ref
+    Fn.ops = ops_ref
+    P.ops = ops_ref
+    ops_ref.set_act_dtype(torch.float32)
+    C, H, W, nH, B = 64, 6, 6, 1, 2
+    g = torch.Generator().manual_seed(11)
+    x_all = torch.randn(world * B, H * W, C, generator=g)
+    gy_all = torch.randn(world * B, H * W, C, generator=g)
+    prm = [1 + 0.1 * torch.randn(C, generator=g), 0.1 * torch.randn(C, generator=g), 0.3 * torch.randn(C, 1, 3, 3, generator=g),
+           1 + 0.1 * torch.randn(C, generator=g), 0.1 * torch.randn(C, generator=g), 0.05 * torch.randn(3 * C, C, 1, 1, generator=g),
+           0.02 * torch.randn(3 * C, generator=g), 0.05 * torch.randn(C, C, 1, 1, generator=g), 0.02 * torch.randn(C, generator=g)]
+
+    def run(x, gy, group):
+        ps = [p.clone().requires_grad_(True) for p in prm]
+        xx = x.clone().requires_grad_(True)
+        y = Fn.CvtAttnFn.apply(xx, H, W, nH, 7, None, {"group": group}, *ps)
+        y.backward(gy)
+        return y.detach(), xx.grad, [p.grad for p in ps]
+    y, gx, gp = run(x_all[rank * B:(rank + 1) * B], gy_all[rank * B:(rank + 1) * B], None)      # synchronised statistics
+    y1, gx1, gp1 = run(x_all, gy_all, False)                                                      # one process, whole batch
+    ok = torch.allclose(y, y1[rank * B:(rank + 1) * B], rtol=1e-4, atol=1e-5) and torch.allclose(gx, gx1[rank * B:(rank + 1) * B], rtol=1e-4, atol=1e-5)
+    for a, b in zip(gp, gp1):
+        tot = a.clone()
+        dist.all_reduce(tot)
+        ok = ok and torch.allclose(tot, b, rtol=2e-4, atol=1e-5)
+    out[rank] = bool(ok)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("worker,port", [(_reducer_worker, 29611), (_center_worker, 29612), (_syncbn_worker, 29613)])
 def test_world2_gloo(worker, port, lib_built):
     world = 2
     out = mp.Manager().dict()
