@@ -65,18 +65,35 @@ __global__ void col2im_kernel(const T* __restrict__ dcols, int nB, int H, int W,
     }
 }
 
-// one thread per (position, 4-channel group)
+// Thread layout shared by the three per-channel kernels below: a workgroup is C4 = C/4 channel lanes x PY position
+// lanes (C4 * PY <= 256).  A thread keeps ONE group of 4 channels for its whole life -- its 36 taps (or its accumulators)
+// sit in registers -- and strides over positions p = blockIdx.x * PY + ty, += gridDim.x * PY.
+__device__ __forceinline__ f32x4 load4c(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ f32x4 load4c(const bf16* p) {
+    const bf16x4 v = *reinterpret_cast<const bf16x4*>(p);
+    return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+}
+__device__ __forceinline__ void store4c(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+__device__ __forceinline__ void store4c(bf16* p, f32x4 v) {
+    *reinterpret_cast<bf16x4*>(p) = bf16x4{(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+}
+
 template <typename T>
-__global__ void dwconv3x3_kernel(const T* __restrict__ x, const float* __restrict__ w, int flip, int nB, int H, int W, int C,
-                                 T* __restrict__ y) {
-    const int C4 = C / 4;
-    const long total = (long)nB * H * W * C4;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % C4) * 4;
-        const long p = i / C4;
+__global__ __launch_bounds__(256) void dwconv3x3_kernel(const T* __restrict__ x, const float* __restrict__ w, int flip, int nB, int H, int W, int C,
+                                                        T* __restrict__ y) {
+    const int c = threadIdx.x * 4, PY = blockDim.y;
+    f32x4 wt[9];  // wt[t][e] = tap t of channel c+e
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int ts = flip ? 8 - t : t;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) wt[t][e] = w[(c + e) * 9 + ts];
+    }
+    const long P = (long)nB * H * W;
+    for (long p = (long)blockIdx.x * PY + threadIdx.y; p < P; p += (long)gridDim.x * PY) {
         const int ix = (int)(p % W), iy = (int)((p / W) % H);
         const long b = p / ((long)W * H);
-        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
             const int sy = iy + ky - 1;
@@ -85,61 +102,77 @@ __global__ void dwconv3x3_kernel(const T* __restrict__ x, const float* __restric
             for (int kx = 0; kx < 3; ++kx) {
                 const int sx = ix + kx - 1;
                 if (sx < 0 || sx >= W) continue;
-                const T* xp = x + ((b * H + sy) * W + sx) * C + c;
-                const int t = flip ? (2 - ky) * 3 + (2 - kx) : ky * 3 + kx;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) acc[e] += to_f32(xp[e]) * w[(c + e) * 9 + t];
+                acc += load4c(x + ((b * H + sy) * W + sx) * C + c) * wt[ky * 3 + kx];
             }
         }
-        T* yp = y + p * C + c;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) yp[e] = from_f32<T>(acc[e]);
+        store4c(y + p * C + c, acc);
     }
 }
 
-// ws[blk][c*9 + t] = sum over the block's positions of x(shifted by tap t) * dy
+// ws[blk][(c+e)*9 + t] = sum over the block's positions of x(shifted by tap t) * dy
 template <typename T>
 __global__ __launch_bounds__(256) void dwconv3x3_wgrad_kernel(const T* __restrict__ x, const T* __restrict__ dy, int nB, int H, int W, int C,
                                                               float* __restrict__ ws) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    f32x4* sm = reinterpret_cast<f32x4*>(smem_raw);  // [PY][C4][9]
+    const int c4 = threadIdx.x, c = c4 * 4, PY = blockDim.y, C4 = blockDim.x;
+    f32x4 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     const long P = (long)nB * H * W;
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        float acc[9];
+    for (long p = (long)blockIdx.x * PY + threadIdx.y; p < P; p += (long)gridDim.x * PY) {
+        const int ix = (int)(p % W), iy = (int)((p / W) % H);
+        const long b = p / ((long)W * H);
+        const f32x4 g = load4c(dy + p * C + c);
 #pragma unroll
-        for (int t = 0; t < 9; ++t) acc[t] = 0.f;
-        for (long p = blockIdx.x; p < P; p += gridDim.x) {
-            const int ix = (int)(p % W), iy = (int)((p / W) % H);
-            const long b = p / ((long)W * H);
-            const float g = to_f32(dy[p * C + c]);
+        for (int ky = 0; ky < 3; ++ky) {
+            const int sy = iy + ky - 1;
+            if (sy < 0 || sy >= H) continue;
 #pragma unroll
-            for (int ky = 0; ky < 3; ++ky) {
-                const int sy = iy + ky - 1;
-                if (sy < 0 || sy >= H) continue;
-#pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-                    const int sx = ix + kx - 1;
-                    if (sx < 0 || sx >= W) continue;
-                    acc[ky * 3 + kx] += g * to_f32(x[((b * H + sy) * W + sx) * C + c]);
-                }
+            for (int kx = 0; kx < 3; ++kx) {
+                const int sx = ix + kx - 1;
+                if (sx < 0 || sx >= W) continue;
+                acc[ky * 3 + kx] += g * load4c(x + ((b * H + sy) * W + sx) * C + c);
             }
         }
+    }
 #pragma unroll
-        for (int t = 0; t < 9; ++t) ws[((long)blockIdx.x * C + c) * 9 + t] = acc[t];
+    for (int t = 0; t < 9; ++t) sm[(threadIdx.y * C4 + c4) * 9 + t] = acc[t];
+    __syncthreads();
+    if (threadIdx.y == 0) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            f32x4 s = sm[c4 * 9 + t];
+            for (int yy = 1; yy < PY; ++yy) s += sm[(yy * C4 + c4) * 9 + t];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ws[((long)blockIdx.x * C + c + e) * 9 + t] = s[e];
+        }
     }
 }
 
-// ws[blk][0..C) = sum_r a[r][c],  ws[blk][C..2C) = sum_r a[r][c] * b[r][c]   (rows strided over the grid)
+// ws[blk][0..C) = sum_r a[r][c],  ws[blk][C..2C) = sum_r a[r][c] * b[r][c]
 template <typename T>
 __global__ __launch_bounds__(256) void col_sums2_kernel(const T* __restrict__ a, const T* __restrict__ b, long rows, int C,
                                                         float* __restrict__ ws) {
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        float s1 = 0.f, s2 = 0.f;
-        for (long r = blockIdx.x; r < rows; r += gridDim.x) {
-            const float av = to_f32(a[r * C + c]);
-            s1 += av;
-            s2 += av * to_f32(b[r * C + c]);
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    f32x4* sm = reinterpret_cast<f32x4*>(smem_raw);  // [PY][C4][2]
+    const int c4 = threadIdx.x, c = c4 * 4, PY = blockDim.y, C4 = blockDim.x;
+    f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+    for (long r = (long)blockIdx.x * PY + threadIdx.y; r < rows; r += (long)gridDim.x * PY) {
+        const f32x4 av = load4c(a + r * C + c);
+        s1 += av;
+        s2 += av * load4c(b + r * C + c);
+    }
+    sm[(threadIdx.y * C4 + c4) * 2 + 0] = s1;
+    sm[(threadIdx.y * C4 + c4) * 2 + 1] = s2;
+    __syncthreads();
+    if (threadIdx.y == 0) {
+        for (int yy = 1; yy < PY; ++yy) {
+            s1 += sm[(yy * C4 + c4) * 2 + 0];
+            s2 += sm[(yy * C4 + c4) * 2 + 1];
         }
-        ws[(long)blockIdx.x * 2 * C + c] = s1;
-        ws[(long)blockIdx.x * 2 * C + C + c] = s2;
+        store4c(ws + (long)blockIdx.x * 2 * C + c, s1);
+        store4c(ws + (long)blockIdx.x * 2 * C + C + c, s2);
     }
 }
 
@@ -159,6 +192,13 @@ inline int grid_for(long n, int threads = 256, int cap = 8192) {
     if (g > cap) g = cap;
     if (g < 1) g = 1;
     return (int)g;
+}
+
+inline dim3 chan_block(int C) {  // C/4 channel lanes x as many position lanes as fit 256 threads
+    const int c4 = C / 4;
+    int py = 256 / c4;
+    if (py < 1) py = 1;
+    return dim3(c4, py);
 }
 
 inline int reduce_blocks(long rows) {
@@ -211,13 +251,15 @@ extern "C" int esvit_dwconv3x3(int dtype, const void* x, const float* w, int fli
     STREAM(s_);
     ESVIT_CHECK_ARG(x && w && y && nB > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "esvit_dwconv3x3: bad args (C=%d)", C);
     ESVIT_CHECK_ARG(dtype == ESVIT_BF16 || dtype == ESVIT_F32, "esvit_dwconv3x3: bad dtype");
-    const long total = (long)nB * H * W * (C / 4);
+    ESVIT_CHECK_ARG(C / 4 <= 256, "esvit_dwconv3x3: C=%d too wide", C);
+    const dim3 block = chan_block(C);
+    const int grid = grid_for((long)nB * H * W, (int)block.y, 4096);
     if (dtype == ESVIT_BF16)
-        hipLaunchKernelGGL(dwconv3x3_kernel<bf16>, dim3(grid_for(total)), dim3(256), 0, stream, reinterpret_cast<const bf16*>(x), w, flip, nB,
-                           H, W, C, reinterpret_cast<bf16*>(y));
+        hipLaunchKernelGGL(dwconv3x3_kernel<bf16>, dim3(grid), block, 0, stream, reinterpret_cast<const bf16*>(x), w, flip, nB, H, W, C,
+                           reinterpret_cast<bf16*>(y));
     else
-        hipLaunchKernelGGL(dwconv3x3_kernel<float>, dim3(grid_for(total)), dim3(256), 0, stream, reinterpret_cast<const float*>(x), w, flip, nB,
-                           H, W, C, reinterpret_cast<float*>(y));
+        hipLaunchKernelGGL(dwconv3x3_kernel<float>, dim3(grid), block, 0, stream, reinterpret_cast<const float*>(x), w, flip, nB, H, W, C,
+                           reinterpret_cast<float*>(y));
     ESVIT_CHECK_LAUNCH("dwconv3x3");
     return ESVIT_OK;
 }
@@ -229,12 +271,15 @@ extern "C" int esvit_dwconv3x3_wgrad(int dtype, const void* x, const void* dy, i
     STREAM(s_);
     ESVIT_CHECK_ARG(x && dy && dw && ws && nB > 0 && H > 0 && W > 0 && C > 0, "esvit_dwconv3x3_wgrad: bad args");
     ESVIT_CHECK_ARG(dtype == ESVIT_BF16 || dtype == ESVIT_F32, "esvit_dwconv3x3_wgrad: bad dtype");
+    ESVIT_CHECK_ARG(C % 4 == 0 && C / 4 <= 256, "esvit_dwconv3x3_wgrad: bad C=%d", C);
     const int nblk = reduce_blocks((long)nB * H * W);
+    const dim3 block = chan_block(C);
+    const size_t lds = (size_t)block.x * block.y * 9 * sizeof(f32x4);
     if (dtype == ESVIT_BF16)
-        hipLaunchKernelGGL(dwconv3x3_wgrad_kernel<bf16>, dim3(nblk), dim3(256), 0, stream, reinterpret_cast<const bf16*>(x),
+        hipLaunchKernelGGL(dwconv3x3_wgrad_kernel<bf16>, dim3(nblk), block, lds, stream, reinterpret_cast<const bf16*>(x),
                            reinterpret_cast<const bf16*>(dy), nB, H, W, C, ws);
     else
-        hipLaunchKernelGGL(dwconv3x3_wgrad_kernel<float>, dim3(nblk), dim3(256), 0, stream, reinterpret_cast<const float*>(x),
+        hipLaunchKernelGGL(dwconv3x3_wgrad_kernel<float>, dim3(nblk), block, lds, stream, reinterpret_cast<const float*>(x),
                            reinterpret_cast<const float*>(dy), nB, H, W, C, ws);
     ESVIT_CHECK_LAUNCH("dwconv3x3_wgrad");
     return esvit_partial_reduce(ws, nblk, 9 * C, 9L * C, dw, 0, stream);
@@ -244,12 +289,15 @@ extern "C" int esvit_col_sums2(int dtype, const void* a, const void* b, int64_t 
     STREAM(s_);
     ESVIT_CHECK_ARG(a && b && out && ws && rows > 0 && C > 0, "esvit_col_sums2: bad args");
     ESVIT_CHECK_ARG(dtype == ESVIT_BF16 || dtype == ESVIT_F32, "esvit_col_sums2: bad dtype");
+    ESVIT_CHECK_ARG(C % 4 == 0 && C / 4 <= 256, "esvit_col_sums2: bad C=%d", C);
     const int nblk = reduce_blocks(rows);
+    const dim3 block = chan_block(C);
+    const size_t lds = (size_t)block.x * block.y * 2 * sizeof(f32x4);
     if (dtype == ESVIT_BF16)
-        hipLaunchKernelGGL(col_sums2_kernel<bf16>, dim3(nblk), dim3(256), 0, stream, reinterpret_cast<const bf16*>(a),
+        hipLaunchKernelGGL(col_sums2_kernel<bf16>, dim3(nblk), block, lds, stream, reinterpret_cast<const bf16*>(a),
                            reinterpret_cast<const bf16*>(b), (long)rows, C, ws);
     else
-        hipLaunchKernelGGL(col_sums2_kernel<float>, dim3(nblk), dim3(256), 0, stream, reinterpret_cast<const float*>(a),
+        hipLaunchKernelGGL(col_sums2_kernel<float>, dim3(nblk), block, lds, stream, reinterpret_cast<const float*>(a),
                            reinterpret_cast<const float*>(b), (long)rows, C, ws);
     ESVIT_CHECK_LAUNCH("col_sums2");
     return esvit_partial_reduce(ws, nblk, 2 * C, 2L * C, out, 0, stream);
