@@ -140,6 +140,40 @@ __device__ __forceinline__ void store_block_rows(const f32x4 (&acc)[2][2], float
         }
 }
 
+// same result, but through an LDS transpose ([32][LDQ] image private to the wave): every lane stores 16-byte row vectors
+// (2 per lane) instead of 16 two-byte scatters.  pad-slot rows are summed into padacc[VEC] (columns dv*VEC.., dv = lane % VPR).
+template <typename T>
+__device__ __forceinline__ void store_block_rows_vec(const f32x4 (&acc)[2][2], float mul, T* stg, T* __restrict__ dst, long row_stride,
+                                                     const int* tok_lds, long tok_base, int s0, int N, bool active, float* padacc, int lane,
+                                                     int c, int g) {
+    constexpr int VEC = BigCfg<T>::VEC, LDQ = BigCfg<T>::LDQ, VPR = HD / VEC;
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            stg[(16 * ti + 4 * g + r) * LDQ + c] = from_f32<T>(acc[ti][0][r] * mul);
+            stg[(16 * ti + 4 * g + r) * LDQ + 16 + c] = from_f32<T>(acc[ti][1][r] * mul);
+        }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int i = 0; i < 32 * VPR / 64; ++i) {
+        const int v = lane + 64 * i;
+        const int rl = v / VPR, dv = v % VPR;
+        const int t = s0 + rl;
+        if (!active || t >= N) continue;
+        const int tok = tok_lds[t];
+        const Vec16<T> x = ld16<T>(stg + rl * LDQ + dv * VEC);
+        if (tok >= 0) {
+            st16<T>(dst + (tok_base + tok) * row_stride + dv * VEC, x);
+        } else if (padacc) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) padacc[e] += x.get(e);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
 // -------------------------------------------------------------------------------------------------------------
 // forward
 // -------------------------------------------------------------------------------------------------------------
@@ -177,9 +211,10 @@ __global__ __launch_bounds__(BigCfg<T>::WAVES * 64) void attn_big_fwd_kernel(
         const int qb = wave + pass * WAVES;
         const bool valid = qb < NQB;
         const int q0 = valid ? 32 * qb : 0;
-        __syncthreads();  // K, V staged (first pass) / previous pass finished with Qs, Ps
+        if (pass == 0) __syncthreads();  // K, V staged by the whole workgroup; Qs / Ps below are private to the wave
+        __builtin_amdgcn_wave_barrier();
         stage_slots<T>(src, 3L * C, tb.tok, tok_base, q0, 32, N, scale, qkv_bias + h * HD, Qs, lane, 64);
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();
 
         f32x4 p[NT][2];
         {
@@ -246,7 +281,7 @@ __global__ __launch_bounds__(BigCfg<T>::WAVES * 64) void attn_big_fwd_kernel(
         for (int i = 0; i < NT; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j) store_frag4<T>(Ps + (16 * j + c) * LDP + 16 * i + 4 * g, p[i][j]);
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();
 
         f32x4 o[2][2];
 #pragma unroll
@@ -265,7 +300,7 @@ __global__ __launch_bounds__(BigCfg<T>::WAVES * 64) void attn_big_fwd_kernel(
                 mma(pf, v1, o[a][1]);
             }
         }
-        store_block_rows<T>(o, 1.f, out + h * HD, (long)C, tb.tok, tok_base, q0, N, valid, nullptr, c, g);
+        store_block_rows_vec<T>(o, 1.f, Qs, out + h * HD, (long)C, tb.tok, tok_base, q0, N, valid, nullptr, lane, c, g);
     }
 }
 
@@ -398,7 +433,7 @@ __global__ __launch_bounds__(BigCfg<T>::WAVES * 64) void attn_big_bwd_dq_kernel(
                 store_frag4<T>(Ss + (16 * j + c) * LDP + 16 * i + 4 * g, ds);
             }
         }
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();  // the dS image is private to the wave
         // dQ = scale * dS K
         f32x4 aq[2][2];
 #pragma unroll
@@ -417,7 +452,7 @@ __global__ __launch_bounds__(BigCfg<T>::WAVES * 64) void attn_big_bwd_dq_kernel(
                 mma(sf, k1, aq[a][1]);
             }
         }
-        store_block_rows<T>(aq, scale, dqkv + h * HD, 3L * C, tb.tok, tok_base, q0, N, active, nullptr, c, g);
+        store_block_rows_vec<T>(aq, scale, Qs, dqkv + h * HD, 3L * C, tb.tok, tok_base, q0, N, active, nullptr, lane, c, g);
     }
     if (wave_ok) {
         // frag layout of the NPB x NPB bias gradient: ((ki*NT + qj)*64 + lane)*4 + r, qj = 2*qb + j
@@ -472,22 +507,29 @@ __global__ __launch_bounds__(BigCfg<T>::WAVES * 64) void attn_big_bwd_dkv_kernel
                 const T* orow = fout + (tok_base + tok) * (long)C + h * HD;
                 const T* grow = dout + (tok_base + tok) * (long)C + h * HD;
 #pragma unroll
-                for (int e = 0; e < HD; ++e) d += to_f32(orow[e]) * to_f32(grow[e]);
+                for (int vv = 0; vv < HD / Cfg::VEC; ++vv) {
+                    const Vec16<T> ov = ld16<T>(orow + vv * Cfg::VEC), gv = ld16<T>(grow + vv * Cfg::VEC);
+#pragma unroll
+                    for (int e = 0; e < Cfg::VEC; ++e) d += ov.get(e) * gv.get(e);
+                }
             }
         }
         tb.lse[t] = l;
         tb.delta[t] = d;
     }
-    f32x2 padk = {0.f, 0.f}, padv = {0.f, 0.f};
+    float padk[Cfg::VEC], padv[Cfg::VEC];
+#pragma unroll
+    for (int e = 0; e < Cfg::VEC; ++e) padk[e] = padv[e] = 0.f;
 
     for (int pass = 0; pass < (NQB + WAVES - 1) / WAVES; ++pass) {
         const int kb = wave + pass * WAVES;
         const bool valid = kb < NQB;
         const int k0 = valid ? 32 * kb : 0;
-        __syncthreads();
+        if (pass == 0) __syncthreads();  // Q, dO, lse, delta staged by the whole workgroup; Kb / Vb / Pq are private to the wave
+        __builtin_amdgcn_wave_barrier();
         stage_slots<T>(src + C, 3L * C, tb.tok, tok_base, k0, 32, N, 1.f, qkv_bias + C + h * HD, Kb, lane, 64);
         stage_slots<T>(src + 2 * C, 3L * C, tb.tok, tok_base, k0, 32, N, 1.f, qkv_bias + 2 * C + h * HD, Vb, lane, 64);
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();
 
         // P^T block: rows = this block's 32 keys (2 tiles), columns = all queries (14 tiles)
         f32x4 p[2][NT];
@@ -525,7 +567,7 @@ __global__ __launch_bounds__(BigCfg<T>::WAVES * 64) void attn_big_bwd_dkv_kernel
                 }
             }
         }
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();
         // dV[key][d] = sum_q P[q][key] dO[q][d]
         {
             f32x4 av[2][2];
@@ -545,9 +587,9 @@ __global__ __launch_bounds__(BigCfg<T>::WAVES * 64) void attn_big_bwd_dkv_kernel
                     mma(pf, o1, av[a][1]);
                 }
             }
-            store_block_rows<T>(av, 1.f, dqkv + 2 * C + h * HD, 3L * C, tb.tok, tok_base, k0, N, valid, &padv, c, g);
+            store_block_rows_vec<T>(av, 1.f, Kb, dqkv + 2 * C + h * HD, 3L * C, tb.tok, tok_base, k0, N, valid, padv, lane, c, g);
         }
-        __syncthreads();  // reads of Pq (= P) complete
+        __builtin_amdgcn_wave_barrier();  // reads of Pq (= P) precede the dS writes below (same wave: LDS in order)
         // dS^T = P^T o (dP^T - delta), dP^T[key][q] = sum_d V[key][d] dO[q][d]
         {
             Frag<T> vf[2];
@@ -566,7 +608,7 @@ __global__ __launch_bounds__(BigCfg<T>::WAVES * 64) void attn_big_bwd_dkv_kernel
                 }
             }
         }
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();
         // dK[key][d] = sum_q dS[q][key] (scale q)[q][d]
         {
             f32x4 ak[2][2];
@@ -586,19 +628,25 @@ __global__ __launch_bounds__(BigCfg<T>::WAVES * 64) void attn_big_bwd_dkv_kernel
                     mma(sf, q1f, ak[a][1]);
                 }
             }
-            store_block_rows<T>(ak, 1.f, dqkv + C + h * HD, 3L * C, tb.tok, tok_base, k0, N, valid, &padk, c, g);
+            store_block_rows_vec<T>(ak, 1.f, Kb, dqkv + C + h * HD, 3L * C, tb.tok, tok_base, k0, N, valid, padk, lane, c, g);
         }
     }
-    padk[0] += __shfl_xor(padk[0], 16, 64); padk[0] += __shfl_xor(padk[0], 32, 64);
-    padk[1] += __shfl_xor(padk[1], 16, 64); padk[1] += __shfl_xor(padk[1], 32, 64);
-    padv[0] += __shfl_xor(padv[0], 16, 64); padv[0] += __shfl_xor(padv[0], 32, 64);
-    padv[1] += __shfl_xor(padv[1], 16, 64); padv[1] += __shfl_xor(padv[1], 32, 64);
-    if (g == 0) {  // one slab row per (unit, wave): [k | v][nH][hd]
-        float* pw = dpad_ws + ((long)unit * WAVES + wave) * 2 * C + h * HD;
-        pw[c] = padk[0];
-        pw[16 + c] = padk[1];
-        pw[C + c] = padv[0];
-        pw[C + 16 + c] = padv[1];
+    // lanes with equal dv = lane % VPR hold partial sums of the same VEC columns
+    constexpr int VPR = HD / Cfg::VEC;
+#pragma unroll
+    for (int e = 0; e < Cfg::VEC; ++e)
+#pragma unroll
+        for (int o = VPR; o < 64; o <<= 1) {
+            padk[e] += __shfl_xor(padk[e], o, 64);
+            padv[e] += __shfl_xor(padv[e], o, 64);
+        }
+    if (lane < VPR) {  // one slab row per (unit, wave): [k | v][nH][hd]
+        float* pw = dpad_ws + ((long)unit * WAVES + wave) * 2 * C + h * HD + lane * Cfg::VEC;
+#pragma unroll
+        for (int e = 0; e < Cfg::VEC; ++e) {
+            pw[e] = padk[e];
+            pw[C + e] = padv[e];
+        }
     }
 }
 
