@@ -109,6 +109,37 @@ __device__ __forceinline__ void store_frag4(T* p, f32x4 v) {
     }
 }
 
+// bias_frag[h][((ki*NT + qj)*64 + lane)*4 + r] = table[a(q) - a(key) + off][h] for q = 16qj + c, key = 16ki + 4g + r
+// (0 for padded queries, -1e30 for padded keys): one 16-byte load per lane per 16x16 score tile replaces four LDS table
+// gathers and ~40 VALU instructions -- the first version of these kernels spent 40-50 VALU instructions per MFMA on it.
+__global__ void relpos_bias_frag_big_kernel(const float* __restrict__ table, int ws, int N, int nH, float* __restrict__ out) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int FE = NT * NT * 256;
+    if (i >= (long)nH * FE) return;
+    const int h = (int)(i / FE), e = (int)(i % FE);
+    const int r = e & 3, lane = (e >> 2) & 63, f = e >> 8;
+    const int c = lane & 15, g = lane >> 4;
+    const int q = 16 * (f % NT) + c, key = 16 * (f / NT) + 4 * g + r;
+    float v = 0.f;
+    if (key >= N) v = -1.0e30f;
+    else if (q < N) {
+        const int w2 = 2 * ws - 1;
+        v = table[(long)((q / ws - key / ws + ws - 1) * w2 + (q % ws - key % ws + ws - 1)) * nH + h];
+    }
+    out[i] = v;
+}
+
+// bias tile (ki, qj) of this head + the shift mask rebuilt from the region labels packed in tb.pk (bits 16..)
+__device__ __forceinline__ f32x4 bias_tile(const float* __restrict__ bias_h, const BigTables& tb, int ki, int qj, int lane, int g, bool masked) {
+    f32x4 b = *reinterpret_cast<const f32x4*>(bias_h + ((ki * NT + qj) * 64 + lane) * 4);
+    if (masked) {
+        const int rq = tb.pk[16 * qj + (lane & 15)] >> 16;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) b[r] += ((tb.pk[16 * ki + 4 * g + r] >> 16) != rq) ? -100.f : 0.f;
+    }
+    return b;
+}
+
 // bias + mask value of the score element (query slot q, key slot k)
 __device__ __forceinline__ float score_bias(const BigTables& tb, int pq, int pkk, bool qok, bool kok, int off, bool masked) {
     float v = (qok && kok) ? tb.tab[(pq & 0xffff) - (pkk & 0xffff) + off] : 0.f;
@@ -180,7 +211,7 @@ __device__ __forceinline__ void store_block_rows_vec(const f32x4 (&acc)[2][2], f
 template <typename T>
 __global__ __launch_bounds__(BigCfg<T>::WAVES * 64) void attn_big_fwd_kernel(
     const T* __restrict__ qkv, const float* __restrict__ qkv_bias, const int* __restrict__ win2tok, int L,
-    const float* __restrict__ rel_table, int rel_rows, int ws, const int* __restrict__ region_ids, int nW, int Bw, int N, int nH,
+    const float* __restrict__ bias_frag, int rel_rows, int ws, const int* __restrict__ region_ids, int nW, int Bw, int N, int nH,
     float scale, T* __restrict__ out, float* __restrict__ lse_out, float* __restrict__ attn_out) {
     using Cfg = BigCfg<T>;
     constexpr int LDQ = Cfg::LDQ, LDP = Cfg::LDP, WAVES = Cfg::WAVES;
@@ -202,7 +233,7 @@ __global__ __launch_bounds__(BigCfg<T>::WAVES * 64) void attn_big_fwd_kernel(
     const int off = (ws - 1) * 2 * ws;
 
     load_window_tables(tb, win2tok, region_ids, bw % nW, N, ws, true);
-    load_table_column(tb, rel_table, rel_rows, nH, h);
+    const float* bias_h = bias_frag + (long)h * (NT * NT * 256);
     __syncthreads();
     stage_slots<T>(src + C, 3L * C, tb.tok, tok_base, 0, NPB, N, 1.f, qkv_bias + C + h * HD, Ks, threadIdx.x, WAVES * 64);
     stage_slots<T>(src + 2 * C, 3L * C, tb.tok, tok_base, 0, NPB, N, 1.f, qkv_bias + 2 * C + h * HD, Vs, threadIdx.x, WAVES * 64);
@@ -221,21 +252,11 @@ __global__ __launch_bounds__(BigCfg<T>::WAVES * 64) void attn_big_fwd_kernel(
             Frag<T> qf[2];
             qf[0] = frag_kc<T>(Qs, LDQ, 0, 0, c, g);
             qf[1] = frag_kc<T>(Qs, LDQ, 16, 0, c, g);
-            const int pq0 = tb.pk[q0 + c], pq1 = tb.pk[q0 + 16 + c];
-            const bool qok0 = q0 + c < N, qok1 = q0 + 16 + c < N;
 #pragma unroll
             for (int i = 0; i < NT; ++i) {
                 const Frag<T> kf = frag_kc<T>(Ks, LDQ, 16 * i, 0, c, g);
-                f32x4 b0, b1;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int k = 16 * i + 4 * g + r;
-                    const int pkk = tb.pk[k];
-                    b0[r] = score_bias(tb, pq0, pkk, qok0, k < N, off, masked);
-                    b1[r] = score_bias(tb, pq1, pkk, qok1, k < N, off, masked);
-                }
-                p[i][0] = b0;
-                p[i][1] = b1;
+                p[i][0] = bias_tile(bias_h, tb, i, (q0 >> 4), lane, g, masked);
+                p[i][1] = bias_tile(bias_h, tb, i, (q0 >> 4) + 1, lane, g, masked);
                 mma(kf, qf[0], p[i][0]);
                 mma(kf, qf[1], p[i][1]);
             }
@@ -311,7 +332,7 @@ __global__ __launch_bounds__(BigCfg<T>::WAVES * 64) void attn_big_fwd_kernel(
 template <typename T, bool USE_TR>
 __global__ __launch_bounds__(BigCfg<T>::WAVES * 64) void attn_big_bwd_dq_kernel(
     const T* __restrict__ qkv, const float* __restrict__ qkv_bias, const int* __restrict__ win2tok, int L, const T* __restrict__ dout,
-    const float* __restrict__ rel_table, int rel_rows, int ws, const int* __restrict__ region_ids, int nW, int Bw, int N, int nH,
+    const float* __restrict__ bias_frag, int rel_rows, int ws, const int* __restrict__ region_ids, int nW, int Bw, int N, int nH,
     float scale, int parts, T* __restrict__ dqkv, float* __restrict__ dbias_ws) {
     using Cfg = BigCfg<T>;
     constexpr int LDQ = Cfg::LDQ, LDP = Cfg::LDP, WAVES = Cfg::WAVES;
@@ -343,7 +364,7 @@ __global__ __launch_bounds__(BigCfg<T>::WAVES * 64) void attn_big_bwd_dq_kernel(
         db[i][0] = f32x4{0.f, 0.f, 0.f, 0.f};
         db[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    load_table_column(tb, rel_table, rel_rows, nH, h);
+    const float* bias_h = bias_frag + (long)h * (NT * NT * 256);
 
     const int iters = (Bw + parts - 1) / parts;
     for (int it = 0; it < iters; ++it) {
@@ -367,21 +388,11 @@ __global__ __launch_bounds__(BigCfg<T>::WAVES * 64) void attn_big_bwd_dq_kernel(
             Frag<T> qf[2];
             qf[0] = frag_kc<T>(Qs, LDQ, 0, 0, c, g);
             qf[1] = frag_kc<T>(Qs, LDQ, 16, 0, c, g);
-            const int pq0 = tb.pk[q0 + c], pq1 = tb.pk[q0 + 16 + c];
-            const bool qok0 = q0 + c < N, qok1 = q0 + 16 + c < N;
 #pragma unroll
             for (int i = 0; i < NT; ++i) {
                 const Frag<T> kf = frag_kc<T>(Ks, LDQ, 16 * i, 0, c, g);
-                f32x4 b0, b1;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int k = 16 * i + 4 * g + r;
-                    const int pkk = tb.pk[k];
-                    b0[r] = score_bias(tb, pq0, pkk, qok0, k < N, off, masked);
-                    b1[r] = score_bias(tb, pq1, pkk, qok1, k < N, off, masked);
-                }
-                p[i][0] = b0;
-                p[i][1] = b1;
+                p[i][0] = bias_tile(bias_h, tb, i, (q0 >> 4), lane, g, masked);
+                p[i][1] = bias_tile(bias_h, tb, i, (q0 >> 4) + 1, lane, g, masked);
                 mma(kf, qf[0], p[i][0]);
                 mma(kf, qf[1], p[i][1]);
             }
@@ -470,7 +481,7 @@ __global__ __launch_bounds__(BigCfg<T>::WAVES * 64) void attn_big_bwd_dq_kernel(
 template <typename T, bool USE_TR>
 __global__ __launch_bounds__(BigCfg<T>::WAVES * 64) void attn_big_bwd_dkv_kernel(
     const T* __restrict__ qkv, const float* __restrict__ qkv_bias, const int* __restrict__ win2tok, int L, const T* __restrict__ dout,
-    const T* __restrict__ fout, const float* __restrict__ lse_in, const float* __restrict__ rel_table, int rel_rows, int ws,
+    const T* __restrict__ fout, const float* __restrict__ lse_in, const float* __restrict__ bias_frag, int rel_rows, int ws,
     const int* __restrict__ region_ids, int nW, int Bw, int N, int nH, float scale, T* __restrict__ dqkv, float* __restrict__ dpad_ws) {
     using Cfg = BigCfg<T>;
     constexpr int LDQ = Cfg::LDQ, WAVES = Cfg::WAVES;
@@ -493,7 +504,7 @@ __global__ __launch_bounds__(BigCfg<T>::WAVES * 64) void attn_big_bwd_dkv_kernel
     const int off = (ws - 1) * 2 * ws;
 
     load_window_tables(tb, win2tok, region_ids, bw % nW, N, ws, true);
-    load_table_column(tb, rel_table, rel_rows, nH, h);
+    const float* bias_h = bias_frag + (long)h * (NT * NT * 256);
     __syncthreads();
     stage_slots<T>(src, 3L * C, tb.tok, tok_base, 0, NPB, N, scale, qkv_bias + h * HD, Qs, threadIdx.x, WAVES * 64);
     stage_slots<T>(dout + h * HD, (long)C, tb.tok, tok_base, 0, NPB, N, 1.f, nullptr, Os, threadIdx.x, WAVES * 64);
@@ -537,28 +548,15 @@ __global__ __launch_bounds__(BigCfg<T>::WAVES * 64) void attn_big_bwd_dkv_kernel
             Frag<T> kf[2];
             kf[0] = frag_kc<T>(Kb, LDQ, 0, 0, c, g);
             kf[1] = frag_kc<T>(Kb, LDQ, 16, 0, c, g);
-            int pkk[2][4];
-            bool kok[2][4];
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int k = k0 + 16 * a + 4 * g + r;
-                    pkk[a][r] = tb.pk[k];
-                    kok[a][r] = k < N;
-                }
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
                 const Frag<T> qf = frag_kc<T>(Qs, LDQ, 16 * j, 0, c, g);
                 const int q = 16 * j + c;
-                const int pq = tb.pk[q];
                 const bool qok = q < N;
                 const float l = tb.lse[q];
 #pragma unroll
                 for (int a = 0; a < 2; ++a) {
-                    f32x4 b;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) b[r] = score_bias(tb, pq, pkk[a][r], qok, kok[a][r], off, masked);
+                    f32x4 b = bias_tile(bias_h, tb, (k0 >> 4) + a, j, lane, g, masked);
                     mma(kf[a], qf, b);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) b[r] = qok ? __expf(b[r] - l) : 0.f;  // padded query columns carry no gradient
@@ -693,6 +691,13 @@ int esvit_big_npb() { return NPB; }
 int esvit_big_parts(int Bw, int nH) { return big_parts(Bw, nH); }
 int esvit_big_pad_rows(int Bw, int nH, int dtype) { return Bw * nH * (dtype == ESVIT_BF16 ? 4 : 2); }
 
+static int fill_bias_frag_big(const float* rel_table, int ws, int N, int nH, float* bias_frag_ws, hipStream_t stream) {
+    const long n = (long)nH * NT * NT * 256;
+    hipLaunchKernelGGL(relpos_bias_frag_big_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, stream, rel_table, ws, N, nH, bias_frag_ws);
+    ESVIT_CHECK_LAUNCH("relpos_bias(frag, 14x14)");
+    return ESVIT_OK;
+}
+
 template <typename T>
 static int big_fwd_launch(const void* qkv, const float* qkv_bias, const int32_t* win2tok, int L, const float* rel_table, int rel_rows, int ws,
                           const int32_t* region_ids, int nW, int Bw, int N, int nH, float scale, void* out, float* lse, float* attn_out,
@@ -707,14 +712,19 @@ static int big_fwd_launch(const void* qkv, const float* qkv_bias, const int32_t*
 }
 
 int esvit_big_attn_fwd(int dtype, const void* qkv, const float* qkv_bias, const int32_t* win2tok, int L, const float* rel_table, int ws,
-                       const int32_t* region_ids, int nW, int nB, int N, int nH, float scale, void* out, float* lse, float* attn_out,
-                       hipStream_t stream) {
+                       float* bias_frag_ws, const int32_t* region_ids, int nW, int nB, int N, int nH, float scale, void* out, float* lse,
+                       float* attn_out, hipStream_t stream) {
     const int rel_rows = (2 * ws - 1) * (2 * ws - 1);
-    ESVIT_CHECK_ARG(rel_rows <= TAB_FLOATS && N <= NPB, "window_attn: window %d too large", ws);
+    ESVIT_CHECK_ARG(N <= NPB, "window_attn: window %d too large", ws);
+    ESVIT_CHECK_ARG(bias_frag_ws != nullptr, "esvit_window_attn_fwd: the bias_frag_ws scratch is required");
+    {
+        int rc = fill_bias_frag_big(rel_table, ws, N, nH, bias_frag_ws, stream);
+        if (rc != ESVIT_OK) return rc;
+    }
     const int Bw = nB * nW;
     if (dtype == ESVIT_BF16)
-        return big_fwd_launch<bf16>(qkv, qkv_bias, win2tok, L, rel_table, rel_rows, ws, region_ids, nW, Bw, N, nH, scale, out, lse, attn_out, stream);
-    return big_fwd_launch<float>(qkv, qkv_bias, win2tok, L, rel_table, rel_rows, ws, region_ids, nW, Bw, N, nH, scale, out, lse, attn_out, stream);
+        return big_fwd_launch<bf16>(qkv, qkv_bias, win2tok, L, bias_frag_ws, rel_rows, ws, region_ids, nW, Bw, N, nH, scale, out, lse, attn_out, stream);
+    return big_fwd_launch<float>(qkv, qkv_bias, win2tok, L, bias_frag_ws, rel_rows, ws, region_ids, nW, Bw, N, nH, scale, out, lse, attn_out, stream);
 }
 
 template <typename T, bool TR>
@@ -744,11 +754,17 @@ static int big_bwd_launch(const void* qkv, const float* qkv_bias, const int32_t*
 }
 
 int esvit_big_attn_bwd(int dtype, int use_tr, const void* qkv, const float* qkv_bias, const int32_t* win2tok, int L, const void* dout,
-                       const void* fout, const float* lse, const float* rel_table, int ws, const int32_t* region_ids, int nW, int nB, int N,
-                       int nH, float scale, void* dqkv, float* dbias_ws, float* dpad_ws, hipStream_t stream) {
+                       const void* fout, const float* lse, const float* rel_table_, int ws, float* bias_frag_ws, const int32_t* region_ids,
+                       int nW, int nB, int N, int nH, float scale, void* dqkv, float* dbias_ws, float* dpad_ws, hipStream_t stream) {
     const int rel_rows = (2 * ws - 1) * (2 * ws - 1);
-    ESVIT_CHECK_ARG(rel_rows <= TAB_FLOATS && N <= NPB, "window_attn: window %d too large", ws);
+    ESVIT_CHECK_ARG(N <= NPB, "window_attn: window %d too large", ws);
     ESVIT_CHECK_ARG(fout && lse, "esvit_window_attn_bwd: 14x14 windows need the forward output and log-sum-exp");
+    ESVIT_CHECK_ARG(bias_frag_ws != nullptr, "esvit_window_attn_bwd: the bias_frag_ws scratch is required");
+    {
+        int rc = fill_bias_frag_big(rel_table_, ws, N, nH, bias_frag_ws, stream);
+        if (rc != ESVIT_OK) return rc;
+    }
+    const float* rel_table = bias_frag_ws;  // the kernels read the frag-layout bias
     const int Bw = nB * nW;
     if (dtype == ESVIT_BF16) {
         if (use_tr)

@@ -165,10 +165,11 @@ int esvit_dense_to_frag(const float* dense, int n_mats, int N, float* frag, esvi
  * qkv_bias fp32 [3C]: the value of q,k,v at a zero-pad slot (LayerNorm output is zero-padded, so qkv = bias there;
  * pad keys/values take part in every softmax exactly as in the reference, pad query rows are dropped).
  * rel_table fp32 [(2ws-1)^2, nH] is the relative_position_bias_table parameter itself (swin_transformer.py:133-136,
- * index in closed form).  bias_frag_ws (7x7 windows, optional): fp32 scratch [nH, esvit_attn_frag_elems(N)] the
- * library fills with the bias in fragment order (faster than gathering from the table inside the kernel); ignored for
- * 14x14 windows.  region_ids int32 [nW*N] (esvit_shift_region_ids) for shifted blocks or NULL.
- * scale = hd^-0.5 applied to q before the product (swin_transformer.py:130).  N = ws*ws in {49, 196}, hd = 32.
+ * index in closed form).  bias_frag_ws (required): fp32 scratch [nH, esvit_attn_frag_elems(N)] the library fills with
+ * the bias in MFMA fragment order (one 16-byte load per lane per score tile instead of table gathers in the kernel).
+ * region_ids int32 [nW*N] (esvit_shift_region_ids) for shifted blocks or NULL.
+ * scale: applied to q before the product (swin_transformer.py:130: hd^-0.5; CvT passes dim^-0.5).  N = ws*ws <= 64 with
+ * hd in {32, 64} (7x7 Swin windows; 7x7 / 6x6 / 3x3 CvT windows at hd 64), or N = 196 (14x14) with hd = 32.
  * lse fp32 [nB*nW*nH, esvit_window_attn_lse_elems(N)]: per-query log-sum-exp, written for 14x14 windows (the blocked
  * backward needs it), unused (may be NULL) for 7x7.
  * attn_out (optional, fp32 [nB*nW,nH,N,N]) receives the softmax (swin_transformer.py:146,152). */
