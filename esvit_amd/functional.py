@@ -422,17 +422,21 @@ class CvtAttnFn(torch.autograd.Function):
         xp = _pad_tokens(xn, nB, H, W, Hp, Wp)
         dw9 = dw_w.detach().reshape(C, 9).contiguous()
         d = o.dwconv3x3(xp, dw9, nB, Hp, Wp)
-        # BatchNorm2d, training statistics over every position of the (padded) map on every rank
         rows = nB * Hp * Wp
-        stats = torch.cat([o.col_sums2(d, d).view(-1), torch.tensor([float(rows)], device=x.device)])
-        _allreduce_stats(stats, bn_state.get("group"))
-        n = stats[-1]
-        bmean = stats[:C] / n
-        bvar = (stats[C:2 * C] / n - bmean * bmean).clamp_min_(0.0)
+        eval_bn = bool(bn_state.get("eval"))
+        if eval_bn:  # inference: the running statistics (nn.BatchNorm2d in eval mode)
+            n = torch.tensor(float(rows), device=x.device)
+            bmean, bvar = bn_state["eval_mean"].detach().float(), bn_state["eval_var"].detach().float()
+        else:        # BatchNorm2d, training statistics over every position of the (padded) map on every rank
+            stats = torch.cat([o.col_sums2(d, d).view(-1), torch.tensor([float(rows)], device=x.device)])
+            _allreduce_stats(stats, bn_state.get("group"))
+            n = stats[-1]
+            bmean = stats[:C] / n
+            bvar = (stats[C:2 * C] / n - bmean * bmean).clamp_min_(0.0)
         brstd = torch.rsqrt(bvar + BN_EPS)
         a = bn_g.detach() * brstd
         bnout = o.col_affine2(d, a.contiguous(), (bn_b.detach() - bmean * a).contiguous())
-        if bn_state.get("running_mean") is not None:  # buffers of the nn.BatchNorm2d holder (momentum 0.1, unbiased variance)
+        if not eval_bn and bn_state.get("running_mean") is not None:  # buffers of the nn.BatchNorm2d holder (momentum 0.1, unbiased variance)
             with torch.no_grad():
                 bn_state["running_mean"].mul_(1 - BN_MOMENTUM).add_(BN_MOMENTUM * bmean)
                 bn_state["running_var"].mul_(1 - BN_MOMENTUM).add_(BN_MOMENTUM * bvar * (n / (n - 1)))
@@ -445,7 +449,7 @@ class CvtAttnFn(torch.autograd.Function):
         ao, lse = o.window_attn_fwd(qkv, pw_b, geom.win2tok, Hp * Wp, table, w, None, geom.nW, geom.N, nH, scale)
         aoc = _crop_tokens(ao, nB, H, W, Hp, Wp)
         x1 = o.linear_fwd(aoc, Wproj, proj_b, residual=x2d, rowscale=dp, rows_per_sample=L, out_f32=True)
-        ctx.meta = (H, W, Hp, Wp, w, nH, scale, dp, bn_state.get("group"))
+        ctx.meta = (H, W, Hp, Wp, w, nH, scale, dp, bn_state.get("group"), eval_bn)
         ctx.save_for_backward(x, mean1, rstd1, g1, xp, dw9, d, bmean, brstd, n, bn_g, bnout, Wpw, pw_b, qkv, ao, aoc, Wproj)
         return x1.view(nB, L, C)
 
@@ -453,7 +457,7 @@ class CvtAttnFn(torch.autograd.Function):
     def backward(ctx, gy):
         o = ops_module()
         x, mean1, rstd1, g1, xp, dw9, d, bmean, brstd, n, bn_g, bnout, Wpw, pw_b, qkv, ao, aoc, Wproj = ctx.saved_tensors
-        H, W, Hp, Wp, w, nH, scale, dp, group = ctx.meta
+        H, W, Hp, Wp, w, nH, scale, dp, group, eval_bn = ctx.meta
         nB, L, C = x.shape
         M = nB * L
         gy = gy.contiguous().view(M, C)
@@ -471,7 +475,10 @@ class CvtAttnFn(torch.autograd.Function):
         s_dyx = brstd * (s_dyd - bmean * s_dy)          # sum(dy * xhat), local
         dgam, dbet = s_dyx.clone(), s_dy.clone()
         red = torch.cat([s_dy, s_dyx])
-        _allreduce_stats(red, group)
+        if eval_bn:  # fixed statistics: the normalisation is a per-channel affine map, no batch terms in its gradient
+            red = torch.zeros_like(red)
+        else:
+            _allreduce_stats(red, group)
         m1, m2 = red[:C] / n, red[C:] / n
         gam = bn_g.detach()
         A = gam * brstd

@@ -7,7 +7,8 @@ interchangeable; the modules are parameter holders only -- the computation runs 
 (``esvit_amd.functional``: ConvEmbedFn, CvtAttnFn, CvtFfnFn) on token-major NHWC activations.
 
 Scope (what experiments/imagenet/cvt_v4/s1.yaml uses): no relative-position embedding, no shifted windows, no residual
-stem; ``REL_POS_EMBED`` / ``SHIFT`` / ``RES_STEM`` raise NotImplementedError.
+stem; ``REL_POS_EMBED`` / ``SHIFT`` / ``RES_STEM`` raise NotImplementedError.  Train mode uses batch statistics
+(synchronised over the ranks), eval mode the running statistics, as ``nn.BatchNorm2d`` / ``SyncBatchNorm`` do.
 """
 from functools import partial
 
@@ -85,8 +86,8 @@ class Transformer(nn.Module):
         self.shift = shift
         self.sync_bn_group = None  # process group of the SyncBatchNorm statistics (None: default group; False: local statistics)
 
-    def forward_tokens(self, x, H, W):
-        """x fp32 [nB, H*W, C] (token-major)"""
+    def forward_tokens(self, x, H, W, feats=None):
+        """x fp32 [nB, H*W, C] (token-major); feats: optional list that receives every block's output (forward_with_features)"""
         nB = x.shape[0]
         for attn, ff, drop_path in self.layers:
             dp1 = dp2 = None
@@ -94,15 +95,17 @@ class Transformer(nn.Module):
                 dp1, dp2 = drop_path.factors(nB, x.device), drop_path.factors(nB, x.device)
             a, bn = attn.fn, attn.fn.qkv.bn
             bn_state = {"group": self.sync_bn_group}
-            if self.training and bn.track_running_stats:
-                bn_state.update(running_mean=bn.running_mean, running_var=bn.running_var, num_batches_tracked=bn.num_batches_tracked)
-            if not self.training:
-                raise NotImplementedError("CvT eval-mode BatchNorm (running statistics) is not built: the EsViT step keeps both networks "
-                                          "in train mode (main_esvit.py never calls .eval() on student or teacher)")
+            if self.training:
+                if bn.track_running_stats:
+                    bn_state.update(running_mean=bn.running_mean, running_var=bn.running_var, num_batches_tracked=bn.num_batches_tracked)
+            else:  # nn.BatchNorm2d.eval(): the running statistics
+                bn_state.update(eval=True, eval_mean=bn.running_mean, eval_var=bn.running_var)
             x = Fn.CvtAttnFn.apply(x, H, W, a.heads, a.window_size, dp1, bn_state, attn.norm.weight, attn.norm.bias, a.qkv.dw.weight,
                                    bn.weight, bn.bias, a.qkv.pw.weight, a.qkv.pw.bias, a.proj_out.weight, a.proj_out.bias)
             x = Fn.CvtFfnFn.apply(x, dp2, ff.norm.weight, ff.norm.bias, ff.fn.net[0].weight, ff.fn.net[0].bias, ff.fn.net[2].weight,
                                   ff.fn.net[2].bias)
+            if feats is not None:
+                feats.append(x)
         return x
 
 
@@ -173,6 +176,29 @@ class CvT(nn.Module):
     def forward_features(self, x):
         cls, region = self.forward_feature_maps(x)
         return (cls, region) if self.use_dense_prediction else cls
+
+    def forward_return_n_last_blocks(self, x, n=1, return_patch_avgpool=False, depth=[]):
+        """token-averaged features of the n last blocks, concatenated (cvt_v4_transformer.py:567-617; eval_linear.py)"""
+        start_idx = sum(depth) - n
+        sum_cur = 0
+        for i, d in enumerate(depth):
+            if sum_cur <= start_idx < sum_cur + d:
+                start_stage, start_blk = i, start_idx - sum_cur
+            sum_cur += d
+        nB, _, H, W = x.shape
+        src, nchw, output = x, True, []
+        for i in range(self.num_stages):
+            conv, tr = getattr(self, f'stage{i}')
+            t, H, W = conv.forward_tokens(src, nchw, nB, H, W)
+            fea = []
+            src, nchw = tr.forward_tokens(t, H, W, fea), False
+            if i >= start_stage:
+                for x_ in fea[start_blk:]:
+                    if i == self.num_stages - 1:  # the last stage's features go through the final norm
+                        x_ = Fn.FinalNormFn.apply(x_, self.norm.weight, self.norm.bias, Fn.CVT_LN_EPS)
+                    output.append(Fn.TokenMeanFn.apply(x_))
+                start_blk = 0
+        return torch.cat(output, dim=-1)
 
     def forward(self, x):
         if not isinstance(x, list):

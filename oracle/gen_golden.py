@@ -198,6 +198,17 @@ def gen_nano_cvt(ns):
     g["grad_norms"] = {n: p.grad.norm().item() for n, p in student.named_parameters() if p.grad is not None}
     g["no_grad"] = [n for n, p in student.named_parameters() if p.grad is None]
     g["bn_buffers"] = {k: v.detach().clone() for k, v in student.state_dict().items() if "running_" in k or "num_batches" in k}
+    # inference consumers (eval_linear.py / eval_knn.py): eval-mode BatchNorm (running statistics) on a fresh parameter fill
+    GU.fill_state_dict(student.state_dict(), seed=0)
+    for k, v in student.state_dict().items():
+        if k.endswith("running_var"):
+            v.abs_().add_(0.5)
+    student.eval()
+    with torch.no_grad():
+        cls, region = student.forward_features(crops[0])
+        g["eval_cls"], g["eval_region"] = GU.probe(cls), GU.probe(region)
+        g["eval_last_blocks"] = student.forward_return_n_last_blocks(crops[2], n=2, depth=list(GU.NANO_CVT["depths"])).clone()
+    student.train()
     torch.save(g, os.path.join(OUT, "nano_cvt_step.pt"))
     print("nano_cvt_step.pt: loss", g["ddino_loss"], "npatch", g["npatch"], "params", len(g["param_names"]), "no_grad", g["no_grad"])
 

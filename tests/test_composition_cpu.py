@@ -218,3 +218,17 @@ def test_cvt_composition_matches_reference_golden(cpu_ops):
     student, teacher = nano_cvt_pair()
     s_out, t_out, loss = run_nano_cvt_step(student, teacher, L)
     check_nano_cvt(g, student, s_out, t_out, loss, rt=3e-4, loss_tol=2e-5, grad_tol=2e-3, buf_tol=1e-4)
+
+
+def test_cvt_eval_mode_matches_reference_golden(cpu_ops):
+    """inference consumers (eval_linear.py / eval_knn.py): eval-mode BatchNorm and forward_return_n_last_blocks"""
+    g = torch.load(os.path.join(GOLD, "nano_cvt_step.pt"), weights_only=False)
+    student, _ = nano_cvt_pair()
+    student.eval()
+    crops = GU.make_crops(2, n_local=3, sizes=GU.NANO_CVT["sizes"])
+    with torch.no_grad():
+        cls, region = student.forward_features(crops[0])
+        probe_close("eval cls", cls, g["eval_cls"], rtol=3e-4)
+        probe_close("eval region", region, g["eval_region"], rtol=3e-4)
+        feats = student.forward_return_n_last_blocks(crops[2], n=2, depth=list(GU.NANO_CVT["depths"]))
+    assert torch.allclose(feats, g["eval_last_blocks"], rtol=3e-4, atol=1e-5)

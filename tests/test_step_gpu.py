@@ -198,3 +198,21 @@ def test_nano_cvt_step_matches_reference_golden(prec, lib_built):
                 assert abs(got[n].norm().item() - ref) <= 0.2 * ref + 1e-6, (n, got[n].norm().item(), ref)
     finally:
         _teardown()
+
+
+def test_nano_cvt_eval_matches_reference_golden(lib_built):
+    """eval-mode BatchNorm + forward_return_n_last_blocks of the CvT through the HIP path (fp32 precision mode)"""
+    g = torch.load(os.path.join(GOLD, "nano_cvt_step.pt"), weights_only=False)
+    dev = _setup("fp32")
+    try:
+        student, _ = nano_cvt_pair(dev)
+        student.eval()
+        crops = _to(GU.make_crops(2, n_local=3, sizes=GU.NANO_CVT["sizes"]), dev)
+        with torch.no_grad():
+            cls, region = student.forward_features(crops[0])
+            probe_close("eval cls", cls.cpu(), g["eval_cls"], rtol=5e-4)
+            probe_close("eval region", region.cpu(), g["eval_region"], rtol=5e-4)
+            feats = student.forward_return_n_last_blocks(crops[2], n=2, depth=list(GU.NANO_CVT["depths"]))
+        assert torch.allclose(feats.cpu(), g["eval_last_blocks"], rtol=5e-4, atol=2e-5)
+    finally:
+        _teardown()
