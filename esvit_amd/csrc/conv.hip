@@ -187,6 +187,77 @@ __global__ void col_affine2_kernel(const T* __restrict__ x1, const T* __restrict
     }
 }
 
+// BatchNorm2d coefficient arithmetic on [C]-sized vectors (one launch instead of ~15 tiny elementwise launches per layer).
+// forward: sums = [sum d | sum d^2] over n positions -> coef = [a | shift | mean | rstd] with y = a*d + shift; updates the
+// running statistics (momentum, unbiased variance) when they are given.
+__global__ void bn_fwd_coeffs_kernel(const float* __restrict__ sums, float n, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                     float eps, float momentum, float* __restrict__ running_mean, float* __restrict__ running_var, int C,
+                                     float* __restrict__ coef) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float mean = sums[c] / n;
+    const float var = fmaxf(sums[C + c] / n - mean * mean, 0.f);
+    const float rstd = rsqrtf(var + eps);
+    const float a = gamma[c] * rstd;
+    coef[c] = a;
+    coef[C + c] = beta[c] - mean * a;
+    coef[2 * C + c] = mean;
+    coef[3 * C + c] = rstd;
+    if (running_mean) {
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * var * (n / (n - 1.f));
+    }
+}
+// eval mode: coefficients from the running statistics
+__global__ void bn_eval_coeffs_kernel(const float* __restrict__ rmean, const float* __restrict__ rvar, const float* __restrict__ gamma,
+                                      const float* __restrict__ beta, float eps, int C, float* __restrict__ coef) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float rstd = rsqrtf(rvar[c] + eps);
+    const float a = gamma[c] * rstd;
+    coef[c] = a;
+    coef[C + c] = beta[c] - rmean[c] * a;
+    coef[2 * C + c] = rmean[c];
+    coef[3 * C + c] = rstd;
+}
+// backward, local part: sums = [sum dy | sum dy*d] -> red = [sum dy | sum dy*xhat]  (= d beta | d gamma of this rank)
+__global__ void bn_bwd_local_kernel(const float* __restrict__ sums, const float* __restrict__ coef, int C, float* __restrict__ red) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float mean = coef[2 * C + c], rstd = coef[3 * C + c];
+    red[c] = sums[c];
+    red[C + c] = rstd * (sums[C + c] - mean * sums[c]);
+}
+// backward, after the cross-rank sum of red: d(d) = A*dy + B*d + Cc;  red == nullptr: fixed (eval) statistics, B = Cc = 0
+__global__ void bn_bwd_coeffs_kernel(const float* __restrict__ red, float n, const float* __restrict__ gamma, const float* __restrict__ coef,
+                                     int C, float* __restrict__ abc) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float mean = coef[2 * C + c], rstd = coef[3 * C + c], g = gamma[c];
+    const float m1 = red ? red[c] / n : 0.f, m2 = red ? red[C + c] / n : 0.f;
+    const float A = g * rstd, B = -g * rstd * rstd * m2;
+    abc[c] = A;
+    abc[C + c] = B;
+    abc[2 * C + c] = -g * rstd * m1 - B * mean;
+}
+
+// dst[b, y, x, :] = src[b, y, x, :] if (y < Hs && x < Ws) else 0, for y < Hd, x < Wd: zero-pads (Hd > Hs) or crops (Hd < Hs) a token grid
+template <typename T>
+__global__ void pad_crop_kernel(const T* __restrict__ src, int nB, int Hs, int Ws, int Hd, int Wd, int C, T* __restrict__ dst) {
+    constexpr int VEC = ElemTraits<T>::VEC;
+    const int CV = C / VEC;
+    const long total = (long)nB * Hd * Wd * CV;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int cv = (int)(i % CV);
+        const long p = i / CV;
+        const int x = (int)(p % Wd), y = (int)((p / Wd) % Hd);
+        const long b = p / ((long)Wd * Hd);
+        Vec16<T> v = zero16<T>();
+        if (y < Hs && x < Ws) v = ld16<T>(src + ((b * Hs + y) * Ws + x) * C + cv * VEC);
+        st16<T>(dst + p * C + cv * VEC, v);
+    }
+}
+
 inline int grid_for(long n, int threads = 256, int cap = 8192) {
     long g = (n + threads - 1) / threads;
     if (g > cap) g = cap;
@@ -316,5 +387,55 @@ extern "C" int esvit_col_affine2(int dtype, const void* x1, const void* x2, int6
         hipLaunchKernelGGL(col_affine2_kernel<float>, dim3(grid_for(n)), dim3(256), 0, stream, reinterpret_cast<const float*>(x1),
                            reinterpret_cast<const float*>(x2), n, C, a1, a2, a3, reinterpret_cast<float*>(y));
     ESVIT_CHECK_LAUNCH("col_affine2");
+    return ESVIT_OK;
+}
+
+extern "C" int esvit_bn_fwd_coeffs(const float* sums, float n, const float* gamma, const float* beta, float eps, float momentum,
+                                   float* running_mean, float* running_var, int C, float* coef, esvit_stream_t s_) {
+    STREAM(s_);
+    ESVIT_CHECK_ARG(sums && gamma && beta && coef && C > 0 && n > 1.f && (!running_mean == !running_var), "esvit_bn_fwd_coeffs: bad args");
+    hipLaunchKernelGGL(bn_fwd_coeffs_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, stream, sums, n, gamma, beta, eps, momentum, running_mean,
+                       running_var, C, coef);
+    ESVIT_CHECK_LAUNCH("bn_fwd_coeffs");
+    return ESVIT_OK;
+}
+
+extern "C" int esvit_bn_eval_coeffs(const float* running_mean, const float* running_var, const float* gamma, const float* beta, float eps,
+                                    int C, float* coef, esvit_stream_t s_) {
+    STREAM(s_);
+    ESVIT_CHECK_ARG(running_mean && running_var && gamma && beta && coef && C > 0, "esvit_bn_eval_coeffs: bad args");
+    hipLaunchKernelGGL(bn_eval_coeffs_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, stream, running_mean, running_var, gamma, beta, eps, C, coef);
+    ESVIT_CHECK_LAUNCH("bn_eval_coeffs");
+    return ESVIT_OK;
+}
+
+extern "C" int esvit_bn_bwd_local(const float* sums, const float* coef, int C, float* red, esvit_stream_t s_) {
+    STREAM(s_);
+    ESVIT_CHECK_ARG(sums && coef && red && C > 0, "esvit_bn_bwd_local: bad args");
+    hipLaunchKernelGGL(bn_bwd_local_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, stream, sums, coef, C, red);
+    ESVIT_CHECK_LAUNCH("bn_bwd_local");
+    return ESVIT_OK;
+}
+
+extern "C" int esvit_bn_bwd_coeffs(const float* red, float n, const float* gamma, const float* coef, int C, float* abc, esvit_stream_t s_) {
+    STREAM(s_);
+    ESVIT_CHECK_ARG(gamma && coef && abc && C > 0 && n > 0.f, "esvit_bn_bwd_coeffs: bad args");
+    hipLaunchKernelGGL(bn_bwd_coeffs_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, stream, red, n, gamma, coef, C, abc);
+    ESVIT_CHECK_LAUNCH("bn_bwd_coeffs");
+    return ESVIT_OK;
+}
+
+extern "C" int esvit_pad_crop_tokens(int dtype, const void* src, int nB, int Hs, int Ws, int Hd, int Wd, int C, void* dst, esvit_stream_t s_) {
+    STREAM(s_);
+    ESVIT_CHECK_ARG(src && dst && nB > 0 && Hs > 0 && Ws > 0 && Hd > 0 && Wd > 0 && C > 0, "esvit_pad_crop_tokens: bad args");
+    ESVIT_CHECK_ARG(dtype == ESVIT_BF16 || dtype == ESVIT_F32, "esvit_pad_crop_tokens: bad dtype");
+    ESVIT_CHECK_ARG(C % (dtype == ESVIT_BF16 ? 8 : 4) == 0, "esvit_pad_crop_tokens: C=%d must be a multiple of the 16-byte vector", C);
+    if (dtype == ESVIT_BF16)
+        hipLaunchKernelGGL(pad_crop_kernel<bf16>, dim3(grid_for((long)nB * Hd * Wd * (C / 8))), dim3(256), 0, stream,
+                           reinterpret_cast<const bf16*>(src), nB, Hs, Ws, Hd, Wd, C, reinterpret_cast<bf16*>(dst));
+    else
+        hipLaunchKernelGGL(pad_crop_kernel<float>, dim3(grid_for((long)nB * Hd * Wd * (C / 4))), dim3(256), 0, stream,
+                           reinterpret_cast<const float*>(src), nB, Hs, Ws, Hd, Wd, C, reinterpret_cast<float*>(dst));
+    ESVIT_CHECK_LAUNCH("pad_crop_tokens");
     return ESVIT_OK;
 }

@@ -343,17 +343,13 @@ def _pad_tokens(t, nB, H, W, Hp, Wp):
     """[nB*H*W, C] -> [nB*Hp*Wp, C] with zero rows/cols appended bottom/right (F.pad of cvt_v4_transformer.py:173)"""
     if Hp == H and Wp == W:
         return t
-    C = t.shape[1]
-    out = torch.zeros((nB, Hp, Wp, C), dtype=t.dtype, device=t.device)
-    out[:, :H, :W] = t.view(nB, H, W, C)
-    return out.view(nB * Hp * Wp, C)
+    return ops_module().pad_crop_tokens(t, nB, H, W, Hp, Wp)
 
 
 def _crop_tokens(t, nB, H, W, Hp, Wp):
     if Hp == H and Wp == W:
         return t
-    C = t.shape[1]
-    return t.view(nB, Hp, Wp, C)[:, :H, :W].contiguous().view(nB * H * W, C)
+    return ops_module().pad_crop_tokens(t, nB, Hp, Wp, H, W)
 
 
 def _allreduce_stats(t, group):
@@ -424,23 +420,17 @@ class CvtAttnFn(torch.autograd.Function):
         d = o.dwconv3x3(xp, dw9, nB, Hp, Wp)
         rows = nB * Hp * Wp
         eval_bn = bool(bn_state.get("eval"))
+        gam, bet = bn_g.detach().contiguous(), bn_b.detach().contiguous()
         if eval_bn:  # inference: the running statistics (nn.BatchNorm2d in eval mode)
-            n = torch.tensor(float(rows), device=x.device)
-            bmean, bvar = bn_state["eval_mean"].detach().float(), bn_state["eval_var"].detach().float()
+            n = float(rows)
+            coef = o.bn_eval_coeffs(bn_state["eval_mean"], bn_state["eval_var"], gam, bet, BN_EPS)
         else:        # BatchNorm2d, training statistics over every position of the (padded) map on every rank
-            stats = torch.cat([o.col_sums2(d, d).view(-1), torch.tensor([float(rows)], device=x.device)])
-            _allreduce_stats(stats, bn_state.get("group"))
-            n = stats[-1]
-            bmean = stats[:C] / n
-            bvar = (stats[C:2 * C] / n - bmean * bmean).clamp_min_(0.0)
-        brstd = torch.rsqrt(bvar + BN_EPS)
-        a = bn_g.detach() * brstd
-        bnout = o.col_affine2(d, a.contiguous(), (bn_b.detach() - bmean * a).contiguous())
-        if not eval_bn and bn_state.get("running_mean") is not None:  # buffers of the nn.BatchNorm2d holder (momentum 0.1, unbiased variance)
-            with torch.no_grad():
-                bn_state["running_mean"].mul_(1 - BN_MOMENTUM).add_(BN_MOMENTUM * bmean)
-                bn_state["running_var"].mul_(1 - BN_MOMENTUM).add_(BN_MOMENTUM * bvar * (n / (n - 1)))
+            sums = o.col_sums2(d, d)
+            n = float(rows * _allreduce_stats(sums, bn_state.get("group")))  # every rank runs the same per-GPU batch
+            coef = o.bn_fwd_coeffs(sums, n, gam, bet, BN_EPS, BN_MOMENTUM, bn_state.get("running_mean"), bn_state.get("running_var"))
+            if bn_state.get("num_batches_tracked") is not None:
                 bn_state["num_batches_tracked"].add_(1)
+        bnout = o.col_affine2(d, coef[0], coef[1])
         Wpw, Wproj = _weight(pw_Wp, (3 * C, C)), _weight(proj_Wp, (C, C))
         qkv = o.linear_fwd(bnout, Wpw, pw_b)
         geom = geometry(Hp, Wp, w, 0, x.device)
@@ -450,13 +440,15 @@ class CvtAttnFn(torch.autograd.Function):
         aoc = _crop_tokens(ao, nB, H, W, Hp, Wp)
         x1 = o.linear_fwd(aoc, Wproj, proj_b, residual=x2d, rowscale=dp, rows_per_sample=L, out_f32=True)
         ctx.meta = (H, W, Hp, Wp, w, nH, scale, dp, bn_state.get("group"), eval_bn)
-        ctx.save_for_backward(x, mean1, rstd1, g1, xp, dw9, d, bmean, brstd, n, bn_g, bnout, Wpw, pw_b, qkv, ao, aoc, Wproj)
+        ctx.n = n
+        ctx.save_for_backward(x, mean1, rstd1, g1, xp, dw9, d, coef, gam, bnout, Wpw, pw_b, qkv, ao, aoc, Wproj)
         return x1.view(nB, L, C)
 
     @staticmethod
     def backward(ctx, gy):
         o = ops_module()
-        x, mean1, rstd1, g1, xp, dw9, d, bmean, brstd, n, bn_g, bnout, Wpw, pw_b, qkv, ao, aoc, Wproj = ctx.saved_tensors
+        x, mean1, rstd1, g1, xp, dw9, d, coef, gam, bnout, Wpw, pw_b, qkv, ao, aoc, Wproj = ctx.saved_tensors
+        n = ctx.n
         H, W, Hp, Wp, w, nH, scale, dp, group, eval_bn = ctx.meta
         nB, L, C = x.shape
         M = nB * L
@@ -470,21 +462,14 @@ class CvtAttnFn(torch.autograd.Function):
         dWpw, dbpw = o.linear_wgrad(dqkv, bnout, want_bias=True)
         dbn = o.linear_dgrad(dqkv, Wpw)
         # BatchNorm backward: d(d) = gamma rstd (dy - mean(dy) - xhat mean(dy xhat)), xhat = (d - mean) rstd
-        sums = o.col_sums2(dbn, d)
-        s_dy, s_dyd = sums[0].clone(), sums[1].clone()
-        s_dyx = brstd * (s_dyd - bmean * s_dy)          # sum(dy * xhat), local
-        dgam, dbet = s_dyx.clone(), s_dy.clone()
-        red = torch.cat([s_dy, s_dyx])
+        red = o.bn_bwd_local(o.col_sums2(dbn, d), coef)   # (sum dy, sum dy*xhat) of this rank = (d beta, d gamma)
+        dbet, dgam = red[0].clone(), red[1].clone()
         if eval_bn:  # fixed statistics: the normalisation is a per-channel affine map, no batch terms in its gradient
-            red = torch.zeros_like(red)
+            abc = o.bn_bwd_coeffs(None, n, gam, coef)
         else:
             _allreduce_stats(red, group)
-        m1, m2 = red[:C] / n, red[C:] / n
-        gam = bn_g.detach()
-        A = gam * brstd
-        B = -gam * brstd * brstd * m2
-        Cc = -gam * brstd * m1 - B * bmean
-        dd = o.col_affine2(dbn, A.contiguous(), Cc.contiguous(), d, B.contiguous())
+            abc = o.bn_bwd_coeffs(red, n, gam, coef)
+        dd = o.col_affine2(dbn, abc[0], abc[2], d, abc[1])
         ddw = o.dwconv3x3_wgrad(xp, dd, nB, Hp, Wp).view(C, 1, 3, 3)
         dxn = _crop_tokens(o.dwconv3x3(dd, dw9, nB, Hp, Wp, flip=True), nB, H, W, Hp, Wp)
         gx, dg1, db1 = o.layernorm_bwd(dxn, x.view(M, C), mean1, rstd1, g1, g_in=gy)

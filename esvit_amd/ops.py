@@ -663,3 +663,45 @@ def col_affine2(x1, a1, a3, x2=None, a2=None):
     check(lib.esvit_col_affine2(_code(x1.dtype), _p(x1), _p(x2), rows, Cc, _p(_f32c(a1)), _p(a2), _p(_f32c(a3)), _p(y), _stream()),
           "col_affine2")
     return y
+
+
+def bn_fwd_coeffs(sums, n, gamma, beta, eps, momentum, running_mean=None, running_var=None):
+    """sums fp32 [2, C] (sum d, sum d^2; already summed over the ranks) -> coef fp32 [4, C] = (a, shift, mean, rstd)"""
+    Cc = gamma.numel()
+    coef = torch.empty((4, Cc), dtype=torch.float32, device=sums.device)
+    check(lib.esvit_bn_fwd_coeffs(_p(_f32c(sums)), float(n), _p(_f32c(gamma)), _p(_f32c(beta)), float(eps), float(momentum),
+                                  _p(running_mean), _p(running_var), Cc, _p(coef), _stream()), "bn_fwd_coeffs")
+    return coef
+
+
+def bn_eval_coeffs(running_mean, running_var, gamma, beta, eps):
+    Cc = gamma.numel()
+    coef = torch.empty((4, Cc), dtype=torch.float32, device=gamma.device)
+    check(lib.esvit_bn_eval_coeffs(_p(_f32c(running_mean)), _p(_f32c(running_var)), _p(_f32c(gamma)), _p(_f32c(beta)), float(eps), Cc,
+                                   _p(coef), _stream()), "bn_eval_coeffs")
+    return coef
+
+
+def bn_bwd_local(sums, coef):
+    """sums fp32 [2, C] (sum dy, sum dy*d) -> red fp32 [2, C] (sum dy, sum dy*xhat)"""
+    Cc = coef.shape[1]
+    red = torch.empty((2, Cc), dtype=torch.float32, device=sums.device)
+    check(lib.esvit_bn_bwd_local(_p(_f32c(sums)), _p(_f32c(coef)), Cc, _p(red), _stream()), "bn_bwd_local")
+    return red
+
+
+def bn_bwd_coeffs(red, n, gamma, coef):
+    """-> abc fp32 [3, C]: d(d) = A*dy + B*d + C (red=None: fixed / eval statistics)"""
+    Cc = coef.shape[1]
+    abc = torch.empty((3, Cc), dtype=torch.float32, device=coef.device)
+    check(lib.esvit_bn_bwd_coeffs(_p(red), float(n), _p(_f32c(gamma)), _p(_f32c(coef)), Cc, _p(abc), _stream()), "bn_bwd_coeffs")
+    return abc
+
+
+def pad_crop_tokens(src, nB, Hs, Ws, Hd, Wd):
+    """[nB*Hs*Ws, C] -> [nB*Hd*Wd, C]: zero-pad at the bottom / right, or crop"""
+    src = _actc(src)
+    Cc = src.shape[1]
+    dst = torch.empty((nB * Hd * Wd, Cc), dtype=src.dtype, device=src.device)
+    check(lib.esvit_pad_crop_tokens(_code(src.dtype), _p(src), nB, Hs, Ws, Hd, Wd, Cc, _p(dst), _stream()), "pad_crop_tokens")
+    return dst

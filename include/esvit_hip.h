@@ -281,6 +281,22 @@ int esvit_col_sums2(int dtype, const void* a, const void* b, int64_t rows, int C
                     esvit_stream_t stream);
 int esvit_col_affine2(int dtype, const void* x1, const void* x2, int64_t rows, int C, const float* a1, const float* a2,
                       const float* a3, void* y, esvit_stream_t stream);
+/* token grid [nB,Hs,Ws,C] -> [nB,Hd,Wd,C]: zero-pad at the bottom / right (F.pad of cvt_v4_transformer.py:173) or crop (:216) */
+int esvit_pad_crop_tokens(int dtype, const void* src, int nB, int Hs, int Ws, int Hd, int Wd, int C, void* dst,
+                          esvit_stream_t stream);
+/* BatchNorm2d coefficient vectors (nn.BatchNorm2d of cvt_v4_transformer.py:95; eps 1e-5, momentum 0.1).
+ * fwd:  sums = [sum d | sum d^2] over n positions (already summed over the ranks for SyncBatchNorm) ->
+ *       coef fp32 [4*C] = [a | shift | mean | rstd], y = a*d + shift; running_mean / running_var (both or neither) are
+ *       updated in place with the unbiased variance.   eval: the same coef from the running statistics.
+ * bwd:  esvit_bn_bwd_local: sums = [sum dy | sum dy*d] -> red = [sum dy | sum dy*xhat] (= this rank's d beta | d gamma);
+ *       esvit_bn_bwd_coeffs: red summed over the ranks (NULL = eval statistics) -> abc = [A | B | C], d(d) = A*dy + B*d + C. */
+int esvit_bn_fwd_coeffs(const float* sums, float n, const float* gamma, const float* beta, float eps, float momentum,
+                        float* running_mean, float* running_var, int C, float* coef, esvit_stream_t stream);
+int esvit_bn_eval_coeffs(const float* running_mean, const float* running_var, const float* gamma, const float* beta,
+                         float eps, int C, float* coef, esvit_stream_t stream);
+int esvit_bn_bwd_local(const float* sums, const float* coef, int C, float* red, esvit_stream_t stream);
+int esvit_bn_bwd_coeffs(const float* red, float n, const float* gamma, const float* coef, int C, float* abc,
+                        esvit_stream_t stream);
 
 /* ---- debug switches (tests only) ---------------------------------------- */
 void esvit_debug_set_tr_read(int on);      /* GEMM: ds_read_b64_tr_b16 vs scalar LDS gathers */

@@ -569,3 +569,42 @@ def col_affine2(x1, a1, a3, x2=None, a2=None):
     if x2 is not None:
         y = y + x2.float() * a2
     return _r(y, x1.dtype)
+
+
+def bn_fwd_coeffs(sums, n, gamma, beta, eps, momentum, running_mean=None, running_var=None):
+    n = float(n)
+    mean = sums[0] / n
+    var = (sums[1] / n - mean * mean).clamp_min(0.0)
+    rstd = torch.rsqrt(var + eps)
+    a = gamma * rstd
+    if running_mean is not None:
+        running_mean.mul_(1 - momentum).add_(momentum * mean)
+        running_var.mul_(1 - momentum).add_(momentum * var * (n / (n - 1)))
+    return torch.stack([a, beta - mean * a, mean, rstd], 0)
+
+
+def bn_eval_coeffs(running_mean, running_var, gamma, beta, eps):
+    rstd = torch.rsqrt(running_var + eps)
+    a = gamma * rstd
+    return torch.stack([a, beta - running_mean * a, running_mean.clone(), rstd], 0)
+
+
+def bn_bwd_local(sums, coef):
+    return torch.stack([sums[0], coef[3] * (sums[1] - coef[2] * sums[0])], 0)
+
+
+def bn_bwd_coeffs(red, n, gamma, coef):
+    mean, rstd = coef[2], coef[3]
+    m1 = red[0] / float(n) if red is not None else torch.zeros_like(mean)
+    m2 = red[1] / float(n) if red is not None else torch.zeros_like(mean)
+    A = gamma * rstd
+    B = -gamma * rstd * rstd * m2
+    return torch.stack([A, B, -gamma * rstd * m1 - B * mean], 0)
+
+
+def pad_crop_tokens(src, nB, Hs, Ws, Hd, Wd):
+    Cc = src.shape[1]
+    out = torch.zeros((nB, Hd, Wd, Cc), dtype=src.dtype, device=src.device)
+    h, w = min(Hs, Hd), min(Ws, Wd)
+    out[:, :h, :w] = src.view(nB, Hs, Ws, Cc)[:, :h, :w]
+    return out.view(nB * Hd * Wd, Cc)

@@ -341,6 +341,21 @@ def test_cvt_conv_pieces(mods, dt):
         a1, a2, a3 = _rand((Cc,), dev, 76), _rand((Cc,), dev, 77), _rand((Cc,), dev, 78)
         _close("affine", ops.col_affine2(x, a1, a3), ref.col_affine2(x, a1, a3), _tol(dt, bf=2e-2))
         _close("affine2", ops.col_affine2(x, a1, a3, dy, a2), ref.col_affine2(x, a1, a3, dy, a2), _tol(dt, bf=2e-2))
+        _close("pad", ops.pad_crop_tokens(x, 2, H, H, H + 2, H + 1), ref.pad_crop_tokens(x, 2, H, H, H + 2, H + 1), 0.0)
+        _close("crop", ops.pad_crop_tokens(x, 2, H, H, H - 1, H - 2), ref.pad_crop_tokens(x, 2, H, H, H - 1, H - 2), 0.0)
+        # BatchNorm coefficient vectors
+        sums, gam, bet = ops.col_sums2(x, x), 1 + 0.1 * _rand((Cc,), dev, 79), 0.1 * _rand((Cc,), dev, 80)
+        rm, rv = _rand((Cc,), dev, 81) * 0.1, 1 + 0.1 * _rand((Cc,), dev, 82).abs()
+        rm2, rv2 = rm.clone(), rv.clone()
+        coef, coefr = ops.bn_fwd_coeffs(sums, 2 * H * H, gam, bet, 1e-5, 0.1, rm, rv), ref.bn_fwd_coeffs(sums, 2 * H * H, gam, bet, 1e-5, 0.1, rm2, rv2)
+        _close("bn coef", coef, coefr, 1e-4)
+        _close("bn running mean", rm, rm2, 1e-5)
+        _close("bn running var", rv, rv2, 1e-4)
+        _close("bn eval coef", ops.bn_eval_coeffs(rm, rv, gam, bet, 1e-5), ref.bn_eval_coeffs(rm, rv, gam, bet, 1e-5), 1e-5)
+        red, redr = ops.bn_bwd_local(ops.col_sums2(dy, x), coef), ref.bn_bwd_local(ref.col_sums2(dy, x), coefr)
+        _close("bn bwd local", red, redr, _tol(dt, f32=1e-3, bf=1e-3))
+        _close("bn bwd coef", ops.bn_bwd_coeffs(red, 2 * H * H, gam, coef), ref.bn_bwd_coeffs(red, 2 * H * H, gam, coef), 1e-4)
+        _close("bn bwd coef eval", ops.bn_bwd_coeffs(None, 2 * H * H, gam, coef), ref.bn_bwd_coeffs(None, 2 * H * H, gam, coef), 1e-4)
 
 
 @pytest.mark.parametrize("dt", DTYPES)
