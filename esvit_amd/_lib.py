@@ -59,6 +59,7 @@ SIGNATURES = {
     "esvit_bn_bwd_local": (C.c_int, [vp, vp, C.c_int, vp, vp]),
     "esvit_bn_bwd_coeffs": (C.c_int, [vp, f32, vp, vp, C.c_int, vp, vp]),
     "esvit_layernorm_bwd": (C.c_int, [C.c_int, vp, vp, vp, vp, vp, vp, i64, C.c_int, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp]),
+    "esvit_layernorm_bwd_cast": (C.c_int, [C.c_int, vp, vp, vp, vp, vp, vp, i64, C.c_int, vp, vp, vp, vp, vp, vp, C.c_int, vp]),
     "esvit_gather_cast": (C.c_int, [C.c_int, vp, vp, i64, C.c_int, vp, C.c_int, C.c_int, vp, C.c_int, vp]),
     "esvit_cast_f32_to": (C.c_int, [C.c_int, vp, vp, i64, vp]),
     "esvit_cast_to_f32": (C.c_int, [C.c_int, vp, vp, i64, vp]),

@@ -118,7 +118,9 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(RowSrc src, const T*
                                                              const float* __restrict__ gamma,
                                                              const float* __restrict__ g_in, long rows,
                                                              float* __restrict__ dx, float* __restrict__ ws,
-                                                             const int* __restrict__ rowmap, int tokens, int period_in) {
+                                                             const int* __restrict__ rowmap, int tokens, int period_in,
+                                                             T* __restrict__ dx_act, const float* __restrict__ rowscale,
+                                                             int rows_per_sample) {
     constexpr int RPB = LN_THREADS / G;
     const int C = src.C, C4 = C / 4;
     const int gl = threadIdx.x % G, grp = threadIdx.x / G;
@@ -162,6 +164,10 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(RowSrc src, const T*
                 float* dp = src.dptr(dx, r, c4);
                 if (g_in) o += *reinterpret_cast<const f32x4*>(g_in + (dp - dx));
                 *reinterpret_cast<f32x4*>(dp) = o;
+                if (dx_act) {  // the activation-dtype, DropPath-scaled copy the next GEMMs of the backward read (saves a cast pass)
+                    const float sc = rowscale ? rowscale[r / rows_per_sample] : 1.f;
+                    store4<T>(dx_act + r * (long)C + c4 * 4, o * sc);
+                }
             }
         }
     }
@@ -268,7 +274,8 @@ int ln_fwd_launch(RowSrc src, const float* gamma, const float* beta, float eps, 
 template <typename T>
 int ln_bwd_launch(RowSrc src, const void* dy, const float* mean, const float* rstd, const float* gamma,
                   const float* g_in, long rows, float* dx, float* dgamma, float* dbeta, float* ws, const int* rowmap,
-                  int tokens, int period_in, hipStream_t stream) {
+                  int tokens, int period_in, hipStream_t stream, void* dx_act = nullptr, const float* rowscale = nullptr,
+                  int rows_per_sample = 1) {
     LnCfg cfg;
     ESVIT_CHECK_ARG(ln_cfg(src.C, &cfg), "layernorm: unsupported channel count %d", src.C);
     const int nblk = ln_bwd_nblk(rows, src.C);
@@ -282,7 +289,8 @@ int ln_bwd_launch(RowSrc src, const void* dy, const float* mean, const float* rs
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)lds);
         hipLaunchKernelGGL(kern, dim3(nblk), dim3(LN_THREADS), lds, stream, src, reinterpret_cast<const T*>(dy), mean,
-                           rstd, gamma, g_in, rows, dx, ws, rowmap, tokens, period_in);
+                           rstd, gamma, g_in, rows, dx, ws, rowmap, tokens, period_in, reinterpret_cast<T*>(dx_act), rowscale,
+                           rows_per_sample);
     });
     ESVIT_CHECK_LAUNCH("layernorm_bwd");
     // ws rows are [dgamma(C) | dbeta(C)]; reduce both halves (dgamma and dbeta may be separate allocations)
@@ -468,6 +476,27 @@ extern "C" int esvit_layernorm_bwd(int dtype, const void* dy, const float* x, co
     if (dtype == ESVIT_F32)
         return ln_bwd_launch<float>(src, dy, mean, rstd, gamma, g_in, rows, dx, dgamma, dbeta, ws, rowmap, tokens, period_in, stream);
     esvit_set_error("esvit_layernorm_bwd: bad dtype");
+    return ESVIT_ERR_ARG;
+}
+
+// LayerNorm backward that also writes dx_act = cast(rowscale[row / rows_per_sample] * dx): the DropPath-scaled, activation-dtype
+// gradient the following dgrad / wgrad GEMMs read (otherwise a separate esvit_gather_cast pass over dx)
+extern "C" int esvit_layernorm_bwd_cast(int dtype, const void* dy, const float* x, const float* mean, const float* rstd,
+                                        const float* gamma, const float* g_in, int64_t rows, int C, float* dx, float* dgamma,
+                                        float* dbeta, float* ws, void* dx_act, const float* rowscale, int rows_per_sample,
+                                        esvit_stream_t s_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(s_);
+    ESVIT_CHECK_ARG(dy && x && mean && rstd && gamma && dx && dgamma && dbeta && ws && dx_act && rows > 0,
+                    "esvit_layernorm_bwd_cast: bad args");
+    if (rowscale) ESVIT_CHECK_ARG(rows_per_sample > 0, "esvit_layernorm_bwd_cast: rowscale needs rows_per_sample");
+    RowSrc src{x, C, 0, 0, 0, 0};
+    if (dtype == ESVIT_BF16)
+        return ln_bwd_launch<bf16>(src, dy, mean, rstd, gamma, g_in, rows, dx, dgamma, dbeta, ws, nullptr, 0, 0, stream, dx_act, rowscale,
+                                   rows_per_sample > 0 ? rows_per_sample : 1);
+    if (dtype == ESVIT_F32)
+        return ln_bwd_launch<float>(src, dy, mean, rstd, gamma, g_in, rows, dx, dgamma, dbeta, ws, nullptr, 0, 0, stream, dx_act, rowscale,
+                                    rows_per_sample > 0 ? rows_per_sample : 1);
+    esvit_set_error("esvit_layernorm_bwd_cast: bad dtype");
     return ESVIT_ERR_ARG;
 }
 

@@ -11,8 +11,8 @@
 //                  P^T from the saved log-sum-exp, delta = rowsum(dO o O), dV = P^T dO, dK = dS^T (scale Q).
 //
 // Tokens are padded to 224 = 14 MFMA tiles (keys >= 196 get -1e30, never any probability).  Small per-window tables live
-// in LDS: slot->token map, a(t) = (t/ws)(2ws-1) + t%ws packed with the shift-mask region label, and the head's column
-// of the (2ws-1)^2-entry relative-position table (bias = table[a(q) - a(key) + (ws-1) 2ws]).
+// in LDS: slot->token map and the shift-mask region label of every slot.  The relative-position bias arrives precomputed
+// in MFMA fragment order (relpos_bias_frag_big_kernel), one 16-byte load per lane per 16x16 score tile.
 #include "common.h"
 #include "mfma.h"
 #include "../../include/esvit_hip.h"
@@ -68,9 +68,6 @@ __device__ __forceinline__ void load_window_tables(const BigTables& tb, const in
         tb.tok[t] = tok;
         tb.pk[t] = pk;
     }
-}
-__device__ __forceinline__ void load_table_column(const BigTables& tb, const float* __restrict__ table, int rows, int nH, int h) {
-    for (int t = threadIdx.x; t < rows; t += blockDim.x) tb.tab[t] = table[(long)t * nH + h];
 }
 
 // stage `nrows` window slots (first slot s0) of a token-ordered matrix into a [nrows][LDQ] image; `nthr` threads cooperate
@@ -140,13 +137,6 @@ __device__ __forceinline__ f32x4 bias_tile(const float* __restrict__ bias_h, con
     return b;
 }
 
-// bias + mask value of the score element (query slot q, key slot k)
-__device__ __forceinline__ float score_bias(const BigTables& tb, int pq, int pkk, bool qok, bool kok, int off, bool masked) {
-    float v = (qok && kok) ? tb.tab[(pq & 0xffff) - (pkk & 0xffff) + off] : 0.f;
-    if (!kok) v = -1.0e30f;
-    if (masked && (pq >> 16) != (pkk >> 16)) v += -100.f;
-    return v;
-}
 
 // write a [32 rows][32 d] result (D layout acc[ti][jd]: row 16ti+4g+r, cols 16jd+c) to token rows; pad slots -> pad sums
 template <typename T>
@@ -230,7 +220,6 @@ __global__ __launch_bounds__(BigCfg<T>::WAVES * 64) void attn_big_fwd_kernel(
     const long tok_base = (long)(bw / nW) * L;
     const T* src = qkv + h * HD;
     const bool masked = region_ids != nullptr;
-    const int off = (ws - 1) * 2 * ws;
 
     load_window_tables(tb, win2tok, region_ids, bw % nW, N, ws, true);
     const float* bias_h = bias_frag + (long)h * (NT * NT * 256);
@@ -355,7 +344,6 @@ __global__ __launch_bounds__(BigCfg<T>::WAVES * 64) void attn_big_bwd_dq_kernel(
     const int q0 = wave_ok ? 32 * qb : 0;
     const int C = nH * HD;
     const bool masked = region_ids != nullptr;
-    const int off = (ws - 1) * 2 * ws;
     const T* src = qkv + h * HD;
 
     f32x4 db[NT][2];
@@ -501,7 +489,6 @@ __global__ __launch_bounds__(BigCfg<T>::WAVES * 64) void attn_big_bwd_dkv_kernel
     const long tok_base = (long)(bw / nW) * L;
     const T* src = qkv + h * HD;
     const bool masked = region_ids != nullptr;
-    const int off = (ws - 1) * 2 * ws;
 
     load_window_tables(tb, win2tok, region_ids, bw % nW, N, ws, true);
     const float* bias_h = bias_frag + (long)h * (NT * NT * 256);

@@ -124,9 +124,8 @@ class SwinBlockFn(torch.autograd.Function):
         da1 = o.linear_dgrad(dyb, W2, gelu_preact=a1)
         dW1, dbfc1 = o.linear_wgrad(da1, h, want_bias=True)
         dh = o.linear_dgrad(da1, W1)
-        gx1, dg2, db2 = o.layernorm_bwd(dh, x1, mean2, rstd2, g2, g_in=gy)
-        # ---- attention branch ----
-        dyw = o.gather_cast(gx1, M, rowscale=dp1, rows_per_sample=L)
+        # ---- attention branch ---- (the LayerNorm backward also emits the DropPath-scaled activation-dtype copy of gx1)
+        gx1, dyw, dg2, db2 = o.layernorm_bwd_cast(dh, x1, mean2, rstd2, g2, g_in=gy, rowscale=dp1, rows_per_sample=L)
         dWproj, dbproj = o.linear_wgrad(dyw, ao, want_bias=True)
         dao = o.linear_dgrad(dyw, Wproj)
         dqkv, dbias_ws, dpad_ws = o.window_attn_bwd(qkv, bqkv, geom.win2tok, L, dao, ao, lse, table, geom.ws, geom.region_ids,

@@ -296,6 +296,20 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, *, g_in=None, rowmap=None, period_in
     return dx, dgamma, dbeta
 
 
+def layernorm_bwd_cast(dy, x, mean, rstd, gamma, *, g_in=None, rowscale=None, rows_per_sample=0):
+    """-> (dx fp32, dx_act = cast(rowscale * dx) in dy's dtype, dgamma, dbeta): layernorm_bwd + gather_cast in one pass"""
+    x, dy = _f32c(x), _actc(dy)
+    Cc = x.shape[-1]
+    rows = x.numel() // Cc
+    dx = torch.empty_like(x)
+    dxa = torch.empty((rows, Cc), dtype=dy.dtype, device=x.device)
+    gb = torch.empty((2, Cc), dtype=torch.float32, device=x.device)
+    ws = workspace(lib.esvit_layernorm_bwd_blocks(rows, Cc) * 2 * Cc, x.device, slot=1)
+    check(lib.esvit_layernorm_bwd_cast(_code(dy.dtype), _p(dy), _p(x), _p(mean), _p(rstd), _p(gamma), _p(g_in), rows, Cc, _p(dx), _p(gb[0]),
+                                       _p(gb[1]), _p(ws), _p(dxa), _p(rowscale), rows_per_sample, _stream()), "layernorm_bwd_cast")
+    return dx, dxa, gb[0], gb[1]
+
+
 def merge_ln_fwd(x, gamma, beta, eps, H, W, dtype=None):
     """x fp32 [nB, H*W, C] -> (y act [nB*H/2*W/2, 4C], mean, rstd)."""
     x = _f32c(x)

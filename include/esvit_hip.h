@@ -108,6 +108,12 @@ int esvit_layernorm_bwd(int dtype, const void* dy, const float* x, const float* 
                         const float* gamma, const float* g_in, int64_t rows, int C, float* dx,
                         float* dgamma, float* dbeta, float* ws, const int32_t* rowmap, int tokens,
                         int period_in, esvit_stream_t stream);
+/* same, and additionally dx_act (activation dtype) = rowscale[row / rows_per_sample] * dx: the DropPath-scaled copy the next
+ * dgrad / wgrad GEMMs of the backward read (rowscale may be NULL = 1) -- saves one esvit_gather_cast pass over dx */
+int esvit_layernorm_bwd_cast(int dtype, const void* dy, const float* x, const float* mean, const float* rstd,
+                             const float* gamma, const float* g_in, int64_t rows, int C, float* dx, float* dgamma,
+                             float* dbeta, float* ws, void* dx_act, const float* rowscale, int rows_per_sample,
+                             esvit_stream_t stream);
 
 /* ---- element-wise / data-movement helpers ------------------------------ */
 /* dst[r,:] = cast(scale[r/rows_per_sample] * src[map(r),:]); src fp32 [*, C]; dst dtype [rows, C].

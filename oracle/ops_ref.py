@@ -211,6 +211,15 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, *, g_in=None, rowmap=None, period_in
     return dx.reshape(x.shape), (d * xh).sum(0), d.sum(0)
 
 
+def layernorm_bwd_cast(dy, x, mean, rstd, gamma, *, g_in=None, rowscale=None, rows_per_sample=0):
+    dx, dg, db = layernorm_bwd(dy, x, mean, rstd, gamma, g_in=g_in)
+    C = x.shape[-1]
+    d2 = dx.reshape(-1, C)
+    if rowscale is not None:
+        d2 = d2 * rowscale[torch.arange(d2.shape[0], device=x.device) // rows_per_sample].unsqueeze(1)
+    return dx, _r(d2, dy.dtype), dg, db
+
+
 def _merge_gather(x, H, W):
     nB, L, C = x.shape
     xg = x.view(nB, H, W, C)

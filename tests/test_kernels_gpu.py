@@ -181,6 +181,12 @@ def test_layernorm(mods, dt, C):
     _close("ln dx", dx, dxr, 5e-5)
     _close("ln dgamma", dg, dgr, 5e-5)
     _close("ln dbeta", db, dbr, 5e-5)
+    rs = _rand((9,), dev, 25).abs() + 0.5  # 333 rows = 9 samples x 37 rows
+    dx2, dxa, dg2, db2 = ops.layernorm_bwd_cast(dy, x, meanr, rstdr, g, g_in=gin, rowscale=rs, rows_per_sample=37)
+    _, dxar, _, _ = ref.layernorm_bwd_cast(dy, x, meanr, rstdr, g, g_in=gin, rowscale=rs, rows_per_sample=37)
+    _close("ln dx (cast variant)", dx2, dxr, 5e-5)
+    _close("ln dx_act", dxa, dxar, _tol(dt, bf=8e-3))
+    _close("ln dgamma (cast variant)", dg2, dgr, 5e-5)
 
 
 @pytest.mark.parametrize("dt", DTYPES)
