@@ -1167,11 +1167,10 @@ __global__ __launch_bounds__(WS_THREADS, 3) void gemm_ws_kernel(const esvit_gemm
 // flight and 9 workgroups.
 constexpr int SKR_QUADS = 64, SKR_SLICES = 4;
 template <typename TO>
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, int splits, long n, TO* __restrict__ out,
-                                                            int accumulate) {
-    __shared__ f32x4 sm[SKR_SLICES][SKR_QUADS];
+__device__ __forceinline__ void splitk_reduce_block(const float* __restrict__ part, int splits, long n, TO* __restrict__ out, int accumulate,
+                                                    long block, f32x4 (&sm)[SKR_SLICES][SKR_QUADS]) {
     const int q = threadIdx.x & (SKR_QUADS - 1), sl = threadIdx.x / SKR_QUADS;
-    const long i4 = ((long)blockIdx.x * SKR_QUADS + q) * 4;
+    const long i4 = (block * SKR_QUADS + q) * 4;
     const int cnt = i4 < n ? (int)min(4L, n - i4) : 0;
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
     if (cnt == 4) {
@@ -1200,6 +1199,16 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     }
 }
 
+// blocks [0, blocks1): the split-K partial slabs of C;  blocks [blocks1, ..): the fused bias-gradient partials (part2, n2 -> out2)
+template <typename TO>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, int splits, long n, TO* __restrict__ out,
+                                                            int accumulate, int blocks1, const float* __restrict__ part2, long n2,
+                                                            float* __restrict__ out2) {
+    __shared__ f32x4 sm[SKR_SLICES][SKR_QUADS];
+    if ((int)blockIdx.x < blocks1) splitk_reduce_block<TO>(part, splits, n, out, accumulate, blockIdx.x, sm);
+    else splitk_reduce_block<float>(part2, splits, n2, out2, 0, (long)blockIdx.x - blocks1, sm);
+}
+
 static int g_xcd_map = 0;  // 0: tiles on grid.x (XCD-remapped), z on grid.y; 1: 1-D grid, XCD-contiguous over (z, tile) -- measured 8% slower on the wgrad family (profiles/r01_gemm_xcdmap_ab.txt)
 
 template <typename T, bool AKS, bool BKS, int BM, int BN, bool USE_TR>
@@ -1224,14 +1233,14 @@ int launch_gemm(const esvit_gemm_desc& d, hipStream_t stream) {
     if (d.splitk > 1) {
         const long n = (long)d.M * d.N;
         const int blocks = ceil_div(ceil_div(n, 4), SKR_QUADS);
+        const int blocks2 = d.colsum ? ceil_div(ceil_div((long)d.M, 4), SKR_QUADS) : 0;  // bias-gradient partials ride along
         if (d.out_f32)
-            hipLaunchKernelGGL(splitk_reduce_kernel<float>, dim3(blocks), dim3(256), 0, stream, d.partial, d.splitk, n,
-                               reinterpret_cast<float*>(d.C), d.accumulate);
+            hipLaunchKernelGGL(splitk_reduce_kernel<float>, dim3(blocks + blocks2), dim3(256), 0, stream, d.partial, d.splitk, n,
+                               reinterpret_cast<float*>(d.C), d.accumulate, blocks, d.colsum_partial, (long)d.M, d.colsum);
         else
-            hipLaunchKernelGGL(splitk_reduce_kernel<T>, dim3(blocks), dim3(256), 0, stream, d.partial, d.splitk, n,
-                               reinterpret_cast<T*>(d.C), d.accumulate);
+            hipLaunchKernelGGL(splitk_reduce_kernel<T>, dim3(blocks + blocks2), dim3(256), 0, stream, d.partial, d.splitk, n,
+                               reinterpret_cast<T*>(d.C), d.accumulate, blocks, d.colsum_partial, (long)d.M, d.colsum);
         ESVIT_CHECK_LAUNCH("esvit_gemm(splitk_reduce)");
-        if (d.colsum) return esvit_partial_reduce(d.colsum_partial, d.splitk, d.M, d.M, d.colsum, 0, stream);
     }
     return ESVIT_OK;
 }
@@ -1257,14 +1266,14 @@ int launch_gemm_dma(const esvit_gemm_desc& d, hipStream_t stream) {
     if (d.splitk > 1) {
         const long n = (long)d.M * d.N;
         const int blocks = ceil_div(ceil_div(n, 4), SKR_QUADS);
+        const int blocks2 = d.colsum ? ceil_div(ceil_div((long)d.M, 4), SKR_QUADS) : 0;  // bias-gradient partials ride along
         if (d.out_f32)
-            hipLaunchKernelGGL(splitk_reduce_kernel<float>, dim3(blocks), dim3(256), 0, stream, d.partial, d.splitk, n,
-                               reinterpret_cast<float*>(d.C), d.accumulate);
+            hipLaunchKernelGGL(splitk_reduce_kernel<float>, dim3(blocks + blocks2), dim3(256), 0, stream, d.partial, d.splitk, n,
+                               reinterpret_cast<float*>(d.C), d.accumulate, blocks, d.colsum_partial, (long)d.M, d.colsum);
         else
-            hipLaunchKernelGGL(splitk_reduce_kernel<bf16>, dim3(blocks), dim3(256), 0, stream, d.partial, d.splitk, n,
-                               reinterpret_cast<bf16*>(d.C), d.accumulate);
+            hipLaunchKernelGGL(splitk_reduce_kernel<bf16>, dim3(blocks + blocks2), dim3(256), 0, stream, d.partial, d.splitk, n,
+                               reinterpret_cast<bf16*>(d.C), d.accumulate, blocks, d.colsum_partial, (long)d.M, d.colsum);
         ESVIT_CHECK_LAUNCH("esvit_gemm(dma splitk_reduce)");
-        if (d.colsum) return esvit_partial_reduce(d.colsum_partial, d.splitk, d.M, d.M, d.colsum, 0, stream);
     }
     return ESVIT_OK;
 }
@@ -1304,14 +1313,14 @@ int launch_gemm_ws(const esvit_gemm_desc& d, hipStream_t stream) {
     if (d.splitk > 1) {
         const long n = (long)d.M * d.N;
         const int blocks = ceil_div(ceil_div(n, 4), SKR_QUADS);
+        const int blocks2 = d.colsum ? ceil_div(ceil_div((long)d.M, 4), SKR_QUADS) : 0;  // bias-gradient partials ride along
         if (d.out_f32)
-            hipLaunchKernelGGL(splitk_reduce_kernel<float>, dim3(blocks), dim3(256), 0, stream, d.partial, d.splitk, n,
-                               reinterpret_cast<float*>(d.C), d.accumulate);
+            hipLaunchKernelGGL(splitk_reduce_kernel<float>, dim3(blocks + blocks2), dim3(256), 0, stream, d.partial, d.splitk, n,
+                               reinterpret_cast<float*>(d.C), d.accumulate, blocks, d.colsum_partial, (long)d.M, d.colsum);
         else
-            hipLaunchKernelGGL(splitk_reduce_kernel<bf16>, dim3(blocks), dim3(256), 0, stream, d.partial, d.splitk, n,
-                               reinterpret_cast<bf16*>(d.C), d.accumulate);
+            hipLaunchKernelGGL(splitk_reduce_kernel<bf16>, dim3(blocks + blocks2), dim3(256), 0, stream, d.partial, d.splitk, n,
+                               reinterpret_cast<bf16*>(d.C), d.accumulate, blocks, d.colsum_partial, (long)d.M, d.colsum);
         ESVIT_CHECK_LAUNCH("esvit_gemm(ws splitk_reduce)");
-        if (d.colsum) return esvit_partial_reduce(d.colsum_partial, d.splitk, d.M, d.M, d.colsum, 0, stream);
     }
     return ESVIT_OK;
 }
