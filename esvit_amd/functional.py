@@ -139,6 +139,95 @@ class SwinBlockFn(torch.autograd.Function):
                 dW2, dbfc2)
 
 
+# ---- ragged multi-resolution block: all crops of a step in ONE set of GEMM / LayerNorm launches ---------------------
+# LayerNorm, the four GEMMs and the residual adds of a block are row-wise, so the token rows of the 224^2 crops and of the
+# 96^2 crops can run through them together; only the window attention depends on the image geometry and is launched once per
+# resolution group on its row range.  Compared with one pass per group (swin_transformer.py:729-751) this halves the GEMM /
+# LayerNorm launches, removes the gradient-accumulation adds of every parameter used by both passes, halves the split-K
+# partial traffic of the weight gradients and gives the small local-crop GEMMs of stages 2-3 full grids.
+def _block_forward_multi(X, segs, nH, dp_rows, prm, wts, save):
+    """X fp32 [M, C]; segs: tuple of (row0, nB, L, geom); dp_rows: None or (per-row DropPath scale attn [M], mlp [M])"""
+    o = ops_module()
+    (g1, b1, table, bqkv, bproj, g2, b2, bfc1, bfc2) = prm
+    (Wqkv, Wproj, W1, W2) = wts
+    M, C = X.shape
+    scale = (C // nH) ** -0.5
+    dp1, dp2 = (None, None) if dp_rows is None else dp_rows
+    xw, _, mean1, rstd1 = o.layernorm_fwd(X, g1, b1, LN_EPS)
+    qkv = o.linear_fwd(xw, Wqkv, bqkv)
+    ao = torch.empty((M, C), dtype=qkv.dtype, device=X.device)
+    lses = []
+    for (r0, nB, L, geom) in segs:
+        r1 = r0 + nB * L
+        _, lse = o.window_attn_fwd(qkv[r0:r1], bqkv, geom.win2tok, L, table, geom.ws, geom.region_ids, geom.nW, geom.N, nH, scale, out=ao[r0:r1])
+        lses.append(lse)
+    x1 = o.linear_fwd(ao, Wproj, bproj, residual=X, rowscale=dp1, rows_per_sample=1, out_f32=True)
+    h, _, mean2, rstd2 = o.layernorm_fwd(x1, g2, b2, LN_EPS)
+    if save:
+        a1g, a1 = o.linear_fwd(h, W1, bfc1, gelu=True, want_preact=True)
+    else:
+        a1g, a1 = o.linear_fwd(h, W1, bfc1, gelu=True), None
+    x2 = o.linear_fwd(a1g, W2, bfc2, residual=x1, rowscale=dp2, rows_per_sample=1, out_f32=True)
+    saved = (mean1, rstd1, xw, qkv, ao, x1, mean2, rstd2, h, a1, a1g) if save else None
+    return x2, saved, lses
+
+
+class SwinBlockMultiFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, X, segs, nH, index, dp_rows, g1, b1, table, Wqkv_p, bqkv, Wproj_p, bproj, g2, b2, W1_p, bfc1, W2_p, bfc2):
+        wts = (_weight(Wqkv_p), _weight(Wproj_p), _weight(W1_p), _weight(W2_p))
+        X = X.contiguous()
+        y, saved, lses = _block_forward_multi(X, segs, nH, dp_rows, (g1, b1, table, bqkv, bproj, g2, b2, bfc1, bfc2), wts, True)
+        ctx.segs, ctx.nH, ctx.dp_rows, ctx.lses = segs, nH, dp_rows, lses
+        ctx.save_for_backward(X, index, g1, table, g2, bqkv, *wts, *saved)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        o = ops_module()
+        segs, nH, dp_rows = ctx.segs, ctx.nH, ctx.dp_rows
+        (X, index, g1, table, g2, bqkv, Wqkv, Wproj, W1, W2, mean1, rstd1, xw, qkv, ao, x1, mean2, rstd2, h, a1, a1g) = ctx.saved_tensors
+        M, C = X.shape
+        scale = (C // nH) ** -0.5
+        dp1, dp2 = (None, None) if dp_rows is None else dp_rows
+        gy = gy.contiguous()
+        # ---- MLP branch ----
+        dyb = o.gather_cast(gy, M, rowscale=dp2, rows_per_sample=1)
+        dW2, dbfc2 = o.linear_wgrad(dyb, a1g, want_bias=True)
+        da1 = o.linear_dgrad(dyb, W2, gelu_preact=a1)
+        dW1, dbfc1 = o.linear_wgrad(da1, h, want_bias=True)
+        dh = o.linear_dgrad(da1, W1)
+        gx1, dyw, dg2, db2 = o.layernorm_bwd_cast(dh, x1, mean2, rstd2, g2, g_in=gy, rowscale=dp1, rows_per_sample=1)
+        # ---- attention branch ----
+        dWproj, dbproj = o.linear_wgrad(dyw, ao, want_bias=True)
+        dao = o.linear_dgrad(dyw, Wproj)
+        dqkv = torch.empty_like(qkv)
+        dtable, pads = None, []
+        for (r0, nB, L, geom), lse in zip(segs, ctx.lses):
+            r1 = r0 + nB * L
+            _, dbias_ws, dpad_ws = o.window_attn_bwd(qkv[r0:r1], bqkv, geom.win2tok, L, dao[r0:r1], ao[r0:r1], lse, table, geom.ws, geom.region_ids,
+                                                     geom.nW, geom.N, nH, scale, dqkv_out=dqkv[r0:r1])
+            dt_g = o.relpos_bias_bwd(dbias_ws, index, geom.N, table.shape[0])
+            dtable = dt_g if dtable is None else dtable.add_(dt_g)
+            pads.append(dpad_ws)
+        dWqkv, dbqkv = o.linear_wgrad(dqkv, xw, want_bias=True)
+        for dpad_ws in pads:
+            o.colsum(dpad_ws, out=dbqkv[C:], accumulate=True)  # k/v bias gradient from the zero-pad slots
+        dxw = o.linear_dgrad(dqkv, Wqkv)
+        gx, dg1, db1 = o.layernorm_bwd(dxw, X, mean1, rstd1, g1, g_in=gx1)
+        return (gx, None, None, None, None, dg1, db1, dtable, dWqkv, dbqkv, dWproj, dbproj, dg2, db2, dW1, dbfc1, dW2, dbfc2)
+
+
+def swin_block_multi(X, segs, nH, index, dp_rows, prm_list):
+    """one Swin block over the token rows of several resolution groups; X fp32 [M, C]"""
+    if torch.is_grad_enabled() and (X.requires_grad or any(p.requires_grad for p in prm_list)):
+        return SwinBlockMultiFn.apply(X, segs, nH, index, dp_rows, *prm_list)
+    g1, b1, table, Wqkv, bqkv, Wproj, bproj, g2, b2, W1, bfc1, W2, bfc2 = prm_list
+    wts = (_weight(Wqkv), _weight(Wproj), _weight(W1), _weight(W2))
+    y, _, _ = _block_forward_multi(X.contiguous(), segs, nH, dp_rows, (g1, b1, table, bqkv, bproj, g2, b2, bfc1, bfc2), wts, False)
+    return y
+
+
 def swin_block(x, geom, nH, index, dp, prm_list):
     """prm_list: [g1, b1, table, Wqkv, bqkv, Wproj, bproj, g2, b2, W1, bfc1, W2, bfc2] (fp32 parameters)."""
     if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in prm_list)):

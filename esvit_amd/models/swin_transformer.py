@@ -109,6 +109,16 @@ class SwinTransformerBlock(nn.Module):
         return y, attn
 
 
+def _block_forward_multi(blk, X, groups, dp):
+    """blk: SwinTransformerBlock; X fp32 [M, C]; groups: list of (row0, nB, H, W); dp: None or (f1 [samples], f2, rowsample [M])"""
+    segs = tuple((r0, nB, H * W, Fn.geometry(H, W, blk.window_size, blk.shift_size, X.device)) for (r0, nB, H, W) in groups)
+    dp_rows = None
+    if dp is not None:
+        f1, f2, rowsample = dp
+        dp_rows = (f1[rowsample], f2[rowsample])  # per-row DropPath scale (rows of one sample share its factor)
+    return Fn.swin_block_multi(X, segs, blk.num_heads, blk.attn.relative_position_index, dp_rows, blk._params())
+
+
 class PatchMerging(nn.Module):
     def __init__(self, input_resolution, dim, norm_layer=nn.LayerNorm):
         super().__init__()
@@ -122,6 +132,14 @@ class PatchMerging(nn.Module):
         if H % 2 or W % 2:
             raise NotImplementedError("odd feature maps are not reachable from 224/96 crops (swin_transformer.py:406-408)")
         return Fn.PatchMergeFn.apply(x, H, W, self.norm.weight, self.norm.bias, self.reduction.weight)
+
+
+def _sample_offsets(groups):
+    off, out = 0, []
+    for (_, nB, _, _) in groups:
+        out.append(off)
+        off += nB
+    return out
 
 
 class BasicLayer(nn.Module):
@@ -139,6 +157,37 @@ class BasicLayer(nn.Module):
         for blk in self.blocks:
             x, _ = blk(x)
         return self.downsample(x) if self.downsample is not None else x
+
+    def forward_multi(self, xs):
+        """xs: list of fp32 token tensors [nB_g, L_g, C], one per resolution group.  The blocks of this stage run over the
+        concatenated rows of all groups (Fn.swin_block_multi); patch merging stays per group (its gather depends on the grid)."""
+        C = xs[0].shape[-1]
+        groups, r0 = [], 0
+        for x in xs:
+            nB, L, _ = x.shape
+            H = W = int(sqrt(L))
+            groups.append((r0, nB, H, W))
+            r0 += nB * L
+        X = torch.cat([x.reshape(-1, C) for x in xs]) if len(xs) > 1 else xs[0].reshape(-1, C)
+        rowsample = None
+        for blk in self.blocks:
+            dp = None
+            if isinstance(blk.drop_path, DropPath) and blk.drop_path.drop_prob and self.training:
+                nS = sum(g[1] for g in groups)
+                pend = blk.__dict__.pop("_dp_pending", None)  # drawn for every block at once by SwinTransformer._draw_drop_path
+                if pend is None or pend[0].shape[0] != nS:
+                    pend = (blk.drop_path.factors(nS, X.device), blk.drop_path.factors(nS, X.device))
+                if rowsample is None:
+                    rowsample = torch.cat([torch.arange(nB, device=X.device).repeat_interleave(H * W) + s0
+                                           for (_, nB, H, W), s0 in zip(groups, _sample_offsets(groups))])
+                dp = (pend[0], pend[1], rowsample)
+            X = _block_forward_multi(blk, X, groups, dp)
+        outs = []
+        parts = torch.split(X, [nB * H * W for (_, nB, H, W) in groups]) if len(groups) > 1 else (X,)  # backward: one cat
+        for part, (r0, nB, H, W) in zip(parts, groups):
+            x = part.view(nB, H * W, C)
+            outs.append(self.downsample(x) if self.downsample is not None else x)
+        return outs
 
     def forward_with_features(self, x):
         fea = []
@@ -202,6 +251,9 @@ class SwinTransformer(nn.Module):
         self.avgpool = nn.AdaptiveAvgPool1d(1)
         self.head = nn.Linear(self.num_features, num_classes) if num_classes > 0 else nn.Identity()
         self.use_dense_prediction = use_dense_prediction
+        # run the 224^2 and the 96^2 crops of a step through the backbone together (BasicLayer.forward_multi); False = one pass
+        # per resolution group exactly as the reference schedules it (swin_transformer.py:729-751) -- same result either way
+        self.ragged_multi_crop = True
         if self.use_dense_prediction:
             self.head_dense = None
         self.apply(self._init_weights)
@@ -249,6 +301,18 @@ class SwinTransformer(nn.Module):
         x_grid = Fn.FinalNormFn.apply(x, self.norm.weight, self.norm.bias)
         return Fn.TokenMeanFn.apply(x_grid), x_grid
 
+    def forward_feature_maps_multi(self, xs):
+        """several image batches of different resolution at once -> list of (cls, region); see BasicLayer.forward_multi"""
+        self._draw_drop_path(sum(x.shape[0] for x in xs), xs[0].device)
+        ts = [self.patch_embed(x) for x in xs]
+        for layer in self.layers:
+            ts = layer.forward_multi(ts)
+        outs = []
+        for t in ts:
+            x_grid = Fn.FinalNormFn.apply(t, self.norm.weight, self.norm.bias)
+            outs.append((Fn.TokenMeanFn.apply(x_grid), x_grid))
+        return outs
+
     def forward_features(self, x):
         cls, region = self.forward_feature_maps(x)
         return (cls, region) if self.use_dense_prediction else cls
@@ -270,8 +334,11 @@ class SwinTransformer(nn.Module):
                 start = i
         if self.use_dense_prediction:
             cls_parts, fea_parts, npatch = [], [], []
-            for a, b in bounds:
-                cls, fea = self.forward_feature_maps(torch.cat(x[a:b]))
+            batches = [torch.cat(x[a:b]) for a, b in bounds]
+            # every resolution group through the backbone at once (row-wise kernels see all rows, attention runs per group)
+            maps = self.forward_feature_maps_multi(batches) if (self.ragged_multi_crop and len(batches) > 1) else \
+                [self.forward_feature_maps(xb) for xb in batches]
+            for cls, fea in maps:
                 B, N, C = fea.shape
                 cls_parts.append(cls)
                 fea_parts.append(fea.reshape(B * N, C))

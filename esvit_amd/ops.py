@@ -432,14 +432,16 @@ def dense_to_frag(dense):
     return out
 
 
-def window_attn_fwd(qkv, qkv_bias, win2tok, L, rel_table, ws, region_ids, nW, N, nH, scale, want_attn=False):
+def window_attn_fwd(qkv, qkv_bias, win2tok, L, rel_table, ws, region_ids, nW, N, nH, scale, want_attn=False, out=None):
     """token-ordered qkv [nB*L, 3C] -> (out [nB*L, C], lse or None[, attn]); win2tok int32 [nW*N] slot -> token (-1 = zero-pad slot).
     lse (per-query log-sum-exp) is produced for 14x14 windows, whose blocked backward needs it."""
     qkv = _actc(qkv)
     rows, C3 = qkv.shape
     Cc = C3 // 3
     nB = rows // L
-    out = torch.empty((rows, Cc), dtype=qkv.dtype, device=qkv.device)
+    if out is None:
+        out = torch.empty((rows, Cc), dtype=qkv.dtype, device=qkv.device)
+    assert out.shape == (rows, Cc) and out.dtype == qkv.dtype and out.is_contiguous()  # may be a row slice of a larger matrix
     attn = torch.empty((nB * nW, nH, N, N), dtype=torch.float32, device=qkv.device) if want_attn else None
     nl = lib.esvit_window_attn_lse_elems(N)
     lse = torch.empty((nB * nW * nH, nl), dtype=torch.float32, device=qkv.device) if nl else None
@@ -450,14 +452,15 @@ def window_attn_fwd(qkv, qkv_bias, win2tok, L, rel_table, ws, region_ids, nW, N,
     return (out, lse, attn) if want_attn else (out, lse)
 
 
-def window_attn_bwd(qkv, qkv_bias, win2tok, L, dout, fwd_out, lse, rel_table, ws, region_ids, nW, N, nH, scale):
+def window_attn_bwd(qkv, qkv_bias, win2tok, L, dout, fwd_out, lse, rel_table, ws, region_ids, nW, N, nH, scale, dqkv_out=None):
     """-> (dqkv act [nB*L, 3C], dbias_ws fp32 [parts, nH, frag], dpad_ws fp32 [rows, 2C])."""
     qkv, dout = _actc(qkv), _actc(dout)
     rows, C3 = qkv.shape
     Cc = C3 // 3
     nB = rows // L
     code = _code(qkv.dtype)
-    dqkv = torch.empty_like(qkv)
+    dqkv = torch.empty_like(qkv) if dqkv_out is None else dqkv_out
+    assert dqkv.shape == qkv.shape and dqkv.dtype == qkv.dtype and dqkv.is_contiguous()
     parts = lib.esvit_window_attn_bwd_parts(N, nB * nW, nH)
     dbias_ws = torch.empty((parts, nH, attn_frag_elems(N)), dtype=torch.float32, device=qkv.device)
     pad = torch.zeros((lib.esvit_window_attn_bwd_pad_rows(code, N, nB * nW, nH), 2 * Cc), dtype=torch.float32, device=qkv.device)

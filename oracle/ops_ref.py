@@ -390,7 +390,8 @@ def _attn_core(qkvw, bias_frag, region_ids, nW, N, nH, scale):
     return q, k, v, p
 
 
-def window_attn_fwd(qkv, qkv_bias, win2tok, L, rel_table, ws, region_ids, nW, N, nH, scale, want_attn=False):
+def window_attn_fwd(qkv, qkv_bias, win2tok, L, rel_table, ws, region_ids, nW, N, nH, scale, want_attn=False, out=None):
+    out_arg = out
     bias_frag = relpos_bias_fwd(rel_table, torch.as_tensor(relative_position_index(ws), device=qkv.device), N)
     C = qkv.shape[1] // 3
     qkvw, pad = _to_windows(qkv, _r(qkv_bias, qkv.dtype), win2tok, L, nW, N)
@@ -401,11 +402,15 @@ def window_attn_fwd(qkv, qkv_bias, win2tok, L, rel_table, ws, region_ids, nW, N,
     idx = (torch.arange(nB, device=qkv.device).view(nB, 1) * L + win2tok.long().view(1, -1).clamp(min=0)).reshape(-1)
     out = torch.zeros((qkv.shape[0], C), dtype=torch.float32, device=qkv.device)
     out[idx[~pad]] = ow[~pad]
-    out = _r(out, qkv.dtype)
+    if out_arg is not None:
+        out_arg.copy_(_r(out, qkv.dtype))
+        out = out_arg
+    else:
+        out = _r(out, qkv.dtype)
     return (out, None, p) if want_attn else (out, None)
 
 
-def window_attn_bwd(qkv, qkv_bias, win2tok, L, dout, fwd_out, lse, rel_table, ws, region_ids, nW, N, nH, scale):
+def window_attn_bwd(qkv, qkv_bias, win2tok, L, dout, fwd_out, lse, rel_table, ws, region_ids, nW, N, nH, scale, dqkv_out=None):
     bias_frag = relpos_bias_fwd(rel_table, torch.as_tensor(relative_position_index(ws), device=qkv.device), N)
     C = qkv.shape[1] // 3
     dt = qkv.dtype
@@ -430,6 +435,9 @@ def window_attn_bwd(qkv, qkv_bias, win2tok, L, dout, fwd_out, lse, rel_table, ws
     dpad = dqkvw[pad][:, C:].sum(0, keepdim=True) if pad.any() else torch.zeros((1, 2 * C), device=qkv.device)
     dbias = ds.sum(0)  # [nH, N, N]
     ws = _frag_from_dense(dbias, 0.0).unsqueeze(0)  # parts = 1
+    if dqkv_out is not None:
+        dqkv_out.copy_(_r(dqkv, dt))
+        return dqkv_out, ws, dpad
     return _r(dqkv, dt), ws, dpad
 
 
