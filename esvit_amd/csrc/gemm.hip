@@ -589,6 +589,25 @@ __device__ __forceinline__ void xcd_tile_map(int ntiles, int& tile, int& z) {
     tile = v - z * ntiles;
 }
 
+// Tile id -> (row block, column block).  group_m <= 1: column-fastest.  Otherwise the ids walk down group_m row blocks
+// before moving to the next column block: the ~64 tiles one XCD has in flight then cover group_m row panels x
+// 64/group_m column panels instead of 1 x 64, so a wide B (N/BN >> 8, e.g. the 65536-wide last layer) is not
+// re-streamed from the Infinity Cache once per row block.
+__device__ __forceinline__ void tile_coords(int pid, int tiles_m, int tiles_n, int group_m, int& tm, int& tn) {
+    if (group_m <= 1) {
+        tm = pid / tiles_n;
+        tn = pid - tm * tiles_n;
+        return;
+    }
+    const int gsize = group_m * tiles_n;
+    const int gid = pid / gsize;
+    const int first = gid * group_m;
+    const int rows = min(tiles_m - first, group_m);
+    const int w = pid - gid * gsize;
+    tn = w / rows;
+    tm = first + (w - tn * rows);
+}
+
 template <typename T, bool AKS, bool BKS, int BM, int BN, bool USE_TR>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const esvit_gemm_desc p) {
     using TA = Tile<T, AKS, BM, USE_TR>;
@@ -830,7 +849,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 // NBUF-deep ring of LDS tiles: NBUF-1 tiles are requested ahead; per k-tile ONE counted wait (only for the tile
 // about to be consumed -- later tiles stay in flight across the barrier) and ONE barrier.
 template <bool AKS, bool BKS, int BM, int BN, int BKD, int NBUF>
-__global__ __launch_bounds__(NTHREADS, (BM >= 256 ? 1 : 2)) void gemm_dma_kernel(const esvit_gemm_desc p) {
+__global__ __launch_bounds__(NTHREADS, (BM >= 256 ? 1 : 2)) void gemm_dma_kernel(const esvit_gemm_desc p, const int group_m) {
     using TA = DmaTile<AKS, BM, BKD>;
     using TB = DmaTile<BKS, BN, BKD>;
     constexpr int WTM = BM / 2, WTN = BN / 2;
@@ -847,7 +866,8 @@ __global__ __launch_bounds__(NTHREADS, (BM >= 256 ? 1 : 2)) void gemm_dma_kernel
     const int ntiles = tiles_m * tiles_n;
     int pid, z;
     xcd_tile_map(ntiles, pid, z);
-    const int tm = pid / tiles_n, tn = pid % tiles_n;
+    int tm, tn;
+    tile_coords(pid, tiles_m, tiles_n, group_m, tm, tn);
     const int m0 = tm * BM, n0 = tn * BN;
     const bf16* A = reinterpret_cast<const bf16*>(p.A);
     const bf16* B = reinterpret_cast<const bf16*>(p.B);
@@ -1209,6 +1229,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     else splitk_reduce_block<float>(part2, splits, n2, out2, 0, (long)blockIdx.x - blocks1, sm);
 }
 
+static int g_group_m = -1;  // -1: automatic (see launch_gemm_dma); >= 0 forces the row-block group of tile_coords()
 static int g_xcd_map = 0;  // 0: tiles on grid.x (XCD-remapped), z on grid.y; 1: 1-D grid, XCD-contiguous over (z, tile) -- measured 8% slower on the wgrad family (profiles/r01_gemm_xcdmap_ab.txt)
 
 template <typename T, bool AKS, bool BKS, int BM, int BN, bool USE_TR>
@@ -1261,7 +1282,11 @@ int launch_gemm_dma(const esvit_gemm_desc& d, hipStream_t stream) {
     const int tiles = ceil_div(d.M, BM) * ceil_div(d.N, BN);
     const int nz = d.splitk > 1 ? d.splitk : d.batch;
     dim3 grid = g_xcd_map ? dim3(tiles * nz) : dim3(tiles, nz);
-    hipLaunchKernelGGL(kern, grid, dim3(NTHREADS), lds, stream, d);
+    // grouped tile order only where a row block's column tiles outnumber what one XCD runs at a time
+    // (measured, profiles/r01_gemm_group_m_ab.txt: +5..13 % for 12..64 column tiles, nothing below, noise above)
+    const int tn_ = ceil_div(d.N, BN);
+    const int group_m = g_group_m >= 0 ? g_group_m : (nz == 1 && tn_ >= 12 && tn_ <= 64 ? 16 : 1);
+    hipLaunchKernelGGL(kern, grid, dim3(NTHREADS), lds, stream, d, group_m);
     ESVIT_CHECK_LAUNCH("esvit_gemm(dma)");
     if (d.splitk > 1) {
         const long n = (long)d.M * d.N;
@@ -1406,6 +1431,7 @@ extern "C" void esvit_debug_set_tr_read(int on) { g_use_tr = on; }
 extern "C" void esvit_debug_set_gemm_dma(int on) { g_use_dma = on; }
 extern "C" void esvit_debug_set_gemm_pipe(int mode) { g_dma_pipe = mode; }
 extern "C" void esvit_debug_set_gemm_m64(int on) { g_tile_m64 = on; }
+extern "C" void esvit_debug_set_gemm_group_m(int g) { g_group_m = g; }
 extern "C" void esvit_debug_set_gemm_m256(int on) { g_tile_m256 = on; }
 extern "C" void esvit_debug_set_gemm_xcdmap(int mode) { g_xcd_map = mode; g_ws_zmajor = mode; }
 extern "C" void esvit_debug_set_gemm_ws_ablate(int bits) { g_ws_ablate = bits; }

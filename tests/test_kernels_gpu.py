@@ -94,6 +94,28 @@ def test_gemm_m64_tiles(mods):
         ops.lib.esvit_debug_set_gemm_m64(0)
 
 
+@pytest.mark.parametrize("group_m", [-1, 8, 3])
+def test_gemm_grouped_tile_order(mods, group_m):
+    """tile_coords(): the grouped tile order (automatic for N/BN >= 16) is a permutation of the tiles -- same result,
+    including ragged last groups (rows % group != 0) and ragged edge tiles"""
+    ops, ref = mods
+    dev = _dev()
+    dt = torch.bfloat16
+    ops.lib.esvit_debug_set_gemm_group_m(group_m)
+    try:
+        for M, N, K in ((1500, 2304, 128), (700, 4096, 64), (2700, 2048 + 96, 192)):
+            x, w, b = _rand((M, K), dev, 1, dt), _rand((N, K), dev, 2, dt, 0.1), _rand((N,), dev, 3)
+            _close("grouped nt", ops.linear_fwd(x, w, b), ref.linear_fwd(x, w, b), _tol(dt))
+            y, pre = ops.linear_fwd(x, w, b, gelu=True, want_preact=True)
+            yr, prer = ref.linear_fwd(x, w, b, gelu=True, want_preact=True)
+            _close("grouped nt+gelu", y, yr, _tol(dt))
+            _close("grouped preact", pre, prer, _tol(dt))
+            dy, wd = _rand((M, K), dev, 5, dt), _rand((K, N), dev, 6, dt, 0.1)
+            _close("grouped dgrad", ops.linear_dgrad(dy, wd), ref.linear_dgrad(dy, wd), _tol(dt))
+    finally:
+        ops.lib.esvit_debug_set_gemm_group_m(-1)
+
+
 @pytest.mark.parametrize("tr", [1, 0])
 @pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("M,N,K", [(300, 96, 384), (257, 192, 576), (1000, 2048, 256), (130, 768, 3072), (40000, 192, 96)])

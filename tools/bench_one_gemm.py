@@ -15,6 +15,8 @@ if os.environ.get("GEMM_M256"):
 if os.environ.get("GEMM_DMA"):
     ops.debug_set_gemm_dma(int(os.environ["GEMM_DMA"]))
 ops.lib.esvit_debug_set_gemm_ws_ablate(ablate)
+if os.environ.get("GEMM_GROUP_M"):
+    ops.lib.esvit_debug_set_gemm_group_m(int(os.environ["GEMM_GROUP_M"]))
 bf = torch.bfloat16
 x = torch.randn(M, K, device=dev).to(bf)
 w = (torch.randn(N, K, device=dev) * 0.05).to(bf)
