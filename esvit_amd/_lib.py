@@ -101,6 +101,7 @@ SIGNATURES = {
     "esvit_debug_set_gemm_pipe": (None, [C.c_int]),
     "esvit_debug_set_gemm_m64": (None, [C.c_int]),
     "esvit_debug_set_gemm_group_m": (None, [C.c_int]),
+    "esvit_debug_set_gemm_l2_prefetch": (None, [C.c_int]),
     "esvit_debug_set_gemm_m256": (None, [C.c_int]),
     "esvit_debug_set_attn_bwd_impl": (None, [C.c_int]),
     "esvit_debug_set_attn_fwd_impl": (None, [C.c_int]),

@@ -839,6 +839,29 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, lo
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)capped, 0x00020000);
 }
 
+// the same descriptor as four dwords, for the inline-asm L2 prefetch loads of gemm_dma_kernel
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ i32x4 make_rsrc_words(const void* base, long bytes_left) {
+    const long capped = bytes_left > 0xfffffff0L ? 0xfffffff0L : (bytes_left < 0 ? 0 : bytes_left);
+    const unsigned long b = reinterpret_cast<unsigned long>(base);
+    return i32x4{(int)(unsigned)(b & 0xffffffffUL), (int)(unsigned)((b >> 32) & 0xffffUL), (int)capped, 0x00020000};
+}
+
+// per-thread byte offset (relative to the tile base at k = 0) of the 128-byte line thread `tg` of a 128-thread group
+// touches when it prefetches one k-tile of an operand; -1 for idle threads
+template <bool KS, int ROWS, int BKD>
+__device__ __forceinline__ int prefetch_line_offset(long ld, int tg) {
+    if constexpr (!KS) {
+        static_assert(BKD * 2 <= 128 && ROWS <= 128, "one line per tile row");
+        return tg < ROWS ? (int)((long)tg * ld * 2) : -1;
+    } else {
+        constexpr int LPR = (ROWS * 2 + 127) / 128;  // lines per k-row
+        static_assert(BKD * LPR <= 128, "one line per thread");
+        const int r = tg / LPR, cs = tg - r * LPR;
+        return r < BKD ? (int)(((long)r * ld + cs * 64) * 2) : -1;
+    }
+}
+
 // counted wait: at most N of this wave's LDS-DMA loads still in flight (loads retire in order)
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
@@ -849,7 +872,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 // NBUF-deep ring of LDS tiles: NBUF-1 tiles are requested ahead; per k-tile ONE counted wait (only for the tile
 // about to be consumed -- later tiles stay in flight across the barrier) and ONE barrier.
 template <bool AKS, bool BKS, int BM, int BN, int BKD, int NBUF>
-__global__ __launch_bounds__(NTHREADS, (BM >= 256 ? 1 : 2)) void gemm_dma_kernel(const esvit_gemm_desc p, const int group_m) {
+__global__ __launch_bounds__(NTHREADS, (BM >= 256 ? 1 : 2)) void gemm_dma_kernel(const esvit_gemm_desc p, const int group_m, const int l2_prefetch) {
     using TA = DmaTile<AKS, BM, BKD>;
     using TB = DmaTile<BKS, BN, BKD>;
     constexpr int WTM = BM / 2, WTN = BN / 2;
@@ -922,15 +945,49 @@ __global__ __launch_bounds__(NTHREADS, (BM >= 256 ? 1 : 2)) void gemm_dma_kernel
         if (fullk && rows_ok_b) TB::issue_fast(rb, sB + slot * B_BYTES, p.ldb, k0, wave, voffB);
         else TB::issue(rb, sB + slot * B_BYTES, p.ldb, N - n0, k0, kend, wave, lane);
     };
+    // L2 prefetch (two-buffer ring only).  With one k-tile in flight per workgroup every iteration waits a full memory
+    // round trip for the tile requested one iteration earlier.  Each thread therefore also touches ONE 128-byte line
+    // of k-tile kt+3 per iteration (waves 0-1 the A tile, waves 2-3 the B tile) with a plain buffer load into a
+    // register nobody reads: it pulls the line into the XCD's L2 two iterations before the LDS-DMA of that tile is
+    // issued, so the DMA is an L2 hit.  The load is issued AFTER the iteration's DMA, so the counted wait at the top of
+    // the next iteration (vmcnt(1): everything but the newest load) covers the DMA tile and leaves the prefetch in
+    // flight; in-order retirement gives every prefetch two iterations to land.  Exactly one prefetch instruction per
+    // iteration (out-of-range offset -> returns 0 without a memory access once past the last tile) keeps the count static.
+    constexpr bool PF_OK = NBUF == 2 && BM <= 128 && BN <= 128 && BKD == 64;
+    const bool pf = PF_OK && l2_prefetch;
+    int pf_off = -1, pf_kmul = 0, pf_sink = 0;
+    i32x4 pf_rsrc = i32x4{0, 0, 0, 0x00020000};
+    if constexpr (PF_OK) if (pf) {
+        const int tg = threadIdx.x & 127;
+        if (wave < 2) {
+            pf_off = prefetch_line_offset<AKS, BM, BKD>(p.lda, tg);
+            pf_kmul = AKS ? (int)(p.lda * 2) : 2;
+            pf_rsrc = make_rsrc_words(a_base, a_left);
+        } else {
+            pf_off = prefetch_line_offset<BKS, BN, BKD>(p.ldb, tg);
+            pf_kmul = BKS ? (int)(p.ldb * 2) : 2;
+            pf_rsrc = make_rsrc_words(b_base, b_left);
+        }
+    }
+    auto prefetch_tile = [&](int t) {
+        const int v = (t < nk && pf_off >= 0) ? pf_off + (kbeg + t * BKD) * pf_kmul : (int)0xfffffff8u;
+        asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "+v"(pf_sink) : "v"(v), "s"(pf_rsrc) : "memory");
+    };
 #pragma unroll
     for (int t = 0; t < NBUF - 1; ++t) {
         if (t < nk) issue_tile(t, t);
+    }
+    if (pf) {
+        prefetch_tile(1);
+        prefetch_tile(2);
     }
     int buf = 0;  // ring slot of tile kt
     for (int kt = 0; kt < nk; ++kt) {
         const int ahead = min(nk - 1 - kt, NBUF - 2);  // tiles requested after kt that may stay in flight
         if (NBUF >= 4 && ahead >= 2) wait_vmcnt<2 * L>();
         else if (NBUF >= 3 && ahead >= 1) wait_vmcnt<L>();
+        else if (pf && kt == 0) wait_vmcnt<2>();
+        else if (pf) wait_vmcnt<1>();
         else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();  // tile kt landed for every wave; every wave is done with tile kt-1
         asm volatile("" ::: "memory");
@@ -939,6 +996,7 @@ __global__ __launch_bounds__(NTHREADS, (BM >= 256 ? 1 : 2)) void gemm_dma_kernel
             const int nb = (buf == 0) ? NBUF - 1 : buf - 1;  // the slot tile kt-1 just vacated
             issue_tile(nt, nb);
         }
+        if (pf) prefetch_tile(kt + 3);
         const bf16* a_lds = reinterpret_cast<const bf16*>(sA + buf * A_BYTES);
         const bf16* b_lds = reinterpret_cast<const bf16*>(sB + buf * B_BYTES);
 #pragma unroll
@@ -960,6 +1018,10 @@ __global__ __launch_bounds__(NTHREADS, (BM >= 256 ? 1 : 2)) void gemm_dma_kernel
             }
         }
         buf = (buf + 1 == NBUF) ? 0 : buf + 1;
+    }
+    if (pf) {
+        wait_vmcnt<0>();  // the sink register is free again only when no prefetch is in flight
+        asm volatile("" ::"v"(pf_sink));
     }
     __syncthreads();  // all waves finished reading the operand tiles before the epilogue reuses the LDS
     if constexpr (AKS) {
@@ -1229,6 +1291,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     else splitk_reduce_block<float>(part2, splits, n2, out2, 0, (long)blockIdx.x - blocks1, sm);
 }
 
+static int g_l2_prefetch = 0;  // 1: the LDS-DMA kernel prefetches k-tile kt+3 into the L2 (see gemm_dma_kernel)
 static int g_group_m = -1;  // -1: automatic (see launch_gemm_dma); >= 0 forces the row-block group of tile_coords()
 static int g_xcd_map = 0;  // 0: tiles on grid.x (XCD-remapped), z on grid.y; 1: 1-D grid, XCD-contiguous over (z, tile) -- measured 8% slower on the wgrad family (profiles/r01_gemm_xcdmap_ab.txt)
 
@@ -1286,7 +1349,7 @@ int launch_gemm_dma(const esvit_gemm_desc& d, hipStream_t stream) {
     // (measured, profiles/r01_gemm_group_m_ab.txt: +5..13 % for 12..64 column tiles, nothing below, noise above)
     const int tn_ = ceil_div(d.N, BN);
     const int group_m = g_group_m >= 0 ? g_group_m : (nz == 1 && tn_ >= 12 && tn_ <= 64 ? 16 : 1);
-    hipLaunchKernelGGL(kern, grid, dim3(NTHREADS), lds, stream, d, group_m);
+    hipLaunchKernelGGL(kern, grid, dim3(NTHREADS), lds, stream, d, group_m, g_l2_prefetch);
     ESVIT_CHECK_LAUNCH("esvit_gemm(dma)");
     if (d.splitk > 1) {
         const long n = (long)d.M * d.N;
@@ -1432,6 +1495,7 @@ extern "C" void esvit_debug_set_gemm_dma(int on) { g_use_dma = on; }
 extern "C" void esvit_debug_set_gemm_pipe(int mode) { g_dma_pipe = mode; }
 extern "C" void esvit_debug_set_gemm_m64(int on) { g_tile_m64 = on; }
 extern "C" void esvit_debug_set_gemm_group_m(int g) { g_group_m = g; }
+extern "C" void esvit_debug_set_gemm_l2_prefetch(int on) { g_l2_prefetch = on; }
 extern "C" void esvit_debug_set_gemm_m256(int on) { g_tile_m256 = on; }
 extern "C" void esvit_debug_set_gemm_xcdmap(int mode) { g_xcd_map = mode; g_ws_zmajor = mode; }
 extern "C" void esvit_debug_set_gemm_ws_ablate(int bits) { g_ws_ablate = bits; }

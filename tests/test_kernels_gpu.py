@@ -94,6 +94,35 @@ def test_gemm_m64_tiles(mods):
         ops.lib.esvit_debug_set_gemm_m64(0)
 
 
+def test_gemm_l2_prefetch(mods):
+    """esvit_debug_set_gemm_l2_prefetch(1): the extra line-touching loads of the LDS-DMA loop change no result -- short
+    and ragged K (1, 2, 3 k-tiles, partial last tile), ragged rows, split-K wgrad with the fused bias gradient"""
+    ops, ref = mods
+    dev = _dev()
+    dt = torch.bfloat16
+    ops.lib.esvit_debug_set_gemm_l2_prefetch(1)
+    try:
+        for M, N, K in ((300, 96, 32), (257, 192, 96), (1000, 384, 160), (1300, 1536, 384), (900, 768, 3072), (40000, 192, 96)):
+            x, w, b = _rand((M, K), dev, 1, dt), _rand((N, K), dev, 2, dt, 0.1), _rand((N,), dev, 3)
+            _close("pf nt", ops.linear_fwd(x, w, b), ref.linear_fwd(x, w, b), _tol(dt))
+            y, pre = ops.linear_fwd(x, w, b, gelu=True, want_preact=True)
+            yr, prer = ref.linear_fwd(x, w, b, gelu=True, want_preact=True)
+            _close("pf nt+gelu", y, yr, _tol(dt))
+            _close("pf preact", pre, prer, _tol(dt))
+            res = _rand((M, N), dev, 4)
+            _close("pf nt+res", ops.linear_fwd(x, w, b, residual=res, out_f32=True), ref.linear_fwd(x, w, b, residual=res, out_f32=True),
+                   _tol(dt, bf=5e-3))
+            dy, wd = _rand((M, K), dev, 5, dt), _rand((K, N), dev, 6, dt, 0.1)
+            _close("pf dgrad", ops.linear_dgrad(dy, wd), ref.linear_dgrad(dy, wd), _tol(dt))
+            g = _rand((M, N), dev, 7, dt)
+            dw, db = ops.linear_wgrad(g, x, want_bias=True)
+            dwr, dbr = ref.linear_wgrad(g, x, want_bias=True)
+            _close("pf wgrad", dw, dwr, _tol(dt, bf=2e-2))
+            _close("pf wgrad bias", db, dbr, _tol(dt, bf=2e-2))
+    finally:
+        ops.lib.esvit_debug_set_gemm_l2_prefetch(0)
+
+
 @pytest.mark.parametrize("group_m", [-1, 8, 3])
 def test_gemm_grouped_tile_order(mods, group_m):
     """tile_coords(): the grouped tile order (automatic for N/BN >= 16) is a permutation of the tiles -- same result,
