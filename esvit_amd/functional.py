@@ -281,6 +281,79 @@ class PatchEmbedFn(torch.autograd.Function):
         return None, dW, dbp, dg, db, None
 
 
+class PatchEmbedMultiFn(torch.autograd.Function):
+    """PatchEmbed of several image batches (one per resolution) at once: the im2col images of all groups share one row
+    buffer, so the projection GEMM, its LayerNorm and their backward run once.  Returns fp32 token rows [sum_g nB_g L_g, E]
+    (group-major, then sample, then token -- the layout Fn.swin_block_multi consumes)."""
+
+    @staticmethod
+    def forward(ctx, Wp, bp, g, b, patch, *imgs):
+        o = ops_module()
+        E = Wp.shape[0]
+        Kc = Wp.shape[1] * patch * patch
+        rows = [im.shape[0] * (im.shape[2] // patch) ** 2 for im in imgs]
+        cols = torch.empty((sum(rows), Kc), dtype=o.act_dtype(), device=imgs[0].device)
+        r0 = 0
+        for im, n in zip(imgs, rows):
+            o.patch_im2col(im.contiguous(), patch, Kc, out=cols[r0:r0 + n])
+            r0 += n
+        y = o.linear_fwd(cols, _weight(Wp, (E, Kc)), bp, out_f32=True)
+        x, _, mean, rstd = o.layernorm_fwd(y, g, b, LN_EPS, dtype=torch.float32)
+        ctx.save_for_backward(cols, y, mean, rstd, g)
+        ctx.wshape, ctx.n_img = tuple(Wp.shape), len(imgs)
+        return x
+
+    @staticmethod
+    def backward(ctx, gx):
+        o = ops_module()
+        cols, y, mean, rstd, g = ctx.saved_tensors
+        M, E = y.shape
+        dy, dg, db = o.layernorm_bwd(gx.contiguous().view(M, E), y, mean, rstd, g)
+        dW, dbp = o.linear_wgrad(o.gather_cast(dy, M), cols, want_bias=True)
+        return (dW.view(ctx.wshape), dbp, dg, db, None) + (None,) * ctx.n_img
+
+
+class PatchMergeMultiFn(torch.autograd.Function):
+    """PatchMerging over the token rows of several resolution groups: the 2x2 gather + LayerNorm(4C) runs per group (it
+    depends on the grid) into one shared row buffer; the reduction GEMM, its dgrad and wgrad run once over all rows.
+    X fp32 [M, C], groups: tuple of (row0, nB, H, W) -> fp32 [M/4, 2C] with the groups in the same order."""
+
+    @staticmethod
+    def forward(ctx, X, groups, g, b, Wr):
+        o = ops_module()
+        X = X.contiguous()
+        M, C = X.shape
+        y = torch.empty((M // 4, 4 * C), dtype=o.act_dtype(), device=X.device)
+        mean = torch.empty((M // 4,), dtype=torch.float32, device=X.device)
+        rstd = torch.empty_like(mean)
+        for (r0, nB, H, W) in groups:
+            q0, q1 = r0 // 4, (r0 + nB * H * W) // 4
+            o.merge_ln_fwd(X[r0:r0 + nB * H * W].view(nB, H * W, C), g, b, LN_EPS, H, W, out=(y[q0:q1], mean[q0:q1], rstd[q0:q1]))
+        Wc = _weight(Wr)
+        out = o.linear_fwd(y, Wc, None, out_f32=True)
+        ctx.save_for_backward(X, y, mean, rstd, g, Wc)
+        ctx.groups = groups
+        return out
+
+    @staticmethod
+    def backward(ctx, go):
+        o = ops_module()
+        X, y, mean, rstd, g, Wc = ctx.saved_tensors
+        M, C = X.shape
+        gb = o.gather_cast(go.contiguous(), M // 4)
+        dWr = o.linear_wgrad(gb, y)
+        dy = o.linear_dgrad(gb, Wc)
+        dX = torch.empty_like(X)
+        dg = db = None
+        for (r0, nB, H, W) in ctx.groups:
+            r1 = r0 + nB * H * W
+            q0, q1 = r0 // 4, r1 // 4
+            _, dg_g, db_g = o.merge_ln_bwd(dy[q0:q1], X[r0:r1].view(nB, H * W, C), mean[q0:q1], rstd[q0:q1], g, H, W, dx_out=dX[r0:r1])
+            dg = dg_g.clone() if dg is None else dg.add_(dg_g)
+            db = db_g.clone() if db is None else db.add_(db_g)
+        return dX, None, dg, db, dWr
+
+
 def patch_embed_nonorm(img, Wp, bp, patch):
     raise NotImplementedError("PATCH_NORM False is not on the hot path")
 

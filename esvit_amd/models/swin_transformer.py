@@ -133,6 +133,13 @@ class PatchMerging(nn.Module):
             raise NotImplementedError("odd feature maps are not reachable from 224/96 crops (swin_transformer.py:406-408)")
         return Fn.PatchMergeFn.apply(x, H, W, self.norm.weight, self.norm.bias, self.reduction.weight)
 
+    def forward_ragged(self, X, groups):
+        """X fp32 [M, C] token rows of several resolution groups ((row0, nB, H, W) each) -> ([M/4, 2C], merged groups)"""
+        if any(H % 2 or W % 2 for (_, _, H, W) in groups):
+            raise NotImplementedError("odd feature maps are not reachable from 224/96 crops (swin_transformer.py:406-408)")
+        Y = Fn.PatchMergeMultiFn.apply(X, tuple(groups), self.norm.weight, self.norm.bias, self.reduction.weight)
+        return Y, [(r0 // 4, nB, H // 2, W // 2) for (r0, nB, H, W) in groups]
+
 
 def _sample_offsets(groups):
     off, out = 0, []
@@ -158,17 +165,10 @@ class BasicLayer(nn.Module):
             x, _ = blk(x)
         return self.downsample(x) if self.downsample is not None else x
 
-    def forward_multi(self, xs):
-        """xs: list of fp32 token tensors [nB_g, L_g, C], one per resolution group.  The blocks of this stage run over the
-        concatenated rows of all groups (Fn.swin_block_multi); patch merging stays per group (its gather depends on the grid)."""
-        C = xs[0].shape[-1]
-        groups, r0 = [], 0
-        for x in xs:
-            nB, L, _ = x.shape
-            H = W = int(sqrt(L))
-            groups.append((r0, nB, H, W))
-            r0 += nB * L
-        X = torch.cat([x.reshape(-1, C) for x in xs]) if len(xs) > 1 else xs[0].reshape(-1, C)
+    def forward_ragged(self, X, groups):
+        """X: fp32 token rows [M, C] of several resolution groups, groups: list of (row0, nB, H, W).  The blocks of this
+        stage run over all rows at once (Fn.swin_block_multi: attention per group, everything row-wise in one launch),
+        then the ragged patch merging.  Returns (rows of the next stage, its groups)."""
         rowsample = None
         for blk in self.blocks:
             dp = None
@@ -182,12 +182,9 @@ class BasicLayer(nn.Module):
                                            for (_, nB, H, W), s0 in zip(groups, _sample_offsets(groups))])
                 dp = (pend[0], pend[1], rowsample)
             X = _block_forward_multi(blk, X, groups, dp)
-        outs = []
-        parts = torch.split(X, [nB * H * W for (_, nB, H, W) in groups]) if len(groups) > 1 else (X,)  # backward: one cat
-        for part, (r0, nB, H, W) in zip(parts, groups):
-            x = part.view(nB, H * W, C)
-            outs.append(self.downsample(x) if self.downsample is not None else x)
-        return outs
+        if self.downsample is not None:
+            return self.downsample.forward_ragged(X, groups)
+        return X, groups
 
     def forward_with_features(self, x):
         fea = []
@@ -302,14 +299,28 @@ class SwinTransformer(nn.Module):
         return Fn.TokenMeanFn.apply(x_grid), x_grid
 
     def forward_feature_maps_multi(self, xs):
-        """several image batches of different resolution at once -> list of (cls, region); see BasicLayer.forward_multi"""
+        """several image batches of different resolution at once -> list of (cls, region).  The token rows of all groups
+        travel through the backbone as ONE [M, C] matrix (patch embedding, every block, patch merging and the final norm
+        are launched once over all of them; only attention, the 2x2 merge gather and the token mean see the grids)."""
         self._draw_drop_path(sum(x.shape[0] for x in xs), xs[0].device)
-        ts = [self.patch_embed(x) for x in xs]
+        pe = self.patch_embed
+        if pe.norm is None:
+            raise NotImplementedError("PATCH_NORM False is not on the hot path")
+        P = pe.patch_size[0]
+        X = Fn.PatchEmbedMultiFn.apply(pe.proj.weight, pe.proj.bias, pe.norm.weight, pe.norm.bias, P, *xs)
+        groups, r0 = [], 0
+        for x in xs:
+            nB, G = x.shape[0], x.shape[-1] // P
+            groups.append((r0, nB, G, G))
+            r0 += nB * G * G
         for layer in self.layers:
-            ts = layer.forward_multi(ts)
+            X, groups = layer.forward_ragged(X, groups)
+        C = X.shape[-1]
+        Xn = Fn.FinalNormFn.apply(X, self.norm.weight, self.norm.bias)
+        parts = torch.split(Xn, [nB * H * W for (_, nB, H, W) in groups]) if len(groups) > 1 else (Xn,)
         outs = []
-        for t in ts:
-            x_grid = Fn.FinalNormFn.apply(t, self.norm.weight, self.norm.bias)
+        for part, (_, nB, H, W) in zip(parts, groups):
+            x_grid = part.view(nB, H * W, C)
             outs.append((Fn.TokenMeanFn.apply(x_grid), x_grid))
         return outs
 

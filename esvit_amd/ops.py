@@ -310,25 +310,34 @@ def layernorm_bwd_cast(dy, x, mean, rstd, gamma, *, g_in=None, rowscale=None, ro
     return dx, dxa, gb[0], gb[1]
 
 
-def merge_ln_fwd(x, gamma, beta, eps, H, W, dtype=None):
-    """x fp32 [nB, H*W, C] -> (y act [nB*H/2*W/2, 4C], mean, rstd)."""
+def merge_ln_fwd(x, gamma, beta, eps, H, W, dtype=None, out=None):
+    """x fp32 [nB, H*W, C] -> (y act [nB*H/2*W/2, 4C], mean, rstd).  out: optional preallocated (y, mean, rstd) -- e.g.
+    row slices of buffers shared by several resolution groups."""
     x = _f32c(x)
     nB, L, Cc = x.shape
     assert L == H * W
     rows = nB * (H // 2) * (W // 2)
     dt = dtype or _ACT_DTYPE
-    y = torch.empty((rows, 4 * Cc), dtype=dt, device=x.device)
-    mean = torch.empty((rows,), dtype=torch.float32, device=x.device)
-    rstd = torch.empty_like(mean)
+    if out is not None:
+        y, mean, rstd = out
+        assert y.shape == (rows, 4 * Cc) and y.dtype == dt and y.is_contiguous() and mean.is_contiguous() and rstd.is_contiguous()
+    else:
+        y = torch.empty((rows, 4 * Cc), dtype=dt, device=x.device)
+        mean = torch.empty((rows,), dtype=torch.float32, device=x.device)
+        rstd = torch.empty_like(mean)
     check(lib.esvit_merge_ln_fwd(_code(dt), _p(x), _p(gamma), _p(beta), eps, nB, H, W, Cc, _p(y), _p(mean), _p(rstd), _stream()),
           "merge_ln_fwd")
     return y, mean, rstd
 
 
-def merge_ln_bwd(dy, x, mean, rstd, gamma, H, W):
+def merge_ln_bwd(dy, x, mean, rstd, gamma, H, W, dx_out=None):
     x, dy = _f32c(x), _actc(dy)
     nB, L, Cc = x.shape
-    dx = torch.empty_like(x)
+    if dx_out is not None:
+        assert dx_out.numel() == x.numel() and dx_out.dtype == torch.float32 and dx_out.is_contiguous()
+        dx = dx_out
+    else:
+        dx = torch.empty_like(x)
     gb = torch.empty((2, 4 * Cc), dtype=torch.float32, device=x.device)
     dgamma, dbeta = gb[0], gb[1]
     rows = nB * (H // 2) * (W // 2)
@@ -376,13 +385,17 @@ def transpose_cast(w, dtype=None):
     return out
 
 
-def patch_im2col(img, P, Kpad, dtype=None):
+def patch_im2col(img, P, Kpad, dtype=None, out=None):
     img = _f32c(img)
     nB, ch, S, S2 = img.shape
     assert ch == 3 and S == S2
     dt = dtype or _ACT_DTYPE
     G = S // P
-    cols = torch.empty((nB * G * G, Kpad), dtype=dt, device=img.device)
+    if out is not None:
+        assert out.shape == (nB * G * G, Kpad) and out.dtype == dt and out.is_contiguous()
+        cols = out
+    else:
+        cols = torch.empty((nB * G * G, Kpad), dtype=dt, device=img.device)
     check(lib.esvit_patch_im2col(_code(dt), _p(img), _p(cols), nB, S, P, Kpad, _stream()), "patch_im2col")
     return cols
 

@@ -226,13 +226,16 @@ def _merge_gather(x, H, W):
     return torch.cat([xg[:, 0::2, 0::2], xg[:, 1::2, 0::2], xg[:, 0::2, 1::2], xg[:, 1::2, 1::2]], -1).reshape(-1, 4 * C)
 
 
-def merge_ln_fwd(x, gamma, beta, eps, H, W, dtype=None):
+def merge_ln_fwd(x, gamma, beta, eps, H, W, dtype=None, out=None):
     g = _merge_gather(x.float(), H, W)
     y, _, mean, rstd = layernorm_fwd(g, gamma, beta, eps, dtype=dtype)
+    if out is not None:
+        out[0].copy_(y), out[1].copy_(mean), out[2].copy_(rstd)
+        return out
     return y, mean, rstd
 
 
-def merge_ln_bwd(dy, x, mean, rstd, gamma, H, W):
+def merge_ln_bwd(dy, x, mean, rstd, gamma, H, W, dx_out=None):
     nB, L, C = x.shape
     g = _merge_gather(x.float(), H, W)
     dg, dgamma, dbeta = layernorm_bwd(dy, g, mean, rstd, gamma)
@@ -242,6 +245,9 @@ def merge_ln_bwd(dy, x, mean, rstd, gamma, H, W):
     dx[:, 1::2, 0::2] = dg[..., C:2 * C]
     dx[:, 0::2, 1::2] = dg[..., 2 * C:3 * C]
     dx[:, 1::2, 1::2] = dg[..., 3 * C:]
+    if dx_out is not None:
+        dx_out.view(nB, L, C).copy_(dx.view(nB, L, C))
+        return dx_out, dgamma, dbeta
     return dx.view(nB, L, C), dgamma, dbeta
 
 
@@ -277,13 +283,16 @@ def transpose_cast(w, dtype=None):
     return _r(w.t().contiguous(), dtype)
 
 
-def patch_im2col(img, P, Kpad, dtype=None):
+def patch_im2col(img, P, Kpad, dtype=None, out=None):
     nB, ch, S, _ = img.shape
     G = S // P
     cols = img.view(nB, ch, G, P, G, P).permute(0, 2, 4, 1, 3, 5).reshape(nB * G * G, ch * P * P)
-    out = torch.zeros((nB * G * G, Kpad), dtype=torch.float32, device=img.device)
-    out[:, :ch * P * P] = cols
-    return _r(out, dtype)
+    full = torch.zeros((nB * G * G, Kpad), dtype=torch.float32, device=img.device)
+    full[:, :ch * P * P] = cols
+    if out is not None:
+        out.copy_(_r(full, dtype))
+        return out
+    return _r(full, dtype)
 
 
 def token_mean_fwd(x, dtype=None):

@@ -63,6 +63,32 @@ def run_nano_step(nano, student, teacher, loss_mod, crops, dev="cpu"):
     return s_out, t_out, loss, loss_fn
 
 
+def check_ragged_equals_reference_schedule(loss_mod, dev="cpu", tol=1e-5):
+    """the ragged multi-crop route (all resolution groups as one row matrix) and the reference's schedule (one backbone pass
+    per group, swin_transformer.py:729-751) give the same outputs, loss and parameter gradients"""
+    nano = torch.load(os.path.join(GOLD, "nano_step.pt"), weights_only=False)
+    crops = [c.to(dev) for c in GU.make_crops(2)]
+    res = []
+    for ragged in (True, False):
+        student, teacher = nano_pair()
+        student, teacher = student.to(dev), teacher.to(dev)
+        student.ragged_multi_crop = ragged
+        s_out, _, loss, _ = run_nano_step(nano, student, teacher, loss_mod, crops, dev)
+        res.append((s_out, loss, {n: p.grad.detach().clone() for n, p in student.named_parameters() if p.grad is not None}))
+    (sa, la, ga), (sb, lb, gb) = res
+    for a, b in zip(sa[:3], sb[:3]):
+        assert (a - b).abs().max().item() <= tol * (b.abs().max().item() + 1e-12)
+    assert abs(la.item() - lb.item()) <= tol
+    assert ga.keys() == gb.keys()
+    for n in ga:
+        assert (ga[n] - gb[n]).abs().max().item() <= 20 * tol * (gb[n].abs().max().item() + 1e-12), n
+
+
+def test_ragged_multi_crop_equals_reference_schedule(cpu_ops):
+    import esvit_amd.loss as L
+    check_ragged_equals_reference_schedule(L)
+
+
 def test_state_dict_layout_matches_golden():
     nano = torch.load(os.path.join(GOLD, "nano_step.pt"), weights_only=False)
     m = build_nano()

@@ -7,7 +7,7 @@ import torch
 
 from oracle import esvit_oracle as O
 from tests import golden_utils as GU
-from tests.test_composition_cpu import (build_nano, check_nano14, check_nano_cvt, nano_cvt_pair, nano_pair, run_nano14_step,
+from tests.test_composition_cpu import (build_nano, check_nano14, check_nano_cvt, check_ragged_equals_reference_schedule, nano_cvt_pair, nano_pair, run_nano14_step,
                                         run_nano_cvt_step, run_nano_step)
 from tests.test_oracle_cpu import GOLD, probe_close
 
@@ -92,6 +92,16 @@ def test_nano_fused_update_matches_reference_golden(nano, lib_built):
             probe_close("student_after " + n, p.detach().cpu(), nano["student_after"][n], rtol=2e-4)
         for n, p in teacher.named_parameters():
             probe_close("teacher_after " + n, p.detach().cpu(), nano["teacher_after"][n], rtol=2e-4)
+    finally:
+        _teardown()
+
+
+def test_ragged_multi_crop_equals_reference_schedule_gpu(lib_built):
+    """HIP path, fp32: ragged patch embedding / blocks / patch merging / final norm vs one pass per resolution group"""
+    import esvit_amd.loss as L
+    dev = _setup("fp32")
+    try:
+        check_ragged_equals_reference_schedule(L, dev, tol=2e-5)
     finally:
         _teardown()
 
