@@ -1,0 +1,80 @@
+"""Inference consumers of an EsViT checkpoint: the feature extraction and the weighted k-NN classifier
+of the reference's eval_knn.py, on the HIP path.
+
+``extract_features`` (eval_knn.py:165-190) runs the backbone (``build_model(config, is_teacher=True)`` with
+``NUM_CLASSES 0``: the pooled cls features) batch by batch and gathers features and dataset indices of all ranks into
+rank 0's feature matrix.  ``knn_classifier`` (eval_knn.py:193-232) scores every test feature against ALL train features
+(cosine similarity of L2-normalised rows), keeps the k nearest, and lets them vote with weight exp(similarity / T).  The
+similarity product -- the only heavy step: 50k x 1.28M x C for ImageNet -- is this library's fp32 MFMA GEMM reading the
+train matrix in its stored [N_train, C] layout (no transposed copy); top-k, the one-hot vote and the ranking are
+PyTorch indexing ops with the reference's tie behaviour.
+"""
+import torch
+import torch.distributed as dist
+
+from . import ops
+
+
+def _dist_on():
+    return dist.is_available() and dist.is_initialized()
+
+
+@torch.no_grad()
+def extract_features(model, data_loader, use_cuda=True):
+    """data_loader yields (samples, index) with ``index`` the position in ``data_loader.dataset`` (the reference's
+    ReturnIndexDataset, eval_knn.py:235-238).  Returns the [len(dataset), C] feature matrix on rank 0, None elsewhere."""
+    rank = dist.get_rank() if _dist_on() else 0
+    world = dist.get_world_size() if _dist_on() else 1
+    features = None
+    dev = next(model.parameters()).device  # the reference hard-wires .cuda(); the model's device is the same thing on a GPU box
+    for samples, index in data_loader:
+        samples = samples.to(dev, non_blocking=True)
+        index = index.to(dev, non_blocking=True)
+        feats = model(samples).clone()
+        if rank == 0 and features is None:
+            features = torch.zeros(len(data_loader.dataset), feats.shape[-1])
+            if use_cuda:
+                features = features.to(dev, non_blocking=True)
+        if world > 1:
+            idx_l = [torch.empty_like(index) for _ in range(world)]
+            dist.all_gather(idx_l, index)
+            feat_l = [torch.empty_like(feats) for _ in range(world)]
+            dist.all_gather(feat_l, feats)
+            index_all, feats_all = torch.cat(idx_l), torch.cat(feat_l)
+        else:
+            index_all, feats_all = index, feats
+        if rank == 0:
+            if use_cuda:
+                features.index_copy_(0, index_all, feats_all.float())
+            else:
+                features.index_copy_(0, index_all.cpu(), feats_all.float().cpu())
+    return features
+
+
+@torch.no_grad()
+def knn_classifier(train_features, train_labels, test_features, test_labels, k, T, num_classes=1000, num_chunks=100):
+    """-> (top1 %, top5 %).  Features are L2-normalised fp32 rows ([N_train, C], [N_test, C]) on the GPU.  The test set is
+    scored in ``num_chunks`` chunks exactly as the reference does (eval_knn.py:197-198)."""
+    train_features = train_features.float().contiguous()
+    test_features = test_features.float().contiguous()
+    train_labels, test_labels = train_labels.to(train_features.device), test_labels.to(train_features.device)
+    top1, top5, total = 0.0, 0.0, 0
+    num_test = test_labels.shape[0]
+    per_chunk = max(1, num_test // num_chunks)  # (the reference divides by 100 unguarded and fails below 100 test images)
+    for idx in range(0, num_test, per_chunk):
+        features = test_features[idx:min(idx + per_chunk, num_test)]
+        targets = test_labels[idx:min(idx + per_chunk, num_test)]
+        bs = targets.shape[0]
+        similarity = ops.linear_fwd(features, train_features)  # [bs, N_train] = features @ train^T, fp32 MFMA GEMM
+        distances, indices = similarity.topk(k, largest=True, sorted=True)
+        neighbors = torch.gather(train_labels.view(1, -1).expand(bs, -1), 1, indices)
+        one_hot = torch.zeros(bs * k, num_classes, device=similarity.device)
+        one_hot.scatter_(1, neighbors.view(-1, 1), 1)
+        weights = distances.clone().div_(T).exp_()
+        probs = torch.sum(one_hot.view(bs, -1, num_classes) * weights.view(bs, -1, 1), 1)
+        _, predictions = probs.sort(1, True)
+        correct = predictions.eq(targets.view(-1, 1))
+        top1 += correct.narrow(1, 0, 1).sum().item()
+        top5 += correct.narrow(1, 0, min(5, num_classes)).sum().item()
+        total += bs
+    return top1 * 100.0 / total, top5 * 100.0 / total

@@ -213,6 +213,22 @@ def gen_nano_cvt(ns):
     print("nano_cvt_step.pt: loss", g["ddino_loss"], "npatch", g["npatch"], "params", len(g["param_names"]), "no_grad", g["no_grad"])
 
 
+def gen_knn(ns):
+    """top-1 / top-5 of the reference's knn_classifier on synthetic feature sets (tests/golden_utils.make_knn_set)"""
+    ref_knn = RL.load_knn_classifier()
+    saved = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self  # the reference calls .cuda() on its scratch tensor (eval_knn.py:199)
+    try:
+        out = []
+        for c in GU.KNN_CASES:
+            xtr, ytr, xte, yte = GU.make_knn_set(c["seed"], noise=c["noise"])
+            out.append(tuple(ref_knn(xtr, ytr, xte, yte, c["k"], c["T"], num_classes=10)))
+    finally:
+        torch.Tensor.cuda = saved
+    torch.save({"cases": GU.KNN_CASES, "top": out}, os.path.join(OUT, "knn.pt"))
+    print("knn golden:", out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ns = RL.load()
@@ -225,6 +241,8 @@ def main():
         gen_nano14(ns)
     if not only or "cvt" in only:
         gen_nano_cvt(ns)
+    if not only or "knn" in only:
+        gen_knn(ns)
 
 
 if __name__ == "__main__":

@@ -94,6 +94,17 @@ def load():
     return ns
 
 
+def load_knn_classifier():
+    """the reference's knn_classifier (eval_knn.py:193-232), executed from its source text (importing eval_knn drags in
+    torchvision); its hard-wired .cuda() calls are neutralised by the caller (gen_golden.gen_knn)"""
+    src = open(os.path.join(REF_ROOT, "eval_knn.py")).read()
+    env = {"torch": torch, "nn": nn}
+    for node in ast.parse(src).body:
+        if isinstance(node, ast.FunctionDef) and node.name == "knn_classifier":
+            exec(compile(ast.Module(body=[node], type_ignores=[]), os.path.join(REF_ROOT, "eval_knn.py"), "exec"), env)
+    return env["knn_classifier"]
+
+
 def ensure_single_process_group():
     if not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

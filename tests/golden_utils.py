@@ -47,3 +47,17 @@ def probe(t, n=16):
     stride = max(1, f.numel() // n)
     return dict(shape=tuple(t.shape), sum=f.double().sum().item(), asum=f.double().abs().sum().item(),
                 head=f[:n].clone(), strided=f[::stride][:n].clone())
+
+
+def make_knn_set(seed, n_train=1500, n_test=400, dim=48, classes=10, noise=1.0):
+    """synthetic L2-normalised features: class centres + gaussian noise (deterministic in `seed`)"""
+    g = torch.Generator().manual_seed(seed)
+    centres = torch.randn(classes, dim, generator=g)
+    ytr = torch.randint(0, classes, (n_train,), generator=g)
+    yte = torch.randint(0, classes, (n_test,), generator=g)
+    xtr = torch.nn.functional.normalize(centres[ytr] + noise * torch.randn(n_train, dim, generator=g), dim=1)
+    xte = torch.nn.functional.normalize(centres[yte] + noise * torch.randn(n_test, dim, generator=g), dim=1)
+    return xtr, ytr, xte, yte
+
+
+KNN_CASES = [dict(seed=5, k=10, T=0.07, noise=2.0), dict(seed=6, k=20, T=0.07, noise=3.0), dict(seed=7, k=20, T=0.5, noise=4.0)]

@@ -258,3 +258,55 @@ def test_cvt_eval_mode_matches_reference_golden(cpu_ops):
         probe_close("eval region", region, g["eval_region"], rtol=3e-4)
         feats = student.forward_return_n_last_blocks(crops[2], n=2, depth=list(GU.NANO_CVT["depths"]))
     assert torch.allclose(feats, g["eval_last_blocks"], rtol=3e-4, atol=1e-5)
+
+
+# ---- eval_knn.py consumers ---------------------------------------------------
+class IndexedSet(torch.utils.data.Dataset):
+    """the reference's ReturnIndexDataset (eval_knn.py:235-238): (sample, position in the dataset)"""
+
+    def __init__(self, x):
+        self.x = x
+
+    def __len__(self):
+        return self.x.shape[0]
+
+    def __getitem__(self, i):
+        return self.x[i], i
+
+
+def build_nano_backbone():
+    """build_model(config, is_teacher=True) with NUM_CLASSES 0 as eval_knn.py:102 builds it: forward returns the cls features"""
+    from esvit_amd import models
+    cfg = RL.swin_config(embed_dim=GU.NANO["embed_dim"], depths=GU.NANO["depths"], heads=GU.NANO["heads"], window=GU.NANO["window"])
+    m = models.build_model(cfg, is_teacher=True)
+    GU.fill_state_dict(m.state_dict(), 21)
+    return m.eval()
+
+
+def check_extract_features(dev="cpu", tol=1e-5):
+    from esvit_amd import eval as E
+    model = build_nano_backbone().to(dev)
+    x = torch.randn(10, 3, 64, 64, generator=torch.Generator().manual_seed(3))
+    order = torch.randperm(10, generator=torch.Generator().manual_seed(4)).tolist()
+    loader = torch.utils.data.DataLoader(torch.utils.data.Subset(IndexedSet(x), order), batch_size=4)
+    feats = E.extract_features(model, loader, use_cuda=(dev != "cpu"))
+    with torch.no_grad():
+        want = model(x.to(dev))
+    assert feats.shape == want.shape == (10, model.num_features)
+    assert (feats - want).abs().max().item() <= tol * want.abs().max().item()
+
+
+def test_extract_features_places_rows_by_index(cpu_ops):
+    check_extract_features()
+
+
+def test_knn_classifier_host_logic_matches_reference_golden(cpu_ops, monkeypatch):
+    """esvit_amd.eval.knn_classifier with the GEMM swapped for the CPU restatement: chunking, top-k vote and ranking vs the
+    reference's numbers"""
+    from esvit_amd import eval as E
+    monkeypatch.setattr(E, "ops", cpu_ops)
+    gold = torch.load(os.path.join(GOLD, "knn.pt"), weights_only=False)
+    for c, want in zip(GU.KNN_CASES, gold["top"]):
+        xtr, ytr, xte, yte = GU.make_knn_set(c["seed"], noise=c["noise"])
+        got = E.knn_classifier(xtr, ytr, xte, yte, c["k"], c["T"], num_classes=10)
+        assert got == pytest.approx(want, abs=1e-9), (c, got, want)

@@ -103,7 +103,40 @@ def _syncbn_worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("worker,port", [(_reducer_worker, 29611), (_center_worker, 29612), (_syncbn_worker, 29613)])
+def _extract_worker(rank, world, port, out):
+    """eval_knn.py:165-190 over two ranks: each rank runs its share of the batches, rank 0 ends up with every row at its
+    dataset index"""
+    _init(rank, world, port)
+    import esvit_amd.functional as Fn
+    import esvit_amd.params as P
+    from esvit_amd import eval as E
+    from oracle import ops_ref
+    from tests.test_composition_cpu import IndexedSet, build_nano_backbone
+    Fn.ops = ops_ref
+    P.ops = ops_ref
+    ops_ref.set_act_dtype(torch.float32)
+    model = build_nano_backbone()
+    x = torch.randn(12, 3, 64, 64, generator=torch.Generator().manual_seed(3))
+    mine = list(range(rank, 12, world))  # DistributedSampler-style interleaving
+    loader = torch.utils.data.DataLoader(torch.utils.data.Subset(IndexedSet(x), mine), batch_size=3)
+    full = torch.utils.data.DataLoader(IndexedSet(x), batch_size=3)
+
+    class Both:  # len(dataset) must be the FULL set (eval_knn.py:175), batches are this rank's share
+        dataset = full.dataset
+
+        def __iter__(self):
+            return iter(loader)
+    feats = E.extract_features(model, Both(), use_cuda=False)
+    if rank == 0:
+        with torch.no_grad():
+            want = model(x)
+        out[rank] = bool(feats.shape == want.shape and torch.allclose(feats, want, rtol=1e-5, atol=1e-6))
+    else:
+        out[rank] = feats is None
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("worker,port", [(_reducer_worker, 29611), (_center_worker, 29612), (_syncbn_worker, 29613), (_extract_worker, 29614)])
 def test_world2_gloo(worker, port, lib_built):
     world = 2
     out = mp.Manager().dict()

@@ -184,3 +184,13 @@ def test_oracle_step_matches_reference_golden(nano):
     with torch.no_grad():
         _, _, attns = O.swin_features(sd, crops[0], GU.NANO, return_attn=True)
         probe_close("last_attn", attns[-1], nano["last_attn"])
+
+
+def test_oracle_knn_matches_reference_golden():
+    """oracle.knn_classifier vs the reference's own knn_classifier (eval_knn.py:193-232) on the committed synthetic sets"""
+    gold = torch.load(os.path.join(GOLD, "knn.pt"), weights_only=False)
+    assert gold["cases"] == GU.KNN_CASES
+    for c, want in zip(GU.KNN_CASES, gold["top"]):
+        xtr, ytr, xte, yte = GU.make_knn_set(c["seed"], noise=c["noise"])
+        got = O.knn_classifier(xtr, ytr, xte, yte, c["k"], c["T"], num_classes=10)
+        assert got == pytest.approx(want, abs=1e-9), (c, got, want)

@@ -226,3 +226,24 @@ def test_nano_cvt_eval_matches_reference_golden(lib_built):
         assert torch.allclose(feats.cpu(), g["eval_last_blocks"], rtol=5e-4, atol=2e-5)
     finally:
         _teardown()
+
+
+def test_eval_knn_consumers_gpu(lib_built):
+    """SURVEY.md 8f-1 on the HIP path: extract_features through the backbone kernels, knn_classifier through the fp32 MFMA GEMM,
+    against the reference's golden top-1 / top-5 and the CPU oracle on a larger set"""
+    from esvit_amd import eval as E
+    from tests.test_composition_cpu import check_extract_features
+    dev = _setup("fp32")
+    try:
+        check_extract_features(dev, tol=2e-5)
+        gold = torch.load(os.path.join(GOLD, "knn.pt"), weights_only=False)
+        for c, want in zip(GU.KNN_CASES, gold["top"]):
+            xtr, ytr, xte, yte = GU.make_knn_set(c["seed"], noise=c["noise"])
+            got = E.knn_classifier(xtr.to(dev), ytr.to(dev), xte.to(dev), yte.to(dev), c["k"], c["T"], num_classes=10)
+            assert got == pytest.approx(want, abs=0.26), (c, got, want)  # one borderline neighbour of 400 may flip under MFMA summation order
+        xtr, ytr, xte, yte = GU.make_knn_set(11, n_train=20000, n_test=3000, dim=384, classes=100, noise=6.0)
+        want = O.knn_classifier(xtr, ytr, xte, yte, 20, 0.07, num_classes=100)
+        got = E.knn_classifier(xtr.to(dev), ytr.to(dev), xte.to(dev), yte.to(dev), 20, 0.07, num_classes=100)
+        assert got == pytest.approx(want, abs=0.1), (got, want)
+    finally:
+        _teardown()
