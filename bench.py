@@ -196,7 +196,8 @@ def main():
     from tests import golden_utils as GU
     esvit_amd.set_precision("bf16")
     for var, setter in (("ESVIT_GEMM_XCDMAP", "esvit_debug_set_gemm_xcdmap"), ("ESVIT_GEMM_PIPE", "esvit_debug_set_gemm_pipe"),
-                        ("ESVIT_GEMM_GROUP_M", "esvit_debug_set_gemm_group_m"), ("ESVIT_GEMM_PF", "esvit_debug_set_gemm_l2_prefetch")):
+                        ("ESVIT_GEMM_GROUP_M", "esvit_debug_set_gemm_group_m"), ("ESVIT_GEMM_PF", "esvit_debug_set_gemm_l2_prefetch"),
+                        ("ESVIT_GEMM_STAGGER", "esvit_debug_set_gemm_stagger")):
         if os.environ.get(var):  # kernel A/B switches for profiling runs; defaults are the shipped configuration
             getattr(ops.lib, setter)(int(os.environ[var]))
     torch.manual_seed(0)

@@ -102,6 +102,7 @@ SIGNATURES = {
     "esvit_debug_set_gemm_m64": (None, [C.c_int]),
     "esvit_debug_set_gemm_group_m": (None, [C.c_int]),
     "esvit_debug_set_gemm_l2_prefetch": (None, [C.c_int]),
+    "esvit_debug_set_gemm_stagger": (None, [C.c_int]),
     "esvit_debug_set_gemm_m256": (None, [C.c_int]),
     "esvit_debug_set_attn_bwd_impl": (None, [C.c_int]),
     "esvit_debug_set_attn_fwd_impl": (None, [C.c_int]),
@@ -113,10 +114,15 @@ SIGNATURES = {
 
 def _open():
     lib = C.CDLL(LIB_PATH)
-    for name, (res, args) in SIGNATURES.items():
-        fn = getattr(lib, name)  # AttributeError if the symbol is missing
-        fn.restype = res
-        fn.argtypes = args
+    try:
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError if the symbol is missing
+            fn.restype = res
+            fn.argtypes = args
+    except AttributeError:
+        import _ctypes
+        _ctypes.dlclose(lib._handle)  # a stale build: unload it, or the rebuilt file would resolve to this mapping again
+        raise
     return lib
 
 

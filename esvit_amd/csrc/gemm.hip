@@ -872,12 +872,26 @@ __device__ __forceinline__ void wait_vmcnt() {
 // NBUF-deep ring of LDS tiles: NBUF-1 tiles are requested ahead; per k-tile ONE counted wait (only for the tile
 // about to be consumed -- later tiles stay in flight across the barrier) and ONE barrier.
 template <bool AKS, bool BKS, int BM, int BN, int BKD, int NBUF>
-__global__ __launch_bounds__(NTHREADS, (BM >= 256 ? 1 : 2)) void gemm_dma_kernel(const esvit_gemm_desc p, const int group_m, const int l2_prefetch) {
+__global__ __launch_bounds__(NTHREADS, (BM >= 256 ? 1 : 2)) void gemm_dma_kernel(const esvit_gemm_desc p, const int group_m, const int l2_prefetch, const int stagger) {
     using TA = DmaTile<AKS, BM, BKD>;
     using TB = DmaTile<BKS, BN, BKD>;
     constexpr int WTM = BM / 2, WTN = BN / 2;
     constexpr int FM = WTM / 16, FN = WTN / 16;
     constexpr int L = TA::INSTR_PER_WAVE + TB::INSTR_PER_WAVE;  // DMA instructions per wave per tile
+    // Phase stagger.  Every tile of a launch costs the same, so the two workgroups that share a CU run their main loops
+    // together (MFMA contended, HBM idle) and then their epilogues together (HBM write path contended, MFMA idle), and
+    // refills keep that lock-step for the whole launch.  Delaying the second workgroup of each CU in the FIRST round by
+    // about half a tile puts one's epilogue under the other's main loop; later rounds inherit the offset.
+    if (stagger > 0) {
+        const int lin = blockIdx.x + blockIdx.y * gridDim.x;
+        const int slot = lin >> 3;  // position among the workgroups of this XCD
+        const bool second = (stagger & (1 << 30)) ? (slot < 64 && (slot & 1)) : (slot >= 32 && slot < 64);
+        if (second) {
+            const long t0 = __builtin_amdgcn_s_memtime();
+            const long want = stagger & 0xfffffff;
+            while ((long)__builtin_amdgcn_s_memtime() - t0 < want) __builtin_amdgcn_s_sleep(16);
+        }
+    }
     static_assert(NBUF >= 2 && NBUF <= 4, "ring depth");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr int A_BYTES = TA::ELEMS * 2, B_BYTES = TB::ELEMS * 2;
@@ -1291,6 +1305,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     else splitk_reduce_block<float>(part2, splits, n2, out2, 0, (long)blockIdx.x - blocks1, sm);
 }
 
+static int g_stagger = 0;      // shader cycles the second workgroup of each CU waits in the first round (bit 30: odd slots instead of slots 32..63)
 static int g_l2_prefetch = 0;  // 1: the LDS-DMA kernel prefetches k-tile kt+3 into the L2 (see gemm_dma_kernel)
 static int g_group_m = -1;  // -1: automatic (see launch_gemm_dma); >= 0 forces the row-block group of tile_coords()
 static int g_xcd_map = 0;  // 0: tiles on grid.x (XCD-remapped), z on grid.y; 1: 1-D grid, XCD-contiguous over (z, tile) -- measured 8% slower on the wgrad family (profiles/r01_gemm_xcdmap_ab.txt)
@@ -1349,7 +1364,7 @@ int launch_gemm_dma(const esvit_gemm_desc& d, hipStream_t stream) {
     // (measured, profiles/r01_gemm_group_m_ab.txt: +5..13 % for 12..64 column tiles, nothing below, noise above)
     const int tn_ = ceil_div(d.N, BN);
     const int group_m = g_group_m >= 0 ? g_group_m : (nz == 1 && tn_ >= 12 && tn_ <= 64 ? 16 : 1);
-    hipLaunchKernelGGL(kern, grid, dim3(NTHREADS), lds, stream, d, group_m, g_l2_prefetch);
+    hipLaunchKernelGGL(kern, grid, dim3(NTHREADS), lds, stream, d, group_m, g_l2_prefetch, tiles * nz > 512 ? g_stagger : 0);
     ESVIT_CHECK_LAUNCH("esvit_gemm(dma)");
     if (d.splitk > 1) {
         const long n = (long)d.M * d.N;
@@ -1496,6 +1511,7 @@ extern "C" void esvit_debug_set_gemm_pipe(int mode) { g_dma_pipe = mode; }
 extern "C" void esvit_debug_set_gemm_m64(int on) { g_tile_m64 = on; }
 extern "C" void esvit_debug_set_gemm_group_m(int g) { g_group_m = g; }
 extern "C" void esvit_debug_set_gemm_l2_prefetch(int on) { g_l2_prefetch = on; }
+extern "C" void esvit_debug_set_gemm_stagger(int cycles) { g_stagger = cycles; }
 extern "C" void esvit_debug_set_gemm_m256(int on) { g_tile_m256 = on; }
 extern "C" void esvit_debug_set_gemm_xcdmap(int mode) { g_xcd_map = mode; g_ws_zmajor = mode; }
 extern "C" void esvit_debug_set_gemm_ws_ablate(int bits) { g_ws_ablate = bits; }

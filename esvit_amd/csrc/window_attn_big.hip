@@ -70,30 +70,69 @@ __device__ __forceinline__ void load_window_tables(const BigTables& tb, const in
     }
 }
 
-// stage `nrows` window slots (first slot s0) of a token-ordered matrix into a [nrows][LDQ] image; `nthr` threads cooperate
-template <typename T>
-__device__ __forceinline__ void stage_slots(const T* __restrict__ g, long row_stride, const int* tok_lds, long tok_base, int s0, int nrows,
-                                            int N, float scale, const float* __restrict__ pad, T* lds, int tid, int nthr) {
-    constexpr int VEC = BigCfg<T>::VEC, LDQ = BigCfg<T>::LDQ, VPR = HD / VEC;
-    for (int v = tid; v < nrows * VPR; v += nthr) {
-        const int rl = v / VPR, dv = v % VPR;
-        const int t = s0 + rl;
-        Vec16<T> x = zero16<T>();
-        if (t < N) {
-            const int tok = tok_lds[t];
-            if (tok >= 0) {
-                x = ld16<T>(g + (tok_base + tok) * row_stride + dv * VEC);
-            } else if (pad) {
+// stage NROWS window slots (first slot s0) of a token-ordered matrix into a [NROWS][LDQ] image; NTHR threads cooperate.
+// Two phases: every global load of the thread is issued before the first LDS store, so a thread waits ONE memory round
+// trip per call instead of one per 16-byte piece (the first version looped load -> store and paid 4-7 serial round trips
+// per (window, head) with one wave per SIMD to hide them).
+template <typename T, int NROWS, int NTHR>
+struct SlotStage {
+    static constexpr int VEC = BigCfg<T>::VEC, LDQ = BigCfg<T>::LDQ, VPR = HD / VEC;
+    static constexpr int ITERS = (NROWS * VPR + NTHR - 1) / NTHR;
+    Vec16<T> x[ITERS];
+
+    __device__ __forceinline__ void load(const T* __restrict__ g, long row_stride, const int* tok_lds, long tok_base, int s0, int N,
+                                         const float* __restrict__ pad, int tid) {
 #pragma unroll
-                for (int e = 0; e < Vec16<T>::N; ++e) x.set(e, pad[dv * VEC + e]);
+        for (int it = 0; it < ITERS; ++it) {
+            const int v = tid + it * NTHR;
+            const int rl = v / VPR, dv = v % VPR;
+            const int t = s0 + rl;
+            x[it] = zero16<T>();
+            if (v < NROWS * VPR && t < N) {
+                const int tok = tok_lds[t];
+                if (tok >= 0) {
+                    x[it] = ld16<T>(g + (tok_base + tok) * row_stride + dv * VEC);
+                } else if (pad) {
+#pragma unroll
+                    for (int e = 0; e < Vec16<T>::N; ++e) x[it].set(e, pad[dv * VEC + e]);
+                }
             }
         }
-        if (scale != 1.f) {
-#pragma unroll
-            for (int e = 0; e < Vec16<T>::N; ++e) x.set(e, x.get(e) * scale);
-        }
-        st16<T>(lds + rl * LDQ + dv * VEC, x);
     }
+    __device__ __forceinline__ void store(T* lds, float scale, int tid) {
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            const int v = tid + it * NTHR;
+            if (v >= NROWS * VPR) continue;
+            const int rl = v / VPR, dv = v % VPR;
+            Vec16<T> y = x[it];
+            if (scale != 1.f) {
+#pragma unroll
+                for (int e = 0; e < Vec16<T>::N; ++e) y.set(e, y.get(e) * scale);
+            }
+            st16<T>(lds + rl * LDQ + dv * VEC, y);
+        }
+    }
+};
+
+template <typename T, int NROWS, int NTHR>
+__device__ __forceinline__ void stage_slots(const T* __restrict__ g, long row_stride, const int* tok_lds, long tok_base, int s0, int N,
+                                            float scale, const float* __restrict__ pad, T* lds, int tid) {
+    SlotStage<T, NROWS, NTHR> st;
+    st.load(g, row_stride, tok_lds, tok_base, s0, N, pad, tid);
+    st.store(lds, scale, tid);
+}
+
+// two matrices at once (K and V, Q and dO): both sets of loads are in flight before either image is written
+template <typename T, int NROWS, int NTHR>
+__device__ __forceinline__ void stage_slots2(const T* __restrict__ ga, long stride_a, float scale_a, const float* __restrict__ pad_a, T* lds_a,
+                                             const T* __restrict__ gb, long stride_b, float scale_b, const float* __restrict__ pad_b, T* lds_b,
+                                             const int* tok_lds, long tok_base, int s0, int N, int tid) {
+    SlotStage<T, NROWS, NTHR> sa, sb;
+    sa.load(ga, stride_a, tok_lds, tok_base, s0, N, pad_a, tid);
+    sb.load(gb, stride_b, tok_lds, tok_base, s0, N, pad_b, tid);
+    sa.store(lds_a, scale_a, tid);
+    sb.store(lds_b, scale_b, tid);
 }
 
 template <typename T>
@@ -224,8 +263,8 @@ __global__ __launch_bounds__(BigCfg<T>::WAVES * 64) void attn_big_fwd_kernel(
     load_window_tables(tb, win2tok, region_ids, bw % nW, N, ws, true);
     const float* bias_h = bias_frag + (long)h * (NT * NT * 256);
     __syncthreads();
-    stage_slots<T>(src + C, 3L * C, tb.tok, tok_base, 0, NPB, N, 1.f, qkv_bias + C + h * HD, Ks, threadIdx.x, WAVES * 64);
-    stage_slots<T>(src + 2 * C, 3L * C, tb.tok, tok_base, 0, NPB, N, 1.f, qkv_bias + 2 * C + h * HD, Vs, threadIdx.x, WAVES * 64);
+    stage_slots2<T, NPB, WAVES * 64>(src + C, 3L * C, 1.f, qkv_bias + C + h * HD, Ks, src + 2 * C, 3L * C, 1.f, qkv_bias + 2 * C + h * HD, Vs,
+                                     tb.tok, tok_base, 0, N, threadIdx.x);
 
     for (int pass = 0; pass < (NQB + WAVES - 1) / WAVES; ++pass) {
         const int qb = wave + pass * WAVES;
@@ -233,7 +272,7 @@ __global__ __launch_bounds__(BigCfg<T>::WAVES * 64) void attn_big_fwd_kernel(
         const int q0 = valid ? 32 * qb : 0;
         if (pass == 0) __syncthreads();  // K, V staged by the whole workgroup; Qs / Ps below are private to the wave
         __builtin_amdgcn_wave_barrier();
-        stage_slots<T>(src, 3L * C, tb.tok, tok_base, q0, 32, N, scale, qkv_bias + h * HD, Qs, lane, 64);
+        stage_slots<T, 32, 64>(src, 3L * C, tb.tok, tok_base, q0, N, scale, qkv_bias + h * HD, Qs, lane);
         __builtin_amdgcn_wave_barrier();
 
         f32x4 p[NT][2];
@@ -319,7 +358,7 @@ __global__ __launch_bounds__(BigCfg<T>::WAVES * 64) void attn_big_fwd_kernel(
 // group `grp` owns query block qb = grp * WAVES + wave for every window bw = part + k * parts.
 // -------------------------------------------------------------------------------------------------------------
 template <typename T, bool USE_TR>
-__global__ __launch_bounds__(BigCfg<T>::WAVES * 64) void attn_big_bwd_dq_kernel(
+__global__ __launch_bounds__(BigCfg<T>::WAVES * 64, 1) void attn_big_bwd_dq_kernel(
     const T* __restrict__ qkv, const float* __restrict__ qkv_bias, const int* __restrict__ win2tok, int L, const T* __restrict__ dout,
     const float* __restrict__ bias_frag, int rel_rows, int ws, const int* __restrict__ region_ids, int nW, int Bw, int N, int nH,
     float scale, int parts, T* __restrict__ dqkv, float* __restrict__ dbias_ws) {
@@ -364,10 +403,18 @@ __global__ __launch_bounds__(BigCfg<T>::WAVES * 64) void attn_big_bwd_dq_kernel(
         __syncthreads();  // previous window's reads are complete
         load_window_tables(tb, win2tok, region_ids, bwc % nW, N, ws, win_ok);
         __syncthreads();
-        stage_slots<T>(src + C, 3L * C, tb.tok, tok_base, 0, NPB, N, 1.f, qkv_bias + C + h * HD, Ks, threadIdx.x, WAVES * 64);
-        stage_slots<T>(src + 2 * C, 3L * C, tb.tok, tok_base, 0, NPB, N, 1.f, qkv_bias + 2 * C + h * HD, Vs, threadIdx.x, WAVES * 64);
-        stage_slots<T>(src, 3L * C, tb.tok, tok_base, q0, 32, N, scale, qkv_bias + h * HD, Qs, lane, 64);
-        stage_slots<T>(dout + h * HD, (long)C, tb.tok, tok_base, q0, 32, N, 1.f, nullptr, Os, lane, 64);
+        {
+            SlotStage<T, NPB, WAVES * 64> sk, sv;
+            SlotStage<T, 32, 64> sq, so;
+            sk.load(src + C, 3L * C, tb.tok, tok_base, 0, N, qkv_bias + C + h * HD, threadIdx.x);
+            sv.load(src + 2 * C, 3L * C, tb.tok, tok_base, 0, N, qkv_bias + 2 * C + h * HD, threadIdx.x);
+            sq.load(src, 3L * C, tb.tok, tok_base, q0, N, qkv_bias + h * HD, lane);
+            so.load(dout + h * HD, (long)C, tb.tok, tok_base, q0, N, nullptr, lane);
+            sk.store(Ks, 1.f, threadIdx.x);
+            sv.store(Vs, 1.f, threadIdx.x);
+            sq.store(Qs, scale, lane);
+            so.store(Os, 1.f, lane);
+        }
         __syncthreads();
 
         // P^T strip (softmax over all keys: the wave holds every key of its 32 queries)
@@ -493,8 +540,8 @@ __global__ __launch_bounds__(BigCfg<T>::WAVES * 64) void attn_big_bwd_dkv_kernel
     load_window_tables(tb, win2tok, region_ids, bw % nW, N, ws, true);
     const float* bias_h = bias_frag + (long)h * (NT * NT * 256);
     __syncthreads();
-    stage_slots<T>(src, 3L * C, tb.tok, tok_base, 0, NPB, N, scale, qkv_bias + h * HD, Qs, threadIdx.x, WAVES * 64);
-    stage_slots<T>(dout + h * HD, (long)C, tb.tok, tok_base, 0, NPB, N, 1.f, nullptr, Os, threadIdx.x, WAVES * 64);
+    stage_slots2<T, NPB, WAVES * 64>(src, 3L * C, scale, qkv_bias + h * HD, Qs, dout + h * HD, (long)C, 1.f, nullptr, Os, tb.tok, tok_base, 0, N,
+                                     threadIdx.x);
     // per-query statistics: saved log-sum-exp and delta = sum_d dO[q,d] * O[q,d]
     for (int t = threadIdx.x; t < NPB; t += WAVES * 64) {
         float l = 0.f, d = 0.f;
@@ -525,8 +572,8 @@ __global__ __launch_bounds__(BigCfg<T>::WAVES * 64) void attn_big_bwd_dkv_kernel
         const int k0 = valid ? 32 * kb : 0;
         if (pass == 0) __syncthreads();  // Q, dO, lse, delta staged by the whole workgroup; Kb / Vb / Pq are private to the wave
         __builtin_amdgcn_wave_barrier();
-        stage_slots<T>(src + C, 3L * C, tb.tok, tok_base, k0, 32, N, 1.f, qkv_bias + C + h * HD, Kb, lane, 64);
-        stage_slots<T>(src + 2 * C, 3L * C, tb.tok, tok_base, k0, 32, N, 1.f, qkv_bias + 2 * C + h * HD, Vb, lane, 64);
+        stage_slots2<T, 32, 64>(src + C, 3L * C, 1.f, qkv_bias + C + h * HD, Kb, src + 2 * C, 3L * C, 1.f, qkv_bias + 2 * C + h * HD, Vb, tb.tok,
+                                tok_base, k0, N, lane);
         __builtin_amdgcn_wave_barrier();
 
         // P^T block: rows = this block's 32 keys (2 tiles), columns = all queries (14 tiles)

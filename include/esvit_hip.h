@@ -318,6 +318,7 @@ void esvit_debug_set_gemm_m256(int on);   /* 1: 256 x 128 x BK32 tiles for large
 void esvit_debug_set_gemm_m64(int on);    /* 1: 64-row tiles where 128-row tiles quantise badly over the resident workgroups (default 0: measured slower) */
 void esvit_debug_set_gemm_group_m(int g); /* -1 (default): grouped tile order (8 row blocks per group) where N/BN >= 16; >= 0 forces the group size (0/1 = column-fastest) */
 void esvit_debug_set_gemm_l2_prefetch(int on); /* 1: LDS-DMA GEMM also touches one line per thread of k-tile kt+3 (L2 prefetch) */
+void esvit_debug_set_gemm_stagger(int cycles); /* first-round delay (shader cycles) of the second workgroup per CU; bit 30 selects odd slots */
 void esvit_debug_set_gemm_pipe(int mode);  /* LDS-DMA pipeline: 1 = BK64 x 2 buffers, 3 = BK64 x 3-deep ring, 4 = BK32 x 4-deep ring */
 
 #ifdef __cplusplus

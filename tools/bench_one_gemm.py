@@ -15,6 +15,8 @@ if os.environ.get("GEMM_M256"):
 if os.environ.get("GEMM_DMA"):
     ops.debug_set_gemm_dma(int(os.environ["GEMM_DMA"]))
 ops.lib.esvit_debug_set_gemm_ws_ablate(ablate)
+if os.environ.get("GEMM_STAGGER"):
+    ops.lib.esvit_debug_set_gemm_stagger(int(os.environ["GEMM_STAGGER"]))
 if os.environ.get("GEMM_PF"):
     ops.lib.esvit_debug_set_gemm_l2_prefetch(int(os.environ["GEMM_PF"]))
 if os.environ.get("GEMM_GROUP_M"):
