@@ -106,6 +106,7 @@ SIGNATURES = {
     "esvit_debug_set_gemm_m256": (None, [C.c_int]),
     "esvit_debug_set_attn_bwd_impl": (None, [C.c_int]),
     "esvit_debug_set_attn_fwd_impl": (None, [C.c_int]),
+    "esvit_debug_set_big_attn_impl": (None, [C.c_int, C.c_int]),
     "esvit_debug_gemm_ws_occupancy": (C.c_int, [C.c_int]),
     "esvit_debug_set_gemm_ws_ablate": (None, [C.c_int]),
     "esvit_debug_set_gemm_xcdmap": (None, [C.c_int]),

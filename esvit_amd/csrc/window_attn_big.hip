@@ -151,11 +151,16 @@ __device__ __forceinline__ void store_frag4(T* p, f32x4 v) {
 __global__ void relpos_bias_frag_big_kernel(const float* __restrict__ table, int ws, int N, int nH, float* __restrict__ out) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const int FE = NT * NT * 256;
-    if (i >= (long)nH * FE) return;
-    const int h = (int)(i / FE), e = (int)(i % FE);
+    if (i >= 2L * nH * FE) return;
+    const bool tr = i >= (long)nH * FE;  // second half: score tiles with rows = queries (the dK/dV kernel), see below
+    const long i2 = tr ? i - (long)nH * FE : i;
+    const int h = (int)(i2 / FE), e = (int)(i2 % FE);
     const int r = e & 3, lane = (e >> 2) & 63, f = e >> 8;
     const int c = lane & 15, g = lane >> 4;
-    const int q = 16 * (f % NT) + c, key = 16 * (f / NT) + 4 * g + r;
+    // first half:  tile f = ki*NT + qj holds S^T: row = key 16ki + 4g + r, column = query 16qj + c
+    // second half: tile f = qj*NT + ki holds S:   row = query 16qj + 4g + r, column = key 16ki + c
+    const int q = tr ? 16 * (f / NT) + 4 * g + r : 16 * (f % NT) + c;
+    const int key = tr ? 16 * (f % NT) + c : 16 * (f / NT) + 4 * g + r;
     float v = 0.f;
     if (key >= N) v = -1.0e30f;
     else if (q < N) {
@@ -345,6 +350,199 @@ __global__ __launch_bounds__(BigCfg<T>::WAVES * 64) void attn_big_fwd_kernel(
 #pragma unroll
             for (int a = 0; a < 2; ++a) {
                 const Frag<T> pf = frag_kc<T>(Ps, LDP, 16 * a, 32 * ks, c, g);
+                mma(pf, v0, o[a][0]);
+                mma(pf, v1, o[a][1]);
+            }
+        }
+        store_block_rows_vec<T>(o, 1.f, Qs, out + h * HD, (long)C, tb.tok, tok_base, q0, N, valid, nullptr, lane, c, g);
+    }
+}
+
+// -------------------------------------------------------------------------------------------------------------
+// forward, second generation (default).  Same mathematics; what changed is where the data waits:
+//   * P never goes through LDS.  The S^T tiles leave lane (c, g) with, for query c, the keys 16i + 4g + r -- for a 32-key
+//     chunk that is 8 keys {32ks + 4g + e, 32ks + 16 + 4g + e}.  An MFMA only needs A and B to agree on which key sits in
+//     which k-slot, so those 8 values ARE the A fragment of P V if V's B fragment is read with the same key permutation
+//     (frag_v_perm: two transpose reads 16 key rows apart).  That removes 56 LDS stores + 14 LDS fragment reads + a wave
+//     barrier per query block and, more importantly, the 59 KB of per-wave P images: the workgroup needs 53 KB instead of
+//     112 KB, so two (bf16) workgroups share a CU and one's softmax overlaps the other's MFMAs and loads.
+//   * K, V and the first Q block are requested together (one round trip), the Q block of the second pass is requested
+//     before the first pass computes, and the shift-mask labels of the keys are packed into 14 registers once per window
+//     instead of being re-read from LDS for every score tile.
+// -------------------------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ Frag<T> frag_v_perm(const T* Vs, int LD, int d0, int ks, int c, int g) {
+    Frag<T> f;
+    if constexpr (sizeof(T) == 2) {
+        typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+        const T* p0 = Vs + (32 * ks + 4 * g + (c >> 2)) * LD + d0 + 4 * (c & 3);
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p0));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p0 + 16 * LD));
+        const s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        f.v = __builtin_bit_cast(bf16x8, both);
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            f.v[e] = Vs[(32 * ks + 4 * g + e) * LD + d0 + c];
+            f.v[4 + e] = Vs[(32 * ks + 16 + 4 * g + e) * LD + d0 + c];
+        }
+    }
+    return f;
+}
+
+template <typename T>
+__device__ __forceinline__ Frag<T> frag_p_regs(const f32x4& lo, const f32x4& hi) {
+    Frag<T> f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        if constexpr (sizeof(T) == 2) {
+            f.v[e] = (bf16)lo[e];
+            f.v[4 + e] = (bf16)hi[e];
+        } else {
+            f.v[e] = lo[e];
+            f.v[4 + e] = hi[e];
+        }
+    }
+    return f;
+}
+
+template <typename T, bool WANT_ATTN>
+__global__ __launch_bounds__(BigCfg<T>::WAVES * 64, 2) void attn_big_fwd2_kernel(
+    const T* __restrict__ qkv, const float* __restrict__ qkv_bias, const int* __restrict__ win2tok, int L,
+    const float* __restrict__ bias_frag, int ws, const int* __restrict__ region_ids, int nW, int Bw, int N, int nH,
+    float scale, T* __restrict__ out, float* __restrict__ lse_out, float* __restrict__ attn_out) {
+    using Cfg = BigCfg<T>;
+    constexpr int LDQ = Cfg::LDQ, WAVES = Cfg::WAVES;
+    constexpr int PASSES = (NQB + WAVES - 1) / WAVES;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const BigTables tb = carve_tables(smem_raw);
+    T* Ks = reinterpret_cast<T*>(smem_raw + Cfg::TABLE_BYTES);
+    T* Vs = Ks + Cfg::FULL;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 15, g = lane >> 4;
+    T* Qs = Vs + Cfg::FULL + wave * Cfg::BLK;  // this wave's [32][LDQ] image: Q block, then the output transpose
+
+    const int unit = blockIdx.x;  // (bw, h)
+    const int bw = unit / nH, h = unit % nH;
+    const int C = nH * HD;
+    const long tok_base = (long)(bw / nW) * L;
+    const T* src = qkv + h * HD;
+    const bool masked = region_ids != nullptr;
+    const float* bias_h = bias_frag + (long)h * (NT * NT * 256);
+
+    load_window_tables(tb, win2tok, region_ids, bw % nW, N, ws, true);
+    __syncthreads();
+    SlotStage<T, 32, 64> sq;
+    {
+        SlotStage<T, NPB, WAVES * 64> sk, sv;
+        sk.load(src + C, 3L * C, tb.tok, tok_base, 0, N, qkv_bias + C + h * HD, threadIdx.x);
+        sv.load(src + 2 * C, 3L * C, tb.tok, tok_base, 0, N, qkv_bias + 2 * C + h * HD, threadIdx.x);
+        sq.load(src, 3L * C, tb.tok, tok_base, 32 * wave, N, qkv_bias + h * HD, lane);
+        sk.store(Ks, 1.f, threadIdx.x);
+        sv.store(Vs, 1.f, threadIdx.x);
+        sq.store(Qs, scale, lane);
+    }
+    // shift-mask region label of this lane's four keys in every key tile, 8 bits each
+    int rk[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        rk[i] = 0;
+        if (masked) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) rk[i] |= ((tb.pk[16 * i + 4 * g + r] >> 16) & 0xff) << (8 * r);
+        }
+    }
+    __syncthreads();  // K, V complete (whole workgroup); everything below is private to the wave
+
+#pragma unroll
+    for (int pass = 0; pass < PASSES; ++pass) {
+        const int qb = wave + pass * WAVES;
+        const bool valid = qb < NQB;
+        const int q0 = valid ? 32 * qb : 0;
+        if (pass > 0) {
+            __builtin_amdgcn_wave_barrier();
+            sq.store(Qs, scale, lane);
+            __builtin_amdgcn_wave_barrier();
+        }
+        Frag<T> qf[2];
+        qf[0] = frag_kc<T>(Qs, LDQ, 0, 0, c, g);
+        qf[1] = frag_kc<T>(Qs, LDQ, 16, 0, c, g);
+        if (pass + 1 < PASSES) {  // next pass's Q rows travel while this pass computes
+            const int qn = wave + (pass + 1) * WAVES;
+            sq.load(src, 3L * C, tb.tok, tok_base, qn < NQB ? 32 * qn : 0, N, qkv_bias + h * HD, lane);
+        }
+        int rq[2] = {0, 0};
+        if (masked) {
+            rq[0] = (tb.pk[q0 + c] >> 16) & 0xff;
+            rq[1] = (tb.pk[q0 + 16 + c] >> 16) & 0xff;
+        }
+        f32x4 p[NT][2];
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            const Frag<T> kf = frag_kc<T>(Ks, LDQ, 16 * i, 0, c, g);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                f32x4 b = *reinterpret_cast<const f32x4*>(bias_h + ((i * NT + (q0 >> 4) + j) * 64 + lane) * 4);
+                if (masked) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) b[r] += (((rk[i] >> (8 * r)) & 0xff) != rq[j]) ? -100.f : 0.f;
+                }
+                p[i][j] = b;
+                mma(kf, qf[j], p[i][j]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            float m = -3.0e38f;
+#pragma unroll
+            for (int i = 0; i < NT; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) m = fmaxf(m, p[i][j][r]);
+            m = fmaxf(m, __shfl_xor(m, 16, 64));
+            m = fmaxf(m, __shfl_xor(m, 32, 64));
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < NT; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float e = __expf(p[i][j][r] - m);
+                    p[i][j][r] = e;
+                    s += e;
+                }
+            s += __shfl_xor(s, 16, 64);
+            s += __shfl_xor(s, 32, 64);
+            const float inv = 1.f / s;
+#pragma unroll
+            for (int i = 0; i < NT; ++i) p[i][j] *= inv;
+            const int q = q0 + 16 * j + c;
+            if (valid && g == 0 && lse_out) lse_out[(long)unit * NPB + q] = m + __logf(s);
+        }
+        if constexpr (WANT_ATTN) {
+            if (valid) {
+#pragma unroll
+                for (int i = 0; i < NT; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int q = q0 + 16 * j + c, key = 16 * i + 4 * g + r;
+                            if (q < N && key < N) attn_out[((long)unit * N + q) * N + key] = p[i][j][r];
+                        }
+            }
+        }
+        f32x4 o[2][2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            o[a][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+            o[a][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int ks = 0; ks < NPB / 32; ++ks) {
+            const Frag<T> v0 = frag_v_perm<T>(Vs, LDQ, 0, ks, c, g);
+            const Frag<T> v1 = frag_v_perm<T>(Vs, LDQ, 16, ks, c, g);
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                const Frag<T> pf = frag_p_regs<T>(p[2 * ks][a], p[2 * ks + 1][a]);
                 mma(pf, v0, o[a][0]);
                 mma(pf, v1, o[a][1]);
             }
@@ -682,6 +880,362 @@ __global__ __launch_bounds__(BigCfg<T>::WAVES * 64) void attn_big_bwd_dkv_kernel
     }
 }
 
+// -------------------------------------------------------------------------------------------------------------
+// backward, second generation (default).  Same split (dQ + bias gradient | dK, dV) and the same mathematics; changes:
+//   * dS / P never go through LDS: a score tile leaves its 4 accumulator rows per lane in exactly the k-slots an MFMA A
+//     operand wants if the other operand is read with the matching row permutation (frag_v_perm) -- rows = keys for
+//     dQ = dS K (tiles oriented S^T as in the forward), rows = queries for dV = P^T dO and dK = dS^T Q (tiles oriented S;
+//     the bias arrives in a second fragment buffer with that orientation).  That frees the 59 / 72 KB of per-wave images
+//     and lets two workgroups share a CU.
+//   * both kernels rebuild P from the saved log-sum-exp (no max / sum passes, no shuffles).
+//   * the relative-position-bias gradient is reduced straight into its (2ws-1)^2-entry table in LDS with ds_add_f32
+//     (index = a(q) - a(key) + off, both a() values are in the per-window tables), 112 LDS adds per wave and window instead
+//     of 112 accumulator registers carried across windows -- the first generation needed > 256 registers for them and
+//     spilled; this one fits two waves per SIMD.  One table per workgroup goes to the workspace; the partial tables are
+//     summed by big_dtable_reduce_kernel (no 200-KB fragment slabs, no index scatter).
+// -------------------------------------------------------------------------------------------------------------
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+constexpr int DTAB = 768;  // >= (2*14-1)^2 = 729
+
+template <typename T>
+__global__ __launch_bounds__(BigCfg<T>::WAVES * 64, sizeof(T) == 2 ? 2 : 1) void attn_big_bwd_dq2_kernel(
+    const T* __restrict__ qkv, const float* __restrict__ qkv_bias, const int* __restrict__ win2tok, int L, const T* __restrict__ dout,
+    const T* __restrict__ fout, const float* __restrict__ lse_in, const float* __restrict__ bias_frag, int ws, const int* __restrict__ region_ids, int nW, int Bw, int N,
+    int nH, float scale, int parts, T* __restrict__ dqkv, float* __restrict__ dtab_ws) {
+    using Cfg = BigCfg<T>;
+    constexpr int LDQ = Cfg::LDQ, WAVES = Cfg::WAVES;
+    constexpr int GROUPS = (NQB + WAVES - 1) / WAVES;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const BigTables tb = carve_tables(smem_raw);
+    T* Ks = reinterpret_cast<T*>(smem_raw + Cfg::TABLE_BYTES);
+    T* Vs = Ks + Cfg::FULL;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 15, g = lane >> 4;
+    T* Qs = Vs + Cfg::FULL + wave * (3 * Cfg::BLK);
+    T* Os = Qs + Cfg::BLK;  // dO rows of this wave's queries
+    T* Fs = Os + Cfg::BLK;  // forward output rows (delta = rowsum(dO o O))
+    float* dtab = reinterpret_cast<float*>(Vs + Cfg::FULL + WAVES * (3 * Cfg::BLK));
+
+    const int grp = blockIdx.x % GROUPS;
+    const int ph = blockIdx.x / GROUPS;  // (part, h)
+    const int h = ph % nH, part = ph / nH;
+    const int qb = grp * WAVES + wave;
+    const bool wave_ok = qb < NQB;
+    const int q0 = wave_ok ? 32 * qb : 0;
+    const int C = nH * HD;
+    const bool masked = region_ids != nullptr;
+    const T* src = qkv + h * HD;
+    const float* bias_h = bias_frag + (long)h * (NT * NT * 256);
+    const int off = (ws - 1) * (2 * ws - 1) + (ws - 1);
+
+    for (int t = threadIdx.x; t < DTAB; t += WAVES * 64) dtab[t] = 0.f;
+
+    const int iters = (Bw + parts - 1) / parts;
+    for (int it = 0; it < iters; ++it) {
+        const int bw = part + it * parts;
+        const bool win_ok = bw < Bw;
+        const int bwc = win_ok ? bw : 0;
+        const bool active = win_ok && wave_ok;
+        const long tok_base = (long)(bwc / nW) * L;
+        __syncthreads();  // previous window's reads are complete
+        load_window_tables(tb, win2tok, region_ids, bwc % nW, N, ws, win_ok);
+        __syncthreads();
+        float lq[2];
+        {
+            SlotStage<T, NPB, WAVES * 64> sk, sv;
+            SlotStage<T, 32, 64> sq, so, sf;
+            sk.load(src + C, 3L * C, tb.tok, tok_base, 0, N, qkv_bias + C + h * HD, threadIdx.x);
+            sv.load(src + 2 * C, 3L * C, tb.tok, tok_base, 0, N, qkv_bias + 2 * C + h * HD, threadIdx.x);
+            sq.load(src, 3L * C, tb.tok, tok_base, q0, N, qkv_bias + h * HD, lane);
+            so.load(dout + h * HD, (long)C, tb.tok, tok_base, q0, N, nullptr, lane);
+            sf.load(fout + h * HD, (long)C, tb.tok, tok_base, q0, N, nullptr, lane);
+            lq[0] = lse_in[((long)bwc * nH + h) * NPB + q0 + c];
+            lq[1] = lse_in[((long)bwc * nH + h) * NPB + q0 + 16 + c];
+            sk.store(Ks, 1.f, threadIdx.x);
+            sv.store(Vs, 1.f, threadIdx.x);
+            sq.store(Qs, scale, lane);
+            so.store(Os, 1.f, lane);
+            sf.store(Fs, 1.f, lane);
+        }
+        __syncthreads();
+        int aq[2], rq[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int pk = tb.pk[q0 + 16 * j + c];
+            aq[j] = (pk & 0xffff) + off;
+            rq[j] = (pk >> 16) & 0xff;
+        }
+        // P^T strip from the saved log-sum-exp: rows = keys, columns = this wave's 32 queries
+        f32x4 p[NT][2];
+        {
+            Frag<T> qf[2];
+            qf[0] = frag_kc<T>(Qs, LDQ, 0, 0, c, g);
+            qf[1] = frag_kc<T>(Qs, LDQ, 16, 0, c, g);
+#pragma unroll
+            for (int i = 0; i < NT; ++i) {
+                const Frag<T> kf = frag_kc<T>(Ks, LDQ, 16 * i, 0, c, g);
+                const i32x4 pk4 = *reinterpret_cast<const i32x4*>(tb.pk + 16 * i + 4 * g);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    f32x4 b = *reinterpret_cast<const f32x4*>(bias_h + ((i * NT + (q0 >> 4) + j) * 64 + lane) * 4);
+                    if (masked) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) b[r] += (((pk4[r] >> 16) & 0xff) != rq[j]) ? -100.f : 0.f;
+                    }
+                    mma(kf, qf[j], b);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) b[r] = __expf(b[r] - lq[j]);
+                    p[i][j] = b;
+                }
+            }
+        }
+        // dP^T = V dO^T, dS = P o (dP - delta) with delta = rowsum(dO o O) of the query; dS overwrites P tile by tile
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const Frag<T> of = frag_kc<T>(Os, LDQ, 16 * j, 0, c, g);
+            float d = 0.f;
+            {
+                const Frag<T> ff = frag_kc<T>(Fs, LDQ, 16 * j, 0, c, g);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) d += (float)of.v[e] * (float)ff.v[e];
+                d += __shfl_xor(d, 16, 64);
+                d += __shfl_xor(d, 32, 64);
+            }
+#pragma unroll
+            for (int i = 0; i < NT; ++i) {
+                const Frag<T> vf = frag_kc<T>(Vs, LDQ, 16 * i, 0, c, g);
+                f32x4 dp = {0.f, 0.f, 0.f, 0.f};
+                mma(vf, of, dp);
+                const f32x4 ds = p[i][j] * (dp - d);
+                p[i][j] = ds;
+                if (active) {
+                    const i32x4 pk4 = *reinterpret_cast<const i32x4*>(tb.pk + 16 * i + 4 * g);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) atomicAdd(dtab + (aq[j] - (pk4[r] & 0xffff)), ds[r]);
+                }
+            }
+        }
+        // dQ = scale * dS K: dS straight from the accumulators, K rows read with the matching key permutation
+        f32x4 acc[2][2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            acc[a][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+            acc[a][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int ks = 0; ks < NPB / 32; ++ks) {
+            const Frag<T> k0 = frag_v_perm<T>(Ks, LDQ, 0, ks, c, g);
+            const Frag<T> k1 = frag_v_perm<T>(Ks, LDQ, 16, ks, c, g);
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                const Frag<T> sf = frag_p_regs<T>(p[2 * ks][a], p[2 * ks + 1][a]);
+                mma(sf, k0, acc[a][0]);
+                mma(sf, k1, acc[a][1]);
+            }
+        }
+        store_block_rows_vec<T>(acc, scale, Qs, dqkv + h * HD, 3L * C, tb.tok, tok_base, q0, N, active, nullptr, lane, c, g);
+    }
+    __syncthreads();
+    float* wsp = dtab_ws + ((long)(part * GROUPS + grp) * nH + h) * DTAB;
+    for (int t = threadIdx.x; t < DTAB; t += WAVES * 64) wsp[t] = dtab[t];
+}
+
+template <typename T>
+__global__ __launch_bounds__(BigCfg<T>::WAVES * 64, sizeof(T) == 2 ? 2 : 1) void attn_big_bwd_dkv2_kernel(
+    const T* __restrict__ qkv, const float* __restrict__ qkv_bias, const int* __restrict__ win2tok, int L, const T* __restrict__ dout,
+    const T* __restrict__ fout, const float* __restrict__ lse_in, const float* __restrict__ bias_frag_s, int ws,
+    const int* __restrict__ region_ids, int nW, int Bw, int N, int nH, float scale, T* __restrict__ dqkv, float* __restrict__ dpad_ws) {
+    using Cfg = BigCfg<T>;
+    constexpr int LDQ = Cfg::LDQ, WAVES = Cfg::WAVES;
+    constexpr int PASSES = (NQB + WAVES - 1) / WAVES;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const BigTables tb = carve_tables(smem_raw);
+    T* Qs = reinterpret_cast<T*>(smem_raw + Cfg::TABLE_BYTES);  // scale*Q, [224][LDQ]
+    T* Os = Qs + Cfg::FULL;                                      // dO,      [224][LDQ]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 15, g = lane >> 4;
+    T* Kb = Os + Cfg::FULL + wave * (2 * Cfg::BLK);
+    T* Vb = Kb + Cfg::BLK;
+
+    const int unit = blockIdx.x;
+    const int bw = unit / nH, h = unit % nH;
+    const int C = nH * HD;
+    const long tok_base = (long)(bw / nW) * L;
+    const T* src = qkv + h * HD;
+    const bool masked = region_ids != nullptr;
+    const float* bias_h = bias_frag_s + (long)h * (NT * NT * 256);
+
+    load_window_tables(tb, win2tok, region_ids, bw % nW, N, ws, true);
+    __syncthreads();
+    SlotStage<T, 32, 64> sk, sv;
+    {
+        SlotStage<T, NPB, WAVES * 64> sq, so;
+        sq.load(src, 3L * C, tb.tok, tok_base, 0, N, qkv_bias + h * HD, threadIdx.x);
+        so.load(dout + h * HD, (long)C, tb.tok, tok_base, 0, N, nullptr, threadIdx.x);
+        sk.load(src + C, 3L * C, tb.tok, tok_base, 32 * wave, N, qkv_bias + C + h * HD, lane);
+        sv.load(src + 2 * C, 3L * C, tb.tok, tok_base, 32 * wave, N, qkv_bias + 2 * C + h * HD, lane);
+        // per-query statistics: saved log-sum-exp and delta = sum_d dO[q,d] * O[q,d]
+        for (int t = threadIdx.x; t < NPB; t += WAVES * 64) {
+            float l = 0.f, d = 0.f;
+            if (t < N) {
+                l = lse_in[(long)unit * NPB + t];
+                const int tok = tb.tok[t];
+                if (tok >= 0) {
+                    const T* orow = fout + (tok_base + tok) * (long)C + h * HD;
+                    const T* grow = dout + (tok_base + tok) * (long)C + h * HD;
+#pragma unroll
+                    for (int vv = 0; vv < HD / Cfg::VEC; ++vv) {
+                        const Vec16<T> ov = ld16<T>(orow + vv * Cfg::VEC), gv = ld16<T>(grow + vv * Cfg::VEC);
+#pragma unroll
+                        for (int e = 0; e < Cfg::VEC; ++e) d += ov.get(e) * gv.get(e);
+                    }
+                }
+            }
+            tb.lse[t] = l;
+            tb.delta[t] = d;
+        }
+        sq.store(Qs, scale, threadIdx.x);
+        so.store(Os, 1.f, threadIdx.x);
+        sk.store(Kb, 1.f, lane);
+        sv.store(Vb, 1.f, lane);
+    }
+    float padk[Cfg::VEC], padv[Cfg::VEC];
+#pragma unroll
+    for (int e = 0; e < Cfg::VEC; ++e) padk[e] = padv[e] = 0.f;
+    __syncthreads();  // Q, dO, lse, delta staged by the whole workgroup; Kb / Vb are private to the wave
+
+#pragma unroll
+    for (int pass = 0; pass < PASSES; ++pass) {
+        const int kb = wave + pass * WAVES;
+        const bool valid = kb < NQB;
+        const int k0 = valid ? 32 * kb : 0;
+        if (pass > 0) {
+            __builtin_amdgcn_wave_barrier();
+            sk.store(Kb, 1.f, lane);
+            sv.store(Vb, 1.f, lane);
+            __builtin_amdgcn_wave_barrier();
+        }
+        Frag<T> kf[2], vf[2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            kf[a] = frag_kc<T>(Kb, LDQ, 16 * a, 0, c, g);
+            vf[a] = frag_kc<T>(Vb, LDQ, 16 * a, 0, c, g);
+        }
+        if (pass + 1 < PASSES) {  // next pass's key / value rows travel while this pass computes
+            const int kn = wave + (pass + 1) * WAVES;
+            const int kn0 = kn < NQB ? 32 * kn : 0;
+            sk.load(src + C, 3L * C, tb.tok, tok_base, kn0, N, qkv_bias + C + h * HD, lane);
+            sv.load(src + 2 * C, 3L * C, tb.tok, tok_base, kn0, N, qkv_bias + 2 * C + h * HD, lane);
+        }
+        int rkey[2] = {0, 0};
+        if (masked) {
+            rkey[0] = (tb.pk[k0 + c] >> 16) & 0xff;
+            rkey[1] = (tb.pk[k0 + 16 + c] >> 16) & 0xff;
+        }
+        // P block, oriented S: rows = queries (14 tiles), columns = this block's 32 keys (2 tiles)
+        f32x4 p[2][NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const Frag<T> qf = frag_kc<T>(Qs, LDQ, 16 * j, 0, c, g);
+            const f32x4 l4 = *reinterpret_cast<const f32x4*>(tb.lse + 16 * j + 4 * g);
+            const i32x4 pk4 = *reinterpret_cast<const i32x4*>(tb.pk + 16 * j + 4 * g);
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                f32x4 b = *reinterpret_cast<const f32x4*>(bias_h + ((j * NT + (k0 >> 4) + a) * 64 + lane) * 4);
+                if (masked) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) b[r] += (((pk4[r] >> 16) & 0xff) != rkey[a]) ? -100.f : 0.f;
+                }
+                mma(qf, kf[a], b);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) b[r] = (16 * j + 4 * g + r < N) ? __expf(b[r] - l4[r]) : 0.f;  // padded queries carry no gradient
+                p[a][j] = b;
+            }
+        }
+        // dV[key][d] = sum_q P[q][key] dO[q][d]
+        {
+            f32x4 av[2][2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                av[a][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+                av[a][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int ks = 0; ks < NPB / 32; ++ks) {
+                const Frag<T> o0 = frag_v_perm<T>(Os, LDQ, 0, ks, c, g);
+                const Frag<T> o1 = frag_v_perm<T>(Os, LDQ, 16, ks, c, g);
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    const Frag<T> pf = frag_p_regs<T>(p[a][2 * ks], p[a][2 * ks + 1]);
+                    mma(pf, o0, av[a][0]);
+                    mma(pf, o1, av[a][1]);
+                }
+            }
+            store_block_rows_vec<T>(av, 1.f, Kb, dqkv + 2 * C + h * HD, 3L * C, tb.tok, tok_base, k0, N, valid, padv, lane, c, g);
+        }
+        // dS = P o (dP - delta), dP[q][key] = sum_d dO[q][d] V[key][d]; dS overwrites P
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const Frag<T> of = frag_kc<T>(Os, LDQ, 16 * j, 0, c, g);
+            const f32x4 dl4 = *reinterpret_cast<const f32x4*>(tb.delta + 16 * j + 4 * g);
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                f32x4 dp = {0.f, 0.f, 0.f, 0.f};
+                mma(of, vf[a], dp);
+                p[a][j] = p[a][j] * (dp - dl4);
+            }
+        }
+        // dK[key][d] = sum_q dS[q][key] (scale q)[q][d]
+        {
+            f32x4 ak[2][2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                ak[a][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+                ak[a][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int ks = 0; ks < NPB / 32; ++ks) {
+                const Frag<T> q0f = frag_v_perm<T>(Qs, LDQ, 0, ks, c, g);
+                const Frag<T> q1f = frag_v_perm<T>(Qs, LDQ, 16, ks, c, g);
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    const Frag<T> sf = frag_p_regs<T>(p[a][2 * ks], p[a][2 * ks + 1]);
+                    mma(sf, q0f, ak[a][0]);
+                    mma(sf, q1f, ak[a][1]);
+                }
+            }
+            store_block_rows_vec<T>(ak, 1.f, Kb, dqkv + C + h * HD, 3L * C, tb.tok, tok_base, k0, N, valid, padk, lane, c, g);
+        }
+    }
+    // lanes with equal dv = lane % VPR hold partial sums of the same VEC columns
+    constexpr int VPR = HD / Cfg::VEC;
+#pragma unroll
+    for (int e = 0; e < Cfg::VEC; ++e)
+#pragma unroll
+        for (int o = VPR; o < 64; o <<= 1) {
+            padk[e] += __shfl_xor(padk[e], o, 64);
+            padv[e] += __shfl_xor(padv[e], o, 64);
+        }
+    if (lane < VPR) {  // one slab row per (unit, wave): [k | v][nH][hd]
+        float* pw = dpad_ws + ((long)unit * WAVES + wave) * 2 * C + h * HD + lane * Cfg::VEC;
+#pragma unroll
+        for (int e = 0; e < Cfg::VEC; ++e) {
+            pw[e] = padk[e];
+            pw[C + e] = padv[e];
+        }
+    }
+}
+
+// dtable[row][h] = sum over the workgroups' partial tables [nparts][nH][DTAB]
+__global__ void big_dtable_reduce_kernel(const float* __restrict__ ws, int nparts, int nH, int rows, float* __restrict__ dtable) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * nH) return;
+    const int row = i / nH, h = i % nH;
+    float s = 0.f;
+    for (int pt = 0; pt < nparts; ++pt) s += ws[((long)pt * nH + h) * DTAB + row];
+    dtable[i] = s;
+}
+
 // dtable[index[q,key]][h] += total[h][frag(q,key)] for the 14-tile frag layout
 __global__ void relpos_bias_bwd_big_kernel(const float* __restrict__ ws, const long* __restrict__ index, int N, int nH,
                                            float* __restrict__ dtable) {
@@ -700,6 +1254,21 @@ size_t fwd_lds() {
     return Cfg::TABLE_BYTES + (size_t)(2 * Cfg::FULL + Cfg::WAVES * (Cfg::BLK + Cfg::PIMG)) * sizeof(T);
 }
 template <typename T>
+size_t fwd2_lds() {
+    using Cfg = BigCfg<T>;
+    return Cfg::TABLE_BYTES + (size_t)(2 * Cfg::FULL + Cfg::WAVES * Cfg::BLK) * sizeof(T);
+}
+template <typename T>
+size_t dq2_lds() {
+    using Cfg = BigCfg<T>;
+    return Cfg::TABLE_BYTES + (size_t)(2 * Cfg::FULL + Cfg::WAVES * 3 * Cfg::BLK) * sizeof(T) + DTAB * sizeof(float);
+}
+template <typename T>
+size_t dkv2_lds() {
+    using Cfg = BigCfg<T>;
+    return Cfg::TABLE_BYTES + (size_t)(2 * Cfg::FULL + Cfg::WAVES * 2 * Cfg::BLK) * sizeof(T);
+}
+template <typename T>
 size_t dq_lds() {
     using Cfg = BigCfg<T>;
     return Cfg::TABLE_BYTES + (size_t)(2 * Cfg::FULL + Cfg::WAVES * (2 * Cfg::BLK + Cfg::PIMG)) * sizeof(T);
@@ -709,6 +1278,11 @@ size_t dkv_lds() {
     using Cfg = BigCfg<T>;
     return Cfg::TABLE_BYTES + (size_t)(2 * Cfg::FULL + Cfg::WAVES * (2 * Cfg::BLK + Cfg::FULL)) * sizeof(T);
 }
+
+int g_big_fwd_impl = 2;  // 1: first generation (P through LDS, one workgroup per CU); 2: P in registers, two per CU
+int g_big_bwd_impl = 3;     // 1: first generation (dS / P^T through LDS, fragment-layout bias gradient in registers); 2: dq2 + dkv2 (bias gradient
+                            // by LDS atomics: measured 3x slower than 1's dQ -- the LDS atomic unit is the bottleneck); 3 (default): 1's dQ + dkv2
+int g_big_bwd_dtype = ESVIT_BF16;  // dtype of the last backward launch (selects the workspace layout the bias-gradient reduce reads)
 
 inline int big_parts(int Bw, int nH) {
     int parts = (512 + nH - 1) / nH;  // ~2 workgroups per CU across heads and query-block groups
@@ -721,12 +1295,16 @@ inline int big_parts(int Bw, int nH) {
 #define STREAM(s_) hipStream_t stream = reinterpret_cast<hipStream_t>(s_)
 
 int esvit_big_frag_elems() { return NT * NT * 256; }
+extern "C" void esvit_debug_set_big_attn_impl(int fwd, int bwd) {
+    g_big_fwd_impl = fwd;
+    g_big_bwd_impl = bwd;
+}
 int esvit_big_npb() { return NPB; }
 int esvit_big_parts(int Bw, int nH) { return big_parts(Bw, nH); }
 int esvit_big_pad_rows(int Bw, int nH, int dtype) { return Bw * nH * (dtype == ESVIT_BF16 ? 4 : 2); }
 
 static int fill_bias_frag_big(const float* rel_table, int ws, int N, int nH, float* bias_frag_ws, hipStream_t stream) {
-    const long n = (long)nH * NT * NT * 256;
+    const long n = 2L * nH * NT * NT * 256;  // S^T-oriented tiles of every head, then S-oriented tiles of every head
     hipLaunchKernelGGL(relpos_bias_frag_big_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, stream, rel_table, ws, N, nH, bias_frag_ws);
     ESVIT_CHECK_LAUNCH("relpos_bias(frag, 14x14)");
     return ESVIT_OK;
@@ -736,6 +1314,22 @@ template <typename T>
 static int big_fwd_launch(const void* qkv, const float* qkv_bias, const int32_t* win2tok, int L, const float* rel_table, int rel_rows, int ws,
                           const int32_t* region_ids, int nW, int Bw, int N, int nH, float scale, void* out, float* lse, float* attn_out,
                           hipStream_t stream) {
+    if (g_big_fwd_impl == 2) {
+        const size_t lds = fwd2_lds<T>();
+        if (attn_out) {
+            auto kern = attn_big_fwd2_kernel<T, true>;
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(kern, dim3(Bw * nH), dim3(BigCfg<T>::WAVES * 64), lds, stream, (const T*)qkv, qkv_bias, win2tok, L, rel_table, ws,
+                               region_ids, nW, Bw, N, nH, scale, (T*)out, lse, attn_out);
+        } else {
+            auto kern = attn_big_fwd2_kernel<T, false>;
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(kern, dim3(Bw * nH), dim3(BigCfg<T>::WAVES * 64), lds, stream, (const T*)qkv, qkv_bias, win2tok, L, rel_table, ws,
+                               region_ids, nW, Bw, N, nH, scale, (T*)out, lse, attn_out);
+        }
+        ESVIT_CHECK_LAUNCH("window_attn_fwd(14x14, gen 2)");
+        return ESVIT_OK;
+    }
     auto kern = attn_big_fwd_kernel<T>;
     const size_t lds = fwd_lds<T>();
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -768,6 +1362,44 @@ static int big_bwd_launch(const void* qkv, const float* qkv_bias, const int32_t*
     using Cfg = BigCfg<T>;
     constexpr int GROUPS = (NQB + Cfg::WAVES - 1) / Cfg::WAVES;
     const int parts = big_parts(Bw, nH);
+    if (g_big_bwd_impl == 3) {  // default: first-generation dQ (bias gradient in registers), second-generation dK / dV
+        {
+            auto kern = attn_big_bwd_dq_kernel<T, TR>;
+            const size_t lds = dq_lds<T>();
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(kern, dim3(parts * nH * GROUPS), dim3(Cfg::WAVES * 64), lds, stream, (const T*)qkv, qkv_bias, win2tok, L,
+                               (const T*)dout, rel_table, rel_rows, ws, region_ids, nW, Bw, N, nH, scale, parts, (T*)dqkv, dbias_ws);
+            ESVIT_CHECK_LAUNCH("window_attn_bwd(14x14, dQ)");
+        }
+        {
+            auto kern = attn_big_bwd_dkv2_kernel<T>;
+            const size_t lds = dkv2_lds<T>();
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(kern, dim3(Bw * nH), dim3(Cfg::WAVES * 64), lds, stream, (const T*)qkv, qkv_bias, win2tok, L, (const T*)dout,
+                               (const T*)fout, lse, rel_table + (long)nH * NT * NT * 256, ws, region_ids, nW, Bw, N, nH, scale, (T*)dqkv, dpad_ws);
+            ESVIT_CHECK_LAUNCH("window_attn_bwd(14x14, dK dV, gen 2)");
+        }
+        return ESVIT_OK;
+    }
+    if (g_big_bwd_impl == 2) {
+        {
+            auto kern = attn_big_bwd_dq2_kernel<T>;
+            const size_t lds = dq2_lds<T>();
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(kern, dim3(parts * nH * GROUPS), dim3(Cfg::WAVES * 64), lds, stream, (const T*)qkv, qkv_bias, win2tok, L,
+                               (const T*)dout, (const T*)fout, lse, rel_table, ws, region_ids, nW, Bw, N, nH, scale, parts, (T*)dqkv, dbias_ws);
+            ESVIT_CHECK_LAUNCH("window_attn_bwd(14x14, dQ, gen 2)");
+        }
+        {
+            auto kern = attn_big_bwd_dkv2_kernel<T>;
+            const size_t lds = dkv2_lds<T>();
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(kern, dim3(Bw * nH), dim3(Cfg::WAVES * 64), lds, stream, (const T*)qkv, qkv_bias, win2tok, L, (const T*)dout,
+                               (const T*)fout, lse, rel_table + (long)nH * NT * NT * 256, ws, region_ids, nW, Bw, N, nH, scale, (T*)dqkv, dpad_ws);
+            ESVIT_CHECK_LAUNCH("window_attn_bwd(14x14, dK dV, gen 2)");
+        }
+        return ESVIT_OK;
+    }
     {
         auto kern = attn_big_bwd_dq_kernel<T, TR>;
         const size_t lds = dq_lds<T>();
@@ -800,6 +1432,7 @@ int esvit_big_attn_bwd(int dtype, int use_tr, const void* qkv, const float* qkv_
     }
     const float* rel_table = bias_frag_ws;  // the kernels read the frag-layout bias
     const int Bw = nB * nW;
+    g_big_bwd_dtype = dtype;
     if (dtype == ESVIT_BF16) {
         if (use_tr)
             return big_bwd_launch<bf16, true>(qkv, qkv_bias, win2tok, L, dout, fout, lse, rel_table, rel_rows, ws, region_ids, nW, Bw, N, nH,
@@ -814,6 +1447,14 @@ int esvit_big_attn_bwd(int dtype, int use_tr, const void* qkv, const float* qkv_
 int esvit_big_relpos_bias_bwd(const float* dbias_ws, int parts, const int64_t* index, int N, int nH, int table_rows, float* dtable,
                               hipStream_t stream) {
     const int FE = NT * NT * 256;
+    if (g_big_bwd_impl == 2) {  // the workspace holds one (2ws-1)^2 table per workgroup of the dQ kernel
+        const int groups_bf16 = (NQB + 3) / 4, groups_f32 = (NQB + 1) / 2;
+        const int nparts = parts * (g_big_bwd_dtype == ESVIT_BF16 ? groups_bf16 : groups_f32);
+        hipLaunchKernelGGL(big_dtable_reduce_kernel, dim3(ceil_div((long)table_rows * nH, 256)), dim3(256), 0, stream, dbias_ws, nparts, nH,
+                           table_rows, dtable);
+        ESVIT_CHECK_LAUNCH("relpos_bias_bwd(14x14, gen 2)");
+        return ESVIT_OK;
+    }
     if (parts > 1) {
         int rc = esvit_partial_reduce(dbias_ws, parts, nH * FE, (long)nH * FE, const_cast<float*>(dbias_ws), 0, stream);
         if (rc != ESVIT_OK) return rc;

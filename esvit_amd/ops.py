@@ -458,7 +458,7 @@ def window_attn_fwd(qkv, qkv_bias, win2tok, L, rel_table, ws, region_ids, nW, N,
     attn = torch.empty((nB * nW, nH, N, N), dtype=torch.float32, device=qkv.device) if want_attn else None
     nl = lib.esvit_window_attn_lse_elems(N)
     lse = torch.empty((nB * nW * nH, nl), dtype=torch.float32, device=qkv.device) if nl else None
-    bias_ws = workspace(nH * attn_frag_elems(N), qkv.device, slot=2)  # frag-layout relative-position bias of every head
+    bias_ws = workspace(2 * nH * attn_frag_elems(N), qkv.device, slot=2)  # frag-layout relative-position bias of every head
     check(lib.esvit_window_attn_fwd(_code(qkv.dtype), _p(qkv), _p(_f32c(qkv_bias)), _p(win2tok), L, _p(_f32c(rel_table)), ws, _p(bias_ws),
                                     _p(region_ids), nW, nB, N, nH, Cc // nH, scale, _p(out), _p(lse), _p(attn), _stream()),
           "window_attn_fwd")
@@ -477,7 +477,7 @@ def window_attn_bwd(qkv, qkv_bias, win2tok, L, dout, fwd_out, lse, rel_table, ws
     parts = lib.esvit_window_attn_bwd_parts(N, nB * nW, nH)
     dbias_ws = torch.empty((parts, nH, attn_frag_elems(N)), dtype=torch.float32, device=qkv.device)
     pad = torch.zeros((lib.esvit_window_attn_bwd_pad_rows(code, N, nB * nW, nH), 2 * Cc), dtype=torch.float32, device=qkv.device)
-    bias_ws = workspace(nH * attn_frag_elems(N), qkv.device, slot=2)
+    bias_ws = workspace(2 * nH * attn_frag_elems(N), qkv.device, slot=2)
     check(lib.esvit_window_attn_bwd(code, _p(qkv), _p(_f32c(qkv_bias)), _p(win2tok), L, _p(dout), _p(fwd_out), _p(lse), _p(_f32c(rel_table)),
                                     ws, _p(bias_ws), _p(region_ids), nW, nB, N, nH, Cc // nH, scale, _p(dqkv), _p(dbias_ws), _p(pad),
                                     _stream()), "window_attn_bwd")

@@ -171,7 +171,7 @@ int esvit_dense_to_frag(const float* dense, int n_mats, int N, float* frag, esvi
  * qkv_bias fp32 [3C]: the value of q,k,v at a zero-pad slot (LayerNorm output is zero-padded, so qkv = bias there;
  * pad keys/values take part in every softmax exactly as in the reference, pad query rows are dropped).
  * rel_table fp32 [(2ws-1)^2, nH] is the relative_position_bias_table parameter itself (swin_transformer.py:133-136,
- * index in closed form).  bias_frag_ws (required): fp32 scratch [nH, esvit_attn_frag_elems(N)] the library fills with
+ * index in closed form).  bias_frag_ws (required): fp32 scratch [2, nH, esvit_attn_frag_elems(N)] the library fills with
  * the bias in MFMA fragment order (one 16-byte load per lane per score tile instead of table gathers in the kernel).
  * region_ids int32 [nW*N] (esvit_shift_region_ids) for shifted blocks or NULL.
  * scale: applied to q before the product (swin_transformer.py:130: hd^-0.5; CvT passes dim^-0.5).  N = ws*ws <= 64 with
@@ -309,6 +309,7 @@ void esvit_debug_set_tr_read(int on);      /* GEMM: ds_read_b64_tr_b16 vs scalar
 void esvit_debug_set_attn_tr_read(int on); /* attention backward: same */
 void esvit_debug_set_attn_bwd_waves(int w); /* attention backward compiled for 2 (256 regs) or 1 (512 regs) waves per SIMD */
 void esvit_debug_set_gemm_dma(int on);     /* GEMM: LDS-DMA main loop (1: by shape, 2: always) vs register-staged main loop (0) */
+void esvit_debug_set_big_attn_impl(int fwd, int bwd); /* 14x14 attention generations: fwd 2 (default) P in registers / 1 P through LDS; bwd 3 (default) gen-1 dQ + gen-2 dK,dV / 2 all gen 2 (LDS-atomic bias gradient) / 1 all gen 1 */
 void esvit_debug_set_attn_fwd_impl(int v);   /* 7x7 attention forward: 3 (default) two waves per (window, head), 2 persistent prefetching kernel, 1 one window per wave */
 void esvit_debug_set_attn_bwd_impl(int v);   /* 7x7 attention backward: 3 (default) two waves per (window, head), 2 prefetching one-wave kernel, 1 first generation */
 void esvit_debug_set_gemm_xcdmap(int mode); /* 0 (default): tiles XCD-remapped, split/batch on grid.y; 1: split-K slices / batch items contiguous per XCD */
