@@ -1040,6 +1040,292 @@ __global__ __launch_bounds__(BigCfg<T>::WAVES * 64, sizeof(T) == 2 ? 2 : 1) void
     for (int t = threadIdx.x; t < DTAB; t += WAVES * 64) wsp[t] = dtab[t];
 }
 
+// dQ + bias gradient, third variant (default): the bias gradient stays in accumulator registers across the windows a wave
+// visits (fragment layout, reduced over `parts` afterwards -- as in the first generation: LDS atomics were 3x slower),
+// but everything else follows the second generation: P from the saved log-sum-exp, delta from the O rows, dS packed to
+// bf16 A fragments as it is produced (no dS image), one query tile (16 queries) at a time so that only 112 (bias gradient)
+// + 56 (P tile column) + 28 (packed dS) accumulator-class registers are live.
+template <typename T>
+__global__ __launch_bounds__(BigCfg<T>::WAVES * 64, 1) void attn_big_bwd_dq3_kernel(
+    const T* __restrict__ qkv, const float* __restrict__ qkv_bias, const int* __restrict__ win2tok, int L, const T* __restrict__ dout,
+    const T* __restrict__ fout, const float* __restrict__ lse_in, const float* __restrict__ bias_frag, int ws,
+    const int* __restrict__ region_ids, int nW, int Bw, int N, int nH, float scale, int parts, T* __restrict__ dqkv,
+    float* __restrict__ dbias_ws) {
+    using Cfg = BigCfg<T>;
+    constexpr int LDQ = Cfg::LDQ, WAVES = Cfg::WAVES;
+    constexpr int GROUPS = (NQB + WAVES - 1) / WAVES;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const BigTables tb = carve_tables(smem_raw);
+    T* Ks = reinterpret_cast<T*>(smem_raw + Cfg::TABLE_BYTES);
+    T* Vs = Ks + Cfg::FULL;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 15, g = lane >> 4;
+    T* Qs = Vs + Cfg::FULL + wave * (3 * Cfg::BLK);
+    T* Os = Qs + Cfg::BLK;  // dO rows of this wave's queries
+    T* Fs = Os + Cfg::BLK;  // forward output rows
+
+    const int grp = blockIdx.x % GROUPS;
+    const int ph = blockIdx.x / GROUPS;  // (part, h)
+    const int h = ph % nH, part = ph / nH;
+    const int qb = grp * WAVES + wave;
+    const bool wave_ok = qb < NQB;
+    const int q0 = wave_ok ? 32 * qb : 0;
+    const int C = nH * HD;
+    const bool masked = region_ids != nullptr;
+    const T* src = qkv + h * HD;
+    const float* bias_h = bias_frag + (long)h * (NT * NT * 256);
+
+    f32x4 db[NT][2];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        db[i][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+        db[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+    const int iters = (Bw + parts - 1) / parts;
+    for (int it = 0; it < iters; ++it) {
+        const int bw = part + it * parts;
+        const bool win_ok = bw < Bw;
+        const int bwc = win_ok ? bw : 0;
+        const bool active = win_ok && wave_ok;
+        const long tok_base = (long)(bwc / nW) * L;
+        __syncthreads();  // previous window's reads are complete
+        load_window_tables(tb, win2tok, region_ids, bwc % nW, N, ws, win_ok);
+        __syncthreads();
+        float lq[2];
+        {
+            SlotStage<T, NPB, WAVES * 64> sk, sv;
+            SlotStage<T, 32, 64> sq, so, sf;
+            sk.load(src + C, 3L * C, tb.tok, tok_base, 0, N, qkv_bias + C + h * HD, threadIdx.x);
+            sv.load(src + 2 * C, 3L * C, tb.tok, tok_base, 0, N, qkv_bias + 2 * C + h * HD, threadIdx.x);
+            sq.load(src, 3L * C, tb.tok, tok_base, q0, N, qkv_bias + h * HD, lane);
+            so.load(dout + h * HD, (long)C, tb.tok, tok_base, q0, N, nullptr, lane);
+            sf.load(fout + h * HD, (long)C, tb.tok, tok_base, q0, N, nullptr, lane);
+            lq[0] = lse_in[((long)bwc * nH + h) * NPB + q0 + c];
+            lq[1] = lse_in[((long)bwc * nH + h) * NPB + q0 + 16 + c];
+            sk.store(Ks, 1.f, threadIdx.x);
+            sv.store(Vs, 1.f, threadIdx.x);
+            sq.store(Qs, scale, lane);
+            so.store(Os, 1.f, lane);
+            sf.store(Fs, 1.f, lane);
+        }
+        __syncthreads();
+        f32x4 acc[2][2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const Frag<T> qf = frag_kc<T>(Qs, LDQ, 16 * j, 0, c, g);
+            const Frag<T> of = frag_kc<T>(Os, LDQ, 16 * j, 0, c, g);
+            const int rq = masked ? ((tb.pk[q0 + 16 * j + c] >> 16) & 0xff) : 0;
+            float d = 0.f;
+            {
+                const Frag<T> ff = frag_kc<T>(Fs, LDQ, 16 * j, 0, c, g);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) d += (float)of.v[e] * (float)ff.v[e];
+                d += __shfl_xor(d, 16, 64);
+                d += __shfl_xor(d, 32, 64);
+            }
+            // P^T tiles of this query tile (rows = keys) from the saved log-sum-exp
+            f32x4 pj[NT];
+#pragma unroll
+            for (int i = 0; i < NT; ++i) {
+                const Frag<T> kf = frag_kc<T>(Ks, LDQ, 16 * i, 0, c, g);
+                f32x4 b = *reinterpret_cast<const f32x4*>(bias_h + ((i * NT + (q0 >> 4) + j) * 64 + lane) * 4);
+                if (masked) {
+                    const i32x4 pk4 = *reinterpret_cast<const i32x4*>(tb.pk + 16 * i + 4 * g);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) b[r] += (((pk4[r] >> 16) & 0xff) != rq) ? -100.f : 0.f;
+                }
+                mma(kf, qf, b);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) b[r] = __expf(b[r] - lq[j]);
+                pj[i] = b;
+            }
+            // dP^T = V dO^T, dS = P o (dP - delta): accumulate the bias gradient, pack dS for the dQ product
+            Frag<T> sfr[NPB / 32];
+#pragma unroll
+            for (int ks = 0; ks < NPB / 32; ++ks) {
+                f32x4 ds2[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int i = 2 * ks + u;
+                    const Frag<T> vf = frag_kc<T>(Vs, LDQ, 16 * i, 0, c, g);
+                    f32x4 dp = {0.f, 0.f, 0.f, 0.f};
+                    mma(vf, of, dp);
+                    ds2[u] = pj[i] * (dp - d);
+                    if (active) db[i][j] += ds2[u];
+                }
+                sfr[ks] = frag_p_regs<T>(ds2[0], ds2[1]);
+            }
+            acc[j][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+            acc[j][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < NPB / 32; ++ks) {
+                const Frag<T> k0 = frag_v_perm<T>(Ks, LDQ, 0, ks, c, g);
+                const Frag<T> k1 = frag_v_perm<T>(Ks, LDQ, 16, ks, c, g);
+                mma(sfr[ks], k0, acc[j][0]);
+                mma(sfr[ks], k1, acc[j][1]);
+            }
+            __builtin_amdgcn_sched_barrier(0);  // keep the two query tiles apart (registers)
+        }
+        store_block_rows_vec<T>(acc, scale, Qs, dqkv + h * HD, 3L * C, tb.tok, tok_base, q0, N, active, nullptr, lane, c, g);
+    }
+    if (wave_ok) {
+        // frag layout of the NPB x NPB bias gradient: ((ki*NT + qj)*64 + lane)*4 + r, qj = 2*qb + j
+        float* wsp = dbias_ws + ((long)part * nH + h) * (NT * NT * 256);
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) *reinterpret_cast<f32x4*>(wsp + ((i * NT + 2 * qb + j) * 64 + lane) * 4) = db[i][j];
+    }
+}
+
+// dQ + bias gradient, fourth variant (default).  The bias gradient has to live in accumulator registers across the windows
+// a wave visits; with a 32-query strip per wave that is 112 registers and the kernel cannot run two waves per SIMD
+// (dq / dq3 above: one wave per SIMD, every load round trip exposed).  Here a workgroup is EIGHT waves and a wave owns ONE
+// query tile (16 queries): 56 bias-gradient + 56 P + 28 packed-dS registers, two waves per SIMD, while K and V are still
+// staged once per 8 (6) query tiles.  Same fragment-layout bias-gradient workspace as the first generation.
+constexpr int DQ4_WAVES = 8;
+constexpr int DQ4_GROUPS = (NT + DQ4_WAVES - 1) / DQ4_WAVES;
+
+template <typename T>
+__global__ __launch_bounds__(DQ4_WAVES * 64) void attn_big_bwd_dq4_kernel(
+    const T* __restrict__ qkv, const float* __restrict__ qkv_bias, const int* __restrict__ win2tok, int L, const T* __restrict__ dout,
+    const T* __restrict__ fout, const float* __restrict__ lse_in, const float* __restrict__ bias_frag, int ws,
+    const int* __restrict__ region_ids, int nW, int Bw, int N, int nH, float scale, int parts, T* __restrict__ dqkv,
+    float* __restrict__ dbias_ws) {
+    using Cfg = BigCfg<T>;
+    constexpr int LDQ = Cfg::LDQ, VEC = Cfg::VEC, VPR = HD / VEC;
+    constexpr int TILE = 16 * LDQ;  // one [16][LDQ] image
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const BigTables tb = carve_tables(smem_raw);
+    T* Ks = reinterpret_cast<T*>(smem_raw + Cfg::TABLE_BYTES);
+    T* Vs = Ks + Cfg::FULL;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 15, g = lane >> 4;
+    T* Qs = Vs + Cfg::FULL + wave * (3 * TILE);
+    T* Os = Qs + TILE;  // dO rows of this wave's queries
+    T* Fs = Os + TILE;  // forward output rows
+
+    const int grp = blockIdx.x % DQ4_GROUPS;
+    const int ph = blockIdx.x / DQ4_GROUPS;  // (part, h)
+    const int h = ph % nH, part = ph / nH;
+    const int qt = grp * DQ4_WAVES + wave;   // query tile of this wave
+    const bool wave_ok = qt < NT;
+    const int q0 = wave_ok ? 16 * qt : 0;
+    const int C = nH * HD;
+    const bool masked = region_ids != nullptr;
+    const T* src = qkv + h * HD;
+    const float* bias_h = bias_frag + (long)h * (NT * NT * 256);
+
+    f32x4 db[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) db[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int iters = (Bw + parts - 1) / parts;
+    for (int it = 0; it < iters; ++it) {
+        const int bw = part + it * parts;
+        const bool win_ok = bw < Bw;
+        const int bwc = win_ok ? bw : 0;
+        const bool active = win_ok && wave_ok;
+        const long tok_base = (long)(bwc / nW) * L;
+        __syncthreads();  // previous window's reads are complete
+        load_window_tables(tb, win2tok, region_ids, bwc % nW, N, ws, win_ok);
+        __syncthreads();
+        float lq;
+        {
+            SlotStage<T, NPB, DQ4_WAVES * 64> sk, sv;
+            SlotStage<T, 16, 64> sq, so, sf;
+            sk.load(src + C, 3L * C, tb.tok, tok_base, 0, N, qkv_bias + C + h * HD, threadIdx.x);
+            sv.load(src + 2 * C, 3L * C, tb.tok, tok_base, 0, N, qkv_bias + 2 * C + h * HD, threadIdx.x);
+            sq.load(src, 3L * C, tb.tok, tok_base, q0, N, qkv_bias + h * HD, lane);
+            so.load(dout + h * HD, (long)C, tb.tok, tok_base, q0, N, nullptr, lane);
+            sf.load(fout + h * HD, (long)C, tb.tok, tok_base, q0, N, nullptr, lane);
+            lq = lse_in[((long)bwc * nH + h) * NPB + q0 + c];
+            sk.store(Ks, 1.f, threadIdx.x);
+            sv.store(Vs, 1.f, threadIdx.x);
+            sq.store(Qs, scale, lane);
+            so.store(Os, 1.f, lane);
+            sf.store(Fs, 1.f, lane);
+        }
+        __syncthreads();
+        const Frag<T> qf = frag_kc<T>(Qs, LDQ, 0, 0, c, g);
+        const Frag<T> of = frag_kc<T>(Os, LDQ, 0, 0, c, g);
+        const int rq = masked ? ((tb.pk[q0 + c] >> 16) & 0xff) : 0;
+        float d = 0.f;
+        {
+            const Frag<T> ff = frag_kc<T>(Fs, LDQ, 0, 0, c, g);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) d += (float)of.v[e] * (float)ff.v[e];
+            d += __shfl_xor(d, 16, 64);
+            d += __shfl_xor(d, 32, 64);
+        }
+        // P^T tiles of this query tile (rows = keys) from the saved log-sum-exp
+        f32x4 pj[NT];
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            const Frag<T> kf = frag_kc<T>(Ks, LDQ, 16 * i, 0, c, g);
+            f32x4 b = *reinterpret_cast<const f32x4*>(bias_h + ((i * NT + (q0 >> 4)) * 64 + lane) * 4);
+            if (masked) {
+                const i32x4 pk4 = *reinterpret_cast<const i32x4*>(tb.pk + 16 * i + 4 * g);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) b[r] += (((pk4[r] >> 16) & 0xff) != rq) ? -100.f : 0.f;
+            }
+            mma(kf, qf, b);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) b[r] = __expf(b[r] - lq);
+            pj[i] = b;
+        }
+        // dP^T = V dO^T, dS = P o (dP - delta): accumulate the bias gradient, pack dS for the dQ product
+        Frag<T> sfr[NPB / 32];
+#pragma unroll
+        for (int ks = 0; ks < NPB / 32; ++ks) {
+            f32x4 ds2[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int i = 2 * ks + u;
+                const Frag<T> vf = frag_kc<T>(Vs, LDQ, 16 * i, 0, c, g);
+                f32x4 dp = {0.f, 0.f, 0.f, 0.f};
+                mma(vf, of, dp);
+                ds2[u] = pj[i] * (dp - d);
+                if (active) db[i] += ds2[u];
+            }
+            sfr[ks] = frag_p_regs<T>(ds2[0], ds2[1]);
+        }
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < NPB / 32; ++ks) {
+            const Frag<T> k0 = frag_v_perm<T>(Ks, LDQ, 0, ks, c, g);
+            const Frag<T> k1 = frag_v_perm<T>(Ks, LDQ, 16, ks, c, g);
+            mma(sfr[ks], k0, acc0);
+            mma(sfr[ks], k1, acc1);
+        }
+        // dQ rows: transpose through the wave's Q image, one 16-byte row piece per lane
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            Qs[(4 * g + r) * LDQ + c] = from_f32<T>(acc0[r] * scale);
+            Qs[(4 * g + r) * LDQ + 16 + c] = from_f32<T>(acc1[r] * scale);
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int i = 0; i < (16 * VPR + 63) / 64; ++i) {
+            const int v = lane + 64 * i;
+            const int rl = v / VPR, dv = v % VPR;
+            const int t = q0 + rl;
+            if (v < 16 * VPR && active && t < N) {
+                const int tok = tb.tok[t];
+                if (tok >= 0) st16<T>(dqkv + h * HD + (tok_base + tok) * 3L * C + dv * VEC, ld16<T>(Qs + rl * LDQ + dv * VEC));
+            }
+        }
+    }
+    if (wave_ok) {
+        // frag layout of the NPB x NPB bias gradient: ((ki*NT + qj)*64 + lane)*4 + r
+        float* wsp = dbias_ws + ((long)part * nH + h) * (NT * NT * 256);
+#pragma unroll
+        for (int i = 0; i < NT; ++i) *reinterpret_cast<f32x4*>(wsp + ((i * NT + qt) * 64 + lane) * 4) = db[i];
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(BigCfg<T>::WAVES * 64, sizeof(T) == 2 ? 2 : 1) void attn_big_bwd_dkv2_kernel(
     const T* __restrict__ qkv, const float* __restrict__ qkv_bias, const int* __restrict__ win2tok, int L, const T* __restrict__ dout,
@@ -1259,6 +1545,11 @@ size_t fwd2_lds() {
     return Cfg::TABLE_BYTES + (size_t)(2 * Cfg::FULL + Cfg::WAVES * Cfg::BLK) * sizeof(T);
 }
 template <typename T>
+size_t dq4_lds() {
+    using Cfg = BigCfg<T>;
+    return Cfg::TABLE_BYTES + (size_t)(2 * Cfg::FULL + DQ4_WAVES * 3 * 16 * Cfg::LDQ) * sizeof(T);
+}
+template <typename T>
 size_t dq2_lds() {
     using Cfg = BigCfg<T>;
     return Cfg::TABLE_BYTES + (size_t)(2 * Cfg::FULL + Cfg::WAVES * 3 * Cfg::BLK) * sizeof(T) + DTAB * sizeof(float);
@@ -1280,7 +1571,7 @@ size_t dkv_lds() {
 }
 
 int g_big_fwd_impl = 2;  // 1: first generation (P through LDS, one workgroup per CU); 2: P in registers, two per CU
-int g_big_bwd_impl = 3;     // 1: first generation (dS / P^T through LDS, fragment-layout bias gradient in registers); 2: dq2 + dkv2 (bias gradient
+int g_big_bwd_impl = 5;     // 1: first generation (dS / P^T through LDS, fragment-layout bias gradient in registers); 2: dq2 + dkv2 (bias gradient
                             // by LDS atomics: measured 3x slower than 1's dQ -- the LDS atomic unit is the bottleneck); 3 (default): 1's dQ + dkv2
 int g_big_bwd_dtype = ESVIT_BF16;  // dtype of the last backward launch (selects the workspace layout the bias-gradient reduce reads)
 
@@ -1362,8 +1653,22 @@ static int big_bwd_launch(const void* qkv, const float* qkv_bias, const int32_t*
     using Cfg = BigCfg<T>;
     constexpr int GROUPS = (NQB + Cfg::WAVES - 1) / Cfg::WAVES;
     const int parts = big_parts(Bw, nH);
-    if (g_big_bwd_impl == 3) {  // default: first-generation dQ (bias gradient in registers), second-generation dK / dV
-        {
+    if (g_big_bwd_impl >= 3) {  // 5 (default): dq4 + dkv2; 3: dq3 + dkv2; 4: first-generation dQ + dkv2
+        if (g_big_bwd_impl == 5) {
+            auto kern = attn_big_bwd_dq4_kernel<T>;
+            const size_t lds = dq4_lds<T>();
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(kern, dim3(parts * nH * DQ4_GROUPS), dim3(DQ4_WAVES * 64), lds, stream, (const T*)qkv, qkv_bias, win2tok, L,
+                               (const T*)dout, (const T*)fout, lse, rel_table, ws, region_ids, nW, Bw, N, nH, scale, parts, (T*)dqkv, dbias_ws);
+            ESVIT_CHECK_LAUNCH("window_attn_bwd(14x14, dQ, gen 4)");
+        } else if (g_big_bwd_impl == 3) {
+            auto kern = attn_big_bwd_dq3_kernel<T>;
+            const size_t lds = dq2_lds<T>();
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(kern, dim3(parts * nH * GROUPS), dim3(Cfg::WAVES * 64), lds, stream, (const T*)qkv, qkv_bias, win2tok, L,
+                               (const T*)dout, (const T*)fout, lse, rel_table, ws, region_ids, nW, Bw, N, nH, scale, parts, (T*)dqkv, dbias_ws);
+            ESVIT_CHECK_LAUNCH("window_attn_bwd(14x14, dQ, gen 3)");
+        } else {
             auto kern = attn_big_bwd_dq_kernel<T, TR>;
             const size_t lds = dq_lds<T>();
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
