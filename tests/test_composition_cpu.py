@@ -89,6 +89,48 @@ def test_ragged_multi_crop_equals_reference_schedule(cpu_ops):
     check_ragged_equals_reference_schedule(L)
 
 
+def check_odd_batches_vs_oracle(loss_mod, dev="cpu", window=None, tol=2e-4, gtol=5e-3):
+    """per-GPU batches that are not multiples of anything (B = 1, 3): outputs, loss and gradient norms of the nano model vs the
+    CPU oracle on the same weights -- exercises the split-K / workgroup sizing and the ragged row matrix away from round sizes"""
+    from oracle import esvit_oracle as O
+    cfg = dict(GU.NANO14 if window == 14 else GU.NANO)
+    K = GU.NANO_HEAD["out_dim"]
+    for B in (1, 3):
+        student, teacher = nano_pair(window=window)
+        sd = {k: v.clone() for k, v in student.state_dict().items()}
+        tsd = {k: v.clone() for k, v in teacher.state_dict().items()}
+        crops = GU.make_crops(B, seed=40 + B)
+        names = [n for n, p in student.named_parameters() if p.requires_grad]
+        leaf = {n: sd[n].clone().requires_grad_(True) for n in names}
+        full = dict(sd)
+        full.update(leaf)
+        s_ref = O.swin_multicrop(full, crops, cfg)
+        with torch.no_grad():
+            t_ref = O.swin_multicrop(tsd, crops[:2], cfg)
+        c0 = torch.zeros(1, K)
+        l_ref, _, _ = O.ddino_loss(s_ref, t_ref, c0, c0, O.teacher_temp(0, 0.04, 0.04, 0, 1), 10)
+        l_ref.backward()
+        student, teacher = student.to(dev), teacher.to(dev)
+        loss_fn = loss_mod.DDINOLoss(K, 10, 0.04, 0.04, 0, 1).to(dev)
+        dcrops = [c.to(dev) for c in crops]
+        t_out = teacher(dcrops[:2])
+        s_out = student(dcrops)
+        loss = loss_fn(s_out, t_out, 0, None)
+        loss.backward()
+        for a, b in zip(s_out[:3], s_ref[:3]):
+            assert ((a.float().cpu() - b).abs().max() / (b.abs().max() + 1e-12)).item() < tol, B
+        assert abs(loss.item() - l_ref.item()) < tol, (B, loss.item(), l_ref.item())
+        for n, p in student.named_parameters():
+            if p.requires_grad:
+                ref = leaf[n].grad.norm().item()
+                assert abs(p.grad.norm().item() - ref) <= gtol * (ref + 1e-6), (B, n, p.grad.norm().item(), ref)
+
+
+def test_odd_batches_match_oracle(cpu_ops):
+    import esvit_amd.loss as L
+    check_odd_batches_vs_oracle(L)
+
+
 def test_state_dict_layout_matches_golden():
     nano = torch.load(os.path.join(GOLD, "nano_step.pt"), weights_only=False)
     m = build_nano()

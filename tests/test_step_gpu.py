@@ -7,7 +7,7 @@ import torch
 
 from oracle import esvit_oracle as O
 from tests import golden_utils as GU
-from tests.test_composition_cpu import (build_nano, check_nano14, check_nano_cvt, check_ragged_equals_reference_schedule, nano_cvt_pair, nano_pair, run_nano14_step,
+from tests.test_composition_cpu import (build_nano, check_nano14, check_nano_cvt, check_odd_batches_vs_oracle, check_ragged_equals_reference_schedule, nano_cvt_pair, nano_pair, run_nano14_step,
                                         run_nano_cvt_step, run_nano_step)
 from tests.test_oracle_cpu import GOLD, probe_close
 
@@ -92,6 +92,17 @@ def test_nano_fused_update_matches_reference_golden(nano, lib_built):
             probe_close("student_after " + n, p.detach().cpu(), nano["student_after"][n], rtol=2e-4)
         for n, p in teacher.named_parameters():
             probe_close("teacher_after " + n, p.detach().cpu(), nano["teacher_after"][n], rtol=2e-4)
+    finally:
+        _teardown()
+
+
+@pytest.mark.parametrize("window", [7, 14])
+def test_odd_batches_match_oracle_gpu(window, lib_built):
+    """B = 1 and B = 3 through the HIP path (fp32 precision mode), 7x7 and 14x14 windows, vs the CPU oracle"""
+    import esvit_amd.loss as L
+    dev = _setup("fp32")
+    try:
+        check_odd_batches_vs_oracle(L, dev, window=window, tol=5e-4, gtol=1e-2)
     finally:
         _teardown()
 
