@@ -201,7 +201,7 @@ def main():
         if os.environ.get(var):  # kernel A/B switches for profiling runs; defaults are the shipped configuration
             getattr(ops.lib, setter)(int(os.environ[var]))
     if os.environ.get("ESVIT_BIG_ATTN_BWD"):
-        ops.lib.esvit_debug_set_big_attn_impl(2, int(os.environ["ESVIT_BIG_ATTN_BWD"]))
+        ops.lib.esvit_debug_set_big_attn_impl(int(os.environ.get("ESVIT_BIG_ATTN_FWD", "3")), int(os.environ["ESVIT_BIG_ATTN_BWD"]))
     torch.manual_seed(0)
     student, teacher, loss_fn = build(dev, args.drop_path, args.arch)
     trainer = EsvitTrainer(student, teacher, loss_fn, clip_grad=3.0, freeze_last_layer=1)

@@ -24,6 +24,7 @@ constexpr int NT = 14;         // 16-wide tiles per window side
 constexpr int NPB = NT * 16;   // 224 padded tokens
 constexpr int NQB = NPB / 32;  // 7 blocks of 32 queries / keys
 constexpr int TAB_FLOATS = 768;
+typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 template <typename T>
 struct BigCfg {
@@ -551,6 +552,136 @@ __global__ __launch_bounds__(BigCfg<T>::WAVES * 64, 2) void attn_big_fwd2_kernel
     }
 }
 
+// forward, third variant (default): the second generation with ONE 16-query tile per wave and pass.  A workgroup is seven
+// waves, wave w takes query tiles w and w + 7 (no idle wave in the second pass, the 32-query blocks left one of four idle);
+// the score strip is 56 registers instead of 112, so the kernel fits four waves per SIMD and two workgroups (14 waves) share
+// a CU -- the second generation's SQ counters still showed 59 % of the wave cycles parked on loads with two waves per SIMD.
+constexpr int FWD3_WAVES = 7;
+
+template <typename T, bool WANT_ATTN>
+__global__ __launch_bounds__(FWD3_WAVES * 64, sizeof(T) == 2 ? 4 : 1) void attn_big_fwd3_kernel(
+    const T* __restrict__ qkv, const float* __restrict__ qkv_bias, const int* __restrict__ win2tok, int L,
+    const float* __restrict__ bias_frag, int ws, const int* __restrict__ region_ids, int nW, int Bw, int N, int nH,
+    float scale, T* __restrict__ out, float* __restrict__ lse_out, float* __restrict__ attn_out) {
+    using Cfg = BigCfg<T>;
+    constexpr int LDQ = Cfg::LDQ, VEC = Cfg::VEC, VPR = HD / VEC;
+    constexpr int TILE = 16 * LDQ;
+    static_assert(NT == 2 * FWD3_WAVES, "two query tiles per wave");
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const BigTables tb = carve_tables(smem_raw);
+    T* Ks = reinterpret_cast<T*>(smem_raw + Cfg::TABLE_BYTES);
+    T* Vs = Ks + Cfg::FULL;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 15, g = lane >> 4;
+    T* Qs = Vs + Cfg::FULL + wave * TILE;  // this wave's [16][LDQ] image: Q tile, then the output transpose
+
+    const int unit = blockIdx.x;  // (bw, h)
+    const int bw = unit / nH, h = unit % nH;
+    const int C = nH * HD;
+    const long tok_base = (long)(bw / nW) * L;
+    const T* src = qkv + h * HD;
+    const bool masked = region_ids != nullptr;
+    const float* bias_h = bias_frag + (long)h * (NT * NT * 256);
+
+    load_window_tables(tb, win2tok, region_ids, bw % nW, N, ws, true);
+    __syncthreads();
+    SlotStage<T, 16, 64> sq;
+    {
+        SlotStage<T, NPB, FWD3_WAVES * 64> sk, sv;
+        sk.load(src + C, 3L * C, tb.tok, tok_base, 0, N, qkv_bias + C + h * HD, threadIdx.x);
+        sv.load(src + 2 * C, 3L * C, tb.tok, tok_base, 0, N, qkv_bias + 2 * C + h * HD, threadIdx.x);
+        sq.load(src, 3L * C, tb.tok, tok_base, 16 * wave, N, qkv_bias + h * HD, lane);
+        sk.store(Ks, 1.f, threadIdx.x);
+        sv.store(Vs, 1.f, threadIdx.x);
+        sq.store(Qs, scale, lane);
+    }
+    __syncthreads();  // K, V complete (whole workgroup); everything below is private to the wave
+
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        const int q0 = 16 * (wave + pass * FWD3_WAVES);
+        if (pass > 0) {
+            __builtin_amdgcn_wave_barrier();
+            sq.store(Qs, scale, lane);
+            __builtin_amdgcn_wave_barrier();
+        }
+        const Frag<T> qf = frag_kc<T>(Qs, LDQ, 0, 0, c, g);
+        if (pass == 0) sq.load(src, 3L * C, tb.tok, tok_base, 16 * (wave + FWD3_WAVES), N, qkv_bias + h * HD, lane);
+        const int rq = masked ? ((tb.pk[q0 + c] >> 16) & 0xff) : 0;
+        f32x4 p[NT];
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            const Frag<T> kf = frag_kc<T>(Ks, LDQ, 16 * i, 0, c, g);
+            f32x4 b = *reinterpret_cast<const f32x4*>(bias_h + ((i * NT + (q0 >> 4)) * 64 + lane) * 4);
+            if (masked) {
+                const i32x4 pk4 = *reinterpret_cast<const i32x4*>(tb.pk + 16 * i + 4 * g);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) b[r] += (((pk4[r] >> 16) & 0xff) != rq) ? -100.f : 0.f;
+            }
+            p[i] = b;
+            mma(kf, qf, p[i]);
+        }
+        float m = -3.0e38f;
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) m = fmaxf(m, p[i][r]);
+        m = fmaxf(m, __shfl_xor(m, 16, 64));
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float e = __expf(p[i][r] - m);
+                p[i][r] = e;
+                sum += e;
+            }
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        const float inv = 1.f / sum;
+#pragma unroll
+        for (int i = 0; i < NT; ++i) p[i] *= inv;
+        if (g == 0 && lse_out) lse_out[(long)unit * NPB + q0 + c] = m + __logf(sum);
+        if constexpr (WANT_ATTN) {
+#pragma unroll
+            for (int i = 0; i < NT; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int q = q0 + c, key = 16 * i + 4 * g + r;
+                    if (q < N && key < N) attn_out[((long)unit * N + q) * N + key] = p[i][r];
+                }
+        }
+        f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < NPB / 32; ++ks) {
+            const Frag<T> v0 = frag_v_perm<T>(Vs, LDQ, 0, ks, c, g);
+            const Frag<T> v1 = frag_v_perm<T>(Vs, LDQ, 16, ks, c, g);
+            const Frag<T> pf = frag_p_regs<T>(p[2 * ks], p[2 * ks + 1]);
+            mma(pf, v0, o0);
+            mma(pf, v1, o1);
+        }
+        // output rows: transpose through the wave's Q image, one 16-byte row piece per lane
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            Qs[(4 * g + r) * LDQ + c] = from_f32<T>(o0[r]);
+            Qs[(4 * g + r) * LDQ + 16 + c] = from_f32<T>(o1[r]);
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int i = 0; i < (16 * VPR + 63) / 64; ++i) {
+            const int v = lane + 64 * i;
+            const int rl = v / VPR, dv = v % VPR;
+            const int t = q0 + rl;
+            if (v < 16 * VPR && t < N) {
+                const int tok = tb.tok[t];
+                if (tok >= 0) st16<T>(out + h * HD + (tok_base + tok) * (long)C + dv * VEC, ld16<T>(Qs + rl * LDQ + dv * VEC));
+            }
+        }
+    }
+}
+
 // -------------------------------------------------------------------------------------------------------------
 // backward, part 1: dQ and the relative-position-bias gradient.  grid = parts * nH * GROUPS workgroups; wave `wave` of
 // group `grp` owns query block qb = grp * WAVES + wave for every window bw = part + k * parts.
@@ -894,7 +1025,6 @@ __global__ __launch_bounds__(BigCfg<T>::WAVES * 64) void attn_big_bwd_dkv_kernel
 //     spilled; this one fits two waves per SIMD.  One table per workgroup goes to the workspace; the partial tables are
 //     summed by big_dtable_reduce_kernel (no 200-KB fragment slabs, no index scatter).
 // -------------------------------------------------------------------------------------------------------------
-typedef int i32x4 __attribute__((ext_vector_type(4)));
 constexpr int DTAB = 768;  // >= (2*14-1)^2 = 729
 
 template <typename T>
@@ -1540,6 +1670,11 @@ size_t fwd_lds() {
     return Cfg::TABLE_BYTES + (size_t)(2 * Cfg::FULL + Cfg::WAVES * (Cfg::BLK + Cfg::PIMG)) * sizeof(T);
 }
 template <typename T>
+size_t fwd3_lds() {
+    using Cfg = BigCfg<T>;
+    return Cfg::TABLE_BYTES + (size_t)(2 * Cfg::FULL + FWD3_WAVES * 16 * Cfg::LDQ) * sizeof(T);
+}
+template <typename T>
 size_t fwd2_lds() {
     using Cfg = BigCfg<T>;
     return Cfg::TABLE_BYTES + (size_t)(2 * Cfg::FULL + Cfg::WAVES * Cfg::BLK) * sizeof(T);
@@ -1570,7 +1705,7 @@ size_t dkv_lds() {
     return Cfg::TABLE_BYTES + (size_t)(2 * Cfg::FULL + Cfg::WAVES * (2 * Cfg::BLK + Cfg::FULL)) * sizeof(T);
 }
 
-int g_big_fwd_impl = 2;  // 1: first generation (P through LDS, one workgroup per CU); 2: P in registers, two per CU
+int g_big_fwd_impl = 3;  // 1: first generation (P through LDS, one workgroup per CU); 2: P in registers, 32-query blocks; 3: 16-query tiles, 7 waves
 int g_big_bwd_impl = 5;     // 1: first generation (dS / P^T through LDS, fragment-layout bias gradient in registers); 2: dq2 + dkv2 (bias gradient
                             // by LDS atomics: measured 3x slower than 1's dQ -- the LDS atomic unit is the bottleneck); 3 (default): 1's dQ + dkv2
 int g_big_bwd_dtype = ESVIT_BF16;  // dtype of the last backward launch (selects the workspace layout the bias-gradient reduce reads)
@@ -1605,6 +1740,22 @@ template <typename T>
 static int big_fwd_launch(const void* qkv, const float* qkv_bias, const int32_t* win2tok, int L, const float* rel_table, int rel_rows, int ws,
                           const int32_t* region_ids, int nW, int Bw, int N, int nH, float scale, void* out, float* lse, float* attn_out,
                           hipStream_t stream) {
+    if (g_big_fwd_impl == 3) {
+        const size_t lds = fwd3_lds<T>();
+        if (attn_out) {
+            auto kern = attn_big_fwd3_kernel<T, true>;
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(kern, dim3(Bw * nH), dim3(FWD3_WAVES * 64), lds, stream, (const T*)qkv, qkv_bias, win2tok, L, rel_table, ws,
+                               region_ids, nW, Bw, N, nH, scale, (T*)out, lse, attn_out);
+        } else {
+            auto kern = attn_big_fwd3_kernel<T, false>;
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(kern, dim3(Bw * nH), dim3(FWD3_WAVES * 64), lds, stream, (const T*)qkv, qkv_bias, win2tok, L, rel_table, ws,
+                               region_ids, nW, Bw, N, nH, scale, (T*)out, lse, attn_out);
+        }
+        ESVIT_CHECK_LAUNCH("window_attn_fwd(14x14, gen 3)");
+        return ESVIT_OK;
+    }
     if (g_big_fwd_impl == 2) {
         const size_t lds = fwd2_lds<T>();
         if (attn_out) {

@@ -355,25 +355,25 @@ def test_window_attention(mods, dt, ws, nH, H, shift, hd):
     _close("attn out", o, orf, _tol(dt, f32=5e-5, bf=2e-2))
     if ws == 14:  # both generations of the 14x14 forward, training variant (no probabilities written)
         try:
-            for impl in (1, 2):
+            for impl in (1, 2, 3):
                 ops.lib.esvit_debug_set_big_attn_impl(impl, 5)
                 res = ops.window_attn_fwd(qkv, qb, w2t, L, table, ws, mask_frag, nW, N, nH, scale)
                 _close("attn out (14x14 gen %d)" % impl, res[0], orf, _tol(dt, f32=5e-5, bf=2e-2))
                 _close("attn lse (14x14 gen %d)" % impl, res[1], lse, _tol(dt, f32=5e-5, bf=2e-2))
         finally:
-            ops.lib.esvit_debug_set_big_attn_impl(2, 5)
+            ops.lib.esvit_debug_set_big_attn_impl(3, 5)
     dout = _rand((nB * L, C), dev, 52, dt)
     # (transpose-read on / off) x (for 14x14 windows: both generations of the backward kernels)
     variants = [(1, 5), (0, 5), (1, 3), (1, 4), (1, 2), (1, 1), (0, 1)] if ws == 14 else [(1, 5), (0, 5)]
     for tr, big_bwd in variants:
         ops.debug_set_tr_read(tr)
-        ops.lib.esvit_debug_set_big_attn_impl(2, big_bwd)
+        ops.lib.esvit_debug_set_big_attn_impl(3, big_bwd)
         try:
             dqkv, ws_, pad_ = ops.window_attn_bwd(qkv, qb, w2t, L, dout, orf, lse, table, ws, mask_frag, nW, N, nH, scale)
             dt_ = ops.relpos_bias_bwd(ws_, index, N, trows)
         finally:
             ops.debug_set_tr_read(1)
-            ops.lib.esvit_debug_set_big_attn_impl(2, 5)
+            ops.lib.esvit_debug_set_big_attn_impl(3, 5)
         dqkvr, wsr, padr = ref.window_attn_bwd(qkv, qb, w2t, L, dout, orf, lse, table, ws, mask_frag, nW, N, nH, scale)
         for i, nm in enumerate("qkv"):
             _close("attn d%s tr=%d" % (nm, tr), dqkv.view(-1, 3, C)[:, i], dqkvr.view(-1, 3, C)[:, i], _tol(dt, f32=1e-4, bf=3e-2))
