@@ -1642,6 +1642,192 @@ __global__ __launch_bounds__(BigCfg<T>::WAVES * 64, sizeof(T) == 2 ? 2 : 1) void
     }
 }
 
+// dK / dV, third variant (default): dkv2 with ONE 16-key tile per wave and pass, seven waves per workgroup (wave w takes
+// key tiles w and w + 7): a 56-register P / dS strip instead of 112, four waves per SIMD, two workgroups per CU.
+template <typename T>
+__global__ __launch_bounds__(FWD3_WAVES * 64, sizeof(T) == 2 ? 4 : 1) void attn_big_bwd_dkv3_kernel(
+    const T* __restrict__ qkv, const float* __restrict__ qkv_bias, const int* __restrict__ win2tok, int L, const T* __restrict__ dout,
+    const T* __restrict__ fout, const float* __restrict__ lse_in, const float* __restrict__ bias_frag_s, int ws,
+    const int* __restrict__ region_ids, int nW, int Bw, int N, int nH, float scale, T* __restrict__ dqkv, float* __restrict__ dpad_ws) {
+    using Cfg = BigCfg<T>;
+    constexpr int LDQ = Cfg::LDQ, VEC = Cfg::VEC, VPR = HD / VEC, WAVES = FWD3_WAVES;
+    constexpr int TILE = 16 * LDQ;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const BigTables tb = carve_tables(smem_raw);
+    T* Qs = reinterpret_cast<T*>(smem_raw + Cfg::TABLE_BYTES);  // scale*Q, [224][LDQ]
+    T* Os = Qs + Cfg::FULL;                                      // dO,      [224][LDQ]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 15, g = lane >> 4;
+    T* Kb = Os + Cfg::FULL + wave * (2 * TILE);
+    T* Vb = Kb + TILE;
+
+    const int unit = blockIdx.x;
+    const int bw = unit / nH, h = unit % nH;
+    const int C = nH * HD;
+    const long tok_base = (long)(bw / nW) * L;
+    const T* src = qkv + h * HD;
+    const bool masked = region_ids != nullptr;
+    const float* bias_h = bias_frag_s + (long)h * (NT * NT * 256);
+
+    load_window_tables(tb, win2tok, region_ids, bw % nW, N, ws, true);
+    __syncthreads();
+    SlotStage<T, 16, 64> sk, sv;
+    {
+        SlotStage<T, NPB, WAVES * 64> sq, so;
+        sq.load(src, 3L * C, tb.tok, tok_base, 0, N, qkv_bias + h * HD, threadIdx.x);
+        so.load(dout + h * HD, (long)C, tb.tok, tok_base, 0, N, nullptr, threadIdx.x);
+        sk.load(src + C, 3L * C, tb.tok, tok_base, 16 * wave, N, qkv_bias + C + h * HD, lane);
+        sv.load(src + 2 * C, 3L * C, tb.tok, tok_base, 16 * wave, N, qkv_bias + 2 * C + h * HD, lane);
+        // per-query statistics: saved log-sum-exp and delta = sum_d dO[q,d] * O[q,d]
+        for (int t = threadIdx.x; t < NPB; t += WAVES * 64) {
+            float l = 0.f, d = 0.f;
+            if (t < N) {
+                l = lse_in[(long)unit * NPB + t];
+                const int tok = tb.tok[t];
+                if (tok >= 0) {
+                    const T* orow = fout + (tok_base + tok) * (long)C + h * HD;
+                    const T* grow = dout + (tok_base + tok) * (long)C + h * HD;
+#pragma unroll
+                    for (int vv = 0; vv < HD / VEC; ++vv) {
+                        const Vec16<T> ov = ld16<T>(orow + vv * VEC), gv = ld16<T>(grow + vv * VEC);
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e) d += ov.get(e) * gv.get(e);
+                    }
+                }
+            }
+            tb.lse[t] = l;
+            tb.delta[t] = d;
+        }
+        sq.store(Qs, scale, threadIdx.x);
+        so.store(Os, 1.f, threadIdx.x);
+        sk.store(Kb, 1.f, lane);
+        sv.store(Vb, 1.f, lane);
+    }
+    float padk[VEC], padv[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) padk[e] = padv[e] = 0.f;
+    __syncthreads();  // Q, dO, lse, delta staged by the whole workgroup; Kb / Vb are private to the wave
+
+    // one [16 keys][32 d] result (rows 4g + r, columns c / 16 + c) to token rows through the wave's K image; pad rows -> pad sums
+    auto store_tile = [&](const f32x4& a0, const f32x4& a1, T* dst, int k0, float* padacc) {
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            Kb[(4 * g + r) * LDQ + c] = from_f32<T>(a0[r]);
+            Kb[(4 * g + r) * LDQ + 16 + c] = from_f32<T>(a1[r]);
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int i = 0; i < (16 * VPR + 63) / 64; ++i) {
+            const int v = lane + 64 * i;
+            const int rl = v / VPR, dv = v % VPR;
+            const int t = k0 + rl;
+            if (v < 16 * VPR && t < N) {
+                const int tok = tb.tok[t];
+                const Vec16<T> x = ld16<T>(Kb + rl * LDQ + dv * VEC);
+                if (tok >= 0) {
+                    st16<T>(dst + (tok_base + tok) * 3L * C + dv * VEC, x);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) padacc[e] += x.get(e);
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    };
+
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        const int k0 = 16 * (wave + pass * WAVES);
+        if (pass > 0) {
+            __builtin_amdgcn_wave_barrier();
+            sk.store(Kb, 1.f, lane);
+            sv.store(Vb, 1.f, lane);
+            __builtin_amdgcn_wave_barrier();
+        }
+        const Frag<T> kf = frag_kc<T>(Kb, LDQ, 0, 0, c, g);
+        const Frag<T> vf = frag_kc<T>(Vb, LDQ, 0, 0, c, g);
+        if (pass == 0) {  // the second key tile's rows travel while the first is computed
+            sk.load(src + C, 3L * C, tb.tok, tok_base, 16 * (wave + WAVES), N, qkv_bias + C + h * HD, lane);
+            sv.load(src + 2 * C, 3L * C, tb.tok, tok_base, 16 * (wave + WAVES), N, qkv_bias + 2 * C + h * HD, lane);
+        }
+        const int rkey = masked ? ((tb.pk[k0 + c] >> 16) & 0xff) : 0;
+        // P tile column, oriented S: rows = queries (14 tiles), columns = this wave's 16 keys
+        f32x4 p[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) p[j] = *reinterpret_cast<const f32x4*>(bias_h + ((j * NT + (k0 >> 4)) * 64 + lane) * 4);
+        __builtin_amdgcn_sched_barrier(0);  // all bias tiles requested; the LDS operands below are read tile by tile (registers)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const Frag<T> qf = frag_kc<T>(Qs, LDQ, 16 * j, 0, c, g);
+            const f32x4 l4 = *reinterpret_cast<const f32x4*>(tb.lse + 16 * j + 4 * g);
+            f32x4 b = p[j];
+            if (masked) {
+                const i32x4 pk4 = *reinterpret_cast<const i32x4*>(tb.pk + 16 * j + 4 * g);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) b[r] += (((pk4[r] >> 16) & 0xff) != rkey) ? -100.f : 0.f;
+            }
+            mma(qf, kf, b);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) b[r] = (16 * j + 4 * g + r < N) ? __expf(b[r] - l4[r]) : 0.f;  // padded queries carry no gradient
+            p[j] = b;
+            if (j & 1) __builtin_amdgcn_sched_barrier(0);
+        }
+        // dV[key][d] = sum_q P[q][key] dO[q][d]
+        {
+            f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < NPB / 32; ++ks) {
+                const Frag<T> o0 = frag_v_perm<T>(Os, LDQ, 0, ks, c, g);
+                const Frag<T> o1 = frag_v_perm<T>(Os, LDQ, 16, ks, c, g);
+                const Frag<T> pf = frag_p_regs<T>(p[2 * ks], p[2 * ks + 1]);
+                mma(pf, o0, a0);
+                mma(pf, o1, a1);
+            }
+            store_tile(a0, a1, dqkv + 2 * C + h * HD, k0, padv);
+        }
+        // dS = P o (dP - delta), dP[q][key] = sum_d dO[q][d] V[key][d]; dS overwrites P
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const Frag<T> of = frag_kc<T>(Os, LDQ, 16 * j, 0, c, g);
+            const f32x4 dl4 = *reinterpret_cast<const f32x4*>(tb.delta + 16 * j + 4 * g);
+            f32x4 dp = {0.f, 0.f, 0.f, 0.f};
+            mma(of, vf, dp);
+            p[j] = p[j] * (dp - dl4);
+            if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        }
+        // dK[key][d] = sum_q dS[q][key] (scale q)[q][d]
+        {
+            f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < NPB / 32; ++ks) {
+                const Frag<T> q0f = frag_v_perm<T>(Qs, LDQ, 0, ks, c, g);
+                const Frag<T> q1f = frag_v_perm<T>(Qs, LDQ, 16, ks, c, g);
+                const Frag<T> sf = frag_p_regs<T>(p[2 * ks], p[2 * ks + 1]);
+                mma(sf, q0f, a0);
+                mma(sf, q1f, a1);
+            }
+            store_tile(a0, a1, dqkv + C + h * HD, k0, padk);
+        }
+    }
+    // lanes with equal dv = lane % VPR hold partial sums of the same VEC columns
+#pragma unroll
+    for (int e = 0; e < VEC; ++e)
+#pragma unroll
+        for (int o = VPR; o < 64; o <<= 1) {
+            padk[e] += __shfl_xor(padk[e], o, 64);
+            padv[e] += __shfl_xor(padv[e], o, 64);
+        }
+    if (lane < VPR) {  // one slab row per (unit, wave): [k | v][nH][hd]
+        float* pw = dpad_ws + ((long)unit * WAVES + wave) * 2 * C + h * HD + lane * VEC;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            pw[e] = padk[e];
+            pw[C + e] = padv[e];
+        }
+    }
+}
+
 // dtable[row][h] = sum over the workgroups' partial tables [nparts][nH][DTAB]
 __global__ void big_dtable_reduce_kernel(const float* __restrict__ ws, int nparts, int nH, int rows, float* __restrict__ dtable) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1668,6 +1854,11 @@ template <typename T>
 size_t fwd_lds() {
     using Cfg = BigCfg<T>;
     return Cfg::TABLE_BYTES + (size_t)(2 * Cfg::FULL + Cfg::WAVES * (Cfg::BLK + Cfg::PIMG)) * sizeof(T);
+}
+template <typename T>
+size_t dkv3_lds() {
+    using Cfg = BigCfg<T>;
+    return Cfg::TABLE_BYTES + (size_t)(2 * Cfg::FULL + FWD3_WAVES * 2 * 16 * Cfg::LDQ) * sizeof(T);
 }
 template <typename T>
 size_t fwd3_lds() {
@@ -1727,7 +1918,7 @@ extern "C" void esvit_debug_set_big_attn_impl(int fwd, int bwd) {
 }
 int esvit_big_npb() { return NPB; }
 int esvit_big_parts(int Bw, int nH) { return big_parts(Bw, nH); }
-int esvit_big_pad_rows(int Bw, int nH, int dtype) { return Bw * nH * (dtype == ESVIT_BF16 ? 4 : 2); }
+int esvit_big_pad_rows(int Bw, int nH, int dtype) { (void)dtype; return Bw * nH * FWD3_WAVES; }  // >= waves per workgroup of every dK/dV variant
 
 static int fill_bias_frag_big(const float* rel_table, int ws, int N, int nH, float* bias_frag_ws, hipStream_t stream) {
     const long n = 2L * nH * NT * NT * 256;  // S^T-oriented tiles of every head, then S-oriented tiles of every head
@@ -1804,8 +1995,8 @@ static int big_bwd_launch(const void* qkv, const float* qkv_bias, const int32_t*
     using Cfg = BigCfg<T>;
     constexpr int GROUPS = (NQB + Cfg::WAVES - 1) / Cfg::WAVES;
     const int parts = big_parts(Bw, nH);
-    if (g_big_bwd_impl >= 3) {  // 5 (default): dq4 + dkv2; 3: dq3 + dkv2; 4: first-generation dQ + dkv2
-        if (g_big_bwd_impl == 5) {
+    if (g_big_bwd_impl >= 3) {  // 5 (default): dq4 + dkv2; 6: dq4 + dkv3; 3: dq3 + dkv2; 4: first-generation dQ + dkv2
+        if (g_big_bwd_impl >= 5) {
             auto kern = attn_big_bwd_dq4_kernel<T>;
             const size_t lds = dq4_lds<T>();
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1827,7 +2018,14 @@ static int big_bwd_launch(const void* qkv, const float* qkv_bias, const int32_t*
                                (const T*)dout, rel_table, rel_rows, ws, region_ids, nW, Bw, N, nH, scale, parts, (T*)dqkv, dbias_ws);
             ESVIT_CHECK_LAUNCH("window_attn_bwd(14x14, dQ)");
         }
-        {
+        if (g_big_bwd_impl == 6) {
+            auto kern = attn_big_bwd_dkv3_kernel<T>;
+            const size_t lds = dkv3_lds<T>();
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(kern, dim3(Bw * nH), dim3(FWD3_WAVES * 64), lds, stream, (const T*)qkv, qkv_bias, win2tok, L, (const T*)dout,
+                               (const T*)fout, lse, rel_table + (long)nH * NT * NT * 256, ws, region_ids, nW, Bw, N, nH, scale, (T*)dqkv, dpad_ws);
+            ESVIT_CHECK_LAUNCH("window_attn_bwd(14x14, dK dV, gen 3)");
+        } else {
             auto kern = attn_big_bwd_dkv2_kernel<T>;
             const size_t lds = dkv2_lds<T>();
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
