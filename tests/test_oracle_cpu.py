@@ -194,3 +194,24 @@ def test_oracle_knn_matches_reference_golden():
         xtr, ytr, xte, yte = GU.make_knn_set(c["seed"], noise=c["noise"])
         got = O.knn_classifier(xtr, ytr, xte, yte, c["k"], c["T"], num_classes=10)
         assert got == pytest.approx(want, abs=1e-9), (c, got, want)
+
+
+def test_lib_exports_every_declared_symbol(lib_built):
+    """the C-ABI library loads on a GPU-less host and exports exactly what include/esvit_hip.h declares; the ctypes
+    binding (esvit_amd/_lib.py) covers every one of them -- no compute is called"""
+    import ctypes
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = open(os.path.join(root, "include", "esvit_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(esvit_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) > 50
+    lib = ctypes.CDLL(lib_built)
+    missing = [n for n in sorted(declared) if not hasattr(lib, n)]
+    assert not missing, missing
+    from esvit_amd import _lib
+    unbound = sorted(declared - set(_lib.SIGNATURES))
+    assert not unbound, unbound
+    undeclared = sorted(set(_lib.SIGNATURES) - declared)
+    assert not undeclared, undeclared
+    assert _lib.lib.esvit_version() > 0
