@@ -1019,299 +1019,16 @@ __global__ __launch_bounds__(BigCfg<T>::WAVES * 64) void attn_big_bwd_dkv_kernel
 //     the bias arrives in a second fragment buffer with that orientation).  That frees the 59 / 72 KB of per-wave images
 //     and lets two workgroups share a CU.
 //   * both kernels rebuild P from the saved log-sum-exp (no max / sum passes, no shuffles).
-//   * the relative-position-bias gradient is reduced straight into its (2ws-1)^2-entry table in LDS with ds_add_f32
-//     (index = a(q) - a(key) + off, both a() values are in the per-window tables), 112 LDS adds per wave and window instead
-//     of 112 accumulator registers carried across windows -- the first generation needed > 256 registers for them and
-//     spilled; this one fits two waves per SIMD.  One table per workgroup goes to the workspace; the partial tables are
-//     summed by big_dtable_reduce_kernel (no 200-KB fragment slabs, no index scatter).
+//   * the relative-position-bias gradient stays in accumulator registers across the windows a wave visits (fragment
+//     layout, reduced over `parts` afterwards).  Reducing it into its (2ws-1)^2-entry table in LDS with ds_add_f32 instead
+//     (112 LDS atomics per wave and window) was tried and measured 3x slower -- the LDS atomic unit saturates
+//     (profiles/r01_kernel_stats_w14_lds_atomic_dq.csv) -- and a 32-query strip per wave needs > 256 registers with those
+//     accumulators, hence dq4 below: eight waves, one 16-query tile each.
 // -------------------------------------------------------------------------------------------------------------
-constexpr int DTAB = 768;  // >= (2*14-1)^2 = 729
-
-template <typename T>
-__global__ __launch_bounds__(BigCfg<T>::WAVES * 64, sizeof(T) == 2 ? 2 : 1) void attn_big_bwd_dq2_kernel(
-    const T* __restrict__ qkv, const float* __restrict__ qkv_bias, const int* __restrict__ win2tok, int L, const T* __restrict__ dout,
-    const T* __restrict__ fout, const float* __restrict__ lse_in, const float* __restrict__ bias_frag, int ws, const int* __restrict__ region_ids, int nW, int Bw, int N,
-    int nH, float scale, int parts, T* __restrict__ dqkv, float* __restrict__ dtab_ws) {
-    using Cfg = BigCfg<T>;
-    constexpr int LDQ = Cfg::LDQ, WAVES = Cfg::WAVES;
-    constexpr int GROUPS = (NQB + WAVES - 1) / WAVES;
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    const BigTables tb = carve_tables(smem_raw);
-    T* Ks = reinterpret_cast<T*>(smem_raw + Cfg::TABLE_BYTES);
-    T* Vs = Ks + Cfg::FULL;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int c = lane & 15, g = lane >> 4;
-    T* Qs = Vs + Cfg::FULL + wave * (3 * Cfg::BLK);
-    T* Os = Qs + Cfg::BLK;  // dO rows of this wave's queries
-    T* Fs = Os + Cfg::BLK;  // forward output rows (delta = rowsum(dO o O))
-    float* dtab = reinterpret_cast<float*>(Vs + Cfg::FULL + WAVES * (3 * Cfg::BLK));
-
-    const int grp = blockIdx.x % GROUPS;
-    const int ph = blockIdx.x / GROUPS;  // (part, h)
-    const int h = ph % nH, part = ph / nH;
-    const int qb = grp * WAVES + wave;
-    const bool wave_ok = qb < NQB;
-    const int q0 = wave_ok ? 32 * qb : 0;
-    const int C = nH * HD;
-    const bool masked = region_ids != nullptr;
-    const T* src = qkv + h * HD;
-    const float* bias_h = bias_frag + (long)h * (NT * NT * 256);
-    const int off = (ws - 1) * (2 * ws - 1) + (ws - 1);
-
-    for (int t = threadIdx.x; t < DTAB; t += WAVES * 64) dtab[t] = 0.f;
-
-    const int iters = (Bw + parts - 1) / parts;
-    for (int it = 0; it < iters; ++it) {
-        const int bw = part + it * parts;
-        const bool win_ok = bw < Bw;
-        const int bwc = win_ok ? bw : 0;
-        const bool active = win_ok && wave_ok;
-        const long tok_base = (long)(bwc / nW) * L;
-        __syncthreads();  // previous window's reads are complete
-        load_window_tables(tb, win2tok, region_ids, bwc % nW, N, ws, win_ok);
-        __syncthreads();
-        float lq[2];
-        {
-            SlotStage<T, NPB, WAVES * 64> sk, sv;
-            SlotStage<T, 32, 64> sq, so, sf;
-            sk.load(src + C, 3L * C, tb.tok, tok_base, 0, N, qkv_bias + C + h * HD, threadIdx.x);
-            sv.load(src + 2 * C, 3L * C, tb.tok, tok_base, 0, N, qkv_bias + 2 * C + h * HD, threadIdx.x);
-            sq.load(src, 3L * C, tb.tok, tok_base, q0, N, qkv_bias + h * HD, lane);
-            so.load(dout + h * HD, (long)C, tb.tok, tok_base, q0, N, nullptr, lane);
-            sf.load(fout + h * HD, (long)C, tb.tok, tok_base, q0, N, nullptr, lane);
-            lq[0] = lse_in[((long)bwc * nH + h) * NPB + q0 + c];
-            lq[1] = lse_in[((long)bwc * nH + h) * NPB + q0 + 16 + c];
-            sk.store(Ks, 1.f, threadIdx.x);
-            sv.store(Vs, 1.f, threadIdx.x);
-            sq.store(Qs, scale, lane);
-            so.store(Os, 1.f, lane);
-            sf.store(Fs, 1.f, lane);
-        }
-        __syncthreads();
-        int aq[2], rq[2];
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int pk = tb.pk[q0 + 16 * j + c];
-            aq[j] = (pk & 0xffff) + off;
-            rq[j] = (pk >> 16) & 0xff;
-        }
-        // P^T strip from the saved log-sum-exp: rows = keys, columns = this wave's 32 queries
-        f32x4 p[NT][2];
-        {
-            Frag<T> qf[2];
-            qf[0] = frag_kc<T>(Qs, LDQ, 0, 0, c, g);
-            qf[1] = frag_kc<T>(Qs, LDQ, 16, 0, c, g);
-#pragma unroll
-            for (int i = 0; i < NT; ++i) {
-                const Frag<T> kf = frag_kc<T>(Ks, LDQ, 16 * i, 0, c, g);
-                const i32x4 pk4 = *reinterpret_cast<const i32x4*>(tb.pk + 16 * i + 4 * g);
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    f32x4 b = *reinterpret_cast<const f32x4*>(bias_h + ((i * NT + (q0 >> 4) + j) * 64 + lane) * 4);
-                    if (masked) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) b[r] += (((pk4[r] >> 16) & 0xff) != rq[j]) ? -100.f : 0.f;
-                    }
-                    mma(kf, qf[j], b);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) b[r] = __expf(b[r] - lq[j]);
-                    p[i][j] = b;
-                }
-            }
-        }
-        // dP^T = V dO^T, dS = P o (dP - delta) with delta = rowsum(dO o O) of the query; dS overwrites P tile by tile
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const Frag<T> of = frag_kc<T>(Os, LDQ, 16 * j, 0, c, g);
-            float d = 0.f;
-            {
-                const Frag<T> ff = frag_kc<T>(Fs, LDQ, 16 * j, 0, c, g);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) d += (float)of.v[e] * (float)ff.v[e];
-                d += __shfl_xor(d, 16, 64);
-                d += __shfl_xor(d, 32, 64);
-            }
-#pragma unroll
-            for (int i = 0; i < NT; ++i) {
-                const Frag<T> vf = frag_kc<T>(Vs, LDQ, 16 * i, 0, c, g);
-                f32x4 dp = {0.f, 0.f, 0.f, 0.f};
-                mma(vf, of, dp);
-                const f32x4 ds = p[i][j] * (dp - d);
-                p[i][j] = ds;
-                if (active) {
-                    const i32x4 pk4 = *reinterpret_cast<const i32x4*>(tb.pk + 16 * i + 4 * g);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) atomicAdd(dtab + (aq[j] - (pk4[r] & 0xffff)), ds[r]);
-                }
-            }
-        }
-        // dQ = scale * dS K: dS straight from the accumulators, K rows read with the matching key permutation
-        f32x4 acc[2][2];
-#pragma unroll
-        for (int a = 0; a < 2; ++a) {
-            acc[a][0] = f32x4{0.f, 0.f, 0.f, 0.f};
-            acc[a][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-#pragma unroll
-        for (int ks = 0; ks < NPB / 32; ++ks) {
-            const Frag<T> k0 = frag_v_perm<T>(Ks, LDQ, 0, ks, c, g);
-            const Frag<T> k1 = frag_v_perm<T>(Ks, LDQ, 16, ks, c, g);
-#pragma unroll
-            for (int a = 0; a < 2; ++a) {
-                const Frag<T> sf = frag_p_regs<T>(p[2 * ks][a], p[2 * ks + 1][a]);
-                mma(sf, k0, acc[a][0]);
-                mma(sf, k1, acc[a][1]);
-            }
-        }
-        store_block_rows_vec<T>(acc, scale, Qs, dqkv + h * HD, 3L * C, tb.tok, tok_base, q0, N, active, nullptr, lane, c, g);
-    }
-    __syncthreads();
-    float* wsp = dtab_ws + ((long)(part * GROUPS + grp) * nH + h) * DTAB;
-    for (int t = threadIdx.x; t < DTAB; t += WAVES * 64) wsp[t] = dtab[t];
-}
-
-// dQ + bias gradient, third variant (default): the bias gradient stays in accumulator registers across the windows a wave
-// visits (fragment layout, reduced over `parts` afterwards -- as in the first generation: LDS atomics were 3x slower),
-// but everything else follows the second generation: P from the saved log-sum-exp, delta from the O rows, dS packed to
-// bf16 A fragments as it is produced (no dS image), one query tile (16 queries) at a time so that only 112 (bias gradient)
-// + 56 (P tile column) + 28 (packed dS) accumulator-class registers are live.
-template <typename T>
-__global__ __launch_bounds__(BigCfg<T>::WAVES * 64, 1) void attn_big_bwd_dq3_kernel(
-    const T* __restrict__ qkv, const float* __restrict__ qkv_bias, const int* __restrict__ win2tok, int L, const T* __restrict__ dout,
-    const T* __restrict__ fout, const float* __restrict__ lse_in, const float* __restrict__ bias_frag, int ws,
-    const int* __restrict__ region_ids, int nW, int Bw, int N, int nH, float scale, int parts, T* __restrict__ dqkv,
-    float* __restrict__ dbias_ws) {
-    using Cfg = BigCfg<T>;
-    constexpr int LDQ = Cfg::LDQ, WAVES = Cfg::WAVES;
-    constexpr int GROUPS = (NQB + WAVES - 1) / WAVES;
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    const BigTables tb = carve_tables(smem_raw);
-    T* Ks = reinterpret_cast<T*>(smem_raw + Cfg::TABLE_BYTES);
-    T* Vs = Ks + Cfg::FULL;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int c = lane & 15, g = lane >> 4;
-    T* Qs = Vs + Cfg::FULL + wave * (3 * Cfg::BLK);
-    T* Os = Qs + Cfg::BLK;  // dO rows of this wave's queries
-    T* Fs = Os + Cfg::BLK;  // forward output rows
-
-    const int grp = blockIdx.x % GROUPS;
-    const int ph = blockIdx.x / GROUPS;  // (part, h)
-    const int h = ph % nH, part = ph / nH;
-    const int qb = grp * WAVES + wave;
-    const bool wave_ok = qb < NQB;
-    const int q0 = wave_ok ? 32 * qb : 0;
-    const int C = nH * HD;
-    const bool masked = region_ids != nullptr;
-    const T* src = qkv + h * HD;
-    const float* bias_h = bias_frag + (long)h * (NT * NT * 256);
-
-    f32x4 db[NT][2];
-#pragma unroll
-    for (int i = 0; i < NT; ++i) {
-        db[i][0] = f32x4{0.f, 0.f, 0.f, 0.f};
-        db[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-
-    const int iters = (Bw + parts - 1) / parts;
-    for (int it = 0; it < iters; ++it) {
-        const int bw = part + it * parts;
-        const bool win_ok = bw < Bw;
-        const int bwc = win_ok ? bw : 0;
-        const bool active = win_ok && wave_ok;
-        const long tok_base = (long)(bwc / nW) * L;
-        __syncthreads();  // previous window's reads are complete
-        load_window_tables(tb, win2tok, region_ids, bwc % nW, N, ws, win_ok);
-        __syncthreads();
-        float lq[2];
-        {
-            SlotStage<T, NPB, WAVES * 64> sk, sv;
-            SlotStage<T, 32, 64> sq, so, sf;
-            sk.load(src + C, 3L * C, tb.tok, tok_base, 0, N, qkv_bias + C + h * HD, threadIdx.x);
-            sv.load(src + 2 * C, 3L * C, tb.tok, tok_base, 0, N, qkv_bias + 2 * C + h * HD, threadIdx.x);
-            sq.load(src, 3L * C, tb.tok, tok_base, q0, N, qkv_bias + h * HD, lane);
-            so.load(dout + h * HD, (long)C, tb.tok, tok_base, q0, N, nullptr, lane);
-            sf.load(fout + h * HD, (long)C, tb.tok, tok_base, q0, N, nullptr, lane);
-            lq[0] = lse_in[((long)bwc * nH + h) * NPB + q0 + c];
-            lq[1] = lse_in[((long)bwc * nH + h) * NPB + q0 + 16 + c];
-            sk.store(Ks, 1.f, threadIdx.x);
-            sv.store(Vs, 1.f, threadIdx.x);
-            sq.store(Qs, scale, lane);
-            so.store(Os, 1.f, lane);
-            sf.store(Fs, 1.f, lane);
-        }
-        __syncthreads();
-        f32x4 acc[2][2];
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const Frag<T> qf = frag_kc<T>(Qs, LDQ, 16 * j, 0, c, g);
-            const Frag<T> of = frag_kc<T>(Os, LDQ, 16 * j, 0, c, g);
-            const int rq = masked ? ((tb.pk[q0 + 16 * j + c] >> 16) & 0xff) : 0;
-            float d = 0.f;
-            {
-                const Frag<T> ff = frag_kc<T>(Fs, LDQ, 16 * j, 0, c, g);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) d += (float)of.v[e] * (float)ff.v[e];
-                d += __shfl_xor(d, 16, 64);
-                d += __shfl_xor(d, 32, 64);
-            }
-            // P^T tiles of this query tile (rows = keys) from the saved log-sum-exp
-            f32x4 pj[NT];
-#pragma unroll
-            for (int i = 0; i < NT; ++i) {
-                const Frag<T> kf = frag_kc<T>(Ks, LDQ, 16 * i, 0, c, g);
-                f32x4 b = *reinterpret_cast<const f32x4*>(bias_h + ((i * NT + (q0 >> 4) + j) * 64 + lane) * 4);
-                if (masked) {
-                    const i32x4 pk4 = *reinterpret_cast<const i32x4*>(tb.pk + 16 * i + 4 * g);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) b[r] += (((pk4[r] >> 16) & 0xff) != rq) ? -100.f : 0.f;
-                }
-                mma(kf, qf, b);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) b[r] = __expf(b[r] - lq[j]);
-                pj[i] = b;
-            }
-            // dP^T = V dO^T, dS = P o (dP - delta): accumulate the bias gradient, pack dS for the dQ product
-            Frag<T> sfr[NPB / 32];
-#pragma unroll
-            for (int ks = 0; ks < NPB / 32; ++ks) {
-                f32x4 ds2[2];
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const int i = 2 * ks + u;
-                    const Frag<T> vf = frag_kc<T>(Vs, LDQ, 16 * i, 0, c, g);
-                    f32x4 dp = {0.f, 0.f, 0.f, 0.f};
-                    mma(vf, of, dp);
-                    ds2[u] = pj[i] * (dp - d);
-                    if (active) db[i][j] += ds2[u];
-                }
-                sfr[ks] = frag_p_regs<T>(ds2[0], ds2[1]);
-            }
-            acc[j][0] = f32x4{0.f, 0.f, 0.f, 0.f};
-            acc[j][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int ks = 0; ks < NPB / 32; ++ks) {
-                const Frag<T> k0 = frag_v_perm<T>(Ks, LDQ, 0, ks, c, g);
-                const Frag<T> k1 = frag_v_perm<T>(Ks, LDQ, 16, ks, c, g);
-                mma(sfr[ks], k0, acc[j][0]);
-                mma(sfr[ks], k1, acc[j][1]);
-            }
-            __builtin_amdgcn_sched_barrier(0);  // keep the two query tiles apart (registers)
-        }
-        store_block_rows_vec<T>(acc, scale, Qs, dqkv + h * HD, 3L * C, tb.tok, tok_base, q0, N, active, nullptr, lane, c, g);
-    }
-    if (wave_ok) {
-        // frag layout of the NPB x NPB bias gradient: ((ki*NT + qj)*64 + lane)*4 + r, qj = 2*qb + j
-        float* wsp = dbias_ws + ((long)part * nH + h) * (NT * NT * 256);
-#pragma unroll
-        for (int i = 0; i < NT; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) *reinterpret_cast<f32x4*>(wsp + ((i * NT + 2 * qb + j) * 64 + lane) * 4) = db[i][j];
-    }
-}
 
 // dQ + bias gradient, fourth variant (default).  The bias gradient has to live in accumulator registers across the windows
 // a wave visits; with a 32-query strip per wave that is 112 registers and the kernel cannot run two waves per SIMD
-// (dq / dq3 above: one wave per SIMD, every load round trip exposed).  Here a workgroup is EIGHT waves and a wave owns ONE
+// (the first-generation dQ kernel: one wave per SIMD, every load round trip exposed).  Here a workgroup is EIGHT waves and a wave owns ONE
 // query tile (16 queries): 56 bias-gradient + 56 P + 28 packed-dS registers, two waves per SIMD, while K and V are still
 // staged once per 8 (6) query tiles.  Same fragment-layout bias-gradient workspace as the first generation.
 constexpr int DQ4_WAVES = 8;
@@ -1828,16 +1545,6 @@ __global__ __launch_bounds__(FWD3_WAVES * 64, sizeof(T) == 2 ? 4 : 1) void attn_
     }
 }
 
-// dtable[row][h] = sum over the workgroups' partial tables [nparts][nH][DTAB]
-__global__ void big_dtable_reduce_kernel(const float* __restrict__ ws, int nparts, int nH, int rows, float* __restrict__ dtable) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= rows * nH) return;
-    const int row = i / nH, h = i % nH;
-    float s = 0.f;
-    for (int pt = 0; pt < nparts; ++pt) s += ws[((long)pt * nH + h) * DTAB + row];
-    dtable[i] = s;
-}
-
 // dtable[index[q,key]][h] += total[h][frag(q,key)] for the 14-tile frag layout
 __global__ void relpos_bias_bwd_big_kernel(const float* __restrict__ ws, const long* __restrict__ index, int N, int nH,
                                            float* __restrict__ dtable) {
@@ -1876,11 +1583,6 @@ size_t dq4_lds() {
     return Cfg::TABLE_BYTES + (size_t)(2 * Cfg::FULL + DQ4_WAVES * 3 * 16 * Cfg::LDQ) * sizeof(T);
 }
 template <typename T>
-size_t dq2_lds() {
-    using Cfg = BigCfg<T>;
-    return Cfg::TABLE_BYTES + (size_t)(2 * Cfg::FULL + Cfg::WAVES * 3 * Cfg::BLK) * sizeof(T) + DTAB * sizeof(float);
-}
-template <typename T>
 size_t dkv2_lds() {
     using Cfg = BigCfg<T>;
     return Cfg::TABLE_BYTES + (size_t)(2 * Cfg::FULL + Cfg::WAVES * 2 * Cfg::BLK) * sizeof(T);
@@ -1897,9 +1599,7 @@ size_t dkv_lds() {
 }
 
 int g_big_fwd_impl = 3;  // 1: first generation (P through LDS, one workgroup per CU); 2: P in registers, 32-query blocks; 3: 16-query tiles, 7 waves
-int g_big_bwd_impl = 5;     // 1: first generation (dS / P^T through LDS, fragment-layout bias gradient in registers); 2: dq2 + dkv2 (bias gradient
-                            // by LDS atomics: measured 3x slower than 1's dQ -- the LDS atomic unit is the bottleneck); 3 (default): 1's dQ + dkv2
-int g_big_bwd_dtype = ESVIT_BF16;  // dtype of the last backward launch (selects the workspace layout the bias-gradient reduce reads)
+int g_big_bwd_impl = 5;  // 1: first generation (dS / P^T through LDS); 4: first-generation dQ + dkv2; 5 (default): dq4 + dkv2; 6: dq4 + dkv3
 
 inline int big_parts(int Bw, int nH) {
     int parts = (512 + nH - 1) / nH;  // ~2 workgroups per CU across heads and query-block groups
@@ -1995,7 +1695,7 @@ static int big_bwd_launch(const void* qkv, const float* qkv_bias, const int32_t*
     using Cfg = BigCfg<T>;
     constexpr int GROUPS = (NQB + Cfg::WAVES - 1) / Cfg::WAVES;
     const int parts = big_parts(Bw, nH);
-    if (g_big_bwd_impl >= 3) {  // 5 (default): dq4 + dkv2; 6: dq4 + dkv3; 3: dq3 + dkv2; 4: first-generation dQ + dkv2
+    if (g_big_bwd_impl >= 4) {  // 5 (default): dq4 + dkv2; 6: dq4 + dkv3; 4: first-generation dQ + dkv2
         if (g_big_bwd_impl >= 5) {
             auto kern = attn_big_bwd_dq4_kernel<T>;
             const size_t lds = dq4_lds<T>();
@@ -2003,13 +1703,6 @@ static int big_bwd_launch(const void* qkv, const float* qkv_bias, const int32_t*
             hipLaunchKernelGGL(kern, dim3(parts * nH * DQ4_GROUPS), dim3(DQ4_WAVES * 64), lds, stream, (const T*)qkv, qkv_bias, win2tok, L,
                                (const T*)dout, (const T*)fout, lse, rel_table, ws, region_ids, nW, Bw, N, nH, scale, parts, (T*)dqkv, dbias_ws);
             ESVIT_CHECK_LAUNCH("window_attn_bwd(14x14, dQ, gen 4)");
-        } else if (g_big_bwd_impl == 3) {
-            auto kern = attn_big_bwd_dq3_kernel<T>;
-            const size_t lds = dq2_lds<T>();
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL(kern, dim3(parts * nH * GROUPS), dim3(Cfg::WAVES * 64), lds, stream, (const T*)qkv, qkv_bias, win2tok, L,
-                               (const T*)dout, (const T*)fout, lse, rel_table, ws, region_ids, nW, Bw, N, nH, scale, parts, (T*)dqkv, dbias_ws);
-            ESVIT_CHECK_LAUNCH("window_attn_bwd(14x14, dQ, gen 3)");
         } else {
             auto kern = attn_big_bwd_dq_kernel<T, TR>;
             const size_t lds = dq_lds<T>();
@@ -2026,25 +1719,6 @@ static int big_bwd_launch(const void* qkv, const float* qkv_bias, const int32_t*
                                (const T*)fout, lse, rel_table + (long)nH * NT * NT * 256, ws, region_ids, nW, Bw, N, nH, scale, (T*)dqkv, dpad_ws);
             ESVIT_CHECK_LAUNCH("window_attn_bwd(14x14, dK dV, gen 3)");
         } else {
-            auto kern = attn_big_bwd_dkv2_kernel<T>;
-            const size_t lds = dkv2_lds<T>();
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL(kern, dim3(Bw * nH), dim3(Cfg::WAVES * 64), lds, stream, (const T*)qkv, qkv_bias, win2tok, L, (const T*)dout,
-                               (const T*)fout, lse, rel_table + (long)nH * NT * NT * 256, ws, region_ids, nW, Bw, N, nH, scale, (T*)dqkv, dpad_ws);
-            ESVIT_CHECK_LAUNCH("window_attn_bwd(14x14, dK dV, gen 2)");
-        }
-        return ESVIT_OK;
-    }
-    if (g_big_bwd_impl == 2) {
-        {
-            auto kern = attn_big_bwd_dq2_kernel<T>;
-            const size_t lds = dq2_lds<T>();
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL(kern, dim3(parts * nH * GROUPS), dim3(Cfg::WAVES * 64), lds, stream, (const T*)qkv, qkv_bias, win2tok, L,
-                               (const T*)dout, (const T*)fout, lse, rel_table, ws, region_ids, nW, Bw, N, nH, scale, parts, (T*)dqkv, dbias_ws);
-            ESVIT_CHECK_LAUNCH("window_attn_bwd(14x14, dQ, gen 2)");
-        }
-        {
             auto kern = attn_big_bwd_dkv2_kernel<T>;
             const size_t lds = dkv2_lds<T>();
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -2086,7 +1760,6 @@ int esvit_big_attn_bwd(int dtype, int use_tr, const void* qkv, const float* qkv_
     }
     const float* rel_table = bias_frag_ws;  // the kernels read the frag-layout bias
     const int Bw = nB * nW;
-    g_big_bwd_dtype = dtype;
     if (dtype == ESVIT_BF16) {
         if (use_tr)
             return big_bwd_launch<bf16, true>(qkv, qkv_bias, win2tok, L, dout, fout, lse, rel_table, rel_rows, ws, region_ids, nW, Bw, N, nH,
@@ -2101,14 +1774,6 @@ int esvit_big_attn_bwd(int dtype, int use_tr, const void* qkv, const float* qkv_
 int esvit_big_relpos_bias_bwd(const float* dbias_ws, int parts, const int64_t* index, int N, int nH, int table_rows, float* dtable,
                               hipStream_t stream) {
     const int FE = NT * NT * 256;
-    if (g_big_bwd_impl == 2) {  // the workspace holds one (2ws-1)^2 table per workgroup of the dQ kernel
-        const int groups_bf16 = (NQB + 3) / 4, groups_f32 = (NQB + 1) / 2;
-        const int nparts = parts * (g_big_bwd_dtype == ESVIT_BF16 ? groups_bf16 : groups_f32);
-        hipLaunchKernelGGL(big_dtable_reduce_kernel, dim3(ceil_div((long)table_rows * nH, 256)), dim3(256), 0, stream, dbias_ws, nparts, nH,
-                           table_rows, dtable);
-        ESVIT_CHECK_LAUNCH("relpos_bias_bwd(14x14, gen 2)");
-        return ESVIT_OK;
-    }
     if (parts > 1) {
         int rc = esvit_partial_reduce(dbias_ws, parts, nH * FE, (long)nH * FE, const_cast<float*>(dbias_ws), 0, stream);
         if (rc != ESVIT_OK) return rc;
