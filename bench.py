@@ -17,6 +17,8 @@ import os
 import sys
 import time
 
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # the host driver only supports dmabuf IPC (RCCL across processes needs it)
+
 import torch
 import torch.distributed as dist
 
