@@ -199,7 +199,7 @@ def main():
     esvit_amd.set_precision("bf16")
     for var, setter in (("ESVIT_GEMM_XCDMAP", "esvit_debug_set_gemm_xcdmap"), ("ESVIT_GEMM_PIPE", "esvit_debug_set_gemm_pipe"),
                         ("ESVIT_GEMM_GROUP_M", "esvit_debug_set_gemm_group_m"), ("ESVIT_GEMM_PF", "esvit_debug_set_gemm_l2_prefetch"),
-                        ("ESVIT_GEMM_STAGGER", "esvit_debug_set_gemm_stagger")):
+                        ("ESVIT_GEMM_STAGGER", "esvit_debug_set_gemm_stagger"), ("ESVIT_ATTN_FWD", "esvit_debug_set_attn_fwd_impl")):
         if os.environ.get(var):  # kernel A/B switches for profiling runs; defaults are the shipped configuration
             getattr(ops.lib, setter)(int(os.environ[var]))
     if os.environ.get("ESVIT_BIG_ATTN_BWD"):

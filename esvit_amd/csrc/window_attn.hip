@@ -889,6 +889,266 @@ __global__ __launch_bounds__(128, (HDIM == 32 ? 3 : 2)) void attn_fwd3_kernel(co
     }
 }
 
+// P V with P in registers (fourth-generation forward): operand helpers, see window_attn_big.hip for the derivation
+template <typename T>
+__device__ __forceinline__ Frag<T> frag_v_perm64(const T* Vs, int LD, int d0, int ks, int c, int g) {
+    Frag<T> f;
+    if constexpr (sizeof(T) == 2) {
+        typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+        const T* p0 = Vs + (32 * ks + 4 * g + (c >> 2)) * LD + d0 + 4 * (c & 3);
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p0));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p0 + 16 * LD));
+        const s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        f.v = __builtin_bit_cast(bf16x8, both);
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            f.v[e] = Vs[(32 * ks + 4 * g + e) * LD + d0 + c];
+            f.v[4 + e] = Vs[(32 * ks + 16 + 4 * g + e) * LD + d0 + c];
+        }
+    }
+    return f;
+}
+template <typename T>
+__device__ __forceinline__ Frag<T> frag_p_regs64(const f32x4& lo, const f32x4& hi) {
+    Frag<T> f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        if constexpr (sizeof(T) == 2) {
+            f.v[e] = (bf16)lo[e];
+            f.v[4 + e] = (bf16)hi[e];
+        } else {
+            f.v[e] = lo[e];
+            f.v[4 + e] = hi[e];
+        }
+    }
+    return f;
+}
+
+// Fourth-generation forward (default): attn_fwd3_kernel with P kept in registers and V staged in its natural [key][d]
+// layout -- no P image, no 2-byte transposed V stores (16 per thread and window), one block barrier less per window.
+template <typename T, bool WANT_ATTN, int HDIM>
+__global__ __launch_bounds__(128, (HDIM == 32 ? 3 : 2)) void attn_fwd4_kernel(const T* __restrict__ qkv, const float* __restrict__ qkv_bias,
+                                                          const int* __restrict__ win2tok, int L, const float* __restrict__ bias_frag,
+                                                          const int* __restrict__ region_ids, int nW, int Bw, int N, int nH, float scale,
+                                                          int parts, T* __restrict__ out, float* __restrict__ attn_out) {
+    using Cfg = AttnCfgH<T, HDIM>;
+    constexpr int KS = HDIM / 32, DT = HDIM / 16;  // k-steps over the head dim, 16-wide output column tiles
+    constexpr int LDQ = Cfg::LDQ, LDP = Cfg::LDP, VEC = Cfg::VEC, ES = sizeof(T);
+    constexpr int VPR = HDIM / VEC, NV = NP * VPR / 128, LSTEP = 128 / VPR;
+    constexpr int NS = 32 * VPR / 64, SSTEP = 64 / VPR;
+    constexpr int OOB = 0x7ffffff0;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int c = lane & 15, g = lane >> 4;
+    T* base = reinterpret_cast<T*>(smem_raw);
+    T* Qs = base;                      // [NP][LDQ]; wave w's own 32 query rows double as its output staging image
+    T* Ks = base + Cfg::QK_ELEMS;      // [NP][LDQ]
+    T* Vs = base + 2 * Cfg::QK_ELEMS;  // [NP][LDQ], natural layout: P V reads it with transpose reads (frag_v_perm64)
+
+    const long unit = blockIdx.x;
+    const bool unit_ok = unit < (long)parts * nH;
+    const int h = (int)(unit % nH);
+    const int part = (int)(unit / nH);
+    const int C = nH * HDIM;
+    const bool masked = region_ids != nullptr;
+    const int lrow0 = tid / VPR, dv = tid % VPR;
+    const int srow0 = 32 * w + lane / VPR;
+    const float* bias_f = bias_frag + (long)h * FRAG_ELEMS;
+
+    Vec16<T> padq, padk_v, padv_v;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+        padq.set(e, qkv_bias[h * HDIM + dv * VEC + e]);
+        padq.set(e, padq.get(e) * scale);
+        padk_v.set(e, qkv_bias[C + h * HDIM + dv * VEC + e]);
+        padv_v.set(e, qkv_bias[2 * C + h * HDIM + dv * VEC + e]);
+    }
+
+    const int iters = (Bw + parts - 1) / parts;
+    auto win_of = [&](int it, bool& act) -> int {
+        const int bw = part + it * parts;
+        act = unit_ok && it < iters && bw < Bw;
+        return act ? bw : 0;
+    };
+    auto load_map = [&](int it, int& tok, int& reg) {
+        bool act;
+        const int bw = win_of(it, act);
+        tok = (act && lane < N) ? win2tok[(long)(bw % nW) * N + lane] : -1;
+        reg = (masked && act && lane < N) ? region_ids[(long)(bw % nW) * N + lane] : -1;
+    };
+    struct Win {
+        u32x4_f q[NV], k[NV], v[NV];
+        int ltok[NV];
+        int mytok, myreg, bw;
+        long tok_base;
+        bool active;
+    };
+    auto issue_rows = [&](int it, int mytok, int myreg, Win& x) {
+        x.bw = win_of(it, x.active);
+        x.mytok = mytok;
+        x.myreg = myreg;
+        x.tok_base = (long)(x.bw / nW) * L;
+        const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(qkv + x.tok_base * 3L * C), 0, (int)(L * 3L * C * ES), 0x00020000);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int tok = __shfl(mytok, lrow0 + LSTEP * i, 64);
+            x.ltok[i] = tok;
+            const int vq = tok >= 0 ? tok * 3 * C * ES + dv * 16 : OOB;
+            x.q[i] = __builtin_amdgcn_raw_buffer_load_b128(rq, vq, h * HDIM * ES, 0);
+            x.k[i] = __builtin_amdgcn_raw_buffer_load_b128(rq, vq, (C + h * HDIM) * ES, 0);
+            x.v[i] = __builtin_amdgcn_raw_buffer_load_b128(rq, vq, (2 * C + h * HDIM) * ES, 0);
+        }
+    };
+
+    Win cur, nxt;
+    int tok1, reg1, tok2 = -1, reg2 = -1;
+    load_map(0, tok1, reg1);
+    issue_rows(0, tok1, reg1, cur);
+    load_map(1, tok1, reg1);
+
+    for (int it = 0; it < iters; ++it) {
+        __syncthreads();  // the other wave is done with the previous window's P / V images
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int t = lrow0 + LSTEP * i;
+            const bool padslot = cur.active && t < N && cur.ltok[i] < 0;
+            Vec16<T> xq, xk, xv;
+            xq.v = __builtin_bit_cast(decltype(xq.v), cur.q[i]);
+            xk.v = __builtin_bit_cast(decltype(xk.v), cur.k[i]);
+            xv.v = __builtin_bit_cast(decltype(xv.v), cur.v[i]);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) xq.set(e, xq.get(e) * scale);
+            if (padslot) {
+                xq = padq;
+                xk = padk_v;
+                xv = padv_v;
+            }
+            st16<T>(Qs + t * LDQ + dv * VEC, xq);
+            st16<T>(Ks + t * LDQ + dv * VEC, xk);
+            st16<T>(Vs + t * LDQ + dv * VEC, xv);
+        }
+        const bool active = cur.active;
+        const int mytok = cur.mytok, myreg = cur.myreg;
+        const long tok_base = cur.tok_base;
+        const long unit_wh = (long)cur.bw * nH + h;
+        int stok[NS];
+#pragma unroll
+        for (int i = 0; i < NS; ++i) stok[i] = __shfl(mytok, srow0 + SSTEP * i, 64);
+        __syncthreads();  // images complete
+        issue_rows(it + 1, tok1, reg1, nxt);
+        load_map(it + 2, tok2, reg2);
+
+        f32x4 p[4][2];
+        {
+            Frag<T> kf[4][KS], qf[2][KS];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) kf[i][ks] = frag_kc<T>(Ks, LDQ, 16 * i, 32 * ks, c, g);
+#pragma unroll
+                for (int jl = 0; jl < 2; ++jl) qf[jl][ks] = frag_kc<T>(Qs, LDQ, 16 * (2 * w + jl), 32 * ks, c, g);
+            }
+            int rq[2];
+#pragma unroll
+            for (int jl = 0; jl < 2; ++jl) rq[jl] = __shfl(myreg, 16 * (2 * w + jl) + c, 64);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                int rk[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) rk[r] = __shfl(myreg, 16 * i + 4 * g + r, 64);
+#pragma unroll
+                for (int jl = 0; jl < 2; ++jl) {
+                    f32x4 b = *reinterpret_cast<const f32x4*>(bias_f + ((i * 4 + 2 * w + jl) * 64 + lane) * 4);
+                    if (masked) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) b[r] += (rk[r] != rq[jl]) ? -100.f : 0.f;
+                    }
+                    p[i][jl] = b;
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) mma(kf[i][ks], qf[jl][ks], p[i][jl]);
+                }
+            }
+#pragma unroll
+            for (int jl = 0; jl < 2; ++jl) {
+                float m = -3.0e38f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) m = fmaxf(m, p[i][jl][r]);
+                m = fmaxf(m, __shfl_xor(m, 16, 64));
+                m = fmaxf(m, __shfl_xor(m, 32, 64));
+                float sum = 0.f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float e = __expf(p[i][jl][r] - m);
+                        p[i][jl][r] = e;
+                        sum += e;
+                    }
+                sum += __shfl_xor(sum, 16, 64);
+                sum += __shfl_xor(sum, 32, 64);
+                const float inv = 1.f / sum;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) p[i][jl] *= inv;
+            }
+        }
+        if constexpr (WANT_ATTN) {
+            if (attn_out && active) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int jl = 0; jl < 2; ++jl)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int q = 16 * (2 * w + jl) + c, key = 16 * i + 4 * g + r;
+                            if (q < N && key < N) attn_out[((unit_wh * N) + q) * N + key] = p[i][jl][r];
+                        }
+            }
+        }
+        // P V straight from the score accumulators: lane (c, g) holds, for query c, keys 16i + 4g + r, i.e. for a 32-key chunk
+        // the keys {32ks + 4g + e, 32ks + 16 + 4g + e}; V's fragment is read with the same key permutation.
+        f32x4 o[2][DT];
+#pragma unroll
+        for (int il = 0; il < 2; ++il)
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) o[il][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {  // 64 keys = two 32-deep steps
+            Frag<T> vf[DT];
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) vf[dt] = frag_v_perm64<T>(Vs, LDQ, 16 * dt, ks, c, g);
+#pragma unroll
+            for (int il = 0; il < 2; ++il) {
+                const Frag<T> pf = frag_p_regs64<T>(p[2 * ks][il], p[2 * ks + 1][il]);
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) mma(pf, vf[dt], o[il][dt]);
+            }
+        }
+        T* Og = Qs + 32 * w * LDQ;  // [32][LDQ]: this wave's own query rows (only it read them, and they are in registers now)
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int il = 0; il < 2; ++il)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) Og[(16 * il + 4 * g + r) * LDQ + 16 * dt + c] = from_f32<T>(o[il][dt][r]);
+        __builtin_amdgcn_wave_barrier();
+        const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(out + tok_base * (long)C, 0, (int)(L * (long)C * ES), 0x00020000);
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            const int tl = lane / VPR + SSTEP * i;
+            const Vec16<T> x = ld16<T>(Og + tl * LDQ + dv * VEC);
+            const int vo = (active && stok[i] >= 0) ? stok[i] * C * ES + dv * 16 : OOB;
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_f, x.v), ro, vo, h * HDIM * ES, 0);
+        }
+        cur = nxt;
+        tok1 = tok2;
+        reg1 = reg2;
+    }
+}
+
 // -------------------------------------------------------------------------------------------------
 // Backward, second generation (the default).  Same math and the same work split as attn_bwd_kernel (wave = one head x a
 // strided set of windows), rebuilt around what the profile showed the first one to be bound by -- exposed memory
@@ -1664,7 +1924,7 @@ __global__ void relpos_bias_bwd_kernel(const float* __restrict__ ws, int parts, 
     atomicAdd(dtable + index[qk] * nH + h, s);
 }
 
-static int g_attn_fwd_impl = 3;  // 3: attn_fwd3_kernel (a window-head per wave pair); 2: attn_fwd2_kernel (persistent waves, prefetch); 1: attn_fwd_kernel
+static int g_attn_fwd_impl = 4;  // 4: attn_fwd4_kernel (P in registers); 3: attn_fwd3_kernel (a window-head per wave pair); 2: attn_fwd2_kernel (persistent waves, prefetch); 1: attn_fwd_kernel
 static int g_attn_bwd_impl = 3;  // 3: attn_bwd3_kernel (bwd2 with a window-head shared by two waves); 2: attn_bwd2_kernel; 1: attn_bwd_kernel
 
 inline int bwd_parts(int Bw, int nH) {
@@ -1779,14 +2039,16 @@ extern "C" int esvit_window_attn_fwd(int dtype, const void* qkv, const float* qk
     }
     const int Bw = nB * nW;
     ESVIT_CHECK_ARG((long)L * 3 * nH * hd * 4 < 0x7fff0000L || hd == HD, "esvit_window_attn_fwd: image too large for head_dim 64");
-    if ((g_attn_fwd_impl == 3 || hd != HD) && (long)L * 3 * nH * hd * 4 < 0x7fff0000L) {
+    if ((g_attn_fwd_impl >= 3 || hd != HD) && (long)L * 3 * nH * hd * 4 < 0x7fff0000L) {
         // persistent wave pairs: 256 CUs x 10 resident two-wave workgroups, one head each, at most one window per pair
         int parts = ((hd == HD ? 2560 : 1024) + nH - 1) / nH;
         if (parts > Bw) parts = Bw;
 #define LAUNCH_FWD3(TT, HH)                                                                                                     \
     {                                                                                                                           \
-        const size_t lds = (size_t)AttnCfgH<TT, HH>::FWD_PER_WAVE * sizeof(TT);                                                 \
-        auto kern = attn_out ? attn_fwd3_kernel<TT, true, HH> : attn_fwd3_kernel<TT, false, HH>;                                \
+        const size_t lds3 = (size_t)AttnCfgH<TT, HH>::FWD_PER_WAVE * sizeof(TT), lds4 = (size_t)3 * AttnCfgH<TT, HH>::QK_ELEMS * sizeof(TT); \
+        const size_t lds = lds3 > lds4 ? lds3 : lds4;                                                                           \
+        auto kern = g_attn_fwd_impl == 4 ? (attn_out ? attn_fwd4_kernel<TT, true, HH> : attn_fwd4_kernel<TT, false, HH>)       \
+                                         : (attn_out ? attn_fwd3_kernel<TT, true, HH> : attn_fwd3_kernel<TT, false, HH>);      \
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);   \
         hipLaunchKernelGGL(kern, dim3(parts * nH), dim3(128), lds, stream, (const TT*)qkv, qkv_bias, win2tok, L,                \
                            (const float*)bias_frag_ws, region_ids, nW, Bw, N, nH, scale, parts, (TT*)out, attn_out);            \

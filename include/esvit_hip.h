@@ -310,7 +310,7 @@ void esvit_debug_set_attn_tr_read(int on); /* attention backward: same */
 void esvit_debug_set_attn_bwd_waves(int w); /* attention backward compiled for 2 (256 regs) or 1 (512 regs) waves per SIMD */
 void esvit_debug_set_gemm_dma(int on);     /* GEMM: LDS-DMA main loop (1: by shape, 2: always) vs register-staged main loop (0) */
 void esvit_debug_set_big_attn_impl(int fwd, int bwd); /* 14x14 attention variants: fwd 3 (default) 16-query tiles / 2 32-query blocks, P in registers / 1 P through LDS; bwd 5 (default) dq4 + dkv2 / 6 dq4 + dkv3 / 4 gen-1 dQ + dkv2 / 1 gen 1 */
-void esvit_debug_set_attn_fwd_impl(int v);   /* 7x7 attention forward: 3 (default) two waves per (window, head), 2 persistent prefetching kernel, 1 one window per wave */
+void esvit_debug_set_attn_fwd_impl(int v);   /* 7x7 attention forward: 4 (default) generation 3 with P kept in registers, 3 two waves per (window, head), 2 persistent prefetching kernel, 1 one window per wave */
 void esvit_debug_set_attn_bwd_impl(int v);   /* 7x7 attention backward: 3 (default) two waves per (window, head), 2 prefetching one-wave kernel, 1 first generation */
 void esvit_debug_set_gemm_xcdmap(int mode); /* 0 (default): tiles XCD-remapped, split/batch on grid.y; 1: split-K slices / batch items contiguous per XCD */
 void esvit_debug_set_gemm_ws_ablate(int bits); /* PROFILING ONLY (results become garbage): 1 no MFMA loop, 2 no DMA loads, 4 no epilogue */

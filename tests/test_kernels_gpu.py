@@ -353,6 +353,17 @@ def test_window_attention(mods, dt, ws, nH, H, shift, hd):
     orf, _, attnr = ref.window_attn_fwd(qkv, qb, w2t, L, table, ws, mask_frag, nW, N, nH, scale, want_attn=True)
     _close("attn probs", attn, attnr, _tol(dt, f32=5e-5, bf=2e-2))
     _close("attn out", o, orf, _tol(dt, f32=5e-5, bf=2e-2))
+    if N <= 64:  # every generation of the small-window forward (training variant: no probabilities written)
+        try:
+            for impl in ((4, 3, 2, 1) if hd == 32 else (4, 3)):
+                ops.lib.esvit_debug_set_attn_fwd_impl(impl)
+                res = ops.window_attn_fwd(qkv, qb, w2t, L, table, ws, mask_frag, nW, N, nH, scale)
+                _close("attn out (gen %d)" % impl, res[0], orf, _tol(dt, f32=5e-5, bf=2e-2))
+                if impl >= 3:
+                    resa = ops.window_attn_fwd(qkv, qb, w2t, L, table, ws, mask_frag, nW, N, nH, scale, want_attn=True)
+                    _close("attn probs (gen %d)" % impl, resa[2], attnr, _tol(dt, f32=5e-5, bf=2e-2))
+        finally:
+            ops.lib.esvit_debug_set_attn_fwd_impl(4)
     if ws == 14:  # both generations of the 14x14 forward, training variant (no probabilities written)
         try:
             for impl in (1, 2, 3):
