@@ -173,17 +173,29 @@ def _block_forward_multi(X, segs, nH, dp_rows, prm, wts, save):
 
 
 class SwinBlockMultiFn(torch.autograd.Function):
+    """One Swin block over the token rows of several resolution groups.
+
+    Besides y the block returns a SHADOW output ysh (an uninitialised [M, C] tensor of the activation dtype, never read or
+    written in the forward).  It exists for the backward: the next block of the stage takes (y, ysh) as inputs and returns,
+    as the "gradient" of ysh, cast(prev_scale * dL/dy) -- the activation-dtype, DropPath-scaled copy of dL/dy that this block's
+    MLP-branch GEMMs need as their operand -- emitted by the LayerNorm-backward pass that produces dL/dy anyway
+    (ops.layernorm_bwd_cast) instead of a separate read-and-cast pass over dL/dy.  If nobody consumes ysh (last block of a
+    stage) its gradient arrives as None and the block casts dL/dy itself."""
+
     @staticmethod
-    def forward(ctx, X, segs, nH, index, dp_rows, g1, b1, table, Wqkv_p, bqkv, Wproj_p, bproj, g2, b2, W1_p, bfc1, W2_p, bfc2):
+    def forward(ctx, X, Xsh, segs, nH, index, dp_rows, prev_scale, g1, b1, table, Wqkv_p, bqkv, Wproj_p, bproj, g2, b2, W1_p, bfc1, W2_p, bfc2):
         wts = (_weight(Wqkv_p), _weight(Wproj_p), _weight(W1_p), _weight(W2_p))
         X = X.contiguous()
         y, saved, lses = _block_forward_multi(X, segs, nH, dp_rows, (g1, b1, table, bqkv, bproj, g2, b2, bfc1, bfc2), wts, True)
         ctx.segs, ctx.nH, ctx.dp_rows, ctx.lses = segs, nH, dp_rows, lses
+        ctx.emit_shadow, ctx.prev_scale = Xsh is not None, prev_scale
+        ctx.set_materialize_grads(False)
         ctx.save_for_backward(X, index, g1, table, g2, bqkv, *wts, *saved)
-        return y
+        ysh = torch.empty(X.shape, dtype=wts[0].dtype, device=X.device)
+        return y, ysh
 
     @staticmethod
-    def backward(ctx, gy):
+    def backward(ctx, gy, gysh):
         o = ops_module()
         segs, nH, dp_rows = ctx.segs, ctx.nH, ctx.dp_rows
         (X, index, g1, table, g2, bqkv, Wqkv, Wproj, W1, W2, mean1, rstd1, xw, qkv, ao, x1, mean2, rstd2, h, a1, a1g) = ctx.saved_tensors
@@ -192,7 +204,7 @@ class SwinBlockMultiFn(torch.autograd.Function):
         dp1, dp2 = (None, None) if dp_rows is None else dp_rows
         gy = gy.contiguous()
         # ---- MLP branch ----
-        dyb = o.gather_cast(gy, M, rowscale=dp2, rows_per_sample=1)
+        dyb = gysh.contiguous() if gysh is not None else o.gather_cast(gy, M, rowscale=dp2, rows_per_sample=1)
         dW2, dbfc2 = o.linear_wgrad(dyb, a1g, want_bias=True)
         da1 = o.linear_dgrad(dyb, W2, gelu_preact=a1)
         dW1, dbfc1 = o.linear_wgrad(da1, h, want_bias=True)
@@ -214,18 +226,24 @@ class SwinBlockMultiFn(torch.autograd.Function):
         for dpad_ws in pads:
             o.colsum(dpad_ws, out=dbqkv[C:], accumulate=True)  # k/v bias gradient from the zero-pad slots
         dxw = o.linear_dgrad(dqkv, Wqkv)
-        gx, dg1, db1 = o.layernorm_bwd(dxw, X, mean1, rstd1, g1, g_in=gx1)
-        return (gx, None, None, None, None, dg1, db1, dtable, dWqkv, dbqkv, dWproj, dbproj, dg2, db2, dW1, dbfc1, dW2, dbfc2)
+        if ctx.emit_shadow:  # the previous block's operand rides along with dL/dX
+            gx, gxb, dg1, db1 = o.layernorm_bwd_cast(dxw, X, mean1, rstd1, g1, g_in=gx1, rowscale=ctx.prev_scale, rows_per_sample=1)
+        else:
+            gx, dg1, db1 = o.layernorm_bwd(dxw, X, mean1, rstd1, g1, g_in=gx1)
+            gxb = None
+        return (gx, gxb, None, None, None, None, None, dg1, db1, dtable, dWqkv, dbqkv, dWproj, dbproj, dg2, db2, dW1, dbfc1, dW2, dbfc2)
 
 
-def swin_block_multi(X, segs, nH, index, dp_rows, prm_list):
-    """one Swin block over the token rows of several resolution groups; X fp32 [M, C]"""
+def swin_block_multi(X, segs, nH, index, dp_rows, prm_list, shadow=None, prev_scale=None):
+    """one Swin block over the token rows of several resolution groups; X fp32 [M, C].  -> (y, shadow of y or None);
+    pass the previous block's shadow and its MLP-branch DropPath row scale to let this block's backward emit that block's
+    cast gradient (see SwinBlockMultiFn)"""
     if torch.is_grad_enabled() and (X.requires_grad or any(p.requires_grad for p in prm_list)):
-        return SwinBlockMultiFn.apply(X, segs, nH, index, dp_rows, *prm_list)
+        return SwinBlockMultiFn.apply(X, shadow, segs, nH, index, dp_rows, prev_scale, *prm_list)
     g1, b1, table, Wqkv, bqkv, Wproj, bproj, g2, b2, W1, bfc1, W2, bfc2 = prm_list
     wts = (_weight(Wqkv), _weight(Wproj), _weight(W1), _weight(W2))
     y, _, _ = _block_forward_multi(X.contiguous(), segs, nH, dp_rows, (g1, b1, table, bqkv, bproj, g2, b2, bfc1, bfc2), wts, False)
-    return y
+    return y, None
 
 
 def swin_block(x, geom, nH, index, dp, prm_list):

@@ -109,14 +109,17 @@ class SwinTransformerBlock(nn.Module):
         return y, attn
 
 
-def _block_forward_multi(blk, X, groups, dp):
-    """blk: SwinTransformerBlock; X fp32 [M, C]; groups: list of (row0, nB, H, W); dp: None or (f1 [samples], f2, rowsample [M])"""
+def _block_forward_multi(blk, X, groups, dp, shadow=None, prev_scale=None):
+    """blk: SwinTransformerBlock; X fp32 [M, C]; groups: list of (row0, nB, H, W); dp: None or (f1 [samples], f2, rowsample [M]).
+    shadow / prev_scale: the previous block's shadow output and MLP-branch DropPath row scale (Fn.SwinBlockMultiFn).
+    -> (y, shadow of y, this block's MLP-branch row scale)"""
     segs = tuple((r0, nB, H * W, Fn.geometry(H, W, blk.window_size, blk.shift_size, X.device)) for (r0, nB, H, W) in groups)
     dp_rows = None
     if dp is not None:
         f1, f2, rowsample = dp
         dp_rows = (f1[rowsample], f2[rowsample])  # per-row DropPath scale (rows of one sample share its factor)
-    return Fn.swin_block_multi(X, segs, blk.num_heads, blk.attn.relative_position_index, dp_rows, blk._params())
+    y, ysh = Fn.swin_block_multi(X, segs, blk.num_heads, blk.attn.relative_position_index, dp_rows, blk._params(), shadow, prev_scale)
+    return y, ysh, (None if dp_rows is None else dp_rows[1])
 
 
 class PatchMerging(nn.Module):
@@ -170,6 +173,7 @@ class BasicLayer(nn.Module):
         stage run over all rows at once (Fn.swin_block_multi: attention per group, everything row-wise in one launch),
         then the ragged patch merging.  Returns (rows of the next stage, its groups)."""
         rowsample = None
+        shadow, prev_scale = None, None  # (the first block of a stage has no predecessor to serve)
         for blk in self.blocks:
             dp = None
             if isinstance(blk.drop_path, DropPath) and blk.drop_path.drop_prob and self.training:
@@ -181,7 +185,7 @@ class BasicLayer(nn.Module):
                     rowsample = torch.cat([torch.arange(nB, device=X.device).repeat_interleave(H * W) + s0
                                            for (_, nB, H, W), s0 in zip(groups, _sample_offsets(groups))])
                 dp = (pend[0], pend[1], rowsample)
-            X = _block_forward_multi(blk, X, groups, dp)
+            X, shadow, prev_scale = _block_forward_multi(blk, X, groups, dp, shadow, prev_scale)
         if self.downsample is not None:
             return self.downsample.forward_ragged(X, groups)
         return X, groups

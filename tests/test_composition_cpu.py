@@ -131,6 +131,82 @@ def test_odd_batches_match_oracle(cpu_ops):
     check_odd_batches_vs_oracle(L)
 
 
+def check_drop_path_vs_oracle(loss_mod, dev="cpu", tol=2e-4, gtol=5e-3):
+    """stochastic depth (DROP_PATH_RATE 0.4, training mode) with the per-sample keep factors FIXED by the test and handed to both
+    sides: the per-row DropPath scale of the ragged route -- in the GEMM epilogues, the LayerNorm-backward casts and the
+    gradient the next block emits for its predecessor (Fn.SwinBlockMultiFn's shadow output) -- vs the CPU oracle"""
+    from esvit_amd import models
+    from esvit_amd.models.swin_transformer import DropPath
+    from oracle import esvit_oracle as O
+    K = GU.NANO_HEAD["out_dim"]
+    B = 2
+    cfg = RL.swin_config(embed_dim=GU.NANO["embed_dim"], depths=GU.NANO["depths"], heads=GU.NANO["heads"], window=GU.NANO["window"], drop_path=0.4)
+    student = models.build_model(cfg, is_teacher=False, use_dense_prediction=True)
+    hk = dict(hidden_dim=GU.NANO_HEAD["hidden_dim"], bottleneck_dim=GU.NANO_HEAD["bottleneck_dim"])
+    student.head = models.DINOHead(student.num_features, K, norm_last_layer=True, **hk)
+    student.head_dense = models.DINOHead(student.num_features, K, norm_last_layer=False, **hk)
+    _, teacher = nano_pair()
+    GU.fill_state_dict(student.state_dict(), 0)
+    student.head.last_layer.weight_g.data.fill_(1)
+    student.train()
+    sd = {k: v.clone() for k, v in student.state_dict().items()}
+    tsd = {k: v.clone() for k, v in teacher.state_dict().items()}
+    crops = GU.make_crops(B, seed=77)
+    group_sizes = [2 * B, 8 * B]  # samples of the 224^2 group, then of the 96^2 group (row order of the ragged matrix)
+    nS = sum(group_sizes)
+    gen = torch.Generator().manual_seed(5)
+    blocks = [b for layer in student.layers for b in layer.blocks]
+    factors = []
+    for b in blocks:
+        p = b.drop_path.drop_prob if isinstance(b.drop_path, DropPath) else 0.0
+        keep = 1.0 - (p or 0.0)
+        f = [(keep + torch.rand(nS, generator=gen)).floor_().div_(keep) for _ in range(2)]
+        factors.append(f)
+    assert any((f[0] == 0).any() for f in factors) and any((f[1] == 0).any() for f in factors)  # some samples are dropped
+    # oracle: per group, per block (attention branch, MLP branch) factors of that group's samples
+    drop_scales = []
+    off = 0
+    for n in group_sizes:
+        drop_scales.append([(f[0][off:off + n], f[1][off:off + n]) for f in factors])
+        off += n
+    names = [n for n, p in student.named_parameters() if p.requires_grad]
+    leaf = {n: sd[n].clone().requires_grad_(True) for n in names}
+    full = dict(sd)
+    full.update(leaf)
+    s_ref = O.swin_multicrop(full, crops, dict(GU.NANO), drop_scales=drop_scales)
+    with torch.no_grad():
+        t_ref = O.swin_multicrop(tsd, crops[:2], dict(GU.NANO))
+    c0 = torch.zeros(1, K)
+    l_ref, _, _ = O.ddino_loss(s_ref, t_ref, c0, c0, O.teacher_temp(0, 0.04, 0.04, 0, 1), 10)
+    l_ref.backward()
+    # ours: same factors installed where SwinTransformer._draw_drop_path would put its own draw
+    student, teacher = student.to(dev), teacher.to(dev)
+    student._draw_drop_path = lambda nB, device: None
+    for b, f in zip(blocks, factors):
+        if isinstance(b.drop_path, DropPath) and b.drop_path.drop_prob:
+            b.__dict__["_dp_pending"] = (f[0].to(dev), f[1].to(dev))
+    loss_fn = loss_mod.DDINOLoss(K, 10, 0.04, 0.04, 0, 1).to(dev)
+    dcrops = [c.to(dev) for c in crops]
+    with torch.no_grad():
+        t_out = teacher(dcrops[:2])
+    s_out = student(dcrops)
+    loss = loss_fn(s_out, t_out, 0, None)
+    loss.backward()
+    for a, b in zip(s_out[:3], s_ref[:3]):
+        assert ((a.float().cpu() - b).abs().max() / (b.abs().max() + 1e-12)).item() < tol
+    assert abs(loss.item() - l_ref.item()) < tol, (loss.item(), l_ref.item())
+    for n, p in student.named_parameters():
+        if p.requires_grad:
+            ref = leaf[n].grad
+            err = (p.grad.float().cpu() - ref).abs().max().item()
+            assert err <= gtol * (ref.abs().max().item() + 1e-7), (n, err, ref.abs().max().item())
+
+
+def test_drop_path_matches_oracle(cpu_ops):
+    import esvit_amd.loss as L
+    check_drop_path_vs_oracle(L)
+
+
 def test_state_dict_layout_matches_golden():
     nano = torch.load(os.path.join(GOLD, "nano_step.pt"), weights_only=False)
     m = build_nano()

@@ -7,7 +7,7 @@ import torch
 
 from oracle import esvit_oracle as O
 from tests import golden_utils as GU
-from tests.test_composition_cpu import (build_nano, check_nano14, check_nano_cvt, check_odd_batches_vs_oracle, check_ragged_equals_reference_schedule, nano_cvt_pair, nano_pair, run_nano14_step,
+from tests.test_composition_cpu import (build_nano, check_drop_path_vs_oracle, check_nano14, check_nano_cvt, check_odd_batches_vs_oracle, check_ragged_equals_reference_schedule, nano_cvt_pair, nano_pair, run_nano14_step,
                                         run_nano_cvt_step, run_nano_step)
 from tests.test_oracle_cpu import GOLD, probe_close
 
@@ -103,6 +103,16 @@ def test_odd_batches_match_oracle_gpu(window, lib_built):
     dev = _setup("fp32")
     try:
         check_odd_batches_vs_oracle(L, dev, window=window, tol=5e-4, gtol=1e-2)
+    finally:
+        _teardown()
+
+
+def test_drop_path_matches_oracle_gpu(lib_built):
+    """stochastic depth through the HIP path (fp32 precision mode) with fixed keep factors vs the CPU oracle"""
+    import esvit_amd.loss as L
+    dev = _setup("fp32")
+    try:
+        check_drop_path_vs_oracle(L, dev, tol=5e-4, gtol=1e-2)
     finally:
         _teardown()
 
