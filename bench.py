@@ -8,7 +8,7 @@ loss, bf16, per-parameter clip + AdamW + teacher EMA, DP over RCCL when --gpus >
 Prints ONE JSON line on rank 0.  A "step" = teacher fwd (2 global crops) + student fwd (10 crops) + DDINOLoss + backward +
 gradient all-reduce (N>1) + fused clip/AdamW/EMA on a fixed synthetic batch resident in HBM.  `value` = images/s over all
 ranks.  `roofline` describes the dominant kernel family (the MFMA GEMM: 99% of the step's FLOPs) from HIP events recorded
-around every GEMM launch inside the timed region; `cpu_baseline` times the CPU oracle (a port of the reference's PyTorch
+around every GEMM launch of every 4th step of the timed region; `cpu_baseline` times the CPU oracle (a port of the reference's PyTorch
 path, oracle/esvit_oracle.py) on the host cores on a bounded sample of the same workload.
 """
 import argparse
@@ -220,13 +220,21 @@ def main():
     for _ in range(args.warmup):
         trainer.step(crops, lr, wd, mom, epoch)
     sync()
-    prof = None
+    # HIP events around every GEMM launch of every PROF_EVERY-th step of the timed region (two event records per launch cost
+    # ~2.7 us of stream time each: ~1.3 ms per step if every step were instrumented)
+    PROF_EVERY = 4
+    prof, prof_steps = None, 0
     if not args.no_roofline:
-        ops._EVENT_POOL.extend(torch.cuda.Event(enable_timing=True) for _ in range(2400 * args.steps))
-        prof = ops.GEMM_PROFILE = []
+        ops._EVENT_POOL.extend(torch.cuda.Event(enable_timing=True) for _ in range(2400 * (args.steps // PROF_EVERY + 1)))
+        prof = []
     t0 = time.perf_counter()
     loss = None
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        if prof is not None and i % PROF_EVERY == 0:
+            ops.GEMM_PROFILE = prof
+            prof_steps += 1
+        else:
+            ops.GEMM_PROFILE = None
         loss = trainer.step(crops, lr, wd, mom, epoch)
     sync()
     dt = time.perf_counter() - t0
@@ -263,7 +271,7 @@ def main():
                 with open(args.gemm_table, "w") as fh:
                     for key, (n, ms, fl, by) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
                         fh.write("M=%7d N=%6d K=%7d aks=%d bks=%d splitk=%3d calls/step %5.1f ms/step %7.3f TF %7.1f GB/s %6.0f MB/call %7.1f\n" % (
-                            key + (n / args.steps, ms / args.steps, fl / ms / 1e9, by / ms / 1e6, by / n / 1e6)))
+                            key + (n / prof_steps, ms / prof_steps, fl / ms / 1e9, by / ms / 1e6, by / n / 1e6)))
             # The GEMM family (all fwd / dgrad / wgrad launches of the step) is the dominant kernel.  Its arithmetic
             # intensity on this workload is ~180 FLOP/B against a ridge of 2500 TFLOP/s / 8 TB/s = 312 FLOP/B, so
             # HBM is the roof that binds; the MFMA figure is kept beside it.
@@ -271,10 +279,10 @@ def main():
             ach_tf = tot_fl / (tot_ms * 1e-3) / 1e12
             out["roofline"] = {"bound": "hbm", "kernel": "gemm_dma_kernel / gemm_kernel (all fwd/dgrad/wgrad GEMM launches of the step)",
                                "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                               "traffic": pmc_gemm_traffic_per_launch(args.arch, B, len(prof) / args.steps),
-                               "launches_per_step": len(prof) / args.steps,
+                               "traffic": pmc_gemm_traffic_per_launch(args.arch, B, len(prof) / prof_steps),
+                               "launches_per_step": len(prof) / prof_steps, "instrumented_steps": prof_steps,
                                "algorithmic_bytes_per_launch": tot_by / len(prof), "flops_per_launch": tot_fl / len(prof),
-                               "avg_launch_us": tot_ms * 1e3 / len(prof), "gemm_ms_per_step": tot_ms / args.steps,
+                               "avg_launch_us": tot_ms * 1e3 / len(prof), "gemm_ms_per_step": tot_ms / prof_steps,
                                "flop_per_byte": tot_fl / tot_by, "mfma_tflops": ach_tf, "mfma_frac": ach_tf / BF16_PEAK_TFLOPS}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
