@@ -21,14 +21,6 @@ constexpr int NT = 256;
 struct MS {
     float m, s;
 };
-__device__ __forceinline__ void ms_add(MS& a, float v) {
-    if (v > a.m) {
-        a.s = a.s * __expf(a.m - v) + 1.f;
-        a.m = v;
-    } else {
-        a.s += __expf(v - a.m);
-    }
-}
 __device__ __forceinline__ MS ms_merge(MS a, MS b) {
     const float m = fmaxf(a.m, b.m);
     MS r;

@@ -934,7 +934,7 @@ __global__ __launch_bounds__(128, (HDIM == 32 ? 3 : 2)) void attn_fwd4_kernel(co
                                                           int parts, T* __restrict__ out, float* __restrict__ attn_out) {
     using Cfg = AttnCfgH<T, HDIM>;
     constexpr int KS = HDIM / 32, DT = HDIM / 16;  // k-steps over the head dim, 16-wide output column tiles
-    constexpr int LDQ = Cfg::LDQ, LDP = Cfg::LDP, VEC = Cfg::VEC, ES = sizeof(T);
+    constexpr int LDQ = Cfg::LDQ, VEC = Cfg::VEC, ES = sizeof(T);
     constexpr int VPR = HDIM / VEC, NV = NP * VPR / 128, LSTEP = 128 / VPR;
     constexpr int NS = 32 * VPR / 64, SSTEP = 64 / VPR;
     constexpr int OOB = 0x7ffffff0;
@@ -1301,7 +1301,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void attn_bwd2_kernel(const T* __res
             st16<T>(Os + t * LDQ + dv * VEC, xo);
         }
         __builtin_amdgcn_wave_barrier();
-        const int mytok = cur.mytok, myreg = cur.myreg;
+        const int myreg = cur.myreg;
         const bool active = cur.active;
         const long tok_base = cur.tok_base;
         int rowoff[NV];
