@@ -1,9 +1,17 @@
-"""``build_model(config, **kwargs)`` -- same signature and error behaviour as the reference (models/build.py:5-10)."""
-from .registry import is_model, model_entrypoints
+"""Backbone factory behind the reference's entry point ``models.build_model`` (models/build.py:5-10).
+
+The reference resolves ``config.MODEL.NAME`` through a registry of per-file constructors; the same names resolve here
+('swin_transformer', 'cvt_v4_transformer').  Keyword arguments (``is_teacher``, ``use_dense_prediction``) are forwarded
+untouched, and an unknown name raises the reference's ValueError (its spelling included) so callers' error handling keeps
+working.
+"""
+from . import registry
 
 
 def build_model(config, **kwargs):
-    model_name = config.MODEL.NAME
-    if not is_model(model_name):
-        raise ValueError(f'Unkown model: {model_name}')
-    return model_entrypoints(model_name)(config, **kwargs)
+    name = config.MODEL.NAME
+    try:
+        factory = registry.model_entrypoints(name)
+    except KeyError:
+        raise ValueError('Unkown model: %s' % name) from None
+    return factory(config, **kwargs)
