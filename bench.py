@@ -116,7 +116,9 @@ def cpu_baseline(bs=2, steps=6):
 
 def torch_eager_gpu_baseline(dev, bs, steps=5):
     """The same CPU-oracle code (a port of the reference's PyTorch path) run on the GPU under torch.autocast(bf16): what
-    stock PyTorch-ROCm (hipBLASLt + eager aten kernels) delivers for this step on the same MI355X.  Informational only."""
+    stock PyTorch-ROCm (hipBLASLt + eager aten kernels) delivers for this step on the same MI355X.  A second BASELINE leg
+    like cpu_baseline (the oracle is the thing compared against, never part of the measured product path); off unless
+    --torch-eager is given, never part of `value`."""
     from oracle import esvit_oracle as O
     from tests import golden_utils as GU
     import esvit_amd
