@@ -199,13 +199,6 @@ def main():
     from esvit_amd.engine import EsvitTrainer
     from tests import golden_utils as GU
     esvit_amd.set_precision("bf16")
-    for var, setter in (("ESVIT_GEMM_XCDMAP", "esvit_debug_set_gemm_xcdmap"), ("ESVIT_GEMM_PIPE", "esvit_debug_set_gemm_pipe"),
-                        ("ESVIT_GEMM_GROUP_M", "esvit_debug_set_gemm_group_m"), ("ESVIT_GEMM_PF", "esvit_debug_set_gemm_l2_prefetch"),
-                        ("ESVIT_GEMM_STAGGER", "esvit_debug_set_gemm_stagger"), ("ESVIT_ATTN_FWD", "esvit_debug_set_attn_fwd_impl")):
-        if os.environ.get(var):  # kernel A/B switches for profiling runs; defaults are the shipped configuration
-            getattr(ops.lib, setter)(int(os.environ[var]))
-    if os.environ.get("ESVIT_BIG_ATTN_BWD"):
-        ops.lib.esvit_debug_set_big_attn_impl(int(os.environ.get("ESVIT_BIG_ATTN_FWD", "3")), int(os.environ["ESVIT_BIG_ATTN_BWD"]))
     torch.manual_seed(0)
     student, teacher, loss_fn = build(dev, args.drop_path, args.arch)
     trainer = EsvitTrainer(student, teacher, loss_fn, clip_grad=3.0, freeze_last_layer=1)

@@ -11,6 +11,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libesvit_hip.so")
 
 F32, BF16 = 0, 1
 EPI_NONE, EPI_GELU, EPI_GELU_BWD, EPI_QGELU, EPI_QGELU_BWD = 0, 1, 2, 3, 4
+GEMM_AUTO, GEMM_REGSTAGE, GEMM_DMA4, GEMM_DMA8 = 0, 1, 2, 3
 
 vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
@@ -30,6 +31,7 @@ class GemmDesc(C.Structure):
         ("epilogue", i32), ("out_f32", i32), ("splitk", i32),
         ("partial", vp), ("accumulate", i32), ("alpha", f32),
         ("colsum", vp), ("colsum_partial", vp),
+        ("kernel", i32),
     ]
 
 
@@ -42,6 +44,7 @@ SIGNATURES = {
     "esvit_shift_mask": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
     "esvit_shift_region_ids": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
     "esvit_gemm": (C.c_int, [C.c_int, C.POINTER(GemmDesc), vp]),
+    "esvit_gemm_select": (C.c_int, [C.c_int, C.POINTER(GemmDesc), vp, vp, vp]),
     "esvit_layernorm_fwd": (C.c_int, [C.c_int, vp, vp, vp, f32, i64, C.c_int, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp]),
     "esvit_layernorm_bwd_blocks": (C.c_int, [i64, C.c_int]),
     "esvit_conv_im2col": (C.c_int, [C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
@@ -94,22 +97,6 @@ SIGNATURES = {
     "esvit_update_chunk_elems": (C.c_int, []),
     "esvit_grad_sqnorm": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, vp]),
     "esvit_fused_clip_adamw_ema": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, f32, f32, f32, f32, f32, f32, f32, vp]),
-    "esvit_debug_set_tr_read": (None, [C.c_int]),
-    "esvit_debug_set_attn_tr_read": (None, [C.c_int]),
-    "esvit_debug_set_attn_bwd_waves": (None, [C.c_int]),
-    "esvit_debug_set_gemm_dma": (None, [C.c_int]),
-    "esvit_debug_set_gemm_pipe": (None, [C.c_int]),
-    "esvit_debug_set_gemm_m64": (None, [C.c_int]),
-    "esvit_debug_set_gemm_group_m": (None, [C.c_int]),
-    "esvit_debug_set_gemm_l2_prefetch": (None, [C.c_int]),
-    "esvit_debug_set_gemm_stagger": (None, [C.c_int]),
-    "esvit_debug_set_gemm_m256": (None, [C.c_int]),
-    "esvit_debug_set_attn_bwd_impl": (None, [C.c_int]),
-    "esvit_debug_set_attn_fwd_impl": (None, [C.c_int]),
-    "esvit_debug_set_big_attn_impl": (None, [C.c_int, C.c_int]),
-    "esvit_debug_gemm_ws_occupancy": (C.c_int, [C.c_int]),
-    "esvit_debug_set_gemm_ws_ablate": (None, [C.c_int]),
-    "esvit_debug_set_gemm_xcdmap": (None, [C.c_int]),
 }
 
 

@@ -1,1533 +1,106 @@
-// MFMA GEMM family for the EsViT hot path (gfx950).
+// esvit_gemm: shape -> kernel dispatch of the MFMA GEMM family (kernels: gemm_kernels.h).
 //
-//   C[M,N] = alpha * op(A)[M,K] * op(B)[K,N]  (+ fused epilogue)
-//
-// One kernel template covers the three shapes autograd needs:
-//   forward  Y  = X  W^T   : A k-contiguous (M x K),  B k-contiguous (N x K)
-//   dgrad    dX = dY W     : A k-contiguous,          B k-strided    (K x N)   [or cached W^T]
-//   wgrad    dW = dY^T X   : A k-strided (K x M),     B k-strided    (K x N), split-K over rows
-//
-// Tiling: 256 threads = 4 waves (2 x 2), block tile BM x BN x 32, wave tile (BM/2) x (BN/2)
-// built from 16x16 MFMA fragments (v_mfma_f32_16x16x32_bf16, or 8 x v_mfma_f32_16x16x4_f32 for
-// the exact-fp32 parity mode).  Operands are register-staged global -> LDS (double-buffered,
-// one barrier per k-tile).  K-contiguous tiles are read as one ds_read_b128 per fragment;
-// K-strided tiles are stored as they lie in HBM and read with the gfx950 transpose read
-// (ds_read_b64_tr_b16), so no operand is ever transposed through HBM.
-//
-// The lane->k assignment inside a fragment is "lane group g holds k = 8g..8g+7" for both A and
-// B; a dot product is invariant to a permutation applied to both operands, so the fp32 path
-// simply feeds element j of that 8-vector to the j-th 16x16x4 MFMA.
-//
-// Epilogue (all optional, fused on the fp32 accumulators): bias, GELU (+ pre-activation side
-// output), GELU', per-sample DropPath scale, window->token row scatter (window_reverse + roll +
-// crop of swin_transformer.py:315-325), residual add, bf16/fp32 store, split-K partial store.
-#include "common.h"
-#include "mfma.h"
-#include "../../include/esvit_hip.h"
+// Three main loops, one fragment / epilogue convention:
+//   ESVIT_GEMM_REGSTAGE  register-staged, 128-row tiles, 4 waves: the exact-fp32 parity mode (v_mfma_f32_16x16x4_f32)
+//                        and the fallback for bf16 operands the LDS-DMA loop cannot take;
+//   ESVIT_GEMM_DMA4      LDS-DMA, 128 x {64, 96, 128} tiles, 4 waves, two workgroups per CU: short-K / small problems;
+//   ESVIT_GEMM_DMA8      LDS-DMA, 256 x {192, 256} (192-row tiles too for the weight gradients), 8 waves, one workgroup
+//                        per CU: half the operand bytes per FLOP -- long-K forward / dgrad GEMMs and the weight gradients.
+// The choice is a pure function of the descriptor (esvit_gemm_select); desc.kernel != 0 forces one (tests, tuning).
+#include "gemm_kernels.h"
 
 namespace {
 
-constexpr int BK = 32;
-constexpr int NTHREADS = 256;
-
-// compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>) -- every index is a constant by
-// construction, so per-iteration register arrays never end up dynamically indexed (i.e. in scratch)
-template <typename F, int... I>
-__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
-    (f(std::integral_constant<int, I>{}), ...);
-}
-template <int N, typename F>
-__device__ __forceinline__ void static_for(F&& f) {
-    static_for_impl(f, std::make_integer_sequence<int, N>{});
-}
-
-__device__ __forceinline__ Frag<bf16> ones_frag(bf16) {
-    Frag<bf16> f;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) f.v[j] = (bf16)1.0f;
-    return f;
-}
-__device__ __forceinline__ Frag<float> ones_frag(float) {
-    Frag<float> f;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) f.v[j] = 1.0f;
-    return f;
-}
-
-// row sums of op(A) (accumulated with an all-ones B fragment): lane c == 0 of each 16-lane group owns rows 4g+r
-template <int FM>
-__device__ __forceinline__ void store_colsum(const esvit_gemm_desc& p, const f32x4 (&accb)[FM], int m0, int wm_rows0, int z, int c, int g) {
-    if (c != 0) return;
-    float* dst = p.splitk > 1 ? p.colsum_partial + (long)z * p.M : p.colsum;
-#pragma unroll
-    for (int i = 0; i < FM; ++i)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int m = m0 + wm_rows0 + i * 16 + 4 * g + r;
-            if (m < p.M) dst[m] = accb[i][r] * p.alpha;
-        }
-}
-
-// One operand tile: ROWS (BM or BN) x BK, in LDS either as [ROWS][BK+pad] (k contiguous) or as
-// [BK][ROWS+pad] (k strided, i.e. exactly the HBM orientation).
-template <typename T, bool KS, int ROWS, bool USE_TR>
-struct Tile {
-    static constexpr int VEC = ElemTraits<T>::VEC;
-    static constexpr int LD = KS ? (ROWS + VEC) : (BK + VEC);
-    static constexpr int ELEMS = KS ? (BK * LD) : (ROWS * LD);
-    static constexpr int NVEC = ROWS * BK / VEC;
-    static constexpr int VPT = (NVEC + NTHREADS - 1) / NTHREADS;
-
-    Vec16<T> regs[VPT];
-
-    // global -> registers.  base: operand pointer; ld: leading dim (elements); row0: first tile
-    // row along the non-K dim; k0: first k; nrows/K: extents for zero-fill guards.
-    __device__ __forceinline__ void load(const T* __restrict__ base, long ld, int row0, int k0, int nrows, int K) {
-#pragma unroll
-        for (int i = 0; i < VPT; ++i) {
-            const int v = threadIdx.x + i * NTHREADS;
-            bool ok = v < NVEC;
-            long off = 0;
-            if (KS) {
-                const int kr = v / (ROWS / VEC), rv = v % (ROWS / VEC);
-                ok = ok && (k0 + kr < K) && (row0 + rv * VEC < nrows);
-                off = (long)(k0 + kr) * ld + row0 + rv * VEC;
-            } else {
-                const int r = v / (BK / VEC), kv = v % (BK / VEC);
-                ok = ok && (row0 + r < nrows) && (k0 + kv * VEC < K);
-                off = (long)(row0 + r) * ld + k0 + kv * VEC;
-            }
-            regs[i] = ok ? ld16<T>(base + off) : zero16<T>();
-        }
-    }
-    // registers -> LDS
-    __device__ __forceinline__ void store(T* lds) const {
-#pragma unroll
-        for (int i = 0; i < VPT; ++i) {
-            const int v = threadIdx.x + i * NTHREADS;
-            if (v < NVEC) {
-                int off;
-                if (KS) {
-                    const int kr = v / (ROWS / VEC), rv = v % (ROWS / VEC);
-                    off = kr * LD + rv * VEC;
-                } else {
-                    const int r = v / (BK / VEC), kv = v % (BK / VEC);
-                    off = r * LD + kv * VEC;
-                }
-                st16<T>(lds + off, regs[i]);
-            }
-        }
-    }
-    // LDS -> MFMA fragment for the 16 tile rows starting at r0: lane (c = l&15, g = l>>4) gets
-    // element (row r0+c, k = 8g+j), j = 0..7.
-    __device__ __forceinline__ static Frag<T> frag(const T* lds, int r0, int c, int g) {
-        if constexpr (KS) return frag_ks<T, USE_TR>(lds, LD, r0, 0, c, g);
-        else return frag_kc<T>(lds, LD, r0, 0, c, g);
-    }
+struct GemmChoice {
+    int kernel, bm, bn;
 };
 
-// ---- epilogue (shared by both main-loop variants) ----
-// SR: rows staged per pass.  The wave's staging region is private (callers barrier once before the epilogue when the
-// region aliases operand buffers), so passes need no workgroup barrier -- LDS instructions of one wave execute in
-// order.  LOCAL: tight LDS budget (persistent kernel) -> no row pad, XOR swizzle instead.
-//
-// Memory-op ordering matters more than anything else here: vmcnt retires in order, so a wave that waits for a load
-// issued AFTER its stores sits out the full store latency.  Every tensor the epilogue reads is therefore requested
-// ahead of the stores it would otherwise queue behind: bias and the row map once per tile, and the per-element
-// inputs of pass ps+1 (residual or GELU pre-activation, DropPath scale) before the stores of pass ps.
-template <typename T, int BM, int BN, int SR = 16, bool LOCAL = false>
-__device__ __forceinline__ void gemm_epilogue(const esvit_gemm_desc& p, f32x4 (&acc)[BM / 32][BN / 32], char* smem_raw, int m0, int n0,
-                                              int z) {
-    constexpr int WTM = BM / 2, WTN = BN / 2;
-    constexpr int FM = WTM / 16, FN = WTN / 16;
-    const int M = p.M, N = p.N;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int c = lane & 15, g = lane >> 4;
-    const int wm = wave >> 1, wn = wave & 1;
-    // Accumulator fragments hold a 4x1 column strip per lane (stride-16 columns), which would mean 2-byte
-    // scattered stores.  Each wave therefore stages SR rows of its tile at a time through its own LDS region
-    // and re-reads them as row-contiguous groups of 8 columns, so every global access of the epilogue (bias,
-    // aux, residual, C) is a 16/32-byte vector.  Bank spread of the four lane groups (rows 4g+r): a 4-float
-    // row pad, or (64-wide wave tiles, no room for a pad) an XOR of the 16-column block with g.
-    constexpr bool SWZ = LOCAL && FN == 4;
-    constexpr int LDE = SWZ ? WTN : WTN + 4;    // floats per staged row
-    constexpr int CG = WTN / 8;                 // 8-column groups per row
-    constexpr int ITEMS = (SR * CG + 63) / 64;  // groups per lane per pass
-    constexpr int FPP = SR / 16;                // fragment rows per pass
-    constexpr int NP = FM / FPP;                // passes
-    constexpr bool CG_FIXED = (64 % CG) == 0;   // a lane keeps its column group across items -> bias loaded once
-    static_assert(FM % FPP == 0 && (SR == 16 || SR == 32), "tile shape");
-    float* stage = reinterpret_cast<float*>(smem_raw) + wave * (SR * LDE);
-    const float alpha = p.alpha;
+inline bool mult192(int n) { return (n % 192 == 0) && (n % 256 != 0); }
 
-    auto stage_pass = [&](int ps) {  // accumulator rows of pass ps -> this wave's private LDS region
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int il = 0; il < FPP; ++il)
-#pragma unroll
-            for (int j = 0; j < FN; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    stage[(il * 16 + 4 * g + r) * LDE + ((j * 16 + c) ^ (SWZ ? (g << 4) : 0))] = acc[FPP * ps + il][j][r] * alpha;
-        __builtin_amdgcn_wave_barrier();
-    };
-    auto read_item = [&](int row_l, int cg, float (&v)[8]) {
-        const int scol = (cg * 8) ^ (SWZ ? (((row_l >> 2) & 3) << 4) : 0);
-        const f32x4 lo = *reinterpret_cast<const f32x4*>(stage + row_l * LDE + scol);
-        const f32x4 hi = *reinterpret_cast<const f32x4*>(stage + row_l * LDE + scol + 4);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            v[e] = lo[e];
-            v[4 + e] = hi[e];
-        }
-    };
-    // item t of pass ps: 8 columns starting at n of row m (false: nothing to do)
-    auto item_geom = [&](int ps, int t, int& row_l, int& cg, int& m, int& n) -> bool {
-        const int id = lane + 64 * t;
-        row_l = id / CG;
-        cg = id % CG;
-        m = m0 + wm * WTM + ps * SR + row_l;
-        n = n0 + wn * WTN + cg * 8;
-        return ((SR * CG) % 64 == 0 || id < SR * CG) && m < M && n < N;
-    };
-
-    if (p.splitk > 1) {  // fp32 partial of this split-K slice: no inputs, no conversions
-        float* part = p.partial + (long)z * M * N;
-        const bool pvec = (N % 4) == 0;
-#pragma unroll
-        for (int ps = 0; ps < NP; ++ps) {
-            stage_pass(ps);
-#pragma unroll
-            for (int t = 0; t < ITEMS; ++t) {
-                int row_l, cg, m, n;
-                if (!item_geom(ps, t, row_l, cg, m, n)) continue;
-                float v[8];
-                read_item(row_l, cg, v);
-                const int ne = min(8, N - n);
-                float* dst = part + (long)m * N + n;
-                if (ne == 8 && pvec) {
-                    *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
-                    *reinterpret_cast<f32x4*>(dst + 4) = f32x4{v[4], v[5], v[6], v[7]};
-                } else {
-                    for (int e = 0; e < ne; ++e) dst[e] = v[e];
-                }
-            }
-        }
-        return;
-    }
-
-    char* Cb = reinterpret_cast<char*>(p.C);
-    const long c_batch = (long)z * p.strideC;
-    T* auxp = reinterpret_cast<T*>(p.aux);
-    const bool c_vec = (p.ldc % 8 == 0) && ((reinterpret_cast<uintptr_t>(p.C) & 15) == 0) && ((c_batch % 8) == 0);
-    const bool aux_vec = auxp && (p.ldaux % 8 == 0) && ((reinterpret_cast<uintptr_t>(p.aux) & 15) == 0);
-    const bool res_vec = p.residual && (p.ldr % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.residual) & 15) == 0);
-    const bool bias_vec = p.bias && ((reinterpret_cast<uintptr_t>(p.bias) & 15) == 0);
-    const int mode = p.epilogue;
-
-    auto load_bias8 = [&](int n, float (&b)[8]) {
-        const int ne = min(8, N - n);
-        if (ne == 8 && bias_vec) {
-            const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + n);
-            const f32x4 b1 = *reinterpret_cast<const f32x4*>(p.bias + n + 4);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                b[e] = b0[e];
-                b[4 + e] = b1[e];
-            }
-        } else {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) b[e] = e < ne ? p.bias[n + e] : 0.f;
-        }
-    };
-
-    // once per tile: bias of this lane's column group(s) -- item t of every pass covers the same 8 columns
-    constexpr int NBH = CG_FIXED ? 1 : ITEMS;
-    float bias_h[NBH][8];
-    static_for<NBH>([&](auto tc) {
-        constexpr int t = decltype(tc)::value;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) bias_h[t][e] = 0.f;
-        const int n = n0 + wn * WTN + ((lane + 64 * t) % CG) * 8;
-        if (p.bias && n < N) load_bias8(n, bias_h[t]);
-    });
-
-    // general path (ragged edge tiles, row maps, unaligned operands, fp32 parity mode): inputs are read where they
-    // are used -- the lean epilogue below covers the tiles that matter for speed
-    auto dest_row = [&](int m, int tk) -> long { return p.rowmap ? (long)(m / p.rowmap_period) * p.rowmap_tokens + tk : (long)m; };
-    static_for<NP>([&](auto psc) {
-        constexpr int ps = decltype(psc)::value;
-        stage_pass(ps);
-        static_for<ITEMS>([&](auto tc) {
-            constexpr int t = decltype(tc)::value;
-            int row_l, cg, m, n;
-            if (!item_geom(ps, t, row_l, cg, m, n)) return;
-            int tk = 0;
-            if (p.rowmap) {
-                tk = p.rowmap[m % p.rowmap_period];
-                if (tk < 0) return;
-            }
-            const int ne = min(8, N - n);
-            const long drow = dest_row(m, tk);
-            float v[8];
-            read_item(row_l, cg, v);
-            if (p.bias) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] += bias_h[CG_FIXED ? 0 : t][e];
-            }
-            if (mode == ESVIT_EPI_GELU || mode == ESVIT_EPI_QGELU) {
-                if (auxp) {
-                    T* ap = auxp + (long)m * p.ldaux + n;
-                    if (ne == 8 && aux_vec) {
-                        if constexpr (sizeof(T) == 2) {
-                            bf16x8 o;
-#pragma unroll
-                            for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
-                            *reinterpret_cast<bf16x8*>(ap) = o;
-                        } else {
-                            *reinterpret_cast<f32x4*>(ap) = f32x4{v[0], v[1], v[2], v[3]};
-                            *reinterpret_cast<f32x4*>(ap + 4) = f32x4{v[4], v[5], v[6], v[7]};
-                        }
-                    } else {
-                        for (int e = 0; e < ne; ++e) ap[e] = from_f32<T>(v[e]);
-                    }
-                }
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = mode == ESVIT_EPI_GELU ? gelu_f(v[e]) : qgelu_f(v[e]);
-            } else if (mode == ESVIT_EPI_GELU_BWD || mode == ESVIT_EPI_QGELU_BWD) {
-                const T* ap = auxp + (long)m * p.ldaux + n;
-                float a[8];
-                if (ne == 8 && aux_vec) {
-                    if constexpr (sizeof(T) == 2) {
-                        const bf16x8 x = *reinterpret_cast<const bf16x8*>(ap);
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) a[e] = (float)x[e];
-                    } else {
-                        const f32x4 x0 = *reinterpret_cast<const f32x4*>(ap), x1 = *reinterpret_cast<const f32x4*>(ap + 4);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            a[e] = x0[e];
-                            a[4 + e] = x1[e];
-                        }
-                    }
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) a[e] = e < ne ? to_f32(ap[e]) : 0.f;
-                }
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] *= mode == ESVIT_EPI_GELU_BWD ? gelu_grad_f(a[e]) : qgelu_grad_f(a[e]);
-            }
-            if (p.rowscale) {
-                const float rs = p.rowscale[drow / p.rows_per_sample];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] *= rs;
-            }
-            if (p.residual) {
-                const float* rp = p.residual + drow * p.ldr + n;
-                if (ne == 8 && res_vec) {
-                    const f32x4 r0 = *reinterpret_cast<const f32x4*>(rp), r1 = *reinterpret_cast<const f32x4*>(rp + 4);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        v[e] += r0[e];
-                        v[4 + e] += r1[e];
-                    }
-                } else {
-                    for (int e = 0; e < ne; ++e) v[e] += rp[e];
-                }
-            }
-            const long o = c_batch + drow * p.ldc + n;
-            if (p.out_f32) {
-                float* cp = reinterpret_cast<float*>(Cb) + o;
-                if (ne == 8 && c_vec) {
-                    *reinterpret_cast<f32x4*>(cp) = f32x4{v[0], v[1], v[2], v[3]};
-                    *reinterpret_cast<f32x4*>(cp + 4) = f32x4{v[4], v[5], v[6], v[7]};
-                } else {
-                    for (int e = 0; e < ne; ++e) cp[e] = v[e];
-                }
-            } else {
-                T* cp = reinterpret_cast<T*>(Cb) + o;
-                if (ne == 8 && c_vec) {
-                    if constexpr (sizeof(T) == 2) {
-                        bf16x8 ov;
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) ov[e] = (bf16)v[e];
-                        *reinterpret_cast<bf16x8*>(cp) = ov;
-                    } else {
-                        *reinterpret_cast<f32x4*>(cp) = f32x4{v[0], v[1], v[2], v[3]};
-                        *reinterpret_cast<f32x4*>(cp + 4) = f32x4{v[4], v[5], v[6], v[7]};
-                    }
-                } else {
-                    for (int e = 0; e < ne; ++e) cp[e] = from_f32<T>(v[e]);
-                }
-            }
-        });
-    });
+// tile of the 8-wave kernel for this problem
+inline void dma8_tile(const esvit_gemm_desc& d, int& bm, int& bn) {
+    bn = mult192(d.N) ? 192 : 256;
+    bm = (d.a_kstrided && mult192(d.M)) ? 192 : 256;
 }
 
-// ---- lean epilogue for the common case ----
-// The GEMM kernels of this path are VALU-bound, not MFMA-bound (profiles/r01_gemm_sq_counters.txt: ~9 VALU
-// instructions per MFMA before this path existed, most of them epilogue address arithmetic, predicates and wait
-// states).  For a FULL interior tile with vector-aligned operands the epilogue below is straight-line code per kind:
-// lane offsets are computed once per tile, staging uses immediate LDS offsets, there are no per-element predicates,
-// and -- because there are no branches -- the compiler's own vmcnt bookkeeping is exact, so the per-element inputs
-// requested one pass ahead never wait for the stores issued after them.
-enum { EK_PLAIN = 0, EK_GELU = 1, EK_RES = 2, EK_GELU_BWD = 3 };
-
-template <int BM, int BN, bool SWZ, int KIND, bool OUTF32>
-__device__ __forceinline__ void epilogue_fast(const esvit_gemm_desc& p, f32x4 (&acc)[BM / 32][BN / 32], float* stage, int m0, int n0,
-                                              void* Cbase, long ldc, long c_first, const float* bias) {
-    constexpr int WTM = BM / 2, WTN = BN / 2;
-    constexpr int FM = WTM / 16, FN = WTN / 16;
-    constexpr int SR = 16;
-    constexpr int LDE = SWZ ? WTN : WTN + 4;
-    constexpr int CG = WTN / 8;
-    constexpr int ITEMS = (SR * CG + 63) / 64;
-    constexpr int NP = FM;
-    constexpr bool RAGGED = (SR * CG) % 64 != 0;  // the last item of a pass covers only some lanes (96-wide tiles)
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int c = lane & 15, g = lane >> 4;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int row_w = m0 + wm * WTM, col_w = n0 + wn * WTN;  // first row / column of the wave tile
-
-    // staging write bases (floats): row 4g, column block j (XOR-swizzled with g when there is no room for a row pad)
-    int wbase[FN];
-#pragma unroll
-    for (int j = 0; j < FN; ++j) wbase[j] = 4 * g * LDE + (SWZ ? ((j ^ g) & (FN - 1)) * 16 + c : j * 16 + c);
-
-    // per item t (fixed over passes): staged row / column group, read offset, destination offsets
-    int rd_off[ITEMS];
-    long c_off[ITEMS], x_off[ITEMS];  // element offsets into C and into aux / residual for pass 0
-    bool live[ITEMS];
-    float bias_h[ITEMS][8];
-    static_for<ITEMS>([&](auto tc) {
-        constexpr int t = decltype(tc)::value;
-        const int id = lane + 64 * t;
-        const int row_l = id / CG, cg = id % CG;
-        live[t] = !RAGGED || id < SR * CG;
-        rd_off[t] = row_l * LDE + ((cg * 8) ^ (SWZ ? (((row_l >> 2) & 3) << 4) : 0));
-        const long row = row_w + row_l;
-        const int n = col_w + cg * 8;
-        c_off[t] = c_first + row * ldc + n;
-        x_off[t] = KIND == EK_RES ? row * p.ldr + n : row * p.ldaux + n;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) bias_h[t][e] = 0.f;
-        if (bias && live[t]) {
-            const f32x4 b0 = *reinterpret_cast<const f32x4*>(bias + n);
-            const f32x4 b1 = *reinterpret_cast<const f32x4*>(bias + n + 4);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                bias_h[t][e] = b0[e];
-                bias_h[t][4 + e] = b1[e];
-            }
-        }
-    });
-    if (p.alpha != 1.f) {
-#pragma unroll
-        for (int i = 0; i < FM; ++i)
-#pragma unroll
-            for (int j = 0; j < FN; ++j) acc[i][j] *= p.alpha;
-    }
-    const bool quick = p.epilogue == ESVIT_EPI_QGELU || p.epilogue == ESVIT_EPI_QGELU_BWD;  // QuickGELU instead of erf-GELU
-    const long c_step = (long)SR * ldc;
-    const long x_step = (long)SR * (KIND == EK_RES ? p.ldr : p.ldaux);
-    bf16* auxp = reinterpret_cast<bf16*>(p.aux);
-
-    // inputs requested one pass ahead: residual (8 fp32) + DropPath scale, or the GELU pre-activation (8 bf16)
-    f32x4 in0[2][ITEMS], in1[2][ITEMS];
-    float rs[2][ITEMS];
-    auto load_in = [&](auto psc) {
-        constexpr int ps = decltype(psc)::value;
-        static_for<ITEMS>([&](auto tc) {
-            constexpr int t = decltype(tc)::value;
-            rs[ps & 1][t] = 1.f;
-            if (!live[t]) return;
-            if constexpr (KIND == EK_RES) {
-                const float* rp = p.residual + x_off[t] + ps * x_step;
-                in0[ps & 1][t] = *reinterpret_cast<const f32x4*>(rp);
-                in1[ps & 1][t] = *reinterpret_cast<const f32x4*>(rp + 4);
-                if (p.rowscale) rs[ps & 1][t] = p.rowscale[(row_w + ps * SR + (lane + 64 * t) / CG) / p.rows_per_sample];
-            } else if constexpr (KIND == EK_GELU_BWD) {
-                in0[ps & 1][t] = *reinterpret_cast<const f32x4*>(auxp + x_off[t] + ps * x_step);
-            }
-        });
-    };
-    if constexpr (KIND == EK_RES || KIND == EK_GELU_BWD) load_in(std::integral_constant<int, 0>{});
-
-    static_for<NP>([&](auto psc) {
-        constexpr int ps = decltype(psc)::value;
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int j = 0; j < FN; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) stage[wbase[j] + r * LDE] = acc[ps][j][r];
-        __builtin_amdgcn_wave_barrier();
-        if constexpr ((KIND == EK_RES || KIND == EK_GELU_BWD) && ps + 1 < NP) load_in(std::integral_constant<int, ps + 1>{});
-        static_for<ITEMS>([&](auto tc) {
-            constexpr int t = decltype(tc)::value;
-            if (!live[t]) return;
-            float v[8];
-            {
-                const f32x4 lo = *reinterpret_cast<const f32x4*>(stage + rd_off[t]);
-                const f32x4 hi = *reinterpret_cast<const f32x4*>(stage + rd_off[t] + 4);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    v[e] = lo[e] + bias_h[t][e];
-                    v[4 + e] = hi[e] + bias_h[t][4 + e];
-                }
-            }
-            if constexpr (KIND == EK_GELU) {
-                if (auxp) {
-                    bf16x8 o;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
-                    *reinterpret_cast<bf16x8*>(auxp + x_off[t] + ps * x_step) = o;
-                }
-                if (quick) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = qgelu_f(v[e]);
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
-                }
-            } else if constexpr (KIND == EK_GELU_BWD) {
-                const bf16x8 x = __builtin_bit_cast(bf16x8, in0[ps & 1][t]);
-                if (quick) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] *= qgelu_grad_f((float)x[e]);
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] *= gelu_grad_f((float)x[e]);
-                }
-            } else if constexpr (KIND == EK_RES) {
-                const float s = rs[ps & 1][t];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    v[e] = v[e] * s + in0[ps & 1][t][e];
-                    v[4 + e] = v[4 + e] * s + in1[ps & 1][t][e];
-                }
-            }
-            if constexpr (OUTF32) {
-                float* cp = reinterpret_cast<float*>(Cbase) + c_off[t] + ps * c_step;
-                *reinterpret_cast<f32x4*>(cp) = f32x4{v[0], v[1], v[2], v[3]};
-                *reinterpret_cast<f32x4*>(cp + 4) = f32x4{v[4], v[5], v[6], v[7]};
-            } else {
-                bf16x8 ov;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) ov[e] = (bf16)v[e];
-                *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(Cbase) + c_off[t] + ps * c_step) = ov;
-            }
-        });
-    });
+inline void dma4_tile(const esvit_gemm_desc& d, int& bm, int& bn) {
+    bm = 128;
+    bn = ((d.N % 96 == 0) && (d.N % 128 != 0)) ? 96 : (d.N <= 64 ? 64 : 128);
 }
 
-// bf16 kernels: pick the lean epilogue when the tile and the operands allow it, else the general one
-template <int BM, int BN, bool LOCAL>
-__device__ __forceinline__ void gemm_epilogue_bf16(const esvit_gemm_desc& p, f32x4 (&acc)[BM / 32][BN / 32], char* smem_raw, int m0, int n0,
-                                                   int z) {
-    constexpr int WTN = BN / 2, FN = WTN / 16;
-    constexpr bool SWZ = LOCAL && FN == 4;
-    constexpr int LDE = SWZ ? WTN : WTN + 4;
-    auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
-    if (p.splitk > 1 && m0 + BM <= p.M && n0 + BN <= p.N && (p.N % 4 == 0) && al16(p.partial)) {
-        // split-K partial of a full tile: a plain fp32 store into this slice's [M, N] plane
-        float* stage = reinterpret_cast<float*>(smem_raw) + (threadIdx.x >> 6) * (16 * LDE);
-        epilogue_fast<BM, BN, SWZ, EK_PLAIN, true>(p, acc, stage, m0, n0, p.partial + (long)z * p.M * p.N, p.N, 0, nullptr);
-        return;
-    }
-    bool fast = p.splitk <= 1 && !p.rowmap && m0 + BM <= p.M && n0 + BN <= p.N && (p.ldc % 8 == 0) && al16(p.C) &&
-                ((p.strideC * (long)z) % 8 == 0) && (!p.bias || al16(p.bias));
-    int kind = EK_PLAIN;
-    if (p.epilogue == ESVIT_EPI_GELU || p.epilogue == ESVIT_EPI_QGELU) {
-        kind = EK_GELU;
-        fast = fast && !p.residual && !p.rowscale && !p.out_f32 && (!p.aux || ((p.ldaux % 8 == 0) && al16(p.aux)));
-    } else if (p.epilogue == ESVIT_EPI_GELU_BWD || p.epilogue == ESVIT_EPI_QGELU_BWD) {
-        kind = EK_GELU_BWD;
-        fast = fast && !p.residual && !p.rowscale && (p.ldaux % 8 == 0) && al16(p.aux);
-    } else if (p.residual) {
-        kind = EK_RES;
-        fast = fast && (p.ldr % 4 == 0) && al16(p.residual);
-    } else {
-        fast = fast && !p.rowscale;
-    }
-    if (!fast) {
-        gemm_epilogue<bf16, BM, BN, 16, LOCAL>(p, acc, smem_raw, m0, n0, z);
-        return;
-    }
-    float* stage = reinterpret_cast<float*>(smem_raw) + (threadIdx.x >> 6) * (16 * LDE);
-    if (kind == EK_GELU) epilogue_fast<BM, BN, SWZ, EK_GELU, false>(p, acc, stage, m0, n0, p.C, p.ldc, (long)z * p.strideC, p.bias);
-    else if (kind == EK_GELU_BWD) {
-        if (p.out_f32) epilogue_fast<BM, BN, SWZ, EK_GELU_BWD, true>(p, acc, stage, m0, n0, p.C, p.ldc, (long)z * p.strideC, p.bias);
-        else epilogue_fast<BM, BN, SWZ, EK_GELU_BWD, false>(p, acc, stage, m0, n0, p.C, p.ldc, (long)z * p.strideC, p.bias);
-    } else if (kind == EK_RES) {
-        if (p.out_f32) epilogue_fast<BM, BN, SWZ, EK_RES, true>(p, acc, stage, m0, n0, p.C, p.ldc, (long)z * p.strideC, p.bias);
-        else epilogue_fast<BM, BN, SWZ, EK_RES, false>(p, acc, stage, m0, n0, p.C, p.ldc, (long)z * p.strideC, p.bias);
-    } else {
-        if (p.out_f32) epilogue_fast<BM, BN, SWZ, EK_PLAIN, true>(p, acc, stage, m0, n0, p.C, p.ldc, (long)z * p.strideC, p.bias);
-        else epilogue_fast<BM, BN, SWZ, EK_PLAIN, false>(p, acc, stage, m0, n0, p.C, p.ldc, (long)z * p.strideC, p.bias);
-    }
+// Every workgroup of a launch runs about equally long, so a launch takes ceil(workgroups / resident slots) rounds.
+inline double round_efficiency(long wgs, long slots) {
+    const long rounds = (wgs + slots - 1) / slots;
+    return (double)wgs / (double)(rounds * slots);
 }
 
-// XCD-aware work order over a 1-D grid of ntiles * nz blocks.  The dispatcher places block b on XCD b % 8; give
-// every XCD a contiguous range of the virtual ids v = z * ntiles + tile (bijective remap), so (a) the tiles of one
-// output row panel share an L2 and (b) all tiles of one split-K slice / batch item run on the same XCD at the same
-// time -- the slice of A and B they all read is then fetched from HBM once instead of once per XCD.
-__device__ __forceinline__ void xcd_tile_map(int ntiles, int& tile, int& z) {
-    if (gridDim.y > 1) {  // debug layout (esvit_debug_set_gemm_xcdmap(0)): remap the tiles only, z on grid.y
-        const int b = blockIdx.x;
-        const int q = ntiles / 8, r = ntiles % 8;
-        const int xcd = b % 8, idx = b / 8;
-        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-        z = blockIdx.y;
-        return;
+GemmChoice choose(int dtype, const esvit_gemm_desc& d) {
+    GemmChoice c{ESVIT_GEMM_REGSTAGE, 128, 128};
+    if (dtype != ESVIT_BF16) {
+        dma4_tile(d, c.bm, c.bn);
+        return c;
     }
-    const int total = gridDim.x;
-    const int b = blockIdx.x;
-    const int q = total / 8, r = total % 8;
-    const int xcd = b % 8, idx = b / 8;
-    const int v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    z = v / ntiles;
-    tile = v - z * ntiles;
-}
-
-// Tile id -> (row block, column block).  group_m <= 1: column-fastest.  Otherwise the ids walk down group_m row blocks
-// before moving to the next column block: the ~64 tiles one XCD has in flight then cover group_m row panels x
-// 64/group_m column panels instead of 1 x 64, so a wide B (N/BN >> 8, e.g. the 65536-wide last layer) is not
-// re-streamed from the Infinity Cache once per row block.
-__device__ __forceinline__ void tile_coords(int pid, int tiles_m, int tiles_n, int group_m, int& tm, int& tn) {
-    if (group_m <= 1) {
-        tm = pid / tiles_n;
-        tn = pid - tm * tiles_n;
-        return;
-    }
-    const int gsize = group_m * tiles_n;
-    const int gid = pid / gsize;
-    const int first = gid * group_m;
-    const int rows = min(tiles_m - first, group_m);
-    const int w = pid - gid * gsize;
-    tn = w / rows;
-    tm = first + (w - tn * rows);
-}
-
-template <typename T, bool AKS, bool BKS, int BM, int BN, bool USE_TR>
-__global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const esvit_gemm_desc p) {
-    using TA = Tile<T, AKS, BM, USE_TR>;
-    using TB = Tile<T, BKS, BN, USE_TR>;
-    constexpr int WTM = BM / 2, WTN = BN / 2;  // wave tile
-    constexpr int FM = WTM / 16, FN = WTN / 16;
-
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    T* smem = reinterpret_cast<T*>(smem_raw);
-    T* sA = smem;                   // 2 buffers
-    T* sB = smem + 2 * TA::ELEMS;   // 2 buffers
-
-    const int M = p.M, N = p.N, K = p.K;
-    const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
-    // XCD-aware tile order: block b runs on XCD b%8; give every XCD a contiguous range of
-    // tile ids so the tiles that share an A panel hit the same L2 (bijective remap).
-    const int ntiles = tiles_m * tiles_n;
-    int pid, z;
-    xcd_tile_map(ntiles, pid, z);
-    const int tm = pid / tiles_n, tn = pid % tiles_n;
-    const int m0 = tm * BM, n0 = tn * BN;
-
-    const T* A = reinterpret_cast<const T*>(p.A);
-    const T* B = reinterpret_cast<const T*>(p.B);
-    int kbeg = 0, kend = K;
-    if (p.splitk > 1) {
-        const int nkt = (K + BK - 1) / BK;
-        const int per = (nkt + p.splitk - 1) / p.splitk;
-        kbeg = z * per * BK;
-        kend = min(K, (z + 1) * per * BK);
-    } else {
-        A += (long)z * p.strideA;
-        B += (long)z * p.strideB;
-    }
-
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int c = lane & 15, g = lane >> 4;
-    const int wm = wave >> 1, wn = wave & 1;
-
-    f32x4 acc[FM][FN];
-#pragma unroll
-    for (int i = 0; i < FM; ++i)
-#pragma unroll
-        for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    const bool do_colsum = p.colsum && tn == 0 && wn == 0;
-    f32x4 accb[FM];
-#pragma unroll
-    for (int i = 0; i < FM; ++i) accb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const Frag<T> ones = ones_frag(T());
-
-    TA ta;
-    TB tb;
-    const int nk = (kend > kbeg) ? (kend - kbeg + BK - 1) / BK : 0;
-    if (nk > 0) {
-        ta.load(A, p.lda, m0, kbeg, M, kend);
-        tb.load(B, p.ldb, n0, kbeg, N, kend);
-        ta.store(sA);
-        tb.store(sB);
-    }
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) {
-            ta.load(A, p.lda, m0, kbeg + (kt + 1) * BK, M, kend);
-            tb.load(B, p.ldb, n0, kbeg + (kt + 1) * BK, N, kend);
-        }
-        const T* a_lds = sA + cur * TA::ELEMS;
-        const T* b_lds = sB + cur * TB::ELEMS;
-        Frag<T> af[FM], bfr[FN];
-#pragma unroll
-        for (int i = 0; i < FM; ++i) af[i] = TA::frag(a_lds, wm * WTM + i * 16, c, g);
-#pragma unroll
-        for (int j = 0; j < FN; ++j) bfr[j] = TB::frag(b_lds, wn * WTN + j * 16, c, g);
-#pragma unroll
-        for (int i = 0; i < FM; ++i)
-#pragma unroll
-            for (int j = 0; j < FN; ++j) mma(af[i], bfr[j], acc[i][j]);
-        if (do_colsum) {
-#pragma unroll
-            for (int i = 0; i < FM; ++i) mma(af[i], ones, accb[i]);
-        }
-        if (kt + 1 < nk) {
-            ta.store(sA + (cur ^ 1) * TA::ELEMS);
-            tb.store(sB + (cur ^ 1) * TB::ELEMS);
-        }
-        __syncthreads();
-    }
-
-    if (do_colsum) store_colsum<FM>(p, accb, m0, wm * WTM, z, c, g);
-    if constexpr (sizeof(T) == 2) gemm_epilogue_bf16<BM, BN, false>(p, acc, smem_raw, m0, n0, z);
-    else gemm_epilogue<T, BM, BN>(p, acc, smem_raw, m0, n0, z);
-}
-
-// =================================================================================================
-// bf16 fast path: operands travel HBM -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds), BK = 64.
-// No staging registers, no ds_write pass; the LDS image is lane-linear (1 KiB per wave instruction), so
-// bank conflicts are removed by an XOR swizzle applied to the per-lane SOURCE address and to the
-// fragment read address (guide rule 21).  k-contiguous tiles: [ROWS][64] with chunk ^= row & 7
-// (conflict-free ds_read_b128); k-strided tiles: [64][ROWS] with a per-k chunk XOR that spreads the
-// 8 k-rows touched by one ds_read_b64_tr_b16 over distinct banks.  Two LDS buffers; the barrier at the
-// end of a k-tile drains the DMA of the next one while this tile's 32 MFMAs per wave run.
-// =================================================================================================
-template <bool KS, int ROWS, int BKD>
-struct DmaTile {
-    static constexpr int ELEMS = ROWS * BKD;
-    static constexpr int CHUNKS = ELEMS / 8;
-    static constexpr int INSTR_PER_WAVE = CHUNKS / 256;
-    static constexpr int CPR = KS ? ROWS / 8 : BKD / 8;  // 16-byte chunks per LDS row
-    static_assert(CHUNKS % 64 == 0, "tile must be a whole number of wave instructions");
-
-    __device__ __forceinline__ static int sw_ks(int k) {
-        if constexpr (ROWS == 128) return ((k & 3) << 1) | (((k >> 3) & 1) << 3);
-        else if constexpr (ROWS == 64) return (((k >> 1) & 1) << 1) | (((k >> 3) & 1) << 2);
-        else return ((k >> 3) & 1) << 1;
-    }
-    __device__ __forceinline__ static int sw_kc(int r) {
-        if constexpr (BKD == 64) return r & 7;               // 128-byte rows: 8 chunks
-        else return (0x78 >> (2 * ((r >> 2) & 3))) & 3;      // 64-byte rows: 4 chunks, f(r>>2) = {0,2,3,1}
-    }
-
-    // one DMA instruction: 64 lanes x 16 bytes -> LDS bytes [slot * 1024, slot * 1024 + 1024) of the tile
-    __device__ __forceinline__ static void issue_slot(__amdgpu_buffer_rsrc_t rsrc, char* lds_tile, long ld, int rows_left, int k0, int K,
-                                                      int slot, int lane) {
-        typedef __attribute__((address_space(3))) void lds_void;
-        const int p = slot * 64 + lane;
-        long off;
-        bool ok;
-        if constexpr (KS) {
-            const int kr = p / CPR, cp = p % CPR;
-            const int col = (cp ^ sw_ks(kr)) * 8;
-            ok = (k0 + kr < K) && (col < rows_left);
-            off = (long)(k0 + kr) * ld + col;
-        } else {
-            const int r = p / CPR, cp = p % CPR;
-            const int k = k0 + ((cp ^ sw_kc(r)) * 8);
-            ok = (r < rows_left) && (k < K);
-            off = (long)r * ld + k;
-        }
-        const int voff = ok ? (int)(off * 2) : (int)0xfffffff8u;  // beyond num_records -> hardware returns 0
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void*)(lds_tile + slot * 1024), 16, voff, 0, 0, 0);
-    }
-
-    // base: operand pointer already advanced to the tile's first row (k-contiguous) / column (k-strided).
-    // The tile's instructions are spread over the workgroup's 4 waves.
-    __device__ __forceinline__ static void issue(__amdgpu_buffer_rsrc_t rsrc, char* lds_tile, long ld, int rows_left, int k0, int K,
-                                                 int wave, int lane) {
-        static_assert(CHUNKS % 256 == 0, "tile must be a whole number of instructions per wave");
-#pragma unroll
-        for (int i = 0; i < INSTR_PER_WAVE; ++i) issue_slot(rsrc, lds_tile, ld, rows_left, k0, K, wave * INSTR_PER_WAVE + i, lane);
-    }
-
-    // Fast path of issue() for a FULL k-tile (see issue_all_fast below): per-lane offsets once per kernel, k0 in the
-    // scalar offset, no per-instruction address arithmetic or predicates.
-    __device__ __forceinline__ static void wave_offsets(long ld, int wave, int lane, int (&voff)[CHUNKS / 256]) {
-        static_for<CHUNKS / 256>([&](auto ic) {
-            constexpr int i = decltype(ic)::value;
-            const int p = (wave * INSTR_PER_WAVE + i) * 64 + lane;
-            const int r = p / CPR, cp = p % CPR;
-            const long off = KS ? (long)r * ld + (cp ^ sw_ks(r)) * 8 : (long)r * ld + (cp ^ sw_kc(r)) * 8;
-            voff[i] = (int)(off * 2);
-        });
-    }
-    __device__ __forceinline__ static void issue_fast(__amdgpu_buffer_rsrc_t rsrc, char* lds_tile, long ld, int k0, int wave,
-                                                      const int (&voff)[CHUNKS / 256]) {
-        typedef __attribute__((address_space(3))) void lds_void;
-        const int soff = (int)(KS ? (long)k0 * ld * 2 : (long)k0 * 2);
-        static_for<INSTR_PER_WAVE>([&](auto ic) {
-            constexpr int i = decltype(ic)::value;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void*)(lds_tile + (wave * INSTR_PER_WAVE + i) * 1024), 16, voff[i], soff, 0, 0);
-        });
-    }
-
-    // the whole tile from ONE wave (producer wave of the warp-specialised kernel)
-    static constexpr int INSTR_PER_TILE = CHUNKS / 64;
-    // Fast path of issue_all for a FULL k-tile: the per-lane byte offsets of the tile's instructions relative to
-    // (tile base, k0 = 0) depend only on ld, so a producer computes them once (lane_offsets) and every k-tile is
-    // INSTR_PER_TILE bare DMA instructions with k0 folded into the scalar offset.  Rows past the end of a
-    // k-contiguous operand fall outside the descriptor's num_records (checked on the vector offset) and read as 0;
-    // a k-strided operand's partial row tile and any partial k-tile need per-lane predicates -> issue_all().
-    __device__ __forceinline__ static void lane_offsets(long ld, int lane, int (&voff)[INSTR_PER_TILE]) {
-#pragma unroll
-        for (int i = 0; i < INSTR_PER_TILE; ++i) {
-            const int p = i * 64 + lane;
-            const int r = p / CPR, cp = p % CPR;
-            const long off = KS ? (long)r * ld + (cp ^ sw_ks(r)) * 8 : (long)r * ld + (cp ^ sw_kc(r)) * 8;
-            voff[i] = (int)(off * 2);
+    int want = d.kernel;
+    if (want == ESVIT_GEMM_AUTO) {
+        want = ESVIT_GEMM_DMA4;
+        int bm, bn;
+        dma8_tile(d, bm, bn);
+        const long t8 = (long)ceil_div(d.M, bm) * ceil_div(d.N, bn);
+        const int nz = d.splitk > 1 ? d.splitk : (d.batch > 1 ? d.batch : 1);
+        if (d.a_kstrided) {
+            // weight gradients: tiny outputs, the whole cost is streaming K rows of both operands -> the wider tile always
+            // wins once both output dims fill a 192-wide tile
+            if (d.M >= 192 && d.N >= 192) want = ESVIT_GEMM_DMA8;
+        } else if (!d.rowmap && d.N >= 192) {
+            // forward / dgrad: one 256-row tile per CU has no second workgroup to hide its epilogue behind, so it pays
+            // only when the main loop dominates (long K) and the grid fills the chip
+            const bool fills = t8 * nz >= 192 && round_efficiency(t8 * nz, 256) >= 0.72;
+            if (d.K >= 768 && fills) want = ESVIT_GEMM_DMA8;
         }
     }
-    __device__ __forceinline__ static void issue_all_fast(__amdgpu_buffer_rsrc_t rsrc, char* lds_tile, long ld, int k0,
-                                                          const int (&voff)[INSTR_PER_TILE]) {
-        typedef __attribute__((address_space(3))) void lds_void;
-        const int soff = (int)(KS ? (long)k0 * ld * 2 : (long)k0 * 2);
-#pragma unroll
-        for (int i = 0; i < INSTR_PER_TILE; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void*)(lds_tile + i * 1024), 16, voff[i], soff, 0, 0);
-    }
-    __device__ __forceinline__ static void issue_all(__amdgpu_buffer_rsrc_t rsrc, char* lds_tile, long ld, int rows_left, int k0, int K,
-                                                     int lane) {
-#pragma unroll
-        for (int i = 0; i < INSTR_PER_TILE; ++i) issue_slot(rsrc, lds_tile, ld, rows_left, k0, K, i, lane);
-    }
-
-    // fragment for the 16 tile rows at r0, k-step kk (32 deep)
-    __device__ __forceinline__ static Frag<bf16> frag(const bf16* lds, int r0, int kk, int c, int g) {
-        Frag<bf16> f;
-        if constexpr (!KS) {
-            const int row = r0 + c;
-            const int pos = row * CPR + ((kk * 4 + g) ^ sw_kc(row));
-            f.v = *reinterpret_cast<const bf16x8*>(lds + pos * 8);
-        } else {
-            typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
-            const int k_lo = kk * 32 + 8 * g + (c >> 2);
-            const int chunk = (r0 >> 3) + ((c & 3) >> 1);
-            const bf16* p0 = lds + (k_lo * CPR + (chunk ^ sw_ks(k_lo))) * 8 + (c & 1) * 4;
-            const int k_hi = k_lo + 4;
-            const bf16* p1 = lds + (k_hi * CPR + (chunk ^ sw_ks(k_hi))) * 8 + (c & 1) * 4;
-            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p0));
-            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p1));
-            const s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-            f.v = __builtin_bit_cast(bf16x8, both);
-        }
-        return f;
-    }
-};
-
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, long bytes_left) {
-    const long capped = bytes_left > 0xfffffff0L ? 0xfffffff0L : (bytes_left < 0 ? 0 : bytes_left);
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)capped, 0x00020000);
-}
-
-// the same descriptor as four dwords, for the inline-asm L2 prefetch loads of gemm_dma_kernel
-typedef int i32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ i32x4 make_rsrc_words(const void* base, long bytes_left) {
-    const long capped = bytes_left > 0xfffffff0L ? 0xfffffff0L : (bytes_left < 0 ? 0 : bytes_left);
-    const unsigned long b = reinterpret_cast<unsigned long>(base);
-    return i32x4{(int)(unsigned)(b & 0xffffffffUL), (int)(unsigned)((b >> 32) & 0xffffUL), (int)capped, 0x00020000};
-}
-
-// per-thread byte offset (relative to the tile base at k = 0) of the 128-byte line thread `tg` of a 128-thread group
-// touches when it prefetches one k-tile of an operand; -1 for idle threads
-template <bool KS, int ROWS, int BKD>
-__device__ __forceinline__ int prefetch_line_offset(long ld, int tg) {
-    if constexpr (!KS) {
-        static_assert(BKD * 2 <= 128 && ROWS <= 128, "one line per tile row");
-        return tg < ROWS ? (int)((long)tg * ld * 2) : -1;
-    } else {
-        constexpr int LPR = (ROWS * 2 + 127) / 128;  // lines per k-row
-        static_assert(BKD * LPR <= 128, "one line per thread");
-        const int r = tg / LPR, cs = tg - r * LPR;
-        return r < BKD ? (int)(((long)r * ld + cs * 64) * 2) : -1;
-    }
-}
-
-// counted wait: at most N of this wave's LDS-DMA loads still in flight (loads retire in order)
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() {
-    static_assert(N >= 0 && N < 64, "vmcnt immediate");
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-
-// NBUF-deep ring of LDS tiles: NBUF-1 tiles are requested ahead; per k-tile ONE counted wait (only for the tile
-// about to be consumed -- later tiles stay in flight across the barrier) and ONE barrier.
-template <bool AKS, bool BKS, int BM, int BN, int BKD, int NBUF>
-__global__ __launch_bounds__(NTHREADS, (BM >= 256 ? 1 : 2)) void gemm_dma_kernel(const esvit_gemm_desc p, const int group_m, const int l2_prefetch, const int stagger) {
-    using TA = DmaTile<AKS, BM, BKD>;
-    using TB = DmaTile<BKS, BN, BKD>;
-    constexpr int WTM = BM / 2, WTN = BN / 2;
-    constexpr int FM = WTM / 16, FN = WTN / 16;
-    constexpr int L = TA::INSTR_PER_WAVE + TB::INSTR_PER_WAVE;  // DMA instructions per wave per tile
-    // Phase stagger.  Every tile of a launch costs the same, so the two workgroups that share a CU run their main loops
-    // together (MFMA contended, HBM idle) and then their epilogues together (HBM write path contended, MFMA idle), and
-    // refills keep that lock-step for the whole launch.  Delaying the second workgroup of each CU in the FIRST round by
-    // about half a tile puts one's epilogue under the other's main loop; later rounds inherit the offset.
-    if (stagger > 0) {
-        const int lin = blockIdx.x + blockIdx.y * gridDim.x;
-        const int slot = lin >> 3;  // position among the workgroups of this XCD
-        const bool second = (stagger & (1 << 30)) ? (slot < 64 && (slot & 1)) : (slot >= 32 && slot < 64);
-        if (second) {
-            const long t0 = __builtin_amdgcn_s_memtime();
-            const long want = stagger & 0xfffffff;
-            while ((long)__builtin_amdgcn_s_memtime() - t0 < want) __builtin_amdgcn_s_sleep(16);
-        }
-    }
-    static_assert(NBUF >= 2 && NBUF <= 4, "ring depth");
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    constexpr int A_BYTES = TA::ELEMS * 2, B_BYTES = TB::ELEMS * 2;
-    char* sA = smem_raw;                   // NBUF buffers
-    char* sB = smem_raw + NBUF * A_BYTES;  // NBUF buffers
-
-    const int M = p.M, N = p.N, K = p.K;
-    const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
-    const int ntiles = tiles_m * tiles_n;
-    int pid, z;
-    xcd_tile_map(ntiles, pid, z);
-    int tm, tn;
-    tile_coords(pid, tiles_m, tiles_n, group_m, tm, tn);
-    const int m0 = tm * BM, n0 = tn * BN;
-    const bf16* A = reinterpret_cast<const bf16*>(p.A);
-    const bf16* B = reinterpret_cast<const bf16*>(p.B);
-    int kbeg = 0, kend = K;
-    if (p.splitk > 1) {
-        const int nkt = (K + BKD - 1) / BKD;
-        const int per = (nkt + p.splitk - 1) / p.splitk;
-        kbeg = z * per * BKD;
-        kend = min(K, (z + 1) * per * BKD);
-    } else {
-        A += (long)z * p.strideA;
-        B += (long)z * p.strideB;
-    }
-    // per-block descriptors: base at the tile's first row / column, so every byte offset fits 32 bits
-    const long a_rows_total = AKS ? (long)K : (long)M;  // rows of the stored matrix
-    const long b_rows_total = BKS ? (long)K : (long)N;
-    const bf16* a_base = AKS ? A + m0 : A + (long)m0 * p.lda;
-    const bf16* b_base = BKS ? B + n0 : B + (long)n0 * p.ldb;
-    const long a_left = ((AKS ? a_rows_total : a_rows_total - m0) * p.lda - (AKS ? m0 : 0)) * 2;
-    const long b_left = ((BKS ? b_rows_total : b_rows_total - n0) * p.ldb - (BKS ? n0 : 0)) * 2;
-    const __amdgpu_buffer_rsrc_t ra = make_rsrc(a_base, a_left);
-    const __amdgpu_buffer_rsrc_t rb = make_rsrc(b_base, b_left);
-
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int c = lane & 15, g = lane >> 4;
-    const int wm = wave >> 1, wn = wave & 1;
-
-    f32x4 acc[FM][FN];
-#pragma unroll
-    for (int i = 0; i < FM; ++i)
-#pragma unroll
-        for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    const bool do_colsum = p.colsum && tn == 0 && wn == 0;
-    f32x4 accb[FM];
-#pragma unroll
-    for (int i = 0; i < FM; ++i) accb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const Frag<bf16> ones = ones_frag(bf16());
-
-    const int nk = (kend > kbeg) ? (kend - kbeg + BKD - 1) / BKD : 0;
-    // full k-tiles of row-complete operand tiles take the bare-DMA path (offsets precomputed, k0 in the scalar offset)
-    int voffA[TA::INSTR_PER_WAVE], voffB[TB::INSTR_PER_WAVE];
-    TA::wave_offsets(p.lda, wave, lane, voffA);
-    TB::wave_offsets(p.ldb, wave, lane, voffB);
-    const bool rows_ok_a = !AKS || (M - m0 >= BM), rows_ok_b = !BKS || (N - n0 >= BN);
-    auto issue_tile = [&](int t, int slot) {
-        const int k0 = kbeg + t * BKD;
-        const bool fullk = k0 + BKD <= kend;
-        if (fullk && rows_ok_a) TA::issue_fast(ra, sA + slot * A_BYTES, p.lda, k0, wave, voffA);
-        else TA::issue(ra, sA + slot * A_BYTES, p.lda, M - m0, k0, kend, wave, lane);
-        if (fullk && rows_ok_b) TB::issue_fast(rb, sB + slot * B_BYTES, p.ldb, k0, wave, voffB);
-        else TB::issue(rb, sB + slot * B_BYTES, p.ldb, N - n0, k0, kend, wave, lane);
-    };
-    // L2 prefetch (two-buffer ring only).  With one k-tile in flight per workgroup every iteration waits a full memory
-    // round trip for the tile requested one iteration earlier.  Each thread therefore also touches ONE 128-byte line
-    // of k-tile kt+3 per iteration (waves 0-1 the A tile, waves 2-3 the B tile) with a plain buffer load into a
-    // register nobody reads: it pulls the line into the XCD's L2 two iterations before the LDS-DMA of that tile is
-    // issued, so the DMA is an L2 hit.  The load is issued AFTER the iteration's DMA, so the counted wait at the top of
-    // the next iteration (vmcnt(1): everything but the newest load) covers the DMA tile and leaves the prefetch in
-    // flight; in-order retirement gives every prefetch two iterations to land.  Exactly one prefetch instruction per
-    // iteration (out-of-range offset -> returns 0 without a memory access once past the last tile) keeps the count static.
-    constexpr bool PF_OK = NBUF == 2 && BM <= 128 && BN <= 128 && BKD == 64;
-    const bool pf = PF_OK && l2_prefetch;
-    int pf_off = -1, pf_kmul = 0, pf_sink = 0;
-    i32x4 pf_rsrc = i32x4{0, 0, 0, 0x00020000};
-    if constexpr (PF_OK) if (pf) {
-        const int tg = threadIdx.x & 127;
-        if (wave < 2) {
-            pf_off = prefetch_line_offset<AKS, BM, BKD>(p.lda, tg);
-            pf_kmul = AKS ? (int)(p.lda * 2) : 2;
-            pf_rsrc = make_rsrc_words(a_base, a_left);
-        } else {
-            pf_off = prefetch_line_offset<BKS, BN, BKD>(p.ldb, tg);
-            pf_kmul = BKS ? (int)(p.ldb * 2) : 2;
-            pf_rsrc = make_rsrc_words(b_base, b_left);
-        }
-    }
-    auto prefetch_tile = [&](int t) {
-        const int v = (t < nk && pf_off >= 0) ? pf_off + (kbeg + t * BKD) * pf_kmul : (int)0xfffffff8u;
-        asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "+v"(pf_sink) : "v"(v), "s"(pf_rsrc) : "memory");
-    };
-#pragma unroll
-    for (int t = 0; t < NBUF - 1; ++t) {
-        if (t < nk) issue_tile(t, t);
-    }
-    if (pf) {
-        prefetch_tile(1);
-        prefetch_tile(2);
-    }
-    int buf = 0;  // ring slot of tile kt
-    for (int kt = 0; kt < nk; ++kt) {
-        const int ahead = min(nk - 1 - kt, NBUF - 2);  // tiles requested after kt that may stay in flight
-        if (NBUF >= 4 && ahead >= 2) wait_vmcnt<2 * L>();
-        else if (NBUF >= 3 && ahead >= 1) wait_vmcnt<L>();
-        else if (pf && kt == 0) wait_vmcnt<2>();
-        else if (pf) wait_vmcnt<1>();
-        else wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();  // tile kt landed for every wave; every wave is done with tile kt-1
-        asm volatile("" ::: "memory");
-        const int nt = kt + NBUF - 1;
-        if (nt < nk) {
-            const int nb = (buf == 0) ? NBUF - 1 : buf - 1;  // the slot tile kt-1 just vacated
-            issue_tile(nt, nb);
-        }
-        if (pf) prefetch_tile(kt + 3);
-        const bf16* a_lds = reinterpret_cast<const bf16*>(sA + buf * A_BYTES);
-        const bf16* b_lds = reinterpret_cast<const bf16*>(sB + buf * B_BYTES);
-#pragma unroll
-        for (int kk = 0; kk < BKD / 32; ++kk) {
-            Frag<bf16> af[FM], bfr[FN];
-#pragma unroll
-            for (int i = 0; i < FM; ++i) af[i] = TA::frag(a_lds, wm * WTM + i * 16, kk, c, g);
-#pragma unroll
-            for (int j = 0; j < FN; ++j) bfr[j] = TB::frag(b_lds, wn * WTN + j * 16, kk, c, g);
-#pragma unroll
-            for (int i = 0; i < FM; ++i)
-#pragma unroll
-                for (int j = 0; j < FN; ++j) mma(af[i], bfr[j], acc[i][j]);
-            if constexpr (AKS) {  // the fused bias gradient exists for wgrad only: no branch in the fwd / dgrad loops
-                if (do_colsum) {
-#pragma unroll
-                    for (int i = 0; i < FM; ++i) mma(af[i], ones, accb[i]);
-                }
-            }
-        }
-        buf = (buf + 1 == NBUF) ? 0 : buf + 1;
-    }
-    if (pf) {
-        wait_vmcnt<0>();  // the sink register is free again only when no prefetch is in flight
-        asm volatile("" ::"v"(pf_sink));
-    }
-    __syncthreads();  // all waves finished reading the operand tiles before the epilogue reuses the LDS
-    if constexpr (AKS) {
-        if (do_colsum) store_colsum<FM>(p, accb, m0, wm * WTM, z, c, g);
-    }
-    gemm_epilogue_bf16<BM, BN, false>(p, acc, smem_raw, m0, n0, z);
-}
-
-// ------------------------------------------------------------------------------------------------------------
-// Persistent, warp-specialised variant (the default bf16 main loop).
-//
-// Why: with one output tile per workgroup the DMA kernel above is latency bound on this path's short-K shapes
-// (K = 96..384 is 2..6 k-tiles): every k-tile waits a full memory round trip with one tile in flight, and the heavy
-// epilogue (GELU, side tensors, residual) runs with nothing in flight at all.  Here a workgroup is 6 waves:
-//   waves 0-3  consumers: MFMA main loop + fused epilogue, one output tile after another (persistent);
-//   wave  4    producer of the A tiles, wave 5 producer of the B tiles: nothing but LDS-DMA issue + counted waits.
-// The producers run NST-1 k-tiles ahead of the consumers ACROSS output tiles, so the next tile's operands stream in
-// while the consumers are still in the epilogue of the current one; a producer's vmcnt only ever counts its own DMA
-// loads, so the counted waits stay exact (the consumers' epilogue loads / stores live on other waves' counters).
-// One s_barrier per k-tile joins all 6 waves: "k-tile t has landed" and "k-tile t-1 has been consumed".
-// Two workgroups share a CU (2 x 80 KiB of LDS), so one's epilogue VALU work overlaps the other's MFMA work.
-constexpr int WS_THREADS = 384;
-
-// this workgroup's sequence of work items (output tile x split-K slice / batch item), XCD-aware: the dispatcher places
-// workgroup b on XCD b % 8; every XCD owns a contiguous range of item ids and its workgroups stride through it, so at
-// any time the tiles in flight on one XCD are neighbours (shared A row panels / B column panels hit the same L2).
-struct WorkIter {
-    int hi, stride, v;
-    __device__ __forceinline__ void init(int total) {
-        const int G = gridDim.x, b = blockIdx.x;
-        if (G >= 8) {
-            const int xcd = b & 7, j = b >> 3;
-            const int q = total / 8, r = total % 8;
-            const int lo = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-            hi = lo + (xcd < r ? q + 1 : q);
-            stride = G / 8 + ((xcd < (G & 7)) ? 1 : 0);
-            v = lo + j;
-        } else {
-            hi = total;
-            stride = G;
-            v = b;
-        }
-    }
-    __device__ __forceinline__ bool valid() const { return v < hi; }
-    __device__ __forceinline__ void next() { v += stride; }
-};
-
-struct WorkItem {
-    int m0, n0, z, kbeg, kend, nk;
-};
-
-template <int BM, int BN, int BKD>
-__device__ __forceinline__ WorkItem decode_item(const esvit_gemm_desc& p, int v, int ntiles, int tiles_n, int nz, int zmajor) {
-    WorkItem w;
-    int tile;
-    if (zmajor) {
-        w.z = v / ntiles;
-        tile = v - w.z * ntiles;
-    } else {
-        tile = v / nz;
-        w.z = v - tile * nz;
-    }
-    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
-    w.m0 = tm * BM;
-    w.n0 = tn * BN;
-    w.kbeg = 0;
-    w.kend = p.K;
-    if (p.splitk > 1) {
-        const int nkt = (p.K + BKD - 1) / BKD;
-        const int per = (nkt + p.splitk - 1) / p.splitk;
-        w.kbeg = w.z * per * BKD;
-        w.kend = min(p.K, (w.z + 1) * per * BKD);
-    }
-    w.nk = w.kend > w.kbeg ? (w.kend - w.kbeg + BKD - 1) / BKD : 0;
-    return w;
-}
-
-// producer wave: streams the ROWS x BKD tiles of one operand (IS_A: rows = m, else rows = n) for every k-tile of every
-// work item of this workgroup into the ring, NST-1 ahead of the consumers.
-template <bool KS, int ROWS, int BM, int BN, int BKD, int NST, bool IS_A>
-__device__ __forceinline__ void ws_producer(const esvit_gemm_desc& p, char* ring, int ntiles, int tiles_n, int nz, int zmajor, int lane, int ablate) {
-    using TT = DmaTile<KS, ROWS, BKD>;
-    constexpr int TILE_BYTES = TT::ELEMS * 2;
-    constexpr int LP = TT::INSTR_PER_TILE;
-    static_assert((NST - 1) * LP < 64, "vmcnt is 6 bits");
-    const bf16* base0 = reinterpret_cast<const bf16*>(IS_A ? p.A : p.B);
-    const long ld = IS_A ? p.lda : p.ldb;
-    const int rows_total = IS_A ? p.M : p.N;
-    const long stride_z = IS_A ? p.strideA : p.strideB;
-
-    WorkIter it;
-    it.init(ntiles * nz);
-    WorkItem w{};
-    int kt = 0;          // next k-tile of the current item to request
-    bool have = false;   // w holds an item with k-tiles left
-    __amdgpu_buffer_rsrc_t rs = make_rsrc(base0, 0);
-    int rows_left = 0;
-    auto fetch_item = [&]() {
-        have = false;
-        while (it.valid()) {
-            w = decode_item<BM, BN, BKD>(p, it.v, ntiles, tiles_n, nz, zmajor);
-            it.next();
-            if (w.nk > 0) {
-                const int r0 = IS_A ? w.m0 : w.n0;
-                const bf16* mat = base0 + (p.splitk > 1 ? 0L : (long)w.z * stride_z);
-                const long rows_stored = KS ? (long)p.K : (long)rows_total;  // rows of the stored matrix
-                const bf16* tb = KS ? mat + r0 : mat + (long)r0 * ld;
-                const long left = ((KS ? rows_stored : rows_stored - r0) * ld - (KS ? r0 : 0)) * 2;
-                rs = make_rsrc(tb, left);
-                rows_left = rows_total - r0;
-                kt = 0;
-                have = true;
-                return;
-            }
-        }
-    };
-    int voff[TT::INSTR_PER_TILE];
-    TT::lane_offsets(ld, lane, voff);
-    int issued = 0, consumed = 0, slot = 0;
-    auto issue_next = [&]() {
-        if (!have) return;
-        const int k0 = w.kbeg + kt * BKD;
-        if (ablate & 2) {  // profiling ablation: no loads (the consumers multiply whatever the LDS holds)
-        } else if (k0 + BKD <= w.kend && (!KS || rows_left >= ROWS)) TT::issue_all_fast(rs, ring + slot * TILE_BYTES, ld, k0, voff);
-        else TT::issue_all(rs, ring + slot * TILE_BYTES, ld, rows_left, k0, w.kend, lane);
-        slot = (slot + 1 == NST) ? 0 : slot + 1;
-        ++issued;
-        if (++kt == w.nk) fetch_item();
-    };
-    fetch_item();
-#pragma unroll
-    for (int t = 0; t < NST - 1; ++t) issue_next();
-    while (consumed < issued) {
-        const int ahead = issued - consumed - 1;  // k-tiles requested after the one the consumers need next
-        if (NST >= 4 && ahead >= 2) wait_vmcnt<(NST >= 4 ? 2 : 0) * LP>();
-        else if (NST >= 3 && ahead >= 1) wait_vmcnt<(NST >= 3 ? 1 : 0) * LP>();
-        else wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();  // k-tile `consumed` is in LDS; the consumers are done with k-tile consumed-1
-        asm volatile("" ::: "memory");
-        issue_next();                  // refills the slot of k-tile consumed-1
-        ++consumed;
-    }
-}
-
-template <bool AKS, bool BKS, int BM, int BN, int BKD, int NST>
-__global__ __launch_bounds__(WS_THREADS, 3) void gemm_ws_kernel(const esvit_gemm_desc p, int zmajor, int ablate) {
-    using TA = DmaTile<AKS, BM, BKD>;
-    using TB = DmaTile<BKS, BN, BKD>;
-    constexpr int WTM = BM / 2, WTN = BN / 2;
-    constexpr int FM = WTM / 16, FN = WTN / 16;
-    static_assert(NST >= 2 && NST <= 4, "ring depth");
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    constexpr int A_BYTES = TA::ELEMS * 2, B_BYTES = TB::ELEMS * 2;
-    char* sA = smem_raw;                  // NST slots
-    char* sB = smem_raw + NST * A_BYTES;  // NST slots
-    char* sE = sB + NST * B_BYTES;        // epilogue staging, one private region per consumer wave
-
-    const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
-    const int ntiles = tiles_m * tiles_n;
-    const int nz = p.splitk > 1 ? p.splitk : p.batch;
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-
-    if (wave == 4) {
-        ws_producer<AKS, BM, BM, BN, BKD, NST, true>(p, sA, ntiles, tiles_n, nz, zmajor, lane, ablate);
-        return;
-    }
-    if (wave == 5) {
-        ws_producer<BKS, BN, BM, BN, BKD, NST, false>(p, sB, ntiles, tiles_n, nz, zmajor, lane, ablate);
-        return;
-    }
-
-    const int c = lane & 15, g = lane >> 4;
-    const int wm = wave >> 1, wn = wave & 1;
-    const Frag<bf16> ones = ones_frag(bf16());
-    WorkIter it;
-    it.init(ntiles * nz);
-    int slot = 0;
-    for (; it.valid(); it.next()) {
-        const WorkItem w = decode_item<BM, BN, BKD>(p, it.v, ntiles, tiles_n, nz, zmajor);
-        f32x4 acc[FM][FN];
-#pragma unroll
-        for (int i = 0; i < FM; ++i)
-#pragma unroll
-            for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const bool do_colsum = p.colsum && w.n0 == 0 && wn == 0;
-        f32x4 accb[FM];
-#pragma unroll
-        for (int i = 0; i < FM; ++i) accb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-        for (int kt = 0; kt < w.nk; ++kt) {
-            __builtin_amdgcn_s_barrier();  // this k-tile has landed (the producers waited for it before arriving)
-            asm volatile("" ::: "memory");
-            const bf16* a_lds = reinterpret_cast<const bf16*>(sA + slot * A_BYTES);
-            const bf16* b_lds = reinterpret_cast<const bf16*>(sB + slot * B_BYTES);
-            if (!(ablate & 1)) {  // profiling ablation bit 0: no LDS reads / MFMAs
-#pragma unroll
-                for (int kk = 0; kk < BKD / 32; ++kk) {
-                    Frag<bf16> af[FM], bfr[FN];
-#pragma unroll
-                    for (int i = 0; i < FM; ++i) af[i] = TA::frag(a_lds, wm * WTM + i * 16, kk, c, g);
-#pragma unroll
-                    for (int j = 0; j < FN; ++j) bfr[j] = TB::frag(b_lds, wn * WTN + j * 16, kk, c, g);
-#pragma unroll
-                    for (int i = 0; i < FM; ++i)
-#pragma unroll
-                        for (int j = 0; j < FN; ++j) mma(af[i], bfr[j], acc[i][j]);
-                    if (do_colsum) {
-#pragma unroll
-                        for (int i = 0; i < FM; ++i) mma(af[i], ones, accb[i]);
-                    }
-                }
-            }
-            slot = (slot + 1 == NST) ? 0 : slot + 1;
-        }
-        if (ablate & 4) continue;  // profiling ablation bit 2: no epilogue
-        if (do_colsum) store_colsum<FM>(p, accb, w.m0, wm * WTM, w.z, c, g);
-        gemm_epilogue_bf16<BM, BN, true>(p, acc, sE, w.m0, w.n0, w.z);
-    }
-}
-
-// sum split-K partials: out[i] (+)= sum_z part[z*n + i]   (TO = float or the activation dtype).
-// 256 threads = 64 element quads x 4 split slices (slice sl sums z = sl, sl+4, ...), four loads in flight per thread,
-// slices combined through LDS: the 512-way reductions of the 96x96 stage-0 weights were latency-bound at one load in
-// flight and 9 workgroups.
-constexpr int SKR_QUADS = 64, SKR_SLICES = 4;
-template <typename TO>
-__device__ __forceinline__ void splitk_reduce_block(const float* __restrict__ part, int splits, long n, TO* __restrict__ out, int accumulate,
-                                                    long block, f32x4 (&sm)[SKR_SLICES][SKR_QUADS]) {
-    const int q = threadIdx.x & (SKR_QUADS - 1), sl = threadIdx.x / SKR_QUADS;
-    const long i4 = (block * SKR_QUADS + q) * 4;
-    const int cnt = i4 < n ? (int)min(4L, n - i4) : 0;
-    f32x4 s = {0.f, 0.f, 0.f, 0.f};
-    if (cnt == 4) {
-        const float* p = part + i4;
-        int z = sl;
-        for (; z + 3 * SKR_SLICES < splits; z += 4 * SKR_SLICES) {
-            const f32x4 v0 = *reinterpret_cast<const f32x4*>(p + (long)z * n);
-            const f32x4 v1 = *reinterpret_cast<const f32x4*>(p + (long)(z + SKR_SLICES) * n);
-            const f32x4 v2 = *reinterpret_cast<const f32x4*>(p + (long)(z + 2 * SKR_SLICES) * n);
-            const f32x4 v3 = *reinterpret_cast<const f32x4*>(p + (long)(z + 3 * SKR_SLICES) * n);
-            s += (v0 + v1) + (v2 + v3);
-        }
-        for (; z < splits; z += SKR_SLICES) s += *reinterpret_cast<const f32x4*>(p + (long)z * n);
-    } else if (cnt > 0) {
-        for (int z = sl; z < splits; z += SKR_SLICES)
-            for (int e = 0; e < cnt; ++e) s[e] += part[(long)z * n + i4 + e];
-    }
-    sm[sl][q] = s;
-    __syncthreads();
-    if (sl != 0 || cnt == 0) return;
-    s = (sm[0][q] + sm[1][q]) + (sm[2][q] + sm[3][q]);
-    for (int e = 0; e < cnt; ++e) {
-        float v = s[e];
-        if (accumulate) v += to_f32(out[i4 + e]);
-        out[i4 + e] = from_f32<TO>(v);
-    }
-}
-
-// blocks [0, blocks1): the split-K partial slabs of C;  blocks [blocks1, ..): the fused bias-gradient partials (part2, n2 -> out2)
-template <typename TO>
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, int splits, long n, TO* __restrict__ out,
-                                                            int accumulate, int blocks1, const float* __restrict__ part2, long n2,
-                                                            float* __restrict__ out2) {
-    __shared__ f32x4 sm[SKR_SLICES][SKR_QUADS];
-    if ((int)blockIdx.x < blocks1) splitk_reduce_block<TO>(part, splits, n, out, accumulate, blockIdx.x, sm);
-    else splitk_reduce_block<float>(part2, splits, n2, out2, 0, (long)blockIdx.x - blocks1, sm);
-}
-
-static int g_stagger = 0;      // shader cycles the second workgroup of each CU waits in the first round (bit 30: odd slots instead of slots 32..63)
-static int g_l2_prefetch = 0;  // 1: the LDS-DMA kernel prefetches k-tile kt+3 into the L2 (see gemm_dma_kernel)
-static int g_group_m = -1;  // -1: automatic (see launch_gemm_dma); >= 0 forces the row-block group of tile_coords()
-static int g_xcd_map = 0;  // 0: tiles on grid.x (XCD-remapped), z on grid.y; 1: 1-D grid, XCD-contiguous over (z, tile) -- measured 8% slower on the wgrad family (profiles/r01_gemm_xcdmap_ab.txt)
-
-template <typename T, bool AKS, bool BKS, int BM, int BN, bool USE_TR>
-int launch_gemm(const esvit_gemm_desc& d, hipStream_t stream) {
-    using TA = Tile<T, AKS, BM, USE_TR>;
-    using TB = Tile<T, BKS, BN, USE_TR>;
-    size_t lds = 2 * (size_t)(TA::ELEMS + TB::ELEMS) * sizeof(T);
-    const size_t stage_bytes = 4 * 32 * (size_t)(BN / 2 + 4) * sizeof(float);
-    if (lds < stage_bytes) lds = stage_bytes;
-    auto kern = gemm_kernel<T, AKS, BKS, BM, BN, USE_TR>;
-    static bool attr_done = false;  // one-time raise of the dynamic LDS cap (per instantiation)
-    if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)lds);
-        attr_done = true;
-    }
-    const int tiles = ceil_div(d.M, BM) * ceil_div(d.N, BN);
-    const int nz = d.splitk > 1 ? d.splitk : d.batch;
-    dim3 grid = g_xcd_map ? dim3(tiles * nz) : dim3(tiles, nz);
-    hipLaunchKernelGGL(kern, grid, dim3(NTHREADS), lds, stream, d);
-    ESVIT_CHECK_LAUNCH("esvit_gemm");
-    if (d.splitk > 1) {
-        const long n = (long)d.M * d.N;
-        const int blocks = ceil_div(ceil_div(n, 4), SKR_QUADS);
-        const int blocks2 = d.colsum ? ceil_div(ceil_div((long)d.M, 4), SKR_QUADS) : 0;  // bias-gradient partials ride along
-        if (d.out_f32)
-            hipLaunchKernelGGL(splitk_reduce_kernel<float>, dim3(blocks + blocks2), dim3(256), 0, stream, d.partial, d.splitk, n,
-                               reinterpret_cast<float*>(d.C), d.accumulate, blocks, d.colsum_partial, (long)d.M, d.colsum);
-        else
-            hipLaunchKernelGGL(splitk_reduce_kernel<T>, dim3(blocks + blocks2), dim3(256), 0, stream, d.partial, d.splitk, n,
-                               reinterpret_cast<T*>(d.C), d.accumulate, blocks, d.colsum_partial, (long)d.M, d.colsum);
-        ESVIT_CHECK_LAUNCH("esvit_gemm(splitk_reduce)");
-    }
-    return ESVIT_OK;
-}
-
-template <bool AKS, bool BKS, int BM, int BN, int BKD, int NBUF>
-int launch_gemm_dma(const esvit_gemm_desc& d, hipStream_t stream) {
-    using TA = DmaTile<AKS, BM, BKD>;
-    using TB = DmaTile<BKS, BN, BKD>;
-    size_t lds = (size_t)NBUF * (TA::ELEMS + TB::ELEMS) * 2;
-    const size_t stage_bytes = 4 * 32 * (size_t)(BN / 2 + 4) * sizeof(float);
-    if (lds < stage_bytes) lds = stage_bytes;
-    auto kern = gemm_dma_kernel<AKS, BKS, BM, BN, BKD, NBUF>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_done = true;
-    }
-    const int tiles = ceil_div(d.M, BM) * ceil_div(d.N, BN);
-    const int nz = d.splitk > 1 ? d.splitk : d.batch;
-    dim3 grid = g_xcd_map ? dim3(tiles * nz) : dim3(tiles, nz);
-    // grouped tile order only where a row block's column tiles outnumber what one XCD runs at a time
-    // (measured, profiles/r01_gemm_group_m_ab.txt: +5..13 % for 12..64 column tiles, nothing below, noise above)
-    const int tn_ = ceil_div(d.N, BN);
-    const int group_m = g_group_m >= 0 ? g_group_m : (nz == 1 && tn_ >= 12 && tn_ <= 64 ? 16 : 1);
-    hipLaunchKernelGGL(kern, grid, dim3(NTHREADS), lds, stream, d, group_m, g_l2_prefetch, tiles * nz > 512 ? g_stagger : 0);
-    ESVIT_CHECK_LAUNCH("esvit_gemm(dma)");
-    if (d.splitk > 1) {
-        const long n = (long)d.M * d.N;
-        const int blocks = ceil_div(ceil_div(n, 4), SKR_QUADS);
-        const int blocks2 = d.colsum ? ceil_div(ceil_div((long)d.M, 4), SKR_QUADS) : 0;  // bias-gradient partials ride along
-        if (d.out_f32)
-            hipLaunchKernelGGL(splitk_reduce_kernel<float>, dim3(blocks + blocks2), dim3(256), 0, stream, d.partial, d.splitk, n,
-                               reinterpret_cast<float*>(d.C), d.accumulate, blocks, d.colsum_partial, (long)d.M, d.colsum);
-        else
-            hipLaunchKernelGGL(splitk_reduce_kernel<bf16>, dim3(blocks + blocks2), dim3(256), 0, stream, d.partial, d.splitk, n,
-                               reinterpret_cast<bf16*>(d.C), d.accumulate, blocks, d.colsum_partial, (long)d.M, d.colsum);
-        ESVIT_CHECK_LAUNCH("esvit_gemm(dma splitk_reduce)");
-    }
-    return ESVIT_OK;
-}
-
-// work-item order of the persistent kernel: 0 = tile-major (all split-K slices of a tile adjacent), 1 = slice-major
-static int g_ws_zmajor = 0;
-static int g_ws_ablate = 0;  // profiling only: bit 0 no MFMA loop, bit 1 no DMA loads, bit 2 no epilogue (results are garbage)
-static int g_num_cus = 0;
-
-template <bool AKS, bool BKS, int BM, int BN, int BKD, int NST>
-int launch_gemm_ws(const esvit_gemm_desc& d, hipStream_t stream) {
-    using TA = DmaTile<AKS, BM, BKD>;
-    using TB = DmaTile<BKS, BN, BKD>;
-    constexpr int WTN = BN / 2;
-    constexpr int LDE = (WTN == 64) ? 64 : WTN + 4;
-    const size_t lds = (size_t)NST * (TA::ELEMS + TB::ELEMS) * 2 + 4 * 16 * (size_t)LDE * sizeof(float);
-    auto kern = gemm_ws_kernel<AKS, BKS, BM, BN, BKD, NST>;
-    static int wg_per_cu = 0;  // per instantiation
-    if (!wg_per_cu) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (!g_num_cus) {
-            int dev = 0;
-            hipDeviceProp_t prop;
-            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) g_num_cus = prop.multiProcessorCount;
-            if (g_num_cus <= 0) g_num_cus = 256;
-        }
-        int occ = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(kern), WS_THREADS, lds) != hipSuccess || occ < 1) occ = 1;
-        wg_per_cu = occ > 2 ? 2 : occ;
-    }
-    const int tiles = ceil_div(d.M, BM) * ceil_div(d.N, BN);
-    const int nz = d.splitk > 1 ? d.splitk : d.batch;
-    const long total = (long)tiles * nz;
-    const int grid = (int)(total < (long)wg_per_cu * g_num_cus ? total : (long)wg_per_cu * g_num_cus);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(WS_THREADS), lds, stream, d, g_ws_zmajor, g_ws_ablate);
-    ESVIT_CHECK_LAUNCH("esvit_gemm(ws)");
-    if (d.splitk > 1) {
-        const long n = (long)d.M * d.N;
-        const int blocks = ceil_div(ceil_div(n, 4), SKR_QUADS);
-        const int blocks2 = d.colsum ? ceil_div(ceil_div((long)d.M, 4), SKR_QUADS) : 0;  // bias-gradient partials ride along
-        if (d.out_f32)
-            hipLaunchKernelGGL(splitk_reduce_kernel<float>, dim3(blocks + blocks2), dim3(256), 0, stream, d.partial, d.splitk, n,
-                               reinterpret_cast<float*>(d.C), d.accumulate, blocks, d.colsum_partial, (long)d.M, d.colsum);
-        else
-            hipLaunchKernelGGL(splitk_reduce_kernel<bf16>, dim3(blocks + blocks2), dim3(256), 0, stream, d.partial, d.splitk, n,
-                               reinterpret_cast<bf16*>(d.C), d.accumulate, blocks, d.colsum_partial, (long)d.M, d.colsum);
-        ESVIT_CHECK_LAUNCH("esvit_gemm(ws splitk_reduce)");
-    }
-    return ESVIT_OK;
-}
-
-
-// pipeline shape (debug switch): 1 = BK64 x 2 buffers (default: 64 KiB -> 2 workgroups/CU); 2 = BK32 x 2 (32 KiB -> 4/CU);
-// 3 = BK64 x 3-deep ring; 4 = BK32 x 4-deep ring; 5 = BK32 x 3-deep ring (48 KiB -> 3/CU)
-static int g_dma_pipe = 1;
-
-template <bool AKS, bool BKS, int BM, int BN>
-int dispatch_pipe(const esvit_gemm_desc& d, hipStream_t stream) {
-    if constexpr (BN != 96) {  // 96-wide tiles are a whole number of DMA instructions only at BK = 64
-        if (g_dma_pipe == 2) return launch_gemm_dma<AKS, BKS, BM, BN, 32, 2>(d, stream);
-        if (g_dma_pipe == 4) return launch_gemm_dma<AKS, BKS, BM, BN, 32, 4>(d, stream);
-        if (g_dma_pipe == 5) return launch_gemm_dma<AKS, BKS, BM, BN, 32, 3>(d, stream);
-    }
-    if (g_dma_pipe == 6) return launch_gemm_ws<AKS, BKS, BM, BN, 64, 2>(d, stream);
-    if (g_dma_pipe == 7) return launch_gemm_ws<AKS, BKS, BM, BN, 32, 4>(d, stream);
-    if (g_dma_pipe >= 3) return launch_gemm_dma<AKS, BKS, BM, BN, 64, 3>(d, stream);
-    return launch_gemm_dma<AKS, BKS, BM, BN, 64, 2>(d, stream);
-}
-
-static int g_tile_m64 = 0;  // 1: use 64-row tiles where 128-row tiles quantise badly over the resident workgroup slots (measured 3 % slower over the step at B = 128: the shorter tile costs more than the 0.58 assumed below -- kept as a switch)
-
-// Every workgroup of a GEMM launch runs about equally long, so the launch takes ceil(tiles / resident slots) rounds:
-// 588 tiles on 512 slots (stage-3 fc2 at B = 128) leave the chip 43 % idle.  Where the 128-row tiling would waste more
-// than a fifth of the last round, 64-row tiles (48 KiB of LDS -> 3 workgroups per CU) give twice as many, shorter,
-// tiles.  Forward / dgrad only: wgrad sizes its grid with split-K instead.
-inline bool prefer_m64(const esvit_gemm_desc& d, int bn) {
-    if (!g_tile_m64 || d.splitk > 1 || d.batch > 1 || d.a_kstrided) return false;
-    const long t128 = (long)ceil_div(d.M, 128) * ceil_div(d.N, bn);
-    const long t64 = (long)ceil_div(d.M, 64) * ceil_div(d.N, bn);
-    const double r128 = (double)((t128 + 511) / 512);          // rounds of full-size tiles
-    const double r64 = (double)((t64 + 767) / 768) * 0.58;     // a 64-row tile costs ~0.58 of a 128-row one
-    return t128 > 256 && r64 < 0.85 * r128;
-}
-
-static int g_tile_m256 = 0;  // 1: 256-row tiles (wave tile 128 x 64|48, BK = 32) for grids that still fill the chip twice over
-
-inline bool prefer_m256(const esvit_gemm_desc& d, int bn) {
-    if (!g_tile_m256 || d.splitk > 1 || d.batch > 1 || d.a_kstrided || d.K < 256) return false;
-    return (long)ceil_div(d.M, 256) * ceil_div(d.N, bn) >= 1024;
+    c.kernel = want;
+    if (want == ESVIT_GEMM_DMA8) dma8_tile(d, c.bm, c.bn);
+    else dma4_tile(d, c.bm, c.bn);
+    return c;
 }
 
 template <bool AKS, bool BKS>
-int dispatch_tile_dma(const esvit_gemm_desc& d, hipStream_t stream) {
-    const bool n96 = (d.N % 96 == 0) && (d.N % 128 != 0);
-    if constexpr (!AKS) {
-        if (g_dma_pipe == 1 && !n96 && d.N > 64 && prefer_m256(d, 128)) return launch_gemm_dma<AKS, BKS, 256, 128, 32, 2>(d, stream);
-        if (g_dma_pipe == 1) {
-            if (n96 && prefer_m64(d, 96)) return launch_gemm_dma<AKS, BKS, 64, 96, 64, 2>(d, stream);
-            if (!n96 && d.N > 64 && prefer_m64(d, 128)) return launch_gemm_dma<AKS, BKS, 64, 128, 64, 2>(d, stream);
-        }
+int run_dma4(const esvit_gemm_desc& d, int bn, hipStream_t stream) {
+    if (bn == 96) return launch_gemm_dma<AKS, BKS, 128, 96, 64, 2, 2, 2>(d, stream);
+    if (bn == 64) return launch_gemm_dma<AKS, BKS, 128, 64, 64, 2, 2, 2>(d, stream);
+    return launch_gemm_dma<AKS, BKS, 128, 128, 64, 2, 2, 2>(d, stream);
+}
+
+// 8 waves: 256 x 256 as 2 x 4 waves of 128 x 64 (128-byte bf16 row pieces in the epilogue), 256 x 192 as 4 x 2 waves of
+// 64 x 96, 192-row tiles (weight gradients of the 96 * 2^s wide backbone) as 2 x 4 waves of 96 x {48, 64}
+template <bool AKS, bool BKS>
+int run_dma8(const esvit_gemm_desc& d, int bm, int bn, hipStream_t stream) {
+    if constexpr (AKS) {
+        if (bm == 192 && bn == 192) return launch_gemm_dma<AKS, BKS, 192, 192, 64, 2, 2, 4>(d, stream);
+        if (bm == 192) return launch_gemm_dma<AKS, BKS, 192, 256, 64, 2, 2, 4>(d, stream);
     }
-    if (n96) return dispatch_pipe<AKS, BKS, 128, 96>(d, stream);
-    if (d.N <= 64) return dispatch_pipe<AKS, BKS, 128, 64>(d, stream);
-    return dispatch_pipe<AKS, BKS, 128, 128>(d, stream);
+    if (bn == 192) return launch_gemm_dma<AKS, BKS, 256, 192, 64, 2, 4, 2>(d, stream);
+    return launch_gemm_dma<AKS, BKS, 256, 256, 64, 2, 2, 4>(d, stream);
 }
 
-template <typename T, bool AKS, bool BKS, bool USE_TR>
-int dispatch_tile(const esvit_gemm_desc& d, hipStream_t stream) {
-    // backbone widths are multiples of 96 (96*2^s, x3, x4); head widths are powers of two.
-    const bool n96 = (d.N % 96 == 0) && (d.N % 128 != 0);
-    if (n96) return launch_gemm<T, AKS, BKS, 128, 96, USE_TR>(d, stream);
-    if (d.N <= 64) return launch_gemm<T, AKS, BKS, 128, 64, USE_TR>(d, stream);
-    return launch_gemm<T, AKS, BKS, 128, 128, USE_TR>(d, stream);
+template <typename T, bool AKS, bool BKS>
+int run_regstage(const esvit_gemm_desc& d, int bn, hipStream_t stream) {
+    if (bn == 96) return launch_gemm<T, AKS, BKS, 128, 96, true>(d, stream);
+    if (bn == 64) return launch_gemm<T, AKS, BKS, 128, 64, true>(d, stream);
+    return launch_gemm<T, AKS, BKS, 128, 128, true>(d, stream);
 }
 
-template <typename T, bool USE_TR>
-int dispatch_layout(const esvit_gemm_desc& d, hipStream_t stream) {
-    if (!d.a_kstrided && !d.b_kstrided) return dispatch_tile<T, false, false, USE_TR>(d, stream);
-    if (!d.a_kstrided && d.b_kstrided) return dispatch_tile<T, false, true, USE_TR>(d, stream);
-    if (d.a_kstrided && d.b_kstrided) return dispatch_tile<T, true, true, USE_TR>(d, stream);
-    esvit_set_error("esvit_gemm: layout a_kstrided=1,b_kstrided=0 is not used on the path");
-    return ESVIT_ERR_UNSUPPORTED;
+template <bool AKS, bool BKS>
+int run_layout(int dtype, const esvit_gemm_desc& d, const GemmChoice& c, hipStream_t stream) {
+    if (dtype == ESVIT_BF16) {
+        if (c.kernel == ESVIT_GEMM_DMA8) return run_dma8<AKS, BKS>(d, c.bm, c.bn, stream);
+        if (c.kernel == ESVIT_GEMM_DMA4) return run_dma4<AKS, BKS>(d, c.bn, stream);
+        return run_regstage<bf16, AKS, BKS>(d, c.bn, stream);
+    }
+    return run_regstage<float, AKS, BKS>(d, c.bn, stream);
 }
 
-}  // namespace
-
-static int g_use_tr = 1;
-static int g_use_dma = 1;
-extern "C" void esvit_debug_set_tr_read(int on) { g_use_tr = on; }
-extern "C" void esvit_debug_set_gemm_dma(int on) { g_use_dma = on; }
-extern "C" void esvit_debug_set_gemm_pipe(int mode) { g_dma_pipe = mode; }
-extern "C" void esvit_debug_set_gemm_m64(int on) { g_tile_m64 = on; }
-extern "C" void esvit_debug_set_gemm_group_m(int g) { g_group_m = g; }
-extern "C" void esvit_debug_set_gemm_l2_prefetch(int on) { g_l2_prefetch = on; }
-extern "C" void esvit_debug_set_gemm_stagger(int cycles) { g_stagger = cycles; }
-extern "C" void esvit_debug_set_gemm_m256(int on) { g_tile_m256 = on; }
-extern "C" void esvit_debug_set_gemm_xcdmap(int mode) { g_xcd_map = mode; g_ws_zmajor = mode; }
-extern "C" void esvit_debug_set_gemm_ws_ablate(int bits) { g_ws_ablate = bits; }
-// resident workgroups per CU of the persistent kernel's 128x128 tile (LDS-limited: 2 x 80 KiB), for tests / tuning
-extern "C" int esvit_debug_gemm_ws_occupancy(int lds_bytes) {
-    int occ = -1;
-    auto kern = gemm_ws_kernel<false, false, 128, 128, 64, 2>;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(kern), WS_THREADS, (size_t)lds_bytes) != hipSuccess) return -1;
-    return occ;
-}
-
-extern "C" int esvit_gemm(int dtype, const esvit_gemm_desc* dp, esvit_stream_t stream_) {
-    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
-    ESVIT_CHECK_ARG(dp != nullptr, "esvit_gemm: null descriptor");
-    esvit_gemm_desc d = *dp;
+int validate(int dtype, esvit_gemm_desc& d) {
     ESVIT_CHECK_ARG(d.A && d.B && d.C, "esvit_gemm: null operand");
     ESVIT_CHECK_ARG(d.M > 0 && d.N > 0 && d.K > 0, "esvit_gemm: bad shape M=%d N=%d K=%d", d.M, d.N, d.K);
     const int vec = dtype == ESVIT_BF16 ? 8 : 4;
@@ -1537,6 +110,7 @@ extern "C" int esvit_gemm(int dtype, const esvit_gemm_desc* dp, esvit_stream_t s
     if (d.a_kstrided) ESVIT_CHECK_ARG(d.M % vec == 0, "esvit_gemm: M=%d must be a multiple of %d (k-strided A)", d.M, vec);
     if (d.b_kstrided) ESVIT_CHECK_ARG(d.N % vec == 0, "esvit_gemm: N=%d must be a multiple of %d (k-strided B)", d.N, vec);
     ESVIT_CHECK_ARG(((uintptr_t)d.A % 16 == 0) && ((uintptr_t)d.B % 16 == 0), "esvit_gemm: operands must be 16-byte aligned");
+    ESVIT_CHECK_ARG(!(d.a_kstrided && !d.b_kstrided), "esvit_gemm: layout a_kstrided=1,b_kstrided=0 is not used on the path");
     if (d.batch < 1) d.batch = 1;
     if (d.splitk > 1) {
         ESVIT_CHECK_ARG(d.batch == 1 && d.partial && d.ldc == d.N, "esvit_gemm: split-K needs batch=1, a workspace and a dense C");
@@ -1550,17 +124,34 @@ extern "C" int esvit_gemm(int dtype, const esvit_gemm_desc* dp, esvit_stream_t s
     ESVIT_CHECK_ARG(d.epilogue >= 0 && d.epilogue <= ESVIT_EPI_QGELU_BWD, "esvit_gemm: bad epilogue %d", d.epilogue);
     if (d.colsum && d.splitk > 1) ESVIT_CHECK_ARG(d.colsum_partial != nullptr, "esvit_gemm: colsum with split-K needs colsum_partial");
     if (d.colsum) ESVIT_CHECK_ARG(d.batch == 1, "esvit_gemm: colsum is not batched");
-    if (dtype == ESVIT_BF16) {
-        // LDS-DMA main loop (BK = 64) for every bf16 GEMM; K = 96 runs two k-tiles with the second half zero-filled
-        // by the descriptor's range check, which costs MFMA issue slots these HBM-bound shapes do not miss
-        // (profiles/r01_gemm_k96_dma_vs_regstage.txt).  g_use_dma = 3 restores the old K >= 192 rule.
-        const bool deep = d.a_kstrided || d.K >= 192;
-        if (g_use_dma && g_use_tr && (deep || g_use_dma != 3)) {
-            if (!d.a_kstrided && !d.b_kstrided) return dispatch_tile_dma<false, false>(d, stream);
-            if (!d.a_kstrided && d.b_kstrided) return dispatch_tile_dma<false, true>(d, stream);
-            if (d.a_kstrided && d.b_kstrided) return dispatch_tile_dma<true, true>(d, stream);
-        }
-        return g_use_tr ? dispatch_layout<bf16, true>(d, stream) : dispatch_layout<bf16, false>(d, stream);
-    }
-    return dispatch_layout<float, false>(d, stream);
+    ESVIT_CHECK_ARG(d.kernel >= ESVIT_GEMM_AUTO && d.kernel <= ESVIT_GEMM_DMA8, "esvit_gemm: bad kernel selector %d", d.kernel);
+    if (dtype != ESVIT_BF16) ESVIT_CHECK_ARG(d.kernel == ESVIT_GEMM_AUTO || d.kernel == ESVIT_GEMM_REGSTAGE, "esvit_gemm: fp32 runs on the register-staged loop only");
+    return ESVIT_OK;
+}
+
+}  // namespace
+
+extern "C" int esvit_gemm_select(int dtype, const esvit_gemm_desc* dp, int* tile_m, int* tile_n, int* resident_slots) {
+    ESVIT_CHECK_ARG(dp != nullptr, "esvit_gemm_select: null descriptor");
+    esvit_gemm_desc d = *dp;
+    if (d.batch < 1) d.batch = 1;
+    ESVIT_CHECK_ARG(d.M > 0 && d.N > 0 && d.K > 0, "esvit_gemm_select: bad shape M=%d N=%d K=%d", d.M, d.N, d.K);
+    ESVIT_CHECK_ARG(d.kernel >= ESVIT_GEMM_AUTO && d.kernel <= ESVIT_GEMM_DMA8, "esvit_gemm_select: bad kernel selector %d", d.kernel);
+    const GemmChoice c = choose(dtype, d);
+    if (tile_m) *tile_m = c.bm;
+    if (tile_n) *tile_n = c.bn;
+    if (resident_slots) *resident_slots = c.kernel == ESVIT_GEMM_DMA8 ? 256 : 512;  // workgroups the chip holds at once (256 CUs)
+    return c.kernel;
+}
+
+extern "C" int esvit_gemm(int dtype, const esvit_gemm_desc* dp, esvit_stream_t stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    ESVIT_CHECK_ARG(dp != nullptr, "esvit_gemm: null descriptor");
+    esvit_gemm_desc d = *dp;
+    const int rc = validate(dtype, d);
+    if (rc != ESVIT_OK) return rc;
+    const GemmChoice c = choose(dtype, d);
+    if (!d.a_kstrided && !d.b_kstrided) return run_layout<false, false>(dtype, d, c, stream);
+    if (!d.a_kstrided && d.b_kstrided) return run_layout<false, true>(dtype, d, c, stream);
+    return run_layout<true, true>(dtype, d, c, stream);
 }

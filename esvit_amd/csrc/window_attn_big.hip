@@ -116,36 +116,6 @@ struct SlotStage {
     }
 };
 
-template <typename T, int NROWS, int NTHR>
-__device__ __forceinline__ void stage_slots(const T* __restrict__ g, long row_stride, const int* tok_lds, long tok_base, int s0, int N,
-                                            float scale, const float* __restrict__ pad, T* lds, int tid) {
-    SlotStage<T, NROWS, NTHR> st;
-    st.load(g, row_stride, tok_lds, tok_base, s0, N, pad, tid);
-    st.store(lds, scale, tid);
-}
-
-// two matrices at once (K and V, Q and dO): both sets of loads are in flight before either image is written
-template <typename T, int NROWS, int NTHR>
-__device__ __forceinline__ void stage_slots2(const T* __restrict__ ga, long stride_a, float scale_a, const float* __restrict__ pad_a, T* lds_a,
-                                             const T* __restrict__ gb, long stride_b, float scale_b, const float* __restrict__ pad_b, T* lds_b,
-                                             const int* tok_lds, long tok_base, int s0, int N, int tid) {
-    SlotStage<T, NROWS, NTHR> sa, sb;
-    sa.load(ga, stride_a, tok_lds, tok_base, s0, N, pad_a, tid);
-    sb.load(gb, stride_b, tok_lds, tok_base, s0, N, pad_b, tid);
-    sa.store(lds_a, scale_a, tid);
-    sb.store(lds_b, scale_b, tid);
-}
-
-template <typename T>
-__device__ __forceinline__ void store_frag4(T* p, f32x4 v) {
-    if constexpr (sizeof(T) == 4) {
-        *reinterpret_cast<f32x4*>(p) = v;
-    } else {
-        bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
-        *reinterpret_cast<bf16x4*>(p) = o;
-    }
-}
-
 // bias_frag[h][((ki*NT + qj)*64 + lane)*4 + r] = table[a(q) - a(key) + off][h] for q = 16qj + c, key = 16ki + 4g + r
 // (0 for padded queries, -1e30 for padded keys): one 16-byte load per lane per 16x16 score tile replaces four LDS table
 // gathers and ~40 VALU instructions -- the first version of these kernels spent 40-50 VALU instructions per MFMA on it.
@@ -171,40 +141,6 @@ __global__ void relpos_bias_frag_big_kernel(const float* __restrict__ table, int
     out[i] = v;
 }
 
-// bias tile (ki, qj) of this head + the shift mask rebuilt from the region labels packed in tb.pk (bits 16..)
-__device__ __forceinline__ f32x4 bias_tile(const float* __restrict__ bias_h, const BigTables& tb, int ki, int qj, int lane, int g, bool masked) {
-    f32x4 b = *reinterpret_cast<const f32x4*>(bias_h + ((ki * NT + qj) * 64 + lane) * 4);
-    if (masked) {
-        const int rq = tb.pk[16 * qj + (lane & 15)] >> 16;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) b[r] += ((tb.pk[16 * ki + 4 * g + r] >> 16) != rq) ? -100.f : 0.f;
-    }
-    return b;
-}
-
-
-// write a [32 rows][32 d] result (D layout acc[ti][jd]: row 16ti+4g+r, cols 16jd+c) to token rows; pad slots -> pad sums
-template <typename T>
-__device__ __forceinline__ void store_block_rows(const f32x4 (&acc)[2][2], float mul, T* __restrict__ dst, long row_stride,
-                                                 const int* tok_lds, long tok_base, int s0, int N, bool active, f32x2* pad, int c, int g) {
-#pragma unroll
-    for (int ti = 0; ti < 2; ++ti)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int t = s0 + 16 * ti + 4 * g + r;
-            if (!active || t >= N) continue;
-            const int tok = tok_lds[t];
-            const float v0 = acc[ti][0][r] * mul, v1 = acc[ti][1][r] * mul;
-            if (tok >= 0) {
-                T* rowp = dst + (tok_base + tok) * row_stride;
-                rowp[c] = from_f32<T>(v0);
-                rowp[16 + c] = from_f32<T>(v1);
-            } else if (pad) {
-                (*pad)[0] += v0;
-                (*pad)[1] += v1;
-            }
-        }
-}
 
 // same result, but through an LDS transpose ([32][LDQ] image private to the wave): every lane stores 16-byte row vectors
 // (2 per lane) instead of 16 two-byte scatters.  pad-slot rows are summed into padacc[VEC] (columns dv*VEC.., dv = lane % VPR).
@@ -238,125 +174,6 @@ __device__ __forceinline__ void store_block_rows_vec(const f32x4 (&acc)[2][2], f
         }
     }
     __builtin_amdgcn_wave_barrier();
-}
-
-// -------------------------------------------------------------------------------------------------------------
-// forward
-// -------------------------------------------------------------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(BigCfg<T>::WAVES * 64) void attn_big_fwd_kernel(
-    const T* __restrict__ qkv, const float* __restrict__ qkv_bias, const int* __restrict__ win2tok, int L,
-    const float* __restrict__ bias_frag, int rel_rows, int ws, const int* __restrict__ region_ids, int nW, int Bw, int N, int nH,
-    float scale, T* __restrict__ out, float* __restrict__ lse_out, float* __restrict__ attn_out) {
-    using Cfg = BigCfg<T>;
-    constexpr int LDQ = Cfg::LDQ, LDP = Cfg::LDP, WAVES = Cfg::WAVES;
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    const BigTables tb = carve_tables(smem_raw);
-    T* Ks = reinterpret_cast<T*>(smem_raw + Cfg::TABLE_BYTES);
-    T* Vs = Ks + Cfg::FULL;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int c = lane & 15, g = lane >> 4;
-    T* Qs = Vs + Cfg::FULL + wave * (Cfg::BLK + Cfg::PIMG);
-    T* Ps = Qs + Cfg::BLK;
-
-    const int unit = blockIdx.x;  // (bw, h)
-    const int bw = unit / nH, h = unit % nH;
-    const int C = nH * HD;
-    const long tok_base = (long)(bw / nW) * L;
-    const T* src = qkv + h * HD;
-    const bool masked = region_ids != nullptr;
-
-    load_window_tables(tb, win2tok, region_ids, bw % nW, N, ws, true);
-    const float* bias_h = bias_frag + (long)h * (NT * NT * 256);
-    __syncthreads();
-    stage_slots2<T, NPB, WAVES * 64>(src + C, 3L * C, 1.f, qkv_bias + C + h * HD, Ks, src + 2 * C, 3L * C, 1.f, qkv_bias + 2 * C + h * HD, Vs,
-                                     tb.tok, tok_base, 0, N, threadIdx.x);
-
-    for (int pass = 0; pass < (NQB + WAVES - 1) / WAVES; ++pass) {
-        const int qb = wave + pass * WAVES;
-        const bool valid = qb < NQB;
-        const int q0 = valid ? 32 * qb : 0;
-        if (pass == 0) __syncthreads();  // K, V staged by the whole workgroup; Qs / Ps below are private to the wave
-        __builtin_amdgcn_wave_barrier();
-        stage_slots<T, 32, 64>(src, 3L * C, tb.tok, tok_base, q0, N, scale, qkv_bias + h * HD, Qs, lane);
-        __builtin_amdgcn_wave_barrier();
-
-        f32x4 p[NT][2];
-        {
-            Frag<T> qf[2];
-            qf[0] = frag_kc<T>(Qs, LDQ, 0, 0, c, g);
-            qf[1] = frag_kc<T>(Qs, LDQ, 16, 0, c, g);
-#pragma unroll
-            for (int i = 0; i < NT; ++i) {
-                const Frag<T> kf = frag_kc<T>(Ks, LDQ, 16 * i, 0, c, g);
-                p[i][0] = bias_tile(bias_h, tb, i, (q0 >> 4), lane, g, masked);
-                p[i][1] = bias_tile(bias_h, tb, i, (q0 >> 4) + 1, lane, g, masked);
-                mma(kf, qf[0], p[i][0]);
-                mma(kf, qf[1], p[i][1]);
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            float m = -3.0e38f;
-#pragma unroll
-            for (int i = 0; i < NT; ++i)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) m = fmaxf(m, p[i][j][r]);
-            m = fmaxf(m, __shfl_xor(m, 16, 64));
-            m = fmaxf(m, __shfl_xor(m, 32, 64));
-            float s = 0.f;
-#pragma unroll
-            for (int i = 0; i < NT; ++i)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float e = __expf(p[i][j][r] - m);
-                    p[i][j][r] = e;
-                    s += e;
-                }
-            s += __shfl_xor(s, 16, 64);
-            s += __shfl_xor(s, 32, 64);
-            const float inv = 1.f / s;
-#pragma unroll
-            for (int i = 0; i < NT; ++i) p[i][j] *= inv;
-            const int q = q0 + 16 * j + c;
-            if (valid && g == 0 && lse_out) lse_out[(long)unit * NPB + q] = m + __logf(s);
-        }
-        if (attn_out && valid) {
-#pragma unroll
-            for (int i = 0; i < NT; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int q = q0 + 16 * j + c, key = 16 * i + 4 * g + r;
-                        if (q < N && key < N) attn_out[((long)unit * N + q) * N + key] = p[i][j][r];
-                    }
-        }
-#pragma unroll
-        for (int i = 0; i < NT; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) store_frag4<T>(Ps + (16 * j + c) * LDP + 16 * i + 4 * g, p[i][j]);
-        __builtin_amdgcn_wave_barrier();
-
-        f32x4 o[2][2];
-#pragma unroll
-        for (int a = 0; a < 2; ++a) {
-            o[a][0] = f32x4{0.f, 0.f, 0.f, 0.f};
-            o[a][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-#pragma unroll
-        for (int ks = 0; ks < NPB / 32; ++ks) {
-            const Frag<T> v0 = frag_ks<T, true>(Vs, LDQ, 0, 32 * ks, c, g);
-            const Frag<T> v1 = frag_ks<T, true>(Vs, LDQ, 16, 32 * ks, c, g);
-#pragma unroll
-            for (int a = 0; a < 2; ++a) {
-                const Frag<T> pf = frag_kc<T>(Ps, LDP, 16 * a, 32 * ks, c, g);
-                mma(pf, v0, o[a][0]);
-                mma(pf, v1, o[a][1]);
-            }
-        }
-        store_block_rows_vec<T>(o, 1.f, Qs, out + h * HD, (long)C, tb.tok, tok_base, q0, N, valid, nullptr, lane, c, g);
-    }
 }
 
 // -------------------------------------------------------------------------------------------------------------
@@ -405,151 +222,6 @@ __device__ __forceinline__ Frag<T> frag_p_regs(const f32x4& lo, const f32x4& hi)
         }
     }
     return f;
-}
-
-template <typename T, bool WANT_ATTN>
-__global__ __launch_bounds__(BigCfg<T>::WAVES * 64, 2) void attn_big_fwd2_kernel(
-    const T* __restrict__ qkv, const float* __restrict__ qkv_bias, const int* __restrict__ win2tok, int L,
-    const float* __restrict__ bias_frag, int ws, const int* __restrict__ region_ids, int nW, int Bw, int N, int nH,
-    float scale, T* __restrict__ out, float* __restrict__ lse_out, float* __restrict__ attn_out) {
-    using Cfg = BigCfg<T>;
-    constexpr int LDQ = Cfg::LDQ, WAVES = Cfg::WAVES;
-    constexpr int PASSES = (NQB + WAVES - 1) / WAVES;
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    const BigTables tb = carve_tables(smem_raw);
-    T* Ks = reinterpret_cast<T*>(smem_raw + Cfg::TABLE_BYTES);
-    T* Vs = Ks + Cfg::FULL;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int c = lane & 15, g = lane >> 4;
-    T* Qs = Vs + Cfg::FULL + wave * Cfg::BLK;  // this wave's [32][LDQ] image: Q block, then the output transpose
-
-    const int unit = blockIdx.x;  // (bw, h)
-    const int bw = unit / nH, h = unit % nH;
-    const int C = nH * HD;
-    const long tok_base = (long)(bw / nW) * L;
-    const T* src = qkv + h * HD;
-    const bool masked = region_ids != nullptr;
-    const float* bias_h = bias_frag + (long)h * (NT * NT * 256);
-
-    load_window_tables(tb, win2tok, region_ids, bw % nW, N, ws, true);
-    __syncthreads();
-    SlotStage<T, 32, 64> sq;
-    {
-        SlotStage<T, NPB, WAVES * 64> sk, sv;
-        sk.load(src + C, 3L * C, tb.tok, tok_base, 0, N, qkv_bias + C + h * HD, threadIdx.x);
-        sv.load(src + 2 * C, 3L * C, tb.tok, tok_base, 0, N, qkv_bias + 2 * C + h * HD, threadIdx.x);
-        sq.load(src, 3L * C, tb.tok, tok_base, 32 * wave, N, qkv_bias + h * HD, lane);
-        sk.store(Ks, 1.f, threadIdx.x);
-        sv.store(Vs, 1.f, threadIdx.x);
-        sq.store(Qs, scale, lane);
-    }
-    // shift-mask region label of this lane's four keys in every key tile, 8 bits each
-    int rk[NT];
-#pragma unroll
-    for (int i = 0; i < NT; ++i) {
-        rk[i] = 0;
-        if (masked) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) rk[i] |= ((tb.pk[16 * i + 4 * g + r] >> 16) & 0xff) << (8 * r);
-        }
-    }
-    __syncthreads();  // K, V complete (whole workgroup); everything below is private to the wave
-
-#pragma unroll
-    for (int pass = 0; pass < PASSES; ++pass) {
-        const int qb = wave + pass * WAVES;
-        const bool valid = qb < NQB;
-        const int q0 = valid ? 32 * qb : 0;
-        if (pass > 0) {
-            __builtin_amdgcn_wave_barrier();
-            sq.store(Qs, scale, lane);
-            __builtin_amdgcn_wave_barrier();
-        }
-        Frag<T> qf[2];
-        qf[0] = frag_kc<T>(Qs, LDQ, 0, 0, c, g);
-        qf[1] = frag_kc<T>(Qs, LDQ, 16, 0, c, g);
-        if (pass + 1 < PASSES) {  // next pass's Q rows travel while this pass computes
-            const int qn = wave + (pass + 1) * WAVES;
-            sq.load(src, 3L * C, tb.tok, tok_base, qn < NQB ? 32 * qn : 0, N, qkv_bias + h * HD, lane);
-        }
-        int rq[2] = {0, 0};
-        if (masked) {
-            rq[0] = (tb.pk[q0 + c] >> 16) & 0xff;
-            rq[1] = (tb.pk[q0 + 16 + c] >> 16) & 0xff;
-        }
-        f32x4 p[NT][2];
-#pragma unroll
-        for (int i = 0; i < NT; ++i) {
-            const Frag<T> kf = frag_kc<T>(Ks, LDQ, 16 * i, 0, c, g);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                f32x4 b = *reinterpret_cast<const f32x4*>(bias_h + ((i * NT + (q0 >> 4) + j) * 64 + lane) * 4);
-                if (masked) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) b[r] += (((rk[i] >> (8 * r)) & 0xff) != rq[j]) ? -100.f : 0.f;
-                }
-                p[i][j] = b;
-                mma(kf, qf[j], p[i][j]);
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            float m = -3.0e38f;
-#pragma unroll
-            for (int i = 0; i < NT; ++i)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) m = fmaxf(m, p[i][j][r]);
-            m = fmaxf(m, __shfl_xor(m, 16, 64));
-            m = fmaxf(m, __shfl_xor(m, 32, 64));
-            float s = 0.f;
-#pragma unroll
-            for (int i = 0; i < NT; ++i)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float e = __expf(p[i][j][r] - m);
-                    p[i][j][r] = e;
-                    s += e;
-                }
-            s += __shfl_xor(s, 16, 64);
-            s += __shfl_xor(s, 32, 64);
-            const float inv = 1.f / s;
-#pragma unroll
-            for (int i = 0; i < NT; ++i) p[i][j] *= inv;
-            const int q = q0 + 16 * j + c;
-            if (valid && g == 0 && lse_out) lse_out[(long)unit * NPB + q] = m + __logf(s);
-        }
-        if constexpr (WANT_ATTN) {
-            if (valid) {
-#pragma unroll
-                for (int i = 0; i < NT; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int q = q0 + 16 * j + c, key = 16 * i + 4 * g + r;
-                            if (q < N && key < N) attn_out[((long)unit * N + q) * N + key] = p[i][j][r];
-                        }
-            }
-        }
-        f32x4 o[2][2];
-#pragma unroll
-        for (int a = 0; a < 2; ++a) {
-            o[a][0] = f32x4{0.f, 0.f, 0.f, 0.f};
-            o[a][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-#pragma unroll
-        for (int ks = 0; ks < NPB / 32; ++ks) {
-            const Frag<T> v0 = frag_v_perm<T>(Vs, LDQ, 0, ks, c, g);
-            const Frag<T> v1 = frag_v_perm<T>(Vs, LDQ, 16, ks, c, g);
-#pragma unroll
-            for (int a = 0; a < 2; ++a) {
-                const Frag<T> pf = frag_p_regs<T>(p[2 * ks][a], p[2 * ks + 1][a]);
-                mma(pf, v0, o[a][0]);
-                mma(pf, v1, o[a][1]);
-            }
-        }
-        store_block_rows_vec<T>(o, 1.f, Qs, out + h * HD, (long)C, tb.tok, tok_base, q0, N, valid, nullptr, lane, c, g);
-    }
 }
 
 // forward, third variant (default): the second generation with ONE 16-query tile per wave and pass.  A workgroup is seven
@@ -678,335 +350,6 @@ __global__ __launch_bounds__(FWD3_WAVES * 64, sizeof(T) == 2 ? 4 : 1) void attn_
                 const int tok = tb.tok[t];
                 if (tok >= 0) st16<T>(out + h * HD + (tok_base + tok) * (long)C + dv * VEC, ld16<T>(Qs + rl * LDQ + dv * VEC));
             }
-        }
-    }
-}
-
-// -------------------------------------------------------------------------------------------------------------
-// backward, part 1: dQ and the relative-position-bias gradient.  grid = parts * nH * GROUPS workgroups; wave `wave` of
-// group `grp` owns query block qb = grp * WAVES + wave for every window bw = part + k * parts.
-// -------------------------------------------------------------------------------------------------------------
-template <typename T, bool USE_TR>
-__global__ __launch_bounds__(BigCfg<T>::WAVES * 64, 1) void attn_big_bwd_dq_kernel(
-    const T* __restrict__ qkv, const float* __restrict__ qkv_bias, const int* __restrict__ win2tok, int L, const T* __restrict__ dout,
-    const float* __restrict__ bias_frag, int rel_rows, int ws, const int* __restrict__ region_ids, int nW, int Bw, int N, int nH,
-    float scale, int parts, T* __restrict__ dqkv, float* __restrict__ dbias_ws) {
-    using Cfg = BigCfg<T>;
-    constexpr int LDQ = Cfg::LDQ, LDP = Cfg::LDP, WAVES = Cfg::WAVES;
-    constexpr int GROUPS = (NQB + WAVES - 1) / WAVES;
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    const BigTables tb = carve_tables(smem_raw);
-    T* Ks = reinterpret_cast<T*>(smem_raw + Cfg::TABLE_BYTES);
-    T* Vs = Ks + Cfg::FULL;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int c = lane & 15, g = lane >> 4;
-    T* Qs = Vs + Cfg::FULL + wave * (2 * Cfg::BLK + Cfg::PIMG);
-    T* Os = Qs + Cfg::BLK;
-    T* Ss = Os + Cfg::BLK;  // dS image [32 q][LDP]
-
-    const int grp = blockIdx.x % GROUPS;
-    const int ph = blockIdx.x / GROUPS;  // (part, h)
-    const int h = ph % nH, part = ph / nH;
-    const int qb = grp * WAVES + wave;
-    const bool wave_ok = qb < NQB;
-    const int q0 = wave_ok ? 32 * qb : 0;
-    const int C = nH * HD;
-    const bool masked = region_ids != nullptr;
-    const T* src = qkv + h * HD;
-
-    f32x4 db[NT][2];
-#pragma unroll
-    for (int i = 0; i < NT; ++i) {
-        db[i][0] = f32x4{0.f, 0.f, 0.f, 0.f};
-        db[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-    const float* bias_h = bias_frag + (long)h * (NT * NT * 256);
-
-    const int iters = (Bw + parts - 1) / parts;
-    for (int it = 0; it < iters; ++it) {
-        const int bw = part + it * parts;
-        const bool win_ok = bw < Bw;
-        const int bwc = win_ok ? bw : 0;
-        const bool active = win_ok && wave_ok;
-        const long tok_base = (long)(bwc / nW) * L;
-        __syncthreads();  // previous window's reads are complete
-        load_window_tables(tb, win2tok, region_ids, bwc % nW, N, ws, win_ok);
-        __syncthreads();
-        {
-            SlotStage<T, NPB, WAVES * 64> sk, sv;
-            SlotStage<T, 32, 64> sq, so;
-            sk.load(src + C, 3L * C, tb.tok, tok_base, 0, N, qkv_bias + C + h * HD, threadIdx.x);
-            sv.load(src + 2 * C, 3L * C, tb.tok, tok_base, 0, N, qkv_bias + 2 * C + h * HD, threadIdx.x);
-            sq.load(src, 3L * C, tb.tok, tok_base, q0, N, qkv_bias + h * HD, lane);
-            so.load(dout + h * HD, (long)C, tb.tok, tok_base, q0, N, nullptr, lane);
-            sk.store(Ks, 1.f, threadIdx.x);
-            sv.store(Vs, 1.f, threadIdx.x);
-            sq.store(Qs, scale, lane);
-            so.store(Os, 1.f, lane);
-        }
-        __syncthreads();
-
-        // P^T strip (softmax over all keys: the wave holds every key of its 32 queries)
-        f32x4 p[NT][2];
-        {
-            Frag<T> qf[2];
-            qf[0] = frag_kc<T>(Qs, LDQ, 0, 0, c, g);
-            qf[1] = frag_kc<T>(Qs, LDQ, 16, 0, c, g);
-#pragma unroll
-            for (int i = 0; i < NT; ++i) {
-                const Frag<T> kf = frag_kc<T>(Ks, LDQ, 16 * i, 0, c, g);
-                p[i][0] = bias_tile(bias_h, tb, i, (q0 >> 4), lane, g, masked);
-                p[i][1] = bias_tile(bias_h, tb, i, (q0 >> 4) + 1, lane, g, masked);
-                mma(kf, qf[0], p[i][0]);
-                mma(kf, qf[1], p[i][1]);
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            float m = -3.0e38f;
-#pragma unroll
-            for (int i = 0; i < NT; ++i)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) m = fmaxf(m, p[i][j][r]);
-            m = fmaxf(m, __shfl_xor(m, 16, 64));
-            m = fmaxf(m, __shfl_xor(m, 32, 64));
-            float s = 0.f;
-#pragma unroll
-            for (int i = 0; i < NT; ++i)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float e = __expf(p[i][j][r] - m);
-                    p[i][j][r] = e;
-                    s += e;
-                }
-            s += __shfl_xor(s, 16, 64);
-            s += __shfl_xor(s, 32, 64);
-            const float inv = 1.f / s;
-#pragma unroll
-            for (int i = 0; i < NT; ++i) p[i][j] *= inv;
-        }
-        // dP^T = V dO^T, dS = P o (dP - delta), one query tile at a time
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const Frag<T> of = frag_kc<T>(Os, LDQ, 16 * j, 0, c, g);
-            f32x4 dp[NT];
-            float d = 0.f;
-#pragma unroll
-            for (int i = 0; i < NT; ++i) {
-                const Frag<T> vf = frag_kc<T>(Vs, LDQ, 16 * i, 0, c, g);
-                dp[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-                mma(vf, of, dp[i]);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) d += p[i][j][r] * dp[i][r];
-            }
-            d += __shfl_xor(d, 16, 64);
-            d += __shfl_xor(d, 32, 64);
-#pragma unroll
-            for (int i = 0; i < NT; ++i) {
-                const f32x4 ds = p[i][j] * (dp[i] - d);
-                if (active) db[i][j] += ds;
-                store_frag4<T>(Ss + (16 * j + c) * LDP + 16 * i + 4 * g, ds);
-            }
-        }
-        __builtin_amdgcn_wave_barrier();  // the dS image is private to the wave
-        // dQ = scale * dS K
-        f32x4 aq[2][2];
-#pragma unroll
-        for (int a = 0; a < 2; ++a) {
-            aq[a][0] = f32x4{0.f, 0.f, 0.f, 0.f};
-            aq[a][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-#pragma unroll
-        for (int ks = 0; ks < NPB / 32; ++ks) {
-            const Frag<T> k0 = frag_ks<T, USE_TR>(Ks, LDQ, 0, 32 * ks, c, g);
-            const Frag<T> k1 = frag_ks<T, USE_TR>(Ks, LDQ, 16, 32 * ks, c, g);
-#pragma unroll
-            for (int a = 0; a < 2; ++a) {
-                const Frag<T> sf = frag_kc<T>(Ss, LDP, 16 * a, 32 * ks, c, g);
-                mma(sf, k0, aq[a][0]);
-                mma(sf, k1, aq[a][1]);
-            }
-        }
-        store_block_rows_vec<T>(aq, scale, Qs, dqkv + h * HD, 3L * C, tb.tok, tok_base, q0, N, active, nullptr, lane, c, g);
-    }
-    if (wave_ok) {
-        // frag layout of the NPB x NPB bias gradient: ((ki*NT + qj)*64 + lane)*4 + r, qj = 2*qb + j
-        float* wsp = dbias_ws + ((long)part * nH + h) * (NT * NT * 256);
-#pragma unroll
-        for (int i = 0; i < NT; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) *reinterpret_cast<f32x4*>(wsp + ((i * NT + 2 * qb + j) * 64 + lane) * 4) = db[i][j];
-    }
-}
-
-// -------------------------------------------------------------------------------------------------------------
-// backward, part 2: dK and dV.  One workgroup per (window, head); every wave owns 32-key blocks.
-// -------------------------------------------------------------------------------------------------------------
-template <typename T, bool USE_TR>
-__global__ __launch_bounds__(BigCfg<T>::WAVES * 64) void attn_big_bwd_dkv_kernel(
-    const T* __restrict__ qkv, const float* __restrict__ qkv_bias, const int* __restrict__ win2tok, int L, const T* __restrict__ dout,
-    const T* __restrict__ fout, const float* __restrict__ lse_in, const float* __restrict__ bias_frag, int rel_rows, int ws,
-    const int* __restrict__ region_ids, int nW, int Bw, int N, int nH, float scale, T* __restrict__ dqkv, float* __restrict__ dpad_ws) {
-    using Cfg = BigCfg<T>;
-    constexpr int LDQ = Cfg::LDQ, WAVES = Cfg::WAVES;
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    const BigTables tb = carve_tables(smem_raw);
-    T* Qs = reinterpret_cast<T*>(smem_raw + Cfg::TABLE_BYTES);  // scale*Q, [224][LDQ]
-    T* Os = Qs + Cfg::FULL;                                      // dO,      [224][LDQ]
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int c = lane & 15, g = lane >> 4;
-    T* Kb = Os + Cfg::FULL + wave * (2 * Cfg::BLK + Cfg::FULL);
-    T* Vb = Kb + Cfg::BLK;
-    T* Pq = Vb + Cfg::BLK;  // [224 q][LDQ]: P (then dS) of this key block, stored [q][key_local]
-
-    const int unit = blockIdx.x;
-    const int bw = unit / nH, h = unit % nH;
-    const int C = nH * HD;
-    const long tok_base = (long)(bw / nW) * L;
-    const T* src = qkv + h * HD;
-    const bool masked = region_ids != nullptr;
-
-    load_window_tables(tb, win2tok, region_ids, bw % nW, N, ws, true);
-    const float* bias_h = bias_frag + (long)h * (NT * NT * 256);
-    __syncthreads();
-    stage_slots2<T, NPB, WAVES * 64>(src, 3L * C, scale, qkv_bias + h * HD, Qs, dout + h * HD, (long)C, 1.f, nullptr, Os, tb.tok, tok_base, 0, N,
-                                     threadIdx.x);
-    // per-query statistics: saved log-sum-exp and delta = sum_d dO[q,d] * O[q,d]
-    for (int t = threadIdx.x; t < NPB; t += WAVES * 64) {
-        float l = 0.f, d = 0.f;
-        if (t < N) {
-            l = lse_in[(long)unit * NPB + t];
-            const int tok = tb.tok[t];
-            if (tok >= 0) {
-                const T* orow = fout + (tok_base + tok) * (long)C + h * HD;
-                const T* grow = dout + (tok_base + tok) * (long)C + h * HD;
-#pragma unroll
-                for (int vv = 0; vv < HD / Cfg::VEC; ++vv) {
-                    const Vec16<T> ov = ld16<T>(orow + vv * Cfg::VEC), gv = ld16<T>(grow + vv * Cfg::VEC);
-#pragma unroll
-                    for (int e = 0; e < Cfg::VEC; ++e) d += ov.get(e) * gv.get(e);
-                }
-            }
-        }
-        tb.lse[t] = l;
-        tb.delta[t] = d;
-    }
-    float padk[Cfg::VEC], padv[Cfg::VEC];
-#pragma unroll
-    for (int e = 0; e < Cfg::VEC; ++e) padk[e] = padv[e] = 0.f;
-
-    for (int pass = 0; pass < (NQB + WAVES - 1) / WAVES; ++pass) {
-        const int kb = wave + pass * WAVES;
-        const bool valid = kb < NQB;
-        const int k0 = valid ? 32 * kb : 0;
-        if (pass == 0) __syncthreads();  // Q, dO, lse, delta staged by the whole workgroup; Kb / Vb / Pq are private to the wave
-        __builtin_amdgcn_wave_barrier();
-        stage_slots2<T, 32, 64>(src + C, 3L * C, 1.f, qkv_bias + C + h * HD, Kb, src + 2 * C, 3L * C, 1.f, qkv_bias + 2 * C + h * HD, Vb, tb.tok,
-                                tok_base, k0, N, lane);
-        __builtin_amdgcn_wave_barrier();
-
-        // P^T block: rows = this block's 32 keys (2 tiles), columns = all queries (14 tiles)
-        f32x4 p[2][NT];
-        {
-            Frag<T> kf[2];
-            kf[0] = frag_kc<T>(Kb, LDQ, 0, 0, c, g);
-            kf[1] = frag_kc<T>(Kb, LDQ, 16, 0, c, g);
-#pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                const Frag<T> qf = frag_kc<T>(Qs, LDQ, 16 * j, 0, c, g);
-                const int q = 16 * j + c;
-                const bool qok = q < N;
-                const float l = tb.lse[q];
-#pragma unroll
-                for (int a = 0; a < 2; ++a) {
-                    f32x4 b = bias_tile(bias_h, tb, (k0 >> 4) + a, j, lane, g, masked);
-                    mma(kf[a], qf, b);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) b[r] = qok ? __expf(b[r] - l) : 0.f;  // padded query columns carry no gradient
-                    p[a][j] = b;
-                    store_frag4<T>(Pq + (16 * j + c) * LDQ + 16 * a + 4 * g, b);
-                }
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-        // dV[key][d] = sum_q P[q][key] dO[q][d]
-        {
-            f32x4 av[2][2];
-#pragma unroll
-            for (int a = 0; a < 2; ++a) {
-                av[a][0] = f32x4{0.f, 0.f, 0.f, 0.f};
-                av[a][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-            }
-#pragma unroll
-            for (int ks = 0; ks < NPB / 32; ++ks) {
-                const Frag<T> o0 = frag_ks<T, USE_TR>(Os, LDQ, 0, 32 * ks, c, g);
-                const Frag<T> o1 = frag_ks<T, USE_TR>(Os, LDQ, 16, 32 * ks, c, g);
-#pragma unroll
-                for (int a = 0; a < 2; ++a) {
-                    const Frag<T> pf = frag_ks<T, USE_TR>(Pq, LDQ, 16 * a, 32 * ks, c, g);
-                    mma(pf, o0, av[a][0]);
-                    mma(pf, o1, av[a][1]);
-                }
-            }
-            store_block_rows_vec<T>(av, 1.f, Kb, dqkv + 2 * C + h * HD, 3L * C, tb.tok, tok_base, k0, N, valid, padv, lane, c, g);
-        }
-        __builtin_amdgcn_wave_barrier();  // reads of Pq (= P) precede the dS writes below (same wave: LDS in order)
-        // dS^T = P^T o (dP^T - delta), dP^T[key][q] = sum_d V[key][d] dO[q][d]
-        {
-            Frag<T> vf[2];
-            vf[0] = frag_kc<T>(Vb, LDQ, 0, 0, c, g);
-            vf[1] = frag_kc<T>(Vb, LDQ, 16, 0, c, g);
-#pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                const Frag<T> of = frag_kc<T>(Os, LDQ, 16 * j, 0, c, g);
-                const float dl = tb.delta[16 * j + c];
-#pragma unroll
-                for (int a = 0; a < 2; ++a) {
-                    f32x4 dp = {0.f, 0.f, 0.f, 0.f};
-                    mma(vf[a], of, dp);
-                    const f32x4 ds = p[a][j] * (dp - dl);
-                    store_frag4<T>(Pq + (16 * j + c) * LDQ + 16 * a + 4 * g, ds);
-                }
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-        // dK[key][d] = sum_q dS[q][key] (scale q)[q][d]
-        {
-            f32x4 ak[2][2];
-#pragma unroll
-            for (int a = 0; a < 2; ++a) {
-                ak[a][0] = f32x4{0.f, 0.f, 0.f, 0.f};
-                ak[a][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-            }
-#pragma unroll
-            for (int ks = 0; ks < NPB / 32; ++ks) {
-                const Frag<T> q0f = frag_ks<T, USE_TR>(Qs, LDQ, 0, 32 * ks, c, g);
-                const Frag<T> q1f = frag_ks<T, USE_TR>(Qs, LDQ, 16, 32 * ks, c, g);
-#pragma unroll
-                for (int a = 0; a < 2; ++a) {
-                    const Frag<T> sf = frag_ks<T, USE_TR>(Pq, LDQ, 16 * a, 32 * ks, c, g);
-                    mma(sf, q0f, ak[a][0]);
-                    mma(sf, q1f, ak[a][1]);
-                }
-            }
-            store_block_rows_vec<T>(ak, 1.f, Kb, dqkv + C + h * HD, 3L * C, tb.tok, tok_base, k0, N, valid, padk, lane, c, g);
-        }
-    }
-    // lanes with equal dv = lane % VPR hold partial sums of the same VEC columns
-    constexpr int VPR = HD / Cfg::VEC;
-#pragma unroll
-    for (int e = 0; e < Cfg::VEC; ++e)
-#pragma unroll
-        for (int o = VPR; o < 64; o <<= 1) {
-            padk[e] += __shfl_xor(padk[e], o, 64);
-            padv[e] += __shfl_xor(padv[e], o, 64);
-        }
-    if (lane < VPR) {  // one slab row per (unit, wave): [k | v][nH][hd]
-        float* pw = dpad_ws + ((long)unit * WAVES + wave) * 2 * C + h * HD + lane * Cfg::VEC;
-#pragma unroll
-        for (int e = 0; e < Cfg::VEC; ++e) {
-            pw[e] = padk[e];
-            pw[C + e] = padv[e];
         }
     }
 }
@@ -1359,192 +702,6 @@ __global__ __launch_bounds__(BigCfg<T>::WAVES * 64, sizeof(T) == 2 ? 2 : 1) void
     }
 }
 
-// dK / dV, third variant (default): dkv2 with ONE 16-key tile per wave and pass, seven waves per workgroup (wave w takes
-// key tiles w and w + 7): a 56-register P / dS strip instead of 112, four waves per SIMD, two workgroups per CU.
-template <typename T>
-__global__ __launch_bounds__(FWD3_WAVES * 64, sizeof(T) == 2 ? 4 : 1) void attn_big_bwd_dkv3_kernel(
-    const T* __restrict__ qkv, const float* __restrict__ qkv_bias, const int* __restrict__ win2tok, int L, const T* __restrict__ dout,
-    const T* __restrict__ fout, const float* __restrict__ lse_in, const float* __restrict__ bias_frag_s, int ws,
-    const int* __restrict__ region_ids, int nW, int Bw, int N, int nH, float scale, T* __restrict__ dqkv, float* __restrict__ dpad_ws) {
-    using Cfg = BigCfg<T>;
-    constexpr int LDQ = Cfg::LDQ, VEC = Cfg::VEC, VPR = HD / VEC, WAVES = FWD3_WAVES;
-    constexpr int TILE = 16 * LDQ;
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    const BigTables tb = carve_tables(smem_raw);
-    T* Qs = reinterpret_cast<T*>(smem_raw + Cfg::TABLE_BYTES);  // scale*Q, [224][LDQ]
-    T* Os = Qs + Cfg::FULL;                                      // dO,      [224][LDQ]
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int c = lane & 15, g = lane >> 4;
-    T* Kb = Os + Cfg::FULL + wave * (2 * TILE);
-    T* Vb = Kb + TILE;
-
-    const int unit = blockIdx.x;
-    const int bw = unit / nH, h = unit % nH;
-    const int C = nH * HD;
-    const long tok_base = (long)(bw / nW) * L;
-    const T* src = qkv + h * HD;
-    const bool masked = region_ids != nullptr;
-    const float* bias_h = bias_frag_s + (long)h * (NT * NT * 256);
-
-    load_window_tables(tb, win2tok, region_ids, bw % nW, N, ws, true);
-    __syncthreads();
-    SlotStage<T, 16, 64> sk, sv;
-    {
-        SlotStage<T, NPB, WAVES * 64> sq, so;
-        sq.load(src, 3L * C, tb.tok, tok_base, 0, N, qkv_bias + h * HD, threadIdx.x);
-        so.load(dout + h * HD, (long)C, tb.tok, tok_base, 0, N, nullptr, threadIdx.x);
-        sk.load(src + C, 3L * C, tb.tok, tok_base, 16 * wave, N, qkv_bias + C + h * HD, lane);
-        sv.load(src + 2 * C, 3L * C, tb.tok, tok_base, 16 * wave, N, qkv_bias + 2 * C + h * HD, lane);
-        // per-query statistics: saved log-sum-exp and delta = sum_d dO[q,d] * O[q,d]
-        for (int t = threadIdx.x; t < NPB; t += WAVES * 64) {
-            float l = 0.f, d = 0.f;
-            if (t < N) {
-                l = lse_in[(long)unit * NPB + t];
-                const int tok = tb.tok[t];
-                if (tok >= 0) {
-                    const T* orow = fout + (tok_base + tok) * (long)C + h * HD;
-                    const T* grow = dout + (tok_base + tok) * (long)C + h * HD;
-#pragma unroll
-                    for (int vv = 0; vv < HD / VEC; ++vv) {
-                        const Vec16<T> ov = ld16<T>(orow + vv * VEC), gv = ld16<T>(grow + vv * VEC);
-#pragma unroll
-                        for (int e = 0; e < VEC; ++e) d += ov.get(e) * gv.get(e);
-                    }
-                }
-            }
-            tb.lse[t] = l;
-            tb.delta[t] = d;
-        }
-        sq.store(Qs, scale, threadIdx.x);
-        so.store(Os, 1.f, threadIdx.x);
-        sk.store(Kb, 1.f, lane);
-        sv.store(Vb, 1.f, lane);
-    }
-    float padk[VEC], padv[VEC];
-#pragma unroll
-    for (int e = 0; e < VEC; ++e) padk[e] = padv[e] = 0.f;
-    __syncthreads();  // Q, dO, lse, delta staged by the whole workgroup; Kb / Vb are private to the wave
-
-    // one [16 keys][32 d] result (rows 4g + r, columns c / 16 + c) to token rows through the wave's K image; pad rows -> pad sums
-    auto store_tile = [&](const f32x4& a0, const f32x4& a1, T* dst, int k0, float* padacc) {
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            Kb[(4 * g + r) * LDQ + c] = from_f32<T>(a0[r]);
-            Kb[(4 * g + r) * LDQ + 16 + c] = from_f32<T>(a1[r]);
-        }
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int i = 0; i < (16 * VPR + 63) / 64; ++i) {
-            const int v = lane + 64 * i;
-            const int rl = v / VPR, dv = v % VPR;
-            const int t = k0 + rl;
-            if (v < 16 * VPR && t < N) {
-                const int tok = tb.tok[t];
-                const Vec16<T> x = ld16<T>(Kb + rl * LDQ + dv * VEC);
-                if (tok >= 0) {
-                    st16<T>(dst + (tok_base + tok) * 3L * C + dv * VEC, x);
-                } else {
-#pragma unroll
-                    for (int e = 0; e < VEC; ++e) padacc[e] += x.get(e);
-                }
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-    };
-
-#pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
-        const int k0 = 16 * (wave + pass * WAVES);
-        if (pass > 0) {
-            __builtin_amdgcn_wave_barrier();
-            sk.store(Kb, 1.f, lane);
-            sv.store(Vb, 1.f, lane);
-            __builtin_amdgcn_wave_barrier();
-        }
-        const Frag<T> kf = frag_kc<T>(Kb, LDQ, 0, 0, c, g);
-        const Frag<T> vf = frag_kc<T>(Vb, LDQ, 0, 0, c, g);
-        if (pass == 0) {  // the second key tile's rows travel while the first is computed
-            sk.load(src + C, 3L * C, tb.tok, tok_base, 16 * (wave + WAVES), N, qkv_bias + C + h * HD, lane);
-            sv.load(src + 2 * C, 3L * C, tb.tok, tok_base, 16 * (wave + WAVES), N, qkv_bias + 2 * C + h * HD, lane);
-        }
-        const int rkey = masked ? ((tb.pk[k0 + c] >> 16) & 0xff) : 0;
-        // P tile column, oriented S: rows = queries (14 tiles), columns = this wave's 16 keys
-        f32x4 p[NT];
-#pragma unroll
-        for (int j = 0; j < NT; ++j) p[j] = *reinterpret_cast<const f32x4*>(bias_h + ((j * NT + (k0 >> 4)) * 64 + lane) * 4);
-        __builtin_amdgcn_sched_barrier(0);  // all bias tiles requested; the LDS operands below are read tile by tile (registers)
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            const Frag<T> qf = frag_kc<T>(Qs, LDQ, 16 * j, 0, c, g);
-            const f32x4 l4 = *reinterpret_cast<const f32x4*>(tb.lse + 16 * j + 4 * g);
-            f32x4 b = p[j];
-            if (masked) {
-                const i32x4 pk4 = *reinterpret_cast<const i32x4*>(tb.pk + 16 * j + 4 * g);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) b[r] += (((pk4[r] >> 16) & 0xff) != rkey) ? -100.f : 0.f;
-            }
-            mma(qf, kf, b);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) b[r] = (16 * j + 4 * g + r < N) ? __expf(b[r] - l4[r]) : 0.f;  // padded queries carry no gradient
-            p[j] = b;
-            if (j & 1) __builtin_amdgcn_sched_barrier(0);
-        }
-        // dV[key][d] = sum_q P[q][key] dO[q][d]
-        {
-            f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int ks = 0; ks < NPB / 32; ++ks) {
-                const Frag<T> o0 = frag_v_perm<T>(Os, LDQ, 0, ks, c, g);
-                const Frag<T> o1 = frag_v_perm<T>(Os, LDQ, 16, ks, c, g);
-                const Frag<T> pf = frag_p_regs<T>(p[2 * ks], p[2 * ks + 1]);
-                mma(pf, o0, a0);
-                mma(pf, o1, a1);
-            }
-            store_tile(a0, a1, dqkv + 2 * C + h * HD, k0, padv);
-        }
-        // dS = P o (dP - delta), dP[q][key] = sum_d dO[q][d] V[key][d]; dS overwrites P
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            const Frag<T> of = frag_kc<T>(Os, LDQ, 16 * j, 0, c, g);
-            const f32x4 dl4 = *reinterpret_cast<const f32x4*>(tb.delta + 16 * j + 4 * g);
-            f32x4 dp = {0.f, 0.f, 0.f, 0.f};
-            mma(of, vf, dp);
-            p[j] = p[j] * (dp - dl4);
-            if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);
-        }
-        // dK[key][d] = sum_q dS[q][key] (scale q)[q][d]
-        {
-            f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int ks = 0; ks < NPB / 32; ++ks) {
-                const Frag<T> q0f = frag_v_perm<T>(Qs, LDQ, 0, ks, c, g);
-                const Frag<T> q1f = frag_v_perm<T>(Qs, LDQ, 16, ks, c, g);
-                const Frag<T> sf = frag_p_regs<T>(p[2 * ks], p[2 * ks + 1]);
-                mma(sf, q0f, a0);
-                mma(sf, q1f, a1);
-            }
-            store_tile(a0, a1, dqkv + C + h * HD, k0, padk);
-        }
-    }
-    // lanes with equal dv = lane % VPR hold partial sums of the same VEC columns
-#pragma unroll
-    for (int e = 0; e < VEC; ++e)
-#pragma unroll
-        for (int o = VPR; o < 64; o <<= 1) {
-            padk[e] += __shfl_xor(padk[e], o, 64);
-            padv[e] += __shfl_xor(padv[e], o, 64);
-        }
-    if (lane < VPR) {  // one slab row per (unit, wave): [k | v][nH][hd]
-        float* pw = dpad_ws + ((long)unit * WAVES + wave) * 2 * C + h * HD + lane * VEC;
-#pragma unroll
-        for (int e = 0; e < VEC; ++e) {
-            pw[e] = padk[e];
-            pw[C + e] = padv[e];
-        }
-    }
-}
-
 // dtable[index[q,key]][h] += total[h][frag(q,key)] for the 14-tile frag layout
 __global__ void relpos_bias_bwd_big_kernel(const float* __restrict__ ws, const long* __restrict__ index, int N, int nH,
                                            float* __restrict__ dtable) {
@@ -1558,24 +715,9 @@ __global__ void relpos_bias_bwd_big_kernel(const float* __restrict__ ws, const l
 }
 
 template <typename T>
-size_t fwd_lds() {
-    using Cfg = BigCfg<T>;
-    return Cfg::TABLE_BYTES + (size_t)(2 * Cfg::FULL + Cfg::WAVES * (Cfg::BLK + Cfg::PIMG)) * sizeof(T);
-}
-template <typename T>
-size_t dkv3_lds() {
-    using Cfg = BigCfg<T>;
-    return Cfg::TABLE_BYTES + (size_t)(2 * Cfg::FULL + FWD3_WAVES * 2 * 16 * Cfg::LDQ) * sizeof(T);
-}
-template <typename T>
 size_t fwd3_lds() {
     using Cfg = BigCfg<T>;
     return Cfg::TABLE_BYTES + (size_t)(2 * Cfg::FULL + FWD3_WAVES * 16 * Cfg::LDQ) * sizeof(T);
-}
-template <typename T>
-size_t fwd2_lds() {
-    using Cfg = BigCfg<T>;
-    return Cfg::TABLE_BYTES + (size_t)(2 * Cfg::FULL + Cfg::WAVES * Cfg::BLK) * sizeof(T);
 }
 template <typename T>
 size_t dq4_lds() {
@@ -1587,19 +729,6 @@ size_t dkv2_lds() {
     using Cfg = BigCfg<T>;
     return Cfg::TABLE_BYTES + (size_t)(2 * Cfg::FULL + Cfg::WAVES * 2 * Cfg::BLK) * sizeof(T);
 }
-template <typename T>
-size_t dq_lds() {
-    using Cfg = BigCfg<T>;
-    return Cfg::TABLE_BYTES + (size_t)(2 * Cfg::FULL + Cfg::WAVES * (2 * Cfg::BLK + Cfg::PIMG)) * sizeof(T);
-}
-template <typename T>
-size_t dkv_lds() {
-    using Cfg = BigCfg<T>;
-    return Cfg::TABLE_BYTES + (size_t)(2 * Cfg::FULL + Cfg::WAVES * (2 * Cfg::BLK + Cfg::FULL)) * sizeof(T);
-}
-
-int g_big_fwd_impl = 3;  // 1: first generation (P through LDS, one workgroup per CU); 2: P in registers, 32-query blocks; 3: 16-query tiles, 7 waves
-int g_big_bwd_impl = 5;  // 1: first generation (dS / P^T through LDS); 4: first-generation dQ + dkv2; 5 (default): dq4 + dkv2; 6: dq4 + dkv3
 
 inline int big_parts(int Bw, int nH) {
     int parts = (512 + nH - 1) / nH;  // ~2 workgroups per CU across heads and query-block groups
@@ -1612,10 +741,6 @@ inline int big_parts(int Bw, int nH) {
 #define STREAM(s_) hipStream_t stream = reinterpret_cast<hipStream_t>(s_)
 
 int esvit_big_frag_elems() { return NT * NT * 256; }
-extern "C" void esvit_debug_set_big_attn_impl(int fwd, int bwd) {
-    g_big_fwd_impl = fwd;
-    g_big_bwd_impl = bwd;
-}
 int esvit_big_npb() { return NPB; }
 int esvit_big_parts(int Bw, int nH) { return big_parts(Bw, nH); }
 int esvit_big_pad_rows(int Bw, int nH, int dtype) { (void)dtype; return Bw * nH * FWD3_WAVES; }  // >= waves per workgroup of every dK/dV variant
@@ -1628,46 +753,21 @@ static int fill_bias_frag_big(const float* rel_table, int ws, int N, int nH, flo
 }
 
 template <typename T>
-static int big_fwd_launch(const void* qkv, const float* qkv_bias, const int32_t* win2tok, int L, const float* rel_table, int rel_rows, int ws,
+static int big_fwd_launch(const void* qkv, const float* qkv_bias, const int32_t* win2tok, int L, const float* rel_table, int ws,
                           const int32_t* region_ids, int nW, int Bw, int N, int nH, float scale, void* out, float* lse, float* attn_out,
                           hipStream_t stream) {
-    if (g_big_fwd_impl == 3) {
-        const size_t lds = fwd3_lds<T>();
-        if (attn_out) {
-            auto kern = attn_big_fwd3_kernel<T, true>;
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL(kern, dim3(Bw * nH), dim3(FWD3_WAVES * 64), lds, stream, (const T*)qkv, qkv_bias, win2tok, L, rel_table, ws,
-                               region_ids, nW, Bw, N, nH, scale, (T*)out, lse, attn_out);
-        } else {
-            auto kern = attn_big_fwd3_kernel<T, false>;
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL(kern, dim3(Bw * nH), dim3(FWD3_WAVES * 64), lds, stream, (const T*)qkv, qkv_bias, win2tok, L, rel_table, ws,
-                               region_ids, nW, Bw, N, nH, scale, (T*)out, lse, attn_out);
-        }
-        ESVIT_CHECK_LAUNCH("window_attn_fwd(14x14, gen 3)");
-        return ESVIT_OK;
+    const size_t lds = fwd3_lds<T>();
+    if (attn_out) {
+        auto kern = attn_big_fwd3_kernel<T, true>;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kern, dim3(Bw * nH), dim3(FWD3_WAVES * 64), lds, stream, (const T*)qkv, qkv_bias, win2tok, L, rel_table, ws,
+                           region_ids, nW, Bw, N, nH, scale, (T*)out, lse, attn_out);
+    } else {
+        auto kern = attn_big_fwd3_kernel<T, false>;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kern, dim3(Bw * nH), dim3(FWD3_WAVES * 64), lds, stream, (const T*)qkv, qkv_bias, win2tok, L, rel_table, ws,
+                           region_ids, nW, Bw, N, nH, scale, (T*)out, lse, attn_out);
     }
-    if (g_big_fwd_impl == 2) {
-        const size_t lds = fwd2_lds<T>();
-        if (attn_out) {
-            auto kern = attn_big_fwd2_kernel<T, true>;
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL(kern, dim3(Bw * nH), dim3(BigCfg<T>::WAVES * 64), lds, stream, (const T*)qkv, qkv_bias, win2tok, L, rel_table, ws,
-                               region_ids, nW, Bw, N, nH, scale, (T*)out, lse, attn_out);
-        } else {
-            auto kern = attn_big_fwd2_kernel<T, false>;
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL(kern, dim3(Bw * nH), dim3(BigCfg<T>::WAVES * 64), lds, stream, (const T*)qkv, qkv_bias, win2tok, L, rel_table, ws,
-                               region_ids, nW, Bw, N, nH, scale, (T*)out, lse, attn_out);
-        }
-        ESVIT_CHECK_LAUNCH("window_attn_fwd(14x14, gen 2)");
-        return ESVIT_OK;
-    }
-    auto kern = attn_big_fwd_kernel<T>;
-    const size_t lds = fwd_lds<T>();
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(kern, dim3(Bw * nH), dim3(BigCfg<T>::WAVES * 64), lds, stream, (const T*)qkv, qkv_bias, win2tok, L, rel_table,
-                       rel_rows, ws, region_ids, nW, Bw, N, nH, scale, (T*)out, lse, attn_out);
     ESVIT_CHECK_LAUNCH("window_attn_fwd(14x14)");
     return ESVIT_OK;
 }
@@ -1675,7 +775,6 @@ static int big_fwd_launch(const void* qkv, const float* qkv_bias, const int32_t*
 int esvit_big_attn_fwd(int dtype, const void* qkv, const float* qkv_bias, const int32_t* win2tok, int L, const float* rel_table, int ws,
                        float* bias_frag_ws, const int32_t* region_ids, int nW, int nB, int N, int nH, float scale, void* out, float* lse,
                        float* attn_out, hipStream_t stream) {
-    const int rel_rows = (2 * ws - 1) * (2 * ws - 1);
     ESVIT_CHECK_ARG(N <= NPB, "window_attn: window %d too large", ws);
     ESVIT_CHECK_ARG(bias_frag_ws != nullptr, "esvit_window_attn_fwd: the bias_frag_ws scratch is required");
     {
@@ -1684,73 +783,38 @@ int esvit_big_attn_fwd(int dtype, const void* qkv, const float* qkv_bias, const 
     }
     const int Bw = nB * nW;
     if (dtype == ESVIT_BF16)
-        return big_fwd_launch<bf16>(qkv, qkv_bias, win2tok, L, bias_frag_ws, rel_rows, ws, region_ids, nW, Bw, N, nH, scale, out, lse, attn_out, stream);
-    return big_fwd_launch<float>(qkv, qkv_bias, win2tok, L, bias_frag_ws, rel_rows, ws, region_ids, nW, Bw, N, nH, scale, out, lse, attn_out, stream);
+        return big_fwd_launch<bf16>(qkv, qkv_bias, win2tok, L, bias_frag_ws, ws, region_ids, nW, Bw, N, nH, scale, out, lse, attn_out, stream);
+    return big_fwd_launch<float>(qkv, qkv_bias, win2tok, L, bias_frag_ws, ws, region_ids, nW, Bw, N, nH, scale, out, lse, attn_out, stream);
 }
 
-template <typename T, bool TR>
+template <typename T>
 static int big_bwd_launch(const void* qkv, const float* qkv_bias, const int32_t* win2tok, int L, const void* dout, const void* fout,
-                          const float* lse, const float* rel_table, int rel_rows, int ws, const int32_t* region_ids, int nW, int Bw, int N,
+                          const float* lse, const float* rel_table, int ws, const int32_t* region_ids, int nW, int Bw, int N,
                           int nH, float scale, void* dqkv, float* dbias_ws, float* dpad_ws, hipStream_t stream) {
     using Cfg = BigCfg<T>;
-    constexpr int GROUPS = (NQB + Cfg::WAVES - 1) / Cfg::WAVES;
     const int parts = big_parts(Bw, nH);
-    if (g_big_bwd_impl >= 4) {  // 5 (default): dq4 + dkv2; 6: dq4 + dkv3; 4: first-generation dQ + dkv2
-        if (g_big_bwd_impl >= 5) {
-            auto kern = attn_big_bwd_dq4_kernel<T>;
-            const size_t lds = dq4_lds<T>();
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL(kern, dim3(parts * nH * DQ4_GROUPS), dim3(DQ4_WAVES * 64), lds, stream, (const T*)qkv, qkv_bias, win2tok, L,
-                               (const T*)dout, (const T*)fout, lse, rel_table, ws, region_ids, nW, Bw, N, nH, scale, parts, (T*)dqkv, dbias_ws);
-            ESVIT_CHECK_LAUNCH("window_attn_bwd(14x14, dQ, gen 4)");
-        } else {
-            auto kern = attn_big_bwd_dq_kernel<T, TR>;
-            const size_t lds = dq_lds<T>();
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL(kern, dim3(parts * nH * GROUPS), dim3(Cfg::WAVES * 64), lds, stream, (const T*)qkv, qkv_bias, win2tok, L,
-                               (const T*)dout, rel_table, rel_rows, ws, region_ids, nW, Bw, N, nH, scale, parts, (T*)dqkv, dbias_ws);
-            ESVIT_CHECK_LAUNCH("window_attn_bwd(14x14, dQ)");
-        }
-        if (g_big_bwd_impl == 6) {
-            auto kern = attn_big_bwd_dkv3_kernel<T>;
-            const size_t lds = dkv3_lds<T>();
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL(kern, dim3(Bw * nH), dim3(FWD3_WAVES * 64), lds, stream, (const T*)qkv, qkv_bias, win2tok, L, (const T*)dout,
-                               (const T*)fout, lse, rel_table + (long)nH * NT * NT * 256, ws, region_ids, nW, Bw, N, nH, scale, (T*)dqkv, dpad_ws);
-            ESVIT_CHECK_LAUNCH("window_attn_bwd(14x14, dK dV, gen 3)");
-        } else {
-            auto kern = attn_big_bwd_dkv2_kernel<T>;
-            const size_t lds = dkv2_lds<T>();
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL(kern, dim3(Bw * nH), dim3(Cfg::WAVES * 64), lds, stream, (const T*)qkv, qkv_bias, win2tok, L, (const T*)dout,
-                               (const T*)fout, lse, rel_table + (long)nH * NT * NT * 256, ws, region_ids, nW, Bw, N, nH, scale, (T*)dqkv, dpad_ws);
-            ESVIT_CHECK_LAUNCH("window_attn_bwd(14x14, dK dV, gen 2)");
-        }
-        return ESVIT_OK;
-    }
     {
-        auto kern = attn_big_bwd_dq_kernel<T, TR>;
-        const size_t lds = dq_lds<T>();
+        auto kern = attn_big_bwd_dq4_kernel<T>;
+        const size_t lds = dq4_lds<T>();
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(kern, dim3(parts * nH * GROUPS), dim3(Cfg::WAVES * 64), lds, stream, (const T*)qkv, qkv_bias, win2tok, L,
-                           (const T*)dout, rel_table, rel_rows, ws, region_ids, nW, Bw, N, nH, scale, parts, (T*)dqkv, dbias_ws);
+        hipLaunchKernelGGL(kern, dim3(parts * nH * DQ4_GROUPS), dim3(DQ4_WAVES * 64), lds, stream, (const T*)qkv, qkv_bias, win2tok, L,
+                           (const T*)dout, (const T*)fout, lse, rel_table, ws, region_ids, nW, Bw, N, nH, scale, parts, (T*)dqkv, dbias_ws);
         ESVIT_CHECK_LAUNCH("window_attn_bwd(14x14, dQ)");
     }
     {
-        auto kern = attn_big_bwd_dkv_kernel<T, TR>;
-        const size_t lds = dkv_lds<T>();
+        auto kern = attn_big_bwd_dkv2_kernel<T>;
+        const size_t lds = dkv2_lds<T>();
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(kern, dim3(Bw * nH), dim3(Cfg::WAVES * 64), lds, stream, (const T*)qkv, qkv_bias, win2tok, L, (const T*)dout,
-                           (const T*)fout, lse, rel_table, rel_rows, ws, region_ids, nW, Bw, N, nH, scale, (T*)dqkv, dpad_ws);
+                           (const T*)fout, lse, rel_table + (long)nH * NT * NT * 256, ws, region_ids, nW, Bw, N, nH, scale, (T*)dqkv, dpad_ws);
         ESVIT_CHECK_LAUNCH("window_attn_bwd(14x14, dK dV)");
     }
     return ESVIT_OK;
 }
 
-int esvit_big_attn_bwd(int dtype, int use_tr, const void* qkv, const float* qkv_bias, const int32_t* win2tok, int L, const void* dout,
+int esvit_big_attn_bwd(int dtype, const void* qkv, const float* qkv_bias, const int32_t* win2tok, int L, const void* dout,
                        const void* fout, const float* lse, const float* rel_table_, int ws, float* bias_frag_ws, const int32_t* region_ids,
                        int nW, int nB, int N, int nH, float scale, void* dqkv, float* dbias_ws, float* dpad_ws, hipStream_t stream) {
-    const int rel_rows = (2 * ws - 1) * (2 * ws - 1);
     ESVIT_CHECK_ARG(N <= NPB, "window_attn: window %d too large", ws);
     ESVIT_CHECK_ARG(fout && lse, "esvit_window_attn_bwd: 14x14 windows need the forward output and log-sum-exp");
     ESVIT_CHECK_ARG(bias_frag_ws != nullptr, "esvit_window_attn_bwd: the bias_frag_ws scratch is required");
@@ -1760,15 +824,11 @@ int esvit_big_attn_bwd(int dtype, int use_tr, const void* qkv, const float* qkv_
     }
     const float* rel_table = bias_frag_ws;  // the kernels read the frag-layout bias
     const int Bw = nB * nW;
-    if (dtype == ESVIT_BF16) {
-        if (use_tr)
-            return big_bwd_launch<bf16, true>(qkv, qkv_bias, win2tok, L, dout, fout, lse, rel_table, rel_rows, ws, region_ids, nW, Bw, N, nH,
-                                              scale, dqkv, dbias_ws, dpad_ws, stream);
-        return big_bwd_launch<bf16, false>(qkv, qkv_bias, win2tok, L, dout, fout, lse, rel_table, rel_rows, ws, region_ids, nW, Bw, N, nH,
-                                           scale, dqkv, dbias_ws, dpad_ws, stream);
-    }
-    return big_bwd_launch<float, false>(qkv, qkv_bias, win2tok, L, dout, fout, lse, rel_table, rel_rows, ws, region_ids, nW, Bw, N, nH, scale,
-                                        dqkv, dbias_ws, dpad_ws, stream);
+    if (dtype == ESVIT_BF16)
+        return big_bwd_launch<bf16>(qkv, qkv_bias, win2tok, L, dout, fout, lse, rel_table, ws, region_ids, nW, Bw, N, nH, scale, dqkv, dbias_ws,
+                                    dpad_ws, stream);
+    return big_bwd_launch<float>(qkv, qkv_bias, win2tok, L, dout, fout, lse, rel_table, ws, region_ids, nW, Bw, N, nH, scale, dqkv, dbias_ws,
+                                 dpad_ws, stream);
 }
 
 int esvit_big_relpos_bias_bwd(const float* dbias_ws, int parts, const int64_t* index, int N, int nH, int table_rows, float* dtable,

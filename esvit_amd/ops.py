@@ -10,7 +10,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import BF16, EPI_GELU, EPI_GELU_BWD, EPI_NONE, EPI_QGELU, EPI_QGELU_BWD, F32, GemmDesc, check, lib
+from ._lib import BF16, EPI_GELU, EPI_GELU_BWD, EPI_NONE, EPI_QGELU, EPI_QGELU_BWD, F32, GEMM_AUTO, GEMM_DMA4, GEMM_DMA8, GEMM_REGSTAGE, GemmDesc, check, lib
 
 _ACT_DTYPE = torch.bfloat16
 
@@ -145,7 +145,12 @@ def gemm_algorithmic_bytes(dt, kw):
     return float(b)
 
 
-def _gemm_launch(dt, **kw):
+# main loop forced on every esvit_gemm call issued through this module (GEMM_AUTO = the library's own choice); the
+# descriptor carries it, the library keeps no state.  Tests sweep it to run every main loop on every shape.
+FORCE_GEMM_KERNEL = GEMM_AUTO
+
+
+def _gemm_desc(kw):
     d = GemmDesc()
     for k in ("A", "B", "C", "bias", "residual", "rowmap", "rowscale", "aux", "partial", "colsum", "colsum_partial"):
         setattr(d, k, _p(kw.get(k)))
@@ -154,7 +159,27 @@ def _gemm_launch(dt, **kw):
         setattr(d, k, int(kw.get(k, 0)))
     d.batch = int(kw.get("batch", 1))
     d.alpha = float(kw.get("alpha", 1.0))
+    d.kernel = int(kw.get("kernel", FORCE_GEMM_KERNEL))
+    return d
+
+
+def _gemm_launch(dt, **kw):
+    d = _gemm_desc(kw)
+    if dt != torch.bfloat16:
+        d.kernel = GEMM_AUTO  # the exact-fp32 mode has one main loop
     check(lib.esvit_gemm(_code(dt), C.byref(d), _stream()), "esvit_gemm")
+
+
+def gemm_select(dt, **kw):
+    """-> (kernel id, tile_m, tile_n, resident workgroup slots) the library would use for this problem (no pointers needed)"""
+    d = _gemm_desc(kw)
+    if dt != torch.bfloat16:
+        d.kernel = GEMM_AUTO
+    tm, tn, slots = C.c_int(0), C.c_int(0), C.c_int(0)
+    k = lib.esvit_gemm_select(_code(dt), C.byref(d), C.byref(tm), C.byref(tn), C.byref(slots))
+    if k <= 0:
+        raise RuntimeError("esvit_gemm_select failed (%d): %s" % (k, lib.esvit_last_error().decode()))
+    return k, tm.value, tn.value, slots.value
 
 
 def linear_fwd(x, w, bias=None, *, gelu=False, want_preact=False, residual=None, rowmap=None, rowmap_tokens=0,
@@ -186,24 +211,30 @@ def linear_dgrad(dy, w, *, gelu_preact=None, out_f32=False, quick=False):
     Kin = w.shape[1]
     assert w.shape[0] == Nout and dy.dtype == w.dtype
     dx = torch.empty((M, Kin), dtype=torch.float32 if out_f32 else dy.dtype, device=dy.device)
-    tiles = (-(-M // 128)) * (-(-Kin // 128))
-    if gelu_preact is None and tiles < 192 and Nout >= 4096:
-        # few output tiles but a very long reduction (DINOHead last layer: K = out_dim): split-K to fill the chip
-        splitk = int(min(16, max(2, 512 // tiles)))
-        part = workspace(splitk * M * Kin, dy.device)
-        _gemm(dy.dtype, A=dy, B=w, C=dx, M=M, N=Kin, K=Nout, lda=Nout, ldb=Kin, ldc=Kin, b_kstrided=1, out_f32=out_f32,
-              splitk=splitk, partial=part)
+    if gelu_preact is None and Nout >= 4096:
+        # a very long reduction (DINOHead last layer: K = out_dim) over few output tiles: the wide-tile loop, split-K to fill the chip
+        kern = GEMM_DMA8 if (FORCE_GEMM_KERNEL == GEMM_AUTO and dy.dtype == torch.bfloat16 and Kin >= 192) else FORCE_GEMM_KERNEL
+        _, tm, tn, slots = gemm_select(dy.dtype, M=M, N=Kin, K=Nout, b_kstrided=1, kernel=kern)
+        tiles = (-(-M // tm)) * (-(-Kin // tn))
+        if tiles <= slots // 2:
+            splitk = int(min(16, max(2, slots // tiles)))
+            part = workspace(splitk * M * Kin, dy.device)
+            _gemm(dy.dtype, A=dy, B=w, C=dx, M=M, N=Kin, K=Nout, lda=Nout, ldb=Kin, ldc=Kin, b_kstrided=1, out_f32=out_f32,
+                  splitk=splitk, partial=part, kernel=kern)
+            return dx
+        _gemm(dy.dtype, A=dy, B=w, C=dx, M=M, N=Kin, K=Nout, lda=Nout, ldb=Kin, ldc=Kin, b_kstrided=1, out_f32=out_f32, kernel=kern)
         return dx
     _gemm(dy.dtype, A=dy, B=w, C=dx, M=M, N=Kin, K=Nout, lda=Nout, ldb=Kin, ldc=Kin, b_kstrided=1, aux=gelu_preact,
           ldaux=Kin, epilogue=(EPI_QGELU_BWD if quick else EPI_GELU_BWD) if gelu_preact is not None else EPI_NONE, out_f32=out_f32)
     return dx
 
 
-def _pick_splitk(rows, Nout, Kin, tiles):
-    """split-K factor for wgrad: as many workgroups as fit the chip AT ONCE (256 CUs x 2 resident 64-KiB workgroups) and
-    never one more -- every workgroup runs for the whole kernel, so a 513th doubles its duration --, >= 512 reduction
-    rows per split, and partial slabs (written + re-read) no larger than the operand traffic"""
-    want = max(1, 512 // max(tiles, 1))
+def _pick_splitk(rows, Nout, Kin, tiles, slots=512):
+    """split-K factor for wgrad: as many workgroups as fit the chip AT ONCE (`slots` resident workgroups: 256 CUs x 2
+    64-KiB workgroups of the 4-wave loop, x 1 of the 8-wave loop) and never one more -- every workgroup runs for the whole
+    kernel, so one extra doubles its duration --, >= 512 reduction rows per split, and partial slabs (written + re-read)
+    no larger than the operand traffic"""
+    want = max(1, slots // max(tiles, 1))
     by_rows = max(1, rows // 512)
     by_bytes = max(1, (rows * (Nout + Kin) * 2) // (Nout * Kin * 8))
     return int(max(1, min(want, by_rows, by_bytes, 512)))
@@ -220,9 +251,9 @@ def linear_wgrad(dy, x, *, out=None, accumulate=False, want_bias=False):
         out = torch.empty((Nout, Kin), dtype=torch.float32, device=dy.device)
         accumulate = False
     db = torch.empty((Nout,), dtype=torch.float32, device=dy.device) if want_bias else None
-    bn = 96 if (Kin % 96 == 0 and Kin % 128 != 0) else (64 if Kin <= 64 else 128)
-    tiles = (-(-Nout // 128)) * (-(-Kin // bn))
-    splitk = _pick_splitk(rows, Nout, Kin, tiles)
+    _, tm, tn, slots = gemm_select(dy.dtype, M=Nout, N=Kin, K=rows, a_kstrided=1, b_kstrided=1)
+    tiles = (-(-Nout // tm)) * (-(-Kin // tn))
+    splitk = _pick_splitk(rows, Nout, Kin, tiles, slots)
     if splitk > 1:
         part = workspace(splitk * Nout * (Kin + 1), dy.device)
         cpart = part[splitk * Nout * Kin:] if want_bias else None
@@ -608,19 +639,6 @@ def grad_sqnorm(tensors, ntensors, chunks, nchunks, sqnorms):
 def fused_clip_adamw_ema(tensors, ntensors, chunks, nchunks, sqnorms, clip, lr, wd, beta1, beta2, eps, ema_m):
     check(lib.esvit_fused_clip_adamw_ema(_p(tensors), ntensors, _p(chunks), nchunks, _p(sqnorms), clip, lr, wd, beta1, beta2, eps,
                                          ema_m, _stream()), "fused_clip_adamw_ema")
-
-
-def debug_set_tr_read(on):
-    lib.esvit_debug_set_tr_read(int(on))
-    lib.esvit_debug_set_attn_tr_read(int(on))
-
-
-def debug_set_gemm_dma(on):
-    lib.esvit_debug_set_gemm_dma(int(on))
-
-
-def debug_set_gemm_pipe(mode):
-    lib.esvit_debug_set_gemm_pipe(int(mode))
 
 
 # ------------------------------------------------------------------------------------------------

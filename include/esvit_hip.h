@@ -83,12 +83,23 @@ typedef struct {
     float alpha;
     float* colsum;         /* optional, fp32 [M]: row sums of op(A) over K (= bias gradient when A = dY^T); fused via an all-ones B fragment */
     float* colsum_partial; /* workspace >= splitk*M floats when splitk > 1 */
+    int32_t kernel;        /* ESVIT_GEMM_AUTO (0): chosen from the shape; otherwise force one main loop (tests / tuning) */
 } esvit_gemm_desc;
+
+/* main loops of the family (esvit_gemm_desc.kernel; what esvit_gemm_select returns) */
+#define ESVIT_GEMM_AUTO 0
+#define ESVIT_GEMM_REGSTAGE 1 /* register-staged 128-row tiles: the exact-fp32 mode, and a bf16 fallback */
+#define ESVIT_GEMM_DMA4 2     /* bf16, LDS-DMA, 128 x {64,96,128} tiles, 4 waves, two workgroups per CU */
+#define ESVIT_GEMM_DMA8 3     /* bf16, LDS-DMA, 256 x {192,256} (192-row too for weight gradients) tiles, 8 waves */
 
 /* C = alpha * op(A) op(B) (+ epilogue).  Replaces every nn.Linear / conv-as-GEMM on the
  * path: swin_transformer.py:31-37,127,150,418,531; vision_transformer.py:414-418;
  * and their autograd backward (dgrad: b_kstrided or cached W^T; wgrad: a_kstrided && b_kstrided). */
 int esvit_gemm(int dtype, const esvit_gemm_desc* d, esvit_stream_t stream);
+/* The main loop esvit_gemm would run for this descriptor (a pure function of it; > 0) with its output tile and the
+ * number of workgroups the chip keeps resident at once -- what a caller needs to size split-K (one workgroup per
+ * (tile, slice); a launch of more workgroups than resident slots runs in rounds) before it allocates `partial`. */
+int esvit_gemm_select(int dtype, const esvit_gemm_desc* d, int* tile_m, int* tile_n, int* resident_slots);
 
 /* ---- normalisation ----------------------------------------------------- */
 /* LayerNorm forward over rows of C channels (swin_transformer.py:283,331,417,546,687;
@@ -177,7 +188,8 @@ int esvit_dense_to_frag(const float* dense, int n_mats, int N, float* frag, esvi
  * scale: applied to q before the product (swin_transformer.py:130: hd^-0.5; CvT passes dim^-0.5).  N = ws*ws <= 64 with
  * hd in {32, 64} (7x7 Swin windows; 7x7 / 6x6 / 3x3 CvT windows at hd 64), or N = 196 (14x14) with hd = 32.
  * lse fp32 [nB*nW*nH, esvit_window_attn_lse_elems(N)]: per-query log-sum-exp, written for 14x14 windows (the blocked
- * backward needs it), unused (may be NULL) for 7x7.
+ * backward needs it), unused (may be NULL) for 7x7.  One image's qkv rows (L * 3C activations) must fit a 2 GiB buffer
+ * descriptor.
  * attn_out (optional, fp32 [nB*nW,nH,N,N]) receives the softmax (swin_transformer.py:146,152). */
 int esvit_window_attn_lse_elems(int N);
 int esvit_window_attn_fwd(int dtype, const void* qkv, const float* qkv_bias, const int32_t* win2tok, int L,
@@ -303,24 +315,6 @@ int esvit_bn_eval_coeffs(const float* running_mean, const float* running_var, co
 int esvit_bn_bwd_local(const float* sums, const float* coef, int C, float* red, esvit_stream_t stream);
 int esvit_bn_bwd_coeffs(const float* red, float n, const float* gamma, const float* coef, int C, float* abc,
                         esvit_stream_t stream);
-
-/* ---- debug switches (tests only) ---------------------------------------- */
-void esvit_debug_set_tr_read(int on);      /* GEMM: ds_read_b64_tr_b16 vs scalar LDS gathers */
-void esvit_debug_set_attn_tr_read(int on); /* attention backward: same */
-void esvit_debug_set_attn_bwd_waves(int w); /* attention backward compiled for 2 (256 regs) or 1 (512 regs) waves per SIMD */
-void esvit_debug_set_gemm_dma(int on);     /* GEMM: LDS-DMA main loop (1: by shape, 2: always) vs register-staged main loop (0) */
-void esvit_debug_set_big_attn_impl(int fwd, int bwd); /* 14x14 attention variants: fwd 3 (default) 16-query tiles / 2 32-query blocks, P in registers / 1 P through LDS; bwd 5 (default) dq4 + dkv2 / 6 dq4 + dkv3 / 4 gen-1 dQ + dkv2 / 1 gen 1 */
-void esvit_debug_set_attn_fwd_impl(int v);   /* 7x7 attention forward: 4 (default) generation 3 with P kept in registers, 3 two waves per (window, head), 2 persistent prefetching kernel, 1 one window per wave */
-void esvit_debug_set_attn_bwd_impl(int v);   /* 7x7 attention backward: 3 (default) two waves per (window, head), 2 prefetching one-wave kernel, 1 first generation */
-void esvit_debug_set_gemm_xcdmap(int mode); /* 0 (default): tiles XCD-remapped, split/batch on grid.y; 1: split-K slices / batch items contiguous per XCD */
-void esvit_debug_set_gemm_ws_ablate(int bits); /* PROFILING ONLY (results become garbage): 1 no MFMA loop, 2 no DMA loads, 4 no epilogue */
-int esvit_debug_gemm_ws_occupancy(int lds_bytes); /* resident workgroups / CU of the persistent GEMM at this LDS size */
-void esvit_debug_set_gemm_m256(int on);   /* 1: 256 x 128 x BK32 tiles for large forward / dgrad grids (default 0) */
-void esvit_debug_set_gemm_m64(int on);    /* 1: 64-row tiles where 128-row tiles quantise badly over the resident workgroups (default 0: measured slower) */
-void esvit_debug_set_gemm_group_m(int g); /* -1 (default): grouped tile order (8 row blocks per group) where N/BN >= 16; >= 0 forces the group size (0/1 = column-fastest) */
-void esvit_debug_set_gemm_l2_prefetch(int on); /* 1: LDS-DMA GEMM also touches one line per thread of k-tile kt+3 (L2 prefetch) */
-void esvit_debug_set_gemm_stagger(int cycles); /* first-round delay (shader cycles) of the second workgroup per CU; bit 30 selects odd slots */
-void esvit_debug_set_gemm_pipe(int mode);  /* LDS-DMA pipeline: 1 = BK64 x 2 buffers, 3 = BK64 x 3-deep ring, 4 = BK32 x 4-deep ring */
 
 #ifdef __cplusplus
 }

@@ -42,23 +42,27 @@ def _rand(shape, dev, seed, dt=torch.float32, scale=1.0):
     return (torch.randn(shape, generator=g) * scale).to(dev).to(dt)
 
 
-@pytest.fixture(params=[6, 7, 1, 2, 3, 4, 5, 0], ids=["ws-2xBK64", "ws-4xBK32", "dma-2xBK64", "dma-2xBK32", "dma-ring3xBK64", "dma-ring4xBK32", "dma-ring3xBK32", "regstage"])
+@pytest.fixture(params=[0, 3, 2, 1], ids=["auto", "dma8", "dma4", "regstage"])
 def gemm_path(request, mods):
-    """every GEMM main loop: the persistent warp-specialised kernel (producer waves + consumer waves), the
-    one-tile-per-workgroup LDS-DMA rings (buffer_load ... lds + counted vmcnt) and the register-staged BK=32 loop"""
+    """every bf16 GEMM main loop on every shape: the library's own choice, the 8-wave 256-row LDS-DMA loop, the 4-wave
+    128-row LDS-DMA loop and the register-staged loop, forced through esvit_gemm_desc.kernel (the library keeps no state);
+    the exact-fp32 mode has one main loop and ignores the selector"""
     ops, _ = mods
-    ops.debug_set_gemm_dma(2 if request.param else 0)
-    if request.param:
-        ops.debug_set_gemm_pipe(request.param)
+    ops.FORCE_GEMM_KERNEL = request.param
     yield request.param
-    ops.debug_set_gemm_dma(1)
-    ops.debug_set_gemm_pipe(1)
+    ops.FORCE_GEMM_KERNEL = 0
+
+
+def _skip_redundant(gemm_path, dt):
+    if dt == torch.float32 and gemm_path != 0:
+        pytest.skip("the fp32 mode has one main loop")
 
 
 @pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("M,N,K", [(300, 96, 96), (257, 288, 96), (128, 384, 192), (1000, 256, 2048), (64, 64, 48), (520, 1024, 256),
                                    (777, 2048, 768), (130, 96, 384), (33000, 384, 200), (37000, 256, 128)])
 def test_gemm_nt(mods, gemm_path, dt, M, N, K):
+    _skip_redundant(gemm_path, dt)
     ops, ref = mods
     dev = _dev()
     x, w, b = _rand((M, K), dev, 1, dt), _rand((N, K), dev, 2, dt, 0.1), _rand((N,), dev, 3)
@@ -75,121 +79,67 @@ def test_gemm_nt(mods, gemm_path, dt, M, N, K):
     _close("nt+res f32", ops.linear_fwd(x, w, b, residual=res, out_f32=True), ref.linear_fwd(x, w, b, residual=res, out_f32=True), _tol(dt, bf=5e-3))
 
 
-def test_gemm_m64_tiles(mods):
-    """the optional 64-row tiling (esvit_debug_set_gemm_m64) on shapes whose 128-row grid quantises badly"""
+def test_gemm_grouped_tile_order(mods, gemm_path):
+    """tile_coords(): the grouped tile order (12..64 column tiles) is a permutation of the tiles -- same result, including
+    ragged last groups (row blocks % 16 != 0) and ragged edge tiles; also long-K shapes with few tiles (the 8-wave loop's
+    ragged k-tiles) and a split-K dgrad over a 65536-long reduction"""
     ops, ref = mods
     dev = _dev()
     dt = torch.bfloat16
-    ops.lib.esvit_debug_set_gemm_m64(1)
-    try:
-        for M, N, K in ((37000, 256, 128), (40000, 192, 96)):
-            x, w, b = _rand((M, K), dev, 1, dt), _rand((N, K), dev, 2, dt, 0.1), _rand((N,), dev, 3)
-            _close("m64 nt", ops.linear_fwd(x, w, b), ref.linear_fwd(x, w, b), _tol(dt))
-            res = _rand((M, N), dev, 4)
-            _close("m64 nt+res", ops.linear_fwd(x, w, b, residual=res, out_f32=True), ref.linear_fwd(x, w, b, residual=res, out_f32=True),
-                   _tol(dt, bf=5e-3))
-            dy, wd = _rand((M, K), dev, 5, dt), _rand((K, N), dev, 6, dt, 0.1)
-            _close("m64 dgrad", ops.linear_dgrad(dy, wd), ref.linear_dgrad(dy, wd), _tol(dt))
-    finally:
-        ops.lib.esvit_debug_set_gemm_m64(0)
+    for M, N, K in ((1500, 2304, 128), (700, 4096, 64), (2700, 2048 + 96, 192), (2700, 3072, 776), (5000, 1536, 1000)):
+        x, w, b = _rand((M, K), dev, 1, dt), _rand((N, K), dev, 2, dt, 0.1), _rand((N,), dev, 3)
+        _close("grouped nt", ops.linear_fwd(x, w, b), ref.linear_fwd(x, w, b), _tol(dt))
+        y, pre = ops.linear_fwd(x, w, b, gelu=True, want_preact=True)
+        yr, prer = ref.linear_fwd(x, w, b, gelu=True, want_preact=True)
+        _close("grouped nt+gelu", y, yr, _tol(dt))
+        _close("grouped preact", pre, prer, _tol(dt))
+        dy, wd = _rand((M, K), dev, 5, dt), _rand((K, N), dev, 6, dt, 0.1)
+        _close("grouped dgrad", ops.linear_dgrad(dy, wd), ref.linear_dgrad(dy, wd), _tol(dt))
+    dy, wd = _rand((1300, 8192), dev, 5, dt), _rand((8192, 256), dev, 6, dt, 0.05)
+    _close("long-K dgrad (split-K)", ops.linear_dgrad(dy, wd), ref.linear_dgrad(dy, wd), _tol(dt))
 
 
-def test_gemm_l2_prefetch(mods):
-    """esvit_debug_set_gemm_l2_prefetch(1): the extra line-touching loads of the LDS-DMA loop change no result -- short
-    and ragged K (1, 2, 3 k-tiles, partial last tile), ragged rows, split-K wgrad with the fused bias gradient"""
-    ops, ref = mods
-    dev = _dev()
-    dt = torch.bfloat16
-    ops.lib.esvit_debug_set_gemm_l2_prefetch(1)
-    try:
-        for M, N, K in ((300, 96, 32), (257, 192, 96), (1000, 384, 160), (1300, 1536, 384), (900, 768, 3072), (40000, 192, 96)):
-            x, w, b = _rand((M, K), dev, 1, dt), _rand((N, K), dev, 2, dt, 0.1), _rand((N,), dev, 3)
-            _close("pf nt", ops.linear_fwd(x, w, b), ref.linear_fwd(x, w, b), _tol(dt))
-            y, pre = ops.linear_fwd(x, w, b, gelu=True, want_preact=True)
-            yr, prer = ref.linear_fwd(x, w, b, gelu=True, want_preact=True)
-            _close("pf nt+gelu", y, yr, _tol(dt))
-            _close("pf preact", pre, prer, _tol(dt))
-            res = _rand((M, N), dev, 4)
-            _close("pf nt+res", ops.linear_fwd(x, w, b, residual=res, out_f32=True), ref.linear_fwd(x, w, b, residual=res, out_f32=True),
-                   _tol(dt, bf=5e-3))
-            dy, wd = _rand((M, K), dev, 5, dt), _rand((K, N), dev, 6, dt, 0.1)
-            _close("pf dgrad", ops.linear_dgrad(dy, wd), ref.linear_dgrad(dy, wd), _tol(dt))
-            g = _rand((M, N), dev, 7, dt)
-            dw, db = ops.linear_wgrad(g, x, want_bias=True)
-            dwr, dbr = ref.linear_wgrad(g, x, want_bias=True)
-            _close("pf wgrad", dw, dwr, _tol(dt, bf=2e-2))
-            _close("pf wgrad bias", db, dbr, _tol(dt, bf=2e-2))
-    finally:
-        ops.lib.esvit_debug_set_gemm_l2_prefetch(0)
-
-
-@pytest.mark.parametrize("group_m", [-1, 8, 3])
-def test_gemm_grouped_tile_order(mods, group_m):
-    """tile_coords(): the grouped tile order (automatic for N/BN >= 16) is a permutation of the tiles -- same result,
-    including ragged last groups (rows % group != 0) and ragged edge tiles"""
-    ops, ref = mods
-    dev = _dev()
-    dt = torch.bfloat16
-    ops.lib.esvit_debug_set_gemm_group_m(group_m)
-    try:
-        for M, N, K in ((1500, 2304, 128), (700, 4096, 64), (2700, 2048 + 96, 192)):
-            x, w, b = _rand((M, K), dev, 1, dt), _rand((N, K), dev, 2, dt, 0.1), _rand((N,), dev, 3)
-            _close("grouped nt", ops.linear_fwd(x, w, b), ref.linear_fwd(x, w, b), _tol(dt))
-            y, pre = ops.linear_fwd(x, w, b, gelu=True, want_preact=True)
-            yr, prer = ref.linear_fwd(x, w, b, gelu=True, want_preact=True)
-            _close("grouped nt+gelu", y, yr, _tol(dt))
-            _close("grouped preact", pre, prer, _tol(dt))
-            dy, wd = _rand((M, K), dev, 5, dt), _rand((K, N), dev, 6, dt, 0.1)
-            _close("grouped dgrad", ops.linear_dgrad(dy, wd), ref.linear_dgrad(dy, wd), _tol(dt))
-    finally:
-        ops.lib.esvit_debug_set_gemm_group_m(-1)
-
-
-@pytest.mark.parametrize("tr", [1, 0])
 @pytest.mark.parametrize("dt", DTYPES)
-@pytest.mark.parametrize("M,N,K", [(300, 96, 384), (257, 192, 576), (1000, 2048, 256), (130, 768, 3072), (40000, 192, 96)])
-def test_gemm_dgrad(mods, gemm_path, dt, tr, M, N, K):
-    """dx[M,N] = dy[M,K] @ w[K,N] (B read k-strided; tr=1 uses ds_read_b64_tr_b16)."""
+@pytest.mark.parametrize("M,N,K", [(300, 96, 384), (257, 192, 576), (1000, 2048, 256), (130, 768, 3072), (40000, 192, 96), (3000, 384, 1536)])
+def test_gemm_dgrad(mods, gemm_path, dt, M, N, K):
+    """dx[M,N] = dy[M,K] @ w[K,N] (B read k-strided with ds_read_b64_tr_b16)."""
+    _skip_redundant(gemm_path, dt)
     ops, ref = mods
     dev = _dev()
-    ops.debug_set_tr_read(tr)
-    try:
-        dy, w = _rand((M, K), dev, 5, dt), _rand((K, N), dev, 6, dt, 0.1)
-        _close("dgrad", ops.linear_dgrad(dy, w), ref.linear_dgrad(dy, w), _tol(dt))
-        pre = _rand((M, N), dev, 7, dt)
-        _close("dgrad+gelu'", ops.linear_dgrad(dy, w, gelu_preact=pre), ref.linear_dgrad(dy, w, gelu_preact=pre), _tol(dt))
-        _close("dgrad+quickgelu'", ops.linear_dgrad(dy, w, gelu_preact=pre, quick=True), ref.linear_dgrad(dy, w, gelu_preact=pre, quick=True),
-               _tol(dt))
-    finally:
-        ops.debug_set_tr_read(1)
+    dy, w = _rand((M, K), dev, 5, dt), _rand((K, N), dev, 6, dt, 0.1)
+    _close("dgrad", ops.linear_dgrad(dy, w), ref.linear_dgrad(dy, w), _tol(dt))
+    pre = _rand((M, N), dev, 7, dt)
+    _close("dgrad+gelu'", ops.linear_dgrad(dy, w, gelu_preact=pre), ref.linear_dgrad(dy, w, gelu_preact=pre), _tol(dt))
+    _close("dgrad+quickgelu'", ops.linear_dgrad(dy, w, gelu_preact=pre, quick=True), ref.linear_dgrad(dy, w, gelu_preact=pre, quick=True),
+           _tol(dt))
 
 
-@pytest.mark.parametrize("tr", [1, 0])
 @pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("rows,Nout,Kin", [(392, 288, 96), (3136, 96, 384), (1000, 256, 2048), (98, 768, 768), (6272, 64, 48),
-                                           (25088, 1152, 384), (12545 * 8, 192, 576)])
-def test_gemm_wgrad(mods, gemm_path, dt, tr, rows, Nout, Kin):
+                                           (25088, 1152, 384), (12545 * 8, 192, 576), (20000, 384, 1536), (9000, 2048, 768),
+                                           (4100, 768, 2304), (7000, 1000, 264)])
+def test_gemm_wgrad(mods, gemm_path, dt, rows, Nout, Kin):
+    """dw = dy^T x, both operands k-strided (transpose reads), split-K over the rows; the shapes cover every tile of the
+    8-wave loop (192 / 256 rows x 192 / 256 columns, ragged edges) and of the 4-wave loop"""
+    _skip_redundant(gemm_path, dt)
     ops, ref = mods
     dev = _dev()
-    ops.debug_set_tr_read(tr)
-    try:
-        dy, x = _rand((rows, Nout), dev, 8, dt), _rand((rows, Kin), dev, 9, dt)
-        _close("wgrad", ops.linear_wgrad(dy, x), ref.linear_wgrad(dy, x), _tol(dt, f32=5e-5, bf=2e-3))
-        dw, db = ops.linear_wgrad(dy, x, want_bias=True)
-        dwr, dbr = ref.linear_wgrad(dy, x, want_bias=True)
-        _close("wgrad(+bias) dw", dw, dwr, _tol(dt, f32=5e-5, bf=2e-3))
-        _close("wgrad(+bias) db", db, dbr, _tol(dt, f32=5e-5, bf=2e-3))
-        acc = _rand((Nout, Kin), dev, 10)
-        acc_ref = acc.clone()
-        _close("wgrad acc", ops.linear_wgrad(dy, x, out=acc, accumulate=True), ref.linear_wgrad(dy, x, out=acc_ref, accumulate=True),
-               _tol(dt, f32=5e-5, bf=2e-3))
-    finally:
-        ops.debug_set_tr_read(1)
+    dy, x = _rand((rows, Nout), dev, 8, dt), _rand((rows, Kin), dev, 9, dt)
+    _close("wgrad", ops.linear_wgrad(dy, x), ref.linear_wgrad(dy, x), _tol(dt, f32=5e-5, bf=2e-3))
+    dw, db = ops.linear_wgrad(dy, x, want_bias=True)
+    dwr, dbr = ref.linear_wgrad(dy, x, want_bias=True)
+    _close("wgrad(+bias) dw", dw, dwr, _tol(dt, f32=5e-5, bf=2e-3))
+    _close("wgrad(+bias) db", db, dbr, _tol(dt, f32=5e-5, bf=2e-3))
+    acc = _rand((Nout, Kin), dev, 10)
+    acc_ref = acc.clone()
+    _close("wgrad acc", ops.linear_wgrad(dy, x, out=acc, accumulate=True), ref.linear_wgrad(dy, x, out=acc_ref, accumulate=True),
+           _tol(dt, f32=5e-5, bf=2e-3))
 
 
 @pytest.mark.parametrize("dt", DTYPES)
 def test_gemm_rowmap_scatter(mods, gemm_path, dt):
     """window rows -> token rows with pad rows dropped, DropPath scale and residual (proj epilogue)."""
+    _skip_redundant(gemm_path, dt)
     ops, ref = mods
     dev = _dev()
     H, ws, shift, C, nB = 6, 7, 3, 96, 3
@@ -353,47 +303,22 @@ def test_window_attention(mods, dt, ws, nH, H, shift, hd):
     orf, _, attnr = ref.window_attn_fwd(qkv, qb, w2t, L, table, ws, mask_frag, nW, N, nH, scale, want_attn=True)
     _close("attn probs", attn, attnr, _tol(dt, f32=5e-5, bf=2e-2))
     _close("attn out", o, orf, _tol(dt, f32=5e-5, bf=2e-2))
-    if N <= 64:  # every generation of the small-window forward (training variant: no probabilities written)
-        try:
-            for impl in ((4, 3, 2, 1) if hd == 32 else (4, 3)):
-                ops.lib.esvit_debug_set_attn_fwd_impl(impl)
-                res = ops.window_attn_fwd(qkv, qb, w2t, L, table, ws, mask_frag, nW, N, nH, scale)
-                _close("attn out (gen %d)" % impl, res[0], orf, _tol(dt, f32=5e-5, bf=2e-2))
-                if impl >= 3:
-                    resa = ops.window_attn_fwd(qkv, qb, w2t, L, table, ws, mask_frag, nW, N, nH, scale, want_attn=True)
-                    _close("attn probs (gen %d)" % impl, resa[2], attnr, _tol(dt, f32=5e-5, bf=2e-2))
-        finally:
-            ops.lib.esvit_debug_set_attn_fwd_impl(4)
-    if ws == 14:  # both generations of the 14x14 forward, training variant (no probabilities written)
-        try:
-            for impl in (1, 2, 3):
-                ops.lib.esvit_debug_set_big_attn_impl(impl, 5)
-                res = ops.window_attn_fwd(qkv, qb, w2t, L, table, ws, mask_frag, nW, N, nH, scale)
-                _close("attn out (14x14 gen %d)" % impl, res[0], orf, _tol(dt, f32=5e-5, bf=2e-2))
-                _close("attn lse (14x14 gen %d)" % impl, res[1], lse, _tol(dt, f32=5e-5, bf=2e-2))
-        finally:
-            ops.lib.esvit_debug_set_big_attn_impl(3, 5)
+    res = ops.window_attn_fwd(qkv, qb, w2t, L, table, ws, mask_frag, nW, N, nH, scale)  # training variant: no probabilities written
+    _close("attn out (train)", res[0], orf, _tol(dt, f32=5e-5, bf=2e-2))
+    if ws == 14:
+        _close("attn lse (train)", res[1], lse, _tol(dt, f32=5e-5, bf=2e-2))
     dout = _rand((nB * L, C), dev, 52, dt)
-    # (transpose-read on / off) x (for 14x14 windows: both generations of the backward kernels)
-    variants = [(1, 5), (0, 5), (1, 6), (1, 4), (1, 1), (0, 1)] if ws == 14 else [(1, 5), (0, 5)]
-    for tr, big_bwd in variants:
-        ops.debug_set_tr_read(tr)
-        ops.lib.esvit_debug_set_big_attn_impl(3, big_bwd)
-        try:
-            dqkv, ws_, pad_ = ops.window_attn_bwd(qkv, qb, w2t, L, dout, orf, lse, table, ws, mask_frag, nW, N, nH, scale)
-            dt_ = ops.relpos_bias_bwd(ws_, index, N, trows)
-        finally:
-            ops.debug_set_tr_read(1)
-            ops.lib.esvit_debug_set_big_attn_impl(3, 5)
-        dqkvr, wsr, padr = ref.window_attn_bwd(qkv, qb, w2t, L, dout, orf, lse, table, ws, mask_frag, nW, N, nH, scale)
-        for i, nm in enumerate("qkv"):
-            _close("attn d%s tr=%d" % (nm, tr), dqkv.view(-1, 3, C)[:, i], dqkvr.view(-1, 3, C)[:, i], _tol(dt, f32=1e-4, bf=3e-2))
-        dtr = ref.relpos_bias_bwd(wsr, index, N, trows)
-        _close("attn dtable tr=%d" % tr, dt_, dtr, _tol(dt, f32=1e-4, bf=3e-2))
-        if (win2tok_np < 0).any():
-            _close("attn dpad tr=%d" % tr, pad_.sum(0, keepdim=True), padr, _tol(dt, f32=1e-4, bf=3e-2))
-        else:
-            assert float(pad_.abs().max()) == 0.0
+    dqkv, ws_, pad_ = ops.window_attn_bwd(qkv, qb, w2t, L, dout, orf, lse, table, ws, mask_frag, nW, N, nH, scale)
+    dt_ = ops.relpos_bias_bwd(ws_, index, N, trows)
+    dqkvr, wsr, padr = ref.window_attn_bwd(qkv, qb, w2t, L, dout, orf, lse, table, ws, mask_frag, nW, N, nH, scale)
+    for i, nm in enumerate("qkv"):
+        _close("attn d%s" % nm, dqkv.view(-1, 3, C)[:, i], dqkvr.view(-1, 3, C)[:, i], _tol(dt, f32=1e-4, bf=3e-2))
+    dtr = ref.relpos_bias_bwd(wsr, index, N, trows)
+    _close("attn dtable", dt_, dtr, _tol(dt, f32=1e-4, bf=3e-2))
+    if (win2tok_np < 0).any():
+        _close("attn dpad", pad_.sum(0, keepdim=True), padr, _tol(dt, f32=1e-4, bf=3e-2))
+    else:
+        assert float(pad_.abs().max()) == 0.0
 
 
 @pytest.mark.parametrize("dt", DTYPES)
