@@ -5,11 +5,15 @@ loss, bf16, per-parameter clip + AdamW + teacher EMA, DP over RCCL when --gpus >
     python bench.py --gpus 1 --steps 20 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
+`python bench.py --gpus N` without a torchrun environment re-executes itself under torch.distributed.run with N ranks.
+
 Prints ONE JSON line on rank 0.  A "step" = teacher fwd (2 global crops) + student fwd (10 crops) + DDINOLoss + backward +
 gradient all-reduce (N>1) + fused clip/AdamW/EMA on a fixed synthetic batch resident in HBM.  `value` = images/s over all
-ranks.  `roofline` describes the dominant kernel family (the MFMA GEMM: 99% of the step's FLOPs) from HIP events recorded
-around every GEMM launch of every 4th step of the timed region; `cpu_baseline` times the CPU oracle (a port of the reference's PyTorch
-path, oracle/esvit_oracle.py) on the host cores on a bounded sample of the same workload.
+ranks; the timed region carries no instrumentation.  `roofline` describes the dominant kernel family (the MFMA GEMM: 99% of
+the step's FLOPs; SURVEY.md 8d bounds it by the bf16 MFMA peak) from HIP events recorded around every GEMM launch of a few
+extra steps AFTER the timed region; `cpu_baseline` times the reference's PyTorch path on the host cores on a bounded sample
+of the same workload -- the reference's own modules when /root/reference is present (kind "reference"), otherwise the
+oracle's restatement of them (kind "port").
 """
 import argparse
 import json
@@ -30,21 +34,22 @@ GFLOP_PER_IMG_BY_ARCH = {"swin_tiny_w7": 154.5, "swin_tiny_w14": 197.0, "swin_ba
 BF16_PEAK_TFLOPS = 2500.0      # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E (MI355X_MICROARCH.md; ~6.3 TB/s is what a streaming kernel reaches)
 OUT_DIM = 65536
-PMC_TRAFFIC_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
+PMC_TRAFFIC_FILES = [os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f) for f in ("r02_pmc_traffic.json", "r01_pmc_traffic.json")]
 
 
 def pmc_gemm_traffic_per_launch(arch, batch, launches_per_step):
     """HBM bytes per GEMM launch from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE in separate
     runs of this same command, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950; produced by
     tools/pmc_traffic.py).  None when no PMC run exists for this arch / batch."""
-    try:
-        with open(PMC_TRAFFIC_FILE) as fh:
-            runs = json.load(fh)["runs"]
-    except (OSError, ValueError, KeyError):
-        return None
-    for r in runs:
-        if r["arch"] == arch and r["batch"] == batch:
-            return r["gemm_bytes_per_step"] / launches_per_step
+    for path in PMC_TRAFFIC_FILES:  # the newest committed PMC run wins
+        try:
+            with open(path) as fh:
+                runs = json.load(fh)["runs"]
+        except (OSError, ValueError, KeyError):
+            continue
+        for r in runs:
+            if r["arch"] == arch and r["batch"] == batch:
+                return r["gemm_bytes_per_step"] / launches_per_step
     return None
 
 
@@ -66,27 +71,35 @@ def build(dev, drop_path, arch="swin_tiny_w7"):
     return student, teacher, loss
 
 
-def cpu_baseline(bs=2, steps=6):
-    """CPU oracle (port of the reference path) on the same workload shape at a bounded batch: fp32, all host cores."""
+def _cpu_threads():
+    # the small per-op tensors of this workload scale poorly past a few dozen threads (128 threads measured 5x slower than
+    # 8), so the baseline uses at most 32 host threads and reports the count it used as `cores`
+    n = min(32, os.cpu_count() or 1)
+    torch.set_num_threads(n)
+    return n
+
+
+def _port_baseline(dense, bs, steps):
+    """oracle/esvit_oracle.py (restatement of the reference's PyTorch path): one full step = teacher fwd, student fwd, loss,
+    backward, clip + AdamW + EMA, centre update; fp32"""
     from oracle import esvit_oracle as O
     from tests import golden_utils as GU
     import esvit_amd
     from esvit_amd import config as CFG
     torch.manual_seed(0)
-    # the small per-op tensors of this workload scale poorly past a few dozen threads (128 threads measured 5x slower than
-    # 8), so the baseline uses at most 32 and reports that count as `cores`
-    torch.set_num_threads(min(32, os.cpu_count() or 1))
     cfg = CFG.swin_config("swin_tiny_w7", DROP_PATH_RATE=0.0)
-    m = esvit_amd.build_model(cfg, use_dense_prediction=True)
+    m = esvit_amd.build_model(cfg, use_dense_prediction=dense)
     m.head = esvit_amd.DINOHead(m.num_features, OUT_DIM)
-    m.head_dense = esvit_amd.DINOHead(m.num_features, OUT_DIM)
+    if dense:
+        m.head_dense = esvit_amd.DINOHead(m.num_features, OUT_DIM)
     sd = {k: v.clone() for k, v in m.state_dict().items()}
     names = [n for n, p in m.named_parameters() if p.requires_grad]
     all_names = [n for n, _ in m.named_parameters()]
     params = {n: sd[n] for n in all_names}
     teacher = {n: sd[n].clone() for n in all_names}
     reg = {n for n in names if not (n.endswith(".bias") or sd[n].ndim == 1)}
-    crops = GU.make_crops(bs)
+    crops = GU.make_crops(bs) if dense else GU.make_crops(bs)[:2]
+    ncrops = len(crops)
     c0, cg0 = torch.zeros(1, OUT_DIM), torch.zeros(1, OUT_DIM)
     state = {}
     times = []
@@ -99,19 +112,85 @@ def cpu_baseline(bs=2, steps=6):
         tfull = dict(sd)
         tfull.update(teacher)
         with torch.no_grad():
-            t_out = O.swin_multicrop(tfull, crops[:2], GU.SWIN_T)
-        s_out = O.swin_multicrop(full, crops, GU.SWIN_T)
-        loss, bc, bg = O.ddino_loss(s_out, t_out, c0, cg0, 0.04, 10)
+            t_out = O.swin_multicrop(tfull, crops[:2], GU.SWIN_T, dense=dense)
+        s_out = O.swin_multicrop(full, crops, GU.SWIN_T, dense=dense)
+        if dense:
+            loss, bc, bg = O.ddino_loss(s_out, t_out, c0, cg0, 0.04, ncrops)
+        else:
+            loss, bc = O.dino_loss(s_out, t_out, c0, 0.04, ncrops)
         loss.backward()
         with torch.no_grad():
-            c0, cg0 = O.center_update(c0, bc, 2 * bs), O.center_update(cg0, bg, 98 * bs)
+            c0 = O.center_update(c0, bc, 2 * bs)
+            if dense:
+                cg0 = O.center_update(cg0, bg, 98 * bs)
             grads = {n: leaf[n].grad for n in names}
             O.clip_adamw_ema(params, grads, state, teacher, reg, 5e-4, 0.04, 0.996, clip=3.0)
         times.append(time.perf_counter() - t0)
     times = sorted(times[1:])
-    med = times[len(times) // 2]
-    return {"value": bs / med, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "oracle/esvit_oracle.py fp32, Swin-T W7 2x224+8x96 V+R, bs=%d, median of %d steps (%.2f s/step)" % (bs, steps, med)}
+    return times[len(times) // 2]
+
+
+def _reference_baseline(dense, bs, steps):
+    """the reference's OWN modules (models.build_model, DINOHead, DINOLoss / DDINOLoss, utils.clip_gradients,
+    torch.optim.AdamW over utils.get_params_groups, the EMA loop of main_esvit.py:587-590) imported from /root/reference under
+    the shims of SURVEY.md 8c; fp32 (the CPU path of main_esvit.py:541-574 with fp16_scaler None)"""
+    from oracle import ref_loader as RL
+    from tests import golden_utils as GU
+    ns = RL.load()
+    RL.ensure_single_process_group()
+    torch.manual_seed(0)
+    cfg = RL.swin_config()
+
+    def make(teacher):
+        m = ns.models.build_model(cfg, is_teacher=teacher, use_dense_prediction=dense)
+        m.head = ns.DINOHead(m.num_features, OUT_DIM)
+        if dense:
+            m.head_dense = ns.DINOHead(m.num_features, OUT_DIM)
+        return m
+    student, teacher = make(False), make(True)
+    teacher.load_state_dict(student.state_dict())
+    for p in teacher.parameters():
+        p.requires_grad = False
+    crops = GU.make_crops(bs) if dense else GU.make_crops(bs)[:2]
+    loss_fn = (ns.DDINOLoss if dense else ns.DINOLoss)(OUT_DIM, len(crops), 0.04, 0.04, 0, 100)
+    opt = torch.optim.AdamW(ns.utils.get_params_groups(student))
+    for i, pg in enumerate(opt.param_groups):
+        pg["lr"] = 5e-4
+        if i == 0:
+            pg["weight_decay"] = 0.04
+    times = []
+    for it in range(steps + 1):
+        t0 = time.perf_counter()
+        teacher_out = teacher(crops[:2])
+        student_out = student(crops)
+        loss = loss_fn(student_out, teacher_out, 1, None)
+        opt.zero_grad()
+        loss.backward()
+        ns.utils.clip_gradients(student, 3.0)
+        opt.step()
+        with torch.no_grad():
+            for pq, pk in zip(student.parameters(), teacher.parameters()):
+                pk.data.mul_(0.996).add_((1 - 0.996) * pq.detach().data)
+        times.append(time.perf_counter() - t0)
+    times = sorted(times[1:])
+    return times[len(times) // 2]
+
+
+def cpu_baseline():
+    """both CPU legs SURVEY.md 8(d) asks for, bounded to ~10-30 s each: BASELINE config 2's CPU twin (2x224 + 8x96 crops, V+R,
+    bs 2) as the main entry, BASELINE config 1 (2x224 crops, view-level loss, bs 4) under `config1`"""
+    from oracle import ref_loader as RL
+    cores = _cpu_threads()
+    use_ref = RL.available()
+    run = _reference_baseline if use_ref else _port_baseline
+    kind = "reference" if use_ref else "port"
+    what = ("the reference's own modules (/root/reference via oracle/ref_loader.py)" if use_ref else "oracle/esvit_oracle.py (restatement of the reference path)")
+    med2 = run(True, 2, 4)
+    med1 = run(False, 4, 4)
+    return {"value": 2 / med2, "unit": "images/s", "cores": cores, "kind": kind,
+            "sample": "%s, fp32, Swin-T W7 2x224+8x96 V+R out_dim 65536, bs=2, median of 4 full steps (%.2f s/step), %d host threads" % (what, med2, cores),
+            "config1": {"value": 4 / med1, "unit": "images/s", "cores": cores, "kind": kind,
+                        "sample": "%s, fp32, Swin-T W7 2x224 crops only, view-level DINOLoss, bs=4, median of 4 full steps (%.2f s/step)" % (what, med1)}}
 
 
 def torch_eager_gpu_baseline(dev, bs, steps=5):
@@ -184,11 +263,20 @@ def main():
                     help="also time the reference-path port under torch eager + autocast(bf16) on this GPU at the given batch")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: become N ranks (one process per GPU) under torch.distributed.run
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        os.execv(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+                                  "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:])
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 or world > 1 or os.environ.get("ESVIT_FORCE_REDUCER") == "1":
-        assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+        if world != args.gpus:
+            raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
         torch.cuda.set_device(local)
         dist.init_process_group("nccl")
     dev = torch.device("cuda", local)
@@ -199,8 +287,9 @@ def main():
     from esvit_amd.engine import EsvitTrainer
     from tests import golden_utils as GU
     esvit_amd.set_precision("bf16")
-    torch.manual_seed(0)
+    torch.manual_seed(0)  # identical replicas ...
     student, teacher, loss_fn = build(dev, args.drop_path, args.arch)
+    torch.manual_seed(1000 + rank)  # ... but every rank draws its own stochastic-depth masks (and has its own crops)
     trainer = EsvitTrainer(student, teacher, loss_fn, clip_grad=3.0, freeze_last_layer=1)
     B = args.batch
     crops = [c.to(dev) for c in GU.make_crops(B, seed=1234 + rank)]
@@ -215,25 +304,25 @@ def main():
     for _ in range(args.warmup):
         trainer.step(crops, lr, wd, mom, epoch)
     sync()
-    # HIP events around every GEMM launch of every PROF_EVERY-th step of the timed region (two event records per launch cost
-    # ~2.7 us of stream time each: ~1.3 ms per step if every step were instrumented)
-    PROF_EVERY = 4
-    prof, prof_steps = None, 0
-    if not args.no_roofline:
-        ops._EVENT_POOL.extend(torch.cuda.Event(enable_timing=True) for _ in range(2400 * (args.steps // PROF_EVERY + 1)))
-        prof = []
     t0 = time.perf_counter()
     loss = None
     for i in range(args.steps):
-        if prof is not None and i % PROF_EVERY == 0:
-            ops.GEMM_PROFILE = prof
-            prof_steps += 1
-        else:
-            ops.GEMM_PROFILE = None
         loss = trainer.step(crops, lr, wd, mom, epoch)
     sync()
     dt = time.perf_counter() - t0
-    ops.GEMM_PROFILE = None
+    # roofline leg, OUTSIDE the timed region: HIP events around every GEMM launch of PROF_STEPS extra steps (two event records
+    # per launch cost ~2.7 us of stream time each, ~1.3 ms per instrumented step)
+    PROF_STEPS = 4
+    prof, prof_steps = None, 0
+    if not args.no_roofline:
+        ops._EVENT_POOL.extend(torch.cuda.Event(enable_timing=True) for _ in range(2400 * PROF_STEPS))
+        prof = []
+        ops.GEMM_PROFILE = prof
+        for _ in range(PROF_STEPS):  # every rank runs them (the collectives need all ranks); rank 0 reports
+            trainer.step(crops, lr, wd, mom, epoch)
+            prof_steps += 1
+        sync()
+        ops.GEMM_PROFILE = None
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -267,18 +356,20 @@ def main():
                     for key, (n, ms, fl, by) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
                         fh.write("M=%7d N=%6d K=%7d aks=%d bks=%d splitk=%3d calls/step %5.1f ms/step %7.3f TF %7.1f GB/s %6.0f MB/call %7.1f\n" % (
                             key + (n / prof_steps, ms / prof_steps, fl / ms / 1e9, by / ms / 1e6, by / n / 1e6)))
-            # The GEMM family (all fwd / dgrad / wgrad launches of the step) is the dominant kernel.  Its arithmetic
-            # intensity on this workload is ~180 FLOP/B against a ridge of 2500 TFLOP/s / 8 TB/s = 312 FLOP/B, so
-            # HBM is the roof that binds; the MFMA figure is kept beside it.
+            # The GEMM family (all fwd / dgrad / wgrad launches of the step) is the dominant kernel; SURVEY.md 8(d) bounds the
+            # dense contractions by the bf16 MFMA peak: achieved = sum(2MNK) / sum(launch time).  The HBM view of the same
+            # launches (algorithmic bytes = A + B + C (+ side tensors) once per launch) is reported beside it: on this
+            # workload's unfused shapes the family moves ~156 FLOP per algorithmic byte, half the 312 FLOP/B ridge.
             gbs = tot_by / (tot_ms * 1e-3) / 1e9
             ach_tf = tot_fl / (tot_ms * 1e-3) / 1e12
-            out["roofline"] = {"bound": "hbm", "kernel": "gemm_dma_kernel / gemm_kernel (all fwd/dgrad/wgrad GEMM launches of the step)",
-                               "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+            out["roofline"] = {"bound": "mfma", "kernel": "gemm_dma_kernel / gemm_kernel (all fwd/dgrad/wgrad GEMM launches of the step)",
+                               "achieved": ach_tf, "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach_tf / BF16_PEAK_TFLOPS,
                                "traffic": pmc_gemm_traffic_per_launch(args.arch, B, len(prof) / prof_steps),
                                "launches_per_step": len(prof) / prof_steps, "instrumented_steps": prof_steps,
-                               "algorithmic_bytes_per_launch": tot_by / len(prof), "flops_per_launch": tot_fl / len(prof),
+                               "flops_per_launch": tot_fl / len(prof), "algorithmic_bytes_per_launch": tot_by / len(prof),
                                "avg_launch_us": tot_ms * 1e3 / len(prof), "gemm_ms_per_step": tot_ms / prof_steps,
-                               "flop_per_byte": tot_fl / tot_by, "mfma_tflops": ach_tf, "mfma_frac": ach_tf / BF16_PEAK_TFLOPS}
+                               "flop_per_byte": tot_fl / tot_by,
+                               "hbm_view": {"achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS}}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
         if args.torch_eager and world == 1:

@@ -1,12 +1,14 @@
 // esvit_gemm: shape -> kernel dispatch of the MFMA GEMM family (kernels: gemm_kernels.h).
 //
-// Three main loops, one fragment / epilogue convention:
-//   ESVIT_GEMM_REGSTAGE  register-staged, 128-row tiles, 4 waves: the exact-fp32 parity mode (v_mfma_f32_16x16x4_f32)
-//                        and the fallback for bf16 operands the LDS-DMA loop cannot take;
-//   ESVIT_GEMM_DMA4      LDS-DMA, 128 x {64, 96, 128} tiles, 4 waves, two workgroups per CU: short-K / small problems;
-//   ESVIT_GEMM_DMA8      LDS-DMA, 256 x {192, 256} (192-row tiles too for the weight gradients), 8 waves, one workgroup
-//                        per CU: half the operand bytes per FLOP -- long-K forward / dgrad GEMMs and the weight gradients.
-// The choice is a pure function of the descriptor (esvit_gemm_select); desc.kernel != 0 forces one (tests, tuning).
+// Main loops (one fragment / epilogue convention; esvit_gemm_desc.kernel forces one, 0 = the rules below):
+//   ESVIT_GEMM_REGSTAGE  register-staged, 128-row tiles, 4 waves: the exact-fp32 parity mode (v_mfma_f32_16x16x4_f32) and a
+//                        bf16 fallback;
+//   ESVIT_GEMM_DMA4      LDS-DMA, 128 x {64, 96, 128} tiles as 2 x 2 waves, two workgroups per CU: the default;
+//   ESVIT_GEMM_DMA4W     the same loop with whole-width wave rows -- 128 x 192 as 2 x 2 waves of 64 x 96, 128 x 96 as 4 x 1
+//                        waves of 32 x 96 -- for the 96 * 2^s wide backbone: 192-byte instead of 96-byte output row pieces
+//                        and fewer operand bytes per FLOP; chosen per epilogue kind from profiles/r02_gemm_kernels_b128.jsonl;
+//   ESVIT_GEMM_DMA8      LDS-DMA, 256 x 256 tiles, 8 waves, one workgroup per CU: very long reductions only.
+// The choice is a pure function of the descriptor (esvit_gemm_select).
 #include "gemm_kernels.h"
 
 namespace {
@@ -15,12 +17,16 @@ struct GemmChoice {
     int kernel, bm, bn;
 };
 
-inline bool mult192(int n) { return (n % 192 == 0) && (n % 256 != 0); }
+// tile of the 8-wave kernel
+inline void dma8_tile(const esvit_gemm_desc&, int& bm, int& bn) {
+    bm = 256;
+    bn = 256;
+}
 
-// tile of the 8-wave kernel for this problem
-inline void dma8_tile(const esvit_gemm_desc& d, int& bm, int& bn) {
-    bn = mult192(d.N) ? 192 : 256;
-    bm = (d.a_kstrided && mult192(d.M)) ? 192 : 256;
+// ESVIT_GEMM_DMA4W: 128 x 192 where N is a multiple of 192, 128 x 96 (4 x 1 waves) for the other multiples of 96
+inline void dma4w_tile(const esvit_gemm_desc& d, int& bm, int& bn) {
+    bm = 128;
+    bn = (d.N % 192 == 0) ? 192 : 96;
 }
 
 inline void dma4_tile(const esvit_gemm_desc& d, int& bm, int& bn) {
@@ -43,23 +49,34 @@ GemmChoice choose(int dtype, const esvit_gemm_desc& d) {
     int want = d.kernel;
     if (want == ESVIT_GEMM_AUTO) {
         want = ESVIT_GEMM_DMA4;
-        int bm, bn;
-        dma8_tile(d, bm, bn);
-        const long t8 = (long)ceil_div(d.M, bm) * ceil_div(d.N, bn);
         const int nz = d.splitk > 1 ? d.splitk : (d.batch > 1 ? d.batch : 1);
-        if (d.a_kstrided) {
-            // weight gradients: tiny outputs, the whole cost is streaming K rows of both operands -> the wider tile always
-            // wins once both output dims fill a 192-wide tile
-            if (d.M >= 192 && d.N >= 192) want = ESVIT_GEMM_DMA8;
-        } else if (!d.rowmap && d.N >= 192) {
-            // forward / dgrad: one 256-row tile per CU has no second workgroup to hide its epilogue behind, so it pays
-            // only when the main loop dominates (long K) and the grid fills the chip
-            const bool fills = t8 * nz >= 192 && round_efficiency(t8 * nz, 256) >= 0.72;
-            if (d.K >= 768 && fills) want = ESVIT_GEMM_DMA8;
+        const long t8 = (long)ceil_div(d.M, 256) * ceil_div(d.N, 256);
+        if (!d.a_kstrided && !d.rowmap && d.K >= 4096 && d.N >= 192 && t8 * nz >= 128) {
+            // One 256 x 256 tile per CU has no second workgroup to hide its prologue / epilogue behind: measured
+            // (profiles/r02_gemm_kernels_b128_first.jsonl) it wins only where the main loop is very long -- the dgrad of
+            // the 65536-wide last layer (K = out_dim, split-K): 1266 -> 865 us.  Everything else, the weight gradients
+            // included, is faster with two 4-wave workgroups per CU.
+            want = ESVIT_GEMM_DMA8;
+        } else if (d.N % 96 == 0 && !d.rowmap && d.batch <= 1) {
+            // whole-width wave rows (profiles/r02_gemm_kernels_b128.jsonl, per epilogue kind):
+            int bm4, bn4, bmw, bnw;
+            dma4_tile(d, bm4, bn4);
+            dma4w_tile(d, bmw, bnw);
+            const double e4 = round_efficiency((long)ceil_div(d.M, bm4) * ceil_div(d.N, bn4) * nz, 512);
+            const double ew = round_efficiency((long)ceil_div(d.M, bmw) * ceil_div(d.N, bnw) * nz, 512);
+            const bool gelu = d.epilogue == ESVIT_EPI_GELU || d.epilogue == ESVIT_EPI_QGELU;
+            const bool gelu_bwd = d.epilogue == ESVIT_EPI_GELU_BWD || d.epilogue == ESVIT_EPI_QGELU_BWD;
+            if (d.a_kstrided) want = ESVIT_GEMM_DMA4W;                                  // weight gradients: +1..28 %
+            else if (gelu_bwd) want = ESVIT_GEMM_DMA4;                                  // -6..-18 %
+            else if (d.residual) want = bnw == 96 ? ESVIT_GEMM_DMA4W : ESVIT_GEMM_DMA4;  // 4 x 1 waves +4..7 %, 128 x 192 -8..-30 %
+            else if (gelu) want = (bnw == 192 && d.N <= 768) ? ESVIT_GEMM_DMA4W : ESVIT_GEMM_DMA4;
+            else want = ew >= 0.9 * e4 ? ESVIT_GEMM_DMA4W : ESVIT_GEMM_DMA4;             // plain / bias: +5..25 % unless the wider tile quantises worse
         }
     }
+    if (want == ESVIT_GEMM_DMA4W && !(d.N % 96 == 0)) want = ESVIT_GEMM_DMA4;
     c.kernel = want;
     if (want == ESVIT_GEMM_DMA8) dma8_tile(d, c.bm, c.bn);
+    else if (want == ESVIT_GEMM_DMA4W) dma4w_tile(d, c.bm, c.bn);
     else dma4_tile(d, c.bm, c.bn);
     return c;
 }
@@ -71,16 +88,16 @@ int run_dma4(const esvit_gemm_desc& d, int bn, hipStream_t stream) {
     return launch_gemm_dma<AKS, BKS, 128, 128, 64, 2, 2, 2>(d, stream);
 }
 
-// 8 waves: 256 x 256 as 2 x 4 waves of 128 x 64 (128-byte bf16 row pieces in the epilogue), 256 x 192 as 4 x 2 waves of
-// 64 x 96, 192-row tiles (weight gradients of the 96 * 2^s wide backbone) as 2 x 4 waves of 96 x {48, 64}
+// 8 waves: 256 x 256 as 4 x 2 waves of 64 x 128 (measured faster than 2 x 4 waves of 128 x 64 on every layout)
 template <bool AKS, bool BKS>
-int run_dma8(const esvit_gemm_desc& d, int bm, int bn, hipStream_t stream) {
-    if constexpr (AKS) {
-        if (bm == 192 && bn == 192) return launch_gemm_dma<AKS, BKS, 192, 192, 64, 2, 2, 4>(d, stream);
-        if (bm == 192) return launch_gemm_dma<AKS, BKS, 192, 256, 64, 2, 2, 4>(d, stream);
-    }
-    if (bn == 192) return launch_gemm_dma<AKS, BKS, 256, 192, 64, 2, 4, 2>(d, stream);
-    return launch_gemm_dma<AKS, BKS, 256, 256, 64, 2, 2, 4>(d, stream);
+int run_dma8(const esvit_gemm_desc& d, hipStream_t stream) {
+    return launch_gemm_dma<AKS, BKS, 256, 256, 64, 2, 4, 2>(d, stream);
+}
+
+template <bool AKS, bool BKS>
+int run_dma4w(const esvit_gemm_desc& d, int bn, hipStream_t stream) {
+    if (bn == 192) return launch_gemm_dma<AKS, BKS, 128, 192, 64, 2, 2, 2>(d, stream);
+    return launch_gemm_dma<AKS, BKS, 128, 96, 64, 2, 4, 1>(d, stream);
 }
 
 template <typename T, bool AKS, bool BKS>
@@ -93,7 +110,8 @@ int run_regstage(const esvit_gemm_desc& d, int bn, hipStream_t stream) {
 template <bool AKS, bool BKS>
 int run_layout(int dtype, const esvit_gemm_desc& d, const GemmChoice& c, hipStream_t stream) {
     if (dtype == ESVIT_BF16) {
-        if (c.kernel == ESVIT_GEMM_DMA8) return run_dma8<AKS, BKS>(d, c.bm, c.bn, stream);
+        if (c.kernel == ESVIT_GEMM_DMA8) return run_dma8<AKS, BKS>(d, stream);
+        if (c.kernel == ESVIT_GEMM_DMA4W) return run_dma4w<AKS, BKS>(d, c.bn, stream);
         if (c.kernel == ESVIT_GEMM_DMA4) return run_dma4<AKS, BKS>(d, c.bn, stream);
         return run_regstage<bf16, AKS, BKS>(d, c.bn, stream);
     }
@@ -124,7 +142,7 @@ int validate(int dtype, esvit_gemm_desc& d) {
     ESVIT_CHECK_ARG(d.epilogue >= 0 && d.epilogue <= ESVIT_EPI_QGELU_BWD, "esvit_gemm: bad epilogue %d", d.epilogue);
     if (d.colsum && d.splitk > 1) ESVIT_CHECK_ARG(d.colsum_partial != nullptr, "esvit_gemm: colsum with split-K needs colsum_partial");
     if (d.colsum) ESVIT_CHECK_ARG(d.batch == 1, "esvit_gemm: colsum is not batched");
-    ESVIT_CHECK_ARG(d.kernel >= ESVIT_GEMM_AUTO && d.kernel <= ESVIT_GEMM_DMA8, "esvit_gemm: bad kernel selector %d", d.kernel);
+    ESVIT_CHECK_ARG(d.kernel >= ESVIT_GEMM_AUTO && d.kernel <= ESVIT_GEMM_DMA4W, "esvit_gemm: bad kernel selector %d", d.kernel);
     if (dtype != ESVIT_BF16) ESVIT_CHECK_ARG(d.kernel == ESVIT_GEMM_AUTO || d.kernel == ESVIT_GEMM_REGSTAGE, "esvit_gemm: fp32 runs on the register-staged loop only");
     return ESVIT_OK;
 }
@@ -136,7 +154,7 @@ extern "C" int esvit_gemm_select(int dtype, const esvit_gemm_desc* dp, int* tile
     esvit_gemm_desc d = *dp;
     if (d.batch < 1) d.batch = 1;
     ESVIT_CHECK_ARG(d.M > 0 && d.N > 0 && d.K > 0, "esvit_gemm_select: bad shape M=%d N=%d K=%d", d.M, d.N, d.K);
-    ESVIT_CHECK_ARG(d.kernel >= ESVIT_GEMM_AUTO && d.kernel <= ESVIT_GEMM_DMA8, "esvit_gemm_select: bad kernel selector %d", d.kernel);
+    ESVIT_CHECK_ARG(d.kernel >= ESVIT_GEMM_AUTO && d.kernel <= ESVIT_GEMM_DMA4W, "esvit_gemm_select: bad kernel selector %d", d.kernel);
     const GemmChoice c = choose(dtype, d);
     if (tile_m) *tile_m = c.bm;
     if (tile_n) *tile_n = c.bn;

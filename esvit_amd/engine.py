@@ -11,83 +11,100 @@ import torch
 import torch.distributed as dist
 
 from . import params as P
-from .update import FusedClipAdamWEMA
+from .update import FusedClipAdamWEMA, bind_torch_optimizer
 
 
-def _world():
-    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+def _world(group=None):
+    return dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
 
 
 class GradBucketReducer:
     """Data-parallel gradient averaging over RCCL/xGMI, overlapped with backward.
 
-    Parameters are packed into flat fp32 buckets in *reverse registration order* (the order autograd produces
-    their gradients).  A post-accumulate hook copies each finished gradient into its bucket slot and, when a
-    bucket is full, launches ``all_reduce`` asynchronously (RCCL runs it on its own stream, concurrently with the
-    rest of backward).  ``finish()`` waits for the collectives and re-points ``p.grad`` at the averaged bucket
-    views.  One process per GPU; world_size 1 short-circuits everything.
+    Parameters are packed into flat fp32 buckets in *reverse registration order* (the order autograd produces their
+    gradients); every slot starts on a 16-byte boundary (the fused update reads gradients with 16-byte vector loads).
+    The weight-gradient GEMMs write straight into their bucket slot (esvit_amd.params.grad_out: the autograd
+    functions pass the slot as the GEMM's output and hand autograd a fresh alias of it, which AccumulateGrad adopts
+    without a copy), so the large tensors are never copied; the small ones (biases, LayerNorm, bias tables) are copied
+    by the post-accumulate hook.  When the last gradient of a bucket has arrived its
+    ``all_reduce`` is launched asynchronously -- RCCL runs it on its own stream, concurrently with the rest of
+    backward -- as an AVG reduction (no separate scale pass; gloo, used by the CPU tests, sums and scales).
+    ``finish()`` waits for the collectives.  One process per GPU; world_size 1 short-circuits everything.
 
     Bucket size: xGMI is point-to-point (7 links x ~153 GB/s), a ring all-reduce of S bytes moves 2*(7/8)*S per
     link, so 64 MiB buckets (~0.8 ms each on one ring) amortise launch latency while leaving 4-5 buckets for
     Swin-T's 295 MB of fp32 gradients to pipeline against backward.
     """
 
+    ALIGN = 4  # floats
+
     def __init__(self, module, bucket_mb=64, process_group=None):
         self.group = process_group
-        self.world = _world()
+        self.world = _world(process_group)
         self.params = [p for p in module.parameters() if p.requires_grad]
         # ESVIT_FORCE_REDUCER=1 exercises the hook/bucket/all-reduce machinery on a single rank (used to validate the
         # RCCL code path on a 1-GPU box)
         self.enabled = self.world > 1 or (os.environ.get("ESVIT_FORCE_REDUCER") == "1" and dist.is_initialized())
         self.buckets, self.slot = [], {}
+        self._hooks = []
         if not self.enabled:
             return
         cap = int(bucket_mb * 1024 * 1024 // 4)
+        al = self.ALIGN
         cur, cur_n = [], 0
         for p in reversed(self.params):
-            if cur and cur_n + p.numel() > cap:
+            n = -(-p.numel() // al) * al
+            if cur and cur_n + n > cap:
                 self.buckets.append(cur)
                 cur, cur_n = [], 0
             cur.append(p)
-            cur_n += p.numel()
+            cur_n += n
         if cur:
             self.buckets.append(cur)
         dev = self.params[0].device
         self.flat, self.pending, self.handles = [], [], []
         for bi, plist in enumerate(self.buckets):
-            n = sum(p.numel() for p in plist)
-            self.flat.append(torch.zeros(n, dtype=torch.float32, device=dev))
             off = 0
             for p in plist:
                 self.slot[id(p)] = (bi, off, p.numel())
-                off += p.numel()
+                off += -(-p.numel() // al) * al
+            self.flat.append(torch.zeros(off, dtype=torch.float32, device=dev))
             self.pending.append(len(plist))
+        assert all(f.data_ptr() % 16 == 0 for f in self.flat)
+        backend = dist.get_backend(self.group) if dist.is_initialized() else ""
+        self._avg = backend == "nccl"  # RCCL reduces with AVG in one pass; gloo has SUM only
         self._inv_world = torch.full((), 1.0 / self.world, dtype=torch.float32, device=dev)
+        self.views = {}
         for p in self.params:
-            p.register_post_accumulate_grad_hook(self._hook)
+            bi, off, n = self.slot[id(p)]
+            self.views[id(p)] = self.flat[bi][off:off + n].view_as(p)
+            self._hooks.append(p.register_post_accumulate_grad_hook(self._arrived))
         self._armed = False
 
     def begin(self):
-        """call before backward"""
+        """call before backward (with every p.grad None: autograd then adopts the bucket views as the gradients)"""
         if not self.enabled:
             return
         self.handles = []
         self.pending = [len(b) for b in self.buckets]
         self._armed = True
+        P.set_grad_sink(self.views)
 
-    def _hook(self, p):
+    def _arrived(self, p):
         if not self._armed or p.grad is None:
             return
-        bi, off, n = self.slot[id(p)]
-        view = self.flat[bi][off:off + n].view_as(p)
-        view.copy_(p.grad)
-        p.grad = view
+        view = self.views[id(p)]
+        if p.grad.data_ptr() != view.data_ptr():  # not produced in place: pack it (the small tensors)
+            view.copy_(p.grad)
+            p.grad = view
+        bi = self.slot[id(p)][0]
         self.pending[bi] -= 1
         if self.pending[bi] == 0:
             self._launch(bi)
 
     def _launch(self, bi):
-        h = dist.all_reduce(self.flat[bi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
+        h = dist.all_reduce(self.flat[bi], op=op, group=self.group, async_op=True)
         self.handles.append((bi, h))
 
     def finish(self):
@@ -95,12 +112,13 @@ class GradBucketReducer:
         if not self.enabled:
             return
         self._armed = False
+        P.set_grad_sink(None)
         for bi, left in enumerate(self.pending):
-            if left > 0:  # e.g. last_layer frozen in epoch 0: its slots keep zeros
+            if left > 0:  # e.g. the weight-normed last layer's frozen g: its slot keeps zeros
                 self._launch(bi)
         for bi, h in self.handles:
             h.wait()
-            if self.world > 1:
+            if not self._avg and self.world > 1:
                 if self.flat[bi].is_cuda:
                     from . import ops
                     ops.scale_inplace(self.flat[bi], self._inv_world)  # SUM -> mean
@@ -108,22 +126,32 @@ class GradBucketReducer:
                     self.flat[bi].mul_(self._inv_world)
         self.handles = []
 
+    def close(self):
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+
 
 class EsvitTrainer:
     """teacher fwd -> student fwd -> loss -> backward (+ overlapped grad all-reduce) -> fused clip/AdamW/EMA."""
 
-    def __init__(self, student, teacher, loss_fn, clip_grad=3.0, freeze_last_layer=1, bucket_mb=64):
+    def __init__(self, student, teacher, loss_fn, clip_grad=3.0, freeze_last_layer=1, bucket_mb=64, updater=None):
         self.student, self.teacher, self.loss_fn = student, teacher, loss_fn
         self.clip_grad, self.freeze_last_layer = clip_grad, freeze_last_layer
-        self.updater = FusedClipAdamWEMA(student, teacher)
+        self.updater = updater if updater is not None else FusedClipAdamWEMA(student, teacher)
         self.reducer = GradBucketReducer(student, bucket_mb)
-        loss_fn.assume_unit_grad = True  # loss.backward() below always uses grad_output == 1
 
     def step(self, images, lr, wd, momentum, epoch):
         with torch.no_grad():
             teacher_out = self.teacher(images[:2])
         student_out = self.student(images)
-        loss = self.loss_fn(student_out, teacher_out, epoch, None)
+        # loss.backward() below always uses grad_output == 1: the loss skips its rescale pass for this call only
+        prev = getattr(self.loss_fn, "assume_unit_grad", False)
+        self.loss_fn.assume_unit_grad = True
+        try:
+            loss = self.loss_fn(student_out, teacher_out, epoch, None)
+        finally:
+            self.loss_fn.assume_unit_grad = prev
         self.reducer.begin()
         loss.backward()
         self.reducer.finish()
@@ -137,28 +165,50 @@ _TRAINERS = {}
 
 def train_one_epoch(student, teacher, teacher_without_ddp, dino_loss, data_loader, optimizer, lr_schedule, wd_schedule,
                     momentum_schedule, epoch, mixup_fn, fp16_scaler, args):
-    """Drop-in for main_esvit.train_one_epoch (same signature).  `optimizer` may be a FusedClipAdamWEMA (its state is
-    then used and checkpointed by the caller) or a torch optimizer (ignored in favour of a trainer-owned fused one);
-    `student` may be DDP-wrapped (its .module is trained, gradients are reduced by GradBucketReducer instead)."""
+    """Drop-in for main_esvit.train_one_epoch (same signature).
+
+    `optimizer`: a FusedClipAdamWEMA is used as is.  A ``torch.optim.AdamW`` (what the unmodified train_esvit builds,
+    main_esvit.py:411) is BOUND to the fused updater: its ``state`` entries (step, exp_avg, exp_avg_sq) are the very
+    tensors the fused kernel updates and its param_groups receive the schedule values, so the caller's
+    ``optimizer.state_dict()`` / ``load_state_dict()`` (main_esvit.py:444-452, 476-488) checkpoint and restore the real
+    moments.  Any other optimizer is refused.  `student` may be DDP-wrapped (its .module is trained, gradients are
+    reduced by GradBucketReducer instead).  Returns the rank-averaged epoch means the reference logs (main_esvit.py:593-600)."""
     if mixup_fn is not None:
         raise NotImplementedError("mixup (main_esvit.py:518-534) is out of scope (SURVEY.md 8f-3)")
+    if fp16_scaler is not None:
+        raise NotImplementedError("fp16 + GradScaler (main_esvit.py:576-584) is out of scope (SURVEY.md 8f-3): run with --use_fp16 false; "
+                                  "the modules keep their own bf16 precision policy")
     net = student.module if hasattr(student, "module") else student
+    if not isinstance(optimizer, (FusedClipAdamWEMA, torch.optim.AdamW)):
+        raise TypeError("esvit_amd.engine.train_one_epoch drives AdamW only (got %s): pass torch.optim.AdamW or "
+                        "esvit_amd.update.FusedClipAdamWEMA (LARS / SGD: SURVEY.md 8f-3)" % type(optimizer).__name__)
     key = (id(net), id(teacher_without_ddp), id(dino_loss))
     tr = _TRAINERS.get(key)
-    if tr is None:
-        tr = EsvitTrainer(net, teacher_without_ddp, dino_loss, clip_grad=args.clip_grad, freeze_last_layer=args.freeze_last_layer)
-        if isinstance(optimizer, FusedClipAdamWEMA):
-            tr.updater = optimizer
+    stale = (tr is None or tr.student is not net or tr.loss_fn is not dino_loss or
+             (tr.updater is not optimizer and getattr(tr.updater, "bound", None) is not optimizer))
+    if stale:
+        if tr is not None:
+            tr.reducer.close()
+        updater = optimizer if isinstance(optimizer, FusedClipAdamWEMA) else bind_torch_optimizer(optimizer, net, teacher_without_ddp)
+        tr = EsvitTrainer(net, teacher_without_ddp, dino_loss, clip_grad=args.clip_grad, freeze_last_layer=args.freeze_last_layer,
+                          updater=updater)
         _TRAINERS[key] = tr
-    n_it, total, last = len(data_loader), 0.0, None
+    n_it = len(data_loader)
+    dev = next(net.parameters()).device
+    loss_sum = torch.zeros((), dtype=torch.float32, device=dev)
+    last = None
     for it, (images, _) in enumerate(data_loader):
         git = n_it * epoch + it
         images = [im.cuda(non_blocking=True) for im in images]
         last = tr.step(images, lr_schedule[git], wd_schedule[git], momentum_schedule[git], epoch)
+        loss_sum += last
         if it % 10 == 0 or it == n_it - 1:  # the reference syncs every iteration (main_esvit.py:546,593); 1-in-10 keeps the NaN guard
             v = last.item()
             if not math.isfinite(v):
                 print("Loss is {}, stopping training".format(v))
                 sys.exit(1)
-            total = v
-    return {"loss": total, "lr": float(lr_schedule[n_it * epoch + n_it - 1]), "wd": float(wd_schedule[n_it * epoch + n_it - 1])}
+    mean = loss_sum / max(n_it, 1)
+    if _world() > 1:  # metric_logger.synchronize_between_processes (main_esvit.py:597)
+        dist.all_reduce(mean)
+        mean = mean / _world()
+    return {"loss": mean.item(), "lr": float(lr_schedule[n_it * epoch + n_it - 1]), "wd": float(wd_schedule[n_it * epoch + n_it - 1])}

@@ -59,6 +59,19 @@ def geometry(H, W, ws, shift, device):
     return g
 
 
+def _wgrad(dy, x, param, shape2d=None, want_bias=False):
+    """weight gradient of `param` = dy^T x; written straight into the data-parallel reducer's bucket slot when one is
+    armed (params.grad_out), and handed to autograd as a fresh alias so that AccumulateGrad adopts it without a copy"""
+    o = ops_module()
+    sink = P.grad_out(param, shape2d)
+    res = o.linear_wgrad(dy, x, out=sink, want_bias=want_bias)
+    if sink is None:
+        return res
+    if want_bias:
+        return res[0].detach(), res[1]
+    return res.detach()
+
+
 def _weight(p, shape2d=None):
     """activation-dtype copy of an fp32 parameter; frozen parameters (the EMA teacher) are recast on every
     use because in-place `.data` updates (main_esvit.py:590) are invisible to version counters."""
@@ -104,6 +117,7 @@ class SwinBlockFn(torch.autograd.Function):
         x = x.contiguous()
         y, saved = _block_forward(x, geom, nH, index, dp, (g1, b1, table, bqkv, bproj, g2, b2, bfc1, bfc2), wts, True)
         ctx.geom, ctx.nH, ctx.dp = geom, nH, dp
+        ctx.wparams = (Wqkv_p, Wproj_p, W1_p, W2_p)
         ctx.save_for_backward(x, index, g1, table, g2, bqkv, *wts, *saved)
         return y
 
@@ -118,20 +132,21 @@ class SwinBlockFn(torch.autograd.Function):
         scale = (C // nH) ** -0.5
         dp1, dp2 = (None, None) if dp is None else dp
         gy = gy.contiguous().view(M, C)
+        Wqkv_p, Wproj_p, W1_p, W2_p = ctx.wparams
         # ---- MLP branch ----
         dyb = o.gather_cast(gy, M, rowscale=dp2, rows_per_sample=L)
-        dW2, dbfc2 = o.linear_wgrad(dyb, a1g, want_bias=True)
+        dW2, dbfc2 = _wgrad(dyb, a1g, W2_p, want_bias=True)
         da1 = o.linear_dgrad(dyb, W2, gelu_preact=a1)
-        dW1, dbfc1 = o.linear_wgrad(da1, h, want_bias=True)
+        dW1, dbfc1 = _wgrad(da1, h, W1_p, want_bias=True)
         dh = o.linear_dgrad(da1, W1)
         # ---- attention branch ---- (the LayerNorm backward also emits the DropPath-scaled activation-dtype copy of gx1)
         gx1, dyw, dg2, db2 = o.layernorm_bwd_cast(dh, x1, mean2, rstd2, g2, g_in=gy, rowscale=dp1, rows_per_sample=L)
-        dWproj, dbproj = o.linear_wgrad(dyw, ao, want_bias=True)
+        dWproj, dbproj = _wgrad(dyw, ao, Wproj_p, want_bias=True)
         dao = o.linear_dgrad(dyw, Wproj)
         dqkv, dbias_ws, dpad_ws = o.window_attn_bwd(qkv, bqkv, geom.win2tok, L, dao, ao, lse, table, geom.ws, geom.region_ids,
                                                     geom.nW, geom.N, nH, scale)
         dtable = o.relpos_bias_bwd(dbias_ws, index, geom.N, table.shape[0])
-        dWqkv, dbqkv = o.linear_wgrad(dqkv, xw, want_bias=True)
+        dWqkv, dbqkv = _wgrad(dqkv, xw, Wqkv_p, want_bias=True)
         o.colsum(dpad_ws, out=dbqkv[C:], accumulate=True)  # k/v bias gradient from the zero-pad slots
         dxw = o.linear_dgrad(dqkv, Wqkv)
         gx, dg1, db1 = o.layernorm_bwd(dxw, x.view(M, C), mean1, rstd1, g1, g_in=gx1)
@@ -188,6 +203,7 @@ class SwinBlockMultiFn(torch.autograd.Function):
         X = X.contiguous()
         y, saved, lses = _block_forward_multi(X, segs, nH, dp_rows, (g1, b1, table, bqkv, bproj, g2, b2, bfc1, bfc2), wts, True)
         ctx.segs, ctx.nH, ctx.dp_rows, ctx.lses = segs, nH, dp_rows, lses
+        ctx.wparams = (Wqkv_p, Wproj_p, W1_p, W2_p)
         ctx.emit_shadow, ctx.prev_scale = Xsh is not None, prev_scale
         ctx.set_materialize_grads(False)
         ctx.save_for_backward(X, index, g1, table, g2, bqkv, *wts, *saved)
@@ -203,15 +219,16 @@ class SwinBlockMultiFn(torch.autograd.Function):
         scale = (C // nH) ** -0.5
         dp1, dp2 = (None, None) if dp_rows is None else dp_rows
         gy = gy.contiguous()
+        Wqkv_p, Wproj_p, W1_p, W2_p = ctx.wparams
         # ---- MLP branch ----
         dyb = gysh.contiguous() if gysh is not None else o.gather_cast(gy, M, rowscale=dp2, rows_per_sample=1)
-        dW2, dbfc2 = o.linear_wgrad(dyb, a1g, want_bias=True)
+        dW2, dbfc2 = _wgrad(dyb, a1g, W2_p, want_bias=True)
         da1 = o.linear_dgrad(dyb, W2, gelu_preact=a1)
-        dW1, dbfc1 = o.linear_wgrad(da1, h, want_bias=True)
+        dW1, dbfc1 = _wgrad(da1, h, W1_p, want_bias=True)
         dh = o.linear_dgrad(da1, W1)
         gx1, dyw, dg2, db2 = o.layernorm_bwd_cast(dh, x1, mean2, rstd2, g2, g_in=gy, rowscale=dp1, rows_per_sample=1)
         # ---- attention branch ----
-        dWproj, dbproj = o.linear_wgrad(dyw, ao, want_bias=True)
+        dWproj, dbproj = _wgrad(dyw, ao, Wproj_p, want_bias=True)
         dao = o.linear_dgrad(dyw, Wproj)
         dqkv = torch.empty_like(qkv)
         dtable, pads = None, []
@@ -222,7 +239,7 @@ class SwinBlockMultiFn(torch.autograd.Function):
             dt_g = o.relpos_bias_bwd(dbias_ws, index, geom.N, table.shape[0])
             dtable = dt_g if dtable is None else dtable.add_(dt_g)
             pads.append(dpad_ws)
-        dWqkv, dbqkv = o.linear_wgrad(dqkv, xw, want_bias=True)
+        dWqkv, dbqkv = _wgrad(dqkv, xw, Wqkv_p, want_bias=True)
         for dpad_ws in pads:
             o.colsum(dpad_ws, out=dbqkv[C:], accumulate=True)  # k/v bias gradient from the zero-pad slots
         dxw = o.linear_dgrad(dqkv, Wqkv)
@@ -350,7 +367,7 @@ class PatchMergeMultiFn(torch.autograd.Function):
         Wc = _weight(Wr)
         out = o.linear_fwd(y, Wc, None, out_f32=True)
         ctx.save_for_backward(X, y, mean, rstd, g, Wc)
-        ctx.groups = groups
+        ctx.groups, ctx.wparam = groups, Wr
         return out
 
     @staticmethod
@@ -359,7 +376,7 @@ class PatchMergeMultiFn(torch.autograd.Function):
         X, y, mean, rstd, g, Wc = ctx.saved_tensors
         M, C = X.shape
         gb = o.gather_cast(go.contiguous(), M // 4)
-        dWr = o.linear_wgrad(gb, y)
+        dWr = _wgrad(gb, y, ctx.wparam)
         dy = o.linear_dgrad(gb, Wc)
         dX = torch.empty_like(X)
         dg = db = None
@@ -386,7 +403,7 @@ class PatchMergeFn(torch.autograd.Function):
         Wc = _weight(Wr)
         out = o.linear_fwd(y, Wc, None, out_f32=True)
         ctx.save_for_backward(x, y, mean, rstd, g, Wc)
-        ctx.hw = (H, W)
+        ctx.hw, ctx.wparam = (H, W), Wr
         return out.view(nB, L // 4, 2 * C)
 
     @staticmethod
@@ -396,7 +413,7 @@ class PatchMergeFn(torch.autograd.Function):
         H, W = ctx.hw
         rows = y.shape[0]
         gb = o.gather_cast(go.contiguous().view(rows, -1), rows)
-        dWr = o.linear_wgrad(gb, y)
+        dWr = _wgrad(gb, y, ctx.wparam)
         dy = o.linear_dgrad(gb, Wc)
         dx, dg, db = o.merge_ln_bwd(dy, x, mean, rstd, g, H, W)
         return dx, None, None, dg, db, dWr
@@ -469,6 +486,7 @@ class DinoHeadFn(torch.autograd.Function):
         logits, saved = _head_forward(x, (W1p, b1, W2p, b2, W3p, b3, v, g), True)
         ctx.save_for_backward(v, g, *saved)
         ctx.need_dg = g.requires_grad
+        ctx.wparams = (W1p, W2p, W3p, v)
         return logits
 
     @staticmethod
@@ -476,15 +494,19 @@ class DinoHeadFn(torch.autograd.Function):
         o = ops_module()
         v, g, W1, W2, W3, xa, h1, h1g, h2, h2g, z, inv, w, winv = ctx.saved_tensors
         dlogits = dlogits.contiguous()
+        W1p, W2p, W3p, vp = ctx.wparams
         dz = o.linear_dgrad(dlogits, w)
         dw = o.linear_wgrad(dlogits, z)
-        dv, dg = o.weightnorm_bwd(dw, v, g, winv, ctx.need_dg)
+        sink = P.grad_out(vp)
+        dv, dg = o.weightnorm_bwd(dw, v, g, winv, ctx.need_dg, dv_out=sink)
+        if sink is not None:
+            dv = dv.detach()  # a fresh alias of the bucket slot (see _wgrad)
         dh3 = o.l2norm_bwd(dz, z, inv)
-        dW3, db3 = o.linear_wgrad(dh3, h2g, want_bias=True)
+        dW3, db3 = _wgrad(dh3, h2g, W3p, want_bias=True)
         dh2 = o.linear_dgrad(dh3, W3, gelu_preact=h2)
-        dW2, db2 = o.linear_wgrad(dh2, h1g, want_bias=True)
+        dW2, db2 = _wgrad(dh2, h1g, W2p, want_bias=True)
         dh1 = o.linear_dgrad(dh2, W2, gelu_preact=h1)
-        dW1, db1 = o.linear_wgrad(dh1, xa, want_bias=True)
+        dW1, db1 = _wgrad(dh1, xa, W1p, want_bias=True)
         dx = o.linear_dgrad(dh1, W1, out_f32=True)
         return dx, dW1, db1, dW2, db2, dW3, db3, dv, dg
 

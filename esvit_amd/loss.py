@@ -48,7 +48,34 @@ def _world():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
 
-class DINOLoss(nn.Module):
+class _DeferredCenter:
+    """The centre update of step n is only needed by the loss of step n+1 (main_esvit.py:748, 752-770): the all-reduce of
+    the batch sums is launched asynchronously right after they are computed -- RCCL runs it on its own stream under the
+    student's backward -- and the EMA is applied when the centres are next read (`synchronize()`: next forward,
+    state_dict(), or explicitly).  With one process there is nothing to wait for and the EMA is applied at once."""
+    _pending = None
+
+    def _reduce_and_apply(self, buf, apply):
+        if _world() > 1:
+            self.synchronize()
+            h = dist.all_reduce(buf, async_op=True)
+            self._pending = (h, buf, apply)
+        else:
+            apply(buf, 1)
+
+    def synchronize(self):
+        if self._pending is not None:
+            h, buf, apply = self._pending
+            self._pending = None
+            h.wait()
+            apply(buf, _world())
+
+    def state_dict(self, *args, **kwargs):
+        self.synchronize()
+        return super().state_dict(*args, **kwargs)
+
+
+class DINOLoss(_DeferredCenter, nn.Module):
     def __init__(self, out_dim, ncrops, warmup_teacher_temp, teacher_temp, warmup_teacher_temp_epochs, nepochs,
                  student_temp=0.1, center_momentum=0.9):
         super().__init__()
@@ -77,6 +104,7 @@ class DINOLoss(nn.Module):
         if targets_mixup:
             raise NotImplementedError("DINOLoss mixup targets (main_esvit.py:639-641) are out of scope (SURVEY.md 8f-3)")
         o = _ops()
+        self.synchronize()
         s, t = student_output.contiguous(), teacher_output.detach().contiguous()
         B = t.shape[0] // 2
         inv_tt = 1.0 / float(self.teacher_temp_schedule[epoch])
@@ -90,13 +118,12 @@ class DINOLoss(nn.Module):
     @torch.no_grad()
     def update_center(self, teacher_output):
         o = _ops()
-        cs = o.colsum(teacher_output)
-        if _world() > 1:
-            dist.all_reduce(cs)
-        o.center_ema(self.center, cs, self.center_momentum, teacher_output.shape[0] * _world())
+        rows = teacher_output.shape[0]
+        self._reduce_and_apply(o.colsum(teacher_output),
+                               lambda cs, w: o.center_ema(self.center, cs, self.center_momentum, rows * w))
 
 
-class DDINOLoss(nn.Module):
+class DDINOLoss(_DeferredCenter, nn.Module):
     def __init__(self, out_dim, ncrops, warmup_teacher_temp, teacher_temp, warmup_teacher_temp_epochs, nepochs,
                  student_temp=0.1, center_momentum=0.9):
         super().__init__()
@@ -141,6 +168,7 @@ class DDINOLoss(nn.Module):
 
     def forward(self, student_output, teacher_output, epoch, targets_mixup=None):
         o = _ops()
+        self.synchronize()
         s_cls, s_reg, s_fea, s_np = student_output
         t_cls, t_reg, t_fea, t_np = teacher_output
         s_cls_c, s_reg_c = s_cls.contiguous(), s_reg.contiguous()
@@ -182,8 +210,9 @@ class DDINOLoss(nn.Module):
         buf = torch.empty((2, K), dtype=torch.float32, device=self.center.device)
         o.colsum(teacher_output, out=buf[0])
         o.colsum(teacher_grid_output, out=buf[1])
-        w = _world()
-        if w > 1:
-            dist.all_reduce(buf)
-        o.center_ema(self.center, buf[0], self.center_momentum, teacher_output.shape[0] * w)
-        o.center_ema(self.center_grid, buf[1], self.center_momentum, teacher_grid_output.shape[0] * w)
+        r_cls, r_reg = teacher_output.shape[0], teacher_grid_output.shape[0]
+
+        def apply(b, w):
+            o.center_ema(self.center, b[0], self.center_momentum, r_cls * w)
+            o.center_ema(self.center_grid, b[1], self.center_momentum, r_reg * w)
+        self._reduce_and_apply(buf, apply)

@@ -10,7 +10,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import BF16, EPI_GELU, EPI_GELU_BWD, EPI_NONE, EPI_QGELU, EPI_QGELU_BWD, F32, GEMM_AUTO, GEMM_DMA4, GEMM_DMA8, GEMM_REGSTAGE, GemmDesc, check, lib
+from ._lib import BF16, EPI_GELU, EPI_GELU_BWD, EPI_NONE, EPI_QGELU, EPI_QGELU_BWD, F32, GEMM_AUTO, GEMM_DMA4, GEMM_DMA4W, GEMM_DMA8, GEMM_REGSTAGE, GemmDesc, check, lib
 
 _ACT_DTYPE = torch.bfloat16
 
@@ -553,10 +553,11 @@ def weightnorm_fwd(v, g, dtype=None):
     return w, inv
 
 
-def weightnorm_bwd(dw, v, g, inv, need_dg):
+def weightnorm_bwd(dw, v, g, inv, need_dg, dv_out=None):
     dw, v, g = _f32c(dw), _f32c(v), _f32c(g)
     K, D = v.shape
-    dv = torch.empty_like(v)
+    dv = torch.empty_like(v) if dv_out is None else _f32c(dv_out)
+    assert dv.shape == v.shape
     dg = torch.empty((K, 1), dtype=torch.float32, device=v.device) if need_dg else None
     check(lib.esvit_weightnorm_bwd(_p(dw), _p(v), _p(g), _p(inv), K, D, _p(dv), _p(dg), _stream()), "weightnorm_bwd")
     return dv, dg

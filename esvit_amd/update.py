@@ -94,6 +94,7 @@ class FusedClipAdamWEMA:
         for tp in self.teacher_params:
             if tp is not None and not tp.requires_grad:
                 P.manage(tp)  # the teacher is written by this updater only: its bf16 copies are refreshed in the same kernel
+        self.bound = None  # a torch.optim.AdamW whose state mirrors this updater (bind_torch_optimizer)
         self._bc_cache = {}
         self._ring_ev = [None] * len(self._ring)
         self._ring_pos = 0
@@ -107,6 +108,8 @@ class FusedClipAdamWEMA:
         """One update.  lr / weight_decay / ema_momentum are the per-iteration schedule values
         (main_esvit.py:506-510, 588); skip_last_layer mirrors cancel_gradients_last_layer (utils.py:118-123)."""
         b1, b2 = self.betas
+        if self.bound is not None:
+            self._adopt_bound_state()
         slot = self._ring_pos
         self._ring_pos = (slot + 1) % len(self._ring)
         if self._ring_ev[slot] is not None:
@@ -152,6 +155,41 @@ class FusedClipAdamWEMA:
         for g in self.param_groups:
             g["lr"] = float(lr)
         self.param_groups[0]["weight_decay"] = float(weight_decay)
+        if self.bound is not None:
+            self._publish_bound_state(lr, weight_decay)
+
+    # ---- a torch.optim.AdamW bound to this updater (integration level L2 with the unmodified train_esvit) -------------
+    def _refresh_static_rows(self, i):
+        for tab in self._ring_np:
+            tab[i, 2] = self.exp_avg[i].data_ptr()
+            tab[i, 3] = self.exp_avg_sq[i].data_ptr()
+
+    def _adopt_bound_state(self):
+        """optimizer.load_state_dict() (resume, utils.py:126-158) replaces the state tensors: adopt them"""
+        st = self.bound.state
+        for i, p in enumerate(self.params):
+            e = st.get(p)
+            if not e or not self.trainable[i]:
+                continue
+            if e["exp_avg"] is not self.exp_avg[i] or e["exp_avg_sq"] is not self.exp_avg_sq[i]:
+                assert e["exp_avg"].dtype == torch.float32 and e["exp_avg"].is_contiguous() and e["exp_avg"].device == p.device
+                self.exp_avg[i], self.exp_avg_sq[i] = e["exp_avg"], e["exp_avg_sq"]
+                self._refresh_static_rows(i)
+            self.steps[i] = int(float(e["step"]))
+
+    def _publish_bound_state(self, lr, weight_decay):
+        st = self.bound.state
+        for i, p in enumerate(self.params):
+            if self.steps[i] <= 0:
+                continue
+            e = st.get(p)
+            if not e:
+                st[p] = {"step": torch.tensor(float(self.steps[i])), "exp_avg": self.exp_avg[i], "exp_avg_sq": self.exp_avg_sq[i]}
+            else:
+                e["step"].fill_(float(self.steps[i]))
+        for g in self.bound.param_groups:
+            g["lr"] = float(lr)
+        self.bound.param_groups[0]["weight_decay"] = float(weight_decay)
 
     def zero_grad(self, set_to_none=True):
         for p in self.params:
@@ -191,3 +229,20 @@ class FusedClipAdamWEMA:
             self.exp_avg_sq[i].copy_(st["exp_avg_sq"])
         for g, sg in zip(self.param_groups, sd["param_groups"]):
             g["lr"], g["weight_decay"] = sg["lr"], sg["weight_decay"]
+
+
+def bind_torch_optimizer(optimizer, student, teacher):
+    """FusedClipAdamWEMA whose moments ARE the `state` of the caller's torch.optim.AdamW (built over
+    get_params_groups(student), main_esvit.py:408-411): the fused kernel updates exp_avg / exp_avg_sq in place, `step` and
+    the param_groups' lr / weight_decay are mirrored after every update, and tensors swapped in by
+    optimizer.load_state_dict() are adopted before the next one.  optimizer.step() itself is never called."""
+    assert isinstance(optimizer, torch.optim.AdamW), type(optimizer)
+    pg = optimizer.param_groups
+    assert len(pg) == 2 and pg[1]["weight_decay"] == 0.0, "expected the two groups of utils.get_params_groups (utils.py:672-683)"
+    upd = FusedClipAdamWEMA(student, teacher, betas=tuple(pg[0]["betas"]), eps=pg[0]["eps"])
+    ours = [[id(p) for p in g["params"]] for g in upd.param_groups]
+    theirs = [[id(p) for p in g["params"]] for g in pg]
+    assert ours == theirs, "the optimizer's parameter groups do not match get_params_groups(student)"
+    upd.bound = optimizer
+    upd._adopt_bound_state()
+    return upd

@@ -90,7 +90,8 @@ typedef struct {
 #define ESVIT_GEMM_AUTO 0
 #define ESVIT_GEMM_REGSTAGE 1 /* register-staged 128-row tiles: the exact-fp32 mode, and a bf16 fallback */
 #define ESVIT_GEMM_DMA4 2     /* bf16, LDS-DMA, 128 x {64,96,128} tiles, 4 waves, two workgroups per CU */
-#define ESVIT_GEMM_DMA8 3     /* bf16, LDS-DMA, 256 x {192,256} (192-row too for weight gradients) tiles, 8 waves */
+#define ESVIT_GEMM_DMA8 3     /* bf16, LDS-DMA, 256 x 256 tiles, 8 waves, one workgroup per CU: very long reductions */
+#define ESVIT_GEMM_DMA4W 4    /* bf16, LDS-DMA, 4 waves, 128 x 192 / 128 x 96 tiles with whole-width wave rows (N % 96 == 0) */
 
 /* C = alpha * op(A) op(B) (+ epilogue).  Replaces every nn.Linear / conv-as-GEMM on the
  * path: swin_transformer.py:31-37,127,150,418,531; vision_transformer.py:414-418;

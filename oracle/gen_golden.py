@@ -103,6 +103,29 @@ def gen_nano(ns):
     l2 = vl(s2, t_out[0], epoch, None)
     g["dino_loss_2crops"] = l2.item()
     g["dino_center1"] = vl.center.clone()
+    # epoch < freeze_last_layer: clip -> cancel_gradients_last_layer -> AdamW -> EMA on copies (main_esvit.py:569-574, utils.py:118-123)
+    s_c, t_c = build_nano(ns), build_nano(ns, teacher=True)  # (weight_norm modules do not deepcopy)
+    s_c.load_state_dict(student.state_dict())
+    t_c.load_state_dict(teacher.state_dict())
+    for p in t_c.parameters():
+        p.requires_grad = False
+    for (n, pc), p0 in zip(s_c.named_parameters(), student.parameters()):
+        pc.requires_grad = p0.requires_grad
+        pc.grad = None if p0.grad is None else p0.grad.clone()
+    opt_c = torch.optim.AdamW(ns.utils.get_params_groups(s_c))
+    for i, pg in enumerate(opt_c.param_groups):
+        pg["lr"] = 5e-4
+        if i == 0:
+            pg["weight_decay"] = 0.04
+    ns.utils.clip_gradients(s_c, 3.0)
+    ns.utils.cancel_gradients_last_layer(0, s_c, 1)
+    g["cancelled"] = [n for n, p in s_c.named_parameters() if p.grad is None and n not in g["no_grad"]]
+    opt_c.step()
+    with torch.no_grad():
+        for pq, pk in zip(s_c.parameters(), t_c.parameters()):
+            pk.data.mul_(0.996).add_((1 - 0.996) * pq.detach().data)
+    g["student_after_cancel"] = {n: GU.probe(p) for n, p in s_c.named_parameters()}
+    g["teacher_after_cancel"] = {n: GU.probe(p) for n, p in t_c.named_parameters()}
     # one update step: clip 3.0 -> AdamW -> EMA (utils.py:106-115, main_esvit.py:574, 587-590)
     opt = torch.optim.AdamW(ns.utils.get_params_groups(student))
     lr, wd, m = 5e-4, 0.04, 0.996
@@ -123,6 +146,9 @@ def gen_nano(ns):
         GU.fill_state_dict(student.state_dict(), seed=0)
         student.head.last_layer.weight_g.data.fill_(1)
         g["last_attn"] = GU.probe(student.forward_selfattention(crops[0]))
+        # eval_linear.py's feature hook (swin_transformer.py:799-837): n = 3 starts inside stage 2, n = 1 is the normed last block
+        g["last_blocks_n3"] = student.forward_return_n_last_blocks(crops[0], n=3, depth=list(GU.NANO["depths"])).clone()
+        g["last_blocks_n1_local"] = student.forward_return_n_last_blocks(crops[2], n=1, depth=list(GU.NANO["depths"])).clone()
     torch.save(g, os.path.join(OUT, "nano_step.pt"))
     print("nano_step.pt: loss", g["ddino_loss"], g["ddino_loss_2"], g["dino_loss_2crops"], "no_grad", g["no_grad"])
 

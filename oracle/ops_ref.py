@@ -475,10 +475,13 @@ def weightnorm_fwd(v, g, dtype=None):
     return _r(v * (g.view(-1) * inv)[:, None], dtype), inv
 
 
-def weightnorm_bwd(dw, v, g, inv, need_dg):
+def weightnorm_bwd(dw, v, g, inv, need_dg, dv_out=None):
     vh = v * inv[:, None]
     dot = (dw * vh).sum(1, keepdim=True)
     dv = (dw - vh * dot) * (g.view(-1, 1) * inv[:, None])
+    if dv_out is not None:
+        dv_out.copy_(dv)
+        dv = dv_out
     return dv, (dot if need_dg else None)
 
 

@@ -94,6 +94,19 @@ def load():
     return ns
 
 
+def load_train_one_epoch():
+    """the reference's UNMODIFIED train_one_epoch (main_esvit.py:499-600), compiled from its source text (importing
+    main_esvit as a module drags in torchvision / timm.data / yacs), with the globals it uses bound to the reference's utils"""
+    import math
+    ns = load()
+    src = open(os.path.join(REF_ROOT, "main_esvit.py")).read()
+    env = {"torch": torch, "nn": nn, "F": F, "np": np, "dist": dist, "math": math, "sys": sys, "os": os, "utils": ns.utils}
+    for node in ast.parse(src).body:
+        if isinstance(node, ast.FunctionDef) and node.name == "train_one_epoch":
+            exec(compile(ast.Module(body=[node], type_ignores=[]), os.path.join(REF_ROOT, "main_esvit.py"), "exec"), env)
+    return env["train_one_epoch"]
+
+
 def load_knn_classifier():
     """the reference's knn_classifier (eval_knn.py:193-232), executed from its source text (importing eval_knn drags in
     torchvision); its hard-wired .cuda() calls are neutralised by the caller (gen_golden.gen_knn)"""

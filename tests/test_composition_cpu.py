@@ -41,6 +41,17 @@ def build_nano(teacher=False, window=None):
     return m
 
 
+def build_nano_view(teacher=False):
+    """BASELINE config 1 in miniature: use_dense_prediction=False, view-level head only (main_esvit.py:235-254 without
+    --use_dense_prediction)"""
+    from esvit_amd import models
+    cfg = RL.swin_config(embed_dim=GU.NANO["embed_dim"], depths=GU.NANO["depths"], heads=GU.NANO["heads"], window=GU.NANO["window"])
+    m = models.build_model(cfg, is_teacher=teacher, use_dense_prediction=False)
+    hk = dict(hidden_dim=GU.NANO_HEAD["hidden_dim"], bottleneck_dim=GU.NANO_HEAD["bottleneck_dim"])
+    m.head = models.DINOHead(m.num_features, GU.NANO_HEAD["out_dim"], norm_last_layer=True, **hk)
+    return m
+
+
 def nano_pair(window=None):
     student, teacher = build_nano(window=window), build_nano(teacher=True, window=window)
     GU.fill_state_dict(student.state_dict(), 0)
@@ -246,6 +257,48 @@ def test_composition_fp32_matches_reference_golden(cpu_ops):
     assert (vl.center - nano["dino_center1"]).abs().max().item() < 1e-6
     with torch.no_grad():
         probe_close("last_attn", student.forward_selfattention(crops[0]), nano["last_attn"])
+
+
+def test_config1_view_only_composition_matches_reference_golden(cpu_ops):
+    """BASELINE config 1 host logic: use_dense_prediction=False forward (swin_transformer.py:753-763) + DINOLoss + backward"""
+    import esvit_amd.loss as L
+    nano = torch.load(os.path.join(GOLD, "nano_step.pt"), weights_only=False)
+    student, teacher = build_nano_view(), build_nano_view(teacher=True)
+    GU.fill_state_dict(student.state_dict(), 0)
+    GU.fill_state_dict(teacher.state_dict(), 7)
+    student.head.last_layer.weight_g.data.fill_(1)
+    crops = GU.make_crops(2)[:2]
+    with torch.no_grad():
+        t_out = teacher(crops)
+    s_out = student(crops)
+    assert torch.is_tensor(s_out) and s_out.shape == (4, GU.NANO_HEAD["out_dim"])
+    probe_close("t_cls", t_out, nano["t_cls"])
+    vl = L.DINOLoss(GU.NANO_HEAD["out_dim"], 2, 0.04, 0.07, 5, 10)
+    vl.center.copy_(nano["center0"])
+    loss = vl(s_out, t_out, 2, None)
+    loss.backward()
+    assert abs(loss.item() - nano["dino_loss_2crops"]) < 2e-5
+    assert (vl.center - nano["dino_center1"]).abs().max().item() < 1e-6
+    assert [n for n, p in student.named_parameters() if p.requires_grad and p.grad is None] == []
+    # the same loss through the oracle restatement
+    sd = {k: v.clone() for k, v in student.state_dict().items()}
+    l_o, _ = O.dino_loss(O.swin_multicrop(sd, crops, dict(GU.NANO), dense=False), t_out, nano["center0"], O.teacher_temp(2, 0.04, 0.07, 5, 10), 2)
+    assert abs(l_o.item() - nano["dino_loss_2crops"]) < 2e-5
+
+
+def test_swin_forward_return_n_last_blocks_matches_reference_golden(cpu_ops):
+    """eval_linear.py's feature hook (swin_transformer.py:799-837): host logic vs the reference golden"""
+    nano = torch.load(os.path.join(GOLD, "nano_step.pt"), weights_only=False)
+    student = build_nano()
+    GU.fill_state_dict(student.state_dict(), 0)
+    student.eval()
+    crops = GU.make_crops(2)
+    depth = list(GU.NANO["depths"])
+    with torch.no_grad():
+        f3 = student.forward_return_n_last_blocks(crops[0], n=3, depth=depth)
+        f1 = student.forward_return_n_last_blocks(crops[2], n=1, depth=depth)
+    assert torch.allclose(f3, nano["last_blocks_n3"], rtol=2e-4, atol=1e-5)
+    assert torch.allclose(f1, nano["last_blocks_n1_local"], rtol=2e-4, atol=1e-5)
 
 
 def test_composition_bf16_emulation_error_budget(cpu_ops):

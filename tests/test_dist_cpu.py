@@ -50,6 +50,57 @@ def _reducer_worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
+def _nano_step_worker(rank, world, port, out):
+    """the whole nano step on two ranks through the product's host code (kernels replaced by their torch restatement):
+    weight gradients are written straight into the reducer's bucket slots (params.grad_out), the rest is packed by the
+    post-accumulate hook; the averaged gradients equal the mean of the per-rank gradients computed without a reducer"""
+    _init(rank, world, port)
+    import esvit_amd.functional as Fn
+    import esvit_amd.loss as L
+    import esvit_amd.params as P
+    from esvit_amd.engine import GradBucketReducer
+    from oracle import ops_ref
+    from tests import golden_utils as GU
+    from tests.test_composition_cpu import nano_pair
+    for mod in (Fn, L, P):
+        mod.ops = ops_ref
+    ops_ref.set_act_dtype(torch.float32)
+    K = GU.NANO_HEAD["out_dim"]
+
+    def grads(student, teacher, r, reducer):
+        crops = GU.make_crops(1, seed=300 + r)
+        loss_fn = L.DDINOLoss(K, 10, 0.04, 0.04, 0, 1)
+        loss_fn._reduce_and_apply = lambda buf, apply: None  # centres are not under test here (and the ranks would desynchronise)
+        for p in student.parameters():
+            p.grad = None
+        with torch.no_grad():
+            t_out = teacher(crops[:2])
+        loss = loss_fn(student(crops), t_out, 0, None)
+        if reducer is not None:
+            reducer.begin()
+        loss.backward()
+        if reducer is not None:
+            reducer.finish()
+        return {n: p.grad.detach().clone() for n, p in student.named_parameters() if p.grad is not None}
+
+    student, teacher = nano_pair()
+    red = GradBucketReducer(student, bucket_mb=0.25)
+    assert red.enabled and len(red.buckets) >= 2
+    assert all(v.data_ptr() % 16 == 0 for v in red.views.values())  # 16-byte slots (the fused update's vector loads)
+    got = grads(student, teacher, rank, red)
+    in_place = sum(1 for n, p in student.named_parameters() if p.grad is not None and p.grad.data_ptr() == red.views[id(p)].data_ptr())
+    assert in_place == len(got), (in_place, len(got))  # every gradient lives in its bucket slot
+    red.close()
+    ref_student, ref_teacher = nano_pair()
+    acc = None
+    for r in range(world):
+        g = grads(ref_student, ref_teacher, r, None)
+        acc = g if acc is None else {n: acc[n] + g[n] for n in g}
+    ok = set(got) == set(acc) and all(torch.allclose(got[n], acc[n] / world, rtol=2e-4, atol=1e-7) for n in got)
+    out[rank] = bool(ok)
+    dist.destroy_process_group()
+
+
 def _center_worker(rank, world, port, out):
     _init(rank, world, port)
     import esvit_amd.loss as L
@@ -60,7 +111,9 @@ def _center_worker(rank, world, port, out):
     g = torch.Generator().manual_seed(7)
     t_cls, t_reg = torch.randn(world, 2 * B, K, generator=g), torch.randn(world, 2 * B * 49, K, generator=g)
     loss = L.DDINOLoss(K, 10, 0.04, 0.04, 0, 1)
-    loss.update_center(t_cls[rank], t_reg[rank])
+    loss.update_center(t_cls[rank], t_reg[rank])   # asynchronous all-reduce ...
+    sd = loss.state_dict()                           # ... applied when the centres are next read
+    assert sd["center"] is loss.center or torch.equal(sd["center"], loss.center)
     want_c = 0.1 * t_cls.reshape(-1, K).mean(0, keepdim=True)
     want_g = 0.1 * t_reg.reshape(-1, K).mean(0, keepdim=True)
     out[rank] = bool(torch.allclose(loss.center, want_c, atol=1e-6) and torch.allclose(loss.center_grid, want_g, atol=1e-6))
@@ -136,7 +189,8 @@ def _extract_worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("worker,port", [(_reducer_worker, 29611), (_center_worker, 29612), (_syncbn_worker, 29613), (_extract_worker, 29614)])
+@pytest.mark.parametrize("worker,port", [(_reducer_worker, 29611), (_center_worker, 29612), (_syncbn_worker, 29613), (_extract_worker, 29614),
+                                         (_nano_step_worker, 29615)])
 def test_world2_gloo(worker, port, lib_built):
     world = 2
     out = mp.Manager().dict()

@@ -42,10 +42,11 @@ def _rand(shape, dev, seed, dt=torch.float32, scale=1.0):
     return (torch.randn(shape, generator=g) * scale).to(dev).to(dt)
 
 
-@pytest.fixture(params=[0, 3, 2, 1], ids=["auto", "dma8", "dma4", "regstage"])
+@pytest.fixture(params=[0, 3, 2, 4, 1], ids=["auto", "dma8", "dma4", "dma4w", "regstage"])
 def gemm_path(request, mods):
     """every bf16 GEMM main loop on every shape: the library's own choice, the 8-wave 256-row LDS-DMA loop, the 4-wave
-    128-row LDS-DMA loop and the register-staged loop, forced through esvit_gemm_desc.kernel (the library keeps no state);
+    128-row LDS-DMA loop in both wave layouts (2 x 2; whole-width wave rows for N % 96 == 0) and the register-staged
+    loop, forced through esvit_gemm_desc.kernel (the library keeps no state);
     the exact-fp32 mode has one main loop and ignores the selector"""
     ops, _ = mods
     ops.FORCE_GEMM_KERNEL = request.param

@@ -271,48 +271,83 @@ def test_eval_knn_consumers_gpu(lib_built):
 
 
 def test_train_one_epoch_drop_in_gpu(lib_built):
-    """engine.train_one_epoch (the reference's signature, main_esvit.py:499-501) over a two-batch loader equals two
-    EsvitTrainer.step calls: same returned stats keys, same final student / teacher parameters"""
+    """engine.train_one_epoch (the reference's signature, main_esvit.py:499-501) with the torch.optim.AdamW the unmodified
+    train_esvit builds (main_esvit.py:408-411): two batches equal two EsvitTrainer.step calls; the caller's optimizer holds
+    the real moments (state_dict() / load_state_dict() round trip = the checkpoint of main_esvit.py:476-488), a resumed run
+    continues exactly like an uninterrupted one, and optimizers other than AdamW are refused"""
     import argparse
     import esvit_amd.loss as L
     from esvit_amd import engine
+    from esvit_amd.update import get_params_groups
     dev = _setup("fp32")
     try:
         K = GU.NANO_HEAD["out_dim"]
-        batches = [[c.to(dev) for c in GU.make_crops(2, seed=70 + i)] for i in range(2)]
-        # schedules are indexed by the global iteration len(loader) * epoch + it (main_esvit.py:507): epoch 1 -> entries 2, 3
-        sched = dict(lr=[9.0, 9.0, 3e-4, 2e-4], wd=[9.0, 9.0, 0.04, 0.05], mom=[0.0, 0.0, 0.99, 0.995])
+        batches = [[c.to(dev) for c in GU.make_crops(2, seed=70 + i)] for i in range(3)]
+        # schedules are indexed by the global iteration len(loader) * epoch + it (main_esvit.py:507)
+        sched = dict(lr=[3e-4, 2e-4, 1e-4, 9.0], wd=[0.04, 0.05, 0.06, 9.0], mom=[0.99, 0.995, 0.996, 0.0])
 
         class Loader:
             sampler = None
 
+            def __init__(self, bs):
+                self.bs = bs
+
             def __len__(self):
-                return 2
+                return len(self.bs)
 
             def __iter__(self):
-                return iter([(b, None) for b in batches])
+                return iter([(b, None) for b in self.bs])
 
         def fresh():
             student, teacher = nano_pair()
             student, teacher = student.to(dev), teacher.to(dev)
             loss_fn = L.DDINOLoss(K, 10, 0.04, 0.07, 5, 10).to(dev)
             return student, teacher, loss_fn
-        # (a) the drop-in
+        args = argparse.Namespace(clip_grad=3.0, freeze_last_layer=0)
+        # (a) the drop-in, three iterations in one epoch, torch AdamW passed by the caller
         student, teacher, loss_fn = fresh()
-        args = argparse.Namespace(clip_grad=3.0, freeze_last_layer=1)
-        stats = engine.train_one_epoch(student, teacher, teacher, loss_fn, Loader(), None, sched["lr"], sched["wd"], sched["mom"], 1, None, None, args)
+        opt = torch.optim.AdamW(get_params_groups(student))
+        stats = engine.train_one_epoch(student, teacher, teacher, loss_fn, Loader(batches), opt, sched["lr"], sched["wd"], sched["mom"], 0, None, None, args)
         assert set(stats) == {"loss", "lr", "wd"} and stats["loss"] == stats["loss"]
-        # (b) two explicit steps
+        sd = opt.state_dict()
+        n_train = sum(1 for n, p in student.named_parameters() if p.requires_grad and n != "head.last_layer.weight_g")
+        assert len(sd["state"]) == n_train and all(float(st["step"]) == 3.0 for st in sd["state"].values())
+        assert any(float(st["exp_avg"].abs().max()) > 0 for st in sd["state"].values())
+        assert opt.param_groups[0]["lr"] == sched["lr"][2] and opt.param_groups[0]["weight_decay"] == sched["wd"][2]
+        # (b) three explicit steps
         s2, t2, l2 = fresh()
-        tr = engine.EsvitTrainer(s2, t2, l2, clip_grad=3.0, freeze_last_layer=1)
-        last = None
-        for i, b in enumerate(batches):
-            last = tr.step(b, sched["lr"][2 + i], sched["wd"][2 + i], sched["mom"][2 + i], 1)
-        assert abs(stats["loss"] - last.item()) < 1e-4
+        tr = engine.EsvitTrainer(s2, t2, l2, clip_grad=3.0, freeze_last_layer=0)
+        losses = [tr.step(b, sched["lr"][i], sched["wd"][i], sched["mom"][i], 0) for i, b in enumerate(batches)]
+        assert abs(stats["loss"] - sum(x.item() for x in losses) / 3) < 1e-4  # the epoch mean the reference logs
         # (fp32 atomics in the bias-gradient scatter make two runs differ in the last bits, hence a tolerance, not equality)
         for (n, a), (_, b) in zip(student.named_parameters(), s2.named_parameters()):
             assert torch.allclose(a, b, rtol=1e-4, atol=1e-6), (n, (a - b).abs().max().item())
         for (n, a), (_, b) in zip(teacher.named_parameters(), t2.named_parameters()):
             assert torch.allclose(a, b, rtol=1e-4, atol=1e-6), (n, (a - b).abs().max().item())
+        # (c) resume: two iterations, checkpoint (the dict of main_esvit.py:476-488 through torch.save), fresh objects,
+        # load, third iteration == the uninterrupted run
+        import io
+        s3, t3, l3 = fresh()
+        o3 = torch.optim.AdamW(get_params_groups(s3))
+        two = Loader(batches[:2])
+        engine.train_one_epoch(s3, t3, t3, l3, two, o3, sched["lr"], sched["wd"], sched["mom"], 0, None, None, args)
+        buf = io.BytesIO()
+        torch.save({"student": s3.state_dict(), "teacher": t3.state_dict(), "optimizer": o3.state_dict(), "dino_loss": l3.state_dict()}, buf)
+        buf.seek(0)
+        ck = torch.load(buf, map_location="cpu")
+        s4, t4, l4 = fresh()
+        o4 = torch.optim.AdamW(get_params_groups(s4))
+        s4.load_state_dict(ck["student"]), t4.load_state_dict(ck["teacher"]), o4.load_state_dict(ck["optimizer"]), l4.load_state_dict(ck["dino_loss"])
+        one = Loader(batches[2:])
+        # the global iteration of the resumed epoch: len(loader) * epoch + it with len 1 -> shift the schedules accordingly
+        engine.train_one_epoch(s4, t4, t4, l4, one, o4, sched["lr"][2:], sched["wd"][2:], sched["mom"][2:], 0, None, None, args)
+        for (n, a), (_, b) in zip(student.named_parameters(), s4.named_parameters()):
+            assert torch.allclose(a, b, rtol=1e-4, atol=1e-6), ("resume", n, (a - b).abs().max().item())
+        assert all(float(st["step"]) == 3.0 for st in o4.state_dict()["state"].values())
+        # (d) anything that is not AdamW is refused instead of silently ignored
+        with pytest.raises(TypeError):
+            engine.train_one_epoch(s4, t4, t4, l4, one, torch.optim.SGD(s4.parameters(), lr=0.1), sched["lr"][2:], sched["wd"][2:], sched["mom"][2:], 0, None, None, args)
+        with pytest.raises(NotImplementedError):
+            engine.train_one_epoch(s4, t4, t4, l4, one, o4, sched["lr"][2:], sched["wd"][2:], sched["mom"][2:], 0, None, object(), args)
     finally:
         _teardown()

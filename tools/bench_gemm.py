@@ -107,11 +107,13 @@ def main():
             fh.write(line + "\n")
             fh.flush()
 
-    tot = {0: 0.0, 2: 0.0, 3: 0.0, "best": 0.0}
+    KERNELS = (0, 2, 3, 4)
+    tot = {k: 0.0 for k in KERNELS}
+    tot["best"] = 0.0
     for name, kind, M, N, K, fl in step_shapes(args.batch):
         if args.only and args.only not in name:
             continue
-        r = run_shape(name, kind, M, N, K, fl, (0, 2, 3))
+        r = run_shape(name, kind, M, N, K, fl, KERNELS)
         flops = 2.0 * M * N * K
         ref = r[2][1]
         scale = ref.abs().max().item() + 1e-12
@@ -123,10 +125,10 @@ def main():
         sel = ops.gemm_select(DT, M=(N if kind == "wgrad" else M), N=(K if kind == "wgrad" else N), K=(M if kind == "wgrad" else K),
                               a_kstrided=int(kind == "wgrad"), b_kstrided=int(kind != "fwd"))
         d["auto_kernel"] = sel[0]
-        d["best"] = min((2, 3), key=lambda k: r[k][0])
-        for k in (0, 2, 3):
+        d["best"] = min(KERNELS[1:], key=lambda k: r[k][0])
+        for k in KERNELS:
             tot[k] += r[k][0]
-        tot["best"] += min(r[2][0], r[3][0])
+        tot["best"] += min(r[k][0] for k in KERNELS[1:])
         emit(d)
         torch.cuda.empty_cache()
     emit({"summary_ms_per_distinct_shape_set": {str(k): round(v * 1e3, 3) for k, v in tot.items()}})
