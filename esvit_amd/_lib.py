@@ -71,7 +71,7 @@ SIGNATURES = {
     "esvit_colsum": (C.c_int, [C.c_int, vp, i64, C.c_int, i64, vp, vp, C.c_int, vp]),
     "esvit_patch_im2col": (C.c_int, [C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "esvit_merge_ln_fwd": (C.c_int, [C.c_int, vp, vp, vp, f32, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]),
-    "esvit_merge_ln_bwd": (C.c_int, [C.c_int, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp]),
+    "esvit_merge_ln_bwd": (C.c_int, [C.c_int, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, C.c_int, vp]),
     "esvit_token_mean_fwd": (C.c_int, [C.c_int, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp]),
     "esvit_token_mean_bwd": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp]),
     "esvit_attn_frag_elems": (C.c_int, [C.c_int]),
@@ -82,7 +82,7 @@ SIGNATURES = {
     "esvit_window_attn_bwd_parts": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "esvit_window_attn_bwd_pad_rows": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "esvit_window_attn_bwd": (C.c_int, [C.c_int, vp, vp, vp, C.c_int, vp, vp, vp, vp, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, f32, vp, vp, vp, vp]),
-    "esvit_relpos_bias_bwd": (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, vp, vp]),
+    "esvit_relpos_bias_bwd": (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp]),
     "esvit_l2norm_fwd": (C.c_int, [C.c_int, vp, i64, C.c_int, vp, vp, vp]),
     "esvit_l2norm_bwd": (C.c_int, [C.c_int, vp, vp, vp, i64, C.c_int, vp, vp]),
     "esvit_weightnorm_fwd": (C.c_int, [C.c_int, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp]),

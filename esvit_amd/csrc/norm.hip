@@ -275,7 +275,7 @@ template <typename T>
 int ln_bwd_launch(RowSrc src, const void* dy, const float* mean, const float* rstd, const float* gamma,
                   const float* g_in, long rows, float* dx, float* dgamma, float* dbeta, float* ws, const int* rowmap,
                   int tokens, int period_in, hipStream_t stream, void* dx_act = nullptr, const float* rowscale = nullptr,
-                  int rows_per_sample = 1) {
+                  int rows_per_sample = 1, int accumulate = 0) {
     LnCfg cfg;
     ESVIT_CHECK_ARG(ln_cfg(src.C, &cfg), "layernorm: unsupported channel count %d", src.C);
     const int nblk = ln_bwd_nblk(rows, src.C);
@@ -295,10 +295,10 @@ int ln_bwd_launch(RowSrc src, const void* dy, const float* mean, const float* rs
     ESVIT_CHECK_LAUNCH("layernorm_bwd");
     // ws rows are [dgamma(C) | dbeta(C)]; reduce both halves (dgamma and dbeta may be separate allocations)
     const int C = src.C;
-    if (dbeta == dgamma + C) return esvit_partial_reduce(ws, nblk, 2 * C, 2L * C, dgamma, 0, stream);
-    int rc = esvit_partial_reduce(ws, nblk, C, 2L * C, dgamma, 0, stream);
+    if (dbeta == dgamma + C) return esvit_partial_reduce(ws, nblk, 2 * C, 2L * C, dgamma, accumulate, stream);
+    int rc = esvit_partial_reduce(ws, nblk, C, 2L * C, dgamma, accumulate, stream);
     if (rc != ESVIT_OK) return rc;
-    return esvit_partial_reduce(ws + C, nblk, C, 2L * C, dbeta, 0, stream);
+    return esvit_partial_reduce(ws + C, nblk, C, 2L * C, dbeta, accumulate, stream);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -515,16 +515,18 @@ extern "C" int esvit_merge_ln_fwd(int dtype, const float* x, const float* gamma,
 
 extern "C" int esvit_merge_ln_bwd(int dtype, const void* dy, const float* x, const float* mean, const float* rstd,
                                   const float* gamma, int nB, int H, int W, int C, float* dx, float* dgamma,
-                                  float* dbeta, float* ws, esvit_stream_t s_) {
+                                  float* dbeta, float* ws, int accumulate, esvit_stream_t s_) {
     hipStream_t stream = reinterpret_cast<hipStream_t>(s_);
     ESVIT_CHECK_ARG(dy && x && mean && rstd && gamma && dx && dgamma && dbeta && ws, "esvit_merge_ln_bwd: null pointer");
     ESVIT_CHECK_ARG(H % 2 == 0 && W % 2 == 0 && C % 4 == 0 && nB > 0, "esvit_merge_ln_bwd: bad geometry");
     RowSrc src{x, 4 * C, 1, H, W, C};
     const long rows = (long)nB * (H / 2) * (W / 2);
     if (dtype == ESVIT_BF16)
-        return ln_bwd_launch<bf16>(src, dy, mean, rstd, gamma, nullptr, rows, dx, dgamma, dbeta, ws, nullptr, 0, 0, stream);
+        return ln_bwd_launch<bf16>(src, dy, mean, rstd, gamma, nullptr, rows, dx, dgamma, dbeta, ws, nullptr, 0, 0, stream, nullptr, nullptr, 1,
+                                   accumulate);
     if (dtype == ESVIT_F32)
-        return ln_bwd_launch<float>(src, dy, mean, rstd, gamma, nullptr, rows, dx, dgamma, dbeta, ws, nullptr, 0, 0, stream);
+        return ln_bwd_launch<float>(src, dy, mean, rstd, gamma, nullptr, rows, dx, dgamma, dbeta, ws, nullptr, 0, 0, stream, nullptr, nullptr, 1,
+                                    accumulate);
     esvit_set_error("esvit_merge_ln_bwd: bad dtype");
     return ESVIT_ERR_ARG;
 }

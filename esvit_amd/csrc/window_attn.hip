@@ -788,16 +788,16 @@ extern "C" int esvit_dense_to_frag(const float* dense, int n_mats, int N, float*
 }
 
 int esvit_big_relpos_bias_bwd(const float* dbias_ws, int parts, const int64_t* index, int N, int nH, int table_rows, float* dtable,
-                              hipStream_t stream);
+                              int accumulate, hipStream_t stream);
 int esvit_big_npb();
 
 extern "C" int esvit_relpos_bias_bwd(const float* dbias_ws, int parts, const int64_t* index, int N, int nH, int table_rows,
-                                     float* dtable, esvit_stream_t s_) {
+                                     float* dtable, int accumulate, esvit_stream_t s_) {
     STREAM(s_);
     ESVIT_CHECK_ARG(dbias_ws && index && dtable && parts > 0 && N > 0 && N <= esvit_big_npb() && nH > 0 && table_rows > 0,
                     "esvit_relpos_bias_bwd: bad args");
-    if (N > NP) return esvit_big_relpos_bias_bwd(dbias_ws, parts, index, N, nH, table_rows, dtable, stream);
-    hipError_t e = hipMemsetAsync(dtable, 0, (size_t)table_rows * nH * sizeof(float), stream);
+    if (N > NP) return esvit_big_relpos_bias_bwd(dbias_ws, parts, index, N, nH, table_rows, dtable, accumulate, stream);
+    hipError_t e = accumulate ? hipSuccess : hipMemsetAsync(dtable, 0, (size_t)table_rows * nH * sizeof(float), stream);
     if (e != hipSuccess) {
         esvit_set_error("esvit_relpos_bias_bwd: memset failed: %s", hipGetErrorString(e));
         return ESVIT_ERR_HIP;
@@ -825,7 +825,7 @@ int esvit_big_attn_bwd(int dtype, const void* qkv, const float* qkv_bias, const 
                        const void* fout, const float* lse, const float* rel_table, int ws, float* bias_frag_ws, const int32_t* region_ids,
                        int nW, int nB, int N, int nH, float scale, void* dqkv, float* dbias_ws, float* dpad_ws, hipStream_t stream);
 int esvit_big_relpos_bias_bwd(const float* dbias_ws, int parts, const int64_t* index, int N, int nH, int table_rows, float* dtable,
-                              hipStream_t stream);
+                              int accumulate, hipStream_t stream);
 
 extern "C" int esvit_attn_frag_elems(int N) { return N <= NP ? FRAG_ELEMS : (N <= esvit_big_npb() ? esvit_big_frag_elems() : -1); }
 extern "C" int esvit_window_attn_lse_elems(int N) { return N <= NP ? 0 : esvit_big_npb(); }

@@ -832,13 +832,13 @@ int esvit_big_attn_bwd(int dtype, const void* qkv, const float* qkv_bias, const 
 }
 
 int esvit_big_relpos_bias_bwd(const float* dbias_ws, int parts, const int64_t* index, int N, int nH, int table_rows, float* dtable,
-                              hipStream_t stream) {
+                              int accumulate, hipStream_t stream) {
     const int FE = NT * NT * 256;
     if (parts > 1) {
         int rc = esvit_partial_reduce(dbias_ws, parts, nH * FE, (long)nH * FE, const_cast<float*>(dbias_ws), 0, stream);
         if (rc != ESVIT_OK) return rc;
     }
-    hipError_t e = hipMemsetAsync(dtable, 0, (size_t)table_rows * nH * sizeof(float), stream);
+    hipError_t e = accumulate ? hipSuccess : hipMemsetAsync(dtable, 0, (size_t)table_rows * nH * sizeof(float), stream);
     if (e != hipSuccess) {
         esvit_set_error("esvit_relpos_bias_bwd: memset failed: %s", hipGetErrorString(e));
         return ESVIT_ERR_HIP;

@@ -236,8 +236,7 @@ class SwinBlockMultiFn(torch.autograd.Function):
             r1 = r0 + nB * L
             _, dbias_ws, dpad_ws = o.window_attn_bwd(qkv[r0:r1], bqkv, geom.win2tok, L, dao[r0:r1], ao[r0:r1], lse, table, geom.ws, geom.region_ids,
                                                      geom.nW, geom.N, nH, scale, dqkv_out=dqkv[r0:r1])
-            dt_g = o.relpos_bias_bwd(dbias_ws, index, geom.N, table.shape[0])
-            dtable = dt_g if dtable is None else dtable.add_(dt_g)
+            dtable = o.relpos_bias_bwd(dbias_ws, index, geom.N, table.shape[0], out=dtable)  # the second group accumulates
             pads.append(dpad_ws)
         dWqkv, dbqkv = _wgrad(dqkv, xw, Wqkv_p, want_bias=True)
         for dpad_ws in pads:
@@ -326,10 +325,10 @@ class PatchEmbedMultiFn(torch.autograd.Function):
         o = ops_module()
         E = Wp.shape[0]
         Kc = Wp.shape[1] * patch * patch
-        rows = [im.shape[0] * (im.shape[2] // patch) ** 2 for im in imgs]
+        rows = [im.shape[0] * (im.shape[2] // patch) ** 2 for im in imgs]  # one entry per crop tensor, in crop order
         cols = torch.empty((sum(rows), Kc), dtype=o.act_dtype(), device=imgs[0].device)
         r0 = 0
-        for im, n in zip(imgs, rows):
+        for im, n in zip(imgs, rows):  # (the reference concatenates the crops of a resolution first, swin_transformer.py:741)
             o.patch_im2col(im.contiguous(), patch, Kc, out=cols[r0:r0 + n])
             r0 += n
         y = o.linear_fwd(cols, _weight(Wp, (E, Kc)), bp, out_f32=True)
@@ -379,14 +378,13 @@ class PatchMergeMultiFn(torch.autograd.Function):
         dWr = _wgrad(gb, y, ctx.wparam)
         dy = o.linear_dgrad(gb, Wc)
         dX = torch.empty_like(X)
-        dg = db = None
-        for (r0, nB, H, W) in ctx.groups:
+        gb = torch.empty((2, 4 * C), dtype=torch.float32, device=X.device)  # dgamma | dbeta: the first group writes, later ones accumulate
+        for gi, (r0, nB, H, W) in enumerate(ctx.groups):
             r1 = r0 + nB * H * W
             q0, q1 = r0 // 4, r1 // 4
-            _, dg_g, db_g = o.merge_ln_bwd(dy[q0:q1], X[r0:r1].view(nB, H * W, C), mean[q0:q1], rstd[q0:q1], g, H, W, dx_out=dX[r0:r1])
-            dg = dg_g.clone() if dg is None else dg.add_(dg_g)
-            db = db_g.clone() if db is None else db.add_(db_g)
-        return dX, None, dg, db, dWr
+            o.merge_ln_bwd(dy[q0:q1], X[r0:r1].view(nB, H * W, C), mean[q0:q1], rstd[q0:q1], g, H, W, dx_out=dX[r0:r1], gb_out=gb,
+                           accumulate=gi > 0)
+        return dX, None, gb[0], gb[1], dWr
 
 
 def patch_embed_nonorm(img, Wp, bp, patch):

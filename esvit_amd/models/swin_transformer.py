@@ -110,14 +110,12 @@ class SwinTransformerBlock(nn.Module):
 
 
 def _block_forward_multi(blk, X, groups, dp, shadow=None, prev_scale=None):
-    """blk: SwinTransformerBlock; X fp32 [M, C]; groups: list of (row0, nB, H, W); dp: None or (f1 [samples], f2, rowsample [M]).
+    """blk: SwinTransformerBlock; X fp32 [M, C]; groups: list of (row0, nB, H, W); dp: None or the per-ROW DropPath scales
+    (attention branch [M], MLP branch [M]; rows of one sample share its factor).
     shadow / prev_scale: the previous block's shadow output and MLP-branch DropPath row scale (Fn.SwinBlockMultiFn).
     -> (y, shadow of y, this block's MLP-branch row scale)"""
     segs = tuple((r0, nB, H * W, Fn.geometry(H, W, blk.window_size, blk.shift_size, X.device)) for (r0, nB, H, W) in groups)
-    dp_rows = None
-    if dp is not None:
-        f1, f2, rowsample = dp
-        dp_rows = (f1[rowsample], f2[rowsample])  # per-row DropPath scale (rows of one sample share its factor)
+    dp_rows = dp
     y, ysh = Fn.swin_block_multi(X, segs, blk.num_heads, blk.attn.relative_position_index, dp_rows, blk._params(), shadow, prev_scale)
     return y, ysh, (None if dp_rows is None else dp_rows[1])
 
@@ -172,19 +170,36 @@ class BasicLayer(nn.Module):
         """X: fp32 token rows [M, C] of several resolution groups, groups: list of (row0, nB, H, W).  The blocks of this
         stage run over all rows at once (Fn.swin_block_multi: attention per group, everything row-wise in one launch),
         then the ragged patch merging.  Returns (rows of the next stage, its groups)."""
-        rowsample = None
         shadow, prev_scale = None, None  # (the first block of a stage has no predecessor to serve)
+        nS = sum(g[1] for g in groups)
+        # stochastic depth: the per-sample keep factors of every block of this stage (drawn at once by
+        # SwinTransformer._draw_drop_path) become per-row scales with ONE gather per stage
+        stage_f = []
         for blk in self.blocks:
-            dp = None
+            pend = None
             if isinstance(blk.drop_path, DropPath) and blk.drop_path.drop_prob and self.training:
-                nS = sum(g[1] for g in groups)
-                pend = blk.__dict__.pop("_dp_pending", None)  # drawn for every block at once by SwinTransformer._draw_drop_path
+                pend = blk.__dict__.pop("_dp_pending", None)
                 if pend is None or pend[0].shape[0] != nS:
                     pend = (blk.drop_path.factors(nS, X.device), blk.drop_path.factors(nS, X.device))
-                if rowsample is None:
-                    rowsample = torch.cat([torch.arange(nB, device=X.device).repeat_interleave(H * W) + s0
-                                           for (_, nB, H, W), s0 in zip(groups, _sample_offsets(groups))])
-                dp = (pend[0], pend[1], rowsample)
+            stage_f.append(pend)
+        rows_f = None
+        live = [i for i, p in enumerate(stage_f) if p is not None]
+        if live:
+            key = tuple(groups)
+            cache = self.__dict__.setdefault("_rowsample", {})
+            rowsample = cache.get(key)
+            if rowsample is None or rowsample.device != X.device:
+                rowsample = torch.cat([torch.arange(nB, device=X.device).repeat_interleave(H * W) + s0
+                                       for (_, nB, H, W), s0 in zip(groups, _sample_offsets(groups))])
+                cache.clear()
+                cache[key] = rowsample
+            F = torch.stack([f for i in live for f in stage_f[i]])  # [2 * live blocks, samples]
+            rows_f = F[:, rowsample]                                   # [2 * live blocks, M]
+        for bi, blk in enumerate(self.blocks):
+            dp = None
+            if stage_f[bi] is not None:
+                k = live.index(bi)
+                dp = (rows_f[2 * k], rows_f[2 * k + 1])
             X, shadow, prev_scale = _block_forward_multi(blk, X, groups, dp, shadow, prev_scale)
         if self.downsample is not None:
             return self.downsample.forward_ragged(X, groups)
@@ -302,19 +317,22 @@ class SwinTransformer(nn.Module):
         x_grid = Fn.FinalNormFn.apply(x, self.norm.weight, self.norm.bias)
         return Fn.TokenMeanFn.apply(x_grid), x_grid
 
-    def forward_feature_maps_multi(self, xs):
-        """several image batches of different resolution at once -> list of (cls, region).  The token rows of all groups
-        travel through the backbone as ONE [M, C] matrix (patch embedding, every block, patch merging and the final norm
-        are launched once over all of them; only attention, the 2x2 merge gather and the token mean see the grids)."""
-        self._draw_drop_path(sum(x.shape[0] for x in xs), xs[0].device)
+    def forward_feature_maps_multi(self, crop_groups):
+        """several resolution groups (each a list of equally sized crop batches, in crop order) at once -> (list of
+        (cls, region), all region rows [M, C] in group order).  The token rows of all groups travel through the backbone as
+        ONE [M, C] matrix (patch embedding, every block, patch merging and the final norm are launched once over all of
+        them; only attention, the 2x2 merge gather and the token mean see the grids); the crops are read where they lie
+        (no concatenation pass over the images, swin_transformer.py:741)."""
+        flat = [c for grp in crop_groups for c in grp]
+        self._draw_drop_path(sum(c.shape[0] for c in flat), flat[0].device)
         pe = self.patch_embed
         if pe.norm is None:
             raise NotImplementedError("PATCH_NORM False is not on the hot path")
         P = pe.patch_size[0]
-        X = Fn.PatchEmbedMultiFn.apply(pe.proj.weight, pe.proj.bias, pe.norm.weight, pe.norm.bias, P, *xs)
+        X = Fn.PatchEmbedMultiFn.apply(pe.proj.weight, pe.proj.bias, pe.norm.weight, pe.norm.bias, P, *flat)
         groups, r0 = [], 0
-        for x in xs:
-            nB, G = x.shape[0], x.shape[-1] // P
+        for grp in crop_groups:
+            nB, G = sum(c.shape[0] for c in grp), grp[0].shape[-1] // P
             groups.append((r0, nB, G, G))
             r0 += nB * G * G
         for layer in self.layers:
@@ -326,7 +344,7 @@ class SwinTransformer(nn.Module):
         for part, (_, nB, H, W) in zip(parts, groups):
             x_grid = part.view(nB, H * W, C)
             outs.append((Fn.TokenMeanFn.apply(x_grid), x_grid))
-        return outs
+        return outs, Xn
 
     def forward_features(self, x):
         cls, region = self.forward_feature_maps(x)
@@ -349,17 +367,20 @@ class SwinTransformer(nn.Module):
                 start = i
         if self.use_dense_prediction:
             cls_parts, fea_parts, npatch = [], [], []
-            batches = [torch.cat(x[a:b]) for a, b in bounds]
-            # every resolution group through the backbone at once (row-wise kernels see all rows, attention runs per group)
-            maps = self.forward_feature_maps_multi(batches) if (self.ragged_multi_crop and len(batches) > 1) else \
-                [self.forward_feature_maps(xb) for xb in batches]
+            all_fea = None
+            if self.ragged_multi_crop and len(bounds) > 1:
+                # every resolution group through the backbone at once (row-wise kernels see all rows, attention runs per group)
+                maps, all_fea = self.forward_feature_maps_multi([x[a:b] for a, b in bounds])
+            else:
+                maps = [self.forward_feature_maps(x[a] if b - a == 1 else torch.cat(x[a:b])) for a, b in bounds]
             for cls, fea in maps:
                 B, N, C = fea.shape
                 cls_parts.append(cls)
                 fea_parts.append(fea.reshape(B * N, C))
                 npatch.append(N)
             output_cls = cls_parts[0] if len(cls_parts) == 1 else torch.cat(cls_parts)
-            output_fea = fea_parts[0] if len(fea_parts) == 1 else torch.cat(fea_parts)
+            # the ragged route's final-norm output already IS the concatenation of the groups' region rows
+            output_fea = all_fea if all_fea is not None else (fea_parts[0] if len(fea_parts) == 1 else torch.cat(fea_parts))
             return self._apply_head(self.head, output_cls), self._apply_head(self.head_dense, output_fea), output_fea, npatch
         outs = [self.forward_features(torch.cat(x[a:b])) for a, b in bounds]
         return self._apply_head(self.head, outs[0] if len(outs) == 1 else torch.cat(outs))

@@ -361,7 +361,9 @@ def merge_ln_fwd(x, gamma, beta, eps, H, W, dtype=None, out=None):
     return y, mean, rstd
 
 
-def merge_ln_bwd(dy, x, mean, rstd, gamma, H, W, dx_out=None):
+def merge_ln_bwd(dy, x, mean, rstd, gamma, H, W, dx_out=None, gb_out=None, accumulate=False):
+    """gb_out: optional fp32 [2, 4C] receiving (dgamma | dbeta); accumulate: add to it instead of overwriting (further
+    resolution groups sharing the parameters)"""
     x, dy = _f32c(x), _actc(dy)
     nB, L, Cc = x.shape
     if dx_out is not None:
@@ -369,12 +371,14 @@ def merge_ln_bwd(dy, x, mean, rstd, gamma, H, W, dx_out=None):
         dx = dx_out
     else:
         dx = torch.empty_like(x)
-    gb = torch.empty((2, 4 * Cc), dtype=torch.float32, device=x.device)
+    acc = bool(accumulate) and gb_out is not None
+    gb = gb_out if gb_out is not None else torch.empty((2, 4 * Cc), dtype=torch.float32, device=x.device)
+    assert gb.shape == (2, 4 * Cc) and gb.is_contiguous()
     dgamma, dbeta = gb[0], gb[1]
     rows = nB * (H // 2) * (W // 2)
     ws = workspace(lib.esvit_layernorm_bwd_blocks(rows, 4 * Cc) * 8 * Cc, x.device, slot=1)
     check(lib.esvit_merge_ln_bwd(_code(dy.dtype), _p(dy), _p(x), _p(mean), _p(rstd), _p(gamma), nB, H, W, Cc, _p(dx), _p(dgamma),
-                                 _p(dbeta), _p(ws), _stream()), "merge_ln_bwd")
+                                 _p(dbeta), _p(ws), int(acc), _stream()), "merge_ln_bwd")
     return dx, dgamma, dbeta
 
 
@@ -507,7 +511,9 @@ def window_attn_bwd(qkv, qkv_bias, win2tok, L, dout, fwd_out, lse, rel_table, ws
     assert dqkv.shape == qkv.shape and dqkv.dtype == qkv.dtype and dqkv.is_contiguous()
     parts = lib.esvit_window_attn_bwd_parts(N, nB * nW, nH)
     dbias_ws = torch.empty((parts, nH, attn_frag_elems(N)), dtype=torch.float32, device=qkv.device)
-    pad = torch.zeros((lib.esvit_window_attn_bwd_pad_rows(code, N, nB * nW, nH), 2 * Cc), dtype=torch.float32, device=qkv.device)
+    # the <= 64-token kernel writes every element of its pad-row slab itself; the 14x14 kernels fill one head's slice per row
+    alloc = torch.empty if N <= 64 else torch.zeros
+    pad = alloc((lib.esvit_window_attn_bwd_pad_rows(code, N, nB * nW, nH), 2 * Cc), dtype=torch.float32, device=qkv.device)
     bias_ws = workspace(2 * nH * attn_frag_elems(N), qkv.device, slot=2)
     check(lib.esvit_window_attn_bwd(code, _p(qkv), _p(_f32c(qkv_bias)), _p(win2tok), L, _p(dout), _p(fwd_out), _p(lse), _p(_f32c(rel_table)),
                                     ws, _p(bias_ws), _p(region_ids), nW, nB, N, nH, Cc // nH, scale, _p(dqkv), _p(dbias_ws), _p(pad),
@@ -515,10 +521,12 @@ def window_attn_bwd(qkv, qkv_bias, win2tok, L, dout, fwd_out, lse, rel_table, ws
     return dqkv, dbias_ws, pad
 
 
-def relpos_bias_bwd(dbias_ws, index, N, table_rows):
+def relpos_bias_bwd(dbias_ws, index, N, table_rows, out=None):
+    """out: optional fp32 [table_rows, nH] to ACCUMULATE into (the second resolution group of a ragged block)"""
     parts, nH, _ = dbias_ws.shape
-    dtable = torch.empty((table_rows, nH), dtype=torch.float32, device=dbias_ws.device)
-    check(lib.esvit_relpos_bias_bwd(_p(dbias_ws), parts, _p(index), N, nH, table_rows, _p(dtable), _stream()), "relpos_bias_bwd")
+    dtable = torch.empty((table_rows, nH), dtype=torch.float32, device=dbias_ws.device) if out is None else _f32c(out)
+    check(lib.esvit_relpos_bias_bwd(_p(dbias_ws), parts, _p(index), N, nH, table_rows, _p(dtable), int(out is not None), _stream()),
+          "relpos_bias_bwd")
     return dtable
 
 

@@ -153,10 +153,11 @@ int esvit_patch_im2col(int dtype, const float* img, void* cols, int nB, int S, i
 int esvit_merge_ln_fwd(int dtype, const float* x, const float* gamma, const float* beta, float eps,
                        int nB, int H, int W, int C, void* y, float* mean, float* rstd,
                        esvit_stream_t stream);
-/* backward of the above: dy dtype [nB*(H/2)*(W/2), 4C] -> dx fp32 [nB,H,W,C] (overwritten) */
+/* backward of the above: dy dtype [nB*(H/2)*(W/2), 4C] -> dx fp32 [nB,H,W,C] (overwritten); dgamma / dbeta overwritten, or
+ * added to when accumulate != 0 (further resolution groups sharing the parameters) */
 int esvit_merge_ln_bwd(int dtype, const void* dy, const float* x, const float* mean, const float* rstd,
                        const float* gamma, int nB, int H, int W, int C, float* dx, float* dgamma,
-                       float* dbeta, float* ws, esvit_stream_t stream);
+                       float* dbeta, float* ws, int accumulate, esvit_stream_t stream);
 /* token mean (swin_transformer.py:688-689): x fp32 [nB,T,C] -> out fp32 [nB,C] (+ act copy) */
 int esvit_token_mean_fwd(int dtype, const float* x, int nB, int T, int C, float* out, void* out_act,
                          esvit_stream_t stream);
@@ -208,9 +209,10 @@ int esvit_window_attn_bwd(int dtype, const void* qkv, const float* qkv_bias, con
                           const void* dout, const void* fwd_out, const float* lse, const float* rel_table, int ws,
                           float* bias_frag_ws, const int32_t* region_ids, int nW, int nB, int N, int nH, int hd,
                           float scale, void* dqkv, float* dbias_ws, float* dpad_ws, esvit_stream_t stream);
-/* dtable fp32 [table_rows, nH] (overwritten) = scatter-add over index of sum_parts dbias_ws */
+/* dtable fp32 [table_rows, nH] (overwritten, or added to when accumulate != 0: the second resolution group of a ragged
+ * multi-crop block) = scatter-add over index of sum_parts dbias_ws */
 int esvit_relpos_bias_bwd(const float* dbias_ws, int parts, const int64_t* index, int N, int nH,
-                          int table_rows, float* dtable, esvit_stream_t stream);
+                          int table_rows, float* dtable, int accumulate, esvit_stream_t stream);
 
 /* ---- DINOHead pieces (vision_transformer.py:414-418) -------------------- */
 /* z = x / max(||x||_2, 1e-12) row-wise; x dtype [R, D]; z dtype; inv_norm fp32 [R] */

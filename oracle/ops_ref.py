@@ -235,10 +235,18 @@ def merge_ln_fwd(x, gamma, beta, eps, H, W, dtype=None, out=None):
     return y, mean, rstd
 
 
-def merge_ln_bwd(dy, x, mean, rstd, gamma, H, W, dx_out=None):
+def merge_ln_bwd(dy, x, mean, rstd, gamma, H, W, dx_out=None, gb_out=None, accumulate=False):
     nB, L, C = x.shape
     g = _merge_gather(x.float(), H, W)
     dg, dgamma, dbeta = layernorm_bwd(dy, g, mean, rstd, gamma)
+    if gb_out is not None:
+        if accumulate:
+            gb_out[0].add_(dgamma)
+            gb_out[1].add_(dbeta)
+        else:
+            gb_out[0].copy_(dgamma)
+            gb_out[1].copy_(dbeta)
+        dgamma, dbeta = gb_out[0], gb_out[1]
     dg = dg.view(nB, H // 2, W // 2, 4 * C)
     dx = torch.zeros((nB, H, W, C), dtype=torch.float32, device=x.device)
     dx[:, 0::2, 0::2] = dg[..., 0:C]
@@ -450,10 +458,10 @@ def window_attn_bwd(qkv, qkv_bias, win2tok, L, dout, fwd_out, lse, rel_table, ws
     return _r(dqkv, dt), ws, dpad
 
 
-def relpos_bias_bwd(dbias_ws, index, N, table_rows):
+def relpos_bias_bwd(dbias_ws, index, N, table_rows, out=None):
     nH = dbias_ws.shape[1]
     dense = _dense_from_frag(dbias_ws.sum(0), N)  # [nH, N, N]
-    dtable = torch.zeros((table_rows, nH), dtype=torch.float32, device=dbias_ws.device)
+    dtable = torch.zeros((table_rows, nH), dtype=torch.float32, device=dbias_ws.device) if out is None else out
     dtable.index_add_(0, index.view(-1), dense.permute(1, 2, 0).reshape(N * N, nH))
     return dtable
 
