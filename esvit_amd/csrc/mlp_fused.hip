@@ -61,6 +61,12 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t mk_rsrc(const void* base, long
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)capped, 0x00020000);
 }
 
+template <typename F>
+__device__ __forceinline__ void static_for2(F&& f) {
+    f(std::integral_constant<int, 0>{});
+    f(std::integral_constant<int, 1>{});
+}
+
 template <int N>
 __device__ __forceinline__ void wait_vm() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -74,7 +80,7 @@ __device__ __forceinline__ int slab_off(int row, int slot8) {
 }
 
 template <int C, bool SAVE>
-__global__ __launch_bounds__(MLP_WAVES * 64, 2) void mlp_fused_fwd_kernel(
+__device__ __forceinline__ void mlp_fused_fwd_body(
     const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
     const bf16* __restrict__ W1, const float* __restrict__ b1, const bf16* __restrict__ W2, const float* __restrict__ b2,
     const float* __restrict__ rowscale, long M, float* __restrict__ y, bf16* __restrict__ h_out, float* __restrict__ mean_out,
@@ -92,6 +98,7 @@ __global__ __launch_bounds__(MLP_WAVES * 64, 2) void mlp_fused_fwd_kernel(
     const long row = row0 + n;
     const bool row_ok = row < M;
     const long rrow = row_ok ? row : (M - 1);  // out-of-range lanes compute on a valid row and store nothing
+    const bool full_tile = row0 + 32 <= M;     // wave-uniform
 
     // ---- weight chunk DMA: per-lane source byte offsets of this wave's instructions for chunk 0; chunk q adds a scalar ----
     const __amdgpu_buffer_rsrc_t r1 = mk_rsrc(W1, (long)H4 * C * 2), r2 = mk_rsrc(W2, (long)C * H4 * 2);
@@ -259,8 +266,9 @@ __global__ __launch_bounds__(MLP_WAVES * 64, 2) void mlp_fused_fwd_kernel(
                     __builtin_amdgcn_wave_barrier();
                 }
             }
-            // the DMA of chunk q + 1 was issued before this chunk's (<= 8) side-output stores: in-order retirement
-            if constexpr (SAVE && half == 1) wait_vm<8>();
+            // the DMA of chunk q + 1 was issued before this chunk's 8 side-output stores (a full tile issues exactly 8): loads
+            // and stores retire in order, so at most 8 outstanding means the DMA has landed while the stores may still fly
+            if (SAVE && half == 1 && full_tile) wait_vm<8>();
             else wait_vm<0>();
             __syncthreads();  // chunk q + 1 landed for every wave; every wave is done reading chunk q
         });
@@ -284,6 +292,15 @@ __global__ __launch_bounds__(MLP_WAVES * 64, 2) void mlp_fused_fwd_kernel(
             if (trow[r] >= 0) y[trow[r] * C + c] = x[trow[r] * C + c] + rs[r] * (acc2[nt][r] + bb);
         }
     }
+}
+
+template <int C, bool SAVE>
+__global__ __launch_bounds__(MLP_WAVES * 64, 2) void mlp_fused_fwd_kernel(
+    const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+    const bf16* __restrict__ W1, const float* __restrict__ b1, const bf16* __restrict__ W2, const float* __restrict__ b2,
+    const float* __restrict__ rowscale, long M, float* __restrict__ y, bf16* __restrict__ h_out, float* __restrict__ mean_out,
+    float* __restrict__ rstd_out, bf16* __restrict__ pre_out, bf16* __restrict__ act_out) {
+    mlp_fused_fwd_body<C, SAVE>(x, gamma, beta, eps, W1, b1, W2, b2, rowscale, M, y, h_out, mean_out, rstd_out, pre_out, act_out);
 }
 
 template <int C>
