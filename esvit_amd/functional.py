@@ -100,8 +100,8 @@ def _block_forward(x, geom, nH, index, dp, prm, wts, save):
     qkv = o.linear_fwd(xw, Wqkv, bqkv)
     ao, lse = o.window_attn_fwd(qkv, bqkv, geom.win2tok, L, table, geom.ws, geom.region_ids, geom.nW, geom.N, nH, scale)
     x1 = o.linear_fwd(ao, Wproj, bproj, residual=x2d, rowscale=dp1, rows_per_sample=L, out_f32=True)
-    if dp2 is None and o.mlp_fused_supported(W1.dtype, C):  # (the fused kernel takes per-row DropPath scales only)
-        x2, h, mean2, rstd2, a1, a1g = o.mlp_fused_fwd(x1, g2, b2, LN_EPS, W1, bfc1, W2, bfc2, save=save)
+    if not save and dp2 is None and o.mlp_fused_supported(W1.dtype, C):  # (the fused kernel takes per-row DropPath scales only)
+        return o.mlp_fused_fwd(x1, g2, b2, LN_EPS, W1, bfc1, W2, bfc2).view(nB, L, C), None
     else:
         h, _, mean2, rstd2 = o.layernorm_fwd(x1, g2, b2, LN_EPS)
         if save:
@@ -180,9 +180,10 @@ def _block_forward_multi(X, segs, nH, dp_rows, prm, wts, save):
         _, lse = o.window_attn_fwd(qkv[r0:r1], bqkv, geom.win2tok, L, table, geom.ws, geom.region_ids, geom.nW, geom.N, nH, scale, out=ao[r0:r1])
         lses.append(lse)
     x1 = o.linear_fwd(ao, Wproj, bproj, residual=X, rowscale=dp1, rows_per_sample=1, out_f32=True)
-    if o.mlp_fused_supported(W1.dtype, C):
-        # narrow stages: LayerNorm -> fc1 + GELU -> fc2 + residual in one kernel, the hidden activation never crosses HBM twice
-        x2, h, mean2, rstd2, a1, a1g = o.mlp_fused_fwd(x1, g2, b2, LN_EPS, W1, bfc1, W2, bfc2, rowscale=dp2, save=save)
+    if not save and o.mlp_fused_supported(W1.dtype, C):
+        # inference-mode pass (the teacher) through a narrow stage: LayerNorm -> fc1 + GELU -> fc2 + residual in one kernel,
+        # the hidden activation never reaches HBM
+        return o.mlp_fused_fwd(x1, g2, b2, LN_EPS, W1, bfc1, W2, bfc2, rowscale=dp2), None, lses
     else:
         h, _, mean2, rstd2 = o.layernorm_fwd(x1, g2, b2, LN_EPS)
         if save:

@@ -295,24 +295,15 @@ def mlp_fused_supported(dt, Cc):
     return bool(lib.esvit_mlp_fused_supported(_code(dt), int(Cc)))
 
 
-def mlp_fused_fwd(x, gamma, beta, eps, W1, b1, W2, b2, *, rowscale=None, save=False):
-    """x fp32 [M, C] -> y fp32 [M, C] = x + rowscale * (GELU(LN(x) W1^T + b1) W2^T + b2); with save also
-    (h, mean, rstd, pre, act) for the backward, else five Nones"""
+def mlp_fused_fwd(x, gamma, beta, eps, W1, b1, W2, b2, *, rowscale=None):
+    """x fp32 [M, C] -> y fp32 [M, C] = x + rowscale * (GELU(LN(x) W1^T + b1) W2^T + b2); nothing is saved for a backward"""
     x, W1, W2 = _f32c(x), _actc(W1), _actc(W2)
     M, Cc = x.shape
     assert W1.shape == (4 * Cc, Cc) and W2.shape == (Cc, 4 * Cc) and W1.dtype == W2.dtype
-    dt = W1.dtype
     y = torch.empty_like(x)
-    h = mean = rstd = pre = act = None
-    if save:
-        h = torch.empty((M, Cc), dtype=dt, device=x.device)
-        mean = torch.empty((M,), dtype=torch.float32, device=x.device)
-        rstd = torch.empty_like(mean)
-        pre = torch.empty((M, 4 * Cc), dtype=dt, device=x.device)
-        act = torch.empty_like(pre)
-    check(lib.esvit_mlp_fused_fwd(_code(dt), _p(x), _p(_f32c(gamma)), _p(_f32c(beta)), eps, _p(W1), _p(_f32c(b1)), _p(W2), _p(_f32c(b2)),
-                                  _p(rowscale), M, Cc, _p(y), _p(h), _p(mean), _p(rstd), _p(pre), _p(act), _stream()), "mlp_fused_fwd")
-    return y, h, mean, rstd, pre, act
+    check(lib.esvit_mlp_fused_fwd(_code(W1.dtype), _p(x), _p(_f32c(gamma)), _p(_f32c(beta)), eps, _p(W1), _p(_f32c(b1)), _p(W2), _p(_f32c(b2)),
+                                  _p(rowscale), M, Cc, _p(y), _stream()), "mlp_fused_fwd")
+    return y
 
 
 # ------------------------------------------------------------------------------------------------

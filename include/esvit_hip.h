@@ -102,17 +102,16 @@ int esvit_gemm(int dtype, const esvit_gemm_desc* d, esvit_stream_t stream);
  * (tile, slice); a launch of more workgroups than resident slots runs in rounds) before it allocates `partial`. */
 int esvit_gemm_select(int dtype, const esvit_gemm_desc* d, int* tile_m, int* tile_n, int* resident_slots);
 
-/* ---- fused Swin MLP forward (swin_transformer.py:331 + 31-37) -------------
- * y = x + rowscale[row] * ( GELU( LayerNorm(x) W1^T + b1 ) W2^T + b2 ) in ONE kernel for the narrow stages, where the
- * unfused LayerNorm -> fc1 (+GELU) -> fc2 (+residual) sequence is bound by the HBM round trips of the 4C-wide hidden
- * activation.  x, y fp32 [M, C]; W1 [4C, C], W2 [C, 4C] in the activation dtype; gamma, beta, b1, b2 fp32; rowscale fp32
- * [M] (per-row DropPath scale) or NULL.  Side outputs for the unchanged backward kernels, all or none: h_out = LayerNorm(x)
- * [M, C] and pre_out / act_out = fc1 pre-activation / GELU output [M, 4C] in the activation dtype, mean_out / rstd_out fp32
- * [M].  esvit_mlp_fused_supported: 1 where the kernel exists (bf16, C in {96, 192}). */
+/* ---- fused Swin MLP forward, inference mode (swin_transformer.py:331 + 31-37) ---
+ * y = x + rowscale[row] * ( GELU( LayerNorm(x) W1^T + b1 ) W2^T + b2 ) in ONE kernel for the narrow stages of passes that
+ * save nothing for a backward (the EMA teacher): the unfused LayerNorm -> fc1 (+GELU) -> fc2 (+residual) sequence is bound
+ * there by the HBM round trips of the 4C-wide hidden activation (32 B per token-channel against 8 fused).
+ * x, y fp32 [M, C]; W1 [4C, C], W2 [C, 4C] in the activation dtype; gamma, beta, b1, b2 fp32; rowscale fp32 [M] or NULL.
+ * esvit_mlp_fused_supported: 1 where the kernel exists (bf16, C in {96, 192}). */
 int esvit_mlp_fused_supported(int dtype, int C);
 int esvit_mlp_fused_fwd(int dtype, const float* x, const float* gamma, const float* beta, float eps, const void* W1,
                         const float* b1, const void* W2, const float* b2, const float* rowscale, int64_t M, int C, float* y,
-                        void* h_out, float* mean_out, float* rstd_out, void* pre_out, void* act_out, esvit_stream_t stream);
+                        esvit_stream_t stream);
 
 /* ---- normalisation ----------------------------------------------------- */
 /* LayerNorm forward over rows of C channels (swin_transformer.py:283,331,417,546,687;

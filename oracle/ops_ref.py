@@ -178,12 +178,11 @@ def mlp_fused_supported(dt, Cc):
     return dt == torch.bfloat16 and Cc in (96, 192)
 
 
-def mlp_fused_fwd(x, gamma, beta, eps, W1, b1, W2, b2, *, rowscale=None, save=False):
+def mlp_fused_fwd(x, gamma, beta, eps, W1, b1, W2, b2, *, rowscale=None):
     """the unfused sequence the fused kernel replaces (same rounding points)"""
-    h, _, mean, rstd = layernorm_fwd(x, gamma, beta, eps, dtype=W1.dtype)
-    act, pre = linear_fwd(h, W1, b1, gelu=True, want_preact=True)
-    y = linear_fwd(act, W2, b2, residual=x, rowscale=rowscale, rows_per_sample=1, out_f32=True)
-    return (y, h, mean, rstd, pre, act) if save else (y, None, None, None, None, None)
+    h, _, _, _ = layernorm_fwd(x, gamma, beta, eps, dtype=W1.dtype)
+    act = linear_fwd(h, W1, b1, gelu=True)
+    return linear_fwd(act, W2, b2, residual=x, rowscale=rowscale, rows_per_sample=1, out_f32=True)
 
 
 def layernorm_fwd(x, gamma, beta, eps, *, rowmap=None, period_out=0, out_rows=None, want_f32=False, dtype=None):

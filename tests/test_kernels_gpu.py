@@ -162,11 +162,10 @@ def test_batched_sim(mods):
     _close("sim", got[:, :, :49], want[:, :, :49], 2e-5)
 
 
-@pytest.mark.parametrize("save", [True, False])
 @pytest.mark.parametrize("C,M", [(96, 128 * 37), (192, 128 * 21), (96, 1000), (192, 77), (96, 128 * 400 + 33)])
-def test_mlp_fused_fwd(mods, C, M, save):
-    """fused LayerNorm -> fc1 + GELU -> fc2 + residual (esvit_mlp_fused_fwd) vs the unfused op sequence it replaces: output,
-    and with save every side tensor the backward reads; full and ragged row tiles, with and without per-row DropPath scales"""
+def test_mlp_fused_fwd(mods, C, M):
+    """fused LayerNorm -> fc1 + GELU -> fc2 + residual (esvit_mlp_fused_fwd, the teacher's narrow stages) vs the unfused op
+    sequence it replaces; full and ragged row tiles, with and without per-row scales"""
     ops, ref = mods
     dev = _dev()
     dt = torch.bfloat16
@@ -176,15 +175,9 @@ def test_mlp_fused_fwd(mods, C, M, save):
     W1, b1 = _rand((4 * C, C), dev, 63, dt, 0.08), 0.1 * _rand((4 * C,), dev, 64)
     W2, b2 = _rand((C, 4 * C), dev, 65, dt, 0.05), 0.1 * _rand((C,), dev, 66)
     for rs in (None, (torch.rand(M, generator=torch.Generator().manual_seed(67)) > 0.3).float().div(0.7).to(dev)):
-        got = ops.mlp_fused_fwd(x, g, b, 1e-6, W1, b1, W2, b2, rowscale=rs, save=save)
-        want = ref.mlp_fused_fwd(x, g, b, 1e-6, W1, b1, W2, b2, rowscale=rs, save=True)
-        _close("mlp y", got[0], want[0], 4e-3)  # fp32 output; the hidden activation is rounded to bf16 on both sides
-        if save:
-            for nm, a, w, tol in (("h", got[1], want[1], 1e-2), ("mean", got[2], want[2], 1e-5), ("rstd", got[3], want[3], 1e-5),
-                                  ("pre", got[4], want[4], 1.5e-2), ("act", got[5], want[5], 1.5e-2)):
-                _close("mlp " + nm, a, w, tol)
-        else:
-            assert all(t is None for t in got[1:])
+        got = ops.mlp_fused_fwd(x, g, b, 1e-6, W1, b1, W2, b2, rowscale=rs)
+        want = ref.mlp_fused_fwd(x, g, b, 1e-6, W1, b1, W2, b2, rowscale=rs)
+        _close("mlp y", got, want, 4e-3)  # fp32 output; the hidden activation is rounded to bf16 on both sides
 
 
 @pytest.mark.parametrize("dt", DTYPES)
