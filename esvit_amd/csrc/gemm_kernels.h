@@ -571,14 +571,26 @@ __device__ __forceinline__ void gemm_epilogue_bf16(const esvit_gemm_desc& p, f32
 
 // XCD-aware work order: tiles on grid.x, split-K slice / batch item on grid.y.  The dispatcher places block b on XCD
 // b % 8; every XCD gets a contiguous range of tile ids (bijective remap), so the tiles of one output row panel share
-// an L2.  (Putting all tiles of one split-K slice on one XCD instead was measured 8 % slower on the weight gradients:
-// profiles/r01_gemm_xcdmap_ab.txt.)
+// an L2.  Used for nz == 1 and batched problems; split-K uses the z-major list below.  (Round 1 measured z-major 8 %
+// slower with the register-staged loop, profiles/r01_gemm_xcdmap_ab.txt; with the LDS-DMA loop the fabric traffic is
+// what limits the weight gradients and z-major wins on every shape, profiles/r02_gemm_workorder_ab.txt.)
 __device__ __forceinline__ void xcd_tile_map(int ntiles, int& tile, int& z) {
     const int b = blockIdx.x;
     const int q = ntiles / 8, r = ntiles % 8;
     const int xcd = b % 8, idx = b / 8;
     tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     z = blockIdx.y;
+}
+// z-major variant: the whole (z, tile) grid is one work list, tile fastest; every XCD gets a contiguous range, i.e. all
+// tiles of ~nz/8 split-K slices, so each K slice of A and B is fetched by one XCD only.
+__device__ __forceinline__ void xcd_work_map_zmajor(int ntiles, int& tile, int& z) {
+    const int total = ntiles * gridDim.y;
+    const int L = blockIdx.y * gridDim.x + blockIdx.x;
+    const int q = total / 8, r = total % 8;
+    const int xcd = L % 8, idx = L / 8;
+    const int w = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    z = w / ntiles;
+    tile = w - z * ntiles;
 }
 
 // Tile id -> (row block, column block).  group_m <= 1: column-fastest.  Otherwise the ids walk down group_m row blocks
@@ -846,7 +858,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8 ? 2 : 2)) void gemm_dma
     const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
     const int ntiles = tiles_m * tiles_n;
     int pid, z;
-    xcd_tile_map(ntiles, pid, z);
+    if (group_m < 0) xcd_work_map_zmajor(ntiles, pid, z);
+    else xcd_tile_map(ntiles, pid, z);
     int tm, tn;
     tile_coords(pid, tiles_m, tiles_n, group_m, tm, tn);
     const int m0 = tm * BM, n0 = tn * BN;
@@ -1050,10 +1063,19 @@ int launch_gemm_dma(const esvit_gemm_desc& d, hipStream_t stream) {
     }
     const int tiles = ceil_div(d.M, BM) * ceil_div(d.N, BN);
     const int nz = d.splitk > 1 ? d.splitk : d.batch;
-    // grouped tile order only where a row block's column tiles outnumber what one XCD runs at a time
-    // (measured, profiles/r01_gemm_group_m_ab.txt: +5..13 % for 12..64 column tiles, nothing below, noise above)
-    const int tn_ = ceil_div(d.N, BN);
-    const int group_m = (nz == 1 && tn_ >= 12 && tn_ <= 64) ? 16 : 1;
+    // Work order (measured on the step's shapes, profiles/r02_gemm_workorder_ab.txt):
+    //  * split-K: z-major work list -- each K slice of A and B is fetched by one XCD (weight gradients 8.3 -> 7.3 ms/step)
+    //  * 12..64 column tiles: walk 16 row blocks per column block (+5..13 %, profiles/r01_gemm_group_m_ab.txt)
+    //  * > 64 column tiles (the 65536-wide last layer): pairs of row blocks share each B column tile (+14 %)
+    //  * 2..11 column tiles on very tall problems (>= 2048 row blocks, stages 0/1): 16 / 32 row blocks (+2..22 %)
+    const int tm_ = ceil_div(d.M, BM), tn_ = ceil_div(d.N, BN);
+    int group_m = 1;
+    if (d.splitk > 1) group_m = -1;
+    else if (nz == 1) {
+        if (tn_ > 64) group_m = 2;
+        else if (tn_ >= 12) group_m = 16;
+        else if (tn_ >= 2 && tm_ >= 2048) group_m = tn_ <= 3 ? 16 : 32;
+    }
     hipLaunchKernelGGL(kern, dim3(tiles, nz), dim3(NT), lds, stream, d, group_m);
     ESVIT_CHECK_LAUNCH("esvit_gemm(dma)");
     if (d.splitk > 1) return launch_splitk_reduce(d, true, stream);

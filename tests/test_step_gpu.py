@@ -319,11 +319,18 @@ def test_train_one_epoch_drop_in_gpu(lib_built):
         tr = engine.EsvitTrainer(s2, t2, l2, clip_grad=3.0, freeze_last_layer=0)
         losses = [tr.step(b, sched["lr"][i], sched["wd"][i], sched["mom"][i], 0) for i, b in enumerate(batches)]
         assert abs(stats["loss"] - sum(x.item() for x in losses) / 3) < 1e-4  # the epoch mean the reference logs
-        # (fp32 atomics in the bias-gradient scatter make two runs differ in the last bits, hence a tolerance, not equality)
-        for (n, a), (_, b) in zip(student.named_parameters(), s2.named_parameters()):
-            assert torch.allclose(a, b, rtol=1e-4, atol=1e-6), (n, (a - b).abs().max().item())
-        for (n, a), (_, b) in zip(teacher.named_parameters(), t2.named_parameters()):
-            assert torch.allclose(a, b, rtol=1e-4, atol=1e-6), (n, (a - b).abs().max().item())
+        # fp32 atomics in the bias-table gradient scatter make two runs differ in the last bits of a few gradients, and an Adam
+        # step moves an entry whose gradient is ~0 by up to +-lr whatever its magnitude: compare the three-step UPDATE as a
+        # vector (relative L2 distance) instead of entry by entry
+        init_s, init_t = fresh()[:2]
+        init_s, init_t = dict(init_s.named_parameters()), dict(init_t.named_parameters())
+
+        def same_update(tag, pa, pb, init, tol):
+            for (n, a), (_, b) in zip(pa, pb):
+                ua, ub = (a - init[n]).detach(), (b - init[n]).detach()
+                assert (ua - ub).norm().item() <= tol * ub.norm().item() + 1e-9, (tag, n, (ua - ub).norm().item(), ub.norm().item())
+        same_update("student", student.named_parameters(), s2.named_parameters(), init_s, 2e-2)
+        same_update("teacher", teacher.named_parameters(), t2.named_parameters(), init_t, 2e-3)
         # (c) resume: two iterations, checkpoint (the dict of main_esvit.py:476-488 through torch.save), fresh objects,
         # load, third iteration == the uninterrupted run
         import io
@@ -341,8 +348,7 @@ def test_train_one_epoch_drop_in_gpu(lib_built):
         one = Loader(batches[2:])
         # the global iteration of the resumed epoch: len(loader) * epoch + it with len 1 -> shift the schedules accordingly
         engine.train_one_epoch(s4, t4, t4, l4, one, o4, sched["lr"][2:], sched["wd"][2:], sched["mom"][2:], 0, None, None, args)
-        for (n, a), (_, b) in zip(student.named_parameters(), s4.named_parameters()):
-            assert torch.allclose(a, b, rtol=1e-4, atol=1e-6), ("resume", n, (a - b).abs().max().item())
+        same_update("resume", student.named_parameters(), s4.named_parameters(), init_s, 2e-2)
         assert all(float(st["step"]) == 3.0 for st in o4.state_dict()["state"].values())
         # (d) anything that is not AdamW is refused instead of silently ignored
         with pytest.raises(TypeError):
