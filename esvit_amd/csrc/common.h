@@ -109,6 +109,15 @@ __device__ __forceinline__ Vec16<T> zero16() {
 // ---------------------------------------------------------------------------
 // wave / block reductions (wave = 64 lanes)
 // ---------------------------------------------------------------------------
+// The dispatcher places workgroup b on XCD b % 8 (eight XCDs, one L2 each).  Bijective renumbering that gives every XCD a
+// contiguous range of unit ids, so units that touch the same cache lines (the heads of one window: a head's 64-byte
+// q/k/v slice is half a 128-byte line) or the same operand panel meet in one L2 instead of being fetched once per XCD.
+__device__ __forceinline__ int xcd_contiguous_id(int b, int total) {
+    const int q = total / 8, r = total % 8;
+    const int xcd = b % 8, idx = b / 8;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

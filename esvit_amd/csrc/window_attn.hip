@@ -128,7 +128,7 @@ __global__ __launch_bounds__(128, (HDIM == 32 ? 3 : 2)) void attn_fwd4_kernel(co
     T* Ks = base + Cfg::QK_ELEMS;      // [NP][LDQ]
     T* Vs = base + 2 * Cfg::QK_ELEMS;  // [NP][LDQ], natural layout: P V reads it with transpose reads (frag_v_perm64)
 
-    const long unit = blockIdx.x;
+    const long unit = xcd_contiguous_id(blockIdx.x, gridDim.x);  // the heads of a part share an XCD (and its L2)
     const bool unit_ok = unit < (long)parts * nH;
     const int h = (int)(unit % nH);
     const int part = (int)(unit / nH);
@@ -372,7 +372,7 @@ __global__ __launch_bounds__(128, (HDIM == 32 ? 2 : 1)) void attn_bwd3_kernel(co
     T* Sg = base + 4 * Cfg::QK_ELEMS + w * (32 * LDQ);  // this wave's half of the output staging image
     T* Ps = base + 5 * Cfg::QK_ELEMS;
 
-    const long unit = blockIdx.x;  // one (head, part) per workgroup
+    const long unit = xcd_contiguous_id(blockIdx.x, gridDim.x);  // one (head, part) per workgroup; the heads of a part share an XCD
     const bool unit_ok = unit < (long)parts * nH;
     const int h = (int)(unit % nH);
     const int part = (int)(unit / nH);

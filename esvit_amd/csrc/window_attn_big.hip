@@ -247,7 +247,7 @@ __global__ __launch_bounds__(FWD3_WAVES * 64, sizeof(T) == 2 ? 4 : 1) void attn_
     const int c = lane & 15, g = lane >> 4;
     T* Qs = Vs + Cfg::FULL + wave * TILE;  // this wave's [16][LDQ] image: Q tile, then the output transpose
 
-    const int unit = blockIdx.x;  // (bw, h)
+    const int unit = xcd_contiguous_id(blockIdx.x, gridDim.x);  // (bw, h); the heads of a window share an XCD
     const int bw = unit / nH, h = unit % nH;
     const int C = nH * HD;
     const long tok_base = (long)(bw / nW) * L;
@@ -396,8 +396,9 @@ __global__ __launch_bounds__(DQ4_WAVES * 64) void attn_big_bwd_dq4_kernel(
     T* Os = Qs + TILE;  // dO rows of this wave's queries
     T* Fs = Os + TILE;  // forward output rows
 
-    const int grp = blockIdx.x % DQ4_GROUPS;
-    const int ph = blockIdx.x / DQ4_GROUPS;  // (part, h)
+    const int unit = xcd_contiguous_id(blockIdx.x, gridDim.x);
+    const int grp = unit % DQ4_GROUPS;
+    const int ph = unit / DQ4_GROUPS;  // (part, h)
     const int h = ph % nH, part = ph / nH;
     const int qt = grp * DQ4_WAVES + wave;   // query tile of this wave
     const bool wave_ok = qt < NT;
@@ -533,7 +534,7 @@ __global__ __launch_bounds__(BigCfg<T>::WAVES * 64, sizeof(T) == 2 ? 2 : 1) void
     T* Kb = Os + Cfg::FULL + wave * (2 * Cfg::BLK);
     T* Vb = Kb + Cfg::BLK;
 
-    const int unit = blockIdx.x;
+    const int unit = xcd_contiguous_id(blockIdx.x, gridDim.x);
     const int bw = unit / nH, h = unit % nH;
     const int C = nH * HD;
     const long tok_base = (long)(bw / nW) * L;
