@@ -40,21 +40,18 @@ SIGNATURES = {
     "esvit_version": (C.c_int, []),
     "esvit_last_error": (C.c_char_p, []),
     "esvit_relative_position_index": (C.c_int, [C.c_int, vp]),
-    "esvit_window_maps": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
+    "esvit_window_maps": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp]),
+    "esvit_query": (i64, [C.c_int, i64, i64, i64]),
     "esvit_shift_mask": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
-    "esvit_shift_region_ids": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
     "esvit_gemm": (C.c_int, [C.c_int, C.POINTER(GemmDesc), vp]),
     "esvit_gemm_select": (C.c_int, [C.c_int, C.POINTER(GemmDesc), vp, vp, vp]),
-    "esvit_mlp_fused_supported": (C.c_int, [C.c_int, C.c_int]),
     "esvit_mlp_fused_fwd": (C.c_int, [C.c_int, vp, vp, vp, f32, vp, vp, vp, vp, vp, i64, C.c_int, vp, vp]),
     "esvit_layernorm_fwd": (C.c_int, [C.c_int, vp, vp, vp, f32, i64, C.c_int, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp]),
-    "esvit_layernorm_bwd_blocks": (C.c_int, [i64, C.c_int]),
     "esvit_conv_im2col": (C.c_int, [C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                     C.c_int, vp, vp]),
     "esvit_conv_col2im": (C.c_int, [C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                     vp, vp]),
     "esvit_dwconv3x3": (C.c_int, [C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
-    "esvit_col_reduce_blocks": (C.c_int, [i64]),
     "esvit_dwconv3x3_wgrad": (C.c_int, [C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp]),
     "esvit_col_sums2": (C.c_int, [C.c_int, vp, vp, i64, C.c_int, vp, vp, vp]),
     "esvit_col_affine2": (C.c_int, [C.c_int, vp, vp, i64, C.c_int, vp, vp, vp, vp, vp]),
@@ -63,26 +60,16 @@ SIGNATURES = {
     "esvit_bn_eval_coeffs": (C.c_int, [vp, vp, vp, vp, f32, C.c_int, vp, vp]),
     "esvit_bn_bwd_local": (C.c_int, [vp, vp, C.c_int, vp, vp]),
     "esvit_bn_bwd_coeffs": (C.c_int, [vp, f32, vp, vp, C.c_int, vp, vp]),
-    "esvit_layernorm_bwd": (C.c_int, [C.c_int, vp, vp, vp, vp, vp, vp, i64, C.c_int, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp]),
-    "esvit_layernorm_bwd_cast": (C.c_int, [C.c_int, vp, vp, vp, vp, vp, vp, i64, C.c_int, vp, vp, vp, vp, vp, vp, C.c_int, vp]),
+    "esvit_layernorm_bwd": (C.c_int, [C.c_int, vp, vp, vp, vp, vp, vp, i64, C.c_int, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp, vp, C.c_int, vp]),
     "esvit_gather_cast": (C.c_int, [C.c_int, vp, vp, i64, C.c_int, vp, C.c_int, C.c_int, vp, C.c_int, vp]),
     "esvit_cast_f32_to": (C.c_int, [C.c_int, vp, vp, i64, vp]),
-    "esvit_cast_to_f32": (C.c_int, [C.c_int, vp, vp, i64, vp]),
-    "esvit_transpose_cast": (C.c_int, [C.c_int, vp, vp, C.c_int, C.c_int, vp]),
-    "esvit_colsum_blocks": (C.c_int, [i64]),
     "esvit_colsum": (C.c_int, [C.c_int, vp, i64, C.c_int, i64, vp, vp, C.c_int, vp]),
     "esvit_patch_im2col": (C.c_int, [C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "esvit_merge_ln_fwd": (C.c_int, [C.c_int, vp, vp, vp, f32, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]),
     "esvit_merge_ln_bwd": (C.c_int, [C.c_int, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, C.c_int, vp]),
     "esvit_token_mean_fwd": (C.c_int, [C.c_int, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp]),
     "esvit_token_mean_bwd": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp]),
-    "esvit_attn_frag_elems": (C.c_int, [C.c_int]),
-    "esvit_relpos_bias_fwd": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, vp]),
-    "esvit_dense_to_frag": (C.c_int, [vp, C.c_int, C.c_int, vp, vp]),
-    "esvit_window_attn_lse_elems": (C.c_int, [C.c_int]),
     "esvit_window_attn_fwd": (C.c_int, [C.c_int, vp, vp, vp, C.c_int, vp, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, f32, vp, vp, vp, vp]),
-    "esvit_window_attn_bwd_parts": (C.c_int, [C.c_int, C.c_int, C.c_int]),
-    "esvit_window_attn_bwd_pad_rows": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "esvit_window_attn_bwd": (C.c_int, [C.c_int, vp, vp, vp, C.c_int, vp, vp, vp, vp, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, f32, vp, vp, vp, vp]),
     "esvit_relpos_bias_bwd": (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp]),
     "esvit_l2norm_fwd": (C.c_int, [C.c_int, vp, i64, C.c_int, vp, vp, vp]),
@@ -90,13 +77,11 @@ SIGNATURES = {
     "esvit_weightnorm_fwd": (C.c_int, [C.c_int, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp]),
     "esvit_weightnorm_bwd": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, vp, vp, vp]),
     "esvit_teacher_row_stats": (C.c_int, [C.c_int, vp, vp, f32, i64, C.c_int, vp, vp, vp]),
-    "esvit_row_argmax": (C.c_int, [vp, i64, C.c_int, C.c_int, vp, vp]),
     "esvit_region_match": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]),
     "esvit_dino_ce_fwd_bwd": (C.c_int, [C.c_int, vp, vp, vp, vp, vp, vp, vp, f32, f32, i64, C.c_int, vp, vp, vp]),
     "esvit_sum_f32": (C.c_int, [vp, i64, vp, vp]),
     "esvit_scale_inplace": (C.c_int, [C.c_int, vp, i64, vp, vp]),
     "esvit_center_ema": (C.c_int, [vp, vp, f32, f32, C.c_int, vp]),
-    "esvit_update_chunk_elems": (C.c_int, []),
     "esvit_grad_sqnorm": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, vp]),
     "esvit_fused_clip_adamw_ema": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, f32, f32, f32, f32, f32, f32, f32, vp]),
 }

@@ -19,7 +19,7 @@ LIB = os.path.join(LIBDIR, "libesvit_hip.so")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",  
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",  # include/esvit_hip.h is the export list
          "-Wno-unused-result", "-I", INCLUDE, "-I", CSRC]
 
 

@@ -335,7 +335,7 @@ extern "C" int esvit_dwconv3x3(int dtype, const void* x, const float* w, int fli
     return ESVIT_OK;
 }
 
-extern "C" int esvit_col_reduce_blocks(int64_t rows) { return reduce_blocks(rows); }
+int esvit_i_col_reduce_blocks(long rows) { return reduce_blocks(rows); }  // esvit_query
 
 extern "C" int esvit_dwconv3x3_wgrad(int dtype, const void* x, const void* dy, int nB, int H, int W, int C, float* dw, float* ws,
                                      esvit_stream_t s_) {

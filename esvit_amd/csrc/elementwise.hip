@@ -45,23 +45,6 @@ __global__ __launch_bounds__(256) void cast_kernel(const TS* __restrict__ src, T
     }
 }
 
-// dst[C][R] = src[R][C]^T through a padded 32x32 LDS tile
-template <typename T>
-__global__ __launch_bounds__(256) void transpose_cast_kernel(const float* __restrict__ src, T* __restrict__ dst, int R, int C) {
-    __shared__ float tile[32][33];
-    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
-    for (int k = ty; k < 32; k += 8) {
-        const int r = r0 + k, c = c0 + tx;
-        tile[k][tx] = (r < R && c < C) ? src[(long)r * C + c] : 0.f;
-    }
-    __syncthreads();
-    for (int k = ty; k < 32; k += 8) {
-        const int c = c0 + k, r = r0 + tx;
-        if (c < C && r < R) dst[(long)c * R + r] = from_f32<T>(tile[tx][k]);
-    }
-}
-
 // ---- column sums (bias gradients, centre partials) ---------------------------------------------
 // stage 1: block = 32 column-vectors (8 columns each, one 16-byte load) x 8 row lanes over COLSUM_ROWS_PER_BLOCK rows
 constexpr int COLSUM_ROWS_PER_BLOCK = 256;
@@ -212,23 +195,6 @@ __global__ void center_ema_kernel(float* __restrict__ center, const float* __res
     if (k < K) center[k] = center[k] * m + colsum[k] * inv_denom * (1.f - m);
 }
 
-// argmax over the first Tt entries of each row (first index on ties), one thread per row
-__global__ void row_argmax_kernel(const float* __restrict__ sim, long rows, int Tt, int ld, int* __restrict__ idx) {
-    const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= rows) return;
-    const float* p = sim + r * ld;
-    float best = p[0];
-    int bi = 0;
-    for (int j = 1; j < Tt; ++j) {
-        const float v = p[j];
-        if (v > best) {
-            best = v;
-            bi = j;
-        }
-    }
-    idx[r] = bi;
-}
-
 }  // namespace
 
 #define STREAM(s_) hipStream_t stream = reinterpret_cast<hipStream_t>(s_)
@@ -269,39 +235,13 @@ extern "C" int esvit_cast_f32_to(int dtype, const float* src, void* dst, int64_t
     return ESVIT_OK;
 }
 
-extern "C" int esvit_cast_to_f32(int dtype, const void* src, float* dst, int64_t n, esvit_stream_t s_) {
-    STREAM(s_);
-    ESVIT_CHECK_ARG(src && dst && n > 0, "esvit_cast_to_f32: bad args");
-    const int grid = ceil_div(ceil_div(n, 4), 256);
-    if (dtype == ESVIT_BF16) hipLaunchKernelGGL((cast_kernel<bf16, float>), dim3(grid), dim3(256), 0, stream, (const bf16*)src, dst, (long)n);
-    else if (dtype == ESVIT_F32) hipLaunchKernelGGL((cast_kernel<float, float>), dim3(grid), dim3(256), 0, stream, (const float*)src, dst, (long)n);
-    else {
-        BAD_DTYPE("esvit_cast_to_f32");
-    }
-    ESVIT_CHECK_LAUNCH("cast_to_f32");
-    return ESVIT_OK;
-}
-
-extern "C" int esvit_transpose_cast(int dtype, const float* src, void* dst, int R, int C, esvit_stream_t s_) {
-    STREAM(s_);
-    ESVIT_CHECK_ARG(src && dst && R > 0 && C > 0, "esvit_transpose_cast: bad args");
-    dim3 grid(ceil_div(C, 32), ceil_div(R, 32));
-    if (dtype == ESVIT_BF16) hipLaunchKernelGGL(transpose_cast_kernel<bf16>, grid, dim3(256), 0, stream, src, (bf16*)dst, R, C);
-    else if (dtype == ESVIT_F32) hipLaunchKernelGGL(transpose_cast_kernel<float>, grid, dim3(256), 0, stream, src, (float*)dst, R, C);
-    else {
-        BAD_DTYPE("esvit_transpose_cast");
-    }
-    ESVIT_CHECK_LAUNCH("transpose_cast");
-    return ESVIT_OK;
-}
-
 int esvit_partial_reduce(const float* ws, int nblk, int ncols, long ld, float* out, int accumulate, hipStream_t stream) {
     hipLaunchKernelGGL(partial_reduce_kernel, dim3(ceil_div(ncols, 32)), dim3(256), 0, stream, ws, nblk, ncols, ld, out, accumulate);
     ESVIT_CHECK_LAUNCH("partial_reduce");
     return ESVIT_OK;
 }
 
-extern "C" int esvit_colsum_blocks(int64_t rows) { return ceil_div(rows, COLSUM_ROWS_PER_BLOCK); }
+int esvit_i_colsum_blocks(long rows) { return ceil_div(rows, COLSUM_ROWS_PER_BLOCK); }  // esvit_query
 
 extern "C" int esvit_colsum(int dtype, const void* x, int64_t rows, int N, int64_t ld, float* out, float* ws, int accumulate,
                             esvit_stream_t s_) {
@@ -390,10 +330,3 @@ extern "C" int esvit_center_ema(float* center, const float* colsum, float moment
     return ESVIT_OK;
 }
 
-extern "C" int esvit_row_argmax(const float* sim, int64_t rows, int Tt, int ld, int32_t* idx, esvit_stream_t s_) {
-    STREAM(s_);
-    ESVIT_CHECK_ARG(sim && idx && rows > 0 && Tt > 0 && ld >= Tt, "esvit_row_argmax: bad args");
-    hipLaunchKernelGGL(row_argmax_kernel, dim3(ceil_div(rows, 128)), dim3(128), 0, stream, sim, (long)rows, Tt, ld, idx);
-    ESVIT_CHECK_LAUNCH("row_argmax");
-    return ESVIT_OK;
-}

@@ -1,8 +1,7 @@
 // esvit_gemm: shape -> kernel dispatch of the MFMA GEMM family (kernels: gemm_kernels.h).
 //
 // Main loops (one fragment / epilogue convention; esvit_gemm_desc.kernel forces one, 0 = the rules below):
-//   ESVIT_GEMM_REGSTAGE  register-staged, 128-row tiles, 4 waves: the exact-fp32 parity mode (v_mfma_f32_16x16x4_f32) and a
-//                        bf16 fallback;
+//   ESVIT_GEMM_REGSTAGE  register-staged, 128-row tiles, 4 waves: the exact-fp32 parity mode (v_mfma_f32_16x16x4_f32) only;
 //   ESVIT_GEMM_DMA4      LDS-DMA, 128 x {64, 96, 128} tiles as 2 x 2 waves, two workgroups per CU: the default;
 //   ESVIT_GEMM_DMA4W     the same loop with whole-width wave rows -- 128 x 192 as 2 x 2 waves of 64 x 96, 128 x 96 as 4 x 1
 //                        waves of 32 x 96 -- for the 96 * 2^s wide backbone: 192-byte instead of 96-byte output row pieces
@@ -110,12 +109,24 @@ int run_regstage(const esvit_gemm_desc& d, int bn, hipStream_t stream) {
 template <bool AKS, bool BKS>
 int run_layout(int dtype, const esvit_gemm_desc& d, const GemmChoice& c, hipStream_t stream) {
     if (dtype == ESVIT_BF16) {
-        if (c.kernel == ESVIT_GEMM_DMA8) return run_dma8<AKS, BKS>(d, stream);
+        if constexpr (!AKS) {  // the 8-wave tile is not instantiated for the weight-gradient layout (measured slower there)
+            if (c.kernel == ESVIT_GEMM_DMA8) return run_dma8<AKS, BKS>(d, stream);
+        }
         if (c.kernel == ESVIT_GEMM_DMA4W) return run_dma4w<AKS, BKS>(d, c.bn, stream);
-        if (c.kernel == ESVIT_GEMM_DMA4) return run_dma4<AKS, BKS>(d, c.bn, stream);
-        return run_regstage<bf16, AKS, BKS>(d, c.bn, stream);
+        return run_dma4<AKS, BKS>(d, c.bn, stream);
     }
     return run_regstage<float, AKS, BKS>(d, c.bn, stream);
+}
+
+// which forced main loops exist for which problem
+int check_selector(int dtype, const esvit_gemm_desc& d) {
+    ESVIT_CHECK_ARG(d.kernel >= ESVIT_GEMM_AUTO && d.kernel <= ESVIT_GEMM_DMA4W, "esvit_gemm: bad kernel selector %d", d.kernel);
+    if (dtype != ESVIT_BF16)
+        ESVIT_CHECK_ARG(d.kernel == ESVIT_GEMM_AUTO || d.kernel == ESVIT_GEMM_REGSTAGE, "esvit_gemm: fp32 runs on the register-staged loop only");
+    else
+        ESVIT_CHECK_ARG(d.kernel != ESVIT_GEMM_REGSTAGE, "esvit_gemm: the register-staged loop is the fp32 parity mode; bf16 runs on the LDS-DMA loops");
+    ESVIT_CHECK_ARG(!(d.kernel == ESVIT_GEMM_DMA8 && d.a_kstrided), "esvit_gemm: the 8-wave tile does not exist for the weight-gradient layout");
+    return ESVIT_OK;
 }
 
 int validate(int dtype, esvit_gemm_desc& d) {
@@ -142,9 +153,7 @@ int validate(int dtype, esvit_gemm_desc& d) {
     ESVIT_CHECK_ARG(d.epilogue >= 0 && d.epilogue <= ESVIT_EPI_QGELU_BWD, "esvit_gemm: bad epilogue %d", d.epilogue);
     if (d.colsum && d.splitk > 1) ESVIT_CHECK_ARG(d.colsum_partial != nullptr, "esvit_gemm: colsum with split-K needs colsum_partial");
     if (d.colsum) ESVIT_CHECK_ARG(d.batch == 1, "esvit_gemm: colsum is not batched");
-    ESVIT_CHECK_ARG(d.kernel >= ESVIT_GEMM_AUTO && d.kernel <= ESVIT_GEMM_DMA4W, "esvit_gemm: bad kernel selector %d", d.kernel);
-    if (dtype != ESVIT_BF16) ESVIT_CHECK_ARG(d.kernel == ESVIT_GEMM_AUTO || d.kernel == ESVIT_GEMM_REGSTAGE, "esvit_gemm: fp32 runs on the register-staged loop only");
-    return ESVIT_OK;
+    return check_selector(dtype, d);
 }
 
 }  // namespace
@@ -154,7 +163,10 @@ extern "C" int esvit_gemm_select(int dtype, const esvit_gemm_desc* dp, int* tile
     esvit_gemm_desc d = *dp;
     if (d.batch < 1) d.batch = 1;
     ESVIT_CHECK_ARG(d.M > 0 && d.N > 0 && d.K > 0, "esvit_gemm_select: bad shape M=%d N=%d K=%d", d.M, d.N, d.K);
-    ESVIT_CHECK_ARG(d.kernel >= ESVIT_GEMM_AUTO && d.kernel <= ESVIT_GEMM_DMA4W, "esvit_gemm_select: bad kernel selector %d", d.kernel);
+    {
+        const int rc = check_selector(dtype, d);
+        if (rc != ESVIT_OK) return rc;
+    }
     const GemmChoice c = choose(dtype, d);
     if (tile_m) *tile_m = c.bm;
     if (tile_n) *tile_n = c.bn;

@@ -267,13 +267,13 @@ int launch_mlp(const float* x, const float* gamma, const float* beta, float eps,
 
 }  // namespace
 
-extern "C" int esvit_mlp_fused_supported(int dtype, int C) { return dtype == ESVIT_BF16 && (C == 96 || C == 192); }
+int esvit_i_mlp_fused_supported(int dtype, int C) { return dtype == ESVIT_BF16 && (C == 96 || C == 192); }  // esvit_query
 
 extern "C" int esvit_mlp_fused_fwd(int dtype, const float* x, const float* gamma, const float* beta, float eps, const void* W1,
                                    const float* b1, const void* W2, const float* b2, const float* rowscale, int64_t M, int C,
                                    float* y, esvit_stream_t s_) {
     hipStream_t stream = reinterpret_cast<hipStream_t>(s_);
-    ESVIT_CHECK_ARG(esvit_mlp_fused_supported(dtype, C), "esvit_mlp_fused_fwd: bf16 activations and C in {96, 192} only (C=%d)", C);
+    ESVIT_CHECK_ARG(esvit_i_mlp_fused_supported(dtype, C), "esvit_mlp_fused_fwd: bf16 activations and C in {96, 192} only (C=%d)", C);
     ESVIT_CHECK_ARG(x && gamma && beta && W1 && b1 && W2 && b2 && y && M > 0, "esvit_mlp_fused_fwd: null pointer / empty input");
     ESVIT_CHECK_ARG(((uintptr_t)x % 16 == 0) && ((uintptr_t)y % 16 == 0) && ((uintptr_t)W1 % 16 == 0) && ((uintptr_t)W2 % 16 == 0) &&
                         ((uintptr_t)gamma % 16 == 0) && ((uintptr_t)beta % 16 == 0),

@@ -460,43 +460,29 @@ extern "C" int esvit_layernorm_fwd(int dtype, const float* x, const float* gamma
     return ESVIT_ERR_ARG;
 }
 
-extern "C" int esvit_layernorm_bwd_blocks(int64_t rows, int C) { return ln_bwd_nblk(rows, C); }
+int esvit_i_ln_bwd_blocks(long rows, int C) { return ln_bwd_nblk(rows, C); }  // esvit_query
 
+// dx_act (optional) = cast(rowscale[row / rows_per_sample] * dx): the DropPath-scaled, activation-dtype gradient the following
+// dgrad / wgrad GEMMs read (otherwise a separate esvit_gather_cast pass over dx)
 extern "C" int esvit_layernorm_bwd(int dtype, const void* dy, const float* x, const float* mean, const float* rstd,
                                    const float* gamma, const float* g_in, int64_t rows, int C, float* dx,
                                    float* dgamma, float* dbeta, float* ws, const int32_t* rowmap, int tokens,
-                                   int period_in, esvit_stream_t s_) {
+                                   int period_in, void* dx_act, const float* rowscale, int rows_per_sample, esvit_stream_t s_) {
     hipStream_t stream = reinterpret_cast<hipStream_t>(s_);
     ESVIT_CHECK_ARG(dy && x && mean && rstd && gamma && dx && dgamma && dbeta && ws && rows > 0,
                     "esvit_layernorm_bwd: bad args");
     if (rowmap) ESVIT_CHECK_ARG(tokens > 0 && period_in > 0, "esvit_layernorm_bwd: bad rowmap geometry");
+    if (dx_act) ESVIT_CHECK_ARG(!rowmap, "esvit_layernorm_bwd: dx_act is written at un-mapped rows only");
+    if (rowscale) ESVIT_CHECK_ARG(dx_act && rows_per_sample > 0, "esvit_layernorm_bwd: rowscale scales dx_act and needs rows_per_sample");
+    const int rps = rows_per_sample > 0 ? rows_per_sample : 1;
     RowSrc src{x, C, 0, 0, 0, 0};
     if (dtype == ESVIT_BF16)
-        return ln_bwd_launch<bf16>(src, dy, mean, rstd, gamma, g_in, rows, dx, dgamma, dbeta, ws, rowmap, tokens, period_in, stream);
+        return ln_bwd_launch<bf16>(src, dy, mean, rstd, gamma, g_in, rows, dx, dgamma, dbeta, ws, rowmap, tokens, period_in, stream, dx_act,
+                                   rowscale, rps);
     if (dtype == ESVIT_F32)
-        return ln_bwd_launch<float>(src, dy, mean, rstd, gamma, g_in, rows, dx, dgamma, dbeta, ws, rowmap, tokens, period_in, stream);
+        return ln_bwd_launch<float>(src, dy, mean, rstd, gamma, g_in, rows, dx, dgamma, dbeta, ws, rowmap, tokens, period_in, stream, dx_act,
+                                    rowscale, rps);
     esvit_set_error("esvit_layernorm_bwd: bad dtype");
-    return ESVIT_ERR_ARG;
-}
-
-// LayerNorm backward that also writes dx_act = cast(rowscale[row / rows_per_sample] * dx): the DropPath-scaled, activation-dtype
-// gradient the following dgrad / wgrad GEMMs read (otherwise a separate esvit_gather_cast pass over dx)
-extern "C" int esvit_layernorm_bwd_cast(int dtype, const void* dy, const float* x, const float* mean, const float* rstd,
-                                        const float* gamma, const float* g_in, int64_t rows, int C, float* dx, float* dgamma,
-                                        float* dbeta, float* ws, void* dx_act, const float* rowscale, int rows_per_sample,
-                                        esvit_stream_t s_) {
-    hipStream_t stream = reinterpret_cast<hipStream_t>(s_);
-    ESVIT_CHECK_ARG(dy && x && mean && rstd && gamma && dx && dgamma && dbeta && ws && dx_act && rows > 0,
-                    "esvit_layernorm_bwd_cast: bad args");
-    if (rowscale) ESVIT_CHECK_ARG(rows_per_sample > 0, "esvit_layernorm_bwd_cast: rowscale needs rows_per_sample");
-    RowSrc src{x, C, 0, 0, 0, 0};
-    if (dtype == ESVIT_BF16)
-        return ln_bwd_launch<bf16>(src, dy, mean, rstd, gamma, g_in, rows, dx, dgamma, dbeta, ws, nullptr, 0, 0, stream, dx_act, rowscale,
-                                   rows_per_sample > 0 ? rows_per_sample : 1);
-    if (dtype == ESVIT_F32)
-        return ln_bwd_launch<float>(src, dy, mean, rstd, gamma, g_in, rows, dx, dgamma, dbeta, ws, nullptr, 0, 0, stream, dx_act, rowscale,
-                                    rows_per_sample > 0 ? rows_per_sample : 1);
-    esvit_set_error("esvit_layernorm_bwd_cast: bad dtype");
     return ESVIT_ERR_ARG;
 }
 

@@ -126,7 +126,7 @@ __global__ __launch_bounds__(256) void clip_adamw_ema_kernel(const long* __restr
 
 }  // namespace
 
-extern "C" int esvit_update_chunk_elems(void) { return CHUNK; }
+int esvit_i_update_chunk_elems() { return CHUNK; }  // esvit_query
 
 extern "C" int esvit_grad_sqnorm(const int64_t* tensors, int ntensors, const int32_t* chunks, int nchunks, float* sqnorms,
                                  esvit_stream_t s_) {

@@ -697,22 +697,9 @@ __global__ __launch_bounds__(128, (HDIM == 32 ? 2 : 1)) void attn_bwd3_kernel(co
     }
 }
 
-// bias_frag[h][frag] from the (2ws-1)^2 x nH table (swin_transformer.py:133-135)
-__global__ void relpos_bias_fwd_kernel(const float* __restrict__ table, const long* __restrict__ index, int N, int nH,
-                                       float* __restrict__ bias_frag) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nH * FRAG_ELEMS) return;
-    const int h = i / FRAG_ELEMS, e = i % FRAG_ELEMS;
-    const int r = e & 3, lane = (e >> 2) & 63, f = e >> 8;
-    const int c = lane & 15, g = lane >> 4;
-    const int q = 16 * (f & 3) + c, key = 16 * (f >> 2) + 4 * g + r;
-    float v = 0.f;
-    if (key >= N) v = -1.0e30f;
-    else if (q < N) v = table[index[(long)q * N + key] * nH + h];
-    bias_frag[i] = v;
-}
 
-// same, with the index computed in closed form (a(q) - a(key) + (ws-1) 2ws) instead of read from the index buffer
+// bias_frag[h][frag] from the (2ws-1)^2 x nH table (swin_transformer.py:133-135); the relative-position index is computed in
+// closed form (a(q) - a(key) + (ws-1) 2ws), same values as the relative_position_index buffer; key columns >= N get -1e30
 __global__ void relpos_bias_frag_from_table_kernel(const float* __restrict__ table, int ws, int N, int nH, float* __restrict__ bias_frag) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nH * FRAG_ELEMS) return;
@@ -728,17 +715,6 @@ __global__ void relpos_bias_frag_from_table_kernel(const float* __restrict__ tab
         v = table[(long)idx * nH + h];
     }
     bias_frag[i] = v;
-}
-
-// dense [nW][N][N] -> frag layout (padding 0)
-__global__ void dense_to_frag_kernel(const float* __restrict__ dense, int nM, int N, float* __restrict__ frag) {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (long)nM * FRAG_ELEMS) return;
-    const int w = (int)(i / FRAG_ELEMS), e = (int)(i % FRAG_ELEMS);
-    const int r = e & 3, lane = (e >> 2) & 63, f = e >> 8;
-    const int c = lane & 15, g = lane >> 4;
-    const int q = 16 * (f & 3) + c, key = 16 * (f >> 2) + 4 * g + r;
-    frag[i] = (q < N && key < N) ? dense[((long)w * N + q) * N + key] : 0.f;
 }
 
 // dtable[index[q,key]][h] += total[h][frag(q,key)]   (total = partials already summed)
@@ -768,24 +744,6 @@ inline int bwd_parts(int Bw, int nH) {
 
 #define STREAM(s_) hipStream_t stream = reinterpret_cast<hipStream_t>(s_)
 
-
-extern "C" int esvit_relpos_bias_fwd(const float* table, const int64_t* index, int N, int nH, float* bias_frag, esvit_stream_t s_) {
-    STREAM(s_);
-    ESVIT_CHECK_ARG(table && index && bias_frag && N > 0 && N <= NP && nH > 0, "esvit_relpos_bias_fwd: bad args (N=%d)", N);
-    hipLaunchKernelGGL(relpos_bias_fwd_kernel, dim3(ceil_div((long)nH * FRAG_ELEMS, 256)), dim3(256), 0, stream, table,
-                       (const long*)index, N, nH, bias_frag);
-    ESVIT_CHECK_LAUNCH("relpos_bias_fwd");
-    return ESVIT_OK;
-}
-
-extern "C" int esvit_dense_to_frag(const float* dense, int n_mats, int N, float* frag, esvit_stream_t s_) {
-    STREAM(s_);
-    ESVIT_CHECK_ARG(dense && frag && n_mats > 0 && N > 0 && N <= NP, "esvit_dense_to_frag: bad args");
-    hipLaunchKernelGGL(dense_to_frag_kernel, dim3(ceil_div((long)n_mats * FRAG_ELEMS, 256)), dim3(256), 0, stream, dense, n_mats,
-                       N, frag);
-    ESVIT_CHECK_LAUNCH("dense_to_frag");
-    return ESVIT_OK;
-}
 
 int esvit_big_relpos_bias_bwd(const float* dbias_ws, int parts, const int64_t* index, int N, int nH, int table_rows, float* dtable,
                               int accumulate, hipStream_t stream);
@@ -827,12 +785,11 @@ int esvit_big_attn_bwd(int dtype, const void* qkv, const float* qkv_bias, const 
 int esvit_big_relpos_bias_bwd(const float* dbias_ws, int parts, const int64_t* index, int N, int nH, int table_rows, float* dtable,
                               int accumulate, hipStream_t stream);
 
-extern "C" int esvit_attn_frag_elems(int N) { return N <= NP ? FRAG_ELEMS : (N <= esvit_big_npb() ? esvit_big_frag_elems() : -1); }
-extern "C" int esvit_window_attn_lse_elems(int N) { return N <= NP ? 0 : esvit_big_npb(); }
-extern "C" int esvit_window_attn_bwd_parts(int N, int Bw, int nH) { return N <= NP ? bwd_parts(Bw, nH) : esvit_big_parts(Bw, nH); }
-extern "C" int esvit_window_attn_bwd_pad_rows(int dtype, int N, int Bw, int nH) {
-    return N <= NP ? bwd_parts(Bw, nH) : esvit_big_pad_rows(Bw, nH, dtype);
-}
+// answers of esvit_query (lib.cpp)
+int esvit_i_attn_frag_elems(int N) { return N <= NP ? FRAG_ELEMS : (N <= esvit_big_npb() ? esvit_big_frag_elems() : -1); }
+int esvit_i_attn_lse_elems(int N) { return N <= NP ? 0 : esvit_big_npb(); }
+int esvit_i_attn_bwd_parts(int N, int Bw, int nH) { return N <= NP ? bwd_parts(Bw, nH) : esvit_big_parts(Bw, nH); }
+int esvit_i_attn_bwd_pad_rows(int dtype, int N, int Bw, int nH) { return N <= NP ? bwd_parts(Bw, nH) : esvit_big_pad_rows(Bw, nH, dtype); }
 
 static int fill_bias_frag(const float* rel_table, int ws, int N, int nH, float* bias_frag_ws, hipStream_t stream) {
     // closed-form index (no index tensor needed): same values as relative_position_index

@@ -80,11 +80,21 @@ def relative_position_index(ws):
     return out
 
 
+# esvit_query questions (include/esvit_hip.h)
+(Q_ATTN_FRAG_ELEMS, Q_ATTN_LSE_ELEMS, Q_ATTN_BWD_PARTS, Q_ATTN_BWD_PAD_ROWS, Q_LN_BWD_BLOCKS, Q_COLSUM_BLOCKS, Q_COL_REDUCE_BLOCKS,
+ Q_UPDATE_CHUNK_ELEMS, Q_MLP_FUSED) = range(1, 10)
+
+
+def query(what, a=0, b=0, c=0):
+    """scratch sizes / capabilities of the library (esvit_query)"""
+    return int(lib.esvit_query(int(what), int(a), int(b), int(c)))
+
+
 def window_maps(H, W, ws, shift):
     Hp, Wp = -(-H // ws) * ws, -(-W // ws) * ws
     win2tok = np.empty((Hp // ws) * (Wp // ws) * ws * ws, dtype=np.int32)
     tok2win = np.empty(H * W, dtype=np.int32)
-    check(lib.esvit_window_maps(H, W, ws, shift, win2tok.ctypes.data_as(C.c_void_p), tok2win.ctypes.data_as(C.c_void_p)),
+    check(lib.esvit_window_maps(H, W, ws, shift, win2tok.ctypes.data_as(C.c_void_p), tok2win.ctypes.data_as(C.c_void_p), None),
           "window_maps")
     return win2tok, tok2win
 
@@ -102,7 +112,7 @@ def shift_mask(H, W, ws, shift):
 def shift_region_ids(H, W, ws, shift):
     Hp, Wp = -(-H // ws) * ws, -(-W // ws) * ws
     ids = np.empty((Hp // ws) * (Wp // ws) * ws * ws, dtype=np.int32)
-    check(lib.esvit_shift_region_ids(H, W, ws, shift, ids.ctypes.data_as(C.c_void_p), None), "shift_region_ids")
+    check(lib.esvit_window_maps(H, W, ws, shift, None, None, ids.ctypes.data_as(C.c_void_p)), "window_maps(region ids)")
     return ids
 
 
@@ -160,6 +170,8 @@ def _gemm_desc(kw):
     d.batch = int(kw.get("batch", 1))
     d.alpha = float(kw.get("alpha", 1.0))
     d.kernel = int(kw.get("kernel", FORCE_GEMM_KERNEL))
+    if d.kernel == GEMM_DMA8 and d.a_kstrided and "kernel" not in kw:
+        d.kernel = GEMM_AUTO  # FORCE_GEMM_KERNEL is a test / bench hook: the 8-wave tile has no weight-gradient instantiation
     return d
 
 
@@ -283,7 +295,7 @@ def colsum(x, *, out=None, accumulate=False):
     if out is None:
         out = torch.empty((N,), dtype=torch.float32, device=x.device)
         accumulate = False
-    ws = workspace(lib.esvit_colsum_blocks(rows) * N, x.device, slot=1)
+    ws = workspace(query(Q_COLSUM_BLOCKS, rows) * N, x.device, slot=1)
     check(lib.esvit_colsum(_code(x.dtype), _p(x), rows, N, N, _p(out), _p(ws), int(accumulate), _stream()), "colsum")
     return out
 
@@ -292,7 +304,7 @@ def colsum(x, *, out=None, accumulate=False):
 # fused MLP forward
 # ------------------------------------------------------------------------------------------------
 def mlp_fused_supported(dt, Cc):
-    return bool(lib.esvit_mlp_fused_supported(_code(dt), int(Cc)))
+    return bool(query(Q_MLP_FUSED, _code(dt), int(Cc)))
 
 
 def mlp_fused_fwd(x, gamma, beta, eps, W1, b1, W2, b2, *, rowscale=None):
@@ -338,10 +350,10 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, *, g_in=None, rowmap=None, period_in
     dx = torch.empty_like(x)
     gb = torch.empty((2, Cc), dtype=torch.float32, device=x.device)
     dgamma, dbeta = gb[0], gb[1]
-    ws = workspace(lib.esvit_layernorm_bwd_blocks(rows, Cc) * 2 * Cc, x.device, slot=1)
+    ws = workspace(query(Q_LN_BWD_BLOCKS, rows, Cc) * 2 * Cc, x.device, slot=1)
     check(lib.esvit_layernorm_bwd(_code(dy.dtype), _p(dy), _p(x), _p(mean), _p(rstd), _p(gamma), _p(g_in), rows, Cc, _p(dx),
                                   _p(dgamma), _p(dbeta), _p(ws), _p(rowmap), 0 if rowmap is None else rowmap.numel(),
-                                  period_in, _stream()), "layernorm_bwd")
+                                  period_in, None, None, 0, _stream()), "layernorm_bwd")
     return dx, dgamma, dbeta
 
 
@@ -353,9 +365,9 @@ def layernorm_bwd_cast(dy, x, mean, rstd, gamma, *, g_in=None, rowscale=None, ro
     dx = torch.empty_like(x)
     dxa = torch.empty((rows, Cc), dtype=dy.dtype, device=x.device)
     gb = torch.empty((2, Cc), dtype=torch.float32, device=x.device)
-    ws = workspace(lib.esvit_layernorm_bwd_blocks(rows, Cc) * 2 * Cc, x.device, slot=1)
-    check(lib.esvit_layernorm_bwd_cast(_code(dy.dtype), _p(dy), _p(x), _p(mean), _p(rstd), _p(gamma), _p(g_in), rows, Cc, _p(dx), _p(gb[0]),
-                                       _p(gb[1]), _p(ws), _p(dxa), _p(rowscale), rows_per_sample, _stream()), "layernorm_bwd_cast")
+    ws = workspace(query(Q_LN_BWD_BLOCKS, rows, Cc) * 2 * Cc, x.device, slot=1)
+    check(lib.esvit_layernorm_bwd(_code(dy.dtype), _p(dy), _p(x), _p(mean), _p(rstd), _p(gamma), _p(g_in), rows, Cc, _p(dx), _p(gb[0]),
+                                  _p(gb[1]), _p(ws), None, 0, 0, _p(dxa), _p(rowscale), rows_per_sample, _stream()), "layernorm_bwd(cast)")
     return dx, dxa, gb[0], gb[1]
 
 
@@ -394,7 +406,7 @@ def merge_ln_bwd(dy, x, mean, rstd, gamma, H, W, dx_out=None, gb_out=None, accum
     assert gb.shape == (2, 4 * Cc) and gb.is_contiguous()
     dgamma, dbeta = gb[0], gb[1]
     rows = nB * (H // 2) * (W // 2)
-    ws = workspace(lib.esvit_layernorm_bwd_blocks(rows, 4 * Cc) * 8 * Cc, x.device, slot=1)
+    ws = workspace(query(Q_LN_BWD_BLOCKS, rows, 4 * Cc) * 8 * Cc, x.device, slot=1)
     check(lib.esvit_merge_ln_bwd(_code(dy.dtype), _p(dy), _p(x), _p(mean), _p(rstd), _p(gamma), nB, H, W, Cc, _p(dx), _p(dgamma),
                                  _p(dbeta), _p(ws), int(acc), _stream()), "merge_ln_bwd")
     return dx, dgamma, dbeta
@@ -422,20 +434,8 @@ def cast_to_act(x, dtype=None):
     return out
 
 
-def cast_to_f32(x):
-    x = _actc(x)
-    out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
-    check(lib.esvit_cast_to_f32(_code(x.dtype), _p(x), _p(out), x.numel(), _stream()), "cast_to_f32")
-    return out
 
 
-def transpose_cast(w, dtype=None):
-    w = _f32c(w)
-    R, Cc = w.shape
-    dt = dtype or _ACT_DTYPE
-    out = torch.empty((Cc, R), dtype=dt, device=w.device)
-    check(lib.esvit_transpose_cast(_code(dt), _p(w), _p(out), R, Cc, _stream()), "transpose_cast")
-    return out
 
 
 def patch_im2col(img, P, Kpad, dtype=None, out=None):
@@ -476,26 +476,14 @@ def token_mean_bwd(g_mean, g_tok, T):
 # window attention
 # ------------------------------------------------------------------------------------------------
 def attn_frag_elems(N):
-    n = lib.esvit_attn_frag_elems(N)
+    n = query(Q_ATTN_FRAG_ELEMS, N)
     if n < 0:
         raise RuntimeError("window size with %d tokens is not supported by the HIP attention kernel yet" % N)
     return n
 
 
-def relpos_bias_fwd(table, index, N):
-    table = _f32c(table)
-    nH = table.shape[1]
-    out = torch.empty((nH, attn_frag_elems(N)), dtype=torch.float32, device=table.device)
-    check(lib.esvit_relpos_bias_fwd(_p(table), _p(index), N, nH, _p(out), _stream()), "relpos_bias_fwd")
-    return out
 
 
-def dense_to_frag(dense):
-    dense = _f32c(dense)
-    n, N, _ = dense.shape
-    out = torch.empty((n, attn_frag_elems(N)), dtype=torch.float32, device=dense.device)
-    check(lib.esvit_dense_to_frag(_p(dense), n, N, _p(out), _stream()), "dense_to_frag")
-    return out
 
 
 def window_attn_fwd(qkv, qkv_bias, win2tok, L, rel_table, ws, region_ids, nW, N, nH, scale, want_attn=False, out=None):
@@ -509,7 +497,7 @@ def window_attn_fwd(qkv, qkv_bias, win2tok, L, rel_table, ws, region_ids, nW, N,
         out = torch.empty((rows, Cc), dtype=qkv.dtype, device=qkv.device)
     assert out.shape == (rows, Cc) and out.dtype == qkv.dtype and out.is_contiguous()  # may be a row slice of a larger matrix
     attn = torch.empty((nB * nW, nH, N, N), dtype=torch.float32, device=qkv.device) if want_attn else None
-    nl = lib.esvit_window_attn_lse_elems(N)
+    nl = query(Q_ATTN_LSE_ELEMS, N)
     lse = torch.empty((nB * nW * nH, nl), dtype=torch.float32, device=qkv.device) if nl else None
     bias_ws = workspace(2 * nH * attn_frag_elems(N), qkv.device, slot=2)  # frag-layout relative-position bias of every head
     check(lib.esvit_window_attn_fwd(_code(qkv.dtype), _p(qkv), _p(_f32c(qkv_bias)), _p(win2tok), L, _p(_f32c(rel_table)), ws, _p(bias_ws),
@@ -527,11 +515,11 @@ def window_attn_bwd(qkv, qkv_bias, win2tok, L, dout, fwd_out, lse, rel_table, ws
     code = _code(qkv.dtype)
     dqkv = torch.empty_like(qkv) if dqkv_out is None else dqkv_out
     assert dqkv.shape == qkv.shape and dqkv.dtype == qkv.dtype and dqkv.is_contiguous()
-    parts = lib.esvit_window_attn_bwd_parts(N, nB * nW, nH)
+    parts = query(Q_ATTN_BWD_PARTS, N, nB * nW, nH)
     dbias_ws = torch.empty((parts, nH, attn_frag_elems(N)), dtype=torch.float32, device=qkv.device)
     # the <= 64-token kernel writes every element of its pad-row slab itself; the 14x14 kernels fill one head's slice per row
     alloc = torch.empty if N <= 64 else torch.zeros
-    pad = alloc((lib.esvit_window_attn_bwd_pad_rows(code, N, nB * nW, nH), 2 * Cc), dtype=torch.float32, device=qkv.device)
+    pad = alloc((query(Q_ATTN_BWD_PAD_ROWS, N, nB * nW, nH | (code << 32)), 2 * Cc), dtype=torch.float32, device=qkv.device)
     bias_ws = workspace(2 * nH * attn_frag_elems(N), qkv.device, slot=2)
     check(lib.esvit_window_attn_bwd(code, _p(qkv), _p(_f32c(qkv_bias)), _p(win2tok), L, _p(dout), _p(fwd_out), _p(lse), _p(_f32c(rel_table)),
                                     ws, _p(bias_ws), _p(region_ids), nW, nB, N, nH, Cc // nH, scale, _p(dqkv), _p(dbias_ws), _p(pad),
@@ -602,13 +590,6 @@ def teacher_row_stats(t, center, inv_temp):
     return mx, lse
 
 
-def row_argmax(sim, Tt):
-    sim = _f32c(sim)
-    ld = sim.shape[-1]
-    rows = sim.numel() // ld
-    idx = torch.empty((rows,), dtype=torch.int32, device=sim.device)
-    check(lib.esvit_row_argmax(_p(sim), rows, Tt, ld, _p(idx), _stream()), "row_argmax")
-    return idx
 
 
 def region_match(sim, Tt, crop_id, cm_row, tmatch):
@@ -656,7 +637,7 @@ def center_ema(center, colsum_, momentum, denom):
 # fused update
 # ------------------------------------------------------------------------------------------------
 def update_chunk_elems():
-    return lib.esvit_update_chunk_elems()
+    return query(Q_UPDATE_CHUNK_ELEMS)
 
 
 def grad_sqnorm(tensors, ntensors, chunks, nchunks, sqnorms):
@@ -714,7 +695,7 @@ def dwconv3x3_wgrad(x, dy, nB, H, W):
     Cc = x.shape[1]
     assert x.dtype == dy.dtype and x.shape == dy.shape
     dw = torch.empty((Cc, 9), dtype=torch.float32, device=x.device)
-    ws = workspace(lib.esvit_col_reduce_blocks(nB * H * W) * 9 * Cc, x.device, slot=1)
+    ws = workspace(query(Q_COL_REDUCE_BLOCKS, nB * H * W) * 9 * Cc, x.device, slot=1)
     check(lib.esvit_dwconv3x3_wgrad(_code(x.dtype), _p(x), _p(dy), nB, H, W, Cc, _p(dw), _p(ws), _stream()), "dwconv3x3_wgrad")
     return dw
 
@@ -725,7 +706,7 @@ def col_sums2(a, b):
     rows, Cc = a.shape
     assert a.dtype == b.dtype and a.shape == b.shape
     out = torch.empty((2, Cc), dtype=torch.float32, device=a.device)
-    ws = workspace(lib.esvit_col_reduce_blocks(rows) * 2 * Cc, a.device, slot=1)
+    ws = workspace(query(Q_COL_REDUCE_BLOCKS, rows) * 2 * Cc, a.device, slot=1)
     check(lib.esvit_col_sums2(_code(a.dtype), _p(a), _p(b), rows, Cc, _p(out), _p(ws), _stream()), "col_sums2")
     return out
 

@@ -20,6 +20,7 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+#pragma GCC visibility push(default) /* the library is built with -fvisibility=hidden: this header IS the export list */
 
 #define ESVIT_F32 0
 #define ESVIT_BF16 1
@@ -34,6 +35,27 @@ typedef void* esvit_stream_t; /* hipStream_t */
 /* ---- library ---------------------------------------------------------- */
 int esvit_version(void);
 const char* esvit_last_error(void);
+/* Sizes of caller-allocated scratch / capability questions, one entry point (no device work, no state):
+ *   ESVIT_Q_ATTN_FRAG_ELEMS (N)                floats per N x N matrix in MFMA fragment order (4096 for N <= 64), -1 unsupported
+ *   ESVIT_Q_ATTN_LSE_ELEMS (N)                 per-(window, head) log-sum-exp floats the forward writes (0 for N <= 64)
+ *   ESVIT_Q_ATTN_BWD_PARTS (N, Bw, nH)         leading dimension of dbias_ws of esvit_window_attn_bwd
+ *   ESVIT_Q_ATTN_BWD_PAD_ROWS (N, Bw, nH | dtype << 32)  rows of dpad_ws of esvit_window_attn_bwd
+ *   ESVIT_Q_LN_BWD_BLOCKS (rows, C)            nblk of the [nblk, 2, C] LayerNorm-backward scratch
+ *   ESVIT_Q_COLSUM_BLOCKS (rows)               blocks of the esvit_colsum scratch
+ *   ESVIT_Q_COL_REDUCE_BLOCKS (rows)           blocks of the esvit_dwconv3x3_wgrad / esvit_col_sums2 scratch
+ *   ESVIT_Q_UPDATE_CHUNK_ELEMS ()              elements per chunk of the fused update's chunk table
+ *   ESVIT_Q_MLP_FUSED (dtype, C)               1 where esvit_mlp_fused_fwd exists (bf16, C in {96, 192})
+ * Unknown `what` returns ESVIT_ERR_ARG. */
+#define ESVIT_Q_ATTN_FRAG_ELEMS 1
+#define ESVIT_Q_ATTN_LSE_ELEMS 2
+#define ESVIT_Q_ATTN_BWD_PARTS 3
+#define ESVIT_Q_ATTN_BWD_PAD_ROWS 4
+#define ESVIT_Q_LN_BWD_BLOCKS 5
+#define ESVIT_Q_COLSUM_BLOCKS 6
+#define ESVIT_Q_COL_REDUCE_BLOCKS 7
+#define ESVIT_Q_UPDATE_CHUNK_ELEMS 8
+#define ESVIT_Q_MLP_FUSED 9
+int64_t esvit_query(int what, int64_t a, int64_t b, int64_t c);
 
 /* ---- host-side integer index maps (bit-exact vs reference) -------------
  * swin_transformer.py:100-110 (relative_position_index), :40-69 + :286-325
@@ -41,13 +63,13 @@ const char* esvit_last_error(void);
 /* out[N*N], N = ws*ws */
 int esvit_relative_position_index(int ws, int64_t* out);
 /* win2tok[nW*N]: source token (i*W+j) for every window slot, -1 for zero-pad slots.
- * tok2win[H*W]: window slot of every real token.  Either pointer may be NULL. */
-int esvit_window_maps(int H, int W, int ws, int shift, int32_t* win2tok, int32_t* tok2win);
+ * tok2win[H*W]: window slot of every real token.
+ * region_ids[nW*N] (shift > 0 only): region label of every window slot; mask[w,p,q] = (ids[w,p] == ids[w,q]) ? 0 : -100
+ * (what the attention kernels consume: the 49x49 mask is rebuilt in registers instead of being loaded).
+ * Any of the three pointers may be NULL. */
+int esvit_window_maps(int H, int W, int ws, int shift, int32_t* win2tok, int32_t* tok2win, int32_t* region_ids);
 /* mask[nW*N*N] in {0,-100}; returns nW through *n_windows */
 int esvit_shift_mask(int H, int W, int ws, int shift, float* mask, int* n_windows);
-/* ids[nW*N]: region label of every window slot; mask[w,p,q] = (ids[w,p] == ids[w,q]) ? 0 : -100 (what the attention
- * kernels consume: the 49x49 mask is rebuilt in registers instead of being loaded) */
-int esvit_shift_region_ids(int H, int W, int ws, int shift, int32_t* ids, int* n_windows);
 
 /* ---- MFMA GEMM family -------------------------------------------------- */
 #define ESVIT_EPI_NONE 0
@@ -107,8 +129,7 @@ int esvit_gemm_select(int dtype, const esvit_gemm_desc* d, int* tile_m, int* til
  * save nothing for a backward (the EMA teacher): the unfused LayerNorm -> fc1 (+GELU) -> fc2 (+residual) sequence is bound
  * there by the HBM round trips of the 4C-wide hidden activation (32 B per token-channel against 8 fused).
  * x, y fp32 [M, C]; W1 [4C, C], W2 [C, 4C] in the activation dtype; gamma, beta, b1, b2 fp32; rowscale fp32 [M] or NULL.
- * esvit_mlp_fused_supported: 1 where the kernel exists (bf16, C in {96, 192}). */
-int esvit_mlp_fused_supported(int dtype, int C);
+ * esvit_query(ESVIT_Q_MLP_FUSED, dtype, C, 0): 1 where the kernel exists (bf16, C in {96, 192}). */
 int esvit_mlp_fused_fwd(int dtype, const float* x, const float* gamma, const float* beta, float eps, const void* W1,
                         const float* b1, const void* W2, const float* b2, const float* rowscale, int64_t M, int C, float* y,
                         esvit_stream_t stream);
@@ -123,20 +144,15 @@ int esvit_layernorm_fwd(int dtype, const float* x, const float* gamma, const flo
                         int64_t rows, int C, void* y, float* y_f32, float* mean, float* rstd,
                         const int32_t* rowmap, int tokens, int period_out, esvit_stream_t stream);
 /* LayerNorm backward.  dy (dtype) is read at the mapped row when rowmap is given.
- * dx = g_in (optional fp32 residual gradient) + LN'(dy).  dgamma/dbeta partials are
- * written to ws ([nblk,2,C] floats, nblk returned via esvit_layernorm_bwd_blocks) and
- * reduced into dgamma/dbeta (fp32, overwritten). */
-int esvit_layernorm_bwd_blocks(int64_t rows, int C);
+ * dx = g_in (optional fp32 residual gradient) + LN'(dy).  dgamma/dbeta partials are written to ws ([nblk,2,C] floats,
+ * nblk = esvit_query(ESVIT_Q_LN_BWD_BLOCKS, rows, C, 0)) and reduced into dgamma/dbeta (fp32, overwritten).
+ * dx_act (optional, activation dtype, un-mapped rows only) = rowscale[row / rows_per_sample] * dx: the DropPath-scaled
+ * copy the next dgrad / wgrad GEMMs of the backward read (rowscale may be NULL = 1) -- saves one esvit_gather_cast pass. */
 int esvit_layernorm_bwd(int dtype, const void* dy, const float* x, const float* mean, const float* rstd,
                         const float* gamma, const float* g_in, int64_t rows, int C, float* dx,
                         float* dgamma, float* dbeta, float* ws, const int32_t* rowmap, int tokens,
-                        int period_in, esvit_stream_t stream);
-/* same, and additionally dx_act (activation dtype) = rowscale[row / rows_per_sample] * dx: the DropPath-scaled copy the next
- * dgrad / wgrad GEMMs of the backward read (rowscale may be NULL = 1) -- saves one esvit_gather_cast pass over dx */
-int esvit_layernorm_bwd_cast(int dtype, const void* dy, const float* x, const float* mean, const float* rstd,
-                             const float* gamma, const float* g_in, int64_t rows, int C, float* dx, float* dgamma,
-                             float* dbeta, float* ws, void* dx_act, const float* rowscale, int rows_per_sample,
-                             esvit_stream_t stream);
+                        int period_in, void* dx_act, const float* rowscale, int rows_per_sample,
+                        esvit_stream_t stream);
 
 /* ---- element-wise / data-movement helpers ------------------------------ */
 /* dst[r,:] = cast(scale[r/rows_per_sample] * src[map(r),:]); src fp32 [*, C]; dst dtype [rows, C].
@@ -145,13 +161,9 @@ int esvit_layernorm_bwd_cast(int dtype, const void* dy, const float* x, const fl
 int esvit_gather_cast(int dtype, const float* src, void* dst, int64_t rows, int C, const int32_t* rowmap,
                       int period, int tokens, const float* rowscale, int rows_per_sample,
                       esvit_stream_t stream);
-/* plain casts between fp32 and activation dtype (weight caches) */
+/* plain cast fp32 -> activation dtype (weight caches) */
 int esvit_cast_f32_to(int dtype, const float* src, void* dst, int64_t n, esvit_stream_t stream);
-int esvit_cast_to_f32(int dtype, const void* src, float* dst, int64_t n, esvit_stream_t stream);
-/* dst[C,R] = cast(src[R,C])^T -- cached W^T for the dgrad GEMMs */
-int esvit_transpose_cast(int dtype, const float* src, void* dst, int R, int C, esvit_stream_t stream);
-/* out[n] (+)= sum_r x[r,n]  (bias gradients).  ws >= esvit_colsum_blocks(rows)*N floats */
-int esvit_colsum_blocks(int64_t rows);
+/* out[n] (+)= sum_r x[r,n]  (bias gradients).  ws >= esvit_query(ESVIT_Q_COLSUM_BLOCKS, rows, 0, 0)*N floats */
 int esvit_colsum(int dtype, const void* x, int64_t rows, int N, int64_t ld, float* out, float* ws,
                  int accumulate, esvit_stream_t stream);
 
@@ -180,42 +192,31 @@ int esvit_token_mean_bwd(const float* g_mean, const float* g_tok, int nB, int T,
  * "frag layout" of an NP x NP matrix X[q][key] (NP = 64 for 7x7 windows): the order in which the
  * MFMA accumulators of the transposed score tile hold it,
  *   X_frag[((ki*4 + qj)*64 + lane)*4 + r] = X[q = 16*qj + c][key = 16*ki + 4*g + r], lane = 16*g + c.
- * esvit_attn_frag_elems(N) = floats per matrix in that layout (4096), -1 if N is unsupported. */
-int esvit_attn_frag_elems(int N);
-/* dense relative-position bias in frag layout (swin_transformer.py:133-135): table fp32
- * [(2ws-1)^2, nH], index int64 [N*N] -> bias_frag fp32 [nH, frag]; key columns >= N get -1e30. */
-int esvit_relpos_bias_fwd(const float* table, const int64_t* index, int N, int nH, float* bias_frag,
-                          esvit_stream_t stream);
-/* dense fp32 [n_mats, N, N] -> frag layout [n_mats, frag] (zero padded); used once per geometry
- * for the shift mask of swin_transformer.py:249-272. */
-int esvit_dense_to_frag(const float* dense, int n_mats, int N, float* frag, esvit_stream_t stream);
+ * esvit_query(ESVIT_Q_ATTN_FRAG_ELEMS, N, 0, 0) = floats per matrix in that layout (4096), -1 if N is unsupported. */
 /* Token-ordered window attention.  qkv dtype [nB*L, 3C] (columns [3][nH][hd]) -> out dtype [nB*L, C].
  * win2tok int32 [nW*N] (esvit_window_maps): window slot -> token of the image, -1 for a zero-pad slot; this map
  * IS pad -> roll -> window_partition and its inverse (swin_transformer.py:286-325), applied on the fly.
  * qkv_bias fp32 [3C]: the value of q,k,v at a zero-pad slot (LayerNorm output is zero-padded, so qkv = bias there;
  * pad keys/values take part in every softmax exactly as in the reference, pad query rows are dropped).
  * rel_table fp32 [(2ws-1)^2, nH] is the relative_position_bias_table parameter itself (swin_transformer.py:133-136,
- * index in closed form).  bias_frag_ws (required): fp32 scratch [2, nH, esvit_attn_frag_elems(N)] the library fills with
+ * index in closed form).  bias_frag_ws (required): fp32 scratch [2, nH, ESVIT_Q_ATTN_FRAG_ELEMS(N)] the library fills with
  * the bias in MFMA fragment order (one 16-byte load per lane per score tile instead of table gathers in the kernel).
- * region_ids int32 [nW*N] (esvit_shift_region_ids) for shifted blocks or NULL.
+ * region_ids int32 [nW*N] (esvit_window_maps) for shifted blocks or NULL.
  * scale: applied to q before the product (swin_transformer.py:130: hd^-0.5; CvT passes dim^-0.5).  N = ws*ws <= 64 with
  * hd in {32, 64} (7x7 Swin windows; 7x7 / 6x6 / 3x3 CvT windows at hd 64), or N = 196 (14x14) with hd = 32.
- * lse fp32 [nB*nW*nH, esvit_window_attn_lse_elems(N)]: per-query log-sum-exp, written for 14x14 windows (the blocked
+ * lse fp32 [nB*nW*nH, ESVIT_Q_ATTN_LSE_ELEMS(N)]: per-query log-sum-exp, written for 14x14 windows (the blocked
  * backward needs it), unused (may be NULL) for 7x7.  One image's qkv rows (L * 3C activations) must fit a 2 GiB buffer
  * descriptor.
  * attn_out (optional, fp32 [nB*nW,nH,N,N]) receives the softmax (swin_transformer.py:146,152). */
-int esvit_window_attn_lse_elems(int N);
 int esvit_window_attn_fwd(int dtype, const void* qkv, const float* qkv_bias, const int32_t* win2tok, int L,
                           const float* rel_table, int ws, float* bias_frag_ws, const int32_t* region_ids, int nW, int nB,
                           int N, int nH, int hd, float scale, void* out, float* lse, float* attn_out,
                           esvit_stream_t stream);
 /* dout dtype [nB*L, C] -> dqkv dtype [nB*L, 3C] (every row written).  fwd_out / lse: the forward's outputs (needed for
- * 14x14 windows only).  Partials: dbias_ws fp32 [esvit_window_attn_bwd_parts(N, nB*nW, nH), nH, frag]
+ * 14x14 windows only).  Partials: dbias_ws fp32 [ESVIT_Q_ATTN_BWD_PARTS(N, nB*nW, nH), nH, frag]
  * (relative-position-bias gradient, reduced by esvit_relpos_bias_bwd) and dpad_ws fp32
- * [esvit_window_attn_bwd_pad_rows(dtype, N, nB*nW, nH), 2C], ZERO-INITIALISED by the caller: sums of the dK / dV rows
+ * [ESVIT_Q_ATTN_BWD_PAD_ROWS(N, nB*nW, nH | dtype << 32), 2C], ZERO-INITIALISED by the caller: sums of the dK / dV rows
  * of zero-pad slots, layout [k|v][nH][hd] -- gradients of qkv_bias[C:3C] (column-sum them into the bias gradient). */
-int esvit_window_attn_bwd_parts(int N, int Bw, int nH);
-int esvit_window_attn_bwd_pad_rows(int dtype, int N, int Bw, int nH);
 int esvit_window_attn_bwd(int dtype, const void* qkv, const float* qkv_bias, const int32_t* win2tok, int L,
                           const void* dout, const void* fwd_out, const float* lse, const float* rel_table, int ws,
                           float* bias_frag_ws, const int32_t* region_ids, int nW, int nB, int N, int nH, int hd,
@@ -245,10 +246,7 @@ int esvit_weightnorm_bwd(const float* dw, const float* v, const float* g, const 
  * for row r: mx[r] = max_k (t[r,k]-c[k])/temp ; lse[r] = log sum exp(.. - mx) */
 int esvit_teacher_row_stats(int dtype, const void* t, const float* center, float inv_temp, int64_t R,
                             int K, float* row_max, float* row_lse, esvit_stream_t stream);
-/* region matching (main_esvit.py:735-736): sim fp32 [P, Ts, ldsim] -> idx int32 [P*Ts] =
- * argmax over first Tt columns (first index on ties) */
-int esvit_row_argmax(const float* sim, int64_t rows, int Tt, int ld, int32_t* idx, esvit_stream_t stream);
-/* fused argmax + row assembly for the region loss: sim fp32 [B, S, ld] holds, for image b, the cosine
+/* region matching (main_esvit.py:735-736), fused argmax (first index on ties) + row assembly for the region loss: sim fp32 [B, S, ld] holds, for image b, the cosine
  * similarities of its S student tokens (all crops, image-major) against the 2*Tt teacher tokens
  * (view 0 then view 1).  For student position s of crop crop_id[s] and teacher view iq:
  *   tmatch[cm_row[b*S+s]*2 + iq] = crop_id[s]==iq ? -1 : iq*B*Tt + b*Tt + argmax_j sim[b,s,iq*Tt+j]
@@ -281,8 +279,7 @@ int esvit_center_ema(float* center, const float* colsum, float momentum, float d
  *    bits(1-beta1^t) | bits(1-beta2^t) << 32, reserved,
  *    bf16 copy of p (0 = none), bf16 copy of teacher_p (0 = none)]   -- the copies are refreshed in the same pass
  * chunk table (device, int32[nchunks*2]): [tensor_id, chunk_index], chunk =
- * esvit_update_chunk_elems() elements.  sqnorms: fp32 scratch [ntensors]. */
-int esvit_update_chunk_elems(void);
+ * esvit_query(ESVIT_Q_UPDATE_CHUNK_ELEMS, 0, 0, 0) elements.  sqnorms: fp32 scratch [ntensors]. */
 int esvit_grad_sqnorm(const int64_t* tensors, int ntensors, const int32_t* chunks, int nchunks,
                       float* sqnorms, esvit_stream_t stream);
 int esvit_fused_clip_adamw_ema(const int64_t* tensors, int ntensors, const int32_t* chunks, int nchunks,
@@ -296,9 +293,9 @@ int esvit_fused_clip_adamw_ema(const int64_t* tensors, int ntensors, const int32
  *   the image and in the tail columns [k*k*Cin, Kpad); src = fp32 NCHW images (nchw=1) or activation-dtype NHWC tokens.
  * esvit_conv_col2im: the adjoint, dsrc fp32 NHWC [nB,H,W,Cin].
  * esvit_dwconv3x3: y[b,y,x,c] = sum_t w[c][t] x[b,y+ky-1,x+kx-1,c] (stride 1, zero pad 1); flip=1 applies the taps
- *   mirrored (the data gradient).  esvit_dwconv3x3_wgrad: dw[c][t]; ws: fp32 [esvit_col_reduce_blocks(rows)*9*C].
+ *   mirrored (the data gradient).  esvit_dwconv3x3_wgrad: dw[c][t]; ws: fp32 [ESVIT_Q_COL_REDUCE_BLOCKS(rows)*9*C].
  * esvit_col_sums2: out[0..C) = sum_r a[r][c], out[C..2C) = sum_r a[r][c]*b[r][c]  (BatchNorm statistics: b = a;
- *   BatchNorm backward: a = dy, b = pre-norm activations); ws: fp32 [esvit_col_reduce_blocks(rows)*2*C].
+ *   BatchNorm backward: a = dy, b = pre-norm activations); ws: fp32 [ESVIT_Q_COL_REDUCE_BLOCKS(rows)*2*C].
  * esvit_col_affine2: y = a1[c]*x1 + a2[c]*x2 + a3[c]  (x2 may be null). */
 int esvit_conv_im2col(int dtype, const void* src, int nchw, int nB, int H, int W, int Cin, int k, int stride, int pad,
                       int Ho, int Wo, int Kpad, void* cols, esvit_stream_t stream);
@@ -306,7 +303,6 @@ int esvit_conv_col2im(int dtype, const void* dcols, int nB, int H, int W, int Ci
                       int Wo, int Kpad, float* dsrc, esvit_stream_t stream);
 int esvit_dwconv3x3(int dtype, const void* x, const float* w, int flip, int nB, int H, int W, int C, void* y,
                     esvit_stream_t stream);
-int esvit_col_reduce_blocks(int64_t rows);
 int esvit_dwconv3x3_wgrad(int dtype, const void* x, const void* dy, int nB, int H, int W, int C, float* dw, float* ws,
                           esvit_stream_t stream);
 int esvit_col_sums2(int dtype, const void* a, const void* b, int64_t rows, int C, float* out, float* ws,
@@ -330,6 +326,7 @@ int esvit_bn_bwd_local(const float* sums, const float* coef, int C, float* red, 
 int esvit_bn_bwd_coeffs(const float* red, float n, const float* gamma, const float* coef, int C, float* abc,
                         esvit_stream_t stream);
 
+#pragma GCC visibility pop
 #ifdef __cplusplus
 }
 #endif

@@ -42,12 +42,12 @@ def _rand(shape, dev, seed, dt=torch.float32, scale=1.0):
     return (torch.randn(shape, generator=g) * scale).to(dev).to(dt)
 
 
-@pytest.fixture(params=[0, 3, 2, 4, 1], ids=["auto", "dma8", "dma4", "dma4w", "regstage"])
+@pytest.fixture(params=[0, 3, 2, 4], ids=["auto", "dma8", "dma4", "dma4w"])
 def gemm_path(request, mods):
-    """every bf16 GEMM main loop on every shape: the library's own choice, the 8-wave 256-row LDS-DMA loop, the 4-wave
-    128-row LDS-DMA loop in both wave layouts (2 x 2; whole-width wave rows for N % 96 == 0) and the register-staged
-    loop, forced through esvit_gemm_desc.kernel (the library keeps no state);
-    the exact-fp32 mode has one main loop and ignores the selector"""
+    """every bf16 GEMM main loop on every shape: the library's own choice, the 8-wave 256-row LDS-DMA loop (forward / dgrad
+    layouts; it is not instantiated for the weight gradients, which then take the library's choice) and the 4-wave
+    128-row LDS-DMA loop in both wave layouts (2 x 2; whole-width wave rows for N % 96 == 0), forced through
+    esvit_gemm_desc.kernel (the library keeps no state); the exact-fp32 mode has one main loop (the register-staged one)"""
     ops, _ = mods
     ops.FORCE_GEMM_KERNEL = request.param
     yield request.param
@@ -269,10 +269,8 @@ def test_small_ops(mods, dt):
     _close("mean bwd", ops.token_mean_bwd(gm, gt, 49), ref.token_mean_bwd(gm, gt, 49), 2e-5)
     w = _rand((300, 520), dev, 44)
     _close("cast", ops.cast_to_act(w, dtype=dt), ref.cast_to_act(w, dtype=dt), _tol(dt, bf=8e-3))
-    _close("transpose", ops.transpose_cast(w, dtype=dt), ref.transpose_cast(w, dtype=dt), _tol(dt, bf=8e-3))
     xa = _rand((1300, 288), dev, 45, dt)
     _close("colsum", ops.colsum(xa), ref.colsum(xa), 5e-5)
-    _close("cast_to_f32", ops.cast_to_f32(xa), ref.cast_to_f32(xa), 1e-7)
     v = _rand((777,), dev, 46)
     _close("sum", ops.sum_f32(v), ref.sum_f32(v), 1e-5)
     xs, xs2 = xa.clone(), xa.clone()
@@ -305,9 +303,6 @@ def test_window_attention(mods, dt, ws, nH, H, shift, hd):
     trows = (2 * ws - 1) ** 2
     table = _rand((trows, nH), dev, 51) * 0.5
     index = torch.from_numpy(ops.relative_position_index(ws)).to(dev)
-    if ws == 7 and hd == 32:
-        bias = ops.relpos_bias_fwd(table, index, N)
-        _close("bias frag", bias.clamp(min=-1e4), ref.relpos_bias_fwd(table, index, N).clamp(min=-1e4), 1e-6)
     mask_frag = None
     if shift:
         ids_np = ops.shift_region_ids(H, H, ws, shift)
@@ -315,8 +310,6 @@ def test_window_attention(mods, dt, ws, nH, H, shift, hd):
         mask_frag = torch.from_numpy(ids_np).to(dev)  # the kernels rebuild the 0/-100 mask from the region labels
         m_np = ops.shift_mask(H, H, ws, shift)
         assert np.array_equal(np.where(ids_np.reshape(nW, N, 1) == ids_np.reshape(nW, 1, N), 0.0, -100.0).astype(np.float32), m_np)
-        if ws == 7:
-            _close("mask frag", ops.dense_to_frag(torch.from_numpy(m_np).to(dev)), ref.dense_to_frag(torch.from_numpy(m_np).to(dev)), 1e-6)
     scale = hd ** -0.5
     o, lse, attn = ops.window_attn_fwd(qkv, qb, w2t, L, table, ws, mask_frag, nW, N, nH, scale, want_attn=True)
     orf, _, attnr = ref.window_attn_fwd(qkv, qb, w2t, L, table, ws, mask_frag, nW, N, nH, scale, want_attn=True)
@@ -430,8 +423,6 @@ def test_dino_loss_kernels(mods, dt, K):
     rlr, dsr = ref.dino_ce(s, t, center, mxr, lser, tm, w, 10.0, 25.0)
     _close("row loss", rl, rlr, 2e-5)
     _close("ds", ds, dsr, _tol(dt, f32=2e-4, bf=1e-2))
-    sim = _rand((200, 64), dev, 74)
-    assert torch.equal(ops.row_argmax(sim, 49), ref.row_argmax(sim, 49))
 
 
 def test_index_maps_match_restatement(mods):

@@ -27,3 +27,7 @@ for ev in prof.events():
         cnt[(ev.name, inner[-70:])] += 1
 for k, v in cnt.most_common(40):
     print(v, k)
+print("---- all ops by count ----")
+allc = collections.Counter(ev.name for ev in prof.events())
+for k, v in allc.most_common(45):
+    print(v, k[:110])
