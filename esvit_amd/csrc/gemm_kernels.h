@@ -838,8 +838,8 @@ __device__ __forceinline__ void wait_vmcnt() {
 
 // NBUF-deep ring of LDS tiles: NBUF-1 tiles are requested ahead; per k-tile ONE counted wait (only for the tile
 // about to be consumed -- later tiles stay in flight across the barrier) and ONE barrier.
-template <bool AKS, bool BKS, int BM, int BN, int BKD, int NBUF, int WM, int WN>
-__global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8 ? 2 : 2)) void gemm_dma_kernel(const esvit_gemm_desc p, const int group_m) {
+template <bool AKS, bool BKS, int BM, int BN, int BKD, int NBUF, int WM, int WN, int MINB = 2>
+__global__ __launch_bounds__(64 * WM * WN, MINB) void gemm_dma_kernel(const esvit_gemm_desc p, const int group_m) {
     constexpr int NT = 64 * WM * WN;
     using TA = DmaTile<AKS, BM, BKD, NT>;
     using TB = DmaTile<BKS, BN, BKD, NT>;
@@ -1047,7 +1047,7 @@ int launch_gemm(const esvit_gemm_desc& d, hipStream_t stream) {
     return ESVIT_OK;
 }
 
-template <bool AKS, bool BKS, int BM, int BN, int BKD, int NBUF, int WM, int WN>
+template <bool AKS, bool BKS, int BM, int BN, int BKD, int NBUF, int WM, int WN, int MINB = 2>
 int launch_gemm_dma(const esvit_gemm_desc& d, hipStream_t stream) {
     constexpr int NT = 64 * WM * WN;
     using TA = DmaTile<AKS, BM, BKD, NT>;
@@ -1055,7 +1055,7 @@ int launch_gemm_dma(const esvit_gemm_desc& d, hipStream_t stream) {
     size_t lds = (size_t)NBUF * (TA::ELEMS + TB::ELEMS) * 2;
     const size_t stage_bytes = (size_t)WM * WN * 16 * (size_t)(BN / WN + 4) * sizeof(float);  // epilogue staging, one region per wave
     if (lds < stage_bytes) lds = stage_bytes;
-    auto kern = gemm_dma_kernel<AKS, BKS, BM, BN, BKD, NBUF, WM, WN>;
+    auto kern = gemm_dma_kernel<AKS, BKS, BM, BN, BKD, NBUF, WM, WN, MINB>;
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
