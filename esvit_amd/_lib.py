@@ -54,7 +54,7 @@ SIGNATURES = {
     "esvit_dwconv3x3": (C.c_int, [C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
     "esvit_dwconv3x3_wgrad": (C.c_int, [C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp]),
     "esvit_col_sums2": (C.c_int, [C.c_int, vp, vp, i64, C.c_int, vp, vp, vp]),
-    "esvit_col_affine2": (C.c_int, [C.c_int, vp, vp, i64, C.c_int, vp, vp, vp, vp, vp]),
+    "esvit_col_affine2": (C.c_int, [C.c_int, vp, vp, i64, C.c_int, vp, vp, vp, C.c_int, vp, vp]),
     "esvit_pad_crop_tokens": (C.c_int, [C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
     "esvit_bn_fwd_coeffs": (C.c_int, [vp, f32, vp, vp, f32, f32, vp, vp, C.c_int, vp, vp]),
     "esvit_bn_eval_coeffs": (C.c_int, [vp, vp, vp, vp, f32, C.c_int, vp, vp]),

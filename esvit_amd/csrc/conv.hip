@@ -176,13 +176,20 @@ __global__ __launch_bounds__(256) void col_sums2_kernel(const T* __restrict__ a,
     }
 }
 
-template <typename T>
+// ACT 0: y = a1 x1 + a2 x2 + a3;  1: y = GELU(a1 x1 + a3);  2: y = x2 * GELU'(a1 x1 + a3)
+template <typename T, int ACT>
 __global__ void col_affine2_kernel(const T* __restrict__ x1, const T* __restrict__ x2, long n, int C, const float* __restrict__ a1,
                                    const float* __restrict__ a2, const float* __restrict__ a3, T* __restrict__ y) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
         const int c = (int)(i % C);
         float v = a1[c] * to_f32(x1[i]) + a3[c];
-        if (x2) v += a2[c] * to_f32(x2[i]);
+        if constexpr (ACT == 0) {
+            if (x2) v += a2[c] * to_f32(x2[i]);
+        } else if constexpr (ACT == 1) {
+            v = gelu_f(v);
+        } else {
+            v = to_f32(x2[i]) * gelu_grad_f(v);
+        }
         y[i] = from_f32<T>(v);
     }
 }
@@ -374,18 +381,26 @@ extern "C" int esvit_col_sums2(int dtype, const void* a, const void* b, int64_t 
     return esvit_partial_reduce(ws, nblk, 2 * C, 2L * C, out, 0, stream);
 }
 
+template <typename T>
+static void launch_col_affine2(int act, const void* x1, const void* x2, long n, int C, const float* a1, const float* a2, const float* a3,
+                               void* y, hipStream_t stream) {
+    const T* p1 = reinterpret_cast<const T*>(x1);
+    const T* p2 = reinterpret_cast<const T*>(x2);
+    T* py = reinterpret_cast<T*>(y);
+    if (act == 1) hipLaunchKernelGGL((col_affine2_kernel<T, 1>), dim3(grid_for(n)), dim3(256), 0, stream, p1, p2, n, C, a1, a2, a3, py);
+    else if (act == 2) hipLaunchKernelGGL((col_affine2_kernel<T, 2>), dim3(grid_for(n)), dim3(256), 0, stream, p1, p2, n, C, a1, a2, a3, py);
+    else hipLaunchKernelGGL((col_affine2_kernel<T, 0>), dim3(grid_for(n)), dim3(256), 0, stream, p1, p2, n, C, a1, a2, a3, py);
+}
+
 extern "C" int esvit_col_affine2(int dtype, const void* x1, const void* x2, int64_t rows, int C, const float* a1, const float* a2,
-                                 const float* a3, void* y, esvit_stream_t s_) {
+                                 const float* a3, int act, void* y, esvit_stream_t s_) {
     STREAM(s_);
-    ESVIT_CHECK_ARG(x1 && a1 && a3 && y && rows > 0 && C > 0 && (!x2 || a2), "esvit_col_affine2: bad args");
+    ESVIT_CHECK_ARG(x1 && a1 && a3 && y && rows > 0 && C > 0 && act >= 0 && act <= 2, "esvit_col_affine2: bad args");
+    ESVIT_CHECK_ARG(act == 0 ? (!x2 || a2) : (act == 1 ? !x2 : x2 != nullptr), "esvit_col_affine2: x2 / a2 do not fit act=%d", act);
     ESVIT_CHECK_ARG(dtype == ESVIT_BF16 || dtype == ESVIT_F32, "esvit_col_affine2: bad dtype");
     const long n = (long)rows * C;
-    if (dtype == ESVIT_BF16)
-        hipLaunchKernelGGL(col_affine2_kernel<bf16>, dim3(grid_for(n)), dim3(256), 0, stream, reinterpret_cast<const bf16*>(x1),
-                           reinterpret_cast<const bf16*>(x2), n, C, a1, a2, a3, reinterpret_cast<bf16*>(y));
-    else
-        hipLaunchKernelGGL(col_affine2_kernel<float>, dim3(grid_for(n)), dim3(256), 0, stream, reinterpret_cast<const float*>(x1),
-                           reinterpret_cast<const float*>(x2), n, C, a1, a2, a3, reinterpret_cast<float*>(y));
+    if (dtype == ESVIT_BF16) launch_col_affine2<bf16>(act, x1, x2, n, C, a1, a2, a3, y, stream);
+    else launch_col_affine2<float>(act, x1, x2, n, C, a1, a2, a3, y, stream);
     ESVIT_CHECK_LAUNCH("col_affine2");
     return ESVIT_OK;
 }

@@ -132,6 +132,20 @@ class GradBucketReducer:
         self._hooks = []
 
 
+class _ScalerOptimizerView:
+    """What ``torch.cuda.amp.GradScaler.unscale_`` / ``.step`` need from an optimizer: ``param_groups`` (whose gradients
+    they check for inf / nan and unscale in place) and ``step()`` (called only when every gradient is finite)."""
+
+    def __init__(self, param_groups):
+        self.param_groups = param_groups
+        self.stepped = False
+        self._fn = None
+
+    def step(self):
+        self.stepped = True
+        self._fn()
+
+
 class EsvitTrainer:
     """teacher fwd -> student fwd -> loss -> backward (+ overlapped grad all-reduce) -> fused clip/AdamW/EMA."""
 
@@ -141,10 +155,13 @@ class EsvitTrainer:
         self.updater = updater if updater is not None else FusedClipAdamWEMA(student, teacher)
         self.reducer = GradBucketReducer(student, bucket_mb)
 
-    def step(self, images, lr, wd, momentum, epoch):
+    def step(self, images, lr, wd, momentum, epoch, scaler=None):
+        """scaler: a ``torch.cuda.amp.GradScaler`` (the reference's --use_fp16 mode, main_esvit.py:417-419, 576-584) or None."""
         with torch.no_grad():
             teacher_out = self.teacher(images[:2])
         student_out = self.student(images)
+        if scaler is not None:
+            return self._scaled_update(scaler, student_out, teacher_out, lr, wd, momentum, epoch)
         # loss.backward() below always uses grad_output == 1: the loss skips its rescale pass for this call only
         prev = getattr(self.loss_fn, "assume_unit_grad", False)
         self.loss_fn.assume_unit_grad = True
@@ -160,6 +177,33 @@ class EsvitTrainer:
         return loss.detach()
 
 
+    def _scaled_update(self, scaler, student_out, teacher_out, lr, wd, momentum, epoch):
+        """main_esvit.py:576-584 with the fused update as the optimizer: scale(loss).backward() -> unscale_ -> (clip +
+        AdamW + EMA if every gradient is finite) -> update().  The activations stay bf16 (the modules keep their own
+        precision policy; fp16 is not an activation dtype of the kernels), so the scale factor only ever matters through
+        GradScaler's own protocol: power-of-two scales are exact in bf16 / fp32 and the step equals the unscaled one."""
+        loss = self.loss_fn(student_out, teacher_out, epoch, None)  # grad_output = scale: the loss rescales its gradient
+        self.reducer.begin()
+        scaler.scale(loss).backward()
+        self.reducer.finish()
+        view = getattr(self, "_scaler_view", None)
+        if view is None:
+            view = self._scaler_view = _ScalerOptimizerView(self.updater.param_groups)
+        view.stepped = False
+        skip = epoch < self.freeze_last_layer
+        view._fn = lambda: self.updater.step(lr, wd, momentum, clip_grad=self.clip_grad, skip_last_layer=skip)
+        if self.clip_grad:
+            scaler.unscale_(view)  # the clip compares true gradient norms (main_esvit.py:579-580)
+        scaler.step(view)          # runs view.step() unless a gradient is inf / nan
+        scaler.update()
+        self.updater.zero_grad(set_to_none=True)
+        if not view.stepped:
+            # optimizer step skipped: the reference's EMA loop (main_esvit.py:587-590) still runs.  With no gradients the
+            # fused kernel leaves the student and the moments untouched and only applies the EMA.
+            self.updater.step(lr, wd, momentum, clip_grad=self.clip_grad, skip_last_layer=skip)
+        return loss.detach()
+
+
 _TRAINERS = {}
 
 
@@ -172,12 +216,11 @@ def train_one_epoch(student, teacher, teacher_without_ddp, dino_loss, data_loade
     tensors the fused kernel updates and its param_groups receive the schedule values, so the caller's
     ``optimizer.state_dict()`` / ``load_state_dict()`` (main_esvit.py:444-452, 476-488) checkpoint and restore the real
     moments.  Any other optimizer is refused.  `student` may be DDP-wrapped (its .module is trained, gradients are
-    reduced by GradBucketReducer instead).  Returns the rank-averaged epoch means the reference logs (main_esvit.py:593-600)."""
+    reduced by GradBucketReducer instead).  `fp16_scaler`: the reference's GradScaler protocol is followed with the fused
+    update in the optimizer's place (EsvitTrainer._scaled_update); the caller keeps checkpointing ``fp16_scaler.state_dict()``.
+    Returns the rank-averaged epoch means the reference logs (main_esvit.py:593-600)."""
     if mixup_fn is not None:
         raise NotImplementedError("mixup (main_esvit.py:518-534) is out of scope (SURVEY.md 8f-3)")
-    if fp16_scaler is not None:
-        raise NotImplementedError("fp16 + GradScaler (main_esvit.py:576-584) is out of scope (SURVEY.md 8f-3): run with --use_fp16 false; "
-                                  "the modules keep their own bf16 precision policy")
     net = student.module if hasattr(student, "module") else student
     if not isinstance(optimizer, (FusedClipAdamWEMA, torch.optim.AdamW)):
         raise TypeError("esvit_amd.engine.train_one_epoch drives AdamW only (got %s): pass torch.optim.AdamW or "
@@ -200,7 +243,7 @@ def train_one_epoch(student, teacher, teacher_without_ddp, dino_loss, data_loade
     for it, (images, _) in enumerate(data_loader):
         git = n_it * epoch + it
         images = [im.cuda(non_blocking=True) for im in images]
-        last = tr.step(images, lr_schedule[git], wd_schedule[git], momentum_schedule[git], epoch)
+        last = tr.step(images, lr_schedule[git], wd_schedule[git], momentum_schedule[git], epoch, scaler=fp16_scaler)
         loss_sum += last
         if it % 10 == 0 or it == n_it - 1:  # the reference syncs every iteration (main_esvit.py:546,593); 1-in-10 keeps the NaN guard
             v = last.item()

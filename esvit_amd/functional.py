@@ -523,6 +523,89 @@ def dino_head(x, prm):
     return _head_forward(x, prm, False)[0]
 
 
+# ---- DINOHead(use_bn=True): Linear -> BatchNorm1d -> GELU (x2) -> Linear -> l2-normalise -> weight-normed last layer
+# (vision_transformer.py:391-402, 414-418).  The Linear writes its pre-norm output d; one pass gives the batch sums, the
+# [C]-sized coefficient kernel turns them into y = a d + shift and updates the running statistics, and GELU rides on the
+# affine pass.  Statistics are summed over the ranks (main_esvit.py:365-379 converts every BatchNorm to SyncBatchNorm).
+HEAD_BN_EPS = 1e-5
+HEAD_BN_MOMENTUM = 0.1
+
+
+def _head_bn_coef(o, d, st, gam, bet):
+    """-> (coef [4, C], n): batch statistics in training mode, the running ones in eval mode"""
+    if st.get("eval"):
+        return o.bn_eval_coeffs(st["eval_mean"], st["eval_var"], gam, bet, HEAD_BN_EPS), float(d.shape[0])
+    sums = o.col_sums2(d, d)
+    n = float(d.shape[0] * _allreduce_stats(sums, st.get("group")))
+    coef = o.bn_fwd_coeffs(sums, n, gam, bet, HEAD_BN_EPS, HEAD_BN_MOMENTUM, st.get("running_mean"), st.get("running_var"))
+    if st.get("num_batches_tracked") is not None:
+        st["num_batches_tracked"].add_(1)
+    return coef, n
+
+
+class DinoHeadBnFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, st1, st2, W1p, b1, g1, be1, W2p, b2, g2, be2, W3p, b3, v, g):
+        o = ops_module()
+        W1, W2, W3 = _weight(W1p), _weight(W2p), _weight(W3p)
+        xa = o.cast_to_act(x.contiguous())
+        gam1, bet1, gam2, bet2 = (t.detach().contiguous() for t in (g1, be1, g2, be2))
+        d1 = o.linear_fwd(xa, W1, b1)
+        coef1, n1 = _head_bn_coef(o, d1, st1, gam1, bet1)
+        h1 = o.col_affine2(d1, coef1[0], coef1[1], act=1)
+        d2 = o.linear_fwd(h1, W2, b2)
+        coef2, n2 = _head_bn_coef(o, d2, st2, gam2, bet2)
+        h2 = o.col_affine2(d2, coef2[0], coef2[1], act=1)
+        h3 = o.linear_fwd(h2, W3, b3)
+        z, inv = o.l2norm_fwd(h3)
+        w, winv = _last_layer_weight(v, g)
+        logits = o.linear_fwd(z, w)
+        ctx.save_for_backward(v, g, W1, W2, W3, xa, d1, coef1, gam1, h1, d2, coef2, gam2, h2, z, inv, w, winv)
+        ctx.meta = (n1, n2, st1.get("group"), bool(st1.get("eval")), g.requires_grad)
+        ctx.wparams = (W1p, W2p, W3p, v)
+        return logits
+
+    @staticmethod
+    def _bn_gelu_bwd(o, dh, d, coef, gam, n, group, eval_bn):
+        """dh = dL/d GELU(BN(d)) -> (dL/dd, dgamma, dbeta)"""
+        du = o.col_affine2(d, coef[0], coef[1], x2=dh, act=2)     # through the GELU, at the rebuilt BN output
+        red = o.bn_bwd_local(o.col_sums2(du, d), coef)            # (sum du, sum du*xhat) of this rank = (d beta, d gamma)
+        dbet, dgam = red[0].clone(), red[1].clone()
+        if eval_bn:
+            abc = o.bn_bwd_coeffs(None, n, gam, coef)
+        else:
+            _allreduce_stats(red, group)
+            abc = o.bn_bwd_coeffs(red, n, gam, coef)
+        return o.col_affine2(du, abc[0], abc[2], d, abc[1]), dgam, dbet
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        o = ops_module()
+        v, g, W1, W2, W3, xa, d1, coef1, gam1, h1, d2, coef2, gam2, h2, z, inv, w, winv = ctx.saved_tensors
+        n1, n2, group, eval_bn, need_dg = ctx.meta
+        W1p, W2p, W3p, vp = ctx.wparams
+        dlogits = dlogits.contiguous()
+        dz = o.linear_dgrad(dlogits, w)
+        dw = o.linear_wgrad(dlogits, z)
+        sink = P.grad_out(vp)
+        dv, dg = o.weightnorm_bwd(dw, v, g, winv, need_dg, dv_out=sink)
+        if sink is not None:
+            dv = dv.detach()
+        dh3 = o.l2norm_bwd(dz, z, inv)
+        dW3, db3 = _wgrad(dh3, h2, W3p, want_bias=True)
+        dd2, dg2, dbe2 = DinoHeadBnFn._bn_gelu_bwd(o, o.linear_dgrad(dh3, W3), d2, coef2, gam2, n2, group, eval_bn)
+        dW2, db2 = _wgrad(dd2, h1, W2p, want_bias=True)
+        dd1, dg1, dbe1 = DinoHeadBnFn._bn_gelu_bwd(o, o.linear_dgrad(dd2, W2), d1, coef1, gam1, n1, group, eval_bn)
+        dW1, db1 = _wgrad(dd1, xa, W1p, want_bias=True)
+        dx = o.linear_dgrad(dd1, W1, out_f32=True)
+        return dx, None, None, dW1, db1, dg1, dbe1, dW2, db2, dg2, dbe2, dW3, db3, dv, dg
+
+
+def dino_head_bn(x, st1, st2, prm):
+    """prm = (W1, b1, bn1.weight, bn1.bias, W2, b2, bn2.weight, bn2.bias, W3, b3, weight_v, weight_g)"""
+    return DinoHeadBnFn.apply(x, st1, st2, *prm)
+
+
 # ------------------------------------------------------------------------------------------------
 # CvT (cvt_v4_transformer.py; BASELINE config 5).  Activations stay token-major NHWC, so the reference's
 # 'b c h w <-> b h w c' rearranges around every LayerNorm do not exist here.

@@ -1,5 +1,5 @@
 """DINOHead behind the reference constructor (vision_transformer.py:384-418): parameters are registered under
-the reference's names -- ``mlp.{0,2,4}.{weight,bias}`` and the legacy weight-norm pair
+the reference's names -- ``mlp.{0,2,4}.{weight,bias}`` (``mlp.{0,3,6}`` + BatchNorm1d ``mlp.{1,4}`` with use_bn) and the legacy weight-norm pair
 ``last_layer.weight_g`` [K,1] / ``last_layer.weight_v`` [K,256] -- and the forward is one fused autograd node."""
 import torch
 import torch.nn as nn
@@ -22,12 +22,16 @@ class _WeightNormLinear(nn.Module):
 class DINOHead(nn.Module):
     def __init__(self, in_dim, out_dim, use_bn=False, norm_last_layer=True, nlayers=3, hidden_dim=2048, bottleneck_dim=256):
         super().__init__()
-        if use_bn:
-            raise NotImplementedError("use_bn_in_head is a 'next' row (SURVEY.md 8f-3)")
         if max(nlayers, 1) != 3:
             raise NotImplementedError("the fused head implements the reference default nlayers=3")
-        self.mlp = nn.Sequential(nn.Linear(in_dim, hidden_dim), nn.GELU(), nn.Linear(hidden_dim, hidden_dim), nn.GELU(),
-                                 nn.Linear(hidden_dim, bottleneck_dim))
+        self.use_bn = bool(use_bn)
+        self.sync_bn_group = None  # process group of the batch statistics (None = default group; False = this rank only)
+        if use_bn:  # --use_bn_in_head (vision_transformer.py:391-402): mlp.{0,3,6} Linear, mlp.{1,4} BatchNorm1d
+            self.mlp = nn.Sequential(nn.Linear(in_dim, hidden_dim), nn.BatchNorm1d(hidden_dim), nn.GELU(), nn.Linear(hidden_dim, hidden_dim),
+                                     nn.BatchNorm1d(hidden_dim), nn.GELU(), nn.Linear(hidden_dim, bottleneck_dim))
+        else:
+            self.mlp = nn.Sequential(nn.Linear(in_dim, hidden_dim), nn.GELU(), nn.Linear(hidden_dim, hidden_dim), nn.GELU(),
+                                     nn.Linear(hidden_dim, bottleneck_dim))
         for m in self.mlp:
             if isinstance(m, nn.Linear):
                 nn.init.trunc_normal_(m.weight, std=.02, a=-2.0, b=2.0)
@@ -37,9 +41,24 @@ class DINOHead(nn.Module):
         if norm_last_layer:
             self.last_layer.weight_g.requires_grad = False
 
+    def _bn_state(self, bn):
+        st = {"group": self.sync_bn_group}
+        if self.training:
+            if bn.track_running_stats:
+                st.update(running_mean=bn.running_mean, running_var=bn.running_var, num_batches_tracked=bn.num_batches_tracked)
+        else:  # nn.BatchNorm1d.eval(): the running statistics
+            st.update(eval=True, eval_mean=bn.running_mean, eval_var=bn.running_var)
+        return st
+
     def forward(self, x):
         lead = x.shape[:-1]
         x2 = x.reshape(-1, x.shape[-1])
+        if self.use_bn:
+            m = self.mlp
+            prm = [m[0].weight, m[0].bias, m[1].weight, m[1].bias, m[3].weight, m[3].bias, m[4].weight, m[4].bias, m[6].weight, m[6].bias,
+                   self.last_layer.weight_v, self.last_layer.weight_g]
+            y = Fn.dino_head_bn(x2, self._bn_state(m[1]), self._bn_state(m[4]), prm)
+            return y.view(*lead, y.shape[-1])
         prm = [self.mlp[0].weight, self.mlp[0].bias, self.mlp[2].weight, self.mlp[2].bias, self.mlp[4].weight, self.mlp[4].bias,
                self.last_layer.weight_v, self.last_layer.weight_g]
         y = Fn.dino_head(x2, prm)

@@ -711,12 +711,13 @@ def col_sums2(a, b):
     return out
 
 
-def col_affine2(x1, a1, a3, x2=None, a2=None):
-    """y = a1[c] * x1 + a2[c] * x2 + a3[c]  (act dtype in / out, fp32 per-channel coefficients)"""
+def col_affine2(x1, a1, a3, x2=None, a2=None, act=0):
+    """act 0: y = a1[c] * x1 + a2[c] * x2 + a3[c];  1: y = GELU(a1[c] * x1 + a3[c]);  2: y = x2 * GELU'(a1[c] * x1 + a3[c])
+    (act dtype in / out, fp32 per-channel coefficients)"""
     x1 = _actc(x1)
     rows, Cc = x1.shape
     y = torch.empty_like(x1)
-    check(lib.esvit_col_affine2(_code(x1.dtype), _p(x1), _p(x2), rows, Cc, _p(_f32c(a1)), _p(a2), _p(_f32c(a3)), _p(y), _stream()),
+    check(lib.esvit_col_affine2(_code(x1.dtype), _p(x1), _p(x2), rows, Cc, _p(_f32c(a1)), _p(a2), _p(_f32c(a3)), int(act), _p(y), _stream()),
           "col_affine2")
     return y
 

@@ -296,7 +296,9 @@ int esvit_fused_clip_adamw_ema(const int64_t* tensors, int ntensors, const int32
  *   mirrored (the data gradient).  esvit_dwconv3x3_wgrad: dw[c][t]; ws: fp32 [ESVIT_Q_COL_REDUCE_BLOCKS(rows)*9*C].
  * esvit_col_sums2: out[0..C) = sum_r a[r][c], out[C..2C) = sum_r a[r][c]*b[r][c]  (BatchNorm statistics: b = a;
  *   BatchNorm backward: a = dy, b = pre-norm activations); ws: fp32 [ESVIT_Q_COL_REDUCE_BLOCKS(rows)*2*C].
- * esvit_col_affine2: y = a1[c]*x1 + a2[c]*x2 + a3[c]  (x2 may be null). */
+ * esvit_col_affine2: act 0: y = a1[c]*x1 + a2[c]*x2 + a3[c]  (x2 may be null);
+ *   act 1: y = GELU(a1[c]*x1 + a3[c]) and act 2: y = x2 * GELU'(a1[c]*x1 + a3[c]) -- BatchNorm1d + GELU of DINOHead(use_bn=True)
+ *   (vision_transformer.py:391-402) and its backward, the normalised value rebuilt from the pre-norm activation. */
 int esvit_conv_im2col(int dtype, const void* src, int nchw, int nB, int H, int W, int Cin, int k, int stride, int pad,
                       int Ho, int Wo, int Kpad, void* cols, esvit_stream_t stream);
 int esvit_conv_col2im(int dtype, const void* dcols, int nB, int H, int W, int Cin, int k, int stride, int pad, int Ho,
@@ -308,7 +310,7 @@ int esvit_dwconv3x3_wgrad(int dtype, const void* x, const void* dy, int nB, int 
 int esvit_col_sums2(int dtype, const void* a, const void* b, int64_t rows, int C, float* out, float* ws,
                     esvit_stream_t stream);
 int esvit_col_affine2(int dtype, const void* x1, const void* x2, int64_t rows, int C, const float* a1, const float* a2,
-                      const float* a3, void* y, esvit_stream_t stream);
+                      const float* a3, int act, void* y, esvit_stream_t stream);
 /* token grid [nB,Hs,Ws,C] -> [nB,Hd,Wd,C]: zero-pad at the bottom / right (F.pad of cvt_v4_transformer.py:173) or crop (:216) */
 int esvit_pad_crop_tokens(int dtype, const void* src, int nB, int Hs, int Ws, int Hd, int Wd, int C, void* dst,
                           esvit_stream_t stream);

@@ -255,6 +255,32 @@ def gen_knn(ns):
     print("knn golden:", out)
 
 
+def gen_variants(ns):
+    """SURVEY.md 8f-3 step variants, each from the reference's own code:
+    bn_head -- DINOHead(use_bn=True) (vision_transformer.py:384-418) in train mode (batch statistics, running-stat update)
+               and in eval mode (running statistics): logits, every gradient of sum(logits * probe), the buffers after."""
+    g = {}
+    c = GU.BN_HEAD
+    head = ns.DINOHead(c["in_dim"], c["out_dim"], use_bn=True, hidden_dim=c["hidden_dim"], bottleneck_dim=c["bottleneck_dim"])
+    GU.fill_bn_head(head.state_dict(), 31)
+    x, probe = GU.bn_head_inputs()
+    x = x.clone().requires_grad_(True)
+    head.train()
+    out = head(x)
+    (out * probe).sum().backward()
+    g["bn_head"] = {
+        "logits": out.detach().clone(),
+        "dx": x.grad.clone(),
+        "grads": {n: p.grad.clone() for n, p in head.named_parameters() if p.grad is not None},
+        "buffers_after": {n: b.clone() for n, b in head.named_buffers()},
+    }
+    head.eval()
+    with torch.no_grad():
+        g["bn_head"]["logits_eval"] = head(x.detach()).clone()
+    torch.save(g, os.path.join(OUT, "variants.pt"))
+    print("variants.pt: bn_head logits", tuple(g["bn_head"]["logits"].shape), "grads", len(g["bn_head"]["grads"]))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ns = RL.load()
@@ -269,6 +295,8 @@ def main():
         gen_nano_cvt(ns)
     if not only or "knn" in only:
         gen_knn(ns)
+    if not only or "variants" in only:
+        gen_variants(ns)
 
 
 if __name__ == "__main__":

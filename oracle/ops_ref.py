@@ -612,9 +612,13 @@ def col_sums2(a, b):
     return torch.stack([af.sum(0), (af * b.float()).sum(0)], 0)
 
 
-def col_affine2(x1, a1, a3, x2=None, a2=None):
+def col_affine2(x1, a1, a3, x2=None, a2=None, act=0):
     y = x1.float() * a1 + a3
-    if x2 is not None:
+    if act == 1:
+        y = F.gelu(y)
+    elif act == 2:
+        y = x2.float() * (0.5 * (1.0 + torch.erf(y * 0.7071067811865476)) + y * torch.exp(-0.5 * y * y) * 0.3989422804014327)
+    elif x2 is not None:
         y = y + x2.float() * a2
     return _r(y, x1.dtype)
 

@@ -61,3 +61,25 @@ def make_knn_set(seed, n_train=1500, n_test=400, dim=48, classes=10, noise=1.0):
 
 
 KNN_CASES = [dict(seed=5, k=10, T=0.07, noise=2.0), dict(seed=6, k=20, T=0.07, noise=3.0), dict(seed=7, k=20, T=0.5, noise=4.0)]
+
+
+# ---- DINOHead(use_bn=True) fixture (tests/golden/variants.pt; oracle/gen_golden.py:gen_variants) -------------------------
+BN_HEAD = dict(in_dim=48, out_dim=96, hidden_dim=64, bottleneck_dim=32, rows=40)
+
+
+def fill_bn_head(sd, seed):
+    """fill_state_dict + sane BatchNorm entries (gamma around 1, positive running variance)"""
+    fill_state_dict(sd, seed)
+    for name, t in sd.items():
+        if name.endswith("running_var"):
+            t.copy_(t.abs() * 4 + 0.5)
+        elif name.startswith(("mlp.1.", "mlp.4.")) and name.endswith("weight"):
+            t.copy_(1.0 + 2.0 * t)
+    return sd
+
+
+def bn_head_inputs():
+    g = torch.Generator().manual_seed(4242)
+    x = torch.randn(BN_HEAD["rows"], BN_HEAD["in_dim"], generator=g)
+    probe = torch.randn(BN_HEAD["rows"], BN_HEAD["out_dim"], generator=g)  # loss = sum(logits * probe)
+    return x, probe

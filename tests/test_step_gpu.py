@@ -367,7 +367,32 @@ def test_train_one_epoch_drop_in_gpu(lib_built):
         # (d) anything that is not AdamW is refused instead of silently ignored
         with pytest.raises(TypeError):
             engine.train_one_epoch(s4, t4, t4, l4, one, torch.optim.SGD(s4.parameters(), lr=0.1), sched["lr"][2:], sched["wd"][2:], sched["mom"][2:], 0, None, None, args)
-        with pytest.raises(NotImplementedError):
-            engine.train_one_epoch(s4, t4, t4, l4, one, o4, sched["lr"][2:], sched["wd"][2:], sched["mom"][2:], 0, None, object(), args)
+        with pytest.raises(NotImplementedError):  # mixup_fn
+            engine.train_one_epoch(s4, t4, t4, l4, one, o4, sched["lr"][2:], sched["wd"][2:], sched["mom"][2:], 0, object(), None, args)
+        # (e) the --use_fp16 protocol (main_esvit.py:417-419, 576-584): GradScaler.scale / unscale_ / step / update around the
+        # fused update.  Power-of-two scales are exact, so the scaled run equals the plain one; the scale grows on schedule.
+        s5, t5, l5 = fresh()
+        o5 = torch.optim.AdamW(get_params_groups(s5))
+        scaler = torch.amp.GradScaler("cuda", init_scale=2.0 ** 10, growth_interval=2)
+        st5 = engine.train_one_epoch(s5, t5, t5, l5, Loader(batches), o5, sched["lr"], sched["wd"], sched["mom"], 0, None, scaler, args)
+        assert abs(st5["loss"] - stats["loss"]) < 1e-4
+        same_update("scaler student", student.named_parameters(), s5.named_parameters(), init_s, 2e-2)
+        same_update("scaler teacher", teacher.named_parameters(), t5.named_parameters(), init_t, 2e-3)
+        assert scaler.get_scale() == 2.0 ** 11  # three finite steps, growth interval 2
+        assert all(float(st["step"]) == 3.0 for st in o5.state_dict()["state"].values())
+        # a non-finite gradient: the optimizer step is skipped (student and moments untouched, scale halved), the EMA still runs
+        before_s = {n: p.detach().clone() for n, p in s5.named_parameters()}
+        before_t = {n: p.detach().clone() for n, p in t5.named_parameters()}
+        victim = dict(s5.named_parameters())["layers.0.blocks.0.mlp.fc1.bias"]
+        h = victim.register_hook(lambda g: g + float("inf"))
+        engine.train_one_epoch(s5, t5, t5, l5, Loader(batches[:1]), o5, sched["lr"], sched["wd"], sched["mom"], 0, None, scaler, args)
+        h.remove()
+        assert scaler.get_scale() == 2.0 ** 10
+        m = sched["mom"][0]
+        for n, p in s5.named_parameters():
+            assert torch.equal(p, before_s[n]), n
+        for (n, p), (_, q) in zip(t5.named_parameters(), s5.named_parameters()):
+            assert torch.allclose(p, before_t[n] * m + q.detach() * (1 - m), rtol=1e-5, atol=1e-7), n
+        assert all(float(st["step"]) == 3.0 for st in o5.state_dict()["state"].values())
     finally:
         _teardown()
