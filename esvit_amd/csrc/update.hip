@@ -1,6 +1,9 @@
-// Fused parameter update: per-parameter L2 clip (utils.py:106-115) + AdamW (torch.optim.AdamW as
-// driven by main_esvit.py:506-510,574) + teacher EMA (main_esvit.py:587-590) in two multi-tensor
-// launches with no host synchronisation (the reference does one .item() per tensor).
+// Fused parameter update: per-parameter L2 clip (utils.py:106-115) + the optimizer rule + teacher EMA
+// (main_esvit.py:587-590) in two multi-tensor launches with no host synchronisation (the reference does one .item() per
+// tensor).  Rules (main_esvit.py:408-415): AdamW (torch.optim.AdamW as driven by main_esvit.py:506-510,574), SGD with
+// momentum (torch.optim.SGD(lr=0, momentum=0.9)), LARS (utils.py:519-557).  SGD / LARS keep their one state tensor
+// (momentum_buffer / mu) in the exp_avg slot; LARS needs |p| and |clipped g + wd p| per tensor, which the statistics
+// pass delivers as (sum g^2, sum p^2, sum g p).
 //
 // Tensor table (device, int64[ntensors * 12]):
 //   0 p  1 g  2 exp_avg  3 exp_avg_sq  4 teacher_p  5 numel  6 group (0: weight decay, 1: none)
@@ -18,6 +21,8 @@ namespace {
 constexpr int CHUNK = 4096;
 constexpr int TFIELDS = 12;
 
+// STATS 1: sqnorms[t] = sum g^2;  STATS 3: sqnorms[3t..3t+2] = (sum g^2, sum p^2, sum g p)
+template <int STATS>
 __global__ __launch_bounds__(256) void grad_sqnorm_kernel(const long* __restrict__ tensors, const int* __restrict__ chunks,
                                                           float* __restrict__ sqnorms) {
     __shared__ float scratch[4];
@@ -25,21 +30,41 @@ __global__ __launch_bounds__(256) void grad_sqnorm_kernel(const long* __restrict
     const long* tt = tensors + (long)tid * TFIELDS;
     if (!(tt[7] & 1)) return;
     const float* g = reinterpret_cast<const float*>(tt[1]);
+    const float* p = reinterpret_cast<const float*>(tt[0]);
     const long n = tt[5];
     const long base = (long)ci * CHUNK;
-    float s = 0.f;
+    float s = 0.f, sp = 0.f, sgp = 0.f;
 #pragma unroll
     for (int i = 0; i < CHUNK / 256 / 4; ++i) {
         const long o = base + (i * 256 + threadIdx.x) * 4;
         if (o + 4 <= n) {
             const f32x4 v = *reinterpret_cast<const f32x4*>(g + o);
             s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+            if constexpr (STATS == 3) {
+                const f32x4 w = *reinterpret_cast<const f32x4*>(p + o);
+                sp += w[0] * w[0] + w[1] * w[1] + w[2] * w[2] + w[3] * w[3];
+                sgp += v[0] * w[0] + v[1] * w[1] + v[2] * w[2] + v[3] * w[3];
+            }
         } else {
-            for (long j = o; j < n; ++j) s += g[j] * g[j];
+            for (long j = o; j < n; ++j) {
+                s += g[j] * g[j];
+                if constexpr (STATS == 3) {
+                    sp += p[j] * p[j];
+                    sgp += g[j] * p[j];
+                }
+            }
         }
     }
     s = block_sum<256>(s, scratch);
-    if (threadIdx.x == 0) atomicAdd(sqnorms + tid, s);
+    if (threadIdx.x == 0) atomicAdd(sqnorms + (long)tid * STATS, s);
+    if constexpr (STATS == 3) {
+        __syncthreads();
+        sp = block_sum<256>(sp, scratch);
+        if (threadIdx.x == 0) atomicAdd(sqnorms + (long)tid * 3 + 1, sp);
+        __syncthreads();
+        sgp = block_sum<256>(sgp, scratch);
+        if (threadIdx.x == 0) atomicAdd(sqnorms + (long)tid * 3 + 2, sgp);
+    }
 }
 
 __device__ __forceinline__ void adamw_elem(float& p, float g, float& m, float& v, float decay, float b1, float b2, float step_size,
@@ -124,31 +149,97 @@ __global__ __launch_bounds__(256) void clip_adamw_ema_kernel(const long* __restr
     }
 }
 
+// SGD with momentum / LARS + EMA.  mu = momentum * mu + dp, p -= lr * mu with
+//   SGD  (torch.optim.SGD, dampening 0, no nesterov): dp = c g + wd p              (wd: group 0 only, as the schedule sets it)
+//   LARS (utils.py:533-557):                          dp = q (c g + wd p), q = eta |p| / |c g + wd p| for ndim != 1 (group 0)
+// c = the per-tensor clip factor.  `stats` holds (sum g^2, sum p^2, sum g p) per tensor for LARS, sum g^2 for SGD.
+template <bool LARS>
+__global__ __launch_bounds__(256) void clip_momentum_ema_kernel(const long* __restrict__ tensors, const int* __restrict__ chunks,
+                                                                const float* __restrict__ stats, float clip, float lr, float wd,
+                                                                float momentum, float eta, float ema_m) {
+    const int tid = chunks[2 * blockIdx.x], ci = chunks[2 * blockIdx.x + 1];
+    const long* tt = tensors + (long)tid * TFIELDS;
+    float* p = reinterpret_cast<float*>(tt[0]);
+    const float* g = reinterpret_cast<const float*>(tt[1]);
+    float* mu = reinterpret_cast<float*>(tt[2]);
+    float* tp = reinterpret_cast<float*>(tt[4]);
+    bf16* pb = reinterpret_cast<bf16*>(tt[10]);
+    bf16* tb = reinterpret_cast<bf16*>(tt[11]);
+    const long n = tt[5];
+    const bool has_grad = tt[7] & 1;
+    const float wdp = (tt[6] == 0) ? wd : 0.f;
+    const float* st = stats + (long)tid * (LARS ? 3 : 1);
+    float c = 1.f, q = 1.f;
+    if (has_grad) {
+        if (clip > 0.f) {
+            const float coef = clip / (sqrtf(st[0]) + 1e-6f);
+            if (coef < 1.f) c = coef;
+        }
+        if (LARS && tt[6] == 0) {
+            const float pn = sqrtf(st[1]);
+            const float un = sqrtf(fmaxf(c * c * st[0] + 2.f * c * wdp * st[2] + wdp * wdp * st[1], 0.f));
+            if (pn > 0.f && un > 0.f) q = eta * pn / un;
+        }
+    }
+    const long base = (long)ci * CHUNK;
+#pragma unroll
+    for (int i = 0; i < CHUNK / 256 / 4; ++i) {
+        const long o = base + (i * 256 + threadIdx.x) * 4;
+        const int cnt = o + 4 <= n ? 4 : (o < n ? (int)(n - o) : 0);
+        for (int e = 0; e < cnt; ++e) {  // (the update is a small fraction of the step: scalar tail-safe form)
+            const long j = o + e;
+            float pe = p[j];
+            if (has_grad) {
+                const float dp = q * (c * g[j] + wdp * pe);
+                const float me = momentum * mu[j] + dp;
+                mu[j] = me;
+                pe -= lr * me;
+                p[j] = pe;
+            }
+            if (pb) pb[j] = (bf16)pe;
+            if (tp) {
+                const float tn = tp[j] * ema_m + pe * (1.f - ema_m);
+                tp[j] = tn;
+                if (tb) tb[j] = (bf16)tn;
+            }
+        }
+    }
+}
+
 }  // namespace
 
 int esvit_i_update_chunk_elems() { return CHUNK; }  // esvit_query
 
-extern "C" int esvit_grad_sqnorm(const int64_t* tensors, int ntensors, const int32_t* chunks, int nchunks, float* sqnorms,
+extern "C" int esvit_grad_sqnorm(const int64_t* tensors, int ntensors, const int32_t* chunks, int nchunks, int stats, float* sqnorms,
                                  esvit_stream_t s_) {
     hipStream_t stream = reinterpret_cast<hipStream_t>(s_);
-    ESVIT_CHECK_ARG(tensors && chunks && sqnorms && ntensors > 0 && nchunks > 0, "esvit_grad_sqnorm: bad args");
-    hipError_t e = hipMemsetAsync(sqnorms, 0, (size_t)ntensors * sizeof(float), stream);
+    ESVIT_CHECK_ARG(tensors && chunks && sqnorms && ntensors > 0 && nchunks > 0 && (stats == 1 || stats == 3), "esvit_grad_sqnorm: bad args");
+    hipError_t e = hipMemsetAsync(sqnorms, 0, (size_t)ntensors * stats * sizeof(float), stream);
     if (e != hipSuccess) {
         esvit_set_error("esvit_grad_sqnorm: memset failed: %s", hipGetErrorString(e));
         return ESVIT_ERR_HIP;
     }
-    hipLaunchKernelGGL(grad_sqnorm_kernel, dim3(nchunks), dim3(256), 0, stream, (const long*)tensors, chunks, sqnorms);
+    if (stats == 3) hipLaunchKernelGGL(grad_sqnorm_kernel<3>, dim3(nchunks), dim3(256), 0, stream, (const long*)tensors, chunks, sqnorms);
+    else hipLaunchKernelGGL(grad_sqnorm_kernel<1>, dim3(nchunks), dim3(256), 0, stream, (const long*)tensors, chunks, sqnorms);
     ESVIT_CHECK_LAUNCH("grad_sqnorm");
     return ESVIT_OK;
 }
 
-extern "C" int esvit_fused_clip_adamw_ema(const int64_t* tensors, int ntensors, const int32_t* chunks, int nchunks,
-                                          const float* sqnorms, float clip, float lr, float wd, float beta1, float beta2, float eps,
-                                          float ema_m, esvit_stream_t s_) {
+extern "C" int esvit_fused_clip_update_ema(int rule, const int64_t* tensors, int ntensors, const int32_t* chunks, int nchunks,
+                                           const float* sqnorms, float clip, float lr, float wd, float beta1, float beta2, float eps,
+                                           float ema_m, esvit_stream_t s_) {
     hipStream_t stream = reinterpret_cast<hipStream_t>(s_);
-    ESVIT_CHECK_ARG(tensors && chunks && sqnorms && ntensors > 0 && nchunks > 0, "esvit_fused_clip_adamw_ema: bad args");
-    hipLaunchKernelGGL(clip_adamw_ema_kernel, dim3(nchunks), dim3(256), 0, stream, (const long*)tensors, chunks, sqnorms, clip, lr, wd,
-                       beta1, beta2, eps, ema_m);
-    ESVIT_CHECK_LAUNCH("fused_clip_adamw_ema");
+    ESVIT_CHECK_ARG(tensors && chunks && sqnorms && ntensors > 0 && nchunks > 0, "esvit_fused_clip_update_ema: bad args");
+    ESVIT_CHECK_ARG(rule == ESVIT_RULE_ADAMW || rule == ESVIT_RULE_SGD || rule == ESVIT_RULE_LARS, "esvit_fused_clip_update_ema: bad rule %d", rule);
+    if (rule == ESVIT_RULE_ADAMW)
+        hipLaunchKernelGGL(clip_adamw_ema_kernel, dim3(nchunks), dim3(256), 0, stream, (const long*)tensors, chunks, sqnorms, clip, lr, wd,
+                           beta1, beta2, eps, ema_m);
+    else if (rule == ESVIT_RULE_SGD)
+        hipLaunchKernelGGL(clip_momentum_ema_kernel<false>, dim3(nchunks), dim3(256), 0, stream, (const long*)tensors, chunks, sqnorms, clip,
+                           lr, wd, beta1, beta2, ema_m);
+    else
+        hipLaunchKernelGGL(clip_momentum_ema_kernel<true>, dim3(nchunks), dim3(256), 0, stream, (const long*)tensors, chunks, sqnorms, clip,
+                           lr, wd, beta1, beta2, ema_m);
+    ESVIT_CHECK_LAUNCH("fused_clip_update_ema");
     return ESVIT_OK;
 }

@@ -11,7 +11,7 @@ import torch
 import torch.distributed as dist
 
 from . import params as P
-from .update import FusedClipAdamWEMA, bind_torch_optimizer
+from .update import FusedClipAdamWEMA, bind_torch_optimizer, optimizer_rule
 
 
 def _world(group=None):
@@ -211,20 +211,20 @@ def train_one_epoch(student, teacher, teacher_without_ddp, dino_loss, data_loade
                     momentum_schedule, epoch, mixup_fn, fp16_scaler, args):
     """Drop-in for main_esvit.train_one_epoch (same signature).
 
-    `optimizer`: a FusedClipAdamWEMA is used as is.  A ``torch.optim.AdamW`` (what the unmodified train_esvit builds,
-    main_esvit.py:411) is BOUND to the fused updater: its ``state`` entries (step, exp_avg, exp_avg_sq) are the very
-    tensors the fused kernel updates and its param_groups receive the schedule values, so the caller's
-    ``optimizer.state_dict()`` / ``load_state_dict()`` (main_esvit.py:444-452, 476-488) checkpoint and restore the real
-    moments.  Any other optimizer is refused.  `student` may be DDP-wrapped (its .module is trained, gradients are
+    `optimizer`: a FusedClipAdamWEMA is used as is.  What the unmodified train_esvit builds (main_esvit.py:408-415:
+    ``torch.optim.AdamW``, ``torch.optim.SGD(lr=0, momentum=0.9)``, ``utils.LARS``) is BOUND to the fused updater: its
+    ``state`` entries (step, exp_avg, exp_avg_sq; momentum_buffer; mu) are the very tensors the fused kernel updates and its
+    param_groups receive the schedule values, so the caller's ``optimizer.state_dict()`` / ``load_state_dict()``
+    (main_esvit.py:444-452, 476-488) checkpoint and restore the real state.  Any other optimizer is refused.  `student` may be DDP-wrapped (its .module is trained, gradients are
     reduced by GradBucketReducer instead).  `fp16_scaler`: the reference's GradScaler protocol is followed with the fused
     update in the optimizer's place (EsvitTrainer._scaled_update); the caller keeps checkpointing ``fp16_scaler.state_dict()``.
     Returns the rank-averaged epoch means the reference logs (main_esvit.py:593-600)."""
     if mixup_fn is not None:
         raise NotImplementedError("mixup (main_esvit.py:518-534) is out of scope (SURVEY.md 8f-3)")
     net = student.module if hasattr(student, "module") else student
-    if not isinstance(optimizer, (FusedClipAdamWEMA, torch.optim.AdamW)):
-        raise TypeError("esvit_amd.engine.train_one_epoch drives AdamW only (got %s): pass torch.optim.AdamW or "
-                        "esvit_amd.update.FusedClipAdamWEMA (LARS / SGD: SURVEY.md 8f-3)" % type(optimizer).__name__)
+    if optimizer_rule(optimizer) is None:
+        raise TypeError("esvit_amd.engine.train_one_epoch drives the optimizers of main_esvit.py:408-415 -- torch.optim.AdamW, "
+                        "torch.optim.SGD(momentum), utils.LARS -- or an esvit_amd.update.FusedClipAdamWEMA; got %s" % type(optimizer).__name__)
     key = (id(net), id(teacher_without_ddp), id(dino_loss))
     tr = _TRAINERS.get(key)
     stale = (tr is None or tr.student is not net or tr.loss_fn is not dino_loss or

@@ -640,13 +640,17 @@ def update_chunk_elems():
     return query(Q_UPDATE_CHUNK_ELEMS)
 
 
-def grad_sqnorm(tensors, ntensors, chunks, nchunks, sqnorms):
-    check(lib.esvit_grad_sqnorm(_p(tensors), ntensors, _p(chunks), nchunks, _p(sqnorms), _stream()), "grad_sqnorm")
+RULE_ADAMW, RULE_SGD, RULE_LARS = 0, 1, 2
 
 
-def fused_clip_adamw_ema(tensors, ntensors, chunks, nchunks, sqnorms, clip, lr, wd, beta1, beta2, eps, ema_m):
-    check(lib.esvit_fused_clip_adamw_ema(_p(tensors), ntensors, _p(chunks), nchunks, _p(sqnorms), clip, lr, wd, beta1, beta2, eps,
-                                         ema_m, _stream()), "fused_clip_adamw_ema")
+def grad_sqnorm(tensors, ntensors, chunks, nchunks, sqnorms, stats=1):
+    check(lib.esvit_grad_sqnorm(_p(tensors), ntensors, _p(chunks), nchunks, int(stats), _p(sqnorms), _stream()), "grad_sqnorm")
+
+
+def fused_clip_update_ema(rule, tensors, ntensors, chunks, nchunks, sqnorms, clip, lr, wd, beta1, beta2, eps, ema_m):
+    """rule AdamW: (beta1, beta2, eps); SGD: beta1 = momentum; LARS: beta1 = momentum, beta2 = eta"""
+    check(lib.esvit_fused_clip_update_ema(int(rule), _p(tensors), ntensors, _p(chunks), nchunks, _p(sqnorms), clip, lr, wd, beta1, beta2,
+                                          eps, ema_m, _stream()), "fused_clip_update_ema")
 
 
 # ------------------------------------------------------------------------------------------------

@@ -44,14 +44,20 @@ def cosine_scheduler(base_value, final_value, epochs, niter_per_ep, warmup_epoch
 
 
 class FusedClipAdamWEMA:
-    """clip -> AdamW -> EMA for (student, teacher) in one pass.
+    """clip -> optimizer rule -> EMA for (student, teacher) in one pass.
 
     student / teacher: modules with positionally matching ``.parameters()`` (main_esvit.py:589).
     Only parameters with ``requires_grad`` are optimised; *every* parameter is EMA-ed, exactly as the
-    reference loop does.
+    reference loop does.  rule: "adamw" (torch.optim.AdamW; the class name dates from when it was the only one),
+    "sgd" (torch.optim.SGD(lr=0, momentum=0.9), main_esvit.py:413) or "lars" (utils.LARS, utils.py:519-557);
+    the latter two keep their single state tensor (momentum_buffer / mu) where AdamW keeps exp_avg.
     """
 
-    def __init__(self, student, teacher, betas=(0.9, 0.999), eps=1e-8):
+    STATE_KEY = {"adamw": "exp_avg", "sgd": "momentum_buffer", "lars": "mu"}
+
+    def __init__(self, student, teacher, betas=(0.9, 0.999), eps=1e-8, rule="adamw", momentum=0.9, eta=0.001):
+        assert rule in self.STATE_KEY, rule
+        self.rule, self.momentum, self.eta = rule, float(momentum), float(eta)
         self.betas, self.eps = betas, eps
         self.params = list(student.parameters())
         self.names = [n for n, _ in student.named_parameters()]
@@ -69,7 +75,7 @@ class FusedClipAdamWEMA:
         dev = self.params[0].device
         self.device = dev
         self.exp_avg = [torch.zeros_like(p) if t else None for p, t in zip(self.params, self.trainable)]
-        self.exp_avg_sq = [torch.zeros_like(p) if t else None for p, t in zip(self.params, self.trainable)]
+        self.exp_avg_sq = [torch.zeros_like(p) if (t and rule == "adamw") else None for p, t in zip(self.params, self.trainable)]
         self.steps = [0] * len(self.params)
         chunk = ops.update_chunk_elems()
         chunks = []
@@ -78,7 +84,7 @@ class FusedClipAdamWEMA:
                 chunks.append((ti, ci))
         self.nchunks = len(chunks)
         self.chunks = torch.tensor(chunks, dtype=torch.int32).to(dev)
-        self.sqnorms = torch.zeros(len(self.params), dtype=torch.float32, device=dev)
+        self.sqnorms = torch.zeros(len(self.params) * (3 if rule == "lars" else 1), dtype=torch.float32, device=dev)
         # ring of pinned staging tables: a buffer is rewritten only after the async H2D copy that read it completed
         self._ring = [torch.zeros((len(self.params), TFIELDS), dtype=torch.int64).pin_memory() for _ in range(4)]
         self._ring_np = [t.numpy() for t in self._ring]
@@ -87,7 +93,7 @@ class FusedClipAdamWEMA:
                 tp = self.teacher_params[i]
                 tab[i, 0] = p.data_ptr()
                 tab[i, 2] = self.exp_avg[i].data_ptr() if self.trainable[i] else 0
-                tab[i, 3] = self.exp_avg_sq[i].data_ptr() if self.trainable[i] else 0
+                tab[i, 3] = self.exp_avg_sq[i].data_ptr() if self.exp_avg_sq[i] is not None else 0
                 tab[i, 4] = tp.data_ptr() if tp is not None else 0
                 tab[i, 5] = p.numel()
                 tab[i, 6] = self.group_of[i]
@@ -147,9 +153,13 @@ class FusedClipAdamWEMA:
         ev.record()
         self._ring_ev[slot] = ev
         n = len(self.params)
-        ops.grad_sqnorm(self._table_dev, n, self.chunks, self.nchunks, self.sqnorms)
-        ops.fused_clip_adamw_ema(self._table_dev, n, self.chunks, self.nchunks, self.sqnorms, float(clip_grad or 0.0), float(lr),
-                                 float(weight_decay), b1, b2, self.eps, float(ema_momentum))
+        ops.grad_sqnorm(self._table_dev, n, self.chunks, self.nchunks, self.sqnorms, stats=3 if self.rule == "lars" else 1)
+        if self.rule == "adamw":
+            rule, h1, h2 = ops.RULE_ADAMW, b1, b2
+        else:
+            rule, h1, h2 = (ops.RULE_SGD if self.rule == "sgd" else ops.RULE_LARS), self.momentum, self.eta
+        ops.fused_clip_update_ema(rule, self._table_dev, n, self.chunks, self.nchunks, self.sqnorms, float(clip_grad or 0.0), float(lr),
+                                  float(weight_decay), h1, h2, self.eps, float(ema_momentum))
         P.invalidate()          # parameters changed behind autograd's back ...
         P.mark_fresh(fresh)     # ... but these cached casts were rewritten by the kernel
         for g in self.param_groups:
@@ -162,7 +172,7 @@ class FusedClipAdamWEMA:
     def _refresh_static_rows(self, i):
         for tab in self._ring_np:
             tab[i, 2] = self.exp_avg[i].data_ptr()
-            tab[i, 3] = self.exp_avg_sq[i].data_ptr()
+            tab[i, 3] = self.exp_avg_sq[i].data_ptr() if self.exp_avg_sq[i] is not None else 0
 
     def _adopt_bound_state(self):
         """optimizer.load_state_dict() (resume, utils.py:126-158) replaces the state tensors: adopt them"""
@@ -171,11 +181,16 @@ class FusedClipAdamWEMA:
             e = st.get(p)
             if not e or not self.trainable[i]:
                 continue
-            if e["exp_avg"] is not self.exp_avg[i] or e["exp_avg_sq"] is not self.exp_avg_sq[i]:
-                assert e["exp_avg"].dtype == torch.float32 and e["exp_avg"].is_contiguous() and e["exp_avg"].device == p.device
-                self.exp_avg[i], self.exp_avg_sq[i] = e["exp_avg"], e["exp_avg_sq"]
+            k = self.STATE_KEY[self.rule]
+            if e.get(k) is None:  # (torch.optim.SGD stores momentum_buffer = None before its first step)
+                continue
+            if e[k] is not self.exp_avg[i] or (self.rule == "adamw" and e["exp_avg_sq"] is not self.exp_avg_sq[i]):
+                assert e[k].dtype == torch.float32 and e[k].is_contiguous() and e[k].device == p.device
+                self.exp_avg[i] = e[k]
+                if self.rule == "adamw":
+                    self.exp_avg_sq[i] = e["exp_avg_sq"]
                 self._refresh_static_rows(i)
-            self.steps[i] = int(float(e["step"]))
+            self.steps[i] = int(float(e["step"])) if "step" in e else max(self.steps[i], 1)
 
     def _publish_bound_state(self, lr, weight_decay):
         st = self.bound.state
@@ -183,7 +198,10 @@ class FusedClipAdamWEMA:
             if self.steps[i] <= 0:
                 continue
             e = st.get(p)
-            if not e:
+            if self.rule != "adamw":
+                if not e or e.get(self.STATE_KEY[self.rule]) is not self.exp_avg[i]:
+                    st[p] = {self.STATE_KEY[self.rule]: self.exp_avg[i]}
+            elif not e:
                 st[p] = {"step": torch.tensor(float(self.steps[i])), "exp_avg": self.exp_avg[i], "exp_avg_sq": self.exp_avg_sq[i]}
             else:
                 e["step"].fill_(float(self.steps[i]))
@@ -211,12 +229,19 @@ class FusedClipAdamWEMA:
         state = {}
         for k, i in enumerate(order):
             if self.steps[i] > 0:
-                state[k] = {"step": torch.tensor(float(self.steps[i])), "exp_avg": self.exp_avg[i], "exp_avg_sq": self.exp_avg_sq[i]}
+                if self.rule == "adamw":
+                    state[k] = {"step": torch.tensor(float(self.steps[i])), "exp_avg": self.exp_avg[i], "exp_avg_sq": self.exp_avg_sq[i]}
+                else:
+                    state[k] = {self.STATE_KEY[self.rule]: self.exp_avg[i]}
         groups, k = [], 0
         for g in self.param_groups:
             n = len(g["params"])
-            groups.append({"lr": g["lr"], "betas": self.betas, "eps": self.eps, "weight_decay": g["weight_decay"],
-                           "amsgrad": False, "params": list(range(k, k + n))})
+            if self.rule == "adamw":
+                groups.append({"lr": g["lr"], "betas": self.betas, "eps": self.eps, "weight_decay": g["weight_decay"],
+                               "amsgrad": False, "params": list(range(k, k + n))})
+            else:
+                groups.append({"lr": g["lr"], "momentum": self.momentum, "weight_decay": g["weight_decay"], "params": list(range(k, k + n)),
+                               **({"eta": self.eta} if self.rule == "lars" else {"dampening": 0, "nesterov": False})})
             k += n
         return {"state": state, "param_groups": groups}
 
@@ -224,22 +249,47 @@ class FusedClipAdamWEMA:
         order = self._ordered()
         for k, st in sd["state"].items():
             i = order[int(k)]
-            self.steps[i] = int(float(st["step"]))
-            self.exp_avg[i].copy_(st["exp_avg"])
-            self.exp_avg_sq[i].copy_(st["exp_avg_sq"])
+            self.steps[i] = int(float(st["step"])) if "step" in st else 1
+            self.exp_avg[i].copy_(st[self.STATE_KEY[self.rule]])
+            if self.rule == "adamw":
+                self.exp_avg_sq[i].copy_(st["exp_avg_sq"])
         for g, sg in zip(self.param_groups, sd["param_groups"]):
             g["lr"], g["weight_decay"] = sg["lr"], sg["weight_decay"]
 
 
+def optimizer_rule(optimizer):
+    """-> "adamw" / "sgd" / "lars" for the optimizers train_esvit can build (main_esvit.py:408-415), else None.
+    LARS is recognised structurally (the reference's class lives in its utils.py): a momentum optimizer with an ``eta`` default."""
+    if isinstance(optimizer, FusedClipAdamWEMA):
+        return optimizer.rule
+    if isinstance(optimizer, torch.optim.AdamW):
+        return "adamw"
+    if isinstance(optimizer, torch.optim.SGD):
+        d = optimizer.defaults
+        if d.get("nesterov") or d.get("dampening", 0) != 0 or d.get("maximize"):
+            return None
+        return "sgd"
+    d = getattr(optimizer, "defaults", {})
+    if type(optimizer).__name__ == "LARS" and "eta" in d and "momentum" in d:
+        if d.get("weight_decay_filter") is not None or d.get("lars_adaptation_filter") is not None:
+            return None  # (utils.LARS.step never consults them; refuse rather than guess)
+        return "lars"
+    return None
+
+
 def bind_torch_optimizer(optimizer, student, teacher):
-    """FusedClipAdamWEMA whose moments ARE the `state` of the caller's torch.optim.AdamW (built over
-    get_params_groups(student), main_esvit.py:408-411): the fused kernel updates exp_avg / exp_avg_sq in place, `step` and
-    the param_groups' lr / weight_decay are mirrored after every update, and tensors swapped in by
-    optimizer.load_state_dict() are adopted before the next one.  optimizer.step() itself is never called."""
-    assert isinstance(optimizer, torch.optim.AdamW), type(optimizer)
+    """Fused updater whose state tensors ARE the `state` of the caller's optimizer (torch.optim.AdamW / torch.optim.SGD /
+    utils.LARS built over get_params_groups(student), main_esvit.py:408-415): the fused kernel updates exp_avg / exp_avg_sq
+    (momentum_buffer; mu) in place, `step` and the param_groups' lr / weight_decay are mirrored after every update, and
+    tensors swapped in by optimizer.load_state_dict() are adopted before the next one.  optimizer.step() itself is never called."""
+    rule = optimizer_rule(optimizer)
+    assert rule is not None, type(optimizer)
     pg = optimizer.param_groups
     assert len(pg) == 2 and pg[1]["weight_decay"] == 0.0, "expected the two groups of utils.get_params_groups (utils.py:672-683)"
-    upd = FusedClipAdamWEMA(student, teacher, betas=tuple(pg[0]["betas"]), eps=pg[0]["eps"])
+    if rule == "adamw":
+        upd = FusedClipAdamWEMA(student, teacher, betas=tuple(pg[0]["betas"]), eps=pg[0]["eps"])
+    else:
+        upd = FusedClipAdamWEMA(student, teacher, rule=rule, momentum=pg[0]["momentum"], eta=pg[0].get("eta", 0.001))
     ours = [[id(p) for p in g["params"]] for g in upd.param_groups]
     theirs = [[id(p) for p in g["params"]] for g in pg]
     assert ours == theirs, "the optimizer's parameter groups do not match get_params_groups(student)"

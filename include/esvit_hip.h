@@ -271,20 +271,29 @@ int esvit_scale_inplace(int dtype, void* x, int64_t n, const float* scale, esvit
 int esvit_center_ema(float* center, const float* colsum, float momentum, float denom, int K,
                      esvit_stream_t stream);
 
-/* ---- fused update: per-parameter clip + AdamW + teacher EMA -------------
- * utils.py:106-115 (clip), torch.optim.AdamW as driven by main_esvit.py:506-510,574,
- * EMA main_esvit.py:587-590.  Tensor table (device, int64[ntensors*12]):
- *   [p, g, exp_avg, exp_avg_sq, teacher_p (0 = none), numel, group (0: weight decay, 1: none),
- *    flags (bit0: has gradient; otherwise only the EMA is applied),
- *    bits(1-beta1^t) | bits(1-beta2^t) << 32, reserved,
+/* ---- fused update: per-parameter clip + optimizer rule + teacher EMA -------------
+ * utils.py:106-115 (clip), the optimizers of main_esvit.py:408-415 as driven by :506-510,574, EMA main_esvit.py:587-590.
+ *   ESVIT_RULE_ADAMW  torch.optim.AdamW          (beta1, beta2, eps as named)
+ *   ESVIT_RULE_SGD    torch.optim.SGD(momentum)  (beta1 = momentum; beta2, eps unused): mu = momentum mu + (c g + wd p)
+ *   ESVIT_RULE_LARS   utils.LARS (utils.py:519-557) (beta1 = momentum, beta2 = eta): mu = momentum mu + q (c g + wd p),
+ *                     q = eta |p| / |c g + wd p| for tensors of group 0 (ndim != 1), 1 otherwise;  p -= lr mu
+ * (c = the clip factor of the tensor).  Tensor table (device, int64[ntensors*12]):
+ *   [p, g, exp_avg (SGD: momentum_buffer, LARS: mu), exp_avg_sq (AdamW only), teacher_p (0 = none), numel,
+ *    group (0: weight decay, 1: none), flags (bit0: has gradient; otherwise only the EMA is applied),
+ *    bits(1-beta1^t) | bits(1-beta2^t) << 32 (AdamW), reserved,
  *    bf16 copy of p (0 = none), bf16 copy of teacher_p (0 = none)]   -- the copies are refreshed in the same pass
  * chunk table (device, int32[nchunks*2]): [tensor_id, chunk_index], chunk =
- * esvit_query(ESVIT_Q_UPDATE_CHUNK_ELEMS, 0, 0, 0) elements.  sqnorms: fp32 scratch [ntensors]. */
-int esvit_grad_sqnorm(const int64_t* tensors, int ntensors, const int32_t* chunks, int nchunks,
+ * esvit_query(ESVIT_Q_UPDATE_CHUNK_ELEMS, 0, 0, 0) elements.
+ * esvit_grad_sqnorm: stats = 1: sqnorms fp32 [ntensors] = sum g^2;  stats = 3 (LARS): fp32 [ntensors*3] =
+ * (sum g^2, sum p^2, sum g p) per tensor.  esvit_fused_clip_update_ema reads the layout its rule needs. */
+#define ESVIT_RULE_ADAMW 0
+#define ESVIT_RULE_SGD 1
+#define ESVIT_RULE_LARS 2
+int esvit_grad_sqnorm(const int64_t* tensors, int ntensors, const int32_t* chunks, int nchunks, int stats,
                       float* sqnorms, esvit_stream_t stream);
-int esvit_fused_clip_adamw_ema(const int64_t* tensors, int ntensors, const int32_t* chunks, int nchunks,
-                               const float* sqnorms, float clip, float lr, float wd, float beta1,
-                               float beta2, float eps, float ema_m, esvit_stream_t stream);
+int esvit_fused_clip_update_ema(int rule, const int64_t* tensors, int ntensors, const int32_t* chunks, int nchunks,
+                                const float* sqnorms, float clip, float lr, float wd, float beta1,
+                                float beta2, float eps, float ema_m, esvit_stream_t stream);
 
 /* ---- CvT backbone pieces (BASELINE config 5) ------------------------------
  * Token-major NHWC activations.  cvt_v4_transformer.py:349-382 (ConvEmbed), :75-105 (DepthWiseConv2d = dw 3x3 +

@@ -277,6 +277,28 @@ def gen_variants(ns):
     head.eval()
     with torch.no_grad():
         g["bn_head"]["logits_eval"] = head(x.detach()).clone()
+    # lars -- the reference's utils.LARS (utils.py:519-557) over the two groups of utils.get_params_groups, three steps with
+    #         utils.clip_gradients' per-tensor rule (utils.py:106-115) applied first, as train_one_epoch does
+    p0, grads = GU.lars_case()
+
+    class Holder(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            for n, t in p0.items():
+                self.register_parameter(n, torch.nn.Parameter(t.clone()))
+    net = Holder()
+    opt = ns.utils.LARS(ns.utils.get_params_groups(net))
+    for (lr, wd), gs in zip(GU.LARS_SCHED, grads):
+        for i, pg in enumerate(opt.param_groups):
+            pg["lr"] = lr
+            if i == 0:
+                pg["weight_decay"] = wd
+        for n, prm in net.named_parameters():
+            prm.grad = gs[n].clone()
+        ns.utils.clip_gradients(net, 3.0)
+        opt.step()
+    g["lars"] = {"params": {n: prm.detach().clone() for n, prm in net.named_parameters()},
+                 "mu": {n: opt.state[prm]["mu"].clone() for n, prm in net.named_parameters()}}
     torch.save(g, os.path.join(OUT, "variants.pt"))
     print("variants.pt: bn_head logits", tuple(g["bn_head"]["logits"].shape), "grads", len(g["bn_head"]["grads"]))
 

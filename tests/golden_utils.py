@@ -83,3 +83,16 @@ def bn_head_inputs():
     x = torch.randn(BN_HEAD["rows"], BN_HEAD["in_dim"], generator=g)
     probe = torch.randn(BN_HEAD["rows"], BN_HEAD["out_dim"], generator=g)  # loss = sum(logits * probe)
     return x, probe
+
+
+# ---- LARS / SGD fixture: a tiny parameter set, three seeded steps -------------------------------------------------------
+LARS_SHAPES = {"w1": (33, 20), "b1": (33,), "w2": (7, 33), "g": (33,), "w3": (5, 3, 3, 3)}
+LARS_SCHED = [(0.3, 1e-4), (0.2, 2e-4), (0.1, 3e-4)]  # (lr, weight decay of the regularised group) per step
+
+
+def lars_case():
+    """-> (params dict, [grads dict per step]); the first tensor's gradient is large enough to be clipped at 3.0"""
+    g = torch.Generator().manual_seed(777)
+    params = {n: torch.randn(s, generator=g) * 0.3 for n, s in LARS_SHAPES.items()}
+    grads = [{n: torch.randn(s, generator=g) * (2.0 if n == "w1" else 0.05) for n, s in LARS_SHAPES.items()} for _ in LARS_SCHED]
+    return params, grads

@@ -288,7 +288,7 @@ def test_train_one_epoch_drop_in_gpu(lib_built):
     """engine.train_one_epoch (the reference's signature, main_esvit.py:499-501) with the torch.optim.AdamW the unmodified
     train_esvit builds (main_esvit.py:408-411): two batches equal two EsvitTrainer.step calls; the caller's optimizer holds
     the real moments (state_dict() / load_state_dict() round trip = the checkpoint of main_esvit.py:476-488), a resumed run
-    continues exactly like an uninterrupted one, and optimizers other than AdamW are refused"""
+    continues exactly like an uninterrupted one, and optimizers outside main_esvit.py:408-415 are refused"""
     import argparse
     import esvit_amd.loss as L
     from esvit_amd import engine
@@ -364,9 +364,9 @@ def test_train_one_epoch_drop_in_gpu(lib_built):
         engine.train_one_epoch(s4, t4, t4, l4, one, o4, sched["lr"][2:], sched["wd"][2:], sched["mom"][2:], 0, None, None, args)
         same_update("resume", student.named_parameters(), s4.named_parameters(), init_s, 2e-2)
         assert all(float(st["step"]) == 3.0 for st in o4.state_dict()["state"].values())
-        # (d) anything that is not AdamW is refused instead of silently ignored
+        # (d) anything train_esvit cannot build (AdamW / SGD / LARS) is refused instead of silently ignored
         with pytest.raises(TypeError):
-            engine.train_one_epoch(s4, t4, t4, l4, one, torch.optim.SGD(s4.parameters(), lr=0.1), sched["lr"][2:], sched["wd"][2:], sched["mom"][2:], 0, None, None, args)
+            engine.train_one_epoch(s4, t4, t4, l4, one, torch.optim.Adam(s4.parameters(), lr=0.1), sched["lr"][2:], sched["wd"][2:], sched["mom"][2:], 0, None, None, args)
         with pytest.raises(NotImplementedError):  # mixup_fn
             engine.train_one_epoch(s4, t4, t4, l4, one, o4, sched["lr"][2:], sched["wd"][2:], sched["mom"][2:], 0, object(), None, args)
         # (e) the --use_fp16 protocol (main_esvit.py:417-419, 576-584): GradScaler.scale / unscale_ / step / update around the

@@ -106,3 +106,102 @@ def test_bn_head_gpu(gold, prec, lib_built):
         _check_bn_head(_bn_head(dev), gold["bn_head"], dev, 2e-5 if prec == "fp32" else 2e-2)
     finally:
         esvit_amd.set_precision("bf16")
+
+
+# ---- LARS / SGD (main_esvit.py:412-415, utils.py:519-557) ---------------------------------------------------------------
+def _oracle_lars_run():
+    p, grads = GU.lars_case()
+    p = {n: t.clone() for n, t in p.items()}
+    mu = {n: torch.zeros_like(t) for n, t in p.items()}
+    for (lr, wd), gs in zip(GU.LARS_SCHED, grads):
+        for n in p:
+            p[n], mu[n] = O.lars_update(p[n], O.clip_gradient(gs[n], 3.0), mu[n], lr, wd if p[n].ndim != 1 else 0.0)
+    return p, mu
+
+
+def test_oracle_lars_matches_reference_golden(gold):
+    p, mu = _oracle_lars_run()
+    for n in p:
+        assert (p[n] - gold["lars"]["params"][n]).abs().max().item() < 1e-6, n
+        assert (mu[n] - gold["lars"]["mu"][n]).abs().max().item() < 1e-6, n
+
+
+class _Holder(torch.nn.Module):
+    def __init__(self, tensors):
+        super().__init__()
+        for n, t in tensors.items():
+            self.register_parameter(n, torch.nn.Parameter(t.clone()))
+
+
+@pytest.mark.gpu
+def test_fused_lars_matches_reference_golden_gpu(gold, lib_built):
+    """the fused clip -> LARS -> EMA update on the fixture of the reference's utils.LARS (+ utils.clip_gradients)"""
+    from esvit_amd.update import FusedClipAdamWEMA
+    dev = torch.device("cuda:0")
+    p0, grads = GU.lars_case()
+    student, teacher = _Holder(p0).to(dev), _Holder({n: t * 0.5 for n, t in p0.items()}).to(dev)
+    upd = FusedClipAdamWEMA(student, teacher, rule="lars")
+    t_ref = {n: t * 0.5 for n, t in p0.items()}
+    ref_p = {n: t.clone() for n, t in p0.items()}
+    ref_mu = {n: torch.zeros_like(t) for n, t in p0.items()}
+    for (lr, wd), gs in zip(GU.LARS_SCHED, grads):
+        for n, prm in student.named_parameters():
+            prm.grad = gs[n].to(dev)
+        upd.step(lr, wd, 0.9, clip_grad=3.0)
+        for n in ref_p:
+            ref_p[n], ref_mu[n] = O.lars_update(ref_p[n], O.clip_gradient(gs[n], 3.0), ref_mu[n], lr, wd if ref_p[n].ndim != 1 else 0.0)
+            t_ref[n] = t_ref[n] * 0.9 + ref_p[n] * 0.1
+    sd = upd.state_dict()
+    for n, prm in student.named_parameters():
+        assert (prm.detach().cpu() - gold["lars"]["params"][n]).abs().max().item() < 2e-6, n
+    for n, prm in teacher.named_parameters():
+        assert (prm.detach().cpu() - t_ref[n]).abs().max().item() < 2e-6, n
+    order = [n for n in p0 if p0[n].ndim != 1] + [n for n in p0 if p0[n].ndim == 1]  # get_params_groups: regularised first
+    for k, n in enumerate(order):
+        assert set(sd["state"][k]) == {"mu"}
+        assert (sd["state"][k]["mu"].cpu() - gold["lars"]["mu"][n]).abs().max().item() < 2e-6, n
+
+
+@pytest.mark.gpu
+def test_fused_sgd_matches_torch_gpu(lib_built):
+    """clip + torch.optim.SGD(lr=0, momentum=0.9) (main_esvit.py:413) + EMA, three steps, through the binding the drop-in uses"""
+    import copy
+    from esvit_amd.update import bind_torch_optimizer, get_params_groups
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(300, 77), torch.nn.LayerNorm(77), torch.nn.Linear(77, 5000)).to(dev)
+    s_ref, t_ref, s_fus, t_fus = (copy.deepcopy(net) for _ in range(4))
+    for t in (t_ref, t_fus):
+        for p in t.parameters():
+            p.data.mul_(0.5)
+    opt_ref = torch.optim.SGD(get_params_groups(s_ref), lr=0, momentum=0.9)
+    opt_fus = torch.optim.SGD(get_params_groups(s_fus), lr=0, momentum=0.9)
+    upd = bind_torch_optimizer(opt_fus, s_fus, t_fus)
+    assert upd.rule == "sgd"
+    for it in range(3):
+        lr, wd, m = 0.05 * (it + 1), 0.04 + 0.01 * it, 0.99
+        grads = [torch.randn_like(p) * (10.0 if i == 0 else 0.01) for i, p in enumerate(s_ref.parameters())]
+        for (p1, p2, g) in zip(s_ref.parameters(), s_fus.parameters(), grads):
+            p1.grad, p2.grad = g.clone(), g.clone()
+        for i, pg in enumerate(opt_ref.param_groups):
+            pg["lr"] = lr
+            if i == 0:
+                pg["weight_decay"] = wd
+        for p in s_ref.parameters():
+            coef = 3.0 / (p.grad.norm(2) + 1e-6)
+            if coef < 1:
+                p.grad.mul_(coef)
+        opt_ref.step()
+        with torch.no_grad():
+            for q, k in zip(s_ref.parameters(), t_ref.parameters()):
+                k.mul_(m).add_((1 - m) * q.detach())
+        upd.step(lr, wd, m, clip_grad=3.0)
+    for a, b in zip(s_ref.parameters(), s_fus.parameters()):
+        assert (a - b).abs().max().item() < 2e-5 * (1 + a.abs().max().item())
+    for a, b in zip(t_ref.parameters(), t_fus.parameters()):
+        assert (a - b).abs().max().item() < 2e-5 * (1 + a.abs().max().item())
+    # the caller's optimizer holds the live momentum buffers and schedule values (its checkpoint is the real state)
+    assert opt_fus.param_groups[0]["lr"] == lr and opt_fus.param_groups[0]["weight_decay"] == wd
+    for pr, pf in zip(s_ref.parameters(), s_fus.parameters()):
+        br, bf = opt_ref.state[pr]["momentum_buffer"], opt_fus.state[pf]["momentum_buffer"]
+        assert (br - bf).abs().max().item() < 2e-5 * (1 + br.abs().max().item())
