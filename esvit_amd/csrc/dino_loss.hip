@@ -141,6 +141,71 @@ __global__ __launch_bounds__(NT) void dino_ce_kernel(const T* __restrict__ s, co
     if (threadIdx.x == 0) row_loss[r] = w * (nterms * lse - dot);
 }
 
+// General form for DINOLoss with mixup targets (main_esvit.py:639-641): student row r is scored against up to NTERM
+// teacher rows tmatch[r*NTERM + j] (-1 = unused) with individual weights term_w[r*NTERM + j]:
+//   row_loss = sum_j w_j (lse - q_j . z),   ds = inv_st ((sum_j w_j) p_s - sum_j w_j q_j)
+template <typename T, int NTERM>
+__global__ __launch_bounds__(NT) void dino_ce_terms_kernel(const T* __restrict__ s, const T* __restrict__ t,
+                                                           const float* __restrict__ center, const float* __restrict__ t_row_max,
+                                                           const float* __restrict__ t_row_lse, const int* __restrict__ tmatch,
+                                                           const float* __restrict__ term_w, float inv_st, float inv_tt, int K,
+                                                           float* __restrict__ row_loss, T* __restrict__ ds) {
+    __shared__ float sm[2 * NT / 64];
+    __shared__ float sm2[NT / 64];
+    constexpr int V = Vec16<T>::N;
+    const long r = blockIdx.x;
+    const T* srow = s + r * K;
+    T* drow = ds + r * K;
+    int tj[NTERM];
+    float wj[NTERM], offj[NTERM];
+    const T* trow[NTERM];
+    float wsum = 0.f;
+#pragma unroll
+    for (int j = 0; j < NTERM; ++j) {
+        tj[j] = tmatch[r * NTERM + j];
+        wj[j] = tj[j] >= 0 ? term_w[r * NTERM + j] : 0.f;
+        wsum += wj[j];
+        trow[j] = t + (long)(tj[j] >= 0 ? tj[j] : 0) * K;
+        offj[j] = tj[j] >= 0 ? t_row_max[tj[j]] + t_row_lse[tj[j]] : 0.f;
+    }
+    MS a{-3.0e38f, 0.f};
+    for (int k = threadIdx.x * V; k < K; k += NT * V) {
+        const Vec16<T> x = ld16<T>(srow + k);
+        float mx = -3.0e38f;
+#pragma unroll
+        for (int e = 0; e < V; ++e) mx = fmaxf(mx, x.get(e) * inv_st);
+        float sum = 0.f;
+#pragma unroll
+        for (int e = 0; e < V; ++e) sum += __expf(x.get(e) * inv_st - mx);
+        a = ms_merge(a, MS{mx, sum});
+    }
+    a = block_ms(a, sm);
+    const float lse = a.m + __logf(a.s);
+    float dot = 0.f;
+    for (int k = threadIdx.x * V; k < K; k += NT * V) {
+        const Vec16<T> x = ld16<T>(srow + k);
+        Vec16<T> y[NTERM];
+#pragma unroll
+        for (int j = 0; j < NTERM; ++j) y[j] = tj[j] >= 0 ? ld16<T>(trow[j] + k) : zero16<T>();
+        Vec16<T> o;
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            const float z = x.get(e) * inv_st;
+            const float ps = __expf(z - lse);
+            const float ck = center[k + e];
+            float pt = 0.f;
+#pragma unroll
+            for (int j = 0; j < NTERM; ++j)
+                if (tj[j] >= 0) pt += wj[j] * __expf((y[j].get(e) - ck) * inv_tt - offj[j]);
+            dot += pt * z;
+            o.set(e, inv_st * (wsum * ps - pt));
+        }
+        st16<T>(drow + k, o);
+    }
+    dot = block_sum<NT>(dot, sm2);
+    if (threadIdx.x == 0) row_loss[r] = wsum * lse - dot;
+}
+
 // region matching (main_esvit.py:735-738): argmax over the Tt teacher tokens of view iq + row assembly
 __global__ void region_match_kernel(const float* __restrict__ sim, int B, int S, int Tt, int ld, const int* __restrict__ crop_id,
                                     const int* __restrict__ cm_row, int* __restrict__ tmatch) {
@@ -190,21 +255,31 @@ extern "C" int esvit_teacher_row_stats(int dtype, const void* t, const float* ce
 }
 
 extern "C" int esvit_dino_ce_fwd_bwd(int dtype, const void* s, const void* t, const float* center, const float* t_row_max,
-                                     const float* t_row_lse, const int32_t* tmatch, const float* row_w, float inv_student_temp,
-                                     float inv_teacher_temp, int64_t Rs, int K, float* row_loss, void* ds, esvit_stream_t s_) {
+                                     const float* t_row_lse, const int32_t* tmatch, const float* row_w, int terms, const float* term_w,
+                                     float inv_student_temp, float inv_teacher_temp, int64_t Rs, int K, float* row_loss, void* ds,
+                                     esvit_stream_t s_) {
     STREAM(s_);
-    ESVIT_CHECK_ARG(s && t && center && t_row_max && t_row_lse && tmatch && row_w && row_loss && ds && Rs > 0 && K > 0 && K % 8 == 0,
+    ESVIT_CHECK_ARG(s && t && center && t_row_max && t_row_lse && tmatch && row_loss && ds && Rs > 0 && K > 0 && K % 8 == 0,
                     "esvit_dino_ce_fwd_bwd: bad args (K=%d)", K);
+    ESVIT_CHECK_ARG(dtype == ESVIT_BF16 || dtype == ESVIT_F32, "esvit_dino_ce_fwd_bwd: bad dtype");
+    if (term_w) {  // individually weighted terms (mixup targets)
+        ESVIT_CHECK_ARG(terms == 4, "esvit_dino_ce_fwd_bwd: weighted terms come four per row (got %d)", terms);
+        if (dtype == ESVIT_BF16)
+            hipLaunchKernelGGL((dino_ce_terms_kernel<bf16, 4>), dim3((unsigned)Rs), dim3(NT), 0, stream, (const bf16*)s, (const bf16*)t, center,
+                               t_row_max, t_row_lse, tmatch, term_w, inv_student_temp, inv_teacher_temp, K, row_loss, (bf16*)ds);
+        else
+            hipLaunchKernelGGL((dino_ce_terms_kernel<float, 4>), dim3((unsigned)Rs), dim3(NT), 0, stream, (const float*)s, (const float*)t,
+                               center, t_row_max, t_row_lse, tmatch, term_w, inv_student_temp, inv_teacher_temp, K, row_loss, (float*)ds);
+        ESVIT_CHECK_LAUNCH("dino_ce_fwd_bwd(terms)");
+        return ESVIT_OK;
+    }
+    ESVIT_CHECK_ARG(row_w && terms == 2, "esvit_dino_ce_fwd_bwd: two equally weighted terms per row need row_w");
     if (dtype == ESVIT_BF16)
         hipLaunchKernelGGL(dino_ce_kernel<bf16>, dim3((unsigned)Rs), dim3(NT), 0, stream, (const bf16*)s, (const bf16*)t, center,
                            t_row_max, t_row_lse, tmatch, row_w, inv_student_temp, inv_teacher_temp, K, row_loss, (bf16*)ds);
-    else if (dtype == ESVIT_F32)
+    else
         hipLaunchKernelGGL(dino_ce_kernel<float>, dim3((unsigned)Rs), dim3(NT), 0, stream, (const float*)s, (const float*)t, center,
                            t_row_max, t_row_lse, tmatch, row_w, inv_student_temp, inv_teacher_temp, K, row_loss, (float*)ds);
-    else {
-        esvit_set_error("esvit_dino_ce_fwd_bwd: bad dtype");
-        return ESVIT_ERR_ARG;
-    }
     ESVIT_CHECK_LAUNCH("dino_ce_fwd_bwd");
     return ESVIT_OK;
 }

@@ -155,18 +155,20 @@ class EsvitTrainer:
         self.updater = updater if updater is not None else FusedClipAdamWEMA(student, teacher)
         self.reducer = GradBucketReducer(student, bucket_mb)
 
-    def step(self, images, lr, wd, momentum, epoch, scaler=None):
-        """scaler: a ``torch.cuda.amp.GradScaler`` (the reference's --use_fp16 mode, main_esvit.py:417-419, 576-584) or None."""
+    def step(self, images, lr, wd, momentum, epoch, scaler=None, teacher_images=None, targets_mixup=None):
+        """scaler: a ``torch.cuda.amp.GradScaler`` (the reference's --use_fp16 mode, main_esvit.py:417-419, 576-584) or None.
+        teacher_images / targets_mixup: the un-mixed global views and the per-crop target matrices of the mixup mode
+        (main_esvit.py:515-538); `images` are then the mixed student inputs."""
         with torch.no_grad():
-            teacher_out = self.teacher(images[:2])
+            teacher_out = self.teacher(images[:2] if teacher_images is None else teacher_images)
         student_out = self.student(images)
         if scaler is not None:
-            return self._scaled_update(scaler, student_out, teacher_out, lr, wd, momentum, epoch)
+            return self._scaled_update(scaler, student_out, teacher_out, lr, wd, momentum, epoch, targets_mixup)
         # loss.backward() below always uses grad_output == 1: the loss skips its rescale pass for this call only
         prev = getattr(self.loss_fn, "assume_unit_grad", False)
         self.loss_fn.assume_unit_grad = True
         try:
-            loss = self.loss_fn(student_out, teacher_out, epoch, None)
+            loss = self.loss_fn(student_out, teacher_out, epoch, targets_mixup)
         finally:
             self.loss_fn.assume_unit_grad = prev
         self.reducer.begin()
@@ -177,12 +179,12 @@ class EsvitTrainer:
         return loss.detach()
 
 
-    def _scaled_update(self, scaler, student_out, teacher_out, lr, wd, momentum, epoch):
+    def _scaled_update(self, scaler, student_out, teacher_out, lr, wd, momentum, epoch, targets_mixup=None):
         """main_esvit.py:576-584 with the fused update as the optimizer: scale(loss).backward() -> unscale_ -> (clip +
         AdamW + EMA if every gradient is finite) -> update().  The activations stay bf16 (the modules keep their own
         precision policy; fp16 is not an activation dtype of the kernels), so the scale factor only ever matters through
         GradScaler's own protocol: power-of-two scales are exact in bf16 / fp32 and the step equals the unscaled one."""
-        loss = self.loss_fn(student_out, teacher_out, epoch, None)  # grad_output = scale: the loss rescales its gradient
+        loss = self.loss_fn(student_out, teacher_out, epoch, targets_mixup)  # grad_output = scale: the loss rescales its gradient
         self.reducer.begin()
         scaler.scale(loss).backward()
         self.reducer.finish()
@@ -218,9 +220,9 @@ def train_one_epoch(student, teacher, teacher_without_ddp, dino_loss, data_loade
     (main_esvit.py:444-452, 476-488) checkpoint and restore the real state.  Any other optimizer is refused.  `student` may be DDP-wrapped (its .module is trained, gradients are
     reduced by GradBucketReducer instead).  `fp16_scaler`: the reference's GradScaler protocol is followed with the fused
     update in the optimizer's place (EsvitTrainer._scaled_update); the caller keeps checkpointing ``fp16_scaler.state_dict()``.
+    `mixup_fn` (timm's Mixup or any callable (samples, targets) -> (samples, target matrix)): the crops are mixed and the
+    target matrices reach the loss exactly as in main_esvit.py:515-544 (DINOLoss uses them, DDINOLoss ignores them).
     Returns the rank-averaged epoch means the reference logs (main_esvit.py:593-600)."""
-    if mixup_fn is not None:
-        raise NotImplementedError("mixup (main_esvit.py:518-534) is out of scope (SURVEY.md 8f-3)")
     net = student.module if hasattr(student, "module") else student
     if optimizer_rule(optimizer) is None:
         raise TypeError("esvit_amd.engine.train_one_epoch drives the optimizers of main_esvit.py:408-415 -- torch.optim.AdamW, "
@@ -243,7 +245,21 @@ def train_one_epoch(student, teacher, teacher_without_ddp, dino_loss, data_loade
     for it, (images, _) in enumerate(data_loader):
         git = n_it * epoch + it
         images = [im.cuda(non_blocking=True) for im in images]
-        last = tr.step(images, lr_schedule[git], wd_schedule[git], momentum_schedule[git], epoch, scaler=fp16_scaler)
+        teacher_images, targets_mixup = None, None
+        if mixup_fn is not None:  # main_esvit.py:515-538: the first num_mixup_views crops are mixed, the teacher sees the originals
+            teacher_images, student_input, targets_mixup, n_mix = images[:2], [], [], 0
+            bs = args.batch_size_per_gpu
+            for samples in images:
+                if n_mix < args.num_mixup_views:
+                    samples, targets = mixup_fn(samples, torch.arange(0, bs, dtype=torch.long, device=samples.device))
+                    n_mix += 1
+                else:
+                    targets = torch.eye(bs, device=samples.device)
+                student_input.append(samples)
+                targets_mixup.append(targets)
+            images = student_input
+        last = tr.step(images, lr_schedule[git], wd_schedule[git], momentum_schedule[git], epoch, scaler=fp16_scaler,
+                       teacher_images=teacher_images, targets_mixup=targets_mixup)
         loss_sum += last
         if it % 10 == 0 or it == n_it - 1:  # the reference syncs every iteration (main_esvit.py:546,593); 1-in-10 keeps the NaN guard
             v = last.item()

@@ -100,17 +100,40 @@ class DINOLoss(_DeferredCenter, nn.Module):
             self._tables[key] = t
         return t
 
+    def _mixup_terms(self, targets_mixup, B, device):
+        """main_esvit.py:639-641: for teacher view iq and student crop v the loss is mean_a -sum_b T_v[a, b] q_a . logp_b, i.e.
+        student row (v, b) is scored against the teacher rows a with T_v[a, b] != 0.  Mixup / cutmix targets (and the identity
+        of the un-mixed crops) have at most two non-zeros per column, which gives at most four weighted terms per student row."""
+        T = torch.stack([t.to(device=device, dtype=torch.float32) for t in targets_mixup])       # [ncrops, a, b]
+        assert T.shape == (self.ncrops, B, B), "targets_mixup: one [B, B] matrix per crop"
+        if int((T != 0).sum(1).max()) > 2:
+            raise NotImplementedError("DINOLoss mixup targets with more than two non-zeros per column")
+        w2, a2 = torch.topk(T.abs(), 2, dim=1)                                                   # [ncrops, 2, b]
+        w2 = torch.gather(T, 1, a2)
+        n_terms = 2 * self.ncrops - 2
+        tm = torch.full((self.ncrops, B, 4), -1, dtype=torch.int32, device=device)
+        tw = torch.zeros((self.ncrops, B, 4), dtype=torch.float32, device=device)
+        for iq in range(2):
+            for j in range(2):
+                tm[:, :, 2 * iq + j] = (iq * B + a2[:, j, :]).to(torch.int32)
+                tw[:, :, 2 * iq + j] = w2[:, j, :] / (n_terms * B)
+            tm[iq, :, 2 * iq:2 * iq + 2] = -1   # student and teacher on the same view: skipped (main_esvit.py:636-638)
+        tm[tw == 0] = -1
+        return tm.view(-1, 4).contiguous(), tw.view(-1, 4).contiguous()
+
     def forward(self, student_output, teacher_output, epoch, targets_mixup=None):
-        if targets_mixup:
-            raise NotImplementedError("DINOLoss mixup targets (main_esvit.py:639-641) are out of scope (SURVEY.md 8f-3)")
         o = _ops()
         self.synchronize()
         s, t = student_output.contiguous(), teacher_output.detach().contiguous()
         B = t.shape[0] // 2
         inv_tt = 1.0 / float(self.teacher_temp_schedule[epoch])
-        tmatch, w = self._static(B, s.device)
         mx, lse = o.teacher_row_stats(t, self.center, inv_tt)
-        row_loss, ds = o.dino_ce(s.detach(), t, self.center, mx, lse, tmatch, w, 1.0 / self.student_temp, inv_tt)
+        if targets_mixup:
+            tmatch, tw = self._mixup_terms(targets_mixup, B, s.device)
+            row_loss, ds = o.dino_ce(s.detach(), t, self.center, mx, lse, tmatch, None, 1.0 / self.student_temp, inv_tt, term_w=tw)
+        else:
+            tmatch, w = self._static(B, s.device)
+            row_loss, ds = o.dino_ce(s.detach(), t, self.center, mx, lse, tmatch, w, 1.0 / self.student_temp, inv_tt)
         loss = o.sum_f32(row_loss)
         self.update_center(t)
         return _LossFn.apply(loss, self.assume_unit_grad, student_output, ds)

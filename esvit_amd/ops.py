@@ -600,8 +600,9 @@ def region_match(sim, Tt, crop_id, cm_row, tmatch):
     return tmatch
 
 
-def dino_ce(s, t, center, t_max, t_lse, tmatch, row_w, inv_student_temp, inv_teacher_temp, row_loss=None):
-    """-> (row_loss fp32 [Rs], ds act [Rs, K])."""
+def dino_ce(s, t, center, t_max, t_lse, tmatch, row_w, inv_student_temp, inv_teacher_temp, row_loss=None, term_w=None):
+    """-> (row_loss fp32 [Rs], ds act [Rs, K]).  tmatch int32 [Rs, 2] with one weight row_w[r] for both terms, or (mixup
+    targets) tmatch [Rs, 4] with term_w fp32 [Rs, 4], one weight per term."""
     s, t = _actc(s), _actc(t)
     Rs, K = s.shape
     assert t.shape[1] == K and s.dtype == t.dtype and tmatch.dtype == torch.int32
@@ -609,8 +610,11 @@ def dino_ce(s, t, center, t_max, t_lse, tmatch, row_w, inv_student_temp, inv_tea
         row_loss = torch.empty((Rs,), dtype=torch.float32, device=s.device)
     assert row_loss.numel() == Rs and row_loss.is_contiguous()
     ds = torch.empty_like(s)
-    check(lib.esvit_dino_ce_fwd_bwd(_code(s.dtype), _p(s), _p(t), _p(center), _p(t_max), _p(t_lse), _p(tmatch), _p(row_w),
-                                    inv_student_temp, inv_teacher_temp, Rs, K, _p(row_loss), _p(ds), _stream()), "dino_ce_fwd_bwd")
+    terms = 2 if term_w is None else 4
+    assert tmatch.numel() == Rs * terms and tmatch.is_contiguous() and (term_w is None or (term_w.numel() == Rs * 4 and term_w.is_contiguous()))
+    check(lib.esvit_dino_ce_fwd_bwd(_code(s.dtype), _p(s), _p(t), _p(center), _p(t_max), _p(t_lse), _p(tmatch), _p(row_w), terms,
+                                    _p(term_w), inv_student_temp, inv_teacher_temp, Rs, K, _p(row_loss), _p(ds), _stream()),
+          "dino_ce_fwd_bwd")
     return row_loss, ds
 
 

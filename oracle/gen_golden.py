@@ -259,6 +259,7 @@ def gen_variants(ns):
     """SURVEY.md 8f-3 step variants, each from the reference's own code:
     bn_head -- DINOHead(use_bn=True) (vision_transformer.py:384-418) in train mode (batch statistics, running-stat update)
                and in eval mode (running statistics): logits, every gradient of sum(logits * probe), the buffers after."""
+    RL.ensure_single_process_group()
     g = {}
     c = GU.BN_HEAD
     head = ns.DINOHead(c["in_dim"], c["out_dim"], use_bn=True, hidden_dim=c["hidden_dim"], bottleneck_dim=c["bottleneck_dim"])
@@ -299,7 +300,17 @@ def gen_variants(ns):
         opt.step()
     g["lars"] = {"params": {n: prm.detach().clone() for n, prm in net.named_parameters()},
                  "mu": {n: opt.state[prm]["mu"].clone() for n, prm in net.named_parameters()}}
+    # mixup -- the reference's DINOLoss.forward with targets_mixup (main_esvit.py:639-641)
+    mc = GU.MIXUP
+    s_l, t_l, c0, T = GU.mixup_case()
+    lf = ns.DINOLoss(mc["K"], mc["ncrops"], 0.04, 0.07, 5, 10)
+    lf.center.copy_(c0)
+    s_l = s_l.clone().requires_grad_(True)
+    lm = lf(s_l, t_l, 2, T)
+    lm.backward()
+    g["mixup"] = {"loss": lm.item(), "ds": s_l.grad.clone(), "center_after": lf.center.clone()}
     torch.save(g, os.path.join(OUT, "variants.pt"))
+    print("variants.pt: mixup loss", g["mixup"]["loss"])
     print("variants.pt: bn_head logits", tuple(g["bn_head"]["logits"].shape), "grads", len(g["bn_head"]["grads"]))
 
 

@@ -526,10 +526,25 @@ def region_match(sim, Tt, crop_id, cm_row, tmatch):
     return tmatch
 
 
-def dino_ce(s, t, center, t_max, t_lse, tmatch, row_w, inv_student_temp, inv_teacher_temp, row_loss=None):
+def dino_ce(s, t, center, t_max, t_lse, tmatch, row_w, inv_student_temp, inv_teacher_temp, row_loss=None, term_w=None):
     z = s.float() * inv_student_temp
     lse = torch.logsumexp(z, 1)
     ps = torch.exp(z - lse[:, None])
+    if term_w is not None:  # four individually weighted terms per row (mixup targets)
+        tm = tmatch.view(-1, 4).long()
+        w = term_w.view(-1, 4) * (tm >= 0)
+        pt = torch.zeros_like(z)
+        for j in range(4):
+            ii = tm[:, j].clamp(min=0)
+            pj = torch.exp((t.float()[ii] - center.view(1, -1)) * inv_teacher_temp - (t_max[ii] + t_lse[ii])[:, None])
+            pt = pt + pj * w[:, j:j + 1]
+        wsum = w.sum(1)
+        rl = wsum * lse - (pt * z).sum(1)
+        if row_loss is not None:
+            row_loss.copy_(rl)
+        else:
+            row_loss = rl
+        return row_loss, _r(inv_student_temp * (wsum[:, None] * ps - pt), s.dtype)
     tm = tmatch.view(-1, 2).long()
     pt = torch.zeros_like(z)
     nterms = (tm >= 0).sum(1).float()

@@ -96,3 +96,21 @@ def lars_case():
     params = {n: torch.randn(s, generator=g) * 0.3 for n, s in LARS_SHAPES.items()}
     grads = [{n: torch.randn(s, generator=g) * (2.0 if n == "w1" else 0.05) for n, s in LARS_SHAPES.items()} for _ in LARS_SCHED]
     return params, grads
+
+
+# ---- DINOLoss with mixup targets (main_esvit.py:518-534, 639-641) ---------------------------------------------------------
+MIXUP = dict(B=6, ncrops=4, K=64, lams=(0.7, 0.35))  # the first two crops are mixed (num_mixup_views = 2), the others are not
+
+
+def mixup_case():
+    """-> (student logits [ncrops*B, K], teacher logits [2B, K], centre [1, K], [T_v [B, B] per crop]).  T_v of a mixed crop is
+    what timm's Mixup returns for targets = arange(B): lam * onehot(a) + (1 - lam) * onehot(B - 1 - a) (batch mode pairs a sample
+    with the flipped batch); un-mixed crops get the identity, as train_one_epoch builds it."""
+    c = MIXUP
+    g = torch.Generator().manual_seed(9090)
+    s = torch.randn(c["ncrops"] * c["B"], c["K"], generator=g)
+    t = torch.randn(2 * c["B"], c["K"], generator=g)
+    center = torch.randn(1, c["K"], generator=g) * 0.1
+    eye = torch.eye(c["B"])
+    T = [lam * eye + (1 - lam) * eye.flip(0) for lam in c["lams"]] + [eye.clone() for _ in range(c["ncrops"] - len(c["lams"]))]
+    return s, t, center, T

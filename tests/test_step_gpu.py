@@ -367,8 +367,6 @@ def test_train_one_epoch_drop_in_gpu(lib_built):
         # (d) anything train_esvit cannot build (AdamW / SGD / LARS) is refused instead of silently ignored
         with pytest.raises(TypeError):
             engine.train_one_epoch(s4, t4, t4, l4, one, torch.optim.Adam(s4.parameters(), lr=0.1), sched["lr"][2:], sched["wd"][2:], sched["mom"][2:], 0, None, None, args)
-        with pytest.raises(NotImplementedError):  # mixup_fn
-            engine.train_one_epoch(s4, t4, t4, l4, one, o4, sched["lr"][2:], sched["wd"][2:], sched["mom"][2:], 0, object(), None, args)
         # (e) the --use_fp16 protocol (main_esvit.py:417-419, 576-584): GradScaler.scale / unscale_ / step / update around the
         # fused update.  Power-of-two scales are exact, so the scaled run equals the plain one; the scale grows on schedule.
         s5, t5, l5 = fresh()

@@ -205,3 +205,125 @@ def test_fused_sgd_matches_torch_gpu(lib_built):
     for pr, pf in zip(s_ref.parameters(), s_fus.parameters()):
         br, bf = opt_ref.state[pr]["momentum_buffer"], opt_fus.state[pf]["momentum_buffer"]
         assert (br - bf).abs().max().item() < 2e-5 * (1 + br.abs().max().item())
+
+
+# ---- DINOLoss with mixup targets (main_esvit.py:518-534, 639-641) -----------------------------------------------------------
+def test_oracle_mixup_loss_matches_reference_golden(gold):
+    s, t, c0, T = GU.mixup_case()
+    s = s.clone().requires_grad_(True)
+    loss, _ = O.dino_loss(s, t, c0, O.teacher_temp(2, 0.04, 0.07, 5, 10), GU.MIXUP["ncrops"], targets_mixup=T)
+    loss.backward()
+    assert abs(loss.item() - gold["mixup"]["loss"]) < 1e-6
+    assert (s.grad - gold["mixup"]["ds"]).abs().max().item() < 1e-7
+
+
+def _check_mixup_loss(dev, gold, tol):
+    import esvit_amd
+    mc = GU.MIXUP
+    s, t, c0, T = GU.mixup_case()
+    lf = esvit_amd.DINOLoss(mc["K"], mc["ncrops"], 0.04, 0.07, 5, 10).to(dev)
+    lf.center.copy_(c0.to(dev))
+    s = s.to(dev).requires_grad_(True)
+    loss = lf(s, t.to(dev), 2, [m.to(dev) for m in T])
+    (loss * 3.0).backward()  # a non-unit grad_output exercises the rescale pass as well
+    lf.synchronize()
+    assert abs(loss.item() - gold["mixup"]["loss"]) < tol * 10
+    assert (s.grad.float().cpu() / 3.0 - gold["mixup"]["ds"]).abs().max().item() < tol
+    assert (lf.center.cpu() - gold["mixup"]["center_after"]).abs().max().item() < 1e-5
+    # without targets the same module still gives the plain loss (the static two-term tables are not disturbed)
+    plain, _ = O.dino_loss(gold["_s"], gold["_t"], gold["mixup"]["center_after"], O.teacher_temp(2, 0.04, 0.07, 5, 10), mc["ncrops"])
+    got = lf(gold["_s"].to(dev), gold["_t"].to(dev), 2, None)
+    assert abs(got.item() - plain.item()) < tol * 10
+
+
+def test_mixup_loss_host_logic_cpu(gold, monkeypatch, lib_built):
+    import esvit_amd
+    import esvit_amd.loss as L
+    esvit_amd.set_precision("fp32")
+    monkeypatch.setattr(L, "ops", ops_ref)
+    g = dict(gold)
+    g["_s"], g["_t"] = GU.mixup_case()[:2]
+    _check_mixup_loss(torch.device("cpu"), g, 5e-6)
+
+
+@pytest.mark.gpu
+def test_mixup_loss_gpu(gold, lib_built):
+    import esvit_amd
+    esvit_amd.set_precision("fp32")
+    try:
+        g = dict(gold)
+        g["_s"], g["_t"] = GU.mixup_case()[:2]
+        _check_mixup_loss(torch.device("cuda:0"), g, 5e-6)
+    finally:
+        esvit_amd.set_precision("bf16")
+
+
+@pytest.mark.gpu
+def test_train_one_epoch_mixup_drop_in_gpu(lib_built):
+    """engine.train_one_epoch with a mixup_fn (main_esvit.py:515-544): the first num_mixup_views crops are mixed, the teacher
+    sees the un-mixed global views, the target matrices reach DINOLoss.  Checked against the oracle on the logits the HIP
+    path produced, and against an explicit EsvitTrainer.step with the same mixed inputs."""
+    import argparse
+    import esvit_amd
+    from esvit_amd import engine
+    from esvit_amd.update import get_params_groups
+    from tests.test_composition_cpu import build_nano_view
+    esvit_amd.set_precision("fp32")
+    try:
+        dev = torch.device("cuda:0")
+        K, B = GU.NANO_HEAD["out_dim"], 4
+
+        def fresh():
+            s, t = build_nano_view(), build_nano_view(teacher=True)
+            GU.fill_state_dict(s.state_dict(), 0)
+            GU.fill_state_dict(t.state_dict(), 7)
+            s.head.last_layer.weight_g.data.fill_(1)
+            for p in t.parameters():
+                p.requires_grad = False
+            return s.to(dev), t.to(dev), esvit_amd.DINOLoss(K, 10, 0.04, 0.07, 5, 10).to(dev)
+
+        lams = iter([0.8, 0.3, 0.8, 0.3])
+
+        def mixup_fn(x, targets):  # timm.data.Mixup in 'batch' mode with a fixed lambda sequence
+            lam = next(lams)
+            onehot = torch.nn.functional.one_hot(targets, B).float()
+            return x * lam + x.flip(0) * (1 - lam), onehot * lam + onehot.flip(0) * (1 - lam)
+
+        crops = [c.to(dev) for c in GU.make_crops(B, seed=5)]
+        args = argparse.Namespace(clip_grad=3.0, freeze_last_layer=0, batch_size_per_gpu=B, num_mixup_views=2)
+
+        class Loader:
+            sampler = None
+
+            def __len__(self):
+                return 1
+
+            def __iter__(self):
+                return iter([(crops, None)])
+
+        s1, t1, l1 = fresh()
+        o1 = torch.optim.AdamW(get_params_groups(s1))
+        init = {n: p.detach().clone() for n, p in s1.named_parameters()}
+        st = engine.train_one_epoch(s1, t1, t1, l1, Loader(), o1, [1e-3], [0.04], [0.99], 0, mixup_fn, None, args)
+        # explicit: same mixing, oracle loss on the HIP logits
+        s2, t2, l2 = fresh()
+        mixed, T = [], []
+        for i, c in enumerate(crops):
+            if i < 2:
+                m, tt = mixup_fn(c, torch.arange(B, device=dev))
+            else:
+                m, tt = c, torch.eye(B, device=dev)
+            mixed.append(m)
+            T.append(tt)
+        with torch.no_grad():
+            s_log, t_log = s2(mixed), t2(crops[:2])
+            want, _ = O.dino_loss(s_log.cpu(), t_log.cpu(), torch.zeros(1, K), O.teacher_temp(0, 0.04, 0.07, 5, 10), 10,
+                                  targets_mixup=[m.cpu() for m in T])
+        assert abs(st["loss"] - want.item()) < 2e-4, (st["loss"], want.item())
+        tr = engine.EsvitTrainer(s2, t2, l2, clip_grad=3.0, freeze_last_layer=0)
+        tr.step(mixed, 1e-3, 0.04, 0.99, 0, teacher_images=crops[:2], targets_mixup=T)
+        for (n, a), (_, b) in zip(s1.named_parameters(), s2.named_parameters()):
+            ua, ub = (a - init[n]).detach(), (b - init[n]).detach()
+            assert (ua - ub).norm().item() <= 2e-2 * ub.norm().item() + 1e-9, n
+    finally:
+        esvit_amd.set_precision("bf16")
