@@ -523,6 +523,31 @@ def dino_head(x, prm):
     return _head_forward(x, prm, False)[0]
 
 
+class ApeAddFn(torch.autograd.Function):
+    """x + absolute_pos_embed (swin_transformer.py:680-681, USE_APE): x fp32 [nB, L, C], ape fp32 [1, L, C].  Viewed as
+    [1, nB, L*C] the broadcast over the images is the token-broadcast of esvit_token_mean_bwd (x_b + nB*ape / nB), and the
+    parameter gradient, the sum over the images, is nB times esvit_token_mean_fwd -- no new kernel."""
+
+    @staticmethod
+    def forward(ctx, x, ape):
+        o = ops_module()
+        nB, L, C = x.shape
+        if tuple(ape.shape) != (1, L, C):
+            raise ValueError("absolute_pos_embed %s does not fit %d tokens: USE_APE supports crops of the construction resolution only "
+                             "(the reference's broadcast add fails the same way)" % (tuple(ape.shape), L))
+        n = torch.full((), float(nB), dtype=torch.float32, device=x.device)
+        g = o.scale_inplace(ape.detach().clone().view(1, L * C), n)
+        ctx.n = n
+        return o.token_mean_bwd(g, x.contiguous().view(1, nB, L * C), nB).view(nB, L, C)
+
+    @staticmethod
+    def backward(ctx, gy):
+        o = ops_module()
+        nB, L, C = gy.shape
+        dape, _ = o.token_mean_fwd(gy.contiguous().view(1, nB, L * C), dtype=torch.float32)
+        return gy, o.scale_inplace(dape, ctx.n).view(1, L, C)
+
+
 # ---- DINOHead(use_bn=True): Linear -> BatchNorm1d -> GELU (x2) -> Linear -> l2-normalise -> weight-normed last layer
 # (vision_transformer.py:391-402, 414-418).  The Linear writes its pre-norm output d; one pass gives the batch sums, the
 # [C]-sized coefficient kernel turns them into y = a d + shift and updates the running statistics, and GELU rides on the

@@ -245,13 +245,14 @@ class SwinTransformer(nn.Module):
                  attn_drop_rate=0., drop_path_rate=0.1, norm_layer=nn.LayerNorm, ape=False, patch_norm=True,
                  use_dense_prediction=False, **kwargs):
         super().__init__()
-        if ape:
-            raise NotImplementedError("USE_APE is False in every reference yaml")
         self.num_classes, self.num_layers, self.embed_dim = num_classes, len(depths), embed_dim
         self.ape, self.patch_norm, self.mlp_ratio = ape, patch_norm, mlp_ratio
         self.num_features = int(embed_dim * 2 ** (self.num_layers - 1))
         self.patch_embed = PatchEmbed(img_size, patch_size, in_chans, embed_dim, norm_layer if patch_norm else None)
         self.patches_resolution = self.patch_embed.patches_resolution
+        if self.ape:  # USE_APE (swin_transformer.py:623-627)
+            self.absolute_pos_embed = nn.Parameter(torch.zeros(1, self.patch_embed.num_patches, embed_dim))
+            _trunc_normal_(self.absolute_pos_embed, std=.02)
         self.pos_drop = nn.Dropout(p=drop_rate)
         dpr = [x.item() for x in torch.linspace(0, drop_path_rate, sum(depths))]
         self.layers = nn.ModuleList()
@@ -294,7 +295,10 @@ class SwinTransformer(nn.Module):
     # ---- forward paths -----------------------------------------------------------------------
     def _tokens(self, x):
         self._draw_drop_path(x.shape[0], x.device)
-        return self.patch_embed(x)
+        x = self.patch_embed(x)
+        if self.ape:
+            x = Fn.ApeAddFn.apply(x, self.absolute_pos_embed)
+        return x
 
     def _draw_drop_path(self, nB, device):
         """Stochastic-depth factors floor(keep + U[0,1)) / keep (vision_transformer.py:30-38) for BOTH residual branches
@@ -368,7 +372,7 @@ class SwinTransformer(nn.Module):
         if self.use_dense_prediction:
             cls_parts, fea_parts, npatch = [], [], []
             all_fea = None
-            if self.ragged_multi_crop and len(bounds) > 1:
+            if self.ragged_multi_crop and len(bounds) > 1 and not self.ape:
                 # every resolution group through the backbone at once (row-wise kernels see all rows, attention runs per group)
                 maps, all_fea = self.forward_feature_maps_multi([x[a:b] for a, b in bounds])
             else:
@@ -427,15 +431,47 @@ class SwinTransformer(nn.Module):
         return torch.cat(output, dim=-1)
 
     def init_weights(self, pretrained='', pretrained_layers=[], verbose=True):
-        """load matching keys of a pretrained state_dict (swin_transformer.py:852-917; bias-table / APE resizing of
-        mismatched window sizes is out of scope: tables must match)."""
-        if os.path.isfile(pretrained):
-            sd = torch.load(pretrained, map_location='cpu')
-            own = self.state_dict()
-            sd = {k: v for k, v in sd.items() if k in own and v.shape == own[k].shape}
+        """Load the keys of a pretrained state_dict this model also has (swin_transformer.py:852-917).  As in the reference
+        every such key is loaded (its `need_init` test is always true, whatever `pretrained_layers` says); a
+        relative_position_bias_table of another window size and an absolute_pos_embed of another grid are resized
+        bicubically (:873-912); any other shape mismatch is an error, as load_state_dict makes it there.  One deliberate
+        difference: the derived integer / mask buffers (`relative_position_index`, `attn_mask`) are skipped when their shape
+        differs -- the reference means to skip them (:866-867) but its test is always true, so there a checkpoint of another
+        window size can never be loaded and the table-resizing branch is unreachable."""
+        if not os.path.isfile(pretrained):
+            return
+        sd = torch.load(pretrained, map_location='cpu')
+        logging.info(f'=> loading pretrained model {pretrained}')
+        own = self.state_dict()
+        picked = {}
+        for k, v in sd.items():
+            if k not in own:
+                continue
             if verbose:
-                logging.info(f'=> loading {len(sd)} tensors from {pretrained}')
-            self.load_state_dict(sd, strict=False)
+                logging.info(f'=> init {k} from {pretrained}')
+            want = own[k].shape
+            if ('relative_position_index' in k or 'attn_mask' in k) and v.shape != want:
+                continue
+            if 'relative_position_bias_table' in k and v.shape != want:
+                (L1, nH1), (L2, nH2) = v.shape, want
+                if nH1 != nH2:
+                    logging.info(f"Error in loading {k}, passing")
+                elif L1 != L2:
+                    logging.info('=> load_pretrained: resized variant: {} to {}'.format((L1, nH1), (L2, nH2)))
+                    S1, S2 = int(L1 ** 0.5), int(L2 ** 0.5)
+                    grid = torch.nn.functional.interpolate(v.permute(1, 0).view(1, nH1, S1, S1), size=(S2, S2), mode='bicubic')
+                    v = grid.view(nH2, L2).permute(1, 0)
+            if 'absolute_pos_embed' in k and v.shape != want:
+                (_, L1, C1), (_, L2, C2) = v.shape, want
+                if C1 != C2:
+                    logging.info(f"Error in loading {k}, passing")
+                elif L1 != L2:
+                    logging.info('=> load_pretrained: resized variant: {} to {}'.format((1, L1, C1), (1, L2, C2)))
+                    S1, S2 = int(L1 ** 0.5), int(L2 ** 0.5)
+                    grid = torch.nn.functional.interpolate(v.reshape(-1, S1, S1, C1).permute(0, 3, 1, 2), size=(S2, S2), mode='bicubic')
+                    v = grid.permute(0, 2, 3, 1).flatten(1, 2)
+            picked[k] = v
+        self.load_state_dict(picked, strict=False)
 
     def freeze_pretrained_layers(self, frozen_layers=[]):
         for name, module in self.named_modules():

@@ -300,6 +300,19 @@ def gen_variants(ns):
         opt.step()
     g["lars"] = {"params": {n: prm.detach().clone() for n, prm in net.named_parameters()},
                  "mu": {n: opt.state[prm]["mu"].clone() for n, prm in net.named_parameters()}}
+    # ape -- USE_APE (swin_transformer.py:623-627, 680-681): three-stage nano Swin at 112^2 (28 x 28 token grid), features of a batch
+    #        and the gradients of sum(cls * probe) wrt the embedding and two other parameters
+    cfg = RL.swin_config(embed_dim=GU.NANO["embed_dim"], depths=(2, 2, 2), heads=(1, 2, 4), window=GU.NANO["window"], img=112)
+    cfg.MODEL["SPEC"]["USE_APE"] = True
+    m = ns.models.build_model(cfg, is_teacher=False, use_dense_prediction=False)
+    GU.fill_state_dict(m.state_dict(), 17)
+    xa, pr = GU.ape_inputs(m.num_features)
+    cls = m.forward_features(xa)
+    (cls * pr).sum().backward()
+    names = ["absolute_pos_embed", "patch_embed.proj.weight", "layers.0.blocks.0.attn.qkv.weight", "norm.weight"]
+    prm = dict(m.named_parameters())
+    g["ape"] = {"keys": [(k, tuple(v.shape)) for k, v in m.state_dict().items()], "cls": cls.detach().clone(),
+                "grads": {n: prm[n].grad.clone() for n in names}}
     # mixup -- the reference's DINOLoss.forward with targets_mixup (main_esvit.py:639-641)
     mc = GU.MIXUP
     s_l, t_l, c0, T = GU.mixup_case()

@@ -114,3 +114,9 @@ def mixup_case():
     eye = torch.eye(c["B"])
     T = [lam * eye + (1 - lam) * eye.flip(0) for lam in c["lams"]] + [eye.clone() for _ in range(c["ncrops"] - len(c["lams"]))]
     return s, t, center, T
+
+
+# ---- USE_APE: three-stage nano Swin at 112^2 -------------------------------------------------------------------------------------------
+def ape_inputs(num_features, B=3):
+    g = torch.Generator().manual_seed(1717)
+    return torch.randn(B, 3, 112, 112, generator=g), torch.randn(B, num_features, generator=g)

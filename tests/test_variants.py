@@ -327,3 +327,77 @@ def test_train_one_epoch_mixup_drop_in_gpu(lib_built):
             assert (ua - ub).norm().item() <= 2e-2 * ub.norm().item() + 1e-9, n
     finally:
         esvit_amd.set_precision("bf16")
+
+
+# ---- USE_APE (swin_transformer.py:623-627, 680-681) -----------------------------------------------------------------------
+def _ape_model():
+    from esvit_amd import models
+    from oracle import ref_loader as RL
+    cfg = RL.swin_config(embed_dim=GU.NANO["embed_dim"], depths=(2, 2, 2), heads=(1, 2, 4), window=GU.NANO["window"], img=112)
+    cfg.MODEL["SPEC"]["USE_APE"] = True
+    m = models.build_model(cfg, is_teacher=False, use_dense_prediction=False)
+    GU.fill_state_dict(m.state_dict(), 17)
+    return m
+
+
+def _check_ape(m, g, dev, tol):
+    assert [(k, tuple(v.shape)) for k, v in m.state_dict().items()] == g["keys"]  # absolute_pos_embed sits where the reference puts it
+    x, pr = GU.ape_inputs(m.num_features)
+    cls = m.forward_features(x.to(dev))
+    (cls * pr.to(dev)).sum().backward()
+
+    def rel(a, b):
+        return ((a.detach().float().cpu() - b).norm() / (b.norm() + 1e-12)).item()
+    assert rel(cls, g["cls"]) < tol, rel(cls, g["cls"])
+    prm = dict(m.named_parameters())
+    for n, want in g["grads"].items():
+        assert rel(prm[n].grad, want) < 5 * tol, (n, rel(prm[n].grad, want))
+    with pytest.raises(ValueError):  # another resolution: the reference's broadcast add fails too
+        m.forward_features(torch.zeros(1, 3, 56, 56, device=dev))
+
+
+def test_ape_host_logic_cpu(gold, monkeypatch, lib_built):
+    import esvit_amd
+    import esvit_amd.functional as Fn
+    import esvit_amd.params as P
+    esvit_amd.set_precision("fp32")
+    for mod in (Fn, P):
+        monkeypatch.setattr(mod, "ops", ops_ref)
+    _check_ape(_ape_model(), gold["ape"], torch.device("cpu"), 2e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_ape_gpu(gold, prec, lib_built):
+    import esvit_amd
+    esvit_amd.set_precision(prec)
+    try:
+        dev = torch.device("cuda:0")
+        _check_ape(_ape_model().to(dev), gold["ape"], dev, 2e-5 if prec == "fp32" else 3e-2)
+    finally:
+        esvit_amd.set_precision("bf16")
+
+
+def test_init_weights_resizes_bias_table_and_ape(tmp_path):
+    """swin_transformer.py:852-917: a checkpoint of another window size / grid is loaded with bicubic resizing (closed form of
+    :873-912; the reference's own init_weights cannot run this case, see the docstring of SwinTransformer.init_weights)"""
+    from esvit_amd import models
+    from oracle import ref_loader as RL
+
+    def cfg(window, img):
+        c = RL.swin_config(embed_dim=32, depths=(2, 2), heads=(1, 2), window=window, img=img)
+        c.MODEL["SPEC"]["USE_APE"] = True
+        return c
+    src = models.build_model(cfg(7, 56), is_teacher=False, use_dense_prediction=False)
+    GU.fill_state_dict(src.state_dict(), 3)
+    ck = os.path.join(tmp_path, "ck.pth")
+    torch.save(src.state_dict(), ck)
+    dst = models.build_model(cfg(14, 112), is_teacher=False, use_dense_prediction=False)
+    dst.init_weights(ck, ["*"], verbose=False)
+    t7 = src.state_dict()["layers.0.blocks.0.attn.relative_position_bias_table"]
+    t14 = dst.state_dict()["layers.0.blocks.0.attn.relative_position_bias_table"]
+    want = torch.nn.functional.interpolate(t7.permute(1, 0).view(1, 1, 13, 13), size=(27, 27), mode="bicubic").view(1, 27 * 27).permute(1, 0)
+    assert t14.shape == (27 * 27, 1) and torch.allclose(t14, want)
+    a = dst.state_dict()["absolute_pos_embed"]
+    assert a.shape == (1, 28 * 28, 32)
+    assert torch.equal(dst.state_dict()["patch_embed.proj.weight"], src.state_dict()["patch_embed.proj.weight"])
