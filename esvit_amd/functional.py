@@ -425,6 +425,23 @@ class PatchMergeFn(torch.autograd.Function):
         return dx, None, None, dg, db, dWr
 
 
+class PadTokensFn(torch.autograd.Function):
+    """zero-pad a token grid at the bottom / right ([nB, H*W, C] -> [nB, Hp*Wp, C]): F.pad of PatchMerging for odd feature
+    maps (swin_transformer.py:406-408); the backward is the crop"""
+
+    @staticmethod
+    def forward(ctx, x, H, W, Hp, Wp):
+        nB, L, C = x.shape
+        ctx.geo = (nB, H, W, Hp, Wp)
+        return ops_module().pad_crop_tokens(x.contiguous().view(nB * L, C), nB, H, W, Hp, Wp).view(nB, Hp * Wp, C)
+
+    @staticmethod
+    def backward(ctx, gy):
+        nB, H, W, Hp, Wp = ctx.geo
+        C = gy.shape[-1]
+        return ops_module().pad_crop_tokens(gy.contiguous().view(nB * Hp * Wp, C), nB, Hp, Wp, H, W).view(nB, H * W, C), None, None, None, None
+
+
 class FinalNormFn(torch.autograd.Function):
     """x fp32 [nB, T, C] -> LayerNorm(x) fp32 (the region features the loss matches on stay fp32)."""
 

@@ -130,14 +130,16 @@ class PatchMerging(nn.Module):
     def forward(self, x):
         B, L, C = x.shape
         H = W = int(sqrt(L))
-        if H % 2 or W % 2:
-            raise NotImplementedError("odd feature maps are not reachable from 224/96 crops (swin_transformer.py:406-408)")
+        if H % 2 or W % 2:  # odd feature map: zero row / column appended first (swin_transformer.py:406-408)
+            x = Fn.PadTokensFn.apply(x, H, W, H + H % 2, W + W % 2)
+            H, W = H + H % 2, W + W % 2
         return Fn.PatchMergeFn.apply(x, H, W, self.norm.weight, self.norm.bias, self.reduction.weight)
 
     def forward_ragged(self, X, groups):
         """X fp32 [M, C] token rows of several resolution groups ((row0, nB, H, W) each) -> ([M/4, 2C], merged groups)"""
         if any(H % 2 or W % 2 for (_, _, H, W) in groups):
-            raise NotImplementedError("odd feature maps are not reachable from 224/96 crops (swin_transformer.py:406-408)")
+            raise NotImplementedError("odd feature maps on the ragged multi-crop route: set model.ragged_multi_crop = False "
+                                      "(the per-group schedule pads them, swin_transformer.py:406-408)")
         Y = Fn.PatchMergeMultiFn.apply(X, tuple(groups), self.norm.weight, self.norm.bias, self.reduction.weight)
         return Y, [(r0 // 4, nB, H // 2, W // 2) for (r0, nB, H, W) in groups]
 
@@ -274,6 +276,12 @@ class SwinTransformer(nn.Module):
         if self.use_dense_prediction:
             self.head_dense = None
         self.apply(self._init_weights)
+        # the fused block functions normalise with a compile-time-free but module-independent epsilon (functional.LN_EPS, what
+        # get_cls_model passes, swin_transformer.py:963): refuse any other instead of silently computing with the wrong one
+        for name, mod in self.named_modules():
+            if isinstance(mod, nn.LayerNorm) and abs(mod.eps - Fn.LN_EPS) > 1e-12:
+                raise ValueError("LayerNorm %s has eps=%g; the HIP path is built for eps=%g (norm_layer=partial(nn.LayerNorm, eps=1e-6), "
+                                 "as models.build_model / get_cls_model construct it)" % (name or "<root>", mod.eps, Fn.LN_EPS))
 
     def _init_weights(self, m):
         if isinstance(m, nn.Linear):

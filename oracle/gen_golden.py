@@ -313,6 +313,16 @@ def gen_variants(ns):
     prm = dict(m.named_parameters())
     g["ape"] = {"keys": [(k, tuple(v.shape)) for k, v in m.state_dict().items()], "cls": cls.detach().clone(),
                 "grads": {n: prm[n].grad.clone() for n in names}}
+    # oddmerge -- PatchMerging on an odd feature map (swin_transformer.py:406-408): four-stage nano Swin at 112^2 (28, 14, 7 -> 4)
+    cfg = RL.swin_config(embed_dim=GU.NANO["embed_dim"], depths=GU.NANO["depths"], heads=GU.NANO["heads"], window=GU.NANO["window"], img=112)
+    m = ns.models.build_model(cfg, is_teacher=False, use_dense_prediction=True)
+    GU.fill_state_dict(m.state_dict(), 23)
+    xa, pr = GU.ape_inputs(m.num_features)
+    cls, region = m.forward_features(xa)
+    ((cls * pr).sum() + region.sum() * 0.01).backward()
+    names = ["patch_embed.proj.weight", "layers.2.downsample.norm.weight", "layers.2.downsample.reduction.weight", "layers.3.blocks.1.mlp.fc2.bias"]
+    prm = dict(m.named_parameters())
+    g["oddmerge"] = {"cls": cls.detach().clone(), "region": region.detach().clone(), "grads": {n: prm[n].grad.clone() for n in names}}
     # mixup -- the reference's DINOLoss.forward with targets_mixup (main_esvit.py:639-641)
     mc = GU.MIXUP
     s_l, t_l, c0, T = GU.mixup_case()

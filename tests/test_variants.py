@@ -401,3 +401,45 @@ def test_init_weights_resizes_bias_table_and_ape(tmp_path):
     a = dst.state_dict()["absolute_pos_embed"]
     assert a.shape == (1, 28 * 28, 32)
     assert torch.equal(dst.state_dict()["patch_embed.proj.weight"], src.state_dict()["patch_embed.proj.weight"])
+
+
+# ---- PatchMerging on an odd feature map (swin_transformer.py:406-408) ------------------------------------------------------
+def _check_oddmerge(g, dev, tol):
+    from esvit_amd import models
+    from oracle import ref_loader as RL
+    cfg = RL.swin_config(embed_dim=GU.NANO["embed_dim"], depths=GU.NANO["depths"], heads=GU.NANO["heads"], window=GU.NANO["window"], img=112)
+    m = models.build_model(cfg, is_teacher=False, use_dense_prediction=True)
+    GU.fill_state_dict(m.state_dict(), 23)
+    m = m.to(dev)
+    x, pr = GU.ape_inputs(m.num_features)
+    cls, region = m.forward_features(x.to(dev))
+    assert region.shape == g["region"].shape  # 28 -> 14 -> 7 -> 4: sixteen tokens in the last stage
+    ((cls * pr.to(dev)).sum() + region.sum() * 0.01).backward()
+
+    def rel(a, b):
+        return ((a.detach().float().cpu() - b).norm() / (b.norm() + 1e-12)).item()
+    assert rel(cls, g["cls"]) < tol and rel(region, g["region"]) < tol, (rel(cls, g["cls"]), rel(region, g["region"]))
+    prm = dict(m.named_parameters())
+    for n, want in g["grads"].items():
+        assert rel(prm[n].grad, want) < 5 * tol, (n, rel(prm[n].grad, want))
+
+
+def test_odd_patch_merging_host_logic_cpu(gold, monkeypatch, lib_built):
+    import esvit_amd
+    import esvit_amd.functional as Fn
+    import esvit_amd.params as P
+    esvit_amd.set_precision("fp32")
+    for mod in (Fn, P):
+        monkeypatch.setattr(mod, "ops", ops_ref)
+    _check_oddmerge(gold["oddmerge"], torch.device("cpu"), 2e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_odd_patch_merging_gpu(gold, prec, lib_built):
+    import esvit_amd
+    esvit_amd.set_precision(prec)
+    try:
+        _check_oddmerge(gold["oddmerge"], torch.device("cuda:0"), 2e-5 if prec == "fp32" else 3e-2)
+    finally:
+        esvit_amd.set_precision("bf16")
