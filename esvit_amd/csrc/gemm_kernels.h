@@ -838,9 +838,26 @@ __device__ __forceinline__ void wait_vmcnt() {
 
 // NBUF-deep ring of LDS tiles: NBUF-1 tiles are requested ahead; per k-tile ONE counted wait (only for the tile
 // about to be consumed -- later tiles stay in flight across the barrier) and ONE barrier.
+#ifdef ESVIT_PROBE_TIMELINE
+// tools/probe only: per-workgroup phase timestamps (s_memrealtime, 100 MHz) and placement, to see how the co-resident
+// workgroups of a CU interleave their main loops and epilogues
+__device__ long* g_probe_timeline = nullptr;
+#define ESVIT_TL(slot) do { if (g_probe_timeline && threadIdx.x == 0) g_probe_timeline[((long)blockIdx.y * gridDim.x + blockIdx.x) * 8 + (slot)] = (long)__builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define ESVIT_TL(slot) do { } while (0)
+#endif
+
 template <bool AKS, bool BKS, int BM, int BN, int BKD, int NBUF, int WM, int WN, int MINB = 2>
 __global__ __launch_bounds__(64 * WM * WN, MINB) void gemm_dma_kernel(const esvit_gemm_desc p, const int group_m) {
     constexpr int NT = 64 * WM * WN;
+    ESVIT_TL(0);
+#ifdef ESVIT_PROBE_TIMELINE
+    if (g_probe_timeline && threadIdx.x == 0) {
+        long* e_ = g_probe_timeline + ((long)blockIdx.y * gridDim.x + blockIdx.x) * 8;
+        e_[3] = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));   // HW_REG_HW_ID, all 32 bits
+        e_[4] = __builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11));  // HW_REG_XCC_ID
+    }
+#endif
     using TA = DmaTile<AKS, BM, BKD, NT>;
     using TB = DmaTile<BKS, BN, BKD, NT>;
     constexpr int WTM = BM / WM, WTN = BN / WN;
@@ -956,10 +973,12 @@ __global__ __launch_bounds__(64 * WM * WN, MINB) void gemm_dma_kernel(const esvi
         buf = (buf + 1 == NBUF) ? 0 : buf + 1;
     }
     __syncthreads();  // all waves finished reading the operand tiles before the epilogue reuses the LDS
+    ESVIT_TL(1);
     if constexpr (AKS) {
         if (do_colsum) store_colsum<FM>(p, accb, m0, wm * WTM, z, c, g);
     }
     gemm_epilogue_bf16<BM, BN, WM, WN>(p, acc, smem_raw, m0, n0, z);
+    ESVIT_TL(2);
 }
 
 // sum split-K partials: out[i] (+)= sum_z part[z*n + i]   (TO = float or the activation dtype).

@@ -1,7 +1,13 @@
 // Experimental main-loop shapes of the LDS-DMA GEMM (NOT part of libesvit_hip.so): instantiations of the product's kernel
 // template (esvit_amd/csrc/gemm_kernels.h) with other ring depths / k-tiles, for A/B timing on the GPU
 // (tools/bench_gemm.py).  Built by tools/probe/build.sh into tools/probe/libgemm_probe.so.
+#define ESVIT_PROBE_TIMELINE 1
 #include "gemm_kernels.h"
+
+// timeline buffer: 8 longs per workgroup [t_start, t_mainloop_end, t_end, hw_id, xcc_id, -, -, -]
+extern "C" int probe_set_timeline(long* buf) {
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_probe_timeline), &buf, sizeof(buf));
+}
 
 extern "C" int probe_gemm(int variant, const esvit_gemm_desc* dp, void* stream_) {
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
@@ -47,3 +53,52 @@ extern "C" int probe_gemm(int variant, const esvit_gemm_desc* dp, void* stream_)
 }
 
 void esvit_set_error(const char*, ...) {}
+
+// ---- L2 -> CU delivery microbenchmark: how many bytes per clock and CU the LDS-DMA path (buffer_load ... lds) and the
+// register path (global_load_dwordx4) sustain when the data are L2-resident (each workgroup re-reads a small window).
+// mode 0: LDS-DMA, 1: loads to registers.  bytes_per_wg = window each workgroup cycles through.
+namespace {
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void l2_stream_kernel(const char* __restrict__ src, long window, int iters, float* __restrict__ sink) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    typedef __attribute__((address_space(3))) void lds_void;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const char* base = src + ((long)blockIdx.x % 64) * window;  // 64 windows: L2-resident working set
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(base), 0, (int)window, 0x00020000);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    // each iteration: the workgroup moves 32 KB (8 instructions of 1 KB per wave), as one k-tile of the 128 x 128 GEMM does
+    for (int it = 0; it < iters; ++it) {
+        const int off0 = (int)(((long)it * 32768) % window);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int off = off0 + (wave * 8 + i) * 1024 + lane * 16;
+            if constexpr (MODE == 0) {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)(lds + ((it & 1) * 32768) + (wave * 8 + i) * 1024), 16, off, 0, 0, 0);
+            } else {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(base + off);
+                acc += v;
+            }
+        }
+        if constexpr (MODE == 0) {
+            if (it & 1) {  // keep two "k-tiles" in flight, then drain: same depth as the GEMM ring
+                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if constexpr (MODE == 0) acc[0] = reinterpret_cast<float*>(lds)[threadIdx.x];
+    if (acc[0] + acc[1] + acc[2] + acc[3] == 123.456f) sink[0] = acc[0];
+}
+}  // namespace
+
+extern "C" int probe_l2_stream(int mode, const void* src, long window, int iters, int wgs, float* sink, void* stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    if (mode == 0) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(l2_stream_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+        hipLaunchKernelGGL(l2_stream_kernel<0>, dim3(wgs), dim3(256), 65536, stream, (const char*)src, window, iters, sink);
+    } else {
+        hipLaunchKernelGGL(l2_stream_kernel<1>, dim3(wgs), dim3(256), 0, stream, (const char*)src, window, iters, sink);
+    }
+    return (int)hipGetLastError();
+}
