@@ -65,11 +65,14 @@ GemmChoice choose(int dtype, const esvit_gemm_desc& d) {
             const double ew = round_efficiency((long)ceil_div(d.M, bmw) * ceil_div(d.N, bnw) * nz, 512);
             const bool gelu = d.epilogue == ESVIT_EPI_GELU || d.epilogue == ESVIT_EPI_QGELU;
             const bool gelu_bwd = d.epilogue == ESVIT_EPI_GELU_BWD || d.epilogue == ESVIT_EPI_QGELU_BWD;
-            if (d.a_kstrided) want = ESVIT_GEMM_DMA4W;                                  // weight gradients: +1..28 %
+            // (rules re-measured with the early-release DMA4 loop: profiles/r02_gemm_kernels_b128_b.jsonl)
+            if (d.a_kstrided)  // weight gradients: the 4 x 1 layout for 96-wide outputs, 128 x 192 where it halves the column tiles
+                want = (bnw == 96 || d.N == 192 || (d.N >= 768 && (long)d.M * d.N >= 1000000L)) ? ESVIT_GEMM_DMA4W : ESVIT_GEMM_DMA4;
             else if (gelu_bwd) want = ESVIT_GEMM_DMA4;                                  // -6..-18 %
             else if (d.residual) want = bnw == 96 ? ESVIT_GEMM_DMA4W : ESVIT_GEMM_DMA4;  // 4 x 1 waves +4..7 %, 128 x 192 -8..-30 %
             else if (gelu) want = (bnw == 192 && d.N <= 768) ? ESVIT_GEMM_DMA4W : ESVIT_GEMM_DMA4;
-            else want = ew >= 0.9 * e4 ? ESVIT_GEMM_DMA4W : ESVIT_GEMM_DMA4;             // plain / bias: +5..25 % unless the wider tile quantises worse
+            else if (d.b_kstrided) want = d.N <= 192 ? ESVIT_GEMM_DMA4W : ESVIT_GEMM_DMA4;  // plain dgrads: early release wins from N = 384 up (+10..35 %)
+            else want = ew >= 0.9 * e4 ? ESVIT_GEMM_DMA4W : ESVIT_GEMM_DMA4;             // plain / bias forward: +5..25 % unless the wider tile quantises worse
         }
     }
     if (want == ESVIT_GEMM_DMA4W && !(d.N % 96 == 0)) want = ESVIT_GEMM_DMA4;
@@ -82,9 +85,11 @@ GemmChoice choose(int dtype, const esvit_gemm_desc& d) {
 
 template <bool AKS, bool BKS>
 int run_dma4(const esvit_gemm_desc& d, int bn, hipStream_t stream) {
-    if (bn == 96) return launch_gemm_dma<AKS, BKS, 128, 96, 64, 2, 2, 2>(d, stream);
-    if (bn == 64) return launch_gemm_dma<AKS, BKS, 128, 64, 64, 2, 2, 2>(d, stream);
-    return launch_gemm_dma<AKS, BKS, 128, 128, 64, 2, 2, 2>(d, stream);
+    // early buffer release (gemm_kernels.h): +6 % over the plain two-buffer loop summed over the step's shapes, up to +20 % on
+    // the dgrad / wgrad layouts (profiles/r02_gemm_early_release.jsonl)
+    if (bn == 96) return launch_gemm_dma<AKS, BKS, 128, 96, 64, 2, 2, 2, 2, true>(d, stream);
+    if (bn == 64) return launch_gemm_dma<AKS, BKS, 128, 64, 64, 2, 2, 2, 2, true>(d, stream);
+    return launch_gemm_dma<AKS, BKS, 128, 128, 64, 2, 2, 2, 2, true>(d, stream);
 }
 
 // 8 waves: 256 x 256 as 4 x 2 waves of 64 x 128 (measured faster than 2 x 4 waves of 128 x 64 on every layout)

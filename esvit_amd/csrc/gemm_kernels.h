@@ -847,7 +847,7 @@ __device__ long* g_probe_timeline = nullptr;
 #define ESVIT_TL(slot) do { } while (0)
 #endif
 
-template <bool AKS, bool BKS, int BM, int BN, int BKD, int NBUF, int WM, int WN, int MINB = 2>
+template <bool AKS, bool BKS, int BM, int BN, int BKD, int NBUF, int WM, int WN, int MINB = 2, bool EARLY = false>
 __global__ __launch_bounds__(64 * WM * WN, MINB) void gemm_dma_kernel(const esvit_gemm_desc p, const int group_m) {
     constexpr int NT = 64 * WM * WN;
     ESVIT_TL(0);
@@ -933,45 +933,88 @@ __global__ __launch_bounds__(64 * WM * WN, MINB) void gemm_dma_kernel(const esvi
         if (fullk && rows_ok_b) TB::issue_fast(rb, sB + slot * B_BYTES, p.ldb, k0, wave, voffB);
         else TB::issue(rb, sB + slot * B_BYTES, p.ldb, N - n0, k0, kend, wave, lane);
     };
+    if constexpr (EARLY) {
+        // "early release": a wave copies ALL fragments of k-tile kt into registers first, so the LDS buffer is free again
+        // before the MFMAs start and the DMA of k-tile kt+2 goes into it -- two k-tiles in flight with two buffers.
+        static_assert(NBUF == 2, "early release works on two buffers");
+        constexpr int KK = BKD / 32;
+        if (nk > 0) issue_tile(0, 0);
+        if (nk > 1) issue_tile(1, 1);
+        for (int kt = 0; kt < nk; ++kt) {
+            const int b = kt & 1;
+            if (kt + 1 < nk) wait_vmcnt<L>();
+            else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();  // k-tile kt landed for every wave
+            asm volatile("" ::: "memory");
+            const bf16* a_lds = reinterpret_cast<const bf16*>(sA + b * A_BYTES);
+            const bf16* b_lds = reinterpret_cast<const bf16*>(sB + b * B_BYTES);
+            Frag<bf16> af[KK][FM], bfr[KK][FN];
 #pragma unroll
-    for (int t = 0; t < NBUF - 1; ++t) {
-        if (t < nk) issue_tile(t, t);
-    }
-    int buf = 0;  // ring slot of tile kt
-    for (int kt = 0; kt < nk; ++kt) {
-        const int ahead = min(nk - 1 - kt, NBUF - 2);  // tiles requested after kt that may stay in flight
-        if (NBUF >= 4 && ahead >= 2) wait_vmcnt<(NBUF >= 4 ? 2 : 0) * L>();
-        else if (NBUF >= 3 && ahead >= 1) wait_vmcnt<(NBUF >= 3 ? 1 : 0) * L>();
-        else wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();  // tile kt landed for every wave; every wave is done with tile kt-1
-        asm volatile("" ::: "memory");
-        const int nt = kt + NBUF - 1;
-        if (nt < nk) {
-            const int nb = (buf == 0) ? NBUF - 1 : buf - 1;  // the slot tile kt-1 just vacated
-            issue_tile(nt, nb);
-        }
-        const bf16* a_lds = reinterpret_cast<const bf16*>(sA + buf * A_BYTES);
-        const bf16* b_lds = reinterpret_cast<const bf16*>(sB + buf * B_BYTES);
+            for (int kk = 0; kk < KK; ++kk) {
 #pragma unroll
-        for (int kk = 0; kk < BKD / 32; ++kk) {
-            Frag<bf16> af[FM], bfr[FN];
+                for (int i = 0; i < FM; ++i) af[kk][i] = TA::frag(a_lds, wm * WTM + i * 16, kk, c, g);
 #pragma unroll
-            for (int i = 0; i < FM; ++i) af[i] = TA::frag(a_lds, wm * WTM + i * 16, kk, c, g);
+                for (int j = 0; j < FN; ++j) bfr[kk][j] = TB::frag(b_lds, wn * WTN + j * 16, kk, c, g);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();  // every wave holds its fragments: buffer b is free
+            asm volatile("" ::: "memory");
+            if (kt + 2 < nk) issue_tile(kt + 2, b);
 #pragma unroll
-            for (int j = 0; j < FN; ++j) bfr[j] = TB::frag(b_lds, wn * WTN + j * 16, kk, c, g);
+            for (int kk = 0; kk < KK; ++kk) {
 #pragma unroll
-            for (int i = 0; i < FM; ++i)
+                for (int i = 0; i < FM; ++i)
 #pragma unroll
-                for (int j = 0; j < FN; ++j) mma(af[i], bfr[j], acc[i][j]);
-            if constexpr (AKS) {  // the fused bias gradient exists for wgrad only: no branch in the fwd / dgrad loops
-                if (do_colsum) {
+                    for (int j = 0; j < FN; ++j) mma(af[kk][i], bfr[kk][j], acc[i][j]);
+                if constexpr (AKS) {
+                    if (do_colsum) {
 #pragma unroll
-                    for (int i = 0; i < FM; ++i) mma(af[i], ones, accb[i]);
+                        for (int i = 0; i < FM; ++i) mma(af[kk][i], ones, accb[i]);
+                    }
                 }
             }
         }
-        buf = (buf + 1 == NBUF) ? 0 : buf + 1;
-    }
+    } else {
+#pragma unroll
+        for (int t = 0; t < NBUF - 1; ++t) {
+            if (t < nk) issue_tile(t, t);
+        }
+        int buf = 0;  // ring slot of tile kt
+        for (int kt = 0; kt < nk; ++kt) {
+            const int ahead = min(nk - 1 - kt, NBUF - 2);  // tiles requested after kt that may stay in flight
+            if (NBUF >= 4 && ahead >= 2) wait_vmcnt<(NBUF >= 4 ? 2 : 0) * L>();
+            else if (NBUF >= 3 && ahead >= 1) wait_vmcnt<(NBUF >= 3 ? 1 : 0) * L>();
+            else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();  // tile kt landed for every wave; every wave is done with tile kt-1
+            asm volatile("" ::: "memory");
+            const int nt = kt + NBUF - 1;
+            if (nt < nk) {
+                const int nb = (buf == 0) ? NBUF - 1 : buf - 1;  // the slot tile kt-1 just vacated
+                issue_tile(nt, nb);
+            }
+            const bf16* a_lds = reinterpret_cast<const bf16*>(sA + buf * A_BYTES);
+            const bf16* b_lds = reinterpret_cast<const bf16*>(sB + buf * B_BYTES);
+    #pragma unroll
+            for (int kk = 0; kk < BKD / 32; ++kk) {
+                Frag<bf16> af[FM], bfr[FN];
+    #pragma unroll
+                for (int i = 0; i < FM; ++i) af[i] = TA::frag(a_lds, wm * WTM + i * 16, kk, c, g);
+    #pragma unroll
+                for (int j = 0; j < FN; ++j) bfr[j] = TB::frag(b_lds, wn * WTN + j * 16, kk, c, g);
+    #pragma unroll
+                for (int i = 0; i < FM; ++i)
+    #pragma unroll
+                    for (int j = 0; j < FN; ++j) mma(af[i], bfr[j], acc[i][j]);
+                if constexpr (AKS) {  // the fused bias gradient exists for wgrad only: no branch in the fwd / dgrad loops
+                    if (do_colsum) {
+    #pragma unroll
+                        for (int i = 0; i < FM; ++i) mma(af[i], ones, accb[i]);
+                    }
+                }
+            }
+            buf = (buf + 1 == NBUF) ? 0 : buf + 1;
+        }
+}
     __syncthreads();  // all waves finished reading the operand tiles before the epilogue reuses the LDS
     ESVIT_TL(1);
     if constexpr (AKS) {
@@ -1066,7 +1109,7 @@ int launch_gemm(const esvit_gemm_desc& d, hipStream_t stream) {
     return ESVIT_OK;
 }
 
-template <bool AKS, bool BKS, int BM, int BN, int BKD, int NBUF, int WM, int WN, int MINB = 2>
+template <bool AKS, bool BKS, int BM, int BN, int BKD, int NBUF, int WM, int WN, int MINB = 2, bool EARLY = false>
 int launch_gemm_dma(const esvit_gemm_desc& d, hipStream_t stream) {
     constexpr int NT = 64 * WM * WN;
     using TA = DmaTile<AKS, BM, BKD, NT>;
@@ -1074,7 +1117,7 @@ int launch_gemm_dma(const esvit_gemm_desc& d, hipStream_t stream) {
     size_t lds = (size_t)NBUF * (TA::ELEMS + TB::ELEMS) * 2;
     const size_t stage_bytes = (size_t)WM * WN * 16 * (size_t)(BN / WN + 4) * sizeof(float);  // epilogue staging, one region per wave
     if (lds < stage_bytes) lds = stage_bytes;
-    auto kern = gemm_dma_kernel<AKS, BKS, BM, BN, BKD, NBUF, WM, WN, MINB>;
+    auto kern = gemm_dma_kernel<AKS, BKS, BM, BN, BKD, NBUF, WM, WN, MINB, EARLY>;
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -107,7 +107,7 @@ def main():
             fh.write(line + "\n")
             fh.flush()
 
-    KERNELS = (0, 2, 3, 4)
+    KERNELS = (0, 2, 4)
     tot = {k: 0.0 for k in KERNELS}
     tot["best"] = 0.0
     for name, kind, M, N, K, fl in step_shapes(args.batch):
