@@ -318,11 +318,13 @@ def main():
         ops._EVENT_POOL.extend(torch.cuda.Event(enable_timing=True) for _ in range(2400 * PROF_STEPS))
         prof = []
         ops.GEMM_PROFILE = prof
+        side, trainer._side = trainer._side, None  # one stream while instrumented: a launch's events then bracket that launch alone
         for _ in range(PROF_STEPS):  # every rank runs them (the collectives need all ranks); rank 0 reports
             trainer.step(crops, lr, wd, mom, epoch)
             prof_steps += 1
         sync()
         ops.GEMM_PROFILE = None
+        trainer._side = side
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -63,7 +63,8 @@ _WS = {}
 
 
 def workspace(nfloats, device, slot=0):
-    key = (device, slot)
+    # stream-ordered reuse: one scratch per (device, slot, stream) -- work enqueued on different streams never shares it
+    key = (device, slot, torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0)
     buf = _WS.get(key)
     if buf is None or buf.numel() < nfloats:
         buf = torch.empty(max(int(nfloats), 1 << 20), dtype=torch.float32, device=device)

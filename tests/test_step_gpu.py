@@ -173,7 +173,7 @@ def test_swin_tiny_step_matches_cpu_oracle(prec, lib_built):
             c0 = torch.zeros(1, K)
             l_ref, _, _ = O.ddino_loss(s_ref, t_ref, c0, c0, temp, 10)
             l_ref.backward()
-            return [t.detach() for t in s_ref], l_ref.detach(), {n: leaf[n].grad for n in names}
+            return [t.detach() if torch.is_tensor(t) else t for t in s_ref], l_ref.detach(), {n: leaf[n].grad for n in names}
 
         s_ref, l_ref, gref = _memo("swin_tiny_k8192_b2", oracle)
         # HIP path
