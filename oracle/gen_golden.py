@@ -337,6 +337,61 @@ def gen_variants(ns):
     print("variants.pt: bn_head logits", tuple(g["bn_head"]["logits"].shape), "grads", len(g["bn_head"]["grads"]))
 
 
+def gen_full(ns):
+    """Full-width steps from the reference's own modules (Swin-T W=7 widths, real out_dim): what the GPU parity tests at full
+    size compare with.  Per case: loss, centres after the loss call, every gradient norm, strided samples of twelve gradient
+    tensors and of the student outputs.  tests/golden_utils.FULL_CASES names weights / crops by seed so that the tests rebuild
+    exactly the same inputs."""
+    RL.ensure_single_process_group()
+    out = {}
+    for name, c in GU.FULL_CASES.items():
+        torch.manual_seed(0)
+        cfg = RL.swin_config(embed_dim=GU.SWIN_T["embed_dim"], depths=GU.SWIN_T["depths"], heads=GU.SWIN_T["heads"], window=GU.SWIN_T["window"])
+        K, B = c["K"], c["B"]
+        student = ns.models.build_model(cfg, is_teacher=False, use_dense_prediction=c["dense"])
+        teacher = ns.models.build_model(cfg, is_teacher=True, use_dense_prediction=c["dense"])
+        student.head, teacher.head = ns.DINOHead(student.num_features, K), ns.DINOHead(teacher.num_features, K)
+        if c["dense"]:
+            nl = name != "swin_t_k8192_b2"  # (that test builds the dense student head with norm_last_layer=False)
+            student.head_dense = ns.DINOHead(student.num_features, K, norm_last_layer=nl)
+            teacher.head_dense = ns.DINOHead(teacher.num_features, K)
+        GU.fill_state_dict(student.state_dict(), c["s_seed"])
+        GU.fill_state_dict(teacher.state_dict(), c["t_seed"])
+        student.head.last_layer.weight_g.data.fill_(1)
+        if c["dense"] and name == "swin_t_k65536_b8":
+            student.head_dense.last_layer.weight_g.data.fill_(1)
+        for p in teacher.parameters():
+            p.requires_grad = False
+        crops = GU.make_crops(B, seed=c["crop_seed"])[:c["ncrops"]]
+        if c["dense"]:
+            loss_fn = ns.DDINOLoss(K, 10, 0.04, 0.04, 0, 1)
+        else:
+            loss_fn = ns.DINOLoss(K, 2, 0.04, 0.04, 0, 1)
+        with torch.no_grad():
+            t_out = teacher(crops[:2])
+        s_out = student(crops)
+        loss = loss_fn(s_out, t_out, 0, None)
+        loss.backward()
+        names = [n for n, p in student.named_parameters() if p.requires_grad]
+        prm = dict(student.named_parameters())
+        g = {"loss": loss.item(), "grad_norm": {n: prm[n].grad.norm().item() for n in names if prm[n].grad is not None},
+             "sampled": {n: GU.strided(prm[n].grad) for n in GU.full_sampled_names(names)},
+             "center": loss_fn.center.clone()}
+        if c["dense"]:
+            g["center_grid"] = loss_fn.center_grid.clone()
+            g["s_out"] = [GU.strided(s_out[0]), GU.strided(s_out[1]), GU.strided(s_out[2])]
+            g["s_out_absmax"] = [s_out[i].detach().abs().max().item() for i in range(3)]
+            g["npatch"] = list(s_out[3])
+        else:
+            g["s_out"] = [GU.strided(s_out)]
+            g["s_out_absmax"] = [s_out.detach().abs().max().item()]
+            g["t_out"] = GU.strided(t_out)
+        out[name] = g
+        print("full_width:", name, "loss", g["loss"], "params with grad", len(g["grad_norm"]))
+        del student, teacher, s_out, t_out, loss
+    torch.save(out, os.path.join(OUT, "full_width.pt"))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ns = RL.load()
@@ -353,6 +408,8 @@ def main():
         gen_knn(ns)
     if not only or "variants" in only:
         gen_variants(ns)
+    if "full" in only:  # minutes of CPU time: regenerated on request only
+        gen_full(ns)
 
 
 if __name__ == "__main__":

@@ -120,3 +120,22 @@ def mixup_case():
 def ape_inputs(num_features, B=3):
     g = torch.Generator().manual_seed(1717)
     return torch.randn(B, 3, 112, 112, generator=g), torch.randn(B, num_features, generator=g)
+
+
+# ---- full-width fixtures (tests/golden/full_width.pt; oracle/gen_golden.py:gen_full) -----------------------------------------
+FULL_CASES = {
+    # name: (dense prediction, out_dim, batch, student seed, teacher seed, crop seed, n crops used, head_dense norm_last_layer)
+    "swin_t_k65536_b8": dict(dense=True, K=65536, B=8, s_seed=31, t_seed=32, crop_seed=55, ncrops=10),
+    "swin_t_k8192_b2": dict(dense=True, K=8192, B=2, s_seed=3, t_seed=4, crop_seed=99, ncrops=10),
+    "config1_bs4": dict(dense=False, K=65536, B=4, s_seed=11, t_seed=12, crop_seed=21, ncrops=2),
+}
+FULL_SAMPLE = 32768  # elements kept per sampled gradient tensor
+
+
+def strided(t, n=FULL_SAMPLE):
+    f = t.detach().reshape(-1)
+    return f[:: max(1, f.numel() // n)][:n].clone()
+
+
+def full_sampled_names(names):
+    return names[:: max(1, len(names) // 10)][:10] + [n for n in ("head.last_layer.weight_v", "head_dense.last_layer.weight_v") if n in names]

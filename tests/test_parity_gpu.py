@@ -43,15 +43,6 @@ def nano():
     return torch.load(os.path.join(GOLD, "nano_step.pt"), weights_only=False)
 
 
-_ORACLE_MEMO = {}
-
-
-def _memo(key, fn):
-    if key not in _ORACLE_MEMO:
-        _ORACLE_MEMO[key] = fn()
-    return _ORACLE_MEMO[key]
-
-
 def _setup(prec):
     import esvit_amd
     assert torch.cuda.is_available()
@@ -108,64 +99,25 @@ def test_config1_nano_matches_reference_golden(nano, prec, lib_built):
 
 
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
-def test_config1_swin_tiny_bs4_matches_cpu_oracle(prec, lib_built):
+def test_config1_swin_tiny_bs4_matches_reference_golden(prec, lib_built):
     """BASELINE.json configs[0] exactly: Swin-T W=7, 2 global 224^2 crops only, view-level loss, bs 4, out_dim 65536 -- HIP
-    path vs the CPU oracle (the reference's PyTorch path restated) on the same weights: logits, loss, every gradient norm"""
-    import esvit_amd
-    from esvit_amd import config as CFG
+    path vs the step of the reference's own modules on the same weights and crops (tests/golden/full_width.pt): logits,
+    loss, centre, every gradient norm, sampled gradient tensors"""
+    from tests.test_step_gpu import FULL_GOLD, full_case_deltas, run_full_case
+    g = torch.load(FULL_GOLD, map_location="cpu", weights_only=False)["config1_bs4"]
     dev = _setup(prec)
     try:
-        K, B = 65536, 4
-        cfg = CFG.swin_config("swin_tiny_w7", DROP_PATH_RATE=0.0)
-        student = esvit_amd.build_model(cfg, use_dense_prediction=False)
-        student.head = esvit_amd.DINOHead(student.num_features, K)
-        teacher = esvit_amd.build_model(cfg, is_teacher=True, use_dense_prediction=False)
-        teacher.head = esvit_amd.DINOHead(teacher.num_features, K)
-        GU.fill_state_dict(student.state_dict(), 11)
-        GU.fill_state_dict(teacher.state_dict(), 12)
-        student.head.last_layer.weight_g.data.fill_(1)
-        sd = {k: v.clone() for k, v in student.state_dict().items()}
-        tsd = {k: v.clone() for k, v in teacher.state_dict().items()}
-        crops = GU.make_crops(B, seed=21)[:2]
-        names = [n for n, p in student.named_parameters() if p.requires_grad]
-
-        def oracle():  # seeded weights / crops: one oracle run serves both precision variants
-            leaf = {n: sd[n].clone().requires_grad_(True) for n in names}
-            full = dict(sd)
-            full.update(leaf)
-            s_ref = O.swin_multicrop(full, crops, GU.SWIN_T, dense=False)
-            with torch.no_grad():
-                t_ref = O.swin_multicrop(tsd, crops, GU.SWIN_T, dense=False)
-            c0 = torch.zeros(1, K)
-            l_ref, _ = O.dino_loss(s_ref, t_ref, c0, O.teacher_temp(0, 0.04, 0.04, 0, 1), 2)
-            l_ref.backward()
-            return s_ref.detach(), t_ref, l_ref.detach(), c0, {n: leaf[n].grad for n in names}
-
-        s_ref, t_ref, l_ref, c0, gref = _memo("config1_bs4", oracle)
-        student, teacher = student.to(dev), teacher.to(dev)
-        for p in teacher.parameters():
-            p.requires_grad = False
-        loss_fn = esvit_amd.DINOLoss(K, 2, 0.04, 0.04, 0, 1).to(dev)
-        dcrops = [c.to(dev) for c in crops]
-        with torch.no_grad():
-            t_out = teacher(dcrops)
-        s_out = student(dcrops)
-        loss = loss_fn(s_out, t_out, 0, None)
-        loss.backward()
+        student, loss_fn, s_out, t_out, loss = run_full_case("config1_bs4", dev)
         fp = prec == "fp32"
-        worst = 0.0
-        for n, p in student.named_parameters():
-            if p.requires_grad:
-                ref = gref[n].norm().item()
-                worst = max(worst, abs(p.grad.norm().item() - ref) / (ref + 1e-12))
-        _record(test="config1_swin_tiny_bs4", prec=prec, loss=loss.item(), ref=l_ref.item(), abs_err=abs(loss.item() - l_ref.item()),
-                logits_rel=_rel(s_out, s_ref), worst_grad_norm_rel=worst)
-        assert _rel(s_out, s_ref) < (1e-4 if fp else 5e-2)
-        assert _rel(t_out, t_ref) < (1e-4 if fp else 5e-2)
-        assert abs(loss.item() - l_ref.item()) < (1e-4 if fp else 5e-3), (loss.item(), l_ref.item())
-        want_c = O.center_update(c0, t_ref.sum(0, keepdim=True), 2 * B)
-        assert (loss_fn.center.cpu() - want_c).abs().max().item() < (1e-6 if fp else 2e-3)
-        assert worst < (5e-3 if fp else 0.2), worst
+        out_rel, norm_rel, worst, worst_name = full_case_deltas(g, student, s_out)
+        t_rel = ((GU.strided(t_out).float().cpu() - g["t_out"]).abs().max() / g["t_out"].abs().max()).item()
+        _record(test="config1_swin_tiny_bs4", prec=prec, loss=loss.item(), ref=g["loss"], abs_err=abs(loss.item() - g["loss"]),
+                logits_rel=out_rel, worst_grad_norm_rel=norm_rel, worst_sampled_grad_rel_l2=worst, worst_tensor=worst_name)
+        assert out_rel < (1e-4 if fp else 5e-2) and t_rel < (1e-4 if fp else 5e-2), (out_rel, t_rel)
+        assert abs(loss.item() - g["loss"]) < (1e-4 if fp else 5e-3), (loss.item(), g["loss"])
+        assert (loss_fn.center.cpu() - g["center"]).abs().max().item() < (1e-6 if fp else 2e-3)
+        assert norm_rel < (5e-3 if fp else 0.2), norm_rel
+        assert worst < (5e-3 if fp else 0.25), (worst_name, worst)
     finally:
         _teardown()
 
@@ -299,59 +251,22 @@ def test_swin_forward_return_n_last_blocks_matches_reference_golden(nano, lib_bu
 # ---------------------------------------------------------------------------------------------------------------------------
 # the benchmark's own configuration at a size the CPU oracle still finishes: out_dim 65536, B = 8
 # ---------------------------------------------------------------------------------------------------------------------------
-def test_swin_tiny_k65536_b8_step_matches_cpu_oracle(lib_built):
+def test_swin_tiny_k65536_b8_step_matches_reference_golden(lib_built):
     """Swin-T W=7, 2x224^2 + 8x96^2 crops, DDINOLoss, out_dim 65536, B = 8 per GPU, bf16 (the precision bench.py times):
-    loss and ten sampled gradient tensors against the fp32 CPU oracle; drop_path 0 so both sides are deterministic"""
-    import esvit_amd
-    from esvit_amd import config as CFG
+    loss, every gradient norm and twelve sampled gradient tensors against the fp32 step of the reference's own modules
+    (tests/golden/full_width.pt); drop_path 0 so both sides are deterministic"""
+    from tests.test_step_gpu import FULL_GOLD, full_case_deltas, run_full_case
+    g = torch.load(FULL_GOLD, map_location="cpu", weights_only=False)["swin_t_k65536_b8"]
     dev = _setup("bf16")
     try:
-        K, B = 65536, 8
-        cfg = CFG.swin_config("swin_tiny_w7", DROP_PATH_RATE=0.0)
-        student = esvit_amd.build_model(cfg, use_dense_prediction=True)
-        student.head = esvit_amd.DINOHead(student.num_features, K)
-        student.head_dense = esvit_amd.DINOHead(student.num_features, K)
-        teacher = esvit_amd.build_model(cfg, is_teacher=True, use_dense_prediction=True)
-        teacher.head = esvit_amd.DINOHead(teacher.num_features, K)
-        teacher.head_dense = esvit_amd.DINOHead(teacher.num_features, K)
-        GU.fill_state_dict(student.state_dict(), 31)
-        GU.fill_state_dict(teacher.state_dict(), 32)
-        for m in (student.head, student.head_dense):
-            m.last_layer.weight_g.data.fill_(1)
-        sd = {k: v.clone() for k, v in student.state_dict().items()}
-        tsd = {k: v.clone() for k, v in teacher.state_dict().items()}
-        crops = GU.make_crops(B, seed=55)
-        names = [n for n, p in student.named_parameters() if p.requires_grad]
-        sampled = names[:: max(1, len(names) // 10)][:10] + ["head.last_layer.weight_v", "head_dense.last_layer.weight_v"]
-        leaf = {n: sd[n].clone().requires_grad_(True) for n in names}
-        full = dict(sd)
-        full.update(leaf)
-        s_ref = O.swin_multicrop(full, crops, GU.SWIN_T)
-        with torch.no_grad():
-            t_ref = O.swin_multicrop(tsd, crops[:2], GU.SWIN_T)
-        c0 = torch.zeros(1, K)
-        l_ref, _, _ = O.ddino_loss(s_ref, t_ref, c0, c0, O.teacher_temp(0, 0.04, 0.04, 0, 1), 10)
-        l_ref.backward()
-        student, teacher = student.to(dev), teacher.to(dev)
-        for p in teacher.parameters():
-            p.requires_grad = False
-        loss_fn = esvit_amd.DDINOLoss(K, 10, 0.04, 0.04, 0, 1).to(dev)
-        dcrops = [c.to(dev) for c in crops]
-        with torch.no_grad():
-            t_out = teacher(dcrops[:2])
-        s_out = student(dcrops)
-        loss = loss_fn(s_out, t_out, 0, None)
-        loss.backward()
-        got = dict(student.named_parameters())
-        worst, worst_name = 0.0, ""
-        for n in sampled:
-            g, r = got[n].grad.float().cpu(), leaf[n].grad
-            d = ((g - r).norm() / (r.norm() + 1e-12)).item()
-            if d > worst:
-                worst, worst_name = d, n
-        _record(test="swin_tiny_k65536_b8", loss_hip_bf16=loss.item(), loss_oracle_fp32=l_ref.item(), abs_err=abs(loss.item() - l_ref.item()),
-                worst_sampled_grad_rel_l2=worst, worst_tensor=worst_name)
-        assert abs(loss.item() - l_ref.item()) < 5e-3, (loss.item(), l_ref.item())
+        student, loss_fn, s_out, t_out, loss = run_full_case("swin_t_k65536_b8", dev)
+        out_rel, norm_rel, worst, worst_name = full_case_deltas(g, student, s_out)
+        _record(test="swin_tiny_k65536_b8", loss_hip_bf16=loss.item(), loss_reference_fp32=g["loss"], abs_err=abs(loss.item() - g["loss"]),
+                outputs_rel=out_rel, worst_grad_norm_rel=norm_rel, worst_sampled_grad_rel_l2=worst, worst_tensor=worst_name)
+        assert abs(loss.item() - g["loss"]) < 5e-3, (loss.item(), g["loss"])
+        assert out_rel < 5e-2, out_rel
+        assert norm_rel < 0.2, norm_rel
         assert worst < 0.1, (worst_name, worst)
+        assert (loss_fn.center.cpu() - g["center"]).abs().max().item() < 2e-3
     finally:
         _teardown()

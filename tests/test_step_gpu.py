@@ -19,15 +19,6 @@ def nano():
     return torch.load(os.path.join(GOLD, "nano_step.pt"), weights_only=False)
 
 
-_ORACLE_MEMO = {}
-
-
-def _memo(key, fn):
-    if key not in _ORACLE_MEMO:
-        _ORACLE_MEMO[key] = fn()
-    return _ORACLE_MEMO[key]
-
-
 def _setup(prec):
     import esvit_amd
     assert torch.cuda.is_available()
@@ -136,71 +127,81 @@ def test_ragged_multi_crop_equals_reference_schedule_gpu(lib_built):
         _teardown()
 
 
-@pytest.mark.parametrize("prec", ["fp32", "bf16"])
-def test_swin_tiny_step_matches_cpu_oracle(prec, lib_built):
-    """real Swin-T widths (96..768, heads 3..24), K = 8192, B = 2, 2x224 + 8x96 crops: loss, logits and gradient norms
-    against the CPU oracle with the same weights."""
+FULL_GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "full_width.pt")
+
+
+def build_full_case(name, dev):
+    """student / teacher / loss / crops of a tests/golden_utils.FULL_CASES entry, exactly as oracle/gen_golden.py:gen_full built
+    them with the reference's modules (same seeds)"""
     import esvit_amd
     from esvit_amd import config as CFG
+    c = GU.FULL_CASES[name]
+    K, B = c["K"], c["B"]
+    cfg = CFG.swin_config("swin_tiny_w7", DROP_PATH_RATE=0.0)
+    student = esvit_amd.build_model(cfg, use_dense_prediction=c["dense"])
+    teacher = esvit_amd.build_model(cfg, is_teacher=True, use_dense_prediction=c["dense"])
+    student.head, teacher.head = esvit_amd.DINOHead(student.num_features, K), esvit_amd.DINOHead(teacher.num_features, K)
+    if c["dense"]:
+        student.head_dense = esvit_amd.DINOHead(student.num_features, K, norm_last_layer=(name != "swin_t_k8192_b2"))
+        teacher.head_dense = esvit_amd.DINOHead(teacher.num_features, K)
+    GU.fill_state_dict(student.state_dict(), c["s_seed"])
+    GU.fill_state_dict(teacher.state_dict(), c["t_seed"])
+    student.head.last_layer.weight_g.data.fill_(1)
+    if c["dense"] and name == "swin_t_k65536_b8":
+        student.head_dense.last_layer.weight_g.data.fill_(1)
+    student, teacher = student.to(dev), teacher.to(dev)
+    for p in teacher.parameters():
+        p.requires_grad = False
+    loss_fn = (esvit_amd.DDINOLoss(K, 10, 0.04, 0.04, 0, 1) if c["dense"] else esvit_amd.DINOLoss(K, 2, 0.04, 0.04, 0, 1)).to(dev)
+    crops = [x.to(dev) for x in GU.make_crops(B, seed=c["crop_seed"])[:c["ncrops"]]]
+    return student, teacher, loss_fn, crops
+
+
+def run_full_case(name, dev):
+    """one forward / loss / backward of the case on the HIP path -> (student, loss_fn, s_out, t_out, loss)"""
+    student, teacher, loss_fn, crops = build_full_case(name, dev)
+    with torch.no_grad():
+        t_out = teacher(crops[:2])
+    s_out = student(crops)
+    loss = loss_fn(s_out, t_out, 0, None)
+    loss.backward()
+    loss_fn.synchronize()
+    return student, loss_fn, s_out, t_out, loss
+
+
+def full_case_deltas(g, student, s_out):
+    """-> (worst relative error of the sampled student outputs, worst relative gradient-norm error, worst relative L2 error of the
+    sampled gradient tensors and its name)"""
+    outs = s_out[:3] if isinstance(s_out, (tuple, list)) else [s_out]
+    out_rel = max(((GU.strided(o).float().cpu() - ref).abs().max() / mx).item() for o, ref, mx in zip(outs, g["s_out"], g["s_out_absmax"]))
+    prm = dict(student.named_parameters())
+    norm_rel = max(abs(prm[n].grad.norm().item() - r) / (r + 1e-12) for n, r in g["grad_norm"].items())
+    worst, worst_name = 0.0, ""
+    for n, ref in g["sampled"].items():
+        d = ((GU.strided(prm[n].grad).float().cpu() - ref).norm() / (ref.norm() + 1e-12)).item()
+        if d > worst:
+            worst, worst_name = d, n
+    return out_rel, norm_rel, worst, worst_name
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_swin_tiny_step_matches_reference_golden(prec, lib_built):
+    """real Swin-T widths (96..768, heads 3..24), K = 8192, B = 2, 2x224 + 8x96 crops: outputs, loss, every gradient norm and
+    twelve sampled gradient tensors against the step of the REFERENCE's own modules on the same weights and crops
+    (tests/golden/full_width.pt, oracle/gen_golden.py:gen_full)."""
+    g = torch.load(FULL_GOLD, map_location="cpu", weights_only=False)["swin_t_k8192_b2"]
     dev = _setup(prec)
     try:
-        torch.manual_seed(0)
-        K = 8192
-        cfg = CFG.swin_config("swin_tiny_w7", DROP_PATH_RATE=0.0)
-        student = esvit_amd.build_model(cfg, use_dense_prediction=True)
-        student.head = esvit_amd.DINOHead(student.num_features, K)
-        student.head_dense = esvit_amd.DINOHead(student.num_features, K, norm_last_layer=False)
-        teacher = esvit_amd.build_model(cfg, is_teacher=True, use_dense_prediction=True)
-        teacher.head = esvit_amd.DINOHead(teacher.num_features, K)
-        teacher.head_dense = esvit_amd.DINOHead(teacher.num_features, K)
-        GU.fill_state_dict(student.state_dict(), 3)
-        GU.fill_state_dict(teacher.state_dict(), 4)
-        student.head.last_layer.weight_g.data.fill_(1)
-        sd = {k: v.clone() for k, v in student.state_dict().items()}
-        tsd = {k: v.clone() for k, v in teacher.state_dict().items()}
-        crops = GU.make_crops(2, seed=99)
-        # oracle (CPU fp32); the weights and crops are seeded, so both precision variants share one oracle run
-        names = [n for n, p in student.named_parameters() if p.requires_grad]
-
-        def oracle():
-            leaf = {n: sd[n].clone().requires_grad_(True) for n in names}
-            full = dict(sd)
-            full.update(leaf)
-            s_ref = O.swin_multicrop(full, crops, GU.SWIN_T)
-            with torch.no_grad():
-                t_ref = O.swin_multicrop(tsd, crops[:2], GU.SWIN_T)
-            temp = O.teacher_temp(0, 0.04, 0.04, 0, 1)
-            c0 = torch.zeros(1, K)
-            l_ref, _, _ = O.ddino_loss(s_ref, t_ref, c0, c0, temp, 10)
-            l_ref.backward()
-            return [t.detach() if torch.is_tensor(t) else t for t in s_ref], l_ref.detach(), {n: leaf[n].grad for n in names}
-
-        s_ref, l_ref, gref = _memo("swin_tiny_k8192_b2", oracle)
-        # HIP path
-        student, teacher = student.to(dev), teacher.to(dev)
-        for p in teacher.parameters():
-            p.requires_grad = False
-        loss_fn = esvit_amd.DDINOLoss(K, 10, 0.04, 0.04, 0, 1).to(dev)
-        dcrops = _to(crops, dev)
-        t_out = teacher(dcrops[:2])
-        s_out = student(dcrops)
-        loss = loss_fn(s_out, t_out, 0, None)
-        loss.backward()
+        student, loss_fn, s_out, t_out, loss = run_full_case("swin_t_k8192_b2", dev)
         fp = prec == "fp32"
-
-        def rel(a, b):
-            return ((a.float().cpu() - b).abs().max() / (b.abs().max() + 1e-12)).item()
-
-        assert rel(s_out[2], s_ref[2]) < (1e-4 if fp else 5e-2), rel(s_out[2], s_ref[2])
-        assert rel(s_out[0], s_ref[0]) < (1e-4 if fp else 5e-2), rel(s_out[0], s_ref[0])
-        assert rel(s_out[1], s_ref[1]) < (1e-4 if fp else 5e-2), rel(s_out[1], s_ref[1])
-        assert abs(loss.item() - l_ref.item()) < (1e-4 if fp else 1e-2), (loss.item(), l_ref.item())
-        worst = 0.0
-        for n, p in student.named_parameters():
-            if p.requires_grad:
-                ref = gref[n].norm().item()
-                worst = max(worst, abs(p.grad.norm().item() - ref) / (ref + 1e-12))
-        assert worst < (5e-3 if fp else 0.2), worst
+        out_rel, norm_rel, worst, worst_name = full_case_deltas(g, student, s_out)
+        assert list(s_out[3]) == g["npatch"]
+        assert out_rel < (1e-4 if fp else 5e-2), out_rel
+        assert abs(loss.item() - g["loss"]) < (1e-4 if fp else 1e-2), (loss.item(), g["loss"])
+        assert norm_rel < (5e-3 if fp else 0.2), norm_rel
+        assert worst < (5e-3 if fp else 0.25), (worst_name, worst)
+        assert (loss_fn.center.cpu() - g["center"]).abs().max().item() < (1e-6 if fp else 2e-3)
+        assert (loss_fn.center_grid.cpu() - g["center_grid"]).abs().max().item() < (1e-6 if fp else 2e-3)
     finally:
         _teardown()
 
