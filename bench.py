@@ -258,6 +258,7 @@ def main():
                     help="BASELINE.json's metric is quoted on swin_tiny_w7 (default); configs 3/4 are swin_tiny_w14 / swin_base_w14")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--single-stream", action="store_true", help="teacher forward on the main stream too (per-kernel profiles: no overlapped durations)")
     ap.add_argument("--gemm-table", default=None, help="write a per-shape GEMM time table to this file")
     ap.add_argument("--torch-eager", type=int, default=0, metavar="BATCH",
                     help="also time the reference-path port under torch eager + autocast(bf16) on this GPU at the given batch")
@@ -290,7 +291,7 @@ def main():
     torch.manual_seed(0)  # identical replicas ...
     student, teacher, loss_fn = build(dev, args.drop_path, args.arch)
     torch.manual_seed(1000 + rank)  # ... but every rank draws its own stochastic-depth masks (and has its own crops)
-    trainer = EsvitTrainer(student, teacher, loss_fn, clip_grad=3.0, freeze_last_layer=1)
+    trainer = EsvitTrainer(student, teacher, loss_fn, clip_grad=3.0, freeze_last_layer=1, teacher_stream=not args.single_stream)
     B = args.batch
     crops = [c.to(dev) for c in GU.make_crops(B, seed=1234 + rank)]
     # constants from the first post-warm-up iteration of the reference schedules
