@@ -803,7 +803,7 @@ extern "C" int esvit_window_attn_fwd(int dtype, const void* qkv, const float* qk
                                      const float* rel_table, int ws, float* bias_frag_ws, const int32_t* region_ids, int nW, int nB, int N,
                                      int nH, int hd, float scale, void* out, float* lse, float* attn_out, esvit_stream_t s_) {
     STREAM(s_);
-    ESVIT_CHECK_ARG(qkv && qkv_bias && win2tok && rel_table && out && nB > 0 && nW > 0 && nH > 0 && L > 0 && ws > 0 && N == ws * ws,
+    ESVIT_CHECK_ARG(qkv && qkv_bias && win2tok && out && nB > 0 && nW > 0 && nH > 0 && L > 0 && ws > 0 && N == ws * ws,
                     "esvit_window_attn_fwd: bad args");
     ESVIT_CHECK_ARG(hd == HD || (hd == 64 && N <= NP), "esvit_window_attn_fwd: head_dim %d unsupported (32, or 64 with N <= 64)", hd);
     ESVIT_CHECK_ARG(dtype == ESVIT_BF16 || dtype == ESVIT_F32, "esvit_window_attn_fwd: bad dtype");
@@ -811,7 +811,7 @@ extern "C" int esvit_window_attn_fwd(int dtype, const void* qkv, const float* qk
         return esvit_big_attn_fwd(dtype, qkv, qkv_bias, win2tok, L, rel_table, ws, bias_frag_ws, region_ids, nW, nB, N, nH, scale, out, lse, attn_out,
                                   stream);
     ESVIT_CHECK_ARG(bias_frag_ws != nullptr, "esvit_window_attn_fwd: 7x7 windows need the bias_frag_ws scratch");
-    {
+    if (rel_table) {  // NULL: bias_frag_ws still holds the fragment-order bias an earlier call of this step put there
         int rc = fill_bias_frag(rel_table, ws, N, nH, bias_frag_ws, stream);
         if (rc != ESVIT_OK) return rc;
     }
@@ -843,7 +843,7 @@ extern "C" int esvit_window_attn_bwd(int dtype, const void* qkv, const float* qk
                                      const int32_t* region_ids, int nW, int nB, int N, int nH, int hd, float scale, void* dqkv,
                                      float* dbias_ws, float* dpad_ws, esvit_stream_t s_) {
     STREAM(s_);
-    ESVIT_CHECK_ARG(qkv && qkv_bias && win2tok && dout && rel_table && dqkv && dbias_ws && dpad_ws && nB > 0 && nW > 0 && nH > 0 && L > 0 &&
+    ESVIT_CHECK_ARG(qkv && qkv_bias && win2tok && dout && dqkv && dbias_ws && dpad_ws && nB > 0 && nW > 0 && nH > 0 && L > 0 &&
                         ws > 0 && N == ws * ws,
                     "esvit_window_attn_bwd: bad args");
     ESVIT_CHECK_ARG(hd == HD || (hd == 64 && N <= NP), "esvit_window_attn_bwd: head_dim %d unsupported (32, or 64 with N <= 64)", hd);
@@ -852,7 +852,7 @@ extern "C" int esvit_window_attn_bwd(int dtype, const void* qkv, const float* qk
         return esvit_big_attn_bwd(dtype, qkv, qkv_bias, win2tok, L, dout, fwd_out, lse, rel_table, ws, bias_frag_ws, region_ids, nW, nB,
                                   N, nH, scale, dqkv, dbias_ws, dpad_ws, stream);
     ESVIT_CHECK_ARG(bias_frag_ws != nullptr, "esvit_window_attn_bwd: 7x7 windows need the bias_frag_ws scratch");
-    {
+    if (rel_table) {  // NULL: bias_frag_ws still holds the fragment-order bias an earlier call of this step put there
         int rc = fill_bias_frag(rel_table, ws, N, nH, bias_frag_ws, stream);
         if (rc != ESVIT_OK) return rc;
     }

@@ -779,7 +779,7 @@ int esvit_big_attn_fwd(int dtype, const void* qkv, const float* qkv_bias, const 
     ESVIT_CHECK_ARG(N <= NPB, "window_attn: window %d too large", ws);
     ESVIT_CHECK_ARG(bias_frag_ws != nullptr, "esvit_window_attn_fwd: the bias_frag_ws scratch is required");
     {
-        int rc = fill_bias_frag_big(rel_table, ws, N, nH, bias_frag_ws, stream);
+        int rc = rel_table ? fill_bias_frag_big(rel_table, ws, N, nH, bias_frag_ws, stream) : ESVIT_OK;
         if (rc != ESVIT_OK) return rc;
     }
     const int Bw = nB * nW;
@@ -820,7 +820,7 @@ int esvit_big_attn_bwd(int dtype, const void* qkv, const float* qkv_bias, const 
     ESVIT_CHECK_ARG(fout && lse, "esvit_window_attn_bwd: 14x14 windows need the forward output and log-sum-exp");
     ESVIT_CHECK_ARG(bias_frag_ws != nullptr, "esvit_window_attn_bwd: the bias_frag_ws scratch is required");
     {
-        int rc = fill_bias_frag_big(rel_table_, ws, N, nH, bias_frag_ws, stream);
+        int rc = rel_table_ ? fill_bias_frag_big(rel_table_, ws, N, nH, bias_frag_ws, stream) : ESVIT_OK;
         if (rc != ESVIT_OK) return rc;
     }
     const float* rel_table = bias_frag_ws;  // the kernels read the frag-layout bias

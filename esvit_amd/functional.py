@@ -98,7 +98,8 @@ def _block_forward(x, geom, nH, index, dp, prm, wts, save):
     # injects the qkv bias at zero-pad slots, so no GEMM ever runs on pad rows
     xw, _, mean1, rstd1 = o.layernorm_fwd(x2d, g1, b1, LN_EPS)
     qkv = o.linear_fwd(xw, Wqkv, bqkv)
-    ao, lse = o.window_attn_fwd(qkv, bqkv, geom.win2tok, L, table, geom.ws, geom.region_ids, geom.nW, geom.N, nH, scale)
+    frag = o.new_bias_frag(nH, geom.N, x.device) if save else None  # kept for the backward (no second fill)
+    ao, lse = o.window_attn_fwd(qkv, bqkv, geom.win2tok, L, table, geom.ws, geom.region_ids, geom.nW, geom.N, nH, scale, bias_frag=frag)
     x1 = o.linear_fwd(ao, Wproj, bproj, residual=x2d, rowscale=dp1, rows_per_sample=L, out_f32=True)
     if not save and dp2 is None and o.mlp_fused_supported(W1.dtype, C):  # (the fused kernel takes per-row DropPath scales only)
         return o.mlp_fused_fwd(x1, g2, b2, LN_EPS, W1, bfc1, W2, bfc2).view(nB, L, C), None
@@ -109,7 +110,7 @@ def _block_forward(x, geom, nH, index, dp, prm, wts, save):
         else:
             a1g, a1 = o.linear_fwd(h, W1, bfc1, gelu=True), None
         x2 = o.linear_fwd(a1g, W2, bfc2, residual=x1, rowscale=dp2, rows_per_sample=L, out_f32=True)
-    saved = (mean1, rstd1, xw, qkv, ao, x1, mean2, rstd2, h, a1, a1g, lse) if save else None
+    saved = (mean1, rstd1, xw, qkv, ao, x1, mean2, rstd2, h, a1, a1g, lse, frag) if save else None
     return x2.view(nB, L, C), saved
 
 
@@ -129,7 +130,7 @@ class SwinBlockFn(torch.autograd.Function):
         o = ops_module()
         geom, nH, dp = ctx.geom, ctx.nH, ctx.dp
         (x, index, g1, table, g2, bqkv, Wqkv, Wproj, W1, W2, mean1, rstd1, xw, qkv, ao, x1, mean2, rstd2, h, a1,
-         a1g, lse) = ctx.saved_tensors
+         a1g, lse, frag) = ctx.saved_tensors
         nB, L, C = x.shape
         M = nB * L
         scale = (C // nH) ** -0.5
@@ -146,8 +147,8 @@ class SwinBlockFn(torch.autograd.Function):
         gx1, dyw, dg2, db2 = o.layernorm_bwd_cast(dh, x1, mean2, rstd2, g2, g_in=gy, rowscale=dp1, rows_per_sample=L)
         dWproj, dbproj = _wgrad(dyw, ao, Wproj_p, want_bias=True)
         dao = o.linear_dgrad(dyw, Wproj)
-        dqkv, dbias_ws, dpad_ws = o.window_attn_bwd(qkv, bqkv, geom.win2tok, L, dao, ao, lse, table, geom.ws, geom.region_ids,
-                                                    geom.nW, geom.N, nH, scale)
+        dqkv, dbias_ws, dpad_ws = o.window_attn_bwd(qkv, bqkv, geom.win2tok, L, dao, ao, lse, None, geom.ws, geom.region_ids,
+                                                    geom.nW, geom.N, nH, scale, bias_frag=frag)
         dtable = o.relpos_bias_bwd(dbias_ws, index, geom.N, table.shape[0])
         dWqkv, dbqkv = _wgrad(dqkv, xw, Wqkv_p, want_bias=True)
         o.colsum(dpad_ws, out=dbqkv[C:], accumulate=True)  # k/v bias gradient from the zero-pad slots
@@ -174,11 +175,16 @@ def _block_forward_multi(X, segs, nH, dp_rows, prm, wts, save):
     xw, _, mean1, rstd1 = o.layernorm_fwd(X, g1, b1, LN_EPS)
     qkv = o.linear_fwd(xw, Wqkv, bqkv)
     ao = torch.empty((M, C), dtype=qkv.dtype, device=X.device)
-    lses = []
+    lses, frags = [], {}
     for (r0, nB, L, geom) in segs:
         r1 = r0 + nB * L
-        _, lse = o.window_attn_fwd(qkv[r0:r1], bqkv, geom.win2tok, L, table, geom.ws, geom.region_ids, geom.nW, geom.N, nH, scale, out=ao[r0:r1])
-        lses.append(lse)
+        # the fragment-order bias is built once per block and step: later groups and the backward reuse it
+        first = (geom.ws, geom.N) not in frags
+        if first:
+            frags[(geom.ws, geom.N)] = o.new_bias_frag(nH, geom.N, X.device)
+        _, lse = o.window_attn_fwd(qkv[r0:r1], bqkv, geom.win2tok, L, table if first else None, geom.ws, geom.region_ids, geom.nW, geom.N, nH, scale,
+                                   out=ao[r0:r1], bias_frag=frags[(geom.ws, geom.N)])
+        lses.append((lse, frags[(geom.ws, geom.N)]))
     x1 = o.linear_fwd(ao, Wproj, bproj, residual=X, rowscale=dp1, rows_per_sample=1, out_f32=True)
     if not save and o.mlp_fused_supported(W1.dtype, C):
         # inference-mode pass (the teacher) through a narrow stage: LayerNorm -> fc1 + GELU -> fc2 + residual in one kernel,
@@ -240,10 +246,10 @@ class SwinBlockMultiFn(torch.autograd.Function):
         dao = o.linear_dgrad(dyw, Wproj)
         dqkv = torch.empty_like(qkv)
         dtable, pads = None, []
-        for (r0, nB, L, geom), lse in zip(segs, ctx.lses):
+        for (r0, nB, L, geom), (lse, frag) in zip(segs, ctx.lses):
             r1 = r0 + nB * L
-            _, dbias_ws, dpad_ws = o.window_attn_bwd(qkv[r0:r1], bqkv, geom.win2tok, L, dao[r0:r1], ao[r0:r1], lse, table, geom.ws, geom.region_ids,
-                                                     geom.nW, geom.N, nH, scale, dqkv_out=dqkv[r0:r1])
+            _, dbias_ws, dpad_ws = o.window_attn_bwd(qkv[r0:r1], bqkv, geom.win2tok, L, dao[r0:r1], ao[r0:r1], lse, None, geom.ws, geom.region_ids,
+                                                     geom.nW, geom.N, nH, scale, dqkv_out=dqkv[r0:r1], bias_frag=frag)
             dtable = o.relpos_bias_bwd(dbias_ws, index, geom.N, table.shape[0], out=dtable)  # the second group accumulates
             pads.append(dpad_ws)
         dWqkv, dbqkv = _wgrad(dqkv, xw, Wqkv_p, want_bias=True)

@@ -487,7 +487,13 @@ def attn_frag_elems(N):
 
 
 
-def window_attn_fwd(qkv, qkv_bias, win2tok, L, rel_table, ws, region_ids, nW, N, nH, scale, want_attn=False, out=None):
+def new_bias_frag(nH, N, device):
+    """scratch for the fragment-order relative-position bias of one block (filled by the first attention call that gets it
+    together with the table; later calls of the step -- the other resolution group, the backward -- pass it with table None)"""
+    return torch.empty(2 * nH * attn_frag_elems(N), dtype=torch.float32, device=device)
+
+
+def window_attn_fwd(qkv, qkv_bias, win2tok, L, rel_table, ws, region_ids, nW, N, nH, scale, want_attn=False, out=None, bias_frag=None):
     """token-ordered qkv [nB*L, 3C] -> (out [nB*L, C], lse or None[, attn]); win2tok int32 [nW*N] slot -> token (-1 = zero-pad slot).
     lse (per-query log-sum-exp) is produced for 14x14 windows, whose blocked backward needs it."""
     qkv = _actc(qkv)
@@ -500,14 +506,16 @@ def window_attn_fwd(qkv, qkv_bias, win2tok, L, rel_table, ws, region_ids, nW, N,
     attn = torch.empty((nB * nW, nH, N, N), dtype=torch.float32, device=qkv.device) if want_attn else None
     nl = query(Q_ATTN_LSE_ELEMS, N)
     lse = torch.empty((nB * nW * nH, nl), dtype=torch.float32, device=qkv.device) if nl else None
-    bias_ws = workspace(2 * nH * attn_frag_elems(N), qkv.device, slot=2)  # frag-layout relative-position bias of every head
-    check(lib.esvit_window_attn_fwd(_code(qkv.dtype), _p(qkv), _p(_f32c(qkv_bias)), _p(win2tok), L, _p(_f32c(rel_table)), ws, _p(bias_ws),
+    # frag-layout relative-position bias of every head: the caller's per-block buffer, or shared scratch refilled by this call
+    bias_ws = bias_frag if bias_frag is not None else workspace(2 * nH * attn_frag_elems(N), qkv.device, slot=2)
+    assert rel_table is not None or bias_frag is not None
+    check(lib.esvit_window_attn_fwd(_code(qkv.dtype), _p(qkv), _p(_f32c(qkv_bias)), _p(win2tok), L, _p(None if rel_table is None else _f32c(rel_table)), ws, _p(bias_ws),
                                     _p(region_ids), nW, nB, N, nH, Cc // nH, scale, _p(out), _p(lse), _p(attn), _stream()),
           "window_attn_fwd")
     return (out, lse, attn) if want_attn else (out, lse)
 
 
-def window_attn_bwd(qkv, qkv_bias, win2tok, L, dout, fwd_out, lse, rel_table, ws, region_ids, nW, N, nH, scale, dqkv_out=None):
+def window_attn_bwd(qkv, qkv_bias, win2tok, L, dout, fwd_out, lse, rel_table, ws, region_ids, nW, N, nH, scale, dqkv_out=None, bias_frag=None):
     """-> (dqkv act [nB*L, 3C], dbias_ws fp32 [parts, nH, frag], dpad_ws fp32 [rows, 2C])."""
     qkv, dout = _actc(qkv), _actc(dout)
     rows, C3 = qkv.shape
@@ -521,8 +529,9 @@ def window_attn_bwd(qkv, qkv_bias, win2tok, L, dout, fwd_out, lse, rel_table, ws
     # the <= 64-token kernel writes every element of its pad-row slab itself; the 14x14 kernels fill one head's slice per row
     alloc = torch.empty if N <= 64 else torch.zeros
     pad = alloc((query(Q_ATTN_BWD_PAD_ROWS, N, nB * nW, nH | (code << 32)), 2 * Cc), dtype=torch.float32, device=qkv.device)
-    bias_ws = workspace(2 * nH * attn_frag_elems(N), qkv.device, slot=2)
-    check(lib.esvit_window_attn_bwd(code, _p(qkv), _p(_f32c(qkv_bias)), _p(win2tok), L, _p(dout), _p(fwd_out), _p(lse), _p(_f32c(rel_table)),
+    bias_ws = bias_frag if bias_frag is not None else workspace(2 * nH * attn_frag_elems(N), qkv.device, slot=2)
+    assert rel_table is not None or bias_frag is not None
+    check(lib.esvit_window_attn_bwd(code, _p(qkv), _p(_f32c(qkv_bias)), _p(win2tok), L, _p(dout), _p(fwd_out), _p(lse), _p(None if rel_table is None else _f32c(rel_table)),
                                     ws, _p(bias_ws), _p(region_ids), nW, nB, N, nH, Cc // nH, scale, _p(dqkv), _p(dbias_ws), _p(pad),
                                     _stream()), "window_attn_bwd")
     return dqkv, dbias_ws, pad

@@ -201,6 +201,8 @@ int esvit_token_mean_bwd(const float* g_mean, const float* g_tok, int nB, int T,
  * rel_table fp32 [(2ws-1)^2, nH] is the relative_position_bias_table parameter itself (swin_transformer.py:133-136,
  * index in closed form).  bias_frag_ws (required): fp32 scratch [2, nH, ESVIT_Q_ATTN_FRAG_ELEMS(N)] the library fills with
  * the bias in MFMA fragment order (one 16-byte load per lane per score tile instead of table gathers in the kernel).
+ * rel_table = NULL: bias_frag_ws already holds that (an earlier forward / backward call with the same table, ws and nH filled
+ * it) -- a block's second resolution group and its backward reuse the forward's fill.
  * region_ids int32 [nW*N] (esvit_window_maps) for shifted blocks or NULL.
  * scale: applied to q before the product (swin_transformer.py:130: hd^-0.5; CvT passes dim^-0.5).  N = ws*ws <= 64 with
  * hd in {32, 64} (7x7 Swin windows; 7x7 / 6x6 / 3x3 CvT windows at hd 64), or N = 196 (14x14) with hd = 32.

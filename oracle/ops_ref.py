@@ -418,8 +418,23 @@ def _attn_core(qkvw, bias_frag, region_ids, nW, N, nH, scale):
     return q, k, v, p
 
 
-def window_attn_fwd(qkv, qkv_bias, win2tok, L, rel_table, ws, region_ids, nW, N, nH, scale, want_attn=False, out=None):
+def new_bias_frag(nH, N, device):
+    """the restatement's "fragment buffer" simply remembers the table the first call was given"""
+    ws = int(round(N ** 0.5))
+    return torch.zeros(((2 * ws - 1) ** 2, nH), dtype=torch.float32, device=device)
+
+
+def _table_of(rel_table, bias_frag):
+    if bias_frag is not None:
+        if rel_table is not None:
+            bias_frag.copy_(rel_table.detach())
+        return bias_frag
+    return rel_table
+
+
+def window_attn_fwd(qkv, qkv_bias, win2tok, L, rel_table, ws, region_ids, nW, N, nH, scale, want_attn=False, out=None, bias_frag=None):
     out_arg = out
+    rel_table = _table_of(rel_table, bias_frag)
     bias_frag = relpos_bias_fwd(rel_table, torch.as_tensor(relative_position_index(ws), device=qkv.device), N)
     C = qkv.shape[1] // 3
     qkvw, pad = _to_windows(qkv, _r(qkv_bias, qkv.dtype), win2tok, L, nW, N)
@@ -438,7 +453,8 @@ def window_attn_fwd(qkv, qkv_bias, win2tok, L, rel_table, ws, region_ids, nW, N,
     return (out, None, p) if want_attn else (out, None)
 
 
-def window_attn_bwd(qkv, qkv_bias, win2tok, L, dout, fwd_out, lse, rel_table, ws, region_ids, nW, N, nH, scale, dqkv_out=None):
+def window_attn_bwd(qkv, qkv_bias, win2tok, L, dout, fwd_out, lse, rel_table, ws, region_ids, nW, N, nH, scale, dqkv_out=None, bias_frag=None):
+    rel_table = _table_of(rel_table, bias_frag)
     bias_frag = relpos_bias_fwd(rel_table, torch.as_tensor(relative_position_index(ws), device=qkv.device), N)
     C = qkv.shape[1] // 3
     dt = qkv.dtype
