@@ -22,6 +22,7 @@ import sys
 import time
 
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # the host driver only supports dmabuf IPC (RCCL across processes needs it)
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")       # kernel arguments in device memory: shorter launch gaps (~1500 launches / step, +0.6 %)
 
 import torch
 import torch.distributed as dist
