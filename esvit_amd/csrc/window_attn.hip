@@ -107,7 +107,7 @@ __device__ __forceinline__ Frag<T> frag_p_regs64(const f32x4& lo, const f32x4& h
     return f;
 }
 
-// Fourth-generation forward (default): attn_fwd3_kernel with P kept in registers and V staged in its natural [key][d]
+// Forward (the fourth generation; its predecessors are gone): a wave pair per (window, head), P kept in registers and V staged in its natural [key][d]
 // layout -- no P image, no 2-byte transposed V stores (16 per thread and window), one block barrier less per window.
 template <typename T, bool WANT_ATTN, int HDIM>
 __global__ __launch_bounds__(128, (HDIM == 32 ? 3 : 2)) void attn_fwd4_kernel(const T* __restrict__ qkv, const float* __restrict__ qkv_bias,
