@@ -38,7 +38,11 @@ class GradBucketReducer:
 
     ALIGN = 4  # floats
 
-    def __init__(self, module, bucket_mb=64, process_group=None):
+    def __init__(self, module, bucket_mb=64, process_group=None, overlap=True):
+        # overlap=False: a parameter may receive several gradient contributions per backward (the per-group schedule runs
+        # every block once per resolution group): no bucket is launched before backward has ended and gradients are not
+        # written into the buckets by their producers (they are packed by the hooks)
+        self.overlap = overlap
         self.group = process_group
         self.world = _world(process_group)
         self.params = [p for p in module.parameters() if p.requires_grad]
@@ -88,7 +92,7 @@ class GradBucketReducer:
         self.handles = []
         self.pending = [len(b) for b in self.buckets]
         self._armed = True
-        P.set_grad_sink(self.views)
+        P.set_grad_sink(self.views if self.overlap else None)
 
     def _arrived(self, p):
         if not self._armed or p.grad is None:
@@ -97,6 +101,8 @@ class GradBucketReducer:
         if p.grad.data_ptr() != view.data_ptr():  # not produced in place: pack it (the small tensors)
             view.copy_(p.grad)
             p.grad = view
+        if not self.overlap:
+            return  # every bucket is launched by finish()
         bi = self.slot[id(p)][0]
         self.pending[bi] -= 1
         if self.pending[bi] == 0:
@@ -156,7 +162,8 @@ class EsvitTrainer:
         self._side = torch.cuda.Stream() if (teacher_stream and next(student.parameters()).is_cuda) else None
         self.clip_grad, self.freeze_last_layer = clip_grad, freeze_last_layer
         self.updater = updater if updater is not None else FusedClipAdamWEMA(student, teacher)
-        self.reducer = GradBucketReducer(student, bucket_mb)
+        # (the ragged multi-crop route uses every parameter exactly once per backward; the per-group schedule does not)
+        self.reducer = GradBucketReducer(student, bucket_mb, overlap=bool(getattr(student, "ragged_multi_crop", False)))
 
     def step(self, images, lr, wd, momentum, epoch, scaler=None, teacher_images=None, targets_mixup=None):
         """scaler: a ``torch.cuda.amp.GradScaler`` (the reference's --use_fp16 mode, main_esvit.py:417-419, 576-584) or None.

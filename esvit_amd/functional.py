@@ -59,17 +59,28 @@ def geometry(H, W, ws, shift, device):
     return g
 
 
-def _wgrad(dy, x, param, shape2d=None, want_bias=False):
-    """weight gradient of `param` = dy^T x; written straight into the data-parallel reducer's bucket slot when one is
-    armed (params.grad_out), and handed to autograd as a fresh alias so that AccumulateGrad adopts it without a copy"""
+def _alias(t, sink):
+    """a gradient that was written into a bucket slot goes to autograd as a FRESH alias of the slot (AccumulateGrad only adopts
+    a tensor nobody else holds; it would clone the stored view)"""
+    return t.detach() if sink is not None else t
+
+
+def _wgrad(dy, x, param, shape2d=None, want_bias=False, bias_param=None):
+    """weight (and bias) gradient of `param` = dy^T x; written straight into the data-parallel reducer's bucket slots when
+    they are armed (params.grad_out), and handed to autograd as fresh aliases so that AccumulateGrad adopts them without a copy"""
     o = ops_module()
     sink = P.grad_out(param, shape2d)
-    res = o.linear_wgrad(dy, x, out=sink, want_bias=want_bias)
-    if sink is None:
-        return res
-    if want_bias:
-        return res[0].detach(), res[1]
-    return res.detach()
+    if not want_bias:
+        return _alias(o.linear_wgrad(dy, x, out=sink), sink)
+    sink_b = P.grad_out(bias_param) if bias_param is not None else None
+    dw, db = o.linear_wgrad(dy, x, out=sink, want_bias=True, db_out=sink_b)
+    return _alias(dw, sink), _alias(db, sink_b)
+
+
+def _ln_sinks(gparam, bparam):
+    """bucket slots of a LayerNorm's (weight, bias) gradients, or None when no reducer is armed / either has none"""
+    sg, sb = P.grad_out(gparam), P.grad_out(bparam)
+    return (sg, sb) if sg is not None and sb is not None else None
 
 
 def _weight(p, shape2d=None):
@@ -218,6 +229,7 @@ class SwinBlockMultiFn(torch.autograd.Function):
         y, saved, lses = _block_forward_multi(X, segs, nH, dp_rows, (g1, b1, table, bqkv, bproj, g2, b2, bfc1, bfc2), wts, True)
         ctx.segs, ctx.nH, ctx.dp_rows, ctx.lses = segs, nH, dp_rows, lses
         ctx.wparams = (Wqkv_p, Wproj_p, W1_p, W2_p)
+        ctx.sparams = (g1, b1, table, bqkv, bproj, g2, b2, bfc1, bfc2)  # small parameters: their gradients go to bucket slots too
         ctx.emit_shadow, ctx.prev_scale = Xsh is not None, prev_scale
         ctx.set_materialize_grads(False)
         ctx.save_for_backward(X, index, g1, table, g2, bqkv, *wts, *saved)
@@ -234,33 +246,45 @@ class SwinBlockMultiFn(torch.autograd.Function):
         dp1, dp2 = (None, None) if dp_rows is None else dp_rows
         gy = gy.contiguous()
         Wqkv_p, Wproj_p, W1_p, W2_p = ctx.wparams
+        g1_p, b1_p, table_p, bqkv_p, bproj_p, g2_p, b2_p, bfc1_p, bfc2_p = ctx.sparams
         # ---- MLP branch ----
         dyb = gysh.contiguous() if gysh is not None else o.gather_cast(gy, M, rowscale=dp2, rows_per_sample=1)
-        dW2, dbfc2 = _wgrad(dyb, a1g, W2_p, want_bias=True)
+        dW2, dbfc2 = _wgrad(dyb, a1g, W2_p, want_bias=True, bias_param=bfc2_p)
         da1 = o.linear_dgrad(dyb, W2, gelu_preact=a1)
-        dW1, dbfc1 = _wgrad(da1, h, W1_p, want_bias=True)
+        dW1, dbfc1 = _wgrad(da1, h, W1_p, want_bias=True, bias_param=bfc1_p)
         dh = o.linear_dgrad(da1, W1)
-        gx1, dyw, dg2, db2 = o.layernorm_bwd_cast(dh, x1, mean2, rstd2, g2, g_in=gy, rowscale=dp1, rows_per_sample=1)
+        ln2 = _ln_sinks(g2_p, b2_p)
+        gx1, dyw, dg2, db2 = o.layernorm_bwd_cast(dh, x1, mean2, rstd2, g2, g_in=gy, rowscale=dp1, rows_per_sample=1, gb_out=ln2)
+        dg2, db2 = _alias(dg2, ln2), _alias(db2, ln2)
         # ---- attention branch ----
-        dWproj, dbproj = _wgrad(dyw, ao, Wproj_p, want_bias=True)
+        dWproj, dbproj = _wgrad(dyw, ao, Wproj_p, want_bias=True, bias_param=bproj_p)
         dao = o.linear_dgrad(dyw, Wproj)
         dqkv = torch.empty_like(qkv)
+        tsink = P.grad_out(table_p)
         dtable, pads = None, []
         for (r0, nB, L, geom), (lse, frag) in zip(segs, ctx.lses):
             r1 = r0 + nB * L
             _, dbias_ws, dpad_ws = o.window_attn_bwd(qkv[r0:r1], bqkv, geom.win2tok, L, dao[r0:r1], ao[r0:r1], lse, None, geom.ws, geom.region_ids,
                                                      geom.nW, geom.N, nH, scale, dqkv_out=dqkv[r0:r1], bias_frag=frag)
-            dtable = o.relpos_bias_bwd(dbias_ws, index, geom.N, table.shape[0], out=dtable)  # the second group accumulates
+            if dtable is None and tsink is not None:  # first group: overwrite the bucket slot
+                dtable = o.relpos_bias_bwd(dbias_ws, index, geom.N, table.shape[0], out=tsink, accumulate=False)
+            else:
+                dtable = o.relpos_bias_bwd(dbias_ws, index, geom.N, table.shape[0], out=dtable)  # the second group accumulates
             pads.append(dpad_ws)
-        dWqkv, dbqkv = _wgrad(dqkv, xw, Wqkv_p, want_bias=True)
+        dtable = _alias(dtable, tsink)
+        wsink, bsink = P.grad_out(Wqkv_p), P.grad_out(bqkv_p)
+        dWqkv, dbqkv = o.linear_wgrad(dqkv, xw, out=wsink, want_bias=True, db_out=bsink)
         for dpad_ws in pads:
             o.colsum(dpad_ws, out=dbqkv[C:], accumulate=True)  # k/v bias gradient from the zero-pad slots
+        dWqkv, dbqkv = _alias(dWqkv, wsink), _alias(dbqkv, bsink)
         dxw = o.linear_dgrad(dqkv, Wqkv)
+        ln1 = _ln_sinks(g1_p, b1_p)
         if ctx.emit_shadow:  # the previous block's operand rides along with dL/dX
-            gx, gxb, dg1, db1 = o.layernorm_bwd_cast(dxw, X, mean1, rstd1, g1, g_in=gx1, rowscale=ctx.prev_scale, rows_per_sample=1)
+            gx, gxb, dg1, db1 = o.layernorm_bwd_cast(dxw, X, mean1, rstd1, g1, g_in=gx1, rowscale=ctx.prev_scale, rows_per_sample=1, gb_out=ln1)
         else:
-            gx, dg1, db1 = o.layernorm_bwd(dxw, X, mean1, rstd1, g1, g_in=gx1)
+            gx, dg1, db1 = o.layernorm_bwd(dxw, X, mean1, rstd1, g1, g_in=gx1, gb_out=ln1)
             gxb = None
+        dg1, db1 = _alias(dg1, ln1), _alias(db1, ln1)
         return (gx, gxb, None, None, None, None, None, dg1, db1, dtable, dWqkv, dbqkv, dWproj, dbproj, dg2, db2, dW1, dbfc1, dW2, dbfc2)
 
 
@@ -457,6 +481,7 @@ class FinalNormFn(torch.autograd.Function):
         x = x.contiguous()
         y, _, mean, rstd = o.layernorm_fwd(x.view(-1, x.shape[-1]), g, b, eps, dtype=torch.float32)
         ctx.save_for_backward(x, mean, rstd, g)
+        ctx.nparams = (g, b)
         return y.view(x.shape)
 
     @staticmethod
@@ -464,8 +489,9 @@ class FinalNormFn(torch.autograd.Function):
         o = ops_module()
         x, mean, rstd, g = ctx.saved_tensors
         C = x.shape[-1]
-        dx, dg, db = o.layernorm_bwd(gy.contiguous().view(-1, C), x.view(-1, C), mean, rstd, g)
-        return dx.view(x.shape), dg, db, None
+        sinks = _ln_sinks(*ctx.nparams)
+        dx, dg, db = o.layernorm_bwd(gy.contiguous().view(-1, C), x.view(-1, C), mean, rstd, g, gb_out=sinks)
+        return dx.view(x.shape), _alias(dg, sinks), _alias(db, sinks), None
 
 
 class TokenMeanFn(torch.autograd.Function):
@@ -516,6 +542,7 @@ class DinoHeadFn(torch.autograd.Function):
         ctx.save_for_backward(v, g, *saved)
         ctx.need_dg = g.requires_grad
         ctx.wparams = (W1p, W2p, W3p, v)
+        ctx.bparams = (b1, b2, b3)
         return logits
 
     @staticmethod
@@ -524,6 +551,7 @@ class DinoHeadFn(torch.autograd.Function):
         v, g, W1, W2, W3, xa, h1, h1g, h2, h2g, z, inv, w, winv = ctx.saved_tensors
         dlogits = dlogits.contiguous()
         W1p, W2p, W3p, vp = ctx.wparams
+        b1p, b2p, b3p = ctx.bparams
         dz = o.linear_dgrad(dlogits, w)
         dw = o.linear_wgrad(dlogits, z)
         sink = P.grad_out(vp)
@@ -531,11 +559,11 @@ class DinoHeadFn(torch.autograd.Function):
         if sink is not None:
             dv = dv.detach()  # a fresh alias of the bucket slot (see _wgrad)
         dh3 = o.l2norm_bwd(dz, z, inv)
-        dW3, db3 = _wgrad(dh3, h2g, W3p, want_bias=True)
+        dW3, db3 = _wgrad(dh3, h2g, W3p, want_bias=True, bias_param=b3p)
         dh2 = o.linear_dgrad(dh3, W3, gelu_preact=h2)
-        dW2, db2 = _wgrad(dh2, h1g, W2p, want_bias=True)
+        dW2, db2 = _wgrad(dh2, h1g, W2p, want_bias=True, bias_param=b2p)
         dh1 = o.linear_dgrad(dh2, W2, gelu_preact=h1)
-        dW1, db1 = _wgrad(dh1, xa, W1p, want_bias=True)
+        dW1, db1 = _wgrad(dh1, xa, W1p, want_bias=True, bias_param=b1p)
         dx = o.linear_dgrad(dh1, W1, out_f32=True)
         return dx, dW1, db1, dW2, db2, dW3, db3, dv, dg
 

@@ -253,9 +253,10 @@ def _pick_splitk(rows, Nout, Kin, tiles, slots=512):
     return int(max(1, min(want, by_rows, by_bytes, 512)))
 
 
-def linear_wgrad(dy, x, *, out=None, accumulate=False, want_bias=False):
+def linear_wgrad(dy, x, *, out=None, accumulate=False, want_bias=False, db_out=None):
     """dw[Nout, Kin] = dy^T @ x (fp32), both operands read k-strided, split-K over the rows.
-    want_bias: also return db[Nout] = column sums of dy, fused into the same kernel (all-ones MFMA fragment)."""
+    want_bias: also return db[Nout] = column sums of dy, fused into the same kernel (all-ones MFMA fragment); db_out: the
+    fp32 [Nout] tensor to write it to (e.g. the parameter's slot of a gradient bucket)."""
     dy, x = _actc(dy), _actc(x)
     rows, Nout = dy.shape
     Kin = x.shape[1]
@@ -263,7 +264,10 @@ def linear_wgrad(dy, x, *, out=None, accumulate=False, want_bias=False):
     if out is None:
         out = torch.empty((Nout, Kin), dtype=torch.float32, device=dy.device)
         accumulate = False
-    db = torch.empty((Nout,), dtype=torch.float32, device=dy.device) if want_bias else None
+    db = None
+    if want_bias:
+        db = db_out if db_out is not None else torch.empty((Nout,), dtype=torch.float32, device=dy.device)
+        assert db.shape == (Nout,) and db.dtype == torch.float32 and db.is_contiguous()
     _, tm, tn, slots = gemm_select(dy.dtype, M=Nout, N=Kin, K=rows, a_kstrided=1, b_kstrided=1)
     tiles = (-(-Nout // tm)) * (-(-Kin // tn))
     splitk = _pick_splitk(rows, Nout, Kin, tiles, slots)
@@ -343,14 +347,23 @@ def layernorm_fwd(x, gamma, beta, eps, *, rowmap=None, period_out=0, out_rows=No
     return y, yf, mean, rstd
 
 
-def layernorm_bwd(dy, x, mean, rstd, gamma, *, g_in=None, rowmap=None, period_in=0):
+def _ln_grad_outs(Cc, device, gb_out):
+    """(dgamma, dbeta) destinations: the caller's pair of fp32 [C] tensors (gradient-bucket slots) or a fresh [2, C]"""
+    if gb_out is not None and gb_out[0] is not None and gb_out[1] is not None:
+        for t in gb_out:
+            assert t.numel() == Cc and t.dtype == torch.float32 and t.is_contiguous()
+        return gb_out[0].view(Cc), gb_out[1].view(Cc)
+    gb = torch.empty((2, Cc), dtype=torch.float32, device=device)
+    return gb[0], gb[1]
+
+
+def layernorm_bwd(dy, x, mean, rstd, gamma, *, g_in=None, rowmap=None, period_in=0, gb_out=None):
     """-> (dx fp32 like x, dgamma, dbeta).  dy act, read through rowmap (token -> window slot) if given."""
     x, dy = _f32c(x), _actc(dy)
     Cc = x.shape[-1]
     rows = x.numel() // Cc
     dx = torch.empty_like(x)
-    gb = torch.empty((2, Cc), dtype=torch.float32, device=x.device)
-    dgamma, dbeta = gb[0], gb[1]
+    dgamma, dbeta = _ln_grad_outs(Cc, x.device, gb_out)
     ws = workspace(query(Q_LN_BWD_BLOCKS, rows, Cc) * 2 * Cc, x.device, slot=1)
     check(lib.esvit_layernorm_bwd(_code(dy.dtype), _p(dy), _p(x), _p(mean), _p(rstd), _p(gamma), _p(g_in), rows, Cc, _p(dx),
                                   _p(dgamma), _p(dbeta), _p(ws), _p(rowmap), 0 if rowmap is None else rowmap.numel(),
@@ -358,18 +371,18 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, *, g_in=None, rowmap=None, period_in
     return dx, dgamma, dbeta
 
 
-def layernorm_bwd_cast(dy, x, mean, rstd, gamma, *, g_in=None, rowscale=None, rows_per_sample=0):
+def layernorm_bwd_cast(dy, x, mean, rstd, gamma, *, g_in=None, rowscale=None, rows_per_sample=0, gb_out=None):
     """-> (dx fp32, dx_act = cast(rowscale * dx) in dy's dtype, dgamma, dbeta): layernorm_bwd + gather_cast in one pass"""
     x, dy = _f32c(x), _actc(dy)
     Cc = x.shape[-1]
     rows = x.numel() // Cc
     dx = torch.empty_like(x)
     dxa = torch.empty((rows, Cc), dtype=dy.dtype, device=x.device)
-    gb = torch.empty((2, Cc), dtype=torch.float32, device=x.device)
+    dgamma, dbeta = _ln_grad_outs(Cc, x.device, gb_out)
     ws = workspace(query(Q_LN_BWD_BLOCKS, rows, Cc) * 2 * Cc, x.device, slot=1)
-    check(lib.esvit_layernorm_bwd(_code(dy.dtype), _p(dy), _p(x), _p(mean), _p(rstd), _p(gamma), _p(g_in), rows, Cc, _p(dx), _p(gb[0]),
-                                  _p(gb[1]), _p(ws), None, 0, 0, _p(dxa), _p(rowscale), rows_per_sample, _stream()), "layernorm_bwd(cast)")
-    return dx, dxa, gb[0], gb[1]
+    check(lib.esvit_layernorm_bwd(_code(dy.dtype), _p(dy), _p(x), _p(mean), _p(rstd), _p(gamma), _p(g_in), rows, Cc, _p(dx), _p(dgamma),
+                                  _p(dbeta), _p(ws), None, 0, 0, _p(dxa), _p(rowscale), rows_per_sample, _stream()), "layernorm_bwd(cast)")
+    return dx, dxa, dgamma, dbeta
 
 
 def merge_ln_fwd(x, gamma, beta, eps, H, W, dtype=None, out=None):
@@ -537,11 +550,13 @@ def window_attn_bwd(qkv, qkv_bias, win2tok, L, dout, fwd_out, lse, rel_table, ws
     return dqkv, dbias_ws, pad
 
 
-def relpos_bias_bwd(dbias_ws, index, N, table_rows, out=None):
-    """out: optional fp32 [table_rows, nH] to ACCUMULATE into (the second resolution group of a ragged block)"""
+def relpos_bias_bwd(dbias_ws, index, N, table_rows, out=None, accumulate=None):
+    """out: optional fp32 [table_rows, nH]; accumulate (default: True when out is given -- the second resolution group of a
+    ragged block) adds to it, False overwrites it (a gradient-bucket slot written for the first time)"""
     parts, nH, _ = dbias_ws.shape
     dtable = torch.empty((table_rows, nH), dtype=torch.float32, device=dbias_ws.device) if out is None else _f32c(out)
-    check(lib.esvit_relpos_bias_bwd(_p(dbias_ws), parts, _p(index), N, nH, table_rows, _p(dtable), int(out is not None), _stream()),
+    acc = (out is not None) if accumulate is None else (bool(accumulate) and out is not None)
+    check(lib.esvit_relpos_bias_bwd(_p(dbias_ws), parts, _p(index), N, nH, table_rows, _p(dtable), int(acc), _stream()),
           "relpos_bias_bwd")
     return dtable
 

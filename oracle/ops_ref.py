@@ -143,7 +143,7 @@ def linear_dgrad(dy, w, *, gelu_preact=None, out_f32=False, quick=False):
     return dx if out_f32 else _r(dx, dy.dtype)
 
 
-def linear_wgrad(dy, x, *, out=None, accumulate=False, want_bias=False):
+def linear_wgrad(dy, x, *, out=None, accumulate=False, want_bias=False, db_out=None):
     dw = dy.float().t() @ x.float()
     if out is not None:
         if accumulate:
@@ -151,7 +151,13 @@ def linear_wgrad(dy, x, *, out=None, accumulate=False, want_bias=False):
         else:
             out.copy_(dw)
         dw = out
-    return (dw, dy.float().sum(0)) if want_bias else dw
+    if not want_bias:
+        return dw
+    db = dy.float().sum(0)
+    if db_out is not None:
+        db_out.copy_(db)
+        db = db_out
+    return dw, db
 
 
 def batched_nt(a, b, out_ld):
@@ -204,7 +210,15 @@ def layernorm_fwd(x, gamma, beta, eps, *, rowmap=None, period_out=0, out_rows=No
     return out, (y if want_f32 else None), mean, rstd
 
 
-def layernorm_bwd(dy, x, mean, rstd, gamma, *, g_in=None, rowmap=None, period_in=0):
+def _to_gb(dg, db, gb_out):
+    if gb_out is not None and gb_out[0] is not None and gb_out[1] is not None:
+        gb_out[0].view(-1).copy_(dg)
+        gb_out[1].view(-1).copy_(db)
+        return gb_out[0].view(-1), gb_out[1].view(-1)
+    return dg, db
+
+
+def layernorm_bwd(dy, x, mean, rstd, gamma, *, g_in=None, rowmap=None, period_in=0, gb_out=None):
     C = x.shape[-1]
     x2 = x.reshape(-1, C).float()
     if rowmap is not None:
@@ -219,11 +233,12 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, *, g_in=None, rowmap=None, period_in
     dx = (gd - gd.mean(1, keepdim=True) - xh * (gd * xh).mean(1, keepdim=True)) * rstd[:, None]
     if g_in is not None:
         dx = dx + g_in.reshape(-1, C)
-    return dx.reshape(x.shape), (d * xh).sum(0), d.sum(0)
+    dg, db = _to_gb((d * xh).sum(0), d.sum(0), gb_out)
+    return dx.reshape(x.shape), dg, db
 
 
-def layernorm_bwd_cast(dy, x, mean, rstd, gamma, *, g_in=None, rowscale=None, rows_per_sample=0):
-    dx, dg, db = layernorm_bwd(dy, x, mean, rstd, gamma, g_in=g_in)
+def layernorm_bwd_cast(dy, x, mean, rstd, gamma, *, g_in=None, rowscale=None, rows_per_sample=0, gb_out=None):
+    dx, dg, db = layernorm_bwd(dy, x, mean, rstd, gamma, g_in=g_in, gb_out=gb_out)
     C = x.shape[-1]
     d2 = dx.reshape(-1, C)
     if rowscale is not None:
@@ -485,10 +500,12 @@ def window_attn_bwd(qkv, qkv_bias, win2tok, L, dout, fwd_out, lse, rel_table, ws
     return _r(dqkv, dt), ws, dpad
 
 
-def relpos_bias_bwd(dbias_ws, index, N, table_rows, out=None):
+def relpos_bias_bwd(dbias_ws, index, N, table_rows, out=None, accumulate=None):
     nH = dbias_ws.shape[1]
     dense = _dense_from_frag(dbias_ws.sum(0), N)  # [nH, N, N]
     dtable = torch.zeros((table_rows, nH), dtype=torch.float32, device=dbias_ws.device) if out is None else out
+    if out is not None and accumulate is not None and not accumulate:
+        dtable.zero_()
     dtable.index_add_(0, index.view(-1), dense.permute(1, 2, 0).reshape(N * N, nH))
     return dtable
 

@@ -50,7 +50,7 @@ def _reducer_worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
-def _nano_step_worker(rank, world, port, out):
+def _nano_step_worker(rank, world, port, out, ragged=True):
     """the whole nano step on two ranks through the product's host code (kernels replaced by their torch restatement):
     weight gradients are written straight into the reducer's bucket slots (params.grad_out), the rest is packed by the
     post-accumulate hook; the averaged gradients equal the mean of the per-rank gradients computed without a reducer"""
@@ -84,7 +84,10 @@ def _nano_step_worker(rank, world, port, out):
         return {n: p.grad.detach().clone() for n, p in student.named_parameters() if p.grad is not None}
 
     student, teacher = nano_pair()
-    red = GradBucketReducer(student, bucket_mb=0.25)
+    student.ragged_multi_crop = ragged
+    # the per-group schedule (ragged False) contributes to every backbone parameter once per resolution group: the reducer then
+    # packs and launches nothing before backward has ended (overlap False)
+    red = GradBucketReducer(student, bucket_mb=0.25, overlap=ragged)
     assert red.enabled and len(red.buckets) >= 2
     assert all(v.data_ptr() % 16 == 0 for v in red.views.values())  # 16-byte slots (the fused update's vector loads)
     got = grads(student, teacher, rank, red)
@@ -92,6 +95,7 @@ def _nano_step_worker(rank, world, port, out):
     assert in_place == len(got), (in_place, len(got))  # every gradient lives in its bucket slot
     red.close()
     ref_student, ref_teacher = nano_pair()
+    ref_student.ragged_multi_crop = ragged
     acc = None
     for r in range(world):
         g = grads(ref_student, ref_teacher, r, None)
@@ -99,6 +103,10 @@ def _nano_step_worker(rank, world, port, out):
     ok = set(got) == set(acc) and all(torch.allclose(got[n], acc[n] / world, rtol=2e-4, atol=1e-7) for n in got)
     out[rank] = bool(ok)
     dist.destroy_process_group()
+
+
+def _nano_step_pergroup_worker(rank, world, port, out):
+    _nano_step_worker(rank, world, port, out, ragged=False)
 
 
 def _center_worker(rank, world, port, out):
@@ -190,7 +198,7 @@ def _extract_worker(rank, world, port, out):
 
 
 @pytest.mark.parametrize("worker,port", [(_reducer_worker, 29611), (_center_worker, 29612), (_syncbn_worker, 29613), (_extract_worker, 29614),
-                                         (_nano_step_worker, 29615)])
+                                         (_nano_step_worker, 29615), (_nano_step_pergroup_worker, 29616)])
 def test_world2_gloo(worker, port, lib_built):
     world = 2
     out = mp.Manager().dict()
