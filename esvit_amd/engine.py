@@ -170,7 +170,9 @@ class EsvitTrainer:
         teacher_images / targets_mixup: the un-mixed global views and the per-crop target matrices of the mixup mode
         (main_esvit.py:515-538); `images` are then the mixed student inputs."""
         t_in = images[:2] if teacher_images is None else teacher_images
-        if self._side is not None:
+        # (the first step stays on one stream: it fills the per-geometry index tables and weight casts both networks share)
+        warm, self._warm = getattr(self, "_warm", False), True
+        if self._side is not None and warm:
             side, main = self._side, torch.cuda.current_stream()
             side.wait_stream(main)
             with torch.cuda.stream(side), torch.no_grad():
