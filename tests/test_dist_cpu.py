@@ -16,6 +16,7 @@ def _init(rank, world, port):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(max(1, (os.cpu_count() or 2) // world))  # the ranks share the host cores
     dist.init_process_group("gloo", rank=rank, world_size=world)
 
 
