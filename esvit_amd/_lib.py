@@ -78,7 +78,7 @@ SIGNATURES = {
     "esvit_weightnorm_bwd": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, vp, vp, vp]),
     "esvit_teacher_row_stats": (C.c_int, [C.c_int, vp, vp, f32, i64, C.c_int, vp, vp, vp]),
     "esvit_region_match": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]),
-    "esvit_dino_ce_fwd_bwd": (C.c_int, [C.c_int, vp, vp, vp, vp, vp, vp, vp, C.c_int, vp, f32, f32, i64, C.c_int, vp, vp, vp]),
+    "esvit_dino_ce_fwd_bwd": (C.c_int, [C.c_int, vp, vp, vp, vp, vp, vp, vp, C.c_int, vp, f32, f32, i64, C.c_int, vp, vp, vp, vp]),
     "esvit_sum_f32": (C.c_int, [vp, i64, vp, vp]),
     "esvit_scale_inplace": (C.c_int, [C.c_int, vp, i64, vp, vp]),
     "esvit_center_ema": (C.c_int, [vp, vp, f32, f32, C.c_int, vp]),

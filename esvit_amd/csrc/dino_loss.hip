@@ -85,11 +85,14 @@ __global__ __launch_bounds__(NT) void dino_ce_kernel(const T* __restrict__ s, co
                                                      const float* __restrict__ center, const float* __restrict__ t_row_max,
                                                      const float* __restrict__ t_row_lse, const int* __restrict__ tmatch,
                                                      const float* __restrict__ row_w, float inv_st, float inv_tt, int K,
-                                                     float* __restrict__ row_loss, T* __restrict__ ds) {
+                                                     float* __restrict__ row_loss, T* __restrict__ ds, const int* __restrict__ row_order) {
     __shared__ float sm[2 * NT / 64];
     __shared__ float sm2[NT / 64];
     constexpr int V = Vec16<T>::N;
-    const long r = blockIdx.x;
+    // work order: consecutive workgroups of an XCD take consecutive entries of row_order (image-major for the region loss), so
+    // the teacher rows an image's student rows are scored against are re-read from that XCD's L2 / the Infinity Cache
+    const int u = xcd_contiguous_id(blockIdx.x, gridDim.x);
+    const long r = row_order ? row_order[u] : u;
     const T* srow = s + r * K;
     T* drow = ds + r * K;
     const int t0 = tmatch[2 * r], t1 = tmatch[2 * r + 1];
@@ -149,11 +152,12 @@ __global__ __launch_bounds__(NT) void dino_ce_terms_kernel(const T* __restrict__
                                                            const float* __restrict__ center, const float* __restrict__ t_row_max,
                                                            const float* __restrict__ t_row_lse, const int* __restrict__ tmatch,
                                                            const float* __restrict__ term_w, float inv_st, float inv_tt, int K,
-                                                           float* __restrict__ row_loss, T* __restrict__ ds) {
+                                                           float* __restrict__ row_loss, T* __restrict__ ds, const int* __restrict__ row_order) {
     __shared__ float sm[2 * NT / 64];
     __shared__ float sm2[NT / 64];
     constexpr int V = Vec16<T>::N;
-    const long r = blockIdx.x;
+    const int u = xcd_contiguous_id(blockIdx.x, gridDim.x);
+    const long r = row_order ? row_order[u] : u;
     const T* srow = s + r * K;
     T* drow = ds + r * K;
     int tj[NTERM];
@@ -257,7 +261,7 @@ extern "C" int esvit_teacher_row_stats(int dtype, const void* t, const float* ce
 extern "C" int esvit_dino_ce_fwd_bwd(int dtype, const void* s, const void* t, const float* center, const float* t_row_max,
                                      const float* t_row_lse, const int32_t* tmatch, const float* row_w, int terms, const float* term_w,
                                      float inv_student_temp, float inv_teacher_temp, int64_t Rs, int K, float* row_loss, void* ds,
-                                     esvit_stream_t s_) {
+                                     const int32_t* row_order, esvit_stream_t s_) {
     STREAM(s_);
     ESVIT_CHECK_ARG(s && t && center && t_row_max && t_row_lse && tmatch && row_loss && ds && Rs > 0 && K > 0 && K % 8 == 0,
                     "esvit_dino_ce_fwd_bwd: bad args (K=%d)", K);
@@ -266,20 +270,20 @@ extern "C" int esvit_dino_ce_fwd_bwd(int dtype, const void* s, const void* t, co
         ESVIT_CHECK_ARG(terms == 4, "esvit_dino_ce_fwd_bwd: weighted terms come four per row (got %d)", terms);
         if (dtype == ESVIT_BF16)
             hipLaunchKernelGGL((dino_ce_terms_kernel<bf16, 4>), dim3((unsigned)Rs), dim3(NT), 0, stream, (const bf16*)s, (const bf16*)t, center,
-                               t_row_max, t_row_lse, tmatch, term_w, inv_student_temp, inv_teacher_temp, K, row_loss, (bf16*)ds);
+                               t_row_max, t_row_lse, tmatch, term_w, inv_student_temp, inv_teacher_temp, K, row_loss, (bf16*)ds, row_order);
         else
             hipLaunchKernelGGL((dino_ce_terms_kernel<float, 4>), dim3((unsigned)Rs), dim3(NT), 0, stream, (const float*)s, (const float*)t,
-                               center, t_row_max, t_row_lse, tmatch, term_w, inv_student_temp, inv_teacher_temp, K, row_loss, (float*)ds);
+                               center, t_row_max, t_row_lse, tmatch, term_w, inv_student_temp, inv_teacher_temp, K, row_loss, (float*)ds, row_order);
         ESVIT_CHECK_LAUNCH("dino_ce_fwd_bwd(terms)");
         return ESVIT_OK;
     }
     ESVIT_CHECK_ARG(row_w && terms == 2, "esvit_dino_ce_fwd_bwd: two equally weighted terms per row need row_w");
     if (dtype == ESVIT_BF16)
         hipLaunchKernelGGL(dino_ce_kernel<bf16>, dim3((unsigned)Rs), dim3(NT), 0, stream, (const bf16*)s, (const bf16*)t, center,
-                           t_row_max, t_row_lse, tmatch, row_w, inv_student_temp, inv_teacher_temp, K, row_loss, (bf16*)ds);
+                           t_row_max, t_row_lse, tmatch, row_w, inv_student_temp, inv_teacher_temp, K, row_loss, (bf16*)ds, row_order);
     else
         hipLaunchKernelGGL(dino_ce_kernel<float>, dim3((unsigned)Rs), dim3(NT), 0, stream, (const float*)s, (const float*)t, center,
-                           t_row_max, t_row_lse, tmatch, row_w, inv_student_temp, inv_teacher_temp, K, row_loss, (float*)ds);
+                           t_row_max, t_row_lse, tmatch, row_w, inv_student_temp, inv_teacher_temp, K, row_loss, (float*)ds, row_order);
     ESVIT_CHECK_LAUNCH("dino_ce_fwd_bwd");
     return ESVIT_OK;
 }

@@ -220,7 +220,7 @@ class DDINOLoss(_DeferredCenter, nn.Module):
         _, ds_cls = o.dino_ce(s_cls_c.detach(), t_cls, self.center, mx_c, lse_c, tb["tm_cls"], tb["w_cls"], inv_st, inv_tt,
                               row_loss=row_loss[:n_cls])
         _, ds_reg = o.dino_ce(s_reg_c.detach(), t_reg, self.center_grid, mx_g, lse_g, tm_reg, tb["w_reg"], inv_st, inv_tt,
-                              row_loss=row_loss[n_cls:])
+                              row_loss=row_loss[n_cls:], row_order=tb["cm_row"])  # image-major work order: teacher rows stay cached
         loss = o.sum_f32(row_loss)
         self.update_center(t_cls, t_reg)
         return _LossFn.apply(loss, self.assume_unit_grad, s_cls, s_reg, ds_cls, ds_reg)

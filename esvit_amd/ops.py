@@ -625,7 +625,7 @@ def region_match(sim, Tt, crop_id, cm_row, tmatch):
     return tmatch
 
 
-def dino_ce(s, t, center, t_max, t_lse, tmatch, row_w, inv_student_temp, inv_teacher_temp, row_loss=None, term_w=None):
+def dino_ce(s, t, center, t_max, t_lse, tmatch, row_w, inv_student_temp, inv_teacher_temp, row_loss=None, term_w=None, row_order=None):
     """-> (row_loss fp32 [Rs], ds act [Rs, K]).  tmatch int32 [Rs, 2] with one weight row_w[r] for both terms, or (mixup
     targets) tmatch [Rs, 4] with term_w fp32 [Rs, 4], one weight per term."""
     s, t = _actc(s), _actc(t)
@@ -636,9 +636,10 @@ def dino_ce(s, t, center, t_max, t_lse, tmatch, row_w, inv_student_temp, inv_tea
     assert row_loss.numel() == Rs and row_loss.is_contiguous()
     ds = torch.empty_like(s)
     terms = 2 if term_w is None else 4
+    assert row_order is None or (row_order.dtype == torch.int32 and row_order.numel() == Rs and row_order.is_contiguous())
     assert tmatch.numel() == Rs * terms and tmatch.is_contiguous() and (term_w is None or (term_w.numel() == Rs * 4 and term_w.is_contiguous()))
     check(lib.esvit_dino_ce_fwd_bwd(_code(s.dtype), _p(s), _p(t), _p(center), _p(t_max), _p(t_lse), _p(tmatch), _p(row_w), terms,
-                                    _p(term_w), inv_student_temp, inv_teacher_temp, Rs, K, _p(row_loss), _p(ds), _stream()),
+                                    _p(term_w), inv_student_temp, inv_teacher_temp, Rs, K, _p(row_loss), _p(ds), _p(row_order), _stream()),
           "dino_ce_fwd_bwd")
     return row_loss, ds
 

@@ -262,11 +262,15 @@ int esvit_region_match(const float* sim, int B, int S, int Tt, int ld, const int
  * Mixup targets (DINOLoss, main_esvit.py:639-641): terms = 4, tmatch[r*4+j] and an individual weight term_w[r*4+j] per term
  * (row_w unused): row r's loss is sum_j w_j CE(teacher row j, student row r).  term_w = NULL selects the two-term form.
  * Outputs: row_loss fp32 [Rs] (sum over the row's terms, already weighted), ds dtype [Rs, K]
- * = d loss / d s (includes 1/student_temp). */
+ * = d loss / d s (includes 1/student_temp).
+ * row_order (optional, int32 [Rs], a permutation of the rows): the order in which workgroups take the rows -- the region loss
+ * passes the image-major order so that the student rows of one image, which share their <= 98 teacher rows, run together and
+ * re-read them from cache instead of HBM.  Results do not depend on it. */
 int esvit_dino_ce_fwd_bwd(int dtype, const void* s, const void* t, const float* center,
                           const float* t_row_max, const float* t_row_lse, const int32_t* tmatch,
                           const float* row_w, int terms, const float* term_w, float inv_student_temp,
-                          float inv_teacher_temp, int64_t Rs, int K, float* row_loss, void* ds, esvit_stream_t stream);
+                          float inv_teacher_temp, int64_t Rs, int K, float* row_loss, void* ds, const int32_t* row_order,
+                          esvit_stream_t stream);
 /* deterministic sum of row_loss -> loss[0] */
 int esvit_sum_f32(const float* x, int64_t n, float* out, esvit_stream_t stream);
 /* ds *= scale[0] (scale on device: grad_output of the scalar loss) */

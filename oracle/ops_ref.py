@@ -559,7 +559,7 @@ def region_match(sim, Tt, crop_id, cm_row, tmatch):
     return tmatch
 
 
-def dino_ce(s, t, center, t_max, t_lse, tmatch, row_w, inv_student_temp, inv_teacher_temp, row_loss=None, term_w=None):
+def dino_ce(s, t, center, t_max, t_lse, tmatch, row_w, inv_student_temp, inv_teacher_temp, row_loss=None, term_w=None, row_order=None):
     z = s.float() * inv_student_temp
     lse = torch.logsumexp(z, 1)
     ps = torch.exp(z - lse[:, None])

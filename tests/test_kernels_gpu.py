@@ -423,6 +423,10 @@ def test_dino_loss_kernels(mods, dt, K):
     rlr, dsr = ref.dino_ce(s, t, center, mxr, lser, tm, w, 10.0, 25.0)
     _close("row loss", rl, rlr, 2e-5)
     _close("ds", ds, dsr, _tol(dt, f32=2e-4, bf=1e-2))
+    # the work order (row_order, XCD-contiguous ids) changes which workgroup takes which row, never the result
+    order = torch.randperm(Rs, generator=g).to(torch.int32).to(dev)
+    rl2, ds2 = ops.dino_ce(s, t, center, mxr, lser, tm, w, 10.0, 25.0, row_order=order)
+    assert torch.equal(rl2, rl) and torch.equal(ds2, ds)
 
 
 def test_index_maps_match_restatement(mods):
