@@ -32,13 +32,14 @@ class GradBucketReducer:
     ``finish()`` waits for the collectives.  One process per GPU; world_size 1 short-circuits everything.
 
     Bucket size: xGMI is point-to-point (7 links x ~153 GB/s), a ring all-reduce of S bytes moves 2*(7/8)*S per
-    link, so 64 MiB buckets (~0.8 ms each on one ring) amortise launch latency while leaving 4-5 buckets for
-    Swin-T's 295 MB of fp32 gradients to pipeline against backward.
+    link, so a 32 MiB bucket is ~0.4 ms on one ring -- long enough to amortise launch latency, and nine to ten of them
+    pipeline Swin-T's 295 MB of fp32 gradients against a ~35 ms backward.  What stays exposed is the LAST bucket (the
+    earliest layers, whose gradients complete when backward ends): halving the bucket halves that tail.
     """
 
     ALIGN = 4  # floats
 
-    def __init__(self, module, bucket_mb=64, process_group=None, overlap=True):
+    def __init__(self, module, bucket_mb=32, process_group=None, overlap=True):
         # overlap=False: a parameter may receive several gradient contributions per backward (the per-group schedule runs
         # every block once per resolution group): no bucket is launched before backward has ended and gradients are not
         # written into the buckets by their producers (they are packed by the hooks)
@@ -155,7 +156,7 @@ class _ScalerOptimizerView:
 class EsvitTrainer:
     """teacher fwd -> student fwd -> loss -> backward (+ overlapped grad all-reduce) -> fused clip/AdamW/EMA."""
 
-    def __init__(self, student, teacher, loss_fn, clip_grad=3.0, freeze_last_layer=1, bucket_mb=64, updater=None, teacher_stream=True):
+    def __init__(self, student, teacher, loss_fn, clip_grad=3.0, freeze_last_layer=1, bucket_mb=32, updater=None, teacher_stream=True):
         self.student, self.teacher, self.loss_fn = student, teacher, loss_fn
         # the teacher forward (no autograd, its own scratch) runs on a second HIP stream beside the student forward: the two
         # streams fill each other's tails and launch gaps (+0.7 % at B = 128; same loss to 1e-5)
