@@ -817,8 +817,10 @@ extern "C" int esvit_window_attn_fwd(int dtype, const void* qkv, const float* qk
     }
     const int Bw = nB * nW;
     ESVIT_CHECK_ARG((long)L * 3 * nH * hd * 4 < 0x7fff0000L, "esvit_window_attn_fwd: one image's qkv rows must fit a 2 GiB buffer descriptor");
-    // persistent wave pairs: 256 CUs x 10 resident two-wave workgroups, one head each, at most one window per pair
-    int parts = ((hd == HD ? 2560 : 1024) + nH - 1) / nH;
+    // persistent wave pairs, one head each, at most one window per pair; exactly as many as the chip keeps resident (163
+    // registers -> three waves per SIMD -> six two-wave workgroups per CU x 256 CUs; 208 registers at head_dim 64 -> four): a
+    // larger grid runs a second, partly empty round (2560 workgroups were 5-12 % slower, tools/bench_attn.py)
+    int parts = ((hd == HD ? 1536 : 1024) + nH - 1) / nH;
     if (parts > Bw) parts = Bw;
 #define LAUNCH_FWD(TT, HH)                                                                                                      \
     {                                                                                                                           \
