@@ -733,8 +733,10 @@ __global__ void relpos_bias_bwd_kernel(const float* __restrict__ ws, int parts, 
 }
 
 inline int bwd_parts(int Bw, int nH) {
-    // enough wave pairs to fill the chip: 256 CUs x 4 resident two-wave workgroups, at most one window per pair
-    int parts = (1024 + nH - 1) / nH;
+    // as many wave pairs as the chip keeps resident and NOT ONE MORE: 256 CUs x 4 two-wave workgroups (256 registers, 34.6 KB
+    // of LDS each); parts * nH workgroups are launched, so round DOWN -- a 1025th workgroup would start only when another has
+    // finished all its windows and run a second round alone
+    int parts = 1024 / nH;
     if (parts > Bw) parts = Bw;
     if (parts < 1) parts = 1;
     return parts;
@@ -820,7 +822,8 @@ extern "C" int esvit_window_attn_fwd(int dtype, const void* qkv, const float* qk
     // persistent wave pairs, one head each, at most one window per pair; exactly as many as the chip keeps resident (163
     // registers -> three waves per SIMD -> six two-wave workgroups per CU x 256 CUs; 208 registers at head_dim 64 -> four): a
     // larger grid runs a second, partly empty round (2560 workgroups were 5-12 % slower, tools/bench_attn.py)
-    int parts = ((hd == HD ? 1536 : 1024) + nH - 1) / nH;
+    int parts = (hd == HD ? 1536 : 1024) / nH;  // (rounded DOWN: one workgroup more than the chip holds costs a second round)
+    if (parts < 1) parts = 1;
     if (parts > Bw) parts = Bw;
 #define LAUNCH_FWD(TT, HH)                                                                                                      \
     {                                                                                                                           \
