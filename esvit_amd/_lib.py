@@ -76,6 +76,7 @@ SIGNATURES = {
     "esvit_l2norm_bwd": (C.c_int, [C.c_int, vp, vp, vp, i64, C.c_int, vp, vp]),
     "esvit_weightnorm_fwd": (C.c_int, [C.c_int, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp]),
     "esvit_weightnorm_bwd": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, vp, vp, vp]),
+    "esvit_aug_crops": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp]),
     "esvit_teacher_row_stats": (C.c_int, [C.c_int, vp, vp, f32, i64, C.c_int, vp, vp, vp]),
     "esvit_region_match": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]),
     "esvit_dino_ce_fwd_bwd": (C.c_int, [C.c_int, vp, vp, vp, vp, vp, vp, vp, C.c_int, vp, f32, f32, i64, C.c_int, vp, vp, vp, vp]),

@@ -31,6 +31,7 @@ int esvit_i_colsum_blocks(long rows);
 int esvit_i_col_reduce_blocks(long rows);
 int esvit_i_update_chunk_elems();
 int esvit_i_mlp_fused_supported(int dtype, int C);
+int64_t esvit_i_aug_max_box(int S);
 
 extern "C" int64_t esvit_query(int what, int64_t a, int64_t b, int64_t c) {
     switch (what) {
@@ -43,6 +44,7 @@ extern "C" int64_t esvit_query(int what, int64_t a, int64_t b, int64_t c) {
         case ESVIT_Q_COL_REDUCE_BLOCKS: return esvit_i_col_reduce_blocks((long)a);
         case ESVIT_Q_UPDATE_CHUNK_ELEMS: return esvit_i_update_chunk_elems();
         case ESVIT_Q_MLP_FUSED: return esvit_i_mlp_fused_supported((int)a, (int)b);
+        case ESVIT_Q_AUG_MAX_BOX: return a > 0 ? esvit_i_aug_max_box((int)a) : 0;
     }
     esvit_set_error("esvit_query: unknown question %d", what);
     return ESVIT_ERR_ARG;

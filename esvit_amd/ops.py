@@ -83,7 +83,7 @@ def relative_position_index(ws):
 
 # esvit_query questions (include/esvit_hip.h)
 (Q_ATTN_FRAG_ELEMS, Q_ATTN_LSE_ELEMS, Q_ATTN_BWD_PARTS, Q_ATTN_BWD_PAD_ROWS, Q_LN_BWD_BLOCKS, Q_COLSUM_BLOCKS, Q_COL_REDUCE_BLOCKS,
- Q_UPDATE_CHUNK_ELEMS, Q_MLP_FUSED) = range(1, 10)
+ Q_UPDATE_CHUNK_ELEMS, Q_MLP_FUSED, Q_AUG_MAX_BOX) = range(1, 11)
 
 
 def query(what, a=0, b=0, c=0):
@@ -796,3 +796,32 @@ def pad_crop_tokens(src, nB, Hs, Ws, Hd, Wd):
     dst = torch.empty((nB * Hd * Wd, Cc), dtype=src.dtype, device=src.device)
     check(lib.esvit_pad_crop_tokens(_code(src.dtype), _p(src), nB, Hs, Ws, Hd, Wd, Cc, _p(dst), _stream()), "pad_crop_tokens")
     return dst
+
+
+# ------------------------------------------------------------------------------------------------
+# crop producer (datasets/build.py:203-261)
+# ------------------------------------------------------------------------------------------------
+AUG_PARAM_INTS = 24
+
+
+def aug_max_box(S):
+    """largest crop-box side aug_crops can resize to S x S"""
+    return query(Q_AUG_MAX_BOX, S)
+
+
+def aug_crops(src, images, params, S, max_h, max_w, planes=None, out=None):
+    """DataAugmentationDINO for the n crops of one output size S described by ``params`` (int32 [n, 24], include/esvit_hip.h):
+    src uint8 packed HWC images, images int64 [n_img, 3] (byte offset, H, W).  Returns (out fp32 [n, 3, S, S], planes uint8
+    [n, 3, S, S] = the crops before blur / solarize)."""
+    assert src.is_cuda and src.dtype == torch.uint8 and src.is_contiguous()
+    assert images.is_cuda and images.dtype == torch.int64 and images.is_contiguous() and images.shape[-1] == 3
+    assert params.is_cuda and params.dtype == torch.int32 and params.is_contiguous() and params.shape[-1] == AUG_PARAM_INTS
+    n = params.shape[0]
+    if planes is None:
+        planes = torch.empty((n, 3, S, S), dtype=torch.uint8, device=src.device)
+    if out is None:
+        out = torch.empty((n, 3, S, S), dtype=torch.float32, device=src.device)
+    assert planes.is_cuda and planes.dtype == torch.uint8 and planes.is_contiguous() and planes.numel() >= n * 3 * S * S
+    assert out.is_cuda and out.dtype == torch.float32 and out.is_contiguous() and out.numel() >= n * 3 * S * S
+    check(lib.esvit_aug_crops(_p(src), _p(images), _p(params), n, S, int(max_h), int(max_w), _p(planes), _p(out), _stream()), "aug_crops")
+    return out, planes

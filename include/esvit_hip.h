@@ -45,6 +45,7 @@ const char* esvit_last_error(void);
  *   ESVIT_Q_COL_REDUCE_BLOCKS (rows)           blocks of the esvit_dwconv3x3_wgrad / esvit_col_sums2 scratch
  *   ESVIT_Q_UPDATE_CHUNK_ELEMS ()              elements per chunk of the fused update's chunk table
  *   ESVIT_Q_MLP_FUSED (dtype, C)               1 where esvit_mlp_fused_fwd exists (bf16, C in {96, 192})
+ *   ESVIT_Q_AUG_MAX_BOX (S)                    largest crop-box side esvit_aug_crops resizes to S x S
  * Unknown `what` returns ESVIT_ERR_ARG. */
 #define ESVIT_Q_ATTN_FRAG_ELEMS 1
 #define ESVIT_Q_ATTN_LSE_ELEMS 2
@@ -55,6 +56,7 @@ const char* esvit_last_error(void);
 #define ESVIT_Q_COL_REDUCE_BLOCKS 7
 #define ESVIT_Q_UPDATE_CHUNK_ELEMS 8
 #define ESVIT_Q_MLP_FUSED 9
+#define ESVIT_Q_AUG_MAX_BOX 10
 int64_t esvit_query(int what, int64_t a, int64_t b, int64_t c);
 
 /* ---- host-side integer index maps (bit-exact vs reference) -------------
@@ -344,6 +346,24 @@ int esvit_bn_eval_coeffs(const float* running_mean, const float* running_var, co
 int esvit_bn_bwd_local(const float* sums, const float* coef, int C, float* red, esvit_stream_t stream);
 int esvit_bn_bwd_coeffs(const float* red, float n, const float* gamma, const float* coef, int C, float* abc,
                         esvit_stream_t stream);
+
+/* ---- crop producer ------------------------------------------------------ */
+/* DataAugmentationDINO (datasets/build.py:203-261; utils.py:43-75 GaussianBlur / Solarization) for n crops of ONE output size S,
+ * given their random draws: img.crop(box).resize((S, S), BICUBIC) -> horizontal flip -> ColorJitter (Brightness / Contrast /
+ * Color / hue in the drawn order) -> grayscale -> GaussianBlur -> solarize -> ToTensor -> Normalize(ImageNet mean / std).
+ * Bit-exact with Pillow's 8-bit arithmetic (Resample.c, Blend.c, Convert.c, BoxBlur.c) at every stage.
+ *   src     uint8, decoded RGB images, HWC, packed back to back;  images  int64 [n_img, 3] = (byte offset into src, H, W)
+ *   params  int32 [n, ESVIT_AUG_PARAM_INTS], one row per crop:
+ *           0 image row | 1 top | 2 left | 3 h | 4 w  (crop box, inside the image) | 5 flip
+ *           6..9  jitter operations in application order: 0 brightness, 1 contrast, 2 saturation, 3 hue, -1 none
+ *           10 brightness | 11 contrast | 12 saturation factor (float bits) | 13 hue shift = uint8(hue_factor * 255)
+ *           14 grayscale | 15 box radius + 1 of the blur (0 = no blur) | 16 ww | 17 fw (BoxBlur.c fixed-point weights of the
+ *           Gaussian radius) | 18 solarize | 19.. reserved (0)
+ *   max_h, max_w  the largest box of the n crops (sizes the LDS of the resize; <= esvit_query(ESVIT_Q_AUG_MAX_BOX, S, 0, 0))
+ *   planes  uint8 scratch [n, 3, S, S]: on return the crops before blur / solarize;  out  fp32 [n, 3, S, S] */
+#define ESVIT_AUG_PARAM_INTS 24
+int esvit_aug_crops(const uint8_t* src, const int64_t* images, const int32_t* params, int n, int S, int max_h, int max_w,
+                    uint8_t* planes, float* out, esvit_stream_t stream);
 
 #pragma GCC visibility pop
 #ifdef __cplusplus
