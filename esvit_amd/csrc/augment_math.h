@@ -13,6 +13,15 @@
 
 #pragma clang fp contract(off)
 
+// products of values known to fit 24 bits: one full-rate instruction on the GPU (a 32-bit integer multiply is quarter rate)
+#ifdef __HIP_DEVICE_COMPILE__
+#define AUG_MUL24(a, b) __mul24((int)(a), (int)(b))
+#define AUG_UMUL24(a, b) __umul24((unsigned)(a), (unsigned)(b))
+#else
+#define AUG_MUL24(a, b) ((int)(a) * (int)(b))
+#define AUG_UMUL24(a, b) ((unsigned)(a) * (unsigned)(b))
+#endif
+
 namespace aug {
 
 constexpr int PRECISION_BITS = 32 - 8 - 2;  // Resample.c: 8 bpc coefficients are 22-bit fixed point
@@ -65,7 +74,7 @@ AUG_HD uint8_t clip8(int32_t ss) {  // Resample.c clip8: arithmetic shift, clamp
 }
 
 // Convert.c rgb2l
-AUG_HD int rgb_to_l(int r, int g, int b) { return (r * 19595 + g * 38470 + b * 7471 + 0x8000) >> 16; }
+AUG_HD int rgb_to_l(int r, int g, int b) { return (AUG_MUL24(r, 19595) + AUG_MUL24(g, 38470) + AUG_MUL24(b, 7471) + 0x8000) >> 16; }
 
 // Blend.c ImagingBlend, one band: float product, float sum, truncation; clipped only when extrapolating
 AUG_HD int blend(int deg, int img, float alpha) {
@@ -77,7 +86,8 @@ AUG_HD int blend(int deg, int img, float alpha) {
     return (int)t;
 }
 
-// Convert.c rgb2hsv_row
+// Convert.c rgb2hsv_row (float quotients, the "2.0 + rc - bc" forms are double expressions stored to a float).  Of rc, gc, bc only
+// the two the branch uses are divided.
 AUG_HD void rgb_to_hsv(int r, int g, int b, int* ph, int* ps, int* pv) {
     const int maxc = r > g ? (r > b ? r : b) : (g > b ? g : b);
     const int minc = r < g ? (r < b ? r : b) : (g < b ? g : b);
@@ -89,13 +99,14 @@ AUG_HD void rgb_to_hsv(int r, int g, int b, int* ph, int* ps, int* pv) {
     }
     const float cr = (float)(maxc - minc);
     const float s = cr / (float)maxc;
-    const float rc = ((float)(maxc - r)) / cr;
-    const float gc = ((float)(maxc - g)) / cr;
-    const float bc = ((float)(maxc - b)) / cr;
+    // h = bc - gc | 2.0 + rc - bc | 4.0 + gc - rc  ==  base + plus - minus
+    const int sel = r == maxc ? 0 : (g == maxc ? 1 : 2);
+    const int nplus = sel == 0 ? maxc - b : (sel == 1 ? maxc - r : maxc - g);
+    const int nminus = sel == 0 ? maxc - g : (sel == 1 ? maxc - b : maxc - r);
+    const float plus = (float)nplus / cr, minus = (float)nminus / cr;
     float h;
-    if (r == maxc) h = bc - gc;
-    else if (g == maxc) h = (float)(2.0 + (double)rc - (double)bc);
-    else h = (float)(4.0 + (double)gc - (double)rc);
+    if (sel == 0) h = plus - minus;
+    else h = (float)((sel == 1 ? 2.0 : 4.0) + (double)plus - (double)minus);
     const double t = (double)h / 6.0 + 1.0;  // in [5/6, 11/6]: fmod(t, 1.0) = t - floor(t), exact
     h = (float)(t - floor(t));
     int uh = (int)((double)h * 255.0), us = (int)((double)s * 255.0);
@@ -103,16 +114,20 @@ AUG_HD void rgb_to_hsv(int r, int g, int b, int* ph, int* ps, int* pv) {
     *ps = us < 0 ? 0 : (us > 255 ? 255 : us);
 }
 
-// Convert.c hsv2rgb
-AUG_HD void hsv_to_rgb(int h, int s, int v, int* pr, int* pg, int* pb) {
+// Convert.c hsv2rgb.  Its sector index i = floor(h * 6 / 255), fraction f and saturation fs = s / 255 depend on one byte each:
+// hsv_sector / hsv_saturation are what a 256-entry table holds (the kernels keep them in LDS), hsv_to_rgb_t is the rest.
+AUG_HD void hsv_sector(int h, int* i, float* f) {
+    const double hf = (double)(float)h * 6.0 / 255.0;
+    *i = (int)floor(hf);
+    *f = (float)(hf - (double)(float)*i);
+}
+AUG_HD float hsv_saturation(int s) { return (float)((double)(float)s / 255.0); }
+
+AUG_HD void hsv_to_rgb_t(int s, int v, int i, float f, float fs, int* pr, int* pg, int* pb) {
     if (s == 0) {
         *pr = *pg = *pb = v;
         return;
     }
-    const double hf = (double)(float)h * 6.0 / 255.0;
-    const int i = (int)floor(hf);
-    const float f = (float)(hf - (double)(float)i);
-    const float fs = (float)((double)(float)s / 255.0);
     const double vf = (double)(float)v, f64 = (double)f, fs64 = (double)fs;
     int p = (int)floor(vf * (1.0 - fs64) + 0.5);  // C round() of a non-negative value
     int q = (int)floor(vf * (1.0 - fs64 * f64) + 0.5);
@@ -130,6 +145,13 @@ AUG_HD void hsv_to_rgb(int h, int s, int v, int* pr, int* pg, int* pb) {
     }
 }
 
+AUG_HD void hsv_to_rgb(int h, int s, int v, int* pr, int* pg, int* pb) {
+    int i;
+    float f;
+    hsv_sector(h, &i, &f);
+    hsv_to_rgb_t(s, v, i, f, hsv_saturation(s), pr, pg, pb);
+}
+
 // one output of BoxBlur.c ImagingLineBoxBlur8 at position x of a line of n values `stride` bytes apart: 2r + 1 full taps of weight
 // ww and the two far taps of weight fw (24-bit fixed point; the host derives r, ww, fw from the Gaussian radius), indices clamped
 AUG_HD uint8_t box_tap(const uint8_t* line, int stride, int n, int x, int r, uint32_t ww, uint32_t fw) {
@@ -142,7 +164,7 @@ AUG_HD uint8_t box_tap(const uint8_t* line, int stride, int n, int x, int r, uin
     int lo = x - r - 1, hi = x + r + 1;
     lo = lo < 0 ? 0 : lo;
     hi = hi > n - 1 ? n - 1 : hi;
-    const uint32_t bulk = acc * ww + ((uint32_t)line[lo * stride] + (uint32_t)line[hi * stride]) * fw;
+    const uint32_t bulk = AUG_UMUL24(acc, ww) + AUG_UMUL24((uint32_t)line[lo * stride] + (uint32_t)line[hi * stride], fw);  // ww, fw < 2^24
     return (uint8_t)((bulk + (1u << 23)) >> 24);
 }
 

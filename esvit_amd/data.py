@@ -115,6 +115,7 @@ class PackedImages:
         self.H, self.W = np.asarray(H, np.int64), np.asarray(W, np.int64)
         sizes = self.H * self.W * 3
         offs = np.concatenate([[0], np.cumsum(sizes)[:-1]])
+        arrs.append(torch.zeros(4, dtype=torch.uint8, device=arrs[0].device))  # the kernels read whole dwords: pad to the boundary
         on_dev = all(a.is_cuda for a in arrs)
         if on_dev:
             self.data = torch.cat(arrs)
@@ -169,7 +170,7 @@ class DataAugmentationDINO:
         crops = [None] * len(self.slots)
         for S, (rows, max_h, max_w) in self.draw(packed, uniforms).items():
             params = torch.from_numpy(rows).pin_memory().to(packed.data.device, non_blocking=True)
-            nbytes = rows.shape[0] * 3 * S * S
+            nbytes = rows.shape[0] * (3 * S * S + 4)
             planes = ops.workspace((nbytes + 3) // 4, packed.data.device, slot="aug_planes").view(torch.uint8)  # stream-ordered scratch
             out, _ = ops.aug_crops(packed.data, packed.table, params, S, max_h, max_w, planes=planes)
             for k, c in enumerate(self.groups[S]):

@@ -811,17 +811,19 @@ def aug_max_box(S):
 
 def aug_crops(src, images, params, S, max_h, max_w, planes=None, out=None):
     """DataAugmentationDINO for the n crops of one output size S described by ``params`` (int32 [n, 24], include/esvit_hip.h):
-    src uint8 packed HWC images, images int64 [n_img, 3] (byte offset, H, W).  Returns (out fp32 [n, 3, S, S], planes uint8
-    [n, 3, S, S] = the crops before blur / solarize)."""
+    src uint8 packed HWC images (readable up to the next 4-byte boundary), images int64 [n_img, 3] (byte offset, H, W).
+    ``planes``: uint8 scratch of n * (3 S^2 + 4) bytes.  Returns (out fp32 [n, 3, S, S], uint8 [n, 3, S, S] view of the scratch =
+    the resized, flipped crops before the jitter)."""
     assert src.is_cuda and src.dtype == torch.uint8 and src.is_contiguous()
     assert images.is_cuda and images.dtype == torch.int64 and images.is_contiguous() and images.shape[-1] == 3
     assert params.is_cuda and params.dtype == torch.int32 and params.is_contiguous() and params.shape[-1] == AUG_PARAM_INTS
     n = params.shape[0]
+    need = n * (3 * S * S + 4)
     if planes is None:
-        planes = torch.empty((n, 3, S, S), dtype=torch.uint8, device=src.device)
+        planes = torch.empty(need, dtype=torch.uint8, device=src.device)
     if out is None:
         out = torch.empty((n, 3, S, S), dtype=torch.float32, device=src.device)
-    assert planes.is_cuda and planes.dtype == torch.uint8 and planes.is_contiguous() and planes.numel() >= n * 3 * S * S
+    assert planes.is_cuda and planes.dtype == torch.uint8 and planes.is_contiguous() and planes.numel() >= need
     assert out.is_cuda and out.dtype == torch.float32 and out.is_contiguous() and out.numel() >= n * 3 * S * S
     check(lib.esvit_aug_crops(_p(src), _p(images), _p(params), n, S, int(max_h), int(max_w), _p(planes), _p(out), _stream()), "aug_crops")
-    return out, planes
+    return out, planes.view(-1)[:n * 3 * S * S].view(n, 3, S, S)

@@ -352,15 +352,18 @@ int esvit_bn_bwd_coeffs(const float* red, float n, const float* gamma, const flo
  * given their random draws: img.crop(box).resize((S, S), BICUBIC) -> horizontal flip -> ColorJitter (Brightness / Contrast /
  * Color / hue in the drawn order) -> grayscale -> GaussianBlur -> solarize -> ToTensor -> Normalize(ImageNet mean / std).
  * Bit-exact with Pillow's 8-bit arithmetic (Resample.c, Blend.c, Convert.c, BoxBlur.c) at every stage.
- *   src     uint8, decoded RGB images, HWC, packed back to back;  images  int64 [n_img, 3] = (byte offset into src, H, W)
+ *   src     uint8, decoded RGB images, HWC, packed back to back (the buffer must be readable up to the next 4-byte boundary
+ *           past its last pixel);  images  int64 [n_img, 3] = (byte offset into src, H, W)
  *   params  int32 [n, ESVIT_AUG_PARAM_INTS], one row per crop:
  *           0 image row | 1 top | 2 left | 3 h | 4 w  (crop box, inside the image) | 5 flip
  *           6..9  jitter operations in application order: 0 brightness, 1 contrast, 2 saturation, 3 hue, -1 none
  *           10 brightness | 11 contrast | 12 saturation factor (float bits) | 13 hue shift = uint8(hue_factor * 255)
  *           14 grayscale | 15 box radius + 1 of the blur (0 = no blur) | 16 ww | 17 fw (BoxBlur.c fixed-point weights of the
  *           Gaussian radius) | 18 solarize | 19.. reserved (0)
- *   max_h, max_w  the largest box of the n crops (sizes the LDS of the resize; <= esvit_query(ESVIT_Q_AUG_MAX_BOX, S, 0, 0))
- *   planes  uint8 scratch [n, 3, S, S]: on return the crops before blur / solarize;  out  fp32 [n, 3, S, S] */
+ *   S       output size, a multiple of 4, <= 280;  max_h, max_w  the largest box of the n crops (sizes the LDS of the resize;
+ *           <= esvit_query(ESVIT_Q_AUG_MAX_BOX, S, 0, 0))
+ *   planes  uint8 scratch of n * (3 S^2 + 4) bytes: on return its first n * 3 S^2 bytes are the resized, flipped crops
+ *           [n, 3, S, S] before the jitter;  out  fp32 [n, 3, S, S] */
 #define ESVIT_AUG_PARAM_INTS 24
 int esvit_aug_crops(const uint8_t* src, const int64_t* images, const int32_t* params, int n, int S, int max_h, int max_w,
                     uint8_t* planes, float* out, esvit_stream_t stream);

@@ -29,7 +29,7 @@ def _check_against_oracle(images, rows, S, out, planes):
         st = {}
         want = A.apply_crop(images[row[0]], A.row_to_params(row, S), st)
         got_planes = planes[k].transpose(1, 2, 0)
-        assert (got_planes == st["color"]).all(), ("colour stage", k, int((got_planes != st["color"]).sum()))
+        assert (got_planes == st["resize"]).all(), ("resize stage", k, int((got_planes != st["resize"]).sum()))
         assert np.array_equal(out[k], want), ("final", k, float(np.abs(out[k] - want).max()))
 
 
@@ -40,9 +40,12 @@ def test_crops_match_pillow_fixtures(lib_built):
     sizes = np.array([g["final%d" % k].shape[0] for k in range(len(rows))])
     for S in sorted(set(sizes)):
         idx = np.nonzero(sizes == S)[0]
-        out, planes = _render(images, rows[idx], int(S))
+        out, _ = _render(images, rows[idx], int(S))
+        unfinished = rows[idx].copy()
+        unfinished[:, 15], unfinished[:, 18] = 0, 0   # the same draws without blur / solarize: the crop after the jitter
+        mid, _ = _render(images, unfinished, int(S))
         for j, k in enumerate(idx):
-            assert (planes[j].transpose(1, 2, 0) == g["color%d" % k]).all(), ("colour stage vs Pillow", k)
+            assert np.array_equal(mid[j], A.to_tensor_normalize(g["color%d" % k])), ("jitter stage vs Pillow", k)
             assert np.array_equal(out[j], A.to_tensor_normalize(g["final%d" % k])), ("final vs Pillow", k)
 
 
@@ -64,6 +67,23 @@ def test_crops_match_oracle_random_batch(lib_built):
         _check_against_oracle(images, rows, S, out, planes)
         for k, c in enumerate(aug.groups[S]):  # the object returns the same crops, slot-major
             assert np.array_equal(crops[c].cpu().numpy(), out[k * 6:(k + 1) * 6])
+
+
+def test_every_blur_radius_path(lib_built):
+    """box radii 0..4 run in the tiled kernel (one template instance each), larger ones in the whole-plane kernel"""
+    rng = np.random.default_rng(14)
+    img = np.ascontiguousarray(rng.integers(0, 256, (300, 260, 3), dtype=np.uint8))
+    img[60:200, 40:180] = (np.add.outer(np.arange(140), np.arange(140))[..., None] * np.array([1, 2, 3]) % 256).astype(np.uint8)
+    rows, radii = [], [0.1, 0.7, 1.1, 2.0, 2.6, 3.4, 4.1, 5.2, 6.0, 9.0]
+    for k, radius in enumerate(radii):
+        p = A.sample_crop_params(rng.random(36), 300, 260, 224, (0.4, 1.0), 1.0, 0.3)
+        p.update(blur=True, blur_radius=radius, solarize=bool(k % 2))
+        rows.append(A.params_row(p, 0))
+    rows = np.stack(rows)
+    assert sorted(set(rows[:, 15] - 1)) == [0, 1, 2, 3, 4, 5, 8], sorted(set(rows[:, 15] - 1))
+    for S in (224, 96):
+        out, planes = _render([img], rows, S)
+        _check_against_oracle([img], rows, S, out, planes)
 
 
 def test_large_boxes_use_smaller_tiles(lib_built):

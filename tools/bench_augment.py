@@ -36,7 +36,7 @@ def main():
         draws = aug.draw(packed)
     draw_ms = (time.perf_counter() - t0) / 5 * 1e3
     dev = {S: (torch.from_numpy(rows).cuda(), mh, mw) for S, (rows, mh, mw) in draws.items()}
-    planes = {S: torch.empty((p.shape[0], 3, S, S), dtype=torch.uint8, device="cuda") for S, (p, _, _) in dev.items()}
+    planes = {S: torch.empty(p.shape[0] * (3 * S * S + 4), dtype=torch.uint8, device="cuda") for S, (p, _, _) in dev.items()}
     outs = {S: torch.empty((p.shape[0], 3, S, S), dtype=torch.float32, device="cuda") for S, (p, _, _) in dev.items()}
 
     def render():
