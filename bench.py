@@ -260,6 +260,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--single-stream", action="store_true", help="teacher forward on the main stream too (per-kernel profiles: no overlapped durations)")
+    ap.add_argument("--augment", action="store_true", help="produce the crops INSIDE the timed step with the GPU crop producer (esvit_amd.data: "
+                    "DataAugmentationDINO on decoded uint8 images resident in HBM) instead of feeding fixed crop tensors")
     ap.add_argument("--gemm-table", default=None, help="write a per-shape GEMM time table to this file")
     ap.add_argument("--torch-eager", type=int, default=0, metavar="BATCH",
                     help="also time the reference-path port under torch eager + autocast(bf16) on this GPU at the given batch")
@@ -303,13 +305,31 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    next_crops = lambda: crops  # noqa: E731
+    if args.augment:  # decoded images (ImageNet-like sizes) resident in HBM -> the 10-crop list, drawn anew every step
+        import numpy as np
+        from esvit_amd import data as D
+        rs = np.random.default_rng(99 + rank)
+        decoded = D.PackedImages([torch.from_numpy(rs.integers(0, 256, (int(h), int(w), 3), dtype=np.uint8)).to(dev)
+                                  for h, w in zip(rs.integers(300, 520, B), rs.integers(300, 520, B))])
+        producer = D.DataAugmentationDINO((0.4, 1.0), (0.05, 0.4), (8,), (96,), seed=7 + rank)
+        # the random draws need the image sizes only: a DataLoader worker makes them (DataAugmentationDINO.collate); here one
+        # background thread draws the next step's rows while this step is being launched
+        from concurrent.futures import ThreadPoolExecutor
+        pool = ThreadPoolExecutor(1)
+        pending = [pool.submit(producer.draw, decoded)]
+
+        def next_crops():
+            draws = pending[0].result()
+            pending[0] = pool.submit(producer.draw, decoded)
+            return producer(decoded, draws=draws)
     for _ in range(args.warmup):
-        trainer.step(crops, lr, wd, mom, epoch)
+        trainer.step(next_crops(), lr, wd, mom, epoch)
     sync()
     t0 = time.perf_counter()
     loss = None
     for i in range(args.steps):
-        loss = trainer.step(crops, lr, wd, mom, epoch)
+        loss = trainer.step(next_crops(), lr, wd, mom, epoch)
     sync()
     dt = time.perf_counter() - t0
     # roofline leg, OUTSIDE the timed region: HIP events around every GEMM launch of PROF_STEPS extra steps (two event records
@@ -337,7 +357,8 @@ def main():
         ips = args.steps * B * world / dt
         out = {"metric": "images/sec (global+local crops) Swin-T W=7 V+R" if args.arch == "swin_tiny_w7" else "images/sec (global+local crops) %s V+R" % args.arch, "value": ips, "unit": "images/s", "n_gpus": world,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-               "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+               "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+               "data": "synthetic decoded uint8 images -> GPU crop producer (in the timed step)" if args.augment else "synthetic",
                "config": {"workload": "%s, 2x224^2+8x96^2 crops, DDINOLoss (view+region), out_dim 65536, per-param clip 3.0 + "
                                       "AdamW + teacher EMA, drop_path %.2f" % ({"swin_tiny_w7": "Swin-T W=7"}.get(args.arch, args.arch), args.drop_path),
                           "global_batch": B * world, "per_gpu_batch": B, "parallelism": "dp%d" % world},

@@ -28,17 +28,18 @@ BLUR_RADIUS = (0.1, 2.0)  # utils.py:47
 
 def box_blur_weights(radius, passes=3):
     """Pillow's BoxBlur.c for ``ImageFilter.GaussianBlur(radius)``: the box radius of each of the three passes (float variables,
-    double expressions) and ImagingHorizontalBoxBlur's integer radius / 24-bit weights -> (r, ww, fw) of esvit_aug_crops"""
-    f32 = np.float32
-    radius = f32(radius)
-    sigma2 = f32(radius * radius / f32(passes))
-    L = f32(math.sqrt(12.0 * float(sigma2) + 1.0))
-    l = f32(math.floor((float(L) - 1.0) / 2.0))
-    a = f32((2 * l + 1) * (l * (l + 1) - 3 * sigma2))
-    a = f32(a / f32(6 * (sigma2 - (l + 1) * (l + 1))))
-    fr = f32(l + a)
-    r = int(fr)
-    ww = int(f32(1 << 24) / (fr * f32(2) + f32(1)))
+    double expressions) and ImagingHorizontalBoxBlur's integer radius / 24-bit weights -> (r, ww, fw) of esvit_aug_crops;
+    ``radius`` may be an array"""
+    f32, f64 = np.float32, np.float64
+    radius = np.asarray(radius, f64).astype(f32)
+    sigma2 = (radius * radius / f32(passes)).astype(f32)
+    L = np.sqrt(12.0 * sigma2.astype(f64) + 1.0).astype(f32)
+    l = np.floor((L.astype(f64) - 1.0) / 2.0).astype(f32)
+    a = ((2 * l + 1) * (l * (l + 1) - 3 * sigma2)).astype(f32)
+    a = (a / (6 * (sigma2 - (l + 1) * (l + 1))).astype(f32)).astype(f32)
+    fr = (l + a).astype(f32)
+    r = fr.astype(np.int64)
+    ww = (f32(1 << 24) / (fr * f32(2) + f32(1))).astype(f32).astype(np.int64)
     fw = ((1 << 24) - (2 * r + 1) * ww) // 2
     return r, ww, fw
 
@@ -54,7 +55,8 @@ def sample_params(u, src, H, W, size, scale, blur_p, solarize_p):
     # RandomResizedCrop.get_params: up to 10 draws of (area, log-uniform aspect); the first box that fits wins
     area = (H * W).astype(np.float64)[:, None]
     ua, ur = u[:, U_ATTEMPT:U_ATTEMPT + 20:2], u[:, U_ATTEMPT + 1:U_ATTEMPT + 20:2]
-    target = area * (scale[0] + (scale[1] - scale[0]) * ua)
+    s0, s1 = np.reshape(np.asarray(scale[0], np.float64), (-1, 1)), np.reshape(np.asarray(scale[1], np.float64), (-1, 1))  # scalar or per crop
+    target = area * (s0 + (s1 - s0) * ua)
     lr0, lr1 = math.log(RATIO[0]), math.log(RATIO[1])
     aspect = np.exp(lr0 + (lr1 - lr0) * ur)
     w = np.rint(np.sqrt(target * aspect)).astype(np.int64)  # round(): half to even, as Python's
@@ -89,9 +91,8 @@ def sample_params(u, src, H, W, size, scale, blur_p, solarize_p):
     # utils.GaussianBlur: random() <= p, radius uniform(0.1, 2.0); utils.Solarization: random() < p
     blur = u[:, U_BLUR_P] <= blur_p
     radius = BLUR_RADIUS[0] + (BLUR_RADIUS[1] - BLUR_RADIUS[0]) * u[:, U_BLUR_R]
-    for i in np.nonzero(blur)[0]:
-        r, ww, fw = box_blur_weights(radius[i])
-        rows[i, 15], rows[i, 16], rows[i, 17] = r + 1, ww, fw
+    r, ww, fw = box_blur_weights(radius)
+    rows[:, 15], rows[:, 16], rows[:, 17] = np.where(blur, r + 1, 0), np.where(blur, ww, 0), np.where(blur, fw, 0)
     rows[:, 18] = u[:, U_SOL] < solarize_p
     return rows
 
@@ -155,33 +156,68 @@ class DataAugmentationDINO:
         B = len(packed)
         out = {}
         for S, slots in self.groups.items():
-            rows = []
-            for c in slots:
-                _, scale, blur_p, sol_p = self.slots[c]
-                u = self.rng.random((B, NDRAWS)) if uniforms is None else uniforms[c]
-                rows.append(sample_params(u, np.arange(B), packed.H, packed.W, S, scale, blur_p, sol_p))
-            rows = np.concatenate(rows)
+            k = len(slots)
+            u = self.rng.random((k * B, NDRAWS)) if uniforms is None else np.concatenate([uniforms[c] for c in slots])
+            per_slot = lambda i: np.repeat(np.asarray([self.slots[c][i] for c in slots], np.float64), B, axis=0)  # noqa: E731
+            scale = per_slot(1)
+            rows = sample_params(u, np.tile(np.arange(B), k), np.tile(packed.H, k), np.tile(packed.W, k), S, (scale[:, 0], scale[:, 1]),
+                                 per_slot(2), per_slot(3))  # one vectorised pass over the slots of a size
             out[S] = (rows, int(rows[:, 3].max()), int(rows[:, 4].max()))
         return out
 
-    def __call__(self, images, uniforms=None):
+    def collate(self, batch):
+        """``collate_fn`` for a DataLoader whose dataset yields ``(uint8 HWC image, label)``: the DataLoader WORKER makes the random
+        draws (they need the image sizes only), the training process just uploads and renders -> ``((images, draws), labels)``"""
+        images = [torch.as_tensor(np.asarray(x)) for x, _ in batch]
+
+        class _Sizes:
+            H, W = np.asarray([im.shape[0] for im in images]), np.asarray([im.shape[1] for im in images])
+
+            def __len__(self):
+                return len(images)
+        return (images, self.draw(_Sizes())), torch.as_tensor([y for _, y in batch])
+
+    def __call__(self, images, uniforms=None, draws=None):
         packed = images if isinstance(images, PackedImages) else PackedImages(images, self.device)
         B = len(packed)
+        dev = packed.data.device
+        if draws is None:
+            draws = self.draw(packed, uniforms)
+        # one host-to-device copy of all parameter rows, out of a pinned staging buffer that is reused every other call
+        total = sum(rows.shape[0] for rows, _, _ in draws.values())
+        stage, ready = self._staging(total, dev)
+        ready.synchronize()  # the copy issued two calls ago has long finished
+        at = 0
+        for rows, _, _ in draws.values():
+            stage[at:at + rows.shape[0]] = torch.from_numpy(rows)
+            at += rows.shape[0]
+        params = stage[:total].to(dev, non_blocking=True)
+        ready.record()
         crops = [None] * len(self.slots)
-        for S, (rows, max_h, max_w) in self.draw(packed, uniforms).items():
-            params = torch.from_numpy(rows).pin_memory().to(packed.data.device, non_blocking=True)
-            nbytes = rows.shape[0] * (3 * S * S + 4)
-            planes = ops.workspace((nbytes + 3) // 4, packed.data.device, slot="aug_planes").view(torch.uint8)  # stream-ordered scratch
-            out, _ = ops.aug_crops(packed.data, packed.table, params, S, max_h, max_w, planes=planes)
+        at = 0
+        for S, (rows, max_h, max_w) in draws.items():
+            n = rows.shape[0]
+            planes = ops.workspace((n * (3 * S * S + 4) + 3) // 4, dev, slot="aug_planes").view(torch.uint8)  # stream-ordered scratch
+            out, _ = ops.aug_crops(packed.data, packed.table, params[at:at + n], S, max_h, max_w, planes=planes)
+            at += n
             for k, c in enumerate(self.groups[S]):
                 crops[c] = out[k * B:(k + 1) * B]
         return crops
 
+    def _staging(self, rows, dev):
+        if dev.type != "cuda":
+            raise RuntimeError("esvit_amd.data: the crop producer runs on the GPU only")
+        bufs = self.__dict__.setdefault("_pinned", [])
+        if not bufs or bufs[0][0].shape[0] < rows:
+            bufs[:] = [(torch.empty((rows, ops.AUG_PARAM_INTS), dtype=torch.int32).pin_memory(), torch.cuda.Event()) for _ in range(2)]
+        self._turn = 1 - getattr(self, "_turn", 0)
+        return bufs[self._turn]
+
 
 class GpuAugmentedLoader:
-    """wraps a DataLoader whose dataset only DECODES (``(list of uint8 HWC images, labels)`` per batch, e.g. with
-    ``collate_fn=lambda b: ([x for x, _ in b], torch.tensor([y for _, y in b]))``) into the iterator ``train_one_epoch`` expects
-    (main_esvit.py:522): ``(crops, labels)`` with the crops produced on the GPU"""
+    """wraps a DataLoader whose dataset only DECODES (``collate_fn=augment.collate``: the workers also make the random draws; or any
+    collate that yields ``(list of uint8 HWC images, labels)``) into the iterator ``train_one_epoch`` expects (main_esvit.py:522):
+    ``(crops, labels)`` with the crops produced on the GPU"""
 
     def __init__(self, loader, augment):
         self.loader, self.augment = loader, augment
@@ -191,4 +227,7 @@ class GpuAugmentedLoader:
 
     def __iter__(self):
         for images, labels in self.loader:
-            yield self.augment(images), labels
+            if isinstance(images, tuple) and len(images) == 2 and isinstance(images[1], dict):  # DataAugmentationDINO.collate
+                yield self.augment(images[0], draws=images[1]), labels
+            else:
+                yield self.augment(images), labels

@@ -211,3 +211,21 @@ def test_augmentation_object_layout(lib_built):
     assert (draws[96][0][:, 0] == np.tile(np.arange(3), 8)).all()        # slot-major: crop slot c of image b at row c * B + b
     with pytest.raises(ValueError):
         D.PackedImages([np.zeros((4, 4), np.uint8)], device="cpu")
+
+
+def test_collate_draws_in_the_worker(lib_built):
+    """DataAugmentationDINO.collate: a picklable collate_fn that makes the draws from the image sizes (DataLoader worker side)"""
+    import torch
+    import esvit_amd.data as D
+    aug = D.DataAugmentationDINO((0.4, 1.0), (0.05, 0.4), (8,), (96,), seed=0)
+    rng = np.random.default_rng(0)
+    batch = [(rng.integers(0, 256, (int(h), int(w), 3), dtype=np.uint8), i) for i, (h, w) in enumerate([(120, 160), (90, 64), (200, 200)])]
+    (images, draws), labels = aug.collate(batch)
+    assert len(images) == 3 and images[0].dtype == torch.uint8 and labels.tolist() == [0, 1, 2]
+    assert set(draws) == {224, 96} and draws[224][0].shape == (6, 24) and draws[96][0].shape == (24, 24)
+    for S, (rows, mh, mw) in draws.items():
+        H, W = np.tile([120, 90, 200], len(rows) // 3), np.tile([160, 64, 200], len(rows) // 3)
+        assert (rows[:, 1] + rows[:, 3] <= H).all() and (rows[:, 2] + rows[:, 4] <= W).all() and mh == rows[:, 3].max() and mw == rows[:, 4].max()
+    loader = torch.utils.data.DataLoader(batch, batch_size=3, collate_fn=aug.collate, num_workers=1)  # crosses a process boundary
+    (images2, draws2), _ = next(iter(loader))
+    assert [tuple(i.shape) for i in images2] == [tuple(i.shape) for i in images] and set(draws2) == {224, 96}
