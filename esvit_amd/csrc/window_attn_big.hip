@@ -732,7 +732,9 @@ size_t dkv2_lds() {
 }
 
 inline int big_parts(int Bw, int nH) {
-    int parts = (512 + nH - 1) / nH;  // ~2 workgroups per CU across heads and query-block groups
+    // the dQ workgroups are persistent (each walks its share of the windows): parts * nH * DQ4_GROUPS of them are launched, rounded
+    // DOWN to 1024 so that the last round of resident workgroups is not a handful of stragglers (cf. bwd_parts in window_attn.hip)
+    int parts = 512 / nH;
     if (parts > Bw) parts = Bw;
     return parts < 1 ? 1 : parts;
 }
