@@ -57,6 +57,17 @@ def pmc_gemm_traffic_per_launch(arch, batch, launches_per_step):
 def build(dev, drop_path, arch="swin_tiny_w7"):
     import esvit_amd
     from esvit_amd import config as CFG
+    if arch in ("deit_tiny", "deit_small", "vit_base"):  # built by name, main_esvit.py:305-327
+        from esvit_amd.models import vision_transformer as vits
+        student = vits.__dict__[arch](patch_size=16, drop_path_rate=drop_path, use_dense_prediction=True)
+        teacher = vits.__dict__[arch](patch_size=16, use_dense_prediction=True)
+        for m in (student, teacher):
+            m.head, m.head_dense = esvit_amd.DINOHead(m.embed_dim, OUT_DIM), esvit_amd.DINOHead(m.embed_dim, OUT_DIM)
+        student, teacher = student.to(dev), teacher.to(dev)
+        teacher.load_state_dict(student.state_dict())
+        for p in teacher.parameters():
+            p.requires_grad = False
+        return student, teacher, esvit_amd.DDINOLoss(OUT_DIM, 10, 0.04, 0.04, 0, 100).to(dev)
     cfg = CFG.model_config(arch, DROP_PATH_RATE=drop_path)
     student = esvit_amd.build_model(cfg, use_dense_prediction=True)
     student.head = esvit_amd.DINOHead(student.num_features, OUT_DIM)
@@ -255,7 +266,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=128, help="images per GPU (BASELINE.json configs 3/4: 1024 over 8 GPUs)")
     ap.add_argument("--drop-path", type=float, default=0.1)
-    ap.add_argument("--arch", default="swin_tiny_w7", choices=["swin_tiny_w7", "swin_tiny_w14", "swin_base_w14", "swin_small_w7", "swin_base_w7", "cvt_s1"],
+    ap.add_argument("--arch", default="swin_tiny_w7", choices=["swin_tiny_w7", "swin_tiny_w14", "swin_base_w14", "swin_small_w7", "swin_base_w7", "cvt_s1", "deit_tiny", "deit_small", "vit_base"],
                     help="BASELINE.json's metric is quoted on swin_tiny_w7 (default); configs 3/4 are swin_tiny_w14 / swin_base_w14")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")

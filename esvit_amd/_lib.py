@@ -77,6 +77,10 @@ SIGNATURES = {
     "esvit_weightnorm_fwd": (C.c_int, [C.c_int, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp]),
     "esvit_weightnorm_bwd": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, vp, vp, vp]),
     "esvit_aug_crops": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp]),
+    "esvit_heads_split": (C.c_int, [C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
+    "esvit_heads_merge": (C.c_int, [C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
+    "esvit_softmax_rows_fwd": (C.c_int, [C.c_int, vp, i64, C.c_int, C.c_int, f32, vp]),
+    "esvit_softmax_rows_bwd": (C.c_int, [C.c_int, vp, vp, i64, C.c_int, C.c_int, f32, vp]),
     "esvit_teacher_row_stats": (C.c_int, [C.c_int, vp, vp, f32, i64, C.c_int, vp, vp, vp]),
     "esvit_region_match": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]),
     "esvit_dino_ce_fwd_bwd": (C.c_int, [C.c_int, vp, vp, vp, vp, vp, vp, vp, C.c_int, vp, f32, f32, i64, C.c_int, vp, vp, vp, vp]),

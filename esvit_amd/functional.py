@@ -888,3 +888,120 @@ class CvtFfnFn(torch.autograd.Function):
         dh = o.linear_dgrad(da1, W1)
         gx, dg2, db2 = o.layernorm_bwd(dh, x.view(M, C), mean, rstd, g2, g_in=gy)
         return gx.view(nB, L, C), None, dg2, db2, dW1.view(Hd, C, 1, 1), dbf1, dW2.view(C, Hd, 1, 1), dbf2
+
+
+# ------------------------------------------------------------------------------------------------
+# monolithic ViT (models/vision_transformer.py:96-381): patch embedding without a norm, blocks with global attention
+# ------------------------------------------------------------------------------------------------
+class VitPatchEmbedFn(torch.autograd.Function):
+    """PatchEmbed (vision_transformer.py:121-139): Conv2d(k = stride = patch) as im2col + GEMM, fp32 tokens out"""
+
+    @staticmethod
+    def forward(ctx, img, Wp, bp, patch):
+        o = ops_module()
+        E = Wp.shape[0]
+        Kc = Wp.shape[1] * patch * patch
+        nB, _, S, _ = img.shape
+        cols = o.patch_im2col(img.contiguous(), patch, Kc)
+        y = o.linear_fwd(cols, _weight(Wp, (E, Kc)), bp, out_f32=True)
+        ctx.save_for_backward(cols)
+        ctx.wparam, ctx.bparam, ctx.wshape = Wp, bp, tuple(Wp.shape)
+        return y.view(nB, (S // patch) ** 2, E)
+
+    @staticmethod
+    def backward(ctx, gx):
+        o = ops_module()
+        (cols,) = ctx.saved_tensors
+        M = cols.shape[0]
+        dyb = o.gather_cast(gx.contiguous().view(M, -1), M)
+        dW, dbp = _wgrad(dyb, cols, ctx.wparam, shape2d=(ctx.wshape[0], cols.shape[1]), want_bias=True, bias_param=ctx.bparam)
+        return None, dW.view(ctx.wshape), dbp, None
+
+
+def _vit_block_forward(x, nH, dp, prm, wts, save):
+    """Block.forward (vision_transformer.py:110-116) on x fp32 [nB, N, C]"""
+    o = ops_module()
+    (g1, b1, bqkv, bproj, g2, b2, bfc1, bfc2) = prm
+    (Wqkv, Wproj, W1, W2) = wts
+    nB, N, C = x.shape
+    x2d = x.view(nB * N, C)
+    scale = (C // nH) ** -0.5
+    dp1, dp2 = (None, None) if dp is None else dp
+    xw, _, mean1, rstd1 = o.layernorm_fwd(x2d, g1, b1, LN_EPS)
+    qkv = o.linear_fwd(xw, Wqkv, bqkv)
+    ao, att = o.vit_attn_fwd(qkv, nB, N, nH, scale)
+    x1 = o.linear_fwd(ao, Wproj, bproj, residual=x2d, rowscale=dp1, rows_per_sample=N, out_f32=True)
+    h, _, mean2, rstd2 = o.layernorm_fwd(x1, g2, b2, LN_EPS)
+    if save:
+        a1g, a1 = o.linear_fwd(h, W1, bfc1, gelu=True, want_preact=True)
+    else:
+        a1g, a1 = o.linear_fwd(h, W1, bfc1, gelu=True), None
+    x2 = o.linear_fwd(a1g, W2, bfc2, residual=x1, rowscale=dp2, rows_per_sample=N, out_f32=True)
+    saved = (mean1, rstd1, xw, ao, x1, mean2, rstd2, h, a1, a1g) if save else None
+    return x2.view(nB, N, C), saved, att
+
+
+class VitBlockFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, nH, dp, g1, b1, Wqkv_p, bqkv, Wproj_p, bproj, g2, b2, W1_p, bfc1, W2_p, bfc2):
+        wts = (_weight(Wqkv_p), _weight(Wproj_p), _weight(W1_p), _weight(W2_p))
+        x = x.contiguous()
+        y, saved, att = _vit_block_forward(x, nH, dp, (g1, b1, bqkv, bproj, g2, b2, bfc1, bfc2), wts, True)
+        ctx.nH, ctx.dp = nH, dp
+        ctx.wparams = (Wqkv_p, Wproj_p, W1_p, W2_p)
+        ctx.bparams = (bqkv, bproj, bfc1, bfc2)
+        ctx.nparams = (g1, b1, g2, b2)
+        ctx.natt = len(att)
+        ctx.save_for_backward(x, g1, g2, *wts, *saved, *att)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        o = ops_module()
+        nH, dp = ctx.nH, ctx.dp
+        t = ctx.saved_tensors
+        x, g1, g2, Wqkv, Wproj, W1, W2, mean1, rstd1, xw, ao, x1, mean2, rstd2, h, a1, a1g = t[:17]
+        att = tuple(t[17:17 + ctx.natt])
+        nB, N, C = x.shape
+        M = nB * N
+        scale = (C // nH) ** -0.5
+        dp1, dp2 = (None, None) if dp is None else dp
+        gy = gy.contiguous().view(M, C)
+        Wqkv_p, Wproj_p, W1_p, W2_p = ctx.wparams
+        bqkv_p, bproj_p, bfc1_p, bfc2_p = ctx.bparams
+        g1_p, b1_p, g2_p, b2_p = ctx.nparams
+        dyb = o.gather_cast(gy, M, rowscale=dp2, rows_per_sample=N)
+        dW2, dbfc2 = _wgrad(dyb, a1g, W2_p, want_bias=True, bias_param=bfc2_p)
+        da1 = o.linear_dgrad(dyb, W2, gelu_preact=a1)
+        dW1, dbfc1 = _wgrad(da1, h, W1_p, want_bias=True, bias_param=bfc1_p)
+        dh = o.linear_dgrad(da1, W1)
+        sink1, sink2 = _ln_sinks(g1_p, b1_p), _ln_sinks(g2_p, b2_p)
+        gx1, dyw, dg2, db2 = o.layernorm_bwd_cast(dh, x1, mean2, rstd2, g2, g_in=gy, rowscale=dp1, rows_per_sample=N, gb_out=sink2)
+        dWproj, dbproj = _wgrad(dyw, ao, Wproj_p, want_bias=True, bias_param=bproj_p)
+        dao = o.linear_dgrad(dyw, Wproj)
+        dqkv = o.vit_attn_bwd(dao, att, nB, N, nH, scale)
+        dWqkv, dbqkv = _wgrad(dqkv, xw, Wqkv_p, want_bias=True, bias_param=bqkv_p)
+        dxw = o.linear_dgrad(dqkv, Wqkv)
+        gx, dg1, db1 = o.layernorm_bwd(dxw, x.view(M, C), mean1, rstd1, g1, g_in=gx1, gb_out=sink1)
+        return (gx.view(nB, N, C), None, None, _alias(dg1, sink1), _alias(db1, sink1), dWqkv, dbqkv, dWproj, dbproj,
+                _alias(dg2, sink2), _alias(db2, sink2), dW1, dbfc1, dW2, dbfc2)
+
+
+def vit_block(x, nH, dp, prm_list):
+    if not torch.is_grad_enabled() or not (x.requires_grad or any(p.requires_grad for p in prm_list)):
+        g1, b1, Wqkv_p, bqkv, Wproj_p, bproj, g2, b2, W1_p, bfc1, W2_p, bfc2 = prm_list
+        wts = (_weight(Wqkv_p), _weight(Wproj_p), _weight(W1_p), _weight(W2_p))
+        return _vit_block_forward(x.contiguous(), nH, dp, (g1, b1, bqkv, bproj, g2, b2, bfc1, bfc2), wts, False)[0]
+    return VitBlockFn.apply(x, nH, dp, *prm_list)
+
+
+def vit_block_attention(x, nH, prm_list):
+    """the attention probabilities [nB, nH, N, N] of a block (Block.forward(return_attention=True), vision_transformer.py:112)"""
+    o = ops_module()
+    g1, b1, Wqkv_p, bqkv = prm_list[:4]
+    nB, N, C = x.shape
+    xw = o.layernorm_fwd(x.contiguous().view(nB * N, C), g1, b1, LN_EPS)[0]
+    qkv = o.linear_fwd(xw, _weight(Wqkv_p), bqkv)
+    _, att = o.vit_attn_fwd(qkv, nB, N, nH, (C // nH) ** -0.5)
+    p = att[-1]
+    return p.reshape(nB, nH, p.shape[-2], p.shape[-1])[:, :, :N, :N].float()

@@ -1,0 +1,219 @@
+"""MI355X-native monolithic ViT backbones behind the reference's module interface (models/vision_transformer.py:96-381:
+``VisionTransformer``, ``deit_tiny`` / ``deit_small`` / ``vit_base`` -- main_esvit.py:305-311 builds them by name).
+
+As for Swin, the module tree only HOLDS parameters -- names, shapes, registration order and init are the reference's, so
+state_dicts are interchangeable -- and every forward runs esvit_amd.functional: one autograd node per block (LayerNorm, the four
+GEMMs with fused epilogues, global attention over the 197 / 37 tokens of a crop on the batched GEMM family + a row softmax, csrc/
+vit_attn.hip).  The class token / position embedding (with the reference's bicubic interpolation for the 96^2 crops) are small
+torch tensor ops.
+"""
+import math
+from functools import partial
+
+import torch
+import torch.nn as nn
+
+from .. import functional as Fn
+from ..head import DINOHead  # noqa: F401  (the reference exports it from this module)
+from .swin_transformer import DropPath, Mlp, _trunc_normal_
+
+
+class Attention(nn.Module):
+    """vision_transformer.py:67-94 (parameters only)"""
+
+    def __init__(self, dim, num_heads=8, qkv_bias=False, qk_scale=None, attn_drop=0., proj_drop=0.):
+        super().__init__()
+        if qk_scale is not None or attn_drop != 0. or proj_drop != 0.:
+            raise NotImplementedError("qk_scale / attention dropout / projection dropout are unused by deit_tiny, deit_small, vit_base")
+        self.num_heads = num_heads
+        self.scale = (dim // num_heads) ** -0.5
+        self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
+        self.attn_drop = nn.Dropout(attn_drop)
+        self.proj = nn.Linear(dim, dim)
+        self.proj_drop = nn.Dropout(proj_drop)
+
+
+class Block(nn.Module):
+    """vision_transformer.py:96-119"""
+
+    def __init__(self, dim, num_heads, mlp_ratio=4., qkv_bias=False, qk_scale=None, drop=0., attn_drop=0., drop_path=0.,
+                 act_layer=nn.GELU, norm_layer=nn.LayerNorm):
+        super().__init__()
+        self.norm1 = norm_layer(dim)
+        self.attn = Attention(dim, num_heads=num_heads, qkv_bias=qkv_bias, qk_scale=qk_scale, attn_drop=attn_drop, proj_drop=drop)
+        self.drop_path = DropPath(drop_path) if drop_path > 0. else nn.Identity()
+        self.norm2 = norm_layer(dim)
+        self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio), act_layer=act_layer, drop=drop)
+
+    def _params(self):
+        a, m = self.attn, self.mlp
+        if a.qkv.bias is None:
+            raise NotImplementedError("qkv_bias=False: every reference ViT factory passes qkv_bias=True")
+        return [self.norm1.weight, self.norm1.bias, a.qkv.weight, a.qkv.bias, a.proj.weight, a.proj.bias, self.norm2.weight,
+                self.norm2.bias, m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias]
+
+    def _dp(self, nB, device):
+        if not isinstance(self.drop_path, DropPath):
+            return None
+        f1, f2 = self.drop_path.factors(nB, device), self.drop_path.factors(nB, device)  # one draw per residual branch, :114-115
+        return None if f1 is None else (f1, f2)
+
+    def forward(self, x, return_attention=False):
+        if return_attention:
+            return Fn.vit_block_attention(x, self.attn.num_heads, self._params())
+        return Fn.vit_block(x, self.attn.num_heads, self._dp(x.shape[0], x.device), self._params())
+
+    def forward_fea_and_attn(self, x):
+        return self.forward(x), Fn.vit_block_attention(x, self.attn.num_heads, self._params())
+
+
+class PatchEmbed(nn.Module):
+    """vision_transformer.py:121-139"""
+
+    def __init__(self, img_size=224, patch_size=16, in_chans=3, embed_dim=768):
+        super().__init__()
+        self.num_patches = (img_size // patch_size) * (img_size // patch_size)
+        self.img_size, self.patch_size = img_size, patch_size
+        self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=patch_size, stride=patch_size)
+
+    def forward(self, x):
+        return Fn.VitPatchEmbedFn.apply(x, self.proj.weight, self.proj.bias, self.patch_size)
+
+
+class VisionTransformer(nn.Module):
+    """vision_transformer.py:142-362"""
+
+    def __init__(self, img_size=[224], patch_size=16, in_chans=3, num_classes=0, embed_dim=768, depth=12, num_heads=12, mlp_ratio=4.,
+                 qkv_bias=False, qk_scale=None, drop_rate=0., attn_drop_rate=0., drop_path_rate=0., norm_layer=nn.LayerNorm,
+                 use_dense_prediction=False, **kwargs):
+        super().__init__()
+        if drop_rate != 0.:
+            raise NotImplementedError("drop_rate: dropout is 0 on the reference's pre-training path")
+        self.num_features = self.embed_dim = embed_dim
+        self.patch_embed = PatchEmbed(img_size=img_size[0], patch_size=patch_size, in_chans=in_chans, embed_dim=embed_dim)
+        num_patches = self.patch_embed.num_patches
+        self.cls_token = nn.Parameter(torch.zeros(1, 1, embed_dim))
+        self.pos_embed = nn.Parameter(torch.zeros(1, num_patches + 1, embed_dim))
+        self.pos_drop = nn.Dropout(p=drop_rate)
+        dpr = [x.item() for x in torch.linspace(0, drop_path_rate, depth)]  # stochastic depth decay rule
+        self.blocks = nn.ModuleList([
+            Block(dim=embed_dim, num_heads=num_heads, mlp_ratio=mlp_ratio, qkv_bias=qkv_bias, qk_scale=qk_scale, drop=drop_rate,
+                  attn_drop=attn_drop_rate, drop_path=dpr[i], norm_layer=norm_layer) for i in range(depth)])
+        self.norm = norm_layer(embed_dim)
+        if abs(self.norm.eps - Fn.LN_EPS) > 1e-12:
+            raise ValueError("LayerNorm eps %g: the kernels are built for the reference factories' eps = 1e-6" % self.norm.eps)
+        self.head = nn.Linear(embed_dim, num_classes) if num_classes > 0 else nn.Identity()
+        self.use_dense_prediction = use_dense_prediction
+        if self.use_dense_prediction:
+            self.head_dense = None
+        _trunc_normal_(self.pos_embed, std=.02)
+        _trunc_normal_(self.cls_token, std=.02)
+        self.apply(self._init_weights)
+
+    def _init_weights(self, m):
+        if isinstance(m, nn.Linear):
+            _trunc_normal_(m.weight, std=.02)
+            if m.bias is not None:
+                nn.init.constant_(m.bias, 0)
+        elif isinstance(m, nn.LayerNorm):
+            nn.init.constant_(m.bias, 0)
+            nn.init.constant_(m.weight, 1.0)
+
+    # ---- tokens ------------------------------------------------------------------------------------------------------
+    def interpolate_pos_encoding(self, x, pos_embed):
+        """vision_transformer.py:263-277 (the same torch call, so the same rounding of the output size)"""
+        npatch = x.shape[1] - 1
+        N = pos_embed.shape[1] - 1
+        if npatch == N:
+            return pos_embed
+        class_emb = pos_embed[:, 0]
+        pos_embed = pos_embed[:, 1:]
+        dim = x.shape[-1]
+        pos_embed = nn.functional.interpolate(
+            pos_embed.reshape(1, int(math.sqrt(N)), int(math.sqrt(N)), dim).permute(0, 3, 1, 2),
+            scale_factor=math.sqrt(npatch / N), mode='bicubic')
+        pos_embed = pos_embed.permute(0, 2, 3, 1).view(1, -1, dim)
+        return torch.cat((class_emb.unsqueeze(0), pos_embed), dim=1)
+
+    def _tokens(self, x):
+        B = x.shape[0]
+        x = self.patch_embed(x)
+        x = torch.cat((self.cls_token.expand(B, -1, -1), x), dim=1)
+        return Fn.ApeAddFn.apply(x, self.interpolate_pos_encoding(x, self.pos_embed).contiguous())
+
+    def forward_feature_maps(self, x):
+        x = self._tokens(x)
+        for blk in self.blocks:
+            x = blk(x)
+        return Fn.FinalNormFn.apply(x, self.norm.weight, self.norm.bias)
+
+    def forward_features(self, x):
+        x = self.forward_feature_maps(x)
+        if self.use_dense_prediction:
+            return x[:, 0], x[:, 1:]
+        return x[:, 0]
+
+    # ---- multi-crop forward (vision_transformer.py:186-233): one pass per run of equal resolutions ---------------------
+    def forward(self, x):
+        if not isinstance(x, list):
+            x = [x]
+        idx_crops = torch.cumsum(torch.unique_consecutive(torch.tensor([inp.shape[-1] for inp in x]), return_counts=True)[1], 0)
+        start_idx = 0
+        if self.use_dense_prediction:
+            cls, fea, npatch = [], [], []
+            for end_idx in idx_crops:
+                _out_cls, _out_fea = self.forward_features(torch.cat(x[start_idx:end_idx]))
+                B, N, C = _out_fea.shape
+                cls.append(_out_cls)
+                fea.append(_out_fea.reshape(B * N, C))
+                npatch.append(N)
+                start_idx = end_idx
+            output_cls, output_fea = torch.cat(cls), torch.cat(fea)
+            return self.head(output_cls), self.head_dense(output_fea), output_fea, npatch
+        outs = []
+        for end_idx in idx_crops:
+            outs.append(self.forward_features(torch.cat(x[start_idx:end_idx])))
+            start_idx = end_idx
+        return self.head(torch.cat(outs))
+
+    # ---- evaluation hooks (vision_transformer.py:279-362) ---------------------------------------------------------------
+    def forward_selfattention(self, x, n=1):
+        x = self._tokens(x)  # (images whose sides are multiples of the patch size: the reference's padding branch is not needed)
+        if n == 1:
+            for i, blk in enumerate(self.blocks):
+                if i < len(self.blocks) - 1:
+                    x = blk(x)
+                else:
+                    return blk(x, return_attention=True)
+        attn_out = []
+        for blk in self.blocks:
+            x, attn = blk.forward_fea_and_attn(x)
+            attn_out.append(attn)
+        return attn_out
+
+    def forward_return_n_last_blocks(self, x, n=1, return_patch_avgpool=False, depths=[]):
+        x = self._tokens(x)
+        output = []
+        for i, blk in enumerate(self.blocks):
+            x = blk(x)
+            if len(self.blocks) - i <= n:
+                output.append(Fn.FinalNormFn.apply(x, self.norm.weight, self.norm.bias)[:, 0])
+        if return_patch_avgpool:
+            xn = Fn.FinalNormFn.apply(x, self.norm.weight, self.norm.bias)
+            output.append(torch.mean(xn[:, 1:], dim=1))
+        return torch.cat(output, dim=-1)
+
+
+def deit_tiny(patch_size=16, **kwargs):
+    return VisionTransformer(patch_size=patch_size, embed_dim=192, depth=12, num_heads=3, mlp_ratio=4, qkv_bias=True,
+                             norm_layer=partial(nn.LayerNorm, eps=1e-6), **kwargs)
+
+
+def deit_small(patch_size=16, **kwargs):
+    return VisionTransformer(patch_size=patch_size, embed_dim=384, depth=12, num_heads=6, mlp_ratio=4, qkv_bias=True,
+                             norm_layer=partial(nn.LayerNorm, eps=1e-6), **kwargs)
+
+
+def vit_base(patch_size=16, **kwargs):
+    return VisionTransformer(patch_size=patch_size, embed_dim=768, depth=12, num_heads=12, mlp_ratio=4, qkv_bias=True,
+                             norm_layer=partial(nn.LayerNorm, eps=1e-6), **kwargs)

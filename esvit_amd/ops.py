@@ -827,3 +827,67 @@ def aug_crops(src, images, params, S, max_h, max_w, planes=None, out=None):
     assert out.is_cuda and out.dtype == torch.float32 and out.is_contiguous() and out.numel() >= n * 3 * S * S
     check(lib.esvit_aug_crops(_p(src), _p(images), _p(params), n, S, int(max_h), int(max_w), _p(planes), _p(out), _stream()), "aug_crops")
     return out, planes.view(-1)[:n * 3 * S * S].view(n, 3, S, S)
+
+
+# ------------------------------------------------------------------------------------------------
+# global attention of the monolithic ViT backbones (models/vision_transformer.py:67-94)
+# ------------------------------------------------------------------------------------------------
+def vit_pad_tokens(N):
+    """tokens per image rounded up to the granularity the batched GEMMs need (k-strided operands: multiples of 16)"""
+    return -(-N // 16) * 16
+
+
+def heads_split(x, B, N, nH, parts):
+    """x [B * N, parts * C] token-major -> [parts, B, nH, Np, hd] (pad rows zero)"""
+    x = _actc(x)
+    C_ = x.shape[1] // parts
+    hd, Np = C_ // nH, vit_pad_tokens(N)
+    y = torch.empty((parts, B, nH, Np, hd), dtype=x.dtype, device=x.device)
+    check(lib.esvit_heads_split(_code(x.dtype), _p(x), B, N, Np, nH, hd, parts, _p(y), _stream()), "heads_split")
+    return y
+
+
+def heads_merge(y, N):
+    """y [parts, B, nH, Np, hd] -> [B * N, parts * nH * hd] token-major"""
+    y = _actc(y)
+    parts, B, nH, Np, hd = y.shape
+    x = torch.empty((B * N, parts * nH * hd), dtype=y.dtype, device=y.device)
+    check(lib.esvit_heads_merge(_code(y.dtype), _p(y), B, N, Np, nH, hd, parts, _p(x), _stream()), "heads_merge")
+    return x
+
+
+def _bmm(a, b, M, N, K, *, a_kstrided=0, b_kstrided=0, out=None):
+    """batched esvit_gemm over the leading axis of contiguous 3-D operands: out[z] = op(a[z]) @ op(b[z]) -> [Z, M, N]"""
+    Z = a.shape[0]
+    if out is None:
+        out = torch.empty((Z, M, N), dtype=a.dtype, device=a.device)
+    assert out.is_contiguous() and out.shape == (Z, M, N) and a.is_contiguous() and b.is_contiguous()
+    _gemm(a.dtype, A=a, B=b, C=out, M=M, N=N, K=K, lda=a.shape[2], ldb=b.shape[2], ldc=N, a_kstrided=a_kstrided, b_kstrided=b_kstrided,
+          batch=Z, strideA=a.shape[1] * a.shape[2], strideB=b.shape[1] * b.shape[2], strideC=M * N)
+    return out
+
+
+def vit_attn_fwd(qkv, B, N, nH, scale):
+    """Attention.forward between the qkv and proj projections (vision_transformer.py:76-83): qkv [B * N, 3C] -> (out [B * N, C],
+    saved = (q | k | v [3, B nH, Np, hd], P [B nH, Np, Np]))"""
+    C_ = qkv.shape[1] // 3
+    hd, Np = C_ // nH, vit_pad_tokens(N)
+    qkvh = heads_split(qkv, B, N, nH, 3).view(3, B * nH, Np, hd)
+    prob = _bmm(qkvh[0], qkvh[1], Np, Np, hd)                                  # S = q k^T
+    check(lib.esvit_softmax_rows_fwd(_code(prob.dtype), _p(prob), B * nH, N, Np, float(scale), _stream()), "softmax_rows_fwd")
+    o = _bmm(prob, qkvh[2], Np, hd, Np, b_kstrided=1)                          # O = P v
+    return heads_merge(o.view(1, B, nH, Np, hd), N), (qkvh, prob)
+
+
+def vit_attn_bwd(dout, saved, B, N, nH, scale):
+    """gradient of vit_attn_fwd with respect to qkv: dout [B * N, C] -> dqkv [B * N, 3C]"""
+    qkvh, prob = saved
+    _, Z, Np, hd = qkvh.shape
+    do = heads_split(dout, B, N, nH, 1).view(Z, Np, hd)
+    dqkvh = torch.empty_like(qkvh)
+    _bmm(prob, do, Np, hd, Np, a_kstrided=1, b_kstrided=1, out=dqkvh[2])      # dv = P^T dO
+    dp = _bmm(do, qkvh[2], Np, Np, hd)                                         # dP = dO v^T
+    check(lib.esvit_softmax_rows_bwd(_code(dp.dtype), _p(prob), _p(dp), Z, N, Np, float(scale), _stream()), "softmax_rows_bwd")
+    _bmm(dp, qkvh[1], Np, hd, Np, b_kstrided=1, out=dqkvh[0])                  # dq = dS k
+    _bmm(dp, qkvh[0], Np, hd, Np, a_kstrided=1, b_kstrided=1, out=dqkvh[1])   # dk = dS^T q
+    return heads_merge(dqkvh.view(3, B, nH, Np, hd), N)

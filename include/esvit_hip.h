@@ -368,6 +368,20 @@ int esvit_bn_bwd_coeffs(const float* red, float n, const float* gamma, const flo
 int esvit_aug_crops(const uint8_t* src, const int64_t* images, const int32_t* params, int n, int S, int max_h, int max_w,
                     uint8_t* planes, float* out, esvit_stream_t stream);
 
+/* ---- global attention of the monolithic ViT backbones --------------------- */
+/* models/vision_transformer.py:67-94 (Attention.forward of deit_tiny / deit_small / vit_base): the score matrix lives in HBM
+ * and the products run on esvit_gemm (batch = B * nH); these are the layout changes and the row softmax around them.
+ *   esvit_heads_split   x [B * N, parts * nH * hd] token-major (the qkv GEMM output: parts = 3; a gradient of the merged heads:
+ *                       parts = 1)  ->  y [parts, B, nH, Np, hd], rows N..Np-1 zero        (:76, reshape + permute)
+ *   esvit_heads_merge   the inverse, dropping the pad rows                                   (:83, transpose + reshape)
+ *   esvit_softmax_rows_fwd   in place over s [batch, Np, Np]: softmax(scale * s[:, :N, :N]) along the last axis, zero on pad rows
+ *                       and columns (Np <= 256)                                              (:79-80)
+ *   esvit_softmax_rows_bwd   in place over dp: scale * p o (dp - sum_j p_j dp_j), zero on pad rows and columns */
+int esvit_heads_split(int dtype, const void* x, int B, int N, int Np, int nH, int hd, int parts, void* y, esvit_stream_t stream);
+int esvit_heads_merge(int dtype, const void* y, int B, int N, int Np, int nH, int hd, int parts, void* x, esvit_stream_t stream);
+int esvit_softmax_rows_fwd(int dtype, void* s, int64_t batch, int N, int Np, float scale, esvit_stream_t stream);
+int esvit_softmax_rows_bwd(int dtype, const void* p, void* dp, int64_t batch, int N, int Np, float scale, esvit_stream_t stream);
+
 #pragma GCC visibility pop
 #ifdef __cplusplus
 }

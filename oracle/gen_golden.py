@@ -239,6 +239,59 @@ def gen_nano_cvt(ns):
     print("nano_cvt_step.pt: loss", g["ddino_loss"], "npatch", g["npatch"], "params", len(g["param_names"]), "no_grad", g["no_grad"])
 
 
+def build_nano_vit(ns, teacher=False):
+    import importlib
+    from functools import partial
+    vits = importlib.import_module("models.vision_transformer")  # the reference's module (main_esvit.py:36, `vits`)
+    v = GU.NANO_VIT
+    m = vits.VisionTransformer(img_size=[v["sizes"][0]], patch_size=v["patch"], embed_dim=v["embed_dim"], depth=v["depth"], num_heads=v["heads"],
+                               mlp_ratio=4, qkv_bias=True, norm_layer=partial(torch.nn.LayerNorm, eps=1e-6), drop_path_rate=0.0,
+                               use_dense_prediction=True)
+    hk = dict(hidden_dim=GU.NANO_HEAD["hidden_dim"], bottleneck_dim=GU.NANO_HEAD["bottleneck_dim"])
+    m.head = ns.DINOHead(v["embed_dim"], GU.NANO_HEAD["out_dim"], norm_last_layer=True, **hk)
+    m.head_dense = ns.DINOHead(v["embed_dim"], GU.NANO_HEAD["out_dim"], norm_last_layer=False, **hk)
+    return m
+
+
+def gen_nano_vit(ns):
+    """the monolithic ViT (models/vision_transformer.py: deit_tiny / deit_small / vit_base, the DEFAULT --arch) in miniature:
+    class token, interpolated position embedding for the local crops, global attention, dense prediction heads"""
+    RL.ensure_single_process_group()
+    student, teacher = build_nano_vit(ns), build_nano_vit(ns, teacher=True)
+    GU.fill_state_dict(student.state_dict(), seed=0)
+    GU.fill_state_dict(teacher.state_dict(), seed=7)
+    student.head.last_layer.weight_g.data.fill_(1)
+    for p in teacher.parameters():
+        p.requires_grad = False
+    crops = GU.make_crops(2, n_local=3, sizes=GU.NANO_VIT["sizes"])
+    K = GU.NANO_HEAD["out_dim"]
+    g = {"keys": [(k, tuple(v.shape), str(v.dtype)) for k, v in student.state_dict().items()],
+         "param_names": [n for n, _ in student.named_parameters()]}
+    loss_fn = ns.DDINOLoss(K, 5, 0.04, 0.07, 5, 10)
+    t_out = teacher(crops[:2])
+    s_out = student(crops)
+    for nm, t in (("s_cls", s_out[0]), ("s_reg", s_out[1]), ("s_fea", s_out[2]), ("t_cls", t_out[0]), ("t_reg", t_out[1]), ("t_fea", t_out[2])):
+        g[nm] = GU.probe(t)
+    g["s_fea_full"] = s_out[2].detach().clone()
+    g["npatch"] = (list(s_out[3]), list(t_out[3]))
+    loss = loss_fn(s_out, t_out, 2, None)
+    g["ddino_loss"] = loss.item()
+    student.zero_grad()
+    loss.backward()
+    g["grads"] = {n: GU.probe(p.grad) for n, p in student.named_parameters() if p.grad is not None}
+    g["grad_norms"] = {n: p.grad.norm().item() for n, p in student.named_parameters() if p.grad is not None}
+    g["no_grad"] = [n for n, p in student.named_parameters() if p.grad is None]
+    # view-level branch (use_dense_prediction False: forward returns head(cls) only) and the evaluation hooks
+    with torch.no_grad():
+        student.use_dense_prediction = False
+        g["view_only"] = GU.probe(student(crops))
+        student.use_dense_prediction = True
+        g["last_blocks"] = student.forward_return_n_last_blocks(crops[2], n=2, return_patch_avgpool=True).clone()
+        g["last_attn"] = student.forward_selfattention(crops[0]).clone()
+    torch.save(g, os.path.join(OUT, "nano_vit_step.pt"))
+    print("nano_vit_step.pt: loss", g["ddino_loss"], "npatch", g["npatch"], "params", len(g["param_names"]), "no_grad", g["no_grad"])
+
+
 def gen_knn(ns):
     """top-1 / top-5 of the reference's knn_classifier on synthetic feature sets (tests/golden_utils.make_knn_set)"""
     ref_knn = RL.load_knn_classifier()
@@ -404,6 +457,8 @@ def main():
         gen_nano14(ns)
     if not only or "cvt" in only:
         gen_nano_cvt(ns)
+    if not only or "vit" in only:
+        gen_nano_vit(ns)
     if not only or "knn" in only:
         gen_knn(ns)
     if not only or "variants" in only:

@@ -708,3 +708,39 @@ def pad_crop_tokens(src, nB, Hs, Ws, Hd, Wd):
     h, w = min(Hs, Hd), min(Ws, Wd)
     out[:, :h, :w] = src.view(nB, Hs, Ws, Cc)[:, :h, :w]
     return out.view(nB * Hd * Wd, Cc)
+
+
+# ------------------------------------------------------------------------------------------------
+# global attention of the monolithic ViT backbones (models/vision_transformer.py:67-94), unfused as the product runs it:
+# S and P are materialised in the activation dtype, the softmax itself is fp32
+# ------------------------------------------------------------------------------------------------
+def vit_pad_tokens(N):
+    return -(-N // 16) * 16
+
+
+def _vit_heads(qkv, B, N, nH, parts):
+    C = qkv.shape[1] // parts
+    return qkv.view(B, N, parts, nH, C // nH).permute(2, 0, 3, 1, 4).float()  # [parts, B, nH, N, hd]
+
+
+def vit_attn_fwd(qkv, B, N, nH, scale):
+    dt = qkv.dtype
+    q, k, v = _vit_heads(qkv, B, N, nH, 3)
+    s = _r(q @ k.transpose(-2, -1), dt).float()
+    p = _r(torch.softmax(scale * s, dim=-1), dt).float()
+    o = _r(p @ v, dt)
+    C = qkv.shape[1] // 3
+    return o.transpose(1, 2).reshape(B * N, C).contiguous(), (q, k, v, p)
+
+
+def vit_attn_bwd(dout, saved, B, N, nH, scale):
+    q, k, v, p = saved
+    dt = dout.dtype
+    do = _vit_heads(dout, B, N, nH, 1)[0]
+    dv = _r(p.transpose(-2, -1) @ do, dt)
+    dp = _r(do @ v.transpose(-2, -1), dt).float()
+    ds = _r(scale * p * (dp - (p * dp).sum(-1, keepdim=True)), dt).float()
+    dq = _r(ds @ k, dt)
+    dk = _r(ds.transpose(-2, -1) @ q, dt)
+    C = dout.shape[1]
+    return torch.stack([dq, dk, dv], 0).permute(1, 3, 0, 2, 4).reshape(B * N, 3 * C).to(dt).contiguous()

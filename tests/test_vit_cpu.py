@@ -1,0 +1,116 @@
+"""Monolithic ViT backbones (models/vision_transformer.py, the reference's default --arch), CPU side: module tree,
+state_dict layout and the autograd glue (VitPatchEmbedFn / VitBlockFn / ApeAddFn / FinalNormFn) on the torch restatement of every
+kernel, against tests/golden/nano_vit_step.pt -- produced by the REFERENCE's own VisionTransformer + DINOHead + DDINOLoss
+(oracle/gen_golden.py vit)."""
+import os
+from functools import partial
+
+import pytest
+import torch
+
+from oracle import ops_ref
+from tests import golden_utils as GU
+from tests.test_composition_cpu import cpu_ops, probe_close  # noqa: F401  (fixture)
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def build_nano_vit():
+    from esvit_amd import models
+    from esvit_amd.models import vision_transformer as V
+    v = GU.NANO_VIT
+    m = V.VisionTransformer(img_size=[v["sizes"][0]], patch_size=v["patch"], embed_dim=v["embed_dim"], depth=v["depth"], num_heads=v["heads"],
+                            mlp_ratio=4, qkv_bias=True, norm_layer=partial(torch.nn.LayerNorm, eps=1e-6), drop_path_rate=0.0,
+                            use_dense_prediction=True)
+    hk = dict(hidden_dim=GU.NANO_HEAD["hidden_dim"], bottleneck_dim=GU.NANO_HEAD["bottleneck_dim"])
+    m.head = models.DINOHead(v["embed_dim"], GU.NANO_HEAD["out_dim"], norm_last_layer=True, **hk)
+    m.head_dense = models.DINOHead(v["embed_dim"], GU.NANO_HEAD["out_dim"], norm_last_layer=False, **hk)
+    return m
+
+
+def nano_vit_pair(dev="cpu"):
+    student, teacher = build_nano_vit(), build_nano_vit()
+    GU.fill_state_dict(student.state_dict(), 0)
+    GU.fill_state_dict(teacher.state_dict(), 7)
+    student.head.last_layer.weight_g.data.fill_(1)
+    for p in teacher.parameters():
+        p.requires_grad = False
+    return student.to(dev), teacher.to(dev)
+
+
+def run_nano_vit_step(student, teacher, loss_mod, dev="cpu"):
+    crops = [c.to(dev) for c in GU.make_crops(2, n_local=3, sizes=GU.NANO_VIT["sizes"])]
+    loss_fn = loss_mod.DDINOLoss(GU.NANO_HEAD["out_dim"], 5, 0.04, 0.07, 5, 10).to(dev)
+    t_out = teacher(crops[:2])
+    s_out = student(crops)
+    loss = loss_fn(s_out, t_out, 2, None)
+    loss.backward()
+    return s_out, t_out, loss
+
+
+def check_nano_vit(g, student, s_out, t_out, loss, rt, loss_tol, grad_tol):
+    assert list(s_out[3]) == g["npatch"][0] and list(t_out[3]) == g["npatch"][1]
+    for nm, t in (("s_cls", s_out[0]), ("s_reg", s_out[1]), ("s_fea", s_out[2]), ("t_cls", t_out[0]), ("t_reg", t_out[1]), ("t_fea", t_out[2])):
+        probe_close(nm, t.float().cpu(), g[nm], rtol=rt)
+    assert abs(loss.item() - g["ddino_loss"]) < loss_tol, (loss.item(), g["ddino_loss"])
+    got = {n: p.grad for n, p in student.named_parameters() if p.grad is not None}
+    assert sorted(got) == sorted(g["grad_norms"]) and [n for n, p in student.named_parameters() if p.grad is None] == g["no_grad"]
+    for n, ref in g["grad_norms"].items():
+        assert abs(got[n].norm().item() - ref) <= grad_tol * ref + 1e-9, (n, got[n].norm().item(), ref)
+    for n, ref in g["grads"].items():
+        probe_close("grad " + n, got[n].float().cpu(), ref, rtol=max(rt, grad_tol))
+
+
+def check_nano_vit_hooks(g, student, dev="cpu", rt=3e-4):
+    crops = [c.to(dev) for c in GU.make_crops(2, n_local=3, sizes=GU.NANO_VIT["sizes"])]
+    with torch.no_grad():
+        student.use_dense_prediction = False
+        probe_close("view-level forward", student(crops).float().cpu(), g["view_only"], rtol=rt)
+        student.use_dense_prediction = True
+        feats = student.forward_return_n_last_blocks(crops[2], n=2, return_patch_avgpool=True)
+        assert feats.shape == g["last_blocks"].shape and torch.allclose(feats.float().cpu(), g["last_blocks"], rtol=rt, atol=rt)
+        attn = student.forward_selfattention(crops[0])
+        assert attn.shape == g["last_attn"].shape and torch.allclose(attn.float().cpu(), g["last_attn"], rtol=rt, atol=1e-5)
+
+
+def test_vit_state_dict_layout_matches_golden(lib_built):
+    g = torch.load(os.path.join(GOLD, "nano_vit_step.pt"), weights_only=False)
+    student = build_nano_vit()
+    assert [(k, tuple(v.shape), str(v.dtype)) for k, v in student.state_dict().items()] == g["keys"]
+    assert [n for n, _ in student.named_parameters()] == g["param_names"]
+    from esvit_amd.models import vision_transformer as V
+    for fn, (dim, heads, params) in {"deit_tiny": (192, 3, 5524416), "deit_small": (384, 6, 21665664), "vit_base": (768, 12, 85798656)}.items():
+        m = getattr(V, fn)(patch_size=16, drop_path_rate=0.1, use_dense_prediction=True)   # main_esvit.py:306-310
+        assert m.embed_dim == dim and m.blocks[0].attn.num_heads == heads and sum(p.numel() for p in m.parameters()) == params
+        assert m.pos_embed.shape == (1, 197, dim) and m.blocks[-1].drop_path.drop_prob == pytest.approx(0.1)
+
+
+def test_vit_composition_matches_reference_golden(cpu_ops):  # noqa: F811
+    import esvit_amd.loss as L
+    g = torch.load(os.path.join(GOLD, "nano_vit_step.pt"), weights_only=False)
+    student, teacher = nano_vit_pair()
+    s_out, t_out, loss = run_nano_vit_step(student, teacher, L)
+    check_nano_vit(g, student, s_out, t_out, loss, rt=3e-4, loss_tol=2e-5, grad_tol=2e-3)
+
+
+def test_vit_hooks_match_reference_golden(cpu_ops):  # noqa: F811
+    g = torch.load(os.path.join(GOLD, "nano_vit_step.pt"), weights_only=False)
+    student, _ = nano_vit_pair()
+    check_nano_vit_hooks(g, student)
+
+
+def test_vit_attention_restatement_matches_autograd():
+    """oracle/ops_ref.vit_attn_fwd / _bwd (what the GPU kernels are compared with) against torch autograd of Attention.forward"""
+    ops_ref.set_act_dtype(torch.float32)
+    torch.manual_seed(0)
+    B, N, nH, hd = 2, 37, 3, 16
+    C = nH * hd
+    qkv = torch.randn(B * N, 3 * C, requires_grad=True)
+    x = qkv.view(B, N, 3, nH, hd).permute(2, 0, 3, 1, 4)
+    a = ((x[0] @ x[1].transpose(-2, -1)) * hd ** -0.5).softmax(-1)
+    y = (a @ x[2]).transpose(1, 2).reshape(B * N, C)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    o, saved = ops_ref.vit_attn_fwd(qkv.detach(), B, N, nH, hd ** -0.5)
+    d = ops_ref.vit_attn_bwd(gy, saved, B, N, nH, hd ** -0.5)
+    assert torch.allclose(o, y, atol=1e-6) and torch.allclose(d, qkv.grad, atol=1e-6)

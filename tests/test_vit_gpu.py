@@ -1,0 +1,145 @@
+"""Monolithic ViT backbones on the MI355X: the layout / softmax kernels of csrc/vit_attn.hip and the batched GEMMs around them
+against the torch restatement (oracle/ops_ref.py), then the whole step -- forward, DDINOLoss, every gradient -- and the evaluation
+hooks against the golden produced by the REFERENCE's VisionTransformer (tests/golden/nano_vit_step.pt).
+Tolerances: fp32 mode 5e-4 relative on outputs / 3e-3 on gradient norms (tf32-free fp32 MFMA, different summation order);
+bf16 mode 2e-2 on the loss and 20 % on gradient norms (the bound the Swin / CvT step tests use)."""
+import math
+import os
+
+import pytest
+import torch
+
+from oracle import ops_ref
+from tests.test_step_gpu import _setup, _teardown
+from tests.test_vit_cpu import check_nano_vit, check_nano_vit_hooks, nano_vit_pair, run_nano_vit_step
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _close(name, got, ref, tol):
+    got, ref = got.float().cpu(), ref.float().cpu()
+    assert got.shape == ref.shape, (name, got.shape, ref.shape)
+    scale = ref.abs().max().item() + 1e-12
+    err = (got - ref).abs().max().item()
+    assert math.isfinite(err), "%s: non-finite output" % name
+    assert err <= tol * scale, "%s: max err %.3e vs scale %.3e (rel %.3e > tol %.1e)" % (name, err, scale, err / scale, tol)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(2, 37, 3, 64), (3, 197, 6, 64), (3, 17, 2, 32), (1, 5, 12, 64), (2, 256, 1, 32)])
+def test_heads_split_merge_and_softmax(dt, shape, lib_built):
+    from esvit_amd import ops
+    B, N, nH, hd = shape
+    C = nH * hd
+    Np = ops.vit_pad_tokens(N)
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(B * N, 3 * C, generator=g).to(dt).cuda()
+    y = ops.heads_split(x, B, N, nH, 3)
+    want = torch.zeros(3, B, nH, Np, hd, dtype=dt, device="cuda")
+    want[:, :, :, :N] = x.view(B, N, 3, nH, hd).permute(2, 0, 3, 1, 4)
+    assert torch.equal(y, want)
+    assert torch.equal(ops.heads_merge(y, N), x)                                       # the exact inverse on the live rows
+    one = ops.heads_split(x[:, :C].contiguous(), B, N, nH, 1)
+    assert torch.equal(one[0, :, :, :N], x[:, :C].reshape(B, N, nH, hd).permute(0, 2, 1, 3))
+    # softmax rows, in place; pad rows / columns come out zero whatever they held
+    Z, scale = B * nH, hd ** -0.5
+    s = (4 * torch.randn(Z, Np, Np, generator=g)).to(dt).cuda()
+    ref = torch.zeros(Z, Np, Np)
+    ref[:, :N, :N] = torch.softmax(scale * s[:, :N, :N].float().cpu(), dim=-1)
+    p = s.clone()
+    ops.check(ops.lib.esvit_softmax_rows_fwd(ops._code(dt), ops._p(p), Z, N, Np, scale, ops._stream()), "softmax_rows_fwd")
+    _close("softmax", p, ref, 1e-6 if dt == torch.float32 else 8e-3)
+    assert (p[:, N:] == 0).all() and (p[:, :, N:] == 0).all()
+    dp = torch.randn(Z, Np, Np, generator=g).to(dt).cuda()
+    pr = p.float().cpu()
+    dref = scale * pr * (dp.float().cpu() - (pr[:, :, :N] * dp.float().cpu()[:, :, :N]).sum(-1, keepdim=True))
+    dref[:, N:], dref[:, :, N:] = 0, 0
+    ops.check(ops.lib.esvit_softmax_rows_bwd(ops._code(dt), ops._p(p), ops._p(dp), Z, N, Np, scale, ops._stream()), "softmax_rows_bwd")
+    _close("softmax backward", dp, dref, 1e-5 if dt == torch.float32 else 1.5e-2)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(2, 37, 3, 64), (4, 197, 6, 64), (3, 17, 2, 32), (2, 197, 12, 64)])
+def test_vit_attention_matches_restatement(dt, shape, lib_built):
+    """Attention.forward between the two projections, and its gradient: batched esvit_gemm + softmax vs oracle/ops_ref"""
+    from esvit_amd import ops
+    B, N, nH, hd = shape
+    C = nH * hd
+    g = torch.Generator().manual_seed(7 + sum(shape))
+    qkv = torch.randn(B * N, 3 * C, generator=g).to(dt)
+    dout = torch.randn(B * N, C, generator=g).to(dt)
+    ops_ref.set_act_dtype(dt)
+    try:
+        o_ref, saved = ops_ref.vit_attn_fwd(qkv, B, N, nH, hd ** -0.5)
+        d_ref = ops_ref.vit_attn_bwd(dout, saved, B, N, nH, hd ** -0.5)
+    finally:
+        ops_ref.set_act_dtype(torch.float32)
+    o, att = ops.vit_attn_fwd(qkv.cuda(), B, N, nH, hd ** -0.5)
+    d = ops.vit_attn_bwd(dout.cuda(), att, B, N, nH, hd ** -0.5)
+    tol = 2e-5 if dt == torch.float32 else 2e-2
+    _close("attention output", o, o_ref, tol)
+    _close("attention probabilities", att[1].view(B, nH, att[1].shape[-2], -1)[:, :, :N, :N], saved[3], tol)
+    _close("d qkv", d, d_ref, tol * 2)
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_nano_vit_step_matches_reference_golden(prec, lib_built):
+    import esvit_amd.loss as L
+    g = torch.load(os.path.join(GOLD, "nano_vit_step.pt"), weights_only=False)
+    dev = _setup(prec)
+    try:
+        student, teacher = nano_vit_pair(dev)
+        s_out, t_out, loss = run_nano_vit_step(student, teacher, L, dev=dev)
+        if prec == "fp32":
+            check_nano_vit(g, student, s_out, t_out, loss, rt=5e-4, loss_tol=1e-4, grad_tol=3e-3)
+        else:
+            assert abs(loss.item() - g["ddino_loss"]) < 2e-2, (loss.item(), g["ddino_loss"])
+            got = {n: p.grad for n, p in student.named_parameters() if p.grad is not None}
+            assert sorted(got) == sorted(g["grad_norms"])
+            for n, ref in g["grad_norms"].items():
+                assert abs(got[n].norm().item() - ref) <= 0.2 * ref + 1e-6, (n, got[n].norm().item(), ref)
+    finally:
+        _teardown()
+
+
+def test_nano_vit_hooks_match_reference_golden(lib_built):
+    g = torch.load(os.path.join(GOLD, "nano_vit_step.pt"), weights_only=False)
+    dev = _setup("fp32")
+    try:
+        student, _ = nano_vit_pair(dev)
+        check_nano_vit_hooks(g, student, dev=dev, rt=5e-4)
+    finally:
+        _teardown()
+
+
+def test_deit_small_step_runs_through_the_trainer(lib_built):
+    """deit_small at full width (197 / 37 tokens, 6 heads of 64) through EsvitTrainer: finite loss near log(K), parameters move,
+    the teacher follows by EMA"""
+    import esvit_amd
+    from esvit_amd.engine import EsvitTrainer
+    from esvit_amd.models import vision_transformer as V
+    from tests import golden_utils as GU
+    dev = _setup("bf16")
+    try:
+        torch.manual_seed(0)
+        K = 4096
+
+        def make(dp):
+            m = V.deit_small(patch_size=16, drop_path_rate=dp, use_dense_prediction=True)
+            m.head, m.head_dense = esvit_amd.DINOHead(384, K), esvit_amd.DINOHead(384, K)
+            return m.to(dev)
+        student, teacher = make(0.1), make(0.0)
+        teacher.load_state_dict(student.state_dict())
+        for p in teacher.parameters():
+            p.requires_grad = False
+        trainer = EsvitTrainer(student, teacher, esvit_amd.DDINOLoss(K, 10, 0.04, 0.04, 0, 10).to(dev), clip_grad=3.0, freeze_last_layer=1)
+        crops = [c.to(dev) for c in GU.make_crops(4)]
+        w0 = student.blocks[5].attn.qkv.weight.detach().clone()
+        t0 = teacher.blocks[5].attn.qkv.weight.detach().clone()
+        losses = [trainer.step(crops, 5e-4, 0.04, 0.99, epoch=1).item() for _ in range(3)]
+        assert all(math.isfinite(v) for v in losses) and abs(losses[0] - math.log(K)) < 1.0, losses  # 0.5 * (view + region), each ~ log K
+        assert (student.blocks[5].attn.qkv.weight - w0).abs().max().item() > 0
+        assert (teacher.blocks[5].attn.qkv.weight - t0).abs().max().item() > 0
+    finally:
+        _teardown()
