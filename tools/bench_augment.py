@@ -22,6 +22,8 @@ def main():
     ap.add_argument("--batch", type=int, default=128)
     ap.add_argument("--iters", type=int, default=50)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--cpu-images", type=int, default=64, help="images of the batch the Pillow baseline renders")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="the Pillow baseline repeats its sample for about this long")
     args = ap.parse_args()
     from esvit_amd import data as D, ops
     rng = np.random.default_rng(args.seed)
@@ -58,7 +60,33 @@ def main():
     crops = aug(packed)  # end to end once more: draw + upload + render
     torch.cuda.synchronize()
     e2e_ms = (time.perf_counter() - t0) * 1e3
-    print(json.dumps({"metric": "images/s through the GPU crop producer (2x224^2 + 8x96^2 crops per image)", "value": B / ms * 1e3, "unit": "images/s",
+    # cpu_baseline: the reference's own engine -- Pillow, one crop at a time as DataAugmentationDINO.__call__ runs it in a
+    # DataLoader worker (datasets/build.py:252-261) -- for the SAME draws on a bounded sample of the batch, one host thread
+    cpu = None
+    try:
+        from oracle import augment_ref as A
+        from oracle.gen_augment_golden import pil_crop
+        host = [im.cpu().numpy() for im in images[:args.cpu_images]]
+        jobs = []
+        for S, (rows, _, _) in draws.items():
+            for r in rows:
+                if r[0] < len(host):
+                    p = A.row_to_params(r, S)
+                    if p["blur"]:  # Pillow takes a Gaussian radius: one with the same box size (the same cost; timing only)
+                        p["blur_radius"] = {0: 0.7, 1: 1.8}.get(p["blur_box"][0], 2.6)
+                    jobs.append((int(r[0]), p))
+        t0, passes = time.perf_counter(), 0
+        while host and time.perf_counter() - t0 < args.cpu_seconds:  # a bounded sample: ~10 s of Pillow work
+            for src, p in jobs:
+                A.to_tensor_normalize(pil_crop(host[src], p))
+            passes += 1
+        dt = max(time.perf_counter() - t0, 1e-9)
+        cpu = None if not host else {"value": passes * len(host) / dt, "unit": "images/s", "cores": 1, "kind": "reference",
+               "sample": "Pillow %s (the arithmetic the reference runs), %d images x 10 crops x %d passes, same draws, one thread, %.1f s" % (
+                   __import__("PIL").__version__, len(host), passes, dt)}
+    except ImportError as e:  # pragma: no cover
+        cpu = {"value": None, "note": "Pillow not importable: %s" % e}
+    print(json.dumps({"cpu_baseline": cpu, "metric": "images/s through the GPU crop producer (2x224^2 + 8x96^2 crops per image)", "value": B / ms * 1e3, "unit": "images/s",
                       "batch": B, "ms_per_batch": ms, "host_draw_ms": draw_ms, "end_to_end_ms": e2e_ms, "crops": len(crops),
                       "roofline": {"bound": "hbm", "achieved": (box_bytes + out_bytes) / ms / 1e6, "peak": 8000.0, "unit": "GB/s",
                                    "frac": (box_bytes + out_bytes) / ms / 1e6 / 8000.0, "box_bytes": box_bytes, "out_bytes": out_bytes}}))
