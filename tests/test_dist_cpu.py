@@ -110,6 +110,53 @@ def _nano_step_pergroup_worker(rank, world, port, out):
     _nano_step_worker(rank, world, port, out, ragged=False)
 
 
+def _nano_vit_step_worker(rank, world, port, out):
+    """the monolithic ViT on two ranks: one backbone pass per resolution group (vision_transformer.py:186-233), i.e. two gradient
+    contributions per parameter -- the reducer's non-overlapped mode; averaged gradients == mean of the per-rank gradients"""
+    _init(rank, world, port)
+    import esvit_amd.functional as Fn
+    import esvit_amd.loss as L
+    import esvit_amd.params as P
+    from esvit_amd.engine import GradBucketReducer
+    from oracle import ops_ref
+    from tests import golden_utils as GU
+    from tests.test_vit_cpu import nano_vit_pair
+    for mod in (Fn, L, P):
+        mod.ops = ops_ref
+    ops_ref.set_act_dtype(torch.float32)
+    K = GU.NANO_HEAD["out_dim"]
+
+    def grads(student, teacher, r, reducer):
+        crops = GU.make_crops(1, n_local=3, sizes=GU.NANO_VIT["sizes"], seed=400 + r)
+        loss_fn = L.DDINOLoss(K, 5, 0.04, 0.04, 0, 1)
+        loss_fn._reduce_and_apply = lambda buf, apply: None
+        for p in student.parameters():
+            p.grad = None
+        with torch.no_grad():
+            t_out = teacher(crops[:2])
+        loss = loss_fn(student(crops), t_out, 0, None)
+        if reducer is not None:
+            reducer.begin()
+        loss.backward()
+        if reducer is not None:
+            reducer.finish()
+        return {n: p.grad.detach().clone() for n, p in student.named_parameters() if p.grad is not None}
+
+    student, teacher = nano_vit_pair()
+    red = GradBucketReducer(student, bucket_mb=0.1, overlap=bool(getattr(student, "ragged_multi_crop", False)))  # as EsvitTrainer arms it
+    assert red.enabled and not red.overlap and len(red.buckets) >= 2
+    got = grads(student, teacher, rank, red)
+    red.close()
+    ref_student, ref_teacher = nano_vit_pair()
+    acc = None
+    for r in range(world):
+        g = grads(ref_student, ref_teacher, r, None)
+        acc = g if acc is None else {n: acc[n] + g[n] for n in g}
+    ok = set(got) == set(acc) and all(torch.allclose(got[n], acc[n] / world, rtol=2e-4, atol=1e-7) for n in got)
+    out[rank] = bool(ok)
+    dist.destroy_process_group()
+
+
 def _center_worker(rank, world, port, out):
     _init(rank, world, port)
     import esvit_amd.loss as L
@@ -199,7 +246,7 @@ def _extract_worker(rank, world, port, out):
 
 
 @pytest.mark.parametrize("worker,port", [(_reducer_worker, 29611), (_center_worker, 29612), (_syncbn_worker, 29613), (_extract_worker, 29614),
-                                         (_nano_step_worker, 29615), (_nano_step_pergroup_worker, 29616)])
+                                         (_nano_step_worker, 29615), (_nano_step_pergroup_worker, 29616), (_nano_vit_step_worker, 29617)])
 def test_world2_gloo(worker, port, lib_built):
     world = 2
     out = mp.Manager().dict()
