@@ -99,48 +99,57 @@ __global__ __launch_bounds__(NT) void dino_ce_kernel(const T* __restrict__ s, co
     const float w = row_w[r];
     const int nterms = (t0 >= 0) + (t1 >= 0);
 
-    // pass 1: log-sum-exp of z = s * inv_st
+    // The kernel is bound by VALU issue (four exponentials per logit at quarter rate), so every exponential is ONE fused
+    // multiply-add feeding v_exp_f32 (base 2): exp(x * inv_st - m) = exp2(x * A - m * A), A = inv_st * log2(e), and the constants of
+    // the teacher terms are folded per column / per row.
+    constexpr float LOG2E = 1.4426950408889634f;
+    const float A = inv_st * LOG2E;
+
+    // pass 1: log-sum-exp of z = s * inv_st (the maximum is taken on the raw logits: inv_st > 0)
     MS a{-3.0e38f, 0.f};
     for (int k = threadIdx.x * V; k < K; k += NT * V) {
         const Vec16<T> x = ld16<T>(srow + k);
-        float mx = -3.0e38f;
+        float mr = -3.0e38f;
 #pragma unroll
-        for (int e = 0; e < V; ++e) mx = fmaxf(mx, x.get(e) * inv_st);
+        for (int e = 0; e < V; ++e) mr = fmaxf(mr, x.get(e));
+        const float nb = -mr * A;
         float sum = 0.f;
 #pragma unroll
-        for (int e = 0; e < V; ++e) sum += __expf(x.get(e) * inv_st - mx);
-        a = ms_merge(a, MS{mx, sum});
+        for (int e = 0; e < V; ++e) sum += __builtin_amdgcn_exp2f(fmaf(x.get(e), A, nb));
+        a = ms_merge(a, MS{mr * inv_st, sum});
     }
     a = block_ms(a, sm);
     const float lse = a.m + __logf(a.s);
 
-    // pass 2: gradient + sum_k p_t[k] z[k]
+    // pass 2: gradient + sum_k p_t[k] z[k].  An unused term gets offset +inf: exp2(-inf) = 0, no select per element.
     const T* trow0 = t + (long)(t0 >= 0 ? t0 : 0) * K;
     const T* trow1 = t + (long)(t1 >= 0 ? t1 : 0) * K;
-    const float off0 = t0 >= 0 ? t_row_max[t0] + t_row_lse[t0] : 0.f;
-    const float off1 = t1 >= 0 ? t_row_max[t1] + t_row_lse[t1] : 0.f;
-    const float gscale = w * inv_st;
-    float dot = 0.f;
+    const float At = inv_tt * LOG2E;
+    const float off0 = t0 >= 0 ? (t_row_max[t0] + t_row_lse[t0]) * LOG2E : INFINITY;
+    const float off1 = t1 >= 0 ? (t_row_max[t1] + t_row_lse[t1]) * LOG2E : INFINITY;
+    const float C = -lse * LOG2E;
+    const float gs = w * inv_st, gsn = gs * nterms;
+    float dot = 0.f;  // sum_k p_t[k] * s[k] (raw logits; scaled by inv_st once at the end)
     for (int k = threadIdx.x * V; k < K; k += NT * V) {
         const Vec16<T> x = ld16<T>(srow + k);
-        Vec16<T> y0 = zero16<T>(), y1 = zero16<T>();
-        if (t0 >= 0) y0 = ld16<T>(trow0 + k);
-        if (t1 >= 0) y1 = ld16<T>(trow1 + k);
+        const Vec16<T> y0 = ld16<T>(trow0 + k), y1 = ld16<T>(trow1 + k);
+        f32x4 cv[V / 4];
+#pragma unroll
+        for (int q = 0; q < V / 4; ++q) cv[q] = *reinterpret_cast<const f32x4*>(center + k + 4 * q);
         Vec16<T> o;
 #pragma unroll
         for (int e = 0; e < V; ++e) {
-            const float z = x.get(e) * inv_st;
-            const float ps = __expf(z - lse);
-            const float ck = center[k + e];
-            float pt = 0.f;
-            if (t0 >= 0) pt += __expf((y0.get(e) - ck) * inv_tt - off0);
-            if (t1 >= 0) pt += __expf((y1.get(e) - ck) * inv_tt - off1);
-            dot += pt * z;
-            o.set(e, gscale * (nterms * ps - pt));
+            const float xe = x.get(e);
+            const float ps = __builtin_amdgcn_exp2f(fmaf(xe, A, C));
+            const float ck = cv[e / 4][e & 3];
+            const float nbk = -ck * At;  // (y - c) * inv_tt * log2(e) = y * At + nbk
+            const float pt = __builtin_amdgcn_exp2f(fmaf(y0.get(e), At, nbk - off0)) + __builtin_amdgcn_exp2f(fmaf(y1.get(e), At, nbk - off1));
+            dot = fmaf(pt, xe, dot);
+            o.set(e, fmaf(ps, gsn, -gs * pt));
         }
         st16<T>(drow + k, o);
     }
-    dot = block_sum<NT>(dot, sm2);
+    dot = block_sum<NT>(dot, sm2) * inv_st;
     if (threadIdx.x == 0) row_loss[r] = w * (nterms * lse - dot);
 }
 
