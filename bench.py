@@ -325,15 +325,32 @@ def main():
                                   for h, w in zip(rs.integers(300, 520, B), rs.integers(300, 520, B))])
         producer = D.DataAugmentationDINO((0.4, 1.0), (0.05, 0.4), (8,), (96,), seed=7 + rank)
         # the random draws need the image sizes only: a DataLoader worker makes them (DataAugmentationDINO.collate); here one
-        # background thread draws the next step's rows while this step is being launched
+        # background thread draws the next step's rows.  As data.GpuAugmentedLoader does, the crops of step n + 1 are rendered on a
+        # second HIP stream while step n runs; the step's stream only waits for an event.
         from concurrent.futures import ThreadPoolExecutor
         pool = ThreadPoolExecutor(1)
-        pending = [pool.submit(producer.draw, decoded)]
+        aug_stream = torch.cuda.Stream()
+        state = {"draws": pool.submit(producer.draw, decoded)}
+
+        def render():
+            draws = state["draws"].result()
+            state["draws"] = pool.submit(producer.draw, decoded)
+            aug_stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(aug_stream):
+                out = producer(decoded, draws=draws)
+                ev = torch.cuda.Event()
+                ev.record(aug_stream)
+            return out, ev
+        state["ready"] = render()
 
         def next_crops():
-            draws = pending[0].result()
-            pending[0] = pool.submit(producer.draw, decoded)
-            return producer(decoded, draws=draws)
+            out, ev = state["ready"]
+            state["ready"] = render()
+            main = torch.cuda.current_stream()
+            main.wait_event(ev)
+            for c in out:
+                c.record_stream(main)
+            return out
     for _ in range(args.warmup):
         trainer.step(next_crops(), lr, wd, mom, epoch)
     sync()

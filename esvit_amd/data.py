@@ -217,17 +217,49 @@ class DataAugmentationDINO:
 class GpuAugmentedLoader:
     """wraps a DataLoader whose dataset only DECODES (``collate_fn=augment.collate``: the workers also make the random draws; or any
     collate that yields ``(list of uint8 HWC images, labels)``) into the iterator ``train_one_epoch`` expects (main_esvit.py:522):
-    ``(crops, labels)`` with the crops produced on the GPU"""
+    ``(crops, labels)`` with the crops produced on the GPU.  With ``prefetch`` (default) batch n + 1 is uploaded and rendered on a
+    second HIP stream while the training step of batch n runs (the producer's kernels are VALU-bound byte arithmetic, the step's are
+    memory / MFMA work: they share the chip well), and the consumer's stream only waits for an event."""
 
-    def __init__(self, loader, augment):
-        self.loader, self.augment = loader, augment
+    def __init__(self, loader, augment, prefetch=True):
+        self.loader, self.augment, self.prefetch = loader, augment, prefetch
+        self._stream = None
 
     def __len__(self):
         return len(self.loader)
 
+    def _render(self, item):
+        images, labels = item
+        if isinstance(images, tuple) and len(images) == 2 and isinstance(images[1], dict):  # DataAugmentationDINO.collate
+            return self.augment(images[0], draws=images[1]), labels
+        return self.augment(images), labels
+
     def __iter__(self):
-        for images, labels in self.loader:
-            if isinstance(images, tuple) and len(images) == 2 and isinstance(images[1], dict):  # DataAugmentationDINO.collate
-                yield self.augment(images[0], draws=images[1]), labels
-            else:
-                yield self.augment(images), labels
+        if not self.prefetch:
+            for item in self.loader:
+                yield self._render(item)
+            return
+        if self._stream is None:
+            self._stream = torch.cuda.Stream()
+        it = iter(self.loader)
+
+        def produce():
+            try:
+                item = next(it)
+            except StopIteration:
+                return None
+            self._stream.wait_stream(torch.cuda.current_stream())  # (a scratch freed by the consumer is not reused too early)
+            with torch.cuda.stream(self._stream):
+                crops, labels = self._render(item)
+                ev = torch.cuda.Event()
+                ev.record(self._stream)
+            return crops, labels, ev
+        nxt = produce()
+        while nxt is not None:
+            crops, labels, ev = nxt
+            nxt = produce()  # enqueued BEFORE the consumer's step: it runs beside it
+            main = torch.cuda.current_stream()
+            main.wait_event(ev)
+            for c in crops:
+                c.record_stream(main)
+            yield crops, labels

@@ -148,3 +148,29 @@ def test_rejects_host_tensors(lib_built):
     from esvit_amd import ops
     with pytest.raises((AssertionError, RuntimeError)):
         ops.aug_crops(torch.zeros(12, dtype=torch.uint8), torch.zeros((1, 3), dtype=torch.int64), torch.zeros((1, 24), dtype=torch.int32), 96, 2, 2)
+
+
+def test_prefetching_loader_equals_inline_rendering(lib_built):
+    """GpuAugmentedLoader renders batch n + 1 on its own stream while batch n is consumed: same crops as rendering inline"""
+    from esvit_amd import data as D
+    rng = np.random.default_rng(21)
+    batches = []
+    for _ in range(4):
+        imgs = [torch.from_numpy(rng.integers(0, 256, (int(h), int(w), 3), dtype=np.uint8)) for h, w in zip(rng.integers(60, 200, 5), rng.integers(60, 200, 5))]
+        batches.append((imgs, torch.arange(5)))
+
+    def run(prefetch):
+        aug = D.DataAugmentationDINO((0.4, 1.0), (0.05, 0.4), (8,), (96,), seed=9)
+        out = []
+        for crops, labels in D.GpuAugmentedLoader(batches, aug, prefetch=prefetch):
+            acc = torch.zeros((), device="cuda")
+            for c in crops:                       # consume on the current stream, as a training step would
+                acc = acc + c.double().sum()
+            out.append(([c.clone() for c in crops], labels, acc))
+        torch.cuda.synchronize()
+        return out
+    a, b = run(True), run(False)
+    assert len(a) == len(b) == 4
+    for (ca, la, sa), (cb, lb, sb) in zip(a, b):
+        assert torch.equal(la, lb) and float(sa) == float(sb)
+        assert all(torch.equal(x, y) for x, y in zip(ca, cb))
