@@ -111,109 +111,107 @@ class VisionTransformer(nn.Module):
         self.apply(self._init_weights)
 
     def _init_weights(self, m):
+        """vision_transformer.py:177-184: truncated-normal Linear weights, zero biases, unit LayerNorm"""
+        if isinstance(m, (nn.Linear, nn.LayerNorm)) and m.bias is not None:
+            nn.init.zeros_(m.bias)
         if isinstance(m, nn.Linear):
             _trunc_normal_(m.weight, std=.02)
-            if m.bias is not None:
-                nn.init.constant_(m.bias, 0)
         elif isinstance(m, nn.LayerNorm):
-            nn.init.constant_(m.bias, 0)
-            nn.init.constant_(m.weight, 1.0)
+            nn.init.ones_(m.weight)
 
     # ---- tokens ------------------------------------------------------------------------------------------------------
     def interpolate_pos_encoding(self, x, pos_embed):
-        """vision_transformer.py:263-277 (the same torch call, so the same rounding of the output size)"""
-        npatch = x.shape[1] - 1
-        N = pos_embed.shape[1] - 1
-        if npatch == N:
+        """vision_transformer.py:263-277.  The patch grid of the position embedding is resampled to the crop's grid with the
+        reference's own call -- F.interpolate(scale_factor=sqrt(npatch / N), mode="bicubic") -- so the output size rounds the same
+        way; the class-token entry is passed through."""
+        n_new, n_old = x.shape[1] - 1, pos_embed.shape[1] - 1
+        if n_new == n_old:
             return pos_embed
-        class_emb = pos_embed[:, 0]
-        pos_embed = pos_embed[:, 1:]
-        dim = x.shape[-1]
-        pos_embed = nn.functional.interpolate(
-            pos_embed.reshape(1, int(math.sqrt(N)), int(math.sqrt(N)), dim).permute(0, 3, 1, 2),
-            scale_factor=math.sqrt(npatch / N), mode='bicubic')
-        pos_embed = pos_embed.permute(0, 2, 3, 1).view(1, -1, dim)
-        return torch.cat((class_emb.unsqueeze(0), pos_embed), dim=1)
+        side, dim = int(math.sqrt(n_old)), x.shape[-1]
+        grid = pos_embed[:, 1:].reshape(1, side, side, dim).permute(0, 3, 1, 2)
+        grid = nn.functional.interpolate(grid, scale_factor=math.sqrt(n_new / n_old), mode='bicubic')
+        return torch.cat((pos_embed[:, :1], grid.permute(0, 2, 3, 1).reshape(1, -1, dim)), dim=1)
 
     def _tokens(self, x):
-        B = x.shape[0]
-        x = self.patch_embed(x)
-        x = torch.cat((self.cls_token.expand(B, -1, -1), x), dim=1)
+        """patches -> [class token | patch tokens] + position embedding (vision_transformer.py:236-243)"""
+        patches = self.patch_embed(x)
+        x = torch.cat((self.cls_token.expand(patches.shape[0], -1, -1), patches), dim=1)
         return Fn.ApeAddFn.apply(x, self.interpolate_pos_encoding(x, self.pos_embed).contiguous())
+
+    def _normed(self, x):
+        return Fn.FinalNormFn.apply(x, self.norm.weight, self.norm.bias)
 
     def forward_feature_maps(self, x):
         x = self._tokens(x)
         for blk in self.blocks:
             x = blk(x)
-        return Fn.FinalNormFn.apply(x, self.norm.weight, self.norm.bias)
+        return self._normed(x)
 
     def forward_features(self, x):
         x = self.forward_feature_maps(x)
-        if self.use_dense_prediction:
-            return x[:, 0], x[:, 1:]
-        return x[:, 0]
+        return (x[:, 0], x[:, 1:]) if self.use_dense_prediction else x[:, 0]
 
-    # ---- multi-crop forward (vision_transformer.py:186-233): one pass per run of equal resolutions ---------------------
+    # ---- multi-crop forward (vision_transformer.py:186-233): one backbone pass per run of crops of equal resolution ------
     def forward(self, x):
-        if not isinstance(x, list):
-            x = [x]
-        idx_crops = torch.cumsum(torch.unique_consecutive(torch.tensor([inp.shape[-1] for inp in x]), return_counts=True)[1], 0)
-        start_idx = 0
-        if self.use_dense_prediction:
-            cls, fea, npatch = [], [], []
-            for end_idx in idx_crops:
-                _out_cls, _out_fea = self.forward_features(torch.cat(x[start_idx:end_idx]))
-                B, N, C = _out_fea.shape
-                cls.append(_out_cls)
-                fea.append(_out_fea.reshape(B * N, C))
-                npatch.append(N)
-                start_idx = end_idx
-            output_cls, output_fea = torch.cat(cls), torch.cat(fea)
-            return self.head(output_cls), self.head_dense(output_fea), output_fea, npatch
-        outs = []
-        for end_idx in idx_crops:
-            outs.append(self.forward_features(torch.cat(x[start_idx:end_idx])))
-            start_idx = end_idx
-        return self.head(torch.cat(outs))
+        crops = x if isinstance(x, list) else [x]
+        runs, start = [], 0
+        for i in range(1, len(crops) + 1):
+            if i == len(crops) or crops[i].shape[-1] != crops[start].shape[-1]:
+                runs.append(torch.cat(crops[start:i]))
+                start = i
+        if not self.use_dense_prediction:
+            return self.head(torch.cat([self.forward_features(r) for r in runs]))
+        cls, fea, npatch = [], [], []
+        for r in runs:
+            c, f = self.forward_features(r)
+            cls.append(c)
+            fea.append(f.reshape(-1, f.shape[-1]))
+            npatch.append(f.shape[1])
+        feats = torch.cat(fea)
+        return self.head(torch.cat(cls)), self.head_dense(feats), feats, npatch
 
     # ---- evaluation hooks (vision_transformer.py:279-362) ---------------------------------------------------------------
     def forward_selfattention(self, x, n=1):
-        x = self._tokens(x)  # (images whose sides are multiples of the patch size: the reference's padding branch is not needed)
-        if n == 1:
-            for i, blk in enumerate(self.blocks):
-                if i < len(self.blocks) - 1:
-                    x = blk(x)
-                else:
-                    return blk(x, return_attention=True)
-        attn_out = []
-        for blk in self.blocks:
-            x, attn = blk.forward_fea_and_attn(x)
-            attn_out.append(attn)
-        return attn_out
+        """attention probabilities of the last block (n = 1) or of every block; images whose sides are multiples of the patch
+        size (the reference's zero-padding branch for other sizes is not needed by its own callers)"""
+        x = self._tokens(x)
+        maps = []
+        for i, blk in enumerate(self.blocks):
+            last = i == len(self.blocks) - 1
+            if n != 1 or last:
+                maps.append(blk(x, return_attention=True))
+            if not last:
+                x = blk(x)
+        return maps[0] if n == 1 else maps
 
     def forward_return_n_last_blocks(self, x, n=1, return_patch_avgpool=False, depths=[]):
+        """eval_linear.py:256,292: class tokens of the n last blocks (each through the final norm), optionally followed by the mean
+        patch token of the last block"""
         x = self._tokens(x)
-        output = []
+        first = len(self.blocks) - n
+        feats = []
         for i, blk in enumerate(self.blocks):
             x = blk(x)
-            if len(self.blocks) - i <= n:
-                output.append(Fn.FinalNormFn.apply(x, self.norm.weight, self.norm.bias)[:, 0])
+            if i >= first:
+                feats.append(self._normed(x))
+        out = [f[:, 0] for f in feats]
         if return_patch_avgpool:
-            xn = Fn.FinalNormFn.apply(x, self.norm.weight, self.norm.bias)
-            output.append(torch.mean(xn[:, 1:], dim=1))
-        return torch.cat(output, dim=-1)
+            out.append(feats[-1][:, 1:].mean(dim=1))
+        return torch.cat(out, dim=-1)
 
 
-def deit_tiny(patch_size=16, **kwargs):
-    return VisionTransformer(patch_size=patch_size, embed_dim=192, depth=12, num_heads=3, mlp_ratio=4, qkv_bias=True,
-                             norm_layer=partial(nn.LayerNorm, eps=1e-6), **kwargs)
+# factories by name (main_esvit.py:305-311 looks them up in this module's __dict__): (embed_dim, num_heads)
+_WIDTHS = {"deit_tiny": (192, 3), "deit_small": (384, 6), "vit_base": (768, 12)}
 
 
-def deit_small(patch_size=16, **kwargs):
-    return VisionTransformer(patch_size=patch_size, embed_dim=384, depth=12, num_heads=6, mlp_ratio=4, qkv_bias=True,
-                             norm_layer=partial(nn.LayerNorm, eps=1e-6), **kwargs)
+def _factory(name):
+    dim, heads = _WIDTHS[name]
+
+    def make(patch_size=16, **kwargs):
+        return VisionTransformer(patch_size=patch_size, embed_dim=dim, depth=12, num_heads=heads, mlp_ratio=4, qkv_bias=True,
+                                 norm_layer=partial(nn.LayerNorm, eps=1e-6), **kwargs)
+    make.__name__ = name
+    return make
 
 
-def vit_base(patch_size=16, **kwargs):
-    return VisionTransformer(patch_size=patch_size, embed_dim=768, depth=12, num_heads=12, mlp_ratio=4, qkv_bias=True,
-                             norm_layer=partial(nn.LayerNorm, eps=1e-6), **kwargs)
+deit_tiny, deit_small, vit_base = _factory("deit_tiny"), _factory("deit_small"), _factory("vit_base")
