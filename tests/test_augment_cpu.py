@@ -229,3 +229,30 @@ def test_collate_draws_in_the_worker(lib_built):
     loader = torch.utils.data.DataLoader(batch, batch_size=3, collate_fn=aug.collate, num_workers=1)  # crosses a process boundary
     (images2, draws2), _ = next(iter(loader))
     assert [tuple(i.shape) for i in images2] == [tuple(i.shape) for i in images] and set(draws2) == {224, 96}
+
+
+@needs_pil
+def test_oracle_full_pipeline_matches_pillow_random_cases():
+    """whole crops -- random image sizes, boxes, operation orders, factors, blur radii -- rendered by the oracle and by the Pillow
+    calls torchvision's PIL back end makes (oracle/gen_augment_golden.pil_crop): every uint8 stage identical"""
+    from oracle.gen_augment_golden import pil_crop
+    rng = np.random.default_rng(2025)
+    for case in range(40):
+        H, W = int(rng.integers(12, 260)), int(rng.integers(12, 260))
+        img = _img(rng, H, W, smooth=bool(case % 2))
+        S = int(rng.choice([32, 96, 224]) if case % 5 else rng.choice([20, 48, 100]))
+        scale = (0.4, 1.0) if case % 3 else (0.05, 0.4)
+        p = A.sample_crop_params(rng.random(36), H, W, S, scale, 0.6, 0.3)
+        if case % 7 == 0:
+            p["order"] = [int(i) for i in rng.permutation(4)]
+        if case % 4 == 0 and (S > 24):
+            p["blur"], p["blur_radius"] = True, float(rng.uniform(0.1, 4.0))
+        st_pil, st_mine = {}, {}
+        final = pil_crop(img, p, st_pil)
+        A.apply_crop(img, p, st_mine)
+        assert (st_mine["color"] == st_pil["color"]).all(), (case, p)
+        assert (st_mine["final_u8"] == final).all(), (case, p)
+        row = A.params_row(p, 0)                                   # and the parameter row round-trips to the same crop
+        st_row = {}
+        A.apply_crop(img, A.row_to_params(row, S), st_row)
+        assert (st_row["final_u8"] == final).all(), case
