@@ -805,7 +805,9 @@ extern "C" int esvit_window_attn_fwd(int dtype, const void* qkv, const float* qk
                                      const float* rel_table, int ws, float* bias_frag_ws, const int32_t* region_ids, int nW, int nB, int N,
                                      int nH, int hd, float scale, void* out, float* lse, float* attn_out, esvit_stream_t s_) {
     STREAM(s_);
-    ESVIT_CHECK_ARG(qkv && qkv_bias && win2tok && out && nB > 0 && nW > 0 && nH > 0 && L > 0 && ws > 0 && N == ws * ws,
+    // (N < ws * ws: a "window" of the first N positions of a ws x ws grid -- the 37 / 17 / 5 tokens of a ViT crop with a zero table)
+    ESVIT_CHECK_ARG(qkv && qkv_bias && win2tok && out && nB > 0 && nW > 0 && nH > 0 && L > 0 && ws > 0 && N > 0 &&
+                        (N == ws * ws || (N < ws * ws && N <= NP)),
                     "esvit_window_attn_fwd: bad args");
     ESVIT_CHECK_ARG(hd == HD || (hd == 64 && N <= NP), "esvit_window_attn_fwd: head_dim %d unsupported (32, or 64 with N <= 64)", hd);
     ESVIT_CHECK_ARG(dtype == ESVIT_BF16 || dtype == ESVIT_F32, "esvit_window_attn_fwd: bad dtype");
@@ -849,7 +851,7 @@ extern "C" int esvit_window_attn_bwd(int dtype, const void* qkv, const float* qk
                                      float* dbias_ws, float* dpad_ws, esvit_stream_t s_) {
     STREAM(s_);
     ESVIT_CHECK_ARG(qkv && qkv_bias && win2tok && dout && dqkv && dbias_ws && dpad_ws && nB > 0 && nW > 0 && nH > 0 && L > 0 &&
-                        ws > 0 && N == ws * ws,
+                        ws > 0 && N > 0 && (N == ws * ws || (N < ws * ws && N <= NP)),
                     "esvit_window_attn_bwd: bad args");
     ESVIT_CHECK_ARG(hd == HD || (hd == 64 && N <= NP), "esvit_window_attn_bwd: head_dim %d unsupported (32, or 64 with N <= 64)", hd);
     ESVIT_CHECK_ARG(dtype == ESVIT_BF16 || dtype == ESVIT_F32, "esvit_window_attn_bwd: bad dtype");

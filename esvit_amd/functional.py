@@ -918,6 +918,45 @@ class VitPatchEmbedFn(torch.autograd.Function):
         return None, dW.view(ctx.wshape), dbp, None
 
 
+VIT_WINDOW_TOKENS = 64  # crops of at most this many tokens run through the fused windowed kernels (one "window" per image)
+_VIT_WIN = {}
+
+
+def _vit_window(N, nH, device):
+    """the geometry a crop of N <= 64 tokens presents to window_attn.hip: one window per image holding tokens 0..N-1, no bias (a
+    zero table over the smallest grid that has N positions), no shift mask"""
+    key = (N, nH, str(device))
+    g = _VIT_WIN.get(key)
+    if g is None:
+        ws = 1
+        while ws * ws < N:
+            ws += 1
+        g = (torch.arange(N, dtype=torch.int32, device=device), ws, _zero_table(ws, nH, device))
+        _VIT_WIN[key] = g
+    return g
+
+
+def vit_attention(o, qkv, bqkv, nB, N, nH, scale, save):
+    """Attention.forward between the projections (vision_transformer.py:76-83) -> (out, tensors for vit_attention_bwd).  The 37 tokens
+    of a 96^2 crop fit ONE 64-slot window of the fused kernels of window_attn.hip (no score matrix in HBM, 2 launches instead of 11);
+    the 197 tokens of a 224^2 crop take the batched-GEMM route of ops.vit_attn_fwd."""
+    hd = qkv.shape[1] // 3 // nH
+    if N <= VIT_WINDOW_TOKENS and hd in (32, 64):
+        win2tok, ws, table = _vit_window(N, nH, qkv.device)
+        frag = o.new_bias_frag(nH, N, qkv.device) if save else None
+        ao, _ = o.window_attn_fwd(qkv, bqkv, win2tok, N, table, ws, None, 1, N, nH, scale, bias_frag=frag)
+        return ao, ((qkv, ao, frag) if save else ())
+    return o.vit_attn_fwd(qkv, nB, N, nH, scale)
+
+
+def vit_attention_bwd(o, dao, att, bqkv, nB, N, nH, scale):
+    if len(att) == 3:  # the windowed route: (qkv, out, bias fragments)
+        qkv, ao, frag = att
+        win2tok, ws, _ = _vit_window(N, nH, qkv.device)
+        return o.window_attn_bwd(qkv, bqkv, win2tok, N, dao, ao, None, None, ws, None, 1, N, nH, scale, bias_frag=frag)[0]
+    return o.vit_attn_bwd(dao, att, nB, N, nH, scale)
+
+
 def _vit_block_forward(x, nH, dp, prm, wts, save):
     """Block.forward (vision_transformer.py:110-116) on x fp32 [nB, N, C]"""
     o = ops_module()
@@ -929,7 +968,7 @@ def _vit_block_forward(x, nH, dp, prm, wts, save):
     dp1, dp2 = (None, None) if dp is None else dp
     xw, _, mean1, rstd1 = o.layernorm_fwd(x2d, g1, b1, LN_EPS)
     qkv = o.linear_fwd(xw, Wqkv, bqkv)
-    ao, att = o.vit_attn_fwd(qkv, nB, N, nH, scale)
+    ao, att = vit_attention(o, qkv, bqkv, nB, N, nH, scale, save)
     x1 = o.linear_fwd(ao, Wproj, bproj, residual=x2d, rowscale=dp1, rows_per_sample=N, out_f32=True)
     h, _, mean2, rstd2 = o.layernorm_fwd(x1, g2, b2, LN_EPS)
     if save:
@@ -952,7 +991,7 @@ class VitBlockFn(torch.autograd.Function):
         ctx.bparams = (bqkv, bproj, bfc1, bfc2)
         ctx.nparams = (g1, b1, g2, b2)
         ctx.natt = len(att)
-        ctx.save_for_backward(x, g1, g2, *wts, *saved, *att)
+        ctx.save_for_backward(x, g1, g2, bqkv, *wts, *saved, *att)
         return y
 
     @staticmethod
@@ -960,8 +999,8 @@ class VitBlockFn(torch.autograd.Function):
         o = ops_module()
         nH, dp = ctx.nH, ctx.dp
         t = ctx.saved_tensors
-        x, g1, g2, Wqkv, Wproj, W1, W2, mean1, rstd1, xw, ao, x1, mean2, rstd2, h, a1, a1g = t[:17]
-        att = tuple(t[17:17 + ctx.natt])
+        x, g1, g2, bqkv, Wqkv, Wproj, W1, W2, mean1, rstd1, xw, ao, x1, mean2, rstd2, h, a1, a1g = t[:18]
+        att = tuple(t[18:18 + ctx.natt])
         nB, N, C = x.shape
         M = nB * N
         scale = (C // nH) ** -0.5
@@ -979,7 +1018,7 @@ class VitBlockFn(torch.autograd.Function):
         gx1, dyw, dg2, db2 = o.layernorm_bwd_cast(dh, x1, mean2, rstd2, g2, g_in=gy, rowscale=dp1, rows_per_sample=N, gb_out=sink2)
         dWproj, dbproj = _wgrad(dyw, ao, Wproj_p, want_bias=True, bias_param=bproj_p)
         dao = o.linear_dgrad(dyw, Wproj)
-        dqkv = o.vit_attn_bwd(dao, att, nB, N, nH, scale)
+        dqkv = vit_attention_bwd(o, dao, att, bqkv, nB, N, nH, scale)
         dWqkv, dbqkv = _wgrad(dqkv, xw, Wqkv_p, want_bias=True, bias_param=bqkv_p)
         dxw = o.linear_dgrad(dqkv, Wqkv)
         gx, dg1, db1 = o.layernorm_bwd(dxw, x.view(M, C), mean1, rstd1, g1, g_in=gx1, gb_out=sink1)
@@ -1002,6 +1041,6 @@ def vit_block_attention(x, nH, prm_list):
     nB, N, C = x.shape
     xw = o.layernorm_fwd(x.contiguous().view(nB * N, C), g1, b1, LN_EPS)[0]
     qkv = o.linear_fwd(xw, _weight(Wqkv_p), bqkv)
-    _, att = o.vit_attn_fwd(qkv, nB, N, nH, (C // nH) ** -0.5)
+    _, att = o.vit_attn_fwd(qkv, nB, N, nH, (C // nH) ** -0.5)  # (evaluation hook: the batched-GEMM route keeps P in memory)
     p = att[-1]
     return p.reshape(nB, nH, p.shape[-2], p.shape[-1])[:, :, :N, :N].float()

@@ -384,6 +384,7 @@ def _frag_from_dense(dense, pad_key_value=0.0):
 
 def relpos_bias_fwd(table, index, N):
     nH = table.shape[1]
+    index = index[:N, :N].contiguous()  # (N < ws^2: the first N positions of the grid -- ViT crops through the windowed kernels)
     dense = table[index.view(-1)].view(N, N, nH).permute(2, 0, 1).contiguous()
     return _frag_from_dense(dense, -1.0e30)
 
@@ -435,7 +436,9 @@ def _attn_core(qkvw, bias_frag, region_ids, nW, N, nH, scale):
 
 def new_bias_frag(nH, N, device):
     """the restatement's "fragment buffer" simply remembers the table the first call was given"""
-    ws = int(round(N ** 0.5))
+    ws = 1
+    while ws * ws < N:  # the smallest grid with N positions (N = ws^2 for Swin / CvT windows, fewer for ViT crops)
+        ws += 1
     return torch.zeros(((2 * ws - 1) ** 2, nH), dtype=torch.float32, device=device)
 
 

@@ -143,3 +143,32 @@ def test_deit_small_step_runs_through_the_trainer(lib_built):
         assert (teacher.blocks[5].attn.qkv.weight - t0).abs().max().item() > 0
     finally:
         _teardown()
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(6, 37, 6, 64), (5, 37, 3, 64), (4, 17, 2, 32), (3, 5, 2, 32), (2, 64, 12, 64), (3, 50, 1, 64)])
+def test_small_crops_through_the_windowed_kernels(dt, shape, lib_built):
+    """crops of <= 64 tokens (the 37 tokens of a 96^2 crop) run as ONE window per image through the fused kernels of window_attn.hip
+    (N < ws^2, zero bias table): same result as the plain attention restatement, forward and backward"""
+    import esvit_amd.functional as Fn
+    from esvit_amd import ops
+    B, N, nH, hd = shape
+    C = nH * hd
+    g = torch.Generator().manual_seed(11 + sum(shape))
+    qkv = torch.randn(B * N, 3 * C, generator=g).to(dt)
+    dout = torch.randn(B * N, C, generator=g).to(dt)
+    bqkv = torch.zeros(3 * C)
+    ops_ref.set_act_dtype(dt)
+    try:
+        o_ref, saved = ops_ref.vit_attn_fwd(qkv, B, N, nH, hd ** -0.5)
+        d_ref = ops_ref.vit_attn_bwd(dout, saved, B, N, nH, hd ** -0.5)
+    finally:
+        ops_ref.set_act_dtype(torch.float32)
+    o, att = Fn.vit_attention(ops, qkv.cuda(), bqkv.cuda(), B, N, nH, hd ** -0.5, True)
+    assert len(att) == 3                                        # the windowed route was taken
+    d = Fn.vit_attention_bwd(ops, dout.cuda(), att, bqkv.cuda(), B, N, nH, hd ** -0.5)
+    tol = 2e-5 if dt == torch.float32 else 2e-2
+    _close("attention output (windowed route)", o, o_ref, tol)
+    _close("d qkv (windowed route)", d, d_ref, tol * 2)
+    big = Fn.vit_attention(ops, torch.randn(2 * 65, 3 * C).to(dt).cuda(), bqkv.cuda(), 2, 65, nH, hd ** -0.5, True)[1]
+    assert len(big) == 2                                        # 65 tokens: the batched-GEMM route
