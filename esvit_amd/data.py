@@ -102,6 +102,8 @@ class PackedImages:
     (byte offset, H, W) -- the input format of esvit_aug_crops"""
 
     def __init__(self, images, device="cuda"):
+        if len(images) == 0:
+            raise ValueError("PackedImages: an empty batch")
         arrs, H, W = [], [], []
         for im in images:
             if isinstance(im, torch.Tensor):

@@ -360,7 +360,7 @@ int esvit_bn_bwd_coeffs(const float* red, float n, const float* gamma, const flo
  *           10 brightness | 11 contrast | 12 saturation factor (float bits) | 13 hue shift = uint8(hue_factor * 255)
  *           14 grayscale | 15 box radius + 1 of the blur (0 = no blur) | 16 ww | 17 fw (BoxBlur.c fixed-point weights of the
  *           Gaussian radius) | 18 solarize | 19.. reserved (0)
- *   S       output size, a multiple of 4, <= 280;  max_h, max_w  the largest box of the n crops (sizes the LDS of the resize;
+ *   n       crops in this call, <= 65535;  S  output size, a multiple of 4, <= 280;  max_h, max_w  the largest box of the n crops (sizes the LDS of the resize;
  *           <= esvit_query(ESVIT_Q_AUG_MAX_BOX, S, 0, 0))
  *   planes  uint8 scratch of n * (3 S^2 + 4) bytes: on return its first n * 3 S^2 bytes are the resized, flipped crops
  *           [n, 3, S, S] before the jitter;  out  fp32 [n, 3, S, S] */
