@@ -292,6 +292,42 @@ def gen_nano_vit(ns):
     print("nano_vit_step.pt: loss", g["ddino_loss"], "npatch", g["npatch"], "params", len(g["param_names"]), "no_grad", g["no_grad"])
 
 
+def gen_full_vit(ns):
+    """deit_small at FULL width from the reference's own modules (197 / 37 tokens, 6 heads of 64, 12 blocks), batch 2, out_dim 4096:
+    the step the GPU parity test of the monolithic ViT compares with at real geometry -- loss, every gradient norm, strided samples
+    of a dozen gradient tensors, probes of the outputs"""
+    import importlib
+    RL.ensure_single_process_group()
+    vits = importlib.import_module("models.vision_transformer")
+    K = 4096
+
+    def make(seed):
+        m = vits.deit_small(patch_size=16, drop_path_rate=0.0, use_dense_prediction=True)
+        m.head, m.head_dense = ns.DINOHead(384, K, norm_last_layer=True), ns.DINOHead(384, K, norm_last_layer=False)
+        GU.fill_state_dict(m.state_dict(), seed)
+        return m
+    student, teacher = make(41), make(42)
+    student.head.last_layer.weight_g.data.fill_(1)
+    for p in teacher.parameters():
+        p.requires_grad = False
+    crops = GU.make_crops(2, seed=77)
+    loss_fn = ns.DDINOLoss(K, 10, 0.04, 0.07, 5, 10)
+    t_out = teacher(crops[:2])
+    s_out = student(crops)
+    loss = loss_fn(s_out, t_out, 2, None)
+    student.zero_grad()
+    loss.backward()
+    names = [n for n, p in student.named_parameters() if p.grad is not None]
+    prm = dict(student.named_parameters())
+    g = {"K": K, "loss": loss.item(), "npatch": (list(s_out[3]), list(t_out[3])),
+         "s_cls": GU.probe(s_out[0]), "s_reg": GU.probe(s_out[1]), "s_fea": GU.probe(s_out[2]), "t_cls": GU.probe(t_out[0]),
+         "grad_norms": {n: prm[n].grad.norm().item() for n in names},
+         "grad_samples": {n: GU.strided(prm[n].grad, 4096) for n in GU.full_sampled_names(names)},
+         "center_after": loss_fn.center.clone(), "center_grid_after": loss_fn.center_grid.clone()}
+    torch.save(g, os.path.join(OUT, "full_vit.pt"))
+    print("full_vit.pt: loss", g["loss"], "npatch", g["npatch"], "grads", len(names))
+
+
 def gen_knn(ns):
     """top-1 / top-5 of the reference's knn_classifier on synthetic feature sets (tests/golden_utils.make_knn_set)"""
     ref_knn = RL.load_knn_classifier()
@@ -465,6 +501,8 @@ def main():
         gen_variants(ns)
     if "full" in only:  # minutes of CPU time: regenerated on request only
         gen_full(ns)
+    if "full_vit" in only:
+        gen_full_vit(ns)
 
 
 if __name__ == "__main__":

@@ -172,3 +172,51 @@ def test_small_crops_through_the_windowed_kernels(dt, shape, lib_built):
     _close("d qkv (windowed route)", d, d_ref, tol * 2)
     big = Fn.vit_attention(ops, torch.randn(2 * 65, 3 * C).to(dt).cuda(), bqkv.cuda(), 2, 65, nH, hd ** -0.5, True)[1]
     assert len(big) == 2                                        # 65 tokens: the batched-GEMM route
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_deit_small_step_matches_reference_golden(prec, lib_built):
+    """deit_small at FULL width (197 / 37 tokens, both attention routes, 12 blocks), batch 2, out_dim 4096: outputs, loss, the loss
+    centres, every gradient norm and a dozen sampled gradient tensors against the step of the REFERENCE's own VisionTransformer on the
+    same weights and crops (tests/golden/full_vit.pt, oracle/gen_golden.py:gen_full_vit)."""
+    import esvit_amd
+    from esvit_amd.models import vision_transformer as V
+    from tests import golden_utils as GU
+    from tests.test_composition_cpu import probe_close
+    g = torch.load(os.path.join(GOLD, "full_vit.pt"), map_location="cpu", weights_only=False)
+    K = g["K"]
+    dev = _setup(prec)
+    try:
+        def make(seed):
+            m = V.deit_small(patch_size=16, drop_path_rate=0.0, use_dense_prediction=True)
+            m.head, m.head_dense = esvit_amd.DINOHead(384, K, norm_last_layer=True), esvit_amd.DINOHead(384, K, norm_last_layer=False)
+            GU.fill_state_dict(m.state_dict(), seed)
+            return m
+        student, teacher = make(41), make(42)
+        student.head.last_layer.weight_g.data.fill_(1)
+        for p in teacher.parameters():
+            p.requires_grad = False
+        student, teacher = student.to(dev), teacher.to(dev)
+        crops = [c.to(dev) for c in GU.make_crops(2, seed=77)]
+        loss_fn = esvit_amd.DDINOLoss(K, 10, 0.04, 0.07, 5, 10).to(dev)
+        t_out = teacher(crops[:2])
+        s_out = student(crops)
+        loss = loss_fn(s_out, t_out, 2, None)
+        loss.backward()
+        fp = prec == "fp32"
+        assert (list(s_out[3]), list(t_out[3])) == g["npatch"]
+        for nm, t in (("s_cls", s_out[0]), ("s_reg", s_out[1]), ("s_fea", s_out[2]), ("t_cls", t_out[0])):
+            probe_close(nm, t.float().cpu(), g[nm], rtol=5e-4 if fp else 6e-2)
+        assert abs(loss.item() - g["loss"]) < (1e-4 if fp else 1e-2), (loss.item(), g["loss"])
+        assert (loss_fn.center.cpu() - g["center_after"]).abs().max().item() < (1e-6 if fp else 2e-3)
+        assert (loss_fn.center_grid.cpu() - g["center_grid_after"]).abs().max().item() < (1e-6 if fp else 2e-3)
+        prm = dict(student.named_parameters())
+        assert sorted(n for n, p in prm.items() if p.grad is not None) == sorted(g["grad_norms"])
+        worst = max(abs(prm[n].grad.norm().item() - ref) / (ref + 1e-12) for n, ref in g["grad_norms"].items())
+        assert worst < (5e-3 if fp else 0.2), worst
+        for n, ref in g["grad_samples"].items():
+            got = GU.strided(prm[n].grad.float().cpu(), 4096)
+            err = (got - ref).abs().max().item() / (ref.abs().max().item() + 1e-12)
+            assert err < (5e-3 if fp else 0.25), (n, err)
+    finally:
+        _teardown()
