@@ -160,3 +160,46 @@ def test_level1_unmodified_train_one_epoch_and_checkpoints(cpu_ops, tmp_path, mo
     same(lf.state_dict(), r_loss.state_dict())
     k0 = sorted(r_sd["state"])[0]
     assert torch.equal(o.state_dict()["state"][k0]["exp_avg"], r_sd["state"][k0]["exp_avg"])
+
+
+def test_level1_vit_behind_unmodified_train_one_epoch(cpu_ops, tmp_path, monkeypatch):  # noqa: F811
+    """the same for the monolithic ViT (the reference's default --arch, main_esvit.py:305-327): our VisionTransformer + DINOHeads +
+    DDINOLoss behind the reference's unmodified loop end with the loss and the parameter updates of the reference's own ViT"""
+    import esvit_amd
+    from tests.test_vit_cpu import nano_vit_pair
+    ns = RL.load()
+    RL.ensure_single_process_group()
+    train_one_epoch = RL.load_train_one_epoch()
+    monkeypatch.setattr(torch.Tensor, "cuda", lambda self, *a, **k: self)
+    monkeypatch.setattr(torch.cuda, "synchronize", lambda *a, **k: None)
+    monkeypatch.setattr(ns.utils, "is_dist_avail_and_initialized", lambda: False)
+    K = GU.NANO_HEAD["out_dim"]
+    batches = [GU.make_crops(2, n_local=3, sizes=GU.NANO_VIT["sizes"], seed=80 + i) for i in range(2)]
+    student, teacher = nano_vit_pair()
+    loss_fn = esvit_amd.DDINOLoss(K, 5, 0.04, 0.07, 5, 10)
+    ddp, opt, stats, _ = _run(train_one_epoch, ns, student, teacher, loss_fn, batches, 1, tmp_path)
+    r_student, r_teacher = GG.build_nano_vit(ns), GG.build_nano_vit(ns, teacher=True)
+    GU.fill_state_dict(r_student.state_dict(), 0)
+    GU.fill_state_dict(r_teacher.state_dict(), 7)
+    r_student.head.last_layer.weight_g.data.fill_(1)
+    for p in r_teacher.parameters():
+        p.requires_grad = False
+    r_loss = ns.DDINOLoss(K, 5, 0.04, 0.07, 5, 10)
+    r_ddp, r_opt, r_stats, _ = _run(train_one_epoch, ns, r_student, r_teacher, r_loss, batches, 1, tmp_path)
+    assert abs(stats["loss"] - r_stats["loss"]) < 1e-4, (stats, r_stats)
+    init_s, init_t = nano_vit_pair()
+    init_s, init_t = dict(init_s.named_parameters()), dict(init_t.named_parameters())
+    assert [n for n, _ in ddp.module.named_parameters()] == [n for n, _ in r_ddp.module.named_parameters()]
+    for (n, a), (_, b) in zip(ddp.module.named_parameters(), r_ddp.module.named_parameters()):
+        ua, ub = (a - init_s[n]).detach(), (b - init_s[n]).detach()
+        if ub.norm() > 0:
+            assert (ua - ub).norm() <= 2e-2 * ub.norm(), (n, (ua - ub).norm().item(), ub.norm().item())
+        else:
+            assert torch.equal(a, b), n
+    for (n, a), (_, b) in zip(teacher.named_parameters(), r_teacher.named_parameters()):
+        ua, ub = (a - init_t[n]).detach(), (b - init_t[n]).detach()
+        assert (ua - ub).norm() <= 1e-3 * ub.norm() + 1e-9, (n, (ua - ub).norm().item(), ub.norm().item())
+    assert torch.allclose(loss_fn.center, r_loss.center, atol=1e-6) and torch.allclose(loss_fn.center_grid, r_loss.center_grid, atol=1e-6)
+    # checkpoints are interchangeable: the reference's modules load ours
+    r_fresh = GG.build_nano_vit(ns)
+    r_fresh.load_state_dict(ddp.module.state_dict())
