@@ -779,11 +779,11 @@ int esvit_big_npb();
 int esvit_big_parts(int Bw, int nH);
 int esvit_big_pad_rows(int Bw, int nH, int dtype);
 int esvit_big_attn_fwd(int dtype, const void* qkv, const float* qkv_bias, const int32_t* win2tok, int L, const float* rel_table, int ws,
-                       float* bias_frag_ws, const int32_t* region_ids, int nW, int nB, int N, int nH, float scale, void* out, float* lse,
+                       float* bias_frag_ws, const int32_t* region_ids, int nW, int nB, int N, int nH, int hd, float scale, void* out, float* lse,
                        float* attn_out, hipStream_t stream);
 int esvit_big_attn_bwd(int dtype, const void* qkv, const float* qkv_bias, const int32_t* win2tok, int L, const void* dout,
                        const void* fout, const float* lse, const float* rel_table, int ws, float* bias_frag_ws, const int32_t* region_ids,
-                       int nW, int nB, int N, int nH, float scale, void* dqkv, float* dbias_ws, float* dpad_ws, hipStream_t stream);
+                       int nW, int nB, int N, int nH, int hd, float scale, void* dqkv, float* dbias_ws, float* dpad_ws, hipStream_t stream);
 int esvit_big_relpos_bias_bwd(const float* dbias_ws, int parts, const int64_t* index, int N, int nH, int table_rows, float* dtable,
                               int accumulate, hipStream_t stream);
 
@@ -805,14 +805,14 @@ extern "C" int esvit_window_attn_fwd(int dtype, const void* qkv, const float* qk
                                      const float* rel_table, int ws, float* bias_frag_ws, const int32_t* region_ids, int nW, int nB, int N,
                                      int nH, int hd, float scale, void* out, float* lse, float* attn_out, esvit_stream_t s_) {
     STREAM(s_);
-    // (N < ws * ws: a "window" of the first N positions of a ws x ws grid -- the 37 / 17 / 5 tokens of a ViT crop with a zero table)
+    // (N < ws * ws: a "window" of the first N positions of a ws x ws grid -- the 197 / 37 tokens of a ViT crop with a zero table)
     ESVIT_CHECK_ARG(qkv && qkv_bias && win2tok && out && nB > 0 && nW > 0 && nH > 0 && L > 0 && ws > 0 && N > 0 &&
-                        (N == ws * ws || (N < ws * ws && N <= NP)),
+                        (N == ws * ws || (N < ws * ws && N <= esvit_big_npb())),
                     "esvit_window_attn_fwd: bad args");
-    ESVIT_CHECK_ARG(hd == HD || (hd == 64 && N <= NP), "esvit_window_attn_fwd: head_dim %d unsupported (32, or 64 with N <= 64)", hd);
+    ESVIT_CHECK_ARG(hd == HD || hd == 64, "esvit_window_attn_fwd: head_dim %d unsupported (32 or 64)", hd);
     ESVIT_CHECK_ARG(dtype == ESVIT_BF16 || dtype == ESVIT_F32, "esvit_window_attn_fwd: bad dtype");
     if (N > NP)
-        return esvit_big_attn_fwd(dtype, qkv, qkv_bias, win2tok, L, rel_table, ws, bias_frag_ws, region_ids, nW, nB, N, nH, scale, out, lse, attn_out,
+        return esvit_big_attn_fwd(dtype, qkv, qkv_bias, win2tok, L, rel_table, ws, bias_frag_ws, region_ids, nW, nB, N, nH, hd, scale, out, lse, attn_out,
                                   stream);
     ESVIT_CHECK_ARG(bias_frag_ws != nullptr, "esvit_window_attn_fwd: 7x7 windows need the bias_frag_ws scratch");
     if (rel_table) {  // NULL: bias_frag_ws still holds the fragment-order bias an earlier call of this step put there
@@ -851,13 +851,13 @@ extern "C" int esvit_window_attn_bwd(int dtype, const void* qkv, const float* qk
                                      float* dbias_ws, float* dpad_ws, esvit_stream_t s_) {
     STREAM(s_);
     ESVIT_CHECK_ARG(qkv && qkv_bias && win2tok && dout && dqkv && dbias_ws && dpad_ws && nB > 0 && nW > 0 && nH > 0 && L > 0 &&
-                        ws > 0 && N > 0 && (N == ws * ws || (N < ws * ws && N <= NP)),
+                        ws > 0 && N > 0 && (N == ws * ws || (N < ws * ws && N <= esvit_big_npb())),
                     "esvit_window_attn_bwd: bad args");
-    ESVIT_CHECK_ARG(hd == HD || (hd == 64 && N <= NP), "esvit_window_attn_bwd: head_dim %d unsupported (32, or 64 with N <= 64)", hd);
+    ESVIT_CHECK_ARG(hd == HD || hd == 64, "esvit_window_attn_bwd: head_dim %d unsupported (32 or 64)", hd);
     ESVIT_CHECK_ARG(dtype == ESVIT_BF16 || dtype == ESVIT_F32, "esvit_window_attn_bwd: bad dtype");
     if (N > NP)
         return esvit_big_attn_bwd(dtype, qkv, qkv_bias, win2tok, L, dout, fwd_out, lse, rel_table, ws, bias_frag_ws, region_ids, nW, nB,
-                                  N, nH, scale, dqkv, dbias_ws, dpad_ws, stream);
+                                  N, nH, hd, scale, dqkv, dbias_ws, dpad_ws, stream);
     ESVIT_CHECK_ARG(bias_frag_ws != nullptr, "esvit_window_attn_bwd: 7x7 windows need the bias_frag_ws scratch");
     if (rel_table) {  // NULL: bias_frag_ws still holds the fragment-order bias an earlier call of this step put there
         int rc = fill_bias_frag(rel_table, ws, N, nH, bias_frag_ws, stream);

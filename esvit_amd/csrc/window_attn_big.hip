@@ -19,19 +19,22 @@
 
 namespace {
 
-constexpr int HD = 32;
 constexpr int NT = 14;         // 16-wide tiles per window side
 constexpr int NPB = NT * 16;   // 224 padded tokens
 constexpr int NQB = NPB / 32;  // 7 blocks of 32 queries / keys
 constexpr int TAB_FLOATS = 768;
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
-template <typename T>
+// HD = head_dim: 32 (the Swin W=14 models) or 64 (the 197-token crops of the monolithic ViTs, bf16 only: two fp32 [224][68] images
+// plus the per-wave images exceed a CU's LDS)
+template <typename T, int HD>
 struct BigCfg {
     static constexpr int VEC = ElemTraits<T>::VEC;
     static constexpr int LDQ = HD + VEC;    // [*][LDQ] images with d contiguous
     static constexpr int LDP = NPB + VEC;   // [32][LDP] P / dS image of one query block
-    static constexpr int WAVES = sizeof(T) == 2 ? 4 : 2;  // fp32 parity mode: half the waves, same LDS budget
+    // waves of the dK/dV kernel.  fp32 parity mode: half the waves, same LDS budget; head_dim 64: one wave per 32-key block (7), the
+    // workgroup is alone on its CU anyway (two [224][72] images)
+    static constexpr int WAVES = sizeof(T) == 2 ? (HD == 32 ? 4 : 7) : 2;
     static constexpr int FULL = NPB * LDQ;  // one [224][LDQ] image
     static constexpr int BLK = 32 * LDQ;    // one [32][LDQ] image
     static constexpr int PIMG = 32 * LDP;
@@ -75,9 +78,9 @@ __device__ __forceinline__ void load_window_tables(const BigTables& tb, const in
 // Two phases: every global load of the thread is issued before the first LDS store, so a thread waits ONE memory round
 // trip per call instead of one per 16-byte piece (the first version looped load -> store and paid 4-7 serial round trips
 // per (window, head) with one wave per SIMD to hide them).
-template <typename T, int NROWS, int NTHR>
+template <typename T, int NROWS, int NTHR, int HD>
 struct SlotStage {
-    static constexpr int VEC = BigCfg<T>::VEC, LDQ = BigCfg<T>::LDQ, VPR = HD / VEC;
+    static constexpr int VEC = BigCfg<T, HD>::VEC, LDQ = BigCfg<T, HD>::LDQ, VPR = HD / VEC;
     static constexpr int ITERS = (NROWS * VPR + NTHR - 1) / NTHR;
     Vec16<T> x[ITERS];
 
@@ -144,19 +147,18 @@ __global__ void relpos_bias_frag_big_kernel(const float* __restrict__ table, int
 
 // same result, but through an LDS transpose ([32][LDQ] image private to the wave): every lane stores 16-byte row vectors
 // (2 per lane) instead of 16 two-byte scatters.  pad-slot rows are summed into padacc[VEC] (columns dv*VEC.., dv = lane % VPR).
-template <typename T>
-__device__ __forceinline__ void store_block_rows_vec(const f32x4 (&acc)[2][2], float mul, T* stg, T* __restrict__ dst, long row_stride,
+template <typename T, int HD>
+__device__ __forceinline__ void store_block_rows_vec(const f32x4 (&acc)[2][HD / 16], float mul, T* stg, T* __restrict__ dst, long row_stride,
                                                      const int* tok_lds, long tok_base, int s0, int N, bool active, float* padacc, int lane,
                                                      int c, int g) {
-    constexpr int VEC = BigCfg<T>::VEC, LDQ = BigCfg<T>::LDQ, VPR = HD / VEC;
+    constexpr int VEC = BigCfg<T, HD>::VEC, LDQ = BigCfg<T, HD>::LDQ, VPR = HD / VEC;
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            stg[(16 * ti + 4 * g + r) * LDQ + c] = from_f32<T>(acc[ti][0][r] * mul);
-            stg[(16 * ti + 4 * g + r) * LDQ + 16 + c] = from_f32<T>(acc[ti][1][r] * mul);
-        }
+        for (int j = 0; j < HD / 16; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) stg[(16 * ti + 4 * g + r) * LDQ + 16 * j + c] = from_f32<T>(acc[ti][j][r] * mul);
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int i = 0; i < 32 * VPR / 64; ++i) {
@@ -230,13 +232,14 @@ __device__ __forceinline__ Frag<T> frag_p_regs(const f32x4& lo, const f32x4& hi)
 // a CU -- the second generation's SQ counters still showed 59 % of the wave cycles parked on loads with two waves per SIMD.
 constexpr int FWD3_WAVES = 7;
 
-template <typename T, bool WANT_ATTN>
-__global__ __launch_bounds__(FWD3_WAVES * 64, sizeof(T) == 2 ? 4 : 1) void attn_big_fwd3_kernel(
+template <typename T, bool WANT_ATTN, int HD>
+__global__ __launch_bounds__(FWD3_WAVES * 64, sizeof(T) == 2 ? (HD == 32 ? 4 : 2) : 1) void attn_big_fwd3_kernel(
     const T* __restrict__ qkv, const float* __restrict__ qkv_bias, const int* __restrict__ win2tok, int L,
     const float* __restrict__ bias_frag, int ws, const int* __restrict__ region_ids, int nW, int Bw, int N, int nH,
     float scale, T* __restrict__ out, float* __restrict__ lse_out, float* __restrict__ attn_out) {
-    using Cfg = BigCfg<T>;
+    using Cfg = BigCfg<T, HD>;
     constexpr int LDQ = Cfg::LDQ, VEC = Cfg::VEC, VPR = HD / VEC;
+    constexpr int KS = HD / 32, DT = HD / 16;  // k-steps of a q.k product, 16-wide tiles of an output row
     constexpr int TILE = 16 * LDQ;
     static_assert(NT == 2 * FWD3_WAVES, "two query tiles per wave");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -257,9 +260,9 @@ __global__ __launch_bounds__(FWD3_WAVES * 64, sizeof(T) == 2 ? 4 : 1) void attn_
 
     load_window_tables(tb, win2tok, region_ids, bw % nW, N, ws, true);
     __syncthreads();
-    SlotStage<T, 16, 64> sq;
+    SlotStage<T, 16, 64, HD> sq;
     {
-        SlotStage<T, NPB, FWD3_WAVES * 64> sk, sv;
+        SlotStage<T, NPB, FWD3_WAVES * 64, HD> sk, sv;
         sk.load(src + C, 3L * C, tb.tok, tok_base, 0, N, qkv_bias + C + h * HD, threadIdx.x);
         sv.load(src + 2 * C, 3L * C, tb.tok, tok_base, 0, N, qkv_bias + 2 * C + h * HD, threadIdx.x);
         sq.load(src, 3L * C, tb.tok, tok_base, 16 * wave, N, qkv_bias + h * HD, lane);
@@ -277,13 +280,14 @@ __global__ __launch_bounds__(FWD3_WAVES * 64, sizeof(T) == 2 ? 4 : 1) void attn_
             sq.store(Qs, scale, lane);
             __builtin_amdgcn_wave_barrier();
         }
-        const Frag<T> qf = frag_kc<T>(Qs, LDQ, 0, 0, c, g);
+        Frag<T> qf[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) qf[ks] = frag_kc<T>(Qs, LDQ, 0, 32 * ks, c, g);
         if (pass == 0) sq.load(src, 3L * C, tb.tok, tok_base, 16 * (wave + FWD3_WAVES), N, qkv_bias + h * HD, lane);
         const int rq = masked ? ((tb.pk[q0 + c] >> 16) & 0xff) : 0;
         f32x4 p[NT];
 #pragma unroll
         for (int i = 0; i < NT; ++i) {
-            const Frag<T> kf = frag_kc<T>(Ks, LDQ, 16 * i, 0, c, g);
             f32x4 b = *reinterpret_cast<const f32x4*>(bias_h + ((i * NT + (q0 >> 4)) * 64 + lane) * 4);
             if (masked) {
                 const i32x4 pk4 = *reinterpret_cast<const i32x4*>(tb.pk + 16 * i + 4 * g);
@@ -291,7 +295,8 @@ __global__ __launch_bounds__(FWD3_WAVES * 64, sizeof(T) == 2 ? 4 : 1) void attn_
                 for (int r = 0; r < 4; ++r) b[r] += (((pk4[r] >> 16) & 0xff) != rq) ? -100.f : 0.f;
             }
             p[i] = b;
-            mma(kf, qf, p[i]);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) mma(frag_kc<T>(Ks, LDQ, 16 * i, 32 * ks, c, g), qf[ks], p[i]);
         }
         float m = -3.0e38f;
 #pragma unroll
@@ -324,22 +329,21 @@ __global__ __launch_bounds__(FWD3_WAVES * 64, sizeof(T) == 2 ? 4 : 1) void attn_
                     if (q < N && key < N) attn_out[((long)unit * N + q) * N + key] = p[i][r];
                 }
         }
-        f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
+        f32x4 o[DT];
+#pragma unroll
+        for (int j = 0; j < DT; ++j) o[j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < NPB / 32; ++ks) {
-            const Frag<T> v0 = frag_v_perm<T>(Vs, LDQ, 0, ks, c, g);
-            const Frag<T> v1 = frag_v_perm<T>(Vs, LDQ, 16, ks, c, g);
             const Frag<T> pf = frag_p_regs<T>(p[2 * ks], p[2 * ks + 1]);
-            mma(pf, v0, o0);
-            mma(pf, v1, o1);
+#pragma unroll
+            for (int j = 0; j < DT; ++j) mma(pf, frag_v_perm<T>(Vs, LDQ, 16 * j, ks, c, g), o[j]);
         }
         // output rows: transpose through the wave's Q image, one 16-byte row piece per lane
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            Qs[(4 * g + r) * LDQ + c] = from_f32<T>(o0[r]);
-            Qs[(4 * g + r) * LDQ + 16 + c] = from_f32<T>(o1[r]);
-        }
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int j = 0; j < DT; ++j) Qs[(4 * g + r) * LDQ + 16 * j + c] = from_f32<T>(o[j][r]);
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int i = 0; i < (16 * VPR + 63) / 64; ++i) {
@@ -377,14 +381,18 @@ __global__ __launch_bounds__(FWD3_WAVES * 64, sizeof(T) == 2 ? 4 : 1) void attn_
 constexpr int DQ4_WAVES = 8;
 constexpr int DQ4_GROUPS = (NT + DQ4_WAVES - 1) / DQ4_WAVES;
 
-template <typename T>
+template <typename T, int HD>
 __global__ __launch_bounds__(DQ4_WAVES * 64) void attn_big_bwd_dq4_kernel(
     const T* __restrict__ qkv, const float* __restrict__ qkv_bias, const int* __restrict__ win2tok, int L, const T* __restrict__ dout,
     const T* __restrict__ fout, const float* __restrict__ lse_in, const float* __restrict__ bias_frag, int ws,
     const int* __restrict__ region_ids, int nW, int Bw, int N, int nH, float scale, int parts, T* __restrict__ dqkv,
     float* __restrict__ dbias_ws) {
-    using Cfg = BigCfg<T>;
+    using Cfg = BigCfg<T, HD>;
     constexpr int LDQ = Cfg::LDQ, VEC = Cfg::VEC, VPR = HD / VEC;
+    constexpr int KS = HD / 32, DT = HD / 16;
+    // the relative-position-bias gradient (56 accumulator registers) exists for the windowed Swin models only: head_dim 64 is the
+    // monolithic ViT, which has no bias table -- dbias_ws is left untouched there
+    constexpr bool WANT_DB = HD == 32;
     constexpr int TILE = 16 * LDQ;  // one [16][LDQ] image
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const BigTables tb = carve_tables(smem_raw);
@@ -408,9 +416,9 @@ __global__ __launch_bounds__(DQ4_WAVES * 64) void attn_big_bwd_dq4_kernel(
     const T* src = qkv + h * HD;
     const float* bias_h = bias_frag + (long)h * (NT * NT * 256);
 
-    f32x4 db[NT];
+    f32x4 db[WANT_DB ? NT : 1];
 #pragma unroll
-    for (int i = 0; i < NT; ++i) db[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < (WANT_DB ? NT : 1); ++i) db[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int iters = (Bw + parts - 1) / parts;
     for (int it = 0; it < iters; ++it) {
@@ -424,8 +432,8 @@ __global__ __launch_bounds__(DQ4_WAVES * 64) void attn_big_bwd_dq4_kernel(
         __syncthreads();
         float lq;
         {
-            SlotStage<T, NPB, DQ4_WAVES * 64> sk, sv;
-            SlotStage<T, 16, 64> sq, so, sf;
+            SlotStage<T, NPB, DQ4_WAVES * 64, HD> sk, sv;
+            SlotStage<T, 16, 64, HD> sq, so, sf;
             sk.load(src + C, 3L * C, tb.tok, tok_base, 0, N, qkv_bias + C + h * HD, threadIdx.x);
             sv.load(src + 2 * C, 3L * C, tb.tok, tok_base, 0, N, qkv_bias + 2 * C + h * HD, threadIdx.x);
             sq.load(src, 3L * C, tb.tok, tok_base, q0, N, qkv_bias + h * HD, lane);
@@ -439,29 +447,31 @@ __global__ __launch_bounds__(DQ4_WAVES * 64) void attn_big_bwd_dq4_kernel(
             sf.store(Fs, 1.f, lane);
         }
         __syncthreads();
-        const Frag<T> qf = frag_kc<T>(Qs, LDQ, 0, 0, c, g);
-        const Frag<T> of = frag_kc<T>(Os, LDQ, 0, 0, c, g);
+        Frag<T> qf[KS], of[KS];
         const int rq = masked ? ((tb.pk[q0 + c] >> 16) & 0xff) : 0;
         float d = 0.f;
-        {
-            const Frag<T> ff = frag_kc<T>(Fs, LDQ, 0, 0, c, g);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) d += (float)of.v[e] * (float)ff.v[e];
-            d += __shfl_xor(d, 16, 64);
-            d += __shfl_xor(d, 32, 64);
+        for (int ks = 0; ks < KS; ++ks) {
+            qf[ks] = frag_kc<T>(Qs, LDQ, 0, 32 * ks, c, g);
+            of[ks] = frag_kc<T>(Os, LDQ, 0, 32 * ks, c, g);
+            const Frag<T> ff = frag_kc<T>(Fs, LDQ, 0, 32 * ks, c, g);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) d += (float)of[ks].v[e] * (float)ff.v[e];
         }
+        d += __shfl_xor(d, 16, 64);
+        d += __shfl_xor(d, 32, 64);
         // P^T tiles of this query tile (rows = keys) from the saved log-sum-exp
         f32x4 pj[NT];
 #pragma unroll
         for (int i = 0; i < NT; ++i) {
-            const Frag<T> kf = frag_kc<T>(Ks, LDQ, 16 * i, 0, c, g);
             f32x4 b = *reinterpret_cast<const f32x4*>(bias_h + ((i * NT + (q0 >> 4)) * 64 + lane) * 4);
             if (masked) {
                 const i32x4 pk4 = *reinterpret_cast<const i32x4*>(tb.pk + 16 * i + 4 * g);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) b[r] += (((pk4[r] >> 16) & 0xff) != rq) ? -100.f : 0.f;
             }
-            mma(kf, qf, b);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) mma(frag_kc<T>(Ks, LDQ, 16 * i, 32 * ks, c, g), qf[ks], b);
 #pragma unroll
             for (int r = 0; r < 4; ++r) b[r] = __expf(b[r] - lq);
             pj[i] = b;
@@ -474,29 +484,29 @@ __global__ __launch_bounds__(DQ4_WAVES * 64) void attn_big_bwd_dq4_kernel(
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const int i = 2 * ks + u;
-                const Frag<T> vf = frag_kc<T>(Vs, LDQ, 16 * i, 0, c, g);
                 f32x4 dp = {0.f, 0.f, 0.f, 0.f};
-                mma(vf, of, dp);
+#pragma unroll
+                for (int kd = 0; kd < KS; ++kd) mma(frag_kc<T>(Vs, LDQ, 16 * i, 32 * kd, c, g), of[kd], dp);
                 ds2[u] = pj[i] * (dp - d);
-                if (active) db[i] += ds2[u];
+                if constexpr (WANT_DB) {
+                    if (active) db[i] += ds2[u];
+                }
             }
             sfr[ks] = frag_p_regs<T>(ds2[0], ds2[1]);
         }
-        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        f32x4 acc[DT];
 #pragma unroll
-        for (int ks = 0; ks < NPB / 32; ++ks) {
-            const Frag<T> k0 = frag_v_perm<T>(Ks, LDQ, 0, ks, c, g);
-            const Frag<T> k1 = frag_v_perm<T>(Ks, LDQ, 16, ks, c, g);
-            mma(sfr[ks], k0, acc0);
-            mma(sfr[ks], k1, acc1);
-        }
+        for (int j = 0; j < DT; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < NPB / 32; ++ks)
+#pragma unroll
+            for (int j = 0; j < DT; ++j) mma(sfr[ks], frag_v_perm<T>(Ks, LDQ, 16 * j, ks, c, g), acc[j]);
         // dQ rows: transpose through the wave's Q image, one 16-byte row piece per lane
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            Qs[(4 * g + r) * LDQ + c] = from_f32<T>(acc0[r] * scale);
-            Qs[(4 * g + r) * LDQ + 16 + c] = from_f32<T>(acc1[r] * scale);
-        }
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int j = 0; j < DT; ++j) Qs[(4 * g + r) * LDQ + 16 * j + c] = from_f32<T>(acc[j][r] * scale);
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int i = 0; i < (16 * VPR + 63) / 64; ++i) {
@@ -509,21 +519,22 @@ __global__ __launch_bounds__(DQ4_WAVES * 64) void attn_big_bwd_dq4_kernel(
             }
         }
     }
-    if (wave_ok) {
+    if (WANT_DB && wave_ok) {
         // frag layout of the NPB x NPB bias gradient: ((ki*NT + qj)*64 + lane)*4 + r
         float* wsp = dbias_ws + ((long)part * nH + h) * (NT * NT * 256);
 #pragma unroll
-        for (int i = 0; i < NT; ++i) *reinterpret_cast<f32x4*>(wsp + ((i * NT + qt) * 64 + lane) * 4) = db[i];
+        for (int i = 0; i < (WANT_DB ? NT : 0); ++i) *reinterpret_cast<f32x4*>(wsp + ((i * NT + qt) * 64 + lane) * 4) = db[WANT_DB ? i : 0];
     }
 }
 
-template <typename T>
-__global__ __launch_bounds__(BigCfg<T>::WAVES * 64, sizeof(T) == 2 ? 2 : 1) void attn_big_bwd_dkv2_kernel(
+template <typename T, int HD>
+__global__ __launch_bounds__((BigCfg<T, HD>::WAVES * 64), ((sizeof(T) == 2 && HD == 32) ? 2 : 1)) void attn_big_bwd_dkv2_kernel(
     const T* __restrict__ qkv, const float* __restrict__ qkv_bias, const int* __restrict__ win2tok, int L, const T* __restrict__ dout,
     const T* __restrict__ fout, const float* __restrict__ lse_in, const float* __restrict__ bias_frag_s, int ws,
     const int* __restrict__ region_ids, int nW, int Bw, int N, int nH, float scale, T* __restrict__ dqkv, float* __restrict__ dpad_ws) {
-    using Cfg = BigCfg<T>;
+    using Cfg = BigCfg<T, HD>;
     constexpr int LDQ = Cfg::LDQ, WAVES = Cfg::WAVES;
+    constexpr int KS = HD / 32, DT = HD / 16;
     constexpr int PASSES = (NQB + WAVES - 1) / WAVES;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const BigTables tb = carve_tables(smem_raw);
@@ -544,9 +555,9 @@ __global__ __launch_bounds__(BigCfg<T>::WAVES * 64, sizeof(T) == 2 ? 2 : 1) void
 
     load_window_tables(tb, win2tok, region_ids, bw % nW, N, ws, true);
     __syncthreads();
-    SlotStage<T, 32, 64> sk, sv;
+    SlotStage<T, 32, 64, HD> sk, sv;
     {
-        SlotStage<T, NPB, WAVES * 64> sq, so;
+        SlotStage<T, NPB, WAVES * 64, HD> sq, so;
         sq.load(src, 3L * C, tb.tok, tok_base, 0, N, qkv_bias + h * HD, threadIdx.x);
         so.load(dout + h * HD, (long)C, tb.tok, tok_base, 0, N, nullptr, threadIdx.x);
         sk.load(src + C, 3L * C, tb.tok, tok_base, 32 * wave, N, qkv_bias + C + h * HD, lane);
@@ -592,12 +603,14 @@ __global__ __launch_bounds__(BigCfg<T>::WAVES * 64, sizeof(T) == 2 ? 2 : 1) void
             sv.store(Vb, 1.f, lane);
             __builtin_amdgcn_wave_barrier();
         }
-        Frag<T> kf[2], vf[2];
+        Frag<T> kf[2][KS], vf[2][KS];
 #pragma unroll
-        for (int a = 0; a < 2; ++a) {
-            kf[a] = frag_kc<T>(Kb, LDQ, 16 * a, 0, c, g);
-            vf[a] = frag_kc<T>(Vb, LDQ, 16 * a, 0, c, g);
-        }
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int kd = 0; kd < KS; ++kd) {
+                kf[a][kd] = frag_kc<T>(Kb, LDQ, 16 * a, 32 * kd, c, g);
+                vf[a][kd] = frag_kc<T>(Vb, LDQ, 16 * a, 32 * kd, c, g);
+            }
         if (pass + 1 < PASSES) {  // next pass's key / value rows travel while this pass computes
             const int kn = wave + (pass + 1) * WAVES;
             const int kn0 = kn < NQB ? 32 * kn : 0;
@@ -613,7 +626,9 @@ __global__ __launch_bounds__(BigCfg<T>::WAVES * 64, sizeof(T) == 2 ? 2 : 1) void
         f32x4 p[2][NT];
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
-            const Frag<T> qf = frag_kc<T>(Qs, LDQ, 16 * j, 0, c, g);
+            Frag<T> qf[KS];
+#pragma unroll
+            for (int kd = 0; kd < KS; ++kd) qf[kd] = frag_kc<T>(Qs, LDQ, 16 * j, 32 * kd, c, g);
             const f32x4 l4 = *reinterpret_cast<const f32x4*>(tb.lse + 16 * j + 4 * g);
             const i32x4 pk4 = *reinterpret_cast<const i32x4*>(tb.pk + 16 * j + 4 * g);
 #pragma unroll
@@ -623,7 +638,8 @@ __global__ __launch_bounds__(BigCfg<T>::WAVES * 64, sizeof(T) == 2 ? 2 : 1) void
 #pragma unroll
                     for (int r = 0; r < 4; ++r) b[r] += (((pk4[r] >> 16) & 0xff) != rkey[a]) ? -100.f : 0.f;
                 }
-                mma(qf, kf[a], b);
+#pragma unroll
+                for (int kd = 0; kd < KS; ++kd) mma(qf[kd], kf[a][kd], b);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) b[r] = (16 * j + 4 * g + r < N) ? __expf(b[r] - l4[r]) : 0.f;  // padded queries carry no gradient
                 p[a][j] = b;
@@ -631,57 +647,60 @@ __global__ __launch_bounds__(BigCfg<T>::WAVES * 64, sizeof(T) == 2 ? 2 : 1) void
         }
         // dV[key][d] = sum_q P[q][key] dO[q][d]
         {
-            f32x4 av[2][2];
+            f32x4 av[2][DT];
 #pragma unroll
-            for (int a = 0; a < 2; ++a) {
-                av[a][0] = f32x4{0.f, 0.f, 0.f, 0.f};
-                av[a][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-            }
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int j = 0; j < DT; ++j) av[a][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < NPB / 32; ++ks) {
-                const Frag<T> o0 = frag_v_perm<T>(Os, LDQ, 0, ks, c, g);
-                const Frag<T> o1 = frag_v_perm<T>(Os, LDQ, 16, ks, c, g);
+                Frag<T> pf[2];
 #pragma unroll
-                for (int a = 0; a < 2; ++a) {
-                    const Frag<T> pf = frag_p_regs<T>(p[a][2 * ks], p[a][2 * ks + 1]);
-                    mma(pf, o0, av[a][0]);
-                    mma(pf, o1, av[a][1]);
+                for (int a = 0; a < 2; ++a) pf[a] = frag_p_regs<T>(p[a][2 * ks], p[a][2 * ks + 1]);
+#pragma unroll
+                for (int j = 0; j < DT; ++j) {
+                    const Frag<T> oj = frag_v_perm<T>(Os, LDQ, 16 * j, ks, c, g);
+#pragma unroll
+                    for (int a = 0; a < 2; ++a) mma(pf[a], oj, av[a][j]);
                 }
             }
-            store_block_rows_vec<T>(av, 1.f, Kb, dqkv + 2 * C + h * HD, 3L * C, tb.tok, tok_base, k0, N, valid, padv, lane, c, g);
+            store_block_rows_vec<T, HD>(av, 1.f, Kb, dqkv + 2 * C + h * HD, 3L * C, tb.tok, tok_base, k0, N, valid, padv, lane, c, g);
         }
         // dS = P o (dP - delta), dP[q][key] = sum_d dO[q][d] V[key][d]; dS overwrites P
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
-            const Frag<T> of = frag_kc<T>(Os, LDQ, 16 * j, 0, c, g);
+            Frag<T> of[KS];
+#pragma unroll
+            for (int kd = 0; kd < KS; ++kd) of[kd] = frag_kc<T>(Os, LDQ, 16 * j, 32 * kd, c, g);
             const f32x4 dl4 = *reinterpret_cast<const f32x4*>(tb.delta + 16 * j + 4 * g);
 #pragma unroll
             for (int a = 0; a < 2; ++a) {
                 f32x4 dp = {0.f, 0.f, 0.f, 0.f};
-                mma(of, vf[a], dp);
+#pragma unroll
+                for (int kd = 0; kd < KS; ++kd) mma(of[kd], vf[a][kd], dp);
                 p[a][j] = p[a][j] * (dp - dl4);
             }
         }
         // dK[key][d] = sum_q dS[q][key] (scale q)[q][d]
         {
-            f32x4 ak[2][2];
+            f32x4 ak[2][DT];
 #pragma unroll
-            for (int a = 0; a < 2; ++a) {
-                ak[a][0] = f32x4{0.f, 0.f, 0.f, 0.f};
-                ak[a][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-            }
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int j = 0; j < DT; ++j) ak[a][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < NPB / 32; ++ks) {
-                const Frag<T> q0f = frag_v_perm<T>(Qs, LDQ, 0, ks, c, g);
-                const Frag<T> q1f = frag_v_perm<T>(Qs, LDQ, 16, ks, c, g);
+                Frag<T> sf[2];
 #pragma unroll
-                for (int a = 0; a < 2; ++a) {
-                    const Frag<T> sf = frag_p_regs<T>(p[a][2 * ks], p[a][2 * ks + 1]);
-                    mma(sf, q0f, ak[a][0]);
-                    mma(sf, q1f, ak[a][1]);
+                for (int a = 0; a < 2; ++a) sf[a] = frag_p_regs<T>(p[a][2 * ks], p[a][2 * ks + 1]);
+#pragma unroll
+                for (int j = 0; j < DT; ++j) {
+                    const Frag<T> qj = frag_v_perm<T>(Qs, LDQ, 16 * j, ks, c, g);
+#pragma unroll
+                    for (int a = 0; a < 2; ++a) mma(sf[a], qj, ak[a][j]);
                 }
             }
-            store_block_rows_vec<T>(ak, 1.f, Kb, dqkv + C + h * HD, 3L * C, tb.tok, tok_base, k0, N, valid, padk, lane, c, g);
+            store_block_rows_vec<T, HD>(ak, 1.f, Kb, dqkv + C + h * HD, 3L * C, tb.tok, tok_base, k0, N, valid, padk, lane, c, g);
         }
     }
     // lanes with equal dv = lane % VPR hold partial sums of the same VEC columns
@@ -715,19 +734,19 @@ __global__ void relpos_bias_bwd_big_kernel(const float* __restrict__ ws, const l
     atomicAdd(dtable + index[qk] * nH + h, ws[(long)h * (NT * NT * 256) + (f * 64 + lane) * 4 + r]);
 }
 
-template <typename T>
+template <typename T, int HD>
 size_t fwd3_lds() {
-    using Cfg = BigCfg<T>;
+    using Cfg = BigCfg<T, HD>;
     return Cfg::TABLE_BYTES + (size_t)(2 * Cfg::FULL + FWD3_WAVES * 16 * Cfg::LDQ) * sizeof(T);
 }
-template <typename T>
+template <typename T, int HD>
 size_t dq4_lds() {
-    using Cfg = BigCfg<T>;
+    using Cfg = BigCfg<T, HD>;
     return Cfg::TABLE_BYTES + (size_t)(2 * Cfg::FULL + DQ4_WAVES * 3 * 16 * Cfg::LDQ) * sizeof(T);
 }
-template <typename T>
+template <typename T, int HD>
 size_t dkv2_lds() {
-    using Cfg = BigCfg<T>;
+    using Cfg = BigCfg<T, HD>;
     return Cfg::TABLE_BYTES + (size_t)(2 * Cfg::FULL + Cfg::WAVES * 2 * Cfg::BLK) * sizeof(T);
 }
 
@@ -755,18 +774,18 @@ static int fill_bias_frag_big(const float* rel_table, int ws, int N, int nH, flo
     return ESVIT_OK;
 }
 
-template <typename T>
+template <typename T, int HD>
 static int big_fwd_launch(const void* qkv, const float* qkv_bias, const int32_t* win2tok, int L, const float* rel_table, int ws,
                           const int32_t* region_ids, int nW, int Bw, int N, int nH, float scale, void* out, float* lse, float* attn_out,
                           hipStream_t stream) {
-    const size_t lds = fwd3_lds<T>();
+    const size_t lds = fwd3_lds<T, HD>();
     if (attn_out) {
-        auto kern = attn_big_fwd3_kernel<T, true>;
+        auto kern = attn_big_fwd3_kernel<T, true, HD>;
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(kern, dim3(Bw * nH), dim3(FWD3_WAVES * 64), lds, stream, (const T*)qkv, qkv_bias, win2tok, L, rel_table, ws,
                            region_ids, nW, Bw, N, nH, scale, (T*)out, lse, attn_out);
     } else {
-        auto kern = attn_big_fwd3_kernel<T, false>;
+        auto kern = attn_big_fwd3_kernel<T, false, HD>;
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(kern, dim3(Bw * nH), dim3(FWD3_WAVES * 64), lds, stream, (const T*)qkv, qkv_bias, win2tok, L, rel_table, ws,
                            region_ids, nW, Bw, N, nH, scale, (T*)out, lse, attn_out);
@@ -776,37 +795,40 @@ static int big_fwd_launch(const void* qkv, const float* qkv_bias, const int32_t*
 }
 
 int esvit_big_attn_fwd(int dtype, const void* qkv, const float* qkv_bias, const int32_t* win2tok, int L, const float* rel_table, int ws,
-                       float* bias_frag_ws, const int32_t* region_ids, int nW, int nB, int N, int nH, float scale, void* out, float* lse,
+                       float* bias_frag_ws, const int32_t* region_ids, int nW, int nB, int N, int nH, int hd, float scale, void* out, float* lse,
                        float* attn_out, hipStream_t stream) {
     ESVIT_CHECK_ARG(N <= NPB, "window_attn: window %d too large", ws);
+    ESVIT_CHECK_ARG(hd == 32 || (hd == 64 && dtype == ESVIT_BF16), "window_attn: %d tokens at head_dim %d: 32, or 64 in bf16", N, hd);
     ESVIT_CHECK_ARG(bias_frag_ws != nullptr, "esvit_window_attn_fwd: the bias_frag_ws scratch is required");
     {
         int rc = rel_table ? fill_bias_frag_big(rel_table, ws, N, nH, bias_frag_ws, stream) : ESVIT_OK;
         if (rc != ESVIT_OK) return rc;
     }
     const int Bw = nB * nW;
+    if (hd == 64)
+        return big_fwd_launch<bf16, 64>(qkv, qkv_bias, win2tok, L, bias_frag_ws, ws, region_ids, nW, Bw, N, nH, scale, out, lse, attn_out, stream);
     if (dtype == ESVIT_BF16)
-        return big_fwd_launch<bf16>(qkv, qkv_bias, win2tok, L, bias_frag_ws, ws, region_ids, nW, Bw, N, nH, scale, out, lse, attn_out, stream);
-    return big_fwd_launch<float>(qkv, qkv_bias, win2tok, L, bias_frag_ws, ws, region_ids, nW, Bw, N, nH, scale, out, lse, attn_out, stream);
+        return big_fwd_launch<bf16, 32>(qkv, qkv_bias, win2tok, L, bias_frag_ws, ws, region_ids, nW, Bw, N, nH, scale, out, lse, attn_out, stream);
+    return big_fwd_launch<float, 32>(qkv, qkv_bias, win2tok, L, bias_frag_ws, ws, region_ids, nW, Bw, N, nH, scale, out, lse, attn_out, stream);
 }
 
-template <typename T>
+template <typename T, int HD>
 static int big_bwd_launch(const void* qkv, const float* qkv_bias, const int32_t* win2tok, int L, const void* dout, const void* fout,
                           const float* lse, const float* rel_table, int ws, const int32_t* region_ids, int nW, int Bw, int N,
                           int nH, float scale, void* dqkv, float* dbias_ws, float* dpad_ws, hipStream_t stream) {
-    using Cfg = BigCfg<T>;
+    using Cfg = BigCfg<T, HD>;
     const int parts = big_parts(Bw, nH);
     {
-        auto kern = attn_big_bwd_dq4_kernel<T>;
-        const size_t lds = dq4_lds<T>();
+        auto kern = attn_big_bwd_dq4_kernel<T, HD>;
+        const size_t lds = dq4_lds<T, HD>();
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(kern, dim3(parts * nH * DQ4_GROUPS), dim3(DQ4_WAVES * 64), lds, stream, (const T*)qkv, qkv_bias, win2tok, L,
                            (const T*)dout, (const T*)fout, lse, rel_table, ws, region_ids, nW, Bw, N, nH, scale, parts, (T*)dqkv, dbias_ws);
         ESVIT_CHECK_LAUNCH("window_attn_bwd(14x14, dQ)");
     }
     {
-        auto kern = attn_big_bwd_dkv2_kernel<T>;
-        const size_t lds = dkv2_lds<T>();
+        auto kern = attn_big_bwd_dkv2_kernel<T, HD>;
+        const size_t lds = dkv2_lds<T, HD>();
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(kern, dim3(Bw * nH), dim3(Cfg::WAVES * 64), lds, stream, (const T*)qkv, qkv_bias, win2tok, L, (const T*)dout,
                            (const T*)fout, lse, rel_table + (long)nH * NT * NT * 256, ws, region_ids, nW, Bw, N, nH, scale, (T*)dqkv, dpad_ws);
@@ -817,8 +839,9 @@ static int big_bwd_launch(const void* qkv, const float* qkv_bias, const int32_t*
 
 int esvit_big_attn_bwd(int dtype, const void* qkv, const float* qkv_bias, const int32_t* win2tok, int L, const void* dout,
                        const void* fout, const float* lse, const float* rel_table_, int ws, float* bias_frag_ws, const int32_t* region_ids,
-                       int nW, int nB, int N, int nH, float scale, void* dqkv, float* dbias_ws, float* dpad_ws, hipStream_t stream) {
+                       int nW, int nB, int N, int nH, int hd, float scale, void* dqkv, float* dbias_ws, float* dpad_ws, hipStream_t stream) {
     ESVIT_CHECK_ARG(N <= NPB, "window_attn: window %d too large", ws);
+    ESVIT_CHECK_ARG(hd == 32 || (hd == 64 && dtype == ESVIT_BF16), "window_attn: %d tokens at head_dim %d: 32, or 64 in bf16", N, hd);
     ESVIT_CHECK_ARG(fout && lse, "esvit_window_attn_bwd: 14x14 windows need the forward output and log-sum-exp");
     ESVIT_CHECK_ARG(bias_frag_ws != nullptr, "esvit_window_attn_bwd: the bias_frag_ws scratch is required");
     {
@@ -827,11 +850,14 @@ int esvit_big_attn_bwd(int dtype, const void* qkv, const float* qkv_bias, const 
     }
     const float* rel_table = bias_frag_ws;  // the kernels read the frag-layout bias
     const int Bw = nB * nW;
+    if (hd == 64)
+        return big_bwd_launch<bf16, 64>(qkv, qkv_bias, win2tok, L, dout, fout, lse, rel_table, ws, region_ids, nW, Bw, N, nH, scale, dqkv, dbias_ws,
+                                        dpad_ws, stream);
     if (dtype == ESVIT_BF16)
-        return big_bwd_launch<bf16>(qkv, qkv_bias, win2tok, L, dout, fout, lse, rel_table, ws, region_ids, nW, Bw, N, nH, scale, dqkv, dbias_ws,
-                                    dpad_ws, stream);
-    return big_bwd_launch<float>(qkv, qkv_bias, win2tok, L, dout, fout, lse, rel_table, ws, region_ids, nW, Bw, N, nH, scale, dqkv, dbias_ws,
-                                 dpad_ws, stream);
+        return big_bwd_launch<bf16, 32>(qkv, qkv_bias, win2tok, L, dout, fout, lse, rel_table, ws, region_ids, nW, Bw, N, nH, scale, dqkv, dbias_ws,
+                                        dpad_ws, stream);
+    return big_bwd_launch<float, 32>(qkv, qkv_bias, win2tok, L, dout, fout, lse, rel_table, ws, region_ids, nW, Bw, N, nH, scale, dqkv, dbias_ws,
+                                     dpad_ws, stream);
 }
 
 int esvit_big_relpos_bias_bwd(const float* dbias_ws, int parts, const int64_t* index, int N, int nH, int table_rows, float* dtable,

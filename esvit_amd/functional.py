@@ -918,13 +918,13 @@ class VitPatchEmbedFn(torch.autograd.Function):
         return None, dW.view(ctx.wshape), dbp, None
 
 
-VIT_WINDOW_TOKENS = 64  # crops of at most this many tokens run through the fused windowed kernels (one "window" per image)
+VIT_WINDOW_TOKENS = 224  # crops of at most this many tokens run through the fused windowed kernels (one "window" per image)
 _VIT_WIN = {}
 
 
 def _vit_window(N, nH, device):
-    """the geometry a crop of N <= 64 tokens presents to window_attn.hip: one window per image holding tokens 0..N-1, no bias (a
-    zero table over the smallest grid that has N positions), no shift mask"""
+    """the geometry a crop of N tokens presents to the windowed kernels: one window per image holding tokens 0..N-1, no bias (a zero
+    table over the smallest grid that has N positions -- the kernels mask the slots beyond N), no shift mask"""
     key = (N, nH, str(device))
     g = _VIT_WIN.get(key)
     if g is None:
@@ -936,24 +936,35 @@ def _vit_window(N, nH, device):
     return g
 
 
+def _vit_fused_route(N, hd, dtype):
+    """window_attn.hip takes <= 64 tokens at head_dim 32 / 64; window_attn_big.hip <= 224 tokens at head_dim 32, or 64 in bf16"""
+    if N <= 64:
+        return hd in (32, 64)
+    return N <= VIT_WINDOW_TOKENS and (hd == 32 or (hd == 64 and dtype == torch.bfloat16))
+
+
 def vit_attention(o, qkv, bqkv, nB, N, nH, scale, save):
-    """Attention.forward between the projections (vision_transformer.py:76-83) -> (out, tensors for vit_attention_bwd).  The 37 tokens
-    of a 96^2 crop fit ONE 64-slot window of the fused kernels of window_attn.hip (no score matrix in HBM, 2 launches instead of 11);
-    the 197 tokens of a 224^2 crop take the batched-GEMM route of ops.vit_attn_fwd."""
+    """Attention.forward between the projections (vision_transformer.py:76-83) -> (out, tensors for vit_attention_bwd).  A crop is ONE
+    window of the fused MFMA kernels: the 37 tokens of a 96^2 crop in the 64-slot kernels of window_attn.hip, the 197 tokens of a
+    224^2 crop in the 224-slot flash-style kernels of window_attn_big.hip (head_dim 64 in bf16) -- no score matrix in HBM.  What
+    does not fit (fp32 parity mode at head_dim 64, longer sequences) takes the batched-GEMM route of ops.vit_attn_fwd."""
     hd = qkv.shape[1] // 3 // nH
-    if N <= VIT_WINDOW_TOKENS and hd in (32, 64):
+    if _vit_fused_route(N, hd, qkv.dtype):
         win2tok, ws, table = _vit_window(N, nH, qkv.device)
         frag = o.new_bias_frag(nH, N, qkv.device) if save else None
-        ao, _ = o.window_attn_fwd(qkv, bqkv, win2tok, N, table, ws, None, 1, N, nH, scale, bias_frag=frag)
-        return ao, ((qkv, ao, frag) if save else ())
+        ao, lse = o.window_attn_fwd(qkv, bqkv, win2tok, N, table, ws, None, 1, N, nH, scale, bias_frag=frag)
+        if not save:
+            return ao, ()
+        return ao, ((qkv, ao, frag) if lse is None else (qkv, ao, frag, lse))
     return o.vit_attn_fwd(qkv, nB, N, nH, scale)
 
 
 def vit_attention_bwd(o, dao, att, bqkv, nB, N, nH, scale):
-    if len(att) == 3:  # the windowed route: (qkv, out, bias fragments)
-        qkv, ao, frag = att
+    if len(att) >= 3:  # the windowed routes: (qkv, out, bias fragments[, log-sum-exp of the 224-slot kernels])
+        qkv, ao, frag = att[:3]
+        lse = att[3] if len(att) == 4 else None
         win2tok, ws, _ = _vit_window(N, nH, qkv.device)
-        return o.window_attn_bwd(qkv, bqkv, win2tok, N, dao, ao, None, None, ws, None, 1, N, nH, scale, bias_frag=frag)[0]
+        return o.window_attn_bwd(qkv, bqkv, win2tok, N, dao, ao, lse, None, ws, None, 1, N, nH, scale, bias_frag=frag)[0]
     return o.vit_attn_bwd(dao, att, nB, N, nH, scale)
 
 

@@ -170,8 +170,36 @@ def test_small_crops_through_the_windowed_kernels(dt, shape, lib_built):
     tol = 2e-5 if dt == torch.float32 else 2e-2
     _close("attention output (windowed route)", o, o_ref, tol)
     _close("d qkv (windowed route)", d, d_ref, tol * 2)
-    big = Fn.vit_attention(ops, torch.randn(2 * 65, 3 * C).to(dt).cuda(), bqkv.cuda(), 2, 65, nH, hd ** -0.5, True)[1]
-    assert len(big) == 2                                        # 65 tokens: the batched-GEMM route
+    long_seq = Fn.vit_attention(ops, torch.randn(2 * 230, 3 * C).to(dt).cuda(), bqkv.cuda(), 2, 230, nH, hd ** -0.5, True)[1]
+    assert len(long_seq) == 2                                   # 230 tokens: beyond the windowed kernels, the batched-GEMM route
+
+
+@pytest.mark.parametrize("shape", [(3, 197, 6, 64), (2, 197, 3, 64), (5, 197, 12, 64), (2, 145, 2, 64), (2, 224, 1, 64), (2, 100, 4, 32), (3, 65, 6, 64)])
+def test_large_crops_through_the_flash_kernels(shape, lib_built):
+    """the 197 tokens of a 224^2 crop as ONE window of the 224-slot kernels of window_attn_big.hip (head_dim 64 instances, bf16, zero
+    bias table over a 15 x 15 grid): same result as the plain attention restatement, forward and backward"""
+    import esvit_amd.functional as Fn
+    from esvit_amd import ops
+    B, N, nH, hd = shape
+    C = nH * hd
+    dt = torch.bfloat16
+    g = torch.Generator().manual_seed(3 + sum(shape))
+    qkv = torch.randn(B * N, 3 * C, generator=g).to(dt)
+    dout = torch.randn(B * N, C, generator=g).to(dt)
+    bqkv = torch.zeros(3 * C)
+    ops_ref.set_act_dtype(dt)
+    try:
+        o_ref, saved = ops_ref.vit_attn_fwd(qkv, B, N, nH, hd ** -0.5)
+        d_ref = ops_ref.vit_attn_bwd(dout, saved, B, N, nH, hd ** -0.5)
+    finally:
+        ops_ref.set_act_dtype(torch.float32)
+    o, att = Fn.vit_attention(ops, qkv.cuda(), bqkv.cuda(), B, N, nH, hd ** -0.5, True)
+    assert len(att) == 4                                        # (qkv, out, bias fragments, log-sum-exp): the 224-slot kernels
+    d = Fn.vit_attention_bwd(ops, dout.cuda(), att, bqkv.cuda(), B, N, nH, hd ** -0.5)
+    _close("attention output (224-slot kernels)", o, o_ref, 2e-2)
+    _close("d qkv (224-slot kernels)", d, d_ref, 4e-2)
+    if hd == 64:  # fp32 parity mode at head_dim 64 does not fit them: the batched-GEMM route
+        assert len(Fn.vit_attention(ops, qkv.float().cuda(), bqkv.cuda(), B, N, nH, hd ** -0.5, True)[1]) == 2
 
 
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
