@@ -1,5 +1,6 @@
-// Window attention for 14x14 windows (N = 196 tokens, head_dim 32): the W=14 configurations of the reference
-// (swin_*_patch4_window14_224.yaml).  Same mathematics and token-ordered I/O as window_attn.hip,
+// Window attention for up to 224 tokens per window: the 14x14 windows (N = 196, head_dim 32) of the W=14 configurations of the reference
+// (swin_*_patch4_window14_224.yaml) and, as the head_dim-64 instances, the 197 tokens of a 224^2 crop of the
+// monolithic ViTs (one "window" per image, zero bias table).  Same mathematics and token-ordered I/O as window_attn.hip,
 // but a 196x196 score tile does not fit one wave's registers, so the work is blocked flash-style:
 //
 //   forward        one workgroup per (window, head): K, V staged once in LDS; every wave owns 32-query blocks, forms
