@@ -58,10 +58,13 @@ class Block(nn.Module):
         f1, f2 = self.drop_path.factors(nB, device), self.drop_path.factors(nB, device)  # one draw per residual branch, :114-115
         return None if f1 is None else (f1, f2)
 
-    def forward(self, x, return_attention=False):
+    def forward(self, x, return_attention=False, dp=False):
+        """dp: the DropPath factors of the two residual branches, drawn by VisionTransformer for all blocks at once; False = draw here"""
         if return_attention:
             return Fn.vit_block_attention(x, self.attn.num_heads, self._params())
-        return Fn.vit_block(x, self.attn.num_heads, self._dp(x.shape[0], x.device), self._params())
+        if dp is False:
+            dp = self._dp(x.shape[0], x.device)
+        return Fn.vit_block(x, self.attn.num_heads, dp, self._params())
 
     def forward_fea_and_attn(self, x):
         return self.forward(x), Fn.vit_block_attention(x, self.attn.num_heads, self._params())
@@ -141,11 +144,27 @@ class VisionTransformer(nn.Module):
     def _normed(self, x):
         return Fn.FinalNormFn.apply(x, self.norm.weight, self.norm.bias)
 
+    def _drop_path_factors(self, B, device):
+        """stochastic depth (vision_transformer.py:30-38) for every block and both residual branches in ONE draw: [depth, 2, B]
+        factors floor(keep + u) / keep (four launches per pass instead of 4 x 2 x depth)"""
+        if not self.training:
+            return None
+        rates = [blk.drop_path.drop_prob if isinstance(blk.drop_path, DropPath) else 0.0 for blk in self.blocks]
+        if not any(rates):
+            return None
+        keep = self.__dict__.get("_keep")
+        if keep is None or keep.device != device:
+            keep = self.__dict__["_keep"] = (1.0 - torch.tensor(rates, dtype=torch.float32, device=device)).view(-1, 1, 1)
+        return (keep + torch.rand(len(rates), 2, B, device=device)).floor_().div_(keep)
+
+    def _run_blocks(self, x):
+        f = self._drop_path_factors(x.shape[0], x.device)
+        for i, blk in enumerate(self.blocks):
+            x = blk(x, dp=None if f is None else (f[i, 0], f[i, 1]))
+        return x
+
     def forward_feature_maps(self, x):
-        x = self._tokens(x)
-        for blk in self.blocks:
-            x = blk(x)
-        return self._normed(x)
+        return self._normed(self._run_blocks(self._tokens(x)))
 
     def forward_features(self, x):
         x = self.forward_feature_maps(x)
