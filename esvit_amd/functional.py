@@ -914,7 +914,9 @@ class VitPatchEmbedFn(torch.autograd.Function):
         (cols,) = ctx.saved_tensors
         M = cols.shape[0]
         dyb = o.gather_cast(gx.contiguous().view(M, -1), M)
-        dW, dbp = _wgrad(dyb, cols, ctx.wparam, shape2d=(ctx.wshape[0], cols.shape[1]), want_bias=True, bias_param=ctx.bparam)
+        # (no bucket slots here: the embedding runs once per resolution group, so its parameters receive two contributions per
+        # backward -- autograd sums them and the reducer's hook packs the sum)
+        dW, dbp = o.linear_wgrad(dyb, cols, want_bias=True)
         return None, dW.view(ctx.wshape), dbp, None
 
 
@@ -943,7 +945,7 @@ def _vit_fused_route(N, hd, dtype):
     return N <= VIT_WINDOW_TOKENS and (hd == 32 or (hd == 64 and dtype == torch.bfloat16))
 
 
-def vit_attention(o, qkv, bqkv, nB, N, nH, scale, save):
+def vit_attention(o, qkv, bqkv, nB, N, nH, scale, save, out=None):
     """Attention.forward between the projections (vision_transformer.py:76-83) -> (out, tensors for vit_attention_bwd).  A crop is ONE
     window of the fused MFMA kernels: the 37 tokens of a 96^2 crop in the 64-slot kernels of window_attn.hip, the 197 tokens of a
     224^2 crop in the 224-slot flash-style kernels of window_attn_big.hip (head_dim 64 in bf16) -- no score matrix in HBM.  What
@@ -952,20 +954,28 @@ def vit_attention(o, qkv, bqkv, nB, N, nH, scale, save):
     if _vit_fused_route(N, hd, qkv.dtype):
         win2tok, ws, table = _vit_window(N, nH, qkv.device)
         frag = o.new_bias_frag(nH, N, qkv.device) if save else None
-        ao, lse = o.window_attn_fwd(qkv, bqkv, win2tok, N, table, ws, None, 1, N, nH, scale, bias_frag=frag)
+        ao, lse = o.window_attn_fwd(qkv, bqkv, win2tok, N, table, ws, None, 1, N, nH, scale, out=out, bias_frag=frag)
         if not save:
             return ao, ()
         return ao, ((qkv, ao, frag) if lse is None else (qkv, ao, frag, lse))
-    return o.vit_attn_fwd(qkv, nB, N, nH, scale)
+    ao, att = o.vit_attn_fwd(qkv, nB, N, nH, scale)
+    if out is not None:
+        out.copy_(ao)
+        ao = out
+    return ao, att
 
 
-def vit_attention_bwd(o, dao, att, bqkv, nB, N, nH, scale):
+def vit_attention_bwd(o, dao, att, bqkv, nB, N, nH, scale, dqkv_out=None):
     if len(att) >= 3:  # the windowed routes: (qkv, out, bias fragments[, log-sum-exp of the 224-slot kernels])
         qkv, ao, frag = att[:3]
         lse = att[3] if len(att) == 4 else None
         win2tok, ws, _ = _vit_window(N, nH, qkv.device)
-        return o.window_attn_bwd(qkv, bqkv, win2tok, N, dao, ao, lse, None, ws, None, 1, N, nH, scale, bias_frag=frag)[0]
-    return o.vit_attn_bwd(dao, att, nB, N, nH, scale)
+        return o.window_attn_bwd(qkv, bqkv, win2tok, N, dao, ao, lse, None, ws, None, 1, N, nH, scale, dqkv_out=dqkv_out, bias_frag=frag)[0]
+    dqkv = o.vit_attn_bwd(dao, att, nB, N, nH, scale)
+    if dqkv_out is not None:
+        dqkv_out.copy_(dqkv)
+        dqkv = dqkv_out
+    return dqkv
 
 
 def _vit_block_forward(x, nH, dp, prm, wts, save):
@@ -1055,3 +1065,95 @@ def vit_block_attention(x, nH, prm_list):
     _, att = o.vit_attn_fwd(qkv, nB, N, nH, (C // nH) ** -0.5)  # (evaluation hook: the batched-GEMM route keeps P in memory)
     p = att[-1]
     return p.reshape(nB, nH, p.shape[-2], p.shape[-1])[:, :, :N, :N].float()
+
+
+# ---- ragged multi-crop ViT block: all crops of a step in ONE set of LayerNorm / GEMM launches (cf. SwinBlockMultiFn) ------------
+# LayerNorm, the four GEMMs and the residual adds are row-wise, so the token rows of the 224^2 crops and of the 96^2 crops run
+# through them together; only the attention depends on the crop's token count and is launched once per resolution group on its
+# row range.  Compared with one pass per group (vision_transformer.py:186-233): half the launches, ONE gradient contribution per
+# parameter (no accumulation adds; the data-parallel reducer can overlap), half the split-K partial traffic of the weight gradients.
+def _vit_block_forward_multi(X, segs, nH, dp_rows, prm, wts, save):
+    """X fp32 [M, C]; segs: tuple of (row0, nB, N); dp_rows: None or (per-row DropPath scale of the attention branch [M], MLP branch [M])"""
+    o = ops_module()
+    (g1, b1, bqkv, bproj, g2, b2, bfc1, bfc2) = prm
+    (Wqkv, Wproj, W1, W2) = wts
+    M, C = X.shape
+    scale = (C // nH) ** -0.5
+    dp1, dp2 = (None, None) if dp_rows is None else dp_rows
+    xw, _, mean1, rstd1 = o.layernorm_fwd(X, g1, b1, LN_EPS)
+    qkv = o.linear_fwd(xw, Wqkv, bqkv)
+    ao = torch.empty((M, C), dtype=qkv.dtype, device=X.device)
+    atts = []
+    for (r0, nB, N) in segs:
+        r1 = r0 + nB * N
+        _, att = vit_attention(o, qkv[r0:r1], bqkv, nB, N, nH, scale, save, out=ao[r0:r1])
+        atts.append(att)
+    x1 = o.linear_fwd(ao, Wproj, bproj, residual=X, rowscale=dp1, rows_per_sample=1, out_f32=True)
+    h, _, mean2, rstd2 = o.layernorm_fwd(x1, g2, b2, LN_EPS)
+    if save:
+        a1g, a1 = o.linear_fwd(h, W1, bfc1, gelu=True, want_preact=True)
+    else:
+        a1g, a1 = o.linear_fwd(h, W1, bfc1, gelu=True), None
+    x2 = o.linear_fwd(a1g, W2, bfc2, residual=x1, rowscale=dp2, rows_per_sample=1, out_f32=True)
+    saved = (mean1, rstd1, xw, ao, x1, mean2, rstd2, h, a1, a1g) if save else None
+    return x2, saved, atts
+
+
+class VitBlockMultiFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, X, segs, nH, dp_rows, g1, b1, Wqkv_p, bqkv, Wproj_p, bproj, g2, b2, W1_p, bfc1, W2_p, bfc2):
+        wts = (_weight(Wqkv_p), _weight(Wproj_p), _weight(W1_p), _weight(W2_p))
+        X = X.contiguous()
+        y, saved, atts = _vit_block_forward_multi(X, segs, nH, dp_rows, (g1, b1, bqkv, bproj, g2, b2, bfc1, bfc2), wts, True)
+        ctx.segs, ctx.nH, ctx.dp_rows = segs, nH, dp_rows
+        ctx.wparams = (Wqkv_p, Wproj_p, W1_p, W2_p)
+        ctx.bparams = (bqkv, bproj, bfc1, bfc2)
+        ctx.nparams = (g1, b1, g2, b2)
+        ctx.natt = [len(a) for a in atts]
+        ctx.save_for_backward(X, g1, g2, bqkv, *wts, *saved, *[t for a in atts for t in a])
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        o = ops_module()
+        segs, nH, dp_rows = ctx.segs, ctx.nH, ctx.dp_rows
+        t = ctx.saved_tensors
+        X, g1, g2, bqkv, Wqkv, Wproj, W1, W2, mean1, rstd1, xw, ao, x1, mean2, rstd2, h, a1, a1g = t[:18]
+        flat, atts, at = t[18:], [], 0
+        for n in ctx.natt:
+            atts.append(tuple(flat[at:at + n]))
+            at += n
+        M, C = X.shape
+        scale = (C // nH) ** -0.5
+        dp1, dp2 = (None, None) if dp_rows is None else dp_rows
+        gy = gy.contiguous()
+        Wqkv_p, Wproj_p, W1_p, W2_p = ctx.wparams
+        bqkv_p, bproj_p, bfc1_p, bfc2_p = ctx.bparams
+        g1_p, b1_p, g2_p, b2_p = ctx.nparams
+        dyb = o.gather_cast(gy, M, rowscale=dp2, rows_per_sample=1)
+        dW2, dbfc2 = _wgrad(dyb, a1g, W2_p, want_bias=True, bias_param=bfc2_p)
+        da1 = o.linear_dgrad(dyb, W2, gelu_preact=a1)
+        dW1, dbfc1 = _wgrad(da1, h, W1_p, want_bias=True, bias_param=bfc1_p)
+        dh = o.linear_dgrad(da1, W1)
+        sink1, sink2 = _ln_sinks(g1_p, b1_p), _ln_sinks(g2_p, b2_p)
+        gx1, dyw, dg2, db2 = o.layernorm_bwd_cast(dh, x1, mean2, rstd2, g2, g_in=gy, rowscale=dp1, rows_per_sample=1, gb_out=sink2)
+        dWproj, dbproj = _wgrad(dyw, ao, Wproj_p, want_bias=True, bias_param=bproj_p)
+        dao = o.linear_dgrad(dyw, Wproj)
+        dqkv = torch.empty((M, 3 * C), dtype=dao.dtype, device=dao.device)
+        for (r0, nB, N), att in zip(segs, atts):
+            r1 = r0 + nB * N
+            vit_attention_bwd(o, dao[r0:r1], att, bqkv, nB, N, nH, scale, dqkv_out=dqkv[r0:r1])
+        dWqkv, dbqkv = _wgrad(dqkv, xw, Wqkv_p, want_bias=True, bias_param=bqkv_p)
+        dxw = o.linear_dgrad(dqkv, Wqkv)
+        gx, dg1, db1 = o.layernorm_bwd(dxw, X, mean1, rstd1, g1, g_in=gx1, gb_out=sink1)
+        return (gx, None, None, None, _alias(dg1, sink1), _alias(db1, sink1), dWqkv, dbqkv, dWproj, dbproj,
+                _alias(dg2, sink2), _alias(db2, sink2), dW1, dbfc1, dW2, dbfc2)
+
+
+def vit_block_multi(X, segs, nH, dp_rows, prm_list):
+    """one ViT block over the token rows of several resolution groups; X fp32 [M, C]"""
+    if torch.is_grad_enabled() and (X.requires_grad or any(p.requires_grad for p in prm_list)):
+        return VitBlockMultiFn.apply(X, segs, nH, dp_rows, *prm_list)
+    g1, b1, Wqkv_p, bqkv, Wproj_p, bproj, g2, b2, W1_p, bfc1, W2_p, bfc2 = prm_list
+    wts = (_weight(Wqkv_p), _weight(Wproj_p), _weight(W1_p), _weight(W2_p))
+    return _vit_block_forward_multi(X.contiguous(), segs, nH, dp_rows, (g1, b1, bqkv, bproj, g2, b2, bfc1, bfc2), wts, False)[0]

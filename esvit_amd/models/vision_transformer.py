@@ -170,7 +170,30 @@ class VisionTransformer(nn.Module):
         x = self.forward_feature_maps(x)
         return (x[:, 0], x[:, 1:]) if self.use_dense_prediction else x[:, 0]
 
-    # ---- multi-crop forward (vision_transformer.py:186-233): one backbone pass per run of crops of equal resolution ------
+    # ---- multi-crop forward (vision_transformer.py:186-233) ---------------------------------------------------------------
+    ragged_multi_crop = True  # all resolution groups through one set of LayerNorm / GEMM launches (False: one pass per group)
+
+    def _forward_ragged(self, runs):
+        """every run of equal-resolution crops as token ROWS of one matrix: the row-wise kernels of a block see all crops at once,
+        the attention is launched per run on its row range (functional.VitBlockMultiFn) -> list of normed [B_g, N_g, C]"""
+        toks = [self._tokens(r) for r in runs]
+        C = toks[0].shape[-1]
+        segs, row0 = [], 0
+        for t in toks:
+            segs.append((row0, t.shape[0], t.shape[1]))
+            row0 += t.shape[0] * t.shape[1]
+        X = torch.cat([t.reshape(-1, C) for t in toks])
+        nsamp = sum(t.shape[0] for t in toks)
+        f = self._drop_path_factors(nsamp, X.device)
+        if f is not None:  # rows of a sample share its factor: one gather for all blocks and both branches
+            reps = torch.tensor([n for (_, nB, n) in segs for _ in range(nB)], device=X.device)
+            f = f.repeat_interleave(reps, dim=2)  # [depth, 2, M]
+        segs = tuple(segs)
+        for i, blk in enumerate(self.blocks):
+            X = Fn.vit_block_multi(X, segs, blk.attn.num_heads, None if f is None else (f[i, 0], f[i, 1]), blk._params())
+        Xn = self._normed(X.view(1, -1, C)).view(-1, C)
+        return [Xn[r0:r0 + nB * n].view(nB, n, C) for (r0, nB, n) in segs]
+
     def forward(self, x):
         crops = x if isinstance(x, list) else [x]
         runs, start = [], 0
@@ -178,6 +201,12 @@ class VisionTransformer(nn.Module):
             if i == len(crops) or crops[i].shape[-1] != crops[start].shape[-1]:
                 runs.append(torch.cat(crops[start:i]))
                 start = i
+        if self.ragged_multi_crop and len(runs) > 1:
+            maps = self._forward_ragged(runs)
+            if not self.use_dense_prediction:
+                return self.head(torch.cat([m[:, 0] for m in maps]))
+            feats = torch.cat([m[:, 1:].reshape(-1, m.shape[-1]) for m in maps])
+            return self.head(torch.cat([m[:, 0] for m in maps])), self.head_dense(feats), feats, [m.shape[1] - 1 for m in maps]
         if not self.use_dense_prediction:
             return self.head(torch.cat([self.forward_features(r) for r in runs]))
         cls, fea, npatch = [], [], []

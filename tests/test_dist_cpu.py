@@ -110,9 +110,11 @@ def _nano_step_pergroup_worker(rank, world, port, out):
     _nano_step_worker(rank, world, port, out, ragged=False)
 
 
-def _nano_vit_step_worker(rank, world, port, out):
-    """the monolithic ViT on two ranks: one backbone pass per resolution group (vision_transformer.py:186-233), i.e. two gradient
-    contributions per parameter -- the reducer's non-overlapped mode; averaged gradients == mean of the per-rank gradients"""
+def _nano_vit_step_worker(rank, world, port, out, ragged=True):
+    """the monolithic ViT on two ranks.  ragged: all crops through one set of row-wise launches, one gradient contribution per
+    parameter, written straight into the reducer's bucket slots (overlap mode); not ragged: one backbone pass per resolution group
+    (vision_transformer.py:186-233), two contributions per parameter -- the reducer's non-overlapped mode.  Either way the averaged
+    gradients equal the mean of the per-rank gradients"""
     _init(rank, world, port)
     import esvit_amd.functional as Fn
     import esvit_amd.loss as L
@@ -143,11 +145,15 @@ def _nano_vit_step_worker(rank, world, port, out):
         return {n: p.grad.detach().clone() for n, p in student.named_parameters() if p.grad is not None}
 
     student, teacher = nano_vit_pair()
+    student.ragged_multi_crop = ragged
     red = GradBucketReducer(student, bucket_mb=0.1, overlap=bool(getattr(student, "ragged_multi_crop", False)))  # as EsvitTrainer arms it
-    assert red.enabled and not red.overlap and len(red.buckets) >= 2
+    assert red.enabled and red.overlap == ragged and len(red.buckets) >= 2
     got = grads(student, teacher, rank, red)
+    if ragged:  # every gradient was produced in (or packed into) its bucket slot
+        assert all(p.grad.data_ptr() == red.views[id(p)].data_ptr() for p in student.parameters() if p.grad is not None)
     red.close()
     ref_student, ref_teacher = nano_vit_pair()
+    ref_student.ragged_multi_crop = ragged
     acc = None
     for r in range(world):
         g = grads(ref_student, ref_teacher, r, None)
@@ -155,6 +161,10 @@ def _nano_vit_step_worker(rank, world, port, out):
     ok = set(got) == set(acc) and all(torch.allclose(got[n], acc[n] / world, rtol=2e-4, atol=1e-7) for n in got)
     out[rank] = bool(ok)
     dist.destroy_process_group()
+
+
+def _nano_vit_step_pergroup_worker(rank, world, port, out):
+    _nano_vit_step_worker(rank, world, port, out, ragged=False)
 
 
 def _center_worker(rank, world, port, out):
@@ -246,7 +256,7 @@ def _extract_worker(rank, world, port, out):
 
 
 @pytest.mark.parametrize("worker,port", [(_reducer_worker, 29611), (_center_worker, 29612), (_syncbn_worker, 29613), (_extract_worker, 29614),
-                                         (_nano_step_worker, 29615), (_nano_step_pergroup_worker, 29616), (_nano_vit_step_worker, 29617)])
+                                         (_nano_step_worker, 29615), (_nano_step_pergroup_worker, 29616), (_nano_vit_step_worker, 29617), (_nano_vit_step_pergroup_worker, 29618)])
 def test_world2_gloo(worker, port, lib_built):
     world = 2
     out = mp.Manager().dict()

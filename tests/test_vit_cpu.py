@@ -114,3 +114,22 @@ def test_vit_attention_restatement_matches_autograd():
     o, saved = ops_ref.vit_attn_fwd(qkv.detach(), B, N, nH, hd ** -0.5)
     d = ops_ref.vit_attn_bwd(gy, saved, B, N, nH, hd ** -0.5)
     assert torch.allclose(o, y, atol=1e-6) and torch.allclose(d, qkv.grad, atol=1e-6)
+
+
+def test_vit_ragged_route_equals_per_group_schedule(cpu_ops):  # noqa: F811
+    """all crops as rows of one matrix (the default) == one backbone pass per resolution group (the reference's schedule):
+    outputs, loss and every gradient"""
+    import esvit_amd.loss as L
+    res = []
+    for ragged in (True, False):
+        student, teacher = nano_vit_pair()
+        student.ragged_multi_crop = teacher.ragged_multi_crop = ragged
+        s_out, t_out, loss = run_nano_vit_step(student, teacher, L)
+        res.append((s_out, loss, {n: p.grad.clone() for n, p in student.named_parameters() if p.grad is not None}))
+    (sa, la, ga), (sb, lb, gb) = res
+    assert list(sa[3]) == list(sb[3]) and abs(la.item() - lb.item()) < 1e-6
+    for a, b in zip(sa[:3], sb[:3]):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-6)
+    assert sorted(ga) == sorted(gb)
+    for n in ga:
+        assert torch.allclose(ga[n], gb[n], rtol=2e-4, atol=1e-7), n
