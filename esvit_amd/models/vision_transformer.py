@@ -185,10 +185,14 @@ class VisionTransformer(nn.Module):
         X = torch.cat([t.reshape(-1, C) for t in toks])
         nsamp = sum(t.shape[0] for t in toks)
         f = self._drop_path_factors(nsamp, X.device)
-        if f is not None:  # rows of a sample share its factor: one gather for all blocks and both branches
-            reps = torch.tensor([n for (_, nB, n) in segs for _ in range(nB)], device=X.device)
-            f = f.repeat_interleave(reps, dim=2)  # [depth, 2, M]
         segs = tuple(segs)
+        if f is not None:  # rows of a sample share its factor: one gather for all blocks and both branches -> [depth, 2, M]
+            cache = self.__dict__.setdefault("_row2sample", {})
+            idx = cache.get((segs, X.device))
+            if idx is None:  # (built on the host once per batch geometry: no device synchronisation in the step)
+                import numpy as np
+                idx = cache[(segs, X.device)] = torch.from_numpy(np.repeat(np.arange(nsamp), [n for (_, nB, n) in segs for _ in range(nB)])).to(X.device)
+            f = f.index_select(2, idx)
         for i, blk in enumerate(self.blocks):
             X = Fn.vit_block_multi(X, segs, blk.attn.num_heads, None if f is None else (f[i, 0], f[i, 1]), blk._params())
         Xn = self._normed(X.view(1, -1, C)).view(-1, C)
