@@ -133,3 +133,29 @@ def test_vit_ragged_route_equals_per_group_schedule(cpu_ops):  # noqa: F811
     assert sorted(ga) == sorted(gb)
     for n in ga:
         assert torch.allclose(ga[n], gb[n], rtol=2e-4, atol=1e-7), n
+
+
+def test_vit_drop_path_rows_share_the_sample_factor(cpu_ops):  # noqa: F811
+    """the ragged route expands one DropPath draw per (block, branch, sample) to token rows: with a vanishing rate the factors are 1
+    and the outputs equal the no-drop forward; with rate 1/2 a dropped sample's rows are the block input (both branches skipped)"""
+    from esvit_amd.models.swin_transformer import DropPath
+    student, _ = nano_vit_pair()
+    crops = GU.make_crops(2, n_local=3, sizes=GU.NANO_VIT["sizes"])
+    student.train()
+    with torch.no_grad():
+        want = student(crops)
+        for blk in student.blocks:
+            blk.drop_path = DropPath(1e-9)
+        got = student(crops)
+        for a, b in zip(want[:3], got[:3]):
+            assert torch.allclose(a, b, rtol=1e-5, atol=1e-6)
+        f = student._drop_path_factors(10, torch.device("cpu"))
+        assert f.shape == (GU.NANO_VIT["depth"], 2, 10) and torch.allclose(f, torch.ones_like(f), atol=1e-6)
+        for blk in student.blocks:
+            blk.drop_path = DropPath(0.5)
+        student.__dict__.pop("_keep", None)
+        torch.manual_seed(3)
+        f = student._drop_path_factors(4000, torch.device("cpu"))
+        assert set(f.unique().tolist()) == {0.0, 2.0} and abs(f.mean().item() - 1.0) < 0.05
+        out = student(crops)   # runs through the row expansion with real drops
+        assert all(torch.isfinite(t).all() for t in out[:3])
