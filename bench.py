@@ -273,6 +273,7 @@ def main():
     ap.add_argument("--single-stream", action="store_true", help="teacher forward on the main stream too (per-kernel profiles: no overlapped durations)")
     ap.add_argument("--augment", action="store_true", help="produce the crops INSIDE the timed step with the GPU crop producer (esvit_amd.data: "
                     "DataAugmentationDINO on decoded uint8 images resident in HBM) instead of feeding fixed crop tensors")
+    ap.add_argument("--per-group", action="store_true", help="one backbone pass per resolution group (the reference's schedule) instead of the ragged multi-crop route")
     ap.add_argument("--gemm-table", default=None, help="write a per-shape GEMM time table to this file")
     ap.add_argument("--torch-eager", type=int, default=0, metavar="BATCH",
                     help="also time the reference-path port under torch eager + autocast(bf16) on this GPU at the given batch")
@@ -304,6 +305,8 @@ def main():
     esvit_amd.set_precision("bf16")
     torch.manual_seed(0)  # identical replicas ...
     student, teacher, loss_fn = build(dev, args.drop_path, args.arch)
+    if args.per_group:
+        student.ragged_multi_crop = teacher.ragged_multi_crop = False
     torch.manual_seed(1000 + rank)  # ... but every rank draws its own stochastic-depth masks (and has its own crops)
     trainer = EsvitTrainer(student, teacher, loss_fn, clip_grad=3.0, freeze_last_layer=1, teacher_stream=not args.single_stream)
     B = args.batch
