@@ -1,6 +1,6 @@
 """Times esvit_dino_ce_fwd_bwd at the region-loss shape of the benchmark step (Rs = B * 170 student rows scored against <= 2 of the
 B * 98 teacher rows, out_dim 65536, bf16), image-major work order.   python tools/bench_ce.py [--batch 128] [--rows-per-image 170]"""
-import argparse, json, os, sys, time
+import argparse, json, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
