@@ -98,6 +98,12 @@ def test_large_boxes_use_smaller_tiles(lib_built):
     out, planes = _render([img], rows, 96)
     _check_against_oracle([img], rows, 96, out, planes)
     assert ops.aug_max_box(96) >= 1500 and ops.aug_max_box(224) >= 2000
+    # beyond the staged tiles (scale 29: the source rows of even an 8 x 8 tile do not fit the LDS): the unstaged 8 x 8 variant
+    big = np.ascontiguousarray(rng.integers(0, 256, (2800, 2400, 3), dtype=np.uint8))
+    pb = dict(p, top=10, left=20, h=2780, w=2300, flip=False)
+    rows_b = np.stack([A.params_row(pb, 0)])
+    out_b, planes_b = _render([big], rows_b, 96)
+    _check_against_oracle([big], rows_b, 96, out_b, planes_b)
     with pytest.raises(RuntimeError):
         _render([img], np.stack([A.params_row(dict(p, h=1 << 20), 0)]), 96)
 
