@@ -159,3 +159,31 @@ def test_vit_drop_path_rows_share_the_sample_factor(cpu_ops):  # noqa: F811
         assert set(f.unique().tolist()) == {0.0, 2.0} and abs(f.mean().item() - 1.0) < 0.05
         out = student(crops)   # runs through the row expansion with real drops
         assert all(torch.isfinite(t).all() for t in out[:3])
+
+
+def test_vit_oracle_matches_reference_golden():
+    """oracle/esvit_oracle.vit_multicrop (the functional restatement a GPU box can run at any size) against the step of the
+    reference's own VisionTransformer + DINOHeads + DDINOLoss: outputs, loss, every gradient"""
+    from oracle import esvit_oracle as O
+    g = torch.load(os.path.join(GOLD, "nano_vit_step.pt"), weights_only=False)
+    student, teacher = nano_vit_pair()
+    sd = {k: v.detach().clone().requires_grad_(v.is_floating_point()) for k, v in student.state_dict().items()}
+    td = {k: v.detach().clone() for k, v in teacher.state_dict().items()}
+    cfg = dict(depth=GU.NANO_VIT["depth"], heads=GU.NANO_VIT["heads"], patch=GU.NANO_VIT["patch"])
+    crops = GU.make_crops(2, n_local=3, sizes=GU.NANO_VIT["sizes"])
+    s_out = O.vit_multicrop(sd, crops, cfg)
+    with torch.no_grad():
+        t_out = O.vit_multicrop(td, crops[:2], cfg)
+    assert (list(s_out[3]), list(t_out[3])) == g["npatch"]
+    for nm, t in (("s_cls", s_out[0]), ("s_reg", s_out[1]), ("s_fea", s_out[2]), ("t_cls", t_out[0]), ("t_reg", t_out[1]), ("t_fea", t_out[2])):
+        probe_close(nm, t.detach(), g[nm], rtol=2e-4)
+    K = GU.NANO_HEAD["out_dim"]
+    c0 = torch.zeros(1, K)
+    loss, _, _ = O.ddino_loss(s_out, t_out, c0, c0, O.teacher_temp(2, 0.04, 0.07, 5, 10), 5)
+    assert abs(loss.item() - g["ddino_loss"]) < 2e-5, (loss.item(), g["ddino_loss"])
+    loss.backward()
+    for n, ref in g["grad_norms"].items():
+        got = sd[n].grad.norm().item()
+        assert abs(got - ref) <= 2e-3 * ref + 1e-9, (n, got, ref)
+    with torch.no_grad():
+        probe_close("view-level", O.vit_multicrop(sd, crops, cfg, dense=False), g["view_only"], rtol=2e-4)

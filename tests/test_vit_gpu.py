@@ -248,3 +248,62 @@ def test_deit_small_step_matches_reference_golden(prec, lib_built):
             assert err < (5e-3 if fp else 0.25), (n, err)
     finally:
         _teardown()
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_deit_tiny_step_matches_oracle(prec, lib_built):
+    """deit_tiny at full width (192 wide, 3 heads of 64, 12 blocks; 197 / 37 tokens) against the functional oracle
+    (oracle/esvit_oracle.vit_multicrop, itself pinned against the reference's VisionTransformer): outputs, loss, every gradient norm.
+    A case no fixture holds -- the oracle runs on the GPU box's host."""
+    import esvit_amd
+    from esvit_amd.models import vision_transformer as V
+    from oracle import esvit_oracle as O
+    from tests import golden_utils as GU
+    K = 2048
+    dev = _setup(prec)
+    try:
+        def make(seed):
+            m = V.deit_tiny(patch_size=16, drop_path_rate=0.0, use_dense_prediction=True)
+            m.head, m.head_dense = esvit_amd.DINOHead(192, K, norm_last_layer=True), esvit_amd.DINOHead(192, K, norm_last_layer=False)
+            GU.fill_state_dict(m.state_dict(), seed)
+            return m
+        student, teacher = make(51), make(52)
+        student.head.last_layer.weight_g.data.fill_(1)
+        for p in teacher.parameters():
+            p.requires_grad = False
+        crops = GU.make_crops(2, seed=91)
+        # oracle (CPU, fp32)
+        sd = {k: v.detach().clone().requires_grad_(v.is_floating_point()) for k, v in student.state_dict().items()}
+        td = {k: v.detach().clone() for k, v in teacher.state_dict().items()}
+        cfg = dict(depth=12, heads=3, patch=16)
+        s_ref = O.vit_multicrop(sd, crops, cfg)
+        with torch.no_grad():
+            t_ref = O.vit_multicrop(td, crops[:2], cfg)
+        c0 = torch.zeros(1, K)
+        l_ref, _, _ = O.ddino_loss(s_ref, t_ref, c0, c0, O.teacher_temp(2, 0.04, 0.07, 5, 10), 10)
+        l_ref.backward()
+        # HIP path
+        student, teacher = student.to(dev), teacher.to(dev)
+        loss_fn = esvit_amd.DDINOLoss(K, 10, 0.04, 0.07, 5, 10).to(dev)
+        dcrops = [c.to(dev) for c in crops]
+        t_out = teacher(dcrops[:2])
+        s_out = student(dcrops)
+        loss = loss_fn(s_out, t_out, 2, None)
+        loss.backward()
+        fp = prec == "fp32"
+        assert list(s_out[3]) == list(s_ref[3])
+        for nm, a, b in (("cls logits", s_out[0], s_ref[0]), ("region logits", s_out[1], s_ref[1]), ("features", s_out[2], s_ref[2])):
+            _close(nm, a, b.detach(), 1e-3 if fp else 8e-2)
+        assert abs(loss.item() - l_ref.item()) < (2e-4 if fp else 2e-2), (loss.item(), l_ref.item())
+        worst, name = 0.0, None
+        for n, p in student.named_parameters():
+            if not p.requires_grad:  # norm_last_layer freezes head.last_layer.weight_g (the oracle's dict has no such notion)
+                continue
+            ref = sd[n].grad
+            assert ref is not None and p.grad is not None, n
+            rel = abs(p.grad.norm().item() - ref.norm().item()) / (ref.norm().item() + 1e-12)
+            if rel > worst:
+                worst, name = rel, n
+        assert worst < (5e-3 if fp else 0.2), (name, worst)
+    finally:
+        _teardown()
