@@ -187,3 +187,25 @@ def test_vit_oracle_matches_reference_golden():
         assert abs(got - ref) <= 2e-3 * ref + 1e-9, (n, got, ref)
     with torch.no_grad():
         probe_close("view-level", O.vit_multicrop(sd, crops, cfg, dense=False), g["view_only"], rtol=2e-4)
+
+
+def test_vit_feature_extraction_for_knn(cpu_ops):  # noqa: F811
+    """eval_knn.py:165-190 with a ViT backbone (eval_knn.py:115-118 builds it by name with num_classes = 0): extract_features returns
+    the normed class tokens, row i at dataset index i -- equal to the functional oracle"""
+    from functools import partial
+    from esvit_amd import eval as E
+    from esvit_amd.models import vision_transformer as V
+    from oracle import esvit_oracle as O
+    from tests.test_composition_cpu import IndexedSet
+    v = GU.NANO_VIT
+    model = V.VisionTransformer(img_size=[v["sizes"][0]], patch_size=v["patch"], embed_dim=v["embed_dim"], depth=v["depth"], num_heads=v["heads"],
+                                mlp_ratio=4, qkv_bias=True, norm_layer=partial(torch.nn.LayerNorm, eps=1e-6), num_classes=0)
+    GU.fill_state_dict(model.state_dict(), 5)
+    model.eval()
+    x = torch.randn(7, 3, v["sizes"][0], v["sizes"][0], generator=torch.Generator().manual_seed(4))
+    loader = torch.utils.data.DataLoader(IndexedSet(x), batch_size=3)
+    feats = E.extract_features(model, loader, use_cuda=False)
+    sd = {k: t.detach() for k, t in model.state_dict().items()}
+    with torch.no_grad():
+        want = O.vit_features(sd, x, dict(depth=v["depth"], heads=v["heads"], patch=v["patch"]))[:, 0]
+    assert feats.shape == want.shape and torch.allclose(feats, want, rtol=1e-4, atol=1e-5)
