@@ -109,7 +109,7 @@ class PackedImages:
             if isinstance(im, torch.Tensor):
                 t = im
             else:  # PIL.Image / numpy HWC
-                t = torch.from_numpy(np.ascontiguousarray(np.asarray(im)))
+                t = torch.from_numpy(np.array(im))  # (a copy: arrays viewed from PIL images are read-only)
             if t.dtype != torch.uint8 or t.dim() != 3 or t.shape[2] != 3:
                 raise ValueError("PackedImages: expected uint8 H x W x 3 (decoded RGB) images, got %s %s" % (t.dtype, tuple(t.shape)))
             arrs.append(t.reshape(-1))
@@ -135,7 +135,8 @@ class DataAugmentationDINO:
     """``DataAugmentationDINO(global_crops_scale, local_crops_scale, local_crops_number, local_crops_size)`` (datasets/
     build.py:203-250), called on a BATCH: ``aug(images)`` takes B decoded images (a :class:`PackedImages` or a list of uint8 HWC
     tensors / arrays / PIL images) and returns the reference's collated crop list -- 2 + sum(local_crops_number) float32 CUDA
-    tensors ``[B, 3, S, S]``, crop slot c of image b at ``out[c][b]``."""
+    tensors ``[B, 3, S, S]``, crop slot c of image b at ``out[c][b]``.  Called on ONE image it returns the per-sample list of
+    ``[3, S, S]`` tensors, as the reference's transform does."""
 
     def __init__(self, global_crops_scale, local_crops_scale, local_crops_number, local_crops_size=(96,), seed=None, device="cuda"):
         local_crops_number = [local_crops_number] if isinstance(local_crops_number, int) else list(local_crops_number)
@@ -180,6 +181,10 @@ class DataAugmentationDINO:
         return (images, self.draw(_Sizes())), torch.as_tensor([y for _, y in batch])
 
     def __call__(self, images, uniforms=None, draws=None):
+        if not isinstance(images, (list, tuple, PackedImages)):
+            # one decoded image (PIL.Image / uint8 H x W x 3 array or tensor), the reference's per-sample contract (build.py:252-261):
+            # the crop list without the batch axis
+            return [c[0] for c in self.__call__([images], uniforms=uniforms, draws=draws)]
         packed = images if isinstance(images, PackedImages) else PackedImages(images, self.device)
         B = len(packed)
         dev = packed.data.device

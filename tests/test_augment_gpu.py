@@ -180,3 +180,21 @@ def test_prefetching_loader_equals_inline_rendering(lib_built):
     for (ca, la, sa), (cb, lb, sb) in zip(a, b):
         assert torch.equal(la, lb) and float(sa) == float(sb)
         assert all(torch.equal(x, y) for x, y in zip(ca, cb))
+
+
+def test_single_image_call_matches_the_reference_contract(lib_built):
+    """aug(image) -- one PIL image / array, as a Dataset transform would call it -- returns 2 + 8 tensors [3, S, S]: the rows of the
+    batched call with the same draws"""
+    from esvit_amd import data as D
+    rng = np.random.default_rng(31)
+    img = np.ascontiguousarray(rng.integers(0, 256, (180, 240, 3), dtype=np.uint8))
+    one = D.DataAugmentationDINO((0.4, 1.0), (0.05, 0.4), (8,), (96,), seed=2)(img)
+    batch = D.DataAugmentationDINO((0.4, 1.0), (0.05, 0.4), (8,), (96,), seed=2)([img])
+    assert len(one) == 10 and [tuple(c.shape) for c in one] == [(3, 224, 224)] * 2 + [(3, 96, 96)] * 8
+    assert all(torch.equal(a, b[0]) for a, b in zip(one, batch))
+    try:
+        from PIL import Image
+    except ImportError:
+        return
+    pil = D.DataAugmentationDINO((0.4, 1.0), (0.05, 0.4), (8,), (96,), seed=2)(Image.fromarray(img))
+    assert all(torch.equal(a, b) for a, b in zip(one, pil))
