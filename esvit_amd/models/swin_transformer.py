@@ -58,6 +58,10 @@ class WindowAttention(nn.Module):
         self.dim, self.window_size, self.num_heads = dim, window_size, num_heads
         self.scale = (dim // num_heads) ** -0.5
         ws = window_size[0]
+        if ws * ws > 64 and dim // num_heads != 32:
+            # the head_dim-64 instances of the 224-slot kernels serve the bias-free ViT crops: they do not produce the gradient of
+            # the relative-position table (every reference Swin configuration has head_dim 32)
+            raise NotImplementedError("windows of more than 64 tokens need head_dim 32 (got %d)" % (dim // num_heads))
         self.relative_position_bias_table = nn.Parameter(torch.zeros((2 * ws - 1) * (2 * ws - 1), num_heads))
         p = np.arange(ws * ws)
         rel = (p[:, None] // ws - p[None, :] // ws + ws - 1) * (2 * ws - 1) + (p[:, None] % ws - p[None, :] % ws + ws - 1)

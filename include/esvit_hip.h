@@ -211,7 +211,10 @@ int esvit_token_mean_bwd(const float* g_mean, const float* g_tok, int nB, int T,
  * lse fp32 [nB*nW*nH, ESVIT_Q_ATTN_LSE_ELEMS(N)]: per-query log-sum-exp, written for 14x14 windows (the blocked
  * backward needs it), unused (may be NULL) for 7x7.  One image's qkv rows (L * 3C activations) must fit a 2 GiB buffer
  * descriptor.
- * attn_out (optional, fp32 [nB*nW,nH,N,N]) receives the softmax (swin_transformer.py:146,152). */
+ * attn_out (optional, fp32 [nB*nW,nH,N,N]) receives the softmax (swin_transformer.py:146,152). 
+ * N <= 64: head_dim 32 or 64.  64 < N <= 224: head_dim 32, or 64 in bf16 -- the head_dim-64 instances (whole ViT crops: one window per
+ * image, N < ws * ws allowed, zero table) leave dbias_ws unwritten.
+ */
 int esvit_window_attn_fwd(int dtype, const void* qkv, const float* qkv_bias, const int32_t* win2tok, int L,
                           const float* rel_table, int ws, float* bias_frag_ws, const int32_t* region_ids, int nW, int nB,
                           int N, int nH, int hd, float scale, void* out, float* lse, float* attn_out,
