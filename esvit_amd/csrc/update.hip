@@ -67,6 +67,16 @@ __global__ __launch_bounds__(256) void grad_sqnorm_kernel(const long* __restrict
     }
 }
 
+// Non-finite guard: the reference reads loss.item() every iteration and exits BEFORE the update when it is not finite
+// (main_esvit.py:546-551).  There is no host synchronisation here, so the update kernels look at the per-tensor statistics
+// themselves: if any of them is NaN / inf (a non-finite loss poisons every gradient), the whole update -- student, moments,
+// teacher EMA, weight copies -- is skipped and the state stays what it was; the host finds the non-finite loss at its next look.
+__device__ __forceinline__ bool stats_not_finite(const float* __restrict__ stats, int nstats) {
+    int bad = 0;
+    for (int i = threadIdx.x; i < nstats; i += 256) bad |= !(fabsf(stats[i]) <= 3.0e38f);
+    return __syncthreads_or(bad) != 0;
+}
+
 __device__ __forceinline__ void adamw_elem(float& p, float g, float& m, float& v, float decay, float b1, float b2, float step_size,
                                            float inv_sqrt_bc2, float eps) {
     p *= decay;
@@ -77,8 +87,9 @@ __device__ __forceinline__ void adamw_elem(float& p, float g, float& m, float& v
 }
 
 __global__ __launch_bounds__(256) void clip_adamw_ema_kernel(const long* __restrict__ tensors, const int* __restrict__ chunks,
-                                                             const float* __restrict__ sqnorms, float clip, float lr, float wd,
+                                                             const float* __restrict__ sqnorms, int nstats, float clip, float lr, float wd,
                                                              float b1, float b2, float eps, float ema_m) {
+    if (stats_not_finite(sqnorms, nstats)) return;
     const int tid = chunks[2 * blockIdx.x], ci = chunks[2 * blockIdx.x + 1];
     const long* tt = tensors + (long)tid * TFIELDS;
     float* p = reinterpret_cast<float*>(tt[0]);
@@ -155,8 +166,9 @@ __global__ __launch_bounds__(256) void clip_adamw_ema_kernel(const long* __restr
 // c = the per-tensor clip factor.  `stats` holds (sum g^2, sum p^2, sum g p) per tensor for LARS, sum g^2 for SGD.
 template <bool LARS>
 __global__ __launch_bounds__(256) void clip_momentum_ema_kernel(const long* __restrict__ tensors, const int* __restrict__ chunks,
-                                                                const float* __restrict__ stats, float clip, float lr, float wd,
+                                                                const float* __restrict__ stats, int nstats, float clip, float lr, float wd,
                                                                 float momentum, float eta, float ema_m) {
+    if (stats_not_finite(stats, nstats)) return;
     const int tid = chunks[2 * blockIdx.x], ci = chunks[2 * blockIdx.x + 1];
     const long* tt = tensors + (long)tid * TFIELDS;
     float* p = reinterpret_cast<float*>(tt[0]);
@@ -232,14 +244,14 @@ extern "C" int esvit_fused_clip_update_ema(int rule, const int64_t* tensors, int
     ESVIT_CHECK_ARG(tensors && chunks && sqnorms && ntensors > 0 && nchunks > 0, "esvit_fused_clip_update_ema: bad args");
     ESVIT_CHECK_ARG(rule == ESVIT_RULE_ADAMW || rule == ESVIT_RULE_SGD || rule == ESVIT_RULE_LARS, "esvit_fused_clip_update_ema: bad rule %d", rule);
     if (rule == ESVIT_RULE_ADAMW)
-        hipLaunchKernelGGL(clip_adamw_ema_kernel, dim3(nchunks), dim3(256), 0, stream, (const long*)tensors, chunks, sqnorms, clip, lr, wd,
+        hipLaunchKernelGGL(clip_adamw_ema_kernel, dim3(nchunks), dim3(256), 0, stream, (const long*)tensors, chunks, sqnorms, ntensors, clip, lr, wd,
                            beta1, beta2, eps, ema_m);
     else if (rule == ESVIT_RULE_SGD)
-        hipLaunchKernelGGL(clip_momentum_ema_kernel<false>, dim3(nchunks), dim3(256), 0, stream, (const long*)tensors, chunks, sqnorms, clip,
-                           lr, wd, beta1, beta2, ema_m);
+        hipLaunchKernelGGL(clip_momentum_ema_kernel<false>, dim3(nchunks), dim3(256), 0, stream, (const long*)tensors, chunks, sqnorms, ntensors,
+                           clip, lr, wd, beta1, beta2, ema_m);
     else
-        hipLaunchKernelGGL(clip_momentum_ema_kernel<true>, dim3(nchunks), dim3(256), 0, stream, (const long*)tensors, chunks, sqnorms, clip,
-                           lr, wd, beta1, beta2, ema_m);
+        hipLaunchKernelGGL(clip_momentum_ema_kernel<true>, dim3(nchunks), dim3(256), 0, stream, (const long*)tensors, chunks, sqnorms, 3 * ntensors,
+                           clip, lr, wd, beta1, beta2, ema_m);
     ESVIT_CHECK_LAUNCH("fused_clip_update_ema");
     return ESVIT_OK;
 }

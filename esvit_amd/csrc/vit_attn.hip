@@ -114,6 +114,42 @@ __global__ __launch_bounds__(256) void softmax_rows_bwd_kernel(const T* __restri
     }
 }
 
+// rows longer than 256 padded tokens (patch_size 8: 785 tokens at 224^2; evaluation on larger images): the same arithmetic in
+// passes over the row instead of registers (the row stays in the L2 between the passes)
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_rows_fwd_long_kernel(T* __restrict__ s, long rows, int N, int Np, float scale) {
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    T* p = s + row * Np;
+    const bool live = (int)(row % Np) < N;
+    float m = -INFINITY;
+    if (live)
+        for (int j = lane; j < N; j += 64) m = fmaxf(m, scale * to_f32(p[j]));
+    m = wave_max(m);
+    float sum = 0.f;
+    if (live)
+        for (int j = lane; j < N; j += 64) sum += __expf(scale * to_f32(p[j]) - m);
+    sum = wave_sum(sum);
+    const float inv = live ? 1.f / sum : 0.f;
+    for (int j = lane; j < Np; j += 64) p[j] = from_f32<T>((live && j < N) ? __expf(scale * to_f32(p[j]) - m) * inv : 0.f);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_rows_bwd_long_kernel(const T* __restrict__ prob, T* __restrict__ dp, long rows, int N, int Np, float scale) {
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const T* p = prob + row * Np;
+    T* d = dp + row * Np;
+    const bool live = (int)(row % Np) < N;
+    float dot = 0.f;
+    if (live)
+        for (int j = lane; j < N; j += 64) dot += to_f32(p[j]) * to_f32(d[j]);
+    dot = wave_sum(dot);
+    for (int j = lane; j < Np; j += 64) d[j] = from_f32<T>((live && j < N) ? scale * to_f32(p[j]) * (to_f32(d[j]) - dot) : 0.f);
+}
+
 int grid_for(long total) {
     long g = (total + 255) / 256;
     return (int)(g > 8192 ? 8192 : (g < 1 ? 1 : g));
@@ -149,8 +185,15 @@ extern "C" int esvit_heads_merge(int dtype, const void* y, int B, int N, int Np,
 
 extern "C" int esvit_softmax_rows_fwd(int dtype, void* s, int64_t batch, int N, int Np, float scale, esvit_stream_t stream_) {
     STREAM(stream_);
-    ESVIT_CHECK_ARG(s && batch > 0 && N > 0 && Np >= N && Np <= 64 * SM_MAX, "esvit_softmax_rows_fwd: bad arguments (rows of at most %d padded tokens)", 64 * SM_MAX);
+    ESVIT_CHECK_ARG(s && batch > 0 && N > 0 && Np >= N, "esvit_softmax_rows_fwd: bad arguments");
     const long rows = batch * Np;
+    if (Np > 64 * SM_MAX) {
+        if (dtype == ESVIT_BF16) hipLaunchKernelGGL(softmax_rows_fwd_long_kernel<bf16>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, (bf16*)s, rows, N, Np, scale);
+        else if (dtype == ESVIT_F32) hipLaunchKernelGGL(softmax_rows_fwd_long_kernel<float>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, (float*)s, rows, N, Np, scale);
+        else ESVIT_CHECK_ARG(false, "esvit_softmax_rows_fwd: bad dtype %d", dtype);
+        ESVIT_CHECK_LAUNCH("softmax_rows_fwd");
+        return ESVIT_OK;
+    }
     if (dtype == ESVIT_BF16) hipLaunchKernelGGL(softmax_rows_fwd_kernel<bf16>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, (bf16*)s, rows, N, Np, scale);
     else if (dtype == ESVIT_F32) hipLaunchKernelGGL(softmax_rows_fwd_kernel<float>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, (float*)s, rows, N, Np, scale);
     else ESVIT_CHECK_ARG(false, "esvit_softmax_rows_fwd: bad dtype %d", dtype);
@@ -160,8 +203,15 @@ extern "C" int esvit_softmax_rows_fwd(int dtype, void* s, int64_t batch, int N, 
 
 extern "C" int esvit_softmax_rows_bwd(int dtype, const void* p, void* dp, int64_t batch, int N, int Np, float scale, esvit_stream_t stream_) {
     STREAM(stream_);
-    ESVIT_CHECK_ARG(p && dp && batch > 0 && N > 0 && Np >= N && Np <= 64 * SM_MAX, "esvit_softmax_rows_bwd: bad arguments (rows of at most %d padded tokens)", 64 * SM_MAX);
+    ESVIT_CHECK_ARG(p && dp && batch > 0 && N > 0 && Np >= N, "esvit_softmax_rows_bwd: bad arguments");
     const long rows = batch * Np;
+    if (Np > 64 * SM_MAX) {
+        if (dtype == ESVIT_BF16) hipLaunchKernelGGL(softmax_rows_bwd_long_kernel<bf16>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, (const bf16*)p, (bf16*)dp, rows, N, Np, scale);
+        else if (dtype == ESVIT_F32) hipLaunchKernelGGL(softmax_rows_bwd_long_kernel<float>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, (const float*)p, (float*)dp, rows, N, Np, scale);
+        else ESVIT_CHECK_ARG(false, "esvit_softmax_rows_bwd: bad dtype %d", dtype);
+        ESVIT_CHECK_LAUNCH("softmax_rows_bwd");
+        return ESVIT_OK;
+    }
     if (dtype == ESVIT_BF16) hipLaunchKernelGGL(softmax_rows_bwd_kernel<bf16>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, (const bf16*)p, (bf16*)dp, rows, N, Np, scale);
     else if (dtype == ESVIT_F32) hipLaunchKernelGGL(softmax_rows_bwd_kernel<float>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, (const float*)p, (float*)dp, rows, N, Np, scale);
     else ESVIT_CHECK_ARG(false, "esvit_softmax_rows_bwd: bad dtype %d", dtype);

@@ -40,9 +40,12 @@ class GradBucketReducer:
     ALIGN = 4  # floats
 
     def __init__(self, module, bucket_mb=32, process_group=None, overlap=True):
-        # overlap=False: a parameter may receive several gradient contributions per backward (the per-group schedule runs
-        # every block once per resolution group): no bucket is launched before backward has ended and gradients are not
-        # written into the buckets by their producers (they are packed by the hooks)
+        # A bucket is launched when the post-accumulate hook of its last parameter has fired.  AccumulateGrad runs once
+        # per parameter and backward -- after autograd has summed every contribution of the graph -- so this is correct
+        # for any schedule: the ragged route (one contribution per parameter), one backbone pass per resolution group,
+        # CvT.  A bucket slot is handed to a producer at most once per backward (params.grad_out); a sum that did not end
+        # up in its slot is packed by the hook.  overlap=False (debug): nothing is launched before backward has ended and
+        # no producer writes into a bucket.
         self.overlap = overlap
         self.group = process_group
         self.world = _world(process_group)
@@ -163,8 +166,7 @@ class EsvitTrainer:
         self._side = torch.cuda.Stream() if (teacher_stream and next(student.parameters()).is_cuda) else None
         self.clip_grad, self.freeze_last_layer = clip_grad, freeze_last_layer
         self.updater = updater if updater is not None else FusedClipAdamWEMA(student, teacher)
-        # (the ragged multi-crop route uses every parameter exactly once per backward; the per-group schedule does not)
-        self.reducer = GradBucketReducer(student, bucket_mb, overlap=bool(getattr(student, "ragged_multi_crop", False)))
+        self.reducer = GradBucketReducer(student, bucket_mb)
 
     def step(self, images, lr, wd, momentum, epoch, scaler=None, teacher_images=None, targets_mixup=None):
         """scaler: a ``torch.cuda.amp.GradScaler`` (the reference's --use_fp16 mode, main_esvit.py:417-419, 576-584) or None.
@@ -286,8 +288,11 @@ def train_one_epoch(student, teacher, teacher_without_ddp, dino_loss, data_loade
         last = tr.step(images, lr_schedule[git], wd_schedule[git], momentum_schedule[git], epoch, scaler=fp16_scaler,
                        teacher_images=teacher_images, targets_mixup=targets_mixup)
         loss_sum += last
-        if it % 10 == 0 or it == n_it - 1:  # the reference syncs every iteration (main_esvit.py:546,593); 1-in-10 keeps the NaN guard
-            v = last.item()
+        # the reference syncs on loss.item() every iteration and exits BEFORE the update (main_esvit.py:546-551).  Here the fused
+        # update refuses to touch student, teacher and optimizer state when any gradient is non-finite (device-side flag,
+        # update.hip), so a NaN step leaves the state as it was; the host looks at the loss one iteration in ten
+        if it % 10 == 0 or it == n_it - 1:
+            v = loss_sum.item()  # (a NaN / inf of any earlier iteration stays in the running sum)
             if not math.isfinite(v):
                 print("Loss is {}, stopping training".format(v))
                 sys.exit(1)
@@ -295,4 +300,8 @@ def train_one_epoch(student, teacher, teacher_without_ddp, dino_loss, data_loade
     if _world() > 1:  # metric_logger.synchronize_between_processes (main_esvit.py:597)
         dist.all_reduce(mean)
         mean = mean / _world()
-    return {"loss": mean.item(), "lr": float(lr_schedule[n_it * epoch + n_it - 1]), "wd": float(wd_schedule[n_it * epoch + n_it - 1])}
+    # the reference returns every meter's epoch global_avg (main_esvit.py:598-600): the means of the schedule values of this epoch
+    its = range(n_it * epoch, n_it * epoch + n_it)
+    lr_avg = sum(float(lr_schedule[i]) for i in its) / max(n_it, 1)
+    wd_avg = sum(float(wd_schedule[i]) for i in its) / max(n_it, 1)
+    return {"loss": mean.item(), "lr": lr_avg, "wd": wd_avg}

@@ -137,6 +137,10 @@ class VisionTransformer(nn.Module):
 
     def _tokens(self, x):
         """patches -> [class token | patch tokens] + position embedding (vision_transformer.py:236-243)"""
+        if x.shape[-1] != x.shape[-2]:
+            raise NotImplementedError("VisionTransformer: square images only (got %dx%d): the patch embedding and the position-embedding "
+                                      "interpolation here assume a square patch grid; the reference's (w0, h0) resampling of "
+                                      "vision_transformer.py:236-262 for other shapes is not built" % (x.shape[-2], x.shape[-1]))
         patches = self.patch_embed(x)
         x = torch.cat((self.cls_token.expand(patches.shape[0], -1, -1), patches), dim=1)
         return Fn.ApeAddFn.apply(x, self.interpolate_pos_encoding(x, self.pos_embed).contiguous())

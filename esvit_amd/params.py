@@ -16,6 +16,7 @@ _GEN = 0
 _CACHE = {}        # (id(p), name) -> (weakref(p), tag, value)
 _MANAGED = {}      # id(p) -> weakref(p): frozen parameters whose every update goes through the fused updater (the EMA teacher)
 _GRAD_SINK = None  # id(p) -> preallocated fp32 gradient tensor (a bucket view of engine.GradBucketReducer), or None
+_GRAD_TAKEN = set()  # ids whose slot has been handed to a producer during the current backward
 
 
 def _drop(pid):
@@ -112,13 +113,21 @@ def set_grad_sink(views):
     write into (engine.GradBucketReducer's bucket slots), or None to switch the sink off."""
     global _GRAD_SINK
     _GRAD_SINK = views
+    _GRAD_TAKEN.clear()
 
 
 def grad_out(p, shape2d=None):
-    """the preallocated gradient tensor of parameter `p` (viewed as `shape2d` if given), or None"""
+    """the preallocated gradient tensor of parameter `p` (viewed as `shape2d` if given), or None.
+
+    A slot is handed out AT MOST ONCE per backward.  A schedule that uses a parameter several times in one graph (one
+    backbone pass per resolution group, swin_transformer.py:729-751; CvT) gets the slot for its first contribution and
+    None -- i.e. a fresh tensor -- for the others: autograd sums the contributions before AccumulateGrad runs, and the
+    reducer's hook packs the sum if it did not end up in the slot.  (Handing the slot out twice would make the second
+    producer overwrite the first and autograd add two aliases of the same memory.)"""
     if _GRAD_SINK is None or p is None:
         return None
     v = _GRAD_SINK.get(id(p))
-    if v is None:
+    if v is None or id(p) in _GRAD_TAKEN:
         return None
+    _GRAD_TAKEN.add(id(p))
     return v if shape2d is None else v.view(shape2d)

@@ -298,7 +298,9 @@ int esvit_center_ema(float* center, const float* colsum, float momentum, float d
  * chunk table (device, int32[nchunks*2]): [tensor_id, chunk_index], chunk =
  * esvit_query(ESVIT_Q_UPDATE_CHUNK_ELEMS, 0, 0, 0) elements.
  * esvit_grad_sqnorm: stats = 1: sqnorms fp32 [ntensors] = sum g^2;  stats = 3 (LARS): fp32 [ntensors*3] =
- * (sum g^2, sum p^2, sum g p) per tensor.  esvit_fused_clip_update_ema reads the layout its rule needs. */
+ * (sum g^2, sum p^2, sum g p) per tensor.  esvit_fused_clip_update_ema reads the layout its rule needs.
+ * Non-finite guard: if ANY statistic is NaN / inf (a non-finite loss poisons every gradient) the update launch is a no-op --
+ * student, moments, teacher and weight copies keep their values (the reference exits before its update, main_esvit.py:546-551). */
 #define ESVIT_RULE_ADAMW 0
 #define ESVIT_RULE_SGD 1
 #define ESVIT_RULE_LARS 2

@@ -481,6 +481,55 @@ def gen_full(ns):
     torch.save(out, os.path.join(OUT, "full_width.pt"))
 
 
+def _yaml_config(path):
+    """the reference's experiment yaml as the config object its build_model reads (stochastic depth off: both sides deterministic)"""
+    import yaml
+    with open(os.path.join(RL.REF_ROOT, path)) as fh:
+        y = yaml.safe_load(fh)
+    model = dict(NUM_CLASSES=0, INIT_WEIGHTS=False, PRETRAINED="", PRETRAINED_LAYERS=["*"])
+    model.update(y["MODEL"])
+    model["SPEC"] = dict(model["SPEC"], DROP_PATH_RATE=0.0)
+    return RL.AttrDict(MODEL=model, TRAIN=dict(IMAGE_SIZE=[224, 224]), FINETUNE=dict(FINETUNE=False, FROZEN_LAYERS=[]), VERBOSE=False)
+
+
+def gen_full_configs(ns):
+    """BASELINE.json configs 3-5 at FULL width from the reference's own modules and experiment yamls: Swin-T W=14, Swin-B W=14
+    (widths 128..1024: a GEMM tile family no W=7 fixture touches) and CvT-13 (cvt_v4 s1.yaml), 2x224^2 + 8x96^2 crops, V+R heads,
+    DDINOLoss, B = 2, out_dim 8192.  Same contents per case as gen_full."""
+    RL.ensure_single_process_group()
+    out = {}
+    for name, c in GU.FULL_CFG_CASES.items():
+        torch.manual_seed(0)
+        cfg = _yaml_config(c["yaml"])
+        K, B = c["K"], c["B"]
+        student = ns.models.build_model(cfg, is_teacher=False, use_dense_prediction=True)
+        teacher = ns.models.build_model(cfg, is_teacher=True, use_dense_prediction=True)
+        fea = student.num_features if hasattr(student, "num_features") else cfg.MODEL.SPEC.DIM_EMBED[-1]
+        student.head, teacher.head = ns.DINOHead(fea, K), ns.DINOHead(fea, K)
+        student.head_dense, teacher.head_dense = ns.DINOHead(fea, K), ns.DINOHead(fea, K)
+        GU.fill_full_cfg_pair(student, teacher, c)
+        crops = GU.make_crops(B, seed=c["crop_seed"])
+        loss_fn = ns.DDINOLoss(K, 10, 0.04, 0.04, 0, 1)
+        with torch.no_grad():
+            t_out = teacher(crops[:2])
+        s_out = student(crops)
+        loss = loss_fn(s_out, t_out, 0, None)
+        loss.backward()
+        names = [n for n, p in student.named_parameters() if p.requires_grad]
+        prm = dict(student.named_parameters())
+        n = GU.FULL_CFG_SAMPLE
+        g = {"loss": loss.item(), "grad_norm": {k: prm[k].grad.norm().item() for k in names if prm[k].grad is not None},
+             "sampled": {k: GU.strided(prm[k].grad, n) for k in GU.full_sampled_names(names)},
+             "center": loss_fn.center.clone(), "center_grid": loss_fn.center_grid.clone(),
+             "s_out": [GU.strided(s_out[i], n) for i in range(3)], "s_out_absmax": [s_out[i].detach().abs().max().item() for i in range(3)],
+             "npatch": list(s_out[3]), "param_names": [k for k, _ in student.named_parameters()],
+             "keys": [(k, tuple(v.shape)) for k, v in student.state_dict().items()]}
+        out[name] = g
+        print("full_configs:", name, "loss", g["loss"], "params with grad", len(g["grad_norm"]), "npatch", g["npatch"])
+        del student, teacher, s_out, t_out, loss
+    torch.save(out, os.path.join(OUT, "full_configs.pt"))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ns = RL.load()
@@ -503,6 +552,8 @@ def main():
         gen_full(ns)
     if "full_vit" in only:
         gen_full_vit(ns)
+    if "full_configs" in only:
+        gen_full_configs(ns)
 
 
 if __name__ == "__main__":

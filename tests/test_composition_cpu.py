@@ -481,3 +481,21 @@ def test_knn_classifier_host_logic_matches_reference_golden(cpu_ops, monkeypatch
         xtr, ytr, xte, yte = GU.make_knn_set(c["seed"], noise=c["noise"])
         got = E.knn_classifier(xtr, ytr, xte, yte, c["k"], c["T"], num_classes=10)
         assert got == pytest.approx(want, abs=1e-9), (c, got, want)
+
+
+@pytest.mark.parametrize("name", sorted(GU.FULL_CFG_CASES))
+def test_baseline_configs_3_to_5_full_width_composition_matches_reference_golden(name, cpu_ops):
+    """BASELINE configs 3-5 at FULL width through the product's host code (kernels replaced by their torch restatement, fp32) vs
+    the fixtures produced by the reference's own modules from its own experiment yamls (tests/golden/full_configs.pt): module
+    tree / state_dict layout, outputs, loss, centres, every gradient norm, sampled gradient tensors"""
+    from tests.test_step_gpu import FULL_CFG_GOLD, full_case_deltas, run_full_cfg_case
+    g = torch.load(FULL_CFG_GOLD, map_location="cpu", weights_only=False)[name]
+    student, loss_fn, s_out, t_out, loss = run_full_cfg_case(name, torch.device("cpu"))
+    assert [k for k, _ in student.named_parameters()] == g["param_names"]
+    assert [(k, tuple(v.shape)) for k, v in student.state_dict().items()] == g["keys"]
+    assert list(s_out[3]) == g["npatch"]
+    out_rel, norm_rel, worst, worst_name = full_case_deltas(g, student, s_out, GU.FULL_CFG_SAMPLE)
+    assert out_rel < 1e-4, out_rel
+    assert abs(loss.item() - g["loss"]) < 1e-4, (loss.item(), g["loss"])
+    assert norm_rel < 2e-3 and worst < 5e-3, (norm_rel, worst_name, worst)
+    assert (loss_fn.center - g["center"]).abs().max().item() < 1e-6 and (loss_fn.center_grid - g["center_grid"]).abs().max().item() < 1e-6

@@ -86,9 +86,10 @@ def _nano_step_worker(rank, world, port, out, ragged=True):
 
     student, teacher = nano_pair()
     student.ragged_multi_crop = ragged
-    # the per-group schedule (ragged False) contributes to every backbone parameter once per resolution group: the reducer then
-    # packs and launches nothing before backward has ended (overlap False)
-    red = GradBucketReducer(student, bucket_mb=0.25, overlap=ragged)
+    # the per-group schedule (ragged False) contributes to every backbone parameter once per resolution group: the bucket slot is
+    # handed to the first contribution only (params.grad_out), autograd sums, the hook packs what did not land in the slot -- the
+    # reducer overlaps for every schedule
+    red = GradBucketReducer(student, bucket_mb=0.25)
     assert red.enabled and len(red.buckets) >= 2
     assert all(v.data_ptr() % 16 == 0 for v in red.views.values())  # 16-byte slots (the fused update's vector loads)
     got = grads(student, teacher, rank, red)
@@ -110,11 +111,77 @@ def _nano_step_pergroup_worker(rank, world, port, out):
     _nano_step_worker(rank, world, port, out, ragged=False)
 
 
+def _nano_view_step_worker(rank, world, port, out, ragged=True):
+    """BASELINE config 1 in miniature on two ranks: use_dense_prediction=False + DINOLoss.  The view-level Swin forward runs one
+    backbone pass per resolution group whatever `ragged_multi_crop` says (swin_transformer.py:729-751), so every block parameter
+    gets two gradient contributions per backward while the reducer overlaps (the round-2 advisor's reproduction: with the slot
+    handed out twice, 37 of 126 gradients were wrong); also with `ragged_multi_crop` switched off AFTER the reducer exists"""
+    _init(rank, world, port)
+    import esvit_amd.functional as Fn
+    import esvit_amd.loss as L
+    import esvit_amd.params as P
+    from esvit_amd.engine import GradBucketReducer
+    from oracle import ops_ref
+    from tests import golden_utils as GU
+    from tests.test_composition_cpu import build_nano_view
+    for mod in (Fn, L, P):
+        mod.ops = ops_ref
+    ops_ref.set_act_dtype(torch.float32)
+    K = GU.NANO_HEAD["out_dim"]
+
+    def pair():
+        student, teacher = build_nano_view(), build_nano_view(teacher=True)
+        GU.fill_state_dict(student.state_dict(), 0)
+        GU.fill_state_dict(teacher.state_dict(), 7)
+        student.head.last_layer.weight_g.data.fill_(1)
+        for p in teacher.parameters():
+            p.requires_grad = False
+        return student, teacher
+
+    def grads(student, teacher, r, reducer):
+        crops = GU.make_crops(1, n_local=2, seed=500 + r)
+        loss_fn = L.DINOLoss(K, 4, 0.04, 0.04, 0, 1)
+        loss_fn._reduce_and_apply = lambda buf, apply: None
+        for p in student.parameters():
+            p.grad = None
+        with torch.no_grad():
+            t_out = teacher(crops[:2])
+        loss = loss_fn(student(crops), t_out, 0, None)
+        if reducer is not None:
+            reducer.begin()
+        loss.backward()
+        if reducer is not None:
+            reducer.finish()
+        return {n: p.grad.detach().clone() for n, p in student.named_parameters() if p.grad is not None}
+
+    student, teacher = pair()
+    red = GradBucketReducer(student, bucket_mb=0.25)
+    assert red.enabled and red.overlap and len(red.buckets) >= 2
+    student.ragged_multi_crop = ragged  # (set after the reducer was built, as the odd-feature-map error message suggests)
+    got = grads(student, teacher, rank, red)
+    got = grads(student, teacher, rank, red)  # a second step: slots are handed out afresh
+    assert all(p.grad.data_ptr() == red.views[id(p)].data_ptr() for p in student.parameters() if p.grad is not None)
+    red.close()
+    ref_student, ref_teacher = pair()
+    ref_student.ragged_multi_crop = ragged
+    acc = None
+    for r in range(world):
+        g = grads(ref_student, ref_teacher, r, None)
+        acc = g if acc is None else {n: acc[n] + g[n] for n in g}
+    ok = set(got) == set(acc) and all(torch.allclose(got[n], acc[n] / world, rtol=2e-4, atol=1e-7) for n in got)
+    out[rank] = bool(ok)
+    dist.destroy_process_group()
+
+
+def _nano_view_step_noragged_worker(rank, world, port, out):
+    _nano_view_step_worker(rank, world, port, out, ragged=False)
+
+
 def _nano_vit_step_worker(rank, world, port, out, ragged=True):
     """the monolithic ViT on two ranks.  ragged: all crops through one set of row-wise launches, one gradient contribution per
-    parameter, written straight into the reducer's bucket slots (overlap mode); not ragged: one backbone pass per resolution group
-    (vision_transformer.py:186-233), two contributions per parameter -- the reducer's non-overlapped mode.  Either way the averaged
-    gradients equal the mean of the per-rank gradients"""
+    parameter, written straight into the reducer's bucket slots; not ragged: one backbone pass per resolution group
+    (vision_transformer.py:186-233), two contributions per parameter (the first into the slot, the sum packed by the hook).  Either
+    way the reducer overlaps and the averaged gradients equal the mean of the per-rank gradients"""
     _init(rank, world, port)
     import esvit_amd.functional as Fn
     import esvit_amd.loss as L
@@ -146,11 +213,11 @@ def _nano_vit_step_worker(rank, world, port, out, ragged=True):
 
     student, teacher = nano_vit_pair()
     student.ragged_multi_crop = ragged
-    red = GradBucketReducer(student, bucket_mb=0.1, overlap=bool(getattr(student, "ragged_multi_crop", False)))  # as EsvitTrainer arms it
-    assert red.enabled and red.overlap == ragged and len(red.buckets) >= 2
+    red = GradBucketReducer(student, bucket_mb=0.1)  # as EsvitTrainer arms it
+    assert red.enabled and red.overlap and len(red.buckets) >= 2
     got = grads(student, teacher, rank, red)
-    if ragged:  # every gradient was produced in (or packed into) its bucket slot
-        assert all(p.grad.data_ptr() == red.views[id(p)].data_ptr() for p in student.parameters() if p.grad is not None)
+    # every gradient was produced in (or packed into) its bucket slot
+    assert all(p.grad.data_ptr() == red.views[id(p)].data_ptr() for p in student.parameters() if p.grad is not None)
     red.close()
     ref_student, ref_teacher = nano_vit_pair()
     ref_student.ragged_multi_crop = ragged
@@ -256,7 +323,8 @@ def _extract_worker(rank, world, port, out):
 
 
 @pytest.mark.parametrize("worker,port", [(_reducer_worker, 29611), (_center_worker, 29612), (_syncbn_worker, 29613), (_extract_worker, 29614),
-                                         (_nano_step_worker, 29615), (_nano_step_pergroup_worker, 29616), (_nano_vit_step_worker, 29617), (_nano_vit_step_pergroup_worker, 29618)])
+                                         (_nano_step_worker, 29615), (_nano_step_pergroup_worker, 29616), (_nano_vit_step_worker, 29617), (_nano_vit_step_pergroup_worker, 29618),
+                                         (_nano_view_step_worker, 29619), (_nano_view_step_noragged_worker, 29620)])
 def test_world2_gloo(worker, port, lib_built):
     world = 2
     out = mp.Manager().dict()

@@ -490,3 +490,37 @@ def test_fused_update_matches_torch(mods):
         _close("exp_avg", sd_fus["state"][k]["exp_avg"], sd_ref["state"][k]["exp_avg"], 2e-5)
         _close("exp_avg_sq", sd_fus["state"][k]["exp_avg_sq"], sd_ref["state"][k]["exp_avg_sq"], 2e-5)
         assert float(sd_fus["state"][k]["step"]) == float(sd_ref["state"][k]["step"])
+
+
+@pytest.mark.parametrize("rule", ["adamw", "sgd", "lars"])
+def test_fused_update_skips_non_finite_step(mods, rule):
+    """a NaN / inf gradient anywhere makes the whole fused update a no-op (the reference exits before its update on a non-finite
+    loss, main_esvit.py:546-551): student, optimizer state and teacher keep their values; the next finite step updates again"""
+    import copy
+    from esvit_amd.update import FusedClipAdamWEMA
+    dev = _dev()
+    torch.manual_seed(1)
+    net = torch.nn.Sequential(torch.nn.Linear(64, 33), torch.nn.LayerNorm(33), torch.nn.Linear(33, 700)).to(dev)
+    teacher = copy.deepcopy(net)
+    for p in teacher.parameters():
+        p.data.mul_(0.5)
+        p.requires_grad_(False)
+    kw = {} if rule == "adamw" else dict(rule=rule, momentum=0.9)
+    opt = FusedClipAdamWEMA(net, teacher, **kw)
+
+    def step(poison):
+        for i, p in enumerate(net.parameters()):
+            p.grad = torch.randn_like(p)
+        if poison is not None:
+            list(net.parameters())[2].grad.view(-1)[5] = poison
+        opt.step(1e-2, 0.05, 0.9, clip_grad=3.0)
+        torch.cuda.synchronize()
+
+    step(None)
+    snap = [p.detach().clone() for p in list(net.parameters()) + list(teacher.parameters()) + list(opt.exp_avg)]
+    for bad in (float("nan"), float("inf")):
+        step(bad)
+        now = list(net.parameters()) + list(teacher.parameters()) + list(opt.exp_avg)
+        assert all(torch.equal(a, b.detach()) for a, b in zip(snap, now)), "a non-finite step changed the state"
+    step(None)
+    assert not torch.equal(snap[0], list(net.parameters())[0].detach())

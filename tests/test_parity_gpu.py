@@ -9,7 +9,6 @@
   clip -> cancel -> AdamW -> EMA result;
 * Swin forward_return_n_last_blocks (swin_transformer.py:799-837) vs the reference golden;
 * one Swin-T step at out_dim 65536, B = 8 vs the CPU oracle (loss + sampled gradient tensors)."""
-import json
 import os
 
 import pytest
@@ -23,19 +22,7 @@ from tests.test_oracle_cpu import GOLD, probe_close
 
 pytestmark = pytest.mark.gpu
 
-OBSERVED = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "parity_observed.jsonl")
-
-
-def _record(**kw):
-    """observed deltas go to the test log (pytest -s / -rP) and, when the directory exists, to gpurun_out/ for the profiles"""
-    line = json.dumps(kw)
-    print("PARITY", line)
-    try:
-        if os.path.isdir(os.path.dirname(OBSERVED)):
-            with open(OBSERVED, "a") as fh:
-                fh.write(line + "\n")
-    except OSError:
-        pass
+_record = GU.record_parity
 
 
 @pytest.fixture(scope="module")
@@ -111,13 +98,17 @@ def test_config1_swin_tiny_bs4_matches_reference_golden(prec, lib_built):
         fp = prec == "fp32"
         out_rel, norm_rel, worst, worst_name = full_case_deltas(g, student, s_out)
         t_rel = ((GU.strided(t_out).float().cpu() - g["t_out"]).abs().max() / g["t_out"].abs().max()).item()
+        c_err = (loss_fn.center.cpu() - g["center"]).abs().max().item()
         _record(test="config1_swin_tiny_bs4", prec=prec, loss=loss.item(), ref=g["loss"], abs_err=abs(loss.item() - g["loss"]),
-                logits_rel=out_rel, worst_grad_norm_rel=norm_rel, worst_sampled_grad_rel_l2=worst, worst_tensor=worst_name)
-        assert out_rel < (1e-4 if fp else 5e-2) and t_rel < (1e-4 if fp else 5e-2), (out_rel, t_rel)
-        assert abs(loss.item() - g["loss"]) < (1e-4 if fp else 5e-3), (loss.item(), g["loss"])
-        assert (loss_fn.center.cpu() - g["center"]).abs().max().item() < (1e-6 if fp else 2e-3)
-        assert norm_rel < (5e-3 if fp else 0.2), norm_rel
-        assert worst < (5e-3 if fp else 0.25), (worst_name, worst)
+                logits_rel=out_rel, teacher_logits_rel=t_rel, center_abs=c_err, worst_grad_norm_rel=norm_rel, worst_sampled_grad_rel_l2=worst,
+                worst_tensor=worst_name)
+        # bf16 bounds: <= 3x the deltas observed on MI355X (profiles/r03_parity_observed.jsonl; round 2: loss 3.1e-5, logits 6.3e-3,
+        # gradient norms 5.9e-3, sampled gradient tensors 2.3e-2 relative L2)
+        assert out_rel < (1e-4 if fp else 2e-2) and t_rel < (1e-4 if fp else 2e-2), (out_rel, t_rel)
+        assert abs(loss.item() - g["loss"]) < (1e-4 if fp else 1e-4), (loss.item(), g["loss"])
+        assert c_err < (1e-6 if fp else 2e-3)
+        assert norm_rel < (5e-3 if fp else 1.8e-2), norm_rel
+        assert worst < (5e-3 if fp else 7e-2), (worst_name, worst)
     finally:
         _teardown()
 
@@ -181,11 +172,12 @@ def test_bf16_step_like_for_like(nano, monkeypatch, lib_built):
                 hip_vs_emulated=abs(loss.item() - l_emu), hip_vs_fp32_reference=abs(loss.item() - nano["ddino_loss"]),
                 worst_grad_rel_l2_vs_emulated=worst_l2, worst_grad_tensor=worst_name, worst_grad_norm_rel_vs_fp32_reference=worst_vs_fp32,
                 logits_rel_vs_emulated=logit_rel)
+        # <= 3x observed (round 2: 2.0e-3, 7.5e-4, 9.3e-3, 0.138, 8.2e-3)
         assert abs(loss.item() - l_emu) < 5e-3, (loss.item(), l_emu)
-        assert abs(loss.item() - nano["ddino_loss"]) < 3e-3, (loss.item(), nano["ddino_loss"])
-        assert logit_rel < 3e-2, logit_rel
+        assert abs(loss.item() - nano["ddino_loss"]) < 2.2e-3, (loss.item(), nano["ddino_loss"])
+        assert logit_rel < 2.8e-2, logit_rel
         assert worst_l2 < 0.25, (worst_name, worst_l2)
-        assert worst_vs_fp32 < 0.05, worst_vs_fp32
+        assert worst_vs_fp32 < 2.5e-2, worst_vs_fp32
     finally:
         _teardown()
 
@@ -263,9 +255,10 @@ def test_swin_tiny_k65536_b8_step_matches_reference_golden(lib_built):
         out_rel, norm_rel, worst, worst_name = full_case_deltas(g, student, s_out)
         _record(test="swin_tiny_k65536_b8", loss_hip_bf16=loss.item(), loss_reference_fp32=g["loss"], abs_err=abs(loss.item() - g["loss"]),
                 outputs_rel=out_rel, worst_grad_norm_rel=norm_rel, worst_sampled_grad_rel_l2=worst, worst_tensor=worst_name)
-        assert abs(loss.item() - g["loss"]) < 5e-3, (loss.item(), g["loss"])
-        assert out_rel < 5e-2, out_rel
-        assert norm_rel < 0.2, norm_rel
+        # <= 3x observed (round 2: loss 5.1e-5, outputs 8.5e-3, gradient norms 9.2e-3, sampled gradient tensors 5.6e-2)
+        assert abs(loss.item() - g["loss"]) < 1.5e-4, (loss.item(), g["loss"])
+        assert out_rel < 2.6e-2, out_rel
+        assert norm_rel < 2.8e-2, norm_rel
         assert worst < 0.1, (worst_name, worst)
         assert (loss_fn.center.cpu() - g["center"]).abs().max().item() < 2e-3
     finally:

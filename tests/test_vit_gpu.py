@@ -60,7 +60,7 @@ def test_heads_split_merge_and_softmax(dt, shape, lib_built):
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("shape", [(2, 37, 3, 64), (4, 197, 6, 64), (3, 17, 2, 32), (2, 197, 12, 64)])
+@pytest.mark.parametrize("shape", [(2, 37, 3, 64), (4, 197, 6, 64), (3, 17, 2, 32), (2, 197, 12, 64), (1, 785, 3, 64), (2, 401, 2, 32)])
 def test_vit_attention_matches_restatement(dt, shape, lib_built):
     """Attention.forward between the two projections, and its gradient: batched esvit_gemm + softmax vs oracle/ops_ref"""
     from esvit_amd import ops
