@@ -171,14 +171,17 @@ def run_full_case(name, dev):
 
 def full_case_deltas(g, student, s_out, n=GU.FULL_SAMPLE):
     """-> (worst relative error of the sampled student outputs, worst relative gradient-norm error, worst relative L2 error of the
-    sampled gradient tensors and its name)"""
+    sampled gradient tensors and its name).  Gradients that are ZERO in exact arithmetic are compared on an absolute scale: the
+    LayerNorm weight in front of CvT's depthwise-conv + BatchNorm projection has no gradient (BatchNorm removes any per-channel
+    scale), the reference's 1e-8 there is fp32 rounding noise -- denominators are floored at 1e-5 of the largest gradient norm."""
     outs = s_out[:3] if isinstance(s_out, (tuple, list)) else [s_out]
     out_rel = max(((GU.strided(o, n).float().cpu() - ref).abs().max() / mx).item() for o, ref, mx in zip(outs, g["s_out"], g["s_out_absmax"]))
     prm = dict(student.named_parameters())
-    norm_rel = max(abs(prm[n].grad.norm().item() - r) / (r + 1e-12) for n, r in g["grad_norm"].items())
+    floor = 1e-5 * max(g["grad_norm"].values())
+    norm_rel = max(abs(prm[k].grad.norm().item() - r) / max(r, floor) for k, r in g["grad_norm"].items())
     worst, worst_name = 0.0, ""
     for k, ref in g["sampled"].items():
-        d = ((GU.strided(prm[k].grad, n).float().cpu() - ref).norm() / (ref.norm() + 1e-12)).item()
+        d = ((GU.strided(prm[k].grad, n).float().cpu() - ref).norm() / max(ref.norm().item(), floor)).item()
         if d > worst:
             worst, worst_name = d, k
     return out_rel, norm_rel, worst, worst_name
@@ -214,10 +217,11 @@ def run_full_cfg_case(name, dev):
 
 
 # bf16 bounds per case: <= 3x the deltas observed on MI355X (profiles/r03_parity_observed.jsonl): (outputs, loss, grad norms, sampled)
+# (observed in round 3: W14-T 8.2e-3 / 6.2e-4 / 1.4e-2 / 8.5e-2, W14-B 1.1e-2 / 3.7e-4 / 1.0e-2 / 5.7e-2, CvT-13 7.8e-3 / 1.4e-4 / 3.9e-2 / 6.6e-2)
 FULL_CFG_BF16_BOUNDS = {
-    "swin_t_w14_k8192_b2": (5e-2, 1e-2, 0.2, 0.25),
-    "swin_b_w14_k8192_b2": (5e-2, 1e-2, 0.2, 0.25),
-    "cvt13_s1_k8192_b2": (5e-2, 1e-2, 0.2, 0.25),
+    "swin_t_w14_k8192_b2": (2.5e-2, 1.9e-3, 4.3e-2, 0.25),
+    "swin_b_w14_k8192_b2": (3.2e-2, 1.1e-3, 3.2e-2, 0.17),
+    "cvt13_s1_k8192_b2": (2.4e-2, 4.2e-4, 0.12, 0.2),
 }
 
 
