@@ -1,36 +1,48 @@
-// Fused Swin MLP forward for inference-mode passes (swin_transformer.py:331 + 31-37):
+// Fused Swin MLP branch for the narrow stages (C = 96, 192), forward AND backward (swin_transformer.py:331 + 31-37):
 //
 //     y = x + rowscale * ( GELU( LN(x) W1^T + b1 ) W2^T + b2 )          x, y: fp32 [M, C];  W1: [4C, C];  W2: [C, 4C]
 //
-// for the narrow stages (C = 96, 192) of the TEACHER, which saves nothing for a backward: the unfused sequence LayerNorm ->
-// fc1 (+GELU) -> fc2 (+residual) moves 32 B per token-channel through HBM, most of it the 4C-wide hidden activation; fused
-// it is 8 B.  (A variant that also wrote the LayerNorm output / pre-activation / GELU output the student's backward reads
-// was measured: those 18 B per token-channel of side outputs leave it no faster than the unfused kernels --
-// profiles/r02_mlp_fused.jsonl -- so the student keeps the unfused path.)
+// The unfused sequence LayerNorm -> fc1 (+GELU) -> fc2 (+residual) moves 40 B per token-channel through HBM in the forward
+// (most of it the 4C-wide hidden activation, written twice for the backward) and 64 B in the backward.  Here:
 //
-// Work split.  A workgroup is 4 waves; a wave OWNS 32 token rows for the whole MLP, so nothing but the weight tiles is
-// shared between waves.  MFMA shape: v_mfma_f32_32x32x16_bf16.  For a 32-wide chunk of the hidden dimension the wave
-// computes the TRANSPOSED pre-activation  P^T[hidden 32][token 32] = W1_chunk[32 x C] * LN(x)^T  with LN(x) as the B
-// operand, held in registers for the whole tile (lane (n, h): token n, channels 16s + 8h .. +7).  In the accumulator
-// layout (col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)) lane (n, h) then holds, for ITS token n, the
-// MFMA rows {8m + 4h + e}: after bias + GELU + rounding these 16 values ARE two A-operand fragments of the second GEMM
-// y[token][c] += H[token][hidden] W2[c][hidden], so H never leaves the registers (the trick the 14x14 attention kernels use
-// for P, window_attn_big.hip).  Which hidden unit an MFMA row computes is free -- it is just the W1 row the A fragment
-// reads -- so row i is given hidden unit rho(i) (bits 2 and 3 of i swapped): each lane half then owns 8 CONSECUTIVE hidden
-// units per k-step and W2 is read in its natural order, one 16-byte LDS read per fragment.
+//   esvit_mlp_fused_fwd   8 B per token-channel (x in, y out); NOTHING hidden-sized is saved -- the backward recomputes it.
+//                         Optionally it also emits LayerNorm(y) with the NEXT block's norm1 parameters (bf16) and its row
+//                         statistics, so that block's LayerNorm launch disappears.
+//   esvit_mlp_fused_bwd   recomputes LN(x) and the pre-activation chunk by chunk, forms dA = (dy W2) o GELU'(A) and
+//                         dH = dA W1 with the hidden tile in registers, applies the LayerNorm backward in registers and writes
+//                         dL/dx (fp32), its activation-dtype copy, and -- once, coalesced -- the three operands the two
+//                         weight-gradient GEMMs need: GELU(A), dA (bf16 [M, 4C]) and xhat = (x - mean) rstd (bf16 [M, C]).
+//                         The LayerNorm parameter gradients come out of the fc1 weight gradient (esvit_ln_fold_finish below),
+//                         so no cross-lane column reduction exists in the kernel.
 //
-// Weights stream L2 -> LDS by LDS-DMA (buffer_load ... lds) in 32-hidden chunks (W1 rows [32 x C], W2 columns [C x 32]),
-// three buffers (chunk q + 2 is requested while chunk q is computed), one workgroup barrier per chunk; bank conflicts are
-// removed by XOR-swizzling the 16-byte chunk index on the source address and on the fragment read (guide rule 21; measured
-// SQ_LDS_BANK_CONFLICT = 0).  The loop body contains no vector-memory operation besides the DMA (the fc1 bias arrives
-// through scalar loads), so the counted wait at the end of a chunk is exact.  LDS: 3 x (W1 + W2 chunk) = 36 / 72 KiB.
+// Work split.  A workgroup is 4 waves; a wave OWNS 32 token rows for the whole branch, so nothing but the weight tiles is
+// shared between waves.  MFMA shape: v_mfma_f32_32x32x16_bf16.  Every product is formed TRANSPOSED -- hidden / channel index
+// on the MFMA rows, the wave's 32 tokens on the MFMA columns:
+//     P^T [32 hidden][32 tok] = W1_chunk [32 x C]  * LN(x)^T          (A: weight rows from LDS, B: token fragments in registers)
+//     y^T [C][32 tok]        += W2_chunk [C x 32]  * GELU(P)^T        (B: the accumulator registers of the line above)
+// In the accumulator layout (col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)) lane (n, h) holds, for ITS token n,
+// MFMA rows {8m + 4h + e}: after bias + GELU + rounding these 16 values ARE two B-operand fragments of the next product, so the
+// hidden tile never leaves the registers (the trick the 14x14 attention kernels use for P, window_attn_big.hip).  Which hidden
+// unit an MFMA row computes is free -- it is just the W1 row the A fragment reads -- so row i is given hidden unit rho(i) (bits
+// 2 and 3 of i swapped): each lane half then owns 8 CONSECUTIVE hidden units per k-step and the second weight is read in its
+// natural order, one 16-byte LDS read per fragment.  Because the OUTPUT tiles are transposed as well, a lane ends up with 16 of
+// every 32 channels of its own token (its partner lane n + 32 has the other 16): row statistics (the next LayerNorm, the
+// LayerNorm backward) are in-lane sums plus one cross-half exchange, and all global accesses are 16-byte vectors.
+//
+// Weights stream L2 -> LDS by LDS-DMA (buffer_load ... lds) in 32-hidden chunks, NBUF buffers, one workgroup barrier per
+// chunk; bank conflicts are removed by XOR-swizzling the 16-byte chunk index on the source address and on the fragment read
+// (guide rule 21).  The forward loop contains no vector-memory operation besides the DMA; the backward loop also stores the two
+// hidden tiles, and its counted wait accounts for them (vmcnt retires in order).
+#include <stdlib.h>
+
 #include "common.h"
 #include "../../include/esvit_hip.h"
 
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef short s16x8v __attribute__((ext_vector_type(8)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int MLP_WAVES = 4;
 constexpr int MLP_ROWS = 32 * MLP_WAVES;  // token rows per workgroup
@@ -38,24 +50,31 @@ constexpr int HCH = 32;                   // hidden units per chunk
 
 template <int C>
 struct MlpCfg {
-    static constexpr int KS1 = C / 16;            // k-steps of GEMM1 (k = channel)
-    static constexpr int NT2 = C / 32;            // 32-channel output tiles of GEMM2
-    static constexpr int W1_BYTES = HCH * C * 2;  // [32 hidden][C]
-    static constexpr int W2_BYTES = C * HCH * 2;  // [C][32 hidden]
-    static constexpr int P1 = W1_BYTES / 1024;    // 1 KiB DMA pieces of the W1 image, then of the W2 image
-    static constexpr int PPW = (W1_BYTES + W2_BYTES) / 1024 / MLP_WAVES;  // pieces (= DMA instructions) per wave and chunk
-    static_assert((W1_BYTES + W2_BYTES) % (1024 * MLP_WAVES) == 0, "every wave issues the same number of DMA instructions");
-    static constexpr int WBUF = W1_BYTES + W2_BYTES;
-    static constexpr int NBUF = 3;                                   // chunk q + 2 is requested while chunk q is computed
-    static constexpr int LDS_BYTES = NBUF * WBUF;
-    static constexpr int M1 = C == 192 ? 7 : 3;  // swizzle mask of the W1 image (chunks per row: 24 = 3 x 8, 12 = 3 x 4)
-    // W1 image: rows of 2C bytes.  One A-fragment read = 32 rows x 16 bytes at one chunk index: the 384-byte pitch (C = 192)
+    static constexpr int KS1 = C / 16;            // k-steps of a product over the channels
+    static constexpr int NT2 = C / 32;            // 32-channel output tiles
+    static constexpr int W1_BYTES = HCH * C * 2;  // image A: [32 hidden][C]      (rows of W1, or of W2^T)
+    static constexpr int W2_BYTES = C * HCH * 2;  // image B: [C][32 hidden]      (columns of W2, or of W1^T)
+    static constexpr int PA = W1_BYTES / 1024;    // 1 KiB DMA pieces per image
+    static constexpr int PB = W2_BYTES / 1024;
+    static constexpr int M1 = C == 192 ? 7 : 3;   // swizzle mask of image A (chunks per row: 24 = 3 x 8, 12 = 3 x 4)
+    // image A: rows of 2C bytes.  One fragment read = 32 rows x 16 bytes at one chunk index: the 384-byte pitch (C = 192)
     // alternates two bank phases -> XOR the chunk with (row >> 1) & 7; the 192-byte pitch (C = 96) cycles four -> (row >> 2) & 3.
     __device__ __forceinline__ static int sw1(int row) { return C == 192 ? ((row >> 1) & 7) : ((row >> 2) & 3); }
     __device__ __forceinline__ static int pos1(int chunk, int row) { return (chunk & ~M1) | ((chunk ^ sw1(row)) & M1); }
-    // W2 image: rows of 64 bytes = 4 chunks; a fragment read touches 32 consecutive rows at one 8-byte slot -> XOR the
-    // chunk with (row >> 2) & 3 (rows n and n + 16 still share a bank: 2-way on an 8-byte read, off the critical path)
+    // image B: rows of 64 bytes = 4 chunks; a fragment read touches 32 consecutive rows at one 16-byte slot -> XOR the
+    // chunk with (row >> 2) & 3
     __device__ __forceinline__ static int sw2(int row) { return (row >> 2) & 3; }
+    // per-lane source byte offset of DMA piece `piece` of an image (chunk 0); chunk q adds a scalar offset
+    __device__ __forceinline__ static int voff_a(int piece, int lane) {
+        const int p = piece * 64 + lane;              // 16-byte chunk index inside the image
+        const int r = p / (C / 8), cp = p % (C / 8);  // image row (hidden unit of the chunk), chunk position in the row
+        return (r * C + pos1(cp, r) * 8) * 2;         // (XOR is an involution: image position cp holds source chunk pos1(cp))
+    }
+    __device__ __forceinline__ static int voff_b(int piece, int lane) {
+        const int p = piece * 64 + lane;
+        const int r = p / 4, cp = p % 4;              // image row (channel), chunk position (8 hidden units each)
+        return (r * 4 * C + (cp ^ sw2(r)) * 8) * 2;
+    }
 };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t mk_rsrc(const void* base, long bytes) {
@@ -68,12 +87,63 @@ __device__ __forceinline__ void wait_vm() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+// Workgroup barrier of the chunk loops.  NOT __syncthreads(): its fence makes hipcc emit s_waitcnt vmcnt(0) in front of the
+// s_barrier, which drains the LDS-DMA of the chunk after next (and, in the backward, the hidden-tile stores to HBM) at every
+// chunk -- the loop would run at memory latency.  The data hazards are covered explicitly: the counted vmcnt before the barrier
+// (this wave's DMA pieces of the next chunk have landed), lgkmcnt(0) (this wave's LDS reads of the current chunk have returned).
+__device__ __forceinline__ void chunk_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+__device__ __forceinline__ unsigned pack2(float a, float b) {
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    const bf16x2 v = {(bf16)a, (bf16)b};
+    return __builtin_bit_cast(unsigned, v);
+}
+
+// lanes n and n + 32 each hold two 4-channel groups (x: channels 8j' + 4h .., y: channels 8(j'+1) + 4h ..): exchange so that
+// the low lane holds channels 8j' .. 8j' + 7 and the high lane 8(j'+1) .. 8(j'+1) + 7 (v_permlane32_swap)
+__device__ __forceinline__ void pair_swap(unsigned& x, unsigned& y) {
+    const u32x2 r = __builtin_amdgcn_permlane32_swap(x, y, false, false);
+    x = r[0];
+    y = r[1];
+}
+
+// exact erf-GELU and its derivative from ONE exponential: erf's exp(-u^2) with u = v / sqrt(2) is the Gaussian of GELU'
+__device__ __forceinline__ void gelu_both(float v, float& g, float& dg) {
+    const float av = fabsf(v) * 0.70710678118654752f;
+    const float t = __builtin_amdgcn_rcpf(1.f + 0.3275911f * av);
+    const float e = __expf(-0.5f * v * v);
+    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    const float erfv = copysignf(1.f - poly * e, v);
+    const float cdf = 0.5f * (1.f + erfv);
+    g = v * cdf;
+    dg = cdf + v * 0.39894228040143268f * e;
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------------------------------------
 template <int C>
+struct FwdCfg : MlpCfg<C> {
+    using B = MlpCfg<C>;
+    static constexpr int NP = B::PA + B::PB;                  // DMA pieces per chunk
+    static constexpr int PPW = NP / MLP_WAVES;                // per wave
+    static_assert(NP % MLP_WAVES == 0, "every wave issues the same number of DMA instructions");
+    static constexpr int WBUF = B::W1_BYTES + B::W2_BYTES;
+    static constexpr int NBUF = 3;                            // chunk q + 2 is requested while chunk q is computed
+    static constexpr int LDS_BYTES = NBUF * WBUF;
+};
+
+template <int C, bool LNN>
 __device__ __forceinline__ void mlp_fused_fwd_body(
     const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
     const bf16* __restrict__ W1, const float* __restrict__ b1, const bf16* __restrict__ W2, const float* __restrict__ b2,
-    const float* __restrict__ rowscale, long M, float* __restrict__ y) {
-    using Cfg = MlpCfg<C>;
+    const float* __restrict__ rowscale, long M, float* __restrict__ y, const float* __restrict__ gamma_n,
+    const float* __restrict__ beta_n, bf16* __restrict__ xw_n, float* __restrict__ mean_n, float* __restrict__ rstd_n) {
+    using Cfg = FwdCfg<C>;
     constexpr int H4 = 4 * C;
     constexpr int NCHUNK = H4 / HCH;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -87,21 +157,13 @@ __device__ __forceinline__ void mlp_fused_fwd_body(
     const bool row_ok = row < M;
     const long rrow = row_ok ? row : (M - 1);  // out-of-range lanes compute on a valid row and store nothing
 
-    // ---- weight chunk DMA: per-lane source byte offsets of this wave's instructions for chunk 0; chunk q adds a scalar ----
+    // ---- weight chunk DMA ----
     const __amdgpu_buffer_rsrc_t r1 = mk_rsrc(W1, (long)H4 * C * 2), r2 = mk_rsrc(W2, (long)C * H4 * 2);
     int voff[Cfg::PPW];
 #pragma unroll
     for (int i = 0; i < Cfg::PPW; ++i) {
         const int piece = wave * Cfg::PPW + i;  // wave-uniform
-        if (piece < Cfg::P1) {
-            const int p = piece * 64 + lane;              // 16-byte chunk index inside the W1 image
-            const int r = p / (C / 8), cp = p % (C / 8);  // image row (hidden unit of the chunk), chunk position in the row
-            voff[i] = (r * C + Cfg::pos1(cp, r) * 8) * 2;  // (XOR is an involution: image position cp holds source chunk pos1(cp))
-        } else {
-            const int p = (piece - Cfg::P1) * 64 + lane;
-            const int r = p / 4, cp = p % 4;              // image row (output channel), chunk position (8 hidden units each)
-            voff[i] = (r * H4 + (cp ^ Cfg::sw2(r)) * 8) * 2;
-        }
+        voff[i] = piece < Cfg::PA ? Cfg::voff_a(piece, lane) : Cfg::voff_b(piece - Cfg::PA, lane);
     }
     auto issue_chunk = [&](int q, int buf) {
         char* img = smem + buf * Cfg::WBUF;  // W1 image, then W2 image
@@ -109,14 +171,14 @@ __device__ __forceinline__ void mlp_fused_fwd_body(
 #pragma unroll
         for (int i = 0; i < Cfg::PPW; ++i) {
             const int piece = wave * Cfg::PPW + i;
-            if (piece < Cfg::P1) __builtin_amdgcn_raw_ptr_buffer_load_lds(r1, (lds_void*)(img + piece * 1024), 16, voff[i], so1, 0, 0);
+            if (piece < Cfg::PA) __builtin_amdgcn_raw_ptr_buffer_load_lds(r1, (lds_void*)(img + piece * 1024), 16, voff[i], so1, 0, 0);
             else __builtin_amdgcn_raw_ptr_buffer_load_lds(r2, (lds_void*)(img + piece * 1024), 16, voff[i], so2, 0, 0);
         }
     };
     issue_chunk(0, 0);
     issue_chunk(1, 1);
 
-    // ---- LayerNorm of this lane's half row, straight into the B-operand fragments of GEMM1 ----
+    // ---- LayerNorm of this lane's half row, straight into the B-operand fragments of the first product ----
     bf16x8 xb[Cfg::KS1];
     {
         const float* xr = x + rrow * C + 8 * hh;
@@ -158,19 +220,15 @@ __device__ __forceinline__ void mlp_fused_fwd_body(
         }
     }
 
-    f32x16 acc2[Cfg::NT2];
+    f32x16 acc2[Cfg::NT2];  // y^T: tile mt, register r <-> channel 32 mt + (r & 3) + 8 (r >> 2) + 4 hh of token n
 #pragma unroll
     for (int t = 0; t < Cfg::NT2; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc2[t][r] = 0.f;
 
-    wait_vm<0>();     // this wave's parts of chunks 0 and 1 have landed (and its LN loads / stores are done)
+    wait_vm<0>();     // this wave's parts of chunks 0 and 1 have landed (and its LN loads are done)
     __syncthreads();  // ... everybody else's too
 
-    // MFMA row i of the transposed pre-activation tile holds hidden unit rho(i) of the chunk, rho swapping bits 2 and 3 of i:
-    // lane (n, hh) then owns, for k-step t of the second GEMM, the EIGHT CONSECUTIVE hidden units 16t + 8hh .. +7 (registers
-    // 8t .. 8t+7), i.e. the standard "half hh holds k = 8hh + j" operand convention -- W2 is read in its natural order with one
-    // 16-byte LDS read per fragment.
     const int rho_n = (n & ~12) | ((n & 4) << 1) | ((n & 8) >> 1);
     int buf = 0;
     for (int q = 0; q < NCHUNK; ++q) {
@@ -179,7 +237,7 @@ __device__ __forceinline__ void mlp_fused_fwd_body(
         const char* w1 = smem + buf * Cfg::WBUF;
         const char* w2 = w1 + Cfg::W1_BYTES;
 
-        // ---- GEMM1: P^T[32 hidden][32 tokens] = W1_chunk * LN(x)^T (two accumulators: half the dependent-MFMA chain) ----
+        // ---- P^T[32 hidden][32 tokens] = W1_chunk * LN(x)^T (two accumulators: half the dependent-MFMA chain) ----
         f32x16 acc1a, acc1b;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc1a[r] = acc1b[r] = 0.f;
@@ -196,88 +254,507 @@ __device__ __forceinline__ void mlp_fused_fwd_body(
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                // MFMA row of register 8t + e: (r & 3) + 8 (r >> 2) + 4hh with r = 8t + e  ->  hidden rho(row) = 16t + 8hh + e
                 const float blo = bq[16 * t + e], bhi = bq[16 * t + 8 + e];
                 const float v = acc1a[8 * t + e] + acc1b[8 * t + e] + (hh ? bhi : blo);
                 hf[t][e] = (bf16)gelu_f(v);
             }
-        // ---- GEMM2: y[32 tokens][C] += H[32 tokens][32 hidden] W2_chunk^T ----
+        // ---- y^T[C][32 tokens] += W2_chunk[C x 32 hidden] * H^T ----
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
 #pragma unroll
-            for (int nt = 0; nt < Cfg::NT2; ++nt) {
-                const int c = 32 * nt + n;  // B fragment: output channel c, hidden 16t + 8hh .. +7 of the chunk
-                const bf16x8 b = *reinterpret_cast<const bf16x8*>(w2 + c * 64 + (((2 * t + hh) ^ Cfg::sw2(c)) * 16));
-                acc2[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hf[t], b, acc2[nt], 0, 0, 0);
+            for (int mt = 0; mt < Cfg::NT2; ++mt) {
+                const int c = 32 * mt + n;  // A fragment: output channel c, hidden 16t + 8hh .. +7 of the chunk
+                const bf16x8 a = *reinterpret_cast<const bf16x8*>(w2 + c * 64 + (((2 * t + hh) ^ Cfg::sw2(c)) * 16));
+                acc2[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, hf[t], acc2[mt], 0, 0, 0);
             }
         }
         // chunk q + 1 must have landed before the barrier; the DMA of chunk q + 2, issued after it, may stay in flight
         if (more) wait_vm<Cfg::PPW>();
         else wait_vm<0>();
-        __syncthreads();  // chunk q + 1 landed for every wave; every wave is done reading chunk q
+        chunk_barrier();  // chunk q + 1 landed for every wave; every wave is done reading chunk q
         buf = buf == 2 ? 0 : buf + 1;
     }
 
-    // ---- epilogue: y = x + rowscale * (acc2 + b2); lane: channel 32nt + n, tokens (r & 3) + 8 (r >> 2) + 4hh ----
-    float rs[16];
-    long trow[16];
+    // ---- epilogue: y = x + rowscale * (acc2 + b2); this lane: token n, channels 32 mt + 8 j + 4 hh + (0..3) ----
+    const float rs = rowscale ? rowscale[rrow] : 1.f;
+    float s1 = 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const long tr = row0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-        trow[r] = tr < M ? tr : -1;
-        rs[r] = (rowscale && tr < M) ? rowscale[tr] : 1.f;
-    }
+    for (int mt = 0; mt < Cfg::NT2; ++mt)
 #pragma unroll
-    for (int nt = 0; nt < Cfg::NT2; ++nt) {
-        const int c = 32 * nt + n;
-        const float bb = b2[c];
+        for (int j = 0; j < 4; ++j) {
+            const int c0 = 32 * mt + 8 * j + 4 * hh;
+            const f32x4 xv = *reinterpret_cast<const f32x4*>(x + rrow * C + c0);
+            const f32x4 bb = *reinterpret_cast<const f32x4*>(b2 + c0);
+            f32x4 o;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            if (trow[r] >= 0) y[trow[r] * C + c] = x[trow[r] * C + c] + rs[r] * (acc2[nt][r] + bb);
+            for (int i = 0; i < 4; ++i) {
+                o[i] = xv[i] + rs * (acc2[mt][4 * j + i] + bb[i]);
+                if constexpr (LNN) {
+                    acc2[mt][4 * j + i] = o[i];
+                    s1 += o[i];
+                }
+            }
+            if (row_ok) *reinterpret_cast<f32x4*>(y + row * C + c0) = o;
         }
+    if constexpr (LNN) {  // LayerNorm(y) with the next block's norm1 parameters, bf16, + its row statistics
+        s1 += __shfl_xor(s1, 32, 64);
+        const float mean = s1 * (1.f / C);
+        float s2 = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < Cfg::NT2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float d = acc2[mt][r] - mean;
+                s2 += d * d;
+            }
+        s2 += __shfl_xor(s2, 32, 64);
+        const float rstd = rsqrtf(s2 * (1.f / C) + eps);
+        if (row_ok && hh == 0) {
+            mean_n[row] = mean;
+            rstd_n[row] = rstd;
+        }
+#pragma unroll
+        for (int mt = 0; mt < Cfg::NT2; ++mt)
+#pragma unroll
+            for (int jp = 0; jp < 2; ++jp) {
+                unsigned w[2][2];  // [j & 1][dword]
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    const int j = 2 * jp + jj;
+                    const int c0 = 32 * mt + 8 * j + 4 * hh;
+                    const f32x4 g = *reinterpret_cast<const f32x4*>(gamma_n + c0), b = *reinterpret_cast<const f32x4*>(beta_n + c0);
+                    float v[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] = (acc2[mt][4 * j + i] - mean) * rstd * g[i] + b[i];
+                    w[jj][0] = pack2(v[0], v[1]);
+                    w[jj][1] = pack2(v[2], v[3]);
+                }
+                pair_swap(w[0][0], w[1][0]);
+                pair_swap(w[0][1], w[1][1]);
+                // low lane: channels 32 mt + 16 jp + 0..7, high lane: + 8..15
+                if (row_ok) *reinterpret_cast<u32x4*>(xw_n + row * C + 32 * mt + 16 * jp + 8 * hh) = u32x4{w[0][0], w[0][1], w[1][0], w[1][1]};
+            }
     }
 }
 
-// waves per SIMD the register allocation is asked to fit: C = 96 needs ~128 registers -> 4; C = 192 (96 accumulator + 48
-// operand registers) -> 2
-template <int C>
-__global__ __launch_bounds__(MLP_WAVES * 64, (C == 96 ? 4 : 2)) void mlp_fused_fwd_kernel(
+template <int C, bool LNN>
+__global__ __launch_bounds__(MLP_WAVES * 64, (C == 96 ? (LNN ? 3 : 4) : 2)) void mlp_fused_fwd_kernel(
     const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
     const bf16* __restrict__ W1, const float* __restrict__ b1, const bf16* __restrict__ W2, const float* __restrict__ b2,
-    const float* __restrict__ rowscale, long M, float* __restrict__ y) {
-    mlp_fused_fwd_body<C>(x, gamma, beta, eps, W1, b1, W2, b2, rowscale, M, y);
+    const float* __restrict__ rowscale, long M, float* __restrict__ y, const float* __restrict__ gamma_n,
+    const float* __restrict__ beta_n, bf16* __restrict__ xw_n, float* __restrict__ mean_n, float* __restrict__ rstd_n) {
+    mlp_fused_fwd_body<C, LNN>(x, gamma, beta, eps, W1, b1, W2, b2, rowscale, M, y, gamma_n, beta_n, xw_n, mean_n, rstd_n);
 }
 
-template <int C>
+template <int C, bool LNN>
 int launch_mlp(const float* x, const float* gamma, const float* beta, float eps, const void* W1, const float* b1, const void* W2,
-               const float* b2, const float* rowscale, long M, float* y, hipStream_t stream) {
+               const float* b2, const float* rowscale, long M, float* y, const float* gamma_n, const float* beta_n, void* xw_n,
+               float* mean_n, float* rstd_n, hipStream_t stream) {
     const int grid = ceil_div(M, MLP_ROWS);
-    const size_t lds = MlpCfg<C>::LDS_BYTES;
-    auto kern = mlp_fused_fwd_kernel<C>;
+    const size_t lds = FwdCfg<C>::LDS_BYTES;
+    auto kern = mlp_fused_fwd_kernel<C, LNN>;
     static bool done = false;  // one-time raise of the dynamic LDS cap (idempotent)
     if (!done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         done = true;
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(MLP_WAVES * 64), lds, stream, x, gamma, beta, eps, (const bf16*)W1, b1, (const bf16*)W2, b2,
-                       rowscale, M, y);
+                       rowscale, M, y, gamma_n, beta_n, (bf16*)xw_n, mean_n, rstd_n);
     ESVIT_CHECK_LAUNCH("esvit_mlp_fused_fwd");
     return ESVIT_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// backward (data-gradient path; the weight gradients are two esvit_gemm calls on the tensors written here)
+// ------------------------------------------------------------------------------------------------------------------------
+template <int C, int NB>
+struct BwdCfg : MlpCfg<C> {
+    using B = MlpCfg<C>;
+    static constexpr int NP = 2 * B::PA + B::PB;              // pieces per chunk: W1 rows | W2^T rows | W1^T columns
+    static constexpr int PPW = (NP + MLP_WAVES - 1) / MLP_WAVES;  // wave w issues pieces w, w + 4, ... (the last may be missing)
+    static constexpr int WBUF = 2 * B::W1_BYTES + B::W2_BYTES;
+    static constexpr int NBUF = NB;                           // chunk q + NBUF - 1 is requested while chunk q is computed
+    static constexpr int LDS_BYTES = NBUF * WBUF;
+    static constexpr int STORES = 4;                          // vector stores per lane and chunk (two hidden tiles x two fragments)
+};
+
+template <int C, int NB>
+__device__ __forceinline__ void mlp_fused_bwd_body(
+    const float* __restrict__ x, const float* __restrict__ gy, const float* __restrict__ rs_mlp, const float* __restrict__ rs_out,
+    const float* __restrict__ gamma, const float* __restrict__ beta, float eps, const bf16* __restrict__ W1,
+    const bf16* __restrict__ W2T, const bf16* __restrict__ W1T, const float* __restrict__ b1, long M, float* __restrict__ gx,
+    bf16* __restrict__ gxa, bf16* __restrict__ xhat, bf16* __restrict__ a1g, bf16* __restrict__ da1) {
+    using Cfg = BwdCfg<C, NB>;
+    constexpr int H4 = 4 * C;
+    constexpr int NCHUNK = H4 / HCH;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef __attribute__((address_space(3))) void lds_void;
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n = lane & 31, hh = lane >> 5;
+    const long row0 = (long)blockIdx.x * MLP_ROWS + wave * 32;
+    const long row = row0 + n;
+    const bool row_ok = row < M;
+    const long rrow = row_ok ? row : (M - 1);
+
+    // ---- weight chunk DMA: pieces [0, PA) W1 rows, [PA, 2 PA) W2^T rows, [2 PA, NP) W1^T columns ----
+    const __amdgpu_buffer_rsrc_t r1 = mk_rsrc(W1, (long)H4 * C * 2), r2 = mk_rsrc(W2T, (long)H4 * C * 2), r3 = mk_rsrc(W1T, (long)C * H4 * 2);
+    int voff[Cfg::PPW];
+#pragma unroll
+    for (int i = 0; i < Cfg::PPW; ++i) {
+        const int piece = wave + MLP_WAVES * i;  // wave-uniform
+        voff[i] = piece < 2 * Cfg::PA ? Cfg::voff_a(piece < Cfg::PA ? piece : piece - Cfg::PA, lane)
+                                      : Cfg::voff_b((piece < Cfg::NP ? piece : Cfg::NP - 1) - 2 * Cfg::PA, lane);
+    }
+    const bool wave_live = row0 < M;  // wave-uniform: a wave without a valid row issues no stores (its counted wait differs)
+    auto issue_chunk = [&](int q, int buf) {
+        char* img = smem + buf * Cfg::WBUF;
+        const int soa = q * HCH * C * 2, sob = q * HCH * 2;
+#pragma unroll
+        for (int i = 0; i < Cfg::PPW; ++i) {
+            const int piece = wave + MLP_WAVES * i;
+            if (piece < Cfg::PA) __builtin_amdgcn_raw_ptr_buffer_load_lds(r1, (lds_void*)(img + piece * 1024), 16, voff[i], soa, 0, 0);
+            else if (piece < 2 * Cfg::PA) __builtin_amdgcn_raw_ptr_buffer_load_lds(r2, (lds_void*)(img + piece * 1024), 16, voff[i], soa, 0, 0);
+            else if (piece < Cfg::NP) __builtin_amdgcn_raw_ptr_buffer_load_lds(r3, (lds_void*)(img + piece * 1024), 16, voff[i], sob, 0, 0);
+        }
+    };
+    issue_chunk(0, 0);
+    if constexpr (Cfg::NBUF == 3) issue_chunk(1, 1);
+    const bool five = ((Cfg::NP - wave + MLP_WAVES - 1) / MLP_WAVES) == Cfg::PPW;  // wave-uniform: this wave issues PPW (not PPW - 1) pieces
+
+    // ---- prologue: LayerNorm of this lane's half row (statistics recomputed), xhat out, dy fragments ----
+    bf16x8 xb[Cfg::KS1], dyb[Cfg::KS1];
+    float mean, rstd;
+    {
+        const float* xr = x + rrow * C + 8 * hh;
+        float xv[Cfg::KS1][8];
+        float s1 = 0.f;
+#pragma unroll
+        for (int s = 0; s < Cfg::KS1; ++s) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(xr + 16 * s), b = *reinterpret_cast<const f32x4*>(xr + 16 * s + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                xv[s][e] = a[e];
+                xv[s][4 + e] = b[e];
+                s1 += a[e] + b[e];
+            }
+        }
+        s1 += __shfl_xor(s1, 32, 64);
+        mean = s1 * (1.f / C);
+        float s2 = 0.f;
+#pragma unroll
+        for (int s = 0; s < Cfg::KS1; ++s)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float d = xv[s][e] - mean;
+                s2 += d * d;
+            }
+        s2 += __shfl_xor(s2, 32, 64);
+        rstd = rsqrtf(s2 * (1.f / C) + eps);
+#pragma unroll
+        for (int s = 0; s < Cfg::KS1; ++s) {
+            const float* gp = gamma + 16 * s + 8 * hh;
+            const float* bp = beta + 16 * s + 8 * hh;
+            const f32x4 g0 = *reinterpret_cast<const f32x4*>(gp), g1 = *reinterpret_cast<const f32x4*>(gp + 4);
+            const f32x4 c0 = *reinterpret_cast<const f32x4*>(bp), c1 = *reinterpret_cast<const f32x4*>(bp + 4);
+            bf16x8 xh;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float h0 = (xv[s][e] - mean) * rstd, h1 = (xv[s][4 + e] - mean) * rstd;
+                xh[e] = (bf16)h0;
+                xh[4 + e] = (bf16)h1;
+                xb[s][e] = (bf16)(h0 * g0[e] + c0[e]);
+                xb[s][4 + e] = (bf16)(h1 * g1[e] + c1[e]);
+            }
+            if (row_ok) *reinterpret_cast<bf16x8*>(xhat + row * C + 16 * s + 8 * hh) = xh;
+        }
+        const float sm = rs_mlp ? rs_mlp[rrow] : 1.f;
+        const float* gr = gy + rrow * C + 8 * hh;
+#pragma unroll
+        for (int s = 0; s < Cfg::KS1; ++s) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(gr + 16 * s), b = *reinterpret_cast<const f32x4*>(gr + 16 * s + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                dyb[s][e] = (bf16)(sm * a[e]);
+                dyb[s][4 + e] = (bf16)(sm * b[e]);
+            }
+        }
+    }
+
+    f32x16 acc3[Cfg::NT2];  // dH^T: tile mt, register r <-> channel 32 mt + (r & 3) + 8 (r >> 2) + 4 hh of token n
+#pragma unroll
+    for (int t = 0; t < Cfg::NT2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc3[t][r] = 0.f;
+
+    wait_vm<0>();     // chunk 0 landed (this wave's part), prologue loads / stores retired
+    __syncthreads();
+
+    const int rho_n = (n & ~12) | ((n & 4) << 1) | ((n & 8) >> 1);
+    bf16* a1g_row = a1g + row * H4 + 8 * hh;
+    bf16* da1_row = da1 + row * H4 + 8 * hh;
+    int buf = 0;
+    for (int q = 0; q < NCHUNK; ++q) {
+        const bool more = q + Cfg::NBUF - 1 < NCHUNK;
+        // (the buffer of chunk q - 1, released by the barrier that ended it)
+        if (more) issue_chunk(q + Cfg::NBUF - 1, Cfg::NBUF == 2 ? (buf ^ 1) : (buf == 0 ? 2 : buf - 1));
+        const char* wa = smem + buf * Cfg::WBUF;   // W1 rows of the chunk
+        const char* wb = wa + Cfg::W1_BYTES;       // W2^T rows of the chunk
+        const char* wc = wb + Cfg::W1_BYTES;       // W1^T columns of the chunk  [C][32 hidden]
+
+        // ---- P^T = W1_chunk * LN(x)^T  and  G^T = W2^T_chunk * dy^T   ([32 hidden][32 tokens] each) ----
+        f32x16 accp, accg;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accp[r] = accg[r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < Cfg::KS1; ++s) {
+            const int off = (rho_n * (C / 8) + Cfg::pos1(2 * s + hh, rho_n)) * 16;
+            const bf16x8 a = *reinterpret_cast<const bf16x8*>(wa + off);
+            const bf16x8 b = *reinterpret_cast<const bf16x8*>(wb + off);
+            accp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, xb[s], accp, 0, 0, 0);
+            accg = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, dyb[s], accg, 0, 0, 0);
+        }
+        // ---- GELU, GELU', dA: register 8t + e holds hidden unit 32q + 16t + 8hh + e of token n ----
+        bf16x8 hf[2], df[2];
+        const float* bq = b1 + q * HCH;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float blo = bq[16 * t + e], bhi = bq[16 * t + 8 + e];
+                const float v = accp[8 * t + e] + (hh ? bhi : blo);
+                float g, dg;
+                gelu_both(v, g, dg);
+                hf[t][e] = (bf16)g;
+                df[t][e] = (bf16)(accg[8 * t + e] * dg);
+            }
+        if (row_ok) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                *reinterpret_cast<bf16x8*>(a1g_row + q * HCH + 16 * t) = hf[t];
+                *reinterpret_cast<bf16x8*>(da1_row + q * HCH + 16 * t) = df[t];
+            }
+        }
+        // ---- dH^T[C][32 tokens] += W1^T_chunk[C x 32 hidden] * dA^T ----
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+#pragma unroll
+            for (int mt = 0; mt < Cfg::NT2; ++mt) {
+                const int c = 32 * mt + n;
+                const bf16x8 a = *reinterpret_cast<const bf16x8*>(wc + c * 64 + (((2 * t + hh) ^ Cfg::sw2(c)) * 16));
+                acc3[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, df[t], acc3[mt], 0, 0, 0);
+            }
+        }
+        // chunk q + 1 must have landed before the barrier; everything this wave issued AFTER that chunk's DMA may stay in flight
+        // (vmcnt retires in order).  Two buffers: that is this chunk's STORES.  Three buffers: the stores of the previous chunk,
+        // the DMA of chunk q + 2 and this chunk's stores -- a store then has two chunk times, not one, to be acknowledged
+        // before anything waits behind it.  A wave with no valid row issues no stores and simply drains.
+        if constexpr (Cfg::NBUF == 2) {
+            if (more && wave_live) wait_vm<Cfg::STORES>();
+            else wait_vm<0>();
+        } else {
+            if (!wave_live) wait_vm<0>();
+            else if (more) {
+                if (five) wait_vm<Cfg::PPW + 2 * Cfg::STORES>();
+                else wait_vm<Cfg::PPW - 1 + 2 * Cfg::STORES>();
+            } else if (q + 1 < NCHUNK) wait_vm<2 * Cfg::STORES>();
+        }
+        chunk_barrier();
+        if constexpr (Cfg::NBUF == 2) buf ^= 1;
+        else buf = buf == 2 ? 0 : buf + 1;
+    }
+
+    // ---- epilogue: LayerNorm backward in registers.  This lane: token n, channels 32 mt + 8 j + 4 hh + (0..3) ----
+    //   g = dH o gamma;  dx = rstd (g - mean_c(g) - xhat mean_c(g xhat));  gx = gy + dx;  gxa = bf16(rs_out gx)
+    float xh[Cfg::NT2][16];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < Cfg::NT2; ++mt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c0 = 32 * mt + 8 * j + 4 * hh;
+            const f32x4 xv = *reinterpret_cast<const f32x4*>(x + rrow * C + c0);
+            const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + c0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float h = (xv[i] - mean) * rstd;
+                const float g = acc3[mt][4 * j + i] * gm[i];
+                xh[mt][4 * j + i] = h;
+                acc3[mt][4 * j + i] = g;
+                s1 += g;
+                s2 += g * h;
+            }
+        }
+    s1 += __shfl_xor(s1, 32, 64);
+    s2 += __shfl_xor(s2, 32, 64);
+    const float m1 = s1 * (1.f / C), m2 = s2 * (1.f / C);
+    const float ro = rs_out ? rs_out[rrow] : 1.f;
+#pragma unroll
+    for (int mt = 0; mt < Cfg::NT2; ++mt)
+#pragma unroll
+        for (int jp = 0; jp < 2; ++jp) {
+            unsigned w[2][2];
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                const int j = 2 * jp + jj;
+                const int c0 = 32 * mt + 8 * j + 4 * hh;
+                const f32x4 gv = *reinterpret_cast<const f32x4*>(gy + rrow * C + c0);
+                f32x4 o;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) o[i] = gv[i] + rstd * (acc3[mt][4 * j + i] - m1 - xh[mt][4 * j + i] * m2);
+                if (row_ok) *reinterpret_cast<f32x4*>(gx + row * C + c0) = o;
+                w[jj][0] = pack2(ro * o[0], ro * o[1]);
+                w[jj][1] = pack2(ro * o[2], ro * o[3]);
+            }
+            pair_swap(w[0][0], w[1][0]);
+            pair_swap(w[0][1], w[1][1]);
+            if (row_ok) *reinterpret_cast<u32x4*>(gxa + row * C + 32 * mt + 16 * jp + 8 * hh) = u32x4{w[0][0], w[0][1], w[1][0], w[1][1]};
+        }
+}
+
+template <int C, int NB>
+__global__ __launch_bounds__(MLP_WAVES * 64, (C == 96 ? 2 : 1)) void mlp_fused_bwd_kernel(
+    const float* __restrict__ x, const float* __restrict__ gy, const float* __restrict__ rs_mlp, const float* __restrict__ rs_out,
+    const float* __restrict__ gamma, const float* __restrict__ beta, float eps, const bf16* __restrict__ W1,
+    const bf16* __restrict__ W2T, const bf16* __restrict__ W1T, const float* __restrict__ b1, long M, float* __restrict__ gx,
+    bf16* __restrict__ gxa, bf16* __restrict__ xhat, bf16* __restrict__ a1g, bf16* __restrict__ da1) {
+    mlp_fused_bwd_body<C, NB>(x, gy, rs_mlp, rs_out, gamma, beta, eps, W1, W2T, W1T, b1, M, gx, gxa, xhat, a1g, da1);
+}
+
+template <int C, int NB>
+int launch_mlp_bwd(const float* x, const float* gy, const float* rs_mlp, const float* rs_out, const float* gamma, const float* beta,
+                   float eps, const void* W1, const void* W2T, const void* W1T, const float* b1, long M, float* gx, void* gxa, void* xhat,
+                   void* a1g, void* da1, hipStream_t stream) {
+    const int grid = ceil_div(M, MLP_ROWS);
+    const size_t lds = BwdCfg<C, NB>::LDS_BYTES;
+    auto kern = mlp_fused_bwd_kernel<C, NB>;
+    static bool done = false;
+    if (!done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        done = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(MLP_WAVES * 64), lds, stream, x, gy, rs_mlp, rs_out, gamma, beta, eps, (const bf16*)W1,
+                       (const bf16*)W2T, (const bf16*)W1T, b1, M, gx, (bf16*)gxa, (bf16*)xhat, (bf16*)a1g, (bf16*)da1);
+    ESVIT_CHECK_LAUNCH("esvit_mlp_fused_bwd");
+    return ESVIT_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// small helpers of the fused branch
+// ------------------------------------------------------------------------------------------------------------------------
+// dst[s][r] = bf16(src[r][s]): the transposed activation-dtype weight copies the backward kernel streams (W2^T, W1^T)
+__global__ __launch_bounds__(256) void cast_transpose_kernel(const float* __restrict__ src, bf16* __restrict__ dst, int R, int S) {
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    const int r0 = blockIdx.y * 32, s0 = blockIdx.x * 32;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = r0 + ty + 8 * i, s = s0 + tx;
+        tile[ty + 8 * i][tx] = (r < R && s < S) ? src[(long)r * S + s] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int s = s0 + ty + 8 * i, r = r0 + tx;
+        if (s < S && r < R) dst[(long)s * R + r] = (bf16)tile[tx][ty + 8 * i];
+    }
+}
+
+// LayerNorm folded out of a weight gradient.  For y = LN(x) W^T + b with LN(x) = xhat o gamma + beta the GEMM was run on
+// xhat:  G = dY^T xhat  [J, C],  db = colsum(dY)  [J].  Then
+//     dW = G o gamma (per column) + db (x) beta,     dgamma[c] = sum_j W[j, c] G[j, c],     dbeta[c] = sum_j db[j] W[j, c]
+// (W: the fp32 master).  One workgroup per 32 columns, 32 x 32 threads; G is overwritten by dW.
+__global__ __launch_bounds__(1024) void ln_fold_finish_kernel(float* __restrict__ G, const float* __restrict__ db, const float* __restrict__ W,
+                                                              const float* __restrict__ gamma, const float* __restrict__ beta, int J, int Cc,
+                                                              float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate) {
+    __shared__ float sg[32][33], sb[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + tx;
+    float ag = 0.f, ab = 0.f;
+    if (c < Cc) {
+        const float gm = gamma[c], bt = beta[c];
+        for (int j = ty; j < J; j += 32) {
+            const long o = (long)j * Cc + c;
+            const float g = G[o], w = W[o], d = db[j];
+            ag += w * g;
+            ab += d * w;
+            G[o] = g * gm + d * bt;
+        }
+    }
+    sg[ty][tx] = ag;
+    sb[ty][tx] = ab;
+    __syncthreads();
+    if (ty == 0 && c < Cc) {
+        float a = 0.f, b = 0.f;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            a += sg[i][tx];
+            b += sb[i][tx];
+        }
+        dgamma[c] = accumulate ? dgamma[c] + a : a;
+        dbeta[c] = accumulate ? dbeta[c] + b : b;
+    }
 }
 
 }  // namespace
 
 int esvit_i_mlp_fused_supported(int dtype, int C) { return dtype == ESVIT_BF16 && (C == 96 || C == 192); }  // esvit_query
 
+#define AL16(p_) (((uintptr_t)(p_) % 16) == 0)
+
 extern "C" int esvit_mlp_fused_fwd(int dtype, const float* x, const float* gamma, const float* beta, float eps, const void* W1,
                                    const float* b1, const void* W2, const float* b2, const float* rowscale, int64_t M, int C,
-                                   float* y, esvit_stream_t s_) {
+                                   float* y, const float* gamma_next, const float* beta_next, void* xw_next, float* mean_next,
+                                   float* rstd_next, esvit_stream_t s_) {
     hipStream_t stream = reinterpret_cast<hipStream_t>(s_);
     ESVIT_CHECK_ARG(esvit_i_mlp_fused_supported(dtype, C), "esvit_mlp_fused_fwd: bf16 activations and C in {96, 192} only (C=%d)", C);
     ESVIT_CHECK_ARG(x && gamma && beta && W1 && b1 && W2 && b2 && y && M > 0, "esvit_mlp_fused_fwd: null pointer / empty input");
-    ESVIT_CHECK_ARG(((uintptr_t)x % 16 == 0) && ((uintptr_t)y % 16 == 0) && ((uintptr_t)W1 % 16 == 0) && ((uintptr_t)W2 % 16 == 0) &&
-                        ((uintptr_t)gamma % 16 == 0) && ((uintptr_t)beta % 16 == 0),
+    ESVIT_CHECK_ARG(AL16(x) && AL16(y) && AL16(W1) && AL16(W2) && AL16(gamma) && AL16(beta) && AL16(b2),
                     "esvit_mlp_fused_fwd: operands must be 16-byte aligned");
-    if (C == 96) return launch_mlp<96>(x, gamma, beta, eps, W1, b1, W2, b2, rowscale, M, y, stream);
-    return launch_mlp<192>(x, gamma, beta, eps, W1, b1, W2, b2, rowscale, M, y, stream);
+    const bool lnn = gamma_next != nullptr;
+    if (lnn)
+        ESVIT_CHECK_ARG(beta_next && xw_next && mean_next && rstd_next && AL16(gamma_next) && AL16(beta_next) && AL16(xw_next),
+                        "esvit_mlp_fused_fwd: the next-LayerNorm outputs come together (gamma, beta, xw, mean, rstd; 16-byte aligned)");
+    if (C == 96)
+        return lnn ? launch_mlp<96, true>(x, gamma, beta, eps, W1, b1, W2, b2, rowscale, M, y, gamma_next, beta_next, xw_next, mean_next, rstd_next, stream)
+                   : launch_mlp<96, false>(x, gamma, beta, eps, W1, b1, W2, b2, rowscale, M, y, nullptr, nullptr, nullptr, nullptr, nullptr, stream);
+    return lnn ? launch_mlp<192, true>(x, gamma, beta, eps, W1, b1, W2, b2, rowscale, M, y, gamma_next, beta_next, xw_next, mean_next, rstd_next, stream)
+               : launch_mlp<192, false>(x, gamma, beta, eps, W1, b1, W2, b2, rowscale, M, y, nullptr, nullptr, nullptr, nullptr, nullptr, stream);
+}
+
+extern "C" int esvit_mlp_fused_bwd(int dtype, const float* x, const float* gy, const float* rowscale_mlp, const float* rowscale_out,
+                                   const float* gamma, const float* beta, float eps, const void* W1, const void* W2T, const void* W1T,
+                                   const float* b1, int64_t M, int C, float* gx, void* gx_act, void* xhat, void* a1g, void* da1,
+                                   esvit_stream_t s_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(s_);
+    ESVIT_CHECK_ARG(esvit_i_mlp_fused_supported(dtype, C), "esvit_mlp_fused_bwd: bf16 activations and C in {96, 192} only (C=%d)", C);
+    ESVIT_CHECK_ARG(x && gy && gamma && beta && W1 && W2T && W1T && b1 && gx && gx_act && xhat && a1g && da1 && M > 0,
+                    "esvit_mlp_fused_bwd: null pointer / empty input");
+    ESVIT_CHECK_ARG(AL16(x) && AL16(gy) && AL16(gx) && AL16(gx_act) && AL16(xhat) && AL16(a1g) && AL16(da1) && AL16(W1) && AL16(W2T) &&
+                        AL16(W1T) && AL16(gamma) && AL16(beta),
+                    "esvit_mlp_fused_bwd: operands must be 16-byte aligned");
+    static const int nbuf = getenv("ESVIT_MLP_BWD_NBUF") ? atoi(getenv("ESVIT_MLP_BWD_NBUF")) : 3;  // (A/B knob of round 3, to be removed)
+    if (C == 96)
+        return nbuf == 2 ? launch_mlp_bwd<96, 2>(x, gy, rowscale_mlp, rowscale_out, gamma, beta, eps, W1, W2T, W1T, b1, M, gx, gx_act, xhat, a1g, da1, stream)
+                         : launch_mlp_bwd<96, 3>(x, gy, rowscale_mlp, rowscale_out, gamma, beta, eps, W1, W2T, W1T, b1, M, gx, gx_act, xhat, a1g, da1, stream);
+    return nbuf == 2 ? launch_mlp_bwd<192, 2>(x, gy, rowscale_mlp, rowscale_out, gamma, beta, eps, W1, W2T, W1T, b1, M, gx, gx_act, xhat, a1g, da1, stream)
+                     : launch_mlp_bwd<192, 3>(x, gy, rowscale_mlp, rowscale_out, gamma, beta, eps, W1, W2T, W1T, b1, M, gx, gx_act, xhat, a1g, da1, stream);
+}
+
+extern "C" int esvit_cast_transpose(const float* src, void* dst_bf16, int R, int S, esvit_stream_t s_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(s_);
+    ESVIT_CHECK_ARG(src && dst_bf16 && R > 0 && S > 0, "esvit_cast_transpose: bad arguments");
+    hipLaunchKernelGGL(cast_transpose_kernel, dim3(ceil_div(S, 32), ceil_div(R, 32)), dim3(256), 0, stream, src, (bf16*)dst_bf16, R, S);
+    ESVIT_CHECK_LAUNCH("esvit_cast_transpose");
+    return ESVIT_OK;
+}
+
+extern "C" int esvit_ln_fold_finish(float* G, const float* db, const float* W, const float* gamma, const float* beta, int J, int C,
+                                    float* dgamma, float* dbeta, int accumulate, esvit_stream_t s_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(s_);
+    ESVIT_CHECK_ARG(G && db && W && gamma && beta && dgamma && dbeta && J > 0 && C > 0, "esvit_ln_fold_finish: bad arguments");
+    hipLaunchKernelGGL(ln_fold_finish_kernel, dim3(ceil_div(C, 32)), dim3(1024), 0, stream, G, db, W, gamma, beta, J, C, dgamma, dbeta, accumulate);
+    ESVIT_CHECK_LAUNCH("esvit_ln_fold_finish");
+    return ESVIT_OK;
 }

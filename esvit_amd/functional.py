@@ -12,6 +12,8 @@ Stages (reference lines):
   DinoHeadFn       vision_transformer.py:414-418
   ConvEmbedFn, CvtAttnFn, CvtFfnFn   cvt_v4_transformer.py:349-382, 108-220 (+75-105), 62-72  (BASELINE config 5)
 """
+import os
+
 import numpy as np
 import torch
 
@@ -92,6 +94,38 @@ def _weight(p, shape2d=None):
     return ops_module().cast_to_act(src.contiguous())
 
 
+def _weight_t(p):
+    """activation-dtype copy of the TRANSPOSE of an fp32 [R, S] parameter (what esvit_mlp_fused_bwd streams for W2 and W1),
+    cached per parameter version like the plain cast"""
+    return P.cached(p, "castT", lambda: ops_module().cast_transpose(p.detach().contiguous()))
+
+
+# ---- fused MLP branch (narrow stages, bf16): nothing hidden-sized is kept between forward and backward ------------------------
+# forward: ONE kernel x1 -> x2 (esvit_mlp_fused_fwd).  backward: esvit_mlp_fused_bwd recomputes LayerNorm + pre-activation,
+# produces dL/dx1 (+ its activation-dtype copy) and the operands of the two weight-gradient GEMMs; the LayerNorm parameter
+# gradients fall out of the fc1 weight gradient (esvit_ln_fold_finish).
+MLP_FUSED_TRAIN = os.environ.get("ESVIT_MLP_FUSED_TRAIN", "1") != "0"  # (A-B runs switch the training path back to the unfused sequence)
+
+
+def _mlp_fused_train(W1, C):
+    return MLP_FUSED_TRAIN and ops_module().mlp_fused_supported(W1.dtype, C)
+
+
+def _mlp_branch_bwd(o, x1, gy, dyb, g2, b2, W1, bfc1, params, dp_mlp, dp_out):
+    """-> (gx1 fp32, gx1 act copy (scaled by dp_out), dg2, db2, dW1, dbfc1, dW2, dbfc2); dyb: cast(dp_mlp * gy) [M, C] act"""
+    g2_p, b2_p, W1_p, bfc1_p, W2_p, bfc2_p = params
+    gx1, dyw, xhat, a1g, da1 = o.mlp_fused_bwd(x1, gy, g2, b2, LN_EPS, W1, _weight_t(W2_p), _weight_t(W1_p), bfc1,
+                                               rowscale_mlp=dp_mlp, rowscale_out=dp_out)
+    dW2, dbfc2 = _wgrad(dyb, a1g, W2_p, want_bias=True, bias_param=bfc2_p)
+    del a1g
+    wsink, bsink = P.grad_out(W1_p), P.grad_out(bfc1_p)
+    G, dbfc1 = o.linear_wgrad(da1, xhat, out=wsink, want_bias=True, db_out=bsink)  # G = dA^T xhat: LayerNorm folded out
+    del da1, xhat
+    ln2 = _ln_sinks(g2_p, b2_p)
+    dW1, dg2, db2 = o.ln_fold_finish(G, dbfc1, W1_p.detach(), g2, b2, gb_out=ln2)
+    return gx1, dyw, _alias(dg2, ln2), _alias(db2, ln2), _alias(dW1, wsink), _alias(dbfc1, bsink), dW2, dbfc2
+
+
 # ------------------------------------------------------------------------------------------------
 # Swin block
 # ------------------------------------------------------------------------------------------------
@@ -112,8 +146,11 @@ def _block_forward(x, geom, nH, index, dp, prm, wts, save):
     frag = o.new_bias_frag(nH, geom.N, x.device) if save else None  # kept for the backward (no second fill)
     ao, lse = o.window_attn_fwd(qkv, bqkv, geom.win2tok, L, table, geom.ws, geom.region_ids, geom.nW, geom.N, nH, scale, bias_frag=frag)
     x1 = o.linear_fwd(ao, Wproj, bproj, residual=x2d, rowscale=dp1, rows_per_sample=L, out_f32=True)
-    if not save and dp2 is None and o.mlp_fused_supported(W1.dtype, C):  # (the fused kernel takes per-row DropPath scales only)
-        return o.mlp_fused_fwd(x1, g2, b2, LN_EPS, W1, bfc1, W2, bfc2).view(nB, L, C), None
+    if (not save and o.mlp_fused_supported(W1.dtype, C)) or (save and _mlp_fused_train(W1, C)):
+        rs2 = None if dp2 is None else dp2.repeat_interleave(L)  # (the fused kernels take per-row DropPath factors)
+        x2 = o.mlp_fused_fwd(x1, g2, b2, LN_EPS, W1, bfc1, W2, bfc2, rowscale=rs2)
+        saved = (mean1, rstd1, xw, qkv, ao, x1, lse, frag) if save else None
+        return x2.view(nB, L, C), saved
     else:
         h, _, mean2, rstd2 = o.layernorm_fwd(x1, g2, b2, LN_EPS)
         if save:
@@ -133,15 +170,20 @@ class SwinBlockFn(torch.autograd.Function):
         y, saved = _block_forward(x, geom, nH, index, dp, (g1, b1, table, bqkv, bproj, g2, b2, bfc1, bfc2), wts, True)
         ctx.geom, ctx.nH, ctx.dp = geom, nH, dp
         ctx.wparams = (Wqkv_p, Wproj_p, W1_p, W2_p)
-        ctx.save_for_backward(x, index, g1, table, g2, bqkv, *wts, *saved)
+        ctx.mlp_params = (g2, b2, W1_p, bfc1, W2_p, bfc2)
+        ctx.fused_mlp = len(saved) == 8
+        ctx.save_for_backward(x, index, g1, table, g2, bqkv, b2, bfc1, *wts, *saved)
         return y
 
     @staticmethod
     def backward(ctx, gy):
         o = ops_module()
         geom, nH, dp = ctx.geom, ctx.nH, ctx.dp
-        (x, index, g1, table, g2, bqkv, Wqkv, Wproj, W1, W2, mean1, rstd1, xw, qkv, ao, x1, mean2, rstd2, h, a1,
-         a1g, lse, frag) = ctx.saved_tensors
+        if ctx.fused_mlp:
+            (x, index, g1, table, g2, bqkv, b2, bfc1, Wqkv, Wproj, W1, W2, mean1, rstd1, xw, qkv, ao, x1, lse, frag) = ctx.saved_tensors
+        else:
+            (x, index, g1, table, g2, bqkv, b2, bfc1, Wqkv, Wproj, W1, W2, mean1, rstd1, xw, qkv, ao, x1, mean2, rstd2, h, a1,
+             a1g, lse, frag) = ctx.saved_tensors
         nB, L, C = x.shape
         M = nB * L
         scale = (C // nH) ** -0.5
@@ -150,12 +192,17 @@ class SwinBlockFn(torch.autograd.Function):
         Wqkv_p, Wproj_p, W1_p, W2_p = ctx.wparams
         # ---- MLP branch ----
         dyb = o.gather_cast(gy, M, rowscale=dp2, rows_per_sample=L)
-        dW2, dbfc2 = _wgrad(dyb, a1g, W2_p, want_bias=True)
-        da1 = o.linear_dgrad(dyb, W2, gelu_preact=a1)
-        dW1, dbfc1 = _wgrad(da1, h, W1_p, want_bias=True)
-        dh = o.linear_dgrad(da1, W1)
-        # ---- attention branch ---- (the LayerNorm backward also emits the DropPath-scaled activation-dtype copy of gx1)
-        gx1, dyw, dg2, db2 = o.layernorm_bwd_cast(dh, x1, mean2, rstd2, g2, g_in=gy, rowscale=dp1, rows_per_sample=L)
+        if ctx.fused_mlp:
+            rs2 = None if dp2 is None else dp2.repeat_interleave(L)
+            rs1 = None if dp1 is None else dp1.repeat_interleave(L)
+            gx1, dyw, dg2, db2, dW1, dbfc1, dW2, dbfc2 = _mlp_branch_bwd(o, x1, gy, dyb, g2, b2, W1, bfc1, ctx.mlp_params, rs2, rs1)
+        else:
+            dW2, dbfc2 = _wgrad(dyb, a1g, W2_p, want_bias=True)
+            da1 = o.linear_dgrad(dyb, W2, gelu_preact=a1)
+            dW1, dbfc1 = _wgrad(da1, h, W1_p, want_bias=True)
+            dh = o.linear_dgrad(da1, W1)
+            # ---- attention branch ---- (the LayerNorm backward also emits the DropPath-scaled activation-dtype copy of gx1)
+            gx1, dyw, dg2, db2 = o.layernorm_bwd_cast(dh, x1, mean2, rstd2, g2, g_in=gy, rowscale=dp1, rows_per_sample=L)
         dWproj, dbproj = _wgrad(dyw, ao, Wproj_p, want_bias=True)
         dao = o.linear_dgrad(dyw, Wproj)
         dqkv, dbias_ws, dpad_ws = o.window_attn_bwd(qkv, bqkv, geom.win2tok, L, dao, ao, lse, None, geom.ws, geom.region_ids,
@@ -175,15 +222,21 @@ class SwinBlockFn(torch.autograd.Function):
 # resolution group on its row range.  Compared with one pass per group (swin_transformer.py:729-751) this halves the GEMM /
 # LayerNorm launches, removes the gradient-accumulation adds of every parameter used by both passes, halves the split-K
 # partial traffic of the weight gradients and gives the small local-crop GEMMs of stages 2-3 full grids.
-def _block_forward_multi(X, segs, nH, dp_rows, prm, wts, save):
-    """X fp32 [M, C]; segs: tuple of (row0, nB, L, geom); dp_rows: None or (per-row DropPath scale attn [M], mlp [M])"""
+def _block_forward_multi(X, segs, nH, dp_rows, prm, wts, save, pre=None, next_norm=None):
+    """X fp32 [M, C]; segs: tuple of (row0, nB, L, geom); dp_rows: None or (per-row DropPath scale attn [M], mlp [M]).
+    pre: (norm1(X) in the activation dtype, mean, rstd) when the previous block's fused MLP kernel already produced them;
+    next_norm: (weight, bias) of the NEXT block's norm1 -- the fused MLP kernel then also emits that block's `pre`.
+    -> (y, saved, lses, next block's pre or None)"""
     o = ops_module()
     (g1, b1, table, bqkv, bproj, g2, b2, bfc1, bfc2) = prm
     (Wqkv, Wproj, W1, W2) = wts
     M, C = X.shape
     scale = (C // nH) ** -0.5
     dp1, dp2 = (None, None) if dp_rows is None else dp_rows
-    xw, _, mean1, rstd1 = o.layernorm_fwd(X, g1, b1, LN_EPS)
+    if pre is not None:
+        xw, mean1, rstd1 = pre
+    else:
+        xw, _, mean1, rstd1 = o.layernorm_fwd(X, g1, b1, LN_EPS)
     qkv = o.linear_fwd(xw, Wqkv, bqkv)
     ao = torch.empty((M, C), dtype=qkv.dtype, device=X.device)
     lses, frags = [], {}
@@ -197,10 +250,15 @@ def _block_forward_multi(X, segs, nH, dp_rows, prm, wts, save):
                                    out=ao[r0:r1], bias_frag=frags[(geom.ws, geom.N)])
         lses.append((lse, frags[(geom.ws, geom.N)]))
     x1 = o.linear_fwd(ao, Wproj, bproj, residual=X, rowscale=dp1, rows_per_sample=1, out_f32=True)
-    if not save and o.mlp_fused_supported(W1.dtype, C):
-        # inference-mode pass (the teacher) through a narrow stage: LayerNorm -> fc1 + GELU -> fc2 + residual in one kernel,
-        # the hidden activation never reaches HBM
-        return o.mlp_fused_fwd(x1, g2, b2, LN_EPS, W1, bfc1, W2, bfc2, rowscale=dp2), None, lses
+    if (not save and o.mlp_fused_supported(W1.dtype, C)) or (save and _mlp_fused_train(W1, C)):
+        # narrow stage: LayerNorm -> fc1 + GELU -> fc2 + residual in one kernel, the hidden activation never reaches HBM (the
+        # training pass keeps x1 only: the backward recomputes)
+        nxt = None
+        if next_norm is not None:
+            x2, nxt = o.mlp_fused_fwd(x1, g2, b2, LN_EPS, W1, bfc1, W2, bfc2, rowscale=dp2, next_norm=(next_norm[0].detach(), next_norm[1].detach()))
+        else:
+            x2 = o.mlp_fused_fwd(x1, g2, b2, LN_EPS, W1, bfc1, W2, bfc2, rowscale=dp2)
+        return x2, ((mean1, rstd1, xw, qkv, ao, x1) if save else None), lses, nxt
     else:
         h, _, mean2, rstd2 = o.layernorm_fwd(x1, g2, b2, LN_EPS)
         if save:
@@ -209,7 +267,7 @@ def _block_forward_multi(X, segs, nH, dp_rows, prm, wts, save):
             a1g, a1 = o.linear_fwd(h, W1, bfc1, gelu=True), None
         x2 = o.linear_fwd(a1g, W2, bfc2, residual=x1, rowscale=dp2, rows_per_sample=1, out_f32=True)
     saved = (mean1, rstd1, xw, qkv, ao, x1, mean2, rstd2, h, a1, a1g) if save else None
-    return x2, saved, lses
+    return x2, saved, lses, None
 
 
 class SwinBlockMultiFn(torch.autograd.Function):
@@ -223,24 +281,34 @@ class SwinBlockMultiFn(torch.autograd.Function):
     stage) its gradient arrives as None and the block casts dL/dy itself."""
 
     @staticmethod
-    def forward(ctx, X, Xsh, segs, nH, index, dp_rows, prev_scale, g1, b1, table, Wqkv_p, bqkv, Wproj_p, bproj, g2, b2, W1_p, bfc1, W2_p, bfc2):
+    def forward(ctx, X, Xsh, segs, nH, index, dp_rows, prev_scale, pre, next_norm, g1, b1, table, Wqkv_p, bqkv, Wproj_p, bproj, g2, b2, W1_p, bfc1,
+                W2_p, bfc2):
+        """pre / next_norm: see _block_forward_multi (plain tuples: no gradient flows through them -- norm1's own backward uses
+        the saved statistics).  Third output: the next block's `pre` tuple flattened (xw, mean, rstd), or three None"""
         wts = (_weight(Wqkv_p), _weight(Wproj_p), _weight(W1_p), _weight(W2_p))
         X = X.contiguous()
-        y, saved, lses = _block_forward_multi(X, segs, nH, dp_rows, (g1, b1, table, bqkv, bproj, g2, b2, bfc1, bfc2), wts, True)
+        y, saved, lses, nxt = _block_forward_multi(X, segs, nH, dp_rows, (g1, b1, table, bqkv, bproj, g2, b2, bfc1, bfc2), wts, True, pre, next_norm)
         ctx.segs, ctx.nH, ctx.dp_rows, ctx.lses = segs, nH, dp_rows, lses
         ctx.wparams = (Wqkv_p, Wproj_p, W1_p, W2_p)
         ctx.sparams = (g1, b1, table, bqkv, bproj, g2, b2, bfc1, bfc2)  # small parameters: their gradients go to bucket slots too
         ctx.emit_shadow, ctx.prev_scale = Xsh is not None, prev_scale
         ctx.set_materialize_grads(False)
-        ctx.save_for_backward(X, index, g1, table, g2, bqkv, *wts, *saved)
+        ctx.fused_mlp = len(saved) == 6
+        ctx.save_for_backward(X, index, g1, table, g2, bqkv, b2, bfc1, *wts, *saved)
         ysh = torch.empty(X.shape, dtype=wts[0].dtype, device=X.device)
-        return y, ysh
+        if nxt is None:
+            return y, ysh, None, None, None
+        ctx.mark_non_differentiable(*nxt)
+        return (y, ysh) + tuple(nxt)
 
     @staticmethod
-    def backward(ctx, gy, gysh):
+    def backward(ctx, gy, gysh, *_unused):
         o = ops_module()
         segs, nH, dp_rows = ctx.segs, ctx.nH, ctx.dp_rows
-        (X, index, g1, table, g2, bqkv, Wqkv, Wproj, W1, W2, mean1, rstd1, xw, qkv, ao, x1, mean2, rstd2, h, a1, a1g) = ctx.saved_tensors
+        if ctx.fused_mlp:
+            (X, index, g1, table, g2, bqkv, b2, bfc1, Wqkv, Wproj, W1, W2, mean1, rstd1, xw, qkv, ao, x1) = ctx.saved_tensors
+        else:
+            (X, index, g1, table, g2, bqkv, b2, bfc1, Wqkv, Wproj, W1, W2, mean1, rstd1, xw, qkv, ao, x1, mean2, rstd2, h, a1, a1g) = ctx.saved_tensors
         M, C = X.shape
         scale = (C // nH) ** -0.5
         dp1, dp2 = (None, None) if dp_rows is None else dp_rows
@@ -249,13 +317,17 @@ class SwinBlockMultiFn(torch.autograd.Function):
         g1_p, b1_p, table_p, bqkv_p, bproj_p, g2_p, b2_p, bfc1_p, bfc2_p = ctx.sparams
         # ---- MLP branch ----
         dyb = gysh.contiguous() if gysh is not None else o.gather_cast(gy, M, rowscale=dp2, rows_per_sample=1)
-        dW2, dbfc2 = _wgrad(dyb, a1g, W2_p, want_bias=True, bias_param=bfc2_p)
-        da1 = o.linear_dgrad(dyb, W2, gelu_preact=a1)
-        dW1, dbfc1 = _wgrad(da1, h, W1_p, want_bias=True, bias_param=bfc1_p)
-        dh = o.linear_dgrad(da1, W1)
-        ln2 = _ln_sinks(g2_p, b2_p)
-        gx1, dyw, dg2, db2 = o.layernorm_bwd_cast(dh, x1, mean2, rstd2, g2, g_in=gy, rowscale=dp1, rows_per_sample=1, gb_out=ln2)
-        dg2, db2 = _alias(dg2, ln2), _alias(db2, ln2)
+        if ctx.fused_mlp:
+            gx1, dyw, dg2, db2, dW1, dbfc1, dW2, dbfc2 = _mlp_branch_bwd(o, x1, gy, dyb, g2, b2, W1, bfc1,
+                                                                          (g2_p, b2_p, W1_p, bfc1_p, W2_p, bfc2_p), dp2, dp1)
+        else:
+            dW2, dbfc2 = _wgrad(dyb, a1g, W2_p, want_bias=True, bias_param=bfc2_p)
+            da1 = o.linear_dgrad(dyb, W2, gelu_preact=a1)
+            dW1, dbfc1 = _wgrad(da1, h, W1_p, want_bias=True, bias_param=bfc1_p)
+            dh = o.linear_dgrad(da1, W1)
+            ln2 = _ln_sinks(g2_p, b2_p)
+            gx1, dyw, dg2, db2 = o.layernorm_bwd_cast(dh, x1, mean2, rstd2, g2, g_in=gy, rowscale=dp1, rows_per_sample=1, gb_out=ln2)
+            dg2, db2 = _alias(dg2, ln2), _alias(db2, ln2)
         # ---- attention branch ----
         dWproj, dbproj = _wgrad(dyw, ao, Wproj_p, want_bias=True, bias_param=bproj_p)
         dao = o.linear_dgrad(dyw, Wproj)
@@ -285,19 +357,21 @@ class SwinBlockMultiFn(torch.autograd.Function):
             gx, dg1, db1 = o.layernorm_bwd(dxw, X, mean1, rstd1, g1, g_in=gx1, gb_out=ln1)
             gxb = None
         dg1, db1 = _alias(dg1, ln1), _alias(db1, ln1)
-        return (gx, gxb, None, None, None, None, None, dg1, db1, dtable, dWqkv, dbqkv, dWproj, dbproj, dg2, db2, dW1, dbfc1, dW2, dbfc2)
+        return (gx, gxb, None, None, None, None, None, None, None, dg1, db1, dtable, dWqkv, dbqkv, dWproj, dbproj, dg2, db2, dW1, dbfc1, dW2, dbfc2)
 
 
-def swin_block_multi(X, segs, nH, index, dp_rows, prm_list, shadow=None, prev_scale=None):
-    """one Swin block over the token rows of several resolution groups; X fp32 [M, C].  -> (y, shadow of y or None);
-    pass the previous block's shadow and its MLP-branch DropPath row scale to let this block's backward emit that block's
-    cast gradient (see SwinBlockMultiFn)"""
+def swin_block_multi(X, segs, nH, index, dp_rows, prm_list, shadow=None, prev_scale=None, pre=None, next_norm=None):
+    """one Swin block over the token rows of several resolution groups; X fp32 [M, C].  -> (y, shadow of y or None, next block's
+    `pre` or None); pass the previous block's shadow and its MLP-branch DropPath row scale to let this block's backward emit that
+    block's cast gradient (see SwinBlockMultiFn).  pre / next_norm: the LayerNorm hand-over between the blocks of a stage
+    (_block_forward_multi)"""
     if torch.is_grad_enabled() and (X.requires_grad or any(p.requires_grad for p in prm_list)):
-        return SwinBlockMultiFn.apply(X, shadow, segs, nH, index, dp_rows, prev_scale, *prm_list)
+        y, ysh, xw, mean, rstd = SwinBlockMultiFn.apply(X, shadow, segs, nH, index, dp_rows, prev_scale, pre, next_norm, *prm_list)
+        return y, ysh, (None if xw is None else (xw, mean, rstd))
     g1, b1, table, Wqkv, bqkv, Wproj, bproj, g2, b2, W1, bfc1, W2, bfc2 = prm_list
     wts = (_weight(Wqkv), _weight(Wproj), _weight(W1), _weight(W2))
-    y, _, _ = _block_forward_multi(X.contiguous(), segs, nH, dp_rows, (g1, b1, table, bqkv, bproj, g2, b2, bfc1, bfc2), wts, False)
-    return y, None
+    y, _, _, nxt = _block_forward_multi(X.contiguous(), segs, nH, dp_rows, (g1, b1, table, bqkv, bproj, g2, b2, bfc1, bfc2), wts, False, pre, next_norm)
+    return y, None, nxt
 
 
 def swin_block(x, geom, nH, index, dp, prm_list):

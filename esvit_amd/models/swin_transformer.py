@@ -113,15 +113,19 @@ class SwinTransformerBlock(nn.Module):
         return y, attn
 
 
-def _block_forward_multi(blk, X, groups, dp, shadow=None, prev_scale=None):
+def _block_forward_multi(blk, X, groups, dp, shadow=None, prev_scale=None, pre=None, next_blk=None):
     """blk: SwinTransformerBlock; X fp32 [M, C]; groups: list of (row0, nB, H, W); dp: None or the per-ROW DropPath scales
     (attention branch [M], MLP branch [M]; rows of one sample share its factor).
     shadow / prev_scale: the previous block's shadow output and MLP-branch DropPath row scale (Fn.SwinBlockMultiFn).
-    -> (y, shadow of y, this block's MLP-branch row scale)"""
+    pre: norm1(X) + statistics if the previous block's fused MLP kernel produced them; next_blk: the next block of the stage (its
+    norm1 then rides on this block's fused MLP kernel).
+    -> (y, shadow of y, this block's MLP-branch row scale, the next block's pre or None)"""
     segs = tuple((r0, nB, H * W, Fn.geometry(H, W, blk.window_size, blk.shift_size, X.device)) for (r0, nB, H, W) in groups)
     dp_rows = dp
-    y, ysh = Fn.swin_block_multi(X, segs, blk.num_heads, blk.attn.relative_position_index, dp_rows, blk._params(), shadow, prev_scale)
-    return y, ysh, (None if dp_rows is None else dp_rows[1])
+    nn_ = None if next_blk is None else (next_blk.norm1.weight, next_blk.norm1.bias)
+    y, ysh, nxt = Fn.swin_block_multi(X, segs, blk.num_heads, blk.attn.relative_position_index, dp_rows, blk._params(), shadow, prev_scale,
+                                      pre, nn_)
+    return y, ysh, (None if dp_rows is None else dp_rows[1]), nxt
 
 
 class PatchMerging(nn.Module):
@@ -201,12 +205,14 @@ class BasicLayer(nn.Module):
                 cache[key] = rowsample
             F = torch.stack([f for i in live for f in stage_f[i]])  # [2 * live blocks, samples]
             rows_f = F[:, rowsample]                                   # [2 * live blocks, M]
+        pre = None
         for bi, blk in enumerate(self.blocks):
             dp = None
             if stage_f[bi] is not None:
                 k = live.index(bi)
                 dp = (rows_f[2 * k], rows_f[2 * k + 1])
-            X, shadow, prev_scale = _block_forward_multi(blk, X, groups, dp, shadow, prev_scale)
+            nxt_blk = self.blocks[bi + 1] if bi + 1 < len(self.blocks) else None
+            X, shadow, prev_scale, pre = _block_forward_multi(blk, X, groups, dp, shadow, prev_scale, pre, nxt_blk)
         if self.downsample is not None:
             return self.downsample.forward_ragged(X, groups)
         return X, groups

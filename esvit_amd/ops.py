@@ -312,15 +312,60 @@ def mlp_fused_supported(dt, Cc):
     return bool(query(Q_MLP_FUSED, _code(dt), int(Cc)))
 
 
-def mlp_fused_fwd(x, gamma, beta, eps, W1, b1, W2, b2, *, rowscale=None):
-    """x fp32 [M, C] -> y fp32 [M, C] = x + rowscale * (GELU(LN(x) W1^T + b1) W2^T + b2); nothing is saved for a backward"""
+def mlp_fused_fwd(x, gamma, beta, eps, W1, b1, W2, b2, *, rowscale=None, next_norm=None):
+    """x fp32 [M, C] -> y fp32 [M, C] = x + rowscale * (GELU(LN(x) W1^T + b1) W2^T + b2); nothing hidden-sized is written.
+    next_norm = (gamma_next, beta_next): also return (xw_next act [M, C], mean_next, rstd_next) = LayerNorm(y) with the next
+    block's norm1 parameters -> (y, (xw, mean, rstd))"""
     x, W1, W2 = _f32c(x), _actc(W1), _actc(W2)
     M, Cc = x.shape
     assert W1.shape == (4 * Cc, Cc) and W2.shape == (Cc, 4 * Cc) and W1.dtype == W2.dtype
     y = torch.empty_like(x)
+    gn = bn = xw = mn = rn = None
+    if next_norm is not None:
+        gn, bn = _f32c(next_norm[0]), _f32c(next_norm[1])
+        xw = torch.empty((M, Cc), dtype=W1.dtype, device=x.device)
+        mn = torch.empty((M,), dtype=torch.float32, device=x.device)
+        rn = torch.empty_like(mn)
     check(lib.esvit_mlp_fused_fwd(_code(W1.dtype), _p(x), _p(_f32c(gamma)), _p(_f32c(beta)), eps, _p(W1), _p(_f32c(b1)), _p(W2), _p(_f32c(b2)),
-                                  _p(rowscale), M, Cc, _p(y), _stream()), "mlp_fused_fwd")
-    return y
+                                  _p(rowscale), M, Cc, _p(y), _p(gn), _p(bn), _p(xw), _p(mn), _p(rn), _stream()), "mlp_fused_fwd")
+    return y if next_norm is None else (y, (xw, mn, rn))
+
+
+def cast_transpose(w):
+    """fp32 [R, S] -> bf16 [S, R] (the transposed weight copies esvit_mlp_fused_bwd streams)"""
+    w = _f32c(w)
+    R, S = w.shape
+    out = torch.empty((S, R), dtype=torch.bfloat16, device=w.device)
+    check(lib.esvit_cast_transpose(_p(w), _p(out), R, S, _stream()), "cast_transpose")
+    return out
+
+
+def mlp_fused_bwd(x, gy, gamma, beta, eps, W1, W2T, W1T, b1, *, rowscale_mlp=None, rowscale_out=None):
+    """data-gradient path of the fused MLP branch: x (branch input) fp32 [M, C], gy = dL/dy fp32 [M, C] ->
+    (gx fp32 [M, C], gx_act act [M, C] = cast(rowscale_out * gx), xhat act [M, C], a1g act [M, 4C], da1 act [M, 4C])"""
+    x, gy, W1, W2T, W1T = _f32c(x), _f32c(gy), _actc(W1), _actc(W2T), _actc(W1T)
+    M, Cc = x.shape
+    assert gy.shape == x.shape and W1.shape == (4 * Cc, Cc) and W2T.shape == (4 * Cc, Cc) and W1T.shape == (Cc, 4 * Cc)
+    dt = W1.dtype
+    gx = torch.empty_like(x)
+    gxa = torch.empty((M, Cc), dtype=dt, device=x.device)
+    xhat = torch.empty((M, Cc), dtype=dt, device=x.device)
+    a1g = torch.empty((M, 4 * Cc), dtype=dt, device=x.device)
+    da1 = torch.empty((M, 4 * Cc), dtype=dt, device=x.device)
+    check(lib.esvit_mlp_fused_bwd(_code(dt), _p(x), _p(gy), _p(rowscale_mlp), _p(rowscale_out), _p(_f32c(gamma)), _p(_f32c(beta)), eps, _p(W1),
+                                  _p(W2T), _p(W1T), _p(_f32c(b1)), M, Cc, _p(gx), _p(gxa), _p(xhat), _p(a1g), _p(da1), _stream()), "mlp_fused_bwd")
+    return gx, gxa, xhat, a1g, da1
+
+
+def ln_fold_finish(G, db, W, gamma, beta, *, gb_out=None):
+    """LayerNorm folded out of a weight gradient: G = dY^T xhat [J, C] (overwritten by dW = G o gamma + db (x) beta), db = colsum(dY),
+    W the fp32 master -> (dW, dgamma, dbeta)"""
+    G, db, W = _f32c(G), _f32c(db), _f32c(W)
+    J, Cc = G.shape
+    assert W.shape == (J, Cc) and db.shape == (J,)
+    dgamma, dbeta = _ln_grad_outs(Cc, G.device, gb_out)
+    check(lib.esvit_ln_fold_finish(_p(G), _p(db), _p(W), _p(_f32c(gamma)), _p(_f32c(beta)), J, Cc, _p(dgamma), _p(dbeta), 0, _stream()), "ln_fold_finish")
+    return G, dgamma, dbeta
 
 
 # ------------------------------------------------------------------------------------------------

@@ -44,7 +44,7 @@ const char* esvit_last_error(void);
  *   ESVIT_Q_COLSUM_BLOCKS (rows)               blocks of the esvit_colsum scratch
  *   ESVIT_Q_COL_REDUCE_BLOCKS (rows)           blocks of the esvit_dwconv3x3_wgrad / esvit_col_sums2 scratch
  *   ESVIT_Q_UPDATE_CHUNK_ELEMS ()              elements per chunk of the fused update's chunk table
- *   ESVIT_Q_MLP_FUSED (dtype, C)               1 where esvit_mlp_fused_fwd exists (bf16, C in {96, 192})
+ *   ESVIT_Q_MLP_FUSED (dtype, C)               1 where esvit_mlp_fused_fwd / _bwd exist (bf16, C in {96, 192})
  *   ESVIT_Q_AUG_MAX_BOX (S)                    largest crop-box side esvit_aug_crops resizes to S x S
  * Unknown `what` returns ESVIT_ERR_ARG. */
 #define ESVIT_Q_ATTN_FRAG_ELEMS 1
@@ -126,15 +126,39 @@ int esvit_gemm(int dtype, const esvit_gemm_desc* d, esvit_stream_t stream);
  * (tile, slice); a launch of more workgroups than resident slots runs in rounds) before it allocates `partial`. */
 int esvit_gemm_select(int dtype, const esvit_gemm_desc* d, int* tile_m, int* tile_n, int* resident_slots);
 
-/* ---- fused Swin MLP forward, inference mode (swin_transformer.py:331 + 31-37) ---
- * y = x + rowscale[row] * ( GELU( LayerNorm(x) W1^T + b1 ) W2^T + b2 ) in ONE kernel for the narrow stages of passes that
- * save nothing for a backward (the EMA teacher): the unfused LayerNorm -> fc1 (+GELU) -> fc2 (+residual) sequence is bound
- * there by the HBM round trips of the 4C-wide hidden activation (32 B per token-channel against 8 fused).
- * x, y fp32 [M, C]; W1 [4C, C], W2 [C, 4C] in the activation dtype; gamma, beta, b1, b2 fp32; rowscale fp32 [M] or NULL.
- * esvit_query(ESVIT_Q_MLP_FUSED, dtype, C, 0): 1 where the kernel exists (bf16, C in {96, 192}). */
+/* ---- fused Swin MLP branch, forward and backward (swin_transformer.py:331 + 31-37) ---
+ * y = x + rowscale[row] * ( GELU( LayerNorm(x) W1^T + b1 ) W2^T + b2 ) for the narrow stages (bf16, C in {96, 192};
+ * esvit_query(ESVIT_Q_MLP_FUSED, dtype, C, 0) = 1 where the kernels exist).  The unfused LayerNorm -> fc1 (+GELU) -> fc2
+ * (+residual) sequence is bound there by the HBM round trips of the 4C-wide hidden activation (40 B per token-channel forward,
+ * 64 B backward).  x, y fp32 [M, C]; W1 [4C, C], W2 [C, 4C] in the activation dtype; gamma, beta, b1, b2 fp32; rowscale fp32 [M]
+ * (the DropPath factor of each row) or NULL.
+ *
+ * esvit_mlp_fused_fwd: one kernel, 8 B per token-channel, NOTHING hidden-sized is written (inference passes and training alike:
+ *   the backward below recomputes).  Optional second output (gamma_next != NULL): LayerNorm(y) with the parameters of the
+ *   NEXT block's norm1 (swin_transformer.py:283) -- xw_next [M, C] in the activation dtype, mean_next / rstd_next fp32 [M] --
+ *   so that block needs no LayerNorm launch.
+ * esvit_mlp_fused_bwd: the data-gradient path of the branch in one kernel.  Inputs: x (the branch input), gy = dL/dy fp32,
+ *   rowscale_mlp (the forward's rowscale), W1, and the transposed copies W2T = W2^T [4C, C], W1T = W1^T [C, 4C]
+ *   (esvit_cast_transpose).  It recomputes LayerNorm(x) and the pre-activation, forms dA = (rowscale gy W2) o GELU'(A) and
+ *   dH = dA W1 with the hidden tile in registers, applies the LayerNorm backward and writes
+ *     gx      fp32 [M, C]   dL/dx = gy + LN'(dH)                 gx_act  act [M, C]  cast(rowscale_out[row] * gx) (NULL scale = 1)
+ *     xhat    act [M, C]    (x - mean) rstd                      a1g     act [M, 4C] GELU(A)          da1  act [M, 4C]  dA
+ *   The weight gradients are two esvit_gemm calls: dW2 = (rowscale gy)^T a1g, and G = da1^T xhat, db1 = colsum(da1) followed by
+ * esvit_ln_fold_finish: LayerNorm folded out of a weight gradient.  With LN(x) = xhat o gamma + beta and G = dY^T xhat [J, C],
+ *   db = colsum(dY) [J], W the fp32 master [J, C]:  dW = G o gamma + db (x) beta (written over G),
+ *   dgamma[c] (+)= sum_j W[j, c] G[j, c],  dbeta[c] (+)= sum_j db[j] W[j, c]   (swin_transformer.py:331 autograd).
+ * esvit_cast_transpose: dst (bf16 [S, R]) = cast(src (fp32 [R, S]))^T. */
 int esvit_mlp_fused_fwd(int dtype, const float* x, const float* gamma, const float* beta, float eps, const void* W1,
                         const float* b1, const void* W2, const float* b2, const float* rowscale, int64_t M, int C, float* y,
+                        const float* gamma_next, const float* beta_next, void* xw_next, float* mean_next, float* rstd_next,
                         esvit_stream_t stream);
+int esvit_mlp_fused_bwd(int dtype, const float* x, const float* gy, const float* rowscale_mlp, const float* rowscale_out,
+                        const float* gamma, const float* beta, float eps, const void* W1, const void* W2T, const void* W1T,
+                        const float* b1, int64_t M, int C, float* gx, void* gx_act, void* xhat, void* a1g, void* da1,
+                        esvit_stream_t stream);
+int esvit_ln_fold_finish(float* G, const float* db, const float* W, const float* gamma, const float* beta, int J, int C,
+                         float* dgamma, float* dbeta, int accumulate, esvit_stream_t stream);
+int esvit_cast_transpose(const float* src, void* dst_bf16, int R, int S, esvit_stream_t stream);
 
 /* ---- normalisation ----------------------------------------------------- */
 /* LayerNorm forward over rows of C channels (swin_transformer.py:283,331,417,546,687;

@@ -184,11 +184,54 @@ def mlp_fused_supported(dt, Cc):
     return dt == torch.bfloat16 and Cc in (96, 192)
 
 
-def mlp_fused_fwd(x, gamma, beta, eps, W1, b1, W2, b2, *, rowscale=None):
+def mlp_fused_fwd(x, gamma, beta, eps, W1, b1, W2, b2, *, rowscale=None, next_norm=None):
     """the unfused sequence the fused kernel replaces (same rounding points)"""
     h, _, _, _ = layernorm_fwd(x, gamma, beta, eps, dtype=W1.dtype)
     act = linear_fwd(h, W1, b1, gelu=True)
-    return linear_fwd(act, W2, b2, residual=x, rowscale=rowscale, rows_per_sample=1, out_f32=True)
+    y = linear_fwd(act, W2, b2, residual=x, rowscale=rowscale, rows_per_sample=1, out_f32=True)
+    if next_norm is None:
+        return y
+    xw, _, mean, rstd = layernorm_fwd(y, next_norm[0], next_norm[1], eps, dtype=W1.dtype)
+    return y, (xw, mean, rstd)
+
+
+def cast_transpose(w):
+    return _r(w.float().t().contiguous(), torch.bfloat16 if _ACT_DTYPE == torch.bfloat16 else torch.float32)
+
+
+def mlp_fused_bwd(x, gy, gamma, beta, eps, W1, W2T, W1T, b1, *, rowscale_mlp=None, rowscale_out=None):
+    """restatement of esvit_mlp_fused_bwd (same rounding points: LN(x), GELU(A), dA and the scaled dy are rounded to the
+    activation dtype where the kernel feeds them to an MFMA or stores them)"""
+    dt = W1.dtype
+    xf = x.float()
+    mean = xf.mean(1, keepdim=True)
+    rstd = torch.rsqrt(((xf - mean) ** 2).mean(1, keepdim=True) + eps)
+    xhat = (xf - mean) * rstd
+    xn = _r(xhat * gamma + beta, dt).float()
+    dy = gy.float() if rowscale_mlp is None else gy.float() * rowscale_mlp[:, None]
+    dyb = _r(dy, dt).float()
+    A = xn @ W1.float().t() + b1
+    cdf = 0.5 * (1 + torch.erf(A * 0.7071067811865476))
+    a1g = _r(A * cdf, dt)
+    dgelu = cdf + A * torch.exp(-0.5 * A * A) * 0.3989422804014327
+    da1 = _r((dyb @ W2T.float().t()) * dgelu, dt)
+    dh = da1.float() @ W1T.float().t()
+    g = dh * gamma
+    dx = rstd * (g - g.mean(1, keepdim=True) - xhat * (g * xhat).mean(1, keepdim=True))
+    gx = gy.float() + dx
+    gxa = _r(gx if rowscale_out is None else gx * rowscale_out[:, None], dt)
+    return gx, gxa, _r(xhat, dt), a1g, da1
+
+
+def ln_fold_finish(G, db, W, gamma, beta, *, gb_out=None):
+    dgamma = (W * G).sum(0)
+    dbeta = db @ W
+    G.copy_(G * gamma + db[:, None] * beta[None, :])
+    if gb_out is not None and gb_out[0] is not None and gb_out[1] is not None:
+        gb_out[0].view(-1).copy_(dgamma)
+        gb_out[1].view(-1).copy_(dbeta)
+        return G, gb_out[0].view(-1), gb_out[1].view(-1)
+    return G, dgamma, dbeta
 
 
 def layernorm_fwd(x, gamma, beta, eps, *, rowmap=None, period_out=0, out_rows=None, want_f32=False, dtype=None):

@@ -499,3 +499,23 @@ def test_baseline_configs_3_to_5_full_width_composition_matches_reference_golden
     assert abs(loss.item() - g["loss"]) < 1e-4, (loss.item(), g["loss"])
     assert norm_rel < 2e-3 and worst < 5e-3, (norm_rel, worst_name, worst)
     assert (loss_fn.center - g["center"]).abs().max().item() < 1e-6 and (loss_fn.center_grid - g["center_grid"]).abs().max().item() < 1e-6
+
+
+def test_fused_mlp_branch_host_logic_matches_reference_golden(cpu_ops, monkeypatch):
+    """the training path of the fused MLP branch (esvit_mlp_fused_fwd / _bwd, LayerNorm folded out of the fc1 weight gradient by
+    esvit_ln_fold_finish) through the product's autograd glue, kernels replaced by their fp32 restatement: Swin-T at full width
+    (stages 0 / 1 take the fused branch) reproduces the reference's own step -- loss, every gradient norm, sampled gradients"""
+    import esvit_amd.functional as Fn
+    from tests.test_step_gpu import FULL_GOLD, full_case_deltas, run_full_case
+    monkeypatch.setattr(ops_ref, "mlp_fused_supported", lambda dt, C: C in (96, 192))
+    calls = {"fwd": 0, "bwd": 0}
+    f0, b0 = ops_ref.mlp_fused_fwd, ops_ref.mlp_fused_bwd
+    monkeypatch.setattr(ops_ref, "mlp_fused_fwd", lambda *a, **k: (calls.__setitem__("fwd", calls["fwd"] + 1), f0(*a, **k))[1])
+    monkeypatch.setattr(ops_ref, "mlp_fused_bwd", lambda *a, **k: (calls.__setitem__("bwd", calls["bwd"] + 1), b0(*a, **k))[1])
+    assert Fn.MLP_FUSED_TRAIN
+    g = torch.load(FULL_GOLD, map_location="cpu", weights_only=False)["swin_t_k8192_b2"]
+    student, loss_fn, s_out, t_out, loss = run_full_case("swin_t_k8192_b2", torch.device("cpu"))
+    assert calls["bwd"] == 4 and calls["fwd"] == 8, calls  # stages 0 and 1, two blocks each: student (fwd + bwd) and teacher (fwd)
+    out_rel, norm_rel, worst, worst_name = full_case_deltas(g, student, s_out)
+    assert out_rel < 1e-4 and abs(loss.item() - g["loss"]) < 1e-4, (out_rel, loss.item(), g["loss"])
+    assert norm_rel < 2e-3 and worst < 5e-3, (norm_rel, worst_name, worst)

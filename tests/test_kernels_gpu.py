@@ -178,6 +178,65 @@ def test_mlp_fused_fwd(mods, C, M):
         got = ops.mlp_fused_fwd(x, g, b, 1e-6, W1, b1, W2, b2, rowscale=rs)
         want = ref.mlp_fused_fwd(x, g, b, 1e-6, W1, b1, W2, b2, rowscale=rs)
         _close("mlp y", got, want, 4e-3)  # fp32 output; the hidden activation is rounded to bf16 on both sides
+        # second output: LayerNorm(y) with the next block's norm1 parameters + its row statistics
+        gn, bn = 1.0 + 0.3 * _rand((C,), dev, 68), 0.2 * _rand((C,), dev, 69)
+        got2, (xw, mean, rstd) = ops.mlp_fused_fwd(x, g, b, 1e-6, W1, b1, W2, b2, rowscale=rs, next_norm=(gn, bn))
+        assert torch.equal(got2, got)
+        xw_r, _, mean_r, rstd_r = ref.layernorm_fwd(got, gn, bn, 1e-6, dtype=dt)  # (statistics of the kernel's own y)
+        _close("next-norm xw", xw, xw_r, 8e-3)
+        _close("next-norm mean", mean, mean_r, 2e-5)
+        _close("next-norm rstd", rstd, rstd_r, 2e-5)
+
+
+@pytest.mark.parametrize("C,M", [(96, 128 * 29), (192, 128 * 9), (96, 1000), (192, 77), (96, 128 * 300 + 33)])
+def test_mlp_fused_bwd(mods, C, M):
+    """data-gradient path of the fused MLP branch (esvit_mlp_fused_bwd) vs its torch restatement: dL/dx, its activation-dtype
+    copy, xhat, GELU(A), dA; full and ragged row tiles, with and without DropPath row factors.  Then the whole branch backward
+    (two weight-gradient GEMMs + esvit_ln_fold_finish) against torch autograd of the unfused fp32 formula"""
+    ops, ref = mods
+    dev = _dev()
+    dt = torch.bfloat16
+    x = _rand((M, C), dev, 70) * 1.5 + 0.3
+    gy = _rand((M, C), dev, 71) * 0.5
+    g, b = 1.0 + 0.2 * _rand((C,), dev, 72), 0.1 * _rand((C,), dev, 73)
+    W1f, b1 = _rand((4 * C, C), dev, 74, torch.float32, 0.08), 0.1 * _rand((4 * C,), dev, 75)
+    W2f = _rand((C, 4 * C), dev, 76, torch.float32, 0.05)
+    W1, W2 = W1f.to(dt), W2f.to(dt)
+    W1T, W2T = ops.cast_transpose(W1f), ops.cast_transpose(W2f)
+    assert torch.equal(W1T, W1.t().contiguous()) and torch.equal(W2T, W2.t().contiguous())
+    gen = torch.Generator().manual_seed(77)
+    for rs_mlp, rs_out in ((None, None), ((torch.rand(M, generator=gen) > 0.3).float().div(0.7).to(dev), (torch.rand(M, generator=gen) > 0.2).float().div(0.8).to(dev))):
+        got = ops.mlp_fused_bwd(x, gy, g, b, 1e-6, W1, W2T, W1T, b1, rowscale_mlp=rs_mlp, rowscale_out=rs_out)
+        want = ref.mlp_fused_bwd(x, gy, g, b, 1e-6, W1, W2T, W1T, b1, rowscale_mlp=rs_mlp, rowscale_out=rs_out)
+        for name, a, r, tol in zip(("gx", "gx_act", "xhat", "a1g", "da1"), got, want, (6e-3, 1e-2, 8e-3, 8e-3, 1.2e-2)):
+            _close("mlp bwd " + name, a, r, tol)
+    # the whole branch against autograd (fp32 formula on the same bf16-rounded weights)
+    gx, gxa, xhat, a1g, da1 = ops.mlp_fused_bwd(x, gy, g, b, 1e-6, W1, W2T, W1T, b1)
+    dyb = gy.to(dt)
+    dW2, db2 = ops.linear_wgrad(dyb, a1g, want_bias=True)
+    G, db1 = ops.linear_wgrad(da1, xhat, want_bias=True)
+    dW1, dg, dbeta = ops.ln_fold_finish(G, db1, W1.float(), g, b)
+    xa = x.clone().requires_grad_(True)
+    prm = [t.clone().float().requires_grad_(True) for t in (g, b, W1, b1, W2)]
+    h = torch.nn.functional.layer_norm(xa, (C,), prm[0], prm[1], 1e-6)
+    y = xa + torch.nn.functional.gelu(h @ prm[2].t() + prm[3]) @ prm[4].t()
+    y.backward(gy)
+    _close("branch dx", gx, xa.grad, 1.5e-2)
+    for name, a, r in (("dgamma", dg, prm[0].grad), ("dbeta", dbeta, prm[1].grad), ("dW1", dW1, prm[2].grad), ("db1", db1, prm[3].grad),
+                       ("dW2", dW2, prm[4].grad), ("db2", db2, gy.sum(0))):
+        _close("branch " + name, a, r, 2e-2)
+
+
+def test_ln_fold_finish(mods):
+    ops, ref = mods
+    dev = _dev()
+    J, C = 384, 96
+    G, db, W = _rand((J, C), dev, 80), _rand((J,), dev, 81), _rand((J, C), dev, 82)
+    g, b = 1.0 + 0.2 * _rand((C,), dev, 83), 0.1 * _rand((C,), dev, 84)
+    want = ref.ln_fold_finish(G.clone(), db, W, g, b)
+    got = ops.ln_fold_finish(G.clone(), db, W, g, b)
+    for name, a, r in zip(("dW", "dgamma", "dbeta"), got, want):
+        _close("ln fold " + name, a, r, 2e-5)
 
 
 @pytest.mark.parametrize("dt", DTYPES)

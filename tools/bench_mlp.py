@@ -27,6 +27,50 @@ def main():
     B = ap.parse_args().batch
     dt = torch.bfloat16
     for C, rows_s, rows_t in ((96, B * (2 * 3136 + 8 * 576), B * 2 * 3136), (192, B * (2 * 784 + 8 * 144), B * 2 * 784)):
+        # ---- training branch: forward + backward, fused (recompute) vs the unfused sequence of the same step ----
+        M = rows_s
+        x = torch.randn(M, C, device=dev)
+        gy = torch.randn(M, C, device=dev) * 0.1
+        g, b = torch.ones(C, device=dev), torch.zeros(C, device=dev)
+        W1f, b1 = torch.randn(4 * C, C, device=dev) * 0.05, torch.zeros(4 * C, device=dev)
+        W2f, b2 = torch.randn(C, 4 * C, device=dev) * 0.05, torch.zeros(C, device=dev)
+        W1, W2 = W1f.to(dt), W2f.to(dt)
+        W1T, W2T = ops.cast_transpose(W1f), ops.cast_transpose(W2f)
+        dyb = gy.to(dt)
+
+        def unf_fwd():
+            h, _, mean, rstd = ops.layernorm_fwd(x, g, b, 1e-6)
+            a1g, a1 = ops.linear_fwd(h, W1, b1, gelu=True, want_preact=True)
+            return h, mean, rstd, a1g, a1, ops.linear_fwd(a1g, W2, b2, residual=x, out_f32=True)
+        h, mean, rstd, a1g, a1, _ = unf_fwd()
+
+        def unf_bwd():
+            dW2, dbb = ops.linear_wgrad(dyb, a1g, want_bias=True)
+            da1 = ops.linear_dgrad(dyb, W2, gelu_preact=a1)
+            dW1, dbb1 = ops.linear_wgrad(da1, h, want_bias=True)
+            dh = ops.linear_dgrad(da1, W1)
+            return ops.layernorm_bwd_cast(dh, x, mean, rstd, g, g_in=gy)
+
+        def fus_bwd_kernel():
+            return ops.mlp_fused_bwd(x, gy, g, b, 1e-6, W1, W2T, W1T, b1)
+
+        def fus_bwd():
+            gx, gxa, xhat, a1g_, da1_ = ops.mlp_fused_bwd(x, gy, g, b, 1e-6, W1, W2T, W1T, b1)
+            dW2, dbb = ops.linear_wgrad(dyb, a1g_, want_bias=True)
+            G, dbb1 = ops.linear_wgrad(da1_, xhat, want_bias=True)
+            return ops.ln_fold_finish(G, dbb1, W1f, g, b)
+        res = dict(C=C, rows=M, who="student")
+        for name, fn in (("unfused_fwd", unf_fwd), ("fused_fwd", lambda: ops.mlp_fused_fwd(x, g, b, 1e-6, W1, b1, W2, b2)),
+                         ("fused_fwd_nextnorm", lambda: ops.mlp_fused_fwd(x, g, b, 1e-6, W1, b1, W2, b2, next_norm=(g, b))),
+                         ("unfused_bwd", unf_bwd), ("fused_bwd_kernel", fus_bwd_kernel), ("fused_bwd_all", fus_bwd)):
+            res[name + "_us"] = round(timeit(fn) * 1e6, 1)
+        res["fwd_speedup"] = round(res["unfused_fwd_us"] / res["fused_fwd_us"], 2)
+        res["bwd_speedup"] = round(res["unfused_bwd_us"] / res["fused_bwd_all_us"], 2)
+        res["fused_fwd_GBs"] = round(M * C * 8 / res["fused_fwd_us"] / 1e3)
+        res["fused_bwd_kernel_GBs"] = round(M * C * 32 / res["fused_bwd_kernel_us"] / 1e3)
+        print(json.dumps(res), flush=True)
+        del x, gy, h, a1g, a1, dyb
+        torch.cuda.empty_cache()
         for M, save, who in ((rows_t, False, "teacher"),):
             x = torch.randn(M, C, device=dev)
             g, b = torch.ones(C, device=dev), torch.zeros(C, device=dev)
