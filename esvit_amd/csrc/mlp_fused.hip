@@ -33,8 +33,6 @@
 // chunk; bank conflicts are removed by XOR-swizzling the 16-byte chunk index on the source address and on the fragment read
 // (guide rule 21).  The forward loop contains no vector-memory operation besides the DMA; the backward loop also stores the two
 // hidden tiles, and its counted wait accounts for them (vmcnt retires in order).
-#include <stdlib.h>
-
 #include "common.h"
 #include "../../include/esvit_hip.h"
 
@@ -237,15 +235,13 @@ __device__ __forceinline__ void mlp_fused_fwd_body(
         const char* w1 = smem + buf * Cfg::WBUF;
         const char* w2 = w1 + Cfg::W1_BYTES;
 
-        // ---- P^T[32 hidden][32 tokens] = W1_chunk * LN(x)^T (two accumulators: half the dependent-MFMA chain) ----
-        f32x16 acc1a, acc1b;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc1a[r] = acc1b[r] = 0.f;
+        // ---- P^T[32 hidden][32 tokens] = W1_chunk * LN(x)^T (the first step takes a literal zero accumulator: no zero-fill) ----
+        f32x16 acc1;
 #pragma unroll
         for (int s = 0; s < Cfg::KS1; ++s) {  // A fragment: W1 row rho(n) of the chunk, channels 16s + 8hh .. +7
             const bf16x8 a = *reinterpret_cast<const bf16x8*>(w1 + (rho_n * (C / 8) + Cfg::pos1(2 * s + hh, rho_n)) * 16);
-            if (s & 1) acc1b = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, xb[s], acc1b, 0, 0, 0);
-            else acc1a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, xb[s], acc1a, 0, 0, 0);
+            if (s == 0) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, xb[s], f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, 0, 0, 0);
+            else acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, xb[s], acc1, 0, 0, 0);
         }
         // ---- bias, GELU, rounding: register 8t + e (e < 8) holds hidden unit 32q + 16t + 8hh + e of token n ----
         bf16x8 hf[2];
@@ -255,8 +251,7 @@ __device__ __forceinline__ void mlp_fused_fwd_body(
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const float blo = bq[16 * t + e], bhi = bq[16 * t + 8 + e];
-                const float v = acc1a[8 * t + e] + acc1b[8 * t + e] + (hh ? bhi : blo);
-                hf[t][e] = (bf16)gelu_f(v);
+                hf[t][e] = (bf16)gelu_f(acc1[8 * t + e] + (hh ? bhi : blo));
             }
         // ---- y^T[C][32 tokens] += W2_chunk[C x 32 hidden] * H^T ----
 #pragma unroll
@@ -338,7 +333,7 @@ __device__ __forceinline__ void mlp_fused_fwd_body(
 }
 
 template <int C, bool LNN>
-__global__ __launch_bounds__(MLP_WAVES * 64, (C == 96 ? (LNN ? 3 : 4) : 2)) void mlp_fused_fwd_kernel(
+__global__ __launch_bounds__(MLP_WAVES * 64, (C == 96 ? 4 : 2)) void mlp_fused_fwd_kernel(
     const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
     const bf16* __restrict__ W1, const float* __restrict__ b1, const bf16* __restrict__ W2, const float* __restrict__ b2,
     const float* __restrict__ rowscale, long M, float* __restrict__ y, const float* __restrict__ gamma_n,
@@ -506,20 +501,23 @@ __device__ __forceinline__ void mlp_fused_bwd_body(
         // ---- P^T = W1_chunk * LN(x)^T  and  G^T = W2^T_chunk * dy^T   ([32 hidden][32 tokens] each) ----
         f32x16 accp, accg;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) accp[r] = accg[r] = 0.f;
-#pragma unroll
         for (int s = 0; s < Cfg::KS1; ++s) {
             const int off = (rho_n * (C / 8) + Cfg::pos1(2 * s + hh, rho_n)) * 16;
             const bf16x8 a = *reinterpret_cast<const bf16x8*>(wa + off);
             const bf16x8 b = *reinterpret_cast<const bf16x8*>(wb + off);
-            accp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, xb[s], accp, 0, 0, 0);
-            accg = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, dyb[s], accg, 0, 0, 0);
+            if (s == 0) {
+                accp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, xb[s], f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, 0, 0, 0);
+                accg = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, dyb[s], f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, 0, 0, 0);
+            } else {
+                accp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, xb[s], accp, 0, 0, 0);
+                accg = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, dyb[s], accg, 0, 0, 0);
+            }
         }
         // ---- GELU, GELU', dA: register 8t + e holds hidden unit 32q + 16t + 8hh + e of token n ----
         bf16x8 hf[2], df[2];
         const float* bq = b1 + q * HCH;
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < 2; ++t) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const float blo = bq[16 * t + e], bhi = bq[16 * t + 8 + e];
@@ -529,6 +527,7 @@ __device__ __forceinline__ void mlp_fused_bwd_body(
                 hf[t][e] = (bf16)g;
                 df[t][e] = (bf16)(accg[8 * t + e] * dg);
             }
+        }
         if (row_ok) {
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
@@ -734,12 +733,10 @@ extern "C" int esvit_mlp_fused_bwd(int dtype, const float* x, const float* gy, c
     ESVIT_CHECK_ARG(AL16(x) && AL16(gy) && AL16(gx) && AL16(gx_act) && AL16(xhat) && AL16(a1g) && AL16(da1) && AL16(W1) && AL16(W2T) &&
                         AL16(W1T) && AL16(gamma) && AL16(beta),
                     "esvit_mlp_fused_bwd: operands must be 16-byte aligned");
-    static const int nbuf = getenv("ESVIT_MLP_BWD_NBUF") ? atoi(getenv("ESVIT_MLP_BWD_NBUF")) : 3;  // (A/B knob of round 3, to be removed)
-    if (C == 96)
-        return nbuf == 2 ? launch_mlp_bwd<96, 2>(x, gy, rowscale_mlp, rowscale_out, gamma, beta, eps, W1, W2T, W1T, b1, M, gx, gx_act, xhat, a1g, da1, stream)
-                         : launch_mlp_bwd<96, 3>(x, gy, rowscale_mlp, rowscale_out, gamma, beta, eps, W1, W2T, W1T, b1, M, gx, gx_act, xhat, a1g, da1, stream);
-    return nbuf == 2 ? launch_mlp_bwd<192, 2>(x, gy, rowscale_mlp, rowscale_out, gamma, beta, eps, W1, W2T, W1T, b1, M, gx, gx_act, xhat, a1g, da1, stream)
-                     : launch_mlp_bwd<192, 3>(x, gy, rowscale_mlp, rowscale_out, gamma, beta, eps, W1, W2T, W1T, b1, M, gx, gx_act, xhat, a1g, da1, stream);
+    // three weight buffers at C = 96 (a hidden-tile store then has two chunk times to be acknowledged before a wait stands behind
+    // it: 1515 -> 1369 us on the stage-0 rows of B = 128); at C = 192 the kernel holds one wave per SIMD either way: two buffers
+    if (C == 96) return launch_mlp_bwd<96, 3>(x, gy, rowscale_mlp, rowscale_out, gamma, beta, eps, W1, W2T, W1T, b1, M, gx, gx_act, xhat, a1g, da1, stream);
+    return launch_mlp_bwd<192, 2>(x, gy, rowscale_mlp, rowscale_out, gamma, beta, eps, W1, W2T, W1T, b1, M, gx, gx_act, xhat, a1g, da1, stream);
 }
 
 extern "C" int esvit_cast_transpose(const float* src, void* dst_bf16, int R, int S, esvit_stream_t s_) {
