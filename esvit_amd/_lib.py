@@ -48,7 +48,8 @@ SIGNATURES = {
     "esvit_mlp_fused_fwd": (C.c_int, [C.c_int, vp, vp, vp, f32, vp, vp, vp, vp, vp, i64, C.c_int, vp, vp, vp, vp, vp, vp, vp]),
     "esvit_mlp_fused_bwd": (C.c_int, [C.c_int, vp, vp, vp, vp, vp, vp, f32, vp, vp, vp, vp, i64, C.c_int, vp, vp, vp, vp, vp, vp]),
     "esvit_ln_fold_finish": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, vp, vp, C.c_int, vp]),
-    "esvit_cast_transpose": (C.c_int, [vp, vp, C.c_int, C.c_int, vp]),
+    "esvit_mlp_fused_weight": (C.c_int, [C.c_int, vp, vp, C.c_int, vp]),
+    "esvit_cast_weight": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "esvit_layernorm_fwd": (C.c_int, [C.c_int, vp, vp, vp, f32, i64, C.c_int, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp]),
     "esvit_conv_im2col": (C.c_int, [C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                     C.c_int, vp, vp]),

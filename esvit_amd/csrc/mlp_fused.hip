@@ -15,6 +15,13 @@
 //                         The LayerNorm parameter gradients come out of the fc1 weight gradient (esvit_ln_fold_finish below),
 //                         so no cross-lane column reduction exists in the kernel.
 //
+// THIS FILE holds the first generation of the forward (32 token rows per wave, v_mfma_f32_32x32x16_bf16), which is what runs at
+// C = 192, the entry points, and esvit_ln_fold_finish.  The forward at C = 96 and the backward at both widths run the second
+// generation (16 token rows per wave, mlp_fused16.hip: half the registers, 64-byte row pieces): measured on the rows of the
+// B = 128 step (profiles/r03_mlp_fused_generations.jsonl) forward 96: 580 -> 553 us (teacher rows 347 -> 304), backward kernel 96:
+// 1427 -> 1366, backward kernel 192: 960 -> 893, but forward 192: 432 -> 643 (twice the LDS weight bytes per token and a chunk
+// too short to hide its DMA), so that one stays here.
+//
 // Work split.  A workgroup is 4 waves; a wave OWNS 32 token rows for the whole branch, so nothing but the weight tiles is
 // shared between waves.  MFMA shape: v_mfma_f32_32x32x16_bf16.  Every product is formed TRANSPOSED -- hidden / channel index
 // on the MFMA rows, the wave's 32 tokens on the MFMA columns:
@@ -360,306 +367,8 @@ int launch_mlp(const float* x, const float* gamma, const float* beta, float eps,
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
-// backward (data-gradient path; the weight gradients are two esvit_gemm calls on the tensors written here)
-// ------------------------------------------------------------------------------------------------------------------------
-template <int C, int NB>
-struct BwdCfg : MlpCfg<C> {
-    using B = MlpCfg<C>;
-    static constexpr int NP = 2 * B::PA + B::PB;              // pieces per chunk: W1 rows | W2^T rows | W1^T columns
-    static constexpr int PPW = (NP + MLP_WAVES - 1) / MLP_WAVES;  // wave w issues pieces w, w + 4, ... (the last may be missing)
-    static constexpr int WBUF = 2 * B::W1_BYTES + B::W2_BYTES;
-    static constexpr int NBUF = NB;                           // chunk q + NBUF - 1 is requested while chunk q is computed
-    static constexpr int LDS_BYTES = NBUF * WBUF;
-    static constexpr int STORES = 4;                          // vector stores per lane and chunk (two hidden tiles x two fragments)
-};
-
-template <int C, int NB>
-__device__ __forceinline__ void mlp_fused_bwd_body(
-    const float* __restrict__ x, const float* __restrict__ gy, const float* __restrict__ rs_mlp, const float* __restrict__ rs_out,
-    const float* __restrict__ gamma, const float* __restrict__ beta, float eps, const bf16* __restrict__ W1,
-    const bf16* __restrict__ W2T, const bf16* __restrict__ W1T, const float* __restrict__ b1, long M, float* __restrict__ gx,
-    bf16* __restrict__ gxa, bf16* __restrict__ xhat, bf16* __restrict__ a1g, bf16* __restrict__ da1) {
-    using Cfg = BwdCfg<C, NB>;
-    constexpr int H4 = 4 * C;
-    constexpr int NCHUNK = H4 / HCH;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    typedef __attribute__((address_space(3))) void lds_void;
-
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int n = lane & 31, hh = lane >> 5;
-    const long row0 = (long)blockIdx.x * MLP_ROWS + wave * 32;
-    const long row = row0 + n;
-    const bool row_ok = row < M;
-    const long rrow = row_ok ? row : (M - 1);
-
-    // ---- weight chunk DMA: pieces [0, PA) W1 rows, [PA, 2 PA) W2^T rows, [2 PA, NP) W1^T columns ----
-    const __amdgpu_buffer_rsrc_t r1 = mk_rsrc(W1, (long)H4 * C * 2), r2 = mk_rsrc(W2T, (long)H4 * C * 2), r3 = mk_rsrc(W1T, (long)C * H4 * 2);
-    int voff[Cfg::PPW];
-#pragma unroll
-    for (int i = 0; i < Cfg::PPW; ++i) {
-        const int piece = wave + MLP_WAVES * i;  // wave-uniform
-        voff[i] = piece < 2 * Cfg::PA ? Cfg::voff_a(piece < Cfg::PA ? piece : piece - Cfg::PA, lane)
-                                      : Cfg::voff_b((piece < Cfg::NP ? piece : Cfg::NP - 1) - 2 * Cfg::PA, lane);
-    }
-    const bool wave_live = row0 < M;  // wave-uniform: a wave without a valid row issues no stores (its counted wait differs)
-    auto issue_chunk = [&](int q, int buf) {
-        char* img = smem + buf * Cfg::WBUF;
-        const int soa = q * HCH * C * 2, sob = q * HCH * 2;
-#pragma unroll
-        for (int i = 0; i < Cfg::PPW; ++i) {
-            const int piece = wave + MLP_WAVES * i;
-            if (piece < Cfg::PA) __builtin_amdgcn_raw_ptr_buffer_load_lds(r1, (lds_void*)(img + piece * 1024), 16, voff[i], soa, 0, 0);
-            else if (piece < 2 * Cfg::PA) __builtin_amdgcn_raw_ptr_buffer_load_lds(r2, (lds_void*)(img + piece * 1024), 16, voff[i], soa, 0, 0);
-            else if (piece < Cfg::NP) __builtin_amdgcn_raw_ptr_buffer_load_lds(r3, (lds_void*)(img + piece * 1024), 16, voff[i], sob, 0, 0);
-        }
-    };
-    issue_chunk(0, 0);
-    if constexpr (Cfg::NBUF == 3) issue_chunk(1, 1);
-    const bool five = ((Cfg::NP - wave + MLP_WAVES - 1) / MLP_WAVES) == Cfg::PPW;  // wave-uniform: this wave issues PPW (not PPW - 1) pieces
-
-    // ---- prologue: LayerNorm of this lane's half row (statistics recomputed), xhat out, dy fragments ----
-    bf16x8 xb[Cfg::KS1], dyb[Cfg::KS1];
-    float mean, rstd;
-    {
-        const float* xr = x + rrow * C + 8 * hh;
-        float xv[Cfg::KS1][8];
-        float s1 = 0.f;
-#pragma unroll
-        for (int s = 0; s < Cfg::KS1; ++s) {
-            const f32x4 a = *reinterpret_cast<const f32x4*>(xr + 16 * s), b = *reinterpret_cast<const f32x4*>(xr + 16 * s + 4);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                xv[s][e] = a[e];
-                xv[s][4 + e] = b[e];
-                s1 += a[e] + b[e];
-            }
-        }
-        s1 += __shfl_xor(s1, 32, 64);
-        mean = s1 * (1.f / C);
-        float s2 = 0.f;
-#pragma unroll
-        for (int s = 0; s < Cfg::KS1; ++s)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float d = xv[s][e] - mean;
-                s2 += d * d;
-            }
-        s2 += __shfl_xor(s2, 32, 64);
-        rstd = rsqrtf(s2 * (1.f / C) + eps);
-#pragma unroll
-        for (int s = 0; s < Cfg::KS1; ++s) {
-            const float* gp = gamma + 16 * s + 8 * hh;
-            const float* bp = beta + 16 * s + 8 * hh;
-            const f32x4 g0 = *reinterpret_cast<const f32x4*>(gp), g1 = *reinterpret_cast<const f32x4*>(gp + 4);
-            const f32x4 c0 = *reinterpret_cast<const f32x4*>(bp), c1 = *reinterpret_cast<const f32x4*>(bp + 4);
-            bf16x8 xh;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float h0 = (xv[s][e] - mean) * rstd, h1 = (xv[s][4 + e] - mean) * rstd;
-                xh[e] = (bf16)h0;
-                xh[4 + e] = (bf16)h1;
-                xb[s][e] = (bf16)(h0 * g0[e] + c0[e]);
-                xb[s][4 + e] = (bf16)(h1 * g1[e] + c1[e]);
-            }
-            if (row_ok) *reinterpret_cast<bf16x8*>(xhat + row * C + 16 * s + 8 * hh) = xh;
-        }
-        const float sm = rs_mlp ? rs_mlp[rrow] : 1.f;
-        const float* gr = gy + rrow * C + 8 * hh;
-#pragma unroll
-        for (int s = 0; s < Cfg::KS1; ++s) {
-            const f32x4 a = *reinterpret_cast<const f32x4*>(gr + 16 * s), b = *reinterpret_cast<const f32x4*>(gr + 16 * s + 4);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                dyb[s][e] = (bf16)(sm * a[e]);
-                dyb[s][4 + e] = (bf16)(sm * b[e]);
-            }
-        }
-    }
-
-    f32x16 acc3[Cfg::NT2];  // dH^T: tile mt, register r <-> channel 32 mt + (r & 3) + 8 (r >> 2) + 4 hh of token n
-#pragma unroll
-    for (int t = 0; t < Cfg::NT2; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc3[t][r] = 0.f;
-
-    wait_vm<0>();     // chunk 0 landed (this wave's part), prologue loads / stores retired
-    __syncthreads();
-
-    const int rho_n = (n & ~12) | ((n & 4) << 1) | ((n & 8) >> 1);
-    bf16* a1g_row = a1g + row * H4 + 8 * hh;
-    bf16* da1_row = da1 + row * H4 + 8 * hh;
-    int buf = 0;
-    for (int q = 0; q < NCHUNK; ++q) {
-        const bool more = q + Cfg::NBUF - 1 < NCHUNK;
-        // (the buffer of chunk q - 1, released by the barrier that ended it)
-        if (more) issue_chunk(q + Cfg::NBUF - 1, Cfg::NBUF == 2 ? (buf ^ 1) : (buf == 0 ? 2 : buf - 1));
-        const char* wa = smem + buf * Cfg::WBUF;   // W1 rows of the chunk
-        const char* wb = wa + Cfg::W1_BYTES;       // W2^T rows of the chunk
-        const char* wc = wb + Cfg::W1_BYTES;       // W1^T columns of the chunk  [C][32 hidden]
-
-        // ---- P^T = W1_chunk * LN(x)^T  and  G^T = W2^T_chunk * dy^T   ([32 hidden][32 tokens] each) ----
-        f32x16 accp, accg;
-#pragma unroll
-        for (int s = 0; s < Cfg::KS1; ++s) {
-            const int off = (rho_n * (C / 8) + Cfg::pos1(2 * s + hh, rho_n)) * 16;
-            const bf16x8 a = *reinterpret_cast<const bf16x8*>(wa + off);
-            const bf16x8 b = *reinterpret_cast<const bf16x8*>(wb + off);
-            if (s == 0) {
-                accp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, xb[s], f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, 0, 0, 0);
-                accg = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, dyb[s], f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, 0, 0, 0);
-            } else {
-                accp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, xb[s], accp, 0, 0, 0);
-                accg = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, dyb[s], accg, 0, 0, 0);
-            }
-        }
-        // ---- GELU, GELU', dA: register 8t + e holds hidden unit 32q + 16t + 8hh + e of token n ----
-        bf16x8 hf[2], df[2];
-        const float* bq = b1 + q * HCH;
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float blo = bq[16 * t + e], bhi = bq[16 * t + 8 + e];
-                const float v = accp[8 * t + e] + (hh ? bhi : blo);
-                float g, dg;
-                gelu_both(v, g, dg);
-                hf[t][e] = (bf16)g;
-                df[t][e] = (bf16)(accg[8 * t + e] * dg);
-            }
-        }
-        if (row_ok) {
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                *reinterpret_cast<bf16x8*>(a1g_row + q * HCH + 16 * t) = hf[t];
-                *reinterpret_cast<bf16x8*>(da1_row + q * HCH + 16 * t) = df[t];
-            }
-        }
-        // ---- dH^T[C][32 tokens] += W1^T_chunk[C x 32 hidden] * dA^T ----
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-#pragma unroll
-            for (int mt = 0; mt < Cfg::NT2; ++mt) {
-                const int c = 32 * mt + n;
-                const bf16x8 a = *reinterpret_cast<const bf16x8*>(wc + c * 64 + (((2 * t + hh) ^ Cfg::sw2(c)) * 16));
-                acc3[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, df[t], acc3[mt], 0, 0, 0);
-            }
-        }
-        // chunk q + 1 must have landed before the barrier; everything this wave issued AFTER that chunk's DMA may stay in flight
-        // (vmcnt retires in order).  Two buffers: that is this chunk's STORES.  Three buffers: the stores of the previous chunk,
-        // the DMA of chunk q + 2 and this chunk's stores -- a store then has two chunk times, not one, to be acknowledged
-        // before anything waits behind it.  A wave with no valid row issues no stores and simply drains.
-        if constexpr (Cfg::NBUF == 2) {
-            if (more && wave_live) wait_vm<Cfg::STORES>();
-            else wait_vm<0>();
-        } else {
-            if (!wave_live) wait_vm<0>();
-            else if (more) {
-                if (five) wait_vm<Cfg::PPW + 2 * Cfg::STORES>();
-                else wait_vm<Cfg::PPW - 1 + 2 * Cfg::STORES>();
-            } else if (q + 1 < NCHUNK) wait_vm<2 * Cfg::STORES>();
-        }
-        chunk_barrier();
-        if constexpr (Cfg::NBUF == 2) buf ^= 1;
-        else buf = buf == 2 ? 0 : buf + 1;
-    }
-
-    // ---- epilogue: LayerNorm backward in registers.  This lane: token n, channels 32 mt + 8 j + 4 hh + (0..3) ----
-    //   g = dH o gamma;  dx = rstd (g - mean_c(g) - xhat mean_c(g xhat));  gx = gy + dx;  gxa = bf16(rs_out gx)
-    float xh[Cfg::NT2][16];
-    float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-    for (int mt = 0; mt < Cfg::NT2; ++mt)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int c0 = 32 * mt + 8 * j + 4 * hh;
-            const f32x4 xv = *reinterpret_cast<const f32x4*>(x + rrow * C + c0);
-            const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + c0);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float h = (xv[i] - mean) * rstd;
-                const float g = acc3[mt][4 * j + i] * gm[i];
-                xh[mt][4 * j + i] = h;
-                acc3[mt][4 * j + i] = g;
-                s1 += g;
-                s2 += g * h;
-            }
-        }
-    s1 += __shfl_xor(s1, 32, 64);
-    s2 += __shfl_xor(s2, 32, 64);
-    const float m1 = s1 * (1.f / C), m2 = s2 * (1.f / C);
-    const float ro = rs_out ? rs_out[rrow] : 1.f;
-#pragma unroll
-    for (int mt = 0; mt < Cfg::NT2; ++mt)
-#pragma unroll
-        for (int jp = 0; jp < 2; ++jp) {
-            unsigned w[2][2];
-#pragma unroll
-            for (int jj = 0; jj < 2; ++jj) {
-                const int j = 2 * jp + jj;
-                const int c0 = 32 * mt + 8 * j + 4 * hh;
-                const f32x4 gv = *reinterpret_cast<const f32x4*>(gy + rrow * C + c0);
-                f32x4 o;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) o[i] = gv[i] + rstd * (acc3[mt][4 * j + i] - m1 - xh[mt][4 * j + i] * m2);
-                if (row_ok) *reinterpret_cast<f32x4*>(gx + row * C + c0) = o;
-                w[jj][0] = pack2(ro * o[0], ro * o[1]);
-                w[jj][1] = pack2(ro * o[2], ro * o[3]);
-            }
-            pair_swap(w[0][0], w[1][0]);
-            pair_swap(w[0][1], w[1][1]);
-            if (row_ok) *reinterpret_cast<u32x4*>(gxa + row * C + 32 * mt + 16 * jp + 8 * hh) = u32x4{w[0][0], w[0][1], w[1][0], w[1][1]};
-        }
-}
-
-template <int C, int NB>
-__global__ __launch_bounds__(MLP_WAVES * 64, (C == 96 ? 2 : 1)) void mlp_fused_bwd_kernel(
-    const float* __restrict__ x, const float* __restrict__ gy, const float* __restrict__ rs_mlp, const float* __restrict__ rs_out,
-    const float* __restrict__ gamma, const float* __restrict__ beta, float eps, const bf16* __restrict__ W1,
-    const bf16* __restrict__ W2T, const bf16* __restrict__ W1T, const float* __restrict__ b1, long M, float* __restrict__ gx,
-    bf16* __restrict__ gxa, bf16* __restrict__ xhat, bf16* __restrict__ a1g, bf16* __restrict__ da1) {
-    mlp_fused_bwd_body<C, NB>(x, gy, rs_mlp, rs_out, gamma, beta, eps, W1, W2T, W1T, b1, M, gx, gxa, xhat, a1g, da1);
-}
-
-template <int C, int NB>
-int launch_mlp_bwd(const float* x, const float* gy, const float* rs_mlp, const float* rs_out, const float* gamma, const float* beta,
-                   float eps, const void* W1, const void* W2T, const void* W1T, const float* b1, long M, float* gx, void* gxa, void* xhat,
-                   void* a1g, void* da1, hipStream_t stream) {
-    const int grid = ceil_div(M, MLP_ROWS);
-    const size_t lds = BwdCfg<C, NB>::LDS_BYTES;
-    auto kern = mlp_fused_bwd_kernel<C, NB>;
-    static bool done = false;
-    if (!done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        done = true;
-    }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(MLP_WAVES * 64), lds, stream, x, gy, rs_mlp, rs_out, gamma, beta, eps, (const bf16*)W1,
-                       (const bf16*)W2T, (const bf16*)W1T, b1, M, gx, (bf16*)gxa, (bf16*)xhat, (bf16*)a1g, (bf16*)da1);
-    ESVIT_CHECK_LAUNCH("esvit_mlp_fused_bwd");
-    return ESVIT_OK;
-}
-
-// ------------------------------------------------------------------------------------------------------------------------
 // small helpers of the fused branch
 // ------------------------------------------------------------------------------------------------------------------------
-// dst[s][r] = bf16(src[r][s]): the transposed activation-dtype weight copies the backward kernel streams (W2^T, W1^T)
-__global__ __launch_bounds__(256) void cast_transpose_kernel(const float* __restrict__ src, bf16* __restrict__ dst, int R, int S) {
-    __shared__ float tile[32][33];
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
-    const int r0 = blockIdx.y * 32, s0 = blockIdx.x * 32;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int r = r0 + ty + 8 * i, s = s0 + tx;
-        tile[ty + 8 * i][tx] = (r < R && s < S) ? src[(long)r * S + s] : 0.f;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int s = s0 + ty + 8 * i, r = r0 + tx;
-        if (s < S && r < R) dst[(long)s * R + r] = (bf16)tile[tx][ty + 8 * i];
-    }
-}
-
 // LayerNorm folded out of a weight gradient.  For y = LN(x) W^T + b with LN(x) = xhat o gamma + beta the GEMM was run on
 // xhat:  G = dY^T xhat  [J, C],  db = colsum(dY)  [J].  Then
 //     dW = G o gamma (per column) + db (x) beta,     dgamma[c] = sum_j W[j, c] G[j, c],     dbeta[c] = sum_j db[j] W[j, c]
@@ -700,6 +409,14 @@ __global__ __launch_bounds__(1024) void ln_fold_finish_kernel(float* __restrict_
 
 int esvit_i_mlp_fused_supported(int dtype, int C) { return dtype == ESVIT_BF16 && (C == 96 || C == 192); }  // esvit_query
 
+// second generation (mlp_fused16.hip)
+int esvit_i_mlp16_fwd(const float* x, const float* gamma, const float* beta, float eps, const void* W1p, const float* b1, const void* W2,
+                      const float* b2, const float* rowscale, long M, int C, float* y, const float* gn, const float* bn, void* xw, float* mn,
+                      float* rn, hipStream_t stream);
+int esvit_i_mlp16_bwd(const float* x, const float* gy, const float* rs_mlp, const float* rs_out, const float* gamma, const float* beta, float eps,
+                      const void* W1p, const void* W2Tp, const void* W1T, const float* b1, long M, int C, float* gx, void* gxa, void* xhat,
+                      void* a1g, void* da1, hipStream_t stream);
+
 #define AL16(p_) (((uintptr_t)(p_) % 16) == 0)
 
 extern "C" int esvit_mlp_fused_fwd(int dtype, const float* x, const float* gamma, const float* beta, float eps, const void* W1,
@@ -709,15 +426,14 @@ extern "C" int esvit_mlp_fused_fwd(int dtype, const float* x, const float* gamma
     hipStream_t stream = reinterpret_cast<hipStream_t>(s_);
     ESVIT_CHECK_ARG(esvit_i_mlp_fused_supported(dtype, C), "esvit_mlp_fused_fwd: bf16 activations and C in {96, 192} only (C=%d)", C);
     ESVIT_CHECK_ARG(x && gamma && beta && W1 && b1 && W2 && b2 && y && M > 0, "esvit_mlp_fused_fwd: null pointer / empty input");
-    ESVIT_CHECK_ARG(AL16(x) && AL16(y) && AL16(W1) && AL16(W2) && AL16(gamma) && AL16(beta) && AL16(b2),
+    ESVIT_CHECK_ARG(AL16(x) && AL16(y) && AL16(W1) && AL16(W2) && AL16(gamma) && AL16(beta) && AL16(b1) && AL16(b2),
                     "esvit_mlp_fused_fwd: operands must be 16-byte aligned");
     const bool lnn = gamma_next != nullptr;
     if (lnn)
         ESVIT_CHECK_ARG(beta_next && xw_next && mean_next && rstd_next && AL16(gamma_next) && AL16(beta_next) && AL16(xw_next),
                         "esvit_mlp_fused_fwd: the next-LayerNorm outputs come together (gamma, beta, xw, mean, rstd; 16-byte aligned)");
-    if (C == 96)
-        return lnn ? launch_mlp<96, true>(x, gamma, beta, eps, W1, b1, W2, b2, rowscale, M, y, gamma_next, beta_next, xw_next, mean_next, rstd_next, stream)
-                   : launch_mlp<96, false>(x, gamma, beta, eps, W1, b1, W2, b2, rowscale, M, y, nullptr, nullptr, nullptr, nullptr, nullptr, stream);
+    if (C == 96)  // 16 tokens per wave; W1 in the permuted channel order (ESVIT_MLP_W1_FWD of esvit_mlp_fused_weight)
+        return esvit_i_mlp16_fwd(x, gamma, beta, eps, W1, b1, W2, b2, rowscale, M, C, y, gamma_next, beta_next, xw_next, mean_next, rstd_next, stream);
     return lnn ? launch_mlp<192, true>(x, gamma, beta, eps, W1, b1, W2, b2, rowscale, M, y, gamma_next, beta_next, xw_next, mean_next, rstd_next, stream)
                : launch_mlp<192, false>(x, gamma, beta, eps, W1, b1, W2, b2, rowscale, M, y, nullptr, nullptr, nullptr, nullptr, nullptr, stream);
 }
@@ -731,20 +447,9 @@ extern "C" int esvit_mlp_fused_bwd(int dtype, const float* x, const float* gy, c
     ESVIT_CHECK_ARG(x && gy && gamma && beta && W1 && W2T && W1T && b1 && gx && gx_act && xhat && a1g && da1 && M > 0,
                     "esvit_mlp_fused_bwd: null pointer / empty input");
     ESVIT_CHECK_ARG(AL16(x) && AL16(gy) && AL16(gx) && AL16(gx_act) && AL16(xhat) && AL16(a1g) && AL16(da1) && AL16(W1) && AL16(W2T) &&
-                        AL16(W1T) && AL16(gamma) && AL16(beta),
+                        AL16(W1T) && AL16(gamma) && AL16(beta) && AL16(b1),
                     "esvit_mlp_fused_bwd: operands must be 16-byte aligned");
-    // three weight buffers at C = 96 (a hidden-tile store then has two chunk times to be acknowledged before a wait stands behind
-    // it: 1515 -> 1369 us on the stage-0 rows of B = 128); at C = 192 the kernel holds one wave per SIMD either way: two buffers
-    if (C == 96) return launch_mlp_bwd<96, 3>(x, gy, rowscale_mlp, rowscale_out, gamma, beta, eps, W1, W2T, W1T, b1, M, gx, gx_act, xhat, a1g, da1, stream);
-    return launch_mlp_bwd<192, 2>(x, gy, rowscale_mlp, rowscale_out, gamma, beta, eps, W1, W2T, W1T, b1, M, gx, gx_act, xhat, a1g, da1, stream);
-}
-
-extern "C" int esvit_cast_transpose(const float* src, void* dst_bf16, int R, int S, esvit_stream_t s_) {
-    hipStream_t stream = reinterpret_cast<hipStream_t>(s_);
-    ESVIT_CHECK_ARG(src && dst_bf16 && R > 0 && S > 0, "esvit_cast_transpose: bad arguments");
-    hipLaunchKernelGGL(cast_transpose_kernel, dim3(ceil_div(S, 32), ceil_div(R, 32)), dim3(256), 0, stream, src, (bf16*)dst_bf16, R, S);
-    ESVIT_CHECK_LAUNCH("esvit_cast_transpose");
-    return ESVIT_OK;
+    return esvit_i_mlp16_bwd(x, gy, rowscale_mlp, rowscale_out, gamma, beta, eps, W1, W2T, W1T, b1, M, C, gx, gx_act, xhat, a1g, da1, stream);
 }
 
 extern "C" int esvit_ln_fold_finish(float* G, const float* db, const float* W, const float* gamma, const float* beta, int J, int C,

@@ -94,10 +94,14 @@ def _weight(p, shape2d=None):
     return ops_module().cast_to_act(src.contiguous())
 
 
-def _weight_t(p):
-    """activation-dtype copy of the TRANSPOSE of an fp32 [R, S] parameter (what esvit_mlp_fused_bwd streams for W2 and W1),
-    cached per parameter version like the plain cast"""
-    return P.cached(p, "castT", lambda: ops_module().cast_transpose(p.detach().contiguous()))
+def _mlp_w(p, kind):
+    """the copy of fc1.weight / fc2.weight the fused MLP kernels stream (ops.mlp_fused_weight), cached per parameter version like
+    the plain cast; frozen parameters that nobody manages (a teacher outside the fused updater) are converted on every use"""
+    o = ops_module()
+    fn = lambda: o.mlp_fused_weight(getattr(o, kind), p.detach().contiguous())  # noqa: E731
+    if p.requires_grad or P.is_managed(p):
+        return P.cached(p, kind, fn)
+    return fn()
 
 
 # ---- fused MLP branch (narrow stages, bf16): nothing hidden-sized is kept between forward and backward ------------------------
@@ -114,7 +118,7 @@ def _mlp_fused_train(W1, C):
 def _mlp_branch_bwd(o, x1, gy, dyb, g2, b2, W1, bfc1, params, dp_mlp, dp_out):
     """-> (gx1 fp32, gx1 act copy (scaled by dp_out), dg2, db2, dW1, dbfc1, dW2, dbfc2); dyb: cast(dp_mlp * gy) [M, C] act"""
     g2_p, b2_p, W1_p, bfc1_p, W2_p, bfc2_p = params
-    gx1, dyw, xhat, a1g, da1 = o.mlp_fused_bwd(x1, gy, g2, b2, LN_EPS, W1, _weight_t(W2_p), _weight_t(W1_p), bfc1,
+    gx1, dyw, xhat, a1g, da1 = o.mlp_fused_bwd(x1, gy, g2, b2, LN_EPS, _mlp_w(W1_p, "MLP_W1_BWD"), _mlp_w(W2_p, "MLP_W2T_BWD"), _mlp_w(W1_p, "MLP_W1T_BWD"), bfc1,
                                                rowscale_mlp=dp_mlp, rowscale_out=dp_out)
     dW2, dbfc2 = _wgrad(dyb, a1g, W2_p, want_bias=True, bias_param=bfc2_p)
     del a1g
@@ -129,7 +133,7 @@ def _mlp_branch_bwd(o, x1, gy, dyb, g2, b2, W1, bfc1, params, dp_mlp, dp_out):
 # ------------------------------------------------------------------------------------------------
 # Swin block
 # ------------------------------------------------------------------------------------------------
-def _block_forward(x, geom, nH, index, dp, prm, wts, save):
+def _block_forward(x, geom, nH, index, dp, prm, wts, save, w1p=None):
     """x fp32 [nB, L, C].  prm: fp32 parameters; wts: activation-dtype weight copies.
     dp: None or (scale_attn [nB], scale_mlp [nB]) DropPath factors."""
     o = ops_module()
@@ -148,7 +152,7 @@ def _block_forward(x, geom, nH, index, dp, prm, wts, save):
     x1 = o.linear_fwd(ao, Wproj, bproj, residual=x2d, rowscale=dp1, rows_per_sample=L, out_f32=True)
     if (not save and o.mlp_fused_supported(W1.dtype, C)) or (save and _mlp_fused_train(W1, C)):
         rs2 = None if dp2 is None else dp2.repeat_interleave(L)  # (the fused kernels take per-row DropPath factors)
-        x2 = o.mlp_fused_fwd(x1, g2, b2, LN_EPS, W1, bfc1, W2, bfc2, rowscale=rs2)
+        x2 = o.mlp_fused_fwd(x1, g2, b2, LN_EPS, _mlp_w(w1p, "MLP_W1_FWD"), bfc1, W2, bfc2, rowscale=rs2)
         saved = (mean1, rstd1, xw, qkv, ao, x1, lse, frag) if save else None
         return x2.view(nB, L, C), saved
     else:
@@ -167,7 +171,7 @@ class SwinBlockFn(torch.autograd.Function):
     def forward(ctx, x, geom, nH, index, dp, g1, b1, table, Wqkv_p, bqkv, Wproj_p, bproj, g2, b2, W1_p, bfc1, W2_p, bfc2):
         wts = (_weight(Wqkv_p), _weight(Wproj_p), _weight(W1_p), _weight(W2_p))
         x = x.contiguous()
-        y, saved = _block_forward(x, geom, nH, index, dp, (g1, b1, table, bqkv, bproj, g2, b2, bfc1, bfc2), wts, True)
+        y, saved = _block_forward(x, geom, nH, index, dp, (g1, b1, table, bqkv, bproj, g2, b2, bfc1, bfc2), wts, True, W1_p)
         ctx.geom, ctx.nH, ctx.dp = geom, nH, dp
         ctx.wparams = (Wqkv_p, Wproj_p, W1_p, W2_p)
         ctx.mlp_params = (g2, b2, W1_p, bfc1, W2_p, bfc2)
@@ -222,7 +226,7 @@ class SwinBlockFn(torch.autograd.Function):
 # resolution group on its row range.  Compared with one pass per group (swin_transformer.py:729-751) this halves the GEMM /
 # LayerNorm launches, removes the gradient-accumulation adds of every parameter used by both passes, halves the split-K
 # partial traffic of the weight gradients and gives the small local-crop GEMMs of stages 2-3 full grids.
-def _block_forward_multi(X, segs, nH, dp_rows, prm, wts, save, pre=None, next_norm=None):
+def _block_forward_multi(X, segs, nH, dp_rows, prm, wts, save, pre=None, next_norm=None, w1p=None):
     """X fp32 [M, C]; segs: tuple of (row0, nB, L, geom); dp_rows: None or (per-row DropPath scale attn [M], mlp [M]).
     pre: (norm1(X) in the activation dtype, mean, rstd) when the previous block's fused MLP kernel already produced them;
     next_norm: (weight, bias) of the NEXT block's norm1 -- the fused MLP kernel then also emits that block's `pre`.
@@ -255,9 +259,9 @@ def _block_forward_multi(X, segs, nH, dp_rows, prm, wts, save, pre=None, next_no
         # training pass keeps x1 only: the backward recomputes)
         nxt = None
         if next_norm is not None:
-            x2, nxt = o.mlp_fused_fwd(x1, g2, b2, LN_EPS, W1, bfc1, W2, bfc2, rowscale=dp2, next_norm=(next_norm[0].detach(), next_norm[1].detach()))
+            x2, nxt = o.mlp_fused_fwd(x1, g2, b2, LN_EPS, _mlp_w(w1p, "MLP_W1_FWD"), bfc1, W2, bfc2, rowscale=dp2, next_norm=(next_norm[0].detach(), next_norm[1].detach()))
         else:
-            x2 = o.mlp_fused_fwd(x1, g2, b2, LN_EPS, W1, bfc1, W2, bfc2, rowscale=dp2)
+            x2 = o.mlp_fused_fwd(x1, g2, b2, LN_EPS, _mlp_w(w1p, "MLP_W1_FWD"), bfc1, W2, bfc2, rowscale=dp2)
         return x2, ((mean1, rstd1, xw, qkv, ao, x1) if save else None), lses, nxt
     else:
         h, _, mean2, rstd2 = o.layernorm_fwd(x1, g2, b2, LN_EPS)
@@ -287,7 +291,7 @@ class SwinBlockMultiFn(torch.autograd.Function):
         the saved statistics).  Third output: the next block's `pre` tuple flattened (xw, mean, rstd), or three None"""
         wts = (_weight(Wqkv_p), _weight(Wproj_p), _weight(W1_p), _weight(W2_p))
         X = X.contiguous()
-        y, saved, lses, nxt = _block_forward_multi(X, segs, nH, dp_rows, (g1, b1, table, bqkv, bproj, g2, b2, bfc1, bfc2), wts, True, pre, next_norm)
+        y, saved, lses, nxt = _block_forward_multi(X, segs, nH, dp_rows, (g1, b1, table, bqkv, bproj, g2, b2, bfc1, bfc2), wts, True, pre, next_norm, W1_p)
         ctx.segs, ctx.nH, ctx.dp_rows, ctx.lses = segs, nH, dp_rows, lses
         ctx.wparams = (Wqkv_p, Wproj_p, W1_p, W2_p)
         ctx.sparams = (g1, b1, table, bqkv, bproj, g2, b2, bfc1, bfc2)  # small parameters: their gradients go to bucket slots too
@@ -370,7 +374,7 @@ def swin_block_multi(X, segs, nH, index, dp_rows, prm_list, shadow=None, prev_sc
         return y, ysh, (None if xw is None else (xw, mean, rstd))
     g1, b1, table, Wqkv, bqkv, Wproj, bproj, g2, b2, W1, bfc1, W2, bfc2 = prm_list
     wts = (_weight(Wqkv), _weight(Wproj), _weight(W1), _weight(W2))
-    y, _, _, nxt = _block_forward_multi(X.contiguous(), segs, nH, dp_rows, (g1, b1, table, bqkv, bproj, g2, b2, bfc1, bfc2), wts, False, pre, next_norm)
+    y, _, _, nxt = _block_forward_multi(X.contiguous(), segs, nH, dp_rows, (g1, b1, table, bqkv, bproj, g2, b2, bfc1, bfc2), wts, False, pre, next_norm, W1)
     return y, None, nxt
 
 
@@ -380,7 +384,7 @@ def swin_block(x, geom, nH, index, dp, prm_list):
         return SwinBlockFn.apply(x, geom, nH, index, dp, *prm_list)
     g1, b1, table, Wqkv, bqkv, Wproj, bproj, g2, b2, W1, bfc1, W2, bfc2 = prm_list
     wts = (_weight(Wqkv), _weight(Wproj), _weight(W1), _weight(W2))
-    y, _ = _block_forward(x.contiguous(), geom, nH, index, dp, (g1, b1, table, bqkv, bproj, g2, b2, bfc1, bfc2), wts, False)
+    y, _ = _block_forward(x.contiguous(), geom, nH, index, dp, (g1, b1, table, bqkv, bproj, g2, b2, bfc1, bfc2), wts, False, W1)
     return y
 
 

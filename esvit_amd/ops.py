@@ -331,12 +331,26 @@ def mlp_fused_fwd(x, gamma, beta, eps, W1, b1, W2, b2, *, rowscale=None, next_no
     return y if next_norm is None else (y, (xw, mn, rn))
 
 
-def cast_transpose(w):
-    """fp32 [R, S] -> bf16 [S, R] (the transposed weight copies esvit_mlp_fused_bwd streams)"""
+def cast_weight(w, transpose=False, perm32=False):
+    """fp32 [R, S] -> bf16 ([S, R] if transpose), rows optionally in the 32-block channel order of the 16-token kernels"""
     w = _f32c(w)
     R, S = w.shape
-    out = torch.empty((S, R), dtype=torch.bfloat16, device=w.device)
-    check(lib.esvit_cast_transpose(_p(w), _p(out), R, S, _stream()), "cast_transpose")
+    out = torch.empty((S, R) if transpose else (R, S), dtype=torch.bfloat16, device=w.device)
+    check(lib.esvit_cast_weight(_p(w), _p(out), R, S, int(transpose), int(perm32), _stream()), "cast_weight")
+    return out
+
+
+MLP_W1_FWD, MLP_W1_BWD, MLP_W1T_BWD, MLP_W2T_BWD = range(4)  # ESVIT_MLP_* of include/esvit_hip.h
+
+
+def mlp_fused_weight(kind, w):
+    """the weight copy the fused MLP kernels stream, from the fp32 master: kind MLP_W1_FWD / MLP_W1_BWD (fc1.weight [4C, C] for
+    esvit_mlp_fused_fwd / _bwd), MLP_W1T_BWD (its transpose), MLP_W2T_BWD (the transpose of fc2.weight [C, 4C]).  fc2.weight itself
+    is used as the plain activation-dtype cast.  The channel order of a copy is private to the library."""
+    w = _f32c(w)
+    Cc = min(w.shape)
+    out = torch.empty((w.shape[1], w.shape[0]) if kind in (MLP_W1T_BWD, MLP_W2T_BWD) else tuple(w.shape), dtype=torch.bfloat16, device=w.device)
+    check(lib.esvit_mlp_fused_weight(int(kind), _p(w), _p(out), Cc, _stream()), "mlp_fused_weight")
     return out
 
 

@@ -139,7 +139,7 @@ int esvit_gemm_select(int dtype, const esvit_gemm_desc* d, int* tile_m, int* til
  *   so that block needs no LayerNorm launch.
  * esvit_mlp_fused_bwd: the data-gradient path of the branch in one kernel.  Inputs: x (the branch input), gy = dL/dy fp32,
  *   rowscale_mlp (the forward's rowscale), W1, and the transposed copies W2T = W2^T [4C, C], W1T = W1^T [C, 4C]
- *   (esvit_cast_transpose).  It recomputes LayerNorm(x) and the pre-activation, forms dA = (rowscale gy W2) o GELU'(A) and
+ *   (esvit_mlp_fused_weight).  It recomputes LayerNorm(x) and the pre-activation, forms dA = (rowscale gy W2) o GELU'(A) and
  *   dH = dA W1 with the hidden tile in registers, applies the LayerNorm backward and writes
  *     gx      fp32 [M, C]   dL/dx = gy + LN'(dH)                 gx_act  act [M, C]  cast(rowscale_out[row] * gx) (NULL scale = 1)
  *     xhat    act [M, C]    (x - mean) rstd                      a1g     act [M, 4C] GELU(A)          da1  act [M, 4C]  dA
@@ -147,7 +147,7 @@ int esvit_gemm_select(int dtype, const esvit_gemm_desc* d, int* tile_m, int* til
  * esvit_ln_fold_finish: LayerNorm folded out of a weight gradient.  With LN(x) = xhat o gamma + beta and G = dY^T xhat [J, C],
  *   db = colsum(dY) [J], W the fp32 master [J, C]:  dW = G o gamma + db (x) beta (written over G),
  *   dgamma[c] (+)= sum_j W[j, c] G[j, c],  dbeta[c] (+)= sum_j db[j] W[j, c]   (swin_transformer.py:331 autograd).
- * esvit_cast_transpose: dst (bf16 [S, R]) = cast(src (fp32 [R, S]))^T. */
+ */
 int esvit_mlp_fused_fwd(int dtype, const float* x, const float* gamma, const float* beta, float eps, const void* W1,
                         const float* b1, const void* W2, const float* b2, const float* rowscale, int64_t M, int C, float* y,
                         const float* gamma_next, const float* beta_next, void* xw_next, float* mean_next, float* rstd_next,
@@ -158,7 +158,18 @@ int esvit_mlp_fused_bwd(int dtype, const float* x, const float* gy, const float*
                         esvit_stream_t stream);
 int esvit_ln_fold_finish(float* G, const float* db, const float* W, const float* gamma, const float* beta, int J, int C,
                          float* dgamma, float* dbeta, int accumulate, esvit_stream_t stream);
-int esvit_cast_transpose(const float* src, void* dst_bf16, int R, int S, esvit_stream_t stream);
+/* The weight copies the fused kernels stream, produced from the fp32 masters (fc1.weight [4C, C], fc2.weight [C, 4C]); fc2.weight
+ * itself is consumed as its plain activation-dtype cast.  esvit_mlp_fused_fwd takes W1 = ESVIT_MLP_W1_FWD; esvit_mlp_fused_bwd
+ * takes W1 = ESVIT_MLP_W1_BWD, W2T = ESVIT_MLP_W2T_BWD, W1T = ESVIT_MLP_W1T_BWD (the channel order of a copy follows the kernel
+ * generation that consumes it and is private to the library). */
+#define ESVIT_MLP_W1_FWD 0
+#define ESVIT_MLP_W1_BWD 1
+#define ESVIT_MLP_W1T_BWD 2
+#define ESVIT_MLP_W2T_BWD 3
+int esvit_mlp_fused_weight(int kind, const float* src, void* dst_bf16, int C, esvit_stream_t stream);
+/* dst (bf16) = cast(src fp32 [R, S]), transposed to [S, R] if `transpose`, and with perm32 != 0 every aligned 32-block of a dst row
+ * reordered so that position 8g + e holds column 4g + e (e < 4) / 16 + 4g + (e - 4): the channel order of the 16-token kernels. */
+int esvit_cast_weight(const float* src, void* dst_bf16, int R, int S, int transpose, int perm32, esvit_stream_t stream);
 
 /* ---- normalisation ----------------------------------------------------- */
 /* LayerNorm forward over rows of C channels (swin_transformer.py:283,331,417,546,687;

@@ -199,6 +199,14 @@ def cast_transpose(w):
     return _r(w.float().t().contiguous(), torch.bfloat16 if _ACT_DTYPE == torch.bfloat16 else torch.float32)
 
 
+MLP_W1_FWD, MLP_W1_BWD, MLP_W1T_BWD, MLP_W2T_BWD = range(4)
+
+
+def mlp_fused_weight(kind, w):
+    """(the restatement keeps the natural channel order)"""
+    return _r(w.float()) if kind in (MLP_W1_FWD, MLP_W1_BWD) else cast_transpose(w)
+
+
 def mlp_fused_bwd(x, gy, gamma, beta, eps, W1, W2T, W1T, b1, *, rowscale_mlp=None, rowscale_out=None):
     """restatement of esvit_mlp_fused_bwd (same rounding points: LN(x), GELU(A), dA and the scaled dy are rounded to the
     activation dtype where the kernel feeds them to an MFMA or stores them)"""

@@ -172,15 +172,16 @@ def test_mlp_fused_fwd(mods, C, M):
     assert ops.mlp_fused_supported(dt, C) and not ops.mlp_fused_supported(dt, 384) and not ops.mlp_fused_supported(torch.float32, C)
     x = _rand((M, C), dev, 60) * 1.5 + 0.3
     g, b = 1.0 + 0.2 * _rand((C,), dev, 61), 0.1 * _rand((C,), dev, 62)
-    W1, b1 = _rand((4 * C, C), dev, 63, dt, 0.08), 0.1 * _rand((4 * C,), dev, 64)
+    W1f, b1 = _rand((4 * C, C), dev, 63, torch.float32, 0.08), 0.1 * _rand((4 * C,), dev, 64)
     W2, b2 = _rand((C, 4 * C), dev, 65, dt, 0.05), 0.1 * _rand((C,), dev, 66)
+    W1, W1k = W1f.to(dt), ops.mlp_fused_weight(ops.MLP_W1_FWD, W1f)  # natural cast (restatement) / the kernels' own format
     for rs in (None, (torch.rand(M, generator=torch.Generator().manual_seed(67)) > 0.3).float().div(0.7).to(dev)):
-        got = ops.mlp_fused_fwd(x, g, b, 1e-6, W1, b1, W2, b2, rowscale=rs)
+        got = ops.mlp_fused_fwd(x, g, b, 1e-6, W1k, b1, W2, b2, rowscale=rs)
         want = ref.mlp_fused_fwd(x, g, b, 1e-6, W1, b1, W2, b2, rowscale=rs)
         _close("mlp y", got, want, 4e-3)  # fp32 output; the hidden activation is rounded to bf16 on both sides
         # second output: LayerNorm(y) with the next block's norm1 parameters + its row statistics
         gn, bn = 1.0 + 0.3 * _rand((C,), dev, 68), 0.2 * _rand((C,), dev, 69)
-        got2, (xw, mean, rstd) = ops.mlp_fused_fwd(x, g, b, 1e-6, W1, b1, W2, b2, rowscale=rs, next_norm=(gn, bn))
+        got2, (xw, mean, rstd) = ops.mlp_fused_fwd(x, g, b, 1e-6, W1k, b1, W2, b2, rowscale=rs, next_norm=(gn, bn))
         assert torch.equal(got2, got)
         xw_r, _, mean_r, rstd_r = ref.layernorm_fwd(got, gn, bn, 1e-6, dtype=dt)  # (statistics of the kernel's own y)
         _close("next-norm xw", xw, xw_r, 8e-3)
@@ -202,16 +203,21 @@ def test_mlp_fused_bwd(mods, C, M):
     W1f, b1 = _rand((4 * C, C), dev, 74, torch.float32, 0.08), 0.1 * _rand((4 * C,), dev, 75)
     W2f = _rand((C, 4 * C), dev, 76, torch.float32, 0.05)
     W1, W2 = W1f.to(dt), W2f.to(dt)
-    W1T, W2T = ops.cast_transpose(W1f), ops.cast_transpose(W2f)
-    assert torch.equal(W1T, W1.t().contiguous()) and torch.equal(W2T, W2.t().contiguous())
+    W1T, W2T = W1.t().contiguous(), W2.t().contiguous()
+    # esvit_cast_weight: transpose and / or the 32-block channel order of the 16-token kernels
+    perm = torch.tensor([32 * (p >> 5) + (4 * ((p >> 3) & 3) + (p & 7) if (p & 7) < 4 else 16 + 4 * ((p >> 3) & 3) + (p & 7) - 4) for p in range(C)], device=dev)
+    assert torch.equal(ops.cast_weight(W1f), W1) and torch.equal(ops.cast_weight(W1f, transpose=True), W1T)
+    assert torch.equal(ops.cast_weight(W1f, perm32=True), W1[:, perm]) and torch.equal(ops.cast_weight(W2f, transpose=True, perm32=True), W2T[:, perm])
+    K1, K2T, K1T = (ops.mlp_fused_weight(k, w) for k, w in ((ops.MLP_W1_BWD, W1f), (ops.MLP_W2T_BWD, W2f), (ops.MLP_W1T_BWD, W1f)))  # the kernels' own format
+    assert torch.equal(K1, W1[:, perm]) and torch.equal(K2T, W2T[:, perm]) and torch.equal(K1T, W1T)
     gen = torch.Generator().manual_seed(77)
     for rs_mlp, rs_out in ((None, None), ((torch.rand(M, generator=gen) > 0.3).float().div(0.7).to(dev), (torch.rand(M, generator=gen) > 0.2).float().div(0.8).to(dev))):
-        got = ops.mlp_fused_bwd(x, gy, g, b, 1e-6, W1, W2T, W1T, b1, rowscale_mlp=rs_mlp, rowscale_out=rs_out)
+        got = ops.mlp_fused_bwd(x, gy, g, b, 1e-6, K1, K2T, K1T, b1, rowscale_mlp=rs_mlp, rowscale_out=rs_out)
         want = ref.mlp_fused_bwd(x, gy, g, b, 1e-6, W1, W2T, W1T, b1, rowscale_mlp=rs_mlp, rowscale_out=rs_out)
         for name, a, r, tol in zip(("gx", "gx_act", "xhat", "a1g", "da1"), got, want, (6e-3, 1e-2, 8e-3, 8e-3, 1.2e-2)):
             _close("mlp bwd " + name, a, r, tol)
     # the whole branch against autograd (fp32 formula on the same bf16-rounded weights)
-    gx, gxa, xhat, a1g, da1 = ops.mlp_fused_bwd(x, gy, g, b, 1e-6, W1, W2T, W1T, b1)
+    gx, gxa, xhat, a1g, da1 = ops.mlp_fused_bwd(x, gy, g, b, 1e-6, K1, K2T, K1T, b1)
     dyb = gy.to(dt)
     dW2, db2 = ops.linear_wgrad(dyb, a1g, want_bias=True)
     G, db1 = ops.linear_wgrad(da1, xhat, want_bias=True)

@@ -35,7 +35,8 @@ def main():
         W1f, b1 = torch.randn(4 * C, C, device=dev) * 0.05, torch.zeros(4 * C, device=dev)
         W2f, b2 = torch.randn(C, 4 * C, device=dev) * 0.05, torch.zeros(C, device=dev)
         W1, W2 = W1f.to(dt), W2f.to(dt)
-        W1T, W2T = ops.cast_transpose(W1f), ops.cast_transpose(W2f)
+        K1f = ops.mlp_fused_weight(ops.MLP_W1_FWD, W1f)
+        K1, W2T, W1T = ops.mlp_fused_weight(ops.MLP_W1_BWD, W1f), ops.mlp_fused_weight(ops.MLP_W2T_BWD, W2f), ops.mlp_fused_weight(ops.MLP_W1T_BWD, W1f)
         dyb = gy.to(dt)
 
         def unf_fwd():
@@ -52,16 +53,16 @@ def main():
             return ops.layernorm_bwd_cast(dh, x, mean, rstd, g, g_in=gy)
 
         def fus_bwd_kernel():
-            return ops.mlp_fused_bwd(x, gy, g, b, 1e-6, W1, W2T, W1T, b1)
+            return ops.mlp_fused_bwd(x, gy, g, b, 1e-6, K1, W2T, W1T, b1)
 
         def fus_bwd():
-            gx, gxa, xhat, a1g_, da1_ = ops.mlp_fused_bwd(x, gy, g, b, 1e-6, W1, W2T, W1T, b1)
+            gx, gxa, xhat, a1g_, da1_ = ops.mlp_fused_bwd(x, gy, g, b, 1e-6, K1, W2T, W1T, b1)
             dW2, dbb = ops.linear_wgrad(dyb, a1g_, want_bias=True)
             G, dbb1 = ops.linear_wgrad(da1_, xhat, want_bias=True)
             return ops.ln_fold_finish(G, dbb1, W1f, g, b)
         res = dict(C=C, rows=M, who="student")
-        for name, fn in (("unfused_fwd", unf_fwd), ("fused_fwd", lambda: ops.mlp_fused_fwd(x, g, b, 1e-6, W1, b1, W2, b2)),
-                         ("fused_fwd_nextnorm", lambda: ops.mlp_fused_fwd(x, g, b, 1e-6, W1, b1, W2, b2, next_norm=(g, b))),
+        for name, fn in (("unfused_fwd", unf_fwd), ("fused_fwd", lambda: ops.mlp_fused_fwd(x, g, b, 1e-6, K1f, b1, W2, b2)),
+                         ("fused_fwd_nextnorm", lambda: ops.mlp_fused_fwd(x, g, b, 1e-6, K1f, b1, W2, b2, next_norm=(g, b))),
                          ("unfused_bwd", unf_bwd), ("fused_bwd_kernel", fus_bwd_kernel), ("fused_bwd_all", fus_bwd)):
             res[name + "_us"] = round(timeit(fn) * 1e6, 1)
         res["fwd_speedup"] = round(res["unfused_fwd_us"] / res["fused_fwd_us"], 2)
@@ -74,7 +75,8 @@ def main():
         for M, save, who in ((rows_t, False, "teacher"),):
             x = torch.randn(M, C, device=dev)
             g, b = torch.ones(C, device=dev), torch.zeros(C, device=dev)
-            W1, b1 = (torch.randn(4 * C, C, device=dev) * 0.05).to(dt), torch.zeros(4 * C, device=dev)
+            W1f, b1 = torch.randn(4 * C, C, device=dev) * 0.05, torch.zeros(4 * C, device=dev)
+            W1, K1 = W1f.to(dt), ops.mlp_fused_weight(ops.MLP_W1_FWD, W1f)
             W2, b2 = (torch.randn(C, 4 * C, device=dev) * 0.05).to(dt), torch.zeros(C, device=dev)
 
             def unfused():
@@ -85,8 +87,8 @@ def main():
                     a1g = ops.linear_fwd(h, W1, b1, gelu=True)
                 return ops.linear_fwd(a1g, W2, b2, residual=x, out_f32=True)
             tu = timeit(unfused)
-            tf = timeit(lambda: ops.mlp_fused_fwd(x, g, b, 1e-6, W1, b1, W2, b2))
-            yu, yf = unfused(), ops.mlp_fused_fwd(x, g, b, 1e-6, W1, b1, W2, b2)
+            tf = timeit(lambda: ops.mlp_fused_fwd(x, g, b, 1e-6, K1, b1, W2, b2))
+            yu, yf = unfused(), ops.mlp_fused_fwd(x, g, b, 1e-6, K1, b1, W2, b2)
             err = ((yu - yf).abs().max() / yu.abs().max()).item()
             byt = M * C * (26 if save else 8)
             print(json.dumps(dict(C=C, rows=M, who=who, unfused_us=round(tu * 1e6, 1), fused_us=round(tf * 1e6, 1), speedup=round(tu / tf, 2),
