@@ -273,6 +273,8 @@ def main():
     ap.add_argument("--single-stream", action="store_true", help="teacher forward on the main stream too (per-kernel profiles: no overlapped durations)")
     ap.add_argument("--augment", action="store_true", help="produce the crops INSIDE the timed step with the GPU crop producer (esvit_amd.data: "
                     "DataAugmentationDINO on decoded uint8 images resident in HBM) instead of feeding fixed crop tensors")
+    ap.add_argument("--grad-payload", default="fp32", choices=["fp32", "bf16"], help="wire format of the data-parallel gradient all-reduce "
+                    "(bf16: half the bytes per xGMI link; moments and parameters stay fp32)")
     ap.add_argument("--per-group", action="store_true", help="one backbone pass per resolution group (the reference's schedule) instead of the ragged multi-crop route")
     ap.add_argument("--gemm-table", default=None, help="write a per-shape GEMM time table to this file")
     ap.add_argument("--torch-eager", type=int, default=0, metavar="BATCH",
@@ -308,7 +310,8 @@ def main():
     if args.per_group:
         student.ragged_multi_crop = teacher.ragged_multi_crop = False
     torch.manual_seed(1000 + rank)  # ... but every rank draws its own stochastic-depth masks (and has its own crops)
-    trainer = EsvitTrainer(student, teacher, loss_fn, clip_grad=3.0, freeze_last_layer=1, teacher_stream=not args.single_stream)
+    trainer = EsvitTrainer(student, teacher, loss_fn, clip_grad=3.0, freeze_last_layer=1, teacher_stream=not args.single_stream,
+                           grad_payload=args.grad_payload)
     B = args.batch
     crops = [c.to(dev) for c in GU.make_crops(B, seed=1234 + rank)]
     # constants from the first post-warm-up iteration of the reference schedules

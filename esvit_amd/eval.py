@@ -78,3 +78,94 @@ def knn_classifier(train_features, train_labels, test_features, test_labels, k, 
         top5 += correct.narrow(1, 0, min(5, num_classes)).sum().item()
         total += bs
     return top1 * 100.0 / total, top5 * 100.0 / total
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# eval_linear.py: the linear probe on frozen features (eval_linear.py:244-325)
+# ------------------------------------------------------------------------------------------------------------------------
+class _ProbeLinearFn(torch.autograd.Function):
+    """y = x W^T + b on the library's fp32 MFMA GEMM (forward, data gradient is not needed -- the features are frozen --,
+    weight gradient with the bias gradient fused)"""
+
+    @staticmethod
+    def forward(ctx, x, W, b):
+        x = x.contiguous()
+        ctx.save_for_backward(x)
+        return ops.linear_fwd(x, W.detach().contiguous(), b.detach())
+
+    @staticmethod
+    def backward(ctx, gy):
+        (x,) = ctx.saved_tensors
+        dW, db = ops.linear_wgrad(gy.contiguous(), x, want_bias=True)
+        return None, dW, db
+
+
+class LinearClassifier(torch.nn.Module):
+    """eval_linear.py:307-321: one nn.Linear on the flattened frozen features, N(0, 0.01) weights, zero bias -- same module tree
+    (``linear.weight`` / ``linear.bias``), so the reference's probe checkpoints (checkpoint.pth.tar: "state_dict") load"""
+
+    def __init__(self, dim, num_labels=1000):
+        super().__init__()
+        self.linear = torch.nn.Linear(dim, num_labels)
+        self.linear.weight.data.normal_(mean=0.0, std=0.01)
+        self.linear.bias.data.zero_()
+
+    def forward(self, x):
+        x = x.view(x.size(0), -1)
+        if x.is_cuda and x.dtype == torch.float32 and x.shape[1] % 4 == 0:
+            return _ProbeLinearFn.apply(x, self.linear.weight, self.linear.bias)
+        return self.linear(x)  # (host tensors: the CPU tests of the loop logic)
+
+
+def accuracy(output, target, topk=(1,)):
+    """utils.py:559-566"""
+    maxk = max(topk)
+    _, pred = output.topk(maxk, 1, True, True)
+    correct = pred.t().eq(target.reshape(1, -1).expand_as(pred.t()))
+    return [correct[:k].reshape(-1).float().sum(0) * 100.0 / target.size(0) for k in topk]
+
+
+def _features(model, inp, n, avgpool, depths):
+    with torch.no_grad():
+        return model.forward_return_n_last_blocks(inp, n, avgpool, depths).float()
+
+
+def train_linear_epoch(model, linear_classifier, optimizer, loader, epoch, n, avgpool, depths):
+    """eval_linear.train (eval_linear.py:244-277): frozen backbone features (forward_return_n_last_blocks, HIP path) -> linear
+    classifier -> cross-entropy -> SGD step.  Returns the epoch means the reference logs ({"loss", "lr"}), rank-averaged."""
+    linear_classifier.train()
+    dev = next(linear_classifier.parameters()).device
+    loss_sum, lr_sum, count = torch.zeros((), device=dev), 0.0, 0
+    for inp, target in loader:
+        inp, target = inp.to(dev, non_blocking=True), target.to(dev, non_blocking=True)
+        output = linear_classifier(_features(model, inp, n, avgpool, depths))
+        loss = torch.nn.functional.cross_entropy(output, target)
+        optimizer.zero_grad()
+        loss.backward()
+        optimizer.step()
+        loss_sum += loss.detach()
+        lr_sum += optimizer.param_groups[0]["lr"]
+        count += 1
+    stats = torch.stack([loss_sum, torch.tensor(float(count), device=dev)])
+    if _dist_on():
+        dist.all_reduce(stats)
+    return {"loss": (stats[0] / stats[1].clamp(min=1)).item(), "lr": lr_sum / max(count, 1)}
+
+
+@torch.no_grad()
+def validate_network(val_loader, model, linear_classifier, n, avgpool, depths):
+    """eval_linear.validate_network (eval_linear.py:280-304) -> {"loss", "acc1", "acc5"}: loss averaged per batch, accuracies per
+    sample, as the reference's MetricLogger does"""
+    linear_classifier.eval()
+    dev = next(linear_classifier.parameters()).device
+    acc = torch.zeros(5, device=dev)  # sum of batch losses, batches, sum acc1 * bs, sum acc5 * bs, samples
+    for inp, target in val_loader:
+        inp, target = inp.to(dev, non_blocking=True), target.to(dev, non_blocking=True)
+        output = linear_classifier(_features(model, inp, n, avgpool, depths))
+        loss = torch.nn.functional.cross_entropy(output, target)
+        a1, a5 = accuracy(output, target, topk=(1, min(5, output.shape[1])))
+        bs = inp.shape[0]
+        acc += torch.stack([loss, torch.ones((), device=dev), a1 * bs, a5 * bs, torch.tensor(float(bs), device=dev)])
+    if _dist_on():
+        dist.all_reduce(acc)
+    return {"loss": (acc[0] / acc[1].clamp(min=1)).item(), "acc1": (acc[2] / acc[4].clamp(min=1)).item(), "acc5": (acc[3] / acc[4].clamp(min=1)).item()}

@@ -499,10 +499,12 @@ def gather_cast(src, rows, *, rowmap=None, tokens=0, rowscale=None, rows_per_sam
     return dst
 
 
-def cast_to_act(x, dtype=None):
+def cast_to_act(x, dtype=None, out=None):
     x = _f32c(x)
     dt = dtype or _ACT_DTYPE
-    out = torch.empty(x.shape, dtype=dt, device=x.device)
+    if out is None:
+        out = torch.empty(x.shape, dtype=dt, device=x.device)
+    assert out.dtype == dt and out.numel() == x.numel() and out.is_contiguous()
     check(lib.esvit_cast_f32_to(_code(dt), _p(x), _p(out), x.numel(), _stream()), "cast_f32_to")
     return out
 

@@ -344,6 +344,36 @@ def gen_knn(ns):
     print("knn golden:", out)
 
 
+def gen_linear_probe(ns):
+    """eval_linear.py's linear probe from the reference's own train / validate_network / LinearClassifier on its own nano Swin
+    backbone (forward_return_n_last_blocks): per-epoch train stats, validation stats and the classifier after two epochs"""
+    import torch.nn as nn
+    train, validate, LinearClassifier = RL.load_eval_linear()
+    c = GU.LINEAR_PROBE
+    model = build_nano(ns)
+    GU.fill_state_dict(model.state_dict(), 0)
+    model.eval()
+    depths = list(GU.NANO["depths"])
+    dims = [GU.NANO["embed_dim"] * 2 ** i for i in range(4) for _ in range(depths[i])]
+    clf = LinearClassifier(sum(dims[-c["n_last_blocks"]:]), c["num_labels"])
+    GU.linear_probe_init(clf)
+    opt = torch.optim.SGD(clf.parameters(), c["lr"], momentum=0.9, weight_decay=0)
+    tr, va = GU.linear_probe_data()
+    saved = (torch.Tensor.cuda, nn.Module.cuda, torch.cuda.synchronize, ns.utils.is_dist_avail_and_initialized)
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    torch.cuda.synchronize = lambda *a, **k: None
+    ns.utils.is_dist_avail_and_initialized = lambda: False
+    try:
+        stats = [train(model, clf, opt, tr, ep, c["n_last_blocks"], c["avgpool"], depths) for ep in range(2)]
+        val = validate(va, model, clf, c["n_last_blocks"], c["avgpool"], depths)
+    finally:
+        torch.Tensor.cuda, nn.Module.cuda, torch.cuda.synchronize, ns.utils.is_dist_avail_and_initialized = saved
+    out = {"train": stats, "val": val, "weight": clf.linear.weight.detach().clone(), "bias": clf.linear.bias.detach().clone(),
+           "keys": list(clf.state_dict().keys()), "dim": clf.linear.weight.shape[1]}
+    torch.save(out, os.path.join(OUT, "linear_probe.pt"))
+    print("linear_probe.pt:", stats, val)
+
+
 def gen_variants(ns):
     """SURVEY.md 8f-3 step variants, each from the reference's own code:
     bn_head -- DINOHead(use_bn=True) (vision_transformer.py:384-418) in train mode (batch statistics, running-stat update)
@@ -548,6 +578,8 @@ def main():
         gen_knn(ns)
     if not only or "variants" in only:
         gen_variants(ns)
+    if not only or "linear" in only:
+        gen_linear_probe(ns)
     if "full" in only:  # minutes of CPU time: regenerated on request only
         gen_full(ns)
     if "full_vit" in only:

@@ -118,6 +118,18 @@ def load_knn_classifier():
     return env["knn_classifier"]
 
 
+def load_eval_linear():
+    """the reference's linear-probe pieces -- train, validate_network, LinearClassifier (eval_linear.py:244-321) -- executed from
+    the source text (importing eval_linear drags in torchvision); their .cuda() calls are neutralised by the caller"""
+    ns = load()
+    src = open(os.path.join(REF_ROOT, "eval_linear.py")).read()
+    env = {"torch": torch, "nn": nn, "utils": ns.utils}
+    for node in ast.parse(src).body:
+        if isinstance(node, (ast.FunctionDef, ast.ClassDef)) and node.name in ("train", "validate_network", "LinearClassifier"):
+            exec(compile(ast.Module(body=[node], type_ignores=[]), os.path.join(REF_ROOT, "eval_linear.py"), "exec"), env)
+    return env["train"], env["validate_network"], env["LinearClassifier"]
+
+
 def ensure_single_process_group():
     if not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

@@ -39,7 +39,7 @@ def _models(kind, dev):
     return student, teacher, crops, ncrops
 
 
-def _steps(kind, dev, force, n_steps=3):
+def _steps(kind, dev, force, n_steps=3, payload="fp32"):
     """n trainer steps -> (student state, teacher state, losses, reducer enabled)"""
     import esvit_amd
     import esvit_amd.loss as L
@@ -55,7 +55,7 @@ def _steps(kind, dev, force, n_steps=3):
     torch.manual_seed(0)
     student, teacher, crops, ncrops = _models(kind, dev)
     loss_fn = L.DDINOLoss(GU.NANO_HEAD["out_dim"], ncrops, 0.04, 0.07, 5, 10).to(dev)
-    tr = EsvitTrainer(student, teacher, loss_fn, clip_grad=3.0, freeze_last_layer=0, teacher_stream=False)
+    tr = EsvitTrainer(student, teacher, loss_fn, clip_grad=3.0, freeze_last_layer=0, teacher_stream=False, grad_payload=payload)
     losses = [tr.step(crops(900 + i), 5e-4, 0.04, 0.996, epoch=1).item() for i in range(n_steps)]
     torch.cuda.synchronize()
     out = ({k: v.detach().clone() for k, v in student.state_dict().items()}, {k: v.detach().clone() for k, v in teacher.state_dict().items()},
@@ -73,6 +73,12 @@ def one_rank(dev):
         rel = max(((a[k].float() - b[k].float()).abs().max() / (a[k].float().abs().max() + 1e-12)).item()
                   for a, b in ((s0, s1), (t0, t1)) for k in a if a[k].numel())
         res[kind] = dict(bit_identical=bool(same), max_rel=rel, losses_equal=l0 == l1, reducer_off=not en0, reducer_on=bool(en1), buckets=nb)
+    # bf16 gradient payload: the same three steps with the buckets rounded to bf16 on the wire -- parameters within bf16 rounding of
+    # the gradients' effect (AdamW's normalised step is bounded by lr per element: compare against lr)
+    s0, t0, l0, _, _ = _steps("ragged", dev, force=False)
+    s2, t2, l2, en2, _ = _steps("ragged", dev, force=True, payload="bf16")
+    dmax = max((s0[k].float() - s2[k].float()).abs().max().item() for k in s0 if s0[k].numel())
+    res["ragged_bf16_payload"] = dict(reducer_on=bool(en2), max_abs_param_diff=dmax, loss_diff=max(abs(a - b) for a, b in zip(l0, l2)))
     return res
 
 

@@ -185,3 +185,21 @@ def record_parity(**kw):
                 fh.write(line + "\n")
     except OSError:
         pass
+
+
+# ---- linear probe (eval_linear.py) fixture: tests/golden/linear_probe.pt --------------------------------------------------------
+LINEAR_PROBE = dict(n_last_blocks=2, avgpool=False, num_labels=7, batches=3, batch=4, lr=0.05, crop=224, seed=2024)
+
+
+def linear_probe_data():
+    """-> (train batches, val batches) of (images, labels) for the linear-probe fixture"""
+    c = LINEAR_PROBE
+    g = torch.Generator().manual_seed(c["seed"])
+    mk = lambda: (torch.randn(c["batch"], 3, c["crop"], c["crop"], generator=g), torch.randint(0, c["num_labels"], (c["batch"],), generator=g))  # noqa: E731
+    return [mk() for _ in range(c["batches"])], [mk() for _ in range(2)]
+
+
+def linear_probe_init(clf, seed=5):
+    g = torch.Generator().manual_seed(seed)
+    clf.linear.weight.data.copy_(0.01 * torch.randn(clf.linear.weight.shape, generator=g))
+    clf.linear.bias.data.zero_()

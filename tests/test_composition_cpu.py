@@ -519,3 +519,36 @@ def test_fused_mlp_branch_host_logic_matches_reference_golden(cpu_ops, monkeypat
     out_rel, norm_rel, worst, worst_name = full_case_deltas(g, student, s_out)
     assert out_rel < 1e-4 and abs(loss.item() - g["loss"]) < 1e-4, (out_rel, loss.item(), g["loss"])
     assert norm_rel < 2e-3 and worst < 5e-3, (norm_rel, worst_name, worst)
+
+
+def check_linear_probe(dev="cpu", tol=2e-4):
+    """eval_linear.py's probe (train + validate_network + LinearClassifier) through esvit_amd.eval over our backbone's
+    forward_return_n_last_blocks vs the fixture produced by the reference's own functions on its own backbone"""
+    from esvit_amd import eval as E
+    g = torch.load(os.path.join(GOLD, "linear_probe.pt"), weights_only=False)
+    c = GU.LINEAR_PROBE
+    model = build_nano()
+    GU.fill_state_dict(model.state_dict(), 0)
+    model = model.to(dev).eval()
+    clf = E.LinearClassifier(g["dim"], c["num_labels"])
+    assert list(clf.state_dict().keys()) == g["keys"]
+    GU.linear_probe_init(clf)
+    clf = clf.to(dev)
+    opt = torch.optim.SGD(clf.parameters(), c["lr"], momentum=0.9, weight_decay=0)
+    tr, va = GU.linear_probe_data()
+    depths = list(GU.NANO["depths"])
+    stats = [E.train_linear_epoch(model, clf, opt, tr, ep, c["n_last_blocks"], c["avgpool"], depths) for ep in range(2)]
+    val = E.validate_network(va, model, clf, c["n_last_blocks"], c["avgpool"], depths)
+    for got, want in zip(stats, g["train"]):
+        assert abs(got["loss"] - want["loss"]) < tol * 10 and abs(got["lr"] - want["lr"]) < 1e-9, (got, want)
+    assert abs(val["loss"] - g["val"]["loss"]) < tol * 10 and val["acc1"] == pytest.approx(g["val"]["acc1"], abs=1e-3), (val, g["val"])
+    assert val["acc5"] == pytest.approx(g["val"]["acc5"], abs=1e-3)
+    assert (clf.linear.weight.detach().cpu() - g["weight"]).abs().max().item() < tol
+    assert (clf.linear.bias.detach().cpu() - g["bias"]).abs().max().item() < tol
+    # a probe checkpoint written by the reference's loop (eval_linear.py:232-238: "state_dict") loads
+    clf2 = E.LinearClassifier(g["dim"], c["num_labels"])
+    clf2.load_state_dict({"linear.weight": g["weight"], "linear.bias": g["bias"]})
+
+
+def test_linear_probe_host_logic_matches_reference_golden(cpu_ops):
+    check_linear_probe("cpu")

@@ -51,6 +51,35 @@ def _reducer_worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
+def _reducer_bf16_worker(rank, world, port, out):
+    """payload="bf16": the buckets travel as bf16 (half the bytes per link) and come back as the fp32 mean of the rounded values"""
+    _init(rank, world, port)
+    from esvit_amd.engine import GradBucketReducer
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(40, 300), torch.nn.GELU(), torch.nn.Linear(300, 300), torch.nn.Linear(300, 7))
+    red = GradBucketReducer(net, bucket_mb=0.2, payload="bf16")
+    assert red.enabled and len(red.buckets) >= 2 and all(w.dtype == torch.bfloat16 for w in red.wire)
+    g = torch.Generator().manual_seed(100)
+    xs = torch.randn(world, 16, 40, generator=g)
+    per_rank = []
+    for r in range(world):
+        net.zero_grad(set_to_none=True)
+        (net(xs[r]) ** 2).mean().backward()
+        per_rank.append({n: p.grad.clone() for n, p in net.named_parameters()})
+    net.zero_grad(set_to_none=True)
+    red.begin()
+    (net(xs[rank]) ** 2).mean().backward()
+    red.finish()
+    ok = True
+    for n, p in net.named_parameters():
+        want = sum(pr[n].bfloat16().float() for pr in per_rank) / world  # mean of the bf16-rounded per-rank gradients
+        ok = ok and p.grad.dtype == torch.float32 and torch.allclose(p.grad, want, rtol=1e-2, atol=1e-6)
+        exact = sum(pr[n] for pr in per_rank) / world
+        ok = ok and (p.grad - exact).norm() <= 8e-3 * exact.norm() + 1e-9
+    out[rank] = bool(ok)
+    dist.destroy_process_group()
+
+
 def _nano_step_worker(rank, world, port, out, ragged=True):
     """the whole nano step on two ranks through the product's host code (kernels replaced by their torch restatement):
     weight gradients are written straight into the reducer's bucket slots (params.grad_out), the rest is packed by the
@@ -324,7 +353,7 @@ def _extract_worker(rank, world, port, out):
 
 @pytest.mark.parametrize("worker,port", [(_reducer_worker, 29611), (_center_worker, 29612), (_syncbn_worker, 29613), (_extract_worker, 29614),
                                          (_nano_step_worker, 29615), (_nano_step_pergroup_worker, 29616), (_nano_vit_step_worker, 29617), (_nano_vit_step_pergroup_worker, 29618),
-                                         (_nano_view_step_worker, 29619), (_nano_view_step_noragged_worker, 29620)])
+                                         (_nano_view_step_worker, 29619), (_nano_view_step_noragged_worker, 29620), (_reducer_bf16_worker, 29621)])
 def test_world2_gloo(worker, port, lib_built):
     world = 2
     out = mp.Manager().dict()

@@ -357,6 +357,17 @@ def test_eval_knn_consumers_gpu(lib_built):
         _teardown()
 
 
+def test_eval_linear_probe_gpu(lib_built):
+    """SURVEY.md 8f-1, eval_linear.py on the HIP path: frozen-backbone features, the probe's linear layer on the fp32 MFMA GEMM
+    (forward + fused weight / bias gradient), SGD, validation -- against the fixture from the reference's own loop"""
+    from tests.test_composition_cpu import check_linear_probe
+    dev = _setup("fp32")
+    try:
+        check_linear_probe(dev, tol=3e-4)
+    finally:
+        _teardown()
+
+
 def test_train_one_epoch_drop_in_gpu(lib_built):
     """engine.train_one_epoch (the reference's signature, main_esvit.py:499-501) with the torch.optim.AdamW the unmodified
     train_esvit builds (main_esvit.py:408-411): two batches equal two EsvitTrainer.step calls; the caller's optimizer holds
