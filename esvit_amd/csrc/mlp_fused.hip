@@ -407,7 +407,11 @@ __global__ __launch_bounds__(1024) void ln_fold_finish_kernel(float* __restrict_
 
 }  // namespace
 
-int esvit_i_mlp_fused_supported(int dtype, int C) { return dtype == ESVIT_BF16 && (C == 96 || C == 192); }  // esvit_query
+// esvit_query(ESVIT_Q_MLP_FUSED): bit 0 = esvit_mlp_fused_fwd exists, bit 1 = esvit_mlp_fused_bwd exists
+int esvit_i_mlp_fused_supported(int dtype, int C) {
+    if (dtype != ESVIT_BF16) return 0;
+    return (C == 96 || C == 192) ? 3 : 0;
+}
 
 // second generation (mlp_fused16.hip)
 int esvit_i_mlp16_fwd(const float* x, const float* gamma, const float* beta, float eps, const void* W1p, const float* b1, const void* W2,
@@ -424,7 +428,7 @@ extern "C" int esvit_mlp_fused_fwd(int dtype, const float* x, const float* gamma
                                    float* y, const float* gamma_next, const float* beta_next, void* xw_next, float* mean_next,
                                    float* rstd_next, esvit_stream_t s_) {
     hipStream_t stream = reinterpret_cast<hipStream_t>(s_);
-    ESVIT_CHECK_ARG(esvit_i_mlp_fused_supported(dtype, C), "esvit_mlp_fused_fwd: bf16 activations and C in {96, 192} only (C=%d)", C);
+    ESVIT_CHECK_ARG(esvit_i_mlp_fused_supported(dtype, C) & 1, "esvit_mlp_fused_fwd: bf16 activations and C in {96, 192} only (C=%d)", C);
     ESVIT_CHECK_ARG(x && gamma && beta && W1 && b1 && W2 && b2 && y && M > 0, "esvit_mlp_fused_fwd: null pointer / empty input");
     ESVIT_CHECK_ARG(AL16(x) && AL16(y) && AL16(W1) && AL16(W2) && AL16(gamma) && AL16(beta) && AL16(b1) && AL16(b2),
                     "esvit_mlp_fused_fwd: operands must be 16-byte aligned");
@@ -443,7 +447,7 @@ extern "C" int esvit_mlp_fused_bwd(int dtype, const float* x, const float* gy, c
                                    const float* b1, int64_t M, int C, float* gx, void* gx_act, void* xhat, void* a1g, void* da1,
                                    esvit_stream_t s_) {
     hipStream_t stream = reinterpret_cast<hipStream_t>(s_);
-    ESVIT_CHECK_ARG(esvit_i_mlp_fused_supported(dtype, C), "esvit_mlp_fused_bwd: bf16 activations and C in {96, 192} only (C=%d)", C);
+    ESVIT_CHECK_ARG(esvit_i_mlp_fused_supported(dtype, C) & 2, "esvit_mlp_fused_bwd: bf16 activations and C in {96, 192} only (C=%d)", C);
     ESVIT_CHECK_ARG(x && gy && gamma && beta && W1 && W2T && W1T && b1 && gx && gx_act && xhat && a1g && da1 && M > 0,
                     "esvit_mlp_fused_bwd: null pointer / empty input");
     ESVIT_CHECK_ARG(AL16(x) && AL16(gy) && AL16(gx) && AL16(gx_act) && AL16(xhat) && AL16(a1g) && AL16(da1) && AL16(W1) && AL16(W2T) &&

@@ -112,7 +112,7 @@ MLP_FUSED_TRAIN = os.environ.get("ESVIT_MLP_FUSED_TRAIN", "1") != "0"  # (A-B ru
 
 
 def _mlp_fused_train(W1, C):
-    return MLP_FUSED_TRAIN and ops_module().mlp_fused_supported(W1.dtype, C)
+    return MLP_FUSED_TRAIN and ops_module().mlp_fused_supported(W1.dtype, C, backward=True)
 
 
 def _mlp_branch_bwd(o, x1, gy, dyb, g2, b2, W1, bfc1, params, dp_mlp, dp_out):

@@ -308,8 +308,9 @@ def colsum(x, *, out=None, accumulate=False):
 # ------------------------------------------------------------------------------------------------
 # fused MLP forward
 # ------------------------------------------------------------------------------------------------
-def mlp_fused_supported(dt, Cc):
-    return bool(query(Q_MLP_FUSED, _code(dt), int(Cc)))
+def mlp_fused_supported(dt, Cc, backward=False):
+    """the fused MLP forward exists for this width (inference passes); backward=True: the training pair exists"""
+    return bool(query(Q_MLP_FUSED, _code(dt), int(Cc)) & (2 if backward else 1))
 
 
 def mlp_fused_fwd(x, gamma, beta, eps, W1, b1, W2, b2, *, rowscale=None, next_norm=None):

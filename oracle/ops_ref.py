@@ -180,7 +180,7 @@ def colsum(x, *, out=None, accumulate=False):
 
 
 # ---- normalisation ---------------------------------------------------------------------------
-def mlp_fused_supported(dt, Cc):
+def mlp_fused_supported(dt, Cc, backward=False):
     return dt == torch.bfloat16 and Cc in (96, 192)
 
 

@@ -507,7 +507,7 @@ def test_fused_mlp_branch_host_logic_matches_reference_golden(cpu_ops, monkeypat
     (stages 0 / 1 take the fused branch) reproduces the reference's own step -- loss, every gradient norm, sampled gradients"""
     import esvit_amd.functional as Fn
     from tests.test_step_gpu import FULL_GOLD, full_case_deltas, run_full_case
-    monkeypatch.setattr(ops_ref, "mlp_fused_supported", lambda dt, C: C in (96, 192))
+    monkeypatch.setattr(ops_ref, "mlp_fused_supported", lambda dt, C, backward=False: C in (96, 192))
     calls = {"fwd": 0, "bwd": 0}
     f0, b0 = ops_ref.mlp_fused_fwd, ops_ref.mlp_fused_bwd
     monkeypatch.setattr(ops_ref, "mlp_fused_fwd", lambda *a, **k: (calls.__setitem__("fwd", calls["fwd"] + 1), f0(*a, **k))[1])

@@ -170,6 +170,7 @@ def test_mlp_fused_fwd(mods, C, M):
     dev = _dev()
     dt = torch.bfloat16
     assert ops.mlp_fused_supported(dt, C) and not ops.mlp_fused_supported(dt, 384) and not ops.mlp_fused_supported(torch.float32, C)
+    assert ops.mlp_fused_supported(dt, C, backward=True)
     x = _rand((M, C), dev, 60) * 1.5 + 0.3
     g, b = 1.0 + 0.2 * _rand((C,), dev, 61), 0.1 * _rand((C,), dev, 62)
     W1f, b1 = _rand((4 * C, C), dev, 63, torch.float32, 0.08), 0.1 * _rand((4 * C,), dev, 64)
