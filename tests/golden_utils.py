@@ -188,7 +188,7 @@ def record_parity(**kw):
 
 
 # ---- linear probe (eval_linear.py) fixture: tests/golden/linear_probe.pt --------------------------------------------------------
-LINEAR_PROBE = dict(n_last_blocks=2, avgpool=False, num_labels=7, batches=3, batch=4, lr=0.05, crop=224, seed=2024)
+LINEAR_PROBE = dict(n_last_blocks=2, avgpool=False, num_labels=12, batches=3, batch=4, lr=0.05, crop=224, seed=2024)
 
 
 def linear_probe_data():

@@ -102,12 +102,12 @@ def test_config1_swin_tiny_bs4_matches_reference_golden(prec, lib_built):
         _record(test="config1_swin_tiny_bs4", prec=prec, loss=loss.item(), ref=g["loss"], abs_err=abs(loss.item() - g["loss"]),
                 logits_rel=out_rel, teacher_logits_rel=t_rel, center_abs=c_err, worst_grad_norm_rel=norm_rel, worst_sampled_grad_rel_l2=worst,
                 worst_tensor=worst_name)
-        # bf16 bounds: <= 3x the deltas observed on MI355X (profiles/r03_parity_observed.jsonl; round 2: loss 3.1e-5, logits 6.3e-3,
-        # gradient norms 5.9e-3, sampled gradient tensors 2.3e-2 relative L2)
-        assert out_rel < (1e-4 if fp else 2e-2) and t_rel < (1e-4 if fp else 2e-2), (out_rel, t_rel)
-        assert abs(loss.item() - g["loss"]) < (1e-4 if fp else 1e-4), (loss.item(), g["loss"])
-        assert c_err < (1e-6 if fp else 2e-3)
-        assert norm_rel < (5e-3 if fp else 1.8e-2), norm_rel
+        # bf16 bounds: <= 3x the deltas observed on MI355X (profiles/r03_parity_observed.jsonl: loss 8.9e-5, logits 6.9e-3 / 8.5e-3,
+        # centre 1.5e-4, gradient norms 6.9e-3, sampled gradient tensors 2.2e-2 relative L2)
+        assert out_rel < (1e-4 if fp else 2e-2) and t_rel < (1e-4 if fp else 2.5e-2), (out_rel, t_rel)
+        assert abs(loss.item() - g["loss"]) < (1e-4 if fp else 2.7e-4), (loss.item(), g["loss"])
+        assert c_err < (1e-6 if fp else 4.5e-4)
+        assert norm_rel < (5e-3 if fp else 2e-2), norm_rel
         assert worst < (5e-3 if fp else 7e-2), (worst_name, worst)
     finally:
         _teardown()
@@ -255,10 +255,10 @@ def test_swin_tiny_k65536_b8_step_matches_reference_golden(lib_built):
         out_rel, norm_rel, worst, worst_name = full_case_deltas(g, student, s_out)
         _record(test="swin_tiny_k65536_b8", loss_hip_bf16=loss.item(), loss_reference_fp32=g["loss"], abs_err=abs(loss.item() - g["loss"]),
                 outputs_rel=out_rel, worst_grad_norm_rel=norm_rel, worst_sampled_grad_rel_l2=worst, worst_tensor=worst_name)
-        # <= 3x observed (round 2: loss 5.1e-5, outputs 8.5e-3, gradient norms 9.2e-3, sampled gradient tensors 5.6e-2)
-        assert abs(loss.item() - g["loss"]) < 1.5e-4, (loss.item(), g["loss"])
-        assert out_rel < 2.6e-2, out_rel
-        assert norm_rel < 2.8e-2, norm_rel
+        # <= 3x observed (round 3: loss 5.8e-5, outputs 8.2e-3, gradient norms 1.0e-2, sampled gradient tensors 5.2e-2)
+        assert abs(loss.item() - g["loss"]) < 1.7e-4, (loss.item(), g["loss"])
+        assert out_rel < 2.5e-2, out_rel
+        assert norm_rel < 3e-2, norm_rel
         assert worst < 0.1, (worst_name, worst)
         assert (loss_fn.center.cpu() - g["center"]).abs().max().item() < 2e-3
     finally:

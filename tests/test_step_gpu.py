@@ -268,12 +268,13 @@ def test_swin_tiny_step_matches_reference_golden(prec, lib_built):
         assert list(s_out[3]) == g["npatch"]
         GU.record_parity(test="swin_tiny_k8192_b2", prec=prec, loss=loss.item(), ref=g["loss"], abs_err=abs(loss.item() - g["loss"]),
                          outputs_rel=out_rel, worst_grad_norm_rel=norm_rel, worst_sampled_grad_rel_l2=worst, worst_tensor=worst_name)
-        assert out_rel < (1e-4 if fp else 5e-2), out_rel
-        assert abs(loss.item() - g["loss"]) < (1e-4 if fp else 1e-2), (loss.item(), g["loss"])
-        assert norm_rel < (5e-3 if fp else 0.2), norm_rel
-        assert worst < (5e-3 if fp else 0.25), (worst_name, worst)
-        assert (loss_fn.center.cpu() - g["center"]).abs().max().item() < (1e-6 if fp else 2e-3)
-        assert (loss_fn.center_grid.cpu() - g["center_grid"]).abs().max().item() < (1e-6 if fp else 2e-3)
+        # bf16: <= 3x observed (profiles/r03_parity_observed.jsonl: outputs 8.1e-3, loss 2.8e-4, gradient norms 1.3e-2, sampled 7.6e-2)
+        assert out_rel < (1e-4 if fp else 2.5e-2), out_rel
+        assert abs(loss.item() - g["loss"]) < (1e-4 if fp else 8.4e-4), (loss.item(), g["loss"])
+        assert norm_rel < (5e-3 if fp else 3.9e-2), norm_rel
+        assert worst < (5e-3 if fp else 0.23), (worst_name, worst)
+        assert (loss_fn.center.cpu() - g["center"]).abs().max().item() < (1e-6 if fp else 6e-4)
+        assert (loss_fn.center_grid.cpu() - g["center_grid"]).abs().max().item() < (1e-6 if fp else 6e-4)
     finally:
         _teardown()
 
