@@ -32,6 +32,7 @@ class GemmDesc(C.Structure):
         ("partial", vp), ("accumulate", i32), ("alpha", f32),
         ("colsum", vp), ("colsum_partial", vp),
         ("kernel", i32),
+        ("rowstat", vp), ("rowstat_center", vp), ("rowstat_scale", f32),
     ]
 
 
@@ -87,7 +88,8 @@ SIGNATURES = {
     "esvit_softmax_rows_bwd": (C.c_int, [C.c_int, vp, vp, i64, C.c_int, C.c_int, f32, vp]),
     "esvit_teacher_row_stats": (C.c_int, [C.c_int, vp, vp, f32, i64, C.c_int, vp, vp, vp]),
     "esvit_region_match": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]),
-    "esvit_dino_ce_fwd_bwd": (C.c_int, [C.c_int, vp, vp, vp, vp, vp, vp, vp, C.c_int, vp, f32, f32, i64, C.c_int, vp, vp, vp, vp]),
+    "esvit_dino_ce_fwd_bwd": (C.c_int, [C.c_int, vp, vp, vp, vp, vp, vp, vp, C.c_int, vp, f32, f32, i64, C.c_int, vp, vp, vp, vp, vp, vp]),
+    "esvit_rowstat_combine": (C.c_int, [vp, i64, C.c_int, vp, vp, vp]),
     "esvit_sum_f32": (C.c_int, [vp, i64, vp, vp]),
     "esvit_scale_inplace": (C.c_int, [C.c_int, vp, i64, vp, vp]),
     "esvit_center_ema": (C.c_int, [vp, vp, f32, f32, C.c_int, vp]),

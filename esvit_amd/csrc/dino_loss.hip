@@ -80,12 +80,41 @@ __global__ __launch_bounds__(NT) void teacher_stats_kernel(const T* __restrict__
     }
 }
 
+// Fold the per-64-column (max, sum 2^(z - max)) pairs the last-layer GEMM left behind (esvit_gemm_desc::rowstat, base 2) into the
+// natural-log statistics of teacher_stats_kernel: one wave per row, row_max = M / log2(e), row_lse = ln(sum).
+__global__ __launch_bounds__(NT) void rowstat_combine_kernel(const float* __restrict__ st, long R, int nb, float* __restrict__ row_max,
+                                                             float* __restrict__ row_lse) {
+    const long r = (long)blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
+    if (r >= R) return;
+    const int l = threadIdx.x & 63;
+    const f32x2* p = reinterpret_cast<const f32x2*>(st) + r * nb;
+    float m = -3.0e38f, sum = 0.f;
+    for (int j = l; j < nb; j += 64) {
+        const f32x2 v = p[j];
+        const float mm = fmaxf(m, v[0]);
+        sum = sum * __builtin_amdgcn_exp2f(m - mm) + v[1] * __builtin_amdgcn_exp2f(v[0] - mm);
+        m = mm;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float m2 = __shfl_xor(m, o, 64), s2 = __shfl_xor(sum, o, 64);
+        const float mm = fmaxf(m, m2);
+        sum = sum * __builtin_amdgcn_exp2f(m - mm) + s2 * __builtin_amdgcn_exp2f(m2 - mm);
+        m = mm;
+    }
+    if (l == 0) {
+        row_max[r] = m * 0.6931471805599453f;
+        row_lse[r] = __logf(sum);
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(NT) void dino_ce_kernel(const T* __restrict__ s, const T* __restrict__ t,
                                                      const float* __restrict__ center, const float* __restrict__ t_row_max,
                                                      const float* __restrict__ t_row_lse, const int* __restrict__ tmatch,
                                                      const float* __restrict__ row_w, float inv_st, float inv_tt, int K,
-                                                     float* __restrict__ row_loss, T* __restrict__ ds, const int* __restrict__ row_order) {
+                                                     float* __restrict__ row_loss, T* __restrict__ ds, const int* __restrict__ row_order,
+                                                     const float* __restrict__ s_row_max, const float* __restrict__ s_row_lse) {
     __shared__ float sm[2 * NT / 64];
     __shared__ float sm2[NT / 64];
     constexpr int V = Vec16<T>::N;
@@ -105,21 +134,27 @@ __global__ __launch_bounds__(NT) void dino_ce_kernel(const T* __restrict__ s, co
     constexpr float LOG2E = 1.4426950408889634f;
     const float A = inv_st * LOG2E;
 
-    // pass 1: log-sum-exp of z = s * inv_st (the maximum is taken on the raw logits: inv_st > 0)
-    MS a{-3.0e38f, 0.f};
-    for (int k = threadIdx.x * V; k < K; k += NT * V) {
-        const Vec16<T> x = ld16<T>(srow + k);
-        float mr = -3.0e38f;
+    // pass 1: log-sum-exp of z = s * inv_st (the maximum is taken on the raw logits: inv_st > 0) -- unless the GEMM that wrote the
+    // logits already produced it (s_row_max + s_row_lse, esvit_rowstat_combine)
+    float lse;
+    if (s_row_max) {
+        lse = s_row_max[r] + s_row_lse[r];
+    } else {
+        MS a{-3.0e38f, 0.f};
+        for (int k = threadIdx.x * V; k < K; k += NT * V) {
+            const Vec16<T> x = ld16<T>(srow + k);
+            float mr = -3.0e38f;
 #pragma unroll
-        for (int e = 0; e < V; ++e) mr = fmaxf(mr, x.get(e));
-        const float nb = -mr * A;
-        float sum = 0.f;
+            for (int e = 0; e < V; ++e) mr = fmaxf(mr, x.get(e));
+            const float nb = -mr * A;
+            float sum = 0.f;
 #pragma unroll
-        for (int e = 0; e < V; ++e) sum += __builtin_amdgcn_exp2f(fmaf(x.get(e), A, nb));
-        a = ms_merge(a, MS{mr * inv_st, sum});
+            for (int e = 0; e < V; ++e) sum += __builtin_amdgcn_exp2f(fmaf(x.get(e), A, nb));
+            a = ms_merge(a, MS{mr * inv_st, sum});
+        }
+        a = block_ms(a, sm);
+        lse = a.m + __logf(a.s);
     }
-    a = block_ms(a, sm);
-    const float lse = a.m + __logf(a.s);
 
     // pass 2: gradient + sum_k p_t[k] z[k].  An unused term gets offset +inf: exp2(-inf) = 0, no select per element.
     const T* trow0 = t + (long)(t0 >= 0 ? t0 : 0) * K;
@@ -267,11 +302,22 @@ extern "C" int esvit_teacher_row_stats(int dtype, const void* t, const float* ce
     return ESVIT_OK;
 }
 
+extern "C" int esvit_rowstat_combine(const float* rowstat, int64_t R, int nblocks, float* row_max, float* row_lse, esvit_stream_t s_) {
+    STREAM(s_);
+    ESVIT_CHECK_ARG(rowstat && row_max && row_lse && R > 0 && nblocks > 0, "esvit_rowstat_combine: bad args");
+    hipLaunchKernelGGL(rowstat_combine_kernel, dim3((unsigned)ceil_div(R, (long)(NT / 64))), dim3(NT), 0, stream, rowstat, (long)R, nblocks,
+                       row_max, row_lse);
+    ESVIT_CHECK_LAUNCH("rowstat_combine");
+    return ESVIT_OK;
+}
+
 extern "C" int esvit_dino_ce_fwd_bwd(int dtype, const void* s, const void* t, const float* center, const float* t_row_max,
                                      const float* t_row_lse, const int32_t* tmatch, const float* row_w, int terms, const float* term_w,
                                      float inv_student_temp, float inv_teacher_temp, int64_t Rs, int K, float* row_loss, void* ds,
-                                     const int32_t* row_order, esvit_stream_t s_) {
+                                     const int32_t* row_order, const float* s_row_max, const float* s_row_lse, esvit_stream_t s_) {
     STREAM(s_);
+    ESVIT_CHECK_ARG((s_row_max == nullptr) == (s_row_lse == nullptr) && !(s_row_max && term_w),
+                    "esvit_dino_ce_fwd_bwd: student row statistics come as a (max, lse) pair, for the two-term form");
     ESVIT_CHECK_ARG(s && t && center && t_row_max && t_row_lse && tmatch && row_loss && ds && Rs > 0 && K > 0 && K % 8 == 0,
                     "esvit_dino_ce_fwd_bwd: bad args (K=%d)", K);
     ESVIT_CHECK_ARG(dtype == ESVIT_BF16 || dtype == ESVIT_F32, "esvit_dino_ce_fwd_bwd: bad dtype");
@@ -289,10 +335,12 @@ extern "C" int esvit_dino_ce_fwd_bwd(int dtype, const void* s, const void* t, co
     ESVIT_CHECK_ARG(row_w && terms == 2, "esvit_dino_ce_fwd_bwd: two equally weighted terms per row need row_w");
     if (dtype == ESVIT_BF16)
         hipLaunchKernelGGL(dino_ce_kernel<bf16>, dim3((unsigned)Rs), dim3(NT), 0, stream, (const bf16*)s, (const bf16*)t, center,
-                           t_row_max, t_row_lse, tmatch, row_w, inv_student_temp, inv_teacher_temp, K, row_loss, (bf16*)ds, row_order);
+                           t_row_max, t_row_lse, tmatch, row_w, inv_student_temp, inv_teacher_temp, K, row_loss, (bf16*)ds, row_order, s_row_max,
+                           s_row_lse);
     else
         hipLaunchKernelGGL(dino_ce_kernel<float>, dim3((unsigned)Rs), dim3(NT), 0, stream, (const float*)s, (const float*)t, center,
-                           t_row_max, t_row_lse, tmatch, row_w, inv_student_temp, inv_teacher_temp, K, row_loss, (float*)ds, row_order);
+                           t_row_max, t_row_lse, tmatch, row_w, inv_student_temp, inv_teacher_temp, K, row_loss, (float*)ds, row_order, s_row_max,
+                           s_row_lse);
     ESVIT_CHECK_LAUNCH("dino_ce_fwd_bwd");
     return ESVIT_OK;
 }

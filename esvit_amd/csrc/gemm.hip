@@ -46,6 +46,11 @@ GemmChoice choose(int dtype, const esvit_gemm_desc& d) {
         return c;
     }
     int want = d.kernel;
+    if (d.rowstat) {  // the statistics epilogue lives in the 128 x 128 tile (2 x 2 waves of 64 x 64)
+        c.kernel = ESVIT_GEMM_DMA4;
+        c.bm = c.bn = 128;
+        return c;
+    }
     if (want == ESVIT_GEMM_AUTO) {
         want = ESVIT_GEMM_DMA4;
         const int nz = d.splitk > 1 ? d.splitk : (d.batch > 1 ? d.batch : 1);
@@ -158,6 +163,15 @@ int validate(int dtype, esvit_gemm_desc& d) {
     ESVIT_CHECK_ARG(d.epilogue >= 0 && d.epilogue <= ESVIT_EPI_QGELU_BWD, "esvit_gemm: bad epilogue %d", d.epilogue);
     if (d.colsum && d.splitk > 1) ESVIT_CHECK_ARG(d.colsum_partial != nullptr, "esvit_gemm: colsum with split-K needs colsum_partial");
     if (d.colsum) ESVIT_CHECK_ARG(d.batch == 1, "esvit_gemm: colsum is not batched");
+    if (d.rowstat) {
+        ESVIT_CHECK_ARG(dtype == ESVIT_BF16 && !d.a_kstrided && !d.b_kstrided && d.batch == 1 && d.splitk <= 1 && !d.out_f32 && d.epilogue == 0 &&
+                            !d.residual && !d.rowmap && !d.rowscale && !d.bias && d.alpha == 1.f,
+                        "esvit_gemm: row statistics come with the plain bf16 forward epilogue only");
+        ESVIT_CHECK_ARG(d.M % 128 == 0 && d.N % 128 == 0 && d.ldc % 8 == 0 && ((uintptr_t)d.C % 16 == 0) &&
+                            (!d.rowstat_center || (uintptr_t)d.rowstat_center % 16 == 0),
+                        "esvit_gemm: row statistics need M and N in whole 128 x 128 tiles (M=%d N=%d)", d.M, d.N);
+        ESVIT_CHECK_ARG(d.kernel == ESVIT_GEMM_AUTO || d.kernel == ESVIT_GEMM_DMA4, "esvit_gemm: row statistics exist in the 128 x 128 tile of the default main loop");
+    }
     return check_selector(dtype, d);
 }
 

@@ -375,7 +375,7 @@ __device__ __forceinline__ void gemm_epilogue(const esvit_gemm_desc& p, f32x4 (&
 // requested one pass ahead never wait for the stores issued after them.
 enum { EK_PLAIN = 0, EK_GELU = 1, EK_RES = 2, EK_GELU_BWD = 3 };
 
-template <int BM, int BN, int WM, int WN, int KIND, bool OUTF32>
+template <int BM, int BN, int WM, int WN, int KIND, bool OUTF32, bool RS = false>
 __device__ __forceinline__ void epilogue_fast(const esvit_gemm_desc& p, f32x4 (&acc)[BM / (16 * WM)][BN / (16 * WN)], float* stage, int m0, int n0,
                                               void* Cbase, long ldc, long c_first, const float* bias) {
     constexpr int WTM = BM / WM, WTN = BN / WN;
@@ -402,6 +402,8 @@ __device__ __forceinline__ void epilogue_fast(const esvit_gemm_desc& p, f32x4 (&
     long c_off[ITEMS], x_off[ITEMS];  // element offsets into C and into aux / residual for pass 0
     bool live[ITEMS];
     float bias_h[ITEMS][8];
+    float cen_h[RS ? ITEMS : 1][8];  // softmax statistics (RS): the centre of this item's eight columns
+    static_assert(!RS || (CG == 8 && !RAGGED && !OUTF32 && KIND == EK_PLAIN), "row statistics: 64-column wave tiles, plain bf16 epilogue");
     static_for<ITEMS>([&](auto tc) {
         constexpr int t = decltype(tc)::value;
         const int id = lane + 64 * t;
@@ -421,6 +423,19 @@ __device__ __forceinline__ void epilogue_fast(const esvit_gemm_desc& p, f32x4 (&
             for (int e = 0; e < 4; ++e) {
                 bias_h[t][e] = b0[e];
                 bias_h[t][4 + e] = b1[e];
+            }
+        }
+        if constexpr (RS) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) cen_h[t][e] = 0.f;
+            if (p.rowstat_center) {
+                const f32x4 c0 = *reinterpret_cast<const f32x4*>(p.rowstat_center + n);
+                const f32x4 c1 = *reinterpret_cast<const f32x4*>(p.rowstat_center + n + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    cen_h[t][e] = c0[e];
+                    cen_h[t][4 + e] = c1[e];
+                }
             }
         }
     });
@@ -518,6 +533,32 @@ __device__ __forceinline__ void epilogue_fast(const esvit_gemm_desc& p, f32x4 (&
 #pragma unroll
                 for (int e = 0; e < 8; ++e) ov[e] = (bf16)v[e];
                 *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(Cbase) + c_off[t] + ps * c_step) = ov;
+                if constexpr (RS) {
+                    // (max, sum 2^(z - max)) of this row's 64 columns: 8 columns here, then the 8 lanes that share the row
+                    float z[8];
+                    float m = -3.0e38f;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        z[e] = ((float)ov[e] - cen_h[t][e]) * p.rowstat_scale;
+                        m = fmaxf(m, z[e]);
+                    }
+                    float sum = 0.f;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) sum += __builtin_amdgcn_exp2f(z[e] - m);
+#pragma unroll
+                    for (int o = 1; o < 8; o <<= 1) {
+                        const float m2 = __shfl_xor(m, o, 64), s2 = __shfl_xor(sum, o, 64);
+                        const float mm = fmaxf(m, m2);
+                        sum = sum * __builtin_amdgcn_exp2f(m - mm) + s2 * __builtin_amdgcn_exp2f(m2 - mm);
+                        m = mm;
+                    }
+                    const int id = lane + 64 * t;
+                    if ((id & 7) == 0) {
+                        const long row = row_w + ps * SR + id / CG;
+                        float* sp = p.rowstat + (row * (p.N >> 6) + (col_w >> 6)) * 2;
+                        *reinterpret_cast<f32x2*>(sp) = f32x2{m, sum};
+                    }
+                }
             }
         });
     });
@@ -565,7 +606,12 @@ __device__ __forceinline__ void gemm_epilogue_bf16(const esvit_gemm_desc& p, f32
         else epilogue_fast<BM, BN, WM, WN, EK_RES, false>(p, acc, stage, m0, n0, p.C, p.ldc, (long)z * p.strideC, p.bias);
     } else {
         if (p.out_f32) epilogue_fast<BM, BN, WM, WN, EK_PLAIN, true>(p, acc, stage, m0, n0, p.C, p.ldc, (long)z * p.strideC, p.bias);
-        else epilogue_fast<BM, BN, WM, WN, EK_PLAIN, false>(p, acc, stage, m0, n0, p.C, p.ldc, (long)z * p.strideC, p.bias);
+        else if constexpr (BN / WN == 64 && BM == 128) {
+            if (p.rowstat) epilogue_fast<BM, BN, WM, WN, EK_PLAIN, false, true>(p, acc, stage, m0, n0, p.C, p.ldc, (long)z * p.strideC, p.bias);
+            else epilogue_fast<BM, BN, WM, WN, EK_PLAIN, false>(p, acc, stage, m0, n0, p.C, p.ldc, (long)z * p.strideC, p.bias);
+        } else {
+            epilogue_fast<BM, BN, WM, WN, EK_PLAIN, false>(p, acc, stage, m0, n0, p.C, p.ldc, (long)z * p.strideC, p.bias);
+        }
     }
 }
 

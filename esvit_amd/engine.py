@@ -191,22 +191,14 @@ class EsvitTrainer:
         teacher_images / targets_mixup: the un-mixed global views and the per-crop target matrices of the mixup mode
         (main_esvit.py:515-538); `images` are then the mixed student inputs."""
         t_in = images[:2] if teacher_images is None else teacher_images
-        # (the first step stays on one stream: it fills the per-geometry index tables and weight casts both networks share)
-        warm, self._warm = getattr(self, "_warm", False), True
-        if self._side is not None and warm:
-            side, main = self._side, torch.cuda.current_stream()
-            side.wait_stream(main)
-            with torch.cuda.stream(side), torch.no_grad():
-                teacher_out = self.teacher(t_in)
-            student_out = self.student(images)
-            main.wait_stream(side)
-            for t in (teacher_out if isinstance(teacher_out, (tuple, list)) else [teacher_out]):
-                if torch.is_tensor(t):
-                    t.record_stream(main)
-        else:
-            with torch.no_grad():
-                teacher_out = self.teacher(t_in)
-            student_out = self.student(images)
+        arm = getattr(self.loss_fn, "arm_logit_stats", None)
+        if arm is not None:  # the heads' last-layer GEMMs also emit the softmax statistics of this step's loss (loss.py)
+            arm(self.student, self.teacher, epoch)
+        try:
+            student_out, teacher_out = self._forwards(images, t_in)
+        finally:
+            if arm is not None:
+                self.loss_fn.disarm_logit_stats(self.student, self.teacher)
         if scaler is not None:
             return self._scaled_update(scaler, student_out, teacher_out, lr, wd, momentum, epoch, targets_mixup)
         # loss.backward() below always uses grad_output == 1: the loss skips its rescale pass for this call only
@@ -223,6 +215,26 @@ class EsvitTrainer:
         self.updater.zero_grad(set_to_none=True)  # (the updater invalidated / refreshed the cached weight casts itself)
         return loss.detach()
 
+    def _forwards(self, images, t_in):
+        # (the first step stays on one stream: it fills the per-geometry index tables and weight casts both networks share)
+        warm, self._warm = getattr(self, "_warm", False), True
+        if self._side is not None and warm:
+            side, main = self._side, torch.cuda.current_stream()
+            side.wait_stream(main)
+            with torch.cuda.stream(side), torch.no_grad():
+                teacher_out = self.teacher(t_in)
+            student_out = self.student(images)
+            main.wait_stream(side)
+            for t in (teacher_out if isinstance(teacher_out, (tuple, list)) else [teacher_out]):
+                if torch.is_tensor(t):
+                    t.record_stream(main)
+                    for st in getattr(t, "esvit_row_stats", (None,))[1:]:
+                        st.record_stream(main)
+        else:
+            with torch.no_grad():
+                teacher_out = self.teacher(t_in)
+            student_out = self.student(images)
+        return student_out, teacher_out
 
     def _scaled_update(self, scaler, student_out, teacher_out, lr, wd, momentum, epoch, targets_mixup=None):
         """main_esvit.py:576-584 with the fused update as the optimizer: scale(loss).backward() -> unscale_ -> (clip +

@@ -595,7 +595,15 @@ def _last_layer_weight(v, g):
     return o.weightnorm_fwd(v.detach(), g.detach())
 
 
-def _head_forward(x, prm, save):
+def _last_logits(o, z, w, stats):
+    """logits of the weight-normed last layer (vision_transformer.py:418); with stats = (inv_temp, center) and a shape the GEMM's
+    statistics epilogue covers also their softmax row statistics -> (logits, row_max | None, row_lse | None)"""
+    if stats is not None and o.row_stats_supported(z.dtype, z.shape[0], w.shape[0]):
+        return o.linear_fwd(z, w, row_stats=stats)
+    return o.linear_fwd(z, w), None, None
+
+
+def _head_forward(x, prm, save, stats=None):
     o = ops_module()
     W1p, b1, W2p, b2, W3p, b3, v, g = prm
     W1, W2, W3 = _weight(W1p), _weight(W2p), _weight(W3p)
@@ -609,22 +617,24 @@ def _head_forward(x, prm, save):
     h3 = o.linear_fwd(h2g, W3, b3)
     z, inv = o.l2norm_fwd(h3)
     w, winv = _last_layer_weight(v, g)
-    logits = o.linear_fwd(z, w)
+    logits = _last_logits(o, z, w, stats)
     return logits, (W1, W2, W3, xa, h1, h1g, h2, h2g, z, inv, w, winv)
 
 
 class DinoHeadFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, W1p, b1, W2p, b2, W3p, b3, v, g):
-        logits, saved = _head_forward(x, (W1p, b1, W2p, b2, W3p, b3, v, g), True)
+    def forward(ctx, x, stats, W1p, b1, W2p, b2, W3p, b3, v, g):
+        (logits, mx, lse), saved = _head_forward(x, (W1p, b1, W2p, b2, W3p, b3, v, g), True, stats)
         ctx.save_for_backward(v, g, *saved)
         ctx.need_dg = g.requires_grad
         ctx.wparams = (W1p, W2p, W3p, v)
         ctx.bparams = (b1, b2, b3)
-        return logits
+        if mx is not None:
+            ctx.mark_non_differentiable(mx, lse)
+        return logits, mx, lse
 
     @staticmethod
-    def backward(ctx, dlogits):
+    def backward(ctx, dlogits, _gmx=None, _glse=None):
         o = ops_module()
         v, g, W1, W2, W3, xa, h1, h1g, h2, h2g, z, inv, w, winv = ctx.saved_tensors
         dlogits = dlogits.contiguous()
@@ -643,13 +653,14 @@ class DinoHeadFn(torch.autograd.Function):
         dh1 = o.linear_dgrad(dh2, W2, gelu_preact=h1)
         dW1, db1 = _wgrad(dh1, xa, W1p, want_bias=True, bias_param=b1p)
         dx = o.linear_dgrad(dh1, W1, out_f32=True)
-        return dx, dW1, db1, dW2, db2, dW3, db3, dv, dg
+        return dx, None, dW1, db1, dW2, db2, dW3, db3, dv, dg
 
 
-def dino_head(x, prm):
+def dino_head(x, prm, stats=None):
+    """-> (logits, row_max, row_lse): the statistics are None unless stats = (inv_temp, center) was given and the shape allows"""
     if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in prm)):
-        return DinoHeadFn.apply(x, *prm)
-    return _head_forward(x, prm, False)[0]
+        return DinoHeadFn.apply(x, stats, *prm)
+    return _head_forward(x, prm, False, stats)[0]
 
 
 class ApeAddFn(torch.autograd.Function):
@@ -699,7 +710,7 @@ def _head_bn_coef(o, d, st, gam, bet):
 
 class DinoHeadBnFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, st1, st2, W1p, b1, g1, be1, W2p, b2, g2, be2, W3p, b3, v, g):
+    def forward(ctx, x, st1, st2, stats, W1p, b1, g1, be1, W2p, b2, g2, be2, W3p, b3, v, g):
         o = ops_module()
         W1, W2, W3 = _weight(W1p), _weight(W2p), _weight(W3p)
         xa = o.cast_to_act(x.contiguous())
@@ -713,11 +724,13 @@ class DinoHeadBnFn(torch.autograd.Function):
         h3 = o.linear_fwd(h2, W3, b3)
         z, inv = o.l2norm_fwd(h3)
         w, winv = _last_layer_weight(v, g)
-        logits = o.linear_fwd(z, w)
+        logits, mx, lse = _last_logits(o, z, w, stats)
         ctx.save_for_backward(v, g, W1, W2, W3, xa, d1, coef1, gam1, h1, d2, coef2, gam2, h2, z, inv, w, winv)
         ctx.meta = (n1, n2, st1.get("group"), bool(st1.get("eval")), g.requires_grad)
         ctx.wparams = (W1p, W2p, W3p, v)
-        return logits
+        if mx is not None:
+            ctx.mark_non_differentiable(mx, lse)
+        return logits, mx, lse
 
     @staticmethod
     def _bn_gelu_bwd(o, dh, d, coef, gam, n, group, eval_bn):
@@ -733,7 +746,7 @@ class DinoHeadBnFn(torch.autograd.Function):
         return o.col_affine2(du, abc[0], abc[2], d, abc[1]), dgam, dbet
 
     @staticmethod
-    def backward(ctx, dlogits):
+    def backward(ctx, dlogits, _gmx=None, _glse=None):
         o = ops_module()
         v, g, W1, W2, W3, xa, d1, coef1, gam1, h1, d2, coef2, gam2, h2, z, inv, w, winv = ctx.saved_tensors
         n1, n2, group, eval_bn, need_dg = ctx.meta
@@ -752,12 +765,12 @@ class DinoHeadBnFn(torch.autograd.Function):
         dd1, dg1, dbe1 = DinoHeadBnFn._bn_gelu_bwd(o, o.linear_dgrad(dd2, W2), d1, coef1, gam1, n1, group, eval_bn)
         dW1, db1 = _wgrad(dd1, xa, W1p, want_bias=True)
         dx = o.linear_dgrad(dd1, W1, out_f32=True)
-        return dx, None, None, dW1, db1, dg1, dbe1, dW2, db2, dg2, dbe2, dW3, db3, dv, dg
+        return dx, None, None, None, dW1, db1, dg1, dbe1, dW2, db2, dg2, dbe2, dW3, db3, dv, dg
 
 
-def dino_head_bn(x, st1, st2, prm):
-    """prm = (W1, b1, bn1.weight, bn1.bias, W2, b2, bn2.weight, bn2.bias, W3, b3, weight_v, weight_g)"""
-    return DinoHeadBnFn.apply(x, st1, st2, *prm)
+def dino_head_bn(x, st1, st2, prm, stats=None):
+    """prm = (W1, b1, bn1.weight, bn1.bias, W2, b2, bn2.weight, bn2.bias, W3, b3, weight_v, weight_g) -> (logits, row_max, row_lse)"""
+    return DinoHeadBnFn.apply(x, st1, st2, stats, *prm)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -26,6 +26,9 @@ class DINOHead(nn.Module):
             raise NotImplementedError("the fused head implements the reference default nlayers=3")
         self.use_bn = bool(use_bn)
         self.sync_bn_group = None  # process group of the batch statistics (None = default group; False = this rank only)
+        # (inv_temp, centre | None, token) set by the loss for one step (loss.arm_logit_stats): the last-layer GEMM then also emits
+        # the softmax row statistics the loss needs, handed over as the attribute `esvit_row_stats` of the returned logits
+        self.logit_stats = None
         if use_bn:  # --use_bn_in_head (vision_transformer.py:391-402): mlp.{0,3,6} Linear, mlp.{1,4} BatchNorm1d
             self.mlp = nn.Sequential(nn.Linear(in_dim, hidden_dim), nn.BatchNorm1d(hidden_dim), nn.GELU(), nn.Linear(hidden_dim, hidden_dim),
                                      nn.BatchNorm1d(hidden_dim), nn.GELU(), nn.Linear(hidden_dim, bottleneck_dim))
@@ -57,9 +60,17 @@ class DINOHead(nn.Module):
             m = self.mlp
             prm = [m[0].weight, m[0].bias, m[1].weight, m[1].bias, m[3].weight, m[3].bias, m[4].weight, m[4].bias, m[6].weight, m[6].bias,
                    self.last_layer.weight_v, self.last_layer.weight_g]
-            y = Fn.dino_head_bn(x2, self._bn_state(m[1]), self._bn_state(m[4]), prm)
-            return y.view(*lead, y.shape[-1])
+            return self._finish(Fn.dino_head_bn(x2, self._bn_state(m[1]), self._bn_state(m[4]), prm, self._stats_request()), lead)
         prm = [self.mlp[0].weight, self.mlp[0].bias, self.mlp[2].weight, self.mlp[2].bias, self.mlp[4].weight, self.mlp[4].bias,
                self.last_layer.weight_v, self.last_layer.weight_g]
-        y = Fn.dino_head(x2, prm)
-        return y.view(*lead, y.shape[-1])
+        return self._finish(Fn.dino_head(x2, prm, self._stats_request()), lead)
+
+    def _stats_request(self):
+        return None if self.logit_stats is None else self.logit_stats[:2]
+
+    def _finish(self, out, lead):
+        y, mx, lse = out
+        y = y.view(*lead, y.shape[-1])
+        if mx is not None:
+            y.esvit_row_stats = (self.logit_stats[2], mx, lse)
+        return y

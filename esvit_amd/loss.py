@@ -8,6 +8,8 @@ log-softmax tensors and the gathered teacher rows of the reference are never mat
 ``targets_mixup`` is accepted and ignored by DDINOLoss exactly as in the reference; the DINOLoss mixup branch
 (main_esvit.py:639-641) is a 'next' row.
 """
+import os
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -48,6 +50,25 @@ def _world():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
 
+LOGIT_STATS = os.environ.get("ESVIT_LOGIT_STATS", "1") != "0"
+
+
+def _heads_of(model):
+    """the DINOHead modules of a (possibly wrapped) backbone: (view-level head, region-level head), either may be None"""
+    from .head import DINOHead
+    m = getattr(model, "module", model)
+    hv, hd = getattr(m, "head", None), getattr(m, "head_dense", None)
+    return (hv if isinstance(hv, DINOHead) else None), (hd if isinstance(hd, DINOHead) else None)
+
+
+def _taken_stats(x, token):
+    """(row_max, row_lse) a head attached to its logits for exactly this request, else None"""
+    st = getattr(x, "esvit_row_stats", None)
+    if st is not None and st[0] == token:
+        return st[1], st[2]
+    return None
+
+
 class _DeferredCenter:
     """The centre update of step n is only needed by the loss of step n+1 (main_esvit.py:748, 752-770): the all-reduce of
     the batch sums is launched asynchronously right after they are computed -- RCCL runs it on its own stream under the
@@ -69,6 +90,37 @@ class _DeferredCenter:
             self._pending = None
             h.wait()
             apply(buf, _world())
+
+    # ---- softmax statistics from the heads' last-layer GEMM (esvit_gemm_desc::rowstat) ----
+    # The train step announces the coming loss call: the heads then emit, next to the logits, the row statistics this loss would
+    # otherwise compute in a pass of its own (teacher: esvit_teacher_row_stats; student: the first pass of the CE kernel).  A request
+    # is (inverse temperature, centre, token); the token ties the statistics to the centre values they were computed with -- any
+    # centre update in between changes `_center_version` and the loss falls back to its own passes.
+    _center_version = 0
+
+    def _token(self, who, inv_temp):
+        return (id(self), who, self._center_version, float(inv_temp))
+
+    def _centers(self):
+        return (self.center, getattr(self, "center_grid", None))
+
+    def arm_logit_stats(self, student, teacher, epoch):
+        """call before the teacher / student forwards of one step (engine.EsvitTrainer.step does)"""
+        if not LOGIT_STATS:
+            return
+        self.synchronize()  # the centres the teacher statistics use must be final
+        inv_tt, inv_st = 1.0 / float(self.teacher_temp_schedule[epoch]), 1.0 / self.student_temp
+        for who, model, inv_t, cens in (("t", teacher, inv_tt, self._centers()), ("s", student, inv_st, (None, None))):
+            for lvl, (head, cen) in enumerate(zip(_heads_of(model), cens)):
+                if head is not None:
+                    head.logit_stats = (inv_t, None if cen is None else cen.view(-1), self._token(who + str(lvl), inv_t))
+
+    @staticmethod
+    def disarm_logit_stats(student, teacher):
+        for model in (student, teacher):
+            for head in _heads_of(model):
+                if head is not None:
+                    head.logit_stats = None
 
     def state_dict(self, *args, **kwargs):
         self.synchronize()
@@ -127,13 +179,15 @@ class DINOLoss(_DeferredCenter, nn.Module):
         s, t = student_output.contiguous(), teacher_output.detach().contiguous()
         B = t.shape[0] // 2
         inv_tt = 1.0 / float(self.teacher_temp_schedule[epoch])
-        mx, lse = o.teacher_row_stats(t, self.center, inv_tt)
+        inv_st = 1.0 / self.student_temp
+        t_st, s_st = _taken_stats(teacher_output, self._token("t0", inv_tt)), _taken_stats(student_output, self._token("s0", inv_st))
+        mx, lse = t_st if t_st is not None else o.teacher_row_stats(t, self.center, inv_tt)
         if targets_mixup:
             tmatch, tw = self._mixup_terms(targets_mixup, B, s.device)
-            row_loss, ds = o.dino_ce(s.detach(), t, self.center, mx, lse, tmatch, None, 1.0 / self.student_temp, inv_tt, term_w=tw)
+            row_loss, ds = o.dino_ce(s.detach(), t, self.center, mx, lse, tmatch, None, inv_st, inv_tt, term_w=tw)
         else:
             tmatch, w = self._static(B, s.device)
-            row_loss, ds = o.dino_ce(s.detach(), t, self.center, mx, lse, tmatch, w, 1.0 / self.student_temp, inv_tt)
+            row_loss, ds = o.dino_ce(s.detach(), t, self.center, mx, lse, tmatch, w, inv_st, inv_tt, s_stats=s_st)
         loss = o.sum_f32(row_loss)
         self.update_center(t)
         return _LossFn.apply(loss, self.assume_unit_grad, student_output, ds)
@@ -142,8 +196,11 @@ class DINOLoss(_DeferredCenter, nn.Module):
     def update_center(self, teacher_output):
         o = _ops()
         rows = teacher_output.shape[0]
-        self._reduce_and_apply(o.colsum(teacher_output),
-                               lambda cs, w: o.center_ema(self.center, cs, self.center_momentum, rows * w))
+
+        def apply(cs, w):
+            self._center_version += 1
+            o.center_ema(self.center, cs, self.center_momentum, rows * w)
+        self._reduce_and_apply(o.colsum(teacher_output), apply)
 
 
 class DDINOLoss(_DeferredCenter, nn.Module):
@@ -194,14 +251,16 @@ class DDINOLoss(_DeferredCenter, nn.Module):
         self.synchronize()
         s_cls, s_reg, s_fea, s_np = student_output
         t_cls, t_reg, t_fea, t_np = teacher_output
+        inv_tt = 1.0 / float(self.teacher_temp_schedule[epoch])
+        inv_st = 1.0 / self.student_temp
+        st_tc, st_tg = _taken_stats(t_cls, self._token("t0", inv_tt)), _taken_stats(t_reg, self._token("t1", inv_tt))
+        st_sc, st_sg = _taken_stats(s_cls, self._token("s0", inv_st)), _taken_stats(s_reg, self._token("s1", inv_st))
         s_cls_c, s_reg_c = s_cls.contiguous(), s_reg.contiguous()
         t_cls, t_reg = t_cls.detach().contiguous(), t_reg.detach().contiguous()
         Tt = int(t_np[0])
         B = t_reg.shape[0] // (2 * Tt)
         tb = self._static(B, [int(n) for n in s_np], Tt, s_cls.device)
         S = tb["S"]
-        inv_tt = 1.0 / float(self.teacher_temp_schedule[epoch])
-        inv_st = 1.0 / self.student_temp
         # region matching on fp32 backbone features (main_esvit.py:735-736)
         sf = o.gather_cast(s_fea.detach().float().contiguous(), B * S, rowmap=tb["cm_row"], tokens=1, dtype=torch.float32)
         tf = o.gather_cast(t_fea.detach().float().contiguous(), B * 2 * Tt, rowmap=tb["t_perm"], tokens=1, dtype=torch.float32)
@@ -213,14 +272,14 @@ class DDINOLoss(_DeferredCenter, nn.Module):
         tm_reg = torch.empty((B * S, 2), dtype=torch.int32, device=s_cls.device)
         o.region_match(sim, Tt, tb["crop_id"], tb["cm_row"], tm_reg)
         # teacher statistics, student CE + gradient
-        mx_c, lse_c = o.teacher_row_stats(t_cls, self.center, inv_tt)
-        mx_g, lse_g = o.teacher_row_stats(t_reg, self.center_grid, inv_tt)
+        mx_c, lse_c = st_tc if st_tc is not None else o.teacher_row_stats(t_cls, self.center, inv_tt)
+        mx_g, lse_g = st_tg if st_tg is not None else o.teacher_row_stats(t_reg, self.center_grid, inv_tt)
         n_cls = s_cls_c.shape[0]
         row_loss = torch.empty((n_cls + s_reg_c.shape[0],), dtype=torch.float32, device=s_cls.device)
         _, ds_cls = o.dino_ce(s_cls_c.detach(), t_cls, self.center, mx_c, lse_c, tb["tm_cls"], tb["w_cls"], inv_st, inv_tt,
-                              row_loss=row_loss[:n_cls])
+                              row_loss=row_loss[:n_cls], s_stats=st_sc)
         _, ds_reg = o.dino_ce(s_reg_c.detach(), t_reg, self.center_grid, mx_g, lse_g, tm_reg, tb["w_reg"], inv_st, inv_tt,
-                              row_loss=row_loss[n_cls:], row_order=tb["cm_row"])  # image-major work order: teacher rows stay cached
+                              row_loss=row_loss[n_cls:], row_order=tb["cm_row"], s_stats=st_sg)  # image-major work order: teacher rows stay cached
         loss = o.sum_f32(row_loss)
         self.update_center(t_cls, t_reg)
         return _LossFn.apply(loss, self.assume_unit_grad, s_cls, s_reg, ds_cls, ds_reg)
@@ -236,6 +295,7 @@ class DDINOLoss(_DeferredCenter, nn.Module):
         r_cls, r_reg = teacher_output.shape[0], teacher_grid_output.shape[0]
 
         def apply(b, w):
+            self._center_version += 1
             o.center_ema(self.center, b[0], self.center_momentum, r_cls * w)
             o.center_ema(self.center_grid, b[1], self.center_momentum, r_reg * w)
         self._reduce_and_apply(buf, apply)

@@ -163,8 +163,9 @@ FORCE_GEMM_KERNEL = GEMM_AUTO
 
 def _gemm_desc(kw):
     d = GemmDesc()
-    for k in ("A", "B", "C", "bias", "residual", "rowmap", "rowscale", "aux", "partial", "colsum", "colsum_partial"):
+    for k in ("A", "B", "C", "bias", "residual", "rowmap", "rowscale", "aux", "partial", "colsum", "colsum_partial", "rowstat", "rowstat_center"):
         setattr(d, k, _p(kw.get(k)))
+    d.rowstat_scale = float(kw.get("rowstat_scale", 0.0))
     for k in ("M", "N", "K", "lda", "ldb", "ldc", "a_kstrided", "b_kstrided", "strideA", "strideB", "strideC", "ldr",
               "rowmap_period", "rowmap_tokens", "rows_per_sample", "ldaux", "epilogue", "out_f32", "splitk", "accumulate"):
         setattr(d, k, int(kw.get(k, 0)))
@@ -195,18 +196,41 @@ def gemm_select(dt, **kw):
     return k, tm.value, tn.value, slots.value
 
 
+LOG2E = 1.4426950408889634
+
+
+def row_stats_supported(dt, M, N):
+    """can the GEMM that writes logits [M, N] also emit their softmax row statistics (esvit_gemm_desc::rowstat)?"""
+    return dt == torch.bfloat16 and M > 0 and M % 128 == 0 and N % 128 == 0
+
+
 def linear_fwd(x, w, bias=None, *, gelu=False, want_preact=False, residual=None, rowmap=None, rowmap_tokens=0,
-               out_rows=None, rowscale=None, rows_per_sample=0, out_f32=False, quick=False):
+               out_rows=None, rowscale=None, rows_per_sample=0, out_f32=False, quick=False, row_stats=None):
     """y = x @ w^T (+bias) with the fused epilogue of the GEMM kernel.  gelu: exact erf-GELU, or (quick=True) the
     QuickGELU x*sigmoid(1.702x) of the CvT feed-forward.
 
     x [M, K] act; w [N, K] act (cached cast of the fp32 parameter); bias fp32 [N].
     rowmap (int32 [period]) scatters window rows to token rows (out_rows rows, tokens per image =
-    rowmap_tokens); residual fp32 [out_rows, N] is added at the destination row."""
+    rowmap_tokens); residual fp32 [out_rows, N] is added at the destination row.
+    row_stats = (inv_temp, center fp32 [N] or None): also return the softmax statistics of z = (y - center) * inv_temp, the
+    outputs of teacher_row_stats -> (y, row_max, row_lse); the shape must pass row_stats_supported."""
     x, w = _actc(x), _actc(w)
     M, K = x.shape
     N = w.shape[0]
     assert w.shape[1] == K and x.dtype == w.dtype
+    if row_stats is not None:
+        inv_temp, cen = row_stats
+        assert row_stats_supported(x.dtype, M, N) and bias is None and not gelu and residual is None and rowmap is None and not out_f32
+        y = torch.empty((M, N), dtype=x.dtype, device=x.device)
+        nb = N // 64
+        st = torch.empty((M, nb, 2), dtype=torch.float32, device=x.device)
+        cen = None if cen is None else _f32c(cen)
+        _gemm(x.dtype, A=x, B=w, C=y, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, rowstat=st, rowstat_center=cen, rowstat_scale=float(inv_temp) * LOG2E,
+              kernel=GEMM_AUTO)
+        mx = torch.empty((M,), dtype=torch.float32, device=x.device)
+        lse = torch.empty_like(mx)
+        check(lib.esvit_rowstat_combine(_p(st), M, nb, _p(mx), _p(lse), _stream()), "rowstat_combine")
+        return y, mx, lse
     rows = M if out_rows is None else out_rows
     y = torch.empty((rows, N), dtype=torch.float32 if out_f32 else x.dtype, device=x.device)
     pre = torch.empty((M, N), dtype=x.dtype, device=x.device) if (gelu and want_preact) else None
@@ -687,9 +711,11 @@ def region_match(sim, Tt, crop_id, cm_row, tmatch):
     return tmatch
 
 
-def dino_ce(s, t, center, t_max, t_lse, tmatch, row_w, inv_student_temp, inv_teacher_temp, row_loss=None, term_w=None, row_order=None):
+def dino_ce(s, t, center, t_max, t_lse, tmatch, row_w, inv_student_temp, inv_teacher_temp, row_loss=None, term_w=None, row_order=None,
+            s_stats=None):
     """-> (row_loss fp32 [Rs], ds act [Rs, K]).  tmatch int32 [Rs, 2] with one weight row_w[r] for both terms, or (mixup
-    targets) tmatch [Rs, 4] with term_w fp32 [Rs, 4], one weight per term."""
+    targets) tmatch [Rs, 4] with term_w fp32 [Rs, 4], one weight per term.  s_stats = (row_max, row_lse) of s * inv_student_temp
+    (linear_fwd(row_stats=(inv_student_temp, None))) spares the kernel its first pass over the student rows."""
     s, t = _actc(s), _actc(t)
     Rs, K = s.shape
     assert t.shape[1] == K and s.dtype == t.dtype and tmatch.dtype == torch.int32
@@ -700,8 +726,11 @@ def dino_ce(s, t, center, t_max, t_lse, tmatch, row_w, inv_student_temp, inv_tea
     terms = 2 if term_w is None else 4
     assert row_order is None or (row_order.dtype == torch.int32 and row_order.numel() == Rs and row_order.is_contiguous())
     assert tmatch.numel() == Rs * terms and tmatch.is_contiguous() and (term_w is None or (term_w.numel() == Rs * 4 and term_w.is_contiguous()))
+    s_mx, s_lse = (None, None) if s_stats is None else s_stats
+    assert s_stats is None or (term_w is None and s_mx.numel() == Rs and s_lse.numel() == Rs and s_mx.dtype == s_lse.dtype == torch.float32)
     check(lib.esvit_dino_ce_fwd_bwd(_code(s.dtype), _p(s), _p(t), _p(center), _p(t_max), _p(t_lse), _p(tmatch), _p(row_w), terms,
-                                    _p(term_w), inv_student_temp, inv_teacher_temp, Rs, K, _p(row_loss), _p(ds), _p(row_order), _stream()),
+                                    _p(term_w), inv_student_temp, inv_teacher_temp, Rs, K, _p(row_loss), _p(ds), _p(row_order), _p(s_mx),
+                                    _p(s_lse), _stream()),
           "dino_ce_fwd_bwd")
     return row_loss, ds
 

@@ -108,6 +108,15 @@ typedef struct {
     float* colsum;         /* optional, fp32 [M]: row sums of op(A) over K (= bias gradient when A = dY^T); fused via an all-ones B fragment */
     float* colsum_partial; /* workspace >= splitk*M floats when splitk > 1 */
     int32_t kernel;        /* ESVIT_GEMM_AUTO (0): chosen from the shape; otherwise force one main loop (tests / tuning) */
+    /* optional softmax statistics of the OUTPUT rows (the logits of the DINO head, vision_transformer.py:418): for every row and
+     * every 64-column block j the pair (m, s) = (max_k z_k, sum_k 2^(z_k - m)) over k in [64 j, 64 j + 64) of
+     * z_k = (C[row][k] as stored, i.e. rounded to the activation dtype, - rowstat_center[k]) * rowstat_scale
+     * (scale = log2(e) / temperature; center NULL = 0).  rowstat: fp32 [M, N / 64, 2].  Only for the plain bf16 epilogue of a
+     * dense forward GEMM with M % 128 == 0 and N % 128 == 0 (rejected otherwise); esvit_rowstat_combine folds the blocks of a row,
+     * esvit_dino_ce_fwd_bwd takes them in place of its first pass over the logits (main_esvit.py:728-742). */
+    float* rowstat;
+    const float* rowstat_center;
+    float rowstat_scale;
 } esvit_gemm_desc;
 
 /* main loops of the family (esvit_gemm_desc.kernel; what esvit_gemm_select returns) */
@@ -305,12 +314,17 @@ int esvit_region_match(const float* sim, int B, int S, int Tt, int ld, const int
  * = d loss / d s (includes 1/student_temp).
  * row_order (optional, int32 [Rs], a permutation of the rows): the order in which workgroups take the rows -- the region loss
  * passes the image-major order so that the student rows of one image, which share their <= 98 teacher rows, run together and
- * re-read them from cache instead of HBM.  Results do not depend on it. */
+ * re-read them from cache instead of HBM.  Results do not depend on it.
+ * s_row_max / s_row_lse (optional pair, fp32 [Rs]): statistics of z = s / tau_s already known (esvit_rowstat_combine of the
+ * last-layer GEMM's side output): lse(z) = s_row_max + s_row_lse and the kernel's first pass over the row is skipped. */
 int esvit_dino_ce_fwd_bwd(int dtype, const void* s, const void* t, const float* center,
                           const float* t_row_max, const float* t_row_lse, const int32_t* tmatch,
                           const float* row_w, int terms, const float* term_w, float inv_student_temp,
                           float inv_teacher_temp, int64_t Rs, int K, float* row_loss, void* ds, const int32_t* row_order,
-                          esvit_stream_t stream);
+                          const float* s_row_max, const float* s_row_lse, esvit_stream_t stream);
+/* fold esvit_gemm_desc::rowstat (fp32 [R, nblocks, 2], base-2 block statistics) into natural-log row statistics, the outputs of
+ * esvit_teacher_row_stats: row_max[r] = max_k z_k, row_lse[r] = log sum_k exp(z_k - row_max[r]) */
+int esvit_rowstat_combine(const float* rowstat, int64_t R, int nblocks, float* row_max, float* row_lse, esvit_stream_t stream);
 /* deterministic sum of row_loss -> loss[0] */
 int esvit_sum_f32(const float* x, int64_t n, float* out, esvit_stream_t stream);
 /* ds *= scale[0] (scale on device: grad_output of the scalar loss) */

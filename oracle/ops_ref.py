@@ -103,8 +103,17 @@ def workspace(n, device, slot=0):
 
 
 # ---- GEMM family -------------------------------------------------------------------------
+def row_stats_supported(dt, M, N):
+    return dt == torch.bfloat16 and M > 0 and M % 128 == 0 and N % 128 == 0
+
+
 def linear_fwd(x, w, bias=None, *, gelu=False, want_preact=False, residual=None, rowmap=None, rowmap_tokens=0,
-               out_rows=None, rowscale=None, rows_per_sample=0, out_f32=False, quick=False):
+               out_rows=None, rowscale=None, rows_per_sample=0, out_f32=False, quick=False, row_stats=None):
+    if row_stats is not None:  # the logits as stored (rounded) and their softmax statistics (vision_transformer.py:418 + main_esvit.py:629,694)
+        inv_temp, cen = row_stats
+        y = _r(x.float() @ w.float().t(), x.dtype)
+        mx, lse = teacher_row_stats(y, torch.zeros(y.shape[1], device=y.device) if cen is None else cen, inv_temp)
+        return y, mx, lse
     acc = x.float() @ w.float().t()
     if bias is not None:
         acc = acc + bias
@@ -613,9 +622,10 @@ def region_match(sim, Tt, crop_id, cm_row, tmatch):
     return tmatch
 
 
-def dino_ce(s, t, center, t_max, t_lse, tmatch, row_w, inv_student_temp, inv_teacher_temp, row_loss=None, term_w=None, row_order=None):
+def dino_ce(s, t, center, t_max, t_lse, tmatch, row_w, inv_student_temp, inv_teacher_temp, row_loss=None, term_w=None, row_order=None,
+            s_stats=None):
     z = s.float() * inv_student_temp
-    lse = torch.logsumexp(z, 1)
+    lse = torch.logsumexp(z, 1) if s_stats is None else s_stats[0] + s_stats[1]
     ps = torch.exp(z - lse[:, None])
     if term_w is not None:  # four individually weighted terms per row (mixup targets)
         tm = tmatch.view(-1, 4).long()

@@ -521,6 +521,34 @@ def test_fused_mlp_branch_host_logic_matches_reference_golden(cpu_ops, monkeypat
     assert norm_rel < 2e-3 and worst < 5e-3, (norm_rel, worst_name, worst)
 
 
+def test_logit_statistics_handover_host_logic_matches_reference_golden(cpu_ops, monkeypatch):
+    """the softmax row statistics the heads' last-layer GEMM emits for the loss (esvit_gemm_desc::rowstat -> loss.arm_logit_stats,
+    DINOHead.logit_stats, the `esvit_row_stats` attribute, the token check): with the kernel replaced by its restatement and the shape
+    gate opened, all four logit tensors arrive with statistics, the loss uses them, and the step still reproduces the reference's"""
+    import esvit_amd.loss as L
+    from tests.test_step_gpu import FULL_GOLD, full_case_deltas, run_full_case
+    monkeypatch.setattr(ops_ref, "row_stats_supported", lambda dt, M, N: True)
+    taken = []
+    f0 = L._taken_stats
+    monkeypatch.setattr(L, "_taken_stats", lambda x, tok: (taken.append(f0(x, tok) is not None), f0(x, tok))[1])
+    g = torch.load(FULL_GOLD, map_location="cpu", weights_only=False)["swin_t_k8192_b2"]
+    student, loss_fn, s_out, t_out, loss = run_full_case("swin_t_k8192_b2", torch.device("cpu"), armed=True)
+    assert taken == [True] * 4, taken
+    assert student.head.logit_stats is None and student.head_dense.logit_stats is None  # disarmed: later forwards emit nothing
+    out_rel, norm_rel, worst, worst_name = full_case_deltas(g, student, s_out)
+    assert out_rel < 1e-4 and abs(loss.item() - g["loss"]) < 1e-4, (out_rel, loss.item(), g["loss"])
+    assert norm_rel < 2e-3 and worst < 5e-3, (norm_rel, worst_name, worst)
+    # statistics computed for other centre values are refused: a centre update between the forwards and the loss changes the token
+    taken.clear()
+    loss_fn.arm_logit_stats(student, student, 0)
+    crops = [torch.randn(2, 3, 224, 224), torch.randn(2, 3, 224, 224)]
+    with torch.no_grad():
+        t2 = student(crops)
+    loss_fn.disarm_logit_stats(student, student)
+    loss_fn.update_center(t2[0], t2[1])
+    assert L._taken_stats(t2[0], loss_fn._token("t0", 1.0 / float(loss_fn.teacher_temp_schedule[0]))) is None
+
+
 def check_linear_probe(dev="cpu", tol=2e-4):
     """eval_linear.py's probe (train + validate_network + LinearClassifier) through esvit_amd.eval over our backbone's
     forward_return_n_last_blocks vs the fixture produced by the reference's own functions on its own backbone"""

@@ -495,6 +495,55 @@ def test_dino_loss_kernels(mods, dt, K):
     assert torch.equal(rl2, rl) and torch.equal(ds2, ds)
 
 
+@pytest.mark.parametrize("M,N,K", [(256, 4096, 64), (640, 8192, 256), (128, 65536, 256)])
+@pytest.mark.parametrize("centred", [False, True])
+def test_last_layer_row_statistics(mods, M, N, K, centred):
+    """esvit_gemm_desc::rowstat + esvit_rowstat_combine: the GEMM that writes the logits also returns the softmax statistics of the
+    STORED (bf16-rounded) logits -- compared with esvit_teacher_row_stats on the very tensor it wrote (same values, fp32 sums in
+    another order: 2e-5), then used as the student statistics of the CE kernel in place of its first pass"""
+    ops, ref = mods
+    dev = _dev()
+    dt = torch.bfloat16
+    assert ops.row_stats_supported(dt, M, N) and not ops.row_stats_supported(dt, M + 8, N) and not ops.row_stats_supported(torch.float32, M, N)
+    z = torch.nn.functional.normalize(_rand((M, K), dev, 75), dim=1).to(dt)
+    w = torch.nn.functional.normalize(_rand((N, K), dev, 76), dim=1).to(dt)
+    cen = (_rand((N,), dev, 77) * 0.2) if centred else None
+    inv_t = 25.0 if centred else 10.0
+    y, mx, lse = ops.linear_fwd(z, w, row_stats=(inv_t, cen))
+    assert torch.equal(y, ops.linear_fwd(z, w))  # the logits themselves do not change
+    zero = torch.zeros(N, device=dev)
+    mx0, lse0 = ops.teacher_row_stats(y, zero if cen is None else cen, inv_t)
+    _close("row max", mx, mx0, 1e-6)
+    _close("row lse", mx + lse, mx0 + lse0, 2e-5)
+    yr, mxr, lser = ref.linear_fwd(z, w, row_stats=(inv_t, cen))
+    _close("logits", y, yr, 1e-2)
+    _close("lse vs restatement", mx + lse, mxr + lser, 2e-3)  # (a logit rounded the other way moves the row maximum)
+    if not centred:
+        Rt = 16
+        t = _rand((Rt, N), dev, 78, dt)
+        c1 = _rand((1, N), dev, 79) * 0.3
+        tmx, tlse = ref.teacher_row_stats(t, c1, 25.0)
+        g = torch.Generator().manual_seed(80)
+        tm = torch.randint(-1, Rt, (M, 2), generator=g).to(torch.int32).to(dev)
+        wr = (torch.rand(M, generator=g) * 0.1).to(dev)
+        rl0, ds0 = ops.dino_ce(y, t, c1, tmx, tlse, tm, wr, inv_t, 25.0)
+        rl1, ds1 = ops.dino_ce(y, t, c1, tmx, tlse, tm, wr, inv_t, 25.0, s_stats=(mx, lse))
+        _close("row loss with handed-over statistics", rl1, rl0, 2e-5)
+        _close("ds with handed-over statistics", ds1, ds0, 1e-2)
+
+
+def test_row_statistics_are_refused_outside_their_epilogue(mods):
+    ops, _ = mods
+    dev = _dev()
+    z, w = _rand((128, 64), dev, 81, torch.bfloat16), _rand((256, 64), dev, 82, torch.bfloat16)
+    y = torch.empty((128, 256), dtype=torch.bfloat16, device=dev)
+    st = torch.empty((128, 4, 2), device=dev)
+    with pytest.raises(RuntimeError, match="row statistics"):
+        ops._gemm(torch.bfloat16, A=z, B=w, C=y, M=128, N=256, K=64, lda=64, ldb=64, ldc=256, rowstat=st, rowstat_scale=1.0, bias=torch.zeros(256, device=dev))
+    with pytest.raises(RuntimeError, match="row statistics"):
+        ops._gemm(torch.bfloat16, A=z, B=w, C=y, M=120, N=256, K=64, lda=64, ldb=64, ldc=256, rowstat=st, rowstat_scale=1.0)
+
+
 def test_index_maps_match_restatement(mods):
     ops, ref = mods
     for ws in (7, 14):

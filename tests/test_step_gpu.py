@@ -157,12 +157,17 @@ def build_full_case(name, dev):
     return student, teacher, loss_fn, crops
 
 
-def run_full_case(name, dev):
-    """one forward / loss / backward of the case on the HIP path -> (student, loss_fn, s_out, t_out, loss)"""
+def run_full_case(name, dev, armed=False):
+    """one forward / loss / backward of the case on the HIP path -> (student, loss_fn, s_out, t_out, loss).
+    armed: the loss announces itself to the heads first, as engine.EsvitTrainer.step does (loss.arm_logit_stats)"""
     student, teacher, loss_fn, crops = build_full_case(name, dev)
+    if armed:
+        loss_fn.arm_logit_stats(student, teacher, 0)
     with torch.no_grad():
         t_out = teacher(crops[:2])
     s_out = student(crops)
+    if armed:
+        loss_fn.disarm_logit_stats(student, teacher)
     loss = loss_fn(s_out, t_out, 0, None)
     loss.backward()
     loss_fn.synchronize()
@@ -477,5 +482,44 @@ def test_train_one_epoch_drop_in_gpu(lib_built):
         for (n, p), (_, q) in zip(t5.named_parameters(), s5.named_parameters()):
             assert torch.allclose(p, before_t[n] * m + q.detach() * (1 - m), rtol=1e-5, atol=1e-7), n
         assert all(float(st["step"]) == 3.0 for st in o5.state_dict()["state"].values())
+    finally:
+        _teardown()
+
+
+def test_trainer_step_with_logit_statistics_from_the_gemm(lib_built, monkeypatch):
+    """engine.EsvitTrainer.step with the heads' last-layer GEMMs emitting the loss's softmax statistics (the default) vs the same
+    steps with the loss computing them in its own passes (ESVIT_LOGIT_STATS=0): B = 128 so that every logit tensor comes in whole
+    128-row tiles; the statistics path must actually be taken (no esvit_teacher_row_stats call), losses agree to 1e-5 relative,
+    parameters after three steps to bf16-gradient noise"""
+    import esvit_amd
+    import esvit_amd.loss as L
+    from esvit_amd import ops
+    from esvit_amd import params as P
+    from esvit_amd.engine import EsvitTrainer
+    dev = _setup("bf16")
+    calls = {"t": 0}
+    f0 = ops.teacher_row_stats
+    monkeypatch.setattr(ops, "teacher_row_stats", lambda *a, **k: (calls.__setitem__("t", calls["t"] + 1), f0(*a, **k))[1])
+
+    def run(on):
+        monkeypatch.setattr(L, "LOGIT_STATS", on)
+        P.clear()
+        student, teacher = nano_pair()
+        student, teacher = student.to(dev), teacher.to(dev)
+        loss_fn = L.DDINOLoss(GU.NANO_HEAD["out_dim"], 10, 0.04, 0.07, 5, 10).to(dev)
+        tr = EsvitTrainer(student, teacher, loss_fn, clip_grad=3.0, freeze_last_layer=0)
+        calls["t"] = 0
+        losses = [tr.step(_to(GU.make_crops(128, seed=40 + i), dev), 5e-4, 0.04, 0.996, epoch=i).item() for i in range(3)]
+        torch.cuda.synchronize()
+        tr.reducer.close()
+        return losses, {k: v.detach().float().clone() for k, v in student.state_dict().items()}, calls["t"]
+
+    try:
+        l_on, p_on, n_on = run(True)
+        l_off, p_off, n_off = run(False)
+        assert n_on == 0 and n_off == 6, (n_on, n_off)
+        assert max(abs(a - b) / abs(b) for a, b in zip(l_on, l_off)) < 1e-5, (l_on, l_off)
+        # AdamW's normalised step is bounded by lr per element and step (a near-zero gradient may flip sign: 2 lr per step)
+        assert max((p_on[k] - p_off[k]).abs().max().item() for k in p_on if p_on[k].numel()) < 6 * 5e-4
     finally:
         _teardown()
