@@ -489,8 +489,8 @@ def test_train_one_epoch_drop_in_gpu(lib_built):
 def test_trainer_step_with_logit_statistics_from_the_gemm(lib_built, monkeypatch):
     """engine.EsvitTrainer.step with the heads' last-layer GEMMs emitting the loss's softmax statistics (the default) vs the same
     steps with the loss computing them in its own passes (ESVIT_LOGIT_STATS=0): B = 128 so that every logit tensor comes in whole
-    128-row tiles; the statistics path must actually be taken (no esvit_teacher_row_stats call), losses agree to 1e-5 relative,
-    parameters after three steps to bf16-gradient noise"""
+    128-row tiles; the statistics path must actually be taken (no esvit_teacher_row_stats call), the first loss agrees to 1e-6 relative, the
+    next two (after updates) to 1e-3, parameters after three steps to the AdamW step bound"""
     import esvit_amd
     import esvit_amd.loss as L
     from esvit_amd import ops
@@ -518,7 +518,10 @@ def test_trainer_step_with_logit_statistics_from_the_gemm(lib_built, monkeypatch
         l_on, p_on, n_on = run(True)
         l_off, p_off, n_off = run(False)
         assert n_on == 0 and n_off == 6, (n_on, n_off)
-        assert max(abs(a - b) / abs(b) for a, b in zip(l_on, l_off)) < 1e-5, (l_on, l_off)
+        # same parameters in step 1: the two losses differ by fp32 summation order only; afterwards the updates have diverged by
+        # the sign flips of near-zero gradients under AdamW
+        assert abs(l_on[0] - l_off[0]) / abs(l_off[0]) < 1e-6, (l_on, l_off)
+        assert max(abs(a - b) / abs(b) for a, b in zip(l_on, l_off)) < 1e-3, (l_on, l_off)
         # AdamW's normalised step is bounded by lr per element and step (a near-zero gradient may flip sign: 2 lr per step)
         assert max((p_on[k] - p_off[k]).abs().max().item() for k in p_on if p_on[k].numel()) < 6 * 5e-4
     finally:
