@@ -136,7 +136,9 @@ struct Tile {
 // issued AFTER its stores sits out the full store latency.  Every tensor the epilogue reads is therefore requested
 // ahead of the stores it would otherwise queue behind: bias and the row map once per tile, and the per-element
 // inputs of pass ps+1 (residual or GELU pre-activation, DropPath scale) before the stores of pass ps.
-template <typename T, int BM, int BN, int WM, int WN, int SR = 16>
+// TR: the accumulators hold the TRANSPOSED fragment layout of the LDS-DMA kernels (acc[r] = C[row c][column 4g + r], see
+// epilogue_direct) -- only the staging write differs.
+template <typename T, int BM, int BN, int WM, int WN, int SR = 16, bool TR = false>
 __device__ __forceinline__ void gemm_epilogue(const esvit_gemm_desc& p, f32x4 (&acc)[BM / (16 * WM)][BN / (16 * WN)], char* smem_raw, int m0, int n0,
                                               int z) {
     constexpr int WTM = BM / WM, WTN = BN / WN;
@@ -167,10 +169,16 @@ __device__ __forceinline__ void gemm_epilogue(const esvit_gemm_desc& p, f32x4 (&
 #pragma unroll
         for (int il = 0; il < FPP; ++il)
 #pragma unroll
-            for (int j = 0; j < FN; ++j)
+            for (int j = 0; j < FN; ++j) {
+                if constexpr (TR) {
+                    static_assert(!TR || !SWZ, "transposed staging uses the padded rows");
+                    *reinterpret_cast<f32x4*>(stage + (il * 16 + c) * LDE + j * 16 + 4 * g) = acc[FPP * ps + il][j] * alpha;
+                } else {
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    stage[(il * 16 + 4 * g + r) * LDE + ((j * 16 + c) ^ (SWZ ? (g << 4) : 0))] = acc[FPP * ps + il][j][r] * alpha;
+                    for (int r = 0; r < 4; ++r)
+                        stage[(il * 16 + 4 * g + r) * LDE + ((j * 16 + c) ^ (SWZ ? (g << 4) : 0))] = acc[FPP * ps + il][j][r] * alpha;
+                }
+            }
         __builtin_amdgcn_wave_barrier();
     };
     auto read_item = [&](int row_l, int cg, float (&v)[8]) {
@@ -366,79 +374,70 @@ __device__ __forceinline__ void gemm_epilogue(const esvit_gemm_desc& p, f32x4 (&
     });
 }
 
-// ---- lean epilogue for the common case ----
-// The GEMM kernels of this path are VALU-bound, not MFMA-bound (profiles/r01_gemm_sq_counters.txt: ~9 VALU
-// instructions per MFMA before this path existed, most of them epilogue address arithmetic, predicates and wait
-// states).  For a FULL interior tile with vector-aligned operands the epilogue below is straight-line code per kind:
-// lane offsets are computed once per tile, staging uses immediate LDS offsets, there are no per-element predicates,
-// and -- because there are no branches -- the compiler's own vmcnt bookkeeping is exact, so the per-element inputs
-// requested one pass ahead never wait for the stores issued after them.
+// ---- direct epilogue of the LDS-DMA kernels: no LDS staging ----
+// Those kernels issue every MFMA with the operands SWAPPED (the weight-side fragment in the A slot, the activation-side one
+// in the B slot), which costs nothing in the main loop -- both fragments are "row c, k = 8g .. 8g+7" reads -- and leaves
+// the TRANSPOSE of the usual accumulator layout behind:
+//     acc[i][j][r] = C[row 16 i + c][column 16 j + 4 g + r]          (lane = 16 g + c)
+// i.e. four CONSECUTIVE columns of one row per lane.  fp32 outputs, the fp32 residual and the bias are therefore plain 16-byte
+// vectors straight from / to the accumulators (four lane groups = 64 contiguous bytes of a row); bf16 outputs pack two column
+// blocks to 2 x 2 dwords and exchange one pair between the lane groups g and g ^ 1 (v_permlane16_swap), after which every lane
+// holds eight consecutive columns = one 16-byte store.  The LDS round trip of the staged epilogue (64 ds_write_b32 + 16
+// ds_read_b128 per 64 x 64 wave tile, plus its address arithmetic) is gone -- the GEMMs of this path are short-K and were
+// bound by exactly that (profiles/r01_gemm_sq_counters.txt: ~9 VALU instructions per MFMA, most of them epilogue).
+// Straight-line code per kind for a FULL interior tile with vector-aligned operands; everything else takes gemm_epilogue<TR>.
+// Inputs of row block i+1 (residual / GELU pre-activation) are requested before the stores of row block i: vmcnt retires in order.
 enum { EK_PLAIN = 0, EK_GELU = 1, EK_RES = 2, EK_GELU_BWD = 3 };
 
+__device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    const bf16x2_t v = {(bf16)a, (bf16)b};
+    return __builtin_bit_cast(unsigned, v);
+}
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+
+// four columns (block j) | four columns (block j + 1) of one row per lane -> eight consecutive columns per lane:
+// even g: block j, columns 4g .. 4g+7;  odd g: block j + 1, columns 4(g-1) .. 4(g-1)+7
+__device__ __forceinline__ u32x4_t pair_rows(const f32x4& x, const f32x4& y) {
+    const unsigned x0 = pack_bf16x2(x[0], x[1]), x1 = pack_bf16x2(x[2], x[3]);
+    const unsigned y0 = pack_bf16x2(y[0], y[1]), y1 = pack_bf16x2(y[2], y[3]);
+    const u32x2_t s0 = __builtin_amdgcn_permlane16_swap(x0, y0, false, false);
+    const u32x2_t s1 = __builtin_amdgcn_permlane16_swap(x1, y1, false, false);
+    return u32x4_t{s0[0], s1[0], s0[1], s1[1]};
+}
+
+// bf16 row block: v[j] = this lane's four columns of block j -> dst (the lane's row, at the wave tile's first column)
+template <int FN>
+__device__ __forceinline__ void store_row_bf16(bf16* dst, const f32x4 (&v)[FN], int g) {
+    const int pc = 16 * (g & 1) + 4 * (g & ~1);  // column of the lane's 8-vector inside a block pair
+#pragma unroll
+    for (int j = 0; j + 1 < FN; j += 2) *reinterpret_cast<u32x4_t*>(dst + 16 * j + pc) = pair_rows(v[j], v[j + 1]);
+    if constexpr (FN & 1)
+        *reinterpret_cast<u32x2_t*>(dst + 16 * (FN - 1) + 4 * g) = u32x2_t{pack_bf16x2(v[FN - 1][0], v[FN - 1][1]), pack_bf16x2(v[FN - 1][2], v[FN - 1][3])};
+}
+
 template <int BM, int BN, int WM, int WN, int KIND, bool OUTF32, bool RS = false>
-__device__ __forceinline__ void epilogue_fast(const esvit_gemm_desc& p, f32x4 (&acc)[BM / (16 * WM)][BN / (16 * WN)], float* stage, int m0, int n0,
-                                              void* Cbase, long ldc, long c_first, const float* bias) {
+__device__ __forceinline__ void epilogue_direct(const esvit_gemm_desc& p, f32x4 (&acc)[BM / (16 * WM)][BN / (16 * WN)], int m0, int n0, void* Cbase,
+                                                long ldc, long c_first, const float* bias) {
     constexpr int WTM = BM / WM, WTN = BN / WN;
-    constexpr bool SWZ = false;
     constexpr int FM = WTM / 16, FN = WTN / 16;
-    constexpr int SR = 16;
-    constexpr int LDE = SWZ ? WTN : WTN + 4;
-    constexpr int CG = WTN / 8;
-    constexpr int ITEMS = (SR * CG + 63) / 64;
-    constexpr int NP = FM;
-    constexpr bool RAGGED = (SR * CG) % 64 != 0;  // the last item of a pass covers only some lanes (96-wide tiles)
+    static_assert(!RS || (WTN == 64 && !OUTF32 && KIND == EK_PLAIN), "row statistics: 64-column wave tiles, plain bf16 epilogue");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane & 15, g = lane >> 4;
     const int wm = wave / WN, wn = wave % WN;
-    const int row_w = m0 + wm * WTM, col_w = n0 + wn * WTN;  // first row / column of the wave tile
+    const long row = m0 + wm * WTM + c;      // this lane's row of row block 0
+    const int col = n0 + wn * WTN + 4 * g;  // this lane's first column of column block 0
 
-    // staging write bases (floats): row 4g, column block j (XOR-swizzled with g when there is no room for a row pad)
-    int wbase[FN];
+    f32x4 bias_h[FN];
+    f32x4 cen_h[RS ? FN : 1];  // softmax statistics: centre * scale of the lane's columns
 #pragma unroll
-    for (int j = 0; j < FN; ++j) wbase[j] = 4 * g * LDE + (SWZ ? ((j ^ g) & (FN - 1)) * 16 + c : j * 16 + c);
-
-    // per item t (fixed over passes): staged row / column group, read offset, destination offsets
-    int rd_off[ITEMS];
-    long c_off[ITEMS], x_off[ITEMS];  // element offsets into C and into aux / residual for pass 0
-    bool live[ITEMS];
-    float bias_h[ITEMS][8];
-    float cen_h[RS ? ITEMS : 1][8];  // softmax statistics (RS): the centre of this item's eight columns
-    static_assert(!RS || (CG == 8 && !RAGGED && !OUTF32 && KIND == EK_PLAIN), "row statistics: 64-column wave tiles, plain bf16 epilogue");
-    static_for<ITEMS>([&](auto tc) {
-        constexpr int t = decltype(tc)::value;
-        const int id = lane + 64 * t;
-        const int row_l = id / CG, cg = id % CG;
-        live[t] = !RAGGED || id < SR * CG;
-        rd_off[t] = row_l * LDE + ((cg * 8) ^ (SWZ ? (((row_l >> 2) & 3) << 4) : 0));
-        const long row = row_w + row_l;
-        const int n = col_w + cg * 8;
-        c_off[t] = c_first + row * ldc + n;
-        x_off[t] = KIND == EK_RES ? row * p.ldr + n : row * p.ldaux + n;
+    for (int j = 0; j < FN; ++j) bias_h[j] = bias ? *reinterpret_cast<const f32x4*>(bias + col + 16 * j) : f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (RS) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) bias_h[t][e] = 0.f;
-        if (bias && live[t]) {
-            const f32x4 b0 = *reinterpret_cast<const f32x4*>(bias + n);
-            const f32x4 b1 = *reinterpret_cast<const f32x4*>(bias + n + 4);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                bias_h[t][e] = b0[e];
-                bias_h[t][4 + e] = b1[e];
-            }
-        }
-        if constexpr (RS) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) cen_h[t][e] = 0.f;
-            if (p.rowstat_center) {
-                const f32x4 c0 = *reinterpret_cast<const f32x4*>(p.rowstat_center + n);
-                const f32x4 c1 = *reinterpret_cast<const f32x4*>(p.rowstat_center + n + 4);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    cen_h[t][e] = c0[e];
-                    cen_h[t][4 + e] = c1[e];
-                }
-            }
-        }
-    });
+        for (int j = 0; j < FN; ++j)
+            cen_h[j] = p.rowstat_center ? *reinterpret_cast<const f32x4*>(p.rowstat_center + col + 16 * j) * p.rowstat_scale : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     if (p.alpha != 1.f) {
 #pragma unroll
         for (int i = 0; i < FM; ++i)
@@ -446,135 +445,117 @@ __device__ __forceinline__ void epilogue_fast(const esvit_gemm_desc& p, f32x4 (&
             for (int j = 0; j < FN; ++j) acc[i][j] *= p.alpha;
     }
     const bool quick = p.epilogue == ESVIT_EPI_QGELU || p.epilogue == ESVIT_EPI_QGELU_BWD;  // QuickGELU instead of erf-GELU
-    const long c_step = (long)SR * ldc;
-    const long x_step = (long)SR * (KIND == EK_RES ? p.ldr : p.ldaux);
+    const long c_step = 16 * ldc;
+    const long x_ld = KIND == EK_RES ? p.ldr : p.ldaux;
+    const long c_off = c_first + row * ldc + (col - 4 * g);  // the wave tile's first column in this lane's row
+    const long x_off = row * x_ld + col;
     bf16* auxp = reinterpret_cast<bf16*>(p.aux);
 
-    // inputs requested one pass ahead: residual (8 fp32) + DropPath scale, or the GELU pre-activation (8 bf16)
-    f32x4 in0[2][ITEMS], in1[2][ITEMS];
-    float rs[2][ITEMS];
-    auto load_in = [&](auto psc) {
-        constexpr int ps = decltype(psc)::value;
-        static_for<ITEMS>([&](auto tc) {
-            constexpr int t = decltype(tc)::value;
-            rs[ps & 1][t] = 1.f;
-            if (!live[t]) return;
-            if constexpr (KIND == EK_RES) {
-                const float* rp = p.residual + x_off[t] + ps * x_step;
-                in0[ps & 1][t] = *reinterpret_cast<const f32x4*>(rp);
-                in1[ps & 1][t] = *reinterpret_cast<const f32x4*>(rp + 4);
-                if (p.rowscale) rs[ps & 1][t] = p.rowscale[(row_w + ps * SR + (lane + 64 * t) / CG) / p.rows_per_sample];
-            } else if constexpr (KIND == EK_GELU_BWD) {
-                in0[ps & 1][t] = *reinterpret_cast<const f32x4*>(auxp + x_off[t] + ps * x_step);
-            }
-        });
+    // inputs of the next row block: residual (4 fp32 per block) + DropPath scale, or the GELU pre-activation (4 bf16 per block)
+    f32x4 in_r[2][KIND == EK_RES ? FN : 1];
+    u32x2_t in_a[2][KIND == EK_GELU_BWD ? FN : 1];
+    float rs[2] = {1.f, 1.f};
+    auto load_in = [&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        if constexpr (KIND == EK_RES) {
+            const float* rp = p.residual + x_off + 16 * i * x_ld;
+#pragma unroll
+            for (int j = 0; j < FN; ++j) in_r[i & 1][j] = *reinterpret_cast<const f32x4*>(rp + 16 * j);
+            if (p.rowscale) rs[i & 1] = p.rowscale[(row + 16 * i) / p.rows_per_sample];
+        } else if constexpr (KIND == EK_GELU_BWD) {
+            const bf16* ap = auxp + x_off + 16 * i * x_ld;
+#pragma unroll
+            for (int j = 0; j < FN; ++j) in_a[i & 1][j] = *reinterpret_cast<const u32x2_t*>(ap + 16 * j);
+        }
     };
     if constexpr (KIND == EK_RES || KIND == EK_GELU_BWD) load_in(std::integral_constant<int, 0>{});
 
-    static_for<NP>([&](auto psc) {
-        constexpr int ps = decltype(psc)::value;
-        __builtin_amdgcn_wave_barrier();
+    static_for<FM>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        if constexpr ((KIND == EK_RES || KIND == EK_GELU_BWD) && i + 1 < FM) load_in(std::integral_constant<int, i + 1>{});
+        f32x4 v[FN];
 #pragma unroll
-        for (int j = 0; j < FN; ++j)
+        for (int j = 0; j < FN; ++j) v[j] = acc[i][j] + bias_h[j];
+        if constexpr (KIND == EK_GELU) {
+            if (auxp) store_row_bf16<FN>(auxp + x_off - 4 * g + 16 * i * x_ld, v, g);
+            if (quick) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) stage[wbase[j] + r * LDE] = acc[ps][j][r];
-        __builtin_amdgcn_wave_barrier();
-        if constexpr ((KIND == EK_RES || KIND == EK_GELU_BWD) && ps + 1 < NP) load_in(std::integral_constant<int, ps + 1>{});
-        static_for<ITEMS>([&](auto tc) {
-            constexpr int t = decltype(tc)::value;
-            if (!live[t]) return;
-            float v[8];
-            {
-                const f32x4 lo = *reinterpret_cast<const f32x4*>(stage + rd_off[t]);
-                const f32x4 hi = *reinterpret_cast<const f32x4*>(stage + rd_off[t] + 4);
+                for (int j = 0; j < FN; ++j)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    v[e] = lo[e] + bias_h[t][e];
-                    v[4 + e] = hi[e] + bias_h[t][4 + e];
-                }
-            }
-            if constexpr (KIND == EK_GELU) {
-                if (auxp) {
-                    bf16x8 o;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
-                    *reinterpret_cast<bf16x8*>(auxp + x_off[t] + ps * x_step) = o;
-                }
-                if (quick) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = qgelu_f(v[e]);
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
-                }
-            } else if constexpr (KIND == EK_GELU_BWD) {
-                const bf16x8 x = __builtin_bit_cast(bf16x8, in0[ps & 1][t]);
-                if (quick) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] *= qgelu_grad_f((float)x[e]);
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] *= gelu_grad_f((float)x[e]);
-                }
-            } else if constexpr (KIND == EK_RES) {
-                const float s = rs[ps & 1][t];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    v[e] = v[e] * s + in0[ps & 1][t][e];
-                    v[4 + e] = v[4 + e] * s + in1[ps & 1][t][e];
-                }
-            }
-            if constexpr (OUTF32) {
-                float* cp = reinterpret_cast<float*>(Cbase) + c_off[t] + ps * c_step;
-                *reinterpret_cast<f32x4*>(cp) = f32x4{v[0], v[1], v[2], v[3]};
-                *reinterpret_cast<f32x4*>(cp + 4) = f32x4{v[4], v[5], v[6], v[7]};
+                    for (int e = 0; e < 4; ++e) v[j][e] = qgelu_f(v[j][e]);
             } else {
-                bf16x8 ov;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) ov[e] = (bf16)v[e];
-                *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(Cbase) + c_off[t] + ps * c_step) = ov;
-                if constexpr (RS) {
-                    // (max, sum 2^(z - max)) of this row's 64 columns: 8 columns here, then the 8 lanes that share the row
-                    float z[8];
-                    float m = -3.0e38f;
+                for (int j = 0; j < FN; ++j)
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        z[e] = ((float)ov[e] - cen_h[t][e]) * p.rowstat_scale;
-                        m = fmaxf(m, z[e]);
+                    for (int e = 0; e < 4; ++e) v[j][e] = gelu_f(v[j][e]);
+            }
+        } else if constexpr (KIND == EK_GELU_BWD) {
+            f32x4 x[FN];
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                const u32x2_t a = in_a[i & 1][j];
+                x[j] = f32x4{__builtin_bit_cast(float, a[0] << 16), __builtin_bit_cast(float, a[0] & 0xffff0000u),
+                             __builtin_bit_cast(float, a[1] << 16), __builtin_bit_cast(float, a[1] & 0xffff0000u)};
+            }
+            if (quick) {
+#pragma unroll
+                for (int j = 0; j < FN; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[j][e] *= qgelu_grad_f(x[j][e]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < FN; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[j][e] *= gelu_grad_f(x[j][e]);
+            }
+        } else if constexpr (KIND == EK_RES) {
+#pragma unroll
+            for (int j = 0; j < FN; ++j) v[j] = v[j] * rs[i & 1] + in_r[i & 1][j];
+        }
+        if constexpr (OUTF32) {
+            float* cp = reinterpret_cast<float*>(Cbase) + c_off + 4 * g + i * c_step;
+#pragma unroll
+            for (int j = 0; j < FN; ++j) *reinterpret_cast<f32x4*>(cp + 16 * j) = v[j];
+        } else {
+            store_row_bf16<FN>(reinterpret_cast<bf16*>(Cbase) + c_off + i * c_step, v, g);
+            if constexpr (RS) {
+                // (max, sum 2^(z - max)) over this row's 64 columns of z = (stored logit - centre) * scale: 16 columns here,
+                // then the four lane groups that share the row
+                float z[FN][4];
+                float m = -3.0e38f;
+#pragma unroll
+                for (int j = 0; j < FN; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        z[j][e] = fmaf((float)(bf16)v[j][e], p.rowstat_scale, -cen_h[j][e]);
+                        m = fmaxf(m, z[j][e]);
                     }
-                    float sum = 0.f;
+                m = fmaxf(m, __shfl_xor(m, 16, 64));
+                m = fmaxf(m, __shfl_xor(m, 32, 64));
+                float sum = 0.f;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) sum += __builtin_amdgcn_exp2f(z[e] - m);
+                for (int j = 0; j < FN; ++j)
 #pragma unroll
-                    for (int o = 1; o < 8; o <<= 1) {
-                        const float m2 = __shfl_xor(m, o, 64), s2 = __shfl_xor(sum, o, 64);
-                        const float mm = fmaxf(m, m2);
-                        sum = sum * __builtin_amdgcn_exp2f(m - mm) + s2 * __builtin_amdgcn_exp2f(m2 - mm);
-                        m = mm;
-                    }
-                    const int id = lane + 64 * t;
-                    if ((id & 7) == 0) {
-                        const long row = row_w + ps * SR + id / CG;
-                        float* sp = p.rowstat + (row * (p.N >> 6) + (col_w >> 6)) * 2;
-                        *reinterpret_cast<f32x2*>(sp) = f32x2{m, sum};
-                    }
+                    for (int e = 0; e < 4; ++e) sum += __builtin_amdgcn_exp2f(z[j][e] - m);
+                sum += __shfl_xor(sum, 16, 64);
+                sum += __shfl_xor(sum, 32, 64);
+                if (g == 0) {
+                    float* sp = p.rowstat + ((row + 16 * i) * (p.N >> 6) + ((n0 + wn * WTN) >> 6)) * 2;
+                    *reinterpret_cast<f32x2*>(sp) = f32x2{m, sum};
                 }
             }
-        });
+        }
     });
 }
 
-// bf16 kernels: pick the lean epilogue when the tile and the operands allow it, else the general one
+// LDS-DMA kernels: the direct epilogue when the tile and the operands allow it, else the general (staged) one
 template <int BM, int BN, int WM, int WN>
 __device__ __forceinline__ void gemm_epilogue_bf16(const esvit_gemm_desc& p, f32x4 (&acc)[BM / (16 * WM)][BN / (16 * WN)], char* smem_raw, int m0, int n0,
                                                    int z) {
-    constexpr int WTN = BN / WN;
-    constexpr int LDE = WTN + 4;
     auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
     if (p.splitk > 1 && m0 + BM <= p.M && n0 + BN <= p.N && (p.N % 4 == 0) && al16(p.partial)) {
         // split-K partial of a full tile: a plain fp32 store into this slice's [M, N] plane
-        float* stage = reinterpret_cast<float*>(smem_raw) + (threadIdx.x >> 6) * (16 * LDE);
-        epilogue_fast<BM, BN, WM, WN, EK_PLAIN, true>(p, acc, stage, m0, n0, p.partial + (long)z * p.M * p.N, p.N, 0, nullptr);
+        epilogue_direct<BM, BN, WM, WN, EK_PLAIN, true>(p, acc, m0, n0, p.partial + (long)z * p.M * p.N, p.N, 0, nullptr);
         return;
     }
     bool fast = p.splitk <= 1 && !p.rowmap && m0 + BM <= p.M && n0 + BN <= p.N && (p.ldc % 8 == 0) && al16(p.C) &&
@@ -593,24 +574,24 @@ __device__ __forceinline__ void gemm_epilogue_bf16(const esvit_gemm_desc& p, f32
         fast = fast && !p.rowscale;
     }
     if (!fast) {
-        gemm_epilogue<bf16, BM, BN, WM, WN, 16>(p, acc, smem_raw, m0, n0, z);
+        __syncthreads();  // the staging regions alias the operand buffers: every wave is done reading them
+        gemm_epilogue<bf16, BM, BN, WM, WN, 16, true>(p, acc, smem_raw, m0, n0, z);
         return;
     }
-    float* stage = reinterpret_cast<float*>(smem_raw) + (threadIdx.x >> 6) * (16 * LDE);
-    if (kind == EK_GELU) epilogue_fast<BM, BN, WM, WN, EK_GELU, false>(p, acc, stage, m0, n0, p.C, p.ldc, (long)z * p.strideC, p.bias);
+    if (kind == EK_GELU) epilogue_direct<BM, BN, WM, WN, EK_GELU, false>(p, acc, m0, n0, p.C, p.ldc, (long)z * p.strideC, p.bias);
     else if (kind == EK_GELU_BWD) {
-        if (p.out_f32) epilogue_fast<BM, BN, WM, WN, EK_GELU_BWD, true>(p, acc, stage, m0, n0, p.C, p.ldc, (long)z * p.strideC, p.bias);
-        else epilogue_fast<BM, BN, WM, WN, EK_GELU_BWD, false>(p, acc, stage, m0, n0, p.C, p.ldc, (long)z * p.strideC, p.bias);
+        if (p.out_f32) epilogue_direct<BM, BN, WM, WN, EK_GELU_BWD, true>(p, acc, m0, n0, p.C, p.ldc, (long)z * p.strideC, p.bias);
+        else epilogue_direct<BM, BN, WM, WN, EK_GELU_BWD, false>(p, acc, m0, n0, p.C, p.ldc, (long)z * p.strideC, p.bias);
     } else if (kind == EK_RES) {
-        if (p.out_f32) epilogue_fast<BM, BN, WM, WN, EK_RES, true>(p, acc, stage, m0, n0, p.C, p.ldc, (long)z * p.strideC, p.bias);
-        else epilogue_fast<BM, BN, WM, WN, EK_RES, false>(p, acc, stage, m0, n0, p.C, p.ldc, (long)z * p.strideC, p.bias);
+        if (p.out_f32) epilogue_direct<BM, BN, WM, WN, EK_RES, true>(p, acc, m0, n0, p.C, p.ldc, (long)z * p.strideC, p.bias);
+        else epilogue_direct<BM, BN, WM, WN, EK_RES, false>(p, acc, m0, n0, p.C, p.ldc, (long)z * p.strideC, p.bias);
     } else {
-        if (p.out_f32) epilogue_fast<BM, BN, WM, WN, EK_PLAIN, true>(p, acc, stage, m0, n0, p.C, p.ldc, (long)z * p.strideC, p.bias);
-        else if constexpr (BN / WN == 64 && BM == 128) {
-            if (p.rowstat) epilogue_fast<BM, BN, WM, WN, EK_PLAIN, false, true>(p, acc, stage, m0, n0, p.C, p.ldc, (long)z * p.strideC, p.bias);
-            else epilogue_fast<BM, BN, WM, WN, EK_PLAIN, false>(p, acc, stage, m0, n0, p.C, p.ldc, (long)z * p.strideC, p.bias);
+        if (p.out_f32) epilogue_direct<BM, BN, WM, WN, EK_PLAIN, true>(p, acc, m0, n0, p.C, p.ldc, (long)z * p.strideC, p.bias);
+        else if constexpr (BN / WN == 64) {
+            if (p.rowstat) epilogue_direct<BM, BN, WM, WN, EK_PLAIN, false, true>(p, acc, m0, n0, p.C, p.ldc, (long)z * p.strideC, p.bias);
+            else epilogue_direct<BM, BN, WM, WN, EK_PLAIN, false>(p, acc, m0, n0, p.C, p.ldc, (long)z * p.strideC, p.bias);
         } else {
-            epilogue_fast<BM, BN, WM, WN, EK_PLAIN, false>(p, acc, stage, m0, n0, p.C, p.ldc, (long)z * p.strideC, p.bias);
+            epilogue_direct<BM, BN, WM, WN, EK_PLAIN, false>(p, acc, m0, n0, p.C, p.ldc, (long)z * p.strideC, p.bias);
         }
     }
 }
@@ -748,8 +729,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const esvit_gemm_desc
     }
 
     if (do_colsum) store_colsum<FM>(p, accb, m0, wm * WTM, z, c, g);
-    if constexpr (sizeof(T) == 2) gemm_epilogue_bf16<BM, BN, 2, 2>(p, acc, smem_raw, m0, n0, z);
-    else gemm_epilogue<T, BM, BN, 2, 2>(p, acc, smem_raw, m0, n0, z);
+    gemm_epilogue<T, BM, BN, 2, 2>(p, acc, smem_raw, m0, n0, z);
 }
 
 // =================================================================================================
@@ -1011,7 +991,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINB) void gemm_dma_kernel(const esvi
 #pragma unroll
                 for (int i = 0; i < FM; ++i)
 #pragma unroll
-                    for (int j = 0; j < FN; ++j) mma(af[kk][i], bfr[kk][j], acc[i][j]);
+                    for (int j = 0; j < FN; ++j) mma(bfr[kk][j], af[kk][i], acc[i][j]);  // operands swapped: see epilogue_direct
                 if constexpr (AKS) {
                     if (do_colsum) {
 #pragma unroll
@@ -1050,7 +1030,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINB) void gemm_dma_kernel(const esvi
     #pragma unroll
                 for (int i = 0; i < FM; ++i)
     #pragma unroll
-                    for (int j = 0; j < FN; ++j) mma(af[i], bfr[j], acc[i][j]);
+                    for (int j = 0; j < FN; ++j) mma(bfr[j], af[i], acc[i][j]);  // operands swapped: see epilogue_direct
                 if constexpr (AKS) {  // the fused bias gradient exists for wgrad only: no branch in the fwd / dgrad loops
                     if (do_colsum) {
     #pragma unroll
@@ -1061,12 +1041,11 @@ __global__ __launch_bounds__(64 * WM * WN, MINB) void gemm_dma_kernel(const esvi
             buf = (buf + 1 == NBUF) ? 0 : buf + 1;
         }
 }
-    __syncthreads();  // all waves finished reading the operand tiles before the epilogue reuses the LDS
     ESVIT_TL(1);
     if constexpr (AKS) {
         if (do_colsum) store_colsum<FM>(p, accb, m0, wm * WTM, z, c, g);
     }
-    gemm_epilogue_bf16<BM, BN, WM, WN>(p, acc, smem_raw, m0, n0, z);
+    gemm_epilogue_bf16<BM, BN, WM, WN>(p, acc, smem_raw, m0, n0, z);  // (the staged fallback barriers before it reuses the LDS)
     ESVIT_TL(2);
 }
 
