@@ -975,6 +975,9 @@ __global__ __launch_bounds__(64 * WM * WN, MINB) void gemm_dma_kernel(const esvi
             const bf16* a_lds = reinterpret_cast<const bf16*>(sA + b * A_BYTES);
             const bf16* b_lds = reinterpret_cast<const bf16*>(sB + b * B_BYTES);
             Frag<bf16> af[KK][FM], bfr[KK][FN];
+#ifdef ESVIT_PROBE_SKIP_FRAG  // tools/probe only: the loop without its LDS reads (fragments of k-tile 0 only) -- what the DMA path alone sustains
+            if (kt == 0)
+#endif
 #pragma unroll
             for (int kk = 0; kk < KK; ++kk) {
 #pragma unroll
@@ -986,6 +989,13 @@ __global__ __launch_bounds__(64 * WM * WN, MINB) void gemm_dma_kernel(const esvi
             __builtin_amdgcn_s_barrier();  // every wave holds its fragments: buffer b is free
             asm volatile("" ::: "memory");
             if (kt + 2 < nk) issue_tile(kt + 2, b);
+#ifdef ESVIT_PROBE_SKIP_MFMA  // tools/probe only: one MFMA column per k-tile instead of all
+#pragma unroll
+            for (int kk = 0; kk < KK; ++kk)
+#pragma unroll
+                for (int i = 0; i < FM; ++i) mma(bfr[kk][i % FN], af[kk][i], acc[i][i % FN]);
+            if (false)
+#endif
 #pragma unroll
             for (int kk = 0; kk < KK; ++kk) {
 #pragma unroll

@@ -25,9 +25,10 @@ def main():
     ap.add_argument("--layout", default="nt")
     ap.add_argument("--variant", type=int, default=6)
     ap.add_argument("--tile", type=int, nargs=2, default=[128, 128])
+    ap.add_argument("--lib", default="libgemm_probe.so", help="probe build (tools/probe/build.sh ablate: libgemm_probe_skip_mfma.so, ..._skip_mfma_skip_frag.so)")
     args = ap.parse_args()
     M, N, K = args.shape
-    lib = C.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "probe", "libgemm_probe.so"))
+    lib = C.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "probe", args.lib))
     bks = int(args.layout == "nn")
     A = (torch.randn((M, K), device=dev)).to(torch.bfloat16)
     B = (torch.randn((K, N) if bks else (N, K), device=dev) * 0.05).to(torch.bfloat16)
@@ -75,6 +76,17 @@ def main():
     res["cu_time_fractions"] = {"main+epilogue overlapped": both / tot, "two in main loop": mains2 / tot, "two in epilogue": epis2 / tot,
                                 "one in main loop only": one_main / tot, "one in epilogue only": one_epi / tot, "idle": idle / tot}
     res["wgs_per_cu_mean"] = float(np.mean([len(v) for v in per_cu.values()]))
+    # turnaround: with two workgroups resident per CU, the time between the end of a workgroup and the start stamp of the workgroup that
+    # takes its place (the k-th start on a CU, k >= 2, follows the (k-2)-th end)
+    gaps = []
+    for c, idx in per_cu.items():
+        s_sorted = np.sort(start[idx])
+        e_sorted = np.sort(end[idx])
+        for k in range(2, len(idx)):
+            gaps.append(s_sorted[k] - e_sorted[k - 2])
+    if gaps:
+        res["turnaround_us_mean_p10_p90"] = [float(np.mean(gaps)), float(np.percentile(gaps, 10)), float(np.percentile(gaps, 90))]
+    res["wg_lifetime_us_mean"] = float((end - start).mean())
     # first CU's first eight workgroups, for eyeballing
     c0 = sorted(per_cu)[0]
     res["example_cu"] = [[round(float(start[i]), 2), round(float(mid[i]), 2), round(float(end[i]), 2)] for i in sorted(per_cu[c0], key=lambda i: start[i])[:10]]
