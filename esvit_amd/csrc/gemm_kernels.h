@@ -921,7 +921,11 @@ __global__ __launch_bounds__(64 * WM * WN, MINB) void gemm_dma_kernel(const esvi
     // per-block descriptors: base at the tile's first row / column, so every byte offset fits 32 bits
     const long a_rows_total = AKS ? (long)K : (long)M;  // rows of the stored matrix
     const long b_rows_total = BKS ? (long)K : (long)N;
+#ifdef ESVIT_PROBE_A_RESIDENT  // tools/probe only: every row block reads the rows of row block 0 (an always-L2-resident A operand)
+    const bf16* a_base = A;
+#else
     const bf16* a_base = AKS ? A + m0 : A + (long)m0 * p.lda;
+#endif
     const bf16* b_base = BKS ? B + n0 : B + (long)n0 * p.ldb;
     const long a_left = ((AKS ? a_rows_total : a_rows_total - m0) * p.lda - (AKS ? m0 : 0)) * 2;
     const long b_left = ((BKS ? b_rows_total : b_rows_total - n0) * p.ldb - (BKS ? n0 : 0)) * 2;

@@ -7,7 +7,7 @@ here=$(cd "$(dirname "$0")" && pwd); root=$(cd "$here/../.." && pwd)
 echo built "$here/libgemm_probe.so"
 # ablations of the default main loop for tools/gemm_timeline.py --lib: without the MFMAs / without MFMAs and fragment reads
 if [ "$1" = "ablate" ]; then
-  for v in SKIP_MFMA "SKIP_MFMA -DESVIT_PROBE_SKIP_FRAG"; do
+  for v in SKIP_MFMA "SKIP_MFMA -DESVIT_PROBE_SKIP_FRAG" A_RESIDENT; do
     n=$(echo $v | tr -d ' ' | sed 's/-DESVIT_PROBE_/_/' | tr 'A-Z' 'a-z')
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-unused-result -DESVIT_PROBE_ONLY7 -DESVIT_PROBE_$v -I "$root/include" -I "$root/esvit_amd/csrc" \
         -x hip "$here/gemm_probe.hip" -o "$here/libgemm_probe_$n.so"

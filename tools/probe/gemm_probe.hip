@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256, 2) void l2_stream_kernel(const char* __restric
 // ranges of consecutive workgroups (0: all workgroups read the same rows = cache resident).
 template <int MODE, int DEPTH>
 __global__ __launch_bounds__(256, 2) void inflight_kernel(const char* __restrict__ src, long pitch, int ktiles, int row_blocks, long wg_stride_rows,
-                                                          float* __restrict__ sink) {
+                                                          float* __restrict__ sink, int order) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     typedef __attribute__((address_space(3))) void lds_void;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -123,7 +123,14 @@ __global__ __launch_bounds__(256, 2) void inflight_kernel(const char* __restrict
         // per wave: 4 instructions per tile; instruction q covers rows (wave * 4 + q) * 8 .. +7, lane: row l / 8, 16-byte piece l % 8
         int voff[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) voff[q] = (int)(((wave * 4 + q) * 8 + lane / 8) * pitch + (lane % 8) * 16);
+        for (int q = 0; q < 4; ++q) {
+            const int row = (wave * 4 + q) * 8 + lane / 8;
+            int ch = lane % 8;  // 16-byte piece of the row's 128-byte line this lane fetches
+            if (order == 1) ch ^= row & 7;              // the GEMM's XOR swizzle (sw_kc)
+            else if (order == 2) ch = (ch + row) & 7;   // rotation: ascending with one wrap
+            else if (order == 3) ch ^= (row >> 1) & 3;  // XOR confined to 64-byte halves... (pairs of lanes stay adjacent)
+            voff[q] = (int)(row * pitch + ch * 16);
+        }
         auto issue = [&](int t) {
             const int so = tile_off(t);
             char* dst = lds + (t % DEPTH) * 16384;
@@ -177,18 +184,19 @@ __global__ __launch_bounds__(256, 2) void inflight_kernel(const char* __restrict
 }
 
 template <int MODE, int DEPTH>
-static int launch_inflight(const void* src, long pitch, int ktiles, int row_blocks, long wg_stride_rows, int wgs, float* sink, hipStream_t stream) {
+static int launch_inflight(const void* src, long pitch, int ktiles, int row_blocks, long wg_stride_rows, int wgs, float* sink, hipStream_t stream, int order) {
     auto kern = inflight_kernel<MODE, DEPTH>;
     const int lds = MODE == 0 ? DEPTH * 16384 : 0;
     if (lds) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    hipLaunchKernelGGL(kern, dim3(wgs), dim3(256), lds, stream, (const char*)src, pitch, ktiles, row_blocks, wg_stride_rows, sink);
+    hipLaunchKernelGGL(kern, dim3(wgs), dim3(256), lds, stream, (const char*)src, pitch, ktiles, row_blocks, wg_stride_rows, sink, order);
     return (int)hipGetLastError();
 }
 
+// order (LDS-DMA mode): which 16-byte piece of its row's line a lane fetches -- 0 ascending, 1 the GEMM's XOR swizzle, 2 rotation, 3 XOR of piece pairs
 extern "C" int probe_inflight(int mode, int depth, const void* src, long pitch, int ktiles, int row_blocks, long wg_stride_rows, int wgs, float* sink,
-                              void* stream_) {
+                              void* stream_, int order) {
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
-#define CASE(M_, D_) if (mode == M_ && depth == D_) return launch_inflight<M_, D_>(src, pitch, ktiles, row_blocks, wg_stride_rows, wgs, sink, stream);
+#define CASE(M_, D_) if (mode == M_ && depth == D_) return launch_inflight<M_, D_>(src, pitch, ktiles, row_blocks, wg_stride_rows, wgs, sink, stream, order);
     CASE(0, 1) CASE(0, 2) CASE(0, 3) CASE(0, 4) CASE(0, 5)
     CASE(1, 1) CASE(1, 2) CASE(1, 4) CASE(1, 6) CASE(1, 8) CASE(1, 12)
 #undef CASE
