@@ -68,7 +68,7 @@ def build(dev, drop_path, arch="swin_tiny_w7"):
         for p in teacher.parameters():
             p.requires_grad = False
         return student, teacher, esvit_amd.DDINOLoss(OUT_DIM, 10, 0.04, 0.04, 0, 100).to(dev)
-    cfg = CFG.model_config(arch, DROP_PATH_RATE=drop_path)
+    cfg = CFG.model_config(arch, DROP_PATH=drop_path) if arch.startswith("vil_") else CFG.model_config(arch, DROP_PATH_RATE=drop_path)
     student = esvit_amd.build_model(cfg, use_dense_prediction=True)
     student.head = esvit_amd.DINOHead(student.num_features, OUT_DIM)
     student.head_dense = esvit_amd.DINOHead(student.num_features, OUT_DIM)
@@ -266,7 +266,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=128, help="images per GPU (BASELINE.json configs 3/4: 1024 over 8 GPUs)")
     ap.add_argument("--drop-path", type=float, default=0.1)
-    ap.add_argument("--arch", default="swin_tiny_w7", choices=["swin_tiny_w7", "swin_tiny_w14", "swin_base_w14", "swin_small_w7", "swin_base_w7", "cvt_s1", "deit_tiny", "deit_small", "vit_base"],
+    ap.add_argument("--arch", default="swin_tiny_w7", choices=["swin_tiny_w7", "swin_tiny_w14", "swin_base_w14", "swin_small_w7", "swin_base_w7", "cvt_s1", "deit_tiny", "deit_small", "vit_base", "vil_tiny", "vil_small"],
                     help="BASELINE.json's metric is quoted on swin_tiny_w7 (default); configs 3/4 are swin_tiny_w14 / swin_base_w14")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")

@@ -66,8 +66,23 @@ def cvt_config(name="cvt_s1", **spec_overrides):
     return CfgNode(cfg)
 
 
+# experiments/imagenet/vil/{vil_tiny,vil_small}/base.yaml (Vision Longformer; ARCH strings: esvit_amd/models/vision_longformer.py)
+VIL_MSVIT = dict(LN_EPS=1e-6, SHARE_W=True, ATTN_TYPE="longformerhand", SHARE_KV=True, ONLY_GLOBAL=False, SW_EXACT=0, MODE=0,
+                 VIL_MODE_SWITCH=0.5, POOL_METHOD=None, WITH_SE=None)
+
+
+def vil_config(name="vil_tiny", arch=None, **spec_overrides):
+    from .models.vision_longformer import VIL_SPECS
+    spec = dict(AVG_POOL=False, DROP=0.0, DROP_PATH=0.1, NORM_EMBED=True, MSVIT=dict(VIL_MSVIT, ARCH=arch or VIL_SPECS[name]))
+    spec.update(spec_overrides)
+    cfg = _merge(_DEFAULTS, dict(MODEL=dict(NAME="vision_longformer", SPEC=spec)))
+    return CfgNode(cfg)
+
+
 def model_config(name, **spec_overrides):
-    """named architecture -> config (swin_* -> swin_transformer, cvt_* -> cvt_v4_transformer)"""
+    """named architecture -> config (swin_* -> swin_transformer, cvt_* -> cvt_v4_transformer, vil_* -> vision_longformer)"""
+    if name.startswith("vil_"):
+        return vil_config(name, **spec_overrides)
     return cvt_config(name, **spec_overrides) if name in CVT_SPECS else swin_config(name, **spec_overrides)
 
 

@@ -55,27 +55,41 @@ __global__ __launch_bounds__(256) void heads_merge_kernel(const T* __restrict__ 
 
 constexpr int SM_MAX = 4;  // elements per lane: rows of up to 256 padded tokens
 
+// Vision Longformer's sliding-chunk neighbourhood (layers/slidingchunk_2d.py:268-287, exact = 0; layers/longformer2d.py:163-262) as a
+// predicate on token pairs: chunk[t] = -1 for a global token, else (chunk row << 16) | chunk column of the token's w x w chunk.  A
+// query sees every global token, and the local tokens of its own and the eight adjacent chunks; a global query sees everything.
+__device__ __forceinline__ bool chunk_allows(int ci, int cj) {
+    if ((ci | cj) < 0) return true;
+    const int dx = (ci >> 16) - (cj >> 16), dy = (ci & 0xffff) - (cj & 0xffff);
+    return dx >= -1 && dx <= 1 && dy >= -1 && dy <= 1;
+}
+
 // one wave per row of the [rows = batch * Np, Np] score matrices, in place: P = softmax(scale * S[:, :N]), zero elsewhere
+// (chunk != nullptr: only over the keys chunk_allows admits)
 template <typename T>
-__global__ __launch_bounds__(256) void softmax_rows_fwd_kernel(T* __restrict__ s, long rows, int N, int Np, float scale) {
+__global__ __launch_bounds__(256) void softmax_rows_fwd_kernel(T* __restrict__ s, long rows, int N, int Np, float scale, const int* __restrict__ chunk) {
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int lane = threadIdx.x & 63;
     T* p = s + row * Np;
-    const bool live = (int)(row % Np) < N;
+    const int qi = (int)(row % Np);
+    const bool live = qi < N;
+    const int ci = (chunk && live) ? chunk[qi] : -1;
     float v[SM_MAX];
+    bool ok[SM_MAX];
     float m = -INFINITY;
 #pragma unroll
     for (int k = 0; k < SM_MAX; ++k) {
         const int j = lane + 64 * k;
-        v[k] = (live && j < N) ? scale * to_f32(p[j]) : -INFINITY;
+        ok[k] = live && j < N && (!chunk || chunk_allows(ci, chunk[j]));
+        v[k] = ok[k] ? scale * to_f32(p[j]) : -INFINITY;
         m = fmaxf(m, v[k]);
     }
     m = wave_max(m);
     float sum = 0.f;
 #pragma unroll
     for (int k = 0; k < SM_MAX; ++k) {
-        v[k] = (live && lane + 64 * k < N) ? __expf(v[k] - m) : 0.f;
+        v[k] = ok[k] ? __expf(v[k] - m) : 0.f;
         sum += v[k];
     }
     sum = wave_sum(sum);
@@ -117,22 +131,27 @@ __global__ __launch_bounds__(256) void softmax_rows_bwd_kernel(const T* __restri
 // rows longer than 256 padded tokens (patch_size 8: 785 tokens at 224^2; evaluation on larger images): the same arithmetic in
 // passes over the row instead of registers (the row stays in the L2 between the passes)
 template <typename T>
-__global__ __launch_bounds__(256) void softmax_rows_fwd_long_kernel(T* __restrict__ s, long rows, int N, int Np, float scale) {
+__global__ __launch_bounds__(256) void softmax_rows_fwd_long_kernel(T* __restrict__ s, long rows, int N, int Np, float scale, const int* __restrict__ chunk) {
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int lane = threadIdx.x & 63;
     T* p = s + row * Np;
-    const bool live = (int)(row % Np) < N;
+    const int qi = (int)(row % Np);
+    const bool live = qi < N;
+    const int ci = (chunk && live) ? chunk[qi] : -1;
+    auto ok = [&](int j) { return !chunk || chunk_allows(ci, chunk[j]); };
     float m = -INFINITY;
     if (live)
-        for (int j = lane; j < N; j += 64) m = fmaxf(m, scale * to_f32(p[j]));
+        for (int j = lane; j < N; j += 64)
+            if (ok(j)) m = fmaxf(m, scale * to_f32(p[j]));
     m = wave_max(m);
     float sum = 0.f;
     if (live)
-        for (int j = lane; j < N; j += 64) sum += __expf(scale * to_f32(p[j]) - m);
+        for (int j = lane; j < N; j += 64)
+            if (ok(j)) sum += __expf(scale * to_f32(p[j]) - m);
     sum = wave_sum(sum);
     const float inv = live ? 1.f / sum : 0.f;
-    for (int j = lane; j < Np; j += 64) p[j] = from_f32<T>((live && j < N) ? __expf(scale * to_f32(p[j]) - m) * inv : 0.f);
+    for (int j = lane; j < Np; j += 64) p[j] = from_f32<T>((live && j < N && ok(j)) ? __expf(scale * to_f32(p[j]) - m) * inv : 0.f);
 }
 
 template <typename T>
@@ -183,22 +202,33 @@ extern "C" int esvit_heads_merge(int dtype, const void* y, int B, int N, int Np,
     return ESVIT_OK;
 }
 
-extern "C" int esvit_softmax_rows_fwd(int dtype, void* s, int64_t batch, int N, int Np, float scale, esvit_stream_t stream_) {
-    STREAM(stream_);
+static int softmax_rows_fwd_impl(int dtype, void* s, int64_t batch, int N, int Np, float scale, const int32_t* chunk, hipStream_t stream) {
     ESVIT_CHECK_ARG(s && batch > 0 && N > 0 && Np >= N, "esvit_softmax_rows_fwd: bad arguments");
     const long rows = batch * Np;
+    const dim3 grid((unsigned)((rows + 3) / 4));
     if (Np > 64 * SM_MAX) {
-        if (dtype == ESVIT_BF16) hipLaunchKernelGGL(softmax_rows_fwd_long_kernel<bf16>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, (bf16*)s, rows, N, Np, scale);
-        else if (dtype == ESVIT_F32) hipLaunchKernelGGL(softmax_rows_fwd_long_kernel<float>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, (float*)s, rows, N, Np, scale);
+        if (dtype == ESVIT_BF16) hipLaunchKernelGGL(softmax_rows_fwd_long_kernel<bf16>, grid, dim3(256), 0, stream, (bf16*)s, rows, N, Np, scale, chunk);
+        else if (dtype == ESVIT_F32) hipLaunchKernelGGL(softmax_rows_fwd_long_kernel<float>, grid, dim3(256), 0, stream, (float*)s, rows, N, Np, scale, chunk);
         else ESVIT_CHECK_ARG(false, "esvit_softmax_rows_fwd: bad dtype %d", dtype);
         ESVIT_CHECK_LAUNCH("softmax_rows_fwd");
         return ESVIT_OK;
     }
-    if (dtype == ESVIT_BF16) hipLaunchKernelGGL(softmax_rows_fwd_kernel<bf16>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, (bf16*)s, rows, N, Np, scale);
-    else if (dtype == ESVIT_F32) hipLaunchKernelGGL(softmax_rows_fwd_kernel<float>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, (float*)s, rows, N, Np, scale);
+    if (dtype == ESVIT_BF16) hipLaunchKernelGGL(softmax_rows_fwd_kernel<bf16>, grid, dim3(256), 0, stream, (bf16*)s, rows, N, Np, scale, chunk);
+    else if (dtype == ESVIT_F32) hipLaunchKernelGGL(softmax_rows_fwd_kernel<float>, grid, dim3(256), 0, stream, (float*)s, rows, N, Np, scale, chunk);
     else ESVIT_CHECK_ARG(false, "esvit_softmax_rows_fwd: bad dtype %d", dtype);
     ESVIT_CHECK_LAUNCH("softmax_rows_fwd");
     return ESVIT_OK;
+}
+
+extern "C" int esvit_softmax_rows_fwd(int dtype, void* s, int64_t batch, int N, int Np, float scale, esvit_stream_t stream_) {
+    STREAM(stream_);
+    return softmax_rows_fwd_impl(dtype, s, batch, N, Np, scale, nullptr, stream);
+}
+
+extern "C" int esvit_softmax_rows_chunked_fwd(int dtype, void* s, int64_t batch, int N, int Np, float scale, const int32_t* chunk, esvit_stream_t stream_) {
+    STREAM(stream_);
+    ESVIT_CHECK_ARG(chunk != nullptr, "esvit_softmax_rows_chunked_fwd: the chunk table is required");
+    return softmax_rows_fwd_impl(dtype, s, batch, N, Np, scale, chunk, stream);
 }
 
 extern "C" int esvit_softmax_rows_bwd(int dtype, const void* p, void* dp, int64_t batch, int N, int Np, float scale, esvit_stream_t stream_) {

@@ -825,7 +825,8 @@ class ConvEmbedFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, src, geo, Wp, bp, g, b):
         o = ops_module()
-        nchw, nB, H, W, Cin, k, stride, pad = geo
+        nchw, nB, H, W, Cin, k, stride, pad = geo[:8]
+        eps = geo[8] if len(geo) > 8 else CVT_LN_EPS  # (Vision Longformer's patch embeddings: eps 1e-6)
         src = src.contiguous()
         if nchw:
             cols = o.conv_im2col(src, True, nB, H, W, Cin, k, stride, pad)
@@ -833,7 +834,7 @@ class ConvEmbedFn(torch.autograd.Function):
             cols = o.conv_im2col(o.gather_cast(src.view(nB * H * W, Cin), nB * H * W), False, nB, H, W, Cin, k, stride, pad)
         Wk = _conv_weight_matrix(Wp)
         y = o.linear_fwd(cols, Wk, bp, out_f32=True)
-        t, _, mean, rstd = o.layernorm_fwd(y, g, b, CVT_LN_EPS, dtype=torch.float32)
+        t, _, mean, rstd = o.layernorm_fwd(y, g, b, eps, dtype=torch.float32)
         ctx.geo = geo
         ctx.wshape = tuple(Wp.shape)
         ctx.save_for_backward(cols, Wk, y, mean, rstd, g)
@@ -844,7 +845,7 @@ class ConvEmbedFn(torch.autograd.Function):
     def backward(ctx, gt):
         o = ops_module()
         cols, Wk, y, mean, rstd, g = ctx.saved_tensors
-        nchw, nB, H, W, Cin, k, stride, pad = ctx.geo
+        nchw, nB, H, W, Cin, k, stride, pad = ctx.geo[:8]
         E = y.shape[1]
         dy, dg, db = o.layernorm_bwd(gt.contiguous().view(-1, E), y, mean, rstd, g)
         dyb = o.gather_cast(dy, dy.shape[0])
@@ -1156,6 +1157,117 @@ def vit_block_attention(x, nH, prm_list):
     _, att = o.vit_attn_fwd(qkv, nB, N, nH, (C // nH) ** -0.5)  # (evaluation hook: the batched-GEMM route keeps P in memory)
     p = att[-1]
     return p.reshape(nB, nH, p.shape[-2], p.shape[-1])[:, :, :N, :N].float()
+
+
+# ------------------------------------------------------------------------------------------------
+# Vision Longformer (models/vision_longformer.py:406-770): an AttnBlock followed by its MlpBlock is one autograd node, like a ViT
+# block.  'full' stages project with one qkv Linear (vision_longformer.py:36-118); 'longformerhand' stages (layers/longformer2d.py)
+# with `query` and `kv` Linears -- shared by local and global tokens (sharew) -- and restrict every local query to the global tokens
+# plus its own and the eight adjacent w x w chunks (`chunk`, esvit_softmax_rows_chunked_fwd).  rpe off (the ape = 1 default of
+# the reference's yaml files): no bias tables.
+# ------------------------------------------------------------------------------------------------
+def _vil_block_forward(x, nH, dp, chunk, prm, wts, save):
+    o = ops_module()
+    (g1, b1, bq, bkv, bproj, g2, b2, bfc1, bfc2) = prm
+    (Wq, Wkv, Wproj, W1, W2) = wts
+    nB, N, C = x.shape
+    x2d = x.view(nB * N, C)
+    scale = (C // nH) ** -0.5
+    dp1, dp2 = (None, None) if dp is None else dp
+    xw, _, mean1, rstd1 = o.layernorm_fwd(x2d, g1, b1, LN_EPS)
+    if Wkv is None:   # one qkv Linear
+        qkv, bqkv = o.linear_fwd(xw, Wq, bq), bq
+    else:             # query | kv Linears: the same [q | k | v] column layout (longformer2d.py:160-162)
+        qkv = torch.cat((o.linear_fwd(xw, Wq, bq), o.linear_fwd(xw, Wkv, bkv)), dim=1)
+        bqkv = torch.cat((bq.detach(), bkv.detach()))
+    if chunk is None:
+        ao, att = vit_attention(o, qkv, bqkv, nB, N, nH, scale, save)
+    else:
+        ao, att = o.vit_attn_fwd(qkv, nB, N, nH, scale, chunk=chunk)
+        att = att if save else ()
+    x1 = o.linear_fwd(ao, Wproj, bproj, residual=x2d, rowscale=dp1, rows_per_sample=N, out_f32=True)
+    h, _, mean2, rstd2 = o.layernorm_fwd(x1, g2, b2, LN_EPS)
+    if save:
+        a1g, a1 = o.linear_fwd(h, W1, bfc1, gelu=True, want_preact=True)
+    else:
+        a1g, a1 = o.linear_fwd(h, W1, bfc1, gelu=True), None
+    x2 = o.linear_fwd(a1g, W2, bfc2, residual=x1, rowscale=dp2, rows_per_sample=N, out_f32=True)
+    saved = (mean1, rstd1, xw, ao, x1, mean2, rstd2, h, a1, a1g, bqkv) if save else None
+    return x2.view(nB, N, C), saved, att
+
+
+class VilBlockFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, nH, dp, chunk, g1, b1, Wq_p, bq, Wkv_p, bkv, Wproj_p, bproj, g2, b2, W1_p, bfc1, W2_p, bfc2):
+        split = Wkv_p is not None
+        wts = (_weight(Wq_p), _weight(Wkv_p) if split else None, _weight(Wproj_p), _weight(W1_p), _weight(W2_p))
+        x = x.contiguous()
+        y, saved, att = _vil_block_forward(x, nH, dp, chunk, (g1, b1, bq, bkv, bproj, g2, b2, bfc1, bfc2), wts, True)
+        ctx.nH, ctx.dp, ctx.split, ctx.chunked = nH, dp, split, chunk is not None
+        ctx.wparams = (Wq_p, Wkv_p, Wproj_p, W1_p, W2_p)
+        ctx.bparams = (bq, bkv, bproj, bfc1, bfc2)
+        ctx.nparams = (g1, b1, g2, b2)
+        ctx.natt = len(att)
+        wsave = [w for w in wts if w is not None]
+        ctx.save_for_backward(x, g1, g2, *wsave, *saved, *att)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        o = ops_module()
+        nH, dp, split = ctx.nH, ctx.dp, ctx.split
+        t = list(ctx.saved_tensors)
+        x, g1, g2 = t[:3]
+        nw = 5 if split else 4
+        ws = t[3:3 + nw]
+        if split:
+            Wq, Wkv, Wproj, W1, W2 = ws
+        else:
+            (Wq, Wproj, W1, W2), Wkv = ws, None
+        mean1, rstd1, xw, ao, x1, mean2, rstd2, h, a1, a1g, bqkv = t[3 + nw:14 + nw]
+        att = tuple(t[14 + nw:14 + nw + ctx.natt])
+        nB, N, C = x.shape
+        M = nB * N
+        scale = (C // nH) ** -0.5
+        dp1, dp2 = (None, None) if dp is None else dp
+        gy = gy.contiguous().view(M, C)
+        Wq_p, Wkv_p, Wproj_p, W1_p, W2_p = ctx.wparams
+        bq_p, bkv_p, bproj_p, bfc1_p, bfc2_p = ctx.bparams
+        g1_p, b1_p, g2_p, b2_p = ctx.nparams
+        dyb = o.gather_cast(gy, M, rowscale=dp2, rows_per_sample=N)
+        dW2, dbfc2 = _wgrad(dyb, a1g, W2_p, want_bias=True, bias_param=bfc2_p)
+        da1 = o.linear_dgrad(dyb, W2, gelu_preact=a1)
+        dW1, dbfc1 = _wgrad(da1, h, W1_p, want_bias=True, bias_param=bfc1_p)
+        dh = o.linear_dgrad(da1, W1)
+        sink1, sink2 = _ln_sinks(g1_p, b1_p), _ln_sinks(g2_p, b2_p)
+        gx1, dyw, dg2, db2 = o.layernorm_bwd_cast(dh, x1, mean2, rstd2, g2, g_in=gy, rowscale=dp1, rows_per_sample=N, gb_out=sink2)
+        dWproj, dbproj = _wgrad(dyw, ao, Wproj_p, want_bias=True, bias_param=bproj_p)
+        dao = o.linear_dgrad(dyw, Wproj)
+        if ctx.chunked:
+            dqkv = o.vit_attn_bwd(dao, att, nB, N, nH, scale)
+        else:
+            dqkv = vit_attention_bwd(o, dao, att, bqkv, nB, N, nH, scale)
+        if split:
+            dq, dkv = dqkv[:, :C].contiguous(), dqkv[:, C:].contiguous()
+            dWq, dbq = _wgrad(dq, xw, Wq_p, want_bias=True, bias_param=bq_p)
+            dWkv, dbkv = _wgrad(dkv, xw, Wkv_p, want_bias=True, bias_param=bkv_p)
+            dxw = o.linear_dgrad(dqkv, torch.cat((Wq, Wkv), 0))  # dq Wq + dkv Wkv as one product over the stacked (tiny) weights
+        else:
+            dWq, dbq = _wgrad(dqkv, xw, Wq_p, want_bias=True, bias_param=bq_p)
+            dWkv, dbkv = None, None
+            dxw = o.linear_dgrad(dqkv, Wq)
+        gx, dg1, db1 = o.layernorm_bwd(dxw, x.view(M, C), mean1, rstd1, g1, g_in=gx1, gb_out=sink1)
+        return (gx.view(nB, N, C), None, None, None, _alias(dg1, sink1), _alias(db1, sink1), dWq, dbq, dWkv, dbkv, dWproj, dbproj,
+                _alias(dg2, sink2), _alias(db2, sink2), dW1, dbfc1, dW2, dbfc2)
+
+
+def vil_block(x, nH, dp, chunk, prm_list):
+    """prm_list = (norm.w, norm.b, Wq | Wqkv, bq | bqkv, Wkv | None, bkv | None, Wproj, bproj, norm2.w, norm2.b, W1, b1, W2, b2)"""
+    if not torch.is_grad_enabled() or not (x.requires_grad or any(p is not None and p.requires_grad for p in prm_list)):
+        g1, b1, Wq_p, bq, Wkv_p, bkv, Wproj_p, bproj, g2, b2, W1_p, bfc1, W2_p, bfc2 = prm_list
+        wts = (_weight(Wq_p), _weight(Wkv_p) if Wkv_p is not None else None, _weight(Wproj_p), _weight(W1_p), _weight(W2_p))
+        return _vil_block_forward(x.contiguous(), nH, dp, chunk, (g1, b1, bq, bkv, bproj, g2, b2, bfc1, bfc2), wts, False)[0]
+    return VilBlockFn.apply(x, nH, dp, chunk, *prm_list)
 
 
 # ---- ragged multi-crop ViT block: all crops of a step in ONE set of LayerNorm / GEMM launches (cf. SwinBlockMultiFn) ------------

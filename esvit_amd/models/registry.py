@@ -8,9 +8,12 @@ def register_model(fn):
     return fn
 
 
+_ALIASES = {"cls_vil": "vision_longformer"}  # experiments/imagenet/vil/vil_tiny/base.yaml names the model this way
+
+
 def model_entrypoints(model_name):
-    return _ENTRYPOINTS[model_name]
+    return _ENTRYPOINTS[_ALIASES.get(model_name, model_name)]
 
 
 def is_model(model_name):
-    return model_name in _ENTRYPOINTS
+    return _ALIASES.get(model_name, model_name) in _ENTRYPOINTS

@@ -958,14 +958,19 @@ def _bmm(a, b, M, N, K, *, a_kstrided=0, b_kstrided=0, out=None):
     return out
 
 
-def vit_attn_fwd(qkv, B, N, nH, scale):
+def vit_attn_fwd(qkv, B, N, nH, scale, chunk=None):
     """Attention.forward between the qkv and proj projections (vision_transformer.py:76-83): qkv [B * N, 3C] -> (out [B * N, C],
-    saved = (q | k | v [3, B nH, Np, hd], P [B nH, Np, Np]))"""
+    saved = (q | k | v [3, B nH, Np, hd], P [B nH, Np, Np])).  chunk (int32 [N]): Vision Longformer's sliding-chunk neighbourhood
+    (esvit_softmax_rows_chunked_fwd) instead of global attention."""
     C_ = qkv.shape[1] // 3
     hd, Np = C_ // nH, vit_pad_tokens(N)
     qkvh = heads_split(qkv, B, N, nH, 3).view(3, B * nH, Np, hd)
     prob = _bmm(qkvh[0], qkvh[1], Np, Np, hd)                                  # S = q k^T
-    check(lib.esvit_softmax_rows_fwd(_code(prob.dtype), _p(prob), B * nH, N, Np, float(scale), _stream()), "softmax_rows_fwd")
+    if chunk is not None:
+        assert chunk.dtype == torch.int32 and chunk.numel() == N and chunk.is_contiguous()
+        check(lib.esvit_softmax_rows_chunked_fwd(_code(prob.dtype), _p(prob), B * nH, N, Np, float(scale), _p(chunk), _stream()), "softmax_rows_chunked_fwd")
+    else:
+        check(lib.esvit_softmax_rows_fwd(_code(prob.dtype), _p(prob), B * nH, N, Np, float(scale), _stream()), "softmax_rows_fwd")
     o = _bmm(prob, qkvh[2], Np, hd, Np, b_kstrided=1)                          # O = P v
     return heads_merge(o.view(1, B, nH, Np, hd), N), (qkvh, prob)
 

@@ -435,6 +435,13 @@ int esvit_heads_split(int dtype, const void* x, int B, int N, int Np, int nH, in
 int esvit_heads_merge(int dtype, const void* y, int B, int N, int Np, int nH, int hd, int parts, void* x, esvit_stream_t stream);
 int esvit_softmax_rows_fwd(int dtype, void* s, int64_t batch, int N, int Np, float scale, esvit_stream_t stream);
 int esvit_softmax_rows_bwd(int dtype, const void* p, void* dp, int64_t batch, int N, int Np, float scale, esvit_stream_t stream);
+/* Vision Longformer's sliding-chunk attention (models/vision_longformer.py AttnBlock 'longformerhand' -> layers/longformer2d.py:138-262
+ * with layers/slidingchunk_2d.py, mode 0, exact 0, rpe off, shared global weights) on the same route: the row softmax restricted to
+ * the keys a query may see.  chunk int32 [N]: -1 for a global token, else (chunk row << 16) | chunk column of the token's w x w
+ * chunk; a query sees all global tokens and the local tokens of its own and the eight adjacent chunks (the reference's zero-padded
+ * and out-of-range positions are exactly the ones that do not exist here); a global query sees every token (longformer2d.py:310-327).
+ * Masked entries of P are zero, so esvit_softmax_rows_bwd needs no mask. */
+int esvit_softmax_rows_chunked_fwd(int dtype, void* s, int64_t batch, int N, int Np, float scale, const int32_t* chunk, esvit_stream_t stream);
 
 #pragma GCC visibility pop
 #ifdef __cplusplus

@@ -522,42 +522,66 @@ def _yaml_config(path):
     return RL.AttrDict(MODEL=model, TRAIN=dict(IMAGE_SIZE=[224, 224]), FINETUNE=dict(FINETUNE=False, FROZEN_LAYERS=[]), VERBOSE=False)
 
 
+def _full_cfg_case(ns, name, c):
+    torch.manual_seed(0)
+    cfg = _yaml_config(c["yaml"])
+    if c["arch"].startswith("vil_"):
+        # vil_tiny/base.yaml names the model 'cls_vil' (the registry key is the module name) and leaves out the optional MSVIT keys
+        # get_cls_model reads (vision_longformer.py:755-786); DROP_PATH is this family's stochastic-depth key
+        cfg["MODEL"]["NAME"] = "vision_longformer"   # (item access: attribute access hands out copies)
+        spec = cfg["MODEL"]["SPEC"]
+        spec["DROP_PATH"] = 0.0
+        spec["MSVIT"] = dict(dict(POOL_METHOD=None, WITH_SE=None, SE_MLP_RATIO=0.625, SE_MLP_BALANCE=False), **spec["MSVIT"])
+        for k in ("POOL_METHOD", "WITH_SE"):
+            if spec["MSVIT"][k] == "None":
+                spec["MSVIT"][k] = None
+    K, B = c["K"], c["B"]
+    student = ns.models.build_model(cfg, is_teacher=False, use_dense_prediction=True)
+    teacher = ns.models.build_model(cfg, is_teacher=True, use_dense_prediction=True)
+    fea = student.num_features if hasattr(student, "num_features") else (student.out_planes if hasattr(student, "out_planes") else cfg.MODEL.SPEC.DIM_EMBED[-1])
+    student.head, teacher.head = ns.DINOHead(fea, K), ns.DINOHead(fea, K)
+    student.head_dense, teacher.head_dense = ns.DINOHead(fea, K), ns.DINOHead(fea, K)
+    GU.fill_full_cfg_pair(student, teacher, c)
+    crops = GU.make_crops(B, seed=c["crop_seed"])
+    loss_fn = ns.DDINOLoss(K, 10, 0.04, 0.04, 0, 1)
+    with torch.no_grad():
+        t_out = teacher(crops[:2])
+    s_out = student(crops)
+    loss = loss_fn(s_out, t_out, 0, None)
+    loss.backward()
+    names = [n for n, p in student.named_parameters() if p.requires_grad]
+    prm = dict(student.named_parameters())
+    n = GU.FULL_CFG_SAMPLE
+    g = {"loss": loss.item(), "grad_norm": {k: prm[k].grad.norm().item() for k in names if prm[k].grad is not None},
+         "sampled": {k: GU.strided(prm[k].grad, n) for k in GU.full_sampled_names(names)},
+         "center": loss_fn.center.clone(), "center_grid": loss_fn.center_grid.clone(),
+         "s_out": [GU.strided(s_out[i], n) for i in range(3)], "s_out_absmax": [s_out[i].detach().abs().max().item() for i in range(3)],
+         "npatch": list(s_out[3]), "param_names": [k for k, _ in student.named_parameters()],
+         "keys": [(k, tuple(v.shape)) for k, v in student.state_dict().items()]}
+    if c["arch"].startswith("vil_"):  # the evaluation hook of eval_linear.py / eval_knn.py on the same weights
+        student.eval()
+        with torch.no_grad():
+            depth = [cf['n'] for cf in student.layer_cfgs]
+            g["last_blocks"] = student.forward_return_n_last_blocks(crops[2][:1], n=4, depth=depth).clone()
+        student.train()
+    print("full fixture:", name, "loss", g["loss"], "params with grad", len(g["grad_norm"]), "npatch", g["npatch"])
+    return g
+
+
 def gen_full_configs(ns):
     """BASELINE.json configs 3-5 at FULL width from the reference's own modules and experiment yamls: Swin-T W=14, Swin-B W=14
     (widths 128..1024: a GEMM tile family no W=7 fixture touches) and CvT-13 (cvt_v4 s1.yaml), 2x224^2 + 8x96^2 crops, V+R heads,
     DDINOLoss, B = 2, out_dim 8192.  Same contents per case as gen_full."""
     RL.ensure_single_process_group()
-    out = {}
-    for name, c in GU.FULL_CFG_CASES.items():
-        torch.manual_seed(0)
-        cfg = _yaml_config(c["yaml"])
-        K, B = c["K"], c["B"]
-        student = ns.models.build_model(cfg, is_teacher=False, use_dense_prediction=True)
-        teacher = ns.models.build_model(cfg, is_teacher=True, use_dense_prediction=True)
-        fea = student.num_features if hasattr(student, "num_features") else cfg.MODEL.SPEC.DIM_EMBED[-1]
-        student.head, teacher.head = ns.DINOHead(fea, K), ns.DINOHead(fea, K)
-        student.head_dense, teacher.head_dense = ns.DINOHead(fea, K), ns.DINOHead(fea, K)
-        GU.fill_full_cfg_pair(student, teacher, c)
-        crops = GU.make_crops(B, seed=c["crop_seed"])
-        loss_fn = ns.DDINOLoss(K, 10, 0.04, 0.04, 0, 1)
-        with torch.no_grad():
-            t_out = teacher(crops[:2])
-        s_out = student(crops)
-        loss = loss_fn(s_out, t_out, 0, None)
-        loss.backward()
-        names = [n for n, p in student.named_parameters() if p.requires_grad]
-        prm = dict(student.named_parameters())
-        n = GU.FULL_CFG_SAMPLE
-        g = {"loss": loss.item(), "grad_norm": {k: prm[k].grad.norm().item() for k in names if prm[k].grad is not None},
-             "sampled": {k: GU.strided(prm[k].grad, n) for k in GU.full_sampled_names(names)},
-             "center": loss_fn.center.clone(), "center_grid": loss_fn.center_grid.clone(),
-             "s_out": [GU.strided(s_out[i], n) for i in range(3)], "s_out_absmax": [s_out[i].detach().abs().max().item() for i in range(3)],
-             "npatch": list(s_out[3]), "param_names": [k for k, _ in student.named_parameters()],
-             "keys": [(k, tuple(v.shape)) for k, v in student.state_dict().items()]}
-        out[name] = g
-        print("full_configs:", name, "loss", g["loss"], "params with grad", len(g["grad_norm"]), "npatch", g["npatch"])
-        del student, teacher, s_out, t_out, loss
-    torch.save(out, os.path.join(OUT, "full_configs.pt"))
+    torch.save({name: _full_cfg_case(ns, name, c) for name, c in GU.FULL_CFG_CASES.items()}, os.path.join(OUT, "full_configs.pt"))
+
+
+def gen_full_vil(ns):
+    """Vision Longformer: the reference's own MsViT from experiments/imagenet/vil/vil_tiny/base.yaml (sliding-chunk
+    attention of layers/longformer2d.py + layers/slidingchunk_2d.py in stages 1-2, head_dim 48 in stage 1), same step and contents as
+    gen_full_configs, plus forward_return_n_last_blocks"""
+    RL.ensure_single_process_group()
+    torch.save({name: _full_cfg_case(ns, name, c) for name, c in GU.FULL_VIL_CASES.items()}, os.path.join(OUT, "full_vil.pt"))
 
 
 def main():
@@ -586,6 +610,8 @@ def main():
         gen_full_vit(ns)
     if "full_configs" in only:
         gen_full_configs(ns)
+    if "full_vil" in only:
+        gen_full_vil(ns)
 
 
 if __name__ == "__main__":

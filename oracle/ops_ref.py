@@ -787,18 +787,30 @@ def _vit_heads(qkv, B, N, nH, parts):
     return qkv.view(B, N, parts, nH, C // nH).permute(2, 0, 3, 1, 4).float()  # [parts, B, nH, N, hd]
 
 
-def vit_attn_fwd(qkv, B, N, nH, scale):
+def chunk_mask(chunk):
+    """[N, N] bool: may query i see key j?  (layers/slidingchunk_2d.py:268-287 exact = 0, layers/longformer2d.py:163-262, 310-327: global
+    tokens see and are seen by everything, local tokens see their own and the eight adjacent w x w chunks)"""
+    c = chunk.long()
+    glob = c < 0
+    cx, cy = c >> 16, c & 0xffff
+    near = ((cx[:, None] - cx[None, :]).abs() <= 1) & ((cy[:, None] - cy[None, :]).abs() <= 1)
+    return near | glob[:, None] | glob[None, :]
+
+
+def vit_attn_fwd(qkv, B, N, nH, scale, chunk=None):
     dt = qkv.dtype
     q, k, v = _vit_heads(qkv, B, N, nH, 3)
     s = _r(q @ k.transpose(-2, -1), dt).float()
+    if chunk is not None:
+        s = s.masked_fill(~chunk_mask(chunk).to(s.device), float("-inf"))
     p = _r(torch.softmax(scale * s, dim=-1), dt).float()
     o = _r(p @ v, dt)
     C = qkv.shape[1] // 3
-    return o.transpose(1, 2).reshape(B * N, C).contiguous(), (q, k, v, p)
+    return o.transpose(1, 2).reshape(B * N, C).contiguous(), (torch.stack((q, k, v)), p)  # (two tensors, like ops.vit_attn_fwd)
 
 
 def vit_attn_bwd(dout, saved, B, N, nH, scale):
-    q, k, v, p = saved
+    (q, k, v), p = saved
     dt = dout.dtype
     do = _vit_heads(dout, B, N, nH, 1)[0]
     dv = _r(p.transpose(-2, -1) @ do, dt)

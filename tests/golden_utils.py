@@ -143,6 +143,10 @@ FULL_CFG_CASES = {
     "cvt13_s1_k8192_b2": dict(arch="cvt_s1", yaml="experiments/imagenet/cvt_v4/s1.yaml",
                               K=8192, B=2, s_seed=45, t_seed=46, crop_seed=79),
 }
+# Vision Longformer at full width: experiments/imagenet/vil/vil_tiny/base.yaml
+FULL_VIL_CASES = {
+    "vil_tiny_k8192_b2": dict(arch="vil_tiny", yaml="experiments/imagenet/vil/vil_tiny/base.yaml", K=8192, B=2, s_seed=47, t_seed=48, crop_seed=80),
+}
 FULL_CFG_SAMPLE = 8192
 
 

@@ -521,6 +521,27 @@ def test_fused_mlp_branch_host_logic_matches_reference_golden(cpu_ops, monkeypat
     assert norm_rel < 2e-3 and worst < 5e-3, (norm_rel, worst_name, worst)
 
 
+@pytest.mark.parametrize("name", sorted(GU.FULL_VIL_CASES))
+def test_vil_full_width_composition_matches_reference_golden(name, cpu_ops):
+    """Vision Longformer (vil_tiny) through the product's host code -- module tree, patch embeddings with resampled position
+    embeddings, the chunk-neighbourhood attention, block pairs -- with the kernels replaced by their fp32 restatement, vs the
+    fixture produced by the reference's own MsViT (sliding-chunk implementation of layers/) from its own yaml"""
+    from tests.test_step_gpu import check_full_vil_case
+    check_full_vil_case(name, torch.device("cpu"), True, (1e-4, 1e-4, 2e-3, 5e-3))
+
+
+def test_vil_refuses_what_is_not_built():
+    from esvit_amd import config as CFG
+    import esvit_amd
+    with pytest.raises(NotImplementedError):
+        esvit_amd.build_model(CFG.vil_config("vil_tiny", arch='l1,h1,d48,n1,s1,g1,p4,f7,a0_l2,h3,d96,n1,s1,g1,p2,f7_l3,h3,d192,n1,s0,g1,p2,f7'))
+    cfg = CFG.vil_config("vil_tiny")
+    cfg["MODEL"]["SPEC"]["MSVIT"]["SHARE_W"] = False
+    with pytest.raises(NotImplementedError):
+        esvit_amd.build_model(cfg)
+    assert esvit_amd.models.is_model("cls_vil") and esvit_amd.models.is_model("vision_longformer")
+
+
 def test_logit_statistics_handover_host_logic_matches_reference_golden(cpu_ops, monkeypatch):
     """the softmax row statistics the heads' last-layer GEMM emits for the loss (esvit_gemm_desc::rowstat -> loss.arm_logit_stats,
     DINOHead.logit_stats, the `esvit_row_stats` attribute, the token check): with the kernel replaced by its restatement and the shape

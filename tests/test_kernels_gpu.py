@@ -544,6 +544,29 @@ def test_row_statistics_are_refused_outside_their_epilogue(mods):
         ops._gemm(torch.bfloat16, A=z, B=w, C=y, M=120, N=256, K=64, lda=64, ldb=64, ldc=256, rowstat=st, rowstat_scale=1.0)
 
 
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("grid,w,nglo,hd", [((28, 28), 7, 1, 48), ((12, 12), 7, 1, 32), ((14, 14), 7, 2, 64)])
+def test_sliding_chunk_attention(mods, dt, grid, w, nglo, hd):
+    """Vision Longformer's chunk-neighbourhood attention (esvit_softmax_rows_chunked_fwd on the batched-GEMM route) forward and
+    backward vs the restatement, whose mask is checked against the reference's sliding-chunk implementation by the ViL fixtures"""
+    ops, ref = mods
+    dev = _dev()
+    nx, ny = grid
+    N, B, nH = nglo + nx * ny, 2, 2
+    ix, iy = np.meshgrid(np.arange(nx), np.arange(ny), indexing="ij")
+    chunk = torch.from_numpy(np.concatenate([np.full(nglo, -1), ((ix // w) << 16 | (iy // w)).reshape(-1)]).astype(np.int32)).to(dev)
+    qkv = _rand((B * N, 3 * nH * hd), dev, 90, dt)
+    scale = hd ** -0.5
+    out, saved = ops.vit_attn_fwd(qkv, B, N, nH, scale, chunk=chunk)
+    outr, savedr = ref.vit_attn_fwd(qkv, B, N, nH, scale, chunk=chunk)
+    _close("sliding-chunk out", out, outr, _tol(dt, f32=2e-5, bf=2e-2))
+    p = saved[1].float().view(B * nH, saved[1].shape[-2], saved[1].shape[-1])[:, :N, :N]
+    allowed = ref.chunk_mask(chunk).to(dev)
+    assert (p[:, ~allowed] == 0).all() and abs(p.sum(-1).mean().item() - 1.0) < 2e-2  # nothing outside the neighbourhood, rows sum to one
+    dout = _rand((B * N, nH * hd), dev, 91, dt)
+    _close("sliding-chunk dqkv", ops.vit_attn_bwd(dout, saved, B, N, nH, scale), ref.vit_attn_bwd(dout, savedr, B, N, nH, scale), _tol(dt, f32=5e-5, bf=3e-2))
+
+
 def test_index_maps_match_restatement(mods):
     ops, ref = mods
     for ws in (7, 14):

@@ -36,9 +36,10 @@ def main():
     ap.add_argument("--batch", type=int, default=128)
     ap.add_argument("--out", default=None)
     ap.add_argument("--only-stage", type=int, default=None)
+    ap.add_argument("--window", type=int, default=7, help="7 (Swin W7) or 14 (the W14 configurations: 224-slot kernels)")
     args = ap.parse_args()
     fh = open(args.out, "w") if args.out else None
-    B, ws = args.batch, 7
+    B, ws = args.batch, args.window
     tot_f = tot_b = 0.0
     blocks = (2, 2, 6, 2)
     for s, (C, nH) in enumerate(((96, 3), (192, 6), (384, 12), (768, 24))):
@@ -50,6 +51,8 @@ def main():
             for shift in (0, ws // 2):
                 if shift and min(H, W) <= ws:
                     continue
+                if ws == 14 and min(H, W) < 12:
+                    continue  # stage 2 of the 96^2 crops (6 x 6) and stage 3 run on the 64-slot kernels
                 w2t, _ = ops.window_maps(H, W, ws, shift)
                 nW, N = len(w2t) // (ws * ws), ws * ws
                 win2tok = torch.from_numpy(w2t).to(dev)
