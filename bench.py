@@ -32,6 +32,52 @@ sys.path.insert(0, ROOT)
 
 GFLOP_PER_IMG = 154.5          # Swin-T W7 V+R, teacher fwd + student fwd + 2x student bwd + loss
 GFLOP_PER_IMG_BY_ARCH = {"swin_tiny_w7": 154.5, "swin_tiny_w14": 197.0, "swin_base_w14": 628.5, "cvt_s1": 136.7}
+
+
+def _head_flops(rows, C, K=65536):
+    """DINOHead (vision_transformer.py:391-418): C -> 2048 -> 2048 -> 256 -> K per row"""
+    return 2.0 * rows * (C * 2048 + 2048 * 2048 + 2048 * 256 + 256 * K)
+
+
+def _blocks_flops(N, C, depth, keys=None):
+    """depth transformer blocks on N tokens of width C: qkv + proj + 4C MLP, and attention over `keys` keys per query (default: all)"""
+    keys = N if keys is None else min(keys, N)
+    return depth * (2.0 * N * (3 * C * C + C * C + 8 * C * C) + 4.0 * N * keys * C)
+
+
+def _vit_crop_flops(S, C, depth, patch=16):
+    N = (S // patch) ** 2 + 1
+    return 2.0 * (N - 1) * 3 * patch * patch * C + _blocks_flops(N, C, depth) + _head_flops(1, C) + _head_flops(N - 1, C)
+
+
+def _vil_crop_flops(S, arch):
+    """Vision Longformer: ALGORITHMIC flops -- a local query of a sliding-chunk stage sees its global tokens and nine w x w chunks
+    (layers/longformer2d.py:140-152), whatever the implementation multiplies"""
+    fl, side, cin = 0.0, S, 3
+    for layer in arch.split('_'):
+        c = {'h': 3, 'd': 192, 'n': 1, 's': 1, 'g': 1, 'p': 2, 'f': 7}
+        c.update({a[0]: int(a[1:]) for a in layer.split(',')})
+        side //= c['p']
+        N = side * side + c['g']
+        fl += 2.0 * side * side * cin * c['p'] ** 2 * c['d'] + _blocks_flops(N, c['d'], c['n'], keys=(c['g'] + 9 * c['f'] ** 2) if c['s'] else None)
+        cin = c['d']
+    return fl + _head_flops(1, cin) + _head_flops(side * side, cin)
+
+
+def _step_gflop_per_img(crop_flops):
+    """teacher forward on the two 224^2 crops + student forward and backward (2x forward) on all ten crops"""
+    g, l = crop_flops(224), crop_flops(96)
+    return (2 * g + 3 * (2 * g + 8 * l)) / 1e9
+
+
+def _analytic_gflops():
+    from esvit_amd.models.vision_longformer import VIL_SPECS
+    out = {name: _step_gflop_per_img(lambda S, a=arch: _vil_crop_flops(S, a)) for name, arch in VIL_SPECS.items()}
+    for name, (C, depth) in {"deit_tiny": (192, 12), "deit_small": (384, 12), "vit_base": (768, 12)}.items():
+        out[name] = _step_gflop_per_img(lambda S, C=C, depth=depth: _vit_crop_flops(S, C, depth))
+    return out
+
+
 BF16_PEAK_TFLOPS = 2500.0      # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E (MI355X_MICROARCH.md; ~6.3 TB/s is what a streaming kernel reaches)
 OUT_DIM = 65536
@@ -397,8 +443,11 @@ def main():
                                       "AdamW + teacher EMA, drop_path %.2f" % ({"swin_tiny_w7": "Swin-T W=7"}.get(args.arch, args.arch), args.drop_path),
                           "global_batch": B * world, "per_gpu_batch": B, "parallelism": "dp%d" % world},
                "final_loss": loss_v,
-               "step_mfma_frac": (ips / world * GFLOP_PER_IMG_BY_ARCH[args.arch] / 1e3 / BF16_PEAK_TFLOPS
-                                  if args.arch in GFLOP_PER_IMG_BY_ARCH else None)}
+               "step_mfma_frac": None}
+        gf = GFLOP_PER_IMG_BY_ARCH.get(args.arch) or _analytic_gflops().get(args.arch)  # SURVEY.md 8(d), or counted here (ViT / ViL)
+        if gf:
+            out["gflop_per_image"] = gf
+            out["step_mfma_frac"] = ips / world * gf / 1e3 / BF16_PEAK_TFLOPS
         if prof:
             tot_fl = sum(r[0] for r in prof)
             tot_by = sum(r[4] for r in prof)

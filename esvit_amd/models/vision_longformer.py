@@ -30,6 +30,29 @@ from .registry import register_model
 from .swin_transformer import DropPath, Mlp, _trunc_normal_
 
 
+_BICUBIC = {}
+
+
+def _bicubic_matrix(n_in, scale_factor, device):
+    """[n_out, n_in] fp32: one axis of torch's upsample_bicubic2d (align_corners False, cubic coefficient -0.75, scales as given:
+    source = (dst + 0.5) / scale_factor - 0.5, neighbours clamped to the grid), n_out = floor(n_in * scale_factor)"""
+    key = (n_in, float(scale_factor), str(device))
+    m = _BICUBIC.get(key)
+    if m is None:
+        n_out = int(math.floor(n_in * scale_factor))
+        A = -0.75
+        src = (np.arange(n_out, dtype=np.float64) + 0.5) / scale_factor - 0.5
+        x0 = np.floor(src)
+        t = src - x0
+        w = np.stack([((A * (t + 1) - 5 * A) * (t + 1) + 8 * A) * (t + 1) - 4 * A, ((A + 2) * t - (A + 3)) * t * t + 1,
+                      ((A + 2) * (1 - t) - (A + 3)) * (1 - t) * (1 - t) + 1, ((A * (2 - t) - 5 * A) * (2 - t) + 8 * A) * (2 - t) - 4 * A], 1)
+        M = np.zeros((n_out, n_in), dtype=np.float64)
+        for k in range(4):
+            np.add.at(M, (np.arange(n_out), np.clip(x0.astype(np.int64) - 1 + k, 0, n_in - 1)), w[:, k])
+        m = _BICUBIC[key] = torch.from_numpy(M.astype(np.float32)).to(device)
+    return m
+
+
 class Attention(nn.Module):
     """parameter holder of the full-attention blocks (vision_longformer.py:36-50): qkv, proj"""
 
@@ -100,8 +123,13 @@ class PatchEmbed(nn.Module):
         N = pos.shape[1]
         if ntok != N:
             dim, side = pos.shape[-1], int(math.sqrt(N))
-            pos = nn.functional.interpolate(pos.reshape(1, side, side, dim).permute(0, 3, 1, 2), scale_factor=math.sqrt(ntok / N), mode='bicubic')
-            pos = pos.permute(0, 2, 3, 1).contiguous().view(1, -1, dim)
+            # F.interpolate(scale_factor = sqrt(ntok / N), mode='bicubic') as torch's CPU kernel evaluates it (the reference fixtures):
+            # written out as two small matrix products, because torch's device kernel copies its input whenever the output SIZE
+            # equals the input size -- which is the case at the construction resolution, where the reference's scale factor is
+            # sqrt((N + 1) / N) ~ 1.00016 and its CPU path does resample (1e-3 absolute in the embedding)
+            sf = math.sqrt(ntok / N)
+            R = _bicubic_matrix(side, sf, pos.device)
+            pos = torch.einsum('oh,bhwc,pw->bopc', R, pos.reshape(1, side, side, dim), R).contiguous().view(1, -1, dim)
         return torch.cat([self.cls_pos_embed, pos], dim=1)
 
     def forward(self, src, nB, H, W, nchw):
