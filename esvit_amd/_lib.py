@@ -86,7 +86,8 @@ SIGNATURES = {
     "esvit_heads_merge": (C.c_int, [C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
     "esvit_softmax_rows_fwd": (C.c_int, [C.c_int, vp, i64, C.c_int, C.c_int, f32, vp]),
     "esvit_softmax_rows_bwd": (C.c_int, [C.c_int, vp, vp, i64, C.c_int, C.c_int, f32, vp]),
-    "esvit_softmax_rows_chunked_fwd": (C.c_int, [C.c_int, vp, i64, C.c_int, C.c_int, f32, vp, vp]),
+    "esvit_softmax_rows_chunked_fwd": (C.c_int, [C.c_int, vp, i64, C.c_int, C.c_int, f32, vp, C.c_int, C.c_int, vp]),
+    "esvit_softmax_rows_chunked_bwd": (C.c_int, [C.c_int, vp, vp, i64, C.c_int, C.c_int, f32, vp, C.c_int, C.c_int, vp]),
     "esvit_teacher_row_stats": (C.c_int, [C.c_int, vp, vp, f32, i64, C.c_int, vp, vp, vp]),
     "esvit_region_match": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]),
     "esvit_dino_ce_fwd_bwd": (C.c_int, [C.c_int, vp, vp, vp, vp, vp, vp, vp, C.c_int, vp, f32, f32, i64, C.c_int, vp, vp, vp, vp, vp, vp]),

@@ -128,10 +128,33 @@ __global__ __launch_bounds__(256) void softmax_rows_bwd_kernel(const T* __restri
     }
 }
 
-// rows longer than 256 padded tokens (patch_size 8: 785 tokens at 224^2; evaluation on larger images): the same arithmetic in
-// passes over the row instead of registers (the row stays in the L2 between the passes)
+// rows longer than 256 padded tokens (patch_size 8: 785 tokens at 224^2; evaluation on larger images; the 3137-token first stage of
+// Vision Longformer): the same arithmetic in passes over the row instead of registers, 16-byte vectors per lane, max and sum in ONE
+// pass (online rescaling).  With a chunk table whose local tokens are ordered chunk row by chunk row (rowtok = tokens per chunk row,
+// nglo global tokens in front) a local query only scans [0, nglo) and the three chunk rows around its own -- everything else is
+// written as zero without being read.
+struct RowSpan {
+    int a_end, b_lo, b_hi;  // element ranges [0, a_end) and [b_lo, b_hi), vector-aligned, inside [0, Np)
+};
+template <int V>
+__device__ __forceinline__ RowSpan row_span(int N, int Np, int ci, int nglo, int rowtok) {
+    RowSpan r{0, 0, Np};
+    if (ci >= 0 && rowtok > 0) {
+        const int cx = ci >> 16;
+        int lo = nglo + max(cx - 1, 0) * rowtok, hi = min(N, nglo + (cx + 2) * rowtok);
+        lo = (lo / V) * V;
+        hi = min(Np, ((hi + V - 1) / V) * V);
+        r.a_end = min(((nglo + V - 1) / V) * V, lo);
+        r.b_lo = lo;
+        r.b_hi = hi;
+    }
+    return r;
+}
+
 template <typename T>
-__global__ __launch_bounds__(256) void softmax_rows_fwd_long_kernel(T* __restrict__ s, long rows, int N, int Np, float scale, const int* __restrict__ chunk) {
+__global__ __launch_bounds__(256) void softmax_rows_fwd_long_kernel(T* __restrict__ s, long rows, int N, int Np, float scale, const int* __restrict__ chunk,
+                                                                    int nglo, int rowtok) {
+    constexpr int V = Vec16<T>::N;
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int lane = threadIdx.x & 63;
@@ -139,34 +162,85 @@ __global__ __launch_bounds__(256) void softmax_rows_fwd_long_kernel(T* __restric
     const int qi = (int)(row % Np);
     const bool live = qi < N;
     const int ci = (chunk && live) ? chunk[qi] : -1;
-    auto ok = [&](int j) { return !chunk || chunk_allows(ci, chunk[j]); };
-    float m = -INFINITY;
-    if (live)
-        for (int j = lane; j < N; j += 64)
-            if (ok(j)) m = fmaxf(m, scale * to_f32(p[j]));
-    m = wave_max(m);
-    float sum = 0.f;
-    if (live)
-        for (int j = lane; j < N; j += 64)
-            if (ok(j)) sum += __expf(scale * to_f32(p[j]) - m);
-    sum = wave_sum(sum);
+    const RowSpan sp = row_span<V>(N, Np, chunk ? ci : -1, nglo, rowtok);
+    auto okv = [&](int j0, bool (&ok)[V]) {
+#pragma unroll
+        for (int e = 0; e < V; ++e) ok[e] = j0 + e < N && (!chunk || chunk_allows(ci, chunk[j0 + e]));
+    };
+    float m = -INFINITY, sum = 0.f;
+    auto scan = [&](int lo, int hi) {
+        for (int j0 = lo + lane * V; j0 < hi; j0 += 64 * V) {
+            const Vec16<T> x = ld16<T>(p + j0);
+            bool ok[V];
+            okv(j0, ok);
+            float mv = -INFINITY;
+#pragma unroll
+            for (int e = 0; e < V; ++e) mv = fmaxf(mv, ok[e] ? scale * x.get(e) : -INFINITY);
+            if (mv > -INFINITY) {
+                const float mn = fmaxf(m, mv);
+                float sv = 0.f;
+#pragma unroll
+                for (int e = 0; e < V; ++e) sv += ok[e] ? __expf(scale * x.get(e) - mn) : 0.f;
+                sum = sum * __expf(m - mn) + sv;
+                m = mn;
+            }
+        }
+    };
+    if (live) {
+        scan(0, sp.a_end);
+        scan(sp.b_lo, sp.b_hi);
+    }
+    const float mw = wave_max(m);
+    sum = wave_sum(m > -INFINITY ? sum * __expf(m - mw) : 0.f);
     const float inv = live ? 1.f / sum : 0.f;
-    for (int j = lane; j < Np; j += 64) p[j] = from_f32<T>((live && j < N && ok(j)) ? __expf(scale * to_f32(p[j]) - m) * inv : 0.f);
+    for (int j0 = lane * V; j0 < Np; j0 += 64 * V) {
+        Vec16<T> o = zero16<T>();
+        if (live && (j0 < sp.a_end || (j0 >= sp.b_lo && j0 < sp.b_hi))) {
+            const Vec16<T> x = ld16<T>(p + j0);
+            bool ok[V];
+            okv(j0, ok);
+#pragma unroll
+            for (int e = 0; e < V; ++e) o.set(e, ok[e] ? __expf(scale * x.get(e) - mw) * inv : 0.f);
+        }
+        st16<T>(p + j0, o);
+    }
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void softmax_rows_bwd_long_kernel(const T* __restrict__ prob, T* __restrict__ dp, long rows, int N, int Np, float scale) {
+__global__ __launch_bounds__(256) void softmax_rows_bwd_long_kernel(const T* __restrict__ prob, T* __restrict__ dp, long rows, int N, int Np, float scale,
+                                                                    const int* __restrict__ chunk, int nglo, int rowtok) {
+    constexpr int V = Vec16<T>::N;
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int lane = threadIdx.x & 63;
     const T* p = prob + row * Np;
     T* d = dp + row * Np;
-    const bool live = (int)(row % Np) < N;
+    const int qi = (int)(row % Np);
+    const bool live = qi < N;
+    const int ci = (chunk && live) ? chunk[qi] : -1;
+    const RowSpan sp = row_span<V>(N, Np, chunk ? ci : -1, nglo, rowtok);  // (P is zero outside the span: nothing to read there)
     float dot = 0.f;
-    if (live)
-        for (int j = lane; j < N; j += 64) dot += to_f32(p[j]) * to_f32(d[j]);
+    auto scan = [&](int lo, int hi) {
+        for (int j0 = lo + lane * V; j0 < hi; j0 += 64 * V) {
+            const Vec16<T> x = ld16<T>(p + j0), y = ld16<T>(d + j0);
+#pragma unroll
+            for (int e = 0; e < V; ++e) dot += (j0 + e < N) ? x.get(e) * y.get(e) : 0.f;
+        }
+    };
+    if (live) {
+        scan(0, sp.a_end);
+        scan(sp.b_lo, sp.b_hi);
+    }
     dot = wave_sum(dot);
-    for (int j = lane; j < Np; j += 64) d[j] = from_f32<T>((live && j < N) ? scale * to_f32(p[j]) * (to_f32(d[j]) - dot) : 0.f);
+    for (int j0 = lane * V; j0 < Np; j0 += 64 * V) {
+        Vec16<T> o = zero16<T>();
+        if (live && (j0 < sp.a_end || (j0 >= sp.b_lo && j0 < sp.b_hi))) {
+            const Vec16<T> x = ld16<T>(p + j0), y = ld16<T>(d + j0);
+#pragma unroll
+            for (int e = 0; e < V; ++e) o.set(e, (j0 + e < N) ? scale * x.get(e) * (y.get(e) - dot) : 0.f);
+        }
+        st16<T>(d + j0, o);
+    }
 }
 
 int grid_for(long total) {
@@ -202,13 +276,15 @@ extern "C" int esvit_heads_merge(int dtype, const void* y, int B, int N, int Np,
     return ESVIT_OK;
 }
 
-static int softmax_rows_fwd_impl(int dtype, void* s, int64_t batch, int N, int Np, float scale, const int32_t* chunk, hipStream_t stream) {
+static int softmax_rows_fwd_impl(int dtype, void* s, int64_t batch, int N, int Np, float scale, const int32_t* chunk, int nglo, int rowtok,
+                                 hipStream_t stream) {
     ESVIT_CHECK_ARG(s && batch > 0 && N > 0 && Np >= N, "esvit_softmax_rows_fwd: bad arguments");
+    ESVIT_CHECK_ARG(Np <= 64 * SM_MAX || Np % 8 == 0, "esvit_softmax_rows_fwd: long rows are read as 16-byte vectors (Np = %d)", Np);
     const long rows = batch * Np;
     const dim3 grid((unsigned)((rows + 3) / 4));
     if (Np > 64 * SM_MAX) {
-        if (dtype == ESVIT_BF16) hipLaunchKernelGGL(softmax_rows_fwd_long_kernel<bf16>, grid, dim3(256), 0, stream, (bf16*)s, rows, N, Np, scale, chunk);
-        else if (dtype == ESVIT_F32) hipLaunchKernelGGL(softmax_rows_fwd_long_kernel<float>, grid, dim3(256), 0, stream, (float*)s, rows, N, Np, scale, chunk);
+        if (dtype == ESVIT_BF16) hipLaunchKernelGGL(softmax_rows_fwd_long_kernel<bf16>, grid, dim3(256), 0, stream, (bf16*)s, rows, N, Np, scale, chunk, nglo, rowtok);
+        else if (dtype == ESVIT_F32) hipLaunchKernelGGL(softmax_rows_fwd_long_kernel<float>, grid, dim3(256), 0, stream, (float*)s, rows, N, Np, scale, chunk, nglo, rowtok);
         else ESVIT_CHECK_ARG(false, "esvit_softmax_rows_fwd: bad dtype %d", dtype);
         ESVIT_CHECK_LAUNCH("softmax_rows_fwd");
         return ESVIT_OK;
@@ -222,29 +298,46 @@ static int softmax_rows_fwd_impl(int dtype, void* s, int64_t batch, int N, int N
 
 extern "C" int esvit_softmax_rows_fwd(int dtype, void* s, int64_t batch, int N, int Np, float scale, esvit_stream_t stream_) {
     STREAM(stream_);
-    return softmax_rows_fwd_impl(dtype, s, batch, N, Np, scale, nullptr, stream);
+    return softmax_rows_fwd_impl(dtype, s, batch, N, Np, scale, nullptr, 0, 0, stream);
 }
 
-extern "C" int esvit_softmax_rows_chunked_fwd(int dtype, void* s, int64_t batch, int N, int Np, float scale, const int32_t* chunk, esvit_stream_t stream_) {
+extern "C" int esvit_softmax_rows_chunked_fwd(int dtype, void* s, int64_t batch, int N, int Np, float scale, const int32_t* chunk, int nglo,
+                                              int chunk_row_tokens, esvit_stream_t stream_) {
     STREAM(stream_);
-    ESVIT_CHECK_ARG(chunk != nullptr, "esvit_softmax_rows_chunked_fwd: the chunk table is required");
-    return softmax_rows_fwd_impl(dtype, s, batch, N, Np, scale, chunk, stream);
+    ESVIT_CHECK_ARG(chunk != nullptr && nglo >= 0 && chunk_row_tokens >= 0, "esvit_softmax_rows_chunked_fwd: bad chunk arguments");
+    return softmax_rows_fwd_impl(dtype, s, batch, N, Np, scale, chunk, nglo, chunk_row_tokens, stream);
 }
 
-extern "C" int esvit_softmax_rows_bwd(int dtype, const void* p, void* dp, int64_t batch, int N, int Np, float scale, esvit_stream_t stream_) {
-    STREAM(stream_);
+static int softmax_rows_bwd_impl(int dtype, const void* p, void* dp, int64_t batch, int N, int Np, float scale, const int32_t* chunk, int nglo,
+                                 int rowtok, hipStream_t stream) {
     ESVIT_CHECK_ARG(p && dp && batch > 0 && N > 0 && Np >= N, "esvit_softmax_rows_bwd: bad arguments");
+    ESVIT_CHECK_ARG(Np <= 64 * SM_MAX || Np % 8 == 0, "esvit_softmax_rows_bwd: long rows are read as 16-byte vectors (Np = %d)", Np);
     const long rows = batch * Np;
+    const dim3 grid((unsigned)((rows + 3) / 4));
     if (Np > 64 * SM_MAX) {
-        if (dtype == ESVIT_BF16) hipLaunchKernelGGL(softmax_rows_bwd_long_kernel<bf16>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, (const bf16*)p, (bf16*)dp, rows, N, Np, scale);
-        else if (dtype == ESVIT_F32) hipLaunchKernelGGL(softmax_rows_bwd_long_kernel<float>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, (const float*)p, (float*)dp, rows, N, Np, scale);
+        if (dtype == ESVIT_BF16)
+            hipLaunchKernelGGL(softmax_rows_bwd_long_kernel<bf16>, grid, dim3(256), 0, stream, (const bf16*)p, (bf16*)dp, rows, N, Np, scale, chunk, nglo, rowtok);
+        else if (dtype == ESVIT_F32)
+            hipLaunchKernelGGL(softmax_rows_bwd_long_kernel<float>, grid, dim3(256), 0, stream, (const float*)p, (float*)dp, rows, N, Np, scale, chunk, nglo, rowtok);
         else ESVIT_CHECK_ARG(false, "esvit_softmax_rows_bwd: bad dtype %d", dtype);
         ESVIT_CHECK_LAUNCH("softmax_rows_bwd");
         return ESVIT_OK;
     }
-    if (dtype == ESVIT_BF16) hipLaunchKernelGGL(softmax_rows_bwd_kernel<bf16>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, (const bf16*)p, (bf16*)dp, rows, N, Np, scale);
-    else if (dtype == ESVIT_F32) hipLaunchKernelGGL(softmax_rows_bwd_kernel<float>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, (const float*)p, (float*)dp, rows, N, Np, scale);
+    if (dtype == ESVIT_BF16) hipLaunchKernelGGL(softmax_rows_bwd_kernel<bf16>, grid, dim3(256), 0, stream, (const bf16*)p, (bf16*)dp, rows, N, Np, scale);
+    else if (dtype == ESVIT_F32) hipLaunchKernelGGL(softmax_rows_bwd_kernel<float>, grid, dim3(256), 0, stream, (const float*)p, (float*)dp, rows, N, Np, scale);
     else ESVIT_CHECK_ARG(false, "esvit_softmax_rows_bwd: bad dtype %d", dtype);
     ESVIT_CHECK_LAUNCH("softmax_rows_bwd");
     return ESVIT_OK;
+}
+
+extern "C" int esvit_softmax_rows_bwd(int dtype, const void* p, void* dp, int64_t batch, int N, int Np, float scale, esvit_stream_t stream_) {
+    STREAM(stream_);
+    return softmax_rows_bwd_impl(dtype, p, dp, batch, N, Np, scale, nullptr, 0, 0, stream);
+}
+
+extern "C" int esvit_softmax_rows_chunked_bwd(int dtype, const void* p, void* dp, int64_t batch, int N, int Np, float scale, const int32_t* chunk,
+                                              int nglo, int chunk_row_tokens, esvit_stream_t stream_) {
+    STREAM(stream_);
+    ESVIT_CHECK_ARG(chunk != nullptr && nglo >= 0 && chunk_row_tokens >= 0, "esvit_softmax_rows_chunked_bwd: bad chunk arguments");
+    return softmax_rows_bwd_impl(dtype, p, dp, batch, N, Np, scale, chunk, nglo, chunk_row_tokens, stream);
 }

@@ -1203,7 +1203,7 @@ class VilBlockFn(torch.autograd.Function):
         wts = (_weight(Wq_p), _weight(Wkv_p) if split else None, _weight(Wproj_p), _weight(W1_p), _weight(W2_p))
         x = x.contiguous()
         y, saved, att = _vil_block_forward(x, nH, dp, chunk, (g1, b1, bq, bkv, bproj, g2, b2, bfc1, bfc2), wts, True)
-        ctx.nH, ctx.dp, ctx.split, ctx.chunked = nH, dp, split, chunk is not None
+        ctx.nH, ctx.dp, ctx.split, ctx.chunk = nH, dp, split, chunk
         ctx.wparams = (Wq_p, Wkv_p, Wproj_p, W1_p, W2_p)
         ctx.bparams = (bq, bkv, bproj, bfc1, bfc2)
         ctx.nparams = (g1, b1, g2, b2)
@@ -1243,8 +1243,8 @@ class VilBlockFn(torch.autograd.Function):
         gx1, dyw, dg2, db2 = o.layernorm_bwd_cast(dh, x1, mean2, rstd2, g2, g_in=gy, rowscale=dp1, rows_per_sample=N, gb_out=sink2)
         dWproj, dbproj = _wgrad(dyw, ao, Wproj_p, want_bias=True, bias_param=bproj_p)
         dao = o.linear_dgrad(dyw, Wproj)
-        if ctx.chunked:
-            dqkv = o.vit_attn_bwd(dao, att, nB, N, nH, scale)
+        if ctx.chunk is not None:
+            dqkv = o.vit_attn_bwd(dao, att, nB, N, nH, scale, chunk=ctx.chunk)
         else:
             dqkv = vit_attention_bwd(o, dao, att, bqkv, nB, N, nH, scale)
         if split:

@@ -286,7 +286,8 @@ class MsViT(nn.Module):
     def _stage(self, layer, cfg, src, nB, H, W, nchw, collect=None):
         x, nx, ny = layer[0](src, nB, H, W, nchw)
         sparse = isinstance(layer[1].attn, Long2DSCSelfAttention)
-        chunk = self._chunk_table(cfg['g'], nx, ny, cfg['f'], x.device) if sparse else None
+        # (chunk table, global tokens, tokens per chunk row): the local tokens are ordered (x, y), i.e. chunk row by chunk row
+        chunk = (self._chunk_table(cfg['g'], nx, ny, cfg['f'], x.device), cfg['g'], cfg['f'] * ny) if sparse else None
         for b in range(1, len(layer), 2):
             ab, mb = layer[b], layer[b + 1]
             dp = None

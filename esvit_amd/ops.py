@@ -961,29 +961,37 @@ def _bmm(a, b, M, N, K, *, a_kstrided=0, b_kstrided=0, out=None):
 def vit_attn_fwd(qkv, B, N, nH, scale, chunk=None):
     """Attention.forward between the qkv and proj projections (vision_transformer.py:76-83): qkv [B * N, 3C] -> (out [B * N, C],
     saved = (q | k | v [3, B nH, Np, hd], P [B nH, Np, Np])).  chunk (int32 [N]): Vision Longformer's sliding-chunk neighbourhood
-    (esvit_softmax_rows_chunked_fwd) instead of global attention."""
+    (esvit_softmax_rows_chunked_fwd) instead of global attention; or (table, nglo, tokens per chunk row) when the local tokens are
+    ordered chunk row by chunk row, which lets the kernels skip the chunk rows a query cannot see."""
     C_ = qkv.shape[1] // 3
     hd, Np = C_ // nH, vit_pad_tokens(N)
     qkvh = heads_split(qkv, B, N, nH, 3).view(3, B * nH, Np, hd)
     prob = _bmm(qkvh[0], qkvh[1], Np, Np, hd)                                  # S = q k^T
     if chunk is not None:
-        assert chunk.dtype == torch.int32 and chunk.numel() == N and chunk.is_contiguous()
-        check(lib.esvit_softmax_rows_chunked_fwd(_code(prob.dtype), _p(prob), B * nH, N, Np, float(scale), _p(chunk), _stream()), "softmax_rows_chunked_fwd")
+        tab, nglo, rowtok = chunk if isinstance(chunk, tuple) else (chunk, 0, 0)
+        assert tab.dtype == torch.int32 and tab.numel() == N and tab.is_contiguous()
+        check(lib.esvit_softmax_rows_chunked_fwd(_code(prob.dtype), _p(prob), B * nH, N, Np, float(scale), _p(tab), int(nglo), int(rowtok), _stream()),
+              "softmax_rows_chunked_fwd")
     else:
         check(lib.esvit_softmax_rows_fwd(_code(prob.dtype), _p(prob), B * nH, N, Np, float(scale), _stream()), "softmax_rows_fwd")
     o = _bmm(prob, qkvh[2], Np, hd, Np, b_kstrided=1)                          # O = P v
     return heads_merge(o.view(1, B, nH, Np, hd), N), (qkvh, prob)
 
 
-def vit_attn_bwd(dout, saved, B, N, nH, scale):
-    """gradient of vit_attn_fwd with respect to qkv: dout [B * N, C] -> dqkv [B * N, 3C]"""
+def vit_attn_bwd(dout, saved, B, N, nH, scale, chunk=None):
+    """gradient of vit_attn_fwd with respect to qkv: dout [B * N, C] -> dqkv [B * N, 3C] (chunk: as given to the forward; only the
+    (table, nglo, tokens per chunk row) form changes anything -- the backward then skips the columns that are zero in P)"""
     qkvh, prob = saved
     _, Z, Np, hd = qkvh.shape
     do = heads_split(dout, B, N, nH, 1).view(Z, Np, hd)
     dqkvh = torch.empty_like(qkvh)
     _bmm(prob, do, Np, hd, Np, a_kstrided=1, b_kstrided=1, out=dqkvh[2])      # dv = P^T dO
     dp = _bmm(do, qkvh[2], Np, Np, hd)                                         # dP = dO v^T
-    check(lib.esvit_softmax_rows_bwd(_code(dp.dtype), _p(prob), _p(dp), Z, N, Np, float(scale), _stream()), "softmax_rows_bwd")
+    if isinstance(chunk, tuple) and chunk[2] > 0:
+        check(lib.esvit_softmax_rows_chunked_bwd(_code(dp.dtype), _p(prob), _p(dp), Z, N, Np, float(scale), _p(chunk[0]), int(chunk[1]), int(chunk[2]),
+                                                 _stream()), "softmax_rows_chunked_bwd")
+    else:
+        check(lib.esvit_softmax_rows_bwd(_code(dp.dtype), _p(prob), _p(dp), Z, N, Np, float(scale), _stream()), "softmax_rows_bwd")
     _bmm(dp, qkvh[1], Np, hd, Np, b_kstrided=1, out=dqkvh[0])                  # dq = dS k
     _bmm(dp, qkvh[0], Np, hd, Np, a_kstrided=1, b_kstrided=1, out=dqkvh[1])   # dk = dS^T q
     return heads_merge(dqkvh.view(3, B, nH, Np, hd), N)

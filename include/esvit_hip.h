@@ -440,8 +440,14 @@ int esvit_softmax_rows_bwd(int dtype, const void* p, void* dp, int64_t batch, in
  * the keys a query may see.  chunk int32 [N]: -1 for a global token, else (chunk row << 16) | chunk column of the token's w x w
  * chunk; a query sees all global tokens and the local tokens of its own and the eight adjacent chunks (the reference's zero-padded
  * and out-of-range positions are exactly the ones that do not exist here); a global query sees every token (longformer2d.py:310-327).
- * Masked entries of P are zero, so esvit_softmax_rows_bwd needs no mask. */
-int esvit_softmax_rows_chunked_fwd(int dtype, void* s, int64_t batch, int N, int Np, float scale, const int32_t* chunk, esvit_stream_t stream);
+ * Masked entries of P are zero, so the backward needs no mask for correctness.  nglo / chunk_row_tokens (optional, 0 = unknown)
+ * describe the token order -- nglo global tokens, then the local tokens chunk row by chunk row, chunk_row_tokens (= w * grid width)
+ * per chunk row: the kernels then read only the global columns and the three chunk rows around the query's own (everything else is
+ * written as zero unread). */
+int esvit_softmax_rows_chunked_fwd(int dtype, void* s, int64_t batch, int N, int Np, float scale, const int32_t* chunk, int nglo,
+                                   int chunk_row_tokens, esvit_stream_t stream);
+int esvit_softmax_rows_chunked_bwd(int dtype, const void* p, void* dp, int64_t batch, int N, int Np, float scale, const int32_t* chunk,
+                                   int nglo, int chunk_row_tokens, esvit_stream_t stream);
 
 #pragma GCC visibility pop
 #ifdef __cplusplus

@@ -802,14 +802,14 @@ def vit_attn_fwd(qkv, B, N, nH, scale, chunk=None):
     q, k, v = _vit_heads(qkv, B, N, nH, 3)
     s = _r(q @ k.transpose(-2, -1), dt).float()
     if chunk is not None:
-        s = s.masked_fill(~chunk_mask(chunk).to(s.device), float("-inf"))
+        s = s.masked_fill(~chunk_mask(chunk[0] if isinstance(chunk, tuple) else chunk).to(s.device), float("-inf"))
     p = _r(torch.softmax(scale * s, dim=-1), dt).float()
     o = _r(p @ v, dt)
     C = qkv.shape[1] // 3
     return o.transpose(1, 2).reshape(B * N, C).contiguous(), (torch.stack((q, k, v)), p)  # (two tensors, like ops.vit_attn_fwd)
 
 
-def vit_attn_bwd(dout, saved, B, N, nH, scale):
+def vit_attn_bwd(dout, saved, B, N, nH, scale, chunk=None):
     (q, k, v), p = saved
     dt = dout.dtype
     do = _vit_heads(dout, B, N, nH, 1)[0]

@@ -545,7 +545,7 @@ def test_row_statistics_are_refused_outside_their_epilogue(mods):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
-@pytest.mark.parametrize("grid,w,nglo,hd", [((28, 28), 7, 1, 48), ((12, 12), 7, 1, 32), ((14, 14), 7, 2, 64)])
+@pytest.mark.parametrize("grid,w,nglo,hd", [((28, 28), 7, 1, 48), ((12, 12), 7, 1, 32), ((14, 14), 7, 2, 64), ((56, 56), 7, 1, 48)])
 def test_sliding_chunk_attention(mods, dt, grid, w, nglo, hd):
     """Vision Longformer's chunk-neighbourhood attention (esvit_softmax_rows_chunked_fwd on the batched-GEMM route) forward and
     backward vs the restatement, whose mask is checked against the reference's sliding-chunk implementation by the ViL fixtures"""
@@ -559,12 +559,18 @@ def test_sliding_chunk_attention(mods, dt, grid, w, nglo, hd):
     scale = hd ** -0.5
     out, saved = ops.vit_attn_fwd(qkv, B, N, nH, scale, chunk=chunk)
     outr, savedr = ref.vit_attn_fwd(qkv, B, N, nH, scale, chunk=chunk)
+    # with the token order declared (chunk row by chunk row) the kernels skip what a query cannot see: same result
+    lay = (chunk, nglo, w * ny)
+    out2, saved2 = ops.vit_attn_fwd(qkv, B, N, nH, scale, chunk=lay)
+    assert torch.equal(out2, out) and torch.equal(saved2[1], saved[1])
     _close("sliding-chunk out", out, outr, _tol(dt, f32=2e-5, bf=2e-2))
     p = saved[1].float().view(B * nH, saved[1].shape[-2], saved[1].shape[-1])[:, :N, :N]
     allowed = ref.chunk_mask(chunk).to(dev)
     assert (p[:, ~allowed] == 0).all() and abs(p.sum(-1).mean().item() - 1.0) < 2e-2  # nothing outside the neighbourhood, rows sum to one
     dout = _rand((B * N, nH * hd), dev, 91, dt)
-    _close("sliding-chunk dqkv", ops.vit_attn_bwd(dout, saved, B, N, nH, scale), ref.vit_attn_bwd(dout, savedr, B, N, nH, scale), _tol(dt, f32=5e-5, bf=3e-2))
+    dq = ops.vit_attn_bwd(dout, saved, B, N, nH, scale)
+    _close("sliding-chunk dqkv", dq, ref.vit_attn_bwd(dout, savedr, B, N, nH, scale), _tol(dt, f32=5e-5, bf=3e-2))
+    assert torch.equal(ops.vit_attn_bwd(dout, saved2, B, N, nH, scale, chunk=lay), dq)
 
 
 def test_index_maps_match_restatement(mods):
