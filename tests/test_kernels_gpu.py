@@ -559,10 +559,12 @@ def test_sliding_chunk_attention(mods, dt, grid, w, nglo, hd):
     scale = hd ** -0.5
     out, saved = ops.vit_attn_fwd(qkv, B, N, nH, scale, chunk=chunk)
     outr, savedr = ref.vit_attn_fwd(qkv, B, N, nH, scale, chunk=chunk)
-    # with the token order declared (chunk row by chunk row) the kernels skip what a query cannot see: same result
+    # with the token order declared (chunk row by chunk row) the kernels skip what a query cannot see: same result up to the
+    # order of the partial sums (lanes start at another column)
     lay = (chunk, nglo, w * ny)
     out2, saved2 = ops.vit_attn_fwd(qkv, B, N, nH, scale, chunk=lay)
-    assert torch.equal(out2, out) and torch.equal(saved2[1], saved[1])
+    _close("span vs full scan: out", out2, out, _tol(dt, f32=2e-6, bf=8e-3))
+    _close("span vs full scan: P", saved2[1], saved[1], _tol(dt, f32=2e-6, bf=8e-3))
     _close("sliding-chunk out", out, outr, _tol(dt, f32=2e-5, bf=2e-2))
     p = saved[1].float().view(B * nH, saved[1].shape[-2], saved[1].shape[-1])[:, :N, :N]
     allowed = ref.chunk_mask(chunk).to(dev)
@@ -570,7 +572,7 @@ def test_sliding_chunk_attention(mods, dt, grid, w, nglo, hd):
     dout = _rand((B * N, nH * hd), dev, 91, dt)
     dq = ops.vit_attn_bwd(dout, saved, B, N, nH, scale)
     _close("sliding-chunk dqkv", dq, ref.vit_attn_bwd(dout, savedr, B, N, nH, scale), _tol(dt, f32=5e-5, bf=3e-2))
-    assert torch.equal(ops.vit_attn_bwd(dout, saved2, B, N, nH, scale, chunk=lay), dq)
+    _close("span vs full scan: dqkv", ops.vit_attn_bwd(dout, saved, B, N, nH, scale, chunk=lay), dq, _tol(dt, f32=2e-6, bf=8e-3))
 
 
 def test_index_maps_match_restatement(mods):
