@@ -158,8 +158,13 @@ class DINOLoss(_DeferredCenter, nn.Module):
         of the un-mixed crops) have at most two non-zeros per column, which gives at most four weighted terms per student row."""
         T = torch.stack([t.to(device=device, dtype=torch.float32) for t in targets_mixup])       # [ncrops, a, b]
         assert T.shape == (self.ncrops, B, B), "targets_mixup: one [B, B] matrix per crop"
-        if int((T != 0).sum(1).max()) > 2:
-            raise NotImplementedError("DINOLoss mixup targets with more than two non-zeros per column")
+        if not self.__dict__.get("_mixup_checked"):
+            # structure check on the FIRST call only (it reads a value back from the device: not something for every step); mixup /
+            # cutmix targets keep this structure for the whole run, label smoothing (dense targets) never has it
+            if int((T != 0).sum(1).max()) > 2:
+                raise NotImplementedError("DINOLoss mixup targets with more than two non-zeros per column (e.g. --smoothing > 0: dense "
+                                          "targets) are not built: the four-term cross-entropy kernel covers mixup / cutmix")
+            self.__dict__["_mixup_checked"] = True
         w2, a2 = torch.topk(T.abs(), 2, dim=1)                                                   # [ncrops, 2, b]
         w2 = torch.gather(T, 1, a2)
         n_terms = 2 * self.ncrops - 2
