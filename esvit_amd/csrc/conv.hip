@@ -13,6 +13,7 @@
 
 namespace {
 
+// General form: one element per thread (any Cin; the fp32 parity mode of the NCHW stem; odd channel counts).
 template <typename T>
 __global__ void im2col_kernel(const void* __restrict__ src_, int nchw, int nB, int H, int W, int Cin, int k, int stride, int pad,
                               int Ho, int Wo, int Kpad, T* __restrict__ cols) {
@@ -34,6 +35,68 @@ __global__ void im2col_kernel(const void* __restrict__ src_, int nchw, int nB, i
             }
         }
         cols[i] = from_f32<T>(v);
+    }
+}
+
+// Token sources (NHWC) whose channel count is a whole number of 16-byte vectors: a thread copies one vector of one tap -- the
+// columns of a tap are Cin contiguous channels of one source token, so loads and stores are both 16-byte and coalesced over c.
+// (The element-wise form above spends two 64-bit divisions and a 2-byte store per element: 0.3 ms per launch on CvT's stages.)
+template <typename T>
+__global__ __launch_bounds__(256) void im2col_nhwc_vec_kernel(const T* __restrict__ src, int nB, int H, int W, int Cin, int k, int stride, int pad,
+                                                              int Ho, int Wo, int Kpad, T* __restrict__ cols) {
+    constexpr int V = Vec16<T>::N;
+    const int cv = Cin / V;               // vectors per tap
+    const int per_row = Kpad / V;         // vectors per output row (the zero tail included)
+    const int taps_v = k * k * cv;
+    const long total = (long)nB * Ho * Wo * per_row;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int jv = (int)(i % per_row);
+        const long r = i / per_row;
+        Vec16<T> v = zero16<T>();
+        if (jv < taps_v) {
+            const int kk = jv / cv, c0 = (jv - kk * cv) * V;
+            const int ky = kk / k, kx = kk - ky * k;
+            const int ox = (int)(r % Wo);
+            const long t = r / Wo;
+            const int oy = (int)(t % Ho);
+            const long b = t / Ho;
+            const int iy = oy * stride - pad + ky, ix = ox * stride - pad + kx;
+            if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = ld16<T>(src + ((b * H + iy) * W + ix) * Cin + c0);
+        }
+        st16<T>(cols + r * Kpad + (long)jv * V, v);
+    }
+}
+
+// fp32 NCHW images -> bf16 columns (ky, kx, c): a thread produces eight consecutive columns of one output position (eight cached
+// 4-byte reads from the image planes -- every pixel is read k^2 / stride^2 times over the launch, from the L1 / L2 --, ONE 16-byte
+// store); the lanes of a wave cover consecutive column vectors, so the stores are contiguous.
+__global__ __launch_bounds__(256) void im2col_nchw_vec_kernel(const float* __restrict__ src, int nB, int H, int W, int Cin, int k, int stride, int pad,
+                                                              int Ho, int Wo, int Kpad, bf16* __restrict__ cols) {
+    const int per_row = Kpad / 8;
+    const int KK = k * k * Cin;
+    const long total = (long)nB * Ho * Wo * per_row;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int jv = (int)(i % per_row);
+        const long r = i / per_row;
+        const int ox = (int)(r % Wo);
+        const long t = r / Wo;
+        const int oy = (int)(t % Ho);
+        const long b = t / Ho;
+        const float* img = src + b * Cin * (long)H * W;
+        Vec16<bf16> v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int j = jv * 8 + e;
+            float x = 0.f;
+            if (j < KK) {
+                const int kk = j / Cin, c = j - kk * Cin;
+                const int ky = kk / k, kx = kk - ky * k;
+                const int iy = oy * stride - pad + ky, ix = ox * stride - pad + kx;
+                if (iy >= 0 && iy < H && ix >= 0 && ix < W) x = img[((long)c * H + iy) * W + ix];
+            }
+            v.set(e, x);
+        }
+        st16<bf16>(cols + r * Kpad + (long)jv * 8, v);
     }
 }
 
@@ -62,6 +125,40 @@ __global__ void col2im_kernel(const T* __restrict__ dcols, int nB, int H, int W,
             }
         }
         dsrc[i] = s;
+    }
+}
+
+// the same gather, eight channels (one 16-byte vector of bf16 columns, two of fp32 output) per thread
+__global__ __launch_bounds__(256) void col2im_vec_kernel(const bf16* __restrict__ dcols, int nB, int H, int W, int Cin, int k, int stride, int pad,
+                                                         int Ho, int Wo, int Kpad, float* __restrict__ dsrc) {
+    const int cv = Cin / 8;
+    const long total = (long)nB * H * W * cv;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c0 = (int)(i % cv) * 8;
+        const long p = i / cv;
+        const int ix = (int)(p % W);
+        const long t = p / W;
+        const int iy = (int)(t % H);
+        const long b = t / H;
+        float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int ky = 0; ky < k; ++ky) {
+            const int ty = iy + pad - ky;
+            if (ty < 0 || ty % stride != 0) continue;
+            const int oy = ty / stride;
+            if (oy >= Ho) continue;
+            for (int kx = 0; kx < k; ++kx) {
+                const int tx = ix + pad - kx;
+                if (tx < 0 || tx % stride != 0) continue;
+                const int ox = tx / stride;
+                if (ox >= Wo) continue;
+                const Vec16<bf16> v = ld16<bf16>(dcols + ((b * Ho + oy) * Wo + ox) * Kpad + (ky * k + kx) * Cin + c0);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s[e] += v.get(e);
+            }
+        }
+        float* d = dsrc + p * Cin + c0;
+        *reinterpret_cast<f32x4*>(d) = f32x4{s[0], s[1], s[2], s[3]};
+        *reinterpret_cast<f32x4*>(d + 4) = f32x4{s[4], s[5], s[6], s[7]};
     }
 }
 
@@ -147,6 +244,123 @@ __global__ __launch_bounds__(256) void dwconv3x3_wgrad_kernel(const T* __restric
 #pragma unroll
             for (int e = 0; e < 4; ++e) ws[((long)blockIdx.x * C + c + e) * 9 + t] = s[e];
         }
+    }
+}
+
+// ---- strip versions (bf16, C % 8 == 0): a thread owns eight channels of FOUR consecutive positions of a row.  The three source rows
+// of a strip are loaded once as six 16-byte vectors each (18 loads for 4 outputs instead of 36 eight-byte loads), the index
+// arithmetic is paid once per strip, and the 3 x 3 taps slide over registers.  (The per-position kernels above are issue-bound:
+// 83 us / 200 us per launch on CvT-13's stages against ~20 us of traffic.)
+constexpr int DW_SW = 4;
+
+__device__ __forceinline__ void dw_load_row(const bf16* __restrict__ row, int ix0, int W, int C, Vec16<bf16> (&v)[DW_SW + 2]) {
+#pragma unroll
+    for (int q = 0; q < DW_SW + 2; ++q) {
+        const int sx = ix0 - 1 + q;
+        v[q] = (sx >= 0 && sx < W) ? ld16<bf16>(row + (long)sx * C) : zero16<bf16>();
+    }
+}
+
+__global__ __launch_bounds__(256) void dwconv3x3_strip_kernel(const bf16* __restrict__ x, const float* __restrict__ w, int flip, int nB, int H, int W,
+                                                              int C, bf16* __restrict__ y) {
+    const int c = threadIdx.x * 8, PY = blockDim.y;
+    // the 72 taps of this thread's eight channels are contiguous in w [C][9]: eighteen 16-byte loads
+    float wraw[72];
+#pragma unroll
+    for (int q = 0; q < 18; ++q) {
+        const f32x4 v4 = *reinterpret_cast<const f32x4*>(w + c * 9 + 4 * q);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) wraw[4 * q + e] = v4[e];
+    }
+    float wt[9][8];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) wt[t][e] = flip ? wraw[e * 9 + 8 - t] : wraw[e * 9 + t];
+    const int strips_w = (W + DW_SW - 1) / DW_SW;
+    const long S = (long)nB * H * strips_w;
+    for (long s = (long)blockIdx.x * PY + threadIdx.y; s < S; s += (long)gridDim.x * PY) {
+        const int ix0 = (int)(s % strips_w) * DW_SW;
+        const long t = s / strips_w;
+        const int iy = (int)(t % H);
+        const long b = t / H;
+        float acc[DW_SW][8];
+#pragma unroll
+        for (int o = 0; o < DW_SW; ++o)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[o][e] = 0.f;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int sy = iy + ky - 1;
+            if (sy < 0 || sy >= H) continue;
+            Vec16<bf16> v[DW_SW + 2];
+            dw_load_row(x + ((b * H + sy) * (long)W) * C + c, ix0, W, C, v);
+#pragma unroll
+            for (int o = 0; o < DW_SW; ++o)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[o][e] = fmaf(v[o + kx].get(e), wt[ky * 3 + kx][e], acc[o][e]);
+        }
+#pragma unroll
+        for (int o = 0; o < DW_SW; ++o) {
+            if (ix0 + o >= W) break;
+            Vec16<bf16> ov;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ov.set(e, acc[o][e]);
+            st16<bf16>(y + ((b * H + iy) * (long)W + ix0 + o) * C + c, ov);
+        }
+    }
+}
+
+// ws[blk][(c+e)*9 + t]: the same partial layout as dwconv3x3_wgrad_kernel
+__global__ __launch_bounds__(256) void dwconv3x3_wgrad_strip_kernel(const bf16* __restrict__ x, const bf16* __restrict__ dy, int nB, int H, int W, int C,
+                                                                    float* __restrict__ ws) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* sm = reinterpret_cast<float*>(smem_raw);  // [PY][CV][72]
+    const int cv = threadIdx.x, c = cv * 8, PY = blockDim.y, CV = blockDim.x;
+    float acc[9][8];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[t][e] = 0.f;
+    const int strips_w = (W + DW_SW - 1) / DW_SW;
+    const long S = (long)nB * H * strips_w;
+    for (long s = (long)blockIdx.x * PY + threadIdx.y; s < S; s += (long)gridDim.x * PY) {
+        const int ix0 = (int)(s % strips_w) * DW_SW;
+        const long t = s / strips_w;
+        const int iy = (int)(t % H);
+        const long b = t / H;
+        Vec16<bf16> g[DW_SW];
+#pragma unroll
+        for (int o = 0; o < DW_SW; ++o) g[o] = (ix0 + o < W) ? ld16<bf16>(dy + ((b * H + iy) * (long)W + ix0 + o) * C + c) : zero16<bf16>();
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int sy = iy + ky - 1;
+            if (sy < 0 || sy >= H) continue;
+            Vec16<bf16> v[DW_SW + 2];
+            dw_load_row(x + ((b * H + sy) * (long)W) * C + c, ix0, W, C, v);
+#pragma unroll
+            for (int o = 0; o < DW_SW; ++o)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[ky * 3 + kx][e] = fmaf(g[o].get(e), v[o + kx].get(e), acc[ky * 3 + kx][e]);
+        }
+    }
+    float* mine = sm + ((long)threadIdx.y * CV + cv) * 72;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) mine[t * 8 + e] = acc[t][e];
+    __syncthreads();
+    // 72 CV sums over the PY position lanes, spread over the block's threads
+    const int tid = threadIdx.y * CV + cv, nthr = PY * CV;
+    for (int i = tid; i < CV * 72; i += nthr) {
+        const int cvi = i / 72, te = i % 72;
+        float sum = 0.f;
+        for (int yy = 0; yy < PY; ++yy) sum += sm[((long)yy * CV + cvi) * 72 + te];
+        ws[((long)blockIdx.x * C + cvi * 8 + (te & 7)) * 9 + (te >> 3)] = sum;
     }
 }
 
@@ -298,6 +512,18 @@ extern "C" int esvit_conv_im2col(int dtype, const void* src, int nchw, int nB, i
     ESVIT_CHECK_ARG(Ho == (H + 2 * pad - k) / stride + 1 && Wo == (W + 2 * pad - k) / stride + 1, "esvit_conv_im2col: bad output size");
     ESVIT_CHECK_ARG(dtype == ESVIT_BF16 || dtype == ESVIT_F32, "esvit_conv_im2col: bad dtype");
     const long total = (long)nB * Ho * Wo * Kpad;
+    if (dtype == ESVIT_BF16 && !nchw && Cin % 8 == 0 && Kpad % 8 == 0 && ((uintptr_t)src % 16 == 0) && ((uintptr_t)cols % 16 == 0)) {
+        hipLaunchKernelGGL(im2col_nhwc_vec_kernel<bf16>, dim3(grid_for(total / 8)), dim3(256), 0, stream, reinterpret_cast<const bf16*>(src), nB, H, W, Cin,
+                           k, stride, pad, Ho, Wo, Kpad, reinterpret_cast<bf16*>(cols));
+        ESVIT_CHECK_LAUNCH("conv_im2col(nhwc)");
+        return ESVIT_OK;
+    }
+    if (dtype == ESVIT_BF16 && nchw && Kpad % 8 == 0 && ((uintptr_t)cols % 16 == 0)) {
+        hipLaunchKernelGGL(im2col_nchw_vec_kernel, dim3(grid_for(total / 8)), dim3(256), 0, stream, reinterpret_cast<const float*>(src), nB, H, W, Cin, k,
+                           stride, pad, Ho, Wo, Kpad, reinterpret_cast<bf16*>(cols));
+        ESVIT_CHECK_LAUNCH("conv_im2col(nchw)");
+        return ESVIT_OK;
+    }
     if (dtype == ESVIT_BF16)
         hipLaunchKernelGGL(im2col_kernel<bf16>, dim3(grid_for(total)), dim3(256), 0, stream, src, nchw, nB, H, W, Cin, k, stride, pad, Ho, Wo,
                            Kpad, reinterpret_cast<bf16*>(cols));
@@ -315,6 +541,12 @@ extern "C" int esvit_conv_col2im(int dtype, const void* dcols, int nB, int H, in
                     "esvit_conv_col2im: bad args");
     ESVIT_CHECK_ARG(dtype == ESVIT_BF16 || dtype == ESVIT_F32, "esvit_conv_col2im: bad dtype");
     const long total = (long)nB * H * W * Cin;
+    if (dtype == ESVIT_BF16 && Cin % 8 == 0 && Kpad % 8 == 0 && ((uintptr_t)dcols % 16 == 0) && ((uintptr_t)dsrc % 16 == 0)) {
+        hipLaunchKernelGGL(col2im_vec_kernel, dim3(grid_for(total / 8)), dim3(256), 0, stream, reinterpret_cast<const bf16*>(dcols), nB, H, W, Cin, k,
+                           stride, pad, Ho, Wo, Kpad, dsrc);
+        ESVIT_CHECK_LAUNCH("conv_col2im(vec)");
+        return ESVIT_OK;
+    }
     if (dtype == ESVIT_BF16)
         hipLaunchKernelGGL(col2im_kernel<bf16>, dim3(grid_for(total)), dim3(256), 0, stream, reinterpret_cast<const bf16*>(dcols), nB, H, W,
                            Cin, k, stride, pad, Ho, Wo, Kpad, dsrc);
@@ -330,6 +562,15 @@ extern "C" int esvit_dwconv3x3(int dtype, const void* x, const float* w, int fli
     ESVIT_CHECK_ARG(x && w && y && nB > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "esvit_dwconv3x3: bad args (C=%d)", C);
     ESVIT_CHECK_ARG(dtype == ESVIT_BF16 || dtype == ESVIT_F32, "esvit_dwconv3x3: bad dtype");
     ESVIT_CHECK_ARG(C / 4 <= 256, "esvit_dwconv3x3: C=%d too wide", C);
+    if (dtype == ESVIT_BF16 && C % 8 == 0 && C / 8 <= 256 && ((uintptr_t)x % 16 == 0) && ((uintptr_t)y % 16 == 0) && ((uintptr_t)w % 16 == 0)) {
+        const int cvn = C / 8;
+        const dim3 blk(cvn, 256 / cvn > 0 ? 256 / cvn : 1);
+        const long strips = (long)nB * H * ((W + DW_SW - 1) / DW_SW);
+        hipLaunchKernelGGL(dwconv3x3_strip_kernel, dim3(grid_for(strips, (int)blk.y, 2048)), blk, 0, stream, reinterpret_cast<const bf16*>(x), w, flip, nB, H,
+                           W, C, reinterpret_cast<bf16*>(y));
+        ESVIT_CHECK_LAUNCH("dwconv3x3(strip)");
+        return ESVIT_OK;
+    }
     const dim3 block = chan_block(C);
     const int grid = grid_for((long)nB * H * W, (int)block.y, 4096);
     if (dtype == ESVIT_BF16)
@@ -351,6 +592,20 @@ extern "C" int esvit_dwconv3x3_wgrad(int dtype, const void* x, const void* dy, i
     ESVIT_CHECK_ARG(dtype == ESVIT_BF16 || dtype == ESVIT_F32, "esvit_dwconv3x3_wgrad: bad dtype");
     ESVIT_CHECK_ARG(C % 4 == 0 && C / 4 <= 256, "esvit_dwconv3x3_wgrad: bad C=%d", C);
     const int nblk = reduce_blocks((long)nB * H * W);
+    if (dtype == ESVIT_BF16 && C % 8 == 0 && C / 8 <= 256 && ((uintptr_t)x % 16 == 0) && ((uintptr_t)dy % 16 == 0)) {
+        const int cvn = C / 8;
+        const dim3 blk(cvn, 256 / cvn > 0 ? 256 / cvn : 1);
+        const size_t lds_s = (size_t)blk.x * blk.y * 72 * sizeof(float);
+        static bool attr_done = false;
+        if (!attr_done) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dwconv3x3_wgrad_strip_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 73728);
+            attr_done = true;
+        }
+        hipLaunchKernelGGL(dwconv3x3_wgrad_strip_kernel, dim3(nblk), blk, lds_s, stream, reinterpret_cast<const bf16*>(x),
+                           reinterpret_cast<const bf16*>(dy), nB, H, W, C, ws);
+        ESVIT_CHECK_LAUNCH("dwconv3x3_wgrad(strip)");
+        return esvit_partial_reduce(ws, nblk, 9 * C, 9L * C, dw, 0, stream);
+    }
     const dim3 block = chan_block(C);
     const size_t lds = (size_t)block.x * block.y * 9 * sizeof(f32x4);
     if (dtype == ESVIT_BF16)

@@ -408,6 +408,12 @@ def test_cvt_conv_pieces(mods, dt):
     img = _rand((3, 3, 40, 40), dev, 70)
     _close("im2col nchw", ops.conv_im2col(img, True, 3, 40, 40, 3, 7, 4, 2, dtype=dt), ref.conv_im2col(img, True, 3, 40, 40, 3, 7, 4, 2, dtype=dt),
            _tol(dt))
+    # Vision Longformer's patch embeddings: 4x4 stride 4 on images, 2x2 stride 2 on tokens, no padding
+    _close("im2col nchw k4", ops.conv_im2col(img, True, 3, 40, 40, 3, 4, 4, 0, dtype=dt), ref.conv_im2col(img, True, 3, 40, 40, 3, 4, 4, 0, dtype=dt), _tol(dt))
+    tok = _rand((2 * 12 * 12, 48), dev, 76, dt)
+    _close("im2col nhwc k2", ops.conv_im2col(tok, False, 2, 12, 12, 48, 2, 2, 0), ref.conv_im2col(tok, False, 2, 12, 12, 48, 2, 2, 0), _tol(dt))
+    dcols = _rand((2 * 6 * 6, 4 * 48), dev, 77, dt)
+    _close("col2im k2", ops.conv_col2im(dcols, 2, 12, 12, 48, 2, 2, 0), ref.conv_col2im(dcols, 2, 12, 12, 48, 2, 2, 0), _tol(dt, f32=1e-5, bf=1e-5))
     # later embeds: 3x3 stride 2 pad 1 on NHWC tokens, odd and even grids
     for H, Cin in ((14, 64), (5, 24)):
         tok = _rand((2 * H * H, Cin), dev, 71, dt)
