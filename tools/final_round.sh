@@ -9,7 +9,7 @@ timeout 900 python -m pytest tests -m gpu -q -rP 2>&1 | grep -v "Warning\|warn" 
 cp gpurun_out/parity_observed.jsonl $out/parity_observed.jsonl 2>/dev/null
 bash tools/gpu_profile.sh $tag 128 > $out/profile.log 2>&1; tail -c 600 gpurun_out/prof_$tag/bench.json; echo
 python tools/pmc_traffic.py gpurun_out/prof_$tag/pmc/fetch_counter_collection.csv gpurun_out/prof_$tag/pmc/write_counter_collection.csv swin_tiny_w7 128 3
-for cfg in "swin_tiny_w7 64" "swin_tiny_w7 32" "swin_tiny_w14 128" "swin_base_w14 32" "swin_base_w14 64" "cvt_s1 64" "cvt_s1 128" "deit_tiny 128" "deit_small 128" "vit_base 64"; do
+for cfg in "swin_tiny_w7 64" "swin_tiny_w7 32" "swin_tiny_w14 128" "swin_base_w14 32" "swin_base_w14 64" "cvt_s1 64" "cvt_s1 128" "deit_tiny 128" "deit_small 128" "vit_base 64" "vil_tiny 64" "vil_tiny 128" "vil_small 64"; do
   set -- $cfg
   python bench.py --arch $1 --batch $2 --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | tail -1 > $out/bench_$1_b$2.json
   python -c "import json; d=json.load(open('$out/bench_$1_b$2.json')); print('$1 B=$2', round(d['value'],1), 'img/s', round(d['ms_per_step'],2), 'ms', 'step_mfma_frac', d.get('step_mfma_frac'))"

@@ -9,7 +9,7 @@ import bench
 dev = torch.device("cuda:0")
 esvit_amd.set_precision("bf16")
 torch.manual_seed(0)
-student, teacher, loss_fn = bench.build(dev, 0.1, "swin_tiny_w7")
+student, teacher, loss_fn = bench.build(dev, 0.1, sys.argv[1] if len(sys.argv) > 1 else "swin_tiny_w7")
 tr = EsvitTrainer(student, teacher, loss_fn, clip_grad=3.0, freeze_last_layer=1)
 crops = [c.to(dev) for c in GU.make_crops(8, seed=1)]
 for _ in range(2):
@@ -21,7 +21,7 @@ with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stac
     torch.cuda.synchronize()
 cnt = collections.Counter()
 for ev in prof.events():
-    if ev.name in ("aten::copy_", "aten::fill_", "aten::zero_", "aten::add_", "aten::add", "aten::clone", "aten::cat", "aten::mul", "aten::index", "aten::zeros"):
+    if ev.name in ("aten::copy_", "aten::fill_", "aten::zero_", "aten::add_", "aten::add", "aten::clone", "aten::cat", "aten::mul", "aten::index", "aten::zeros", "aten::div_", "aten::mul_", "aten::floor_", "aten::uniform_", "aten::rand", "aten::to", "aten::_to_copy", "aten::contiguous", "aten::sub", "aten::abs_"):
         st = ev.stack or []
         inner = next((f for f in st if "esvit_amd" in f), None) or (st[0] if st else "engine/unknown")
         cnt[(ev.name, inner[-70:])] += 1
