@@ -49,13 +49,15 @@ __global__ __launch_bounds__(256) void cast_kernel(const TS* __restrict__ src, T
 // stage 1: block = 32 column-vectors (8 columns each, one 16-byte load) x 8 row lanes over COLSUM_ROWS_PER_BLOCK rows
 constexpr int COLSUM_ROWS_PER_BLOCK = 256;
 template <typename T>
-__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, long rows, int N, long ld, float* __restrict__ ws) {
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, long rows, int N, long ld, float* __restrict__ ws, long rows_per_block,
+                                                     int direct_accumulate) {
+    // direct_accumulate >= 0: ONE row block (gridDim.y == 1) whose sums are the result: ws is the output, += when the flag is 1
     constexpr int V = Vec16<T>::N;
     __shared__ float sm[8][32 * V + 1];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const int n0 = (blockIdx.x * 32 + tx) * V;
-    const long r0 = (long)blockIdx.y * COLSUM_ROWS_PER_BLOCK;
-    const long r1 = min(rows, r0 + COLSUM_ROWS_PER_BLOCK);
+    const long r0 = (long)blockIdx.y * rows_per_block;
+    const long r1 = min(rows, r0 + rows_per_block);
     float acc[V];
 #pragma unroll
     for (int e = 0; e < V; ++e) acc[e] = 0.f;
@@ -80,6 +82,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, lo
             float s2 = 0.f;
 #pragma unroll
             for (int k = 0; k < 8; ++k) s2 += sm[k][i];
+            if (direct_accumulate == 1) s2 += ws[n];
             ws[(long)blockIdx.y * N + n] = s2;
         }
     }
@@ -249,14 +252,23 @@ extern "C" int esvit_colsum(int dtype, const void* x, int64_t rows, int N, int64
     ESVIT_CHECK_ARG(x && out && ws && rows > 0 && N > 0 && ld >= N, "esvit_colsum: bad args");
     ESVIT_CHECK_ARG(((uintptr_t)x % 16) == 0, "esvit_colsum: x must be 16-byte aligned");
     const int nblk = ceil_div(rows, COLSUM_ROWS_PER_BLOCK);
+    // few rows (the per-wave partial rows of the attention backward's pad-slot gradients, <= 4 row blocks): one pass straight into `out`
+    const bool direct = nblk <= 4;
+    const long rpb = direct ? rows : COLSUM_ROWS_PER_BLOCK;
+    float* dst = direct ? out : ws;
+    const int dflag = direct ? (accumulate ? 1 : 0) : -1;
     if (dtype == ESVIT_BF16) {
-        dim3 grid(ceil_div(N, 32 * 8), nblk);
-        hipLaunchKernelGGL(colsum_kernel<bf16>, grid, dim3(256), 0, stream, (const bf16*)x, (long)rows, N, (long)ld, ws);
+        dim3 grid(ceil_div(N, 32 * 8), direct ? 1 : nblk);
+        hipLaunchKernelGGL(colsum_kernel<bf16>, grid, dim3(256), 0, stream, (const bf16*)x, (long)rows, N, (long)ld, dst, rpb, dflag);
     } else if (dtype == ESVIT_F32) {
-        dim3 grid(ceil_div(N, 32 * 4), nblk);
-        hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, stream, (const float*)x, (long)rows, N, (long)ld, ws);
+        dim3 grid(ceil_div(N, 32 * 4), direct ? 1 : nblk);
+        hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, stream, (const float*)x, (long)rows, N, (long)ld, dst, rpb, dflag);
     } else {
         BAD_DTYPE("esvit_colsum");
+    }
+    if (direct) {
+        ESVIT_CHECK_LAUNCH("colsum");
+        return ESVIT_OK;
     }
     ESVIT_CHECK_LAUNCH("colsum");
     return esvit_partial_reduce(ws, nblk, N, N, out, accumulate, stream);

@@ -337,6 +337,12 @@ def test_small_ops(mods, dt):
     _close("cast", ops.cast_to_act(w, dtype=dt), ref.cast_to_act(w, dtype=dt), _tol(dt, bf=8e-3))
     xa = _rand((1300, 288), dev, 45, dt)
     _close("colsum", ops.colsum(xa), ref.colsum(xa), 5e-5)
+    for rows in (7, 600, 1024):  # few rows: the single-pass form, plain and accumulating into an existing vector
+        xb = _rand((rows, 200), dev, 48, torch.float32)
+        _close("colsum (few rows)", ops.colsum(xb), ref.colsum(xb), 5e-5)
+        base = _rand((200,), dev, 49)
+        got = ops.colsum(xb, out=base.clone(), accumulate=True)
+        _close("colsum (few rows, accumulate)", got, base + ref.colsum(xb), 5e-5)
     v = _rand((777,), dev, 46)
     _close("sum", ops.sum_f32(v), ref.sum_f32(v), 1e-5)
     xs, xs2 = xa.clone(), xa.clone()
