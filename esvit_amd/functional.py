@@ -663,6 +663,66 @@ def dino_head(x, prm, stats=None):
     return _head_forward(x, prm, False, stats)[0]
 
 
+class DinoHeadNFn(torch.autograd.Function):
+    """DINOHead with any number of Linear layers (vision_transformer.py:388-402, nlayers != 3, no BatchNorm): nlayers = 1 is one
+    Linear into the bottleneck, otherwise Linear + GELU (nlayers - 1 times) and a last Linear; then l2-normalise and the weight-normed
+    last layer as in DinoHeadFn.  params = (W_1, b_1, ..., W_L, b_L, weight_v, weight_g)."""
+
+    @staticmethod
+    def forward(ctx, x, stats, *params):
+        o = ops_module()
+        L = (len(params) - 2) // 2
+        Wp, bp = params[0:2 * L:2], params[1:2 * L:2]
+        v, g = params[2 * L], params[2 * L + 1]
+        Ws = [_weight(w) for w in Wp]
+        h = o.cast_to_act(x.contiguous())
+        acts, pres = [h], []
+        for i in range(L - 1):
+            hg, hpre = o.linear_fwd(acts[-1], Ws[i], bp[i], gelu=True, want_preact=True)
+            acts.append(hg)
+            pres.append(hpre)
+        hL = o.linear_fwd(acts[-1], Ws[L - 1], bp[L - 1])
+        z, inv = o.l2norm_fwd(hL)
+        w, winv = _last_layer_weight(v, g)
+        logits, mx, lse = _last_logits(o, z, w, stats)
+        ctx.L = L
+        ctx.need_dg = g.requires_grad
+        ctx.wparams, ctx.bparams, ctx.vparam = tuple(Wp), tuple(bp), v
+        ctx.save_for_backward(v, g, z, inv, w, winv, *Ws, *acts, *pres)
+        if mx is not None:
+            ctx.mark_non_differentiable(mx, lse)
+        return logits, mx, lse
+
+    @staticmethod
+    def backward(ctx, dlogits, _gmx=None, _glse=None):
+        o = ops_module()
+        L = ctx.L
+        t = ctx.saved_tensors
+        v, g, z, inv, w, winv = t[:6]
+        Ws, acts, pres = t[6:6 + L], t[6 + L:6 + 2 * L], t[6 + 2 * L:]
+        dlogits = dlogits.contiguous()
+        dz = o.linear_dgrad(dlogits, w)
+        dw = o.linear_wgrad(dlogits, z)
+        sink = P.grad_out(ctx.vparam)
+        dv, dg = o.weightnorm_bwd(dw, v, g, winv, ctx.need_dg, dv_out=sink)
+        if sink is not None:
+            dv = dv.detach()
+        dh = o.l2norm_bwd(dz, z, inv)
+        grads = [None] * (2 * L)
+        for i in range(L - 1, -1, -1):
+            grads[2 * i], grads[2 * i + 1] = _wgrad(dh, acts[i], ctx.wparams[i], want_bias=True, bias_param=ctx.bparams[i])
+            if i > 0:
+                dh = o.linear_dgrad(dh, Ws[i], gelu_preact=pres[i - 1])
+        dx = o.linear_dgrad(dh, Ws[0], out_f32=True)
+        return (dx, None) + tuple(grads) + (dv, dg)
+
+
+def dino_head_n(x, lin_params, v, g, stats=None):
+    """lin_params: [(W, b), ...] of the head's Linear layers in order -> (logits, row_max | None, row_lse | None)"""
+    flat = [p for wb in lin_params for p in wb]
+    return DinoHeadNFn.apply(x, stats, *flat, v, g)
+
+
 class ApeAddFn(torch.autograd.Function):
     """x + absolute_pos_embed (swin_transformer.py:680-681, USE_APE): x fp32 [nB, L, C], ape fp32 [1, L, C].  Viewed as
     [1, nB, L*C] the broadcast over the images is the token-broadcast of esvit_token_mean_bwd (x_b + nB*ape / nB), and the

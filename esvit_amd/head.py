@@ -22,8 +22,10 @@ class _WeightNormLinear(nn.Module):
 class DINOHead(nn.Module):
     def __init__(self, in_dim, out_dim, use_bn=False, norm_last_layer=True, nlayers=3, hidden_dim=2048, bottleneck_dim=256):
         super().__init__()
-        if max(nlayers, 1) != 3:
-            raise NotImplementedError("the fused head implements the reference default nlayers=3")
+        nlayers = max(nlayers, 1)
+        self.nlayers = nlayers
+        if nlayers != 3 and use_bn:
+            raise NotImplementedError("DINOHead with BatchNorm is built for the reference default nlayers = 3")
         self.use_bn = bool(use_bn)
         self.sync_bn_group = None  # process group of the batch statistics (None = default group; False = this rank only)
         # (inv_temp, centre | None, token) set by the loss for one step (loss.arm_logit_stats): the last-layer GEMM then also emits
@@ -32,10 +34,15 @@ class DINOHead(nn.Module):
         if use_bn:  # --use_bn_in_head (vision_transformer.py:391-402): mlp.{0,3,6} Linear, mlp.{1,4} BatchNorm1d
             self.mlp = nn.Sequential(nn.Linear(in_dim, hidden_dim), nn.BatchNorm1d(hidden_dim), nn.GELU(), nn.Linear(hidden_dim, hidden_dim),
                                      nn.BatchNorm1d(hidden_dim), nn.GELU(), nn.Linear(hidden_dim, bottleneck_dim))
-        else:
-            self.mlp = nn.Sequential(nn.Linear(in_dim, hidden_dim), nn.GELU(), nn.Linear(hidden_dim, hidden_dim), nn.GELU(),
-                                     nn.Linear(hidden_dim, bottleneck_dim))
-        for m in self.mlp:
+        elif nlayers == 1:  # vision_transformer.py:388-389
+            self.mlp = nn.Linear(in_dim, bottleneck_dim)
+        else:               # Linear + GELU (nlayers - 1 times), then the Linear into the bottleneck (vision_transformer.py:391-402)
+            layers = [nn.Linear(in_dim, hidden_dim), nn.GELU()]
+            for _ in range(nlayers - 2):
+                layers += [nn.Linear(hidden_dim, hidden_dim), nn.GELU()]
+            layers.append(nn.Linear(hidden_dim, bottleneck_dim))
+            self.mlp = nn.Sequential(*layers)
+        for m in (self.mlp.modules() if isinstance(self.mlp, nn.Sequential) else [self.mlp]):
             if isinstance(m, nn.Linear):
                 nn.init.trunc_normal_(m.weight, std=.02, a=-2.0, b=2.0)
                 nn.init.constant_(m.bias, 0)
@@ -61,6 +68,10 @@ class DINOHead(nn.Module):
             prm = [m[0].weight, m[0].bias, m[1].weight, m[1].bias, m[3].weight, m[3].bias, m[4].weight, m[4].bias, m[6].weight, m[6].bias,
                    self.last_layer.weight_v, self.last_layer.weight_g]
             return self._finish(Fn.dino_head_bn(x2, self._bn_state(m[1]), self._bn_state(m[4]), prm, self._stats_request()), lead)
+        if self.nlayers != 3:
+            lins = [self.mlp] if isinstance(self.mlp, nn.Linear) else [m for m in self.mlp if isinstance(m, nn.Linear)]
+            return self._finish(Fn.dino_head_n(x2, [(m.weight, m.bias) for m in lins], self.last_layer.weight_v, self.last_layer.weight_g,
+                                               self._stats_request()), lead)
         prm = [self.mlp[0].weight, self.mlp[0].bias, self.mlp[2].weight, self.mlp[2].bias, self.mlp[4].weight, self.mlp[4].bias,
                self.last_layer.weight_v, self.last_layer.weight_g]
         return self._finish(Fn.dino_head(x2, prm, self._stats_request()), lead)

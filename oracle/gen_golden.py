@@ -584,6 +584,23 @@ def gen_full_vil(ns):
     torch.save({name: _full_cfg_case(ns, name, c) for name, c in GU.FULL_VIL_CASES.items()}, os.path.join(OUT, "full_vil.pt"))
 
 
+def gen_head_nlayers(ns):
+    """the reference's DINOHead with nlayers = 1, 2, 4 (vision_transformer.py:388-402): logits, input gradient, parameter gradients"""
+    c = GU.HEAD_NLAYERS
+    out = {}
+    x, probe = GU.head_nlayers_inputs()
+    for n in c["cases"]:
+        head = ns.DINOHead(c["in_dim"], c["out_dim"], nlayers=n, hidden_dim=c["hidden_dim"], bottleneck_dim=c["bottleneck_dim"], norm_last_layer=False)
+        GU.fill_state_dict(head.state_dict(), 60 + n)
+        xr = x.clone().requires_grad_(True)
+        y = head(xr)
+        (y * probe).sum().backward()
+        out[n] = {"keys": [(k, tuple(v.shape)) for k, v in head.state_dict().items()], "logits": y.detach().clone(), "dx": xr.grad.clone(),
+                  "grads": {k: p.grad.clone() for k, p in head.named_parameters()}}
+    torch.save(out, os.path.join(OUT, "head_nlayers.pt"))
+    print("head_nlayers.pt:", {n: len(v["grads"]) for n, v in out.items()})
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ns = RL.load()
@@ -604,6 +621,8 @@ def main():
         gen_variants(ns)
     if not only or "linear" in only:
         gen_linear_probe(ns)
+    if not only or "head_nlayers" in only:
+        gen_head_nlayers(ns)
     if "full" in only:  # minutes of CPU time: regenerated on request only
         gen_full(ns)
     if "full_vit" in only:

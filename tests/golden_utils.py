@@ -207,3 +207,13 @@ def linear_probe_init(clf, seed=5):
     g = torch.Generator().manual_seed(seed)
     clf.linear.weight.data.copy_(0.01 * torch.randn(clf.linear.weight.shape, generator=g))
     clf.linear.bias.data.zero_()
+
+
+# ---- DINOHead(nlayers != 3) (vision_transformer.py:388-402) -------------------------------------------------------------
+HEAD_NLAYERS = dict(in_dim=48, out_dim=512, hidden_dim=64, bottleneck_dim=32, rows=24, cases=(1, 2, 4))
+
+
+def head_nlayers_inputs():
+    g = torch.Generator().manual_seed(515)
+    c = HEAD_NLAYERS
+    return torch.randn(c["rows"], c["in_dim"], generator=g), torch.randn(c["rows"], c["out_dim"], generator=g)

@@ -443,3 +443,50 @@ def test_odd_patch_merging_gpu(gold, prec, lib_built):
         _check_oddmerge(gold["oddmerge"], torch.device("cuda:0"), 2e-5 if prec == "fp32" else 3e-2)
     finally:
         esvit_amd.set_precision("bf16")
+
+
+# ---- DINOHead(nlayers != 3) (vision_transformer.py:388-402) -------------------------------------------------------------
+def _check_head_nlayers(dev, tol):
+    import esvit_amd
+    g = torch.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "head_nlayers.pt"), weights_only=False)
+    c = GU.HEAD_NLAYERS
+    x, probe = GU.head_nlayers_inputs()
+    for n in c["cases"]:
+        head = esvit_amd.DINOHead(c["in_dim"], c["out_dim"], nlayers=n, hidden_dim=c["hidden_dim"], bottleneck_dim=c["bottleneck_dim"],
+                                  norm_last_layer=False)
+        assert [(k, tuple(v.shape)) for k, v in head.state_dict().items()] == g[n]["keys"], n
+        GU.fill_state_dict(head.state_dict(), 60 + n)
+        head = head.to(dev)
+        xr = x.clone().to(dev).requires_grad_(True)
+        y = head(xr)
+        (y.float() * probe.to(dev)).sum().backward()
+        rel = lambda a, b: ((a.float().cpu() - b).abs().max() / (b.abs().max() + 1e-12)).item()
+        assert rel(y.detach(), g[n]["logits"]) < tol, (n, rel(y.detach(), g[n]["logits"]))
+        assert rel(xr.grad, g[n]["dx"]) < 3 * tol, (n, rel(xr.grad, g[n]["dx"]))
+        for k, p in head.named_parameters():
+            assert rel(p.grad, g[n]["grads"][k]) < 3 * tol, (n, k, rel(p.grad, g[n]["grads"][k]))
+
+
+def test_head_nlayers_host_logic_cpu(monkeypatch, lib_built):
+    """DINOHead with 1, 2 and 4 Linear layers (functional.DinoHeadNFn) vs the reference's own module (tests/golden/head_nlayers.pt)"""
+    import esvit_amd
+    import esvit_amd.functional as Fn
+    import esvit_amd.params as P
+    esvit_amd.set_precision("fp32")
+    for mod in (Fn, P):
+        monkeypatch.setattr(mod, "ops", ops_ref)
+    P.clear()
+    _check_head_nlayers(torch.device("cpu"), 2e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_head_nlayers_gpu(prec, lib_built):
+    import esvit_amd
+    from esvit_amd import params as P
+    esvit_amd.set_precision(prec)
+    P.clear()
+    try:
+        _check_head_nlayers(torch.device("cuda:0"), 2e-5 if prec == "fp32" else 2.5e-2)
+    finally:
+        esvit_amd.set_precision("bf16")
