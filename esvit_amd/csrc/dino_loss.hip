@@ -165,24 +165,53 @@ __global__ __launch_bounds__(NT) void dino_ce_kernel(const T* __restrict__ s, co
     const float C = -lse * LOG2E;
     const float gs = w * inv_st, gsn = gs * nterms;
     float dot = 0.f;  // sum_k p_t[k] * s[k] (raw logits; scaled by inv_st once at the end)
-    for (int k = threadIdx.x * V; k < K; k += NT * V) {
-        const Vec16<T> x = ld16<T>(srow + k);
-        const Vec16<T> y0 = ld16<T>(trow0 + k), y1 = ld16<T>(trow1 + k);
-        f32x4 cv[V / 4];
+    if (nterms == 2) {
+        for (int k = threadIdx.x * V; k < K; k += NT * V) {
+            const Vec16<T> x = ld16<T>(srow + k);
+            const Vec16<T> y0 = ld16<T>(trow0 + k), y1 = ld16<T>(trow1 + k);
+            f32x4 cv[V / 4];
 #pragma unroll
-        for (int q = 0; q < V / 4; ++q) cv[q] = *reinterpret_cast<const f32x4*>(center + k + 4 * q);
-        Vec16<T> o;
+            for (int q = 0; q < V / 4; ++q) cv[q] = *reinterpret_cast<const f32x4*>(center + k + 4 * q);
+            Vec16<T> o;
 #pragma unroll
-        for (int e = 0; e < V; ++e) {
-            const float xe = x.get(e);
-            const float ps = __builtin_amdgcn_exp2f(fmaf(xe, A, C));
-            const float ck = cv[e / 4][e & 3];
-            const float nbk = -ck * At;  // (y - c) * inv_tt * log2(e) = y * At + nbk
-            const float pt = __builtin_amdgcn_exp2f(fmaf(y0.get(e), At, nbk - off0)) + __builtin_amdgcn_exp2f(fmaf(y1.get(e), At, nbk - off1));
-            dot = fmaf(pt, xe, dot);
-            o.set(e, fmaf(ps, gsn, -gs * pt));
+            for (int e = 0; e < V; ++e) {
+                const float xe = x.get(e);
+                const float ps = __builtin_amdgcn_exp2f(fmaf(xe, A, C));
+                const float ck = cv[e / 4][e & 3];
+                const float nbk = -ck * At;  // (y - c) * inv_tt * log2(e) = y * At + nbk
+                const float pt = __builtin_amdgcn_exp2f(fmaf(y0.get(e), At, nbk - off0)) + __builtin_amdgcn_exp2f(fmaf(y1.get(e), At, nbk - off1));
+                dot = fmaf(pt, xe, dot);
+                o.set(e, fmaf(ps, gsn, -gs * pt));
+            }
+            st16<T>(drow + k, o);
         }
-        st16<T>(drow + k, o);
+    } else {
+        // one teacher term (the rows of a global crop are not scored against their own view, main_esvit.py:636-638, 719-721: 58 % of the
+        // region rows): one exponential and one teacher row less per logit; no term at all: the gradient is zero
+        const T* trow = t0 >= 0 ? trow0 : trow1;
+        const float off = t0 >= 0 ? off0 : off1;
+        for (int k = threadIdx.x * V; k < K; k += NT * V) {
+            const Vec16<T> x = ld16<T>(srow + k);
+            Vec16<T> o;
+            if (nterms == 1) {
+                const Vec16<T> y = ld16<T>(trow + k);
+                f32x4 cv[V / 4];
+#pragma unroll
+                for (int q = 0; q < V / 4; ++q) cv[q] = *reinterpret_cast<const f32x4*>(center + k + 4 * q);
+#pragma unroll
+                for (int e = 0; e < V; ++e) {
+                    const float xe = x.get(e);
+                    const float ps = __builtin_amdgcn_exp2f(fmaf(xe, A, C));
+                    const float pt = __builtin_amdgcn_exp2f(fmaf(y.get(e), At, -cv[e / 4][e & 3] * At - off));
+                    dot = fmaf(pt, xe, dot);
+                    o.set(e, fmaf(ps, gsn, -gs * pt));
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < V; ++e) o.set(e, 0.f);
+            }
+            st16<T>(drow + k, o);
+        }
     }
     dot = block_sum<NT>(dot, sm2) * inv_st;
     if (threadIdx.x == 0) row_loss[r] = w * (nterms * lse - dot);
