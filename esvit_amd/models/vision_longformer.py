@@ -347,6 +347,72 @@ class MsViT(nn.Module):
                 start_blk = 0
         return torch.cat(output, dim=-1)
 
+    # ---- ragged multi-crop route: the full-attention stages see the token rows of all resolution groups at once ------------------
+    ragged_multi_crop = True  # (False: one pass per resolution group, the reference's schedule)
+
+    def _forward_ragged(self, runs):
+        """-> LayerNorm-ed last-stage tokens per group.  Patch embeddings and sliding-chunk stages run per group (their geometry
+        differs); in the full-attention stages LayerNorm, the four GEMMs and the residual adds of a block pair are row-wise, so the rows
+        of all groups go through ONE set of launches (functional.vit_block_multi: the attention per group on its row range) -- half the
+        launches there, one gradient contribution per parameter, half the split-K partial traffic (cf. the ViT route, section 10)"""
+        dev = runs[0].device
+        st = [dict(src=r, nB=r.shape[0], H=r.shape[2], W=r.shape[3], nchw=True) for r in runs]
+        nsamp = sum(g["nB"] for g in st)
+        outs = None
+        for i, (layer, cfg) in enumerate(zip(self._layers(), self.layer_cfgs)):
+            sparse = isinstance(layer[1].attn, Long2DSCSelfAttention)
+            if sparse:
+                xs = []
+                for g in st:
+                    x, nx, ny = self._stage(layer, cfg, g["src"], g["nB"], g["H"], g["W"], g["nchw"])
+                    xs.append(x)
+                    g["nx"], g["ny"] = nx, ny
+            else:
+                toks = []
+                for g in st:
+                    t, nx, ny = layer[0](g["src"], g["nB"], g["H"], g["W"], g["nchw"])
+                    toks.append(t)
+                    g["nx"], g["ny"] = nx, ny
+                C = toks[0].shape[-1]
+                segs, row0 = [], 0
+                for t in toks:
+                    segs.append((row0, t.shape[0], t.shape[1]))
+                    row0 += t.shape[0] * t.shape[1]
+                segs = tuple(segs)
+                X = torch.cat([t.reshape(-1, C) for t in toks])
+                idx = None
+                for b in range(1, len(layer), 2):
+                    ab, mb = layer[b], layer[b + 1]
+                    dp = None
+                    if self.training and isinstance(ab.drop_path, DropPath) and ab.drop_path.drop_prob > 0:
+                        keep = 1.0 - ab.drop_path.drop_prob
+                        f = (keep + torch.rand(2, nsamp, device=dev)).floor_().div_(keep)
+                        if idx is None:  # rows of a sample share its factor (built on the host once per batch geometry)
+                            cache = self.__dict__.setdefault("_row2sample", {})
+                            idx = cache.get((segs, str(dev)))
+                            if idx is None:
+                                idx = cache[(segs, str(dev))] = torch.from_numpy(np.repeat(np.arange(nsamp), [n for (_, nB, n) in segs for _ in range(nB)])).to(dev)
+                        fr = f.index_select(1, idx)
+                        dp = (fr[0], fr[1])
+                    a = ab.attn
+                    prm = (ab.norm.weight, ab.norm.bias, a.qkv.weight, a.qkv.bias, a.proj.weight, a.proj.bias, mb.norm.weight, mb.norm.bias,
+                           mb.mlp.fc1.weight, mb.mlp.fc1.bias, mb.mlp.fc2.weight, mb.mlp.fc2.bias)
+                    X = Fn.vit_block_multi(X, segs, cfg['h'], dp, prm)
+                if i + 1 == self.num_layers:
+                    X = Fn.FinalNormFn.apply(X.view(1, -1, C), self.norm.weight, self.norm.bias).view(-1, C)
+                xs = [X[r0:r0 + nB * n].view(nB, n, C) for (r0, nB, n) in segs]
+            if i + 1 < self.num_layers:
+                for g, x in zip(st, xs):
+                    g.update(src=x[:, cfg['g']:].contiguous(), H=g["nx"], W=g["ny"], nchw=False)
+            else:
+                outs = xs if not sparse else [Fn.FinalNormFn.apply(x, self.norm.weight, self.norm.bias) for x in xs]
+        return outs
+
+    def _split_features(self, x):
+        if self.Nglos[-1] > 0 and not self.avg_pool:
+            return x[:, 0], x[:, 1:]
+        return Fn.TokenMeanFn.apply(x), x
+
     # ---- multi-crop forward (vision_longformer.py:699-752) ---------------------------------------------------------------
     def forward(self, x):
         crops = x if isinstance(x, list) else [x]
@@ -355,6 +421,12 @@ class MsViT(nn.Module):
             if i == len(crops) or crops[i].shape[-1] != crops[start].shape[-1]:
                 runs.append(torch.cat(crops[start:i]))
                 start = i
+        if self.ragged_multi_crop and len(runs) > 1:
+            parts = [self._split_features(m) for m in self._forward_ragged(runs)]
+            if not self.use_dense_prediction:
+                return self.head(torch.cat([c for c, _ in parts]))
+            feats = torch.cat([f.reshape(-1, f.shape[-1]) for _, f in parts])
+            return self.head(torch.cat([c for c, _ in parts])), self.head_dense(feats), feats, [f.shape[1] for _, f in parts]
         if not self.use_dense_prediction:
             return self.head(torch.cat([self.forward_features(r) for r in runs]))
         cls, fea, npatch = [], [], []

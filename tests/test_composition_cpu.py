@@ -530,6 +530,33 @@ def test_vil_full_width_composition_matches_reference_golden(name, cpu_ops):
     check_full_vil_case(name, torch.device("cpu"), True, (1e-4, 1e-4, 2e-3, 5e-3))
 
 
+def test_vil_ragged_route_equals_reference_schedule(cpu_ops):
+    """the full-attention stages over the rows of all resolution groups at once (MsViT._forward_ragged) vs one pass per group
+    (vision_longformer.py:699-752): same outputs and gradients"""
+    import esvit_amd
+    from esvit_amd import config as CFG
+    arch = 'l1,h1,d32,n1,s1,g1,p4,f7_l2,h2,d64,n1,s1,g1,p2,f7_l3,h2,d64,n2,s0,g1,p2,f7_l4,h2,d64,n1,s0,g0,p2,f7'
+    cfg = CFG.vil_config("vil_tiny", arch=arch, DROP_PATH=0.0)
+    crops = [torch.randn(2, 3, 112, 112) for _ in range(2)] + [torch.randn(2, 3, 48, 48) for _ in range(3)]
+    outs, grads = [], []
+    for ragged in (True, False):
+        torch.manual_seed(0)
+        m = esvit_amd.build_model(cfg, use_dense_prediction=True)
+        GU.fill_state_dict(m.state_dict(), 3)
+        m.head_dense = torch.nn.Identity()
+        m.ragged_multi_crop = ragged
+        o = m([c.clone() for c in crops])
+        (o[0].square().sum() + o[1].square().mean()).backward()
+        outs.append(o)
+        grads.append({k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None})
+    assert outs[0][3] == outs[1][3]
+    for a, b in zip(outs[0][:3], outs[1][:3]):
+        assert (a - b).abs().max().item() < 1e-5 * (1 + b.abs().max().item())
+    assert set(grads[0]) == set(grads[1])
+    for k in grads[0]:
+        assert (grads[0][k] - grads[1][k]).norm().item() < 1e-4 * (1e-6 + grads[1][k].norm().item()), k
+
+
 def test_vil_refuses_what_is_not_built():
     from esvit_amd import config as CFG
     import esvit_amd
