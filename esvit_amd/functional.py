@@ -922,15 +922,25 @@ class ConvEmbedFn(torch.autograd.Function):
 class CvtAttnFn(torch.autograd.Function):
     """x + DropPath(Attention(LayerNorm(x)))  (cvt_v4_transformer.py:331-336, 49-58, 108-220): LN -> zero-pad the grid to a
     multiple of the window -> depthwise 3x3 -> BatchNorm (batch statistics, synchronised across ranks) -> 1x1 to q|k|v ->
-    windowed attention (w = min(window, H, W), scale = dim ** -0.5, no bias / mask in s1.yaml) -> crop -> 1x1 proj."""
+    windowed attention (w = min(window, H, W), scale = dim ** -0.5) -> crop -> 1x1 proj.  Optional (s1_rpe.yaml / s1_shift.yaml):
+    a relative-position bias table (`table_p`, `index`) and the shifted-window mask of a half-window shift on the UNROLLED map
+    (`shift`: cvt_v4_transformer.py:291-329 builds the Swin mask, :332 hands it to every block, nothing rolls)."""
 
     @staticmethod
-    def forward(ctx, x, H, W, nH, window, dp, bn_state, g1, b1, dw_w, bn_g, bn_b, pw_Wp, pw_b, proj_Wp, proj_b):
+    def forward(ctx, x, H, W, nH, window, dp, bn_state, g1, b1, dw_w, bn_g, bn_b, pw_Wp, pw_b, proj_Wp, proj_b, table_p=None, index=None,
+                shift=False):
         o = ops_module()
         nB, L, C = x.shape
         x = x.contiguous()
         x2d = x.view(nB * L, C)
         w = min(window, H, W)
+        if (table_p is not None or shift) and w != window:
+            # the reference adds a [window^2, window^2] bias / mask to [w^2, w^2] scores here and fails on the shapes
+            raise RuntimeError("CvT relative-position bias / shift mask on a %dx%d map: smaller than the %dx%d window" % (H, W, window, window))
+        if shift and (H % w or W % w):
+            # the reference's masked branch overwrites its map height with the head count (cvt_v4_transformer.py:201) and then crops
+            # the padded output with it: only maps that need no padding come through
+            raise RuntimeError("CvT shift mask on a %dx%d map: not a multiple of the %dx%d window" % (H, W, window, window))
         Hp, Wp = -(-H // w) * w, -(-W // w) * w
         xn, _, mean1, rstd1 = o.layernorm_fwd(x2d, g1, b1, CVT_LN_EPS)
         xp = _pad_tokens(xn, nB, H, W, Hp, Wp)
@@ -952,22 +962,23 @@ class CvtAttnFn(torch.autograd.Function):
         Wpw, Wproj = _weight(pw_Wp, (3 * C, C)), _weight(proj_Wp, (C, C))
         qkv = o.linear_fwd(bnout, Wpw, pw_b)
         geom = geometry(Hp, Wp, w, 0, x.device)
-        table = _zero_table(w, nH, x.device)
+        table = _zero_table(w, nH, x.device) if table_p is None else table_p.detach()
+        regions = geometry(Hp, Wp, w, w // 2, x.device).region_ids if shift else None
         scale = float(C) ** -0.5
-        ao, lse = o.window_attn_fwd(qkv, pw_b, geom.win2tok, Hp * Wp, table, w, None, geom.nW, geom.N, nH, scale)
+        ao, lse = o.window_attn_fwd(qkv, pw_b, geom.win2tok, Hp * Wp, table, w, regions, geom.nW, geom.N, nH, scale)
         aoc = _crop_tokens(ao, nB, H, W, Hp, Wp)
         x1 = o.linear_fwd(aoc, Wproj, proj_b, residual=x2d, rowscale=dp, rows_per_sample=L, out_f32=True)
-        ctx.meta = (H, W, Hp, Wp, w, nH, scale, dp, bn_state.get("group"), eval_bn)
+        ctx.meta = (H, W, Hp, Wp, w, nH, scale, dp, bn_state.get("group"), eval_bn, table_p is not None, shift)
         ctx.n = n
-        ctx.save_for_backward(x, mean1, rstd1, g1, xp, dw9, d, coef, gam, bnout, Wpw, pw_b, qkv, ao, aoc, Wproj)
+        ctx.save_for_backward(x, mean1, rstd1, g1, xp, dw9, d, coef, gam, bnout, Wpw, pw_b, qkv, ao, aoc, Wproj, lse, table, index)
         return x1.view(nB, L, C)
 
     @staticmethod
     def backward(ctx, gy):
         o = ops_module()
-        x, mean1, rstd1, g1, xp, dw9, d, coef, gam, bnout, Wpw, pw_b, qkv, ao, aoc, Wproj = ctx.saved_tensors
+        x, mean1, rstd1, g1, xp, dw9, d, coef, gam, bnout, Wpw, pw_b, qkv, ao, aoc, Wproj, lse, table, index = ctx.saved_tensors
         n = ctx.n
-        H, W, Hp, Wp, w, nH, scale, dp, group, eval_bn = ctx.meta
+        H, W, Hp, Wp, w, nH, scale, dp, group, eval_bn, has_table, shift = ctx.meta
         nB, L, C = x.shape
         M = nB * L
         gy = gy.contiguous().view(M, C)
@@ -975,8 +986,9 @@ class CvtAttnFn(torch.autograd.Function):
         dWproj, dbproj = o.linear_wgrad(dyb, aoc, want_bias=True)
         dao = _pad_tokens(o.linear_dgrad(dyb, Wproj), nB, H, W, Hp, Wp)
         geom = geometry(Hp, Wp, w, 0, x.device)
-        table = _zero_table(w, nH, x.device)
-        dqkv, _, _ = o.window_attn_bwd(qkv, pw_b, geom.win2tok, Hp * Wp, dao, ao, None, table, w, None, geom.nW, geom.N, nH, scale)
+        regions = geometry(Hp, Wp, w, w // 2, x.device).region_ids if shift else None
+        dqkv, dbias_ws, _ = o.window_attn_bwd(qkv, pw_b, geom.win2tok, Hp * Wp, dao, ao, lse, table, w, regions, geom.nW, geom.N, nH, scale)
+        dtable = o.relpos_bias_bwd(dbias_ws, index, geom.N, table.shape[0]) if has_table else None
         dWpw, dbpw = o.linear_wgrad(dqkv, bnout, want_bias=True)
         dbn = o.linear_dgrad(dqkv, Wpw)
         # BatchNorm backward: d(d) = gamma rstd (dy - mean(dy) - xhat mean(dy xhat)), xhat = (d - mean) rstd
@@ -992,7 +1004,7 @@ class CvtAttnFn(torch.autograd.Function):
         dxn = _crop_tokens(o.dwconv3x3(dd, dw9, nB, Hp, Wp, flip=True), nB, H, W, Hp, Wp)
         gx, dg1, db1 = o.layernorm_bwd(dxn, x.view(M, C), mean1, rstd1, g1, g_in=gy)
         return (gx.view(nB, L, C), None, None, None, None, None, None, dg1, db1, ddw, dgam, dbet, dWpw.view(3 * C, C, 1, 1), dbpw,
-                dWproj.view(C, C, 1, 1), dbproj)
+                dWproj.view(C, C, 1, 1), dbproj, dtable, None, None)
 
 
 _ZTAB = {}

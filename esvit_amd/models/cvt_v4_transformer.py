@@ -6,12 +6,16 @@ The module tree reproduces the reference's parameter / buffer names, shapes and 
 interchangeable; the modules are parameter holders only -- the computation runs through the HIP kernels
 (``esvit_amd.functional``: ConvEmbedFn, CvtAttnFn, CvtFfnFn) on token-major NHWC activations.
 
-Scope (what experiments/imagenet/cvt_v4/s1.yaml uses): no relative-position embedding, no shifted windows, no residual
-stem; ``REL_POS_EMBED`` / ``SHIFT`` / ``RES_STEM`` raise NotImplementedError.  Train mode uses batch statistics
+Besides what experiments/imagenet/cvt_v4/s1.yaml uses, the variants of the other cvt_v4 yaml files are built:
+``REL_POS_EMBED`` (a relative-position bias table per attention, s1_rpe.yaml) and ``SHIFT`` (s1_shift.yaml: the reference adds
+the shifted-window mask of a half-window shift to EVERY block of the stage and never rolls the map -- its ``shift_size`` is
+stored and unused, cvt_v4_transformer.py:263,332 -- and that is what runs here).  Both need every stage's map to be at least
+one window wide, as in the reference (its bias / mask shapes do not fit a shrunken window).  Train mode uses batch statistics
 (synchronised over the ranks), eval mode the running statistics, as ``nn.BatchNorm2d`` / ``SyncBatchNorm`` do.
 """
 from functools import partial
 
+import numpy as np
 import torch
 import torch.nn as nn
 
@@ -47,12 +51,21 @@ class DepthWiseConv2d(nn.Module):
 class Attention(nn.Module):
     def __init__(self, dim_in, dim_out, num_heads, qkv_bias, kernel_size, padding, window_size, shift_size, rel_pos_embed, **kwargs):
         super().__init__()
-        if rel_pos_embed or shift_size:
-            raise NotImplementedError("CvT relative-position embedding / shifted windows are not on the s1.yaml path")
         self.heads = num_heads
         self.window_size = window_size
+        self.shift_size = shift_size  # (kept like the reference keeps it; nothing reads it)
         self.qkv = DepthWiseConv2d(dim_in, dim_out * 3, kernel_size, padding=padding, stride=1, bias=qkv_bias)
         self.proj_out = nn.Conv2d(dim_out, dim_in, 1)
+        self.rel_pos_embed = rel_pos_embed
+        if rel_pos_embed:  # cvt_v4_transformer.py:141-163: the Swin index formula, one table row per relative offset
+            if window_size * window_size > 64 and dim_out // num_heads != 32:
+                raise NotImplementedError("relative-position tables on windows of more than 64 tokens need head_dim 32 (got %d)"
+                                          % (dim_out // num_heads))
+            c = np.stack(np.meshgrid(np.arange(window_size), np.arange(window_size), indexing="ij")).reshape(2, -1)
+            rel = (c[:, :, None] - c[:, None, :]).transpose(1, 2, 0) + (window_size - 1)
+            self.register_buffer("rel_pos_idx", torch.from_numpy((rel[:, :, 0] * (2 * window_size - 1) + rel[:, :, 1]).astype(np.int64)))
+            self.rel_pos_bias_table = nn.Parameter(torch.zeros((2 * window_size - 1) ** 2, num_heads))
+            _trunc_normal_(self.rel_pos_bias_table, std=.02)
 
 
 class FeedForward(nn.Module):
@@ -72,14 +85,13 @@ class Transformer(nn.Module):
     def __init__(self, embed_dim=768, depth=12, num_heads=12, mlp_ratio=4., qkv_bias=False, drop_path_rate=None, act_layer=QuickGELU,
                  norm_layer=nn.LayerNorm, kernel_qkv=3, padding_qkv=1, window_size=-1, shift=False, rel_pos_embed=False, **kwargs):
         super().__init__()
-        if shift:
-            raise NotImplementedError("CvT shifted windows are not on the s1.yaml path")
         self.layers = nn.ModuleList([])
         for i in range(depth):
+            shift_size = window_size // 2 if shift and i % 2 == 1 else 0
             self.layers.append(nn.ModuleList([
                 PreNorm(norm_layer, embed_dim,
                         Attention(dim_in=embed_dim, dim_out=embed_dim, num_heads=num_heads, qkv_bias=qkv_bias, kernel_size=kernel_qkv,
-                                  padding=padding_qkv, window_size=window_size, shift_size=0, rel_pos_embed=rel_pos_embed)),
+                                  padding=padding_qkv, window_size=window_size, shift_size=shift_size, rel_pos_embed=rel_pos_embed)),
                 PreNorm(norm_layer, embed_dim, FeedForward(embed_dim, act_layer, mlp_ratio)),
                 DropPath(drop_path_rate[i]) if isinstance(drop_path_rate, list) else nn.Identity()]))
         self.window_size = window_size
@@ -114,8 +126,10 @@ class Transformer(nn.Module):
                     bn_state.update(running_mean=bn.running_mean, running_var=bn.running_var, num_batches_tracked=bn.num_batches_tracked)
             else:  # nn.BatchNorm2d.eval(): the running statistics
                 bn_state.update(eval=True, eval_mean=bn.running_mean, eval_var=bn.running_var)
+            rpe = (a.rel_pos_bias_table, a.rel_pos_idx) if a.rel_pos_embed else (None, None)
             x = Fn.CvtAttnFn.apply(x, H, W, a.heads, a.window_size, dp1, bn_state, attn.norm.weight, attn.norm.bias, a.qkv.dw.weight,
-                                   bn.weight, bn.bias, a.qkv.pw.weight, a.qkv.pw.bias, a.proj_out.weight, a.proj_out.bias)
+                                   bn.weight, bn.bias, a.qkv.pw.weight, a.qkv.pw.bias, a.proj_out.weight, a.proj_out.bias,
+                                   rpe[0], rpe[1], bool(self.shift))
             x = Fn.CvtFfnFn.apply(x, dp2, ff.norm.weight, ff.norm.bias, ff.fn.net[0].weight, ff.fn.net[0].bias, ff.fn.net[2].weight,
                                   ff.fn.net[2].bias)
             if feats is not None:
@@ -145,8 +159,8 @@ class CvT(nn.Module):
         self.num_stages = spec['NUM_STAGES']
         total_depth = sum(spec['DEPTH'])
         dpr = [x.item() for x in torch.linspace(0, spec['DROP_PATH_RATE'], total_depth)]
-        if spec['REL_POS_EMBED'] or any(spec['SHIFT']) or spec.get('RES_STEM', False):
-            raise NotImplementedError("CvT REL_POS_EMBED / SHIFT / RES_STEM variants are not built (s1.yaml uses none of them)")
+        if getattr(spec, 'RES_STEM', False):
+            raise NotImplementedError("CvT RES_STEM is not built")
         in_chans, depth_accum = 3, 0
         for i in range(self.num_stages):
             conv = ConvEmbed(patch_size=spec['PATCH_SIZE'][i], in_chans=in_chans, embed_dim=spec['DIM_EMBED'][i],

@@ -239,6 +239,52 @@ def gen_nano_cvt(ns):
     print("nano_cvt_step.pt: loss", g["ddino_loss"], "npatch", g["npatch"], "params", len(g["param_names"]), "no_grad", g["no_grad"])
 
 
+def build_cvt_variant(ns, case, teacher=False):
+    m = ns.models.build_model(RL.cvt_config(**case["cfg"]), is_teacher=teacher, use_dense_prediction=True)
+    hk = dict(hidden_dim=GU.NANO_HEAD["hidden_dim"], bottleneck_dim=GU.NANO_HEAD["bottleneck_dim"])
+    fea = case["cfg"]["dims"][-1]
+    m.head = ns.DINOHead(fea, GU.NANO_HEAD["out_dim"], norm_last_layer=True, **hk)
+    m.head_dense = ns.DINOHead(fea, GU.NANO_HEAD["out_dim"], norm_last_layer=False, **hk)
+    return m
+
+
+def gen_cvt_variants(ns):
+    """the CvT variants of the other cvt_v4 yaml files (REL_POS_EMBED, SHIFT, RES_STEM) in miniature, one training step each through
+    the reference's own modules"""
+    RL.ensure_single_process_group()
+    out = {}
+    for name, case in GU.NANO_CVT_VARIANTS.items():
+        student, teacher = build_cvt_variant(ns, case), build_cvt_variant(ns, case, teacher=True)
+        GU.fill_state_dict(student.state_dict(), seed=0)
+        GU.fill_state_dict(teacher.state_dict(), seed=7)
+        for m in (student, teacher):
+            for k, v in m.state_dict().items():
+                if k.endswith("running_var"):
+                    v.abs_().add_(0.5)
+        student.head.last_layer.weight_g.data.fill_(1)
+        for p in teacher.parameters():
+            p.requires_grad = False
+        crops = GU.make_crops(2, n_local=case["n_local"], sizes=case["sizes"])
+        g = {"keys": [(k, tuple(v.shape), str(v.dtype)) for k, v in student.state_dict().items()],
+             "param_names": [n for n, _ in student.named_parameters()]}
+        loss_fn = ns.DDINOLoss(GU.NANO_HEAD["out_dim"], 2 + case["n_local"], 0.04, 0.07, 5, 10)
+        t_out = teacher(crops[:2])
+        s_out = student(crops)
+        for nm, t in (("s_cls", s_out[0]), ("s_reg", s_out[1]), ("s_fea", s_out[2]), ("t_cls", t_out[0]), ("t_reg", t_out[1]), ("t_fea", t_out[2])):
+            g[nm] = GU.probe(t)
+        g["npatch"] = (list(s_out[3]), list(t_out[3]))
+        loss = loss_fn(s_out, t_out, 2, None)
+        g["ddino_loss"] = loss.item()
+        student.zero_grad()
+        loss.backward()
+        g["grads"] = {n: GU.probe(p.grad) for n, p in student.named_parameters() if p.grad is not None}
+        g["grad_norms"] = {n: p.grad.norm().item() for n, p in student.named_parameters() if p.grad is not None}
+        g["bn_buffers"] = {k: v.detach().clone() for k, v in student.state_dict().items() if "running_" in k or "num_batches" in k}
+        out[name] = g
+        print("nano_cvt_variants.pt:", name, "loss", g["ddino_loss"], "npatch", g["npatch"], "params", len(g["param_names"]))
+    torch.save(out, os.path.join(OUT, "nano_cvt_variants.pt"))
+
+
 def build_nano_vit(ns, teacher=False):
     import importlib
     from functools import partial
@@ -613,6 +659,8 @@ def main():
         gen_nano14(ns)
     if not only or "cvt" in only:
         gen_nano_cvt(ns)
+    if not only or "cvt_variants" in only:
+        gen_cvt_variants(ns)
     if not only or "vit" in only:
         gen_nano_vit(ns)
     if not only or "knn" in only:

@@ -156,12 +156,16 @@ def swin_config(embed_dim=96, depths=(2, 2, 6, 2), heads=(3, 6, 12, 24), window=
                     TRAIN=dict(IMAGE_SIZE=[img, img]), FINETUNE=dict(FINETUNE=False, FROZEN_LAYERS=[]), VERBOSE=False)
 
 
-def cvt_config(dims=(64, 192, 384, 768), heads=(1, 3, 6, 12), depths=(2, 2, 6, 2), drop_path=0.0, num_classes=0):
-    """experiments/imagenet/cvt_v4/s1.yaml with the stage lists cut to len(dims) (no relative-position embedding, no shift)."""
+def cvt_config(dims=(64, 192, 384, 768), heads=(1, 3, 6, 12), depths=(2, 2, 6, 2), drop_path=0.0, num_classes=0, rel_pos_embed=False,
+               shift=False, res_stem=False, windows=None):
+    """experiments/imagenet/cvt_v4/s1.yaml with the stage lists cut to len(dims); rel_pos_embed / shift / res_stem / windows: the
+    variants of s1_rpe.yaml, s1_shift.yaml, res_stem/s3_w14.yaml"""
     n = len(dims)
+    spec = dict(INIT="trunc_norm", NUM_STAGES=n, REL_POS_EMBED=rel_pos_embed, SHIFT=[shift] * n, DROP_PATH_RATE=drop_path,
+                PATCH_SIZE=[7] + [3] * (n - 1), PATCH_STRIDE=[4] + [2] * (n - 1), PATCH_PADDING=[2] + [1] * (n - 1),
+                WINDOW_SIZE=list(windows) if windows else [7] * n, DIM_EMBED=list(dims), NUM_HEADS=list(heads), DEPTH=list(depths),
+                MLP_RATIO=[4.0] * n, QKV_BIAS=[True] * n, KERNEL_QKV=[3] * n, PADDING_QKV=[1] * n)
+    if res_stem:
+        spec["RES_STEM"] = True
     return AttrDict(MODEL=dict(NAME="cvt_v4_transformer", NUM_CLASSES=num_classes, INIT_WEIGHTS=False, PRETRAINED="", PRETRAINED_LAYERS=["*"],
-                               SPEC=dict(INIT="trunc_norm", NUM_STAGES=n, REL_POS_EMBED=False, SHIFT=[False] * n, DROP_PATH_RATE=drop_path,
-                                         PATCH_SIZE=[7] + [3] * (n - 1), PATCH_STRIDE=[4] + [2] * (n - 1), PATCH_PADDING=[2] + [1] * (n - 1),
-                                         WINDOW_SIZE=[7] * n, DIM_EMBED=list(dims), NUM_HEADS=list(heads), DEPTH=list(depths),
-                                         MLP_RATIO=[4.0] * n, QKV_BIAS=[True] * n, KERNEL_QKV=[3] * n, PADDING_QKV=[1] * n)),
-                    VERBOSE=False)
+                               SPEC=spec), VERBOSE=False)

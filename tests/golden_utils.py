@@ -10,6 +10,14 @@ NANO_HEAD = dict(out_dim=4096, hidden_dim=256, bottleneck_dim=64)
 NANO14 = dict(embed_dim=32, depths=(2, 2, 2, 2), heads=(1, 2, 4, 8), window=14, img=224)
 # CvT (BASELINE config 5) in miniature: head_dim 64 everywhere, crops 112 / 48 -> grids 28,14,7 / 12 (padded to 14),6,3
 NANO_CVT = dict(dims=(64, 128, 192), heads=(1, 2, 3), depths=(1, 2, 1), sizes=(112, 48))
+# the other cvt_v4 yaml files (s1_rpe.yaml, s1_shift.yaml, s1_rpe_shift.yaml, res_stem/*): every stage's map must hold a whole window
+# (the reference's bias / mask shapes) and, with SHIFT, be a multiple of it (the reference's masked path loses the map height when it
+# has to crop a padded map): two stages; 112 / 56 crops -> grids 28, 14 / 14, 7; 112 / 64 crops -> 28, 14 / 16 (padded to 21), 8 (to 14)
+NANO_CVT_VARIANTS = {
+    "rpe_shift": dict(cfg=dict(dims=(64, 128), heads=(1, 2), depths=(2, 2), rel_pos_embed=True, shift=True), sizes=(112, 56), n_local=2),
+    "shift": dict(cfg=dict(dims=(64, 128), heads=(1, 2), depths=(1, 2), shift=True), sizes=(112, 56), n_local=2),
+    "rpe": dict(cfg=dict(dims=(64, 128), heads=(1, 2), depths=(1, 1), rel_pos_embed=True), sizes=(112, 64), n_local=2),
+}
 NANO_VIT = dict(embed_dim=64, depth=2, heads=2, patch=16, sizes=(64, 32))  # 16 + 1 and 4 + 1 tokens: the position embedding is interpolated
 SWIN_T = dict(embed_dim=96, depths=(2, 2, 6, 2), heads=(3, 6, 12, 24), window=7, img=224)
 

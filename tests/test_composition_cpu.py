@@ -431,6 +431,70 @@ def test_cvt_eval_mode_matches_reference_golden(cpu_ops):
     assert torch.allclose(feats, g["eval_last_blocks"], rtol=3e-4, atol=1e-5)
 
 
+def build_cvt_variant(case, teacher=False):
+    from esvit_amd import models
+    m = models.build_model(RL.cvt_config(**case["cfg"]), is_teacher=teacher, use_dense_prediction=True)
+    hk = dict(hidden_dim=GU.NANO_HEAD["hidden_dim"], bottleneck_dim=GU.NANO_HEAD["bottleneck_dim"])
+    fea = case["cfg"]["dims"][-1]
+    m.head = models.DINOHead(fea, GU.NANO_HEAD["out_dim"], norm_last_layer=True, **hk)
+    m.head_dense = models.DINOHead(fea, GU.NANO_HEAD["out_dim"], norm_last_layer=False, **hk)
+    return m
+
+
+def check_cvt_variant(name, loss_mod, dev="cpu", rt=3e-4, loss_tol=2e-5, grad_tol=2e-3, buf_tol=1e-4, probes=True):
+    """one training step of a CvT variant (REL_POS_EMBED / SHIFT / RES_STEM) against the reference's own module"""
+    case = GU.NANO_CVT_VARIANTS[name]
+    g = torch.load(os.path.join(GOLD, "nano_cvt_variants.pt"), weights_only=False)[name]
+    student, teacher = build_cvt_variant(case), build_cvt_variant(case, teacher=True)
+    assert [(k, tuple(v.shape), str(v.dtype)) for k, v in student.state_dict().items()] == g["keys"]
+    assert [n for n, _ in student.named_parameters()] == g["param_names"]
+    GU.fill_state_dict(student.state_dict(), 0)
+    GU.fill_state_dict(teacher.state_dict(), 7)
+    for m in (student, teacher):
+        for k, v in m.state_dict().items():
+            if k.endswith("running_var"):
+                v.abs_().add_(0.5)
+    student.head.last_layer.weight_g.data.fill_(1)
+    for p in teacher.parameters():
+        p.requires_grad = False
+    student, teacher = student.to(dev), teacher.to(dev)
+    crops = [c.to(dev) for c in GU.make_crops(2, n_local=case["n_local"], sizes=case["sizes"])]
+    loss_fn = loss_mod.DDINOLoss(GU.NANO_HEAD["out_dim"], 2 + case["n_local"], 0.04, 0.07, 5, 10).to(dev)
+    t_out = teacher(crops[:2])
+    s_out = student(crops)
+    loss = loss_fn(s_out, t_out, 2, None)
+    loss.backward()
+    if probes:
+        check_nano_cvt(g, student, s_out, t_out, loss, rt, loss_tol, grad_tol, buf_tol)
+    else:  # (bf16 on the GPU: loss and gradient norms, like the plain nano CvT step)
+        assert abs(loss.item() - g["ddino_loss"]) < loss_tol, (loss.item(), g["ddino_loss"])
+        got = {n: p.grad for n, p in student.named_parameters() if p.grad is not None}
+        assert sorted(got) == sorted(g["grad_norms"])
+        for n, ref in g["grad_norms"].items():
+            assert abs(got[n].norm().item() - ref) <= grad_tol * ref + 1e-6, (n, got[n].norm().item(), ref)
+    if probes:
+        for n, p in student.named_parameters():
+            if "rel_pos_bias_table" in n or "stem" in n:
+                probe_close(n, p.grad.float().cpu(), g["grads"][n], rtol=max(rt, grad_tol))
+    return student
+
+
+@pytest.mark.parametrize("name", sorted(GU.NANO_CVT_VARIANTS))
+def test_cvt_variants_composition_matches_reference_golden(name, cpu_ops):
+    """REL_POS_EMBED / SHIFT (s1_rpe.yaml, s1_shift.yaml, s1_rpe_shift.yaml) on the torch restatement of every kernel"""
+    import esvit_amd.loss as L
+    check_cvt_variant(name, L)
+
+
+def test_cvt_variants_refuse_what_the_reference_cannot_run(cpu_ops):
+    """a map narrower than the window (bias / mask shapes) or, with SHIFT, not a multiple of it fails in the reference as well"""
+    m = build_cvt_variant(GU.NANO_CVT_VARIANTS["rpe_shift"])
+    with pytest.raises(RuntimeError, match="smaller than"):
+        m([torch.randn(1, 3, 24, 24)])
+    with pytest.raises(RuntimeError, match="multiple"):
+        m([torch.randn(1, 3, 64, 64)])
+
+
 # ---- eval_knn.py consumers (SURVEY.md 8f-1) ---------------------------------------------------
 class IndexedSet(torch.utils.data.Dataset):
     """the reference's ReturnIndexDataset (eval_knn.py:235-238): (sample, position in the dataset)"""

@@ -369,6 +369,23 @@ def test_nano_cvt_step_matches_reference_golden(prec, lib_built):
         _teardown()
 
 
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("name", sorted(GU.NANO_CVT_VARIANTS))
+def test_cvt_variants_step_matches_reference_golden(name, prec, lib_built):
+    """the CvT variants of the other cvt_v4 yaml files through the HIP path: relative-position tables and the unrolled shift mask in
+    the head_dim-64 window attention (table gradient included), the residual stem's convolutions"""
+    import esvit_amd.loss as L
+    from tests.test_composition_cpu import check_cvt_variant
+    dev = _setup(prec)
+    try:
+        if prec == "fp32":
+            check_cvt_variant(name, L, dev=dev, rt=5e-4, loss_tol=1e-4, grad_tol=3e-3, buf_tol=1e-4)
+        else:
+            check_cvt_variant(name, L, dev=dev, rt=6e-2, loss_tol=2e-2, grad_tol=0.2, buf_tol=2e-2, probes=False)
+    finally:
+        _teardown()
+
+
 def test_nano_cvt_eval_matches_reference_golden(lib_built):
     """eval-mode BatchNorm + forward_return_n_last_blocks of the CvT through the HIP path (fp32 precision mode)"""
     g = torch.load(os.path.join(GOLD, "nano_cvt_step.pt"), weights_only=False)
