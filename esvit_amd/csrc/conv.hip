@@ -390,7 +390,8 @@ __global__ __launch_bounds__(256) void col_sums2_kernel(const T* __restrict__ a,
     }
 }
 
-// ACT 0: y = a1 x1 + a2 x2 + a3;  1: y = GELU(a1 x1 + a3);  2: y = x2 * GELU'(a1 x1 + a3)
+// ACT 0: y = a1 x1 + a2 x2 + a3;  1: y = GELU(a1 x1 + a3);  2: y = x2 * GELU'(a1 x1 + a3);  3: y = max(a1 x1 + a3, 0);
+// 4: y = x2 where a1 x1 + a3 > 0, else 0  (BatchNorm + ReLU of the residual stem and its backward)
 template <typename T, int ACT>
 __global__ void col_affine2_kernel(const T* __restrict__ x1, const T* __restrict__ x2, long n, int C, const float* __restrict__ a1,
                                    const float* __restrict__ a2, const float* __restrict__ a3, T* __restrict__ y) {
@@ -401,8 +402,12 @@ __global__ void col_affine2_kernel(const T* __restrict__ x1, const T* __restrict
             if (x2) v += a2[c] * to_f32(x2[i]);
         } else if constexpr (ACT == 1) {
             v = gelu_f(v);
-        } else {
+        } else if constexpr (ACT == 2) {
             v = to_f32(x2[i]) * gelu_grad_f(v);
+        } else if constexpr (ACT == 3) {
+            v = fmaxf(v, 0.f);
+        } else {
+            v = v > 0.f ? to_f32(x2[i]) : 0.f;
         }
         y[i] = from_f32<T>(v);
     }
@@ -644,14 +649,16 @@ static void launch_col_affine2(int act, const void* x1, const void* x2, long n, 
     T* py = reinterpret_cast<T*>(y);
     if (act == 1) hipLaunchKernelGGL((col_affine2_kernel<T, 1>), dim3(grid_for(n)), dim3(256), 0, stream, p1, p2, n, C, a1, a2, a3, py);
     else if (act == 2) hipLaunchKernelGGL((col_affine2_kernel<T, 2>), dim3(grid_for(n)), dim3(256), 0, stream, p1, p2, n, C, a1, a2, a3, py);
+    else if (act == 3) hipLaunchKernelGGL((col_affine2_kernel<T, 3>), dim3(grid_for(n)), dim3(256), 0, stream, p1, p2, n, C, a1, a2, a3, py);
+    else if (act == 4) hipLaunchKernelGGL((col_affine2_kernel<T, 4>), dim3(grid_for(n)), dim3(256), 0, stream, p1, p2, n, C, a1, a2, a3, py);
     else hipLaunchKernelGGL((col_affine2_kernel<T, 0>), dim3(grid_for(n)), dim3(256), 0, stream, p1, p2, n, C, a1, a2, a3, py);
 }
 
 extern "C" int esvit_col_affine2(int dtype, const void* x1, const void* x2, int64_t rows, int C, const float* a1, const float* a2,
                                  const float* a3, int act, void* y, esvit_stream_t s_) {
     STREAM(s_);
-    ESVIT_CHECK_ARG(x1 && a1 && a3 && y && rows > 0 && C > 0 && act >= 0 && act <= 2, "esvit_col_affine2: bad args");
-    ESVIT_CHECK_ARG(act == 0 ? (!x2 || a2) : (act == 1 ? !x2 : x2 != nullptr), "esvit_col_affine2: x2 / a2 do not fit act=%d", act);
+    ESVIT_CHECK_ARG(x1 && a1 && a3 && y && rows > 0 && C > 0 && act >= 0 && act <= 4, "esvit_col_affine2: bad args");
+    ESVIT_CHECK_ARG(act == 0 ? (!x2 || a2) : ((act == 1 || act == 3) ? !x2 : x2 != nullptr), "esvit_col_affine2: x2 / a2 do not fit act=%d", act);
     ESVIT_CHECK_ARG(dtype == ESVIT_BF16 || dtype == ESVIT_F32, "esvit_col_affine2: bad dtype");
     const long n = (long)rows * C;
     if (dtype == ESVIT_BF16) launch_col_affine2<bf16>(act, x1, x2, n, C, a1, a2, a3, y, stream);

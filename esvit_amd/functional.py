@@ -919,6 +919,64 @@ class ConvEmbedFn(torch.autograd.Function):
         return dsrc, None, dWp, dbp, dg, db
 
 
+class ConvBnReluFn(torch.autograd.Function):
+    """one unit of the residual stem (cvt_v4_transformer.py:385-430): Conv2d(3x3, no bias) -> BatchNorm2d -> ReLU as im2col + GEMM,
+    per-channel sums, one affine + ReLU pass.  src: fp32 NCHW images or activation-dtype tokens [nB*H*W, Cin]; returns activation-dtype
+    tokens [nB*Ho*Wo, E].  BatchNorm as in CvtAttnFn (batch statistics summed over the ranks in train mode, running statistics in eval)."""
+
+    @staticmethod
+    def forward(ctx, src, geo, bn_state, Wp, bn_g, bn_b):
+        o = ops_module()
+        nchw, nB, H, W, Cin, k, stride, pad = geo
+        src = src.contiguous()
+        cols = o.conv_im2col(src if nchw else src.view(nB * H * W, Cin), nchw, nB, H, W, Cin, k, stride, pad)
+        Wk = _conv_weight_matrix(Wp)
+        d = o.linear_fwd(cols, Wk, None)
+        rows = d.shape[0]
+        eval_bn = bool(bn_state.get("eval"))
+        gam, bet = bn_g.detach().contiguous(), bn_b.detach().contiguous()
+        if eval_bn:
+            n = float(rows)
+            coef = o.bn_eval_coeffs(bn_state["eval_mean"], bn_state["eval_var"], gam, bet, BN_EPS)
+        else:
+            sums = o.col_sums2(d, d)
+            n = float(rows * _allreduce_stats(sums, bn_state.get("group")))
+            coef = o.bn_fwd_coeffs(sums, n, gam, bet, BN_EPS, BN_MOMENTUM, bn_state.get("running_mean"), bn_state.get("running_var"))
+            if bn_state.get("num_batches_tracked") is not None:
+                bn_state["num_batches_tracked"].add_(1)
+        y = o.col_affine2(d, coef[0], coef[1], act=3)
+        ctx.geo, ctx.n, ctx.eval_bn, ctx.group, ctx.wshape = geo, n, eval_bn, bn_state.get("group"), tuple(Wp.shape)
+        ctx.save_for_backward(cols, Wk, d, coef, gam)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        o = ops_module()
+        cols, Wk, d, coef, gam = ctx.saved_tensors
+        nchw, nB, H, W, Cin, k, stride, pad = ctx.geo
+        E = d.shape[1]
+        gy = gy.contiguous()
+        if gy.dtype != d.dtype:
+            gy = o.cast_to_act(gy.float())
+        dz = o.col_affine2(d, coef[0], coef[1], gy, act=4)        # through the ReLU, its argument rebuilt from the conv output
+        red = o.bn_bwd_local(o.col_sums2(dz, d), coef)            # (d beta, d gamma) of this rank
+        dbet, dgam = red[0].clone(), red[1].clone()
+        if ctx.eval_bn:
+            abc = o.bn_bwd_coeffs(None, ctx.n, gam, coef)
+        else:
+            _allreduce_stats(red, ctx.group)
+            abc = o.bn_bwd_coeffs(red, ctx.n, gam, coef)
+        dd = o.col_affine2(dz, abc[0], abc[2], d, abc[1])
+        dWk = o.linear_wgrad(dd, cols)
+        K = k * k * Cin
+        dWp = dWk[:, :K].reshape(E, k, k, Cin).permute(0, 3, 1, 2).contiguous()
+        dsrc = None
+        if not nchw and ctx.needs_input_grad[0]:
+            dsrc = o.conv_col2im(o.linear_dgrad(dd, Wk), nB, H, W, Cin, k, stride, pad)
+            dsrc = o.gather_cast(dsrc, dsrc.shape[0])
+        return dsrc, None, None, dWp, dgam, dbet
+
+
 class CvtAttnFn(torch.autograd.Function):
     """x + DropPath(Attention(LayerNorm(x)))  (cvt_v4_transformer.py:331-336, 49-58, 108-220): LN -> zero-pad the grid to a
     multiple of the window -> depthwise 3x3 -> BatchNorm (batch statistics, synchronised across ranks) -> 1x1 to q|k|v ->

@@ -9,7 +9,8 @@ interchangeable; the modules are parameter holders only -- the computation runs 
 Besides what experiments/imagenet/cvt_v4/s1.yaml uses, the variants of the other cvt_v4 yaml files are built:
 ``REL_POS_EMBED`` (a relative-position bias table per attention, s1_rpe.yaml) and ``SHIFT`` (s1_shift.yaml: the reference adds
 the shifted-window mask of a half-window shift to EVERY block of the stage and never rolls the map -- its ``shift_size`` is
-stored and unused, cvt_v4_transformer.py:263,332 -- and that is what runs here).  Both need every stage's map to be at least
+stored and unused, cvt_v4_transformer.py:263,332 -- and that is what runs here) and ``RES_STEM`` (res_stem/*.yaml: three
+Conv 3x3 -> BatchNorm -> ReLU units instead of the first ConvEmbed).  Both need every stage's map to be at least
 one window wide, as in the reference (its bias / mask shapes do not fit a shrunken window).  Train mode uses batch statistics
 (synchronised over the ranks), eval mode the running statistics, as ``nn.BatchNorm2d`` / ``SyncBatchNorm`` do.
 """
@@ -153,18 +154,50 @@ class ConvEmbed(nn.Module):
         return t, o.conv_out_size(H, self.patch_size, self.stride, self.padding), o.conv_out_size(W, self.patch_size, self.stride, self.padding)
 
 
+class ResStem(nn.Module):
+    """two (deep: three) units of Conv2d 3x3 (no bias) -> BatchNorm2d -> ReLU, strides 2 / (1) / 2 (cvt_v4_transformer.py:385-430;
+    RES_STEM: True in experiments/imagenet/cvt_v4/res_stem/*.yaml): parameter holder, each unit is one Fn.ConvBnReluFn node"""
+
+    def __init__(self, channels_stem, deep=False):
+        super().__init__()
+        units, cin = [], 3
+        for stride in ((2, 1, 2) if deep else (2, 2)):
+            units += [nn.Conv2d(cin, channels_stem, kernel_size=3, stride=stride, padding=1, bias=False), nn.BatchNorm2d(channels_stem),
+                      nn.ReLU(inplace=True)]
+            cin = channels_stem
+        self.stem = nn.Sequential(*units)
+        self.sync_bn_group = None  # as Transformer.sync_bn_group
+
+    def forward_tokens(self, src, nchw, nB, H, W):
+        assert nchw, "the residual stem reads the images"
+        o = Fn.ops_module()
+        t = src
+        for i in range(0, len(self.stem), 3):
+            conv, bn = self.stem[i], self.stem[i + 1]
+            st = {"group": self.sync_bn_group}
+            if self.training:
+                if bn.track_running_stats:
+                    st.update(running_mean=bn.running_mean, running_var=bn.running_var, num_batches_tracked=bn.num_batches_tracked)
+            else:
+                st.update(eval=True, eval_mean=bn.running_mean, eval_var=bn.running_var)
+            t = Fn.ConvBnReluFn.apply(t, (i == 0, nB, H, W, conv.in_channels, 3, conv.stride[0], 1), st, conv.weight, bn.weight, bn.bias)
+            H, W = o.conv_out_size(H, 3, conv.stride[0], 1), o.conv_out_size(W, 3, conv.stride[0], 1)
+        return t.float().view(nB, H * W, -1), H, W
+
+
 class CvT(nn.Module):
     def __init__(self, *, num_classes, act_layer=QuickGELU, norm_layer=nn.LayerNorm, init='trunc_norm', use_dense_prediction=False, spec=None):
         super().__init__()
         self.num_stages = spec['NUM_STAGES']
         total_depth = sum(spec['DEPTH'])
         dpr = [x.item() for x in torch.linspace(0, spec['DROP_PATH_RATE'], total_depth)]
-        if getattr(spec, 'RES_STEM', False):
-            raise NotImplementedError("CvT RES_STEM is not built")
         in_chans, depth_accum = 3, 0
         for i in range(self.num_stages):
-            conv = ConvEmbed(patch_size=spec['PATCH_SIZE'][i], in_chans=in_chans, embed_dim=spec['DIM_EMBED'][i],
-                             stride=spec['PATCH_STRIDE'][i], padding=spec['PATCH_PADDING'][i], norm_layer=norm_layer)
+            if i == 0 and getattr(spec, 'RES_STEM', False):  # (getattr like the reference: a plain dict spec never has it)
+                conv = ResStem(spec['DIM_EMBED'][i], True)
+            else:
+                conv = ConvEmbed(patch_size=spec['PATCH_SIZE'][i], in_chans=in_chans, embed_dim=spec['DIM_EMBED'][i],
+                                 stride=spec['PATCH_STRIDE'][i], padding=spec['PATCH_PADDING'][i], norm_layer=norm_layer)
             tr = Transformer(embed_dim=spec['DIM_EMBED'][i], depth=spec['DEPTH'][i], num_heads=spec['NUM_HEADS'][i],
                              mlp_ratio=spec['MLP_RATIO'][i], qkv_bias=spec['QKV_BIAS'][i],
                              drop_path_rate=dpr[depth_accum: depth_accum + spec['DEPTH'][i]], act_layer=act_layer, norm_layer=norm_layer,

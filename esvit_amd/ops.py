@@ -837,8 +837,8 @@ def col_sums2(a, b):
 
 
 def col_affine2(x1, a1, a3, x2=None, a2=None, act=0):
-    """act 0: y = a1[c] * x1 + a2[c] * x2 + a3[c];  1: y = GELU(a1[c] * x1 + a3[c]);  2: y = x2 * GELU'(a1[c] * x1 + a3[c])
-    (act dtype in / out, fp32 per-channel coefficients)"""
+    """act 0: y = a1[c] * x1 + a2[c] * x2 + a3[c];  1: y = GELU(a1[c] * x1 + a3[c]);  2: y = x2 * GELU'(a1[c] * x1 + a3[c]);
+    3: y = max(a1[c] * x1 + a3[c], 0);  4: y = x2 where a1[c] * x1 + a3[c] > 0 else 0  (act dtype in / out, fp32 coefficients)"""
     x1 = _actc(x1)
     rows, Cc = x1.shape
     y = torch.empty_like(x1)

@@ -371,7 +371,9 @@ int esvit_fused_clip_update_ema(int rule, const int64_t* tensors, int ntensors, 
  *   BatchNorm backward: a = dy, b = pre-norm activations); ws: fp32 [ESVIT_Q_COL_REDUCE_BLOCKS(rows)*2*C].
  * esvit_col_affine2: act 0: y = a1[c]*x1 + a2[c]*x2 + a3[c]  (x2 may be null);
  *   act 1: y = GELU(a1[c]*x1 + a3[c]) and act 2: y = x2 * GELU'(a1[c]*x1 + a3[c]) -- BatchNorm1d + GELU of DINOHead(use_bn=True)
- *   (vision_transformer.py:391-402) and its backward, the normalised value rebuilt from the pre-norm activation. */
+ *   (vision_transformer.py:391-402) and its backward, the normalised value rebuilt from the pre-norm activation;
+ *   act 3: y = max(a1[c]*x1 + a3[c], 0) and act 4: y = x2 where a1[c]*x1 + a3[c] > 0, else 0 -- BatchNorm2d + ReLU of the
+ *   residual stem (cvt_v4_transformer.py:385-430) and its backward. */
 int esvit_conv_im2col(int dtype, const void* src, int nchw, int nB, int H, int W, int Cin, int k, int stride, int pad,
                       int Ho, int Wo, int Kpad, void* cols, esvit_stream_t stream);
 int esvit_conv_col2im(int dtype, const void* dcols, int nB, int H, int W, int Cin, int k, int stride, int pad, int Ho,

@@ -730,6 +730,10 @@ def col_affine2(x1, a1, a3, x2=None, a2=None, act=0):
         y = F.gelu(y)
     elif act == 2:
         y = x2.float() * (0.5 * (1.0 + torch.erf(y * 0.7071067811865476)) + y * torch.exp(-0.5 * y * y) * 0.3989422804014327)
+    elif act == 3:
+        y = y.clamp_min(0.0)
+    elif act == 4:
+        y = torch.where(y > 0, x2.float(), torch.zeros_like(y))
     elif x2 is not None:
         y = y + x2.float() * a2
     return _r(y, x1.dtype)

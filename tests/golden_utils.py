@@ -17,6 +17,8 @@ NANO_CVT_VARIANTS = {
     "rpe_shift": dict(cfg=dict(dims=(64, 128), heads=(1, 2), depths=(2, 2), rel_pos_embed=True, shift=True), sizes=(112, 56), n_local=2),
     "shift": dict(cfg=dict(dims=(64, 128), heads=(1, 2), depths=(1, 2), shift=True), sizes=(112, 56), n_local=2),
     "rpe": dict(cfg=dict(dims=(64, 128), heads=(1, 2), depths=(1, 1), rel_pos_embed=True), sizes=(112, 64), n_local=2),
+    # res_stem/s3_w14.yaml in miniature: 14x14 windows at head_dim 32 on the 28x28 maps, crops 112 / 48 -> 28, 14 / 12, 6
+    "res_stem": dict(cfg=dict(dims=(64, 128), heads=(2, 4), depths=(1, 1), res_stem=True, windows=(14, 7)), sizes=(112, 48), n_local=2),
 }
 NANO_VIT = dict(embed_dim=64, depth=2, heads=2, patch=16, sizes=(64, 32))  # 16 + 1 and 4 + 1 tokens: the position embedding is interpolated
 SWIN_T = dict(embed_dim=96, depths=(2, 2, 6, 2), heads=(3, 6, 12, 24), window=7, img=224)

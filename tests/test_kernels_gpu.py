@@ -439,6 +439,9 @@ def test_cvt_conv_pieces(mods, dt):
         a1, a2, a3 = _rand((Cc,), dev, 76), _rand((Cc,), dev, 77), _rand((Cc,), dev, 78)
         _close("affine", ops.col_affine2(x, a1, a3), ref.col_affine2(x, a1, a3), _tol(dt, bf=2e-2))
         _close("affine2", ops.col_affine2(x, a1, a3, dy, a2), ref.col_affine2(x, a1, a3, dy, a2), _tol(dt, bf=2e-2))
+        _close("affine relu", ops.col_affine2(x, a1, a3, act=3), ref.col_affine2(x, a1, a3, act=3), _tol(dt, bf=2e-2))
+        gate, gate_ref = ops.col_affine2(x, a1, a3, dy, act=4), ref.col_affine2(x, a1, a3, dy, act=4)
+        assert (gate != gate_ref).sum().item() <= 2, "affine relu bwd"  # (a pre-activation within rounding of zero may gate either way)
         _close("pad", ops.pad_crop_tokens(x, 2, H, H, H + 2, H + 1), ref.pad_crop_tokens(x, 2, H, H, H + 2, H + 1), 0.0)
         _close("crop", ops.pad_crop_tokens(x, 2, H, H, H - 1, H - 2), ref.pad_crop_tokens(x, 2, H, H, H - 1, H - 2), 0.0)
         # BatchNorm coefficient vectors
