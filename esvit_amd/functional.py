@@ -414,14 +414,22 @@ class PatchEmbedFn(torch.autograd.Function):
         cols = o.patch_im2col(img.contiguous(), patch, Kc)
         W = _weight(Wp, (E, Kc))
         y = o.linear_fwd(cols, W, bp, out_f32=True)
+        ctx.wshape = tuple(Wp.shape)
+        if g is None:  # PATCH_NORM False (swin_transformer.py:476-477, 492-493): the projection is the embedding
+            ctx.save_for_backward(cols)
+            return y.view(nB, (S // patch) ** 2, E)
         x, _, mean, rstd = o.layernorm_fwd(y, g, b, LN_EPS, dtype=torch.float32)
         ctx.save_for_backward(cols, y, mean, rstd, g)
-        ctx.wshape = tuple(Wp.shape)
         return x.view(nB, (S // patch) ** 2, E)
 
     @staticmethod
     def backward(ctx, gx):
         o = ops_module()
+        if len(ctx.saved_tensors) == 1:
+            (cols,) = ctx.saved_tensors
+            M = cols.shape[0]
+            dW, dbp = o.linear_wgrad(o.gather_cast(gx.contiguous().view(M, -1), M), cols, want_bias=True)
+            return None, dW.view(ctx.wshape), dbp, None, None, None
         cols, y, mean, rstd, g = ctx.saved_tensors
         M, E = y.shape
         dy, dg, db = o.layernorm_bwd(gx.contiguous().view(M, E), y, mean, rstd, g)
@@ -448,14 +456,22 @@ class PatchEmbedMultiFn(torch.autograd.Function):
             o.patch_im2col(im.contiguous(), patch, Kc, out=cols[r0:r0 + n])
             r0 += n
         y = o.linear_fwd(cols, _weight(Wp, (E, Kc)), bp, out_f32=True)
+        ctx.wshape, ctx.n_img = tuple(Wp.shape), len(imgs)
+        if g is None:  # PATCH_NORM False
+            ctx.save_for_backward(cols)
+            return y
         x, _, mean, rstd = o.layernorm_fwd(y, g, b, LN_EPS, dtype=torch.float32)
         ctx.save_for_backward(cols, y, mean, rstd, g)
-        ctx.wshape, ctx.n_img = tuple(Wp.shape), len(imgs)
         return x
 
     @staticmethod
     def backward(ctx, gx):
         o = ops_module()
+        if len(ctx.saved_tensors) == 1:
+            (cols,) = ctx.saved_tensors
+            M = cols.shape[0]
+            dW, dbp = o.linear_wgrad(o.gather_cast(gx.contiguous().view(M, -1), M), cols, want_bias=True)
+            return (dW.view(ctx.wshape), dbp, None, None, None) + (None,) * ctx.n_img
         cols, y, mean, rstd, g = ctx.saved_tensors
         M, E = y.shape
         dy, dg, db = o.layernorm_bwd(gx.contiguous().view(M, E), y, mean, rstd, g)
@@ -501,10 +517,6 @@ class PatchMergeMultiFn(torch.autograd.Function):
             o.merge_ln_bwd(dy[q0:q1], X[r0:r1].view(nB, H * W, C), mean[q0:q1], rstd[q0:q1], g, H, W, dx_out=dX[r0:r1], gb_out=gb,
                            accumulate=gi > 0)
         return dX, None, gb[0], gb[1], dWr
-
-
-def patch_embed_nonorm(img, Wp, bp, patch):
-    raise NotImplementedError("PATCH_NORM False is not on the hot path")
 
 
 class PatchMergeFn(torch.autograd.Function):

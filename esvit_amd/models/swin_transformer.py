@@ -244,9 +244,8 @@ class PatchEmbed(nn.Module):
         self.norm = norm_layer(embed_dim) if norm_layer is not None else None
 
     def forward(self, x):
-        if self.norm is None:
-            raise NotImplementedError("PATCH_NORM False is not used by any reference yaml")
-        return Fn.PatchEmbedFn.apply(x, self.proj.weight, self.proj.bias, self.norm.weight, self.norm.bias, self.patch_size[0])
+        g, b = (self.norm.weight, self.norm.bias) if self.norm is not None else (None, None)  # (PATCH_NORM False: no norm)
+        return Fn.PatchEmbedFn.apply(x, self.proj.weight, self.proj.bias, g, b, self.patch_size[0])
 
 
 class SwinTransformer(nn.Module):
@@ -348,10 +347,9 @@ class SwinTransformer(nn.Module):
         flat = [c for grp in crop_groups for c in grp]
         self._draw_drop_path(sum(c.shape[0] for c in flat), flat[0].device)
         pe = self.patch_embed
-        if pe.norm is None:
-            raise NotImplementedError("PATCH_NORM False is not on the hot path")
         P = pe.patch_size[0]
-        X = Fn.PatchEmbedMultiFn.apply(pe.proj.weight, pe.proj.bias, pe.norm.weight, pe.norm.bias, P, *flat)
+        g, b = (pe.norm.weight, pe.norm.bias) if pe.norm is not None else (None, None)
+        X = Fn.PatchEmbedMultiFn.apply(pe.proj.weight, pe.proj.bias, g, b, P, *flat)
         groups, r0 = [], 0
         for grp in crop_groups:
             nB, G = sum(c.shape[0] for c in grp), grp[0].shape[-1] // P

@@ -647,6 +647,30 @@ def gen_head_nlayers(ns):
     print("head_nlayers.pt:", {n: len(v["grads"]) for n, v in out.items()})
 
 
+def gen_patch_norm(ns):
+    """PATCH_NORM False (swin_transformer.py:532-535, 545-546: PatchEmbed without its LayerNorm): three-stage nano Swin, features of a
+    112^2 batch and the multi-crop forward over a (112^2, 64^2) pair, with the gradients of a probe-weighted sum"""
+    names = ["patch_embed.proj.weight", "patch_embed.proj.bias", "layers.0.blocks.0.norm1.weight", "layers.1.downsample.reduction.weight", "norm.bias"]
+    out = {}
+    for mode in ("features", "multi_crop"):
+        cfg = RL.swin_config(embed_dim=GU.NANO["embed_dim"], depths=(2, 2, 2), heads=(1, 2, 4), window=GU.NANO["window"], img=112)
+        cfg.MODEL["SPEC"]["PATCH_NORM"] = False
+        m = ns.models.build_model(cfg, is_teacher=False, use_dense_prediction=False)
+        GU.fill_state_dict(m.state_dict(), 29)
+        xa, xb, pa, pab = GU.patch_norm_inputs(m.num_features)
+        if mode == "features":
+            y = m.forward_features(xa)
+            (y * pa).sum().backward()
+        else:
+            y = m([xa, xb])
+            (y * pab).sum().backward()
+        prm = dict(m.named_parameters())
+        out[mode] = {"keys": [(k, tuple(v.shape)) for k, v in m.state_dict().items()], "y": y.detach().clone(),
+                     "grads": {n: prm[n].grad.clone() for n in names}}
+    torch.save(out, os.path.join(OUT, "patch_norm.pt"))
+    print("patch_norm.pt:", {k: tuple(v["y"].shape) for k, v in out.items()})
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ns = RL.load()
@@ -671,6 +695,8 @@ def main():
         gen_linear_probe(ns)
     if not only or "head_nlayers" in only:
         gen_head_nlayers(ns)
+    if not only or "patch_norm" in only:
+        gen_patch_norm(ns)
     if "full" in only:  # minutes of CPU time: regenerated on request only
         gen_full(ns)
     if "full_vit" in only:

@@ -129,6 +129,13 @@ def mixup_case():
 
 
 # ---- USE_APE: three-stage nano Swin at 112^2 -------------------------------------------------------------------------------------------
+def patch_norm_inputs(num_features, B=2):
+    """PATCH_NORM False fixture: one 112^2 batch for forward_features, a (112^2, 64^2) crop pair for the multi-crop forward"""
+    g = torch.Generator().manual_seed(2929)
+    return (torch.randn(B, 3, 112, 112, generator=g), torch.randn(B, 3, 64, 64, generator=g), torch.randn(B, num_features, generator=g),
+            torch.randn(2 * B, num_features, generator=g))
+
+
 def ape_inputs(num_features, B=3):
     g = torch.Generator().manual_seed(1717)
     return torch.randn(B, 3, 112, 112, generator=g), torch.randn(B, num_features, generator=g)

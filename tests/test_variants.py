@@ -378,6 +378,56 @@ def test_ape_gpu(gold, prec, lib_built):
         esvit_amd.set_precision("bf16")
 
 
+# ---- PATCH_NORM False (swin_transformer.py:532-535, 545-546) ---------------------------------------------------------------
+def _check_patch_norm(dev, tol):
+    from esvit_amd import models
+    from oracle import ref_loader as RL
+    gold = torch.load(os.path.join(os.path.dirname(GOLD), "patch_norm.pt"), weights_only=False)
+    for mode, g in gold.items():
+        cfg = RL.swin_config(embed_dim=GU.NANO["embed_dim"], depths=(2, 2, 2), heads=(1, 2, 4), window=GU.NANO["window"], img=112)
+        cfg.MODEL["SPEC"]["PATCH_NORM"] = False
+        m = models.build_model(cfg, is_teacher=False, use_dense_prediction=False)
+        assert m.patch_embed.norm is None
+        assert [(k, tuple(v.shape)) for k, v in m.state_dict().items()] == g["keys"]
+        GU.fill_state_dict(m.state_dict(), 29)
+        m = m.to(dev)
+        xa, xb, pa, pab = (t.to(dev) for t in GU.patch_norm_inputs(m.num_features))
+        if mode == "features":
+            y = m.forward_features(xa)
+            (y * pa).sum().backward()
+        else:  # both resolutions through the ragged route: one embedding GEMM over the rows of both crops
+            y = m([xa, xb])
+            (y * pab).sum().backward()
+
+        def rel(a, b):
+            return ((a.detach().float().cpu() - b).norm() / (b.norm() + 1e-12)).item()
+        assert rel(y, g["y"]) < tol, (mode, rel(y, g["y"]))
+        prm = dict(m.named_parameters())
+        for n, want in g["grads"].items():
+            assert rel(prm[n].grad, want) < 5 * tol, (mode, n, rel(prm[n].grad, want))
+
+
+def test_patch_norm_false_host_logic_cpu(monkeypatch, lib_built):
+    import esvit_amd
+    import esvit_amd.functional as Fn
+    import esvit_amd.params as P
+    esvit_amd.set_precision("fp32")
+    for mod in (Fn, P):
+        monkeypatch.setattr(mod, "ops", ops_ref)
+    _check_patch_norm(torch.device("cpu"), 2e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_patch_norm_false_gpu(prec, lib_built):
+    import esvit_amd
+    esvit_amd.set_precision(prec)
+    try:
+        _check_patch_norm(torch.device("cuda:0"), 2e-5 if prec == "fp32" else 3e-2)
+    finally:
+        esvit_amd.set_precision("bf16")
+
+
 def test_init_weights_resizes_bias_table_and_ape(tmp_path):
     """swin_transformer.py:852-917: a checkpoint of another window size / grid is loaded with bicubic resizing (closed form of
     :873-912; the reference's own init_weights cannot run this case, see the docstring of SwinTransformer.init_weights)"""
