@@ -9,6 +9,8 @@ similarity product -- the only heavy step: 50k x 1.28M x C for ImageNet -- is th
 train matrix in its stored [N_train, C] layout (no transposed copy); top-k, the one-hot vote and the ranking are
 PyTorch indexing ops with the reference's tie behaviour.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -17,6 +19,26 @@ from . import ops
 
 def _dist_on():
     return dist.is_available() and dist.is_initialized()
+
+
+def load_pretrained_weights(model, pretrained_weights, checkpoint_key, model_name=None, patch_size=None):
+    """utils.load_pretrained_weights (utils.py:78-103): take `checkpoint_key` ("teacher" / "student") out of a training checkpoint
+    written by main_esvit.py (utils.save_on_master), strip the DistributedDataParallel prefix, load non-strictly (the heads of the
+    checkpoint have no place in a NUM_CLASSES 0 backbone).  Without a file the reference tries to download DINO's public ViT
+    weights; there is no network on this side, so that branch leaves the random initialisation and says so.  Returns the
+    load_state_dict message (the reference prints it)."""
+    if os.path.isfile(pretrained_weights):
+        state_dict = torch.load(pretrained_weights, map_location="cpu", weights_only=False)
+        if checkpoint_key is not None and checkpoint_key in state_dict:
+            print(f"Take key {checkpoint_key} in provided checkpoint dict")
+            state_dict = state_dict[checkpoint_key]
+        state_dict = {k.replace("module.", ""): v for k, v in state_dict.items()}
+        msg = model.load_state_dict(state_dict, strict=False)
+        print('Pretrained weights found at {} and loaded with msg: {}'.format(pretrained_weights, msg))
+        return msg
+    print("Please use the `--pretrained_weights` argument to indicate the path of the checkpoint to evaluate.")
+    print("There is no reference weights available for this model => We use random weights.")
+    return None
 
 
 @torch.no_grad()

@@ -647,6 +647,49 @@ def gen_head_nlayers(ns):
     print("head_nlayers.pt:", {n: len(v["grads"]) for n, v in out.items()})
 
 
+def gen_ref_checkpoint(ns):
+    """a training checkpoint as main_esvit.py writes it (utils.save_on_master: DistributedDataParallel student, plain teacher, loss
+    state) and the eval_knn.py path over it -- build_model(is_teacher=True) with NUM_CLASSES 0, utils.load_pretrained_weights,
+    the backbone's features of a synthetic set, knn_classifier -- all with the reference's own functions"""
+    import torch.nn as nn
+    RL.ensure_single_process_group()
+    c = GU.REF_CKPT
+    cfg = RL.swin_config(embed_dim=c["embed_dim"], depths=c["depths"], heads=c["heads"], window=c["window"])
+
+    def with_heads(teacher):
+        m = ns.models.build_model(cfg, is_teacher=teacher, use_dense_prediction=True)
+        fea = m.num_features
+        m.head = ns.DINOHead(fea, c["head"]["out_dim"], norm_last_layer=True, hidden_dim=c["head"]["hidden_dim"], bottleneck_dim=c["head"]["bottleneck_dim"])
+        m.head_dense = ns.DINOHead(fea, c["head"]["out_dim"], norm_last_layer=False, hidden_dim=c["head"]["hidden_dim"],
+                                   bottleneck_dim=c["head"]["bottleneck_dim"])
+        return m
+    student, teacher = with_heads(False), with_heads(True)
+    GU.fill_state_dict(student.state_dict(), 41)
+    GU.fill_state_dict(teacher.state_dict(), 42)
+    ddp = nn.parallel.DistributedDataParallel(student)  # (CPU, one gloo rank: the state_dict keys carry DDP's "module." prefix)
+    loss = ns.DDINOLoss(c["head"]["out_dim"], 10, 0.04, 0.07, 5, 10)
+    path = os.path.join(OUT, "ref_checkpoint.pth")
+    ns.utils.save_on_master({"student": ddp.state_dict(), "teacher": teacher.state_dict(), "epoch": 3, "dino_loss": loss.state_dict()}, path)
+    xtr, ytr, xte, yte = GU.ref_ckpt_data()
+    ref_knn = RL.load_knn_classifier()
+    out = {"student_keys": list(ddp.state_dict().keys())[:4]}
+    saved = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        for key in ("teacher", "student"):
+            model = ns.models.build_model(cfg, is_teacher=True)
+            ns.utils.load_pretrained_weights(model, path, key, "swin_nano", 4)
+            model.eval()
+            with torch.no_grad():
+                ftr, fte = model(xtr), model(xte)
+            ntr, nte = nn.functional.normalize(ftr, dim=1, p=2), nn.functional.normalize(fte, dim=1, p=2)
+            out[key] = {"train": ftr.clone(), "test": fte.clone(), "top": tuple(ref_knn(ntr, ytr, nte, yte, c["k"], c["T"], num_classes=c["classes"]))}
+    finally:
+        torch.Tensor.cuda = saved
+    torch.save(out, os.path.join(OUT, "ref_checkpoint.pt"))
+    print("ref_checkpoint.pth:", os.path.getsize(path), "bytes; knn", {k: out[k]["top"] for k in ("teacher", "student")})
+
+
 def gen_patch_norm(ns):
     """PATCH_NORM False (swin_transformer.py:532-535, 545-546: PatchEmbed without its LayerNorm): three-stage nano Swin, features of a
     112^2 batch and the multi-crop forward over a (112^2, 64^2) pair, with the gradients of a probe-weighted sum"""
@@ -697,6 +740,8 @@ def main():
         gen_head_nlayers(ns)
     if not only or "patch_norm" in only:
         gen_patch_norm(ns)
+    if not only or "ref_checkpoint" in only:
+        gen_ref_checkpoint(ns)
     if "full" in only:  # minutes of CPU time: regenerated on request only
         gen_full(ns)
     if "full_vit" in only:

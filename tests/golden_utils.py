@@ -72,6 +72,24 @@ def make_knn_set(seed, n_train=1500, n_test=400, dim=48, classes=10, noise=1.0):
     return xtr, ytr, xte, yte
 
 
+# a training checkpoint written by the reference (utils.save_on_master of a DistributedDataParallel student and a plain teacher, three-stage
+# nano Swin + V / R heads) and what the reference's eval_knn.py path makes of it (tests/golden/ref_checkpoint.{pth,pt})
+REF_CKPT = dict(embed_dim=32, depths=(1, 1, 1), heads=(1, 2, 4), window=7, head=dict(out_dim=256, hidden_dim=64, bottleneck_dim=32),
+                n_train=120, n_test=100, classes=6, size=64, k=5, T=0.07)
+
+
+def ref_ckpt_data():
+    """class-dependent synthetic images: a per-class pattern plus noise, so that the k-NN vote is not a coin toss"""
+    c = REF_CKPT
+    g = torch.Generator().manual_seed(4242)
+    protos = torch.randn(c["classes"], 3, c["size"], c["size"], generator=g)
+    ytr = torch.arange(c["n_train"]) % c["classes"]
+    yte = torch.arange(c["n_test"]) % c["classes"]
+    xtr = protos[ytr] + 6.0 * torch.randn(c["n_train"], 3, c["size"], c["size"], generator=g)
+    xte = protos[yte] + 6.0 * torch.randn(c["n_test"], 3, c["size"], c["size"], generator=g)
+    return xtr, ytr, xte, yte
+
+
 KNN_CASES = [dict(seed=5, k=10, T=0.07, noise=2.0), dict(seed=6, k=20, T=0.07, noise=3.0), dict(seed=7, k=20, T=0.5, noise=4.0)]
 
 

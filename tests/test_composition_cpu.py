@@ -467,8 +467,10 @@ def check_cvt_variant(name, loss_mod, dev="cpu", rt=3e-4, loss_tol=2e-5, grad_to
     if probes:
         check_nano_cvt(g, student, s_out, t_out, loss, rt, loss_tol, grad_tol, buf_tol)
     else:  # (bf16 on the GPU: loss and gradient norms, like the plain nano CvT step)
-        assert abs(loss.item() - g["ddino_loss"]) < loss_tol, (loss.item(), g["ddino_loss"])
         got = {n: p.grad for n, p in student.named_parameters() if p.grad is not None}
+        GU.record_parity(test="cvt_variant_" + name, prec="bf16", abs_err=abs(loss.item() - g["ddino_loss"]),
+                         worst_grad_norm_rel=max(abs(got[n].norm().item() - ref) / (ref + 1e-9) for n, ref in g["grad_norms"].items() if n in got))
+        assert abs(loss.item() - g["ddino_loss"]) < loss_tol, (loss.item(), g["ddino_loss"])
         assert sorted(got) == sorted(g["grad_norms"])
         for n, ref in g["grad_norms"].items():
             assert abs(got[n].norm().item() - ref) <= grad_tol * ref + 1e-6, (n, got[n].norm().item(), ref)
@@ -545,6 +547,43 @@ def test_knn_classifier_host_logic_matches_reference_golden(cpu_ops, monkeypatch
         xtr, ytr, xte, yte = GU.make_knn_set(c["seed"], noise=c["noise"])
         got = E.knn_classifier(xtr, ytr, xte, yte, c["k"], c["T"], num_classes=10)
         assert got == pytest.approx(want, abs=1e-9), (c, got, want)
+
+
+def check_ref_checkpoint(dev="cpu", tol=2e-5, top_tol=1.0):
+    """eval_knn.py end to end over a checkpoint FILE the reference wrote (utils.save_on_master; DistributedDataParallel student, plain
+    teacher, heads, loss state): load_pretrained_weights -> extract_features -> knn_classifier, against the reference's own features
+    and votes for both checkpoint keys"""
+    from esvit_amd import eval as E
+    from esvit_amd import models
+    c = GU.REF_CKPT
+    gold = torch.load(os.path.join(GOLD, "ref_checkpoint.pt"), weights_only=False)
+    path = os.path.join(GOLD, "ref_checkpoint.pth")
+    xtr, ytr, xte, yte = GU.ref_ckpt_data()
+    for key in ("teacher", "student"):
+        cfg = RL.swin_config(embed_dim=c["embed_dim"], depths=c["depths"], heads=c["heads"], window=c["window"])
+        model = models.build_model(cfg, is_teacher=True)
+        msg = E.load_pretrained_weights(model, path, key, "swin_nano", 4)
+        assert not msg.missing_keys and all(k.startswith(("head.", "head_dense.")) for k in msg.unexpected_keys)
+        model = model.to(dev).eval()
+        feats = []
+        for x in (xtr, xte):
+            loader = torch.utils.data.DataLoader(IndexedSet(x), batch_size=32)
+            feats.append(E.extract_features(model, loader, use_cuda=(dev != "cpu")))
+        ntr, nte = (torch.nn.functional.normalize(f, dim=1, p=2) for f in feats)
+        top = E.knn_classifier(ntr, ytr.to(ntr.device), nte, yte.to(ntr.device), c["k"], c["T"], num_classes=c["classes"])
+        if dev != "cpu":
+            GU.record_parity(test="ref_checkpoint_" + key, prec=str(E.ops.act_dtype()), top=top, ref_top=gold[key]["top"],
+                             feat_rel=max(((f.cpu() - w).abs().max() / w.abs().max()).item() for f, w in zip(feats, (gold[key]["train"], gold[key]["test"]))))
+        for f, want in zip(feats, (gold[key]["train"], gold[key]["test"])):
+            assert (f.cpu() - want).abs().max().item() <= tol * want.abs().max().item(), (key, (f.cpu() - want).abs().max().item())
+        assert abs(top[0] - gold[key]["top"][0]) <= top_tol and abs(top[1] - gold[key]["top"][1]) <= top_tol, (key, top, gold[key]["top"])
+    assert E.load_pretrained_weights(model, path + ".absent", "teacher") is None  # (no file: the random initialisation stays)
+
+
+def test_reference_written_checkpoint_through_the_knn_consumers(cpu_ops, monkeypatch):
+    from esvit_amd import eval as E
+    monkeypatch.setattr(E, "ops", cpu_ops)
+    check_ref_checkpoint()
 
 
 @pytest.mark.parametrize("name", sorted(GU.FULL_CFG_CASES))

@@ -404,6 +404,21 @@ def test_nano_cvt_eval_matches_reference_golden(lib_built):
         _teardown()
 
 
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_reference_written_checkpoint_through_the_knn_consumers_gpu(prec, lib_built):
+    """a checkpoint file written by the reference's utils.save_on_master, loaded and evaluated end to end on the HIP path
+    (load_pretrained_weights -> extract_features -> knn_classifier) against the reference's own features and k-NN votes"""
+    from tests.test_composition_cpu import check_ref_checkpoint
+    dev = _setup(prec)
+    try:
+        if prec == "fp32":
+            check_ref_checkpoint(dev, tol=1e-4, top_tol=2.0)
+        else:  # bf16 activations move the features by ~1e-2 and with them a few of the hundred votes
+            check_ref_checkpoint(dev, tol=5e-2, top_tol=8.0)
+    finally:
+        _teardown()
+
+
 def test_eval_knn_consumers_gpu(lib_built):
     """SURVEY.md 8f-1 on the HIP path: extract_features through the backbone kernels, knn_classifier through the fp32 MFMA GEMM,
     against the reference's golden top-1 / top-5 and the CPU oracle on a larger set"""
