@@ -75,7 +75,7 @@ def make_knn_set(seed, n_train=1500, n_test=400, dim=48, classes=10, noise=1.0):
 # a training checkpoint written by the reference (utils.save_on_master of a DistributedDataParallel student and a plain teacher, three-stage
 # nano Swin + V / R heads) and what the reference's eval_knn.py path makes of it (tests/golden/ref_checkpoint.{pth,pt})
 REF_CKPT = dict(embed_dim=32, depths=(1, 1, 1), heads=(1, 2, 4), window=7, head=dict(out_dim=256, hidden_dim=64, bottleneck_dim=32),
-                n_train=120, n_test=100, classes=6, size=64, k=5, T=0.07)
+                n_train=120, n_test=100, classes=6, size=64, k=40, T=0.07)
 
 
 def ref_ckpt_data():

@@ -381,7 +381,8 @@ def test_cvt_variants_step_matches_reference_golden(name, prec, lib_built):
         if prec == "fp32":
             check_cvt_variant(name, L, dev=dev, rt=5e-4, loss_tol=1e-4, grad_tol=3e-3, buf_tol=1e-4)
         else:
-            check_cvt_variant(name, L, dev=dev, rt=6e-2, loss_tol=2e-2, grad_tol=0.2, buf_tol=2e-2, probes=False)
+            # observed (profiles/r03_parity_observed.jsonl): loss 4e-5 .. 9.6e-4, gradient norms 1.2 .. 2.7 %
+            check_cvt_variant(name, L, dev=dev, rt=6e-2, loss_tol=3e-3, grad_tol=0.08, buf_tol=2e-2, probes=False)
     finally:
         _teardown()
 
@@ -412,9 +413,9 @@ def test_reference_written_checkpoint_through_the_knn_consumers_gpu(prec, lib_bu
     dev = _setup(prec)
     try:
         if prec == "fp32":
-            check_ref_checkpoint(dev, tol=1e-4, top_tol=2.0)
-        else:  # bf16 activations move the features by ~1e-2 and with them a few of the hundred votes
-            check_ref_checkpoint(dev, tol=5e-2, top_tol=8.0)
+            check_ref_checkpoint(dev, tol=5e-6, top_tol=1.0)
+        else:  # bf16 activations move the features by 4e-3 (observed) and with them at most a few of the hundred votes
+            check_ref_checkpoint(dev, tol=1.2e-2, top_tol=3.0)
     finally:
         _teardown()
 
