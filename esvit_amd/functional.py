@@ -14,7 +14,6 @@ Stages (reference lines):
 """
 import os
 
-import numpy as np
 import torch
 
 from . import ops

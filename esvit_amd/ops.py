@@ -9,8 +9,7 @@ import ctypes as C
 import numpy as np
 import torch
 
-from . import _lib
-from ._lib import BF16, EPI_GELU, EPI_GELU_BWD, EPI_NONE, EPI_QGELU, EPI_QGELU_BWD, F32, GEMM_AUTO, GEMM_DMA4, GEMM_DMA4W, GEMM_DMA8, GEMM_REGSTAGE, GemmDesc, check, lib
+from ._lib import BF16, EPI_GELU, EPI_GELU_BWD, EPI_NONE, EPI_QGELU, EPI_QGELU_BWD, F32, GEMM_AUTO, GEMM_DMA8, GemmDesc, check, lib
 
 _ACT_DTYPE = torch.bfloat16
 

@@ -7,8 +7,6 @@ host synchronisation.
 ``optimizer`` entry: per-parameter ``step``, ``exp_avg``, ``exp_avg_sq``; two param groups from
 ``get_params_groups``), so checkpoints stay interchangeable with the unmodified caller.
 """
-import math
-
 import numpy as np
 import torch
 

@@ -10,8 +10,6 @@ __graft_entry__.smoke() may.
 Everything is computed in fp32 (fp64 where cheap) from the *given* inputs; outputs are rounded
 to the activation dtype only at the points where the HIP kernels store activations.
 """
-import math
-
 import numpy as np
 import torch
 import torch.nn.functional as F
