@@ -155,18 +155,25 @@ class DINOLoss(_DeferredCenter, nn.Module):
     def _mixup_terms(self, targets_mixup, B, device):
         """main_esvit.py:639-641: for teacher view iq and student crop v the loss is mean_a -sum_b T_v[a, b] q_a . logp_b, i.e.
         student row (v, b) is scored against the teacher rows a with T_v[a, b] != 0.  Mixup / cutmix targets (and the identity
-        of the un-mixed crops) have at most two non-zeros per column, which gives at most four weighted terms per student row."""
+        of the un-mixed crops) have at most two non-zeros per column, which gives at most four weighted terms per student row.
+        Label smoothing (--smoothing > 0, main_esvit.py:230) adds the same constant off_v = smoothing / B to every entry of a mixed
+        crop's matrix: T_v = S_v + off_v 1 1^T with S_v sparse as before, and the constant part scores every student row against the
+        MEAN teacher distribution of the view (`_smoothing_term`).  -> (tmatch [ncrops*B, 4], weights [ncrops*B, 4], off [ncrops])"""
         T = torch.stack([t.to(device=device, dtype=torch.float32) for t in targets_mixup])       # [ncrops, a, b]
         assert T.shape == (self.ncrops, B, B), "targets_mixup: one [B, B] matrix per crop"
+        off = T.amin(dim=(1, 2))                                                                  # 0 without smoothing
+        S = T - off.view(-1, 1, 1)
         if not self.__dict__.get("_mixup_checked"):
-            # structure check on the FIRST call only (it reads a value back from the device: not something for every step); mixup /
-            # cutmix targets keep this structure for the whole run, label smoothing (dense targets) never has it
-            if int((T != 0).sum(1).max()) > 2:
-                raise NotImplementedError("DINOLoss mixup targets with more than two non-zeros per column (e.g. --smoothing > 0: dense "
-                                          "targets) are not built: the four-term cross-entropy kernel covers mixup / cutmix")
+            # structure check on the FIRST call only (it reads values back from the device: not something for every step); mixup /
+            # cutmix / smoothing settings keep this structure for the whole run
+            tol = 1e-6 * float(T.abs().max())  # (per-sample mixing ratios leave the constant part exact to an ulp only)
+            if int((S.abs() > tol).sum(1).max()) > 2:
+                raise NotImplementedError("DINOLoss mixup targets that are not (at most two entries per column) + (one constant per crop): "
+                                          "the four-term cross-entropy kernel and the mean-teacher term cover mixup / cutmix / label smoothing")
+            self.__dict__["_mixup_smoothed"] = bool((off > 0).any())
             self.__dict__["_mixup_checked"] = True
-        w2, a2 = torch.topk(T.abs(), 2, dim=1)                                                   # [ncrops, 2, b]
-        w2 = torch.gather(T, 1, a2)
+        w2, a2 = torch.topk(S.abs(), 2, dim=1)                                                   # [ncrops, 2, b]
+        w2 = torch.gather(S, 1, a2)
         n_terms = 2 * self.ncrops - 2
         tm = torch.full((self.ncrops, B, 4), -1, dtype=torch.int32, device=device)
         tw = torch.zeros((self.ncrops, B, 4), dtype=torch.float32, device=device)
@@ -176,7 +183,29 @@ class DINOLoss(_DeferredCenter, nn.Module):
                 tw[:, :, 2 * iq + j] = w2[:, j, :] / (n_terms * B)
             tm[iq, :, 2 * iq:2 * iq + 2] = -1   # student and teacher on the same view: skipped (main_esvit.py:636-638)
         tm[tw == 0] = -1
-        return tm.view(-1, 4).contiguous(), tw.view(-1, 4).contiguous()
+        return tm.view(-1, 4).contiguous(), tw.view(-1, 4).contiguous(), off
+
+    def _smoothing_term(self, o, s, t, mx, lse, off, B, inv_st, inv_tt):
+        """the constant part of smoothed mixup targets: (1 / B) sum_a sum_b off_v q_a . logp_b = off_v sum_b qbar . logp_b with
+        qbar the mean teacher distribution of the view.  qbar enters the same cross-entropy kernel as a teacher row of its own:
+        the logit row  c + temp * log(qbar)  has exactly qbar as its centred, sharpened softmax.  (A handful of small torch
+        launches on [2B, K]; only runs with --use_mixup and --smoothing > 0.)"""
+        K = t.shape[1]
+        q = torch.exp((t.float() - self.center) * inv_tt - (mx + lse)[:, None])
+        qbar = q.view(2, B, K).mean(1)
+        tbar = (torch.log(qbar).clamp_min(-80.0) / inv_tt + self.center).to(t.dtype).contiguous()
+        mx2, lse2 = o.teacher_row_stats(tbar, self.center, inv_tt)
+        n_terms = 2 * self.ncrops - 2
+        tm = torch.full((self.ncrops, B, 4), -1, dtype=torch.int32, device=s.device)
+        tw = torch.zeros((self.ncrops, B, 4), dtype=torch.float32, device=s.device)
+        for iq in range(2):
+            tm[:, :, iq] = iq
+            tw[:, :, iq] = (off / n_terms).view(-1, 1)
+            tm[iq, :, iq] = -1
+            tw[iq, :, iq] = 0.0
+        tm[tw == 0] = -1
+        return o.dino_ce(s.detach(), tbar, self.center, mx2, lse2, tm.view(-1, 4).contiguous(), None, inv_st, inv_tt,
+                         term_w=tw.view(-1, 4).contiguous())
 
     def forward(self, student_output, teacher_output, epoch, targets_mixup=None):
         o = _ops()
@@ -188,8 +217,11 @@ class DINOLoss(_DeferredCenter, nn.Module):
         t_st, s_st = _taken_stats(teacher_output, self._token("t0", inv_tt)), _taken_stats(student_output, self._token("s0", inv_st))
         mx, lse = t_st if t_st is not None else o.teacher_row_stats(t, self.center, inv_tt)
         if targets_mixup:
-            tmatch, tw = self._mixup_terms(targets_mixup, B, s.device)
+            tmatch, tw, off = self._mixup_terms(targets_mixup, B, s.device)
             row_loss, ds = o.dino_ce(s.detach(), t, self.center, mx, lse, tmatch, None, inv_st, inv_tt, term_w=tw)
+            if self.__dict__.get("_mixup_smoothed"):
+                row2, ds2 = self._smoothing_term(o, s, t, mx, lse, off, B, inv_st, inv_tt)
+                row_loss, ds = row_loss + row2, ds + ds2
         else:
             tmatch, w = self._static(B, s.device)
             row_loss, ds = o.dino_ce(s.detach(), t, self.center, mx, lse, tmatch, w, inv_st, inv_tt, s_stats=s_st)

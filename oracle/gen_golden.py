@@ -690,6 +690,20 @@ def gen_ref_checkpoint(ns):
     print("ref_checkpoint.pth:", os.path.getsize(path), "bytes; knn", {k: out[k]["top"] for k in ("teacher", "student")})
 
 
+def gen_mixup_smoothing(ns):
+    """the reference's DINOLoss.forward with label-smoothed mixup targets (main_esvit.py:230, 639-641): dense [B, B] matrices"""
+    RL.ensure_single_process_group()
+    mc = GU.MIXUP
+    s_l, t_l, c0, T = GU.mixup_case(GU.MIXUP_SMOOTHING)
+    lf = ns.DINOLoss(mc["K"], mc["ncrops"], 0.04, 0.07, 5, 10)
+    lf.center.copy_(c0)
+    s_l = s_l.clone().requires_grad_(True)
+    lm = lf(s_l, t_l, 2, T)
+    lm.backward()
+    torch.save({"loss": lm.item(), "ds": s_l.grad.clone(), "center_after": lf.center.clone()}, os.path.join(OUT, "mixup_smoothing.pt"))
+    print("mixup_smoothing.pt: loss", lm.item())
+
+
 def gen_patch_norm(ns):
     """PATCH_NORM False (swin_transformer.py:532-535, 545-546: PatchEmbed without its LayerNorm): three-stage nano Swin, features of a
     112^2 batch and the multi-crop forward over a (112^2, 64^2) pair, with the gradients of a probe-weighted sum"""
@@ -740,6 +754,8 @@ def main():
         gen_head_nlayers(ns)
     if not only or "patch_norm" in only:
         gen_patch_norm(ns)
+    if not only or "mixup_smoothing" in only:
+        gen_mixup_smoothing(ns)
     if not only or "ref_checkpoint" in only:
         gen_ref_checkpoint(ns)
     if "full" in only:  # minutes of CPU time: regenerated on request only

@@ -132,17 +132,33 @@ def lars_case():
 MIXUP = dict(B=6, ncrops=4, K=64, lams=(0.7, 0.35))  # the first two crops are mixed (num_mixup_views = 2), the others are not
 
 
-def mixup_case():
+MIXUP_SMOOTHING = 0.1  # the second fixture (tests/golden/mixup_smoothing.pt): --smoothing 0.1, and per-sample mixing ratios for crop 1
+
+
+def mixup_case(smoothing=0.0):
     """-> (student logits [ncrops*B, K], teacher logits [2B, K], centre [1, K], [T_v [B, B] per crop]).  T_v of a mixed crop is
     what timm's Mixup returns for targets = arange(B): lam * onehot(a) + (1 - lam) * onehot(B - 1 - a) (batch mode pairs a sample
-    with the flipped batch); un-mixed crops get the identity, as train_one_epoch builds it."""
+    with the flipped batch); un-mixed crops get the identity, as train_one_epoch builds it.  With label smoothing the one-hot rows
+    are timm's `one_hot(x, num_classes, on_value = 1 - smoothing + off, off_value = off = smoothing / num_classes)` (num_classes is
+    the batch size, main_esvit.py:230), and the second mixed crop uses per-sample ratios (mixup_mode 'elem')."""
     c = MIXUP
     g = torch.Generator().manual_seed(9090)
     s = torch.randn(c["ncrops"] * c["B"], c["K"], generator=g)
     t = torch.randn(2 * c["B"], c["K"], generator=g)
     center = torch.randn(1, c["K"], generator=g) * 0.1
     eye = torch.eye(c["B"])
-    T = [lam * eye + (1 - lam) * eye.flip(0) for lam in c["lams"]] + [eye.clone() for _ in range(c["ncrops"] - len(c["lams"]))]
+    if smoothing == 0.0:
+        T = [lam * eye + (1 - lam) * eye.flip(0) for lam in c["lams"]]
+    else:
+        B = c["B"]
+        off = smoothing / B
+        on = 1.0 - smoothing + off
+        idx = torch.arange(B).view(-1, 1)
+        y1 = torch.full((B, B), off).scatter_(1, idx, on)
+        y2 = torch.full((B, B), off).scatter_(1, idx.flip(0), on)
+        lam_elem = torch.rand(B, 1, generator=g) * 0.6 + 0.2
+        T = [y1 * c["lams"][0] + y2 * (1.0 - c["lams"][0]), y1 * lam_elem + y2 * (1.0 - lam_elem)]
+    T += [eye.clone() for _ in range(c["ncrops"] - len(c["lams"]))]
     return s, t, center, T
 
 

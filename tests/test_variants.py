@@ -258,6 +258,58 @@ def test_mixup_loss_gpu(gold, lib_built):
         esvit_amd.set_precision("bf16")
 
 
+# ---- label-smoothed mixup targets (--smoothing > 0, main_esvit.py:230): dense [B, B] matrices = sparse part + one constant per crop
+def _smoothing_gold():
+    return torch.load(os.path.join(os.path.dirname(GOLD), "mixup_smoothing.pt"), weights_only=False)
+
+
+def test_oracle_smoothed_mixup_loss_matches_reference_golden():
+    g = _smoothing_gold()
+    s, t, c0, T = GU.mixup_case(GU.MIXUP_SMOOTHING)
+    s = s.clone().requires_grad_(True)
+    loss, _ = O.dino_loss(s, t, c0, O.teacher_temp(2, 0.04, 0.07, 5, 10), GU.MIXUP["ncrops"], targets_mixup=T)
+    loss.backward()
+    assert abs(loss.item() - g["loss"]) < 2e-6 and (s.grad - g["ds"]).abs().max().item() < 1e-7
+
+
+def _check_smoothed_mixup_loss(dev, tol):
+    import esvit_amd
+    g, mc = _smoothing_gold(), GU.MIXUP
+    s, t, c0, T = GU.mixup_case(GU.MIXUP_SMOOTHING)
+    lf = esvit_amd.DINOLoss(mc["K"], mc["ncrops"], 0.04, 0.07, 5, 10).to(dev)
+    lf.center.copy_(c0.to(dev))
+    s = s.to(dev).requires_grad_(True)
+    loss = lf(s, t.to(dev), 2, [m.to(dev) for m in T])
+    loss.backward()
+    lf.synchronize()
+    assert abs(loss.item() - g["loss"]) < tol * 10 * max(1.0, abs(g["loss"])), (loss.item(), g["loss"])
+    assert (s.grad.float().cpu() - g["ds"]).abs().max().item() < tol * max(1.0, g["ds"].abs().max().item())
+    assert (lf.center.cpu() - g["center_after"]).abs().max().item() < 1e-5
+    # a matrix that is neither sparse nor sparse + constant is refused (on a fresh module: the structure is checked once per run)
+    lf2 = esvit_amd.DINOLoss(mc["K"], mc["ncrops"], 0.04, 0.07, 5, 10).to(dev)
+    bad = [torch.rand(mc["B"], mc["B"], device=dev) for _ in T]
+    with pytest.raises(NotImplementedError):
+        lf2(s.detach(), t.to(dev), 2, bad)
+
+
+def test_smoothed_mixup_loss_host_logic_cpu(monkeypatch, lib_built):
+    import esvit_amd
+    import esvit_amd.loss as L
+    esvit_amd.set_precision("fp32")
+    monkeypatch.setattr(L, "ops", ops_ref)
+    _check_smoothed_mixup_loss(torch.device("cpu"), 5e-6)
+
+
+@pytest.mark.gpu
+def test_smoothed_mixup_loss_gpu(lib_built):
+    import esvit_amd
+    esvit_amd.set_precision("fp32")
+    try:
+        _check_smoothed_mixup_loss(torch.device("cuda:0"), 5e-6)
+    finally:
+        esvit_amd.set_precision("bf16")
+
+
 @pytest.mark.gpu
 def test_train_one_epoch_mixup_drop_in_gpu(lib_built):
     """engine.train_one_epoch with a mixup_fn (main_esvit.py:515-544): the first num_mixup_views crops are mixed, the teacher
