@@ -388,7 +388,7 @@ class SwinTransformer(nn.Module):
         if self.use_dense_prediction:
             cls_parts, fea_parts, npatch = [], [], []
             all_fea = None
-            if self.ragged_multi_crop and len(bounds) > 1 and not self.ape:
+            if self.ragged_multi_crop and len(bounds) > 1 and not self.ape and self._even_maps([x[a].shape[-1] for a, _ in bounds]):
                 # every resolution group through the backbone at once (row-wise kernels see all rows, attention runs per group)
                 maps, all_fea = self.forward_feature_maps_multi([x[a:b] for a, b in bounds])
             else:
@@ -404,6 +404,18 @@ class SwinTransformer(nn.Module):
             return self._apply_head(self.head, output_cls), self._apply_head(self.head_dense, output_fea), output_fea, npatch
         outs = [self.forward_features(torch.cat(x[a:b])) for a, b in bounds]
         return self._apply_head(self.head, outs[0] if len(outs) == 1 else torch.cat(outs))
+
+    def _even_maps(self, sizes):
+        """the ragged route merges 2 x 2 patches of every group in one launch and has no padding step: crops whose feature map is odd
+        at some PatchMerging (e.g. 112^2 at four stages: 28, 14, 7) take the per-group schedule, which pads them as the reference
+        does (swin_transformer.py:406-408)"""
+        for S in sizes:
+            G = S // self.patch_embed.patch_size[0]
+            for _ in range(self.num_layers - 1):
+                if G % 2:
+                    return False
+                G //= 2
+        return True
 
     def forward_selfattention(self, x, n=1):
         x = self._tokens(x)

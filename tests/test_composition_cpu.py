@@ -100,6 +100,25 @@ def test_ragged_multi_crop_equals_reference_schedule(cpu_ops):
     check_ragged_equals_reference_schedule(L)
 
 
+def test_odd_feature_maps_take_the_per_group_schedule(cpu_ops):
+    """crops whose feature map is odd at a PatchMerging (112^2 at four stages: 28, 14, 7) cannot ride the ragged route (it has no
+    padding step): the default forward falls back to the reference's per-group schedule, which pads them (swin_transformer.py:406-408),
+    instead of refusing -- same outputs as with the ragged route switched off by hand"""
+    crops = [torch.randn(2, 3, 224, 224, generator=torch.Generator().manual_seed(5)),
+             torch.randn(2, 3, 112, 112, generator=torch.Generator().manual_seed(6))]
+    outs = []
+    for ragged in (True, False):
+        student = build_nano()
+        GU.fill_state_dict(student.state_dict(), 0)
+        student.ragged_multi_crop = ragged
+        assert not student._even_maps([224, 112]) and student._even_maps([224, 96])
+        with torch.no_grad():
+            outs.append(student(crops))
+    for a, b in zip(outs[0][:3], outs[1][:3]):
+        assert torch.equal(a, b)
+    assert outs[0][3] == outs[1][3] == [49, 16]
+
+
 def check_odd_batches_vs_oracle(loss_mod, dev="cpu", window=None, tol=2e-4, gtol=5e-3):
     """per-GPU batches that are not multiples of anything (B = 1, 3): outputs, loss and gradient norms of the nano model vs the
     CPU oracle on the same weights -- exercises the split-K / workgroup sizing and the ragged row matrix away from round sizes"""
