@@ -839,6 +839,76 @@ class DinoHeadBnFn(torch.autograd.Function):
         return dx, None, None, None, dW1, db1, dg1, dbe1, dW2, db2, dg2, dbe2, dW3, db3, dv, dg
 
 
+class DinoHeadBnNFn(torch.autograd.Function):
+    """DINOHead(use_bn=True) with any number of layers (vision_transformer.py:391-402, nlayers != 3): (Linear -> BatchNorm1d -> GELU)
+    nlayers - 1 times, a Linear into the bottleneck, l2-normalise, the weight-normed last layer -- the passes of DinoHeadBnFn in a
+    loop.  params = (W_1, b_1, bn_1.weight, bn_1.bias, ..., W_L, b_L, weight_v, weight_g); bn_states: one dict per BatchNorm."""
+
+    @staticmethod
+    def forward(ctx, x, bn_states, stats, *params):
+        o = ops_module()
+        L = (len(params) - 2 + 2) // 4                      # hidden layers carry four tensors, the last Linear two
+        hid = [params[4 * i:4 * i + 4] for i in range(L - 1)]
+        Wl, bl = params[4 * (L - 1)], params[4 * (L - 1) + 1]
+        v, g = params[-2], params[-1]
+        h = o.cast_to_act(x.contiguous())
+        saved, meta = [], []
+        for (Wp, b, gam, bet), st in zip(hid, bn_states):
+            W = _weight(Wp)
+            gam_, bet_ = gam.detach().contiguous(), bet.detach().contiguous()
+            d = o.linear_fwd(h, W, b)
+            coef, n = _head_bn_coef(o, d, st, gam_, bet_)
+            saved += [W, h, d, coef, gam_]
+            meta.append(n)
+            h = o.col_affine2(d, coef[0], coef[1], act=1)
+        WL = _weight(Wl)
+        hL = o.linear_fwd(h, WL, bl)
+        z, inv = o.l2norm_fwd(hL)
+        w, winv = _last_layer_weight(v, g)
+        logits, mx, lse = _last_logits(o, z, w, stats)
+        ctx.L, ctx.ns = L, meta
+        ctx.group, ctx.eval_bn = (bn_states[0].get("group"), bool(bn_states[0].get("eval"))) if bn_states else (None, False)
+        ctx.need_dg = g.requires_grad
+        ctx.wparams = tuple(hp[0] for hp in hid) + (Wl,)
+        ctx.vparam = v
+        ctx.save_for_backward(v, g, z, inv, w, winv, WL, h, *saved)
+        if mx is not None:
+            ctx.mark_non_differentiable(mx, lse)
+        return logits, mx, lse
+
+    @staticmethod
+    def backward(ctx, dlogits, _gmx=None, _glse=None):
+        o = ops_module()
+        L = ctx.L
+        t = ctx.saved_tensors
+        v, g, z, inv, w, winv, WL, hlast = t[:8]
+        per = [t[8 + 5 * i:8 + 5 * i + 5] for i in range(L - 1)]   # (W, input, pre-norm output, coef, gamma) of hidden layer i
+        dlogits = dlogits.contiguous()
+        dz = o.linear_dgrad(dlogits, w)
+        dw = o.linear_wgrad(dlogits, z)
+        sink = P.grad_out(ctx.vparam)
+        dv, dg = o.weightnorm_bwd(dw, v, g, winv, ctx.need_dg, dv_out=sink)
+        if sink is not None:
+            dv = dv.detach()
+        dh = o.l2norm_bwd(dz, z, inv)
+        dWl, dbl = _wgrad(dh, hlast, ctx.wparams[L - 1], want_bias=True)
+        dh = o.linear_dgrad(dh, WL)
+        grads = [None] * (4 * (L - 1))
+        for i in range(L - 2, -1, -1):
+            W, hin, d, coef, gam = per[i]
+            dd, dgam, dbet = DinoHeadBnFn._bn_gelu_bwd(o, dh, d, coef, gam, ctx.ns[i], ctx.group, ctx.eval_bn)
+            dW, db = _wgrad(dd, hin, ctx.wparams[i], want_bias=True)
+            grads[4 * i:4 * i + 4] = [dW, db, dgam, dbet]
+            dh = o.linear_dgrad(dd, W, out_f32=(i == 0))
+        return (dh, None, None) + tuple(grads) + (dWl, dbl, dv, dg)
+
+
+def dino_head_bn_n(x, bn_states, hidden, last, v, g, stats=None):
+    """hidden: [(W, b, bn.weight, bn.bias), ...]; last: (W, b) of the Linear into the bottleneck -> (logits, row_max, row_lse)"""
+    flat = [p for h in hidden for p in h]
+    return DinoHeadBnNFn.apply(x, list(bn_states), stats, *flat, *last, v, g)
+
+
 def dino_head_bn(x, st1, st2, prm, stats=None):
     """prm = (W1, b1, bn1.weight, bn1.bias, W2, b2, bn2.weight, bn2.bias, W3, b3, weight_v, weight_g) -> (logits, row_max, row_lse)"""
     return DinoHeadBnFn.apply(x, st1, st2, stats, *prm)

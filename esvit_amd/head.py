@@ -24,18 +24,19 @@ class DINOHead(nn.Module):
         super().__init__()
         nlayers = max(nlayers, 1)
         self.nlayers = nlayers
-        if nlayers != 3 and use_bn:
-            raise NotImplementedError("DINOHead with BatchNorm is built for the reference default nlayers = 3")
         self.use_bn = bool(use_bn)
         self.sync_bn_group = None  # process group of the batch statistics (None = default group; False = this rank only)
         # (inv_temp, centre | None, token) set by the loss for one step (loss.arm_logit_stats): the last-layer GEMM then also emits
         # the softmax row statistics the loss needs, handed over as the attribute `esvit_row_stats` of the returned logits
         self.logit_stats = None
-        if use_bn:  # --use_bn_in_head (vision_transformer.py:391-402): mlp.{0,3,6} Linear, mlp.{1,4} BatchNorm1d
-            self.mlp = nn.Sequential(nn.Linear(in_dim, hidden_dim), nn.BatchNorm1d(hidden_dim), nn.GELU(), nn.Linear(hidden_dim, hidden_dim),
-                                     nn.BatchNorm1d(hidden_dim), nn.GELU(), nn.Linear(hidden_dim, bottleneck_dim))
-        elif nlayers == 1:  # vision_transformer.py:388-389
+        if nlayers == 1:  # vision_transformer.py:388-389 (no BatchNorm either way)
             self.mlp = nn.Linear(in_dim, bottleneck_dim)
+        elif use_bn:  # --use_bn_in_head (vision_transformer.py:391-402): Linear, BatchNorm1d, GELU per hidden layer (nlayers = 3: mlp.{0,3,6}, mlp.{1,4})
+            layers = [nn.Linear(in_dim, hidden_dim), nn.BatchNorm1d(hidden_dim), nn.GELU()]
+            for _ in range(nlayers - 2):
+                layers += [nn.Linear(hidden_dim, hidden_dim), nn.BatchNorm1d(hidden_dim), nn.GELU()]
+            layers.append(nn.Linear(hidden_dim, bottleneck_dim))
+            self.mlp = nn.Sequential(*layers)
         else:               # Linear + GELU (nlayers - 1 times), then the Linear into the bottleneck (vision_transformer.py:391-402)
             layers = [nn.Linear(in_dim, hidden_dim), nn.GELU()]
             for _ in range(nlayers - 2):
@@ -63,7 +64,13 @@ class DINOHead(nn.Module):
     def forward(self, x):
         lead = x.shape[:-1]
         x2 = x.reshape(-1, x.shape[-1])
-        if self.use_bn:
+        if self.use_bn and self.nlayers not in (1, 3):
+            mods = list(self.mlp)
+            hidden = [(mods[i].weight, mods[i].bias, mods[i + 1].weight, mods[i + 1].bias) for i in range(0, len(mods) - 1, 3)]
+            return self._finish(Fn.dino_head_bn_n(x2, [self._bn_state(mods[i + 1]) for i in range(0, len(mods) - 1, 3)], hidden,
+                                                  (mods[-1].weight, mods[-1].bias), self.last_layer.weight_v, self.last_layer.weight_g,
+                                                  self._stats_request()), lead)
+        if self.use_bn and self.nlayers == 3:
             m = self.mlp
             prm = [m[0].weight, m[0].bias, m[1].weight, m[1].bias, m[3].weight, m[3].bias, m[4].weight, m[4].bias, m[6].weight, m[6].bias,
                    self.last_layer.weight_v, self.last_layer.weight_g]

@@ -647,6 +647,27 @@ def gen_head_nlayers(ns):
     print("head_nlayers.pt:", {n: len(v["grads"]) for n, v in out.items()})
 
 
+def gen_head_bn_nlayers(ns):
+    """the reference's DINOHead(use_bn=True) with nlayers = 1, 2, 4 (vision_transformer.py:388-402) in train mode: logits, input and
+    parameter gradients of sum(logits * probe), the BatchNorm buffers after the pass"""
+    c = GU.HEAD_NLAYERS
+    out = {}
+    x, probe = GU.head_nlayers_inputs()
+    for n in GU.HEAD_BN_NLAYERS:
+        head = ns.DINOHead(c["in_dim"], c["out_dim"], use_bn=True, nlayers=n, hidden_dim=c["hidden_dim"], bottleneck_dim=c["bottleneck_dim"],
+                           norm_last_layer=False)
+        GU.fill_bn_head_n(head.state_dict(), 80 + n)
+        head.train()
+        xr = x.clone().requires_grad_(True)
+        y = head(xr)
+        (y * probe).sum().backward()
+        out[n] = {"keys": [(k, tuple(v.shape)) for k, v in head.state_dict().items()], "logits": y.detach().clone(), "dx": xr.grad.clone(),
+                  "grads": {k: p.grad.clone() for k, p in head.named_parameters()},
+                  "buffers": {k: v.detach().clone() for k, v in head.state_dict().items() if "running_" in k or "num_batches" in k}}
+    torch.save(out, os.path.join(OUT, "head_bn_nlayers.pt"))
+    print("head_bn_nlayers.pt:", {n: len(v["grads"]) for n, v in out.items()})
+
+
 def gen_ref_checkpoint(ns):
     """a training checkpoint as main_esvit.py writes it (utils.save_on_master: DistributedDataParallel student, plain teacher, loss
     state) and the eval_knn.py path over it -- build_model(is_teacher=True) with NUM_CLASSES 0, utils.load_pretrained_weights,
@@ -752,6 +773,8 @@ def main():
         gen_linear_probe(ns)
     if not only or "head_nlayers" in only:
         gen_head_nlayers(ns)
+    if not only or "head_bn_nlayers" in only:
+        gen_head_bn_nlayers(ns)
     if not only or "patch_norm" in only:
         gen_patch_norm(ns)
     if not only or "mixup_smoothing" in only:

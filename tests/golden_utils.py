@@ -264,6 +264,20 @@ def linear_probe_init(clf, seed=5):
 HEAD_NLAYERS = dict(in_dim=48, out_dim=512, hidden_dim=64, bottleneck_dim=32, rows=24, cases=(1, 2, 4))
 
 
+HEAD_BN_NLAYERS = (1, 2, 4)  # DINOHead(use_bn=True) beside the default nlayers = 3 (tests/golden/head_bn_nlayers.pt)
+
+
+def fill_bn_head_n(sd, seed):
+    """fill_state_dict + sane BatchNorm entries for any depth (BatchNorm1d weights are the 1-d `mlp.N.weight` tensors)"""
+    fill_state_dict(sd, seed)
+    for name, t in sd.items():
+        if name.endswith("running_var"):
+            t.copy_(t.abs() * 4 + 0.5)
+        elif name.startswith("mlp.") and name.endswith("weight") and t.dim() == 1:
+            t.copy_(1.0 + 2.0 * t)
+    return sd
+
+
 def head_nlayers_inputs():
     g = torch.Generator().manual_seed(515)
     c = HEAD_NLAYERS

@@ -569,6 +569,60 @@ def _check_head_nlayers(dev, tol):
             assert rel(p.grad, g[n]["grads"][k]) < 3 * tol, (n, k, rel(p.grad, g[n]["grads"][k]))
 
 
+def _check_head_bn_nlayers(dev, tol, zero_floor=1e-2):
+    """DINOHead(use_bn=True) with 1, 2 and 4 layers (functional.DinoHeadBnNFn) vs the reference's own module in train mode"""
+    import esvit_amd
+    g = torch.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "head_bn_nlayers.pt"), weights_only=False)
+    c = GU.HEAD_NLAYERS
+    x, probe = GU.head_nlayers_inputs()
+    for n in GU.HEAD_BN_NLAYERS:
+        head = esvit_amd.DINOHead(c["in_dim"], c["out_dim"], use_bn=True, nlayers=n, hidden_dim=c["hidden_dim"], bottleneck_dim=c["bottleneck_dim"],
+                                  norm_last_layer=False)
+        assert [(k, tuple(v.shape)) for k, v in head.state_dict().items()] == g[n]["keys"], n
+        GU.fill_bn_head_n(head.state_dict(), 80 + n)
+        head = head.to(dev).train()
+        xr = x.clone().to(dev).requires_grad_(True)
+        y = head(xr)
+        (y.float() * probe.to(dev)).sum().backward()
+        rel = lambda a, b: ((a.float().cpu() - b).abs().max() / (b.abs().max() + 1e-12)).item()
+        assert rel(y.detach(), g[n]["logits"]) < tol, (n, rel(y.detach(), g[n]["logits"]))
+        assert rel(xr.grad, g[n]["dx"]) < 3 * tol, (n, rel(xr.grad, g[n]["dx"]))
+        gmax = max(v.abs().max().item() for v in g[n]["grads"].values())
+        for k, p in head.named_parameters():
+            # (the bias of a Linear in front of a BatchNorm has a mathematically zero gradient: rounding noise on both sides, so the
+            # error is measured against the largest gradient of the head)
+            err = (p.grad.float().cpu() - g[n]["grads"][k]).abs().max().item()
+            assert err < 3 * tol * max(g[n]["grads"][k].abs().max().item(), zero_floor * gmax), (n, k, err)
+        sd = head.state_dict()
+        for k, want in g[n]["buffers"].items():
+            assert torch.allclose(sd[k].float().cpu(), want.float(), rtol=max(tol, 1e-4), atol=max(tol, 1e-4)), (n, k)
+
+
+def test_head_bn_nlayers_host_logic_cpu(monkeypatch, lib_built):
+    import esvit_amd
+    import esvit_amd.functional as Fn
+    import esvit_amd.params as P
+    esvit_amd.set_precision("fp32")
+    for mod in (Fn, P):
+        monkeypatch.setattr(mod, "ops", ops_ref)
+    P.clear()
+    _check_head_bn_nlayers(torch.device("cpu"), 2e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_head_bn_nlayers_gpu(prec, lib_built):
+    import esvit_amd
+    from esvit_amd import params as P
+    esvit_amd.set_precision(prec)
+    P.clear()
+    try:
+        # (bf16: the noise of the zero gradients is a sum of rounded rows, a percent of the head's largest gradient)
+        _check_head_bn_nlayers(torch.device("cuda:0"), 2e-5 if prec == "fp32" else 2.5e-2, zero_floor=1e-2 if prec == "fp32" else 1.0)
+    finally:
+        esvit_amd.set_precision("bf16")
+
+
 def test_head_nlayers_host_logic_cpu(monkeypatch, lib_built):
     """DINOHead with 1, 2 and 4 Linear layers (functional.DinoHeadNFn) vs the reference's own module (tests/golden/head_nlayers.pt)"""
     import esvit_amd
