@@ -97,6 +97,8 @@ def main():
     ap.add_argument("--probe", action="store_true")
     ap.add_argument("--out", default=None)
     ap.add_argument("--only", default=None, help="substring filter on the shape name")
+    ap.add_argument("--probe-variants", default="6,1,5,2,3,4", help="probe_gemm variants to time (the first one is the reference result)")
+    ap.add_argument("--probe-cases", default=None, help="comma-separated indices into the probe case list")
     args = ap.parse_args()
     fh = open(args.out, "w") if args.out else None
 
@@ -137,7 +139,11 @@ def main():
         lib = C.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "probe", "libgemm_probe.so"))
         lib.probe_gemm.restype = C.c_int
         cases = [("nt", 8192, 8192, 4096), ("nt", 21760, 768, 3072), ("nt", 21760, 3072, 768), ("nt", 87040, 1536, 384), ("nt", 87040, 384, 1536),
-                 ("nn", 21760, 256, 65536), ("nn", 87040, 1536, 384), ("tn", 1536, 384, 87040), ("tn", 768, 3072, 21760), ("tn", 2048, 2048, 21760)]
+                 ("nn", 21760, 256, 65536), ("nn", 87040, 1536, 384), ("tn", 1536, 384, 87040), ("tn", 768, 3072, 21760), ("tn", 2048, 2048, 21760),
+                 ("nt", 21760, 65536, 256), ("nt", 21760, 2048, 2048), ("nn", 21760, 768, 3072)]
+        if args.probe_cases:
+            cases = [cases[int(i)] for i in args.probe_cases.split(",")]
+        variants = [int(v) for v in args.probe_variants.split(",")]
         for lay, M, N, K in cases:
             aks, bks = int(lay == "tn"), int(lay != "nt")
             A = rnd((K, M) if aks else (M, K))
@@ -150,7 +156,7 @@ def main():
             part = torch.empty((max(splitk, 1) * M * N,), dtype=torch.float32, device=dev) if splitk > 1 else None
             d = {"probe": lay, "M": M, "N": N, "K": K, "splitk": splitk}
             ref = None
-            for v in (6, 1, 5, 2, 3, 4):
+            for v in variants:
                 sk = splitk
                 if v == 6 and splitk:  # 128-wide tiles: four times the tiles
                     sk = max(1, 512 // (-(-M // 128) * -(-N // 128)))

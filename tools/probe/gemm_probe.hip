@@ -9,6 +9,148 @@ extern "C" int probe_set_timeline(long* buf) {
     return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_probe_timeline), &buf, sizeof(buf));
 }
 
+// ---- prototype (round 3, NOT in the product): the 256 x 256 LDS-DMA loop as a PERSISTENT workgroup.  One workgroup per CU walks
+// its list of tiles as ONE k-tile stream: the k-tile after the last one of a tile is the first one of the next tile, requested before
+// the last k-tile is computed, so it lands during the (LDS-free, direct) epilogue -- the prologue of every tile but the first is
+// hidden, and with one workgroup per CU nothing else could hide it.  Full tiles only (M % BM == N % BN == 0), no split-K, no
+// batch, no row map, no fused column sums: what the forward / data-gradient GEMMs of stages 2-3 and of the head need.
+template <bool AKS, bool BKS, int BM, int BN, int BKD, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8 ? 2 : 1)) void gemm_dma_persist_kernel(const esvit_gemm_desc p, const int group_m) {
+    constexpr int NT = 64 * WM * WN;
+    using TA = DmaTile<AKS, BM, BKD, NT>;
+    using TB = DmaTile<BKS, BN, BKD, NT>;
+    constexpr int WTM = BM / WM, WTN = BN / WN;
+    constexpr int FM = WTM / 16, FN = WTN / 16;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    constexpr int A_BYTES = TA::ELEMS * 2, B_BYTES = TB::ELEMS * 2;
+    char* sA = smem_raw;
+    char* sB = smem_raw + 2 * A_BYTES;
+    const int M = p.M, N = p.N, K = p.K;
+    const int tiles_m = M / BM, tiles_n = N / BN;
+    const int ntiles = tiles_m * tiles_n;
+    // tiles of this workgroup: every XCD owns a contiguous range of tile ids, its workgroups take them round robin
+    const int G8 = gridDim.x / 8;
+    const int xcd = blockIdx.x % 8, idx = blockIdx.x / 8;
+    const int q = ntiles / 8, r = ntiles % 8;
+    const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    const int cnt = q + (xcd < r ? 1 : 0);
+    const int my_tiles = idx < cnt ? (cnt - idx + G8 - 1) / G8 : 0;
+    if (my_tiles == 0) return;
+    const int nk = (K + BKD - 1) / BKD;
+    const bf16* A = reinterpret_cast<const bf16*>(p.A);
+    const bf16* B = reinterpret_cast<const bf16*>(p.B);
+    const long a_rows_total = AKS ? (long)K : (long)M;
+    const long b_rows_total = BKS ? (long)K : (long)N;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c = lane & 15, g = lane >> 4;
+    const int wm = wave / WN, wn = wave % WN;
+    int voffA[TA::INSTR_PER_WAVE], voffB[TB::INSTR_PER_WAVE];
+    TA::wave_offsets(p.lda, wave, lane, voffA);
+    TB::wave_offsets(p.ldb, wave, lane, voffB);
+
+    auto tile_origin = [&](int it, int& m0, int& n0) {
+        int tm, tn;
+        tile_coords(start + idx + it * G8, tiles_m, tiles_n, group_m, tm, tn);
+        m0 = tm * BM;
+        n0 = tn * BN;
+    };
+    // the tile being LOADED runs ahead of the tile being COMPUTED
+    int l_it = 0, l_kt = 0, lm0, ln0;
+    tile_origin(0, lm0, ln0);
+    __amdgpu_buffer_rsrc_t ra, rb;
+    auto point_at = [&](int m0, int n0) {
+        const bf16* a_base = AKS ? A + m0 : A + (long)m0 * p.lda;
+        const bf16* b_base = BKS ? B + n0 : B + (long)n0 * p.ldb;
+        ra = make_rsrc(a_base, ((AKS ? a_rows_total : a_rows_total - m0) * p.lda - (AKS ? m0 : 0)) * 2);
+        rb = make_rsrc(b_base, ((BKS ? b_rows_total : b_rows_total - n0) * p.ldb - (BKS ? n0 : 0)) * 2);
+    };
+    point_at(lm0, ln0);
+    auto issue_next = [&](int slot) {
+        const int k0 = l_kt * BKD;
+        if (k0 + BKD <= K) {
+            TA::issue_fast(ra, sA + slot * A_BYTES, p.lda, k0, wave, voffA);
+            TB::issue_fast(rb, sB + slot * B_BYTES, p.ldb, k0, wave, voffB);
+        } else {
+            TA::issue(ra, sA + slot * A_BYTES, p.lda, M - lm0, k0, K, wave, lane);
+            TB::issue(rb, sB + slot * B_BYTES, p.ldb, N - ln0, k0, K, wave, lane);
+        }
+        if (++l_kt == nk) {
+            l_kt = 0;
+            if (++l_it < my_tiles) {
+                tile_origin(l_it, lm0, ln0);
+                point_at(lm0, ln0);
+            }
+        }
+    };
+
+    f32x4 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int c_it = 0, c_kt = 0, cm0, cn0;
+    tile_origin(0, cm0, cn0);
+    const int nsteps = my_tiles * nk;
+    issue_next(0);
+    for (int s = 0; s < nsteps; ++s) {
+        wait_vmcnt<0>();                 // k-tile s landed (and the stores of the previous tile's epilogue are out)
+        __builtin_amdgcn_s_barrier();    // ... for every wave; every wave is done with the other buffer
+        asm volatile("" ::: "memory");
+        if (s + 1 < nsteps) issue_next((s + 1) & 1);
+        const bf16* a_lds = reinterpret_cast<const bf16*>(sA + (s & 1) * A_BYTES);
+        const bf16* b_lds = reinterpret_cast<const bf16*>(sB + (s & 1) * B_BYTES);
+#pragma unroll 1
+        for (int kk = 0; kk < BKD / 32; ++kk) {  // (not unrolled: one k-step's fragments live at a time -- 48 registers at 256 x 256)
+            Frag<bf16> af[FM], bfr[FN];
+#pragma unroll
+            for (int i = 0; i < FM; ++i) af[i] = TA::frag(a_lds, wm * WTM + i * 16, kk, c, g);
+#pragma unroll
+            for (int j = 0; j < FN; ++j) bfr[j] = TB::frag(b_lds, wn * WTN + j * 16, kk, c, g);
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j) mma(bfr[j], af[i], acc[i][j]);
+        }
+        if (++c_kt == nk) {
+            gemm_epilogue_bf16<BM, BN, WM, WN>(p, acc, smem_raw, cm0, cn0, 0);
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            c_kt = 0;
+            if (++c_it < my_tiles) tile_origin(c_it, cm0, cn0);
+        }
+    }
+}
+
+template <bool AKS, bool BKS, int BM, int BN, int BKD, int WM, int WN>
+int launch_gemm_dma_persist(const esvit_gemm_desc& d, hipStream_t stream) {
+    constexpr int NT = 64 * WM * WN;
+    using TA = DmaTile<AKS, BM, BKD, NT>;
+    using TB = DmaTile<BKS, BN, BKD, NT>;
+    if (d.splitk > 1 || d.batch > 1 || d.rowmap || d.colsum || d.rowstat || d.M % BM || d.N % BN) return ESVIT_ERR_UNSUPPORTED;
+    const size_t lds = (size_t)2 * (TA::ELEMS + TB::ELEMS) * 2;
+    auto kern = gemm_dma_persist_kernel<AKS, BKS, BM, BN, BKD, WM, WN>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    const int tm_ = d.M / BM, tn_ = d.N / BN;
+    const int tiles = tm_ * tn_;
+    const int per_cu = lds <= 80 * 1024 ? 2 : 1;
+    int grid = 256 * per_cu;
+    if (grid > tiles) grid = tiles;
+    grid = grid / 8 * 8;
+    if (grid < 8) return ESVIT_ERR_UNSUPPORTED;
+    int group_m = 1;
+    if (tn_ > 64) group_m = 2;
+    else if (tn_ >= 12) group_m = 16;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds, stream, d, group_m);
+    return hipGetLastError() == hipSuccess ? ESVIT_OK : -100;
+}
+
 extern "C" int probe_gemm(int variant, const esvit_gemm_desc* dp, void* stream_) {
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     esvit_gemm_desc d = *dp;
@@ -48,6 +190,18 @@ extern "C" int probe_gemm(int variant, const esvit_gemm_desc* dp, void* stream_)
         if (tn) return launch_gemm_dma<true, true, 128, 128, 64, 2, 2, 2>(d, stream);
         break;
 #endif
+    case 8:  // prototype: persistent 256 x 256 (4 x 2 waves of 64 x 128), next tile's first k-tile in flight during the epilogue
+        if (nt) return launch_gemm_dma_persist<false, false, 256, 256, 64, 4, 2>(d, stream);
+        if (nn) return launch_gemm_dma_persist<false, true, 256, 256, 64, 4, 2>(d, stream);
+        break;
+    case 9:  // prototype: persistent 256 x 128 (4 x 2 waves of 64 x 64): 96 KiB of buffers
+        if (nt) return launch_gemm_dma_persist<false, false, 256, 128, 64, 4, 2>(d, stream);
+        if (nn) return launch_gemm_dma_persist<false, true, 256, 128, 64, 4, 2>(d, stream);
+        break;
+    case 10:  // prototype: persistent 256 x 256 as 2 x 2 waves of 128 x 128 -- one wave per SIMD, 512 registers per lane (accumulators in AGPRs)
+        if (nt) return launch_gemm_dma_persist<false, false, 256, 256, 64, 2, 2>(d, stream);
+        if (nn) return launch_gemm_dma_persist<false, true, 256, 256, 64, 2, 2>(d, stream);
+        break;
     case 7:  // the product's default: 128 x 128, early buffer release
         if (nt) return launch_gemm_dma<false, false, 128, 128, 64, 2, 2, 2, 2, true>(d, stream);
         if (nn) return launch_gemm_dma<false, true, 128, 128, 64, 2, 2, 2, 2, true>(d, stream);
