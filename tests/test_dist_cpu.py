@@ -318,6 +318,64 @@ def _syncbn_worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
+def _syncbn_stem_worker(rank, world, port, out):
+    """the residual stem's Conv 3x3 -> BatchNorm -> ReLU unit (functional.ConvBnReluFn, RES_STEM) and the N-layer BatchNorm head
+    (functional.DinoHeadBnNFn): statistics and backward reductions synchronised over two ranks == one process on the whole batch"""
+    _init(rank, world, port)
+    import esvit_amd.functional as Fn
+    import esvit_amd.params as P
+    from oracle import ops_ref
+    Fn.ops = ops_ref
+    P.ops = ops_ref
+    ops_ref.set_act_dtype(torch.float32)
+    g = torch.Generator().manual_seed(17)
+    B, Cin, E, H = 2, 8, 16, 6
+    x_all = torch.randn(world * B * H * H, Cin, generator=g)
+    gy_all = torch.randn(world * B * 3 * 3, E, generator=g)
+    prm = [0.2 * torch.randn(E, Cin, 3, 3, generator=g), 1 + 0.1 * torch.randn(E, generator=g), 0.1 * torch.randn(E, generator=g)]
+
+    def run(x, gy, group, nB):
+        ps = [p.clone().requires_grad_(True) for p in prm]
+        xx = x.clone().requires_grad_(True)
+        y = Fn.ConvBnReluFn.apply(xx, (False, nB, H, H, Cin, 3, 2, 1), {"group": group}, *ps)
+        y.backward(gy)
+        return y.detach(), xx.grad, [p.grad for p in ps]
+    rows_in, rows_out = B * H * H, B * 9
+    y, gx, gp = run(x_all[rank * rows_in:(rank + 1) * rows_in], gy_all[rank * rows_out:(rank + 1) * rows_out], None, B)
+    y1, gx1, gp1 = run(x_all, gy_all, False, world * B)
+    ok = torch.allclose(y, y1[rank * rows_out:(rank + 1) * rows_out], rtol=1e-4, atol=1e-5)
+    ok = ok and torch.allclose(gx, gx1[rank * rows_in:(rank + 1) * rows_in], rtol=1e-4, atol=1e-5)
+    for a, b in zip(gp, gp1):
+        tot = a.clone()
+        dist.all_reduce(tot)
+        ok = ok and torch.allclose(tot, b, rtol=2e-4, atol=1e-5)
+    # the BatchNorm head with four layers
+    import esvit_amd
+    rows, D = 6, 12
+    xh = torch.randn(world * rows, D, generator=g)
+    gh = torch.randn(world * rows, 32, generator=g)
+
+    def run_head(x, gy, group):
+        head = esvit_amd.DINOHead(D, 32, use_bn=True, nlayers=4, hidden_dim=16, bottleneck_dim=8, norm_last_layer=False)
+        from tests import golden_utils as GU
+        GU.fill_bn_head_n(head.state_dict(), 5)
+        head.sync_bn_group = group
+        head.train()
+        xx = x.clone().requires_grad_(True)
+        yy = head(xx)
+        yy.backward(gy)
+        return yy.detach(), xx.grad, [p.grad for p in head.parameters()]
+    y, gx, gp = run_head(xh[rank * rows:(rank + 1) * rows], gh[rank * rows:(rank + 1) * rows], None)
+    y1, gx1, gp1 = run_head(xh, gh, False)
+    ok = ok and torch.allclose(y, y1[rank * rows:(rank + 1) * rows], rtol=1e-4, atol=1e-5) and torch.allclose(gx, gx1[rank * rows:(rank + 1) * rows], rtol=1e-4, atol=1e-5)
+    for a, b in zip(gp, gp1):
+        tot = a.clone()
+        dist.all_reduce(tot)
+        ok = ok and torch.allclose(tot, b, rtol=2e-4, atol=2e-5)
+    out[rank] = bool(ok)
+    dist.destroy_process_group()
+
+
 def _extract_worker(rank, world, port, out):
     """eval_knn.py:165-190 over two ranks: each rank runs its share of the batches, rank 0 ends up with every row at its
     dataset index"""
@@ -353,7 +411,7 @@ def _extract_worker(rank, world, port, out):
 
 @pytest.mark.parametrize("worker,port", [(_reducer_worker, 29611), (_center_worker, 29612), (_syncbn_worker, 29613), (_extract_worker, 29614),
                                          (_nano_step_worker, 29615), (_nano_step_pergroup_worker, 29616), (_nano_vit_step_worker, 29617), (_nano_vit_step_pergroup_worker, 29618),
-                                         (_nano_view_step_worker, 29619), (_nano_view_step_noragged_worker, 29620), (_reducer_bf16_worker, 29621)])
+                                         (_nano_view_step_worker, 29619), (_nano_view_step_noragged_worker, 29620), (_reducer_bf16_worker, 29621), (_syncbn_stem_worker, 29622)])
 def test_world2_gloo(worker, port, lib_built):
     world = 2
     out = mp.Manager().dict()
