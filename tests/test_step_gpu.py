@@ -53,8 +53,8 @@ def test_nano_step_matches_reference_golden(nano, prec, lib_built):
             probe_close(nm, t.float().cpu(), nano[nm], rtol=rt)
         assert (list(s_out[3]), list(t_out[3])) == nano["npatch"]
         # loss within 1e-3 of the reference (north_star); fp32 mode is far tighter
-        assert abs(loss.item() - nano["ddino_loss"]) < (1e-4 if fp else 1e-2), (loss.item(), nano["ddino_loss"])
-        tol_c = 1e-6 if fp else 1e-3
+        assert abs(loss.item() - nano["ddino_loss"]) < (1e-4 if fp else NANO_BF16["nano_step"][0]), (loss.item(), nano["ddino_loss"])
+        tol_c = 1e-6 if fp else 7.5e-4  # (bf16: 2.5e-4 observed)
         assert (loss_fn.center.cpu() - nano["center1"]).abs().max().item() < tol_c
         assert (loss_fn.center_grid.cpu() - nano["center_grid1"]).abs().max().item() < tol_c
         assert [n for n, p in student.named_parameters() if p.grad is None] == nano["no_grad"]
@@ -65,7 +65,11 @@ def test_nano_step_matches_reference_golden(nano, prec, lib_built):
                 worst = max(worst, abs(p.grad.norm().item() - ref) / (ref + 1e-12))
                 if fp:
                     probe_close("grad " + n, p.grad.cpu(), nano["grads"][n], rtol=2e-3)
-        assert worst < (2e-3 if fp else 0.15), worst
+        if not fp:
+            GU.record_parity(test="nano_step", prec="bf16", abs_err=abs(loss.item() - nano["ddino_loss"]), worst_grad_norm_rel=worst,
+                             center_err=max((loss_fn.center.cpu() - nano["center1"]).abs().max().item(),
+                                            (loss_fn.center_grid.cpu() - nano["center_grid1"]).abs().max().item()))
+        assert worst < (2e-3 if fp else NANO_BF16["nano_step"][1]), worst
         if fp:
             with torch.no_grad():
                 probe_close("last_attn", student.forward_selfattention(crops[0]).cpu(), nano["last_attn"], rtol=3e-4)
@@ -329,6 +333,12 @@ def test_swin_tiny_step_matches_reference_golden(prec, lib_built):
         _teardown()
 
 
+# bf16 bounds of the nano-width steps: (|loss - reference|, worst relative gradient-norm error), <= 3x the deltas observed on the MI355X
+# (profiles/r03_parity_observed.jsonl)
+# observed: nano_step 7.5e-4 / 0.81 %, nano_w14_step 6.7e-4 / 2.1 %, nano_cvt_step 8.0e-4 / 1.3 %
+NANO_BF16 = {"nano_step": (2.4e-3, 0.025), "nano_w14_step": (2e-3, 0.06), "nano_cvt_step": (2.4e-3, 0.04)}
+
+
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
 def test_nano_w14_step_matches_reference_golden(prec, lib_built):
     """14x14 windows through the blocked attention kernels (window_attn_big.hip) vs the reference golden"""
@@ -340,8 +350,12 @@ def test_nano_w14_step_matches_reference_golden(prec, lib_built):
         student, teacher = student.to(dev), teacher.to(dev)
         s_out, t_out, loss = run_nano14_step(student, teacher, L, dev=dev)
         fp = prec == "fp32"
-        check_nano14(g14, student, s_out, t_out, loss, rt=3e-4 if fp else 3e-2, loss_tol=1e-4 if fp else 1e-2,
-                     grad_tol=2e-3 if fp else 0.15, probes=fp)
+        if not fp:
+            GU.record_parity(test="nano_w14_step", prec="bf16", abs_err=abs(loss.item() - g14["ddino_loss"]),
+                             worst_grad_norm_rel=max(abs(p.grad.norm().item() - g14["grad_norms"][n]) / (g14["grad_norms"][n] + 1e-12)
+                                                     for n, p in student.named_parameters() if p.grad is not None))
+        check_nano14(g14, student, s_out, t_out, loss, rt=3e-4 if fp else 3e-2, loss_tol=1e-4 if fp else NANO_BF16["nano_w14_step"][0],
+                     grad_tol=2e-3 if fp else NANO_BF16["nano_w14_step"][1], probes=fp)
     finally:
         _teardown()
 
@@ -360,11 +374,13 @@ def test_nano_cvt_step_matches_reference_golden(prec, lib_built):
         if fp:
             check_nano_cvt(g, student, s_out, t_out, loss, rt=5e-4, loss_tol=1e-4, grad_tol=3e-3, buf_tol=1e-4)
         else:
-            assert abs(loss.item() - g["ddino_loss"]) < 2e-2, (loss.item(), g["ddino_loss"])
             got = {n: p.grad for n, p in student.named_parameters() if p.grad is not None}
+            GU.record_parity(test="nano_cvt_step", prec="bf16", abs_err=abs(loss.item() - g["ddino_loss"]),
+                             worst_grad_norm_rel=max(max(abs(got[n].norm().item() - ref) - 1e-6, 0.0) / (ref + 1e-12) for n, ref in g["grad_norms"].items()))
+            assert abs(loss.item() - g["ddino_loss"]) < NANO_BF16["nano_cvt_step"][0], (loss.item(), g["ddino_loss"])
             assert sorted(got) == sorted(g["grad_norms"])
             for n, ref in g["grad_norms"].items():
-                assert abs(got[n].norm().item() - ref) <= 0.2 * ref + 1e-6, (n, got[n].norm().item(), ref)
+                assert abs(got[n].norm().item() - ref) <= NANO_BF16["nano_cvt_step"][1] * ref + 1e-6, (n, got[n].norm().item(), ref)
     finally:
         _teardown()
 

@@ -2,7 +2,7 @@
 against the torch restatement (oracle/ops_ref.py), then the whole step -- forward, DDINOLoss, every gradient -- and the evaluation
 hooks against the golden produced by the REFERENCE's VisionTransformer (tests/golden/nano_vit_step.pt).
 Tolerances: fp32 mode 5e-4 relative on outputs / 3e-3 on gradient norms (tf32-free fp32 MFMA, different summation order);
-bf16 mode 2e-2 on the loss and 20 % on gradient norms (the bound the Swin / CvT step tests use)."""
+bf16 mode: bounds at three times the observed deltas (NANO_VIT_BF16)."""
 import math
 import os
 
@@ -10,6 +10,7 @@ import pytest
 import torch
 
 from oracle import ops_ref
+from tests import golden_utils as GU
 from tests.test_step_gpu import _setup, _teardown
 from tests.test_vit_cpu import check_nano_vit, check_nano_vit_hooks, nano_vit_pair, run_nano_vit_step
 
@@ -83,6 +84,9 @@ def test_vit_attention_matches_restatement(dt, shape, lib_built):
     _close("d qkv", d, d_ref, tol * 2)
 
 
+NANO_VIT_BF16 = (2.3e-3, 0.026)  # (|loss - reference|, relative gradient-norm error): <= 3x the observed 7.4e-4 / 0.85 % (profiles/r03_parity_observed.jsonl)
+
+
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
 def test_nano_vit_step_matches_reference_golden(prec, lib_built):
     import esvit_amd.loss as L
@@ -94,11 +98,13 @@ def test_nano_vit_step_matches_reference_golden(prec, lib_built):
         if prec == "fp32":
             check_nano_vit(g, student, s_out, t_out, loss, rt=5e-4, loss_tol=1e-4, grad_tol=3e-3)
         else:
-            assert abs(loss.item() - g["ddino_loss"]) < 2e-2, (loss.item(), g["ddino_loss"])
             got = {n: p.grad for n, p in student.named_parameters() if p.grad is not None}
+            GU.record_parity(test="nano_vit_step", prec="bf16", abs_err=abs(loss.item() - g["ddino_loss"]),
+                             worst_grad_norm_rel=max(max(abs(got[n].norm().item() - ref) - 1e-6, 0.0) / (ref + 1e-12) for n, ref in g["grad_norms"].items()))
+            assert abs(loss.item() - g["ddino_loss"]) < NANO_VIT_BF16[0], (loss.item(), g["ddino_loss"])
             assert sorted(got) == sorted(g["grad_norms"])
             for n, ref in g["grad_norms"].items():
-                assert abs(got[n].norm().item() - ref) <= 0.2 * ref + 1e-6, (n, got[n].norm().item(), ref)
+                assert abs(got[n].norm().item() - ref) <= NANO_VIT_BF16[1] * ref + 1e-6, (n, got[n].norm().item(), ref)
     finally:
         _teardown()
 
