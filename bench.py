@@ -17,6 +17,7 @@ oracle's restatement of them (kind "port").
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -443,6 +444,9 @@ def main():
                                       "AdamW + teacher EMA, drop_path %.2f" % ({"swin_tiny_w7": "Swin-T W=7"}.get(args.arch, args.arch), args.drop_path),
                           "global_batch": B * world, "per_gpu_batch": B, "parallelism": "dp%d" % world},
                "final_loss": loss_v,
+               # (sanity reference, not a parity claim: with random-init heads both cross-entropies start at ln(out_dim) = 11.09; parity
+               # of the loss against the reference's own module is asserted in tests/test_parity_gpu.py / test_step_gpu.py)
+               "ln_out_dim": math.log(65536.0),
                "step_mfma_frac": None}
         gf = GFLOP_PER_IMG_BY_ARCH.get(args.arch) or _analytic_gflops().get(args.arch)  # SURVEY.md 8(d), or counted here (ViT / ViL)
         if gf:
