@@ -6,7 +6,9 @@
 //   ESVIT_GEMM_DMA4W     the same loop with whole-width wave rows -- 128 x 192 as 2 x 2 waves of 64 x 96, 128 x 96 as 4 x 1
 //                        waves of 32 x 96 -- for the 96 * 2^s wide backbone: 192-byte instead of 96-byte output row pieces
 //                        and fewer operand bytes per FLOP; chosen per epilogue kind from profiles/r02_gemm_kernels_b128.jsonl;
-//   ESVIT_GEMM_DMA8      LDS-DMA, 256 x 256 tiles, 8 waves, one workgroup per CU: very long reductions only.
+//   ESVIT_GEMM_DMA8      LDS-DMA, 256 x 256 tiles, 8 waves, one workgroup per CU: very long reductions only;
+//   ESVIT_GEMM_P8        the 256 x 256 eight-phase loop (gemm_p8.hip): counted DMA waits that never drain the queue, staggered wave
+//                        halves, accumulators in AccVGPRs -- K % 64 == 0, no row map / row statistics / fused bias gradient.
 // The choice is a pure function of the descriptor (esvit_gemm_select).
 #include "gemm_kernels.h"
 
@@ -37,6 +39,15 @@ inline void dma4_tile(const esvit_gemm_desc& d, int& bm, int& bn) {
 inline double round_efficiency(long wgs, long slots) {
     const long rounds = (wgs + slots - 1) / slots;
     return (double)wgs / (double)(rounds * slots);
+}
+
+// what the eight-phase loop can run: whole 64-deep k-tiles (its DMA has no per-lane k predicate), 32-bit DMA offsets, and none of
+// the epilogue extras that live in the 128-row kernels
+bool p8_supports(int dtype, const esvit_gemm_desc& d) {
+    if (dtype != ESVIT_BF16 || d.K % 64 != 0 || d.rowmap || d.rowstat || d.colsum) return false;
+    if (d.a_kstrided && !d.b_kstrided) return false;
+    const long a_bytes = (d.a_kstrided ? (long)d.K : (long)d.M) * d.lda * 2, b_bytes = (d.b_kstrided ? (long)d.K : (long)d.N) * d.ldb * 2;
+    return a_bytes < 0xfff00000L && b_bytes < 0xfff00000L;
 }
 
 GemmChoice choose(int dtype, const esvit_gemm_desc& d) {
@@ -82,7 +93,8 @@ GemmChoice choose(int dtype, const esvit_gemm_desc& d) {
     }
     if (want == ESVIT_GEMM_DMA4W && !(d.N % 96 == 0)) want = ESVIT_GEMM_DMA4;
     c.kernel = want;
-    if (want == ESVIT_GEMM_DMA8) dma8_tile(d, c.bm, c.bn);
+    if (want == ESVIT_GEMM_P8) c.bm = c.bn = 256;
+    else if (want == ESVIT_GEMM_DMA8) dma8_tile(d, c.bm, c.bn);
     else if (want == ESVIT_GEMM_DMA4W) dma4w_tile(d, c.bm, c.bn);
     else dma4_tile(d, c.bm, c.bn);
     return c;
@@ -119,6 +131,7 @@ int run_regstage(const esvit_gemm_desc& d, int bn, hipStream_t stream) {
 template <bool AKS, bool BKS>
 int run_layout(int dtype, const esvit_gemm_desc& d, const GemmChoice& c, hipStream_t stream) {
     if (dtype == ESVIT_BF16) {
+        if (c.kernel == ESVIT_GEMM_P8) return esvit_gemm_p8_launch(d, stream);
         if constexpr (!AKS) {  // the 8-wave tile is not instantiated for the weight-gradient layout (measured slower there)
             if (c.kernel == ESVIT_GEMM_DMA8) return run_dma8<AKS, BKS>(d, stream);
         }
@@ -130,7 +143,9 @@ int run_layout(int dtype, const esvit_gemm_desc& d, const GemmChoice& c, hipStre
 
 // which forced main loops exist for which problem
 int check_selector(int dtype, const esvit_gemm_desc& d) {
-    ESVIT_CHECK_ARG(d.kernel >= ESVIT_GEMM_AUTO && d.kernel <= ESVIT_GEMM_DMA4W, "esvit_gemm: bad kernel selector %d", d.kernel);
+    ESVIT_CHECK_ARG(d.kernel >= ESVIT_GEMM_AUTO && d.kernel <= ESVIT_GEMM_P8, "esvit_gemm: bad kernel selector %d", d.kernel);
+    ESVIT_CHECK_ARG(!(d.kernel == ESVIT_GEMM_P8 && !p8_supports(dtype, d)),
+                    "esvit_gemm: the eight-phase loop needs bf16, K %% 64 == 0 and no row map / row statistics / fused bias gradient");
     if (dtype != ESVIT_BF16)
         ESVIT_CHECK_ARG(d.kernel == ESVIT_GEMM_AUTO || d.kernel == ESVIT_GEMM_REGSTAGE, "esvit_gemm: fp32 runs on the register-staged loop only");
     else
@@ -189,7 +204,7 @@ extern "C" int esvit_gemm_select(int dtype, const esvit_gemm_desc* dp, int* tile
     const GemmChoice c = choose(dtype, d);
     if (tile_m) *tile_m = c.bm;
     if (tile_n) *tile_n = c.bn;
-    if (resident_slots) *resident_slots = c.kernel == ESVIT_GEMM_DMA8 ? 256 : 512;  // workgroups the chip holds at once (256 CUs)
+    if (resident_slots) *resident_slots = (c.kernel == ESVIT_GEMM_DMA8 || c.kernel == ESVIT_GEMM_P8) ? 256 : 512;  // workgroups the chip holds at once (256 CUs)
     return c.kernel;
 }
 

@@ -26,6 +26,9 @@
 #include "mfma.h"
 #include "../../include/esvit_hip.h"
 
+// the 256 x 256 eight-phase bf16 main loop (gemm_p8.hip); esvit_gemm's dispatcher (gemm.hip) checks what it requires
+int esvit_gemm_p8_launch(const esvit_gemm_desc& d, hipStream_t stream);
+
 namespace {
 
 constexpr int BK = 32;          // k-tile of the register-staged loop
@@ -417,17 +420,16 @@ __device__ __forceinline__ void store_row_bf16(bf16* dst, const f32x4 (&v)[FN], 
         *reinterpret_cast<u32x2_t*>(dst + 16 * (FN - 1) + 4 * g) = u32x2_t{pack_bf16x2(v[FN - 1][0], v[FN - 1][1]), pack_bf16x2(v[FN - 1][2], v[FN - 1][3])};
 }
 
-template <int BM, int BN, int WM, int WN, int KIND, bool OUTF32, bool RS = false>
-__device__ __forceinline__ void epilogue_direct(const esvit_gemm_desc& p, f32x4 (&acc)[BM / (16 * WM)][BN / (16 * WN)], int m0, int n0, void* Cbase,
-                                                long ldc, long c_first, const float* bias) {
-    constexpr int WTM = BM / WM, WTN = BN / WN;
-    constexpr int FM = WTM / 16, FN = WTN / 16;
-    static_assert(!RS || (WTN == 64 && !OUTF32 && KIND == EK_PLAIN), "row statistics: 64-column wave tiles, plain bf16 epilogue");
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+// core: one FM x FN block of transposed 16 x 16 accumulator fragments whose first row / first column are wrow0 / wcol0
+template <int FM, int FN, int KIND, bool OUTF32, bool RS = false>
+__device__ __forceinline__ void epilogue_direct_at(const esvit_gemm_desc& p, f32x4 (&acc)[FM][FN], long wrow0, int wcol0, void* Cbase, long ldc,
+                                                   long c_first, const float* bias) {
+    static_assert(!RS || (FN == 4 && !OUTF32 && KIND == EK_PLAIN), "row statistics: 64-column wave tiles, plain bf16 epilogue");
+    const int lane = threadIdx.x & 63;
     const int c = lane & 15, g = lane >> 4;
-    const int wm = wave / WN, wn = wave % WN;
-    const long row = m0 + wm * WTM + c;      // this lane's row of row block 0
-    const int col = n0 + wn * WTN + 4 * g;  // this lane's first column of column block 0
+    const long row = wrow0 + c;      // this lane's row of row block 0
+    const int col = wcol0 + 4 * g;  // this lane's first column of column block 0
+    const int n0_stat = wcol0;
 
     f32x4 bias_h[FN];
     f32x4 cen_h[RS ? FN : 1];  // softmax statistics: centre * scale of the lane's columns
@@ -540,12 +542,21 @@ __device__ __forceinline__ void epilogue_direct(const esvit_gemm_desc& p, f32x4 
                 sum += __shfl_xor(sum, 16, 64);
                 sum += __shfl_xor(sum, 32, 64);
                 if (g == 0) {
-                    float* sp = p.rowstat + ((row + 16 * i) * (p.N >> 6) + ((n0 + wn * WTN) >> 6)) * 2;
+                    float* sp = p.rowstat + ((row + 16 * i) * (p.N >> 6) + (n0_stat >> 6)) * 2;
                     *reinterpret_cast<f32x2*>(sp) = f32x2{m, sum};
                 }
             }
         }
     });
+}
+
+template <int BM, int BN, int WM, int WN, int KIND, bool OUTF32, bool RS = false>
+__device__ __forceinline__ void epilogue_direct(const esvit_gemm_desc& p, f32x4 (&acc)[BM / (16 * WM)][BN / (16 * WN)], int m0, int n0, void* Cbase,
+                                                long ldc, long c_first, const float* bias) {
+    constexpr int WTM = BM / WM, WTN = BN / WN;
+    const int wave = threadIdx.x >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    epilogue_direct_at<WTM / 16, WTN / 16, KIND, OUTF32, RS>(p, acc, (long)m0 + wm * WTM, n0 + wn * WTN, Cbase, ldc, c_first, bias);
 }
 
 // LDS-DMA kernels: the direct epilogue when the tile and the operands allow it, else the general (staged) one

@@ -9,7 +9,7 @@ import ctypes as C
 import numpy as np
 import torch
 
-from ._lib import BF16, EPI_GELU, EPI_GELU_BWD, EPI_NONE, EPI_QGELU, EPI_QGELU_BWD, F32, GEMM_AUTO, GEMM_DMA8, GemmDesc, check, lib
+from ._lib import BF16, EPI_GELU, EPI_GELU_BWD, EPI_NONE, EPI_QGELU, EPI_QGELU_BWD, F32, GEMM_AUTO, GEMM_DMA8, GEMM_P8, GemmDesc, check, lib
 
 _ACT_DTYPE = torch.bfloat16
 
@@ -160,6 +160,12 @@ def gemm_algorithmic_bytes(dt, kw):
 FORCE_GEMM_KERNEL = GEMM_AUTO
 
 
+def p8_supported(kw):
+    """can the 256 x 256 eight-phase loop (ESVIT_GEMM_P8) run this problem?  Mirrors p8_supports() of csrc/gemm.hip."""
+    return (kw["K"] % 64 == 0 and kw.get("rowmap") is None and kw.get("rowstat") is None and kw.get("colsum") is None
+            and not (kw.get("a_kstrided", 0) and not kw.get("b_kstrided", 0)))
+
+
 def _gemm_desc(kw):
     d = GemmDesc()
     for k in ("A", "B", "C", "bias", "residual", "rowmap", "rowscale", "aux", "partial", "colsum", "colsum_partial", "rowstat", "rowstat_center"):
@@ -173,6 +179,8 @@ def _gemm_desc(kw):
     d.kernel = int(kw.get("kernel", FORCE_GEMM_KERNEL))
     if d.kernel == GEMM_DMA8 and d.a_kstrided and "kernel" not in kw:
         d.kernel = GEMM_AUTO  # FORCE_GEMM_KERNEL is a test / bench hook: the 8-wave tile has no weight-gradient instantiation
+    if d.kernel == GEMM_P8 and "kernel" not in kw and not p8_supported(kw):
+        d.kernel = GEMM_AUTO  # (same hook) the eight-phase loop runs whole 64-deep k-tiles and has no row map / statistics / bias gradient
     return d
 
 
@@ -291,7 +299,7 @@ def linear_wgrad(dy, x, *, out=None, accumulate=False, want_bias=False, db_out=N
     if want_bias:
         db = db_out if db_out is not None else torch.empty((Nout,), dtype=torch.float32, device=dy.device)
         assert db.shape == (Nout,) and db.dtype == torch.float32 and db.is_contiguous()
-    _, tm, tn, slots = gemm_select(dy.dtype, M=Nout, N=Kin, K=rows, a_kstrided=1, b_kstrided=1)
+    _, tm, tn, slots = gemm_select(dy.dtype, M=Nout, N=Kin, K=rows, a_kstrided=1, b_kstrided=1, colsum=db)
     tiles = (-(-Nout // tm)) * (-(-Kin // tn))
     splitk = _pick_splitk(rows, Nout, Kin, tiles, slots)
     if splitk > 1:

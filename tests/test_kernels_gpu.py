@@ -42,11 +42,12 @@ def _rand(shape, dev, seed, dt=torch.float32, scale=1.0):
     return (torch.randn(shape, generator=g) * scale).to(dev).to(dt)
 
 
-@pytest.fixture(params=[0, 3, 2, 4], ids=["auto", "dma8", "dma4", "dma4w"])
+@pytest.fixture(params=[0, 3, 2, 4, 5], ids=["auto", "dma8", "dma4", "dma4w", "p8"])
 def gemm_path(request, mods):
     """every bf16 GEMM main loop on every shape: the library's own choice, the 8-wave 256-row LDS-DMA loop (forward / dgrad
     layouts; it is not instantiated for the weight gradients, which then take the library's choice) and the 4-wave
-    128-row LDS-DMA loop in both wave layouts (2 x 2; whole-width wave rows for N % 96 == 0), forced through
+    128-row LDS-DMA loop in both wave layouts (2 x 2; whole-width wave rows for N % 96 == 0) and the 256 x 256 eight-phase loop
+    (where K is a whole number of 64-deep k-tiles and the call has no row map / fused bias gradient; else the library's choice), forced through
     esvit_gemm_desc.kernel (the library keeps no state); the exact-fp32 mode has one main loop (the register-staged one)"""
     ops, _ = mods
     ops.FORCE_GEMM_KERNEL = request.param
@@ -78,6 +79,46 @@ def test_gemm_nt(mods, gemm_path, dt, M, N, K):
     _close("nt quick preact", pre, prer, _tol(dt))
     res = _rand((M, N), dev, 4)
     _close("nt+res f32", ops.linear_fwd(x, w, b, residual=res, out_f32=True), ref.linear_fwd(x, w, b, residual=res, out_f32=True), _tol(dt, bf=5e-3))
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (512, 256, 128), (1024, 768, 192), (704, 520, 320), (2816, 1536, 384), (5000, 2304, 768),
+                                   (3000, 2048, 2048), (260, 65536 // 8, 256)])
+def test_gemm_p8(mods, M, N, K):
+    """the 256 x 256 eight-phase loop (ESVIT_GEMM_P8) on its own: one, two, odd and many k-tiles (the prologue requests seven half-tiles
+    ahead, the last two k-tiles request nothing), interior and ragged tiles, every epilogue kind, all three operand layouts, split-K"""
+    ops, ref = mods
+    dev = _dev()
+    dt = torch.bfloat16
+    ops.FORCE_GEMM_KERNEL = 5
+    try:
+        assert ops.gemm_select(dt, M=M, N=N, K=K)[0] == 5
+        x, w, b = _rand((M, K), dev, 1, dt), _rand((N, K), dev, 2, dt, 0.1), _rand((N,), dev, 3)
+        _close("p8 nt", ops.linear_fwd(x, w, b), ref.linear_fwd(x, w, b), _tol(dt))
+        _close("p8 nt no bias", ops.linear_fwd(x, w, None), ref.linear_fwd(x, w, None), _tol(dt))
+        y, pre = ops.linear_fwd(x, w, b, gelu=True, want_preact=True)
+        yr, prer = ref.linear_fwd(x, w, b, gelu=True, want_preact=True)
+        _close("p8 nt+gelu", y, yr, _tol(dt))
+        _close("p8 preact", pre, prer, _tol(dt))
+        res = _rand((M, N), dev, 4)
+        sc = torch.rand(M // 4 + 1, device=dev)
+        kw = dict(residual=res, rowscale=sc, rows_per_sample=4, out_f32=True)
+        _close("p8 nt+res f32", ops.linear_fwd(x, w, b, **kw), ref.linear_fwd(x, w, b, **kw), _tol(dt, bf=5e-3))
+        dy, wd = _rand((M, K), dev, 5, dt), _rand((K, N), dev, 6, dt, 0.1)
+        _close("p8 dgrad", ops.linear_dgrad(dy, wd), ref.linear_dgrad(dy, wd), _tol(dt))
+        _close("p8 dgrad f32", ops.linear_dgrad(dy, wd, out_f32=True), ref.linear_dgrad(dy, wd, out_f32=True), _tol(dt))
+        pre = _rand((M, N), dev, 7, dt)
+        _close("p8 dgrad+gelu'", ops.linear_dgrad(dy, wd, gelu_preact=pre), ref.linear_dgrad(dy, wd, gelu_preact=pre), _tol(dt))
+        rows = K * 8  # weight gradient [M', N'] = dy^T x over `rows` (split-K inside linear_wgrad)
+        Mw, Nw = min(M, 1024), min(N, 1024)
+        dyw, xw = _rand((rows, Mw), dev, 8, dt), _rand((rows, Nw), dev, 9, dt)
+        assert ops.gemm_select(dt, M=Mw, N=Nw, K=rows, a_kstrided=1, b_kstrided=1)[0] == 5
+        _close("p8 wgrad", ops.linear_wgrad(dyw, xw), ref.linear_wgrad(dyw, xw), _tol(dt, bf=2e-3))
+        acc = _rand((Mw, Nw), dev, 10)
+        acc_ref = acc.clone()
+        _close("p8 wgrad acc", ops.linear_wgrad(dyw, xw, out=acc, accumulate=True), ref.linear_wgrad(dyw, xw, out=acc_ref, accumulate=True),
+               _tol(dt, bf=2e-3))
+    finally:
+        ops.FORCE_GEMM_KERNEL = 0
 
 
 def test_gemm_grouped_tile_order(mods, gemm_path):

@@ -99,6 +99,7 @@ def main():
     ap.add_argument("--only", default=None, help="substring filter on the shape name")
     ap.add_argument("--probe-variants", default="6,1,5,2,3,4", help="probe_gemm variants to time (the first one is the reference result)")
     ap.add_argument("--probe-cases", default=None, help="comma-separated indices into the probe case list")
+    ap.add_argument("--plain", action="store_true", help="plain bf16 forward problems (random operands) through every forced main loop first")
     args = ap.parse_args()
     fh = open(args.out, "w") if args.out else None
 
@@ -109,7 +110,28 @@ def main():
             fh.write(line + "\n")
             fh.flush()
 
-    KERNELS = (0, 2, 4)
+    if args.plain:
+        for M, N, K in ((8192, 8192, 4096), (4096, 4096, 4096), (8192, 8192, 8192), (21760, 2048, 2048), (21760, 3072, 768), (21760, 768, 3072),
+                        (87040, 1536, 384), (87040, 384, 1536), (21760, 65536, 256)):
+            x, w = rnd((M, K)), rnd((N, K), 0.05)
+            d = {"plain": "nt", "M": M, "N": N, "K": K}
+            ref = None
+            for k in (2, 3, 5):
+                ops.FORCE_GEMM_KERNEL = k
+                try:
+                    fn = lambda: ops.linear_fwd(x, w, None)
+                    o = fn().float().flatten()[:: max(1, M * N // 65536)].clone()
+                    t = timeit(fn)
+                finally:
+                    ops.FORCE_GEMM_KERNEL = 0
+                ref = o if ref is None else ref
+                d["us_k%d" % k] = round(t * 1e6, 1)
+                d["tf_k%d" % k] = round(2.0 * M * N * K / t / 1e12, 1)
+                d["err_k%d" % k] = float((o - ref).abs().max().item() / (ref.abs().max().item() + 1e-12))
+            emit(d)
+            del x, w
+            torch.cuda.empty_cache()
+    KERNELS = (0, 2, 4, 5)
     tot = {k: 0.0 for k in KERNELS}
     tot["best"] = 0.0
     for name, kind, M, N, K, fl in step_shapes(args.batch):
