@@ -8,7 +8,7 @@
 //                        and fewer operand bytes per FLOP; chosen per epilogue kind from profiles/r02_gemm_kernels_b128.jsonl;
 //   ESVIT_GEMM_DMA8      LDS-DMA, 256 x 256 tiles, 8 waves, one workgroup per CU: very long reductions only;
 //   ESVIT_GEMM_P8        the 256 x 256 eight-phase loop (gemm_p8.hip): counted DMA waits that never drain the queue, staggered wave
-//                        halves, accumulators in AccVGPRs -- K % 64 == 0, no row map / row statistics / fused bias gradient.
+//                        halves, accumulators in AccVGPRs -- K % 64 == 0, no row map / row statistics.
 // The choice is a pure function of the descriptor (esvit_gemm_select).
 #include "gemm_kernels.h"
 
@@ -42,9 +42,9 @@ inline double round_efficiency(long wgs, long slots) {
 }
 
 // what the eight-phase loop can run: whole 64-deep k-tiles (its DMA has no per-lane k predicate), 32-bit DMA offsets, and none of
-// the epilogue extras that live in the 128-row kernels
+// the row map / row statistics extras that live in the 128-row kernels
 bool p8_supports(int dtype, const esvit_gemm_desc& d) {
-    if (dtype != ESVIT_BF16 || d.K % 64 != 0 || d.rowmap || d.rowstat || d.colsum) return false;
+    if (dtype != ESVIT_BF16 || d.K % 64 != 0 || d.rowmap || d.rowstat) return false;
     if (d.a_kstrided && !d.b_kstrided) return false;
     const long a_bytes = (d.a_kstrided ? (long)d.K : (long)d.M) * d.lda * 2, b_bytes = (d.b_kstrided ? (long)d.K : (long)d.N) * d.ldb * 2;
     return a_bytes < 0xfff00000L && b_bytes < 0xfff00000L;
@@ -145,7 +145,7 @@ int run_layout(int dtype, const esvit_gemm_desc& d, const GemmChoice& c, hipStre
 int check_selector(int dtype, const esvit_gemm_desc& d) {
     ESVIT_CHECK_ARG(d.kernel >= ESVIT_GEMM_AUTO && d.kernel <= ESVIT_GEMM_P8, "esvit_gemm: bad kernel selector %d", d.kernel);
     ESVIT_CHECK_ARG(!(d.kernel == ESVIT_GEMM_P8 && !p8_supports(dtype, d)),
-                    "esvit_gemm: the eight-phase loop needs bf16, K %% 64 == 0 and no row map / row statistics / fused bias gradient");
+                    "esvit_gemm: the eight-phase loop needs bf16, K %% 64 == 0 and no row map / row statistics");
     if (dtype != ESVIT_BF16)
         ESVIT_CHECK_ARG(d.kernel == ESVIT_GEMM_AUTO || d.kernel == ESVIT_GEMM_REGSTAGE, "esvit_gemm: fp32 runs on the register-staged loop only");
     else

@@ -162,7 +162,7 @@ FORCE_GEMM_KERNEL = GEMM_AUTO
 
 def p8_supported(kw):
     """can the 256 x 256 eight-phase loop (ESVIT_GEMM_P8) run this problem?  Mirrors p8_supports() of csrc/gemm.hip."""
-    return (kw["K"] % 64 == 0 and kw.get("rowmap") is None and kw.get("rowstat") is None and kw.get("colsum") is None
+    return (kw["K"] % 64 == 0 and kw.get("rowmap") is None and kw.get("rowstat") is None
             and not (kw.get("a_kstrided", 0) and not kw.get("b_kstrided", 0)))
 
 
@@ -180,7 +180,7 @@ def _gemm_desc(kw):
     if d.kernel == GEMM_DMA8 and d.a_kstrided and "kernel" not in kw:
         d.kernel = GEMM_AUTO  # FORCE_GEMM_KERNEL is a test / bench hook: the 8-wave tile has no weight-gradient instantiation
     if d.kernel == GEMM_P8 and "kernel" not in kw and not p8_supported(kw):
-        d.kernel = GEMM_AUTO  # (same hook) the eight-phase loop runs whole 64-deep k-tiles and has no row map / statistics / bias gradient
+        d.kernel = GEMM_AUTO  # (same hook) the eight-phase loop runs whole 64-deep k-tiles and has no row map / statistics
     return d
 
 

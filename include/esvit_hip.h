@@ -125,7 +125,7 @@ typedef struct {
 #define ESVIT_GEMM_DMA4 2     /* bf16, LDS-DMA, 128 x {64,96,128} tiles, 4 waves, two workgroups per CU */
 #define ESVIT_GEMM_DMA8 3     /* bf16, LDS-DMA, 256 x 256 tiles, 8 waves, one workgroup per CU: very long reductions */
 #define ESVIT_GEMM_DMA4W 4    /* bf16, LDS-DMA, 4 waves, 128 x 192 / 128 x 96 tiles with whole-width wave rows (N % 96 == 0) */
-#define ESVIT_GEMM_P8 5       /* bf16, LDS-DMA, 256 x 256 tiles, 8 waves, eight-phase schedule with counted DMA waits (K % 64 == 0; no rowmap / rowstat / colsum) */
+#define ESVIT_GEMM_P8 5       /* bf16, LDS-DMA, 256 x 256 tiles, 8 waves, eight-phase schedule with counted DMA waits (K % 64 == 0; no rowmap / rowstat) */
 
 /* C = alpha * op(A) op(B) (+ epilogue).  Replaces every nn.Linear / conv-as-GEMM on the
  * path: swin_transformer.py:31-37,127,150,418,531; vision_transformer.py:414-418;

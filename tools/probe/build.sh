@@ -14,3 +14,7 @@ if [ "$1" = "ablate" ]; then
     echo built "$here/libgemm_probe_$n.so"
   done
 fi
+# the eight-phase loop with per-item timestamps (tools/p8_timeline.py)
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-unused-result -Wno-pass-failed -DESVIT_P8_TIMELINE -I "$root/include" -I "$root/esvit_amd/csrc" \
+    -x hip "$root/esvit_amd/csrc/gemm_p8.hip" -o "$here/libp8_probe.so"
+echo built "$here/libp8_probe.so"
