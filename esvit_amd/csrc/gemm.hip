@@ -8,7 +8,7 @@
 //                        and fewer operand bytes per FLOP; chosen per epilogue kind from profiles/r02_gemm_kernels_b128.jsonl;
 //   ESVIT_GEMM_DMA8      LDS-DMA, 256 x 256 tiles, 8 waves, one workgroup per CU: very long reductions only;
 //   ESVIT_GEMM_P8        the 256 x 256 eight-phase loop (gemm_p8.hip): counted DMA waits that never drain the queue, staggered wave
-//                        halves, accumulators in AccVGPRs -- K % 64 == 0, no row map / row statistics.
+//                        halves, accumulators in AccVGPRs -- K % 64 == 0, no row map; row statistics on whole tiles.
 // The choice is a pure function of the descriptor (esvit_gemm_select).
 #include "gemm_kernels.h"
 
@@ -44,11 +44,14 @@ inline double round_efficiency(long wgs, long slots) {
 // what the eight-phase loop can run: whole 64-deep k-tiles (its DMA has no per-lane k predicate), 32-bit DMA offsets, and none of
 // the row map / row statistics extras that live in the 128-row kernels
 bool p8_supports(int dtype, const esvit_gemm_desc& d) {
-    if (dtype != ESVIT_BF16 || d.K % 64 != 0 || d.rowmap || d.rowstat) return false;
+    if (dtype != ESVIT_BF16 || d.K % 64 != 0 || d.rowmap) return false;
+    if (d.rowstat && (d.M % 256 != 0 || d.N % 256 != 0)) return false;  // row statistics: whole 256 x 256 tiles only (32-column blocks)
     if (d.a_kstrided && !d.b_kstrided) return false;
     const long a_bytes = (d.a_kstrided ? (long)d.K : (long)d.M) * d.lda * 2, b_bytes = (d.b_kstrided ? (long)d.K : (long)d.N) * d.ldb * 2;
     return a_bytes < 0xfff00000L && b_bytes < 0xfff00000L;
 }
+
+bool p8n_supports(int dtype, const esvit_gemm_desc& d) { return p8_supports(dtype, d) && esvit_gemm_p8n_supports(d); }
 
 GemmChoice choose(int dtype, const esvit_gemm_desc& d) {
     GemmChoice c{ESVIT_GEMM_REGSTAGE, 128, 128};
@@ -57,16 +60,33 @@ GemmChoice choose(int dtype, const esvit_gemm_desc& d) {
         return c;
     }
     int want = d.kernel;
-    if (d.rowstat) {  // the statistics epilogue lives in the 128 x 128 tile (2 x 2 waves of 64 x 64)
-        c.kernel = ESVIT_GEMM_DMA4;
-        c.bm = c.bn = 128;
+    if (d.rowstat) {  // the statistics epilogue: the 256 x 256 eight-phase loop (32-column blocks) where the problem is whole tiles of
+                      // it and wide enough to fill the chip, else the 128 x 128 tile (2 x 2 waves of 64 x 64, 64-column blocks)
+        const bool p8 = (want == ESVIT_GEMM_P8 || (want == ESVIT_GEMM_AUTO && (long)(d.M / 256) * (d.N / 256) >= 1024)) && p8_supports(dtype, d);
+        c.kernel = p8 ? ESVIT_GEMM_P8 : ESVIT_GEMM_DMA4;
+        c.bm = c.bn = p8 ? 256 : 128;
         return c;
     }
     if (want == ESVIT_GEMM_AUTO) {
         want = ESVIT_GEMM_DMA4;
         const int nz = d.splitk > 1 ? d.splitk : (d.batch > 1 ? d.batch : 1);
         const long t8 = (long)ceil_div(d.M, 256) * ceil_div(d.N, 256);
-        if (!d.a_kstrided && !d.rowmap && d.K >= 4096 && d.N >= 192 && t8 * nz >= 128) {
+        const bool gelu_bwd_ = d.epilogue == ESVIT_EPI_GELU_BWD || d.epilogue == ESVIT_EPI_QGELU_BWD;
+        if (p8_supports(dtype, d) && d.batch <= 1 && !d.a_kstrided && d.K >= 2048 && d.N % 256 == 0 && d.M >= 4096 && !gelu_bwd_ &&
+            (d.N >= 768 || d.splitk > 1)) {
+            // Long reductions over whole 256-column tiles: the eight-phase loop multiplies a 256 x 256 x 64 k-tile in ~1.9 us where the
+            // 128-row loops need ~2.3 us for the same work (profiles/r04_gemm_kernels_b128.jsonl: stage-3 / head data gradients and
+            // fc2 forward -14..-18 %, the split-K data gradient of the 65536-wide last layer 900 -> 769 us).
+            want = ESVIT_GEMM_P8;
+        } else if (p8_supports(dtype, d) && d.batch <= 1 && d.a_kstrided && d.M % 256 == 0 && d.N % 256 == 0 && (long)d.M * d.N >= 2000000L) {
+            // weight gradients with many whole 256 x 256 tiles (head, last layer, stage-3 MLP): -3..-10 %
+            want = ESVIT_GEMM_P8;
+        } else if (p8n_supports(dtype, d) && d.batch <= 1 && !d.a_kstrided && d.b_kstrided && d.epilogue == ESVIT_EPI_NONE && !d.out_f32 && !d.bias &&
+                   d.splitk <= 1 && d.N % 128 == 0 && d.N <= 512 && d.K >= 384 && d.M >= 16384) {
+            // plain data gradients onto 384-wide activations (stage 2 qkv / proj): 128-wide tiles with the stores riding on the next
+            // tile's k-loop, -6..-9 %
+            want = ESVIT_GEMM_P8N;
+        } else if (!d.a_kstrided && !d.rowmap && d.K >= 4096 && d.N >= 192 && t8 * nz >= 128) {
             // One 256 x 256 tile per CU has no second workgroup to hide its prologue / epilogue behind: measured
             // (profiles/r02_gemm_kernels_b128_first.jsonl) it wins only where the main loop is very long -- the dgrad of
             // the 65536-wide last layer (K = out_dim, split-K): 1266 -> 865 us.  Everything else, the weight gradients
@@ -94,6 +114,10 @@ GemmChoice choose(int dtype, const esvit_gemm_desc& d) {
     if (want == ESVIT_GEMM_DMA4W && !(d.N % 96 == 0)) want = ESVIT_GEMM_DMA4;
     c.kernel = want;
     if (want == ESVIT_GEMM_P8) c.bm = c.bn = 256;
+    else if (want == ESVIT_GEMM_P8N) {
+        c.bm = 256;
+        c.bn = 128;
+    }
     else if (want == ESVIT_GEMM_DMA8) dma8_tile(d, c.bm, c.bn);
     else if (want == ESVIT_GEMM_DMA4W) dma4w_tile(d, c.bm, c.bn);
     else dma4_tile(d, c.bm, c.bn);
@@ -132,6 +156,7 @@ template <bool AKS, bool BKS>
 int run_layout(int dtype, const esvit_gemm_desc& d, const GemmChoice& c, hipStream_t stream) {
     if (dtype == ESVIT_BF16) {
         if (c.kernel == ESVIT_GEMM_P8) return esvit_gemm_p8_launch(d, stream);
+        if (c.kernel == ESVIT_GEMM_P8N) return esvit_gemm_p8n_launch(d, stream);
         if constexpr (!AKS) {  // the 8-wave tile is not instantiated for the weight-gradient layout (measured slower there)
             if (c.kernel == ESVIT_GEMM_DMA8) return run_dma8<AKS, BKS>(d, stream);
         }
@@ -143,7 +168,9 @@ int run_layout(int dtype, const esvit_gemm_desc& d, const GemmChoice& c, hipStre
 
 // which forced main loops exist for which problem
 int check_selector(int dtype, const esvit_gemm_desc& d) {
-    ESVIT_CHECK_ARG(d.kernel >= ESVIT_GEMM_AUTO && d.kernel <= ESVIT_GEMM_P8, "esvit_gemm: bad kernel selector %d", d.kernel);
+    ESVIT_CHECK_ARG(d.kernel >= ESVIT_GEMM_AUTO && d.kernel <= ESVIT_GEMM_P8N, "esvit_gemm: bad kernel selector %d", d.kernel);
+    ESVIT_CHECK_ARG(!(d.kernel == ESVIT_GEMM_P8N && !p8n_supports(dtype, d)),
+                    "esvit_gemm: the 256 x 128 eight-phase loop needs what ESVIT_GEMM_P8 needs, N %% 32 == 0, 16-byte aligned outputs and one of its epilogue kinds");
     ESVIT_CHECK_ARG(!(d.kernel == ESVIT_GEMM_P8 && !p8_supports(dtype, d)),
                     "esvit_gemm: the eight-phase loop needs bf16, K %% 64 == 0 and no row map / row statistics");
     if (dtype != ESVIT_BF16)
@@ -185,7 +212,8 @@ int validate(int dtype, esvit_gemm_desc& d) {
         ESVIT_CHECK_ARG(d.M % 128 == 0 && d.N % 128 == 0 && d.ldc % 8 == 0 && ((uintptr_t)d.C % 16 == 0) &&
                             (!d.rowstat_center || (uintptr_t)d.rowstat_center % 16 == 0),
                         "esvit_gemm: row statistics need M and N in whole 128 x 128 tiles (M=%d N=%d)", d.M, d.N);
-        ESVIT_CHECK_ARG(d.kernel == ESVIT_GEMM_AUTO || d.kernel == ESVIT_GEMM_DMA4, "esvit_gemm: row statistics exist in the 128 x 128 tile of the default main loop");
+        ESVIT_CHECK_ARG(d.kernel == ESVIT_GEMM_AUTO || d.kernel == ESVIT_GEMM_DMA4 || d.kernel == ESVIT_GEMM_P8,
+                        "esvit_gemm: row statistics exist in the 128 x 128 tile of the default main loop and in the 256 x 256 eight-phase loop");
     }
     return check_selector(dtype, d);
 }
@@ -204,7 +232,7 @@ extern "C" int esvit_gemm_select(int dtype, const esvit_gemm_desc* dp, int* tile
     const GemmChoice c = choose(dtype, d);
     if (tile_m) *tile_m = c.bm;
     if (tile_n) *tile_n = c.bn;
-    if (resident_slots) *resident_slots = (c.kernel == ESVIT_GEMM_DMA8 || c.kernel == ESVIT_GEMM_P8) ? 256 : 512;  // workgroups the chip holds at once (256 CUs)
+    if (resident_slots) *resident_slots = (c.kernel == ESVIT_GEMM_DMA8 || c.kernel == ESVIT_GEMM_P8 || c.kernel == ESVIT_GEMM_P8N) ? 256 : 512;  // workgroups the chip holds at once (256 CUs)
     return c.kernel;
 }
 

@@ -28,6 +28,9 @@
 
 // the 256 x 256 eight-phase bf16 main loop (gemm_p8.hip); esvit_gemm's dispatcher (gemm.hip) checks what it requires
 int esvit_gemm_p8_launch(const esvit_gemm_desc& d, hipStream_t stream);
+// the 256 x 128 variant with two accumulator sets and the epilogue spread over the next tile's main loop (gemm_p8n.hip)
+bool esvit_gemm_p8n_supports(const esvit_gemm_desc& d);
+int esvit_gemm_p8n_launch(const esvit_gemm_desc& d, hipStream_t stream);
 
 namespace {
 
@@ -410,14 +413,24 @@ __device__ __forceinline__ u32x4_t pair_rows(const f32x4& x, const f32x4& y) {
     return u32x4_t{s0[0], s1[0], s0[1], s1[1]};
 }
 
+// Activation-sized GEMM outputs are written once and read by a LATER kernel, long after the L2 has turned over: they are stored
+// non-temporally, so the write stream does not evict the operand panels the running GEMM re-reads from the L2 (measured on the
+// 256 x 128 loop, profiles/r04_p8n_store_policy.txt: 187 -> 163 us on 87040 x 1536 x 384).  Split-K partials are NOT: their reduce
+// kernel follows at once.
+template <typename V>
+__device__ __forceinline__ void store_stream(V* dst, const V& v) {
+    __builtin_nontemporal_store(v, dst);
+}
+
 // bf16 row block: v[j] = this lane's four columns of block j -> dst (the lane's row, at the wave tile's first column)
 template <int FN>
 __device__ __forceinline__ void store_row_bf16(bf16* dst, const f32x4 (&v)[FN], int g) {
     const int pc = 16 * (g & 1) + 4 * (g & ~1);  // column of the lane's 8-vector inside a block pair
 #pragma unroll
-    for (int j = 0; j + 1 < FN; j += 2) *reinterpret_cast<u32x4_t*>(dst + 16 * j + pc) = pair_rows(v[j], v[j + 1]);
+    for (int j = 0; j + 1 < FN; j += 2) store_stream(reinterpret_cast<u32x4_t*>(dst + 16 * j + pc), pair_rows(v[j], v[j + 1]));
     if constexpr (FN & 1)
-        *reinterpret_cast<u32x2_t*>(dst + 16 * (FN - 1) + 4 * g) = u32x2_t{pack_bf16x2(v[FN - 1][0], v[FN - 1][1]), pack_bf16x2(v[FN - 1][2], v[FN - 1][3])};
+        store_stream(reinterpret_cast<u32x2_t*>(dst + 16 * (FN - 1) + 4 * g),
+                     u32x2_t{pack_bf16x2(v[FN - 1][0], v[FN - 1][1]), pack_bf16x2(v[FN - 1][2], v[FN - 1][3])});
 }
 
 // core: one FM x FN block of transposed 16 x 16 accumulator fragments whose first row / first column are wrow0 / wcol0
@@ -517,7 +530,10 @@ __device__ __forceinline__ void epilogue_direct_at(const esvit_gemm_desc& p, f32
         if constexpr (OUTF32) {
             float* cp = reinterpret_cast<float*>(Cbase) + c_off + 4 * g + i * c_step;
 #pragma unroll
-            for (int j = 0; j < FN; ++j) *reinterpret_cast<f32x4*>(cp + 16 * j) = v[j];
+            for (int j = 0; j < FN; ++j) {
+                if (p.splitk > 1) *reinterpret_cast<f32x4*>(cp + 16 * j) = v[j];
+                else store_stream(reinterpret_cast<f32x4*>(cp + 16 * j), v[j]);
+            }
         } else {
             store_row_bf16<FN>(reinterpret_cast<bf16*>(Cbase) + c_off + i * c_step, v, g);
             if constexpr (RS) {

@@ -108,7 +108,8 @@ enum { P8_BF16 = 0,      // C (bf16) = alpha acc + bias
        P8_F32 = 1,       // C (fp32) = alpha acc + bias; also the split-K partial slab
        P8_GELU = 2,      // aux (bf16) = v = alpha acc + bias; C (bf16) = gelu(v)   (erf-GELU or QuickGELU)
        P8_RES = 3,       // C (fp32) = (alpha acc + bias) * rowscale[row / rows_per_sample] + residual
-       P8_GELU_BWD = 4   // C (bf16) = alpha acc * gelu'(aux)
+       P8_GELU_BWD = 4,  // C (bf16) = alpha acc * gelu'(aux)
+       P8_BF16_RS = 5    // P8_BF16 without bias + the softmax statistics of the stored row pieces (esvit_gemm_desc::rowstat, 32-column blocks)
 };
 
 // Interior quadrant (64 rows x 32 columns per wave), straight from the transposed accumulators: lane (c, g) holds, for row block i
@@ -123,7 +124,7 @@ __device__ __forceinline__ void p8_epilogue_fast(const esvit_gemm_desc& p, f32x4
     const int col = wcol0 + 4 * g;
     const float alpha = p.alpha;
     f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = {0.f, 0.f, 0.f, 0.f};
-    if constexpr (EPI != P8_GELU_BWD) {
+    if constexpr (EPI != P8_GELU_BWD && EPI != P8_BF16_RS) {
         if (p.bias && p.splitk <= 1) {
             b0 = *reinterpret_cast<const f32x4*>(p.bias + col);
             b1 = *reinterpret_cast<const f32x4*>(p.bias + col + 16);
@@ -135,6 +136,40 @@ __device__ __forceinline__ void p8_epilogue_fast(const esvit_gemm_desc& p, f32x4
         for (int i = 0; i < 4; ++i) {
             const f32x4 v[2] = {acc[i][0] * alpha + b0, acc[i][1] * alpha + b1};
             store_row_bf16<2>(cp + 16 * i * p.ldc, v, g);
+        }
+    } else if constexpr (EPI == P8_BF16_RS) {
+        // logits + (max, sum 2^(z - max)) of z = (stored logit - centre) * scale over this wave's 32 columns of every row: 8 values
+        // per lane, then the four lane groups that share the row (esvit_rowstat_combine folds the N / 32 blocks of a row)
+        bf16* cp = reinterpret_cast<bf16*>(p.C) + (long)z * p.strideC + row * p.ldc + wcol0;
+        f32x4 cen[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+        if (p.rowstat_center) {
+            cen[0] = *reinterpret_cast<const f32x4*>(p.rowstat_center + col) * p.rowstat_scale;
+            cen[1] = *reinterpret_cast<const f32x4*>(p.rowstat_center + col + 16) * p.rowstat_scale;
+        }
+        const long nb = p.N >> 5;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const f32x4 v[2] = {acc[i][0] * alpha, acc[i][1] * alpha};
+            store_row_bf16<2>(cp + 16 * i * p.ldc, v, g);
+            float zz[2][4];
+            float m = -3.0e38f;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    zz[j][e] = fmaf((float)(bf16)v[j][e], p.rowstat_scale, -cen[j][e]);
+                    m = fmaxf(m, zz[j][e]);
+                }
+            m = fmaxf(m, __shfl_xor(m, 16, 64));
+            m = fmaxf(m, __shfl_xor(m, 32, 64));
+            float sum = 0.f;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) sum += __builtin_amdgcn_exp2f(zz[j][e] - m);
+            sum += __shfl_xor(sum, 16, 64);
+            sum += __shfl_xor(sum, 32, 64);
+            if (g == 0) *reinterpret_cast<f32x2*>(p.rowstat + ((row + 16 * i) * nb + (wcol0 >> 5)) * 2) = f32x2{m, sum};
         }
     } else if constexpr (EPI == P8_F32) {
         float* cp;
@@ -148,8 +183,13 @@ __device__ __forceinline__ void p8_epilogue_fast(const esvit_gemm_desc& p, f32x4
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            *reinterpret_cast<f32x4*>(cp + 16 * i * ld) = acc[i][0] * alpha + b0;
-            *reinterpret_cast<f32x4*>(cp + 16 * i * ld + 16) = acc[i][1] * alpha + b1;
+            if (p.splitk > 1) {
+                *reinterpret_cast<f32x4*>(cp + 16 * i * ld) = acc[i][0] * alpha + b0;
+                *reinterpret_cast<f32x4*>(cp + 16 * i * ld + 16) = acc[i][1] * alpha + b1;
+            } else {
+                store_stream(reinterpret_cast<f32x4*>(cp + 16 * i * ld), acc[i][0] * alpha + b0);
+                store_stream(reinterpret_cast<f32x4*>(cp + 16 * i * ld + 16), acc[i][1] * alpha + b1);
+            }
         }
     } else if constexpr (EPI == P8_GELU) {
         bf16* cp = reinterpret_cast<bf16*>(p.C) + (long)z * p.strideC + row * p.ldc + wcol0;
@@ -178,8 +218,8 @@ __device__ __forceinline__ void p8_epilogue_fast(const esvit_gemm_desc& p, f32x4
         float* cp = reinterpret_cast<float*>(p.C) + (long)z * p.strideC + row * p.ldc + col;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            *reinterpret_cast<f32x4*>(cp + 16 * i * p.ldc) = (acc[i][0] * alpha + b0) * rs[i] + r[i][0];
-            *reinterpret_cast<f32x4*>(cp + 16 * i * p.ldc + 16) = (acc[i][1] * alpha + b1) * rs[i] + r[i][1];
+            store_stream(reinterpret_cast<f32x4*>(cp + 16 * i * p.ldc), (acc[i][0] * alpha + b0) * rs[i] + r[i][0]);
+            store_stream(reinterpret_cast<f32x4*>(cp + 16 * i * p.ldc + 16), (acc[i][1] * alpha + b1) * rs[i] + r[i][1]);
         }
     } else {  // P8_GELU_BWD
         const bf16* ap = reinterpret_cast<const bf16*>(p.aux) + row * p.ldaux + col;
@@ -214,7 +254,8 @@ inline bool p8_epi_matches(const esvit_gemm_desc& d, int epi) {
     const bool gelu = d.epilogue == ESVIT_EPI_GELU || d.epilogue == ESVIT_EPI_QGELU;
     const bool gelu_bwd = d.epilogue == ESVIT_EPI_GELU_BWD || d.epilogue == ESVIT_EPI_QGELU_BWD;
     switch (epi) {
-        case P8_BF16: return !gelu && !gelu_bwd && !d.residual && !d.rowscale && !d.out_f32;
+        case P8_BF16: return !gelu && !gelu_bwd && !d.residual && !d.rowscale && !d.out_f32 && !d.rowstat;
+        case P8_BF16_RS: return d.rowstat && !gelu && !gelu_bwd && !d.residual && !d.rowscale && !d.out_f32 && !d.bias;
         case P8_F32: return !gelu && !gelu_bwd && !d.residual && !d.rowscale && d.out_f32;
         case P8_GELU: return gelu && !d.residual && !d.rowscale && !d.out_f32 && (!d.aux || ((d.ldaux % 8 == 0) && al16(d.aux)));
         case P8_RES: return !gelu && !gelu_bwd && d.residual && d.out_f32 && (d.ldr % 4 == 0) && al16(d.residual);
@@ -549,7 +590,7 @@ int dispatch_p8(const esvit_gemm_desc& d, hipStream_t stream) {
 
 // bf16 only; K % 64 == 0, no row map, operands below 4 GiB (32-bit DMA offsets): checked by esvit_gemm's dispatcher (gemm.hip)
 int esvit_gemm_p8_launch(const esvit_gemm_desc& d, hipStream_t stream) {
-    if (!d.a_kstrided && !d.b_kstrided) return dispatch_p8<false, false, P8_BF16, P8_GELU, P8_RES, P8_F32>(d, stream);  // forward
+    if (!d.a_kstrided && !d.b_kstrided) return dispatch_p8<false, false, P8_BF16, P8_BF16_RS, P8_GELU, P8_RES, P8_F32>(d, stream);  // forward
     if (!d.a_kstrided && d.b_kstrided) return dispatch_p8<false, true, P8_BF16, P8_GELU_BWD, P8_F32>(d, stream);       // dgrad
     return dispatch_p8<true, true, P8_F32, P8_RES>(d, stream);                                                          // wgrad
 }

@@ -1,0 +1,646 @@
+// ESVIT_GEMM_P8N: 256 x 128 x 64 bf16 tiles on the eight-wave / staggered-halves / counted-DMA-wait structure of gemm_p8.hip, with
+// TWO accumulator sets and the epilogue of a tile spread over the main loop of the NEXT tile.
+//
+// Why.  profiles/r04_p8_timeline.txt: the persistent 256 x 256 loop multiplies a k-tile in ~1.9 us, but an output tile costs it
+// ~5 us of epilogue in which no MFMA issues -- all 256 workgroups reach their epilogues together and the 32 MB they store drain at
+// the HBM rate while the matrix pipes idle (K = 384: 6 k-tiles of compute, then as long again of stores).  A workgroup that holds the
+// finished tile in one half of its accumulator file and multiplies the next tile into the other half can hand the finished tile
+// to the memory system a row block at a time, between the DMA requests of the next tile's k-tiles: the HBM write stream and the MFMA
+// stream of the whole chip then run side by side, and the GELU arithmetic of the epilogue issues from the wave half whose partner
+// half is in its MFMA block.
+//
+// Geometry.  The k-tile (256 x 64 of A, 128 x 64 of B) is three 16 KiB half-tiles B A0 A1 (128 rows each); a ring of THREE k-tiles
+// (144 KiB) keeps 2.5 k-tiles of requests in flight (the k-tile is half as long as the 256 x 256 one).  Wave (wr, wc), wr in {0,1},
+// wc in {0..3}, owns rows qm * 128 + wr * 64 + [0, 64), qm in {0, 1}, columns wc * 32 + [0, 32): 2 x 4 x 2 fragments = 64
+// accumulator registers per set, two sets = the 128 AccVGPRs.  A k-tile is two phases of 16 MFMAs per wave:
+//     phase 0: read B (2 x 2 fragments), A0 (4 x 2) -> rows qm = 0        phase 1: read A1 -> rows qm = 1
+// Requests: phase 1 of k-tile t asks for B and A0 of t + 3 (into the buffer t is leaving), phase 0 of t + 1 for A1 of t + 3; one
+// counted wait per k-tile (phase 1): everything but the five youngest half-tiles (and the epilogue stores issued since) has landed =
+// k-tile t + 1 is complete.  Every phase is {reads + requests + one epilogue unit | lgkmcnt(0) | barrier | MFMAs | barrier}; the
+// wr = 1 half runs one barrier behind the wr = 0 half.  All LDS reads of a phase are retired before its first barrier, so a
+// half-tile may be re-requested from the next phase on (WAR), and a full barrier lies between the wait that covers a half-tile and
+// its first read (RAW) -- the argument of gemm_p8.hip.
+//
+// Epilogue units.  A finished set is eight units (qm, row block i): two fragments = 64 rows x 32 columns... per wave 16 rows x 32
+// columns, one 16-byte bf16 store (two fp32 stores) per lane.  With DK = 4 the first four k-tiles of the next item each retire two
+// units (one per phase); their stores are counted into that k-tile's vmcnt.  Kinds with epilogue INPUTS (residual, GELU') and
+// ragged edge tiles are stored at the end of their own item instead (as gemm_p8.hip does).  The bias is not an epilogue input:
+// the accumulators START at bias / alpha (scalar loads, no vector-memory traffic).
+#include "gemm_kernels.h"
+
+#ifdef ESVIT_P8_TIMELINE
+// tools/probe only: per-item stamps (s_memrealtime, 100 MHz): [start, after k-tile 0, after k-tile 1, after k-tile 4, end of the k-loop, k-tiles, workgroup, end of item]
+__device__ long* g_p8_timeline = nullptr;
+#define P8_TL(item, slot, val) do { if (g_p8_timeline && threadIdx.x == 0) g_p8_timeline[(long)(item) * 8 + (slot)] = (long)(val); } while (0)
+#define P8_NOW() __builtin_amdgcn_s_memrealtime()
+#else
+#define P8_TL(item, slot, val) do { } while (0)
+#define P8_NOW() 0
+#endif
+
+#ifndef ESVIT_P8N_STORE_AUX
+#define ESVIT_P8N_STORE_AUX 2  // cache policy bits of the output stores (gfx950: bit 0 sc0, bit 1 nt, bit 4 sc1): non-temporal, see store_stream
+#endif
+
+namespace {
+
+constexpr int PN_NT = 512;
+constexpr int PN_HALF = 128 * 64 * 2;  // bytes of one half-tile
+constexpr int PN_BUF = 3 * PN_HALF;    // one k-tile: B, A0, A1
+constexpr int PN_DK = 4;               // k-tiles over which a finished tile is stored
+enum { HN_B = 0, HN_A0 = 1, HN_A1 = 2 };
+enum { PN_BF16 = 0,       // C (bf16) = alpha acc + bias
+       PN_F32 = 1,        // C (fp32) = alpha acc + bias; also the split-K partial slab
+       PN_GELU = 2,       // aux (bf16) = v = alpha acc + bias; C (bf16) = gelu(v)
+       PN_GELU_NOAUX = 3, // C (bf16) = gelu(alpha acc + bias)
+       PN_RES = 4,        // C (fp32) = (alpha acc + bias) * rowscale[row / rows_per_sample] + residual      (end of item)
+       PN_GELU_BWD = 5 }; // C (bf16) = alpha acc * gelu'(aux)                                               (end of item)
+
+template <int EPI>
+struct PnKind {
+    static constexpr bool PIPELINED = EPI == PN_BF16 || EPI == PN_F32 || EPI == PN_GELU || EPI == PN_GELU_NOAUX;
+#ifdef ESVIT_P8N_NOSTORE  // tools/probe only: the pipelined kinds without their stores
+    static constexpr int STORES = 0;
+#else
+    static constexpr int STORES = (EPI == PN_F32 || EPI == PN_GELU) ? 2 : 1;  // vector-memory instructions per unit
+#endif
+};
+
+__device__ __forceinline__ void mma_acc(const Frag<bf16>& a, const Frag<bf16>& b, f32x4& c) {
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a.v), "v"(b.v));
+}
+template <int N>
+__device__ __forceinline__ void wait_lgkmcnt() {
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+}
+
+struct PnItem {
+    int kt0, nk;  // first k-tile, k-tiles
+    int m0, n0, z, tn;
+};
+
+// what the kernel can run at all (the dispatcher falls back to the 128-row kernels otherwise): every output / epilogue tensor is
+// addressed through a buffer descriptor with 32-bit offsets and stored in 16-byte pieces
+inline bool pn_launchable(const esvit_gemm_desc& d) {
+    auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    const long es = d.out_f32 ? 4 : 2;
+    if (d.N % 32 != 0) return false;  // a wave's 32 output columns are all inside or all outside the matrix
+    if (d.splitk > 1) return al16(d.partial) && (long)d.M * d.N * 4 < 0xfff00000L;
+    if (!(al16(d.C) && d.ldc % 8 == 0 && (d.strideC * es) % 16 == 0 && (long)d.M * d.ldc * es < 0xfff00000L)) return false;
+    if (d.bias && (reinterpret_cast<uintptr_t>(d.bias) & 3)) return false;
+    return true;
+}
+
+// the epilogue kind of a descriptor, -1: none of them (fall back)
+inline int pn_kind(const esvit_gemm_desc& d) {
+    auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    if (d.splitk > 1) return PN_F32;
+    const bool gelu = d.epilogue == ESVIT_EPI_GELU || d.epilogue == ESVIT_EPI_QGELU;
+    const bool gelu_bwd = d.epilogue == ESVIT_EPI_GELU_BWD || d.epilogue == ESVIT_EPI_QGELU_BWD;
+    const bool aux_ok = d.aux && (d.ldaux % 8 == 0) && al16(d.aux) && (long)d.M * d.ldaux * 2 < 0xfff00000L;
+    if (gelu) {
+        if (d.residual || d.rowscale || d.out_f32) return -1;
+        if (!d.aux) return PN_GELU_NOAUX;
+        return aux_ok ? PN_GELU : -1;
+    }
+    if (gelu_bwd) return (!d.residual && !d.rowscale && !d.out_f32 && aux_ok) ? PN_GELU_BWD : -1;
+    if (d.residual)
+        return (d.out_f32 && (d.ldr % 4 == 0) && al16(d.residual) && (long)d.M * d.ldr * 4 < 0xfff00000L) ? PN_RES : -1;
+    if (d.rowscale) return -1;
+    return d.out_f32 ? PN_F32 : PN_BF16;
+}
+
+template <bool AKS, bool BKS, int EPI>
+__global__ __launch_bounds__(PN_NT, 1) void gemm_p8n_kernel(const esvit_gemm_desc p, const int group_m) {
+    using HA = DmaTile<AKS, 128, 64, PN_NT>;
+    using HB = DmaTile<BKS, 128, 64, PN_NT>;
+    static_assert(HA::INSTR_PER_WAVE == 2 && HB::INSTR_PER_WAVE == 2, "two LDS-DMA instructions per wave and half-tile");
+    constexpr int STORES = PnKind<EPI>::STORES;
+    constexpr bool F32OUT = EPI == PN_F32 || EPI == PN_RES;
+    constexpr unsigned OOB = 0x80000000u;  // a per-lane offset no descriptor of this kernel reaches (num_records < 2^31): the access is dropped
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    typedef __attribute__((address_space(3))) void lds_void;
+    typedef const float __attribute__((address_space(4))) cfloat4_t;  // scalar (constant-cache) view of the bias
+
+    const int M = p.M, N = p.N, K = p.K;
+    const int tiles_m = (M + 255) / 256, tiles_n = (N + 127) / 128;
+    const int ntiles = tiles_m * tiles_n;
+    const int nz = p.splitk > 1 ? p.splitk : p.batch;
+    const int total = ntiles * nz;
+
+    // work list and its XCD-contiguous ranges: as gemm_p8.hip
+    const int per_xcd = gridDim.x >> 3;
+    const int xcd = blockIdx.x & 7, widx = blockIdx.x >> 3;
+    const int wq = total / 8, wrem = total % 8;
+    const int w_begin = xcd < wrem ? xcd * (wq + 1) : wrem * (wq + 1) + (xcd - wrem) * wq;
+    const int w_end = w_begin + wq + (xcd < wrem ? 1 : 0);
+    if (w_begin + widx >= w_end) return;
+
+    auto make_item = [&](int w) __attribute__((always_inline)) {
+        PnItem it;
+        const int z = w / ntiles, pid = w - z * ntiles;
+        int tm, tn;
+        tile_coords(pid, tiles_m, tiles_n, group_m, tm, tn);
+        it.m0 = tm * 256;
+        it.n0 = tn * 128;
+        it.z = z;
+        it.tn = tn;
+        it.kt0 = 0;
+        it.nk = K / 64;  // K % 64 == 0 (dispatcher)
+        if (p.splitk > 1) {
+            const int per = (it.nk + p.splitk - 1) / p.splitk;
+            it.kt0 = min(it.nk, z * per);
+            it.nk = min(it.nk, (z + 1) * per) - it.kt0;
+        }
+        return it;
+    };
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c = lane & 15, g = lane >> 4;
+    const int wr = wave >> 2, wc = wave & 3;
+
+    int voffA[2], voffB[2];
+    HA::wave_offsets(p.lda, wave, lane, voffA);
+    HB::wave_offsets(p.ldb, wave, lane, voffB);
+
+    // ---- the request stream (gemm_p8.hip): B A0 A1 | B A0 A1 | ... through the k-tiles of an item and on into the workgroup's next
+    // item.  ONE descriptor per operand covers the whole matrix (the scalar offset is part of the hardware range check --
+    // tools/probe/soff_probe.hip -- so the tile origin, the half and the k-tile all travel in it; reads past the end of the matrix
+    // return 0, rows / columns past M / N inside it are garbage that only reaches outputs the epilogue drops).
+    const long a_bytes = (AKS ? (long)K : (long)M) * p.lda * 2, b_bytes = (BKS ? (long)K : (long)N) * p.ldb * 2;
+    const unsigned a_kstep = AKS ? (unsigned)p.lda * 128u : 128u, b_kstep = BKS ? (unsigned)p.ldb * 128u : 128u;  // bytes per k-tile
+    const unsigned a_half = AKS ? 256u : (unsigned)p.lda * 256u;                                                   // bytes between A0 and A1
+    __amdgpu_buffer_rsrc_t sra, srb;
+    unsigned soA = 0, soB = 0;  // scalar offsets of the stream's current k-tile
+    int sw = w_begin + widx - per_xcd, sleft = 0;
+    auto stream_next_item = [&]() __attribute__((always_inline)) {
+        sleft = 0;
+        while (sleft == 0) {  // (an empty split-K slice has nothing to request)
+            sw += per_xcd;
+            if (sw >= w_end) {
+                sra = srb = make_rsrc(p.A, 0);  // zero records: requests past the end of the work touch no memory
+                soA = soB = 0;
+                sleft = 0x7fffffff;
+                return;
+            }
+            const PnItem it = make_item(sw);
+            const bf16* A = reinterpret_cast<const bf16*>(p.A) + (p.splitk > 1 ? 0 : (long)it.z * p.strideA);
+            const bf16* B = reinterpret_cast<const bf16*>(p.B) + (p.splitk > 1 ? 0 : (long)it.z * p.strideB);
+            sra = make_rsrc(A, a_bytes);
+            srb = make_rsrc(B, b_bytes);
+            soA = (AKS ? (unsigned)it.m0 * 2u : (unsigned)it.m0 * (unsigned)p.lda * 2u) + (unsigned)it.kt0 * a_kstep;
+            soB = (BKS ? (unsigned)it.n0 * 2u : (unsigned)it.n0 * (unsigned)p.ldb * 2u) + (unsigned)it.kt0 * b_kstep;
+            sleft = it.nk;
+        }
+    };
+    auto stage = [&](auto hc, int boff) __attribute__((always_inline)) {
+        constexpr int H = decltype(hc)::value;
+        char* dst = smem + boff + H * PN_HALF + wave * 2048;
+        if constexpr (H == HN_B) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(srb, (lds_void*)(dst), 16, voffB[0], (int)soB, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(srb, (lds_void*)(dst + 1024), 16, voffB[1], (int)soB, 0, 0);
+        } else {
+            const int so = (int)(H == HN_A0 ? soA : soA + a_half);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(sra, (lds_void*)(dst), 16, voffA[0], so, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(sra, (lds_void*)(dst + 1024), 16, voffA[1], so, 0, 0);
+        }
+        if constexpr (H == HN_A1) {  // the k-tile is complete: on to the next one
+            soA += a_kstep;
+            soB += b_kstep;
+            if (--sleft == 0) stream_next_item();
+        }
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+
+    f32x4 acc[2][2][4][2];   // [set][qm][row block][column block]
+    float csum[2][4];        // fused bias gradient (weight-gradient layout): this lane's share of the row sums of op(A)
+    Frag<bf16> fa[2][4];     // [k-step][row fragment] of the current A sub-tile
+    Frag<bf16> fb[2][2];     // [k-step][column fragment]
+
+    auto read_a = [&](int boff, auto qmc) __attribute__((always_inline)) {
+        constexpr int QM = decltype(qmc)::value;
+        const bf16* lds = reinterpret_cast<const bf16*>(smem + boff + (QM ? HN_A1 : HN_A0) * PN_HALF);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fa[kk][i] = HA::frag(lds, wr * 64 + i * 16, kk, c, g);
+    };
+    auto read_b = [&](int boff) __attribute__((always_inline)) {
+        const bf16* lds = reinterpret_cast<const bf16*>(smem + boff + HN_B * PN_HALF);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) fb[kk][j] = HB::frag(lds, wc * 32 + j * 16, kk, c, g);
+    };
+    auto mfma_rows = [&](auto setc, auto qmc) __attribute__((always_inline)) {
+        constexpr int SET = decltype(setc)::value, QM = decltype(qmc)::value;
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) mma_acc(fb[kk][j], fa[kk][i], acc[SET][QM][i][j]);  // operands swapped: see epilogue_direct
+        __builtin_amdgcn_s_setprio(0);
+    };
+    auto colsum_a = [&](auto qmc) __attribute__((always_inline)) {  // bias gradient: v_dot2c against (1, 1), see gemm_p8.hip
+        constexpr int QM = decltype(qmc)::value;
+        typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+        const bf16x2_t one2 = {(bf16)1.0f, (bf16)1.0f};
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    csum[QM][i] = __builtin_amdgcn_fdot2_f32_bf16(bf16x2_t{fa[kk][i].v[2 * e], fa[kk][i].v[2 * e + 1]}, one2, csum[QM][i], false);
+    };
+    auto bar = [&]() __attribute__((always_inline)) {
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    // ---- output addressing.  Every output / epilogue tensor goes through a buffer descriptor based at the item's first row (offsets
+    // stay below 2^31; rows past M fall outside num_records and are dropped by the hardware) with a per-lane byte offset that is the
+    // same for the whole kernel: row c of a row block, and either the lane's 8-column piece of a bf16 row (two column blocks exchanged
+    // between lane groups, pair_rows) or its 4 columns of block 0 (block 1 = + 16 columns) of an fp32 row.  Columns past N: the
+    // per-lane offset is replaced by OOB.  The scalar offset carries the rest: wave row / column, unit.
+    const long ldo = p.splitk > 1 ? (long)N : p.ldc;  // leading dimension of the output (elements)
+    constexpr int ES = F32OUT ? 4 : 2;
+    const int pc = 16 * (g & 1) + 4 * (g & ~1);  // first column of the lane's bf16 piece inside the wave's 32 columns
+    const unsigned vo_out = F32OUT ? (unsigned)((c * ldo + 4 * g) * 4) : (unsigned)((c * ldo + pc) * 2);
+    const unsigned vo_aux = EPI == PN_GELU ? (unsigned)((c * p.ldaux + pc) * 2) : EPI == PN_GELU_BWD ? (unsigned)((c * p.ldaux + 4 * g) * 2)
+                                                                                 : EPI == PN_RES     ? (unsigned)((c * p.ldr + 4 * g) * 4)
+                                                                                                     : 0u;
+    struct Out {
+        __amdgpu_buffer_rsrc_t rc, rx;  // output; aux (GELU, GELU') or residual
+        unsigned so_c, so_x;            // scalar offsets of the wave's first row / column inside the item
+        int n0, m0;
+    };
+    auto make_out = [&](const PnItem& it) __attribute__((always_inline)) {
+        Out o;
+        const long rows_left = M - it.m0;
+        const long cap = 0x7ffffff0L;
+        char* cb = p.splitk > 1 ? reinterpret_cast<char*>(p.partial) + ((long)it.z * M * N + (long)it.m0 * N) * 4
+                                : reinterpret_cast<char*>(p.C) + ((long)it.z * p.strideC + (long)it.m0 * p.ldc) * ES;
+        long cbytes = rows_left * ldo * ES;
+        o.rc = make_rsrc(cb, cbytes < cap ? cbytes : cap);
+        o.so_c = (unsigned)((wr * 64 * ldo + it.n0 + wc * 32) * ES);
+        o.rx = o.rc;
+        o.so_x = 0;
+        if constexpr (EPI == PN_GELU || EPI == PN_GELU_BWD) {
+            const long xb = rows_left * p.ldaux * 2;
+            o.rx = make_rsrc(reinterpret_cast<char*>(p.aux) + (long)it.m0 * p.ldaux * 2, xb < cap ? xb : cap);
+            o.so_x = (unsigned)((wr * 64 * p.ldaux + it.n0 + wc * 32) * 2);
+        } else if constexpr (EPI == PN_RES) {
+            const long xb = rows_left * p.ldr * 4;
+            o.rx = make_rsrc(const_cast<float*>(p.residual) + (long)it.m0 * p.ldr, xb < cap ? xb : cap);
+            o.so_x = (unsigned)((wr * 64 * p.ldr + it.n0 + wc * 32) * 4);
+        }
+        o.n0 = it.n0;
+        o.m0 = it.m0;
+        return o;
+    };
+    // per-lane offsets of an item with the column mask applied
+    auto lane_off_bf16 = [&](unsigned vo, int n0) __attribute__((always_inline)) { return (n0 + wc * 32 + pc + 8 <= N) ? vo : OOB; };
+    auto lane_off_4 = [&](unsigned vo, int n0, int blk) __attribute__((always_inline)) { return (n0 + wc * 32 + 16 * blk + 4 * g + 4 <= N) ? vo : OOB; };
+
+    // epilogue unit U (qm = U >> 2, row block i = U & 3) of set SET: kinds without inputs
+    auto unit = [&](auto setc, auto uc, const Out& o) __attribute__((always_inline)) {
+#ifdef ESVIT_P8N_NOSTORE
+        return;
+#endif
+        constexpr int SET = decltype(setc)::value, U = decltype(uc)::value;
+        constexpr int QM = U >> 2, I = U & 3;
+        const unsigned so = o.so_c + (unsigned)((QM * 128 + 16 * I) * ldo * ES);
+        f32x4 v[2] = {acc[SET][QM][I][0] * p.alpha, acc[SET][QM][I][1] * p.alpha};
+        if constexpr (EPI == PN_F32) {
+            if (p.splitk > 1) {  // (partials: read back at once by the reduce kernel)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v[0]), o.rc, lane_off_4(vo_out, o.n0, 0), so, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v[1]), o.rc, lane_off_4(vo_out, o.n0, 1), so + 64, 0);
+            } else {
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v[0]), o.rc, lane_off_4(vo_out, o.n0, 0), so, ESVIT_P8N_STORE_AUX);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v[1]), o.rc, lane_off_4(vo_out, o.n0, 1), so + 64, ESVIT_P8N_STORE_AUX);
+            }
+        } else {
+            const unsigned vo = lane_off_bf16(vo_out, o.n0);
+            if constexpr (EPI == PN_GELU) {
+                const unsigned sx = o.so_x + (unsigned)((QM * 128 + 16 * I) * p.ldaux * 2);
+                __builtin_amdgcn_raw_buffer_store_b128(pair_rows(v[0], v[1]), o.rx, lane_off_bf16(vo_aux, o.n0), sx, ESVIT_P8N_STORE_AUX);
+            }
+            if constexpr (EPI == PN_GELU || EPI == PN_GELU_NOAUX) {
+                const bool quick = p.epilogue == ESVIT_EPI_QGELU;
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[j][e] = quick ? qgelu_f(v[j][e]) : gelu_f(v[j][e]);
+            }
+            __builtin_amdgcn_raw_buffer_store_b128(pair_rows(v[0], v[1]), o.rc, vo, so, ESVIT_P8N_STORE_AUX);
+        }
+    };
+    // all eight units of a set at once (end of the item).  Kinds with inputs request the inputs of four units before the first of
+    // their stores (vmcnt retires in order, and the requests queue behind the k-tiles already in flight for the next item).
+    auto store_set = [&](auto setc, const Out& o) __attribute__((always_inline)) {
+        constexpr int SET = decltype(setc)::value;
+        if constexpr (EPI == PN_RES) {
+            static_for<2>([&](auto hc) {
+                constexpr int QM = decltype(hc)::value;
+                f32x4 r[4][2];
+                float rs[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const unsigned sx = o.so_x + (unsigned)((QM * 128 + 16 * i) * p.ldr * 4);
+                    r[i][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(o.rx, lane_off_4(vo_aux, o.n0, 0), sx, 0));
+                    r[i][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(o.rx, lane_off_4(vo_aux, o.n0, 1), sx + 64, 0));
+                    rs[i] = 1.f;
+                }
+                if (p.rowscale) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const long row = (long)o.m0 + QM * 128 + wr * 64 + 16 * i + c;
+                        rs[i] = row < M ? p.rowscale[row / p.rows_per_sample] : 0.f;
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const unsigned so = o.so_c + (unsigned)((QM * 128 + 16 * i) * ldo * 4);
+                    const f32x4 y0 = acc[SET][QM][i][0] * p.alpha * rs[i] + r[i][0], y1 = acc[SET][QM][i][1] * p.alpha * rs[i] + r[i][1];
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, y0), o.rc, lane_off_4(vo_out, o.n0, 0), so, ESVIT_P8N_STORE_AUX);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, y1), o.rc, lane_off_4(vo_out, o.n0, 1), so + 64, ESVIT_P8N_STORE_AUX);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        } else if constexpr (EPI == PN_GELU_BWD) {
+            const bool quick = p.epilogue == ESVIT_EPI_QGELU_BWD;
+            static_for<2>([&](auto hc) {
+                constexpr int QM = decltype(hc)::value;
+                u32x2_t a[4][2];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const unsigned sx = o.so_x + (unsigned)((QM * 128 + 16 * i) * p.ldaux * 2);
+                    a[i][0] = __builtin_amdgcn_raw_buffer_load_b64(o.rx, lane_off_4(vo_aux, o.n0, 0), sx, 0);
+                    a[i][1] = __builtin_amdgcn_raw_buffer_load_b64(o.rx, lane_off_4(vo_aux, o.n0, 1), sx + 32, 0);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    f32x4 v[2];
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const f32x4 x = {__builtin_bit_cast(float, a[i][j][0] << 16), __builtin_bit_cast(float, a[i][j][0] & 0xffff0000u),
+                                         __builtin_bit_cast(float, a[i][j][1] << 16), __builtin_bit_cast(float, a[i][j][1] & 0xffff0000u)};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[j][e] = acc[SET][QM][i][j][e] * p.alpha * (quick ? qgelu_grad_f(x[e]) : gelu_grad_f(x[e]));
+                    }
+                    const unsigned so = o.so_c + (unsigned)((QM * 128 + 16 * i) * ldo * 2);
+                    __builtin_amdgcn_raw_buffer_store_b128(pair_rows(v[0], v[1]), o.rc, lane_off_bf16(vo_out, o.n0), so, ESVIT_P8N_STORE_AUX);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        } else {
+            static_for<8>([&](auto uc) {
+                unit(setc, uc, o);
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        }
+    };
+
+    // ---- one item: multiply into set SET; DRAIN: the previous item's set (SET ^ 1) is stored on the way, one unit per phase of the
+    // first DK k-tiles (nk > DK: caller) ----
+    int b0 = 0, b1 = PN_BUF, b2 = 2 * PN_BUF;  // byte offsets of the buffers of k-tiles t, t + 1, t + 2
+    int tl_w = 0;
+    auto run_item = [&](auto setc, auto drainc, const PnItem& cur, const Out& oprev) __attribute__((always_inline)) {
+        constexpr int SET = decltype(setc)::value;
+        constexpr bool DRAIN = decltype(drainc)::value;
+        using SC = std::integral_constant<int, SET>;
+        using SP = std::integral_constant<int, SET ^ 1>;
+        // the accumulators start at bias / alpha
+        {
+            f32x4 binit[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+            if (p.bias && p.splitk <= 1 && cur.n0 + wc * 32 < N) {  // (N % 32 == 0: a wave's 32 columns are all inside or all outside)
+                cfloat4_t* bp = (cfloat4_t*)(uintptr_t)(p.bias + cur.n0 + wc * 32);
+                const float inv = 1.f / p.alpha;
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float s0 = bp[16 * j + e], s1 = bp[16 * j + 4 + e], s2 = bp[16 * j + 8 + e], s3 = bp[16 * j + 12 + e];
+                        binit[j][e] = ((g & 2) ? ((g & 1) ? s3 : s2) : ((g & 1) ? s1 : s0)) * inv;
+                    }
+            }
+#pragma unroll
+            for (int qm = 0; qm < 2; ++qm)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    acc[SET][qm][i][0] = binit[0];
+                    acc[SET][qm][i][1] = binit[1];
+                }
+        }
+        const bool do_colsum = AKS && p.colsum && cur.tn == 0 && wc == 0;
+        if constexpr (AKS) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) csum[0][i] = csum[1][i] = 0.f;
+        }
+        bool have_a1 = false;
+        P8_TL(tl_w, 0, P8_NOW());
+        P8_TL(tl_w, 5, cur.nk);
+        P8_TL(tl_w, 6, blockIdx.x);
+        if (wr == 1) bar();  // the wr = 1 half runs one barrier behind
+
+        // k-tile: U0 / U1 = units of the previous set retired in its two phases (-1: none); NW = such units whose stores were issued
+        // since the request this k-tile's wait has to cover (phases (t - 1, 0), (t - 1, 1), (t, 0))
+        auto ktile = [&](auto du0c, auto du1c, auto nwc) __attribute__((always_inline)) {
+            constexpr int U0 = decltype(du0c)::value, U1 = decltype(du1c)::value, NW = decltype(nwc)::value;
+            // phase 0
+            if constexpr (AKS) {
+                if (do_colsum && have_a1) colsum_a(I1{});  // (the A1 fragments of the previous k-tile are still in registers)
+            }
+            read_b(b0);
+            read_a(b0, I0{});
+            stage(I2{}, b2);  // A1 of k-tile t + 2
+            if constexpr (U0 >= 0) unit(SP{}, std::integral_constant<int, (U0 >= 0 ? U0 : 0)>{}, oprev);
+            wait_lgkmcnt<0>();
+            bar();
+            mfma_rows(SC{}, I0{});
+            bar();
+            // phase 1
+            if constexpr (AKS) {
+                if (do_colsum) colsum_a(I0{});  // (before the A0 fragments of phase 0 are overwritten)
+                have_a1 = true;
+            }
+            read_a(b0, I1{});
+            stage(I0{}, b0);  // B, A0 of k-tile t + 3: into the half-tiles phase 0 has finished with
+            stage(I1{}, b0);
+            wait_vmcnt<10 + STORES * NW>();  // all of k-tile t + 1 has landed; the five youngest half-tiles (and stores) stay in flight
+            if constexpr (U1 >= 0) unit(SP{}, std::integral_constant<int, (U1 >= 0 ? U1 : 0)>{}, oprev);
+            wait_lgkmcnt<0>();
+            bar();
+            mfma_rows(SC{}, I1{});
+            bar();
+            const int tmp = b0;
+            b0 = b1;
+            b1 = b2;
+            b2 = tmp;
+        };
+        using N1 = std::integral_constant<int, -1>;
+        int t = 0;
+        if constexpr (DRAIN) {
+            static_assert(PN_DK == 4, "unit schedule below");
+            ktile(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
+            P8_TL(tl_w, 1, P8_NOW());
+            ktile(std::integral_constant<int, 2>{}, std::integral_constant<int, 3>{}, std::integral_constant<int, 3>{});
+            P8_TL(tl_w, 2, P8_NOW());
+            ktile(std::integral_constant<int, 4>{}, std::integral_constant<int, 5>{}, std::integral_constant<int, 3>{});
+            ktile(std::integral_constant<int, 6>{}, std::integral_constant<int, 7>{}, std::integral_constant<int, 3>{});
+            ktile(N1{}, N1{}, std::integral_constant<int, 2>{});
+            P8_TL(tl_w, 3, P8_NOW());
+            t = PN_DK + 1;
+        }
+        for (; t < cur.nk; ++t) ktile(N1{}, N1{}, I0{});
+        if (wr == 0) bar();
+        P8_TL(tl_w, 4, P8_NOW());
+        if constexpr (AKS) {
+            if (do_colsum) {  // the four lane groups hold four k-slices of the same rows
+                colsum_a(I1{});
+                float* dst = p.splitk > 1 ? p.colsum_partial + (long)cur.z * M : p.colsum;
+#pragma unroll
+                for (int qm = 0; qm < 2; ++qm)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        float v = csum[qm][i];
+                        v += __shfl_xor(v, 16, 64);
+                        v += __shfl_xor(v, 32, 64);
+                        const int m = cur.m0 + qm * 128 + wr * 64 + i * 16 + c;
+                        if (g == 0 && m < M) dst[m] = v * p.alpha;
+                    }
+            }
+        }
+    };
+
+    // prologue: k-tiles 0 and 1 of the stream and B, A0 of k-tile 2
+    stream_next_item();
+    stage(I0{}, b0);
+    stage(I1{}, b0);
+    stage(I2{}, b0);
+    stage(I0{}, b1);
+    stage(I1{}, b1);
+    stage(I2{}, b1);
+    stage(I0{}, b2);
+    stage(I1{}, b2);
+    wait_vmcnt<10>();
+    bar();
+
+    // items alternate between the accumulator sets; a finished set waits (pending) to be stored during the next item when the kind
+    // is a pipelined one, the next item is long enough and there is a next item
+    int w = w_begin + widx;
+    PnItem cur = make_item(w);
+    Out ocur = make_out(cur), oprev = ocur;
+    bool pending = false;
+    using T = std::true_type;
+    using F = std::false_type;
+    auto step = [&](auto setc) __attribute__((always_inline)) {  // -> false: this was the last item
+        constexpr int SET = decltype(setc)::value;
+        using SC = std::integral_constant<int, SET>;
+        using SP = std::integral_constant<int, SET ^ 1>;
+        tl_w = w;
+        if (pending && cur.nk <= PN_DK) {  // too short to carry the previous tile's stores
+            store_set(SP{}, oprev);
+            pending = false;
+        }
+        if (pending) run_item(SC{}, T{}, cur, oprev);
+        else run_item(SC{}, F{}, cur, oprev);
+        const bool last = w + per_xcd >= w_end;
+        if (PnKind<EPI>::PIPELINED && !last) {
+            pending = true;
+            oprev = ocur;
+        } else {
+            store_set(SC{}, ocur);
+            pending = false;
+        }
+        P8_TL(w, 7, P8_NOW());
+        if (last) return false;
+        w += per_xcd;
+        cur = make_item(w);
+        ocur = make_out(cur);
+        return true;
+    };
+    while (true) {
+        if (!step(I0{})) break;
+        if (!step(I1{})) break;
+    }
+}
+
+template <bool AKS, bool BKS, int EPI>
+int launch_p8n(const esvit_gemm_desc& d, hipStream_t stream) {
+    auto kern = gemm_p8n_kernel<AKS, BKS, EPI>;
+    constexpr int lds = 3 * PN_BUF;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_done = true;
+    }
+    const int tm_ = ceil_div(d.M, 256), tn_ = ceil_div(d.N, 128);
+    const int nz = d.splitk > 1 ? d.splitk : d.batch;
+    int group_m = 1;
+    if (nz == 1) {
+        if (tn_ > 64) group_m = 2;
+        else if (tn_ >= 12) group_m = 8;
+        else if (tn_ >= 2 && tm_ >= 1024) group_m = 16;
+    }
+    const long total = (long)tm_ * tn_ * nz;
+    const int grid = total > 256 ? 256 : (int)((total + 7) / 8 * 8);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(PN_NT), lds, stream, d, group_m);
+    ESVIT_CHECK_LAUNCH("esvit_gemm(p8n)");
+    if (d.splitk > 1) return launch_splitk_reduce(d, true, stream);
+    return ESVIT_OK;
+}
+
+template <bool AKS, bool BKS, int... EPIS>
+int dispatch_p8n(const esvit_gemm_desc& d, int kind, hipStream_t stream) {
+    int rc = ESVIT_ERR_UNSUPPORTED;
+    auto try_one = [&](auto ec) {
+        constexpr int E = decltype(ec)::value;
+        if (kind == E) rc = launch_p8n<AKS, BKS, E>(d, stream);
+    };
+    (try_one(std::integral_constant<int, EPIS>{}), ...);
+    return rc;
+}
+
+}  // namespace
+
+// can ESVIT_GEMM_P8N run this descriptor?  (bf16, K % 64 == 0, no row map / row statistics: checked by the caller, gemm.hip)
+bool esvit_gemm_p8n_supports(const esvit_gemm_desc& d) {
+    if (!pn_launchable(d)) return false;
+    const int k = pn_kind(d);
+    if (k < 0) return false;
+    // The kinds with epilogue INPUTS (residual, GELU') are not offered: their end-of-item form gains nothing over the 128-row kernels
+    // and did not pass test_gemm_p8n in round 4 (wrong values in rows 12..15 of a row block) -- the code below is kept for the next
+    // attempt but never instantiated.
+    if (k == PN_RES || k == PN_GELU_BWD) return false;
+    if (!d.a_kstrided && !d.b_kstrided) return true;
+    if (!d.a_kstrided && d.b_kstrided) return k == PN_BF16 || k == PN_F32;
+    return k == PN_F32;
+}
+
+int esvit_gemm_p8n_launch(const esvit_gemm_desc& d, hipStream_t stream) {
+    const int k = pn_kind(d);
+    if (!d.a_kstrided && !d.b_kstrided) return dispatch_p8n<false, false, PN_BF16, PN_GELU, PN_GELU_NOAUX, PN_F32>(d, k, stream);  // forward
+    if (!d.a_kstrided && d.b_kstrided) return dispatch_p8n<false, true, PN_BF16, PN_F32>(d, k, stream);  // dgrad
+    return dispatch_p8n<true, true, PN_F32>(d, k, stream);  // wgrad
+}
+
+#ifdef ESVIT_P8_TIMELINE
+extern "C" __attribute__((visibility("default"))) int p8n_probe_set_timeline(long* buf) {
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_p8_timeline), &buf, sizeof(buf));
+}
+extern "C" __attribute__((visibility("default"))) int p8n_probe_gemm(const esvit_gemm_desc* d, void* stream) {
+    esvit_gemm_desc dd = *d;
+    if (dd.batch < 1) dd.batch = 1;
+    if (dd.splitk < 1) dd.splitk = 1;
+    return esvit_gemm_p8n_launch(dd, reinterpret_cast<hipStream_t>(stream));
+}
+void esvit_set_error(const char*, ...) {}
+#endif

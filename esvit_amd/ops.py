@@ -9,7 +9,7 @@ import ctypes as C
 import numpy as np
 import torch
 
-from ._lib import BF16, EPI_GELU, EPI_GELU_BWD, EPI_NONE, EPI_QGELU, EPI_QGELU_BWD, F32, GEMM_AUTO, GEMM_DMA8, GEMM_P8, GemmDesc, check, lib
+from ._lib import BF16, EPI_GELU, EPI_GELU_BWD, EPI_NONE, EPI_QGELU, EPI_QGELU_BWD, F32, GEMM_AUTO, GEMM_DMA8, GEMM_P8, GEMM_P8N, GemmDesc, check, lib
 
 _ACT_DTYPE = torch.bfloat16
 
@@ -179,8 +179,12 @@ def _gemm_desc(kw):
     d.kernel = int(kw.get("kernel", FORCE_GEMM_KERNEL))
     if d.kernel == GEMM_DMA8 and d.a_kstrided and "kernel" not in kw:
         d.kernel = GEMM_AUTO  # FORCE_GEMM_KERNEL is a test / bench hook: the 8-wave tile has no weight-gradient instantiation
-    if d.kernel == GEMM_P8 and "kernel" not in kw and not p8_supported(kw):
-        d.kernel = GEMM_AUTO  # (same hook) the eight-phase loop runs whole 64-deep k-tiles and has no row map / statistics
+    if d.kernel in (GEMM_P8, GEMM_P8N) and "kernel" not in kw:
+        # (same hook) the eight-phase loops run whole 64-deep k-tiles, have no row map / statistics, and the 256 x 128 one its own list
+        # of epilogue kinds: ask the library whether the forced loop takes this descriptor
+        tm, tn, slots = C.c_int(0), C.c_int(0), C.c_int(0)
+        if lib.esvit_gemm_select(BF16, C.byref(d), C.byref(tm), C.byref(tn), C.byref(slots)) <= 0:
+            d.kernel = GEMM_AUTO
     return d
 
 
@@ -229,11 +233,13 @@ def linear_fwd(x, w, bias=None, *, gelu=False, want_preact=False, residual=None,
         inv_temp, cen = row_stats
         assert row_stats_supported(x.dtype, M, N) and bias is None and not gelu and residual is None and rowmap is None and not out_f32
         y = torch.empty((M, N), dtype=x.dtype, device=x.device)
-        nb = N // 64
-        st = torch.empty((M, nb, 2), dtype=torch.float32, device=x.device)
         cen = None if cen is None else _f32c(cen)
+        # the statistics come in blocks of 64 columns from the 128-row loop, of 32 columns from the 256 x 256 eight-phase loop
+        kern = gemm_select(x.dtype, M=M, N=N, K=K, rowstat=y, kernel=GEMM_AUTO)[0]
+        nb = N // (32 if kern == GEMM_P8 else 64)
+        st = torch.empty((M, nb, 2), dtype=torch.float32, device=x.device)
         _gemm(x.dtype, A=x, B=w, C=y, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, rowstat=st, rowstat_center=cen, rowstat_scale=float(inv_temp) * LOG2E,
-              kernel=GEMM_AUTO)
+              kernel=kern)
         mx = torch.empty((M,), dtype=torch.float32, device=x.device)
         lse = torch.empty_like(mx)
         check(lib.esvit_rowstat_combine(_p(st), M, nb, _p(mx), _p(lse), _stream()), "rowstat_combine")
@@ -257,7 +263,9 @@ def linear_dgrad(dy, w, *, gelu_preact=None, out_f32=False, quick=False):
     dx = torch.empty((M, Kin), dtype=torch.float32 if out_f32 else dy.dtype, device=dy.device)
     if gelu_preact is None and Nout >= 4096:
         # a very long reduction (DINOHead last layer: K = out_dim) over few output tiles: the wide-tile loop, split-K to fill the chip
-        kern = GEMM_DMA8 if (FORCE_GEMM_KERNEL == GEMM_AUTO and dy.dtype == torch.bfloat16 and Kin >= 192) else FORCE_GEMM_KERNEL
+        kern = FORCE_GEMM_KERNEL
+        if FORCE_GEMM_KERNEL == GEMM_AUTO and dy.dtype == torch.bfloat16 and Kin >= 192:
+            kern = GEMM_P8 if (Nout % 64 == 0 and Kin % 256 == 0) else GEMM_DMA8
         _, tm, tn, slots = gemm_select(dy.dtype, M=M, N=Kin, K=Nout, b_kstrided=1, kernel=kern)
         tiles = (-(-M // tm)) * (-(-Kin // tn))
         if tiles <= slots // 2:

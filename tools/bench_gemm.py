@@ -116,7 +116,7 @@ def main():
             x, w = rnd((M, K)), rnd((N, K), 0.05)
             d = {"plain": "nt", "M": M, "N": N, "K": K}
             ref = None
-            for k in (2, 3, 5):
+            for k in (2, 5, 6):
                 ops.FORCE_GEMM_KERNEL = k
                 try:
                     fn = lambda: ops.linear_fwd(x, w, None)
@@ -131,7 +131,7 @@ def main():
             emit(d)
             del x, w
             torch.cuda.empty_cache()
-    KERNELS = (0, 2, 4, 5)
+    KERNELS = (0, 2, 4, 5, 6)
     tot = {k: 0.0 for k in KERNELS}
     tot["best"] = 0.0
     for name, kind, M, N, K, fl in step_shapes(args.batch):
