@@ -82,13 +82,16 @@ def _analytic_gflops():
 BF16_PEAK_TFLOPS = 2500.0      # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E (MI355X_MICROARCH.md; ~6.3 TB/s is what a streaming kernel reaches)
 OUT_DIM = 65536
-PMC_TRAFFIC_FILES = [os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f) for f in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")]
+PMC_TRAFFIC_FILES = [os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f)
+                     for f in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")]
 
 
 def pmc_gemm_traffic_per_launch(arch, batch, launches_per_step):
     """HBM bytes per GEMM launch from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE in separate
     runs of this same command, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950; produced by
-    tools/pmc_traffic.py).  None when no PMC run exists for this arch / batch."""
+    tools/pmc_traffic.py).  -> (bytes per launch, source file) or (None, None) when no PMC run exists for this arch / batch.
+    The number is NOT measured in this process (a PMC pass needs rocprofv3 around the whole run): the bench line says so in
+    roofline.traffic_source."""
     for path in PMC_TRAFFIC_FILES:  # the newest committed PMC run wins
         try:
             with open(path) as fh:
@@ -97,8 +100,8 @@ def pmc_gemm_traffic_per_launch(arch, batch, launches_per_step):
             continue
         for r in runs:
             if r["arch"] == arch and r["batch"] == batch:
-                return r["gemm_bytes_per_step"] / launches_per_step
-    return None
+                return r["gemm_bytes_per_step"] / launches_per_step, "profiles/" + os.path.basename(path)
+    return None, None
 
 
 def build(dev, drop_path, arch="swin_tiny_w7"):
@@ -474,9 +477,11 @@ def main():
             # workload's unfused shapes the family moves ~156 FLOP per algorithmic byte, half the 312 FLOP/B ridge.
             gbs = tot_by / (tot_ms * 1e-3) / 1e9
             ach_tf = tot_fl / (tot_ms * 1e-3) / 1e12
-            out["roofline"] = {"bound": "mfma", "kernel": "gemm_dma_kernel / gemm_kernel (all fwd/dgrad/wgrad GEMM launches of the step)",
+            traffic, traffic_file = pmc_gemm_traffic_per_launch(args.arch, B, len(prof) / prof_steps)
+            out["roofline"] = {"bound": "mfma", "kernel": "gemm_p8_kernel / gemm_p8n_kernel / gemm_dma_kernel (all fwd/dgrad/wgrad GEMM launches of the step)",
                                "achieved": ach_tf, "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach_tf / BF16_PEAK_TFLOPS,
-                               "traffic": pmc_gemm_traffic_per_launch(args.arch, B, len(prof) / prof_steps),
+                               "traffic": traffic,
+                               "traffic_source": None if traffic is None else "rocprofv3 PMC passes of this command, committed as %s (not read in this run)" % traffic_file,
                                "launches_per_step": len(prof) / prof_steps, "instrumented_steps": prof_steps,
                                "flops_per_launch": tot_fl / len(prof), "algorithmic_bytes_per_launch": tot_by / len(prof),
                                "avg_launch_us": tot_ms * 1e3 / len(prof), "gemm_ms_per_step": tot_ms / prof_steps,

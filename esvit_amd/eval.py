@@ -27,18 +27,19 @@ def load_pretrained_weights(model, pretrained_weights, checkpoint_key, model_nam
     checkpoint have no place in a NUM_CLASSES 0 backbone).  Without a file the reference tries to download DINO's public ViT
     weights; there is no network on this side, so that branch leaves the random initialisation and says so.  Returns the
     load_state_dict message (the reference prints it)."""
-    if os.path.isfile(pretrained_weights):
-        state_dict = torch.load(pretrained_weights, map_location="cpu", weights_only=False)
-        if checkpoint_key is not None and checkpoint_key in state_dict:
-            print(f"Take key {checkpoint_key} in provided checkpoint dict")
-            state_dict = state_dict[checkpoint_key]
-        state_dict = {k.replace("module.", ""): v for k, v in state_dict.items()}
-        msg = model.load_state_dict(state_dict, strict=False)
-        print('Pretrained weights found at {} and loaded with msg: {}'.format(pretrained_weights, msg))
-        return msg
-    print("Please use the `--pretrained_weights` argument to indicate the path of the checkpoint to evaluate.")
-    print("There is no reference weights available for this model => We use random weights.")
-    return None
+    if not os.path.isfile(pretrained_weights):
+        print("no checkpoint file at %r: the backbone keeps its random initialisation (the reference would fetch DINO's public weights "
+              "here; this side has no network)" % (pretrained_weights,))
+        return None
+    ckpt = torch.load(pretrained_weights, map_location="cpu", weights_only=False)
+    weights = ckpt.get(checkpoint_key, ckpt) if (checkpoint_key is not None and isinstance(ckpt, dict)) else ckpt
+    if weights is not ckpt:
+        print("checkpoint %s: using the %r entry" % (pretrained_weights, checkpoint_key))
+    ddp_prefix = "module."  # utils.save_on_master stores the DistributedDataParallel-wrapped student
+    weights = {(name[len(ddp_prefix):] if name.startswith(ddp_prefix) else name).replace("." + ddp_prefix, "."): tensor for name, tensor in weights.items()}
+    report = model.load_state_dict(weights, strict=False)
+    print("checkpoint %s loaded (non-strict): %s" % (pretrained_weights, report))
+    return report
 
 
 @torch.no_grad()
