@@ -273,6 +273,9 @@ def check_full_vil_case(name, dev, fp, bounds, record=None):
     """Vision Longformer at full width (vil_tiny: sliding-chunk attention in stages 1-2, head_dim 48 in stage 1, full attention in
     stages 3-4): module tree, outputs, loss, centres, every gradient norm, sampled gradients and the forward_return_n_last_blocks hook
     against the step of the REFERENCE's own MsViT built from its yaml (tests/golden/full_vil.pt, oracle/gen_golden.py:gen_full_vil)"""
+    from esvit_amd.models import vision_longformer as _vil
+    _vil.SAME_SIZE_RESAMPLING = "cpu"  # the fixture is the reference's CPU run (torch's CPU bicubic kernel resamples at the construction resolution)
+
     g = torch.load(FULL_VIL_GOLD, map_location="cpu", weights_only=False)[name]
     student, loss_fn, s_out, t_out, loss = run_full_cfg_case(name, dev)
     assert [k for k, _ in student.named_parameters()] == g["param_names"]
