@@ -265,7 +265,8 @@ def linear_dgrad(dy, w, *, gelu_preact=None, out_f32=False, quick=False):
         # a very long reduction (DINOHead last layer: K = out_dim) over few output tiles: the wide-tile loop, split-K to fill the chip
         kern = FORCE_GEMM_KERNEL
         if FORCE_GEMM_KERNEL == GEMM_AUTO and dy.dtype == torch.bfloat16 and Kin >= 192:
-            kern = GEMM_P8 if (Nout % 64 == 0 and Kin % 256 == 0) else GEMM_DMA8
+            # (the eight-phase loop addresses its operands with 32-bit DMA offsets: d(logits) below 4 GiB)
+            kern = GEMM_P8 if (Nout % 64 == 0 and Kin % 256 == 0 and dy.numel() * 2 < 0xfff00000) else GEMM_DMA8
         _, tm, tn, slots = gemm_select(dy.dtype, M=M, N=Kin, K=Nout, b_kstrided=1, kernel=kern)
         tiles = (-(-M // tm)) * (-(-Kin // tn))
         if tiles <= slots // 2:
