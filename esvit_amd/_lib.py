@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libesvit_hip.so")
+LIB_PATH = os.environ.get("ESVIT_HIP_LIB") or os.path.join(_HERE, "lib", "libesvit_hip.so")  # (the override: A/B builds of tools/)
 
 F32, BF16 = 0, 1
 EPI_NONE, EPI_GELU, EPI_GELU_BWD, EPI_QGELU, EPI_QGELU_BWD = 0, 1, 2, 3, 4

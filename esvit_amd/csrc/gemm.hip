@@ -60,9 +60,9 @@ GemmChoice choose(int dtype, const esvit_gemm_desc& d) {
         return c;
     }
     int want = d.kernel;
-    if (d.rowstat) {  // the statistics epilogue: the 256 x 256 eight-phase loop (32-column blocks) where the problem is whole tiles of
-                      // it and wide enough to fill the chip, else the 128 x 128 tile (2 x 2 waves of 64 x 64, 64-column blocks)
-        const bool p8 = (want == ESVIT_GEMM_P8 || (want == ESVIT_GEMM_AUTO && (long)(d.M / 256) * (d.N / 256) >= 1024)) && p8_supports(dtype, d);
+    if (d.rowstat) {  // the statistics epilogue: the 128 x 128 tile (2 x 2 waves of 64 x 64, 64-column blocks); on request the 256 x 256
+                      // eight-phase loop (32-column blocks, whole tiles only)
+        const bool p8 = want == ESVIT_GEMM_P8 && p8_supports(dtype, d);  // (AUTO: in the step the 128-row loop is 3-5 % faster, see below)
         c.kernel = p8 ? ESVIT_GEMM_P8 : ESVIT_GEMM_DMA4;
         c.bm = c.bn = p8 ? 256 : 128;
         return c;
@@ -72,20 +72,20 @@ GemmChoice choose(int dtype, const esvit_gemm_desc& d) {
         const int nz = d.splitk > 1 ? d.splitk : (d.batch > 1 ? d.batch : 1);
         const long t8 = (long)ceil_div(d.M, 256) * ceil_div(d.N, 256);
         const bool gelu_bwd_ = d.epilogue == ESVIT_EPI_GELU_BWD || d.epilogue == ESVIT_EPI_QGELU_BWD;
-        if (p8_supports(dtype, d) && d.batch <= 1 && !d.a_kstrided && d.K >= 2048 && d.N % 256 == 0 && d.M >= 4096 && !gelu_bwd_ &&
-            (d.N >= 768 || d.splitk > 1)) {
-            // Long reductions over whole 256-column tiles: the eight-phase loop multiplies a 256 x 256 x 64 k-tile in ~1.9 us where the
-            // 128-row loops need ~2.3 us for the same work (profiles/r04_gemm_kernels_b128.jsonl: stage-3 / head data gradients and
-            // fc2 forward -14..-18 %, the split-K data gradient of the 65536-wide last layer 900 -> 769 us).
+#ifdef ESVIT_NO_P8_ROUTING  // tools/ab_routing.sh only: the round-3 choice, for a same-box A/B of the rules below
+        if (false) {
+#else
+        // The eight-phase loops win most problems in ISOLATION (tools/bench_gemm.py: operands of the repeated call stay in the 256 MiB
+        // Infinity Cache) and lose most of them INSIDE the step, where every operand comes cold from HBM and one workgroup per CU with
+        // 64 KiB of requests in flight tolerates that latency worse than two 4-wave workgroups (tools/trace_ab.sh, per-launch in-step
+        // durations, profiles/r04_gemm_instep_ab.txt: weight gradients +31..+160 %, the 65536-wide logits + row statistics +3..5 %,
+        // 384-wide data gradients +11 %).  AUTO therefore takes them only where the in-step trace shows a gain:
+        //   * forward GEMMs with a residual epilogue over a long reduction (stage-3 fc2: K = 3072, -13.5 %);
+        //   * the split-K data gradient of the 65536-wide last layer (-5 %; ops.linear_dgrad asks for it by name).
+        if (p8_supports(dtype, d) && d.batch <= 1 && !d.a_kstrided && !d.b_kstrided && d.residual && d.out_f32 && d.K >= 2048 && d.N % 256 == 0 &&
+            d.N >= 768 && d.M >= 4096) {
             want = ESVIT_GEMM_P8;
-        } else if (p8_supports(dtype, d) && d.batch <= 1 && d.a_kstrided && d.M % 256 == 0 && d.N % 256 == 0 && (long)d.M * d.N >= 2000000L) {
-            // weight gradients with many whole 256 x 256 tiles (head, last layer, stage-3 MLP): -3..-10 %
-            want = ESVIT_GEMM_P8;
-        } else if (p8n_supports(dtype, d) && d.batch <= 1 && !d.a_kstrided && d.b_kstrided && d.epilogue == ESVIT_EPI_NONE && !d.out_f32 && !d.bias &&
-                   d.splitk <= 1 && d.N % 128 == 0 && d.N <= 512 && d.K >= 384 && d.M >= 16384) {
-            // plain data gradients onto 384-wide activations (stage 2 qkv / proj): 128-wide tiles with the stores riding on the next
-            // tile's k-loop, -6..-9 %
-            want = ESVIT_GEMM_P8N;
+#endif
         } else if (!d.a_kstrided && !d.rowmap && d.K >= 4096 && d.N >= 192 && t8 * nz >= 128) {
             // One 256 x 256 tile per CU has no second workgroup to hide its prologue / epilogue behind: measured
             // (profiles/r02_gemm_kernels_b128_first.jsonl) it wins only where the main loop is very long -- the dgrad of

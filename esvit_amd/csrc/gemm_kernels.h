@@ -419,7 +419,11 @@ __device__ __forceinline__ u32x4_t pair_rows(const f32x4& x, const f32x4& y) {
 // kernel follows at once.
 template <typename V>
 __device__ __forceinline__ void store_stream(V* dst, const V& v) {
+#ifdef ESVIT_NO_NT_STORES  // tools/ab_routing.sh only
+    *dst = v;
+#else
     __builtin_nontemporal_store(v, dst);
+#endif
 }
 
 // bf16 row block: v[j] = this lane's four columns of block j -> dst (the lane's row, at the wave tile's first column)

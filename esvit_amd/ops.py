@@ -5,6 +5,7 @@ allocates) and enqueues on torch's current stream.  There is no CPU or eager fal
 non-CUDA tensor is an error.  Shapes and semantics are documented in include/esvit_hip.h.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -235,7 +236,7 @@ def linear_fwd(x, w, bias=None, *, gelu=False, want_preact=False, residual=None,
         y = torch.empty((M, N), dtype=x.dtype, device=x.device)
         cen = None if cen is None else _f32c(cen)
         # the statistics come in blocks of 64 columns from the 128-row loop, of 32 columns from the 256 x 256 eight-phase loop
-        kern = gemm_select(x.dtype, M=M, N=N, K=K, rowstat=y, kernel=GEMM_AUTO)[0]
+        kern = gemm_select(x.dtype, M=M, N=N, K=K, rowstat=y)[0]
         nb = N // (32 if kern == GEMM_P8 else 64)
         st = torch.empty((M, nb, 2), dtype=torch.float32, device=x.device)
         _gemm(x.dtype, A=x, B=w, C=y, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, rowstat=st, rowstat_center=cen, rowstat_scale=float(inv_temp) * LOG2E,
@@ -266,7 +267,7 @@ def linear_dgrad(dy, w, *, gelu_preact=None, out_f32=False, quick=False):
         kern = FORCE_GEMM_KERNEL
         if FORCE_GEMM_KERNEL == GEMM_AUTO and dy.dtype == torch.bfloat16 and Kin >= 192:
             # (the eight-phase loop addresses its operands with 32-bit DMA offsets: d(logits) below 4 GiB)
-            kern = GEMM_P8 if (Nout % 64 == 0 and Kin % 256 == 0 and dy.numel() * 2 < 0xfff00000) else GEMM_DMA8
+            kern = GEMM_P8 if (Nout % 64 == 0 and Kin % 256 == 0 and dy.numel() * 2 < 0xfff00000 and not os.environ.get("ESVIT_NO_P8_ROUTING")) else GEMM_DMA8
         _, tm, tn, slots = gemm_select(dy.dtype, M=M, N=Kin, K=Nout, b_kstrided=1, kernel=kern)
         tiles = (-(-M // tm)) * (-(-Kin // tn))
         if tiles <= slots // 2:

@@ -616,7 +616,13 @@ def test_last_layer_row_statistics(mods, M, N, K, centred):
     w = torch.nn.functional.normalize(_rand((N, K), dev, 76), dim=1).to(dt)
     cen = (_rand((N,), dev, 77) * 0.2) if centred else None
     inv_t = 25.0 if centred else 10.0
-    y, mx, lse = ops.linear_fwd(z, w, row_stats=(inv_t, cen))
+    # (the largest case is whole 256 x 256 tiles: it runs on the eight-phase loop, whose statistics come in 32-column blocks)
+    ops.FORCE_GEMM_KERNEL = 5 if (M % 256 == 0 and N % 256 == 0 and M >= 1024) else 0
+    try:
+        assert ops.gemm_select(dt, M=M, N=N, K=K, rowstat=z)[0] == (5 if ops.FORCE_GEMM_KERNEL else 2)
+        y, mx, lse = ops.linear_fwd(z, w, row_stats=(inv_t, cen))
+    finally:
+        ops.FORCE_GEMM_KERNEL = 0
     assert torch.equal(y, ops.linear_fwd(z, w))  # the logits themselves do not change
     zero = torch.zeros(N, device=dev)
     mx0, lse0 = ops.teacher_row_stats(y, zero if cen is None else cen, inv_t)
