@@ -266,7 +266,9 @@ def test_baseline_configs_3_to_5_full_width_match_reference_golden(name, prec, l
 FULL_VIL_GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "full_vil.pt")
 # (outputs, loss, grad norms, sampled): bf16 bounds <= 3x the deltas observed on MI355X (profiles/r03_parity_observed.jsonl)
 # (observed in round 3: outputs 7.8e-3, loss 8.9e-5, gradient norms 5.5e-3, sampled gradients 3.5e-2; fp32 mode: loss exact, outputs 1.6e-6)
-FULL_VIL_BF16_BOUNDS = {"vil_tiny_k8192_b2": (2.4e-2, 2.7e-4, 1.7e-2, 0.11)}
+# (vil_small, observed in round 4: outputs 8.7e-3, loss 1.5e-4, gradient norms 4.1e-3, sampled gradients 0.108 -- the 8192 x 256 last-layer
+# direction tensor of the dense head, whose entries are ~1e-6; fp32 mode: loss exact, outputs 2.4e-6; profiles/r04_parity_observed.jsonl)
+FULL_VIL_BF16_BOUNDS = {"vil_tiny_k8192_b2": (2.4e-2, 2.7e-4, 1.7e-2, 0.11), "vil_small_k8192_b2": (2.6e-2, 4.5e-4, 1.2e-2, 0.32)}
 
 
 def check_full_vil_case(name, dev, fp, bounds, record=None):
