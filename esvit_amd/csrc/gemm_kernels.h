@@ -413,16 +413,16 @@ __device__ __forceinline__ u32x4_t pair_rows(const f32x4& x, const f32x4& y) {
     return u32x4_t{s0[0], s1[0], s0[1], s1[1]};
 }
 
-// Activation-sized GEMM outputs are written once and read by a LATER kernel, long after the L2 has turned over: they are stored
-// non-temporally, so the write stream does not evict the operand panels the running GEMM re-reads from the L2 (measured on the
-// 256 x 128 loop, profiles/r04_p8n_store_policy.txt: 187 -> 163 us on 87040 x 1536 x 384).  Split-K partials are NOT: their reduce
-// kernel follows at once.
+// Output stores of the direct epilogues.  Non-temporal stores were measured in round 4 (profiles/r04_p8_timeline.txt,
+// r04_gemm_instep_ab.txt, r04_pmc_traffic_nt.json): on the 256 x 128 two-set loop they stop the write stream from evicting the operand
+// panels (187 -> 163 us on 87040 x 1536 x 384); on the 128-row kernels of the step they change nothing in time (four-way same-box A/B)
+// and RAISE the traffic below the L2 (GEMM writes 30.4 -> 38.5 GB per step, reads 67.9 -> 61.4): plain stores here.
 template <typename V>
 __device__ __forceinline__ void store_stream(V* dst, const V& v) {
-#ifdef ESVIT_NO_NT_STORES  // tools/ab_routing.sh only
-    *dst = v;
-#else
+#ifdef ESVIT_NT_STORES  // tools/ab_routing.sh only
     __builtin_nontemporal_store(v, dst);
+#else
+    *dst = v;
 #endif
 }
 

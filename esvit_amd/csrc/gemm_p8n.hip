@@ -38,9 +38,6 @@ __device__ long* g_p8_timeline = nullptr;
 #define P8_NOW() 0
 #endif
 
-#if defined(ESVIT_NO_NT_STORES) && !defined(ESVIT_P8N_STORE_AUX)
-#define ESVIT_P8N_STORE_AUX 0
-#endif
 #ifndef ESVIT_P8N_STORE_AUX
 #define ESVIT_P8N_STORE_AUX 2  // cache policy bits of the output stores (gfx950: bit 0 sc0, bit 1 nt, bit 4 sc1): non-temporal, see store_stream
 #endif

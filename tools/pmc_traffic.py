@@ -1,5 +1,5 @@
 """Fold two rocprofv3 PMC passes (one with --pmc FETCH_SIZE, one with --pmc WRITE_SIZE; both with --kernel-trace
--f csv) of `python bench.py --steps S --warmup W --batch B` into profiles/r03_pmc_traffic.json.
+-f csv) of `python bench.py --steps S --warmup W --batch B` into profiles/r04_pmc_traffic.json (ESVIT_PMC_TRAFFIC_OUT overrides the name).
 
   python tools/pmc_traffic.py FETCH_counter_collection.csv WRITE_counter_collection.csv ARCH BATCH STEPS_TOTAL
 
@@ -9,7 +9,7 @@ at 64 bytes (MI355X_MICROARCH.md, HBM section).  Both counters sit on the L2's f
 hits are included: this is traffic below the L2, an upper bound on HBM traffic."""
 import collections, csv, json, os, re, sys
 
-GEMM_KERNELS = ("gemm_dma_kernel", "gemm_kernel", "splitk_reduce_kernel")
+GEMM_KERNELS = ("gemm_dma_kernel", "gemm_kernel", "gemm_p8_kernel", "gemm_p8n_kernel", "splitk_reduce_kernel")
 
 
 def family(name):
@@ -35,7 +35,7 @@ def main():
     total = sum(v["fetch_bytes_per_step"] + v["write_bytes_per_step"] for v in per_kernel.values())
     run = {"arch": arch, "batch": batch, "steps_counted": steps, "gemm_bytes_per_step": gemm, "all_kernels_bytes_per_step": total,
            "fetch_correction": 2.0, "per_kernel": per_kernel}
-    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r03_pmc_traffic.json")
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", os.environ.get("ESVIT_PMC_TRAFFIC_OUT", "r04_pmc_traffic.json"))
     doc = {"runs": []}
     if os.path.exists(out):
         with open(out) as fh:
