@@ -96,7 +96,7 @@ SIGNATURES = {
     "esvit_scale_inplace": (C.c_int, [C.c_int, vp, i64, vp, vp]),
     "esvit_center_ema": (C.c_int, [vp, vp, f32, f32, C.c_int, vp]),
     "esvit_grad_sqnorm": (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_int, vp, vp]),
-    "esvit_fused_clip_update_ema": (C.c_int, [C.c_int, vp, C.c_int, vp, C.c_int, vp, f32, f32, f32, f32, f32, f32, f32, vp]),
+    "esvit_fused_clip_update_ema": (C.c_int, [C.c_int, vp, C.c_int, vp, C.c_int, vp, f32, f32, f32, f32, f32, f32, f32, vp, vp]),
 }
 
 

@@ -71,10 +71,14 @@ __global__ __launch_bounds__(256) void grad_sqnorm_kernel(const long* __restrict
 // (main_esvit.py:546-551).  There is no host synchronisation here, so the update kernels look at the per-tensor statistics
 // themselves: if any of them is NaN / inf (a non-finite loss poisons every gradient), the whole update -- student, moments,
 // teacher EMA, weight copies -- is skipped and the state stays what it was; the host finds the non-finite loss at its next look.
-__device__ __forceinline__ bool stats_not_finite(const float* __restrict__ stats, int nstats) {
+// `skipped` (optional device counter): bumped once per skipped update launch, so that the host can tell -- at its next look -- how many
+// updates did not happen (a gradient overflow with a FINITE loss would otherwise go unnoticed) and take them back out of its step counts.
+__device__ __forceinline__ bool stats_not_finite(const float* __restrict__ stats, int nstats, int* __restrict__ skipped) {
     int bad = 0;
     for (int i = threadIdx.x; i < nstats; i += 256) bad |= !(fabsf(stats[i]) <= 3.0e38f);
-    return __syncthreads_or(bad) != 0;
+    const bool any = __syncthreads_or(bad) != 0;
+    if (any && skipped && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(skipped, 1);
+    return any;
 }
 
 __device__ __forceinline__ void adamw_elem(float& p, float g, float& m, float& v, float decay, float b1, float b2, float step_size,
@@ -88,8 +92,8 @@ __device__ __forceinline__ void adamw_elem(float& p, float g, float& m, float& v
 
 __global__ __launch_bounds__(256) void clip_adamw_ema_kernel(const long* __restrict__ tensors, const int* __restrict__ chunks,
                                                              const float* __restrict__ sqnorms, int nstats, float clip, float lr, float wd,
-                                                             float b1, float b2, float eps, float ema_m) {
-    if (stats_not_finite(sqnorms, nstats)) return;
+                                                             float b1, float b2, float eps, float ema_m, int* __restrict__ skipped) {
+    if (stats_not_finite(sqnorms, nstats, skipped)) return;
     const int tid = chunks[2 * blockIdx.x], ci = chunks[2 * blockIdx.x + 1];
     const long* tt = tensors + (long)tid * TFIELDS;
     float* p = reinterpret_cast<float*>(tt[0]);
@@ -167,8 +171,8 @@ __global__ __launch_bounds__(256) void clip_adamw_ema_kernel(const long* __restr
 template <bool LARS>
 __global__ __launch_bounds__(256) void clip_momentum_ema_kernel(const long* __restrict__ tensors, const int* __restrict__ chunks,
                                                                 const float* __restrict__ stats, int nstats, float clip, float lr, float wd,
-                                                                float momentum, float eta, float ema_m) {
-    if (stats_not_finite(stats, nstats)) return;
+                                                                float momentum, float eta, float ema_m, int* __restrict__ skipped) {
+    if (stats_not_finite(stats, nstats, skipped)) return;
     const int tid = chunks[2 * blockIdx.x], ci = chunks[2 * blockIdx.x + 1];
     const long* tt = tensors + (long)tid * TFIELDS;
     float* p = reinterpret_cast<float*>(tt[0]);
@@ -239,19 +243,19 @@ extern "C" int esvit_grad_sqnorm(const int64_t* tensors, int ntensors, const int
 
 extern "C" int esvit_fused_clip_update_ema(int rule, const int64_t* tensors, int ntensors, const int32_t* chunks, int nchunks,
                                            const float* sqnorms, float clip, float lr, float wd, float beta1, float beta2, float eps,
-                                           float ema_m, esvit_stream_t s_) {
+                                           float ema_m, int32_t* skipped, esvit_stream_t s_) {
     hipStream_t stream = reinterpret_cast<hipStream_t>(s_);
     ESVIT_CHECK_ARG(tensors && chunks && sqnorms && ntensors > 0 && nchunks > 0, "esvit_fused_clip_update_ema: bad args");
     ESVIT_CHECK_ARG(rule == ESVIT_RULE_ADAMW || rule == ESVIT_RULE_SGD || rule == ESVIT_RULE_LARS, "esvit_fused_clip_update_ema: bad rule %d", rule);
     if (rule == ESVIT_RULE_ADAMW)
         hipLaunchKernelGGL(clip_adamw_ema_kernel, dim3(nchunks), dim3(256), 0, stream, (const long*)tensors, chunks, sqnorms, ntensors, clip, lr, wd,
-                           beta1, beta2, eps, ema_m);
+                           beta1, beta2, eps, ema_m, skipped);
     else if (rule == ESVIT_RULE_SGD)
         hipLaunchKernelGGL(clip_momentum_ema_kernel<false>, dim3(nchunks), dim3(256), 0, stream, (const long*)tensors, chunks, sqnorms, ntensors,
-                           clip, lr, wd, beta1, beta2, ema_m);
+                           clip, lr, wd, beta1, beta2, ema_m, skipped);
     else
         hipLaunchKernelGGL(clip_momentum_ema_kernel<true>, dim3(nchunks), dim3(256), 0, stream, (const long*)tensors, chunks, sqnorms, 3 * ntensors,
-                           clip, lr, wd, beta1, beta2, ema_m);
+                           clip, lr, wd, beta1, beta2, ema_m, skipped);
     ESVIT_CHECK_LAUNCH("fused_clip_update_ema");
     return ESVIT_OK;
 }

@@ -326,6 +326,14 @@ def train_one_epoch(student, teacher, teacher_without_ddp, dino_loss, data_loade
             if not math.isfinite(v):
                 print("Loss is {}, stopping training".format(v))
                 sys.exit(1)
+            # a gradient overflow with a FINITE loss (bf16 backward) is refused by the update kernel too: say so, take the refused
+            # updates back out of the step counts, and stop when nothing but refusals happened since the last look
+            refused = tr.updater.take_skipped()
+            if refused:
+                print("WARNING: %d of the last %d updates were skipped (non-finite gradients, finite loss)" % (refused, min(10, it + 1)))
+                if refused >= min(10, it + 1) and it >= 10:
+                    print("every update since the last check was skipped, stopping training")
+                    sys.exit(1)
     mean = loss_sum / max(n_it, 1)
     if _world() > 1:  # metric_logger.synchronize_between_processes (main_esvit.py:597)
         dist.all_reduce(mean)

@@ -170,7 +170,6 @@ class DINOLoss(_DeferredCenter, nn.Module):
             if int((S.abs() > tol).sum(1).max()) > 2:
                 raise NotImplementedError("DINOLoss mixup targets that are not (at most two entries per column) + (one constant per crop): "
                                           "the four-term cross-entropy kernel and the mean-teacher term cover mixup / cutmix / label smoothing")
-            self.__dict__["_mixup_smoothed"] = bool((off > 0).any())
             self.__dict__["_mixup_checked"] = True
         w2, a2 = torch.topk(S.abs(), 2, dim=1)                                                   # [ncrops, 2, b]
         w2 = torch.gather(S, 1, a2)
@@ -219,7 +218,10 @@ class DINOLoss(_DeferredCenter, nn.Module):
         if targets_mixup:
             tmatch, tw, off = self._mixup_terms(targets_mixup, B, s.device)
             row_loss, ds = o.dino_ce(s.detach(), t, self.center, mx, lse, tmatch, None, inv_st, inv_tt, term_w=tw)
-            if self.__dict__.get("_mixup_smoothed"):
+            # The constant part of the targets (label smoothing) is scored on EVERY call unless the caller declared it absent
+            # (mixup_smoothing = 0.0): whether a batch carries it is not latched from the first batch -- with off = 0 the
+            # term is an exact no-op that costs a handful of small launches on the mixup path only.
+            if getattr(self, "mixup_smoothing", None) is None or self.mixup_smoothing > 0:
                 row2, ds2 = self._smoothing_term(o, s, t, mx, lse, off, B, inv_st, inv_tt)
                 row_loss, ds = row_loss + row2, ds + ds2
         else:

@@ -785,10 +785,10 @@ def grad_sqnorm(tensors, ntensors, chunks, nchunks, sqnorms, stats=1):
     check(lib.esvit_grad_sqnorm(_p(tensors), ntensors, _p(chunks), nchunks, int(stats), _p(sqnorms), _stream()), "grad_sqnorm")
 
 
-def fused_clip_update_ema(rule, tensors, ntensors, chunks, nchunks, sqnorms, clip, lr, wd, beta1, beta2, eps, ema_m):
+def fused_clip_update_ema(rule, tensors, ntensors, chunks, nchunks, sqnorms, clip, lr, wd, beta1, beta2, eps, ema_m, skipped=None):
     """rule AdamW: (beta1, beta2, eps); SGD: beta1 = momentum; LARS: beta1 = momentum, beta2 = eta"""
     check(lib.esvit_fused_clip_update_ema(int(rule), _p(tensors), ntensors, _p(chunks), nchunks, _p(sqnorms), clip, lr, wd, beta1, beta2,
-                                          eps, ema_m, _stream()), "fused_clip_update_ema")
+                                          eps, ema_m, _p(skipped), _stream()), "fused_clip_update_ema")
 
 
 # ------------------------------------------------------------------------------------------------

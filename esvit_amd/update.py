@@ -83,6 +83,10 @@ class FusedClipAdamWEMA:
         self.nchunks = len(chunks)
         self.chunks = torch.tensor(chunks, dtype=torch.int32).to(dev)
         self.sqnorms = torch.zeros(len(self.params) * (3 if rule == "lars" else 1), dtype=torch.float32, device=dev)
+        # updates the kernel refused (a non-finite gradient statistic): counted on the device, collected by take_skipped()
+        self.skipped = torch.zeros(1, dtype=torch.int32, device=dev)
+        self._skipped_seen = 0
+        self._stepped_log = []  # per update launch since the last take_skipped(): the parameter indices whose step count it advanced
         # ring of pinned staging tables: a buffer is rewritten only after the async H2D copy that read it completed
         self._ring = [torch.zeros((len(self.params), TFIELDS), dtype=torch.int64).pin_memory() for _ in range(4)]
         self._ring_np = [t.numpy() for t in self._ring]
@@ -120,12 +124,17 @@ class FusedClipAdamWEMA:
             self._ring_ev[slot].synchronize()
         tab = self._ring_np[slot]
         gptr, flags, bcs = [0] * len(self.params), [0] * len(self.params), [0] * len(self.params)
+        stepped = []
+        self._stepped_log.append(stepped)
+        if len(self._stepped_log) > 4096:  # (nobody collects: keep the log bounded)
+            del self._stepped_log[:2048]
         for i, p in enumerate(self.params):
             g = p.grad
             if g is None or not self.trainable[i] or (skip_last_layer and "last_layer" in self.names[i]):
                 continue
             assert g.is_contiguous() and g.dtype == torch.float32
             self.steps[i] += 1
+            stepped.append(i)
             t = self.steps[i]
             bc = self._bc_cache.get(t)
             if bc is None:
@@ -157,7 +166,7 @@ class FusedClipAdamWEMA:
         else:
             rule, h1, h2 = (ops.RULE_SGD if self.rule == "sgd" else ops.RULE_LARS), self.momentum, self.eta
         ops.fused_clip_update_ema(rule, self._table_dev, n, self.chunks, self.nchunks, self.sqnorms, float(clip_grad or 0.0), float(lr),
-                                  float(weight_decay), h1, h2, self.eps, float(ema_momentum))
+                                  float(weight_decay), h1, h2, self.eps, float(ema_momentum), skipped=self.skipped)
         P.invalidate()          # parameters changed behind autograd's back ...
         P.mark_fresh(fresh)     # ... but these cached casts were rewritten by the kernel
         for g in self.param_groups:
@@ -165,6 +174,20 @@ class FusedClipAdamWEMA:
         self.param_groups[0]["weight_decay"] = float(weight_decay)
         if self.bound is not None:
             self._publish_bound_state(lr, weight_decay)
+
+    def take_skipped(self):
+        """How many update launches since the last call were refused by the kernel's non-finite guard (SYNCHRONISES with the
+        device).  Their step counts (the bias correction of AdamW, the 'step' entries of the optimizer state) are taken back: a
+        refused update advanced nothing.  Which launches were refused is not recorded, only how many; the launches of one epoch step
+        the same parameters, so the most recent ones are rolled back."""
+        total = int(self.skipped.item())
+        new = total - self._skipped_seen
+        self._skipped_seen = total
+        for stepped in self._stepped_log[len(self._stepped_log) - new:] if new > 0 else []:
+            for i in stepped:
+                self.steps[i] -= 1
+        self._stepped_log = []
+        return new
 
     # ---- a torch.optim.AdamW bound to this updater (integration level L2 with the unmodified train_esvit) -------------
     def _refresh_static_rows(self, i):

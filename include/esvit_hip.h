@@ -352,7 +352,9 @@ int esvit_center_ema(float* center, const float* colsum, float momentum, float d
  * esvit_grad_sqnorm: stats = 1: sqnorms fp32 [ntensors] = sum g^2;  stats = 3 (LARS): fp32 [ntensors*3] =
  * (sum g^2, sum p^2, sum g p) per tensor.  esvit_fused_clip_update_ema reads the layout its rule needs.
  * Non-finite guard: if ANY statistic is NaN / inf (a non-finite loss poisons every gradient) the update launch is a no-op --
- * student, moments, teacher and weight copies keep their values (the reference exits before its update, main_esvit.py:546-551). */
+ * student, moments, teacher and weight copies keep their values (the reference exits before its update, main_esvit.py:546-551);
+ * `skipped` (device int32, may be NULL) is then incremented by one, so that a host that looks at the loss only now and then can still
+ * count the updates that did not happen (a gradient overflow with a finite loss) and correct its step counters. */
 #define ESVIT_RULE_ADAMW 0
 #define ESVIT_RULE_SGD 1
 #define ESVIT_RULE_LARS 2
@@ -360,7 +362,7 @@ int esvit_grad_sqnorm(const int64_t* tensors, int ntensors, const int32_t* chunk
                       float* sqnorms, esvit_stream_t stream);
 int esvit_fused_clip_update_ema(int rule, const int64_t* tensors, int ntensors, const int32_t* chunks, int nchunks,
                                 const float* sqnorms, float clip, float lr, float wd, float beta1,
-                                float beta2, float eps, float ema_m, esvit_stream_t stream);
+                                float beta2, float eps, float ema_m, int32_t* skipped, esvit_stream_t stream);
 
 /* ---- CvT backbone pieces (BASELINE config 5) ------------------------------
  * Token-major NHWC activations.  cvt_v4_transformer.py:349-382 (ConvEmbed), :75-105 (DepthWiseConv2d = dw 3x3 +

@@ -776,10 +776,13 @@ def test_fused_update_skips_non_finite_step(mods, rule):
         torch.cuda.synchronize()
 
     step(None)
+    assert opt.take_skipped() == 0 and set(opt.steps) == {1}
     snap = [p.detach().clone() for p in list(net.parameters()) + list(teacher.parameters()) + list(opt.exp_avg)]
     for bad in (float("nan"), float("inf")):
         step(bad)
         now = list(net.parameters()) + list(teacher.parameters()) + list(opt.exp_avg)
         assert all(torch.equal(a, b.detach()) for a, b in zip(snap, now)), "a non-finite step changed the state"
+    # the refused updates are counted on the device and come back out of the host's step counts
+    assert set(opt.steps) == {3} and opt.take_skipped() == 2 and set(opt.steps) == {1} and opt.take_skipped() == 0
     step(None)
-    assert not torch.equal(snap[0], list(net.parameters())[0].detach())
+    assert not torch.equal(snap[0], list(net.parameters())[0].detach()) and set(opt.steps) == {2}

@@ -473,6 +473,72 @@ def test_eval_linear_probe_gpu(lib_built):
         _teardown()
 
 
+def test_logit_stats_handover_is_taken_and_falls_back(lib_built):
+    """engine.EsvitTrainer arms the heads so that their last-layer GEMMs emit the softmax row statistics of the coming loss
+    (esvit_gemm_desc::rowstat -> loss.py): (1) with every logits tensor in whole 128-row tiles the loss really takes them -- not one
+    esvit_teacher_row_stats launch in the step, and the CE kernel is handed the student statistics; (2) a centre update between the
+    forwards and the loss changes the token, the loss falls back to its own passes and equals the un-armed loss (nothing
+    tested which path ran)"""
+    import esvit_amd.loss as L
+    from esvit_amd import engine, ops
+    dev = _setup("bf16")
+    calls = {"teacher_row_stats": 0, "ce_with_student_stats": 0, "ce": 0}
+    real_trs, real_ce = ops.teacher_row_stats, ops.dino_ce
+
+    def trs(*a, **k):
+        calls["teacher_row_stats"] += 1
+        return real_trs(*a, **k)
+
+    def ce(*a, **k):
+        calls["ce"] += 1
+        calls["ce_with_student_stats"] += int(k.get("s_stats") is not None)
+        return real_ce(*a, **k)
+    try:
+        ops.teacher_row_stats, ops.dino_ce = trs, ce
+        K, B = GU.NANO_HEAD["out_dim"], 64  # rows: student 10 B / 170 B, teacher 2 B / 98 B -- all whole 128-row tiles at B = 64
+        crops = _to(GU.make_crops(B, seed=91), dev)
+
+        def fresh():
+            torch.manual_seed(5)
+            student, teacher = nano_pair()
+            loss_fn = L.DDINOLoss(K, 10, 0.04, 0.07, 5, 10).to(dev)
+            loss_fn.center.normal_(0, 0.05)
+            loss_fn.center_grid.normal_(0, 0.05)
+            return student.to(dev), teacher.to(dev), loss_fn
+        # (1) the armed step
+        student, teacher, loss_fn = fresh()
+        tr = engine.EsvitTrainer(student, teacher, loss_fn, clip_grad=3.0, freeze_last_layer=0)
+        tr.step(crops, 1e-4, 0.04, 0.996, 0)  # (first step: one stream, fills the tables)
+        for k in calls:
+            calls[k] = 0
+        tr.step(crops, 1e-4, 0.04, 0.996, 0)
+        assert L.LOGIT_STATS and calls["teacher_row_stats"] == 0, calls
+        assert calls["ce"] >= 2 and calls["ce_with_student_stats"] == calls["ce"], calls
+        # (2) armed forwards, then the centres move before the loss is called: own passes, same value as a loss that was never armed
+        student, teacher, loss_fn = fresh()
+        with torch.no_grad():
+            loss_fn.arm_logit_stats(student, teacher, 0)
+            s_out, t_out = student(crops), teacher(crops[:2])
+            loss_fn.disarm_logit_stats(student, teacher)
+            loss_fn.center.add_(0.01)
+            loss_fn.center_grid.sub_(0.02)
+            loss_fn._center_version += 1
+            for k in calls:
+                calls[k] = 0
+            armed_then_stale = loss_fn(s_out, t_out, 0).item()
+            assert calls["teacher_row_stats"] >= 2, calls  # both teacher levels fell back to their own pass
+        student, teacher, loss_fn = fresh()
+        with torch.no_grad():
+            s_out, t_out = student(crops), teacher(crops[:2])
+            loss_fn.center.add_(0.01)
+            loss_fn.center_grid.sub_(0.02)
+            never_armed = loss_fn(s_out, t_out, 0).item()
+        assert abs(armed_then_stale - never_armed) < 1e-6, (armed_then_stale, never_armed)
+    finally:
+        ops.teacher_row_stats, ops.dino_ce = real_trs, real_ce
+        _teardown()
+
+
 def test_train_one_epoch_drop_in_gpu(lib_built):
     """engine.train_one_epoch (the reference's signature, main_esvit.py:499-501) with the torch.optim.AdamW the unmodified
     train_esvit builds (main_esvit.py:408-411): two batches equal two EsvitTrainer.step calls; the caller's optimizer holds
