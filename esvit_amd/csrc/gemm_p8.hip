@@ -63,7 +63,8 @@ __device__ __forceinline__ void wait_lgkmcnt() {
 
 // masked epilogue of one quadrant (ragged edge tiles, unaligned operands): every option of the descriptor, four columns at a time
 __device__ __forceinline__ void p8_epilogue_masked(const esvit_gemm_desc& p, f32x4 (&acc)[4][2], long wrow0, int wcol0, int z) {
-    const int lane = threadIdx.x & 63;
+    int lane = threadIdx.x & 63;
+    asm volatile("" : "+v"(lane));  // (the lane-dependent address pieces are recomputed here: kept live across the k-loop they get spilled)
     const int c = lane & 15, g = lane >> 4;
     const int M = p.M, N = p.N;
     const int mode = p.epilogue;
@@ -118,7 +119,8 @@ enum { P8_BF16 = 0,      // C (bf16) = alpha acc + bias
 // (residual / GELU pre-activation) are all requested before its first store: vmcnt retires in order.
 template <int EPI>
 __device__ __forceinline__ void p8_epilogue_fast(const esvit_gemm_desc& p, f32x4 (&acc)[4][2], long wrow0, int wcol0, int z) {
-    const int lane = threadIdx.x & 63;
+    int lane = threadIdx.x & 63;
+    asm volatile("" : "+v"(lane));  // (the lane-dependent address pieces are recomputed here: kept live across the k-loop they get spilled)
     const int c = lane & 15, g = lane >> 4;
     const long row = wrow0 + c;
     const int col = wcol0 + 4 * g;
