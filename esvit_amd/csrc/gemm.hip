@@ -62,7 +62,11 @@ GemmChoice choose(int dtype, const esvit_gemm_desc& d) {
     int want = d.kernel;
     if (d.rowstat) {  // the statistics epilogue: the 128 x 128 tile (2 x 2 waves of 64 x 64, 64-column blocks); on request the 256 x 256
                       // eight-phase loop (32-column blocks, whole tiles only)
-        const bool p8 = want == ESVIT_GEMM_P8 && p8_supports(dtype, d);  // (AUTO: in the step the 128-row loop is 3-5 % faster, see below)
+#ifdef ESVIT_P8_ROWSTAT_AUTO  // tools/ab_routing.sh only
+        const bool p8 = (want == ESVIT_GEMM_P8 || (want == ESVIT_GEMM_AUTO && (long)(d.M / 256) * (d.N / 256) >= 1024)) && p8_supports(dtype, d);
+#else
+        const bool p8 = want == ESVIT_GEMM_P8 && p8_supports(dtype, d);
+#endif
         c.kernel = p8 ? ESVIT_GEMM_P8 : ESVIT_GEMM_DMA4;
         c.bm = c.bn = p8 ? 256 : 128;
         return c;
@@ -75,16 +79,25 @@ GemmChoice choose(int dtype, const esvit_gemm_desc& d) {
 #ifdef ESVIT_NO_P8_ROUTING  // tools/ab_routing.sh only: the round-3 choice, for a same-box A/B of the rules below
         if (false) {
 #else
-        // The eight-phase loops win most problems in ISOLATION (tools/bench_gemm.py: operands of the repeated call stay in the 256 MiB
-        // Infinity Cache) and lose most of them INSIDE the step, where every operand comes cold from HBM and one workgroup per CU with
-        // 64 KiB of requests in flight tolerates that latency worse than two 4-wave workgroups (tools/trace_ab.sh, per-launch in-step
-        // durations, profiles/r04_gemm_instep_ab.txt: weight gradients +31..+160 %, the 65536-wide logits + row statistics +3..5 %,
-        // 384-wide data gradients +11 %).  AUTO therefore takes them only where the in-step trace shows a gain:
-        //   * forward GEMMs with a residual epilogue over a long reduction (stage-3 fc2: K = 3072, -13.5 %);
-        //   * the split-K data gradient of the 65536-wide last layer (-5 %; ops.linear_dgrad asks for it by name).
-        if (p8_supports(dtype, d) && d.batch <= 1 && !d.a_kstrided && !d.b_kstrided && d.residual && d.out_f32 && d.K >= 2048 && d.N % 256 == 0 &&
-            d.N >= 768 && d.M >= 4096) {
+        // The eight-phase loop (staggered schedule) is taken where the PER-LAUNCH IN-STEP trace shows a gain (tools/trace_ab.sh,
+        // profiles/r04_gemm_instep_ab.txt, section 5): long reductions over whole 256-column tiles -- stage-3 / head data gradients
+        // -12..-16 %, stage-3 fc2 forward -25 %, head fc2 forward -6..-9 %, the split-K data gradient of the last layer -6 %, its
+        // weight gradient -11 %.  NOT taken: 384-wide data gradients on the 256 x 128 variant (+11 % in the step), and anything
+        // with a short reduction (the workgroup has no partner to hide its epilogue behind).
+        if (p8_supports(dtype, d) && d.batch <= 1 && !d.a_kstrided && d.K >= 2048 && d.N % 256 == 0 && d.M >= 4096 && !gelu_bwd_ &&
+            (d.N >= 768 || d.splitk > 1)) {
             want = ESVIT_GEMM_P8;
+        } else if (p8_supports(dtype, d) && d.batch <= 1 && d.a_kstrided && d.M % 256 == 0 && d.N % 256 == 0 && (long)d.M * d.N >= 2000000L
+#ifndef ESVIT_P8_WGRAD_COLSUM  // tools/ab_routing.sh: weight gradients with the fused bias gradient too
+                   && !d.colsum
+#endif
+        ) {
+            want = ESVIT_GEMM_P8;
+#ifdef ESVIT_P8_BROAD_ROUTING  // tools/ab_routing.sh only
+        } else if (p8n_supports(dtype, d) && d.batch <= 1 && !d.a_kstrided && d.b_kstrided && d.epilogue == ESVIT_EPI_NONE && !d.out_f32 && !d.bias &&
+                   d.splitk <= 1 && d.N % 128 == 0 && d.N <= 512 && d.K >= 384 && d.M >= 16384) {
+            want = ESVIT_GEMM_P8N;
+#endif
 #endif
         } else if (!d.a_kstrided && !d.rowmap && d.K >= 4096 && d.N >= 192 && t8 * nz >= 128) {
             // One 256 x 256 tile per CU has no second workgroup to hide its prologue / epilogue behind: measured

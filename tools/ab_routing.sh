@@ -1,7 +1,7 @@
 #!/bin/bash
 # Same-box A/B of the round-4 GEMM changes over the default bench (and any other bench command line given after the round count):
-#   A  the product library (round-4 routing, plain output stores)      B  round-3 kernel choice (-DESVIT_NO_P8_ROUTING), non-temporal stores
-#   C  round-3 choice, plain stores (= round 3)                        D  round-4 routing, non-temporal stores
+#   A  the product library                                                 B  + P8 for weight gradients with a fused bias gradient and for the logits with row statistics
+#   C  round-3 kernel choice (-DESVIT_NO_P8_ROUTING)                       D  product routing, non-temporal output stores
 # Usage: bash tools/ab_routing.sh [build | rounds [bench args]]
 set -e
 root=$(cd "$(dirname "$0")/.." && pwd); cd $root
@@ -14,7 +14,7 @@ build_variant() {  # name, defines
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $out $objs /tmp/gemm_$1.o /tmp/gemm_p8_$1.o /tmp/gemm_p8n_$1.o
   echo built $out
 }
-build_variant B "-DESVIT_NO_P8_ROUTING -DESVIT_NT_STORES"
+build_variant B "-DESVIT_P8_WGRAD_COLSUM -DESVIT_P8_ROWSTAT_AUTO"
 build_variant C "-DESVIT_NO_P8_ROUTING"
 build_variant D "-DESVIT_NT_STORES"
 [ "$1" = "build" ] && exit 0
@@ -22,8 +22,8 @@ rounds=${1:-3}; shift || true
 ms() { python bench.py --steps 12 --warmup 3 --no-cpu-baseline --no-roofline "$@" 2>/dev/null | tail -1 | python -c "import sys,json; print('%.2f' % json.loads(sys.stdin.read())['ms_per_step'])"; }
 for r in $(seq 1 $rounds); do
   a=$(ms "$@")
-  b=$(ESVIT_HIP_LIB=$root/tools/probe/libesvit_hip_B.so ESVIT_NO_P8_ROUTING=1 ms "$@")
+  b=$(ESVIT_HIP_LIB=$root/tools/probe/libesvit_hip_B.so ms "$@")
   c=$(ESVIT_HIP_LIB=$root/tools/probe/libesvit_hip_C.so ESVIT_NO_P8_ROUTING=1 ms "$@")
   d=$(ESVIT_HIP_LIB=$root/tools/probe/libesvit_hip_D.so ms "$@")
-  echo "round $r: A routed $a   B r3-choice+nt $b   C r3-choice $c   D routed+nt $d   (ms per step)"
+  echo "round $r: A product $a   B + colsum wgrads, rowstat $b   C r3-choice $c   D product+nt $d   (ms per step)"
 done

@@ -27,10 +27,6 @@
 //        phase are retired before ITS first barrier of the phase (B0: the counted lgkmcnt below, issued first; A0, B1, A1: re-filled
 //        two or more intervals after their reads were waited for by the MFMAs that consumed them).
 //
-// (A second schedule -- LDS reads of the next half-phase slipped between the MFMAs, one barrier per phase, no stagger -- was built in
-// round 4 as well: equal on the nt probes, 25-30 % SLOWER on the k-strided layouts (two ds_read_b64_tr_b16 per fragment crowd the MFMA
-// issue slots): tools/probe/gemm_p8_pipelined.hip keeps it.)
-//
 // The epilogue works straight from the (transposed) accumulators, one 64 x 32 quadrant at a time: epilogue_direct_at (plain / bias,
 // GELU + pre-activation, GELU', residual + DropPath scale, fp32 / bf16, split-K partial); ragged edge tiles take a masked path.
 #include "gemm_kernels.h"
@@ -282,7 +278,6 @@ __global__ __launch_bounds__(P8_NT, 1) void gemm_p8_kernel(const esvit_gemm_desc
     using HA = DmaTile<AKS, 128, 64, P8_NT>;
     using HB = DmaTile<BKS, 128, 64, P8_NT>;
     static_assert(HA::INSTR_PER_WAVE == 2 && HB::INSTR_PER_WAVE == 2, "two LDS-DMA instructions per wave and half-tile");
-    constexpr int NRA = AKS ? 16 : 8;  // LDS read instructions of one A sub-tile (4 x 2 fragments)
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     typedef __attribute__((address_space(3))) void lds_void;
 
@@ -291,7 +286,6 @@ __global__ __launch_bounds__(P8_NT, 1) void gemm_p8_kernel(const esvit_gemm_desc
     const int ntiles = tiles_m * tiles_n;
     const int nz = p.splitk > 1 ? p.splitk : p.batch;
     const int total = ntiles * nz;
-    const long a_rows = AKS ? (long)K : (long)M, b_rows = BKS ? (long)K : (long)N;
 
     // Work list: item w = (z = w / ntiles, tile = w % ntiles), tiles in tile_coords order.  The dispatcher places workgroup b on XCD
     // b % 8: every XCD owns a contiguous range of the list and its gridDim.x / 8 workgroups walk it with that stride, so the tiles
@@ -331,42 +325,38 @@ __global__ __launch_bounds__(P8_NT, 1) void gemm_p8_kernel(const esvit_gemm_desc
     int voffA[2], voffB[2];
     HA::wave_offsets(p.lda, wave, lane, voffA);
     HB::wave_offsets(p.ldb, wave, lane, voffB);
-    const long a_kstep = AKS ? p.lda * 128 : 128, b_kstep = BKS ? p.ldb * 128 : 128;  // bytes per k-tile in the scalar offset
 
     // ---- the request stream ----
-    // Half-tiles are requested in ONE sequence B0 A0 B1 A1 | B0 A0 B1 A1 | ... that runs through the k-tiles of an item and on
-    // into the next item of this workgroup, seven half-tiles ahead of the k-tile being multiplied: the DMA queue does not drain
-    // at an output-tile boundary either, the first k-tiles of the next tile land while this tile's epilogue stores.  Past the end of
-    // the work the requests go through a descriptor of zero records: no memory access, and the wave's vmcnt bookkeeping is the
-    // same in every k-tile.  State: the item being requested (sw), its four half-tile descriptors, the k-tile (absolute index skt,
-    // sleft left in the item).
-    // One buffer descriptor per half-tile, based at the half's first row (k-contiguous operand) / first column (k-strided):
-    // per-lane offsets stay small, rows past the end of a k-contiguous operand fall outside num_records and read as 0.
-    __amdgpu_buffer_rsrc_t sra0, sra1, srb0, srb1;
-    int sw = w_begin + widx - per_xcd, skt = 0, sleft = 0;
-    auto half_rsrc = [&](const bf16* base, bool ks, long rows_total, long ld, int first) __attribute__((always_inline)) {
-        const bf16* b = ks ? base + first : base + (long)first * ld;
-        const long left = ks ? (rows_total * ld - first) * 2 : (rows_total - first) * ld * 2;
-        return make_rsrc(b, left);
-    };
+    // Half-tiles are requested in ONE sequence A0 B0 B1 A1 | A0 B0 B1 A1 | ... that runs through the k-tiles of an item and on into
+    // the next item of this workgroup: the DMA queue does not drain at an output-tile boundary either, the first k-tiles of the next
+    // tile land while this tile's epilogue stores.  Past the end of the work the requests go through a descriptor of zero records:
+    // no memory access, and the wave's vmcnt bookkeeping is the same in every k-tile.  ONE descriptor per operand covers the whole
+    // matrix (the scalar offset is part of the hardware range check, tools/probe/soff_probe.hip): tile origin, half and k-tile all
+    // travel in the scalar offset; reads past the end of the matrix return 0, rows / columns past M / N inside it are garbage that
+    // only reaches outputs the epilogue masks.
+    const long a_bytes = (AKS ? (long)K : (long)M) * p.lda * 2, b_bytes = (BKS ? (long)K : (long)N) * p.ldb * 2;
+    const unsigned a_kstep = AKS ? (unsigned)p.lda * 128u : 128u, b_kstep = BKS ? (unsigned)p.ldb * 128u : 128u;  // bytes per k-tile
+    const unsigned a_half = AKS ? 256u : (unsigned)p.lda * 256u, b_half = BKS ? 256u : (unsigned)p.ldb * 256u;    // bytes between the halves
+    __amdgpu_buffer_rsrc_t sra, srb;
+    unsigned soA = 0, soB = 0;  // scalar offsets of the stream's current k-tile
+    int sw = w_begin + widx - per_xcd, sleft = 0;
     auto stream_next_item = [&]() __attribute__((always_inline)) {
         sleft = 0;
         while (sleft == 0) {  // (an empty split-K slice has nothing to request)
             sw += per_xcd;
             if (sw >= w_end) {
-                sra0 = sra1 = srb0 = srb1 = make_rsrc(p.A, 0);
-                skt = 0;
+                sra = srb = make_rsrc(p.A, 0);
+                soA = soB = 0;
                 sleft = 0x7fffffff;
                 return;
             }
             const P8Item it = make_item(sw);
             const bf16* A = reinterpret_cast<const bf16*>(p.A) + (p.splitk > 1 ? 0 : (long)it.z * p.strideA);
             const bf16* B = reinterpret_cast<const bf16*>(p.B) + (p.splitk > 1 ? 0 : (long)it.z * p.strideB);
-            sra0 = half_rsrc(A, AKS, a_rows, p.lda, it.m0);
-            sra1 = half_rsrc(A, AKS, a_rows, p.lda, it.m0 + 128);
-            srb0 = half_rsrc(B, BKS, b_rows, p.ldb, it.n0);
-            srb1 = half_rsrc(B, BKS, b_rows, p.ldb, it.n0 + 128);
-            skt = it.kt0;
+            sra = make_rsrc(A, a_bytes);
+            srb = make_rsrc(B, b_bytes);
+            soA = (AKS ? (unsigned)it.m0 * 2u : (unsigned)it.m0 * (unsigned)p.lda * 2u) + (unsigned)it.kt0 * a_kstep;
+            soB = (BKS ? (unsigned)it.n0 * 2u : (unsigned)it.n0 * (unsigned)p.ldb * 2u) + (unsigned)it.kt0 * b_kstep;
             sleft = it.nk;
         }
     };
@@ -375,18 +365,17 @@ __global__ __launch_bounds__(P8_NT, 1) void gemm_p8_kernel(const esvit_gemm_desc
         constexpr int H = decltype(hc)::value;
         char* dst = smem + boff + H * P8_HALF + wave * 2048;
         if constexpr (H == H_A0 || H == H_A1) {
-            const int soff = (int)(skt * a_kstep);
-            const __amdgpu_buffer_rsrc_t r = H == H_A0 ? sra0 : sra1;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void*)(dst), 16, voffA[0], soff, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void*)(dst + 1024), 16, voffA[1], soff, 0, 0);
+            const int so = (int)(H == H_A0 ? soA : soA + a_half);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(sra, (lds_void*)(dst), 16, voffA[0], so, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(sra, (lds_void*)(dst + 1024), 16, voffA[1], so, 0, 0);
         } else {
-            const int soff = (int)(skt * b_kstep);
-            const __amdgpu_buffer_rsrc_t r = H == H_B0 ? srb0 : srb1;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void*)(dst), 16, voffB[0], soff, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void*)(dst + 1024), 16, voffB[1], soff, 0, 0);
+            const int so = (int)(H == H_B0 ? soB : soB + b_half);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(srb, (lds_void*)(dst), 16, voffB[0], so, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(srb, (lds_void*)(dst + 1024), 16, voffB[1], so, 0, 0);
         }
         if constexpr (H == H_A1) {  // the k-tile is complete: on to the next one
-            ++skt;
+            soA += a_kstep;
+            soB += b_kstep;
             if (--sleft == 0) stream_next_item();
         }
     };
@@ -396,40 +385,22 @@ __global__ __launch_bounds__(P8_NT, 1) void gemm_p8_kernel(const esvit_gemm_desc
     using I3 = std::integral_constant<int, 3>;
 
     f32x4 acc[2][2][4][2];
-    float csum[2][4];        // fused bias gradient (weight-gradient layout only): this lane's share of the row sums of op(A)
-    Frag<bf16> fa[2][4];     // [k-step][row fragment] of the current A sub-tile
-    Frag<bf16> fb[2][2][2];  // [qn][k-step][column fragment]: both B sub-tiles stay in registers (quadrant (1,0) re-uses B0)
+    float csum[2][4];            // fused bias gradient (weight-gradient layout only): this lane's share of the row sums of op(A)
+    Frag<bf16> fA[2][4];            // [k-step][row fragment] of the current A sub-tile (A0 in phases 0 / 1, A1 in phases 2 / 3)
+    Frag<bf16> fX[2][2], fY[2][2];  // [k-step][column fragment] of B0 / B1
 
-    auto read_a = [&](int boff, auto qmc) __attribute__((always_inline)) {
-        constexpr int QM = decltype(qmc)::value;
-        const bf16* lds = reinterpret_cast<const bf16*>(smem + boff + (QM ? H_A1 : H_A0) * P8_HALF);
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) fa[kk][i] = HA::frag(lds, wr * 64 + i * 16, kk, c, g);
+    // fragment r of a sub-tile (A: r = 4 kk + i, B: r = 2 kk + j) from half-tile slot H of the buffer at boff
+    auto read_a1 = [&](int boff, auto hc, auto rc) __attribute__((always_inline)) {
+        constexpr int H = decltype(hc)::value, R = decltype(rc)::value;
+        fA[R >> 2][R & 3] = HA::frag(reinterpret_cast<const bf16*>(smem + boff + H * P8_HALF), wr * 64 + (R & 3) * 16, R >> 2, c, g);
     };
-    auto read_b = [&](int boff, auto qnc) __attribute__((always_inline)) {
-        constexpr int QN = decltype(qnc)::value;
-        const bf16* lds = reinterpret_cast<const bf16*>(smem + boff + (QN ? H_B1 : H_B0) * P8_HALF);
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) fb[QN][kk][j] = HB::frag(lds, wc * 32 + j * 16, kk, c, g);
-    };
-    auto mfma_quadrant = [&](auto qmc, auto qnc) __attribute__((always_inline)) {
-        constexpr int QM = decltype(qmc)::value, QN = decltype(qnc)::value;
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) mma_acc(fb[QN][kk][j], fa[kk][i], acc[QM][QN][i][j]);  // operands swapped: see epilogue_direct
-        __builtin_amdgcn_s_setprio(0);
+    auto read_b1 = [&](Frag<bf16> (&dst)[2][2], int boff, auto hc, auto rc) __attribute__((always_inline)) {
+        constexpr int H = decltype(hc)::value, R = decltype(rc)::value;
+        dst[R >> 1][R & 1] = HB::frag(reinterpret_cast<const bf16*>(smem + boff + H * P8_HALF), wc * 32 + (R & 1) * 16, R >> 1, c, g);
     };
     // bias gradient: row c of row fragment i, this lane's eight k of every k-step: v_dot2c_f32_bf16 against (1, 1) -- eight VALU
-    // instructions per k-tile and quadrant row in the two wc = 0 waves, issued in their read interval (the matrix pipe is busy with
-    // the other half's MFMAs then); an all-ones MFMA fragment would need 32 more accumulator registers than the file has
+    // instructions per k-tile and quadrant row in the two wc = 0 waves; an all-ones MFMA fragment would need 32 more accumulator
+    // registers than the file has
     auto colsum_a = [&](auto qmc) __attribute__((always_inline)) {
         constexpr int QM = decltype(qmc)::value;
         typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
@@ -440,25 +411,91 @@ __global__ __launch_bounds__(P8_NT, 1) void gemm_p8_kernel(const esvit_gemm_desc
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
-                    csum[QM][i] = __builtin_amdgcn_fdot2_f32_bf16(bf16x2_t{fa[kk][i].v[2 * e], fa[kk][i].v[2 * e + 1]}, one2, csum[QM][i], false);
+                    csum[QM][i] = __builtin_amdgcn_fdot2_f32_bf16(bf16x2_t{fA[kk][i].v[2 * e], fA[kk][i].v[2 * e + 1]}, one2, csum[QM][i], false);
     };
     auto bar = [&]() __attribute__((always_inline)) {
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
     };
+    // One phase: the 16 MFMAs of quadrant (QM, QN) -- k-step 0 first, then k-step 1 -- with the LDS reads of what comes NEXT slipped
+    // in between them (pre(m) after MFMA m), then the counted wait -- the four youngest half-tiles stay in flight -- and ONE
+    // workgroup barrier.  The matrix pipe runs while the reads issue; the two waves of a SIMD fill each other's issue gaps.
+    auto phase = [&](auto qmc, auto qnc, Frag<bf16> (&fb)[2][2], auto&& pre) __attribute__((always_inline)) {
+        constexpr int QM = decltype(qmc)::value, QN = decltype(qnc)::value;
+        static_for<16>([&](auto mc) {
+            constexpr int m = decltype(mc)::value;
+            constexpr int kk = m >> 3, i = (m >> 1) & 3, j = m & 1;
+            mma_acc(fb[kk][j], fA[kk][i], acc[QM][QN][i][j]);  // operands swapped: see epilogue_direct
+            __builtin_amdgcn_sched_barrier(0);
+            pre(mc);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        wait_vmcnt<8>();
+        bar();
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using HA0 = std::integral_constant<int, H_A0>;
+    using HA1 = std::integral_constant<int, H_A1>;
+    using HB0 = std::integral_constant<int, H_B0>;
+    using HB1 = std::integral_constant<int, H_B1>;
 
-    // prologue: the first k-tile of the stream and the first three half-tiles of the second
+    // One k-tile (in the buffer at boff; `other` holds the next one).  A fragment register is re-loaded as soon as the last MFMA that
+    // reads it has issued -- half a phase ahead of its next use -- so the 64 fragment registers of the plain schedule suffice:
+    //   phase 0  (0,0) = A0 x B0   k-step 0 block: reads the k-step-1 halves of B0, A0 (this k-tile);  k-step 1 block: reads B1
+    //   phase 1  (0,1) = A0 x B1   k-step 1 block: reads the k-step-0 half of A1
+    //   phase 2  (1,1) = A1 x B1   k-step 0 block: reads the k-step-1 half of A1
+    //   phase 3  (1,0) = A1 x B0   k-step 1 block: reads the k-step-0 halves of A0, B0 of the NEXT k-tile
+    // Requests (one half-tile per phase, before its MFMAs): A1 of the next k-tile, then A0, B0, B1 of the one after.
+    // RAW: a half-tile is first read in the phase after the wait + barrier that covers it (four requests stay in flight: see the order).
+    // WAR: a half-tile is re-requested at the earliest in the phase after the one whose MFMAs consumed the last fragment read from it.
+    auto ktile = [&](int boff, int other, bool do_colsum) __attribute__((always_inline)) {
+        stage(HA1{}, other);
+        phase(I0{}, I0{}, fX, [&](auto mc) {
+            constexpr int m = decltype(mc)::value;
+            if constexpr (m < 2) read_b1(fX, boff, HB0{}, std::integral_constant<int, 2 + (m < 2 ? m : 0)>{});
+            else if constexpr (m < 6) read_a1(boff, HA0{}, std::integral_constant<int, 4 + (m >= 2 && m < 6 ? m - 2 : 0)>{});
+            else if constexpr (m >= 8 && m < 12) read_b1(fY, boff, HB1{}, std::integral_constant<int, (m >= 8 && m < 12 ? m - 8 : 0)>{});
+        });
+        stage(HA0{}, boff);
+        if constexpr (AKS) {
+            if (do_colsum) colsum_a(I0{});
+        }
+        phase(I0{}, I1{}, fY, [&](auto mc) {
+            constexpr int m = decltype(mc)::value;
+            if constexpr (m >= 8 && m < 12) read_a1(boff, HA1{}, std::integral_constant<int, (m >= 8 && m < 12 ? m - 8 : 0)>{});
+        });
+        stage(HB0{}, boff);
+        phase(I1{}, I1{}, fY, [&](auto mc) {
+            constexpr int m = decltype(mc)::value;
+            if constexpr (m < 4) read_a1(boff, HA1{}, std::integral_constant<int, 4 + (m < 4 ? m : 0)>{});
+        });
+        stage(HB1{}, boff);
+        if constexpr (AKS) {
+            if (do_colsum) colsum_a(I1{});
+        }
+        phase(I1{}, I0{}, fX, [&](auto mc) {
+            constexpr int m = decltype(mc)::value;
+            if constexpr (m >= 8 && m < 12) read_a1(other, HA0{}, std::integral_constant<int, (m >= 8 && m < 12 ? m - 8 : 0)>{});
+            else if constexpr (m >= 12 && m < 14) read_b1(fX, other, HB0{}, std::integral_constant<int, (m >= 12 && m < 14 ? m - 12 : 0)>{});
+        });
+    };
+
+    // prologue: the first k-tile of the stream and the first three half-tiles of the second; the k-step-0 halves of A0 and B0 of
+    // the first into registers
     stream_next_item();
-    stage(I0{}, 0);
-    stage(I1{}, 0);
-    stage(I2{}, 0);
-    stage(I3{}, 0);
-    stage(I0{}, P8_BUF);
-    stage(I1{}, P8_BUF);
-    stage(I2{}, P8_BUF);
-    wait_vmcnt<6>();
+    stage(HA0{}, 0);
+    stage(HB0{}, 0);
+    stage(HB1{}, 0);
+    stage(HA1{}, 0);
+    stage(HA0{}, P8_BUF);
+    stage(HB0{}, P8_BUF);
+    stage(HB1{}, P8_BUF);
+    wait_vmcnt<8>();
     bar();
+    static_for<4>([&](auto rc) { read_a1(0, HA0{}, rc); });
+    static_for<2>([&](auto rc) { read_b1(fX, 0, HB0{}, rc); });
     int boff = 0;  // byte offset of the buffer that holds the k-tile being multiplied
 
     for (int w = w_begin + widx; w < w_end; w += per_xcd) {
@@ -476,46 +513,12 @@ __global__ __launch_bounds__(P8_NT, 1) void gemm_p8_kernel(const esvit_gemm_desc
         P8_TL(w, 0, P8_NOW());
         P8_TL(w, 5, cur.nk);
         P8_TL(w, 6, blockIdx.x);
-        if (wr == 1) bar();  // the wr = 1 half runs one barrier behind
         for (int t = 0; t < cur.nk; ++t) {
             const int other = boff ^ P8_BUF;
-            // phase 0
-            read_b(boff, I0{});
-            __builtin_amdgcn_sched_barrier(0);
-            read_a(boff, I0{});
-            stage(I3{}, other);                     // A1 of the next k-tile
-            wait_lgkmcnt<(NRA < 15 ? NRA : 15)>();  // the B0 reads (issued first) are retired: B0 may be re-filled from the next phase on
-            bar();
-            mfma_quadrant(I0{}, I0{});
-            bar();
-            // phase 1
-            read_b(boff, I1{});
-            stage(I0{}, boff);  // B0 of the k-tile after the next: into the half-tile phase 0 has finished with
-            if constexpr (AKS) {
-                if (do_colsum) colsum_a(I0{});  // (the A0 fragments of phase 0 are still in registers)
-            }
-            bar();
-            mfma_quadrant(I0{}, I1{});
-            bar();
-            // phase 2
-            read_a(boff, I1{});
-            stage(I1{}, boff);  // A0
-            bar();
-            mfma_quadrant(I1{}, I1{});
-            bar();
-            // phase 3
-            stage(I2{}, boff);  // B1
-            if constexpr (AKS) {
-                if (do_colsum) colsum_a(I1{});
-            }
-            wait_vmcnt<6>();    // all of the next k-tile has landed; the three half-tiles just requested stay in flight
-            bar();
-            mfma_quadrant(I1{}, I0{});
-            bar();
+            ktile(boff, other, do_colsum);
             boff = other;
             if (t < 2) P8_TL(w, 1 + t, P8_NOW());
         }
-        if (wr == 0) bar();
         P8_TL(w, 3, P8_NOW());
 
         // ---- epilogue of the item: straight from the accumulators; nothing waits for its stores, the next item's first k-tiles
