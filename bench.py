@@ -411,9 +411,10 @@ def main():
         trainer.step(next_crops(), lr, wd, mom, epoch)
     sync()
     t0 = time.perf_counter()
-    loss = None
+    loss, losses = None, []
     for i in range(args.steps):
         loss = trainer.step(next_crops(), lr, wd, mom, epoch)
+        losses.append(loss)  # (device scalars: read after the timed region)
     sync()
     dt = time.perf_counter() - t0
     # roofline leg, OUTSIDE the timed region: HIP events around every GEMM launch of PROF_STEPS extra steps (two event records
@@ -436,6 +437,10 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = t.item()
     loss_v = loss.item()
+    # a step whose loss is not finite had its update refused by the non-finite guard: such a line is not a measurement (rounds
+    # 2-4 reported the ViT / CvT / ViL configurations that way without noticing: DESIGN.md 6, the head_dim-64 attention store)
+    losses_finite = bool(torch.isfinite(torch.stack(losses).float()).all())
+    refused = int(trainer.updater.take_skipped()) if hasattr(trainer.updater, "take_skipped") else 0
 
     if rank == 0:
         ips = args.steps * B * world / dt
@@ -446,7 +451,7 @@ def main():
                "config": {"workload": "%s, 2x224^2+8x96^2 crops, DDINOLoss (view+region), out_dim 65536, per-param clip 3.0 + "
                                       "AdamW + teacher EMA, drop_path %.2f" % ({"swin_tiny_w7": "Swin-T W=7"}.get(args.arch, args.arch), args.drop_path),
                           "global_batch": B * world, "per_gpu_batch": B, "parallelism": "dp%d" % world},
-               "final_loss": loss_v,
+               "final_loss": loss_v, "losses_finite": losses_finite, "refused_updates": refused,
                # (sanity reference, not a parity claim: with random-init heads both cross-entropies start at ln(out_dim) = 11.09; parity
                # of the loss against the reference's own module is asserted in tests/test_parity_gpu.py / test_step_gpu.py)
                "ln_out_dim": math.log(65536.0),
@@ -496,6 +501,9 @@ def main():
         print(json.dumps(out))
     if dist.is_initialized():
         dist.destroy_process_group()
+    if not losses_finite:
+        print("bench.py: a timed step produced a non-finite loss (its update was refused) -- this line is not a measurement", file=sys.stderr)
+        sys.exit(3)
 
 
 if __name__ == "__main__":

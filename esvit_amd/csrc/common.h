@@ -107,6 +107,21 @@ __device__ __forceinline__ Vec16<T> zero16() {
 }
 
 // ---------------------------------------------------------------------------
+// 16-byte raw-buffer store with the uniform part of the address added to the per-lane offset instead of riding in the instruction's
+// SGPR offset field.  Measured on MI355X (tools/probe/diag_attn64b.py, tools/isa_store_hazard.py): with every CU fully occupied, a
+// `buffer_store_dwordx4 ... offen` with an SGPR offset that is DIRECTLY followed by a VALU write of its first data register stored the
+// new register value in a quarter of the lanes -- the case LLVM's hazard recogniser exempts from the "VMEM store of more than 64 bits,
+// then a write of its data VGPRs" wait state.  With a constant-zero offset field the compiler inserts that wait state itself.
+// (Out-of-range lanes stay out of range: the offsets are unsigned 32-bit and the ranges are below 2 GiB.)
+// ---------------------------------------------------------------------------
+typedef unsigned int esvit_u32x4 __attribute__((ext_vector_type(4)));
+template <int AUX = 0, typename V>
+__device__ __forceinline__ void buffer_store_b128(const V& data, __amdgpu_buffer_rsrc_t rsrc, unsigned lane_offset, unsigned uniform_offset) {
+    static_assert(sizeof(V) == 16, "buffer_store_b128 takes 16 bytes");
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(esvit_u32x4, data), rsrc, (int)(lane_offset + uniform_offset), 0, AUX);
+}
+
+// ---------------------------------------------------------------------------
 // wave / block reductions (wave = 64 lanes)
 // ---------------------------------------------------------------------------
 // The dispatcher places workgroup b on XCD b % 8 (eight XCDs, one L2 each).  Bijective renumbering that gives every XCD a

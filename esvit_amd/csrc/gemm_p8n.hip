@@ -320,17 +320,17 @@ __global__ __launch_bounds__(PN_NT, 1) void gemm_p8n_kernel(const esvit_gemm_des
         f32x4 v[2] = {acc[SET][QM][I][0] * p.alpha, acc[SET][QM][I][1] * p.alpha};
         if constexpr (EPI == PN_F32) {
             if (p.splitk > 1) {  // (partials: read back at once by the reduce kernel)
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v[0]), o.rc, lane_off_4(vo_out, o.n0, 0), so, 0);
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v[1]), o.rc, lane_off_4(vo_out, o.n0, 1), so + 64, 0);
+                buffer_store_b128<0>(v[0], o.rc, lane_off_4(vo_out, o.n0, 0), so);
+                buffer_store_b128<0>(v[1], o.rc, lane_off_4(vo_out, o.n0, 1), so + 64);
             } else {
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v[0]), o.rc, lane_off_4(vo_out, o.n0, 0), so, ESVIT_P8N_STORE_AUX);
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v[1]), o.rc, lane_off_4(vo_out, o.n0, 1), so + 64, ESVIT_P8N_STORE_AUX);
+                buffer_store_b128<ESVIT_P8N_STORE_AUX>(v[0], o.rc, lane_off_4(vo_out, o.n0, 0), so);
+                buffer_store_b128<ESVIT_P8N_STORE_AUX>(v[1], o.rc, lane_off_4(vo_out, o.n0, 1), so + 64);
             }
         } else {
             const unsigned vo = lane_off_bf16(vo_out, o.n0);
             if constexpr (EPI == PN_GELU) {
                 const unsigned sx = o.so_x + (unsigned)((QM * 128 + 16 * I) * p.ldaux * 2);
-                __builtin_amdgcn_raw_buffer_store_b128(pair_rows(v[0], v[1]), o.rx, lane_off_bf16(vo_aux, o.n0), sx, ESVIT_P8N_STORE_AUX);
+                buffer_store_b128<ESVIT_P8N_STORE_AUX>(pair_rows(v[0], v[1]), o.rx, lane_off_bf16(vo_aux, o.n0), sx);
             }
             if constexpr (EPI == PN_GELU || EPI == PN_GELU_NOAUX) {
                 const bool quick = p.epilogue == ESVIT_EPI_QGELU;
@@ -339,7 +339,7 @@ __global__ __launch_bounds__(PN_NT, 1) void gemm_p8n_kernel(const esvit_gemm_des
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[j][e] = quick ? qgelu_f(v[j][e]) : gelu_f(v[j][e]);
             }
-            __builtin_amdgcn_raw_buffer_store_b128(pair_rows(v[0], v[1]), o.rc, vo, so, ESVIT_P8N_STORE_AUX);
+            buffer_store_b128<ESVIT_P8N_STORE_AUX>(pair_rows(v[0], v[1]), o.rc, vo, so);
         }
     };
     // all eight units of a set at once (end of the item).  Kinds with inputs request the inputs of four units before the first of
@@ -369,8 +369,8 @@ __global__ __launch_bounds__(PN_NT, 1) void gemm_p8n_kernel(const esvit_gemm_des
                 for (int i = 0; i < 4; ++i) {
                     const unsigned so = o.so_c + (unsigned)((QM * 128 + 16 * i) * ldo * 4);
                     const f32x4 y0 = acc[SET][QM][i][0] * p.alpha * rs[i] + r[i][0], y1 = acc[SET][QM][i][1] * p.alpha * rs[i] + r[i][1];
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, y0), o.rc, lane_off_4(vo_out, o.n0, 0), so, ESVIT_P8N_STORE_AUX);
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, y1), o.rc, lane_off_4(vo_out, o.n0, 1), so + 64, ESVIT_P8N_STORE_AUX);
+                    buffer_store_b128<ESVIT_P8N_STORE_AUX>(y0, o.rc, lane_off_4(vo_out, o.n0, 0), so);
+                    buffer_store_b128<ESVIT_P8N_STORE_AUX>(y1, o.rc, lane_off_4(vo_out, o.n0, 1), so + 64);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             });
@@ -396,7 +396,7 @@ __global__ __launch_bounds__(PN_NT, 1) void gemm_p8n_kernel(const esvit_gemm_des
                         for (int e = 0; e < 4; ++e) v[j][e] = acc[SET][QM][i][j][e] * p.alpha * (quick ? qgelu_grad_f(x[e]) : gelu_grad_f(x[e]));
                     }
                     const unsigned so = o.so_c + (unsigned)((QM * 128 + 16 * i) * ldo * 2);
-                    __builtin_amdgcn_raw_buffer_store_b128(pair_rows(v[0], v[1]), o.rc, lane_off_bf16(vo_out, o.n0), so, ESVIT_P8N_STORE_AUX);
+                    buffer_store_b128<ESVIT_P8N_STORE_AUX>(pair_rows(v[0], v[1]), o.rc, lane_off_bf16(vo_out, o.n0), so);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             });

@@ -323,7 +323,7 @@ __global__ __launch_bounds__(128, (HDIM == 32 ? 3 : 2)) void attn_fwd4_kernel(co
             const int tl = lane / VPR + SSTEP * i;
             const Vec16<T> x = ld16<T>(Og + tl * LDQ + dv * VEC);
             const int vo = (active && stok[i] >= 0) ? stok[i] * C * ES + dv * 16 : OOB;
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_f, x.v), ro, vo, h * HDIM * ES, 0);
+            buffer_store_b128(x.v, ro, vo, h * HDIM * ES);  // (common.h: no SGPR offset on 16-byte stores)
         }
         cur = nxt;
         tok1 = tok2;
@@ -562,7 +562,7 @@ __global__ __launch_bounds__(128, (HDIM == 32 ? 2 : 1)) void attn_bwd3_kernel(co
                 const int t = 32 * w + tl;
                 const Vec16<T> x = ld16<T>(Sg + tl * LDQ + dv * VEC);
                 const int vo = (active && stok[i] >= 0) ? stok[i] * 3 * C * ES + dv * 16 : OOB;
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, x.v), rd, vo, (col0 + h * HDIM) * ES, 0);
+                buffer_store_b128(x.v, rd, vo, (col0 + h * HDIM) * ES);
                 if (padacc && active && t < N && stok[i] < 0) {
 #pragma unroll
                     for (int e = 0; e < VEC; ++e) padacc[e] += x.get(e);

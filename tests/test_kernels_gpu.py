@@ -498,6 +498,49 @@ def test_window_attention(mods, dt, ws, nH, H, shift, hd):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("geom", ["vit37_h3", "vit37_h6", "cvt56_h1", "cvt28_h3", "swin56_h3_hd32"])
+def test_window_attention_full_occupancy(mods, dt, geom):
+    """head_dim 64 (and 32 as the control) with MORE window-heads than the chip keeps resident: every CU fully occupied and
+    several windows per workgroup.  Regression for the bench lines of the ViT / CvT / ViL configurations, whose bf16 forward
+    stored 0x7ffffff0 (two bf16 NaNs) into four rows of some windows at this occupancy (common.h: buffer_store_b128); the
+    unit geometries of test_window_attention (<= 48 window-heads) never showed it."""
+    ops, ref = mods
+    import esvit_amd.functional as Fn
+    dev = _dev()
+    vit = geom.startswith("vit")
+    hd = 32 if geom.endswith("hd32") else 64
+    nH = int(geom.split("_h")[1].split("_")[0])
+    C = nH * hd
+    if vit:
+        N = L = 37
+        nB, nW = 1280, 1
+        w2t, ws, table = Fn._vit_window(N, nH, dev)
+    else:
+        H, ws, nB = (56, 7, 40) if "56" in geom else (28, 7, 64)
+        N, L = ws * ws, H * H
+        w2t = torch.from_numpy(ops.window_maps(H, H, ws, 0)[0]).to(dev)
+        nW = w2t.numel() // N
+        table = _rand(((2 * ws - 1) ** 2, nH), dev, 51) * 0.5
+    qkv = _rand((nB * L, 3 * C), dev, 50, dt)
+    qb = _rand((3 * C,), dev, 49) * 0.5
+    dout = _rand((nB * L, C), dev, 52, dt)
+    scale = hd ** -0.5
+    junk = [torch.full((1 << 26,), float("nan"), device=dev) for _ in range(8)]  # (what torch.empty hands out next is poisoned)
+    del junk
+    for rep in range(2):
+        o, lse = ops.window_attn_fwd(qkv, qb, w2t, L, table, ws, None, nW, N, nH, scale)
+        dqkv = ops.window_attn_bwd(qkv, qb, w2t, L, dout, o, lse, table, ws, None, nW, N, nH, scale)[0]
+        assert bool(torch.isfinite(o.float()).all()) and bool(torch.isfinite(dqkv.float()).all())
+        step = 160 if vit else 4
+        for b0 in range(0, nB, step):
+            sl = slice(b0 * L, min(nB, b0 + step) * L)
+            orf = ref.window_attn_fwd(qkv[sl], qb, w2t, L, table, ws, None, nW, N, nH, scale)
+            _close("attn out, images %d.." % b0, o[sl], orf[0], _tol(dt, f32=5e-5, bf=2e-2))
+            dr = ref.window_attn_bwd(qkv[sl], qb, w2t, L, dout[sl], orf[0], orf[1], table, ws, None, nW, N, nH, scale)[0]
+            _close("attn dqkv, images %d.." % b0, dqkv[sl], dr, _tol(dt, f32=1e-4, bf=3e-2))
+
+
+@pytest.mark.parametrize("dt", DTYPES)
 def test_cvt_conv_pieces(mods, dt):
     """ConvEmbed im2col / col2im, depthwise 3x3 (+ flipped, + weight gradient), BatchNorm reductions and affine apply"""
     ops, ref = mods
