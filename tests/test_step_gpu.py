@@ -691,3 +691,35 @@ def test_trainer_step_with_logit_statistics_from_the_gemm(lib_built, monkeypatch
         assert max((p_on[k] - p_off[k]).abs().max().item() for k in p_on if p_on[k].numel()) < 6 * 5e-4
     finally:
         _teardown()
+
+
+@pytest.mark.parametrize("arch,B", [("swin_tiny_w7", 32), ("swin_tiny_w14", 16), ("deit_small", 32), ("cvt_s1", 32), ("vil_tiny", 32)])
+def test_full_width_bf16_tracks_fp32_mode(arch, B):
+    """The bench configurations at FULL width and a batch that fills every CU (>= 1024 window-heads in the attention kernels), three
+    steps in bf16 against the fp32 mode of the same library -- mostly disjoint kernels, the same math.  The fixtures of the reference
+    stop at batch 2-4 per crop; this is the check that runs at the occupancy of the bench lines (the head_dim-64 attention store of
+    round 4 passed every small-geometry test and poisoned every step of the ViT / CvT / ViL benches).  Observed on MI355X
+    (tools/probe/diag_prec.py): loss differences 4e-5 .. 1.2e-4, parameter norms equal to 7e-8."""
+    import bench
+    import esvit_amd
+    from esvit_amd.engine import EsvitTrainer
+    dev = torch.device("cuda:0")
+    res = {}
+    try:
+        for prec in ("fp32", "bf16"):
+            esvit_amd.set_precision(prec)
+            torch.manual_seed(0)
+            student, teacher, loss_fn = bench.build(dev, 0.0, arch)
+            trainer = EsvitTrainer(student, teacher, loss_fn, clip_grad=3.0, freeze_last_layer=1, teacher_stream=False)
+            crops = [c.to(dev) for c in GU.make_crops(B, seed=1234)]
+            losses = [trainer.step(crops, 5e-4 * B / 256.0, 0.04, 0.996, 1).item() for _ in range(3)]
+            norm = torch.sqrt(sum((p.detach().float() ** 2).sum() for p in student.parameters())).item()
+            assert trainer.updater.take_skipped() == 0
+            res[prec] = (losses, norm)
+            del student, teacher, loss_fn, trainer, crops
+            torch.cuda.empty_cache()
+    finally:
+        esvit_amd.set_precision("bf16")
+    for a, b in zip(res["fp32"][0], res["bf16"][0]):
+        assert a == a and b == b and abs(a - b) < 4e-4, (arch, res)
+    assert abs(res["fp32"][1] - res["bf16"][1]) / res["fp32"][1] < 1e-6, (arch, res)
