@@ -187,10 +187,13 @@ __device__ __forceinline__ float erf_fast(float x) {
 }
 // erf-GELU (reference: nn.GELU default, "none" approximation) and its derivative
 __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erf_fast(x * 0.70710678118654752f)); }
-__device__ __forceinline__ float gelu_grad_f(float x) {
-    const float cdf = 0.5f * (1.f + erf_fast(x * 0.70710678118654752f));
-    const float pdf = 0.39894228040143268f * __expf(-0.5f * x * x);
-    return cdf + x * pdf;
+__device__ __forceinline__ float gelu_grad_f(float x) {  // one exponential: exp(-x^2 / 2) serves the erf fit and the density (as mlp_fused16's gelu_both)
+    const float ax = fabsf(x) * 0.70710678118654752f;
+    const float t = __builtin_amdgcn_rcpf(1.f + 0.3275911f * ax);
+    const float e = __expf(-0.5f * x * x);
+    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    const float cdf = 0.5f * (1.f + copysignf(1.f - poly * e, x));
+    return cdf + x * 0.39894228040143268f * e;
 }
 
 // QuickGELU of the CvT feed-forward (cvt_v4_transformer.py:44-46) and its derivative

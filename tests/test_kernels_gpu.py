@@ -158,7 +158,7 @@ def test_gemm_p8n(mods, M, N, K):
         rows = K * 8  # weight gradient [M', N'] = dy^T x over `rows` (split-K inside linear_wgrad)
         Mw, Nw = min(M // 8 * 8, 1536), min(N, 1536)
         dyw, xw = _rand((rows, Mw), dev, 8, dt), _rand((rows, Nw), dev, 9, dt)
-        # (weight gradients, residual and GELU' epilogues are not offered by this loop: those calls take the library's choice)
+        # (bias-fused weight gradients are not offered by this loop: those calls take the library's choice)
         _close("p8n wgrad", ops.linear_wgrad(dyw, xw), ref.linear_wgrad(dyw, xw), _tol(dt, bf=2e-3))
         dw, db = ops.linear_wgrad(dyw, xw, want_bias=True)
         dwr, dbr = ref.linear_wgrad(dyw, xw, want_bias=True)
