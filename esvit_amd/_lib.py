@@ -65,13 +65,13 @@ SIGNATURES = {
     "esvit_bn_eval_coeffs": (C.c_int, [vp, vp, vp, vp, f32, C.c_int, vp, vp]),
     "esvit_bn_bwd_local": (C.c_int, [vp, vp, C.c_int, vp, vp]),
     "esvit_bn_bwd_coeffs": (C.c_int, [vp, f32, vp, vp, C.c_int, vp, vp]),
-    "esvit_layernorm_bwd": (C.c_int, [C.c_int, vp, vp, vp, vp, vp, vp, i64, C.c_int, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp, vp, C.c_int, vp]),
+    "esvit_layernorm_bwd": (C.c_int, [C.c_int, vp, vp, vp, vp, vp, vp, i64, C.c_int, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp, C.c_int, vp, C.c_int, vp]),
     "esvit_gather_cast": (C.c_int, [C.c_int, vp, vp, i64, C.c_int, vp, C.c_int, C.c_int, vp, C.c_int, vp]),
     "esvit_cast_f32_to": (C.c_int, [C.c_int, vp, vp, i64, vp]),
     "esvit_colsum": (C.c_int, [C.c_int, vp, i64, C.c_int, i64, vp, vp, C.c_int, vp]),
     "esvit_patch_im2col": (C.c_int, [C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "esvit_merge_ln_fwd": (C.c_int, [C.c_int, vp, vp, vp, f32, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]),
-    "esvit_merge_ln_bwd": (C.c_int, [C.c_int, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, C.c_int, vp]),
+    "esvit_merge_ln_bwd": (C.c_int, [C.c_int, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp]),
     "esvit_token_mean_fwd": (C.c_int, [C.c_int, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp]),
     "esvit_token_mean_bwd": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp]),
     "esvit_window_attn_fwd": (C.c_int, [C.c_int, vp, vp, vp, C.c_int, vp, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, f32, vp, vp, vp, vp]),

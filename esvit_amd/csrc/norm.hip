@@ -56,6 +56,17 @@ struct RowSrc {
     __device__ __forceinline__ float* dptr(float* dx, long r, int c4) const {
         return dx + (ptr(r, c4) - x);
     }
+    // element offset of (row r, vector c4) in the un-gathered [.., C or Cin] layout, and the token row it belongs to
+    __device__ __forceinline__ long off(long r, int c4) const { return ptr(r, c4) - x; }
+    __device__ __forceinline__ long dst_row(long r, int c4) const {  // (the same sub-expressions as ptr(): folded by the compiler)
+        if (!merge) return r;
+        const int Ho = H / 2, Wo = W / 2;
+        const long b = r / (Ho * Wo);
+        const int rem = (int)(r % (Ho * Wo));
+        const int i = rem / Wo, j = rem % Wo;
+        const int blk = (c4 * 4) / Cin;
+        return (b * H + (2 * i + (blk & 1))) * W + (2 * j + (blk >> 1));
+    }
 };
 
 template <typename T, int G, int ITERS>
@@ -111,7 +122,7 @@ __global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(RowSrc src, const fl
 }
 
 // backward: dx = rstd * (gdy - mean(gdy) - xhat * mean(gdy*xhat)), gdy = gamma*dy
-template <typename T, int G, int ITERS>
+template <typename T, int G, int ITERS, typename TA = T>  // TA: type of dx_act (bf16 from an fp32 upstream gradient: the patch-embedding norm)
 __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(RowSrc src, const T* __restrict__ dy,
                                                              const float* __restrict__ mean,
                                                              const float* __restrict__ rstd,
@@ -119,7 +130,7 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(RowSrc src, const T*
                                                              const float* __restrict__ g_in, long rows,
                                                              float* __restrict__ dx, float* __restrict__ ws,
                                                              const int* __restrict__ rowmap, int tokens, int period_in,
-                                                             T* __restrict__ dx_act, const float* __restrict__ rowscale,
+                                                             TA* __restrict__ dx_act, const float* __restrict__ rowscale,
                                                              int rows_per_sample) {
     constexpr int RPB = LN_THREADS / G;
     const int C = src.C, C4 = C / 4;
@@ -161,12 +172,12 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(RowSrc src, const T*
             const int c4 = gl + it * G;
             if (c4 < C4) {
                 f32x4 o = (gd[it] - s1 - xh[it] * s2) * rs;
-                float* dp = src.dptr(dx, r, c4);
-                if (g_in) o += *reinterpret_cast<const f32x4*>(g_in + (dp - dx));
-                *reinterpret_cast<f32x4*>(dp) = o;
+                const long off = src.off(r, c4);  // (the 2x2 merge scatters a row over four token rows)
+                if (g_in) o += *reinterpret_cast<const f32x4*>(g_in + off);
+                if (dx) *reinterpret_cast<f32x4*>(dx + off) = o;  // (NULL: only the activation-dtype copy is wanted)
                 if (dx_act) {  // the activation-dtype, DropPath-scaled copy the next GEMMs of the backward read (saves a cast pass)
-                    const float sc = rowscale ? rowscale[r / rows_per_sample] : 1.f;
-                    store4<T>(dx_act + r * (long)C + c4 * 4, o * sc);
+                    const float sc = rowscale ? rowscale[src.dst_row(r, c4) / rows_per_sample] : 1.f;
+                    store4<TA>(dx_act + off, o * sc);
                 }
             }
         }
@@ -271,7 +282,7 @@ int ln_fwd_launch(RowSrc src, const float* gamma, const float* beta, float eps, 
     return ESVIT_OK;
 }
 
-template <typename T>
+template <typename T, typename TA = T>
 int ln_bwd_launch(RowSrc src, const void* dy, const float* mean, const float* rstd, const float* gamma,
                   const float* g_in, long rows, float* dx, float* dgamma, float* dbeta, float* ws, const int* rowmap,
                   int tokens, int period_in, hipStream_t stream, void* dx_act = nullptr, const float* rowscale = nullptr,
@@ -284,12 +295,12 @@ int ln_bwd_launch(RowSrc src, const void* dy, const float* mean, const float* rs
     ESVIT_CHECK_ARG(lds <= 160 * 1024, "layernorm_bwd: C=%d too large", src.C);
     ln_dispatch(cfg, [&](auto shp) {
         using S = decltype(shp);
-        auto kern = ln_bwd_kernel<T, S::G, S::ITERS>;
+        auto kern = ln_bwd_kernel<T, S::G, S::ITERS, TA>;
         if (lds > 48 * 1024)
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)lds);
         hipLaunchKernelGGL(kern, dim3(nblk), dim3(LN_THREADS), lds, stream, src, reinterpret_cast<const T*>(dy), mean,
-                           rstd, gamma, g_in, rows, dx, ws, rowmap, tokens, period_in, reinterpret_cast<T*>(dx_act), rowscale,
+                           rstd, gamma, g_in, rows, dx, ws, rowmap, tokens, period_in, reinterpret_cast<TA*>(dx_act), rowscale,
                            rows_per_sample);
     });
     ESVIT_CHECK_LAUNCH("layernorm_bwd");
@@ -467,18 +478,24 @@ int esvit_i_ln_bwd_blocks(long rows, int C) { return ln_bwd_nblk(rows, C); }  //
 extern "C" int esvit_layernorm_bwd(int dtype, const void* dy, const float* x, const float* mean, const float* rstd,
                                    const float* gamma, const float* g_in, int64_t rows, int C, float* dx,
                                    float* dgamma, float* dbeta, float* ws, const int32_t* rowmap, int tokens,
-                                   int period_in, void* dx_act, const float* rowscale, int rows_per_sample, esvit_stream_t s_) {
+                                   int period_in, void* dx_act, int act_dtype, const float* rowscale, int rows_per_sample,
+                                   esvit_stream_t s_) {
     hipStream_t stream = reinterpret_cast<hipStream_t>(s_);
-    ESVIT_CHECK_ARG(dy && x && mean && rstd && gamma && dx && dgamma && dbeta && ws && rows > 0,
+    ESVIT_CHECK_ARG(dy && x && mean && rstd && gamma && (dx || dx_act) && dgamma && dbeta && ws && rows > 0,
                     "esvit_layernorm_bwd: bad args");
     if (rowmap) ESVIT_CHECK_ARG(tokens > 0 && period_in > 0, "esvit_layernorm_bwd: bad rowmap geometry");
     if (dx_act) ESVIT_CHECK_ARG(!rowmap, "esvit_layernorm_bwd: dx_act is written at un-mapped rows only");
+    if (dx_act) ESVIT_CHECK_ARG(act_dtype == dtype || (dtype == ESVIT_F32 && act_dtype == ESVIT_BF16), "esvit_layernorm_bwd: dx_act has dy's dtype, or bf16 from fp32");
+    if (!dx) ESVIT_CHECK_ARG(!g_in, "esvit_layernorm_bwd: g_in is added to dx");
     if (rowscale) ESVIT_CHECK_ARG(dx_act && rows_per_sample > 0, "esvit_layernorm_bwd: rowscale scales dx_act and needs rows_per_sample");
     const int rps = rows_per_sample > 0 ? rows_per_sample : 1;
     RowSrc src{x, C, 0, 0, 0, 0};
     if (dtype == ESVIT_BF16)
         return ln_bwd_launch<bf16>(src, dy, mean, rstd, gamma, g_in, rows, dx, dgamma, dbeta, ws, rowmap, tokens, period_in, stream, dx_act,
                                    rowscale, rps);
+    if (dtype == ESVIT_F32 && dx_act && act_dtype == ESVIT_BF16)
+        return ln_bwd_launch<float, bf16>(src, dy, mean, rstd, gamma, g_in, rows, dx, dgamma, dbeta, ws, rowmap, tokens, period_in, stream,
+                                          dx_act, rowscale, rps);
     if (dtype == ESVIT_F32)
         return ln_bwd_launch<float>(src, dy, mean, rstd, gamma, g_in, rows, dx, dgamma, dbeta, ws, rowmap, tokens, period_in, stream, dx_act,
                                     rowscale, rps);
@@ -501,17 +518,20 @@ extern "C" int esvit_merge_ln_fwd(int dtype, const float* x, const float* gamma,
 
 extern "C" int esvit_merge_ln_bwd(int dtype, const void* dy, const float* x, const float* mean, const float* rstd,
                                   const float* gamma, int nB, int H, int W, int C, float* dx, float* dgamma,
-                                  float* dbeta, float* ws, int accumulate, esvit_stream_t s_) {
+                                  float* dbeta, float* ws, void* dx_act, const float* rowscale, int rows_per_sample, int accumulate,
+                                  esvit_stream_t s_) {
     hipStream_t stream = reinterpret_cast<hipStream_t>(s_);
     ESVIT_CHECK_ARG(dy && x && mean && rstd && gamma && dx && dgamma && dbeta && ws, "esvit_merge_ln_bwd: null pointer");
     ESVIT_CHECK_ARG(H % 2 == 0 && W % 2 == 0 && C % 4 == 0 && nB > 0, "esvit_merge_ln_bwd: bad geometry");
+    if (rowscale) ESVIT_CHECK_ARG(dx_act && rows_per_sample > 0, "esvit_merge_ln_bwd: rowscale scales dx_act and needs rows_per_sample");
+    const int rps = rows_per_sample > 0 ? rows_per_sample : 1;
     RowSrc src{x, 4 * C, 1, H, W, C};
     const long rows = (long)nB * (H / 2) * (W / 2);
     if (dtype == ESVIT_BF16)
-        return ln_bwd_launch<bf16>(src, dy, mean, rstd, gamma, nullptr, rows, dx, dgamma, dbeta, ws, nullptr, 0, 0, stream, nullptr, nullptr, 1,
+        return ln_bwd_launch<bf16>(src, dy, mean, rstd, gamma, nullptr, rows, dx, dgamma, dbeta, ws, nullptr, 0, 0, stream, dx_act, rowscale, rps,
                                    accumulate);
     if (dtype == ESVIT_F32)
-        return ln_bwd_launch<float>(src, dy, mean, rstd, gamma, nullptr, rows, dx, dgamma, dbeta, ws, nullptr, 0, 0, stream, nullptr, nullptr, 1,
+        return ln_bwd_launch<float>(src, dy, mean, rstd, gamma, nullptr, rows, dx, dgamma, dbeta, ws, nullptr, 0, 0, stream, dx_act, rowscale, rps,
                                     accumulate);
     esvit_set_error("esvit_merge_ln_bwd: bad dtype");
     return ESVIT_ERR_ARG;

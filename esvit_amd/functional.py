@@ -431,8 +431,7 @@ class PatchEmbedFn(torch.autograd.Function):
             return None, dW.view(ctx.wshape), dbp, None, None, None
         cols, y, mean, rstd, g = ctx.saved_tensors
         M, E = y.shape
-        dy, dg, db = o.layernorm_bwd(gx.contiguous().view(M, E), y, mean, rstd, g)
-        dyb = o.gather_cast(dy, M)
+        dyb, dg, db = o.layernorm_bwd_to_act(gx.contiguous().view(M, E), y, mean, rstd, g)  # (as PatchEmbedMultiFn)
         dW, dbp = o.linear_wgrad(dyb, cols, want_bias=True)
         dW = dW.view(ctx.wshape)
         return None, dW, dbp, dg, db, None
@@ -473,18 +472,24 @@ class PatchEmbedMultiFn(torch.autograd.Function):
             return (dW.view(ctx.wshape), dbp, None, None, None) + (None,) * ctx.n_img
         cols, y, mean, rstd, g = ctx.saved_tensors
         M, E = y.shape
-        dy, dg, db = o.layernorm_bwd(gx.contiguous().view(M, E), y, mean, rstd, g)
-        dW, dbp = o.linear_wgrad(o.gather_cast(dy, M), cols, want_bias=True)
+        # dL/dy of the norm is only ever the operand of the projection's weight gradient: written once, in the activation dtype
+        dya, dg, db = o.layernorm_bwd_to_act(gx.contiguous().view(M, E), y, mean, rstd, g)
+        dW, dbp = o.linear_wgrad(dya, cols, want_bias=True)
         return (dW.view(ctx.wshape), dbp, dg, db, None) + (None,) * ctx.n_img
 
 
 class PatchMergeMultiFn(torch.autograd.Function):
     """PatchMerging over the token rows of several resolution groups: the 2x2 gather + LayerNorm(4C) runs per group (it
     depends on the grid) into one shared row buffer; the reduction GEMM, its dgrad and wgrad run once over all rows.
-    X fp32 [M, C], groups: tuple of (row0, nB, H, W) -> fp32 [M/4, 2C] with the groups in the same order."""
+    X fp32 [M, C], groups: tuple of (row0, nB, H, W) -> fp32 [M/4, 2C] with the groups in the same order.
+
+    The node takes part in the shadow protocol of SwinBlockMultiFn on both sides.  Xsh / prev_scale: the shadow output and the
+    MLP-branch DropPath row scale of the stage's last block -- the LayerNorm backward that produces dL/dX also emits
+    cast(prev_scale * dL/dX), that block's GEMM operand.  Second output: a shadow of the merged rows for the next stage's first block,
+    whose LayerNorm backward hands back cast(dL/dY) -- the operand of this node's reduction GEMMs -- instead of a cast pass over dL/dY."""
 
     @staticmethod
-    def forward(ctx, X, groups, g, b, Wr):
+    def forward(ctx, X, Xsh, prev_scale, groups, g, b, Wr):
         o = ops_module()
         X = X.contiguous()
         M, C = X.shape
@@ -498,24 +503,29 @@ class PatchMergeMultiFn(torch.autograd.Function):
         out = o.linear_fwd(y, Wc, None, out_f32=True)
         ctx.save_for_backward(X, y, mean, rstd, g, Wc)
         ctx.groups, ctx.wparam = groups, Wr
-        return out
+        ctx.emit_shadow, ctx.prev_scale = Xsh is not None, prev_scale
+        ctx.set_materialize_grads(False)
+        outsh = torch.empty(out.shape, dtype=y.dtype, device=X.device) if any(ctx.needs_input_grad) else None
+        return out, outsh
 
     @staticmethod
-    def backward(ctx, go):
+    def backward(ctx, go, gosh):
         o = ops_module()
         X, y, mean, rstd, g, Wc = ctx.saved_tensors
         M, C = X.shape
-        gb = o.gather_cast(go.contiguous(), M // 4)
+        gb = gosh.contiguous() if gosh is not None else o.gather_cast(go.contiguous(), M // 4)
         dWr = _wgrad(gb, y, ctx.wparam)
         dy = o.linear_dgrad(gb, Wc)
         dX = torch.empty_like(X)
+        dXsh = torch.empty((M, C), dtype=y.dtype, device=X.device) if ctx.emit_shadow else None
+        ps = ctx.prev_scale
         gb = torch.empty((2, 4 * C), dtype=torch.float32, device=X.device)  # dgamma | dbeta: the first group writes, later ones accumulate
         for gi, (r0, nB, H, W) in enumerate(ctx.groups):
             r1 = r0 + nB * H * W
             q0, q1 = r0 // 4, r1 // 4
             o.merge_ln_bwd(dy[q0:q1], X[r0:r1].view(nB, H * W, C), mean[q0:q1], rstd[q0:q1], g, H, W, dx_out=dX[r0:r1], gb_out=gb,
-                           accumulate=gi > 0)
-        return dX, None, gb[0], gb[1], dWr
+                           accumulate=gi > 0, act_out=None if dXsh is None else dXsh[r0:r1], rowscale=None if (ps is None or dXsh is None) else ps[r0:r1])
+        return dX, dXsh, None, None, gb[0], gb[1], dWr
 
 
 class PatchMergeFn(torch.autograd.Function):

@@ -143,13 +143,16 @@ class PatchMerging(nn.Module):
             H, W = H + H % 2, W + W % 2
         return Fn.PatchMergeFn.apply(x, H, W, self.norm.weight, self.norm.bias, self.reduction.weight)
 
-    def forward_ragged(self, X, groups):
-        """X fp32 [M, C] token rows of several resolution groups ((row0, nB, H, W) each) -> ([M/4, 2C], merged groups)"""
+    def forward_ragged(self, X, groups, shadow=None, prev_scale=None):
+        """X fp32 [M, C] token rows of several resolution groups ((row0, nB, H, W) each) -> ([M/4, 2C], merged groups, shadow of the
+        output).  shadow / prev_scale: the stage's last block's shadow output and MLP-branch DropPath row scale -- the merge's
+        backward then emits that block's cast gradient; the returned shadow is for the next stage's first block, which hands this
+        node the cast dL/dY its GEMMs read (Fn.SwinBlockMultiFn)"""
         if any(H % 2 or W % 2 for (_, _, H, W) in groups):
             raise NotImplementedError("odd feature maps on the ragged multi-crop route: set model.ragged_multi_crop = False "
                                       "(the per-group schedule pads them, swin_transformer.py:406-408)")
-        Y = Fn.PatchMergeMultiFn.apply(X, tuple(groups), self.norm.weight, self.norm.bias, self.reduction.weight)
-        return Y, [(r0 // 4, nB, H // 2, W // 2) for (r0, nB, H, W) in groups]
+        Y, Ysh = Fn.PatchMergeMultiFn.apply(X, shadow, prev_scale, tuple(groups), self.norm.weight, self.norm.bias, self.reduction.weight)
+        return Y, [(r0 // 4, nB, H // 2, W // 2) for (r0, nB, H, W) in groups], Ysh
 
 
 def _sample_offsets(groups):
@@ -176,11 +179,12 @@ class BasicLayer(nn.Module):
             x, _ = blk(x)
         return self.downsample(x) if self.downsample is not None else x
 
-    def forward_ragged(self, X, groups):
+    def forward_ragged(self, X, groups, shadow=None):
         """X: fp32 token rows [M, C] of several resolution groups, groups: list of (row0, nB, H, W).  The blocks of this
         stage run over all rows at once (Fn.swin_block_multi: attention per group, everything row-wise in one launch),
-        then the ragged patch merging.  Returns (rows of the next stage, its groups)."""
-        shadow, prev_scale = None, None  # (the first block of a stage has no predecessor to serve)
+        then the ragged patch merging.  shadow: the shadow output of the node that produced X (the previous stage's patch merging),
+        served by this stage's first block.  Returns (rows of the next stage, its groups, the shadow of those rows or None)."""
+        prev_scale = None  # (the producer of X reads dL/dX unscaled)
         nS = sum(g[1] for g in groups)
         # stochastic depth: the per-sample keep factors of every block of this stage (drawn at once by
         # SwinTransformer._draw_drop_path) become per-row scales with ONE gather per stage
@@ -214,8 +218,8 @@ class BasicLayer(nn.Module):
             nxt_blk = self.blocks[bi + 1] if bi + 1 < len(self.blocks) else None
             X, shadow, prev_scale, pre = _block_forward_multi(blk, X, groups, dp, shadow, prev_scale, pre, nxt_blk)
         if self.downsample is not None:
-            return self.downsample.forward_ragged(X, groups)
-        return X, groups
+            return self.downsample.forward_ragged(X, groups, shadow, prev_scale)
+        return X, groups, None
 
     def forward_with_features(self, x):
         fea = []
@@ -355,8 +359,9 @@ class SwinTransformer(nn.Module):
             nB, G = sum(c.shape[0] for c in grp), grp[0].shape[-1] // P
             groups.append((r0, nB, G, G))
             r0 += nB * G * G
+        shadow = None
         for layer in self.layers:
-            X, groups = layer.forward_ragged(X, groups)
+            X, groups, shadow = layer.forward_ragged(X, groups, shadow)
         C = X.shape[-1]
         Xn = Fn.FinalNormFn.apply(X, self.norm.weight, self.norm.bias)
         parts = torch.split(Xn, [nB * H * W for (_, nB, H, W) in groups]) if len(groups) > 1 else (Xn,)
@@ -388,7 +393,8 @@ class SwinTransformer(nn.Module):
         if self.use_dense_prediction:
             cls_parts, fea_parts, npatch = [], [], []
             all_fea = None
-            if self.ragged_multi_crop and len(bounds) > 1 and not self.ape and self._even_maps([x[a].shape[-1] for a, _ in bounds]):
+            several = len(bounds) > 1 or bounds[0][1] - bounds[0][0] > 1  # (one group of several crops -- the teacher's two global views -- is read where it lies too)
+            if self.ragged_multi_crop and several and not self.ape and self._even_maps([x[a].shape[-1] for a, _ in bounds]):
                 # every resolution group through the backbone at once (row-wise kernels see all rows, attention runs per group)
                 maps, all_fea = self.forward_feature_maps_multi([x[a:b] for a, b in bounds])
             else:

@@ -468,7 +468,7 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, *, g_in=None, rowmap=None, period_in
     ws = workspace(query(Q_LN_BWD_BLOCKS, rows, Cc) * 2 * Cc, x.device, slot=1)
     check(lib.esvit_layernorm_bwd(_code(dy.dtype), _p(dy), _p(x), _p(mean), _p(rstd), _p(gamma), _p(g_in), rows, Cc, _p(dx),
                                   _p(dgamma), _p(dbeta), _p(ws), _p(rowmap), 0 if rowmap is None else rowmap.numel(),
-                                  period_in, None, None, 0, _stream()), "layernorm_bwd")
+                                  period_in, None, 0, None, 0, _stream()), "layernorm_bwd")
     return dx, dgamma, dbeta
 
 
@@ -482,8 +482,23 @@ def layernorm_bwd_cast(dy, x, mean, rstd, gamma, *, g_in=None, rowscale=None, ro
     dgamma, dbeta = _ln_grad_outs(Cc, x.device, gb_out)
     ws = workspace(query(Q_LN_BWD_BLOCKS, rows, Cc) * 2 * Cc, x.device, slot=1)
     check(lib.esvit_layernorm_bwd(_code(dy.dtype), _p(dy), _p(x), _p(mean), _p(rstd), _p(gamma), _p(g_in), rows, Cc, _p(dx), _p(dgamma),
-                                  _p(dbeta), _p(ws), None, 0, 0, _p(dxa), _p(rowscale), rows_per_sample, _stream()), "layernorm_bwd(cast)")
+                                  _p(dbeta), _p(ws), None, 0, 0, _p(dxa), _code(dxa.dtype), _p(rowscale), rows_per_sample, _stream()), "layernorm_bwd(cast)")
     return dx, dxa, dgamma, dbeta
+
+
+def layernorm_bwd_to_act(dy, x, mean, rstd, gamma, *, gb_out=None):
+    """-> (cast(dx) in the activation dtype, dgamma, dbeta) from an fp32 upstream gradient `dy`, read as it is: the LayerNorm of the patch
+    embedding, whose dL/dy is the fp32 residual-stream gradient and whose dL/dx is only ever read as the operand of the projection's
+    weight gradient -- no fp32 dx is written and no cast pass follows"""
+    x, dy = _f32c(x), _f32c(dy)
+    Cc = x.shape[-1]
+    rows = x.numel() // Cc
+    dxa = torch.empty((rows, Cc), dtype=_ACT_DTYPE, device=x.device)
+    dgamma, dbeta = _ln_grad_outs(Cc, x.device, gb_out)
+    ws = workspace(query(Q_LN_BWD_BLOCKS, rows, Cc) * 2 * Cc, x.device, slot=1)
+    check(lib.esvit_layernorm_bwd(_code(dy.dtype), _p(dy), _p(x), _p(mean), _p(rstd), _p(gamma), None, rows, Cc, None, _p(dgamma),
+                                  _p(dbeta), _p(ws), None, 0, 0, _p(dxa), _code(dxa.dtype), None, 0, _stream()), "layernorm_bwd(to act)")
+    return dxa, dgamma, dbeta
 
 
 def merge_ln_fwd(x, gamma, beta, eps, H, W, dtype=None, out=None):
@@ -506,9 +521,10 @@ def merge_ln_fwd(x, gamma, beta, eps, H, W, dtype=None, out=None):
     return y, mean, rstd
 
 
-def merge_ln_bwd(dy, x, mean, rstd, gamma, H, W, dx_out=None, gb_out=None, accumulate=False):
+def merge_ln_bwd(dy, x, mean, rstd, gamma, H, W, dx_out=None, gb_out=None, accumulate=False, act_out=None, rowscale=None):
     """gb_out: optional fp32 [2, 4C] receiving (dgamma | dbeta); accumulate: add to it instead of overwriting (further
-    resolution groups sharing the parameters)"""
+    resolution groups sharing the parameters).  act_out: optional activation-dtype [nB*H*W, C] receiving cast(rowscale * dx)
+    (rowscale: per token row, or None) -- the MLP-branch operand of the block whose dL/dy this dx is (SwinBlockMultiFn's shadow)"""
     x, dy = _f32c(x), _actc(dy)
     nB, L, Cc = x.shape
     if dx_out is not None:
@@ -516,6 +532,11 @@ def merge_ln_bwd(dy, x, mean, rstd, gamma, H, W, dx_out=None, gb_out=None, accum
         dx = dx_out
     else:
         dx = torch.empty_like(x)
+    if act_out is not None:
+        assert act_out.numel() == x.numel() and act_out.dtype == dy.dtype and act_out.is_contiguous()
+        assert rowscale is None or (rowscale.numel() == nB * L and rowscale.dtype == torch.float32 and rowscale.is_contiguous())
+    else:
+        assert rowscale is None
     acc = bool(accumulate) and gb_out is not None
     gb = gb_out if gb_out is not None else torch.empty((2, 4 * Cc), dtype=torch.float32, device=x.device)
     assert gb.shape == (2, 4 * Cc) and gb.is_contiguous()
@@ -523,7 +544,7 @@ def merge_ln_bwd(dy, x, mean, rstd, gamma, H, W, dx_out=None, gb_out=None, accum
     rows = nB * (H // 2) * (W // 2)
     ws = workspace(query(Q_LN_BWD_BLOCKS, rows, 4 * Cc) * 8 * Cc, x.device, slot=1)
     check(lib.esvit_merge_ln_bwd(_code(dy.dtype), _p(dy), _p(x), _p(mean), _p(rstd), _p(gamma), nB, H, W, Cc, _p(dx), _p(dgamma),
-                                 _p(dbeta), _p(ws), int(acc), _stream()), "merge_ln_bwd")
+                                 _p(dbeta), _p(ws), _p(act_out), _p(rowscale), 1, int(acc), _stream()), "merge_ln_bwd")
     return dx, dgamma, dbeta
 
 

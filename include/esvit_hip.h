@@ -195,12 +195,14 @@ int esvit_layernorm_fwd(int dtype, const float* x, const float* gamma, const flo
 /* LayerNorm backward.  dy (dtype) is read at the mapped row when rowmap is given.
  * dx = g_in (optional fp32 residual gradient) + LN'(dy).  dgamma/dbeta partials are written to ws ([nblk,2,C] floats,
  * nblk = esvit_query(ESVIT_Q_LN_BWD_BLOCKS, rows, C, 0)) and reduced into dgamma/dbeta (fp32, overwritten).
- * dx_act (optional, activation dtype, un-mapped rows only) = rowscale[row / rows_per_sample] * dx: the DropPath-scaled
- * copy the next dgrad / wgrad GEMMs of the backward read (rowscale may be NULL = 1) -- saves one esvit_gather_cast pass. */
+ * dx_act (optional, un-mapped rows only) = rowscale[row / rows_per_sample] * dx: the DropPath-scaled copy the next dgrad / wgrad
+ * GEMMs of the backward read (rowscale may be NULL = 1) -- saves one esvit_gather_cast pass.  act_dtype: its dtype -- `dtype`, or
+ * ESVIT_BF16 while dy is fp32 (the patch-embedding norm, whose upstream gradient is the fp32 residual-stream gradient).  dx may be NULL
+ * when dx_act is given (only the copy is wanted; g_in must then be NULL). */
 int esvit_layernorm_bwd(int dtype, const void* dy, const float* x, const float* mean, const float* rstd,
                         const float* gamma, const float* g_in, int64_t rows, int C, float* dx,
                         float* dgamma, float* dbeta, float* ws, const int32_t* rowmap, int tokens,
-                        int period_in, void* dx_act, const float* rowscale, int rows_per_sample,
+                        int period_in, void* dx_act, int act_dtype, const float* rowscale, int rows_per_sample,
                         esvit_stream_t stream);
 
 /* ---- element-wise / data-movement helpers ------------------------------ */
@@ -226,10 +228,13 @@ int esvit_merge_ln_fwd(int dtype, const float* x, const float* gamma, const floa
                        int nB, int H, int W, int C, void* y, float* mean, float* rstd,
                        esvit_stream_t stream);
 /* backward of the above: dy dtype [nB*(H/2)*(W/2), 4C] -> dx fp32 [nB,H,W,C] (overwritten); dgamma / dbeta overwritten, or
- * added to when accumulate != 0 (further resolution groups sharing the parameters) */
+ * added to when accumulate != 0 (further resolution groups sharing the parameters).  dx_act (optional, `dtype`, [nB,H,W,C]) =
+ * rowscale[token row / rows_per_sample] * dx as in esvit_layernorm_bwd: the MLP-branch operand of the stage's LAST block, whose
+ * dL/dy this is. */
 int esvit_merge_ln_bwd(int dtype, const void* dy, const float* x, const float* mean, const float* rstd,
                        const float* gamma, int nB, int H, int W, int C, float* dx, float* dgamma,
-                       float* dbeta, float* ws, int accumulate, esvit_stream_t stream);
+                       float* dbeta, float* ws, void* dx_act, const float* rowscale, int rows_per_sample, int accumulate,
+                       esvit_stream_t stream);
 /* token mean (swin_transformer.py:688-689): x fp32 [nB,T,C] -> out fp32 [nB,C] (+ act copy) */
 int esvit_token_mean_fwd(int dtype, const float* x, int nB, int T, int C, float* out, void* out_act,
                          esvit_stream_t stream);

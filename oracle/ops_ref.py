@@ -304,6 +304,12 @@ def layernorm_bwd_cast(dy, x, mean, rstd, gamma, *, g_in=None, rowscale=None, ro
     return dx, _r(d2, dy.dtype), dg, db
 
 
+def layernorm_bwd_to_act(dy, x, mean, rstd, gamma, *, gb_out=None):
+    """fp32 upstream gradient in, only the activation-dtype dx out (esvit_amd/ops.py: the patch-embedding norm)"""
+    dx, dg, db = layernorm_bwd(dy.float(), x, mean, rstd, gamma, gb_out=gb_out)
+    return _r(dx.reshape(-1, x.shape[-1])), dg, db
+
+
 def _merge_gather(x, H, W):
     nB, L, C = x.shape
     xg = x.view(nB, H, W, C)
@@ -319,7 +325,7 @@ def merge_ln_fwd(x, gamma, beta, eps, H, W, dtype=None, out=None):
     return y, mean, rstd
 
 
-def merge_ln_bwd(dy, x, mean, rstd, gamma, H, W, dx_out=None, gb_out=None, accumulate=False):
+def merge_ln_bwd(dy, x, mean, rstd, gamma, H, W, dx_out=None, gb_out=None, accumulate=False, act_out=None, rowscale=None):
     nB, L, C = x.shape
     g = _merge_gather(x.float(), H, W)
     dg, dgamma, dbeta = layernorm_bwd(dy, g, mean, rstd, gamma)
@@ -337,6 +343,11 @@ def merge_ln_bwd(dy, x, mean, rstd, gamma, H, W, dx_out=None, gb_out=None, accum
     dx[:, 1::2, 0::2] = dg[..., C:2 * C]
     dx[:, 0::2, 1::2] = dg[..., 2 * C:3 * C]
     dx[:, 1::2, 1::2] = dg[..., 3 * C:]
+    if act_out is not None:  # cast(rowscale * dx): the MLP-branch operand of the block whose dL/dy this is
+        d2 = dx.view(nB * L, C)
+        if rowscale is not None:
+            d2 = d2 * rowscale.view(-1, 1)
+        act_out.view(nB * L, C).copy_(_r(d2, act_out.dtype))
     if dx_out is not None:
         dx_out.view(nB, L, C).copy_(dx.view(nB, L, C))
         return dx_out, dgamma, dbeta

@@ -100,6 +100,27 @@ def test_ragged_multi_crop_equals_reference_schedule(cpu_ops):
     check_ragged_equals_reference_schedule(L)
 
 
+def test_one_group_of_several_crops_rides_the_ragged_route(cpu_ops):
+    """the teacher's input -- two crops of ONE resolution -- is read where it lies (no torch.cat pass over the images): same outputs as
+    the reference's schedule, which concatenates them first (swin_transformer.py:741)"""
+    crops = [torch.randn(2, 3, 224, 224, generator=torch.Generator().manual_seed(7)),
+             torch.randn(2, 3, 224, 224, generator=torch.Generator().manual_seed(8))]
+    outs, routes = [], []
+    for ragged in (True, False):
+        teacher = build_nano()
+        GU.fill_state_dict(teacher.state_dict(), 0)
+        teacher.ragged_multi_crop = ragged
+        calls = []
+        orig = teacher.forward_feature_maps_multi
+        teacher.forward_feature_maps_multi = lambda groups, _o=orig, _c=calls: (_c.append(len(groups)), _o(groups))[1]
+        with torch.no_grad():
+            outs.append(teacher(crops))
+        routes.append(calls)
+    assert routes == [[1], []]
+    for a, b in zip(outs[0][:3], outs[1][:3]):
+        assert a.shape == b.shape and (a - b).abs().max().item() <= 1e-5 * (b.abs().max().item() + 1e-12)
+
+
 def test_odd_feature_maps_take_the_per_group_schedule(cpu_ops):
     """crops whose feature map is odd at a PatchMerging (112^2 at four stages: 28, 14, 7) cannot ride the ragged route (it has no
     padding step): the default forward falls back to the reference's per-group schedule, which pads them (swin_transformer.py:406-408),

@@ -365,6 +365,14 @@ def test_layernorm(mods, dt, C):
     _close("ln dx (cast variant)", dx2, dxr, 5e-5)
     _close("ln dx_act", dxa, dxar, _tol(dt, bf=8e-3))
     _close("ln dgamma (cast variant)", dg2, dgr, 5e-5)
+    # fp32 upstream gradient, only the activation-dtype dx (the patch-embedding norm: no fp32 dx, no cast pass)
+    dyf = _rand((rows, C), dev, 26)
+    dxa3, dg3, db3 = ops.layernorm_bwd_to_act(dyf, x, meanr, rstdr, g)
+    dxr3, dgr3, dbr3 = ref.layernorm_bwd(dyf, x, meanr, rstdr, g)
+    assert dxa3.dtype == ops.act_dtype()
+    _close("ln dx (fp32 dy -> act)", dxa3, dxr3, _tol(ops.act_dtype(), f32=5e-5, bf=8e-3))
+    _close("ln dgamma (fp32 dy -> act)", dg3, dgr3, 5e-5)
+    _close("ln dbeta (fp32 dy -> act)", db3, dbr3, 5e-5)
 
 
 @pytest.mark.parametrize("dt", DTYPES)
@@ -410,6 +418,14 @@ def test_merge_ln(mods, dt):
     _close("merge dx", dx, dxr, 5e-5)
     _close("merge dgamma", dg, dgr, 5e-5)
     _close("merge dbeta", db, dbr, 5e-5)
+    # + the cast, row-scaled copy at the un-merged token rows (the shadow of the stage's last block)
+    for rs in (_rand((nB * H * H,), dev, 34).abs() + 0.5, None):
+        act, actr = torch.empty((nB * H * H, C), dtype=dt, device=dev), torch.empty((nB * H * H, C), dtype=dt, device=dev)
+        dx2, dg2, _ = ops.merge_ln_bwd(dy, x, meanr, rstdr, g, H, H, act_out=act, rowscale=rs)
+        ref.merge_ln_bwd(dy, x, meanr, rstdr, g, H, H, act_out=actr, rowscale=rs)
+        _close("merge dx (shadow variant)", dx2, dxr, 5e-5)
+        _close("merge dgamma (shadow variant)", dg2, dgr, 5e-5)
+        _close("merge dx_act", act, actr, _tol(dt, bf=8e-3))
 
 
 @pytest.mark.parametrize("dt", DTYPES)
