@@ -33,6 +33,7 @@ class GemmDesc(C.Structure):
         ("colsum", vp), ("colsum_partial", vp),
         ("kernel", i32),
         ("rowstat", vp), ("rowstat_center", vp), ("rowstat_scale", f32),
+        ("colstat", vp),
     ]
 
 

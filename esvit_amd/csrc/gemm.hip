@@ -45,7 +45,7 @@ inline double round_efficiency(long wgs, long slots) {
 // the row map / row statistics extras that live in the 128-row kernels
 bool p8_supports(int dtype, const esvit_gemm_desc& d) {
     if (dtype != ESVIT_BF16 || d.K % 64 != 0 || d.rowmap) return false;
-    if (d.rowstat && (d.M % 256 != 0 || d.N % 256 != 0)) return false;  // row statistics: whole 256 x 256 tiles only (32-column blocks)
+    if (d.rowstat && (d.M % 256 != 0 || d.N % 256 != 0 || d.colstat)) return false;  // row statistics: whole 256 x 256 tiles only (32-column blocks), no column sums
     if (d.a_kstrided && !d.b_kstrided) return false;
     const long a_bytes = (d.a_kstrided ? (long)d.K : (long)d.M) * d.lda * 2, b_bytes = (d.b_kstrided ? (long)d.K : (long)d.N) * d.ldb * 2;
     return a_bytes < 0xfff00000L && b_bytes < 0xfff00000L;
@@ -218,6 +218,7 @@ int validate(int dtype, esvit_gemm_desc& d) {
     ESVIT_CHECK_ARG(d.epilogue >= 0 && d.epilogue <= ESVIT_EPI_QGELU_BWD, "esvit_gemm: bad epilogue %d", d.epilogue);
     if (d.colsum && d.splitk > 1) ESVIT_CHECK_ARG(d.colsum_partial != nullptr, "esvit_gemm: colsum with split-K needs colsum_partial");
     if (d.colsum) ESVIT_CHECK_ARG(d.batch == 1, "esvit_gemm: colsum is not batched");
+    if (d.colstat) ESVIT_CHECK_ARG(d.rowstat != nullptr, "esvit_gemm: colstat comes with rowstat");
     if (d.rowstat) {
         ESVIT_CHECK_ARG(dtype == ESVIT_BF16 && !d.a_kstrided && !d.b_kstrided && d.batch == 1 && d.splitk <= 1 && !d.out_f32 && d.epilogue == 0 &&
                             !d.residual && !d.rowmap && !d.rowscale && !d.bias && d.alpha == 1.f,
@@ -225,6 +226,7 @@ int validate(int dtype, esvit_gemm_desc& d) {
         ESVIT_CHECK_ARG(d.M % 128 == 0 && d.N % 128 == 0 && d.ldc % 8 == 0 && ((uintptr_t)d.C % 16 == 0) &&
                             (!d.rowstat_center || (uintptr_t)d.rowstat_center % 16 == 0),
                         "esvit_gemm: row statistics need M and N in whole 128 x 128 tiles (M=%d N=%d)", d.M, d.N);
+        if (d.colstat) ESVIT_CHECK_ARG(d.kernel != ESVIT_GEMM_P8 && (uintptr_t)d.colstat % 16 == 0, "esvit_gemm: colstat lives in the 128 x 128 statistics epilogue");
         ESVIT_CHECK_ARG(d.kernel == ESVIT_GEMM_AUTO || d.kernel == ESVIT_GEMM_DMA4 || d.kernel == ESVIT_GEMM_P8,
                         "esvit_gemm: row statistics exist in the 128 x 128 tile of the default main loop and in the 256 x 256 eight-phase loop");
     }

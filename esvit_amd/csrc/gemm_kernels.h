@@ -568,6 +568,32 @@ __device__ __forceinline__ void epilogue_direct_at(const esvit_gemm_desc& p, f32
             }
         }
     });
+    if constexpr (RS) {
+        // esvit_gemm_desc::colstat: the stored logits (alpha = 1, no bias on this path: the accumulators rounded to bf16) summed over the
+        // wave tile's 16 * FM rows per column.  The 16 rows of a block sit in lanes c = 0 .. 15: fold the row blocks in registers, then the
+        // lanes; lane c == 0 of every group writes its 4 x FN columns.  (Kept out of the row loop above: one column block at a time.)
+        // (the pointer is fetched from the kernel-argument segment HERE: as one more descriptor field live across the main loop it
+        // pushed two scalars of every instance of the kernel into scratch memory, whose reloads cost this epilogue ~1 us per tile)
+        float* colstat;
+        asm volatile("s_load_dwordx2 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)"
+                     : "=s"(colstat)
+                     : "s"(__builtin_amdgcn_kernarg_segment_ptr()), "n"(offsetof(esvit_gemm_desc, colstat))
+                     : "memory");
+        if (colstat) {
+            float* cp = colstat + (wrow0 / (16 * FM)) * (long)p.N + col;
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                f32x4 t = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) t[e] += (float)(bf16)acc[i][j][e];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) t[e] = row16_sum(t[e]);
+                if (c == 0) *reinterpret_cast<f32x4*>(cp + 16 * j) = t;
+            }
+        }
+    }
 }
 
 template <int BM, int BN, int WM, int WN, int KIND, bool OUTF32, bool RS = false>

@@ -84,11 +84,14 @@ class DINOHead(nn.Module):
         return self._finish(Fn.dino_head(x2, prm, self._stats_request()), lead)
 
     def _stats_request(self):
-        return None if self.logit_stats is None else self.logit_stats[:2]
+        if self.logit_stats is None:
+            return None
+        return self.logit_stats[:2] + (bool(self.logit_stats[3]) if len(self.logit_stats) > 3 else False,)
 
     def _finish(self, out, lead):
         y, mx, lse = out
         y = y.view(*lead, y.shape[-1])
         if mx is not None:
-            y.esvit_row_stats = (self.logit_stats[2], mx, lse)
+            # (token, row max, row log-sum-exp, batch sums per column or None: the last one does not depend on centre / temperature)
+            y.esvit_row_stats = (self.logit_stats[2], mx, lse, getattr(mx, "esvit_col_sums", None))
         return y

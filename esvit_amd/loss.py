@@ -69,6 +69,12 @@ def _taken_stats(x, token):
     return None
 
 
+def _taken_col_sums(x):
+    """batch sums per column a teacher head's last-layer GEMM attached to its logits (fp32 [K]), else None"""
+    st = getattr(x, "esvit_row_stats", None)
+    return st[3] if st is not None and len(st) > 3 else None
+
+
 class _DeferredCenter:
     """The centre update of step n is only needed by the loss of step n+1 (main_esvit.py:748, 752-770): the all-reduce of
     the batch sums is launched asynchronously right after they are computed -- RCCL runs it on its own stream under the
@@ -113,7 +119,8 @@ class _DeferredCenter:
         for who, model, inv_t, cens in (("t", teacher, inv_tt, self._centers()), ("s", student, inv_st, (None, None))):
             for lvl, (head, cen) in enumerate(zip(_heads_of(model), cens)):
                 if head is not None:
-                    head.logit_stats = (inv_t, None if cen is None else cen.view(-1), self._token(who + str(lvl), inv_t))
+                    # (the teacher heads also hand over the column sums of their logits: the centre update's input)
+                    head.logit_stats = (inv_t, None if cen is None else cen.view(-1), self._token(who + str(lvl), inv_t), who == "t")
 
     @staticmethod
     def disarm_logit_stats(student, teacher):
@@ -294,6 +301,7 @@ class DDINOLoss(_DeferredCenter, nn.Module):
         inv_st = 1.0 / self.student_temp
         st_tc, st_tg = _taken_stats(t_cls, self._token("t0", inv_tt)), _taken_stats(t_reg, self._token("t1", inv_tt))
         st_sc, st_sg = _taken_stats(s_cls, self._token("s0", inv_st)), _taken_stats(s_reg, self._token("s1", inv_st))
+        cs_tc, cs_tg = _taken_col_sums(t_cls), _taken_col_sums(t_reg)
         s_cls_c, s_reg_c = s_cls.contiguous(), s_reg.contiguous()
         t_cls, t_reg = t_cls.detach().contiguous(), t_reg.detach().contiguous()
         Tt = int(t_np[0])
@@ -320,17 +328,21 @@ class DDINOLoss(_DeferredCenter, nn.Module):
         _, ds_reg = o.dino_ce(s_reg_c.detach(), t_reg, self.center_grid, mx_g, lse_g, tm_reg, tb["w_reg"], inv_st, inv_tt,
                               row_loss=row_loss[n_cls:], row_order=tb["cm_row"], s_stats=st_sg)  # image-major work order: teacher rows stay cached
         loss = o.sum_f32(row_loss)
-        self.update_center(t_cls, t_reg)
+        self.update_center(t_cls, t_reg, col_sums=(cs_tc, cs_tg))
         return _LossFn.apply(loss, self.assume_unit_grad, s_cls, s_reg, ds_cls, ds_reg)
 
     @torch.no_grad()
-    def update_center(self, teacher_output, teacher_grid_output):
-        """main_esvit.py:752-770; the two (1,K) partial sums travel in ONE all-reduce."""
+    def update_center(self, teacher_output, teacher_grid_output, col_sums=(None, None)):
+        """main_esvit.py:752-770; the two (1,K) partial sums travel in ONE all-reduce.  col_sums: the batch sums the heads' last-layer
+        GEMMs already produced (a 1.6 GB read of the region logits less per step at B = 128), else they are computed here."""
         o = _ops()
         K = self.center.shape[1]
         buf = torch.empty((2, K), dtype=torch.float32, device=self.center.device)
-        o.colsum(teacher_output, out=buf[0])
-        o.colsum(teacher_grid_output, out=buf[1])
+        for row, (t, cs) in enumerate(zip((teacher_output, teacher_grid_output), col_sums)):
+            if cs is not None and cs.numel() == K:
+                buf[row].copy_(cs.view(-1))
+            else:
+                o.colsum(t, out=buf[row])
         r_cls, r_reg = teacher_output.shape[0], teacher_grid_output.shape[0]
 
         def apply(b, w):

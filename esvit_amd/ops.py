@@ -169,7 +169,7 @@ def p8_supported(kw):
 
 def _gemm_desc(kw):
     d = GemmDesc()
-    for k in ("A", "B", "C", "bias", "residual", "rowmap", "rowscale", "aux", "partial", "colsum", "colsum_partial", "rowstat", "rowstat_center"):
+    for k in ("A", "B", "C", "bias", "residual", "rowmap", "rowscale", "aux", "partial", "colsum", "colsum_partial", "rowstat", "rowstat_center", "colstat"):
         setattr(d, k, _p(kw.get(k)))
     d.rowstat_scale = float(kw.get("rowstat_scale", 0.0))
     for k in ("M", "N", "K", "lda", "ldb", "ldc", "a_kstrided", "b_kstrided", "strideA", "strideB", "strideC", "ldr",
@@ -224,14 +224,17 @@ def linear_fwd(x, w, bias=None, *, gelu=False, want_preact=False, residual=None,
     x [M, K] act; w [N, K] act (cached cast of the fp32 parameter); bias fp32 [N].
     rowmap (int32 [period]) scatters window rows to token rows (out_rows rows, tokens per image =
     rowmap_tokens); residual fp32 [out_rows, N] is added at the destination row.
-    row_stats = (inv_temp, center fp32 [N] or None): also return the softmax statistics of z = (y - center) * inv_temp, the
-    outputs of teacher_row_stats -> (y, row_max, row_lse); the shape must pass row_stats_supported."""
+    row_stats = (inv_temp, center fp32 [N] or None[, want_col_sums]): also return the softmax statistics of z = (y - center) * inv_temp,
+    the outputs of teacher_row_stats -> (y, row_max, row_lse); the shape must pass row_stats_supported.  With want_col_sums the batch
+    sum of the stored logits per column (what the centre update reads, main_esvit.py:752-770) rides along as the attribute
+    `esvit_col_sums` of row_max (fp32 [N]; absent when the main loop in use has no such epilogue)."""
     x, w = _actc(x), _actc(w)
     M, K = x.shape
     N = w.shape[0]
     assert w.shape[1] == K and x.dtype == w.dtype
     if row_stats is not None:
-        inv_temp, cen = row_stats
+        inv_temp, cen = row_stats[:2]
+        want_cs = len(row_stats) > 2 and bool(row_stats[2])
         assert row_stats_supported(x.dtype, M, N) and bias is None and not gelu and residual is None and rowmap is None and not out_f32
         y = torch.empty((M, N), dtype=x.dtype, device=x.device)
         cen = None if cen is None else _f32c(cen)
@@ -239,11 +242,15 @@ def linear_fwd(x, w, bias=None, *, gelu=False, want_preact=False, residual=None,
         kern = gemm_select(x.dtype, M=M, N=N, K=K, rowstat=y)[0]
         nb = N // (32 if kern == GEMM_P8 else 64)
         st = torch.empty((M, nb, 2), dtype=torch.float32, device=x.device)
+        # column sums of the stored logits per 64-row wave tile (the statistics epilogue of the 128 x 128 tile only)
+        cst = torch.empty((M // 64, N), dtype=torch.float32, device=x.device) if (want_cs and kern != GEMM_P8) else None
         _gemm(x.dtype, A=x, B=w, C=y, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, rowstat=st, rowstat_center=cen, rowstat_scale=float(inv_temp) * LOG2E,
-              kernel=kern)
+              colstat=cst, kernel=kern)
         mx = torch.empty((M,), dtype=torch.float32, device=x.device)
         lse = torch.empty_like(mx)
         check(lib.esvit_rowstat_combine(_p(st), M, nb, _p(mx), _p(lse), _stream()), "rowstat_combine")
+        if cst is not None:
+            mx.esvit_col_sums = colsum(cst)
         return y, mx, lse
     rows = M if out_rows is None else out_rows
     y = torch.empty((rows, N), dtype=torch.float32 if out_f32 else x.dtype, device=x.device)

@@ -118,6 +118,10 @@ typedef struct {
     float* rowstat;
     const float* rowstat_center;
     float rowstat_scale;
+    /* optional, with rowstat on the 128 x 128 tile only (not ESVIT_GEMM_P8): fp32 [M / 64, N], the sums of the STORED logits over
+     * each 64-row wave tile per column -- esvit_partial_reduce folds them into the batch sum the centre update needs
+     * (main_esvit.py:752-770) without another pass over the logits. */
+    float* colstat;
 } esvit_gemm_desc;
 
 /* main loops of the family (esvit_gemm_desc.kernel; what esvit_gemm_select returns) */

@@ -108,9 +108,11 @@ def row_stats_supported(dt, M, N):
 def linear_fwd(x, w, bias=None, *, gelu=False, want_preact=False, residual=None, rowmap=None, rowmap_tokens=0,
                out_rows=None, rowscale=None, rows_per_sample=0, out_f32=False, quick=False, row_stats=None):
     if row_stats is not None:  # the logits as stored (rounded) and their softmax statistics (vision_transformer.py:418 + main_esvit.py:629,694)
-        inv_temp, cen = row_stats
+        inv_temp, cen = row_stats[:2]
         y = _r(x.float() @ w.float().t(), x.dtype)
         mx, lse = teacher_row_stats(y, torch.zeros(y.shape[1], device=y.device) if cen is None else cen, inv_temp)
+        if len(row_stats) > 2 and row_stats[2]:  # + the batch sums of the stored logits per column (esvit_gemm_desc::colstat)
+            mx.esvit_col_sums = y.float().sum(0)
         return y, mx, lse
     acc = x.float() @ w.float().t()
     if bias is not None:

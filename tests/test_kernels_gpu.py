@@ -679,10 +679,19 @@ def test_last_layer_row_statistics(mods, M, N, K, centred):
     ops.FORCE_GEMM_KERNEL = 5 if (M % 256 == 0 and N % 256 == 0 and M >= 1024) else 0
     try:
         assert ops.gemm_select(dt, M=M, N=N, K=K, rowstat=z)[0] == (5 if ops.FORCE_GEMM_KERNEL else 2)
-        y, mx, lse = ops.linear_fwd(z, w, row_stats=(inv_t, cen))
+        y, mx, lse = ops.linear_fwd(z, w, row_stats=(inv_t, cen, True))
     finally:
         ops.FORCE_GEMM_KERNEL = 0
     assert torch.equal(y, ops.linear_fwd(z, w))  # the logits themselves do not change
+    # esvit_gemm_desc::colstat: the batch sum of the STORED logits per column (the centre update's input) from the same epilogue --
+    # the 128 x 128 tile only; the eight-phase loop does not offer it and the attribute is then absent
+    cs = getattr(mx, "esvit_col_sums", None)
+    if M % 256 == 0 and N % 256 == 0 and M >= 1024:
+        assert cs is None
+    else:
+        assert cs is not None and cs.shape == (N,)
+        _close("column sums of the stored logits", cs, y.float().sum(0), 2e-5)
+        _close("column sums vs esvit_colsum", cs, ops.colsum(y), 2e-5)
     zero = torch.zeros(N, device=dev)
     mx0, lse0 = ops.teacher_row_stats(y, zero if cen is None else cen, inv_t)
     _close("row max", mx, mx0, 1e-6)

@@ -482,8 +482,12 @@ def test_logit_stats_handover_is_taken_and_falls_back(lib_built):
     import esvit_amd.loss as L
     from esvit_amd import engine, ops
     dev = _setup("bf16")
-    calls = {"teacher_row_stats": 0, "ce_with_student_stats": 0, "ce": 0}
-    real_trs, real_ce = ops.teacher_row_stats, ops.dino_ce
+    calls = {"teacher_row_stats": 0, "ce_with_student_stats": 0, "ce": 0, "colsum_of_logits": 0}
+    real_trs, real_ce, real_cs = ops.teacher_row_stats, ops.dino_ce, ops.colsum
+
+    def cs(x, **k):  # (the centre update's own pass over the teacher logits: bf16 [rows, K])
+        calls["colsum_of_logits"] += int(x.dtype == torch.bfloat16 and x.shape[-1] == GU.NANO_HEAD["out_dim"])
+        return real_cs(x, **k)
 
     def trs(*a, **k):
         calls["teacher_row_stats"] += 1
@@ -494,7 +498,7 @@ def test_logit_stats_handover_is_taken_and_falls_back(lib_built):
         calls["ce_with_student_stats"] += int(k.get("s_stats") is not None)
         return real_ce(*a, **k)
     try:
-        ops.teacher_row_stats, ops.dino_ce = trs, ce
+        ops.teacher_row_stats, ops.dino_ce, ops.colsum = trs, ce, cs
         K, B = GU.NANO_HEAD["out_dim"], 64  # rows: student 10 B / 170 B, teacher 2 B / 98 B -- all whole 128-row tiles at B = 64
         crops = _to(GU.make_crops(B, seed=91), dev)
 
@@ -509,11 +513,24 @@ def test_logit_stats_handover_is_taken_and_falls_back(lib_built):
         student, teacher, loss_fn = fresh()
         tr = engine.EsvitTrainer(student, teacher, loss_fn, clip_grad=3.0, freeze_last_layer=0)
         tr.step(crops, 1e-4, 0.04, 0.996, 0)  # (first step: one stream, fills the tables)
+        c_armed = (loss_fn.center.clone(), loss_fn.center_grid.clone())
         for k in calls:
             calls[k] = 0
         tr.step(crops, 1e-4, 0.04, 0.996, 0)
         assert L.LOGIT_STATS and calls["teacher_row_stats"] == 0, calls
         assert calls["ce"] >= 2 and calls["ce_with_student_stats"] == calls["ce"], calls
+        assert calls["colsum_of_logits"] == 0, calls  # the centre update took the column sums of the teacher heads' GEMMs
+        # the first step with the hand-over switched off (same weights, same logits): the centres from the loss's own column sums
+        student, teacher, loss_fn = fresh()
+        L.LOGIT_STATS = False
+        try:
+            tr2 = engine.EsvitTrainer(student, teacher, loss_fn, clip_grad=3.0, freeze_last_layer=0)
+            tr2.step(crops, 1e-4, 0.04, 0.996, 0)
+        finally:
+            L.LOGIT_STATS = True
+        assert calls["colsum_of_logits"] >= 2, calls
+        for a, b in zip(c_armed, (loss_fn.center, loss_fn.center_grid)):
+            assert (a - b).abs().max().item() < 2e-6 * (1 + b.abs().max().item()), (a - b).abs().max().item()
         # (2) armed forwards, then the centres move before the loss is called: own passes, same value as a loss that was never armed
         student, teacher, loss_fn = fresh()
         with torch.no_grad():
@@ -535,7 +552,7 @@ def test_logit_stats_handover_is_taken_and_falls_back(lib_built):
             never_armed = loss_fn(s_out, t_out, 0).item()
         assert abs(armed_then_stale - never_armed) < 1e-6, (armed_then_stale, never_armed)
     finally:
-        ops.teacher_row_stats, ops.dino_ce = real_trs, real_ce
+        ops.teacher_row_stats, ops.dino_ce, ops.colsum = real_trs, real_ce, real_cs
         _teardown()
 
 
