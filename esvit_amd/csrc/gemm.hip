@@ -125,6 +125,9 @@ GemmChoice choose(int dtype, const esvit_gemm_desc& d) {
         }
     }
     if (want == ESVIT_GEMM_DMA4W && !(d.N % 96 == 0)) want = ESVIT_GEMM_DMA4;
+#ifdef ESVIT_NO_TILE192  // tools/trace_two_libs.sh: what the launches on the (spilling) 128 x 192 instance cost on the 128 x 128 / 128 x 96 ones
+    if (want == ESVIT_GEMM_DMA4W && d.N % 192 == 0 && d.kernel == ESVIT_GEMM_AUTO) want = ESVIT_GEMM_DMA4;
+#endif
     c.kernel = want;
     if (want == ESVIT_GEMM_P8) c.bm = c.bn = 256;
     else if (want == ESVIT_GEMM_P8N) {
