@@ -360,7 +360,7 @@ def main():
     if args.per_group:
         student.ragged_multi_crop = teacher.ragged_multi_crop = False
     torch.manual_seed(1000 + rank)  # ... but every rank draws its own stochastic-depth masks (and has its own crops)
-    trainer = EsvitTrainer(student, teacher, loss_fn, clip_grad=3.0, freeze_last_layer=1, teacher_stream=not args.single_stream, wgrad_stream=not args.single_stream,
+    trainer = EsvitTrainer(student, teacher, loss_fn, clip_grad=3.0, freeze_last_layer=1, teacher_stream=not args.single_stream,
                            grad_payload=args.grad_payload)
     B = args.batch
     crops = [c.to(dev) for c in GU.make_crops(B, seed=1234 + rank)]
@@ -426,15 +426,12 @@ def main():
         prof = []
         ops.GEMM_PROFILE = prof
         side, trainer._side = trainer._side, None  # one stream while instrumented: a launch's events then bracket that launch alone
-        import esvit_amd.functional as _Fn
-        wg_side, _Fn.WGRAD_STREAM = _Fn.WGRAD_STREAM, None
         for _ in range(PROF_STEPS):  # every rank runs them (the collectives need all ranks); rank 0 reports
             trainer.step(crops, lr, wd, mom, epoch)
             prof_steps += 1
         sync()
         ops.GEMM_PROFILE = None
         trainer._side = side
-        _Fn.WGRAD_STREAM = wg_side
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -177,16 +177,8 @@ class EsvitTrainer:
     """teacher fwd -> student fwd -> loss -> backward (+ overlapped grad all-reduce) -> fused clip/AdamW/EMA."""
 
     def __init__(self, student, teacher, loss_fn, clip_grad=3.0, freeze_last_layer=1, bucket_mb=32, updater=None, teacher_stream=True,
-                 grad_payload="fp32", wgrad_stream=True):
+                 grad_payload="fp32"):
         self.student, self.teacher, self.loss_fn = student, teacher, loss_fn
-        # weight-gradient GEMMs of the ragged Swin blocks on a second HIP stream beside the data-gradient chain (functional._wgrad)
-        from . import functional as _Fn
-        on_gpu = next(student.parameters()).is_cuda
-        if wgrad_stream and on_gpu and not os.environ.get("ESVIT_NO_WGRAD_STREAM"):  # (the variable: same-box A/B runs)
-            if _Fn.WGRAD_STREAM is None:
-                _Fn.WGRAD_STREAM = torch.cuda.Stream()
-        elif on_gpu:
-            _Fn.WGRAD_STREAM = None
         # the teacher forward (no autograd, its own scratch) runs on a second HIP stream beside the student forward: the two
         # streams fill each other's tails and launch gaps (+0.7 % at B = 128; same loss to 1e-5)
         self._side = torch.cuda.Stream() if (teacher_stream and next(student.parameters()).is_cuda) else None

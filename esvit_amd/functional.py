@@ -66,51 +66,15 @@ def _alias(t, sink):
     return t.detach() if sink is not None else t
 
 
-# Weight gradients beside the data-gradient chain.  Nothing in a block's backward reads a weight gradient, so inside the backward of a
-# ragged Swin block (`_wgrad_overlap`) the weight-gradient GEMMs are enqueued on a second HIP stream: they fill the tails and the launch
-# gaps of the chain of data-gradient GEMMs, LayerNorm and attention backwards on the main stream.  The block's backward joins the two
-# streams before it returns, so autograd, the gradient hooks of the reducer and the update only ever see finished gradients.  The
-# stream is set by the trainer (engine.EsvitTrainer(wgrad_stream=True)); None = everything on the current stream.
-WGRAD_STREAM = None
-_wgrad_side = None  # the stream while a backward that joins it is running, else None
-
-
-class _wgrad_overlap:
-    def __enter__(self):
-        global _wgrad_side
-        _wgrad_side = WGRAD_STREAM if (WGRAD_STREAM is not None and torch.cuda.is_available()) else None
-        return self
-
-    def __exit__(self, *exc):
-        global _wgrad_side
-        side, _wgrad_side = _wgrad_side, None
-        if side is not None:
-            torch.cuda.current_stream().wait_stream(side)
-        return False
-
-
 def _wgrad(dy, x, param, shape2d=None, want_bias=False, bias_param=None):
     """weight (and bias) gradient of `param` = dy^T x; written straight into the data-parallel reducer's bucket slots when
     they are armed (params.grad_out), and handed to autograd as fresh aliases so that AccumulateGrad adopts them without a copy"""
     o = ops_module()
     sink = P.grad_out(param, shape2d)
-    sink_b = P.grad_out(bias_param) if (want_bias and bias_param is not None) else None
-    side = _wgrad_side
-    if side is None or not dy.is_cuda:
-        if not want_bias:
-            return _alias(o.linear_wgrad(dy, x, out=sink), sink)
-        dw, db = o.linear_wgrad(dy, x, out=sink, want_bias=True, db_out=sink_b)
-        return _alias(dw, sink), _alias(db, sink_b)
-    side.wait_stream(torch.cuda.current_stream())  # the operands were produced on the main stream
-    with torch.cuda.stream(side):
-        if want_bias:
-            dw, db = o.linear_wgrad(dy, x, out=sink, want_bias=True, db_out=sink_b)
-        else:
-            dw, db = o.linear_wgrad(dy, x, out=sink), None
-    for t in (dy, x):
-        t.record_stream(side)  # (their memory must not be handed out again before the side stream has read it)
     if not want_bias:
-        return _alias(dw, sink)
+        return _alias(o.linear_wgrad(dy, x, out=sink), sink)
+    sink_b = P.grad_out(bias_param) if bias_param is not None else None
+    dw, db = o.linear_wgrad(dy, x, out=sink, want_bias=True, db_out=sink_b)
     return _alias(dw, sink), _alias(db, sink_b)
 
 
@@ -342,11 +306,6 @@ class SwinBlockMultiFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gy, gysh, *_unused):
-        with _wgrad_overlap():  # (joined before the gradients are handed back)
-            return SwinBlockMultiFn._backward(ctx, gy, gysh)
-
-    @staticmethod
-    def _backward(ctx, gy, gysh):
         o = ops_module()
         segs, nH, dp_rows = ctx.segs, ctx.nH, ctx.dp_rows
         if ctx.fused_mlp:
