@@ -84,7 +84,12 @@ GemmChoice choose(int dtype, const esvit_gemm_desc& d) {
         // -12..-16 %, stage-3 fc2 forward -25 %, head fc2 forward -6..-9 %, the split-K data gradient of the last layer -6 %, its
         // weight gradient -11 %.  NOT taken: 384-wide data gradients on the 256 x 128 variant (+11 % in the step), and anything
         // with a short reduction (the workgroup has no partner to hide its epilogue behind).
-        if (p8_supports(dtype, d) && d.batch <= 1 && !d.a_kstrided && d.K >= 2048 && d.N % 256 == 0 && d.M >= 4096 && !gelu_bwd_ &&
+#ifdef ESVIT_P8_K768  // tools/trace_two_libs.sh: the K = 768 forwards of stage 3 and of the head's first layer (N >= 2048) too
+        const bool k_ok = d.K >= 2048 || (d.K >= 768 && d.N >= 2048 && !d.b_kstrided);
+#else
+        const bool k_ok = d.K >= 2048;
+#endif
+        if (p8_supports(dtype, d) && d.batch <= 1 && !d.a_kstrided && k_ok && d.N % 256 == 0 && d.M >= 4096 && !gelu_bwd_ &&
             (d.N >= 768 || d.splitk > 1)) {
             want = ESVIT_GEMM_P8;
         } else if (p8_supports(dtype, d) && d.batch <= 1 && d.a_kstrided && d.M % 256 == 0 && d.N % 256 == 0 && (long)d.M * d.N >= 2000000L
