@@ -75,6 +75,8 @@ SIGNATURES = {
     "esvit_merge_ln_bwd": (C.c_int, [C.c_int, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp]),
     "esvit_token_mean_fwd": (C.c_int, [C.c_int, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp]),
     "esvit_token_mean_bwd": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp]),
+    "esvit_attn_branch_fwd": (C.c_int, [C.c_int, vp, vp, vp, f32, vp, vp, vp, vp, vp, C.c_int, vp, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, f32,
+                                        vp, vp, vp, vp, vp, vp, vp, vp]),
     "esvit_window_attn_fwd": (C.c_int, [C.c_int, vp, vp, vp, C.c_int, vp, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, f32, vp, vp, vp, vp]),
     "esvit_window_attn_bwd": (C.c_int, [C.c_int, vp, vp, vp, C.c_int, vp, vp, vp, vp, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, f32, vp, vp, vp, vp]),
     "esvit_relpos_bias_bwd": (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp]),

@@ -801,6 +801,11 @@ static int fill_bias_frag(const float* rel_table, int ws, int N, int nH, float* 
     return ESVIT_OK;
 }
 
+// (attn_branch.hip fills the same fragment-order bias)
+int esvit_i_fill_bias_frag(const float* rel_table, int ws, int N, int nH, float* bias_frag_ws, hipStream_t stream) {
+    return fill_bias_frag(rel_table, ws, N, nH, bias_frag_ws, stream);
+}
+
 extern "C" int esvit_window_attn_fwd(int dtype, const void* qkv, const float* qkv_bias, const int32_t* win2tok, int L,
                                      const float* rel_table, int ws, float* bias_frag_ws, const int32_t* region_ids, int nW, int nB, int N,
                                      int nH, int hd, float scale, void* out, float* lse, float* attn_out, esvit_stream_t s_) {

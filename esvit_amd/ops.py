@@ -659,6 +659,37 @@ def window_attn_fwd(qkv, qkv_bias, win2tok, L, rel_table, ws, region_ids, nW, N,
     return (out, lse, attn) if want_attn else (out, lse)
 
 
+def attn_branch_supported(dt, Cc, nH, N):
+    """the fused attention branch (esvit_attn_branch_fwd) exists for this shape: bf16, head_dim 32, C in {96, 192}, <= 64-token windows"""
+    return dt == torch.bfloat16 and Cc in (96, 192) and Cc == 32 * nH and N <= 64
+
+
+def attn_branch_fwd(x, gamma, beta, eps, Wqkv_p, bqkv, Wproj_p, bproj, win2tok, L, rel_table, ws, region_ids, nW, N, nH, scale, *,
+                    rowscale=None, out=None, bias_frag=None, save=False):
+    """x fp32 [nB*L, C] token rows of one resolution group -> y fp32 = x + rowscale * (proj(window_attention(qkv(LayerNorm(x)))) + b_proj)
+    in one kernel.  Wqkv_p / Wproj_p: cast_weight(W, perm32=True) of qkv.weight / proj.weight.  save=True also returns what the
+    unfused backward reads: (y, (xw, mean, rstd, qkv, ao)).  bias_frag / rel_table as for window_attn_fwd."""
+    x = _f32c(x)
+    rows, Cc = x.shape
+    nB = rows // L
+    assert rows == nB * L and Wqkv_p.shape == (3 * Cc, Cc) and Wproj_p.shape == (Cc, Cc) and Wqkv_p.dtype == torch.bfloat16
+    y = torch.empty_like(x) if out is None else out
+    assert y.shape == x.shape and y.dtype == torch.float32 and y.is_contiguous()
+    xw = qkv = ao = mean = rstd = None
+    if save:
+        xw = torch.empty((rows, Cc), dtype=torch.bfloat16, device=x.device)
+        qkv = torch.empty((rows, 3 * Cc), dtype=torch.bfloat16, device=x.device)
+        ao = torch.empty((rows, Cc), dtype=torch.bfloat16, device=x.device)
+        mean = torch.empty((rows,), dtype=torch.float32, device=x.device)
+        rstd = torch.empty_like(mean)
+    bias_ws = bias_frag if bias_frag is not None else workspace(2 * nH * attn_frag_elems(N), x.device, slot=2)
+    assert rel_table is not None or bias_frag is not None
+    check(lib.esvit_attn_branch_fwd(BF16, _p(x), _p(_f32c(gamma)), _p(_f32c(beta)), eps, _p(Wqkv_p), _p(_f32c(bqkv)), _p(Wproj_p), _p(_f32c(bproj)),
+                                    _p(win2tok), L, _p(None if rel_table is None else _f32c(rel_table)), ws, _p(bias_ws), _p(region_ids), nW, nB, N, nH,
+                                    scale, _p(rowscale), _p(y), _p(xw), _p(qkv), _p(ao), _p(mean), _p(rstd), _stream()), "attn_branch_fwd")
+    return (y, (xw, mean, rstd, qkv, ao)) if save else y
+
+
 def window_attn_bwd(qkv, qkv_bias, win2tok, L, dout, fwd_out, lse, rel_table, ws, region_ids, nW, N, nH, scale, dqkv_out=None, bias_frag=None):
     """-> (dqkv act [nB*L, 3C], dbias_ws fp32 [parts, nH, frag], dpad_ws fp32 [rows, 2C])."""
     qkv, dout = _actc(qkv), _actc(dout)

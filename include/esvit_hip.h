@@ -246,6 +246,21 @@ int esvit_token_mean_fwd(int dtype, const float* x, int nB, int T, int C, float*
 int esvit_token_mean_bwd(const float* g_mean, const float* g_tok, int nB, int T, int C, float* dx,
                          esvit_stream_t stream);
 
+/* ---- fused attention branch of a Swin block (swin_transformer.py:283-330 with 120-152) --------------------
+ * y = x + rowscale * (proj(window_attention(qkv(LayerNorm(x)))) + b_proj) in ONE kernel for 7x7 windows (N = ws*ws <= 64),
+ * head_dim 32, C = 32 nH in {96, 192}, bf16 activations: LayerNorm output, qkv and the attention output stay on the chip
+ * (8 B per token-channel through HBM).  x, y fp32 [nB*L, C] token-ordered rows of one resolution group; win2tok / region_ids /
+ * rel_table / bias_frag_ws / scale as for esvit_window_attn_fwd (zero-pad slots carry q / k / v = bias, pad query rows are
+ * dropped).  Wqkv_p bf16 [3C, C] and Wproj_p bf16 [C, C]: esvit_cast_weight(W, perm32 = 1) of qkv.weight / proj.weight.
+ * rowscale fp32 [nB*L] (DropPath factor of every row) or NULL.  Side outputs for a training pass whose backward runs the
+ * unfused kernels -- all five or none: xw bf16 [nB*L, C] = LayerNorm(x), qkv bf16 [nB*L, 3C], ao bf16 [nB*L, C] (attention
+ * output before the projection), mean / rstd fp32 [nB*L].  The rows of one call must fit 2 GiB buffer ranges. */
+int esvit_attn_branch_fwd(int dtype, const float* x, const float* gamma, const float* beta, float eps, const void* Wqkv_p,
+                          const float* bqkv, const void* Wproj_p, const float* bproj, const int32_t* win2tok, int L,
+                          const float* rel_table, int ws, float* bias_frag_ws, const int32_t* region_ids, int nW, int nB, int N,
+                          int nH, float scale, const float* rowscale, float* y, void* xw, void* qkv, void* ao, float* mean,
+                          float* rstd, esvit_stream_t stream);
+
 /* ---- window attention (swin_transformer.py:126-152) ---------------------
  * "frag layout" of an NP x NP matrix X[q][key] (NP = 64 for 7x7 windows): the order in which the
  * MFMA accumulators of the transposed score tile hold it,

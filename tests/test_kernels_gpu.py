@@ -513,6 +513,69 @@ def test_window_attention(mods, dt, ws, nH, H, shift, hd):
         assert float(pad_.abs().max()) == 0.0
 
 
+def _attn_branch_unfused(ops, x, g1, b1, Wqkv, bqkv, Wproj, bproj, w2t, L, table, ws, regions, nW, N, nH, scale, rowscale):
+    """the four-kernel sequence the fused branch replaces (functional._block_forward_multi), bf16 activations"""
+    xw, _, mean, rstd = ops.layernorm_fwd(x, g1, b1, 1e-6)
+    qkv = ops.linear_fwd(xw, Wqkv.to(torch.bfloat16), bqkv)
+    ao, _ = ops.window_attn_fwd(qkv, bqkv, w2t, L, table, ws, regions, nW, N, nH, scale)
+    y = ops.linear_fwd(ao, Wproj.to(torch.bfloat16), bproj, residual=x, rowscale=rowscale, rows_per_sample=1, out_f32=True)
+    return y, xw, mean, rstd, qkv, ao
+
+
+@pytest.mark.parametrize("nH,H,shift,nB", [(3, 14, 3, 3), (3, 12, 3, 5), (6, 12, 0, 2), (3, 56, 0, 2), (6, 28, 3, 3), (3, 24, 3, 9), (6, 7, 0, 1),
+                                           (3, 56, 3, 24), (6, 28, 3, 40), (6, 12, 3, 300)])
+@pytest.mark.parametrize("save", [False, True])
+def test_attn_branch_fwd(mods, nH, H, shift, nB, save):
+    """LayerNorm -> qkv -> 7x7 window attention -> proj -> DropPath-scaled residual in one kernel vs the unfused kernel sequence (same
+    bf16 rounding points) and vs the fp32 restatement, over padded / shifted geometries, few and many windows per workgroup"""
+    ops, ref = mods
+    old = ops.act_dtype()
+    ops.set_act_dtype(torch.bfloat16)
+    try:
+        dev = _dev()
+        ws, hd = 7, 32
+        N, C, L = ws * ws, nH * hd, H * H
+        w2t = torch.from_numpy(ops.window_maps(H, H, ws, shift)[0]).to(dev)
+        nW = w2t.numel() // N
+        regions = torch.from_numpy(ops.shift_region_ids(H, H, ws, shift)).to(dev) if shift else None
+        x = _rand((nB * L, C), dev, 60) + 0.1 * _rand((1, C), dev, 61)
+        g1, b1 = 1.0 + 0.1 * _rand((C,), dev, 62), 0.1 * _rand((C,), dev, 63)
+        Wqkv, bqkv = _rand((3 * C, C), dev, 64) * C ** -0.5, _rand((3 * C,), dev, 65) * 0.5
+        Wproj, bproj = _rand((C, C), dev, 66) * C ** -0.5, _rand((C,), dev, 67) * 0.5
+        table = _rand(((2 * ws - 1) ** 2, nH), dev, 68) * 0.5
+        keep = (torch.rand(nB, generator=torch.Generator().manual_seed(69)) > 0.3).float() / 0.7
+        rowscale = keep.repeat_interleave(L).to(dev)
+        scale = hd ** -0.5
+        yr, xwr, meanr, rstdr, qkvr, aor = _attn_branch_unfused(ops, x, g1, b1, Wqkv, bqkv, Wproj, bproj, w2t, L, table, ws, regions, nW, N, nH, scale, rowscale)
+        Wq_p, Wp_p = ops.cast_weight(Wqkv, perm32=True), ops.cast_weight(Wproj, perm32=True)
+        res = ops.attn_branch_fwd(x, g1, b1, 1e-6, Wq_p, bqkv, Wp_p, bproj, w2t, L, table, ws, regions, nW, N, nH, scale, rowscale=rowscale, save=save)
+        y = res[0] if save else res
+        assert bool(torch.isfinite(y).all())
+        _close("branch delta", y - x, yr - x, 2.5e-2)  # two bf16 pipelines with different summation orders
+        # fp32 restatement of the same branch
+        xw32 = torch.nn.functional.layer_norm(x, (C,), g1, b1, 1e-6)
+        qkv32 = xw32 @ Wqkv.t() + bqkv
+        ao32 = ref.window_attn_fwd(qkv32, bqkv, w2t, L, table, ws, regions, nW, N, nH, scale)[0]
+        y32 = x + rowscale[:, None] * (ao32 @ Wproj.t() + bproj)
+        _close("branch delta vs fp32", y - x, y32 - x, 2.5e-2)
+        if save:
+            xw, mean, rstd, qkv, ao = res[1]
+            _close("xw", xw, xwr, 1e-2)
+            _close("mean", mean, meanr, 1e-5)
+            _close("rstd", rstd, rstdr, 1e-5)
+            _close("qkv", qkv, qkvr, 1.5e-2)
+            _close("ao", ao, aor, 2e-2)
+        # no DropPath vector, prefilled bias fragment, output into a given tensor
+        frag = ops.new_bias_frag(nH, N, dev)
+        ops.attn_branch_fwd(x, g1, b1, 1e-6, Wq_p, bqkv, Wp_p, bproj, w2t, L, table, ws, regions, nW, N, nH, scale, bias_frag=frag)
+        out = torch.empty_like(x)
+        ops.attn_branch_fwd(x, g1, b1, 1e-6, Wq_p, bqkv, Wp_p, bproj, w2t, L, None, ws, regions, nW, N, nH, scale, bias_frag=frag, out=out)
+        y1 = x + (ao32 @ Wproj.t() + bproj)
+        _close("branch delta, no rowscale", out - x, y1 - x, 2.5e-2)
+    finally:
+        ops.set_act_dtype(old)
+
+
 @pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("geom", ["vit37_h3", "vit37_h6", "cvt56_h1", "cvt28_h3", "swin56_h3_hd32"])
 def test_window_attention_full_occupancy(mods, dt, geom):
