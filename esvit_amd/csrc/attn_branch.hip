@@ -54,7 +54,22 @@ struct ABParams {
     int nW, Bw, N, L;
     long rows;
     float scale;
+    unsigned* timeline;     // tools/attn_branch_timeline.py builds only (ESVIT_AB_TIMELINE): per-phase cycle stamps, else unused
 };
+
+// per-phase cycle stamps of wave 0 and the last wave of workgroups 0 and 1, first AB_TL_STEPS steps, kept in LDS and written out at
+// the end of the kernel (tools/attn_branch_timeline.py; never defined in the product build)
+#ifdef ESVIT_AB_TIMELINE
+#define AB_TL_STEPS 48
+#define AB_TL_BYTES (AB_TL_STEPS * 2 * 12 * 4)
+#define TL(i_)                                                                                                                     \
+    do {                                                                                                                           \
+        if (tl_on && tl_step < AB_TL_STEPS) tl_lds[(tl_step * 2 + tl_w) * 12 + (i_)] = (unsigned)__builtin_readcyclecounter();     \
+    } while (0)
+#else
+#define AB_TL_BYTES 0
+#define TL(i_)
+#endif
 
 namespace {
 
@@ -63,6 +78,7 @@ constexpr int K_BYTES = 64 * 64;    // K image [64 slots][32 d] bf16: 64-byte ro
 constexpr int VT_LD = 136;          // V^T image [32 d][64 slots] bf16: 128-byte rows padded to 136 (8-byte fragment reads, conflict-free)
 constexpr int KV_BYTES = K_BYTES + ((32 * VT_LD + 1023) / 1024) * 1024;  // one K | V^T pair
 constexpr unsigned AB_OOB = 0x7ffffff0u;
+constexpr float LOG2E = 1.4426950408889634f;
 
 template <int I>
 struct IC {
@@ -76,21 +92,48 @@ __device__ __forceinline__ void static_for(F&& f) {
     }
 }
 
+// v_permlane16_swap / v_permlane32_swap exchange the odd 16- / 32-lane rows of their first operand with the even rows of their
+// second: fed the same value twice, the two results are v[l] and v[l ^ 16] (v[l ^ 32]) in some order on every lane -- a butterfly
+// step on the VALU (__shfl_xor goes through the LDS crossbar).  Operands and results pass through empty asm statements: hipcc 7.2
+// folds `bitcast<float>(r[1])` of the swap's result pair to `bitcast<float>(r[0])` (tools/probe/permlane_swap_fold.hip: k7 emits
+// `v_add_f32 v1, v1, v1`); integer uses of the pair (fused16.h: row_swap) are not affected.
+__device__ __forceinline__ void swap16(float v, float& x, float& y) {
+    unsigned a = __builtin_bit_cast(unsigned, v), b = a;
+    asm volatile("" : "+v"(b));
+    const u32x2 r = __builtin_amdgcn_permlane16_swap(a, b, false, false);
+    unsigned r0 = r[0], r1 = r[1];
+    asm volatile("" : "+v"(r0), "+v"(r1));
+    x = __builtin_bit_cast(float, r0);
+    y = __builtin_bit_cast(float, r1);
+}
+__device__ __forceinline__ void swap32(float v, float& x, float& y) {
+    unsigned a = __builtin_bit_cast(unsigned, v), b = a;
+    asm volatile("" : "+v"(b));
+    const u32x2 r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+    unsigned r0 = r[0], r1 = r[1];
+    asm volatile("" : "+v"(r0), "+v"(r1));
+    x = __builtin_bit_cast(float, r0);
+    y = __builtin_bit_cast(float, r1);
+}
 __device__ __forceinline__ float xor16_sum(float v) {
-    const u32x2 r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
-    return __builtin_bit_cast(float, r[0]) + __builtin_bit_cast(float, r[1]);
+    float x, y;
+    swap16(v, x, y);
+    return x + y;
 }
 __device__ __forceinline__ float xor32_sum(float v) {
-    const u32x2 r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
-    return __builtin_bit_cast(float, r[0]) + __builtin_bit_cast(float, r[1]);
+    float x, y;
+    swap32(v, x, y);
+    return x + y;
 }
 __device__ __forceinline__ float xor16_max(float v) {
-    const u32x2 r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
-    return fmaxf(__builtin_bit_cast(float, r[0]), __builtin_bit_cast(float, r[1]));
+    float x, y;
+    swap16(v, x, y);
+    return fmaxf(x, y);
 }
 __device__ __forceinline__ float xor32_max(float v) {
-    const u32x2 r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
-    return fmaxf(__builtin_bit_cast(float, r[0]), __builtin_bit_cast(float, r[1]));
+    float x, y;
+    swap32(v, x, y);
+    return fmaxf(x, y);
 }
 // sum / max over the four lanes (c, g = 0..3) of a token
 __device__ __forceinline__ float tok_sum(float v) { return xor32_sum(xor16_sum(v)); }
@@ -116,16 +159,20 @@ struct ABCfg {
     static constexpr int QBUF = 3 * Cf::A_BYTES + 1024;  // q | k | v row images of a head, then its 96 biases (fp32)
     static constexpr int PBUF = Cf::B_BYTES;             // [C][32]: the head's columns of Wproj
     static constexpr int CONST_BYTES = ((3 * C * 4 + 1023) / 1024) * 1024;  // gamma | beta | b_proj
+    // ring depth of the weight slices: every head resident (requested once, during the workgroup's first window) when that fits
+    // beside the K / V images, else two slots and a request per step
+    static constexpr bool RES = CONST_BYTES + NH * (QBUF + PBUF) + NWIN * 2 * KV_BYTES + 1024 + AB_TL_BYTES <= 160 * 1024;
+    static constexpr int RING = RES ? NH : 2;
     static constexpr int OFF_Q = CONST_BYTES;
-    static constexpr int OFF_P = OFF_Q + 2 * QBUF;
-    static constexpr int OFF_KV = OFF_P + 2 * PBUF;      // [NWIN][2 buffers][K | V^T]
+    static constexpr int OFF_P = OFF_Q + RING * QBUF;
+    static constexpr int OFF_KV = OFF_P + RING * PBUF;   // [NWIN][2 buffers][K | V^T]
     static constexpr int OFF_DUMMY = OFF_KV + NWIN * 2 * KV_BYTES;  // landing KiB of the DMA pieces a wave issues only to keep every wave's count equal
-    static constexpr int LDS = OFF_DUMMY + 1024;
+    static constexpr int LDS = OFF_DUMMY + 1024 + AB_TL_BYTES;
     static constexpr int NPQ = 3 * Cf::PA + 1;           // DMA pieces of a q | k | v slice (+ the bias piece)
     static constexpr int PPQ = (NPQ + NW - 1) / NW;
     static constexpr int PPP = (Cf::PB + NW - 1) / NW;
     static constexpr int NXL = 2 * Cf::KS;               // 16-byte row loads per lane and window
-    static constexpr int PF = (NXL + NH - 2) / (NH - 1); // of them per step (steps 0 .. NH-2 of the previous window)
+    static constexpr int PF = (NXL + NH - 2) / (NH - 1); // of them per step (steps 1 .. NH-1 of the previous window)
 };
 
 
@@ -143,6 +190,12 @@ __device__ __forceinline__ void attn_branch_fwd_body(const ABParams& p) {
     const int wj = wave >> 2, w = wave & 3;  // window slot of the workgroup, 16-slot tile of the window
     const int slot = 16 * w + c;
 
+#ifdef ESVIT_AB_TIMELINE
+    unsigned* tl_lds = reinterpret_cast<unsigned*>(smem + AC::OFF_DUMMY + 1024);
+    const bool tl_on = p.timeline && blockIdx.x < 2 && lane == 0 && (wave == 0 || wave == NW - 1);
+    const int tl_w = wave == 0 ? 0 : 1;
+    int tl_step = 0;
+#endif
     // ---- constants into LDS ----
     {
         float* cst = reinterpret_cast<float*>(smem);
@@ -255,12 +308,14 @@ __device__ __forceinline__ void attn_branch_fwd_body(const ABParams& p) {
     bf16x8 xb[KS];
     f32x4 accy[MT];
     bf16x8 qf = {}, qf_n;
-    f32x4 bias_c[4];  // fragment-order bias of the pair `attend` handles next (16 keys x this lane's query)
-    const int boff = (w * 64 + lane) * 16;
-    auto load_bias = [&](int h) {
+    // fragment-order bias of every head (16 keys x this lane's query each), resident: a load inside the loop would have to be
+    // waited for within its step and, vmcnt retiring in order, would drag the HBM row prefetch issued before it along
+    f32x4 bias_r[NH][4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) bias_c[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rbf, boff, (h * AB_FRAG + i * 1024) * 4, 0));
-    };
+    for (int h = 0; h < NH; ++h)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            bias_r[h][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rbf, (w * 64 + lane) * 16, (h * AB_FRAG + i * 1024) * 4, 0)) * LOG2E;
     u32x4 sv_q = {}, sv_k = {}, sv_v = {};  // side-output rows of the step (SAVE)
 
     // ---- prologue: first slice, first window's rows ----
@@ -273,24 +328,27 @@ __device__ __forceinline__ void attn_branch_fwd_body(const ABParams& p) {
     for (int i = 0; i < NXL; ++i) xn[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, xoff(row_nxt, i), 0, 0));
     const bool has_rs = p.rowscale != nullptr;
     rs_n = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrs, row_off(row_nxt, (unsigned)row_nxt * 4), 0, 0));
-    load_bias(0);
     wait_vm<0>();
     __syncthreads();
 
     // the attention + projection half of a step: pair (window of `row_cur`, head hp); kvo: LDS offset of the window's K image of
     // that pair, po: of the pair's Wproj columns; hn: the head whose bias fragment is requested for the next step
-    auto attend = [&](int hn, int kvo, int po, u32x4& sv_o) {
+    auto attend = [&](auto Hp, int kvo, int po, u32x4& sv_o) {
+        constexpr int hp = decltype(Hp)::value;
         f32x4 pr[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const bf16x8 kf = *reinterpret_cast<const bf16x8*>(smem + kvo + kr + 1024 * i);
-            f32x4 b = bias_c[i];
+            f32x4 b = bias_r[hp][i];
             if (masked) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) b[r] += ((mbits >> (4 * i + r)) & 1u) ? -100.f : 0.f;
+                for (int r = 0; r < 4; ++r) b[r] += ((mbits >> (4 * i + r)) & 1u) ? -100.f * LOG2E : 0.f;
             }
             pr[i] = mfma16(kf, qf, b);
         }
+        TL(2);
+        // softmax over the 64 keys in the base-2 domain (q and the bias carry log2(e)): one v_exp_f32 per score; P stays
+        // unnormalised (<= 1) and 1 / sum rides in the scale of O
         float m = -3.0e38f;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -302,20 +360,21 @@ __device__ __forceinline__ void attn_branch_fwd_body(const ABParams& p) {
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float e = __expf(pr[i][r] - m);
+                const float e = __builtin_amdgcn_exp2f(pr[i][r] - m);
                 pr[i][r] = e;
                 sum += e;
             }
         sum = tok_sum(sum);
-        const float inv = 1.f / sum;
+        const float inv = __builtin_amdgcn_rcpf(sum);
+        TL(3);
         f32x4 o[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             bf16x8 pf;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                pf[e] = (bf16)(pr[2 * ks][e] * inv);
-                pf[4 + e] = (bf16)(pr[2 * ks + 1][e] * inv);
+                pf[e] = (bf16)pr[2 * ks][e];
+                pf[4 + e] = (bf16)pr[2 * ks + 1][e];
             }
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt) {
@@ -324,30 +383,32 @@ __device__ __forceinline__ void attn_branch_fwd_body(const ABParams& p) {
                 o[dt] = mfma16(__builtin_bit_cast(bf16x8, u32x4{lo[0], lo[1], hi[0], hi[1]}), pf, o[dt]);
             }
         }
-        __builtin_amdgcn_sched_barrier(0);
-        load_bias(hn);  // for the next pair; lands during the rest of this step
+        TL(4);
         if constexpr (SAVE) {  // attention output row, channels 32 hp + (d = 4g + e | 16 + 4g + e) -> 8 consecutive after the row swap
-            unsigned x0 = pack2(o[0][0], o[0][1]), x1 = pack2(o[0][2], o[0][3]), y0 = pack2(o[1][0], o[1][1]), y1 = pack2(o[1][2], o[1][3]);
+            unsigned x0 = pack2(o[0][0] * inv, o[0][1] * inv), x1 = pack2(o[0][2] * inv, o[0][3] * inv);
+            unsigned y0 = pack2(o[1][0] * inv, o[1][1] * inv), y1 = pack2(o[1][2] * inv, o[1][3] * inv);
             row_swap(x0, y0);
             row_swap(x1, y1);
             sv_o = u32x4{x0, x1, y0, y1};
         }
+        const float osc = inv * rs_cur;
         bf16x8 of;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            of[e] = (bf16)(o[0][e] * rs_cur);
-            of[4 + e] = (bf16)(o[1][e] * rs_cur);
+            of[e] = (bf16)(o[0][e] * osc);
+            of[4 + e] = (bf16)(o[1][e] * osc);
         }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             const bf16x8 a = *reinterpret_cast<const bf16x8*>(smem + po + fb + 1024 * mt);
             accy[mt] = mfma16(a, of, accy[mt]);
         }
+        TL(5);
     };
     // uniform ring offsets of a step, opaque to the optimiser (it would otherwise keep one set of lane addresses per ring slot)
-    auto ring = [&](int par, int& qo, int& po, int& kvo) {
-        qo = AC::OFF_Q + par * AC::QBUF;
-        po = AC::OFF_P + par * AC::PBUF;
+    auto ring = [&](int slot, int par, int& qo, int& po, int& kvo) {
+        qo = AC::OFF_Q + slot * AC::QBUF;
+        po = AC::OFF_P + slot * AC::PBUF;
         kvo = AC::OFF_KV + (wj * 2 + par) * KV_BYTES;
         asm volatile("" : "+s"(qo), "+s"(po), "+s"(kvo));
     };
@@ -355,104 +416,126 @@ __device__ __forceinline__ void attn_branch_fwd_body(const ABParams& p) {
     for (int it = 0; it < iters; ++it) {
         static_for<0, NH>([&](auto Hc) {
             constexpr int h = decltype(Hc)::value;
+            constexpr int hprev = h == 0 ? NH - 1 : h - 1, hnext = h + 1 == NH ? 0 : h + 1;
             const int s = it * NH + h;
             const int par = s & 1;
+            const int rs0 = AC::RES ? h : par, rs1 = AC::RES ? hprev : (par ^ 1), rsn = AC::RES ? hnext : (par ^ 1);  // ring slots: this / previous / next pair
             int qo, po, kvo, qo1, po1, kvo1;
-            ring(par, qo, po, kvo);         // this pair: q | k | v slice read, K / V images written, Wproj columns requested
-            ring(par ^ 1, qo1, po1, kvo1);  // the previous pair: K / V images and Wproj columns read
-            // ---- top: next slices, the map of window it + 2 ----
-            issue_q(h + 1 == NH ? 0 : h + 1, par ^ 1);  // (past the last pair: a slice nobody reads)
-            issue_p(h, par);
+            ring(rs0, par, qo, po, kvo);          // this pair: q | k | v slice read, K / V images written, Wproj columns requested
+            ring(rs1, par ^ 1, qo1, po1, kvo1);   // the previous pair: K / V images and Wproj columns read
+            // ---- top: the map of window it + 2, the next slices, then rows of the next window.  The row loads come from HBM and are
+            // the youngest loads of the step: the closing wait lets them (and the stores) fly on, so they have until the next
+            // step's close -- issued at the end of a step they would have to land within ONE step, behind which every step waited ----
+            TL(0);
             if constexpr (h == 1) issue_map(it + 2, tok_nn, rg_nn, base_nn);  // (the previous answer was taken at h == 0)
+            if (!AC::RES || it == 0) {
+                if (!AC::RES || h + 1 < NH) issue_q(hnext, rsn);  // (past the last pair: a slice nobody reads)
+                issue_p(h, rs0);
+            }
+            constexpr int pf0 = h == 0 ? NXL : (h - 1) * PF, pf1 = h == 0 ? NXL : (h * PF < NXL ? h * PF : NXL);
+            static_for<pf0, (pf0 < pf1 ? pf1 : pf0)>([&](auto Ic) {
+                constexpr int i = decltype(Ic)::value;
+                xn[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, xoff(row_nxt, i), 0, 0));
+            });
+            if constexpr (h == 1) rs_n = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrs, row_off(row_nxt, (unsigned)row_nxt * 4), 0, 0));
             mem_fence_compiler();
+            TL(1);
 
-            // ---- attention + projection of the previous pair ----
+            // The step's three pieces.  A: attention + projection of the previous pair (and, at h == 0, the finished window's rows
+            // out + the new window's accumulator start).  N (h == 0 only): LayerNorm of the new window's rows.  Q: q, k, v of this
+            // pair.  The window slots of a workgroup run them in opposite orders (even: A N Q, odd: N Q A): the two waves of a SIMD
+            // belong to different slots, so one is in its MFMA / LDS-bound piece while the other runs the VALU-bound softmax.
             u32x4 sv_o = {};
             const bool have_prev = s > 0;
-            attend(h, kvo1, po1, sv_o);  // (s == 0: on images nobody wrote; nothing of it is kept)
-            __builtin_amdgcn_sched_barrier(0);
-            const int row_prev = have_prev ? row_cur : -1;  // (row_cur is still the previous window's row at h == 0)
+            const int row_prev = have_prev ? row_cur : -1;  // the previous pair's row (row_cur changes in piece A at h == 0)
+            int row_q = row_cur;                            // this pair's row (side outputs)
+            if constexpr (h == 0) row_q = row_nxt;
 
-            // ---- late operations, part 1: the previous pair's side output; at h == 0 the finished window's output rows ----
-            mem_fence_compiler();
-            if constexpr (SAVE) {
-                const unsigned vo = row_off(row_prev, (unsigned)row_prev * (C * 2) + (32 * (h == 0 ? NH - 1 : h - 1) + 16 * (g & 1) + 4 * (g & ~1)) * 2);
-                buffer_store_b128(sv_o, rao, vo, 0);
-            }
-            if constexpr (h == 0) {
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) {
-                    const unsigned vo = row_off(row_prev, (unsigned)row_prev * (C * 4) + (16 * mt + 4 * g) * 4);
-                    buffer_store_b128(accy[mt], ry, vo, 0);
+            auto piece_A = [&]() {
+                attend(IC<hprev>{}, kvo1, po1, sv_o);  // (s == 0: on images nobody wrote; nothing of it is kept)
+                __builtin_amdgcn_sched_barrier(0);
+                mem_fence_compiler();
+                if constexpr (SAVE) {
+                    const unsigned vo = row_off(row_prev, (unsigned)row_prev * (C * 2) + (32 * hprev + 16 * (g & 1) + 4 * (g & ~1)) * 2);
+                    buffer_store_b128(sv_o, rao, vo, 0);
                 }
-                // ---- the new window: LayerNorm of its rows (landed during the previous window), accumulator start ----
-                row_cur = row_nxt;
-                reg_cur = reg_nxt;
-                rs_cur = has_rs ? rs_n : 1.f;
-                float mean, rstd;
-                {
-                    float s1 = 0.f;
+                if constexpr (h == 0) {
 #pragma unroll
-                    for (int i = 0; i < NXL; ++i) s1 += xn[i][0] + xn[i][1] + xn[i][2] + xn[i][3];
-                    mean = tok_sum(s1) * (1.f / C);
-                    float s2 = 0.f;
+                    for (int mt = 0; mt < MT; ++mt) {
+                        const unsigned vo = row_off(row_prev, (unsigned)row_prev * (C * 4) + (16 * mt + 4 * g) * 4);
+                        buffer_store_b128(accy[mt], ry, vo, 0);
+                    }
+                    // the new window takes over: accumulator start x + rowscale * b_proj, DropPath factor, shift-mask bits
+                    row_cur = row_nxt;
+                    reg_cur = reg_nxt;
+                    rs_cur = has_rs ? rs_n : 1.f;
 #pragma unroll
-                    for (int i = 0; i < NXL; ++i)
+                    for (int mt = 0; mt < MT; ++mt) {
+                        const f32x4 bp = *reinterpret_cast<const f32x4*>(smem + lc + (2 * C + 16 * mt) * 4);
+                        accy[mt] = xn[mt] + rs_cur * bp;
+                    }
+                    mbits = 0;
+                    if (masked) {
+                        const int rq_ = __shfl(reg_cur, slot, 64);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const float d = xn[i][e] - mean;
-                            s2 += d * d;
+                        for (int i = 0; i < 4; ++i)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) mbits |= (__shfl(reg_cur, 16 * i + 4 * g + r, 64) != rq_ ? 1u : 0u) << (4 * i + r);
+                    }
+                    row_nxt = map_row(tok_nn, base_nn);
+                    reg_nxt = map_reg(rg_nn, base_nn);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            auto piece_N = [&]() {
+                if constexpr (h == 0) {
+                    float mean, rstd;
+                    {
+                        float s1 = 0.f;
+#pragma unroll
+                        for (int i = 0; i < NXL; ++i) s1 += xn[i][0] + xn[i][1] + xn[i][2] + xn[i][3];
+                        mean = tok_sum(s1) * (1.f / C);
+                        float s2 = 0.f;
+#pragma unroll
+                        for (int i = 0; i < NXL; ++i)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const float d = xn[i][e] - mean;
+                                s2 += d * d;
+                            }
+                        rstd = rsqrtf(tok_sum(s2) * (1.f / C) + p.eps);
+                    }
+                    const float live = row_q >= 0 ? 1.f : 0.f;  // zero-pad and idle slots: LayerNorm output 0 (the reference pads after norm1)
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) {
+                        float hv[8];
+#pragma unroll
+                        for (int t = 0; t < 2; ++t) {
+                            const f32x4 gm = *reinterpret_cast<const f32x4*>(smem + lc + (32 * ks + 16 * t) * 4);
+                            const f32x4 bt = *reinterpret_cast<const f32x4*>(smem + lc + (C + 32 * ks + 16 * t) * 4);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                hv[4 * t + e] = live * ((xn[2 * ks + t][e] - mean) * rstd * gm[e] + bt[e]);
+                                xb[ks][4 * t + e] = (bf16)hv[4 * t + e];
+                            }
                         }
-                    rstd = rsqrtf(tok_sum(s2) * (1.f / C) + p.eps);
-                }
-                const float live = row_cur >= 0 ? 1.f : 0.f;  // zero-pad and idle slots: LayerNorm output 0 (the reference pads after norm1)
-#pragma unroll
-                for (int ks = 0; ks < KS; ++ks) {
-                    float hv[8];
-#pragma unroll
-                    for (int t = 0; t < 2; ++t) {
-                        const f32x4 gm = *reinterpret_cast<const f32x4*>(smem + lc + (32 * ks + 16 * t) * 4);
-                        const f32x4 bt = *reinterpret_cast<const f32x4*>(smem + lc + (C + 32 * ks + 16 * t) * 4);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            hv[4 * t + e] = live * ((xn[2 * ks + t][e] - mean) * rstd * gm[e] + bt[e]);
-                            xb[ks][4 * t + e] = (bf16)hv[4 * t + e];
+                        if constexpr (SAVE) {
+                            unsigned x0 = pack2(hv[0], hv[1]), x1 = pack2(hv[2], hv[3]), y0 = pack2(hv[4], hv[5]), y1 = pack2(hv[6], hv[7]);
+                            row_swap(x0, y0);
+                            row_swap(x1, y1);
+                            const unsigned vo = row_off(row_q, (unsigned)row_q * (C * 2) + (32 * ks + 16 * (g & 1) + 4 * (g & ~1)) * 2);
+                            buffer_store_b128(u32x4{x0, x1, y0, y1}, rxw, vo, 0);
                         }
                     }
                     if constexpr (SAVE) {
-                        unsigned x0 = pack2(hv[0], hv[1]), x1 = pack2(hv[2], hv[3]), y0 = pack2(hv[4], hv[5]), y1 = pack2(hv[6], hv[7]);
-                        row_swap(x0, y0);
-                        row_swap(x1, y1);
-                        const unsigned vo = row_off(row_cur, (unsigned)row_cur * (C * 2) + (32 * ks + 16 * (g & 1) + 4 * (g & ~1)) * 2);
-                        buffer_store_b128(u32x4{x0, x1, y0, y1}, rxw, vo, 0);
+                        const unsigned vo = row_off(g == 0 ? row_q : -1, (unsigned)row_q * 4);
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, mean), rmean, vo, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, rstd), rrstd, vo, 0, 0);
                     }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-                if constexpr (SAVE) {
-                    const unsigned vo = row_off(g == 0 ? row_cur : -1, (unsigned)row_cur * 4);
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, mean), rmean, vo, 0, 0);
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, rstd), rrstd, vo, 0, 0);
-                }
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) {
-                    const f32x4 bp = *reinterpret_cast<const f32x4*>(smem + lc + (2 * C + 16 * mt) * 4);
-                    accy[mt] = xn[mt] + rs_cur * bp;
-                }
-                // shift-mask bits of this lane's query against its 16 keys
-                mbits = 0;
-                if (masked) {
-                    const int rq_ = __shfl(reg_cur, slot, 64);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) mbits |= (__shfl(reg_cur, 16 * i + 4 * g + r, 64) != rq_ ? 1u : 0u) << (4 * i + r);
-                }
-                row_nxt = map_row(tok_nn, base_nn);
-                reg_nxt = map_reg(rg_nn, base_nn);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-
-            // ---- q, k, v of pair s ----
-            {
+            };
+            auto piece_Q = [&]() {
                 const float* sb = reinterpret_cast<const float*>(smem + qo + 3 * Cf::A_BYTES);
                 static_for<0, 3>([&](auto Pc) {
                     constexpr int part = decltype(Pc)::value;
@@ -476,13 +559,14 @@ __device__ __forceinline__ void attn_branch_fwd_body(const ABParams& p) {
                         const f32x4 b0 = *reinterpret_cast<const f32x4*>(sb + 32 * part + 8 * g), b1 = *reinterpret_cast<const f32x4*>(sb + 32 * part + 8 * g + 4);
                         a0 += b0;
                         a1 += b1;
-                        pk = u32x4{pack2(a0[0], a0[1]), pack2(a0[2], a0[3]), pack2(a1[0], a1[1]), pack2(a1[2], a1[3])};
+                        if constexpr (part != 0 || SAVE) pk = u32x4{pack2(a0[0], a0[1]), pack2(a0[2], a0[3]), pack2(a1[0], a1[1]), pack2(a1[2], a1[3])};
                     }
                     if constexpr (part == 0) {
+                        const float qs = p.scale * LOG2E;  // scores in the base-2 domain
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            qf_n[e] = (bf16)(a0[e] * p.scale);
-                            qf_n[4 + e] = (bf16)(a1[e] * p.scale);
+                            qf_n[e] = (bf16)(a0[e] * qs);
+                            qf_n[4 + e] = (bf16)(a1[e] * qs);
                         }
                         if constexpr (SAVE) sv_q = pk;
                     } else if constexpr (part == 1) {
@@ -497,36 +581,47 @@ __device__ __forceinline__ void attn_branch_fwd_body(const ABParams& p) {
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 });
+                mem_fence_compiler();
+                if constexpr (SAVE) {  // side-output rows of this pair
+                    const unsigned vo = row_off(row_q, (unsigned)row_q * (3 * C * 2) + (32 * h + 8 * g) * 2);
+                    buffer_store_b128(sv_q, rqkv, vo, 0);
+                    buffer_store_b128(sv_k, rqkv, vo, C * 2);
+                    buffer_store_b128(sv_v, rqkv, vo, 2 * C * 2);
+                }
+            };
+            if (wj & 1) {
+                piece_N();
+                TL(6);
+                piece_Q();
+                TL(7);
+                piece_A();
+            } else {
+                piece_A();
+                piece_N();
+                TL(6);
+                piece_Q();
+                TL(7);
             }
-
-            // ---- late operations, part 2: side-output rows of this pair, row prefetch of the next window ----
-            mem_fence_compiler();
-            if constexpr (SAVE) {
-                const unsigned vo = row_off(row_cur, (unsigned)row_cur * (3 * C * 2) + (32 * h + 8 * g) * 2);
-                buffer_store_b128(sv_q, rqkv, vo, 0);
-                buffer_store_b128(sv_k, rqkv, vo, C * 2);
-                buffer_store_b128(sv_v, rqkv, vo, 2 * C * 2);
-            }
-            constexpr int pf0 = h * PF, pf1 = (h + 1) * PF < NXL ? (h + 1) * PF : NXL;
-            static_for<pf0, (pf0 < pf1 ? pf1 : pf0)>([&](auto Ic) {
-                constexpr int i = decltype(Ic)::value;
-                xn[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, xoff(row_nxt, i), 0, 0));
-            });
-            if constexpr (h == 0) rs_n = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrs, row_off(row_nxt, (unsigned)row_nxt * 4), 0, 0));
-            // everything older than the late operations has landed; they stay in flight through the next step
+            // everything older than the row loads of this step has landed (the weight slices above all); the row loads and the
+            // stores stay in flight through the next step.  Resident weights: nothing to wait for after the first window
             constexpr int NPFL = (pf0 < pf1 ? pf1 - pf0 : 0);
-            constexpr int LATE = NPFL + (SAVE ? 4 : 0) + (h == 0 ? MT + 1 + (SAVE ? KS + 2 : 0) : 0);
-            wait_vm<LATE>();
+            constexpr int LATE = NPFL + (h == 1 ? 1 : 0) + (SAVE ? 4 : 0) + (h == 0 ? MT + (SAVE ? KS + 2 : 0) : 0);
+            if (!AC::RES || it == 0) wait_vm<LATE>();
+            TL(8);
             chunk_barrier();
+            TL(9);
+#ifdef ESVIT_AB_TIMELINE
+            ++tl_step;
+#endif
             qf = qf_n;
         });
     }
     // ---- drain: the last pair's attention, the last window's rows ----
     {
         int qo, po, kvo;
-        ring((steps & 1) ^ 1, qo, po, kvo);
+        ring(AC::RES ? NH - 1 : ((steps & 1) ^ 1), (steps & 1) ^ 1, qo, po, kvo);
         u32x4 sv_o = {};
-        attend(0, kvo, po, sv_o);
+        attend(IC<NH - 1>{}, kvo, po, sv_o);
         if constexpr (SAVE) {
             const unsigned vo = row_off(row_cur, (unsigned)row_cur * (C * 2) + (32 * (NH - 1) + 16 * (g & 1) + 4 * (g & ~1)) * 2);
             buffer_store_b128(sv_o, rao, vo, 0);
@@ -537,6 +632,11 @@ __device__ __forceinline__ void attn_branch_fwd_body(const ABParams& p) {
             buffer_store_b128(accy[mt], ry, vo, 0);
         }
     }
+#ifdef ESVIT_AB_TIMELINE
+    __syncthreads();
+    if (p.timeline && blockIdx.x < 2)
+        for (int i = threadIdx.x; i < AB_TL_BYTES / 4; i += NW * 64) p.timeline[blockIdx.x * (AB_TL_BYTES / 4) + i] = tl_lds[i];
+#endif
 }
 
 template <int C, int NWIN, bool SAVE>
@@ -564,6 +664,11 @@ int launch_ab(const ABParams& prm, hipStream_t stream) {
 
 int esvit_i_fill_bias_frag(const float* rel_table, int ws, int N, int nH, float* bias_frag_ws, hipStream_t stream);
 
+#ifdef ESVIT_AB_TIMELINE
+static unsigned* g_ab_timeline = nullptr;
+extern "C" __attribute__((visibility("default"))) void esvit_attn_branch_timeline(void* buf) { g_ab_timeline = (unsigned*)buf; }
+#endif
+
 extern "C" int esvit_attn_branch_fwd(int dtype, const float* x, const float* gamma, const float* beta, float eps, const void* Wqkv_p,
                                      const float* bqkv, const void* Wproj_p, const float* bproj, const int32_t* win2tok, int L,
                                      const float* rel_table, int ws, float* bias_frag_ws, const int32_t* region_ids, int nW, int nB, int N,
@@ -588,6 +693,11 @@ extern "C" int esvit_attn_branch_fwd(int dtype, const float* x, const float* gam
     prm.Wqkv = (const bf16*)Wqkv_p; prm.bqkv = bqkv; prm.Wproj = (const bf16*)Wproj_p; prm.bproj = bproj;
     prm.bias_frag = bias_frag_ws; prm.win2tok = win2tok; prm.region_ids = region_ids; prm.rowscale = rowscale;
     prm.y = y; prm.xw = (bf16*)xw; prm.qkv = (bf16*)qkv; prm.ao = (bf16*)ao; prm.mean = mean; prm.rstd = rstd;
+#ifdef ESVIT_AB_TIMELINE
+    prm.timeline = g_ab_timeline;
+#else
+    prm.timeline = nullptr;
+#endif
     prm.nW = nW; prm.Bw = nB * nW; prm.N = N; prm.L = L; prm.rows = rows; prm.scale = scale;
     int rc;
     static const int nwin = getenv("ESVIT_AB_NWIN") ? atoi(getenv("ESVIT_AB_NWIN")) : 0;  // (tuning switch of tools/bench_attn_branch.py)

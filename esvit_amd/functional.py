@@ -103,6 +103,25 @@ def _mlp_w(p, kind):
     return fn()
 
 
+def _perm_w(p):
+    """the copy of qkv.weight / proj.weight the fused attention branch streams (ops.cast_weight, perm32), cached like _mlp_w"""
+    o = ops_module()
+    fn = lambda: o.cast_weight(p.detach().contiguous(), perm32=True)  # noqa: E731
+    if p.requires_grad or P.is_managed(p):
+        return P.cached(p, "ATTN_PERM32", fn)
+    return fn()
+
+
+# ---- fused attention branch (narrow stages, bf16): LayerNorm -> qkv -> 7x7 window attention -> proj -> residual in one kernel per
+# resolution group (esvit_attn_branch_fwd).  Inference passes (the EMA teacher) write nothing but the branch output; a training
+# pass also gets the tensors its (unfused) backward reads as side outputs of the same kernel.
+ATTN_FUSED = os.environ.get("ESVIT_ATTN_FUSED", "1") != "0"  # (A-B runs switch back to the four-kernel sequence)
+
+
+def _attn_fused(dt, C, nH, geoms):
+    return ATTN_FUSED and all(g.ws == 7 for g in geoms) and ops_module().attn_branch_supported(dt, C, nH, max(g.N for g in geoms))
+
+
 # ---- fused MLP branch (narrow stages, bf16): nothing hidden-sized is kept between forward and backward ------------------------
 # forward: ONE kernel x1 -> x2 (esvit_mlp_fused_fwd).  backward: esvit_mlp_fused_bwd recomputes LayerNorm + pre-activation,
 # produces dL/dx1 (+ its activation-dtype copy) and the operands of the two weight-gradient GEMMs; the LayerNorm parameter
@@ -132,7 +151,7 @@ def _mlp_branch_bwd(o, x1, gy, dyb, g2, b2, W1, bfc1, params, dp_mlp, dp_out):
 # ------------------------------------------------------------------------------------------------
 # Swin block
 # ------------------------------------------------------------------------------------------------
-def _block_forward(x, geom, nH, index, dp, prm, wts, save, w1p=None):
+def _block_forward(x, geom, nH, index, dp, prm, wts, save, w1p=None, wattn=None):
     """x fp32 [nB, L, C].  prm: fp32 parameters; wts: activation-dtype weight copies.
     dp: None or (scale_attn [nB], scale_mlp [nB]) DropPath factors."""
     o = ops_module()
@@ -144,11 +163,22 @@ def _block_forward(x, geom, nH, index, dp, prm, wts, save, w1p=None):
     dp1, dp2 = (None, None) if dp is None else dp
     # everything stays in token order: the attention kernel applies pad/roll/partition through geom.win2tok and
     # injects the qkv bias at zero-pad slots, so no GEMM ever runs on pad rows
-    xw, _, mean1, rstd1 = o.layernorm_fwd(x2d, g1, b1, LN_EPS)
-    qkv = o.linear_fwd(xw, Wqkv, bqkv)
     frag = o.new_bias_frag(nH, geom.N, x.device) if save else None  # kept for the backward (no second fill)
-    ao, lse = o.window_attn_fwd(qkv, bqkv, geom.win2tok, L, table, geom.ws, geom.region_ids, geom.nW, geom.N, nH, scale, bias_frag=frag)
-    x1 = o.linear_fwd(ao, Wproj, bproj, residual=x2d, rowscale=dp1, rows_per_sample=L, out_f32=True)
+    if wattn is not None and _attn_fused(Wqkv.dtype, C, nH, (geom,)):
+        rs1 = None if dp1 is None else dp1.repeat_interleave(L)
+        res = o.attn_branch_fwd(x2d, g1, b1, LN_EPS, _perm_w(wattn[0]), bqkv, _perm_w(wattn[1]), bproj, geom.win2tok, L, table, geom.ws, geom.region_ids,
+                                geom.nW, geom.N, nH, scale, rowscale=rs1, bias_frag=frag, save=bool(save))
+        lse = None
+        if save:
+            x1, (xw, mean1, rstd1, qkv, ao) = res
+        else:
+            x1 = res
+            xw = mean1 = rstd1 = qkv = ao = None
+    else:
+        xw, _, mean1, rstd1 = o.layernorm_fwd(x2d, g1, b1, LN_EPS)
+        qkv = o.linear_fwd(xw, Wqkv, bqkv)
+        ao, lse = o.window_attn_fwd(qkv, bqkv, geom.win2tok, L, table, geom.ws, geom.region_ids, geom.nW, geom.N, nH, scale, bias_frag=frag)
+        x1 = o.linear_fwd(ao, Wproj, bproj, residual=x2d, rowscale=dp1, rows_per_sample=L, out_f32=True)
     if (not save and o.mlp_fused_supported(W1.dtype, C)) or (save and _mlp_fused_train(W1, C)):
         rs2 = None if dp2 is None else dp2.repeat_interleave(L)  # (the fused kernels take per-row DropPath factors)
         x2 = o.mlp_fused_fwd(x1, g2, b2, LN_EPS, _mlp_w(w1p, "MLP_W1_FWD"), bfc1, W2, bfc2, rowscale=rs2)
@@ -170,7 +200,7 @@ class SwinBlockFn(torch.autograd.Function):
     def forward(ctx, x, geom, nH, index, dp, g1, b1, table, Wqkv_p, bqkv, Wproj_p, bproj, g2, b2, W1_p, bfc1, W2_p, bfc2):
         wts = (_weight(Wqkv_p), _weight(Wproj_p), _weight(W1_p), _weight(W2_p))
         x = x.contiguous()
-        y, saved = _block_forward(x, geom, nH, index, dp, (g1, b1, table, bqkv, bproj, g2, b2, bfc1, bfc2), wts, True, W1_p)
+        y, saved = _block_forward(x, geom, nH, index, dp, (g1, b1, table, bqkv, bproj, g2, b2, bfc1, bfc2), wts, True, W1_p, (Wqkv_p, Wproj_p))
         ctx.geom, ctx.nH, ctx.dp = geom, nH, dp
         ctx.wparams = (Wqkv_p, Wproj_p, W1_p, W2_p)
         ctx.mlp_params = (g2, b2, W1_p, bfc1, W2_p, bfc2)
@@ -225,7 +255,7 @@ class SwinBlockFn(torch.autograd.Function):
 # resolution group on its row range.  Compared with one pass per group (swin_transformer.py:729-751) this halves the GEMM /
 # LayerNorm launches, removes the gradient-accumulation adds of every parameter used by both passes, halves the split-K
 # partial traffic of the weight gradients and gives the small local-crop GEMMs of stages 2-3 full grids.
-def _block_forward_multi(X, segs, nH, dp_rows, prm, wts, save, pre=None, next_norm=None, w1p=None):
+def _block_forward_multi(X, segs, nH, dp_rows, prm, wts, save, pre=None, next_norm=None, w1p=None, wattn=None):
     """X fp32 [M, C]; segs: tuple of (row0, nB, L, geom); dp_rows: None or (per-row DropPath scale attn [M], mlp [M]).
     pre: (norm1(X) in the activation dtype, mean, rstd) when the previous block's fused MLP kernel already produced them;
     next_norm: (weight, bias) of the NEXT block's norm1 -- the fused MLP kernel then also emits that block's `pre`.
@@ -236,23 +266,49 @@ def _block_forward_multi(X, segs, nH, dp_rows, prm, wts, save, pre=None, next_no
     M, C = X.shape
     scale = (C // nH) ** -0.5
     dp1, dp2 = (None, None) if dp_rows is None else dp_rows
-    if pre is not None:
-        xw, mean1, rstd1 = pre
-    else:
-        xw, _, mean1, rstd1 = o.layernorm_fwd(X, g1, b1, LN_EPS)
-    qkv = o.linear_fwd(xw, Wqkv, bqkv)
-    ao = torch.empty((M, C), dtype=qkv.dtype, device=X.device)
+    fused_attn = wattn is not None and _attn_fused(Wqkv.dtype, C, nH, [sg[3] for sg in segs])
     lses, frags = [], {}
-    for (r0, nB, L, geom) in segs:
-        r1 = r0 + nB * L
-        # the fragment-order bias is built once per block and step: later groups and the backward reuse it
-        first = (geom.ws, geom.N) not in frags
-        if first:
-            frags[(geom.ws, geom.N)] = o.new_bias_frag(nH, geom.N, X.device)
-        _, lse = o.window_attn_fwd(qkv[r0:r1], bqkv, geom.win2tok, L, table if first else None, geom.ws, geom.region_ids, geom.nW, geom.N, nH, scale,
-                                   out=ao[r0:r1], bias_frag=frags[(geom.ws, geom.N)])
-        lses.append((lse, frags[(geom.ws, geom.N)]))
-    x1 = o.linear_fwd(ao, Wproj, bproj, residual=X, rowscale=dp1, rows_per_sample=1, out_f32=True)
+    if fused_attn:
+        # the whole branch in one kernel per resolution group; `pre` (the LayerNorm output the previous block's fused MLP kernel may
+        # have produced) is not needed: the kernel normalises the rows it loads for the residual anyway
+        Wq_p, Wp_p = _perm_w(wattn[0]), _perm_w(wattn[1])
+        x1 = torch.empty_like(X)
+        if save:
+            xw = torch.empty((M, C), dtype=Wqkv.dtype, device=X.device)
+            qkv = torch.empty((M, 3 * C), dtype=Wqkv.dtype, device=X.device)
+            ao = torch.empty((M, C), dtype=Wqkv.dtype, device=X.device)
+            mean1 = torch.empty((M,), dtype=torch.float32, device=X.device)
+            rstd1 = torch.empty_like(mean1)
+        else:
+            xw = qkv = ao = mean1 = rstd1 = None
+        for (r0, nB, L, geom) in segs:
+            r1 = r0 + nB * L
+            first = (geom.ws, geom.N) not in frags
+            if first:
+                frags[(geom.ws, geom.N)] = o.new_bias_frag(nH, geom.N, X.device)
+            sv = (xw[r0:r1], mean1[r0:r1], rstd1[r0:r1], qkv[r0:r1], ao[r0:r1]) if save else False
+            o.attn_branch_fwd(X[r0:r1], g1, b1, LN_EPS, Wq_p, bqkv, Wp_p, bproj, geom.win2tok, L, table if first else None, geom.ws, geom.region_ids,
+                              geom.nW, geom.N, nH, scale, rowscale=None if dp1 is None else dp1[r0:r1], out=x1[r0:r1],
+                              bias_frag=frags[(geom.ws, geom.N)], save=sv)
+            lses.append((None, frags[(geom.ws, geom.N)]))
+        next_norm = None  # (the next block of the stage is fused as well and takes no hand-over)
+    else:
+        if pre is not None:
+            xw, mean1, rstd1 = pre
+        else:
+            xw, _, mean1, rstd1 = o.layernorm_fwd(X, g1, b1, LN_EPS)
+        qkv = o.linear_fwd(xw, Wqkv, bqkv)
+        ao = torch.empty((M, C), dtype=qkv.dtype, device=X.device)
+        for (r0, nB, L, geom) in segs:
+            r1 = r0 + nB * L
+            # the fragment-order bias is built once per block and step: later groups and the backward reuse it
+            first = (geom.ws, geom.N) not in frags
+            if first:
+                frags[(geom.ws, geom.N)] = o.new_bias_frag(nH, geom.N, X.device)
+            _, lse = o.window_attn_fwd(qkv[r0:r1], bqkv, geom.win2tok, L, table if first else None, geom.ws, geom.region_ids, geom.nW, geom.N, nH, scale,
+                                       out=ao[r0:r1], bias_frag=frags[(geom.ws, geom.N)])
+            lses.append((lse, frags[(geom.ws, geom.N)]))
+        x1 = o.linear_fwd(ao, Wproj, bproj, residual=X, rowscale=dp1, rows_per_sample=1, out_f32=True)
     if (not save and o.mlp_fused_supported(W1.dtype, C)) or (save and _mlp_fused_train(W1, C)):
         # narrow stage: LayerNorm -> fc1 + GELU -> fc2 + residual in one kernel, the hidden activation never reaches HBM (the
         # training pass keeps x1 only: the backward recomputes)
@@ -290,7 +346,8 @@ class SwinBlockMultiFn(torch.autograd.Function):
         the saved statistics).  Third output: the next block's `pre` tuple flattened (xw, mean, rstd), or three None"""
         wts = (_weight(Wqkv_p), _weight(Wproj_p), _weight(W1_p), _weight(W2_p))
         X = X.contiguous()
-        y, saved, lses, nxt = _block_forward_multi(X, segs, nH, dp_rows, (g1, b1, table, bqkv, bproj, g2, b2, bfc1, bfc2), wts, True, pre, next_norm, W1_p)
+        y, saved, lses, nxt = _block_forward_multi(X, segs, nH, dp_rows, (g1, b1, table, bqkv, bproj, g2, b2, bfc1, bfc2), wts, True, pre, next_norm, W1_p,
+                                                   (Wqkv_p, Wproj_p))
         ctx.segs, ctx.nH, ctx.dp_rows, ctx.lses = segs, nH, dp_rows, lses
         ctx.wparams = (Wqkv_p, Wproj_p, W1_p, W2_p)
         ctx.sparams = (g1, b1, table, bqkv, bproj, g2, b2, bfc1, bfc2)  # small parameters: their gradients go to bucket slots too
@@ -373,7 +430,8 @@ def swin_block_multi(X, segs, nH, index, dp_rows, prm_list, shadow=None, prev_sc
         return y, ysh, (None if xw is None else (xw, mean, rstd))
     g1, b1, table, Wqkv, bqkv, Wproj, bproj, g2, b2, W1, bfc1, W2, bfc2 = prm_list
     wts = (_weight(Wqkv), _weight(Wproj), _weight(W1), _weight(W2))
-    y, _, _, nxt = _block_forward_multi(X.contiguous(), segs, nH, dp_rows, (g1, b1, table, bqkv, bproj, g2, b2, bfc1, bfc2), wts, False, pre, next_norm, W1)
+    y, _, _, nxt = _block_forward_multi(X.contiguous(), segs, nH, dp_rows, (g1, b1, table, bqkv, bproj, g2, b2, bfc1, bfc2), wts, False, pre, next_norm, W1,
+                                        (Wqkv, Wproj))
     return y, None, nxt
 
 
@@ -383,7 +441,7 @@ def swin_block(x, geom, nH, index, dp, prm_list):
         return SwinBlockFn.apply(x, geom, nH, index, dp, *prm_list)
     g1, b1, table, Wqkv, bqkv, Wproj, bproj, g2, b2, W1, bfc1, W2, bfc2 = prm_list
     wts = (_weight(Wqkv), _weight(Wproj), _weight(W1), _weight(W2))
-    y, _ = _block_forward(x.contiguous(), geom, nH, index, dp, (g1, b1, table, bqkv, bproj, g2, b2, bfc1, bfc2), wts, False, W1)
+    y, _ = _block_forward(x.contiguous(), geom, nH, index, dp, (g1, b1, table, bqkv, bproj, g2, b2, bfc1, bfc2), wts, False, W1, (Wqkv, Wproj))
     return y
 
 

@@ -668,7 +668,8 @@ def attn_branch_fwd(x, gamma, beta, eps, Wqkv_p, bqkv, Wproj_p, bproj, win2tok, 
                     rowscale=None, out=None, bias_frag=None, save=False):
     """x fp32 [nB*L, C] token rows of one resolution group -> y fp32 = x + rowscale * (proj(window_attention(qkv(LayerNorm(x)))) + b_proj)
     in one kernel.  Wqkv_p / Wproj_p: cast_weight(W, perm32=True) of qkv.weight / proj.weight.  save=True also returns what the
-    unfused backward reads: (y, (xw, mean, rstd, qkv, ao)).  bias_frag / rel_table as for window_attn_fwd."""
+    unfused backward reads: (y, (xw, mean, rstd, qkv, ao)); save=(xw, mean, rstd, qkv, ao) writes them into the given tensors (row
+    slices of a stage's matrices).  bias_frag / rel_table as for window_attn_fwd."""
     x = _f32c(x)
     rows, Cc = x.shape
     nB = rows // L
@@ -676,12 +677,18 @@ def attn_branch_fwd(x, gamma, beta, eps, Wqkv_p, bqkv, Wproj_p, bproj, win2tok, 
     y = torch.empty_like(x) if out is None else out
     assert y.shape == x.shape and y.dtype == torch.float32 and y.is_contiguous()
     xw = qkv = ao = mean = rstd = None
-    if save:
+    if save is True:
         xw = torch.empty((rows, Cc), dtype=torch.bfloat16, device=x.device)
         qkv = torch.empty((rows, 3 * Cc), dtype=torch.bfloat16, device=x.device)
         ao = torch.empty((rows, Cc), dtype=torch.bfloat16, device=x.device)
         mean = torch.empty((rows,), dtype=torch.float32, device=x.device)
         rstd = torch.empty_like(mean)
+    elif save:
+        xw, mean, rstd, qkv, ao = save
+        assert xw.shape == (rows, Cc) and qkv.shape == (rows, 3 * Cc) and ao.shape == (rows, Cc) and mean.shape == (rows,) and rstd.shape == (rows,)
+        assert all(t.is_contiguous() for t in save) and xw.dtype == qkv.dtype == ao.dtype == torch.bfloat16 and mean.dtype == rstd.dtype == torch.float32
+    if rowscale is not None:
+        assert rowscale.shape == (rows,) and rowscale.dtype == torch.float32 and rowscale.is_contiguous()
     bias_ws = bias_frag if bias_frag is not None else workspace(2 * nH * attn_frag_elems(N), x.device, slot=2)
     assert rel_table is not None or bias_frag is not None
     check(lib.esvit_attn_branch_fwd(BF16, _p(x), _p(_f32c(gamma)), _p(_f32c(beta)), eps, _p(Wqkv_p), _p(_f32c(bqkv)), _p(Wproj_p), _p(_f32c(bproj)),

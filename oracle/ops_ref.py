@@ -188,6 +188,34 @@ def colsum(x, *, out=None, accumulate=False):
     return s
 
 
+# ---- fused attention branch (esvit_attn_branch_fwd): the unfused sequence it replaces, same rounding points -------------------
+def attn_branch_supported(dt, Cc, nH, N):
+    return dt == torch.bfloat16 and Cc in (96, 192) and Cc == 32 * nH and N <= 64
+
+
+def cast_weight(w, transpose=False, perm32=False):
+    """(the restatement keeps the natural channel order)"""
+    return _r(w.float().t().contiguous() if transpose else w.float(), torch.bfloat16)
+
+
+def attn_branch_fwd(x, gamma, beta, eps, Wqkv_p, bqkv, Wproj_p, bproj, win2tok, L, rel_table, ws, region_ids, nW, N, nH, scale, *,
+                    rowscale=None, out=None, bias_frag=None, save=False):
+    xw, _, mean, rstd = layernorm_fwd(x, gamma, beta, eps, dtype=Wqkv_p.dtype)
+    qkv = linear_fwd(xw, Wqkv_p, bqkv)
+    ao = window_attn_fwd(qkv, bqkv, win2tok, L, rel_table, ws, region_ids, nW, N, nH, scale, bias_frag=bias_frag)[0]
+    y = linear_fwd(ao, Wproj_p, bproj, residual=x, rowscale=rowscale, rows_per_sample=1, out_f32=True)
+    if out is not None:
+        out.copy_(y)
+        y = out
+    if save is True:
+        return y, (xw, mean, rstd, qkv, ao)
+    if save:
+        for dst, src in zip(save, (xw, mean, rstd, qkv, ao)):
+            dst.copy_(src)
+        return y, save
+    return y
+
+
 # ---- normalisation ---------------------------------------------------------------------------
 def mlp_fused_supported(dt, Cc, backward=False):
     return dt == torch.bfloat16 and Cc in (96, 192)
