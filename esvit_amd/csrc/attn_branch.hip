@@ -71,6 +71,13 @@ struct ABParams {
 #define TL(i_)
 #endif
 
+// scheduling fences between the pieces of a step (register pressure against overlap: tools/bench_attn_branch.py decides)
+#ifdef ESVIT_AB_NO_SCHED_BARRIER
+#define AB_SCHED_BARRIER()
+#else
+#define AB_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
+#endif
+
 namespace {
 
 constexpr int AB_FRAG = 16 * 256;   // floats per head of the fragment-order bias (window_attn.hip: FRAG_ELEMS)
@@ -347,6 +354,16 @@ __device__ __forceinline__ void attn_branch_fwd_body(const ABParams& p) {
             pr[i] = mfma16(kf, qf, b);
         }
         TL(2);
+        // (the fragments of the two products behind the softmax are requested now: their LDS latency hides behind its arithmetic)
+        u32x2 vf[2][2][2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                const char* a0 = smem + kvo + K_BYTES + vr + 16 * VT_LD * dt + 64 * ks;
+                vf[ks][dt][0] = *reinterpret_cast<const u32x2*>(a0);
+                vf[ks][dt][1] = *reinterpret_cast<const u32x2*>(a0 + 32);
+            }
         // softmax over the 64 keys in the base-2 domain (q and the bias carry log2(e)): one v_exp_f32 per score; P stays
         // unnormalised (<= 1) and 1 / sum rides in the scale of O
         float m = -3.0e38f;
@@ -378,8 +395,7 @@ __device__ __forceinline__ void attn_branch_fwd_body(const ABParams& p) {
             }
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt) {
-                const char* a0 = smem + kvo + K_BYTES + vr + 16 * VT_LD * dt + 64 * ks;
-                const u32x2 lo = *reinterpret_cast<const u32x2*>(a0), hi = *reinterpret_cast<const u32x2*>(a0 + 32);
+                const u32x2 lo = vf[ks][dt][0], hi = vf[ks][dt][1];
                 o[dt] = mfma16(__builtin_bit_cast(bf16x8, u32x4{lo[0], lo[1], hi[0], hi[1]}), pf, o[dt]);
             }
         }
@@ -453,7 +469,7 @@ __device__ __forceinline__ void attn_branch_fwd_body(const ABParams& p) {
 
             auto piece_A = [&]() {
                 attend(IC<hprev>{}, kvo1, po1, sv_o);  // (s == 0: on images nobody wrote; nothing of it is kept)
-                __builtin_amdgcn_sched_barrier(0);
+                AB_SCHED_BARRIER();
                 mem_fence_compiler();
                 if constexpr (SAVE) {
                     const unsigned vo = row_off(row_prev, (unsigned)row_prev * (C * 2) + (32 * hprev + 16 * (g & 1) + 4 * (g & ~1)) * 2);
@@ -485,7 +501,7 @@ __device__ __forceinline__ void attn_branch_fwd_body(const ABParams& p) {
                     row_nxt = map_row(tok_nn, base_nn);
                     reg_nxt = map_reg(rg_nn, base_nn);
                 }
-                __builtin_amdgcn_sched_barrier(0);
+                AB_SCHED_BARRIER();
             };
             auto piece_N = [&]() {
                 if constexpr (h == 0) {
@@ -532,26 +548,36 @@ __device__ __forceinline__ void attn_branch_fwd_body(const ABParams& p) {
                         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, mean), rmean, vo, 0, 0);
                         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, rstd), rrstd, vo, 0, 0);
                     }
-                    __builtin_amdgcn_sched_barrier(0);
+                    AB_SCHED_BARRIER();
                 }
             };
             auto piece_Q = [&]() {
                 const float* sb = reinterpret_cast<const float*>(smem + qo + 3 * Cf::A_BYTES);
+                // software pipeline over the three parts: the weight fragments of part p + 1 are requested before the MFMAs of part p
+                bf16x8 wf[2][2 * KS];
+                auto load_part = [&](int part, bf16x8 (&dst)[2 * KS]) {
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) {
+                        dst[2 * ks] = *reinterpret_cast<const bf16x8*>(smem + qo + fa(0, ks) + part * Cf::A_BYTES);
+                        dst[2 * ks + 1] = *reinterpret_cast<const bf16x8*>(smem + qo + fa(1, ks) + part * Cf::A_BYTES);
+                    }
+                };
+                load_part(0, wf[0]);
                 static_for<0, 3>([&](auto Pc) {
                     constexpr int part = decltype(Pc)::value;
                     constexpr bool TRANSPOSED = part < 2 || SAVE;  // q, k (and the side-output copy of v): [32 channels][16 slots]
+                    if constexpr (part < 2) load_part(part + 1, wf[(part + 1) & 1]);
+                    const bf16x8 (&wc)[2 * KS] = wf[part & 1];
                     f32x4 a0 = f32x4{0.f, 0.f, 0.f, 0.f}, a1 = a0, v0 = a0, v1 = a0;
 #pragma unroll
                     for (int ks = 0; ks < KS; ++ks) {
-                        const bf16x8 w0 = *reinterpret_cast<const bf16x8*>(smem + qo + fa(0, ks) + part * Cf::A_BYTES);
-                        const bf16x8 w1 = *reinterpret_cast<const bf16x8*>(smem + qo + fa(1, ks) + part * Cf::A_BYTES);
                         if constexpr (TRANSPOSED) {
-                            a0 = mfma16(w0, xb[ks], a0);
-                            a1 = mfma16(w1, xb[ks], a1);
+                            a0 = mfma16(wc[2 * ks], xb[ks], a0);
+                            a1 = mfma16(wc[2 * ks + 1], xb[ks], a1);
                         }
                         if constexpr (part == 2) {  // V [16 slots][32 channels]: the same fragments with the operands exchanged
-                            v0 = mfma16(xb[ks], w0, v0);
-                            v1 = mfma16(xb[ks], w1, v1);
+                            v0 = mfma16(xb[ks], wc[2 * ks], v0);
+                            v1 = mfma16(xb[ks], wc[2 * ks + 1], v1);
                         }
                     }
                     u32x4 pk = {};
@@ -579,7 +605,6 @@ __device__ __forceinline__ void attn_branch_fwd_body(const ABParams& p) {
                         *reinterpret_cast<u32x2*>(smem + kvo + K_BYTES + vw + 4 * VT_LD) = u32x2{pack2(v1[0] + bv1, v1[1] + bv1), pack2(v1[2] + bv1, v1[3] + bv1)};
                         if constexpr (SAVE) sv_v = pk;
                     }
-                    __builtin_amdgcn_sched_barrier(0);
                 });
                 mem_fence_compiler();
                 if constexpr (SAVE) {  // side-output rows of this pair

@@ -193,7 +193,7 @@ int check_selector(int dtype, const esvit_gemm_desc& d) {
     ESVIT_CHECK_ARG(!(d.kernel == ESVIT_GEMM_P8N && !p8n_supports(dtype, d)),
                     "esvit_gemm: the 256 x 128 eight-phase loop needs what ESVIT_GEMM_P8 needs, N %% 32 == 0, 16-byte aligned outputs and one of its epilogue kinds");
     ESVIT_CHECK_ARG(!(d.kernel == ESVIT_GEMM_P8 && !p8_supports(dtype, d)),
-                    "esvit_gemm: the eight-phase loop needs bf16, K %% 64 == 0 and no row map / row statistics");
+                    "esvit_gemm: the eight-phase loop needs bf16, K %% 64 == 0, no row map, and row statistics only over whole 256 x 256 tiles without column sums");
     if (dtype != ESVIT_BF16)
         ESVIT_CHECK_ARG(d.kernel == ESVIT_GEMM_AUTO || d.kernel == ESVIT_GEMM_REGSTAGE, "esvit_gemm: fp32 runs on the register-staged loop only");
     else

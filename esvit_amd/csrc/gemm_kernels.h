@@ -574,6 +574,8 @@ __device__ __forceinline__ void epilogue_direct_at(const esvit_gemm_desc& p, f32
         // lanes; lane c == 0 of every group writes its 4 x FN columns.  (Kept out of the row loop above: one column block at a time.)
         // (the pointer is fetched from the kernel-argument segment HERE: as one more descriptor field live across the main loop it
         // pushed two scalars of every instance of the kernel into scratch memory, whose reloads cost this epilogue ~1 us per tile)
+        // (valid because every kernel that instantiates this epilogue takes the descriptor BY VALUE AS ITS FIRST ARGUMENT: the
+        // kernel-argument segment then starts with it -- gemm_dma_kernel / gemm_kernel, checked where they are declared)
         float* colstat;
         asm volatile("s_load_dwordx2 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)"
                      : "=s"(colstat)
@@ -698,6 +700,8 @@ __device__ __forceinline__ void tile_coords(int pid, int tiles_m, int tiles_n, i
 
 template <typename T, bool AKS, bool BKS, int BM, int BN, bool USE_TR>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const esvit_gemm_desc p) {
+    // (the descriptor stays the FIRST argument, by value: the statistics epilogue reads esvit_gemm_desc::colstat from the
+    // kernel-argument segment at offsetof(esvit_gemm_desc, colstat), epilogue_direct_at<RS>)
     using TA = Tile<T, AKS, BM, USE_TR>;
     using TB = Tile<T, BKS, BN, USE_TR>;
     constexpr int WTM = BM / 2, WTN = BN / 2;  // wave tile
@@ -932,6 +936,8 @@ __device__ long* g_probe_timeline = nullptr;
 
 template <bool AKS, bool BKS, int BM, int BN, int BKD, int NBUF, int WM, int WN, int MINB = 2, bool EARLY = false>
 __global__ __launch_bounds__(64 * WM * WN, MINB) void gemm_dma_kernel(const esvit_gemm_desc p, const int group_m) {
+    // (the descriptor stays the FIRST argument, by value: the statistics epilogue reads esvit_gemm_desc::colstat from the
+    // kernel-argument segment at offsetof(esvit_gemm_desc, colstat), epilogue_direct_at<RS>)
     constexpr int NT = 64 * WM * WN;
     ESVIT_TL(0);
 #ifdef ESVIT_PROBE_TIMELINE

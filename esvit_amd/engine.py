@@ -299,6 +299,7 @@ def train_one_epoch(student, teacher, teacher_without_ddp, dino_loss, data_loade
     dev = next(net.parameters()).device
     loss_sum = torch.zeros((), dtype=torch.float32, device=dev)
     last = None
+    last_look = -1  # iteration of the previous look at the loss / the refused-update counter
     for it, (images, _) in enumerate(data_loader):
         git = n_it * epoch + it
         images = [im.cuda(non_blocking=True) for im in images]
@@ -329,9 +330,11 @@ def train_one_epoch(student, teacher, teacher_without_ddp, dino_loss, data_loade
             # a gradient overflow with a FINITE loss (bf16 backward) is refused by the update kernel too: say so, take the refused
             # updates back out of the step counts, and stop when nothing but refusals happened since the last look
             refused = tr.updater.take_skipped()
+            since = it - last_look  # updates launched since the previous look (the first look of an epoch follows one update)
+            last_look = it
             if refused:
-                print("WARNING: %d of the last %d updates were skipped (non-finite gradients, finite loss)" % (refused, min(10, it + 1)))
-                if refused >= min(10, it + 1) and it >= 10:
+                print("WARNING: %d of the last %d updates were skipped (non-finite gradients, finite loss)" % (refused, since))
+                if refused >= since and it > 0:
                     print("every update since the last check was skipped, stopping training")
                     sys.exit(1)
     mean = loss_sum / max(n_it, 1)

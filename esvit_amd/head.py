@@ -93,5 +93,6 @@ class DINOHead(nn.Module):
         y = y.view(*lead, y.shape[-1])
         if mx is not None:
             # (token, row max, row log-sum-exp, batch sums per column or None: the last one does not depend on centre / temperature)
-            y.esvit_row_stats = (self.logit_stats[2], mx, lse, getattr(mx, "esvit_col_sums", None))
+            cs = getattr(mx, "esvit_col_sums", None)
+            y.esvit_row_stats = (self.logit_stats[2], mx, lse, None if cs is None else (int(mx.shape[0]), cs))
         return y

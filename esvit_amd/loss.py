@@ -69,10 +69,14 @@ def _taken_stats(x, token):
     return None
 
 
-def _taken_col_sums(x):
-    """batch sums per column a teacher head's last-layer GEMM attached to its logits (fp32 [K]), else None"""
+def _taken_col_sums(x, token):
+    """batch sums per column a teacher head's last-layer GEMM attached to its logits for exactly this request (fp32 [K] over the
+    x.shape[0] rows of x), else None"""
     st = getattr(x, "esvit_row_stats", None)
-    return st[3] if st is not None and len(st) > 3 else None
+    if st is None or len(st) <= 3 or st[3] is None or st[0] != token:
+        return None
+    rows, sums = st[3]
+    return sums if rows == x.shape[0] and sums.numel() == x.shape[-1] else None
 
 
 class _DeferredCenter:
@@ -103,6 +107,7 @@ class _DeferredCenter:
     # is (inverse temperature, centre, token); the token ties the statistics to the centre values they were computed with -- any
     # centre update in between changes `_center_version` and the loss falls back to its own passes.
     _center_version = 0
+    wants_col_sums = False  # a loss whose update_center takes the teacher logits' column sums from the heads sets this
 
     def _token(self, who, inv_temp):
         return (id(self), who, self._center_version, float(inv_temp))
@@ -120,7 +125,7 @@ class _DeferredCenter:
             for lvl, (head, cen) in enumerate(zip(_heads_of(model), cens)):
                 if head is not None:
                     # (the teacher heads also hand over the column sums of their logits: the centre update's input)
-                    head.logit_stats = (inv_t, None if cen is None else cen.view(-1), self._token(who + str(lvl), inv_t), who == "t")
+                    head.logit_stats = (inv_t, None if cen is None else cen.view(-1), self._token(who + str(lvl), inv_t), who == "t" and self.wants_col_sums)
 
     @staticmethod
     def disarm_logit_stats(student, teacher):
@@ -250,6 +255,8 @@ class DINOLoss(_DeferredCenter, nn.Module):
 
 
 class DDINOLoss(_DeferredCenter, nn.Module):
+    wants_col_sums = True  # update_center below consumes them
+
     def __init__(self, out_dim, ncrops, warmup_teacher_temp, teacher_temp, warmup_teacher_temp_epochs, nepochs,
                  student_temp=0.1, center_momentum=0.9):
         super().__init__()
@@ -301,7 +308,7 @@ class DDINOLoss(_DeferredCenter, nn.Module):
         inv_st = 1.0 / self.student_temp
         st_tc, st_tg = _taken_stats(t_cls, self._token("t0", inv_tt)), _taken_stats(t_reg, self._token("t1", inv_tt))
         st_sc, st_sg = _taken_stats(s_cls, self._token("s0", inv_st)), _taken_stats(s_reg, self._token("s1", inv_st))
-        cs_tc, cs_tg = _taken_col_sums(t_cls), _taken_col_sums(t_reg)
+        cs_tc, cs_tg = _taken_col_sums(t_cls, self._token("t0", inv_tt)), _taken_col_sums(t_reg, self._token("t1", inv_tt))
         s_cls_c, s_reg_c = s_cls.contiguous(), s_reg.contiguous()
         t_cls, t_reg = t_cls.detach().contiguous(), t_reg.detach().contiguous()
         Tt = int(t_np[0])

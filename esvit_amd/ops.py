@@ -161,12 +161,6 @@ def gemm_algorithmic_bytes(dt, kw):
 FORCE_GEMM_KERNEL = GEMM_AUTO
 
 
-def p8_supported(kw):
-    """can the 256 x 256 eight-phase loop (ESVIT_GEMM_P8) run this problem?  Mirrors p8_supports() of csrc/gemm.hip."""
-    return (kw["K"] % 64 == 0 and kw.get("rowmap") is None and kw.get("rowstat") is None
-            and not (kw.get("a_kstrided", 0) and not kw.get("b_kstrided", 0)))
-
-
 def _gemm_desc(kw):
     d = GemmDesc()
     for k in ("A", "B", "C", "bias", "residual", "rowmap", "rowscale", "aux", "partial", "colsum", "colsum_partial", "rowstat", "rowstat_center", "colstat"):
@@ -239,7 +233,7 @@ def linear_fwd(x, w, bias=None, *, gelu=False, want_preact=False, residual=None,
         y = torch.empty((M, N), dtype=x.dtype, device=x.device)
         cen = None if cen is None else _f32c(cen)
         # the statistics come in blocks of 64 columns from the 128-row loop, of 32 columns from the 256 x 256 eight-phase loop
-        kern = gemm_select(x.dtype, M=M, N=N, K=K, rowstat=y)[0]
+        kern = gemm_select(x.dtype, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, rowstat=y)[0]
         nb = N // (32 if kern == GEMM_P8 else 64)
         st = torch.empty((M, nb, 2), dtype=torch.float32, device=x.device)
         # column sums of the stored logits per 64-row wave tile (the statistics epilogue of the 128 x 128 tile only)
@@ -275,7 +269,7 @@ def linear_dgrad(dy, w, *, gelu_preact=None, out_f32=False, quick=False):
         if FORCE_GEMM_KERNEL == GEMM_AUTO and dy.dtype == torch.bfloat16 and Kin >= 192:
             # (the eight-phase loop addresses its operands with 32-bit DMA offsets: d(logits) below 4 GiB)
             kern = GEMM_P8 if (Nout % 64 == 0 and Kin % 256 == 0 and dy.numel() * 2 < 0xfff00000 and not os.environ.get("ESVIT_NO_P8_ROUTING")) else GEMM_DMA8
-        _, tm, tn, slots = gemm_select(dy.dtype, M=M, N=Kin, K=Nout, b_kstrided=1, kernel=kern)
+        _, tm, tn, slots = gemm_select(dy.dtype, M=M, N=Kin, K=Nout, lda=Nout, ldb=Kin, ldc=Kin, b_kstrided=1, kernel=kern)
         tiles = (-(-M // tm)) * (-(-Kin // tn))
         if tiles <= slots // 2:
             splitk = int(min(16, max(2, slots // tiles)))
@@ -316,7 +310,7 @@ def linear_wgrad(dy, x, *, out=None, accumulate=False, want_bias=False, db_out=N
     if want_bias:
         db = db_out if db_out is not None else torch.empty((Nout,), dtype=torch.float32, device=dy.device)
         assert db.shape == (Nout,) and db.dtype == torch.float32 and db.is_contiguous()
-    _, tm, tn, slots = gemm_select(dy.dtype, M=Nout, N=Kin, K=rows, a_kstrided=1, b_kstrided=1, colsum=db)
+    _, tm, tn, slots = gemm_select(dy.dtype, M=Nout, N=Kin, K=rows, lda=Nout, ldb=Kin, ldc=Kin, a_kstrided=1, b_kstrided=1, colsum=db)
     tiles = (-(-Nout // tm)) * (-(-Kin // tn))
     splitk = _pick_splitk(rows, Nout, Kin, tiles, slots)
     if splitk > 1:

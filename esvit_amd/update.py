@@ -175,19 +175,34 @@ class FusedClipAdamWEMA:
         if self.bound is not None:
             self._publish_bound_state(lr, weight_decay)
 
-    def take_skipped(self):
-        """How many update launches since the last call were refused by the kernel's non-finite guard (SYNCHRONISES with the
-        device).  Their step counts (the bias correction of AdamW, the 'step' entries of the optimizer state) are taken back: a
-        refused update advanced nothing.  Which launches were refused is not recorded, only how many; the launches of one epoch step
-        the same parameters, so the most recent ones are rolled back."""
+    def _settle_skipped(self):
+        """look at the kernel's refused-update counter (SYNCHRONISES with the device) and take the refused launches back out of the
+        step counts (the bias correction of AdamW, the 'step' entries of the optimizer state): a refused update advanced nothing.
+        Which launches were refused is not recorded, only how many; the launches between two looks step the same parameters (a look
+        happens at every epoch end, where freeze_last_layer may change the set), so the most recent ones are rolled back.  A bound
+        torch optimizer's published 'step' entries are corrected at once, so a checkpoint written right after a look is exact."""
         total = int(self.skipped.item())
         new = total - self._skipped_seen
         self._skipped_seen = total
-        for stepped in self._stepped_log[len(self._stepped_log) - new:] if new > 0 else []:
-            for i in stepped:
-                self.steps[i] -= 1
+        if new > 0:
+            for stepped in self._stepped_log[len(self._stepped_log) - new:]:
+                for i in stepped:
+                    self.steps[i] -= 1
+            if self.bound is not None:
+                for i, p in enumerate(self.params):
+                    e = self.bound.state.get(p)
+                    if e and "step" in e:
+                        e["step"].fill_(float(self.steps[i]))
+            self._unreported = getattr(self, "_unreported", 0) + new
         self._stepped_log = []
-        return new
+
+    def take_skipped(self):
+        """How many update launches since the last call were refused by the kernel's non-finite guard (synchronises; see
+        _settle_skipped for what happens to their step counts)."""
+        self._settle_skipped()
+        n = getattr(self, "_unreported", 0)
+        self._unreported = 0
+        return n
 
     # ---- a torch.optim.AdamW bound to this updater (integration level L2 with the unmodified train_esvit) -------------
     def _refresh_static_rows(self, i):
@@ -246,6 +261,7 @@ class FusedClipAdamWEMA:
         return [pos[id(p)] for p in order]
 
     def state_dict(self):
+        self._settle_skipped()  # (a checkpoint never carries the step of a refused update)
         order = self._ordered()
         state = {}
         for k, i in enumerate(order):

@@ -112,7 +112,8 @@ typedef struct {
      * every 64-column block j the pair (m, s) = (max_k z_k, sum_k 2^(z_k - m)) over k in [64 j, 64 j + 64) of
      * z_k = (C[row][k] as stored, i.e. rounded to the activation dtype, - rowstat_center[k]) * rowstat_scale
      * (scale = log2(e) / temperature; center NULL = 0).  rowstat: fp32 [M, N / 64, 2] -- or [M, N / 32, 2], blocks of 32 columns,
-     * when esvit_gemm_select reports ESVIT_GEMM_P8 for the descriptor (M and N whole 256-tiles and >= 1024 of them).  Only for the plain bf16 epilogue of a
+     * when the descriptor asks for ESVIT_GEMM_P8 (M and N whole 256-tiles; esvit_gemm_select reports what a descriptor resolves to -- AUTO keeps
+     * the 128 x 128 tile for statistics, measured faster inside the step).  Only for the plain bf16 epilogue of a
      * dense forward GEMM with M % 128 == 0 and N % 128 == 0 (rejected otherwise); esvit_rowstat_combine folds the blocks of a row,
      * esvit_dino_ce_fwd_bwd takes them in place of its first pass over the logits (main_esvit.py:728-742). */
     float* rowstat;
@@ -130,7 +131,7 @@ typedef struct {
 #define ESVIT_GEMM_DMA4 2     /* bf16, LDS-DMA, 128 x {64,96,128} tiles, 4 waves, two workgroups per CU */
 #define ESVIT_GEMM_DMA8 3     /* bf16, LDS-DMA, 256 x 256 tiles, 8 waves, one workgroup per CU: very long reductions */
 #define ESVIT_GEMM_DMA4W 4    /* bf16, LDS-DMA, 4 waves, 128 x 192 / 128 x 96 tiles with whole-width wave rows (N % 96 == 0) */
-#define ESVIT_GEMM_P8 5       /* bf16, LDS-DMA, 256 x 256 tiles, 8 waves, eight-phase schedule with counted DMA waits (K % 64 == 0; no rowmap / rowstat) */
+#define ESVIT_GEMM_P8 5       /* bf16, LDS-DMA, 256 x 256 tiles, 8 waves, eight-phase schedule with counted DMA waits (K % 64 == 0, no rowmap; rowstat only over whole 256 x 256 tiles, in 32-column blocks, without colstat) */
 #define ESVIT_GEMM_P8N 6      /* the same structure on 256 x 128 tiles with two accumulator sets: a tile's epilogue is spread over the next tile's main loop (additionally N % 32 == 0, 16-byte aligned outputs) */
 
 /* C = alpha * op(A) op(B) (+ epilogue).  Replaces every nn.Linear / conv-as-GEMM on the
