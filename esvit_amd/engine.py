@@ -228,8 +228,10 @@ class EsvitTrainer:
             for t in (teacher_out if isinstance(teacher_out, (tuple, list)) else [teacher_out]):
                 if torch.is_tensor(t):
                     t.record_stream(main)
-                    for st in getattr(t, "esvit_row_stats", (None,))[1:]:
-                        st.record_stream(main)
+                    for st in getattr(t, "esvit_row_stats", (None,))[1:]:  # (row max, row lse, (rows, column sums) or None)
+                        for u in (st if isinstance(st, tuple) else (st,)):
+                            if torch.is_tensor(u):
+                                u.record_stream(main)
         else:
             with torch.no_grad():
                 teacher_out = self.teacher(t_in)
