@@ -293,13 +293,19 @@ __device__ __forceinline__ void attn_branch_fwd_body(const ABParams& p) {
     // later (map_row / map_reg) -- a use right behind the loads would make hipcc wait for them and, in-order, for the weight
     // slices requested just before
     const int* regs_or_map = masked ? p.region_ids : p.win2tok;
+    const float inv_nw = 1.0f / (float)p.nW;
     auto issue_map = [&](int it, int& tok, int& rg, int& base) {
         const int bw = (it * (int)gridDim.x + (int)blockIdx.x) * NWIN + wj;  // (wave-uniform)
         const bool act = it < iters && bw < p.Bw;
-        const int wi = act ? bw % p.nW : 0;
+        // image / window of bw without an integer division (bw < 2^22, checked by the host): a float quotient, corrected by one
+        int img = (int)(((float)bw + 0.5f) * inv_nw);
+        int wi = bw - img * p.nW;
+        if (wi < 0) { wi += p.nW; --img; }
+        if (wi >= p.nW) { wi -= p.nW; ++img; }
+        if (!act) wi = 0;
         tok = p.win2tok[(long)wi * p.N + (slot < p.N ? slot : 0)];
         rg = regs_or_map[(long)wi * p.N + (lane < p.N ? lane : 0)];
-        base = act ? (bw / p.nW) * p.L : -1;
+        base = act ? img * p.L : -1;
     };
     auto map_row = [&](int tok, int base) -> int { return (base >= 0 && slot < p.N && tok >= 0) ? base + tok : -1; };  // row of this lane's slot or -1
     auto map_reg = [&](int rg, int base) -> int { return (masked && base >= 0 && lane < p.N) ? rg : -1; };             // region id of slot `lane` or -1
@@ -709,6 +715,7 @@ extern "C" int esvit_attn_branch_fwd(int dtype, const float* x, const float* gam
     const int C = 32 * nH;
     const long rows = (long)nB * L;
     ESVIT_CHECK_ARG(rows * 3 * C * 2 < 0x7fff0000L && rows * C * 4 < 0x7fff0000L, "esvit_attn_branch_fwd: the rows of one call must fit 2 GiB buffer ranges");
+    ESVIT_CHECK_ARG((long)nB * nW < (1L << 22), "esvit_attn_branch_fwd: at most 2^22 windows per call");
     if (rel_table) {
         int rc = esvit_i_fill_bias_frag(rel_table, ws, N, nH, bias_frag_ws, stream);
         if (rc != ESVIT_OK) return rc;
