@@ -1,5 +1,5 @@
 """Fold two rocprofv3 PMC passes (one with --pmc FETCH_SIZE, one with --pmc WRITE_SIZE; both with --kernel-trace
--f csv) of `python bench.py --steps S --warmup W --batch B` into profiles/r04_pmc_traffic.json (ESVIT_PMC_TRAFFIC_OUT overrides the name).
+-f csv) of `python bench.py --steps S --warmup W --batch B` into profiles/r05_pmc_traffic.json (ESVIT_PMC_TRAFFIC_OUT overrides the name).
 
   python tools/pmc_traffic.py FETCH_counter_collection.csv WRITE_counter_collection.csv ARCH BATCH STEPS_TOTAL
 
@@ -35,7 +35,7 @@ def main():
     total = sum(v["fetch_bytes_per_step"] + v["write_bytes_per_step"] for v in per_kernel.values())
     run = {"arch": arch, "batch": batch, "steps_counted": steps, "gemm_bytes_per_step": gemm, "all_kernels_bytes_per_step": total,
            "fetch_correction": 2.0, "per_kernel": per_kernel}
-    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", os.environ.get("ESVIT_PMC_TRAFFIC_OUT", "r04_pmc_traffic.json"))
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", os.environ.get("ESVIT_PMC_TRAFFIC_OUT", "r05_pmc_traffic.json"))
     doc = {"runs": []}
     if os.path.exists(out):
         with open(out) as fh:
