@@ -27,7 +27,6 @@
 // images are double-buffered per window, so one barrier per step orders everything.  The token rows of the NEXT window group are
 // prefetched into registers a few 16-byte loads per step; those loads, the output stores and the side-output stores are the
 // YOUNGEST memory operations of a step and are the only ones the step's closing `s_waitcnt vmcnt(n)` leaves in flight.
-#include <stdlib.h>
 #include "common.h"
 #include "fused16.h"
 #include "../../include/esvit_hip.h"
@@ -352,12 +351,13 @@ __device__ __forceinline__ void attn_branch_fwd_body(const ABParams& p) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const bf16x8 kf = *reinterpret_cast<const bf16x8*>(smem + kvo + kr + 1024 * i);
-            f32x4 b = bias_r[hp][i];
-            if (masked) {
+            pr[i] = mfma16(kf, qf, bias_r[hp][i]);  // (the bias rides in as the C operand: no copy, no add)
+        }
+        if (mbits) {  // shift mask: -100 where key and query lie in different regions (only windows that straddle a region border)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) b[r] += ((mbits >> (4 * i + r)) & 1u) ? -100.f * LOG2E : 0.f;
-            }
-            pr[i] = mfma16(kf, qf, b);
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pr[i][r] += ((mbits >> (4 * i + r)) & 1u) ? -100.f * LOG2E : 0.f;
         }
         TL(2);
         // (the fragments of the two products behind the softmax are requested now: their LDS latency hides behind its arithmetic)
@@ -574,7 +574,19 @@ __device__ __forceinline__ void attn_branch_fwd_body(const ABParams& p) {
                     constexpr bool TRANSPOSED = part < 2 || SAVE;  // q, k (and the side-output copy of v): [32 channels][16 slots]
                     if constexpr (part < 2) load_part(part + 1, wf[(part + 1) & 1]);
                     const bf16x8 (&wc)[2 * KS] = wf[part & 1];
+                    // (biases as the accumulators' initial values: channels 8g .. 8g+7 of the part for the transposed tiles, one
+                    // channel per lane for the V tiles)
                     f32x4 a0 = f32x4{0.f, 0.f, 0.f, 0.f}, a1 = a0, v0 = a0, v1 = a0;
+                    if constexpr (TRANSPOSED) {
+                        a0 = *reinterpret_cast<const f32x4*>(sb + 32 * part + 8 * g);
+                        a1 = *reinterpret_cast<const f32x4*>(sb + 32 * part + 8 * g + 4);
+                    }
+                    if constexpr (part == 2) {
+                        const float bv0 = *reinterpret_cast<const float*>(smem + qo + 3 * Cf::A_BYTES + 64 * 4 + vb);
+                        const float bv1 = *reinterpret_cast<const float*>(smem + qo + 3 * Cf::A_BYTES + 64 * 4 + vb + 16);
+                        v0 = f32x4{bv0, bv0, bv0, bv0};
+                        v1 = f32x4{bv1, bv1, bv1, bv1};
+                    }
 #pragma unroll
                     for (int ks = 0; ks < KS; ++ks) {
                         if constexpr (TRANSPOSED) {
@@ -587,12 +599,7 @@ __device__ __forceinline__ void attn_branch_fwd_body(const ABParams& p) {
                         }
                     }
                     u32x4 pk = {};
-                    if constexpr (TRANSPOSED) {
-                        const f32x4 b0 = *reinterpret_cast<const f32x4*>(sb + 32 * part + 8 * g), b1 = *reinterpret_cast<const f32x4*>(sb + 32 * part + 8 * g + 4);
-                        a0 += b0;
-                        a1 += b1;
-                        if constexpr (part != 0 || SAVE) pk = u32x4{pack2(a0[0], a0[1]), pack2(a0[2], a0[3]), pack2(a1[0], a1[1]), pack2(a1[2], a1[3])};
-                    }
+                    if constexpr (TRANSPOSED && (part != 0 || SAVE)) pk = u32x4{pack2(a0[0], a0[1]), pack2(a0[2], a0[3]), pack2(a1[0], a1[1]), pack2(a1[2], a1[3])};
                     if constexpr (part == 0) {
                         const float qs = p.scale * LOG2E;  // scores in the base-2 domain
 #pragma unroll
@@ -605,10 +612,8 @@ __device__ __forceinline__ void attn_branch_fwd_body(const ABParams& p) {
                         *reinterpret_cast<u32x4*>(smem + kvo + kw) = pk;
                         if constexpr (SAVE) sv_k = pk;
                     } else {
-                        const float bv0 = *reinterpret_cast<const float*>(smem + qo + 3 * Cf::A_BYTES + 64 * 4 + vb);
-                        const float bv1 = *reinterpret_cast<const float*>(smem + qo + 3 * Cf::A_BYTES + 64 * 4 + vb + 16);
-                        *reinterpret_cast<u32x2*>(smem + kvo + K_BYTES + vw) = u32x2{pack2(v0[0] + bv0, v0[1] + bv0), pack2(v0[2] + bv0, v0[3] + bv0)};
-                        *reinterpret_cast<u32x2*>(smem + kvo + K_BYTES + vw + 4 * VT_LD) = u32x2{pack2(v1[0] + bv1, v1[1] + bv1), pack2(v1[2] + bv1, v1[3] + bv1)};
+                        *reinterpret_cast<u32x2*>(smem + kvo + K_BYTES + vw) = u32x2{pack2(v0[0], v0[1]), pack2(v0[2], v0[3])};
+                        *reinterpret_cast<u32x2*>(smem + kvo + K_BYTES + vw + 4 * VT_LD) = u32x2{pack2(v1[0], v1[1]), pack2(v1[2], v1[3])};
                         if constexpr (SAVE) sv_v = pk;
                     }
                 });
@@ -732,15 +737,11 @@ extern "C" int esvit_attn_branch_fwd(int dtype, const float* x, const float* gam
 #endif
     prm.nW = nW; prm.Bw = nB * nW; prm.N = N; prm.L = L; prm.rows = rows; prm.scale = scale;
     int rc;
-    static const int nwin = getenv("ESVIT_AB_NWIN") ? atoi(getenv("ESVIT_AB_NWIN")) : 0;  // (tuning switch of tools/bench_attn_branch.py)
-    if (nH == 3) {
-        if (nwin == 1) rc = save ? launch_ab<96, 1, true>(prm, stream) : launch_ab<96, 1, false>(prm, stream);
-        else if (nwin == 3) rc = save ? launch_ab<96, 3, true>(prm, stream) : launch_ab<96, 3, false>(prm, stream);
-        else rc = save ? launch_ab<96, 2, true>(prm, stream) : launch_ab<96, 2, false>(prm, stream);
-    } else {
-        if (nwin == 2) rc = save ? launch_ab<192, 2, true>(prm, stream) : launch_ab<192, 2, false>(prm, stream);
-        else rc = save ? launch_ab<192, 1, true>(prm, stream) : launch_ab<192, 1, false>(prm, stream);
-    }
+    // windows per workgroup, measured on the B = 128 row counts (tools/bench_attn_branch.py): C = 96: two (eight waves, two per SIMD, 216-233
+    // registers; one: 303 us, three: 283 us against 227 us on the 224-crop rows); C = 192: one (four waves at 472-487 registers: the q | k | v
+    // weights of a head alone are 37 KB of fragments, two windows per workgroup spill)
+    if (nH == 3) rc = save ? launch_ab<96, 2, true>(prm, stream) : launch_ab<96, 2, false>(prm, stream);
+    else rc = save ? launch_ab<192, 1, true>(prm, stream) : launch_ab<192, 1, false>(prm, stream);
     if (rc != ESVIT_OK) return rc;
     ESVIT_CHECK_LAUNCH("esvit_attn_branch_fwd");
     return ESVIT_OK;

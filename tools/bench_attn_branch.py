@@ -1,7 +1,6 @@
 """fused attention branch (esvit_attn_branch_fwd) vs the unfused LayerNorm -> qkv -> window attention -> proj sequence on the
 stage-0 / stage-1 geometries of one Swin-T W7 step (run on the MI355X):
-    python tools/bench_attn_branch.py [--batch 128] [--out gpurun_out/attn_branch.jsonl]
-ESVIT_AB_NWIN = windows per workgroup of the fused kernel (tuning switch, read once per process)."""
+    python tools/bench_attn_branch.py [--batch 128] [--out gpurun_out/attn_branch.jsonl]"""
 import argparse, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -64,7 +63,7 @@ def main():
             yr = unfused()
             yf = fused()
             err = float(((yf - x) - (yr - x)).abs().max() / ((yr - x).abs().max() + 1e-12))
-            r = {"C": C, "H": H, "images": nB, "shift": shift, "rows": nB * L, "windows": nB * nW, "who": who, "nwin": os.environ.get("ESVIT_AB_NWIN", "default"),
+            r = {"C": C, "H": H, "images": nB, "shift": shift, "rows": nB * L, "windows": nB * nW, "who": who,
                  "unfused_us": round(timeit(unfused), 1), "fused_us": round(timeit(fused), 1), "fused_save_us": round(timeit(fused_save), 1), "rel_err": err}
             r["bytes_min"] = nB * L * C * 8
             r["fused_TBps"] = round(r["bytes_min"] / r["fused_us"] * 1e-6, 3)
