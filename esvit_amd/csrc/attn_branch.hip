@@ -98,49 +98,6 @@ __device__ __forceinline__ void static_for(F&& f) {
     }
 }
 
-// v_permlane16_swap / v_permlane32_swap exchange the odd 16- / 32-lane rows of their first operand with the even rows of their
-// second: fed the same value twice, the two results are v[l] and v[l ^ 16] (v[l ^ 32]) in some order on every lane -- a butterfly
-// step on the VALU (__shfl_xor goes through the LDS crossbar).  Operands and results pass through empty asm statements: hipcc 7.2
-// folds `bitcast<float>(r[1])` of the swap's result pair to `bitcast<float>(r[0])` (tools/probe/permlane_swap_fold.hip: k7 emits
-// `v_add_f32 v1, v1, v1`); integer uses of the pair (fused16.h: row_swap) are not affected.
-__device__ __forceinline__ void swap16(float v, float& x, float& y) {
-    unsigned a = __builtin_bit_cast(unsigned, v), b = a;
-    asm volatile("" : "+v"(b));
-    const u32x2 r = __builtin_amdgcn_permlane16_swap(a, b, false, false);
-    unsigned r0 = r[0], r1 = r[1];
-    asm volatile("" : "+v"(r0), "+v"(r1));
-    x = __builtin_bit_cast(float, r0);
-    y = __builtin_bit_cast(float, r1);
-}
-__device__ __forceinline__ void swap32(float v, float& x, float& y) {
-    unsigned a = __builtin_bit_cast(unsigned, v), b = a;
-    asm volatile("" : "+v"(b));
-    const u32x2 r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
-    unsigned r0 = r[0], r1 = r[1];
-    asm volatile("" : "+v"(r0), "+v"(r1));
-    x = __builtin_bit_cast(float, r0);
-    y = __builtin_bit_cast(float, r1);
-}
-__device__ __forceinline__ float xor16_sum(float v) {
-    float x, y;
-    swap16(v, x, y);
-    return x + y;
-}
-__device__ __forceinline__ float xor32_sum(float v) {
-    float x, y;
-    swap32(v, x, y);
-    return x + y;
-}
-__device__ __forceinline__ float xor16_max(float v) {
-    float x, y;
-    swap16(v, x, y);
-    return fmaxf(x, y);
-}
-__device__ __forceinline__ float xor32_max(float v) {
-    float x, y;
-    swap32(v, x, y);
-    return fmaxf(x, y);
-}
 // sum / max over the four lanes (c, g = 0..3) of a token
 __device__ __forceinline__ float tok_sum(float v) { return xor32_sum(xor16_sum(v)); }
 __device__ __forceinline__ float tok_max(float v) { return xor32_max(xor16_max(v)); }

@@ -122,6 +122,74 @@ __device__ __forceinline__ void buffer_store_b128(const V& data, __amdgpu_buffer
 }
 
 // ---------------------------------------------------------------------------
+// 16-byte row stores straight from TRANSPOSED accumulators (a product formed as D^T = B^T A^T leaves lane (c, g) with, for its
+// column c -- a token / window slot --, the 4 consecutive rows 16 t + 4g + r of every 16-row tile t -- channels).  fp32: each tile
+// is a 16-byte vector as it is.  bf16: two tiles t, t + 1 are packed to 2 x 2 dwords and one pair is exchanged between lanes g and
+// g ^ 1 (v_permlane16_swap), after which an even g holds channels 16 t + 4g .. + 7 and an odd g channels 16 (t + 1) + 4 (g - 1) .. + 7.
+// ---------------------------------------------------------------------------
+typedef unsigned int esvit_u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned esvit_pack2_bf16(float a, float b) {
+    typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
+    const bf16x2_ v = {(bf16)a, (bf16)b};
+    return __builtin_bit_cast(unsigned, v);
+}
+__device__ __forceinline__ esvit_u32x4 esvit_pack_tile_pair_bf16(const f32x4& t0, const f32x4& t1) {
+    unsigned x0 = esvit_pack2_bf16(t0[0], t0[1]), x1 = esvit_pack2_bf16(t0[2], t0[3]);
+    unsigned y0 = esvit_pack2_bf16(t1[0], t1[1]), y1 = esvit_pack2_bf16(t1[2], t1[3]);
+    const esvit_u32x2 a = __builtin_amdgcn_permlane16_swap(x0, y0, false, false), b = __builtin_amdgcn_permlane16_swap(x1, y1, false, false);
+    return esvit_u32x4{a[0], b[0], a[1], b[1]};
+}
+// first channel (relative to tile t) of the 8 consecutive channels a lane holds after esvit_pack_tile_pair_bf16
+__device__ __forceinline__ int esvit_tile_pair_ch0(int g) { return 16 * (g & 1) + 4 * (g & ~1); }
+
+// ---------------------------------------------------------------------------
+// butterfly steps across the four 16-lane rows of a wave on the VALU
+// ---------------------------------------------------------------------------
+// v_permlane16_swap / v_permlane32_swap exchange the odd 16- / 32-lane rows of their first operand with the even rows of their
+// second: fed the same value twice, the two results are v[l] and v[l ^ 16] (v[l ^ 32]) in some order on every lane -- a butterfly
+// step on the VALU (__shfl_xor goes through the LDS crossbar).  Operands and results pass through empty asm statements: hipcc 7.2
+// folds `bitcast<float>(r[1])` of the swap's result pair to `bitcast<float>(r[0])` (tools/probe/permlane_swap_fold.hip: k7 emits
+// `v_add_f32 v1, v1, v1`); integer uses of the pair (esvit_pack_tile_pair_bf16, fused16.h: row_swap) are not affected.
+__device__ __forceinline__ void swap16(float v, float& x, float& y) {
+    unsigned a = __builtin_bit_cast(unsigned, v), b = a;
+    asm volatile("" : "+v"(b));
+    const esvit_u32x2 r = __builtin_amdgcn_permlane16_swap(a, b, false, false);
+    unsigned r0 = r[0], r1 = r[1];
+    asm volatile("" : "+v"(r0), "+v"(r1));
+    x = __builtin_bit_cast(float, r0);
+    y = __builtin_bit_cast(float, r1);
+}
+__device__ __forceinline__ void swap32(float v, float& x, float& y) {
+    unsigned a = __builtin_bit_cast(unsigned, v), b = a;
+    asm volatile("" : "+v"(b));
+    const esvit_u32x2 r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+    unsigned r0 = r[0], r1 = r[1];
+    asm volatile("" : "+v"(r0), "+v"(r1));
+    x = __builtin_bit_cast(float, r0);
+    y = __builtin_bit_cast(float, r1);
+}
+__device__ __forceinline__ float xor16_sum(float v) {
+    float x, y;
+    swap16(v, x, y);
+    return x + y;
+}
+__device__ __forceinline__ float xor32_sum(float v) {
+    float x, y;
+    swap32(v, x, y);
+    return x + y;
+}
+__device__ __forceinline__ float xor16_max(float v) {
+    float x, y;
+    swap16(v, x, y);
+    return fmaxf(x, y);
+}
+__device__ __forceinline__ float xor32_max(float v) {
+    float x, y;
+    swap32(v, x, y);
+    return fmaxf(x, y);
+}
+
+// ---------------------------------------------------------------------------
 // wave / block reductions (wave = 64 lanes)
 // ---------------------------------------------------------------------------
 // The dispatcher places workgroup b on XCD b % 8 (eight XCDs, one L2 each).  Bijective renumbering that gives every XCD a

@@ -214,9 +214,6 @@ __global__ __launch_bounds__(128, (HDIM == 32 ? 3 : 2)) void attn_fwd4_kernel(co
         const int mytok = cur.mytok, myreg = cur.myreg;
         const long tok_base = cur.tok_base;
         const long unit_wh = (long)cur.bw * nH + h;
-        int stok[NS];
-#pragma unroll
-        for (int i = 0; i < NS; ++i) stok[i] = __shfl(mytok, srow0 + SSTEP * i, 64);
         __syncthreads();  // images complete
         issue_rows(it + 1, tok1, reg1, nxt);
         load_map(it + 2, tok2, reg2);
@@ -258,8 +255,7 @@ __global__ __launch_bounds__(128, (HDIM == 32 ? 3 : 2)) void attn_fwd4_kernel(co
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) m = fmaxf(m, p[i][jl][r]);
-                m = fmaxf(m, __shfl_xor(m, 16, 64));
-                m = fmaxf(m, __shfl_xor(m, 32, 64));
+                m = xor32_max(xor16_max(m));  // (VALU butterflies: common.h)
                 float sum = 0.f;
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
@@ -269,8 +265,7 @@ __global__ __launch_bounds__(128, (HDIM == 32 ? 3 : 2)) void attn_fwd4_kernel(co
                         p[i][jl][r] = e;
                         sum += e;
                     }
-                sum += __shfl_xor(sum, 16, 64);
-                sum += __shfl_xor(sum, 32, 64);
+                sum = xor32_sum(xor16_sum(sum));
                 const float inv = 1.f / sum;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) p[i][jl] *= inv;
@@ -291,6 +286,9 @@ __global__ __launch_bounds__(128, (HDIM == 32 ? 3 : 2)) void attn_fwd4_kernel(co
         }
         // P V straight from the score accumulators: lane (c, g) holds, for query c, keys 16i + 4g + r, i.e. for a 32-key chunk
         // the keys {32ks + 4g + e, 32ks + 16 + 4g + e}; V's fragment is read with the same key permutation.
+        // The product is formed TRANSPOSED (the two MFMA operands exchanged: their fragment layouts are symmetric): O^T [d][query],
+        // lane (c, g) = head channels 16 dt + 4g + r of query 16 il + c -- a row piece that leaves as a 16-byte vector without the
+        // LDS transpose (2-byte scattered writes) the [query][d] orientation needed.
         f32x4 o[2][DT];
 #pragma unroll
         for (int il = 0; il < 2; ++il)
@@ -305,25 +303,24 @@ __global__ __launch_bounds__(128, (HDIM == 32 ? 3 : 2)) void attn_fwd4_kernel(co
             for (int il = 0; il < 2; ++il) {
                 const Frag<T> pf = frag_p_regs64<T>(p[2 * ks][il], p[2 * ks + 1][il]);
 #pragma unroll
-                for (int dt = 0; dt < DT; ++dt) mma(pf, vf[dt], o[il][dt]);
+                for (int dt = 0; dt < DT; ++dt) mma(vf[dt], pf, o[il][dt]);
             }
         }
-        T* Og = Qs + 32 * w * LDQ;  // [32][LDQ]: this wave's own query rows (only it read them, and they are in registers now)
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int il = 0; il < 2; ++il)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int dt = 0; dt < DT; ++dt) Og[(16 * il + 4 * g + r) * LDQ + 16 * dt + c] = from_f32<T>(o[il][dt][r]);
-        __builtin_amdgcn_wave_barrier();
         const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(out + tok_base * (long)C, 0, (int)(L * (long)C * ES), 0x00020000);
 #pragma unroll
-        for (int i = 0; i < NS; ++i) {
-            const int tl = lane / VPR + SSTEP * i;
-            const Vec16<T> x = ld16<T>(Og + tl * LDQ + dv * VEC);
-            const int vo = (active && stok[i] >= 0) ? stok[i] * C * ES + dv * 16 : OOB;
-            buffer_store_b128(x.v, ro, vo, h * HDIM * ES);  // (common.h: no SGPR offset on 16-byte stores)
+        for (int il = 0; il < 2; ++il) {
+            const int tok = __shfl(mytok, 32 * w + 16 * il + c, 64);
+            const bool ok = active && tok >= 0;
+            if constexpr (sizeof(T) == 2) {
+#pragma unroll
+                for (int dt = 0; dt < DT; dt += 2) {
+                    const esvit_u32x4 x = esvit_pack_tile_pair_bf16(o[il][dt], o[il][dt + 1]);
+                    buffer_store_b128(x, ro, ok ? tok * C * ES + (16 * dt + esvit_tile_pair_ch0(g)) * ES : OOB, h * HDIM * ES);
+                }
+            } else {
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) buffer_store_b128(o[il][dt], ro, ok ? tok * C * ES + (16 * dt + 4 * g) * ES : OOB, h * HDIM * ES);
+            }
         }
         cur = nxt;
         tok1 = tok2;
@@ -402,9 +399,9 @@ __global__ __launch_bounds__(128, (HDIM == 32 ? 2 : 1)) void attn_bwd3_kernel(co
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int jl = 0; jl < 2; ++jl) db[i][jl] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float padk[VEC], padv[VEC];
+    float padk[4 * DT], padv[4 * DT];  // pad-slot rows of dK / dV summed: head channels 16 dt + 4g + r of this lane's slots
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) padk[e] = padv[e] = 0.f;
+    for (int e = 0; e < 4 * DT; ++e) padk[e] = padv[e] = 0.f;
 
     const int iters = (Bw + parts - 1) / parts;
     auto win_of = [&](int it, bool& act) -> int {
@@ -477,9 +474,9 @@ __global__ __launch_bounds__(128, (HDIM == 32 ? 2 : 1)) void attn_bwd3_kernel(co
         const int mytok = cur.mytok, myreg = cur.myreg;
         const bool active = cur.active;
         const long tok_base = cur.tok_base;
-        int stok[NS];  // token rows of the slots this lane stores
+        int stok[2];  // token rows of the two slots (32w + 16 il + c) whose result rows this lane stores
 #pragma unroll
-        for (int i = 0; i < NS; ++i) stok[i] = __shfl(mytok, srow0 + SSTEP * i, 64);
+        for (int il = 0; il < 2; ++il) stok[il] = __shfl(mytok, 32 * w + 16 * il + c, 64);
         __syncthreads();  // images complete
         issue_rows(it + 1, tok1, reg1, nxt);
         load_map(it + 2, tok2, reg2);
@@ -522,8 +519,7 @@ __global__ __launch_bounds__(128, (HDIM == 32 ? 2 : 1)) void attn_bwd3_kernel(co
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) m = fmaxf(m, p[i][jl][r]);
-                m = fmaxf(m, __shfl_xor(m, 16, 64));
-                m = fmaxf(m, __shfl_xor(m, 32, 64));
+                m = xor32_max(xor16_max(m));  // (VALU butterflies: common.h)
                 float s = 0.f;
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
@@ -533,8 +529,7 @@ __global__ __launch_bounds__(128, (HDIM == 32 ? 2 : 1)) void attn_bwd3_kernel(co
                         p[i][jl][r] = e;
                         s += e;
                     }
-                s += __shfl_xor(s, 16, 64);
-                s += __shfl_xor(s, 32, 64);
+                s = xor32_sum(xor16_sum(s));
                 const float inv = 1.f / s;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -545,27 +540,40 @@ __global__ __launch_bounds__(128, (HDIM == 32 ? 2 : 1)) void attn_bwd3_kernel(co
         }
         __syncthreads();  // P complete (both waves' query tiles)
 
-        // 32 result rows (slots 32w .. 32w+31) x HDIM: LDS transpose, 16-byte row stores, pad-slot rows into `padacc`
+        // 32 result rows (slots 32w .. 32w+31) x HDIM from TRANSPOSED accumulators (acc[il][dt][r] = result[d = 16 dt + 4g + r][slot
+        // 32w + 16 il + c]: the producing MFMAs take their operands exchanged): 16-byte row pieces straight from the registers --
+        // no LDS transpose.  Pad-slot rows (dropped by the out-of-range offset) are summed into `padacc` [4 DT] (the values as stored)
         auto emit = [&](const f32x4 (&acc)[2][DT], float mul, int col0, float* padacc) {
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int il = 0; il < 2; ++il)
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-#pragma unroll
-                    for (int dt = 0; dt < DT; ++dt) Sg[(16 * il + 4 * g + r) * LDQ + 16 * dt + c] = from_f32<T>(acc[il][dt][r] * mul);
-            __builtin_amdgcn_wave_barrier();
             const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(dqkv + tok_base * 3L * C, 0, (int)(L * 3L * C * ES), 0x00020000);
 #pragma unroll
-            for (int i = 0; i < NS; ++i) {
-                const int tl = lane / VPR + SSTEP * i;  // row inside the wave's 32-row tile
-                const int t = 32 * w + tl;
-                const Vec16<T> x = ld16<T>(Sg + tl * LDQ + dv * VEC);
-                const int vo = (active && stok[i] >= 0) ? stok[i] * 3 * C * ES + dv * 16 : OOB;
-                buffer_store_b128(x.v, rd, vo, (col0 + h * HDIM) * ES);
-                if (padacc && active && t < N && stok[i] < 0) {
+            for (int il = 0; il < 2; ++il) {
+                const int t = 32 * w + 16 * il + c;
+                const int tok = stok[il];
+                const bool ok = active && tok >= 0;
+                f32x4 v[DT];
 #pragma unroll
-                    for (int e = 0; e < VEC; ++e) padacc[e] += x.get(e);
+                for (int dt = 0; dt < DT; ++dt) {
+                    v[dt] = acc[il][dt] * mul;
+                    if constexpr (sizeof(T) == 2) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[dt][r] = (float)(bf16)v[dt][r];
+                    }
+                }
+                if constexpr (sizeof(T) == 2) {
+#pragma unroll
+                    for (int dt = 0; dt < DT; dt += 2) {
+                        const esvit_u32x4 x = esvit_pack_tile_pair_bf16(v[dt], v[dt + 1]);
+                        buffer_store_b128(x, rd, ok ? tok * 3 * C * ES + (16 * dt + esvit_tile_pair_ch0(g)) * ES : OOB, (col0 + h * HDIM) * ES);
+                    }
+                } else {
+#pragma unroll
+                    for (int dt = 0; dt < DT; ++dt) buffer_store_b128(v[dt], rd, ok ? tok * 3 * C * ES + (16 * dt + 4 * g) * ES : OOB, (col0 + h * HDIM) * ES);
+                }
+                if (padacc && active && t < N && tok < 0) {
+#pragma unroll
+                    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) padacc[4 * dt + r] += v[dt][r];
                 }
             }
         };
@@ -586,7 +594,7 @@ __global__ __launch_bounds__(128, (HDIM == 32 ? 2 : 1)) void attn_bwd3_kernel(co
                 for (int il = 0; il < 2; ++il) {
                     const Frag<T> a = frag_ks<T, USE_TR>(Ps, LDP, 16 * (2 * w + il), 32 * ks, c, g);
 #pragma unroll
-                    for (int dt = 0; dt < DT; ++dt) mma(a, bo[dt], acc[il][dt]);
+                    for (int dt = 0; dt < DT; ++dt) mma(bo[dt], a, acc[il][dt]);  // (transposed: emit)
                 }
             }
             emit(acc, 1.f, 2 * C, padv);
@@ -616,8 +624,7 @@ __global__ __launch_bounds__(128, (HDIM == 32 ? 2 : 1)) void attn_bwd3_kernel(co
 #pragma unroll
                     for (int r = 0; r < 4; ++r) d += pj[i][r] * dpj[i][r];
                 }
-                d += __shfl_xor(d, 16, 64);
-                d += __shfl_xor(d, 32, 64);
+                d = xor32_sum(xor16_sum(d));
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const f32x4 ds = pj[i] * (dpj[i] - d);
@@ -652,8 +659,8 @@ __global__ __launch_bounds__(128, (HDIM == 32 ? 2 : 1)) void attn_bwd3_kernel(co
                     const Frag<T> at = frag_ks<T, USE_TR>(Ps, LDP, 16 * (2 * w + il), 32 * ks, c, g);
 #pragma unroll
                     for (int dt = 0; dt < DT; ++dt) {
-                        mma(a, kb[dt], aq[il][dt]);
-                        mma(at, qb[dt], ak[il][dt]);
+                        mma(kb[dt], a, aq[il][dt]);  // (transposed: emit)
+                        mma(qb[dt], at, ak[il][dt]);
                     }
                 }
             }
@@ -672,23 +679,22 @@ __global__ __launch_bounds__(128, (HDIM == 32 ? 2 : 1)) void attn_bwd3_kernel(co
 #pragma unroll
             for (int jl = 0; jl < 2; ++jl) *reinterpret_cast<f32x4*>(ws + ((i * 4 + 2 * w + jl) * 64 + lane) * 4) = db[i][jl];
     }
-    // pad-row sums: reduce over the row bits inside the wave, then over the two waves through LDS
+    // pad-row sums: over the 16 slots of a lane group (DPP row reduction), then over the two waves through LDS
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) {
-#pragma unroll
-        for (int o = VPR; o < 64; o <<= 1) {
-            padk[e] += __shfl_xor(padk[e], o, 64);
-            padv[e] += __shfl_xor(padv[e], o, 64);
-        }
+    for (int e = 0; e < 4 * DT; ++e) {
+        padk[e] = row16_sum(padk[e]);
+        padv[e] = row16_sum(padv[e]);
     }
     __syncthreads();
     float* red = reinterpret_cast<float*>(smem_raw);  // [2 waves][k|v][HDIM]
-    if (lane < VPR) {
+    if (c == 0) {
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) {
-            red[(w * 2 + 0) * HDIM + dv * VEC + e] = padk[e];
-            red[(w * 2 + 1) * HDIM + dv * VEC + e] = padv[e];
-        }
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                red[(w * 2 + 0) * HDIM + 16 * dt + 4 * g + r] = padk[4 * dt + r];
+                red[(w * 2 + 1) * HDIM + 16 * dt + 4 * g + r] = padv[4 * dt + r];
+            }
     }
     __syncthreads();
     if (unit_ok && tid < 2 * HDIM) {

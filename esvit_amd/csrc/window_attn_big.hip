@@ -304,8 +304,7 @@ __global__ __launch_bounds__(FWD3_WAVES * 64, sizeof(T) == 2 ? (HD == 32 ? 4 : 2
         for (int i = 0; i < NT; ++i)
 #pragma unroll
             for (int r = 0; r < 4; ++r) m = fmaxf(m, p[i][r]);
-        m = fmaxf(m, __shfl_xor(m, 16, 64));
-        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        m = xor32_max(xor16_max(m));  // (VALU butterflies: common.h)
         float sum = 0.f;
 #pragma unroll
         for (int i = 0; i < NT; ++i)
@@ -315,8 +314,7 @@ __global__ __launch_bounds__(FWD3_WAVES * 64, sizeof(T) == 2 ? (HD == 32 ? 4 : 2
                 p[i][r] = e;
                 sum += e;
             }
-        sum += __shfl_xor(sum, 16, 64);
-        sum += __shfl_xor(sum, 32, 64);
+        sum = xor32_sum(xor16_sum(sum));
         const float inv = 1.f / sum;
 #pragma unroll
         for (int i = 0; i < NT; ++i) p[i] *= inv;
@@ -459,8 +457,7 @@ __global__ __launch_bounds__(DQ4_WAVES * 64) void attn_big_bwd_dq4_kernel(
 #pragma unroll
             for (int e = 0; e < 8; ++e) d += (float)of[ks].v[e] * (float)ff.v[e];
         }
-        d += __shfl_xor(d, 16, 64);
-        d += __shfl_xor(d, 32, 64);
+        d = xor32_sum(xor16_sum(d));
         // P^T tiles of this query tile (rows = keys) from the saved log-sum-exp
         f32x4 pj[NT];
 #pragma unroll
