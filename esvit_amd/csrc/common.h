@@ -147,26 +147,24 @@ __device__ __forceinline__ int esvit_tile_pair_ch0(int g) { return 16 * (g & 1) 
 // ---------------------------------------------------------------------------
 // v_permlane16_swap / v_permlane32_swap exchange the odd 16- / 32-lane rows of their first operand with the even rows of their
 // second: fed the same value twice, the two results are v[l] and v[l ^ 16] (v[l ^ 32]) in some order on every lane -- a butterfly
-// step on the VALU (__shfl_xor goes through the LDS crossbar).  Operands and results pass through empty asm statements: hipcc 7.2
-// folds `bitcast<float>(r[1])` of the swap's result pair to `bitcast<float>(r[0])` (tools/probe/permlane_swap_fold.hip: k7 emits
-// `v_add_f32 v1, v1, v1`); integer uses of the pair (esvit_pack_tile_pair_bf16, fused16.h: row_swap) are not affected.
+// step on the VALU (__shfl_xor goes through the LDS crossbar).  The instruction is written in inline asm WITH ITS OWN WAIT STATES:
+//  * through the builtin, hipcc 7.2 folds `bitcast<float>(r[1])` of the result pair to `bitcast<float>(r[0])`
+//    (tools/probe/permlane_swap_fold.hip: `v_add_f32 v1, v1, v1` after the swap; the integer uses -- esvit_pack_tile_pair_bf16,
+//    fused16.h: row_swap -- are right);
+//  * with the builtin and empty asm statements around it as a workaround, the compiler put ONE wait state between the swap and
+//    the VALU instruction that reads its results; in attn_bwd3's reductions that made the step's gradients differ between
+//    identical runs on some boxes (tests/test_dist_gpu.py, round 5: 0 / 10 failures with ds_bpermute reductions, 12 / 14 with
+//    these) -- a read-after-swap hazard the hazard recogniser does not cover.  Four wait states on either side here.
+// Used by the fused attention branch only; the older attention kernels keep their ds_bpermute reductions.
 __device__ __forceinline__ void swap16(float v, float& x, float& y) {
-    unsigned a = __builtin_bit_cast(unsigned, v), b = a;
-    asm volatile("" : "+v"(b));
-    const esvit_u32x2 r = __builtin_amdgcn_permlane16_swap(a, b, false, false);
-    unsigned r0 = r[0], r1 = r[1];
-    asm volatile("" : "+v"(r0), "+v"(r1));
-    x = __builtin_bit_cast(float, r0);
-    y = __builtin_bit_cast(float, r1);
+    x = v;
+    y = v;
+    asm volatile("s_nop 3\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 3" : "+v"(x), "+v"(y));
 }
 __device__ __forceinline__ void swap32(float v, float& x, float& y) {
-    unsigned a = __builtin_bit_cast(unsigned, v), b = a;
-    asm volatile("" : "+v"(b));
-    const esvit_u32x2 r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
-    unsigned r0 = r[0], r1 = r[1];
-    asm volatile("" : "+v"(r0), "+v"(r1));
-    x = __builtin_bit_cast(float, r0);
-    y = __builtin_bit_cast(float, r1);
+    x = v;
+    y = v;
+    asm volatile("s_nop 3\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 3" : "+v"(x), "+v"(y));
 }
 __device__ __forceinline__ float xor16_sum(float v) {
     float x, y;

@@ -255,7 +255,8 @@ __global__ __launch_bounds__(128, (HDIM == 32 ? 3 : 2)) void attn_fwd4_kernel(co
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) m = fmaxf(m, p[i][jl][r]);
-                m = xor32_max(xor16_max(m));  // (VALU butterflies: common.h)
+                m = fmaxf(m, __shfl_xor(m, 16, 64));
+                m = fmaxf(m, __shfl_xor(m, 32, 64));
                 float sum = 0.f;
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
@@ -265,7 +266,8 @@ __global__ __launch_bounds__(128, (HDIM == 32 ? 3 : 2)) void attn_fwd4_kernel(co
                         p[i][jl][r] = e;
                         sum += e;
                     }
-                sum = xor32_sum(xor16_sum(sum));
+                sum += __shfl_xor(sum, 16, 64);
+                sum += __shfl_xor(sum, 32, 64);
                 const float inv = 1.f / sum;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) p[i][jl] *= inv;
@@ -519,7 +521,8 @@ __global__ __launch_bounds__(128, (HDIM == 32 ? 2 : 1)) void attn_bwd3_kernel(co
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) m = fmaxf(m, p[i][jl][r]);
-                m = xor32_max(xor16_max(m));  // (VALU butterflies: common.h)
+                m = fmaxf(m, __shfl_xor(m, 16, 64));
+                m = fmaxf(m, __shfl_xor(m, 32, 64));
                 float s = 0.f;
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
@@ -529,7 +532,8 @@ __global__ __launch_bounds__(128, (HDIM == 32 ? 2 : 1)) void attn_bwd3_kernel(co
                         p[i][jl][r] = e;
                         s += e;
                     }
-                s = xor32_sum(xor16_sum(s));
+                s += __shfl_xor(s, 16, 64);
+                s += __shfl_xor(s, 32, 64);
                 const float inv = 1.f / s;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -624,7 +628,8 @@ __global__ __launch_bounds__(128, (HDIM == 32 ? 2 : 1)) void attn_bwd3_kernel(co
 #pragma unroll
                     for (int r = 0; r < 4; ++r) d += pj[i][r] * dpj[i][r];
                 }
-                d = xor32_sum(xor16_sum(d));
+                d += __shfl_xor(d, 16, 64);
+                d += __shfl_xor(d, 32, 64);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const f32x4 ds = pj[i] * (dpj[i] - d);

@@ -304,7 +304,8 @@ __global__ __launch_bounds__(FWD3_WAVES * 64, sizeof(T) == 2 ? (HD == 32 ? 4 : 2
         for (int i = 0; i < NT; ++i)
 #pragma unroll
             for (int r = 0; r < 4; ++r) m = fmaxf(m, p[i][r]);
-        m = xor32_max(xor16_max(m));  // (VALU butterflies: common.h)
+        m = fmaxf(m, __shfl_xor(m, 16, 64));
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
         float sum = 0.f;
 #pragma unroll
         for (int i = 0; i < NT; ++i)
@@ -314,7 +315,8 @@ __global__ __launch_bounds__(FWD3_WAVES * 64, sizeof(T) == 2 ? (HD == 32 ? 4 : 2
                 p[i][r] = e;
                 sum += e;
             }
-        sum = xor32_sum(xor16_sum(sum));
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
         const float inv = 1.f / sum;
 #pragma unroll
         for (int i = 0; i < NT; ++i) p[i] *= inv;
@@ -457,7 +459,8 @@ __global__ __launch_bounds__(DQ4_WAVES * 64) void attn_big_bwd_dq4_kernel(
 #pragma unroll
             for (int e = 0; e < 8; ++e) d += (float)of[ks].v[e] * (float)ff.v[e];
         }
-        d = xor32_sum(xor16_sum(d));
+        d += __shfl_xor(d, 16, 64);
+        d += __shfl_xor(d, 32, 64);
         // P^T tiles of this query tile (rows = keys) from the saved log-sum-exp
         f32x4 pj[NT];
 #pragma unroll

@@ -72,7 +72,9 @@ def one_rank(dev):
         same = all(torch.equal(s0[k], s1[k]) for k in s0) and all(torch.equal(t0[k], t1[k]) for k in t0)
         rel = max(((a[k].float() - b[k].float()).abs().max() / (a[k].float().abs().max() + 1e-12)).item()
                   for a, b in ((s0, s1), (t0, t1)) for k in a if a[k].numel())
-        res[kind] = dict(bit_identical=bool(same), max_rel=rel, losses_equal=l0 == l1, reducer_off=not en0, reducer_on=bool(en1), buckets=nb)
+        worst = max((((s0[k].float() - s1[k].float()).abs().max() / (s0[k].float().abs().max() + 1e-12)).item(), k) for k in s0 if s0[k].numel())
+        res[kind] = dict(bit_identical=bool(same), max_rel=rel, losses_equal=l0 == l1, reducer_off=not en0, reducer_on=bool(en1), buckets=nb,
+                         losses=[l0, l1], worst_param=worst[1])
     # bf16 gradient payload: the same three steps with the buckets rounded to bf16 on the wire -- parameters within bf16 rounding of
     # the gradients' effect (AdamW's normalised step is bounded by lr per element: compare against lr)
     s0, t0, l0, _, _ = _steps("ragged", dev, force=False)
