@@ -146,37 +146,67 @@ __global__ void relpos_bias_frag_big_kernel(const float* __restrict__ table, int
 }
 
 
-// same result, but through an LDS transpose ([32][LDQ] image private to the wave): every lane stores 16-byte row vectors
-// (2 per lane) instead of 16 two-byte scatters.  pad-slot rows are summed into padacc[VEC] (columns dv*VEC.., dv = lane % VPR).
+// 32 result rows (window slots s0 .. s0 + 31) x HD from TRANSPOSED accumulators (acc[ti][j][r] = result[d = 16 j + 4g + r][slot s0 +
+// 16 ti + c]: the producing MFMAs take their two operands exchanged, whose fragments have the same register layout): 16-byte row pieces
+// straight from the registers (common.h: esvit_pack_tile_pair_bf16) instead of an LDS transpose with 2-byte scattered writes.  Pad-slot
+// rows are summed (as stored) into padacc[4 HD / 16]: head channels 16 j + 4g + r of this lane's slots.
 template <typename T, int HD>
-__device__ __forceinline__ void store_block_rows_vec(const f32x4 (&acc)[2][HD / 16], float mul, T* stg, T* __restrict__ dst, long row_stride,
-                                                     const int* tok_lds, long tok_base, int s0, int N, bool active, float* padacc, int lane,
-                                                     int c, int g) {
-    constexpr int VEC = BigCfg<T, HD>::VEC, LDQ = BigCfg<T, HD>::LDQ, VPR = HD / VEC;
-    __builtin_amdgcn_wave_barrier();
+__device__ __forceinline__ void store_block_rows_t(const f32x4 (&acc)[2][HD / 16], float mul, T* __restrict__ dst, long row_stride, const int* tok_lds,
+                                                   long tok_base, int s0, int N, bool active, float* padacc, int c, int g) {
+    constexpr int DT = HD / 16;
 #pragma unroll
-    for (int ti = 0; ti < 2; ++ti)
+    for (int ti = 0; ti < 2; ++ti) {
+        const int t = s0 + 16 * ti + c;
+        const bool live = active && t < N;  // (no branch around the lane exchange below)
+        const int tok = live ? tok_lds[t] : -1;
+        f32x4 v[DT];
 #pragma unroll
-        for (int j = 0; j < HD / 16; ++j)
+        for (int j = 0; j < DT; ++j) {
+            v[j] = acc[ti][j] * mul;
+            if constexpr (sizeof(T) == 2) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) stg[(16 * ti + 4 * g + r) * LDQ + 16 * j + c] = from_f32<T>(acc[ti][j][r] * mul);
-    __builtin_amdgcn_wave_barrier();
+                for (int r = 0; r < 4; ++r) v[j][r] = (float)(bf16)v[j][r];
+            }
+        }
+        if constexpr (sizeof(T) == 2) {
 #pragma unroll
-    for (int i = 0; i < 32 * VPR / 64; ++i) {
-        const int v = lane + 64 * i;
-        const int rl = v / VPR, dv = v % VPR;
-        const int t = s0 + rl;
-        if (!active || t >= N) continue;
-        const int tok = tok_lds[t];
-        const Vec16<T> x = ld16<T>(stg + rl * LDQ + dv * VEC);
-        if (tok >= 0) {
-            st16<T>(dst + (tok_base + tok) * row_stride + dv * VEC, x);
-        } else if (padacc) {
+            for (int j = 0; j < DT; j += 2) {
+                const esvit_u32x4 x = esvit_pack_tile_pair_bf16(v[j], v[j + 1]);  // (every lane takes part in the exchange)
+                if (tok >= 0) *reinterpret_cast<esvit_u32x4*>(dst + (tok_base + tok) * row_stride + 16 * j + esvit_tile_pair_ch0(g)) = x;
+            }
+        } else {
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) padacc[e] += x.get(e);
+            for (int j = 0; j < DT; ++j)
+                if (tok >= 0) *reinterpret_cast<f32x4*>(dst + (tok_base + tok) * row_stride + 16 * j + 4 * g) = v[j];
+        }
+        if (live && tok < 0 && padacc) {
+#pragma unroll
+            for (int j = 0; j < DT; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) padacc[4 * j + r] += v[j][r];
         }
     }
-    __builtin_amdgcn_wave_barrier();
+}
+
+// one 16-slot tile (slots s0 .. s0 + 15) of result rows from transposed accumulators acc[j][r] = result[d = 16 j + 4g + r][slot s0 + c]
+template <typename T, int HD>
+__device__ __forceinline__ void store_tile_rows_t(const f32x4 (&acc)[HD / 16], float mul, T* __restrict__ dst, long row_stride, const int* tok_lds,
+                                                  long tok_base, int s0, int N, bool active, int c, int g) {
+    constexpr int DT = HD / 16;
+    const int t = s0 + c;
+    const bool live = active && t < N;
+    const int tok = live ? tok_lds[t] : -1;
+    if constexpr (sizeof(T) == 2) {
+#pragma unroll
+        for (int j = 0; j < DT; j += 2) {
+            const esvit_u32x4 x = esvit_pack_tile_pair_bf16(acc[j] * mul, acc[j + 1] * mul);
+            if (tok >= 0) *reinterpret_cast<esvit_u32x4*>(dst + (tok_base + tok) * row_stride + 16 * j + esvit_tile_pair_ch0(g)) = x;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < DT; ++j)
+            if (tok >= 0) *reinterpret_cast<f32x4*>(dst + (tok_base + tok) * row_stride + 16 * j + 4 * g) = acc[j] * mul;
+    }
 }
 
 // -------------------------------------------------------------------------------------------------------------
@@ -337,25 +367,9 @@ __global__ __launch_bounds__(FWD3_WAVES * 64, sizeof(T) == 2 ? (HD == 32 ? 4 : 2
         for (int ks = 0; ks < NPB / 32; ++ks) {
             const Frag<T> pf = frag_p_regs<T>(p[2 * ks], p[2 * ks + 1]);
 #pragma unroll
-            for (int j = 0; j < DT; ++j) mma(pf, frag_v_perm<T>(Vs, LDQ, 16 * j, ks, c, g), o[j]);
+            for (int j = 0; j < DT; ++j) mma(frag_v_perm<T>(Vs, LDQ, 16 * j, ks, c, g), pf, o[j]);  // O^T [d][query]: operands exchanged
         }
-        // output rows: transpose through the wave's Q image, one 16-byte row piece per lane
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int j = 0; j < DT; ++j) Qs[(4 * g + r) * LDQ + 16 * j + c] = from_f32<T>(o[j][r]);
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int i = 0; i < (16 * VPR + 63) / 64; ++i) {
-            const int v = lane + 64 * i;
-            const int rl = v / VPR, dv = v % VPR;
-            const int t = q0 + rl;
-            if (v < 16 * VPR && t < N) {
-                const int tok = tb.tok[t];
-                if (tok >= 0) st16<T>(out + h * HD + (tok_base + tok) * (long)C + dv * VEC, ld16<T>(Qs + rl * LDQ + dv * VEC));
-            }
-        }
+        store_tile_rows_t<T, HD>(o, 1.f, out + h * HD, (long)C, tb.tok, tok_base, q0, N, true, c, g);
     }
 }
 
@@ -501,24 +515,8 @@ __global__ __launch_bounds__(DQ4_WAVES * 64) void attn_big_bwd_dq4_kernel(
 #pragma unroll
         for (int ks = 0; ks < NPB / 32; ++ks)
 #pragma unroll
-            for (int j = 0; j < DT; ++j) mma(sfr[ks], frag_v_perm<T>(Ks, LDQ, 16 * j, ks, c, g), acc[j]);
-        // dQ rows: transpose through the wave's Q image, one 16-byte row piece per lane
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int j = 0; j < DT; ++j) Qs[(4 * g + r) * LDQ + 16 * j + c] = from_f32<T>(acc[j][r] * scale);
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int i = 0; i < (16 * VPR + 63) / 64; ++i) {
-            const int v = lane + 64 * i;
-            const int rl = v / VPR, dv = v % VPR;
-            const int t = q0 + rl;
-            if (v < 16 * VPR && active && t < N) {
-                const int tok = tb.tok[t];
-                if (tok >= 0) st16<T>(dqkv + h * HD + (tok_base + tok) * 3L * C + dv * VEC, ld16<T>(Qs + rl * LDQ + dv * VEC));
-            }
-        }
+            for (int j = 0; j < DT; ++j) mma(frag_v_perm<T>(Ks, LDQ, 16 * j, ks, c, g), sfr[ks], acc[j]);  // dQ^T [d][query]: operands exchanged
+        store_tile_rows_t<T, HD>(acc, scale, dqkv + h * HD, 3L * C, tb.tok, tok_base, q0, N, active, c, g);
     }
     if (WANT_DB && wave_ok) {
         // frag layout of the NPB x NPB bias gradient: ((ki*NT + qj)*64 + lane)*4 + r
@@ -588,9 +586,9 @@ __global__ __launch_bounds__((BigCfg<T, HD>::WAVES * 64), ((sizeof(T) == 2 && HD
         sk.store(Kb, 1.f, lane);
         sv.store(Vb, 1.f, lane);
     }
-    float padk[Cfg::VEC], padv[Cfg::VEC];
+    float padk[4 * (HD / 16)], padv[4 * (HD / 16)];  // pad-slot rows of dK / dV: head channels 16 j + 4g + r of this lane's slots
 #pragma unroll
-    for (int e = 0; e < Cfg::VEC; ++e) padk[e] = padv[e] = 0.f;
+    for (int e = 0; e < 4 * (HD / 16); ++e) padk[e] = padv[e] = 0.f;
     __syncthreads();  // Q, dO, lse, delta staged by the whole workgroup; Kb / Vb are private to the wave
 
 #pragma unroll
@@ -662,10 +660,10 @@ __global__ __launch_bounds__((BigCfg<T, HD>::WAVES * 64), ((sizeof(T) == 2 && HD
                 for (int j = 0; j < DT; ++j) {
                     const Frag<T> oj = frag_v_perm<T>(Os, LDQ, 16 * j, ks, c, g);
 #pragma unroll
-                    for (int a = 0; a < 2; ++a) mma(pf[a], oj, av[a][j]);
+                    for (int a = 0; a < 2; ++a) mma(oj, pf[a], av[a][j]);  // dV^T [d][key]: operands exchanged
                 }
             }
-            store_block_rows_vec<T, HD>(av, 1.f, Kb, dqkv + 2 * C + h * HD, 3L * C, tb.tok, tok_base, k0, N, valid, padv, lane, c, g);
+            store_block_rows_t<T, HD>(av, 1.f, dqkv + 2 * C + h * HD, 3L * C, tb.tok, tok_base, k0, N, valid, padv, c, g);
         }
         // dS = P o (dP - delta), dP[q][key] = sum_d dO[q][d] V[key][d]; dS overwrites P
 #pragma unroll
@@ -698,28 +696,27 @@ __global__ __launch_bounds__((BigCfg<T, HD>::WAVES * 64), ((sizeof(T) == 2 && HD
                 for (int j = 0; j < DT; ++j) {
                     const Frag<T> qj = frag_v_perm<T>(Qs, LDQ, 16 * j, ks, c, g);
 #pragma unroll
-                    for (int a = 0; a < 2; ++a) mma(sf[a], qj, ak[a][j]);
+                    for (int a = 0; a < 2; ++a) mma(qj, sf[a], ak[a][j]);  // dK^T [d][key]
                 }
             }
-            store_block_rows_vec<T, HD>(ak, 1.f, Kb, dqkv + C + h * HD, 3L * C, tb.tok, tok_base, k0, N, valid, padk, lane, c, g);
+            store_block_rows_t<T, HD>(ak, 1.f, dqkv + C + h * HD, 3L * C, tb.tok, tok_base, k0, N, valid, padk, c, g);
         }
     }
-    // lanes with equal dv = lane % VPR hold partial sums of the same VEC columns
-    constexpr int VPR = HD / Cfg::VEC;
+    // sum over the 16 slots of a lane group (DPP row adds); lane c == 0 of every group holds channels 16 j + 4g + r
 #pragma unroll
-    for (int e = 0; e < Cfg::VEC; ++e)
+    for (int e = 0; e < 4 * (HD / 16); ++e) {
+        padk[e] = row16_sum(padk[e]);
+        padv[e] = row16_sum(padv[e]);
+    }
+    if (c == 0) {  // one slab row per (unit, wave): [k | v][nH][hd]
+        float* pw = dpad_ws + ((long)unit * WAVES + wave) * 2 * C + h * HD;
 #pragma unroll
-        for (int o = VPR; o < 64; o <<= 1) {
-            padk[e] += __shfl_xor(padk[e], o, 64);
-            padv[e] += __shfl_xor(padv[e], o, 64);
-        }
-    if (lane < VPR) {  // one slab row per (unit, wave): [k | v][nH][hd]
-        float* pw = dpad_ws + ((long)unit * WAVES + wave) * 2 * C + h * HD + lane * Cfg::VEC;
+        for (int j = 0; j < HD / 16; ++j)
 #pragma unroll
-        for (int e = 0; e < Cfg::VEC; ++e) {
-            pw[e] = padk[e];
-            pw[C + e] = padv[e];
-        }
+            for (int r = 0; r < 4; ++r) {
+                pw[16 * j + 4 * g + r] = padk[4 * j + r];
+                pw[C + 16 * j + 4 * g + r] = padv[4 * j + r];
+            }
     }
 }
 
