@@ -195,7 +195,7 @@ def attn_branch_supported(dt, Cc, nH, N):
 
 def cast_weight(w, transpose=False, perm32=False):
     """(the restatement keeps the natural channel order)"""
-    return _r(w.float().t().contiguous() if transpose else w.float(), torch.bfloat16)
+    return _r(w.float().t().contiguous() if transpose else w.float(), torch.bfloat16 if _ACT_DTYPE == torch.bfloat16 else torch.float32)
 
 
 def attn_branch_fwd(x, gamma, beta, eps, Wqkv_p, bqkv, Wproj_p, bproj, win2tok, L, rel_table, ws, region_ids, nW, N, nH, scale, *,

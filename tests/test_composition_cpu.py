@@ -664,6 +664,31 @@ def test_fused_mlp_branch_host_logic_matches_reference_golden(cpu_ops, monkeypat
     assert norm_rel < 2e-3 and worst < 5e-3, (norm_rel, worst_name, worst)
 
 
+def test_fused_attention_branch_host_logic_matches_reference_golden(cpu_ops, monkeypatch):
+    """the fused attention branch (esvit_attn_branch_fwd) through the product's autograd glue -- per-group row slices of the stage's
+    matrices, side outputs for the unfused backward, DropPath row scales, the LayerNorm hand-over it replaces -- with the kernel
+    replaced by its fp32 restatement: Swin-T at full width reproduces the reference's own step.  The teacher takes the kernel in
+    stages 0 and 1 (no side outputs), the student in stage 0 (C = 96) with side outputs"""
+    import esvit_amd.functional as Fn
+    from tests.test_step_gpu import FULL_GOLD, full_case_deltas, run_full_case
+    monkeypatch.setattr(ops_ref, "attn_branch_supported", lambda dt, C, nH, N: C in (96, 192) and C == 32 * nH and N <= 64)
+    calls = {"plain": 0, "save": 0}
+    f0 = ops_ref.attn_branch_fwd
+
+    def counted(*a, **k):
+        calls["save" if k.get("save") else "plain"] += 1
+        return f0(*a, **k)
+    monkeypatch.setattr(ops_ref, "attn_branch_fwd", counted)
+    assert Fn.ATTN_FUSED
+    g = torch.load(FULL_GOLD, map_location="cpu", weights_only=False)["swin_t_k8192_b2"]
+    student, loss_fn, s_out, t_out, loss = run_full_case("swin_t_k8192_b2", torch.device("cpu"))
+    # student: stage 0, two blocks x two resolution groups; teacher: stages 0 and 1, two blocks each, one group
+    assert calls == {"plain": 4, "save": 4}, calls
+    out_rel, norm_rel, worst, worst_name = full_case_deltas(g, student, s_out)
+    assert out_rel < 1e-4 and abs(loss.item() - g["loss"]) < 1e-4, (out_rel, loss.item(), g["loss"])
+    assert norm_rel < 2e-3 and worst < 5e-3, (norm_rel, worst_name, worst)
+
+
 @pytest.mark.parametrize("name", sorted(GU.FULL_VIL_CASES))
 def test_vil_full_width_composition_matches_reference_golden(name, cpu_ops):
     """Vision Longformer (vil_tiny) through the product's host code -- module tree, patch embeddings with resampled position
