@@ -7,26 +7,39 @@
 //
 // Work split.  A workgroup owns NWIN windows at a time, four waves per window; wave (j, w) owns the 16 slots 16w .. 16w+15 of
 // window j (49 tokens in 64 slots) as the MFMA COLUMNS of every product it forms (fragment conventions: mlp_fused16.hip / fused16.h):
-//   q^T, k^T, v^T [32 x 16] = W_{q,k,v}[head] * LN(x)^T        A: weight rows from LDS (perm32 columns), B: LN(x) in registers;
+//   q^T, k^T [32 x 16]      = W_{q,k}[head] * LN(x)^T          A: weight rows from LDS (perm32 columns), B: LN(x) in registers;
 //                                                              MFMA row i of tile t <-> head channel 8 (i >> 2) + 4 t + (i & 3), so a
 //                                                              lane (c, g) ends up with channels 8g .. 8g+7 of its token: q^T IS the B
-//                                                              fragment of the score product, k / v rows leave as one 16-byte LDS store
-//   S^T [64 keys x 16 q]    = K * (scale q)^T + bias           A: K rows from the window's LDS image (all four waves wrote it)
-//   softmax over keys: in registers + two cross-lane steps (v_permlane16_swap / v_permlane32_swap)
-//   O^T [32 x 16]           = V^T * P^T                        A: transpose reads of the V image with the key permutation the score
-//                                                              accumulators carry (window_attn.hip: frag_v_perm64), B: P from registers
+//                                                              fragment of the score product, k leaves as one 16-byte LDS store
+//   V [16 x 32]             = LN(x) * W_v[head]^T              the same fragments with the MFMA operands exchanged: a lane holds 4
+//                                                              slots of one channel -> one 8-byte store into the V^T image
+//   S^T [64 keys x 16 q]    = K * (scale log2e q)^T + bias     A: K rows from the window's LDS image (all four waves wrote it)
+//   softmax over keys, base 2: in registers + two VALU butterfly steps (v_permlane16_swap / v_permlane32_swap, common.h)
+//   O^T [32 x 16]           = V^T * P^T                        A: two 8-byte reads of the V^T image per fragment, in the key order the
+//                                                              score accumulators carry; B: P (unnormalised) from registers
 //   y^T [C x 16]           += Wproj[:, head] * O^T             A: the head's 32 columns of Wproj from LDS (perm32 columns: the two
-//                                                              16-channel tiles of O^T are the permuted k-slots), B: O from registers
+//                                                              16-channel tiles of O^T are the permuted k-slots), B: O * (rowscale /
+//                                                              softmax sum) from registers
 // The accumulator of y^T starts as x + rowscale * b_proj and O is scaled by the row's DropPath factor, so the finished accumulator IS
 // the output row.  Zero-pad slots (win2tok = -1) and the idle slots 49 .. 63 carry LN(x) = 0, i.e. q / k / v = bias as in the
 // reference (padding happens after norm1); idle keys are masked by the -1e30 columns of the fragment-order bias.
 //
 // Pipeline.  The (window group, head) pairs of a workgroup are ONE sequence of steps; step s runs the attention + projection of
-// pair s-1 and the qkv product of pair s between two workgroup barriers.  Weights stream L2 -> LDS by LDS-DMA per head (q | k | v
-// row images + the head's biases into a two-deep ring, the projection columns into another), requested one step ahead.  K / V
-// images are double-buffered per window, so one barrier per step orders everything.  The token rows of the NEXT window group are
-// prefetched into registers a few 16-byte loads per step; those loads, the output stores and the side-output stores are the
-// YOUNGEST memory operations of a step and are the only ones the step's closing `s_waitcnt vmcnt(n)` leaves in flight.
+// pair s-1 (piece A) and the q | k | v products of pair s (piece Q; at a window's first head also the LayerNorm of its rows, piece N)
+// between two workgroup barriers.  K / V^T images are double-buffered per window, so one barrier per step orders everything.  The
+// window slots of a workgroup run the pieces in opposite orders (A N Q / N Q A): the two waves of a SIMD belong to different slots,
+// so one is in its MFMA / LDS-bound piece while the other runs the VALU-bound softmax.  Weights: when the slices of all heads fit
+// beside the images (C = 96: 77 KB) they are requested once, during the workgroup's first window, and stay resident; otherwise
+// (C = 192) they stream L2 -> LDS by LDS-DMA per head through two-deep rings, one step ahead.  V is kept as a V^T image written from a
+// NON-transposed product (the same weight fragments with the MFMA operands exchanged), so P V needs no transposing LDS read.
+//
+// Memory operations are counted, not waited for.  The token rows of the NEXT window (HBM) are prefetched into registers, a few
+// 16-byte loads at the top of every step after the weight requests; they, the output stores and the side-output stores are the
+// YOUNGEST operations of a step and the only ones its closing `s_waitcnt vmcnt(n)` leaves in flight (with resident weights there is
+// nothing to wait for after the first window).  For the count -- and hipcc's own inserted waits -- to be exact, every memory
+// operation of the loop is unconditional: rows that do not exist are addressed out of range (row_off), a wave without a DMA piece
+// issues one into a spare KiB.  The fragment-order bias of all heads lives in registers: a load inside the step would have to be
+// waited for behind the HBM prefetch (vmcnt retires in order).  DESIGN.md 4.2b has the measurements behind each of these.
 #include "common.h"
 #include "fused16.h"
 #include "../../include/esvit_hip.h"
