@@ -576,6 +576,36 @@ def test_attn_branch_fwd(mods, nH, H, shift, nB, save):
         ops.set_act_dtype(old)
 
 
+@pytest.mark.parametrize("nH,H,shift,nB", [(3, 56, 3, 48), (6, 28, 0, 64)])
+def test_attn_branch_fwd_is_bit_reproducible(mods, nH, H, shift, nB):
+    """the fused branch at full occupancy, 25 launches on the same inputs: every output (with and without side outputs) identical to
+    the bit.  Its cross-lane reductions are hand-written v_permlane16/32_swap sequences; the form that first shipped (the builtin with
+    too few wait states behind it) gave run-to-run different results in another kernel"""
+    ops, _ = mods
+    dev = _dev()
+    ws, hd = 7, 32
+    N, C, L = ws * ws, nH * hd, H * H
+    w2t = torch.from_numpy(ops.window_maps(H, H, ws, shift)[0]).to(dev)
+    nW = w2t.numel() // N
+    regions = torch.from_numpy(ops.shift_region_ids(H, H, ws, shift)).to(dev) if shift else None
+    x = _rand((nB * L, C), dev, 70)
+    g1, b1 = 1.0 + 0.1 * _rand((C,), dev, 71), 0.1 * _rand((C,), dev, 72)
+    Wq_p, bqkv = ops.cast_weight(_rand((3 * C, C), dev, 73) * C ** -0.5, perm32=True), _rand((3 * C,), dev, 74) * 0.5
+    Wp_p, bproj = ops.cast_weight(_rand((C, C), dev, 75) * C ** -0.5, perm32=True), _rand((C,), dev, 76) * 0.5
+    table = _rand(((2 * ws - 1) ** 2, nH), dev, 77) * 0.5
+    ref = None
+    for rep in range(25):
+        y, side = ops.attn_branch_fwd(x, g1, b1, 1e-6, Wq_p, bqkv, Wp_p, bproj, w2t, L, table, ws, regions, nW, N, nH, hd ** -0.5, save=True)
+        y2 = ops.attn_branch_fwd(x, g1, b1, 1e-6, Wq_p, bqkv, Wp_p, bproj, w2t, L, table, ws, regions, nW, N, nH, hd ** -0.5)
+        cur = [y, y2] + list(side)
+        assert torch.equal(y, y2), "side outputs change the branch output (rep %d)" % rep
+        if ref is None:
+            ref = [t.clone() for t in cur]
+        else:
+            for i, (a, b) in enumerate(zip(cur, ref)):
+                assert torch.equal(a, b), "tensor %d differs between launch 0 and launch %d" % (i, rep)
+
+
 @pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("geom", ["vit37_h3", "vit37_h6", "cvt56_h1", "cvt28_h3", "swin56_h3_hd32"])
 def test_window_attention_full_occupancy(mods, dt, geom):
