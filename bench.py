@@ -483,7 +483,7 @@ def main():
             gbs = tot_by / (tot_ms * 1e-3) / 1e9
             ach_tf = tot_fl / (tot_ms * 1e-3) / 1e12
             traffic, traffic_file = pmc_gemm_traffic_per_launch(args.arch, B, len(prof) / prof_steps)
-            out["roofline"] = {"bound": "mfma", "kernel": "gemm_p8_kernel / gemm_p8n_kernel / gemm_dma_kernel (all fwd/dgrad/wgrad GEMM launches of the step)",
+            out["roofline"] = {"bound": "mfma", "kernel": "gemm_p8_kernel / gemm_dma_kernel (all fwd/dgrad/wgrad GEMM launches of the step)",
                                "achieved": ach_tf, "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach_tf / BF16_PEAK_TFLOPS,
                                "traffic": traffic,
                                "traffic_source": None if traffic is None else "rocprofv3 PMC passes of this command, committed as %s (not read in this run)" % traffic_file,

@@ -11,7 +11,7 @@ LIB_PATH = os.environ.get("ESVIT_HIP_LIB") or os.path.join(_HERE, "lib", "libesv
 
 F32, BF16 = 0, 1
 EPI_NONE, EPI_GELU, EPI_GELU_BWD, EPI_QGELU, EPI_QGELU_BWD = 0, 1, 2, 3, 4
-GEMM_AUTO, GEMM_REGSTAGE, GEMM_DMA4, GEMM_DMA8, GEMM_DMA4W, GEMM_P8, GEMM_P8N = 0, 1, 2, 3, 4, 5, 6
+GEMM_AUTO, GEMM_REGSTAGE, GEMM_DMA4, GEMM_DMA8, GEMM_DMA4W, GEMM_P8 = 0, 1, 2, 3, 4, 5
 
 vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 

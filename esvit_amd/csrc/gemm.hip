@@ -51,8 +51,6 @@ bool p8_supports(int dtype, const esvit_gemm_desc& d) {
     return a_bytes < 0xfff00000L && b_bytes < 0xfff00000L;
 }
 
-bool p8n_supports(int dtype, const esvit_gemm_desc& d) { return p8_supports(dtype, d) && esvit_gemm_p8n_supports(d); }
-
 GemmChoice choose(int dtype, const esvit_gemm_desc& d) {
     GemmChoice c{ESVIT_GEMM_REGSTAGE, 128, 128};
     if (dtype != ESVIT_BF16) {
@@ -98,11 +96,6 @@ GemmChoice choose(int dtype, const esvit_gemm_desc& d) {
 #endif
         ) {
             want = ESVIT_GEMM_P8;
-#ifdef ESVIT_P8_BROAD_ROUTING  // tools/ab_routing.sh only
-        } else if (p8n_supports(dtype, d) && d.batch <= 1 && !d.a_kstrided && d.b_kstrided && d.epilogue == ESVIT_EPI_NONE && !d.out_f32 && !d.bias &&
-                   d.splitk <= 1 && d.N % 128 == 0 && d.N <= 512 && d.K >= 384 && d.M >= 16384) {
-            want = ESVIT_GEMM_P8N;
-#endif
 #endif
         } else if (!d.a_kstrided && !d.rowmap && d.K >= 4096 && d.N >= 192 && t8 * nz >= 128) {
             // One 256 x 256 tile per CU has no second workgroup to hide its prologue / epilogue behind: measured
@@ -135,10 +128,6 @@ GemmChoice choose(int dtype, const esvit_gemm_desc& d) {
 #endif
     c.kernel = want;
     if (want == ESVIT_GEMM_P8) c.bm = c.bn = 256;
-    else if (want == ESVIT_GEMM_P8N) {
-        c.bm = 256;
-        c.bn = 128;
-    }
     else if (want == ESVIT_GEMM_DMA8) dma8_tile(d, c.bm, c.bn);
     else if (want == ESVIT_GEMM_DMA4W) dma4w_tile(d, c.bm, c.bn);
     else dma4_tile(d, c.bm, c.bn);
@@ -177,7 +166,6 @@ template <bool AKS, bool BKS>
 int run_layout(int dtype, const esvit_gemm_desc& d, const GemmChoice& c, hipStream_t stream) {
     if (dtype == ESVIT_BF16) {
         if (c.kernel == ESVIT_GEMM_P8) return esvit_gemm_p8_launch(d, stream);
-        if (c.kernel == ESVIT_GEMM_P8N) return esvit_gemm_p8n_launch(d, stream);
         if constexpr (!AKS) {  // the 8-wave tile is not instantiated for the weight-gradient layout (measured slower there)
             if (c.kernel == ESVIT_GEMM_DMA8) return run_dma8<AKS, BKS>(d, stream);
         }
@@ -189,9 +177,7 @@ int run_layout(int dtype, const esvit_gemm_desc& d, const GemmChoice& c, hipStre
 
 // which forced main loops exist for which problem
 int check_selector(int dtype, const esvit_gemm_desc& d) {
-    ESVIT_CHECK_ARG(d.kernel >= ESVIT_GEMM_AUTO && d.kernel <= ESVIT_GEMM_P8N, "esvit_gemm: bad kernel selector %d", d.kernel);
-    ESVIT_CHECK_ARG(!(d.kernel == ESVIT_GEMM_P8N && !p8n_supports(dtype, d)),
-                    "esvit_gemm: the 256 x 128 eight-phase loop needs what ESVIT_GEMM_P8 needs, N %% 32 == 0, 16-byte aligned outputs and one of its epilogue kinds");
+    ESVIT_CHECK_ARG(d.kernel >= ESVIT_GEMM_AUTO && d.kernel <= ESVIT_GEMM_P8, "esvit_gemm: bad kernel selector %d", d.kernel);
     ESVIT_CHECK_ARG(!(d.kernel == ESVIT_GEMM_P8 && !p8_supports(dtype, d)),
                     "esvit_gemm: the eight-phase loop needs bf16, K %% 64 == 0, no row map, and row statistics only over whole 256 x 256 tiles without column sums");
     if (dtype != ESVIT_BF16)
@@ -255,7 +241,7 @@ extern "C" int esvit_gemm_select(int dtype, const esvit_gemm_desc* dp, int* tile
     const GemmChoice c = choose(dtype, d);
     if (tile_m) *tile_m = c.bm;
     if (tile_n) *tile_n = c.bn;
-    if (resident_slots) *resident_slots = (c.kernel == ESVIT_GEMM_DMA8 || c.kernel == ESVIT_GEMM_P8 || c.kernel == ESVIT_GEMM_P8N) ? 256 : 512;  // workgroups the chip holds at once (256 CUs)
+    if (resident_slots) *resident_slots = (c.kernel == ESVIT_GEMM_DMA8 || c.kernel == ESVIT_GEMM_P8) ? 256 : 512;  // workgroups the chip holds at once (256 CUs)
     return c.kernel;
 }
 

@@ -28,9 +28,6 @@
 
 // the 256 x 256 eight-phase bf16 main loop (gemm_p8.hip); esvit_gemm's dispatcher (gemm.hip) checks what it requires
 int esvit_gemm_p8_launch(const esvit_gemm_desc& d, hipStream_t stream);
-// the 256 x 128 variant with two accumulator sets and the epilogue spread over the next tile's main loop (gemm_p8n.hip)
-bool esvit_gemm_p8n_supports(const esvit_gemm_desc& d);
-int esvit_gemm_p8n_launch(const esvit_gemm_desc& d, hipStream_t stream);
 
 namespace {
 

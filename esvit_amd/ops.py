@@ -10,7 +10,7 @@ import os
 import numpy as np
 import torch
 
-from ._lib import BF16, EPI_GELU, EPI_GELU_BWD, EPI_NONE, EPI_QGELU, EPI_QGELU_BWD, F32, GEMM_AUTO, GEMM_DMA8, GEMM_P8, GEMM_P8N, GemmDesc, check, lib
+from ._lib import BF16, EPI_GELU, EPI_GELU_BWD, EPI_NONE, EPI_QGELU, EPI_QGELU_BWD, F32, GEMM_AUTO, GEMM_DMA8, GEMM_P8, GemmDesc, check, lib
 
 _ACT_DTYPE = torch.bfloat16
 
@@ -174,7 +174,7 @@ def _gemm_desc(kw):
     d.kernel = int(kw.get("kernel", FORCE_GEMM_KERNEL))
     if d.kernel == GEMM_DMA8 and d.a_kstrided and "kernel" not in kw:
         d.kernel = GEMM_AUTO  # FORCE_GEMM_KERNEL is a test / bench hook: the 8-wave tile has no weight-gradient instantiation
-    if d.kernel in (GEMM_P8, GEMM_P8N) and "kernel" not in kw:
+    if d.kernel == GEMM_P8 and "kernel" not in kw:
         # (same hook) the eight-phase loops run whole 64-deep k-tiles, have no row map / statistics, and the 256 x 128 one its own list
         # of epilogue kinds: ask the library whether the forced loop takes this descriptor
         tm, tn, slots = C.c_int(0), C.c_int(0), C.c_int(0)

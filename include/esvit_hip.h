@@ -132,7 +132,6 @@ typedef struct {
 #define ESVIT_GEMM_DMA8 3     /* bf16, LDS-DMA, 256 x 256 tiles, 8 waves, one workgroup per CU: very long reductions */
 #define ESVIT_GEMM_DMA4W 4    /* bf16, LDS-DMA, 4 waves, 128 x 192 / 128 x 96 tiles with whole-width wave rows (N % 96 == 0) */
 #define ESVIT_GEMM_P8 5       /* bf16, LDS-DMA, 256 x 256 tiles, 8 waves, eight-phase schedule with counted DMA waits (K % 64 == 0, no rowmap; rowstat only over whole 256 x 256 tiles, in 32-column blocks, without colstat) */
-#define ESVIT_GEMM_P8N 6      /* the same structure on 256 x 128 tiles with two accumulator sets: a tile's epilogue is spread over the next tile's main loop (additionally N % 32 == 0, 16-byte aligned outputs) */
 
 /* C = alpha * op(A) op(B) (+ epilogue).  Replaces every nn.Linear / conv-as-GEMM on the
  * path: swin_transformer.py:31-37,127,150,418,531; vision_transformer.py:414-418;

@@ -8,10 +8,10 @@ root=$(cd "$(dirname "$0")/.." && pwd); cd $root
 flags="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -Wno-unused-result -Wno-pass-failed -I include -I esvit_amd/csrc -x hip -c"
 build_variant() {  # name, defines
   out=$root/tools/probe/libesvit_hip_$1.so
-  if [ -f $out ] && [ ! esvit_amd/csrc/gemm.hip -nt $out ] && [ ! esvit_amd/csrc/gemm_kernels.h -nt $out ] && [ ! esvit_amd/csrc/gemm_p8.hip -nt $out ] && [ ! esvit_amd/csrc/gemm_p8n.hip -nt $out ]; then return; fi
-  objs=$(ls esvit_amd/csrc/build/*.o | grep -v "/gemm.o\|/gemm_p8.o\|/gemm_p8n.o")
-  for f in gemm gemm_p8 gemm_p8n; do /opt/rocm/bin/hipcc $flags $2 esvit_amd/csrc/$f.hip -o /tmp/${f}_$1.o & done; wait
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $out $objs /tmp/gemm_$1.o /tmp/gemm_p8_$1.o /tmp/gemm_p8n_$1.o
+  if [ -f $out ] && [ ! esvit_amd/csrc/gemm.hip -nt $out ] && [ ! esvit_amd/csrc/gemm_kernels.h -nt $out ] && [ ! esvit_amd/csrc/gemm_p8.hip -nt $out ]; then return; fi
+  objs=$(ls esvit_amd/csrc/build/*.o | grep -v "/gemm.o\|/gemm_p8.o")
+  for f in gemm gemm_p8; do /opt/rocm/bin/hipcc $flags $2 esvit_amd/csrc/$f.hip -o /tmp/${f}_$1.o & done; wait
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $out $objs /tmp/gemm_$1.o /tmp/gemm_p8_$1.o
   echo built $out
 }
 build_variant B "-DESVIT_P8_WGRAD_COLSUM -DESVIT_P8_ROWSTAT_AUTO"

@@ -18,10 +18,11 @@ fi
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-unused-result -Wno-pass-failed -DESVIT_P8_TIMELINE -I "$root/include" -I "$root/esvit_amd/csrc" \
     -x hip "$root/esvit_amd/csrc/gemm_p8.hip" -o "$here/libp8_probe.so"
 echo built "$here/libp8_probe.so"
-# the 256 x 128 two-set loop with per-item timestamps, and the same without its epilogue stores (tools/p8_timeline.py --lib)
+# the 256 x 128 two-set loop (tools/probe/gemm_p8n.hip: measured in round 4, routed to nothing, not part of the product library since
+# round 5) with per-item timestamps, and the same without its epilogue stores (tools/p8_timeline.py --lib)
 for v in "" "-DESVIT_P8N_NOSTORE"; do
   n=$( [ -z "$v" ] && echo libp8n_probe.so || echo libp8n_probe_nostore.so )
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-unused-result -Wno-pass-failed -DESVIT_P8_TIMELINE $v -I "$root/include" -I "$root/esvit_amd/csrc" \
-      -x hip "$root/esvit_amd/csrc/gemm_p8n.hip" -o "$here/$n"
+      -x hip "$here/gemm_p8n.hip" -o "$here/$n"
   echo built "$here/$n"
 done

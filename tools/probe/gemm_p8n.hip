@@ -1,4 +1,9 @@
-// ESVIT_GEMM_P8N: 256 x 128 x 64 bf16 tiles on the eight-wave / staggered-halves / counted-DMA-wait structure of gemm_p8.hip, with
+// PROBE (not part of libesvit_hip.so since round 5; built by tools/probe/build.sh into libp8n_probe*.so for tools/p8_timeline.py).
+// Status: correct on every epilogue kind and layout it offers (round 4's test_gemm_p8n, 6 shapes), measured in the step with
+// tools/trace_ab.sh and routed to NOTHING: the only launches it won in isolation (384-wide data gradients) lost 11 % inside the step
+// (DESIGN.md 0a row "1 (d)", profiles/r04_gemm_instep_ab.txt), so the selector ESVIT_GEMM_P8N was removed from include/esvit_hip.h.
+//
+// 256 x 128 x 64 bf16 tiles on the eight-wave / staggered-halves / counted-DMA-wait structure of gemm_p8.hip, with
 // TWO accumulator sets and the epilogue of a tile spread over the main loop of the NEXT tile.
 //
 // Why.  profiles/r04_p8_timeline.txt: the persistent 256 x 256 loop multiplies a k-tile in ~1.9 us, but an output tile costs it
