@@ -691,6 +691,8 @@ extern "C" int esvit_attn_branch_fwd(int dtype, const float* x, const float* gam
     const long rows = (long)nB * L;
     ESVIT_CHECK_ARG(rows * 3 * C * 2 < 0x7fff0000L && rows * C * 4 < 0x7fff0000L, "esvit_attn_branch_fwd: the rows of one call must fit 2 GiB buffer ranges");
     ESVIT_CHECK_ARG((long)nB * nW < (1L << 22), "esvit_attn_branch_fwd: at most 2^22 windows per call");
+    ESVIT_CHECK_ARG((((uintptr_t)x | (uintptr_t)y | (uintptr_t)Wqkv_p | (uintptr_t)Wproj_p | (uintptr_t)xw | (uintptr_t)qkv | (uintptr_t)ao | (uintptr_t)bias_frag_ws) & 15) == 0,
+                    "esvit_attn_branch_fwd: x, y, the weights, the bias fragments and the side outputs are read / written in 16-byte pieces: align them");
     if (rel_table) {
         int rc = esvit_i_fill_bias_frag(rel_table, ws, N, nH, bias_frag_ws, stream);
         if (rc != ESVIT_OK) return rc;
