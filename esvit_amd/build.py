@@ -55,7 +55,8 @@ def build(force=False, verbose=True):
         results = list(ex.map(lambda s: _compile(s, force, hdr), srcs))
     objs = [o for o, _ in results]
     rebuilt = any(r for _, r in results)
-    if rebuilt or not os.path.exists(LIB) or force:
+    stale = os.path.exists(LIB) and any(os.path.getmtime(o) > os.path.getmtime(LIB) for o in objs)  # (an object compiled by hand / by tools/)
+    if rebuilt or stale or not os.path.exists(LIB) or force:
         cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
         r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
         if r.returncode != 0:

@@ -75,6 +75,24 @@ __device__ __forceinline__ void load_window_tables(const BigTables& tb, const in
     }
 }
 
+// which of the window's NT query tiles hold a token at all (bit j: some slot 16 j .. 16 j + 15 is live) -- wave-uniform, from the
+// slot -> token table in LDS.  The windows of the 96^2 crops are mostly padding from stage 1 on (a 6 x 6 map in a 14 x 14 window: 36
+// live slots in tiles 0..4 of 14): a pad-slot QUERY produces nothing (its output row is cropped away, its dO row is zero, so its dS
+// row is zero), only pad-slot KEYS take part (swin_transformer.py:292-300 pads after norm1: their k, v are the qkv bias).  The three
+// kernels skip query tiles without a live slot; the results are the same to the bit (the skipped products add zeros).
+__device__ __forceinline__ unsigned live_query_tiles(const int* tok_lds, int lane) {
+    bool l = false;
+    if (lane < NPB / 4) {
+        const i32x4 t = *reinterpret_cast<const i32x4*>(tok_lds + 4 * lane);
+        l = (t[0] & t[1] & t[2] & t[3]) >= 0;  // some token index is non-negative
+    }
+    const unsigned long long b = __ballot(l);
+    unsigned m = 0;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) m |= (((b >> (4 * j)) & 0xfull) != 0 ? 1u : 0u) << j;
+    return m;
+}
+
 // stage NROWS window slots (first slot s0) of a token-ordered matrix into a [NROWS][LDQ] image; NTHR threads cooperate.
 // Two phases: every global load of the thread is issued before the first LDS store, so a thread waits ONE memory round
 // trip per call instead of one per 16-byte piece (the first version looped load -> store and paid 4-7 serial round trips
@@ -301,20 +319,29 @@ __global__ __launch_bounds__(FWD3_WAVES * 64, sizeof(T) == 2 ? (HD == 32 ? 4 : 2
         sv.store(Vs, 1.f, threadIdx.x);
         sq.store(Qs, scale, lane);
     }
+    // query tiles without a live slot are skipped (live_query_tiles); the probabilities export computes every row it writes
+    const unsigned live = WANT_ATTN ? ((1u << NT) - 1) : live_query_tiles(tb.tok, lane);
     __syncthreads();  // K, V complete (whole workgroup); everything below is private to the wave
 
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
         const int q0 = 16 * (wave + pass * FWD3_WAVES);
-        if (pass > 0) {
+        const bool tile_live = (live >> (wave + pass * FWD3_WAVES)) & 1;
+        if (pass > 0 && tile_live) {
             __builtin_amdgcn_wave_barrier();
             sq.store(Qs, scale, lane);
             __builtin_amdgcn_wave_barrier();
         }
         Frag<T> qf[KS];
+        if (tile_live) {
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) qf[ks] = frag_kc<T>(Qs, LDQ, 0, 32 * ks, c, g);
-        if (pass == 0) sq.load(src, 3L * C, tb.tok, tok_base, 16 * (wave + FWD3_WAVES), N, qkv_bias + h * HD, lane);
+            for (int ks = 0; ks < KS; ++ks) qf[ks] = frag_kc<T>(Qs, LDQ, 0, 32 * ks, c, g);
+        }
+        if (pass == 0 && ((live >> (wave + FWD3_WAVES)) & 1)) sq.load(src, 3L * C, tb.tok, tok_base, 16 * (wave + FWD3_WAVES), N, qkv_bias + h * HD, lane);
+        if (!tile_live) {
+            if (g == 0 && lse_out) lse_out[(long)unit * NPB + q0 + c] = 0.f;  // (never read: the backward skips the same tiles)
+            continue;
+        }
         const int rq = masked ? ((tb.pk[q0 + c] >> 16) & 0xff) : 0;
         f32x4 p[NT];
 #pragma unroll
@@ -445,23 +472,31 @@ __global__ __launch_bounds__(DQ4_WAVES * 64) void attn_big_bwd_dq4_kernel(
         __syncthreads();  // previous window's reads are complete
         load_window_tables(tb, win2tok, region_ids, bwc % nW, N, ws, win_ok);
         __syncthreads();
-        float lq;
+        const unsigned live = live_query_tiles(tb.tok, lane);
+        if (((live >> (grp * DQ4_WAVES)) & ((1u << DQ4_WAVES) - 1)) == 0) continue;  // no query of this workgroup's tiles is live (whole workgroup: the table is shared)
+        const bool tile_live = wave_ok && ((live >> qt) & 1);
+        float lq = 0.f;
         {
             SlotStage<T, NPB, DQ4_WAVES * 64, HD> sk, sv;
             SlotStage<T, 16, 64, HD> sq, so, sf;
             sk.load(src + C, 3L * C, tb.tok, tok_base, 0, N, qkv_bias + C + h * HD, threadIdx.x);
             sv.load(src + 2 * C, 3L * C, tb.tok, tok_base, 0, N, qkv_bias + 2 * C + h * HD, threadIdx.x);
-            sq.load(src, 3L * C, tb.tok, tok_base, q0, N, qkv_bias + h * HD, lane);
-            so.load(dout + h * HD, (long)C, tb.tok, tok_base, q0, N, nullptr, lane);
-            sf.load(fout + h * HD, (long)C, tb.tok, tok_base, q0, N, nullptr, lane);
-            lq = lse_in[((long)bwc * nH + h) * NPB + q0 + c];
+            if (tile_live) {
+                sq.load(src, 3L * C, tb.tok, tok_base, q0, N, qkv_bias + h * HD, lane);
+                so.load(dout + h * HD, (long)C, tb.tok, tok_base, q0, N, nullptr, lane);
+                sf.load(fout + h * HD, (long)C, tb.tok, tok_base, q0, N, nullptr, lane);
+                lq = lse_in[((long)bwc * nH + h) * NPB + q0 + c];
+            }
             sk.store(Ks, 1.f, threadIdx.x);
             sv.store(Vs, 1.f, threadIdx.x);
-            sq.store(Qs, scale, lane);
-            so.store(Os, 1.f, lane);
-            sf.store(Fs, 1.f, lane);
+            if (tile_live) {
+                sq.store(Qs, scale, lane);
+                so.store(Os, 1.f, lane);
+                sf.store(Fs, 1.f, lane);
+            }
         }
         __syncthreads();
+        if (!tile_live) continue;  // (no workgroup barrier below this line)
         Frag<T> qf[KS], of[KS];
         const int rq = masked ? ((tb.pk[q0 + c] >> 16) & 0xff) : 0;
         float d = 0.f;
@@ -554,6 +589,7 @@ __global__ __launch_bounds__((BigCfg<T, HD>::WAVES * 64), ((sizeof(T) == 2 && HD
 
     load_window_tables(tb, win2tok, region_ids, bw % nW, N, ws, true);
     __syncthreads();
+    const unsigned live = HD == 32 ? live_query_tiles(tb.tok, lane) : (1u << NT) - 1;
     SlotStage<T, 32, 64, HD> sk, sv;
     {
         SlotStage<T, NPB, WAVES * 64, HD> sq, so;
@@ -621,85 +657,104 @@ __global__ __launch_bounds__((BigCfg<T, HD>::WAVES * 64), ((sizeof(T) == 2 && HD
             rkey[0] = (tb.pk[k0 + c] >> 16) & 0xff;
             rkey[1] = (tb.pk[k0 + 16 + c] >> 16) & 0xff;
         }
-        // P block, oriented S: rows = queries (14 tiles), columns = this block's 32 keys (2 tiles)
-        f32x4 p[2][NT];
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            Frag<T> qf[KS];
-#pragma unroll
-            for (int kd = 0; kd < KS; ++kd) qf[kd] = frag_kc<T>(Qs, LDQ, 16 * j, 32 * kd, c, g);
-            const f32x4 l4 = *reinterpret_cast<const f32x4*>(tb.lse + 16 * j + 4 * g);
-            const i32x4 pk4 = *reinterpret_cast<const i32x4*>(tb.pk + 16 * j + 4 * g);
-#pragma unroll
-            for (int a = 0; a < 2; ++a) {
-                f32x4 b = *reinterpret_cast<const f32x4*>(bias_h + ((j * NT + (k0 >> 4) + a) * 64 + lane) * 4);
-                if (masked) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) b[r] += (((pk4[r] >> 16) & 0xff) != rkey[a]) ? -100.f : 0.f;
+        // P, dV, dS, dK over the window's query tiles.  full: every query tile; otherwise only the tiles of `live` (live_query_tiles) --
+        // the branches around single tiles cost the full windows their instruction-level parallelism, so this form is taken only for
+        // windows that are mostly padding (a constant per call site: two specialised copies after inlining).
+        auto block = [&](const bool full) __attribute__((always_inline)) {
+            // P block, oriented S: rows = queries (14 tiles), columns = this block's 32 keys (2 tiles)
+            f32x4 p[2][NT];
+        #pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                if (!full && !((live >> j) & 1)) {
+                    p[0][j] = p[1][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    continue;
                 }
-#pragma unroll
-                for (int kd = 0; kd < KS; ++kd) mma(qf[kd], kf[a][kd], b);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) b[r] = (16 * j + 4 * g + r < N) ? __expf(b[r] - l4[r]) : 0.f;  // padded queries carry no gradient
-                p[a][j] = b;
-            }
-        }
-        // dV[key][d] = sum_q P[q][key] dO[q][d]
-        {
-            f32x4 av[2][DT];
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int j = 0; j < DT; ++j) av[a][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int ks = 0; ks < NPB / 32; ++ks) {
-                Frag<T> pf[2];
-#pragma unroll
-                for (int a = 0; a < 2; ++a) pf[a] = frag_p_regs<T>(p[a][2 * ks], p[a][2 * ks + 1]);
-#pragma unroll
-                for (int j = 0; j < DT; ++j) {
-                    const Frag<T> oj = frag_v_perm<T>(Os, LDQ, 16 * j, ks, c, g);
-#pragma unroll
-                    for (int a = 0; a < 2; ++a) mma(oj, pf[a], av[a][j]);  // dV^T [d][key]: operands exchanged
+                Frag<T> qf[KS];
+        #pragma unroll
+                for (int kd = 0; kd < KS; ++kd) qf[kd] = frag_kc<T>(Qs, LDQ, 16 * j, 32 * kd, c, g);
+                const f32x4 l4 = *reinterpret_cast<const f32x4*>(tb.lse + 16 * j + 4 * g);
+                const i32x4 pk4 = *reinterpret_cast<const i32x4*>(tb.pk + 16 * j + 4 * g);
+        #pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    f32x4 b = *reinterpret_cast<const f32x4*>(bias_h + ((j * NT + (k0 >> 4) + a) * 64 + lane) * 4);
+                    if (masked) {
+        #pragma unroll
+                        for (int r = 0; r < 4; ++r) b[r] += (((pk4[r] >> 16) & 0xff) != rkey[a]) ? -100.f : 0.f;
+                    }
+        #pragma unroll
+                    for (int kd = 0; kd < KS; ++kd) mma(qf[kd], kf[a][kd], b);
+        #pragma unroll
+                    for (int r = 0; r < 4; ++r) b[r] = (16 * j + 4 * g + r < N) ? __expf(b[r] - l4[r]) : 0.f;  // padded queries carry no gradient
+                    p[a][j] = b;
                 }
             }
-            store_block_rows_t<T, HD>(av, 1.f, dqkv + 2 * C + h * HD, 3L * C, tb.tok, tok_base, k0, N, valid, padv, c, g);
-        }
-        // dS = P o (dP - delta), dP[q][key] = sum_d dO[q][d] V[key][d]; dS overwrites P
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            Frag<T> of[KS];
-#pragma unroll
-            for (int kd = 0; kd < KS; ++kd) of[kd] = frag_kc<T>(Os, LDQ, 16 * j, 32 * kd, c, g);
-            const f32x4 dl4 = *reinterpret_cast<const f32x4*>(tb.delta + 16 * j + 4 * g);
-#pragma unroll
-            for (int a = 0; a < 2; ++a) {
-                f32x4 dp = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int kd = 0; kd < KS; ++kd) mma(of[kd], vf[a][kd], dp);
-                p[a][j] = p[a][j] * (dp - dl4);
+            // dV[key][d] = sum_q P[q][key] dO[q][d]
+            {
+                f32x4 av[2][DT];
+        #pragma unroll
+                for (int a = 0; a < 2; ++a)
+        #pragma unroll
+                    for (int j = 0; j < DT; ++j) av[a][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        #pragma unroll
+                for (int ks = 0; ks < NPB / 32; ++ks) {
+                    if (!full && !((live >> (2 * ks)) & 3)) continue;  // both query tiles of this k-step are dead: P = 0
+                    Frag<T> pf[2];
+        #pragma unroll
+                    for (int a = 0; a < 2; ++a) pf[a] = frag_p_regs<T>(p[a][2 * ks], p[a][2 * ks + 1]);
+        #pragma unroll
+                    for (int j = 0; j < DT; ++j) {
+                        const Frag<T> oj = frag_v_perm<T>(Os, LDQ, 16 * j, ks, c, g);
+        #pragma unroll
+                        for (int a = 0; a < 2; ++a) mma(oj, pf[a], av[a][j]);  // dV^T [d][key]: operands exchanged
+                    }
+                }
+                store_block_rows_t<T, HD>(av, 1.f, dqkv + 2 * C + h * HD, 3L * C, tb.tok, tok_base, k0, N, valid, padv, c, g);
             }
-        }
-        // dK[key][d] = sum_q dS[q][key] (scale q)[q][d]
-        {
-            f32x4 ak[2][DT];
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int j = 0; j < DT; ++j) ak[a][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int ks = 0; ks < NPB / 32; ++ks) {
-                Frag<T> sf[2];
-#pragma unroll
-                for (int a = 0; a < 2; ++a) sf[a] = frag_p_regs<T>(p[a][2 * ks], p[a][2 * ks + 1]);
-#pragma unroll
-                for (int j = 0; j < DT; ++j) {
-                    const Frag<T> qj = frag_v_perm<T>(Qs, LDQ, 16 * j, ks, c, g);
-#pragma unroll
-                    for (int a = 0; a < 2; ++a) mma(qj, sf[a], ak[a][j]);  // dK^T [d][key]
+            // dS = P o (dP - delta), dP[q][key] = sum_d dO[q][d] V[key][d]; dS overwrites P
+        #pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                if (!full && !((live >> j) & 1)) continue;  // (p stays 0)
+                Frag<T> of[KS];
+        #pragma unroll
+                for (int kd = 0; kd < KS; ++kd) of[kd] = frag_kc<T>(Os, LDQ, 16 * j, 32 * kd, c, g);
+                const f32x4 dl4 = *reinterpret_cast<const f32x4*>(tb.delta + 16 * j + 4 * g);
+        #pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    f32x4 dp = {0.f, 0.f, 0.f, 0.f};
+        #pragma unroll
+                    for (int kd = 0; kd < KS; ++kd) mma(of[kd], vf[a][kd], dp);
+                    p[a][j] = p[a][j] * (dp - dl4);
                 }
             }
-            store_block_rows_t<T, HD>(ak, 1.f, dqkv + C + h * HD, 3L * C, tb.tok, tok_base, k0, N, valid, padk, c, g);
+            // dK[key][d] = sum_q dS[q][key] (scale q)[q][d]
+            {
+                f32x4 ak[2][DT];
+        #pragma unroll
+                for (int a = 0; a < 2; ++a)
+        #pragma unroll
+                    for (int j = 0; j < DT; ++j) ak[a][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        #pragma unroll
+                for (int ks = 0; ks < NPB / 32; ++ks) {
+                    if (!full && !((live >> (2 * ks)) & 3)) continue;
+                    Frag<T> sf[2];
+        #pragma unroll
+                    for (int a = 0; a < 2; ++a) sf[a] = frag_p_regs<T>(p[a][2 * ks], p[a][2 * ks + 1]);
+        #pragma unroll
+                    for (int j = 0; j < DT; ++j) {
+                        const Frag<T> qj = frag_v_perm<T>(Qs, LDQ, 16 * j, ks, c, g);
+        #pragma unroll
+                        for (int a = 0; a < 2; ++a) mma(qj, sf[a], ak[a][j]);  // dK^T [d][key]
+                    }
+                }
+                store_block_rows_t<T, HD>(ak, 1.f, dqkv + C + h * HD, 3L * C, tb.tok, tok_base, k0, N, valid, padk, c, g);
+            }
+        };
+        // (head_dim 64 = the monolithic ViTs: 197 of 224 slots live in every "window", the second form would only cost registers)
+        if constexpr (HD == 32) {
+            if (__builtin_popcount(live) <= NT - 4) block(false);
+            else block(true);
+        } else {
+            block(true);
         }
     }
     // sum over the 16 slots of a lane group (DPP row adds); lane c == 0 of every group holds channels 16 j + 4g + r

@@ -418,7 +418,7 @@ def test_small_ops(mods, dt):
 @pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("ws,nH,H,shift,hd", [(7, 3, 14, 3, 32), (7, 3, 12, 3, 32), (7, 6, 12, 0, 32), (7, 12, 6, 3, 32), (7, 24, 3, 0, 32),
                                               (7, 6, 7, 0, 32), (14, 3, 28, 7, 32), (14, 3, 24, 7, 32), (14, 6, 12, 7, 32), (14, 4, 14, 0, 32),
-                                              (14, 2, 6, 0, 32),
+                                              (14, 2, 6, 0, 32), (14, 2, 7, 0, 32), (14, 3, 3, 0, 32),
                                               # head_dim 64 (CvT: dim / heads): 7x7 windows, and the 6x6 / 3x3 windows of 96^2 crops
                                               (7, 1, 14, 0, 64), (7, 3, 12, 3, 64), (6, 6, 6, 0, 64), (3, 12, 3, 0, 64), (7, 3, 28, 0, 64)])
 def test_window_attention(mods, dt, ws, nH, H, shift, hd):
@@ -451,7 +451,11 @@ def test_window_attention(mods, dt, ws, nH, H, shift, hd):
     res = ops.window_attn_fwd(qkv, qb, w2t, L, table, ws, mask_frag, nW, N, nH, scale)  # training variant: no probabilities written
     _close("attn out (train)", res[0], orf, _tol(dt, f32=5e-5, bf=2e-2))
     if ws == 14:
-        _close("attn lse (train)", res[1], lse, _tol(dt, f32=5e-5, bf=2e-2))
+        # the training variant skips query tiles (16 slots) without a live token -- the backward skips the same tiles -- and writes 0 there
+        live = torch.zeros((nW, 224), dtype=torch.bool, device=dev)
+        live[:, :N] = w2t.view(nW, N) >= 0
+        live = live.view(nW, 14, 16).any(-1, keepdim=True).expand(nW, 14, 16).reshape(1, nW, 1, 224).expand(nB, nW, nH, 224).reshape(res[1].shape)
+        _close("attn lse (train)", res[1], torch.where(live, lse, torch.zeros_like(lse)), _tol(dt, f32=5e-5, bf=2e-2))
     dout = _rand((nB * L, C), dev, 52, dt)
     dqkv, ws_, pad_ = ops.window_attn_bwd(qkv, qb, w2t, L, dout, orf, lse, table, ws, mask_frag, nW, N, nH, scale)
     dt_ = ops.relpos_bias_bwd(ws_, index, N, trows)
@@ -560,7 +564,7 @@ def test_attn_branch_fwd_is_bit_reproducible(mods, nH, H, shift, nB):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
-@pytest.mark.parametrize("geom", ["vit37_h3", "vit37_h6", "cvt56_h1", "cvt28_h3", "swin56_h3_hd32"])
+@pytest.mark.parametrize("geom", ["vit37_h3", "vit37_h6", "cvt56_h1", "cvt28_h3", "swin56_h3_hd32", "w14map6_h12_hd32", "w14map24_h3_hd32"])
 def test_window_attention_full_occupancy(mods, dt, geom):
     """head_dim 64 (and 32 as the control) with MORE window-heads than the chip keeps resident: every CU fully occupied and
     several windows per workgroup.  Regression for the bench lines of the ViT / CvT / ViL configurations, whose bf16 forward
@@ -578,7 +582,9 @@ def test_window_attention_full_occupancy(mods, dt, geom):
         nB, nW = 1280, 1
         w2t, ws, table = Fn._vit_window(N, nH, dev)
     else:
-        H, ws, nB = (56, 7, 40) if "56" in geom else (28, 7, 64)
+        # (w14map*: 14 x 14 windows that are mostly padding -- the 6 x 6 / 24 x 24 maps of the 96^2 crops; the three kernels skip the query
+        # tiles without a live slot there, per window)
+        H, ws, nB = {"cvt56": (56, 7, 40), "swin56": (56, 7, 40), "cvt28": (28, 7, 64), "w14map6": (6, 14, 96), "w14map24": (24, 14, 64)}[geom.split("_")[0]]
         N, L = ws * ws, H * H
         w2t = torch.from_numpy(ops.window_maps(H, H, ws, 0)[0]).to(dev)
         nW = w2t.numel() // N
@@ -593,7 +599,7 @@ def test_window_attention_full_occupancy(mods, dt, geom):
         o, lse = ops.window_attn_fwd(qkv, qb, w2t, L, table, ws, None, nW, N, nH, scale)
         dqkv = ops.window_attn_bwd(qkv, qb, w2t, L, dout, o, lse, table, ws, None, nW, N, nH, scale)[0]
         assert bool(torch.isfinite(o.float()).all()) and bool(torch.isfinite(dqkv.float()).all())
-        step = 160 if vit else 4
+        step = 160 if vit else (32 if ws == 14 else 4)
         for b0 in range(0, nB, step):
             sl = slice(b0 * L, min(nB, b0 + step) * L)
             orf = ref.window_attn_fwd(qkv[sl], qb, w2t, L, table, ws, None, nW, N, nH, scale)
