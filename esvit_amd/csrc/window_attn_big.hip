@@ -103,8 +103,19 @@ struct SlotStage {
     static constexpr int ITERS = (NROWS * VPR + NTHR - 1) / NTHR;
     Vec16<T> x[ITERS];
 
+    // the 16-byte piece a pad slot holds in this thread's column of the image: the qkv bias of the head (swin_transformer.py:292-300 pads
+    // after norm1, so a pad token's q, k, v are the bias).  NTHR is a multiple of the pieces per row, so a thread stages the same
+    // column piece in every iteration and for every window: loaded ONCE per kernel (the first version read it element by element for
+    // every pad slot -- eight scalar loads per piece, and four of five slots of a 96^2 crop's 14 x 14 window are pad slots).
+    static_assert(NTHR % VPR == 0, "a thread keeps its column piece");
+    static __device__ __forceinline__ Vec16<T> pad_piece(const float* __restrict__ pad, int tid) {
+        Vec16<T> r;
+#pragma unroll
+        for (int e = 0; e < Vec16<T>::N; ++e) r.set(e, pad[(tid % VPR) * VEC + e]);
+        return r;
+    }
     __device__ __forceinline__ void load(const T* __restrict__ g, long row_stride, const int* tok_lds, long tok_base, int s0, int N,
-                                         const float* __restrict__ pad, int tid) {
+                                         const Vec16<T>* padv, int tid) {
 #pragma unroll
         for (int it = 0; it < ITERS; ++it) {
             const int v = tid + it * NTHR;
@@ -113,12 +124,8 @@ struct SlotStage {
             x[it] = zero16<T>();
             if (v < NROWS * VPR && t < N) {
                 const int tok = tok_lds[t];
-                if (tok >= 0) {
-                    x[it] = ld16<T>(g + (tok_base + tok) * row_stride + dv * VEC);
-                } else if (pad) {
-#pragma unroll
-                    for (int e = 0; e < Vec16<T>::N; ++e) x[it].set(e, pad[dv * VEC + e]);
-                }
+                if (tok >= 0) x[it] = ld16<T>(g + (tok_base + tok) * row_stride + dv * VEC);
+                else if (padv) x[it] = *padv;
             }
         }
     }
@@ -310,11 +317,14 @@ __global__ __launch_bounds__(FWD3_WAVES * 64, sizeof(T) == 2 ? (HD == 32 ? 4 : 2
     load_window_tables(tb, win2tok, region_ids, bw % nW, N, ws, true);
     __syncthreads();
     SlotStage<T, 16, 64, HD> sq;
+    const Vec16<T> padq = SlotStage<T, 16, 64, HD>::pad_piece(qkv_bias + h * HD, lane);
     {
         SlotStage<T, NPB, FWD3_WAVES * 64, HD> sk, sv;
-        sk.load(src + C, 3L * C, tb.tok, tok_base, 0, N, qkv_bias + C + h * HD, threadIdx.x);
-        sv.load(src + 2 * C, 3L * C, tb.tok, tok_base, 0, N, qkv_bias + 2 * C + h * HD, threadIdx.x);
-        sq.load(src, 3L * C, tb.tok, tok_base, 16 * wave, N, qkv_bias + h * HD, lane);
+        const Vec16<T> padk = SlotStage<T, NPB, FWD3_WAVES * 64, HD>::pad_piece(qkv_bias + C + h * HD, threadIdx.x);
+        const Vec16<T> padv = SlotStage<T, NPB, FWD3_WAVES * 64, HD>::pad_piece(qkv_bias + 2 * C + h * HD, threadIdx.x);
+        sk.load(src + C, 3L * C, tb.tok, tok_base, 0, N, &padk, threadIdx.x);
+        sv.load(src + 2 * C, 3L * C, tb.tok, tok_base, 0, N, &padv, threadIdx.x);
+        sq.load(src, 3L * C, tb.tok, tok_base, 16 * wave, N, &padq, lane);
         sk.store(Ks, 1.f, threadIdx.x);
         sv.store(Vs, 1.f, threadIdx.x);
         sq.store(Qs, scale, lane);
@@ -337,7 +347,7 @@ __global__ __launch_bounds__(FWD3_WAVES * 64, sizeof(T) == 2 ? (HD == 32 ? 4 : 2
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) qf[ks] = frag_kc<T>(Qs, LDQ, 0, 32 * ks, c, g);
         }
-        if (pass == 0 && ((live >> (wave + FWD3_WAVES)) & 1)) sq.load(src, 3L * C, tb.tok, tok_base, 16 * (wave + FWD3_WAVES), N, qkv_bias + h * HD, lane);
+        if (pass == 0 && ((live >> (wave + FWD3_WAVES)) & 1)) sq.load(src, 3L * C, tb.tok, tok_base, 16 * (wave + FWD3_WAVES), N, &padq, lane);
         if (!tile_live) {
             if (g == 0 && lse_out) lse_out[(long)unit * NPB + q0 + c] = 0.f;  // (never read: the backward skips the same tiles)
             continue;
@@ -462,6 +472,9 @@ __global__ __launch_bounds__(DQ4_WAVES * 64) void attn_big_bwd_dq4_kernel(
 #pragma unroll
     for (int i = 0; i < (WANT_DB ? NT : 1); ++i) db[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    const Vec16<T> padk = SlotStage<T, NPB, DQ4_WAVES * 64, HD>::pad_piece(qkv_bias + C + h * HD, threadIdx.x);
+    const Vec16<T> padv = SlotStage<T, NPB, DQ4_WAVES * 64, HD>::pad_piece(qkv_bias + 2 * C + h * HD, threadIdx.x);
+    const Vec16<T> padq = SlotStage<T, 16, 64, HD>::pad_piece(qkv_bias + h * HD, lane);
     const int iters = (Bw + parts - 1) / parts;
     for (int it = 0; it < iters; ++it) {
         const int bw = part + it * parts;
@@ -479,10 +492,10 @@ __global__ __launch_bounds__(DQ4_WAVES * 64) void attn_big_bwd_dq4_kernel(
         {
             SlotStage<T, NPB, DQ4_WAVES * 64, HD> sk, sv;
             SlotStage<T, 16, 64, HD> sq, so, sf;
-            sk.load(src + C, 3L * C, tb.tok, tok_base, 0, N, qkv_bias + C + h * HD, threadIdx.x);
-            sv.load(src + 2 * C, 3L * C, tb.tok, tok_base, 0, N, qkv_bias + 2 * C + h * HD, threadIdx.x);
+            sk.load(src + C, 3L * C, tb.tok, tok_base, 0, N, &padk, threadIdx.x);
+            sv.load(src + 2 * C, 3L * C, tb.tok, tok_base, 0, N, &padv, threadIdx.x);
             if (tile_live) {
-                sq.load(src, 3L * C, tb.tok, tok_base, q0, N, qkv_bias + h * HD, lane);
+                sq.load(src, 3L * C, tb.tok, tok_base, q0, N, &padq, lane);
                 so.load(dout + h * HD, (long)C, tb.tok, tok_base, q0, N, nullptr, lane);
                 sf.load(fout + h * HD, (long)C, tb.tok, tok_base, q0, N, nullptr, lane);
                 lq = lse_in[((long)bwc * nH + h) * NPB + q0 + c];
@@ -591,12 +604,15 @@ __global__ __launch_bounds__((BigCfg<T, HD>::WAVES * 64), ((sizeof(T) == 2 && HD
     __syncthreads();
     const unsigned live = HD == 32 ? live_query_tiles(tb.tok, lane) : (1u << NT) - 1;
     SlotStage<T, 32, 64, HD> sk, sv;
+    const Vec16<T> padk_piece = SlotStage<T, 32, 64, HD>::pad_piece(qkv_bias + C + h * HD, lane);
+    const Vec16<T> padv_piece = SlotStage<T, 32, 64, HD>::pad_piece(qkv_bias + 2 * C + h * HD, lane);
     {
         SlotStage<T, NPB, WAVES * 64, HD> sq, so;
-        sq.load(src, 3L * C, tb.tok, tok_base, 0, N, qkv_bias + h * HD, threadIdx.x);
+        const Vec16<T> padq_piece = SlotStage<T, NPB, WAVES * 64, HD>::pad_piece(qkv_bias + h * HD, threadIdx.x);
+        sq.load(src, 3L * C, tb.tok, tok_base, 0, N, &padq_piece, threadIdx.x);
         so.load(dout + h * HD, (long)C, tb.tok, tok_base, 0, N, nullptr, threadIdx.x);
-        sk.load(src + C, 3L * C, tb.tok, tok_base, 32 * wave, N, qkv_bias + C + h * HD, lane);
-        sv.load(src + 2 * C, 3L * C, tb.tok, tok_base, 32 * wave, N, qkv_bias + 2 * C + h * HD, lane);
+        sk.load(src + C, 3L * C, tb.tok, tok_base, 32 * wave, N, &padk_piece, lane);
+        sv.load(src + 2 * C, 3L * C, tb.tok, tok_base, 32 * wave, N, &padv_piece, lane);
         // per-query statistics: saved log-sum-exp and delta = sum_d dO[q,d] * O[q,d]
         for (int t = threadIdx.x; t < NPB; t += WAVES * 64) {
             float l = 0.f, d = 0.f;
@@ -649,8 +665,8 @@ __global__ __launch_bounds__((BigCfg<T, HD>::WAVES * 64), ((sizeof(T) == 2 && HD
         if (pass + 1 < PASSES) {  // next pass's key / value rows travel while this pass computes
             const int kn = wave + (pass + 1) * WAVES;
             const int kn0 = kn < NQB ? 32 * kn : 0;
-            sk.load(src + C, 3L * C, tb.tok, tok_base, kn0, N, qkv_bias + C + h * HD, lane);
-            sv.load(src + 2 * C, 3L * C, tb.tok, tok_base, kn0, N, qkv_bias + 2 * C + h * HD, lane);
+            sk.load(src + C, 3L * C, tb.tok, tok_base, kn0, N, &padk_piece, lane);
+            sv.load(src + 2 * C, 3L * C, tb.tok, tok_base, kn0, N, &padv_piece, lane);
         }
         int rkey[2] = {0, 0};
         if (masked) {
