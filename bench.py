@@ -133,6 +133,11 @@ def build(dev, drop_path, arch="swin_tiny_w7"):
     return student, teacher, loss
 
 
+def synthetic_crops(*a, **k):
+    from esvit_amd.data import synthetic_crops as f
+    return f(*a, **k)
+
+
 def _cpu_threads():
     # the small per-op tensors of this workload scale poorly past a few dozen threads (128 threads measured 5x slower than
     # 8), so the baseline uses at most 32 host threads and reports the count it used as `cores`
@@ -145,7 +150,6 @@ def _port_baseline(dense, bs, steps):
     """oracle/esvit_oracle.py (restatement of the reference's PyTorch path): one full step = teacher fwd, student fwd, loss,
     backward, clip + AdamW + EMA, centre update; fp32"""
     from oracle import esvit_oracle as O
-    from tests import golden_utils as GU
     import esvit_amd
     from esvit_amd import config as CFG
     torch.manual_seed(0)
@@ -160,7 +164,7 @@ def _port_baseline(dense, bs, steps):
     params = {n: sd[n] for n in all_names}
     teacher = {n: sd[n].clone() for n in all_names}
     reg = {n for n in names if not (n.endswith(".bias") or sd[n].ndim == 1)}
-    crops = GU.make_crops(bs) if dense else GU.make_crops(bs)[:2]
+    crops = synthetic_crops(bs) if dense else synthetic_crops(bs)[:2]
     ncrops = len(crops)
     c0, cg0 = torch.zeros(1, OUT_DIM), torch.zeros(1, OUT_DIM)
     state = {}
@@ -174,8 +178,8 @@ def _port_baseline(dense, bs, steps):
         tfull = dict(sd)
         tfull.update(teacher)
         with torch.no_grad():
-            t_out = O.swin_multicrop(tfull, crops[:2], GU.SWIN_T, dense=dense)
-        s_out = O.swin_multicrop(full, crops, GU.SWIN_T, dense=dense)
+            t_out = O.swin_multicrop(tfull, crops[:2], O.SWIN_T, dense=dense)
+        s_out = O.swin_multicrop(full, crops, O.SWIN_T, dense=dense)
         if dense:
             loss, bc, bg = O.ddino_loss(s_out, t_out, c0, cg0, 0.04, ncrops)
         else:
@@ -197,7 +201,6 @@ def _reference_baseline(dense, bs, steps):
     torch.optim.AdamW over utils.get_params_groups, the EMA loop of main_esvit.py:587-590) imported from /root/reference under
     the shims of SURVEY.md 8c; fp32 (the CPU path of main_esvit.py:541-574 with fp16_scaler None)"""
     from oracle import ref_loader as RL
-    from tests import golden_utils as GU
     ns = RL.load()
     RL.ensure_single_process_group()
     torch.manual_seed(0)
@@ -213,7 +216,7 @@ def _reference_baseline(dense, bs, steps):
     teacher.load_state_dict(student.state_dict())
     for p in teacher.parameters():
         p.requires_grad = False
-    crops = GU.make_crops(bs) if dense else GU.make_crops(bs)[:2]
+    crops = synthetic_crops(bs) if dense else synthetic_crops(bs)[:2]
     loss_fn = (ns.DDINOLoss if dense else ns.DINOLoss)(OUT_DIM, len(crops), 0.04, 0.04, 0, 100)
     opt = torch.optim.AdamW(ns.utils.get_params_groups(student))
     for i, pg in enumerate(opt.param_groups):
@@ -261,7 +264,6 @@ def torch_eager_gpu_baseline(dev, bs, steps=5):
     like cpu_baseline (the oracle is the thing compared against, never part of the measured product path); off unless
     --torch-eager is given, never part of `value`."""
     from oracle import esvit_oracle as O
-    from tests import golden_utils as GU
     import esvit_amd
     from esvit_amd import config as CFG
     torch.manual_seed(0)
@@ -275,7 +277,7 @@ def torch_eager_gpu_baseline(dev, bs, steps=5):
     params = {n: sd[n] for n in all_names}
     teacher = {n: sd[n].clone() for n in all_names}
     reg = {n for n in names if not (n.endswith(".bias") or sd[n].ndim == 1)}
-    crops = [c.to(dev) for c in GU.make_crops(bs)]
+    crops = [c.to(dev) for c in synthetic_crops(bs)]
     c0, cg0 = torch.zeros(1, OUT_DIM, device=dev), torch.zeros(1, OUT_DIM, device=dev)
     state = {}
 
@@ -289,8 +291,8 @@ def torch_eager_gpu_baseline(dev, bs, steps=5):
         tfull.update(teacher)
         with torch.autocast("cuda", dtype=torch.bfloat16):
             with torch.no_grad():
-                t_out = O.swin_multicrop(tfull, crops[:2], GU.SWIN_T)
-            s_out = O.swin_multicrop(full, crops, GU.SWIN_T)
+                t_out = O.swin_multicrop(tfull, crops[:2], O.SWIN_T)
+            s_out = O.swin_multicrop(full, crops, O.SWIN_T)
             loss, bc, bg = O.ddino_loss(s_out, t_out, c0, cg0, 0.04, 10)
         loss.backward()
         with torch.no_grad():
@@ -353,7 +355,6 @@ def main():
     import esvit_amd
     from esvit_amd import ops
     from esvit_amd.engine import EsvitTrainer
-    from tests import golden_utils as GU
     esvit_amd.set_precision("bf16")
     torch.manual_seed(0)  # identical replicas ...
     student, teacher, loss_fn = build(dev, args.drop_path, args.arch)
@@ -363,7 +364,7 @@ def main():
     trainer = EsvitTrainer(student, teacher, loss_fn, clip_grad=3.0, freeze_last_layer=1, teacher_stream=not args.single_stream,
                            grad_payload=args.grad_payload)
     B = args.batch
-    crops = [c.to(dev) for c in GU.make_crops(B, seed=1234 + rank)]
+    crops = [c.to(dev) for c in synthetic_crops(B, seed=1234 + rank)]
     # constants from the first post-warm-up iteration of the reference schedules
     lr, wd, mom, epoch = 5e-4 * B * world / 256.0, 0.04, 0.996, 1
 

@@ -654,11 +654,8 @@ template <int C, int NWIN, bool SAVE>
 int launch_ab(const ABParams& prm, hipStream_t stream) {
     using AC = ABCfg<C, NWIN>;
     auto k = attn_branch_fwd_kernel<C, NWIN, SAVE>;
-    static bool done = false;
-    if (!done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, AC::LDS);
-        done = true;
-    }
+    static unsigned long long lds_set = 0;
+    esvit_raise_lds(k, AC::LDS, lds_set);
     const int groups = (prm.Bw + NWIN - 1) / NWIN;
     const int per_cu = AC::LDS * 2 <= 160 * 1024 ? 2 : 1;  // persistent workgroups: as many as the LDS of the 256 CUs holds
     const int grid = groups < 256 * per_cu ? groups : 256 * per_cu;

@@ -281,5 +281,20 @@ __device__ __forceinline__ float qgelu_grad_f(float x) {
 
 static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
 
+// One-time raise of a kernel's dynamic-LDS cap, per DEVICE: the attribute lives with the device's copy of the code object, so a
+// process that drives a second GPU (tests, a single-process launcher) must set it there too.  `mask`: one static word per kernel
+// instantiation at the call site (bit = device ordinal).
+template <typename K>
+static inline void esvit_raise_lds(K kern, int bytes, unsigned long long& mask) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(mask & bit)) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        mask |= bit;
+    }
+}
+
+
 // out[c] (+)= sum_b ws[b*ld + c], c < ncols  (elementwise.hip) -- second stage of every two-stage column reduction
 int esvit_partial_reduce(const float* ws, int nblk, int ncols, long ld, float* out, int accumulate, hipStream_t stream);

@@ -601,11 +601,8 @@ extern "C" int esvit_dwconv3x3_wgrad(int dtype, const void* x, const void* dy, i
         const int cvn = C / 8;
         const dim3 blk(cvn, 256 / cvn > 0 ? 256 / cvn : 1);
         const size_t lds_s = (size_t)blk.x * blk.y * 72 * sizeof(float);
-        static bool attr_done = false;
-        if (!attr_done) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dwconv3x3_wgrad_strip_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 73728);
-            attr_done = true;
-        }
+        static unsigned long long lds_set = 0;
+        esvit_raise_lds(dwconv3x3_wgrad_strip_kernel, 73728, lds_set);
         hipLaunchKernelGGL(dwconv3x3_wgrad_strip_kernel, dim3(nblk), blk, lds_s, stream, reinterpret_cast<const bf16*>(x),
                            reinterpret_cast<const bf16*>(dy), nB, H, W, C, ws);
         ESVIT_CHECK_LAUNCH("dwconv3x3_wgrad(strip)");

@@ -1195,11 +1195,8 @@ int launch_gemm(const esvit_gemm_desc& d, hipStream_t stream) {
     const size_t stage_bytes = 4 * 32 * (size_t)(BN / 2 + 4) * sizeof(float);
     if (lds < stage_bytes) lds = stage_bytes;
     auto kern = gemm_kernel<T, AKS, BKS, BM, BN, USE_TR>;
-    static bool attr_done = false;  // one-time raise of the dynamic LDS cap (per instantiation; idempotent)
-    if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_done = true;
-    }
+    static unsigned long long lds_set = 0;  // one-time raise of the dynamic LDS cap (per instantiation and device; idempotent)
+    esvit_raise_lds(kern, (int)lds, lds_set);
     const int tiles = ceil_div(d.M, BM) * ceil_div(d.N, BN);
     const int nz = d.splitk > 1 ? d.splitk : d.batch;
     hipLaunchKernelGGL(kern, dim3(tiles, nz), dim3(NTHREADS), lds, stream, d);
@@ -1217,11 +1214,8 @@ int launch_gemm_dma(const esvit_gemm_desc& d, hipStream_t stream) {
     const size_t stage_bytes = (size_t)WM * WN * 16 * (size_t)(BN / WN + 4) * sizeof(float);  // epilogue staging, one region per wave
     if (lds < stage_bytes) lds = stage_bytes;
     auto kern = gemm_dma_kernel<AKS, BKS, BM, BN, BKD, NBUF, WM, WN, MINB, EARLY>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_done = true;
-    }
+    static unsigned long long lds_set = 0;
+    esvit_raise_lds(kern, (int)lds, lds_set);
     const int tiles = ceil_div(d.M, BM) * ceil_div(d.N, BN);
     const int nz = d.splitk > 1 ? d.splitk : d.batch;
     // Work order (measured on the step's shapes, profiles/r02_gemm_workorder_ab.txt):

@@ -552,11 +552,8 @@ template <bool AKS, bool BKS, int EPI>
 int launch_p8(const esvit_gemm_desc& d, bool epi_fast, hipStream_t stream) {
     auto kern = gemm_p8_kernel<AKS, BKS, EPI>;
     constexpr int lds = 2 * P8_BUF;
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr_done = true;
-    }
+    static unsigned long long lds_set = 0;
+    esvit_raise_lds(kern, lds, lds_set);
     const int tm_ = ceil_div(d.M, 256), tn_ = ceil_div(d.N, 256);
     const int nz = d.splitk > 1 ? d.splitk : d.batch;
     int group_m = 1;

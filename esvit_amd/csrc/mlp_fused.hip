@@ -355,11 +355,8 @@ int launch_mlp(const float* x, const float* gamma, const float* beta, float eps,
     const int grid = ceil_div(M, MLP_ROWS);
     const size_t lds = FwdCfg<C>::LDS_BYTES;
     auto kern = mlp_fused_fwd_kernel<C, LNN>;
-    static bool done = false;  // one-time raise of the dynamic LDS cap (idempotent)
-    if (!done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        done = true;
-    }
+    static unsigned long long lds_set = 0;  // one-time raise of the dynamic LDS cap (per device; idempotent)
+    esvit_raise_lds(kern, (int)lds, lds_set);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(MLP_WAVES * 64), lds, stream, x, gamma, beta, eps, (const bf16*)W1, b1, (const bf16*)W2, b2,
                        rowscale, M, y, gamma_n, beta_n, (bf16*)xw_n, mean_n, rstd_n);
     ESVIT_CHECK_LAUNCH("esvit_mlp_fused_fwd");

@@ -429,11 +429,6 @@ __global__ __launch_bounds__(256) void cast_weight_kernel(const float* __restric
     }
 }
 
-template <typename K>
-void raise_lds(K kern, size_t lds) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-}
-
 }  // namespace
 
 #define AL16(p_) (((uintptr_t)(p_) % 16) == 0)
@@ -451,14 +446,14 @@ int esvit_i_mlp16_fwd(const float* x, const float* gamma, const float* beta, flo
         const int grid = ceil_div(M, 16 * NW_);                                                                                          \
         if (lnn) {                                                                                                                       \
             auto k = fwd16_kernel<C_, NW_, true, WPS_>;                                                                                  \
-            static bool done = false;                                                                                                    \
-            if (!done) { raise_lds(k, lds); done = true; }                                                                               \
+            static unsigned long long lds_set = 0;                                                                                       \
+            esvit_raise_lds(k, (int)lds, lds_set);                                                                                       \
             hipLaunchKernelGGL(k, dim3(grid), dim3(NW_ * 64), lds, stream, x, gamma, beta, eps, (const bf16*)W1p, b1, (const bf16*)W2,   \
                                b2, rowscale, M, y, gn, bn, (bf16*)xw, mn, rn);                                                           \
         } else {                                                                                                                         \
             auto k = fwd16_kernel<C_, NW_, false, WPS_>;                                                                                 \
-            static bool done = false;                                                                                                    \
-            if (!done) { raise_lds(k, lds); done = true; }                                                                               \
+            static unsigned long long lds_set = 0;                                                                                       \
+            esvit_raise_lds(k, (int)lds, lds_set);                                                                                       \
             hipLaunchKernelGGL(k, dim3(grid), dim3(NW_ * 64), lds, stream, x, gamma, beta, eps, (const bf16*)W1p, b1, (const bf16*)W2,   \
                                b2, rowscale, M, y, nullptr, nullptr, nullptr, nullptr, nullptr);                                         \
         }                                                                                                                                \
@@ -480,8 +475,8 @@ int esvit_i_mlp16_bwd(const float* x, const float* gy, const float* rs_mlp, cons
         constexpr size_t lds = NB_ * (2 * Cfg16<C_>::A_BYTES + Cfg16<C_>::B_BYTES + 1024);                                               \
         const int grid = ceil_div(M, 16 * NW_);                                                                                          \
         auto k = bwd16_kernel<C_, NW_, NB_, WPS_>;                                                                                       \
-        static bool done = false;                                                                                                        \
-        if (!done) { raise_lds(k, lds); done = true; }                                                                                   \
+        static unsigned long long lds_set = 0;                                                                                           \
+        esvit_raise_lds(k, (int)lds, lds_set);                                                                                           \
         hipLaunchKernelGGL(k, dim3(grid), dim3(NW_ * 64), lds, stream, x, gy, rs_mlp, rs_out, gamma, beta, eps, (const bf16*)W1p,        \
                            (const bf16*)W2Tp, (const bf16*)W1T, b1, M, gx, (bf16*)gxa, (bf16*)xhat, (bf16*)a1g, (bf16*)da1);             \
     } while (0)

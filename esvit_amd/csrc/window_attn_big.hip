@@ -349,7 +349,7 @@ __global__ __launch_bounds__(FWD3_WAVES * 64, sizeof(T) == 2 ? (HD == 32 ? 4 : 2
         }
         if (pass == 0 && ((live >> (wave + FWD3_WAVES)) & 1)) sq.load(src, 3L * C, tb.tok, tok_base, 16 * (wave + FWD3_WAVES), N, &padq, lane);
         if (!tile_live) {
-            if (g == 0 && lse_out) lse_out[(long)unit * NPB + q0 + c] = 0.f;  // (never read: the backward skips the same tiles)
+            if (g == 0 && lse_out) lse_out[(long)unit * NPB + q0 + c] = 0.f;  // (a placeholder: the backward kernels skip these tiles or replace the value, attn_big_bwd_dkv2)
             continue;
         }
         const int rq = masked ? ((tb.pk[q0 + c] >> 16) & 0xff) : 0;
@@ -630,6 +630,9 @@ __global__ __launch_bounds__((BigCfg<T, HD>::WAVES * 64), ((sizeof(T) == 2 && HD
                     }
                 }
             }
+            // a dead query tile (no live token: the forward skipped it and left lse = 0) contributes P = exp(s - lse) = 0 in BOTH forms of
+            // the block below -- the full form walks dead tiles too, and with lse = 0 an s > 88 there would be inf * (dO = 0) = NaN
+            if (!((live >> (t >> 4)) & 1)) l = 3.0e38f;
             tb.lse[t] = l;
             tb.delta[t] = d;
         }

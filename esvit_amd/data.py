@@ -26,6 +26,15 @@ P_FLIP, P_JITTER, P_GRAY = 0.5, 0.8, 0.2  # build.py:207-212
 BLUR_RADIUS = (0.1, 2.0)  # utils.py:47
 
 
+def synthetic_crops(B, n_local=8, seed=1234, sizes=(224, 96)):
+    """torch.randn multi-crop batch in the reference's list order [global, global, local x n_local] (main_esvit.py:513: ten
+    tensors, 2 x (B,3,224,224) + 8 x (B,3,96,96)): the synthetic input of bench.py, of smoke() and of the parity tests."""
+    g = torch.Generator().manual_seed(seed)
+    crops = [torch.randn(B, 3, sizes[0], sizes[0], generator=g) for _ in range(2)]
+    crops += [torch.randn(B, 3, sizes[1], sizes[1], generator=g) for _ in range(n_local)]
+    return crops
+
+
 def box_blur_weights(radius, passes=3):
     """Pillow's BoxBlur.c for ``ImageFilter.GaussianBlur(radius)``: the box radius of each of the three passes (float variables,
     double expressions) and ImagingHorizontalBoxBlur's integer radius / 24-bit weights -> (r, ww, fw) of esvit_aug_crops;

@@ -302,6 +302,7 @@ def train_one_epoch(student, teacher, teacher_without_ddp, dino_loss, data_loade
     loss_sum = torch.zeros((), dtype=torch.float32, device=dev)
     last = None
     last_look = -1  # iteration of the previous look at the loss / the refused-update counter
+    win_refused = win_seen = 0  # consecutive looks in which every update was refused: refusals / updates in them
     for it, (images, _) in enumerate(data_loader):
         git = n_it * epoch + it
         images = [im.cuda(non_blocking=True) for im in images]
@@ -334,10 +335,17 @@ def train_one_epoch(student, teacher, teacher_without_ddp, dino_loss, data_loade
             refused = tr.updater.take_skipped()
             since = it - last_look  # updates launched since the previous look (the first look of an epoch follows one update)
             last_look = it
+            # stop only on a full window of refusals: looks can be 1-9 iterations apart (the end-of-epoch look), and one transient
+            # bf16 overflow in such a short window is not "nothing but refusals" -- refusals accumulate across looks until at
+            # least 10 updates have been seen, a look with an accepted update in it clears the window
+            if refused < since:
+                win_refused = win_seen = 0
+            else:
+                win_refused, win_seen = win_refused + refused, win_seen + since
             if refused:
                 print("WARNING: %d of the last %d updates were skipped (non-finite gradients, finite loss)" % (refused, since))
-                if refused >= since and it > 0:
-                    print("every update since the last check was skipped, stopping training")
+                if win_seen >= 10 and win_refused >= win_seen:
+                    print("every one of the last %d updates was skipped, stopping training" % win_seen)
                     sys.exit(1)
     mean = loss_sum / max(n_it, 1)
     if _world() > 1:  # metric_logger.synchronize_between_processes (main_esvit.py:597)

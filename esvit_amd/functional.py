@@ -118,12 +118,13 @@ def _perm_w(p):
 ATTN_FUSED = os.environ.get("ESVIT_ATTN_FUSED", "1") != "0"  # (A-B runs switch back to the four-kernel sequence)
 
 
-def _attn_fused(dt, C, nH, geoms, save):
+def _attn_fused(dt, C, nH, geoms, save, sizes=None):
     """save: a training pass (side outputs on).  Measured on the MI355X (tools/bench_attn_branch.py, B = 128 row counts): without
     side outputs the kernel beats the four-kernel sequence at both widths (C = 96: 226 vs 610 us on the 224-crop rows; C = 192:
     226 vs 299); WITH the 10 B per token-channel of side outputs it still wins at C = 96 (387 + 309 vs ~900 us per block over both
     groups) and loses at C = 192 (292 + 283 vs ~470), so a training pass takes it at C = 96 only"""
-    if not (ATTN_FUSED and all(g.ws == 7 for g in geoms) and ops_module().attn_branch_supported(dt, C, nH, max(g.N for g in geoms))):
+    rows, wins = (max(r for r, _ in sizes), max(w for _, w in sizes)) if sizes else (0, 0)  # (token rows, windows) of the largest call
+    if not (ATTN_FUSED and all(g.ws == 7 for g in geoms) and ops_module().attn_branch_supported(dt, C, nH, max(g.N for g in geoms), rows, wins)):
         return False
     return C == 96 or not save
 
@@ -170,7 +171,7 @@ def _block_forward(x, geom, nH, index, dp, prm, wts, save, w1p=None, wattn=None)
     # everything stays in token order: the attention kernel applies pad/roll/partition through geom.win2tok and
     # injects the qkv bias at zero-pad slots, so no GEMM ever runs on pad rows
     frag = o.new_bias_frag(nH, geom.N, x.device) if save else None  # kept for the backward (no second fill)
-    if wattn is not None and _attn_fused(Wqkv.dtype, C, nH, (geom,), save):
+    if wattn is not None and _attn_fused(Wqkv.dtype, C, nH, (geom,), save, [(nB * L, nB * geom.nW)]):
         rs1 = None if dp1 is None else dp1.repeat_interleave(L)
         res = o.attn_branch_fwd(x2d, g1, b1, LN_EPS, _perm_w(wattn[0]), bqkv, _perm_w(wattn[1]), bproj, geom.win2tok, L, table, geom.ws, geom.region_ids,
                                 geom.nW, geom.N, nH, scale, rowscale=rs1, bias_frag=frag, save=bool(save))
@@ -272,7 +273,7 @@ def _block_forward_multi(X, segs, nH, dp_rows, prm, wts, save, pre=None, next_no
     M, C = X.shape
     scale = (C // nH) ** -0.5
     dp1, dp2 = (None, None) if dp_rows is None else dp_rows
-    fused_attn = wattn is not None and _attn_fused(Wqkv.dtype, C, nH, [sg[3] for sg in segs], save)
+    fused_attn = wattn is not None and _attn_fused(Wqkv.dtype, C, nH, [sg[3] for sg in segs], save, [(sg[1] * sg[2], sg[1] * sg[3].nW) for sg in segs])
     lses, frags = [], {}
     if fused_attn:
         # the whole branch in one kernel per resolution group; `pre` (the LayerNorm output the previous block's fused MLP kernel may

@@ -653,9 +653,12 @@ def window_attn_fwd(qkv, qkv_bias, win2tok, L, rel_table, ws, region_ids, nW, N,
     return (out, lse, attn) if want_attn else (out, lse)
 
 
-def attn_branch_supported(dt, Cc, nH, N):
-    """the fused attention branch (esvit_attn_branch_fwd) exists for this shape: bf16, head_dim 32, C in {96, 192}, <= 64-token windows"""
-    return dt == torch.bfloat16 and Cc in (96, 192) and Cc == 32 * nH and N <= 64
+def attn_branch_supported(dt, Cc, nH, N, rows=0, windows=0):
+    """the fused attention branch (esvit_attn_branch_fwd) exists for this shape: bf16, head_dim 32, C in {96, 192}, <= 64-token windows,
+    and -- when given -- a call of `rows` token rows / `windows` windows stays inside the kernel's 2 GiB buffer ranges and 2^22-window
+    limit (esvit_hip.h), so that an oversized per-GPU batch takes the four-kernel sequence instead of raising"""
+    return (dt == torch.bfloat16 and Cc in (96, 192) and Cc == 32 * nH and N <= 64
+            and rows * 3 * Cc * 2 < 0x7fff0000 and rows * Cc * 4 < 0x7fff0000 and windows < (1 << 22))
 
 
 def attn_branch_fwd(x, gamma, beta, eps, Wqkv_p, bqkv, Wproj_p, bproj, win2tok, L, rel_table, ws, region_ids, nW, N, nH, scale, *,

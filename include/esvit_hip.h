@@ -282,7 +282,8 @@ int esvit_attn_branch_fwd(int dtype, const float* x, const float* gamma, const f
  * lse fp32 [nB*nW*nH, ESVIT_Q_ATTN_LSE_ELEMS(N)]: per-query log-sum-exp, written for 14x14 windows (the blocked
  * backward needs it), unused (may be NULL) for 7x7.  Without attn_out, the 16-slot query tiles of a window that hold no live
  * token (win2tok < 0 in all 16 slots: the padding of a 96^2 crop's window) are not computed -- their output rows do not exist and
- * their lse entries read 0; esvit_window_attn_bwd skips the same tiles.  One image's qkv rows (L * 3C activations) must fit a 2 GiB buffer
+ * their lse entries read 0 (a placeholder: esvit_window_attn_bwd either skips the same tiles or treats them as P = 0, it never exponentiates
+ * against that 0).  One image's qkv rows (L * 3C activations) must fit a 2 GiB buffer
  * descriptor.
  * attn_out (optional, fp32 [nB*nW,nH,N,N]) receives the softmax (swin_transformer.py:146,152). 
  * N <= 64: head_dim 32 or 64.  64 < N <= 224: head_dim 32, or 64 in bf16 -- the head_dim-64 instances (whole ViT crops: one window per

@@ -189,7 +189,7 @@ def colsum(x, *, out=None, accumulate=False):
 
 
 # ---- fused attention branch (esvit_attn_branch_fwd): the unfused sequence it replaces, same rounding points -------------------
-def attn_branch_supported(dt, Cc, nH, N):
+def attn_branch_supported(dt, Cc, nH, N, rows=0, windows=0):
     return dt == torch.bfloat16 and Cc in (96, 192) and Cc == 32 * nH and N <= 64
 
 

@@ -46,11 +46,9 @@ def fill_state_dict(sd, seed=0):
 
 
 def make_crops(B, n_local=8, seed=1234, sizes=(224, 96)):
-    """torch.randn crops, list order [g, g, l x n_local]."""
-    g = torch.Generator().manual_seed(seed)
-    crops = [torch.randn(B, 3, sizes[0], sizes[0], generator=g) for _ in range(2)]
-    crops += [torch.randn(B, 3, sizes[1], sizes[1], generator=g) for _ in range(n_local)]
-    return crops
+    """torch.randn crops, list order [g, g, l x n_local]: the package's generator, so that bench.py needs nothing from tests/."""
+    from esvit_amd.data import synthetic_crops
+    return synthetic_crops(B, n_local=n_local, seed=seed, sizes=sizes)
 
 
 def probe(t, n=16):

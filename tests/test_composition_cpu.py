@@ -671,7 +671,7 @@ def test_fused_attention_branch_host_logic_matches_reference_golden(cpu_ops, mon
     stages 0 and 1 (no side outputs), the student in stage 0 (C = 96) with side outputs"""
     import esvit_amd.functional as Fn
     from tests.test_step_gpu import FULL_GOLD, full_case_deltas, run_full_case
-    monkeypatch.setattr(ops_ref, "attn_branch_supported", lambda dt, C, nH, N: C in (96, 192) and C == 32 * nH and N <= 64)
+    monkeypatch.setattr(ops_ref, "attn_branch_supported", lambda dt, C, nH, N, rows=0, windows=0: C in (96, 192) and C == 32 * nH and N <= 64)
     calls = {"plain": 0, "save": 0}
     f0 = ops_ref.attn_branch_fwd
 

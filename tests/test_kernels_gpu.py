@@ -563,6 +563,46 @@ def test_attn_branch_fwd_is_bit_reproducible(mods, nH, H, shift, nB):
                 assert torch.equal(a, b), "tensor %d differs between launch 0 and launch %d" % (i, rep)
 
 
+@pytest.mark.parametrize("ws,H,shift,nH,nB", [(7, 56, 3, 3, 48), (7, 14, 3, 12, 160), (14, 28, 7, 6, 48), (14, 12, 0, 12, 96)])
+def test_window_attention_is_bit_reproducible(mods, ws, H, shift, nH, nB):
+    """the 7x7 and 14x14 window-attention forward and backward (bf16) at full occupancy, 12 launches each on the same inputs: every
+    output identical to the bit.  Their 16-byte row stores pack two accumulator tiles through the v_permlane16_swap BUILTIN
+    (common.h: esvit_pack_tile_pair_bf16; the integer uses the hazard recogniser pads itself) -- the float butterflies that gave
+    run-to-run differences in round 5 were a different use of the instruction (common.h: swap16 / swap32) and live in the fused
+    branch only.  This is the check that the store path of these kernels is deterministic under load."""
+    ops, _ = mods
+    dev = _dev()
+    old = ops.act_dtype()
+    ops.set_act_dtype(torch.bfloat16)
+    try:
+        _window_attention_repro(ops, dev, ws, H, shift, nH, nB)
+    finally:
+        ops.set_act_dtype(old)
+
+
+def _window_attention_repro(ops, dev, ws, H, shift, nH, nB):
+    hd = 32
+    N, C, L = ws * ws, nH * hd, H * H
+    w2t = torch.from_numpy(ops.window_maps(H, H, ws, shift)[0]).to(dev)
+    nW = w2t.numel() // N
+    regions = torch.from_numpy(ops.shift_region_ids(H, H, ws, shift)).to(dev) if shift else None
+    qkv = _rand((nB * L, 3 * C), dev, 80, torch.bfloat16)
+    qb = _rand((3 * C,), dev, 81) * 0.5
+    table = _rand(((2 * ws - 1) ** 2, nH), dev, 82) * 0.5
+    dout = _rand((nB * L, C), dev, 83, torch.bfloat16)
+    first = None
+    for rep in range(12):
+        o, lse = ops.window_attn_fwd(qkv, qb, w2t, L, table, ws, regions, nW, N, nH, hd ** -0.5)
+        dqkv, dbias_ws, dpad_ws = ops.window_attn_bwd(qkv, qb, w2t, L, dout, o, lse, table, ws, regions, nW, N, nH, hd ** -0.5)
+        cur = [o, dqkv, dbias_ws, dpad_ws] + ([lse] if lse is not None else [])
+        assert all(bool(torch.isfinite(t.float()).all()) for t in cur)
+        if first is None:
+            first = [t.clone() for t in cur]
+        else:
+            for i, (a, b) in enumerate(zip(cur, first)):
+                assert torch.equal(a, b), "tensor %d differs between launch 0 and launch %d" % (i, rep)
+
+
 @pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("geom", ["vit37_h3", "vit37_h6", "cvt56_h1", "cvt28_h3", "swin56_h3_hd32", "w14map6_h12_hd32", "w14map24_h3_hd32"])
 def test_window_attention_full_occupancy(mods, dt, geom):
