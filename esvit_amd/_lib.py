@@ -48,6 +48,7 @@ SIGNATURES = {
     "esvit_gemm": (C.c_int, [C.c_int, C.POINTER(GemmDesc), vp]),
     "esvit_gemm_select": (C.c_int, [C.c_int, C.POINTER(GemmDesc), vp, vp, vp]),
     "esvit_mlp_fused_fwd": (C.c_int, [C.c_int, vp, vp, vp, f32, vp, vp, vp, vp, vp, i64, C.c_int, vp, vp, vp, vp, vp, vp, vp]),
+    "esvit_mlp_fused_fwd_train": (C.c_int, [C.c_int, vp, vp, vp, f32, vp, vp, vp, vp, vp, i64, C.c_int, vp, vp, vp, vp, vp, vp, vp]),
     "esvit_mlp_fused_bwd": (C.c_int, [C.c_int, vp, vp, vp, vp, vp, vp, f32, vp, vp, vp, vp, i64, C.c_int, vp, vp, vp, vp, vp, vp]),
     "esvit_ln_fold_finish": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, vp, vp, C.c_int, vp]),
     "esvit_mlp_fused_weight": (C.c_int, [C.c_int, vp, vp, C.c_int, vp]),

@@ -407,8 +407,14 @@ __global__ __launch_bounds__(1024) void ln_fold_finish_kernel(float* __restrict_
 // esvit_query(ESVIT_Q_MLP_FUSED): bit 0 = esvit_mlp_fused_fwd exists, bit 1 = esvit_mlp_fused_bwd exists
 int esvit_i_mlp_fused_supported(int dtype, int C) {
     if (dtype != ESVIT_BF16) return 0;
+    if (C == 384) return 1;  // mlp_fused32p.hip: forward (inference pass; the training pass has its own entry point, esvit_mlp_fused_fwd_train)
     return (C == 96 || C == 192) ? 3 : 0;
 }
+
+// third generation (mlp_fused32p.hip): C = 384
+int esvit_i_mlp32p_fwd(const float* x, const float* gamma, const float* beta, float eps, const void* W1, const float* b1, const void* W2,
+                       const float* b2, const float* rowscale, long M, int C, float* y, void* a1, void* a1g, void* h, float* mean, float* rstd,
+                       hipStream_t stream);
 
 // second generation (mlp_fused16.hip)
 int esvit_i_mlp16_fwd(const float* x, const float* gamma, const float* beta, float eps, const void* W1p, const float* b1, const void* W2,
@@ -425,7 +431,7 @@ extern "C" int esvit_mlp_fused_fwd(int dtype, const float* x, const float* gamma
                                    float* y, const float* gamma_next, const float* beta_next, void* xw_next, float* mean_next,
                                    float* rstd_next, esvit_stream_t s_) {
     hipStream_t stream = reinterpret_cast<hipStream_t>(s_);
-    ESVIT_CHECK_ARG(esvit_i_mlp_fused_supported(dtype, C) & 1, "esvit_mlp_fused_fwd: bf16 activations and C in {96, 192} only (C=%d)", C);
+    ESVIT_CHECK_ARG(esvit_i_mlp_fused_supported(dtype, C) & 1, "esvit_mlp_fused_fwd: bf16 activations and C in {96, 192, 384} only (C=%d)", C);
     ESVIT_CHECK_ARG(x && gamma && beta && W1 && b1 && W2 && b2 && y && M > 0, "esvit_mlp_fused_fwd: null pointer / empty input");
     ESVIT_CHECK_ARG(AL16(x) && AL16(y) && AL16(W1) && AL16(W2) && AL16(gamma) && AL16(beta) && AL16(b1) && AL16(b2),
                     "esvit_mlp_fused_fwd: operands must be 16-byte aligned");
@@ -433,10 +439,25 @@ extern "C" int esvit_mlp_fused_fwd(int dtype, const float* x, const float* gamma
     if (lnn)
         ESVIT_CHECK_ARG(beta_next && xw_next && mean_next && rstd_next && AL16(gamma_next) && AL16(beta_next) && AL16(xw_next),
                         "esvit_mlp_fused_fwd: the next-LayerNorm outputs come together (gamma, beta, xw, mean, rstd; 16-byte aligned)");
+    if (C == 384) {
+        ESVIT_CHECK_ARG(!lnn, "esvit_mlp_fused_fwd: C = 384 does not emit the next LayerNorm");
+        return esvit_i_mlp32p_fwd(x, gamma, beta, eps, W1, b1, W2, b2, rowscale, M, C, y, nullptr, nullptr, nullptr, nullptr, nullptr, stream);
+    }
     if (C == 96)  // 16 tokens per wave; W1 in the permuted channel order (ESVIT_MLP_W1_FWD of esvit_mlp_fused_weight)
         return esvit_i_mlp16_fwd(x, gamma, beta, eps, W1, b1, W2, b2, rowscale, M, C, y, gamma_next, beta_next, xw_next, mean_next, rstd_next, stream);
     return lnn ? launch_mlp<192, true>(x, gamma, beta, eps, W1, b1, W2, b2, rowscale, M, y, gamma_next, beta_next, xw_next, mean_next, rstd_next, stream)
                : launch_mlp<192, false>(x, gamma, beta, eps, W1, b1, W2, b2, rowscale, M, y, nullptr, nullptr, nullptr, nullptr, nullptr, stream);
+}
+
+extern "C" int esvit_mlp_fused_fwd_train(int dtype, const float* x, const float* gamma, const float* beta, float eps, const void* W1,
+                                         const float* b1, const void* W2, const float* b2, const float* rowscale, int64_t M, int C, float* y,
+                                         void* a1, void* a1g, void* h, float* mean, float* rstd, esvit_stream_t s_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(s_);
+    ESVIT_CHECK_ARG(dtype == ESVIT_BF16 && C == 384, "esvit_mlp_fused_fwd_train: bf16 activations and C = 384 only (C=%d)", C);
+    ESVIT_CHECK_ARG(x && gamma && beta && W1 && b1 && W2 && b2 && y && a1 && a1g && h && mean && rstd && M > 0, "esvit_mlp_fused_fwd_train: null pointer / empty input");
+    ESVIT_CHECK_ARG(AL16(x) && AL16(y) && AL16(W1) && AL16(W2) && AL16(gamma) && AL16(beta) && AL16(b1) && AL16(b2) && AL16(a1) && AL16(a1g) && AL16(h),
+                    "esvit_mlp_fused_fwd_train: operands must be 16-byte aligned");
+    return esvit_i_mlp32p_fwd(x, gamma, beta, eps, W1, b1, W2, b2, rowscale, M, C, y, a1, a1g, h, mean, rstd, stream);
 }
 
 extern "C" int esvit_mlp_fused_bwd(int dtype, const float* x, const float* gy, const float* rowscale_mlp, const float* rowscale_out,

@@ -489,9 +489,9 @@ int esvit_i_mlp16_bwd(const float* x, const float* gy, const float* rs_mlp, cons
 
 extern "C" int esvit_mlp_fused_weight(int kind, const float* src, void* dst_bf16, int C, esvit_stream_t s_) {
     // the four weight copies of the fused branch; which generation consumes a copy decides its channel order (mlp_fused.hip entry points)
-    ESVIT_CHECK_ARG(C == 96 || C == 192, "esvit_mlp_fused_weight: C in {96, 192} only (C=%d)", C);
+    ESVIT_CHECK_ARG(C == 96 || C == 192 || (C == 384 && kind == ESVIT_MLP_W1_FWD), "esvit_mlp_fused_weight: C in {96, 192} (and the forward's copy at 384) only (C=%d)", C);
     switch (kind) {
-        case ESVIT_MLP_W1_FWD: return esvit_cast_weight(src, dst_bf16, 4 * C, C, 0, C == 96, s_);   // fc1.weight [4C, C] for the forward
+        case ESVIT_MLP_W1_FWD: return esvit_cast_weight(src, dst_bf16, 4 * C, C, 0, C == 96, s_);   // fc1.weight [4C, C] for the forward (the plain cast above 96)
         case ESVIT_MLP_W1_BWD: return esvit_cast_weight(src, dst_bf16, 4 * C, C, 0, 1, s_);          // ... for the backward
         case ESVIT_MLP_W1T_BWD: return esvit_cast_weight(src, dst_bf16, 4 * C, C, 1, 0, s_);         // fc1.weight^T [C, 4C]
         case ESVIT_MLP_W2T_BWD: return esvit_cast_weight(src, dst_bf16, C, 4 * C, 1, 1, s_);         // fc2.weight^T [4C, C] from fc2.weight [C, 4C]

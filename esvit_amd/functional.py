@@ -136,6 +136,22 @@ def _attn_fused(dt, C, nH, geoms, save, sizes=None):
 MLP_FUSED_TRAIN = os.environ.get("ESVIT_MLP_FUSED_TRAIN", "1") != "0"  # (A-B runs switch the training path back to the unfused sequence)
 
 
+# the C = 384 branch: "0" the LayerNorm + two-GEMM sequence everywhere, "1" the fused kernel in inference passes (the EMA teacher), "2" also
+# in the training pass (esvit_mlp_fused_fwd_train)
+_WIDE = os.environ.get("ESVIT_MLP_WIDE_FUSED", "1")
+MLP_WIDE_FUSED = _WIDE != "0"
+MLP_WIDE_TRAIN = _WIDE == "2"
+
+
+def _mlp_wide_train(W1, C):
+    """the wide stage's training pass: forward fused (esvit_mlp_fused_fwd_train writes the operands of the unfused backward)"""
+    return MLP_WIDE_TRAIN and ops_module().mlp_fused_train_supported(W1.dtype, C)
+
+
+def _mlp_fused_infer(W1, C):
+    return ops_module().mlp_fused_supported(W1.dtype, C) and (MLP_WIDE_FUSED or C != 384)
+
+
 def _mlp_fused_train(W1, C):
     return MLP_FUSED_TRAIN and ops_module().mlp_fused_supported(W1.dtype, C, backward=True)
 
@@ -186,11 +202,14 @@ def _block_forward(x, geom, nH, index, dp, prm, wts, save, w1p=None, wattn=None)
         qkv = o.linear_fwd(xw, Wqkv, bqkv)
         ao, lse = o.window_attn_fwd(qkv, bqkv, geom.win2tok, L, table, geom.ws, geom.region_ids, geom.nW, geom.N, nH, scale, bias_frag=frag)
         x1 = o.linear_fwd(ao, Wproj, bproj, residual=x2d, rowscale=dp1, rows_per_sample=L, out_f32=True)
-    if (not save and o.mlp_fused_supported(W1.dtype, C)) or (save and _mlp_fused_train(W1, C)):
+    if (not save and _mlp_fused_infer(W1, C)) or (save and _mlp_fused_train(W1, C)):
         rs2 = None if dp2 is None else dp2.repeat_interleave(L)  # (the fused kernels take per-row DropPath factors)
-        x2 = o.mlp_fused_fwd(x1, g2, b2, LN_EPS, _mlp_w(w1p, "MLP_W1_FWD"), bfc1, W2, bfc2, rowscale=rs2)
+        x2 = o.mlp_fused_fwd(x1, g2, b2, LN_EPS, W1 if C == 384 else _mlp_w(w1p, "MLP_W1_FWD"), bfc1, W2, bfc2, rowscale=rs2)
         saved = (mean1, rstd1, xw, qkv, ao, x1, lse, frag) if save else None
         return x2.view(nB, L, C), saved
+    elif save and _mlp_wide_train(W1, C):
+        rs2 = None if dp2 is None else dp2.repeat_interleave(L)
+        x2, a1, a1g, h, mean2, rstd2 = o.mlp_fused_fwd_train(x1, g2, b2, LN_EPS, W1, bfc1, W2, bfc2, rowscale=rs2)
     else:
         h, _, mean2, rstd2 = o.layernorm_fwd(x1, g2, b2, LN_EPS)
         if save:
@@ -317,15 +336,20 @@ def _block_forward_multi(X, segs, nH, dp_rows, prm, wts, save, pre=None, next_no
                                        out=ao[r0:r1], bias_frag=frags[(geom.ws, geom.N)])
             lses.append((lse, frags[(geom.ws, geom.N)]))
         x1 = o.linear_fwd(ao, Wproj, bproj, residual=X, rowscale=dp1, rows_per_sample=1, out_f32=True)
-    if (not save and o.mlp_fused_supported(W1.dtype, C)) or (save and _mlp_fused_train(W1, C)):
+    if (not save and _mlp_fused_infer(W1, C)) or (save and _mlp_fused_train(W1, C)):
         # narrow stage: LayerNorm -> fc1 + GELU -> fc2 + residual in one kernel, the hidden activation never reaches HBM (the
-        # training pass keeps x1 only: the backward recomputes)
+        # training pass keeps x1 only: the backward recomputes).  Wide stage (C = 384), inference pass: the same, without the next LayerNorm
         nxt = None
-        if next_norm is not None:
-            x2, nxt = o.mlp_fused_fwd(x1, g2, b2, LN_EPS, _mlp_w(w1p, "MLP_W1_FWD"), bfc1, W2, bfc2, rowscale=dp2, next_norm=(next_norm[0].detach(), next_norm[1].detach()))
+        w1k = W1 if C == 384 else _mlp_w(w1p, "MLP_W1_FWD")
+        if next_norm is not None and C != 384:
+            x2, nxt = o.mlp_fused_fwd(x1, g2, b2, LN_EPS, w1k, bfc1, W2, bfc2, rowscale=dp2, next_norm=(next_norm[0].detach(), next_norm[1].detach()))
         else:
-            x2 = o.mlp_fused_fwd(x1, g2, b2, LN_EPS, _mlp_w(w1p, "MLP_W1_FWD"), bfc1, W2, bfc2, rowscale=dp2)
+            x2 = o.mlp_fused_fwd(x1, g2, b2, LN_EPS, w1k, bfc1, W2, bfc2, rowscale=dp2)
         return x2, ((mean1, rstd1, xw, qkv, ao, x1) if save else None), lses, nxt
+    elif save and _mlp_wide_train(W1, C):
+        # wide stage, training pass: one kernel writes x2 and what the unfused backward below reads (LayerNorm output and statistics,
+        # pre-activation, GELU) in place of the LayerNorm launch and the two GEMM launches
+        x2, a1, a1g, h, mean2, rstd2 = o.mlp_fused_fwd_train(x1, g2, b2, LN_EPS, W1, bfc1, W2, bfc2, rowscale=dp2)
     else:
         h, _, mean2, rstd2 = o.layernorm_fwd(x1, g2, b2, LN_EPS)
         if save:

@@ -374,6 +374,28 @@ def mlp_fused_fwd(x, gamma, beta, eps, W1, b1, W2, b2, *, rowscale=None, next_no
     return y if next_norm is None else (y, (xw, mn, rn))
 
 
+def mlp_fused_fwd_train(x, gamma, beta, eps, W1, b1, W2, b2, *, rowscale=None):
+    """the wide-stage (C = 384) training pass: y as mlp_fused_fwd plus what the UNFUSED backward reads, written by the same kernel:
+    -> (y fp32 [M, C], a1 act [M, 4C] pre-activation, a1g act [M, 4C] GELU(a1), h act [M, C] LayerNorm(x), mean fp32 [M], rstd fp32 [M])"""
+    x, W1, W2 = _f32c(x), _actc(W1), _actc(W2)
+    M, Cc = x.shape
+    assert W1.shape == (4 * Cc, Cc) and W2.shape == (Cc, 4 * Cc) and W1.dtype == W2.dtype
+    y = torch.empty_like(x)
+    a1 = torch.empty((M, 4 * Cc), dtype=W1.dtype, device=x.device)
+    a1g = torch.empty_like(a1)
+    h = torch.empty((M, Cc), dtype=W1.dtype, device=x.device)
+    mean = torch.empty((M,), dtype=torch.float32, device=x.device)
+    rstd = torch.empty_like(mean)
+    check(lib.esvit_mlp_fused_fwd_train(_code(W1.dtype), _p(x), _p(_f32c(gamma)), _p(_f32c(beta)), eps, _p(W1), _p(_f32c(b1)), _p(W2), _p(_f32c(b2)),
+                                        _p(rowscale), M, Cc, _p(y), _p(a1), _p(a1g), _p(h), _p(mean), _p(rstd), _stream()), "mlp_fused_fwd_train")
+    return y, a1, a1g, h, mean, rstd
+
+
+def mlp_fused_train_supported(dt, Cc):
+    """esvit_mlp_fused_fwd_train exists for this width (bf16, C = 384: forward fused, backward through the GEMMs)"""
+    return dt == torch.bfloat16 and int(Cc) == 384 and mlp_fused_supported(dt, Cc)
+
+
 def cast_weight(w, transpose=False, perm32=False):
     """fp32 [R, S] -> bf16 ([S, R] if transpose), rows optionally in the 32-block channel order of the 16-token kernels"""
     w = _f32c(w)

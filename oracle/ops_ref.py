@@ -232,6 +232,18 @@ def mlp_fused_fwd(x, gamma, beta, eps, W1, b1, W2, b2, *, rowscale=None, next_no
     return y, (xw, mean, rstd)
 
 
+def mlp_fused_fwd_train(x, gamma, beta, eps, W1, b1, W2, b2, *, rowscale=None):
+    """the unfused training sequence esvit_mlp_fused_fwd_train replaces: (y, a1, a1g, h, mean, rstd)"""
+    h, _, mean, rstd = layernorm_fwd(x, gamma, beta, eps, dtype=W1.dtype)
+    a1g, a1 = linear_fwd(h, W1, b1, gelu=True, want_preact=True)
+    y = linear_fwd(a1g, W2, b2, residual=x, rowscale=rowscale, rows_per_sample=1, out_f32=True)
+    return y, a1, a1g, h, mean, rstd
+
+
+def mlp_fused_train_supported(dt, Cc):
+    return False  # (the restatement keeps the unfused sequence: tests call mlp_fused_fwd_train directly)
+
+
 def cast_transpose(w):
     return _r(w.float().t().contiguous(), torch.bfloat16 if _ACT_DTYPE == torch.bfloat16 else torch.float32)
 

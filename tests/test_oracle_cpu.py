@@ -205,7 +205,7 @@ def test_lib_exports_every_declared_symbol(lib_built):
     hdr = open(os.path.join(root, "include", "esvit_hip.h")).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
     declared = set(re.findall(r"\b(esvit_[a-z0-9_]+)\s*\(", hdr))
-    assert 40 <= len(declared) <= 58, len(declared)  # the ABI is meant to stay this small (the step, the crop producer, ViT / ViL attention: 57 in round 3)
+    assert 40 <= len(declared) <= 60, len(declared)  # the ABI is meant to stay this small (the step, the crop producer, ViT / ViL attention: 57 in round 3, 59 with the wide MLP's training entry)
     lib = ctypes.CDLL(lib_built)
     missing = [n for n in sorted(declared) if not hasattr(lib, n)]
     assert not missing, missing
