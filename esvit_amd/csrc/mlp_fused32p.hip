@@ -258,6 +258,10 @@ __device__ __forceinline__ void mlp32p_fwd_body(const P32Args& A) {
         }
     }
 
+    // side outputs (training pass): one descriptor per tensor, per-lane byte offset of this lane's 32 bytes of chunk 0 (out of range for rows past M)
+    const __amdgpu_buffer_rsrc_t ra1 = p32_rsrc(A.a1, SIDE ? A.M * H4 * 2 : 0), ra1g = p32_rsrc(A.a1g, SIDE ? A.M * H4 * 2 : 0);
+    const unsigned side_off = row_ok ? (unsigned)(row * (H4 * 2) + 32 * hh) : 0x80000000u;  // (the tensors are below 2 GiB: the host checks)
+
     f32x16 acc[Cf::NT2];  // y^T: tile mt, register i <-> channel 32 mt + 16 hh + i of token n
 #pragma unroll
     for (int t = 0; t < Cf::NT2; ++t)
@@ -407,26 +411,42 @@ __device__ __forceinline__ void mlp32p_fwd_body(const P32Args& A) {
             }
             __builtin_amdgcn_sched_barrier(0);
         });
-        if constexpr (GL && SIDE) {
-            // chunk q of the side outputs: hidden units 32 q + 16 hh + 0 .. 15 of token n (two 16-byte stores per tensor and lane)
-            if (row_ok) {
-                bf16* pa = A.a1 + row * H4 + q * P32_HCH + 16 * hh;
-                bf16* pg = A.a1g + row * H4 + q * P32_HCH + 16 * hh;
+        constexpr bool STORES = GL && SIDE;
+        if constexpr (STORES) {
+            // chunk q of the side outputs: hidden units 32 q + 16 hh + 0 .. 15 of token n (two 16-byte stores per tensor and lane).  Buffer stores:
+            // rows past M fall outside the descriptors' ranges, so every wave issues exactly four store instructions per iteration and the
+            // counted wait below can leave them in flight (vmcnt retires in order: the DMA pieces issued before them have landed)
+            const unsigned so = side_off + (unsigned)(q * P32_HCH * 2);
 #pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    bf16x8 pre;
+            for (int t = 0; t < 2; ++t) {
+                bf16x8 pre;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) pre[e] = (bf16)P_in[8 * t + e];
-                    *reinterpret_cast<bf16x8*>(pa + 8 * t) = pre;
-                    *reinterpret_cast<bf16x8*>(pg + 8 * t) = H_out[t];
+                for (int e = 0; e < 8; ++e) pre[e] = (bf16)P_in[8 * t + e];
+#if defined(ESVIT_P32_PROBE) && defined(P32_NO_SIDE_STORE)
+                asm volatile("" :: "v"(pre), "v"(H_out[t]), "v"(so));
+#elif defined(ESVIT_P32_PROBE) && defined(P32_SIDE_LINEAR)
+                // (timing probe, wrong layout: the same bytes as whole 1 KiB lines per wave-instruction -- what coalesced stores would cost)
+                {
+                    const unsigned lo = (unsigned)((((long)blockIdx.x * P32_WAVES + wave) * NCH + q) * 2 + t) * 1024u + (unsigned)lane * 16u;
+                    buffer_store_b128(pre, ra1, lo, 0);
+                    buffer_store_b128(H_out[t], ra1g, lo, 0);
                 }
+#else
+                buffer_store_b128(pre, ra1, so + 16 * t, 0);
+                buffer_store_b128(H_out[t], ra1g, so + 16 * t, 0);
+#endif
             }
         }
         P32_TL(q + 1, 1);
 #if defined(ESVIT_P32_PROBE) && defined(P32_NO_DMA_WAIT)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #else
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#if defined(ESVIT_P32_PROBE) && defined(P32_NO_SIDE_STORE)
+        if constexpr (STORES) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#else
+        if constexpr (STORES) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+#endif
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 #endif
         P32_TL(q + 1, 2);
         __builtin_amdgcn_s_barrier();
@@ -515,6 +535,7 @@ int esvit_i_mlp32p_fwd(const float* x, const float* gamma, const float* beta, fl
                        hipStream_t stream) {
     if (C != 384) return ESVIT_ERR_UNSUPPORTED;
     if (a1) {
+        if ((long)M * 4 * C * 2 >= 0x7ff00000L) return ESVIT_ERR_UNSUPPORTED;  // (the side outputs are addressed through 32-bit buffer offsets, rows past M at 2 GiB)
         P32Args a{x, gamma, beta, eps, (const bf16*)W1, b1, (const bf16*)W2, b2, rowscale, M, y, (bf16*)a1, (bf16*)a1g, (bf16*)h, mean, rstd};
         return launch_p32<384, true>(a, stream);
     }

@@ -143,9 +143,9 @@ MLP_WIDE_FUSED = _WIDE != "0"
 MLP_WIDE_TRAIN = _WIDE == "2"
 
 
-def _mlp_wide_train(W1, C):
+def _mlp_wide_train(W1, C, rows):
     """the wide stage's training pass: forward fused (esvit_mlp_fused_fwd_train writes the operands of the unfused backward)"""
-    return MLP_WIDE_TRAIN and ops_module().mlp_fused_train_supported(W1.dtype, C)
+    return MLP_WIDE_TRAIN and ops_module().mlp_fused_train_supported(W1.dtype, C, rows)
 
 
 def _mlp_fused_infer(W1, C):
@@ -207,7 +207,7 @@ def _block_forward(x, geom, nH, index, dp, prm, wts, save, w1p=None, wattn=None)
         x2 = o.mlp_fused_fwd(x1, g2, b2, LN_EPS, W1 if C == 384 else _mlp_w(w1p, "MLP_W1_FWD"), bfc1, W2, bfc2, rowscale=rs2)
         saved = (mean1, rstd1, xw, qkv, ao, x1, lse, frag) if save else None
         return x2.view(nB, L, C), saved
-    elif save and _mlp_wide_train(W1, C):
+    elif save and _mlp_wide_train(W1, C, nB * L):
         rs2 = None if dp2 is None else dp2.repeat_interleave(L)
         x2, a1, a1g, h, mean2, rstd2 = o.mlp_fused_fwd_train(x1, g2, b2, LN_EPS, W1, bfc1, W2, bfc2, rowscale=rs2)
     else:
@@ -346,7 +346,7 @@ def _block_forward_multi(X, segs, nH, dp_rows, prm, wts, save, pre=None, next_no
         else:
             x2 = o.mlp_fused_fwd(x1, g2, b2, LN_EPS, w1k, bfc1, W2, bfc2, rowscale=dp2)
         return x2, ((mean1, rstd1, xw, qkv, ao, x1) if save else None), lses, nxt
-    elif save and _mlp_wide_train(W1, C):
+    elif save and _mlp_wide_train(W1, C, M):
         # wide stage, training pass: one kernel writes x2 and what the unfused backward below reads (LayerNorm output and statistics,
         # pre-activation, GELU) in place of the LayerNorm launch and the two GEMM launches
         x2, a1, a1g, h, mean2, rstd2 = o.mlp_fused_fwd_train(x1, g2, b2, LN_EPS, W1, bfc1, W2, bfc2, rowscale=dp2)

@@ -391,9 +391,10 @@ def mlp_fused_fwd_train(x, gamma, beta, eps, W1, b1, W2, b2, *, rowscale=None):
     return y, a1, a1g, h, mean, rstd
 
 
-def mlp_fused_train_supported(dt, Cc):
-    """esvit_mlp_fused_fwd_train exists for this width (bf16, C = 384: forward fused, backward through the GEMMs)"""
-    return dt == torch.bfloat16 and int(Cc) == 384 and mlp_fused_supported(dt, Cc)
+def mlp_fused_train_supported(dt, Cc, rows=0):
+    """esvit_mlp_fused_fwd_train exists for this width (bf16, C = 384: forward fused, backward through the GEMMs) and row count (its side outputs
+    are addressed through 32-bit offsets: [rows, 4C] bf16 below 2 GiB)"""
+    return dt == torch.bfloat16 and int(Cc) == 384 and mlp_fused_supported(dt, Cc) and rows * 4 * Cc * 2 < 0x7ff00000
 
 
 def cast_weight(w, transpose=False, perm32=False):
