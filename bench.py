@@ -83,7 +83,25 @@ BF16_PEAK_TFLOPS = 2500.0      # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E (MI355X_MICROARCH.md; ~6.3 TB/s is what a streaming kernel reaches)
 OUT_DIM = 65536
 PMC_TRAFFIC_FILES = [os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f)
-                     for f in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")]
+                     for f in ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")]
+
+
+def pmc_mfma_busy(arch, batch):
+    """Counter-derived MFMA-busy of the whole step and of the GEMM family from the committed rocprofv3 PMC pass of this command
+    (tools/pmc_mfma_busy.sh: sum SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE per XCD instance)) -- BASELINE.json's metric asks
+    for "MFMA util %".  Not measured in this process.  -> dict or None"""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r06_step_mfma_busy.json")
+    try:
+        with open(path) as fh:
+            d = json.load(fh)
+    except (OSError, ValueError):
+        return None
+    if d.get("arch") != arch or d.get("batch") != batch:
+        return None
+    fam = d.get("families", {})
+    return {"step": d.get("mfma_busy"), "step_vs_kernel_time_at_2p4GHz": d.get("mfma_busy_vs_kernel_time_at_2p4GHz"),
+            "gemm_dma_kernel": (fam.get("gemm_dma_kernel") or {}).get("mfma_busy"), "gemm_p8_kernel": (fam.get("gemm_p8_kernel") or {}).get("mfma_busy"),
+            "source": "rocprofv3 PMC pass of this command, committed as profiles/r06_step_mfma_busy.json (not read in this run)"}
 
 
 def pmc_gemm_traffic_per_launch(arch, batch, launches_per_step):
@@ -491,7 +509,7 @@ def main():
                                "launches_per_step": len(prof) / prof_steps, "instrumented_steps": prof_steps,
                                "flops_per_launch": tot_fl / len(prof), "algorithmic_bytes_per_launch": tot_by / len(prof),
                                "avg_launch_us": tot_ms * 1e3 / len(prof), "gemm_ms_per_step": tot_ms / prof_steps,
-                               "flop_per_byte": tot_fl / tot_by,
+                               "flop_per_byte": tot_fl / tot_by, "mfma_busy": pmc_mfma_busy(args.arch, B),
                                "hbm_view": {"achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS}}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
