@@ -431,6 +431,12 @@ __device__ __forceinline__ void mlp32p_fwd_body(const P32Args& A) {
                     buffer_store_b128(pre, ra1, lo, 0);
                     buffer_store_b128(H_out[t], ra1g, lo, 0);
                 }
+#elif defined(ESVIT_P32_PROBE) && defined(P32_SIDE_NT)
+                buffer_store_b128<2>(pre, ra1, so + 16 * t, 0);  // (timing probe: non-temporal)
+                buffer_store_b128<2>(H_out[t], ra1g, so + 16 * t, 0);
+#elif defined(ESVIT_P32_PROBE) && defined(P32_SIDE_SC1)
+                buffer_store_b128<16>(pre, ra1, so + 16 * t, 0);  // (timing probe: write-through)
+                buffer_store_b128<16>(H_out[t], ra1g, so + 16 * t, 0);
 #else
                 buffer_store_b128(pre, ra1, so + 16 * t, 0);
                 buffer_store_b128(H_out[t], ra1g, so + 16 * t, 0);

@@ -802,6 +802,10 @@ def _grad_probes(named_grads, g_ref):
             if key in n and n not in picked and n in g_ref:
                 picked.append(n)
                 break
+    # a backbone whose parameter names match few of the keys (CvT: stageN.M.layers...): fill up to ten tensors at regular strides of the name list
+    rest = [n for n in sorted(names) if n not in picked and n in g_ref and g_ref[n].numel() >= 64]
+    while len(picked) < 10 and rest:
+        picked.append(rest.pop((len(rest) * 5) // 11))
     out = []
     for n in picked:
         a = named_grads[n].detach().float().cpu().reshape(-1)

@@ -20,3 +20,6 @@ ESVIT_FORCE_REDUCER=1 HSA_ENABLE_IPC_MODE_LEGACY=0 timeout 300 python -m torch.d
 python -c "import json; d=json.load(open('$out/bench_rccl1_bf16_payload.json')); print('rccl nproc=1, bf16 payload', round(d['value'],1), 'img/s')"
 bash tools/pmc_kernel_sq.sh step_$tag -- python $PWD/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --single-stream > /dev/null 2>&1; head -14 gpurun_out/pmc_step_$tag/summary.txt | cut -c1-200
 python bench.py --no-cpu-baseline --no-roofline --augment --steps 10 --warmup 3 2>/dev/null | tail -1 > $out/bench_with_crop_producer.json
+# round 6: counter-derived MFMA-busy of the step (BASELINE.json's "MFMA util %"), kernel-family table of the single-stream stats run
+bash tools/pmc_mfma_busy.sh 128 swin_tiny_w7 $out/step_mfma_busy.json > $out/mfma_busy.log 2>&1; tail -14 $out/mfma_busy.log
+python tools/kernel_families.py $(ls gpurun_out/prof_$tag/stats/*kernel_stats.csv 2>/dev/null | head -1) 4 > $out/step_kernel_families.txt 2>/dev/null; head -24 $out/step_kernel_families.txt
