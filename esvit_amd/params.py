@@ -72,11 +72,14 @@ def cached_cast(p, shape2d=None):
     return w
 
 
+_PROBE_STALE = __import__("os").environ.get("ESVIT_PROBE_STALE_DERIVED", "0") == "1"  # timing probe ONLY (wrong results): derived copies never refreshed
+
+
 def cached(p, name, fn):
     """generic per-parameter cache for derived tensors (e.g. the weight-normed last layer)."""
     tag = _tag(p)
     ent = _lookup(p, name)
-    if ent is not None and ent[1] == tag:
+    if ent is not None and (ent[1] == tag or (_PROBE_STALE and name.startswith(("MLP_", "ATTN_")))):
         return ent[2]
     val = fn()
     _CACHE[(id(p), name)] = (_ref(p), tag, val)
