@@ -276,6 +276,31 @@ def test_mlp_fused_fwd_wide(mods, M):
     _close("wide mlp y, extreme", tre[0], wante[0], 4e-3)
 
 
+def test_mlp_fused_fwd_wide_is_bit_reproducible(mods):
+    """the wide fused MLP at the step's occupancy (87040 rows = 2.66 rounds of 256 workgroups), 15 launches of each entry point on the same inputs:
+    identical to the bit.  Its MFMAs are asm statements whose results compiler-generated code reads (accumulator reads, the bias operand) -- the two
+    orderings that were wrong while the kernel was written (a1 off by O(1) in the last two chunks; stale bias operand) showed up as run-to-run
+    differences at exactly this size, not at 640 rows."""
+    ops, _ = mods
+    dev = _dev()
+    dt, C, M = torch.bfloat16, 384, 87040
+    x = _rand((M, C), dev, 170) * 1.5 + 0.3
+    g, b = 1.0 + 0.2 * _rand((C,), dev, 171), 0.1 * _rand((C,), dev, 172)
+    W1, b1 = _rand((4 * C, C), dev, 173, dt, 0.06), 0.1 * _rand((4 * C,), dev, 174)
+    W2, b2 = _rand((C, 4 * C), dev, 175, dt, 0.04), 0.1 * _rand((C,), dev, 176)
+    first = None
+    for rep in range(15):
+        y = ops.mlp_fused_fwd(x, g, b, 1e-6, W1, b1, W2, b2)
+        tr = ops.mlp_fused_fwd_train(x, g, b, 1e-6, W1, b1, W2, b2)
+        cur = [y] + list(tr)
+        if first is None:
+            first = [t.clone() for t in cur]
+            assert all(bool(torch.isfinite(t.float()).all()) for t in cur)
+        else:
+            for i, (a, r) in enumerate(zip(cur, first)):
+                assert torch.equal(a, r), "tensor %d differs between launch 0 and launch %d" % (i, rep)
+
+
 @pytest.mark.parametrize("C,M", [(96, 128 * 29), (192, 128 * 9), (96, 1000), (192, 77), (96, 128 * 300 + 33)])
 def test_mlp_fused_bwd(mods, C, M):
     """data-gradient path of the fused MLP branch (esvit_mlp_fused_bwd) vs its torch restatement: dL/dx, its activation-dtype
