@@ -96,6 +96,10 @@ GemmChoice choose(int dtype, const esvit_gemm_desc& d) {
 #endif
         ) {
             want = ESVIT_GEMM_P8;
+#ifdef ESVIT_P8_WGRAD_STAGE2  // round-6 A/B: the stage-2 weight gradients (384 / 1152 / 1536-wide, K = 87040) on ragged 256 x 256 tiles, bias gradient fused
+        } else if (p8_supports(dtype, d) && d.batch <= 1 && d.a_kstrided && (long)d.M * d.N >= 400000L && d.K >= 16384 && d.M % 128 == 0 && d.N % 128 == 0) {
+            want = ESVIT_GEMM_P8;
+#endif
 #endif
         } else if (!d.a_kstrided && !d.rowmap && d.K >= 4096 && d.N >= 192 && t8 * nz >= 128) {
             // One 256 x 256 tile per CU has no second workgroup to hide its prologue / epilogue behind: measured
