@@ -408,7 +408,7 @@ __global__ __launch_bounds__(1024) void ln_fold_finish_kernel(float* __restrict_
 int esvit_i_mlp_fused_supported(int dtype, int C) {
     if (dtype != ESVIT_BF16) return 0;
     if (C == 384) return 1;  // mlp_fused32p.hip: forward (inference pass; the training pass has its own entry point, esvit_mlp_fused_fwd_train)
-    return (C == 96 || C == 192) ? 3 : 0;
+    return (C == 96 || C == 128 || C == 192 || C == 256) ? 3 : 0;
 }
 
 // third generation (mlp_fused32p.hip): C = 384
@@ -431,7 +431,7 @@ extern "C" int esvit_mlp_fused_fwd(int dtype, const float* x, const float* gamma
                                    float* y, const float* gamma_next, const float* beta_next, void* xw_next, float* mean_next,
                                    float* rstd_next, esvit_stream_t s_) {
     hipStream_t stream = reinterpret_cast<hipStream_t>(s_);
-    ESVIT_CHECK_ARG(esvit_i_mlp_fused_supported(dtype, C) & 1, "esvit_mlp_fused_fwd: bf16 activations and C in {96, 192, 384} only (C=%d)", C);
+    ESVIT_CHECK_ARG(esvit_i_mlp_fused_supported(dtype, C) & 1, "esvit_mlp_fused_fwd: bf16 activations and C in {96, 128, 192, 256, 384} only (C=%d)", C);
     ESVIT_CHECK_ARG(x && gamma && beta && W1 && b1 && W2 && b2 && y && M > 0, "esvit_mlp_fused_fwd: null pointer / empty input");
     ESVIT_CHECK_ARG(AL16(x) && AL16(y) && AL16(W1) && AL16(W2) && AL16(gamma) && AL16(beta) && AL16(b1) && AL16(b2),
                     "esvit_mlp_fused_fwd: operands must be 16-byte aligned");
@@ -443,7 +443,7 @@ extern "C" int esvit_mlp_fused_fwd(int dtype, const float* x, const float* gamma
         ESVIT_CHECK_ARG(!lnn, "esvit_mlp_fused_fwd: C = 384 does not emit the next LayerNorm");
         return esvit_i_mlp32p_fwd(x, gamma, beta, eps, W1, b1, W2, b2, rowscale, M, C, y, nullptr, nullptr, nullptr, nullptr, nullptr, stream);
     }
-    if (C == 96)  // 16 tokens per wave; W1 in the permuted channel order (ESVIT_MLP_W1_FWD of esvit_mlp_fused_weight)
+    if (C == 96 || C == 128 || C == 256)  // 16 tokens per wave; W1 in the permuted channel order (ESVIT_MLP_W1_FWD of esvit_mlp_fused_weight)
         return esvit_i_mlp16_fwd(x, gamma, beta, eps, W1, b1, W2, b2, rowscale, M, C, y, gamma_next, beta_next, xw_next, mean_next, rstd_next, stream);
     return lnn ? launch_mlp<192, true>(x, gamma, beta, eps, W1, b1, W2, b2, rowscale, M, y, gamma_next, beta_next, xw_next, mean_next, rstd_next, stream)
                : launch_mlp<192, false>(x, gamma, beta, eps, W1, b1, W2, b2, rowscale, M, y, nullptr, nullptr, nullptr, nullptr, nullptr, stream);
@@ -465,7 +465,7 @@ extern "C" int esvit_mlp_fused_bwd(int dtype, const float* x, const float* gy, c
                                    const float* b1, int64_t M, int C, float* gx, void* gx_act, void* xhat, void* a1g, void* da1,
                                    esvit_stream_t s_) {
     hipStream_t stream = reinterpret_cast<hipStream_t>(s_);
-    ESVIT_CHECK_ARG(esvit_i_mlp_fused_supported(dtype, C) & 2, "esvit_mlp_fused_bwd: bf16 activations and C in {96, 192} only (C=%d)", C);
+    ESVIT_CHECK_ARG(esvit_i_mlp_fused_supported(dtype, C) & 2, "esvit_mlp_fused_bwd: bf16 activations and C in {96, 128, 192, 256} only (C=%d)", C);
     ESVIT_CHECK_ARG(x && gy && gamma && beta && W1 && W2T && W1T && b1 && gx && gx_act && xhat && a1g && da1 && M > 0,
                     "esvit_mlp_fused_bwd: null pointer / empty input");
     ESVIT_CHECK_ARG(AL16(x) && AL16(gy) && AL16(gx) && AL16(gx_act) && AL16(xhat) && AL16(a1g) && AL16(da1) && AL16(W1) && AL16(W2T) &&

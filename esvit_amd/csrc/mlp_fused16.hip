@@ -460,7 +460,10 @@ int esvit_i_mlp16_fwd(const float* x, const float* gamma, const float* beta, flo
     } while (0)
     // (C = 384 was measured as well -- 8 waves, 2 per SIMD, 147 KiB of weight buffers: 385 us against 468 unfused on the student's
     // stage-2 rows, 258 against 245 on the teacher's; without a backward of that width it has no user and is not instantiated)
+    // (C = 128 / 256: the narrow stages of Swin-B, round 6 -- the general swizzle of fused16.h covers every C whose rows are whole 256-byte bank rows)
     if (C == 96) LAUNCH_F(96, 8, 6);
+    else if (C == 128) LAUNCH_F(128, 8, 4);
+    else if (C == 256) LAUNCH_F(256, 8, 2);
     else LAUNCH_F(192, 6, 3);
 #undef LAUNCH_F
     ESVIT_CHECK_LAUNCH("esvit_mlp_fused_fwd(16)");
@@ -481,6 +484,8 @@ int esvit_i_mlp16_bwd(const float* x, const float* gy, const float* rs_mlp, cons
                            (const bf16*)W2Tp, (const bf16*)W1T, b1, M, gx, (bf16*)gxa, (bf16*)xhat, (bf16*)a1g, (bf16*)da1);             \
     } while (0)
     if (C == 96) LAUNCH_B(96, 6, 3, 3);
+    else if (C == 128) LAUNCH_B(128, 6, 3, 3);
+    else if (C == 256) LAUNCH_B(256, 8, 2, 2);
     else LAUNCH_B(192, 4, 2, 2);
 #undef LAUNCH_B
     ESVIT_CHECK_LAUNCH("esvit_mlp_fused_bwd(16)");
@@ -489,9 +494,10 @@ int esvit_i_mlp16_bwd(const float* x, const float* gy, const float* rs_mlp, cons
 
 extern "C" int esvit_mlp_fused_weight(int kind, const float* src, void* dst_bf16, int C, esvit_stream_t s_) {
     // the four weight copies of the fused branch; which generation consumes a copy decides its channel order (mlp_fused.hip entry points)
-    ESVIT_CHECK_ARG(C == 96 || C == 192 || (C == 384 && kind == ESVIT_MLP_W1_FWD), "esvit_mlp_fused_weight: C in {96, 192} (and the forward's copy at 384) only (C=%d)", C);
+    ESVIT_CHECK_ARG(C == 96 || C == 128 || C == 192 || C == 256 || (C == 384 && kind == ESVIT_MLP_W1_FWD),
+                    "esvit_mlp_fused_weight: C in {96, 128, 192, 256} (and the forward's copy at 384) only (C=%d)", C);
     switch (kind) {
-        case ESVIT_MLP_W1_FWD: return esvit_cast_weight(src, dst_bf16, 4 * C, C, 0, C == 96, s_);   // fc1.weight [4C, C] for the forward (the plain cast above 96)
+        case ESVIT_MLP_W1_FWD: return esvit_cast_weight(src, dst_bf16, 4 * C, C, 0, C == 96 || C == 128 || C == 256, s_);   // fc1.weight [4C, C] for the forward (16-token kernels: permuted; 192 / 384: the plain cast)
         case ESVIT_MLP_W1_BWD: return esvit_cast_weight(src, dst_bf16, 4 * C, C, 0, 1, s_);          // ... for the backward
         case ESVIT_MLP_W1T_BWD: return esvit_cast_weight(src, dst_bf16, 4 * C, C, 1, 0, s_);         // fc1.weight^T [C, 4C]
         case ESVIT_MLP_W2T_BWD: return esvit_cast_weight(src, dst_bf16, C, 4 * C, 1, 1, s_);         // fc2.weight^T [4C, C] from fc2.weight [C, 4C]

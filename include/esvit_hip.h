@@ -44,7 +44,7 @@ const char* esvit_last_error(void);
  *   ESVIT_Q_COLSUM_BLOCKS (rows)               blocks of the esvit_colsum scratch
  *   ESVIT_Q_COL_REDUCE_BLOCKS (rows)           blocks of the esvit_dwconv3x3_wgrad / esvit_col_sums2 scratch
  *   ESVIT_Q_UPDATE_CHUNK_ELEMS ()              elements per chunk of the fused update's chunk table
- *   ESVIT_Q_MLP_FUSED (dtype, C)               bit 0: esvit_mlp_fused_fwd exists (bf16, C in {96, 192, 384}), bit 1: esvit_mlp_fused_bwd exists (bf16, C in {96, 192})
+ *   ESVIT_Q_MLP_FUSED (dtype, C)               bit 0: esvit_mlp_fused_fwd exists (bf16, C in {96, 128, 192, 256, 384}), bit 1: esvit_mlp_fused_bwd exists (bf16, C in {96, 128, 192, 256})
  *   ESVIT_Q_AUG_MAX_BOX (S)                    largest crop-box side esvit_aug_crops resizes to S x S
  * Unknown `what` returns ESVIT_ERR_ARG. */
 #define ESVIT_Q_ATTN_FRAG_ELEMS 1
@@ -143,7 +143,7 @@ int esvit_gemm(int dtype, const esvit_gemm_desc* d, esvit_stream_t stream);
 int esvit_gemm_select(int dtype, const esvit_gemm_desc* d, int* tile_m, int* tile_n, int* resident_slots);
 
 /* ---- fused Swin MLP branch, forward and backward (swin_transformer.py:331 + 31-37) ---
- * y = x + rowscale[row] * ( GELU( LayerNorm(x) W1^T + b1 ) W2^T + b2 ) for the narrow stages (bf16, C in {96, 192}; C = 384: see below;
+ * y = x + rowscale[row] * ( GELU( LayerNorm(x) W1^T + b1 ) W2^T + b2 ) for the narrow stages (bf16, C in {96, 192}: Swin-T / -S, {128, 256}: Swin-B; C = 384: see below;
  * esvit_query(ESVIT_Q_MLP_FUSED, dtype, C, 0) bit 0 = forward, bit 1 = backward).  The unfused LayerNorm -> fc1 (+GELU) -> fc2
  * (+residual) sequence is bound there by the HBM round trips of the 4C-wide hidden activation (40 B per token-channel forward,
  * 64 B backward).  x, y fp32 [M, C]; W1 [4C, C], W2 [C, 4C] in the activation dtype; gamma, beta, b1, b2 fp32; rowscale fp32 [M]

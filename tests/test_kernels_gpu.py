@@ -207,7 +207,7 @@ def test_batched_sim(mods):
     _close("sim", got[:, :, :49], want[:, :, :49], 2e-5)
 
 
-@pytest.mark.parametrize("C,M", [(96, 128 * 37), (192, 128 * 21), (96, 1000), (192, 77), (96, 128 * 400 + 33)])
+@pytest.mark.parametrize("C,M", [(96, 128 * 37), (192, 128 * 21), (96, 1000), (192, 77), (96, 128 * 400 + 33), (128, 128 * 33 + 5), (256, 128 * 17), (256, 61)])
 def test_mlp_fused_fwd(mods, C, M):
     """fused LayerNorm -> fc1 + GELU -> fc2 + residual (esvit_mlp_fused_fwd, the teacher's narrow stages) vs the unfused op
     sequence it replaces; full and ragged row tiles, with and without per-row scales"""
@@ -301,7 +301,7 @@ def test_mlp_fused_fwd_wide_is_bit_reproducible(mods):
                 assert torch.equal(a, r), "tensor %d differs between launch 0 and launch %d" % (i, rep)
 
 
-@pytest.mark.parametrize("C,M", [(96, 128 * 29), (192, 128 * 9), (96, 1000), (192, 77), (96, 128 * 300 + 33)])
+@pytest.mark.parametrize("C,M", [(96, 128 * 29), (192, 128 * 9), (96, 1000), (192, 77), (96, 128 * 300 + 33), (128, 128 * 19 + 7), (256, 128 * 11), (256, 45)])
 def test_mlp_fused_bwd(mods, C, M):
     """data-gradient path of the fused MLP branch (esvit_mlp_fused_bwd) vs its torch restatement: dL/dx, its activation-dtype
     copy, xhat, GELU(A), dA; full and ragged row tiles, with and without DropPath row factors.  Then the whole branch backward
