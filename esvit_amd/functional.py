@@ -1394,6 +1394,11 @@ def _vit_block_forward(x, nH, dp, prm, wts, save):
     qkv = o.linear_fwd(xw, Wqkv, bqkv)
     ao, att = vit_attention(o, qkv, bqkv, nB, N, nH, scale, save)
     x1 = o.linear_fwd(ao, Wproj, bproj, residual=x2d, rowscale=dp1, rows_per_sample=N, out_f32=True)
+    if not save and C in (192, 384) and _mlp_fused_infer(W1, C):
+        # inference pass (the EMA teacher, the eval consumers): the branch in one kernel (deit_tiny / deit_small widths, whose fused kernels
+        # take the plain weight cast)
+        x2 = o.mlp_fused_fwd(x1, g2, b2, LN_EPS, W1, bfc1, W2, bfc2, rowscale=None if dp2 is None else dp2.repeat_interleave(N))
+        return x2.view(nB, N, C), None, att
     h, _, mean2, rstd2 = o.layernorm_fwd(x1, g2, b2, LN_EPS)
     if save:
         a1g, a1 = o.linear_fwd(h, W1, bfc1, gelu=True, want_preact=True)
@@ -1603,6 +1608,8 @@ def _vit_block_forward_multi(X, segs, nH, dp_rows, prm, wts, save):
         _, att = vit_attention(o, qkv[r0:r1], bqkv, nB, N, nH, scale, save, out=ao[r0:r1])
         atts.append(att)
     x1 = o.linear_fwd(ao, Wproj, bproj, residual=X, rowscale=dp1, rows_per_sample=1, out_f32=True)
+    if not save and C in (192, 384) and _mlp_fused_infer(W1, C):
+        return o.mlp_fused_fwd(x1, g2, b2, LN_EPS, W1, bfc1, W2, bfc2, rowscale=dp2), None, atts  # (inference pass: see _vit_block_forward)
     h, _, mean2, rstd2 = o.layernorm_fwd(x1, g2, b2, LN_EPS)
     if save:
         a1g, a1 = o.linear_fwd(h, W1, bfc1, gelu=True, want_preact=True)
