@@ -78,6 +78,45 @@ def _wgrad(dy, x, param, shape2d=None, want_bias=False, bias_param=None):
     return _alias(dw, sink), _alias(db, sink_b)
 
 
+
+# ---- weight gradients on a second stream -------------------------------------------------------------------------------------------
+# The weight-gradient GEMMs are leaves of the backward's dependency chain: nothing downstream in the same node reads them.  A Swin
+# block's / head's / PatchMerging's backward launches them on a (high-priority) side stream behind an event and joins before it returns --
+# every gradient is complete on the autograd stream when the node hands it over -- so that they share the CUs with the dgrad /
+# LayerNorm / attention kernels of the chain (same-box A-B, profiles/r06_wgrad_stream_ab.txt: 48.47 -> 47.87 ms per step).
+# ESVIT_WGRAD_STREAM=0 puts them back in line.
+WGRAD_STREAM = os.environ.get("ESVIT_WGRAD_STREAM", "1") != "0"
+_wg_state = {}
+
+
+def _side_run(fn, *keep):
+    """fn() launches kernels whose inputs are ready on the current stream; `keep`: the tensors they read (held until _side_join, so
+    that the caching allocator cannot hand their memory to the autograd stream while the side stream still reads it)"""
+    if not (WGRAD_STREAM and keep[0].is_cuda):
+        return fn()
+    dev = keep[0].device.index
+    st = _wg_state.get(dev)
+    if st is None:
+        st = _wg_state[dev] = {"stream": torch.cuda.Stream(device=dev, priority=int(os.environ.get("ESVIT_WGRAD_PRIO", "-1"))), "keep": [],
+                               "pending": False}
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(dev))
+    st["stream"].wait_event(ev)
+    with torch.cuda.stream(st["stream"]):
+        out = fn()
+    st["keep"].append(keep)
+    st["pending"] = True
+    return out
+
+
+def _side_join():
+    for dev, st in _wg_state.items():
+        if st["pending"]:
+            torch.cuda.current_stream(dev).wait_stream(st["stream"])
+            st["keep"].clear()
+            st["pending"] = False
+
+
 def _ln_sinks(gparam, bparam):
     """bucket slots of a LayerNorm's (weight, bias) gradients, or None when no reducer is armed / either has none"""
     sg, sb = P.grad_out(gparam), P.grad_out(bparam)
@@ -161,13 +200,17 @@ def _mlp_branch_bwd(o, x1, gy, dyb, g2, b2, W1, bfc1, params, dp_mlp, dp_out):
     g2_p, b2_p, W1_p, bfc1_p, W2_p, bfc2_p = params
     gx1, dyw, xhat, a1g, da1 = o.mlp_fused_bwd(x1, gy, g2, b2, LN_EPS, _mlp_w(W1_p, "MLP_W1_BWD"), _mlp_w(W2_p, "MLP_W2T_BWD"), _mlp_w(W1_p, "MLP_W1T_BWD"), bfc1,
                                                rowscale_mlp=dp_mlp, rowscale_out=dp_out)
-    dW2, dbfc2 = _wgrad(dyb, a1g, W2_p, want_bias=True, bias_param=bfc2_p)
-    del a1g
-    wsink, bsink = P.grad_out(W1_p), P.grad_out(bfc1_p)
-    G, dbfc1 = o.linear_wgrad(da1, xhat, out=wsink, want_bias=True, db_out=bsink)  # G = dA^T xhat: LayerNorm folded out
-    del da1, xhat
     ln2 = _ln_sinks(g2_p, b2_p)
-    dW1, dg2, db2 = o.ln_fold_finish(G, dbfc1, W1_p.detach(), g2, b2, gb_out=ln2)
+    wsink, bsink = P.grad_out(W1_p), P.grad_out(bfc1_p)
+
+    def wgrads():
+        dW2, dbfc2 = _wgrad(dyb, a1g, W2_p, want_bias=True, bias_param=bfc2_p)
+        G, dbfc1 = o.linear_wgrad(da1, xhat, out=wsink, want_bias=True, db_out=bsink)  # G = dA^T xhat: LayerNorm folded out
+        dW1, dg2, db2 = o.ln_fold_finish(G, dbfc1, W1_p.detach(), g2, b2, gb_out=ln2)
+        return dW2, dbfc2, dbfc1, dW1, dg2, db2
+
+    dW2, dbfc2, dbfc1, dW1, dg2, db2 = _side_run(wgrads, dyb, a1g, da1, xhat)
+    del a1g, da1, xhat
     return gx1, dyw, _alias(dg2, ln2), _alias(db2, ln2), _alias(dW1, wsink), _alias(dbfc1, bsink), dW2, dbfc2
 
 
@@ -271,6 +314,7 @@ class SwinBlockFn(torch.autograd.Function):
         o.colsum(dpad_ws, out=dbqkv[C:], accumulate=True)  # k/v bias gradient from the zero-pad slots
         dxw = o.linear_dgrad(dqkv, Wqkv)
         gx, dg1, db1 = o.layernorm_bwd(dxw, x.view(M, C), mean1, rstd1, g1, g_in=gx1)
+        _side_join()
         return (gx.view(nB, L, C), None, None, None, None, dg1, db1, dtable, dWqkv, dbqkv, dWproj, dbproj, dg2, db2, dW1, dbfc1,
                 dW2, dbfc2)
 
@@ -413,15 +457,15 @@ class SwinBlockMultiFn(torch.autograd.Function):
             gx1, dyw, dg2, db2, dW1, dbfc1, dW2, dbfc2 = _mlp_branch_bwd(o, x1, gy, dyb, g2, b2, W1, bfc1,
                                                                           (g2_p, b2_p, W1_p, bfc1_p, W2_p, bfc2_p), dp2, dp1)
         else:
-            dW2, dbfc2 = _wgrad(dyb, a1g, W2_p, want_bias=True, bias_param=bfc2_p)
+            dW2, dbfc2 = _side_run(lambda: _wgrad(dyb, a1g, W2_p, want_bias=True, bias_param=bfc2_p), dyb, a1g)
             da1 = o.linear_dgrad(dyb, W2, gelu_preact=a1)
-            dW1, dbfc1 = _wgrad(da1, h, W1_p, want_bias=True, bias_param=bfc1_p)
+            dW1, dbfc1 = _side_run(lambda: _wgrad(da1, h, W1_p, want_bias=True, bias_param=bfc1_p), da1, h)
             dh = o.linear_dgrad(da1, W1)
             ln2 = _ln_sinks(g2_p, b2_p)
             gx1, dyw, dg2, db2 = o.layernorm_bwd_cast(dh, x1, mean2, rstd2, g2, g_in=gy, rowscale=dp1, rows_per_sample=1, gb_out=ln2)
             dg2, db2 = _alias(dg2, ln2), _alias(db2, ln2)
         # ---- attention branch ----
-        dWproj, dbproj = _wgrad(dyw, ao, Wproj_p, want_bias=True, bias_param=bproj_p)
+        dWproj, dbproj = _side_run(lambda: _wgrad(dyw, ao, Wproj_p, want_bias=True, bias_param=bproj_p), dyw, ao)
         dao = o.linear_dgrad(dyw, Wproj)
         dqkv = torch.empty_like(qkv)
         tsink = P.grad_out(table_p)
@@ -437,9 +481,14 @@ class SwinBlockMultiFn(torch.autograd.Function):
             pads.append(dpad_ws)
         dtable = _alias(dtable, tsink)
         wsink, bsink = P.grad_out(Wqkv_p), P.grad_out(bqkv_p)
-        dWqkv, dbqkv = o.linear_wgrad(dqkv, xw, out=wsink, want_bias=True, db_out=bsink)
-        for dpad_ws in pads:
-            o.colsum(dpad_ws, out=dbqkv[C:], accumulate=True)  # k/v bias gradient from the zero-pad slots
+
+        def wqkv():
+            dWqkv, dbqkv = o.linear_wgrad(dqkv, xw, out=wsink, want_bias=True, db_out=bsink)
+            for dpad_ws in pads:
+                o.colsum(dpad_ws, out=dbqkv[C:], accumulate=True)  # k/v bias gradient from the zero-pad slots
+            return dWqkv, dbqkv
+
+        dWqkv, dbqkv = _side_run(wqkv, dqkv, xw, pads)
         dWqkv, dbqkv = _alias(dWqkv, wsink), _alias(dbqkv, bsink)
         dxw = o.linear_dgrad(dqkv, Wqkv)
         ln1 = _ln_sinks(g1_p, b1_p)
@@ -449,6 +498,7 @@ class SwinBlockMultiFn(torch.autograd.Function):
             gx, dg1, db1 = o.layernorm_bwd(dxw, X, mean1, rstd1, g1, g_in=gx1, gb_out=ln1)
             gxb = None
         dg1, db1 = _alias(dg1, ln1), _alias(db1, ln1)
+        _side_join()
         return (gx, gxb, None, None, None, None, None, None, None, dg1, db1, dtable, dWqkv, dbqkv, dWproj, dbproj, dg2, db2, dW1, dbfc1, dW2, dbfc2)
 
 
@@ -603,9 +653,9 @@ class PatchMergeMultiFn(torch.autograd.Function):
         o = ops_module()
         X, y, mean, rstd, g, Wc = ctx.saved_tensors
         M, C = X.shape
-        gb = gosh.contiguous() if gosh is not None else o.gather_cast(go.contiguous(), M // 4)
-        dWr = _wgrad(gb, y, ctx.wparam)
-        dy = o.linear_dgrad(gb, Wc)
+        gob = gosh.contiguous() if gosh is not None else o.gather_cast(go.contiguous(), M // 4)
+        dWr = _side_run(lambda: _wgrad(gob, y, ctx.wparam), gob, y)
+        dy = o.linear_dgrad(gob, Wc)
         dX = torch.empty_like(X)
         dXsh = torch.empty((M, C), dtype=y.dtype, device=X.device) if ctx.emit_shadow else None
         ps = ctx.prev_scale
@@ -615,6 +665,7 @@ class PatchMergeMultiFn(torch.autograd.Function):
             q0, q1 = r0 // 4, r1 // 4
             o.merge_ln_bwd(dy[q0:q1], X[r0:r1].view(nB, H * W, C), mean[q0:q1], rstd[q0:q1], g, H, W, dx_out=dX[r0:r1], gb_out=gb,
                            accumulate=gi > 0, act_out=None if dXsh is None else dXsh[r0:r1], rowscale=None if (ps is None or dXsh is None) else ps[r0:r1])
+        _side_join()
         return dX, dXsh, None, None, gb[0], gb[1], dWr
 
 
@@ -752,18 +803,23 @@ class DinoHeadFn(torch.autograd.Function):
         W1p, W2p, W3p, vp = ctx.wparams
         b1p, b2p, b3p = ctx.bparams
         dz = o.linear_dgrad(dlogits, w)
-        dw = o.linear_wgrad(dlogits, z)
         sink = P.grad_out(vp)
-        dv, dg = o.weightnorm_bwd(dw, v, g, winv, ctx.need_dg, dv_out=sink)
+
+        def wlast():
+            dw = o.linear_wgrad(dlogits, z)
+            return o.weightnorm_bwd(dw, v, g, winv, ctx.need_dg, dv_out=sink)
+
+        dv, dg = _side_run(wlast, dlogits, z)
         if sink is not None:
             dv = dv.detach()  # a fresh alias of the bucket slot (see _wgrad)
         dh3 = o.l2norm_bwd(dz, z, inv)
-        dW3, db3 = _wgrad(dh3, h2g, W3p, want_bias=True, bias_param=b3p)
+        dW3, db3 = _side_run(lambda: _wgrad(dh3, h2g, W3p, want_bias=True, bias_param=b3p), dh3, h2g)
         dh2 = o.linear_dgrad(dh3, W3, gelu_preact=h2)
-        dW2, db2 = _wgrad(dh2, h1g, W2p, want_bias=True, bias_param=b2p)
+        dW2, db2 = _side_run(lambda: _wgrad(dh2, h1g, W2p, want_bias=True, bias_param=b2p), dh2, h1g)
         dh1 = o.linear_dgrad(dh2, W2, gelu_preact=h1)
-        dW1, db1 = _wgrad(dh1, xa, W1p, want_bias=True, bias_param=b1p)
+        dW1, db1 = _side_run(lambda: _wgrad(dh1, xa, W1p, want_bias=True, bias_param=b1p), dh1, xa)
         dx = o.linear_dgrad(dh1, W1, out_f32=True)
+        _side_join()
         return dx, None, dW1, db1, dW2, db2, dW3, db3, dv, dg
 
 
@@ -1222,13 +1278,13 @@ class CvtAttnFn(torch.autograd.Function):
         M = nB * L
         gy = gy.contiguous().view(M, C)
         dyb = o.gather_cast(gy, M, rowscale=dp, rows_per_sample=L)
-        dWproj, dbproj = o.linear_wgrad(dyb, aoc, want_bias=True)
+        dWproj, dbproj = _side_run(lambda: o.linear_wgrad(dyb, aoc, want_bias=True), dyb, aoc)
         dao = _pad_tokens(o.linear_dgrad(dyb, Wproj), nB, H, W, Hp, Wp)
         geom = geometry(Hp, Wp, w, 0, x.device)
         regions = geometry(Hp, Wp, w, w // 2, x.device).region_ids if shift else None
         dqkv, dbias_ws, _ = o.window_attn_bwd(qkv, pw_b, geom.win2tok, Hp * Wp, dao, ao, lse, table, w, regions, geom.nW, geom.N, nH, scale)
         dtable = o.relpos_bias_bwd(dbias_ws, index, geom.N, table.shape[0]) if has_table else None
-        dWpw, dbpw = o.linear_wgrad(dqkv, bnout, want_bias=True)
+        dWpw, dbpw = _side_run(lambda: o.linear_wgrad(dqkv, bnout, want_bias=True), dqkv, bnout)
         dbn = o.linear_dgrad(dqkv, Wpw)
         # BatchNorm backward: d(d) = gamma rstd (dy - mean(dy) - xhat mean(dy xhat)), xhat = (d - mean) rstd
         red = o.bn_bwd_local(o.col_sums2(dbn, d), coef)   # (sum dy, sum dy*xhat) of this rank = (d beta, d gamma)
@@ -1239,9 +1295,10 @@ class CvtAttnFn(torch.autograd.Function):
             _allreduce_stats(red, group)
             abc = o.bn_bwd_coeffs(red, n, gam, coef)
         dd = o.col_affine2(dbn, abc[0], abc[2], d, abc[1])
-        ddw = o.dwconv3x3_wgrad(xp, dd, nB, Hp, Wp).view(C, 1, 3, 3)
+        ddw = _side_run(lambda: o.dwconv3x3_wgrad(xp, dd, nB, Hp, Wp), xp, dd).view(C, 1, 3, 3)
         dxn = _crop_tokens(o.dwconv3x3(dd, dw9, nB, Hp, Wp, flip=True), nB, H, W, Hp, Wp)
         gx, dg1, db1 = o.layernorm_bwd(dxn, x.view(M, C), mean1, rstd1, g1, g_in=gy)
+        _side_join()
         return (gx.view(nB, L, C), None, None, None, None, None, None, dg1, db1, ddw, dgam, dbet, dWpw.view(3 * C, C, 1, 1), dbpw,
                 dWproj.view(C, C, 1, 1), dbproj, dtable, None, None)
 
@@ -1285,11 +1342,12 @@ class CvtFfnFn(torch.autograd.Function):
         Hd = W1.shape[0]
         gy = gy.contiguous().view(M, C)
         dyb = o.gather_cast(gy, M, rowscale=ctx.dp, rows_per_sample=L)
-        dW2, dbf2 = o.linear_wgrad(dyb, a1g, want_bias=True)
+        dW2, dbf2 = _side_run(lambda: o.linear_wgrad(dyb, a1g, want_bias=True), dyb, a1g)
         da1 = o.linear_dgrad(dyb, W2, gelu_preact=a1, quick=True)
-        dW1, dbf1 = o.linear_wgrad(da1, h, want_bias=True)
+        dW1, dbf1 = _side_run(lambda: o.linear_wgrad(da1, h, want_bias=True), da1, h)
         dh = o.linear_dgrad(da1, W1)
         gx, dg2, db2 = o.layernorm_bwd(dh, x.view(M, C), mean, rstd, g2, g_in=gy)
+        _side_join()
         return gx.view(nB, L, C), None, dg2, db2, dW1.view(Hd, C, 1, 1), dbf1, dW2.view(C, Hd, 1, 1), dbf2
 
 
@@ -1551,13 +1609,13 @@ class VilBlockFn(torch.autograd.Function):
         bq_p, bkv_p, bproj_p, bfc1_p, bfc2_p = ctx.bparams
         g1_p, b1_p, g2_p, b2_p = ctx.nparams
         dyb = o.gather_cast(gy, M, rowscale=dp2, rows_per_sample=N)
-        dW2, dbfc2 = _wgrad(dyb, a1g, W2_p, want_bias=True, bias_param=bfc2_p)
+        dW2, dbfc2 = _side_run(lambda: _wgrad(dyb, a1g, W2_p, want_bias=True, bias_param=bfc2_p), dyb, a1g)
         da1 = o.linear_dgrad(dyb, W2, gelu_preact=a1)
-        dW1, dbfc1 = _wgrad(da1, h, W1_p, want_bias=True, bias_param=bfc1_p)
+        dW1, dbfc1 = _side_run(lambda: _wgrad(da1, h, W1_p, want_bias=True, bias_param=bfc1_p), da1, h)
         dh = o.linear_dgrad(da1, W1)
         sink1, sink2 = _ln_sinks(g1_p, b1_p), _ln_sinks(g2_p, b2_p)
         gx1, dyw, dg2, db2 = o.layernorm_bwd_cast(dh, x1, mean2, rstd2, g2, g_in=gy, rowscale=dp1, rows_per_sample=N, gb_out=sink2)
-        dWproj, dbproj = _wgrad(dyw, ao, Wproj_p, want_bias=True, bias_param=bproj_p)
+        dWproj, dbproj = _side_run(lambda: _wgrad(dyw, ao, Wproj_p, want_bias=True, bias_param=bproj_p), dyw, ao)
         dao = o.linear_dgrad(dyw, Wproj)
         if ctx.chunk is not None:
             dqkv = o.vit_attn_bwd(dao, att, nB, N, nH, scale, chunk=ctx.chunk)
@@ -1565,14 +1623,15 @@ class VilBlockFn(torch.autograd.Function):
             dqkv = vit_attention_bwd(o, dao, att, bqkv, nB, N, nH, scale)
         if split:
             dq, dkv = dqkv[:, :C].contiguous(), dqkv[:, C:].contiguous()
-            dWq, dbq = _wgrad(dq, xw, Wq_p, want_bias=True, bias_param=bq_p)
-            dWkv, dbkv = _wgrad(dkv, xw, Wkv_p, want_bias=True, bias_param=bkv_p)
+            dWq, dbq = _side_run(lambda: _wgrad(dq, xw, Wq_p, want_bias=True, bias_param=bq_p), dq, xw)
+            dWkv, dbkv = _side_run(lambda: _wgrad(dkv, xw, Wkv_p, want_bias=True, bias_param=bkv_p), dkv, xw)
             dxw = o.linear_dgrad(dqkv, torch.cat((Wq, Wkv), 0))  # dq Wq + dkv Wkv as one product over the stacked (tiny) weights
         else:
-            dWq, dbq = _wgrad(dqkv, xw, Wq_p, want_bias=True, bias_param=bq_p)
+            dWq, dbq = _side_run(lambda: _wgrad(dqkv, xw, Wq_p, want_bias=True, bias_param=bq_p), dqkv, xw)
             dWkv, dbkv = None, None
             dxw = o.linear_dgrad(dqkv, Wq)
         gx, dg1, db1 = o.layernorm_bwd(dxw, x.view(M, C), mean1, rstd1, g1, g_in=gx1, gb_out=sink1)
+        _side_join()
         return (gx.view(nB, N, C), None, None, None, _alias(dg1, sink1), _alias(db1, sink1), dWq, dbq, dWkv, dbkv, dWproj, dbproj,
                 _alias(dg2, sink2), _alias(db2, sink2), dW1, dbfc1, dW2, dbfc2)
 
@@ -1652,21 +1711,22 @@ class VitBlockMultiFn(torch.autograd.Function):
         bqkv_p, bproj_p, bfc1_p, bfc2_p = ctx.bparams
         g1_p, b1_p, g2_p, b2_p = ctx.nparams
         dyb = o.gather_cast(gy, M, rowscale=dp2, rows_per_sample=1)
-        dW2, dbfc2 = _wgrad(dyb, a1g, W2_p, want_bias=True, bias_param=bfc2_p)
+        dW2, dbfc2 = _side_run(lambda: _wgrad(dyb, a1g, W2_p, want_bias=True, bias_param=bfc2_p), dyb, a1g)
         da1 = o.linear_dgrad(dyb, W2, gelu_preact=a1)
-        dW1, dbfc1 = _wgrad(da1, h, W1_p, want_bias=True, bias_param=bfc1_p)
+        dW1, dbfc1 = _side_run(lambda: _wgrad(da1, h, W1_p, want_bias=True, bias_param=bfc1_p), da1, h)
         dh = o.linear_dgrad(da1, W1)
         sink1, sink2 = _ln_sinks(g1_p, b1_p), _ln_sinks(g2_p, b2_p)
         gx1, dyw, dg2, db2 = o.layernorm_bwd_cast(dh, x1, mean2, rstd2, g2, g_in=gy, rowscale=dp1, rows_per_sample=1, gb_out=sink2)
-        dWproj, dbproj = _wgrad(dyw, ao, Wproj_p, want_bias=True, bias_param=bproj_p)
+        dWproj, dbproj = _side_run(lambda: _wgrad(dyw, ao, Wproj_p, want_bias=True, bias_param=bproj_p), dyw, ao)
         dao = o.linear_dgrad(dyw, Wproj)
         dqkv = torch.empty((M, 3 * C), dtype=dao.dtype, device=dao.device)
         for (r0, nB, N), att in zip(segs, atts):
             r1 = r0 + nB * N
             vit_attention_bwd(o, dao[r0:r1], att, bqkv, nB, N, nH, scale, dqkv_out=dqkv[r0:r1])
-        dWqkv, dbqkv = _wgrad(dqkv, xw, Wqkv_p, want_bias=True, bias_param=bqkv_p)
+        dWqkv, dbqkv = _side_run(lambda: _wgrad(dqkv, xw, Wqkv_p, want_bias=True, bias_param=bqkv_p), dqkv, xw)
         dxw = o.linear_dgrad(dqkv, Wqkv)
         gx, dg1, db1 = o.layernorm_bwd(dxw, X, mean1, rstd1, g1, g_in=gx1, gb_out=sink1)
+        _side_join()
         return (gx, None, None, None, _alias(dg1, sink1), _alias(db1, sink1), dWqkv, dbqkv, dWproj, dbproj,
                 _alias(dg2, sink2), _alias(db2, sink2), dW1, dbfc1, dW2, dbfc2)
 

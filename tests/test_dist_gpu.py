@@ -34,8 +34,10 @@ def test_reducer_one_rank_rccl_equals_plain_step(lib_built, tmp_path):
     (res,) = _run("one_rank", 1, 29731, tmp_path)
     print("REDUCER one-rank RCCL:", json.dumps(res))
     bf = res.pop("ragged_bf16_payload")
-    # three AdamW steps of lr 5e-4 move a parameter by at most 1.5e-3; the bf16 nano step itself carries 3e-3 of loss noise
-    assert bf["reducer_on"] and bf["max_abs_param_diff"] < 3 * 5e-4 and bf["loss_diff"] < 2e-2, bf
+    # AdamW's normalised step moves an element by at most lr = 5e-4 per step, so two runs whose (near-zero) gradient elements round to
+    # opposite signs end at most 2 * 3 * lr apart after three steps (observed 1.2e-3 .. 1.5e-3); the bf16 nano step itself carries 3e-3
+    # of loss noise
+    assert bf["reducer_on"] and bf["max_abs_param_diff"] < 2 * 3 * 5e-4 and bf["loss_diff"] < 2e-2, bf
     for kind, r in res.items():
         assert r["reducer_on"] and r["reducer_off"] and r["buckets"] >= 1, (kind, r)
         assert r["losses_equal"], (kind, r)
