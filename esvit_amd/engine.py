@@ -10,6 +10,7 @@ import sys
 import torch
 import torch.distributed as dist
 
+from . import functional as F
 from . import params as P
 from .update import FusedClipAdamWEMA, bind_torch_optimizer, optimizer_rule
 
@@ -210,6 +211,7 @@ class EsvitTrainer:
             self.loss_fn.assume_unit_grad = prev
         self.reducer.begin()
         loss.backward()
+        F._side_join(final=True)
         self.reducer.finish()
         self.updater.step(lr, wd, momentum, clip_grad=self.clip_grad, skip_last_layer=epoch < self.freeze_last_layer)
         self.updater.zero_grad(set_to_none=True)  # (the updater invalidated / refreshed the cached weight casts itself)

@@ -109,7 +109,12 @@ def _side_run(fn, *keep):
     return out
 
 
-def _side_join():
+_DEFER_PROBE = os.environ.get("ESVIT_PROBE_WGRAD_DEFER", "0") == "1"  # timing probe only (UNSAFE: gradients may be read before they are complete)
+
+
+def _side_join(final=False):
+    if _DEFER_PROBE and not final:
+        return
     for dev, st in _wg_state.items():
         if st["pending"]:
             torch.cuda.current_stream(dev).wait_stream(st["stream"])
