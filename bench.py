@@ -340,7 +340,7 @@ def main():
                     help="BASELINE.json's metric is quoted on swin_tiny_w7 (default); configs 3/4 are swin_tiny_w14 / swin_base_w14")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--single-stream", action="store_true", help="teacher forward on the main stream too (per-kernel profiles: no overlapped durations)")
+    ap.add_argument("--single-stream", action="store_true", help="teacher forward and weight-gradient GEMMs on the main stream too (per-kernel profiles: no overlapped durations)")
     ap.add_argument("--augment", action="store_true", help="produce the crops INSIDE the timed step with the GPU crop producer (esvit_amd.data: "
                     "DataAugmentationDINO on decoded uint8 images resident in HBM) instead of feeding fixed crop tensors")
     ap.add_argument("--grad-payload", default="fp32", choices=["fp32", "bf16"], help="wire format of the data-parallel gradient all-reduce "
@@ -371,6 +371,7 @@ def main():
     torch.cuda.set_device(dev)
 
     import esvit_amd
+    from esvit_amd import functional as F
     from esvit_amd import ops
     from esvit_amd.engine import EsvitTrainer
     esvit_amd.set_precision("bf16")
@@ -379,6 +380,8 @@ def main():
     if args.per_group:
         student.ragged_multi_crop = teacher.ragged_multi_crop = False
     torch.manual_seed(1000 + rank)  # ... but every rank draws its own stochastic-depth masks (and has its own crops)
+    if args.single_stream:
+        F.WGRAD_STREAM = False
     trainer = EsvitTrainer(student, teacher, loss_fn, clip_grad=3.0, freeze_last_layer=1, teacher_stream=not args.single_stream,
                            grad_payload=args.grad_payload)
     B = args.batch
@@ -445,12 +448,13 @@ def main():
         prof = []
         ops.GEMM_PROFILE = prof
         side, trainer._side = trainer._side, None  # one stream while instrumented: a launch's events then bracket that launch alone
+        wg, F.WGRAD_STREAM = F.WGRAD_STREAM, False  # (the weight-gradient GEMMs back in line too: functional._side_run)
         for _ in range(PROF_STEPS):  # every rank runs them (the collectives need all ranks); rank 0 reports
             trainer.step(crops, lr, wd, mom, epoch)
             prof_steps += 1
         sync()
         ops.GEMM_PROFILE = None
-        trainer._side = side
+        trainer._side, F.WGRAD_STREAM = side, wg
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -81,9 +81,10 @@ def _wgrad(dy, x, param, shape2d=None, want_bias=False, bias_param=None):
 
 # ---- weight gradients on a second stream -------------------------------------------------------------------------------------------
 # The weight-gradient GEMMs are leaves of the backward's dependency chain: nothing downstream in the same node reads them.  A Swin
-# block's / head's / PatchMerging's backward launches them on a (high-priority) side stream behind an event and joins before it returns --
+# block's / head's / PatchMerging's backward launches them on a side stream behind an event and joins before it returns --
 # every gradient is complete on the autograd stream when the node hands it over -- so that they share the CUs with the dgrad /
-# LayerNorm / attention kernels of the chain (same-box A-B, profiles/r06_wgrad_stream_ab.txt: 48.47 -> 47.87 ms per step).
+# LayerNorm / attention kernels of the chain (same-box A-B, profiles/r06_wgrad_stream_ab.txt: 48.47 -> 47.96 ms per step).  The stream has
+# the default priority: a high-priority one measured 0.09 ms better alone and 10 ms WORSE beside RCCL's stream (ibid.).
 # ESVIT_WGRAD_STREAM=0 puts them back in line.
 WGRAD_STREAM = os.environ.get("ESVIT_WGRAD_STREAM", "1") != "0"
 _wg_state = {}
@@ -97,7 +98,7 @@ def _side_run(fn, *keep):
     dev = keep[0].device.index
     st = _wg_state.get(dev)
     if st is None:
-        st = _wg_state[dev] = {"stream": torch.cuda.Stream(device=dev, priority=int(os.environ.get("ESVIT_WGRAD_PRIO", "-1"))), "keep": [],
+        st = _wg_state[dev] = {"stream": torch.cuda.Stream(device=dev, priority=int(os.environ.get("ESVIT_WGRAD_PRIO", "0"))), "keep": [],
                                "pending": False}
     ev = torch.cuda.Event()
     ev.record(torch.cuda.current_stream(dev))
