@@ -757,6 +757,60 @@ def test_full_width_bf16_tracks_fp32_mode(arch, B):
 
 
 
+@pytest.mark.parametrize("arch,B", [("swin_tiny_w7", 32), ("swin_base_w14", 8), ("deit_small", 16), ("cvt_s1", 16), ("vil_tiny", 16)])
+def test_weight_gradient_stream_is_bit_identical_to_inline(arch, B, lib_built):
+    """functional._side_run launches the weight-gradient GEMMs of a backward node on a side stream and joins before the node returns.  The
+    same kernels on the same operands in a different launch order: every gradient of one backward must equal, bit for bit, the gradient
+    with the GEMMs in line (ESVIT_WGRAD_STREAM=0) -- at a batch that fills every CU, and repeated, so that a missing dependency (an operand
+    read before its producer finished, a buffer re-used while the side stream still reads it) shows up as a difference"""
+    import bench
+    import esvit_amd
+    import esvit_amd.functional as F
+    dev = torch.device("cuda:0")
+    esvit_amd.set_precision("bf16")
+    was = F.WGRAD_STREAM
+    try:
+        torch.manual_seed(0)
+        student, teacher, loss_fn = bench.build(dev, 0.0, arch)
+        crops = [c.to(dev) for c in GU.make_crops(B, seed=77)]
+        with torch.no_grad():
+            t_out = teacher(crops[:2])
+
+        state = {k: v.clone() for k, v in loss_fn.state_dict().items()}  # (the loss moves its centres in every forward)
+
+        def grads(on):
+            F.WGRAD_STREAM = on
+            loss_fn.load_state_dict(state)
+            torch.cuda.synchronize()
+            for p in student.parameters():
+                p.grad = None
+            loss = loss_fn(student(crops), t_out, 1, None)
+            loss.backward()
+            torch.cuda.synchronize()
+            return loss.item(), {n: p.grad.clone() for n, p in student.named_parameters() if p.grad is not None}
+
+        l_ref, g_ref = grads(False)
+        l_ref2, g_ref2 = grads(False)
+        assert l_ref == l_ref and len(g_ref) > 50
+        # (tensors whose gradient is summed with float atomics are not bit-reproducible even in line: those are compared to 1e-5 of their range)
+        exact = [n for n in g_ref if torch.equal(g_ref[n], g_ref2[n])]
+        assert len(exact) >= 0.9 * len(g_ref), (arch, len(exact), len(g_ref))
+        for rep in range(4):
+            l_on, g_on = grads(True)
+            assert abs(l_on - l_ref) <= abs(l_ref2 - l_ref) + 1e-6
+            assert g_on.keys() == g_ref.keys()
+            bad = [n for n in exact if not torch.equal(g_on[n], g_ref[n])]
+            assert not bad, (arch, rep, bad[:5])
+            for n in g_ref:
+                if n not in exact:
+                    scale = g_ref[n].abs().max().item() + 1e-30
+                    assert (g_on[n] - g_ref[n]).abs().max().item() <= 1e-5 * scale, (arch, rep, n)
+        assert any(st["stream"] is not None for st in F._wg_state.values())  # (the side stream was really in use)
+    finally:
+        F.WGRAD_STREAM = was
+        _teardown()
+
+
 ORACLE_SWIN = {"swin_tiny_w7": GU.SWIN_T,
                "swin_tiny_w14": dict(embed_dim=96, depths=(2, 2, 6, 2), heads=(3, 6, 12, 24), window=14, img=224),
                "swin_base_w14": dict(embed_dim=128, depths=(2, 2, 18, 2), heads=(4, 8, 16, 32), window=14, img=224)}
