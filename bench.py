@@ -11,7 +11,8 @@ Prints ONE JSON line on rank 0.  A "step" = teacher fwd (2 global crops) + stude
 gradient all-reduce (N>1) + fused clip/AdamW/EMA on a fixed synthetic batch resident in HBM.  `value` = images/s over all
 ranks; the timed region carries no instrumentation.  `roofline` describes the dominant kernel family (the MFMA GEMM: 99% of
 the step's FLOPs; SURVEY.md 8d bounds it by the bf16 MFMA peak) from HIP events recorded around every GEMM launch of a few
-extra steps AFTER the timed region; `cpu_baseline` times the reference's PyTorch path on the host cores on a bounded sample
+extra steps AFTER the timed region (those steps run on ONE stream -- the teacher pass and the weight-gradient GEMMs, which the timed steps
+overlap on side streams, are back in line -- so that a launch's duration is its own); `cpu_baseline` times the reference's PyTorch path on the host cores on a bounded sample
 of the same workload -- the reference's own modules when /root/reference is present (kind "reference"), otherwise the
 oracle's restatement of them (kind "port").
 """
