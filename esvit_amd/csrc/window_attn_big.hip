@@ -890,6 +890,20 @@ static int big_bwd_launch(const void* qkv, const float* qkv_bias, const int32_t*
                           int nH, float scale, void* dqkv, float* dbias_ws, float* dpad_ws, hipStream_t stream) {
     using Cfg = BigCfg<T, HD>;
     const int parts = big_parts(Bw, nH);
+#ifdef ESVIT_BIG_BWD_FORK  // probe (tools/probe/ab_big_bwd_fork.sh): the dK / dV kernel on a second stream beside the dQ kernel (disjoint outputs)
+    static hipStream_t s2 = nullptr;
+    static hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    if (!s2) {
+        (void)hipStreamCreateWithFlags(&s2, hipStreamNonBlocking);
+        (void)hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming);
+        (void)hipEventCreateWithFlags(&ev_join, hipEventDisableTiming);
+    }
+    (void)hipEventRecord(ev_fork, stream);
+    (void)hipStreamWaitEvent(s2, ev_fork, 0);
+    hipStream_t stream_kv = s2;
+#else
+    hipStream_t stream_kv = stream;
+#endif
     {
         auto kern = attn_big_bwd_dq4_kernel<T, HD>;
         const size_t lds = dq4_lds<T, HD>();
@@ -902,10 +916,14 @@ static int big_bwd_launch(const void* qkv, const float* qkv_bias, const int32_t*
         auto kern = attn_big_bwd_dkv2_kernel<T, HD>;
         const size_t lds = dkv2_lds<T, HD>();
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(kern, dim3(Bw * nH), dim3(Cfg::WAVES * 64), lds, stream, (const T*)qkv, qkv_bias, win2tok, L, (const T*)dout,
+        hipLaunchKernelGGL(kern, dim3(Bw * nH), dim3(Cfg::WAVES * 64), lds, stream_kv, (const T*)qkv, qkv_bias, win2tok, L, (const T*)dout,
                            (const T*)fout, lse, rel_table + (long)nH * NT * NT * 256, ws, region_ids, nW, Bw, N, nH, scale, (T*)dqkv, dpad_ws);
         ESVIT_CHECK_LAUNCH("window_attn_bwd(14x14, dK dV)");
     }
+#ifdef ESVIT_BIG_BWD_FORK
+    (void)hipEventRecord(ev_join, s2);
+    (void)hipStreamWaitEvent(stream, ev_join, 0);
+#endif
     return ESVIT_OK;
 }
 
