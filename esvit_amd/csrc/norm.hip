@@ -306,6 +306,9 @@ int ln_bwd_launch(RowSrc src, const void* dy, const float* mean, const float* rs
     ESVIT_CHECK_LAUNCH("layernorm_bwd");
     // ws rows are [dgamma(C) | dbeta(C)]; reduce both halves (dgamma and dbeta may be separate allocations)
     const int C = src.C;
+#ifdef ESVIT_PROBE_SKIP_FINISH  // timing probe (WRONG gradients): what the finishing launches cost on the main stream (profiles/r06_finish_offchain_ab.txt)
+    return ESVIT_OK;
+#endif
     if (dbeta == dgamma + C) return esvit_partial_reduce(ws, nblk, 2 * C, 2L * C, dgamma, accumulate, stream);
     int rc = esvit_partial_reduce(ws, nblk, C, 2L * C, dgamma, accumulate, stream);
     if (rc != ESVIT_OK) return rc;
