@@ -728,19 +728,44 @@ __global__ void relpos_bias_frag_from_table_kernel(const float* __restrict__ tab
     bias_frag[i] = v;
 }
 
-// dtable[index[q,key]][h] += total[h][frag(q,key)]   (total = partials already summed)
-__global__ void relpos_bias_bwd_kernel(const float* __restrict__ ws, int parts, const long* __restrict__ index, int N, int nH,
-                                       float* __restrict__ dtable) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nH * N * N) return;
-    const int h = i / (N * N), qk = i % (N * N);
-    const int q = qk / N, key = qk % N;
-    const int f = (key >> 4) * 4 + (q >> 4);
-    const int lane = ((key & 15) >> 2) * 16 + (q & 15), r = key & 3;
-    const int e = (f * 64 + lane) * 4 + r;
+// dtable[index[q,key]][h] += sum over the `parts` per-wave slabs of ws[part][h][frag(q,key)], in ONE launch (the bias-table gradient sits
+// between the large kernels of the backward chain: every launch there is ~10 us of step time, profiles/r06_finish_offchain_ab.txt; rounds 1-5
+// ran a partial_reduce launch and a scatter launch): block = 32 frag-layout columns x 8 slices of the slabs (the shape of
+// partial_reduce_kernel), then the eight slice sums of a column are folded and scattered by its first thread.
+// nt = 16-key tiles per window side (4 for <= 64 tokens, NT for 14 x 14): column e of head h is (q, key) with
+// f = e / 256 = (key / 16) * nt + q / 16, lane = (e / 4) % 64 = ((key % 16) / 4) * 16 + q % 16, r = e % 4 = key % 4.
+__global__ __launch_bounds__(256) void relpos_bias_bwd_fold_kernel(const float* __restrict__ ws, int parts, int nt, const long* __restrict__ index,
+                                                                    int N, int nH, float* __restrict__ dtable) {
+    __shared__ float sm[8][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int fe = nt * nt * 256;
+    const long ld = (long)nH * fe;
+    const int c = blockIdx.x * 32 + tx;  // < nH * fe: the launch covers whole heads (fe % 32 == 0)
+    const int h = c / fe, e = c % fe;
+    const int f = e >> 8, lane = (e >> 2) & 63, r = e & 3;
+    const int key = (f / nt) * 16 + (lane >> 4) * 4 + r, q = (f % nt) * 16 + (lane & 15);
+    const bool live = q < N && key < N;
     float s = 0.f;
-    for (int p = 0; p < parts; ++p) s += ws[((long)p * nH + h) * FRAG_ELEMS + e];
-    atomicAdd(dtable + index[qk] * nH + h, s);
+    if (live) {
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int b = ty;
+        for (; b + 24 < parts; b += 32) {
+            s0 += ws[(long)b * ld + c];
+            s1 += ws[(long)(b + 8) * ld + c];
+            s2 += ws[(long)(b + 16) * ld + c];
+            s3 += ws[(long)(b + 24) * ld + c];
+        }
+        for (; b < parts; b += 8) s0 += ws[(long)b * ld + c];
+        s = (s0 + s1) + (s2 + s3);
+    }
+    sm[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0 && live) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += sm[k][tx];
+        atomicAdd(dtable + index[q * N + key] * nH + h, t);
+    }
 }
 
 inline int bwd_parts(int Bw, int nH) {
@@ -762,6 +787,14 @@ int esvit_big_relpos_bias_bwd(const float* dbias_ws, int parts, const int64_t* i
                               int accumulate, hipStream_t stream);
 int esvit_big_npb();
 
+// fold `parts` frag-layout slabs ([parts][nH][nt * nt * 256]) and scatter the sums into dtable (window_attn_big.hip calls it with nt = NT)
+int esvit_i_relpos_fold(const float* dbias_ws, int parts, int nt, const int64_t* index, int N, int nH, float* dtable, hipStream_t stream) {
+    hipLaunchKernelGGL(relpos_bias_bwd_fold_kernel, dim3(nH * nt * nt * 256 / 32), dim3(256), 0, stream, dbias_ws, parts, nt, (const long*)index, N,
+                       nH, dtable);
+    ESVIT_CHECK_LAUNCH("relpos_bias_bwd");
+    return ESVIT_OK;
+}
+
 extern "C" int esvit_relpos_bias_bwd(const float* dbias_ws, int parts, const int64_t* index, int N, int nH, int table_rows,
                                      float* dtable, int accumulate, esvit_stream_t s_) {
     STREAM(s_);
@@ -776,15 +809,9 @@ extern "C" int esvit_relpos_bias_bwd(const float* dbias_ws, int parts, const int
         esvit_set_error("esvit_relpos_bias_bwd: memset failed: %s", hipGetErrorString(e));
         return ESVIT_ERR_HIP;
     }
-    // sum the per-wave partial slabs in place into slab 0 (out may alias row 0: each column is read then written by one thread)
-    if (parts > 1) {
-        int rc = esvit_partial_reduce(dbias_ws, parts, nH * FRAG_ELEMS, (long)nH * FRAG_ELEMS, const_cast<float*>(dbias_ws), 0, stream);
-        if (rc != ESVIT_OK) return rc;
-    }
-    hipLaunchKernelGGL(relpos_bias_bwd_kernel, dim3(ceil_div((long)nH * N * N, 256)), dim3(256), 0, stream, dbias_ws, 1,
-                       (const long*)index, N, nH, dtable);
-    ESVIT_CHECK_LAUNCH("relpos_bias_bwd");
-    return ESVIT_OK;
+    // fold the per-wave partial slabs and scatter in one launch (dbias_ws is left as it was)
+    static_assert(FRAG_ELEMS == 4 * 4 * 256, "frag layout of the <= 64-token kernels");
+    return esvit_i_relpos_fold(dbias_ws, parts, 4, index, N, nH, dtable, stream);
 }
 
 // 14x14-window kernels (window_attn_big.hip)

@@ -794,18 +794,6 @@ __global__ __launch_bounds__((BigCfg<T, HD>::WAVES * 64), ((sizeof(T) == 2 && HD
     }
 }
 
-// dtable[index[q,key]][h] += total[h][frag(q,key)] for the 14-tile frag layout
-__global__ void relpos_bias_bwd_big_kernel(const float* __restrict__ ws, const long* __restrict__ index, int N, int nH,
-                                           float* __restrict__ dtable) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nH * N * N) return;
-    const int h = i / (N * N), qk = i % (N * N);
-    const int q = qk / N, key = qk % N;
-    const int f = (key >> 4) * NT + (q >> 4);
-    const int lane = ((key & 15) >> 2) * 16 + (q & 15), r = key & 3;
-    atomicAdd(dtable + index[qk] * nH + h, ws[(long)h * (NT * NT * 256) + (f * 64 + lane) * 4 + r]);
-}
-
 template <typename T, int HD>
 size_t fwd3_lds() {
     using Cfg = BigCfg<T, HD>;
@@ -950,20 +938,14 @@ int esvit_big_attn_bwd(int dtype, const void* qkv, const float* qkv_bias, const 
                                      dpad_ws, stream);
 }
 
+int esvit_i_relpos_fold(const float* dbias_ws, int parts, int nt, const int64_t* index, int N, int nH, float* dtable, hipStream_t stream);
+
 int esvit_big_relpos_bias_bwd(const float* dbias_ws, int parts, const int64_t* index, int N, int nH, int table_rows, float* dtable,
                               int accumulate, hipStream_t stream) {
-    const int FE = NT * NT * 256;
-    if (parts > 1) {
-        int rc = esvit_partial_reduce(dbias_ws, parts, nH * FE, (long)nH * FE, const_cast<float*>(dbias_ws), 0, stream);
-        if (rc != ESVIT_OK) return rc;
-    }
     hipError_t e = accumulate ? hipSuccess : hipMemsetAsync(dtable, 0, (size_t)table_rows * nH * sizeof(float), stream);
     if (e != hipSuccess) {
         esvit_set_error("esvit_relpos_bias_bwd: memset failed: %s", hipGetErrorString(e));
         return ESVIT_ERR_HIP;
     }
-    hipLaunchKernelGGL(relpos_bias_bwd_big_kernel, dim3(ceil_div((long)nH * N * N, 256)), dim3(256), 0, stream, dbias_ws, (const long*)index, N,
-                       nH, dtable);
-    ESVIT_CHECK_LAUNCH("relpos_bias_bwd(14x14)");
-    return ESVIT_OK;
+    return esvit_i_relpos_fold(dbias_ws, parts, NT, index, N, nH, dtable, stream);  // fold of the per-workgroup slabs + scatter, one launch
 }

@@ -475,16 +475,18 @@ class SwinBlockMultiFn(torch.autograd.Function):
         dao = o.linear_dgrad(dyw, Wproj)
         dqkv = torch.empty_like(qkv)
         tsink = P.grad_out(table_p)
-        dtable, pads = None, []
-        for (r0, nB, L, geom), (lse, frag) in zip(segs, ctx.lses):
+        # the bias-gradient slabs of all groups in one buffer: ONE fold + scatter launch per block (every launch between the large kernels of
+        # this chain is ~10 us of step time, profiles/r06_finish_offchain_ab.txt)
+        N = segs[0][3].N
+        assert all(geom.N == N for (_, _, _, geom) in segs)
+        dbuf, dslabs = o.attn_dbias_slabs(N, [nB * geom.nW for (_, nB, _, geom) in segs], nH, qkv.device)
+        pads = []
+        for (r0, nB, L, geom), (lse, frag), dslab in zip(segs, ctx.lses, dslabs):
             r1 = r0 + nB * L
-            _, dbias_ws, dpad_ws = o.window_attn_bwd(qkv[r0:r1], bqkv, geom.win2tok, L, dao[r0:r1], ao[r0:r1], lse, None, geom.ws, geom.region_ids,
-                                                     geom.nW, geom.N, nH, scale, dqkv_out=dqkv[r0:r1], bias_frag=frag)
-            if dtable is None and tsink is not None:  # first group: overwrite the bucket slot
-                dtable = o.relpos_bias_bwd(dbias_ws, index, geom.N, table.shape[0], out=tsink, accumulate=False)
-            else:
-                dtable = o.relpos_bias_bwd(dbias_ws, index, geom.N, table.shape[0], out=dtable)  # the second group accumulates
+            _, _, dpad_ws = o.window_attn_bwd(qkv[r0:r1], bqkv, geom.win2tok, L, dao[r0:r1], ao[r0:r1], lse, None, geom.ws, geom.region_ids,
+                                              geom.nW, geom.N, nH, scale, dqkv_out=dqkv[r0:r1], bias_frag=frag, dbias_out=dslab)
             pads.append(dpad_ws)
+        dtable = o.relpos_bias_bwd(dbuf, index, N, table.shape[0], out=tsink, accumulate=False if tsink is not None else None)
         dtable = _alias(dtable, tsink)
         wsink, bsink = P.grad_out(Wqkv_p), P.grad_out(bqkv_p)
 

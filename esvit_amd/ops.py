@@ -717,8 +717,22 @@ def attn_branch_fwd(x, gamma, beta, eps, Wqkv_p, bqkv, Wproj_p, bproj, win2tok, 
     return (y, (xw, mean, rstd, qkv, ao)) if save else y
 
 
-def window_attn_bwd(qkv, qkv_bias, win2tok, L, dout, fwd_out, lse, rel_table, ws, region_ids, nW, N, nH, scale, dqkv_out=None, bias_frag=None):
-    """-> (dqkv act [nB*L, 3C], dbias_ws fp32 [parts, nH, frag], dpad_ws fp32 [rows, 2C])."""
+def attn_dbias_slabs(N, windows, nH, device):
+    """One buffer for the bias-gradient slabs of several window_attn_bwd calls over the same window size (the resolution groups of a
+    ragged block), so that ONE relpos_bias_bwd folds and scatters them all: -> (buffer [sum of parts, nH, frag], its per-call slices).
+    windows: the calls' window counts (nB * nW)"""
+    parts = [query(Q_ATTN_BWD_PARTS, N, w, nH) for w in windows]
+    buf = torch.empty((sum(parts), nH, attn_frag_elems(N)), dtype=torch.float32, device=device)
+    out, at = [], 0
+    for p_ in parts:
+        out.append(buf[at:at + p_])
+        at += p_
+    return buf, out
+
+
+def window_attn_bwd(qkv, qkv_bias, win2tok, L, dout, fwd_out, lse, rel_table, ws, region_ids, nW, N, nH, scale, dqkv_out=None, bias_frag=None,
+                    dbias_out=None):
+    """-> (dqkv act [nB*L, 3C], dbias_ws fp32 [parts, nH, frag], dpad_ws fp32 [rows, 2C]).  dbias_out: this call's slice of attn_dbias_slabs"""
     qkv, dout = _actc(qkv), _actc(dout)
     rows, C3 = qkv.shape
     Cc = C3 // 3
@@ -727,7 +741,11 @@ def window_attn_bwd(qkv, qkv_bias, win2tok, L, dout, fwd_out, lse, rel_table, ws
     dqkv = torch.empty_like(qkv) if dqkv_out is None else dqkv_out
     assert dqkv.shape == qkv.shape and dqkv.dtype == qkv.dtype and dqkv.is_contiguous()
     parts = query(Q_ATTN_BWD_PARTS, N, nB * nW, nH)
-    dbias_ws = torch.empty((parts, nH, attn_frag_elems(N)), dtype=torch.float32, device=qkv.device)
+    if dbias_out is None:
+        dbias_ws = torch.empty((parts, nH, attn_frag_elems(N)), dtype=torch.float32, device=qkv.device)
+    else:
+        dbias_ws = _f32c(dbias_out)
+        assert tuple(dbias_ws.shape) == (parts, nH, attn_frag_elems(N)), (dbias_ws.shape, parts, nH)
     # the <= 64-token kernel writes every element of its pad-row slab itself; the 14x14 kernels fill one head's slice per row
     alloc = torch.empty if N <= 64 else torch.zeros
     pad = alloc((query(Q_ATTN_BWD_PAD_ROWS, N, nB * nW, nH | (code << 32)), 2 * Cc), dtype=torch.float32, device=qkv.device)

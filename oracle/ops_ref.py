@@ -582,7 +582,14 @@ def window_attn_fwd(qkv, qkv_bias, win2tok, L, rel_table, ws, region_ids, nW, N,
     return (out, None, p) if want_attn else (out, None)
 
 
-def window_attn_bwd(qkv, qkv_bias, win2tok, L, dout, fwd_out, lse, rel_table, ws, region_ids, nW, N, nH, scale, dqkv_out=None, bias_frag=None):
+def attn_dbias_slabs(N, windows, nH, device):
+    """esvit_amd/ops.py: one buffer for the bias-gradient slabs of several window_attn_bwd calls (here: one slab per call)"""
+    buf = torch.zeros((len(windows), nH, attn_frag_elems(N)), dtype=torch.float32, device=device)
+    return buf, [buf[i:i + 1] for i in range(len(windows))]
+
+
+def window_attn_bwd(qkv, qkv_bias, win2tok, L, dout, fwd_out, lse, rel_table, ws, region_ids, nW, N, nH, scale, dqkv_out=None, bias_frag=None,
+                    dbias_out=None):
     rel_table = _table_of(rel_table, bias_frag)
     bias_frag = relpos_bias_fwd(rel_table, torch.as_tensor(relative_position_index(ws), device=qkv.device), N)
     C = qkv.shape[1] // 3
@@ -608,6 +615,9 @@ def window_attn_bwd(qkv, qkv_bias, win2tok, L, dout, fwd_out, lse, rel_table, ws
     dpad = dqkvw[pad][:, C:].sum(0, keepdim=True) if pad.any() else torch.zeros((1, 2 * C), device=qkv.device)
     dbias = ds.sum(0)  # [nH, N, N]
     ws = _frag_from_dense(dbias, 0.0).unsqueeze(0)  # parts = 1
+    if dbias_out is not None:
+        dbias_out.copy_(ws)
+        ws = dbias_out
     if dqkv_out is not None:
         dqkv_out.copy_(_r(dqkv, dt))
         return dqkv_out, ws, dpad
