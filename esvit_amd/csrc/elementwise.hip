@@ -88,24 +88,27 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, lo
     }
 }
 
-// stage 2 (shared): block = 32 columns x 8 row slices
-__global__ __launch_bounds__(256) void partial_reduce_kernel(const float* __restrict__ ws, int nblk, int ncols, long ld,
-                                                             float* __restrict__ out, int accumulate) {
-    __shared__ float sm[8][33];
+// stage 2 (shared): block = 32 columns x SLICES row slices.  The grid is a few dozen workgroups (ncols / 32), so the kernel is bound by the
+// latency of its dependent loads: 32 slices (1024 threads) where there are hundreds of partial rows -- the folds of the LayerNorm backward sit
+// on the backward chain, where every microsecond of a small launch is step time (profiles/r06_finish_offchain_ab.txt) --, 8 otherwise
+template <int SLICES>
+__global__ __launch_bounds__(32 * SLICES) void partial_reduce_kernel(const float* __restrict__ ws, int nblk, int ncols, long ld,
+                                                                      float* __restrict__ out, int accumulate) {
+    __shared__ float sm[SLICES][33];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + tx;
     float s = 0.f;
     if (c < ncols) {
-        // 4 independent partial sums: the loads are latency-bound (tiny grid), keep several in flight
+        // 4 independent partial sums: keep several loads in flight
         float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
         int b = ty;
-        for (; b + 24 < nblk; b += 32) {
+        for (; b + 3 * SLICES < nblk; b += 4 * SLICES) {
             s0 += ws[(long)b * ld + c];
-            s1 += ws[(long)(b + 8) * ld + c];
-            s2 += ws[(long)(b + 16) * ld + c];
-            s3 += ws[(long)(b + 24) * ld + c];
+            s1 += ws[(long)(b + SLICES) * ld + c];
+            s2 += ws[(long)(b + 2 * SLICES) * ld + c];
+            s3 += ws[(long)(b + 3 * SLICES) * ld + c];
         }
-        for (; b < nblk; b += 8) s0 += ws[(long)b * ld + c];
+        for (; b < nblk; b += SLICES) s0 += ws[(long)b * ld + c];
         s = (s0 + s1) + (s2 + s3);
     }
     sm[ty][tx] = s;
@@ -113,7 +116,7 @@ __global__ __launch_bounds__(256) void partial_reduce_kernel(const float* __rest
     if (ty == 0 && c < ncols) {
         float t = 0.f;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) t += sm[k][tx];
+        for (int k = 0; k < SLICES; ++k) t += sm[k][tx];
         out[c] = accumulate ? out[c] + t : t;
     }
 }
@@ -239,7 +242,10 @@ extern "C" int esvit_cast_f32_to(int dtype, const float* src, void* dst, int64_t
 }
 
 int esvit_partial_reduce(const float* ws, int nblk, int ncols, long ld, float* out, int accumulate, hipStream_t stream) {
-    hipLaunchKernelGGL(partial_reduce_kernel, dim3(ceil_div(ncols, 32)), dim3(256), 0, stream, ws, nblk, ncols, ld, out, accumulate);
+    if (nblk >= 256)
+        hipLaunchKernelGGL(partial_reduce_kernel<32>, dim3(ceil_div(ncols, 32)), dim3(1024), 0, stream, ws, nblk, ncols, ld, out, accumulate);
+    else
+        hipLaunchKernelGGL(partial_reduce_kernel<8>, dim3(ceil_div(ncols, 32)), dim3(256), 0, stream, ws, nblk, ncols, ld, out, accumulate);
     ESVIT_CHECK_LAUNCH("partial_reduce");
     return ESVIT_OK;
 }
