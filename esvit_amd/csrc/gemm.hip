@@ -231,6 +231,30 @@ int validate(int dtype, esvit_gemm_desc& d) {
     return check_selector(dtype, d);
 }
 
+#ifdef ESVIT_ASTAT  // probe build only (tools/probe/astat_check.py, profiles/r06_gemm_astat_probe.txt)
+// the A-stationary short-K kernel (gemm_kernels.h): plain / bias / GELU(+pre-activation) bf16 forwards over whole 128 x 128 tiles, K = 256 / 384
+bool astat_supports(int dtype, const esvit_gemm_desc& d) {
+    if (dtype != ESVIT_BF16 || d.kernel != ESVIT_GEMM_AUTO || d.a_kstrided || d.b_kstrided || d.batch > 1 || d.splitk > 1) return false;
+    if (d.rowmap || d.rowstat || d.colstat || d.colsum || d.residual || d.rowscale || d.out_f32 || d.alpha != 1.f) return false;
+    if (!(d.epilogue == 0 || d.epilogue == ESVIT_EPI_GELU)) return false;
+    if (d.M % 128 != 0 || d.N % 128 != 0 || !(d.K == 256 || d.K == 384)) return false;
+    if (d.lda % 8 != 0 || d.ldc % 8 != 0 || ((uintptr_t)d.C % 16) != 0) return false;
+    if (d.epilogue == ESVIT_EPI_GELU && d.aux && (d.ldaux % 8 != 0 || ((uintptr_t)d.aux % 16) != 0)) return false;
+    if ((long)d.N * d.ldb * 2 >= 0x7ff00000L) return false;  // 32-bit DMA offsets inside a column chunk
+    return (long)d.M * d.N >= 8000000L;                       // (small problems stay where they were measured)
+}
+
+int run_astat(const esvit_gemm_desc& d, hipStream_t stream) {
+    const bool gelu = d.epilogue == ESVIT_EPI_GELU, pre = gelu && d.aux;
+    if (d.K == 256) {
+        if (!gelu) return launch_gemm_astat<8, false, false>(d, stream);
+        return pre ? launch_gemm_astat<8, true, true>(d, stream) : launch_gemm_astat<8, true, false>(d, stream);
+    }
+    if (!gelu) return launch_gemm_astat<12, false, false>(d, stream);
+    return pre ? launch_gemm_astat<12, true, true>(d, stream) : launch_gemm_astat<12, true, false>(d, stream);
+}
+#endif
+
 }  // namespace
 
 extern "C" int esvit_gemm_select(int dtype, const esvit_gemm_desc* dp, int* tile_m, int* tile_n, int* resident_slots) {
@@ -255,6 +279,9 @@ extern "C" int esvit_gemm(int dtype, const esvit_gemm_desc* dp, esvit_stream_t s
     esvit_gemm_desc d = *dp;
     const int rc = validate(dtype, d);
     if (rc != ESVIT_OK) return rc;
+#ifdef ESVIT_ASTAT
+    if (astat_supports(dtype, d)) return run_astat(d, stream);
+#endif
     const GemmChoice c = choose(dtype, d);
     if (!d.a_kstrided && !d.b_kstrided) return run_layout<false, false>(dtype, d, c, stream);
     if (!d.a_kstrided && d.b_kstrided) return run_layout<false, true>(dtype, d, c, stream);

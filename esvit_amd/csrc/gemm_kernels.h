@@ -1123,6 +1123,156 @@ __global__ __launch_bounds__(64 * WM * WN, MINB) void gemm_dma_kernel(const esvi
     ESVIT_TL(2);
 }
 
+// =================================================================================================
+// A-stationary short-K kernel (round 6).  C[M,N] = A[M,K] B^T (+ bias, GELU), A row-major, B = weight [N, K] row-major, bf16 out.
+//
+// The short-K forwards of the step (K = 256 / 384: stage-2 fc1 / qkv) spend their time delivering operands: a 128 x 128 tile of the loop
+// above fetches 2 x 128 x K x 2 bytes for 128 x 128 x K MACs -- 1.6 GB through the L2 for fc1's 0.6 GB of algorithmic traffic -- and its
+// four to six k-tiles are all pipeline fill and drain.  Here a workgroup owns 128 rows and WALKS over column tiles: every wave loads the
+// fragments of ITS 32 rows (4 x 1 waves: whole K, K / 8 registers per lane) straight from global memory once, and only the weight streams
+// through the LDS-DMA ring -- continuously, across the column tiles, so the ring never drains: the epilogue of tile t (stores only; the bias
+// of the walked columns sits in LDS) runs while the first k-tiles of tile t + 1 are in flight.  Half the operand bytes per tile, no per-tile
+// prologue.  A PROBE (-DESVIT_ASTAT, profiles/r06_gemm_astat_probe.txt): -8 % on fc1 with its two outputs, +3..+39 % elsewhere, not routed.
+// Work item = (row block, column chunk) = (blockIdx / chunks, blockIdx % chunks): with chunks dividing 8 or a multiple of 8 the workgroups of
+// an XCD walk the same weight columns (its L2 holds them).
+// =================================================================================================
+template <int KSTEPS, bool GELU, bool PREACT, int NBUF = 4>
+__global__ __launch_bounds__(256, 2) void gemm_astat_kernel(const esvit_gemm_desc p, const int tiles_per_wg, const int chunks) {
+    constexpr int BN = 128, BKD = 64, NT = 256;
+    constexpr int K = KSTEPS * 32, NKT = K / BKD, FM = 2, FN = 8;
+    static_assert(K % BKD == 0, "whole k-tiles");
+    using TB = DmaTile<false, BN, BKD, NT>;
+    constexpr int L = TB::INSTR_PER_WAVE;
+    constexpr int B_BYTES = TB::ELEMS * 2;
+    static_assert((NBUF - 2) * L < 64, "vmcnt is 6 bits");
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    char* sB = smem_raw;                                                   // NBUF buffers
+    float* sBias = reinterpret_cast<float*>(smem_raw + NBUF * B_BYTES);    // tiles_per_wg * BN floats
+
+    const int tiles_n = p.N / BN;
+    const int rb = blockIdx.x / chunks, chunk = blockIdx.x % chunks;
+    const int tile0 = chunk * tiles_per_wg;
+    const int ntile = min(tiles_per_wg, tiles_n - tile0);
+    if (ntile <= 0) return;
+    const int m0 = rb * 128;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c = lane & 15, g = lane >> 4;
+    const bf16* A = reinterpret_cast<const bf16*>(p.A);
+    const bf16* B = reinterpret_cast<const bf16*>(p.B);
+    const bf16* b_base = B + (long)tile0 * BN * p.ldb;
+    const __amdgpu_buffer_rsrc_t rbuf = make_rsrc(b_base, ((long)(p.N - tile0 * BN) * p.ldb) * 2);
+    int voffB[L];
+    TB::wave_offsets(p.ldb, wave, lane, voffB);
+    const int total = ntile * NKT;
+    auto issue = [&](int s_, int slot) {  // k-tile s_ of the walk: column tile s_ / NKT, k-tile s_ % NKT
+        typedef __attribute__((address_space(3))) void lds_void;
+        const int t = s_ / NKT, kt = s_ - t * NKT;
+        const int soff = (int)(((long)t * BN * p.ldb + kt * BKD) * 2);
+        static_for<L>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rbuf, (lds_void*)(sB + slot * B_BYTES + (wave * L + i) * 1024), 16, voffB[i], soff, 0, 0);
+        });
+    };
+    // this wave's rows of A, whole K: fragment (row block i, k-step ks) = 8 consecutive k of row 16 i + c at k = 32 ks + 8 g
+    Frag<bf16> af[FM][KSTEPS];
+    {
+        const bf16* ap = A + (long)(m0 + wave * 32 + c) * p.lda + 8 * g;
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int ks = 0; ks < KSTEPS; ++ks) af[i][ks].v = *reinterpret_cast<const bf16x8*>(ap + (long)16 * i * p.lda + 32 * ks);
+    }
+    if (p.bias) {
+        for (int e = threadIdx.x; e < ntile * BN; e += NT) sBias[e] = p.bias[tile0 * BN + e];
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // A fragments and the bias have arrived: from here on only ring DMAs and stores are counted
+    __syncthreads();
+#pragma unroll
+    for (int s_ = 0; s_ < NBUF - 1; ++s_)
+        if (s_ < total) issue(s_, s_);
+
+    bf16* Cb = reinterpret_cast<bf16*>(p.C);
+    bf16* Xb = reinterpret_cast<bf16*>(p.aux);
+    const long row = m0 + wave * 32 + c;
+    int buf = 0, s = 0;
+    for (int t = 0; t < ntile; ++t) {
+        f32x4 acc[FM][FN];
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        static_for<NKT>([&](auto ktc) {
+            constexpr int kt = decltype(ktc)::value;
+            // k-tile s must have landed.  Requested after it: the k-tiles s + 1 .. s + NBUF - 2 (when they exist).  The previous tile's stores are
+            // NOT added to the allowance although they were issued after k-tile s: loads retire in order among themselves, but stores retire out of
+            // order with respect to loads, so "at most 2 L + EPI_OPS outstanding" can hold with k-tile s still in flight (measured: wrong tiles,
+            // profiles/r06_gemm_astat_probe.txt).  The price: a wave waits for its stores at the first k-tiles of the next column tile.
+            const int ahead = min(total - 1 - s, NBUF - 2);
+            if (ahead >= 2) wait_vmcnt<2 * L>();
+            else if (ahead == 1) wait_vmcnt<L>();
+            else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();  // k-tile s landed for every wave; every wave is done with k-tile s - 1
+            asm volatile("" ::: "memory");
+            if (s + NBUF - 1 < total) issue(s + NBUF - 1, (buf == 0) ? NBUF - 1 : buf - 1);
+            const bf16* b_lds = reinterpret_cast<const bf16*>(sB + buf * B_BYTES);
+#pragma unroll
+            for (int kk = 0; kk < BKD / 32; ++kk) {
+                Frag<bf16> bfr[FN];
+#pragma unroll
+                for (int j = 0; j < FN; ++j) bfr[j] = TB::frag(b_lds, j * 16, kk, c, g);
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+#pragma unroll
+                    for (int j = 0; j < FN; ++j) mma(bfr[j], af[i][2 * kt + kk], acc[i][j]);  // operands swapped: see epilogue_direct
+            }
+            buf = (buf + 1 == NBUF) ? 0 : buf + 1;
+            ++s;
+        });
+        // epilogue: acc[i][j][r] = C[row 16 i + c][column 16 j + 4 g + r]; stores only (EPI_OPS of them per lane)
+        const int n0 = (tile0 + t) * BN;
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+            f32x4 v[FN];
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                v[j] = acc[i][j];
+                if (p.bias) v[j] += *reinterpret_cast<const f32x4*>(sBias + t * BN + 16 * j + 4 * g);
+            }
+            if constexpr (GELU) {
+                if constexpr (PREACT) store_row_bf16<FN>(Xb + (row + 16 * i) * p.ldaux + n0, v, g);
+#pragma unroll
+                for (int j = 0; j < FN; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[j][e] = gelu_f(v[j][e]);
+            }
+            store_row_bf16<FN>(Cb + (row + 16 * i) * p.ldc + n0, v, g);
+        }
+    }
+}
+
+template <int KSTEPS, bool GELU, bool PREACT>
+int launch_gemm_astat(const esvit_gemm_desc& d, hipStream_t stream) {
+    constexpr int NBUF = 4;
+    using TB = DmaTile<false, 128, 64, 256>;
+    const int tiles_m = d.M / 128, tiles_n = d.N / 128;
+    // column chunks: enough workgroups for >= 4 rounds of the chip's 512 slots when the problem allows, chunks | 8 or 8 | chunks, and at
+    // most 16 column tiles per workgroup (their bias slice sits in LDS)
+    int chunks = 1;
+    while ((long)tiles_m * chunks < 2048 && chunks < tiles_n) chunks *= 2;
+    while (ceil_div(tiles_n, chunks) > 16) chunks *= 2;
+    if (chunks > tiles_n) chunks = tiles_n;
+    const int tpw = ceil_div(tiles_n, chunks);
+    chunks = ceil_div(tiles_n, tpw);
+    const size_t lds = (size_t)NBUF * TB::ELEMS * 2 + (size_t)tpw * 128 * sizeof(float);
+    auto kern = gemm_astat_kernel<KSTEPS, GELU, PREACT, NBUF>;
+    static unsigned long long lds_set = 0;
+    esvit_raise_lds(kern, (int)lds, lds_set);
+    hipLaunchKernelGGL(kern, dim3(tiles_m * chunks), dim3(256), lds, stream, d, tpw, chunks);
+    ESVIT_CHECK_LAUNCH("esvit_gemm(a-stationary)");
+    return ESVIT_OK;
+}
+
 // sum split-K partials: out[i] (+)= sum_z part[z*n + i]   (TO = float or the activation dtype).
 // 256 threads = 64 element quads x 4 split slices (slice sl sums z = sl, sl+4, ...), four loads in flight per thread,
 // slices combined through LDS: the 512-way reductions of the 96x96 stage-0 weights were latency-bound at one load in
