@@ -35,7 +35,8 @@
 //
 // Memory operations are counted, not waited for.  The token rows of the NEXT window (HBM) are prefetched into registers, a few
 // 16-byte loads at the top of every step after the weight requests; they, the output stores and the side-output stores are the
-// YOUNGEST operations of a step and the only ones its closing `s_waitcnt vmcnt(n)` leaves in flight (with resident weights there is
+// YOUNGEST operations of a step; its closing `s_waitcnt vmcnt(n)` leaves the row LOADS in flight and waits for everything else, the stores
+// included (stores retire out of order with respect to loads: an allowance that counts them is unsound; with resident weights there is
 // nothing to wait for after the first window).  For the count -- and hipcc's own inserted waits -- to be exact, every memory
 // operation of the loop is unconditional: rows that do not exist are addressed out of range (row_off), a wave without a DMA piece
 // issues one into a spare KiB.  The fragment-order bias of all heads lives in registers: a load inside the step would have to be
@@ -611,7 +612,10 @@ __device__ __forceinline__ void attn_branch_fwd_body(const ABParams& p) {
             // everything older than the row loads of this step has landed (the weight slices above all); the row loads and the
             // stores stay in flight through the next step.  Resident weights: nothing to wait for after the first window
             constexpr int NPFL = (pf0 < pf1 ? pf1 - pf0 : 0);
-            constexpr int LATE = NPFL + (h == 1 ? 1 : 0) + (SAVE ? 4 : 0) + (h == 0 ? MT + (SAVE ? KS + 2 : 0) : 0);
+            // (only the row LOADS count: loads retire in order among themselves, stores retire out of order with respect to loads, so the
+            // allowance of rounds 5-6 -- row loads + this step's output / side-output stores -- could be met with a weight slice still on its
+            // way; profiles/r06_gemm_astat_probe.txt.  Same step time.)
+            constexpr int LATE = NPFL;
             if (!AC::RES || it == 0) wait_vm<LATE>();
             TL(8);
             chunk_barrier();

@@ -217,7 +217,6 @@ __device__ __forceinline__ void bwd16_body(const float* __restrict__ x, const fl
     constexpr int NP = 2 * Cf::PA + Cf::PB + 1;  // W1 rows | W2^T rows | W1^T columns | biases
     constexpr int PPW = (NP + NW - 1) / NW;
     constexpr int WBUF = 2 * Cf::A_BYTES + Cf::B_BYTES + 1024;
-    constexpr int STORES = 2;  // vector stores per lane and chunk (the two hidden tiles)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef __attribute__((address_space(3))) void lds_void;
 
@@ -349,16 +348,18 @@ __device__ __forceinline__ void bwd16_body(const float* __restrict__ x, const fl
             const bf16x8 a = *reinterpret_cast<const bf16x8*>(wc + Cf::frag_b(mt, c, g));
             acc3[mt] = mfma16(a, df, acc3[mt]);
         }
-        // chunk q + 1 must have landed; what this wave issued after that chunk's DMA may stay in flight (vmcnt retires in order)
+        // chunk q + 1 must have landed.  Only the LOADS this wave issued after that chunk's DMA are allowed to stay in flight (the DMA pieces of
+        // chunk q + 2): loads retire in order among themselves, but stores retire out of order with respect to loads, so an allowance that
+        // counted the side-output stores as well (rounds 4-5) could be met with chunk q + 1 still on its way (profiles/r06_gemm_astat_probe.txt:
+        // seen in a probe kernel; never here, the chunk has a whole iteration to land).  Same step time (47.36 vs 47.37 ms, same box).
         if constexpr (NBUF == 2) {
-            if (more && wave_live) wait_vm<STORES>();
-            else wait_vm<0>();
+            wait_vm<0>();
         } else {
             if (!wave_live) wait_vm<0>();
             else if (more) {
-                if (full) wait_vm<PPW + 2 * STORES>();
-                else wait_vm<PPW - 1 + 2 * STORES>();
-            } else if (q + 1 < NCHUNK) wait_vm<2 * STORES>();
+                if (full) wait_vm<PPW>();
+                else wait_vm<PPW - 1>();
+            } else wait_vm<0>();
         }
         chunk_barrier();
         if constexpr (NBUF == 2) buf ^= 1;

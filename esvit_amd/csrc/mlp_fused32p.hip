@@ -414,8 +414,9 @@ __device__ __forceinline__ void mlp32p_fwd_body(const P32Args& A) {
         constexpr bool STORES = GL && SIDE;
         if constexpr (STORES) {
             // chunk q of the side outputs: hidden units 32 q + 16 hh + 0 .. 15 of token n (two 16-byte stores per tensor and lane).  Buffer stores:
-            // rows past M fall outside the descriptors' ranges, so every wave issues exactly four store instructions per iteration and the
-            // counted wait below can leave them in flight (vmcnt retires in order: the DMA pieces issued before them have landed)
+            // rows past M fall outside the descriptors' ranges, so every wave issues exactly four store instructions per iteration.  (The
+            // measurements of this variant were taken with "vmcnt(4)" below -- the stores left in flight; that is only sound if stores and loads
+            // retire in ONE order, and they do not: profiles/r06_gemm_astat_probe.txt.  The wait is vmcnt(0) now.)
             const unsigned so = side_off + (unsigned)(q * P32_HCH * 2);
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
@@ -450,7 +451,7 @@ __device__ __forceinline__ void mlp32p_fwd_body(const P32Args& A) {
 #if defined(ESVIT_P32_PROBE) && defined(P32_NO_SIDE_STORE)
         if constexpr (STORES) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 #else
-        if constexpr (STORES) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+        if constexpr (STORES) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 #endif
         else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 #endif
