@@ -99,8 +99,8 @@ def _side_run(fn, *keep):
     st = _wg_state.get(dev)
     if st is None:
         st = _wg_state[dev] = {"stream": torch.cuda.Stream(device=dev, priority=int(os.environ.get("ESVIT_WGRAD_PRIO", "0"))), "keep": [],
-                               "pending": False}
-    ev = torch.cuda.Event()
+                               "pending": False, "event": torch.cuda.Event()}
+    ev = st["event"]  # one event per device, re-recorded: a wait refers to the record that precedes it in program order
     ev.record(torch.cuda.current_stream(dev))
     st["stream"].wait_event(ev)
     with torch.cuda.stream(st["stream"]):
